@@ -1,0 +1,197 @@
+/* akmi.h -- C ABI of the MI355X-native MeshBlock finite-volume update (AthenaK hot path).
+ *
+ * AthenaK has no FFI layer; the seam this library replaces is the *task member function*
+ *     TaskStatus (Hydro|MHD)::Name(Driver *pdriver, int stage)
+ * (reference: src/tasklist/task_list.hpp:178-185, src/hydro/hydro.hpp:124-154,
+ * src/mhd/mhd.hpp:155-199).  Each entry point below is the body of one such task, taking
+ * what the task reads from pmy_pack as plain pointers and scalars.  See INTEGRATION.md for
+ * the one-line binding a maintainer adds inside each reference task.
+ *
+ * Conventions
+ *  - All field pointers are DEVICE pointers (HBM) to IEEE fp64 in the reference's
+ *    LayoutRight order (src/athena.hpp:111,127-128):
+ *        cell array   (nmb, nvar, N3, N2, N1)            i fastest, no padding
+ *        x1-face      (nmb, [nvar,] N3,   N2,   N1+1)    (src/athena.hpp:178-196)
+ *        x2-face      (nmb, [nvar,] N3,   N2+1, N1  )
+ *        x3-face      (nmb, [nvar,] N3+1, N2,   N1  )
+ *        x1-edge      (nmb, N3+1, N2+1, N1  )            (src/athena.hpp:223-231)
+ *        x2-edge      (nmb, N3+1, N2,   N1+1)
+ *        x3-edge      (nmb, N3,   N2+1, N1+1)
+ *    with N1 = nx1+2*ng, N2 = nx2>1 ? nx2+2*ng : 1, N3 likewise
+ *    (src/hydro/hydro.cpp:283-288, src/mhd/mhd.cpp:148-160).
+ *  - The library never allocates, frees or reallocates a caller's array.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls enqueue
+ *    work and return; only functions documented as synchronous block.
+ *  - Return value mirrors TaskStatus (src/tasklist/task_list.hpp:30):
+ *        AKMI_COMPLETE 0, AKMI_INCOMPLETE 1, AKMI_FAIL <0 (message via akmi_last_error()).
+ */
+#ifndef AKMI_H_
+#define AKMI_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AKMI_COMPLETE    0
+#define AKMI_INCOMPLETE  1
+#define AKMI_FAIL       -1
+
+/* variable indices, src/athena.hpp:65-67 */
+enum { AKMI_IDN = 0, AKMI_IM1 = 1, AKMI_IM2 = 2, AKMI_IM3 = 3, AKMI_IEN = 4 };
+enum { AKMI_IBX = 0, AKMI_IBY = 1, AKMI_IBZ = 2 };
+
+/* ReconstructionMethod, src/athena.hpp (enum class) ; only dc/plm/ppm4 are on the path */
+enum { AKMI_RECON_DC = 0, AKMI_RECON_PLM = 1, AKMI_RECON_PPM4 = 2 };
+/* Hydro_RSolver / MHD_RSolver */
+enum { AKMI_RS_LLF = 0, AKMI_RS_HLLE = 1, AKMI_RS_HLLC = 2, AKMI_RS_HLLD = 3 };
+/* BoundaryFlag, src/mesh/mesh.hpp */
+enum { AKMI_BC_BLOCK = -1, AKMI_BC_PERIODIC = 0, AKMI_BC_OUTFLOW = 1, AKMI_BC_REFLECT = 2 };
+
+/* MeshBlockPack descriptor: RegionIndcs (src/mesh/mesh.hpp:35-41), mb_size.dx1..3
+ * (src/mesh/mesh.hpp:25-29) and EOS_Data (src/eos/eos.hpp:27-34) by value. */
+typedef struct akmi_pack {
+  int nmb;               /* nmb_thispack: MeshBlocks looped over                        */
+  int nvar;              /* nhydro|nmhd + nscalars (5 on this path)                     */
+  int nx1, nx2, nx3;     /* active cells per MeshBlock                                  */
+  int ng;                /* ghost cells                                                 */
+  const double *dx;      /* [nmb][3] dx1,dx2,dx3 per block, same memory space as fields */
+  double gamma;          /* EOS_Data::gamma (ideal gas)                                 */
+  double dfloor, pfloor, tfloor, sfloor;   /* default FLT_MIN, src/eos/eos.cpp:22-25    */
+  double sigma_max;      /* default FLT_MAX, src/eos/ideal_mhd.cpp:22                   */
+} akmi_pack;
+
+const char *akmi_last_error(void);
+int akmi_version(void);
+
+/* ---- Hydro tasks ------------------------------------------------------------------ */
+/* Hydro::CopyCons (src/hydro/hydro_tasks.cpp:130-152): u1 <- u0 */
+int akmi_copy_cons(const akmi_pack *p, const double *u0, double *u1, void *stream);
+
+/* Hydro::Fluxes -> CalculateFluxes<hllc> (src/hydro/hydro_fluxes.cpp:77-229): reconstruct
+ * w0 (recon), solve Riemann problem at faces i in [is,ie+1] (x1), j in [js,je+1] (x2),
+ * k in [ks,ke+1] (x3).  flx arrays are cell-shaped (nmb,nvar,N3,N2,N1) as Hydro::uflx
+ * (src/hydro/hydro.cpp:290-292) when face_shaped==0, or face-shaped as MHD::uflx when 1. */
+int akmi_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                      double *flx1, double *flx2, double *flx3, int face_shaped,
+                      void *stream);
+
+/* Hydro::RKUpdate / MHD::RKUpdate (src/hydro/hydro_update.cpp:23-83,
+ * src/mhd/mhd_update.cpp:24-84):  u0 = gam0*u0 + gam1*u1 - beta_dt*divF */
+int akmi_rk_update(const akmi_pack *p, double gam0, double gam1, double beta_dt,
+                   double *u0, const double *u1, const double *flx1, const double *flx2,
+                   const double *flx3, int face_shaped, void *stream);
+
+/* IdealHydro::ConsToPrim (src/eos/ideal_hyd.cpp:29-115) over [il,iu]x[jl,ju]x[kl,ku];
+ * counters = device int[3] (dfloor,efloor,tfloor), incremented (not reset). */
+int akmi_hydro_c2p(const akmi_pack *p, double *u0, double *w0, int il, int iu, int jl,
+                   int ju, int kl, int ku, int *counters, void *stream);
+
+/* Hydro::NewTimeStep (src/hydro/hydro_newdt.cpp:30-139): dt3 = device double[3] receiving
+ * min over active cells of dx1/(|vx|+cs), dx2/(|vy|+cs), dx3/(|vz|+cs); initial value
+ * FLT_MAX as in the reference. */
+int akmi_hydro_newdt(const akmi_pack *p, const double *w0, double *dt3, void *stream);
+
+/* ---- MHD tasks -------------------------------------------------------------------- */
+/* MHD::Fluxes -> CalculateFluxes<hlld> (src/mhd/mhd_fluxes.cpp:84-266).  flx face-shaped
+ * (src/mhd/mhd.cpp:341-343); face EMFs e3x1,e2x1,e1x2,e3x2,e2x3,e1x3 cell-shaped
+ * (src/mhd/mhd.cpp:349-354).  Ranges are the reference's CT-extended ranges. */
+int akmi_mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                    const double *bcc0, const double *bx1f, const double *bx2f,
+                    const double *bx3f, double *flx1, double *flx2, double *flx3,
+                    double *e3x1, double *e2x1, double *e1x2, double *e3x2, double *e2x3,
+                    double *e1x3, void *stream);
+
+/* MHD::CornerE (src/mhd/mhd_corner_e.cpp:26-417), Newtonian 1D/2D/3D branches. */
+int akmi_mhd_corner_e(const akmi_pack *p, const double *w0, const double *bcc0,
+                      const double *e3x1, const double *e2x1, const double *e1x2,
+                      const double *e3x2, const double *e2x3, const double *e1x3,
+                      const double *flx1, const double *flx2, const double *flx3,
+                      double *e1, double *e2, double *e3, void *stream);
+
+/* MHD::CT (src/mhd/mhd_ct.cpp:23-80) */
+int akmi_mhd_ct(const akmi_pack *p, double gam0, double gam1, double beta_dt,
+                const double *e1, const double *e2, const double *e3, double *b0x1f,
+                double *b0x2f, double *b0x3f, const double *b1x1f, const double *b1x2f,
+                const double *b1x3f, void *stream);
+
+/* IdealMHD::ConsToPrim (src/eos/ideal_mhd.cpp:30-134) */
+int akmi_mhd_c2p(const akmi_pack *p, double *u0, const double *bx1f, const double *bx2f,
+                 const double *bx3f, double *w0, double *bcc0, int il, int iu, int jl,
+                 int ju, int kl, int ku, int *counters, void *stream);
+
+/* MHD::NewTimeStep (src/mhd/mhd_newdt.cpp:31-174) */
+int akmi_mhd_newdt(const akmi_pack *p, const double *w0, const double *bcc0, double *dt3,
+                   void *stream);
+
+/* ---- Boundary values (same-level) -------------------------------------------------- */
+/* Neighbour table: int nghbr[nmb][27], direction d = (ox3+1)*9 + (ox2+1)*3 + (ox1+1)
+ * (the reference's NeighborBlock table, src/mesh/mesh.hpp:47-52, reduced to the
+ * same-level case).  Entry >= 0: local index of the neighbour MeshBlock in this pack
+ * (same-rank path, src/bvals/bvals_cc.cpp:122-135).  Entry == -1: no neighbour (physical
+ * boundary, filled later by akmi_*_bcs).  Entry <= -2: neighbour on another rank; the
+ * ghost region is filled from receive-buffer segment  s = -(entry+2)  whose start offset
+ * (in doubles) is seg_off[s]. */
+
+/* MeshBoundaryValuesCC::PackAndSendCC + RecvAndUnpackCC, same-rank part
+ * (src/bvals/bvals_cc.cpp:42-447; index ranges src/bvals/buffs_cc.cpp:28-70,150-190). */
+int akmi_bvals_cc_local(const akmi_pack *p, int nvar, const int *nghbr, double *u,
+                        void *stream);
+/* off-rank part: send_tab[nsend][2] = {local block m, direction d towards the receiver};
+ * send_off[nsend] = start offset (doubles) of that segment in sendbuf. A segment holds
+ * [n][k][j][i] of the ng innermost active layers the receiver needs. */
+int akmi_bvals_cc_pack(const akmi_pack *p, int nvar, int nsend, const int *send_tab,
+                       const long long *send_off, const double *u, double *sendbuf,
+                       void *stream);
+int akmi_bvals_cc_unpack(const akmi_pack *p, int nvar, const int *nghbr,
+                         const long long *seg_off, const double *recvbuf, double *u,
+                         void *stream);
+/* number of doubles in the CC segment for direction d (per variable) */
+long long akmi_bvals_cc_segsize(const akmi_pack *p, int d);
+
+/* MeshBoundaryValuesFC::PackAndSendFC + RecvAndUnpackFC (src/bvals/bvals_fc.cpp:63,289;
+ * ranges src/bvals/buffs_fc.cpp:29-110,396-431): shared faces are never exchanged. */
+int akmi_bvals_fc_local(const akmi_pack *p, const int *nghbr, double *bx1f, double *bx2f,
+                        double *bx3f, void *stream);
+int akmi_bvals_fc_pack(const akmi_pack *p, int nsend, const int *send_tab,
+                       const long long *send_off, const double *bx1f, const double *bx2f,
+                       const double *bx3f, double *sendbuf, void *stream);
+int akmi_bvals_fc_unpack(const akmi_pack *p, const int *nghbr, const long long *seg_off,
+                         const double *recvbuf, double *bx1f, double *bx2f, double *bx3f,
+                         void *stream);
+/* doubles in the FC segment for direction d (x1f+x2f+x3f parts, in that order) */
+long long akmi_bvals_fc_segsize(const akmi_pack *p, int d);
+
+/* MeshBoundaryValues::HydroBCs / BFieldBCs (src/bvals/physics/hydro_bcs.cpp:28-...,
+ * src/bvals/physics/bfield_bcs.cpp:25-...).  bcs = device int[nmb][6] of AKMI_BC_* for
+ * inner_x1,outer_x1,inner_x2,outer_x2,inner_x3,outer_x3 (mb_bcs). */
+int akmi_hydro_bcs(const akmi_pack *p, int nvar, const int *bcs, double *u, void *stream);
+int akmi_bfield_bcs(const akmi_pack *p, const int *bcs, double *bx1f, double *bx2f,
+                    double *bx3f, void *stream);
+
+/* ---- Fused fast path ("one kernel sequence per MeshBlockPack stage") ----------------- *
+ * Must produce results identical to the task chain above.  ws = device workspace of
+ * akmi_stage_workspace_bytes() bytes owned by the caller. */
+long long akmi_stage_workspace_bytes(const akmi_pack *p, int is_mhd);
+
+/* Hydro: Fluxes + RKUpdate fused (stage 1 reads u0 as u1 when u1==NULL is not allowed;
+ * CopyCons semantics are folded in when copy_u1 != 0: u1 <- u0 before the update). */
+int akmi_hydro_stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
+                            double gam1, double beta_dt, int copy_u1, const double *w0,
+                            double *u0, double *u1, void *ws, void *stream);
+/* MHD: Fluxes + CornerE + RKUpdate + CT fused */
+int akmi_mhd_stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
+                          double gam1, double beta_dt, int copy_u1, const double *w0,
+                          const double *bcc0, double *u0, double *u1, double *b0x1f,
+                          double *b0x2f, double *b0x3f, double *b1x1f, double *b1x2f,
+                          double *b1x3f, void *ws, void *stream);
+/* ConsToPrim + (optionally, last stage) NewTimeStep fused */
+int akmi_hydro_c2p_newdt(const akmi_pack *p, double *u0, double *w0, int do_newdt,
+                         int *counters, double *dt3, void *stream);
+int akmi_mhd_c2p_newdt(const akmi_pack *p, double *u0, const double *bx1f,
+                       const double *bx2f, const double *bx3f, double *w0, double *bcc0,
+                       int do_newdt, int *counters, double *dt3, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AKMI_H_ */

@@ -1,0 +1,151 @@
+/* akref.h -- CPU ORACLE for the akmi hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C restatement of the reference's (IAS-Astrophysics/athenak) algorithm for the
+ * MeshBlock finite-volume update, in the reference's own split-kernel order
+ * (reconstruct -> L/R buffers -> Riemann solve -> CornerE -> RKUpdate -> CT -> halo -> c2p
+ * -> dt).  Every function cites the reference file:line it follows.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library -- as the checker / reported CPU baseline, never as the product path.
+ *
+ * PARITY PIN.  The reference cannot be built in the authoring container (its Kokkos
+ * submodule is empty, /root/reference/kokkos, .gitmodules:1-3; writing stand-in headers is
+ * not permitted), so this oracle is pinned by the reference's own known-answer tests:
+ *   tst/test_suite/nr/test_nr_lwave1d_cpu.py:15-96,155-160  (L1-RMS thresholds, 32->64
+ *       convergence ratio, exact L/R-going wave error equality for PLM),
+ *   tst/test_suite/nr/test_nr_sod_cpu.py:20-86, test_nr_rj2a_cpu.py:21-96 (convergence
+ *       against the exact Riemann solutions),
+ * and by the reference outputs recorded in BASELINE.md section 2b (7 digits).
+ * See tests/test_oracle_pins.py.
+ */
+#ifndef AKREF_H_
+#define AKREF_H_
+#include "../include/akmi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+void akref_set_threads(int n);
+int  akref_get_threads(void);
+
+/* ---- kernel-level restatements: same arguments as the akmi_* entry points ---------- */
+int akref_copy_cons(const akmi_pack *p, const double *u0, double *u1);
+int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                       double *flx1, double *flx2, double *flx3, int face_shaped);
+int akref_rk_update(const akmi_pack *p, double gam0, double gam1, double beta_dt,
+                    double *u0, const double *u1, const double *flx1, const double *flx2,
+                    const double *flx3, int face_shaped);
+int akref_hydro_c2p(const akmi_pack *p, double *u0, double *w0, int il, int iu, int jl,
+                    int ju, int kl, int ku, int *counters);
+int akref_hydro_newdt(const akmi_pack *p, const double *w0, double *dt3);
+int akref_mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                     const double *bcc0, const double *bx1f, const double *bx2f,
+                     const double *bx3f, double *flx1, double *flx2, double *flx3,
+                     double *e3x1, double *e2x1, double *e1x2, double *e3x2, double *e2x3,
+                     double *e1x3);
+int akref_mhd_corner_e(const akmi_pack *p, const double *w0, const double *bcc0,
+                       const double *e3x1, const double *e2x1, const double *e1x2,
+                       const double *e3x2, const double *e2x3, const double *e1x3,
+                       const double *flx1, const double *flx2, const double *flx3,
+                       double *e1, double *e2, double *e3);
+int akref_mhd_ct(const akmi_pack *p, double gam0, double gam1, double beta_dt,
+                 const double *e1, const double *e2, const double *e3, double *b0x1f,
+                 double *b0x2f, double *b0x3f, const double *b1x1f, const double *b1x2f,
+                 const double *b1x3f);
+int akref_mhd_c2p(const akmi_pack *p, double *u0, const double *bx1f, const double *bx2f,
+                  const double *bx3f, double *w0, double *bcc0, int il, int iu, int jl,
+                  int ju, int kl, int ku, int *counters);
+int akref_mhd_newdt(const akmi_pack *p, const double *w0, const double *bcc0, double *dt3);
+int akref_bvals_cc_local(const akmi_pack *p, int nvar, const int *nghbr, double *u);
+int akref_bvals_cc_pack(const akmi_pack *p, int nvar, int nsend, const int *send_tab,
+                        const long long *send_off, const double *u, double *sendbuf);
+int akref_bvals_cc_unpack(const akmi_pack *p, int nvar, const int *nghbr,
+                          const long long *seg_off, const double *recvbuf, double *u);
+long long akref_bvals_cc_segsize(const akmi_pack *p, int d);
+int akref_bvals_fc_local(const akmi_pack *p, const int *nghbr, double *bx1f, double *bx2f,
+                         double *bx3f);
+int akref_bvals_fc_pack(const akmi_pack *p, int nsend, const int *send_tab,
+                        const long long *send_off, const double *bx1f, const double *bx2f,
+                        const double *bx3f, double *sendbuf);
+int akref_bvals_fc_unpack(const akmi_pack *p, const int *nghbr, const long long *seg_off,
+                          const double *recvbuf, double *bx1f, double *bx2f, double *bx3f);
+long long akref_bvals_fc_segsize(const akmi_pack *p, int d);
+int akref_hydro_bcs(const akmi_pack *p, int nvar, const int *bcs, double *u);
+int akref_bfield_bcs(const akmi_pack *p, const int *bcs, double *bx1f, double *bx2f,
+                     double *bx3f);
+
+/* single-state functions exposed for unit pins */
+void akref_plm(double qim1, double qi, double qip1, double *ql_ip1, double *qr_i);
+void akref_ppm4(double qim2, double qim1, double qi, double qip1, double qip2,
+                double *ql_ip1, double *qr_i);
+void akref_hllc(double gamma, const double wl[5], const double wr[5], double flx[5]);
+void akref_hlld(double gamma, const double wl[7], const double wr[7], double bx,
+                double flx[7]);
+
+/* ---- whole-run oracle: mesh + pgen + driver (single process, all MeshBlocks) ------- */
+enum { AKREF_PGEN_LINEAR_WAVE = 0, AKREF_PGEN_SHOCK_TUBE = 1, AKREF_PGEN_ORSZAG_TANG = 2,
+       AKREF_PGEN_BLAST = 3 };
+
+typedef struct akref_params {
+  /* <mesh> */
+  int nx1, nx2, nx3;               /* mesh cells */
+  int mb_nx1, mb_nx2, mb_nx3;      /* <meshblock> cells */
+  int ng;
+  double x1min, x1max, x2min, x2max, x3min, x3max;
+  int bcs[6];                      /* AKMI_BC_* ix1,ox1,ix2,ox2,ix3,ox3 */
+  /* <time> */
+  int nstages;                     /* rk1/rk2/rk3 -> 1/2/3 */
+  double cfl, tlim;
+  int nlim;
+  /* <hydro>/<mhd> */
+  int is_mhd, recon, rsolver;
+  double gamma, dfloor, pfloor, tfloor, sfloor, sigma_max;
+  /* <problem> */
+  int pgen;
+  /* linear_wave */
+  int wave_flag, along_x1, along_x2, along_x3;
+  double amp, dens, pgas, vx0, vy0, vz0, bx0, by0, bz0;
+  /* shock_tube */
+  int shock_dir;
+  double xshock, wl[8], wr[8];     /* d,u,v,w,p,bx,by,bz  */
+  /* blast */
+  double pi_amb, di_amb, prat, drat, b_amb, inner_radius, outer_radius;
+  /* decomposition */
+  int split_kernels;               /* unused (always split); reserved */
+} akref_params;
+
+typedef struct akref_sim akref_sim;
+
+void akref_params_default(akref_params *p);
+akref_sim *akref_create(const akref_params *p);
+void akref_destroy(akref_sim *s);
+/* ProblemGenerator + Driver::Initialize (src/main.cpp:325-375, driver.cpp:314-371) */
+void akref_initialize(akref_sim *s);
+/* one cycle of Driver::Execute (src/driver/driver.cpp:394-456); returns 0 when
+ * time>=tlim or ncycle==nlim before the step */
+int akref_step(akref_sim *s);
+/* run to tlim/nlim; returns cycles executed */
+int akref_run(akref_sim *s);
+double akref_time(const akref_sim *s);
+double akref_dt(const akref_sim *s);
+double akref_tlim(const akref_sim *s);
+int akref_ncycle(const akref_sim *s);
+int akref_nmb(const akref_sim *s);
+void akref_pack(const akref_sim *s, akmi_pack *out);
+/* name in {u0,w0,u1,bcc0,b0x1f,b0x2f,b0x3f,b1x1f,b1x2f,b1x3f,flx1,flx2,flx3,
+ *          e1,e2,e3,dx,nghbr,bcs,lloc}; returns pointer, writes element count */
+void *akref_array(akref_sim *s, const char *name, long long *count);
+/* ProblemGenerator::OutputErrors after LinearWaveErrors (src/pgen/pgen.cpp:680-...,
+ * src/pgen/tests/linear_wave.cpp:1430-1437): out[0]=RMS-L1, out[1]=L-infty, out[2..] =
+ * per-variable L1 (5 hydro; 5+3 MHD).  returns number of values. */
+int akref_linear_wave_errors(akref_sim *s, double *out);
+/* face-centred div(B): out[0]=max|divB|, out[1]=mean|divB| over active cells */
+void akref_divb(akref_sim *s, double *out);
+/* conserved totals over active cells (volume weighted): d,M1,M2,M3,E */
+void akref_totals(akref_sim *s, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

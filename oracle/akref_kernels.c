@@ -1,0 +1,1221 @@
+/* akref_kernels.c -- CPU ORACLE (test infrastructure, see akref.h): per-task restatements
+ * of the reference's kernels in the reference's own split order.  Arithmetic follows the
+ * cited reference lines operation by operation (same parenthesisation, divisions kept as
+ * divisions) so results are bit-comparable with a -ffp-contract=off build.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "akref.h"
+
+#define SQR(x) ((x)*(x))
+enum { IDN = 0, IVX = 1, IVY = 2, IVZ = 3, IEN = 4 };
+enum { IBX = 0, IBY = 1, IBZ = 2 };
+
+static int g_threads = 1;
+void akref_set_threads(int n) {
+  g_threads = n < 1 ? 1 : n;
+#ifdef _OPENMP
+  omp_set_num_threads(g_threads);
+#endif
+}
+int akref_get_threads(void) { return g_threads; }
+
+/* index bookkeeping: RegionIndcs, src/mesh/mesh.cpp:285-330 */
+typedef struct {
+  int nmb, nvar, nx1, nx2, nx3, ng, N1, N2, N3;
+  int is, ie, js, je, ks, ke, multi_d, three_d;
+} G;
+
+static G mkG(const akmi_pack *p) {
+  G g;
+  g.nmb = p->nmb; g.nvar = p->nvar; g.nx1 = p->nx1; g.nx2 = p->nx2; g.nx3 = p->nx3;
+  g.ng = p->ng;
+  g.multi_d = (p->nx2 > 1); g.three_d = (p->nx3 > 1);
+  g.N1 = p->nx1 + 2*p->ng;
+  g.N2 = g.multi_d ? p->nx2 + 2*p->ng : 1;
+  g.N3 = g.three_d ? p->nx3 + 2*p->ng : 1;
+  g.is = p->ng; g.ie = g.is + p->nx1 - 1;
+  g.js = g.multi_d ? p->ng : 0; g.je = g.multi_d ? g.js + p->nx2 - 1 : 0;
+  g.ks = g.three_d ? p->ng : 0; g.ke = g.three_d ? g.ks + p->nx3 - 1 : 0;
+  return g;
+}
+
+static inline size_t ix5(int nv, int n3, int n2, int n1, int m, int n, int k, int j, int i) {
+  return ((((size_t)m*nv + n)*n3 + k)*n2 + j)*n1 + i;
+}
+static inline size_t ix4(int n3, int n2, int n1, int m, int k, int j, int i) {
+  return (((size_t)m*n3 + k)*n2 + j)*n1 + i;
+}
+
+/* cached scratch (wl/wr/bl/br L/R buffers etc., src/hydro/hydro.hpp:102-113) */
+#define NWS 12
+static double *g_ws[NWS];
+static size_t g_wsn[NWS];
+static double *ws_get(int slot, size_t n) {
+  if (g_wsn[slot] < n) {
+    free(g_ws[slot]);
+    g_ws[slot] = (double *)malloc(n*sizeof(double));
+    g_wsn[slot] = n;
+    memset(g_ws[slot], 0, n*sizeof(double));
+  }
+  return g_ws[slot];
+}
+
+/* ------------------------------------------------------------------------------------
+ * Reconstruction: src/reconstruct/plm.hpp:20-37, src/reconstruct/ppm.hpp:44-77 */
+void akref_plm(double q_im1, double q_i, double q_ip1, double *ql_ip1, double *qr_i) {
+  double dql = (q_i - q_im1);
+  double dqr = (q_ip1 - q_i);
+  double dq2 = dql*dqr;
+  double dqm = dq2/(dql + dqr);
+  if (dq2 <= 0.0) dqm = 0.0;
+  *ql_ip1 = q_i + dqm;
+  *qr_i   = q_i - dqm;
+}
+
+void akref_ppm4(double q_im2, double q_im1, double q_i, double q_ip1, double q_ip2,
+                double *ql_ip1, double *qr_i) {
+  double qlv = (7.*(q_i + q_im1) - (q_im2 + q_ip1))/12.0;
+  double qrv = (7.*(q_i + q_ip1) - (q_im1 + q_ip2))/12.0;
+  qlv = fmax(qlv, fmin(q_i, q_im1));
+  qlv = fmin(qlv, fmax(q_i, q_im1));
+  qrv = fmax(qrv, fmin(q_i, q_ip1));
+  qrv = fmin(qrv, fmax(q_i, q_ip1));
+  double qc = qrv - q_i;
+  double qd = qlv - q_i;
+  if ((qc*qd) >= 0.0) {
+    qlv = q_i;
+    qrv = q_i;
+  } else {
+    if (fabs(qc) >= 2.0*fabs(qd)) qrv = q_i - 2.0*qd;
+    if (fabs(qd) >= 2.0*fabs(qc)) qlv = q_i - 2.0*qc;
+  }
+  *ql_ip1 = qrv;
+  *qr_i   = qlv;
+}
+
+/* ReconCellT / ReconDispatch (src/reconstruct/recon.hpp:40-118,134-185): cell (k,j,i)
+ * writes ql to face +1 along dir and qr to its own face index. */
+static void recon_dir(const G *g, int recon, int dir, int nv, const double *q, double *ql,
+                      double *qr, int kl, int ku, int jl, int ju, int il, int iu) {
+  const int di = (dir == 0), dj = (dir == 1), dk = (dir == 2);
+  const int N1 = g->N1, N2 = g->N2, N3 = g->N3;
+  const long so = (long)dk*N2*N1 + (long)dj*N1 + di;   /* stencil offset */
+#pragma omp parallel for collapse(3) schedule(static)
+  for (int m = 0; m < g->nmb; ++m)
+    for (int n = 0; n < nv; ++n)
+      for (int k = kl; k <= ku; ++k)
+        for (int j = jl; j <= ju; ++j) {
+          size_t b = ix5(nv, N3, N2, N1, m, n, k, j, 0);
+          for (int i = il; i <= iu; ++i) {
+            size_t c = b + i;
+            double a, bq;
+            if (recon == AKMI_RECON_PLM) {
+              akref_plm(q[c - so], q[c], q[c + so], &a, &bq);
+            } else if (recon == AKMI_RECON_PPM4) {
+              akref_ppm4(q[c - 2*so], q[c - so], q[c], q[c + so], q[c + 2*so], &a, &bq);
+            } else {
+              a = q[c]; bq = q[c];
+            }
+            ql[c + so] = a;
+            qr[c] = bq;
+          }
+        }
+}
+
+/* ------------------------------------------------------------------------------------
+ * HLLC, src/hydro/rsolvers/hllc_hyd.hpp:20-115.  wl/wr = (d, vx, vy, vz, e_int) in the
+ * sweep-aligned frame; flx = (d, mx, my, mz, E). */
+void akref_hllc(double gamma, const double wl[5], const double wr[5], double flx[5]) {
+  const double gm1 = gamma - 1.0;
+  const double igm1 = 1.0/gm1;
+  const double alpha = (gamma + 1.0)/(2.0*gamma);
+  double wl_idn = wl[0], wl_ivx = wl[1], wl_ivy = wl[2], wl_ivz = wl[3];
+  double wr_idn = wr[0], wr_ivx = wr[1], wr_ivy = wr[2], wr_ivz = wr[3];
+  double wl_ipr = (gamma - 1.0)*wl[4];      /* IdealGasPressure, src/eos/eos.hpp:37-40 */
+  double wr_ipr = (gamma - 1.0)*wr[4];
+  double qa, qb, qc, qd, qe, qf;
+  qa = sqrt(gamma*wl_ipr/wl_idn);           /* IdealHydroSoundSpeed, eos.hpp:43-46 */
+  qb = sqrt(gamma*wr_ipr/wr_idn);
+  double el = wl_ipr*igm1 + 0.5*wl_idn*(SQR(wl_ivx) + SQR(wl_ivy) + SQR(wl_ivz));
+  double er = wr_ipr*igm1 + 0.5*wr_idn*(SQR(wr_ivx) + SQR(wr_ivy) + SQR(wr_ivz));
+  qc = 0.25*(wl_idn + wr_idn)*(qa + qb);
+  qd = 0.5*(wl_ipr + wr_ipr + (wl_ivx - wr_ivx)*qc);
+  qe = (qd <= wl_ipr) ? 1.0 : sqrt(1.0 + alpha*((qd/wl_ipr) - 1.0));
+  qf = (qd <= wr_ipr) ? 1.0 : sqrt(1.0 + alpha*((qd/wr_ipr) - 1.0));
+  qc = wl_ivx - qa*qe;
+  qd = wr_ivx + qb*qf;
+  qa = qd > 0.0 ? qd : 1.0e-20;
+  qb = qc < 0.0 ? qc : -1.0e-20;
+  qe = wl_ivx - qc;
+  qf = wr_ivx - qd;
+  qc = wl_ipr + qe*wl_idn*wl_ivx;
+  qd = wr_ipr + qf*wr_idn*wr_ivx;
+  double ml = wl_idn*qe;
+  double mr = -(wr_idn*qf);
+  double am = (qc - qd)/(ml + mr);
+  double cp = (ml*qd + mr*qc)/(ml + mr);
+  cp = cp > 0.0 ? cp : 0.0;
+  qe = wl_idn*(wl_ivx - qb);
+  qf = wr_idn*(wr_ivx - qa);
+  double fl_d = qe, fr_d = qf;
+  double fl_mx = qe*wl_ivx + wl_ipr, fr_mx = qf*wr_ivx + wr_ipr;
+  double fl_my = qe*wl_ivy, fr_my = qf*wr_ivy;
+  double fl_mz = qe*wl_ivz, fr_mz = qf*wr_ivz;
+  double fl_e = el*(wl_ivx - qb) + wl_ipr*wl_ivx;
+  double fr_e = er*(wr_ivx - qa) + wr_ipr*wr_ivx;
+  if (am >= 0.0) {
+    qc = am/(am - qb);
+    qd = 0.0;
+    qe = -qb/(am - qb);
+  } else {
+    qc = 0.0;
+    qd = -am/(qa - am);
+    qe = qa/(qa - am);
+  }
+  flx[0] = qc*fl_d + qd*fr_d;
+  flx[1] = qc*fl_mx + qd*fr_mx + qe*cp;
+  flx[2] = qc*fl_my + qd*fr_my;
+  flx[3] = qc*fl_mz + qd*fr_mz;
+  flx[4] = qc*fl_e + qd*fr_e + qe*cp*am;
+}
+
+/* IdealMHDFastSpeed, src/eos/eos.hpp:49-57 */
+static inline double fast_speed(double gamma, double d, double p, double bx, double by,
+                                double bz) {
+  double asq = gamma*p;
+  double ct2 = by*by + bz*bz;
+  double qsq = bx*bx + ct2 + asq;
+  double tmp = bx*bx + ct2 - asq;
+  return sqrt(0.5*(qsq + sqrt(tmp*tmp + 4.0*asq*ct2))/d);
+}
+
+typedef struct { double d, mx, my, mz, e, by, bz; } cons1d;
+#define HLLD_SMALL_NUMBER 1.0e-4
+
+/* HLLD ideal-gas branch, src/mhd/rsolvers/hlld_mhd.hpp:41-347.
+ * wl/wr = (d, vx, vy, vz, e_int, by, bz) sweep-aligned; flx = (d,mx,my,mz,E,by,bz). */
+void akref_hlld(double gamma, const double wl[7], const double wr[7], double bxi,
+                double flx[7]) {
+  double spd[5];
+  double gm1 = gamma - 1.0;
+  double igm1 = 1.0/gm1;
+  double wl_idn = wl[0], wl_ivx = wl[1], wl_ivy = wl[2], wl_ivz = wl[3];
+  double wl_iby = wl[5], wl_ibz = wl[6];
+  double wr_idn = wr[0], wr_ivx = wr[1], wr_ivy = wr[2], wr_ivz = wr[3];
+  double wr_iby = wr[5], wr_ibz = wr[6];
+  double wl_ipr = (gamma - 1.0)*wl[4];
+  double wr_ipr = (gamma - 1.0)*wr[4];
+
+  double bxsq = bxi*bxi;
+  double pbl = 0.5*(bxsq + (SQR(wl_iby) + SQR(wl_ibz)));
+  double pbr = 0.5*(bxsq + (SQR(wr_iby) + SQR(wr_ibz)));
+  double kel = 0.5*wl_idn*(SQR(wl_ivx) + (SQR(wl_ivy) + SQR(wl_ivz)));
+  double ker = 0.5*wr_idn*(SQR(wr_ivx) + (SQR(wr_ivy) + SQR(wr_ivz)));
+
+  cons1d ul, ur;
+  ul.d = wl_idn; ul.mx = wl_ivx*ul.d; ul.my = wl_ivy*ul.d; ul.mz = wl_ivz*ul.d;
+  ul.e = wl_ipr*igm1 + kel + pbl; ul.by = wl_iby; ul.bz = wl_ibz;
+  ur.d = wr_idn; ur.mx = wr_ivx*ur.d; ur.my = wr_ivy*ur.d; ur.mz = wr_ivz*ur.d;
+  ur.e = wr_ipr*igm1 + ker + pbr; ur.by = wr_iby; ur.bz = wr_ibz;
+
+  double cfl = fast_speed(gamma, wl_idn, wl_ipr, bxi, wl_iby, wl_ibz);
+  double cfr = fast_speed(gamma, wr_idn, wr_ipr, bxi, wr_iby, wr_ibz);
+  spd[0] = fmin(wl_ivx - cfl, wr_ivx - cfr);
+  spd[4] = fmax(wl_ivx + cfl, wr_ivx + cfr);
+
+  double ptl = wl_ipr + pbl;
+  double ptr = wr_ipr + pbr;
+
+  cons1d fl, fr, flxi;
+  fl.d = ul.mx;
+  fl.mx = ul.mx*wl_ivx + ptl - bxsq;
+  fl.my = ul.my*wl_ivx - bxi*ul.by;
+  fl.mz = ul.mz*wl_ivx - bxi*ul.bz;
+  fl.e = wl_ivx*(ul.e + ptl - bxsq) - bxi*(wl_ivy*ul.by + wl_ivz*ul.bz);
+  fl.by = ul.by*wl_ivx - bxi*wl_ivy;
+  fl.bz = ul.bz*wl_ivx - bxi*wl_ivz;
+
+  fr.d = ur.mx;
+  fr.mx = ur.mx*wr_ivx + ptr - bxsq;
+  fr.my = ur.my*wr_ivx - bxi*ur.by;
+  fr.mz = ur.mz*wr_ivx - bxi*ur.bz;
+  fr.e = wr_ivx*(ur.e + ptr - bxsq) - bxi*(wr_ivy*ur.by + wr_ivz*ur.bz);
+  fr.by = ur.by*wr_ivx - bxi*wr_ivy;
+  fr.bz = ur.bz*wr_ivx - bxi*wr_ivz;
+
+  double sdl = spd[0] - wl_ivx;
+  double sdr = spd[4] - wr_ivx;
+  spd[2] = (sdr*ur.mx - sdl*ul.mx + (ptl - ptr))/(sdr*ur.d - sdl*ul.d);
+
+  double sdml = spd[0] - spd[2];
+  double sdmr = spd[4] - spd[2];
+  double sdml_inv = 1.0/sdml;
+  double sdmr_inv = 1.0/sdmr;
+
+  cons1d ulst, uldst, urdst, urst;
+  ulst.d = ul.d*sdl*sdml_inv;
+  urst.d = ur.d*sdr*sdmr_inv;
+  double ulst_d_inv = 1.0/ulst.d;
+  double urst_d_inv = 1.0/urst.d;
+  double sqrtdl = sqrt(ulst.d);
+  double sqrtdr = sqrt(urst.d);
+
+  spd[1] = spd[2] - fabs(bxi)/sqrtdl;
+  spd[3] = spd[2] + fabs(bxi)/sqrtdr;
+
+  double ptstl = ptl + ul.d*sdl*(spd[2] - wl_ivx);
+  double ptstr = ptr + ur.d*sdr*(spd[2] - wr_ivx);
+  double ptst = 0.5*(ptstr + ptstl);
+
+  ulst.mx = ulst.d*spd[2];
+  if (fabs(ul.d*sdl*sdml - bxsq) < (HLLD_SMALL_NUMBER)*ptst) {
+    ulst.my = ulst.d*wl_ivy;
+    ulst.mz = ulst.d*wl_ivz;
+    ulst.by = ul.by;
+    ulst.bz = ul.bz;
+  } else {
+    double tmp = bxi*(sdl - sdml)/(ul.d*sdl*sdml - bxsq);
+    ulst.my = ulst.d*(wl_ivy - ul.by*tmp);
+    ulst.mz = ulst.d*(wl_ivz - ul.bz*tmp);
+    tmp = (ul.d*SQR(sdl) - bxsq)/(ul.d*sdl*sdml - bxsq);
+    ulst.by = ul.by*tmp;
+    ulst.bz = ul.bz*tmp;
+  }
+  double vbstl = (ulst.mx*bxi + (ulst.my*ulst.by + ulst.mz*ulst.bz))*ulst_d_inv;
+  ulst.e = (sdl*ul.e - ptl*wl_ivx + ptst*spd[2] +
+            bxi*(wl_ivx*bxi + (wl_ivy*ul.by + wl_ivz*ul.bz) - vbstl))*sdml_inv;
+
+  urst.mx = urst.d*spd[2];
+  if (fabs(ur.d*sdr*sdmr - bxsq) < (HLLD_SMALL_NUMBER)*ptst) {
+    urst.my = urst.d*wr_ivy;
+    urst.mz = urst.d*wr_ivz;
+    urst.by = ur.by;
+    urst.bz = ur.bz;
+  } else {
+    double tmp = bxi*(sdr - sdmr)/(ur.d*sdr*sdmr - bxsq);
+    urst.my = urst.d*(wr_ivy - ur.by*tmp);
+    urst.mz = urst.d*(wr_ivz - ur.bz*tmp);
+    tmp = (ur.d*SQR(sdr) - bxsq)/(ur.d*sdr*sdmr - bxsq);
+    urst.by = ur.by*tmp;
+    urst.bz = ur.bz*tmp;
+  }
+  double vbstr = (urst.mx*bxi + (urst.my*urst.by + urst.mz*urst.bz))*urst_d_inv;
+  urst.e = (sdr*ur.e - ptr*wr_ivx + ptst*spd[2] +
+            bxi*(wr_ivx*bxi + (wr_ivy*ur.by + wr_ivz*ur.bz) - vbstr))*sdmr_inv;
+
+  if (0.5*bxsq < (HLLD_SMALL_NUMBER)*ptst) {
+    uldst = ulst;
+    urdst = urst;
+  } else {
+    double invsumd = 1.0/(sqrtdl + sqrtdr);
+    double bxsig = (bxi > 0.0 ? 1.0 : -1.0);
+    uldst.d = ulst.d;
+    urdst.d = urst.d;
+    uldst.mx = ulst.mx;
+    urdst.mx = urst.mx;
+    double tmp = invsumd*(sqrtdl*(ulst.my*ulst_d_inv) + sqrtdr*(urst.my*urst_d_inv) +
+                          bxsig*(urst.by - ulst.by));
+    uldst.my = uldst.d*tmp;
+    urdst.my = urdst.d*tmp;
+    tmp = invsumd*(sqrtdl*(ulst.mz*ulst_d_inv) + sqrtdr*(urst.mz*urst_d_inv) +
+                   bxsig*(urst.bz - ulst.bz));
+    uldst.mz = uldst.d*tmp;
+    urdst.mz = urdst.d*tmp;
+    tmp = invsumd*(sqrtdl*urst.by + sqrtdr*ulst.by +
+                   bxsig*sqrtdl*sqrtdr*((urst.my*urst_d_inv) - (ulst.my*ulst_d_inv)));
+    uldst.by = urdst.by = tmp;
+    tmp = invsumd*(sqrtdl*urst.bz + sqrtdr*ulst.bz +
+                   bxsig*sqrtdl*sqrtdr*((urst.mz*urst_d_inv) - (ulst.mz*ulst_d_inv)));
+    uldst.bz = urdst.bz = tmp;
+    tmp = spd[2]*bxi + (uldst.my*uldst.by + uldst.mz*uldst.bz)/uldst.d;
+    uldst.e = ulst.e - sqrtdl*bxsig*(vbstl - tmp);
+    urdst.e = urst.e + sqrtdr*bxsig*(vbstr - tmp);
+  }
+
+  uldst.d = spd[1]*(uldst.d - ulst.d);
+  uldst.mx = spd[1]*(uldst.mx - ulst.mx);
+  uldst.my = spd[1]*(uldst.my - ulst.my);
+  uldst.mz = spd[1]*(uldst.mz - ulst.mz);
+  uldst.e = spd[1]*(uldst.e - ulst.e);
+  uldst.by = spd[1]*(uldst.by - ulst.by);
+  uldst.bz = spd[1]*(uldst.bz - ulst.bz);
+
+  ulst.d = spd[0]*(ulst.d - ul.d);
+  ulst.mx = spd[0]*(ulst.mx - ul.mx);
+  ulst.my = spd[0]*(ulst.my - ul.my);
+  ulst.mz = spd[0]*(ulst.mz - ul.mz);
+  ulst.e = spd[0]*(ulst.e - ul.e);
+  ulst.by = spd[0]*(ulst.by - ul.by);
+  ulst.bz = spd[0]*(ulst.bz - ul.bz);
+
+  urdst.d = spd[3]*(urdst.d - urst.d);
+  urdst.mx = spd[3]*(urdst.mx - urst.mx);
+  urdst.my = spd[3]*(urdst.my - urst.my);
+  urdst.mz = spd[3]*(urdst.mz - urst.mz);
+  urdst.e = spd[3]*(urdst.e - urst.e);
+  urdst.by = spd[3]*(urdst.by - urst.by);
+  urdst.bz = spd[3]*(urdst.bz - urst.bz);
+
+  urst.d = spd[4]*(urst.d - ur.d);
+  urst.mx = spd[4]*(urst.mx - ur.mx);
+  urst.my = spd[4]*(urst.my - ur.my);
+  urst.mz = spd[4]*(urst.mz - ur.mz);
+  urst.e = spd[4]*(urst.e - ur.e);
+  urst.by = spd[4]*(urst.by - ur.by);
+  urst.bz = spd[4]*(urst.bz - ur.bz);
+
+  if (spd[0] >= 0.0) {
+    flxi = fl;
+  } else if (spd[4] <= 0.0) {
+    flxi = fr;
+  } else if (spd[1] >= 0.0) {
+    flxi.d = fl.d + ulst.d;   flxi.mx = fl.mx + ulst.mx; flxi.my = fl.my + ulst.my;
+    flxi.mz = fl.mz + ulst.mz; flxi.e = fl.e + ulst.e;
+    flxi.by = fl.by + ulst.by; flxi.bz = fl.bz + ulst.bz;
+  } else if (spd[2] >= 0.0) {
+    flxi.d = fl.d + ulst.d + uldst.d;     flxi.mx = fl.mx + ulst.mx + uldst.mx;
+    flxi.my = fl.my + ulst.my + uldst.my; flxi.mz = fl.mz + ulst.mz + uldst.mz;
+    flxi.e = fl.e + ulst.e + uldst.e;
+    flxi.by = fl.by + ulst.by + uldst.by; flxi.bz = fl.bz + ulst.bz + uldst.bz;
+  } else if (spd[3] > 0.0) {
+    flxi.d = fr.d + urst.d + urdst.d;     flxi.mx = fr.mx + urst.mx + urdst.mx;
+    flxi.my = fr.my + urst.my + urdst.my; flxi.mz = fr.mz + urst.mz + urdst.mz;
+    flxi.e = fr.e + urst.e + urdst.e;
+    flxi.by = fr.by + urst.by + urdst.by; flxi.bz = fr.bz + urst.bz + urdst.bz;
+  } else {
+    flxi.d = fr.d + urst.d;   flxi.mx = fr.mx + urst.mx; flxi.my = fr.my + urst.my;
+    flxi.mz = fr.mz + urst.mz; flxi.e = fr.e + urst.e;
+    flxi.by = fr.by + urst.by; flxi.bz = fr.bz + urst.bz;
+  }
+  flx[0] = flxi.d; flx[1] = flxi.mx; flx[2] = flxi.my; flx[3] = flxi.mz; flx[4] = flxi.e;
+  flx[5] = flxi.by; flx[6] = flxi.bz;
+}
+
+/* ------------------------------------------------------------------------------------ */
+int akref_copy_cons(const akmi_pack *p, const double *u0, double *u1) {
+  G g = mkG(p);
+  memcpy(u1, u0, sizeof(double)*(size_t)g.nmb*g.nvar*g.N3*g.N2*g.N1);
+  return 0;
+}
+
+/* Hydro::CalculateFluxes<hllc>, src/hydro/hydro_fluxes.cpp:77-229 (no FOFC, no scalars) */
+int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                       double *flx1, double *flx2, double *flx3, int fs) {
+  if (rsolver != AKMI_RS_HLLC) return AKMI_FAIL;
+  G g = mkG(p);
+  const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  size_t ncell = (size_t)g.nmb*nv*N3*N2*N1;
+  double *wl = ws_get(0, ncell), *wr = ws_get(1, ncell);
+  const double gamma = p->gamma;
+  for (int dir = 0; dir < 3; ++dir) {
+    if (dir == 1 && !g.multi_d) continue;
+    if (dir == 2 && !g.three_d) continue;
+    int il = g.is, iu = g.ie, jl = g.js, ju = g.je, kl = g.ks, ku = g.ke;
+    double *flx = flx1;
+    int f3 = N3, f2 = N2, f1 = N1 + fs;
+    if (dir == 0) { recon_dir(&g, recon, 0, nv, w0, wl, wr, kl, ku, jl, ju, il-1, iu+1); iu = g.ie+1; }
+    if (dir == 1) { recon_dir(&g, recon, 1, nv, w0, wl, wr, kl, ku, jl-1, ju+1, il, iu); ju = g.je+1;
+                    flx = flx2; f1 = N1; f2 = N2 + fs; }
+    if (dir == 2) { recon_dir(&g, recon, 2, nv, w0, wl, wr, kl-1, ku+1, jl, ju, il, iu); ku = g.ke+1;
+                    flx = flx3; f1 = N1; f3 = N3 + fs; }
+    const int ivx = IVX + dir, ivy = IVX + (dir + 1)%3, ivz = IVX + (dir + 2)%3;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int m = 0; m < g.nmb; ++m)
+      for (int k = kl; k <= ku; ++k)
+        for (int j = jl; j <= ju; ++j)
+          for (int i = il; i <= iu; ++i) {
+            double a[5], b[5], f[5];
+            a[0] = wl[ix5(nv,N3,N2,N1,m,IDN,k,j,i)]; b[0] = wr[ix5(nv,N3,N2,N1,m,IDN,k,j,i)];
+            a[1] = wl[ix5(nv,N3,N2,N1,m,ivx,k,j,i)]; b[1] = wr[ix5(nv,N3,N2,N1,m,ivx,k,j,i)];
+            a[2] = wl[ix5(nv,N3,N2,N1,m,ivy,k,j,i)]; b[2] = wr[ix5(nv,N3,N2,N1,m,ivy,k,j,i)];
+            a[3] = wl[ix5(nv,N3,N2,N1,m,ivz,k,j,i)]; b[3] = wr[ix5(nv,N3,N2,N1,m,ivz,k,j,i)];
+            a[4] = wl[ix5(nv,N3,N2,N1,m,IEN,k,j,i)]; b[4] = wr[ix5(nv,N3,N2,N1,m,IEN,k,j,i)];
+            akref_hllc(gamma, a, b, f);
+            flx[ix5(nv,f3,f2,f1,m,IDN,k,j,i)] = f[0];
+            flx[ix5(nv,f3,f2,f1,m,ivx,k,j,i)] = f[1];
+            flx[ix5(nv,f3,f2,f1,m,ivy,k,j,i)] = f[2];
+            flx[ix5(nv,f3,f2,f1,m,ivz,k,j,i)] = f[3];
+            flx[ix5(nv,f3,f2,f1,m,IEN,k,j,i)] = f[4];
+          }
+  }
+  return 0;
+}
+
+/* RKUpdate, src/hydro/hydro_update.cpp:23-83 == src/mhd/mhd_update.cpp:24-84 */
+int akref_rk_update(const akmi_pack *p, double gam0, double gam1, double beta_dt,
+                    double *u0, const double *u1, const double *flx1, const double *flx2,
+                    const double *flx3, int fs) {
+  G g = mkG(p);
+  const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
+#pragma omp parallel for collapse(3) schedule(static)
+  for (int m = 0; m < g.nmb; ++m)
+    for (int n = 0; n < nv; ++n)
+      for (int k = g.ks; k <= g.ke; ++k)
+        for (int j = g.js; j <= g.je; ++j) {
+          const double dx1 = p->dx[3*m], dx2 = p->dx[3*m+1], dx3 = p->dx[3*m+2];
+          for (int i = g.is; i <= g.ie; ++i) {
+            double divf = (flx1[ix5(nv,N3,N2,N1+fs,m,n,k,j,i+1)] -
+                           flx1[ix5(nv,N3,N2,N1+fs,m,n,k,j,i)])/dx1;
+            if (g.multi_d)
+              divf += (flx2[ix5(nv,N3,N2+fs,N1,m,n,k,j+1,i)] -
+                       flx2[ix5(nv,N3,N2+fs,N1,m,n,k,j,i)])/dx2;
+            if (g.three_d)
+              divf += (flx3[ix5(nv,N3+fs,N2,N1,m,n,k+1,j,i)] -
+                       flx3[ix5(nv,N3+fs,N2,N1,m,n,k,j,i)])/dx3;
+            size_t c = ix5(nv,N3,N2,N1,m,n,k,j,i);
+            u0[c] = gam0*u0[c] + gam1*u1[c] - beta_dt*divf;
+          }
+        }
+  return 0;
+}
+
+/* SingleC2P_IdealHyd, src/eos/ideal_c2p_hyd.hpp:22-66 ; wrapper src/eos/ideal_hyd.cpp:29-115 */
+int akref_hydro_c2p(const akmi_pack *p, double *u0, double *w0, int il, int iu, int jl,
+                    int ju, int kl, int ku, int *counters) {
+  G g = mkG(p);
+  const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  const double gm1 = p->gamma - 1.0;
+  const double efloor = p->pfloor/(p->gamma - 1.0);
+  const double tfloor = p->tfloor, sfloor = p->sfloor, dfloor_ = p->dfloor;
+  int sumd = 0, sume = 0, sumt = 0;
+#pragma omp parallel for collapse(2) schedule(static) reduction(+:sumd,sume,sumt)
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = kl; k <= ku; ++k)
+      for (int j = jl; j <= ju; ++j)
+        for (int i = il; i <= iu; ++i) {
+          size_t cd = ix5(nv,N3,N2,N1,m,IDN,k,j,i), cx = ix5(nv,N3,N2,N1,m,IVX,k,j,i);
+          size_t cy = ix5(nv,N3,N2,N1,m,IVY,k,j,i), cz = ix5(nv,N3,N2,N1,m,IVZ,k,j,i);
+          size_t ce = ix5(nv,N3,N2,N1,m,IEN,k,j,i);
+          double ud = u0[cd], umx = u0[cx], umy = u0[cy], umz = u0[cz], ue = u0[ce];
+          int dfl = 0, efl = 0, tfl = 0;
+          if (ud < dfloor_) { ud = dfloor_; dfl = 1; }
+          double wd = ud;
+          double di = 1.0/ud;
+          double wvx = di*umx, wvy = di*umy, wvz = di*umz;
+          double e_k = 0.5*di*(SQR(umx) + SQR(umy) + SQR(umz));
+          double we = (ue - e_k);
+          if (we < efloor) { we = efloor; ue = efloor + e_k; efl = 1; }
+          if (gm1*we*di < tfloor) { we = wd*tfloor/gm1; ue = we + e_k; tfl = 1; }
+          double spe_over_eps = gm1/pow(wd, gm1);
+          double spe = spe_over_eps*we*di;
+          if (spe <= sfloor) { we = wd*sfloor/spe_over_eps; efl = 1; }
+          if (dfl) { u0[cd] = ud; sumd++; }
+          if (efl) { u0[ce] = ue; sume++; }
+          if (tfl) { u0[ce] = ue; sumt++; }
+          w0[cd] = wd; w0[cx] = wvx; w0[cy] = wvy; w0[cz] = wvz; w0[ce] = we;
+        }
+  if (counters) { counters[0] += sumd; counters[1] += sume; counters[2] += sumt; }
+  return 0;
+}
+
+/* Hydro::NewTimeStep, src/hydro/hydro_newdt.cpp:30-139 (Newtonian ideal branch 97-118) */
+int akref_hydro_newdt(const akmi_pack *p, const double *w0, double *dt3) {
+  G g = mkG(p);
+  const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  double dt1 = (double)FLT_MAX, dt2 = (double)FLT_MAX, dt3_ = (double)FLT_MAX;
+#pragma omp parallel for collapse(2) schedule(static) reduction(min:dt1,dt2,dt3_)
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = g.ks; k <= g.ke; ++k)
+      for (int j = g.js; j <= g.je; ++j)
+        for (int i = g.is; i <= g.ie; ++i) {
+          double pr = (p->gamma - 1.0)*w0[ix5(nv,N3,N2,N1,m,IEN,k,j,i)];
+          double cs = sqrt(p->gamma*pr/w0[ix5(nv,N3,N2,N1,m,IDN,k,j,i)]);
+          double max_dv1 = fabs(w0[ix5(nv,N3,N2,N1,m,IVX,k,j,i)]) + cs;
+          double max_dv2 = fabs(w0[ix5(nv,N3,N2,N1,m,IVY,k,j,i)]) + cs;
+          double max_dv3 = fabs(w0[ix5(nv,N3,N2,N1,m,IVZ,k,j,i)]) + cs;
+          dt1 = fmin(p->dx[3*m]/max_dv1, dt1);
+          dt2 = fmin(p->dx[3*m+1]/max_dv2, dt2);
+          dt3_ = fmin(p->dx[3*m+2]/max_dv3, dt3_);
+        }
+  dt3[0] = dt1; dt3[1] = dt2; dt3[2] = dt3_;
+  return 0;
+}
+
+/* MHD::CalculateFluxes<hlld>, src/mhd/mhd_fluxes.cpp:84-266 */
+int akref_mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                     const double *bcc0, const double *bx1f, const double *bx2f,
+                     const double *bx3f, double *flx1, double *flx2, double *flx3,
+                     double *e3x1, double *e2x1, double *e1x2, double *e3x2, double *e2x3,
+                     double *e1x3) {
+  if (rsolver != AKMI_RS_HLLD) return AKMI_FAIL;
+  G g = mkG(p);
+  const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  size_t ncell = (size_t)g.nmb*N3*N2*N1;
+  double *wl = ws_get(0, ncell*nv), *wr = ws_get(1, ncell*nv);
+  double *bl = ws_get(2, ncell*3), *br = ws_get(3, ncell*3);
+  const double gamma = p->gamma;
+  for (int dir = 0; dir < 3; ++dir) {
+    if (dir == 1 && !g.multi_d) continue;
+    if (dir == 2 && !g.three_d) continue;
+    int il, iu, jl, ju, kl, ku;
+    const double *bx; double *flx, *ey, *ez;
+    int f3 = N3, f2 = N2, f1 = N1;
+    if (dir == 0) {
+      jl = g.js; ju = g.je; kl = g.ks; ku = g.ke;
+      if (g.multi_d) { jl = g.js-1; ju = g.je+1; }
+      if (g.three_d) { kl = g.ks-1; ku = g.ke+1; }
+      recon_dir(&g, recon, 0, nv, w0, wl, wr, kl, ku, jl, ju, g.is-1, g.ie+1);
+      recon_dir(&g, recon, 0, 3, bcc0, bl, br, kl, ku, jl, ju, g.is-1, g.ie+1);
+      il = g.is; iu = g.ie+1;
+      bx = bx1f; flx = flx1; ey = e3x1; ez = e2x1; f1 = N1+1;
+    } else if (dir == 1) {
+      kl = g.ks; ku = g.ke;
+      if (g.three_d) { kl = g.ks-1; ku = g.ke+1; }
+      recon_dir(&g, recon, 1, nv, w0, wl, wr, kl, ku, g.js-1, g.je+1, g.is-1, g.ie+1);
+      recon_dir(&g, recon, 1, 3, bcc0, bl, br, kl, ku, g.js-1, g.je+1, g.is-1, g.ie+1);
+      il = g.is-1; iu = g.ie+1; jl = g.js; ju = g.je+1;
+      bx = bx2f; flx = flx2; ey = e1x2; ez = e3x2; f2 = N2+1;
+    } else {
+      recon_dir(&g, recon, 2, nv, w0, wl, wr, g.ks-1, g.ke+1, g.js-1, g.je+1, g.is-1, g.ie+1);
+      recon_dir(&g, recon, 2, 3, bcc0, bl, br, g.ks-1, g.ke+1, g.js-1, g.je+1, g.is-1, g.ie+1);
+      il = g.is-1; iu = g.ie+1; jl = g.js-1; ju = g.je+1; kl = g.ks; ku = g.ke+1;
+      bx = bx3f; flx = flx3; ey = e2x3; ez = e1x3; f3 = N3+1;
+    }
+    const int ivx = IVX + dir, ivy = IVX + (dir + 1)%3, ivz = IVX + (dir + 2)%3;
+    const int iby = (dir + 1)%3, ibz = (dir + 2)%3;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int m = 0; m < g.nmb; ++m)
+      for (int k = kl; k <= ku; ++k)
+        for (int j = jl; j <= ju; ++j)
+          for (int i = il; i <= iu; ++i) {
+            double a[7], b[7], f[7];
+            a[0] = wl[ix5(nv,N3,N2,N1,m,IDN,k,j,i)]; b[0] = wr[ix5(nv,N3,N2,N1,m,IDN,k,j,i)];
+            a[1] = wl[ix5(nv,N3,N2,N1,m,ivx,k,j,i)]; b[1] = wr[ix5(nv,N3,N2,N1,m,ivx,k,j,i)];
+            a[2] = wl[ix5(nv,N3,N2,N1,m,ivy,k,j,i)]; b[2] = wr[ix5(nv,N3,N2,N1,m,ivy,k,j,i)];
+            a[3] = wl[ix5(nv,N3,N2,N1,m,ivz,k,j,i)]; b[3] = wr[ix5(nv,N3,N2,N1,m,ivz,k,j,i)];
+            a[4] = wl[ix5(nv,N3,N2,N1,m,IEN,k,j,i)]; b[4] = wr[ix5(nv,N3,N2,N1,m,IEN,k,j,i)];
+            a[5] = bl[ix5(3,N3,N2,N1,m,iby,k,j,i)];  b[5] = br[ix5(3,N3,N2,N1,m,iby,k,j,i)];
+            a[6] = bl[ix5(3,N3,N2,N1,m,ibz,k,j,i)];  b[6] = br[ix5(3,N3,N2,N1,m,ibz,k,j,i)];
+            double bxi = bx[ix4(f3,f2,f1,m,k,j,i)];
+            akref_hlld(gamma, a, b, bxi, f);
+            flx[ix5(nv,f3,f2,f1,m,IDN,k,j,i)] = f[0];
+            flx[ix5(nv,f3,f2,f1,m,ivx,k,j,i)] = f[1];
+            flx[ix5(nv,f3,f2,f1,m,ivy,k,j,i)] = f[2];
+            flx[ix5(nv,f3,f2,f1,m,ivz,k,j,i)] = f[3];
+            flx[ix5(nv,f3,f2,f1,m,IEN,k,j,i)] = f[4];
+            ey[ix4(N3,N2,N1,m,k,j,i)] = -f[5];
+            ez[ix4(N3,N2,N1,m,k,j,i)] = f[6];
+          }
+  }
+  return 0;
+}
+
+/* MHD::CornerE, src/mhd/mhd_corner_e.cpp:26-417 (Newtonian branches: 1D :39-53,
+ * 2D :58-66,139-192, 3D :303-414) */
+int akref_mhd_corner_e(const akmi_pack *p, const double *w0, const double *bcc0,
+                       const double *e3x1, const double *e2x1, const double *e1x2,
+                       const double *e3x2, const double *e2x3, const double *e1x3,
+                       const double *flx1, const double *flx2, const double *flx3,
+                       double *e1, double *e2, double *e3) {
+  G g = mkG(p);
+  const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  const int is = g.is, ie = g.ie, js = g.js, je = g.je, ks = g.ks, ke = g.ke;
+#define CC(a,m,k,j,i)  a[ix4(N3,N2,N1,m,k,j,i)]
+#define E1(m,k,j,i) e1[ix4(N3+1,N2+1,N1,m,k,j,i)]
+#define E2(m,k,j,i) e2[ix4(N3+1,N2,N1+1,m,k,j,i)]
+#define E3(m,k,j,i) e3[ix4(N3,N2+1,N1+1,m,k,j,i)]
+#define F1D(m,k,j,i) flx1[ix5(nv,N3,N2,N1+1,m,IDN,k,j,i)]
+#define F2D(m,k,j,i) flx2[ix5(nv,N3,N2+1,N1,m,IDN,k,j,i)]
+#define F3D(m,k,j,i) flx3[ix5(nv,N3+1,N2,N1,m,IDN,k,j,i)]
+#define W(n,m,k,j,i) w0[ix5(nv,N3,N2,N1,m,n,k,j,i)]
+#define B(n,m,k,j,i) bcc0[ix5(3,N3,N2,N1,m,n,k,j,i)]
+  if (!g.multi_d) {
+    for (int m = 0; m < g.nmb; ++m)
+      for (int i = is; i <= ie+1; ++i) {
+        E2(m,ks,js,i) = CC(e2x1,m,ks,js,i);
+        E2(m,ke+1,js,i) = CC(e2x1,m,ks,js,i);
+        E3(m,ks,js,i) = CC(e3x1,m,ks,js,i);
+        E3(m,ks,je+1,i) = CC(e3x1,m,ks,js,i);
+      }
+    return 0;
+  }
+  size_t ncell = (size_t)g.nmb*N3*N2*N1;
+  double *e1cc = ws_get(4, ncell), *e2cc = ws_get(5, ncell), *e3cc = ws_get(6, ncell);
+  if (!g.three_d) {
+    for (int m = 0; m < g.nmb; ++m)
+      for (int j = js-1; j <= je+1; ++j)
+        for (int i = is-1; i <= ie+1; ++i)
+          CC(e3cc,m,ks,j,i) = W(IVY,m,ks,j,i)*B(IBX,m,ks,j,i) - W(IVX,m,ks,j,i)*B(IBY,m,ks,j,i);
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < g.nmb; ++m)
+      for (int j = js; j <= je+1; ++j)
+        for (int i = is; i <= ie+1; ++i) {
+          E2(m,ks,j,i) = CC(e2x1,m,ks,j,i);
+          E2(m,ke+1,j,i) = CC(e2x1,m,ks,j,i);
+          E1(m,ks,j,i) = CC(e1x2,m,ks,j,i);
+          E1(m,ke+1,j,i) = CC(e1x2,m,ks,j,i);
+          double e3_l2, e3_r2, e3_l1, e3_r1;
+          if (F1D(m,ks,j-1,i) >= 0.0) e3_l2 = CC(e3x2,m,ks,j,i-1) - CC(e3cc,m,ks,j-1,i-1);
+          else                        e3_l2 = CC(e3x2,m,ks,j,i  ) - CC(e3cc,m,ks,j-1,i  );
+          if (F1D(m,ks,j,i) >= 0.0)   e3_r2 = CC(e3x2,m,ks,j,i-1) - CC(e3cc,m,ks,j  ,i-1);
+          else                        e3_r2 = CC(e3x2,m,ks,j,i  ) - CC(e3cc,m,ks,j  ,i  );
+          if (F2D(m,ks,j,i-1) >= 0.0) e3_l1 = CC(e3x1,m,ks,j-1,i) - CC(e3cc,m,ks,j-1,i-1);
+          else                        e3_l1 = CC(e3x1,m,ks,j  ,i) - CC(e3cc,m,ks,j  ,i-1);
+          if (F2D(m,ks,j,i) >= 0.0)   e3_r1 = CC(e3x1,m,ks,j-1,i) - CC(e3cc,m,ks,j-1,i  );
+          else                        e3_r1 = CC(e3x1,m,ks,j  ,i) - CC(e3cc,m,ks,j  ,i  );
+          E3(m,ks,j,i) = 0.25*(e3_l1 + e3_r1 + e3_l2 + e3_r2 +
+              CC(e3x2,m,ks,j,i-1) + CC(e3x2,m,ks,j,i) + CC(e3x1,m,ks,j-1,i) + CC(e3x1,m,ks,j,i));
+        }
+    return 0;
+  }
+  /* 3D: e_cc_3d (src/mhd/mhd_corner_e.cpp:309-317) */
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = ks-1; k <= ke+1; ++k)
+      for (int j = js-1; j <= je+1; ++j)
+        for (int i = is-1; i <= ie+1; ++i) {
+          CC(e1cc,m,k,j,i) = W(IVZ,m,k,j,i)*B(IBY,m,k,j,i) - W(IVY,m,k,j,i)*B(IBZ,m,k,j,i);
+          CC(e2cc,m,k,j,i) = W(IVX,m,k,j,i)*B(IBZ,m,k,j,i) - W(IVZ,m,k,j,i)*B(IBX,m,k,j,i);
+          CC(e3cc,m,k,j,i) = W(IVY,m,k,j,i)*B(IBX,m,k,j,i) - W(IVX,m,k,j,i)*B(IBY,m,k,j,i);
+        }
+  /* emf3 (src/mhd/mhd_corner_e.cpp:338-414) */
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = ks; k <= ke+1; ++k)
+      for (int j = js; j <= je+1; ++j)
+        for (int i = is; i <= ie+1; ++i) {
+          double e1_l3, e1_r3, e1_l2, e1_r2;
+          if (F2D(m,k-1,j,i) >= 0.0) e1_l3 = CC(e1x3,m,k,j-1,i) - CC(e1cc,m,k-1,j-1,i);
+          else                       e1_l3 = CC(e1x3,m,k,j  ,i) - CC(e1cc,m,k-1,j  ,i);
+          if (F2D(m,k,j,i) >= 0.0)   e1_r3 = CC(e1x3,m,k,j-1,i) - CC(e1cc,m,k  ,j-1,i);
+          else                       e1_r3 = CC(e1x3,m,k,j  ,i) - CC(e1cc,m,k  ,j  ,i);
+          if (F3D(m,k,j-1,i) >= 0.0) e1_l2 = CC(e1x2,m,k-1,j,i) - CC(e1cc,m,k-1,j-1,i);
+          else                       e1_l2 = CC(e1x2,m,k  ,j,i) - CC(e1cc,m,k  ,j-1,i);
+          if (F3D(m,k,j,i) >= 0.0)   e1_r2 = CC(e1x2,m,k-1,j,i) - CC(e1cc,m,k-1,j  ,i);
+          else                       e1_r2 = CC(e1x2,m,k  ,j,i) - CC(e1cc,m,k  ,j  ,i);
+          /* the reference writes all three components over the full (k,j,i) range */
+          E1(m,k,j,i) = 0.25*(e1_l3 + e1_r3 + e1_l2 + e1_r2 +
+              CC(e1x2,m,k-1,j,i) + CC(e1x2,m,k,j,i) + CC(e1x3,m,k,j-1,i) + CC(e1x3,m,k,j,i));
+
+          double e2_l3, e2_r3, e2_l1, e2_r1;
+          if (F1D(m,k-1,j,i) >= 0.0) e2_l3 = CC(e2x3,m,k,j,i-1) - CC(e2cc,m,k-1,j,i-1);
+          else                       e2_l3 = CC(e2x3,m,k,j,i  ) - CC(e2cc,m,k-1,j,i  );
+          if (F1D(m,k,j,i) >= 0.0)   e2_r3 = CC(e2x3,m,k,j,i-1) - CC(e2cc,m,k  ,j,i-1);
+          else                       e2_r3 = CC(e2x3,m,k,j,i  ) - CC(e2cc,m,k  ,j,i  );
+          if (F3D(m,k,j,i-1) >= 0.0) e2_l1 = CC(e2x1,m,k-1,j,i) - CC(e2cc,m,k-1,j,i-1);
+          else                       e2_l1 = CC(e2x1,m,k  ,j,i) - CC(e2cc,m,k  ,j,i-1);
+          if (F3D(m,k,j,i) >= 0.0)   e2_r1 = CC(e2x1,m,k-1,j,i) - CC(e2cc,m,k-1,j,i  );
+          else                       e2_r1 = CC(e2x1,m,k  ,j,i) - CC(e2cc,m,k  ,j,i  );
+          E2(m,k,j,i) = 0.25*(e2_l3 + e2_r3 + e2_l1 + e2_r1 +
+              CC(e2x3,m,k,j,i-1) + CC(e2x3,m,k,j,i) + CC(e2x1,m,k-1,j,i) + CC(e2x1,m,k,j,i));
+
+          double e3_l2, e3_r2, e3_l1, e3_r1;
+          if (F1D(m,k,j-1,i) >= 0.0) e3_l2 = CC(e3x2,m,k,j,i-1) - CC(e3cc,m,k,j-1,i-1);
+          else                       e3_l2 = CC(e3x2,m,k,j,i  ) - CC(e3cc,m,k,j-1,i  );
+          if (F1D(m,k,j,i) >= 0.0)   e3_r2 = CC(e3x2,m,k,j,i-1) - CC(e3cc,m,k,j  ,i-1);
+          else                       e3_r2 = CC(e3x2,m,k,j,i  ) - CC(e3cc,m,k,j  ,i  );
+          if (F2D(m,k,j,i-1) >= 0.0) e3_l1 = CC(e3x1,m,k,j-1,i) - CC(e3cc,m,k,j-1,i-1);
+          else                       e3_l1 = CC(e3x1,m,k,j  ,i) - CC(e3cc,m,k,j  ,i-1);
+          if (F2D(m,k,j,i) >= 0.0)   e3_r1 = CC(e3x1,m,k,j-1,i) - CC(e3cc,m,k,j-1,i  );
+          else                       e3_r1 = CC(e3x1,m,k,j  ,i) - CC(e3cc,m,k,j  ,i  );
+          E3(m,k,j,i) = 0.25*(e3_l1 + e3_r1 + e3_l2 + e3_r2 +
+              CC(e3x2,m,k,j,i-1) + CC(e3x2,m,k,j,i) + CC(e3x1,m,k,j-1,i) + CC(e3x1,m,k,j,i));
+        }
+  return 0;
+}
+
+/* MHD::CT, src/mhd/mhd_ct.cpp:23-80 */
+int akref_mhd_ct(const akmi_pack *p, double gam0, double gam1, double beta_dt,
+                 const double *e1, const double *e2, const double *e3, double *b0x1f,
+                 double *b0x2f, double *b0x3f, const double *b1x1f, const double *b1x2f,
+                 const double *b1x3f) {
+  G g = mkG(p);
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  const int is = g.is, ie = g.ie, js = g.js, je = g.je, ks = g.ks, ke = g.ke;
+  if (g.multi_d) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int m = 0; m < g.nmb; ++m)
+      for (int k = ks; k <= ke; ++k)
+        for (int j = js; j <= je; ++j)
+          for (int i = is; i <= ie+1; ++i) {
+            size_t c = ix4(N3,N2,N1+1,m,k,j,i);
+            b0x1f[c] = gam0*b0x1f[c] + gam1*b1x1f[c];
+            b0x1f[c] -= beta_dt*(E3(m,k,j+1,i) - E3(m,k,j,i))/p->dx[3*m+1];
+            if (g.three_d)
+              b0x1f[c] += beta_dt*(E2(m,k+1,j,i) - E2(m,k,j,i))/p->dx[3*m+2];
+          }
+  }
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = ks; k <= ke; ++k)
+      for (int j = js; j <= je+1; ++j)
+        for (int i = is; i <= ie; ++i) {
+          size_t c = ix4(N3,N2+1,N1,m,k,j,i);
+          b0x2f[c] = gam0*b0x2f[c] + gam1*b1x2f[c];
+          b0x2f[c] += beta_dt*(E3(m,k,j,i+1) - E3(m,k,j,i))/p->dx[3*m];
+          if (g.three_d)
+            b0x2f[c] -= beta_dt*(E1(m,k+1,j,i) - E1(m,k,j,i))/p->dx[3*m+2];
+        }
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = ks; k <= ke+1; ++k)
+      for (int j = js; j <= je; ++j)
+        for (int i = is; i <= ie; ++i) {
+          size_t c = ix4(N3+1,N2,N1,m,k,j,i);
+          b0x3f[c] = gam0*b0x3f[c] + gam1*b1x3f[c];
+          b0x3f[c] -= beta_dt*(E2(m,k,j,i+1) - E2(m,k,j,i))/p->dx[3*m];
+          if (g.multi_d)
+            b0x3f[c] += beta_dt*(E1(m,k,j+1,i) - E1(m,k,j,i))/p->dx[3*m+1];
+        }
+  return 0;
+}
+
+/* IdealMHD::ConsToPrim, src/eos/ideal_mhd.cpp:30-134 + SingleC2P_IdealMHD,
+ * src/eos/ideal_c2p_mhd.hpp:20-67 */
+int akref_mhd_c2p(const akmi_pack *p, double *u0, const double *bx1f, const double *bx2f,
+                  const double *bx3f, double *w0, double *bcc0, int il, int iu, int jl,
+                  int ju, int kl, int ku, int *counters) {
+  G g = mkG(p);
+  const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  const double gm1 = p->gamma - 1.0;
+  const double efloor = p->pfloor/(p->gamma - 1.0);
+  const double tfloor = p->tfloor, sfloor = p->sfloor;
+  int sumd = 0, sume = 0, sumt = 0;
+#pragma omp parallel for collapse(2) schedule(static) reduction(+:sumd,sume,sumt)
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = kl; k <= ku; ++k)
+      for (int j = jl; j <= ju; ++j)
+        for (int i = il; i <= iu; ++i) {
+          size_t cd = ix5(nv,N3,N2,N1,m,IDN,k,j,i), cx = ix5(nv,N3,N2,N1,m,IVX,k,j,i);
+          size_t cy = ix5(nv,N3,N2,N1,m,IVY,k,j,i), cz = ix5(nv,N3,N2,N1,m,IVZ,k,j,i);
+          size_t ce = ix5(nv,N3,N2,N1,m,IEN,k,j,i);
+          double ud = u0[cd], umx = u0[cx], umy = u0[cy], umz = u0[cz], ue = u0[ce];
+          double ubx = 0.5*(bx1f[ix4(N3,N2,N1+1,m,k,j,i)] + bx1f[ix4(N3,N2,N1+1,m,k,j,i+1)]);
+          double uby = 0.5*(bx2f[ix4(N3,N2+1,N1,m,k,j,i)] + bx2f[ix4(N3,N2+1,N1,m,k,j+1,i)]);
+          double ubz = 0.5*(bx3f[ix4(N3+1,N2,N1,m,k,j,i)] + bx3f[ix4(N3+1,N2,N1,m,k+1,j,i)]);
+          int dfl = 0, efl = 0, tfl = 0;
+          const double b2 = SQR(ubx) + SQR(uby) + SQR(ubz);
+          const double dfloor_ = fmax(p->dfloor, b2/p->sigma_max);
+          if (ud < dfloor_) { ud = dfloor_; dfl = 1; }
+          double wd = ud;
+          double di = 1.0/ud;
+          double wvx = di*umx, wvy = di*umy, wvz = di*umz;
+          double e_k = 0.5*di*(SQR(umx) + SQR(umy) + SQR(umz));
+          double e_m = 0.5*(SQR(ubx) + SQR(uby) + SQR(ubz));
+          double we = (ue - e_k - e_m);
+          if (we < efloor) { we = efloor; ue = efloor + e_k + e_m; efl = 1; }
+          if (gm1*we*di < tfloor) { we = wd*tfloor/gm1; ue = we + e_k + e_m; tfl = 1; }
+          double spe_over_eps = gm1/pow(wd, gm1);
+          double spe = spe_over_eps*we*di;
+          if (spe <= sfloor) { we = wd*sfloor/spe_over_eps; efl = 1; }
+          if (dfl) { u0[cd] = ud; sumd++; }
+          if (efl) { u0[ce] = ue; sume++; }
+          if (tfl) { u0[ce] = ue; sumt++; }
+          w0[cd] = wd; w0[cx] = wvx; w0[cy] = wvy; w0[cz] = wvz; w0[ce] = we;
+          bcc0[ix5(3,N3,N2,N1,m,IBX,k,j,i)] = ubx;
+          bcc0[ix5(3,N3,N2,N1,m,IBY,k,j,i)] = uby;
+          bcc0[ix5(3,N3,N2,N1,m,IBZ,k,j,i)] = ubz;
+        }
+  if (counters) { counters[0] += sumd; counters[1] += sume; counters[2] += sumt; }
+  return 0;
+}
+
+/* MHD::NewTimeStep, src/mhd/mhd_newdt.cpp:31-174 (Newtonian ideal branch :123-136) */
+int akref_mhd_newdt(const akmi_pack *p, const double *w0, const double *bcc0, double *dt3) {
+  G g = mkG(p);
+  const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  double dt1 = (double)FLT_MAX, dt2 = (double)FLT_MAX, dt3_ = (double)FLT_MAX;
+#pragma omp parallel for collapse(2) schedule(static) reduction(min:dt1,dt2,dt3_)
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = g.ks; k <= g.ke; ++k)
+      for (int j = g.js; j <= g.je; ++j)
+        for (int i = g.is; i <= g.ie; ++i) {
+          double w_d = W(IDN,m,k,j,i);
+          double w_bx = B(IBX,m,k,j,i), w_by = B(IBY,m,k,j,i), w_bz = B(IBZ,m,k,j,i);
+          double pr = (p->gamma - 1.0)*W(IEN,m,k,j,i);
+          double cf = fast_speed(p->gamma, w_d, pr, w_bx, w_by, w_bz);
+          double max_dv1 = fabs(W(IVX,m,k,j,i)) + cf;
+          cf = fast_speed(p->gamma, w_d, pr, w_by, w_bz, w_bx);
+          double max_dv2 = fabs(W(IVY,m,k,j,i)) + cf;
+          cf = fast_speed(p->gamma, w_d, pr, w_bz, w_bx, w_by);
+          double max_dv3 = fabs(W(IVZ,m,k,j,i)) + cf;
+          dt1 = fmin(p->dx[3*m]/max_dv1, dt1);
+          dt2 = fmin(p->dx[3*m+1]/max_dv2, dt2);
+          dt3_ = fmin(p->dx[3*m+2]/max_dv3, dt3_);
+        }
+  dt3[0] = dt1; dt3[1] = dt2; dt3[2] = dt3_;
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * Same-level boundary values.  The reference packs the ng innermost active layers of the
+ * sender (src/bvals/buffs_cc.cpp:36-46) and unpacks into the receiver's ghost layers
+ * (:176-203); for a same-rank neighbour the pack kernel writes straight into the
+ * neighbour's receive buffer (src/bvals/bvals_cc.cpp:122-135).  Net effect, restated as a
+ * gather: ghost element (k,j,i) of block m in direction o=(o1,o2,o3) := element
+ * (k-o3*nx3, j-o2*nx2, i-o1*nx1) of the neighbour in that direction. */
+static void cell_range(int o, int s, int e, int ng, int *lo, int *hi) {
+  if (o < 0) { *lo = s - ng; *hi = s - 1; }
+  else if (o > 0) { *lo = e + 1; *hi = e + ng; }
+  else { *lo = s; *hi = e; }
+}
+/* face-like index along the component's own direction: shared faces excluded
+ * (src/bvals/buffs_fc.cpp:39-76): o<0 -> [s-ng,s-1], o==0 -> [s,e+1], o>0 -> [e+2,e+ng+1] */
+static void face_range(int o, int s, int e, int ng, int *lo, int *hi) {
+  if (o < 0) { *lo = s - ng; *hi = s - 1; }
+  else if (o > 0) { *lo = e + 2; *hi = e + ng + 1; }
+  else { *lo = s; *hi = e + 1; }
+}
+static int dir_valid(const G *g, int d, int *o1, int *o2, int *o3) {
+  *o1 = d%3 - 1; *o2 = (d/3)%3 - 1; *o3 = d/9 - 1;
+  if (d == 13) return 0;
+  if (!g->multi_d && *o2 != 0) return 0;
+  if (!g->three_d && *o3 != 0) return 0;
+  return 1;
+}
+
+long long akref_bvals_cc_segsize(const akmi_pack *p, int d) {
+  G g = mkG(p);
+  int o1, o2, o3, il, iu, jl, ju, kl, ku;
+  if (!dir_valid(&g, d, &o1, &o2, &o3)) return 0;
+  cell_range(o1, g.is, g.ie, g.ng, &il, &iu);
+  cell_range(o2, g.js, g.je, g.ng, &jl, &ju);
+  cell_range(o3, g.ks, g.ke, g.ng, &kl, &ku);
+  return (long long)(iu-il+1)*(ju-jl+1)*(ku-kl+1);
+}
+
+int akref_bvals_cc_local(const akmi_pack *p, int nvar, const int *nghbr, double *u) {
+  G g = mkG(p);
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  for (int m = 0; m < g.nmb; ++m)
+    for (int d = 0; d < 27; ++d) {
+      int o1, o2, o3, il, iu, jl, ju, kl, ku;
+      if (!dir_valid(&g, d, &o1, &o2, &o3)) continue;
+      int src = nghbr[m*27 + d];
+      if (src < 0) continue;
+      cell_range(o1, g.is, g.ie, g.ng, &il, &iu);
+      cell_range(o2, g.js, g.je, g.ng, &jl, &ju);
+      cell_range(o3, g.ks, g.ke, g.ng, &kl, &ku);
+      for (int n = 0; n < nvar; ++n)
+        for (int k = kl; k <= ku; ++k)
+          for (int j = jl; j <= ju; ++j)
+            for (int i = il; i <= iu; ++i)
+              u[ix5(nvar,N3,N2,N1,m,n,k,j,i)] =
+                  u[ix5(nvar,N3,N2,N1,src,n,k-o3*g.nx3,j-o2*g.nx2,i-o1*g.nx1)];
+    }
+  return 0;
+}
+
+int akref_bvals_cc_pack(const akmi_pack *p, int nvar, int nsend, const int *send_tab,
+                        const long long *send_off, const double *u, double *sendbuf) {
+  G g = mkG(p);
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  for (int s = 0; s < nsend; ++s) {
+    int m = send_tab[2*s], d = send_tab[2*s+1];
+    /* receiver's ghost direction is o = -d */
+    int o1, o2, o3, il, iu, jl, ju, kl, ku;
+    if (!dir_valid(&g, 26 - d, &o1, &o2, &o3)) continue;
+    cell_range(o1, g.is, g.ie, g.ng, &il, &iu);
+    cell_range(o2, g.js, g.je, g.ng, &jl, &ju);
+    cell_range(o3, g.ks, g.ke, g.ng, &kl, &ku);
+    double *out = sendbuf + send_off[s];
+    for (int n = 0; n < nvar; ++n)
+      for (int k = kl; k <= ku; ++k)
+        for (int j = jl; j <= ju; ++j)
+          for (int i = il; i <= iu; ++i)
+            *out++ = u[ix5(nvar,N3,N2,N1,m,n,k-o3*g.nx3,j-o2*g.nx2,i-o1*g.nx1)];
+  }
+  return 0;
+}
+
+int akref_bvals_cc_unpack(const akmi_pack *p, int nvar, const int *nghbr,
+                          const long long *seg_off, const double *recvbuf, double *u) {
+  G g = mkG(p);
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  for (int m = 0; m < g.nmb; ++m)
+    for (int d = 0; d < 27; ++d) {
+      int o1, o2, o3, il, iu, jl, ju, kl, ku;
+      if (!dir_valid(&g, d, &o1, &o2, &o3)) continue;
+      int e = nghbr[m*27 + d];
+      if (e > -2) continue;
+      const double *in = recvbuf + seg_off[-(e + 2)];
+      cell_range(o1, g.is, g.ie, g.ng, &il, &iu);
+      cell_range(o2, g.js, g.je, g.ng, &jl, &ju);
+      cell_range(o3, g.ks, g.ke, g.ng, &kl, &ku);
+      for (int n = 0; n < nvar; ++n)
+        for (int k = kl; k <= ku; ++k)
+          for (int j = jl; j <= ju; ++j)
+            for (int i = il; i <= iu; ++i)
+              u[ix5(nvar,N3,N2,N1,m,n,k,j,i)] = *in++;
+    }
+  return 0;
+}
+
+/* FC component c (0:x1f 1:x2f 2:x3f) ranges for ghost direction o */
+static void fc_ranges(const G *g, int c, int o1, int o2, int o3, int r[6]) {
+  if (c == 0) face_range(o1, g->is, g->ie, g->ng, &r[0], &r[1]);
+  else        cell_range(o1, g->is, g->ie, g->ng, &r[0], &r[1]);
+  if (c == 1) face_range(o2, g->js, g->je, g->ng, &r[2], &r[3]);
+  else        cell_range(o2, g->js, g->je, g->ng, &r[2], &r[3]);
+  if (c == 2) face_range(o3, g->ks, g->ke, g->ng, &r[4], &r[5]);
+  else        cell_range(o3, g->ks, g->ke, g->ng, &r[4], &r[5]);
+  /* collapsed dimensions keep their single (or two-face) extent */
+  if (!g->multi_d) { r[2] = 0; r[3] = (c == 1) ? 1 : 0; }
+  if (!g->three_d) { r[4] = 0; r[5] = (c == 2) ? 1 : 0; }
+}
+static void fc_dims(const G *g, int c, int *n3, int *n2, int *n1) {
+  *n3 = g->N3 + (c == 2); *n2 = g->N2 + (c == 1); *n1 = g->N1 + (c == 0);
+}
+
+long long akref_bvals_fc_segsize(const akmi_pack *p, int d) {
+  G g = mkG(p);
+  int o1, o2, o3, r[6];
+  if (!dir_valid(&g, d, &o1, &o2, &o3)) return 0;
+  long long tot = 0;
+  for (int c = 0; c < 3; ++c) {
+    fc_ranges(&g, c, o1, o2, o3, r);
+    tot += (long long)(r[1]-r[0]+1)*(r[3]-r[2]+1)*(r[5]-r[4]+1);
+  }
+  return tot;
+}
+
+int akref_bvals_fc_local(const akmi_pack *p, const int *nghbr, double *bx1f, double *bx2f,
+                         double *bx3f) {
+  G g = mkG(p);
+  double *b[3] = {bx1f, bx2f, bx3f};
+  for (int m = 0; m < g.nmb; ++m)
+    for (int d = 0; d < 27; ++d) {
+      int o1, o2, o3, r[6];
+      if (!dir_valid(&g, d, &o1, &o2, &o3)) continue;
+      int src = nghbr[m*27 + d];
+      if (src < 0) continue;
+      for (int c = 0; c < 3; ++c) {
+        int n3, n2, n1;
+        fc_dims(&g, c, &n3, &n2, &n1);
+        fc_ranges(&g, c, o1, o2, o3, r);
+        for (int k = r[4]; k <= r[5]; ++k)
+          for (int j = r[2]; j <= r[3]; ++j)
+            for (int i = r[0]; i <= r[1]; ++i)
+              b[c][ix4(n3,n2,n1,m,k,j,i)] =
+                  b[c][ix4(n3,n2,n1,src,k-o3*(g.three_d?g.nx3:0),j-o2*(g.multi_d?g.nx2:0),i-o1*g.nx1)];
+      }
+    }
+  return 0;
+}
+
+int akref_bvals_fc_pack(const akmi_pack *p, int nsend, const int *send_tab,
+                        const long long *send_off, const double *bx1f, const double *bx2f,
+                        const double *bx3f, double *sendbuf) {
+  G g = mkG(p);
+  const double *b[3] = {bx1f, bx2f, bx3f};
+  for (int s = 0; s < nsend; ++s) {
+    int m = send_tab[2*s], d = send_tab[2*s+1];
+    int o1, o2, o3, r[6];
+    if (!dir_valid(&g, 26 - d, &o1, &o2, &o3)) continue;
+    double *out = sendbuf + send_off[s];
+    for (int c = 0; c < 3; ++c) {
+      int n3, n2, n1;
+      fc_dims(&g, c, &n3, &n2, &n1);
+      fc_ranges(&g, c, o1, o2, o3, r);
+      for (int k = r[4]; k <= r[5]; ++k)
+        for (int j = r[2]; j <= r[3]; ++j)
+          for (int i = r[0]; i <= r[1]; ++i)
+            *out++ = b[c][ix4(n3,n2,n1,m,k-o3*(g.three_d?g.nx3:0),j-o2*(g.multi_d?g.nx2:0),i-o1*g.nx1)];
+    }
+  }
+  return 0;
+}
+
+int akref_bvals_fc_unpack(const akmi_pack *p, const int *nghbr, const long long *seg_off,
+                          const double *recvbuf, double *bx1f, double *bx2f, double *bx3f) {
+  G g = mkG(p);
+  double *b[3] = {bx1f, bx2f, bx3f};
+  for (int m = 0; m < g.nmb; ++m)
+    for (int d = 0; d < 27; ++d) {
+      int o1, o2, o3, r[6];
+      if (!dir_valid(&g, d, &o1, &o2, &o3)) continue;
+      int e = nghbr[m*27 + d];
+      if (e > -2) continue;
+      const double *in = recvbuf + seg_off[-(e + 2)];
+      for (int c = 0; c < 3; ++c) {
+        int n3, n2, n1;
+        fc_dims(&g, c, &n3, &n2, &n1);
+        fc_ranges(&g, c, o1, o2, o3, r);
+        for (int k = r[4]; k <= r[5]; ++k)
+          for (int j = r[2]; j <= r[3]; ++j)
+            for (int i = r[0]; i <= r[1]; ++i)
+              b[c][ix4(n3,n2,n1,m,k,j,i)] = *in++;
+      }
+    }
+  return 0;
+}
+
+/* HydroBCs, src/bvals/physics/hydro_bcs.cpp:69-... (outflow, reflect); x1 over all (k,j)
+ * incl. ghosts, then x2 over all (k,i), then x3 over all (j,i). */
+int akref_hydro_bcs(const akmi_pack *p, int nvar, const int *bcs, double *u) {
+  G g = mkG(p);
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3, ng = g.ng;
+#define U(m,n,k,j,i) u[ix5(nvar,N3,N2,N1,m,n,k,j,i)]
+  for (int m = 0; m < g.nmb; ++m)
+    for (int n = 0; n < nvar; ++n)
+      for (int k = 0; k < N3; ++k)
+        for (int j = 0; j < N2; ++j) {
+          int bi = bcs[6*m], bo = bcs[6*m+1];
+          for (int i = 0; i < ng; ++i) {
+            if (bi == AKMI_BC_REFLECT) U(m,n,k,j,g.is-i-1) = (n == IVX ? -1.0 : 1.0)*U(m,n,k,j,g.is+i);
+            else if (bi == AKMI_BC_OUTFLOW) U(m,n,k,j,g.is-i-1) = U(m,n,k,j,g.is);
+          }
+          for (int i = 0; i < ng; ++i) {
+            if (bo == AKMI_BC_REFLECT) U(m,n,k,j,g.ie+i+1) = (n == IVX ? -1.0 : 1.0)*U(m,n,k,j,g.ie-i);
+            else if (bo == AKMI_BC_OUTFLOW) U(m,n,k,j,g.ie+i+1) = U(m,n,k,j,g.ie);
+          }
+        }
+  if (!g.multi_d) return 0;
+  for (int m = 0; m < g.nmb; ++m)
+    for (int n = 0; n < nvar; ++n)
+      for (int k = 0; k < N3; ++k)
+        for (int i = 0; i < N1; ++i) {
+          int bi = bcs[6*m+2], bo = bcs[6*m+3];
+          for (int j = 0; j < ng; ++j) {
+            if (bi == AKMI_BC_REFLECT) U(m,n,k,g.js-j-1,i) = (n == IVY ? -1.0 : 1.0)*U(m,n,k,g.js+j,i);
+            else if (bi == AKMI_BC_OUTFLOW) U(m,n,k,g.js-j-1,i) = U(m,n,k,g.js,i);
+          }
+          for (int j = 0; j < ng; ++j) {
+            if (bo == AKMI_BC_REFLECT) U(m,n,k,g.je+j+1,i) = (n == IVY ? -1.0 : 1.0)*U(m,n,k,g.je-j,i);
+            else if (bo == AKMI_BC_OUTFLOW) U(m,n,k,g.je+j+1,i) = U(m,n,k,g.je,i);
+          }
+        }
+  if (!g.three_d) return 0;
+  for (int m = 0; m < g.nmb; ++m)
+    for (int n = 0; n < nvar; ++n)
+      for (int j = 0; j < N2; ++j)
+        for (int i = 0; i < N1; ++i) {
+          int bi = bcs[6*m+4], bo = bcs[6*m+5];
+          for (int k = 0; k < ng; ++k) {
+            if (bi == AKMI_BC_REFLECT) U(m,n,g.ks-k-1,j,i) = (n == IVZ ? -1.0 : 1.0)*U(m,n,g.ks+k,j,i);
+            else if (bi == AKMI_BC_OUTFLOW) U(m,n,g.ks-k-1,j,i) = U(m,n,g.ks,j,i);
+          }
+          for (int k = 0; k < ng; ++k) {
+            if (bo == AKMI_BC_REFLECT) U(m,n,g.ke+k+1,j,i) = (n == IVZ ? -1.0 : 1.0)*U(m,n,g.ke-k,j,i);
+            else if (bo == AKMI_BC_OUTFLOW) U(m,n,g.ke+k+1,j,i) = U(m,n,g.ke,j,i);
+          }
+        }
+#undef U
+  return 0;
+}
+
+/* BFieldBCs, src/bvals/physics/bfield_bcs.cpp:66-... (outflow, reflect) */
+int akref_bfield_bcs(const akmi_pack *p, const int *bcs, double *bx1f, double *bx2f,
+                     double *bx3f) {
+  G g = mkG(p);
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3, ng = g.ng;
+  const int is = g.is, ie = g.ie, js = g.js, je = g.je, ks = g.ks, ke = g.ke;
+#define B1(m,k,j,i) bx1f[ix4(N3,N2,N1+1,m,k,j,i)]
+#define B2(m,k,j,i) bx2f[ix4(N3,N2+1,N1,m,k,j,i)]
+#define B3(m,k,j,i) bx3f[ix4(N3+1,N2,N1,m,k,j,i)]
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = 0; k < N3; ++k)
+      for (int j = 0; j < N2; ++j) {
+        int bi = bcs[6*m], bo = bcs[6*m+1];
+        for (int i = 0; i < ng; ++i) {
+          if (bi == AKMI_BC_REFLECT) {
+            B1(m,k,j,is-i-1) = -B1(m,k,j,is+i+1);
+            B2(m,k,j,is-i-1) = B2(m,k,j,is+i);
+            if (j == N2-1) B2(m,k,j+1,is-i-1) = B2(m,k,j+1,is+i);
+            B3(m,k,j,is-i-1) = B3(m,k,j,is+i);
+            if (k == N3-1) B3(m,k+1,j,is-i-1) = B3(m,k+1,j,is+i);
+          } else if (bi == AKMI_BC_OUTFLOW) {
+            B1(m,k,j,is-i-1) = B1(m,k,j,is);
+            B2(m,k,j,is-i-1) = B2(m,k,j,is);
+            if (j == N2-1) B2(m,k,j+1,is-i-1) = B2(m,k,j+1,is);
+            B3(m,k,j,is-i-1) = B3(m,k,j,is);
+            if (k == N3-1) B3(m,k+1,j,is-i-1) = B3(m,k+1,j,is);
+          }
+        }
+        for (int i = 0; i < ng; ++i) {
+          if (bo == AKMI_BC_REFLECT) {
+            B1(m,k,j,ie+i+2) = -B1(m,k,j,ie-i);
+            B2(m,k,j,ie+i+1) = B2(m,k,j,ie-i);
+            if (j == N2-1) B2(m,k,j+1,ie+i+1) = B2(m,k,j+1,ie-i);
+            B3(m,k,j,ie+i+1) = B3(m,k,j,ie-i);
+            if (k == N3-1) B3(m,k+1,j,ie+i+1) = B3(m,k+1,j,ie-i);
+          } else if (bo == AKMI_BC_OUTFLOW) {
+            B1(m,k,j,ie+i+2) = B1(m,k,j,ie+1);
+            B2(m,k,j,ie+i+1) = B2(m,k,j,ie);
+            if (j == N2-1) B2(m,k,j+1,ie+i+1) = B2(m,k,j+1,ie);
+            B3(m,k,j,ie+i+1) = B3(m,k,j,ie);
+            if (k == N3-1) B3(m,k+1,j,ie+i+1) = B3(m,k+1,j,ie);
+          }
+        }
+      }
+  if (!g.multi_d) return 0;
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = 0; k < N3; ++k)
+      for (int i = 0; i < N1; ++i) {
+        int bi = bcs[6*m+2], bo = bcs[6*m+3];
+        for (int j = 0; j < ng; ++j) {
+          if (bi == AKMI_BC_REFLECT) {
+            B1(m,k,js-j-1,i) = B1(m,k,js+j,i);
+            if (i == N1-1) B1(m,k,js-j-1,i+1) = B1(m,k,js+j,i+1);
+            B2(m,k,js-j-1,i) = -B2(m,k,js+j+1,i);
+            B3(m,k,js-j-1,i) = B3(m,k,js+j,i);
+            if (k == N3-1) B3(m,k+1,js-j-1,i) = B3(m,k+1,js+j,i);
+          } else if (bi == AKMI_BC_OUTFLOW) {
+            B1(m,k,js-j-1,i) = B1(m,k,js,i);
+            if (i == N1-1) B1(m,k,js-j-1,i+1) = B1(m,k,js,i+1);
+            B2(m,k,js-j-1,i) = B2(m,k,js,i);
+            B3(m,k,js-j-1,i) = B3(m,k,js,i);
+            if (k == N3-1) B3(m,k+1,js-j-1,i) = B3(m,k+1,js,i);
+          }
+        }
+        for (int j = 0; j < ng; ++j) {
+          if (bo == AKMI_BC_REFLECT) {
+            B1(m,k,je+j+1,i) = B1(m,k,je-j,i);
+            if (i == N1-1) B1(m,k,je+j+1,i+1) = B1(m,k,je-j,i+1);
+            B2(m,k,je+j+2,i) = -B2(m,k,je-j,i);
+            B3(m,k,je+j+1,i) = B3(m,k,je-j,i);
+            if (k == N3-1) B3(m,k+1,je+j+1,i) = B3(m,k+1,je-j,i);
+          } else if (bo == AKMI_BC_OUTFLOW) {
+            B1(m,k,je+j+1,i) = B1(m,k,je,i);
+            if (i == N1-1) B1(m,k,je+j+1,i+1) = B1(m,k,je,i+1);
+            B2(m,k,je+j+2,i) = B2(m,k,je+1,i);
+            B3(m,k,je+j+1,i) = B3(m,k,je,i);
+            if (k == N3-1) B3(m,k+1,je+j+1,i) = B3(m,k+1,je,i);
+          }
+        }
+      }
+  if (!g.three_d) return 0;
+  for (int m = 0; m < g.nmb; ++m)
+    for (int j = 0; j < N2; ++j)
+      for (int i = 0; i < N1; ++i) {
+        int bi = bcs[6*m+4], bo = bcs[6*m+5];
+        for (int k = 0; k < ng; ++k) {
+          if (bi == AKMI_BC_REFLECT) {
+            B1(m,ks-k-1,j,i) = B1(m,ks+k,j,i);
+            if (i == N1-1) B1(m,ks-k-1,j,i+1) = B1(m,ks+k,j,i+1);
+            B2(m,ks-k-1,j,i) = B2(m,ks+k,j,i);
+            if (j == N2-1) B2(m,ks-k-1,j+1,i) = B2(m,ks+k,j+1,i);
+            B3(m,ks-k-1,j,i) = -B3(m,ks+k+1,j,i);
+          } else if (bi == AKMI_BC_OUTFLOW) {
+            B1(m,ks-k-1,j,i) = B1(m,ks,j,i);
+            if (i == N1-1) B1(m,ks-k-1,j,i+1) = B1(m,ks,j,i+1);
+            B2(m,ks-k-1,j,i) = B2(m,ks,j,i);
+            if (j == N2-1) B2(m,ks-k-1,j+1,i) = B2(m,ks,j+1,i);
+            B3(m,ks-k-1,j,i) = B3(m,ks,j,i);
+          }
+        }
+        for (int k = 0; k < ng; ++k) {
+          if (bo == AKMI_BC_REFLECT) {
+            B1(m,ke+k+1,j,i) = B1(m,ke-k,j,i);
+            if (i == N1-1) B1(m,ke+k+1,j,i+1) = B1(m,ke-k,j,i+1);
+            B2(m,ke+k+1,j,i) = B2(m,ke-k,j,i);
+            if (j == N2-1) B2(m,ke+k+1,j+1,i) = B2(m,ke-k,j+1,i);
+            B3(m,ke+k+2,j,i) = -B3(m,ke-k,j,i);
+          } else if (bo == AKMI_BC_OUTFLOW) {
+            B1(m,ke+k+1,j,i) = B1(m,ke,j,i);
+            if (i == N1-1) B1(m,ke+k+1,j,i+1) = B1(m,ke,j,i+1);
+            B2(m,ke+k+1,j,i) = B2(m,ke,j,i);
+            if (j == N2-1) B2(m,ke+k+1,j+1,i) = B2(m,ke,j+1,i);
+            B3(m,ke+k+2,j,i) = B3(m,ke+1,j,i);
+          }
+        }
+      }
+  return 0;
+}
