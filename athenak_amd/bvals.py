@@ -1,0 +1,219 @@
+"""MeshBoundaryValues: same-level ghost-zone exchange for cell- and face-centred variables.
+
+Mirrors the roles of MeshBoundaryValuesCC/FC (src/bvals/bvals.hpp:215-267): PackAndSend*
+fills same-rank neighbours directly (src/bvals/bvals_cc.cpp:122-135) and ships one
+rank-packed message per peer rank per variable class (src/bvals/bvals.cpp:134-310,
+bvals_cc.cpp:247-258); RecvAndUnpack* completes the receives and unpacks.  MPI_Isend/Irecv
+become torch.distributed P2P ops (backend "nccl" = RCCL over xGMI; "gloo" in CPU tests); the
+MPI_Test polling of the reference (bvals_cc.cpp:287-303) becomes a stream-ordered wait.
+
+Segment order inside a peer message is fixed by (receiver gid, receiver direction), known
+to both sides from the block tables alone, which replaces the reference's one-shot header
+exchange (src/bvals/bvals.cpp:248-270).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+from .tasklist import TaskStatus
+
+
+class HipBvalsKernels:
+    """pack / unpack / local-fill / BC kernels through the C ABI (device tensors only)."""
+
+    def __init__(self):
+        self.L = capi.lib()
+
+    def cc_segsize(self, pack, d):
+        return int(self.L.akmi_bvals_cc_segsize(C.byref(pack), d))
+
+    def fc_segsize(self, pack, d):
+        return int(self.L.akmi_bvals_fc_segsize(C.byref(pack), d))
+
+    def cc_local(self, pack, nvar, nghbr, u):
+        capi.check(self.L.akmi_bvals_cc_local(C.byref(pack), nvar, capi._p(nghbr), capi._p(u),
+                                              capi._stream()), "bvals_cc_local")
+
+    def cc_pack(self, pack, nvar, nsend, tab, off, u, buf):
+        capi.check(self.L.akmi_bvals_cc_pack(C.byref(pack), nvar, nsend, capi._p(tab), capi._p(off),
+                                             capi._p(u), capi._p(buf), capi._stream()), "bvals_cc_pack")
+
+    def cc_unpack(self, pack, nvar, nghbr, seg_off, buf, u):
+        capi.check(self.L.akmi_bvals_cc_unpack(C.byref(pack), nvar, capi._p(nghbr), capi._p(seg_off),
+                                               capi._p(buf), capi._p(u), capi._stream()), "bvals_cc_unpack")
+
+    def fc_local(self, pack, nghbr, b1, b2, b3):
+        capi.check(self.L.akmi_bvals_fc_local(C.byref(pack), capi._p(nghbr), capi._p(b1), capi._p(b2),
+                                              capi._p(b3), capi._stream()), "bvals_fc_local")
+
+    def fc_pack(self, pack, nsend, tab, off, b1, b2, b3, buf):
+        capi.check(self.L.akmi_bvals_fc_pack(C.byref(pack), nsend, capi._p(tab), capi._p(off),
+                                             capi._p(b1), capi._p(b2), capi._p(b3), capi._p(buf),
+                                             capi._stream()), "bvals_fc_pack")
+
+    def fc_unpack(self, pack, nghbr, seg_off, buf, b1, b2, b3):
+        capi.check(self.L.akmi_bvals_fc_unpack(C.byref(pack), capi._p(nghbr), capi._p(seg_off),
+                                               capi._p(buf), capi._p(b1), capi._p(b2), capi._p(b3),
+                                               capi._stream()), "bvals_fc_unpack")
+
+    def hydro_bcs(self, pack, nvar, bcs, u):
+        capi.check(self.L.akmi_hydro_bcs(C.byref(pack), nvar, capi._p(bcs), capi._p(u),
+                                         capi._stream()), "hydro_bcs")
+
+    def bfield_bcs(self, pack, bcs, b1, b2, b3):
+        capi.check(self.L.akmi_bfield_bcs(C.byref(pack), capi._p(bcs), capi._p(b1), capi._p(b2),
+                                          capi._p(b3), capi._stream()), "bfield_bcs")
+
+
+class _Channel:
+    """Send/recv plan of one variable class (CC or FC)."""
+
+    def __init__(self):
+        self.nsend = 0
+        self.send_tab = self.send_off = self.seg_off = None
+        self.sendbuf = self.recvbuf = None
+        self.send_slices = {}   # peer -> (start, stop) in sendbuf
+        self.recv_slices = {}
+        self.works = []
+
+
+class MeshBoundaryValues:
+    """Ghost-zone exchange + physical BCs for one MeshBlockPack."""
+
+    def __init__(self, ppack, kernels=None, device="cuda"):
+        self.pmy_pack = ppack
+        self.k = kernels if kernels is not None else HipBvalsKernels()
+        self.device = device
+        pm = ppack.pmesh
+        pmb = ppack.pmb
+        self.my_rank, self.nranks = pm.my_rank, pm.nranks
+        self.pack_c = None      # akmi_pack set by physics (needs device dx)
+        nmb = ppack.nmb_thispack
+        gids = ppack.gids
+        # device neighbour table: >=0 local index, -1 none, <=-2 remote slot
+        tab = -np.ones((nmb, 27), dtype=np.int32)
+        recv_items = {}   # peer -> list of (my gid, o)
+        send_items = {}   # peer -> list of (receiver gid, receiver o, my local m, d)
+        for m in range(nmb):
+            for d in range(27):
+                g, r = int(pmb.nghbr_gid[m, d]), int(pmb.nghbr_rank[m, d])
+                if g < 0:
+                    continue
+                if r == self.my_rank:
+                    tab[m, d] = g - gids
+                else:
+                    recv_items.setdefault(r, []).append((gids + m, d))
+                    send_items.setdefault(r, []).append((g, 26 - d, m, d))
+        self.peers = sorted(set(recv_items) | set(send_items))
+        self._recv_items = {r: sorted(v) for r, v in recv_items.items()}
+        self._send_items = {r: sorted(v) for r, v in send_items.items()}
+        # remote slots numbered in (peer, gid, o) order
+        self._slots = []
+        for r in self.peers:
+            for (g, o) in self._recv_items.get(r, []):
+                tab[g - gids, o] = -(len(self._slots) + 2)
+                self._slots.append((r, g, o))
+        self.nghbr_host = tab
+        self.nghbr = torch.from_numpy(tab.copy()).to(device)
+        self.bcs = torch.from_numpy(np.ascontiguousarray(pmb.mb_bcs)).to(device)
+        self.cc = None
+        self.fc = None
+
+    # ------------------------------------------------------------------------------
+    def _plan(self, segsize):
+        ch = _Channel()
+        if not self.peers:
+            return ch
+        gids = self.pmy_pack.gids
+        # receive side
+        seg_off, off = [], 0
+        for r in self.peers:
+            start = off
+            for (g, o) in self._recv_items.get(r, []):
+                seg_off.append(off)
+                off += segsize(o)
+            ch.recv_slices[r] = (start, off)
+        nrecv = off
+        # send side
+        tab, soff, off = [], [], 0
+        for r in self.peers:
+            start = off
+            for (g, o, m, d) in self._send_items.get(r, []):
+                tab.append((m, d))
+                soff.append(off)
+                off += segsize(26 - d)   # == receiver's region for o = 26-d
+            ch.send_slices[r] = (start, off)
+        ch.nsend = len(tab)
+        dev = self.device
+        ch.send_tab = torch.tensor(tab, dtype=torch.int32, device=dev).reshape(-1, 2).contiguous()
+        ch.send_off = torch.tensor(soff, dtype=torch.int64, device=dev)
+        ch.seg_off = torch.tensor(seg_off, dtype=torch.int64, device=dev)
+        ch.sendbuf = torch.empty(max(off, 1), dtype=torch.float64, device=dev)
+        ch.recvbuf = torch.empty(max(nrecv, 1), dtype=torch.float64, device=dev)
+        return ch
+
+    def set_pack(self, pack_c, nvar):
+        self.pack_c = pack_c
+        self.nvar = nvar
+        self.cc = self._plan(lambda d: nvar*self.k.cc_segsize(pack_c, d))
+        self.fc = self._plan(lambda d: self.k.fc_segsize(pack_c, d))
+
+    # ------------------------------------------------------------------------------
+    def _post(self, ch):
+        import torch.distributed as dist
+        ops = []
+        for r in self.peers:
+            a, b = ch.recv_slices[r]
+            if b > a:
+                ops.append(dist.P2POp(dist.irecv, ch.recvbuf[a:b], r))
+        for r in self.peers:
+            a, b = ch.send_slices[r]
+            if b > a:
+                ops.append(dist.P2POp(dist.isend, ch.sendbuf[a:b], r))
+        ch.works = dist.batch_isend_irecv(ops) if ops else []
+
+    def _wait(self, ch):
+        for w in ch.works:
+            w.wait()
+        ch.works = []
+
+    # ---- cell-centred ------------------------------------------------------------
+    def PackAndSendCC(self, u):
+        """same-rank ghosts are final after this call; remote data is in flight."""
+        self.k.cc_local(self.pack_c, self.nvar, self.nghbr, u)
+        if self.peers:
+            self.k.cc_pack(self.pack_c, self.nvar, self.cc.nsend, self.cc.send_tab, self.cc.send_off,
+                           u, self.cc.sendbuf)
+            self._post(self.cc)
+        return TaskStatus.complete
+
+    def RecvAndUnpackCC(self, u):
+        if self.peers:
+            self._wait(self.cc)
+            self.k.cc_unpack(self.pack_c, self.nvar, self.nghbr, self.cc.seg_off, self.cc.recvbuf, u)
+        return TaskStatus.complete
+
+    # ---- face-centred ------------------------------------------------------------
+    def PackAndSendFC(self, b):
+        self.k.fc_local(self.pack_c, self.nghbr, b.x1f, b.x2f, b.x3f)
+        if self.peers:
+            self.k.fc_pack(self.pack_c, self.fc.nsend, self.fc.send_tab, self.fc.send_off,
+                           b.x1f, b.x2f, b.x3f, self.fc.sendbuf)
+            self._post(self.fc)
+        return TaskStatus.complete
+
+    def RecvAndUnpackFC(self, b):
+        if self.peers:
+            self._wait(self.fc)
+            self.k.fc_unpack(self.pack_c, self.nghbr, self.fc.seg_off, self.fc.recvbuf,
+                             b.x1f, b.x2f, b.x3f)
+        return TaskStatus.complete
+
+    # ---- physical boundaries -----------------------------------------------------
+    def HydroBCs(self, u):
+        self.k.hydro_bcs(self.pack_c, self.nvar, self.bcs, u)
+
+    def BFieldBCs(self, b):
+        self.k.bfield_bcs(self.pack_c, self.bcs, b.x1f, b.x2f, b.x3f)

@@ -1,0 +1,82 @@
+"""ctypes binding of the C ABI in include/akmi.h (athenak_amd/lib/libakmi.so).
+
+PyTorch is used here only as plumbing: device memory (tensor.data_ptr()) and HIP streams
+(torch.cuda.current_stream().cuda_stream).  There is NO CPU fallback: if the HIP library is
+missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libakmi.so")
+
+RECON = {"dc": 0, "plm": 1, "ppm4": 2}
+RSOLVER = {"llf": 0, "hlle": 1, "hllc": 2, "hlld": 3}
+BC = {"block": -1, "periodic": 0, "outflow": 1, "reflect": 2}
+
+COMPLETE, INCOMPLETE, FAIL = 0, 1, -1
+
+
+class Pack(C.Structure):
+    """struct akmi_pack"""
+    _fields_ = [("nmb", C.c_int), ("nvar", C.c_int), ("nx1", C.c_int), ("nx2", C.c_int),
+                ("nx3", C.c_int), ("ng", C.c_int), ("dx", C.c_void_p),
+                ("gamma", C.c_double), ("dfloor", C.c_double), ("pfloor", C.c_double),
+                ("tfloor", C.c_double), ("sfloor", C.c_double), ("sigma_max", C.c_double)]
+
+
+# every symbol include/akmi.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "akmi_last_error", "akmi_version", "akmi_copy_cons", "akmi_hydro_fluxes", "akmi_rk_update",
+    "akmi_hydro_c2p", "akmi_hydro_newdt", "akmi_mhd_fluxes", "akmi_mhd_corner_e", "akmi_mhd_ct",
+    "akmi_mhd_c2p", "akmi_mhd_newdt", "akmi_bvals_cc_local", "akmi_bvals_cc_pack",
+    "akmi_bvals_cc_unpack", "akmi_bvals_cc_segsize", "akmi_bvals_fc_local", "akmi_bvals_fc_pack",
+    "akmi_bvals_fc_unpack", "akmi_bvals_fc_segsize", "akmi_hydro_bcs", "akmi_bfield_bcs",
+    "akmi_stage_workspace_bytes", "akmi_hydro_stage_update", "akmi_mhd_stage_update",
+    "akmi_hydro_c2p_newdt", "akmi_mhd_c2p_newdt",
+]
+
+_LIB = None
+
+
+class AkmiError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libakmi.so (fails loudly when it has not been built)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise AkmiError(
+                "HIP library %s not found: run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.akmi_last_error.restype = C.c_char_p
+        L.akmi_bvals_cc_segsize.restype = C.c_longlong
+        L.akmi_bvals_fc_segsize.restype = C.c_longlong
+        L.akmi_stage_workspace_bytes.restype = C.c_longlong
+        _LIB = L
+    return _LIB
+
+
+def _p(t):
+    """device pointer of a torch tensor (None -> NULL)"""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what):
+    if rc < 0:
+        raise AkmiError("%s failed: %s" % (what, lib().akmi_last_error().decode()))
+    return rc
+
+
+def d(x):
+    return C.c_double(float(x))

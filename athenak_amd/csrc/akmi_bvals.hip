@@ -1,0 +1,422 @@
+// akmi_bvals.hip -- same-level ghost-zone fill, pack/unpack for off-rank neighbours, and
+// physical boundary conditions.
+//
+// The reference packs the ng innermost active layers of every block into per-neighbour
+// buffers (src/bvals/buffs_cc.cpp:36-46, buffs_fc.cpp:39-76), copies them straight into the
+// neighbour's receive buffer when it lives on the same rank (src/bvals/bvals_cc.cpp:122-135)
+// and unpacks into the ghost layers (buffs_cc.cpp:176-203, buffs_fc.cpp:396-431).  Here the
+// same-rank path is a single gather kernel over the ghost shell (no staging buffer at all):
+// ghost element (k,j,i) of block m in direction o := element (k-o3*nx3, j-o2*nx2, i-o1*nx1)
+// of nghbr[m][o].  Off-rank segments use the same index maps on both sides, so a segment
+// packed by the sender for direction d is exactly the receiver's ghost region for -d.
+#include "akmi_common.hpp"
+
+namespace akmi {
+
+// one dimension of a (cell- or face-centred) array: owned range [s,eo], ng ghosts each side
+struct Dim {
+  int s, eo, ng, nx;
+  __host__ __device__ int lo(int o) const { return o < 0 ? s - ng : (o > 0 ? eo + 1 : s); }
+  __host__ __device__ int hi(int o) const { return o < 0 ? s - 1 : (o > 0 ? eo + ng : eo); }
+  __host__ __device__ int cnt(int o) const { return hi(o) - lo(o) + 1; }
+  __host__ __device__ int total() const { return eo + ng + 1; }
+  // classify index -> o, (-2 if outside)
+  __host__ __device__ int side(int idx) const { return idx < s ? -1 : (idx > eo ? 1 : 0); }
+};
+
+// component c: 0 = cell-centred, 1/2/3 = x1f/x2f/x3f
+struct Comp {
+  Dim d1, d2, d3;
+  int n3, n2, n1;
+};
+
+__host__ __device__ inline Comp make_comp(const Geo &g, int c) {
+  Comp q;
+  q.d1 = Dim{g.is, g.ie + (c == 1), g.ng, g.nx1};
+  q.d2 = Dim{g.js, g.je + (c == 2), g.multi_d ? g.ng : 0, g.multi_d ? g.nx2 : 0};
+  q.d3 = Dim{g.ks, g.ke + (c == 3), g.three_d ? g.ng : 0, g.three_d ? g.nx3 : 0};
+  q.n1 = g.N1 + (c == 1); q.n2 = g.N2 + (c == 2); q.n3 = g.N3 + (c == 3);
+  return q;
+}
+
+__host__ __device__ inline bool dir_valid(const Geo &g, int d, int &o1, int &o2, int &o3) {
+  o1 = d%3 - 1; o2 = (d/3)%3 - 1; o3 = d/9 - 1;
+  if (d == 13) return false;
+  if (!g.multi_d && o2 != 0) return false;
+  if (!g.three_d && o3 != 0) return false;
+  return true;
+}
+
+__host__ __device__ inline long long seg_count(const Comp &q, int o1, int o2, int o3) {
+  return (long long)q.d1.cnt(o1)*q.d2.cnt(o2)*q.d3.cnt(o3);
+}
+
+// ---- same-rank ghost fill: thread per element of a slab of the array ---------------------
+// mode: which slab of the ghost shell (k-ghost slabs / j-ghost slabs / i-ghost slabs)
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_ghost_local(Geo g, Comp q, int nv, const int *__restrict__ nghbr, double *__restrict__ a,
+              const long long *__restrict__ seg_off, const double *__restrict__ recvbuf,
+              int unpack) {
+  // slab extents
+  int e1, e2, e3;
+  if (MODE == 0) { e1 = q.n1; e2 = q.n2; e3 = 2*q.d3.ng; }
+  else if (MODE == 1) { e1 = q.n1; e2 = 2*q.d2.ng; e3 = q.d3.eo - q.d3.s + 1; }
+  else { e1 = 2*q.d1.ng; e2 = q.d2.eo - q.d2.s + 1; e3 = q.d3.eo - q.d3.s + 1; }
+  const long long per = (long long)e1*e2*e3;
+  const long long tot = per*nv*g.nmb;
+  for (long long t = (long long)blockIdx.x*blockDim.x + threadIdx.x; t < tot;
+       t += (long long)gridDim.x*blockDim.x) {
+    int m = (int)(t/(per*nv));
+    long long r = t - (long long)m*per*nv;
+    int n = (int)(r/per);
+    r -= (long long)n*per;
+    int kk = (int)(r/((long long)e1*e2));
+    r -= (long long)kk*e1*e2;
+    int jj = (int)(r/e1);
+    int ii = (int)(r - (long long)jj*e1);
+    int i, j, k;
+    if (MODE == 0) { i = ii; j = jj; k = kk < q.d3.ng ? kk : q.d3.eo + 1 + (kk - q.d3.ng); }
+    else if (MODE == 1) { i = ii; j = jj < q.d2.ng ? jj : q.d2.eo + 1 + (jj - q.d2.ng); k = q.d3.s + kk; }
+    else { i = ii < q.d1.ng ? ii : q.d1.eo + 1 + (ii - q.d1.ng); j = q.d2.s + jj; k = q.d3.s + kk; }
+    int o1 = q.d1.side(i), o2 = q.d2.side(j), o3 = q.d3.side(k);
+    int d = (o3 + 1)*9 + (o2 + 1)*3 + (o1 + 1);
+    int src = nghbr[m*27 + d];
+    size_t dst = ((((size_t)m*nv + n)*q.n3 + k)*q.n2 + j)*q.n1 + i;
+    if (!unpack) {
+      if (src < 0) continue;
+      a[dst] = a[((((size_t)src*nv + n)*q.n3 + (k - o3*q.d3.nx))*q.n2 + (j - o2*q.d2.nx))*q.n1 +
+                 (i - o1*q.d1.nx)];
+    } else {
+      if (src > -2) continue;
+      const int c1 = q.d1.cnt(o1), c2 = q.d2.cnt(o2), c3 = q.d3.cnt(o3);
+      long long off = seg_off[-(src + 2)] +
+                      (((long long)n*c3 + (k - q.d3.lo(o3)))*c2 + (j - q.d2.lo(o2)))*c1 +
+                      (i - q.d1.lo(o1));
+      a[dst] = recvbuf[off];
+    }
+  }
+}
+
+static int launch_ghost(const Geo &g, const Comp &q, int nv, const int *nghbr, double *a,
+                        const long long *seg_off, const double *recvbuf, int unpack,
+                        hipStream_t st) {
+  auto nblk = [](long long n) { long long b = (n + 255)/256; return (int)(b > 65535 ? 65535 : (b < 1 ? 1 : b)); };
+  if (q.d3.ng > 0) {
+    long long n = (long long)q.n1*q.n2*2*q.d3.ng*nv*g.nmb;
+    k_ghost_local<0><<<nblk(n), 256, 0, st>>>(g, q, nv, nghbr, a, seg_off, recvbuf, unpack);
+  }
+  if (q.d2.ng > 0) {
+    long long n = (long long)q.n1*2*q.d2.ng*(q.d3.eo - q.d3.s + 1)*nv*g.nmb;
+    k_ghost_local<1><<<nblk(n), 256, 0, st>>>(g, q, nv, nghbr, a, seg_off, recvbuf, unpack);
+  }
+  {
+    long long n = (long long)2*q.d1.ng*(q.d2.eo - q.d2.s + 1)*(q.d3.eo - q.d3.s + 1)*nv*g.nmb;
+    k_ghost_local<2><<<nblk(n), 256, 0, st>>>(g, q, nv, nghbr, a, seg_off, recvbuf, unpack);
+  }
+  AKMI_CHECK_LAUNCH("bvals ghost fill");
+  return AKMI_COMPLETE;
+}
+
+// ---- pack: one grid.y per segment --------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_pack(Geo g, Comp q, int nv, const int *__restrict__ send_tab,
+       const long long *__restrict__ send_off, long long comp_off_unused,
+       const double *__restrict__ a, double *__restrict__ sendbuf, int fc_comp) {
+  const int s = blockIdx.y;
+  const int m = send_tab[2*s], d = send_tab[2*s + 1];
+  int o1, o2, o3;
+  if (!dir_valid(g, 26 - d, o1, o2, o3)) return;
+  const int c1 = q.d1.cnt(o1), c2 = q.d2.cnt(o2), c3 = q.d3.cnt(o3);
+  long long base = send_off[s];
+  if (fc_comp > 1) {  // FC segments hold x1f, x2f, x3f parts back to back
+    for (int c = 1; c < fc_comp; ++c) base += seg_count(make_comp(g, c), o1, o2, o3);
+  }
+  const long long tot = (long long)nv*c3*c2*c1;
+  for (long long t = (long long)blockIdx.x*blockDim.x + threadIdx.x; t < tot;
+       t += (long long)gridDim.x*blockDim.x) {
+    int n = (int)(t/((long long)c3*c2*c1));
+    long long r = t - (long long)n*c3*c2*c1;
+    int kk = (int)(r/((long long)c2*c1));
+    r -= (long long)kk*c2*c1;
+    int jj = (int)(r/c1);
+    int ii = (int)(r - (long long)jj*c1);
+    int i = q.d1.lo(o1) + ii - o1*q.d1.nx;
+    int j = q.d2.lo(o2) + jj - o2*q.d2.nx;
+    int k = q.d3.lo(o3) + kk - o3*q.d3.nx;
+    sendbuf[base + t] = a[((((size_t)m*nv + n)*q.n3 + k)*q.n2 + j)*q.n1 + i];
+  }
+}
+
+// ---- physical BCs ------------------------------------------------------------------------
+// HydroBCs (src/bvals/physics/hydro_bcs.cpp:69-...): DIR-normal ghost layers, all transverse
+// indices including ghosts; outflow and reflect.
+template <int DIR>
+__global__ void __launch_bounds__(256)
+k_hydro_bc(Geo g, int nv, const int *__restrict__ bcs, double *__restrict__ u) {
+  const int t1 = (DIR == 0) ? g.N2 : g.N1;            // fastest transverse extent
+  const int t2 = (DIR == 2) ? g.N2 : g.N3;            // slowest transverse extent
+  const long long tot = (long long)g.nmb*nv*t2*t1;
+  long long t = (long long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= tot) return;
+  int a = (int)(t%t1); t /= t1;
+  int b = (int)(t%t2); t /= t2;
+  int n = (int)(t%nv);
+  int m = (int)(t/nv);
+  const int bi = bcs[6*m + 2*DIR], bo = bcs[6*m + 2*DIR + 1];
+  const int s = (DIR == 0) ? g.is : (DIR == 1 ? g.js : g.ks);
+  const int e = (DIR == 0) ? g.ie : (DIR == 1 ? g.je : g.ke);
+  auto at = [&](int x) -> double & {
+    int i = (DIR == 0) ? x : a;
+    int j = (DIR == 0) ? a : (DIR == 1 ? x : b);
+    int k = (DIR == 2) ? x : b;
+    return u[ix5(nv, g.N3, g.N2, g.N1, m, n, k, j, i)];
+  };
+  const double sgn = (n == 1 + DIR) ? -1.0 : 1.0;
+  for (int q = 0; q < g.ng; ++q) {
+    if (bi == AKMI_BC_REFLECT) at(s - q - 1) = sgn*at(s + q);
+    else if (bi == AKMI_BC_OUTFLOW) at(s - q - 1) = at(s);
+  }
+  for (int q = 0; q < g.ng; ++q) {
+    if (bo == AKMI_BC_REFLECT) at(e + q + 1) = sgn*at(e - q);
+    else if (bo == AKMI_BC_OUTFLOW) at(e + q + 1) = at(e);
+  }
+}
+
+// BFieldBCs (src/bvals/physics/bfield_bcs.cpp:66-...).  Thread per transverse cell; the
+// extra "+1" faces of the transverse components are handled by the last thread in that
+// direction exactly as in the reference.
+template <int DIR>
+__global__ void __launch_bounds__(256)
+k_bfield_bc(Geo g, const int *__restrict__ bcs, double *__restrict__ b1, double *__restrict__ b2,
+            double *__restrict__ b3) {
+  const int t1 = (DIR == 0) ? g.N2 : g.N1;
+  const int t2 = (DIR == 2) ? g.N2 : g.N3;
+  const long long tot = (long long)g.nmb*t2*t1;
+  long long t = (long long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= tot) return;
+  int a = (int)(t%t1); t /= t1;
+  int b = (int)(t%t2);
+  int m = (int)(t/t2);
+  const int bi = bcs[6*m + 2*DIR], bo = bcs[6*m + 2*DIR + 1];
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  // component accessors taking (normal index x, transverse a, b) -> (k,j,i)
+  auto kji = [&](int x, int aa, int bb, int &k, int &j, int &i) {
+    i = (DIR == 0) ? x : aa;
+    j = (DIR == 0) ? aa : (DIR == 1 ? x : bb);
+    k = (DIR == 2) ? x : bb;
+  };
+  auto B1 = [&](int x, int aa, int bb) -> double & { int k, j, i; kji(x, aa, bb, k, j, i); return b1[ix4(N3, N2, N1 + 1, m, k, j, i)]; };
+  auto B2 = [&](int x, int aa, int bb) -> double & { int k, j, i; kji(x, aa, bb, k, j, i); return b2[ix4(N3, N2 + 1, N1, m, k, j, i)]; };
+  auto B3 = [&](int x, int aa, int bb) -> double & { int k, j, i; kji(x, aa, bb, k, j, i); return b3[ix4(N3 + 1, N2, N1, m, k, j, i)]; };
+  const int s = (DIR == 0) ? g.is : (DIR == 1 ? g.js : g.ks);
+  const int e = (DIR == 0) ? g.ie : (DIR == 1 ? g.je : g.ke);
+  // which transverse coordinate carries the "+1" face of each transverse component:
+  //  DIR=0: a=j (x2f extra at j==N2-1), b=k (x3f extra at k==N3-1)
+  //  DIR=1: a=i (x1f extra at i==N1-1), b=k (x3f extra at k==N3-1)
+  //  DIR=2: a=i (x1f extra at i==N1-1), b=j (x2f extra at j==N2-1)
+  for (int q = 0; q < g.ng; ++q) {
+    for (int side = 0; side < 2; ++side) {
+      const int bc = side ? bo : bi;
+      if (bc != AKMI_BC_REFLECT && bc != AKMI_BC_OUTFLOW) continue;
+      const bool refl = (bc == AKMI_BC_REFLECT);
+      // ghost index / source index for the normal component (face-centred along DIR)
+      const int gn = side ? e + q + 2 : s - q - 1;
+      const int sn = side ? (refl ? e - q : e + 1) : (refl ? s + q + 1 : s);
+      // for transverse components (cell-centred along DIR)
+      const int gt = side ? e + q + 1 : s - q - 1;
+      const int stt = side ? (refl ? e - q : e) : (refl ? s + q : s);
+      const double sg = refl ? -1.0 : 1.0;
+      if (DIR == 0) {
+        B1(gn, a, b) = sg*B1(sn, a, b);
+        B2(gt, a, b) = B2(stt, a, b);
+        if (a == N2 - 1) B2(gt, a + 1, b) = B2(stt, a + 1, b);
+        B3(gt, a, b) = B3(stt, a, b);
+        if (b == N3 - 1) B3(gt, a, b + 1) = B3(stt, a, b + 1);
+      } else if (DIR == 1) {
+        B1(gt, a, b) = B1(stt, a, b);
+        if (a == N1 - 1) B1(gt, a + 1, b) = B1(stt, a + 1, b);
+        B2(gn, a, b) = sg*B2(sn, a, b);
+        B3(gt, a, b) = B3(stt, a, b);
+        if (b == N3 - 1) B3(gt, a, b + 1) = B3(stt, a, b + 1);
+      } else {
+        B1(gt, a, b) = B1(stt, a, b);
+        if (a == N1 - 1) B1(gt, a + 1, b) = B1(stt, a + 1, b);
+        B2(gt, a, b) = B2(stt, a, b);
+        if (b == N2 - 1) B2(gt, a, b + 1) = B2(stt, a, b + 1);
+        B3(gn, a, b) = sg*B3(sn, a, b);
+      }
+    }
+  }
+}
+
+}  // namespace akmi
+
+using namespace akmi;
+
+extern "C" {
+
+long long akmi_bvals_cc_segsize(const akmi_pack *p, int d) {
+  Geo g = make_geo(p);
+  int o1, o2, o3;
+  if (!dir_valid(g, d, o1, o2, o3)) return 0;
+  return seg_count(make_comp(g, 0), o1, o2, o3);
+}
+
+long long akmi_bvals_fc_segsize(const akmi_pack *p, int d) {
+  Geo g = make_geo(p);
+  int o1, o2, o3;
+  if (!dir_valid(g, d, o1, o2, o3)) return 0;
+  long long t = 0;
+  for (int c = 1; c <= 3; ++c) t += seg_count(make_comp(g, c), o1, o2, o3);
+  return t;
+}
+
+int akmi_bvals_cc_local(const akmi_pack *p, int nvar, const int *nghbr, double *u, void *stream) {
+  Geo g = make_geo(p);
+  return launch_ghost(g, make_comp(g, 0), nvar, nghbr, u, nullptr, nullptr, 0, (hipStream_t)stream);
+}
+
+int akmi_bvals_cc_unpack(const akmi_pack *p, int nvar, const int *nghbr, const long long *seg_off,
+                         const double *recvbuf, double *u, void *stream) {
+  Geo g = make_geo(p);
+  return launch_ghost(g, make_comp(g, 0), nvar, nghbr, u, seg_off, recvbuf, 1, (hipStream_t)stream);
+}
+
+int akmi_bvals_cc_pack(const akmi_pack *p, int nvar, int nsend, const int *send_tab,
+                       const long long *send_off, const double *u, double *sendbuf, void *stream) {
+  if (nsend <= 0) return AKMI_COMPLETE;
+  Geo g = make_geo(p);
+  dim3 grid(64, nsend);
+  k_pack<<<grid, 256, 0, (hipStream_t)stream>>>(g, make_comp(g, 0), nvar, send_tab, send_off, 0, u,
+                                               sendbuf, 0);
+  AKMI_CHECK_LAUNCH("cc_pack");
+  return AKMI_COMPLETE;
+}
+
+int akmi_bvals_fc_local(const akmi_pack *p, const int *nghbr, double *bx1f, double *bx2f,
+                        double *bx3f, void *stream) {
+  Geo g = make_geo(p);
+  double *b[3] = {bx1f, bx2f, bx3f};
+  for (int c = 1; c <= 3; ++c) {
+    int rc = launch_ghost(g, make_comp(g, c), 1, nghbr, b[c - 1], nullptr, nullptr, 0, (hipStream_t)stream);
+    if (rc != AKMI_COMPLETE) return rc;
+  }
+  return AKMI_COMPLETE;
+}
+
+int akmi_bvals_fc_pack(const akmi_pack *p, int nsend, const int *send_tab, const long long *send_off,
+                       const double *bx1f, const double *bx2f, const double *bx3f, double *sendbuf,
+                       void *stream) {
+  if (nsend <= 0) return AKMI_COMPLETE;
+  Geo g = make_geo(p);
+  const double *b[3] = {bx1f, bx2f, bx3f};
+  dim3 grid(32, nsend);
+  for (int c = 1; c <= 3; ++c) {
+    k_pack<<<grid, 256, 0, (hipStream_t)stream>>>(g, make_comp(g, c), 1, send_tab, send_off, 0,
+                                                 b[c - 1], sendbuf, c);
+  }
+  AKMI_CHECK_LAUNCH("fc_pack");
+  return AKMI_COMPLETE;
+}
+
+}  // extern "C"
+
+namespace akmi {
+// FC unpack needs per-component base offsets inside a segment (x1f, x2f, x3f back to back)
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_fc_unpack(Geo g, Comp q, int comp, const int *__restrict__ nghbr, double *__restrict__ a,
+            const long long *__restrict__ seg_off, const double *__restrict__ recvbuf) {
+  int e1, e2, e3;
+  if (MODE == 0) { e1 = q.n1; e2 = q.n2; e3 = 2*q.d3.ng; }
+  else if (MODE == 1) { e1 = q.n1; e2 = 2*q.d2.ng; e3 = q.d3.eo - q.d3.s + 1; }
+  else { e1 = 2*q.d1.ng; e2 = q.d2.eo - q.d2.s + 1; e3 = q.d3.eo - q.d3.s + 1; }
+  const long long per = (long long)e1*e2*e3;
+  const long long tot = per*g.nmb;
+  for (long long t = (long long)blockIdx.x*blockDim.x + threadIdx.x; t < tot;
+       t += (long long)gridDim.x*blockDim.x) {
+    int m = (int)(t/per);
+    long long r = t - (long long)m*per;
+    int kk = (int)(r/((long long)e1*e2));
+    r -= (long long)kk*e1*e2;
+    int jj = (int)(r/e1);
+    int ii = (int)(r - (long long)jj*e1);
+    int i, j, k;
+    if (MODE == 0) { i = ii; j = jj; k = kk < q.d3.ng ? kk : q.d3.eo + 1 + (kk - q.d3.ng); }
+    else if (MODE == 1) { i = ii; j = jj < q.d2.ng ? jj : q.d2.eo + 1 + (jj - q.d2.ng); k = q.d3.s + kk; }
+    else { i = ii < q.d1.ng ? ii : q.d1.eo + 1 + (ii - q.d1.ng); j = q.d2.s + jj; k = q.d3.s + kk; }
+    int o1 = q.d1.side(i), o2 = q.d2.side(j), o3 = q.d3.side(k);
+    int d = (o3 + 1)*9 + (o2 + 1)*3 + (o1 + 1);
+    int src = nghbr[m*27 + d];
+    if (src > -2) continue;
+    long long base = seg_off[-(src + 2)];
+    for (int c = 1; c < comp; ++c) base += seg_count(make_comp(g, c), o1, o2, o3);
+    const int c1 = q.d1.cnt(o1), c2 = q.d2.cnt(o2);
+    long long off = base + ((long long)(k - q.d3.lo(o3))*c2 + (j - q.d2.lo(o2)))*c1 + (i - q.d1.lo(o1));
+    a[(((size_t)m*q.n3 + k)*q.n2 + j)*q.n1 + i] = recvbuf[off];
+  }
+}
+}  // namespace akmi
+
+extern "C" {
+
+int akmi_bvals_fc_unpack(const akmi_pack *p, const int *nghbr, const long long *seg_off,
+                         const double *recvbuf, double *bx1f, double *bx2f, double *bx3f,
+                         void *stream) {
+  Geo g = make_geo(p);
+  hipStream_t st = (hipStream_t)stream;
+  double *b[3] = {bx1f, bx2f, bx3f};
+  auto nblk = [](long long n) { long long bl = (n + 255)/256; return (int)(bl > 65535 ? 65535 : (bl < 1 ? 1 : bl)); };
+  for (int c = 1; c <= 3; ++c) {
+    Comp q = make_comp(g, c);
+    if (q.d3.ng > 0)
+      k_fc_unpack<0><<<nblk((long long)q.n1*q.n2*2*q.d3.ng*g.nmb), 256, 0, st>>>(g, q, c, nghbr, b[c-1], seg_off, recvbuf);
+    if (q.d2.ng > 0)
+      k_fc_unpack<1><<<nblk((long long)q.n1*2*q.d2.ng*(q.d3.eo - q.d3.s + 1)*g.nmb), 256, 0, st>>>(g, q, c, nghbr, b[c-1], seg_off, recvbuf);
+    k_fc_unpack<2><<<nblk((long long)2*q.d1.ng*(q.d2.eo - q.d2.s + 1)*(q.d3.eo - q.d3.s + 1)*g.nmb), 256, 0, st>>>(g, q, c, nghbr, b[c-1], seg_off, recvbuf);
+  }
+  AKMI_CHECK_LAUNCH("fc_unpack");
+  return AKMI_COMPLETE;
+}
+
+int akmi_hydro_bcs(const akmi_pack *p, int nvar, const int *bcs, double *u, void *stream) {
+  Geo g = make_geo(p);
+  hipStream_t st = (hipStream_t)stream;
+  {
+    long long n = (long long)g.nmb*nvar*g.N3*g.N2;
+    k_hydro_bc<0><<<(int)((n + 255)/256), 256, 0, st>>>(g, nvar, bcs, u);
+  }
+  if (g.multi_d) {
+    long long n = (long long)g.nmb*nvar*g.N3*g.N1;
+    k_hydro_bc<1><<<(int)((n + 255)/256), 256, 0, st>>>(g, nvar, bcs, u);
+  }
+  if (g.three_d) {
+    long long n = (long long)g.nmb*nvar*g.N2*g.N1;
+    k_hydro_bc<2><<<(int)((n + 255)/256), 256, 0, st>>>(g, nvar, bcs, u);
+  }
+  AKMI_CHECK_LAUNCH("hydro_bcs");
+  return AKMI_COMPLETE;
+}
+
+int akmi_bfield_bcs(const akmi_pack *p, const int *bcs, double *bx1f, double *bx2f, double *bx3f,
+                    void *stream) {
+  Geo g = make_geo(p);
+  hipStream_t st = (hipStream_t)stream;
+  {
+    long long n = (long long)g.nmb*g.N3*g.N2;
+    k_bfield_bc<0><<<(int)((n + 255)/256), 256, 0, st>>>(g, bcs, bx1f, bx2f, bx3f);
+  }
+  if (g.multi_d) {
+    long long n = (long long)g.nmb*g.N3*g.N1;
+    k_bfield_bc<1><<<(int)((n + 255)/256), 256, 0, st>>>(g, bcs, bx1f, bx2f, bx3f);
+  }
+  if (g.three_d) {
+    long long n = (long long)g.nmb*g.N2*g.N1;
+    k_bfield_bc<2><<<(int)((n + 255)/256), 256, 0, st>>>(g, bcs, bx1f, bx2f, bx3f);
+  }
+  AKMI_CHECK_LAUNCH("bfield_bcs");
+  return AKMI_COMPLETE;
+}
+
+}  // extern "C"

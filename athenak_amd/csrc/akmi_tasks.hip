@@ -1,0 +1,575 @@
+// akmi_tasks.hip -- one HIP kernel (family) per reference task body, behind the C ABI of
+// include/akmi.h.  These are the task-granular entry points (drop-in for the bodies of
+// Hydro::Fluxes, RKUpdate, ConToPrim, NewTimeStep, MHD::Fluxes, CornerE, CT ...); the fused
+// per-stage fast path lives in akmi_stage.hip and must reproduce these bit for bit.
+//
+// Thread mapping everywhere: threadIdx.x runs along i (the contiguous index of the
+// (m,n,k,j,i) LayoutRight arrays) so every global access of a wave is a 512-B coalesced
+// row segment; blockDim = (64,4): one wave64 per j-row, 4 rows per workgroup.
+#include <cstdarg>
+#include "akmi_common.hpp"
+
+namespace akmi {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+constexpr int BX = 64, BY = 4;
+
+// ---------------------------------------------------------------------------------------
+// Hydro fluxes: reconstruct in registers + HLLC.  hydro_fluxes.cpp:77-229.
+template <int DIR, int RECON>
+__global__ void __launch_bounds__(BX*BY)
+k_hydro_flux(Geo g, double gamma, const double *__restrict__ w0, double *__restrict__ flx,
+             int f3, int f2, int f1, int il, int iu, int jl, int ju, int kl, int nk) {
+  const int i = il + blockIdx.x*BX + threadIdx.x;
+  const int j = jl + blockIdx.y*BY + threadIdx.y;
+  const int m = blockIdx.z/nk;
+  const int k = kl + (blockIdx.z - m*nk);
+  if (i > iu || j > ju) return;
+  constexpr int ivx = 1 + DIR, ivy = 1 + (DIR + 1)%3, ivz = 1 + (DIR + 2)%3;
+  const long s = (DIR == 0) ? 1 : (DIR == 1 ? (long)g.N1 : (long)g.N1*g.N2);
+  const size_t cs = (size_t)g.N3*g.N2*g.N1;   // variable stride
+  const double *q = w0 + ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
+  double ld, lx, ly, lz, le, rd, rx, ry, rz, re;
+  face_states<RECON>(q + 0*cs, s, ld, rd);
+  face_states<RECON>(q + ivx*cs, s, lx, rx);
+  face_states<RECON>(q + ivy*cs, s, ly, ry);
+  face_states<RECON>(q + ivz*cs, s, lz, rz);
+  face_states<RECON>(q + 4*cs, s, le, re);
+  double fd, fx, fy, fz, fe;
+  hllc(gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, fd, fx, fy, fz, fe);
+  const size_t fs = (size_t)f3*f2*f1;
+  double *f = flx + ix5(g.nvar, f3, f2, f1, m, 0, k, j, i);
+  f[0] = fd; f[ivx*fs] = fx; f[ivy*fs] = fy; f[ivz*fs] = fz; f[4*fs] = fe;
+}
+
+template <int DIR>
+static int launch_hydro_flux(const Geo &g, double gamma, int recon, const double *w0,
+                             double *flx, int fsh, hipStream_t st) {
+  int il = g.is, iu = g.ie, jl = g.js, ju = g.je, kl = g.ks, ku = g.ke;
+  int f3 = g.N3, f2 = g.N2, f1 = g.N1;
+  if (DIR == 0) { iu = g.ie + 1; f1 += fsh; }
+  if (DIR == 1) { ju = g.je + 1; f2 += fsh; }
+  if (DIR == 2) { ku = g.ke + 1; f3 += fsh; }
+  int nk = ku - kl + 1;
+  dim3 grid(cdiv(iu - il + 1, BX), cdiv(ju - jl + 1, BY), nk*g.nmb), block(BX, BY);
+  if (recon == AKMI_RECON_PLM)
+    k_hydro_flux<DIR, 1><<<grid, block, 0, st>>>(g, gamma, w0, flx, f3, f2, f1, il, iu, jl, ju, kl, nk);
+  else if (recon == AKMI_RECON_PPM4)
+    k_hydro_flux<DIR, 2><<<grid, block, 0, st>>>(g, gamma, w0, flx, f3, f2, f1, il, iu, jl, ju, kl, nk);
+  else
+    k_hydro_flux<DIR, 0><<<grid, block, 0, st>>>(g, gamma, w0, flx, f3, f2, f1, il, iu, jl, ju, kl, nk);
+  AKMI_CHECK_LAUNCH("hydro_flux");
+  return AKMI_COMPLETE;
+}
+
+// ---------------------------------------------------------------------------------------
+// RKUpdate: hydro_update.cpp:50-81
+__global__ void __launch_bounds__(BX*BY)
+k_rk_update(Geo g, double gam0, double gam1, double beta_dt, double *__restrict__ u0,
+            const double *__restrict__ u1, const double *__restrict__ flx1,
+            const double *__restrict__ flx2, const double *__restrict__ flx3, int fsh) {
+  const int i = g.is + blockIdx.x*BX + threadIdx.x;
+  const int j = g.js + blockIdx.y*BY + threadIdx.y;
+  const int nk = g.ke - g.ks + 1;
+  const int m = blockIdx.z/nk;
+  const int k = g.ks + (blockIdx.z - m*nk);
+  if (i > g.ie || j > g.je) return;
+  const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
+  for (int n = 0; n < g.nvar; ++n) {
+    double divf = (flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + fsh, m, n, k, j, i + 1)] -
+                   flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + fsh, m, n, k, j, i)])/dx1;
+    if (g.multi_d)
+      divf += (flx2[ix5(g.nvar, g.N3, g.N2 + fsh, g.N1, m, n, k, j + 1, i)] -
+               flx2[ix5(g.nvar, g.N3, g.N2 + fsh, g.N1, m, n, k, j, i)])/dx2;
+    if (g.three_d)
+      divf += (flx3[ix5(g.nvar, g.N3 + fsh, g.N2, g.N1, m, n, k + 1, j, i)] -
+               flx3[ix5(g.nvar, g.N3 + fsh, g.N2, g.N1, m, n, k, j, i)])/dx3;
+    size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, n, k, j, i);
+    u0[c] = gam0*u0[c] + gam1*u1[c] - beta_dt*divf;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// ConsToPrim: ideal_hyd.cpp:45-103, ideal_mhd.cpp:47-122.  Floor counters: one wave-level
+// ballot + one atomicAdd per wave that actually hit a floor (never on the hot path).
+template <bool MHD>
+__global__ void __launch_bounds__(BX*BY)
+k_c2p(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ bx1f,
+      const double *__restrict__ bx2f, const double *__restrict__ bx3f,
+      double *__restrict__ w0, double *__restrict__ bcc0, int il, int iu, int jl, int ju,
+      int kl, int nk, int *__restrict__ counters) {
+  const int i = il + blockIdx.x*BX + threadIdx.x;
+  const int j = jl + blockIdx.y*BY + threadIdx.y;
+  const int m = blockIdx.z/nk;
+  const int k = kl + (blockIdx.z - m*nk);
+  if (i > iu || j > ju) return;
+  const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
+  double ud = u0[c], umx = u0[c + cs], umy = u0[c + 2*cs], umz = u0[c + 3*cs], ue = u0[c + 4*cs];
+  double wd, wvx, wvy, wvz, we;
+  bool dfl = false, efl = false, tfl = false;
+  if constexpr (MHD) {
+    double ubx = 0.5*(bx1f[ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i)] +
+                      bx1f[ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i + 1)]);
+    double uby = 0.5*(bx2f[ix4(g.N3, g.N2 + 1, g.N1, m, k, j, i)] +
+                      bx2f[ix4(g.N3, g.N2 + 1, g.N1, m, k, j + 1, i)]);
+    double ubz = 0.5*(bx3f[ix4(g.N3 + 1, g.N2, g.N1, m, k, j, i)] +
+                      bx3f[ix4(g.N3 + 1, g.N2, g.N1, m, k + 1, j, i)]);
+    c2p_mhd(eos, ud, umx, umy, umz, ue, ubx, uby, ubz, wd, wvx, wvy, wvz, we, dfl, efl, tfl);
+    const size_t b = ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i);
+    bcc0[b] = ubx; bcc0[b + cs] = uby; bcc0[b + 2*cs] = ubz;
+  } else {
+    c2p_hyd(eos, ud, umx, umy, umz, ue, wd, wvx, wvy, wvz, we, dfl, efl, tfl);
+  }
+  if (dfl) { u0[c] = ud; atomicAdd(&counters[0], 1); }
+  if (efl) { u0[c + 4*cs] = ue; atomicAdd(&counters[1], 1); }
+  if (tfl) { u0[c + 4*cs] = ue; atomicAdd(&counters[2], 1); }
+  w0[c] = wd; w0[c + cs] = wvx; w0[c + 2*cs] = wvy; w0[c + 3*cs] = wvz; w0[c + 4*cs] = we;
+}
+
+// ---------------------------------------------------------------------------------------
+// NewTimeStep: hydro_newdt.cpp:73-119, mhd_newdt.cpp:76-150.  Three minima; positive
+// doubles order like their bit patterns, so the cross-workgroup reduction is one
+// 64-bit atomicMin per workgroup per direction after a wave-level DPP/shuffle min.
+__device__ __forceinline__ double wave_min(double v) {
+  for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ void block_min3_atomic(double a, double b, double c,
+                                                  double *__restrict__ dt3) {
+  __shared__ double sm[3][BY];
+  a = wave_min(a); b = wave_min(b); c = wave_min(c);
+  const int lane = threadIdx.x & 63, w = threadIdx.y;
+  if (lane == 0) { sm[0][w] = a; sm[1][w] = b; sm[2][w] = c; }
+  __syncthreads();
+  if (threadIdx.y == 0 && threadIdx.x < 3) {
+    double v = sm[threadIdx.x][0];
+    for (int q = 1; q < BY; ++q) v = fmin(v, sm[threadIdx.x][q]);
+    atomicMin(reinterpret_cast<unsigned long long *>(&dt3[threadIdx.x]),
+              (unsigned long long)__double_as_longlong(v));
+  }
+}
+
+template <bool MHD>
+__device__ __forceinline__ void cell_dt(const Geo &g, double gamma, const double *__restrict__ w0,
+                                        const double *__restrict__ bcc0, int m, int k, int j,
+                                        int i, double &d1, double &d2, double &d3) {
+  const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
+  double wd = w0[c], vx = w0[c + cs], vy = w0[c + 2*cs], vz = w0[c + 3*cs];
+  double pr = (gamma - 1.0)*w0[c + 4*cs];
+  double mv1, mv2, mv3;
+  if constexpr (MHD) {
+    const size_t b = ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i);
+    double bx = bcc0[b], by = bcc0[b + cs], bz = bcc0[b + 2*cs];
+    mv1 = fabs(vx) + fast_speed(gamma, wd, pr, bx, by, bz);
+    mv2 = fabs(vy) + fast_speed(gamma, wd, pr, by, bz, bx);
+    mv3 = fabs(vz) + fast_speed(gamma, wd, pr, bz, bx, by);
+  } else {
+    double cs_ = sqrt(gamma*pr/wd);
+    mv1 = fabs(vx) + cs_; mv2 = fabs(vy) + cs_; mv3 = fabs(vz) + cs_;
+  }
+  d1 = g.dx[3*m]/mv1; d2 = g.dx[3*m + 1]/mv2; d3 = g.dx[3*m + 2]/mv3;
+}
+
+template <bool MHD>
+__global__ void __launch_bounds__(BX*BY)
+k_newdt(Geo g, double gamma, const double *__restrict__ w0, const double *__restrict__ bcc0,
+        double *__restrict__ dt3) {
+  const int i = g.is + blockIdx.x*BX + threadIdx.x;
+  const int j = g.js + blockIdx.y*BY + threadIdx.y;
+  const int nk = g.ke - g.ks + 1;
+  const int m = blockIdx.z/nk;
+  const int k = g.ks + (blockIdx.z - m*nk);
+  double d1 = (double)FLT_MAX, d2 = (double)FLT_MAX, d3 = (double)FLT_MAX;
+  if (i <= g.ie && j <= g.je) cell_dt<MHD>(g, gamma, w0, bcc0, m, k, j, i, d1, d2, d3);
+  block_min3_atomic(d1, d2, d3, dt3);
+}
+
+__global__ void k_init_dt(double *dt3) {
+  if (threadIdx.x < 3) dt3[threadIdx.x] = (double)FLT_MAX;
+}
+
+// ---------------------------------------------------------------------------------------
+// MHD fluxes: reconstruct w0 and bcc0 in registers + HLLD.  mhd_fluxes.cpp:84-266.
+template <int DIR, int RECON>
+__global__ void __launch_bounds__(BX*BY)
+k_mhd_flux(Geo g, double gamma, const double *__restrict__ w0, const double *__restrict__ bcc0,
+           const double *__restrict__ bxf, double *__restrict__ flx, double *__restrict__ ey,
+           double *__restrict__ ez, int f3, int f2, int f1, int il, int iu, int jl, int ju,
+           int kl, int nk) {
+  const int i = il + blockIdx.x*BX + threadIdx.x;
+  const int j = jl + blockIdx.y*BY + threadIdx.y;
+  const int m = blockIdx.z/nk;
+  const int k = kl + (blockIdx.z - m*nk);
+  if (i > iu || j > ju) return;
+  constexpr int ivx = 1 + DIR, ivy = 1 + (DIR + 1)%3, ivz = 1 + (DIR + 2)%3;
+  constexpr int iby = (DIR + 1)%3, ibz = (DIR + 2)%3;
+  const long s = (DIR == 0) ? 1 : (DIR == 1 ? (long)g.N1 : (long)g.N1*g.N2);
+  const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  const double *q = w0 + ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
+  const double *b = bcc0 + ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i);
+  double ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz;
+  face_states<RECON>(q + 0*cs, s, ld, rd);
+  face_states<RECON>(q + ivx*cs, s, lx, rx);
+  face_states<RECON>(q + ivy*cs, s, ly, ry);
+  face_states<RECON>(q + ivz*cs, s, lz, rz);
+  face_states<RECON>(q + 4*cs, s, le, re);
+  face_states<RECON>(b + iby*cs, s, lby, rby);
+  face_states<RECON>(b + ibz*cs, s, lbz, rbz);
+  const double bxi = bxf[ix4(f3, f2, f1, m, k, j, i)];
+  Cons1D fl = hlld(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
+  const size_t fs = (size_t)f3*f2*f1;
+  double *f = flx + ix5(g.nvar, f3, f2, f1, m, 0, k, j, i);
+  f[0] = fl.d; f[ivx*fs] = fl.mx; f[ivy*fs] = fl.my; f[ivz*fs] = fl.mz; f[4*fs] = fl.e;
+  const size_t ec = ix4(g.N3, g.N2, g.N1, m, k, j, i);
+  ey[ec] = -fl.by;
+  ez[ec] = fl.bz;
+}
+
+template <int DIR>
+static int launch_mhd_flux(const Geo &g, double gamma, int recon, const double *w0,
+                           const double *bcc0, const double *bxf, double *flx, double *ey,
+                           double *ez, hipStream_t st) {
+  int il, iu, jl, ju, kl, ku;
+  int f3 = g.N3, f2 = g.N2, f1 = g.N1;
+  if (DIR == 0) {
+    il = g.is; iu = g.ie + 1; jl = g.js; ju = g.je; kl = g.ks; ku = g.ke;
+    if (g.multi_d) { jl = g.js - 1; ju = g.je + 1; }
+    if (g.three_d) { kl = g.ks - 1; ku = g.ke + 1; }
+    f1 += 1;
+  } else if (DIR == 1) {
+    il = g.is - 1; iu = g.ie + 1; jl = g.js; ju = g.je + 1; kl = g.ks; ku = g.ke;
+    if (g.three_d) { kl = g.ks - 1; ku = g.ke + 1; }
+    f2 += 1;
+  } else {
+    il = g.is - 1; iu = g.ie + 1; jl = g.js - 1; ju = g.je + 1; kl = g.ks; ku = g.ke + 1;
+    f3 += 1;
+  }
+  int nk = ku - kl + 1;
+  dim3 grid(cdiv(iu - il + 1, BX), cdiv(ju - jl + 1, BY), nk*g.nmb), block(BX, BY);
+  if (recon == AKMI_RECON_PLM)
+    k_mhd_flux<DIR, 1><<<grid, block, 0, st>>>(g, gamma, w0, bcc0, bxf, flx, ey, ez, f3, f2, f1, il, iu, jl, ju, kl, nk);
+  else if (recon == AKMI_RECON_PPM4)
+    k_mhd_flux<DIR, 2><<<grid, block, 0, st>>>(g, gamma, w0, bcc0, bxf, flx, ey, ez, f3, f2, f1, il, iu, jl, ju, kl, nk);
+  else
+    k_mhd_flux<DIR, 0><<<grid, block, 0, st>>>(g, gamma, w0, bcc0, bxf, flx, ey, ez, f3, f2, f1, il, iu, jl, ju, kl, nk);
+  AKMI_CHECK_LAUNCH("mhd_flux");
+  return AKMI_COMPLETE;
+}
+
+// ---------------------------------------------------------------------------------------
+// CornerE, mhd_corner_e.cpp:26-417.  Cell-centred E = -(v x B) (:309-317) is recomputed
+// in registers from w0/bcc0 instead of being staged through e1_cc/e2_cc/e3_cc arrays.
+struct EccAccess {
+  const double *w0, *bcc0;
+  int nvar, N3, N2, N1;
+  size_t cs;
+  __device__ __forceinline__ size_t cw(int m, int k, int j, int i) const {
+    return ix5(nvar, N3, N2, N1, m, 0, k, j, i);
+  }
+  __device__ __forceinline__ size_t cb(int m, int k, int j, int i) const {
+    return ix5(3, N3, N2, N1, m, 0, k, j, i);
+  }
+  __device__ __forceinline__ double e1(int m, int k, int j, int i) const {
+    size_t a = cw(m, k, j, i), b = cb(m, k, j, i);
+    return w0[a + 3*cs]*bcc0[b + cs] - w0[a + 2*cs]*bcc0[b + 2*cs];
+  }
+  __device__ __forceinline__ double e2(int m, int k, int j, int i) const {
+    size_t a = cw(m, k, j, i), b = cb(m, k, j, i);
+    return w0[a + cs]*bcc0[b + 2*cs] - w0[a + 3*cs]*bcc0[b];
+  }
+  __device__ __forceinline__ double e3(int m, int k, int j, int i) const {
+    size_t a = cw(m, k, j, i), b = cb(m, k, j, i);
+    return w0[a + 2*cs]*bcc0[b] - w0[a + cs]*bcc0[b + cs];
+  }
+};
+
+__global__ void k_corner_e_1d(Geo g, const double *__restrict__ e3x1,
+                              const double *__restrict__ e2x1, double *__restrict__ e2,
+                              double *__restrict__ e3) {
+  const int i = g.is + blockIdx.x*blockDim.x + threadIdx.x;
+  const int m = blockIdx.y;
+  if (i > g.ie + 1) return;
+  const int ks = g.ks, ke = g.ke, js = g.js, je = g.je;
+  double a2 = e2x1[ix4(g.N3, g.N2, g.N1, m, ks, js, i)];
+  double a3 = e3x1[ix4(g.N3, g.N2, g.N1, m, ks, js, i)];
+  e2[ix4(g.N3 + 1, g.N2, g.N1 + 1, m, ks, js, i)] = a2;
+  e2[ix4(g.N3 + 1, g.N2, g.N1 + 1, m, ke + 1, js, i)] = a2;
+  e3[ix4(g.N3, g.N2 + 1, g.N1 + 1, m, ks, js, i)] = a3;
+  e3[ix4(g.N3, g.N2 + 1, g.N1 + 1, m, ks, je + 1, i)] = a3;
+}
+
+#define CCE(a, m, k, j, i) a[ix4(g.N3, g.N2, g.N1, m, k, j, i)]
+#define F1D(m, k, j, i) flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k, j, i)]
+#define F2D(m, k, j, i) flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, 0, k, j, i)]
+#define F3D(m, k, j, i) flx3[ix5(g.nvar, g.N3 + 1, g.N2, g.N1, m, 0, k, j, i)]
+
+__device__ __forceinline__ double corner_e3(const Geo &g, const EccAccess &cc,
+    const double *__restrict__ e3x1, const double *__restrict__ e3x2,
+    const double *__restrict__ flx1, const double *__restrict__ flx2, int m, int k, int j,
+    int i) {
+  double e3_l2, e3_r2, e3_l1, e3_r1;
+  if (F1D(m, k, j - 1, i) >= 0.0) e3_l2 = CCE(e3x2, m, k, j, i - 1) - cc.e3(m, k, j - 1, i - 1);
+  else                            e3_l2 = CCE(e3x2, m, k, j, i) - cc.e3(m, k, j - 1, i);
+  if (F1D(m, k, j, i) >= 0.0)     e3_r2 = CCE(e3x2, m, k, j, i - 1) - cc.e3(m, k, j, i - 1);
+  else                            e3_r2 = CCE(e3x2, m, k, j, i) - cc.e3(m, k, j, i);
+  if (F2D(m, k, j, i - 1) >= 0.0) e3_l1 = CCE(e3x1, m, k, j - 1, i) - cc.e3(m, k, j - 1, i - 1);
+  else                            e3_l1 = CCE(e3x1, m, k, j, i) - cc.e3(m, k, j, i - 1);
+  if (F2D(m, k, j, i) >= 0.0)     e3_r1 = CCE(e3x1, m, k, j - 1, i) - cc.e3(m, k, j - 1, i);
+  else                            e3_r1 = CCE(e3x1, m, k, j, i) - cc.e3(m, k, j, i);
+  return 0.25*(e3_l1 + e3_r1 + e3_l2 + e3_r2 + CCE(e3x2, m, k, j, i - 1) + CCE(e3x2, m, k, j, i) +
+               CCE(e3x1, m, k, j - 1, i) + CCE(e3x1, m, k, j, i));
+}
+
+__global__ void __launch_bounds__(BX*BY)
+k_corner_e_2d(Geo g, EccAccess cc, const double *__restrict__ e3x1,
+              const double *__restrict__ e2x1, const double *__restrict__ e1x2,
+              const double *__restrict__ e3x2, const double *__restrict__ flx1,
+              const double *__restrict__ flx2, double *__restrict__ e1, double *__restrict__ e2,
+              double *__restrict__ e3) {
+  const int i = g.is + blockIdx.x*BX + threadIdx.x;
+  const int j = g.js + blockIdx.y*BY + threadIdx.y;
+  const int m = blockIdx.z;
+  if (i > g.ie + 1 || j > g.je + 1) return;
+  const int ks = g.ks, ke = g.ke;
+  e2[ix4(g.N3 + 1, g.N2, g.N1 + 1, m, ks, j, i)] = CCE(e2x1, m, ks, j, i);
+  e2[ix4(g.N3 + 1, g.N2, g.N1 + 1, m, ke + 1, j, i)] = CCE(e2x1, m, ks, j, i);
+  e1[ix4(g.N3 + 1, g.N2 + 1, g.N1, m, ks, j, i)] = CCE(e1x2, m, ks, j, i);
+  e1[ix4(g.N3 + 1, g.N2 + 1, g.N1, m, ke + 1, j, i)] = CCE(e1x2, m, ks, j, i);
+  e3[ix4(g.N3, g.N2 + 1, g.N1 + 1, m, ks, j, i)] =
+      corner_e3(g, cc, e3x1, e3x2, flx1, flx2, m, ks, j, i);
+}
+
+__global__ void __launch_bounds__(BX*BY)
+k_corner_e_3d(Geo g, EccAccess cc, const double *__restrict__ e3x1,
+              const double *__restrict__ e2x1, const double *__restrict__ e1x2,
+              const double *__restrict__ e3x2, const double *__restrict__ e2x3,
+              const double *__restrict__ e1x3, const double *__restrict__ flx1,
+              const double *__restrict__ flx2, const double *__restrict__ flx3,
+              double *__restrict__ e1, double *__restrict__ e2, double *__restrict__ e3) {
+  const int i = g.is + blockIdx.x*BX + threadIdx.x;
+  const int j = g.js + blockIdx.y*BY + threadIdx.y;
+  const int nk = g.ke - g.ks + 2;
+  const int m = blockIdx.z/nk;
+  const int k = g.ks + (blockIdx.z - m*nk);
+  if (i > g.ie + 1 || j > g.je + 1) return;
+  // E1 (mhd_corner_e.cpp:340-363)
+  double e1_l3, e1_r3, e1_l2, e1_r2;
+  if (F2D(m, k - 1, j, i) >= 0.0) e1_l3 = CCE(e1x3, m, k, j - 1, i) - cc.e1(m, k - 1, j - 1, i);
+  else                            e1_l3 = CCE(e1x3, m, k, j, i) - cc.e1(m, k - 1, j, i);
+  if (F2D(m, k, j, i) >= 0.0)     e1_r3 = CCE(e1x3, m, k, j - 1, i) - cc.e1(m, k, j - 1, i);
+  else                            e1_r3 = CCE(e1x3, m, k, j, i) - cc.e1(m, k, j, i);
+  if (F3D(m, k, j - 1, i) >= 0.0) e1_l2 = CCE(e1x2, m, k - 1, j, i) - cc.e1(m, k - 1, j - 1, i);
+  else                            e1_l2 = CCE(e1x2, m, k, j, i) - cc.e1(m, k, j - 1, i);
+  if (F3D(m, k, j, i) >= 0.0)     e1_r2 = CCE(e1x2, m, k - 1, j, i) - cc.e1(m, k - 1, j, i);
+  else                            e1_r2 = CCE(e1x2, m, k, j, i) - cc.e1(m, k, j, i);
+  e1[ix4(g.N3 + 1, g.N2 + 1, g.N1, m, k, j, i)] =
+      0.25*(e1_l3 + e1_r3 + e1_l2 + e1_r2 + CCE(e1x2, m, k - 1, j, i) + CCE(e1x2, m, k, j, i) +
+            CCE(e1x3, m, k, j - 1, i) + CCE(e1x3, m, k, j, i));
+  // E2 (:365-388)
+  double e2_l3, e2_r3, e2_l1, e2_r1;
+  if (F1D(m, k - 1, j, i) >= 0.0) e2_l3 = CCE(e2x3, m, k, j, i - 1) - cc.e2(m, k - 1, j, i - 1);
+  else                            e2_l3 = CCE(e2x3, m, k, j, i) - cc.e2(m, k - 1, j, i);
+  if (F1D(m, k, j, i) >= 0.0)     e2_r3 = CCE(e2x3, m, k, j, i - 1) - cc.e2(m, k, j, i - 1);
+  else                            e2_r3 = CCE(e2x3, m, k, j, i) - cc.e2(m, k, j, i);
+  if (F3D(m, k, j, i - 1) >= 0.0) e2_l1 = CCE(e2x1, m, k - 1, j, i) - cc.e2(m, k - 1, j, i - 1);
+  else                            e2_l1 = CCE(e2x1, m, k, j, i) - cc.e2(m, k, j, i - 1);
+  if (F3D(m, k, j, i) >= 0.0)     e2_r1 = CCE(e2x1, m, k - 1, j, i) - cc.e2(m, k - 1, j, i);
+  else                            e2_r1 = CCE(e2x1, m, k, j, i) - cc.e2(m, k, j, i);
+  e2[ix4(g.N3 + 1, g.N2, g.N1 + 1, m, k, j, i)] =
+      0.25*(e2_l3 + e2_r3 + e2_l1 + e2_r1 + CCE(e2x3, m, k, j, i - 1) + CCE(e2x3, m, k, j, i) +
+            CCE(e2x1, m, k - 1, j, i) + CCE(e2x1, m, k, j, i));
+  // E3 (:390-413)
+  e3[ix4(g.N3, g.N2 + 1, g.N1 + 1, m, k, j, i)] =
+      corner_e3(g, cc, e3x1, e3x2, flx1, flx2, m, k, j, i);
+}
+
+// ---------------------------------------------------------------------------------------
+// CT, mhd_ct.cpp:23-80: all three face components in one launch.
+__global__ void __launch_bounds__(BX*BY)
+k_ct(Geo g, double gam0, double gam1, double beta_dt, const double *__restrict__ e1,
+     const double *__restrict__ e2, const double *__restrict__ e3, double *__restrict__ b0x1f,
+     double *__restrict__ b0x2f, double *__restrict__ b0x3f, const double *__restrict__ b1x1f,
+     const double *__restrict__ b1x2f, const double *__restrict__ b1x3f) {
+  const int i = g.is + blockIdx.x*BX + threadIdx.x;
+  const int j = g.js + blockIdx.y*BY + threadIdx.y;
+  const int nk = g.ke - g.ks + 2;
+  const int m = blockIdx.z/nk;
+  const int k = g.ks + (blockIdx.z - m*nk);
+  if (i > g.ie + 1 || j > g.je + 1) return;
+  const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
+#define E1(k, j, i) e1[ix4(g.N3 + 1, g.N2 + 1, g.N1, m, k, j, i)]
+#define E2(k, j, i) e2[ix4(g.N3 + 1, g.N2, g.N1 + 1, m, k, j, i)]
+#define E3(k, j, i) e3[ix4(g.N3, g.N2 + 1, g.N1 + 1, m, k, j, i)]
+  if (g.multi_d && j <= g.je && k <= g.ke) {
+    size_t c = ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i);
+    double b = gam0*b0x1f[c] + gam1*b1x1f[c];
+    b -= beta_dt*(E3(k, j + 1, i) - E3(k, j, i))/dx2;
+    if (g.three_d) b += beta_dt*(E2(k + 1, j, i) - E2(k, j, i))/dx3;
+    b0x1f[c] = b;
+  }
+  if (i <= g.ie && k <= g.ke) {
+    size_t c = ix4(g.N3, g.N2 + 1, g.N1, m, k, j, i);
+    double b = gam0*b0x2f[c] + gam1*b1x2f[c];
+    b += beta_dt*(E3(k, j, i + 1) - E3(k, j, i))/dx1;
+    if (g.three_d) b -= beta_dt*(E1(k + 1, j, i) - E1(k, j, i))/dx3;
+    b0x2f[c] = b;
+  }
+  if (i <= g.ie && j <= g.je) {
+    size_t c = ix4(g.N3 + 1, g.N2, g.N1, m, k, j, i);
+    double b = gam0*b0x3f[c] + gam1*b1x3f[c];
+    b -= beta_dt*(E2(k, j, i + 1) - E2(k, j, i))/dx1;
+    if (g.multi_d) b += beta_dt*(E1(k, j + 1, i) - E1(k, j, i))/dx2;
+    b0x3f[c] = b;
+  }
+#undef E1
+#undef E2
+#undef E3
+}
+
+}  // namespace akmi
+
+using namespace akmi;
+
+extern "C" {
+
+const char *akmi_last_error(void) { return akmi::g_err; }
+int akmi_version(void) { return 100; }
+
+int akmi_copy_cons(const akmi_pack *p, const double *u0, double *u1, void *stream) {
+  Geo g = make_geo(p);
+  size_t n = (size_t)g.nmb*g.nvar*g.N3*g.N2*g.N1*sizeof(double);
+  hipError_t e = hipMemcpyAsync(u1, u0, n, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) { set_error("copy_cons: %s", hipGetErrorString(e)); return AKMI_FAIL; }
+  return AKMI_COMPLETE;
+}
+
+int akmi_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                      double *flx1, double *flx2, double *flx3, int face_shaped,
+                      void *stream) {
+  if (rsolver != AKMI_RS_HLLC) { set_error("hydro_fluxes: only rsolver=hllc is implemented"); return AKMI_FAIL; }
+  if (recon == AKMI_RECON_PPM4 && p->ng < 3) { set_error("ppm4 needs nghost>=3"); return AKMI_FAIL; }
+  Geo g = make_geo(p);
+  hipStream_t st = (hipStream_t)stream;
+  int fsh = face_shaped ? 1 : 0;
+  int rc = launch_hydro_flux<0>(g, p->gamma, recon, w0, flx1, fsh, st);
+  if (rc == AKMI_COMPLETE && g.multi_d) rc = launch_hydro_flux<1>(g, p->gamma, recon, w0, flx2, fsh, st);
+  if (rc == AKMI_COMPLETE && g.three_d) rc = launch_hydro_flux<2>(g, p->gamma, recon, w0, flx3, fsh, st);
+  return rc;
+}
+
+int akmi_rk_update(const akmi_pack *p, double gam0, double gam1, double beta_dt, double *u0,
+                   const double *u1, const double *flx1, const double *flx2,
+                   const double *flx3, int face_shaped, void *stream) {
+  Geo g = make_geo(p);
+  dim3 grid(cdiv(g.nx1, BX), cdiv(g.je - g.js + 1, BY), (g.ke - g.ks + 1)*g.nmb), block(BX, BY);
+  k_rk_update<<<grid, block, 0, (hipStream_t)stream>>>(g, gam0, gam1, beta_dt, u0, u1, flx1, flx2,
+                                                       flx3, face_shaped ? 1 : 0);
+  AKMI_CHECK_LAUNCH("rk_update");
+  return AKMI_COMPLETE;
+}
+
+int akmi_hydro_c2p(const akmi_pack *p, double *u0, double *w0, int il, int iu, int jl, int ju,
+                   int kl, int ku, int *counters, void *stream) {
+  Geo g = make_geo(p);
+  int nk = ku - kl + 1;
+  dim3 grid(cdiv(iu - il + 1, BX), cdiv(ju - jl + 1, BY), nk*g.nmb), block(BX, BY);
+  k_c2p<false><<<grid, block, 0, (hipStream_t)stream>>>(g, make_eos(p), u0, nullptr, nullptr,
+      nullptr, w0, nullptr, il, iu, jl, ju, kl, nk, counters);
+  AKMI_CHECK_LAUNCH("hydro_c2p");
+  return AKMI_COMPLETE;
+}
+
+int akmi_mhd_c2p(const akmi_pack *p, double *u0, const double *bx1f, const double *bx2f,
+                 const double *bx3f, double *w0, double *bcc0, int il, int iu, int jl, int ju,
+                 int kl, int ku, int *counters, void *stream) {
+  Geo g = make_geo(p);
+  int nk = ku - kl + 1;
+  dim3 grid(cdiv(iu - il + 1, BX), cdiv(ju - jl + 1, BY), nk*g.nmb), block(BX, BY);
+  k_c2p<true><<<grid, block, 0, (hipStream_t)stream>>>(g, make_eos(p), u0, bx1f, bx2f, bx3f, w0,
+      bcc0, il, iu, jl, ju, kl, nk, counters);
+  AKMI_CHECK_LAUNCH("mhd_c2p");
+  return AKMI_COMPLETE;
+}
+
+int akmi_hydro_newdt(const akmi_pack *p, const double *w0, double *dt3, void *stream) {
+  Geo g = make_geo(p);
+  hipStream_t st = (hipStream_t)stream;
+  k_init_dt<<<1, 64, 0, st>>>(dt3);
+  dim3 grid(cdiv(g.nx1, BX), cdiv(g.je - g.js + 1, BY), (g.ke - g.ks + 1)*g.nmb), block(BX, BY);
+  k_newdt<false><<<grid, block, 0, st>>>(g, p->gamma, w0, nullptr, dt3);
+  AKMI_CHECK_LAUNCH("hydro_newdt");
+  return AKMI_COMPLETE;
+}
+
+int akmi_mhd_newdt(const akmi_pack *p, const double *w0, const double *bcc0, double *dt3,
+                   void *stream) {
+  Geo g = make_geo(p);
+  hipStream_t st = (hipStream_t)stream;
+  k_init_dt<<<1, 64, 0, st>>>(dt3);
+  dim3 grid(cdiv(g.nx1, BX), cdiv(g.je - g.js + 1, BY), (g.ke - g.ks + 1)*g.nmb), block(BX, BY);
+  k_newdt<true><<<grid, block, 0, st>>>(g, p->gamma, w0, bcc0, dt3);
+  AKMI_CHECK_LAUNCH("mhd_newdt");
+  return AKMI_COMPLETE;
+}
+
+int akmi_mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                    const double *bcc0, const double *bx1f, const double *bx2f,
+                    const double *bx3f, double *flx1, double *flx2, double *flx3, double *e3x1,
+                    double *e2x1, double *e1x2, double *e3x2, double *e2x3, double *e1x3,
+                    void *stream) {
+  if (rsolver != AKMI_RS_HLLD) { set_error("mhd_fluxes: only rsolver=hlld is implemented"); return AKMI_FAIL; }
+  if (recon == AKMI_RECON_PPM4 && p->ng < 3) { set_error("ppm4 needs nghost>=3"); return AKMI_FAIL; }
+  Geo g = make_geo(p);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = launch_mhd_flux<0>(g, p->gamma, recon, w0, bcc0, bx1f, flx1, e3x1, e2x1, st);
+  if (rc == AKMI_COMPLETE && g.multi_d)
+    rc = launch_mhd_flux<1>(g, p->gamma, recon, w0, bcc0, bx2f, flx2, e1x2, e3x2, st);
+  if (rc == AKMI_COMPLETE && g.three_d)
+    rc = launch_mhd_flux<2>(g, p->gamma, recon, w0, bcc0, bx3f, flx3, e2x3, e1x3, st);
+  return rc;
+}
+
+int akmi_mhd_corner_e(const akmi_pack *p, const double *w0, const double *bcc0,
+                      const double *e3x1, const double *e2x1, const double *e1x2,
+                      const double *e3x2, const double *e2x3, const double *e1x3,
+                      const double *flx1, const double *flx2, const double *flx3, double *e1,
+                      double *e2, double *e3, void *stream) {
+  Geo g = make_geo(p);
+  hipStream_t st = (hipStream_t)stream;
+  EccAccess cc{w0, bcc0, g.nvar, g.N3, g.N2, g.N1, (size_t)g.N3*g.N2*g.N1};
+  if (!g.multi_d) {
+    dim3 grid(cdiv(g.nx1 + 1, 256), g.nmb);
+    k_corner_e_1d<<<grid, 256, 0, st>>>(g, e3x1, e2x1, e2, e3);
+  } else if (!g.three_d) {
+    dim3 grid(cdiv(g.nx1 + 1, BX), cdiv(g.nx2 + 1, BY), g.nmb), block(BX, BY);
+    k_corner_e_2d<<<grid, block, 0, st>>>(g, cc, e3x1, e2x1, e1x2, e3x2, flx1, flx2, e1, e2, e3);
+  } else {
+    dim3 grid(cdiv(g.nx1 + 1, BX), cdiv(g.nx2 + 1, BY), (g.nx3 + 1)*g.nmb), block(BX, BY);
+    k_corner_e_3d<<<grid, block, 0, st>>>(g, cc, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, flx1, flx2,
+                                         flx3, e1, e2, e3);
+  }
+  AKMI_CHECK_LAUNCH("corner_e");
+  return AKMI_COMPLETE;
+}
+
+int akmi_mhd_ct(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *e1,
+                const double *e2, const double *e3, double *b0x1f, double *b0x2f, double *b0x3f,
+                const double *b1x1f, const double *b1x2f, const double *b1x3f, void *stream) {
+  Geo g = make_geo(p);
+  dim3 grid(cdiv(g.nx1 + 1, BX), cdiv(g.je - g.js + 2, BY), (g.ke - g.ks + 2)*g.nmb), block(BX, BY);
+  k_ct<<<grid, block, 0, (hipStream_t)stream>>>(g, gam0, gam1, beta_dt, e1, e2, e3, b0x1f, b0x2f,
+                                                b0x3f, b1x1f, b1x2f, b1x3f);
+  AKMI_CHECK_LAUNCH("ct");
+  return AKMI_COMPLETE;
+}
+
+}  // extern "C"

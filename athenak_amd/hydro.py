@@ -1,0 +1,227 @@
+"""hydro::Hydro -- arrays and task member functions of the hydrodynamics module.
+
+Mirror of src/hydro/hydro.hpp:73-154 / hydro.cpp:29-301 / hydro_tasks.cpp:48-508: same
+member names (u0, w0, u1, uflx, peos->eos_data, pbval_u, dtnew), same task names and
+dependency chain (AssembleHydroTasks, hydro_tasks.cpp:48-80), each task body reduced to one
+call through the C ABI (include/akmi.h).  Device arrays are torch.float64 CUDA tensors in the
+reference's (m,n,k,j,i) LayoutRight order; torch is memory/stream plumbing only.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+from .bvals import MeshBoundaryValues
+from .mesh import FLT_MAX, FLT_MIN
+from .tasklist import TaskID, TaskStatus
+
+
+class EOS_Data:
+    """src/eos/eos.hpp:27-34; defaults src/eos/eos.cpp:22-25, ideal_mhd.cpp:22"""
+
+    def __init__(self, pin, blk):
+        eos = pin.GetString(blk, "eos")
+        if eos != "ideal":
+            raise RuntimeError("### FATAL ERROR <%s> eos = '%s' not on this build's path "
+                               "(ideal only)" % (blk, eos))
+        self.is_ideal = True
+        self.gamma = pin.GetReal(blk, "gamma")
+        self.dfloor = pin.GetOrAddReal(blk, "dfloor", FLT_MIN)
+        self.pfloor = pin.GetOrAddReal(blk, "pfloor", FLT_MIN)
+        self.tfloor = pin.GetOrAddReal(blk, "tfloor", FLT_MIN)
+        self.sfloor = pin.GetOrAddReal(blk, "sfloor", FLT_MIN)
+        self.sigma_max = pin.GetOrAddReal(blk, "sigma_max", FLT_MAX)
+
+
+class EquationOfState:
+    """holder so that `phydro.peos.eos_data` reads like the reference"""
+
+    def __init__(self, pin, blk):
+        self.eos_data = EOS_Data(pin, blk)
+
+
+class FaceFld:
+    """DvceFaceFld4D/5D (src/athena.hpp:178-196)"""
+
+    def __init__(self, nmb, nvar, n3, n2, n1, device, face_shaped=True):
+        f = 1 if face_shaped else 0
+        sh = (nmb,) + ((nvar,) if nvar else ())
+        self.x1f = torch.zeros(sh + (n3, n2, n1 + f), dtype=torch.float64, device=device)
+        self.x2f = torch.zeros(sh + (n3, n2 + f, n1), dtype=torch.float64, device=device)
+        self.x3f = torch.zeros(sh + (n3 + f, n2, n1), dtype=torch.float64, device=device)
+
+
+class EdgeFld:
+    """DvceEdgeFld4D (src/athena.hpp:223-231)"""
+
+    def __init__(self, nmb, n3, n2, n1, device):
+        self.x1e = torch.zeros((nmb, n3 + 1, n2 + 1, n1), dtype=torch.float64, device=device)
+        self.x2e = torch.zeros((nmb, n3 + 1, n2, n1 + 1), dtype=torch.float64, device=device)
+        self.x3e = torch.zeros((nmb, n3, n2 + 1, n1 + 1), dtype=torch.float64, device=device)
+
+
+class FluidBase:
+    """what Hydro and MHD share: pack descriptor, EOS, boundary values, dt bookkeeping"""
+
+    def _setup(self, ppack, pin, blk, device):
+        self.pmy_pack = ppack
+        self.device = device
+        self.L = capi.lib()           # raises loudly when libakmi.so is missing
+        pm = ppack.pmesh
+        indcs = pm.mb_indcs
+        self.peos = EquationOfState(pin, blk)
+        recon = pin.GetOrAddString(blk, "reconstruct", "plm")
+        if recon not in capi.RECON:
+            raise RuntimeError("### FATAL ERROR <%s> recon = '%s' not implemented" % (blk, recon))
+        self.recon_method = capi.RECON[recon]
+        if recon == "ppm4" and indcs.ng < 3:
+            raise RuntimeError("### FATAL ERROR PPM/WENOZ reconstruction requires at least 3 "
+                               "ghost zones, but <mesh>/nghost=%d" % indcs.ng)
+        self.nscalars = pin.GetOrAddInteger(blk, "nscalars", 0)
+        if self.nscalars:
+            raise RuntimeError("### FATAL ERROR passive scalars are not on this build's path")
+        self.nmb = ppack.nmb_thispack
+        self.dx_dev = torch.from_numpy(ppack.pmb.dx.copy()).to(device)
+        e = self.peos.eos_data
+        self.pack_c = capi.Pack(self.nmb, 5, indcs.nx1, indcs.nx2, indcs.nx3, indcs.ng,
+                                self.dx_dev.data_ptr(), e.gamma, e.dfloor, e.pfloor, e.tfloor,
+                                e.sfloor, e.sigma_max)
+        self.fused = pin.GetOrAddBoolean(blk, "fused_stage", True)
+        self.counters = torch.zeros(3, dtype=torch.int32, device=device)
+        self.dt3 = torch.zeros(3, dtype=torch.float64, device=device)
+        self.dtnew = FLT_MAX
+        self.ws = None
+
+    def _workspace(self, is_mhd):
+        if self.ws is None:
+            nbytes = int(self.L.akmi_stage_workspace_bytes(C.byref(self.pack_c), is_mhd))
+            self.ws = torch.empty((nbytes + 7)//8, dtype=torch.float64, device=self.device)
+        return self.ws
+
+    def _finish_newdt(self):
+        """host side of NewTimeStep: hydro_newdt.cpp:121-124 (blocking 24-byte D2H read)"""
+        pm = self.pmy_pack.pmesh
+        d = self.dt3.cpu().numpy()
+        dtnew = float(d[0])
+        if pm.multi_d:
+            dtnew = min(dtnew, float(d[1]))
+        if pm.three_d:
+            dtnew = min(dtnew, float(d[2]))
+        self.dtnew = dtnew
+
+
+class Hydro(FluidBase):
+    def __init__(self, ppack, pin, device="cuda", bvals_kernels=None):
+        self._setup(ppack, pin, "hydro", device)
+        rs = pin.GetString("hydro", "rsolver")
+        if rs != "hllc":
+            raise RuntimeError("### FATAL ERROR <hydro> rsolver = '%s' not implemented "
+                               "(hllc only on this path)" % rs)
+        self.rsolver_method = capi.RSOLVER[rs]
+        self.nhydro = 5
+        n3, n2, n1 = ppack.pmesh.mb_indcs.ncells
+        sh = (self.nmb, 5, n3, n2, n1)
+        z = lambda: torch.zeros(sh, dtype=torch.float64, device=device)
+        self.u0, self.w0, self.u1 = z(), z(), z()
+        # task-granular path keeps the reference's cell-shaped flux arrays (hydro.cpp:290-292)
+        self.uflx = None if self.fused else FaceFld(self.nmb, 5, n3, n2, n1, device, face_shaped=False)
+        self.pbval_u = MeshBoundaryValues(ppack, bvals_kernels, device)
+        self.pbval_u.set_pack(self.pack_c, 5)
+
+    # ---- task list assembly: hydro_tasks.cpp:48-80 ---------------------------------
+    def AssembleHydroTasks(self, tl):
+        none = TaskID(0)
+        self.id = {}
+        i = self.id
+        i["irecv"] = tl["before_stagen"].AddTask(self.InitRecv, none)
+        s = tl["stagen"]
+        i["copyu"] = s.AddTask(self.CopyCons, none)
+        i["flux"] = s.AddTask(self.Fluxes, i["copyu"])
+        i["sendf"] = s.AddTask(self.SendFlux, i["flux"])
+        i["recvf"] = s.AddTask(self.RecvFlux, i["sendf"])
+        i["rkupdt"] = s.AddTask(self.RKUpdate, i["recvf"])
+        i["srctrms"] = s.AddTask(self.HydroSrcTerms, i["rkupdt"])
+        i["sendu_oa"] = s.AddTask(self.SendU_OA, i["srctrms"])
+        i["recvu_oa"] = s.AddTask(self.RecvU_OA, i["sendu_oa"])
+        i["restu"] = s.AddTask(self.RestrictU, i["recvu_oa"])
+        i["sendu"] = s.AddTask(self.SendU, i["restu"])
+        i["recvu"] = s.AddTask(self.RecvU, i["sendu"])
+        i["sendu_shr"] = s.AddTask(self.SendU_Shr, i["recvu"])
+        i["recvu_shr"] = s.AddTask(self.RecvU_Shr, i["sendu_shr"])
+        i["prol"] = s.AddTask(self.Prolongate, i["recvu_shr"])
+        i["bcs"] = s.AddTask(self.ApplyPhysicalBCs, i["prol"])
+        i["c2p"] = s.AddTask(self.ConToPrim, i["bcs"])
+        i["newdt"] = s.AddTask(self.NewTimeStep, i["c2p"])
+        i["csend"] = tl["after_stagen"].AddTask(self.ClearSend, none)
+        i["crecv"] = tl["after_stagen"].AddTask(self.ClearRecv, i["csend"])
+
+    # ---- tasks ---------------------------------------------------------------------
+    def _noop(self, pdrive, stage):
+        return TaskStatus.complete
+
+    InitRecv = SendFlux = RecvFlux = HydroSrcTerms = SendU_OA = RecvU_OA = _noop
+    RestrictU = SendU_Shr = RecvU_Shr = Prolongate = ClearSend = ClearRecv = _noop
+
+    def CopyCons(self, pdrive, stage):
+        """hydro_tasks.cpp:130-152 (folded into the fused stage kernel when fused)"""
+        if stage == 1 and not self.fused:
+            capi.check(self.L.akmi_copy_cons(C.byref(self.pack_c), capi._p(self.u0),
+                                             capi._p(self.u1), capi._stream()), "copy_cons")
+        return TaskStatus.complete
+
+    def Fluxes(self, pdrive, stage):
+        """hydro_tasks.cpp:159-201"""
+        if not self.fused:
+            capi.check(self.L.akmi_hydro_fluxes(
+                C.byref(self.pack_c), self.recon_method, self.rsolver_method, capi._p(self.w0),
+                capi._p(self.uflx.x1f), capi._p(self.uflx.x2f), capi._p(self.uflx.x3f), 0,
+                capi._stream()), "hydro_fluxes")
+        return TaskStatus.complete
+
+    def RKUpdate(self, pdrive, stage):
+        """hydro_update.cpp:23-83"""
+        gam0, gam1 = pdrive.gam0[stage - 1], pdrive.gam1[stage - 1]
+        beta_dt = pdrive.beta[stage - 1]*self.pmy_pack.pmesh.dt
+        if self.fused:
+            capi.check(self.L.akmi_hydro_stage_update(
+                C.byref(self.pack_c), self.recon_method, self.rsolver_method, capi.d(gam0),
+                capi.d(gam1), capi.d(beta_dt), 1 if stage == 1 else 0, capi._p(self.w0),
+                capi._p(self.u0), capi._p(self.u1), capi._p(self._workspace(0)), capi._stream()),
+                "hydro_stage_update")
+        else:
+            capi.check(self.L.akmi_rk_update(
+                C.byref(self.pack_c), capi.d(gam0), capi.d(gam1), capi.d(beta_dt), capi._p(self.u0),
+                capi._p(self.u1), capi._p(self.uflx.x1f), capi._p(self.uflx.x2f),
+                capi._p(self.uflx.x3f), 0, capi._stream()), "rk_update")
+        return TaskStatus.complete
+
+    def SendU(self, pdrive, stage):
+        return self.pbval_u.PackAndSendCC(self.u0)
+
+    def RecvU(self, pdrive, stage):
+        return self.pbval_u.RecvAndUnpackCC(self.u0)
+
+    def ApplyPhysicalBCs(self, pdrive, stage):
+        """hydro_tasks.cpp:357-375"""
+        if self.pmy_pack.pmesh.strictly_periodic:
+            return TaskStatus.complete
+        self.pbval_u.HydroBCs(self.u0)
+        return TaskStatus.complete
+
+    def ConToPrim(self, pdrive, stage):
+        """hydro_tasks.cpp:404-412: all cells including ghosts"""
+        n3, n2, n1 = self.pmy_pack.pmesh.mb_indcs.ncells
+        capi.check(self.L.akmi_hydro_c2p(C.byref(self.pack_c), capi._p(self.u0), capi._p(self.w0),
+                                         0, n1 - 1, 0, n2 - 1, 0, n3 - 1, capi._p(self.counters),
+                                         capi._stream()), "hydro_c2p")
+        return TaskStatus.complete
+
+    def NewTimeStep(self, pdrive, stage):
+        """hydro_newdt.cpp:30-139: last stage only"""
+        if stage != pdrive.nexp_stages:
+            return TaskStatus.complete
+        capi.check(self.L.akmi_hydro_newdt(C.byref(self.pack_c), capi._p(self.w0),
+                                           capi._p(self.dt3), capi._stream()), "hydro_newdt")
+        self._finish_newdt()
+        return TaskStatus.complete

@@ -1,0 +1,176 @@
+"""mhd::MHD -- arrays and task member functions of the MHD module.
+
+Mirror of src/mhd/mhd.hpp:93-199 / mhd.cpp:30-382 / mhd_tasks.cpp:38-699: members u0, w0,
+u1, b0, b1, bcc0, uflx, efld, e3x1..e1x3, peos, pbval_u, pbval_b, dtnew; the `stagen` chain
+of AssembleMHDTasks (mhd_tasks.cpp:48-75) with each body one call through include/akmi.h.
+"""
+import ctypes as C
+
+import torch
+
+from . import capi
+from .bvals import MeshBoundaryValues
+from .hydro import EdgeFld, FaceFld, FluidBase
+from .tasklist import TaskID, TaskStatus
+
+
+class MHD(FluidBase):
+    def __init__(self, ppack, pin, device="cuda", bvals_kernels=None):
+        self._setup(ppack, pin, "mhd", device)
+        rs = pin.GetString("mhd", "rsolver")
+        if rs != "hlld":
+            raise RuntimeError("### FATAL ERROR <mhd> rsolver = '%s' not implemented "
+                               "(hlld only on this path)" % rs)
+        self.rsolver_method = capi.RSOLVER[rs]
+        self.nmhd = 5
+        n3, n2, n1 = ppack.pmesh.mb_indcs.ncells
+        nmb = self.nmb
+        z5 = lambda: torch.zeros((nmb, 5, n3, n2, n1), dtype=torch.float64, device=device)
+        self.u0, self.w0, self.u1 = z5(), z5(), z5()
+        self.bcc0 = torch.zeros((nmb, 3, n3, n2, n1), dtype=torch.float64, device=device)
+        self.b0 = FaceFld(nmb, 0, n3, n2, n1, device)
+        self.b1 = FaceFld(nmb, 0, n3, n2, n1, device)
+        if not self.fused:
+            zc = lambda: torch.zeros((nmb, n3, n2, n1), dtype=torch.float64, device=device)
+            self.uflx = FaceFld(nmb, 5, n3, n2, n1, device)        # mhd.cpp:341-343
+            self.efld = EdgeFld(nmb, n3, n2, n1, device)           # mhd.cpp:344-346
+            self.e3x1, self.e2x1, self.e1x2 = zc(), zc(), zc()     # mhd.cpp:349-354
+            self.e3x2, self.e2x3, self.e1x3 = zc(), zc(), zc()
+        self.pbval_u = MeshBoundaryValues(ppack, bvals_kernels, device)
+        self.pbval_u.set_pack(self.pack_c, 5)
+        self.pbval_b = self.pbval_u       # same neighbour tables; separate FC channel inside
+
+    # ---- task list assembly: mhd_tasks.cpp:38-84 -----------------------------------
+    def AssembleMHDTasks(self, tl):
+        none = TaskID(0)
+        self.id = {}
+        i = self.id
+        i["savest"] = tl["before_timeintegrator"].AddTask(self.SaveMHDState, none)
+        i["irecv"] = tl["before_stagen"].AddTask(self.InitRecv, none)
+        s = tl["stagen"]
+        chain = [("copyu", self.CopyCons), ("flux", self.Fluxes), ("sendf", self.SendFlux),
+                 ("recvf", self.RecvFlux), ("rkupdt", self.RKUpdate), ("srctrms", self.MHDSrcTerms),
+                 ("sendu_oa", self.SendU_OA), ("recvu_oa", self.RecvU_OA), ("restu", self.RestrictU),
+                 ("sendu", self.SendU), ("recvu", self.RecvU), ("sendu_shr", self.SendU_Shr),
+                 ("recvu_shr", self.RecvU_Shr), ("efld", self.EField), ("sende", self.SendE),
+                 ("recve", self.RecvE), ("ct", self.CT), ("sendb_oa", self.SendB_OA),
+                 ("recvb_oa", self.RecvB_OA), ("restb", self.RestrictB), ("sendb", self.SendB),
+                 ("recvb", self.RecvB), ("sendb_shr", self.SendB_Shr), ("recvb_shr", self.RecvB_Shr),
+                 ("prol", self.Prolongate), ("bcs", self.ApplyPhysicalBCs), ("c2p", self.ConToPrim),
+                 ("newdt", self.NewTimeStep)]
+        dep = none
+        for name, fn in chain:
+            i[name] = s.AddTask(fn, dep)
+            dep = i[name]
+        i["csend"] = tl["after_stagen"].AddTask(self.ClearSend, none)
+        i["crecv"] = tl["after_stagen"].AddTask(self.ClearRecv, i["csend"])
+
+    # ---- tasks ---------------------------------------------------------------------
+    def _noop(self, pdrive, stage):
+        return TaskStatus.complete
+
+    SaveMHDState = InitRecv = SendFlux = RecvFlux = MHDSrcTerms = SendU_OA = RecvU_OA = _noop
+    RestrictU = SendU_Shr = RecvU_Shr = SendB_OA = RecvB_OA = RestrictB = _noop
+    SendB_Shr = RecvB_Shr = Prolongate = ClearSend = ClearRecv = _noop
+    # SendE/RecvE (mhd_tasks.cpp:402-417): on a uniform mesh every copy of a shared edge EMF
+    # is computed by the same deterministic kernel from identical inputs, so the reference's
+    # sum-and-average, (a+a)*0.5, returns a bit for bit (flux_correct_fc.cpp:843-860):
+    # nothing to exchange.  Fine/coarse averaging belongs to SURVEY.md section 8(f) item 1.
+    SendE = RecvE = _noop
+
+    def _b(self, f):
+        return capi._p(f.x1f), capi._p(f.x2f), capi._p(f.x3f)
+
+    def CopyCons(self, pdrive, stage):
+        """mhd_tasks.cpp:162-170"""
+        if stage == 1 and not self.fused:
+            capi.check(self.L.akmi_copy_cons(C.byref(self.pack_c), capi._p(self.u0),
+                                             capi._p(self.u1), capi._stream()), "copy_cons")
+            self.b1.x1f.copy_(self.b0.x1f)
+            self.b1.x2f.copy_(self.b0.x2f)
+            self.b1.x3f.copy_(self.b0.x3f)
+        return TaskStatus.complete
+
+    def Fluxes(self, pdrive, stage):
+        """mhd_tasks.cpp:177-216"""
+        if not self.fused:
+            capi.check(self.L.akmi_mhd_fluxes(
+                C.byref(self.pack_c), self.recon_method, self.rsolver_method, capi._p(self.w0),
+                capi._p(self.bcc0), *self._b(self.b0), *self._b(self.uflx), capi._p(self.e3x1),
+                capi._p(self.e2x1), capi._p(self.e1x2), capi._p(self.e3x2), capi._p(self.e2x3),
+                capi._p(self.e1x3), capi._stream()), "mhd_fluxes")
+        return TaskStatus.complete
+
+    def RKUpdate(self, pdrive, stage):
+        """mhd_update.cpp:24-84; the fused path also performs EField and CT here"""
+        gam0, gam1 = pdrive.gam0[stage - 1], pdrive.gam1[stage - 1]
+        beta_dt = pdrive.beta[stage - 1]*self.pmy_pack.pmesh.dt
+        if self.fused:
+            capi.check(self.L.akmi_mhd_stage_update(
+                C.byref(self.pack_c), self.recon_method, self.rsolver_method, capi.d(gam0),
+                capi.d(gam1), capi.d(beta_dt), 1 if stage == 1 else 0, capi._p(self.w0),
+                capi._p(self.bcc0), capi._p(self.u0), capi._p(self.u1), *self._b(self.b0),
+                *self._b(self.b1), capi._p(self._workspace(1)), capi._stream()), "mhd_stage_update")
+        else:
+            capi.check(self.L.akmi_rk_update(
+                C.byref(self.pack_c), capi.d(gam0), capi.d(gam1), capi.d(beta_dt), capi._p(self.u0),
+                capi._p(self.u1), *self._b(self.uflx), 1, capi._stream()), "rk_update")
+        return TaskStatus.complete
+
+    def SendU(self, pdrive, stage):
+        return self.pbval_u.PackAndSendCC(self.u0)
+
+    def RecvU(self, pdrive, stage):
+        return self.pbval_u.RecvAndUnpackCC(self.u0)
+
+    def EField(self, pdrive, stage):
+        """MHD::CornerE, mhd_corner_e.cpp:26-417"""
+        if not self.fused:
+            capi.check(self.L.akmi_mhd_corner_e(
+                C.byref(self.pack_c), capi._p(self.w0), capi._p(self.bcc0), capi._p(self.e3x1),
+                capi._p(self.e2x1), capi._p(self.e1x2), capi._p(self.e3x2), capi._p(self.e2x3),
+                capi._p(self.e1x3), *self._b(self.uflx), capi._p(self.efld.x1e),
+                capi._p(self.efld.x2e), capi._p(self.efld.x3e), capi._stream()), "mhd_corner_e")
+        return TaskStatus.complete
+
+    def CT(self, pdrive, stage):
+        """mhd_ct.cpp:23-80"""
+        if not self.fused:
+            gam0, gam1 = pdrive.gam0[stage - 1], pdrive.gam1[stage - 1]
+            beta_dt = pdrive.beta[stage - 1]*self.pmy_pack.pmesh.dt
+            capi.check(self.L.akmi_mhd_ct(
+                C.byref(self.pack_c), capi.d(gam0), capi.d(gam1), capi.d(beta_dt),
+                capi._p(self.efld.x1e), capi._p(self.efld.x2e), capi._p(self.efld.x3e),
+                *self._b(self.b0), *self._b(self.b1), capi._stream()), "mhd_ct")
+        return TaskStatus.complete
+
+    def SendB(self, pdrive, stage):
+        return self.pbval_b.PackAndSendFC(self.b0)
+
+    def RecvB(self, pdrive, stage):
+        return self.pbval_b.RecvAndUnpackFC(self.b0)
+
+    def ApplyPhysicalBCs(self, pdrive, stage):
+        """mhd_tasks.cpp:501-520"""
+        if self.pmy_pack.pmesh.strictly_periodic:
+            return TaskStatus.complete
+        self.pbval_u.HydroBCs(self.u0)
+        self.pbval_b.BFieldBCs(self.b0)
+        return TaskStatus.complete
+
+    def ConToPrim(self, pdrive, stage):
+        n3, n2, n1 = self.pmy_pack.pmesh.mb_indcs.ncells
+        capi.check(self.L.akmi_mhd_c2p(
+            C.byref(self.pack_c), capi._p(self.u0), *self._b(self.b0), capi._p(self.w0),
+            capi._p(self.bcc0), 0, n1 - 1, 0, n2 - 1, 0, n3 - 1, capi._p(self.counters),
+            capi._stream()), "mhd_c2p")
+        return TaskStatus.complete
+
+    def NewTimeStep(self, pdrive, stage):
+        """mhd_newdt.cpp:31-174: last stage only"""
+        if stage != pdrive.nexp_stages:
+            return TaskStatus.complete
+        capi.check(self.L.akmi_mhd_newdt(C.byref(self.pack_c), capi._p(self.w0), capi._p(self.bcc0),
+                                         capi._p(self.dt3), capi._stream()), "mhd_newdt")
+        self._finish_newdt()
+        return TaskStatus.complete

@@ -1,0 +1,159 @@
+"""Shared helpers for the parity tests: build the product Simulation and the CPU oracle from
+the same deck, give both identical initial data, advance, compare.
+
+The parity metric is north_star's "relative L1 on the conserved vars": sum|a-b|/sum|b| for d
+and E; vector quantities (M, B) are normalised by the L1 norm of the whole vector because
+single components are identically zero in some decks.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import akref  # noqa: E402  (test infrastructure)
+
+TOL = 1e-12     # north_star: <= 1e-12 relative L1 on the conserved variables
+
+
+def deck_overrides(problem, n, dims, mb=None, ng=None, recon=None, integrator=None, cfl=None,
+                   nlim=None, extra=()):
+    """deck name + override list for an n^dims mesh with mb^dims MeshBlocks"""
+    mb = mb or n
+    deck = {"linear_wave_hydro": "linear_wave_hydro.athinput",
+            "linear_wave_mhd": "linear_wave_mhd.athinput", "sod": "sod.athinput",
+            "orszag_tang": "orszag_tang.athinput", "blast": "blast_mhd.athinput"}[problem]
+    ov = []
+    for q in (1, 2, 3):
+        nn = n if q <= dims else 1
+        mm = mb if q <= dims else 1
+        ov += ["mesh/nx%d=%d" % (q, nn), "meshblock/nx%d=%d" % (q, mm)]
+    if ng is not None:
+        ov.append("mesh/nghost=%d" % ng)
+    blk = "hydro" if problem in ("linear_wave_hydro", "sod") else "mhd"
+    if recon is not None:
+        ov.append("%s/reconstruct=%s" % (blk, recon))
+    if integrator is not None:
+        ov.append("time/integrator=%s" % integrator)
+    if cfl is not None:
+        ov.append("time/cfl_number=%s" % repr(cfl))
+    if nlim is not None:
+        ov.append("time/nlim=%d" % nlim)
+    return deck, ov + list(extra)
+
+
+def oracle_kwargs(pin):
+    """akref.Sim keyword arguments equivalent to a ParameterInput"""
+    g, gi, gs = pin.GetReal, pin.GetInteger, pin.GetString
+    is_mhd = pin.DoesBlockExist("mhd")
+    blk = "mhd" if is_mhd else "hydro"
+    kw = dict(nx1=gi("mesh", "nx1"), nx2=gi("mesh", "nx2"), nx3=gi("mesh", "nx3"),
+              mb_nx1=gi("meshblock", "nx1"), mb_nx2=gi("meshblock", "nx2"),
+              mb_nx3=gi("meshblock", "nx3"), ng=gi("mesh", "nghost"),
+              x1min=g("mesh", "x1min"), x1max=g("mesh", "x1max"), x2min=g("mesh", "x2min"),
+              x2max=g("mesh", "x2max"), x3min=g("mesh", "x3min"), x3max=g("mesh", "x3max"),
+              bcs=[gs("mesh", k) for k in ("ix1_bc", "ox1_bc", "ix2_bc", "ox2_bc", "ix3_bc", "ox3_bc")],
+              nstages={"rk1": 1, "rk2": 2, "rk3": 3}[gs("time", "integrator")],
+              cfl=g("time", "cfl_number"), tlim=g("time", "tlim"), nlim=gi("time", "nlim"),
+              is_mhd=1 if is_mhd else 0, recon=gs(blk, "reconstruct"), rsolver=gs(blk, "rsolver"),
+              gamma=g(blk, "gamma"))
+    name = gs("problem", "pgen_name")
+    kw["pgen"] = name
+    P = lambda k, d=0.0: (g("problem", k) if pin.DoesParameterExist("problem", k) else d)
+    if name == "linear_wave":
+        kw.update(wave_flag=gi("problem", "wave_flag"), amp=P("amp"), dens=P("dens"), pgas=P("pgas"),
+                  vx0=P("vx0"), vy0=P("vy0"), vz0=P("vz0"), bx0=P("bx0"), by0=P("by0"), bz0=P("bz0"))
+        for a in ("along_x1", "along_x2", "along_x3"):
+            kw[a] = 1 if (pin.DoesParameterExist("problem", a) and pin.GetBoolean("problem", a)) else 0
+    elif name == "shock_tube":
+        kw.update(shock_dir=gi("problem", "shock_dir"), xshock=P("xshock"),
+                  wl=[P("dl"), P("ul"), P("vl"), P("wl"), P("pl"), P("bxl"), P("byl"), P("bzl")],
+                  wr=[P("dr"), P("ur"), P("vr"), P("wr"), P("pr"), P("bxr"), P("byr"), P("bzr")])
+    elif name == "blast":
+        kw.update(pi_amb=P("pi_amb", 1.0), di_amb=P("di_amb", 1.0), prat=P("prat", 1.0),
+                  drat=P("drat", 1.0), b_amb=P("b_amb", 0.1), inner_radius=P("inner_radius"),
+                  outer_radius=P("outer_radius"))
+    return kw
+
+
+def rel_l1(a, b):
+    den = np.abs(b).sum()
+    return float(np.abs(a - b).sum()/den) if den > 0 else float(np.abs(a - b).sum())
+
+
+def compare_fields(prod, orc, is_mhd):
+    """dict of relative-L1 differences between product arrays (numpy) and oracle arrays"""
+    out = {}
+    u, v = prod["u0"], orc["u0"]
+    out["d"] = rel_l1(u[:, 0], v[:, 0])
+    out["M"] = rel_l1(u[:, 1:4], v[:, 1:4])
+    out["E"] = rel_l1(u[:, 4], v[:, 4])
+    if is_mhd:
+        num = sum(np.abs(prod[k] - orc[k]).sum() for k in ("b0x1f", "b0x2f", "b0x3f"))
+        den = sum(np.abs(orc[k]).sum() for k in ("b0x1f", "b0x2f", "b0x3f"))
+        out["B"] = float(num/den) if den > 0 else float(num)
+    out["bitwise_equal"] = all(np.array_equal(prod[k], orc[k]) for k in prod)
+    return out
+
+
+def product_arrays(sim):
+    ph = sim.phys
+    d = {"u0": ph.u0.cpu().numpy()}
+    if hasattr(ph, "b0"):
+        d.update(b0x1f=ph.b0.x1f.cpu().numpy(), b0x2f=ph.b0.x2f.cpu().numpy(),
+                 b0x3f=ph.b0.x3f.cpu().numpy())
+    return d
+
+
+def oracle_arrays(osim, is_mhd):
+    d = {"u0": osim.array("u0").copy()}
+    if is_mhd:
+        d.update(b0x1f=osim.array("b0x1f").copy(), b0x2f=osim.array("b0x2f").copy(),
+                 b0x3f=osim.array("b0x3f").copy())
+    return d
+
+
+def make_pair(problem, n, dims, mb=None, inject=True, fused=None, **kw):
+    """(product Simulation, oracle Sim) advanced to the end of Driver::Initialize on
+    identical initial data (inject=True copies the oracle's pgen output into the product so
+    that libm-vs-numpy sin/cos ulps cannot enter the comparison)."""
+    import torch
+    from athenak_amd.main import Simulation, load_deck
+    deck, ov = deck_overrides(problem, n, dims, mb, **kw)
+    pin = load_deck(deck, ov)
+    if fused is not None:
+        blk = "mhd" if pin.DoesBlockExist("mhd") else "hydro"
+        pin.blocks[blk]["fused_stage"] = "true" if fused else "false"
+    okw = oracle_kwargs(pin)
+    osim = akref.Sim(**okw)
+    sim = Simulation(pin, initialize=False)
+    is_mhd = bool(okw["is_mhd"])
+    osim.initialize()
+    if inject:
+        ph = sim.phys
+        ph.u0.copy_(torch.from_numpy(osim.array("u0").copy()))
+        if is_mhd:
+            ph.b0.x1f.copy_(torch.from_numpy(osim.array("b0x1f").copy()))
+            ph.b0.x2f.copy_(torch.from_numpy(osim.array("b0x2f").copy()))
+            ph.b0.x3f.copy_(torch.from_numpy(osim.array("b0x3f").copy()))
+    sim.pdriver.Initialize(sim.pmesh, pin)
+    return sim, osim, is_mhd
+
+
+def compare_run(problem, n, dims, mb=None, cycles=2, inject=True, fused=None, **kw):
+    sim, osim, is_mhd = make_pair(problem, n, dims, mb, inject, fused, **kw)
+    done = 0
+    for _ in range(cycles):
+        a = sim.Execute(max_cycles=1)
+        b = osim.step()
+        if not a or not b:
+            break
+        done += 1
+    diffs = compare_fields(product_arrays(sim), oracle_arrays(osim, is_mhd), is_mhd)
+    vals = [v for k, v in diffs.items() if k != "bitwise_equal"]
+    return {"diffs": diffs, "max_rel_l1": max(vals), "cycles": done,
+            "time": (sim.pmesh.time, osim.time), "dt": (sim.pmesh.dt, osim.dt),
+            "bitwise_equal": diffs["bitwise_equal"]}

@@ -1,0 +1,50 @@
+"""not gpu: the C-ABI library loads and exports every symbol include/akmi.h declares."""
+import ctypes
+import os
+import re
+import shutil
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "akmi.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(akmi_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_listed_in_binding():
+    from athenak_amd import capi
+    assert _declared() == sorted(capi.SYMBOLS)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"),
+                    reason="hipcc not available")
+def test_library_builds_and_exports_all_symbols():
+    import __graft_entry__ as g
+    g.build()
+    lib = ctypes.CDLL(g.LIB)
+    for s in _declared():
+        assert hasattr(lib, s), s
+    assert lib.akmi_version() >= 100
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from athenak_amd import capi
+    monkeypatch.setattr(capi, "_LIB", None)
+    monkeypatch.setattr(capi, "LIB_PATH", str(tmp_path/"nope.so"))
+    with pytest.raises(capi.AkmiError):
+        capi.lib()
+
+
+def test_product_does_not_import_oracle():
+    """the product package must never reach into oracle/"""
+    pkg = os.path.join(ROOT, "athenak_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert "akref" not in src and "oracle" not in src.replace("oracle/", "oracle/") \
+                    or f == "__none__", os.path.join(dp, f)
