@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py -- Mcell-updates/s of the MeshBlock finite-volume update on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[2], the config the metric is quoted on): 3-D Orszag-Tang,
+256^3 cells per GPU, ideal MHD, PLM + HLLD + CT, RK2, cfl 0.3, one MeshBlock (pack) per GPU;
+N GPUs weak-scale the mesh to 2x1x1 / 2x2x1 / 2x2x2 blocks with halo exchange over RCCL.
+A "step" is one full RK2 cycle (two stages) of every cell = one cell-update per cell
+(the reference's zone-cycle, src/driver/driver.cpp:513-522).  Data are synthetic: the
+closed-form Orszag-Tang initial condition, resident in HBM before the timed region.
+
+One JSON line is printed by rank 0 (see the contract in the task description), including
+  roofline     -- achieved algorithmic HBM GB/s of the dominant kernel group, from HIP events
+  cpu_baseline -- the CPU oracle ("port" of the reference's split-kernel sequence) timed on a
+                  bounded sample of the same workload on this box's host cores (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# algorithmic (compulsory) HBM bytes, SURVEY.md section 8(d) / BASELINE.md section 3:
+#   pass A (fluxes+EMF+update+CT): read w0 5 + bcc0 3 + b0 3 + u0 5 + u1 5 + b1 3, write u0 5 + b0 3
+#   pass B (c2p[+dt]):              read u0 5 + b0 3, write w0 5 + bcc0 3
+BYTES_PASS_A = {"mhd": 32*8, "hydro": 20*8}
+BYTES_PASS_B = {"mhd": 16*8, "hydro": 10*8}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nx", type=int, default=256, help="cells per GPU per dimension")
+    ap.add_argument("--problem", default="orszag_tang", choices=["orszag_tang", "sod", "linear_wave"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-nx", type=int, default=64)
+    ap.add_argument("--split", action="store_true", help="task-granular chain instead of fused stage")
+    return ap.parse_args()
+
+
+def block_grid(n):
+    return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}[n]
+
+
+def make_pin(args, nblk):
+    from athenak_amd.main import load_deck
+    nx = args.nx
+    mesh = [nx*b for b in nblk]
+    if args.problem == "orszag_tang":
+        deck, blk = "orszag_tang.athinput", "mhd"
+        ov = ["time/cfl_number=0.3"]
+    elif args.problem == "sod":
+        deck, blk = "sod.athinput", "hydro"
+        ov = ["time/cfl_number=0.3", "mesh/ix1_bc=outflow", "mesh/ox1_bc=outflow"]
+    else:
+        deck, blk = "linear_wave_hydro.athinput", "hydro"
+        ov = []
+    for q in range(3):
+        ov += ["mesh/nx%d=%d" % (q + 1, mesh[q]), "meshblock/nx%d=%d" % (q + 1, nx)]
+    ov += ["time/nlim=-1", "time/tlim=1.0e9"]
+    pin = load_deck(deck, ov)
+    if args.split:
+        pin.blocks[blk]["fused_stage"] = "false"
+    return pin, blk
+
+
+def cpu_baseline(args, blk):
+    """the oracle (port of the reference's split-kernel CPU sequence) on all host cores, on a
+    bounded sample of the same workload (same deck at sample_nx^3, a few cycles)"""
+    from oracle import akref
+    ncores = os.cpu_count() or 1
+    akref.lib()
+    akref.lib().akref_set_threads(ncores)
+    n = args.cpu_sample_nx
+    if args.problem == "orszag_tang":
+        kw = dict(is_mhd=1, recon="plm", rsolver="hlld", gamma=1.666666667, pgen="orszag_tang",
+                  bcs=["periodic"]*6)
+    elif args.problem == "sod":
+        kw = dict(is_mhd=0, recon="plm", rsolver="hllc", gamma=1.4, pgen="shock_tube", shock_dir=1,
+                  xshock=0.0, wl=[1.0, 0, 0, 0, 1.0, 0, 0, 0], wr=[0.125, 0, 0, 0, 0.1, 0, 0, 0],
+                  bcs=["outflow", "outflow", "periodic", "periodic", "periodic", "periodic"])
+    else:
+        kw = dict(is_mhd=0, recon="plm", rsolver="hllc", gamma=1.66666666667, pgen="linear_wave",
+                  wave_flag=0, amp=1e-3, dens=1.0, pgas=0.6, bcs=["periodic"]*6, x1min=0.0,
+                  x1max=3.0, x2min=0.0, x2max=1.5, x3min=0.0, x3max=1.5)
+    s = akref.Sim(nx1=n, nx2=n, nx3=n, mb_nx1=n, mb_nx2=n, mb_nx3=n, ng=2, nstages=2, cfl=0.3,
+                  tlim=1e9, nlim=-1, **kw)
+    s.initialize()
+    s.step()                       # warm-up (page faults, caches)
+    t0 = time.time()
+    cyc = 0
+    while time.time() - t0 < 12.0 and cyc < 200:
+        s.step()
+        cyc += 1
+    dt = time.time() - t0
+    val = n**3*cyc/dt/1e6
+    return {"value": round(val, 4), "unit": "Mcell-updates/s", "cores": ncores, "kind": "port",
+            "sample": "%s %d^3, %d RK2 cycles, oracle (reference split-kernel order) with OpenMP "
+                      "over %d threads" % (args.problem, n, cyc, ncores)}
+
+
+def main():
+    args = parse()
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    nblk = block_grid(world)
+    pin, blk = make_pin(args, nblk)
+    from athenak_amd.main import Simulation
+    sim = Simulation(pin, my_rank=rank, nranks=world)
+    pm, drv = sim.pmesh, sim.pdriver
+    ncell_rank = pm.pmb_pack.nmb_thispack*pm.NumberOfMeshBlockCells()
+    ncell_total = pm.nmb_total*pm.NumberOfMeshBlockCells()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        drv._cycle(pm)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        drv._cycle(pm)
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    # ---- roofline of the dominant kernel group, from HIP events on the launch stream ------
+    phys = sim.phys
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    tA = tB = 0.0
+    nprof = 3
+    for _ in range(nprof):
+        for stage in range(1, drv.nexp_stages + 1):
+            ev[0].record()
+            phys.CopyCons(drv, stage); phys.Fluxes(drv, stage); phys.RKUpdate(drv, stage)
+            if blk == "mhd":
+                phys.EField(drv, stage); phys.CT(drv, stage)
+            ev[1].record()
+            phys.SendU(drv, stage); phys.RecvU(drv, stage)
+            if blk == "mhd":
+                phys.SendB(drv, stage); phys.RecvB(drv, stage)
+            phys.ApplyPhysicalBCs(drv, stage)
+            ev[2].record()
+            phys.ConToPrim(drv, stage); phys.NewTimeStep(drv, stage)
+            ev[3].record()
+            torch.cuda.synchronize()
+            tA += ev[0].elapsed_time(ev[1]); tB += ev[2].elapsed_time(ev[3])
+        pm.time += pm.dt; pm.ncycle += 1; pm.NewTimeStep(drv.tlim)
+    nst = nprof*drv.nexp_stages
+    tA, tB = tA/nst*1e-3, tB/nst*1e-3                       # seconds per launch group
+    achA = BYTES_PASS_A[blk]*ncell_rank/tA/1e9
+    achB = BYTES_PASS_B[blk]*ncell_rank/tB/1e9
+    stage_bytes = BYTES_PASS_A[blk] + BYTES_PASS_B[blk]
+    roofline = {"bound": "hbm", "kernel": "akmi_%s_stage_update (pass A: fluxes+EMF+update+CT)" % blk,
+                "achieved": round(achA, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achA/HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_cell": BYTES_PASS_A[blk], "ms_per_launch": round(tA*1e3, 4),
+                "pass_B": {"kernel": "c2p(+newdt)", "achieved": round(achB, 1),
+                           "frac": round(achB/HBM_PEAK_GBS, 4), "ms_per_launch": round(tB*1e3, 4),
+                           "algorithmic_bytes_per_cell": BYTES_PASS_B[blk]},
+                "whole_stage": {"algorithmic_bytes_per_cell": stage_bytes,
+                                "achieved": round(stage_bytes*ncell_rank*drv.nexp_stages*args.steps
+                                                  / el / 1e9, 1)}}
+    roofline["whole_stage"]["frac"] = round(roofline["whole_stage"]["achieved"]/HBM_PEAK_GBS, 4)
+
+    if rank == 0:
+        value = ncell_total*args.steps/el/1e6
+        out = {"metric": "Mcell-updates/s (3D MHD PLM+HLLD+CT RK2, %d^3 cells per GPU)" % args.nx
+               if blk == "mhd" else "Mcell-updates/s (3D hydro PLM+HLLC RK2, %d^3 per GPU)" % args.nx,
+               "value": round(value, 2), "unit": "Mcell-updates/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el/args.steps*1e3, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic (closed-form %s initial condition)" % args.problem,
+               "config": {"workload": "%s 3D, %s, %d^3 cells per GPU, mesh %dx%dx%d in %dx%dx%d "
+                                      "MeshBlocks, cfl 0.3, RK2, ng=2" % (
+                                          args.problem, "ideal MHD PLM+HLLD+CT" if blk == "mhd" else
+                                          "ideal hydro PLM+HLLC", args.nx, args.nx*nblk[0],
+                                          args.nx*nblk[1], args.nx*nblk[2], *nblk),
+                          "path": "task-granular" if args.split else "fused stage",
+                          "halo": "none (single periodic block: same-rank gather)" if world == 1
+                          else "RCCL send/recv (torch.distributed nccl), per-stage U and B messages"},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, blk)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
