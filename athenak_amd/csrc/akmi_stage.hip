@@ -1,14 +1,32 @@
 // akmi_stage.hip -- per-stage fast path of a MeshBlockPack (C ABI: akmi_*_stage_update,
 // akmi_*_c2p_newdt).  Results are bit-identical to the task chain of akmi_tasks.hip.
+//
+// Pass A  (akmi_*_stage_update): flux sweeps with everything memory-bound folded into the
+//   VALU-bound Riemann kernels:
+//     sweep x1 .. x(D-1): reconstruct + Riemann, write face fluxes (+ face EMFs); the x1 sweep
+//                         also emits the cell-centred E = -(v x B) that CornerE needs
+//     sweep xD (last)   : reconstruct + Riemann, exchange the normal flux of a tile through
+//                         LDS and apply the RK update  u0 = gam0*u0 + gam1*u1 - beta_dt*divF
+//                         in the same kernel (stage 1 also stores u1 <- u0: CopyCons folded)
+//     corner E          : GS05/07 upwind corner EMFs (select-based, no divergent loads)
+//     CT                : face-B update (stage 1 also stores b1 <- b0)
+// Pass B  (akmi_*_c2p_newdt): ConsToPrim over all cells + (last stage) CFL scan in ONE
+//   kernel: the three direction maxima of |v|+c_f are reduced per wavefront (DPP shuffles),
+//   per workgroup (LDS) and the workgroup's dx/max enters a 64-bit atomicMin.  Division is
+//   monotone, so min_cells fl(dx/a) == fl(dx/max_cells a): identical to the reference scan.
 #include "akmi_common.hpp"
 
 using namespace akmi;
 
 namespace akmi {
 
+constexpr int SX = 64, SY = 4;     // plain flux kernels: one wave per row, 4 rows
+constexpr int TX = 64;             // 1-D tile width
+
 struct StageWs {
   double *flx1, *flx2, *flx3;
   double *efc[6];
+  double *ecc[3];
   double *e1, *e2, *e3;
   size_t total;
 };
@@ -23,16 +41,522 @@ static StageWs carve(const Geo &g, int is_mhd, void *ws) {
   auto take = [&](size_t n) { double *r = p ? p + off : nullptr; off += (n + 31) & ~(size_t)31; return r; };
   w.flx1 = take(n1); w.flx2 = take(n2); w.flx3 = take(n3);
   for (int q = 0; q < 6; ++q) w.efc[q] = nullptr;
+  for (int q = 0; q < 3; ++q) w.ecc[q] = nullptr;
   w.e1 = w.e2 = w.e3 = nullptr;
   if (is_mhd) {
     size_t nc = nmb*g.N3*g.N2*g.N1;
     for (int q = 0; q < 6; ++q) w.efc[q] = take(nc);
+    for (int q = 0; q < 3; ++q) w.ecc[q] = take(nc);
     w.e1 = take(nmb*(g.N3 + 1)*(g.N2 + 1)*g.N1);
     w.e2 = take(nmb*(g.N3 + 1)*g.N2*(g.N1 + 1));
     w.e3 = take(nmb*g.N3*(g.N2 + 1)*(g.N1 + 1));
   }
   w.total = off*sizeof(double);
   return w;
+}
+
+// ---------------------------------------------------------------------------------------
+// face flux from the cell stencil (registers only).  Returns flux in sweep-aligned order.
+template <int DIR, int RECON, bool MHD>
+__device__ __forceinline__ void face_flux(const Geo &g, double gamma,
+    const double *__restrict__ w0, const double *__restrict__ bcc0,
+    const double *__restrict__ bxf, int f3, int f2, int f1, int m, int k, int j, int i,
+    double &fd, double &fx, double &fy, double &fz, double &fe, double &fby, double &fbz) {
+  constexpr int ivx = 1 + DIR, ivy = 1 + (DIR + 1)%3, ivz = 1 + (DIR + 2)%3;
+  const long s = (DIR == 0) ? 1 : (DIR == 1 ? (long)g.N1 : (long)g.N1*g.N2);
+  const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  const double *q = w0 + ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
+  double ld, lx, ly, lz, le, rd, rx, ry, rz, re;
+  face_states<RECON>(q + 0*cs, s, ld, rd);
+  face_states<RECON>(q + ivx*cs, s, lx, rx);
+  face_states<RECON>(q + ivy*cs, s, ly, ry);
+  face_states<RECON>(q + ivz*cs, s, lz, rz);
+  face_states<RECON>(q + 4*cs, s, le, re);
+  if constexpr (MHD) {
+    constexpr int iby = (DIR + 1)%3, ibz = (DIR + 2)%3;
+    const double *b = bcc0 + ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i);
+    double lby, lbz, rby, rbz;
+    face_states<RECON>(b + iby*cs, s, lby, rby);
+    face_states<RECON>(b + ibz*cs, s, lbz, rbz);
+    const double bxi = bxf[ix4(f3, f2, f1, m, k, j, i)];
+    Cons1D fl = hlld(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
+    fd = fl.d; fx = fl.mx; fy = fl.my; fz = fl.mz; fe = fl.e; fby = fl.by; fbz = fl.bz;
+  } else {
+    hllc(gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, fd, fx, fy, fz, fe);
+    fby = fbz = 0.0;
+  }
+}
+
+struct SweepArgs {
+  const double *w0, *bcc0, *bxf;
+  double *flx, *ey, *ez;          // this direction's flux (face-shaped) and face EMFs
+  double *ecc1, *ecc2, *ecc3;     // cell-centred EMFs (x1 sweep only)
+  int il, iu, jl, ju, kl, ku;     // face ranges of this sweep
+  int f3, f2, f1;
+};
+
+// plain sweep (not the last direction): thread per face.  ECC: also emit e_cc for the right
+// cell of every face and for the extra column i = il-1 (mhd_corner_e.cpp:309-317 range
+// [is-1,ie+1] x [js-1,je+1] x [ks-1,ke+1] == the CT-extended x1 sweep, right cells).
+template <int DIR, int RECON, bool MHD, bool ECC>
+__global__ void __launch_bounds__(SX*SY)
+k_sweep(Geo g, double gamma, SweepArgs a, int nk) {
+  const int i = a.il - (ECC ? 1 : 0) + blockIdx.x*SX + threadIdx.x;
+  const int j = a.jl + blockIdx.y*SY + threadIdx.y;
+  const int m = blockIdx.z/nk;
+  const int k = a.kl + (blockIdx.z - m*nk);
+  if (i > a.iu || j > a.ju) return;
+  const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  if constexpr (ECC) {
+    const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
+    const size_t b = ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i);
+    const double vx = a.w0[c + cs], vy = a.w0[c + 2*cs], vz = a.w0[c + 3*cs];
+    const double bx = a.bcc0[b], by = a.bcc0[b + cs], bz = a.bcc0[b + 2*cs];
+    const size_t e = ix4(g.N3, g.N2, g.N1, m, k, j, i);
+    a.ecc1[e] = vz*by - vy*bz;
+    a.ecc2[e] = vx*bz - vz*bx;
+    a.ecc3[e] = vy*bx - vx*by;
+    if (i < a.il) return;
+  }
+  constexpr int ivx = 1 + DIR, ivy = 1 + (DIR + 1)%3, ivz = 1 + (DIR + 2)%3;
+  double fd, fx, fy, fz, fe, fby, fbz;
+  face_flux<DIR, RECON, MHD>(g, gamma, a.w0, a.bcc0, a.bxf, a.f3, a.f2, a.f1, m, k, j, i, fd, fx,
+                             fy, fz, fe, fby, fbz);
+  const size_t fs = (size_t)a.f3*a.f2*a.f1;
+  double *f = a.flx + ix5(g.nvar, a.f3, a.f2, a.f1, m, 0, k, j, i);
+  f[0] = fd; f[ivx*fs] = fx; f[ivy*fs] = fy; f[ivz*fs] = fz; f[4*fs] = fe;
+  if constexpr (MHD) {
+    const size_t ec = ix4(g.N3, g.N2, g.N1, m, k, j, i);
+    a.ey[ec] = -fby;
+    a.ez[ec] = fbz;
+  }
+}
+
+struct UpdArgs {
+  double gam0, gam1, beta_dt;
+  double *u0, *u1;
+  const double *flx1, *flx2;      // fluxes of the earlier sweeps (face-shaped)
+  int copy_u1;
+};
+
+// last-direction sweep with the RK update fused, as a MARCH along the sweep direction:
+// each thread owns one transverse position (lanes run over the contiguous index, so every
+// load/store of a wave is a coalesced row segment), walks ML faces along the sweep, keeps the
+// previous face flux in registers and finishes cell (t-1) as soon as face t is known:
+//   divf = dF1/dx1; divf += dF2/dx2; divf += dF3/dx3; u0 = gam0*u0 + gam1*u1 - beta_dt*divf
+// (hydro_update.cpp:55-80 order).  No LDS, no barrier: waves run free, so the memory-bound
+// update of one wave hides under the Riemann arithmetic of the others.  One face per chunk
+// (1/ML) is computed twice.
+constexpr int ML = 32;            // faces marched per thread (chunk length)
+
+template <int DIR, int RECON, bool MHD>
+__global__ void __launch_bounds__(SX*SY)
+k_sweep_update(Geo g, double gamma, SweepArgs a, UpdArgs u, int nouter) {
+  static_assert(DIR == 1 || DIR == 2, "marching kernel is for the x2/x3 sweeps");
+  int i, j, k, m, s0;
+  bool lane_ok;
+  if constexpr (DIR == 2) {
+    const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;   // rows [jl,ju] x N1
+    const int jj = (int)(p/g.N1);
+    i = (int)(p - (long)jj*g.N1);
+    j = a.jl + jj;
+    m = blockIdx.z;
+    s0 = a.kl + blockIdx.y*ML;
+    k = s0;
+    lane_ok = (j <= a.ju) && (i >= a.il) && (i <= a.iu);
+  } else {
+    i = a.il + blockIdx.x*SX + threadIdx.x;
+    m = blockIdx.z/nouter;
+    k = a.kl + (blockIdx.z - m*nouter);
+    s0 = a.jl + (blockIdx.y*SY + threadIdx.y)*ML;
+    j = s0;
+    lane_ok = (i <= a.iu) && (s0 <= a.ju);
+  }
+  if (!lane_ok) return;
+  constexpr int ivx = 1 + DIR, ivy = 1 + (DIR + 1)%3, ivz = 1 + (DIR + 2)%3;
+  const int shi = (DIR == 1) ? a.ju : a.ku;           // last face along the sweep
+  const bool col_active = (i >= g.is) && (i <= g.ie) &&
+                          ((DIR == 1) ? (k >= g.ks && k <= g.ke) : (j >= g.js && j <= g.je));
+  const int clo = (DIR == 1) ? g.js : g.ks, chi = (DIR == 1) ? g.je : g.ke;
+  const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
+  const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  double fp[5] = {0, 0, 0, 0, 0};
+  for (int t = 0; t <= ML; ++t) {
+    const int s = s0 + t;
+    if (s > shi) break;
+    if constexpr (DIR == 1) j = s; else k = s;
+    double fd, fx, fy, fz, fe, fby, fbz;
+    face_flux<DIR, RECON, MHD>(g, gamma, a.w0, a.bcc0, a.bxf, a.f3, a.f2, a.f1, m, k, j, i, fd, fx,
+                               fy, fz, fe, fby, fbz);
+    if constexpr (MHD) {
+      if (t < ML || s == shi) {
+        // CornerE needs the sign of the mass flux and the two face EMFs of this direction
+        a.flx[ix5(g.nvar, a.f3, a.f2, a.f1, m, 0, k, j, i)] = fd;
+        const size_t ec = ix4(g.N3, g.N2, g.N1, m, k, j, i);
+        a.ey[ec] = -fby;
+        a.ez[ec] = fbz;
+      }
+    }
+    double fv[5];
+    fv[0] = fd; fv[ivx] = fx; fv[ivy] = fy; fv[ivz] = fz; fv[4] = fe;
+    const int sc = s - 1;                               // cell finished by this face
+    if (t > 0 && col_active && sc >= clo && sc <= chi) {
+      const int kc = (DIR == 2) ? sc : k, jc = (DIR == 1) ? sc : j;
+      const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, kc, jc, i);
+#pragma unroll
+      for (int n = 0; n < 5; ++n) {
+        double divf = (u.flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, n, kc, jc, i + 1)] -
+                       u.flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, n, kc, jc, i)])/dx1;
+        if constexpr (DIR == 1) {
+          divf += (fv[n] - fp[n])/dx2;
+        } else {
+          divf += (u.flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, n, kc, jc + 1, i)] -
+                   u.flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, n, kc, jc, i)])/dx2;
+          divf += (fv[n] - fp[n])/dx3;
+        }
+        const double u0v = u.u0[c + n*cs];
+        const double u1v = u.copy_u1 ? u0v : u.u1[c + n*cs];
+        if (u.copy_u1) u.u1[c + n*cs] = u0v;
+        u.u0[c + n*cs] = u.gam0*u0v + u.gam1*u1v - u.beta_dt*divf;
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < 5; ++n) fp[n] = fv[n];
+  }
+}
+
+// 1-D problems: the sweep direction is the lane direction, so neighbouring faces are
+// exchanged through LDS inside a TX-wide tile (overlap of one face between tiles).
+template <int RECON, bool MHD>
+__global__ void __launch_bounds__(TX)
+k_sweep_update_1d(Geo g, double gamma, SweepArgs a, UpdArgs u) {
+  __shared__ double sF[5][TX];
+  const int i = a.il + blockIdx.x*(TX - 1) + threadIdx.x;
+  const int j = a.jl, k = a.kl, m = blockIdx.z;
+  const bool face_ok = (i <= a.iu);
+  double fd = 0, fx = 0, fy = 0, fz = 0, fe = 0, fby = 0, fbz = 0;
+  if (face_ok) {
+    face_flux<0, RECON, MHD>(g, gamma, a.w0, a.bcc0, a.bxf, a.f3, a.f2, a.f1, m, k, j, i, fd, fx, fy,
+                             fz, fe, fby, fbz);
+    if constexpr (MHD) {
+      a.flx[ix5(g.nvar, a.f3, a.f2, a.f1, m, 0, k, j, i)] = fd;
+      const size_t ec = ix4(g.N3, g.N2, g.N1, m, k, j, i);
+      a.ey[ec] = -fby;
+      a.ez[ec] = fbz;
+    }
+  }
+  const double fv[5] = {fd, fx, fy, fz, fe};
+#pragma unroll
+  for (int n = 0; n < 5; ++n) sF[n][threadIdx.x] = fv[n];
+  __syncthreads();
+  if (threadIdx.x >= TX - 1 || i > g.ie) return;
+  const double dx1 = g.dx[3*m];
+  const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
+#pragma unroll
+  for (int n = 0; n < 5; ++n) {
+    const double divf = (sF[n][threadIdx.x + 1] - fv[n])/dx1;
+    const double u0v = u.u0[c + n*cs];
+    const double u1v = u.copy_u1 ? u0v : u.u1[c + n*cs];
+    if (u.copy_u1) u.u1[c + n*cs] = u0v;
+    u.u0[c + n*cs] = u.gam0*u0v + u.gam1*u1v - u.beta_dt*divf;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Corner EMFs (mhd_corner_e.cpp:338-414) from face EMFs, cell-centred EMFs and mass-flux
+// signs.  All operands are loaded unconditionally and chosen with selects.
+#define CCE(a, k, j, i) a[ix4(g.N3, g.N2, g.N1, m, k, j, i)]
+__device__ __forceinline__ double upw(bool pos, double fa, double ca, double fb, double cb) {
+  return pos ? (fa - ca) : (fb - cb);
+}
+
+__global__ void __launch_bounds__(SX*SY)
+k_corner3(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e2x1,
+          const double *__restrict__ e1x2, const double *__restrict__ e3x2,
+          const double *__restrict__ e2x3, const double *__restrict__ e1x3,
+          const double *__restrict__ c1, const double *__restrict__ c2,
+          const double *__restrict__ c3, const double *__restrict__ flx1,
+          const double *__restrict__ flx2, const double *__restrict__ flx3,
+          double *__restrict__ e1, double *__restrict__ e2, double *__restrict__ e3) {
+  const int i = g.is + blockIdx.x*SX + threadIdx.x;
+  const int j = g.js + blockIdx.y*SY + threadIdx.y;
+  const int nk = g.ke - g.ks + 2;
+  const int m = blockIdx.z/nk;
+  const int k = g.ks + (blockIdx.z - m*nk);
+  if (i > g.ie + 1 || j > g.je + 1) return;
+  const double f1_k = flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k, j, i)];
+  const double f1_km = flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k - 1, j, i)];
+  const double f1_jm = flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k, j - 1, i)];
+  const double f2_k = flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, 0, k, j, i)];
+  const double f2_km = flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, 0, k - 1, j, i)];
+  const double f2_im = flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, 0, k, j, i - 1)];
+  const double f3_k = flx3[ix5(g.nvar, g.N3 + 1, g.N2, g.N1, m, 0, k, j, i)];
+  const double f3_jm = flx3[ix5(g.nvar, g.N3 + 1, g.N2, g.N1, m, 0, k, j - 1, i)];
+  const double f3_im = flx3[ix5(g.nvar, g.N3 + 1, g.N2, g.N1, m, 0, k, j, i - 1)];
+  {  // E1 (:340-363)
+    const double x3_jm = CCE(e1x3, k, j - 1, i), x3_j = CCE(e1x3, k, j, i);
+    const double x2_km = CCE(e1x2, k - 1, j, i), x2_k = CCE(e1x2, k, j, i);
+    const double c_mm = CCE(c1, k - 1, j - 1, i), c_m0 = CCE(c1, k - 1, j, i);
+    const double c_0m = CCE(c1, k, j - 1, i), c_00 = CCE(c1, k, j, i);
+    double e1_l3 = upw(f2_km >= 0.0, x3_jm, c_mm, x3_j, c_m0);
+    double e1_r3 = upw(f2_k >= 0.0, x3_jm, c_0m, x3_j, c_00);
+    double e1_l2 = upw(f3_jm >= 0.0, x2_km, c_mm, x2_k, c_0m);
+    double e1_r2 = upw(f3_k >= 0.0, x2_km, c_m0, x2_k, c_00);
+    e1[ix4(g.N3 + 1, g.N2 + 1, g.N1, m, k, j, i)] =
+        0.25*(e1_l3 + e1_r3 + e1_l2 + e1_r2 + x2_km + x2_k + x3_jm + x3_j);
+  }
+  {  // E2 (:365-388)
+    const double x3_im = CCE(e2x3, k, j, i - 1), x3_i = CCE(e2x3, k, j, i);
+    const double x1_km = CCE(e2x1, k - 1, j, i), x1_k = CCE(e2x1, k, j, i);
+    const double c_mm = CCE(c2, k - 1, j, i - 1), c_m0 = CCE(c2, k - 1, j, i);
+    const double c_0m = CCE(c2, k, j, i - 1), c_00 = CCE(c2, k, j, i);
+    double e2_l3 = upw(f1_km >= 0.0, x3_im, c_mm, x3_i, c_m0);
+    double e2_r3 = upw(f1_k >= 0.0, x3_im, c_0m, x3_i, c_00);
+    double e2_l1 = upw(f3_im >= 0.0, x1_km, c_mm, x1_k, c_0m);
+    double e2_r1 = upw(f3_k >= 0.0, x1_km, c_m0, x1_k, c_00);
+    e2[ix4(g.N3 + 1, g.N2, g.N1 + 1, m, k, j, i)] =
+        0.25*(e2_l3 + e2_r3 + e2_l1 + e2_r1 + x3_im + x3_i + x1_km + x1_k);
+  }
+  {  // E3 (:390-413)
+    const double x2_im = CCE(e3x2, k, j, i - 1), x2_i = CCE(e3x2, k, j, i);
+    const double x1_jm = CCE(e3x1, k, j - 1, i), x1_j = CCE(e3x1, k, j, i);
+    const double c_mm = CCE(c3, k, j - 1, i - 1), c_m0 = CCE(c3, k, j - 1, i);
+    const double c_0m = CCE(c3, k, j, i - 1), c_00 = CCE(c3, k, j, i);
+    double e3_l2 = upw(f1_jm >= 0.0, x2_im, c_mm, x2_i, c_m0);
+    double e3_r2 = upw(f1_k >= 0.0, x2_im, c_0m, x2_i, c_00);
+    double e3_l1 = upw(f2_im >= 0.0, x1_jm, c_mm, x1_j, c_0m);
+    double e3_r1 = upw(f2_k >= 0.0, x1_jm, c_m0, x1_j, c_00);
+    e3[ix4(g.N3, g.N2 + 1, g.N1 + 1, m, k, j, i)] =
+        0.25*(e3_l1 + e3_r1 + e3_l2 + e3_r2 + x2_im + x2_i + x1_jm + x1_j);
+  }
+}
+
+// CT (mhd_ct.cpp:23-80) with CopyCons for B folded in at stage 1 (b1 <- b0 old)
+__global__ void __launch_bounds__(SX*SY)
+k_ct_copy(Geo g, double gam0, double gam1, double beta_dt, const double *__restrict__ e1,
+          const double *__restrict__ e2, const double *__restrict__ e3, double *__restrict__ b0x1f,
+          double *__restrict__ b0x2f, double *__restrict__ b0x3f, double *__restrict__ b1x1f,
+          double *__restrict__ b1x2f, double *__restrict__ b1x3f, int copy_b1) {
+  const int i = g.is + blockIdx.x*SX + threadIdx.x;
+  const int j = g.js + blockIdx.y*SY + threadIdx.y;
+  const int nk = g.ke - g.ks + 2;
+  const int m = blockIdx.z/nk;
+  const int k = g.ks + (blockIdx.z - m*nk);
+  if (i > g.ie + 1 || j > g.je + 1) return;
+  const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
+#define E1(k, j, i) e1[ix4(g.N3 + 1, g.N2 + 1, g.N1, m, k, j, i)]
+#define E2(k, j, i) e2[ix4(g.N3 + 1, g.N2, g.N1 + 1, m, k, j, i)]
+#define E3(k, j, i) e3[ix4(g.N3, g.N2 + 1, g.N1 + 1, m, k, j, i)]
+  if (j <= g.je && k <= g.ke) {
+    size_t c = ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i);
+    const double b0v = b0x1f[c];
+    const double b1v = copy_b1 ? b0v : b1x1f[c];
+    if (g.multi_d) {
+      double b = gam0*b0v + gam1*b1v;
+      b -= beta_dt*(E3(k, j + 1, i) - E3(k, j, i))/dx2;
+      if (g.three_d) b += beta_dt*(E2(k + 1, j, i) - E2(k, j, i))/dx3;
+      b0x1f[c] = b;
+    }
+    if (copy_b1) b1x1f[c] = b0v;
+  }
+  if (i <= g.ie && k <= g.ke) {
+    size_t c = ix4(g.N3, g.N2 + 1, g.N1, m, k, j, i);
+    const double b0v = b0x2f[c];
+    const double b1v = copy_b1 ? b0v : b1x2f[c];
+    double b = gam0*b0v + gam1*b1v;
+    b += beta_dt*(E3(k, j, i + 1) - E3(k, j, i))/dx1;
+    if (g.three_d) b -= beta_dt*(E1(k + 1, j, i) - E1(k, j, i))/dx3;
+    b0x2f[c] = b;
+    if (copy_b1) b1x2f[c] = b0v;
+  }
+  if (i <= g.ie && j <= g.je) {
+    size_t c = ix4(g.N3 + 1, g.N2, g.N1, m, k, j, i);
+    const double b0v = b0x3f[c];
+    const double b1v = copy_b1 ? b0v : b1x3f[c];
+    double b = gam0*b0v + gam1*b1v;
+    b -= beta_dt*(E2(k, j, i + 1) - E2(k, j, i))/dx1;
+    if (g.multi_d) b += beta_dt*(E1(k, j + 1, i) - E1(k, j, i))/dx2;
+    b0x3f[c] = b;
+    if (copy_b1) b1x3f[c] = b0v;
+  }
+#undef E1
+#undef E2
+#undef E3
+}
+
+// ---------------------------------------------------------------------------------------
+// Pass B: c2p over all cells (+ CFL scan over active cells on the last stage)
+__device__ __forceinline__ double wave_max(double v) {
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+template <bool MHD>
+__global__ void __launch_bounds__(SX*SY)
+k_c2p_newdt(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ bx1f,
+            const double *__restrict__ bx2f, const double *__restrict__ bx3f,
+            double *__restrict__ w0, double *__restrict__ bcc0, int do_newdt,
+            int *__restrict__ counters, double *__restrict__ dt3) {
+  __shared__ double sm[3][SY];
+  const int i = blockIdx.x*SX + threadIdx.x;
+  const int j = blockIdx.y*SY + threadIdx.y;
+  const int m = blockIdx.z/g.N3;
+  const int k = blockIdx.z - m*g.N3;
+  double mv1 = 0.0, mv2 = 0.0, mv3 = 0.0;
+  if (i < g.N1 && j < g.N2) {
+    const size_t cs = (size_t)g.N3*g.N2*g.N1;
+    const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
+    double ud = u0[c], umx = u0[c + cs], umy = u0[c + 2*cs], umz = u0[c + 3*cs], ue = u0[c + 4*cs];
+    double wd, wvx, wvy, wvz, we, ubx = 0, uby = 0, ubz = 0;
+    bool dfl = false, efl = false, tfl = false;
+    if constexpr (MHD) {
+      ubx = 0.5*(bx1f[ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i)] +
+                 bx1f[ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i + 1)]);
+      uby = 0.5*(bx2f[ix4(g.N3, g.N2 + 1, g.N1, m, k, j, i)] +
+                 bx2f[ix4(g.N3, g.N2 + 1, g.N1, m, k, j + 1, i)]);
+      ubz = 0.5*(bx3f[ix4(g.N3 + 1, g.N2, g.N1, m, k, j, i)] +
+                 bx3f[ix4(g.N3 + 1, g.N2, g.N1, m, k + 1, j, i)]);
+      c2p_mhd(eos, ud, umx, umy, umz, ue, ubx, uby, ubz, wd, wvx, wvy, wvz, we, dfl, efl, tfl);
+      const size_t b = ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i);
+      bcc0[b] = ubx; bcc0[b + cs] = uby; bcc0[b + 2*cs] = ubz;
+    } else {
+      c2p_hyd(eos, ud, umx, umy, umz, ue, wd, wvx, wvy, wvz, we, dfl, efl, tfl);
+    }
+    if (dfl) { u0[c] = ud; atomicAdd(&counters[0], 1); }
+    if (efl) { u0[c + 4*cs] = ue; atomicAdd(&counters[1], 1); }
+    if (tfl) { u0[c + 4*cs] = ue; atomicAdd(&counters[2], 1); }
+    w0[c] = wd; w0[c + cs] = wvx; w0[c + 2*cs] = wvy; w0[c + 3*cs] = wvz; w0[c + 4*cs] = we;
+    if (do_newdt && i >= g.is && i <= g.ie && j >= g.js && j <= g.je && k >= g.ks && k <= g.ke) {
+      // hydro_newdt.cpp:97-118 / mhd_newdt.cpp:123-136
+      const double pr = (eos.gamma - 1.0)*we;
+      if constexpr (MHD) {
+        mv1 = fabs(wvx) + fast_speed(eos.gamma, wd, pr, ubx, uby, ubz);
+        mv2 = fabs(wvy) + fast_speed(eos.gamma, wd, pr, uby, ubz, ubx);
+        mv3 = fabs(wvz) + fast_speed(eos.gamma, wd, pr, ubz, ubx, uby);
+      } else {
+        const double cs_ = sqrt(eos.gamma*pr/wd);
+        mv1 = fabs(wvx) + cs_; mv2 = fabs(wvy) + cs_; mv3 = fabs(wvz) + cs_;
+      }
+    }
+  }
+  if (!do_newdt) return;        // uniform across the grid
+  mv1 = wave_max(mv1); mv2 = wave_max(mv2); mv3 = wave_max(mv3);
+  if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.y] = mv1; sm[1][threadIdx.y] = mv2; sm[2][threadIdx.y] = mv3; }
+  __syncthreads();
+  if (threadIdx.y == 0 && threadIdx.x < 3) {
+    double v = sm[threadIdx.x][0];
+    for (int q = 1; q < SY; ++q) v = fmax(v, sm[threadIdx.x][q]);
+    if (v > 0.0) {
+      // min over cells of fl(dx/a) == fl(dx/max a): correctly rounded division is monotone
+      const double d = g.dx[3*m + threadIdx.x]/v;
+      atomicMin(reinterpret_cast<unsigned long long *>(&dt3[threadIdx.x]),
+                (unsigned long long)__double_as_longlong(d));
+    }
+  }
+}
+
+__global__ void k_init_dt3(double *dt3) {
+  if (threadIdx.x < 3) dt3[threadIdx.x] = (double)FLT_MAX;
+}
+
+// ---------------------------------------------------------------------------------------
+template <int DIR, bool MHD, bool ECC>
+static int launch_sweep(const Geo &g, double gamma, int recon, const SweepArgs &a, hipStream_t st) {
+  int nk = a.ku - a.kl + 1;
+  dim3 grid(cdiv(a.iu - a.il + 1 + (ECC ? 1 : 0), SX), cdiv(a.ju - a.jl + 1, SY), nk*g.nmb), block(SX, SY);
+  if (recon == AKMI_RECON_PLM) k_sweep<DIR, 1, MHD, ECC><<<grid, block, 0, st>>>(g, gamma, a, nk);
+  else if (recon == AKMI_RECON_PPM4) k_sweep<DIR, 2, MHD, ECC><<<grid, block, 0, st>>>(g, gamma, a, nk);
+  else k_sweep<DIR, 0, MHD, ECC><<<grid, block, 0, st>>>(g, gamma, a, nk);
+  AKMI_CHECK_LAUNCH("sweep");
+  return AKMI_COMPLETE;
+}
+
+template <int DIR, bool MHD>
+static int launch_sweep_update(const Geo &g, double gamma, int recon, const SweepArgs &a,
+                               const UpdArgs &u, hipStream_t st) {
+  if constexpr (DIR == 0) {
+    dim3 grid(cdiv(a.iu - a.il + 1, TX - 1), 1, g.nmb), block(TX, 1);
+    if (recon == AKMI_RECON_PLM) k_sweep_update_1d<1, MHD><<<grid, block, 0, st>>>(g, gamma, a, u);
+    else if (recon == AKMI_RECON_PPM4) k_sweep_update_1d<2, MHD><<<grid, block, 0, st>>>(g, gamma, a, u);
+    else k_sweep_update_1d<0, MHD><<<grid, block, 0, st>>>(g, gamma, a, u);
+  } else {
+    dim3 grid, block(SX, SY);
+    int nouter = 1;
+    if (DIR == 2) {
+      long np = (long)(a.ju - a.jl + 1)*g.N1;          // flattened rows
+      grid = dim3((unsigned)((np + SX*SY - 1)/(SX*SY)), cdiv(a.ku - a.kl + 1, ML), g.nmb);
+    } else {
+      nouter = a.ku - a.kl + 1;
+      grid = dim3(cdiv(a.iu - a.il + 1, SX), cdiv(cdiv(a.ju - a.jl + 1, ML), SY), nouter*g.nmb);
+    }
+    constexpr int D = (DIR == 0) ? 1 : DIR;
+    if (recon == AKMI_RECON_PLM) k_sweep_update<D, 1, MHD><<<grid, block, 0, st>>>(g, gamma, a, u, nouter);
+    else if (recon == AKMI_RECON_PPM4) k_sweep_update<D, 2, MHD><<<grid, block, 0, st>>>(g, gamma, a, u, nouter);
+    else k_sweep_update<D, 0, MHD><<<grid, block, 0, st>>>(g, gamma, a, u, nouter);
+  }
+  AKMI_CHECK_LAUNCH("sweep_update");
+  return AKMI_COMPLETE;
+}
+
+template <bool MHD>
+static int stage_update(const akmi_pack *p, int recon, double gam0, double gam1, double beta_dt,
+                        int copy_u1, const double *w0, const double *bcc0, double *u0, double *u1,
+                        double *b0x1f, double *b0x2f, double *b0x3f, double *b1x1f, double *b1x2f,
+                        double *b1x3f, void *ws, hipStream_t st) {
+  Geo g = make_geo(p);
+  StageWs w = carve(g, MHD ? 1 : 0, ws);
+  const int ndim = g.three_d ? 3 : (g.multi_d ? 2 : 1);
+  UpdArgs u{gam0, gam1, beta_dt, u0, u1, w.flx1, w.flx2, copy_u1};
+  int rc = AKMI_COMPLETE;
+  // sweep ranges: hydro_fluxes.cpp:95-104 (no FOFC) / mhd_fluxes.cpp:117-248 (CT-extended)
+  SweepArgs a1{w0, bcc0, b0x1f, w.flx1, w.efc[0], w.efc[1], w.ecc[0], w.ecc[1], w.ecc[2],
+               g.is, g.ie + 1, g.js, g.je, g.ks, g.ke, g.N3, g.N2, g.N1 + 1};
+  SweepArgs a2{w0, bcc0, b0x2f, w.flx2, w.efc[2], w.efc[3], nullptr, nullptr, nullptr,
+               g.is, g.ie, g.js, g.je + 1, g.ks, g.ke, g.N3, g.N2 + 1, g.N1};
+  SweepArgs a3{w0, bcc0, b0x3f, w.flx3, w.efc[4], w.efc[5], nullptr, nullptr, nullptr,
+               g.is, g.ie, g.js, g.je, g.ks, g.ke + 1, g.N3 + 1, g.N2, g.N1};
+  if (MHD) {
+    if (g.multi_d) { a1.jl = g.js - 1; a1.ju = g.je + 1; }
+    if (g.three_d) { a1.kl = g.ks - 1; a1.ku = g.ke + 1; }
+    a2.il = g.is - 1; a2.iu = g.ie + 1;
+    if (g.three_d) { a2.kl = g.ks - 1; a2.ku = g.ke + 1; }
+    a3.il = g.is - 1; a3.iu = g.ie + 1; a3.jl = g.js - 1; a3.ju = g.je + 1;
+  }
+  if (ndim == 1) {
+    rc = launch_sweep_update<0, MHD>(g, p->gamma, recon, a1, u, st);
+  } else {
+    // e_cc is needed by CornerE in 2-D (e3 only) and 3-D
+    rc = MHD ? launch_sweep<0, MHD, MHD>(g, p->gamma, recon, a1, st)
+             : launch_sweep<0, MHD, false>(g, p->gamma, recon, a1, st);
+    if (rc != AKMI_COMPLETE) return rc;
+    if (ndim == 2) {
+      rc = launch_sweep_update<1, MHD>(g, p->gamma, recon, a2, u, st);
+    } else {
+      rc = launch_sweep<1, MHD, false>(g, p->gamma, recon, a2, st);
+      if (rc != AKMI_COMPLETE) return rc;
+      rc = launch_sweep_update<2, MHD>(g, p->gamma, recon, a3, u, st);
+    }
+  }
+  if (rc != AKMI_COMPLETE || !MHD) return rc;
+  // corner E + CT
+  if (ndim == 3) {
+    dim3 grid(cdiv(g.nx1 + 1, SX), cdiv(g.nx2 + 1, SY), (g.nx3 + 1)*g.nmb), block(SX, SY);
+    k_corner3<<<grid, block, 0, st>>>(g, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5],
+                                      w.ecc[0], w.ecc[1], w.ecc[2], w.flx1, w.flx2, w.flx3, w.e1,
+                                      w.e2, w.e3);
+    AKMI_CHECK_LAUNCH("corner3");
+  } else {
+    // 1-D / 2-D: the task-level kernels (tiny problems; CornerE recomputes e_cc itself)
+    rc = akmi_mhd_corner_e(p, w0, bcc0, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5],
+                           w.flx1, w.flx2, w.flx3, w.e1, w.e2, w.e3, st);
+    if (rc != AKMI_COMPLETE) return rc;
+  }
+  dim3 grid(cdiv(g.nx1 + 1, SX), cdiv(g.je - g.js + 2, SY), (g.ke - g.ks + 2)*g.nmb), block(SX, SY);
+  k_ct_copy<<<grid, block, 0, st>>>(g, gam0, gam1, beta_dt, w.e1, w.e2, w.e3, b0x1f, b0x2f, b0x3f,
+                                    b1x1f, b1x2f, b1x3f, copy_u1);
+  AKMI_CHECK_LAUNCH("ct");
+  return AKMI_COMPLETE;
 }
 
 }  // namespace akmi
@@ -47,60 +571,45 @@ long long akmi_stage_workspace_bytes(const akmi_pack *p, int is_mhd) {
 int akmi_hydro_stage_update(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1,
                             double beta_dt, int copy_u1, const double *w0, double *u0, double *u1,
                             void *ws, void *stream) {
-  Geo g = make_geo(p);
-  StageWs w = carve(g, 0, ws);
-  int rc = AKMI_COMPLETE;
-  if (copy_u1) rc = akmi_copy_cons(p, u0, u1, stream);
-  if (rc == AKMI_COMPLETE) rc = akmi_hydro_fluxes(p, recon, rsolver, w0, w.flx1, w.flx2, w.flx3, 1, stream);
-  if (rc == AKMI_COMPLETE) rc = akmi_rk_update(p, gam0, gam1, beta_dt, u0, u1, w.flx1, w.flx2, w.flx3, 1, stream);
-  return rc;
+  if (rsolver != AKMI_RS_HLLC) { set_error("hydro_stage_update: only rsolver=hllc is implemented"); return AKMI_FAIL; }
+  if (recon == AKMI_RECON_PPM4 && p->ng < 3) { set_error("ppm4 needs nghost>=3"); return AKMI_FAIL; }
+  return stage_update<false>(p, recon, gam0, gam1, beta_dt, copy_u1, w0, nullptr, u0, u1, nullptr,
+                             nullptr, nullptr, nullptr, nullptr, nullptr, ws, (hipStream_t)stream);
 }
 
 int akmi_mhd_stage_update(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1,
                           double beta_dt, int copy_u1, const double *w0, const double *bcc0,
                           double *u0, double *u1, double *b0x1f, double *b0x2f, double *b0x3f,
                           double *b1x1f, double *b1x2f, double *b1x3f, void *ws, void *stream) {
-  Geo g = make_geo(p);
-  StageWs w = carve(g, 1, ws);
-  hipStream_t st = (hipStream_t)stream;
-  int rc = AKMI_COMPLETE;
-  if (copy_u1) {
-    rc = akmi_copy_cons(p, u0, u1, stream);
-    size_t nmb = g.nmb;
-    hipMemcpyAsync(b1x1f, b0x1f, sizeof(double)*nmb*g.N3*g.N2*(g.N1 + 1), hipMemcpyDeviceToDevice, st);
-    hipMemcpyAsync(b1x2f, b0x2f, sizeof(double)*nmb*g.N3*(g.N2 + 1)*g.N1, hipMemcpyDeviceToDevice, st);
-    hipMemcpyAsync(b1x3f, b0x3f, sizeof(double)*nmb*(g.N3 + 1)*g.N2*g.N1, hipMemcpyDeviceToDevice, st);
-  }
-  if (rc == AKMI_COMPLETE)
-    rc = akmi_mhd_fluxes(p, recon, rsolver, w0, bcc0, b0x1f, b0x2f, b0x3f, w.flx1, w.flx2, w.flx3,
-                         w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5], stream);
-  if (rc == AKMI_COMPLETE)
-    rc = akmi_rk_update(p, gam0, gam1, beta_dt, u0, u1, w.flx1, w.flx2, w.flx3, 1, stream);
-  if (rc == AKMI_COMPLETE)
-    rc = akmi_mhd_corner_e(p, w0, bcc0, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5],
-                           w.flx1, w.flx2, w.flx3, w.e1, w.e2, w.e3, stream);
-  if (rc == AKMI_COMPLETE)
-    rc = akmi_mhd_ct(p, gam0, gam1, beta_dt, w.e1, w.e2, w.e3, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f,
-                     b1x3f, stream);
-  return rc;
+  if (rsolver != AKMI_RS_HLLD) { set_error("mhd_stage_update: only rsolver=hlld is implemented"); return AKMI_FAIL; }
+  if (recon == AKMI_RECON_PPM4 && p->ng < 3) { set_error("ppm4 needs nghost>=3"); return AKMI_FAIL; }
+  return stage_update<true>(p, recon, gam0, gam1, beta_dt, copy_u1, w0, bcc0, u0, u1, b0x1f, b0x2f,
+                            b0x3f, b1x1f, b1x2f, b1x3f, ws, (hipStream_t)stream);
 }
 
 int akmi_hydro_c2p_newdt(const akmi_pack *p, double *u0, double *w0, int do_newdt, int *counters,
                          double *dt3, void *stream) {
   Geo g = make_geo(p);
-  int rc = akmi_hydro_c2p(p, u0, w0, 0, g.N1 - 1, 0, g.N2 - 1, 0, g.N3 - 1, counters, stream);
-  if (rc == AKMI_COMPLETE && do_newdt) rc = akmi_hydro_newdt(p, w0, dt3, stream);
-  return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (do_newdt) k_init_dt3<<<1, 64, 0, st>>>(dt3);
+  dim3 grid(cdiv(g.N1, SX), cdiv(g.N2, SY), g.N3*g.nmb), block(SX, SY);
+  k_c2p_newdt<false><<<grid, block, 0, st>>>(g, make_eos(p), u0, nullptr, nullptr, nullptr, w0,
+                                             nullptr, do_newdt, counters, dt3);
+  AKMI_CHECK_LAUNCH("hydro_c2p_newdt");
+  return AKMI_COMPLETE;
 }
 
 int akmi_mhd_c2p_newdt(const akmi_pack *p, double *u0, const double *bx1f, const double *bx2f,
                        const double *bx3f, double *w0, double *bcc0, int do_newdt, int *counters,
                        double *dt3, void *stream) {
   Geo g = make_geo(p);
-  int rc = akmi_mhd_c2p(p, u0, bx1f, bx2f, bx3f, w0, bcc0, 0, g.N1 - 1, 0, g.N2 - 1, 0, g.N3 - 1,
-                        counters, stream);
-  if (rc == AKMI_COMPLETE && do_newdt) rc = akmi_mhd_newdt(p, w0, bcc0, dt3, stream);
-  return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (do_newdt) k_init_dt3<<<1, 64, 0, st>>>(dt3);
+  dim3 grid(cdiv(g.N1, SX), cdiv(g.N2, SY), g.N3*g.nmb), block(SX, SY);
+  k_c2p_newdt<true><<<grid, block, 0, st>>>(g, make_eos(p), u0, bx1f, bx2f, bx3f, w0, bcc0,
+                                            do_newdt, counters, dt3);
+  AKMI_CHECK_LAUNCH("mhd_c2p_newdt");
+  return AKMI_COMPLETE;
 }
 
 }  // extern "C"

@@ -210,8 +210,16 @@ class Hydro(FluidBase):
         return TaskStatus.complete
 
     def ConToPrim(self, pdrive, stage):
-        """hydro_tasks.cpp:404-412: all cells including ghosts"""
+        """hydro_tasks.cpp:404-412: all cells including ghosts (the fused path also performs
+        the CFL scan of NewTimeStep in the same kernel on the last stage)"""
         n3, n2, n1 = self.pmy_pack.pmesh.mb_indcs.ncells
+        if self.fused:
+            do_dt = 1 if stage == pdrive.nexp_stages else 0
+            capi.check(self.L.akmi_hydro_c2p_newdt(
+                C.byref(self.pack_c), capi._p(self.u0), capi._p(self.w0), do_dt,
+                capi._p(self.counters), capi._p(self.dt3), capi._stream()), "hydro_c2p_newdt")
+            self._dt_ready = bool(do_dt)
+            return TaskStatus.complete
         capi.check(self.L.akmi_hydro_c2p(C.byref(self.pack_c), capi._p(self.u0), capi._p(self.w0),
                                          0, n1 - 1, 0, n2 - 1, 0, n3 - 1, capi._p(self.counters),
                                          capi._stream()), "hydro_c2p")
@@ -221,7 +229,9 @@ class Hydro(FluidBase):
         """hydro_newdt.cpp:30-139: last stage only"""
         if stage != pdrive.nexp_stages:
             return TaskStatus.complete
-        capi.check(self.L.akmi_hydro_newdt(C.byref(self.pack_c), capi._p(self.w0),
-                                           capi._p(self.dt3), capi._stream()), "hydro_newdt")
+        if not getattr(self, "_dt_ready", False):
+            capi.check(self.L.akmi_hydro_newdt(C.byref(self.pack_c), capi._p(self.w0),
+                                               capi._p(self.dt3), capi._stream()), "hydro_newdt")
+        self._dt_ready = False
         self._finish_newdt()
         return TaskStatus.complete

@@ -159,7 +159,16 @@ class MHD(FluidBase):
         return TaskStatus.complete
 
     def ConToPrim(self, pdrive, stage):
+        """mhd_tasks.cpp: all cells incl. ghosts; fused path: + CFL scan on the last stage"""
         n3, n2, n1 = self.pmy_pack.pmesh.mb_indcs.ncells
+        if self.fused:
+            do_dt = 1 if stage == pdrive.nexp_stages else 0
+            capi.check(self.L.akmi_mhd_c2p_newdt(
+                C.byref(self.pack_c), capi._p(self.u0), *self._b(self.b0), capi._p(self.w0),
+                capi._p(self.bcc0), do_dt, capi._p(self.counters), capi._p(self.dt3),
+                capi._stream()), "mhd_c2p_newdt")
+            self._dt_ready = bool(do_dt)
+            return TaskStatus.complete
         capi.check(self.L.akmi_mhd_c2p(
             C.byref(self.pack_c), capi._p(self.u0), *self._b(self.b0), capi._p(self.w0),
             capi._p(self.bcc0), 0, n1 - 1, 0, n2 - 1, 0, n3 - 1, capi._p(self.counters),
@@ -170,7 +179,10 @@ class MHD(FluidBase):
         """mhd_newdt.cpp:31-174: last stage only"""
         if stage != pdrive.nexp_stages:
             return TaskStatus.complete
-        capi.check(self.L.akmi_mhd_newdt(C.byref(self.pack_c), capi._p(self.w0), capi._p(self.bcc0),
-                                         capi._p(self.dt3), capi._stream()), "mhd_newdt")
+        if not getattr(self, "_dt_ready", False):
+            capi.check(self.L.akmi_mhd_newdt(C.byref(self.pack_c), capi._p(self.w0),
+                                             capi._p(self.bcc0), capi._p(self.dt3), capi._stream()),
+                       "mhd_newdt")
+        self._dt_ready = False
         self._finish_newdt()
         return TaskStatus.complete
