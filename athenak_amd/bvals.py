@@ -82,7 +82,8 @@ class _Channel:
 class MeshBoundaryValues:
     """Ghost-zone exchange + physical BCs for one MeshBlockPack."""
 
-    def __init__(self, ppack, kernels=None, device="cuda"):
+    def __init__(self, ppack, kernels=None, device=None):
+        device = device or capi.DEVICE
         self.pmy_pack = ppack
         self.k = kernels if kernels is not None else HipBvalsKernels()
         self.device = device

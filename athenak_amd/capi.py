@@ -67,7 +67,13 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
+DEVICE = "cuda"      # device of all field tensors; CPU-only unit tests of the host logic
+                     # override it together with _LIB (see tests/cpu_backend.py)
+
+
 def _stream():
+    if DEVICE != "cuda":
+        return None
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 

@@ -112,7 +112,8 @@ class FluidBase:
 
 
 class Hydro(FluidBase):
-    def __init__(self, ppack, pin, device="cuda", bvals_kernels=None):
+    def __init__(self, ppack, pin, device=None, bvals_kernels=None):
+        device = device or capi.DEVICE
         self._setup(ppack, pin, "hydro", device)
         rs = pin.GetString("hydro", "rsolver")
         if rs != "hllc":

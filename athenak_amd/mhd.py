@@ -15,7 +15,8 @@ from .tasklist import TaskID, TaskStatus
 
 
 class MHD(FluidBase):
-    def __init__(self, ppack, pin, device="cuda", bvals_kernels=None):
+    def __init__(self, ppack, pin, device=None, bvals_kernels=None):
+        device = device or capi.DEVICE
         self._setup(ppack, pin, "mhd", device)
         rs = pin.GetString("mhd", "rsolver")
         if rs != "hlld":

@@ -75,9 +75,11 @@ def cpu_baseline(args, blk):
     """the oracle (port of the reference's split-kernel CPU sequence) on all host cores, on a
     bounded sample of the same workload (same deck at sample_nx^3, a few cycles)"""
     from oracle import akref
-    ncores = os.cpu_count() or 1
+    try:
+        navail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        navail = os.cpu_count() or 1
     akref.lib()
-    akref.lib().akref_set_threads(ncores)
     n = args.cpu_sample_nx
     if args.problem == "orszag_tang":
         kw = dict(is_mhd=1, recon="plm", rsolver="hlld", gamma=1.666666667, pgen="orszag_tang",
@@ -90,20 +92,35 @@ def cpu_baseline(args, blk):
         kw = dict(is_mhd=0, recon="plm", rsolver="hllc", gamma=1.66666666667, pgen="linear_wave",
                   wave_flag=0, amp=1e-3, dens=1.0, pgas=0.6, bcs=["periodic"]*6, x1min=0.0,
                   x1max=3.0, x2min=0.0, x2max=1.5, x3min=0.0, x3max=1.5)
-    s = akref.Sim(nx1=n, nx2=n, nx3=n, mb_nx1=n, mb_nx2=n, mb_nx3=n, ng=2, nstages=2, cfl=0.3,
-                  tlim=1e9, nlim=-1, **kw)
-    s.initialize()
-    s.step()                       # warm-up (page faults, caches)
-    t0 = time.time()
-    cyc = 0
-    while time.time() - t0 < 12.0 and cyc < 200:
-        s.step()
-        cyc += 1
-    dt = time.time() - t0
-    val = n**3*cyc/dt/1e6
-    return {"value": round(val, 4), "unit": "Mcell-updates/s", "cores": ncores, "kind": "port",
-            "sample": "%s %d^3, %d RK2 cycles, oracle (reference split-kernel order) with OpenMP "
-                      "over %d threads" % (args.problem, n, cyc, ncores)}
+
+    def timed(threads, budget):
+        akref.lib().akref_set_threads(threads)
+        s = akref.Sim(nx1=n, nx2=n, nx3=n, mb_nx1=n, mb_nx2=n, mb_nx3=n, ng=2, nstages=2, cfl=0.3,
+                      tlim=1e9, nlim=-1, **kw)
+        s.initialize()
+        s.step()                   # warm-up (page faults, caches)
+        t0 = time.time()
+        cyc = 0
+        while time.time() - t0 < budget and cyc < 400:
+            s.step()
+            cyc += 1
+        dt = time.time() - t0
+        s.close()
+        return n**3*cyc/dt/1e6, cyc
+
+    # the oracle's OpenMP loops run over (block, k) planes: at most n-way parallel
+    candidates = sorted({1, min(navail, 16), min(navail, n)})
+    best = None
+    results = []
+    for th in candidates:
+        v, cyc = timed(th, 6.0)
+        results.append("%d thr: %.3f" % (th, v))
+        if best is None or v > best[0]:
+            best = (v, th, cyc)
+    return {"value": round(best[0], 4), "unit": "Mcell-updates/s", "cores": best[1], "kind": "port",
+            "sample": "%s %d^3 RK2, ~6 s per thread count, oracle = port of the reference's "
+                      "split-kernel CPU sequence with OpenMP; Mcell-updates/s by threads: %s "
+                      "(host has %d usable cores)" % (args.problem, n, "; ".join(results), navail)}
 
 
 def main():

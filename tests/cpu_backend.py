@@ -1,0 +1,44 @@
+"""TEST INFRASTRUCTURE: run the product's HOST logic (Mesh, TaskList, Driver, bvals, multi-rank
+exchange) on CPU tensors by standing the oracle's akref_* functions in for the akmi_* C ABI.
+Used only by the not-gpu tests of the distributed path (gloo); the shipped package never
+does this -- without libakmi.so it raises (tests/test_capi_symbols.py)."""
+import ctypes as C
+
+from oracle import akref
+
+
+class OracleAsAkmi:
+    """object with akmi_* attributes that forward to akref_* (dropping the stream argument)"""
+
+    def __init__(self):
+        self.R = akref.lib()
+
+    def akmi_last_error(self):
+        return b"(cpu test backend)"
+
+    def akmi_version(self):
+        return 100
+
+    def __getattr__(self, name):
+        if not name.startswith("akmi_"):
+            raise AttributeError(name)
+        fn = getattr(self.R, "akref_" + name[5:])
+        if name.endswith("segsize"):
+            fn.restype = C.c_longlong
+            return fn
+
+        def call(*args):
+            return fn(*args[:-1])          # last argument is the HIP stream
+        return call
+
+
+def install():
+    from athenak_amd import capi
+    capi._LIB = OracleAsAkmi()
+    capi.DEVICE = "cpu"
+
+
+def uninstall():
+    from athenak_amd import capi
+    capi._LIB = None
+    capi.DEVICE = "cuda"

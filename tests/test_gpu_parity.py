@@ -297,3 +297,30 @@ def test_task_bvals_pack_unpack_roundtrip(dims):
                                               *[capi._p(x) for x in bd2], None), "unpack")
             for x, y in zip(b_ref, bd2):
                 assert np.array_equal(x, y.cpu().numpy())
+
+
+@pytest.mark.parametrize("name", ["ot3d_16_mb8_plm_rk2_c3", "sod3d_16_plm_rk2_c4",
+                                  "blast2d_24_ppm4_rk3_c3", "lwave_hydro1d_64_c10"])
+def test_against_committed_golden_snapshots(name):
+    """HIP path from the committed initial state to the committed final state
+    (tests/golden/*.npz): bit-identical, without running the oracle"""
+    import os
+    import torch
+    from athenak_amd.main import Simulation, load_deck
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    pin = load_deck(str(g["deck"]), str(g["overrides"]).split("\n"))
+    sim = Simulation(pin, initialize=False)
+    ph = sim.phys
+    ph.u0.copy_(torch.from_numpy(g["init_u0"]))
+    if "init_b0x1f" in g:
+        ph.b0.x1f.copy_(torch.from_numpy(g["init_b0x1f"]))
+        ph.b0.x2f.copy_(torch.from_numpy(g["init_b0x2f"]))
+        ph.b0.x3f.copy_(torch.from_numpy(g["init_b0x3f"]))
+    sim.pdriver.Initialize(sim.pmesh, pin)
+    sim.Execute(max_cycles=int(g["cycles"]))
+    assert sim.pmesh.time == float(g["time"])
+    assert np.array_equal(ph.u0.cpu().numpy(), g["final_u0"])
+    if "final_b0x1f" in g:
+        assert np.array_equal(ph.b0.x1f.cpu().numpy(), g["final_b0x1f"])
+        assert np.array_equal(ph.b0.x2f.cpu().numpy(), g["final_b0x2f"])
+        assert np.array_equal(ph.b0.x3f.cpu().numpy(), g["final_b0x3f"])

@@ -169,3 +169,22 @@ def test_decomposition_invariance():
             full[:, l3*mb:(l3+1)*mb, l2*mb:(l2+1)*mb, l1*mb:(l1+1)*mb] = u[m][:, 2:2+mb, 2:2+mb, 2:2+mb]
         outs.append(full)
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("name", ["ot3d_16_mb8_plm_rk2_c3", "sod3d_16_plm_rk2_c4",
+                                  "blast2d_24_ppm4_rk3_c3", "lwave_hydro1d_64_c10"])
+def test_oracle_reproduces_committed_snapshots(name):
+    """tests/golden/*.npz (made by tests/golden/make_golden.py) freeze the pinned oracle"""
+    import os
+    import parity_util as pu
+    from athenak_amd.main import load_deck
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    pin = load_deck(str(g["deck"]), str(g["overrides"]).split("\n"))
+    o = akref.Sim(**pu.oracle_kwargs(pin))
+    o.initialize()
+    for _ in range(int(g["cycles"])):
+        o.step()
+    fin = pu.oracle_arrays(o, bool(o.params.is_mhd))
+    for k, v in fin.items():
+        assert np.array_equal(v, g["final_" + k]), (name, k)
+    assert o.time == float(g["time"])
