@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libakmi.so")
+# AKMI_LIB: developer override used by tools/kbench.py to A/B kernel variants
+LIB_PATH = os.environ.get("AKMI_LIB") or os.path.join(_HERE, "lib", "libakmi.so")
 
 RECON = {"dc": 0, "plm": 1, "ppm4": 2}
 RSOLVER = {"llf": 0, "hlle": 1, "hllc": 2, "hlld": 3}
@@ -33,7 +34,7 @@ SYMBOLS = [
     "akmi_bvals_cc_unpack", "akmi_bvals_cc_segsize", "akmi_bvals_fc_local", "akmi_bvals_fc_pack",
     "akmi_bvals_fc_unpack", "akmi_bvals_fc_segsize", "akmi_hydro_bcs", "akmi_bfield_bcs",
     "akmi_stage_workspace_bytes", "akmi_hydro_stage_update", "akmi_mhd_stage_update",
-    "akmi_hydro_c2p_newdt", "akmi_mhd_c2p_newdt",
+    "akmi_hydro_c2p_newdt", "akmi_mhd_c2p_newdt", "akmi_calib_copy",
 ]
 
 _LIB = None

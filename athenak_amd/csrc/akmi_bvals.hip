@@ -419,4 +419,23 @@ int akmi_bfield_bcs(const akmi_pack *p, const int *bcs, double *bx1f, double *bx
   return AKMI_COMPLETE;
 }
 
+int akmi_calib_copy(double *dst, const double *src, long long n, void *stream);
+
 }  // extern "C"
+
+namespace akmi {
+__global__ void __launch_bounds__(256) k_calib_copy(double *__restrict__ dst,
+                                                    const double *__restrict__ src, long long n) {
+  for (long long t = (long long)blockIdx.x*blockDim.x + threadIdx.x; t < n;
+       t += (long long)gridDim.x*blockDim.x)
+    dst[t] = src[t];
+}
+}  // namespace akmi
+
+extern "C" int akmi_calib_copy(double *dst, const double *src, long long n, void *stream) {
+  long long nb = (n + 255)/256;
+  if (nb > 16384) nb = 16384;
+  akmi::k_calib_copy<<<(int)nb, 256, 0, (hipStream_t)stream>>>(dst, src, n);
+  AKMI_CHECK_LAUNCH("calib_copy");
+  return AKMI_COMPLETE;
+}

@@ -87,6 +87,67 @@ __device__ __forceinline__ void face_flux(const Geo &g, double gamma,
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Rolling reconstruction window for kernels that MARCH along the sweep direction.  Per
+// variable the thread keeps the last NW cells and the pending left state of the next face in
+// registers, loads ONE new cell per step and evaluates ONE limiter per cell (the plain
+// per-face kernels evaluate two: every cell's slope is needed by both of its faces).  The
+// arithmetic per (cell, variable) is the same function of the same inputs as face_states<>,
+// so results are bit-identical.
+template <int RECON> struct RollCfg;
+template <> struct RollCfg<0> { static constexpr int NW = 1, BACK = 1, FWD = 0; };   // dc
+template <> struct RollCfg<1> { static constexpr int NW = 2, BACK = 2, FWD = 1; };   // plm
+template <> struct RollCfg<2> { static constexpr int NW = 4, BACK = 3, FWD = 2; };   // ppm4
+
+template <int RECON, int NV>
+struct Roll {
+  static constexpr int NW = RollCfg<RECON>::NW;
+  double w[NV][NW];     // cells (s-NW+FWD .. s-1+FWD) relative to the current face s
+  double pl[NV];        // left state of the current face (from cell s-1)
+  // p[n] points at cell s0 (right cell of the first face); st = stride along the sweep
+  __device__ __forceinline__ void init(const double *const (&p)[NV], long st) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const double *q = p[n];
+      double dummy;
+      if constexpr (RECON == 1) {
+        plm(q[-2*st], q[-st], q[0], pl[n], dummy);
+        w[n][0] = q[-st]; w[n][1] = q[0];
+      } else if constexpr (RECON == 2) {
+        ppm4(q[-3*st], q[-2*st], q[-st], q[0], q[st], pl[n], dummy);
+        w[n][0] = q[-2*st]; w[n][1] = q[-st]; w[n][2] = q[0]; w[n][3] = q[st];
+      } else {
+        pl[n] = q[-st];
+        w[n][0] = q[0];
+      }
+    }
+  }
+  // states of the current face; p[n] points at its right cell.  Advances the window.
+  __device__ __forceinline__ void step(const double *const (&p)[NV], long st, double (&L)[NV],
+                                       double (&R)[NV]) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const double *q = p[n];
+      double qln;
+      L[n] = pl[n];
+      if constexpr (RECON == 1) {
+        const double qp = q[st];
+        plm(w[n][0], w[n][1], qp, qln, R[n]);
+        w[n][0] = w[n][1]; w[n][1] = qp;
+      } else if constexpr (RECON == 2) {
+        const double qp = q[2*st];
+        ppm4(w[n][0], w[n][1], w[n][2], w[n][3], qp, qln, R[n]);
+        w[n][0] = w[n][1]; w[n][1] = w[n][2]; w[n][2] = w[n][3]; w[n][3] = qp;
+      } else {
+        R[n] = w[n][0];
+        qln = w[n][0];
+        w[n][0] = q[st];
+      }
+      pl[n] = qln;
+    }
+  }
+};
+
 struct SweepArgs {
   const double *w0, *bcc0, *bxf;
   double *flx, *ey, *ez;          // this direction's flux (face-shaped) and face EMFs
@@ -147,7 +208,10 @@ struct UpdArgs {
 // (hydro_update.cpp:55-80 order).  No LDS, no barrier: waves run free, so the memory-bound
 // update of one wave hides under the Riemann arithmetic of the others.  One face per chunk
 // (1/ML) is computed twice.
-constexpr int ML = 32;            // faces marched per thread (chunk length)
+#ifndef AKMI_ML
+#define AKMI_ML 32
+#endif
+constexpr int ML = AKMI_ML;            // faces marched per thread (chunk length)
 
 template <int DIR, int RECON, bool MHD>
 __global__ void __launch_bounds__(SX*SY)
@@ -174,29 +238,51 @@ k_sweep_update(Geo g, double gamma, SweepArgs a, UpdArgs u, int nouter) {
   }
   if (!lane_ok) return;
   constexpr int ivx = 1 + DIR, ivy = 1 + (DIR + 1)%3, ivz = 1 + (DIR + 2)%3;
+  constexpr int iby = (DIR + 1)%3, ibz = (DIR + 2)%3;
+  constexpr int NV = MHD ? 7 : 5;
   const int shi = (DIR == 1) ? a.ju : a.ku;           // last face along the sweep
   const bool col_active = (i >= g.is) && (i <= g.ie) &&
                           ((DIR == 1) ? (k >= g.ks && k <= g.ke) : (j >= g.js && j <= g.je));
   const int clo = (DIR == 1) ? g.js : g.ks, chi = (DIR == 1) ? g.je : g.ke;
   const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
   const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  const long st = (DIR == 1) ? (long)g.N1 : (long)g.N1*g.N2;
+  // sweep-aligned variable order: d, vx, vy, vz, e, (by, bz)
+  const double *pw = a.w0 + ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
+  const double *pv[NV];
+  pv[0] = pw; pv[1] = pw + ivx*cs; pv[2] = pw + ivy*cs; pv[3] = pw + ivz*cs; pv[4] = pw + 4*cs;
+  if constexpr (MHD) {
+    const double *pb = a.bcc0 + ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i);
+    pv[5] = pb + iby*cs; pv[6] = pb + ibz*cs;
+  }
+  Roll<RECON, NV> roll;
+  roll.init(pv, st);
+  const size_t fst = (DIR == 1) ? (size_t)a.f1 : (size_t)a.f1*a.f2;   // face-array stride
+  const double *pbx = MHD ? a.bxf + ix4(a.f3, a.f2, a.f1, m, k, j, i) : nullptr;
   double fp[5] = {0, 0, 0, 0, 0};
   for (int t = 0; t <= ML; ++t) {
     const int s = s0 + t;
     if (s > shi) break;
     if constexpr (DIR == 1) j = s; else k = s;
-    double fd, fx, fy, fz, fe, fby, fbz;
-    face_flux<DIR, RECON, MHD>(g, gamma, a.w0, a.bcc0, a.bxf, a.f3, a.f2, a.f1, m, k, j, i, fd, fx,
-                               fy, fz, fe, fby, fbz);
+    double L[NV], R[NV];
+    roll.step(pv, st, L, R);
+    double fd, fx, fy, fz, fe;
     if constexpr (MHD) {
+      Cons1D fl = hlld(gamma, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1], R[2], R[3], R[4],
+                       R[5], R[6], pbx[(size_t)t*fst]);
+      fd = fl.d; fx = fl.mx; fy = fl.my; fz = fl.mz; fe = fl.e;
       if (t < ML || s == shi) {
         // CornerE needs the sign of the mass flux and the two face EMFs of this direction
         a.flx[ix5(g.nvar, a.f3, a.f2, a.f1, m, 0, k, j, i)] = fd;
         const size_t ec = ix4(g.N3, g.N2, g.N1, m, k, j, i);
-        a.ey[ec] = -fby;
-        a.ez[ec] = fbz;
+        a.ey[ec] = -fl.by;
+        a.ez[ec] = fl.bz;
       }
+    } else {
+      hllc(gamma, L[0], L[1], L[2], L[3], L[4], R[0], R[1], R[2], R[3], R[4], fd, fx, fy, fz, fe);
     }
+#pragma unroll
+    for (int n = 0; n < NV; ++n) pv[n] += st;
     double fv[5];
     fv[0] = fd; fv[ivx] = fx; fv[ivy] = fy; fv[ivz] = fz; fv[4] = fe;
     const int sc = s - 1;                               // cell finished by this face
@@ -450,8 +536,11 @@ k_c2p_newdt(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ 
     if (v > 0.0) {
       // min over cells of fl(dx/a) == fl(dx/max a): correctly rounded division is monotone
       const double d = g.dx[3*m + threadIdx.x]/v;
-      atomicMin(reinterpret_cast<unsigned long long *>(&dt3[threadIdx.x]),
-                (unsigned long long)__double_as_longlong(d));
+      // one word saturates at ~88 atomics/us on this chip: only workgroups that can lower the
+      // running minimum issue the atomic (the plain read is a filter, the atomic decides)
+      if (d < __hip_atomic_load(&dt3[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMin(reinterpret_cast<unsigned long long *>(&dt3[threadIdx.x]),
+                  (unsigned long long)__double_as_longlong(d));
     }
   }
 }

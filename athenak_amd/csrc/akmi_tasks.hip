@@ -152,8 +152,9 @@ __device__ __forceinline__ void block_min3_atomic(double a, double b, double c,
   if (threadIdx.y == 0 && threadIdx.x < 3) {
     double v = sm[threadIdx.x][0];
     for (int q = 1; q < BY; ++q) v = fmin(v, sm[threadIdx.x][q]);
-    atomicMin(reinterpret_cast<unsigned long long *>(&dt3[threadIdx.x]),
-              (unsigned long long)__double_as_longlong(v));
+    if (v < __hip_atomic_load(&dt3[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMin(reinterpret_cast<unsigned long long *>(&dt3[threadIdx.x]),
+                (unsigned long long)__double_as_longlong(v));
   }
 }
 

@@ -191,6 +191,12 @@ int akmi_mhd_c2p_newdt(const akmi_pack *p, double *u0, const double *bx1f,
                        const double *bx2f, const double *bx3f, double *w0, double *bcc0,
                        int do_newdt, int *counters, double *dt3, void *stream);
 
+/* ---- measurement utility ------------------------------------------------------------ *
+ * dst[i] = src[i] for n doubles with the library's own access pattern (8 B per lane,
+ * 512 B per wave, grid-stride): a kernel of KNOWN traffic (8n read + 8n written) used to
+ * calibrate the rocprofv3 FETCH_SIZE/WRITE_SIZE counters on gfx950 (tools/pmc.sh). */
+int akmi_calib_copy(double *dst, const double *src, long long n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
