@@ -70,6 +70,28 @@ AKMI_DEV void face_states(const double *__restrict__ q, long s, double &ql, doub
   }
 }
 
+// Same, addressed as (wave-uniform base pointer) + (32-bit per-lane element offset): the
+// stencil neighbours differ only in the uniform part, so the compiler keeps ONE offset VGPR per
+// lane and forms the neighbour addresses on the scalar unit (global_load ... v_off, s[base]).
+template <int RECON>
+AKMI_DEV void face_states_u(const double *__restrict__ base, unsigned off, long s, double &ql,
+                            double &qr) {
+  double dummy;
+  if constexpr (RECON == 1) {
+    double qm2 = (base - 2*s)[off], qm1 = (base - s)[off], q0 = base[off], qp1 = (base + s)[off];
+    plm(qm2, qm1, q0, ql, dummy);
+    plm(qm1, q0, qp1, dummy, qr);
+  } else if constexpr (RECON == 2) {
+    double qm3 = (base - 3*s)[off], qm2 = (base - 2*s)[off], qm1 = (base - s)[off], q0 = base[off],
+           qp1 = (base + s)[off], qp2 = (base + 2*s)[off];
+    ppm4(qm3, qm2, qm1, q0, qp1, ql, dummy);
+    ppm4(qm2, qm1, q0, qp1, qp2, dummy, qr);
+  } else {
+    ql = (base - s)[off];
+    qr = base[off];
+  }
+}
+
 // HLLC, src/hydro/rsolvers/hllc_hyd.hpp:20-115.  States are (d, vx, vy, vz, e_int) with
 // vx along the sweep; flux is (d, mx, my, mz, E).
 AKMI_DEV void hllc(double gamma, double wl_idn, double wl_ivx, double wl_ivy, double wl_ivz,

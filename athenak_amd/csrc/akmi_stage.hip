@@ -65,19 +65,21 @@ __device__ __forceinline__ void face_flux(const Geo &g, double gamma,
   constexpr int ivx = 1 + DIR, ivy = 1 + (DIR + 1)%3, ivz = 1 + (DIR + 2)%3;
   const long s = (DIR == 0) ? 1 : (DIR == 1 ? (long)g.N1 : (long)g.N1*g.N2);
   const size_t cs = (size_t)g.N3*g.N2*g.N1;
-  const double *q = w0 + ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
+  // wave-uniform bases (m comes from blockIdx) + one 32-bit in-variable offset per lane
+  const double *q = w0 + (size_t)m*g.nvar*cs;
+  const unsigned off = (unsigned)(((size_t)k*g.N2 + j)*g.N1 + i);
   double ld, lx, ly, lz, le, rd, rx, ry, rz, re;
-  face_states<RECON>(q + 0*cs, s, ld, rd);
-  face_states<RECON>(q + ivx*cs, s, lx, rx);
-  face_states<RECON>(q + ivy*cs, s, ly, ry);
-  face_states<RECON>(q + ivz*cs, s, lz, rz);
-  face_states<RECON>(q + 4*cs, s, le, re);
+  face_states_u<RECON>(q + 0*cs, off, s, ld, rd);
+  face_states_u<RECON>(q + ivx*cs, off, s, lx, rx);
+  face_states_u<RECON>(q + ivy*cs, off, s, ly, ry);
+  face_states_u<RECON>(q + ivz*cs, off, s, lz, rz);
+  face_states_u<RECON>(q + 4*cs, off, s, le, re);
   if constexpr (MHD) {
     constexpr int iby = (DIR + 1)%3, ibz = (DIR + 2)%3;
-    const double *b = bcc0 + ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i);
+    const double *b = bcc0 + (size_t)m*3*cs;
     double lby, lbz, rby, rbz;
-    face_states<RECON>(b + iby*cs, s, lby, rby);
-    face_states<RECON>(b + ibz*cs, s, lbz, rbz);
+    face_states_u<RECON>(b + iby*cs, off, s, lby, rby);
+    face_states_u<RECON>(b + ibz*cs, off, s, lbz, rbz);
     const double bxi = bxf[ix4(f3, f2, f1, m, k, j, i)];
     Cons1D fl = hlld(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
     fd = fl.d; fx = fl.mx; fy = fl.my; fz = fl.mz; fe = fl.e; fby = fl.by; fbz = fl.bz;
@@ -87,66 +89,11 @@ __device__ __forceinline__ void face_flux(const Geo &g, double gamma,
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// Rolling reconstruction window for kernels that MARCH along the sweep direction.  Per
-// variable the thread keeps the last NW cells and the pending left state of the next face in
-// registers, loads ONE new cell per step and evaluates ONE limiter per cell (the plain
-// per-face kernels evaluate two: every cell's slope is needed by both of its faces).  The
-// arithmetic per (cell, variable) is the same function of the same inputs as face_states<>,
-// so results are bit-identical.
+// Window sizes of the marching kernels per reconstruction (cells kept per variable)
 template <int RECON> struct RollCfg;
-template <> struct RollCfg<0> { static constexpr int NW = 1, BACK = 1, FWD = 0; };   // dc
-template <> struct RollCfg<1> { static constexpr int NW = 2, BACK = 2, FWD = 1; };   // plm
-template <> struct RollCfg<2> { static constexpr int NW = 4, BACK = 3, FWD = 2; };   // ppm4
-
-template <int RECON, int NV>
-struct Roll {
-  static constexpr int NW = RollCfg<RECON>::NW;
-  double w[NV][NW];     // cells (s-NW+FWD .. s-1+FWD) relative to the current face s
-  double pl[NV];        // left state of the current face (from cell s-1)
-  // p[n] points at cell s0 (right cell of the first face); st = stride along the sweep
-  __device__ __forceinline__ void init(const double *const (&p)[NV], long st) {
-#pragma unroll
-    for (int n = 0; n < NV; ++n) {
-      const double *q = p[n];
-      double dummy;
-      if constexpr (RECON == 1) {
-        plm(q[-2*st], q[-st], q[0], pl[n], dummy);
-        w[n][0] = q[-st]; w[n][1] = q[0];
-      } else if constexpr (RECON == 2) {
-        ppm4(q[-3*st], q[-2*st], q[-st], q[0], q[st], pl[n], dummy);
-        w[n][0] = q[-2*st]; w[n][1] = q[-st]; w[n][2] = q[0]; w[n][3] = q[st];
-      } else {
-        pl[n] = q[-st];
-        w[n][0] = q[0];
-      }
-    }
-  }
-  // states of the current face; p[n] points at its right cell.  Advances the window.
-  __device__ __forceinline__ void step(const double *const (&p)[NV], long st, double (&L)[NV],
-                                       double (&R)[NV]) {
-#pragma unroll
-    for (int n = 0; n < NV; ++n) {
-      const double *q = p[n];
-      double qln;
-      L[n] = pl[n];
-      if constexpr (RECON == 1) {
-        const double qp = q[st];
-        plm(w[n][0], w[n][1], qp, qln, R[n]);
-        w[n][0] = w[n][1]; w[n][1] = qp;
-      } else if constexpr (RECON == 2) {
-        const double qp = q[2*st];
-        ppm4(w[n][0], w[n][1], w[n][2], w[n][3], qp, qln, R[n]);
-        w[n][0] = w[n][1]; w[n][1] = w[n][2]; w[n][2] = w[n][3]; w[n][3] = qp;
-      } else {
-        R[n] = w[n][0];
-        qln = w[n][0];
-        w[n][0] = q[st];
-      }
-      pl[n] = qln;
-    }
-  }
-};
+template <> struct RollCfg<0> { static constexpr int NW = 1; };   // dc
+template <> struct RollCfg<1> { static constexpr int NW = 2; };   // plm
+template <> struct RollCfg<2> { static constexpr int NW = 4; };   // ppm4
 
 struct SweepArgs {
   const double *w0, *bcc0, *bxf;
@@ -162,11 +109,15 @@ struct SweepArgs {
 template <int DIR, int RECON, bool MHD, bool ECC>
 __global__ void __launch_bounds__(SX*SY)
 k_sweep(Geo g, double gamma, SweepArgs a, int nk) {
-  const int i = a.il - (ECC ? 1 : 0) + blockIdx.x*SX + threadIdx.x;
-  const int j = a.jl + blockIdx.y*SY + threadIdx.y;
+  // lanes run over the flattened rows [jl,ju] x [0,N1): contiguous in memory, and the few
+  // ghost columns outside [il,iu] cost 2-4 idle lanes per 260 instead of a mostly empty wave
+  const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;
+  const int jj = (int)(p/g.N1);
+  const int i = (int)(p - (long)jj*g.N1);
+  const int j = a.jl + jj;
   const int m = blockIdx.z/nk;
   const int k = a.kl + (blockIdx.z - m*nk);
-  if (i > a.iu || j > a.ju) return;
+  if (j > a.ju || i < a.il - (ECC ? 1 : 0) || i > a.iu) return;
   const size_t cs = (size_t)g.N3*g.N2*g.N1;
   if constexpr (ECC) {
     const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
@@ -214,7 +165,7 @@ struct UpdArgs {
 constexpr int ML = AKMI_ML;            // faces marched per thread (chunk length)
 
 template <int DIR, int RECON, bool MHD>
-__global__ void __launch_bounds__(SX*SY)
+__global__ void __launch_bounds__(SX*SY, (RECON == 2 ? 2 : 3))
 k_sweep_update(Geo g, double gamma, SweepArgs a, UpdArgs u, int nouter) {
   static_assert(DIR == 1 || DIR == 2, "marching kernel is for the x2/x3 sweeps");
   int i, j, k, m, s0;
@@ -240,6 +191,19 @@ k_sweep_update(Geo g, double gamma, SweepArgs a, UpdArgs u, int nouter) {
   constexpr int ivx = 1 + DIR, ivy = 1 + (DIR + 1)%3, ivz = 1 + (DIR + 2)%3;
   constexpr int iby = (DIR + 1)%3, ibz = (DIR + 2)%3;
   constexpr int NV = MHD ? 7 : 5;
+  constexpr int NW = RollCfg<RECON>::NW;
+  constexpr int NT = SX*SY;
+  // marching state of this thread, parked in LDS ("LDS as an extension of the register file":
+  // slot s of thread t lives at sm[s*NT + t], consecutive lanes -> consecutive banks):
+  //   W(n,c)  last NW cells of variable n       PL(n)  pending left state of the next face
+  //   FP(n)   flux of the previous face
+  // Keeping it out of the VGPRs lets the kernel run at the occupancy of the plain Riemann
+  // kernel while every cell is loaded from HBM exactly once per sweep.
+  __shared__ double sm[(NV*NW + NV + 5)*NT];
+  double *my = sm + threadIdx.y*SX + threadIdx.x;
+#define W_(n, c) my[((n)*NW + (c))*NT]
+#define PL_(n) my[(NV*NW + (n))*NT]
+#define FP_(n) my[(NV*NW + NV + (n))*NT]
   const int shi = (DIR == 1) ? a.ju : a.ku;           // last face along the sweep
   const bool col_active = (i >= g.is) && (i <= g.ie) &&
                           ((DIR == 1) ? (k >= g.ks && k <= g.ke) : (j >= g.js && j <= g.je));
@@ -247,25 +211,65 @@ k_sweep_update(Geo g, double gamma, SweepArgs a, UpdArgs u, int nouter) {
   const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
   const size_t cs = (size_t)g.N3*g.N2*g.N1;
   const long st = (DIR == 1) ? (long)g.N1 : (long)g.N1*g.N2;
-  // sweep-aligned variable order: d, vx, vy, vz, e, (by, bz)
-  const double *pw = a.w0 + ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
-  const double *pv[NV];
-  pv[0] = pw; pv[1] = pw + ivx*cs; pv[2] = pw + ivy*cs; pv[3] = pw + ivz*cs; pv[4] = pw + 4*cs;
-  if constexpr (MHD) {
-    const double *pb = a.bcc0 + ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i);
-    pv[5] = pb + iby*cs; pv[6] = pb + ibz*cs;
+  // wave-uniform variable bases in sweep-aligned order d, vx, vy, vz, e, (by, bz) + one
+  // per-lane element offset that advances by st per step
+  const double *wb = a.w0 + (size_t)m*g.nvar*cs;
+  const double *bb = MHD ? a.bcc0 + (size_t)m*3*cs : nullptr;
+  size_t off = ((size_t)k*g.N2 + j)*g.N1 + i;
+  auto base = [&](int n) -> const double * {
+    return n == 0 ? wb : n == 1 ? wb + ivx*cs : n == 2 ? wb + ivy*cs : n == 3 ? wb + ivz*cs
+         : n == 4 ? wb + 4*cs : n == 5 ? bb + iby*cs : bb + ibz*cs;
+  };
+  // prime the window: left state of the first face comes from cell s0-1
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    const double *q = base(n) + off;
+    double pl, dummy;
+    if constexpr (RECON == 1) {
+      const double qa = q[-2*st], qb = q[-st], qc = q[0];
+      plm(qa, qb, qc, pl, dummy);
+      W_(n, 0) = qb; W_(n, 1) = qc;
+    } else if constexpr (RECON == 2) {
+      const double qa = q[-3*st], qb = q[-2*st], qc = q[-st], qd = q[0], qe = q[st];
+      ppm4(qa, qb, qc, qd, qe, pl, dummy);
+      W_(n, 0) = qb; W_(n, 1) = qc; W_(n, 2) = qd; W_(n, 3) = qe;
+    } else {
+      pl = q[-st];
+      W_(n, 0) = q[0];
+    }
+    PL_(n) = pl;
   }
-  Roll<RECON, NV> roll;
-  roll.init(pv, st);
   const size_t fst = (DIR == 1) ? (size_t)a.f1 : (size_t)a.f1*a.f2;   // face-array stride
   const double *pbx = MHD ? a.bxf + ix4(a.f3, a.f2, a.f1, m, k, j, i) : nullptr;
-  double fp[5] = {0, 0, 0, 0, 0};
   for (int t = 0; t <= ML; ++t) {
     const int s = s0 + t;
     if (s > shi) break;
     if constexpr (DIR == 1) j = s; else k = s;
     double L[NV], R[NV];
-    roll.step(pv, st, L, R);
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const double *q = base(n) + off;
+      double qln;
+      L[n] = PL_(n);
+      if constexpr (RECON == 1) {
+        const double qp = q[st];
+        const double w0 = W_(n, 0), w1 = W_(n, 1);
+        plm(w0, w1, qp, qln, R[n]);
+        W_(n, 0) = w1; W_(n, 1) = qp;
+      } else if constexpr (RECON == 2) {
+        const double qp = q[2*st];
+        const double w0 = W_(n, 0), w1 = W_(n, 1), w2 = W_(n, 2), w3 = W_(n, 3);
+        ppm4(w0, w1, w2, w3, qp, qln, R[n]);
+        W_(n, 0) = w1; W_(n, 1) = w2; W_(n, 2) = w3; W_(n, 3) = qp;
+      } else {
+        const double w0 = W_(n, 0);
+        R[n] = w0;
+        qln = w0;
+        W_(n, 0) = q[st];
+      }
+      PL_(n) = qln;
+    }
+    off += st;
     double fd, fx, fy, fz, fe;
     if constexpr (MHD) {
       Cons1D fl = hlld(gamma, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1], R[2], R[3], R[4],
@@ -281,8 +285,6 @@ k_sweep_update(Geo g, double gamma, SweepArgs a, UpdArgs u, int nouter) {
     } else {
       hllc(gamma, L[0], L[1], L[2], L[3], L[4], R[0], R[1], R[2], R[3], R[4], fd, fx, fy, fz, fe);
     }
-#pragma unroll
-    for (int n = 0; n < NV; ++n) pv[n] += st;
     double fv[5];
     fv[0] = fd; fv[ivx] = fx; fv[ivy] = fy; fv[ivz] = fz; fv[4] = fe;
     const int sc = s - 1;                               // cell finished by this face
@@ -293,12 +295,13 @@ k_sweep_update(Geo g, double gamma, SweepArgs a, UpdArgs u, int nouter) {
       for (int n = 0; n < 5; ++n) {
         double divf = (u.flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, n, kc, jc, i + 1)] -
                        u.flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, n, kc, jc, i)])/dx1;
+        const double fprev = FP_(n);
         if constexpr (DIR == 1) {
-          divf += (fv[n] - fp[n])/dx2;
+          divf += (fv[n] - fprev)/dx2;
         } else {
           divf += (u.flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, n, kc, jc + 1, i)] -
                    u.flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, n, kc, jc, i)])/dx2;
-          divf += (fv[n] - fp[n])/dx3;
+          divf += (fv[n] - fprev)/dx3;
         }
         const double u0v = u.u0[c + n*cs];
         const double u1v = u.copy_u1 ? u0v : u.u1[c + n*cs];
@@ -307,8 +310,11 @@ k_sweep_update(Geo g, double gamma, SweepArgs a, UpdArgs u, int nouter) {
       }
     }
 #pragma unroll
-    for (int n = 0; n < 5; ++n) fp[n] = fv[n];
+    for (int n = 0; n < 5; ++n) FP_(n) = fv[n];
   }
+#undef W_
+#undef PL_
+#undef FP_
 }
 
 // 1-D problems: the sweep direction is the lane direction, so neighbouring faces are
@@ -365,12 +371,14 @@ k_corner3(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e2x
           const double *__restrict__ c3, const double *__restrict__ flx1,
           const double *__restrict__ flx2, const double *__restrict__ flx3,
           double *__restrict__ e1, double *__restrict__ e2, double *__restrict__ e3) {
-  const int i = g.is + blockIdx.x*SX + threadIdx.x;
-  const int j = g.js + blockIdx.y*SY + threadIdx.y;
+  const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;   // rows [js,je+1] x N1
+  const int jj = (int)(p/g.N1);
+  const int i = (int)(p - (long)jj*g.N1);
+  const int j = g.js + jj;
   const int nk = g.ke - g.ks + 2;
   const int m = blockIdx.z/nk;
   const int k = g.ks + (blockIdx.z - m*nk);
-  if (i > g.ie + 1 || j > g.je + 1) return;
+  if (i < g.is || i > g.ie + 1 || j > g.je + 1) return;
   const double f1_k = flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k, j, i)];
   const double f1_km = flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k - 1, j, i)];
   const double f1_jm = flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k, j - 1, i)];
@@ -424,12 +432,14 @@ k_ct_copy(Geo g, double gam0, double gam1, double beta_dt, const double *__restr
           const double *__restrict__ e2, const double *__restrict__ e3, double *__restrict__ b0x1f,
           double *__restrict__ b0x2f, double *__restrict__ b0x3f, double *__restrict__ b1x1f,
           double *__restrict__ b1x2f, double *__restrict__ b1x3f, int copy_b1) {
-  const int i = g.is + blockIdx.x*SX + threadIdx.x;
-  const int j = g.js + blockIdx.y*SY + threadIdx.y;
+  const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;   // rows [js,je+1] x N1
+  const int jj = (int)(p/g.N1);
+  const int i = (int)(p - (long)jj*g.N1);
+  const int j = g.js + jj;
   const int nk = g.ke - g.ks + 2;
   const int m = blockIdx.z/nk;
   const int k = g.ks + (blockIdx.z - m*nk);
-  if (i > g.ie + 1 || j > g.je + 1) return;
+  if (i < g.is || i > g.ie + 1 || j > g.je + 1) return;
   const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
 #define E1(k, j, i) e1[ix4(g.N3 + 1, g.N2 + 1, g.N1, m, k, j, i)]
 #define E2(k, j, i) e2[ix4(g.N3 + 1, g.N2, g.N1 + 1, m, k, j, i)]
@@ -485,12 +495,13 @@ k_c2p_newdt(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ 
             double *__restrict__ w0, double *__restrict__ bcc0, int do_newdt,
             int *__restrict__ counters, double *__restrict__ dt3) {
   __shared__ double sm[3][SY];
-  const int i = blockIdx.x*SX + threadIdx.x;
-  const int j = blockIdx.y*SY + threadIdx.y;
+  const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;   // whole (j,i) plane
+  const int j = (int)(p/g.N1);
+  const int i = (int)(p - (long)j*g.N1);
   const int m = blockIdx.z/g.N3;
   const int k = blockIdx.z - m*g.N3;
   double mv1 = 0.0, mv2 = 0.0, mv3 = 0.0;
-  if (i < g.N1 && j < g.N2) {
+  if (j < g.N2) {
     const size_t cs = (size_t)g.N3*g.N2*g.N1;
     const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
     double ud = u0[c], umx = u0[c + cs], umy = u0[c + 2*cs], umz = u0[c + 3*cs], ue = u0[c + 4*cs];
@@ -553,7 +564,8 @@ __global__ void k_init_dt3(double *dt3) {
 template <int DIR, bool MHD, bool ECC>
 static int launch_sweep(const Geo &g, double gamma, int recon, const SweepArgs &a, hipStream_t st) {
   int nk = a.ku - a.kl + 1;
-  dim3 grid(cdiv(a.iu - a.il + 1 + (ECC ? 1 : 0), SX), cdiv(a.ju - a.jl + 1, SY), nk*g.nmb), block(SX, SY);
+  long np = (long)(a.ju - a.jl + 1)*g.N1;
+  dim3 grid((unsigned)((np + SX*SY - 1)/(SX*SY)), 1, nk*g.nmb), block(SX, SY);
   if (recon == AKMI_RECON_PLM) k_sweep<DIR, 1, MHD, ECC><<<grid, block, 0, st>>>(g, gamma, a, nk);
   else if (recon == AKMI_RECON_PPM4) k_sweep<DIR, 2, MHD, ECC><<<grid, block, 0, st>>>(g, gamma, a, nk);
   else k_sweep<DIR, 0, MHD, ECC><<<grid, block, 0, st>>>(g, gamma, a, nk);
@@ -630,7 +642,8 @@ static int stage_update(const akmi_pack *p, int recon, double gam0, double gam1,
   if (rc != AKMI_COMPLETE || !MHD) return rc;
   // corner E + CT
   if (ndim == 3) {
-    dim3 grid(cdiv(g.nx1 + 1, SX), cdiv(g.nx2 + 1, SY), (g.nx3 + 1)*g.nmb), block(SX, SY);
+    long np = (long)(g.nx2 + 1)*g.N1;
+    dim3 grid((unsigned)((np + SX*SY - 1)/(SX*SY)), 1, (g.nx3 + 1)*g.nmb), block(SX, SY);
     k_corner3<<<grid, block, 0, st>>>(g, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5],
                                       w.ecc[0], w.ecc[1], w.ecc[2], w.flx1, w.flx2, w.flx3, w.e1,
                                       w.e2, w.e3);
@@ -641,7 +654,8 @@ static int stage_update(const akmi_pack *p, int recon, double gam0, double gam1,
                            w.flx1, w.flx2, w.flx3, w.e1, w.e2, w.e3, st);
     if (rc != AKMI_COMPLETE) return rc;
   }
-  dim3 grid(cdiv(g.nx1 + 1, SX), cdiv(g.je - g.js + 2, SY), (g.ke - g.ks + 2)*g.nmb), block(SX, SY);
+  long npc = (long)(g.je - g.js + 2)*g.N1;
+  dim3 grid((unsigned)((npc + SX*SY - 1)/(SX*SY)), 1, (g.ke - g.ks + 2)*g.nmb), block(SX, SY);
   k_ct_copy<<<grid, block, 0, st>>>(g, gam0, gam1, beta_dt, w.e1, w.e2, w.e3, b0x1f, b0x2f, b0x3f,
                                     b1x1f, b1x2f, b1x3f, copy_u1);
   AKMI_CHECK_LAUNCH("ct");
@@ -681,7 +695,7 @@ int akmi_hydro_c2p_newdt(const akmi_pack *p, double *u0, double *w0, int do_newd
   Geo g = make_geo(p);
   hipStream_t st = (hipStream_t)stream;
   if (do_newdt) k_init_dt3<<<1, 64, 0, st>>>(dt3);
-  dim3 grid(cdiv(g.N1, SX), cdiv(g.N2, SY), g.N3*g.nmb), block(SX, SY);
+  dim3 grid((unsigned)(((long)g.N2*g.N1 + SX*SY - 1)/(SX*SY)), 1, g.N3*g.nmb), block(SX, SY);
   k_c2p_newdt<false><<<grid, block, 0, st>>>(g, make_eos(p), u0, nullptr, nullptr, nullptr, w0,
                                              nullptr, do_newdt, counters, dt3);
   AKMI_CHECK_LAUNCH("hydro_c2p_newdt");
@@ -694,7 +708,7 @@ int akmi_mhd_c2p_newdt(const akmi_pack *p, double *u0, const double *bx1f, const
   Geo g = make_geo(p);
   hipStream_t st = (hipStream_t)stream;
   if (do_newdt) k_init_dt3<<<1, 64, 0, st>>>(dt3);
-  dim3 grid(cdiv(g.N1, SX), cdiv(g.N2, SY), g.N3*g.nmb), block(SX, SY);
+  dim3 grid((unsigned)(((long)g.N2*g.N1 + SX*SY - 1)/(SX*SY)), 1, g.N3*g.nmb), block(SX, SY);
   k_c2p_newdt<true><<<grid, block, 0, st>>>(g, make_eos(p), u0, bx1f, bx2f, bx3f, w0, bcc0,
                                             do_newdt, counters, dt3);
   AKMI_CHECK_LAUNCH("mhd_c2p_newdt");
