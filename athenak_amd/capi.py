@@ -34,7 +34,8 @@ SYMBOLS = [
     "akmi_bvals_cc_unpack", "akmi_bvals_cc_segsize", "akmi_bvals_fc_local", "akmi_bvals_fc_pack",
     "akmi_bvals_fc_unpack", "akmi_bvals_fc_segsize", "akmi_hydro_bcs", "akmi_bfield_bcs",
     "akmi_stage_workspace_bytes", "akmi_hydro_stage_update", "akmi_mhd_stage_update",
-    "akmi_hydro_c2p_newdt", "akmi_mhd_c2p_newdt", "akmi_calib_copy",
+    "akmi_hydro_c2p_newdt", "akmi_mhd_c2p_newdt", "akmi_calib_copy", "akmi_hydro_stage_fused", "akmi_mhd_stage_fused",
+    "akmi_hydro_c2p_shell", "akmi_mhd_c2p_shell",
 ]
 
 _LIB = None

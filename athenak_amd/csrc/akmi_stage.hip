@@ -14,6 +14,7 @@
 //   kernel: the three direction maxima of |v|+c_f are reduced per wavefront (DPP shuffles),
 //   per workgroup (LDS) and the workgroup's dx/max enters a 64-bit atomicMin.  Division is
 //   monotone, so min_cells fl(dx/a) == fl(dx/max_cells a): identical to the reference scan.
+#include <cstdlib>
 #include "akmi_common.hpp"
 
 using namespace akmi;
@@ -28,6 +29,7 @@ struct StageWs {
   double *efc[6];
   double *ecc[3];
   double *e1, *e2, *e3;
+  double *acc;                    // dF1/dx1 + dF2/dx2 per cell and variable (3-D path)
   size_t total;
 };
 
@@ -40,6 +42,7 @@ static StageWs carve(const Geo &g, int is_mhd, void *ws) {
   size_t off = 0;
   auto take = [&](size_t n) { double *r = p ? p + off : nullptr; off += (n + 31) & ~(size_t)31; return r; };
   w.flx1 = take(n1); w.flx2 = take(n2); w.flx3 = take(n3);
+  w.acc = take(nmb*nv*g.N3*g.N2*g.N1);
   for (int q = 0; q < 6; ++q) w.efc[q] = nullptr;
   for (int q = 0; q < 3; ++q) w.ecc[q] = nullptr;
   w.e1 = w.e2 = w.e3 = nullptr;
@@ -149,6 +152,7 @@ struct UpdArgs {
   double *u0, *u1;
   const double *flx1, *flx2;      // fluxes of the earlier sweeps (face-shaped)
   int copy_u1;
+  double *acc;                    // partial divergence (written by the x2 march, read by x3)
 };
 
 // last-direction sweep with the RK update fused, as a MARCH along the sweep direction:
@@ -159,12 +163,18 @@ struct UpdArgs {
 // (hydro_update.cpp:55-80 order).  No LDS, no barrier: waves run free, so the memory-bound
 // update of one wave hides under the Riemann arithmetic of the others.  One face per chunk
 // (1/ML) is computed twice.
+#ifndef AKMI_X2_MARCH
+#define AKMI_X2_MARCH 1
+#endif
 #ifndef AKMI_ML
 #define AKMI_ML 32
 #endif
 constexpr int ML = AKMI_ML;            // faces marched per thread (chunk length)
 
-template <int DIR, int RECON, bool MHD>
+// MODE 0: last direction -- finish the RK update.  MODE 1 (x2 sweep of 3-D runs): store the
+// partial divergence acc = dF1/dx1 + dF2/dx2 for the x3 march, which then needs one array
+// instead of two face pairs per variable (USEACC).  Rounding sequence unchanged.
+template <int DIR, int RECON, bool MHD, int MODE, bool USEACC>
 __global__ void __launch_bounds__(SX*SY, (RECON == 2 ? 2 : 3))
 k_sweep_update(Geo g, double gamma, SweepArgs a, UpdArgs u, int nouter) {
   static_assert(DIR == 1 || DIR == 2, "marching kernel is for the x2/x3 sweeps");
@@ -180,12 +190,14 @@ k_sweep_update(Geo g, double gamma, SweepArgs a, UpdArgs u, int nouter) {
     k = s0;
     lane_ok = (j <= a.ju) && (i >= a.il) && (i <= a.iu);
   } else {
-    i = a.il + blockIdx.x*SX + threadIdx.x;
-    m = blockIdx.z/nouter;
-    k = a.kl + (blockIdx.z - m*nouter);
-    s0 = a.jl + (blockIdx.y*SY + threadIdx.y)*ML;
+    const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;   // planes [kl,ku] x N1
+    const int kk = (int)(p/g.N1);
+    i = (int)(p - (long)kk*g.N1);
+    k = a.kl + kk;
+    m = blockIdx.z;
+    s0 = a.jl + blockIdx.y*ML;
     j = s0;
-    lane_ok = (i <= a.iu) && (s0 <= a.ju);
+    lane_ok = (k <= a.ku) && (i >= a.il) && (i <= a.iu);
   }
   if (!lane_ok) return;
   constexpr int ivx = 1 + DIR, ivy = 1 + (DIR + 1)%3, ivz = 1 + (DIR + 2)%3;
@@ -293,20 +305,30 @@ k_sweep_update(Geo g, double gamma, SweepArgs a, UpdArgs u, int nouter) {
       const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, kc, jc, i);
 #pragma unroll
       for (int n = 0; n < 5; ++n) {
-        double divf = (u.flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, n, kc, jc, i + 1)] -
-                       u.flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, n, kc, jc, i)])/dx1;
         const double fprev = FP_(n);
+        double divf;
+        if constexpr (USEACC) {
+          divf = u.acc[c + n*cs];
+        } else {
+          divf = (u.flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, n, kc, jc, i + 1)] -
+                  u.flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, n, kc, jc, i)])/dx1;
+        }
         if constexpr (DIR == 1) {
           divf += (fv[n] - fprev)/dx2;
         } else {
-          divf += (u.flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, n, kc, jc + 1, i)] -
-                   u.flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, n, kc, jc, i)])/dx2;
+          if constexpr (!USEACC)
+            divf += (u.flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, n, kc, jc + 1, i)] -
+                     u.flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, n, kc, jc, i)])/dx2;
           divf += (fv[n] - fprev)/dx3;
         }
-        const double u0v = u.u0[c + n*cs];
-        const double u1v = u.copy_u1 ? u0v : u.u1[c + n*cs];
-        if (u.copy_u1) u.u1[c + n*cs] = u0v;
-        u.u0[c + n*cs] = u.gam0*u0v + u.gam1*u1v - u.beta_dt*divf;
+        if constexpr (MODE == 1) {
+          u.acc[c + n*cs] = divf;
+        } else {
+          const double u0v = u.u0[c + n*cs];
+          const double u1v = u.copy_u1 ? u0v : u.u1[c + n*cs];
+          if (u.copy_u1) u.u1[c + n*cs] = u0v;
+          u.u0[c + n*cs] = u.gam0*u0v + u.gam1*u1v - u.beta_dt*divf;
+        }
       }
     }
 #pragma unroll
@@ -370,14 +392,14 @@ k_corner3(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e2x
           const double *__restrict__ c1, const double *__restrict__ c2,
           const double *__restrict__ c3, const double *__restrict__ flx1,
           const double *__restrict__ flx2, const double *__restrict__ flx3,
-          double *__restrict__ e1, double *__restrict__ e2, double *__restrict__ e3) {
+          double *__restrict__ e1, double *__restrict__ e2, double *__restrict__ e3, int k0,
+          int nk) {
   const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;   // rows [js,je+1] x N1
   const int jj = (int)(p/g.N1);
   const int i = (int)(p - (long)jj*g.N1);
   const int j = g.js + jj;
-  const int nk = g.ke - g.ks + 2;
   const int m = blockIdx.z/nk;
-  const int k = g.ks + (blockIdx.z - m*nk);
+  const int k = k0 + (blockIdx.z - m*nk);
   if (i < g.is || i > g.ie + 1 || j > g.je + 1) return;
   const double f1_k = flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k, j, i)];
   const double f1_km = flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k - 1, j, i)];
@@ -431,20 +453,22 @@ __global__ void __launch_bounds__(SX*SY)
 k_ct_copy(Geo g, double gam0, double gam1, double beta_dt, const double *__restrict__ e1,
           const double *__restrict__ e2, const double *__restrict__ e3, double *__restrict__ b0x1f,
           double *__restrict__ b0x2f, double *__restrict__ b0x3f, double *__restrict__ b1x1f,
-          double *__restrict__ b1x2f, double *__restrict__ b1x3f, int copy_b1) {
+          double *__restrict__ b1x2f, double *__restrict__ b1x3f, int copy_b1, int k0, int nk,
+          int kb) {
+  // planes k in [k0, k0+nk-1]; x1f/x2f faces are updated for k <= kb (cells of this slab),
+  // x3f faces for every k of the launch (the last slab also owns face ke+1)
   const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;   // rows [js,je+1] x N1
   const int jj = (int)(p/g.N1);
   const int i = (int)(p - (long)jj*g.N1);
   const int j = g.js + jj;
-  const int nk = g.ke - g.ks + 2;
   const int m = blockIdx.z/nk;
-  const int k = g.ks + (blockIdx.z - m*nk);
+  const int k = k0 + (blockIdx.z - m*nk);
   if (i < g.is || i > g.ie + 1 || j > g.je + 1) return;
   const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
 #define E1(k, j, i) e1[ix4(g.N3 + 1, g.N2 + 1, g.N1, m, k, j, i)]
 #define E2(k, j, i) e2[ix4(g.N3 + 1, g.N2, g.N1 + 1, m, k, j, i)]
 #define E3(k, j, i) e3[ix4(g.N3, g.N2 + 1, g.N1 + 1, m, k, j, i)]
-  if (j <= g.je && k <= g.ke) {
+  if (j <= g.je && k <= kb) {
     size_t c = ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i);
     const double b0v = b0x1f[c];
     const double b1v = copy_b1 ? b0v : b1x1f[c];
@@ -456,7 +480,7 @@ k_ct_copy(Geo g, double gam0, double gam1, double beta_dt, const double *__restr
     }
     if (copy_b1) b1x1f[c] = b0v;
   }
-  if (i <= g.ie && k <= g.ke) {
+  if (i <= g.ie && k <= kb) {
     size_t c = ix4(g.N3, g.N2 + 1, g.N1, m, k, j, i);
     const double b0v = b0x2f[c];
     const double b1v = copy_b1 ? b0v : b1x2f[c];
@@ -493,15 +517,18 @@ __global__ void __launch_bounds__(SX*SY)
 k_c2p_newdt(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ bx1f,
             const double *__restrict__ bx2f, const double *__restrict__ bx3f,
             double *__restrict__ w0, double *__restrict__ bcc0, int do_newdt,
-            int *__restrict__ counters, double *__restrict__ dt3) {
+            int *__restrict__ counters, double *__restrict__ dt3, int il, int iu, int jl, int ju,
+            int k0, int nk) {
+  // cells [il,iu] x [jl,ju] x [k0,k0+nk-1]; lanes run over the flattened rows [jl,ju] x N1
   __shared__ double sm[3][SY];
-  const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;   // whole (j,i) plane
-  const int j = (int)(p/g.N1);
-  const int i = (int)(p - (long)j*g.N1);
-  const int m = blockIdx.z/g.N3;
-  const int k = blockIdx.z - m*g.N3;
+  const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;
+  const int jj = (int)(p/g.N1);
+  const int j = jl + jj;
+  const int i = (int)(p - (long)jj*g.N1);
+  const int m = blockIdx.z/nk;
+  const int k = k0 + (blockIdx.z - m*nk);
   double mv1 = 0.0, mv2 = 0.0, mv3 = 0.0;
-  if (j < g.N2) {
+  if (j <= ju && i >= il && i <= iu) {
     const size_t cs = (size_t)g.N3*g.N2*g.N1;
     const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
     double ud = u0[c], umx = u0[c + cs], umy = u0[c + 2*cs], umz = u0[c + 3*cs], ue = u0[c + 4*cs];
@@ -573,7 +600,7 @@ static int launch_sweep(const Geo &g, double gamma, int recon, const SweepArgs &
   return AKMI_COMPLETE;
 }
 
-template <int DIR, bool MHD>
+template <int DIR, bool MHD, int MODE = 0, bool USEACC = false>
 static int launch_sweep_update(const Geo &g, double gamma, int recon, const SweepArgs &a,
                                const UpdArgs &u, hipStream_t st) {
   if constexpr (DIR == 0) {
@@ -583,32 +610,160 @@ static int launch_sweep_update(const Geo &g, double gamma, int recon, const Swee
     else k_sweep_update_1d<0, MHD><<<grid, block, 0, st>>>(g, gamma, a, u);
   } else {
     dim3 grid, block(SX, SY);
-    int nouter = 1;
     if (DIR == 2) {
       long np = (long)(a.ju - a.jl + 1)*g.N1;          // flattened rows
-      grid = dim3((unsigned)((np + SX*SY - 1)/(SX*SY)), cdiv(a.ku - a.kl + 1, ML), g.nmb);
+      grid = dim3((unsigned)((np + SX*SY - 1)/(SX*SY)), cdiv(a.ku - a.kl > 0 ? a.ku - a.kl : 1, ML), g.nmb);
     } else {
-      nouter = a.ku - a.kl + 1;
-      grid = dim3(cdiv(a.iu - a.il + 1, SX), cdiv(cdiv(a.ju - a.jl + 1, ML), SY), nouter*g.nmb);
+      long np = (long)(a.ku - a.kl + 1)*g.N1;          // flattened (k,i)
+      grid = dim3((unsigned)((np + SX*SY - 1)/(SX*SY)), cdiv(a.ju - a.jl > 0 ? a.ju - a.jl : 1, ML), g.nmb);
     }
     constexpr int D = (DIR == 0) ? 1 : DIR;
-    if (recon == AKMI_RECON_PLM) k_sweep_update<D, 1, MHD><<<grid, block, 0, st>>>(g, gamma, a, u, nouter);
-    else if (recon == AKMI_RECON_PPM4) k_sweep_update<D, 2, MHD><<<grid, block, 0, st>>>(g, gamma, a, u, nouter);
-    else k_sweep_update<D, 0, MHD><<<grid, block, 0, st>>>(g, gamma, a, u, nouter);
+    if (recon == AKMI_RECON_PLM) k_sweep_update<D, 1, MHD, MODE, USEACC><<<grid, block, 0, st>>>(g, gamma, a, u, 1);
+    else if (recon == AKMI_RECON_PPM4) k_sweep_update<D, 2, MHD, MODE, USEACC><<<grid, block, 0, st>>>(g, gamma, a, u, 1);
+    else k_sweep_update<D, 0, MHD, MODE, USEACC><<<grid, block, 0, st>>>(g, gamma, a, u, 1);
   }
   AKMI_CHECK_LAUNCH("sweep_update");
   return AKMI_COMPLETE;
 }
 
+// ---------------------------------------------------------------------------------------
+// c2p on the ghost SHELL only (after the halo exchange): the interior was converted inside
+// the slab pipeline.  MODE 0: k-ghost planes (all j,i); 1: j-ghost rows of active planes;
+// 2: i-ghost columns of active rows.  Flattened 1-D over the slab so that the 2*ng-wide
+// i-slabs do not waste 60 of 64 lanes.
+template <bool MHD, int MODE>
+__global__ void __launch_bounds__(256)
+k_c2p_shell(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ bx1f,
+            const double *__restrict__ bx2f, const double *__restrict__ bx3f,
+            double *__restrict__ w0, double *__restrict__ bcc0, int *__restrict__ counters) {
+  const int ng3 = g.three_d ? g.ng : 0, ng2 = g.multi_d ? g.ng : 0;
+  int e1, e2, e3;
+  if (MODE == 0) { e1 = g.N1; e2 = g.N2; e3 = 2*ng3; }
+  else if (MODE == 1) { e1 = g.N1; e2 = 2*ng2; e3 = g.nx3; }
+  else { e1 = 2*g.ng; e2 = g.nx2; e3 = g.nx3; }
+  const long long per = (long long)e1*e2*e3;
+  const long long t = (long long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= per*g.nmb) return;
+  const int m = (int)(t/per);
+  long long r = t - (long long)m*per;
+  const int kk = (int)(r/((long long)e1*e2));
+  r -= (long long)kk*e1*e2;
+  const int jj = (int)(r/e1);
+  const int ii = (int)(r - (long long)jj*e1);
+  int i, j, k;
+  if (MODE == 0) { i = ii; j = jj; k = kk < ng3 ? kk : g.ke + 1 + (kk - ng3); }
+  else if (MODE == 1) { i = ii; j = jj < ng2 ? jj : g.je + 1 + (jj - ng2); k = g.ks + kk; }
+  else { i = ii < g.ng ? ii : g.ie + 1 + (ii - g.ng); j = g.js + jj; k = g.ks + kk; }
+  const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
+  double ud = u0[c], umx = u0[c + cs], umy = u0[c + 2*cs], umz = u0[c + 3*cs], ue = u0[c + 4*cs];
+  double wd, wvx, wvy, wvz, we;
+  bool dfl = false, efl = false, tfl = false;
+  if constexpr (MHD) {
+    const double ubx = 0.5*(bx1f[ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i)] +
+                            bx1f[ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i + 1)]);
+    const double uby = 0.5*(bx2f[ix4(g.N3, g.N2 + 1, g.N1, m, k, j, i)] +
+                            bx2f[ix4(g.N3, g.N2 + 1, g.N1, m, k, j + 1, i)]);
+    const double ubz = 0.5*(bx3f[ix4(g.N3 + 1, g.N2, g.N1, m, k, j, i)] +
+                            bx3f[ix4(g.N3 + 1, g.N2, g.N1, m, k + 1, j, i)]);
+    c2p_mhd(eos, ud, umx, umy, umz, ue, ubx, uby, ubz, wd, wvx, wvy, wvz, we, dfl, efl, tfl);
+    const size_t b = ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i);
+    bcc0[b] = ubx; bcc0[b + cs] = uby; bcc0[b + 2*cs] = ubz;
+  } else {
+    c2p_hyd(eos, ud, umx, umy, umz, ue, wd, wvx, wvy, wvz, we, dfl, efl, tfl);
+  }
+  if (dfl) { u0[c] = ud; atomicAdd(&counters[0], 1); }
+  if (efl) { u0[c + 4*cs] = ue; atomicAdd(&counters[1], 1); }
+  if (tfl) { u0[c + 4*cs] = ue; atomicAdd(&counters[2], 1); }
+  w0[c] = wd; w0[c + cs] = wvx; w0[c + 2*cs] = wvy; w0[c + 3*cs] = wvz; w0[c + 4*cs] = we;
+}
+
+template <bool MHD>
+static int c2p_shell(const akmi_pack *p, double *u0, const double *bx1f, const double *bx2f,
+                     const double *bx3f, double *w0, double *bcc0, int *counters, hipStream_t st) {
+  Geo g = make_geo(p);
+  Eos eos = make_eos(p);
+  auto nb = [](long long n) { return (unsigned)((n + 255)/256); };
+  if (g.three_d) {
+    long long n = (long long)g.N1*g.N2*2*g.ng*g.nmb;
+    k_c2p_shell<MHD, 0><<<nb(n), 256, 0, st>>>(g, eos, u0, bx1f, bx2f, bx3f, w0, bcc0, counters);
+  }
+  if (g.multi_d) {
+    long long n = (long long)g.N1*2*g.ng*g.nx3*g.nmb;
+    k_c2p_shell<MHD, 1><<<nb(n), 256, 0, st>>>(g, eos, u0, bx1f, bx2f, bx3f, w0, bcc0, counters);
+  }
+  {
+    long long n = (long long)2*g.ng*g.nx2*g.nx3*g.nmb;
+    k_c2p_shell<MHD, 2><<<nb(n), 256, 0, st>>>(g, eos, u0, bx1f, bx2f, bx3f, w0, bcc0, counters);
+  }
+  AKMI_CHECK_LAUNCH("c2p_shell");
+  return AKMI_COMPLETE;
+}
+
+template <bool MHD>
+static int launch_c2p(const Geo &g, const Eos &eos, double *u0, const double *bx1f,
+                      const double *bx2f, const double *bx3f, double *w0, double *bcc0,
+                      int do_newdt, int *counters, double *dt3, int il, int iu, int jl, int ju,
+                      int k0, int nk, hipStream_t st) {
+  dim3 grid((unsigned)(((long)(ju - jl + 1)*g.N1 + SX*SY - 1)/(SX*SY)), 1, nk*g.nmb), block(SX, SY);
+  k_c2p_newdt<MHD><<<grid, block, 0, st>>>(g, eos, u0, bx1f, bx2f, bx3f, w0, bcc0, do_newdt, counters,
+                                           dt3, il, iu, jl, ju, k0, nk);
+  AKMI_CHECK_LAUNCH("c2p");
+  return AKMI_COMPLETE;
+}
+
+// ---------------------------------------------------------------------------------------
+// helper stream + events for the slab pipeline (one process drives one GPU)
+constexpr int MAX_SLABS = 64;
+static hipStream_t g_aux = nullptr;
+static hipEvent_t g_ev[MAX_SLABS + 2];
+static bool g_ev_ready = false;
+static int ensure_aux() {
+  if (g_ev_ready) return AKMI_COMPLETE;
+  if (hipStreamCreateWithFlags(&g_aux, hipStreamNonBlocking) != hipSuccess) {
+    set_error("cannot create helper stream"); return AKMI_FAIL;
+  }
+  for (int q = 0; q < MAX_SLABS + 2; ++q)
+    if (hipEventCreateWithFlags(&g_ev[q], hipEventDisableTiming) != hipSuccess) {
+      set_error("cannot create event"); return AKMI_FAIL;
+    }
+  g_ev_ready = true;
+  return AKMI_COMPLETE;
+}
+
+struct C2PArgs {          // interior c2p (+CFL scan) folded into the slab pipeline
+  int enable, do_newdt;
+  int *counters;
+  double *dt3;
+};
+
+#ifndef AKMI_SLAB
+#define AKMI_SLAB 4096    // cells per k-slab of the pipeline (default: one slab)
+#endif
+
+// Pass A (+ optionally the interior part of pass B) of one stage.
+//
+// 3-D packs are cut into k-slabs that behave like independent sub-blocks: each slab runs its
+// x1/x2 sweeps on planes [kA-1,kB+1] and its x3 march on faces [kA,kB+1] (the same
+// CT-extension a MeshBlock applies at its own surface, mhd_fluxes.cpp:125-128), so CornerE
+// and CT of a slab need nothing from its neighbours; the duplicated planes receive
+// bit-identical values from both owners.  The VALU-bound chain (3 Riemann sweeps) is
+// enqueued on the caller's stream, the HBM-bound chain (CornerE, CT, interior c2p + CFL
+// scan) on a helper stream one slab behind, so the two kinds of kernels share the chip
+// instead of alternating.  Hazards (a slab's CT rewrites b0 and its c2p rewrites w0/bcc0,
+// which neighbouring slabs' sweeps still read) are ordered by events:
+//    CornerE(s) after sweeps(s);  CT(s) after sweeps(s-1), sweeps(s+1);
+//    c2p(s) after CT(s), CT(s+1), sweeps(s-1), sweeps(s+1).
 template <bool MHD>
 static int stage_update(const akmi_pack *p, int recon, double gam0, double gam1, double beta_dt,
                         int copy_u1, const double *w0, const double *bcc0, double *u0, double *u1,
                         double *b0x1f, double *b0x2f, double *b0x3f, double *b1x1f, double *b1x2f,
-                        double *b1x3f, void *ws, hipStream_t st) {
+                        double *b1x3f, void *ws, const C2PArgs &cp, hipStream_t st) {
   Geo g = make_geo(p);
+  Eos eos = make_eos(p);
   StageWs w = carve(g, MHD ? 1 : 0, ws);
   const int ndim = g.three_d ? 3 : (g.multi_d ? 2 : 1);
-  UpdArgs u{gam0, gam1, beta_dt, u0, u1, w.flx1, w.flx2, copy_u1};
+  UpdArgs u{gam0, gam1, beta_dt, u0, u1, w.flx1, w.flx2, copy_u1, w.acc};
   int rc = AKMI_COMPLETE;
   // sweep ranges: hydro_fluxes.cpp:95-104 (no FOFC) / mhd_fluxes.cpp:117-248 (CT-extended)
   SweepArgs a1{w0, bcc0, b0x1f, w.flx1, w.efc[0], w.efc[1], w.ecc[0], w.ecc[1], w.ecc[2],
@@ -624,41 +779,123 @@ static int stage_update(const akmi_pack *p, int recon, double gam0, double gam1,
     if (g.three_d) { a2.kl = g.ks - 1; a2.ku = g.ke + 1; }
     a3.il = g.is - 1; a3.iu = g.ie + 1; a3.jl = g.js - 1; a3.ju = g.je + 1;
   }
-  if (ndim == 1) {
-    rc = launch_sweep_update<0, MHD>(g, p->gamma, recon, a1, u, st);
-  } else {
-    // e_cc is needed by CornerE in 2-D (e3 only) and 3-D
-    rc = MHD ? launch_sweep<0, MHD, MHD>(g, p->gamma, recon, a1, st)
-             : launch_sweep<0, MHD, false>(g, p->gamma, recon, a1, st);
-    if (rc != AKMI_COMPLETE) return rc;
-    if (ndim == 2) {
-      rc = launch_sweep_update<1, MHD>(g, p->gamma, recon, a2, u, st);
+  if (cp.enable && cp.do_newdt) k_init_dt3<<<1, 64, 0, st>>>(cp.dt3);
+
+  if (ndim < 3) {
+    // 1-D / 2-D: small problems, plain sequence on the caller's stream
+    if (ndim == 1) {
+      rc = launch_sweep_update<0, MHD>(g, p->gamma, recon, a1, u, st);
     } else {
-      rc = launch_sweep<1, MHD, false>(g, p->gamma, recon, a2, st);
+      rc = MHD ? launch_sweep<0, MHD, MHD>(g, p->gamma, recon, a1, st)
+               : launch_sweep<0, MHD, false>(g, p->gamma, recon, a1, st);
+      if (rc == AKMI_COMPLETE) rc = launch_sweep_update<1, MHD>(g, p->gamma, recon, a2, u, st);
+    }
+    if (rc != AKMI_COMPLETE) return rc;
+    if (MHD) {
+      rc = akmi_mhd_corner_e(p, w0, bcc0, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5],
+                             w.flx1, w.flx2, w.flx3, w.e1, w.e2, w.e3, st);
       if (rc != AKMI_COMPLETE) return rc;
-      rc = launch_sweep_update<2, MHD>(g, p->gamma, recon, a3, u, st);
+      const int nkc = g.ke - g.ks + 2;
+      long npc = (long)(g.je - g.js + 2)*g.N1;
+      dim3 grid((unsigned)((npc + SX*SY - 1)/(SX*SY)), 1, nkc*g.nmb), block(SX, SY);
+      k_ct_copy<<<grid, block, 0, st>>>(g, gam0, gam1, beta_dt, w.e1, w.e2, w.e3, b0x1f, b0x2f, b0x3f,
+                                        b1x1f, b1x2f, b1x3f, copy_u1, g.ks, nkc, g.ke);
+      AKMI_CHECK_LAUNCH("ct");
+    }
+    if (cp.enable)
+      rc = launch_c2p<MHD>(g, eos, u0, b0x1f, b0x2f, b0x3f, const_cast<double *>(w0),
+                           const_cast<double *>(bcc0), cp.do_newdt, cp.counters, cp.dt3, g.is, g.ie,
+                           g.js, g.je, g.ks, g.ke - g.ks + 1, st);
+    return rc;
+  }
+
+  // ---- 3-D: slab pipeline on two streams ------------------------------------------------
+  // developer/test knobs: AKMI_SLAB_CELLS (slab thickness), AKMI_ONE_STREAM=1 (no helper stream)
+  static const int env_slab = getenv("AKMI_SLAB_CELLS") ? atoi(getenv("AKMI_SLAB_CELLS")) : 0;
+  static const bool env_one = getenv("AKMI_ONE_STREAM") && atoi(getenv("AKMI_ONE_STREAM")) != 0;
+  const int T = env_slab > 1 ? env_slab : AKMI_SLAB;
+  const int S = (g.nx3 + T - 1)/T;
+  if (S > MAX_SLABS) { set_error("too many slabs"); return AKMI_FAIL; }
+  const bool two = (S > 1) && (MHD || cp.enable) && !env_one;
+  hipStream_t sb = st;
+  if (two) {
+    if ((rc = ensure_aux()) != AKMI_COMPLETE) return rc;
+    sb = g_aux;
+    // fork: the helper stream starts after everything already enqueued on the caller's stream
+    hipEventRecord(g_ev[MAX_SLABS], st);
+    hipStreamWaitEvent(sb, g_ev[MAX_SLABS], 0);
+  }
+  auto kA = [&](int s) { return g.ks + s*T; };
+  auto kB = [&](int s) { int e = g.ks + (s + 1)*T - 1; return e > g.ke ? g.ke : e; };
+  auto corner = [&](int s) -> int {
+    const int k0 = kA(s), nk = kB(s) - kA(s) + 2;                  // edges [kA, kB+1]
+    long np = (long)(g.nx2 + 1)*g.N1;
+    dim3 grid((unsigned)((np + SX*SY - 1)/(SX*SY)), 1, nk*g.nmb), block(SX, SY);
+    k_corner3<<<grid, block, 0, sb>>>(g, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5],
+                                      w.ecc[0], w.ecc[1], w.ecc[2], w.flx1, w.flx2, w.flx3, w.e1,
+                                      w.e2, w.e3, k0, nk);
+    AKMI_CHECK_LAUNCH("corner3");
+    return AKMI_COMPLETE;
+  };
+  auto ct = [&](int s) -> int {
+    const int top = (s == S - 1) ? 1 : 0;
+    const int k0 = kA(s), nk = kB(s) - kA(s) + 1 + top;
+    long npc = (long)(g.je - g.js + 2)*g.N1;
+    dim3 grid((unsigned)((npc + SX*SY - 1)/(SX*SY)), 1, nk*g.nmb), block(SX, SY);
+    k_ct_copy<<<grid, block, 0, sb>>>(g, gam0, gam1, beta_dt, w.e1, w.e2, w.e3, b0x1f, b0x2f, b0x3f,
+                                      b1x1f, b1x2f, b1x3f, copy_u1, k0, nk, kB(s));
+    AKMI_CHECK_LAUNCH("ct");
+    return AKMI_COMPLETE;
+  };
+  auto c2p = [&](int s) -> int {
+    return launch_c2p<MHD>(g, eos, u0, b0x1f, b0x2f, b0x3f, const_cast<double *>(w0),
+                           const_cast<double *>(bcc0), cp.do_newdt, cp.counters, cp.dt3, g.is, g.ie,
+                           g.js, g.je, kA(s), kB(s) - kA(s) + 1, sb);
+  };
+  for (int s = 0; s < S; ++s) {
+    // VALU-bound chain of slab s on the caller's stream
+    SweepArgs b1 = a1, b2 = a2, b3 = a3;
+    b1.kl = kA(s) - (MHD ? 1 : 0); b1.ku = kB(s) + (MHD ? 1 : 0);
+    b2.kl = b1.kl; b2.ku = b1.ku;
+    b3.kl = kA(s); b3.ku = kB(s) + 1;
+    rc = MHD ? launch_sweep<0, MHD, MHD>(g, p->gamma, recon, b1, st)
+             : launch_sweep<0, MHD, false>(g, p->gamma, recon, b1, st);
+#if AKMI_X2_MARCH
+    // x2 sweep as a march along j that leaves acc = dF1/dx1 + dF2/dx2; x3 march consumes it
+    if (rc == AKMI_COMPLETE) rc = launch_sweep_update<1, MHD, 1, false>(g, p->gamma, recon, b2, u, st);
+    if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD, 0, true>(g, p->gamma, recon, b3, u, st);
+#else
+    if (rc == AKMI_COMPLETE) rc = launch_sweep<1, MHD, false>(g, p->gamma, recon, b2, st);
+    if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD>(g, p->gamma, recon, b3, u, st);
+#endif
+    if (rc != AKMI_COMPLETE) return rc;
+    if (two) {
+      hipEventRecord(g_ev[s], st);
+      hipStreamWaitEvent(sb, g_ev[s], 0);       // everything below needs sweeps(<= s)
+    }
+    // HBM-bound chain, one slab behind (in-order on the helper stream)
+    if (MHD) {
+      if ((rc = corner(s)) != AKMI_COMPLETE) return rc;
+      if (s >= 1 && (rc = ct(s - 1)) != AKMI_COMPLETE) return rc;      // needs sweeps(s) done
+      if (cp.enable && s >= 2 && (rc = c2p(s - 2)) != AKMI_COMPLETE) return rc;
+    } else if (cp.enable) {
+      if (s >= 1 && (rc = c2p(s - 1)) != AKMI_COMPLETE) return rc;     // needs sweeps(s) done
     }
   }
-  if (rc != AKMI_COMPLETE || !MHD) return rc;
-  // corner E + CT
-  if (ndim == 3) {
-    long np = (long)(g.nx2 + 1)*g.N1;
-    dim3 grid((unsigned)((np + SX*SY - 1)/(SX*SY)), 1, (g.nx3 + 1)*g.nmb), block(SX, SY);
-    k_corner3<<<grid, block, 0, st>>>(g, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5],
-                                      w.ecc[0], w.ecc[1], w.ecc[2], w.flx1, w.flx2, w.flx3, w.e1,
-                                      w.e2, w.e3);
-    AKMI_CHECK_LAUNCH("corner3");
-  } else {
-    // 1-D / 2-D: the task-level kernels (tiny problems; CornerE recomputes e_cc itself)
-    rc = akmi_mhd_corner_e(p, w0, bcc0, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5],
-                           w.flx1, w.flx2, w.flx3, w.e1, w.e2, w.e3, st);
-    if (rc != AKMI_COMPLETE) return rc;
+  if (MHD) {
+    if ((rc = ct(S - 1)) != AKMI_COMPLETE) return rc;
+    if (cp.enable) {
+      if (S >= 2 && (rc = c2p(S - 2)) != AKMI_COMPLETE) return rc;
+      if ((rc = c2p(S - 1)) != AKMI_COMPLETE) return rc;
+    }
+  } else if (cp.enable) {
+    if ((rc = c2p(S - 1)) != AKMI_COMPLETE) return rc;
   }
-  long npc = (long)(g.je - g.js + 2)*g.N1;
-  dim3 grid((unsigned)((npc + SX*SY - 1)/(SX*SY)), 1, (g.ke - g.ks + 2)*g.nmb), block(SX, SY);
-  k_ct_copy<<<grid, block, 0, st>>>(g, gam0, gam1, beta_dt, w.e1, w.e2, w.e3, b0x1f, b0x2f, b0x3f,
-                                    b1x1f, b1x2f, b1x3f, copy_u1);
-  AKMI_CHECK_LAUNCH("ct");
+  if (two) {
+    // join: later work on the caller's stream sees the helper stream's results
+    hipEventRecord(g_ev[MAX_SLABS + 1], sb);
+    hipStreamWaitEvent(st, g_ev[MAX_SLABS + 1], 0);
+  }
   return AKMI_COMPLETE;
 }
 
@@ -676,8 +913,9 @@ int akmi_hydro_stage_update(const akmi_pack *p, int recon, int rsolver, double g
                             void *ws, void *stream) {
   if (rsolver != AKMI_RS_HLLC) { set_error("hydro_stage_update: only rsolver=hllc is implemented"); return AKMI_FAIL; }
   if (recon == AKMI_RECON_PPM4 && p->ng < 3) { set_error("ppm4 needs nghost>=3"); return AKMI_FAIL; }
+  C2PArgs cp{0, 0, nullptr, nullptr};
   return stage_update<false>(p, recon, gam0, gam1, beta_dt, copy_u1, w0, nullptr, u0, u1, nullptr,
-                             nullptr, nullptr, nullptr, nullptr, nullptr, ws, (hipStream_t)stream);
+                             nullptr, nullptr, nullptr, nullptr, nullptr, ws, cp, (hipStream_t)stream);
 }
 
 int akmi_mhd_stage_update(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1,
@@ -686,8 +924,9 @@ int akmi_mhd_stage_update(const akmi_pack *p, int recon, int rsolver, double gam
                           double *b1x1f, double *b1x2f, double *b1x3f, void *ws, void *stream) {
   if (rsolver != AKMI_RS_HLLD) { set_error("mhd_stage_update: only rsolver=hlld is implemented"); return AKMI_FAIL; }
   if (recon == AKMI_RECON_PPM4 && p->ng < 3) { set_error("ppm4 needs nghost>=3"); return AKMI_FAIL; }
+  C2PArgs cp{0, 0, nullptr, nullptr};
   return stage_update<true>(p, recon, gam0, gam1, beta_dt, copy_u1, w0, bcc0, u0, u1, b0x1f, b0x2f,
-                            b0x3f, b1x1f, b1x2f, b1x3f, ws, (hipStream_t)stream);
+                            b0x3f, b1x1f, b1x2f, b1x3f, ws, cp, (hipStream_t)stream);
 }
 
 int akmi_hydro_c2p_newdt(const akmi_pack *p, double *u0, double *w0, int do_newdt, int *counters,
@@ -695,11 +934,8 @@ int akmi_hydro_c2p_newdt(const akmi_pack *p, double *u0, double *w0, int do_newd
   Geo g = make_geo(p);
   hipStream_t st = (hipStream_t)stream;
   if (do_newdt) k_init_dt3<<<1, 64, 0, st>>>(dt3);
-  dim3 grid((unsigned)(((long)g.N2*g.N1 + SX*SY - 1)/(SX*SY)), 1, g.N3*g.nmb), block(SX, SY);
-  k_c2p_newdt<false><<<grid, block, 0, st>>>(g, make_eos(p), u0, nullptr, nullptr, nullptr, w0,
-                                             nullptr, do_newdt, counters, dt3);
-  AKMI_CHECK_LAUNCH("hydro_c2p_newdt");
-  return AKMI_COMPLETE;
+  return launch_c2p<false>(g, make_eos(p), u0, nullptr, nullptr, nullptr, w0, nullptr, do_newdt,
+                           counters, dt3, 0, g.N1 - 1, 0, g.N2 - 1, 0, g.N3, st);
 }
 
 int akmi_mhd_c2p_newdt(const akmi_pack *p, double *u0, const double *bx1f, const double *bx2f,
@@ -708,11 +944,39 @@ int akmi_mhd_c2p_newdt(const akmi_pack *p, double *u0, const double *bx1f, const
   Geo g = make_geo(p);
   hipStream_t st = (hipStream_t)stream;
   if (do_newdt) k_init_dt3<<<1, 64, 0, st>>>(dt3);
-  dim3 grid((unsigned)(((long)g.N2*g.N1 + SX*SY - 1)/(SX*SY)), 1, g.N3*g.nmb), block(SX, SY);
-  k_c2p_newdt<true><<<grid, block, 0, st>>>(g, make_eos(p), u0, bx1f, bx2f, bx3f, w0, bcc0,
-                                            do_newdt, counters, dt3);
-  AKMI_CHECK_LAUNCH("mhd_c2p_newdt");
-  return AKMI_COMPLETE;
+  return launch_c2p<true>(g, make_eos(p), u0, bx1f, bx2f, bx3f, w0, bcc0, do_newdt, counters, dt3,
+                          0, g.N1 - 1, 0, g.N2 - 1, 0, g.N3, st);
+}
+
+int akmi_hydro_stage_fused(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1,
+                           double beta_dt, int copy_u1, double *w0, double *u0, double *u1,
+                           int do_newdt, int *counters, double *dt3, void *ws, void *stream) {
+  if (rsolver != AKMI_RS_HLLC) { set_error("hydro_stage_fused: only rsolver=hllc is implemented"); return AKMI_FAIL; }
+  if (recon == AKMI_RECON_PPM4 && p->ng < 3) { set_error("ppm4 needs nghost>=3"); return AKMI_FAIL; }
+  C2PArgs cp{1, do_newdt, counters, dt3};
+  return stage_update<false>(p, recon, gam0, gam1, beta_dt, copy_u1, w0, nullptr, u0, u1, nullptr,
+                             nullptr, nullptr, nullptr, nullptr, nullptr, ws, cp, (hipStream_t)stream);
+}
+
+int akmi_mhd_stage_fused(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1,
+                         double beta_dt, int copy_u1, double *w0, double *bcc0, double *u0, double *u1,
+                         double *b0x1f, double *b0x2f, double *b0x3f, double *b1x1f, double *b1x2f,
+                         double *b1x3f, int do_newdt, int *counters, double *dt3, void *ws,
+                         void *stream) {
+  if (rsolver != AKMI_RS_HLLD) { set_error("mhd_stage_fused: only rsolver=hlld is implemented"); return AKMI_FAIL; }
+  if (recon == AKMI_RECON_PPM4 && p->ng < 3) { set_error("ppm4 needs nghost>=3"); return AKMI_FAIL; }
+  C2PArgs cp{1, do_newdt, counters, dt3};
+  return stage_update<true>(p, recon, gam0, gam1, beta_dt, copy_u1, w0, bcc0, u0, u1, b0x1f, b0x2f,
+                            b0x3f, b1x1f, b1x2f, b1x3f, ws, cp, (hipStream_t)stream);
+}
+
+int akmi_hydro_c2p_shell(const akmi_pack *p, double *u0, double *w0, int *counters, void *stream) {
+  return c2p_shell<false>(p, u0, nullptr, nullptr, nullptr, w0, nullptr, counters, (hipStream_t)stream);
+}
+
+int akmi_mhd_c2p_shell(const akmi_pack *p, double *u0, const double *bx1f, const double *bx2f,
+                       const double *bx3f, double *w0, double *bcc0, int *counters, void *stream) {
+  return c2p_shell<true>(p, u0, bx1f, bx2f, bx3f, w0, bcc0, counters, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -185,11 +185,17 @@ class Hydro(FluidBase):
         gam0, gam1 = pdrive.gam0[stage - 1], pdrive.gam1[stage - 1]
         beta_dt = pdrive.beta[stage - 1]*self.pmy_pack.pmesh.dt
         if self.fused:
-            capi.check(self.L.akmi_hydro_stage_update(
+            # pass A + ConsToPrim of the active cells (+ CFL scan on the last stage) in one
+            # slab-pipelined call; the ghost shell is converted in ConToPrim after the halo
+            do_dt = 1 if stage == pdrive.nexp_stages else 0
+            capi.check(self.L.akmi_hydro_stage_fused(
                 C.byref(self.pack_c), self.recon_method, self.rsolver_method, capi.d(gam0),
                 capi.d(gam1), capi.d(beta_dt), 1 if stage == 1 else 0, capi._p(self.w0),
-                capi._p(self.u0), capi._p(self.u1), capi._p(self._workspace(0)), capi._stream()),
-                "hydro_stage_update")
+                capi._p(self.u0), capi._p(self.u1), do_dt, capi._p(self.counters),
+                capi._p(self.dt3), capi._p(self._workspace(0)), capi._stream()),
+                "hydro_stage_fused")
+            self._interior_done = True
+            self._dt_ready = bool(do_dt)
         else:
             capi.check(self.L.akmi_rk_update(
                 C.byref(self.pack_c), capi.d(gam0), capi.d(gam1), capi.d(beta_dt), capi._p(self.u0),
@@ -214,6 +220,12 @@ class Hydro(FluidBase):
         """hydro_tasks.cpp:404-412: all cells including ghosts (the fused path also performs
         the CFL scan of NewTimeStep in the same kernel on the last stage)"""
         n3, n2, n1 = self.pmy_pack.pmesh.mb_indcs.ncells
+        if self.fused and getattr(self, "_interior_done", False):
+            self._interior_done = False
+            capi.check(self.L.akmi_hydro_c2p_shell(
+                C.byref(self.pack_c), capi._p(self.u0), capi._p(self.w0), capi._p(self.counters),
+                capi._stream()), "hydro_c2p_shell")
+            return TaskStatus.complete
         if self.fused:
             do_dt = 1 if stage == pdrive.nexp_stages else 0
             capi.check(self.L.akmi_hydro_c2p_newdt(

@@ -107,11 +107,17 @@ class MHD(FluidBase):
         gam0, gam1 = pdrive.gam0[stage - 1], pdrive.gam1[stage - 1]
         beta_dt = pdrive.beta[stage - 1]*self.pmy_pack.pmesh.dt
         if self.fused:
-            capi.check(self.L.akmi_mhd_stage_update(
+            # pass A (fluxes, update, CornerE, CT) + ConsToPrim of the active cells (+ CFL scan
+            # on the last stage) in one slab-pipelined call
+            do_dt = 1 if stage == pdrive.nexp_stages else 0
+            capi.check(self.L.akmi_mhd_stage_fused(
                 C.byref(self.pack_c), self.recon_method, self.rsolver_method, capi.d(gam0),
                 capi.d(gam1), capi.d(beta_dt), 1 if stage == 1 else 0, capi._p(self.w0),
                 capi._p(self.bcc0), capi._p(self.u0), capi._p(self.u1), *self._b(self.b0),
-                *self._b(self.b1), capi._p(self._workspace(1)), capi._stream()), "mhd_stage_update")
+                *self._b(self.b1), do_dt, capi._p(self.counters), capi._p(self.dt3),
+                capi._p(self._workspace(1)), capi._stream()), "mhd_stage_fused")
+            self._interior_done = True
+            self._dt_ready = bool(do_dt)
         else:
             capi.check(self.L.akmi_rk_update(
                 C.byref(self.pack_c), capi.d(gam0), capi.d(gam1), capi.d(beta_dt), capi._p(self.u0),
@@ -162,6 +168,12 @@ class MHD(FluidBase):
     def ConToPrim(self, pdrive, stage):
         """mhd_tasks.cpp: all cells incl. ghosts; fused path: + CFL scan on the last stage"""
         n3, n2, n1 = self.pmy_pack.pmesh.mb_indcs.ncells
+        if self.fused and getattr(self, "_interior_done", False):
+            self._interior_done = False
+            capi.check(self.L.akmi_mhd_c2p_shell(
+                C.byref(self.pack_c), capi._p(self.u0), *self._b(self.b0), capi._p(self.w0),
+                capi._p(self.bcc0), capi._p(self.counters), capi._stream()), "mhd_c2p_shell")
+            return TaskStatus.complete
         if self.fused:
             do_dt = 1 if stage == pdrive.nexp_stages else 0
             capi.check(self.L.akmi_mhd_c2p_newdt(

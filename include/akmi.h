@@ -191,6 +191,27 @@ int akmi_mhd_c2p_newdt(const akmi_pack *p, double *u0, const double *bx1f,
                        const double *bx2f, const double *bx3f, double *w0, double *bcc0,
                        int do_newdt, int *counters, double *dt3, void *stream);
 
+/* Whole stage in one call: pass A (as akmi_*_stage_update) + ConsToPrim of the ACTIVE cells
+ * (+ the CFL scan when do_newdt) folded into the same slab pipeline, so that the HBM-bound
+ * kernels overlap the Riemann sweeps of other slabs.  w0/bcc0 are read (old primitives) and
+ * rewritten for the active cells.  After the halo exchange / physical BCs the caller converts
+ * the ghost shell with akmi_*_c2p_shell; together they equal akmi_*_c2p_newdt over all cells
+ * (ConToPrim covers ghosts: src/hydro/hydro_tasks.cpp:404-412). */
+int akmi_hydro_stage_fused(const akmi_pack *p, int recon, int rsolver, double gam0,
+                           double gam1, double beta_dt, int copy_u1, double *w0, double *u0,
+                           double *u1, int do_newdt, int *counters, double *dt3, void *ws,
+                           void *stream);
+int akmi_mhd_stage_fused(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1,
+                         double beta_dt, int copy_u1, double *w0, double *bcc0, double *u0,
+                         double *u1, double *b0x1f, double *b0x2f, double *b0x3f,
+                         double *b1x1f, double *b1x2f, double *b1x3f, int do_newdt,
+                         int *counters, double *dt3, void *ws, void *stream);
+int akmi_hydro_c2p_shell(const akmi_pack *p, double *u0, double *w0, int *counters,
+                         void *stream);
+int akmi_mhd_c2p_shell(const akmi_pack *p, double *u0, const double *bx1f, const double *bx2f,
+                       const double *bx3f, double *w0, double *bcc0, int *counters,
+                       void *stream);
+
 /* ---- measurement utility ------------------------------------------------------------ *
  * dst[i] = src[i] for n doubles with the library's own access pattern (8 B per lane,
  * 512 B per wave, grid-stride): a kernel of KNOWN traffic (8n read + 8n written) used to
