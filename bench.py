@@ -165,10 +165,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
-    # ---- roofline of the dominant kernel group, from HIP events on the launch stream ------
+    # ---- roofline of the dominant launch group, from HIP events on the launch stream --------
+    # akmi_*_stage_fused = the whole stage except the halo exchange and the ghost-shell c2p:
+    # algorithmic bytes = SURVEY 8(d)'s per-cell-stage figure (MHD 384 B, hydro 240 B).
     phys = sim.phys
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    tA = tB = 0.0
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    tS = tH = 0.0
     nprof = 3
     for _ in range(nprof):
         for stage in range(1, drv.nexp_stages + 1):
@@ -181,27 +183,40 @@ def main():
             if blk == "mhd":
                 phys.SendB(drv, stage); phys.RecvB(drv, stage)
             phys.ApplyPhysicalBCs(drv, stage)
-            ev[2].record()
             phys.ConToPrim(drv, stage); phys.NewTimeStep(drv, stage)
-            ev[3].record()
+            ev[2].record()
             torch.cuda.synchronize()
-            tA += ev[0].elapsed_time(ev[1]); tB += ev[2].elapsed_time(ev[3])
+            tS += ev[0].elapsed_time(ev[1]); tH += ev[1].elapsed_time(ev[2])
         pm.time += pm.dt; pm.ncycle += 1; pm.NewTimeStep(drv.tlim)
     nst = nprof*drv.nexp_stages
-    tA, tB = tA/nst*1e-3, tB/nst*1e-3                       # seconds per launch group
-    achA = BYTES_PASS_A[blk]*ncell_rank/tA/1e9
-    achB = BYTES_PASS_B[blk]*ncell_rank/tB/1e9
+    tS, tH = tS/nst*1e-3, tH/nst*1e-3                       # seconds per launch group
     stage_bytes = BYTES_PASS_A[blk] + BYTES_PASS_B[blk]
-    roofline = {"bound": "hbm", "kernel": "akmi_%s_stage_update (pass A: fluxes+EMF+update+CT)" % blk,
-                "achieved": round(achA, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achA/HBM_PEAK_GBS, 4), "traffic": None,
-                "algorithmic_bytes_per_cell": BYTES_PASS_A[blk], "ms_per_launch": round(tA*1e3, 4),
-                "pass_B": {"kernel": "c2p(+newdt)", "achieved": round(achB, 1),
-                           "frac": round(achB/HBM_PEAK_GBS, 4), "ms_per_launch": round(tB*1e3, 4),
-                           "algorithmic_bytes_per_cell": BYTES_PASS_B[blk]},
-                "whole_stage": {"algorithmic_bytes_per_cell": stage_bytes,
-                                "achieved": round(stage_bytes*ncell_rank*drv.nexp_stages*args.steps
-                                                  / el / 1e9, 1)}}
+    ach = stage_bytes*ncell_rank/tS/1e9
+    traffic, tsrc = None, None
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+    if os.path.exists(tfile) and blk == "mhd" and args.nx == 256 and not args.split:
+        # HBM-side bytes per stage from rocprofv3 PMC counters (FETCH_SIZE / WRITE_SIZE in
+        # separate passes, calibrated on a copy of known size; tools/pmc.sh), recorded for this
+        # workload in a separate profiling run
+        t = json.load(open(tfile))
+        stage_kernels = [k for k in t["kernels"] if k.startswith("akmi::k_sweep") or
+                         k.startswith("akmi::k_corner3") or k.startswith("akmi::k_ct_copy") or
+                         k.startswith("akmi::k_c2p_newdt")]
+        traffic = round(sum(t["kernels"][k]["hbm_bytes_per_launch"] for k in stage_kernels))
+        tsrc = "profiles/pmc_traffic_latest.json (%s)" % t.get("tag", "")
+    roofline = {"bound": "hbm",
+                "kernel": "akmi_%s_stage_fused launch group (sweeps + update%s + c2p of active cells)"
+                          % (blk, " + CornerE + CT" if blk == "mhd" else ""),
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach/HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+                "algorithmic_bytes_per_cell_stage": stage_bytes,
+                "algorithmic_bytes_per_launch": stage_bytes*ncell_rank,
+                "ms_per_launch": round(tS*1e3, 4),
+                "halo_bcs_shell_c2p_ms": round(tH*1e3, 4),
+                "whole_stage": {"achieved": round(stage_bytes*ncell_rank*drv.nexp_stages*args.steps
+                                                  / el / 1e9, 1)},
+                "note": "the Riemann sweeps are fp64-VALU bound (~1000 instructions per face); "
+                        "see DESIGN.md section 3"}
     roofline["whole_stage"]["frac"] = round(roofline["whole_stage"]["achieved"]/HBM_PEAK_GBS, 4)
 
     if rank == 0:

@@ -349,3 +349,32 @@ def test_slab_pipeline_is_bit_identical(case):
         out = subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip().splitlines()[-1]
         r = json.loads(out)
         assert r["ok"] and r["cyc"] == cycles, (slab, r)
+
+
+def test_shared_edge_emfs_identical_across_blocks():
+    """premise of skipping SendE/RecvE on uniform meshes: every copy of a
+    block-surface edge EMF computed by the two (four) MeshBlocks that share it is bit-identical,
+    so the reference's sum-and-average (flux_correct_fc.cpp:843-860) is the identity"""
+    sim, osim, is_mhd = pu.make_pair("orszag_tang", 16, 3, 8, fused=False, cfl=0.3)
+    for _ in range(2):
+        sim.Execute(max_cycles=1)
+    ph = sim.phys
+    pm = sim.pmesh
+    ind = pm.mb_indcs
+    e1, e2, e3 = ph.efld.x1e.cpu().numpy(), ph.efld.x2e.cpu().numpy(), ph.efld.x3e.cpu().numpy()
+    nb = ph.pbval_u.nghbr_host
+    ks, ke, js, je, is_, ie = ind.ks, ind.ke, ind.js, ind.je, ind.is_, ind.ie
+    checked = 0
+    for m in range(ph.nmb):
+        # +x1 neighbour: my face i=ie+1 is its face i=is
+        n = nb[m, 13 + 1]
+        assert np.array_equal(e2[m, ks:ke+2, js:je+1, ie+1], e2[n, ks:ke+2, js:je+1, is_])
+        assert np.array_equal(e3[m, ks:ke+1, js:je+2, ie+1], e3[n, ks:ke+1, js:je+2, is_])
+        n = nb[m, 13 + 3]      # +x2
+        assert np.array_equal(e1[m, ks:ke+2, je+1, is_:ie+1], e1[n, ks:ke+2, js, is_:ie+1])
+        assert np.array_equal(e3[m, ks:ke+1, je+1, is_:ie+2], e3[n, ks:ke+1, js, is_:ie+2])
+        n = nb[m, 13 + 9]      # +x3
+        assert np.array_equal(e1[m, ke+1, js:je+2, is_:ie+1], e1[n, ks, js:je+2, is_:ie+1])
+        assert np.array_equal(e2[m, ke+1, js:je+1, is_:ie+2], e2[n, ks, js:je+1, is_:ie+2])
+        checked += 6
+    assert checked == 48 and np.abs(e3).max() > 0
