@@ -35,7 +35,9 @@ SYMBOLS = [
     "akmi_bvals_fc_unpack", "akmi_bvals_fc_segsize", "akmi_hydro_bcs", "akmi_bfield_bcs",
     "akmi_stage_workspace_bytes", "akmi_hydro_stage_update", "akmi_mhd_stage_update",
     "akmi_hydro_c2p_newdt", "akmi_mhd_c2p_newdt", "akmi_calib_copy", "akmi_hydro_stage_fused", "akmi_mhd_stage_fused",
-    "akmi_hydro_c2p_shell", "akmi_mhd_c2p_shell",
+    "akmi_hydro_c2p_shell", "akmi_mhd_c2p_shell", "akmi_sim_create", "akmi_sim_initialize",
+    "akmi_sim_execute", "akmi_sim_destroy", "akmi_sim_time", "akmi_sim_dt", "akmi_sim_tlim",
+    "akmi_sim_ncycle", "akmi_sim_nmb", "akmi_sim_array", "akmi_sim_lloc",
 ]
 
 _LIB = None
@@ -58,6 +60,11 @@ def lib():
         L.akmi_bvals_cc_segsize.restype = C.c_longlong
         L.akmi_bvals_fc_segsize.restype = C.c_longlong
         L.akmi_stage_workspace_bytes.restype = C.c_longlong
+        L.akmi_sim_create.restype = C.c_void_p
+        L.akmi_sim_array.restype = C.c_void_p
+        L.akmi_sim_lloc.restype = C.POINTER(C.c_int)
+        for f in ("akmi_sim_time", "akmi_sim_dt", "akmi_sim_tlim"):
+            getattr(L, f).restype = C.c_double
         _LIB = L
     return _LIB
 

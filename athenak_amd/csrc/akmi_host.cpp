@@ -1,0 +1,742 @@
+// akmi_host.cpp -- C++ host mirror (see akmi_host.hpp) + its C entry points akmi_sim_*.
+#include "akmi_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+
+namespace akmi {
+namespace host {
+
+[[noreturn]] void Fatal(const char *file, int line, const std::string &msg) {
+  std::fprintf(stderr, "### FATAL ERROR in %s at line %d\n%s\n", file, line, msg.c_str());
+  std::exit(EXIT_FAILURE);     // the reference's error convention (e.g. src/mesh/mesh.cpp:234)
+}
+
+#define HIPCHK(x)                                                                   \
+  do {                                                                              \
+    hipError_t e_ = (x);                                                            \
+    if (e_ != hipSuccess) AKMI_FATAL(std::string(#x) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+#define AKCHK(x)                                                              \
+  do {                                                                        \
+    if ((x) < 0) AKMI_FATAL(std::string(#x) + ": " + akmi_last_error());      \
+  } while (0)
+
+// ---- ParameterInput (src/parameter_input.cpp:155-209,369-409,508-552) -------------------
+static std::string trim(const std::string &s) {
+  size_t a = s.find_first_not_of(" \t\r"), b = s.find_last_not_of(" \t\r");
+  return a == std::string::npos ? std::string() : s.substr(a, b - a + 1);
+}
+
+void ParameterInput::LoadFromString(const std::string &text) {
+  std::istringstream in(text);
+  std::string raw, block;
+  bool have = false;
+  while (std::getline(in, raw)) {
+    std::string line = trim(raw);
+    if (line.empty() || line[0] == '#') continue;
+    if (line[0] == '<') {
+      std::string name = trim(line.substr(1, line.find('>') - 1));
+      if (name == "par_end") break;
+      block = name; have = true;
+      blocks_[block];
+      continue;
+    }
+    if (!have) AKMI_FATAL("parameter outside of a <block>: " + raw);
+    size_t eq = line.find('=');
+    if (eq == std::string::npos) AKMI_FATAL("no '=' in line: " + raw);
+    std::string k = trim(line.substr(0, eq)), v = line.substr(eq + 1);
+    size_t hash = v.find('#');
+    if (hash != std::string::npos) v = v.substr(0, hash);
+    blocks_[block][k] = trim(v);
+  }
+}
+
+void ParameterInput::ModifyFromCmdline(const std::vector<std::string> &args) {
+  for (const auto &a : args) {
+    size_t sl = a.find('/'), eq = a.find('=');
+    if (sl == std::string::npos || eq == std::string::npos) AKMI_FATAL("cannot parse override " + a);
+    std::string b = a.substr(0, sl), n = a.substr(sl + 1, eq - sl - 1), v = a.substr(eq + 1);
+    if (!DoesBlockExist(b)) AKMI_FATAL("block <" + b + "> not found");
+    if (!DoesParameterExist(b, n)) AKMI_FATAL("parameter " + b + "/" + n + " not found");
+    blocks_[b][n] = v;
+  }
+}
+
+bool ParameterInput::DoesParameterExist(const std::string &b, const std::string &n) const {
+  auto it = blocks_.find(b);
+  return it != blocks_.end() && it->second.count(n) != 0;
+}
+std::string ParameterInput::GetString(const std::string &b, const std::string &n) const {
+  if (!DoesParameterExist(b, n)) AKMI_FATAL("parameter " + b + "/" + n + " does not exist");
+  return blocks_.at(b).at(n);
+}
+int ParameterInput::GetInteger(const std::string &b, const std::string &n) const {
+  return std::atoi(GetString(b, n).c_str());
+}
+Real ParameterInput::GetReal(const std::string &b, const std::string &n) const {
+  return std::strtod(GetString(b, n).c_str(), nullptr);
+}
+bool ParameterInput::GetBoolean(const std::string &b, const std::string &n) const {
+  std::string v = GetString(b, n);
+  std::transform(v.begin(), v.end(), v.begin(), ::tolower);
+  if (v == "1" || v == "true") return true;
+  if (v == "0" || v == "false") return false;
+  AKMI_FATAL("bad boolean " + b + "/" + n + "=" + v);
+}
+std::string ParameterInput::GetOrAddString(const std::string &b, const std::string &n,
+                                           const std::string &d) {
+  if (DoesParameterExist(b, n)) return GetString(b, n);
+  blocks_[b][n] = d;
+  return d;
+}
+int ParameterInput::GetOrAddInteger(const std::string &b, const std::string &n, int d) {
+  if (DoesParameterExist(b, n)) return GetInteger(b, n);
+  blocks_[b][n] = std::to_string(d);
+  return d;
+}
+Real ParameterInput::GetOrAddReal(const std::string &b, const std::string &n, Real d) {
+  if (DoesParameterExist(b, n)) return GetReal(b, n);
+  char buf[64]; std::snprintf(buf, sizeof(buf), "%.17g", d);
+  blocks_[b][n] = buf;
+  return d;
+}
+bool ParameterInput::GetOrAddBoolean(const std::string &b, const std::string &n, bool d) {
+  if (DoesParameterExist(b, n)) return GetBoolean(b, n);
+  blocks_[b][n] = d ? "true" : "false";
+  return d;
+}
+void ParameterInput::SetReal(const std::string &b, const std::string &n, Real v) {
+  char buf[64]; std::snprintf(buf, sizeof(buf), "%.17g", v);
+  blocks_[b][n] = buf;
+}
+
+// ---- TaskList ---------------------------------------------------------------------------
+bool TaskList::IsComplete() {
+  for (auto &it : task_list_)
+    if (!tasks_completed_.CheckDependencies(it.GetID())) return false;
+  return true;
+}
+void TaskList::Reset() {
+  tasks_completed_.Clear();
+  for (auto &it : task_list_) it.SetIncomplete();
+}
+TaskListStatus TaskList::DoAvailable(Driver *d, int s) {
+  for (auto &task : task_list_) {
+    auto dep = task.GetDependency();
+    if (tasks_completed_.CheckDependencies(dep) && !task.IsComplete()) {
+      TaskStatus status = task(d, s);
+      if (status == TaskStatus::fail) AKMI_FATAL("task failed");
+      if (status == TaskStatus::complete) {
+        task.SetComplete();
+        tasks_completed_.SetComplete(task.GetID());
+      }
+    }
+  }
+  return IsComplete() ? TaskListStatus::complete : TaskListStatus::running;
+}
+
+// ---- device arrays ------------------------------------------------------------------------
+template <typename T> void DvceArray<T>::Realloc(size_t count) {
+  Free();
+  n = count;
+  HIPCHK(hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1)*sizeof(T)));
+  HIPCHK(hipMemset(p, 0, std::max<size_t>(count, 1)*sizeof(T)));
+}
+template <typename T> void DvceArray<T>::Free() {
+  if (p) (void)hipFree(p);
+  p = nullptr; n = 0;
+}
+template struct DvceArray<Real>;
+template struct DvceArray<int>;
+template struct DvceArray<char>;
+
+// ---- Mesh -----------------------------------------------------------------------------------
+static Real LeftEdgeX(int ith, int n, Real xmin, Real xmax) {   // cell_locations.hpp:23-28
+  Real x = static_cast<Real>(ith)/static_cast<Real>(n);
+  return (x*xmax - x*xmin) - (0.5*xmax - 0.5*xmin) + (0.5*xmin + 0.5*xmax);
+}
+static std::uint64_t Morton(int x, int y, int z) {
+  std::uint64_t r = 0;
+  for (int b = 0; b < 20; ++b) {
+    r |= (static_cast<std::uint64_t>((x >> b) & 1)) << (3*b);
+    r |= (static_cast<std::uint64_t>((y >> b) & 1)) << (3*b + 1);
+    r |= (static_cast<std::uint64_t>((z >> b) & 1)) << (3*b + 2);
+  }
+  return r;
+}
+static RegionIndcs MakeIndcs(int ng, int nx1, int nx2, int nx3) {   // mesh.cpp:285-330
+  RegionIndcs r;
+  r.ng = ng; r.nx1 = nx1; r.nx2 = nx2; r.nx3 = nx3;
+  r.is = ng; r.ie = ng + nx1 - 1;
+  r.js = nx2 > 1 ? ng : 0; r.je = nx2 > 1 ? ng + nx2 - 1 : 0;
+  r.ks = nx3 > 1 ? ng : 0; r.ke = nx3 > 1 ? ng + nx3 - 1 : 0;
+  return r;
+}
+static int BCFlag(const std::string &v) {
+  if (v == "periodic") return AKMI_BC_PERIODIC;
+  if (v == "outflow") return AKMI_BC_OUTFLOW;
+  if (v == "reflect") return AKMI_BC_REFLECT;
+  AKMI_FATAL("boundary flag '" + v + "' not supported on this path (periodic/outflow/reflect)");
+}
+
+Mesh::Mesh(ParameterInput *pin) {
+  mesh_size.x1min = pin->GetReal("mesh", "x1min"); mesh_size.x1max = pin->GetReal("mesh", "x1max");
+  mesh_size.x2min = pin->GetReal("mesh", "x2min"); mesh_size.x2max = pin->GetReal("mesh", "x2max");
+  mesh_size.x3min = pin->GetReal("mesh", "x3min"); mesh_size.x3max = pin->GetReal("mesh", "x3max");
+  int ng = pin->GetOrAddInteger("mesh", "nghost", 2);
+  int nx1 = pin->GetInteger("mesh", "nx1"), nx2 = pin->GetInteger("mesh", "nx2"),
+      nx3 = pin->GetInteger("mesh", "nx3");
+  mesh_indcs = MakeIndcs(ng, nx1, nx2, nx3);
+  one_d = (nx2 == 1 && nx3 == 1); two_d = (nx2 > 1 && nx3 == 1); three_d = nx3 > 1; multi_d = nx2 > 1;
+  if (nx2 == 1 && nx3 > 1) AKMI_FATAL("In mesh block in input file nx3>1 requires nx2>1");
+  if (ng < 2) AKMI_FATAL("More than 1 ghost zone required");
+  const char *names[6] = {"ix1_bc", "ox1_bc", "ix2_bc", "ox2_bc", "ix3_bc", "ox3_bc"};
+  for (int q = 0; q < 6; ++q) mesh_bcs[q] = BCFlag(pin->GetOrAddString("mesh", names[q], "periodic"));
+  auto per = [&](int q) { return mesh_bcs[q] == AKMI_BC_PERIODIC; };
+  strictly_periodic = per(0) && per(1) && (!multi_d || (per(2) && per(3))) &&
+                      (!three_d || (per(4) && per(5)));
+  int mb1 = pin->GetOrAddInteger("meshblock", "nx1", nx1);
+  int mb2 = pin->GetOrAddInteger("meshblock", "nx2", nx2);
+  int mb3 = pin->GetOrAddInteger("meshblock", "nx3", nx3);
+  if (nx1 % mb1 || nx2 % mb2 || nx3 % mb3) AKMI_FATAL("Mesh must be evenly divisible by MeshBlocks");
+  mb_indcs = MakeIndcs(ng, mb1, mb2, mb3);
+  nmb_rootx1 = nx1/mb1; nmb_rootx2 = nx2/mb2; nmb_rootx3 = nx3/mb3;
+  nmb_total = nmb_rootx1*nmb_rootx2*nmb_rootx3;
+  if (pin->DoesBlockExist("mesh_refinement") &&
+      pin->GetOrAddString("mesh_refinement", "refinement", "none") != "none")
+    AKMI_FATAL("mesh refinement is not on this build's path (SURVEY.md section 8(f) item 1)");
+  // Z-ordered logical locations (build_tree.cpp:243-258)
+  struct Z { std::uint64_t key; int l[3]; };
+  std::vector<Z> z;
+  for (int l3 = 0; l3 < nmb_rootx3; ++l3)
+    for (int l2 = 0; l2 < nmb_rootx2; ++l2)
+      for (int l1 = 0; l1 < nmb_rootx1; ++l1) z.push_back({Morton(l1, l2, l3), {l1, l2, l3}});
+  std::sort(z.begin(), z.end(), [](const Z &a, const Z &b) { return a.key < b.key; });
+  lloc_eachmb.resize(3*nmb_total);
+  for (int m = 0; m < nmb_total; ++m)
+    for (int q = 0; q < 3; ++q) lloc_eachmb[3*m + q] = z[m].l[q];
+  time = pin->GetOrAddReal("time", "start_time", 0.0);
+  dt = static_cast<Real>(FLT_MAX);            // build_tree.cpp:301
+  dtold = 0.0;
+  cfl_no = pin->GetReal("time", "cfl_number");
+  ncycle = 0;
+  pmb_pack = new MeshBlockPack(this, 0, nmb_total - 1);
+  pmb_pack->pmb = new MeshBlock(pmb_pack, 0, nmb_total);
+}
+Mesh::~Mesh() { delete pmb_pack; }
+
+MeshBlock::MeshBlock(MeshBlockPack *ppack, int igids, int nmb_) : nmb(nmb_) {
+  Mesh *pm = ppack->pmesh;
+  const RegionSize &ms = pm->mesh_size;
+  const int nb[3] = {pm->nmb_rootx1, pm->nmb_rootx2, pm->nmb_rootx3};
+  const bool active[3] = {true, pm->multi_d, pm->three_d};
+  const Real mmin[3] = {ms.x1min, ms.x2min, ms.x3min}, mmax[3] = {ms.x1max, ms.x2max, ms.x3max};
+  const int nxb[3] = {pm->mb_indcs.nx1, pm->mb_indcs.nx2, pm->mb_indcs.nx3};
+  mb_gid.resize(nmb); mb_size.resize(nmb); mb_bcs.resize(6*nmb); nghbr.assign(27*nmb, -1);
+  std::vector<int> gid_of(nmb);
+  for (int m = 0; m < nmb; ++m) {
+    const int *l = &pm->lloc_eachmb[3*(igids + m)];
+    gid_of[(l[2]*nb[1] + l[1])*nb[0] + l[0]] = m;
+  }
+  std::vector<Real> dx(3*nmb);
+  for (int m = 0; m < nmb; ++m) {
+    mb_gid[m] = igids + m;
+    const int *l = &pm->lloc_eachmb[3*(igids + m)];
+    Real lim[6];
+    for (int q = 0; q < 3; ++q) {
+      if (!active[q] || l[q] == 0) { lim[2*q] = mmin[q]; mb_bcs[6*m + 2*q] = pm->mesh_bcs[2*q]; }
+      else { lim[2*q] = LeftEdgeX(l[q], nb[q], mmin[q], mmax[q]); mb_bcs[6*m + 2*q] = AKMI_BC_BLOCK; }
+      if (!active[q] || l[q] == nb[q] - 1) { lim[2*q + 1] = mmax[q]; mb_bcs[6*m + 2*q + 1] = pm->mesh_bcs[2*q + 1]; }
+      else { lim[2*q + 1] = LeftEdgeX(l[q] + 1, nb[q], mmin[q], mmax[q]); mb_bcs[6*m + 2*q + 1] = AKMI_BC_BLOCK; }
+      dx[3*m + q] = (lim[2*q + 1] - lim[2*q])/static_cast<Real>(nxb[q]);
+    }
+    RegionSize &s = mb_size[m];
+    s.x1min = lim[0]; s.x1max = lim[1]; s.x2min = lim[2]; s.x2max = lim[3]; s.x3min = lim[4]; s.x3max = lim[5];
+    s.dx1 = dx[3*m]; s.dx2 = dx[3*m + 1]; s.dx3 = dx[3*m + 2];
+    for (int d = 0; d < 27; ++d) {
+      int o[3] = {d%3 - 1, (d/3)%3 - 1, d/9 - 1};
+      if (d == 13 || (!pm->multi_d && o[1]) || (!pm->three_d && o[2])) continue;
+      int ll[3]; bool ok = true;
+      for (int q = 0; q < 3 && ok; ++q) {
+        ll[q] = l[q] + o[q];
+        if (ll[q] < 0) { if (pm->mesh_bcs[2*q] == AKMI_BC_PERIODIC) ll[q] += nb[q]; else ok = false; }
+        else if (ll[q] >= nb[q]) { if (pm->mesh_bcs[2*q + 1] == AKMI_BC_PERIODIC) ll[q] -= nb[q]; else ok = false; }
+      }
+      if (ok) nghbr[27*m + d] = gid_of[(ll[2]*nb[1] + ll[1])*nb[0] + ll[0]];
+    }
+  }
+  d_dx.Realloc(3*nmb); d_bcs.Realloc(6*nmb); d_nghbr.Realloc(27*nmb);
+  HIPCHK(hipMemcpy(d_dx.p, dx.data(), sizeof(Real)*3*nmb, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_bcs.p, mb_bcs.data(), sizeof(int)*6*nmb, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_nghbr.p, nghbr.data(), sizeof(int)*27*nmb, hipMemcpyHostToDevice));
+}
+MeshBlock::~MeshBlock() { d_dx.Free(); d_bcs.Free(); d_nghbr.Free(); }
+
+MeshBlockPack::MeshBlockPack(Mesh *pm, int igids, int igide)
+    : pmesh(pm), gids(igids), gide(igide), nmb_thispack(igide - igids + 1) {
+  for (const char *n : {"before_timeintegrator", "after_timeintegrator", "before_stagen", "stagen",
+                        "after_stagen"})
+    tl_map[n] = std::make_shared<TaskList>();          // meshblock_pack.cpp:40-50
+}
+MeshBlockPack::~MeshBlockPack() { delete phydro; delete pmhd; delete pmb; }
+
+void MeshBlockPack::AddPhysics(ParameterInput *pin) {   // meshblock_pack.cpp:102-262
+  int nphys = 0;
+  if (pin->DoesBlockExist("hydro")) { phydro = new hydro::Hydro(this, pin); ++nphys; }
+  if (pin->DoesBlockExist("mhd")) { pmhd = new mhd::MHD(this, pin); ++nphys; }
+  if (nphys == 0) AKMI_FATAL("At least one physics module must be specified in input file");
+  if (phydro) phydro->AssembleHydroTasks(tl_map);
+  if (pmhd) pmhd->AssembleMHDTasks(tl_map);
+}
+
+void Mesh::NewTimeStep(const Real tlim) {               // mesh.cpp:573-643
+  dtold = dt;
+  if (dt == static_cast<Real>(FLT_MAX)) dtold = 0.;
+  dt = 2.0*dt;
+  if (pmb_pack->phydro) dt = std::min(dt, cfl_no*pmb_pack->phydro->dtnew);
+  if (pmb_pack->pmhd) dt = std::min(dt, cfl_no*pmb_pack->pmhd->dtnew);
+  if ((time < tlim) && ((time + dt) > tlim)) dt = tlim - time;
+}
+
+// ---- physics ----------------------------------------------------------------------------------
+static int ReconFlag(const std::string &r) {
+  if (r == "dc") return AKMI_RECON_DC;
+  if (r == "plm") return AKMI_RECON_PLM;
+  if (r == "ppm4") return AKMI_RECON_PPM4;
+  AKMI_FATAL("reconstruct = '" + r + "' not implemented on this path");
+}
+
+FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &blk) : pmy_pack(pp) {
+  if (pin->GetString(blk, "eos") != "ideal") AKMI_FATAL("<" + blk + "> eos must be ideal on this path");
+  peos = new EquationOfState;
+  EOS_Data &e = peos->eos_data;
+  e.is_ideal = true;
+  e.gamma = pin->GetReal(blk, "gamma");
+  e.dfloor = pin->GetOrAddReal(blk, "dfloor", static_cast<Real>(FLT_MIN));   // eos.cpp:22-25
+  e.pfloor = pin->GetOrAddReal(blk, "pfloor", static_cast<Real>(FLT_MIN));
+  e.tfloor = pin->GetOrAddReal(blk, "tfloor", static_cast<Real>(FLT_MIN));
+  e.sfloor = pin->GetOrAddReal(blk, "sfloor", static_cast<Real>(FLT_MIN));
+  e.sigma_max = pin->GetOrAddReal(blk, "sigma_max", static_cast<Real>(FLT_MAX));
+  const RegionIndcs &ind = pp->pmesh->mb_indcs;
+  std::string rec = pin->GetOrAddString(blk, "reconstruct", "plm");
+  recon_method = ReconFlag(rec);
+  if (rec == "ppm4" && ind.ng < 3)
+    AKMI_FATAL("PPM/WENOZ reconstruction requires at least 3 ghost zones");
+  if (pin->GetOrAddInteger(blk, "nscalars", 0) != 0) AKMI_FATAL("passive scalars are not on this path");
+  fused = pin->GetOrAddBoolean(blk, "fused_stage", true);
+  pack_c.nmb = pp->nmb_thispack; pack_c.nvar = 5;
+  pack_c.nx1 = ind.nx1; pack_c.nx2 = ind.nx2; pack_c.nx3 = ind.nx3; pack_c.ng = ind.ng;
+  pack_c.dx = pp->pmb->d_dx.p;
+  pack_c.gamma = e.gamma; pack_c.dfloor = e.dfloor; pack_c.pfloor = e.pfloor;
+  pack_c.tfloor = e.tfloor; pack_c.sfloor = e.sfloor; pack_c.sigma_max = e.sigma_max;
+  const size_t n1 = ind.nx1 + 2*ind.ng, n2 = ind.nx2 > 1 ? ind.nx2 + 2*ind.ng : 1,
+               n3 = ind.nx3 > 1 ? ind.nx3 + 2*ind.ng : 1;
+  const size_t ncc = static_cast<size_t>(pp->nmb_thispack)*5*n3*n2*n1;
+  u0.Realloc(ncc); w0.Realloc(ncc); u1.Realloc(ncc);
+  counters.Realloc(3); dt3.Realloc(3);
+}
+FluidBase::~FluidBase() {
+  u0.Free(); w0.Free(); u1.Free(); counters.Free(); dt3.Free(); ws.Free();
+  delete peos;
+}
+void FluidBase::FinishNewDt() {        // hydro_newdt.cpp:121-124
+  Real d[3];
+  HIPCHK(hipMemcpyAsync(d, dt3.p, sizeof(d), hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  Mesh *pm = pmy_pack->pmesh;
+  dtnew = d[0];
+  if (pm->multi_d) dtnew = std::min(dtnew, d[1]);
+  if (pm->three_d) dtnew = std::min(dtnew, d[2]);
+}
+
+static void FaceAlloc(DvceFaceFld &f, size_t nmb, size_t nv, size_t n3, size_t n2, size_t n1, int fs) {
+  f.x1f.Realloc(nmb*nv*n3*n2*(n1 + fs)); f.x2f.Realloc(nmb*nv*n3*(n2 + fs)*n1);
+  f.x3f.Realloc(nmb*nv*(n3 + fs)*n2*n1);
+}
+static void FaceFree(DvceFaceFld &f) { f.x1f.Free(); f.x2f.Free(); f.x3f.Free(); }
+
+namespace hydro {
+Hydro::Hydro(MeshBlockPack *pp, ParameterInput *pin) : FluidBase(pp, pin, "hydro") {
+  if (pin->GetString("hydro", "rsolver") != "hllc") AKMI_FATAL("<hydro> rsolver: hllc only on this path");
+  rsolver_method = AKMI_RS_HLLC;
+  const RegionIndcs &ind = pp->pmesh->mb_indcs;
+  const size_t n1 = ind.nx1 + 2*ind.ng, n2 = ind.nx2 > 1 ? ind.nx2 + 2*ind.ng : 1,
+               n3 = ind.nx3 > 1 ? ind.nx3 + 2*ind.ng : 1;
+  if (fused) ws.Realloc(static_cast<size_t>(akmi_stage_workspace_bytes(&pack_c, 0)));
+  else FaceAlloc(uflx, pp->nmb_thispack, 5, n3, n2, n1, 0);      // hydro.cpp:290-292
+}
+Hydro::~Hydro() { FaceFree(uflx); }
+
+void Hydro::AssembleHydroTasks(std::map<std::string, std::shared_ptr<TaskList>> tl) {
+  TaskID none(0);                                                  // hydro_tasks.cpp:48-80
+  tl["before_stagen"]->AddTask(&Hydro::InitRecv, this, none);
+  auto &s = tl["stagen"];
+  TaskID copyu = s->AddTask(&Hydro::CopyCons, this, none);
+  TaskID flux = s->AddTask(&Hydro::Fluxes, this, copyu);
+  TaskID sendf = s->AddTask(&Hydro::SendFlux, this, flux);
+  TaskID recvf = s->AddTask(&Hydro::RecvFlux, this, sendf);
+  TaskID rkupdt = s->AddTask(&Hydro::RKUpdate, this, recvf);
+  TaskID srctrms = s->AddTask(&Hydro::HydroSrcTerms, this, rkupdt);
+  TaskID restu = s->AddTask(&Hydro::RestrictU, this, srctrms);
+  TaskID sendu = s->AddTask(&Hydro::SendU, this, restu);
+  TaskID recvu = s->AddTask(&Hydro::RecvU, this, sendu);
+  TaskID prol = s->AddTask(&Hydro::Prolongate, this, recvu);
+  TaskID bcs = s->AddTask(&Hydro::ApplyPhysicalBCs, this, prol);
+  TaskID c2p = s->AddTask(&Hydro::ConToPrim, this, bcs);
+  s->AddTask(&Hydro::NewTimeStep, this, c2p);
+  TaskID csend = tl["after_stagen"]->AddTask(&Hydro::ClearSend, this, none);
+  tl["after_stagen"]->AddTask(&Hydro::ClearRecv, this, csend);
+}
+}  // namespace hydro
+
+namespace mhd {
+MHD::MHD(MeshBlockPack *pp, ParameterInput *pin) : FluidBase(pp, pin, "mhd") {
+  if (pin->GetString("mhd", "rsolver") != "hlld") AKMI_FATAL("<mhd> rsolver: hlld only on this path");
+  rsolver_method = AKMI_RS_HLLD;
+  const RegionIndcs &ind = pp->pmesh->mb_indcs;
+  const size_t nmb = pp->nmb_thispack;
+  const size_t n1 = ind.nx1 + 2*ind.ng, n2 = ind.nx2 > 1 ? ind.nx2 + 2*ind.ng : 1,
+               n3 = ind.nx3 > 1 ? ind.nx3 + 2*ind.ng : 1;
+  bcc0.Realloc(nmb*3*n3*n2*n1);
+  FaceAlloc(b0, nmb, 1, n3, n2, n1, 1);
+  FaceAlloc(b1, nmb, 1, n3, n2, n1, 1);
+  if (fused) {
+    ws.Realloc(static_cast<size_t>(akmi_stage_workspace_bytes(&pack_c, 1)));
+  } else {
+    FaceAlloc(uflx, nmb, 5, n3, n2, n1, 1);                        // mhd.cpp:341-343
+    efld.x1e.Realloc(nmb*(n3 + 1)*(n2 + 1)*n1); efld.x2e.Realloc(nmb*(n3 + 1)*n2*(n1 + 1));
+    efld.x3e.Realloc(nmb*n3*(n2 + 1)*(n1 + 1));
+    for (DvceArray<Real> *a : {&e3x1, &e2x1, &e1x2, &e3x2, &e2x3, &e1x3}) a->Realloc(nmb*n3*n2*n1);
+  }
+}
+MHD::~MHD() {
+  bcc0.Free(); FaceFree(b0); FaceFree(b1); FaceFree(uflx);
+  efld.x1e.Free(); efld.x2e.Free(); efld.x3e.Free();
+  for (DvceArray<Real> *a : {&e3x1, &e2x1, &e1x2, &e3x2, &e2x3, &e1x3}) a->Free();
+}
+
+void MHD::AssembleMHDTasks(std::map<std::string, std::shared_ptr<TaskList>> tl) {
+  TaskID none(0);                                                  // mhd_tasks.cpp:38-84
+  tl["before_timeintegrator"]->AddTask(&MHD::SaveMHDState, this, none);
+  tl["before_stagen"]->AddTask(&MHD::InitRecv, this, none);
+  auto &s = tl["stagen"];
+  TaskID copyu = s->AddTask(&MHD::CopyCons, this, none);
+  TaskID flux = s->AddTask(&MHD::Fluxes, this, copyu);
+  TaskID sendf = s->AddTask(&MHD::SendFlux, this, flux);
+  TaskID recvf = s->AddTask(&MHD::RecvFlux, this, sendf);
+  TaskID rkupdt = s->AddTask(&MHD::RKUpdate, this, recvf);
+  TaskID srctrms = s->AddTask(&MHD::MHDSrcTerms, this, rkupdt);
+  TaskID restu = s->AddTask(&MHD::RestrictU, this, srctrms);
+  TaskID sendu = s->AddTask(&MHD::SendU, this, restu);
+  TaskID recvu = s->AddTask(&MHD::RecvU, this, sendu);
+  TaskID efld_ = s->AddTask(&MHD::EField, this, recvu);
+  TaskID sende = s->AddTask(&MHD::SendE, this, efld_);
+  TaskID recve = s->AddTask(&MHD::RecvE, this, sende);
+  TaskID ct = s->AddTask(&MHD::CT, this, recve);
+  TaskID restb = s->AddTask(&MHD::RestrictB, this, ct);
+  TaskID sendb = s->AddTask(&MHD::SendB, this, restb);
+  TaskID recvb = s->AddTask(&MHD::RecvB, this, sendb);
+  TaskID prol = s->AddTask(&MHD::Prolongate, this, recvb);
+  TaskID bcs = s->AddTask(&MHD::ApplyPhysicalBCs, this, prol);
+  TaskID c2p = s->AddTask(&MHD::ConToPrim, this, bcs);
+  s->AddTask(&MHD::NewTimeStep, this, c2p);
+  TaskID csend = tl["after_stagen"]->AddTask(&MHD::ClearSend, this, none);
+  tl["after_stagen"]->AddTask(&MHD::ClearRecv, this, csend);
+}
+}  // namespace mhd
+
+// ---- Driver -----------------------------------------------------------------------------------
+Driver::Driver(ParameterInput *pin, Mesh *pmesh) {       // driver.cpp:85-162
+  if (pin->GetOrAddString("time", "evolution", "dynamic") != "dynamic")
+    AKMI_FATAL("<time> evolution must be dynamic on this path");
+  integrator = pin->GetOrAddString("time", "integrator", "rk2");
+  tlim = pin->GetReal("time", "tlim");
+  nlim = pin->GetOrAddInteger("time", "nlim", -1);
+  for (int q = 0; q < 4; ++q) gam0[q] = gam1[q] = beta[q] = 0.0;
+  if (integrator == "rk1") {
+    nexp_stages = 1; gam0[0] = 0.0; gam1[0] = 1.0; beta[0] = 1.0;
+  } else if (integrator == "rk2") {
+    nexp_stages = 2;
+    gam0[0] = 0.0; gam1[0] = 1.0; beta[0] = 1.0;
+    gam0[1] = 0.5; gam1[1] = 0.5; beta[1] = 0.5;
+  } else if (integrator == "rk3") {
+    nexp_stages = 3;
+    gam0[0] = 0.0; gam1[0] = 1.0; beta[0] = 1.0;
+    gam0[1] = 0.25; gam1[1] = 0.75; beta[1] = 0.25;
+    gam0[2] = 2.0/3.0; gam1[2] = 1.0/3.0; beta[2] = 2.0/3.0;
+  } else {
+    AKMI_FATAL("integrator=" + integrator + " not implemented. Valid choices are [rk1,rk2,rk3].");
+  }
+}
+
+void Driver::ExecuteTaskList(Mesh *pm, const std::string &tl, int stage) {   // driver.cpp:290-307
+  auto &t = pm->pmb_pack->tl_map[tl];
+  if (t->Empty()) return;
+  t->Reset();
+  while (!t->IsComplete())
+    if (t->DoAvailable(this, stage) == TaskListStatus::complete) break;
+}
+
+void Driver::InitBoundaryValuesAndPrimitives(Mesh *pm) {   // driver.cpp:569-653
+  if (auto *ph = pm->pmb_pack->phydro) {
+    ph->SendU(this, 0); ph->RecvU(this, 0); ph->ApplyPhysicalBCs(this, 0); ph->ConToPrim(this, 0);
+  }
+  if (auto *pm_ = pm->pmb_pack->pmhd) {
+    pm_->SendU(this, 0); pm_->RecvU(this, 0); pm_->SendB(this, 0); pm_->RecvB(this, 0);
+    pm_->ApplyPhysicalBCs(this, 0); pm_->ConToPrim(this, 0);
+  }
+}
+
+void Driver::Initialize(Mesh *pm) {                        // driver.cpp:314-371
+  InitBoundaryValuesAndPrimitives(pm);
+  if (pm->pmb_pack->phydro) pm->pmb_pack->phydro->NewTimeStep(this, nexp_stages);
+  if (pm->pmb_pack->pmhd) pm->pmb_pack->pmhd->NewTimeStep(this, nexp_stages);
+  pm->NewTimeStep(tlim);
+  nmb_updated_ = 0;
+}
+
+int Driver::Execute(Mesh *pm, int max_cycles) {            // driver.cpp:380-459
+  int n = 0;
+  while ((pm->time < tlim) && (pm->ncycle < nlim || nlim < 0)) {
+    if (max_cycles >= 0 && n >= max_cycles) break;
+    ExecuteTaskList(pm, "before_timeintegrator", 0);
+    for (int stage = 1; stage <= nexp_stages; ++stage) {
+      ExecuteTaskList(pm, "before_stagen", stage);
+      ExecuteTaskList(pm, "stagen", stage);
+      ExecuteTaskList(pm, "after_stagen", stage);
+    }
+    ExecuteTaskList(pm, "after_timeintegrator", 1);
+    pm->time = pm->time + pm->dt;
+    pm->ncycle++;
+    nmb_updated_ += pm->nmb_total;
+    pm->NewTimeStep(tlim);
+    ++n;
+  }
+  return n;
+}
+
+// ---- task bodies: one C-ABI call each ------------------------------------------------------------
+namespace hydro {
+TaskStatus Hydro::CopyCons(Driver *d, int stage) {         // hydro_tasks.cpp:130-152
+  if (stage == 1 && !fused) AKCHK(akmi_copy_cons(&pack_c, u0.p, u1.p, stream));
+  return TaskStatus::complete;
+}
+TaskStatus Hydro::Fluxes(Driver *d, int stage) {           // hydro_tasks.cpp:159-201
+  if (!fused)
+    AKCHK(akmi_hydro_fluxes(&pack_c, recon_method, rsolver_method, w0.p, uflx.x1f.p, uflx.x2f.p,
+                            uflx.x3f.p, 0, stream));
+  return TaskStatus::complete;
+}
+TaskStatus Hydro::RKUpdate(Driver *d, int stage) {         // hydro_update.cpp:23-83
+  Real beta_dt = d->beta[stage - 1]*pmy_pack->pmesh->dt;
+  if (fused) {
+    int do_dt = (stage == d->nexp_stages);
+    AKCHK(akmi_hydro_stage_fused(&pack_c, recon_method, rsolver_method, d->gam0[stage - 1],
+                                 d->gam1[stage - 1], beta_dt, stage == 1, w0.p, u0.p, u1.p, do_dt,
+                                 counters.p, dt3.p, ws.p, stream));
+    interior_done_ = true; dt_ready_ = do_dt;
+  } else {
+    AKCHK(akmi_rk_update(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1], beta_dt, u0.p, u1.p,
+                         uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, 0, stream));
+  }
+  return TaskStatus::complete;
+}
+TaskStatus Hydro::SendU(Driver *d, int stage) {            // hydro_tasks.cpp:308-320 (same rank)
+  AKCHK(akmi_bvals_cc_local(&pack_c, 5, pmy_pack->pmb->d_nghbr.p, u0.p, stream));
+  return TaskStatus::complete;
+}
+TaskStatus Hydro::ApplyPhysicalBCs(Driver *d, int stage) { // hydro_tasks.cpp:357-375
+  if (pmy_pack->pmesh->strictly_periodic) return TaskStatus::complete;
+  AKCHK(akmi_hydro_bcs(&pack_c, 5, pmy_pack->pmb->d_bcs.p, u0.p, stream));
+  return TaskStatus::complete;
+}
+TaskStatus Hydro::ConToPrim(Driver *d, int stage) {        // hydro_tasks.cpp:404-412
+  const RegionIndcs &ind = pmy_pack->pmesh->mb_indcs;
+  const int n1 = ind.nx1 + 2*ind.ng, n2 = ind.nx2 > 1 ? ind.nx2 + 2*ind.ng : 1,
+            n3 = ind.nx3 > 1 ? ind.nx3 + 2*ind.ng : 1;
+  if (fused && interior_done_) {
+    interior_done_ = false;
+    AKCHK(akmi_hydro_c2p_shell(&pack_c, u0.p, w0.p, counters.p, stream));
+  } else if (fused) {
+    int do_dt = (stage == d->nexp_stages);
+    AKCHK(akmi_hydro_c2p_newdt(&pack_c, u0.p, w0.p, do_dt, counters.p, dt3.p, stream));
+    dt_ready_ = do_dt;
+  } else {
+    AKCHK(akmi_hydro_c2p(&pack_c, u0.p, w0.p, 0, n1 - 1, 0, n2 - 1, 0, n3 - 1, counters.p, stream));
+  }
+  return TaskStatus::complete;
+}
+TaskStatus Hydro::NewTimeStep(Driver *d, int stage) {      // hydro_newdt.cpp:30-139
+  if (stage != d->nexp_stages) return TaskStatus::complete;
+  if (!dt_ready_) AKCHK(akmi_hydro_newdt(&pack_c, w0.p, dt3.p, stream));
+  dt_ready_ = false;
+  FinishNewDt();
+  return TaskStatus::complete;
+}
+}  // namespace hydro
+
+namespace mhd {
+TaskStatus MHD::CopyCons(Driver *d, int stage) {           // mhd_tasks.cpp:162-170
+  if (stage == 1 && !fused) {
+    AKCHK(akmi_copy_cons(&pack_c, u0.p, u1.p, stream));
+    HIPCHK(hipMemcpyAsync(b1.x1f.p, b0.x1f.p, sizeof(Real)*b0.x1f.n, hipMemcpyDeviceToDevice, stream));
+    HIPCHK(hipMemcpyAsync(b1.x2f.p, b0.x2f.p, sizeof(Real)*b0.x2f.n, hipMemcpyDeviceToDevice, stream));
+    HIPCHK(hipMemcpyAsync(b1.x3f.p, b0.x3f.p, sizeof(Real)*b0.x3f.n, hipMemcpyDeviceToDevice, stream));
+  }
+  return TaskStatus::complete;
+}
+TaskStatus MHD::Fluxes(Driver *d, int stage) {             // mhd_tasks.cpp:177-216
+  if (!fused)
+    AKCHK(akmi_mhd_fluxes(&pack_c, recon_method, rsolver_method, w0.p, bcc0.p, b0.x1f.p, b0.x2f.p,
+                          b0.x3f.p, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, e3x1.p, e2x1.p, e1x2.p,
+                          e3x2.p, e2x3.p, e1x3.p, stream));
+  return TaskStatus::complete;
+}
+TaskStatus MHD::RKUpdate(Driver *d, int stage) {           // mhd_update.cpp:24-84
+  Real beta_dt = d->beta[stage - 1]*pmy_pack->pmesh->dt;
+  if (fused) {
+    int do_dt = (stage == d->nexp_stages);
+    AKCHK(akmi_mhd_stage_fused(&pack_c, recon_method, rsolver_method, d->gam0[stage - 1],
+                               d->gam1[stage - 1], beta_dt, stage == 1, w0.p, bcc0.p, u0.p, u1.p,
+                               b0.x1f.p, b0.x2f.p, b0.x3f.p, b1.x1f.p, b1.x2f.p, b1.x3f.p, do_dt,
+                               counters.p, dt3.p, ws.p, stream));
+    interior_done_ = true; dt_ready_ = do_dt;
+  } else {
+    AKCHK(akmi_rk_update(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1], beta_dt, u0.p, u1.p,
+                         uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, 1, stream));
+  }
+  return TaskStatus::complete;
+}
+TaskStatus MHD::SendU(Driver *d, int stage) {
+  AKCHK(akmi_bvals_cc_local(&pack_c, 5, pmy_pack->pmb->d_nghbr.p, u0.p, stream));
+  return TaskStatus::complete;
+}
+TaskStatus MHD::EField(Driver *d, int stage) {             // mhd_corner_e.cpp:26-417
+  if (!fused)
+    AKCHK(akmi_mhd_corner_e(&pack_c, w0.p, bcc0.p, e3x1.p, e2x1.p, e1x2.p, e3x2.p, e2x3.p, e1x3.p,
+                            uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, efld.x1e.p, efld.x2e.p, efld.x3e.p,
+                            stream));
+  return TaskStatus::complete;
+}
+TaskStatus MHD::CT(Driver *d, int stage) {                 // mhd_ct.cpp:23-80
+  if (!fused)
+    AKCHK(akmi_mhd_ct(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1],
+                      d->beta[stage - 1]*pmy_pack->pmesh->dt, efld.x1e.p, efld.x2e.p, efld.x3e.p,
+                      b0.x1f.p, b0.x2f.p, b0.x3f.p, b1.x1f.p, b1.x2f.p, b1.x3f.p, stream));
+  return TaskStatus::complete;
+}
+TaskStatus MHD::SendB(Driver *d, int stage) {
+  AKCHK(akmi_bvals_fc_local(&pack_c, pmy_pack->pmb->d_nghbr.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, stream));
+  return TaskStatus::complete;
+}
+TaskStatus MHD::ApplyPhysicalBCs(Driver *d, int stage) {   // mhd_tasks.cpp:501-520
+  if (pmy_pack->pmesh->strictly_periodic) return TaskStatus::complete;
+  AKCHK(akmi_hydro_bcs(&pack_c, 5, pmy_pack->pmb->d_bcs.p, u0.p, stream));
+  AKCHK(akmi_bfield_bcs(&pack_c, pmy_pack->pmb->d_bcs.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, stream));
+  return TaskStatus::complete;
+}
+TaskStatus MHD::ConToPrim(Driver *d, int stage) {
+  const RegionIndcs &ind = pmy_pack->pmesh->mb_indcs;
+  const int n1 = ind.nx1 + 2*ind.ng, n2 = ind.nx2 > 1 ? ind.nx2 + 2*ind.ng : 1,
+            n3 = ind.nx3 > 1 ? ind.nx3 + 2*ind.ng : 1;
+  if (fused && interior_done_) {
+    interior_done_ = false;
+    AKCHK(akmi_mhd_c2p_shell(&pack_c, u0.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, w0.p, bcc0.p, counters.p, stream));
+  } else if (fused) {
+    int do_dt = (stage == d->nexp_stages);
+    AKCHK(akmi_mhd_c2p_newdt(&pack_c, u0.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, w0.p, bcc0.p, do_dt,
+                             counters.p, dt3.p, stream));
+    dt_ready_ = do_dt;
+  } else {
+    AKCHK(akmi_mhd_c2p(&pack_c, u0.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, w0.p, bcc0.p, 0, n1 - 1, 0, n2 - 1,
+                       0, n3 - 1, counters.p, stream));
+  }
+  return TaskStatus::complete;
+}
+TaskStatus MHD::NewTimeStep(Driver *d, int stage) {        // mhd_newdt.cpp:31-174
+  if (stage != d->nexp_stages) return TaskStatus::complete;
+  if (!dt_ready_) AKCHK(akmi_mhd_newdt(&pack_c, w0.p, bcc0.p, dt3.p, stream));
+  dt_ready_ = false;
+  FinishNewDt();
+  return TaskStatus::complete;
+}
+}  // namespace mhd
+
+// ---- the simulation object behind akmi_sim_* --------------------------------------------------------
+struct Sim {
+  ParameterInput pin;
+  Mesh *pmesh = nullptr;
+  Driver *pdriver = nullptr;
+  ~Sim() { delete pdriver; delete pmesh; }
+};
+
+}  // namespace host
+}  // namespace akmi
+
+using namespace akmi::host;
+
+extern "C" {
+
+void *akmi_sim_create(const char *deck_text, void *stream) {
+  Sim *s = new Sim;
+  s->pin.LoadFromString(deck_text);
+  s->pmesh = new Mesh(&s->pin);
+  s->pmesh->pmb_pack->AddPhysics(&s->pin);
+  if (auto *ph = s->pmesh->pmb_pack->phydro) ph->stream = (hipStream_t)stream;
+  if (auto *pm = s->pmesh->pmb_pack->pmhd) pm->stream = (hipStream_t)stream;
+  return s;
+}
+
+/* the Driver reads <time>/tlim, which the linear-wave problem generator rescales: create it
+ * after the initial conditions have been uploaded */
+int akmi_sim_initialize(void *h, double tlim_override) {
+  Sim *s = static_cast<Sim *>(h);
+  if (tlim_override > 0.0) s->pin.SetReal("time", "tlim", tlim_override);
+  delete s->pdriver;
+  s->pdriver = new Driver(&s->pin, s->pmesh);
+  s->pdriver->Initialize(s->pmesh);
+  return AKMI_COMPLETE;
+}
+
+int akmi_sim_execute(void *h, int max_cycles) {
+  Sim *s = static_cast<Sim *>(h);
+  return s->pdriver->Execute(s->pmesh, max_cycles);
+}
+
+void akmi_sim_destroy(void *h) { delete static_cast<Sim *>(h); }
+
+double akmi_sim_time(void *h) { return static_cast<Sim *>(h)->pmesh->time; }
+double akmi_sim_dt(void *h) { return static_cast<Sim *>(h)->pmesh->dt; }
+double akmi_sim_tlim(void *h) { Sim *s = static_cast<Sim *>(h); return s->pdriver ? s->pdriver->tlim : s->pin.GetReal("time", "tlim"); }
+int akmi_sim_ncycle(void *h) { return static_cast<Sim *>(h)->pmesh->ncycle; }
+int akmi_sim_nmb(void *h) { return static_cast<Sim *>(h)->pmesh->nmb_total; }
+
+/* device pointer + element count of a named array: u0 w0 u1 bcc0 b0x1f b0x2f b0x3f b1x1f b1x2f
+ * b1x3f dx ; lloc (host int[nmb][3]) via akmi_sim_lloc */
+void *akmi_sim_array(void *h, const char *name, long long *count) {
+  Sim *s = static_cast<Sim *>(h);
+  MeshBlockPack *pk = s->pmesh->pmb_pack;
+  FluidBase *f = pk->phydro ? static_cast<FluidBase *>(pk->phydro) : static_cast<FluidBase *>(pk->pmhd);
+  std::string n(name);
+  DvceArray<Real> *a = nullptr;
+  if (n == "u0") a = &f->u0; else if (n == "w0") a = &f->w0; else if (n == "u1") a = &f->u1;
+  else if (n == "dx") a = &pk->pmb->d_dx;
+  else if (pk->pmhd) {
+    auto *m = pk->pmhd;
+    if (n == "bcc0") a = &m->bcc0;
+    else if (n == "b0x1f") a = &m->b0.x1f; else if (n == "b0x2f") a = &m->b0.x2f; else if (n == "b0x3f") a = &m->b0.x3f;
+    else if (n == "b1x1f") a = &m->b1.x1f; else if (n == "b1x2f") a = &m->b1.x2f; else if (n == "b1x3f") a = &m->b1.x3f;
+  }
+  if (!a) { if (count) *count = 0; return nullptr; }
+  if (count) *count = static_cast<long long>(a->n);
+  return a->p;
+}
+
+const int *akmi_sim_lloc(void *h) { return static_cast<Sim *>(h)->pmesh->lloc_eachmb.data(); }
+
+}  // extern "C"

@@ -1,0 +1,283 @@
+// akmi_host.hpp -- C++ host mirror of the reference's operator surface for the hot path.
+//
+// Same class and member names as the reference so that a task body reads like its original:
+//   ParameterInput   src/parameter_input.hpp:67-127
+//   TaskStatus/TaskID/Task/TaskList   src/tasklist/task_list.hpp:30-236
+//   RegionSize/RegionIndcs/Mesh/MeshBlock/MeshBlockPack   src/mesh/mesh.hpp:25-185,
+//                                                          src/mesh/meshblock_pack.hpp:44-97
+//   hydro::Hydro / mhd::MHD (arrays + task member functions)   src/hydro/hydro.hpp:73-154,
+//                                                              src/mhd/mhd.hpp:93-199
+//   Driver   src/driver/driver.cpp:93-162,290-307,314-459
+// Every task body is ONE call through the C ABI of include/akmi.h.  Single rank (all
+// MeshBlocks of the mesh in one pack on one GPU); multi-rank runs are driven by the Python
+// mirror (athenak_amd/*.py) because the launch contract is torch.distributed.
+#ifndef AKMI_HOST_HPP_
+#define AKMI_HOST_HPP_
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdint>
+#include <functional>
+#include <list>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+#include "../../include/akmi.h"
+
+namespace akmi {
+namespace host {
+
+using Real = double;
+
+// ---------------------------------------------------------------------------------------
+class ParameterInput {
+ public:
+  ParameterInput() = default;
+  explicit ParameterInput(const std::string &text) { LoadFromString(text); }
+  void LoadFromString(const std::string &text);
+  void ModifyFromCmdline(const std::vector<std::string> &args);
+  bool DoesBlockExist(const std::string &b) const { return blocks_.count(b) != 0; }
+  bool DoesParameterExist(const std::string &b, const std::string &n) const;
+  std::string GetString(const std::string &b, const std::string &n) const;
+  int GetInteger(const std::string &b, const std::string &n) const;
+  Real GetReal(const std::string &b, const std::string &n) const;
+  bool GetBoolean(const std::string &b, const std::string &n) const;
+  std::string GetOrAddString(const std::string &b, const std::string &n, const std::string &d);
+  int GetOrAddInteger(const std::string &b, const std::string &n, int d);
+  Real GetOrAddReal(const std::string &b, const std::string &n, Real d);
+  bool GetOrAddBoolean(const std::string &b, const std::string &n, bool d);
+  void SetReal(const std::string &b, const std::string &n, Real v);
+ private:
+  std::map<std::string, std::map<std::string, std::string>> blocks_;
+};
+
+[[noreturn]] void Fatal(const char *file, int line, const std::string &msg);
+#define AKMI_FATAL(msg) ::akmi::host::Fatal(__FILE__, __LINE__, (msg))
+
+// ---------------------------------------------------------------------------------------
+class Driver;
+enum class TaskStatus {fail, complete, incomplete};
+enum class TaskListStatus {running, stuck, complete, nothing_to_do};
+
+class TaskID {   // task_list.hpp:37-81
+ public:
+  TaskID() = default;
+  explicit TaskID(unsigned int id) { bits_ = (id == 0) ? 0ull : (1ull << (id - 1)); }
+  void Clear() { bits_ = 0; }
+  bool CheckDependencies(const TaskID &dep) const { return (bits_ & dep.bits_) == dep.bits_; }
+  void SetComplete(const TaskID &rhs) { bits_ |= rhs.bits_; }
+  bool operator==(const TaskID &rhs) const { return bits_ == rhs.bits_; }
+  bool operator!=(const TaskID &rhs) const { return bits_ != rhs.bits_; }
+  TaskID operator|(const TaskID &rhs) const { TaskID r; r.bits_ = bits_ | rhs.bits_; return r; }
+ private:
+  std::uint64_t bits_ = 0;
+};
+
+class Task {     // task_list.hpp:88-110
+ public:
+  Task(TaskID id, TaskID dep, std::function<TaskStatus(Driver *, int)> func)
+      : myid_(id), dep_(dep), func_(func) {}
+  TaskStatus operator()(Driver *d, int s) { return func_(d, s); }
+  TaskID GetID() { return myid_; }
+  TaskID GetDependency() { return dep_; }
+  void SetComplete() { complete_ = true; }
+  void SetIncomplete() { complete_ = false; }
+  bool IsComplete() { return complete_; }
+ private:
+  TaskID myid_, dep_;
+  bool complete_ = false;
+  std::function<TaskStatus(Driver *, int)> func_;
+};
+
+class TaskList {  // task_list.hpp:117-236
+ public:
+  bool IsComplete();
+  bool Empty() { return task_list_.empty(); }
+  int Size() { return static_cast<int>(task_list_.size()); }
+  void Reset();
+  TaskListStatus DoAvailable(Driver *d, int s);
+  template <class F, class T>
+  TaskID AddTask(F func, T *obj, TaskID &dep) {
+    TaskID id(static_cast<unsigned int>(task_list_.size()) + 1);
+    task_list_.push_back(Task(id, dep, [=](Driver *d, int s) mutable -> TaskStatus {
+      return (obj->*func)(d, s);
+    }));
+    return id;
+  }
+ private:
+  std::list<Task> task_list_;
+  TaskID tasks_completed_;
+};
+
+// ---------------------------------------------------------------------------------------
+struct RegionSize {     // mesh.hpp:25-29
+  Real x1min, x2min, x3min, x1max, x2max, x3max, dx1, dx2, dx3;
+};
+struct RegionIndcs {    // mesh.hpp:35-41
+  int ng, nx1, nx2, nx3, is, ie, js, je, ks, ke;
+};
+
+template <typename T>
+struct DvceArray {      // flat device array (layout contract: include/akmi.h)
+  T *p = nullptr;
+  size_t n = 0;
+  void Realloc(size_t count);
+  void Free();
+  T *data() const { return p; }
+};
+struct DvceFaceFld { DvceArray<Real> x1f, x2f, x3f; };
+struct DvceEdgeFld { DvceArray<Real> x1e, x2e, x3e; };
+
+class Mesh;
+class MeshBlockPack;
+
+class MeshBlock {       // meshblock.cpp:25-131 (uniform level)
+ public:
+  MeshBlock(MeshBlockPack *ppack, int igids, int nmb);
+  ~MeshBlock();
+  int nmb;
+  std::vector<int> mb_gid;
+  std::vector<RegionSize> mb_size;
+  std::vector<int> mb_bcs;        // [nmb][6]
+  std::vector<int> nghbr;         // [nmb][27] local index or -1 (single rank)
+  DvceArray<Real> d_dx;           // [nmb][3]
+  DvceArray<int> d_bcs, d_nghbr;
+};
+
+namespace hydro { class Hydro; }
+namespace mhd { class MHD; }
+
+class MeshBlockPack {   // meshblock_pack.hpp:44-97
+ public:
+  MeshBlockPack(Mesh *pm, int igids, int igide);
+  ~MeshBlockPack();
+  void AddPhysics(ParameterInput *pin);
+  Mesh *pmesh;
+  int gids, gide, nmb_thispack;
+  MeshBlock *pmb = nullptr;
+  hydro::Hydro *phydro = nullptr;
+  mhd::MHD *pmhd = nullptr;
+  std::map<std::string, std::shared_ptr<TaskList>> tl_map;
+};
+
+class Mesh {            // mesh.hpp:92-185
+ public:
+  explicit Mesh(ParameterInput *pin);
+  ~Mesh();
+  void NewTimeStep(const Real tlim);   // mesh.cpp:573-643
+  int NumberOfMeshBlockCells() const { return mb_indcs.nx1*mb_indcs.nx2*mb_indcs.nx3; }
+  RegionSize mesh_size;
+  RegionIndcs mesh_indcs, mb_indcs;
+  int mesh_bcs[6];
+  bool one_d, two_d, three_d, multi_d, strictly_periodic;
+  int nmb_rootx1, nmb_rootx2, nmb_rootx3, nmb_total;
+  std::vector<int> lloc_eachmb;   // [nmb_total][3], Z-ordered
+  Real time, dt, dtold, cfl_no;
+  int ncycle;
+  MeshBlockPack *pmb_pack = nullptr;
+};
+
+// physics base: what Hydro and MHD share ------------------------------------------------
+struct EOS_Data { Real gamma, dfloor, pfloor, tfloor, sfloor, sigma_max; bool is_ideal; };
+struct EquationOfState { EOS_Data eos_data; };
+
+class FluidBase {
+ public:
+  FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &blk);
+  virtual ~FluidBase();
+  MeshBlockPack *pmy_pack;
+  EquationOfState *peos;
+  int recon_method, rsolver_method;
+  bool fused;
+  akmi_pack pack_c;
+  DvceArray<Real> u0, w0, u1;
+  DvceArray<int> counters;
+  DvceArray<Real> dt3;
+  DvceArray<char> ws;
+  Real dtnew = static_cast<Real>(FLT_MAX);
+  hipStream_t stream = nullptr;
+ protected:
+  void FinishNewDt();
+  bool interior_done_ = false, dt_ready_ = false;
+};
+
+namespace hydro {
+class Hydro : public FluidBase {    // hydro.hpp:73-154
+ public:
+  Hydro(MeshBlockPack *pp, ParameterInput *pin);
+  ~Hydro() override;
+  DvceFaceFld uflx;
+  void AssembleHydroTasks(std::map<std::string, std::shared_ptr<TaskList>> tl);
+  TaskStatus InitRecv(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus CopyCons(Driver *d, int stage);
+  TaskStatus Fluxes(Driver *d, int stage);
+  TaskStatus SendFlux(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus RecvFlux(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus RKUpdate(Driver *d, int stage);
+  TaskStatus HydroSrcTerms(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus RestrictU(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus SendU(Driver *d, int stage);
+  TaskStatus RecvU(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus Prolongate(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus ApplyPhysicalBCs(Driver *d, int stage);
+  TaskStatus ConToPrim(Driver *d, int stage);
+  TaskStatus NewTimeStep(Driver *d, int stage);
+  TaskStatus ClearSend(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus ClearRecv(Driver *d, int stage) { return TaskStatus::complete; }
+};
+}  // namespace hydro
+
+namespace mhd {
+class MHD : public FluidBase {      // mhd.hpp:93-199
+ public:
+  MHD(MeshBlockPack *pp, ParameterInput *pin);
+  ~MHD() override;
+  DvceArray<Real> bcc0;
+  DvceFaceFld b0, b1, uflx;
+  DvceEdgeFld efld;
+  DvceArray<Real> e3x1, e2x1, e1x2, e3x2, e2x3, e1x3;
+  void AssembleMHDTasks(std::map<std::string, std::shared_ptr<TaskList>> tl);
+  TaskStatus SaveMHDState(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus InitRecv(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus CopyCons(Driver *d, int stage);
+  TaskStatus Fluxes(Driver *d, int stage);
+  TaskStatus SendFlux(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus RecvFlux(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus RKUpdate(Driver *d, int stage);
+  TaskStatus MHDSrcTerms(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus RestrictU(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus SendU(Driver *d, int stage);
+  TaskStatus RecvU(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus EField(Driver *d, int stage);
+  TaskStatus SendE(Driver *d, int stage) { return TaskStatus::complete; }   // identity on uniform meshes
+  TaskStatus RecvE(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus CT(Driver *d, int stage);
+  TaskStatus RestrictB(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus SendB(Driver *d, int stage);
+  TaskStatus RecvB(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus Prolongate(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus ApplyPhysicalBCs(Driver *d, int stage);
+  TaskStatus ConToPrim(Driver *d, int stage);
+  TaskStatus NewTimeStep(Driver *d, int stage);
+  TaskStatus ClearSend(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus ClearRecv(Driver *d, int stage) { return TaskStatus::complete; }
+};
+}  // namespace mhd
+
+class Driver {          // driver.cpp
+ public:
+  Driver(ParameterInput *pin, Mesh *pmesh);
+  void ExecuteTaskList(Mesh *pm, const std::string &tl, int stage);
+  void InitBoundaryValuesAndPrimitives(Mesh *pm);
+  void Initialize(Mesh *pm);
+  int Execute(Mesh *pm, int max_cycles);
+  std::string integrator;
+  Real tlim;
+  int nlim, nexp_stages;
+  Real gam0[4], gam1[4], beta[4];
+  std::int64_t nmb_updated_ = 0;
+};
+
+}  // namespace host
+}  // namespace akmi
+#endif  // AKMI_HOST_HPP_

@@ -1,0 +1,107 @@
+"""NativeSimulation: the C++ host driver (csrc/akmi_host.cpp) behind the same Python surface
+as main.Simulation.  Mesh, MeshBlockPack, TaskList, Hydro/MHD tasks and the Driver loop run
+in C++ (akmi_sim_*); Python only evaluates the closed-form initial conditions into the native
+device arrays (aliased as torch tensors through __cuda_array_interface__)."""
+import ctypes as C
+
+import torch
+
+from . import capi
+from .mesh import Mesh
+from .pgen import ProblemGenerator
+
+
+class _DevAlias:
+    """exposes a raw device pointer to torch (zero-copy)"""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (ptr, False),
+                                         "version": 3, "strides": None}
+
+
+class _Face:
+    pass
+
+
+class _Eos:
+    def __init__(self, gamma):
+        self.eos_data = type("EOS_Data", (), {"gamma": gamma})()
+
+
+class _PhysAlias:
+    """the attributes ProblemGenerator needs, backed by the native arrays"""
+
+
+class NativeSimulation:
+    def __init__(self, pin, initialize=True):
+        self.pin = pin
+        self.L = capi.lib()
+        stream = capi._stream()
+        self.h = C.c_void_p(self.L.akmi_sim_create(pin.Dump().encode(), stream))
+        # a Python Mesh of the same deck gives the problem generators their coordinates
+        self.pmesh = Mesh(pin)
+        is_mhd = pin.DoesBlockExist("mhd")
+        blk = "mhd" if is_mhd else "hydro"
+        n3, n2, n1 = self.pmesh.mb_indcs.ncells
+        nmb = self.pmesh.nmb_total
+        ph = _PhysAlias()
+        ph.peos = _Eos(pin.GetReal(blk, "gamma"))
+        ph.u0 = self._alias("u0", (nmb, 5, n3, n2, n1))
+        ph.w0 = self._alias("w0", (nmb, 5, n3, n2, n1))
+        ph.u1 = self._alias("u1", (nmb, 5, n3, n2, n1))
+        if is_mhd:
+            ph.bcc0 = self._alias("bcc0", (nmb, 3, n3, n2, n1))
+            for reg in ("b0", "b1"):
+                f = _Face()
+                f.x1f = self._alias(reg + "x1f", (nmb, n3, n2, n1 + 1))
+                f.x2f = self._alias(reg + "x2f", (nmb, n3, n2 + 1, n1))
+                f.x3f = self._alias(reg + "x3f", (nmb, n3 + 1, n2, n1))
+                setattr(ph, reg, f)
+            self.pmesh.pmb_pack.pmhd = ph
+        else:
+            self.pmesh.pmb_pack.phydro = ph
+        self._phys = ph
+        self.pmesh.pgen = ProblemGenerator(pin, self.pmesh)
+        if initialize:
+            self.Initialize()
+
+    def _alias(self, name, shape):
+        cnt = C.c_longlong(0)
+        p = self.L.akmi_sim_array(self.h, name.encode(), C.byref(cnt))
+        n = 1
+        for s in shape:
+            n *= s
+        assert p and cnt.value == n, (name, cnt.value, n)
+        return torch.as_tensor(_DevAlias(p, shape), device="cuda")
+
+    @property
+    def phys(self):
+        return self._phys
+
+    def Initialize(self):
+        torch.cuda.synchronize()
+        capi.check(self.L.akmi_sim_initialize(self.h, C.c_double(self.pin.GetReal("time", "tlim"))),
+                   "sim_initialize")
+
+    def Execute(self, max_cycles=None):
+        n = self.L.akmi_sim_execute(self.h, -1 if max_cycles is None else int(max_cycles))
+        self.pmesh.time = self.time
+        self.pmesh.dt = self.dt
+        self.pmesh.ncycle = self.ncycle
+        return n
+
+    time = property(lambda s: s.L.akmi_sim_time(s.h))
+    dt = property(lambda s: s.L.akmi_sim_dt(s.h))
+    tlim = property(lambda s: s.L.akmi_sim_tlim(s.h))
+    ncycle = property(lambda s: s.L.akmi_sim_ncycle(s.h))
+
+    def close(self):
+        if self.h:
+            self.L.akmi_sim_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

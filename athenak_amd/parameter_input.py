@@ -102,5 +102,13 @@ class ParameterInput:
     def SetReal(self, blk, name, val):
         self.blocks.setdefault(blk, {})[name] = repr(float(val))
 
+    def Dump(self):
+        """deck text of the current state (ParameterDump of the reference, src/main.cpp:380)"""
+        out = []
+        for b, d in self.blocks.items():
+            out.append("<%s>" % b)
+            out += ["%s = %s" % (k, v) for k, v in d.items()]
+        return "\n".join(out) + "\n"
+
     def SetString(self, blk, name, val):
         self.blocks.setdefault(blk, {})[name] = str(val)

@@ -212,6 +212,27 @@ int akmi_mhd_c2p_shell(const akmi_pack *p, double *u0, const double *bx1f, const
                        const double *bx3f, double *w0, double *bcc0, int *counters,
                        void *stream);
 
+/* ---- native host driver (C++ mirror of Mesh/MeshBlockPack/TaskList/Driver/Hydro/MHD) ----- *
+ * athenak_amd/csrc/akmi_host.{hpp,cpp}: the reference's operator surface for this path in
+ * C++, every task body one call of the entries above.  Single rank: all MeshBlocks of the mesh
+ * in one pack on the current GPU.  deck_text is an athinput deck (src/parameter_input.cpp
+ * grammar).  Initial conditions are written by the caller into the arrays returned by
+ * akmi_sim_array (device pointers, layouts as above) before akmi_sim_initialize, which performs
+ * Driver::Initialize (src/driver/driver.cpp:314-371); tlim_override > 0 replaces <time>/tlim
+ * (the linear-wave generator rescales it).  akmi_sim_execute runs Driver::Execute for at most
+ * max_cycles (<0: until tlim/nlim) and returns the number of cycles done. */
+void *akmi_sim_create(const char *deck_text, void *stream);
+int akmi_sim_initialize(void *sim, double tlim_override);
+int akmi_sim_execute(void *sim, int max_cycles);
+void akmi_sim_destroy(void *sim);
+double akmi_sim_time(void *sim);
+double akmi_sim_dt(void *sim);
+double akmi_sim_tlim(void *sim);
+int akmi_sim_ncycle(void *sim);
+int akmi_sim_nmb(void *sim);
+void *akmi_sim_array(void *sim, const char *name, long long *count);
+const int *akmi_sim_lloc(void *sim);
+
 /* ---- measurement utility ------------------------------------------------------------ *
  * dst[i] = src[i] for n doubles with the library's own access pattern (8 B per lane,
  * 512 B per wave, grid-stride): a kernel of KNOWN traffic (8n read + 8n written) used to

@@ -116,7 +116,7 @@ def oracle_arrays(osim, is_mhd):
     return d
 
 
-def make_pair(problem, n, dims, mb=None, inject=True, fused=None, **kw):
+def make_pair(problem, n, dims, mb=None, inject=True, fused=None, native=False, **kw):
     """(product Simulation, oracle Sim) advanced to the end of Driver::Initialize on
     identical initial data (inject=True copies the oracle's pgen output into the product so
     that libm-vs-numpy sin/cos ulps cannot enter the comparison)."""
@@ -129,7 +129,11 @@ def make_pair(problem, n, dims, mb=None, inject=True, fused=None, **kw):
         pin.blocks[blk]["fused_stage"] = "true" if fused else "false"
     okw = oracle_kwargs(pin)
     osim = akref.Sim(**okw)
-    sim = Simulation(pin, initialize=False)
+    if native:
+        from athenak_amd.native import NativeSimulation
+        sim = NativeSimulation(pin, initialize=False)
+    else:
+        sim = Simulation(pin, initialize=False)
     is_mhd = bool(okw["is_mhd"])
     osim.initialize()
     if inject:
@@ -139,12 +143,15 @@ def make_pair(problem, n, dims, mb=None, inject=True, fused=None, **kw):
             ph.b0.x1f.copy_(torch.from_numpy(osim.array("b0x1f").copy()))
             ph.b0.x2f.copy_(torch.from_numpy(osim.array("b0x2f").copy()))
             ph.b0.x3f.copy_(torch.from_numpy(osim.array("b0x3f").copy()))
-    sim.pdriver.Initialize(sim.pmesh, pin)
+    if native:
+        sim.Initialize()
+    else:
+        sim.pdriver.Initialize(sim.pmesh, pin)
     return sim, osim, is_mhd
 
 
-def compare_run(problem, n, dims, mb=None, cycles=2, inject=True, fused=None, **kw):
-    sim, osim, is_mhd = make_pair(problem, n, dims, mb, inject, fused, **kw)
+def compare_run(problem, n, dims, mb=None, cycles=2, inject=True, fused=None, native=False, **kw):
+    sim, osim, is_mhd = make_pair(problem, n, dims, mb, inject, fused, native, **kw)
     done = 0
     for _ in range(cycles):
         a = sim.Execute(max_cycles=1)

@@ -378,3 +378,24 @@ def test_shared_edge_emfs_identical_across_blocks():
         assert np.array_equal(e2[m, ke+1, js:je+1, is_:ie+2], e2[n, ks, js:je+1, is_:ie+2])
         checked += 6
     assert checked == 48 and np.abs(e3).max() > 0
+
+
+NATIVE_CASES = [("linear_wave_hydro", 256, 1, 256, 10, dict(extra=["problem/along_x1=true"])),
+                ("sod", 32, 3, 16, 4, dict(cfl=0.3)),
+                ("sod", 64, 1, 32, 6, dict(cfl=0.3)),
+                ("orszag_tang", 32, 2, 16, 4, dict(cfl=0.3)),
+                ("orszag_tang", 32, 3, 16, 3, dict(cfl=0.3)),
+                ("linear_wave_mhd", 24, 3, 12, 3, dict(integrator="rk3")),
+                ("blast", 24, 3, 12, 2, {})]
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("case", NATIVE_CASES, ids=lambda c: "%s-%d^%d-mb%d" % (c[0], c[1], c[2], c[3]))
+def test_native_cpp_driver_parity(case, fused):
+    """the C++ host mirror (akmi_sim_*: Mesh, MeshBlockPack, TaskList, Hydro/MHD tasks, Driver in
+    csrc/akmi_host.cpp) against the oracle: bit-identical, same dt sequence"""
+    problem, n, dims, mb, cycles, kw = case
+    res = pu.compare_run(problem, n, dims, mb, cycles, fused=fused, native=True, **kw)
+    assert res["cycles"] == cycles
+    assert res["time"][0] == res["time"][1], res["time"]
+    assert res["bitwise_equal"], res["diffs"]

@@ -43,8 +43,39 @@ def child(nx):
              nx**3/(2*tot*1e-3)/1e6))
 
 
+def native_vs_python(problem, nx, cycles):
+    """whole-cycle wall time of the Python host mirror vs the C++ host driver"""
+    import time
+    import torch
+    from athenak_amd.main import Simulation, load_deck
+    from athenak_amd.native import NativeSimulation
+    torch.cuda.set_device(0)
+    deck = {"sod": "sod.athinput", "orszag_tang": "orszag_tang.athinput",
+            "lw1d": "linear_wave_hydro.athinput"}[problem]
+    ov = ["time/cfl_number=0.3", "time/nlim=-1", "time/tlim=1.0e9"]
+    dims = 1 if problem == "lw1d" else 3
+    for q in (1, 2, 3):
+        n = nx if q <= dims else 1
+        ov += ["mesh/nx%d=%d" % (q, n), "meshblock/nx%d=%d" % (q, n)]
+    if problem == "lw1d":
+        ov += ["problem/along_x1=true"]
+    for name, cls in (("python host", Simulation), ("c++ host", NativeSimulation)):
+        sim = cls(load_deck(deck, ov))
+        sim.Execute(max_cycles=3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sim.Execute(max_cycles=cycles)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        print("%-12s %s %d^%d: %.1f us/cycle  %.1f Mcell-updates/s" % (name, problem, nx, dims,
+              el/cycles*1e6, nx**dims*cycles/el/1e6))
+
+
 if __name__ == "__main__":
-    if os.environ.get("AKMI_KBENCH_CHILD"):
+    if len(sys.argv) > 1 and sys.argv[1] == "hosts":
+        for prob, nx, cyc in (("lw1d", 256, 300), ("sod", 64, 100), ("sod", 128, 50), ("orszag_tang", 128, 30)):
+            native_vs_python(prob, nx, cyc)
+    elif os.environ.get("AKMI_KBENCH_CHILD"):
         child(int(sys.argv[1]))
     else:
         nx = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 256
