@@ -74,6 +74,7 @@ class _Channel:
         self.nsend = 0
         self.send_tab = self.send_off = self.seg_off = None
         self.sendbuf = self.recvbuf = None
+        self.h_send = self.h_recv = None     # pinned host mirrors (host-staged transport only)
         self.send_slices = {}   # peer -> (start, stop) in sendbuf
         self.recv_slices = {}
         self.works = []
@@ -162,23 +163,40 @@ class MeshBoundaryValues:
         self.fc = self._plan(lambda d: self.k.fc_segsize(pack_c, d))
 
     # ------------------------------------------------------------------------------
+    def _staged(self):
+        """device buffers + a transport that cannot move device memory (anything but RCCL):
+        stage the messages through pinned host buffers, like the reference built without
+        GPU-aware MPI"""
+        import torch.distributed as dist
+        return torch.device(self.device).type == "cuda" and dist.get_backend() != "nccl"
+
     def _post(self, ch):
         import torch.distributed as dist
+        sbuf, rbuf = ch.sendbuf, ch.recvbuf
+        if self._staged():
+            if ch.h_send is None:
+                ch.h_send = torch.empty(ch.sendbuf.shape, dtype=torch.float64, pin_memory=True)
+                ch.h_recv = torch.empty(ch.recvbuf.shape, dtype=torch.float64, pin_memory=True)
+            ch.h_send.copy_(ch.sendbuf, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            sbuf, rbuf = ch.h_send, ch.h_recv
         ops = []
         for r in self.peers:
             a, b = ch.recv_slices[r]
             if b > a:
-                ops.append(dist.P2POp(dist.irecv, ch.recvbuf[a:b], r))
+                ops.append(dist.P2POp(dist.irecv, rbuf[a:b], r))
         for r in self.peers:
             a, b = ch.send_slices[r]
             if b > a:
-                ops.append(dist.P2POp(dist.isend, ch.sendbuf[a:b], r))
+                ops.append(dist.P2POp(dist.isend, sbuf[a:b], r))
         ch.works = dist.batch_isend_irecv(ops) if ops else []
 
     def _wait(self, ch):
         for w in ch.works:
             w.wait()
         ch.works = []
+        if ch.h_recv is not None:
+            ch.recvbuf.copy_(ch.h_recv, non_blocking=True)
 
     # ---- cell-centred ------------------------------------------------------------
     def PackAndSendCC(self, u):

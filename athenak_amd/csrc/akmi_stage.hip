@@ -758,10 +758,17 @@ template <bool MHD>
 static int stage_update(const akmi_pack *p, int recon, double gam0, double gam1, double beta_dt,
                         int copy_u1, const double *w0, const double *bcc0, double *u0, double *u1,
                         double *b0x1f, double *b0x2f, double *b0x3f, double *b1x1f, double *b1x2f,
-                        double *b1x3f, void *ws, const C2PArgs &cp, hipStream_t st) {
+                        double *b1x3f, void *ws, const C2PArgs &cp_in, hipStream_t st,
+                        int phases = AKMI_PHASE_ALL) {
   Geo g = make_geo(p);
   Eos eos = make_eos(p);
   StageWs w = carve(g, MHD ? 1 : 0, ws);
+  // phases: a caller that exchanges halos between the parts of a stage (multi-rank runs) asks
+  // for them one at a time; the parts communicate through u0/b0 and the workspace only
+  const bool do_sweeps = (phases & AKMI_PHASE_SWEEPS) != 0;
+  const bool do_emf = MHD && (phases & AKMI_PHASE_EMF_CT) != 0;
+  C2PArgs cp = cp_in;
+  if (!(phases & AKMI_PHASE_C2P)) cp.enable = 0;
   const int ndim = g.three_d ? 3 : (g.multi_d ? 2 : 1);
   UpdArgs u{gam0, gam1, beta_dt, u0, u1, w.flx1, w.flx2, copy_u1, w.acc};
   int rc = AKMI_COMPLETE;
@@ -783,7 +790,8 @@ static int stage_update(const akmi_pack *p, int recon, double gam0, double gam1,
 
   if (ndim < 3) {
     // 1-D / 2-D: small problems, plain sequence on the caller's stream
-    if (ndim == 1) {
+    if (!do_sweeps) {
+    } else if (ndim == 1) {
       rc = launch_sweep_update<0, MHD>(g, p->gamma, recon, a1, u, st);
     } else {
       rc = MHD ? launch_sweep<0, MHD, MHD>(g, p->gamma, recon, a1, st)
@@ -791,7 +799,7 @@ static int stage_update(const akmi_pack *p, int recon, double gam0, double gam1,
       if (rc == AKMI_COMPLETE) rc = launch_sweep_update<1, MHD>(g, p->gamma, recon, a2, u, st);
     }
     if (rc != AKMI_COMPLETE) return rc;
-    if (MHD) {
+    if (do_emf) {
       rc = akmi_mhd_corner_e(p, w0, bcc0, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5],
                              w.flx1, w.flx2, w.flx3, w.e1, w.e2, w.e3, st);
       if (rc != AKMI_COMPLETE) return rc;
@@ -813,7 +821,7 @@ static int stage_update(const akmi_pack *p, int recon, double gam0, double gam1,
   // developer/test knobs: AKMI_SLAB_CELLS (slab thickness), AKMI_ONE_STREAM=1 (no helper stream)
   static const int env_slab = getenv("AKMI_SLAB_CELLS") ? atoi(getenv("AKMI_SLAB_CELLS")) : 0;
   static const bool env_one = getenv("AKMI_ONE_STREAM") && atoi(getenv("AKMI_ONE_STREAM")) != 0;
-  const int T = env_slab > 1 ? env_slab : AKMI_SLAB;
+  const int T = (phases != AKMI_PHASE_ALL) ? g.nx3 : (env_slab > 1 ? env_slab : AKMI_SLAB);
   const int S = (g.nx3 + T - 1)/T;
   if (S > MAX_SLABS) { set_error("too many slabs"); return AKMI_FAIL; }
   const bool two = (S > 1) && (MHD || cp.enable) && !env_one;
@@ -858,6 +866,7 @@ static int stage_update(const akmi_pack *p, int recon, double gam0, double gam1,
     b1.kl = kA(s) - (MHD ? 1 : 0); b1.ku = kB(s) + (MHD ? 1 : 0);
     b2.kl = b1.kl; b2.ku = b1.ku;
     b3.kl = kA(s); b3.ku = kB(s) + 1;
+    if (do_sweeps) {
     rc = MHD ? launch_sweep<0, MHD, MHD>(g, p->gamma, recon, b1, st)
              : launch_sweep<0, MHD, false>(g, p->gamma, recon, b1, st);
 #if AKMI_X2_MARCH
@@ -868,13 +877,16 @@ static int stage_update(const akmi_pack *p, int recon, double gam0, double gam1,
     if (rc == AKMI_COMPLETE) rc = launch_sweep<1, MHD, false>(g, p->gamma, recon, b2, st);
     if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD>(g, p->gamma, recon, b3, u, st);
 #endif
+    }
     if (rc != AKMI_COMPLETE) return rc;
     if (two) {
       hipEventRecord(g_ev[s], st);
       hipStreamWaitEvent(sb, g_ev[s], 0);       // everything below needs sweeps(<= s)
     }
     // HBM-bound chain, one slab behind (in-order on the helper stream)
-    if (MHD) {
+    if (MHD && !do_emf) {
+      if (cp.enable && (rc = c2p(s)) != AKMI_COMPLETE) return rc;      // partial phases: S == 1
+    } else if (MHD) {
       if ((rc = corner(s)) != AKMI_COMPLETE) return rc;
       if (s >= 1 && (rc = ct(s - 1)) != AKMI_COMPLETE) return rc;      // needs sweeps(s) done
       if (cp.enable && s >= 2 && (rc = c2p(s - 2)) != AKMI_COMPLETE) return rc;
@@ -882,7 +894,8 @@ static int stage_update(const akmi_pack *p, int recon, double gam0, double gam1,
       if (s >= 1 && (rc = c2p(s - 1)) != AKMI_COMPLETE) return rc;     // needs sweeps(s) done
     }
   }
-  if (MHD) {
+  if (MHD && !do_emf) {
+  } else if (MHD) {
     if ((rc = ct(S - 1)) != AKMI_COMPLETE) return rc;
     if (cp.enable) {
       if (S >= 2 && (rc = c2p(S - 2)) != AKMI_COMPLETE) return rc;
@@ -968,6 +981,32 @@ int akmi_mhd_stage_fused(const akmi_pack *p, int recon, int rsolver, double gam0
   C2PArgs cp{1, do_newdt, counters, dt3};
   return stage_update<true>(p, recon, gam0, gam1, beta_dt, copy_u1, w0, bcc0, u0, u1, b0x1f, b0x2f,
                             b0x3f, b1x1f, b1x2f, b1x3f, ws, cp, (hipStream_t)stream);
+}
+
+int akmi_hydro_stage_phase(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1,
+                           double beta_dt, int copy_u1, double *w0, double *u0, double *u1,
+                           int do_newdt, int *counters, double *dt3, int phases, void *ws,
+                           void *stream) {
+  if (rsolver != AKMI_RS_HLLC) { set_error("hydro_stage_phase: only rsolver=hllc is implemented"); return AKMI_FAIL; }
+  if (recon == AKMI_RECON_PPM4 && p->ng < 3) { set_error("ppm4 needs nghost>=3"); return AKMI_FAIL; }
+  if (phases <= 0 || phases > AKMI_PHASE_ALL) { set_error("stage_phase: bad phase mask"); return AKMI_FAIL; }
+  C2PArgs cp{1, do_newdt, counters, dt3};
+  return stage_update<false>(p, recon, gam0, gam1, beta_dt, copy_u1, w0, nullptr, u0, u1, nullptr,
+                             nullptr, nullptr, nullptr, nullptr, nullptr, ws, cp,
+                             (hipStream_t)stream, phases);
+}
+
+int akmi_mhd_stage_phase(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1,
+                         double beta_dt, int copy_u1, double *w0, double *bcc0, double *u0, double *u1,
+                         double *b0x1f, double *b0x2f, double *b0x3f, double *b1x1f, double *b1x2f,
+                         double *b1x3f, int do_newdt, int *counters, double *dt3, int phases,
+                         void *ws, void *stream) {
+  if (rsolver != AKMI_RS_HLLD) { set_error("mhd_stage_phase: only rsolver=hlld is implemented"); return AKMI_FAIL; }
+  if (recon == AKMI_RECON_PPM4 && p->ng < 3) { set_error("ppm4 needs nghost>=3"); return AKMI_FAIL; }
+  if (phases <= 0 || phases > AKMI_PHASE_ALL) { set_error("stage_phase: bad phase mask"); return AKMI_FAIL; }
+  C2PArgs cp{1, do_newdt, counters, dt3};
+  return stage_update<true>(p, recon, gam0, gam1, beta_dt, copy_u1, w0, bcc0, u0, u1, b0x1f, b0x2f,
+                            b0x3f, b1x1f, b1x2f, b1x3f, ws, cp, (hipStream_t)stream, phases);
 }
 
 int akmi_hydro_c2p_shell(const akmi_pack *p, double *u0, double *w0, int *counters, void *stream) {

@@ -184,18 +184,14 @@ class Hydro(FluidBase):
         """hydro_update.cpp:23-83"""
         gam0, gam1 = pdrive.gam0[stage - 1], pdrive.gam1[stage - 1]
         beta_dt = pdrive.beta[stage - 1]*self.pmy_pack.pmesh.dt
-        if self.fused:
+        if self.fused and self.pbval_u.peers:
+            # off-rank neighbours: only the sweeps + update here, so that SendU can post the
+            # halo messages before the c2p of the active cells is enqueued (see SendU)
+            self._stage_phase(pdrive, stage, capi.PHASE_SWEEPS)
+        elif self.fused:
             # pass A + ConsToPrim of the active cells (+ CFL scan on the last stage) in one
-            # slab-pipelined call; the ghost shell is converted in ConToPrim after the halo
-            do_dt = 1 if stage == pdrive.nexp_stages else 0
-            capi.check(self.L.akmi_hydro_stage_fused(
-                C.byref(self.pack_c), self.recon_method, self.rsolver_method, capi.d(gam0),
-                capi.d(gam1), capi.d(beta_dt), 1 if stage == 1 else 0, capi._p(self.w0),
-                capi._p(self.u0), capi._p(self.u1), do_dt, capi._p(self.counters),
-                capi._p(self.dt3), capi._p(self._workspace(0)), capi._stream()),
-                "hydro_stage_fused")
-            self._interior_done = True
-            self._dt_ready = bool(do_dt)
+            # call; the ghost shell is converted in ConToPrim after the halo
+            self._stage_phase(pdrive, stage, capi.PHASE_ALL)
         else:
             capi.check(self.L.akmi_rk_update(
                 C.byref(self.pack_c), capi.d(gam0), capi.d(gam1), capi.d(beta_dt), capi._p(self.u0),
@@ -203,8 +199,28 @@ class Hydro(FluidBase):
                 capi._p(self.uflx.x3f), 0, capi._stream()), "rk_update")
         return TaskStatus.complete
 
+    def _stage_phase(self, pdrive, stage, phases):
+        """akmi_hydro_stage_phase: the parts of the fused stage named by the mask `phases`"""
+        gam0, gam1 = pdrive.gam0[stage - 1], pdrive.gam1[stage - 1]
+        beta_dt = pdrive.beta[stage - 1]*self.pmy_pack.pmesh.dt
+        do_dt = 1 if stage == pdrive.nexp_stages else 0
+        capi.check(self.L.akmi_hydro_stage_phase(
+            C.byref(self.pack_c), self.recon_method, self.rsolver_method, capi.d(gam0),
+            capi.d(gam1), capi.d(beta_dt), 1 if stage == 1 else 0, capi._p(self.w0),
+            capi._p(self.u0), capi._p(self.u1), do_dt, capi._p(self.counters),
+            capi._p(self.dt3), phases, capi._p(self._workspace(0)), capi._stream()),
+            "hydro_stage_phase")
+        if phases & capi.PHASE_C2P:
+            self._interior_done = True
+            self._dt_ready = bool(do_dt)
+
     def SendU(self, pdrive, stage):
-        return self.pbval_u.PackAndSendCC(self.u0)
+        st = self.pbval_u.PackAndSendCC(self.u0)
+        if self.fused and self.pbval_u.peers:
+            # the messages are in flight on the transport's stream: convert the active cells
+            # (they do not depend on the halo) underneath them
+            self._stage_phase(pdrive, stage, capi.PHASE_C2P)
+        return st
 
     def RecvU(self, pdrive, stage):
         return self.pbval_u.RecvAndUnpackCC(self.u0)

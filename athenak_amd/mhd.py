@@ -106,28 +106,43 @@ class MHD(FluidBase):
         """mhd_update.cpp:24-84; the fused path also performs EField and CT here"""
         gam0, gam1 = pdrive.gam0[stage - 1], pdrive.gam1[stage - 1]
         beta_dt = pdrive.beta[stage - 1]*self.pmy_pack.pmesh.dt
-        if self.fused:
+        if self.fused and self.pbval_u.peers:
+            # off-rank neighbours: the stage is issued in parts so that the halo messages are
+            # posted as early as the reference's task list allows and travel underneath the
+            # remaining kernels:  sweeps+update | SendU | CornerE+CT | SendB | c2p of the
+            # active cells | RecvU, RecvB | BCs | c2p of the ghost shell
+            self._stage_phase(pdrive, stage, capi.PHASE_SWEEPS)
+        elif self.fused:
             # pass A (fluxes, update, CornerE, CT) + ConsToPrim of the active cells (+ CFL scan
-            # on the last stage) in one slab-pipelined call
-            do_dt = 1 if stage == pdrive.nexp_stages else 0
-            capi.check(self.L.akmi_mhd_stage_fused(
-                C.byref(self.pack_c), self.recon_method, self.rsolver_method, capi.d(gam0),
-                capi.d(gam1), capi.d(beta_dt), 1 if stage == 1 else 0, capi._p(self.w0),
-                capi._p(self.bcc0), capi._p(self.u0), capi._p(self.u1), *self._b(self.b0),
-                *self._b(self.b1), do_dt, capi._p(self.counters), capi._p(self.dt3),
-                capi._p(self._workspace(1)), capi._stream()), "mhd_stage_fused")
-            self._interior_done = True
-            self._dt_ready = bool(do_dt)
+            # on the last stage) in one call
+            self._stage_phase(pdrive, stage, capi.PHASE_ALL)
         else:
             capi.check(self.L.akmi_rk_update(
                 C.byref(self.pack_c), capi.d(gam0), capi.d(gam1), capi.d(beta_dt), capi._p(self.u0),
                 capi._p(self.u1), *self._b(self.uflx), 1, capi._stream()), "rk_update")
         return TaskStatus.complete
 
+    def _stage_phase(self, pdrive, stage, phases):
+        """akmi_mhd_stage_phase: the parts of the fused stage named by the mask `phases`"""
+        gam0, gam1 = pdrive.gam0[stage - 1], pdrive.gam1[stage - 1]
+        beta_dt = pdrive.beta[stage - 1]*self.pmy_pack.pmesh.dt
+        do_dt = 1 if stage == pdrive.nexp_stages else 0
+        capi.check(self.L.akmi_mhd_stage_phase(
+            C.byref(self.pack_c), self.recon_method, self.rsolver_method, capi.d(gam0),
+            capi.d(gam1), capi.d(beta_dt), 1 if stage == 1 else 0, capi._p(self.w0),
+            capi._p(self.bcc0), capi._p(self.u0), capi._p(self.u1), *self._b(self.b0),
+            *self._b(self.b1), do_dt, capi._p(self.counters), capi._p(self.dt3), phases,
+            capi._p(self._workspace(1)), capi._stream()), "mhd_stage_phase")
+        if phases & capi.PHASE_C2P:
+            self._interior_done = True
+            self._dt_ready = bool(do_dt)
+
     def SendU(self, pdrive, stage):
         return self.pbval_u.PackAndSendCC(self.u0)
 
     def RecvU(self, pdrive, stage):
+        if self.fused and self.pbval_u.peers:
+            return TaskStatus.complete      # completed in RecvB, after the kernels it can hide under
         return self.pbval_u.RecvAndUnpackCC(self.u0)
 
     def EField(self, pdrive, stage):
@@ -142,7 +157,9 @@ class MHD(FluidBase):
 
     def CT(self, pdrive, stage):
         """mhd_ct.cpp:23-80"""
-        if not self.fused:
+        if self.fused and self.pbval_u.peers:
+            self._stage_phase(pdrive, stage, capi.PHASE_EMF_CT)
+        elif not self.fused:
             gam0, gam1 = pdrive.gam0[stage - 1], pdrive.gam1[stage - 1]
             beta_dt = pdrive.beta[stage - 1]*self.pmy_pack.pmesh.dt
             capi.check(self.L.akmi_mhd_ct(
@@ -152,9 +169,14 @@ class MHD(FluidBase):
         return TaskStatus.complete
 
     def SendB(self, pdrive, stage):
-        return self.pbval_b.PackAndSendFC(self.b0)
+        st = self.pbval_b.PackAndSendFC(self.b0)
+        if self.fused and self.pbval_u.peers:
+            self._stage_phase(pdrive, stage, capi.PHASE_C2P)
+        return st
 
     def RecvB(self, pdrive, stage):
+        if self.fused and self.pbval_u.peers:
+            self.pbval_u.RecvAndUnpackCC(self.u0)
         return self.pbval_b.RecvAndUnpackFC(self.b0)
 
     def ApplyPhysicalBCs(self, pdrive, stage):

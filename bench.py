@@ -132,8 +132,17 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # developer knobs for a functional check of the N>1 path on a 1-GPU box (RCCL refuses two
+        # ranks on one device): AKMI_SHARE_GPU=1 puts every rank on cuda:0, AKMI_DIST_BACKEND=gloo
+        # moves the halos through pinned host buffers.  Numbers from such a run mean nothing.
+        backend = os.environ.get("AKMI_DIST_BACKEND", "nccl")
+        if os.environ.get("AKMI_SHARE_GPU", "0") == "1":
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
@@ -161,7 +170,8 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64,
+                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 

@@ -206,6 +206,25 @@ int akmi_mhd_stage_fused(const akmi_pack *p, int recon, int rsolver, double gam0
                          double *u1, double *b0x1f, double *b0x2f, double *b0x3f,
                          double *b1x1f, double *b1x2f, double *b1x3f, int do_newdt,
                          int *counters, double *dt3, void *ws, void *stream);
+/* The same stage cut into its parts for callers that post halo messages in between (a rank
+ * with off-rank neighbours sends u0 after SWEEPS and b0 after EMF_CT, so the transfers run
+ * under CornerE/CT and under the c2p of the active cells, in the order of the reference's
+ * task list: RKUpdate -> SendU -> EField -> CT -> SendB, src/mhd/mhd_tasks.cpp:48-75).
+ * phases is a mask of AKMI_PHASE_*; the parts must be called in increasing order within a
+ * stage with identical arguments; AKMI_PHASE_ALL equals akmi_*_stage_fused. */
+enum { AKMI_PHASE_SWEEPS = 1,   /* reconstruct + Riemann x1..x3 + RK update of u0 (+ face EMFs) */
+       AKMI_PHASE_EMF_CT = 2,   /* CornerE + CT of b0 (MHD only; ignored for hydro)            */
+       AKMI_PHASE_C2P    = 4,   /* ConsToPrim of the active cells (+ CFL scan if do_newdt)     */
+       AKMI_PHASE_ALL    = 7 };
+int akmi_hydro_stage_phase(const akmi_pack *p, int recon, int rsolver, double gam0,
+                           double gam1, double beta_dt, int copy_u1, double *w0, double *u0,
+                           double *u1, int do_newdt, int *counters, double *dt3, int phases,
+                           void *ws, void *stream);
+int akmi_mhd_stage_phase(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1,
+                         double beta_dt, int copy_u1, double *w0, double *bcc0, double *u0,
+                         double *u1, double *b0x1f, double *b0x2f, double *b0x3f,
+                         double *b1x1f, double *b1x2f, double *b1x3f, int do_newdt,
+                         int *counters, double *dt3, int phases, void *ws, void *stream);
 int akmi_hydro_c2p_shell(const akmi_pack *p, double *u0, double *w0, int *counters,
                          void *stream);
 int akmi_mhd_c2p_shell(const akmi_pack *p, double *u0, const double *bx1f, const double *bx2f,
