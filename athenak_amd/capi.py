@@ -11,8 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # AKMI_LIB: developer override used by tools/kbench.py to A/B kernel variants
 LIB_PATH = os.environ.get("AKMI_LIB") or os.path.join(_HERE, "lib", "libakmi.so")
 
-RECON = {"dc": 0, "plm": 1, "ppm4": 2}
-RSOLVER = {"llf": 0, "hlle": 1, "hllc": 2, "hlld": 3}
+RECON = {"dc": 0, "plm": 1, "ppm4": 2, "ppmx": 3, "wenoz": 4, "teno": 5}
+RSOLVER = {"llf": 0, "hlle": 1, "hllc": 2, "hlld": 3, "roe": 4}
 BC = {"block": -1, "periodic": 0, "outflow": 1, "reflect": 2}
 
 COMPLETE, INCOMPLETE, FAIL = 0, 1, -1

@@ -41,9 +41,10 @@ enum { AKMI_IDN = 0, AKMI_IM1 = 1, AKMI_IM2 = 2, AKMI_IM3 = 3, AKMI_IEN = 4 };
 enum { AKMI_IBX = 0, AKMI_IBY = 1, AKMI_IBZ = 2 };
 
 /* ReconstructionMethod, src/athena.hpp (enum class) ; only dc/plm/ppm4 are on the path */
-enum { AKMI_RECON_DC = 0, AKMI_RECON_PLM = 1, AKMI_RECON_PPM4 = 2 };
+enum { AKMI_RECON_DC = 0, AKMI_RECON_PLM = 1, AKMI_RECON_PPM4 = 2, AKMI_RECON_PPMX = 3,
+       AKMI_RECON_WENOZ = 4, AKMI_RECON_TENO = 5 };
 /* Hydro_RSolver / MHD_RSolver */
-enum { AKMI_RS_LLF = 0, AKMI_RS_HLLE = 1, AKMI_RS_HLLC = 2, AKMI_RS_HLLD = 3 };
+enum { AKMI_RS_LLF = 0, AKMI_RS_HLLE = 1, AKMI_RS_HLLC = 2, AKMI_RS_HLLD = 3, AKMI_RS_ROE = 4 };
 /* BoundaryFlag, src/mesh/mesh.hpp */
 enum { AKMI_BC_BLOCK = -1, AKMI_BC_PERIODIC = 0, AKMI_BC_OUTFLOW = 1, AKMI_BC_REFLECT = 2 };
 

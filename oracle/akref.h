@@ -79,7 +79,20 @@ int akref_bfield_bcs(const akmi_pack *p, const int *bcs, double *bx1f, double *b
 void akref_plm(double qim1, double qi, double qip1, double *ql_ip1, double *qr_i);
 void akref_ppm4(double qim2, double qim1, double qi, double qip1, double qip2,
                 double *ql_ip1, double *qr_i);
+void akref_ppmx(double qim2, double qim1, double qi, double qip1, double qip2,
+                double *ql_ip1, double *qr_i);
+void akref_wenoz(double qim2, double qim1, double qi, double qip1, double qip2,
+                 double *ql_ip1, double *qr_i);
+void akref_teno(double qim2, double qim1, double qi, double qip1, double qip2,
+                double *ql_ip1, double *qr_i);
 void akref_hllc(double gamma, const double wl[5], const double wr[5], double flx[5]);
+void akref_llf_hyd(double gamma, const double wl[5], const double wr[5], double flx[5]);
+void akref_hlle_hyd(double gamma, const double wl[5], const double wr[5], double flx[5]);
+void akref_roe_hyd(double gamma, const double wl[5], const double wr[5], double flx[5]);
+void akref_llf_mhd(double gamma, const double wl[7], const double wr[7], double bx,
+                   double flx[7]);
+void akref_hlle_mhd(double gamma, const double wl[7], const double wr[7], double bx,
+                    double flx[7]);
 void akref_hlld(double gamma, const double wl[7], const double wr[7], double bx,
                 double flx[7]);
 

@@ -100,10 +100,126 @@ void akref_ppm4(double q_im2, double q_im1, double q_i, double q_ip1, double q_i
   *qr_i   = qlv;
 }
 
+/* PPMX (Colella & Sekora extremum-preserving limiters), src/reconstruct/ppm.hpp:84-181 */
+#define SGN(x) (((x) < 0.0) ? -1.0 : 1.0)          /* SIGN, src/athena.hpp:52 */
+void akref_ppmx(double q_im2, double q_im1, double q_i, double q_ip1, double q_ip2,
+                double *ql_ip1, double *qr_i) {
+  double qlv = (7.*(q_i + q_im1) - (q_im2 + q_ip1))/12.0;
+  double qrv = (7.*(q_i + q_ip1) - (q_im1 + q_ip2))/12.0;
+  /* face i-1/2: limited second derivative (:98-115) */
+  double d2qc = 3.0*((q_im1 + q_i) - 2.0*qlv);
+  double d2ql = (q_im2 + q_i) - 2.0*q_im1;
+  double d2qr = (q_im1 + q_ip1) - 2.0*q_i;
+  double d2qlim = 0.0;
+  double lim_slope = fmin(fabs(d2ql), fabs(d2qr));
+  if (d2qc > 0.0 && d2ql > 0.0 && d2qr > 0.0) d2qlim = SGN(d2qc)*fmin(1.25*lim_slope, fabs(d2qc));
+  if (d2qc < 0.0 && d2ql < 0.0 && d2qr < 0.0) d2qlim = SGN(d2qc)*fmin(1.25*lim_slope, fabs(d2qc));
+  if (((q_im1 - qlv)*(q_i - qlv)) > 0.0) qlv = 0.5*(q_i + q_im1) - d2qlim/6.0;
+  /* face i+1/2 (:117-135) */
+  d2qc = 3.0*((q_i + q_ip1) - 2.0*qrv);
+  d2ql = d2qr;
+  d2qr = (q_i + q_ip2) - 2.0*q_ip1;
+  d2qlim = 0.0;
+  lim_slope = fmin(fabs(d2ql), fabs(d2qr));
+  if (d2qc > 0.0 && d2ql > 0.0 && d2qr > 0.0) d2qlim = SGN(d2qc)*fmin(1.25*lim_slope, fabs(d2qc));
+  if (d2qc < 0.0 && d2ql < 0.0 && d2qr < 0.0) d2qlim = SGN(d2qc)*fmin(1.25*lim_slope, fabs(d2qc));
+  if (((q_i - qrv)*(q_ip1 - qrv)) > 0.0) qrv = 0.5*(q_i + q_ip1) - d2qlim/6.0;
+  /* extrema (:137-166) or CW monotonisation (:167-177) */
+  double qa = (qrv - q_i)*(q_i - qlv);
+  double qb = (q_im1 - q_i)*(q_i - q_ip1);
+  if (qa <= 0.0 || qb <= 0.0) {
+    double d2q = 6.0*(qlv + qrv - 2.0*q_i);
+    double e2qc = (q_im1 + q_ip1) - 2.0*q_i;
+    double e2ql = (q_im2 + q_i) - 2.0*q_im1;
+    double e2qr = (q_i + q_ip2) - 2.0*q_ip1;
+    d2qlim = 0.0;
+    lim_slope = fmin(fabs(e2ql), fabs(e2qr));
+    lim_slope = fmin(fabs(e2qc), lim_slope);
+    if (e2qc > 0.0 && e2ql > 0.0 && e2qr > 0.0 && d2q > 0.0)
+      d2qlim = SGN(d2q)*fmin(1.25*lim_slope, fabs(d2q));
+    if (e2qc < 0.0 && e2ql < 0.0 && e2qr < 0.0 && d2q < 0.0)
+      d2qlim = SGN(d2q)*fmin(1.25*lim_slope, fabs(d2q));
+    double rho = 0.0;
+    if (fabs(d2q) > (1.0e-12)*fmax(fabs(q_im1), fmax(fabs(q_i), fabs(q_ip1)))) rho = d2qlim/d2q;
+    qlv = q_i + (qlv - q_i)*rho;
+    qrv = q_i + (qrv - q_i)*rho;
+  } else {
+    double qc = qrv - q_i;
+    double qd = qlv - q_i;
+    if (fabs(qc) >= 2.0*fabs(qd)) qrv = q_i - 2.0*qd;
+    if (fabs(qd) >= 2.0*fabs(qc)) qlv = q_i - 2.0*qc;
+  }
+  *ql_ip1 = qrv;
+  *qr_i   = qlv;
+}
+
+/* smoothness indicators shared by WENO-Z and TENO (Jiang & Shu 1996), wenoz.hpp:32-43 */
+static inline void js_beta(double q_im2, double q_im1, double q_i, double q_ip1, double q_ip2,
+                           double beta[3]) {
+  const double c0 = 13./12., c1 = 0.25;
+  beta[0] = c0*SQR(q_im2 + q_i - 2.0*q_im1) + c1*SQR(q_im2 + 3.0*q_i - 4.0*q_im1);
+  beta[1] = c0*SQR(q_im1 + q_ip1 - 2.0*q_i) + c1*SQR(q_im1 - q_ip1);
+  beta[2] = c0*SQR(q_ip2 + q_i - 2.0*q_ip1) + c1*SQR(q_ip2 + 3.0*q_i - 4.0*q_ip1);
+}
+
+/* the two 5th-order face values from candidate stencils and un-normalised weights a0,a1,a2
+ * (a1 shared; outer weights swap sides), wenoz.hpp:58-81 == teno.hpp:64-86 */
+static inline void weno_faces(double q_im2, double q_im1, double q_i, double q_ip1, double q_ip2,
+                              double wa, double wb, double wc, double va, double vc,
+                              double *ql_ip1, double *qr_i) {
+  double f0 = (2.0*q_im2 - 7.0*q_im1 + 11.0*q_i);
+  double f1 = (-1.0*q_im1 + 5.0*q_i + 2.0*q_ip1);
+  double f2 = (2.0*q_i + 5.0*q_ip1 - q_ip2);
+  double asum = 6.0*(wa + wb + wc);
+  *ql_ip1 = (f0*wa + f1*wb + f2*wc)/asum;
+  f0 = (2.0*q_ip2 - 7.0*q_ip1 + 11.0*q_i);
+  f1 = (-1.0*q_ip1 + 5.0*q_i + 2.0*q_im1);
+  f2 = (2.0*q_i + 5.0*q_im1 - q_im2);
+  asum = 6.0*(va + wb + vc);
+  *qr_i = (f0*va + f1*wb + f2*vc)/asum;
+}
+
+/* WENO-Z (Borges et al. 2008), src/reconstruct/wenoz.hpp:29-84 */
+void akref_wenoz(double q_im2, double q_im1, double q_i, double q_ip1, double q_ip2,
+                 double *ql_ip1, double *qr_i) {
+  double beta[3];
+  js_beta(q_im2, q_im1, q_i, q_ip1, q_ip2, beta);
+  const double epsL = 1.0e-42;
+  const double tau_5 = fabs(beta[0] - beta[2]);
+  double ind0 = SQR(tau_5/(beta[0] + epsL));
+  double ind1 = SQR(tau_5/(beta[1] + epsL));
+  double ind2 = SQR(tau_5/(beta[2] + epsL));
+  weno_faces(q_im2, q_im1, q_i, q_ip1, q_ip2, 0.1*(1.0 + ind0), 0.6*(1.0 + ind1),
+             0.3*(1.0 + ind2), 0.1*(1.0 + ind2), 0.3*(1.0 + ind0), ql_ip1, qr_i);
+}
+
+/* TENO (Fu et al. 2016/2019 cut-off weights), src/reconstruct/teno.hpp:30-89 */
+void akref_teno(double q_im2, double q_im1, double q_i, double q_ip1, double q_ip2,
+                double *ql_ip1, double *qr_i) {
+  double beta[3];
+  js_beta(q_im2, q_im1, q_i, q_ip1, q_ip2, beta);
+  const double epsT = 1.0e-40, cT = 1.0e-6;
+#define CUBE(x) ((x)*(x)*(x))
+  double a0 = 1.0/SQR(CUBE(beta[0] + epsT));
+  double a1 = 1.0/SQR(CUBE(beta[1] + epsT));
+  double a2 = 1.0/SQR(CUBE(beta[2] + epsT));
+#undef CUBE
+  double asum = a0 + a1 + a2;
+  double ind0 = (a0 < cT*asum ? 0.0 : 1.0);
+  double ind1 = (a1 < cT*asum ? 0.0 : 1.0);
+  double ind2 = (a2 < cT*asum ? 0.0 : 1.0);
+  weno_faces(q_im2, q_im1, q_i, q_ip1, q_ip2, 0.1*ind0, 0.6*ind1, 0.3*ind2, 0.1*ind2, 0.3*ind0,
+             ql_ip1, qr_i);
+}
+
 /* ReconCellT / ReconDispatch (src/reconstruct/recon.hpp:40-118,134-185): cell (k,j,i)
  * writes ql to face +1 along dir and qr to its own face index. */
-static void recon_dir(const G *g, int recon, int dir, int nv, const double *q, double *ql,
-                      double *qr, int kl, int ku, int jl, int ju, int il, int iu) {
+static void recon_dir(const G *g, const akmi_pack *p, int apply_floors, int recon, int dir, int nv,
+                      const double *q, double *ql, double *qr, int kl, int ku, int jl, int ju,
+                      int il, int iu) {
+  /* floors on the L/R states exist only in the ppmx/wenoz/teno branches and only for the
+   * fluid primitives d and e (recon.hpp:59-103: dfloor, efloor = pfloor/(gamma-1)) */
+  const double dfloor = p->dfloor, efloor = p->pfloor/(p->gamma - 1.0);
   const int di = (dir == 0), dj = (dir == 1), dk = (dir == 2);
   const int N1 = g->N1, N2 = g->N2, N3 = g->N3;
   const long so = (long)dk*N2*N1 + (long)dj*N1 + di;   /* stencil offset */
@@ -120,6 +236,18 @@ static void recon_dir(const G *g, int recon, int dir, int nv, const double *q, d
               akref_plm(q[c - so], q[c], q[c + so], &a, &bq);
             } else if (recon == AKMI_RECON_PPM4) {
               akref_ppm4(q[c - 2*so], q[c - so], q[c], q[c + so], q[c + 2*so], &a, &bq);
+            } else if (recon == AKMI_RECON_PPMX || recon == AKMI_RECON_WENOZ ||
+                       recon == AKMI_RECON_TENO) {
+              if (recon == AKMI_RECON_PPMX)
+                akref_ppmx(q[c - 2*so], q[c - so], q[c], q[c + so], q[c + 2*so], &a, &bq);
+              else if (recon == AKMI_RECON_WENOZ)
+                akref_wenoz(q[c - 2*so], q[c - so], q[c], q[c + so], q[c + 2*so], &a, &bq);
+              else
+                akref_teno(q[c - 2*so], q[c - so], q[c], q[c + so], q[c + 2*so], &a, &bq);
+              if (apply_floors) {
+                if (n == IDN) { a = fmax(a, dfloor); bq = fmax(bq, dfloor); }
+                if (n == IEN) { a = fmax(a, efloor); bq = fmax(bq, efloor); }
+              }
             } else {
               a = q[c]; bq = q[c];
             }
@@ -184,6 +312,189 @@ void akref_hllc(double gamma, const double wl[5], const double wr[5], double flx
   flx[2] = qc*fl_my + qd*fr_my;
   flx[3] = qc*fl_mz + qd*fr_mz;
   flx[4] = qc*fl_e + qd*fr_e + qe*cp*am;
+}
+
+/* LLF (Rusanov), src/hydro/rsolvers/llf_hyd_singlestate.hpp:28-78 (ideal gas) */
+void akref_llf_hyd(double gamma, const double wl[5], const double wr[5], double flx[5]) {
+  double qa = wl[0]*wl[1];
+  double qb = wr[0]*wr[1];
+  double s_d = qa + qb;
+  double s_mx = qa*wl[1] + qb*wr[1];
+  double s_my = qa*wl[2] + qb*wr[2];
+  double s_mz = qa*wl[3] + qb*wr[3];
+  double pl = (gamma - 1.0)*wl[4];
+  double pr = (gamma - 1.0)*wr[4];
+  double el = wl[4] + 0.5*wl[0]*(SQR(wl[1]) + SQR(wl[2]) + SQR(wl[3]));
+  double er = wr[4] + 0.5*wr[0]*(SQR(wr[1]) + SQR(wr[2]) + SQR(wr[3]));
+  s_mx += (pl + pr);
+  double s_e = (el + pl)*wl[1] + (er + pr)*wr[1];
+  qa = sqrt(gamma*pl/wl[0]);
+  qb = sqrt(gamma*pr/wr[0]);
+  double a = fmax((fabs(wl[1]) + qa), (fabs(wr[1]) + qb));
+  double du_d = a*(wr[0] - wl[0]);
+  double du_mx = a*(wr[0]*wr[1] - wl[0]*wl[1]);
+  double du_my = a*(wr[0]*wr[2] - wl[0]*wl[2]);
+  double du_mz = a*(wr[0]*wr[3] - wl[0]*wl[3]);
+  double du_e = a*(er - el);
+  flx[0] = 0.5*(s_d - du_d);
+  flx[1] = 0.5*(s_mx - du_mx);
+  flx[2] = 0.5*(s_my - du_my);
+  flx[3] = 0.5*(s_mz - du_mz);
+  flx[4] = 0.5*(s_e - du_e);
+}
+
+/* HLLE with Roe-averaged + L/R wave-speed bounds, src/hydro/rsolvers/hlle_hyd.hpp:27-129 */
+void akref_hlle_hyd(double gamma, const double wl[5], const double wr[5], double flx[5]) {
+  const double gm1 = gamma - 1.0;
+  const double igm1 = 1.0/gm1;
+  double dl = wl[0], ul = wl[1], vl = wl[2], zl = wl[3], pl = (gamma - 1.0)*wl[4];
+  double dr = wr[0], ur = wr[1], vr = wr[2], zr = wr[3], pr = (gamma - 1.0)*wr[4];
+  double sqrtdl = sqrt(dl);
+  double sqrtdr = sqrt(dr);
+  double isdlpdr = 1.0/(sqrtdl + sqrtdr);
+  double roe_vx = (sqrtdl*ul + sqrtdr*ur)*isdlpdr;
+  double roe_vy = (sqrtdl*vl + sqrtdr*vr)*isdlpdr;
+  double roe_vz = (sqrtdl*zl + sqrtdr*zr)*isdlpdr;
+  double el = pl*igm1 + 0.5*dl*(SQR(ul) + SQR(vl) + SQR(zl));
+  double er = pr*igm1 + 0.5*dr*(SQR(ur) + SQR(vr) + SQR(zr));
+  double hroe = ((el + pl)/sqrtdl + (er + pr)/sqrtdr)*isdlpdr;
+  double qa = sqrt(gamma*pl/dl);
+  double qb = sqrt(gamma*pr/dr);
+  double a = hroe - 0.5*(SQR(roe_vx) + SQR(roe_vy) + SQR(roe_vz));
+  a = (a < 0.0) ? 0.0 : sqrt(gm1*a);
+  double al = fmin((roe_vx - a), (ul - qa));
+  double ar = fmax((roe_vx + a), (ur + qb));
+  double bp = (ar > 0.0) ? ar : 1.0e-20;
+  double bm = (al < 0.0) ? al : -1.0e-20;
+  qa = ul - bm;
+  qb = ur - bp;
+  double fl_d = dl*qa, fr_d = dr*qb;
+  double fl_mx = dl*ul*qa, fr_mx = dr*ur*qb;
+  double fl_my = dl*vl*qa, fr_my = dr*vr*qb;
+  double fl_mz = dl*zl*qa, fr_mz = dr*zr*qb;
+  fl_mx += pl;
+  fr_mx += pr;
+  double fl_e = el*qa + pl*ul;
+  double fr_e = er*qb + pr*ur;
+  qa = 0.0;
+  if (bp != bm) qa = 0.5*(bp + bm)/(bp - bm);
+  flx[0] = 0.5*(fl_d + fr_d) + qa*(fl_d - fr_d);
+  flx[1] = 0.5*(fl_mx + fr_mx) + qa*(fl_mx - fr_mx);
+  flx[2] = 0.5*(fl_my + fr_my) + qa*(fl_my - fr_my);
+  flx[3] = 0.5*(fl_mz + fr_mz) + qa*(fl_mz - fr_mz);
+  flx[4] = 0.5*(fl_e + fr_e) + qa*(fl_e - fr_e);
+}
+
+/* Roe's linearised solver with LLF fallback, src/hydro/rsolvers/roe_hyd.hpp:40-268 (adiabatic:
+ * RoeFluxAdb :183-268, eigen-decomposition of Stone et al. 2008 App. B) */
+void akref_roe_hyd(double gamma, const double wl[5], const double wr[5], double flx[5]) {
+  const double gm1 = gamma - 1.0;
+  double wli[5], wri[5], fl[5], fr[5], du[5], ev[5], f[5];
+  for (int n = 0; n < 4; ++n) { wli[n] = wl[n]; wri[n] = wr[n]; }
+  wli[4] = (gamma - 1.0)*wl[4];
+  wri[4] = (gamma - 1.0)*wr[4];
+  double sqrtdl = sqrt(wli[0]);
+  double sqrtdr = sqrt(wri[0]);
+  double isdlpdr = 1.0/(sqrtdl + sqrtdr);
+  double v1 = (sqrtdl*wli[1] + sqrtdr*wri[1])*isdlpdr;
+  double v2 = (sqrtdl*wli[2] + sqrtdr*wri[2])*isdlpdr;
+  double v3 = (sqrtdl*wli[3] + sqrtdr*wri[3])*isdlpdr;
+  double el = wli[4]/gm1 + 0.5*wli[0]*(SQR(wli[1]) + SQR(wli[2]) + SQR(wli[3]));
+  double er = wri[4]/gm1 + 0.5*wri[0]*(SQR(wri[1]) + SQR(wri[2]) + SQR(wri[3]));
+  double h = ((el + wli[4])/sqrtdl + (er + wri[4])/sqrtdr)*isdlpdr;
+  double mxl = wli[0]*wli[1];
+  double mxr = wri[0]*wri[1];
+  fl[0] = mxl;            fr[0] = mxr;
+  fl[1] = mxl*wli[1];     fr[1] = mxr*wri[1];
+  fl[2] = mxl*wli[2];     fr[2] = mxr*wri[2];
+  fl[3] = mxl*wli[3];     fr[3] = mxr*wri[3];
+  fl[1] += wli[4];        fr[1] += wri[4];
+  fl[4] = (el + wli[4])*wli[1];
+  fr[4] = (er + wri[4])*wri[1];
+  du[0] = wri[0] - wli[0];
+  du[1] = wri[0]*wri[1] - wli[0]*wli[1];
+  du[2] = wri[0]*wri[2] - wli[0]*wli[2];
+  du[3] = wri[0]*wri[3] - wli[0]*wli[3];
+  du[4] = er - el;
+  for (int n = 0; n < 5; ++n) f[n] = 0.5*(fl[n] + fr[n]);
+  int llf_flag = 0;
+  {
+    double vsq = v1*v1 + v2*v2 + v3*v3;
+    double q = h - 0.5*vsq;
+    double cs_sq = (q < 0.0) ? (double)(FLT_MIN) : gm1*q;
+    double cs = sqrt(cs_sq);
+    ev[0] = v1 - cs; ev[1] = v1; ev[2] = v1; ev[3] = v1; ev[4] = v1 + cs;
+    double a[5];
+    double na = 0.5/cs_sq;
+    a[0]  = du[0]*(0.5*gm1*vsq + v1*cs);
+    a[0] -= du[1]*(gm1*v1 + cs);
+    a[0] -= du[2]*gm1*v2;
+    a[0] -= du[3]*gm1*v3;
+    a[0] += du[4]*gm1;
+    a[0] *= na;
+    a[1]  = du[0]*(-v2);
+    a[1] += du[2];
+    a[2]  = du[0]*(-v3);
+    a[2] += du[3];
+    double qa = gm1/cs_sq;
+    a[3]  = du[0]*(1.0 - na*gm1*vsq);
+    a[3] += du[1]*qa*v1;
+    a[3] += du[2]*qa*v2;
+    a[3] += du[3]*qa*v3;
+    a[3] -= du[4]*qa;
+    a[4]  = du[0]*(0.5*gm1*vsq - v1*cs);
+    a[4] -= du[1]*(gm1*v1 - cs);
+    a[4] -= du[2]*gm1*v2;
+    a[4] -= du[3]*gm1*v3;
+    a[4] += du[4]*gm1;
+    a[4] *= na;
+    double co[5];
+    for (int n = 0; n < 5; ++n) co[n] = -0.5*fabs(ev[n])*a[n];
+    double dens = wli[0] + a[0];
+    if (dens < 0.0) llf_flag = 1;
+    dens += a[3];
+    if (dens < 0.0) llf_flag = 1;
+    f[0] += co[0];
+    f[0] += co[3];
+    f[0] += co[4];
+    f[1] += co[0]*(v1 - cs);
+    f[1] += co[3]*v1;
+    f[1] += co[4]*(v1 + cs);
+    f[2] += co[0]*v2;
+    f[2] += co[1];
+    f[2] += co[3]*v2;
+    f[2] += co[4]*v2;
+    f[3] += co[0]*v3;
+    f[3] += co[2];
+    f[3] += co[3]*v3;
+    f[3] += co[4]*v3;
+    f[4] += co[0]*(h - v1*cs);
+    f[4] += co[1]*v2;
+    f[4] += co[2]*v3;
+    f[4] += co[3]*0.5*vsq;
+    f[4] += co[4]*(h + v1*cs);
+  }
+  if (ev[0] >= 0.0) for (int n = 0; n < 5; ++n) f[n] = fl[n];      /* supersonic: upwind (:146-163) */
+  if (ev[4] <= 0.0) for (int n = 0; n < 5; ++n) f[n] = fr[n];
+  if (llf_flag != 0) {                                              /* negative density (:166-181) */
+    double cl = sqrt(gamma*wli[4]/wli[0]);
+    double cr = sqrt(gamma*wri[4]/wri[0]);
+    double a = 0.5*fmax((fabs(wli[1]) + cl), (fabs(wri[1]) + cr));
+    for (int n = 0; n < 5; ++n) f[n] = 0.5*(fl[n] + fr[n]) - a*du[n];
+  }
+  for (int n = 0; n < 5; ++n) flx[n] = f[n];
+}
+
+/* solver selection of Hydro::CalculateFluxes (hydro_fluxes.cpp: template <Hydro_RSolver>) */
+static inline int hyd_riemann(int rs, double gamma, const double a[5], const double b[5],
+                              double f[5]) {
+  switch (rs) {
+    case AKMI_RS_LLF:  akref_llf_hyd(gamma, a, b, f); return 0;
+    case AKMI_RS_HLLE: akref_hlle_hyd(gamma, a, b, f); return 0;
+    case AKMI_RS_HLLC: akref_hllc(gamma, a, b, f); return 0;
+    case AKMI_RS_ROE:  akref_roe_hyd(gamma, a, b, f); return 0;
+  }
+  return 1;
 }
 
 /* IdealMHDFastSpeed, src/eos/eos.hpp:49-57 */
@@ -399,6 +710,132 @@ void akref_hlld(double gamma, const double wl[7], const double wr[7], double bxi
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* LLF for MHD, src/mhd/rsolvers/llf_mhd_singlestate.hpp:28-89 (ideal gas).  States and flux
+ * as akref_hlld: w = (d,vx,vy,vz,e,by,bz), flx = (d,mx,my,mz,E,F(by),F(bz)); the caller stores
+ * ey = -flx[5], ez = +flx[6]. */
+void akref_llf_mhd(double gamma, const double wl[7], const double wr[7], double bxi,
+                   double flx[7]) {
+  double qa = wl[0]*wl[1];
+  double qb = wr[0]*wr[1];
+  double qc = 0.5*(SQR(wl[5]) + SQR(wl[6]) - SQR(bxi));
+  double qd = 0.5*(SQR(wr[5]) + SQR(wr[6]) - SQR(bxi));
+  double s_d = qa + qb;
+  double s_mx = qa*wl[1] + qb*wr[1] + qc + qd;
+  double s_my = qa*wl[2] + qb*wr[2] - bxi*(wl[5] + wr[5]);
+  double s_mz = qa*wl[3] + qb*wr[3] - bxi*(wl[6] + wr[6]);
+  double s_by = wl[5]*wl[1] + wr[5]*wr[1] - bxi*(wl[2] + wr[2]);
+  double s_bz = wl[6]*wl[1] + wr[6]*wr[1] - bxi*(wl[3] + wr[3]);
+  double pl = (gamma - 1.0)*wl[4];
+  double pr = (gamma - 1.0)*wr[4];
+  double el = wl[4] + 0.5*wl[0]*(SQR(wl[1]) + SQR(wl[2]) + SQR(wl[3])) + qc + SQR(bxi);
+  double er = wr[4] + 0.5*wr[0]*(SQR(wr[1]) + SQR(wr[2]) + SQR(wr[3])) + qd + SQR(bxi);
+  s_mx += (pl + pr);
+  double s_e = (el + pl + qc)*wl[1] + (er + pr + qd)*wr[1];
+  s_e -= bxi*(wl[5]*wl[2] + wl[6]*wl[3]);
+  s_e -= bxi*(wr[5]*wr[2] + wr[6]*wr[3]);
+  qa = fast_speed(gamma, wl[0], pl, bxi, wl[5], wl[6]);
+  qb = fast_speed(gamma, wr[0], pr, bxi, wr[5], wr[6]);
+  double a = fmax((fabs(wl[1]) + qa), (fabs(wr[1]) + qb));
+  double du_d = a*(wr[0] - wl[0]);
+  double du_mx = a*(wr[0]*wr[1] - wl[0]*wl[1]);
+  double du_my = a*(wr[0]*wr[2] - wl[0]*wl[2]);
+  double du_mz = a*(wr[0]*wr[3] - wl[0]*wl[3]);
+  double du_e = a*(er - el);
+  double du_by = a*(wr[5] - wl[5]);
+  double du_bz = a*(wr[6] - wl[6]);
+  flx[0] = 0.5*(s_d - du_d);
+  flx[1] = 0.5*(s_mx - du_mx);
+  flx[2] = 0.5*(s_my - du_my);
+  flx[3] = 0.5*(s_mz - du_mz);
+  flx[4] = 0.5*(s_e - du_e);
+  flx[5] = 0.5*(s_by - du_by);      /* reference stores ey = -0.5*(...) == -(flx[5]) exactly */
+  flx[6] = 0.5*(s_bz - du_bz);
+}
+
+/* HLLE for MHD with Roe-averaged fast speed (eq. B18 of Stone et al. 2008),
+ * src/mhd/rsolvers/hlle_mhd.hpp:24-178 (ideal gas) */
+void akref_hlle_mhd(double gamma, const double wl[7], const double wr[7], double bxi,
+                    double flx[7]) {
+  double gm1 = gamma - 1.0;
+  double igm1 = 1.0/gm1;
+  double dl = wl[0], ul = wl[1], vl = wl[2], zl = wl[3], pl = (gamma - 1.0)*wl[4], byl = wl[5],
+         bzl = wl[6];
+  double dr = wr[0], ur = wr[1], vr = wr[2], zr = wr[3], pr = (gamma - 1.0)*wr[4], byr = wr[5],
+         bzr = wr[6];
+  double sqrtdl = sqrt(dl);
+  double sqrtdr = sqrt(dr);
+  double isdlpdr = 1.0/(sqrtdl + sqrtdr);
+  double roe_d = sqrtdl*sqrtdr;
+  double roe_vx = (sqrtdl*ul + sqrtdr*ur)*isdlpdr;
+  double roe_vy = (sqrtdl*vl + sqrtdr*vr)*isdlpdr;
+  double roe_vz = (sqrtdl*zl + sqrtdr*zr)*isdlpdr;
+  double roe_by = (sqrtdr*byl + sqrtdl*byr)*isdlpdr;
+  double roe_bz = (sqrtdr*bzl + sqrtdl*bzr)*isdlpdr;
+  double x = 0.5*(SQR(byl - byr) + SQR(bzl - bzr))/(SQR(sqrtdl + sqrtdr));
+  double y = 0.5*(dl + dr)/roe_d;
+  double pbl = 0.5*(bxi*bxi + SQR(byl) + SQR(bzl));
+  double pbr = 0.5*(bxi*bxi + SQR(byr) + SQR(bzr));
+  double el = pl*igm1 + 0.5*dl*(SQR(ul) + SQR(vl) + SQR(zl)) + pbl;
+  double er = pr*igm1 + 0.5*dr*(SQR(ur) + SQR(vr) + SQR(zr)) + pbr;
+  double hroe = ((el + pl + pbl)/sqrtdl + (er + pr + pbr)/sqrtdr)*isdlpdr;
+  double cl = fast_speed(gamma, dl, pl, bxi, byl, bzl);
+  double cr = fast_speed(gamma, dr, pr, bxi, byr, bzr);
+  double btsq = SQR(roe_by) + SQR(roe_bz);
+  double vaxsq = bxi*bxi/roe_d;
+  double bt_starsq = (gm1 - (gm1 - 1.0)*y)*btsq;
+  double hp = hroe - (vaxsq + btsq/roe_d);
+  double vsq = SQR(roe_vx) + SQR(roe_vy) + SQR(roe_vz);
+  double twid_asq = fmax((gm1*(hp - 0.5*vsq) - (gm1 - 1.0)*x), 0.0);
+  double ct2 = bt_starsq/roe_d;
+  double tsum = vaxsq + ct2 + twid_asq;
+  double tdif = vaxsq + ct2 - twid_asq;
+  double cf2_cs2 = sqrt(tdif*tdif + 4.0*twid_asq*ct2);
+  double cfsq = 0.5*(tsum + cf2_cs2);
+  double a = sqrt(cfsq);
+  double al = fmin((roe_vx - a), (ul - cl));
+  double ar = fmax((roe_vx + a), (ur + cr));
+  double bp = ar > 0.0 ? ar : 1.0e-20;
+  double bm = al < 0.0 ? al : -1.0e-20;
+  double vxl = ul - bm;
+  double vxr = ur - bp;
+  double fl_d = dl*vxl, fr_d = dr*vxr;
+  double fl_mx = dl*ul*vxl + pbl - SQR(bxi);
+  double fr_mx = dr*ur*vxr + pbr - SQR(bxi);
+  double fl_my = dl*vl*vxl - bxi*byl;
+  double fr_my = dr*vr*vxr - bxi*byr;
+  double fl_mz = dl*zl*vxl - bxi*bzl;
+  double fr_mz = dr*zr*vxr - bxi*bzr;
+  fl_mx += pl;
+  fr_mx += pr;
+  double fl_e = el*vxl + ul*(pl + pbl - bxi*bxi);
+  double fr_e = er*vxr + ur*(pr + pbr - bxi*bxi);
+  fl_e -= bxi*(byl*vl + bzl*zl);
+  fr_e -= bxi*(byr*vr + bzr*zr);
+  double fl_by = byl*vxl - bxi*vl;
+  double fr_by = byr*vxr - bxi*vr;
+  double fl_bz = bzl*vxl - bxi*zl;
+  double fr_bz = bzr*vxr - bxi*zr;
+  double tmp = 0.0;
+  if (bp != bm) tmp = 0.5*(bp + bm)/(bp - bm);
+  flx[0] = 0.5*(fl_d + fr_d) + (fl_d - fr_d)*tmp;
+  flx[1] = 0.5*(fl_mx + fr_mx) + (fl_mx - fr_mx)*tmp;
+  flx[2] = 0.5*(fl_my + fr_my) + (fl_my - fr_my)*tmp;
+  flx[3] = 0.5*(fl_mz + fr_mz) + (fl_mz - fr_mz)*tmp;
+  flx[4] = 0.5*(fl_e + fr_e) + (fl_e - fr_e)*tmp;
+  flx[5] = 0.5*(fl_by + fr_by) + (fl_by - fr_by)*tmp;   /* ey = -0.5*(..) - (..)*tmp == -flx[5] */
+  flx[6] = 0.5*(fl_bz + fr_bz) + (fl_bz - fr_bz)*tmp;
+}
+
+static inline int mhd_riemann(int rs, double gamma, const double a[7], const double b[7],
+                              double bxi, double f[7]) {
+  switch (rs) {
+    case AKMI_RS_LLF:  akref_llf_mhd(gamma, a, b, bxi, f); return 0;
+    case AKMI_RS_HLLE: akref_hlle_mhd(gamma, a, b, bxi, f); return 0;
+    case AKMI_RS_HLLD: akref_hlld(gamma, a, b, bxi, f); return 0;
+  }
+  return 1;
+}
+
 int akref_copy_cons(const akmi_pack *p, const double *u0, double *u1) {
   G g = mkG(p);
   memcpy(u1, u0, sizeof(double)*(size_t)g.nmb*g.nvar*g.N3*g.N2*g.N1);
@@ -408,7 +845,8 @@ int akref_copy_cons(const akmi_pack *p, const double *u0, double *u1) {
 /* Hydro::CalculateFluxes<hllc>, src/hydro/hydro_fluxes.cpp:77-229 (no FOFC, no scalars) */
 int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
                        double *flx1, double *flx2, double *flx3, int fs) {
-  if (rsolver != AKMI_RS_HLLC) return AKMI_FAIL;
+  if (rsolver != AKMI_RS_LLF && rsolver != AKMI_RS_HLLE && rsolver != AKMI_RS_HLLC &&
+      rsolver != AKMI_RS_ROE) return AKMI_FAIL;
   G g = mkG(p);
   const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
   size_t ncell = (size_t)g.nmb*nv*N3*N2*N1;
@@ -420,10 +858,10 @@ int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double 
     int il = g.is, iu = g.ie, jl = g.js, ju = g.je, kl = g.ks, ku = g.ke;
     double *flx = flx1;
     int f3 = N3, f2 = N2, f1 = N1 + fs;
-    if (dir == 0) { recon_dir(&g, recon, 0, nv, w0, wl, wr, kl, ku, jl, ju, il-1, iu+1); iu = g.ie+1; }
-    if (dir == 1) { recon_dir(&g, recon, 1, nv, w0, wl, wr, kl, ku, jl-1, ju+1, il, iu); ju = g.je+1;
+    if (dir == 0) { recon_dir(&g, p, 1, recon, 0, nv, w0, wl, wr, kl, ku, jl, ju, il-1, iu+1); iu = g.ie+1; }
+    if (dir == 1) { recon_dir(&g, p, 1, recon, 1, nv, w0, wl, wr, kl, ku, jl-1, ju+1, il, iu); ju = g.je+1;
                     flx = flx2; f1 = N1; f2 = N2 + fs; }
-    if (dir == 2) { recon_dir(&g, recon, 2, nv, w0, wl, wr, kl-1, ku+1, jl, ju, il, iu); ku = g.ke+1;
+    if (dir == 2) { recon_dir(&g, p, 1, recon, 2, nv, w0, wl, wr, kl-1, ku+1, jl, ju, il, iu); ku = g.ke+1;
                     flx = flx3; f1 = N1; f3 = N3 + fs; }
     const int ivx = IVX + dir, ivy = IVX + (dir + 1)%3, ivz = IVX + (dir + 2)%3;
 #pragma omp parallel for collapse(2) schedule(static)
@@ -437,7 +875,7 @@ int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double 
             a[2] = wl[ix5(nv,N3,N2,N1,m,ivy,k,j,i)]; b[2] = wr[ix5(nv,N3,N2,N1,m,ivy,k,j,i)];
             a[3] = wl[ix5(nv,N3,N2,N1,m,ivz,k,j,i)]; b[3] = wr[ix5(nv,N3,N2,N1,m,ivz,k,j,i)];
             a[4] = wl[ix5(nv,N3,N2,N1,m,IEN,k,j,i)]; b[4] = wr[ix5(nv,N3,N2,N1,m,IEN,k,j,i)];
-            akref_hllc(gamma, a, b, f);
+            hyd_riemann(rsolver, gamma, a, b, f);
             flx[ix5(nv,f3,f2,f1,m,IDN,k,j,i)] = f[0];
             flx[ix5(nv,f3,f2,f1,m,ivx,k,j,i)] = f[1];
             flx[ix5(nv,f3,f2,f1,m,ivy,k,j,i)] = f[2];
@@ -544,7 +982,7 @@ int akref_mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w
                      const double *bx3f, double *flx1, double *flx2, double *flx3,
                      double *e3x1, double *e2x1, double *e1x2, double *e3x2, double *e2x3,
                      double *e1x3) {
-  if (rsolver != AKMI_RS_HLLD) return AKMI_FAIL;
+  if (rsolver != AKMI_RS_LLF && rsolver != AKMI_RS_HLLE && rsolver != AKMI_RS_HLLD) return AKMI_FAIL;
   G g = mkG(p);
   const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
   size_t ncell = (size_t)g.nmb*N3*N2*N1;
@@ -561,20 +999,20 @@ int akref_mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w
       jl = g.js; ju = g.je; kl = g.ks; ku = g.ke;
       if (g.multi_d) { jl = g.js-1; ju = g.je+1; }
       if (g.three_d) { kl = g.ks-1; ku = g.ke+1; }
-      recon_dir(&g, recon, 0, nv, w0, wl, wr, kl, ku, jl, ju, g.is-1, g.ie+1);
-      recon_dir(&g, recon, 0, 3, bcc0, bl, br, kl, ku, jl, ju, g.is-1, g.ie+1);
+      recon_dir(&g, p, 1, recon, 0, nv, w0, wl, wr, kl, ku, jl, ju, g.is-1, g.ie+1);
+      recon_dir(&g, p, 0, recon, 0, 3, bcc0, bl, br, kl, ku, jl, ju, g.is-1, g.ie+1);
       il = g.is; iu = g.ie+1;
       bx = bx1f; flx = flx1; ey = e3x1; ez = e2x1; f1 = N1+1;
     } else if (dir == 1) {
       kl = g.ks; ku = g.ke;
       if (g.three_d) { kl = g.ks-1; ku = g.ke+1; }
-      recon_dir(&g, recon, 1, nv, w0, wl, wr, kl, ku, g.js-1, g.je+1, g.is-1, g.ie+1);
-      recon_dir(&g, recon, 1, 3, bcc0, bl, br, kl, ku, g.js-1, g.je+1, g.is-1, g.ie+1);
+      recon_dir(&g, p, 1, recon, 1, nv, w0, wl, wr, kl, ku, g.js-1, g.je+1, g.is-1, g.ie+1);
+      recon_dir(&g, p, 0, recon, 1, 3, bcc0, bl, br, kl, ku, g.js-1, g.je+1, g.is-1, g.ie+1);
       il = g.is-1; iu = g.ie+1; jl = g.js; ju = g.je+1;
       bx = bx2f; flx = flx2; ey = e1x2; ez = e3x2; f2 = N2+1;
     } else {
-      recon_dir(&g, recon, 2, nv, w0, wl, wr, g.ks-1, g.ke+1, g.js-1, g.je+1, g.is-1, g.ie+1);
-      recon_dir(&g, recon, 2, 3, bcc0, bl, br, g.ks-1, g.ke+1, g.js-1, g.je+1, g.is-1, g.ie+1);
+      recon_dir(&g, p, 1, recon, 2, nv, w0, wl, wr, g.ks-1, g.ke+1, g.js-1, g.je+1, g.is-1, g.ie+1);
+      recon_dir(&g, p, 0, recon, 2, 3, bcc0, bl, br, g.ks-1, g.ke+1, g.js-1, g.je+1, g.is-1, g.ie+1);
       il = g.is-1; iu = g.ie+1; jl = g.js-1; ju = g.je+1; kl = g.ks; ku = g.ke+1;
       bx = bx3f; flx = flx3; ey = e2x3; ez = e1x3; f3 = N3+1;
     }
@@ -594,7 +1032,7 @@ int akref_mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w
             a[5] = bl[ix5(3,N3,N2,N1,m,iby,k,j,i)];  b[5] = br[ix5(3,N3,N2,N1,m,iby,k,j,i)];
             a[6] = bl[ix5(3,N3,N2,N1,m,ibz,k,j,i)];  b[6] = br[ix5(3,N3,N2,N1,m,ibz,k,j,i)];
             double bxi = bx[ix4(f3,f2,f1,m,k,j,i)];
-            akref_hlld(gamma, a, b, bxi, f);
+            mhd_riemann(rsolver, gamma, a, b, bxi, f);
             flx[ix5(nv,f3,f2,f1,m,IDN,k,j,i)] = f[0];
             flx[ix5(nv,f3,f2,f1,m,ivx,k,j,i)] = f[1];
             flx[ix5(nv,f3,f2,f1,m,ivy,k,j,i)] = f[2];
