@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 #include "../../include/akmi.h"
 #include "akmi_numerics.hpp"
 
@@ -38,6 +39,69 @@ inline Eos make_eos(const akmi_pack *p) {
   e.gamma = p->gamma; e.dfloor = p->dfloor; e.pfloor = p->pfloor; e.tfloor = p->tfloor;
   e.sfloor = p->sfloor; e.sigma_max = p->sigma_max;
   return e;
+}
+
+inline FaceEos make_face_eos(const akmi_pack *p) {
+  FaceEos e;
+  e.gamma = p->gamma; e.dfloor = p->dfloor; e.efloor = p->pfloor/(p->gamma - 1.0);
+  return e;
+}
+
+void set_error(const char *fmt, ...);
+
+// reconstruction x Riemann solver of a flux launch; the kernels are templated on both, the
+// (grid-uniform) run-time choice is resolved here on the host, as ReconDispatch and the
+// CalculateFluxes<rsolver> templates do in the reference (recon.hpp:134-185)
+struct Scheme {
+  int recon, rsolver;
+  FaceEos eos;
+};
+template <int V> using IC = std::integral_constant<int, V>;
+
+template <class F>
+inline int dispatch_recon(int recon, F &&f) {
+  switch (recon) {
+    case AKMI_RECON_DC:    return f(IC<0>{});
+    case AKMI_RECON_PLM:   return f(IC<1>{});
+    case AKMI_RECON_PPM4:  return f(IC<2>{});
+    case AKMI_RECON_PPMX:  return f(IC<3>{});
+    case AKMI_RECON_WENOZ: return f(IC<4>{});
+    case AKMI_RECON_TENO:  return f(IC<5>{});
+  }
+  set_error("reconstruct = %d not implemented", recon);
+  return AKMI_FAIL;
+}
+
+template <bool MHD, class F>
+inline int dispatch_rsolver(int rs, F &&f) {
+  if (rs == AKMI_RS_LLF) return f(IC<0>{});
+  if (rs == AKMI_RS_HLLE) return f(IC<1>{});
+  if constexpr (MHD) {
+    if (rs == AKMI_RS_HLLD) return f(IC<3>{});
+    set_error("<mhd> rsolver = %d not implemented (llf, hlle, hlld)", rs);
+  } else {
+    if (rs == AKMI_RS_HLLC) return f(IC<2>{});
+    if (rs == AKMI_RS_ROE) return f(IC<4>{});
+    set_error("<hydro> rsolver = %d not implemented (llf, hlle, hllc, roe)", rs);
+  }
+  return AKMI_FAIL;
+}
+
+// f(IC<RECON>, IC<RS>) for the run-time pair
+template <bool MHD, class F>
+inline int dispatch_scheme(const Scheme &sc, F &&f) {
+  return dispatch_recon(sc.recon, [&](auto R) {
+    return dispatch_rsolver<MHD>(sc.rsolver, [&](auto S) { return f(R, S); });
+  });
+}
+
+inline int check_scheme(const akmi_pack *p, int recon, const char *who) {
+  if (recon >= AKMI_RECON_PPM4 && recon <= AKMI_RECON_TENO && p->ng < 3) {
+    // hydro.cpp:173-179: the +/-2 stencil requires at least 3 ghost zones
+    set_error("%s: ppm4/ppmx/wenoz/teno need nghost>=3", who);
+    return AKMI_FAIL;
+  }
+  return AKMI_COMPLETE;
 }
 
 // LayoutRight offsets (src/athena.hpp:111,127-128)

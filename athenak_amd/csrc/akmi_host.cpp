@@ -308,6 +308,9 @@ static int ReconFlag(const std::string &r) {
   if (r == "dc") return AKMI_RECON_DC;
   if (r == "plm") return AKMI_RECON_PLM;
   if (r == "ppm4") return AKMI_RECON_PPM4;
+  if (r == "ppmx") return AKMI_RECON_PPMX;
+  if (r == "wenoz") return AKMI_RECON_WENOZ;
+  if (r == "teno") return AKMI_RECON_TENO;
   AKMI_FATAL("reconstruct = '" + r + "' not implemented on this path");
 }
 
@@ -325,7 +328,7 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
   const RegionIndcs &ind = pp->pmesh->mb_indcs;
   std::string rec = pin->GetOrAddString(blk, "reconstruct", "plm");
   recon_method = ReconFlag(rec);
-  if (rec == "ppm4" && ind.ng < 3)
+  if (recon_method >= AKMI_RECON_PPM4 && ind.ng < 3)
     AKMI_FATAL("PPM/WENOZ reconstruction requires at least 3 ghost zones");
   if (pin->GetOrAddInteger(blk, "nscalars", 0) != 0) AKMI_FATAL("passive scalars are not on this path");
   fused = pin->GetOrAddBoolean(blk, "fused_stage", true);
@@ -362,8 +365,12 @@ static void FaceFree(DvceFaceFld &f) { f.x1f.Free(); f.x2f.Free(); f.x3f.Free();
 
 namespace hydro {
 Hydro::Hydro(MeshBlockPack *pp, ParameterInput *pin) : FluidBase(pp, pin, "hydro") {
-  if (pin->GetString("hydro", "rsolver") != "hllc") AKMI_FATAL("<hydro> rsolver: hllc only on this path");
-  rsolver_method = AKMI_RS_HLLC;
+  const std::string rs = pin->GetString("hydro", "rsolver");
+  if (rs == "llf") rsolver_method = AKMI_RS_LLF;
+  else if (rs == "hlle") rsolver_method = AKMI_RS_HLLE;
+  else if (rs == "hllc") rsolver_method = AKMI_RS_HLLC;
+  else if (rs == "roe") rsolver_method = AKMI_RS_ROE;
+  else AKMI_FATAL("<hydro> rsolver = '" + rs + "' not implemented (llf, hlle, hllc, roe)");
   const RegionIndcs &ind = pp->pmesh->mb_indcs;
   const size_t n1 = ind.nx1 + 2*ind.ng, n2 = ind.nx2 > 1 ? ind.nx2 + 2*ind.ng : 1,
                n3 = ind.nx3 > 1 ? ind.nx3 + 2*ind.ng : 1;
@@ -396,8 +403,11 @@ void Hydro::AssembleHydroTasks(std::map<std::string, std::shared_ptr<TaskList>> 
 
 namespace mhd {
 MHD::MHD(MeshBlockPack *pp, ParameterInput *pin) : FluidBase(pp, pin, "mhd") {
-  if (pin->GetString("mhd", "rsolver") != "hlld") AKMI_FATAL("<mhd> rsolver: hlld only on this path");
-  rsolver_method = AKMI_RS_HLLD;
+  const std::string rs = pin->GetString("mhd", "rsolver");
+  if (rs == "llf") rsolver_method = AKMI_RS_LLF;
+  else if (rs == "hlle") rsolver_method = AKMI_RS_HLLE;
+  else if (rs == "hlld") rsolver_method = AKMI_RS_HLLD;
+  else AKMI_FATAL("<mhd> rsolver = '" + rs + "' not implemented (llf, hlle, hlld)");
   const RegionIndcs &ind = pp->pmesh->mb_indcs;
   const size_t nmb = pp->nmb_thispack;
   const size_t n1 = ind.nx1 + 2*ind.ng, n2 = ind.nx2 > 1 ? ind.nx2 + 2*ind.ng : 1,

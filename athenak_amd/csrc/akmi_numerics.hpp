@@ -49,21 +49,152 @@ AKMI_DEV void ppm4(double qm2, double qm1, double q, double qp1, double qp2, dou
   qr_i = qlv;
 }
 
+AKMI_DEV double sgn(double x) { return (x < 0.0) ? -1.0 : 1.0; }   // SIGN, src/athena.hpp:52
+
+// PPMX, src/reconstruct/ppm.hpp:84-181 (Colella & Sekora limiters, PH = Peterson & Hammett)
+AKMI_DEV void ppmx(double qm2, double qm1, double q, double qp1, double qp2, double &ql_ip1,
+                   double &qr_i) {
+  double qlv = (7.*(q + qm1) - (qm2 + qp1))/12.0;
+  double qrv = (7.*(q + qp1) - (qm1 + qp2))/12.0;
+  double d2qc = 3.0*((qm1 + q) - 2.0*qlv);
+  double d2ql = (qm2 + q) - 2.0*qm1;
+  double d2qr = (qm1 + qp1) - 2.0*q;
+  double d2qlim = 0.0;
+  double lim_slope = fmin(fabs(d2ql), fabs(d2qr));
+  if (d2qc > 0.0 && d2ql > 0.0 && d2qr > 0.0) d2qlim = sgn(d2qc)*fmin(1.25*lim_slope, fabs(d2qc));
+  if (d2qc < 0.0 && d2ql < 0.0 && d2qr < 0.0) d2qlim = sgn(d2qc)*fmin(1.25*lim_slope, fabs(d2qc));
+  if (((qm1 - qlv)*(q - qlv)) > 0.0) qlv = 0.5*(q + qm1) - d2qlim/6.0;
+  d2qc = 3.0*((q + qp1) - 2.0*qrv);
+  d2ql = d2qr;
+  d2qr = (q + qp2) - 2.0*qp1;
+  d2qlim = 0.0;
+  lim_slope = fmin(fabs(d2ql), fabs(d2qr));
+  if (d2qc > 0.0 && d2ql > 0.0 && d2qr > 0.0) d2qlim = sgn(d2qc)*fmin(1.25*lim_slope, fabs(d2qc));
+  if (d2qc < 0.0 && d2ql < 0.0 && d2qr < 0.0) d2qlim = sgn(d2qc)*fmin(1.25*lim_slope, fabs(d2qc));
+  if (((q - qrv)*(qp1 - qrv)) > 0.0) qrv = 0.5*(q + qp1) - d2qlim/6.0;
+  double qa = (qrv - q)*(q - qlv);
+  double qb = (qm1 - q)*(q - qp1);
+  if (qa <= 0.0 || qb <= 0.0) {
+    double d2q = 6.0*(qlv + qrv - 2.0*q);
+    double e2qc = (qm1 + qp1) - 2.0*q;
+    double e2ql = (qm2 + q) - 2.0*qm1;
+    double e2qr = (q + qp2) - 2.0*qp1;
+    d2qlim = 0.0;
+    lim_slope = fmin(fabs(e2ql), fabs(e2qr));
+    lim_slope = fmin(fabs(e2qc), lim_slope);
+    if (e2qc > 0.0 && e2ql > 0.0 && e2qr > 0.0 && d2q > 0.0)
+      d2qlim = sgn(d2q)*fmin(1.25*lim_slope, fabs(d2q));
+    if (e2qc < 0.0 && e2ql < 0.0 && e2qr < 0.0 && d2q < 0.0)
+      d2qlim = sgn(d2q)*fmin(1.25*lim_slope, fabs(d2q));
+    double rho = 0.0;
+    if (fabs(d2q) > (1.0e-12)*fmax(fabs(qm1), fmax(fabs(q), fabs(qp1)))) rho = d2qlim/d2q;
+    qlv = q + (qlv - q)*rho;
+    qrv = q + (qrv - q)*rho;
+  } else {
+    double qc = qrv - q;
+    double qd = qlv - q;
+    if (fabs(qc) >= 2.0*fabs(qd)) qrv = q - 2.0*qd;
+    if (fabs(qd) >= 2.0*fabs(qc)) qlv = q - 2.0*qc;
+  }
+  ql_ip1 = qrv;
+  qr_i = qlv;
+}
+
+// Jiang-Shu smoothness indicators (wenoz.hpp:32-43 == teno.hpp:33-44) and the two 5th-order
+// face values for un-normalised weights (wenoz.hpp:58-81 == teno.hpp:64-86)
+AKMI_DEV void js_beta(double qm2, double qm1, double q, double qp1, double qp2, double &b0,
+                      double &b1, double &b2) {
+  const double c0 = 13./12., c1 = 0.25;
+  b0 = c0*sqr(qm2 + q - 2.0*qm1) + c1*sqr(qm2 + 3.0*q - 4.0*qm1);
+  b1 = c0*sqr(qm1 + qp1 - 2.0*q) + c1*sqr(qm1 - qp1);
+  b2 = c0*sqr(qp2 + q - 2.0*qp1) + c1*sqr(qp2 + 3.0*q - 4.0*qp1);
+}
+AKMI_DEV void weno_faces(double qm2, double qm1, double q, double qp1, double qp2, double wa,
+                         double wb, double wc, double va, double vc, double &ql_ip1,
+                         double &qr_i) {
+  double f0 = (2.0*qm2 - 7.0*qm1 + 11.0*q);
+  double f1 = (-1.0*qm1 + 5.0*q + 2.0*qp1);
+  double f2 = (2.0*q + 5.0*qp1 - qp2);
+  double asum = 6.0*(wa + wb + wc);
+  ql_ip1 = (f0*wa + f1*wb + f2*wc)/asum;
+  f0 = (2.0*qp2 - 7.0*qp1 + 11.0*q);
+  f1 = (-1.0*qp1 + 5.0*q + 2.0*qm1);
+  f2 = (2.0*q + 5.0*qm1 - qm2);
+  asum = 6.0*(va + wb + vc);
+  qr_i = (f0*va + f1*wb + f2*vc)/asum;
+}
+
+// WENO-Z, src/reconstruct/wenoz.hpp:29-84
+AKMI_DEV void wenoz(double qm2, double qm1, double q, double qp1, double qp2, double &ql_ip1,
+                    double &qr_i) {
+  double b0, b1, b2;
+  js_beta(qm2, qm1, q, qp1, qp2, b0, b1, b2);
+  const double epsL = 1.0e-42;
+  const double tau_5 = fabs(b0 - b2);
+  double ind0 = sqr(tau_5/(b0 + epsL));
+  double ind1 = sqr(tau_5/(b1 + epsL));
+  double ind2 = sqr(tau_5/(b2 + epsL));
+  weno_faces(qm2, qm1, q, qp1, qp2, 0.1*(1.0 + ind0), 0.6*(1.0 + ind1), 0.3*(1.0 + ind2),
+             0.1*(1.0 + ind2), 0.3*(1.0 + ind0), ql_ip1, qr_i);
+}
+
+// TENO, src/reconstruct/teno.hpp:30-89
+AKMI_DEV double cube(double x) { return x*x*x; }
+AKMI_DEV void teno(double qm2, double qm1, double q, double qp1, double qp2, double &ql_ip1,
+                   double &qr_i) {
+  double b0, b1, b2;
+  js_beta(qm2, qm1, q, qp1, qp2, b0, b1, b2);
+  const double epsT = 1.0e-40, cT = 1.0e-6;
+  double a0 = 1.0/sqr(cube(b0 + epsT));
+  double a1 = 1.0/sqr(cube(b1 + epsT));
+  double a2 = 1.0/sqr(cube(b2 + epsT));
+  double asum = a0 + a1 + a2;
+  double ind0 = (a0 < cT*asum ? 0.0 : 1.0);
+  double ind1 = (a1 < cT*asum ? 0.0 : 1.0);
+  double ind2 = (a2 < cT*asum ? 0.0 : 1.0);
+  weno_faces(qm2, qm1, q, qp1, qp2, 0.1*ind0, 0.6*ind1, 0.3*ind2, 0.1*ind2, 0.3*ind0, ql_ip1,
+             qr_i);
+}
+
+// what the flux kernels need of EOS_Data: gamma and the floors of the L/R states
+// (recon.hpp:52-53: dfloor, efloor = pfloor/(gamma-1))
+struct FaceEos { double gamma, dfloor, efloor; };
+
+// five-point reconstructions behind one name.  RECON: 2 ppm4, 3 ppmx, 4 wenoz, 5 teno
+template <int RECON>
+AKMI_DEV void recon5(double qm2, double qm1, double q, double qp1, double qp2, double &ql_ip1,
+                     double &qr_i) {
+  if constexpr (RECON == 2) ppm4(qm2, qm1, q, qp1, qp2, ql_ip1, qr_i);
+  else if constexpr (RECON == 3) ppmx(qm2, qm1, q, qp1, qp2, ql_ip1, qr_i);
+  else if constexpr (RECON == 4) wenoz(qm2, qm1, q, qp1, qp2, ql_ip1, qr_i);
+  else teno(qm2, qm1, q, qp1, qp2, ql_ip1, qr_i);
+}
+
+// floors of ReconCellT (recon.hpp:72-103): only in the ppmx/wenoz/teno branches, only for the
+// fluid density (FL == 1) and internal energy (FL == 2); FL == 0: velocities, B
+template <int RECON, int FL>
+AKMI_DEV void floor_lr(const FaceEos &eos, double &a, double &b) {
+  if constexpr (RECON >= 3 && FL == 1) { a = fmax(a, eos.dfloor); b = fmax(b, eos.dfloor); }
+  if constexpr (RECON >= 3 && FL == 2) { a = fmax(a, eos.efloor); b = fmax(b, eos.efloor); }
+}
+
 // L/R states of the face between cells (c-1) and c along a direction, for one variable.
 // q points at cell c; s is the element stride along the direction.
-// RECON: 0 dc, 1 plm, 2 ppm4 (ReconCellT, src/reconstruct/recon.hpp:40-118: cell c-1
-// writes wl(c), cell c writes wr(c)).
-template <int RECON>
-AKMI_DEV void face_states(const double *__restrict__ q, long s, double &ql, double &qr) {
+// RECON: 0 dc, 1 plm, 2 ppm4, 3 ppmx, 4 wenoz, 5 teno (ReconCellT,
+// src/reconstruct/recon.hpp:40-118: cell c-1 writes wl(c), cell c writes wr(c)).
+template <int RECON, int FL = 0>
+AKMI_DEV void face_states(const double *__restrict__ q, long s, const FaceEos &eos, double &ql,
+                          double &qr) {
   double dummy;
   if constexpr (RECON == 1) {
     double qm2 = q[-2*s], qm1 = q[-s], q0 = q[0], qp1 = q[s];
     plm(qm2, qm1, q0, ql, dummy);
     plm(qm1, q0, qp1, dummy, qr);
-  } else if constexpr (RECON == 2) {
+  } else if constexpr (RECON >= 2) {
     double qm3 = q[-3*s], qm2 = q[-2*s], qm1 = q[-s], q0 = q[0], qp1 = q[s], qp2 = q[2*s];
-    ppm4(qm3, qm2, qm1, q0, qp1, ql, dummy);
-    ppm4(qm2, qm1, q0, qp1, qp2, dummy, qr);
+    recon5<RECON>(qm3, qm2, qm1, q0, qp1, ql, dummy);
+    recon5<RECON>(qm2, qm1, q0, qp1, qp2, dummy, qr);
+    floor_lr<RECON, FL>(eos, ql, qr);
   } else {
     ql = q[-s];
     qr = q[0];
@@ -73,19 +204,20 @@ AKMI_DEV void face_states(const double *__restrict__ q, long s, double &ql, doub
 // Same, addressed as (wave-uniform base pointer) + (32-bit per-lane element offset): the
 // stencil neighbours differ only in the uniform part, so the compiler keeps ONE offset VGPR per
 // lane and forms the neighbour addresses on the scalar unit (global_load ... v_off, s[base]).
-template <int RECON>
-AKMI_DEV void face_states_u(const double *__restrict__ base, unsigned off, long s, double &ql,
-                            double &qr) {
+template <int RECON, int FL = 0>
+AKMI_DEV void face_states_u(const double *__restrict__ base, unsigned off, long s,
+                            const FaceEos &eos, double &ql, double &qr) {
   double dummy;
   if constexpr (RECON == 1) {
     double qm2 = (base - 2*s)[off], qm1 = (base - s)[off], q0 = base[off], qp1 = (base + s)[off];
     plm(qm2, qm1, q0, ql, dummy);
     plm(qm1, q0, qp1, dummy, qr);
-  } else if constexpr (RECON == 2) {
+  } else if constexpr (RECON >= 2) {
     double qm3 = (base - 3*s)[off], qm2 = (base - 2*s)[off], qm1 = (base - s)[off], q0 = base[off],
            qp1 = (base + s)[off], qp2 = (base + 2*s)[off];
-    ppm4(qm3, qm2, qm1, q0, qp1, ql, dummy);
-    ppm4(qm2, qm1, q0, qp1, qp2, dummy, qr);
+    recon5<RECON>(qm3, qm2, qm1, q0, qp1, ql, dummy);
+    recon5<RECON>(qm2, qm1, q0, qp1, qp2, dummy, qr);
+    floor_lr<RECON, FL>(eos, ql, qr);
   } else {
     ql = (base - s)[off];
     qr = base[off];
@@ -147,6 +279,200 @@ AKMI_DEV void hllc(double gamma, double wl_idn, double wl_ivx, double wl_ivy, do
   f_my = qc*fl_my + qd*fr_my;
   f_mz = qc*fl_mz + qd*fr_mz;
   f_e = qc*fl_e + qd*fr_e + qe*cp*am;
+}
+
+// LLF, src/hydro/rsolvers/llf_hyd_singlestate.hpp:28-78 (ideal gas)
+AKMI_DEV void llf_hyd(double gamma, double ld, double lx, double ly, double lz, double le,
+                      double rd, double rx, double ry, double rz, double re, double &f_d,
+                      double &f_mx, double &f_my, double &f_mz, double &f_e) {
+  double qa = ld*lx;
+  double qb = rd*rx;
+  double s_d = qa + qb;
+  double s_mx = qa*lx + qb*rx;
+  double s_my = qa*ly + qb*ry;
+  double s_mz = qa*lz + qb*rz;
+  double pl = (gamma - 1.0)*le;
+  double pr = (gamma - 1.0)*re;
+  double el = le + 0.5*ld*(sqr(lx) + sqr(ly) + sqr(lz));
+  double er = re + 0.5*rd*(sqr(rx) + sqr(ry) + sqr(rz));
+  s_mx += (pl + pr);
+  double s_e = (el + pl)*lx + (er + pr)*rx;
+  qa = sqrt(gamma*pl/ld);
+  qb = sqrt(gamma*pr/rd);
+  double a = fmax((fabs(lx) + qa), (fabs(rx) + qb));
+  double du_d = a*(rd - ld);
+  double du_mx = a*(rd*rx - ld*lx);
+  double du_my = a*(rd*ry - ld*ly);
+  double du_mz = a*(rd*rz - ld*lz);
+  double du_e = a*(er - el);
+  f_d = 0.5*(s_d - du_d);
+  f_mx = 0.5*(s_mx - du_mx);
+  f_my = 0.5*(s_my - du_my);
+  f_mz = 0.5*(s_mz - du_mz);
+  f_e = 0.5*(s_e - du_e);
+}
+
+// HLLE, src/hydro/rsolvers/hlle_hyd.hpp:27-129 (ideal gas)
+AKMI_DEV void hlle_hyd(double gamma, double dl, double ul, double vl, double zl, double eil,
+                       double dr, double ur, double vr, double zr, double eir, double &f_d,
+                       double &f_mx, double &f_my, double &f_mz, double &f_e) {
+  const double gm1 = gamma - 1.0;
+  const double igm1 = 1.0/gm1;
+  double pl = (gamma - 1.0)*eil, pr = (gamma - 1.0)*eir;
+  double sqrtdl = sqrt(dl);
+  double sqrtdr = sqrt(dr);
+  double isdlpdr = 1.0/(sqrtdl + sqrtdr);
+  double roe_vx = (sqrtdl*ul + sqrtdr*ur)*isdlpdr;
+  double roe_vy = (sqrtdl*vl + sqrtdr*vr)*isdlpdr;
+  double roe_vz = (sqrtdl*zl + sqrtdr*zr)*isdlpdr;
+  double el = pl*igm1 + 0.5*dl*(sqr(ul) + sqr(vl) + sqr(zl));
+  double er = pr*igm1 + 0.5*dr*(sqr(ur) + sqr(vr) + sqr(zr));
+  double hroe = ((el + pl)/sqrtdl + (er + pr)/sqrtdr)*isdlpdr;
+  double qa = sqrt(gamma*pl/dl);
+  double qb = sqrt(gamma*pr/dr);
+  double a = hroe - 0.5*(sqr(roe_vx) + sqr(roe_vy) + sqr(roe_vz));
+  a = (a < 0.0) ? 0.0 : sqrt(gm1*a);
+  double al = fmin((roe_vx - a), (ul - qa));
+  double ar = fmax((roe_vx + a), (ur + qb));
+  double bp = (ar > 0.0) ? ar : 1.0e-20;
+  double bm = (al < 0.0) ? al : -1.0e-20;
+  qa = ul - bm;
+  qb = ur - bp;
+  double fl_d = dl*qa, fr_d = dr*qb;
+  double fl_mx = dl*ul*qa, fr_mx = dr*ur*qb;
+  double fl_my = dl*vl*qa, fr_my = dr*vr*qb;
+  double fl_mz = dl*zl*qa, fr_mz = dr*zr*qb;
+  fl_mx += pl;
+  fr_mx += pr;
+  double fl_e = el*qa + pl*ul;
+  double fr_e = er*qb + pr*ur;
+  qa = 0.0;
+  if (bp != bm) qa = 0.5*(bp + bm)/(bp - bm);
+  f_d = 0.5*(fl_d + fr_d) + qa*(fl_d - fr_d);
+  f_mx = 0.5*(fl_mx + fr_mx) + qa*(fl_mx - fr_mx);
+  f_my = 0.5*(fl_my + fr_my) + qa*(fl_my - fr_my);
+  f_mz = 0.5*(fl_mz + fr_mz) + qa*(fl_mz - fr_mz);
+  f_e = 0.5*(fl_e + fr_e) + qa*(fl_e - fr_e);
+}
+
+// Roe with LLF fallback, src/hydro/rsolvers/roe_hyd.hpp:40-268 (RoeFluxAdb :183-268)
+AKMI_DEV void roe_hyd(double gamma, double ld, double lx, double ly, double lz, double lei,
+                      double rd, double rx, double ry, double rz, double rei, double &f_d,
+                      double &f_mx, double &f_my, double &f_mz, double &f_e) {
+  const double gm1 = gamma - 1.0;
+  double wli[5] = {ld, lx, ly, lz, (gamma - 1.0)*lei};
+  double wri[5] = {rd, rx, ry, rz, (gamma - 1.0)*rei};
+  double fl[5], fr[5], du[5], ev[5], f[5];
+  double sqrtdl = sqrt(wli[0]);
+  double sqrtdr = sqrt(wri[0]);
+  double isdlpdr = 1.0/(sqrtdl + sqrtdr);
+  double v1 = (sqrtdl*wli[1] + sqrtdr*wri[1])*isdlpdr;
+  double v2 = (sqrtdl*wli[2] + sqrtdr*wri[2])*isdlpdr;
+  double v3 = (sqrtdl*wli[3] + sqrtdr*wri[3])*isdlpdr;
+  double el = wli[4]/gm1 + 0.5*wli[0]*(sqr(wli[1]) + sqr(wli[2]) + sqr(wli[3]));
+  double er = wri[4]/gm1 + 0.5*wri[0]*(sqr(wri[1]) + sqr(wri[2]) + sqr(wri[3]));
+  double h = ((el + wli[4])/sqrtdl + (er + wri[4])/sqrtdr)*isdlpdr;
+  double mxl = wli[0]*wli[1];
+  double mxr = wri[0]*wri[1];
+  fl[0] = mxl;            fr[0] = mxr;
+  fl[1] = mxl*wli[1];     fr[1] = mxr*wri[1];
+  fl[2] = mxl*wli[2];     fr[2] = mxr*wri[2];
+  fl[3] = mxl*wli[3];     fr[3] = mxr*wri[3];
+  fl[1] += wli[4];        fr[1] += wri[4];
+  fl[4] = (el + wli[4])*wli[1];
+  fr[4] = (er + wri[4])*wri[1];
+  du[0] = wri[0] - wli[0];
+  du[1] = wri[0]*wri[1] - wli[0]*wli[1];
+  du[2] = wri[0]*wri[2] - wli[0]*wli[2];
+  du[3] = wri[0]*wri[3] - wli[0]*wli[3];
+  du[4] = er - el;
+#pragma unroll
+  for (int n = 0; n < 5; ++n) f[n] = 0.5*(fl[n] + fr[n]);
+  bool llf_flag = false;
+  {
+    double vsq = v1*v1 + v2*v2 + v3*v3;
+    double q = h - 0.5*vsq;
+    double cs_sq = (q < 0.0) ? (double)(FLT_MIN) : gm1*q;
+    double cs = sqrt(cs_sq);
+    ev[0] = v1 - cs; ev[1] = v1; ev[2] = v1; ev[3] = v1; ev[4] = v1 + cs;
+    double a[5];
+    double na = 0.5/cs_sq;
+    a[0]  = du[0]*(0.5*gm1*vsq + v1*cs);
+    a[0] -= du[1]*(gm1*v1 + cs);
+    a[0] -= du[2]*gm1*v2;
+    a[0] -= du[3]*gm1*v3;
+    a[0] += du[4]*gm1;
+    a[0] *= na;
+    a[1]  = du[0]*(-v2);
+    a[1] += du[2];
+    a[2]  = du[0]*(-v3);
+    a[2] += du[3];
+    double qa = gm1/cs_sq;
+    a[3]  = du[0]*(1.0 - na*gm1*vsq);
+    a[3] += du[1]*qa*v1;
+    a[3] += du[2]*qa*v2;
+    a[3] += du[3]*qa*v3;
+    a[3] -= du[4]*qa;
+    a[4]  = du[0]*(0.5*gm1*vsq - v1*cs);
+    a[4] -= du[1]*(gm1*v1 - cs);
+    a[4] -= du[2]*gm1*v2;
+    a[4] -= du[3]*gm1*v3;
+    a[4] += du[4]*gm1;
+    a[4] *= na;
+    double co[5];
+#pragma unroll
+    for (int n = 0; n < 5; ++n) co[n] = -0.5*fabs(ev[n])*a[n];
+    double dens = wli[0] + a[0];
+    if (dens < 0.0) llf_flag = true;
+    dens += a[3];
+    if (dens < 0.0) llf_flag = true;
+    f[0] += co[0];
+    f[0] += co[3];
+    f[0] += co[4];
+    f[1] += co[0]*(v1 - cs);
+    f[1] += co[3]*v1;
+    f[1] += co[4]*(v1 + cs);
+    f[2] += co[0]*v2;
+    f[2] += co[1];
+    f[2] += co[3]*v2;
+    f[2] += co[4]*v2;
+    f[3] += co[0]*v3;
+    f[3] += co[2];
+    f[3] += co[3]*v3;
+    f[3] += co[4]*v3;
+    f[4] += co[0]*(h - v1*cs);
+    f[4] += co[1]*v2;
+    f[4] += co[2]*v3;
+    f[4] += co[3]*0.5*vsq;
+    f[4] += co[4]*(h + v1*cs);
+  }
+  if (ev[0] >= 0.0) {
+#pragma unroll
+    for (int n = 0; n < 5; ++n) f[n] = fl[n];
+  }
+  if (ev[4] <= 0.0) {
+#pragma unroll
+    for (int n = 0; n < 5; ++n) f[n] = fr[n];
+  }
+  if (llf_flag) {
+    double cl = sqrt(gamma*wli[4]/wli[0]);
+    double cr = sqrt(gamma*wri[4]/wri[0]);
+    double a = 0.5*fmax((fabs(wli[1]) + cl), (fabs(wri[1]) + cr));
+#pragma unroll
+    for (int n = 0; n < 5; ++n) f[n] = 0.5*(fl[n] + fr[n]) - a*du[n];
+  }
+  f_d = f[0]; f_mx = f[1]; f_my = f[2]; f_mz = f[3]; f_e = f[4];
+}
+
+// Hydro_RSolver selection at compile time: RS = AKMI_RS_LLF 0, HLLE 1, HLLC 2, ROE 4
+template <int RS>
+AKMI_DEV void riemann_hyd(double gamma, double ld, double lx, double ly, double lz, double le,
+                          double rd, double rx, double ry, double rz, double re, double &f_d,
+                          double &f_mx, double &f_my, double &f_mz, double &f_e) {
+  if constexpr (RS == 0) llf_hyd(gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, f_d, f_mx, f_my, f_mz, f_e);
+  else if constexpr (RS == 1) hlle_hyd(gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, f_d, f_mx, f_my, f_mz, f_e);
+  else if constexpr (RS == 4) roe_hyd(gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, f_d, f_mx, f_my, f_mz, f_e);
+  else hllc(gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, f_d, f_mx, f_my, f_mz, f_e);
 }
 
 // IdealMHDFastSpeed, src/eos/eos.hpp:49-57
@@ -354,6 +680,126 @@ AKMI_DEV Cons1D hlld(double gamma, double wl_idn, double wl_ivx, double wl_ivy, 
     flxi.e = fr.e + urst.e;     flxi.by = fr.by + urst.by;  flxi.bz = fr.bz + urst.bz;
   }
   return flxi;
+}
+
+// LLF for MHD, src/mhd/rsolvers/llf_mhd_singlestate.hpp:28-89 (ideal gas).  by/bz of the
+// result are F(by), F(bz) in the convention of hlld(): the caller stores ey=-by, ez=+bz.
+AKMI_DEV Cons1D llf_mhd(double gamma, double ld, double lx, double ly, double lz, double le,
+                        double lby, double lbz, double rd, double rx, double ry, double rz,
+                        double re, double rby, double rbz, double bxi) {
+  double qa = ld*lx;
+  double qb = rd*rx;
+  double qc = 0.5*(sqr(lby) + sqr(lbz) - sqr(bxi));
+  double qd = 0.5*(sqr(rby) + sqr(rbz) - sqr(bxi));
+  double s_d = qa + qb;
+  double s_mx = qa*lx + qb*rx + qc + qd;
+  double s_my = qa*ly + qb*ry - bxi*(lby + rby);
+  double s_mz = qa*lz + qb*rz - bxi*(lbz + rbz);
+  double s_by = lby*lx + rby*rx - bxi*(ly + ry);
+  double s_bz = lbz*lx + rbz*rx - bxi*(lz + rz);
+  double pl = (gamma - 1.0)*le;
+  double pr = (gamma - 1.0)*re;
+  double el = le + 0.5*ld*(sqr(lx) + sqr(ly) + sqr(lz)) + qc + sqr(bxi);
+  double er = re + 0.5*rd*(sqr(rx) + sqr(ry) + sqr(rz)) + qd + sqr(bxi);
+  s_mx += (pl + pr);
+  double s_e = (el + pl + qc)*lx + (er + pr + qd)*rx;
+  s_e -= bxi*(lby*ly + lbz*lz);
+  s_e -= bxi*(rby*ry + rbz*rz);
+  qa = fast_speed(gamma, ld, pl, bxi, lby, lbz);
+  qb = fast_speed(gamma, rd, pr, bxi, rby, rbz);
+  double a = fmax((fabs(lx) + qa), (fabs(rx) + qb));
+  Cons1D f;
+  f.d = 0.5*(s_d - a*(rd - ld));
+  f.mx = 0.5*(s_mx - a*(rd*rx - ld*lx));
+  f.my = 0.5*(s_my - a*(rd*ry - ld*ly));
+  f.mz = 0.5*(s_mz - a*(rd*rz - ld*lz));
+  f.e = 0.5*(s_e - a*(er - el));
+  f.by = 0.5*(s_by - a*(rby - lby));
+  f.bz = 0.5*(s_bz - a*(rbz - lbz));
+  return f;
+}
+
+// HLLE for MHD, src/mhd/rsolvers/hlle_mhd.hpp:24-178 (ideal gas)
+AKMI_DEV Cons1D hlle_mhd(double gamma, double dl, double ul, double vl, double zl, double eil,
+                         double byl, double bzl, double dr, double ur, double vr, double zr,
+                         double eir, double byr, double bzr, double bxi) {
+  double gm1 = gamma - 1.0;
+  double igm1 = 1.0/gm1;
+  double pl = (gamma - 1.0)*eil, pr = (gamma - 1.0)*eir;
+  double sqrtdl = sqrt(dl);
+  double sqrtdr = sqrt(dr);
+  double isdlpdr = 1.0/(sqrtdl + sqrtdr);
+  double roe_d = sqrtdl*sqrtdr;
+  double roe_vx = (sqrtdl*ul + sqrtdr*ur)*isdlpdr;
+  double roe_vy = (sqrtdl*vl + sqrtdr*vr)*isdlpdr;
+  double roe_vz = (sqrtdl*zl + sqrtdr*zr)*isdlpdr;
+  double roe_by = (sqrtdr*byl + sqrtdl*byr)*isdlpdr;
+  double roe_bz = (sqrtdr*bzl + sqrtdl*bzr)*isdlpdr;
+  double x = 0.5*(sqr(byl - byr) + sqr(bzl - bzr))/(sqr(sqrtdl + sqrtdr));
+  double y = 0.5*(dl + dr)/roe_d;
+  double pbl = 0.5*(bxi*bxi + sqr(byl) + sqr(bzl));
+  double pbr = 0.5*(bxi*bxi + sqr(byr) + sqr(bzr));
+  double el = pl*igm1 + 0.5*dl*(sqr(ul) + sqr(vl) + sqr(zl)) + pbl;
+  double er = pr*igm1 + 0.5*dr*(sqr(ur) + sqr(vr) + sqr(zr)) + pbr;
+  double hroe = ((el + pl + pbl)/sqrtdl + (er + pr + pbr)/sqrtdr)*isdlpdr;
+  double cl = fast_speed(gamma, dl, pl, bxi, byl, bzl);
+  double cr = fast_speed(gamma, dr, pr, bxi, byr, bzr);
+  double btsq = sqr(roe_by) + sqr(roe_bz);
+  double vaxsq = bxi*bxi/roe_d;
+  double bt_starsq = (gm1 - (gm1 - 1.0)*y)*btsq;
+  double hp = hroe - (vaxsq + btsq/roe_d);
+  double vsq = sqr(roe_vx) + sqr(roe_vy) + sqr(roe_vz);
+  double twid_asq = fmax((gm1*(hp - 0.5*vsq) - (gm1 - 1.0)*x), 0.0);
+  double ct2 = bt_starsq/roe_d;
+  double tsum = vaxsq + ct2 + twid_asq;
+  double tdif = vaxsq + ct2 - twid_asq;
+  double cf2_cs2 = sqrt(tdif*tdif + 4.0*twid_asq*ct2);
+  double cfsq = 0.5*(tsum + cf2_cs2);
+  double a = sqrt(cfsq);
+  double al = fmin((roe_vx - a), (ul - cl));
+  double ar = fmax((roe_vx + a), (ur + cr));
+  double bp = ar > 0.0 ? ar : 1.0e-20;
+  double bm = al < 0.0 ? al : -1.0e-20;
+  double vxl = ul - bm;
+  double vxr = ur - bp;
+  double fl_d = dl*vxl, fr_d = dr*vxr;
+  double fl_mx = dl*ul*vxl + pbl - sqr(bxi);
+  double fr_mx = dr*ur*vxr + pbr - sqr(bxi);
+  double fl_my = dl*vl*vxl - bxi*byl;
+  double fr_my = dr*vr*vxr - bxi*byr;
+  double fl_mz = dl*zl*vxl - bxi*bzl;
+  double fr_mz = dr*zr*vxr - bxi*bzr;
+  fl_mx += pl;
+  fr_mx += pr;
+  double fl_e = el*vxl + ul*(pl + pbl - bxi*bxi);
+  double fr_e = er*vxr + ur*(pr + pbr - bxi*bxi);
+  fl_e -= bxi*(byl*vl + bzl*zl);
+  fr_e -= bxi*(byr*vr + bzr*zr);
+  double fl_by = byl*vxl - bxi*vl;
+  double fr_by = byr*vxr - bxi*vr;
+  double fl_bz = bzl*vxl - bxi*zl;
+  double fr_bz = bzr*vxr - bxi*zr;
+  double tmp = 0.0;
+  if (bp != bm) tmp = 0.5*(bp + bm)/(bp - bm);
+  Cons1D f;
+  f.d = 0.5*(fl_d + fr_d) + (fl_d - fr_d)*tmp;
+  f.mx = 0.5*(fl_mx + fr_mx) + (fl_mx - fr_mx)*tmp;
+  f.my = 0.5*(fl_my + fr_my) + (fl_my - fr_my)*tmp;
+  f.mz = 0.5*(fl_mz + fr_mz) + (fl_mz - fr_mz)*tmp;
+  f.e = 0.5*(fl_e + fr_e) + (fl_e - fr_e)*tmp;
+  f.by = 0.5*(fl_by + fr_by) + (fl_by - fr_by)*tmp;
+  f.bz = 0.5*(fl_bz + fr_bz) + (fl_bz - fr_bz)*tmp;
+  return f;
+}
+
+// MHD_RSolver selection at compile time: RS = AKMI_RS_LLF 0, HLLE 1, HLLD 3
+template <int RS>
+AKMI_DEV Cons1D riemann_mhd(double gamma, double ld, double lx, double ly, double lz, double le,
+                            double lby, double lbz, double rd, double rx, double ry, double rz,
+                            double re, double rby, double rbz, double bxi) {
+  if constexpr (RS == 0) return llf_mhd(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
+  else if constexpr (RS == 1) return hlle_mhd(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
+  else return hlld(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
 }
 
 // EOS_Data by value (src/eos/eos.hpp:27-34), ideal gas only on this path

@@ -60,8 +60,8 @@ static StageWs carve(const Geo &g, int is_mhd, void *ws) {
 
 // ---------------------------------------------------------------------------------------
 // face flux from the cell stencil (registers only).  Returns flux in sweep-aligned order.
-template <int DIR, int RECON, bool MHD>
-__device__ __forceinline__ void face_flux(const Geo &g, double gamma,
+template <int DIR, int RECON, bool MHD, int RS>
+__device__ __forceinline__ void face_flux(const Geo &g, const FaceEos &eos,
     const double *__restrict__ w0, const double *__restrict__ bcc0,
     const double *__restrict__ bxf, int f3, int f2, int f1, int m, int k, int j, int i,
     double &fd, double &fx, double &fy, double &fz, double &fe, double &fby, double &fbz) {
@@ -72,22 +72,23 @@ __device__ __forceinline__ void face_flux(const Geo &g, double gamma,
   const double *q = w0 + (size_t)m*g.nvar*cs;
   const unsigned off = (unsigned)(((size_t)k*g.N2 + j)*g.N1 + i);
   double ld, lx, ly, lz, le, rd, rx, ry, rz, re;
-  face_states_u<RECON>(q + 0*cs, off, s, ld, rd);
-  face_states_u<RECON>(q + ivx*cs, off, s, lx, rx);
-  face_states_u<RECON>(q + ivy*cs, off, s, ly, ry);
-  face_states_u<RECON>(q + ivz*cs, off, s, lz, rz);
-  face_states_u<RECON>(q + 4*cs, off, s, le, re);
+  face_states_u<RECON, 1>(q + 0*cs, off, s, eos, ld, rd);
+  face_states_u<RECON, 0>(q + ivx*cs, off, s, eos, lx, rx);
+  face_states_u<RECON, 0>(q + ivy*cs, off, s, eos, ly, ry);
+  face_states_u<RECON, 0>(q + ivz*cs, off, s, eos, lz, rz);
+  face_states_u<RECON, 2>(q + 4*cs, off, s, eos, le, re);
   if constexpr (MHD) {
     constexpr int iby = (DIR + 1)%3, ibz = (DIR + 2)%3;
     const double *b = bcc0 + (size_t)m*3*cs;
     double lby, lbz, rby, rbz;
-    face_states_u<RECON>(b + iby*cs, off, s, lby, rby);
-    face_states_u<RECON>(b + ibz*cs, off, s, lbz, rbz);
+    face_states_u<RECON, 0>(b + iby*cs, off, s, eos, lby, rby);
+    face_states_u<RECON, 0>(b + ibz*cs, off, s, eos, lbz, rbz);
     const double bxi = bxf[ix4(f3, f2, f1, m, k, j, i)];
-    Cons1D fl = hlld(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
+    Cons1D fl = riemann_mhd<RS>(eos.gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby,
+                                rbz, bxi);
     fd = fl.d; fx = fl.mx; fy = fl.my; fz = fl.mz; fe = fl.e; fby = fl.by; fbz = fl.bz;
   } else {
-    hllc(gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, fd, fx, fy, fz, fe);
+    riemann_hyd<RS>(eos.gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, fd, fx, fy, fz, fe);
     fby = fbz = 0.0;
   }
 }
@@ -97,6 +98,9 @@ template <int RECON> struct RollCfg;
 template <> struct RollCfg<0> { static constexpr int NW = 1; };   // dc
 template <> struct RollCfg<1> { static constexpr int NW = 2; };   // plm
 template <> struct RollCfg<2> { static constexpr int NW = 4; };   // ppm4
+template <> struct RollCfg<3> { static constexpr int NW = 4; };   // ppmx
+template <> struct RollCfg<4> { static constexpr int NW = 4; };   // wenoz
+template <> struct RollCfg<5> { static constexpr int NW = 4; };   // teno
 
 struct SweepArgs {
   const double *w0, *bcc0, *bxf;
@@ -109,9 +113,9 @@ struct SweepArgs {
 // plain sweep (not the last direction): thread per face.  ECC: also emit e_cc for the right
 // cell of every face and for the extra column i = il-1 (mhd_corner_e.cpp:309-317 range
 // [is-1,ie+1] x [js-1,je+1] x [ks-1,ke+1] == the CT-extended x1 sweep, right cells).
-template <int DIR, int RECON, bool MHD, bool ECC>
+template <int DIR, int RECON, bool MHD, bool ECC, int RS>
 __global__ void __launch_bounds__(SX*SY)
-k_sweep(Geo g, double gamma, SweepArgs a, int nk) {
+k_sweep(Geo g, FaceEos eos, SweepArgs a, int nk) {
   // lanes run over the flattened rows [jl,ju] x [0,N1): contiguous in memory, and the few
   // ghost columns outside [il,iu] cost 2-4 idle lanes per 260 instead of a mostly empty wave
   const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;
@@ -135,8 +139,8 @@ k_sweep(Geo g, double gamma, SweepArgs a, int nk) {
   }
   constexpr int ivx = 1 + DIR, ivy = 1 + (DIR + 1)%3, ivz = 1 + (DIR + 2)%3;
   double fd, fx, fy, fz, fe, fby, fbz;
-  face_flux<DIR, RECON, MHD>(g, gamma, a.w0, a.bcc0, a.bxf, a.f3, a.f2, a.f1, m, k, j, i, fd, fx,
-                             fy, fz, fe, fby, fbz);
+  face_flux<DIR, RECON, MHD, RS>(g, eos, a.w0, a.bcc0, a.bxf, a.f3, a.f2, a.f1, m, k, j, i, fd,
+                                 fx, fy, fz, fe, fby, fbz);
   const size_t fs = (size_t)a.f3*a.f2*a.f1;
   double *f = a.flx + ix5(g.nvar, a.f3, a.f2, a.f1, m, 0, k, j, i);
   f[0] = fd; f[ivx*fs] = fx; f[ivy*fs] = fy; f[ivz*fs] = fz; f[4*fs] = fe;
@@ -174,9 +178,9 @@ constexpr int ML = AKMI_ML;            // faces marched per thread (chunk length
 // MODE 0: last direction -- finish the RK update.  MODE 1 (x2 sweep of 3-D runs): store the
 // partial divergence acc = dF1/dx1 + dF2/dx2 for the x3 march, which then needs one array
 // instead of two face pairs per variable (USEACC).  Rounding sequence unchanged.
-template <int DIR, int RECON, bool MHD, int MODE, bool USEACC>
-__global__ void __launch_bounds__(SX*SY, (RECON == 2 ? 2 : 3))
-k_sweep_update(Geo g, double gamma, SweepArgs a, UpdArgs u, int nouter) {
+template <int DIR, int RECON, bool MHD, int MODE, bool USEACC, int RS>
+__global__ void __launch_bounds__(SX*SY, (RECON >= 2 ? 2 : 3))
+k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int nouter) {
   static_assert(DIR == 1 || DIR == 2, "marching kernel is for the x2/x3 sweeps");
   int i, j, k, m, s0;
   bool lane_ok;
@@ -241,9 +245,11 @@ k_sweep_update(Geo g, double gamma, SweepArgs a, UpdArgs u, int nouter) {
       const double qa = q[-2*st], qb = q[-st], qc = q[0];
       plm(qa, qb, qc, pl, dummy);
       W_(n, 0) = qb; W_(n, 1) = qc;
-    } else if constexpr (RECON == 2) {
+    } else if constexpr (RECON >= 2) {
       const double qa = q[-3*st], qb = q[-2*st], qc = q[-st], qd = q[0], qe = q[st];
-      ppm4(qa, qb, qc, qd, qe, pl, dummy);
+      recon5<RECON>(qa, qb, qc, qd, qe, pl, dummy);
+      if (n == 0) floor_lr<RECON, 1>(eos, pl, dummy);
+      if (n == 4) floor_lr<RECON, 2>(eos, pl, dummy);
       W_(n, 0) = qb; W_(n, 1) = qc; W_(n, 2) = qd; W_(n, 3) = qe;
     } else {
       pl = q[-st];
@@ -268,10 +274,12 @@ k_sweep_update(Geo g, double gamma, SweepArgs a, UpdArgs u, int nouter) {
         const double w0 = W_(n, 0), w1 = W_(n, 1);
         plm(w0, w1, qp, qln, R[n]);
         W_(n, 0) = w1; W_(n, 1) = qp;
-      } else if constexpr (RECON == 2) {
+      } else if constexpr (RECON >= 2) {
         const double qp = q[2*st];
         const double w0 = W_(n, 0), w1 = W_(n, 1), w2 = W_(n, 2), w3 = W_(n, 3);
-        ppm4(w0, w1, w2, w3, qp, qln, R[n]);
+        recon5<RECON>(w0, w1, w2, w3, qp, qln, R[n]);
+        if (n == 0) floor_lr<RECON, 1>(eos, qln, R[n]);
+        if (n == 4) floor_lr<RECON, 2>(eos, qln, R[n]);
         W_(n, 0) = w1; W_(n, 1) = w2; W_(n, 2) = w3; W_(n, 3) = qp;
       } else {
         const double w0 = W_(n, 0);
@@ -284,8 +292,8 @@ k_sweep_update(Geo g, double gamma, SweepArgs a, UpdArgs u, int nouter) {
     off += st;
     double fd, fx, fy, fz, fe;
     if constexpr (MHD) {
-      Cons1D fl = hlld(gamma, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1], R[2], R[3], R[4],
-                       R[5], R[6], pbx[(size_t)t*fst]);
+      Cons1D fl = riemann_mhd<RS>(eos.gamma, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1],
+                                  R[2], R[3], R[4], R[5], R[6], pbx[(size_t)t*fst]);
       fd = fl.d; fx = fl.mx; fy = fl.my; fz = fl.mz; fe = fl.e;
       if (t < ML || s == shi) {
         // CornerE needs the sign of the mass flux and the two face EMFs of this direction
@@ -295,7 +303,8 @@ k_sweep_update(Geo g, double gamma, SweepArgs a, UpdArgs u, int nouter) {
         a.ez[ec] = fl.bz;
       }
     } else {
-      hllc(gamma, L[0], L[1], L[2], L[3], L[4], R[0], R[1], R[2], R[3], R[4], fd, fx, fy, fz, fe);
+      riemann_hyd<RS>(eos.gamma, L[0], L[1], L[2], L[3], L[4], R[0], R[1], R[2], R[3], R[4], fd, fx,
+                      fy, fz, fe);
     }
     double fv[5];
     fv[0] = fd; fv[ivx] = fx; fv[ivy] = fy; fv[ivz] = fz; fv[4] = fe;
@@ -341,17 +350,17 @@ k_sweep_update(Geo g, double gamma, SweepArgs a, UpdArgs u, int nouter) {
 
 // 1-D problems: the sweep direction is the lane direction, so neighbouring faces are
 // exchanged through LDS inside a TX-wide tile (overlap of one face between tiles).
-template <int RECON, bool MHD>
+template <int RECON, bool MHD, int RS>
 __global__ void __launch_bounds__(TX)
-k_sweep_update_1d(Geo g, double gamma, SweepArgs a, UpdArgs u) {
+k_sweep_update_1d(Geo g, FaceEos eos, SweepArgs a, UpdArgs u) {
   __shared__ double sF[5][TX];
   const int i = a.il + blockIdx.x*(TX - 1) + threadIdx.x;
   const int j = a.jl, k = a.kl, m = blockIdx.z;
   const bool face_ok = (i <= a.iu);
   double fd = 0, fx = 0, fy = 0, fz = 0, fe = 0, fby = 0, fbz = 0;
   if (face_ok) {
-    face_flux<0, RECON, MHD>(g, gamma, a.w0, a.bcc0, a.bxf, a.f3, a.f2, a.f1, m, k, j, i, fd, fx, fy,
-                             fz, fe, fby, fbz);
+    face_flux<0, RECON, MHD, RS>(g, eos, a.w0, a.bcc0, a.bxf, a.f3, a.f2, a.f1, m, k, j, i, fd, fx,
+                                 fy, fz, fe, fby, fbz);
     if constexpr (MHD) {
       a.flx[ix5(g.nvar, a.f3, a.f2, a.f1, m, 0, k, j, i)] = fd;
       const size_t ec = ix4(g.N3, g.N2, g.N1, m, k, j, i);
@@ -589,25 +598,31 @@ __global__ void k_init_dt3(double *dt3) {
 
 // ---------------------------------------------------------------------------------------
 template <int DIR, bool MHD, bool ECC>
-static int launch_sweep(const Geo &g, double gamma, int recon, const SweepArgs &a, hipStream_t st) {
+static int launch_sweep(const Geo &g, const Scheme &sc, const SweepArgs &a, hipStream_t st) {
   int nk = a.ku - a.kl + 1;
   long np = (long)(a.ju - a.jl + 1)*g.N1;
   dim3 grid((unsigned)((np + SX*SY - 1)/(SX*SY)), 1, nk*g.nmb), block(SX, SY);
-  if (recon == AKMI_RECON_PLM) k_sweep<DIR, 1, MHD, ECC><<<grid, block, 0, st>>>(g, gamma, a, nk);
-  else if (recon == AKMI_RECON_PPM4) k_sweep<DIR, 2, MHD, ECC><<<grid, block, 0, st>>>(g, gamma, a, nk);
-  else k_sweep<DIR, 0, MHD, ECC><<<grid, block, 0, st>>>(g, gamma, a, nk);
+  int rc = dispatch_scheme<MHD>(sc, [&](auto R, auto S) {
+    k_sweep<DIR, decltype(R)::value, MHD, ECC, decltype(S)::value><<<grid, block, 0, st>>>(
+        g, sc.eos, a, nk);
+    return AKMI_COMPLETE;
+  });
+  if (rc != AKMI_COMPLETE) return rc;
   AKMI_CHECK_LAUNCH("sweep");
   return AKMI_COMPLETE;
 }
 
 template <int DIR, bool MHD, int MODE = 0, bool USEACC = false>
-static int launch_sweep_update(const Geo &g, double gamma, int recon, const SweepArgs &a,
+static int launch_sweep_update(const Geo &g, const Scheme &sc, const SweepArgs &a,
                                const UpdArgs &u, hipStream_t st) {
+  int rc;
   if constexpr (DIR == 0) {
     dim3 grid(cdiv(a.iu - a.il + 1, TX - 1), 1, g.nmb), block(TX, 1);
-    if (recon == AKMI_RECON_PLM) k_sweep_update_1d<1, MHD><<<grid, block, 0, st>>>(g, gamma, a, u);
-    else if (recon == AKMI_RECON_PPM4) k_sweep_update_1d<2, MHD><<<grid, block, 0, st>>>(g, gamma, a, u);
-    else k_sweep_update_1d<0, MHD><<<grid, block, 0, st>>>(g, gamma, a, u);
+    rc = dispatch_scheme<MHD>(sc, [&](auto R, auto S) {
+      k_sweep_update_1d<decltype(R)::value, MHD, decltype(S)::value><<<grid, block, 0, st>>>(
+          g, sc.eos, a, u);
+      return AKMI_COMPLETE;
+    });
   } else {
     dim3 grid, block(SX, SY);
     if (DIR == 2) {
@@ -618,10 +633,13 @@ static int launch_sweep_update(const Geo &g, double gamma, int recon, const Swee
       grid = dim3((unsigned)((np + SX*SY - 1)/(SX*SY)), cdiv(a.ju - a.jl > 0 ? a.ju - a.jl : 1, ML), g.nmb);
     }
     constexpr int D = (DIR == 0) ? 1 : DIR;
-    if (recon == AKMI_RECON_PLM) k_sweep_update<D, 1, MHD, MODE, USEACC><<<grid, block, 0, st>>>(g, gamma, a, u, 1);
-    else if (recon == AKMI_RECON_PPM4) k_sweep_update<D, 2, MHD, MODE, USEACC><<<grid, block, 0, st>>>(g, gamma, a, u, 1);
-    else k_sweep_update<D, 0, MHD, MODE, USEACC><<<grid, block, 0, st>>>(g, gamma, a, u, 1);
+    rc = dispatch_scheme<MHD>(sc, [&](auto R, auto S) {
+      k_sweep_update<D, decltype(R)::value, MHD, MODE, USEACC, decltype(S)::value>
+          <<<grid, block, 0, st>>>(g, sc.eos, a, u, 1);
+      return AKMI_COMPLETE;
+    });
   }
+  if (rc != AKMI_COMPLETE) return rc;
   AKMI_CHECK_LAUNCH("sweep_update");
   return AKMI_COMPLETE;
 }
@@ -755,13 +773,16 @@ struct C2PArgs {          // interior c2p (+CFL scan) folded into the slab pipel
 //    CornerE(s) after sweeps(s);  CT(s) after sweeps(s-1), sweeps(s+1);
 //    c2p(s) after CT(s), CT(s+1), sweeps(s-1), sweeps(s+1).
 template <bool MHD>
-static int stage_update(const akmi_pack *p, int recon, double gam0, double gam1, double beta_dt,
+static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1,
+                        double beta_dt,
                         int copy_u1, const double *w0, const double *bcc0, double *u0, double *u1,
                         double *b0x1f, double *b0x2f, double *b0x3f, double *b1x1f, double *b1x2f,
                         double *b1x3f, void *ws, const C2PArgs &cp_in, hipStream_t st,
                         int phases = AKMI_PHASE_ALL) {
+  if (check_scheme(p, recon, "stage") != AKMI_COMPLETE) return AKMI_FAIL;
   Geo g = make_geo(p);
   Eos eos = make_eos(p);
+  const Scheme sc{recon, rsolver, make_face_eos(p)};
   StageWs w = carve(g, MHD ? 1 : 0, ws);
   // phases: a caller that exchanges halos between the parts of a stage (multi-rank runs) asks
   // for them one at a time; the parts communicate through u0/b0 and the workspace only
@@ -792,11 +813,11 @@ static int stage_update(const akmi_pack *p, int recon, double gam0, double gam1,
     // 1-D / 2-D: small problems, plain sequence on the caller's stream
     if (!do_sweeps) {
     } else if (ndim == 1) {
-      rc = launch_sweep_update<0, MHD>(g, p->gamma, recon, a1, u, st);
+      rc = launch_sweep_update<0, MHD>(g, sc, a1, u, st);
     } else {
-      rc = MHD ? launch_sweep<0, MHD, MHD>(g, p->gamma, recon, a1, st)
-               : launch_sweep<0, MHD, false>(g, p->gamma, recon, a1, st);
-      if (rc == AKMI_COMPLETE) rc = launch_sweep_update<1, MHD>(g, p->gamma, recon, a2, u, st);
+      rc = MHD ? launch_sweep<0, MHD, MHD>(g, sc, a1, st)
+               : launch_sweep<0, MHD, false>(g, sc, a1, st);
+      if (rc == AKMI_COMPLETE) rc = launch_sweep_update<1, MHD>(g, sc, a2, u, st);
     }
     if (rc != AKMI_COMPLETE) return rc;
     if (do_emf) {
@@ -867,15 +888,15 @@ static int stage_update(const akmi_pack *p, int recon, double gam0, double gam1,
     b2.kl = b1.kl; b2.ku = b1.ku;
     b3.kl = kA(s); b3.ku = kB(s) + 1;
     if (do_sweeps) {
-    rc = MHD ? launch_sweep<0, MHD, MHD>(g, p->gamma, recon, b1, st)
-             : launch_sweep<0, MHD, false>(g, p->gamma, recon, b1, st);
+    rc = MHD ? launch_sweep<0, MHD, MHD>(g, sc, b1, st)
+             : launch_sweep<0, MHD, false>(g, sc, b1, st);
 #if AKMI_X2_MARCH
     // x2 sweep as a march along j that leaves acc = dF1/dx1 + dF2/dx2; x3 march consumes it
-    if (rc == AKMI_COMPLETE) rc = launch_sweep_update<1, MHD, 1, false>(g, p->gamma, recon, b2, u, st);
-    if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD, 0, true>(g, p->gamma, recon, b3, u, st);
+    if (rc == AKMI_COMPLETE) rc = launch_sweep_update<1, MHD, 1, false>(g, sc, b2, u, st);
+    if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD, 0, true>(g, sc, b3, u, st);
 #else
-    if (rc == AKMI_COMPLETE) rc = launch_sweep<1, MHD, false>(g, p->gamma, recon, b2, st);
-    if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD>(g, p->gamma, recon, b3, u, st);
+    if (rc == AKMI_COMPLETE) rc = launch_sweep<1, MHD, false>(g, sc, b2, st);
+    if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD>(g, sc, b3, u, st);
 #endif
     }
     if (rc != AKMI_COMPLETE) return rc;
@@ -924,10 +945,8 @@ long long akmi_stage_workspace_bytes(const akmi_pack *p, int is_mhd) {
 int akmi_hydro_stage_update(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1,
                             double beta_dt, int copy_u1, const double *w0, double *u0, double *u1,
                             void *ws, void *stream) {
-  if (rsolver != AKMI_RS_HLLC) { set_error("hydro_stage_update: only rsolver=hllc is implemented"); return AKMI_FAIL; }
-  if (recon == AKMI_RECON_PPM4 && p->ng < 3) { set_error("ppm4 needs nghost>=3"); return AKMI_FAIL; }
   C2PArgs cp{0, 0, nullptr, nullptr};
-  return stage_update<false>(p, recon, gam0, gam1, beta_dt, copy_u1, w0, nullptr, u0, u1, nullptr,
+  return stage_update<false>(p, recon, rsolver, gam0, gam1, beta_dt, copy_u1, w0, nullptr, u0, u1, nullptr,
                              nullptr, nullptr, nullptr, nullptr, nullptr, ws, cp, (hipStream_t)stream);
 }
 
@@ -935,10 +954,8 @@ int akmi_mhd_stage_update(const akmi_pack *p, int recon, int rsolver, double gam
                           double beta_dt, int copy_u1, const double *w0, const double *bcc0,
                           double *u0, double *u1, double *b0x1f, double *b0x2f, double *b0x3f,
                           double *b1x1f, double *b1x2f, double *b1x3f, void *ws, void *stream) {
-  if (rsolver != AKMI_RS_HLLD) { set_error("mhd_stage_update: only rsolver=hlld is implemented"); return AKMI_FAIL; }
-  if (recon == AKMI_RECON_PPM4 && p->ng < 3) { set_error("ppm4 needs nghost>=3"); return AKMI_FAIL; }
   C2PArgs cp{0, 0, nullptr, nullptr};
-  return stage_update<true>(p, recon, gam0, gam1, beta_dt, copy_u1, w0, bcc0, u0, u1, b0x1f, b0x2f,
+  return stage_update<true>(p, recon, rsolver, gam0, gam1, beta_dt, copy_u1, w0, bcc0, u0, u1, b0x1f, b0x2f,
                             b0x3f, b1x1f, b1x2f, b1x3f, ws, cp, (hipStream_t)stream);
 }
 
@@ -964,10 +981,8 @@ int akmi_mhd_c2p_newdt(const akmi_pack *p, double *u0, const double *bx1f, const
 int akmi_hydro_stage_fused(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1,
                            double beta_dt, int copy_u1, double *w0, double *u0, double *u1,
                            int do_newdt, int *counters, double *dt3, void *ws, void *stream) {
-  if (rsolver != AKMI_RS_HLLC) { set_error("hydro_stage_fused: only rsolver=hllc is implemented"); return AKMI_FAIL; }
-  if (recon == AKMI_RECON_PPM4 && p->ng < 3) { set_error("ppm4 needs nghost>=3"); return AKMI_FAIL; }
   C2PArgs cp{1, do_newdt, counters, dt3};
-  return stage_update<false>(p, recon, gam0, gam1, beta_dt, copy_u1, w0, nullptr, u0, u1, nullptr,
+  return stage_update<false>(p, recon, rsolver, gam0, gam1, beta_dt, copy_u1, w0, nullptr, u0, u1, nullptr,
                              nullptr, nullptr, nullptr, nullptr, nullptr, ws, cp, (hipStream_t)stream);
 }
 
@@ -976,10 +991,8 @@ int akmi_mhd_stage_fused(const akmi_pack *p, int recon, int rsolver, double gam0
                          double *b0x1f, double *b0x2f, double *b0x3f, double *b1x1f, double *b1x2f,
                          double *b1x3f, int do_newdt, int *counters, double *dt3, void *ws,
                          void *stream) {
-  if (rsolver != AKMI_RS_HLLD) { set_error("mhd_stage_fused: only rsolver=hlld is implemented"); return AKMI_FAIL; }
-  if (recon == AKMI_RECON_PPM4 && p->ng < 3) { set_error("ppm4 needs nghost>=3"); return AKMI_FAIL; }
   C2PArgs cp{1, do_newdt, counters, dt3};
-  return stage_update<true>(p, recon, gam0, gam1, beta_dt, copy_u1, w0, bcc0, u0, u1, b0x1f, b0x2f,
+  return stage_update<true>(p, recon, rsolver, gam0, gam1, beta_dt, copy_u1, w0, bcc0, u0, u1, b0x1f, b0x2f,
                             b0x3f, b1x1f, b1x2f, b1x3f, ws, cp, (hipStream_t)stream);
 }
 
@@ -987,11 +1000,9 @@ int akmi_hydro_stage_phase(const akmi_pack *p, int recon, int rsolver, double ga
                            double beta_dt, int copy_u1, double *w0, double *u0, double *u1,
                            int do_newdt, int *counters, double *dt3, int phases, void *ws,
                            void *stream) {
-  if (rsolver != AKMI_RS_HLLC) { set_error("hydro_stage_phase: only rsolver=hllc is implemented"); return AKMI_FAIL; }
-  if (recon == AKMI_RECON_PPM4 && p->ng < 3) { set_error("ppm4 needs nghost>=3"); return AKMI_FAIL; }
   if (phases <= 0 || phases > AKMI_PHASE_ALL) { set_error("stage_phase: bad phase mask"); return AKMI_FAIL; }
   C2PArgs cp{1, do_newdt, counters, dt3};
-  return stage_update<false>(p, recon, gam0, gam1, beta_dt, copy_u1, w0, nullptr, u0, u1, nullptr,
+  return stage_update<false>(p, recon, rsolver, gam0, gam1, beta_dt, copy_u1, w0, nullptr, u0, u1, nullptr,
                              nullptr, nullptr, nullptr, nullptr, nullptr, ws, cp,
                              (hipStream_t)stream, phases);
 }
@@ -1001,11 +1012,9 @@ int akmi_mhd_stage_phase(const akmi_pack *p, int recon, int rsolver, double gam0
                          double *b0x1f, double *b0x2f, double *b0x3f, double *b1x1f, double *b1x2f,
                          double *b1x3f, int do_newdt, int *counters, double *dt3, int phases,
                          void *ws, void *stream) {
-  if (rsolver != AKMI_RS_HLLD) { set_error("mhd_stage_phase: only rsolver=hlld is implemented"); return AKMI_FAIL; }
-  if (recon == AKMI_RECON_PPM4 && p->ng < 3) { set_error("ppm4 needs nghost>=3"); return AKMI_FAIL; }
   if (phases <= 0 || phases > AKMI_PHASE_ALL) { set_error("stage_phase: bad phase mask"); return AKMI_FAIL; }
   C2PArgs cp{1, do_newdt, counters, dt3};
-  return stage_update<true>(p, recon, gam0, gam1, beta_dt, copy_u1, w0, bcc0, u0, u1, b0x1f, b0x2f,
+  return stage_update<true>(p, recon, rsolver, gam0, gam1, beta_dt, copy_u1, w0, bcc0, u0, u1, b0x1f, b0x2f,
                             b0x3f, b1x1f, b1x2f, b1x3f, ws, cp, (hipStream_t)stream, phases);
 }
 

@@ -22,10 +22,10 @@ void set_error(const char *fmt, ...) {
 constexpr int BX = 64, BY = 4;
 
 // ---------------------------------------------------------------------------------------
-// Hydro fluxes: reconstruct in registers + HLLC.  hydro_fluxes.cpp:77-229.
-template <int DIR, int RECON>
+// Hydro fluxes: reconstruct in registers + Riemann solver RS.  hydro_fluxes.cpp:77-229.
+template <int DIR, int RECON, int RS>
 __global__ void __launch_bounds__(BX*BY)
-k_hydro_flux(Geo g, double gamma, const double *__restrict__ w0, double *__restrict__ flx,
+k_hydro_flux(Geo g, FaceEos eos, const double *__restrict__ w0, double *__restrict__ flx,
              int f3, int f2, int f1, int il, int iu, int jl, int ju, int kl, int nk) {
   const int i = il + blockIdx.x*BX + threadIdx.x;
   const int j = jl + blockIdx.y*BY + threadIdx.y;
@@ -37,20 +37,20 @@ k_hydro_flux(Geo g, double gamma, const double *__restrict__ w0, double *__restr
   const size_t cs = (size_t)g.N3*g.N2*g.N1;   // variable stride
   const double *q = w0 + ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
   double ld, lx, ly, lz, le, rd, rx, ry, rz, re;
-  face_states<RECON>(q + 0*cs, s, ld, rd);
-  face_states<RECON>(q + ivx*cs, s, lx, rx);
-  face_states<RECON>(q + ivy*cs, s, ly, ry);
-  face_states<RECON>(q + ivz*cs, s, lz, rz);
-  face_states<RECON>(q + 4*cs, s, le, re);
+  face_states<RECON, 1>(q + 0*cs, s, eos, ld, rd);
+  face_states<RECON, 0>(q + ivx*cs, s, eos, lx, rx);
+  face_states<RECON, 0>(q + ivy*cs, s, eos, ly, ry);
+  face_states<RECON, 0>(q + ivz*cs, s, eos, lz, rz);
+  face_states<RECON, 2>(q + 4*cs, s, eos, le, re);
   double fd, fx, fy, fz, fe;
-  hllc(gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, fd, fx, fy, fz, fe);
+  riemann_hyd<RS>(eos.gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, fd, fx, fy, fz, fe);
   const size_t fs = (size_t)f3*f2*f1;
   double *f = flx + ix5(g.nvar, f3, f2, f1, m, 0, k, j, i);
   f[0] = fd; f[ivx*fs] = fx; f[ivy*fs] = fy; f[ivz*fs] = fz; f[4*fs] = fe;
 }
 
 template <int DIR>
-static int launch_hydro_flux(const Geo &g, double gamma, int recon, const double *w0,
+static int launch_hydro_flux(const Geo &g, const Scheme &sc, const double *w0,
                              double *flx, int fsh, hipStream_t st) {
   int il = g.is, iu = g.ie, jl = g.js, ju = g.je, kl = g.ks, ku = g.ke;
   int f3 = g.N3, f2 = g.N2, f1 = g.N1;
@@ -59,12 +59,12 @@ static int launch_hydro_flux(const Geo &g, double gamma, int recon, const double
   if (DIR == 2) { ku = g.ke + 1; f3 += fsh; }
   int nk = ku - kl + 1;
   dim3 grid(cdiv(iu - il + 1, BX), cdiv(ju - jl + 1, BY), nk*g.nmb), block(BX, BY);
-  if (recon == AKMI_RECON_PLM)
-    k_hydro_flux<DIR, 1><<<grid, block, 0, st>>>(g, gamma, w0, flx, f3, f2, f1, il, iu, jl, ju, kl, nk);
-  else if (recon == AKMI_RECON_PPM4)
-    k_hydro_flux<DIR, 2><<<grid, block, 0, st>>>(g, gamma, w0, flx, f3, f2, f1, il, iu, jl, ju, kl, nk);
-  else
-    k_hydro_flux<DIR, 0><<<grid, block, 0, st>>>(g, gamma, w0, flx, f3, f2, f1, il, iu, jl, ju, kl, nk);
+  int rc = dispatch_scheme<false>(sc, [&](auto R, auto S) {
+    k_hydro_flux<DIR, decltype(R)::value, decltype(S)::value><<<grid, block, 0, st>>>(
+        g, sc.eos, w0, flx, f3, f2, f1, il, iu, jl, ju, kl, nk);
+    return AKMI_COMPLETE;
+  });
+  if (rc != AKMI_COMPLETE) return rc;
   AKMI_CHECK_LAUNCH("hydro_flux");
   return AKMI_COMPLETE;
 }
@@ -199,10 +199,10 @@ __global__ void k_init_dt(double *dt3) {
 }
 
 // ---------------------------------------------------------------------------------------
-// MHD fluxes: reconstruct w0 and bcc0 in registers + HLLD.  mhd_fluxes.cpp:84-266.
-template <int DIR, int RECON>
+// MHD fluxes: reconstruct w0 and bcc0 in registers + Riemann solver RS.  mhd_fluxes.cpp:84-266.
+template <int DIR, int RECON, int RS>
 __global__ void __launch_bounds__(BX*BY)
-k_mhd_flux(Geo g, double gamma, const double *__restrict__ w0, const double *__restrict__ bcc0,
+k_mhd_flux(Geo g, FaceEos eos, const double *__restrict__ w0, const double *__restrict__ bcc0,
            const double *__restrict__ bxf, double *__restrict__ flx, double *__restrict__ ey,
            double *__restrict__ ez, int f3, int f2, int f1, int il, int iu, int jl, int ju,
            int kl, int nk) {
@@ -218,15 +218,16 @@ k_mhd_flux(Geo g, double gamma, const double *__restrict__ w0, const double *__r
   const double *q = w0 + ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
   const double *b = bcc0 + ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i);
   double ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz;
-  face_states<RECON>(q + 0*cs, s, ld, rd);
-  face_states<RECON>(q + ivx*cs, s, lx, rx);
-  face_states<RECON>(q + ivy*cs, s, ly, ry);
-  face_states<RECON>(q + ivz*cs, s, lz, rz);
-  face_states<RECON>(q + 4*cs, s, le, re);
-  face_states<RECON>(b + iby*cs, s, lby, rby);
-  face_states<RECON>(b + ibz*cs, s, lbz, rbz);
+  face_states<RECON, 1>(q + 0*cs, s, eos, ld, rd);
+  face_states<RECON, 0>(q + ivx*cs, s, eos, lx, rx);
+  face_states<RECON, 0>(q + ivy*cs, s, eos, ly, ry);
+  face_states<RECON, 0>(q + ivz*cs, s, eos, lz, rz);
+  face_states<RECON, 2>(q + 4*cs, s, eos, le, re);
+  face_states<RECON, 0>(b + iby*cs, s, eos, lby, rby);
+  face_states<RECON, 0>(b + ibz*cs, s, eos, lbz, rbz);
   const double bxi = bxf[ix4(f3, f2, f1, m, k, j, i)];
-  Cons1D fl = hlld(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
+  Cons1D fl = riemann_mhd<RS>(eos.gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby,
+                              rbz, bxi);
   const size_t fs = (size_t)f3*f2*f1;
   double *f = flx + ix5(g.nvar, f3, f2, f1, m, 0, k, j, i);
   f[0] = fl.d; f[ivx*fs] = fl.mx; f[ivy*fs] = fl.my; f[ivz*fs] = fl.mz; f[4*fs] = fl.e;
@@ -236,7 +237,7 @@ k_mhd_flux(Geo g, double gamma, const double *__restrict__ w0, const double *__r
 }
 
 template <int DIR>
-static int launch_mhd_flux(const Geo &g, double gamma, int recon, const double *w0,
+static int launch_mhd_flux(const Geo &g, const Scheme &sc, const double *w0,
                            const double *bcc0, const double *bxf, double *flx, double *ey,
                            double *ez, hipStream_t st) {
   int il, iu, jl, ju, kl, ku;
@@ -256,12 +257,12 @@ static int launch_mhd_flux(const Geo &g, double gamma, int recon, const double *
   }
   int nk = ku - kl + 1;
   dim3 grid(cdiv(iu - il + 1, BX), cdiv(ju - jl + 1, BY), nk*g.nmb), block(BX, BY);
-  if (recon == AKMI_RECON_PLM)
-    k_mhd_flux<DIR, 1><<<grid, block, 0, st>>>(g, gamma, w0, bcc0, bxf, flx, ey, ez, f3, f2, f1, il, iu, jl, ju, kl, nk);
-  else if (recon == AKMI_RECON_PPM4)
-    k_mhd_flux<DIR, 2><<<grid, block, 0, st>>>(g, gamma, w0, bcc0, bxf, flx, ey, ez, f3, f2, f1, il, iu, jl, ju, kl, nk);
-  else
-    k_mhd_flux<DIR, 0><<<grid, block, 0, st>>>(g, gamma, w0, bcc0, bxf, flx, ey, ez, f3, f2, f1, il, iu, jl, ju, kl, nk);
+  int rc = dispatch_scheme<true>(sc, [&](auto R, auto S) {
+    k_mhd_flux<DIR, decltype(R)::value, decltype(S)::value><<<grid, block, 0, st>>>(
+        g, sc.eos, w0, bcc0, bxf, flx, ey, ez, f3, f2, f1, il, iu, jl, ju, kl, nk);
+    return AKMI_COMPLETE;
+  });
+  if (rc != AKMI_COMPLETE) return rc;
   AKMI_CHECK_LAUNCH("mhd_flux");
   return AKMI_COMPLETE;
 }
@@ -456,14 +457,14 @@ int akmi_copy_cons(const akmi_pack *p, const double *u0, double *u1, void *strea
 int akmi_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
                       double *flx1, double *flx2, double *flx3, int face_shaped,
                       void *stream) {
-  if (rsolver != AKMI_RS_HLLC) { set_error("hydro_fluxes: only rsolver=hllc is implemented"); return AKMI_FAIL; }
-  if (recon == AKMI_RECON_PPM4 && p->ng < 3) { set_error("ppm4 needs nghost>=3"); return AKMI_FAIL; }
+  if (check_scheme(p, recon, "hydro_fluxes") != AKMI_COMPLETE) return AKMI_FAIL;
   Geo g = make_geo(p);
+  const Scheme sc{recon, rsolver, make_face_eos(p)};
   hipStream_t st = (hipStream_t)stream;
   int fsh = face_shaped ? 1 : 0;
-  int rc = launch_hydro_flux<0>(g, p->gamma, recon, w0, flx1, fsh, st);
-  if (rc == AKMI_COMPLETE && g.multi_d) rc = launch_hydro_flux<1>(g, p->gamma, recon, w0, flx2, fsh, st);
-  if (rc == AKMI_COMPLETE && g.three_d) rc = launch_hydro_flux<2>(g, p->gamma, recon, w0, flx3, fsh, st);
+  int rc = launch_hydro_flux<0>(g, sc, w0, flx1, fsh, st);
+  if (rc == AKMI_COMPLETE && g.multi_d) rc = launch_hydro_flux<1>(g, sc, w0, flx2, fsh, st);
+  if (rc == AKMI_COMPLETE && g.three_d) rc = launch_hydro_flux<2>(g, sc, w0, flx3, fsh, st);
   return rc;
 }
 
@@ -527,15 +528,15 @@ int akmi_mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0
                     const double *bx3f, double *flx1, double *flx2, double *flx3, double *e3x1,
                     double *e2x1, double *e1x2, double *e3x2, double *e2x3, double *e1x3,
                     void *stream) {
-  if (rsolver != AKMI_RS_HLLD) { set_error("mhd_fluxes: only rsolver=hlld is implemented"); return AKMI_FAIL; }
-  if (recon == AKMI_RECON_PPM4 && p->ng < 3) { set_error("ppm4 needs nghost>=3"); return AKMI_FAIL; }
+  if (check_scheme(p, recon, "mhd_fluxes") != AKMI_COMPLETE) return AKMI_FAIL;
   Geo g = make_geo(p);
+  const Scheme sc{recon, rsolver, make_face_eos(p)};
   hipStream_t st = (hipStream_t)stream;
-  int rc = launch_mhd_flux<0>(g, p->gamma, recon, w0, bcc0, bx1f, flx1, e3x1, e2x1, st);
+  int rc = launch_mhd_flux<0>(g, sc, w0, bcc0, bx1f, flx1, e3x1, e2x1, st);
   if (rc == AKMI_COMPLETE && g.multi_d)
-    rc = launch_mhd_flux<1>(g, p->gamma, recon, w0, bcc0, bx2f, flx2, e1x2, e3x2, st);
+    rc = launch_mhd_flux<1>(g, sc, w0, bcc0, bx2f, flx2, e1x2, e3x2, st);
   if (rc == AKMI_COMPLETE && g.three_d)
-    rc = launch_mhd_flux<2>(g, p->gamma, recon, w0, bcc0, bx3f, flx3, e2x3, e1x3, st);
+    rc = launch_mhd_flux<2>(g, sc, w0, bcc0, bx3f, flx3, e2x3, e1x3, st);
   return rc;
 }
 

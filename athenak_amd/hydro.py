@@ -75,7 +75,7 @@ class FluidBase:
         if recon not in capi.RECON:
             raise RuntimeError("### FATAL ERROR <%s> recon = '%s' not implemented" % (blk, recon))
         self.recon_method = capi.RECON[recon]
-        if recon == "ppm4" and indcs.ng < 3:
+        if recon in ("ppm4", "ppmx", "wenoz", "teno") and indcs.ng < 3:       # hydro.cpp:173-179
             raise RuntimeError("### FATAL ERROR PPM/WENOZ reconstruction requires at least 3 "
                                "ghost zones, but <mesh>/nghost=%d" % indcs.ng)
         self.nscalars = pin.GetOrAddInteger(blk, "nscalars", 0)
@@ -116,9 +116,9 @@ class Hydro(FluidBase):
         device = device or capi.DEVICE
         self._setup(ppack, pin, "hydro", device)
         rs = pin.GetString("hydro", "rsolver")
-        if rs != "hllc":
+        if rs not in ("llf", "hlle", "hllc", "roe"):            # hydro.cpp: Hydro_RSolver
             raise RuntimeError("### FATAL ERROR <hydro> rsolver = '%s' not implemented "
-                               "(hllc only on this path)" % rs)
+                               "(llf, hlle, hllc, roe on this path)" % rs)
         self.rsolver_method = capi.RSOLVER[rs]
         self.nhydro = 5
         n3, n2, n1 = ppack.pmesh.mb_indcs.ncells

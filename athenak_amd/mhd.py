@@ -19,9 +19,9 @@ class MHD(FluidBase):
         device = device or capi.DEVICE
         self._setup(ppack, pin, "mhd", device)
         rs = pin.GetString("mhd", "rsolver")
-        if rs != "hlld":
+        if rs not in ("llf", "hlle", "hlld"):                   # mhd.cpp: MHD_RSolver
             raise RuntimeError("### FATAL ERROR <mhd> rsolver = '%s' not implemented "
-                               "(hlld only on this path)" % rs)
+                               "(llf, hlle, hlld on this path)" % rs)
         self.rsolver_method = capi.RSOLVER[rs]
         self.nmhd = 5
         n3, n2, n1 = ppack.pmesh.mb_indcs.ncells

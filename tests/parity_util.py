@@ -20,7 +20,7 @@ TOL = 1e-12     # north_star: <= 1e-12 relative L1 on the conserved variables
 
 
 def deck_overrides(problem, n, dims, mb=None, ng=None, recon=None, integrator=None, cfl=None,
-                   nlim=None, extra=()):
+                   nlim=None, extra=(), rsolver=None):
     """deck name + override list for an n^dims mesh with mb^dims MeshBlocks (mb may be a
     per-direction tuple)"""
     mb = mb or n
@@ -37,6 +37,8 @@ def deck_overrides(problem, n, dims, mb=None, ng=None, recon=None, integrator=No
     blk = "hydro" if problem in ("linear_wave_hydro", "sod") else "mhd"
     if recon is not None:
         ov.append("%s/reconstruct=%s" % (blk, recon))
+    if rsolver is not None:
+        ov.append("%s/rsolver=%s" % (blk, rsolver))
     if integrator is not None:
         ov.append("time/integrator=%s" % integrator)
     if cfl is not None:

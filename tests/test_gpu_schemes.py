@@ -1,0 +1,177 @@
+"""gpu: every reconstruction x Riemann-solver pair of the reference's lwave1d matrix
+(test_nr_lwave1d_cpu.py:98-105: plm/ppm4/ppmx/wenoz x hydro llf/hlle/hllc/roe, mhd llf/hlle/hlld;
+plus dc and teno) on the HIP path -- fused stage kernels, task-granular kernels and the C++
+driver -- against the CPU oracle.  Bar: bit-identical (the oracle itself is pinned on the
+reference's thresholds for the whole matrix in test_oracle_pins.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import parity_util as pu  # noqa: E402
+from oracle import akref  # noqa: E402
+
+RECONS = ["dc", "plm", "ppm4", "ppmx", "wenoz", "teno"]
+RS = {"hydro": ["llf", "hlle", "hllc", "roe"], "mhd": ["llf", "hlle", "hlld"]}
+
+
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "split"])
+@pytest.mark.parametrize("recon", RECONS)
+@pytest.mark.parametrize("soe", ["hydro", "mhd"])
+def test_lwave1d_matrix_is_bit_identical(soe, recon, fused):
+    """the reference's lwave1d run arguments (N=64, 4 MeshBlocks, ng=3, cfl 0.4), RK2 and RK3,
+    every solver: 12 cycles each"""
+    for rs in RS[soe]:
+        for integ in ("rk2", "rk3"):
+            res = pu.compare_run("linear_wave_%s" % soe, 64, 1, 16, 12, fused=fused, ng=3,
+                                 recon=recon, rsolver=rs, integrator=integ, cfl=0.4,
+                                 extra=["problem/along_x1=true", "problem/amp=1.0e-6"])
+            assert res["cycles"] == 12
+            assert res["time"][0] == res["time"][1]
+            assert res["bitwise_equal"], (soe, recon, rs, integ, res["diffs"])
+
+
+MULTI_D = [
+    # problem, n, dims, mb, cycles, kwargs
+    ("orszag_tang", 24, 3, 12, 3, dict(cfl=0.3, ng=3, recon="wenoz", rsolver="hlle")),
+    ("orszag_tang", 24, 3, 12, 3, dict(cfl=0.3, ng=3, recon="ppmx", rsolver="llf")),
+    ("orszag_tang", 24, 3, 24, 3, dict(cfl=0.3, ng=3, recon="teno", rsolver="hlld", integrator="rk3")),
+    ("orszag_tang", 32, 2, 16, 4, dict(cfl=0.3, ng=3, recon="wenoz", rsolver="llf")),
+    ("orszag_tang", 32, 2, 16, 4, dict(cfl=0.3, recon="plm", rsolver="hlle")),
+    ("blast", 24, 3, 12, 3, dict(rsolver="hlle")),                       # ppm4, ng=4, strong shock
+    ("blast", 32, 2, 16, 4, dict(recon="ppmx", rsolver="llf")),
+    ("sod", 32, 3, 16, 4, dict(cfl=0.3, ng=3, recon="ppmx", rsolver="roe")),
+    ("sod", 32, 3, 16, 4, dict(cfl=0.3, ng=3, recon="wenoz", rsolver="llf")),
+    ("sod", 32, 3, 32, 4, dict(cfl=0.3, recon="plm", rsolver="hlle", integrator="rk3")),
+    ("sod", 64, 2, 32, 5, dict(cfl=0.3, ng=3, recon="teno", rsolver="roe")),
+    ("linear_wave_hydro", 24, 3, 12, 3, dict(ng=3, recon="ppm4", rsolver="roe")),
+]
+
+
+def _id(c):
+    return "%s-%d^%d-mb%d-%s-%s" % (c[0], c[1], c[2], c[3], c[5].get("recon", "deck"), c[5]["rsolver"])
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "split"])
+@pytest.mark.parametrize("case", MULTI_D, ids=_id)
+def test_multi_d_schemes_are_bit_identical(case, fused):
+    """marching x2/x3 kernels, CT-extended sweeps, multi-block halos with the wider stencils"""
+    problem, n, dims, mb, cycles, kw = case
+    res = pu.compare_run(problem, n, dims, mb, cycles, fused=fused, **kw)
+    assert res["cycles"] == cycles
+    assert res["time"][0] == res["time"][1], res["time"]
+    assert res["bitwise_equal"], res["diffs"]
+
+
+@pytest.mark.parametrize("case", [MULTI_D[0], MULTI_D[7], MULTI_D[6]], ids=_id)
+def test_native_cpp_driver_schemes(case):
+    problem, n, dims, mb, cycles, kw = case
+    res = pu.compare_run(problem, n, dims, mb, cycles, native=True, **kw)
+    assert res["cycles"] == cycles and res["bitwise_equal"], res["diffs"]
+
+
+def _wild_states(shape5, rng, mhd):
+    """primitive states with jumps of many decades between neighbouring cells: exercises the
+    supersonic branches, the HLLE/HLLC pressure estimates, Roe's negative-density fallback and
+    the L/R floors of ppmx/wenoz/teno"""
+    w = np.empty(shape5)
+    w[:, 0] = 10.0**rng.uniform(-4, 2, size=w[:, 0].shape)
+    w[:, 1:4] = rng.normal(0, 3.0, size=w[:, 1:4].shape)
+    w[:, 4] = 10.0**rng.uniform(-5, 2, size=w[:, 4].shape)
+    return w
+
+
+@pytest.mark.parametrize("recon", RECONS)
+@pytest.mark.parametrize("rs", RS["hydro"])
+def test_task_hydro_fluxes_wild_states(recon, rs):
+    from athenak_amd import capi
+    o = akref.Sim(nx1=20, nx2=12, nx3=8, mb_nx1=10, mb_nx2=12, mb_nx3=8, ng=3, nstages=2, cfl=0.3,
+                  tlim=1.0, nlim=-1, is_mhd=0, recon="plm", rsolver="hllc", gamma=1.4,
+                  pgen="shock_tube", shock_dir=1, xshock=0.0, wl=[1, 0, 0, 0, 1, 0, 0, 0],
+                  wr=[0.125, 0, 0, 0, 0.1, 0, 0, 0], bcs=["outflow"]*6, dfloor=1e-3, pfloor=1e-4)
+    o.initialize()
+    L, R = capi.lib(), akref.lib()
+    pk = o.pack()
+    dxd = _t(o.array("dx"))
+    pkd = capi.Pack.from_buffer_copy(bytes(pk))
+    pkd.dx = dxd.data_ptr()
+    rng = np.random.default_rng(1234)
+    n3, n2, n1 = o.dims()
+    w0 = _wild_states((o.nmb, 5, n3, n2, n1), rng, False)
+    f = [np.zeros((o.nmb, 5, n3, n2, n1 + 1)), np.zeros((o.nmb, 5, n3, n2 + 1, n1)),
+         np.zeros((o.nmb, 5, n3 + 1, n2, n1))]
+    rc, sc = akref.RECON[recon], akref.RSOLVER[rs]
+    assert R.akref_hydro_fluxes(C.byref(pk), rc, sc, akref.ptr(w0), *[akref.ptr(x) for x in f], 1) == 0
+    fd = [_t(np.zeros_like(x)) for x in f]
+    w0d = _t(w0)
+    capi.check(L.akmi_hydro_fluxes(C.byref(pkd), rc, sc, capi._p(w0d), *[capi._p(x) for x in fd], 1,
+                                   None), "fluxes")
+    for a, b in zip(f, fd):
+        b = b.cpu().numpy()
+        assert np.isfinite(a).all()
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("recon", RECONS)
+@pytest.mark.parametrize("rs", RS["mhd"])
+def test_task_mhd_fluxes_wild_states(recon, rs):
+    from athenak_amd import capi
+    o = akref.Sim(nx1=16, nx2=12, nx3=8, mb_nx1=8, mb_nx2=12, mb_nx3=8, ng=3, nstages=2, cfl=0.3,
+                  tlim=1.0, nlim=-1, is_mhd=1, recon="plm", rsolver="hlld", gamma=1.666666667,
+                  pgen="orszag_tang", bcs=["periodic"]*6, dfloor=1e-3, pfloor=1e-4)
+    o.initialize()
+    L, R = capi.lib(), akref.lib()
+    pk = o.pack()
+    dxd = _t(o.array("dx"))
+    pkd = capi.Pack.from_buffer_copy(bytes(pk))
+    pkd.dx = dxd.data_ptr()
+    rng = np.random.default_rng(4321)
+    n3, n2, n1 = o.dims()
+    h = {"w0": _wild_states((o.nmb, 5, n3, n2, n1), rng, True),
+         "bcc0": rng.normal(0, 2.0, size=(o.nmb, 3, n3, n2, n1)),
+         "b0x1f": rng.normal(0, 2.0, size=(o.nmb, n3, n2, n1 + 1)),
+         "b0x2f": rng.normal(0, 2.0, size=(o.nmb, n3, n2 + 1, n1)),
+         "b0x3f": rng.normal(0, 2.0, size=(o.nmb, n3 + 1, n2, n1))}
+    h["b0x1f"][:, :, :, ::3] = 0.0          # Bx = 0 faces (degenerate HLLD branches)
+    names_in = ["w0", "bcc0", "b0x1f", "b0x2f", "b0x3f"]
+    names_out = ["flx1", "flx2", "flx3", "e3x1", "e2x1", "e1x2", "e3x2", "e2x3", "e1x3"]
+    for k in names_out:
+        h[k] = np.zeros_like(o.array(k))
+    dv = {k: _t(v) for k, v in h.items()}
+    rc, sc = akref.RECON[recon], akref.RSOLVER[rs]
+    assert R.akref_mhd_fluxes(C.byref(pk), rc, sc, *[akref.ptr(h[k]) for k in names_in + names_out]) == 0
+    capi.check(L.akmi_mhd_fluxes(C.byref(pkd), rc, sc, *[capi._p(dv[k]) for k in names_in + names_out],
+                                 None), "mhd_fluxes")
+    for k in names_out:
+        assert np.isfinite(h[k]).all(), k
+        assert np.array_equal(h[k], dv[k].cpu().numpy()), k
+
+
+def test_unknown_scheme_is_rejected():
+    """hydro has no hlld, mhd has no hllc/roe: the entry points fail loudly"""
+    from athenak_amd import capi
+    o = akref.Sim(nx1=8, nx2=1, nx3=1, mb_nx1=8, mb_nx2=1, mb_nx3=1, ng=2, nstages=2, cfl=0.3,
+                  tlim=1.0, nlim=-1, is_mhd=0, recon="plm", rsolver="hllc", gamma=1.4,
+                  pgen="shock_tube", shock_dir=1, xshock=0.0, wl=[1, 0, 0, 0, 1, 0, 0, 0],
+                  wr=[0.125, 0, 0, 0, 0.1, 0, 0, 0], bcs=["outflow"]*6)
+    o.initialize()
+    L = capi.lib()
+    pk = o.pack()
+    dxd = _t(o.array("dx"))
+    pkd = capi.Pack.from_buffer_copy(bytes(pk))
+    pkd.dx = dxd.data_ptr()
+    w0 = _t(o.array("w0"))
+    n3, n2, n1 = o.dims()
+    f = [_t(np.zeros((1, 5, n3, n2, n1 + 1))), _t(np.zeros((1, 5, n3, n2 + 1, n1))),
+         _t(np.zeros((1, 5, n3 + 1, n2, n1)))]
+    assert L.akmi_hydro_fluxes(C.byref(pkd), 1, 3, capi._p(w0), *[capi._p(x) for x in f], 1, None) < 0
+    assert b"rsolver" in L.akmi_last_error()
+    assert L.akmi_hydro_fluxes(C.byref(pkd), 4, 2, capi._p(w0), *[capi._p(x) for x in f], 1, None) < 0
+    assert b"nghost" in L.akmi_last_error()
