@@ -26,7 +26,8 @@ def deck_overrides(problem, n, dims, mb=None, ng=None, recon=None, integrator=No
     mb = mb or n
     deck = {"linear_wave_hydro": "linear_wave_hydro.athinput",
             "linear_wave_mhd": "linear_wave_mhd.athinput", "sod": "sod.athinput",
-            "orszag_tang": "orszag_tang.athinput", "blast": "blast_mhd.athinput"}[problem]
+            "orszag_tang": "orszag_tang.athinput", "blast": "blast_mhd.athinput",
+            "rj2a": "rj2a.athinput"}[problem]
     ov = []
     for q in (1, 2, 3):
         nn = n if q <= dims else 1

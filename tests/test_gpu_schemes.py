@@ -52,6 +52,10 @@ MULTI_D = [
     ("sod", 32, 3, 32, 4, dict(cfl=0.3, recon="plm", rsolver="hlle", integrator="rk3")),
     ("sod", 64, 2, 32, 5, dict(cfl=0.3, ng=3, recon="teno", rsolver="roe")),
     ("linear_wave_hydro", 24, 3, 12, 3, dict(ng=3, recon="ppm4", rsolver="roe")),
+    # Ryu-Jones 2a (test_nr_rj2a_cpu.py): two blocks, outflow, every MHD solver
+    ("rj2a", 256, 1, 128, 12, dict(cfl=0.3, rsolver="llf")),
+    ("rj2a", 256, 1, 128, 12, dict(cfl=0.3, ng=3, recon="ppmx", rsolver="hlle", integrator="rk3")),
+    ("rj2a", 256, 1, 128, 12, dict(cfl=0.3, ng=3, recon="wenoz", rsolver="hlld", integrator="rk3")),
 ]
 
 

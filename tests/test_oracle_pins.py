@@ -126,6 +126,51 @@ def test_plm_left_right_wave_errors_equal_every_solver(rs):
                 assert "%e" % a[0] == "%e" % b[0]
 
 
+def _rj2a_error(res, recon, rs):
+    """test_nr_rj2a_cpu.py:20-50: mean |dens - piecewise-constant analytic density| of the
+    Ryu & Jones (1995) fig. 2a Riemann problem at t=0.2, density as printed with %12.5e"""
+    import json
+    import os
+    ka = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "known_answers.json")))["rj2a"]
+    ng = 2 if recon == "plm" else 3
+    s = akref.Sim(nx1=res, nx2=1, nx3=1, mb_nx1=128, mb_nx2=1, mb_nx3=1, ng=ng, x1min=-0.5, x1max=0.5,
+                  x2min=-0.5, x2max=0.5, x3min=-0.5, x3max=0.5,
+                  bcs=["outflow", "outflow", "periodic", "periodic", "periodic", "periodic"],
+                  nstages=2 if recon == "plm" else 3, cfl=ka["cfl"], tlim=ka["tlim"], nlim=-1,
+                  is_mhd=1, recon=recon, rsolver=rs, gamma=ka["gamma"], pgen="shock_tube",
+                  shock_dir=1, xshock=0.0, wl=ka["wl"], wr=ka["wr"])
+    s.initialize()
+    s.run()
+    w = s.array("w0")
+    d = np.concatenate([w[m, 0, 0, 0, ng:ng + 128] for m in range(s.nmb)])
+    d = np.array([float("%12.5e" % v) for v in d])
+    x = -0.5 + (np.arange(res) + 0.5)/res
+    t = ka["tlim"]
+    a = ka["analytic_density"]
+    xfp = a["xfp"]*t
+    xrp = (a["xrp"][0] + 1.0/np.sqrt(np.pi*a["xrp"][1]))*t
+    xsp = (a["xsp"][0] + a["xsp"][1]/a["xsp"][2])*t
+    xc = a["xc"]*t
+    xsm = (a["xsm"][0] - a["xsm"][1]/a["xsm"][2])*t
+    xrm = (a["xrm"][0] - 1.0/np.sqrt(np.pi*a["xrm"][1]))*t
+    xfm = (a["xfm"][0] - a["xfm"][1]/a["xfm"][2])*t
+    pl = a["plateaus"]
+    dens = np.full(res, pl[7])
+    for edge, val in ((xfm, pl[6]), (xrm, pl[5]), (xsm, pl[4]), (xc, pl[3]), (xsp, pl[2]), (xrp, pl[1]),
+                      (xfp, pl[0])):
+        dens = np.where(x > edge, val, dens)
+    return np.abs(d - dens).mean()
+
+
+@pytest.mark.parametrize("rs", ["llf", "hlle", "hlld"])
+@pytest.mark.parametrize("recon", ["plm", "ppm4", "ppmx", "wenoz"])
+def test_rj2a_shock_tube_convergence(recon, rs):
+    """test_nr_rj2a_cpu.py:70-92: error(256)/error(128) <= 0.6 for every reconstruction x MHD
+    Riemann solver (rk2 for plm, rk3 otherwise; two MeshBlocks at N=256)"""
+    e128, e256 = _rj2a_error(128, recon, rs), _rj2a_error(256, recon, rs)
+    assert e256/e128 <= 0.6, (recon, rs, e128, e256)
+
+
 def test_mhd_lwave1d_close_to_recorded_reference_value():
     """BASELINE.md 2b records 8.812266e-08 / 2.448591e-08 for MHD+HLLD.  The oracle gives
     8.812260e-08 / 2.448581e-08: equal to 5 digits (4e-6 relative), see DESIGN.md
