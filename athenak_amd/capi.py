@@ -37,7 +37,7 @@ SYMBOLS = [
     "akmi_bvals_fc_unpack", "akmi_bvals_fc_segsize", "akmi_hydro_bcs", "akmi_bfield_bcs",
     "akmi_stage_workspace_bytes", "akmi_hydro_stage_update", "akmi_mhd_stage_update",
     "akmi_hydro_c2p_newdt", "akmi_mhd_c2p_newdt", "akmi_calib_copy", "akmi_hydro_stage_fused", "akmi_mhd_stage_fused",
-    "akmi_hydro_stage_phase", "akmi_mhd_stage_phase",
+    "akmi_hydro_stage_phase", "akmi_mhd_stage_phase", "akmi_history_sums",
     "akmi_hydro_c2p_shell", "akmi_mhd_c2p_shell", "akmi_sim_create", "akmi_sim_initialize",
     "akmi_sim_execute", "akmi_sim_destroy", "akmi_sim_time", "akmi_sim_dt", "akmi_sim_tlim",
     "akmi_sim_ncycle", "akmi_sim_nmb", "akmi_sim_array", "akmi_sim_lloc",

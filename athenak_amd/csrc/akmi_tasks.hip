@@ -199,6 +199,63 @@ __global__ void k_init_dt(double *dt3) {
 }
 
 // ---------------------------------------------------------------------------------------
+// History sums (src/outputs/history.cpp:78-160, 272-374): volume-weighted sums over the active
+// cells of the conserved variables, the three kinetic energies and (MHD) the three magnetic
+// energies.  One cell per thread, wave reduction by shuffles, workgroup reduction through LDS,
+// one fp64 atomicAdd per workgroup and quantity (the reference's Kokkos reduction is not
+// order-deterministic either; values agree to round-off).
+AKMI_DEV double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <bool MHD>
+__global__ void __launch_bounds__(BX*BY)
+k_history(Geo g, const double *__restrict__ u0, const double *__restrict__ bx1f,
+          const double *__restrict__ bx2f, const double *__restrict__ bx3f,
+          double *__restrict__ out) {
+  constexpr int NH = MHD ? 11 : 8;
+  __shared__ double sm[NH][BY];
+  const int i = g.is + blockIdx.x*BX + threadIdx.x;
+  const int j = g.js + blockIdx.y*BY + threadIdx.y;
+  const int nk = g.ke - g.ks + 1;
+  const int m = blockIdx.z/nk;
+  const int k = g.ks + (blockIdx.z - m*nk);
+  double h[NH];
+#pragma unroll
+  for (int n = 0; n < NH; ++n) h[n] = 0.0;
+  if (i <= g.ie && j <= g.je) {
+    const double vol = g.dx[3*m]*g.dx[3*m + 1]*g.dx[3*m + 2];
+    const size_t cs = (size_t)g.N3*g.N2*g.N1;
+    const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
+    const double d = u0[c], m1 = u0[c + cs], m2 = u0[c + 2*cs], m3 = u0[c + 3*cs], e = u0[c + 4*cs];
+    h[0] = vol*d; h[1] = vol*m1; h[2] = vol*m2; h[3] = vol*m3; h[4] = vol*e;
+    h[5] = vol*0.5*sqr(m1)/d;
+    h[6] = vol*0.5*sqr(m2)/d;
+    h[7] = vol*0.5*sqr(m3)/d;
+    if constexpr (MHD) {
+      h[8] = vol*0.25*(sqr(bx1f[ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i + 1)]) +
+                       sqr(bx1f[ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i)]));
+      h[9] = vol*0.25*(sqr(bx2f[ix4(g.N3, g.N2 + 1, g.N1, m, k, j + 1, i)]) +
+                       sqr(bx2f[ix4(g.N3, g.N2 + 1, g.N1, m, k, j, i)]));
+      h[10] = vol*0.25*(sqr(bx3f[ix4(g.N3 + 1, g.N2, g.N1, m, k + 1, j, i)]) +
+                        sqr(bx3f[ix4(g.N3 + 1, g.N2, g.N1, m, k, j, i)]));
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NH; ++n) {
+    const double v = wave_sum(h[n]);
+    if (threadIdx.x == 0) sm[n][threadIdx.y] = v;
+  }
+  __syncthreads();
+  if (threadIdx.y == 0 && threadIdx.x < NH) {
+    double v = sm[threadIdx.x][0];
+    for (int q = 1; q < BY; ++q) v += sm[threadIdx.x][q];
+    atomicAdd(&out[threadIdx.x], v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // MHD fluxes: reconstruct w0 and bcc0 in registers + Riemann solver RS.  mhd_fluxes.cpp:84-266.
 template <int DIR, int RECON, int RS>
 __global__ void __launch_bounds__(BX*BY)
@@ -538,6 +595,21 @@ int akmi_mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0
   if (rc == AKMI_COMPLETE && g.three_d)
     rc = launch_mhd_flux<2>(g, sc, w0, bcc0, bx3f, flx3, e2x3, e1x3, st);
   return rc;
+}
+
+int akmi_history_sums(const akmi_pack *p, int is_mhd, const double *u0, const double *bx1f,
+                      const double *bx2f, const double *bx3f, double *out, void *stream) {
+  Geo g = make_geo(p);
+  hipStream_t st = (hipStream_t)stream;
+  const int nh = is_mhd ? 11 : 8;
+  if (hipMemsetAsync(out, 0, sizeof(double)*nh, st) != hipSuccess) {
+    set_error("history_sums: memset failed"); return AKMI_FAIL;
+  }
+  dim3 grid(cdiv(g.nx1, BX), cdiv(g.je - g.js + 1, BY), (g.ke - g.ks + 1)*g.nmb), block(BX, BY);
+  if (is_mhd) k_history<true><<<grid, block, 0, st>>>(g, u0, bx1f, bx2f, bx3f, out);
+  else k_history<false><<<grid, block, 0, st>>>(g, u0, nullptr, nullptr, nullptr, out);
+  AKMI_CHECK_LAUNCH("history_sums");
+  return AKMI_COMPLETE;
 }
 
 int akmi_mhd_corner_e(const akmi_pack *p, const double *w0, const double *bcc0,

@@ -77,8 +77,9 @@ class Driver:
             pmhd.ApplyPhysicalBCs(self, 0)
             pmhd.ConToPrim(self, 0)
 
-    def Initialize(self, pm, pin=None):
-        """driver.cpp:314-371"""
+    def Initialize(self, pm, pin=None, pout=None):
+        """driver.cpp:314-371; with pout: the initial outputs (driver.cpp:340-346)"""
+        self.pout, self.pin_ = pout, pin
         self.InitBoundaryValuesAndPrimitives(pm)
         ph, pmhd = pm.pmb_pack.phydro, pm.pmb_pack.pmhd
         if ph is not None:
@@ -87,6 +88,8 @@ class Driver:
             pmhd.NewTimeStep(self, self.nexp_stages)
         pm.NewTimeStep(self.tlim)
         self.nmb_updated_ = 0
+        if pout is not None:
+            pout.MakeOutputs(pm, pin)
 
     def _cycle(self, pm):
         self.ExecuteTaskList(pm, "before_timeintegrator", 0)
@@ -98,7 +101,21 @@ class Driver:
         pm.time = pm.time + pm.dt
         pm.ncycle += 1
         self.nmb_updated_ += pm.nmb_total
+        if getattr(self, "pout", None) is not None:
+            self.pout.TestAndMakeOutputs(pm, self.pin_, self.tlim)     # driver.cpp:432-445
         pm.NewTimeStep(self.tlim)
+
+    def Finalize(self, pm, pin, pout=None):
+        """driver.cpp:467-500: final outputs, then the problem generator's final work (the
+        linear-wave error file)"""
+        if pout is not None:
+            pout.MakeOutputs(pm, pin)
+        if pm.pgen is not None and pm.pgen.pgen_final_func is not None:
+            pm.pgen.write_errors_file = True
+            errs = pm.pgen.pgen_final_func()
+            pm.pgen.write_errors_file = False
+            return errs
+        return None
 
     def Execute(self, pm, pin=None, max_cycles=None):
         """driver.cpp:380-459; returns cycles executed by this call"""

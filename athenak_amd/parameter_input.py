@@ -110,5 +110,22 @@ class ParameterInput:
             out += ["%s = %s" % (k, v) for k, v in d.items()]
         return "\n".join(out) + "\n"
 
+    def SetInteger(self, blk, name, val):
+        self.blocks.setdefault(blk, {})[name] = str(int(val))
+
+    def ParameterDump(self):
+        """src/parameter_input.cpp:771-795: the text that heads bin files (and restarts); names
+        and values padded to the longest of their block"""
+        out = ["#------------------------- PAR_DUMP -------------------------"]
+        for b, d in self.blocks.items():
+            out.append("<%s>" % b)
+            ln = max([len(k) for k in d] + [0])
+            lv = max([len(str(v)) for v in d.values()] + [0])
+            for k, v in d.items():
+                out.append("%s= %s" % (k.ljust(ln + 1), str(v).ljust(lv + 1)))
+        out.append("#------------------------- PAR_DUMP -------------------------")
+        out.append("<par_end>")
+        return "\n".join(out) + "\n"
+
     def SetString(self, blk, name, val):
         self.blocks.setdefault(blk, {})[name] = str(val)

@@ -332,7 +332,34 @@ class ProblemGenerator:
         volm = (ms.x1max - ms.x1min)*(ms.x2max - ms.x2min)*(ms.x3max - ms.x3min)
         l1 = l1/volm
         rms = math.sqrt(float((l1*l1).sum()))
-        return np.concatenate([[rms, linf_arr[0]/volm], l1])
+        errs = np.concatenate([[rms, linf_arr[0]/volm], l1])
+        if self.write_errors_file and pm.my_rank == 0:
+            self.WriteErrorsFile(errs)
+        return errs
+
+    write_errors_file = False       # set by Driver.Finalize: <basename>-errs.dat (pgen.cpp:850-898)
+
+    def WriteErrorsFile(self, errs):
+        """pgen.cpp:850-898: header on first use, then one appended line per run; column 4 is
+        the RMS-L1 error the reference's regression tests read (testutils.py:273-276)"""
+        import os
+        pm = self.pmy_mesh_
+        is_mhd = pm.pmb_pack.pmhd is not None
+        fname = self.pin.GetString("job", "basename") + "-errs.dat"
+        new = not os.path.exists(fname)
+        with open(fname, "a") as f:
+            if new:
+                f.write("# Nx1  Nx2  Nx3   Ncycle   RMS-L1       L-infty       ")
+                f.write("d_L1          M1_L1         M2_L1         M3_L1         ")
+                f.write("E_L1          ")
+                if is_mhd:
+                    f.write("B1_L1         B2_L1         B3_L1")
+                f.write("\n")
+            mi = pm.mesh_indcs
+            f.write("%04d  %04d  %04d  %05d  %e %e" % (mi.nx1, mi.nx2, mi.nx3, pm.ncycle, errs[0], errs[1]))
+            for v in errs[2:]:
+                f.write("  %e" % v)
+            f.write("\n")
 
     # ---- shock tube ----------------------------------------------------------------
     def ShockTube(self, pin, restart):

@@ -232,6 +232,14 @@ int akmi_mhd_c2p_shell(const akmi_pack *p, double *u0, const double *bx1f, const
                        const double *bx3f, double *w0, double *bcc0, int *counters,
                        void *stream);
 
+/* History sums (HistoryOutput::LoadHydroHistoryData / LoadMHDHistoryData,
+ * src/outputs/history.cpp:78-160,272-374): out[0..7] = volume sums over the active cells of
+ * d, M1, M2, M3, E, and the kinetic energies 0.5*Mi^2/d; MHD adds out[8..10] = the magnetic
+ * energies 0.25*(B_face^2 + B_face+1^2) per direction.  out is a device array of 8 (11)
+ * doubles; it is zeroed by the call. */
+int akmi_history_sums(const akmi_pack *p, int is_mhd, const double *u0, const double *bx1f,
+                      const double *bx2f, const double *bx3f, double *out, void *stream);
+
 /* ---- native host driver (C++ mirror of Mesh/MeshBlockPack/TaskList/Driver/Hydro/MHD) ----- *
  * athenak_amd/csrc/akmi_host.{hpp,cpp}: the reference's operator surface for this path in
  * C++, every task body one call of the entries above.  Single rank: all MeshBlocks of the mesh

@@ -75,6 +75,9 @@ int akref_hydro_bcs(const akmi_pack *p, int nvar, const int *bcs, double *u);
 int akref_bfield_bcs(const akmi_pack *p, const int *bcs, double *bx1f, double *bx2f,
                      double *bx3f);
 
+int akref_history_sums(const akmi_pack *p, int is_mhd, const double *u0, const double *bx1f,
+                       const double *bx2f, const double *bx3f, double *out);
+
 /* single-state functions exposed for unit pins */
 void akref_plm(double qim1, double qi, double qip1, double *ql_ip1, double *qr_i);
 void akref_ppm4(double qim2, double qim1, double qi, double qip1, double qip2,

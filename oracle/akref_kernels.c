@@ -1045,6 +1045,35 @@ int akref_mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w
   return 0;
 }
 
+/* History sums, src/outputs/history.cpp:78-160 (hydro), 272-374 (MHD); sequential (m,k,j,i) */
+int akref_history_sums(const akmi_pack *p, int is_mhd, const double *u0, const double *bx1f,
+                       const double *bx2f, const double *bx3f, double *out) {
+  G g = mkG(p);
+  const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  const int nh = is_mhd ? 11 : 8;
+  for (int n = 0; n < nh; ++n) out[n] = 0.0;
+  for (int m = 0; m < g.nmb; ++m) {
+    const double vol = p->dx[3*m]*p->dx[3*m+1]*p->dx[3*m+2];
+    for (int k = g.ks; k <= g.ke; ++k)
+      for (int j = g.js; j <= g.je; ++j)
+        for (int i = g.is; i <= g.ie; ++i) {
+          double d = u0[ix5(nv,N3,N2,N1,m,IDN,k,j,i)];
+          double m1 = u0[ix5(nv,N3,N2,N1,m,1,k,j,i)], m2 = u0[ix5(nv,N3,N2,N1,m,2,k,j,i)];
+          double m3 = u0[ix5(nv,N3,N2,N1,m,3,k,j,i)], e = u0[ix5(nv,N3,N2,N1,m,IEN,k,j,i)];
+          out[0] += vol*d; out[1] += vol*m1; out[2] += vol*m2; out[3] += vol*m3; out[4] += vol*e;
+          out[5] += vol*0.5*SQR(m1)/d;
+          out[6] += vol*0.5*SQR(m2)/d;
+          out[7] += vol*0.5*SQR(m3)/d;
+          if (is_mhd) {
+            out[8] += vol*0.25*(SQR(bx1f[ix4(N3,N2,N1+1,m,k,j,i+1)]) + SQR(bx1f[ix4(N3,N2,N1+1,m,k,j,i)]));
+            out[9] += vol*0.25*(SQR(bx2f[ix4(N3,N2+1,N1,m,k,j+1,i)]) + SQR(bx2f[ix4(N3,N2+1,N1,m,k,j,i)]));
+            out[10] += vol*0.25*(SQR(bx3f[ix4(N3+1,N2,N1,m,k+1,j,i)]) + SQR(bx3f[ix4(N3+1,N2,N1,m,k,j,i)]));
+          }
+        }
+  }
+  return 0;
+}
+
 /* MHD::CornerE, src/mhd/mhd_corner_e.cpp:26-417 (Newtonian branches: 1D :39-53,
  * 2D :58-66,139-192, 3D :303-414) */
 int akref_mhd_corner_e(const akmi_pack *p, const double *w0, const double *bcc0,
