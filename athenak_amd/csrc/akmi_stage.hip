@@ -457,6 +457,150 @@ k_corner3(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e2x
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// CornerE + CT in ONE kernel (3-D).  The corner EMFs never go to memory: a workgroup owns a
+// (j,i) tile with a one-column/one-row overlap, marches along k, exchanges the three edge values
+// of a plane through LDS (i+1 and j+1 neighbours) and keeps its own previous plane in registers
+// (k+1 differences), so that
+//     x3-faces of plane k         are updated at step k      (need e1,e2 of plane k),
+//     x1-/x2-faces of plane k-1   are updated at step k      (need e3 of plane k-1, e1/e2 of both).
+// The k-1 operands of the corner formulas are the previous step's k operands (25 instead of 33
+// loads per corner).  Every face is read and written by exactly one thread (the overlap
+// column/row only computes edges), so the in-place update of b0 has no cross-workgroup hazard.
+// Arithmetic: the expressions of k_corner3 and k_ct_copy, unchanged.
+#ifndef AKMI_FUSED_CT
+#define AKMI_FUSED_CT 1
+#endif
+#ifndef AKMI_CJ
+#define AKMI_CJ 8
+#endif
+#ifndef AKMI_CKL
+#define AKMI_CKL 32
+#endif
+constexpr int CI = 64, CJ = AKMI_CJ;   // tile of edge positions (threads); owners: (CI-1) x (CJ-1)
+constexpr int CKL = AKMI_CKL;          // cell planes per k-chunk (one plane of edges recomputed)
+
+__global__ void __launch_bounds__(CI*CJ)
+k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e2x1,
+            const double *__restrict__ e1x2, const double *__restrict__ e3x2,
+            const double *__restrict__ e2x3, const double *__restrict__ e1x3,
+            const double *__restrict__ c1, const double *__restrict__ c2,
+            const double *__restrict__ c3, const double *__restrict__ flx1,
+            const double *__restrict__ flx2, const double *__restrict__ flx3, double gam0,
+            double gam1, double beta_dt, double *__restrict__ b0x1f, double *__restrict__ b0x2f,
+            double *__restrict__ b0x3f, double *__restrict__ b1x1f, double *__restrict__ b1x2f,
+            double *__restrict__ b1x3f, int copy_b1, int kA, int kB, int top, int nchunk) {
+  __shared__ double s1[2][CJ][CI], s2[2][CJ][CI], s3[3][CJ][CI];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int i = g.is + blockIdx.x*(CI - 1) + tx;
+  const int j = g.js + blockIdx.y*(CJ - 1) + ty;
+  const int m = blockIdx.z/nchunk;
+  const int ch = blockIdx.z - m*nchunk;
+  const int k0 = kA + ch*CKL;                                   // first cell plane of this chunk
+  const int k1 = (k0 + CKL - 1 < kB) ? k0 + CKL - 1 : kB;       // last cell plane
+  const bool wtop = top && (k1 == kB);                          // this chunk owns the x3-faces kB+1
+  const bool edge_ok = (i <= g.ie + 1) && (j <= g.je + 1);
+  const bool own = edge_ok && (tx < CI - 1) && (ty < CJ - 1);
+  const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
+  double e1p = 0.0, e2p = 0.0, e3p = 0.0;                       // own edges of the previous plane
+  // operands of the corner formulas that belong to plane k-1 (rolled from step to step)
+  double f1_km = 0.0, f2_km = 0.0, x2_km = 0.0, x1_km = 0.0, c1_mm = 0.0, c1_m0 = 0.0, c2_mm = 0.0,
+         c2_m0 = 0.0;
+  if (edge_ok) {
+    const int k = k0;
+    f1_km = flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k - 1, j, i)];
+    f2_km = flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, 0, k - 1, j, i)];
+    x2_km = CCE(e1x2, k - 1, j, i);
+    x1_km = CCE(e2x1, k - 1, j, i);
+    c1_mm = CCE(c1, k - 1, j - 1, i); c1_m0 = CCE(c1, k - 1, j, i);
+    c2_mm = CCE(c2, k - 1, j, i - 1); c2_m0 = CCE(c2, k - 1, j, i);
+  }
+  for (int k = k0; k <= k1 + 1; ++k) {
+    const int t = k - k0;
+    const int p2 = t & 1, p3 = t % 3;
+    double e1 = 0.0, e2 = 0.0, e3 = 0.0;
+    if (edge_ok) {
+      const double f1_k = flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k, j, i)];
+      const double f1_jm = flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k, j - 1, i)];
+      const double f2_k = flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, 0, k, j, i)];
+      const double f2_im = flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, 0, k, j, i - 1)];
+      const double f3_k = flx3[ix5(g.nvar, g.N3 + 1, g.N2, g.N1, m, 0, k, j, i)];
+      const double f3_jm = flx3[ix5(g.nvar, g.N3 + 1, g.N2, g.N1, m, 0, k, j - 1, i)];
+      const double f3_im = flx3[ix5(g.nvar, g.N3 + 1, g.N2, g.N1, m, 0, k, j, i - 1)];
+      const double c1_0m = CCE(c1, k, j - 1, i), c1_00 = CCE(c1, k, j, i);
+      const double c2_0m = CCE(c2, k, j, i - 1), c2_00 = CCE(c2, k, j, i);
+      const double x2_k = CCE(e1x2, k, j, i), x1_k = CCE(e2x1, k, j, i);
+      {  // E1 (mhd_corner_e.cpp:340-363)
+        const double x3_jm = CCE(e1x3, k, j - 1, i), x3_j = CCE(e1x3, k, j, i);
+        double e1_l3 = upw(f2_km >= 0.0, x3_jm, c1_mm, x3_j, c1_m0);
+        double e1_r3 = upw(f2_k >= 0.0, x3_jm, c1_0m, x3_j, c1_00);
+        double e1_l2 = upw(f3_jm >= 0.0, x2_km, c1_mm, x2_k, c1_0m);
+        double e1_r2 = upw(f3_k >= 0.0, x2_km, c1_m0, x2_k, c1_00);
+        e1 = 0.25*(e1_l3 + e1_r3 + e1_l2 + e1_r2 + x2_km + x2_k + x3_jm + x3_j);
+      }
+      {  // E2 (:365-388)
+        const double x3_im = CCE(e2x3, k, j, i - 1), x3_i = CCE(e2x3, k, j, i);
+        double e2_l3 = upw(f1_km >= 0.0, x3_im, c2_mm, x3_i, c2_m0);
+        double e2_r3 = upw(f1_k >= 0.0, x3_im, c2_0m, x3_i, c2_00);
+        double e2_l1 = upw(f3_im >= 0.0, x1_km, c2_mm, x1_k, c2_0m);
+        double e2_r1 = upw(f3_k >= 0.0, x1_km, c2_m0, x1_k, c2_00);
+        e2 = 0.25*(e2_l3 + e2_r3 + e2_l1 + e2_r1 + x3_im + x3_i + x1_km + x1_k);
+      }
+      {  // E3 (:390-413)
+        const double x2_im = CCE(e3x2, k, j, i - 1), x2_i = CCE(e3x2, k, j, i);
+        const double x1_jm = CCE(e3x1, k, j - 1, i), x1_j = CCE(e3x1, k, j, i);
+        const double c_mm = CCE(c3, k, j - 1, i - 1), c_m0 = CCE(c3, k, j - 1, i);
+        const double c_0m = CCE(c3, k, j, i - 1), c_00 = CCE(c3, k, j, i);
+        double e3_l2 = upw(f1_jm >= 0.0, x2_im, c_mm, x2_i, c_m0);
+        double e3_r2 = upw(f1_k >= 0.0, x2_im, c_0m, x2_i, c_00);
+        double e3_l1 = upw(f2_im >= 0.0, x1_jm, c_mm, x1_j, c_0m);
+        double e3_r1 = upw(f2_k >= 0.0, x1_jm, c_m0, x1_j, c_00);
+        e3 = 0.25*(e3_l1 + e3_r1 + e3_l2 + e3_r2 + x2_im + x2_i + x1_jm + x1_j);
+      }
+      f1_km = f1_k; f2_km = f2_k; x2_km = x2_k; x1_km = x1_k;
+      c1_mm = c1_0m; c1_m0 = c1_00; c2_mm = c2_0m; c2_m0 = c2_00;
+    }
+    s1[p2][ty][tx] = e1; s2[p2][ty][tx] = e2; s3[p3][ty][tx] = e3;
+    __syncthreads();
+    if (own) {
+      if (i <= g.ie && j <= g.je && (k <= k1 || wtop)) {          // x3-face of plane k (mhd_ct.cpp:67-77)
+        const size_t c = ix4(g.N3 + 1, g.N2, g.N1, m, k, j, i);
+        const double b0v = b0x3f[c];
+        const double b1v = copy_b1 ? b0v : b1x3f[c];
+        double b = gam0*b0v + gam1*b1v;
+        b -= beta_dt*(s2[p2][ty][tx + 1] - e2)/dx1;
+        b += beta_dt*(s1[p2][ty + 1][tx] - e1)/dx2;
+        b0x3f[c] = b;
+        if (copy_b1) b1x3f[c] = b0v;
+      }
+      if (k > k0) {
+        const int kc = k - 1, q3 = (t + 2) % 3;                    // plane k-1 and its e3 buffer
+        if (j <= g.je) {                                           // x1-face (:45-54)
+          const size_t c = ix4(g.N3, g.N2, g.N1 + 1, m, kc, j, i);
+          const double b0v = b0x1f[c];
+          const double b1v = copy_b1 ? b0v : b1x1f[c];
+          double b = gam0*b0v + gam1*b1v;
+          b -= beta_dt*(s3[q3][ty + 1][tx] - e3p)/dx2;
+          b += beta_dt*(e2 - e2p)/dx3;
+          b0x1f[c] = b;
+          if (copy_b1) b1x1f[c] = b0v;
+        }
+        if (i <= g.ie) {                                           // x2-face (:56-65)
+          const size_t c = ix4(g.N3, g.N2 + 1, g.N1, m, kc, j, i);
+          const double b0v = b0x2f[c];
+          const double b1v = copy_b1 ? b0v : b1x2f[c];
+          double b = gam0*b0v + gam1*b1v;
+          b += beta_dt*(s3[q3][ty][tx + 1] - e3p)/dx1;
+          b -= beta_dt*(e1 - e1p)/dx3;
+          b0x2f[c] = b;
+          if (copy_b1) b1x2f[c] = b0v;
+        }
+      }
+    }
+    e1p = e1; e2p = e2; e3p = e3;
+  }
+}
+
 // CT (mhd_ct.cpp:23-80) with CopyCons for B folded in at stage 1 (b1 <- b0 old)
 __global__ void __launch_bounds__(SX*SY)
 k_ct_copy(Geo g, double gam0, double gam1, double beta_dt, const double *__restrict__ e1,
@@ -857,6 +1001,9 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
   auto kA = [&](int s) { return g.ks + s*T; };
   auto kB = [&](int s) { int e = g.ks + (s + 1)*T - 1; return e > g.ke ? g.ke : e; };
   auto corner = [&](int s) -> int {
+#if AKMI_FUSED_CT
+    return AKMI_COMPLETE;                                          // folded into ct(s)
+#endif
     const int k0 = kA(s), nk = kB(s) - kA(s) + 2;                  // edges [kA, kB+1]
     long np = (long)(g.nx2 + 1)*g.N1;
     dim3 grid((unsigned)((np + SX*SY - 1)/(SX*SY)), 1, nk*g.nmb), block(SX, SY);
@@ -868,6 +1015,18 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
   };
   auto ct = [&](int s) -> int {
     const int top = (s == S - 1) ? 1 : 0;
+#if AKMI_FUSED_CT
+    {
+      const int nchunk = cdiv(kB(s) - kA(s) + 1, CKL);
+      dim3 grid(cdiv(g.nx1 + 1, CI - 1), cdiv(g.nx2 + 1, CJ - 1), nchunk*g.nmb), block(CI, CJ);
+      k_corner_ct<<<grid, block, 0, sb>>>(g, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4],
+                                          w.efc[5], w.ecc[0], w.ecc[1], w.ecc[2], w.flx1, w.flx2,
+                                          w.flx3, gam0, gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f,
+                                          b1x2f, b1x3f, copy_u1, kA(s), kB(s), top, nchunk);
+      AKMI_CHECK_LAUNCH("corner_ct");
+      return AKMI_COMPLETE;
+    }
+#endif
     const int k0 = kA(s), nk = kB(s) - kA(s) + 1 + top;
     long npc = (long)(g.je - g.js + 2)*g.N1;
     dim3 grid((unsigned)((npc + SX*SY - 1)/(SX*SY)), 1, nk*g.nmb), block(SX, SY);
