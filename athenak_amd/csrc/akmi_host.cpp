@@ -111,7 +111,8 @@ bool ParameterInput::GetOrAddBoolean(const std::string &b, const std::string &n,
   return d;
 }
 void ParameterInput::SetReal(const std::string &b, const std::string &n, Real v) {
-  char buf[64]; std::snprintf(buf, sizeof(buf), "%.17g", v);
+  // src/parameter_input.cpp:722-731 stores `stringstream << Real`: 6 significant digits
+  char buf[64]; std::snprintf(buf, sizeof(buf), "%g", v);
   blocks_[b][n] = buf;
 }
 

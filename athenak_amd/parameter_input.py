@@ -100,7 +100,10 @@ class ParameterInput:
         return self._get_or_add(blk, name, default, self.GetBoolean)
 
     def SetReal(self, blk, name, val):
-        self.blocks.setdefault(blk, {})[name] = repr(float(val))
+        """src/parameter_input.cpp:722-731: the value is stored as `stringstream << Real`, i.e.
+        with 6 significant digits ("%g").  This is observable: the linear-wave generator passes
+        its rescaled time limit through here (2.999999999997 -> 3, 1.4999999787 -> 1.5)."""
+        self.blocks.setdefault(blk, {})[name] = "%g" % float(val)
 
     def Dump(self):
         """deck text of the current state (ParameterDump of the reference, src/main.cpp:380)"""

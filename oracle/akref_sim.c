@@ -364,7 +364,14 @@ static void pgen_linear_wave(akref_sim *s, int set_ic) {
     r0 = remm[0][lw.wave_flag]; r1 = remm[1][lw.wave_flag]; r2 = remm[2][lw.wave_flag];
     r3 = remm[3][lw.wave_flag]; r4 = remm[4][lw.wave_flag]; evw = evm[lw.wave_flag];
   }
-  if (set_ic) s->tlim = p->tlim*(fabs(lx/evw));
+  if (set_ic) {
+    /* the new time limit travels through ParameterInput::SetReal, i.e. `stringstream << Real`
+     * = 6 significant digits (src/parameter_input.cpp:722-731), before the Driver reads it back:
+     * 2.999999999997 -> 3, 1.4999999787 -> 1.5 */
+    char buf[64];
+    snprintf(buf, sizeof(buf), "%g", p->tlim*(fabs(lx/evw)));
+    s->tlim = strtod(buf, NULL);
+  }
 
   const int nx1 = p->mb_nx1, nx2 = p->mb_nx2, nx3 = p->mb_nx3;
   for (int m = 0; m < s->nmb; ++m) {

@@ -108,22 +108,15 @@ def test_lwave1d_full_matrix(soe, integ):
 
 @pytest.mark.parametrize("rs", ["llf", "hlle", "hllc", "roe", "hlld"])
 def test_plm_left_right_wave_errors_equal_every_solver(rs):
-    """test_nr_lwave1d_cpu.py:155-160 inside the loop over Riemann solvers.  The reference
-    compares the values as printed with %e (7 significant digits).  Hydro: the strings are
-    equal.  MHD: the oracle's L/R errors agree to <= 4e-8 relative (round-off of a scheme that
-    is mirror-symmetric only in exact arithmetic), which is below the resolution of the
-    reference's comparison but can straddle a %e rounding boundary (hlle+rk2:
-    2.4485835777e-08 vs 2.4485834964e-08), so the MHD check is made at 1e-7 relative."""
+    """test_nr_lwave1d_cpu.py:155-160 inside the loop over Riemann solvers: the values as printed
+    with %e (7 significant digits) are equal for the left- and right-going wave"""
     for is_mhd, (wl, wr) in ((0, (0, 4)), (1, (0, 6))):
         if (rs in ("hllc", "roe") and is_mhd) or (rs == "hlld" and not is_mhd):
             continue
         for nst in (2, 3):
             a, _ = lwave1d(is_mhd, 64, wl, nst=nst, rsolver=rs)
             b, _ = lwave1d(is_mhd, 64, wr, nst=nst, rsolver=rs)
-            if is_mhd:
-                assert abs(a[0] - b[0]) <= 1e-7*a[0]
-            else:
-                assert "%e" % a[0] == "%e" % b[0]
+            assert "%e" % a[0] == "%e" % b[0]
 
 
 def _rj2a_error(res, recon, rs):
@@ -171,14 +164,17 @@ def test_rj2a_shock_tube_convergence(recon, rs):
     assert e256/e128 <= 0.6, (recon, rs, e128, e256)
 
 
-def test_mhd_lwave1d_close_to_recorded_reference_value():
-    """BASELINE.md 2b records 8.812266e-08 / 2.448591e-08 for MHD+HLLD.  The oracle gives
-    8.812260e-08 / 2.448581e-08: equal to 5 digits (4e-6 relative), see DESIGN.md
-    'Oracle pinning' for the discussion of the 6th digit."""
-    e32, _ = lwave1d(1, 32, 0)
-    e64, _ = lwave1d(1, 64, 0)
-    assert abs(e32[0]/8.812266e-08 - 1.0) < 1e-5
-    assert abs(e64[0]/2.448591e-08 - 1.0) < 1e-5
+@pytest.mark.parametrize("wave", [0, 6])
+def test_mhd_lwave1d_reference_numbers(wave):
+    """the reference prints RMS-L1 = 8.812266e-08 (N=32) and 2.448591e-08 (N=64)
+    for MHD + HLLD, identical for waves 0 and 6.  Reproducing the 6th and 7th digit needs the
+    reference's 6-significant-digit round trip of the rescaled time limit through
+    ParameterInput::SetReal (parameter_input.cpp:722-731: 1.4999999787 -> "1.5"); without it the
+    run stops 2e-8 early and the numbers read 8.812260e-08 / 2.448581e-08."""
+    e32, _ = lwave1d(1, 32, wave)
+    e64, _ = lwave1d(1, 64, wave)
+    assert "%.6e" % e32[0] == "8.812266e-08"
+    assert "%.6e" % e64[0] == "2.448591e-08"
 
 
 def sod_error(res, recon="plm"):

@@ -101,7 +101,7 @@ def test_reference_readers_parse_the_files():
     e = athena_read.error_dat(os.path.join(GOLD, "lwave_hydro", "LinWave-errs.dat"))
     assert e.shape == (1, 11) and "%.6e" % e[0][4] == "7.390252e-08" and int(e[0][0]) == 32
     e = athena_read.error_dat(os.path.join(GOLD, "lwave_mhd", "LinWave-errs.dat"))
-    assert e.shape == (1, 14) and "%.6e" % e[0][4] == "8.812260e-08"
+    assert e.shape == (1, 14) and "%.6e" % e[0][4] == "8.812266e-08"
     # --- bin: the reference's reader returns per-MeshBlock float32 arrays
     b = bin_convert.read_binary(os.path.join(GOLD, "ot", "bin", "OrszagTang.mhd_bcc.00000.bin"))
     assert b["var_names"] == ["bcc1", "bcc2", "bcc3"] and b["n_mbs"] == 4 and b["cycle"] == 0
