@@ -214,7 +214,7 @@ def main():
         # workload in a separate profiling run
         t = json.load(open(tfile))
         stage_kernels = [k for k in t["kernels"] if k.startswith("akmi::k_sweep") or
-                         k.startswith("akmi::k_corner3") or k.startswith("akmi::k_ct_copy") or
+                         k.startswith("akmi::k_corner") or k.startswith("akmi::k_ct_copy") or
                          k.startswith("akmi::k_c2p_newdt")]
         traffic = round(sum(t["kernels"][k]["hbm_bytes_per_launch"] for k in stage_kernels))
         tsrc = "profiles/pmc_traffic_latest.json (%s)" % t.get("tag", "")
