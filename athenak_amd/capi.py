@@ -23,7 +23,8 @@ class Pack(C.Structure):
     _fields_ = [("nmb", C.c_int), ("nvar", C.c_int), ("nx1", C.c_int), ("nx2", C.c_int),
                 ("nx3", C.c_int), ("ng", C.c_int), ("dx", C.c_void_p),
                 ("gamma", C.c_double), ("dfloor", C.c_double), ("pfloor", C.c_double),
-                ("tfloor", C.c_double), ("sfloor", C.c_double), ("sigma_max", C.c_double)]
+                ("tfloor", C.c_double), ("sfloor", C.c_double), ("sigma_max", C.c_double),
+                ("iso_cs", C.c_double), ("is_ideal", C.c_int)]
 
 
 PHASE_SWEEPS, PHASE_EMF_CT, PHASE_C2P, PHASE_ALL = 1, 2, 4, 7     # AKMI_PHASE_* of include/akmi.h

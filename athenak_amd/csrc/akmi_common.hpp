@@ -38,12 +38,15 @@ inline Eos make_eos(const akmi_pack *p) {
   Eos e;
   e.gamma = p->gamma; e.dfloor = p->dfloor; e.pfloor = p->pfloor; e.tfloor = p->tfloor;
   e.sfloor = p->sfloor; e.sigma_max = p->sigma_max;
+  e.iso_cs = p->iso_cs; e.is_ideal = p->is_ideal;
   return e;
 }
 
 inline FaceEos make_face_eos(const akmi_pack *p) {
   FaceEos e;
-  e.gamma = p->gamma; e.dfloor = p->dfloor; e.efloor = p->pfloor/(p->gamma - 1.0);
+  e.gamma = p->gamma; e.dfloor = p->dfloor;
+  e.efloor = p->is_ideal ? p->pfloor/(p->gamma - 1.0) : 0.0;
+  e.iso_cs = p->iso_cs;
   return e;
 }
 
@@ -55,6 +58,7 @@ void set_error(const char *fmt, ...);
 struct Scheme {
   int recon, rsolver;
   FaceEos eos;
+  bool iso = false;       // EOS_Data::is_ideal == false (task-granular kernels only)
 };
 template <int V> using IC = std::integral_constant<int, V>;
 
@@ -96,6 +100,11 @@ inline int dispatch_scheme(const Scheme &sc, F &&f) {
 }
 
 inline int check_scheme(const akmi_pack *p, int recon, const char *who) {
+  if (p->nvar != (p->is_ideal ? 5 : 4)) {
+    set_error("%s: nvar = %d does not match the EOS (5 ideal gas, 4 isothermal; passive scalars "
+              "are not on this path)", who, p->nvar);
+    return AKMI_FAIL;
+  }
   if (recon >= AKMI_RECON_PPM4 && recon <= AKMI_RECON_TENO && p->ng < 3) {
     // hydro.cpp:173-179: the +/-2 stencil requires at least 3 ghost zones
     set_error("%s: ppm4/ppmx/wenoz/teno need nghost>=3", who);

@@ -338,6 +338,7 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
   pack_c.dx = pp->pmb->d_dx.p;
   pack_c.gamma = e.gamma; pack_c.dfloor = e.dfloor; pack_c.pfloor = e.pfloor;
   pack_c.tfloor = e.tfloor; pack_c.sfloor = e.sfloor; pack_c.sigma_max = e.sigma_max;
+  pack_c.iso_cs = 0.0; pack_c.is_ideal = 1;     // isothermal runs: Python host (task-granular kernels)
   const size_t n1 = ind.nx1 + 2*ind.ng, n2 = ind.nx2 > 1 ? ind.nx2 + 2*ind.ng : 1,
                n3 = ind.nx3 > 1 ? ind.nx3 + 2*ind.ng : 1;
   const size_t ncc = static_cast<size_t>(pp->nmb_thispack)*5*n3*n2*n1;

@@ -158,7 +158,7 @@ AKMI_DEV void teno(double qm2, double qm1, double q, double qp1, double qp2, dou
 
 // what the flux kernels need of EOS_Data: gamma and the floors of the L/R states
 // (recon.hpp:52-53: dfloor, efloor = pfloor/(gamma-1))
-struct FaceEos { double gamma, dfloor, efloor; };
+struct FaceEos { double gamma, dfloor, efloor, iso_cs; };
 
 // five-point reconstructions behind one name.  RECON: 2 ppm4, 3 ppmx, 4 wenoz, 5 teno
 template <int RECON>
@@ -802,9 +802,341 @@ AKMI_DEV Cons1D riemann_mhd(double gamma, double ld, double lx, double ly, doubl
   else return hlld(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
 }
 
-// EOS_Data by value (src/eos/eos.hpp:27-34), ideal gas only on this path
+// ---- isothermal EOS (EOS_Data::is_ideal == false): the same source lines as the ideal-gas
+// functions above, with the branches the reference takes when there is no energy equation.
+// States (d, vx, vy, vz[, by, bz]); the energy slots of the common signatures are ignored.
+AKMI_DEV void llf_hyd_iso(double cs, double ld, double lx, double ly, double lz, double rd,
+                          double rx, double ry, double rz, double &f_d, double &f_mx, double &f_my,
+                          double &f_mz) {
+  double qa = ld*lx;
+  double qb = rd*rx;
+  double s_d = qa + qb;
+  double s_mx = qa*lx + qb*rx;
+  double s_my = qa*ly + qb*ry;
+  double s_mz = qa*lz + qb*rz;
+  s_mx += sqr(cs)*(ld + rd);
+  double a = fmax((fabs(lx) + cs), (fabs(rx) + cs));
+  f_d = 0.5*(s_d - a*(rd - ld));
+  f_mx = 0.5*(s_mx - a*(rd*rx - ld*lx));
+  f_my = 0.5*(s_my - a*(rd*ry - ld*ly));
+  f_mz = 0.5*(s_mz - a*(rd*rz - ld*lz));
+}
+
+AKMI_DEV void hlle_hyd_iso(double iso_cs, double dl, double ul, double vl, double zl, double dr,
+                           double ur, double vr, double zr, double &f_d, double &f_mx,
+                           double &f_my, double &f_mz) {
+  double sqrtdl = sqrt(dl);
+  double sqrtdr = sqrt(dr);
+  double isdlpdr = 1.0/(sqrtdl + sqrtdr);
+  double roe_vx = (sqrtdl*ul + sqrtdr*ur)*isdlpdr;
+  double al = fmin((roe_vx - iso_cs), (ul - iso_cs));
+  double ar = fmax((roe_vx + iso_cs), (ur + iso_cs));
+  double bp = (ar > 0.0) ? ar : 1.0e-20;
+  double bm = (al < 0.0) ? al : -1.0e-20;
+  double qa = ul - bm;
+  double qb = ur - bp;
+  double fl_d = dl*qa, fr_d = dr*qb;
+  double fl_mx = dl*ul*qa, fr_mx = dr*ur*qb;
+  double fl_my = dl*vl*qa, fr_my = dr*vr*qb;
+  double fl_mz = dl*zl*qa, fr_mz = dr*zr*qb;
+  fl_mx += (iso_cs*iso_cs)*dl;
+  fr_mx += (iso_cs*iso_cs)*dr;
+  qa = 0.0;
+  if (bp != bm) qa = 0.5*(bp + bm)/(bp - bm);
+  f_d = 0.5*(fl_d + fr_d) + qa*(fl_d - fr_d);
+  f_mx = 0.5*(fl_mx + fr_mx) + qa*(fl_mx - fr_mx);
+  f_my = 0.5*(fl_my + fr_my) + qa*(fl_my - fr_my);
+  f_mz = 0.5*(fl_mz + fr_mz) + qa*(fl_mz - fr_mz);
+}
+
+// roe_hyd.hpp:40-181 with RoeFluxIso (:275-346)
+AKMI_DEV void roe_hyd_iso(double iso_cs, double ld, double lx, double ly, double lz, double rd,
+                          double rx, double ry, double rz, double &f_d, double &f_mx, double &f_my,
+                          double &f_mz) {
+  double wl[4] = {ld, lx, ly, lz}, wr[4] = {rd, rx, ry, rz};
+  double fl[4], fr[4], du[4], ev[4], f[4];
+  double sqrtdl = sqrt(wl[0]);
+  double sqrtdr = sqrt(wr[0]);
+  double isdlpdr = 1.0/(sqrtdl + sqrtdr);
+  double v1 = (sqrtdl*wl[1] + sqrtdr*wr[1])*isdlpdr;
+  double v2 = (sqrtdl*wl[2] + sqrtdr*wr[2])*isdlpdr;
+  double v3 = (sqrtdl*wl[3] + sqrtdr*wr[3])*isdlpdr;
+  double mxl = wl[0]*wl[1];
+  double mxr = wr[0]*wr[1];
+  fl[0] = mxl;           fr[0] = mxr;
+  fl[1] = mxl*wl[1];     fr[1] = mxr*wr[1];
+  fl[2] = mxl*wl[2];     fr[2] = mxr*wr[2];
+  fl[3] = mxl*wl[3];     fr[3] = mxr*wr[3];
+  fl[1] += (iso_cs*iso_cs)*wl[0];
+  fr[1] += (iso_cs*iso_cs)*wr[0];
+  du[0] = wr[0] - wl[0];
+  du[1] = wr[0]*wr[1] - wl[0]*wl[1];
+  du[2] = wr[0]*wr[2] - wl[0]*wl[2];
+  du[3] = wr[0]*wr[3] - wl[0]*wl[3];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) f[n] = 0.5*(fl[n] + fr[n]);
+  bool llf_flag = false;
+  {
+    ev[0] = v1 - iso_cs; ev[1] = v1; ev[2] = v1; ev[3] = v1 + iso_cs;
+    double a[4];
+    a[0]  = du[0]*(0.5 + 0.5*v1/iso_cs);
+    a[0] -= du[1]*0.5/iso_cs;
+    a[1]  = du[0]*(-v2);
+    a[1] += du[2];
+    a[2]  = du[0]*(-v3);
+    a[2] += du[3];
+    a[3]  = du[0]*(0.5 - 0.5*v1/iso_cs);
+    a[3] += du[1]*0.5/iso_cs;
+    double co[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) co[n] = -0.5*fabs(ev[n])*a[n];
+    double dens = wl[0] + a[0];
+    if (dens < 0.0) llf_flag = true;
+    dens += a[3];
+    if (dens < 0.0) llf_flag = true;
+    f[0] += co[0];
+    f[0] += co[3];
+    f[1] += co[0]*(v1 - iso_cs);
+    f[1] += co[3]*(v1 + iso_cs);
+    f[2] += co[0]*v2;
+    f[2] += co[1];
+    f[2] += co[3]*v2;
+    f[3] += co[0]*v3;
+    f[3] += co[2];
+    f[3] += co[3]*v3;
+  }
+  if (ev[0] >= 0.0) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) f[n] = fl[n];
+  }
+  if (ev[3] <= 0.0) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) f[n] = fr[n];
+  }
+  if (llf_flag) {
+    double a = 0.5*fmax((fabs(wl[1]) + iso_cs), (fabs(wr[1]) + iso_cs));
+#pragma unroll
+    for (int n = 0; n < 4; ++n) f[n] = 0.5*(fl[n] + fr[n]) - a*du[n];
+  }
+  f_d = f[0]; f_mx = f[1]; f_my = f[2]; f_mz = f[3];
+}
+
+// RS as in riemann_hyd (hllc does not exist for the isothermal EOS)
+template <int RS>
+AKMI_DEV void riemann_hyd_iso(double cs, double ld, double lx, double ly, double lz, double rd,
+                              double rx, double ry, double rz, double &f_d, double &f_mx,
+                              double &f_my, double &f_mz) {
+  if constexpr (RS == 0) llf_hyd_iso(cs, ld, lx, ly, lz, rd, rx, ry, rz, f_d, f_mx, f_my, f_mz);
+  else if constexpr (RS == 1) hlle_hyd_iso(cs, ld, lx, ly, lz, rd, rx, ry, rz, f_d, f_mx, f_my, f_mz);
+  else roe_hyd_iso(cs, ld, lx, ly, lz, rd, rx, ry, rz, f_d, f_mx, f_my, f_mz);
+}
+
+// isothermal fast speed, src/eos/eos.hpp:60-68
+AKMI_DEV double fast_speed_iso(double cs, double d, double bx, double by, double bz) {
+  double asq = (cs*cs)*d;
+  double ct2 = by*by + bz*bz;
+  double qsq = bx*bx + ct2 + asq;
+  double tmp = bx*bx + ct2 - asq;
+  return sqrt(0.5*(qsq + sqrt(tmp*tmp + 4.0*asq*ct2))/d);
+}
+
+AKMI_DEV Cons1D llf_mhd_iso(double cs, double ld, double lx, double ly, double lz, double lby,
+                            double lbz, double rd, double rx, double ry, double rz, double rby,
+                            double rbz, double bxi) {
+  double qa = ld*lx;
+  double qb = rd*rx;
+  double qc = 0.5*(sqr(lby) + sqr(lbz) - sqr(bxi));
+  double qd = 0.5*(sqr(rby) + sqr(rbz) - sqr(bxi));
+  double s_d = qa + qb;
+  double s_mx = qa*lx + qb*rx + qc + qd;
+  double s_my = qa*ly + qb*ry - bxi*(lby + rby);
+  double s_mz = qa*lz + qb*rz - bxi*(lbz + rbz);
+  double s_by = lby*lx + rby*rx - bxi*(ly + ry);
+  double s_bz = lbz*lx + rbz*rx - bxi*(lz + rz);
+  s_mx += sqr(cs)*(ld + rd);
+  qa = fast_speed_iso(cs, ld, bxi, lby, lbz);
+  qb = fast_speed_iso(cs, rd, bxi, rby, rbz);
+  double a = fmax((fabs(lx) + qa), (fabs(rx) + qb));
+  Cons1D f;
+  f.d = 0.5*(s_d - a*(rd - ld));
+  f.mx = 0.5*(s_mx - a*(rd*rx - ld*lx));
+  f.my = 0.5*(s_my - a*(rd*ry - ld*ly));
+  f.mz = 0.5*(s_mz - a*(rd*rz - ld*lz));
+  f.e = 0.0;
+  f.by = 0.5*(s_by - a*(rby - lby));
+  f.bz = 0.5*(s_bz - a*(rbz - lbz));
+  return f;
+}
+
+AKMI_DEV Cons1D hlle_mhd_iso(double iso_cs, double dl, double ul, double vl, double zl,
+                             double byl, double bzl, double dr, double ur, double vr, double zr,
+                             double byr, double bzr, double bxi) {
+  double sqrtdl = sqrt(dl);
+  double sqrtdr = sqrt(dr);
+  double isdlpdr = 1.0/(sqrtdl + sqrtdr);
+  double roe_d = sqrtdl*sqrtdr;
+  double roe_vx = (sqrtdl*ul + sqrtdr*ur)*isdlpdr;
+  double roe_by = (sqrtdr*byl + sqrtdl*byr)*isdlpdr;
+  double roe_bz = (sqrtdr*bzl + sqrtdl*bzr)*isdlpdr;
+  double x = 0.5*(sqr(byl - byr) + sqr(bzl - bzr))/(sqr(sqrtdl + sqrtdr));
+  double y = 0.5*(dl + dr)/roe_d;
+  double pbl = 0.5*(bxi*bxi + sqr(byl) + sqr(bzl));
+  double pbr = 0.5*(bxi*bxi + sqr(byr) + sqr(bzr));
+  double cl = fast_speed_iso(iso_cs, dl, bxi, byl, bzl);
+  double cr = fast_speed_iso(iso_cs, dr, bxi, byr, bzr);
+  double btsq = sqr(roe_by) + sqr(roe_bz);
+  double vaxsq = bxi*bxi/roe_d;
+  double bt_starsq = btsq*y;
+  double twid_asq = iso_cs*iso_cs + x;
+  double ct2 = bt_starsq/roe_d;
+  double tsum = vaxsq + ct2 + twid_asq;
+  double tdif = vaxsq + ct2 - twid_asq;
+  double cf2_cs2 = sqrt(tdif*tdif + 4.0*twid_asq*ct2);
+  double cfsq = 0.5*(tsum + cf2_cs2);
+  double a = sqrt(cfsq);
+  double al = fmin((roe_vx - a), (ul - cl));
+  double ar = fmax((roe_vx + a), (ur + cr));
+  double bp = ar > 0.0 ? ar : 1.0e-20;
+  double bm = al < 0.0 ? al : -1.0e-20;
+  double vxl = ul - bm;
+  double vxr = ur - bp;
+  double fl_d = dl*vxl, fr_d = dr*vxr;
+  double fl_mx = dl*ul*vxl + pbl - sqr(bxi);
+  double fr_mx = dr*ur*vxr + pbr - sqr(bxi);
+  double fl_my = dl*vl*vxl - bxi*byl;
+  double fr_my = dr*vr*vxr - bxi*byr;
+  double fl_mz = dl*zl*vxl - bxi*bzl;
+  double fr_mz = dr*zr*vxr - bxi*bzr;
+  fl_mx += (iso_cs*iso_cs)*dl;
+  fr_mx += (iso_cs*iso_cs)*dr;
+  double fl_by = byl*vxl - bxi*vl;
+  double fr_by = byr*vxr - bxi*vr;
+  double fl_bz = bzl*vxl - bxi*zl;
+  double fr_bz = bzr*vxr - bxi*zr;
+  double tmp = 0.0;
+  if (bp != bm) tmp = 0.5*(bp + bm)/(bp - bm);
+  Cons1D f;
+  f.d = 0.5*(fl_d + fr_d) + (fl_d - fr_d)*tmp;
+  f.mx = 0.5*(fl_mx + fr_mx) + (fl_mx - fr_mx)*tmp;
+  f.my = 0.5*(fl_my + fr_my) + (fl_my - fr_my)*tmp;
+  f.mz = 0.5*(fl_mz + fr_mz) + (fl_mz - fr_mz)*tmp;
+  f.e = 0.0;
+  f.by = 0.5*(fl_by + fr_by) + (fl_by - fr_by)*tmp;
+  f.bz = 0.5*(fl_bz + fr_bz) + (fl_bz - fr_bz)*tmp;
+  return f;
+}
+
+// isothermal HLLD (Mignone 2007), src/mhd/rsolvers/hlld_mhd.hpp:349-545
+AKMI_DEV Cons1D hlld_iso(double iso_cs, double dfloor_, double wl_idn, double wl_ivx, double wl_ivy,
+                         double wl_ivz, double wl_iby, double wl_ibz, double wr_idn, double wr_ivx,
+                         double wr_ivy, double wr_ivz, double wr_iby, double wr_ibz, double bxi) {
+  constexpr double SMALL = 1.0e-4;
+  double ul_d = wl_idn, ul_mx = wl_ivx*ul_d, ul_my = wl_ivy*ul_d, ul_mz = wl_ivz*ul_d;
+  double ul_by = wl_iby, ul_bz = wl_ibz;
+  double ur_d = wr_idn, ur_mx = wr_ivx*ur_d, ur_my = wr_ivy*ur_d, ur_mz = wr_ivz*ur_d;
+  double ur_by = wr_iby, ur_bz = wr_ibz;
+  double cfl = fast_speed_iso(iso_cs, wl_idn, bxi, wl_iby, wl_ibz);
+  double cfr = fast_speed_iso(iso_cs, wr_idn, bxi, wr_iby, wr_ibz);
+  double spd0 = fmin(wl_ivx - cfl, wr_ivx - cfr);
+  double spd4 = fmax(wl_ivx + cfl, wr_ivx + cfr);
+  double bxsq = bxi*bxi;
+  double ptl = sqr(iso_cs)*wl_idn + 0.5*(bxsq + sqr(wl_iby) + sqr(wl_ibz));
+  double ptr = sqr(iso_cs)*wr_idn + 0.5*(bxsq + sqr(wr_iby) + sqr(wr_ibz));
+  double fl_d = ul_mx;
+  double fl_mx = ul_mx*wl_ivx + ptl - bxsq;
+  double fl_my = ul_my*wl_ivx - bxi*ul_by;
+  double fl_mz = ul_mz*wl_ivx - bxi*ul_bz;
+  double fl_by = ul_by*wl_ivx - bxi*wl_ivy;
+  double fl_bz = ul_bz*wl_ivx - bxi*wl_ivz;
+  double fr_d = ur_mx;
+  double fr_mx = ur_mx*wr_ivx + ptr - bxsq;
+  double fr_my = ur_my*wr_ivx - bxi*ur_by;
+  double fr_mz = ur_mz*wr_ivx - bxi*ur_bz;
+  double fr_by = ur_by*wr_ivx - bxi*wr_ivy;
+  double fr_bz = ur_bz*wr_ivx - bxi*wr_ivz;
+  double idspd = 1.0/(spd4 - spd0);
+  double dhll = (spd4*ur_d - spd0*ul_d - fr_d + fl_d)*idspd;
+  dhll = fmax(dhll, dfloor_);
+  double sqrtdhll = sqrt(dhll);
+  double fdhll = (spd4*fl_d - spd0*fr_d + spd4*spd0*(ur_d - ul_d))*idspd;
+  double fmxhll = (spd4*fl_mx - spd0*fr_mx + spd4*spd0*(ur_mx - ul_mx))*idspd;
+  double ustar = fdhll/dhll;
+  double mxhll = (spd4*ur_mx - spd0*ul_mx - fr_mx + fl_mx)*idspd;
+  double spd1 = ustar - fabs(bxi)/sqrtdhll;
+  double spd3 = ustar + fabs(bxi)/sqrtdhll;
+  double ulst_my, ulst_mz, ulst_by, ulst_bz, urst_my, urst_mz, urst_by, urst_bz;
+  double tmp = (spd0 - spd1)*(spd0 - spd3);
+  if (fabs(spd0 - spd1) < (SMALL)*iso_cs) {
+    ulst_my = ul_my; ulst_mz = ul_mz; ulst_by = ul_by; ulst_bz = ul_bz;
+  } else {
+    double mfact = bxi*(ustar - wl_ivx)/tmp;
+    double bfact = (ul_d*sqr(spd0 - wl_ivx) - bxsq)/(dhll*tmp);
+    ulst_my = dhll*wl_ivy - ul_by*mfact;
+    ulst_mz = dhll*wl_ivz - ul_bz*mfact;
+    ulst_by = ul_by*bfact;
+    ulst_bz = ul_bz*bfact;
+  }
+  tmp = (spd4 - spd1)*(spd4 - spd3);
+  if (fabs(spd4 - spd3) < (SMALL)*iso_cs) {
+    urst_my = ur_my; urst_mz = ur_mz; urst_by = ur_by; urst_bz = ur_bz;
+  } else {
+    double mfact = bxi*(ustar - wr_ivx)/tmp;
+    double bfact = (ur_d*sqr(spd4 - wr_ivx) - bxsq)/(dhll*tmp);
+    urst_my = dhll*wr_ivy - ur_by*mfact;
+    urst_mz = dhll*wr_ivz - ur_bz*mfact;
+    urst_by = ur_by*bfact;
+    urst_bz = ur_bz*bfact;
+  }
+  double x = sqrtdhll*(bxi > 0.0 ? 1.0 : -1.0);
+  double ucst_d = dhll;
+  double ucst_my = 0.5*(ulst_my + urst_my + (urst_by - ulst_by)*x);
+  double ucst_mz = 0.5*(ulst_mz + urst_mz + (urst_bz - ulst_bz)*x);
+  double ucst_by = 0.5*(ulst_by + urst_by + (urst_my - ulst_my)/x);
+  double ucst_bz = 0.5*(ulst_bz + urst_bz + (urst_mz - ulst_mz)/x);
+  Cons1D f;
+  f.e = 0.0;
+  if (spd0 >= 0.0) {
+    f.d = fl_d; f.mx = fl_mx; f.my = fl_my; f.mz = fl_mz; f.by = fl_by; f.bz = fl_bz;
+  } else if (spd4 <= 0.0) {
+    f.d = fr_d; f.mx = fr_mx; f.my = fr_my; f.mz = fr_mz; f.by = fr_by; f.bz = fr_bz;
+  } else if (spd1 >= 0.0) {
+    f.d = fl_d + spd0*(dhll - ul_d);
+    f.mx = fl_mx + spd0*(mxhll - ul_mx);
+    f.my = fl_my + spd0*(ulst_my - ul_my);
+    f.mz = fl_mz + spd0*(ulst_mz - ul_mz);
+    f.by = fl_by + spd0*(ulst_by - ul_by);
+    f.bz = fl_bz + spd0*(ulst_bz - ul_bz);
+  } else if (spd3 <= 0.0) {
+    f.d = fr_d + spd4*(dhll - ur_d);
+    f.mx = fr_mx + spd4*(mxhll - ur_mx);
+    f.my = fr_my + spd4*(urst_my - ur_my);
+    f.mz = fr_mz + spd4*(urst_mz - ur_mz);
+    f.by = fr_by + spd4*(urst_by - ur_by);
+    f.bz = fr_bz + spd4*(urst_bz - ur_bz);
+  } else {
+    f.d = dhll*ustar;
+    f.mx = fmxhll;
+    f.my = ucst_my*ustar - bxi*ucst_by;
+    f.mz = ucst_mz*ustar - bxi*ucst_bz;
+    f.by = ucst_by*ustar - bxi*ucst_my/ucst_d;
+    f.bz = ucst_bz*ustar - bxi*ucst_mz/ucst_d;
+  }
+  return f;
+}
+
+template <int RS>
+AKMI_DEV Cons1D riemann_mhd_iso(const FaceEos &eos, double ld, double lx, double ly, double lz,
+                                double lby, double lbz, double rd, double rx, double ry, double rz,
+                                double rby, double rbz, double bxi) {
+  if constexpr (RS == 0) return llf_mhd_iso(eos.iso_cs, ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
+  else if constexpr (RS == 1) return hlle_mhd_iso(eos.iso_cs, ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
+  else return hlld_iso(eos.iso_cs, eos.dfloor, ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
+}
+
+// EOS_Data by value (src/eos/eos.hpp:27-34)
 struct Eos {
-  double gamma, dfloor, pfloor, tfloor, sfloor, sigma_max;
+  double gamma, dfloor, pfloor, tfloor, sfloor, sigma_max, iso_cs;
+  int is_ideal;
 };
 
 // Entropy-floor predicate of SingleC2P_Ideal* (src/eos/ideal_c2p_hyd.hpp:57-63):

@@ -23,7 +23,7 @@ constexpr int BX = 64, BY = 4;
 
 // ---------------------------------------------------------------------------------------
 // Hydro fluxes: reconstruct in registers + Riemann solver RS.  hydro_fluxes.cpp:77-229.
-template <int DIR, int RECON, int RS>
+template <int DIR, int RECON, int RS, bool ISO>
 __global__ void __launch_bounds__(BX*BY)
 k_hydro_flux(Geo g, FaceEos eos, const double *__restrict__ w0, double *__restrict__ flx,
              int f3, int f2, int f1, int il, int iu, int jl, int ju, int kl, int nk) {
@@ -41,12 +41,18 @@ k_hydro_flux(Geo g, FaceEos eos, const double *__restrict__ w0, double *__restri
   face_states<RECON, 0>(q + ivx*cs, s, eos, lx, rx);
   face_states<RECON, 0>(q + ivy*cs, s, eos, ly, ry);
   face_states<RECON, 0>(q + ivz*cs, s, eos, lz, rz);
-  face_states<RECON, 2>(q + 4*cs, s, eos, le, re);
-  double fd, fx, fy, fz, fe;
-  riemann_hyd<RS>(eos.gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, fd, fx, fy, fz, fe);
+  double fd, fx, fy, fz, fe = 0.0;
+  if constexpr (ISO) {                      // no energy variable: g.nvar == 4
+    le = re = 0.0;
+    riemann_hyd_iso<RS>(eos.iso_cs, ld, lx, ly, lz, rd, rx, ry, rz, fd, fx, fy, fz);
+  } else {
+    face_states<RECON, 2>(q + 4*cs, s, eos, le, re);
+    riemann_hyd<RS>(eos.gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, fd, fx, fy, fz, fe);
+  }
   const size_t fs = (size_t)f3*f2*f1;
   double *f = flx + ix5(g.nvar, f3, f2, f1, m, 0, k, j, i);
-  f[0] = fd; f[ivx*fs] = fx; f[ivy*fs] = fy; f[ivz*fs] = fz; f[4*fs] = fe;
+  f[0] = fd; f[ivx*fs] = fx; f[ivy*fs] = fy; f[ivz*fs] = fz;
+  if constexpr (!ISO) f[4*fs] = fe;
 }
 
 template <int DIR>
@@ -60,8 +66,12 @@ static int launch_hydro_flux(const Geo &g, const Scheme &sc, const double *w0,
   int nk = ku - kl + 1;
   dim3 grid(cdiv(iu - il + 1, BX), cdiv(ju - jl + 1, BY), nk*g.nmb), block(BX, BY);
   int rc = dispatch_scheme<false>(sc, [&](auto R, auto S) {
-    k_hydro_flux<DIR, decltype(R)::value, decltype(S)::value><<<grid, block, 0, st>>>(
-        g, sc.eos, w0, flx, f3, f2, f1, il, iu, jl, ju, kl, nk);
+    if (sc.iso)
+      k_hydro_flux<DIR, decltype(R)::value, decltype(S)::value, true><<<grid, block, 0, st>>>(
+          g, sc.eos, w0, flx, f3, f2, f1, il, iu, jl, ju, kl, nk);
+    else
+      k_hydro_flux<DIR, decltype(R)::value, decltype(S)::value, false><<<grid, block, 0, st>>>(
+          g, sc.eos, w0, flx, f3, f2, f1, il, iu, jl, ju, kl, nk);
     return AKMI_COMPLETE;
   });
   if (rc != AKMI_COMPLETE) return rc;
@@ -112,19 +122,34 @@ k_c2p(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ bx1f,
   if (i > iu || j > ju) return;
   const size_t cs = (size_t)g.N3*g.N2*g.N1;
   const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
+  double ubx = 0.0, uby = 0.0, ubz = 0.0;
+  if constexpr (MHD) {
+    ubx = 0.5*(bx1f[ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i)] +
+               bx1f[ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i + 1)]);
+    uby = 0.5*(bx2f[ix4(g.N3, g.N2 + 1, g.N1, m, k, j, i)] +
+               bx2f[ix4(g.N3, g.N2 + 1, g.N1, m, k, j + 1, i)]);
+    ubz = 0.5*(bx3f[ix4(g.N3 + 1, g.N2, g.N1, m, k, j, i)] +
+               bx3f[ix4(g.N3 + 1, g.N2, g.N1, m, k + 1, j, i)]);
+    const size_t b = ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i);
+    bcc0[b] = ubx; bcc0[b + cs] = uby; bcc0[b + 2*cs] = ubz;
+  }
+  if (!eos.is_ideal) {
+    // SingleC2P_IsothermalHyd / _IsothermalMHD (isothermal_hyd.cpp:30-45, isothermal_mhd.cpp:32-47,
+    // density floor fmax(dfloor, b^2/sigma_max) :104-106): no energy variable (g.nvar == 4)
+    double ud = u0[c];
+    double dfloor_ = eos.dfloor;
+    if constexpr (MHD) dfloor_ = fmax(eos.dfloor, (sqr(ubx) + sqr(uby) + sqr(ubz))/eos.sigma_max);
+    if (ud < dfloor_) { ud = dfloor_; u0[c] = ud; atomicAdd(&counters[0], 1); }
+    const double di = 1.0/ud;
+    w0[c] = ud; w0[c + cs] = di*u0[c + cs]; w0[c + 2*cs] = di*u0[c + 2*cs];
+    w0[c + 3*cs] = di*u0[c + 3*cs];
+    return;
+  }
   double ud = u0[c], umx = u0[c + cs], umy = u0[c + 2*cs], umz = u0[c + 3*cs], ue = u0[c + 4*cs];
   double wd, wvx, wvy, wvz, we;
   bool dfl = false, efl = false, tfl = false;
   if constexpr (MHD) {
-    double ubx = 0.5*(bx1f[ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i)] +
-                      bx1f[ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i + 1)]);
-    double uby = 0.5*(bx2f[ix4(g.N3, g.N2 + 1, g.N1, m, k, j, i)] +
-                      bx2f[ix4(g.N3, g.N2 + 1, g.N1, m, k, j + 1, i)]);
-    double ubz = 0.5*(bx3f[ix4(g.N3 + 1, g.N2, g.N1, m, k, j, i)] +
-                      bx3f[ix4(g.N3 + 1, g.N2, g.N1, m, k + 1, j, i)]);
     c2p_mhd(eos, ud, umx, umy, umz, ue, ubx, uby, ubz, wd, wvx, wvy, wvz, we, dfl, efl, tfl);
-    const size_t b = ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i);
-    bcc0[b] = ubx; bcc0[b + cs] = uby; bcc0[b + 2*cs] = ubz;
   } else {
     c2p_hyd(eos, ud, umx, umy, umz, ue, wd, wvx, wvy, wvz, we, dfl, efl, tfl);
   }
@@ -159,14 +184,28 @@ __device__ __forceinline__ void block_min3_atomic(double a, double b, double c,
 }
 
 template <bool MHD>
-__device__ __forceinline__ void cell_dt(const Geo &g, double gamma, const double *__restrict__ w0,
+__device__ __forceinline__ void cell_dt(const Geo &g, const Eos &eos, const double *__restrict__ w0,
                                         const double *__restrict__ bcc0, int m, int k, int j,
                                         int i, double &d1, double &d2, double &d3) {
+  const double gamma = eos.gamma;
   const size_t cs = (size_t)g.N3*g.N2*g.N1;
   const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
   double wd = w0[c], vx = w0[c + cs], vy = w0[c + 2*cs], vz = w0[c + 3*cs];
-  double pr = (gamma - 1.0)*w0[c + 4*cs];
   double mv1, mv2, mv3;
+  if (!eos.is_ideal) {                     // hydro_newdt.cpp:109-111, mhd_newdt.cpp:137-144
+    if constexpr (MHD) {
+      const size_t b = ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i);
+      double bx = bcc0[b], by = bcc0[b + cs], bz = bcc0[b + 2*cs];
+      mv1 = fabs(vx) + fast_speed_iso(eos.iso_cs, wd, bx, by, bz);
+      mv2 = fabs(vy) + fast_speed_iso(eos.iso_cs, wd, by, bz, bx);
+      mv3 = fabs(vz) + fast_speed_iso(eos.iso_cs, wd, bz, bx, by);
+    } else {
+      mv1 = fabs(vx) + eos.iso_cs; mv2 = fabs(vy) + eos.iso_cs; mv3 = fabs(vz) + eos.iso_cs;
+    }
+    d1 = g.dx[3*m]/mv1; d2 = g.dx[3*m + 1]/mv2; d3 = g.dx[3*m + 2]/mv3;
+    return;
+  }
+  double pr = (gamma - 1.0)*w0[c + 4*cs];
   if constexpr (MHD) {
     const size_t b = ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i);
     double bx = bcc0[b], by = bcc0[b + cs], bz = bcc0[b + 2*cs];
@@ -182,7 +221,7 @@ __device__ __forceinline__ void cell_dt(const Geo &g, double gamma, const double
 
 template <bool MHD>
 __global__ void __launch_bounds__(BX*BY)
-k_newdt(Geo g, double gamma, const double *__restrict__ w0, const double *__restrict__ bcc0,
+k_newdt(Geo g, Eos eos, const double *__restrict__ w0, const double *__restrict__ bcc0,
         double *__restrict__ dt3) {
   const int i = g.is + blockIdx.x*BX + threadIdx.x;
   const int j = g.js + blockIdx.y*BY + threadIdx.y;
@@ -190,7 +229,7 @@ k_newdt(Geo g, double gamma, const double *__restrict__ w0, const double *__rest
   const int m = blockIdx.z/nk;
   const int k = g.ks + (blockIdx.z - m*nk);
   double d1 = (double)FLT_MAX, d2 = (double)FLT_MAX, d3 = (double)FLT_MAX;
-  if (i <= g.ie && j <= g.je) cell_dt<MHD>(g, gamma, w0, bcc0, m, k, j, i, d1, d2, d3);
+  if (i <= g.ie && j <= g.je) cell_dt<MHD>(g, eos, w0, bcc0, m, k, j, i, d1, d2, d3);
   block_min3_atomic(d1, d2, d3, dt3);
 }
 
@@ -211,7 +250,7 @@ AKMI_DEV double wave_sum(double v) {
 
 template <bool MHD>
 __global__ void __launch_bounds__(BX*BY)
-k_history(Geo g, const double *__restrict__ u0, const double *__restrict__ bx1f,
+k_history(Geo g, int ideal, const double *__restrict__ u0, const double *__restrict__ bx1f,
           const double *__restrict__ bx2f, const double *__restrict__ bx3f,
           double *__restrict__ out) {
   constexpr int NH = MHD ? 11 : 8;
@@ -228,17 +267,20 @@ k_history(Geo g, const double *__restrict__ u0, const double *__restrict__ bx1f,
     const double vol = g.dx[3*m]*g.dx[3*m + 1]*g.dx[3*m + 2];
     const size_t cs = (size_t)g.N3*g.N2*g.N1;
     const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
-    const double d = u0[c], m1 = u0[c + cs], m2 = u0[c + 2*cs], m3 = u0[c + 3*cs], e = u0[c + 4*cs];
-    h[0] = vol*d; h[1] = vol*m1; h[2] = vol*m2; h[3] = vol*m3; h[4] = vol*e;
-    h[5] = vol*0.5*sqr(m1)/d;
-    h[6] = vol*0.5*sqr(m2)/d;
-    h[7] = vol*0.5*sqr(m3)/d;
+    const double d = u0[c], m1 = u0[c + cs], m2 = u0[c + 2*cs], m3 = u0[c + 3*cs];
+    // history.cpp: the kinetic energies start at slot nhydro|nmhd (4 without an energy variable)
+    const int o = ideal ? 5 : 4;
+    h[0] = vol*d; h[1] = vol*m1; h[2] = vol*m2; h[3] = vol*m3;
+    if (ideal) h[4] = vol*u0[c + 4*cs];
+    h[o] = vol*0.5*sqr(m1)/d;
+    h[o + 1] = vol*0.5*sqr(m2)/d;
+    h[o + 2] = vol*0.5*sqr(m3)/d;
     if constexpr (MHD) {
-      h[8] = vol*0.25*(sqr(bx1f[ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i + 1)]) +
+      h[o + 3] = vol*0.25*(sqr(bx1f[ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i + 1)]) +
                        sqr(bx1f[ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i)]));
-      h[9] = vol*0.25*(sqr(bx2f[ix4(g.N3, g.N2 + 1, g.N1, m, k, j + 1, i)]) +
+      h[o + 4] = vol*0.25*(sqr(bx2f[ix4(g.N3, g.N2 + 1, g.N1, m, k, j + 1, i)]) +
                        sqr(bx2f[ix4(g.N3, g.N2 + 1, g.N1, m, k, j, i)]));
-      h[10] = vol*0.25*(sqr(bx3f[ix4(g.N3 + 1, g.N2, g.N1, m, k + 1, j, i)]) +
+      h[o + 5] = vol*0.25*(sqr(bx3f[ix4(g.N3 + 1, g.N2, g.N1, m, k + 1, j, i)]) +
                         sqr(bx3f[ix4(g.N3 + 1, g.N2, g.N1, m, k, j, i)]));
     }
   }
@@ -257,7 +299,7 @@ k_history(Geo g, const double *__restrict__ u0, const double *__restrict__ bx1f,
 
 // ---------------------------------------------------------------------------------------
 // MHD fluxes: reconstruct w0 and bcc0 in registers + Riemann solver RS.  mhd_fluxes.cpp:84-266.
-template <int DIR, int RECON, int RS>
+template <int DIR, int RECON, int RS, bool ISO>
 __global__ void __launch_bounds__(BX*BY)
 k_mhd_flux(Geo g, FaceEos eos, const double *__restrict__ w0, const double *__restrict__ bcc0,
            const double *__restrict__ bxf, double *__restrict__ flx, double *__restrict__ ey,
@@ -279,15 +321,21 @@ k_mhd_flux(Geo g, FaceEos eos, const double *__restrict__ w0, const double *__re
   face_states<RECON, 0>(q + ivx*cs, s, eos, lx, rx);
   face_states<RECON, 0>(q + ivy*cs, s, eos, ly, ry);
   face_states<RECON, 0>(q + ivz*cs, s, eos, lz, rz);
-  face_states<RECON, 2>(q + 4*cs, s, eos, le, re);
   face_states<RECON, 0>(b + iby*cs, s, eos, lby, rby);
   face_states<RECON, 0>(b + ibz*cs, s, eos, lbz, rbz);
   const double bxi = bxf[ix4(f3, f2, f1, m, k, j, i)];
-  Cons1D fl = riemann_mhd<RS>(eos.gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby,
-                              rbz, bxi);
+  Cons1D fl;
+  if constexpr (ISO) {
+    le = re = 0.0;
+    fl = riemann_mhd_iso<RS>(eos, ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
+  } else {
+    face_states<RECON, 2>(q + 4*cs, s, eos, le, re);
+    fl = riemann_mhd<RS>(eos.gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
+  }
   const size_t fs = (size_t)f3*f2*f1;
   double *f = flx + ix5(g.nvar, f3, f2, f1, m, 0, k, j, i);
-  f[0] = fl.d; f[ivx*fs] = fl.mx; f[ivy*fs] = fl.my; f[ivz*fs] = fl.mz; f[4*fs] = fl.e;
+  f[0] = fl.d; f[ivx*fs] = fl.mx; f[ivy*fs] = fl.my; f[ivz*fs] = fl.mz;
+  if constexpr (!ISO) f[4*fs] = fl.e;
   const size_t ec = ix4(g.N3, g.N2, g.N1, m, k, j, i);
   ey[ec] = -fl.by;
   ez[ec] = fl.bz;
@@ -315,8 +363,12 @@ static int launch_mhd_flux(const Geo &g, const Scheme &sc, const double *w0,
   int nk = ku - kl + 1;
   dim3 grid(cdiv(iu - il + 1, BX), cdiv(ju - jl + 1, BY), nk*g.nmb), block(BX, BY);
   int rc = dispatch_scheme<true>(sc, [&](auto R, auto S) {
-    k_mhd_flux<DIR, decltype(R)::value, decltype(S)::value><<<grid, block, 0, st>>>(
-        g, sc.eos, w0, bcc0, bxf, flx, ey, ez, f3, f2, f1, il, iu, jl, ju, kl, nk);
+    if (sc.iso)
+      k_mhd_flux<DIR, decltype(R)::value, decltype(S)::value, true><<<grid, block, 0, st>>>(
+          g, sc.eos, w0, bcc0, bxf, flx, ey, ez, f3, f2, f1, il, iu, jl, ju, kl, nk);
+    else
+      k_mhd_flux<DIR, decltype(R)::value, decltype(S)::value, false><<<grid, block, 0, st>>>(
+          g, sc.eos, w0, bcc0, bxf, flx, ey, ez, f3, f2, f1, il, iu, jl, ju, kl, nk);
     return AKMI_COMPLETE;
   });
   if (rc != AKMI_COMPLETE) return rc;
@@ -515,8 +567,11 @@ int akmi_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *
                       double *flx1, double *flx2, double *flx3, int face_shaped,
                       void *stream) {
   if (check_scheme(p, recon, "hydro_fluxes") != AKMI_COMPLETE) return AKMI_FAIL;
+  if (!p->is_ideal && rsolver == AKMI_RS_HLLC) {
+    set_error("hydro_fluxes: rsolver = hllc needs the ideal-gas EOS"); return AKMI_FAIL;
+  }
   Geo g = make_geo(p);
-  const Scheme sc{recon, rsolver, make_face_eos(p)};
+  const Scheme sc{recon, rsolver, make_face_eos(p), !p->is_ideal};
   hipStream_t st = (hipStream_t)stream;
   int fsh = face_shaped ? 1 : 0;
   int rc = launch_hydro_flux<0>(g, sc, w0, flx1, fsh, st);
@@ -564,7 +619,7 @@ int akmi_hydro_newdt(const akmi_pack *p, const double *w0, double *dt3, void *st
   hipStream_t st = (hipStream_t)stream;
   k_init_dt<<<1, 64, 0, st>>>(dt3);
   dim3 grid(cdiv(g.nx1, BX), cdiv(g.je - g.js + 1, BY), (g.ke - g.ks + 1)*g.nmb), block(BX, BY);
-  k_newdt<false><<<grid, block, 0, st>>>(g, p->gamma, w0, nullptr, dt3);
+  k_newdt<false><<<grid, block, 0, st>>>(g, make_eos(p), w0, nullptr, dt3);
   AKMI_CHECK_LAUNCH("hydro_newdt");
   return AKMI_COMPLETE;
 }
@@ -575,7 +630,7 @@ int akmi_mhd_newdt(const akmi_pack *p, const double *w0, const double *bcc0, dou
   hipStream_t st = (hipStream_t)stream;
   k_init_dt<<<1, 64, 0, st>>>(dt3);
   dim3 grid(cdiv(g.nx1, BX), cdiv(g.je - g.js + 1, BY), (g.ke - g.ks + 1)*g.nmb), block(BX, BY);
-  k_newdt<true><<<grid, block, 0, st>>>(g, p->gamma, w0, bcc0, dt3);
+  k_newdt<true><<<grid, block, 0, st>>>(g, make_eos(p), w0, bcc0, dt3);
   AKMI_CHECK_LAUNCH("mhd_newdt");
   return AKMI_COMPLETE;
 }
@@ -587,7 +642,7 @@ int akmi_mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0
                     void *stream) {
   if (check_scheme(p, recon, "mhd_fluxes") != AKMI_COMPLETE) return AKMI_FAIL;
   Geo g = make_geo(p);
-  const Scheme sc{recon, rsolver, make_face_eos(p)};
+  const Scheme sc{recon, rsolver, make_face_eos(p), !p->is_ideal};
   hipStream_t st = (hipStream_t)stream;
   int rc = launch_mhd_flux<0>(g, sc, w0, bcc0, bx1f, flx1, e3x1, e2x1, st);
   if (rc == AKMI_COMPLETE && g.multi_d)
@@ -606,8 +661,8 @@ int akmi_history_sums(const akmi_pack *p, int is_mhd, const double *u0, const do
     set_error("history_sums: memset failed"); return AKMI_FAIL;
   }
   dim3 grid(cdiv(g.nx1, BX), cdiv(g.je - g.js + 1, BY), (g.ke - g.ks + 1)*g.nmb), block(BX, BY);
-  if (is_mhd) k_history<true><<<grid, block, 0, st>>>(g, u0, bx1f, bx2f, bx3f, out);
-  else k_history<false><<<grid, block, 0, st>>>(g, u0, nullptr, nullptr, nullptr, out);
+  if (is_mhd) k_history<true><<<grid, block, 0, st>>>(g, p->is_ideal, u0, bx1f, bx2f, bx3f, out);
+  else k_history<false><<<grid, block, 0, st>>>(g, p->is_ideal, u0, nullptr, nullptr, nullptr, out);
   AKMI_CHECK_LAUNCH("history_sums");
   return AKMI_COMPLETE;
 }

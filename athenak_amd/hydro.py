@@ -22,11 +22,16 @@ class EOS_Data:
 
     def __init__(self, pin, blk):
         eos = pin.GetString(blk, "eos")
-        if eos != "ideal":
-            raise RuntimeError("### FATAL ERROR <%s> eos = '%s' not on this build's path "
-                               "(ideal only)" % (blk, eos))
-        self.is_ideal = True
-        self.gamma = pin.GetReal(blk, "gamma")
+        if eos == "ideal":
+            self.is_ideal = True
+            self.gamma = pin.GetReal(blk, "gamma")
+            self.iso_cs = 0.0
+        elif eos == "isothermal":                    # isothermal_hyd.cpp:17-23, isothermal_mhd.cpp
+            self.is_ideal = False
+            self.iso_cs = pin.GetReal(blk, "iso_sound_speed")
+            self.gamma = 0.0
+        else:
+            raise RuntimeError("### FATAL ERROR <%s>/eos = '%s' not implemented" % (blk, eos))
         self.dfloor = pin.GetOrAddReal(blk, "dfloor", FLT_MIN)
         self.pfloor = pin.GetOrAddReal(blk, "pfloor", FLT_MIN)
         self.tfloor = pin.GetOrAddReal(blk, "tfloor", FLT_MIN)
@@ -84,10 +89,15 @@ class FluidBase:
         self.nmb = ppack.nmb_thispack
         self.dx_dev = torch.from_numpy(ppack.pmb.dx.copy()).to(device)
         e = self.peos.eos_data
-        self.pack_c = capi.Pack(self.nmb, 5, indcs.nx1, indcs.nx2, indcs.nx3, indcs.ng,
+        self.nfluid = 5 if e.is_ideal else 4         # nhydro / nmhd: no energy when isothermal
+        self.pack_c = capi.Pack(self.nmb, self.nfluid, indcs.nx1, indcs.nx2, indcs.nx3, indcs.ng,
                                 self.dx_dev.data_ptr(), e.gamma, e.dfloor, e.pfloor, e.tfloor,
-                                e.sfloor, e.sigma_max)
+                                e.sfloor, e.sigma_max, e.iso_cs, 1 if e.is_ideal else 0)
         self.fused = pin.GetOrAddBoolean(blk, "fused_stage", True)
+        if not e.is_ideal:
+            # the fused stage kernels are specialised for the ideal-gas variable set; isothermal
+            # runs use the task-granular kernels (same results, one kernel per task)
+            self.fused = False
         self.counters = torch.zeros(3, dtype=torch.int32, device=device)
         self.dt3 = torch.zeros(3, dtype=torch.float64, device=device)
         self.dtnew = FLT_MAX
@@ -120,15 +130,15 @@ class Hydro(FluidBase):
             raise RuntimeError("### FATAL ERROR <hydro> rsolver = '%s' not implemented "
                                "(llf, hlle, hllc, roe on this path)" % rs)
         self.rsolver_method = capi.RSOLVER[rs]
-        self.nhydro = 5
+        self.nhydro = self.nfluid
         n3, n2, n1 = ppack.pmesh.mb_indcs.ncells
-        sh = (self.nmb, 5, n3, n2, n1)
+        sh = (self.nmb, self.nhydro, n3, n2, n1)
         z = lambda: torch.zeros(sh, dtype=torch.float64, device=device)
         self.u0, self.w0, self.u1 = z(), z(), z()
         # task-granular path keeps the reference's cell-shaped flux arrays (hydro.cpp:290-292)
-        self.uflx = None if self.fused else FaceFld(self.nmb, 5, n3, n2, n1, device, face_shaped=False)
+        self.uflx = None if self.fused else FaceFld(self.nmb, self.nhydro, n3, n2, n1, device, face_shaped=False)
         self.pbval_u = MeshBoundaryValues(ppack, bvals_kernels, device)
-        self.pbval_u.set_pack(self.pack_c, 5)
+        self.pbval_u.set_pack(self.pack_c, self.nhydro)
 
     # ---- task list assembly: hydro_tasks.cpp:48-80 ---------------------------------
     def AssembleHydroTasks(self, tl):

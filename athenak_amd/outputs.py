@@ -69,10 +69,12 @@ class OutputMeshBlockInfo:
 
 # variable groups of basetype_output.cpp:196-520 for Newtonian hydro/MHD without scalars:
 # name -> list of (label, component, array)
-def _outvars(variable, is_mhd):
+def _outvars(variable, is_mhd, is_ideal=True):
     blk = "mhd" if is_mhd else "hydro"
     u = [("dens", 0, "u0"), ("mom1", 1, "u0"), ("mom2", 2, "u0"), ("mom3", 3, "u0"), ("ener", 4, "u0")]
     w = [("dens", 0, "w0"), ("velx", 1, "w0"), ("vely", 2, "w0"), ("velz", 3, "w0"), ("eint", 4, "w0")]
+    if not is_ideal:                       # basetype_output.cpp:252-271: energies only if is_ideal
+        u, w = u[:4], w[:4]
     b = [("bcc1", 0, "bcc0"), ("bcc2", 1, "bcc0"), ("bcc3", 2, "bcc0")]
     table = {blk + "_u": u, blk + "_w": w}
     for sfx, (lab, n, arr) in zip(("d", "m1", "m2", "m3", "e"), u):
@@ -96,7 +98,8 @@ class BaseTypeOutput:
         self.outarray = None
         pk = pm.pmb_pack
         if op.file_type not in ("hst",):
-            self.outvars = _outvars(op.variable, pk.pmhd is not None)
+            phys = pk.pmhd if pk.pmhd is not None else pk.phydro
+            self.outvars = _outvars(op.variable, pk.pmhd is not None, phys.peos.eos_data.is_ideal)
 
     def LoadOutputData(self, pm):
         """basetype_output.cpp:729-862: per-block index ranges (ghost zones, slices) and a
@@ -230,6 +233,9 @@ class HistoryOutput(BaseTypeOutput):
         pk = pm.pmb_pack
         self.is_mhd = pk.pmhd is not None
         self.labels = ["mass", "1-mom", "2-mom", "3-mom", "tot-E", "1-KE", "2-KE", "3-KE"]
+        phys = pk.pmhd if self.is_mhd else pk.phydro
+        if not phys.peos.eos_data.is_ideal:
+            self.labels.remove("tot-E")
         if self.is_mhd:
             self.labels += ["1-ME", "2-ME", "3-ME"]
         self.hdata = None

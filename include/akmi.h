@@ -52,13 +52,16 @@ enum { AKMI_BC_BLOCK = -1, AKMI_BC_PERIODIC = 0, AKMI_BC_OUTFLOW = 1, AKMI_BC_RE
  * (src/mesh/mesh.hpp:25-29) and EOS_Data (src/eos/eos.hpp:27-34) by value. */
 typedef struct akmi_pack {
   int nmb;               /* nmb_thispack: MeshBlocks looped over                        */
-  int nvar;              /* nhydro|nmhd + nscalars (5 on this path)                     */
+  int nvar;              /* nhydro|nmhd (+ nscalars): 5 ideal gas, 4 isothermal         */
   int nx1, nx2, nx3;     /* active cells per MeshBlock                                  */
   int ng;                /* ghost cells                                                 */
   const double *dx;      /* [nmb][3] dx1,dx2,dx3 per block, same memory space as fields */
   double gamma;          /* EOS_Data::gamma (ideal gas)                                 */
   double dfloor, pfloor, tfloor, sfloor;   /* default FLT_MIN, src/eos/eos.cpp:22-25    */
   double sigma_max;      /* default FLT_MAX, src/eos/ideal_mhd.cpp:22                   */
+  double iso_cs;         /* EOS_Data::iso_cs (isothermal sound speed)                   */
+  int is_ideal;          /* EOS_Data::is_ideal: 1 ideal gas (nvar 5), 0 isothermal (nvar 4:
+                          * no energy variable, src/eos/isothermal_hyd.cpp:20-23)        */
 } akmi_pack;
 
 const char *akmi_last_error(void);

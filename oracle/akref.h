@@ -117,6 +117,8 @@ typedef struct akref_params {
   /* <hydro>/<mhd> */
   int is_mhd, recon, rsolver;
   double gamma, dfloor, pfloor, tfloor, sfloor, sigma_max;
+  int is_ideal;                    /* eos = ideal (1) | isothermal (0) */
+  double iso_cs;                   /* iso_sound_speed */
   /* <problem> */
   int pgen;
   /* linear_wave */

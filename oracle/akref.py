@@ -23,7 +23,8 @@ class Pack(C.Structure):
     _fields_ = [("nmb", C.c_int), ("nvar", C.c_int), ("nx1", C.c_int), ("nx2", C.c_int),
                 ("nx3", C.c_int), ("ng", C.c_int), ("dx", C.c_void_p),
                 ("gamma", C.c_double), ("dfloor", C.c_double), ("pfloor", C.c_double),
-                ("tfloor", C.c_double), ("sfloor", C.c_double), ("sigma_max", C.c_double)]
+                ("tfloor", C.c_double), ("sfloor", C.c_double), ("sigma_max", C.c_double),
+                ("iso_cs", C.c_double), ("is_ideal", C.c_int)]
 
 
 class Params(C.Structure):
@@ -39,6 +40,7 @@ class Params(C.Structure):
                 ("is_mhd", C.c_int), ("recon", C.c_int), ("rsolver", C.c_int),
                 ("gamma", C.c_double), ("dfloor", C.c_double), ("pfloor", C.c_double),
                 ("tfloor", C.c_double), ("sfloor", C.c_double), ("sigma_max", C.c_double),
+                ("is_ideal", C.c_int), ("iso_cs", C.c_double),
                 ("pgen", C.c_int),
                 ("wave_flag", C.c_int), ("along_x1", C.c_int), ("along_x2", C.c_int),
                 ("along_x3", C.c_int),
@@ -133,7 +135,7 @@ def make_pack(nmb, nx1, nx2, nx3, ng, dx, gamma, nvar=5, dfloor=None, pfloor=Non
     pk = Pack(nmb, nvar, nx1, nx2, nx3, ng, dx.ctypes.data, gamma,
               flt_min if dfloor is None else dfloor, flt_min if pfloor is None else pfloor,
               flt_min if tfloor is None else tfloor, flt_min if sfloor is None else sfloor,
-              flt_max if sigma_max is None else sigma_max)
+              flt_max if sigma_max is None else sigma_max, 1.0, 1)
     return pk, dx
 
 
@@ -208,13 +210,14 @@ class Sim:
         n3, n2, n1 = self.dims()
         nmb = self.nmb
         fs = 1 if self.params.is_mhd else 0
+        nv = 5 if self.params.is_ideal else 4
         shapes = {
-            "u0": (nmb, 5, n3, n2, n1), "w0": (nmb, 5, n3, n2, n1), "u1": (nmb, 5, n3, n2, n1),
+            "u0": (nmb, nv, n3, n2, n1), "w0": (nmb, nv, n3, n2, n1), "u1": (nmb, nv, n3, n2, n1),
             "bcc0": (nmb, 3, n3, n2, n1),
             "b0x1f": (nmb, n3, n2, n1+1), "b0x2f": (nmb, n3, n2+1, n1), "b0x3f": (nmb, n3+1, n2, n1),
             "b1x1f": (nmb, n3, n2, n1+1), "b1x2f": (nmb, n3, n2+1, n1), "b1x3f": (nmb, n3+1, n2, n1),
-            "flx1": (nmb, 5, n3, n2, n1+fs), "flx2": (nmb, 5, n3, n2+fs, n1),
-            "flx3": (nmb, 5, n3+fs, n2, n1),
+            "flx1": (nmb, nv, n3, n2, n1+fs), "flx2": (nmb, nv, n3, n2+fs, n1),
+            "flx3": (nmb, nv, n3+fs, n2, n1),
             "e1": (nmb, n3+1, n2+1, n1), "e2": (nmb, n3+1, n2, n1+1), "e3": (nmb, n3, n2+1, n1+1),
             "dx": (nmb, 3), "xminmax": (nmb, 6), "nghbr": (nmb, 27), "bcs": (nmb, 6),
             "lloc": (nmb, 3), "counters": (3,),

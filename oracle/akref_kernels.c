@@ -219,7 +219,8 @@ static void recon_dir(const G *g, const akmi_pack *p, int apply_floors, int reco
                       int il, int iu) {
   /* floors on the L/R states exist only in the ppmx/wenoz/teno branches and only for the
    * fluid primitives d and e (recon.hpp:59-103: dfloor, efloor = pfloor/(gamma-1)) */
-  const double dfloor = p->dfloor, efloor = p->pfloor/(p->gamma - 1.0);
+  const double dfloor = p->dfloor, efloor = p->is_ideal ? p->pfloor/(p->gamma - 1.0) : 0.0;
+  const int ideal = p->is_ideal;
   const int di = (dir == 0), dj = (dir == 1), dk = (dir == 2);
   const int N1 = g->N1, N2 = g->N2, N3 = g->N3;
   const long so = (long)dk*N2*N1 + (long)dj*N1 + di;   /* stencil offset */
@@ -246,7 +247,7 @@ static void recon_dir(const G *g, const akmi_pack *p, int apply_floors, int reco
                 akref_teno(q[c - 2*so], q[c - so], q[c], q[c + so], q[c + 2*so], &a, &bq);
               if (apply_floors) {
                 if (n == IDN) { a = fmax(a, dfloor); bq = fmax(bq, dfloor); }
-                if (n == IEN) { a = fmax(a, efloor); bq = fmax(bq, efloor); }
+                if (ideal && n == IEN) { a = fmax(a, efloor); bq = fmax(bq, efloor); }
               }
             } else {
               a = q[c]; bq = q[c];
@@ -495,6 +496,128 @@ static inline int hyd_riemann(int rs, double gamma, const double a[5], const dou
     case AKMI_RS_ROE:  akref_roe_hyd(gamma, a, b, f); return 0;
   }
   return 1;
+}
+
+/* ---- isothermal branches (EOS_Data::is_ideal == false): states (d, vx, vy, vz), flux (d, mx,
+ * my, mz).  Same source lines as the ideal-gas functions above. */
+void akref_llf_hyd_iso(double cs, const double wl[4], const double wr[4], double flx[4]) {
+  double qa = wl[0]*wl[1];
+  double qb = wr[0]*wr[1];
+  double s_d = qa + qb;
+  double s_mx = qa*wl[1] + qb*wr[1];
+  double s_my = qa*wl[2] + qb*wr[2];
+  double s_mz = qa*wl[3] + qb*wr[3];
+  s_mx += SQR(cs)*(wl[0] + wr[0]);
+  qa = cs;
+  qb = cs;
+  double a = fmax((fabs(wl[1]) + qa), (fabs(wr[1]) + qb));
+  double du_d = a*(wr[0] - wl[0]);
+  double du_mx = a*(wr[0]*wr[1] - wl[0]*wl[1]);
+  double du_my = a*(wr[0]*wr[2] - wl[0]*wl[2]);
+  double du_mz = a*(wr[0]*wr[3] - wl[0]*wl[3]);
+  flx[0] = 0.5*(s_d - du_d);
+  flx[1] = 0.5*(s_mx - du_mx);
+  flx[2] = 0.5*(s_my - du_my);
+  flx[3] = 0.5*(s_mz - du_mz);
+}
+
+void akref_hlle_hyd_iso(double iso_cs, const double wl[4], const double wr[4], double flx[4]) {
+  double dl = wl[0], ul = wl[1], vl = wl[2], zl = wl[3];
+  double dr = wr[0], ur = wr[1], vr = wr[2], zr = wr[3];
+  double sqrtdl = sqrt(dl);
+  double sqrtdr = sqrt(dr);
+  double isdlpdr = 1.0/(sqrtdl + sqrtdr);
+  double roe_vx = (sqrtdl*ul + sqrtdr*ur)*isdlpdr;
+  double a = iso_cs;
+  double qa = iso_cs, qb = iso_cs;
+  double al = fmin((roe_vx - a), (ul - qa));
+  double ar = fmax((roe_vx + a), (ur + qb));
+  double bp = (ar > 0.0) ? ar : 1.0e-20;
+  double bm = (al < 0.0) ? al : -1.0e-20;
+  qa = ul - bm;
+  qb = ur - bp;
+  double fl_d = dl*qa, fr_d = dr*qb;
+  double fl_mx = dl*ul*qa, fr_mx = dr*ur*qb;
+  double fl_my = dl*vl*qa, fr_my = dr*vr*qb;
+  double fl_mz = dl*zl*qa, fr_mz = dr*zr*qb;
+  fl_mx += (iso_cs*iso_cs)*dl;
+  fr_mx += (iso_cs*iso_cs)*dr;
+  qa = 0.0;
+  if (bp != bm) qa = 0.5*(bp + bm)/(bp - bm);
+  flx[0] = 0.5*(fl_d + fr_d) + qa*(fl_d - fr_d);
+  flx[1] = 0.5*(fl_mx + fr_mx) + qa*(fl_mx - fr_mx);
+  flx[2] = 0.5*(fl_my + fr_my) + qa*(fl_my - fr_my);
+  flx[3] = 0.5*(fl_mz + fr_mz) + qa*(fl_mz - fr_mz);
+}
+
+/* roe_hyd.hpp:40-181 with RoeFluxIso (:275-346) */
+void akref_roe_hyd_iso(double iso_cs, const double wl[4], const double wr[4], double flx[4]) {
+  double fl[4], fr[4], du[4], ev[4], f[4];
+  double sqrtdl = sqrt(wl[0]);
+  double sqrtdr = sqrt(wr[0]);
+  double isdlpdr = 1.0/(sqrtdl + sqrtdr);
+  double v1 = (sqrtdl*wl[1] + sqrtdr*wr[1])*isdlpdr;
+  double v2 = (sqrtdl*wl[2] + sqrtdr*wr[2])*isdlpdr;
+  double v3 = (sqrtdl*wl[3] + sqrtdr*wr[3])*isdlpdr;
+  double mxl = wl[0]*wl[1];
+  double mxr = wr[0]*wr[1];
+  fl[0] = mxl;           fr[0] = mxr;
+  fl[1] = mxl*wl[1];     fr[1] = mxr*wr[1];
+  fl[2] = mxl*wl[2];     fr[2] = mxr*wr[2];
+  fl[3] = mxl*wl[3];     fr[3] = mxr*wr[3];
+  fl[1] += (iso_cs*iso_cs)*wl[0];
+  fr[1] += (iso_cs*iso_cs)*wr[0];
+  du[0] = wr[0] - wl[0];
+  du[1] = wr[0]*wr[1] - wl[0]*wl[1];
+  du[2] = wr[0]*wr[2] - wl[0]*wl[2];
+  du[3] = wr[0]*wr[3] - wl[0]*wl[3];
+  for (int n = 0; n < 4; ++n) f[n] = 0.5*(fl[n] + fr[n]);
+  int llf_flag = 0;
+  {
+    ev[0] = v1 - iso_cs; ev[1] = v1; ev[2] = v1; ev[3] = v1 + iso_cs;
+    double a[4];
+    a[0]  = du[0]*(0.5 + 0.5*v1/iso_cs);
+    a[0] -= du[1]*0.5/iso_cs;
+    a[1]  = du[0]*(-v2);
+    a[1] += du[2];
+    a[2]  = du[0]*(-v3);
+    a[2] += du[3];
+    a[3]  = du[0]*(0.5 - 0.5*v1/iso_cs);
+    a[3] += du[1]*0.5/iso_cs;
+    double co[4];
+    for (int n = 0; n < 4; ++n) co[n] = -0.5*fabs(ev[n])*a[n];
+    double dens = wl[0] + a[0];
+    if (dens < 0.0) llf_flag = 1;
+    dens += a[3];
+    if (dens < 0.0) llf_flag = 1;
+    f[0] += co[0];
+    f[0] += co[3];
+    f[1] += co[0]*(v1 - iso_cs);
+    f[1] += co[3]*(v1 + iso_cs);
+    f[2] += co[0]*v2;
+    f[2] += co[1];
+    f[2] += co[3]*v2;
+    f[3] += co[0]*v3;
+    f[3] += co[2];
+    f[3] += co[3]*v3;
+  }
+  if (ev[0] >= 0.0) for (int n = 0; n < 4; ++n) f[n] = fl[n];
+  if (ev[3] <= 0.0) for (int n = 0; n < 4; ++n) f[n] = fr[n];
+  if (llf_flag != 0) {
+    double a = 0.5*fmax((fabs(wl[1]) + iso_cs), (fabs(wr[1]) + iso_cs));
+    for (int n = 0; n < 4; ++n) f[n] = 0.5*(fl[n] + fr[n]) - a*du[n];
+  }
+  for (int n = 0; n < 4; ++n) flx[n] = f[n];
+}
+
+static inline int hyd_riemann_iso(int rs, double cs, const double a[4], const double b[4],
+                                  double f[4]) {
+  switch (rs) {
+    case AKMI_RS_LLF:  akref_llf_hyd_iso(cs, a, b, f); return 0;
+    case AKMI_RS_HLLE: akref_hlle_hyd_iso(cs, a, b, f); return 0;
+    case AKMI_RS_ROE:  akref_roe_hyd_iso(cs, a, b, f); return 0;
+  }
+  return 1;                       /* hllc is an ideal-gas solver (hydro.cpp: rsolver checks) */
 }
 
 /* IdealMHDFastSpeed, src/eos/eos.hpp:49-57 */
@@ -836,6 +959,202 @@ static inline int mhd_riemann(int rs, double gamma, const double a[7], const dou
   return 1;
 }
 
+/* isothermal fast speed, src/eos/eos.hpp:60-68 */
+static inline double fast_speed_iso(double cs, double d, double bx, double by, double bz) {
+  double asq = (cs*cs)*d;
+  double ct2 = by*by + bz*bz;
+  double qsq = bx*bx + ct2 + asq;
+  double tmp = bx*bx + ct2 - asq;
+  return sqrt(0.5*(qsq + sqrt(tmp*tmp + 4.0*asq*ct2))/d);
+}
+
+/* isothermal MHD solvers: states (d,vx,vy,vz,by,bz), flux (d,mx,my,mz,F(by),F(bz)) */
+void akref_llf_mhd_iso(double cs, const double wl[6], const double wr[6], double bxi,
+                       double flx[6]) {
+  double qa = wl[0]*wl[1];
+  double qb = wr[0]*wr[1];
+  double qc = 0.5*(SQR(wl[4]) + SQR(wl[5]) - SQR(bxi));
+  double qd = 0.5*(SQR(wr[4]) + SQR(wr[5]) - SQR(bxi));
+  double s_d = qa + qb;
+  double s_mx = qa*wl[1] + qb*wr[1] + qc + qd;
+  double s_my = qa*wl[2] + qb*wr[2] - bxi*(wl[4] + wr[4]);
+  double s_mz = qa*wl[3] + qb*wr[3] - bxi*(wl[5] + wr[5]);
+  double s_by = wl[4]*wl[1] + wr[4]*wr[1] - bxi*(wl[2] + wr[2]);
+  double s_bz = wl[5]*wl[1] + wr[5]*wr[1] - bxi*(wl[3] + wr[3]);
+  s_mx += SQR(cs)*(wl[0] + wr[0]);
+  qa = fast_speed_iso(cs, wl[0], bxi, wl[4], wl[5]);
+  qb = fast_speed_iso(cs, wr[0], bxi, wr[4], wr[5]);
+  double a = fmax((fabs(wl[1]) + qa), (fabs(wr[1]) + qb));
+  flx[0] = 0.5*(s_d - a*(wr[0] - wl[0]));
+  flx[1] = 0.5*(s_mx - a*(wr[0]*wr[1] - wl[0]*wl[1]));
+  flx[2] = 0.5*(s_my - a*(wr[0]*wr[2] - wl[0]*wl[2]));
+  flx[3] = 0.5*(s_mz - a*(wr[0]*wr[3] - wl[0]*wl[3]));
+  flx[4] = 0.5*(s_by - a*(wr[4] - wl[4]));
+  flx[5] = 0.5*(s_bz - a*(wr[5] - wl[5]));
+}
+
+void akref_hlle_mhd_iso(double iso_cs, const double wl[6], const double wr[6], double bxi,
+                        double flx[6]) {
+  double dl = wl[0], ul = wl[1], vl = wl[2], zl = wl[3], byl = wl[4], bzl = wl[5];
+  double dr = wr[0], ur = wr[1], vr = wr[2], zr = wr[3], byr = wr[4], bzr = wr[5];
+  double sqrtdl = sqrt(dl);
+  double sqrtdr = sqrt(dr);
+  double isdlpdr = 1.0/(sqrtdl + sqrtdr);
+  double roe_d = sqrtdl*sqrtdr;
+  double roe_vx = (sqrtdl*ul + sqrtdr*ur)*isdlpdr;
+  double roe_by = (sqrtdr*byl + sqrtdl*byr)*isdlpdr;
+  double roe_bz = (sqrtdr*bzl + sqrtdl*bzr)*isdlpdr;
+  double x = 0.5*(SQR(byl - byr) + SQR(bzl - bzr))/(SQR(sqrtdl + sqrtdr));
+  double y = 0.5*(dl + dr)/roe_d;
+  double pbl = 0.5*(bxi*bxi + SQR(byl) + SQR(bzl));
+  double pbr = 0.5*(bxi*bxi + SQR(byr) + SQR(bzr));
+  double cl = fast_speed_iso(iso_cs, dl, bxi, byl, bzl);
+  double cr = fast_speed_iso(iso_cs, dr, bxi, byr, bzr);
+  double btsq = SQR(roe_by) + SQR(roe_bz);
+  double vaxsq = bxi*bxi/roe_d;
+  double bt_starsq = btsq*y;
+  double twid_asq = iso_cs*iso_cs + x;
+  double ct2 = bt_starsq/roe_d;
+  double tsum = vaxsq + ct2 + twid_asq;
+  double tdif = vaxsq + ct2 - twid_asq;
+  double cf2_cs2 = sqrt(tdif*tdif + 4.0*twid_asq*ct2);
+  double cfsq = 0.5*(tsum + cf2_cs2);
+  double a = sqrt(cfsq);
+  double al = fmin((roe_vx - a), (ul - cl));
+  double ar = fmax((roe_vx + a), (ur + cr));
+  double bp = ar > 0.0 ? ar : 1.0e-20;
+  double bm = al < 0.0 ? al : -1.0e-20;
+  double vxl = ul - bm;
+  double vxr = ur - bp;
+  double fl_d = dl*vxl, fr_d = dr*vxr;
+  double fl_mx = dl*ul*vxl + pbl - SQR(bxi);
+  double fr_mx = dr*ur*vxr + pbr - SQR(bxi);
+  double fl_my = dl*vl*vxl - bxi*byl;
+  double fr_my = dr*vr*vxr - bxi*byr;
+  double fl_mz = dl*zl*vxl - bxi*bzl;
+  double fr_mz = dr*zr*vxr - bxi*bzr;
+  fl_mx += (iso_cs*iso_cs)*dl;
+  fr_mx += (iso_cs*iso_cs)*dr;
+  double fl_by = byl*vxl - bxi*vl;
+  double fr_by = byr*vxr - bxi*vr;
+  double fl_bz = bzl*vxl - bxi*zl;
+  double fr_bz = bzr*vxr - bxi*zr;
+  double tmp = 0.0;
+  if (bp != bm) tmp = 0.5*(bp + bm)/(bp - bm);
+  flx[0] = 0.5*(fl_d + fr_d) + (fl_d - fr_d)*tmp;
+  flx[1] = 0.5*(fl_mx + fr_mx) + (fl_mx - fr_mx)*tmp;
+  flx[2] = 0.5*(fl_my + fr_my) + (fl_my - fr_my)*tmp;
+  flx[3] = 0.5*(fl_mz + fr_mz) + (fl_mz - fr_mz)*tmp;
+  flx[4] = 0.5*(fl_by + fr_by) + (fl_by - fr_by)*tmp;
+  flx[5] = 0.5*(fl_bz + fr_bz) + (fl_bz - fr_bz)*tmp;
+}
+
+/* isothermal HLLD (Mignone 2007), src/mhd/rsolvers/hlld_mhd.hpp:349-545 */
+void akref_hlld_iso(double iso_cs, double dfloor_, const double wl[6], const double wr[6], double bxi,
+                    double flx[6]) {
+  double wl_idn = wl[0], wl_ivx = wl[1], wl_ivy = wl[2], wl_ivz = wl[3], wl_iby = wl[4], wl_ibz = wl[5];
+  double wr_idn = wr[0], wr_ivx = wr[1], wr_ivy = wr[2], wr_ivz = wr[3], wr_iby = wr[4], wr_ibz = wr[5];
+  double spd[5];
+  double ul_d = wl_idn, ul_mx = wl_ivx*ul_d, ul_my = wl_ivy*ul_d, ul_mz = wl_ivz*ul_d;
+  double ul_by = wl_iby, ul_bz = wl_ibz;
+  double ur_d = wr_idn, ur_mx = wr_ivx*ur_d, ur_my = wr_ivy*ur_d, ur_mz = wr_ivz*ur_d;
+  double ur_by = wr_iby, ur_bz = wr_ibz;
+  double cfl = fast_speed_iso(iso_cs, wl_idn, bxi, wl_iby, wl_ibz);
+  double cfr = fast_speed_iso(iso_cs, wr_idn, bxi, wr_iby, wr_ibz);
+  spd[0] = fmin(wl_ivx - cfl, wr_ivx - cfr);
+  spd[4] = fmax(wl_ivx + cfl, wr_ivx + cfr);
+  double bxsq = bxi*bxi;
+  double ptl = SQR(iso_cs)*wl_idn + 0.5*(bxsq + SQR(wl_iby) + SQR(wl_ibz));
+  double ptr = SQR(iso_cs)*wr_idn + 0.5*(bxsq + SQR(wr_iby) + SQR(wr_ibz));
+  double fl_d = ul_mx;
+  double fl_mx = ul_mx*wl_ivx + ptl - bxsq;
+  double fl_my = ul_my*wl_ivx - bxi*ul_by;
+  double fl_mz = ul_mz*wl_ivx - bxi*ul_bz;
+  double fl_by = ul_by*wl_ivx - bxi*wl_ivy;
+  double fl_bz = ul_bz*wl_ivx - bxi*wl_ivz;
+  double fr_d = ur_mx;
+  double fr_mx = ur_mx*wr_ivx + ptr - bxsq;
+  double fr_my = ur_my*wr_ivx - bxi*ur_by;
+  double fr_mz = ur_mz*wr_ivx - bxi*ur_bz;
+  double fr_by = ur_by*wr_ivx - bxi*wr_ivy;
+  double fr_bz = ur_bz*wr_ivx - bxi*wr_ivz;
+  double idspd = 1.0/(spd[4] - spd[0]);
+  double dhll = (spd[4]*ur_d - spd[0]*ul_d - fr_d + fl_d)*idspd;
+  dhll = fmax(dhll, dfloor_);
+  double sqrtdhll = sqrt(dhll);
+  double fdhll = (spd[4]*fl_d - spd[0]*fr_d + spd[4]*spd[0]*(ur_d - ul_d))*idspd;
+  double fmxhll = (spd[4]*fl_mx - spd[0]*fr_mx + spd[4]*spd[0]*(ur_mx - ul_mx))*idspd;
+  double ustar = fdhll/dhll;
+  double mxhll = (spd[4]*ur_mx - spd[0]*ul_mx - fr_mx + fl_mx)*idspd;
+  spd[1] = ustar - fabs(bxi)/sqrtdhll;
+  spd[3] = ustar + fabs(bxi)/sqrtdhll;
+  double ulst_my, ulst_mz, ulst_by, ulst_bz, urst_my, urst_mz, urst_by, urst_bz;
+  double tmp = (spd[0] - spd[1])*(spd[0] - spd[3]);
+  if (fabs(spd[0] - spd[1]) < (HLLD_SMALL_NUMBER)*iso_cs) {
+    ulst_my = ul_my; ulst_mz = ul_mz; ulst_by = ul_by; ulst_bz = ul_bz;
+  } else {
+    double mfact = bxi*(ustar - wl_ivx)/tmp;
+    double bfact = (ul_d*SQR(spd[0] - wl_ivx) - bxsq)/(dhll*tmp);
+    ulst_my = dhll*wl_ivy - ul_by*mfact;
+    ulst_mz = dhll*wl_ivz - ul_bz*mfact;
+    ulst_by = ul_by*bfact;
+    ulst_bz = ul_bz*bfact;
+  }
+  tmp = (spd[4] - spd[1])*(spd[4] - spd[3]);
+  if (fabs(spd[4] - spd[3]) < (HLLD_SMALL_NUMBER)*iso_cs) {
+    urst_my = ur_my; urst_mz = ur_mz; urst_by = ur_by; urst_bz = ur_bz;
+  } else {
+    double mfact = bxi*(ustar - wr_ivx)/tmp;
+    double bfact = (ur_d*SQR(spd[4] - wr_ivx) - bxsq)/(dhll*tmp);
+    urst_my = dhll*wr_ivy - ur_by*mfact;
+    urst_mz = dhll*wr_ivz - ur_bz*mfact;
+    urst_by = ur_by*bfact;
+    urst_bz = ur_bz*bfact;
+  }
+  double x = sqrtdhll*(bxi > 0.0 ? 1.0 : -1.0);
+  double ucst_d = dhll;
+  double ucst_my = 0.5*(ulst_my + urst_my + (urst_by - ulst_by)*x);
+  double ucst_mz = 0.5*(ulst_mz + urst_mz + (urst_bz - ulst_bz)*x);
+  double ucst_by = 0.5*(ulst_by + urst_by + (urst_my - ulst_my)/x);
+  double ucst_bz = 0.5*(ulst_bz + urst_bz + (urst_mz - ulst_mz)/x);
+  if (spd[0] >= 0.0) {
+    flx[0] = fl_d; flx[1] = fl_mx; flx[2] = fl_my; flx[3] = fl_mz; flx[4] = fl_by; flx[5] = fl_bz;
+  } else if (spd[4] <= 0.0) {
+    flx[0] = fr_d; flx[1] = fr_mx; flx[2] = fr_my; flx[3] = fr_mz; flx[4] = fr_by; flx[5] = fr_bz;
+  } else if (spd[1] >= 0.0) {
+    flx[0] = fl_d + spd[0]*(dhll - ul_d);
+    flx[1] = fl_mx + spd[0]*(mxhll - ul_mx);
+    flx[2] = fl_my + spd[0]*(ulst_my - ul_my);
+    flx[3] = fl_mz + spd[0]*(ulst_mz - ul_mz);
+    flx[4] = fl_by + spd[0]*(ulst_by - ul_by);
+    flx[5] = fl_bz + spd[0]*(ulst_bz - ul_bz);
+  } else if (spd[3] <= 0.0) {
+    flx[0] = fr_d + spd[4]*(dhll - ur_d);
+    flx[1] = fr_mx + spd[4]*(mxhll - ur_mx);
+    flx[2] = fr_my + spd[4]*(urst_my - ur_my);
+    flx[3] = fr_mz + spd[4]*(urst_mz - ur_mz);
+    flx[4] = fr_by + spd[4]*(urst_by - ur_by);
+    flx[5] = fr_bz + spd[4]*(urst_bz - ur_bz);
+  } else {
+    flx[0] = dhll*ustar;
+    flx[1] = fmxhll;
+    flx[2] = ucst_my*ustar - bxi*ucst_by;
+    flx[3] = ucst_mz*ustar - bxi*ucst_bz;
+    flx[4] = ucst_by*ustar - bxi*ucst_my/ucst_d;
+    flx[5] = ucst_bz*ustar - bxi*ucst_mz/ucst_d;
+  }
+}
+
+static inline int mhd_riemann_iso(int rs, double cs, double dfloor_, const double a[6],
+                                  const double b[6], double bxi, double f[6]) {
+  switch (rs) {
+    case AKMI_RS_LLF:  akref_llf_mhd_iso(cs, a, b, bxi, f); return 0;
+    case AKMI_RS_HLLE: akref_hlle_mhd_iso(cs, a, b, bxi, f); return 0;
+    case AKMI_RS_HLLD: akref_hlld_iso(cs, dfloor_, a, b, bxi, f); return 0;
+  }
+  return 1;
+}
+
 int akref_copy_cons(const akmi_pack *p, const double *u0, double *u1) {
   G g = mkG(p);
   memcpy(u1, u0, sizeof(double)*(size_t)g.nmb*g.nvar*g.N3*g.N2*g.N1);
@@ -847,6 +1166,8 @@ int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double 
                        double *flx1, double *flx2, double *flx3, int fs) {
   if (rsolver != AKMI_RS_LLF && rsolver != AKMI_RS_HLLE && rsolver != AKMI_RS_HLLC &&
       rsolver != AKMI_RS_ROE) return AKMI_FAIL;
+  if (!p->is_ideal && rsolver == AKMI_RS_HLLC) return AKMI_FAIL;   /* hllc is ideal-gas only */
+  const int ideal = p->is_ideal;
   G g = mkG(p);
   const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
   size_t ncell = (size_t)g.nmb*nv*N3*N2*N1;
@@ -874,13 +1195,17 @@ int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double 
             a[1] = wl[ix5(nv,N3,N2,N1,m,ivx,k,j,i)]; b[1] = wr[ix5(nv,N3,N2,N1,m,ivx,k,j,i)];
             a[2] = wl[ix5(nv,N3,N2,N1,m,ivy,k,j,i)]; b[2] = wr[ix5(nv,N3,N2,N1,m,ivy,k,j,i)];
             a[3] = wl[ix5(nv,N3,N2,N1,m,ivz,k,j,i)]; b[3] = wr[ix5(nv,N3,N2,N1,m,ivz,k,j,i)];
-            a[4] = wl[ix5(nv,N3,N2,N1,m,IEN,k,j,i)]; b[4] = wr[ix5(nv,N3,N2,N1,m,IEN,k,j,i)];
-            hyd_riemann(rsolver, gamma, a, b, f);
+            if (ideal) {
+              a[4] = wl[ix5(nv,N3,N2,N1,m,IEN,k,j,i)]; b[4] = wr[ix5(nv,N3,N2,N1,m,IEN,k,j,i)];
+              hyd_riemann(rsolver, gamma, a, b, f);
+            } else {
+              hyd_riemann_iso(rsolver, p->iso_cs, a, b, f);
+            }
             flx[ix5(nv,f3,f2,f1,m,IDN,k,j,i)] = f[0];
             flx[ix5(nv,f3,f2,f1,m,ivx,k,j,i)] = f[1];
             flx[ix5(nv,f3,f2,f1,m,ivy,k,j,i)] = f[2];
             flx[ix5(nv,f3,f2,f1,m,ivz,k,j,i)] = f[3];
-            flx[ix5(nv,f3,f2,f1,m,IEN,k,j,i)] = f[4];
+            if (ideal) flx[ix5(nv,f3,f2,f1,m,IEN,k,j,i)] = f[4];
           }
   }
   return 0;
@@ -919,6 +1244,23 @@ int akref_hydro_c2p(const akmi_pack *p, double *u0, double *w0, int il, int iu, 
                     int ju, int kl, int ku, int *counters) {
   G g = mkG(p);
   const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  if (!p->is_ideal) {
+    /* SingleC2P_IsothermalHyd, src/eos/isothermal_hyd.cpp:30-45,61-124 */
+    int sumd_ = 0;
+    for (int m = 0; m < g.nmb; ++m)
+      for (int k = kl; k <= ku; ++k)
+        for (int j = jl; j <= ju; ++j)
+          for (int i = il; i <= iu; ++i) {
+            size_t cd = ix5(nv,N3,N2,N1,m,IDN,k,j,i), cx = ix5(nv,N3,N2,N1,m,IVX,k,j,i);
+            size_t cy = ix5(nv,N3,N2,N1,m,IVY,k,j,i), cz = ix5(nv,N3,N2,N1,m,IVZ,k,j,i);
+            double ud = u0[cd];
+            if (ud < p->dfloor) { ud = p->dfloor; u0[cd] = ud; sumd_++; }
+            double di = 1.0/ud;
+            w0[cd] = ud; w0[cx] = di*u0[cx]; w0[cy] = di*u0[cy]; w0[cz] = di*u0[cz];
+          }
+    if (counters) counters[0] += sumd_;
+    return 0;
+  }
   const double gm1 = p->gamma - 1.0;
   const double efloor = p->pfloor/(p->gamma - 1.0);
   const double tfloor = p->tfloor, sfloor = p->sfloor, dfloor_ = p->dfloor;
@@ -963,8 +1305,13 @@ int akref_hydro_newdt(const akmi_pack *p, const double *w0, double *dt3) {
     for (int k = g.ks; k <= g.ke; ++k)
       for (int j = g.js; j <= g.je; ++j)
         for (int i = g.is; i <= g.ie; ++i) {
-          double pr = (p->gamma - 1.0)*w0[ix5(nv,N3,N2,N1,m,IEN,k,j,i)];
-          double cs = sqrt(p->gamma*pr/w0[ix5(nv,N3,N2,N1,m,IDN,k,j,i)]);
+          double cs;
+          if (p->is_ideal) {
+            double pr = (p->gamma - 1.0)*w0[ix5(nv,N3,N2,N1,m,IEN,k,j,i)];
+            cs = sqrt(p->gamma*pr/w0[ix5(nv,N3,N2,N1,m,IDN,k,j,i)]);
+          } else {
+            cs = p->iso_cs;                       /* hydro_newdt.cpp:109-111 */
+          }
           double max_dv1 = fabs(w0[ix5(nv,N3,N2,N1,m,IVX,k,j,i)]) + cs;
           double max_dv2 = fabs(w0[ix5(nv,N3,N2,N1,m,IVY,k,j,i)]) + cs;
           double max_dv3 = fabs(w0[ix5(nv,N3,N2,N1,m,IVZ,k,j,i)]) + cs;
@@ -983,6 +1330,7 @@ int akref_mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w
                      double *e3x1, double *e2x1, double *e1x2, double *e3x2, double *e2x3,
                      double *e1x3) {
   if (rsolver != AKMI_RS_LLF && rsolver != AKMI_RS_HLLE && rsolver != AKMI_RS_HLLD) return AKMI_FAIL;
+  const int ideal = p->is_ideal;
   G g = mkG(p);
   const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
   size_t ncell = (size_t)g.nmb*N3*N2*N1;
@@ -1028,18 +1376,20 @@ int akref_mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w
             a[1] = wl[ix5(nv,N3,N2,N1,m,ivx,k,j,i)]; b[1] = wr[ix5(nv,N3,N2,N1,m,ivx,k,j,i)];
             a[2] = wl[ix5(nv,N3,N2,N1,m,ivy,k,j,i)]; b[2] = wr[ix5(nv,N3,N2,N1,m,ivy,k,j,i)];
             a[3] = wl[ix5(nv,N3,N2,N1,m,ivz,k,j,i)]; b[3] = wr[ix5(nv,N3,N2,N1,m,ivz,k,j,i)];
-            a[4] = wl[ix5(nv,N3,N2,N1,m,IEN,k,j,i)]; b[4] = wr[ix5(nv,N3,N2,N1,m,IEN,k,j,i)];
-            a[5] = bl[ix5(3,N3,N2,N1,m,iby,k,j,i)];  b[5] = br[ix5(3,N3,N2,N1,m,iby,k,j,i)];
-            a[6] = bl[ix5(3,N3,N2,N1,m,ibz,k,j,i)];  b[6] = br[ix5(3,N3,N2,N1,m,ibz,k,j,i)];
             double bxi = bx[ix4(f3,f2,f1,m,k,j,i)];
-            mhd_riemann(rsolver, gamma, a, b, bxi, f);
+            const int ob = ideal ? 5 : 4;               /* first B slot of the state vector */
+            if (ideal) { a[4] = wl[ix5(nv,N3,N2,N1,m,IEN,k,j,i)]; b[4] = wr[ix5(nv,N3,N2,N1,m,IEN,k,j,i)]; }
+            a[ob] = bl[ix5(3,N3,N2,N1,m,iby,k,j,i)];      b[ob] = br[ix5(3,N3,N2,N1,m,iby,k,j,i)];
+            a[ob + 1] = bl[ix5(3,N3,N2,N1,m,ibz,k,j,i)];  b[ob + 1] = br[ix5(3,N3,N2,N1,m,ibz,k,j,i)];
+            if (ideal) mhd_riemann(rsolver, gamma, a, b, bxi, f);
+            else mhd_riemann_iso(rsolver, p->iso_cs, p->dfloor, a, b, bxi, f);
             flx[ix5(nv,f3,f2,f1,m,IDN,k,j,i)] = f[0];
             flx[ix5(nv,f3,f2,f1,m,ivx,k,j,i)] = f[1];
             flx[ix5(nv,f3,f2,f1,m,ivy,k,j,i)] = f[2];
             flx[ix5(nv,f3,f2,f1,m,ivz,k,j,i)] = f[3];
-            flx[ix5(nv,f3,f2,f1,m,IEN,k,j,i)] = f[4];
-            ey[ix4(N3,N2,N1,m,k,j,i)] = -f[5];
-            ez[ix4(N3,N2,N1,m,k,j,i)] = f[6];
+            if (ideal) flx[ix5(nv,f3,f2,f1,m,IEN,k,j,i)] = f[4];
+            ey[ix4(N3,N2,N1,m,k,j,i)] = -f[ob];
+            ez[ix4(N3,N2,N1,m,k,j,i)] = f[ob + 1];
           }
   }
   return 0;
@@ -1050,7 +1400,8 @@ int akref_history_sums(const akmi_pack *p, int is_mhd, const double *u0, const d
                        const double *bx2f, const double *bx3f, double *out) {
   G g = mkG(p);
   const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
-  const int nh = is_mhd ? 11 : 8;
+  const int ideal = p->is_ideal, o = ideal ? 5 : 4;       /* history.cpp: KE starts at nhydro */
+  const int nh = (is_mhd ? 11 : 8) - (ideal ? 0 : 1);
   for (int n = 0; n < nh; ++n) out[n] = 0.0;
   for (int m = 0; m < g.nmb; ++m) {
     const double vol = p->dx[3*m]*p->dx[3*m+1]*p->dx[3*m+2];
@@ -1059,15 +1410,16 @@ int akref_history_sums(const akmi_pack *p, int is_mhd, const double *u0, const d
         for (int i = g.is; i <= g.ie; ++i) {
           double d = u0[ix5(nv,N3,N2,N1,m,IDN,k,j,i)];
           double m1 = u0[ix5(nv,N3,N2,N1,m,1,k,j,i)], m2 = u0[ix5(nv,N3,N2,N1,m,2,k,j,i)];
-          double m3 = u0[ix5(nv,N3,N2,N1,m,3,k,j,i)], e = u0[ix5(nv,N3,N2,N1,m,IEN,k,j,i)];
-          out[0] += vol*d; out[1] += vol*m1; out[2] += vol*m2; out[3] += vol*m3; out[4] += vol*e;
-          out[5] += vol*0.5*SQR(m1)/d;
-          out[6] += vol*0.5*SQR(m2)/d;
-          out[7] += vol*0.5*SQR(m3)/d;
+          double m3 = u0[ix5(nv,N3,N2,N1,m,3,k,j,i)];
+          out[0] += vol*d; out[1] += vol*m1; out[2] += vol*m2; out[3] += vol*m3;
+          if (ideal) out[4] += vol*u0[ix5(nv,N3,N2,N1,m,IEN,k,j,i)];
+          out[o] += vol*0.5*SQR(m1)/d;
+          out[o+1] += vol*0.5*SQR(m2)/d;
+          out[o+2] += vol*0.5*SQR(m3)/d;
           if (is_mhd) {
-            out[8] += vol*0.25*(SQR(bx1f[ix4(N3,N2,N1+1,m,k,j,i+1)]) + SQR(bx1f[ix4(N3,N2,N1+1,m,k,j,i)]));
-            out[9] += vol*0.25*(SQR(bx2f[ix4(N3,N2+1,N1,m,k,j+1,i)]) + SQR(bx2f[ix4(N3,N2+1,N1,m,k,j,i)]));
-            out[10] += vol*0.25*(SQR(bx3f[ix4(N3+1,N2,N1,m,k+1,j,i)]) + SQR(bx3f[ix4(N3+1,N2,N1,m,k,j,i)]));
+            out[o+3] += vol*0.25*(SQR(bx1f[ix4(N3,N2,N1+1,m,k,j,i+1)]) + SQR(bx1f[ix4(N3,N2,N1+1,m,k,j,i)]));
+            out[o+4] += vol*0.25*(SQR(bx2f[ix4(N3,N2+1,N1,m,k,j+1,i)]) + SQR(bx2f[ix4(N3,N2+1,N1,m,k,j,i)]));
+            out[o+5] += vol*0.25*(SQR(bx3f[ix4(N3+1,N2,N1,m,k+1,j,i)]) + SQR(bx3f[ix4(N3+1,N2,N1,m,k,j,i)]));
           }
         }
   }
@@ -1241,6 +1593,31 @@ int akref_mhd_c2p(const akmi_pack *p, double *u0, const double *bx1f, const doub
                   int ju, int kl, int ku, int *counters) {
   G g = mkG(p);
   const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  if (!p->is_ideal) {
+    /* SingleC2P_IsothermalMHD, src/eos/isothermal_mhd.cpp:32-47,68-150 */
+    int sumd_ = 0;
+    for (int m = 0; m < g.nmb; ++m)
+      for (int k = kl; k <= ku; ++k)
+        for (int j = jl; j <= ju; ++j)
+          for (int i = il; i <= iu; ++i) {
+            size_t cd = ix5(nv,N3,N2,N1,m,IDN,k,j,i), cx = ix5(nv,N3,N2,N1,m,IVX,k,j,i);
+            size_t cy = ix5(nv,N3,N2,N1,m,IVY,k,j,i), cz = ix5(nv,N3,N2,N1,m,IVZ,k,j,i);
+            double ubx = 0.5*(bx1f[ix4(N3,N2,N1+1,m,k,j,i)] + bx1f[ix4(N3,N2,N1+1,m,k,j,i+1)]);
+            double uby = 0.5*(bx2f[ix4(N3,N2+1,N1,m,k,j,i)] + bx2f[ix4(N3,N2+1,N1,m,k,j+1,i)]);
+            double ubz = 0.5*(bx3f[ix4(N3+1,N2,N1,m,k,j,i)] + bx3f[ix4(N3+1,N2,N1,m,k+1,j,i)]);
+            const double b2 = SQR(ubx) + SQR(uby) + SQR(ubz);
+            const double dfloor_ = fmax(p->dfloor, b2/p->sigma_max);
+            double ud = u0[cd];
+            if (ud < dfloor_) { ud = dfloor_; u0[cd] = ud; sumd_++; }
+            double di = 1.0/ud;
+            w0[cd] = ud; w0[cx] = di*u0[cx]; w0[cy] = di*u0[cy]; w0[cz] = di*u0[cz];
+            bcc0[ix5(3,N3,N2,N1,m,IBX,k,j,i)] = ubx;
+            bcc0[ix5(3,N3,N2,N1,m,IBY,k,j,i)] = uby;
+            bcc0[ix5(3,N3,N2,N1,m,IBZ,k,j,i)] = ubz;
+          }
+    if (counters) counters[0] += sumd_;
+    return 0;
+  }
   const double gm1 = p->gamma - 1.0;
   const double efloor = p->pfloor/(p->gamma - 1.0);
   const double tfloor = p->tfloor, sfloor = p->sfloor;
@@ -1296,13 +1673,23 @@ int akref_mhd_newdt(const akmi_pack *p, const double *w0, const double *bcc0, do
         for (int i = g.is; i <= g.ie; ++i) {
           double w_d = W(IDN,m,k,j,i);
           double w_bx = B(IBX,m,k,j,i), w_by = B(IBY,m,k,j,i), w_bz = B(IBZ,m,k,j,i);
-          double pr = (p->gamma - 1.0)*W(IEN,m,k,j,i);
-          double cf = fast_speed(p->gamma, w_d, pr, w_bx, w_by, w_bz);
-          double max_dv1 = fabs(W(IVX,m,k,j,i)) + cf;
-          cf = fast_speed(p->gamma, w_d, pr, w_by, w_bz, w_bx);
-          double max_dv2 = fabs(W(IVY,m,k,j,i)) + cf;
-          cf = fast_speed(p->gamma, w_d, pr, w_bz, w_bx, w_by);
-          double max_dv3 = fabs(W(IVZ,m,k,j,i)) + cf;
+          double cf, max_dv1, max_dv2, max_dv3;
+          if (p->is_ideal) {
+            double pr = (p->gamma - 1.0)*W(IEN,m,k,j,i);
+            cf = fast_speed(p->gamma, w_d, pr, w_bx, w_by, w_bz);
+            max_dv1 = fabs(W(IVX,m,k,j,i)) + cf;
+            cf = fast_speed(p->gamma, w_d, pr, w_by, w_bz, w_bx);
+            max_dv2 = fabs(W(IVY,m,k,j,i)) + cf;
+            cf = fast_speed(p->gamma, w_d, pr, w_bz, w_bx, w_by);
+            max_dv3 = fabs(W(IVZ,m,k,j,i)) + cf;
+          } else {                                  /* mhd_newdt.cpp:137-144 */
+            cf = fast_speed_iso(p->iso_cs, w_d, w_bx, w_by, w_bz);
+            max_dv1 = fabs(W(IVX,m,k,j,i)) + cf;
+            cf = fast_speed_iso(p->iso_cs, w_d, w_by, w_bz, w_bx);
+            max_dv2 = fabs(W(IVY,m,k,j,i)) + cf;
+            cf = fast_speed_iso(p->iso_cs, w_d, w_bz, w_bx, w_by);
+            max_dv3 = fabs(W(IVZ,m,k,j,i)) + cf;
+          }
           dt1 = fmin(p->dx[3*m]/max_dv1, dt1);
           dt2 = fmin(p->dx[3*m+1]/max_dv2, dt2);
           dt3_ = fmin(p->dx[3*m+2]/max_dv3, dt3_);

@@ -27,6 +27,7 @@ struct akref_sim {
   double *bcc0, *b0[3], *b1[3], *efc[6], *e[3];
   size_t ncc, nf[3], ne[3], nfl[3];
   double time, dt, dtnew, tlim;
+  int nv;                          /* nhydro|nmhd: 5 ideal gas, 4 isothermal */
   int ncycle;
   int counters[3];
   double gam0[3], gam1[3], beta[3];
@@ -50,6 +51,7 @@ void akref_params_default(akref_params *p) {
   p->nstages = 2; p->cfl = 0.3; p->tlim = 1.0; p->nlim = -1;
   p->recon = AKMI_RECON_PLM; p->rsolver = AKMI_RS_HLLC;
   p->gamma = 5.0/3.0;
+  p->is_ideal = 1; p->iso_cs = 1.0;
   p->dfloor = p->pfloor = p->tfloor = p->sfloor = (double)FLT_MIN;  /* src/eos/eos.cpp:22-25 */
   p->sigma_max = (double)FLT_MAX;                                  /* src/eos/ideal_mhd.cpp:22 */
   p->dens = 1.0; p->pgas = 0.6; p->amp = 1e-6;
@@ -154,12 +156,13 @@ akref_sim *akref_create(const akref_params *par) {
   /* arrays: src/hydro/hydro.cpp:283-298, src/mhd/mhd.cpp:148-160,335-366 */
   const int N1 = s->N1, N2 = s->N2, N3 = s->N3;
   s->ncc = (size_t)nmb*N3*N2*N1;
-  s->u0 = dalloc(5*s->ncc); s->w0 = dalloc(5*s->ncc); s->u1 = dalloc(5*s->ncc);
+  const int nv = s->nv = p->is_ideal ? 5 : 4;    /* isothermal_hyd.cpp: no energy variable */
+  s->u0 = dalloc(nv*s->ncc); s->w0 = dalloc(nv*s->ncc); s->u1 = dalloc(nv*s->ncc);
   s->nf[0] = (size_t)nmb*N3*N2*(N1+1); s->nf[1] = (size_t)nmb*N3*(N2+1)*N1;
   s->nf[2] = (size_t)nmb*(N3+1)*N2*N1;
   int fs = p->is_mhd ? 1 : 0;
-  s->nfl[0] = (size_t)nmb*5*N3*N2*(N1+fs); s->nfl[1] = (size_t)nmb*5*N3*(N2+fs)*N1;
-  s->nfl[2] = (size_t)nmb*5*(N3+fs)*N2*N1;
+  s->nfl[0] = (size_t)nmb*nv*N3*N2*(N1+fs); s->nfl[1] = (size_t)nmb*nv*N3*(N2+fs)*N1;
+  s->nfl[2] = (size_t)nmb*nv*(N3+fs)*N2*N1;
   s->flx1 = dalloc(s->nfl[0]); s->flx2 = dalloc(s->nfl[1]); s->flx3 = dalloc(s->nfl[2]);
   if (p->is_mhd) {
     s->bcc0 = dalloc(3*s->ncc);
@@ -169,7 +172,8 @@ akref_sim *akref_create(const akref_params *par) {
     s->ne[2] = (size_t)nmb*N3*(N2+1)*(N1+1);
     for (int q = 0; q < 3; ++q) s->e[q] = dalloc(s->ne[q]);
   }
-  s->pack.nmb = nmb; s->pack.nvar = 5;
+  s->pack.nmb = nmb; s->pack.nvar = nv;
+  s->pack.iso_cs = p->iso_cs; s->pack.is_ideal = p->is_ideal;
   s->pack.nx1 = p->mb_nx1; s->pack.nx2 = p->mb_nx2; s->pack.nx3 = p->mb_nx3; s->pack.ng = ng;
   s->pack.dx = s->dx; s->pack.gamma = p->gamma;
   s->pack.dfloor = p->dfloor; s->pack.pfloor = p->pfloor; s->pack.tfloor = p->tfloor;
@@ -200,7 +204,7 @@ void akref_destroy(akref_sim *s) {
   free(s);
 }
 
-#define IX5(m,n,k,j,i) (((((size_t)(m)*5 + (n))*s->N3 + (k))*s->N2 + (j))*s->N1 + (i))
+#define IX5(m,n,k,j,i) (((((size_t)(m)*s->nv + (n))*s->N3 + (k))*s->N2 + (j))*s->N1 + (i))
 #define IB3(m,n,k,j,i) (((((size_t)(m)*3 + (n))*s->N3 + (k))*s->N2 + (j))*s->N1 + (i))
 #define IF1(m,k,j,i) ((((size_t)(m)*s->N3 + (k))*s->N2 + (j))*(s->N1+1) + (i))
 #define IF2(m,k,j,i) ((((size_t)(m)*s->N3 + (k))*(s->N2+1) + (j))*s->N1 + (i))
@@ -215,11 +219,12 @@ static void prim_to_cons(akref_sim *s, double *u) {
         for (int i = s->is; i <= s->ie; ++i) {
           double d = s->w0[IX5(m,IDN,k,j,i)], vx = s->w0[IX5(m,IVX,k,j,i)];
           double vy = s->w0[IX5(m,IVY,k,j,i)], vz = s->w0[IX5(m,IVZ,k,j,i)];
-          double e = s->w0[IX5(m,IEN,k,j,i)];
           u[IX5(m,IDN,k,j,i)] = d;
           u[IX5(m,IVX,k,j,i)] = d*vx;
           u[IX5(m,IVY,k,j,i)] = d*vy;
           u[IX5(m,IVZ,k,j,i)] = d*vz;
+          if (!s->par.is_ideal) continue;       /* SingleP2C_Isothermal*: no energy */
+          double e = s->w0[IX5(m,IEN,k,j,i)];
           if (s->par.is_mhd) {
             double bx = s->bcc0[IB3(m,0,k,j,i)], by = s->bcc0[IB3(m,1,k,j,i)];
             double bz = s->bcc0[IB3(m,2,k,j,i)];
@@ -271,6 +276,61 @@ static void hydro_eigen(double d, double v1, double p, double gamma, double ev[5
   rem[2][2] = 1.0;
   rem[3][3] = 1.0;
   rem[0][4] = 1.0; rem[1][4] = a/d; rem[4][4] = a*a;
+}
+
+/* isothermal hydro, linear_wave.cpp:838-866: waves 0 (v-cs), 1, 2 (shear), 3 (v+cs) */
+static void hydro_eigen_iso(double d, double v1, double cs, double ev[4], double rem[4][4]) {
+  ev[0] = v1 - cs; ev[1] = v1; ev[2] = v1; ev[3] = v1 + cs;
+  memset(rem, 0, sizeof(double)*16);
+  rem[0][0] = 1.0; rem[1][0] = -cs/d;
+  rem[2][1] = 1.0;
+  rem[3][2] = 1.0;
+  rem[0][3] = 1.0; rem[1][3] = cs/d;
+}
+
+/* isothermal MHD, linear_wave.cpp:1005-1098: rows d,vx,vy,vz,by,bz; 6 waves */
+static void mhd_eigen_iso(double d, double v1, double b1, double b2, double b3, double y,
+                          double iso_cs, double ev[6], double rem[6][6]) {
+  double btsq = b2*b2 + b3*b3;
+  double bt = sqrt(btsq);
+  double bet2, bet3;
+  if (bt == 0.0) { bet2 = 1.0; bet3 = 0.0; } else { bet2 = b2/bt; bet3 = b3/bt; }
+  double bt_starsq = btsq*y;
+  double vaxsq = b1*b1/d;
+  double iso_cs2 = (iso_cs*iso_cs);
+  double ct2 = bt_starsq/d;
+  double tsum = vaxsq + ct2 + iso_cs2;
+  double tdif = vaxsq + ct2 - iso_cs2;
+  double cf2_cs2 = sqrt(tdif*tdif + 4.0*iso_cs2*ct2);
+  double cfsq = 0.5*(tsum + cf2_cs2);
+  double cf = sqrt(cfsq);
+  double cssq = iso_cs2*vaxsq/cfsq;
+  double cs = sqrt(cssq);
+  double alpha_f, alpha_s;
+  if ((cfsq - cssq) == 0.0) { alpha_f = 1.0; alpha_s = 0.0; }
+  else if ((iso_cs2 - cssq) <= 0.0) { alpha_f = 0.0; alpha_s = 1.0; }
+  else if ((cfsq - iso_cs2) <= 0.0) { alpha_f = 1.0; alpha_s = 0.0; }
+  else { alpha_f = sqrt((iso_cs2 - cssq)/(cfsq - cssq)); alpha_s = sqrt((cfsq - iso_cs2)/(cfsq - cssq)); }
+  double sqrtd = sqrt(d);
+  double sg = SIGN(b1);
+  double qf = cf*alpha_f*sg;
+  double qs = cs*alpha_s*sg;
+  double af = (iso_cs)*alpha_f*sqrtd;
+  double as = (iso_cs)*alpha_s*sqrtd;
+  double vax = sqrt(vaxsq);
+  ev[0] = v1 - cf; ev[1] = v1 - vax; ev[2] = v1 - cs; ev[3] = v1 + cs; ev[4] = v1 + vax; ev[5] = v1 + cf;
+  rem[0][0] = d*alpha_f; rem[1][0] = -cf*alpha_f; rem[2][0] = qs*bet2; rem[3][0] = qs*bet3;
+  rem[4][0] = as*bet2; rem[5][0] = as*bet3;
+  rem[0][1] = 0.0; rem[1][1] = 0.0; rem[2][1] = -bet3; rem[3][1] = bet2;
+  rem[4][1] = -bet3*sg*sqrtd; rem[5][1] = bet2*sg*sqrtd;
+  rem[0][2] = d*alpha_s; rem[1][2] = -cs*alpha_s; rem[2][2] = -qf*bet2; rem[3][2] = -qf*bet3;
+  rem[4][2] = -af*bet2; rem[5][2] = -af*bet3;
+  rem[0][3] = d*alpha_s; rem[1][3] = cs*alpha_s; rem[2][3] = qf*bet2; rem[3][3] = qf*bet3;
+  rem[4][3] = rem[4][2]; rem[5][3] = rem[5][2];
+  rem[0][4] = 0.0; rem[1][4] = 0.0; rem[2][4] = bet3; rem[3][4] = -bet2;
+  rem[4][4] = rem[4][1]; rem[5][4] = rem[5][1];
+  rem[0][5] = d*alpha_f; rem[1][5] = cf*alpha_f; rem[2][5] = -qs*bet2; rem[3][5] = -qs*bet3;
+  rem[4][5] = rem[4][0]; rem[5][5] = rem[5][0];
 }
 
 /* MHDEigensystemPrim, linear_wave.cpp:876-1010 (ideal gas) */
@@ -352,8 +412,20 @@ static void pgen_linear_wave(akref_sim *s, int set_ic) {
   lw.bx_0 = p->bx0; lw.by_0 = p->by0; lw.bz_0 = p->bz0; lw.dby = 0.0; lw.dbz = 0.0;
   const double gm1 = p->gamma - 1.0;
   double remh[5][5], evh[5], remm[7][7], evm[7];
-  double r0, r1, r2, r3, r4, evw;
-  if (!p->is_mhd) {
+  double r0, r1, r2, r3, r4 = 0.0, evw;
+  if (!p->is_ideal && !p->is_mhd) {
+    double r[4][4], e[4];
+    hydro_eigen_iso(lw.d0, lw.vx_0, p->iso_cs, e, r);
+    r0 = r[0][lw.wave_flag]; r1 = r[1][lw.wave_flag]; r2 = r[2][lw.wave_flag];
+    r3 = r[3][lw.wave_flag]; evw = e[lw.wave_flag];
+  } else if (!p->is_ideal) {
+    double r[6][6], e[6];
+    mhd_eigen_iso(lw.d0, lw.vx_0, lw.bx_0, lw.by_0, lw.bz_0, 1.0, p->iso_cs, e, r);
+    lw.dby = amp*r[4][lw.wave_flag];           /* rem[nmhd_][wave], nmhd_ = 4 */
+    lw.dbz = amp*r[5][lw.wave_flag];
+    r0 = r[0][lw.wave_flag]; r1 = r[1][lw.wave_flag]; r2 = r[2][lw.wave_flag];
+    r3 = r[3][lw.wave_flag]; evw = e[lw.wave_flag];
+  } else if (!p->is_mhd) {
     hydro_eigen(lw.d0, lw.vx_0, lw.p0, p->gamma, evh, remh);
     r0 = remh[0][lw.wave_flag]; r1 = remh[1][lw.wave_flag]; r2 = remh[2][lw.wave_flag];
     r3 = remh[3][lw.wave_flag]; r4 = remh[4][lw.wave_flag]; evw = evh[lw.wave_flag];
@@ -388,12 +460,11 @@ static void pgen_linear_wave(akref_sim *s, int set_ic) {
           double vx = lw.vx_0 + amp*sn*r1;
           double vy = lw.vy_0 + amp*sn*r2;
           double vz = lw.vz_0 + amp*sn*r3;
-          double egas = (lw.p0 + amp*sn*r4)/gm1;
           s->w0[IX5(m,IDN,k,j,i)] = rho;
           s->w0[IX5(m,IVX,k,j,i)] = vx*lw.cos_a2*lw.cos_a3 - vy*lw.sin_a3 - vz*lw.sin_a2*lw.cos_a3;
           s->w0[IX5(m,IVY,k,j,i)] = vx*lw.cos_a2*lw.sin_a3 + vy*lw.cos_a3 - vz*lw.sin_a2*lw.sin_a3;
           s->w0[IX5(m,IVZ,k,j,i)] = vx*lw.sin_a2 + vz*lw.cos_a2;
-          s->w0[IX5(m,IEN,k,j,i)] = egas;
+          if (p->is_ideal) s->w0[IX5(m,IEN,k,j,i)] = (lw.p0 + amp*sn*r4)/gm1;
         }
   }
   if (p->is_mhd) {
@@ -481,7 +552,7 @@ static void pgen_shock_tube(akref_sim *s) {
           s->w0[IX5(m,ivx,k,j,i)] = w[1]*1.0;
           s->w0[IX5(m,ivy,k,j,i)] = w[2]*1.0;
           s->w0[IX5(m,ivz,k,j,i)] = w[3]*1.0;
-          s->w0[IX5(m,IEN,k,j,i)] = w[4]/gm1;
+          if (p->is_ideal) s->w0[IX5(m,IEN,k,j,i)] = w[4]/gm1;
           if (p->is_mhd) {
             s->b0[0][IF1(m,k,j,i)] = b[0];
             s->b0[1][IF2(m,k,j,i)] = b[1];
@@ -621,10 +692,10 @@ static int strictly_periodic(const akref_sim *s) {
  * (src/hydro/hydro_tasks.cpp:308-320,357-412; src/mhd/mhd_tasks.cpp:478-520) */
 static void halo_bcs_c2p(akref_sim *s) {
   const akmi_pack *pk = &s->pack;
-  akref_bvals_cc_local(pk, 5, s->nghbr, s->u0);
+  akref_bvals_cc_local(pk, s->nv, s->nghbr, s->u0);
   if (s->par.is_mhd) akref_bvals_fc_local(pk, s->nghbr, s->b0[0], s->b0[1], s->b0[2]);
   if (!strictly_periodic(s)) {
-    akref_hydro_bcs(pk, 5, s->bcs, s->u0);
+    akref_hydro_bcs(pk, s->nv, s->bcs, s->u0);
     if (s->par.is_mhd) akref_bfield_bcs(pk, s->bcs, s->b0[0], s->b0[1], s->b0[2]);
   }
   if (s->par.is_mhd)
@@ -719,7 +790,7 @@ void akref_pack(const akref_sim *s, akmi_pack *out) { *out = s->pack; }
 
 void *akref_array(akref_sim *s, const char *name, long long *count) {
   struct { const char *n; void *p; size_t c; } tab[] = {
-    {"u0", s->u0, 5*s->ncc}, {"w0", s->w0, 5*s->ncc}, {"u1", s->u1, 5*s->ncc},
+    {"u0", s->u0, s->nv*s->ncc}, {"w0", s->w0, s->nv*s->ncc}, {"u1", s->u1, s->nv*s->ncc},
     {"bcc0", s->bcc0, 3*s->ncc},
     {"b0x1f", s->b0[0], s->nf[0]}, {"b0x2f", s->b0[1], s->nf[1]}, {"b0x3f", s->b0[2], s->nf[2]},
     {"b1x1f", s->b1[0], s->nf[0]}, {"b1x2f", s->b1[1], s->nf[1]}, {"b1x3f", s->b1[2], s->nf[2]},
@@ -741,7 +812,8 @@ void *akref_array(akref_sim *s, const char *name, long long *count) {
  * src/pgen/pgen.cpp:680-900 */
 int akref_linear_wave_errors(akref_sim *s, double *out) {
   pgen_linear_wave(s, 0);
-  int nvars = s->par.is_mhd ? 8 : 5;
+  const int nf = s->nv;                       /* pgen.cpp:756-766: bindx = nmhd */
+  int nvars = s->par.is_mhd ? nf + 3 : nf;
   double l1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   double linf = 0.0;
   for (int m = 0; m < s->nmb; ++m) {
@@ -749,21 +821,22 @@ int akref_linear_wave_errors(akref_sim *s, double *out) {
     for (int k = s->ks; k <= s->ke; ++k)
       for (int j = s->js; j <= s->je; ++j)
         for (int i = s->is; i <= s->ie; ++i) {
-          double ev[8];
-          for (int n = 0; n < 5; ++n) {
+          double ev[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+          for (int n = 0; n < nf; ++n) {
             ev[n] = vol*fabs(s->u0[IX5(m,n,k,j,i)] - s->u1[IX5(m,n,k,j,i)]);
             linf = fmax(linf, ev[n]);
           }
           if (s->par.is_mhd) {
             double a = 0.5*(s->b0[0][IF1(m,k,j,i)] + s->b0[0][IF1(m,k,j,i+1)]);
             double b = 0.5*(s->b1[0][IF1(m,k,j,i)] + s->b1[0][IF1(m,k,j,i+1)]);
-            ev[5] = vol*fabs(a - b);
+            ev[nf] = vol*fabs(a - b);
             a = 0.5*(s->b0[1][IF2(m,k,j,i)] + s->b0[1][IF2(m,k,j+1,i)]);
             b = 0.5*(s->b1[1][IF2(m,k,j,i)] + s->b1[1][IF2(m,k,j+1,i)]);
-            ev[6] = vol*fabs(a - b);
+            ev[nf+1] = vol*fabs(a - b);
             a = 0.5*(s->b0[2][IF3(m,k,j,i)] + s->b0[2][IF3(m,k+1,j,i)]);
             b = 0.5*(s->b1[2][IF3(m,k,j,i)] + s->b1[2][IF3(m,k+1,j,i)]);
-            ev[7] = vol*fabs(a - b);
+            ev[nf+2] = vol*fabs(a - b);
+            /* pgen.cpp:793-805 takes the maxima from slots IEN+1..IEN+3 = 5,6,7 whatever bindx is */
             linf = fmax(linf, fmax(ev[5], fmax(ev[6], ev[7])));
           }
           for (int n = 0; n < nvars; ++n) l1[n] += ev[n];

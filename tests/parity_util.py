@@ -64,6 +64,8 @@ def oracle_kwargs(pin):
               cfl=g("time", "cfl_number"), tlim=g("time", "tlim"), nlim=gi("time", "nlim"),
               is_mhd=1 if is_mhd else 0, recon=gs(blk, "reconstruct"), rsolver=gs(blk, "rsolver"),
               gamma=g(blk, "gamma"))
+    if gs(blk, "eos") == "isothermal":
+        kw.update(is_ideal=0, iso_cs=g(blk, "iso_sound_speed"))
     name = gs("problem", "pgen_name")
     kw["pgen"] = name
     P = lambda k, d=0.0: (g("problem", k) if pin.DoesParameterExist("problem", k) else d)

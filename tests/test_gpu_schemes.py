@@ -179,3 +179,109 @@ def test_unknown_scheme_is_rejected():
     assert b"rsolver" in L.akmi_last_error()
     assert L.akmi_hydro_fluxes(C.byref(pkd), 4, 2, capi._p(w0), *[capi._p(x) for x in f], 1, None) < 0
     assert b"nghost" in L.akmi_last_error()
+
+
+# ---- isothermal EOS (task-granular kernels; the host falls back from the fused stage) ----------
+ISO_RS = {"hydro": ["llf", "hlle", "roe"], "mhd": ["llf", "hlle", "hlld"]}
+
+
+@pytest.mark.parametrize("recon", ["plm", "ppm4", "ppmx", "wenoz"])
+@pytest.mark.parametrize("soe", ["hydro", "mhd"])
+def test_isothermal_lwave1d_matrix_is_bit_identical(soe, recon):
+    """run arguments of test_nr_isolwave1d_cpu.py (eos=isothermal, N=64, 4 blocks, ng=3) for every
+    solver; initial data from the product's own problem generator (inject=False) so that the
+    isothermal eigenvectors of pgen.py are compared with the oracle's as well"""
+    for rs in ISO_RS[soe]:
+        for wave in ((0, 3) if soe == "hydro" else (0, 2, 5)):
+            res = pu.compare_run("linear_wave_%s" % soe, 64, 1, 16, 10, ng=3, recon=recon, rsolver=rs,
+                                 integrator="rk2" if recon == "plm" else "rk3", cfl=0.4, inject=False,
+                                 extra=["problem/along_x1=true", "problem/amp=1.0e-6",
+                                        "problem/wave_flag=%d" % wave, "%s/eos=isothermal" % soe])
+            assert res["cycles"] == 10 and res["time"][0] == res["time"][1]
+            assert res["max_rel_l1"] <= pu.TOL, (soe, recon, rs, wave, res["diffs"])
+
+
+@pytest.mark.parametrize("case", [
+    ("linear_wave_hydro", 24, 3, 12, 3, dict(ng=3, recon="wenoz", rsolver="roe")),
+    ("linear_wave_hydro", 32, 2, 16, 4, dict(recon="plm", rsolver="hlle")),
+    ("linear_wave_mhd", 24, 3, 12, 3, dict(ng=3, recon="ppmx", rsolver="hlld", integrator="rk3")),
+    ("linear_wave_mhd", 32, 2, 16, 4, dict(recon="plm", rsolver="llf")),
+    ("sod", 64, 1, 32, 8, dict(cfl=0.3, recon="plm", rsolver="roe")),
+    ("rj2a", 128, 1, 64, 8, dict(cfl=0.3, rsolver="hlld")),
+], ids=lambda c: "%s-%d^%d-%s" % (c[0], c[1], c[2], c[5]["rsolver"]))
+def test_isothermal_multi_d_runs_are_bit_identical(case):
+    problem, n, dims, mb, cycles, kw = case
+    blk = "hydro" if problem in ("linear_wave_hydro", "sod") else "mhd"
+    kw = dict(kw)
+    kw["extra"] = list(kw.get("extra", [])) + ["%s/eos=isothermal" % blk]
+    res = pu.compare_run(problem, n, dims, mb, cycles, **kw)
+    assert res["cycles"] == cycles and res["time"][0] == res["time"][1]
+    assert res["bitwise_equal"], res["diffs"]
+
+
+@pytest.mark.parametrize("rs", ["llf", "hlle", "roe"])
+@pytest.mark.parametrize("recon", ["plm", "wenoz"])
+def test_task_hydro_fluxes_wild_states_isothermal(recon, rs):
+    from athenak_amd import capi
+    o = akref.Sim(nx1=20, nx2=12, nx3=8, mb_nx1=10, mb_nx2=12, mb_nx3=8, ng=3, nstages=2, cfl=0.3,
+                  tlim=1.0, nlim=-1, is_mhd=0, recon="plm", rsolver="llf", gamma=1.4, is_ideal=0,
+                  iso_cs=0.7, pgen="shock_tube", shock_dir=1, xshock=0.0, wl=[1, 0, 0, 0, 1, 0, 0, 0],
+                  wr=[0.125, 0, 0, 0, 0.1, 0, 0, 0], bcs=["outflow"]*6, dfloor=1e-3)
+    o.initialize()
+    L, R = capi.lib(), akref.lib()
+    pk = o.pack()
+    dxd = _t(o.array("dx"))
+    pkd = capi.Pack.from_buffer_copy(bytes(pk))
+    pkd.dx = dxd.data_ptr()
+    rng = np.random.default_rng(99)
+    n3, n2, n1 = o.dims()
+    w0 = _wild_states((o.nmb, 5, n3, n2, n1), rng, False)[:, :4].copy()
+    f = [np.zeros((o.nmb, 4, n3, n2, n1 + 1)), np.zeros((o.nmb, 4, n3, n2 + 1, n1)),
+         np.zeros((o.nmb, 4, n3 + 1, n2, n1))]
+    rc, sc = akref.RECON[recon], akref.RSOLVER[rs]
+    assert R.akref_hydro_fluxes(C.byref(pk), rc, sc, akref.ptr(w0), *[akref.ptr(x) for x in f], 1) == 0
+    fd = [_t(np.zeros_like(x)) for x in f]
+    w0d = _t(w0)
+    capi.check(L.akmi_hydro_fluxes(C.byref(pkd), rc, sc, capi._p(w0d), *[capi._p(x) for x in fd], 1,
+                                   None), "fluxes")
+    for a, b in zip(f, fd):
+        assert np.isfinite(a).all() and np.array_equal(a, b.cpu().numpy())
+    # hllc does not exist for the isothermal EOS
+    assert L.akmi_hydro_fluxes(C.byref(pkd), rc, 2, capi._p(w0d), *[capi._p(x) for x in fd], 1, None) < 0
+
+
+@pytest.mark.parametrize("rs", ["llf", "hlle", "hlld"])
+@pytest.mark.parametrize("recon", ["plm", "wenoz"])
+def test_task_mhd_fluxes_wild_states_isothermal(recon, rs):
+    from athenak_amd import capi
+    o = akref.Sim(nx1=16, nx2=12, nx3=8, mb_nx1=8, mb_nx2=12, mb_nx3=8, ng=3, nstages=2, cfl=0.3,
+                  tlim=1.0, nlim=-1, is_mhd=1, recon="plm", rsolver="llf", gamma=1.4, is_ideal=0,
+                  iso_cs=0.7, pgen="shock_tube", shock_dir=1, xshock=0.0,
+                  wl=[1, 0, 0, 0, 1, 0.5, 1, 0], wr=[0.125, 0, 0, 0, 0.1, 0.5, -1, 0],
+                  bcs=["outflow"]*6, dfloor=1e-3)
+    o.initialize()
+    L, R = capi.lib(), akref.lib()
+    pk = o.pack()
+    dxd = _t(o.array("dx"))
+    pkd = capi.Pack.from_buffer_copy(bytes(pk))
+    pkd.dx = dxd.data_ptr()
+    rng = np.random.default_rng(77)
+    n3, n2, n1 = o.dims()
+    h = {"w0": _wild_states((o.nmb, 5, n3, n2, n1), rng, True)[:, :4].copy(),
+         "bcc0": rng.normal(0, 2.0, size=(o.nmb, 3, n3, n2, n1)),
+         "b0x1f": rng.normal(0, 2.0, size=(o.nmb, n3, n2, n1 + 1)),
+         "b0x2f": rng.normal(0, 2.0, size=(o.nmb, n3, n2 + 1, n1)),
+         "b0x3f": rng.normal(0, 2.0, size=(o.nmb, n3 + 1, n2, n1))}
+    h["b0x1f"][:, :, :, ::3] = 0.0
+    names_in = ["w0", "bcc0", "b0x1f", "b0x2f", "b0x3f"]
+    names_out = ["flx1", "flx2", "flx3", "e3x1", "e2x1", "e1x2", "e3x2", "e2x3", "e1x3"]
+    for k in names_out:
+        h[k] = np.zeros_like(o.array(k))
+    dv = {k: _t(v) for k, v in h.items()}
+    rc, sc = akref.RECON[recon], akref.RSOLVER[rs]
+    assert R.akref_mhd_fluxes(C.byref(pk), rc, sc, *[akref.ptr(h[k]) for k in names_in + names_out]) == 0
+    capi.check(L.akmi_mhd_fluxes(C.byref(pkd), rc, sc, *[capi._p(dv[k]) for k in names_in + names_out],
+                                 None), "mhd_fluxes")
+    for k in names_out:
+        assert np.isfinite(h[k]).all(), k
+        assert np.array_equal(h[k], dv[k].cpu().numpy()), k

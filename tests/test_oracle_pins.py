@@ -12,14 +12,14 @@ from oracle import akref
 
 
 def lwave1d(is_mhd, res, wave, recon="plm", nst=2, amp=1e-6, cfl=0.4, ng=3, mb=16, vx0=0.0,
-            rsolver=None):
+            rsolver=None, iso=False):
     s = akref.Sim(nx1=res, nx2=1, nx3=1, mb_nx1=mb, mb_nx2=1, mb_nx3=1, ng=ng, x1min=0., x1max=3.,
                   x2min=0., x2max=1.5, x3min=0., x3max=1.5, bcs=["periodic"]*6, nstages=nst,
                   cfl=cfl, tlim=1.0, is_mhd=is_mhd, recon=recon,
                   rsolver=rsolver or ("hlld" if is_mhd else "hllc"), gamma=1.66666666667,
                   pgen="linear_wave",
                   wave_flag=wave, along_x1=1, amp=amp, dens=1.0, pgas=0.6, vx0=vx0, bx0=1.0,
-                  by0=1.4142136, bz0=0.5)
+                  by0=1.4142136, bz0=0.5, is_ideal=0 if iso else 1, iso_cs=1.0)
     s.initialize()
     n = s.run()
     return s.linear_wave_errors(), n
@@ -117,6 +117,33 @@ def test_plm_left_right_wave_errors_equal_every_solver(rs):
             a, _ = lwave1d(is_mhd, 64, wl, nst=nst, rsolver=rs)
             b, _ = lwave1d(is_mhd, 64, wr, nst=nst, rsolver=rs)
             assert "%e" % a[0] == "%e" % b[0]
+
+
+@pytest.mark.parametrize("soe", ["hydro", "mhd"])
+def test_isothermal_lwave1d_full_matrix(soe):
+    """test_nr_isolwave1d_cpu.py: eos=isothermal, every (reconstruction, wave) threshold pair for
+    every solver the reference loops over (hydro llf/hlle/roe, mhd llf/hlle/hlld; rk2 for plm,
+    rk3 otherwise), plus the L/R equality of :104-109 for plm"""
+    import json
+    import os
+    ka = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "known_answers.json")))
+    t = ka["isolwave1d_thresholds"]
+    mh = int(soe == "mhd")
+    for key in sorted(t["values"]):
+        s_, integ, recon, wave = key.split(",")
+        if s_ != soe:
+            continue
+        nst = {"rk2": 2, "rk3": 3}[integ]
+        for rs in t["rsolvers"][soe]:
+            e32, _ = lwave1d(mh, 32, int(wave), recon, nst, rsolver=rs, iso=True)
+            e64, _ = lwave1d(mh, 64, int(wave), recon, nst, rsolver=rs, iso=True)
+            assert e64[0] <= t["values"][key][0], (key, rs, e64[0])
+            assert e64[0]/e32[0] <= t["values"][key][1], (key, rs, e64[0]/e32[0])
+    wl, wr = t["left_right"][soe]
+    for rs in t["rsolvers"][soe]:
+        a, _ = lwave1d(mh, 64, wl, rsolver=rs, iso=True)
+        b, _ = lwave1d(mh, 64, wr, rsolver=rs, iso=True)
+        assert "%e" % a[0] == "%e" % b[0], (soe, rs)
 
 
 def _rj2a_error(res, recon, rs):
