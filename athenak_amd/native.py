@@ -25,7 +25,8 @@ class _Face:
 
 class _Eos:
     def __init__(self, gamma):
-        self.eos_data = type("EOS_Data", (), {"gamma": gamma})()
+        # the C++ driver runs the ideal-gas EOS only (isothermal decks: Python host)
+        self.eos_data = type("EOS_Data", (), {"gamma": gamma, "is_ideal": True, "iso_cs": 0.0})()
 
 
 class _PhysAlias:
@@ -46,6 +47,7 @@ class NativeSimulation:
         nmb = self.pmesh.nmb_total
         ph = _PhysAlias()
         ph.peos = _Eos(pin.GetReal(blk, "gamma"))
+        ph.nfluid = 5
         ph.u0 = self._alias("u0", (nmb, 5, n3, n2, n1))
         ph.w0 = self._alias("w0", (nmb, 5, n3, n2, n1))
         ph.u1 = self._alias("u1", (nmb, 5, n3, n2, n1))

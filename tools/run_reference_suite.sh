@@ -23,7 +23,7 @@ python - "$@" <<'PY'
 import os, sys, pytest
 sys.path.insert(0, os.getcwd())
 import test_suite.testutils  # noqa: F401  (resolves ../vis/python relative to tst/)
-tests = [os.path.abspath("test_suite/nr/test_nr_%s_cpu.py" % t) for t in ("lwave1d", "sod", "rj2a")]
+tests = [os.path.abspath("test_suite/nr/test_nr_%s_cpu.py" % t) for t in ("lwave1d", "isolwave1d", "sod", "rj2a")]
 os.chdir("build/src")
 args = tests + ["-p", "no:cacheprovider", "-q"] + ([] if os.environ.get("AKMI_SUITE_KEEP_GOING") else ["-x"])
 if len(sys.argv) > 1:
