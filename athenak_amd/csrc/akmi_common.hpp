@@ -100,9 +100,9 @@ inline int dispatch_scheme(const Scheme &sc, F &&f) {
 }
 
 inline int check_scheme(const akmi_pack *p, int recon, const char *who) {
-  if (p->nvar != (p->is_ideal ? 5 : 4)) {
-    set_error("%s: nvar = %d does not match the EOS (5 ideal gas, 4 isothermal; passive scalars "
-              "are not on this path)", who, p->nvar);
+  if (p->nvar < (p->is_ideal ? 5 : 4)) {
+    set_error("%s: nvar = %d is smaller than the fluid variable set of the EOS (5 ideal gas, 4 "
+              "isothermal)", who, p->nvar);
     return AKMI_FAIL;
   }
   if (recon >= AKMI_RECON_PPM4 && recon <= AKMI_RECON_TENO && p->ng < 3) {

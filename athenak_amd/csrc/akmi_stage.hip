@@ -924,9 +924,9 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
                         double *b1x3f, void *ws, const C2PArgs &cp_in, hipStream_t st,
                         int phases = AKMI_PHASE_ALL) {
   if (check_scheme(p, recon, "stage") != AKMI_COMPLETE) return AKMI_FAIL;
-  if (!p->is_ideal) {
-    set_error("fused stage kernels are specialised for the ideal-gas variable set; use the "
-              "task-granular entries for eos = isothermal");
+  if (!p->is_ideal || p->nvar != 5) {
+    set_error("fused stage kernels are specialised for the ideal-gas variable set without passive "
+              "scalars; use the task-granular entries for eos = isothermal or nscalars > 0");
     return AKMI_FAIL;
   }
   Geo g = make_geo(p);

@@ -53,6 +53,14 @@ k_hydro_flux(Geo g, FaceEos eos, const double *__restrict__ w0, double *__restri
   double *f = flx + ix5(g.nvar, f3, f2, f1, m, 0, k, j, i);
   f[0] = fd; f[ivx*fs] = fx; f[ivy*fs] = fy; f[ivz*fs] = fz;
   if constexpr (!ISO) f[4*fs] = fe;
+  // passive scalars: reconstructed like any primitive, upwinded by the sign of the mass flux
+  // (hydro_fluxes.cpp:135-147)
+  constexpr int NF = ISO ? 4 : 5;
+  for (int n = NF; n < g.nvar; ++n) {
+    double sl, sr;
+    face_states<RECON, 0>(q + n*cs, s, eos, sl, sr);
+    f[n*fs] = fd*((fd >= 0.0) ? sl : sr);
+  }
 }
 
 template <int DIR>
@@ -143,6 +151,7 @@ k_c2p(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ bx1f,
     const double di = 1.0/ud;
     w0[c] = ud; w0[c + cs] = di*u0[c + cs]; w0[c + 2*cs] = di*u0[c + 2*cs];
     w0[c + 3*cs] = di*u0[c + 3*cs];
+    for (int n = 4; n < g.nvar; ++n) w0[c + n*cs] = u0[c + n*cs]/ud;   // isothermal_*.cpp: no floor
     return;
   }
   double ud = u0[c], umx = u0[c + cs], umy = u0[c + 2*cs], umz = u0[c + 3*cs], ue = u0[c + 4*cs];
@@ -157,6 +166,11 @@ k_c2p(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ bx1f,
   if (efl) { u0[c + 4*cs] = ue; atomicAdd(&counters[1], 1); }
   if (tfl) { u0[c + 4*cs] = ue; atomicAdd(&counters[2], 1); }
   w0[c] = wd; w0[c + cs] = wvx; w0[c + 2*cs] = wvy; w0[c + 3*cs] = wvz; w0[c + 4*cs] = we;
+  for (int n = 5; n < g.nvar; ++n) {        // scalars with their floor, ideal_hyd.cpp:94-101
+    double us = u0[c + n*cs];
+    if (us < 0.0) { us = 0.0; u0[c + n*cs] = 0.0; }
+    w0[c + n*cs] = us/ud;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -336,6 +350,16 @@ k_mhd_flux(Geo g, FaceEos eos, const double *__restrict__ w0, const double *__re
   double *f = flx + ix5(g.nvar, f3, f2, f1, m, 0, k, j, i);
   f[0] = fl.d; f[ivx*fs] = fl.mx; f[ivy*fs] = fl.my; f[ivz*fs] = fl.mz;
   if constexpr (!ISO) f[4*fs] = fl.e;
+  // passive scalars, active transverse range only (mhd_fluxes.cpp:153-166)
+  constexpr int NF = ISO ? 4 : 5;
+  if (g.nvar > NF && i >= g.is && i <= g.ie + (DIR == 0) && j >= g.js && j <= g.je + (DIR == 1) &&
+      k >= g.ks && k <= g.ke + (DIR == 2)) {
+    for (int n = NF; n < g.nvar; ++n) {
+      double sl, sr;
+      face_states<RECON, 0>(q + n*cs, s, eos, sl, sr);
+      f[n*fs] = fl.d*((fl.d >= 0.0) ? sl : sr);
+    }
+  }
   const size_t ec = ix4(g.N3, g.N2, g.N1, m, k, j, i);
   ey[ec] = -fl.by;
   ez[ec] = fl.bz;

@@ -84,19 +84,18 @@ class FluidBase:
             raise RuntimeError("### FATAL ERROR PPM/WENOZ reconstruction requires at least 3 "
                                "ghost zones, but <mesh>/nghost=%d" % indcs.ng)
         self.nscalars = pin.GetOrAddInteger(blk, "nscalars", 0)
-        if self.nscalars:
-            raise RuntimeError("### FATAL ERROR passive scalars are not on this build's path")
         self.nmb = ppack.nmb_thispack
         self.dx_dev = torch.from_numpy(ppack.pmb.dx.copy()).to(device)
         e = self.peos.eos_data
         self.nfluid = 5 if e.is_ideal else 4         # nhydro / nmhd: no energy when isothermal
-        self.pack_c = capi.Pack(self.nmb, self.nfluid, indcs.nx1, indcs.nx2, indcs.nx3, indcs.ng,
+        self.nvars = self.nfluid + self.nscalars     # scalars follow the fluid variables
+        self.pack_c = capi.Pack(self.nmb, self.nvars, indcs.nx1, indcs.nx2, indcs.nx3, indcs.ng,
                                 self.dx_dev.data_ptr(), e.gamma, e.dfloor, e.pfloor, e.tfloor,
                                 e.sfloor, e.sigma_max, e.iso_cs, 1 if e.is_ideal else 0)
         self.fused = pin.GetOrAddBoolean(blk, "fused_stage", True)
-        if not e.is_ideal:
+        if not e.is_ideal or self.nscalars > 0:
             # the fused stage kernels are specialised for the ideal-gas variable set; isothermal
-            # runs use the task-granular kernels (same results, one kernel per task)
+            # runs and runs with passive scalars use the task-granular kernels (one kernel per task)
             self.fused = False
         self.counters = torch.zeros(3, dtype=torch.int32, device=device)
         self.dt3 = torch.zeros(3, dtype=torch.float64, device=device)
@@ -132,13 +131,13 @@ class Hydro(FluidBase):
         self.rsolver_method = capi.RSOLVER[rs]
         self.nhydro = self.nfluid
         n3, n2, n1 = ppack.pmesh.mb_indcs.ncells
-        sh = (self.nmb, self.nhydro, n3, n2, n1)
+        sh = (self.nmb, self.nvars, n3, n2, n1)
         z = lambda: torch.zeros(sh, dtype=torch.float64, device=device)
         self.u0, self.w0, self.u1 = z(), z(), z()
         # task-granular path keeps the reference's cell-shaped flux arrays (hydro.cpp:290-292)
-        self.uflx = None if self.fused else FaceFld(self.nmb, self.nhydro, n3, n2, n1, device, face_shaped=False)
+        self.uflx = None if self.fused else FaceFld(self.nmb, self.nvars, n3, n2, n1, device, face_shaped=False)
         self.pbval_u = MeshBoundaryValues(ppack, bvals_kernels, device)
-        self.pbval_u.set_pack(self.pack_c, self.nhydro)
+        self.pbval_u.set_pack(self.pack_c, self.nvars)
 
     # ---- task list assembly: hydro_tasks.cpp:48-80 ---------------------------------
     def AssembleHydroTasks(self, tl):

@@ -26,19 +26,19 @@ class MHD(FluidBase):
         self.nmhd = self.nfluid
         n3, n2, n1 = ppack.pmesh.mb_indcs.ncells
         nmb = self.nmb
-        z5 = lambda: torch.zeros((nmb, self.nmhd, n3, n2, n1), dtype=torch.float64, device=device)
+        z5 = lambda: torch.zeros((nmb, self.nvars, n3, n2, n1), dtype=torch.float64, device=device)
         self.u0, self.w0, self.u1 = z5(), z5(), z5()
         self.bcc0 = torch.zeros((nmb, 3, n3, n2, n1), dtype=torch.float64, device=device)
         self.b0 = FaceFld(nmb, 0, n3, n2, n1, device)
         self.b1 = FaceFld(nmb, 0, n3, n2, n1, device)
         if not self.fused:
             zc = lambda: torch.zeros((nmb, n3, n2, n1), dtype=torch.float64, device=device)
-            self.uflx = FaceFld(nmb, self.nmhd, n3, n2, n1, device)        # mhd.cpp:341-343
+            self.uflx = FaceFld(nmb, self.nvars, n3, n2, n1, device)        # mhd.cpp:341-343
             self.efld = EdgeFld(nmb, n3, n2, n1, device)           # mhd.cpp:344-346
             self.e3x1, self.e2x1, self.e1x2 = zc(), zc(), zc()     # mhd.cpp:349-354
             self.e3x2, self.e2x3, self.e1x3 = zc(), zc(), zc()
         self.pbval_u = MeshBoundaryValues(ppack, bvals_kernels, device)
-        self.pbval_u.set_pack(self.pack_c, self.nmhd)
+        self.pbval_u.set_pack(self.pack_c, self.nvars)
         self.pbval_b = self.pbval_u       # same neighbour tables; separate FC channel inside
 
     # ---- task list assembly: mhd_tasks.cpp:38-84 -----------------------------------

@@ -47,7 +47,7 @@ class NativeSimulation:
         nmb = self.pmesh.nmb_total
         ph = _PhysAlias()
         ph.peos = _Eos(pin.GetReal(blk, "gamma"))
-        ph.nfluid = 5
+        ph.nfluid = ph.nvars = 5
         ph.u0 = self._alias("u0", (nmb, 5, n3, n2, n1))
         ph.w0 = self._alias("w0", (nmb, 5, n3, n2, n1))
         ph.u1 = self._alias("u1", (nmb, 5, n3, n2, n1))

@@ -181,7 +181,10 @@ class ProblemGenerator:
         u[:, 1] = d*vx
         u[:, 2] = d*vy
         u[:, 3] = d*vz
-        if w.shape[1] == 4:              # SingleP2C_Isothermal*: no energy
+        ideal = self._phys().peos.eos_data.is_ideal
+        for n in range(5 if ideal else 4, w.shape[1]):       # scalars: d*s
+            u[:, n] = d*w[:, n]
+        if not ideal:                    # SingleP2C_Isothermal*: no energy
             return u
         e = w[:, 4]
         if bcc is None:
@@ -221,7 +224,7 @@ class ProblemGenerator:
         pm = self.pmy_mesh_
         n3, n2, n1 = pm.mb_indcs.ncells
         nmb = pm.pmb_pack.nmb_thispack
-        w = np.zeros((nmb, self._phys().nfluid, n3, n2, n1))
+        w = np.zeros((nmb, self._phys().nvars, n3, n2, n1))      # scalars (if any) start at zero
         b = (np.zeros((nmb, n3, n2, n1 + 1)), np.zeros((nmb, n3, n2 + 1, n1)),
              np.zeros((nmb, n3 + 1, n2, n1)))
         return w, b
@@ -472,7 +475,7 @@ class ProblemGenerator:
             w[m, ivx][ks, js, is_] = sel(wl[1]*1.0, wr[1]*1.0)
             w[m, ivy][ks, js, is_] = sel(wl[2]*1.0, wr[2]*1.0)
             w[m, ivz][ks, js, is_] = sel(wl[3]*1.0, wr[3]*1.0)
-            if w.shape[1] == 5:
+            if self._phys().peos.eos_data.is_ideal:
                 w[m, IEN][ks, js, is_] = sel(wl[4], wr[4])
             if is_mhd:
                 v1, v2, v3 = sel(bL[0], bR[0]), sel(bL[1], bR[1]), sel(bL[2], bR[2])
@@ -502,7 +505,7 @@ class ProblemGenerator:
 
         n3, n2, n1 = pm.mb_indcs.ncells
         nmb = pm.pmb_pack.nmb_thispack
-        u = np.zeros((nmb, 5, n3, n2, n1))
+        u = np.zeros((nmb, phys.nvars, n3, n2, n1))
         _, bf = self._alloc_host()
         ks, js, is_ = self._active()
         for m in range(nmb):

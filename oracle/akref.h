@@ -119,6 +119,7 @@ typedef struct akref_params {
   double gamma, dfloor, pfloor, tfloor, sfloor, sigma_max;
   int is_ideal;                    /* eos = ideal (1) | isothermal (0) */
   double iso_cs;                   /* iso_sound_speed */
+  int nscalars;                    /* passive scalars appended to the fluid variables */
   /* <problem> */
   int pgen;
   /* linear_wave */
@@ -140,6 +141,7 @@ akref_sim *akref_create(const akref_params *p);
 void akref_destroy(akref_sim *s);
 /* ProblemGenerator + Driver::Initialize (src/main.cpp:325-375, driver.cpp:314-371) */
 void akref_initialize(akref_sim *s);
+void akref_reinitialize(akref_sim *s);
 /* one cycle of Driver::Execute (src/driver/driver.cpp:394-456); returns 0 when
  * time>=tlim or ncycle==nlim before the step */
 int akref_step(akref_sim *s);

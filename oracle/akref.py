@@ -40,7 +40,7 @@ class Params(C.Structure):
                 ("is_mhd", C.c_int), ("recon", C.c_int), ("rsolver", C.c_int),
                 ("gamma", C.c_double), ("dfloor", C.c_double), ("pfloor", C.c_double),
                 ("tfloor", C.c_double), ("sfloor", C.c_double), ("sigma_max", C.c_double),
-                ("is_ideal", C.c_int), ("iso_cs", C.c_double),
+                ("is_ideal", C.c_int), ("iso_cs", C.c_double), ("nscalars", C.c_int),
                 ("pgen", C.c_int),
                 ("wave_flag", C.c_int), ("along_x1", C.c_int), ("along_x2", C.c_int),
                 ("along_x3", C.c_int),
@@ -84,7 +84,7 @@ def lib():
         for f in ("akref_ncycle", "akref_nmb", "akref_step", "akref_run"):
             getattr(L, f).restype = C.c_int
             getattr(L, f).argtypes = [C.c_void_p]
-        for f in ("akref_initialize", "akref_destroy"):
+        for f in ("akref_initialize", "akref_reinitialize", "akref_destroy"):
             getattr(L, f).restype = None
             getattr(L, f).argtypes = [C.c_void_p]
         L.akref_linear_wave_errors.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
@@ -93,6 +93,9 @@ def lib():
         L.akref_pack.argtypes = [C.c_void_p, C.POINTER(Pack)]
         L.akref_bvals_cc_segsize.restype = C.c_longlong
         L.akref_bvals_fc_segsize.restype = C.c_longlong
+        # the checker is serial unless a caller (bench.py's cpu_baseline) asks for threads: without
+        # this call libgomp starts one spinning thread per core in every test process
+        L.akref_set_threads(1)
         _LIB = L
     return _LIB
 
@@ -172,6 +175,9 @@ class Sim:
     def initialize(self):
         self.L.akref_initialize(self.h)
 
+    def reinitialize(self):
+        self.L.akref_reinitialize(self.h)
+
     def step(self):
         return self.L.akref_step(self.h)
 
@@ -210,7 +216,7 @@ class Sim:
         n3, n2, n1 = self.dims()
         nmb = self.nmb
         fs = 1 if self.params.is_mhd else 0
-        nv = 5 if self.params.is_ideal else 4
+        nv = (5 if self.params.is_ideal else 4) + self.params.nscalars
         shapes = {
             "u0": (nmb, nv, n3, n2, n1), "w0": (nmb, nv, n3, n2, n1), "u1": (nmb, nv, n3, n2, n1),
             "bcc0": (nmb, 3, n3, n2, n1),

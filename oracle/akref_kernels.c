@@ -1207,6 +1207,21 @@ int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double 
             flx[ix5(nv,f3,f2,f1,m,ivz,k,j,i)] = f[3];
             if (ideal) flx[ix5(nv,f3,f2,f1,m,IEN,k,j,i)] = f[4];
           }
+    /* passive scalars: upwinded by the sign of the mass flux (hydro_fluxes.cpp:135-147) */
+    const int nf = ideal ? 5 : 4;
+    if (nv > nf) {
+      const int sil = g.is, siu = g.ie + (dir == 0), sjl = g.js, sju = g.je + (dir == 1);
+      const int skl = g.ks, sku = g.ke + (dir == 2);
+      for (int m = 0; m < g.nmb; ++m)
+        for (int k = skl; k <= sku; ++k)
+          for (int j = sjl; j <= sju; ++j)
+            for (int i = sil; i <= siu; ++i) {
+              double fd = flx[ix5(nv,f3,f2,f1,m,IDN,k,j,i)];
+              for (int n = nf; n < nv; ++n)
+                flx[ix5(nv,f3,f2,f1,m,n,k,j,i)] =
+                    fd*((fd >= 0.0) ? wl[ix5(nv,N3,N2,N1,m,n,k,j,i)] : wr[ix5(nv,N3,N2,N1,m,n,k,j,i)]);
+            }
+    }
   }
   return 0;
 }
@@ -1257,6 +1272,8 @@ int akref_hydro_c2p(const akmi_pack *p, double *u0, double *w0, int il, int iu, 
             if (ud < p->dfloor) { ud = p->dfloor; u0[cd] = ud; sumd_++; }
             double di = 1.0/ud;
             w0[cd] = ud; w0[cx] = di*u0[cx]; w0[cy] = di*u0[cy]; w0[cz] = di*u0[cz];
+            for (int n = 4; n < nv; ++n)           /* scalars, isothermal_hyd.cpp:119-122 (no floor) */
+              w0[ix5(nv,N3,N2,N1,m,n,k,j,i)] = u0[ix5(nv,N3,N2,N1,m,n,k,j,i)]/ud;
           }
     if (counters) counters[0] += sumd_;
     return 0;
@@ -1290,6 +1307,11 @@ int akref_hydro_c2p(const akmi_pack *p, double *u0, double *w0, int il, int iu, 
           if (efl) { u0[ce] = ue; sume++; }
           if (tfl) { u0[ce] = ue; sumt++; }
           w0[cd] = wd; w0[cx] = wvx; w0[cy] = wvy; w0[cz] = wvz; w0[ce] = we;
+          for (int n = 5; n < nv; ++n) {          /* scalars, ideal_hyd.cpp:94-101 */
+            size_t cn = ix5(nv,N3,N2,N1,m,n,k,j,i);
+            if (u0[cn] < 0.0) u0[cn] = 0.0;
+            w0[cn] = u0[cn]/ud;
+          }
         }
   if (counters) { counters[0] += sumd; counters[1] += sume; counters[2] += sumt; }
   return 0;
@@ -1391,6 +1413,21 @@ int akref_mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w
             ey[ix4(N3,N2,N1,m,k,j,i)] = -f[ob];
             ez[ix4(N3,N2,N1,m,k,j,i)] = f[ob + 1];
           }
+    /* passive scalars over the ACTIVE transverse range (mhd_fluxes.cpp:153-166) */
+    const int nf = ideal ? 5 : 4;
+    if (nv > nf) {
+      const int sil = g.is, siu = g.ie + (dir == 0), sjl = g.js, sju = g.je + (dir == 1);
+      const int skl = g.ks, sku = g.ke + (dir == 2);
+      for (int m = 0; m < g.nmb; ++m)
+        for (int k = skl; k <= sku; ++k)
+          for (int j = sjl; j <= sju; ++j)
+            for (int i = sil; i <= siu; ++i) {
+              double fd = flx[ix5(nv,f3,f2,f1,m,IDN,k,j,i)];
+              for (int n = nf; n < nv; ++n)
+                flx[ix5(nv,f3,f2,f1,m,n,k,j,i)] =
+                    fd*((fd >= 0.0) ? wl[ix5(nv,N3,N2,N1,m,n,k,j,i)] : wr[ix5(nv,N3,N2,N1,m,n,k,j,i)]);
+            }
+    }
   }
   return 0;
 }
@@ -1614,6 +1651,8 @@ int akref_mhd_c2p(const akmi_pack *p, double *u0, const double *bx1f, const doub
             bcc0[ix5(3,N3,N2,N1,m,IBX,k,j,i)] = ubx;
             bcc0[ix5(3,N3,N2,N1,m,IBY,k,j,i)] = uby;
             bcc0[ix5(3,N3,N2,N1,m,IBZ,k,j,i)] = ubz;
+            for (int n = 4; n < nv; ++n)           /* scalars, isothermal_mhd.cpp:143-146 */
+              w0[ix5(nv,N3,N2,N1,m,n,k,j,i)] = u0[ix5(nv,N3,N2,N1,m,n,k,j,i)]/ud;
           }
     if (counters) counters[0] += sumd_;
     return 0;
@@ -1656,6 +1695,11 @@ int akref_mhd_c2p(const akmi_pack *p, double *u0, const double *bx1f, const doub
           bcc0[ix5(3,N3,N2,N1,m,IBX,k,j,i)] = ubx;
           bcc0[ix5(3,N3,N2,N1,m,IBY,k,j,i)] = uby;
           bcc0[ix5(3,N3,N2,N1,m,IBZ,k,j,i)] = ubz;
+          for (int n = 5; n < nv; ++n) {          /* scalars, ideal_mhd.cpp:113-120 */
+            size_t cn = ix5(nv,N3,N2,N1,m,n,k,j,i);
+            if (u0[cn] < 0.0) u0[cn] = 0.0;
+            w0[cn] = u0[cn]/ud;
+          }
         }
   if (counters) { counters[0] += sumd; counters[1] += sume; counters[2] += sumt; }
   return 0;

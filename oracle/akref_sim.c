@@ -51,7 +51,7 @@ void akref_params_default(akref_params *p) {
   p->nstages = 2; p->cfl = 0.3; p->tlim = 1.0; p->nlim = -1;
   p->recon = AKMI_RECON_PLM; p->rsolver = AKMI_RS_HLLC;
   p->gamma = 5.0/3.0;
-  p->is_ideal = 1; p->iso_cs = 1.0;
+  p->is_ideal = 1; p->iso_cs = 1.0; p->nscalars = 0;
   p->dfloor = p->pfloor = p->tfloor = p->sfloor = (double)FLT_MIN;  /* src/eos/eos.cpp:22-25 */
   p->sigma_max = (double)FLT_MAX;                                  /* src/eos/ideal_mhd.cpp:22 */
   p->dens = 1.0; p->pgas = 0.6; p->amp = 1e-6;
@@ -156,7 +156,7 @@ akref_sim *akref_create(const akref_params *par) {
   /* arrays: src/hydro/hydro.cpp:283-298, src/mhd/mhd.cpp:148-160,335-366 */
   const int N1 = s->N1, N2 = s->N2, N3 = s->N3;
   s->ncc = (size_t)nmb*N3*N2*N1;
-  const int nv = s->nv = p->is_ideal ? 5 : 4;    /* isothermal_hyd.cpp: no energy variable */
+  const int nv = s->nv = (p->is_ideal ? 5 : 4) + p->nscalars;   /* nhydro|nmhd + nscalars */
   s->u0 = dalloc(nv*s->ncc); s->w0 = dalloc(nv*s->ncc); s->u1 = dalloc(nv*s->ncc);
   s->nf[0] = (size_t)nmb*N3*N2*(N1+1); s->nf[1] = (size_t)nmb*N3*(N2+1)*N1;
   s->nf[2] = (size_t)nmb*(N3+1)*N2*N1;
@@ -223,6 +223,8 @@ static void prim_to_cons(akref_sim *s, double *u) {
           u[IX5(m,IVX,k,j,i)] = d*vx;
           u[IX5(m,IVY,k,j,i)] = d*vy;
           u[IX5(m,IVZ,k,j,i)] = d*vz;
+          for (int n = (s->par.is_ideal ? 5 : 4); n < s->nv; ++n)     /* scalars: d*s */
+            u[IX5(m,n,k,j,i)] = d*s->w0[IX5(m,n,k,j,i)];
           if (!s->par.is_ideal) continue;       /* SingleP2C_Isothermal*: no energy */
           double e = s->w0[IX5(m,IEN,k,j,i)];
           if (s->par.is_mhd) {
@@ -736,6 +738,15 @@ void akref_initialize(akref_sim *s) {
   mesh_new_dt(s);
 }
 
+/* Driver::Initialize again on state a test wrote into u0/b0 after akref_initialize (e.g. passive
+ * scalars, which none of the problem generators of this path sets) */
+void akref_reinitialize(akref_sim *s) {
+  s->dt = (double)FLT_MAX;
+  halo_bcs_c2p(s);
+  new_dt_task(s);
+  mesh_new_dt(s);
+}
+
 int akref_step(akref_sim *s) {
   const akref_params *p = &s->par;
   if (!(s->time < s->tlim && (s->ncycle < p->nlim || p->nlim < 0))) return 0;
@@ -812,7 +823,7 @@ void *akref_array(akref_sim *s, const char *name, long long *count) {
  * src/pgen/pgen.cpp:680-900 */
 int akref_linear_wave_errors(akref_sim *s, double *out) {
   pgen_linear_wave(s, 0);
-  const int nf = s->nv;                       /* pgen.cpp:756-766: bindx = nmhd */
+  const int nf = s->par.is_ideal ? 5 : 4;     /* pgen.cpp:756-766: bindx = nmhd */
   int nvars = s->par.is_mhd ? nf + 3 : nf;
   double l1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   double linf = 0.0;
@@ -869,10 +880,11 @@ void akref_divb(akref_sim *s, double *out) {
 }
 
 void akref_totals(akref_sim *s, double *out) {
+  const int nt = s->nv < 5 ? s->nv : 5;
   for (int n = 0; n < 5; ++n) out[n] = 0.0;
   for (int m = 0; m < s->nmb; ++m) {
     double vol = s->dx[3*m]*s->dx[3*m+1]*s->dx[3*m+2];
-    for (int n = 0; n < 5; ++n)
+    for (int n = 0; n < nt; ++n)
       for (int k = s->ks; k <= s->ke; ++k)
         for (int j = s->js; j <= s->je; ++j)
           for (int i = s->is; i <= s->ie; ++i) out[n] += vol*s->u0[IX5(m,n,k,j,i)];

@@ -66,6 +66,8 @@ def oracle_kwargs(pin):
               gamma=g(blk, "gamma"))
     if gs(blk, "eos") == "isothermal":
         kw.update(is_ideal=0, iso_cs=g(blk, "iso_sound_speed"))
+    if pin.DoesParameterExist(blk, "nscalars"):
+        kw["nscalars"] = gi(blk, "nscalars")
     name = gs("problem", "pgen_name")
     kw["pgen"] = name
     P = lambda k, d=0.0: (g("problem", k) if pin.DoesParameterExist("problem", k) else d)

@@ -285,3 +285,43 @@ def test_task_mhd_fluxes_wild_states_isothermal(recon, rs):
     for k in names_out:
         assert np.isfinite(h[k]).all(), k
         assert np.array_equal(h[k], dv[k].cpu().numpy()), k
+
+
+# ---- passive scalars (task-granular kernels) -----------------------------------------------
+@pytest.mark.parametrize("case", [
+    ("sod", 32, 3, 16, 4, dict(cfl=0.3, recon="plm", rsolver="hllc")),
+    ("sod", 64, 1, 32, 8, dict(cfl=0.3, ng=3, recon="wenoz", rsolver="roe")),
+    ("orszag_tang", 24, 3, 12, 3, dict(cfl=0.3, recon="plm", rsolver="hlld")),
+    ("orszag_tang", 32, 2, 16, 4, dict(cfl=0.3, ng=3, recon="ppm4", rsolver="hlle")),
+    ("linear_wave_mhd", 32, 1, 16, 6, dict(ng=3, recon="plm", rsolver="llf",
+                                            extra=["problem/along_x1=true", "mhd/eos=isothermal"])),
+], ids=lambda c: "%s-%d^%d-%s" % (c[0], c[1], c[2], c[5]["rsolver"]))
+def test_passive_scalars(case):
+    """two passive scalars (hydro_fluxes.cpp:135-147, ideal_hyd.cpp:94-101): s0 == 1, s1 = a
+    profile.  Bit-identical to the oracle, and the mass density of scalar 0 stays bit-identical to
+    the density itself (its flux is the mass flux times exactly 1)."""
+    import torch
+    problem, n, dims, mb, cycles, kw = case
+    blk = "hydro" if problem in ("linear_wave_hydro", "sod") else "mhd"
+    kw = dict(kw)
+    kw["extra"] = list(kw.get("extra", [])) + ["%s/nscalars=2" % blk]
+    sim, osim, is_mhd = pu.make_pair(problem, n, dims, mb, **kw)
+    u = osim.array("u0")
+    nf = u.shape[1] - 2
+    prof = 0.5 + 0.25*np.sin(np.arange(u[:, 0].size, dtype=np.float64)*0.37).reshape(u[:, 0].shape)
+    u[:, nf] = u[:, 0]*1.0
+    u[:, nf + 1] = u[:, 0]*prof
+    osim.reinitialize()
+    sim.phys.u0.copy_(torch.from_numpy(u.copy()))
+    sim.pdriver.Initialize(sim.pmesh, sim.pin)
+    for _ in range(cycles):
+        assert sim.Execute(max_cycles=1) == 1 and osim.step() == 1
+    got, ref = sim.phys.u0.cpu().numpy(), osim.array("u0")
+    assert sim.pmesh.time == osim.time
+    assert np.array_equal(got, ref)
+    assert np.array_equal(sim.phys.w0.cpu().numpy(), osim.array("w0"))
+    ind = sim.pmesh.mb_indcs
+    a = (slice(None), slice(ind.ks, ind.ke + 1), slice(ind.js, ind.je + 1), slice(ind.is_, ind.ie + 1))
+    assert np.array_equal(got[:, nf][a], got[:, 0][a])           # scalar 0: rho*1 == rho
+    s1 = (got[:, nf + 1]/got[:, 0])[a]
+    assert s1.min() >= 0.25 - 1e-12 and s1.max() <= 0.75 + 1e-12 and s1.std() > 0.01
