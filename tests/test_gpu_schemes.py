@@ -322,6 +322,9 @@ def test_passive_scalars(case):
     assert np.array_equal(sim.phys.w0.cpu().numpy(), osim.array("w0"))
     ind = sim.pmesh.mb_indcs
     a = (slice(None), slice(ind.ks, ind.ke + 1), slice(ind.js, ind.je + 1), slice(ind.is_, ind.ie + 1))
-    assert np.array_equal(got[:, nf][a], got[:, 0][a])           # scalar 0: rho*1 == rho
+    if kw.get("recon") in ("plm", "ppm4"):                       # scalar 0: rho*1 == rho, exactly
+        assert np.array_equal(got[:, nf][a], got[:, 0][a])        # (limited slopes of a constant are 0)
+    else:                                                        # WENO weights do not sum to 1 exactly
+        assert np.allclose(got[:, nf][a], got[:, 0][a], rtol=1e-13, atol=0.0)
     s1 = (got[:, nf + 1]/got[:, 0])[a]
     assert s1.min() >= 0.25 - 1e-12 and s1.max() <= 0.75 + 1e-12 and s1.std() > 0.01
