@@ -8,8 +8,9 @@
 //     sweep xD (last)   : reconstruct + Riemann, exchange the normal flux of a tile through
 //                         LDS and apply the RK update  u0 = gam0*u0 + gam1*u1 - beta_dt*divF
 //                         in the same kernel (stage 1 also stores u1 <- u0: CopyCons folded)
-//     corner E          : GS05/07 upwind corner EMFs (select-based, no divergent loads)
-//     CT                : face-B update (stage 1 also stores b1 <- b0)
+//     corner E + CT     : GS05/07 upwind corner EMFs (select-based, no divergent loads) and the
+//                         face-B update in one k-marching kernel in 3-D (stage 1 also stores
+//                         b1 <- b0); 1-D/2-D: akmi_mhd_corner_e + k_ct_copy
 // Pass B  (akmi_*_c2p_newdt): ConsToPrim over all cells + (last stage) CFL scan in ONE
 //   kernel: the three direction maxima of |v|+c_f are reduced per wavefront (DPP shuffles),
 //   per workgroup (LDS) and the workgroup's dx/max enters a 64-bit atomicMin.  Division is
@@ -50,9 +51,11 @@ static StageWs carve(const Geo &g, int is_mhd, void *ws) {
     size_t nc = nmb*g.N3*g.N2*g.N1;
     for (int q = 0; q < 6; ++q) w.efc[q] = take(nc);
     for (int q = 0; q < 3; ++q) w.ecc[q] = take(nc);
-    w.e1 = take(nmb*(g.N3 + 1)*(g.N2 + 1)*g.N1);
-    w.e2 = take(nmb*(g.N3 + 1)*g.N2*(g.N1 + 1));
-    w.e3 = take(nmb*g.N3*(g.N2 + 1)*(g.N1 + 1));
+    if (!g.three_d) {       // 3-D: the corner EMFs never leave k_corner_ct
+      w.e1 = take(nmb*(g.N3 + 1)*(g.N2 + 1)*g.N1);
+      w.e2 = take(nmb*(g.N3 + 1)*g.N2*(g.N1 + 1));
+      w.e3 = take(nmb*g.N3*(g.N2 + 1)*(g.N1 + 1));
+    }
   }
   w.total = off*sizeof(double);
   return w;
@@ -167,9 +170,6 @@ struct UpdArgs {
 // (hydro_update.cpp:55-80 order).  No LDS, no barrier: waves run free, so the memory-bound
 // update of one wave hides under the Riemann arithmetic of the others.  One face per chunk
 // (1/ML) is computed twice.
-#ifndef AKMI_X2_MARCH
-#define AKMI_X2_MARCH 1
-#endif
 #ifndef AKMI_ML
 #define AKMI_ML 32
 #endif
@@ -394,69 +394,6 @@ __device__ __forceinline__ double upw(bool pos, double fa, double ca, double fb,
   return pos ? (fa - ca) : (fb - cb);
 }
 
-__global__ void __launch_bounds__(SX*SY)
-k_corner3(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e2x1,
-          const double *__restrict__ e1x2, const double *__restrict__ e3x2,
-          const double *__restrict__ e2x3, const double *__restrict__ e1x3,
-          const double *__restrict__ c1, const double *__restrict__ c2,
-          const double *__restrict__ c3, const double *__restrict__ flx1,
-          const double *__restrict__ flx2, const double *__restrict__ flx3,
-          double *__restrict__ e1, double *__restrict__ e2, double *__restrict__ e3, int k0,
-          int nk) {
-  const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;   // rows [js,je+1] x N1
-  const int jj = (int)(p/g.N1);
-  const int i = (int)(p - (long)jj*g.N1);
-  const int j = g.js + jj;
-  const int m = blockIdx.z/nk;
-  const int k = k0 + (blockIdx.z - m*nk);
-  if (i < g.is || i > g.ie + 1 || j > g.je + 1) return;
-  const double f1_k = flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k, j, i)];
-  const double f1_km = flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k - 1, j, i)];
-  const double f1_jm = flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k, j - 1, i)];
-  const double f2_k = flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, 0, k, j, i)];
-  const double f2_km = flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, 0, k - 1, j, i)];
-  const double f2_im = flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, 0, k, j, i - 1)];
-  const double f3_k = flx3[ix5(g.nvar, g.N3 + 1, g.N2, g.N1, m, 0, k, j, i)];
-  const double f3_jm = flx3[ix5(g.nvar, g.N3 + 1, g.N2, g.N1, m, 0, k, j - 1, i)];
-  const double f3_im = flx3[ix5(g.nvar, g.N3 + 1, g.N2, g.N1, m, 0, k, j, i - 1)];
-  {  // E1 (:340-363)
-    const double x3_jm = CCE(e1x3, k, j - 1, i), x3_j = CCE(e1x3, k, j, i);
-    const double x2_km = CCE(e1x2, k - 1, j, i), x2_k = CCE(e1x2, k, j, i);
-    const double c_mm = CCE(c1, k - 1, j - 1, i), c_m0 = CCE(c1, k - 1, j, i);
-    const double c_0m = CCE(c1, k, j - 1, i), c_00 = CCE(c1, k, j, i);
-    double e1_l3 = upw(f2_km >= 0.0, x3_jm, c_mm, x3_j, c_m0);
-    double e1_r3 = upw(f2_k >= 0.0, x3_jm, c_0m, x3_j, c_00);
-    double e1_l2 = upw(f3_jm >= 0.0, x2_km, c_mm, x2_k, c_0m);
-    double e1_r2 = upw(f3_k >= 0.0, x2_km, c_m0, x2_k, c_00);
-    e1[ix4(g.N3 + 1, g.N2 + 1, g.N1, m, k, j, i)] =
-        0.25*(e1_l3 + e1_r3 + e1_l2 + e1_r2 + x2_km + x2_k + x3_jm + x3_j);
-  }
-  {  // E2 (:365-388)
-    const double x3_im = CCE(e2x3, k, j, i - 1), x3_i = CCE(e2x3, k, j, i);
-    const double x1_km = CCE(e2x1, k - 1, j, i), x1_k = CCE(e2x1, k, j, i);
-    const double c_mm = CCE(c2, k - 1, j, i - 1), c_m0 = CCE(c2, k - 1, j, i);
-    const double c_0m = CCE(c2, k, j, i - 1), c_00 = CCE(c2, k, j, i);
-    double e2_l3 = upw(f1_km >= 0.0, x3_im, c_mm, x3_i, c_m0);
-    double e2_r3 = upw(f1_k >= 0.0, x3_im, c_0m, x3_i, c_00);
-    double e2_l1 = upw(f3_im >= 0.0, x1_km, c_mm, x1_k, c_0m);
-    double e2_r1 = upw(f3_k >= 0.0, x1_km, c_m0, x1_k, c_00);
-    e2[ix4(g.N3 + 1, g.N2, g.N1 + 1, m, k, j, i)] =
-        0.25*(e2_l3 + e2_r3 + e2_l1 + e2_r1 + x3_im + x3_i + x1_km + x1_k);
-  }
-  {  // E3 (:390-413)
-    const double x2_im = CCE(e3x2, k, j, i - 1), x2_i = CCE(e3x2, k, j, i);
-    const double x1_jm = CCE(e3x1, k, j - 1, i), x1_j = CCE(e3x1, k, j, i);
-    const double c_mm = CCE(c3, k, j - 1, i - 1), c_m0 = CCE(c3, k, j - 1, i);
-    const double c_0m = CCE(c3, k, j, i - 1), c_00 = CCE(c3, k, j, i);
-    double e3_l2 = upw(f1_jm >= 0.0, x2_im, c_mm, x2_i, c_m0);
-    double e3_r2 = upw(f1_k >= 0.0, x2_im, c_0m, x2_i, c_00);
-    double e3_l1 = upw(f2_im >= 0.0, x1_jm, c_mm, x1_j, c_0m);
-    double e3_r1 = upw(f2_k >= 0.0, x1_jm, c_m0, x1_j, c_00);
-    e3[ix4(g.N3, g.N2 + 1, g.N1 + 1, m, k, j, i)] =
-        0.25*(e3_l1 + e3_r1 + e3_l2 + e3_r2 + x2_im + x2_i + x1_jm + x1_j);
-  }
-}
-
 // ---------------------------------------------------------------------------------------
 // CornerE + CT in ONE kernel (3-D).  The corner EMFs never go to memory: a workgroup owns a
 // (j,i) tile with a one-column/one-row overlap, marches along k, exchanges the three edge values
@@ -467,10 +404,7 @@ k_corner3(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e2x
 // The k-1 operands of the corner formulas are the previous step's k operands (25 instead of 33
 // loads per corner).  Every face is read and written by exactly one thread (the overlap
 // column/row only computes edges), so the in-place update of b0 has no cross-workgroup hazard.
-// Arithmetic: the expressions of k_corner3 and k_ct_copy, unchanged.
-#ifndef AKMI_FUSED_CT
-#define AKMI_FUSED_CT 1
-#endif
+// Arithmetic: the expressions of akmi_mhd_corner_e (akmi_tasks.hip) and k_ct_copy, unchanged.
 #ifndef AKMI_CJ
 #define AKMI_CJ 8
 #endif
@@ -1005,39 +939,16 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
   }
   auto kA = [&](int s) { return g.ks + s*T; };
   auto kB = [&](int s) { int e = g.ks + (s + 1)*T - 1; return e > g.ke ? g.ke : e; };
-  auto corner = [&](int s) -> int {
-#if AKMI_FUSED_CT
-    return AKMI_COMPLETE;                                          // folded into ct(s)
-#endif
-    const int k0 = kA(s), nk = kB(s) - kA(s) + 2;                  // edges [kA, kB+1]
-    long np = (long)(g.nx2 + 1)*g.N1;
-    dim3 grid((unsigned)((np + SX*SY - 1)/(SX*SY)), 1, nk*g.nmb), block(SX, SY);
-    k_corner3<<<grid, block, 0, sb>>>(g, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5],
-                                      w.ecc[0], w.ecc[1], w.ecc[2], w.flx1, w.flx2, w.flx3, w.e1,
-                                      w.e2, w.e3, k0, nk);
-    AKMI_CHECK_LAUNCH("corner3");
-    return AKMI_COMPLETE;
-  };
   auto ct = [&](int s) -> int {
+    // CornerE + CT of slab s in one kernel (corner EMFs of the planes [kA, kB+1] stay on chip)
     const int top = (s == S - 1) ? 1 : 0;
-#if AKMI_FUSED_CT
-    {
-      const int nchunk = cdiv(kB(s) - kA(s) + 1, CKL);
-      dim3 grid(cdiv(g.nx1 + 1, CI - 1), cdiv(g.nx2 + 1, CJ - 1), nchunk*g.nmb), block(CI, CJ);
-      k_corner_ct<<<grid, block, 0, sb>>>(g, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4],
-                                          w.efc[5], w.ecc[0], w.ecc[1], w.ecc[2], w.flx1, w.flx2,
-                                          w.flx3, gam0, gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f,
-                                          b1x2f, b1x3f, copy_u1, kA(s), kB(s), top, nchunk);
-      AKMI_CHECK_LAUNCH("corner_ct");
-      return AKMI_COMPLETE;
-    }
-#endif
-    const int k0 = kA(s), nk = kB(s) - kA(s) + 1 + top;
-    long npc = (long)(g.je - g.js + 2)*g.N1;
-    dim3 grid((unsigned)((npc + SX*SY - 1)/(SX*SY)), 1, nk*g.nmb), block(SX, SY);
-    k_ct_copy<<<grid, block, 0, sb>>>(g, gam0, gam1, beta_dt, w.e1, w.e2, w.e3, b0x1f, b0x2f, b0x3f,
-                                      b1x1f, b1x2f, b1x3f, copy_u1, k0, nk, kB(s));
-    AKMI_CHECK_LAUNCH("ct");
+    const int nchunk = cdiv(kB(s) - kA(s) + 1, CKL);
+    dim3 grid(cdiv(g.nx1 + 1, CI - 1), cdiv(g.nx2 + 1, CJ - 1), nchunk*g.nmb), block(CI, CJ);
+    k_corner_ct<<<grid, block, 0, sb>>>(g, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5],
+                                        w.ecc[0], w.ecc[1], w.ecc[2], w.flx1, w.flx2, w.flx3, gam0,
+                                        gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f,
+                                        copy_u1, kA(s), kB(s), top, nchunk);
+    AKMI_CHECK_LAUNCH("corner_ct");
     return AKMI_COMPLETE;
   };
   auto c2p = [&](int s) -> int {
@@ -1054,14 +965,9 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
     if (do_sweeps) {
     rc = MHD ? launch_sweep<0, MHD, MHD>(g, sc, b1, st)
              : launch_sweep<0, MHD, false>(g, sc, b1, st);
-#if AKMI_X2_MARCH
     // x2 sweep as a march along j that leaves acc = dF1/dx1 + dF2/dx2; x3 march consumes it
     if (rc == AKMI_COMPLETE) rc = launch_sweep_update<1, MHD, 1, false>(g, sc, b2, u, st);
     if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD, 0, true>(g, sc, b3, u, st);
-#else
-    if (rc == AKMI_COMPLETE) rc = launch_sweep<1, MHD, false>(g, sc, b2, st);
-    if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD>(g, sc, b3, u, st);
-#endif
     }
     if (rc != AKMI_COMPLETE) return rc;
     if (two) {
@@ -1072,7 +978,6 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
     if (MHD && !do_emf) {
       if (cp.enable && (rc = c2p(s)) != AKMI_COMPLETE) return rc;      // partial phases: S == 1
     } else if (MHD) {
-      if ((rc = corner(s)) != AKMI_COMPLETE) return rc;
       if (s >= 1 && (rc = ct(s - 1)) != AKMI_COMPLETE) return rc;      // needs sweeps(s) done
       if (cp.enable && s >= 2 && (rc = c2p(s - 2)) != AKMI_COMPLETE) return rc;
     } else if (cp.enable) {
