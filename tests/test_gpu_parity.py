@@ -399,3 +399,54 @@ def test_native_cpp_driver_parity(case, fused):
     assert res["cycles"] == cycles
     assert res["time"][0] == res["time"][1], res["time"]
     assert res["bitwise_equal"], res["diffs"]
+
+
+ODD = [
+    # problem, mesh (n1,n2,n3), block (b1,b2,b3), cycles, kwargs: sizes that are not multiples of the
+    # wave, tile, march-chunk or k-chunk lengths of the kernels (64, 63x7 tiles, 32, 32)
+    ("orszag_tang", (40, 24, 20), (20, 12, 10), 3, dict(cfl=0.3)),
+    ("orszag_tang", (36, 20, 12), (36, 20, 12), 3, dict(cfl=0.3, ng=3, recon="ppm4")),
+    ("orszag_tang", (70, 66, 34), (70, 66, 34), 2, dict(cfl=0.3)),                 # > one tile / chunk
+    ("orszag_tang", (8, 8, 8), (4, 4, 4), 3, dict(cfl=0.3)),                       # minimum block
+    ("blast", (36, 28, 20), (18, 14, 10), 2, {}),                                  # ng=4
+    ("sod", (50, 18, 14), (25, 18, 14), 4, dict(cfl=0.3)),
+    ("sod", (130, 6, 6), (130, 6, 6), 4, dict(cfl=0.3, ng=3, recon="wenoz", rsolver="hlle")),
+    ("linear_wave_hydro", (66, 34, 1), (33, 17, 1), 4, {}),                        # 2-D
+    ("linear_wave_mhd", (66, 34, 1), (66, 34, 1), 4, dict(ng=3, recon="ppmx", rsolver="hlle")),
+]
+
+
+def _run_odd(case, fused):
+    import torch
+    from athenak_amd.main import Simulation, load_deck
+    problem, mesh, blk, cycles, kw = case
+    deck, ov = pu.deck_overrides(problem, 8, 3, **kw)
+    ov = [o for o in ov if not (o.startswith("mesh/nx") or o.startswith("meshblock/nx"))]
+    for q in range(3):
+        ov += ["mesh/nx%d=%d" % (q + 1, mesh[q]), "meshblock/nx%d=%d" % (q + 1, blk[q])]
+    pin = load_deck(deck, ov)
+    b = "mhd" if pin.DoesBlockExist("mhd") else "hydro"
+    pin.blocks[b]["fused_stage"] = "true" if fused else "false"
+    osim = akref.Sim(**pu.oracle_kwargs(pin))
+    osim.initialize()
+    sim = Simulation(pin, initialize=False)
+    ph = sim.phys
+    ph.u0.copy_(torch.from_numpy(osim.array("u0").copy()))
+    if b == "mhd":
+        for a, n in (("x1f", "b0x1f"), ("x2f", "b0x2f"), ("x3f", "b0x3f")):
+            getattr(ph.b0, a).copy_(torch.from_numpy(osim.array(n).copy()))
+    sim.pdriver.Initialize(sim.pmesh, pin)
+    for _ in range(cycles):
+        assert sim.Execute(max_cycles=1) == 1 and osim.step() == 1
+    assert sim.pmesh.time == osim.time and sim.pmesh.dt == osim.dt
+    assert np.array_equal(ph.u0.cpu().numpy(), osim.array("u0"))
+    assert np.array_equal(ph.w0.cpu().numpy(), osim.array("w0"))
+    if b == "mhd":
+        for a, n in (("x1f", "b0x1f"), ("x2f", "b0x2f"), ("x3f", "b0x3f")):
+            assert np.array_equal(getattr(ph.b0, a).cpu().numpy(), osim.array(n)), n
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "split"])
+@pytest.mark.parametrize("case", ODD, ids=lambda c: "%s-%dx%dx%d-mb%dx%dx%d" % ((c[0],) + c[1] + c[2]))
+def test_odd_sizes_are_bit_identical(case, fused):
+    _run_odd(case, fused)
