@@ -173,14 +173,26 @@ struct UpdArgs {
 #ifndef AKMI_ML
 #define AKMI_ML 32
 #endif
-constexpr int ML = AKMI_ML;            // faces marched per thread (chunk length)
+constexpr int ML = AKMI_ML;            // faces marched per thread (chunk length), full-size packs
+
+// chunk length of a marching kernel: ML when that still gives several workgroups per CU, shorter
+// marches (more, smaller chunks; one face per chunk is recomputed) for small packs, which would
+// otherwise leave most of the 256 CUs idle behind a few long serial chains.  Results do not
+// depend on the chunking.
+static int march_len(long col_blocks, int ncells, int nmb, int lmax) {
+  const long want = 1024;                       // workgroups per launch
+  long ml = col_blocks*(long)ncells*nmb/want;
+  if (ml > lmax) ml = lmax;
+  if (ml < 4) ml = 4;
+  return (int)ml;
+}
 
 // MODE 0: last direction -- finish the RK update.  MODE 1 (x2 sweep of 3-D runs): store the
 // partial divergence acc = dF1/dx1 + dF2/dx2 for the x3 march, which then needs one array
 // instead of two face pairs per variable (USEACC).  Rounding sequence unchanged.
 template <int DIR, int RECON, bool MHD, int MODE, bool USEACC, int RS>
 __global__ void __launch_bounds__(SX*SY, (RECON >= 2 ? 2 : 3))
-k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int nouter) {
+k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int ml) {
   static_assert(DIR == 1 || DIR == 2, "marching kernel is for the x2/x3 sweeps");
   int i, j, k, m, s0;
   bool lane_ok;
@@ -190,7 +202,7 @@ k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int nouter) {
     i = (int)(p - (long)jj*g.N1);
     j = a.jl + jj;
     m = blockIdx.z;
-    s0 = a.kl + blockIdx.y*ML;
+    s0 = a.kl + blockIdx.y*ml;
     k = s0;
     lane_ok = (j <= a.ju) && (i >= a.il) && (i <= a.iu);
   } else {
@@ -199,7 +211,7 @@ k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int nouter) {
     i = (int)(p - (long)kk*g.N1);
     k = a.kl + kk;
     m = blockIdx.z;
-    s0 = a.jl + blockIdx.y*ML;
+    s0 = a.jl + blockIdx.y*ml;
     j = s0;
     lane_ok = (k <= a.ku) && (i >= a.il) && (i <= a.iu);
   }
@@ -259,7 +271,7 @@ k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int nouter) {
   }
   const size_t fst = (DIR == 1) ? (size_t)a.f1 : (size_t)a.f1*a.f2;   // face-array stride
   const double *pbx = MHD ? a.bxf + ix4(a.f3, a.f2, a.f1, m, k, j, i) : nullptr;
-  for (int t = 0; t <= ML; ++t) {
+  for (int t = 0; t <= ml; ++t) {
     const int s = s0 + t;
     if (s > shi) break;
     if constexpr (DIR == 1) j = s; else k = s;
@@ -295,7 +307,7 @@ k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int nouter) {
       Cons1D fl = riemann_mhd<RS>(eos.gamma, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1],
                                   R[2], R[3], R[4], R[5], R[6], pbx[(size_t)t*fst]);
       fd = fl.d; fx = fl.mx; fy = fl.my; fz = fl.mz; fe = fl.e;
-      if (t < ML || s == shi) {
+      if (t < ml || s == shi) {
         // CornerE needs the sign of the mass flux and the two face EMFs of this direction
         a.flx[ix5(g.nvar, a.f3, a.f2, a.f1, m, 0, k, j, i)] = fd;
         const size_t ec = ix4(g.N3, g.N2, g.N1, m, k, j, i);
@@ -423,15 +435,16 @@ k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e
             const double *__restrict__ flx2, const double *__restrict__ flx3, double gam0,
             double gam1, double beta_dt, double *__restrict__ b0x1f, double *__restrict__ b0x2f,
             double *__restrict__ b0x3f, double *__restrict__ b1x1f, double *__restrict__ b1x2f,
-            double *__restrict__ b1x3f, int copy_b1, int kA, int kB, int top, int nchunk) {
+            double *__restrict__ b1x3f, int copy_b1, int kA, int kB, int top, int nchunk,
+            int ckl) {
   __shared__ double s1[2][CJ][CI], s2[2][CJ][CI], s3[3][CJ][CI];
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int i = g.is + blockIdx.x*(CI - 1) + tx;
   const int j = g.js + blockIdx.y*(CJ - 1) + ty;
   const int m = blockIdx.z/nchunk;
   const int ch = blockIdx.z - m*nchunk;
-  const int k0 = kA + ch*CKL;                                   // first cell plane of this chunk
-  const int k1 = (k0 + CKL - 1 < kB) ? k0 + CKL - 1 : kB;       // last cell plane
+  const int k0 = kA + ch*ckl;                                   // first cell plane of this chunk
+  const int k1 = (k0 + ckl - 1 < kB) ? k0 + ckl - 1 : kB;       // last cell plane
   const bool wtop = top && (k1 == kB);                          // this chunk owns the x3-faces kB+1
   const bool edge_ok = (i <= g.ie + 1) && (j <= g.je + 1);
   const bool own = edge_ok && (tx < CI - 1) && (ty < CJ - 1);
@@ -703,17 +716,24 @@ static int launch_sweep_update(const Geo &g, const Scheme &sc, const SweepArgs &
     });
   } else {
     dim3 grid, block(SX, SY);
+    int ml;
     if (DIR == 2) {
       long np = (long)(a.ju - a.jl + 1)*g.N1;          // flattened rows
-      grid = dim3((unsigned)((np + SX*SY - 1)/(SX*SY)), cdiv(a.ku - a.kl > 0 ? a.ku - a.kl : 1, ML), g.nmb);
+      const unsigned nb = (unsigned)((np + SX*SY - 1)/(SX*SY));
+      const int nc = a.ku - a.kl > 0 ? a.ku - a.kl : 1;
+      ml = march_len(nb, nc, g.nmb, ML);
+      grid = dim3(nb, cdiv(nc, ml), g.nmb);
     } else {
       long np = (long)(a.ku - a.kl + 1)*g.N1;          // flattened (k,i)
-      grid = dim3((unsigned)((np + SX*SY - 1)/(SX*SY)), cdiv(a.ju - a.jl > 0 ? a.ju - a.jl : 1, ML), g.nmb);
+      const unsigned nb = (unsigned)((np + SX*SY - 1)/(SX*SY));
+      const int nc = a.ju - a.jl > 0 ? a.ju - a.jl : 1;
+      ml = march_len(nb, nc, g.nmb, ML);
+      grid = dim3(nb, cdiv(nc, ml), g.nmb);
     }
     constexpr int D = (DIR == 0) ? 1 : DIR;
     rc = dispatch_scheme<MHD>(sc, [&](auto R, auto S) {
       k_sweep_update<D, decltype(R)::value, MHD, MODE, USEACC, decltype(S)::value>
-          <<<grid, block, 0, st>>>(g, sc.eos, a, u, 1);
+          <<<grid, block, 0, st>>>(g, sc.eos, a, u, ml);
       return AKMI_COMPLETE;
     });
   }
@@ -942,12 +962,14 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
   auto ct = [&](int s) -> int {
     // CornerE + CT of slab s in one kernel (corner EMFs of the planes [kA, kB+1] stay on chip)
     const int top = (s == S - 1) ? 1 : 0;
-    const int nchunk = cdiv(kB(s) - kA(s) + 1, CKL);
+    const int ckl = march_len((long)cdiv(g.nx1 + 1, CI - 1)*cdiv(g.nx2 + 1, CJ - 1),
+                              kB(s) - kA(s) + 1, g.nmb, CKL);
+    const int nchunk = cdiv(kB(s) - kA(s) + 1, ckl);
     dim3 grid(cdiv(g.nx1 + 1, CI - 1), cdiv(g.nx2 + 1, CJ - 1), nchunk*g.nmb), block(CI, CJ);
     k_corner_ct<<<grid, block, 0, sb>>>(g, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5],
                                         w.ecc[0], w.ecc[1], w.ecc[2], w.flx1, w.flx2, w.flx3, gam0,
                                         gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f,
-                                        copy_u1, kA(s), kB(s), top, nchunk);
+                                        copy_u1, kA(s), kB(s), top, nchunk, ckl);
     AKMI_CHECK_LAUNCH("corner_ct");
     return AKMI_COMPLETE;
   };

@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from athenak_amd.main import load_deck, Simulation
 from athenak_amd.native import NativeSimulation
 for nx in (128, 64):
