@@ -180,7 +180,7 @@ constexpr int ML = AKMI_ML;            // faces marched per thread (chunk length
 // otherwise leave most of the 256 CUs idle behind a few long serial chains.  Results do not
 // depend on the chunking.
 static int march_len(long col_blocks, int ncells, int nmb, int lmax) {
-  static const long want = getenv("AKMI_WANT_WG") ? atol(getenv("AKMI_WANT_WG")) : 2048;   // workgroups per launch
+  const long want = 2048;                       // workgroups per launch (scan: profiles/r01_small_packs.txt)
   long ml = col_blocks*(long)ncells*nmb/want;
   if (ml > lmax) ml = lmax;
   if (ml < 4) ml = 4;
