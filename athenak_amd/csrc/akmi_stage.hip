@@ -173,6 +173,9 @@ struct UpdArgs {
 #ifndef AKMI_ML
 #define AKMI_ML 32
 #endif
+#ifndef AKMI_PREFETCH_UPD
+#define AKMI_PREFETCH_UPD 1
+#endif
 constexpr int ML = AKMI_ML;            // faces marched per thread (chunk length), full-size packs
 
 // chunk length of a marching kernel: ML when that still gives several workgroups per CU, shorter
@@ -302,6 +305,20 @@ k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int ml) {
       PL_(n) = qln;
     }
     off += st;
+    // x3 march: fetch the update operands of the cell this face finishes BEFORE the Riemann solve,
+    // so that their latency is covered by ~1000 VALU instructions instead of following them
+    // (this kernel moves the most bytes of the stage and runs at 3 waves/SIMD)
+    constexpr bool PRE = (DIR == 2) && USEACC && (MODE == 0) && AKMI_PREFETCH_UPD;
+    const int sc = s - 1;                               // cell finished by this face
+    const bool upd = t > 0 && col_active && sc >= clo && sc <= chi;
+    double pa[5], pu[5];
+    if constexpr (PRE) {
+      if (upd) {
+        const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, sc, j, i);
+#pragma unroll
+        for (int n = 0; n < 5; ++n) { pa[n] = u.acc[c + n*cs]; pu[n] = u.u0[c + n*cs]; }
+      }
+    }
     double fd, fx, fy, fz, fe;
     if constexpr (MHD) {
       Cons1D fl = riemann_mhd<RS>(eos.gamma, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1],
@@ -320,15 +337,16 @@ k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int ml) {
     }
     double fv[5];
     fv[0] = fd; fv[ivx] = fx; fv[ivy] = fy; fv[ivz] = fz; fv[4] = fe;
-    const int sc = s - 1;                               // cell finished by this face
-    if (t > 0 && col_active && sc >= clo && sc <= chi) {
+    if (upd) {
       const int kc = (DIR == 2) ? sc : k, jc = (DIR == 1) ? sc : j;
       const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, kc, jc, i);
 #pragma unroll
       for (int n = 0; n < 5; ++n) {
         const double fprev = FP_(n);
         double divf;
-        if constexpr (USEACC) {
+        if constexpr (PRE) {
+          divf = pa[n];
+        } else if constexpr (USEACC) {
           divf = u.acc[c + n*cs];
         } else {
           divf = (u.flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, n, kc, jc, i + 1)] -
@@ -345,7 +363,8 @@ k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int ml) {
         if constexpr (MODE == 1) {
           u.acc[c + n*cs] = divf;
         } else {
-          const double u0v = u.u0[c + n*cs];
+          double u0v;
+          if constexpr (PRE) u0v = pu[n]; else u0v = u.u0[c + n*cs];
           const double u1v = u.copy_u1 ? u0v : u.u1[c + n*cs];
           if (u.copy_u1) u.u1[c + n*cs] = u0v;
           u.u0[c + n*cs] = u.gam0*u0v + u.gam1*u1v - u.beta_dt*divf;
