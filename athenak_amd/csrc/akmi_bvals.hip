@@ -51,17 +51,31 @@ __host__ __device__ inline long long seg_count(const Comp &q, int o1, int o2, in
   return (long long)q.d1.cnt(o1)*q.d2.cnt(o2)*q.d3.cnt(o3);
 }
 
-// ---- same-rank ghost fill: thread per element of a slab of the array ---------------------
-// mode: which slab of the ghost shell (k-ghost slabs / j-ghost slabs / i-ghost slabs)
-template <int MODE>
+// ---- ghost fill: thread per element of the ghost shell -----------------------------------
+// ONE launch covers the whole shell of every component: blockIdx.y = component of the set,
+// blockIdx.z = slab of the shell (0: k-ghost slabs incl. all j,i; 1: j-ghost slabs of the owned
+// k range; 2: i-ghost slabs of the owned k,j range), blockIdx.x grid-strides over the slab.
+//   KIND 0  gather from same-rank neighbours (nghbr >= 0)
+//   KIND 1  cell-centred unpack of off-rank segments (nghbr <= -2)
+//   KIND 2  face-centred unpack (segment = x1f, x2f, x3f parts back to back)
+struct GhostSet {
+  Comp q[3];
+  double *a[3];
+  int comp[3];       // 0 cell-centred, 1/2/3 x1f/x2f/x3f
+  int ncomp;
+};
+
+template <int KIND>
 __global__ void __launch_bounds__(256)
-k_ghost_local(Geo g, Comp q, int nv, const int *__restrict__ nghbr, double *__restrict__ a,
-              const long long *__restrict__ seg_off, const double *__restrict__ recvbuf,
-              int unpack) {
-  // slab extents
+k_ghost_fill(Geo g, GhostSet gs, int nv, const int *__restrict__ nghbr,
+             const long long *__restrict__ seg_off, const double *__restrict__ recvbuf) {
+  const Comp q = gs.q[blockIdx.y];
+  double *__restrict__ a = gs.a[blockIdx.y];
+  const int comp = gs.comp[blockIdx.y];
+  const int mode = blockIdx.z;
   int e1, e2, e3;
-  if (MODE == 0) { e1 = q.n1; e2 = q.n2; e3 = 2*q.d3.ng; }
-  else if (MODE == 1) { e1 = q.n1; e2 = 2*q.d2.ng; e3 = q.d3.eo - q.d3.s + 1; }
+  if (mode == 0) { e1 = q.n1; e2 = q.n2; e3 = 2*q.d3.ng; }
+  else if (mode == 1) { e1 = q.n1; e2 = 2*q.d2.ng; e3 = q.d3.eo - q.d3.s + 1; }
   else { e1 = 2*q.d1.ng; e2 = q.d2.eo - q.d2.s + 1; e3 = q.d3.eo - q.d3.s + 1; }
   const long long per = (long long)e1*e2*e3;
   const long long tot = per*nv*g.nmb;
@@ -76,46 +90,60 @@ k_ghost_local(Geo g, Comp q, int nv, const int *__restrict__ nghbr, double *__re
     int jj = (int)(r/e1);
     int ii = (int)(r - (long long)jj*e1);
     int i, j, k;
-    if (MODE == 0) { i = ii; j = jj; k = kk < q.d3.ng ? kk : q.d3.eo + 1 + (kk - q.d3.ng); }
-    else if (MODE == 1) { i = ii; j = jj < q.d2.ng ? jj : q.d2.eo + 1 + (jj - q.d2.ng); k = q.d3.s + kk; }
+    if (mode == 0) { i = ii; j = jj; k = kk < q.d3.ng ? kk : q.d3.eo + 1 + (kk - q.d3.ng); }
+    else if (mode == 1) { i = ii; j = jj < q.d2.ng ? jj : q.d2.eo + 1 + (jj - q.d2.ng); k = q.d3.s + kk; }
     else { i = ii < q.d1.ng ? ii : q.d1.eo + 1 + (ii - q.d1.ng); j = q.d2.s + jj; k = q.d3.s + kk; }
     int o1 = q.d1.side(i), o2 = q.d2.side(j), o3 = q.d3.side(k);
     int d = (o3 + 1)*9 + (o2 + 1)*3 + (o1 + 1);
     int src = nghbr[m*27 + d];
     size_t dst = ((((size_t)m*nv + n)*q.n3 + k)*q.n2 + j)*q.n1 + i;
-    if (!unpack) {
+    if constexpr (KIND == 0) {
       if (src < 0) continue;
       a[dst] = a[((((size_t)src*nv + n)*q.n3 + (k - o3*q.d3.nx))*q.n2 + (j - o2*q.d2.nx))*q.n1 +
                  (i - o1*q.d1.nx)];
     } else {
       if (src > -2) continue;
       const int c1 = q.d1.cnt(o1), c2 = q.d2.cnt(o2), c3 = q.d3.cnt(o3);
-      long long off = seg_off[-(src + 2)] +
-                      (((long long)n*c3 + (k - q.d3.lo(o3)))*c2 + (j - q.d2.lo(o2)))*c1 +
+      long long base = seg_off[-(src + 2)];
+      if constexpr (KIND == 2)
+        for (int c = 1; c < comp; ++c) base += seg_count(make_comp(g, c), o1, o2, o3);
+      long long off = base + (((long long)n*c3 + (k - q.d3.lo(o3)))*c2 + (j - q.d2.lo(o2)))*c1 +
                       (i - q.d1.lo(o1));
       a[dst] = recvbuf[off];
     }
   }
 }
 
-static int launch_ghost(const Geo &g, const Comp &q, int nv, const int *nghbr, double *a,
-                        const long long *seg_off, const double *recvbuf, int unpack,
-                        hipStream_t st) {
-  auto nblk = [](long long n) { long long b = (n + 255)/256; return (int)(b > 65535 ? 65535 : (b < 1 ? 1 : b)); };
-  if (q.d3.ng > 0) {
-    long long n = (long long)q.n1*q.n2*2*q.d3.ng*nv*g.nmb;
-    k_ghost_local<0><<<nblk(n), 256, 0, st>>>(g, q, nv, nghbr, a, seg_off, recvbuf, unpack);
+template <int KIND>
+static int launch_ghost(const Geo &g, const GhostSet &gs, int nv, const int *nghbr,
+                        const long long *seg_off, const double *recvbuf, hipStream_t st) {
+  long long nmax = 1;
+  for (int c = 0; c < gs.ncomp; ++c) {
+    const Comp &q = gs.q[c];
+    long long n0 = (long long)q.n1*q.n2*2*q.d3.ng;
+    long long n1 = (long long)q.n1*2*q.d2.ng*(q.d3.eo - q.d3.s + 1);
+    long long n2 = (long long)2*q.d1.ng*(q.d2.eo - q.d2.s + 1)*(q.d3.eo - q.d3.s + 1);
+    long long n = (n0 > n1 ? (n0 > n2 ? n0 : n2) : (n1 > n2 ? n1 : n2))*nv*g.nmb;
+    if (n > nmax) nmax = n;
   }
-  if (q.d2.ng > 0) {
-    long long n = (long long)q.n1*2*q.d2.ng*(q.d3.eo - q.d3.s + 1)*nv*g.nmb;
-    k_ghost_local<1><<<nblk(n), 256, 0, st>>>(g, q, nv, nghbr, a, seg_off, recvbuf, unpack);
-  }
-  {
-    long long n = (long long)2*q.d1.ng*(q.d2.eo - q.d2.s + 1)*(q.d3.eo - q.d3.s + 1)*nv*g.nmb;
-    k_ghost_local<2><<<nblk(n), 256, 0, st>>>(g, q, nv, nghbr, a, seg_off, recvbuf, unpack);
-  }
+  long long nb = (nmax + 255)/256;
+  dim3 grid((unsigned)(nb > 65535 ? 65535 : nb), gs.ncomp, 3);
+  k_ghost_fill<KIND><<<grid, 256, 0, st>>>(g, gs, nv, nghbr, seg_off, recvbuf);
   AKMI_CHECK_LAUNCH("bvals ghost fill");
   return AKMI_COMPLETE;
+}
+
+static GhostSet cc_set(const Geo &g, double *u) {
+  GhostSet gs{};
+  gs.q[0] = make_comp(g, 0); gs.a[0] = u; gs.comp[0] = 0; gs.ncomp = 1;
+  return gs;
+}
+static GhostSet fc_set(const Geo &g, double *b1, double *b2, double *b3) {
+  GhostSet gs{};
+  double *b[3] = {b1, b2, b3};
+  for (int c = 0; c < 3; ++c) { gs.q[c] = make_comp(g, c + 1); gs.a[c] = b[c]; gs.comp[c] = c + 1; }
+  gs.ncomp = 3;
+  return gs;
 }
 
 // ---- pack: one grid.y per segment --------------------------------------------------------
@@ -274,13 +302,13 @@ long long akmi_bvals_fc_segsize(const akmi_pack *p, int d) {
 
 int akmi_bvals_cc_local(const akmi_pack *p, int nvar, const int *nghbr, double *u, void *stream) {
   Geo g = make_geo(p);
-  return launch_ghost(g, make_comp(g, 0), nvar, nghbr, u, nullptr, nullptr, 0, (hipStream_t)stream);
+  return launch_ghost<0>(g, cc_set(g, u), nvar, nghbr, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int akmi_bvals_cc_unpack(const akmi_pack *p, int nvar, const int *nghbr, const long long *seg_off,
                          const double *recvbuf, double *u, void *stream) {
   Geo g = make_geo(p);
-  return launch_ghost(g, make_comp(g, 0), nvar, nghbr, u, seg_off, recvbuf, 1, (hipStream_t)stream);
+  return launch_ghost<1>(g, cc_set(g, u), nvar, nghbr, seg_off, recvbuf, (hipStream_t)stream);
 }
 
 int akmi_bvals_cc_pack(const akmi_pack *p, int nvar, int nsend, const int *send_tab,
@@ -297,12 +325,7 @@ int akmi_bvals_cc_pack(const akmi_pack *p, int nvar, int nsend, const int *send_
 int akmi_bvals_fc_local(const akmi_pack *p, const int *nghbr, double *bx1f, double *bx2f,
                         double *bx3f, void *stream) {
   Geo g = make_geo(p);
-  double *b[3] = {bx1f, bx2f, bx3f};
-  for (int c = 1; c <= 3; ++c) {
-    int rc = launch_ghost(g, make_comp(g, c), 1, nghbr, b[c - 1], nullptr, nullptr, 0, (hipStream_t)stream);
-    if (rc != AKMI_COMPLETE) return rc;
-  }
-  return AKMI_COMPLETE;
+  return launch_ghost<0>(g, fc_set(g, bx1f, bx2f, bx3f), 1, nghbr, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int akmi_bvals_fc_pack(const akmi_pack *p, int nsend, const int *send_tab, const long long *send_off,
@@ -322,62 +345,14 @@ int akmi_bvals_fc_pack(const akmi_pack *p, int nsend, const int *send_tab, const
 
 }  // extern "C"
 
-namespace akmi {
-// FC unpack needs per-component base offsets inside a segment (x1f, x2f, x3f back to back)
-template <int MODE>
-__global__ void __launch_bounds__(256)
-k_fc_unpack(Geo g, Comp q, int comp, const int *__restrict__ nghbr, double *__restrict__ a,
-            const long long *__restrict__ seg_off, const double *__restrict__ recvbuf) {
-  int e1, e2, e3;
-  if (MODE == 0) { e1 = q.n1; e2 = q.n2; e3 = 2*q.d3.ng; }
-  else if (MODE == 1) { e1 = q.n1; e2 = 2*q.d2.ng; e3 = q.d3.eo - q.d3.s + 1; }
-  else { e1 = 2*q.d1.ng; e2 = q.d2.eo - q.d2.s + 1; e3 = q.d3.eo - q.d3.s + 1; }
-  const long long per = (long long)e1*e2*e3;
-  const long long tot = per*g.nmb;
-  for (long long t = (long long)blockIdx.x*blockDim.x + threadIdx.x; t < tot;
-       t += (long long)gridDim.x*blockDim.x) {
-    int m = (int)(t/per);
-    long long r = t - (long long)m*per;
-    int kk = (int)(r/((long long)e1*e2));
-    r -= (long long)kk*e1*e2;
-    int jj = (int)(r/e1);
-    int ii = (int)(r - (long long)jj*e1);
-    int i, j, k;
-    if (MODE == 0) { i = ii; j = jj; k = kk < q.d3.ng ? kk : q.d3.eo + 1 + (kk - q.d3.ng); }
-    else if (MODE == 1) { i = ii; j = jj < q.d2.ng ? jj : q.d2.eo + 1 + (jj - q.d2.ng); k = q.d3.s + kk; }
-    else { i = ii < q.d1.ng ? ii : q.d1.eo + 1 + (ii - q.d1.ng); j = q.d2.s + jj; k = q.d3.s + kk; }
-    int o1 = q.d1.side(i), o2 = q.d2.side(j), o3 = q.d3.side(k);
-    int d = (o3 + 1)*9 + (o2 + 1)*3 + (o1 + 1);
-    int src = nghbr[m*27 + d];
-    if (src > -2) continue;
-    long long base = seg_off[-(src + 2)];
-    for (int c = 1; c < comp; ++c) base += seg_count(make_comp(g, c), o1, o2, o3);
-    const int c1 = q.d1.cnt(o1), c2 = q.d2.cnt(o2);
-    long long off = base + ((long long)(k - q.d3.lo(o3))*c2 + (j - q.d2.lo(o2)))*c1 + (i - q.d1.lo(o1));
-    a[(((size_t)m*q.n3 + k)*q.n2 + j)*q.n1 + i] = recvbuf[off];
-  }
-}
-}  // namespace akmi
-
 extern "C" {
 
 int akmi_bvals_fc_unpack(const akmi_pack *p, const int *nghbr, const long long *seg_off,
                          const double *recvbuf, double *bx1f, double *bx2f, double *bx3f,
                          void *stream) {
   Geo g = make_geo(p);
-  hipStream_t st = (hipStream_t)stream;
-  double *b[3] = {bx1f, bx2f, bx3f};
-  auto nblk = [](long long n) { long long bl = (n + 255)/256; return (int)(bl > 65535 ? 65535 : (bl < 1 ? 1 : bl)); };
-  for (int c = 1; c <= 3; ++c) {
-    Comp q = make_comp(g, c);
-    if (q.d3.ng > 0)
-      k_fc_unpack<0><<<nblk((long long)q.n1*q.n2*2*q.d3.ng*g.nmb), 256, 0, st>>>(g, q, c, nghbr, b[c-1], seg_off, recvbuf);
-    if (q.d2.ng > 0)
-      k_fc_unpack<1><<<nblk((long long)q.n1*2*q.d2.ng*(q.d3.eo - q.d3.s + 1)*g.nmb), 256, 0, st>>>(g, q, c, nghbr, b[c-1], seg_off, recvbuf);
-    k_fc_unpack<2><<<nblk((long long)2*q.d1.ng*(q.d2.eo - q.d2.s + 1)*(q.d3.eo - q.d3.s + 1)*g.nmb), 256, 0, st>>>(g, q, c, nghbr, b[c-1], seg_off, recvbuf);
-  }
-  AKMI_CHECK_LAUNCH("fc_unpack");
-  return AKMI_COMPLETE;
+  return launch_ghost<2>(g, fc_set(g, bx1f, bx2f, bx3f), 1, nghbr, seg_off, recvbuf,
+                         (hipStream_t)stream);
 }
 
 int akmi_hydro_bcs(const akmi_pack *p, int nvar, const int *bcs, double *u, void *stream) {

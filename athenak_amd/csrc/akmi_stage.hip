@@ -766,11 +766,12 @@ static int launch_sweep_update(const Geo &g, const Scheme &sc, const SweepArgs &
 // the slab pipeline.  MODE 0: k-ghost planes (all j,i); 1: j-ghost rows of active planes;
 // 2: i-ghost columns of active rows.  Flattened 1-D over the slab so that the 2*ng-wide
 // i-slabs do not waste 60 of 64 lanes.
-template <bool MHD, int MODE>
+template <bool MHD>
 __global__ void __launch_bounds__(256)
 k_c2p_shell(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ bx1f,
             const double *__restrict__ bx2f, const double *__restrict__ bx3f,
             double *__restrict__ w0, double *__restrict__ bcc0, int *__restrict__ counters) {
+  const int MODE = blockIdx.y;                 // slab of the shell, one launch for all three
   const int ng3 = g.three_d ? g.ng : 0, ng2 = g.multi_d ? g.ng : 0;
   int e1, e2, e3;
   if (MODE == 0) { e1 = g.N1; e2 = g.N2; e3 = 2*ng3; }
@@ -818,19 +819,12 @@ static int c2p_shell(const akmi_pack *p, double *u0, const double *bx1f, const d
                      const double *bx3f, double *w0, double *bcc0, int *counters, hipStream_t st) {
   Geo g = make_geo(p);
   Eos eos = make_eos(p);
-  auto nb = [](long long n) { return (unsigned)((n + 255)/256); };
-  if (g.three_d) {
-    long long n = (long long)g.N1*g.N2*2*g.ng*g.nmb;
-    k_c2p_shell<MHD, 0><<<nb(n), 256, 0, st>>>(g, eos, u0, bx1f, bx2f, bx3f, w0, bcc0, counters);
-  }
-  if (g.multi_d) {
-    long long n = (long long)g.N1*2*g.ng*g.nx3*g.nmb;
-    k_c2p_shell<MHD, 1><<<nb(n), 256, 0, st>>>(g, eos, u0, bx1f, bx2f, bx3f, w0, bcc0, counters);
-  }
-  {
-    long long n = (long long)2*g.ng*g.nx2*g.nx3*g.nmb;
-    k_c2p_shell<MHD, 2><<<nb(n), 256, 0, st>>>(g, eos, u0, bx1f, bx2f, bx3f, w0, bcc0, counters);
-  }
+  const long long n0 = g.three_d ? (long long)g.N1*g.N2*2*g.ng*g.nmb : 0;
+  const long long n1 = g.multi_d ? (long long)g.N1*2*g.ng*g.nx3*g.nmb : 0;
+  const long long n2 = (long long)2*g.ng*g.nx2*g.nx3*g.nmb;
+  const long long nmax = n0 > n1 ? (n0 > n2 ? n0 : n2) : (n1 > n2 ? n1 : n2);
+  dim3 grid((unsigned)((nmax + 255)/256), 3);
+  k_c2p_shell<MHD><<<grid, 256, 0, st>>>(g, eos, u0, bx1f, bx2f, bx3f, w0, bcc0, counters);
   AKMI_CHECK_LAUNCH("c2p_shell");
   return AKMI_COMPLETE;
 }
