@@ -469,20 +469,27 @@ Driver::Driver(ParameterInput *pin, Mesh *pmesh) {       // driver.cpp:85-162
   integrator = pin->GetOrAddString("time", "integrator", "rk2");
   tlim = pin->GetReal("time", "tlim");
   nlim = pin->GetOrAddInteger("time", "nlim", -1);
-  for (int q = 0; q < 4; ++q) gam0[q] = gam1[q] = beta[q] = 0.0;
+  for (int q = 0; q < 4; ++q) gam0[q] = gam1[q] = beta[q] = delta[q] = 0.0;
   if (integrator == "rk1") {
     nexp_stages = 1; gam0[0] = 0.0; gam1[0] = 1.0; beta[0] = 1.0;
   } else if (integrator == "rk2") {
     nexp_stages = 2;
     gam0[0] = 0.0; gam1[0] = 1.0; beta[0] = 1.0;
     gam0[1] = 0.5; gam1[1] = 0.5; beta[1] = 0.5;
+  } else if (integrator == "rk4") {   // RK4()4[2S], driver.cpp:131-160
+    nexp_stages = 4;
+    gam0[0] = 0.0; gam1[0] = 1.0; beta[0] = 1.193743905974738;
+    gam0[1] = 0.121098479554482; gam1[1] = 0.721781678111411; beta[1] = 0.099279895495783;
+    gam0[2] = -3.843833699660025; gam1[2] = 2.121209265338722; beta[2] = 1.131678018054042;
+    gam0[3] = 0.546370891121863; gam1[3] = 0.198653035682705; beta[3] = 0.310665766509336;
+    delta[0] = 1.0; delta[1] = 0.217683334308543; delta[2] = 1.065841341361089; delta[3] = 0.0;
   } else if (integrator == "rk3") {
     nexp_stages = 3;
     gam0[0] = 0.0; gam1[0] = 1.0; beta[0] = 1.0;
     gam0[1] = 0.25; gam1[1] = 0.75; beta[1] = 0.25;
     gam0[2] = 2.0/3.0; gam1[2] = 1.0/3.0; beta[2] = 2.0/3.0;
   } else {
-    AKMI_FATAL("integrator=" + integrator + " not implemented. Valid choices are [rk1,rk2,rk3].");
+    AKMI_FATAL("integrator=" + integrator + " not implemented. Valid choices are [rk1,rk2,rk3,rk4].");
   }
 }
 
@@ -536,6 +543,8 @@ int Driver::Execute(Mesh *pm, int max_cycles) {            // driver.cpp:380-459
 namespace hydro {
 TaskStatus Hydro::CopyCons(Driver *d, int stage) {         // hydro_tasks.cpp:130-152
   if (stage == 1 && !fused) AKCHK(akmi_copy_cons(&pack_c, u0.p, u1.p, stream));
+  if (stage > 1 && d->integrator == "rk4")
+    AKCHK(akmi_rk4_copy_cons(&pack_c, d->delta[stage - 1], u0.p, u1.p, stream));
   return TaskStatus::complete;
 }
 TaskStatus Hydro::Fluxes(Driver *d, int stage) {           // hydro_tasks.cpp:159-201

@@ -274,7 +274,7 @@ class Driver {          // driver.cpp
   std::string integrator;
   Real tlim;
   int nlim, nexp_stages;
-  Real gam0[4], gam1[4], beta[4];
+  Real gam0[4], gam1[4], beta[4], delta[4];
   std::int64_t nmb_updated_ = 0;
 };
 

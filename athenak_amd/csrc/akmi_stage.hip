@@ -176,6 +176,9 @@ struct UpdArgs {
 #ifndef AKMI_PREFETCH_UPD
 #define AKMI_PREFETCH_UPD 1
 #endif
+#ifndef AKMI_PREFETCH_X1
+#define AKMI_PREFETCH_X1 1
+#endif
 constexpr int ML = AKMI_ML;            // faces marched per thread (chunk length), full-size packs
 
 // chunk length of a marching kernel: ML when that still gives several workgroups per CU, shorter
@@ -319,6 +322,16 @@ k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int ml) {
         for (int n = 0; n < 5; ++n) { pa[n] = u.acc[c + n*cs]; pu[n] = u.u0[c + n*cs]; }
       }
     }
+    // x2 march of 3-D runs: same idea for the x1 flux difference of the finished cell
+    constexpr bool PRE1 = (DIR == 1) && (MODE == 1) && !USEACC && AKMI_PREFETCH_X1;
+    if constexpr (PRE1) {
+      if (upd) {
+        const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k, sc, i);
+        const size_t fs1 = (size_t)g.N3*g.N2*(g.N1 + 1);
+#pragma unroll
+        for (int n = 0; n < 5; ++n) pa[n] = (u.flx1[c + n*fs1 + 1] - u.flx1[c + n*fs1])/dx1;
+      }
+    }
     double fd, fx, fy, fz, fe;
     if constexpr (MHD) {
       Cons1D fl = riemann_mhd<RS>(eos.gamma, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1],
@@ -344,7 +357,7 @@ k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int ml) {
       for (int n = 0; n < 5; ++n) {
         const double fprev = FP_(n);
         double divf;
-        if constexpr (PRE) {
+        if constexpr (PRE || PRE1) {
           divf = pa[n];
         } else if constexpr (USEACC) {
           divf = u.acc[c + n*cs];
@@ -967,8 +980,8 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
     if ((rc = ensure_aux()) != AKMI_COMPLETE) return rc;
     sb = g_aux;
     // fork: the helper stream starts after everything already enqueued on the caller's stream
-    hipEventRecord(g_ev[MAX_SLABS], st);
-    hipStreamWaitEvent(sb, g_ev[MAX_SLABS], 0);
+    (void)hipEventRecord(g_ev[MAX_SLABS], st);
+    (void)hipStreamWaitEvent(sb, g_ev[MAX_SLABS], 0);
   }
   auto kA = [&](int s) { return g.ks + s*T; };
   auto kB = [&](int s) { int e = g.ks + (s + 1)*T - 1; return e > g.ke ? g.ke : e; };
@@ -1006,8 +1019,8 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
     }
     if (rc != AKMI_COMPLETE) return rc;
     if (two) {
-      hipEventRecord(g_ev[s], st);
-      hipStreamWaitEvent(sb, g_ev[s], 0);       // everything below needs sweeps(<= s)
+      (void)hipEventRecord(g_ev[s], st);
+      (void)hipStreamWaitEvent(sb, g_ev[s], 0);       // everything below needs sweeps(<= s)
     }
     // HBM-bound chain, one slab behind (in-order on the helper stream)
     if (MHD && !do_emf) {
@@ -1031,8 +1044,8 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
   }
   if (two) {
     // join: later work on the caller's stream sees the helper stream's results
-    hipEventRecord(g_ev[MAX_SLABS + 1], sb);
-    hipStreamWaitEvent(st, g_ev[MAX_SLABS + 1], 0);
+    (void)hipEventRecord(g_ev[MAX_SLABS + 1], sb);
+    (void)hipStreamWaitEvent(st, g_ev[MAX_SLABS + 1], 0);
   }
   return AKMI_COMPLETE;
 }

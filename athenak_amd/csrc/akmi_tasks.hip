@@ -570,6 +570,16 @@ k_ct(Geo g, double gam0, double gam1, double beta_dt, const double *__restrict__
 #undef E3
 }
 
+// Hydro::CopyCons for rk4 (hydro_tasks.cpp:134-148): u1 += delta*u0, active cells
+__global__ void __launch_bounds__(256)
+k_rk4_register(Geo g, double delta, const double *__restrict__ u0, double *__restrict__ u1) {
+  const int i = g.is + blockIdx.x*256 + threadIdx.x;
+  if (i > g.ie) return;
+  const int j = g.js + blockIdx.y%g.nx2, k = g.ks + blockIdx.y/g.nx2;
+  const size_t c = (((size_t)blockIdx.z*g.N3 + k)*g.N2 + j)*g.N1 + i;   // blockIdx.z = m*nvar + n
+  u1[c] += delta*u0[c];
+}
+
 }  // namespace akmi
 
 using namespace akmi;
@@ -584,6 +594,14 @@ int akmi_copy_cons(const akmi_pack *p, const double *u0, double *u1, void *strea
   size_t n = (size_t)g.nmb*g.nvar*g.N3*g.N2*g.N1*sizeof(double);
   hipError_t e = hipMemcpyAsync(u1, u0, n, hipMemcpyDeviceToDevice, (hipStream_t)stream);
   if (e != hipSuccess) { set_error("copy_cons: %s", hipGetErrorString(e)); return AKMI_FAIL; }
+  return AKMI_COMPLETE;
+}
+
+int akmi_rk4_copy_cons(const akmi_pack *p, double delta, const double *u0, double *u1, void *stream) {
+  Geo g = make_geo(p);
+  dim3 grid((g.nx1 + 255)/256, g.nx2*g.nx3, g.nmb*g.nvar);
+  k_rk4_register<<<grid, 256, 0, (hipStream_t)stream>>>(g, delta, u0, u1);
+  AKMI_CHECK_LAUNCH("rk4_copy_cons");
   return AKMI_COMPLETE;
 }
 

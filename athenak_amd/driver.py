@@ -18,7 +18,7 @@ class Driver:
         self.tlim = pin.GetReal("time", "tlim")
         self.nlim = pin.GetOrAddInteger("time", "nlim", -1)
         self.ndiag = pin.GetOrAddInteger("time", "ndiag", 1)
-        self.gam0, self.gam1, self.beta = [0.0]*4, [0.0]*4, [0.0]*4
+        self.gam0, self.gam1, self.beta, self.delta = [0.0]*4, [0.0]*4, [0.0]*4, [0.0]*4
         if self.integrator == "rk1":
             self.nexp_stages, self.cfl_limit = 1, 1.0
             self.gam0[0], self.gam1[0], self.beta[0] = 0.0, 1.0, 1.0
@@ -31,9 +31,20 @@ class Driver:
             self.gam0[0], self.gam1[0], self.beta[0] = 0.0, 1.0, 1.0
             self.gam0[1], self.gam1[1], self.beta[1] = 0.25, 0.75, 0.25
             self.gam0[2], self.gam1[2], self.beta[2] = 2.0/3.0, 1.0/3.0, 2.0/3.0
+        elif self.integrator == "rk4":
+            # RK4()4[2S] of Ketcheson (2010), driver.cpp:131-160
+            self.nexp_stages, self.cfl_limit = 4, 1.3925
+            self.gam0[0], self.gam1[0], self.beta[0] = 0.0, 1.0, 1.193743905974738
+            self.gam0[1], self.gam1[1], self.beta[1] = (0.121098479554482, 0.721781678111411,
+                                                        0.099279895495783)
+            self.gam0[2], self.gam1[2], self.beta[2] = (-3.843833699660025, 2.121209265338722,
+                                                        1.131678018054042)
+            self.gam0[3], self.gam1[3], self.beta[3] = (0.546370891121863, 0.198653035682705,
+                                                        0.310665766509336)
+            self.delta = [1.0, 0.217683334308543, 1.065841341361089, 0.0]
         else:
             raise RuntimeError("### FATAL ERROR integrator=%s not implemented. Valid choices on "
-                               "this path are [rk1,rk2,rk3]." % self.integrator)
+                               "this path are [rk1,rk2,rk3,rk4]." % self.integrator)
         self.nimp_stages = 0
         self.nmb_updated_ = 0
         self.run_time_ = 0.0

@@ -178,6 +178,10 @@ class Hydro(FluidBase):
         if stage == 1 and not self.fused:
             capi.check(self.L.akmi_copy_cons(C.byref(self.pack_c), capi._p(self.u0),
                                              capi._p(self.u1), capi._stream()), "copy_cons")
+        elif stage > 1 and pdrive.integrator == "rk4":
+            capi.check(self.L.akmi_rk4_copy_cons(
+                C.byref(self.pack_c), C.c_double(pdrive.delta[stage - 1]), capi._p(self.u0),
+                capi._p(self.u1), capi._stream()), "rk4_copy_cons")
         return TaskStatus.complete
 
     def Fluxes(self, pdrive, stage):

@@ -70,6 +70,9 @@ int akmi_version(void);
 /* ---- Hydro tasks ------------------------------------------------------------------ */
 /* Hydro::CopyCons (src/hydro/hydro_tasks.cpp:130-152): u1 <- u0 */
 int akmi_copy_cons(const akmi_pack *p, const double *u0, double *u1, void *stream);
+/* Hydro::CopyCons, stages 2..4 of integrator rk4 (src/hydro/hydro_tasks.cpp:134-148): the second
+ * register of the 2S scheme, u1 += delta*u0 on the active cells */
+int akmi_rk4_copy_cons(const akmi_pack *p, double delta, const double *u0, double *u1, void *stream);
 
 /* Hydro::Fluxes -> CalculateFluxes<hllc> (src/hydro/hydro_fluxes.cpp:77-229): reconstruct
  * w0 (recon), solve Riemann problem at faces i in [is,ie+1] (x1), j in [js,je+1] (x2),

@@ -31,6 +31,7 @@ int  akref_get_threads(void);
 
 /* ---- kernel-level restatements: same arguments as the akmi_* entry points ---------- */
 int akref_copy_cons(const akmi_pack *p, const double *u0, double *u1);
+int akref_rk4_copy_cons(const akmi_pack *p, double delta, const double *u0, double *u1);
 int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
                        double *flx1, double *flx2, double *flx3, int face_shaped);
 int akref_rk_update(const akmi_pack *p, double gam0, double gam1, double beta_dt,
@@ -111,7 +112,7 @@ typedef struct akref_params {
   double x1min, x1max, x2min, x2max, x3min, x3max;
   int bcs[6];                      /* AKMI_BC_* ix1,ox1,ix2,ox2,ix3,ox3 */
   /* <time> */
-  int nstages;                     /* rk1/rk2/rk3 -> 1/2/3 */
+  int nstages;                     /* rk1..rk4 -> 1..4  */
   double cfl, tlim;
   int nlim;
   /* <hydro>/<mhd> */

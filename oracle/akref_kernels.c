@@ -1161,6 +1161,18 @@ int akref_copy_cons(const akmi_pack *p, const double *u0, double *u1) {
   return 0;
 }
 
+/* Hydro::CopyCons for integrator rk4, src/hydro/hydro_tasks.cpp:134-148 */
+int akref_rk4_copy_cons(const akmi_pack *p, double delta, const double *u0, double *u1) {
+  G g = mkG(p);
+  for (int m = 0; m < g.nmb; ++m) for (int n = 0; n < g.nvar; ++n)
+    for (int k = g.ks; k <= g.ke; ++k) for (int j = g.js; j <= g.je; ++j)
+      for (int i = g.is; i <= g.ie; ++i) {
+        size_t c = ((((size_t)m*g.nvar + n)*g.N3 + k)*g.N2 + j)*g.N1 + i;
+        u1[c] += delta*u0[c];
+      }
+  return 0;
+}
+
 /* Hydro::CalculateFluxes<hllc>, src/hydro/hydro_fluxes.cpp:77-229 (no FOFC, no scalars) */
 int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
                        double *flx1, double *flx2, double *flx3, int fs) {

@@ -30,7 +30,7 @@ struct akref_sim {
   int nv;                          /* nhydro|nmhd: 5 ideal gas, 4 isothermal */
   int ncycle;
   int counters[3];
-  double gam0[3], gam1[3], beta[3];
+  double gam0[4], gam1[4], beta[4], delta[4];
 };
 
 /* src/coordinates/cell_locations.hpp:23-39 */
@@ -184,10 +184,19 @@ akref_sim *akref_create(const akref_params *par) {
   else if (p->nstages == 2) {
     s->gam0[0] = 0.0; s->gam1[0] = 1.0; s->beta[0] = 1.0;
     s->gam0[1] = 0.5; s->gam1[1] = 0.5; s->beta[1] = 0.5;
-  } else {
+  } else if (p->nstages == 3) {
     s->gam0[0] = 0.0; s->gam1[0] = 1.0; s->beta[0] = 1.0;
     s->gam0[1] = 0.25; s->gam1[1] = 0.75; s->beta[1] = 0.25;
     s->gam0[2] = 2.0/3.0; s->gam1[2] = 1.0/3.0; s->beta[2] = 2.0/3.0;
+  } else {
+    /* rk4 = RK4()4[2S], src/driver/driver.cpp:131-160; the second register is advanced in
+     * Hydro::CopyCons only (MHD::CopyCons has no rk4 branch, src/mhd/mhd_tasks.cpp:162-170) */
+    s->gam0[0] = 0.0; s->gam1[0] = 1.0; s->beta[0] = 1.193743905974738;
+    s->gam0[1] = 0.121098479554482; s->gam1[1] = 0.721781678111411; s->beta[1] = 0.099279895495783;
+    s->gam0[2] = -3.843833699660025; s->gam1[2] = 2.121209265338722; s->beta[2] = 1.131678018054042;
+    s->gam0[3] = 0.546370891121863; s->gam1[3] = 0.198653035682705; s->beta[3] = 0.310665766509336;
+    s->delta[0] = 1.0; s->delta[1] = 0.217683334308543; s->delta[2] = 1.065841341361089;
+    s->delta[3] = 0.0;
   }
   s->time = 0.0; s->ncycle = 0; s->tlim = p->tlim;
   s->dt = (double)FLT_MAX;          /* src/mesh/build_tree.cpp:301 */
@@ -774,6 +783,7 @@ int akref_step(akref_sim *s) {
     } else {
       /* stagen chain, src/hydro/hydro_tasks.cpp:55-71 */
       if (stage == 1) akref_copy_cons(pk, s->u0, s->u1);
+      else if (p->nstages == 4) akref_rk4_copy_cons(pk, s->delta[stage-1], s->u0, s->u1);
       akref_hydro_fluxes(pk, p->recon, p->rsolver, s->w0, s->flx1, s->flx2, s->flx3, 0);
       akref_rk_update(pk, gam0, gam1, beta_dt, s->u0, s->u1, s->flx1, s->flx2, s->flx3, 0);
     }

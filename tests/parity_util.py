@@ -60,7 +60,7 @@ def oracle_kwargs(pin):
               x1min=g("mesh", "x1min"), x1max=g("mesh", "x1max"), x2min=g("mesh", "x2min"),
               x2max=g("mesh", "x2max"), x3min=g("mesh", "x3min"), x3max=g("mesh", "x3max"),
               bcs=[gs("mesh", k) for k in ("ix1_bc", "ox1_bc", "ix2_bc", "ox2_bc", "ix3_bc", "ox3_bc")],
-              nstages={"rk1": 1, "rk2": 2, "rk3": 3}[gs("time", "integrator")],
+              nstages={"rk1": 1, "rk2": 2, "rk3": 3, "rk4": 4}[gs("time", "integrator")],
               cfl=g("time", "cfl_number"), tlim=g("time", "tlim"), nlim=gi("time", "nlim"),
               is_mhd=1 if is_mhd else 0, recon=gs(blk, "reconstruct"), rsolver=gs(blk, "rsolver"),
               gamma=g(blk, "gamma"))

@@ -81,6 +81,24 @@ def test_native_cpp_driver_schemes(case):
     assert res["cycles"] == cycles and res["bitwise_equal"], res["diffs"]
 
 
+RK4 = [
+    ("linear_wave_hydro", 64, 1, 32, 8, dict(integrator="rk4", recon="wenoz", ng=3, rsolver="hllc")),
+    ("sod", 24, 3, 12, 4, dict(integrator="rk4", cfl=0.3, rsolver="hlle")),
+    ("sod", 32, 2, 16, 5, dict(integrator="rk4", cfl=0.3, recon="ppm4", ng=3, rsolver="roe")),
+]
+
+
+@pytest.mark.parametrize("mode", ["fused", "split", "native"])
+@pytest.mark.parametrize("case", RK4, ids=_id)
+def test_rk4_is_bit_identical(case, mode):
+    """integrator rk4: u1 += delta*u0 on the active cells before stages 2-4 (akmi_rk4_copy_cons)"""
+    problem, n, dims, mb, cycles, kw = case
+    res = pu.compare_run(problem, n, dims, mb, cycles, fused=(mode != "split"),
+                         native=(mode == "native"), **kw)
+    assert res["cycles"] == cycles and res["time"][0] == res["time"][1]
+    assert res["bitwise_equal"], res["diffs"]
+
+
 def _wild_states(shape5, rng, mhd):
     """primitive states with jumps of many decades between neighbouring cells: exercises the
     supersonic branches, the HLLE/HLLC pressure estimates, Roe's negative-density fallback and
