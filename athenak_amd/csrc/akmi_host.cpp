@@ -155,6 +155,7 @@ template <typename T> void DvceArray<T>::Free() {
 template struct DvceArray<Real>;
 template struct DvceArray<int>;
 template struct DvceArray<char>;
+template struct DvceArray<unsigned char>;
 
 // ---- Mesh -----------------------------------------------------------------------------------
 static Real LeftEdgeX(int ith, int n, Real xmin, Real xmax) {   // cell_locations.hpp:23-28
@@ -376,10 +377,22 @@ Hydro::Hydro(MeshBlockPack *pp, ParameterInput *pin) : FluidBase(pp, pin, "hydro
   const RegionIndcs &ind = pp->pmesh->mb_indcs;
   const size_t n1 = ind.nx1 + 2*ind.ng, n2 = ind.nx2 > 1 ? ind.nx2 + 2*ind.ng : 1,
                n3 = ind.nx3 > 1 ? ind.nx3 + 2*ind.ng : 1;
+  use_fofc = pin->GetOrAddBoolean("hydro", "fofc", false);        // hydro.cpp:153-190
+  if (use_fofc) {
+    const int need = recon_method == AKMI_RECON_PLM ? 3 : (recon_method >= AKMI_RECON_PPM4 ? 4 : 2);
+    if (ind.ng < need)
+      AKMI_FATAL("FOFC and this reconstruction require at least " + std::to_string(need) +
+                 " ghost zones, but <mesh>/nghost=" + std::to_string(ind.ng));
+    fused = false;                      // FOFC works on the flux arrays of the task-granular path
+    fofc.Realloc(static_cast<size_t>(pp->nmb_thispack)*n3*n2*n1);
+    nfofc.Realloc(1);
+    HIPCHK(hipMemset(fofc.p, 0, fofc.n));
+    HIPCHK(hipMemset(nfofc.p, 0, sizeof(int)));
+  }
   if (fused) ws.Realloc(static_cast<size_t>(akmi_stage_workspace_bytes(&pack_c, 0)));
   else FaceAlloc(uflx, pp->nmb_thispack, 5, n3, n2, n1, 0);      // hydro.cpp:290-292
 }
-Hydro::~Hydro() { FaceFree(uflx); }
+Hydro::~Hydro() { FaceFree(uflx); fofc.Free(); nfofc.Free(); }
 
 void Hydro::AssembleHydroTasks(std::map<std::string, std::shared_ptr<TaskList>> tl) {
   TaskID none(0);                                                  // hydro_tasks.cpp:48-80
@@ -548,9 +561,16 @@ TaskStatus Hydro::CopyCons(Driver *d, int stage) {         // hydro_tasks.cpp:13
   return TaskStatus::complete;
 }
 TaskStatus Hydro::Fluxes(Driver *d, int stage) {           // hydro_tasks.cpp:159-201
-  if (!fused)
+  if (use_fofc) {                                           // hydro_tasks.cpp:192-194
+    AKCHK(akmi_hydro_fluxes_fofc(&pack_c, recon_method, rsolver_method, w0.p, uflx.x1f.p,
+                                 uflx.x2f.p, uflx.x3f.p, 0, stream));
+    AKCHK(akmi_hydro_fofc(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1],
+                          d->beta[stage - 1]*pmy_pack->pmesh->dt, w0.p, u0.p, u1.p, uflx.x1f.p,
+                          uflx.x2f.p, uflx.x3f.p, 0, fofc.p, nfofc.p, stream));
+  } else if (!fused) {
     AKCHK(akmi_hydro_fluxes(&pack_c, recon_method, rsolver_method, w0.p, uflx.x1f.p, uflx.x2f.p,
                             uflx.x3f.p, 0, stream));
+  }
   return TaskStatus::complete;
 }
 TaskStatus Hydro::RKUpdate(Driver *d, int stage) {         // hydro_update.cpp:23-83

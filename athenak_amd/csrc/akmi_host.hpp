@@ -207,6 +207,9 @@ class Hydro : public FluidBase {    // hydro.hpp:73-154
   Hydro(MeshBlockPack *pp, ParameterInput *pin);
   ~Hydro() override;
   DvceFaceFld uflx;
+  bool use_fofc = false;                // hydro.hpp:116-117
+  DvceArray<unsigned char> fofc;
+  DvceArray<int> nfofc;                 // EventCounters::nfofc (mesh.hpp:71), kept on the device
   void AssembleHydroTasks(std::map<std::string, std::shared_ptr<TaskList>> tl);
   TaskStatus InitRecv(Driver *d, int stage) { return TaskStatus::complete; }
   TaskStatus CopyCons(Driver *d, int stage);

@@ -65,12 +65,17 @@ k_hydro_flux(Geo g, FaceEos eos, const double *__restrict__ w0, double *__restri
 
 template <int DIR>
 static int launch_hydro_flux(const Geo &g, const Scheme &sc, const double *w0,
-                             double *flx, int fsh, hipStream_t st) {
+                             double *flx, int fsh, hipStream_t st, int ext = 0) {
   int il = g.is, iu = g.ie, jl = g.js, ju = g.je, kl = g.ks, ku = g.ke;
+  if (ext) {                      // <hydro>/fofc: hydro_fluxes.cpp:92-101
+    il = g.is - 1; iu = g.ie + 1;
+    if (g.multi_d) { jl = g.js - 1; ju = g.je + 1; }
+    if (g.three_d) { kl = g.ks - 1; ku = g.ke + 1; }
+  }
   int f3 = g.N3, f2 = g.N2, f1 = g.N1;
-  if (DIR == 0) { iu = g.ie + 1; f1 += fsh; }
-  if (DIR == 1) { ju = g.je + 1; f2 += fsh; }
-  if (DIR == 2) { ku = g.ke + 1; f3 += fsh; }
+  if (DIR == 0) { il = g.is - ext; iu = g.ie + 1 + ext; f1 += fsh; }
+  if (DIR == 1) { jl = g.js - ext; ju = g.je + 1 + ext; f2 += fsh; }
+  if (DIR == 2) { kl = g.ks - ext; ku = g.ke + 1 + ext; f3 += fsh; }
   int nk = ku - kl + 1;
   dim3 grid(cdiv(iu - il + 1, BX), cdiv(ju - jl + 1, BY), nk*g.nmb), block(BX, BY);
   int rc = dispatch_scheme<false>(sc, [&](auto R, auto S) {
@@ -570,6 +575,87 @@ k_ct(Geo g, double gam0, double gam1, double beta_dt, const double *__restrict__
 #undef E3
 }
 
+// Hydro::FOFC part 1 (hydro_fofc.cpp:46-85): trial update + floor test of one cell
+__global__ void __launch_bounds__(BX*BY)
+k_fofc_flag_hyd(Geo g, Eos eos, double gam0, double gam1, double beta_dt,
+                const double *__restrict__ u0, const double *__restrict__ u1,
+                const double *__restrict__ flx1, const double *__restrict__ flx2,
+                const double *__restrict__ flx3, int fsh, int il, int iu, int jl, int ju, int kl,
+                int nk, unsigned char *__restrict__ fofc, int *__restrict__ nfofc) {
+  const int i = il + blockIdx.x*BX + threadIdx.x;
+  const int j = jl + blockIdx.y*BY + threadIdx.y;
+  const int m = blockIdx.z/nk;
+  const int k = kl + (blockIdx.z - m*nk);
+  if (i > iu || j > ju) return;
+  const double dtodx1 = beta_dt/g.dx[3*m], dtodx2 = beta_dt/g.dx[3*m + 1];
+  const double dtodx3 = beta_dt/g.dx[3*m + 2];
+  double ut[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int n = 0; n < g.nvar; ++n) {
+    double divf = dtodx1*(flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + fsh, m, n, k, j, i + 1)] -
+                          flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + fsh, m, n, k, j, i)]);
+    if (g.multi_d)
+      divf += dtodx2*(flx2[ix5(g.nvar, g.N3, g.N2 + fsh, g.N1, m, n, k, j + 1, i)] -
+                      flx2[ix5(g.nvar, g.N3, g.N2 + fsh, g.N1, m, n, k, j, i)]);
+    if (g.three_d)
+      divf += dtodx3*(flx3[ix5(g.nvar, g.N3 + fsh, g.N2, g.N1, m, n, k + 1, j, i)] -
+                      flx3[ix5(g.nvar, g.N3 + fsh, g.N2, g.N1, m, n, k, j, i)]);
+    const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, n, k, j, i);
+    ut[n] = gam0*u0[c] + gam1*u1[c] - divf;
+  }
+  bool fl;
+  if (!eos.is_ideal) {
+    fl = ut[0] < eos.dfloor;                 // isothermal_hyd.cpp: density floor only
+  } else {
+    double wd, wvx, wvy, wvz, we;
+    bool dfl = false, efl = false, tfl = false;
+    c2p_hyd(eos, ut[0], ut[1], ut[2], ut[3], ut[4], wd, wvx, wvy, wvz, we, dfl, efl, tfl);
+    fl = dfl || efl || tfl;
+  }
+  if (fl) {
+    fofc[ix4(g.N3, g.N2, g.N1, m, k, j, i)] = 1;
+    atomicAdd(nfofc, 1);
+  }
+}
+
+// Hydro::FOFC part 2 (hydro_fofc.cpp:100-366): a flagged cell rewrites the fluxes on its own faces
+// with the first-order LLF flux of the two adjacent cell states.  Two flagged neighbours store
+// the same value on their shared face.
+__global__ void __launch_bounds__(BX*BY)
+k_fofc_fix_hyd(Geo g, Eos eos, const double *__restrict__ w0, double *__restrict__ flx1,
+               double *__restrict__ flx2, double *__restrict__ flx3, int fsh, int il, int iu,
+               int jl, int ju, int kl, int nk, const unsigned char *__restrict__ fofc) {
+  const int i = il + blockIdx.x*BX + threadIdx.x;
+  const int j = jl + blockIdx.y*BY + threadIdx.y;
+  const int m = blockIdx.z/nk;
+  const int k = kl + (blockIdx.z - m*nk);
+  if (i > iu || j > ju) return;
+  if (!fofc[ix4(g.N3, g.N2, g.N1, m, k, j, i)]) return;
+  const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  const int ndir = g.three_d ? 3 : (g.multi_d ? 2 : 1);
+  for (int dir = 0; dir < ndir; ++dir) {
+    const int ivx = 1 + dir, ivy = 1 + (dir + 1)%3, ivz = 1 + (dir + 2)%3;
+    const int d1 = dir == 0, d2 = dir == 1, d3 = dir == 2;
+    double *flx = dir == 0 ? flx1 : (dir == 1 ? flx2 : flx3);
+    const int f1 = g.N1 + (d1 ? fsh : 0), f2 = g.N2 + (d2 ? fsh : 0), f3 = g.N3 + (d3 ? fsh : 0);
+    const size_t fs = (size_t)f3*f2*f1;
+    for (int side = 0; side < 2; ++side) {
+      const int kf = k + side*d3, jf = j + side*d2, ic = i + side*d1;
+      const double *ql = w0 + ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, kf - d3, jf - d2, ic - d1);
+      const double *qr = w0 + ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, kf, jf, ic);
+      double fd, fx, fy, fz, fe = 0.0;
+      if (eos.is_ideal)
+        llf_hyd(eos.gamma, ql[0], ql[ivx*cs], ql[ivy*cs], ql[ivz*cs], ql[4*cs], qr[0], qr[ivx*cs],
+                qr[ivy*cs], qr[ivz*cs], qr[4*cs], fd, fx, fy, fz, fe);
+      else
+        llf_hyd_iso(eos.iso_cs, ql[0], ql[ivx*cs], ql[ivy*cs], ql[ivz*cs], qr[0], qr[ivx*cs],
+                    qr[ivy*cs], qr[ivz*cs], fd, fx, fy, fz);
+      double *f = flx + ix5(g.nvar, f3, f2, f1, m, 0, kf, jf, ic);
+      f[0] = fd; f[ivx*fs] = fx; f[ivy*fs] = fy; f[ivz*fs] = fz;
+      if (eos.is_ideal) f[4*fs] = fe;
+    }
+  }
+}
+
 // Hydro::CopyCons for rk4 (hydro_tasks.cpp:134-148): u1 += delta*u0, active cells
 __global__ void __launch_bounds__(256)
 k_rk4_register(Geo g, double delta, const double *__restrict__ u0, double *__restrict__ u1) {
@@ -605,10 +691,20 @@ int akmi_rk4_copy_cons(const akmi_pack *p, double delta, const double *u0, doubl
   return AKMI_COMPLETE;
 }
 
-int akmi_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
-                      double *flx1, double *flx2, double *flx3, int face_shaped,
-                      void *stream) {
+static int hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0, double *flx1,
+                        double *flx2, double *flx3, int face_shaped, void *stream, int ext) {
   if (check_scheme(p, recon, "hydro_fluxes") != AKMI_COMPLETE) return AKMI_FAIL;
+  if (ext) {                      // src/hydro/hydro.cpp:153-190
+    if (p->nvar != (p->is_ideal ? 5 : 4)) {
+      set_error("hydro_fluxes_fofc: FOFC with passive scalars is not on this path"); return AKMI_FAIL;
+    }
+    const int need = recon == AKMI_RECON_PLM ? 3 : (recon >= AKMI_RECON_PPM4 ? 4 : 2);
+    if (p->ng < need) {
+      set_error("hydro_fluxes_fofc: FOFC and this reconstruction require at least %d ghost zones, "
+                "but nghost=%d", need, p->ng);
+      return AKMI_FAIL;
+    }
+  }
   if (!p->is_ideal && rsolver == AKMI_RS_HLLC) {
     set_error("hydro_fluxes: rsolver = hllc needs the ideal-gas EOS"); return AKMI_FAIL;
   }
@@ -616,10 +712,47 @@ int akmi_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *
   const Scheme sc{recon, rsolver, make_face_eos(p), !p->is_ideal};
   hipStream_t st = (hipStream_t)stream;
   int fsh = face_shaped ? 1 : 0;
-  int rc = launch_hydro_flux<0>(g, sc, w0, flx1, fsh, st);
-  if (rc == AKMI_COMPLETE && g.multi_d) rc = launch_hydro_flux<1>(g, sc, w0, flx2, fsh, st);
-  if (rc == AKMI_COMPLETE && g.three_d) rc = launch_hydro_flux<2>(g, sc, w0, flx3, fsh, st);
+  int rc = launch_hydro_flux<0>(g, sc, w0, flx1, fsh, st, ext);
+  if (rc == AKMI_COMPLETE && g.multi_d) rc = launch_hydro_flux<1>(g, sc, w0, flx2, fsh, st, ext);
+  if (rc == AKMI_COMPLETE && g.three_d) rc = launch_hydro_flux<2>(g, sc, w0, flx3, fsh, st, ext);
   return rc;
+}
+
+int akmi_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                      double *flx1, double *flx2, double *flx3, int face_shaped,
+                      void *stream) {
+  return hydro_fluxes(p, recon, rsolver, w0, flx1, flx2, flx3, face_shaped, stream, 0);
+}
+
+int akmi_hydro_fluxes_fofc(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                           double *flx1, double *flx2, double *flx3, int face_shaped,
+                           void *stream) {
+  return hydro_fluxes(p, recon, rsolver, w0, flx1, flx2, flx3, face_shaped, stream, 1);
+}
+
+int akmi_hydro_fofc(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *w0,
+                    const double *u0, const double *u1, double *flx1, double *flx2, double *flx3,
+                    int face_shaped, unsigned char *fofc, int *nfofc, void *stream) {
+  if (p->nvar != (p->is_ideal ? 5 : 4)) {
+    set_error("hydro_fofc: FOFC with passive scalars is not on this path"); return AKMI_FAIL;
+  }
+  Geo g = make_geo(p);
+  hipStream_t st = (hipStream_t)stream;
+  const int il = g.is - 1, iu = g.ie + 1;
+  const int jl = g.multi_d ? g.js - 1 : g.js, ju = g.multi_d ? g.je + 1 : g.je;
+  const int kl = g.three_d ? g.ks - 1 : g.ks, ku = g.three_d ? g.ke + 1 : g.ke;
+  const int nk = ku - kl + 1;
+  dim3 grid(cdiv(iu - il + 1, BX), cdiv(ju - jl + 1, BY), nk*g.nmb), block(BX, BY);
+  const int fsh = face_shaped ? 1 : 0;
+  k_fofc_flag_hyd<<<grid, block, 0, st>>>(g, make_eos(p), gam0, gam1, beta_dt, u0, u1, flx1, flx2,
+                                          flx3, fsh, il, iu, jl, ju, kl, nk, fofc, nfofc);
+  k_fofc_fix_hyd<<<grid, block, 0, st>>>(g, make_eos(p), w0, flx1, flx2, flx3, fsh, il, iu, jl, ju,
+                                         kl, nk, fofc);
+  AKMI_CHECK_LAUNCH("hydro_fofc");
+  // "reset FOFC flag" (hydro_fofc.cpp:364) once every flagged cell has been processed
+  hipError_t e = hipMemsetAsync(fofc, 0, (size_t)g.nmb*g.N3*g.N2*g.N1, st);
+  if (e != hipSuccess) { set_error("hydro_fofc: %s", hipGetErrorString(e)); return AKMI_FAIL; }
+  return AKMI_COMPLETE;
 }
 
 int akmi_rk_update(const akmi_pack *p, double gam0, double gam1, double beta_dt, double *u0,

@@ -130,6 +130,19 @@ class Hydro(FluidBase):
                                "(llf, hlle, hllc, roe on this path)" % rs)
         self.rsolver_method = capi.RSOLVER[rs]
         self.nhydro = self.nfluid
+        # first-order flux correction, hydro.cpp:153-190
+        self.use_fofc = pin.GetOrAddBoolean("hydro", "fofc", False)
+        if self.use_fofc:
+            ng = ppack.pmesh.mb_indcs.ng
+            recon = pin.GetString("hydro", "reconstruct")
+            need = 3 if recon == "plm" else (4 if recon in ("ppm4", "ppmx", "wenoz", "teno") else 2)
+            if ng < need:
+                raise RuntimeError("### FATAL ERROR FOFC and %s reconstruction requires at least %d "
+                                   "ghost zones, but <mesh>/nghost=%d" % (recon, need, ng))
+            if self.nscalars > 0:
+                raise RuntimeError("### FATAL ERROR <hydro>/fofc with passive scalars is not on "
+                                   "this path")
+            self.fused = False       # FOFC works on the flux arrays of the task-granular path
         n3, n2, n1 = ppack.pmesh.mb_indcs.ncells
         sh = (self.nmb, self.nvars, n3, n2, n1)
         z = lambda: torch.zeros(sh, dtype=torch.float64, device=device)
@@ -138,6 +151,9 @@ class Hydro(FluidBase):
         self.uflx = None if self.fused else FaceFld(self.nmb, self.nvars, n3, n2, n1, device, face_shaped=False)
         self.pbval_u = MeshBoundaryValues(ppack, bvals_kernels, device)
         self.pbval_u.set_pack(self.pack_c, self.nvars)
+        if self.use_fofc:
+            self.fofc = torch.zeros((self.nmb, n3, n2, n1), dtype=torch.uint8, device=device)
+            self.nfofc = torch.zeros(1, dtype=torch.int32, device=device)   # EventCounters::nfofc
 
     # ---- task list assembly: hydro_tasks.cpp:48-80 ---------------------------------
     def AssembleHydroTasks(self, tl):
@@ -186,7 +202,20 @@ class Hydro(FluidBase):
 
     def Fluxes(self, pdrive, stage):
         """hydro_tasks.cpp:159-201"""
-        if not self.fused:
+        if self.use_fofc:
+            # hydro_fluxes.cpp:92-101 (extended ranges) + hydro_tasks.cpp:192-194 -> Hydro::FOFC
+            capi.check(self.L.akmi_hydro_fluxes_fofc(
+                C.byref(self.pack_c), self.recon_method, self.rsolver_method, capi._p(self.w0),
+                capi._p(self.uflx.x1f), capi._p(self.uflx.x2f), capi._p(self.uflx.x3f), 0,
+                capi._stream()), "hydro_fluxes_fofc")
+            capi.check(self.L.akmi_hydro_fofc(
+                C.byref(self.pack_c), C.c_double(pdrive.gam0[stage - 1]),
+                C.c_double(pdrive.gam1[stage - 1]),
+                C.c_double(pdrive.beta[stage - 1]*self.pmy_pack.pmesh.dt), capi._p(self.w0),
+                capi._p(self.u0), capi._p(self.u1), capi._p(self.uflx.x1f), capi._p(self.uflx.x2f),
+                capi._p(self.uflx.x3f), 0, capi._p(self.fofc), capi._p(self.nfofc),
+                capi._stream()), "hydro_fofc")
+        elif not self.fused:
             capi.check(self.L.akmi_hydro_fluxes(
                 C.byref(self.pack_c), self.recon_method, self.rsolver_method, capi._p(self.w0),
                 capi._p(self.uflx.x1f), capi._p(self.uflx.x2f), capi._p(self.uflx.x3f), 0,

@@ -70,6 +70,19 @@ int akmi_version(void);
 /* ---- Hydro tasks ------------------------------------------------------------------ */
 /* Hydro::CopyCons (src/hydro/hydro_tasks.cpp:130-152): u1 <- u0 */
 int akmi_copy_cons(const akmi_pack *p, const double *u0, double *u1, void *stream);
+/* Hydro::Fluxes with <hydro>/fofc = true (src/hydro/hydro_fluxes.cpp:92-101): the same fluxes over
+ * ranges extended by one face / one transverse cell, as Hydro::FOFC needs them */
+int akmi_hydro_fluxes_fofc(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                           double *flx1, double *flx2, double *flx3, int face_shaped, void *stream);
+/* Hydro::FOFC (src/hydro/hydro_fofc.cpp:30-371, Newtonian): trial update of the cells
+ * [is-1,ie+1] x [js-1,je+1] x [ks-1,ke+1], flag those whose conversion to primitives would need a
+ * floor (ConsToPrim(..., only_testfloors=true), src/eos/ideal_hyd.cpp:67-72), replace the fluxes on
+ * the faces of flagged cells by first-order LLF fluxes (SingleStateLLF_Hyd), reset the flags.
+ * fofc = Hydro::fofc as unsigned char [nmb][N3][N2][N1], zero on entry and on exit (caller-owned);
+ * nfofc = device int, incremented by the number of flagged cells (EventCounters::nfofc). */
+int akmi_hydro_fofc(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *w0,
+                    const double *u0, const double *u1, double *flx1, double *flx2, double *flx3,
+                    int face_shaped, unsigned char *fofc, int *nfofc, void *stream);
 /* Hydro::CopyCons, stages 2..4 of integrator rk4 (src/hydro/hydro_tasks.cpp:134-148): the second
  * register of the 2S scheme, u1 += delta*u0 on the active cells */
 int akmi_rk4_copy_cons(const akmi_pack *p, double delta, const double *u0, double *u1, void *stream);

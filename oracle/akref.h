@@ -31,6 +31,11 @@ int  akref_get_threads(void);
 
 /* ---- kernel-level restatements: same arguments as the akmi_* entry points ---------- */
 int akref_copy_cons(const akmi_pack *p, const double *u0, double *u1);
+int akref_hydro_fluxes_fofc(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                            double *flx1, double *flx2, double *flx3, int face_shaped);
+int akref_hydro_fofc(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *w0,
+                     const double *u0, const double *u1, double *flx1, double *flx2, double *flx3,
+                     int face_shaped, unsigned char *fofc, int *nfofc);
 int akref_rk4_copy_cons(const akmi_pack *p, double delta, const double *u0, double *u1);
 int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
                        double *flx1, double *flx2, double *flx3, int face_shaped);
@@ -121,6 +126,7 @@ typedef struct akref_params {
   int is_ideal;                    /* eos = ideal (1) | isothermal (0) */
   double iso_cs;                   /* iso_sound_speed */
   int nscalars;                    /* passive scalars appended to the fluid variables */
+  int fofc;                        /* <hydro>/fofc: first-order flux correction */
   /* <problem> */
   int pgen;
   /* linear_wave */
@@ -152,6 +158,7 @@ double akref_time(const akref_sim *s);
 double akref_dt(const akref_sim *s);
 double akref_tlim(const akref_sim *s);
 int akref_ncycle(const akref_sim *s);
+int akref_nfofc(const akref_sim *s);
 int akref_nmb(const akref_sim *s);
 void akref_pack(const akref_sim *s, akmi_pack *out);
 /* name in {u0,w0,u1,bcc0,b0x1f,b0x2f,b0x3f,b1x1f,b1x2f,b1x3f,flx1,flx2,flx3,

@@ -41,6 +41,7 @@ class Params(C.Structure):
                 ("gamma", C.c_double), ("dfloor", C.c_double), ("pfloor", C.c_double),
                 ("tfloor", C.c_double), ("sfloor", C.c_double), ("sigma_max", C.c_double),
                 ("is_ideal", C.c_int), ("iso_cs", C.c_double), ("nscalars", C.c_int),
+                ("fofc", C.c_int),
                 ("pgen", C.c_int),
                 ("wave_flag", C.c_int), ("along_x1", C.c_int), ("along_x2", C.c_int),
                 ("along_x3", C.c_int),
@@ -81,7 +82,7 @@ def lib():
         for f in ("akref_time", "akref_dt", "akref_tlim"):
             getattr(L, f).restype = C.c_double
             getattr(L, f).argtypes = [C.c_void_p]
-        for f in ("akref_ncycle", "akref_nmb", "akref_step", "akref_run"):
+        for f in ("akref_ncycle", "akref_nmb", "akref_nfofc", "akref_step", "akref_run"):
             getattr(L, f).restype = C.c_int
             getattr(L, f).argtypes = [C.c_void_p]
         for f in ("akref_initialize", "akref_reinitialize", "akref_destroy"):
@@ -189,6 +190,7 @@ class Sim:
     tlim = property(lambda s: s.L.akref_tlim(s.h))
     ncycle = property(lambda s: s.L.akref_ncycle(s.h))
     nmb = property(lambda s: s.L.akref_nmb(s.h))
+    nfofc = property(lambda s: s.L.akref_nfofc(s.h))
 
     def pack(self):
         pk = Pack()

@@ -1173,9 +1173,10 @@ int akref_rk4_copy_cons(const akmi_pack *p, double delta, const double *u0, doub
   return 0;
 }
 
-/* Hydro::CalculateFluxes<hllc>, src/hydro/hydro_fluxes.cpp:77-229 (no FOFC, no scalars) */
-int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
-                       double *flx1, double *flx2, double *flx3, int fs) {
+/* Hydro::CalculateFluxes, src/hydro/hydro_fluxes.cpp:77-229.  ext = 1: the ranges of a run with
+ * <hydro>/fofc = true (:92-101): faces and transverse cells extended by one */
+static int hydro_fluxes_impl(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                             double *flx1, double *flx2, double *flx3, int fs, int ext) {
   if (rsolver != AKMI_RS_LLF && rsolver != AKMI_RS_HLLE && rsolver != AKMI_RS_HLLC &&
       rsolver != AKMI_RS_ROE) return AKMI_FAIL;
   if (!p->is_ideal && rsolver == AKMI_RS_HLLC) return AKMI_FAIL;   /* hllc is ideal-gas only */
@@ -1189,12 +1190,21 @@ int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double 
     if (dir == 1 && !g.multi_d) continue;
     if (dir == 2 && !g.three_d) continue;
     int il = g.is, iu = g.ie, jl = g.js, ju = g.je, kl = g.ks, ku = g.ke;
+    if (ext) {                       /* transverse ranges itl..itu etc., hydro_fluxes.cpp:98-100 */
+      il = g.is-1; iu = g.ie+1;
+      if (g.multi_d) { jl = g.js-1; ju = g.je+1; }
+      if (g.three_d) { kl = g.ks-1; ku = g.ke+1; }
+    }
     double *flx = flx1;
     int f3 = N3, f2 = N2, f1 = N1 + fs;
-    if (dir == 0) { recon_dir(&g, p, 1, recon, 0, nv, w0, wl, wr, kl, ku, jl, ju, il-1, iu+1); iu = g.ie+1; }
-    if (dir == 1) { recon_dir(&g, p, 1, recon, 1, nv, w0, wl, wr, kl, ku, jl-1, ju+1, il, iu); ju = g.je+1;
+    /* face-normal ranges: [s, e+1], or [s-1, e+2] with ext (:92,95-97); cells one further left */
+    if (dir == 0) { il = g.is - ext; iu = g.ie + ext;
+                    recon_dir(&g, p, 1, recon, 0, nv, w0, wl, wr, kl, ku, jl, ju, il-1, iu+1); iu = iu+1; }
+    if (dir == 1) { jl = g.js - ext; ju = g.je + ext;
+                    recon_dir(&g, p, 1, recon, 1, nv, w0, wl, wr, kl, ku, jl-1, ju+1, il, iu); ju = ju+1;
                     flx = flx2; f1 = N1; f2 = N2 + fs; }
-    if (dir == 2) { recon_dir(&g, p, 1, recon, 2, nv, w0, wl, wr, kl-1, ku+1, jl, ju, il, iu); ku = g.ke+1;
+    if (dir == 2) { kl = g.ks - ext; ku = g.ke + ext;
+                    recon_dir(&g, p, 1, recon, 2, nv, w0, wl, wr, kl-1, ku+1, jl, ju, il, iu); ku = ku+1;
                     flx = flx3; f1 = N1; f3 = N3 + fs; }
     const int ivx = IVX + dir, ivy = IVX + (dir + 1)%3, ivz = IVX + (dir + 2)%3;
 #pragma omp parallel for collapse(2) schedule(static)
@@ -1235,6 +1245,105 @@ int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double 
             }
     }
   }
+  return 0;
+}
+
+int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                       double *flx1, double *flx2, double *flx3, int fs) {
+  return hydro_fluxes_impl(p, recon, rsolver, w0, flx1, flx2, flx3, fs, 0);
+}
+
+int akref_hydro_fluxes_fofc(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                            double *flx1, double *flx2, double *flx3, int fs) {
+  if (p->nvar != (p->is_ideal ? 5 : 4)) return AKMI_FAIL;      /* FOFC + scalars: not on this path */
+  return hydro_fluxes_impl(p, recon, rsolver, w0, flx1, flx2, flx3, fs, 1);
+}
+
+/* Hydro::FOFC, src/hydro/hydro_fofc.cpp:30-371 (Newtonian): trial update of the cells
+ * [is-1,ie+1] x ..., flag those whose conversion to primitives needs a floor (ConsToPrim with
+ * only_testfloors, src/eos/ideal_hyd.cpp:67-72, isothermal_hyd.cpp), replace the fluxes on the
+ * faces of flagged cells by first-order LLF fluxes of the adjacent cell states
+ * (SingleStateLLF_Hyd, src/hydro/rsolvers/llf_hyd_singlestate.hpp:27-83), reset the flags.
+ * fofc: unsigned char [nmb][N3][N2][N1], all zero on entry and on exit; *nfofc += flagged cells */
+int akref_hydro_fofc(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *w0,
+                     const double *u0, const double *u1, double *flx1, double *flx2, double *flx3,
+                     int fs, unsigned char *fofc, int *nfofc) {
+  G g = mkG(p);
+  const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  const int ideal = p->is_ideal;
+  const int nhyd = ideal ? 5 : 4;
+  if (nv != nhyd) return AKMI_FAIL;
+  int il = g.is-1, iu = g.ie+1, jl = g.js, ju = g.je, kl = g.ks, ku = g.ke;
+  if (g.multi_d) { jl = g.js-1; ju = g.je+1; }
+  if (g.three_d) { kl = g.ks-1; ku = g.ke+1; }
+  const double gm1 = p->gamma - 1.0;
+  const double efloor = p->pfloor/gm1;
+  int nflag = 0;
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = kl; k <= ku; ++k)
+      for (int j = jl; j <= ju; ++j)
+        for (int i = il; i <= iu; ++i) {
+          double dtodx1 = beta_dt/p->dx[3*m];
+          double dtodx2 = beta_dt/p->dx[3*m+1];
+          double dtodx3 = beta_dt/p->dx[3*m+2];
+          double ut[5];
+          for (int n = 0; n < nhyd; ++n) {
+            double divf = dtodx1*(flx1[ix5(nv,N3,N2,N1+fs,m,n,k,j,i+1)] - flx1[ix5(nv,N3,N2,N1+fs,m,n,k,j,i)]);
+            if (g.multi_d)
+              divf += dtodx2*(flx2[ix5(nv,N3,N2+fs,N1,m,n,k,j+1,i)] - flx2[ix5(nv,N3,N2+fs,N1,m,n,k,j,i)]);
+            if (g.three_d)
+              divf += dtodx3*(flx3[ix5(nv,N3+fs,N2,N1,m,n,k+1,j,i)] - flx3[ix5(nv,N3+fs,N2,N1,m,n,k,j,i)]);
+            size_t c = ix5(nv,N3,N2,N1,m,n,k,j,i);
+            ut[n] = gam0*u0[c] + gam1*u1[c] - divf;
+          }
+          int fl = 0;
+          if (!ideal) {
+            fl = ut[0] < p->dfloor;
+          } else {          /* SingleC2P_IdealHyd, src/eos/ideal_c2p_hyd.hpp:22-66 */
+            double ud = ut[0], ue = ut[4];
+            if (ud < p->dfloor) { ud = p->dfloor; fl = 1; }
+            double di = 1.0/ud;
+            double e_k = 0.5*di*(SQR(ut[1]) + SQR(ut[2]) + SQR(ut[3]));
+            double we = (ue - e_k);
+            if (we < efloor) { we = efloor; fl = 1; }
+            if (gm1*we*di < p->tfloor) { we = ud*p->tfloor/gm1; fl = 1; }
+            double spe_over_eps = gm1/pow(ud, gm1);
+            double spe = spe_over_eps*we*di;
+            if (spe <= p->sfloor) fl = 1;
+          }
+          if (fl) { fofc[ix4(N3,N2,N1,m,k,j,i)] = 1; nflag++; }
+        }
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = kl; k <= ku; ++k)
+      for (int j = jl; j <= ju; ++j)
+        for (int i = il; i <= iu; ++i) {
+          if (!fofc[ix4(N3,N2,N1,m,k,j,i)]) continue;
+          for (int dir = 0; dir < 3; ++dir) {
+            if (dir == 1 && !g.multi_d) continue;
+            if (dir == 2 && !g.three_d) continue;
+            const int ivx = IVX + dir, ivy = IVX + (dir + 1)%3, ivz = IVX + (dir + 2)%3;
+            const int d1 = dir == 0, d2 = dir == 1, d3 = dir == 2;
+            double *flx = dir == 0 ? flx1 : (dir == 1 ? flx2 : flx3);
+            const int f1 = N1 + (d1 ? fs : 0), f2 = N2 + (d2 ? fs : 0), f3 = N3 + (d3 ? fs : 0);
+            for (int side = 0; side < 2; ++side) {       /* face at the cell, then the next one */
+              const int kf = k + side*d3, jf = j + side*d2, ifc = i + side*d1;
+              double a[5], b[5], f[5];
+              const int comp[5] = {IDN, ivx, ivy, ivz, IEN};
+              for (int q = 0; q < nhyd; ++q) {
+                a[q] = w0[ix5(nv,N3,N2,N1,m,comp[q],kf-d3,jf-d2,ifc-d1)];
+                b[q] = w0[ix5(nv,N3,N2,N1,m,comp[q],kf,jf,ifc)];
+              }
+              if (ideal) akref_llf_hyd(p->gamma, a, b, f); else akref_llf_hyd_iso(p->iso_cs, a, b, f);
+              for (int q = 0; q < nhyd; ++q) flx[ix5(nv,f3,f2,f1,m,comp[q],kf,jf,ifc)] = f[q];
+            }
+          }
+        }
+  /* "reset FOFC flag" (:364): done after all flagged cells have been processed */
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = kl; k <= ku; ++k)
+      for (int j = jl; j <= ju; ++j)
+        for (int i = il; i <= iu; ++i) fofc[ix4(N3,N2,N1,m,k,j,i)] = 0;
+  if (nfofc) *nfofc += nflag;
   return 0;
 }
 

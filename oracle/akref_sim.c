@@ -30,6 +30,8 @@ struct akref_sim {
   int nv;                          /* nhydro|nmhd: 5 ideal gas, 4 isothermal */
   int ncycle;
   int counters[3];
+  unsigned char *fofc;             /* Hydro::fofc, src/hydro/hydro.hpp:116 */
+  int nfofc;                       /* EventCounters::nfofc, src/mesh/mesh.hpp:71 */
   double gam0[4], gam1[4], beta[4], delta[4];
 };
 
@@ -88,6 +90,11 @@ akref_sim *akref_create(const akref_params *par) {
   const akref_params *p = &s->par;
   s->nb1 = p->nx1/p->mb_nx1; s->nb2 = p->nx2/p->mb_nx2; s->nb3 = p->nx3/p->mb_nx3;
   if (s->nb1*p->mb_nx1 != p->nx1 || s->nb2*p->mb_nx2 != p->nx2 || s->nb3*p->mb_nx3 != p->nx3) {
+    free(s); return NULL;
+  }
+  /* <hydro>/fofc: src/hydro/hydro.cpp:153-190 (ghost-zone checks); MHD FOFC is not restated */
+  if (p->fofc && (p->is_mhd || p->nscalars > 0 || (p->recon == AKMI_RECON_PLM && p->ng < 3) ||
+                  (p->recon >= AKMI_RECON_PPM4 && p->ng < 4))) {
     free(s); return NULL;
   }
   s->nmb = s->nb1*s->nb2*s->nb3;
@@ -164,6 +171,7 @@ akref_sim *akref_create(const akref_params *par) {
   s->nfl[0] = (size_t)nmb*nv*N3*N2*(N1+fs); s->nfl[1] = (size_t)nmb*nv*N3*(N2+fs)*N1;
   s->nfl[2] = (size_t)nmb*nv*(N3+fs)*N2*N1;
   s->flx1 = dalloc(s->nfl[0]); s->flx2 = dalloc(s->nfl[1]); s->flx3 = dalloc(s->nfl[2]);
+  if (p->fofc) s->fofc = (unsigned char *)calloc(s->ncc, 1);
   if (p->is_mhd) {
     s->bcc0 = dalloc(3*s->ncc);
     for (int q = 0; q < 3; ++q) { s->b0[q] = dalloc(s->nf[q]); s->b1[q] = dalloc(s->nf[q]); }
@@ -207,7 +215,7 @@ void akref_destroy(akref_sim *s) {
   if (!s) return;
   free(s->lloc); free(s->nghbr); free(s->bcs); free(s->dx); free(s->xmin);
   free(s->u0); free(s->w0); free(s->u1); free(s->flx1); free(s->flx2); free(s->flx3);
-  free(s->bcc0);
+  free(s->bcc0); free(s->fofc);
   for (int q = 0; q < 3; ++q) { free(s->b0[q]); free(s->b1[q]); free(s->e[q]); }
   for (int q = 0; q < 6; ++q) free(s->efc[q]);
   free(s);
@@ -784,7 +792,13 @@ int akref_step(akref_sim *s) {
       /* stagen chain, src/hydro/hydro_tasks.cpp:55-71 */
       if (stage == 1) akref_copy_cons(pk, s->u0, s->u1);
       else if (p->nstages == 4) akref_rk4_copy_cons(pk, s->delta[stage-1], s->u0, s->u1);
-      akref_hydro_fluxes(pk, p->recon, p->rsolver, s->w0, s->flx1, s->flx2, s->flx3, 0);
+      if (p->fofc) {              /* hydro_tasks.cpp:159-201 with use_fofc */
+        akref_hydro_fluxes_fofc(pk, p->recon, p->rsolver, s->w0, s->flx1, s->flx2, s->flx3, 0);
+        akref_hydro_fofc(pk, gam0, gam1, beta_dt, s->w0, s->u0, s->u1, s->flx1, s->flx2, s->flx3, 0,
+                         s->fofc, &s->nfofc);
+      } else {
+        akref_hydro_fluxes(pk, p->recon, p->rsolver, s->w0, s->flx1, s->flx2, s->flx3, 0);
+      }
       akref_rk_update(pk, gam0, gam1, beta_dt, s->u0, s->u1, s->flx1, s->flx2, s->flx3, 0);
     }
     halo_bcs_c2p(s);
@@ -807,6 +821,7 @@ double akref_dt(const akref_sim *s) { return s->dt; }
 double akref_tlim(const akref_sim *s) { return s->tlim; }
 int akref_ncycle(const akref_sim *s) { return s->ncycle; }
 int akref_nmb(const akref_sim *s) { return s->nmb; }
+int akref_nfofc(const akref_sim *s) { return s->nfofc; }
 void akref_pack(const akref_sim *s, akmi_pack *out) { *out = s->pack; }
 
 void *akref_array(akref_sim *s, const char *name, long long *count) {

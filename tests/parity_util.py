@@ -68,6 +68,11 @@ def oracle_kwargs(pin):
         kw.update(is_ideal=0, iso_cs=g(blk, "iso_sound_speed"))
     if pin.DoesParameterExist(blk, "nscalars"):
         kw["nscalars"] = gi(blk, "nscalars")
+    for fl in ("dfloor", "pfloor", "tfloor", "sfloor", "sigma_max"):
+        if pin.DoesParameterExist(blk, fl):
+            kw[fl] = g(blk, fl)
+    if pin.DoesParameterExist(blk, "fofc") and pin.GetBoolean(blk, "fofc"):
+        kw["fofc"] = 1
     name = gs("problem", "pgen_name")
     kw["pgen"] = name
     P = lambda k, d=0.0: (g("problem", k) if pin.DoesParameterExist("problem", k) else d)

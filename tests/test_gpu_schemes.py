@@ -99,6 +99,44 @@ def test_rk4_is_bit_identical(case, mode):
     assert res["bitwise_equal"], res["diffs"]
 
 
+# <hydro>/fofc: receding streams (see test_fofc_rescues_double_rarefaction) along x1/x2/x3 so that cells
+# are flagged next to MeshBlock faces in every direction; the last case floods the flags (density
+# floor above the ambient density) and the isothermal one takes the density-only test
+def _rare(d, v=4.0, *more):
+    # ul/ur are the velocities along shock_dir (shock_tube.cpp rotates the state)
+    return ("problem/shock_dir=%d" % d, "problem/ul=%r" % -v, "problem/ur=%r" % v, "problem/dr=1.0",
+            "problem/pl=0.4", "problem/pr=0.4", "hydro/fofc=true") + more
+
+
+FOFC = [
+    ("sod", 128, 1, 64, 40, dict(cfl=0.4, recon="ppm4", ng=4, rsolver="hllc", extra=_rare(1))),
+    ("sod", 128, 1, 32, 23, dict(cfl=0.4, recon="wenoz", ng=4, rsolver="hllc", integrator="rk3", extra=_rare(1))),
+    ("sod", 32, 2, 16, 25, dict(cfl=0.3, recon="ppm4", ng=4, rsolver="hllc", extra=_rare(2))),
+    ("sod", 32, 2, (32, 8), 22, dict(cfl=0.3, recon="wenoz", ng=4, rsolver="hllc", extra=_rare(1))),
+    ("sod", 24, 3, 12, 20, dict(cfl=0.3, recon="ppm4", ng=4, rsolver="hllc", extra=_rare(3))),
+    ("sod", 64, 1, 32, 12, dict(cfl=0.3, ng=3, rsolver="roe",
+                                extra=_rare(1, 8.0, "hydro/eos=isothermal", "hydro/iso_sound_speed=0.5",
+                                            "hydro/dfloor=0.05"))),
+]
+
+
+@pytest.mark.parametrize("native", [False, True], ids=["py", "cpp"])
+@pytest.mark.parametrize("case", FOFC, ids=lambda c: "%d^%d-%s-%s" % (c[1], c[2], c[5].get("recon", "plm"), c[5]["rsolver"]))
+def test_fofc_is_bit_identical(case, native):
+    """akmi_hydro_fluxes_fofc + akmi_hydro_fofc against the oracle, with cells actually flagged"""
+    problem, n, dims, mb, cycles, kw = case
+    if native and "hydro/eos=isothermal" in kw["extra"]:
+        pytest.skip("the C++ host runs the ideal-gas EOS only")
+    sim, osim, _ = pu.make_pair(problem, n, dims, mb, **kw)
+    for _ in range(cycles):
+        assert sim.Execute(max_cycles=1) and osim.step()
+    assert osim.nfofc > 0
+    if not native:
+        assert int(sim.phys.nfofc.item()) == osim.nfofc
+    d = pu.compare_fields(pu.product_arrays(sim), pu.oracle_arrays(osim, False), False)
+    assert sim.pmesh.time == osim.time and d["bitwise_equal"], d
+
+
 def _wild_states(shape5, rng, mhd):
     """primitive states with jumps of many decades between neighbouring cells: exercises the
     supersonic branches, the HLLE/HLLC pressure estimates, Roe's negative-density fallback and
