@@ -345,9 +345,19 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
   const size_t ncc = static_cast<size_t>(pp->nmb_thispack)*5*n3*n2*n1;
   u0.Realloc(ncc); w0.Realloc(ncc); u1.Realloc(ncc);
   counters.Realloc(3); dt3.Realloc(3);
+  use_fofc = pin->GetOrAddBoolean(blk, "fofc", false);     // hydro.cpp:153-190, mhd.cpp:199-235
+  if (use_fofc) {
+    const int need = recon_method == AKMI_RECON_PLM ? 3 : (recon_method >= AKMI_RECON_PPM4 ? 4 : 2);
+    if (ind.ng < need)
+      AKMI_FATAL("FOFC and this reconstruction require at least " + std::to_string(need) +
+                 " ghost zones, but <mesh>/nghost=" + std::to_string(ind.ng));
+    fused = false;                      // FOFC works on the flux arrays of the task-granular path
+    fofc.Realloc(static_cast<size_t>(pp->nmb_thispack)*n3*n2*n1);    // zero-filled
+    nfofc.Realloc(1);
+  }
 }
 FluidBase::~FluidBase() {
-  u0.Free(); w0.Free(); u1.Free(); counters.Free(); dt3.Free(); ws.Free();
+  u0.Free(); w0.Free(); u1.Free(); counters.Free(); dt3.Free(); ws.Free(); fofc.Free(); nfofc.Free();
   delete peos;
 }
 void FluidBase::FinishNewDt() {        // hydro_newdt.cpp:121-124
@@ -377,22 +387,10 @@ Hydro::Hydro(MeshBlockPack *pp, ParameterInput *pin) : FluidBase(pp, pin, "hydro
   const RegionIndcs &ind = pp->pmesh->mb_indcs;
   const size_t n1 = ind.nx1 + 2*ind.ng, n2 = ind.nx2 > 1 ? ind.nx2 + 2*ind.ng : 1,
                n3 = ind.nx3 > 1 ? ind.nx3 + 2*ind.ng : 1;
-  use_fofc = pin->GetOrAddBoolean("hydro", "fofc", false);        // hydro.cpp:153-190
-  if (use_fofc) {
-    const int need = recon_method == AKMI_RECON_PLM ? 3 : (recon_method >= AKMI_RECON_PPM4 ? 4 : 2);
-    if (ind.ng < need)
-      AKMI_FATAL("FOFC and this reconstruction require at least " + std::to_string(need) +
-                 " ghost zones, but <mesh>/nghost=" + std::to_string(ind.ng));
-    fused = false;                      // FOFC works on the flux arrays of the task-granular path
-    fofc.Realloc(static_cast<size_t>(pp->nmb_thispack)*n3*n2*n1);
-    nfofc.Realloc(1);
-    HIPCHK(hipMemset(fofc.p, 0, fofc.n));
-    HIPCHK(hipMemset(nfofc.p, 0, sizeof(int)));
-  }
   if (fused) ws.Realloc(static_cast<size_t>(akmi_stage_workspace_bytes(&pack_c, 0)));
   else FaceAlloc(uflx, pp->nmb_thispack, 5, n3, n2, n1, 0);      // hydro.cpp:290-292
 }
-Hydro::~Hydro() { FaceFree(uflx); fofc.Free(); nfofc.Free(); }
+Hydro::~Hydro() { FaceFree(uflx); }
 
 void Hydro::AssembleHydroTasks(std::map<std::string, std::shared_ptr<TaskList>> tl) {
   TaskID none(0);                                                  // hydro_tasks.cpp:48-80
@@ -632,10 +630,20 @@ TaskStatus MHD::CopyCons(Driver *d, int stage) {           // mhd_tasks.cpp:162-
   return TaskStatus::complete;
 }
 TaskStatus MHD::Fluxes(Driver *d, int stage) {             // mhd_tasks.cpp:177-216
-  if (!fused)
+  if (use_fofc) {                                           // mhd_tasks.cpp:209-211
+    AKCHK(akmi_mhd_fluxes_fofc(&pack_c, recon_method, rsolver_method, w0.p, bcc0.p, b0.x1f.p,
+                               b0.x2f.p, b0.x3f.p, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, e3x1.p,
+                               e2x1.p, e1x2.p, e3x2.p, e2x3.p, e1x3.p, stream));
+    AKCHK(akmi_mhd_fofc(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1],
+                        d->beta[stage - 1]*pmy_pack->pmesh->dt, w0.p, bcc0.p, b0.x1f.p, b0.x2f.p,
+                        b0.x3f.p, b1.x1f.p, b1.x2f.p, b1.x3f.p, u0.p, u1.p, uflx.x1f.p, uflx.x2f.p,
+                        uflx.x3f.p, e3x1.p, e2x1.p, e1x2.p, e3x2.p, e2x3.p, e1x3.p, fofc.p, nfofc.p,
+                        stream));
+  } else if (!fused) {
     AKCHK(akmi_mhd_fluxes(&pack_c, recon_method, rsolver_method, w0.p, bcc0.p, b0.x1f.p, b0.x2f.p,
                           b0.x3f.p, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, e3x1.p, e2x1.p, e1x2.p,
                           e3x2.p, e2x3.p, e1x3.p, stream));
+  }
   return TaskStatus::complete;
 }
 TaskStatus MHD::RKUpdate(Driver *d, int stage) {           // mhd_update.cpp:24-84

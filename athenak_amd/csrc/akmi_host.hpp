@@ -194,6 +194,9 @@ class FluidBase {
   DvceArray<int> counters;
   DvceArray<Real> dt3;
   DvceArray<char> ws;
+  bool use_fofc = false;                // hydro.hpp:116-117, mhd.hpp
+  DvceArray<unsigned char> fofc;
+  DvceArray<int> nfofc;                 // EventCounters::nfofc (mesh.hpp:71), kept on the device
   Real dtnew = static_cast<Real>(FLT_MAX);
   hipStream_t stream = nullptr;
  protected:
@@ -207,9 +210,6 @@ class Hydro : public FluidBase {    // hydro.hpp:73-154
   Hydro(MeshBlockPack *pp, ParameterInput *pin);
   ~Hydro() override;
   DvceFaceFld uflx;
-  bool use_fofc = false;                // hydro.hpp:116-117
-  DvceArray<unsigned char> fofc;
-  DvceArray<int> nfofc;                 // EventCounters::nfofc (mesh.hpp:71), kept on the device
   void AssembleHydroTasks(std::map<std::string, std::shared_ptr<TaskList>> tl);
   TaskStatus InitRecv(Driver *d, int stage) { return TaskStatus::complete; }
   TaskStatus CopyCons(Driver *d, int stage);

@@ -373,20 +373,21 @@ k_mhd_flux(Geo g, FaceEos eos, const double *__restrict__ w0, const double *__re
 template <int DIR>
 static int launch_mhd_flux(const Geo &g, const Scheme &sc, const double *w0,
                            const double *bcc0, const double *bxf, double *flx, double *ey,
-                           double *ez, hipStream_t st) {
+                           double *ez, hipStream_t st, int ext = 0) {
+  // ext = 1: <mhd>/fofc, face-normal range one face wider on both sides (mhd_fluxes.cpp:100-105)
   int il, iu, jl, ju, kl, ku;
   int f3 = g.N3, f2 = g.N2, f1 = g.N1;
   if (DIR == 0) {
-    il = g.is; iu = g.ie + 1; jl = g.js; ju = g.je; kl = g.ks; ku = g.ke;
+    il = g.is - ext; iu = g.ie + 1 + ext; jl = g.js; ju = g.je; kl = g.ks; ku = g.ke;
     if (g.multi_d) { jl = g.js - 1; ju = g.je + 1; }
     if (g.three_d) { kl = g.ks - 1; ku = g.ke + 1; }
     f1 += 1;
   } else if (DIR == 1) {
-    il = g.is - 1; iu = g.ie + 1; jl = g.js; ju = g.je + 1; kl = g.ks; ku = g.ke;
+    il = g.is - 1; iu = g.ie + 1; jl = g.js - ext; ju = g.je + 1 + ext; kl = g.ks; ku = g.ke;
     if (g.three_d) { kl = g.ks - 1; ku = g.ke + 1; }
     f2 += 1;
   } else {
-    il = g.is - 1; iu = g.ie + 1; jl = g.js - 1; ju = g.je + 1; kl = g.ks; ku = g.ke + 1;
+    il = g.is - 1; iu = g.ie + 1; jl = g.js - 1; ju = g.je + 1; kl = g.ks - ext; ku = g.ke + 1 + ext;
     f3 += 1;
   }
   int nk = ku - kl + 1;
@@ -656,6 +657,102 @@ k_fofc_fix_hyd(Geo g, Eos eos, const double *__restrict__ w0, double *__restrict
   }
 }
 
+// MHD::FOFC (mhd_fofc.cpp:30-493), ideal gas
+struct FofcMhd {
+  const double *w0, *bcc0, *b0[3], *b1[3], *u0, *u1;
+  double *flx[3], *ey[3], *ez[3];      // per direction: flux, (e3x1,e1x2,e2x3), (e2x1,e3x2,e1x3)
+};
+
+__global__ void __launch_bounds__(BX*BY)
+k_fofc_flag_mhd(Geo g, Eos eos, double gam0, double gam1, double beta_dt, FofcMhd a, int il, int iu,
+                int jl, int ju, int kl, int nk, unsigned char *__restrict__ fofc,
+                int *__restrict__ nfofc) {
+  const int i = il + blockIdx.x*BX + threadIdx.x;
+  const int j = jl + blockIdx.y*BY + threadIdx.y;
+  const int m = blockIdx.z/nk;
+  const int k = kl + (blockIdx.z - m*nk);
+  if (i > iu || j > ju) return;
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  const double dtodx1 = beta_dt/g.dx[3*m], dtodx2 = beta_dt/g.dx[3*m + 1];
+  const double dtodx3 = beta_dt/g.dx[3*m + 2];
+  double ut[5];
+  for (int n = 0; n < 5; ++n) {
+    double divf = dtodx1*(a.flx[0][ix5(5, N3, N2, N1 + 1, m, n, k, j, i + 1)] -
+                          a.flx[0][ix5(5, N3, N2, N1 + 1, m, n, k, j, i)]);
+    if (g.multi_d)
+      divf += dtodx2*(a.flx[1][ix5(5, N3, N2 + 1, N1, m, n, k, j + 1, i)] -
+                      a.flx[1][ix5(5, N3, N2 + 1, N1, m, n, k, j, i)]);
+    if (g.three_d)
+      divf += dtodx3*(a.flx[2][ix5(5, N3 + 1, N2, N1, m, n, k + 1, j, i)] -
+                      a.flx[2][ix5(5, N3 + 1, N2, N1, m, n, k, j, i)]);
+    const size_t c = ix5(5, N3, N2, N1, m, n, k, j, i);
+    ut[n] = gam0*a.u0[c] + gam1*a.u1[c] - divf;
+  }
+  // trial cell-centred field, mhd_fofc.cpp:88-107
+  const double b1old = 0.5*(a.b1[0][ix4(N3, N2, N1 + 1, m, k, j, i)] + a.b1[0][ix4(N3, N2, N1 + 1, m, k, j, i + 1)]);
+  const double b2old = 0.5*(a.b1[1][ix4(N3, N2 + 1, N1, m, k, j, i)] + a.b1[1][ix4(N3, N2 + 1, N1, m, k, j + 1, i)]);
+  const double b3old = 0.5*(a.b1[2][ix4(N3 + 1, N2, N1, m, k, j, i)] + a.b1[2][ix4(N3 + 1, N2, N1, m, k + 1, j, i)]);
+  const size_t cs = (size_t)N3*N2*N1;
+  const size_t bc = ix5(3, N3, N2, N1, m, 0, k, j, i);
+  double bx = gam0*a.bcc0[bc] + gam1*b1old;
+  double by = gam0*a.bcc0[bc + cs] + gam1*b2old;
+  double bz = gam0*a.bcc0[bc + 2*cs] + gam1*b3old;
+  const size_t e = ix4(N3, N2, N1, m, k, j, i);
+  by += dtodx1*(a.ey[0][e + 1] - a.ey[0][e]);              // e3x1
+  bz -= dtodx1*(a.ez[0][e + 1] - a.ez[0][e]);              // e2x1
+  if (g.multi_d) {
+    bx -= dtodx2*(a.ez[1][e + N1] - a.ez[1][e]);           // e3x2
+    bz += dtodx2*(a.ey[1][e + N1] - a.ey[1][e]);           // e1x2
+  }
+  if (g.three_d) {
+    bx += dtodx3*(a.ey[2][e + (size_t)N2*N1] - a.ey[2][e]);   // e2x3
+    by -= dtodx3*(a.ez[2][e + (size_t)N2*N1] - a.ez[2][e]);   // e1x3
+  }
+  double wd, wvx, wvy, wvz, we;
+  bool dfl = false, efl = false, tfl = false;
+  c2p_mhd(eos, ut[0], ut[1], ut[2], ut[3], ut[4], bx, by, bz, wd, wvx, wvy, wvz, we, dfl, efl, tfl);
+  if (dfl || efl || tfl) {
+    fofc[e] = 1;
+    atomicAdd(nfofc, 1);
+  }
+}
+
+__global__ void __launch_bounds__(BX*BY)
+k_fofc_fix_mhd(Geo g, Eos eos, FofcMhd a, int il, int iu, int jl, int ju, int kl, int nk,
+               const unsigned char *__restrict__ fofc) {
+  const int i = il + blockIdx.x*BX + threadIdx.x;
+  const int j = jl + blockIdx.y*BY + threadIdx.y;
+  const int m = blockIdx.z/nk;
+  const int k = kl + (blockIdx.z - m*nk);
+  if (i > iu || j > ju) return;
+  if (!fofc[ix4(g.N3, g.N2, g.N1, m, k, j, i)]) return;
+  const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  const int ndir = g.three_d ? 3 : (g.multi_d ? 2 : 1);
+  for (int dir = 0; dir < ndir; ++dir) {
+    const int ivx = 1 + dir, ivy = 1 + (dir + 1)%3, ivz = 1 + (dir + 2)%3;
+    const int iby = (dir + 1)%3, ibz = (dir + 2)%3;
+    const int d1 = dir == 0, d2 = dir == 1, d3 = dir == 2;
+    const int f1 = g.N1 + d1, f2 = g.N2 + d2, f3 = g.N3 + d3;
+    const size_t fs = (size_t)f3*f2*f1;
+    for (int side = 0; side < 2; ++side) {
+      const int kf = k + side*d3, jf = j + side*d2, ic = i + side*d1;
+      const double *ql = a.w0 + ix5(5, g.N3, g.N2, g.N1, m, 0, kf - d3, jf - d2, ic - d1);
+      const double *qr = a.w0 + ix5(5, g.N3, g.N2, g.N1, m, 0, kf, jf, ic);
+      const double *bl = a.bcc0 + ix5(3, g.N3, g.N2, g.N1, m, 0, kf - d3, jf - d2, ic - d1);
+      const double *br = a.bcc0 + ix5(3, g.N3, g.N2, g.N1, m, 0, kf, jf, ic);
+      const double bxi = a.b0[dir][ix4(f3, f2, f1, m, kf, jf, ic)];
+      const Cons1D fl = llf_mhd(eos.gamma, ql[0], ql[ivx*cs], ql[ivy*cs], ql[ivz*cs], ql[4*cs],
+                                bl[iby*cs], bl[ibz*cs], qr[0], qr[ivx*cs], qr[ivy*cs], qr[ivz*cs],
+                                qr[4*cs], br[iby*cs], br[ibz*cs], bxi);
+      double *f = a.flx[dir] + ix5(5, f3, f2, f1, m, 0, kf, jf, ic);
+      f[0] = fl.d; f[ivx*fs] = fl.mx; f[ivy*fs] = fl.my; f[ivz*fs] = fl.mz; f[4*fs] = fl.e;
+      const size_t ec = ix4(g.N3, g.N2, g.N1, m, kf, jf, ic);
+      a.ey[dir][ec] = -fl.by;            // SingleStateLLF_MHD returns flux.by already negated (:83)
+      a.ez[dir][ec] = fl.bz;
+    }
+  }
+}
+
 // Hydro::CopyCons for rk4 (hydro_tasks.cpp:134-148): u1 += delta*u0, active cells
 __global__ void __launch_bounds__(256)
 k_rk4_register(Geo g, double delta, const double *__restrict__ u0, double *__restrict__ u1) {
@@ -691,20 +788,12 @@ int akmi_rk4_copy_cons(const akmi_pack *p, double delta, const double *u0, doubl
   return AKMI_COMPLETE;
 }
 
+static int fofc_checks(const akmi_pack *p, int recon, const char *what, bool ideal_only);
+
 static int hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0, double *flx1,
                         double *flx2, double *flx3, int face_shaped, void *stream, int ext) {
   if (check_scheme(p, recon, "hydro_fluxes") != AKMI_COMPLETE) return AKMI_FAIL;
-  if (ext) {                      // src/hydro/hydro.cpp:153-190
-    if (p->nvar != (p->is_ideal ? 5 : 4)) {
-      set_error("hydro_fluxes_fofc: FOFC with passive scalars is not on this path"); return AKMI_FAIL;
-    }
-    const int need = recon == AKMI_RECON_PLM ? 3 : (recon >= AKMI_RECON_PPM4 ? 4 : 2);
-    if (p->ng < need) {
-      set_error("hydro_fluxes_fofc: FOFC and this reconstruction require at least %d ghost zones, "
-                "but nghost=%d", need, p->ng);
-      return AKMI_FAIL;
-    }
-  }
+  if (ext && fofc_checks(p, recon, "hydro_fluxes_fofc", false) != AKMI_COMPLETE) return AKMI_FAIL;
   if (!p->is_ideal && rsolver == AKMI_RS_HLLC) {
     set_error("hydro_fluxes: rsolver = hllc needs the ideal-gas EOS"); return AKMI_FAIL;
   }
@@ -810,21 +899,82 @@ int akmi_mhd_newdt(const akmi_pack *p, const double *w0, const double *bcc0, dou
   return AKMI_COMPLETE;
 }
 
+static int fofc_checks(const akmi_pack *p, int recon, const char *what, bool ideal_only) {
+  if (p->nvar != (p->is_ideal ? 5 : 4) || (ideal_only && !p->is_ideal)) {
+    set_error("%s: FOFC with passive scalars%s is not on this path", what,
+              ideal_only ? " or the isothermal EOS" : "");
+    return AKMI_FAIL;
+  }
+  const int need = recon == AKMI_RECON_PLM ? 3 : (recon >= AKMI_RECON_PPM4 ? 4 : 2);
+  if (p->ng < need) {              // src/hydro/hydro.cpp:163-190, src/mhd/mhd.cpp:211-235
+    set_error("%s: FOFC and this reconstruction require at least %d ghost zones, but nghost=%d",
+              what, need, p->ng);
+    return AKMI_FAIL;
+  }
+  return AKMI_COMPLETE;
+}
+
+static int mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                      const double *bcc0, const double *bx1f, const double *bx2f,
+                      const double *bx3f, double *flx1, double *flx2, double *flx3, double *e3x1,
+                      double *e2x1, double *e1x2, double *e3x2, double *e2x3, double *e1x3,
+                      void *stream, int ext) {
+  if (check_scheme(p, recon, "mhd_fluxes") != AKMI_COMPLETE) return AKMI_FAIL;
+  if (ext && fofc_checks(p, recon, "mhd_fluxes_fofc", true) != AKMI_COMPLETE) return AKMI_FAIL;
+  Geo g = make_geo(p);
+  const Scheme sc{recon, rsolver, make_face_eos(p), !p->is_ideal};
+  hipStream_t st = (hipStream_t)stream;
+  int rc = launch_mhd_flux<0>(g, sc, w0, bcc0, bx1f, flx1, e3x1, e2x1, st, ext);
+  if (rc == AKMI_COMPLETE && g.multi_d)
+    rc = launch_mhd_flux<1>(g, sc, w0, bcc0, bx2f, flx2, e1x2, e3x2, st, ext);
+  if (rc == AKMI_COMPLETE && g.three_d)
+    rc = launch_mhd_flux<2>(g, sc, w0, bcc0, bx3f, flx3, e2x3, e1x3, st, ext);
+  return rc;
+}
+
 int akmi_mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
                     const double *bcc0, const double *bx1f, const double *bx2f,
                     const double *bx3f, double *flx1, double *flx2, double *flx3, double *e3x1,
                     double *e2x1, double *e1x2, double *e3x2, double *e2x3, double *e1x3,
                     void *stream) {
-  if (check_scheme(p, recon, "mhd_fluxes") != AKMI_COMPLETE) return AKMI_FAIL;
+  return mhd_fluxes(p, recon, rsolver, w0, bcc0, bx1f, bx2f, bx3f, flx1, flx2, flx3, e3x1, e2x1,
+                    e1x2, e3x2, e2x3, e1x3, stream, 0);
+}
+
+int akmi_mhd_fluxes_fofc(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                         const double *bcc0, const double *bx1f, const double *bx2f,
+                         const double *bx3f, double *flx1, double *flx2, double *flx3, double *e3x1,
+                         double *e2x1, double *e1x2, double *e3x2, double *e2x3, double *e1x3,
+                         void *stream) {
+  return mhd_fluxes(p, recon, rsolver, w0, bcc0, bx1f, bx2f, bx3f, flx1, flx2, flx3, e3x1, e2x1,
+                    e1x2, e3x2, e2x3, e1x3, stream, 1);
+}
+
+int akmi_mhd_fofc(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *w0,
+                  const double *bcc0, const double *b0x1f, const double *b0x2f, const double *b0x3f,
+                  const double *b1x1f, const double *b1x2f, const double *b1x3f, const double *u0,
+                  const double *u1, double *flx1, double *flx2, double *flx3, double *e3x1,
+                  double *e2x1, double *e1x2, double *e3x2, double *e2x3, double *e1x3,
+                  unsigned char *fofc, int *nfofc, void *stream) {
+  if (!p->is_ideal || p->nvar != 5) {
+    set_error("mhd_fofc: ideal gas without passive scalars only"); return AKMI_FAIL;
+  }
   Geo g = make_geo(p);
-  const Scheme sc{recon, rsolver, make_face_eos(p), !p->is_ideal};
   hipStream_t st = (hipStream_t)stream;
-  int rc = launch_mhd_flux<0>(g, sc, w0, bcc0, bx1f, flx1, e3x1, e2x1, st);
-  if (rc == AKMI_COMPLETE && g.multi_d)
-    rc = launch_mhd_flux<1>(g, sc, w0, bcc0, bx2f, flx2, e1x2, e3x2, st);
-  if (rc == AKMI_COMPLETE && g.three_d)
-    rc = launch_mhd_flux<2>(g, sc, w0, bcc0, bx3f, flx3, e2x3, e1x3, st);
-  return rc;
+  const int il = g.is - 1, iu = g.ie + 1;
+  const int jl = g.multi_d ? g.js - 1 : g.js, ju = g.multi_d ? g.je + 1 : g.je;
+  const int kl = g.three_d ? g.ks - 1 : g.ks, ku = g.three_d ? g.ke + 1 : g.ke;
+  const int nk = ku - kl + 1;
+  dim3 grid(cdiv(iu - il + 1, BX), cdiv(ju - jl + 1, BY), nk*g.nmb), block(BX, BY);
+  FofcMhd a{w0, bcc0, {b0x1f, b0x2f, b0x3f}, {b1x1f, b1x2f, b1x3f}, u0, u1, {flx1, flx2, flx3},
+            {e3x1, e1x2, e2x3}, {e2x1, e3x2, e1x3}};
+  k_fofc_flag_mhd<<<grid, block, 0, st>>>(g, make_eos(p), gam0, gam1, beta_dt, a, il, iu, jl, ju, kl,
+                                          nk, fofc, nfofc);
+  k_fofc_fix_mhd<<<grid, block, 0, st>>>(g, make_eos(p), a, il, iu, jl, ju, kl, nk, fofc);
+  AKMI_CHECK_LAUNCH("mhd_fofc");
+  hipError_t e = hipMemsetAsync(fofc, 0, (size_t)g.nmb*g.N3*g.N2*g.N1, st);   // mhd_fofc.cpp:487-489
+  if (e != hipSuccess) { set_error("mhd_fofc: %s", hipGetErrorString(e)); return AKMI_FAIL; }
+  return AKMI_COMPLETE;
 }
 
 int akmi_history_sums(const akmi_pack *p, int is_mhd, const double *u0, const double *bx1f,

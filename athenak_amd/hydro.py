@@ -97,6 +97,20 @@ class FluidBase:
             # the fused stage kernels are specialised for the ideal-gas variable set; isothermal
             # runs and runs with passive scalars use the task-granular kernels (one kernel per task)
             self.fused = False
+        # first-order flux correction, hydro.cpp:153-190 / mhd.cpp:199-235
+        self.use_fofc = pin.GetOrAddBoolean(blk, "fofc", False)
+        if self.use_fofc:
+            need = 3 if recon == "plm" else (4 if recon in ("ppm4", "ppmx", "wenoz", "teno") else 2)
+            if indcs.ng < need:
+                raise RuntimeError("### FATAL ERROR FOFC and %s reconstruction requires at least %d "
+                                   "ghost zones, but <mesh>/nghost=%d" % (recon, need, indcs.ng))
+            if self.nscalars > 0 or (blk == "mhd" and not e.is_ideal):
+                raise RuntimeError("### FATAL ERROR <%s>/fofc with passive scalars%s is not on "
+                                   "this path" % (blk, " or the isothermal EOS" if blk == "mhd" else ""))
+            self.fused = False       # FOFC works on the flux arrays of the task-granular path
+            n3, n2, n1 = indcs.ncells
+            self.fofc = torch.zeros((self.nmb, n3, n2, n1), dtype=torch.uint8, device=device)
+            self.nfofc = torch.zeros(1, dtype=torch.int32, device=device)   # EventCounters::nfofc
         self.counters = torch.zeros(3, dtype=torch.int32, device=device)
         self.dt3 = torch.zeros(3, dtype=torch.float64, device=device)
         self.dtnew = FLT_MAX
@@ -130,19 +144,6 @@ class Hydro(FluidBase):
                                "(llf, hlle, hllc, roe on this path)" % rs)
         self.rsolver_method = capi.RSOLVER[rs]
         self.nhydro = self.nfluid
-        # first-order flux correction, hydro.cpp:153-190
-        self.use_fofc = pin.GetOrAddBoolean("hydro", "fofc", False)
-        if self.use_fofc:
-            ng = ppack.pmesh.mb_indcs.ng
-            recon = pin.GetString("hydro", "reconstruct")
-            need = 3 if recon == "plm" else (4 if recon in ("ppm4", "ppmx", "wenoz", "teno") else 2)
-            if ng < need:
-                raise RuntimeError("### FATAL ERROR FOFC and %s reconstruction requires at least %d "
-                                   "ghost zones, but <mesh>/nghost=%d" % (recon, need, ng))
-            if self.nscalars > 0:
-                raise RuntimeError("### FATAL ERROR <hydro>/fofc with passive scalars is not on "
-                                   "this path")
-            self.fused = False       # FOFC works on the flux arrays of the task-granular path
         n3, n2, n1 = ppack.pmesh.mb_indcs.ncells
         sh = (self.nmb, self.nvars, n3, n2, n1)
         z = lambda: torch.zeros(sh, dtype=torch.float64, device=device)
@@ -151,9 +152,6 @@ class Hydro(FluidBase):
         self.uflx = None if self.fused else FaceFld(self.nmb, self.nvars, n3, n2, n1, device, face_shaped=False)
         self.pbval_u = MeshBoundaryValues(ppack, bvals_kernels, device)
         self.pbval_u.set_pack(self.pack_c, self.nvars)
-        if self.use_fofc:
-            self.fofc = torch.zeros((self.nmb, n3, n2, n1), dtype=torch.uint8, device=device)
-            self.nfofc = torch.zeros(1, dtype=torch.int32, device=device)   # EventCounters::nfofc
 
     # ---- task list assembly: hydro_tasks.cpp:48-80 ---------------------------------
     def AssembleHydroTasks(self, tl):

@@ -95,11 +95,19 @@ class MHD(FluidBase):
     def Fluxes(self, pdrive, stage):
         """mhd_tasks.cpp:177-216"""
         if not self.fused:
-            capi.check(self.L.akmi_mhd_fluxes(
-                C.byref(self.pack_c), self.recon_method, self.rsolver_method, capi._p(self.w0),
-                capi._p(self.bcc0), *self._b(self.b0), *self._b(self.uflx), capi._p(self.e3x1),
-                capi._p(self.e2x1), capi._p(self.e1x2), capi._p(self.e3x2), capi._p(self.e2x3),
-                capi._p(self.e1x3), capi._stream()), "mhd_fluxes")
+            efc = [capi._p(x) for x in (self.e3x1, self.e2x1, self.e1x2, self.e3x2, self.e2x3, self.e1x3)]
+            fn = self.L.akmi_mhd_fluxes_fofc if self.use_fofc else self.L.akmi_mhd_fluxes
+            capi.check(fn(C.byref(self.pack_c), self.recon_method, self.rsolver_method,
+                          capi._p(self.w0), capi._p(self.bcc0), *self._b(self.b0), *self._b(self.uflx),
+                          *efc, capi._stream()), "mhd_fluxes")
+            if self.use_fofc:                    # mhd_tasks.cpp:209-211 -> MHD::FOFC
+                capi.check(self.L.akmi_mhd_fofc(
+                    C.byref(self.pack_c), C.c_double(pdrive.gam0[stage - 1]),
+                    C.c_double(pdrive.gam1[stage - 1]),
+                    C.c_double(pdrive.beta[stage - 1]*self.pmy_pack.pmesh.dt), capi._p(self.w0),
+                    capi._p(self.bcc0), *self._b(self.b0), *self._b(self.b1), capi._p(self.u0),
+                    capi._p(self.u1), *self._b(self.uflx), *efc, capi._p(self.fofc),
+                    capi._p(self.nfofc), capi._stream()), "mhd_fofc")
         return TaskStatus.complete
 
     def RKUpdate(self, pdrive, stage):

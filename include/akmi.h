@@ -83,6 +83,22 @@ int akmi_hydro_fluxes_fofc(const akmi_pack *p, int recon, int rsolver, const dou
 int akmi_hydro_fofc(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *w0,
                     const double *u0, const double *u1, double *flx1, double *flx2, double *flx3,
                     int face_shaped, unsigned char *fofc, int *nfofc, void *stream);
+/* MHD::Fluxes with <mhd>/fofc = true (src/mhd/mhd_fluxes.cpp:100-105): face-normal ranges extended
+ * by one face on both sides (ideal gas, no scalars) */
+int akmi_mhd_fluxes_fofc(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                         const double *bcc0, const double *bx1f, const double *bx2f,
+                         const double *bx3f, double *flx1, double *flx2, double *flx3, double *e3x1,
+                         double *e2x1, double *e1x2, double *e3x2, double *e2x3, double *e1x3,
+                         void *stream);
+/* MHD::FOFC (src/mhd/mhd_fofc.cpp:30-493, Newtonian ideal gas): as akmi_hydro_fofc, with the trial
+ * cell-centred field bcctest = gam0*bcc0 + gam1*avg(b1) -/+ dt/dx * d(face EMFs) (:88-107) in the
+ * floor test, and the face EMFs of flagged cells replaced together with the fluxes. */
+int akmi_mhd_fofc(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *w0,
+                  const double *bcc0, const double *b0x1f, const double *b0x2f, const double *b0x3f,
+                  const double *b1x1f, const double *b1x2f, const double *b1x3f, const double *u0,
+                  const double *u1, double *flx1, double *flx2, double *flx3, double *e3x1,
+                  double *e2x1, double *e1x2, double *e3x2, double *e2x3, double *e1x3,
+                  unsigned char *fofc, int *nfofc, void *stream);
 /* Hydro::CopyCons, stages 2..4 of integrator rk4 (src/hydro/hydro_tasks.cpp:134-148): the second
  * register of the 2S scheme, u1 += delta*u0 on the active cells */
 int akmi_rk4_copy_cons(const akmi_pack *p, double delta, const double *u0, double *u1, void *stream);

@@ -36,6 +36,17 @@ int akref_hydro_fluxes_fofc(const akmi_pack *p, int recon, int rsolver, const do
 int akref_hydro_fofc(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *w0,
                      const double *u0, const double *u1, double *flx1, double *flx2, double *flx3,
                      int face_shaped, unsigned char *fofc, int *nfofc);
+int akref_mhd_fluxes_fofc(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                          const double *bcc0, const double *bx1f, const double *bx2f,
+                          const double *bx3f, double *flx1, double *flx2, double *flx3,
+                          double *e3x1, double *e2x1, double *e1x2, double *e3x2, double *e2x3,
+                          double *e1x3);
+int akref_mhd_fofc(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *w0,
+                   const double *bcc0, const double *b0x1f, const double *b0x2f, const double *b0x3f,
+                   const double *b1x1f, const double *b1x2f, const double *b1x3f, const double *u0,
+                   const double *u1, double *flx1, double *flx2, double *flx3, double *e3x1,
+                   double *e2x1, double *e1x2, double *e3x2, double *e2x3, double *e1x3,
+                   unsigned char *fofc, int *nfofc);
 int akref_rk4_copy_cons(const akmi_pack *p, double delta, const double *u0, double *u1);
 int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
                        double *flx1, double *flx2, double *flx3, int face_shaped);

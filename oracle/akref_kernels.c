@@ -1467,11 +1467,11 @@ int akref_hydro_newdt(const akmi_pack *p, const double *w0, double *dt3) {
 }
 
 /* MHD::CalculateFluxes<hlld>, src/mhd/mhd_fluxes.cpp:84-266 */
-int akref_mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
+static int mhd_fluxes_impl(const akmi_pack *p, int recon, int rsolver, const double *w0,
                      const double *bcc0, const double *bx1f, const double *bx2f,
                      const double *bx3f, double *flx1, double *flx2, double *flx3,
                      double *e3x1, double *e2x1, double *e1x2, double *e3x2, double *e2x3,
-                     double *e1x3) {
+                     double *e1x3, int ext) {
   if (rsolver != AKMI_RS_LLF && rsolver != AKMI_RS_HLLE && rsolver != AKMI_RS_HLLD) return AKMI_FAIL;
   const int ideal = p->is_ideal;
   G g = mkG(p);
@@ -1490,21 +1490,22 @@ int akref_mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w
       jl = g.js; ju = g.je; kl = g.ks; ku = g.ke;
       if (g.multi_d) { jl = g.js-1; ju = g.je+1; }
       if (g.three_d) { kl = g.ks-1; ku = g.ke+1; }
-      recon_dir(&g, p, 1, recon, 0, nv, w0, wl, wr, kl, ku, jl, ju, g.is-1, g.ie+1);
-      recon_dir(&g, p, 0, recon, 0, 3, bcc0, bl, br, kl, ku, jl, ju, g.is-1, g.ie+1);
-      il = g.is; iu = g.ie+1;
+      /* ext: face-normal range [is-1,ie+2] with <mhd>/fofc = true, src/mhd/mhd_fluxes.cpp:100-105 */
+      recon_dir(&g, p, 1, recon, 0, nv, w0, wl, wr, kl, ku, jl, ju, g.is-1-ext, g.ie+1+ext);
+      recon_dir(&g, p, 0, recon, 0, 3, bcc0, bl, br, kl, ku, jl, ju, g.is-1-ext, g.ie+1+ext);
+      il = g.is-ext; iu = g.ie+1+ext;
       bx = bx1f; flx = flx1; ey = e3x1; ez = e2x1; f1 = N1+1;
     } else if (dir == 1) {
       kl = g.ks; ku = g.ke;
       if (g.three_d) { kl = g.ks-1; ku = g.ke+1; }
-      recon_dir(&g, p, 1, recon, 1, nv, w0, wl, wr, kl, ku, g.js-1, g.je+1, g.is-1, g.ie+1);
-      recon_dir(&g, p, 0, recon, 1, 3, bcc0, bl, br, kl, ku, g.js-1, g.je+1, g.is-1, g.ie+1);
-      il = g.is-1; iu = g.ie+1; jl = g.js; ju = g.je+1;
+      recon_dir(&g, p, 1, recon, 1, nv, w0, wl, wr, kl, ku, g.js-1-ext, g.je+1+ext, g.is-1, g.ie+1);
+      recon_dir(&g, p, 0, recon, 1, 3, bcc0, bl, br, kl, ku, g.js-1-ext, g.je+1+ext, g.is-1, g.ie+1);
+      il = g.is-1; iu = g.ie+1; jl = g.js-ext; ju = g.je+1+ext;
       bx = bx2f; flx = flx2; ey = e1x2; ez = e3x2; f2 = N2+1;
     } else {
-      recon_dir(&g, p, 1, recon, 2, nv, w0, wl, wr, g.ks-1, g.ke+1, g.js-1, g.je+1, g.is-1, g.ie+1);
-      recon_dir(&g, p, 0, recon, 2, 3, bcc0, bl, br, g.ks-1, g.ke+1, g.js-1, g.je+1, g.is-1, g.ie+1);
-      il = g.is-1; iu = g.ie+1; jl = g.js-1; ju = g.je+1; kl = g.ks; ku = g.ke+1;
+      recon_dir(&g, p, 1, recon, 2, nv, w0, wl, wr, g.ks-1-ext, g.ke+1+ext, g.js-1, g.je+1, g.is-1, g.ie+1);
+      recon_dir(&g, p, 0, recon, 2, 3, bcc0, bl, br, g.ks-1-ext, g.ke+1+ext, g.js-1, g.je+1, g.is-1, g.ie+1);
+      il = g.is-1; iu = g.ie+1; jl = g.js-1; ju = g.je+1; kl = g.ks-ext; ku = g.ke+1+ext;
       bx = bx3f; flx = flx3; ey = e2x3; ez = e1x3; f3 = N3+1;
     }
     const int ivx = IVX + dir, ivy = IVX + (dir + 1)%3, ivz = IVX + (dir + 2)%3;
@@ -1550,6 +1551,132 @@ int akref_mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w
             }
     }
   }
+  return 0;
+}
+
+int akref_mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                     const double *bcc0, const double *bx1f, const double *bx2f,
+                     const double *bx3f, double *flx1, double *flx2, double *flx3,
+                     double *e3x1, double *e2x1, double *e1x2, double *e3x2, double *e2x3,
+                     double *e1x3) {
+  return mhd_fluxes_impl(p, recon, rsolver, w0, bcc0, bx1f, bx2f, bx3f, flx1, flx2, flx3, e3x1, e2x1,
+                         e1x2, e3x2, e2x3, e1x3, 0);
+}
+
+int akref_mhd_fluxes_fofc(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                          const double *bcc0, const double *bx1f, const double *bx2f,
+                          const double *bx3f, double *flx1, double *flx2, double *flx3,
+                          double *e3x1, double *e2x1, double *e1x2, double *e3x2, double *e2x3,
+                          double *e1x3) {
+  if (!p->is_ideal || p->nvar != 5) return AKMI_FAIL;     /* ideal gas, no scalars on this path */
+  return mhd_fluxes_impl(p, recon, rsolver, w0, bcc0, bx1f, bx2f, bx3f, flx1, flx2, flx3, e3x1, e2x1,
+                         e1x2, e3x2, e2x3, e1x3, 1);
+}
+
+/* MHD::FOFC, src/mhd/mhd_fofc.cpp:30-493 (Newtonian ideal gas): trial update of U and of the
+ * cell-centred field (from the face EMFs), floor test with the trial field
+ * (IdealMHD::ConsToPrim only_testfloors, src/eos/ideal_mhd.cpp:66-96), first-order LLF fluxes AND
+ * face EMFs (SingleStateLLF_MHD, src/mhd/rsolvers/llf_mhd_singlestate.hpp:27-89) on the faces
+ * of flagged cells, flags reset. */
+int akref_mhd_fofc(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *w0,
+                   const double *bcc0, const double *b0x1f, const double *b0x2f, const double *b0x3f,
+                   const double *b1x1f, const double *b1x2f, const double *b1x3f, const double *u0,
+                   const double *u1, double *flx1, double *flx2, double *flx3, double *e3x1,
+                   double *e2x1, double *e1x2, double *e3x2, double *e2x3, double *e1x3,
+                   unsigned char *fofc, int *nfofc) {
+  G g = mkG(p);
+  const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  if (!p->is_ideal || nv != 5) return AKMI_FAIL;
+  int il = g.is-1, iu = g.ie+1, jl = g.js, ju = g.je, kl = g.ks, ku = g.ke;
+  if (g.multi_d) { jl = g.js-1; ju = g.je+1; }
+  if (g.three_d) { kl = g.ks-1; ku = g.ke+1; }
+  const double gm1 = p->gamma - 1.0;
+  const double efloor = p->pfloor/gm1;
+  int nflag = 0;
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = kl; k <= ku; ++k)
+      for (int j = jl; j <= ju; ++j)
+        for (int i = il; i <= iu; ++i) {
+          double dtodx1 = beta_dt/p->dx[3*m];
+          double dtodx2 = beta_dt/p->dx[3*m+1];
+          double dtodx3 = beta_dt/p->dx[3*m+2];
+          double ut[5];
+          for (int n = 0; n < 5; ++n) {
+            double divf = dtodx1*(flx1[ix5(nv,N3,N2,N1+1,m,n,k,j,i+1)] - flx1[ix5(nv,N3,N2,N1+1,m,n,k,j,i)]);
+            if (g.multi_d)
+              divf += dtodx2*(flx2[ix5(nv,N3,N2+1,N1,m,n,k,j+1,i)] - flx2[ix5(nv,N3,N2+1,N1,m,n,k,j,i)]);
+            if (g.three_d)
+              divf += dtodx3*(flx3[ix5(nv,N3+1,N2,N1,m,n,k+1,j,i)] - flx3[ix5(nv,N3+1,N2,N1,m,n,k,j,i)]);
+            size_t c = ix5(nv,N3,N2,N1,m,n,k,j,i);
+            ut[n] = gam0*u0[c] + gam1*u1[c] - divf;
+          }
+          double b1old = 0.5*(b1x1f[ix4(N3,N2,N1+1,m,k,j,i)] + b1x1f[ix4(N3,N2,N1+1,m,k,j,i+1)]);
+          double b2old = 0.5*(b1x2f[ix4(N3,N2+1,N1,m,k,j,i)] + b1x2f[ix4(N3,N2+1,N1,m,k,j+1,i)]);
+          double b3old = 0.5*(b1x3f[ix4(N3+1,N2,N1,m,k,j,i)] + b1x3f[ix4(N3+1,N2,N1,m,k+1,j,i)]);
+          double bx = gam0*bcc0[ix5(3,N3,N2,N1,m,0,k,j,i)] + gam1*b1old;
+          double by = gam0*bcc0[ix5(3,N3,N2,N1,m,1,k,j,i)] + gam1*b2old;
+          double bz = gam0*bcc0[ix5(3,N3,N2,N1,m,2,k,j,i)] + gam1*b3old;
+          by += dtodx1*(e3x1[ix4(N3,N2,N1,m,k,j,i+1)] - e3x1[ix4(N3,N2,N1,m,k,j,i)]);
+          bz -= dtodx1*(e2x1[ix4(N3,N2,N1,m,k,j,i+1)] - e2x1[ix4(N3,N2,N1,m,k,j,i)]);
+          if (g.multi_d) {
+            bx -= dtodx2*(e3x2[ix4(N3,N2,N1,m,k,j+1,i)] - e3x2[ix4(N3,N2,N1,m,k,j,i)]);
+            bz += dtodx2*(e1x2[ix4(N3,N2,N1,m,k,j+1,i)] - e1x2[ix4(N3,N2,N1,m,k,j,i)]);
+          }
+          if (g.three_d) {
+            bx += dtodx3*(e2x3[ix4(N3,N2,N1,m,k+1,j,i)] - e2x3[ix4(N3,N2,N1,m,k,j,i)]);
+            by -= dtodx3*(e1x3[ix4(N3,N2,N1,m,k+1,j,i)] - e1x3[ix4(N3,N2,N1,m,k,j,i)]);
+          }
+          /* SingleC2P_IdealMHD, src/eos/ideal_c2p_mhd.hpp:20-67 */
+          int fl = 0;
+          double b2 = SQR(bx) + SQR(by) + SQR(bz);
+          double dfloor_ = fmax(p->dfloor, b2/p->sigma_max);
+          double ud = ut[0];
+          if (ud < dfloor_) { ud = dfloor_; fl = 1; }
+          double di = 1.0/ud;
+          double e_k = 0.5*di*(SQR(ut[1]) + SQR(ut[2]) + SQR(ut[3]));
+          double e_m = 0.5*(SQR(bx) + SQR(by) + SQR(bz));
+          double we = (ut[4] - e_k - e_m);
+          if (we < efloor) { we = efloor; fl = 1; }
+          if (gm1*we*di < p->tfloor) { we = ud*p->tfloor/gm1; fl = 1; }
+          double spe_over_eps = gm1/pow(ud, gm1);
+          double spe = spe_over_eps*we*di;
+          if (spe <= p->sfloor) fl = 1;
+          if (fl) { fofc[ix4(N3,N2,N1,m,k,j,i)] = 1; nflag++; }
+        }
+  const double *bf[3] = {b0x1f, b0x2f, b0x3f};
+  double *fl3[3] = {flx1, flx2, flx3};
+  double *eyv[3] = {e3x1, e1x2, e2x3}, *ezv[3] = {e2x1, e3x2, e1x3};
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = kl; k <= ku; ++k)
+      for (int j = jl; j <= ju; ++j)
+        for (int i = il; i <= iu; ++i) {
+          if (!fofc[ix4(N3,N2,N1,m,k,j,i)]) continue;
+          for (int dir = 0; dir < 3; ++dir) {
+            if (dir == 1 && !g.multi_d) continue;
+            if (dir == 2 && !g.three_d) continue;
+            const int ivx = IVX + dir, ivy = IVX + (dir + 1)%3, ivz = IVX + (dir + 2)%3;
+            const int iby = (dir + 1)%3, ibz = (dir + 2)%3;
+            const int d1 = dir == 0, d2 = dir == 1, d3 = dir == 2;
+            const int f1 = N1 + d1, f2 = N2 + d2, f3 = N3 + d3;
+            for (int side = 0; side < 2; ++side) {
+              const int kf = k + side*d3, jf = j + side*d2, ifc = i + side*d1;
+              double a[7], b[7], f[7];
+              const int comp[5] = {IDN, ivx, ivy, ivz, IEN};
+              for (int q = 0; q < 5; ++q) {
+                a[q] = w0[ix5(nv,N3,N2,N1,m,comp[q],kf-d3,jf-d2,ifc-d1)];
+                b[q] = w0[ix5(nv,N3,N2,N1,m,comp[q],kf,jf,ifc)];
+              }
+              a[5] = bcc0[ix5(3,N3,N2,N1,m,iby,kf-d3,jf-d2,ifc-d1)]; b[5] = bcc0[ix5(3,N3,N2,N1,m,iby,kf,jf,ifc)];
+              a[6] = bcc0[ix5(3,N3,N2,N1,m,ibz,kf-d3,jf-d2,ifc-d1)]; b[6] = bcc0[ix5(3,N3,N2,N1,m,ibz,kf,jf,ifc)];
+              akref_llf_mhd(p->gamma, a, b, bf[dir][ix4(f3,f2,f1,m,kf,jf,ifc)], f);
+              for (int q = 0; q < 5; ++q) fl3[dir][ix5(nv,f3,f2,f1,m,comp[q],kf,jf,ifc)] = f[q];
+              eyv[dir][ix4(N3,N2,N1,m,kf,jf,ifc)] = -f[5];     /* flux.by = -0.5*(...) (:83) */
+              ezv[dir][ix4(N3,N2,N1,m,kf,jf,ifc)] = f[6];
+            }
+          }
+        }
+  memset(fofc, 0, (size_t)g.nmb*N3*N2*N1);                   /* deep_copy(fofc, false), :487-489 */
+  if (nfofc) *nfofc += nflag;
   return 0;
 }
 

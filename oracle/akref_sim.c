@@ -92,8 +92,8 @@ akref_sim *akref_create(const akref_params *par) {
   if (s->nb1*p->mb_nx1 != p->nx1 || s->nb2*p->mb_nx2 != p->nx2 || s->nb3*p->mb_nx3 != p->nx3) {
     free(s); return NULL;
   }
-  /* <hydro>/fofc: src/hydro/hydro.cpp:153-190 (ghost-zone checks); MHD FOFC is not restated */
-  if (p->fofc && (p->is_mhd || p->nscalars > 0 || (p->recon == AKMI_RECON_PLM && p->ng < 3) ||
+  /* <hydro>|<mhd>/fofc: src/hydro/hydro.cpp:153-190, src/mhd/mhd.cpp:199-235 (ghost-zone checks) */
+  if (p->fofc && ((p->is_mhd && !p->is_ideal) || p->nscalars > 0 || (p->recon == AKMI_RECON_PLM && p->ng < 3) ||
                   (p->recon >= AKMI_RECON_PPM4 && p->ng < 4))) {
     free(s); return NULL;
   }
@@ -777,9 +777,19 @@ int akref_step(akref_sim *s) {
         akref_copy_cons(pk, s->u0, s->u1);
         for (int q = 0; q < 3; ++q) memcpy(s->b1[q], s->b0[q], sizeof(double)*s->nf[q]);
       }
+      if (p->fofc) {               /* mhd_tasks.cpp:177-214 with use_fofc */
+        akref_mhd_fluxes_fofc(pk, p->recon, p->rsolver, s->w0, s->bcc0, s->b0[0], s->b0[1], s->b0[2],
+                              s->flx1, s->flx2, s->flx3, s->efc[0], s->efc[1], s->efc[2], s->efc[3],
+                              s->efc[4], s->efc[5]);
+        akref_mhd_fofc(pk, gam0, gam1, beta_dt, s->w0, s->bcc0, s->b0[0], s->b0[1], s->b0[2],
+                       s->b1[0], s->b1[1], s->b1[2], s->u0, s->u1, s->flx1, s->flx2, s->flx3,
+                       s->efc[0], s->efc[1], s->efc[2], s->efc[3], s->efc[4], s->efc[5], s->fofc,
+                       &s->nfofc);
+      } else {
       akref_mhd_fluxes(pk, p->recon, p->rsolver, s->w0, s->bcc0, s->b0[0], s->b0[1], s->b0[2],
                        s->flx1, s->flx2, s->flx3, s->efc[0], s->efc[1], s->efc[2], s->efc[3],
                        s->efc[4], s->efc[5]);
+      }
       akref_rk_update(pk, gam0, gam1, beta_dt, s->u0, s->u1, s->flx1, s->flx2, s->flx3, 1);
       akref_mhd_corner_e(pk, s->w0, s->bcc0, s->efc[0], s->efc[1], s->efc[2], s->efc[3],
                          s->efc[4], s->efc[5], s->flx1, s->flx2, s->flx3, s->e[0], s->e[1],

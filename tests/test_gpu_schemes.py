@@ -120,20 +120,40 @@ FOFC = [
 ]
 
 
+def _rare_mhd(d, v=8.0):
+    tube = {"ul": -v, "ur": v, "vl": 0.0, "wl": 0.0, "dl": 1.0, "dr": 1.0, "pl": 0.04, "pr": 0.04,
+            "bxl": 0.1, "bxr": 0.1, "byl": 0.2, "byr": 0.2, "bzl": 0.1, "bzr": 0.1}
+    return ("problem/shock_dir=%d" % d, "mhd/fofc=true", "mhd/gamma=1.4") + tuple(
+        "problem/%s=%r" % kv for kv in tube.items())
+
+
+_BLAST = ("mhd/fofc=true", "problem/prat=1.0e4", "problem/b_amb=10.0")
+FOFC += [
+    ("rj2a", 128, 1, 64, 60, dict(cfl=0.3, recon="ppm4", ng=4, rsolver="hlld", extra=_rare_mhd(1))),
+    ("rj2a", 128, 1, 32, 60, dict(cfl=0.3, recon="ppm4", ng=4, rsolver="hlle", integrator="rk3",
+                                  extra=_rare_mhd(1))),
+    ("rj2a", 32, 2, 16, 50, dict(cfl=0.3, recon="ppm4", ng=4, rsolver="hlld", extra=_rare_mhd(2))),
+    ("blast", 32, 2, 16, 30, dict(rsolver="hlld", extra=_BLAST)),
+    ("blast", 32, 2, (32, 8), 25, dict(rsolver="hlle", recon="wenoz", extra=_BLAST)),
+    ("blast", 24, 3, 12, 16, dict(rsolver="hlld", extra=_BLAST)),
+]
+
+
 @pytest.mark.parametrize("native", [False, True], ids=["py", "cpp"])
-@pytest.mark.parametrize("case", FOFC, ids=lambda c: "%d^%d-%s-%s" % (c[1], c[2], c[5].get("recon", "plm"), c[5]["rsolver"]))
+@pytest.mark.parametrize("case", FOFC, ids=lambda c: "%s-%d^%d-%s-%s" % (c[0], c[1], c[2], c[5].get("recon", "deck"), c[5]["rsolver"]))
 def test_fofc_is_bit_identical(case, native):
-    """akmi_hydro_fluxes_fofc + akmi_hydro_fofc against the oracle, with cells actually flagged"""
+    """akmi_{hydro,mhd}_fluxes_fofc + akmi_{hydro,mhd}_fofc against the oracle, with cells actually
+    flagged (MHD: the face EMFs of flagged cells are replaced too and feed CornerE/CT)"""
     problem, n, dims, mb, cycles, kw = case
     if native and "hydro/eos=isothermal" in kw["extra"]:
         pytest.skip("the C++ host runs the ideal-gas EOS only")
-    sim, osim, _ = pu.make_pair(problem, n, dims, mb, **kw)
+    sim, osim, is_mhd = pu.make_pair(problem, n, dims, mb, **kw)
     for _ in range(cycles):
         assert sim.Execute(max_cycles=1) and osim.step()
     assert osim.nfofc > 0
     if not native:
         assert int(sim.phys.nfofc.item()) == osim.nfofc
-    d = pu.compare_fields(pu.product_arrays(sim), pu.oracle_arrays(osim, False), False)
+    d = pu.compare_fields(pu.product_arrays(sim), pu.oracle_arrays(osim, is_mhd), is_mhd)
     assert sim.pmesh.time == osim.time and d["bitwise_equal"], d
 
 

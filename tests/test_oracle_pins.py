@@ -130,6 +130,38 @@ def test_fofc_rescues_double_rarefaction(recon):
     assert np.isfinite(d1).all() and d1.min() > 0 and e1.min() > 0
 
 
+def test_mhd_fofc_removes_the_energy_floor_hits():
+    """<mhd>/fofc (mhd_fofc.cpp): weakly magnetised streams receding at v=-/+8 (d=1, p=0.04,
+    B=(0.1,0.2,0.1)), ppm4 + HLLD.  Without FOFC the energy floor is applied hundreds of times; with
+    FOFC a few dozen cells fall back to first-order LLF fluxes and EMFs and no floor is applied."""
+    def run(fofc):
+        s = akref.Sim(nx1=128, mb_nx1=64, ng=4, bcs=["outflow", "outflow"] + ["periodic"]*4, nstages=2,
+                      cfl=0.3, tlim=1.0, nlim=60, is_mhd=1, recon="ppm4", rsolver="hlld", gamma=1.4,
+                      pgen="shock_tube", shock_dir=1, xshock=0.0,
+                      wl=[1.0, -8.0, 0, 0, 0.04, 0.1, 0.2, 0.1], wr=[1.0, 8.0, 0, 0, 0.04, 0.1, 0.2, 0.1],
+                      fofc=fofc)
+        s.initialize()
+        s.run()
+        return s.array("counters").copy(), s.nfofc, s.array("w0").copy()
+    c0, n0, w0 = run(0)
+    c1, n1, w1 = run(1)
+    assert n0 == 0 and c0[1] > 100
+    assert n1 > 0 and c1.sum() == 0 and np.isfinite(w1).all() and w1[:, 0].min() > 0 and w1[:, 4].min() > 0
+
+
+def test_mhd_fofc_keeps_divb_at_roundoff():
+    """the first-order EMFs of flagged faces enter CornerE/CT like any other face EMF: div B of a
+    strongly magnetised 2-D blast (prat=1e4, b_amb=10) with cells flagged stays at round-off"""
+    s = akref.Sim(nx1=32, nx2=32, mb_nx1=16, mb_nx2=16, ng=4, bcs=["periodic"]*6, nstages=2, cfl=0.3,
+                  tlim=1.0, nlim=30, is_mhd=1, recon="ppm4", rsolver="hlld", gamma=1.6666667, pgen="blast",
+                  pi_amb=0.1, di_amb=1.0, prat=1.0e4, drat=1.0, b_amb=10.0, inner_radius=0.1,
+                  outer_radius=0.1, fofc=1)
+    s.initialize()
+    s.run()
+    assert s.nfofc > 0
+    assert s.divb()[0] < 2e-11          # the bound of test_nr_divb_amr_mpicpu.py:38-40
+
+
 def test_fofc_is_inert_on_a_smooth_flow():
     """no flagged cell -> the extended flux ranges alone must not change a single bit"""
     a, _ = lwave1d(0, 64, 0, "plm", 2, ng=3)
