@@ -1,0 +1,361 @@
+// akmi_diffusion.hip -- diffusion hooks of the task chain: constant isotropic
+// viscosity, constant thermal diffusivity and Ohmic resistivity as adders to the face fluxes and
+// the corner EMFs, exactly where the reference calls them:
+//   Hydro/MHD::Fluxes   -> Conduction::AddHeatFluxes, Viscosity::AddViscousFluxes,
+//                          Resistivity::AddResistiveFluxes (hydro_tasks.cpp:183-189, mhd_tasks.cpp:198-206)
+//   MHD::EField         -> Resistivity::AddResistiveEMFs   (mhd_tasks.cpp:381-383)
+// One thread per face (edge), the arithmetic of each expression kept in the reference's order.
+// All of them are streaming kernels: a face reads its two (to eighteen) neighbouring cells.
+#include "akmi_common.hpp"
+#include <cfloat>
+
+namespace akmi {
+
+constexpr int DX = 64, DY = 4;
+
+struct Wv {                      // primitive array access  w(n,k,j,i) of MeshBlock m
+  const double *w;
+  int N3, N2, N1;
+  size_t cs;
+  __device__ double operator()(int n, int k, int j, int i) const {
+    return w[n*cs + ((size_t)k*N2 + j)*N1 + i];
+  }
+};
+
+__device__ __forceinline__ Wv wview(const Geo &g, const double *w0, int m) {
+  const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  return Wv{w0 + (size_t)m*g.nvar*cs, g.N3, g.N2, g.N1, cs};
+}
+
+// Viscosity::AddViscousFluxIso, src/diffusion/viscosity.cpp:64-229
+template <int DIR>
+__global__ void __launch_bounds__(DX*DY)
+k_visc_flux(Geo g, double nu_iso, int ideal, const double *__restrict__ w0, double *__restrict__ flx,
+            int f3, int f2, int f1, int nk) {
+  const int i = g.is + blockIdx.x*DX + threadIdx.x;
+  const int j = g.js + blockIdx.y*DY + threadIdx.y;
+  const int m = blockIdx.z/nk;
+  const int k = g.ks + (blockIdx.z - m*nk);
+  if (i > g.ie + (DIR == 0) || j > g.je + (DIR == 1)) return;
+  const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
+  const Wv W = wview(g, w0, m);
+  constexpr int IDN = 0, IVX = 1, IVY = 2, IVZ = 3, IEN = 4;
+  double fvx, fvy, fvz, nud, ax, ay, az;
+  if constexpr (DIR == 0) {
+    fvx = 4.0*(W(IVX,k,j,i) - W(IVX,k,j,i-1))/(3.0*dx1);
+    fvy =     (W(IVY,k,j,i) - W(IVY,k,j,i-1))/dx1;
+    fvz =     (W(IVZ,k,j,i) - W(IVZ,k,j,i-1))/dx1;
+    if (g.multi_d) {
+      fvx -= ((W(IVY,k,j+1,i) + W(IVY,k,j+1,i-1)) - (W(IVY,k,j-1,i) + W(IVY,k,j-1,i-1)))/(6.0*dx2);
+      fvy += ((W(IVX,k,j+1,i) + W(IVX,k,j+1,i-1)) - (W(IVX,k,j-1,i) + W(IVX,k,j-1,i-1)))/(4.0*dx2);
+    }
+    if (g.three_d) {
+      fvx -= ((W(IVZ,k+1,j,i) + W(IVZ,k+1,j,i-1)) - (W(IVZ,k-1,j,i) + W(IVZ,k-1,j,i-1)))/(6.0*dx3);
+      fvz += ((W(IVX,k+1,j,i) + W(IVX,k+1,j,i-1)) - (W(IVX,k-1,j,i) + W(IVX,k-1,j,i-1)))/(4.0*dx3);
+    }
+    nud = 0.5*nu_iso*(W(IDN,k,j,i) + W(IDN,k,j,i-1));
+    ax = W(IVX,k,j,i-1) + W(IVX,k,j,i); ay = W(IVY,k,j,i-1) + W(IVY,k,j,i);
+    az = W(IVZ,k,j,i-1) + W(IVZ,k,j,i);
+  } else if constexpr (DIR == 1) {
+    fvx = (W(IVX,k,j,i) - W(IVX,k,j-1,i))/dx2 +
+          ((W(IVY,k,j,i+1) + W(IVY,k,j-1,i+1)) - (W(IVY,k,j,i-1) + W(IVY,k,j-1,i-1)))/(4.0*dx1);
+    fvy = (W(IVY,k,j,i) - W(IVY,k,j-1,i))*4.0/(3.0*dx2) -
+          ((W(IVX,k,j,i+1) + W(IVX,k,j-1,i+1)) - (W(IVX,k,j,i-1) + W(IVX,k,j-1,i-1)))/(6.0*dx1);
+    fvz = (W(IVZ,k,j,i) - W(IVZ,k,j-1,i))/dx2;
+    if (g.three_d) {
+      fvy -= ((W(IVZ,k+1,j,i) + W(IVZ,k+1,j-1,i)) - (W(IVZ,k-1,j,i) + W(IVZ,k-1,j-1,i)))/(6.0*dx3);
+      fvz += ((W(IVY,k+1,j,i) + W(IVY,k+1,j-1,i)) - (W(IVY,k-1,j,i) + W(IVY,k-1,j-1,i)))/(4.0*dx3);
+    }
+    nud = 0.5*nu_iso*(W(IDN,k,j,i) + W(IDN,k,j-1,i));
+    ax = W(IVX,k,j-1,i) + W(IVX,k,j,i); ay = W(IVY,k,j-1,i) + W(IVY,k,j,i);
+    az = W(IVZ,k,j-1,i) + W(IVZ,k,j,i);
+  } else {
+    fvx = (W(IVX,k,j,i) - W(IVX,k-1,j,i))/dx3 +
+          ((W(IVZ,k,j,i+1) + W(IVZ,k-1,j,i+1)) - (W(IVZ,k,j,i-1) + W(IVZ,k-1,j,i-1)))/(4.0*dx1);
+    fvy = (W(IVY,k,j,i) - W(IVY,k-1,j,i))/dx3 +
+          ((W(IVZ,k,j+1,i) + W(IVZ,k-1,j+1,i)) - (W(IVZ,k,j-1,i) + W(IVZ,k-1,j-1,i)))/(4.0*dx2);
+    fvz = (W(IVZ,k,j,i) - W(IVZ,k-1,j,i))*4.0/(3.0*dx3) -
+          ((W(IVX,k,j,i+1) + W(IVX,k-1,j,i+1)) - (W(IVX,k,j,i-1) + W(IVX,k-1,j,i-1)))/(6.0*dx1) -
+          ((W(IVY,k,j+1,i) + W(IVY,k-1,j+1,i)) - (W(IVY,k,j-1,i) + W(IVY,k-1,j-1,i)))/(6.0*dx2);
+    nud = 0.5*nu_iso*(W(IDN,k,j,i) + W(IDN,k-1,j,i));
+    ax = W(IVX,k-1,j,i) + W(IVX,k,j,i); ay = W(IVY,k-1,j,i) + W(IVY,k,j,i);
+    az = W(IVZ,k-1,j,i) + W(IVZ,k,j,i);
+  }
+  const size_t fs = (size_t)f3*f2*f1;
+  double *f = flx + ix5(g.nvar, f3, f2, f1, m, 0, k, j, i);
+  f[IVX*fs] -= nud*fvx;
+  f[IVY*fs] -= nud*fvy;
+  f[IVZ*fs] -= nud*fvz;
+  if (ideal) f[IEN*fs] -= 0.5*nud*(ax*fvx + ay*fvy + az*fvz);
+}
+
+// Conduction::AddHeatFluxIso, src/diffusion/conduction.cpp:106-152
+template <int DIR>
+__global__ void __launch_bounds__(DX*DY)
+k_heat_flux(Geo g, double alpha_iso, double gm1, const double *__restrict__ w0,
+            double *__restrict__ flx, int f3, int f2, int f1, int nk) {
+  const int i = g.is + blockIdx.x*DX + threadIdx.x;
+  const int j = g.js + blockIdx.y*DY + threadIdx.y;
+  const int m = blockIdx.z/nk;
+  const int k = g.ks + (blockIdx.z - m*nk);
+  if (i > g.ie + (DIR == 0) || j > g.je + (DIR == 1)) return;
+  const Wv W = wview(g, w0, m);
+  const int kl = k - (DIR == 2), jl = j - (DIR == 1), il = i - (DIR == 0);
+  const double dx = g.dx[3*m + DIR];
+  const double tempr = W(4,k,j,i)/W(0,k,j,i);
+  const double templ = W(4,kl,jl,il)/W(0,kl,jl,il);
+  const double dtempdx = (tempr - templ) * gm1 / dx;
+  const double densf = 0.5*(W(0,k,j,i) + W(0,kl,jl,il));
+  flx[ix5(g.nvar, f3, f2, f1, m, 4, k, j, i)] -= alpha_iso * densf * dtempdx;
+}
+
+// Conduction::NewTimeStep, conduction.cpp:314-377: min over the active cells of
+// SQR(dx)/alpha*d/gm1 per direction.  Every factor is positive, so the expression is a monotone
+// function of d for a given block and the minimum over a block is the value at its minimum
+// density: reduce min(d) per wave, evaluate once per workgroup, one atomicMin if it can win.
+__global__ void __launch_bounds__(DX*DY)
+k_cond_newdt(Geo g, double alpha_iso, double gm1, const double *__restrict__ w0,
+             double *__restrict__ dtmin, int nk) {
+  const int i = g.is + blockIdx.x*DX + threadIdx.x;
+  const int j = g.js + blockIdx.y*DY + threadIdx.y;
+  const int m = blockIdx.z/nk;
+  const int k = g.ks + (blockIdx.z - m*nk);
+  double d = DBL_MAX;
+  if (i <= g.ie && j <= g.je) d = w0[ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i)];
+  for (int off = 32; off > 0; off >>= 1) d = fmin(d, __shfl_xor(d, off, 64));
+  __shared__ double sm[DY];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.y] = d;
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0) {
+    for (int q = 1; q < DY; ++q) d = fmin(d, sm[q]);
+    if (d == DBL_MAX) return;
+    double v = sqr(g.dx[3*m])/alpha_iso*d/gm1;
+    if (g.multi_d) v = fmin(v, sqr(g.dx[3*m + 1])/alpha_iso*d/gm1);
+    if (g.three_d) v = fmin(v, sqr(g.dx[3*m + 2])/alpha_iso*d/gm1);
+    if (v < __hip_atomic_load(dtmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMin(reinterpret_cast<unsigned long long *>(dtmin),
+                (unsigned long long)__double_as_longlong(v));
+  }
+}
+
+__global__ void k_set_fltmax(double *x) { if (threadIdx.x == 0) *x = (double)FLT_MAX; }
+
+struct Bf {                      // face-field access of MeshBlock m
+  const double *b1, *b2, *b3;
+  int N3, N2, N1;
+  __device__ double x1f(int k, int j, int i) const { return b1[((size_t)k*N2 + j)*(N1 + 1) + i]; }
+  __device__ double x2f(int k, int j, int i) const { return b2[((size_t)k*(N2 + 1) + j)*N1 + i]; }
+  __device__ double x3f(int k, int j, int i) const { return b3[((size_t)k*N2 + j)*N1 + i]; }
+};
+__device__ __forceinline__ Bf bview(const Geo &g, const double *b1, const double *b2,
+                                    const double *b3, int m) {
+  return Bf{b1 + (size_t)m*g.N3*g.N2*(g.N1 + 1), b2 + (size_t)m*g.N3*(g.N2 + 1)*g.N1,
+            b3 + (size_t)m*(g.N3 + 1)*g.N2*g.N1, g.N3, g.N2, g.N1};
+}
+
+// Resistivity::AddEMFConstantResist (resistivity.cpp:78-177) with CurrentDensity
+// (current_density.hpp:30-57): E += eta_ohm*J at the edges [is,ie+1] x [js,je+1] x [ks,ke+1]
+// (1-D / 2-D: the collapsed directions receive the same value on both of their planes)
+__global__ void __launch_bounds__(DX*DY)
+k_resist_emf(Geo g, double eta, const double *__restrict__ bx1f, const double *__restrict__ bx2f,
+             const double *__restrict__ bx3f, double *__restrict__ e1, double *__restrict__ e2,
+             double *__restrict__ e3, int nk) {
+  const int i = g.is + blockIdx.x*DX + threadIdx.x;
+  const int j = g.js + blockIdx.y*DY + threadIdx.y;
+  const int m = blockIdx.z/nk;
+  const int k = g.ks + (blockIdx.z - m*nk);
+  if (i > g.ie + 1 || j > (g.multi_d ? g.je + 1 : g.js)) return;
+  const Bf b = bview(g, bx1f, bx2f, bx3f, m);
+  const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
+  double j1 = 0.0;
+  double j2 = -(b.x3f(k,j,i) - b.x3f(k,j,i-1))/dx1;
+  double j3 =  (b.x2f(k,j,i) - b.x2f(k,j,i-1))/dx1;
+  if (g.multi_d) {
+    j1 += (b.x3f(k,j,i) - b.x3f(k,j-1,i))/dx2;
+    j3 -= (b.x1f(k,j,i) - b.x1f(k,j-1,i))/dx2;
+  }
+  if (g.three_d) {
+    j1 -= (b.x2f(k,j,i) - b.x2f(k-1,j,i))/dx3;
+    j2 += (b.x1f(k,j,i) - b.x1f(k-1,j,i))/dx3;
+  }
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  if (g.three_d) {
+    e1[ix4(N3 + 1, N2 + 1, N1, m, k, j, i)] += eta*j1;
+    e2[ix4(N3 + 1, N2, N1 + 1, m, k, j, i)] += eta*j2;
+    e3[ix4(N3, N2 + 1, N1 + 1, m, k, j, i)] += eta*j3;
+  } else if (g.multi_d) {
+    e1[ix4(N3 + 1, N2 + 1, N1, m, g.ks, j, i)] += eta*j1;
+    e1[ix4(N3 + 1, N2 + 1, N1, m, g.ke + 1, j, i)] += eta*j1;
+    e2[ix4(N3 + 1, N2, N1 + 1, m, g.ks, j, i)] += eta*j2;
+    e2[ix4(N3 + 1, N2, N1 + 1, m, g.ke + 1, j, i)] += eta*j2;
+    e3[ix4(N3, N2 + 1, N1 + 1, m, g.ks, j, i)] += eta*j3;
+  } else {
+    e2[ix4(N3 + 1, N2, N1 + 1, m, g.ks, g.js, i)] += eta*j2;
+    e2[ix4(N3 + 1, N2, N1 + 1, m, g.ke + 1, g.js, i)] += eta*j2;
+    e3[ix4(N3, N2 + 1, N1 + 1, m, g.ks, g.js, i)] += eta*j3;
+    e3[ix4(N3, N2 + 1, N1 + 1, m, g.ks, g.je + 1, i)] += eta*j3;
+  }
+}
+
+// Resistivity::AddFluxConstantResist, resistivity.cpp:185-272 (energy flux, face-shaped arrays)
+template <int DIR>
+__global__ void __launch_bounds__(DX*DY)
+k_resist_flux(Geo g, double eta, const double *__restrict__ bx1f, const double *__restrict__ bx2f,
+              const double *__restrict__ bx3f, double *__restrict__ flx, int nk) {
+  const int i = g.is + blockIdx.x*DX + threadIdx.x;
+  const int j = g.js + blockIdx.y*DY + threadIdx.y;
+  const int m = blockIdx.z/nk;
+  const int k = g.ks + (blockIdx.z - m*nk);
+  if (i > g.ie + (DIR == 0) || j > g.je + (DIR == 1)) return;
+  const Bf b = bview(g, bx1f, bx2f, bx3f, m);
+  const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
+  const double qa = 0.25*eta;
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  if constexpr (DIR == 0) {
+    double j2k   = -(b.x3f(k  ,j,i) - b.x3f(k  ,j,i-1))/dx1;
+    double j2kp1 = -(b.x3f(k+1,j,i) - b.x3f(k+1,j,i-1))/dx1;
+    double j3j   = (b.x2f(k,j  ,i) - b.x2f(k,j  ,i-1))/dx1;
+    double j3jp1 = (b.x2f(k,j+1,i) - b.x2f(k,j+1,i-1))/dx1;
+    if (g.multi_d) {
+      j3j   -= (b.x1f(k,j  ,i) - b.x1f(k,j-1,i))/dx2;
+      j3jp1 -= (b.x1f(k,j+1,i) - b.x1f(k,j  ,i))/dx2;
+    }
+    if (g.three_d) {
+      j2k   += (b.x1f(k  ,j,i) - b.x1f(k-1,j,i))/dx3;
+      j2kp1 += (b.x1f(k+1,j,i) - b.x1f(k  ,j,i))/dx3;
+    }
+    flx[ix5(g.nvar, N3, N2, N1 + 1, m, 4, k, j, i)] +=
+        qa*(j2k  *(b.x3f(k  ,j  ,i) + b.x3f(k  ,j  ,i-1)) +
+            j2kp1*(b.x3f(k+1,j  ,i) + b.x3f(k+1,j  ,i-1)) -
+            j3j  *(b.x2f(k  ,j  ,i) + b.x2f(k  ,j  ,i-1)) -
+            j3jp1*(b.x2f(k  ,j+1,i) + b.x2f(k  ,j+1,i-1)));
+  } else if constexpr (DIR == 1) {
+    double j1k   = (b.x3f(k  ,j,i) - b.x3f(k  ,j-1,i))/dx2;
+    double j1kp1 = (b.x3f(k+1,j,i) - b.x3f(k+1,j-1,i))/dx2;
+    double j3i   = (b.x2f(k,j,i  ) - b.x2f(k,j  ,i-1))/dx1 - (b.x1f(k,j,i  ) - b.x1f(k,j-1,i  ))/dx2;
+    double j3ip1 = (b.x2f(k,j,i+1) - b.x2f(k,j  ,i  ))/dx1 - (b.x1f(k,j,i+1) - b.x1f(k,j-1,i+1))/dx2;
+    if (g.three_d) {
+      j1k   -= (b.x2f(k  ,j,i) - b.x2f(k-1,j,i))/dx3;
+      j1kp1 -= (b.x2f(k+1,j,i) - b.x2f(k  ,j,i))/dx3;
+    }
+    flx[ix5(g.nvar, N3, N2 + 1, N1, m, 4, k, j, i)] +=
+        qa*(j3i  *(b.x1f(k  ,j,i  ) + b.x1f(k  ,j-1,i  )) +
+            j3ip1*(b.x1f(k  ,j,i+1) + b.x1f(k  ,j-1,i+1)) -
+            j1k  *(b.x3f(k  ,j,i  ) + b.x3f(k  ,j-1,i  )) -
+            j1kp1*(b.x3f(k+1,j,i  ) + b.x3f(k+1,j-1,i  )));
+  } else {
+    double j1j   = (b.x3f(k,j  ,i) - b.x3f(k  ,j-1,i))/dx2 - (b.x2f(k,j  ,i) - b.x2f(k-1,j  ,i))/dx3;
+    double j1jp1 = (b.x3f(k,j+1,i) - b.x3f(k  ,j  ,i))/dx2 - (b.x2f(k,j+1,i) - b.x2f(k-1,j+1,i))/dx3;
+    double j2i   = -(b.x3f(k,j,i  ) - b.x3f(k  ,j,i-1))/dx1 + (b.x1f(k,j,i  ) - b.x1f(k-1,j,i  ))/dx3;
+    double j2ip1 = -(b.x3f(k,j,i+1) - b.x3f(k  ,j,i  ))/dx1 + (b.x1f(k,j,i+1) - b.x1f(k-1,j,i+1))/dx3;
+    flx[ix5(g.nvar, N3 + 1, N2, N1, m, 4, k, j, i)] +=
+        qa*(j1j  *(b.x2f(k,j  ,i  ) + b.x2f(k-1,j  ,i  )) +
+            j1jp1*(b.x2f(k,j+1,i  ) + b.x2f(k-1,j+1,i  )) -
+            j2i  *(b.x1f(k,j  ,i  ) + b.x1f(k-1,j  ,i  )) -
+            j2ip1*(b.x1f(k,j  ,i+1) + b.x1f(k-1,j  ,i+1)));
+  }
+}
+
+static dim3 face_grid(const Geo &g, int dir, int &nk) {
+  nk = g.ke - g.ks + 1 + (dir == 2);
+  return dim3(cdiv(g.nx1 + (dir == 0), DX), cdiv(g.je - g.js + 1 + (dir == 1), DY), nk*g.nmb);
+}
+
+}  // namespace akmi
+
+using namespace akmi;
+
+extern "C" {
+
+int akmi_viscous_fluxes(const akmi_pack *p, double nu_iso, const double *w0, double *flx1,
+                        double *flx2, double *flx3, int face_shaped, void *stream) {
+  Geo g = make_geo(p);
+  hipStream_t st = (hipStream_t)stream;
+  const int fs = face_shaped ? 1 : 0;
+  const dim3 block(DX, DY);
+  int nk;
+  dim3 g0 = face_grid(g, 0, nk);
+  k_visc_flux<0><<<g0, block, 0, st>>>(g, nu_iso, p->is_ideal, w0, flx1, g.N3, g.N2, g.N1 + fs, nk);
+  if (g.multi_d) {
+    dim3 g1 = face_grid(g, 1, nk);
+    k_visc_flux<1><<<g1, block, 0, st>>>(g, nu_iso, p->is_ideal, w0, flx2, g.N3, g.N2 + fs, g.N1, nk);
+  }
+  if (g.three_d) {
+    dim3 g2 = face_grid(g, 2, nk);
+    k_visc_flux<2><<<g2, block, 0, st>>>(g, nu_iso, p->is_ideal, w0, flx3, g.N3 + fs, g.N2, g.N1, nk);
+  }
+  AKMI_CHECK_LAUNCH("viscous_fluxes");
+  return AKMI_COMPLETE;
+}
+
+int akmi_heat_fluxes(const akmi_pack *p, double alpha_iso, const double *w0, double *flx1,
+                     double *flx2, double *flx3, int face_shaped, void *stream) {
+  if (!p->is_ideal) {        // src/hydro/hydro.cpp:89-95
+    set_error("heat_fluxes: thermal conduction requires the ideal gas EOS"); return AKMI_FAIL;
+  }
+  Geo g = make_geo(p);
+  hipStream_t st = (hipStream_t)stream;
+  const int fs = face_shaped ? 1 : 0;
+  const double gm1 = p->gamma - 1.0;
+  const dim3 block(DX, DY);
+  int nk;
+  dim3 g0 = face_grid(g, 0, nk);
+  k_heat_flux<0><<<g0, block, 0, st>>>(g, alpha_iso, gm1, w0, flx1, g.N3, g.N2, g.N1 + fs, nk);
+  if (g.multi_d) {
+    dim3 g1 = face_grid(g, 1, nk);
+    k_heat_flux<1><<<g1, block, 0, st>>>(g, alpha_iso, gm1, w0, flx2, g.N3, g.N2 + fs, g.N1, nk);
+  }
+  if (g.three_d) {
+    dim3 g2 = face_grid(g, 2, nk);
+    k_heat_flux<2><<<g2, block, 0, st>>>(g, alpha_iso, gm1, w0, flx3, g.N3 + fs, g.N2, g.N1, nk);
+  }
+  AKMI_CHECK_LAUNCH("heat_fluxes");
+  return AKMI_COMPLETE;
+}
+
+int akmi_conduction_newdt(const akmi_pack *p, double alpha_iso, const double *w0, double *dtmin,
+                          void *stream) {
+  Geo g = make_geo(p);
+  hipStream_t st = (hipStream_t)stream;
+  k_set_fltmax<<<1, 64, 0, st>>>(dtmin);
+  const int nk = g.ke - g.ks + 1;
+  dim3 grid(cdiv(g.nx1, DX), cdiv(g.je - g.js + 1, DY), nk*g.nmb), block(DX, DY);
+  k_cond_newdt<<<grid, block, 0, st>>>(g, alpha_iso, p->gamma - 1.0, w0, dtmin, nk);
+  AKMI_CHECK_LAUNCH("conduction_newdt");
+  return AKMI_COMPLETE;
+}
+
+int akmi_resistive_emfs(const akmi_pack *p, double eta_ohm, const double *bx1f, const double *bx2f,
+                        const double *bx3f, double *e1, double *e2, double *e3, void *stream) {
+  Geo g = make_geo(p);
+  const int nk = g.three_d ? g.ke - g.ks + 2 : 1;
+  dim3 grid(cdiv(g.nx1 + 1, DX), cdiv(g.multi_d ? g.nx2 + 1 : 1, DY), nk*g.nmb), block(DX, DY);
+  k_resist_emf<<<grid, block, 0, (hipStream_t)stream>>>(g, eta_ohm, bx1f, bx2f, bx3f, e1, e2, e3, nk);
+  AKMI_CHECK_LAUNCH("resistive_emfs");
+  return AKMI_COMPLETE;
+}
+
+int akmi_resistive_fluxes(const akmi_pack *p, double eta_ohm, const double *bx1f, const double *bx2f,
+                          const double *bx3f, double *flx1, double *flx2, double *flx3, void *stream) {
+  if (!p->is_ideal) {        // mhd_tasks.cpp:204: only with an energy equation
+    set_error("resistive_fluxes: needs the ideal gas EOS"); return AKMI_FAIL;
+  }
+  Geo g = make_geo(p);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 block(DX, DY);
+  int nk;
+  dim3 g0 = face_grid(g, 0, nk);
+  k_resist_flux<0><<<g0, block, 0, st>>>(g, eta_ohm, bx1f, bx2f, bx3f, flx1, nk);
+  if (g.multi_d) {
+    dim3 g1 = face_grid(g, 1, nk);
+    k_resist_flux<1><<<g1, block, 0, st>>>(g, eta_ohm, bx1f, bx2f, bx3f, flx2, nk);
+  }
+  if (g.three_d) {
+    dim3 g2 = face_grid(g, 2, nk);
+    k_resist_flux<2><<<g2, block, 0, st>>>(g, eta_ohm, bx1f, bx2f, bx3f, flx3, nk);
+  }
+  AKMI_CHECK_LAUNCH("resistive_fluxes");
+  return AKMI_COMPLETE;
+}
+
+}  // extern "C"

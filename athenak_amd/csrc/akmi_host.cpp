@@ -333,6 +333,9 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
   if (recon_method >= AKMI_RECON_PPM4 && ind.ng < 3)
     AKMI_FATAL("PPM/WENOZ reconstruction requires at least 3 ghost zones");
   if (pin->GetOrAddInteger(blk, "nscalars", 0) != 0) AKMI_FATAL("passive scalars are not on this path");
+  for (const char *n : {"nu_iso", "nu_aniso", "alpha_iso", "alpha_aniso", "alpha_spitzer", "eta_ohm", "eta_ad"})
+    if (pin->DoesParameterExist(blk, n))
+      AKMI_FATAL(std::string("<") + blk + ">/" + n + ": the diffusion hooks run on the Python host of this package");
   fused = pin->GetOrAddBoolean(blk, "fused_stage", true);
   pack_c.nmb = pp->nmb_thispack; pack_c.nvar = 5;
   pack_c.nx1 = ind.nx1; pack_c.nx2 = ind.nx2; pack_c.nx3 = ind.nx3; pack_c.ng = ind.ng;

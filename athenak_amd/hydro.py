@@ -111,6 +111,10 @@ class FluidBase:
             n3, n2, n1 = indcs.ncells
             self.fofc = torch.zeros((self.nmb, n3, n2, n1), dtype=torch.uint8, device=device)
             self.nfofc = torch.zeros(1, dtype=torch.int32, device=device)   # EventCounters::nfofc
+        # viscosity / conduction / resistivity objects (hydro.cpp:77-98, mhd.cpp:104-130)
+        from .diffusion import make_diffusion
+        if make_diffusion(self, pin, blk):
+            self.fused = False       # the flux adders work on the flux arrays of the task path
         self.counters = torch.zeros(3, dtype=torch.int32, device=device)
         self.dt3 = torch.zeros(3, dtype=torch.float64, device=device)
         self.dtnew = FLT_MAX
@@ -121,6 +125,15 @@ class FluidBase:
             nbytes = int(self.L.akmi_stage_workspace_bytes(C.byref(self.pack_c), is_mhd))
             self.ws = torch.empty((nbytes + 7)//8, dtype=torch.float64, device=self.device)
         return self.ws
+
+    def _diffusion_newdt(self):
+        """hydro_newdt.cpp:128-133, mhd_newdt.cpp:159-167"""
+        if self.pcond is not None:
+            self.pcond.NewTimeStep(self.w0)
+        if self.pvisc is not None:
+            self.pvisc.NewTimeStep()
+        if self.presist is not None:
+            self.presist.NewTimeStep()
 
     def _finish_newdt(self):
         """host side of NewTimeStep: hydro_newdt.cpp:121-124 (blocking 24-byte D2H read)"""
@@ -200,12 +213,18 @@ class Hydro(FluidBase):
 
     def Fluxes(self, pdrive, stage):
         """hydro_tasks.cpp:159-201"""
-        if self.use_fofc:
-            # hydro_fluxes.cpp:92-101 (extended ranges) + hydro_tasks.cpp:192-194 -> Hydro::FOFC
-            capi.check(self.L.akmi_hydro_fluxes_fofc(
-                C.byref(self.pack_c), self.recon_method, self.rsolver_method, capi._p(self.w0),
-                capi._p(self.uflx.x1f), capi._p(self.uflx.x2f), capi._p(self.uflx.x3f), 0,
-                capi._stream()), "hydro_fluxes_fofc")
+        if self.fused:
+            return TaskStatus.complete
+        # hydro_fluxes.cpp:92-101: ranges extended by one cell when FOFC is on
+        fn = self.L.akmi_hydro_fluxes_fofc if self.use_fofc else self.L.akmi_hydro_fluxes
+        capi.check(fn(C.byref(self.pack_c), self.recon_method, self.rsolver_method, capi._p(self.w0),
+                      capi._p(self.uflx.x1f), capi._p(self.uflx.x2f), capi._p(self.uflx.x3f), 0,
+                      capi._stream()), "hydro_fluxes")
+        if self.pcond is not None:                       # hydro_tasks.cpp:184-189
+            self.pcond.AddHeatFluxes(self.w0, self.uflx, 0)
+        if self.pvisc is not None:
+            self.pvisc.AddViscousFluxes(self.w0, self.uflx, 0)
+        if self.use_fofc:                                # hydro_tasks.cpp:192-194 -> Hydro::FOFC
             capi.check(self.L.akmi_hydro_fofc(
                 C.byref(self.pack_c), C.c_double(pdrive.gam0[stage - 1]),
                 C.c_double(pdrive.gam1[stage - 1]),
@@ -213,11 +232,6 @@ class Hydro(FluidBase):
                 capi._p(self.u0), capi._p(self.u1), capi._p(self.uflx.x1f), capi._p(self.uflx.x2f),
                 capi._p(self.uflx.x3f), 0, capi._p(self.fofc), capi._p(self.nfofc),
                 capi._stream()), "hydro_fofc")
-        elif not self.fused:
-            capi.check(self.L.akmi_hydro_fluxes(
-                C.byref(self.pack_c), self.recon_method, self.rsolver_method, capi._p(self.w0),
-                capi._p(self.uflx.x1f), capi._p(self.uflx.x2f), capi._p(self.uflx.x3f), 0,
-                capi._stream()), "hydro_fluxes")
         return TaskStatus.complete
 
     def RKUpdate(self, pdrive, stage):
@@ -303,4 +317,5 @@ class Hydro(FluidBase):
                                                capi._p(self.dt3), capi._stream()), "hydro_newdt")
         self._dt_ready = False
         self._finish_newdt()
+        self._diffusion_newdt()
         return TaskStatus.complete

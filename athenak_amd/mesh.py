@@ -302,10 +302,14 @@ class Mesh:
             self.dtold = 0.0
         self.dt = 2.0*self.dt
         pk = self.pmb_pack
-        if pk.phydro is not None:
-            self.dt = min(self.dt, self.cfl_no*pk.phydro.dtnew)
-        if pk.pmhd is not None:
-            self.dt = min(self.dt, self.cfl_no*pk.pmhd.dtnew)
+        for ph in (pk.phydro, pk.pmhd):
+            if ph is None:
+                continue
+            self.dt = min(self.dt, self.cfl_no*ph.dtnew)
+            # viscosity, (MHD) resistivity, conduction: mesh.cpp:589-612
+            for d in (ph.pvisc, ph.presist, ph.pcond):
+                if d is not None:
+                    self.dt = min(self.dt, self.cfl_no*d.dtnew)
         if self.nranks > 1:
             # MPI_Allreduce(MIN) of one Real, mesh.cpp:634-637
             import torch

@@ -100,6 +100,12 @@ class MHD(FluidBase):
             capi.check(fn(C.byref(self.pack_c), self.recon_method, self.rsolver_method,
                           capi._p(self.w0), capi._p(self.bcc0), *self._b(self.b0), *self._b(self.uflx),
                           *efc, capi._stream()), "mhd_fluxes")
+            if self.pcond is not None:                   # mhd_tasks.cpp:198-206
+                self.pcond.AddHeatFluxes(self.w0, self.uflx, 1)
+            if self.pvisc is not None:
+                self.pvisc.AddViscousFluxes(self.w0, self.uflx, 1)
+            if self.presist is not None and self.peos.eos_data.is_ideal:
+                self.presist.AddResistiveFluxes(self.b0, self.uflx)
             if self.use_fofc:                    # mhd_tasks.cpp:209-211 -> MHD::FOFC
                 capi.check(self.L.akmi_mhd_fofc(
                     C.byref(self.pack_c), C.c_double(pdrive.gam0[stage - 1]),
@@ -161,6 +167,8 @@ class MHD(FluidBase):
                 capi._p(self.e2x1), capi._p(self.e1x2), capi._p(self.e3x2), capi._p(self.e2x3),
                 capi._p(self.e1x3), *self._b(self.uflx), capi._p(self.efld.x1e),
                 capi._p(self.efld.x2e), capi._p(self.efld.x3e), capi._stream()), "mhd_corner_e")
+            if self.presist is not None:                 # mhd_tasks.cpp:381-383
+                self.presist.AddResistiveEMFs(self.b0, self.efld)
         return TaskStatus.complete
 
     def CT(self, pdrive, stage):
@@ -228,4 +236,5 @@ class MHD(FluidBase):
                        "mhd_newdt")
         self._dt_ready = False
         self._finish_newdt()
+        self._diffusion_newdt()
         return TaskStatus.complete

@@ -99,6 +99,28 @@ int akmi_mhd_fofc(const akmi_pack *p, double gam0, double gam1, double beta_dt, 
                   const double *u1, double *flx1, double *flx2, double *flx3, double *e3x1,
                   double *e2x1, double *e1x2, double *e3x2, double *e2x3, double *e1x3,
                   unsigned char *fofc, int *nfofc, void *stream);
+/* ---- diffusion hooks of the Fluxes / EField tasks (src/hydro/hydro_tasks.cpp:183-189,
+ * src/mhd/mhd_tasks.cpp:198-206,381-383); constant coefficients ---------------------------- */
+/* Viscosity::AddViscousFluxIso (src/diffusion/viscosity.cpp:64-229): momentum and energy fluxes of
+ * the isotropic Navier-Stokes stress subtracted from flx on the faces of the active cells */
+int akmi_viscous_fluxes(const akmi_pack *p, double nu_iso, const double *w0, double *flx1,
+                        double *flx2, double *flx3, int face_shaped, void *stream);
+/* Conduction::AddHeatFluxIso (src/diffusion/conduction.cpp:106-152): q = -alpha*d*grad((gamma-1)e/d) */
+int akmi_heat_fluxes(const akmi_pack *p, double alpha_iso, const double *w0, double *flx1,
+                     double *flx2, double *flx3, int face_shaped, void *stream);
+/* Conduction::NewTimeStep (src/diffusion/conduction.cpp:314-377): *dtmin (device) = min over the
+ * active cells of SQR(dx)/alpha*d/(gamma-1); the caller multiplies by fac = 1/2, 1/4, 1/6 */
+int akmi_conduction_newdt(const akmi_pack *p, double alpha_iso, const double *w0, double *dtmin,
+                          void *stream);
+/* Resistivity::AddEMFConstantResist (src/diffusion/resistivity.cpp:78-177): efld += eta_ohm*J, J from
+ * CurrentDensity (src/diffusion/current_density.hpp:30-57) */
+int akmi_resistive_emfs(const akmi_pack *p, double eta_ohm, const double *bx1f, const double *bx2f,
+                        const double *bx3f, double *e1, double *e2, double *e3, void *stream);
+/* Resistivity::AddFluxConstantResist (src/diffusion/resistivity.cpp:185-272): Poynting flux of the
+ * resistive field added to the energy component of the face-shaped MHD fluxes */
+int akmi_resistive_fluxes(const akmi_pack *p, double eta_ohm, const double *bx1f, const double *bx2f,
+                          const double *bx3f, double *flx1, double *flx2, double *flx3, void *stream);
+
 /* Hydro::CopyCons, stages 2..4 of integrator rk4 (src/hydro/hydro_tasks.cpp:134-148): the second
  * register of the 2S scheme, u1 += delta*u0 on the active cells */
 int akmi_rk4_copy_cons(const akmi_pack *p, double delta, const double *u0, double *u1, void *stream);

@@ -47,6 +47,15 @@ int akref_mhd_fofc(const akmi_pack *p, double gam0, double gam1, double beta_dt,
                    const double *u1, double *flx1, double *flx2, double *flx3, double *e3x1,
                    double *e2x1, double *e1x2, double *e3x2, double *e2x3, double *e1x3,
                    unsigned char *fofc, int *nfofc);
+int akref_viscous_fluxes(const akmi_pack *p, double nu_iso, const double *w0, double *flx1,
+                         double *flx2, double *flx3, int face_shaped);
+int akref_heat_fluxes(const akmi_pack *p, double alpha_iso, const double *w0, double *flx1,
+                      double *flx2, double *flx3, int face_shaped);
+int akref_conduction_newdt(const akmi_pack *p, double alpha_iso, const double *w0, double *dtmin);
+int akref_resistive_emfs(const akmi_pack *p, double eta_ohm, const double *bx1f, const double *bx2f,
+                         const double *bx3f, double *e1, double *e2, double *e3);
+int akref_resistive_fluxes(const akmi_pack *p, double eta_ohm, const double *bx1f, const double *bx2f,
+                           const double *bx3f, double *flx1, double *flx2, double *flx3);
 int akref_rk4_copy_cons(const akmi_pack *p, double delta, const double *u0, double *u1);
 int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
                        double *flx1, double *flx2, double *flx3, int face_shaped);
@@ -138,6 +147,8 @@ typedef struct akref_params {
   double iso_cs;                   /* iso_sound_speed */
   int nscalars;                    /* passive scalars appended to the fluid variables */
   int fofc;                        /* <hydro>/fofc: first-order flux correction */
+  double nu_iso, alpha_iso, eta_ohm; /* constant viscosity / thermal diffusivity / Ohmic resistivity
+                                      * (0 = not requested), src/diffusion */
   /* <problem> */
   int pgen;
   /* linear_wave */

@@ -1680,6 +1680,251 @@ int akref_mhd_fofc(const akmi_pack *p, double gam0, double gam1, double beta_dt,
   return 0;
 }
 
+/* ---- diffusion hooks of the task chain (src/hydro/hydro_tasks.cpp:183-189, src/mhd/mhd_tasks.cpp:198-206,381-383) ---- */
+
+/* Viscosity::AddViscousFluxIso, src/diffusion/viscosity.cpp:64-229 (constant isotropic nu) */
+int akref_viscous_fluxes(const akmi_pack *p, double nu_iso, const double *w0, double *flx1,
+                         double *flx2, double *flx3, int fs) {
+  G g = mkG(p);
+  const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  const int ideal = p->is_ideal;
+#define W(n,k,j,i) w0[ix5(nv,N3,N2,N1,m,(n),(k),(j),(i))]
+  for (int m = 0; m < g.nmb; ++m) {
+    const double dx1 = p->dx[3*m], dx2 = p->dx[3*m+1], dx3 = p->dx[3*m+2];
+    for (int k = g.ks; k <= g.ke; ++k) for (int j = g.js; j <= g.je; ++j)
+      for (int i = g.is; i <= g.ie+1; ++i) {
+        double fvx = 4.0*(W(IVX,k,j,i) - W(IVX,k,j,i-1))/(3.0*dx1);
+        double fvy =     (W(IVY,k,j,i) - W(IVY,k,j,i-1))/dx1;
+        double fvz =     (W(IVZ,k,j,i) - W(IVZ,k,j,i-1))/dx1;
+        if (g.multi_d) {
+          fvx -= ((W(IVY,k,j+1,i) + W(IVY,k,j+1,i-1)) - (W(IVY,k,j-1,i) + W(IVY,k,j-1,i-1)))/(6.0*dx2);
+          fvy += ((W(IVX,k,j+1,i) + W(IVX,k,j+1,i-1)) - (W(IVX,k,j-1,i) + W(IVX,k,j-1,i-1)))/(4.0*dx2);
+        }
+        if (g.three_d) {
+          fvx -= ((W(IVZ,k+1,j,i) + W(IVZ,k+1,j,i-1)) - (W(IVZ,k-1,j,i) + W(IVZ,k-1,j,i-1)))/(6.0*dx3);
+          fvz += ((W(IVX,k+1,j,i) + W(IVX,k+1,j,i-1)) - (W(IVX,k-1,j,i) + W(IVX,k-1,j,i-1)))/(4.0*dx3);
+        }
+        double nud = 0.5*nu_iso*(W(IDN,k,j,i) + W(IDN,k,j,i-1));
+        flx1[ix5(nv,N3,N2,N1+fs,m,IVX,k,j,i)] -= nud*fvx;
+        flx1[ix5(nv,N3,N2,N1+fs,m,IVY,k,j,i)] -= nud*fvy;
+        flx1[ix5(nv,N3,N2,N1+fs,m,IVZ,k,j,i)] -= nud*fvz;
+        if (ideal)
+          flx1[ix5(nv,N3,N2,N1+fs,m,IEN,k,j,i)] -= 0.5*nud*((W(IVX,k,j,i-1) + W(IVX,k,j,i))*fvx +
+                                                           (W(IVY,k,j,i-1) + W(IVY,k,j,i))*fvy +
+                                                           (W(IVZ,k,j,i-1) + W(IVZ,k,j,i))*fvz);
+      }
+    if (!g.multi_d) continue;
+    for (int k = g.ks; k <= g.ke; ++k) for (int j = g.js; j <= g.je+1; ++j)
+      for (int i = g.is; i <= g.ie; ++i) {
+        double fvx = (W(IVX,k,j,i) - W(IVX,k,j-1,i))/dx2 +
+                     ((W(IVY,k,j,i+1) + W(IVY,k,j-1,i+1)) - (W(IVY,k,j,i-1) + W(IVY,k,j-1,i-1)))/(4.0*dx1);
+        double fvy = (W(IVY,k,j,i) - W(IVY,k,j-1,i))*4.0/(3.0*dx2) -
+                     ((W(IVX,k,j,i+1) + W(IVX,k,j-1,i+1)) - (W(IVX,k,j,i-1) + W(IVX,k,j-1,i-1)))/(6.0*dx1);
+        double fvz = (W(IVZ,k,j,i) - W(IVZ,k,j-1,i))/dx2;
+        if (g.three_d) {
+          fvy -= ((W(IVZ,k+1,j,i) + W(IVZ,k+1,j-1,i)) - (W(IVZ,k-1,j,i) + W(IVZ,k-1,j-1,i)))/(6.0*dx3);
+          fvz += ((W(IVY,k+1,j,i) + W(IVY,k+1,j-1,i)) - (W(IVY,k-1,j,i) + W(IVY,k-1,j-1,i)))/(4.0*dx3);
+        }
+        double nud = 0.5*nu_iso*(W(IDN,k,j,i) + W(IDN,k,j-1,i));
+        flx2[ix5(nv,N3,N2+fs,N1,m,IVX,k,j,i)] -= nud*fvx;
+        flx2[ix5(nv,N3,N2+fs,N1,m,IVY,k,j,i)] -= nud*fvy;
+        flx2[ix5(nv,N3,N2+fs,N1,m,IVZ,k,j,i)] -= nud*fvz;
+        if (ideal)
+          flx2[ix5(nv,N3,N2+fs,N1,m,IEN,k,j,i)] -= 0.5*nud*((W(IVX,k,j-1,i) + W(IVX,k,j,i))*fvx +
+                                                           (W(IVY,k,j-1,i) + W(IVY,k,j,i))*fvy +
+                                                           (W(IVZ,k,j-1,i) + W(IVZ,k,j,i))*fvz);
+      }
+    if (!g.three_d) continue;
+    for (int k = g.ks; k <= g.ke+1; ++k) for (int j = g.js; j <= g.je; ++j)
+      for (int i = g.is; i <= g.ie; ++i) {
+        double fvx = (W(IVX,k,j,i) - W(IVX,k-1,j,i))/dx3 +
+                     ((W(IVZ,k,j,i+1) + W(IVZ,k-1,j,i+1)) - (W(IVZ,k,j,i-1) + W(IVZ,k-1,j,i-1)))/(4.0*dx1);
+        double fvy = (W(IVY,k,j,i) - W(IVY,k-1,j,i))/dx3 +
+                     ((W(IVZ,k,j+1,i) + W(IVZ,k-1,j+1,i)) - (W(IVZ,k,j-1,i) + W(IVZ,k-1,j-1,i)))/(4.0*dx2);
+        double fvz = (W(IVZ,k,j,i) - W(IVZ,k-1,j,i))*4.0/(3.0*dx3) -
+                     ((W(IVX,k,j,i+1) + W(IVX,k-1,j,i+1)) - (W(IVX,k,j,i-1) + W(IVX,k-1,j,i-1)))/(6.0*dx1) -
+                     ((W(IVY,k,j+1,i) + W(IVY,k-1,j+1,i)) - (W(IVY,k,j-1,i) + W(IVY,k-1,j-1,i)))/(6.0*dx2);
+        double nud = 0.5*nu_iso*(W(IDN,k,j,i) + W(IDN,k-1,j,i));
+        flx3[ix5(nv,N3+fs,N2,N1,m,IVX,k,j,i)] -= nud*fvx;
+        flx3[ix5(nv,N3+fs,N2,N1,m,IVY,k,j,i)] -= nud*fvy;
+        flx3[ix5(nv,N3+fs,N2,N1,m,IVZ,k,j,i)] -= nud*fvz;
+        if (ideal)
+          flx3[ix5(nv,N3+fs,N2,N1,m,IEN,k,j,i)] -= 0.5*nud*((W(IVX,k-1,j,i) + W(IVX,k,j,i))*fvx +
+                                                           (W(IVY,k-1,j,i) + W(IVY,k,j,i))*fvy +
+                                                           (W(IVZ,k-1,j,i) + W(IVZ,k,j,i))*fvz);
+      }
+  }
+  return 0;
+}
+
+/* Conduction::AddHeatFluxIso, src/diffusion/conduction.cpp:106-152 (constant diffusivity) */
+int akref_heat_fluxes(const akmi_pack *p, double alpha_iso, const double *w0, double *flx1,
+                      double *flx2, double *flx3, int fs) {
+  G g = mkG(p);
+  if (!p->is_ideal) return AKMI_FAIL;
+  const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  const double gm1 = p->gamma - 1.0;
+  for (int m = 0; m < g.nmb; ++m) {
+    const double dx1 = p->dx[3*m], dx2 = p->dx[3*m+1], dx3 = p->dx[3*m+2];
+    for (int k = g.ks; k <= g.ke; ++k) for (int j = g.js; j <= g.je; ++j)
+      for (int i = g.is; i <= g.ie+1; ++i) {
+        double tempr = W(IEN,k,j,i)/W(IDN,k,j,i);
+        double templ = W(IEN,k,j,i-1)/W(IDN,k,j,i-1);
+        double dtempdx = (tempr - templ) * gm1 / dx1;
+        double densf = 0.5*(W(IDN,k,j,i) + W(IDN,k,j,i-1));
+        flx1[ix5(nv,N3,N2,N1+fs,m,IEN,k,j,i)] -= alpha_iso * densf * dtempdx;
+      }
+    if (!g.multi_d) continue;
+    for (int k = g.ks; k <= g.ke; ++k) for (int j = g.js; j <= g.je+1; ++j)
+      for (int i = g.is; i <= g.ie; ++i) {
+        double tempr = W(IEN,k,j,i)/W(IDN,k,j,i);
+        double templ = W(IEN,k,j-1,i)/W(IDN,k,j-1,i);
+        double dtempdx = (tempr - templ) * gm1 / dx2;
+        double densf = 0.5*(W(IDN,k,j,i) + W(IDN,k,j-1,i));
+        flx2[ix5(nv,N3,N2+fs,N1,m,IEN,k,j,i)] -= alpha_iso * densf * dtempdx;
+      }
+    if (!g.three_d) continue;
+    for (int k = g.ks; k <= g.ke+1; ++k) for (int j = g.js; j <= g.je; ++j)
+      for (int i = g.is; i <= g.ie; ++i) {
+        double tempr = W(IEN,k,j,i)/W(IDN,k,j,i);
+        double templ = W(IEN,k-1,j,i)/W(IDN,k-1,j,i);
+        double dtempdx = (tempr - templ) * gm1 / dx3;
+        double densf = 0.5*(W(IDN,k,j,i) + W(IDN,k-1,j,i));
+        flx3[ix5(nv,N3+fs,N2,N1,m,IEN,k,j,i)] -= alpha_iso * densf * dtempdx;
+      }
+  }
+  return 0;
+}
+
+/* Conduction::NewTimeStep, src/diffusion/conduction.cpp:314-377: the cell reduction (before *fac) */
+int akref_conduction_newdt(const akmi_pack *p, double alpha_iso, const double *w0, double *dtmin) {
+  G g = mkG(p);
+  const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  const double gm1 = p->gamma - 1.0;
+  double min_dt = (double)FLT_MAX;
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = g.ks; k <= g.ke; ++k) for (int j = g.js; j <= g.je; ++j)
+      for (int i = g.is; i <= g.ie; ++i) {
+        min_dt = fmin(min_dt, SQR(p->dx[3*m])/alpha_iso*W(IDN,k,j,i)/gm1);
+        if (g.multi_d) min_dt = fmin(min_dt, SQR(p->dx[3*m+1])/alpha_iso*W(IDN,k,j,i)/gm1);
+        if (g.three_d) min_dt = fmin(min_dt, SQR(p->dx[3*m+2])/alpha_iso*W(IDN,k,j,i)/gm1);
+      }
+  *dtmin = min_dt;
+  return 0;
+}
+#undef W
+
+/* Resistivity::AddEMFConstantResist, src/diffusion/resistivity.cpp:78-177 + CurrentDensity
+ * (src/diffusion/current_density.hpp:30-57): E += eta_ohm * J on the cell edges */
+int akref_resistive_emfs(const akmi_pack *p, double eta_ohm, const double *bx1f, const double *bx2f,
+                         const double *bx3f, double *e1, double *e2, double *e3) {
+  G g = mkG(p);
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
+#define B1(k,j,i) bx1f[ix4(N3,N2,N1+1,m,(k),(j),(i))]
+#define B2(k,j,i) bx2f[ix4(N3,N2+1,N1,m,(k),(j),(i))]
+#define B3(k,j,i) bx3f[ix4(N3+1,N2,N1,m,(k),(j),(i))]
+#define E1(k,j,i) e1[ix4(N3+1,N2+1,N1,m,(k),(j),(i))]
+#define E2(k,j,i) e2[ix4(N3+1,N2,N1+1,m,(k),(j),(i))]
+#define E3(k,j,i) e3[ix4(N3,N2+1,N1+1,m,(k),(j),(i))]
+  for (int m = 0; m < g.nmb; ++m) {
+    const double dx1 = p->dx[3*m], dx2 = p->dx[3*m+1], dx3 = p->dx[3*m+2];
+    const int kl = g.ks, ku = g.three_d ? g.ke+1 : g.ks;
+    const int jl = g.js, ju = g.multi_d ? g.je+1 : g.js;
+    for (int k = kl; k <= ku; ++k) for (int j = jl; j <= ju; ++j)
+      for (int i = g.is; i <= g.ie+1; ++i) {
+        double j1 = 0.0;
+        double j2 = -(B3(k,j,i) - B3(k,j,i-1))/dx1;
+        double j3 =  (B2(k,j,i) - B2(k,j,i-1))/dx1;
+        if (g.multi_d) {
+          j1 += (B3(k,j,i) - B3(k,j-1,i))/dx2;
+          j3 -= (B1(k,j,i) - B1(k,j-1,i))/dx2;
+        }
+        if (g.three_d) {
+          j1 -= (B2(k,j,i) - B2(k-1,j,i))/dx3;
+          j2 += (B1(k,j,i) - B1(k-1,j,i))/dx3;
+        }
+        if (g.three_d) {
+          E1(k,j,i) += eta_ohm*j1; E2(k,j,i) += eta_ohm*j2; E3(k,j,i) += eta_ohm*j3;
+        } else if (g.multi_d) {                    /* :124-149 */
+          E1(g.ks,j,i) += eta_ohm*j1; E1(g.ke+1,j,i) += eta_ohm*j1;
+          E2(g.ks,j,i) += eta_ohm*j2; E2(g.ke+1,j,i) += eta_ohm*j2;
+          E3(g.ks,j,i) += eta_ohm*j3;
+        } else {                                   /* :93-121 */
+          E2(g.ks,g.js,i) += eta_ohm*j2; E2(g.ke+1,g.js,i) += eta_ohm*j2;
+          E3(g.ks,g.js,i) += eta_ohm*j3; E3(g.ks,g.je+1,i) += eta_ohm*j3;
+        }
+      }
+  }
+  return 0;
+}
+
+/* Resistivity::AddFluxConstantResist, src/diffusion/resistivity.cpp:185-272: Poynting flux of the
+ * resistive field added to the (face-shaped) energy flux */
+int akref_resistive_fluxes(const akmi_pack *p, double eta_ohm, const double *bx1f, const double *bx2f,
+                           const double *bx3f, double *flx1, double *flx2, double *flx3) {
+  G g = mkG(p);
+  if (!p->is_ideal) return AKMI_FAIL;
+  const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  const double qa = 0.25*eta_ohm;
+  for (int m = 0; m < g.nmb; ++m) {
+    const double dx1 = p->dx[3*m], dx2 = p->dx[3*m+1], dx3 = p->dx[3*m+2];
+    for (int k = g.ks; k <= g.ke; ++k) for (int j = g.js; j <= g.je; ++j)
+      for (int i = g.is; i <= g.ie+1; ++i) {
+        double j2k   = -(B3(k,j,i) - B3(k,j,i-1))/dx1;
+        double j2kp1 = -(B3(k+1,j,i) - B3(k+1,j,i-1))/dx1;
+        double j3j   = (B2(k,j,i) - B2(k,j,i-1))/dx1;
+        double j3jp1 = (B2(k,j+1,i) - B2(k,j+1,i-1))/dx1;
+        if (g.multi_d) {
+          j3j   -= (B1(k,j,i) - B1(k,j-1,i))/dx2;
+          j3jp1 -= (B1(k,j+1,i) - B1(k,j,i))/dx2;
+        }
+        if (g.three_d) {
+          j2k   += (B1(k,j,i) - B1(k-1,j,i))/dx3;
+          j2kp1 += (B1(k+1,j,i) - B1(k,j,i))/dx3;
+        }
+        flx1[ix5(nv,N3,N2,N1+1,m,IEN,k,j,i)] += qa*(j2k  *(B3(k,j,i) + B3(k,j,i-1)) +
+                                                   j2kp1*(B3(k+1,j,i) + B3(k+1,j,i-1)) -
+                                                   j3j  *(B2(k,j,i) + B2(k,j,i-1)) -
+                                                   j3jp1*(B2(k,j+1,i) + B2(k,j+1,i-1)));
+      }
+    if (!g.multi_d) continue;
+    for (int k = g.ks; k <= g.ke; ++k) for (int j = g.js; j <= g.je+1; ++j)
+      for (int i = g.is; i <= g.ie; ++i) {
+        double j1k   = (B3(k,j,i) - B3(k,j-1,i))/dx2;
+        double j1kp1 = (B3(k+1,j,i) - B3(k+1,j-1,i))/dx2;
+        double j3i   = (B2(k,j,i) - B2(k,j,i-1))/dx1 - (B1(k,j,i) - B1(k,j-1,i))/dx2;
+        double j3ip1 = (B2(k,j,i+1) - B2(k,j,i))/dx1 - (B1(k,j,i+1) - B1(k,j-1,i+1))/dx2;
+        if (g.three_d) {
+          j1k   -= (B2(k,j,i) - B2(k-1,j,i))/dx3;
+          j1kp1 -= (B2(k+1,j,i) - B2(k,j,i))/dx3;
+        }
+        flx2[ix5(nv,N3,N2+1,N1,m,IEN,k,j,i)] += qa*(j3i  *(B1(k,j,i) + B1(k,j-1,i)) +
+                                                   j3ip1*(B1(k,j,i+1) + B1(k,j-1,i+1)) -
+                                                   j1k  *(B3(k,j,i) + B3(k,j-1,i)) -
+                                                   j1kp1*(B3(k+1,j,i) + B3(k+1,j-1,i)));
+      }
+    if (!g.three_d) continue;
+    for (int k = g.ks; k <= g.ke+1; ++k) for (int j = g.js; j <= g.je; ++j)
+      for (int i = g.is; i <= g.ie; ++i) {
+        double j1j   = (B3(k,j,i) - B3(k,j-1,i))/dx2 - (B2(k,j,i) - B2(k-1,j,i))/dx3;
+        double j1jp1 = (B3(k,j+1,i) - B3(k,j,i))/dx2 - (B2(k,j+1,i) - B2(k-1,j+1,i))/dx3;
+        double j2i   = -(B3(k,j,i) - B3(k,j,i-1))/dx1 + (B1(k,j,i) - B1(k-1,j,i))/dx3;
+        double j2ip1 = -(B3(k,j,i+1) - B3(k,j,i))/dx1 + (B1(k,j,i+1) - B1(k-1,j,i+1))/dx3;
+        flx3[ix5(nv,N3+1,N2,N1,m,IEN,k,j,i)] += qa*(j1j  *(B2(k,j,i) + B2(k-1,j,i)) +
+                                                   j1jp1*(B2(k,j+1,i) + B2(k-1,j+1,i)) -
+                                                   j2i  *(B1(k,j,i) + B1(k-1,j,i)) -
+                                                   j2ip1*(B1(k,j,i+1) + B1(k-1,j,i+1)));
+      }
+  }
+  return 0;
+}
+#undef B1
+#undef B2
+#undef B3
+#undef E1
+#undef E2
+#undef E3
+
 /* History sums, src/outputs/history.cpp:78-160 (hydro), 272-374 (MHD); sequential (m,k,j,i) */
 int akref_history_sums(const akmi_pack *p, int is_mhd, const double *u0, const double *bx1f,
                        const double *bx2f, const double *bx3f, double *out) {

@@ -27,6 +27,7 @@ struct akref_sim {
   double *bcc0, *b0[3], *b1[3], *efc[6], *e[3];
   size_t ncc, nf[3], ne[3], nfl[3];
   double time, dt, dtnew, tlim;
+  double dt_visc, dt_cond, dt_resist;   /* Viscosity/Conduction/Resistivity::dtnew */
   int nv;                          /* nhydro|nmhd: 5 ideal gas, 4 isothermal */
   int ncycle;
   int counters[3];
@@ -732,12 +733,36 @@ static void new_dt_task(akref_sim *s) {
   if (s->multi_d) dtnew = fmin(dtnew, d3[1]);
   if (s->three_d) dtnew = fmin(dtnew, d3[2]);
   s->dtnew = dtnew;
+  /* diffusive limits: viscosity.cpp:232-251, conduction.cpp:314-377, resistivity.cpp:291-311 */
+  const akref_params *p = &s->par;
+  const double fac = s->three_d ? 1.0/6.0 : (s->multi_d ? 0.25 : 0.5);
+  s->dt_visc = s->dt_cond = s->dt_resist = (double)FLT_MAX;
+  for (int m = 0; m < s->nmb; ++m) {
+    const double *dx = s->dx + 3*m;
+    if (p->nu_iso != 0.0) {
+      s->dt_visc = fmin(s->dt_visc, fac*(dx[0]*dx[0])/p->nu_iso);
+      if (s->multi_d) s->dt_visc = fmin(s->dt_visc, fac*(dx[1]*dx[1])/p->nu_iso);
+      if (s->three_d) s->dt_visc = fmin(s->dt_visc, fac*(dx[2]*dx[2])/p->nu_iso);
+    }
+    if (p->is_mhd && p->eta_ohm > 0.0) {
+      s->dt_resist = fmin(s->dt_resist, fac*(dx[0]*dx[0])/p->eta_ohm);
+      if (s->multi_d) s->dt_resist = fmin(s->dt_resist, fac*(dx[1]*dx[1])/p->eta_ohm);
+      if (s->three_d) s->dt_resist = fmin(s->dt_resist, fac*(dx[2]*dx[2])/p->eta_ohm);
+    }
+  }
+  if (p->alpha_iso != 0.0) {
+    akref_conduction_newdt(&s->pack, p->alpha_iso, s->w0, &s->dt_cond);
+    s->dt_cond *= fac;
+  }
 }
 
 /* Mesh::NewTimeStep, src/mesh/mesh.cpp:573-643 */
 static void mesh_new_dt(akref_sim *s) {
   s->dt = 2.0*s->dt;
   s->dt = fmin(s->dt, s->par.cfl*s->dtnew);
+  if (s->par.nu_iso != 0.0) s->dt = fmin(s->dt, s->par.cfl*s->dt_visc);
+  if (s->par.is_mhd && s->par.eta_ohm != 0.0) s->dt = fmin(s->dt, s->par.cfl*s->dt_resist);
+  if (s->par.alpha_iso != 0.0) s->dt = fmin(s->dt, s->par.cfl*s->dt_cond);
   if ((s->time < s->tlim) && ((s->time + s->dt) > s->tlim)) s->dt = s->tlim - s->time;
 }
 
@@ -777,23 +802,31 @@ int akref_step(akref_sim *s) {
         akref_copy_cons(pk, s->u0, s->u1);
         for (int q = 0; q < 3; ++q) memcpy(s->b1[q], s->b0[q], sizeof(double)*s->nf[q]);
       }
-      if (p->fofc) {               /* mhd_tasks.cpp:177-214 with use_fofc */
+      if (p->fofc)
         akref_mhd_fluxes_fofc(pk, p->recon, p->rsolver, s->w0, s->bcc0, s->b0[0], s->b0[1], s->b0[2],
                               s->flx1, s->flx2, s->flx3, s->efc[0], s->efc[1], s->efc[2], s->efc[3],
                               s->efc[4], s->efc[5]);
+      else
+        akref_mhd_fluxes(pk, p->recon, p->rsolver, s->w0, s->bcc0, s->b0[0], s->b0[1], s->b0[2],
+                         s->flx1, s->flx2, s->flx3, s->efc[0], s->efc[1], s->efc[2], s->efc[3],
+                         s->efc[4], s->efc[5]);
+      /* diffusion fluxes, then FOFC: mhd_tasks.cpp:198-211 */
+      if (p->alpha_iso != 0.0) akref_heat_fluxes(pk, p->alpha_iso, s->w0, s->flx1, s->flx2, s->flx3, 1);
+      if (p->nu_iso != 0.0) akref_viscous_fluxes(pk, p->nu_iso, s->w0, s->flx1, s->flx2, s->flx3, 1);
+      if (p->eta_ohm != 0.0 && p->is_ideal)
+        akref_resistive_fluxes(pk, p->eta_ohm, s->b0[0], s->b0[1], s->b0[2], s->flx1, s->flx2, s->flx3);
+      if (p->fofc) {               /* mhd_tasks.cpp:209-211 */
         akref_mhd_fofc(pk, gam0, gam1, beta_dt, s->w0, s->bcc0, s->b0[0], s->b0[1], s->b0[2],
                        s->b1[0], s->b1[1], s->b1[2], s->u0, s->u1, s->flx1, s->flx2, s->flx3,
                        s->efc[0], s->efc[1], s->efc[2], s->efc[3], s->efc[4], s->efc[5], s->fofc,
                        &s->nfofc);
-      } else {
-      akref_mhd_fluxes(pk, p->recon, p->rsolver, s->w0, s->bcc0, s->b0[0], s->b0[1], s->b0[2],
-                       s->flx1, s->flx2, s->flx3, s->efc[0], s->efc[1], s->efc[2], s->efc[3],
-                       s->efc[4], s->efc[5]);
       }
       akref_rk_update(pk, gam0, gam1, beta_dt, s->u0, s->u1, s->flx1, s->flx2, s->flx3, 1);
       akref_mhd_corner_e(pk, s->w0, s->bcc0, s->efc[0], s->efc[1], s->efc[2], s->efc[3],
                          s->efc[4], s->efc[5], s->flx1, s->flx2, s->flx3, s->e[0], s->e[1],
                          s->e[2]);
+      if (p->eta_ohm != 0.0)         /* MHD::EField, mhd_tasks.cpp:381-383 */
+        akref_resistive_emfs(pk, p->eta_ohm, s->b0[0], s->b0[1], s->b0[2], s->e[0], s->e[1], s->e[2]);
       /* SendE/RecvE: on a uniform mesh every shared edge EMF is computed identically by
        * both owners, (a+a)*0.5==a: numerically a no-op. */
       akref_mhd_ct(pk, gam0, gam1, beta_dt, s->e[0], s->e[1], s->e[2], s->b0[0], s->b0[1],
@@ -802,13 +835,14 @@ int akref_step(akref_sim *s) {
       /* stagen chain, src/hydro/hydro_tasks.cpp:55-71 */
       if (stage == 1) akref_copy_cons(pk, s->u0, s->u1);
       else if (p->nstages == 4) akref_rk4_copy_cons(pk, s->delta[stage-1], s->u0, s->u1);
-      if (p->fofc) {              /* hydro_tasks.cpp:159-201 with use_fofc */
-        akref_hydro_fluxes_fofc(pk, p->recon, p->rsolver, s->w0, s->flx1, s->flx2, s->flx3, 0);
+      if (p->fofc) akref_hydro_fluxes_fofc(pk, p->recon, p->rsolver, s->w0, s->flx1, s->flx2, s->flx3, 0);
+      else akref_hydro_fluxes(pk, p->recon, p->rsolver, s->w0, s->flx1, s->flx2, s->flx3, 0);
+      /* diffusion fluxes, then FOFC: hydro_tasks.cpp:183-199 */
+      if (p->alpha_iso != 0.0) akref_heat_fluxes(pk, p->alpha_iso, s->w0, s->flx1, s->flx2, s->flx3, 0);
+      if (p->nu_iso != 0.0) akref_viscous_fluxes(pk, p->nu_iso, s->w0, s->flx1, s->flx2, s->flx3, 0);
+      if (p->fofc)
         akref_hydro_fofc(pk, gam0, gam1, beta_dt, s->w0, s->u0, s->u1, s->flx1, s->flx2, s->flx3, 0,
                          s->fofc, &s->nfofc);
-      } else {
-        akref_hydro_fluxes(pk, p->recon, p->rsolver, s->w0, s->flx1, s->flx2, s->flx3, 0);
-      }
       akref_rk_update(pk, gam0, gam1, beta_dt, s->u0, s->u1, s->flx1, s->flx2, s->flx3, 0);
     }
     halo_bcs_c2p(s);

@@ -71,6 +71,9 @@ def oracle_kwargs(pin):
     for fl in ("dfloor", "pfloor", "tfloor", "sfloor", "sigma_max"):
         if pin.DoesParameterExist(blk, fl):
             kw[fl] = g(blk, fl)
+    for dc in ("nu_iso", "alpha_iso", "eta_ohm"):
+        if pin.DoesParameterExist(blk, dc):
+            kw[dc] = g(blk, dc)
     if pin.DoesParameterExist(blk, "fofc") and pin.GetBoolean(blk, "fofc"):
         kw["fofc"] = 1
     name = gs("problem", "pgen_name")
@@ -130,7 +133,7 @@ def oracle_arrays(osim, is_mhd):
     return d
 
 
-def make_pair(problem, n, dims, mb=None, inject=True, fused=None, native=False, **kw):
+def make_pair(problem, n, dims, mb=None, inject=True, fused=None, native=False, params=None, **kw):
     """(product Simulation, oracle Sim) advanced to the end of Driver::Initialize on
     identical initial data (inject=True copies the oracle's pgen output into the product so
     that libm-vs-numpy sin/cos ulps cannot enter the comparison)."""
@@ -138,9 +141,11 @@ def make_pair(problem, n, dims, mb=None, inject=True, fused=None, native=False, 
     from athenak_amd.main import Simulation, load_deck
     deck, ov = deck_overrides(problem, n, dims, mb, **kw)
     pin = load_deck(deck, ov)
+    blk = "mhd" if pin.DoesBlockExist("mhd") else "hydro"
     if fused is not None:
-        blk = "mhd" if pin.DoesBlockExist("mhd") else "hydro"
         pin.blocks[blk]["fused_stage"] = "true" if fused else "false"
+    for name, val in (params or {}).items():       # parameters absent from the decks (e.g. nu_iso:
+        pin.blocks[blk][name] = repr(val)           # their presence alone creates the diffusion objects)
     okw = oracle_kwargs(pin)
     osim = akref.Sim(**okw)
     if native:

@@ -157,6 +157,36 @@ def test_fofc_is_bit_identical(case, native):
     assert sim.pmesh.time == osim.time and d["bitwise_equal"], d
 
 
+DIFFUSION = [
+    # viscosity + conduction, hydro: 1-D (cell-shaped flux arrays), 2-D, 3-D multi-block
+    ("linear_wave_hydro", 64, 1, 32, 12, dict(rsolver="hllc"), dict(nu_iso=0.01, alpha_iso=0.02)),
+    ("sod", 32, 2, 16, 6, dict(cfl=0.3, rsolver="hlle"), dict(nu_iso=0.005, alpha_iso=0.01)),
+    ("sod", 24, 3, 12, 4, dict(cfl=0.3, rsolver="hllc", recon="ppm4", ng=3), dict(nu_iso=0.004, alpha_iso=0.003)),
+    ("sod", 24, 3, 12, 4, dict(cfl=0.3, rsolver="roe", ng=3, extra=("hydro/fofc=true",)), dict(nu_iso=0.004)),
+    # viscosity + conduction + Ohmic resistivity, MHD (face-shaped fluxes, edge EMFs) in 1-D/2-D/3-D
+    ("linear_wave_mhd", 64, 1, 32, 10, dict(rsolver="hlld"), dict(nu_iso=0.01, alpha_iso=0.01, eta_ohm=0.02)),
+    ("orszag_tang", 32, 2, 16, 6, dict(rsolver="hlld"), dict(eta_ohm=0.002, nu_iso=0.002)),
+    ("orszag_tang", 24, 3, 12, 4, dict(rsolver="hlle", cfl=0.3), dict(eta_ohm=0.002, alpha_iso=0.004)),
+    ("blast", 24, 3, 12, 4, dict(rsolver="hlld"), dict(eta_ohm=0.003, nu_iso=0.003, alpha_iso=0.003)),
+    ("linear_wave_mhd", 32, 2, (16, 32), 5, dict(rsolver="hlld", extra=("mhd/eos=isothermal",)),
+     dict(eta_ohm=0.003, nu_iso=0.003)),
+]
+
+
+@pytest.mark.parametrize("case", DIFFUSION, ids=lambda c: "%s-%d^%d-%s" % (c[0], c[1], c[2], "+".join(sorted(c[6]))))
+def test_diffusion_hooks_are_bit_identical(case):
+    """akmi_viscous_fluxes / akmi_heat_fluxes / akmi_resistive_fluxes / akmi_resistive_emfs /
+    akmi_conduction_newdt inside the task chain, and the diffusive time-step limits"""
+    problem, n, dims, mb, cycles, kw, params = case
+    sim, osim, is_mhd = pu.make_pair(problem, n, dims, mb, params=params, **kw)
+    assert sim.pmesh.dt == osim.dt
+    for _ in range(cycles):
+        assert sim.Execute(max_cycles=1) and osim.step()
+        assert sim.pmesh.dt == osim.dt
+    d = pu.compare_fields(pu.product_arrays(sim), pu.oracle_arrays(osim, is_mhd), is_mhd)
+    assert sim.pmesh.time == osim.time and d["bitwise_equal"], d
+
+
 def _wild_states(shape5, rng, mhd):
     """primitive states with jumps of many decades between neighbouring cells: exercises the
     supersonic branches, the HLLE/HLLC pressure estimates, Roe's negative-density fallback and
