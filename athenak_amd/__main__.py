@@ -1,4 +1,4 @@
-"""python -m athenak_amd -i <deck> [-d <run_dir>] [block/name=value ...]
+"""python -m athenak_amd (-i <deck> | -r <restart file>) [-d <run_dir>] [block/name=value ...]
 
 Command-line entry with the argument conventions of the reference's executable
 (src/main.cpp:61-420: -i input file, -d run directory, trailing block/name=value overrides), so
@@ -13,28 +13,34 @@ import time
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
-    deck, rundir, overrides = None, None, []
+    deck, rundir, overrides, rstfile = None, None, [], None
     i = 0
     while i < len(argv):
         a = argv[i]
         if a == "-i":
             deck = argv[i + 1]; i += 2
+        elif a == "-r":
+            rstfile = argv[i + 1]; i += 2
         elif a == "-d":
             rundir = argv[i + 1]; i += 2
         elif a in ("-h", "--help"):
             print(__doc__)
             return 0
         elif a.startswith("-"):
-            sys.stderr.write("### FATAL ERROR unknown option %s (supported: -i -d -h)\n" % a)
+            sys.stderr.write("### FATAL ERROR unknown option %s (supported: -i -r -d -h)\n" % a)
             return 1
         else:
             overrides.append(a); i += 1
-    if deck is None:
-        sys.stderr.write("### FATAL ERROR no input file: use -i <deck>\n")
+    if deck is None and rstfile is None:
+        sys.stderr.write("### FATAL ERROR Either an input or restart file must be specified: "
+                         "-i <deck> or -r <file>\n")
         return 1
-    from .main import Simulation, load_deck
+    from .main import Simulation, load_deck, load_restart
     from .outputs import Outputs
-    deck = os.path.abspath(deck) if os.path.exists(deck) else deck
+    if deck is not None:
+        deck = os.path.abspath(deck) if os.path.exists(deck) else deck
+    if rstfile is not None:
+        rstfile = os.path.abspath(rstfile)
     if rundir:
         os.makedirs(rundir, exist_ok=True)
         os.chdir(rundir)
@@ -45,11 +51,15 @@ def main(argv=None):
         import torch.distributed as dist
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group(os.environ.get("AKMI_DIST_BACKEND", "nccl"))
-    pin = load_deck(deck, overrides)
-    sim = Simulation(pin, my_rank=rank, nranks=world, initialize=False)
+    if rstfile is not None:
+        sim = load_restart(rstfile, overrides, my_rank=rank, nranks=world, initialize=False)
+        pin = sim.pin
+    else:
+        pin = load_deck(deck, overrides)
+        sim = Simulation(pin, my_rank=rank, nranks=world, initialize=False)
     pm, drv = sim.pmesh, sim.pdriver
     pout = Outputs(pin, pm)
-    drv.Initialize(pm, pin, pout)
+    drv.Initialize(pm, pin, pout, res_flag=rstfile is not None)
     t0 = time.time()
     drv.Execute(pm, pin)
     import torch

@@ -88,8 +88,9 @@ class Driver:
             pmhd.ApplyPhysicalBCs(self, 0)
             pmhd.ConToPrim(self, 0)
 
-    def Initialize(self, pm, pin=None, pout=None):
-        """driver.cpp:314-371; with pout: the initial outputs (driver.cpp:340-346)"""
+    def Initialize(self, pm, pin=None, pout=None, res_flag=False):
+        """driver.cpp:314-371; with pout: the initial outputs (driver.cpp:340-346), which a restarted
+        run does not repeat"""
         self.pout, self.pin_ = pout, pin
         self.InitBoundaryValuesAndPrimitives(pm)
         ph, pmhd = pm.pmb_pack.phydro, pm.pmb_pack.pmhd
@@ -99,7 +100,7 @@ class Driver:
             pmhd.NewTimeStep(self, self.nexp_stages)
         pm.NewTimeStep(self.tlim)
         self.nmb_updated_ = 0
-        if pout is not None:
+        if pout is not None and not res_flag:
             pout.MakeOutputs(pm, pin)
 
     def _cycle(self, pm):

@@ -8,9 +8,10 @@ Mirrors, for the file types a hydro/MHD run of this path uses:
   FormattedTableOutput   src/outputs/formatted_table.cpp     (tab/<basename>.<id>.NNNNN.tab)
   HistoryOutput          src/outputs/history.cpp             (<basename>.hydro|mhd.hst)
   MeshBinaryOutput       src/outputs/binary.cpp              (bin/<basename>.<id>.NNNNN.bin)
+  RestartOutput          src/outputs/restart.cpp             (rst/<basename>.NNNNN.rst) + read_restart()
 The volume sums of the history file are reduced on the device (akmi_history_sums); everything
 else here is host-side formatting of arrays copied from the device.  Other file types of the
-reference (vtk, rst, pdf, cart, sph, log, trk, cbin) are rejected loudly.
+reference (vtk, pdf, cart, sph, log, trk, cbin) are rejected loudly.
 """
 import ctypes as C
 import os
@@ -97,7 +98,7 @@ class BaseTypeOutput:
         self.outmbs = []
         self.outarray = None
         pk = pm.pmb_pack
-        if op.file_type not in ("hst",):
+        if op.file_type not in ("hst", "rst"):
             phys = pk.pmhd if pk.pmhd is not None else pk.phydro
             self.outvars = _outvars(op.variable, pk.pmhd is not None, phys.peos.eos_data.is_ideal)
 
@@ -321,12 +322,134 @@ class MeshBinaryOutput(BaseTypeOutput):
         self._advance(pm, pin)
 
 
+class RestartOutput(BaseTypeOutput):
+    """restart.cpp:37-560: one file rst/<basename>.<NNNNN>.rst holding the parameter dump, the mesh
+    header, the logical locations and costs of all MeshBlocks and, per MeshBlock (in gid order,
+    `data_size` bytes each), the full-precision dependent variables INCLUDING ghost zones:
+    [hydro u0][mhd u0][b0.x1f][b0.x2f][b0.x3f].  read_restart() below is the inverse."""
+
+    def __init__(self, pin, pm, op):
+        super().__init__(pin, pm, op)
+        if pin.GetOrAddBoolean(op.block_name, "single_file_per_rank", False):
+            _fatal("single_file_per_rank restart files are not on this path")
+        if pm.my_rank == 0:
+            os.makedirs("rst", exist_ok=True)
+
+    def LoadOutputData(self, pm):
+        """restart.cpp:53-137: everything is taken from the physics arrays at write time"""
+
+    def WriteOutputFile(self, pm, pin):
+        op = self.out_params
+        fname = os.path.join("rst", "%s.%05d.rst" % (op.file_basename, op.file_number))
+        # counters advance first so that the values for the NEXT dump are in the file (restart.cpp:193-200)
+        self._advance(pm, pin)
+        sbuf = pin.ParameterDump().encode()
+        pk = pm.pmb_pack
+        arrays = []               # per physics: list of tensors whose [m] slices form one record
+        if pk.phydro is not None:
+            arrays.append(pk.phydro.u0)
+        if pk.pmhd is not None:
+            arrays += [pk.pmhd.u0, pk.pmhd.b0.x1f, pk.pmhd.b0.x2f, pk.pmhd.b0.x3f]
+        data_size = sum(int(a[0].numel())*8 for a in arrays)
+        header = bytearray()
+        header += struct.pack("<ii", pm.nmb_total, _root_level(pm))
+        header += _pack_region_size(pm.mesh_size, pm.mesh_indcs)
+        header += _pack_region_indcs(pm.mesh_indcs, coarse=False)
+        header += _pack_region_indcs(pm.mb_indcs, coarse=True)
+        header += struct.pack("<ddi", pm.time, pm.dt, pm.ncycle)
+        lev = _root_level(pm)
+        for l in pm.lloc_eachmb:                              # LogicalLocation {lx1,lx2,lx3,level}
+            header += struct.pack("<iiii", l[0], l[1], l[2], lev)
+        header += np.asarray(pm.cost_eachmb, dtype="<f4").tobytes()
+        header += struct.pack("<Q", data_size)
+        base = len(sbuf) + len(header)
+        if pm.my_rank == 0:
+            with open(fname, "wb") as f:
+                f.write(sbuf)
+                f.write(header)
+                f.truncate(base + data_size*pm.nmb_total)
+        _barrier(pm)
+        with open(fname, "r+b") as f:
+            for m in range(pk.nmb_thispack):
+                f.seek(base + data_size*(pk.gids + m))
+                for a in arrays:
+                    f.write(np.ascontiguousarray(_to_numpy(a[m]), dtype="<f8").tobytes())
+        _barrier(pm)
+
+
+def _root_level(pm):
+    """build_tree.cpp:43-44"""
+    nmbmax = max(pm.nmb_rootx1, pm.nmb_rootx2, pm.nmb_rootx3)
+    lev = 0
+    while (1 << lev) < nmbmax:
+        lev += 1
+    return lev
+
+
+def _pack_region_size(ms, ind):
+    """struct RegionSize {x1min,x2min,x3min,x1max,x2max,x3max,dx1,dx2,dx3} (mesh.hpp:25-29)"""
+    dx = ((ms.x1max - ms.x1min)/float(ind.nx1), (ms.x2max - ms.x2min)/float(ind.nx2),
+          (ms.x3max - ms.x3min)/float(ind.nx3))
+    return struct.pack("<9d", ms.x1min, ms.x2min, ms.x3min, ms.x1max, ms.x2max, ms.x3max, *dx)
+
+
+def _pack_region_indcs(ind, coarse):
+    """struct RegionIndcs (mesh.hpp:35-41): 19 ints; the coarse members are only set for MeshBlocks
+    (mesh.cpp:286-330)"""
+    v = [ind.ng, ind.nx1, ind.nx2, ind.nx3, ind.is_, ind.ie, ind.js, ind.je, ind.ks, ind.ke]
+    if coarse:
+        cjs = ind.ng if ind.nx2 > 1 else 0
+        cks = ind.ng if ind.nx3 > 1 else 0
+        v += [ind.cnx1, ind.cnx2, ind.cnx3, ind.ng, ind.ng + ind.cnx1 - 1,
+              cjs, cjs + ind.cnx2 - 1 if ind.nx2 > 1 else 0, cks, cks + ind.cnx3 - 1 if ind.nx3 > 1 else 0]
+    else:
+        v += [0]*9
+    return struct.pack("<19i", *v)
+
+
+_RST_HEADER = 2*4 + 9*8 + 2*19*4 + 2*8 + 4          # restart.cpp:296-297 "step1size" without the dump
+
+
+def read_restart(path):
+    """Inverse of RestartOutput: returns (parameter text, header dict, per-gid record reader).
+    Mirrors ParameterInput::LoadFromFile (stop at <par_end>), Mesh::BuildTreeFromRestart
+    (build_tree.cpp:315-370) and the restart constructor of ProblemGenerator (pgen.cpp:97-330)."""
+    with open(path, "rb") as f:
+        blob = f.read(1 << 16)
+    end = blob.find(b"<par_end>")
+    if end < 0:
+        _fatal("<par_end> is not found in the first 64KBytes of restart file " + path)
+    end = blob.index(b"\n", end) + 1
+    text = blob[:end].decode()
+    with open(path, "rb") as f:
+        f.seek(end)
+        h = f.read(_RST_HEADER)
+        nmb_total, root_level = struct.unpack_from("<ii", h, 0)
+        mesh_size = struct.unpack_from("<9d", h, 8)
+        mesh_indcs = struct.unpack_from("<19i", h, 80)
+        mb_indcs = struct.unpack_from("<19i", h, 156)
+        time, dt, ncycle = struct.unpack_from("<ddi", h, 232)
+        lloc = np.frombuffer(f.read(16*nmb_total), dtype="<i4").reshape(nmb_total, 4).copy()
+        cost = np.frombuffer(f.read(4*nmb_total), dtype="<f4").copy()
+        (data_size,) = struct.unpack("<Q", f.read(8))
+        base = f.tell()
+    hdr = dict(nmb_total=nmb_total, root_level=root_level, mesh_size=mesh_size, mesh_indcs=mesh_indcs,
+               mb_indcs=mb_indcs, time=time, dt=dt, ncycle=ncycle, lloc=lloc, cost=cost,
+               data_size=data_size, data_offset=base)
+
+    def record(gid):
+        with open(path, "rb") as f:
+            f.seek(base + data_size*gid)
+            return np.frombuffer(f.read(data_size), dtype="<f8")
+    return text, hdr, record
+
+
 class Outputs:
     """outputs.cpp:47-304"""
 
     def __init__(self, pin, pm):
         self.pout_list = []
-        num_hst = 0
+        num_hst = num_rst = 0
         for name in list(pin.blocks):
             if not name.startswith("output"):
                 continue
@@ -376,11 +499,16 @@ class Outputs:
                 num_hst += 1
             elif op.file_type == "bin":
                 self.pout_list.insert(0, MeshBinaryOutput(pin, pm, op))
+            elif op.file_type == "rst":
+                # tail end of the list, so that the file counters of the other output types are
+                # up to date in the restart file (outputs.cpp:285-292)
+                self.pout_list.append(RestartOutput(pin, pm, op))
+                num_rst += 1
             else:
                 _fatal("Unrecognized or unsupported file format = '%s' in output block '%s' "
-                       "(tab, hst, bin on this path)" % (op.file_type, name))
-        if num_hst > 1:
-            _fatal("More than one history output block found in input file")
+                       "(tab, hst, bin, rst on this path)" % (op.file_type, name))
+        if num_hst > 1 or num_rst > 1:
+            _fatal("More than one history or restart output block found in input file")
 
     def MakeOutputs(self, pm, pin):
         for out in self.pout_list:

@@ -131,7 +131,10 @@ def MHDEigensystemPrimIso(d, v1, b1, b2, b3, y, iso_cs):
 
 
 class ProblemGenerator:
-    def __init__(self, pin, pmesh):
+    def __init__(self, pin, pmesh, restart=False):
+        """restart=True: the restart constructor (src/pgen/pgen.cpp:97-330) -- the dependent
+        variables were read from the rst file, the problem function only re-registers its
+        final-work function"""
         self.pmy_mesh_ = pmesh
         self.pin = pin
         self.pgen_final_func = None
@@ -143,7 +146,7 @@ class ProblemGenerator:
         if name not in table:
             raise RuntimeError("### FATAL ERROR problem/pgen_name = '%s' is not one of the "
                                "decks on this build's path %s" % (name, sorted(table)))
-        table[name](pin, False)
+        table[name](pin, restart)
 
     # ---- helpers -------------------------------------------------------------------
     def _phys(self):
@@ -233,6 +236,8 @@ class ProblemGenerator:
     def LinearWave(self, pin, restart):
         pm = self.pmy_mesh_
         self.pgen_final_func = self.LinearWaveErrors
+        if restart:                                      # linear_wave.cpp:247
+            return
         along_x1 = pin.GetOrAddBoolean("problem", "along_x1", False)
         along_x2 = pin.GetOrAddBoolean("problem", "along_x2", False)
         along_x3 = pin.GetOrAddBoolean("problem", "along_x3", False)
@@ -435,6 +440,8 @@ class ProblemGenerator:
 
     # ---- shock tube ----------------------------------------------------------------
     def ShockTube(self, pin, restart):
+        if restart:                                      # shock_tube.cpp:41
+            return
         pm = self.pmy_mesh_
         shk_dir = pin.GetInteger("problem", "shock_dir")
         if shk_dir < 1 or shk_dir > 3:
@@ -489,6 +496,8 @@ class ProblemGenerator:
 
     # ---- Orszag-Tang ---------------------------------------------------------------
     def OrszagTang(self, pin, restart):
+        if restart:                                      # orszag_tang.cpp:43
+            return
         pm = self.pmy_mesh_
         if pm.pmb_pack.pmhd is None:
             raise RuntimeError("### FATAL ERROR Orszag-Tang test can only be run in MHD, but no "
@@ -538,6 +547,8 @@ class ProblemGenerator:
 
     # ---- blast (user problem in the reference: -D PROBLEM=fluids/blast) --------------
     def UserProblem(self, pin, restart):
+        if restart:
+            return
         pm = self.pmy_mesh_
         phys = self._phys()
         is_mhd = pm.pmb_pack.pmhd is not None

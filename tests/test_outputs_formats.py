@@ -184,3 +184,72 @@ def test_history_sums_kernel(is_mhd):
     got = out.cpu().numpy()
     scale = np.abs(ref).max()
     assert np.all(np.abs(got - ref) <= 1e-12*scale), (got, ref)
+
+
+# ---- restart files (src/outputs/restart.cpp, read back by Mesh::BuildTreeFromRestart + the restart
+# constructor of ProblemGenerator) ------------------------------------------------------------------
+def _restart_roundtrip(name, fused):
+    """uninterrupted run with an rst block vs a run restarted from the middle dump (-r): same tab
+    files byte for byte, same bin payload, same final time/cycle"""
+    import struct
+    deck = (oc.SOD_DECK if name == "sod" else oc.OT_DECK).replace("FUSED", "true" if fused else "false")
+    deck += "<output4>\nfile_type = rst\n" + ("dt = 0.05\n" if name == "sod" else "dcycle = 3\n")
+    from athenak_amd.__main__ import main
+    here = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        try:
+            a, b = os.path.join(d, "full"), os.path.join(d, "resumed")
+            os.makedirs(a)
+            with open(os.path.join(a, "deck.athinput"), "w") as f:
+                f.write(deck)
+            assert main(["-i", os.path.join(a, "deck.athinput"), "-d", a]) == 0
+            base = "Sod" if name == "sod" else "OrszagTang"
+            rst = sorted(os.listdir(os.path.join(a, "rst")))
+            # initial dump, one in the middle (t = 0.05 / cycle 3), [cycle 6,] final dump of Driver::Finalize
+            assert rst == ["%s.%05d.rst" % (base, q) for q in range(3 if name == "sod" else 4)]
+            # layout (restart.cpp:203-246): dump text, then nmb_total, root_level, RegionSize, 2 x RegionIndcs,
+            # time, dt, ncycle, LogicalLocation[nmb], float cost[nmb], uint64 data_size, records
+            blob = open(os.path.join(a, "rst", rst[1]), "rb").read()
+            p = blob.index(b"<par_end>\n") + len(b"<par_end>\n")
+            nmb, lev = struct.unpack_from("<ii", blob, p)
+            ng, nx1, nx2, nx3 = struct.unpack_from("<4i", blob, p + 8 + 72 + 76)
+            t, dt, ncyc = struct.unpack_from("<ddi", blob, p + 8 + 72 + 152)
+            (dsz,) = struct.unpack_from("<Q", blob, p + 252 + 20*nmb)
+            n1, n2, n3 = nx1 + 2*ng, (nx2 + 2*ng if nx2 > 1 else 1), (nx3 + 2*ng if nx3 > 1 else 1)
+            if name == "sod":
+                assert (nmb, lev, ng, nx1) == (2, 1, 2, 32) and dsz == 8*5*n1
+            else:
+                assert (nmb, lev, nx1, nx2, nx3, ncyc) == (4, 1, 8, 8, 8, 3)
+                assert dsz == 8*(5*n3*n2*n1 + n3*n2*(n1 + 1) + n3*(n2 + 1)*n1 + (n3 + 1)*n2*n1)
+            assert len(blob) == p + 252 + 20*nmb + 8 + dsz*nmb and t > 0.0 and dt > 0.0
+            os.chdir(here)
+            assert main(["-r", os.path.join(a, "rst", rst[1]), "-d", b]) == 0
+        finally:
+            os.chdir(here)
+        # files written after the restart point exist in both runs and agree
+        tabs = sorted(os.listdir(os.path.join(b, "tab")))
+        assert tabs and set(tabs) <= set(os.listdir(os.path.join(a, "tab")))
+        for fn in tabs:
+            assert filecmp.cmp(os.path.join(a, "tab", fn), os.path.join(b, "tab", fn), shallow=False), fn
+        bins = sorted(os.listdir(os.path.join(b, "bin")))
+        assert bins
+        for fn in bins:
+            pa, pb = _bin_parts(os.path.join(a, "bin", fn)), _bin_parts(os.path.join(b, "bin", fn))
+            assert pa[0] == pb[0] and pa[2] == pb[2], fn
+        # the last restart dump of both runs holds the same state
+        ra = open(os.path.join(a, "rst", rst[-1]), "rb").read()
+        rb = open(os.path.join(b, "rst", rst[-1]), "rb").read()
+        qa, qb = ra.index(b"<par_end>\n"), rb.index(b"<par_end>\n")
+        assert ra[qa:] == rb[qb:]
+
+
+@pytest.mark.parametrize("case", ["sod", "ot"])
+def test_restart_files_roundtrip(case, cpu_oracle_backend):
+    _restart_roundtrip(case, fused=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "split"])
+@pytest.mark.parametrize("case", ["sod", "ot"])
+def test_restart_files_roundtrip_hip(case, fused):
+    _restart_roundtrip(case, fused)
