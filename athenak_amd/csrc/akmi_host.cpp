@@ -300,8 +300,14 @@ void Mesh::NewTimeStep(const Real tlim) {               // mesh.cpp:573-643
   dtold = dt;
   if (dt == static_cast<Real>(FLT_MAX)) dtold = 0.;
   dt = 2.0*dt;
-  if (pmb_pack->phydro) dt = std::min(dt, cfl_no*pmb_pack->phydro->dtnew);
-  if (pmb_pack->pmhd) dt = std::min(dt, cfl_no*pmb_pack->pmhd->dtnew);
+  FluidBase *phys[2] = {pmb_pack->phydro, pmb_pack->pmhd};
+  for (FluidBase *f : phys) {
+    if (!f) continue;
+    dt = std::min(dt, cfl_no*f->dtnew);
+    if (f->has_visc) dt = std::min(dt, cfl_no*f->dt_visc);          // mesh.cpp:589-612
+    if (f->has_resist) dt = std::min(dt, cfl_no*f->dt_resist);
+    if (f->has_cond) dt = std::min(dt, cfl_no*f->dt_cond);
+  }
   if ((time < tlim) && ((time + dt) > tlim)) dt = tlim - time;
 }
 
@@ -317,11 +323,16 @@ static int ReconFlag(const std::string &r) {
 }
 
 FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &blk) : pmy_pack(pp) {
-  if (pin->GetString(blk, "eos") != "ideal") AKMI_FATAL("<" + blk + "> eos must be ideal on this path");
   peos = new EquationOfState;
   EOS_Data &e = peos->eos_data;
-  e.is_ideal = true;
-  e.gamma = pin->GetReal(blk, "gamma");
+  const std::string eqn_of_state = pin->GetString(blk, "eos");     // hydro.cpp:52-72
+  if (eqn_of_state == "ideal") {
+    e.is_ideal = true; e.gamma = pin->GetReal(blk, "gamma"); e.iso_cs = 0.0;
+  } else if (eqn_of_state == "isothermal") {
+    e.is_ideal = false; e.gamma = 0.0; e.iso_cs = pin->GetReal(blk, "iso_sound_speed");
+  } else {
+    AKMI_FATAL("<" + blk + ">/eos = '" + eqn_of_state + "' not implemented");
+  }
   e.dfloor = pin->GetOrAddReal(blk, "dfloor", static_cast<Real>(FLT_MIN));   // eos.cpp:22-25
   e.pfloor = pin->GetOrAddReal(blk, "pfloor", static_cast<Real>(FLT_MIN));
   e.tfloor = pin->GetOrAddReal(blk, "tfloor", static_cast<Real>(FLT_MIN));
@@ -332,20 +343,33 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
   recon_method = ReconFlag(rec);
   if (recon_method >= AKMI_RECON_PPM4 && ind.ng < 3)
     AKMI_FATAL("PPM/WENOZ reconstruction requires at least 3 ghost zones");
-  if (pin->GetOrAddInteger(blk, "nscalars", 0) != 0) AKMI_FATAL("passive scalars are not on this path");
-  for (const char *n : {"nu_iso", "nu_aniso", "alpha_iso", "alpha_aniso", "alpha_spitzer", "eta_ohm", "eta_ad"})
+  nscalars = pin->GetOrAddInteger(blk, "nscalars", 0);
+  nfluid = e.is_ideal ? 5 : 4;                 // no energy variable with the isothermal EOS
+  nvars = nfluid + nscalars;                   // scalars follow the fluid variables
+  // diffusion objects: hydro.cpp:77-98, mhd.cpp:104-130 (constant isotropic coefficients)
+  for (const char *n : {"nu_aniso", "alpha_aniso", "alpha_spitzer", "eta_ad"})
     if (pin->DoesParameterExist(blk, n))
-      AKMI_FATAL(std::string("<") + blk + ">/" + n + ": the diffusion hooks run on the Python host of this package");
+      AKMI_FATAL(std::string("<") + blk + ">/" + n + " is not on this path");
+  if (pin->DoesParameterExist(blk, "nu_iso")) { has_visc = true; nu_iso = pin->GetReal(blk, "nu_iso"); }
+  if (pin->DoesParameterExist(blk, "alpha_iso")) {
+    if (!e.is_ideal) AKMI_FATAL("Thermal conduction requires ideal gas EOS");
+    has_cond = true; alpha_iso = pin->GetReal(blk, "alpha_iso"); dtmin_cond.Realloc(1);
+  }
+  if (blk == "mhd" && pin->DoesParameterExist(blk, "eta_ohm")) {
+    has_resist = true; eta_ohm = pin->GetReal(blk, "eta_ohm");
+  }
   fused = pin->GetOrAddBoolean(blk, "fused_stage", true);
-  pack_c.nmb = pp->nmb_thispack; pack_c.nvar = 5;
+  // the fused stage kernels are specialised for the ideal-gas variable set without extra fluxes
+  if (!e.is_ideal || nscalars > 0 || has_visc || has_cond || has_resist) fused = false;
+  pack_c.nmb = pp->nmb_thispack; pack_c.nvar = nvars;
   pack_c.nx1 = ind.nx1; pack_c.nx2 = ind.nx2; pack_c.nx3 = ind.nx3; pack_c.ng = ind.ng;
   pack_c.dx = pp->pmb->d_dx.p;
   pack_c.gamma = e.gamma; pack_c.dfloor = e.dfloor; pack_c.pfloor = e.pfloor;
   pack_c.tfloor = e.tfloor; pack_c.sfloor = e.sfloor; pack_c.sigma_max = e.sigma_max;
-  pack_c.iso_cs = 0.0; pack_c.is_ideal = 1;     // isothermal runs: Python host (task-granular kernels)
+  pack_c.iso_cs = e.iso_cs; pack_c.is_ideal = e.is_ideal ? 1 : 0;
   const size_t n1 = ind.nx1 + 2*ind.ng, n2 = ind.nx2 > 1 ? ind.nx2 + 2*ind.ng : 1,
                n3 = ind.nx3 > 1 ? ind.nx3 + 2*ind.ng : 1;
-  const size_t ncc = static_cast<size_t>(pp->nmb_thispack)*5*n3*n2*n1;
+  const size_t ncc = static_cast<size_t>(pp->nmb_thispack)*nvars*n3*n2*n1;
   u0.Realloc(ncc); w0.Realloc(ncc); u1.Realloc(ncc);
   counters.Realloc(3); dt3.Realloc(3);
   use_fofc = pin->GetOrAddBoolean(blk, "fofc", false);     // hydro.cpp:153-190, mhd.cpp:199-235
@@ -354,6 +378,8 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
     if (ind.ng < need)
       AKMI_FATAL("FOFC and this reconstruction require at least " + std::to_string(need) +
                  " ghost zones, but <mesh>/nghost=" + std::to_string(ind.ng));
+    if (nscalars > 0 || (blk == "mhd" && !e.is_ideal))
+      AKMI_FATAL("<" + blk + ">/fofc with passive scalars or (MHD) the isothermal EOS is not on this path");
     fused = false;                      // FOFC works on the flux arrays of the task-granular path
     fofc.Realloc(static_cast<size_t>(pp->nmb_thispack)*n3*n2*n1);    // zero-filled
     nfofc.Realloc(1);
@@ -361,6 +387,7 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
 }
 FluidBase::~FluidBase() {
   u0.Free(); w0.Free(); u1.Free(); counters.Free(); dt3.Free(); ws.Free(); fofc.Free(); nfofc.Free();
+  dtmin_cond.Free();
   delete peos;
 }
 void FluidBase::FinishNewDt() {        // hydro_newdt.cpp:121-124
@@ -371,6 +398,39 @@ void FluidBase::FinishNewDt() {        // hydro_newdt.cpp:121-124
   dtnew = d[0];
   if (pm->multi_d) dtnew = std::min(dtnew, d[1]);
   if (pm->three_d) dtnew = std::min(dtnew, d[2]);
+}
+
+void FluidBase::AddDiffusionFluxes(DvceFaceFld &flx, int fs) {   // hydro_tasks.cpp:183-189, mhd_tasks.cpp:198-203
+  if (has_cond && alpha_iso != 0.0)
+    AKCHK(akmi_heat_fluxes(&pack_c, alpha_iso, w0.p, flx.x1f.p, flx.x2f.p, flx.x3f.p, fs, stream));
+  if (has_visc && nu_iso != 0.0)
+    AKCHK(akmi_viscous_fluxes(&pack_c, nu_iso, w0.p, flx.x1f.p, flx.x2f.p, flx.x3f.p, fs, stream));
+}
+void FluidBase::DiffusionNewDt() {     // viscosity.cpp:232-251, conduction.cpp:314-377, resistivity.cpp:291-311
+  Mesh *pm = pmy_pack->pmesh;
+  const Real fac = pm->three_d ? 1.0/6.0 : (pm->two_d ? 0.25 : 0.5);
+  auto const_dt = [&](Real coeff) {
+    Real dt = static_cast<Real>(FLT_MAX);
+    for (const RegionSize &sz : pmy_pack->pmb->mb_size) {
+      dt = std::min(dt, fac*(sz.dx1*sz.dx1)/coeff);
+      if (pm->multi_d) dt = std::min(dt, fac*(sz.dx2*sz.dx2)/coeff);
+      if (pm->three_d) dt = std::min(dt, fac*(sz.dx3*sz.dx3)/coeff);
+    }
+    return dt;
+  };
+  if (has_visc) dt_visc = nu_iso != 0.0 ? const_dt(nu_iso) : static_cast<Real>(FLT_MAX);
+  if (has_resist) dt_resist = eta_ohm > 0.0 ? const_dt(eta_ohm) : static_cast<Real>(FLT_MAX);
+  if (has_cond) {
+    if (alpha_iso != 0.0) {
+      AKCHK(akmi_conduction_newdt(&pack_c, alpha_iso, w0.p, dtmin_cond.p, stream));
+      Real d;
+      HIPCHK(hipMemcpyAsync(&d, dtmin_cond.p, sizeof(d), hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+      dt_cond = d*fac;
+    } else {
+      dt_cond = static_cast<Real>(FLT_MAX)*fac;
+    }
+  }
 }
 
 static void FaceAlloc(DvceFaceFld &f, size_t nmb, size_t nv, size_t n3, size_t n2, size_t n1, int fs) {
@@ -391,7 +451,7 @@ Hydro::Hydro(MeshBlockPack *pp, ParameterInput *pin) : FluidBase(pp, pin, "hydro
   const size_t n1 = ind.nx1 + 2*ind.ng, n2 = ind.nx2 > 1 ? ind.nx2 + 2*ind.ng : 1,
                n3 = ind.nx3 > 1 ? ind.nx3 + 2*ind.ng : 1;
   if (fused) ws.Realloc(static_cast<size_t>(akmi_stage_workspace_bytes(&pack_c, 0)));
-  else FaceAlloc(uflx, pp->nmb_thispack, 5, n3, n2, n1, 0);      // hydro.cpp:290-292
+  else FaceAlloc(uflx, pp->nmb_thispack, nvars, n3, n2, n1, 0);  // hydro.cpp:290-292
 }
 Hydro::~Hydro() { FaceFree(uflx); }
 
@@ -434,7 +494,7 @@ MHD::MHD(MeshBlockPack *pp, ParameterInput *pin) : FluidBase(pp, pin, "mhd") {
   if (fused) {
     ws.Realloc(static_cast<size_t>(akmi_stage_workspace_bytes(&pack_c, 1)));
   } else {
-    FaceAlloc(uflx, nmb, 5, n3, n2, n1, 1);                        // mhd.cpp:341-343
+    FaceAlloc(uflx, nmb, nvars, n3, n2, n1, 1);                    // mhd.cpp:341-343
     efld.x1e.Realloc(nmb*(n3 + 1)*(n2 + 1)*n1); efld.x2e.Realloc(nmb*(n3 + 1)*n2*(n1 + 1));
     efld.x3e.Realloc(nmb*n3*(n2 + 1)*(n1 + 1));
     for (DvceArray<Real> *a : {&e3x1, &e2x1, &e1x2, &e3x2, &e2x3, &e1x3}) a->Realloc(nmb*n3*n2*n1);
@@ -562,15 +622,18 @@ TaskStatus Hydro::CopyCons(Driver *d, int stage) {         // hydro_tasks.cpp:13
   return TaskStatus::complete;
 }
 TaskStatus Hydro::Fluxes(Driver *d, int stage) {           // hydro_tasks.cpp:159-201
-  if (use_fofc) {                                           // hydro_tasks.cpp:192-194
+  if (fused) return TaskStatus::complete;
+  if (use_fofc)                                             // hydro_fluxes.cpp:92-101
     AKCHK(akmi_hydro_fluxes_fofc(&pack_c, recon_method, rsolver_method, w0.p, uflx.x1f.p,
                                  uflx.x2f.p, uflx.x3f.p, 0, stream));
+  else
+    AKCHK(akmi_hydro_fluxes(&pack_c, recon_method, rsolver_method, w0.p, uflx.x1f.p, uflx.x2f.p,
+                            uflx.x3f.p, 0, stream));
+  AddDiffusionFluxes(uflx, 0);                              // hydro_tasks.cpp:183-189
+  if (use_fofc) {                                           // hydro_tasks.cpp:192-194
     AKCHK(akmi_hydro_fofc(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1],
                           d->beta[stage - 1]*pmy_pack->pmesh->dt, w0.p, u0.p, u1.p, uflx.x1f.p,
                           uflx.x2f.p, uflx.x3f.p, 0, fofc.p, nfofc.p, stream));
-  } else if (!fused) {
-    AKCHK(akmi_hydro_fluxes(&pack_c, recon_method, rsolver_method, w0.p, uflx.x1f.p, uflx.x2f.p,
-                            uflx.x3f.p, 0, stream));
   }
   return TaskStatus::complete;
 }
@@ -589,12 +652,12 @@ TaskStatus Hydro::RKUpdate(Driver *d, int stage) {         // hydro_update.cpp:2
   return TaskStatus::complete;
 }
 TaskStatus Hydro::SendU(Driver *d, int stage) {            // hydro_tasks.cpp:308-320 (same rank)
-  AKCHK(akmi_bvals_cc_local(&pack_c, 5, pmy_pack->pmb->d_nghbr.p, u0.p, stream));
+  AKCHK(akmi_bvals_cc_local(&pack_c, nvars, pmy_pack->pmb->d_nghbr.p, u0.p, stream));
   return TaskStatus::complete;
 }
 TaskStatus Hydro::ApplyPhysicalBCs(Driver *d, int stage) { // hydro_tasks.cpp:357-375
   if (pmy_pack->pmesh->strictly_periodic) return TaskStatus::complete;
-  AKCHK(akmi_hydro_bcs(&pack_c, 5, pmy_pack->pmb->d_bcs.p, u0.p, stream));
+  AKCHK(akmi_hydro_bcs(&pack_c, nvars, pmy_pack->pmb->d_bcs.p, u0.p, stream));
   return TaskStatus::complete;
 }
 TaskStatus Hydro::ConToPrim(Driver *d, int stage) {        // hydro_tasks.cpp:404-412
@@ -618,6 +681,7 @@ TaskStatus Hydro::NewTimeStep(Driver *d, int stage) {      // hydro_newdt.cpp:30
   if (!dt_ready_) AKCHK(akmi_hydro_newdt(&pack_c, w0.p, dt3.p, stream));
   dt_ready_ = false;
   FinishNewDt();
+  DiffusionNewDt();
   return TaskStatus::complete;
 }
 }  // namespace hydro
@@ -633,19 +697,25 @@ TaskStatus MHD::CopyCons(Driver *d, int stage) {           // mhd_tasks.cpp:162-
   return TaskStatus::complete;
 }
 TaskStatus MHD::Fluxes(Driver *d, int stage) {             // mhd_tasks.cpp:177-216
-  if (use_fofc) {                                           // mhd_tasks.cpp:209-211
+  if (fused) return TaskStatus::complete;
+  if (use_fofc)                                             // mhd_fluxes.cpp:100-105
     AKCHK(akmi_mhd_fluxes_fofc(&pack_c, recon_method, rsolver_method, w0.p, bcc0.p, b0.x1f.p,
                                b0.x2f.p, b0.x3f.p, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, e3x1.p,
                                e2x1.p, e1x2.p, e3x2.p, e2x3.p, e1x3.p, stream));
+  else
+    AKCHK(akmi_mhd_fluxes(&pack_c, recon_method, rsolver_method, w0.p, bcc0.p, b0.x1f.p, b0.x2f.p,
+                          b0.x3f.p, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, e3x1.p, e2x1.p, e1x2.p,
+                          e3x2.p, e2x3.p, e1x3.p, stream));
+  AddDiffusionFluxes(uflx, 1);                              // mhd_tasks.cpp:198-203
+  if (has_resist && eta_ohm != 0.0 && peos->eos_data.is_ideal)   // mhd_tasks.cpp:204-206
+    AKCHK(akmi_resistive_fluxes(&pack_c, eta_ohm, b0.x1f.p, b0.x2f.p, b0.x3f.p, uflx.x1f.p,
+                                uflx.x2f.p, uflx.x3f.p, stream));
+  if (use_fofc) {                                           // mhd_tasks.cpp:209-211
     AKCHK(akmi_mhd_fofc(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1],
                         d->beta[stage - 1]*pmy_pack->pmesh->dt, w0.p, bcc0.p, b0.x1f.p, b0.x2f.p,
                         b0.x3f.p, b1.x1f.p, b1.x2f.p, b1.x3f.p, u0.p, u1.p, uflx.x1f.p, uflx.x2f.p,
                         uflx.x3f.p, e3x1.p, e2x1.p, e1x2.p, e3x2.p, e2x3.p, e1x3.p, fofc.p, nfofc.p,
                         stream));
-  } else if (!fused) {
-    AKCHK(akmi_mhd_fluxes(&pack_c, recon_method, rsolver_method, w0.p, bcc0.p, b0.x1f.p, b0.x2f.p,
-                          b0.x3f.p, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, e3x1.p, e2x1.p, e1x2.p,
-                          e3x2.p, e2x3.p, e1x3.p, stream));
   }
   return TaskStatus::complete;
 }
@@ -665,7 +735,7 @@ TaskStatus MHD::RKUpdate(Driver *d, int stage) {           // mhd_update.cpp:24-
   return TaskStatus::complete;
 }
 TaskStatus MHD::SendU(Driver *d, int stage) {
-  AKCHK(akmi_bvals_cc_local(&pack_c, 5, pmy_pack->pmb->d_nghbr.p, u0.p, stream));
+  AKCHK(akmi_bvals_cc_local(&pack_c, nvars, pmy_pack->pmb->d_nghbr.p, u0.p, stream));
   return TaskStatus::complete;
 }
 TaskStatus MHD::EField(Driver *d, int stage) {             // mhd_corner_e.cpp:26-417
@@ -673,6 +743,9 @@ TaskStatus MHD::EField(Driver *d, int stage) {             // mhd_corner_e.cpp:2
     AKCHK(akmi_mhd_corner_e(&pack_c, w0.p, bcc0.p, e3x1.p, e2x1.p, e1x2.p, e3x2.p, e2x3.p, e1x3.p,
                             uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, efld.x1e.p, efld.x2e.p, efld.x3e.p,
                             stream));
+  if (!fused && has_resist && eta_ohm != 0.0)               // mhd_tasks.cpp:381-383
+    AKCHK(akmi_resistive_emfs(&pack_c, eta_ohm, b0.x1f.p, b0.x2f.p, b0.x3f.p, efld.x1e.p, efld.x2e.p,
+                              efld.x3e.p, stream));
   return TaskStatus::complete;
 }
 TaskStatus MHD::CT(Driver *d, int stage) {                 // mhd_ct.cpp:23-80
@@ -688,7 +761,7 @@ TaskStatus MHD::SendB(Driver *d, int stage) {
 }
 TaskStatus MHD::ApplyPhysicalBCs(Driver *d, int stage) {   // mhd_tasks.cpp:501-520
   if (pmy_pack->pmesh->strictly_periodic) return TaskStatus::complete;
-  AKCHK(akmi_hydro_bcs(&pack_c, 5, pmy_pack->pmb->d_bcs.p, u0.p, stream));
+  AKCHK(akmi_hydro_bcs(&pack_c, nvars, pmy_pack->pmb->d_bcs.p, u0.p, stream));
   AKCHK(akmi_bfield_bcs(&pack_c, pmy_pack->pmb->d_bcs.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, stream));
   return TaskStatus::complete;
 }
@@ -715,6 +788,7 @@ TaskStatus MHD::NewTimeStep(Driver *d, int stage) {        // mhd_newdt.cpp:31-1
   if (!dt_ready_) AKCHK(akmi_mhd_newdt(&pack_c, w0.p, bcc0.p, dt3.p, stream));
   dt_ready_ = false;
   FinishNewDt();
+  DiffusionNewDt();
   return TaskStatus::complete;
 }
 }  // namespace mhd

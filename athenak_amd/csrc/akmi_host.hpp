@@ -178,7 +178,7 @@ class Mesh {            // mesh.hpp:92-185
 };
 
 // physics base: what Hydro and MHD share ------------------------------------------------
-struct EOS_Data { Real gamma, dfloor, pfloor, tfloor, sfloor, sigma_max; bool is_ideal; };
+struct EOS_Data { Real gamma, iso_cs, dfloor, pfloor, tfloor, sfloor, sigma_max; bool is_ideal; };
 struct EquationOfState { EOS_Data eos_data; };
 
 class FluidBase {
@@ -194,6 +194,13 @@ class FluidBase {
   DvceArray<int> counters;
   DvceArray<Real> dt3;
   DvceArray<char> ws;
+  int nfluid = 5, nscalars = 0, nvars = 5;   // nhydro|nmhd (4 isothermal), passive scalars
+  // constant-coefficient diffusion (src/diffusion): objects exist when the parameter is in the deck
+  bool has_visc = false, has_cond = false, has_resist = false;
+  Real nu_iso = 0.0, alpha_iso = 0.0, eta_ohm = 0.0;
+  Real dt_visc = static_cast<Real>(FLT_MAX), dt_cond = static_cast<Real>(FLT_MAX),
+       dt_resist = static_cast<Real>(FLT_MAX);
+  DvceArray<Real> dtmin_cond;
   bool use_fofc = false;                // hydro.hpp:116-117, mhd.hpp
   DvceArray<unsigned char> fofc;
   DvceArray<int> nfofc;                 // EventCounters::nfofc (mesh.hpp:71), kept on the device
@@ -201,6 +208,8 @@ class FluidBase {
   hipStream_t stream = nullptr;
  protected:
   void FinishNewDt();
+  void AddDiffusionFluxes(DvceFaceFld &flx, int face_shaped);   // hydro_tasks.cpp:183-189
+  void DiffusionNewDt();                                        // hydro_newdt.cpp:128-133
   bool interior_done_ = false, dt_ready_ = false;
 };
 

@@ -24,9 +24,11 @@ class _Face:
 
 
 class _Eos:
-    def __init__(self, gamma):
-        # the C++ driver runs the ideal-gas EOS only (isothermal decks: Python host)
-        self.eos_data = type("EOS_Data", (), {"gamma": gamma, "is_ideal": True, "iso_cs": 0.0})()
+    def __init__(self, pin, blk):
+        ideal = pin.GetString(blk, "eos") == "ideal"
+        self.eos_data = type("EOS_Data", (), {
+            "gamma": pin.GetReal(blk, "gamma") if ideal else 0.0, "is_ideal": ideal,
+            "iso_cs": 0.0 if ideal else pin.GetReal(blk, "iso_sound_speed")})()
 
 
 class _PhysAlias:
@@ -46,11 +48,13 @@ class NativeSimulation:
         n3, n2, n1 = self.pmesh.mb_indcs.ncells
         nmb = self.pmesh.nmb_total
         ph = _PhysAlias()
-        ph.peos = _Eos(pin.GetReal(blk, "gamma"))
-        ph.nfluid = ph.nvars = 5
-        ph.u0 = self._alias("u0", (nmb, 5, n3, n2, n1))
-        ph.w0 = self._alias("w0", (nmb, 5, n3, n2, n1))
-        ph.u1 = self._alias("u1", (nmb, 5, n3, n2, n1))
+        ph.peos = _Eos(pin, blk)
+        ph.nfluid = 5 if ph.peos.eos_data.is_ideal else 4
+        ph.nscalars = pin.GetOrAddInteger(blk, "nscalars", 0)
+        ph.nvars = nv = ph.nfluid + ph.nscalars
+        ph.u0 = self._alias("u0", (nmb, nv, n3, n2, n1))
+        ph.w0 = self._alias("w0", (nmb, nv, n3, n2, n1))
+        ph.u1 = self._alias("u1", (nmb, nv, n3, n2, n1))
         if is_mhd:
             ph.bcc0 = self._alias("bcc0", (nmb, 3, n3, n2, n1))
             for reg in ("b0", "b1"):

@@ -145,8 +145,6 @@ def test_fofc_is_bit_identical(case, native):
     """akmi_{hydro,mhd}_fluxes_fofc + akmi_{hydro,mhd}_fofc against the oracle, with cells actually
     flagged (MHD: the face EMFs of flagged cells are replaced too and feed CornerE/CT)"""
     problem, n, dims, mb, cycles, kw = case
-    if native and "hydro/eos=isothermal" in kw["extra"]:
-        pytest.skip("the C++ host runs the ideal-gas EOS only")
     sim, osim, is_mhd = pu.make_pair(problem, n, dims, mb, **kw)
     for _ in range(cycles):
         assert sim.Execute(max_cycles=1) and osim.step()
@@ -173,13 +171,14 @@ DIFFUSION = [
 ]
 
 
+@pytest.mark.parametrize("native", [False, True], ids=["py", "cpp"])
 @pytest.mark.parametrize("case", DIFFUSION, ids=lambda c: "%s-%d^%d-%s" % (c[0], c[1], c[2], "+".join(sorted(c[6]))))
-def test_diffusion_hooks_are_bit_identical(case):
+def test_diffusion_hooks_are_bit_identical(case, native):
     """akmi_viscous_fluxes / akmi_heat_fluxes / akmi_resistive_fluxes / akmi_resistive_emfs /
     akmi_conduction_newdt inside the task chain, and the diffusive time-step limits"""
     problem, n, dims, mb, cycles, kw, params = case
-    sim, osim, is_mhd = pu.make_pair(problem, n, dims, mb, params=params, **kw)
-    assert sim.pmesh.dt == osim.dt
+    sim, osim, is_mhd = pu.make_pair(problem, n, dims, mb, params=params, native=native, **kw)
+    assert (sim.dt if native else sim.pmesh.dt) == osim.dt
     for _ in range(cycles):
         assert sim.Execute(max_cycles=1) and osim.step()
         assert sim.pmesh.dt == osim.dt
@@ -315,12 +314,13 @@ def test_isothermal_lwave1d_matrix_is_bit_identical(soe, recon):
     ("sod", 64, 1, 32, 8, dict(cfl=0.3, recon="plm", rsolver="roe")),
     ("rj2a", 128, 1, 64, 8, dict(cfl=0.3, rsolver="hlld")),
 ], ids=lambda c: "%s-%d^%d-%s" % (c[0], c[1], c[2], c[5]["rsolver"]))
-def test_isothermal_multi_d_runs_are_bit_identical(case):
+@pytest.mark.parametrize("native", [False, True], ids=["py", "cpp"])
+def test_isothermal_multi_d_runs_are_bit_identical(case, native):
     problem, n, dims, mb, cycles, kw = case
     blk = "hydro" if problem in ("linear_wave_hydro", "sod") else "mhd"
     kw = dict(kw)
     kw["extra"] = list(kw.get("extra", [])) + ["%s/eos=isothermal" % blk]
-    res = pu.compare_run(problem, n, dims, mb, cycles, **kw)
+    res = pu.compare_run(problem, n, dims, mb, cycles, native=native, **kw)
     assert res["cycles"] == cycles and res["time"][0] == res["time"][1]
     assert res["bitwise_equal"], res["diffs"]
 
@@ -402,7 +402,8 @@ def test_task_mhd_fluxes_wild_states_isothermal(recon, rs):
     ("linear_wave_mhd", 32, 1, 16, 6, dict(ng=3, recon="plm", rsolver="llf",
                                             extra=["problem/along_x1=true", "mhd/eos=isothermal"])),
 ], ids=lambda c: "%s-%d^%d-%s" % (c[0], c[1], c[2], c[5]["rsolver"]))
-def test_passive_scalars(case):
+@pytest.mark.parametrize("native", [False, True], ids=["py", "cpp"])
+def test_passive_scalars(case, native):
     """two passive scalars (hydro_fluxes.cpp:135-147, ideal_hyd.cpp:94-101): s0 == 1, s1 = a
     profile.  Bit-identical to the oracle, and the mass density of scalar 0 stays bit-identical to
     the density itself (its flux is the mass flux times exactly 1)."""
@@ -411,7 +412,7 @@ def test_passive_scalars(case):
     blk = "hydro" if problem in ("linear_wave_hydro", "sod") else "mhd"
     kw = dict(kw)
     kw["extra"] = list(kw.get("extra", [])) + ["%s/nscalars=2" % blk]
-    sim, osim, is_mhd = pu.make_pair(problem, n, dims, mb, **kw)
+    sim, osim, is_mhd = pu.make_pair(problem, n, dims, mb, native=native, **kw)
     u = osim.array("u0")
     nf = u.shape[1] - 2
     prof = 0.5 + 0.25*np.sin(np.arange(u[:, 0].size, dtype=np.float64)*0.37).reshape(u[:, 0].shape)
@@ -419,7 +420,10 @@ def test_passive_scalars(case):
     u[:, nf + 1] = u[:, 0]*prof
     osim.reinitialize()
     sim.phys.u0.copy_(torch.from_numpy(u.copy()))
-    sim.pdriver.Initialize(sim.pmesh, sim.pin)
+    if native:
+        sim.Initialize()
+    else:
+        sim.pdriver.Initialize(sim.pmesh, sim.pin)
     for _ in range(cycles):
         assert sim.Execute(max_cycles=1) == 1 and osim.step() == 1
     got, ref = sim.phys.u0.cpu().numpy(), osim.array("u0")
