@@ -116,9 +116,90 @@ struct SweepArgs {
 // plain sweep (not the last direction): thread per face.  ECC: also emit e_cc for the right
 // cell of every face and for the extra column i = il-1 (mhd_corner_e.cpp:309-317 range
 // [is-1,ie+1] x [js-1,je+1] x [ks-1,ke+1] == the CT-extended x1 sweep, right cells).
+// x1 sweep with PLM: the limited slope of a cell serves both of its faces, so a lane computes the
+// slopes of ITS cell only (one division per variable instead of two) and takes the left state of
+// its face from the lane below through a wave shuffle.  Waves overlap by one lane (lane 0 only
+// provides): 63 faces per wave.  Same operands, same operations -> same bits.
+#ifndef AKMI_X1_SHARE
+#define AKMI_X1_SHARE 1
+#endif
+template <int DIR, int RECON>
+constexpr bool x1_share() { return DIR == 0 && RECON == 1 && AKMI_X1_SHARE; }
+
+template <int RECON, bool MHD, bool ECC, int RS>
+__device__ __forceinline__ void sweep_x1_shared(const Geo &g, const FaceEos &eos, const SweepArgs &a,
+                                                int nk) {
+  const long p = ((long)blockIdx.x*SY + threadIdx.y)*(SX - 1) + (long)threadIdx.x - 1;
+  const long pc = p < 0 ? 0 : p;
+  const int jj = (int)(pc/g.N1);
+  const int i = (int)(pc - (long)jj*g.N1);
+  const int j = a.jl + jj;
+  const int m = blockIdx.z/nk;
+  const int k = a.kl + (blockIdx.z - m*nk);
+  // a lane owns cell i: slopes need i-1 and i+1 inside the row
+  const bool valid = p >= 0 && j <= a.ju && i >= 1 && i <= g.N1 - 2;
+  constexpr int NV = MHD ? 7 : 5;
+  const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  double qln[NV], qr[NV];                 // left state of face i+1, right state of face i
+#pragma unroll
+  for (int n = 0; n < NV; ++n) { qln[n] = 0.0; qr[n] = 0.0; }
+  double vx = 0.0, vy = 0.0, vz = 0.0, by = 0.0, bz = 0.0;
+  if (valid) {
+    const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const double *q = (n < 5) ? a.w0 + c + n*cs
+                                : a.bcc0 + ix5(3, g.N3, g.N2, g.N1, m, n - 4, k, j, i);   // by, bz
+      const double qm = q[-1], q0 = q[0], qp = q[1];
+      plm(qm, q0, qp, qln[n], qr[n]);
+      if (n == 1) vx = q0;
+      if (n == 2) vy = q0;
+      if (n == 3) vz = q0;
+      if (n == 5) by = q0;
+      if (n == 6) bz = q0;
+    }
+  }
+  double L[NV];
+#pragma unroll
+  for (int n = 0; n < NV; ++n) L[n] = __shfl_up(qln[n], 1, 64);
+  if (!valid) return;
+  if constexpr (ECC) {
+    if (i >= a.il - 1 && i <= a.iu) {
+      const double bx = a.bcc0[ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i)];
+      const size_t e = ix4(g.N3, g.N2, g.N1, m, k, j, i);
+      a.ecc1[e] = vz*by - vy*bz;
+      a.ecc2[e] = vx*bz - vz*bx;
+      a.ecc3[e] = vy*bx - vx*by;
+    }
+  }
+  if (threadIdx.x == 0 || i < a.il || i > a.iu) return;     // lane 0 only provides
+  double fd, fx, fy, fz, fe, fby = 0.0, fbz = 0.0;
+  if constexpr (MHD) {
+    const double bxi = a.bxf[ix4(a.f3, a.f2, a.f1, m, k, j, i)];
+    Cons1D fl = riemann_mhd<RS>(eos.gamma, L[0], L[1], L[2], L[3], L[4], L[5], L[6], qr[0], qr[1],
+                                qr[2], qr[3], qr[4], qr[5], qr[6], bxi);
+    fd = fl.d; fx = fl.mx; fy = fl.my; fz = fl.mz; fe = fl.e; fby = fl.by; fbz = fl.bz;
+  } else {
+    riemann_hyd<RS>(eos.gamma, L[0], L[1], L[2], L[3], L[4], qr[0], qr[1], qr[2], qr[3], qr[4], fd,
+                    fx, fy, fz, fe);
+  }
+  const size_t fs = (size_t)a.f3*a.f2*a.f1;
+  double *f = a.flx + ix5(g.nvar, a.f3, a.f2, a.f1, m, 0, k, j, i);
+  f[0] = fd; f[fs] = fx; f[2*fs] = fy; f[3*fs] = fz; f[4*fs] = fe;
+  if constexpr (MHD) {
+    const size_t ec = ix4(g.N3, g.N2, g.N1, m, k, j, i);
+    a.ey[ec] = -fby;
+    a.ez[ec] = fbz;
+  }
+}
+
 template <int DIR, int RECON, bool MHD, bool ECC, int RS>
 __global__ void __launch_bounds__(SX*SY)
 k_sweep(Geo g, FaceEos eos, SweepArgs a, int nk) {
+  if constexpr (x1_share<DIR, RECON>()) {
+    sweep_x1_shared<RECON, MHD, ECC, RS>(g, eos, a, nk);
+    return;
+  }
   // lanes run over the flattened rows [jl,ju] x [0,N1): contiguous in memory, and the few
   // ghost columns outside [il,iu] cost 2-4 idle lanes per 260 instead of a mostly empty wave
   const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;
@@ -724,8 +805,11 @@ template <int DIR, bool MHD, bool ECC>
 static int launch_sweep(const Geo &g, const Scheme &sc, const SweepArgs &a, hipStream_t st) {
   int nk = a.ku - a.kl + 1;
   long np = (long)(a.ju - a.jl + 1)*g.N1;
-  dim3 grid((unsigned)((np + SX*SY - 1)/(SX*SY)), 1, nk*g.nmb), block(SX, SY);
+  dim3 block(SX, SY);
   int rc = dispatch_scheme<MHD>(sc, [&](auto R, auto S) {
+    // faces per wave: 63 when the lanes share their slopes (lane 0 of a wave only provides)
+    const long per_wg = (long)(x1_share<DIR, decltype(R)::value>() ? SX - 1 : SX)*SY;
+    dim3 grid((unsigned)((np + 1 + per_wg - 1)/per_wg), 1, nk*g.nmb);
     k_sweep<DIR, decltype(R)::value, MHD, ECC, decltype(S)::value><<<grid, block, 0, st>>>(
         g, sc.eos, a, nk);
     return AKMI_COMPLETE;
