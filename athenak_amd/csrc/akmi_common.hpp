@@ -76,10 +76,15 @@ inline int dispatch_recon(int recon, F &&f) {
   return AKMI_FAIL;
 }
 
-template <bool MHD, class F>
+// ADV: also accept rsolver = advect (kinematic runs; instantiated for the task-granular hydro flux
+// kernel only)
+template <bool MHD, bool ADV = false, class F>
 inline int dispatch_rsolver(int rs, F &&f) {
   if (rs == AKMI_RS_LLF) return f(IC<0>{});
   if (rs == AKMI_RS_HLLE) return f(IC<1>{});
+  if constexpr (ADV && !MHD) {
+    if (rs == AKMI_RS_ADVECT) return f(IC<5>{});
+  }
   if constexpr (MHD) {
     if (rs == AKMI_RS_HLLD) return f(IC<3>{});
     set_error("<mhd> rsolver = %d not implemented (llf, hlle, hlld)", rs);
@@ -92,10 +97,10 @@ inline int dispatch_rsolver(int rs, F &&f) {
 }
 
 // f(IC<RECON>, IC<RS>) for the run-time pair
-template <bool MHD, class F>
+template <bool MHD, bool ADV = false, class F>
 inline int dispatch_scheme(const Scheme &sc, F &&f) {
   return dispatch_recon(sc.recon, [&](auto R) {
-    return dispatch_rsolver<MHD>(sc.rsolver, [&](auto S) { return f(R, S); });
+    return dispatch_rsolver<MHD, ADV>(sc.rsolver, [&](auto S) { return f(R, S); });
   });
 }
 

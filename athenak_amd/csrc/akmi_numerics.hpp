@@ -464,7 +464,20 @@ AKMI_DEV void roe_hyd(double gamma, double ld, double lx, double ly, double lz, 
   f_d = f[0]; f_mx = f[1]; f_my = f[2]; f_mz = f[3]; f_e = f[4];
 }
 
-// Hydro_RSolver selection at compile time: RS = AKMI_RS_LLF 0, HLLE 1, HLLC 2, ROE 4
+// Advect, src/hydro/rsolvers/advect_hyd.hpp:19-55: upwind flux by the sign of the left normal
+// velocity (kinematic runs).  As in the reference the transverse components are velocity times
+// velocity (no density factor) and the energy component is e_int*v.
+AKMI_DEV void advect_hyd(double ld, double lx, double ly, double lz, double le, double rd, double rx,
+                         double ry, double rz, double re, double &f_d, double &f_mx, double &f_my,
+                         double &f_mz, double &f_e) {
+  if (lx >= 0.0) {
+    f_d = ld*lx; f_mx = ld*lx*lx; f_my = ly*lx; f_mz = lz*lx; f_e = le*lx;
+  } else {
+    f_d = rd*rx; f_mx = rd*rx*rx; f_my = ry*rx; f_mz = rz*rx; f_e = re*rx;
+  }
+}
+
+// Hydro_RSolver selection at compile time: RS = AKMI_RS_LLF 0, HLLE 1, HLLC 2, ROE 4, ADVECT 5
 template <int RS>
 AKMI_DEV void riemann_hyd(double gamma, double ld, double lx, double ly, double lz, double le,
                           double rd, double rx, double ry, double rz, double re, double &f_d,
@@ -472,6 +485,7 @@ AKMI_DEV void riemann_hyd(double gamma, double ld, double lx, double ly, double 
   if constexpr (RS == 0) llf_hyd(gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, f_d, f_mx, f_my, f_mz, f_e);
   else if constexpr (RS == 1) hlle_hyd(gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, f_d, f_mx, f_my, f_mz, f_e);
   else if constexpr (RS == 4) roe_hyd(gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, f_d, f_mx, f_my, f_mz, f_e);
+  else if constexpr (RS == 5) advect_hyd(ld, lx, ly, lz, le, rd, rx, ry, rz, re, f_d, f_mx, f_my, f_mz, f_e);
   else hllc(gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, f_d, f_mx, f_my, f_mz, f_e);
 }
 
@@ -928,7 +942,10 @@ AKMI_DEV void riemann_hyd_iso(double cs, double ld, double lx, double ly, double
                               double &f_my, double &f_mz) {
   if constexpr (RS == 0) llf_hyd_iso(cs, ld, lx, ly, lz, rd, rx, ry, rz, f_d, f_mx, f_my, f_mz);
   else if constexpr (RS == 1) hlle_hyd_iso(cs, ld, lx, ly, lz, rd, rx, ry, rz, f_d, f_mx, f_my, f_mz);
-  else roe_hyd_iso(cs, ld, lx, ly, lz, rd, rx, ry, rz, f_d, f_mx, f_my, f_mz);
+  else if constexpr (RS == 5) {
+    double fe;
+    advect_hyd(ld, lx, ly, lz, 0.0, rd, rx, ry, rz, 0.0, f_d, f_mx, f_my, f_mz, fe);
+  } else roe_hyd_iso(cs, ld, lx, ly, lz, rd, rx, ry, rz, f_d, f_mx, f_my, f_mz);
 }
 
 // isothermal fast speed, src/eos/eos.hpp:60-68

@@ -78,7 +78,7 @@ static int launch_hydro_flux(const Geo &g, const Scheme &sc, const double *w0,
   if (DIR == 2) { kl = g.ks - ext; ku = g.ke + 1 + ext; f3 += fsh; }
   int nk = ku - kl + 1;
   dim3 grid(cdiv(iu - il + 1, BX), cdiv(ju - jl + 1, BY), nk*g.nmb), block(BX, BY);
-  int rc = dispatch_scheme<false>(sc, [&](auto R, auto S) {
+  int rc = dispatch_scheme<false, true>(sc, [&](auto R, auto S) {
     if (sc.iso)
       k_hydro_flux<DIR, decltype(R)::value, decltype(S)::value, true><<<grid, block, 0, st>>>(
           g, sc.eos, w0, flx, f3, f2, f1, il, iu, jl, ju, kl, nk);
@@ -753,6 +753,27 @@ k_fofc_fix_mhd(Geo g, Eos eos, FofcMhd a, int il, int iu, int jl, int ju, int kl
   }
 }
 
+// NewTimeStep of kinematic runs (hydro_newdt.cpp:55-72): dx/|v| per direction.  |v| may be 0: dx/0 =
+// inf never wins the min.  Reduced like k_newdt: the division is monotone, so min dx/|v| =
+// dx/max|v| ... only for positive max; keep the per-cell form, it is a cold path.
+__global__ void __launch_bounds__(BX*BY)
+k_kinematic_newdt(Geo g, const double *__restrict__ w0, double *__restrict__ dt3) {
+  const int i = g.is + blockIdx.x*BX + threadIdx.x;
+  const int j = g.js + blockIdx.y*BY + threadIdx.y;
+  const int nk = g.ke - g.ks + 1;
+  const int m = blockIdx.z/nk;
+  const int k = g.ks + (blockIdx.z - m*nk);
+  double d1 = DBL_MAX, d2 = DBL_MAX, d3 = DBL_MAX;
+  if (i <= g.ie && j <= g.je) {
+    const size_t cs = (size_t)g.N3*g.N2*g.N1;
+    const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
+    d1 = g.dx[3*m]/fabs(w0[c + cs]);
+    d2 = g.dx[3*m + 1]/fabs(w0[c + 2*cs]);
+    d3 = g.dx[3*m + 2]/fabs(w0[c + 3*cs]);
+  }
+  block_min3_atomic(d1, d2, d3, dt3);
+}
+
 // Hydro::CopyCons for rk4 (hydro_tasks.cpp:134-148): u1 += delta*u0, active cells
 __global__ void __launch_bounds__(256)
 k_rk4_register(Geo g, double delta, const double *__restrict__ u0, double *__restrict__ u1) {
@@ -885,6 +906,16 @@ int akmi_hydro_newdt(const akmi_pack *p, const double *w0, double *dt3, void *st
   dim3 grid(cdiv(g.nx1, BX), cdiv(g.je - g.js + 1, BY), (g.ke - g.ks + 1)*g.nmb), block(BX, BY);
   k_newdt<false><<<grid, block, 0, st>>>(g, make_eos(p), w0, nullptr, dt3);
   AKMI_CHECK_LAUNCH("hydro_newdt");
+  return AKMI_COMPLETE;
+}
+
+int akmi_kinematic_newdt(const akmi_pack *p, const double *w0, double *dt3, void *stream) {
+  Geo g = make_geo(p);
+  hipStream_t st = (hipStream_t)stream;
+  k_init_dt<<<1, 64, 0, st>>>(dt3);
+  dim3 grid(cdiv(g.nx1, BX), cdiv(g.je - g.js + 1, BY), (g.ke - g.ks + 1)*g.nmb), block(BX, BY);
+  k_kinematic_newdt<<<grid, block, 0, st>>>(g, w0, dt3);
+  AKMI_CHECK_LAUNCH("kinematic_newdt");
   return AKMI_COMPLETE;
 }
 

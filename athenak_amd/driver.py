@@ -11,9 +11,9 @@ from .tasklist import TaskListStatus
 class Driver:
     def __init__(self, pin, pmesh):
         self.time_evolution = pin.GetOrAddString("time", "evolution", "dynamic")
-        if self.time_evolution != "dynamic":
+        if self.time_evolution not in ("dynamic", "kinematic"):
             raise RuntimeError("### FATAL ERROR <time> evolution = '%s' is not on this path "
-                               "(dynamic only)" % self.time_evolution)
+                               "(dynamic, kinematic)" % self.time_evolution)
         self.integrator = pin.GetOrAddString("time", "integrator", "rk2")
         self.tlim = pin.GetReal("time", "tlim")
         self.nlim = pin.GetOrAddInteger("time", "nlim", -1)

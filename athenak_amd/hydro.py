@@ -152,9 +152,16 @@ class Hydro(FluidBase):
         device = device or capi.DEVICE
         self._setup(ppack, pin, "hydro", device)
         rs = pin.GetString("hydro", "rsolver")
-        if rs not in ("llf", "hlle", "hllc", "roe"):            # hydro.cpp: Hydro_RSolver
-            raise RuntimeError("### FATAL ERROR <hydro> rsolver = '%s' not implemented "
-                               "(llf, hlle, hllc, roe on this path)" % rs)
+        # dynamic problems: llf/hlle/hllc/roe; kinematic problems: advect (hydro.cpp:244-278)
+        self.kinematic = pin.GetOrAddString("time", "evolution", "dynamic") == "kinematic"
+        if self.kinematic:
+            if rs != "advect":
+                raise RuntimeError("### FATAL ERROR <hydro> rsolver = '%s' not implemented for "
+                                   "kinematic problems" % rs)
+            self.fused = False
+        elif rs not in ("llf", "hlle", "hllc", "roe"):          # hydro.cpp: Hydro_RSolver
+            raise RuntimeError("### FATAL ERROR <hydro> rsolver = '%s' not implemented for dynamic "
+                               "problems (llf, hlle, hllc, roe on this path)" % rs)
         self.rsolver_method = capi.RSOLVER[rs]
         self.nhydro = self.nfluid
         n3, n2, n1 = ppack.pmesh.mb_indcs.ncells
@@ -284,6 +291,9 @@ class Hydro(FluidBase):
         if self.pmy_pack.pmesh.strictly_periodic:
             return TaskStatus.complete
         self.pbval_u.HydroBCs(self.u0)
+        pgen = self.pmy_pack.pmesh.pgen
+        if pgen is not None and pgen.user_bcs:                   # hydro_tasks.cpp:368-371
+            pgen.user_bcs_func()
         return TaskStatus.complete
 
     def ConToPrim(self, pdrive, stage):
@@ -312,7 +322,10 @@ class Hydro(FluidBase):
         """hydro_newdt.cpp:30-139: last stage only"""
         if stage != pdrive.nexp_stages:
             return TaskStatus.complete
-        if not getattr(self, "_dt_ready", False):
+        if self.kinematic:                                       # hydro_newdt.cpp:55-72
+            capi.check(self.L.akmi_kinematic_newdt(C.byref(self.pack_c), capi._p(self.w0),
+                                                   capi._p(self.dt3), capi._stream()), "kinematic_newdt")
+        elif not getattr(self, "_dt_ready", False):
             capi.check(self.L.akmi_hydro_newdt(C.byref(self.pack_c), capi._p(self.w0),
                                                capi._p(self.dt3), capi._stream()), "hydro_newdt")
         self._dt_ready = False

@@ -16,7 +16,7 @@ FLT_MAX = float(np.finfo(np.float32).max)
 FLT_MIN = float(np.finfo(np.float32).tiny)
 
 _BCNAMES = {"periodic": capi.BC["periodic"], "outflow": capi.BC["outflow"],
-            "reflect": capi.BC["reflect"]}
+            "reflect": capi.BC["reflect"], "user": capi.BC["user"]}
 
 
 def LeftEdgeX(ith, n, xmin, xmax):
@@ -243,7 +243,7 @@ class Mesh:
             v = pin.GetOrAddString("mesh", name, "periodic")
             if v not in _BCNAMES:
                 raise RuntimeError("### FATAL ERROR boundary flag '%s' not supported on this "
-                                   "path (periodic/outflow/reflect)" % v)
+                                   "path (periodic/outflow/reflect/user)" % v)
             bcs.append(_BCNAMES[v])
         self.mesh_bcs = bcs
         per = capi.BC["periodic"]

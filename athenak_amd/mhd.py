@@ -18,6 +18,8 @@ class MHD(FluidBase):
     def __init__(self, ppack, pin, device=None, bvals_kernels=None):
         device = device or capi.DEVICE
         self._setup(ppack, pin, "mhd", device)
+        if pin.GetOrAddString("time", "evolution", "dynamic") != "dynamic":
+            raise RuntimeError("### FATAL ERROR kinematic MHD (rsolver = advect) is not on this path")
         rs = pin.GetString("mhd", "rsolver")
         if rs not in ("llf", "hlle", "hlld"):                   # mhd.cpp: MHD_RSolver
             raise RuntimeError("### FATAL ERROR <mhd> rsolver = '%s' not implemented "

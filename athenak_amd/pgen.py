@@ -10,6 +10,7 @@ import math
 import numpy as np
 import torch
 
+from . import capi
 from .mesh import CellCenterX, FLT_MAX, LeftEdgeX
 
 IDN, IVX, IVY, IVZ, IEN = 0, 1, 2, 3, 4
@@ -142,7 +143,10 @@ class ProblemGenerator:
         name = pin.GetOrAddString("problem", "pgen_name", "none")
         self.pgen_name = name
         table = {"linear_wave": self.LinearWave, "shock_tube": self.ShockTube,
-                 "orszag_tang": self.OrszagTang, "blast": self.UserProblem}
+                 "orszag_tang": self.OrszagTang, "blast": self.UserProblem, "diffusion": self.Diffusion}
+        # user-defined boundary conditions (pgen.cpp:57-62): enrolled by the problem function
+        self.user_bcs = any(b == capi.BC["user"] for b in pmesh.mesh_bcs)
+        self.user_bcs_func = None
         if name not in table:
             raise RuntimeError("### FATAL ERROR problem/pgen_name = '%s' is not one of the "
                                "decks on this build's path %s" % (name, sorted(table)))
@@ -493,6 +497,125 @@ class ProblemGenerator:
                 bf[2][m][ks, js, is_] = v3
                 bf[2][m][ks.stop, js, is_] = v3[-1, :, :]
         self._store(w, bf)
+
+    # ---- Gaussian-pulse diffusion tests (src/pgen/tests/diffusion.cpp) --------------------------
+    def _diff_gaussian(self, coef, time, x1, x2, x3):
+        """DiffusionGaussian, diffusion.cpp:63-76"""
+        dv = self.diffvars
+        ndim = float(dv["spread_x1"]) + float(dv["spread_x2"]) + float(dv["spread_x3"])
+        spread = 1.0 + 4.0*coef*time
+        r2 = 0.0
+        if dv["spread_x1"]:
+            r2 = r2 + (x1 - dv["x10"])**2
+        if dv["spread_x2"]:
+            r2 = r2 + (x2 - dv["x20"])**2
+        if dv["spread_x3"]:
+            r2 = r2 + (x3 - dv["x30"])**2
+        return (dv["amp"]/spread**(0.5*ndim))*np.exp(-r2/spread)
+
+    def _diff_cons_state(self, coef, gamma, time, x1, x2, x3):
+        """DiffusionConsState, diffusion.cpp:85-116: (5, ...) conserved state of the analytic solution"""
+        dv = self.diffvars
+        g = self._diff_gaussian(coef, time, x1, x2, x3)
+        gm1 = gamma - 1.0
+        rho = np.ones_like(g)
+        m = [np.zeros_like(g), np.zeros_like(g), np.zeros_like(g)]
+        p0 = np.full_like(g, 1.0/gamma)
+        if dv["conduction_test"]:
+            p0 = g
+        if dv["viscosity_test"]:
+            m[dv["vel_comp"] - 1] = rho*g
+        return np.stack([rho, m[0], m[1], m[2],
+                         p0/gm1 + 0.5*(m[0]**2 + m[1]**2 + m[2]**2)/rho])
+
+    def _diff_coef(self):
+        ph = self.pmy_mesh_.pmb_pack.phydro
+        gamma = ph.peos.eos_data.gamma
+        coef = 0.0
+        if self.diffvars["conduction_test"] and ph.pcond is not None:
+            coef = (gamma - 1.0)*ph.pcond.alpha_iso
+        if self.diffvars["viscosity_test"] and ph.pvisc is not None:
+            coef = ph.pvisc.nu_iso
+        return coef, gamma
+
+    def Diffusion(self, pin, restart):
+        pm = self.pmy_mesh_
+        if pin.GetString("time", "evolution") != "kinematic":
+            raise RuntimeError("### FATAL ERROR Diffusion tests must be run in kinematic mode")
+        self.pgen_final_func = self.DiffusionErrors
+        self.user_bcs_func = self.GaussianProfileBCs
+        if restart:
+            return
+        g, gb = pin.GetOrAddReal, pin.GetOrAddBoolean
+        self.diffvars = dv = dict(
+            amp=g("problem", "amp", 1.0e-6), x10=g("problem", "x10", 0.0), x20=g("problem", "x20", 0.0),
+            x30=g("problem", "x30", 0.0), conduction_test=pin.GetBoolean("problem", "conduction_test"),
+            viscosity_test=pin.GetBoolean("problem", "viscosity_test"),
+            resistivity_test=pin.GetBoolean("problem", "resistivity_test"),
+            spread_x1=gb("problem", "spread_x1", True), spread_x2=gb("problem", "spread_x2", False),
+            spread_x3=gb("problem", "spread_x3", False), vel_comp=pin.GetOrAddInteger("problem", "vel_comp", 2))
+        ntests = int(dv["conduction_test"]) + int(dv["viscosity_test"]) + int(dv["resistivity_test"])
+        if ntests != 1:
+            raise RuntimeError("### FATAL ERROR Exactly one of conduction_test/viscosity_test/"
+                               "resistivity_test must be set true (got %d)" % ntests)
+        ph = pm.pmb_pack.phydro
+        if ph is None:
+            raise RuntimeError("### FATAL ERROR the MHD (resistivity) diffusion test is not on this path")
+        if dv["conduction_test"] and ph.pcond is None:
+            raise RuntimeError("### FATAL ERROR Conduction not defined in Hydro input block")
+        if dv["viscosity_test"] and ph.pvisc is None:
+            raise RuntimeError("### FATAL ERROR Viscosity not defined in Hydro input block")
+        if not ph.peos.eos_data.is_ideal:
+            raise RuntimeError("### FATAL ERROR Diffusion test requires ideal EOS in Hydro block")
+        coef, gamma = self._diff_coef()
+        n3, n2, n1 = pm.mb_indcs.ncells
+        u = np.zeros((pm.pmb_pack.nmb_thispack, 5, n3, n2, n1))
+        ks, js, is_ = self._active()
+        for m in range(u.shape[0]):
+            x1v, x2v, x3v, _, _, _, _ = self._coords(m)
+            X3, X2, X1 = np.meshgrid(x3v, x2v, x1v, indexing="ij")
+            u[m][:, ks, js, is_] = self._diff_cons_state(coef, gamma, pm.time, X1, X2, X3)
+        # solution in u1 when computing errors, in u0 as initial condition (diffusion.cpp:201)
+        self._upload_cc(ph.u0 if self.set_initial_conditions else ph.u1, u)
+
+    def DiffusionErrors(self):
+        """diffusion.cpp:330-337"""
+        self.set_initial_conditions = False
+        self.Diffusion(self.pin, False)
+        self.set_initial_conditions = True
+        return self.OutputErrors()
+
+    def GaussianProfileBCs(self):
+        """diffusion.cpp:344-461: ghost zones of `user` boundaries hold the analytic solution at the
+        current time (all transverse cells incl. ghosts, x1 then x2 then x3)"""
+        pm = self.pmy_mesh_
+        ph = pm.pmb_pack.phydro
+        if ph is None:
+            return
+        coef, gamma = self._diff_coef()
+        ind = pm.mb_indcs
+        ng = ind.ng
+        n3, n2, n1 = ind.ncells
+        user = capi.BC["user"]
+        bcs = pm.pmb_pack.pmb.mb_bcs
+        for m in range(pm.pmb_pack.nmb_thispack):
+            sz = pm.pmb_pack.pmb.mb_size[m]
+            xv = [CellCenterX(np.arange(n) - s, nx, lo, hi) for n, s, nx, lo, hi in (
+                (n1, ind.is_, ind.nx1, sz.x1min, sz.x1max), (n2, ind.js, ind.nx2, sz.x2min, sz.x2max),
+                (n3, ind.ks, ind.nx3, sz.x3min, sz.x3max))]
+            slabs = [(0, slice(0, ng), 2), (1, slice(ind.ie + 1, ind.ie + 1 + ng), 2)]
+            if pm.multi_d:
+                slabs += [(2, slice(0, ng), 1), (3, slice(ind.je + 1, ind.je + 1 + ng), 1)]
+            if pm.three_d:
+                slabs += [(4, slice(0, ng), 0), (5, slice(ind.ke + 1, ind.ke + 1 + ng), 0)]
+            for face, sl, axis in slabs:
+                if int(bcs[m][face]) != user:
+                    continue
+                idx = [slice(None), slice(None), slice(None)]
+                idx[axis] = sl
+                X3, X2, X1 = np.meshgrid(xv[2][idx[0]], xv[1][idx[1]], xv[0][idx[2]], indexing="ij")
+                cons = self._diff_cons_state(coef, gamma, pm.time, X1, X2, X3)
+                ph.u0[m][(slice(None),) + tuple(idx)] = torch.from_numpy(cons).to(ph.u0.device)
 
     # ---- Orszag-Tang ---------------------------------------------------------------
     def OrszagTang(self, pin, restart):

@@ -44,7 +44,8 @@ enum { AKMI_IBX = 0, AKMI_IBY = 1, AKMI_IBZ = 2 };
 enum { AKMI_RECON_DC = 0, AKMI_RECON_PLM = 1, AKMI_RECON_PPM4 = 2, AKMI_RECON_PPMX = 3,
        AKMI_RECON_WENOZ = 4, AKMI_RECON_TENO = 5 };
 /* Hydro_RSolver / MHD_RSolver */
-enum { AKMI_RS_LLF = 0, AKMI_RS_HLLE = 1, AKMI_RS_HLLC = 2, AKMI_RS_HLLD = 3, AKMI_RS_ROE = 4 };
+enum { AKMI_RS_LLF = 0, AKMI_RS_HLLE = 1, AKMI_RS_HLLC = 2, AKMI_RS_HLLD = 3, AKMI_RS_ROE = 4,
+       AKMI_RS_ADVECT = 5 /* kinematic runs (<time>/evolution = kinematic), task-granular entries only */ };
 /* BoundaryFlag, src/mesh/mesh.hpp */
 enum { AKMI_BC_BLOCK = -1, AKMI_BC_PERIODIC = 0, AKMI_BC_OUTFLOW = 1, AKMI_BC_REFLECT = 2 };
 
@@ -99,6 +100,10 @@ int akmi_mhd_fofc(const akmi_pack *p, double gam0, double gam1, double beta_dt, 
                   const double *u1, double *flx1, double *flx2, double *flx3, double *e3x1,
                   double *e2x1, double *e1x2, double *e3x2, double *e2x3, double *e1x3,
                   unsigned char *fofc, int *nfofc, void *stream);
+/* Hydro::NewTimeStep / MHD::NewTimeStep with <time>/evolution = kinematic (src/hydro/hydro_newdt.cpp:55-72,
+ * src/mhd/mhd_newdt.cpp:56-73): dt3[d] = min over the active cells of dx_d/|v_d| */
+int akmi_kinematic_newdt(const akmi_pack *p, const double *w0, double *dt3, void *stream);
+
 /* ---- diffusion hooks of the Fluxes / EField tasks (src/hydro/hydro_tasks.cpp:183-189,
  * src/mhd/mhd_tasks.cpp:198-206,381-383); constant coefficients ---------------------------- */
 /* Viscosity::AddViscousFluxIso (src/diffusion/viscosity.cpp:64-229): momentum and energy fluxes of

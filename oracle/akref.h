@@ -56,6 +56,8 @@ int akref_resistive_emfs(const akmi_pack *p, double eta_ohm, const double *bx1f,
                          const double *bx3f, double *e1, double *e2, double *e3);
 int akref_resistive_fluxes(const akmi_pack *p, double eta_ohm, const double *bx1f, const double *bx2f,
                            const double *bx3f, double *flx1, double *flx2, double *flx3);
+void akref_advect_hyd(int ideal, const double wl[5], const double wr[5], double flx[5]);
+int akref_kinematic_newdt(const akmi_pack *p, const double *w0, double *dt3);
 int akref_rk4_copy_cons(const akmi_pack *p, double delta, const double *u0, double *u1);
 int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
                        double *flx1, double *flx2, double *flx3, int face_shaped);
@@ -147,6 +149,7 @@ typedef struct akref_params {
   double iso_cs;                   /* iso_sound_speed */
   int nscalars;                    /* passive scalars appended to the fluid variables */
   int fofc;                        /* <hydro>/fofc: first-order flux correction */
+  int kinematic;                   /* <time>/evolution = kinematic (with rsolver = advect) */
   double nu_iso, alpha_iso, eta_ohm; /* constant viscosity / thermal diffusivity / Ohmic resistivity
                                       * (0 = not requested), src/diffusion */
   /* <problem> */

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 RECON = {"dc": 0, "plm": 1, "ppm4": 2, "ppmx": 3, "wenoz": 4, "teno": 5}
-RSOLVER = {"llf": 0, "hlle": 1, "hllc": 2, "hlld": 3, "roe": 4}
+RSOLVER = {"llf": 0, "hlle": 1, "hllc": 2, "hlld": 3, "roe": 4, "advect": 5}
 BC = {"block": -1, "periodic": 0, "outflow": 1, "reflect": 2}
 PGEN = {"linear_wave": 0, "shock_tube": 1, "orszag_tang": 2, "blast": 3}
 
@@ -42,6 +42,7 @@ class Params(C.Structure):
                 ("tfloor", C.c_double), ("sfloor", C.c_double), ("sigma_max", C.c_double),
                 ("is_ideal", C.c_int), ("iso_cs", C.c_double), ("nscalars", C.c_int),
                 ("fofc", C.c_int),
+                ("kinematic", C.c_int),
                 ("nu_iso", C.c_double), ("alpha_iso", C.c_double), ("eta_ohm", C.c_double),
                 ("pgen", C.c_int),
                 ("wave_flag", C.c_int), ("along_x1", C.c_int), ("along_x2", C.c_int),

@@ -487,9 +487,21 @@ void akref_roe_hyd(double gamma, const double wl[5], const double wr[5], double 
 }
 
 /* solver selection of Hydro::CalculateFluxes (hydro_fluxes.cpp: template <Hydro_RSolver>) */
+/* Advect, src/hydro/rsolvers/advect_hyd.hpp:19-55 (kinematic runs): upwinded by the sign of the LEFT
+ * normal velocity; transverse components are v_t*v_n (no density), energy e_int*v_n */
+void akref_advect_hyd(int ideal, const double wl[5], const double wr[5], double flx[5]) {
+  const double *w = (wl[1] >= 0.0) ? wl : wr;
+  flx[0] = w[0]*w[1];
+  flx[1] = w[0]*w[1]*w[1];
+  flx[2] = w[2]*w[1];
+  flx[3] = w[3]*w[1];
+  if (ideal) flx[4] = w[4]*w[1];
+}
+
 static inline int hyd_riemann(int rs, double gamma, const double a[5], const double b[5],
                               double f[5]) {
   switch (rs) {
+    case AKMI_RS_ADVECT: akref_advect_hyd(1, a, b, f); return 0;
     case AKMI_RS_LLF:  akref_llf_hyd(gamma, a, b, f); return 0;
     case AKMI_RS_HLLE: akref_hlle_hyd(gamma, a, b, f); return 0;
     case AKMI_RS_HLLC: akref_hllc(gamma, a, b, f); return 0;
@@ -613,6 +625,7 @@ void akref_roe_hyd_iso(double iso_cs, const double wl[4], const double wr[4], do
 static inline int hyd_riemann_iso(int rs, double cs, const double a[4], const double b[4],
                                   double f[4]) {
   switch (rs) {
+    case AKMI_RS_ADVECT: akref_advect_hyd(0, a, b, f); return 0;
     case AKMI_RS_LLF:  akref_llf_hyd_iso(cs, a, b, f); return 0;
     case AKMI_RS_HLLE: akref_hlle_hyd_iso(cs, a, b, f); return 0;
     case AKMI_RS_ROE:  akref_roe_hyd_iso(cs, a, b, f); return 0;
@@ -1178,7 +1191,7 @@ int akref_rk4_copy_cons(const akmi_pack *p, double delta, const double *u0, doub
 static int hydro_fluxes_impl(const akmi_pack *p, int recon, int rsolver, const double *w0,
                              double *flx1, double *flx2, double *flx3, int fs, int ext) {
   if (rsolver != AKMI_RS_LLF && rsolver != AKMI_RS_HLLE && rsolver != AKMI_RS_HLLC &&
-      rsolver != AKMI_RS_ROE) return AKMI_FAIL;
+      rsolver != AKMI_RS_ROE && rsolver != AKMI_RS_ADVECT) return AKMI_FAIL;
   if (!p->is_ideal && rsolver == AKMI_RS_HLLC) return AKMI_FAIL;   /* hllc is ideal-gas only */
   const int ideal = p->is_ideal;
   G g = mkG(p);
@@ -1461,6 +1474,23 @@ int akref_hydro_newdt(const akmi_pack *p, const double *w0, double *dt3) {
           dt1 = fmin(p->dx[3*m]/max_dv1, dt1);
           dt2 = fmin(p->dx[3*m+1]/max_dv2, dt2);
           dt3_ = fmin(p->dx[3*m+2]/max_dv3, dt3_);
+        }
+  dt3[0] = dt1; dt3[1] = dt2; dt3[2] = dt3_;
+  return 0;
+}
+
+/* NewTimeStep of kinematic runs, src/hydro/hydro_newdt.cpp:55-72 == src/mhd/mhd_newdt.cpp:56-73 */
+int akref_kinematic_newdt(const akmi_pack *p, const double *w0, double *dt3) {
+  G g = mkG(p);
+  const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  double dt1 = (double)FLT_MAX, dt2 = (double)FLT_MAX, dt3_ = (double)FLT_MAX;
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = g.ks; k <= g.ke; ++k)
+      for (int j = g.js; j <= g.je; ++j)
+        for (int i = g.is; i <= g.ie; ++i) {
+          dt1 = fmin((p->dx[3*m]/fabs(w0[ix5(nv,N3,N2,N1,m,IVX,k,j,i)])), dt1);
+          dt2 = fmin((p->dx[3*m+1]/fabs(w0[ix5(nv,N3,N2,N1,m,IVY,k,j,i)])), dt2);
+          dt3_ = fmin((p->dx[3*m+2]/fabs(w0[ix5(nv,N3,N2,N1,m,IVZ,k,j,i)])), dt3_);
         }
   dt3[0] = dt1; dt3[1] = dt2; dt3[2] = dt3_;
   return 0;

@@ -93,6 +93,10 @@ akref_sim *akref_create(const akref_params *par) {
   if (s->nb1*p->mb_nx1 != p->nx1 || s->nb2*p->mb_nx2 != p->nx2 || s->nb3*p->mb_nx3 != p->nx3) {
     free(s); return NULL;
   }
+  /* rsolver = advect only for kinematic problems and vice versa (hydro.cpp:244-278); hydro only here */
+  if ((p->kinematic != 0) != (p->rsolver == AKMI_RS_ADVECT) || (p->kinematic && p->is_mhd)) {
+    free(s); return NULL;
+  }
   /* <hydro>|<mhd>/fofc: src/hydro/hydro.cpp:153-190, src/mhd/mhd.cpp:199-235 (ghost-zone checks) */
   if (p->fofc && ((p->is_mhd && !p->is_ideal) || p->nscalars > 0 || (p->recon == AKMI_RECON_PLM && p->ng < 3) ||
                   (p->recon >= AKMI_RECON_PPM4 && p->ng < 4))) {
@@ -727,7 +731,8 @@ static void halo_bcs_c2p(akref_sim *s) {
 
 static void new_dt_task(akref_sim *s) {
   double d3[3];
-  if (s->par.is_mhd) akref_mhd_newdt(&s->pack, s->w0, s->bcc0, d3);
+  if (s->par.kinematic) akref_kinematic_newdt(&s->pack, s->w0, d3);
+  else if (s->par.is_mhd) akref_mhd_newdt(&s->pack, s->w0, s->bcc0, d3);
   else akref_hydro_newdt(&s->pack, s->w0, d3);
   double dtnew = d3[0];
   if (s->multi_d) dtnew = fmin(dtnew, d3[1]);

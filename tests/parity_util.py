@@ -62,6 +62,7 @@ def oracle_kwargs(pin):
               bcs=[gs("mesh", k) for k in ("ix1_bc", "ox1_bc", "ix2_bc", "ox2_bc", "ix3_bc", "ox3_bc")],
               nstages={"rk1": 1, "rk2": 2, "rk3": 3, "rk4": 4}[gs("time", "integrator")],
               cfl=g("time", "cfl_number"), tlim=g("time", "tlim"), nlim=gi("time", "nlim"),
+              kinematic=1 if gs("time", "evolution") == "kinematic" else 0,
               is_mhd=1 if is_mhd else 0, recon=gs(blk, "reconstruct"), rsolver=gs(blk, "rsolver"),
               gamma=g(blk, "gamma"))
     if gs(blk, "eos") == "isothermal":

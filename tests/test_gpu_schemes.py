@@ -5,6 +5,8 @@ driver -- against the CPU oracle.  Bar: bit-identical (the oracle itself is pinn
 reference's thresholds for the whole matrix in test_oracle_pins.py)."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -184,6 +186,67 @@ def test_diffusion_hooks_are_bit_identical(case, native):
         assert sim.pmesh.dt == osim.dt
     d = pu.compare_fields(pu.product_arrays(sim), pu.oracle_arrays(osim, is_mhd), is_mhd)
     assert sim.pmesh.time == osim.time and d["bitwise_equal"], d
+
+
+# ---- kinematic runs: <time>/evolution = kinematic, rsolver = advect ---------------------------------
+_KIN = ("time/evolution=kinematic",)
+KINEMATIC = [
+    ("linear_wave_hydro", 64, 1, 32, 10, dict(rsolver="advect", extra=_KIN + ("problem/vx0=0.5",)), {}),
+    ("sod", 32, 2, 16, 6, dict(rsolver="advect", cfl=0.3, recon="wenoz", ng=3,
+                               extra=_KIN + ("problem/ul=0.7", "problem/ur=-0.4", "problem/vl=0.3")), dict(nu_iso=0.01)),
+    ("sod", 24, 3, 12, 4, dict(rsolver="advect", cfl=0.3, recon="ppm4", ng=3,
+                               extra=_KIN + ("problem/shock_dir=3", "problem/ul=-0.5", "problem/ur=0.6")),
+     dict(alpha_iso=0.02, nu_iso=0.01)),
+    ("linear_wave_hydro", 32, 2, 16, 6, dict(rsolver="advect", extra=_KIN + ("problem/vx0=0.5", "hydro/eos=isothermal")),
+     dict(nu_iso=0.02)),
+]
+
+
+@pytest.mark.parametrize("case", KINEMATIC, ids=lambda c: "%s-%d^%d" % (c[0], c[1], c[2]))
+def test_kinematic_advect_runs_are_bit_identical(case):
+    """advect_hyd + akmi_kinematic_newdt (+ the diffusion adders, which is what kinematic runs are for)"""
+    problem, n, dims, mb, cycles, kw, params = case
+    sim, osim, _ = pu.make_pair(problem, n, dims, mb, params=params, **kw)
+    assert sim.pmesh.dt == osim.dt
+    for _ in range(cycles):
+        assert sim.Execute(max_cycles=1) and osim.step()
+        assert sim.pmesh.dt == osim.dt
+    d = pu.compare_fields(pu.product_arrays(sim), pu.oracle_arrays(osim, False), False)
+    assert sim.pmesh.time == osim.time and d["bitwise_equal"], d
+
+
+@pytest.mark.parametrize("which", ["visc", "cond2d"])
+def test_diffusion_pgen_matches_the_cpu_backend(which):
+    """the reference's diffusion regressions (test_diffusion_{visc,conduct}_cpu.py) run against this
+    implementation through the oracle-backed host (tools/run_reference_suite.sh); here the same
+    set-up runs on the HIP kernels and must give the same error file, digit for digit"""
+    import tempfile
+    from athenak_amd.__main__ import main
+    import cpu_backend
+    args = {"visc": ["mesh/nx1=64", "meshblock/nx1=32", "problem/viscosity_test=true", "problem/vel_comp=3",
+                     "hydro/nu_iso=0.25", "time/tlim=0.3"],
+            "cond2d": ["mesh/nx1=32", "mesh/nx2=32", "meshblock/nx1=16", "meshblock/nx2=16",
+                       "problem/conduction_test=true", "problem/spread_x2=true", "hydro/alpha_iso=0.5",
+                       "time/tlim=0.2"]}[which]
+    here = os.getcwd()
+    out = []
+    try:
+        for backend in ("hip", "oracle"):
+            with tempfile.TemporaryDirectory() as d:
+                if backend == "oracle":
+                    cpu_backend.install()
+                try:
+                    assert main(["-i", "diffusion.athinput", "-d", d] + args) == 0
+                finally:
+                    os.chdir(here)
+                    if backend == "oracle":
+                        cpu_backend.uninstall()
+                out.append(open(os.path.join(d, "diffusion-errs.dat")).read())
+    finally:
+        os.chdir(here)
+    assert out[0] == out[1]
+    err = float(out[0].splitlines()[-1].split()[4])
+    assert 0.0 < err < 2e-9
 
 
 def _wild_states(shape5, rng, mhd):
