@@ -76,13 +76,13 @@ inline int dispatch_recon(int recon, F &&f) {
   return AKMI_FAIL;
 }
 
-// ADV: also accept rsolver = advect (kinematic runs; instantiated for the task-granular hydro flux
-// kernel only)
+// ADV: also accept rsolver = advect (kinematic runs; instantiated for the task-granular flux
+// kernels only)
 template <bool MHD, bool ADV = false, class F>
 inline int dispatch_rsolver(int rs, F &&f) {
   if (rs == AKMI_RS_LLF) return f(IC<0>{});
   if (rs == AKMI_RS_HLLE) return f(IC<1>{});
-  if constexpr (ADV && !MHD) {
+  if constexpr (ADV) {
     if (rs == AKMI_RS_ADVECT) return f(IC<5>{});
   }
   if constexpr (MHD) {

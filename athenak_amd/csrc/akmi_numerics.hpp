@@ -733,6 +733,25 @@ AKMI_DEV Cons1D llf_mhd(double gamma, double ld, double lx, double ly, double lz
   return f;
 }
 
+// Advect for MHD, src/mhd/rsolvers/advect_mhd.hpp:18-58 (kinematic runs).  .e is NOT a flux: the
+// reference leaves the energy flux untouched, and so do the callers of this function.
+AKMI_DEV Cons1D advect_mhd(double ld, double lx, double ly, double lz, double lby, double lbz,
+                           double rd, double rx, double ry, double rz, double rby, double rbz,
+                           double bxi) {
+  Cons1D f;
+  f.my = 0.0; f.mz = 0.0; f.e = 0.0;
+  if (lx >= 0.0) {
+    f.d = ld*lx; f.mx = ld*lx*lx;
+    f.by = -(-lby*lx + bxi*ly);            // the caller stores ey = -f.by
+    f.bz = lbz*lx - bxi*lz;
+  } else {
+    f.d = rd*rx; f.mx = rd*rx*rx;
+    f.by = -(-rby*rx + bxi*ry);
+    f.bz = rbz*rx - bxi*rz;
+  }
+  return f;
+}
+
 // HLLE for MHD, src/mhd/rsolvers/hlle_mhd.hpp:24-178 (ideal gas)
 AKMI_DEV Cons1D hlle_mhd(double gamma, double dl, double ul, double vl, double zl, double eil,
                          double byl, double bzl, double dr, double ur, double vr, double zr,
@@ -811,7 +830,8 @@ template <int RS>
 AKMI_DEV Cons1D riemann_mhd(double gamma, double ld, double lx, double ly, double lz, double le,
                             double lby, double lbz, double rd, double rx, double ry, double rz,
                             double re, double rby, double rbz, double bxi) {
-  if constexpr (RS == 0) return llf_mhd(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
+  if constexpr (RS == 5) return advect_mhd(ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
+  else if constexpr (RS == 0) return llf_mhd(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
   else if constexpr (RS == 1) return hlle_mhd(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
   else return hlld(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
 }
@@ -1145,7 +1165,8 @@ template <int RS>
 AKMI_DEV Cons1D riemann_mhd_iso(const FaceEos &eos, double ld, double lx, double ly, double lz,
                                 double lby, double lbz, double rd, double rx, double ry, double rz,
                                 double rby, double rbz, double bxi) {
-  if constexpr (RS == 0) return llf_mhd_iso(eos.iso_cs, ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
+  if constexpr (RS == 5) return advect_mhd(ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
+  else if constexpr (RS == 0) return llf_mhd_iso(eos.iso_cs, ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
   else if constexpr (RS == 1) return hlle_mhd_iso(eos.iso_cs, ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
   else return hlld_iso(eos.iso_cs, eos.dfloor, ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
 }

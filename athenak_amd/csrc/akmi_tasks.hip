@@ -354,7 +354,7 @@ k_mhd_flux(Geo g, FaceEos eos, const double *__restrict__ w0, const double *__re
   const size_t fs = (size_t)f3*f2*f1;
   double *f = flx + ix5(g.nvar, f3, f2, f1, m, 0, k, j, i);
   f[0] = fl.d; f[ivx*fs] = fl.mx; f[ivy*fs] = fl.my; f[ivz*fs] = fl.mz;
-  if constexpr (!ISO) f[4*fs] = fl.e;
+  if constexpr (!ISO && RS != 5) f[4*fs] = fl.e;      // advect leaves the energy flux untouched
   // passive scalars, active transverse range only (mhd_fluxes.cpp:153-166)
   constexpr int NF = ISO ? 4 : 5;
   if (g.nvar > NF && i >= g.is && i <= g.ie + (DIR == 0) && j >= g.js && j <= g.je + (DIR == 1) &&
@@ -392,7 +392,7 @@ static int launch_mhd_flux(const Geo &g, const Scheme &sc, const double *w0,
   }
   int nk = ku - kl + 1;
   dim3 grid(cdiv(iu - il + 1, BX), cdiv(ju - jl + 1, BY), nk*g.nmb), block(BX, BY);
-  int rc = dispatch_scheme<true>(sc, [&](auto R, auto S) {
+  int rc = dispatch_scheme<true, true>(sc, [&](auto R, auto S) {
     if (sc.iso)
       k_mhd_flux<DIR, decltype(R)::value, decltype(S)::value, true><<<grid, block, 0, st>>>(
           g, sc.eos, w0, bcc0, bxf, flx, ey, ez, f3, f2, f1, il, iu, jl, ju, kl, nk);

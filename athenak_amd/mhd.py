@@ -18,12 +18,17 @@ class MHD(FluidBase):
     def __init__(self, ppack, pin, device=None, bvals_kernels=None):
         device = device or capi.DEVICE
         self._setup(ppack, pin, "mhd", device)
-        if pin.GetOrAddString("time", "evolution", "dynamic") != "dynamic":
-            raise RuntimeError("### FATAL ERROR kinematic MHD (rsolver = advect) is not on this path")
         rs = pin.GetString("mhd", "rsolver")
-        if rs not in ("llf", "hlle", "hlld"):                   # mhd.cpp: MHD_RSolver
-            raise RuntimeError("### FATAL ERROR <mhd> rsolver = '%s' not implemented "
-                               "(llf, hlle, hlld on this path)" % rs)
+        # dynamic problems: llf/hlle/hlld; kinematic problems: advect (mhd.cpp:292-326)
+        self.kinematic = pin.GetOrAddString("time", "evolution", "dynamic") == "kinematic"
+        if self.kinematic:
+            if rs != "advect":
+                raise RuntimeError("### FATAL ERROR <mhd> rsolver = '%s' not implemented for "
+                                   "kinematic problems" % rs)
+            self.fused = False
+        elif rs not in ("llf", "hlle", "hlld"):                 # mhd.cpp: MHD_RSolver
+            raise RuntimeError("### FATAL ERROR <mhd> rsolver = '%s' not implemented for dynamic "
+                               "problems (llf, hlle, hlld on this path)" % rs)
         self.rsolver_method = capi.RSOLVER[rs]
         self.nmhd = self.nfluid
         n3, n2, n1 = ppack.pmesh.mb_indcs.ncells
@@ -232,7 +237,10 @@ class MHD(FluidBase):
         """mhd_newdt.cpp:31-174: last stage only"""
         if stage != pdrive.nexp_stages:
             return TaskStatus.complete
-        if not getattr(self, "_dt_ready", False):
+        if self.kinematic:                                       # mhd_newdt.cpp:56-73
+            capi.check(self.L.akmi_kinematic_newdt(C.byref(self.pack_c), capi._p(self.w0),
+                                                   capi._p(self.dt3), capi._stream()), "kinematic_newdt")
+        elif not getattr(self, "_dt_ready", False):
             capi.check(self.L.akmi_mhd_newdt(C.byref(self.pack_c), capi._p(self.w0),
                                              capi._p(self.bcc0), capi._p(self.dt3), capi._stream()),
                        "mhd_newdt")

@@ -558,9 +558,10 @@ class ProblemGenerator:
         if ntests != 1:
             raise RuntimeError("### FATAL ERROR Exactly one of conduction_test/viscosity_test/"
                                "resistivity_test must be set true (got %d)" % ntests)
+        if pm.pmb_pack.pmhd is not None:
+            self._diffusion_mhd()
+            return
         ph = pm.pmb_pack.phydro
-        if ph is None:
-            raise RuntimeError("### FATAL ERROR the MHD (resistivity) diffusion test is not on this path")
         if dv["conduction_test"] and ph.pcond is None:
             raise RuntimeError("### FATAL ERROR Conduction not defined in Hydro input block")
         if dv["viscosity_test"] and ph.pvisc is None:
@@ -577,6 +578,41 @@ class ProblemGenerator:
             u[m][:, ks, js, is_] = self._diff_cons_state(coef, gamma, pm.time, X1, X2, X3)
         # solution in u1 when computing errors, in u0 as initial condition (diffusion.cpp:201)
         self._upload_cc(ph.u0 if self.set_initial_conditions else ph.u1, u)
+
+    def _diffusion_mhd(self):
+        """diffusion.cpp:237-311: Gaussian pulse in one field component (uniform along its own
+        axis, so the staggered faces carry the cell-centred value and div B = 0), rho = 1, v = 0,
+        p = 1/gamma; diffuses with eta_ohm"""
+        pm = self.pmy_mesh_
+        ph = pm.pmb_pack.pmhd
+        dv = self.diffvars
+        if not dv["resistivity_test"]:
+            raise RuntimeError("### FATAL ERROR MHD diffusion test only supports the resistivity test")
+        if ph.presist is None:
+            raise RuntimeError("### FATAL ERROR Resistivity (mhd/eta_ohm) not defined in MHD input block")
+        if not ph.peos.eos_data.is_ideal:
+            raise RuntimeError("### FATAL ERROR Diffusion test requires ideal EOS in MHD block")
+        gamma = ph.peos.eos_data.gamma
+        coef = ph.presist.eta_ohm
+        bcomp = dv["vel_comp"]
+        w, bf = self._alloc_host()
+        ks, js, is_ = self._active()
+        for m in range(w.shape[0]):
+            x1v, x2v, x3v, _, _, _, _ = self._coords(m)
+            X3, X2, X1 = np.meshgrid(x3v, x2v, x1v, indexing="ij")
+            g = self._diff_gaussian(coef, pm.time, X1, X2, X3)
+            w[m, IDN][ks, js, is_] = 1.0
+            w[m, IEN][ks, js, is_] = (1.0/gamma)/(gamma - 1.0)
+            if bcomp == 1:
+                bf[0][m][ks, js, is_] = g
+                bf[0][m][ks, js, is_.stop] = g[:, :, -1]
+            elif bcomp == 2:
+                bf[1][m][ks, js, is_] = g
+                bf[1][m][ks, js.stop, is_] = g[:, -1, :]
+            else:
+                bf[2][m][ks, js, is_] = g
+                bf[2][m][ks.stop, js, is_] = g[-1, :, :]
+        self._store(w, bf, to_u1=not self.set_initial_conditions)
 
     def DiffusionErrors(self):
         """diffusion.cpp:330-337"""

@@ -57,6 +57,7 @@ int akref_resistive_emfs(const akmi_pack *p, double eta_ohm, const double *bx1f,
 int akref_resistive_fluxes(const akmi_pack *p, double eta_ohm, const double *bx1f, const double *bx2f,
                            const double *bx3f, double *flx1, double *flx2, double *flx3);
 void akref_advect_hyd(int ideal, const double wl[5], const double wr[5], double flx[5]);
+void akref_advect_mhd(int nb, const double wl[7], const double wr[7], double bxi, double flx[7]);
 int akref_kinematic_newdt(const akmi_pack *p, const double *w0, double *dt3);
 int akref_rk4_copy_cons(const akmi_pack *p, double delta, const double *u0, double *u1);
 int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,

@@ -962,9 +962,25 @@ void akref_hlle_mhd(double gamma, const double wl[7], const double wr[7], double
   flx[6] = 0.5*(fl_bz + fr_bz) + (fl_bz - fr_bz)*tmp;
 }
 
+/* Advect for MHD, src/mhd/rsolvers/advect_mhd.hpp:18-58 (kinematic runs): mass and normal-momentum
+ * flux upwinded by the sign of the left normal velocity, transverse momentum fluxes zero, EMFs of
+ * the upwind state; the ENERGY flux is not touched by the reference (flx[4] is left as it is).
+ * nb = index of the first field slot (5 ideal gas, 4 isothermal) */
+void akref_advect_mhd(int nb, const double wl[7], const double wr[7], double bxi, double flx[7]) {
+  const double *w = (wl[1] >= 0.0) ? wl : wr;
+  flx[0] = w[0]*w[1];
+  flx[1] = w[0]*w[1]*w[1];
+  flx[2] = 0.0;
+  flx[3] = 0.0;
+  /* ey = -by*vx + bxi*vy is stored as ey = -flx[nb]; ez = bz*vx - bxi*vz = flx[nb+1] */
+  flx[nb] = -(-w[nb]*w[1] + bxi*w[2]);
+  flx[nb + 1] = w[nb + 1]*w[1] - bxi*w[3];
+}
+
 static inline int mhd_riemann(int rs, double gamma, const double a[7], const double b[7],
                               double bxi, double f[7]) {
   switch (rs) {
+    case AKMI_RS_ADVECT: akref_advect_mhd(5, a, b, bxi, f); return 0;
     case AKMI_RS_LLF:  akref_llf_mhd(gamma, a, b, bxi, f); return 0;
     case AKMI_RS_HLLE: akref_hlle_mhd(gamma, a, b, bxi, f); return 0;
     case AKMI_RS_HLLD: akref_hlld(gamma, a, b, bxi, f); return 0;
@@ -1502,7 +1518,8 @@ static int mhd_fluxes_impl(const akmi_pack *p, int recon, int rsolver, const dou
                      const double *bx3f, double *flx1, double *flx2, double *flx3,
                      double *e3x1, double *e2x1, double *e1x2, double *e3x2, double *e2x3,
                      double *e1x3, int ext) {
-  if (rsolver != AKMI_RS_LLF && rsolver != AKMI_RS_HLLE && rsolver != AKMI_RS_HLLD) return AKMI_FAIL;
+  if (rsolver != AKMI_RS_LLF && rsolver != AKMI_RS_HLLE && rsolver != AKMI_RS_HLLD &&
+      rsolver != AKMI_RS_ADVECT) return AKMI_FAIL;
   const int ideal = p->is_ideal;
   G g = mkG(p);
   const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
@@ -1555,13 +1572,14 @@ static int mhd_fluxes_impl(const akmi_pack *p, int recon, int rsolver, const dou
             if (ideal) { a[4] = wl[ix5(nv,N3,N2,N1,m,IEN,k,j,i)]; b[4] = wr[ix5(nv,N3,N2,N1,m,IEN,k,j,i)]; }
             a[ob] = bl[ix5(3,N3,N2,N1,m,iby,k,j,i)];      b[ob] = br[ix5(3,N3,N2,N1,m,iby,k,j,i)];
             a[ob + 1] = bl[ix5(3,N3,N2,N1,m,ibz,k,j,i)];  b[ob + 1] = br[ix5(3,N3,N2,N1,m,ibz,k,j,i)];
-            if (ideal) mhd_riemann(rsolver, gamma, a, b, bxi, f);
+            if (rsolver == AKMI_RS_ADVECT) akref_advect_mhd(ob, a, b, bxi, f);
+            else if (ideal) mhd_riemann(rsolver, gamma, a, b, bxi, f);
             else mhd_riemann_iso(rsolver, p->iso_cs, p->dfloor, a, b, bxi, f);
             flx[ix5(nv,f3,f2,f1,m,IDN,k,j,i)] = f[0];
             flx[ix5(nv,f3,f2,f1,m,ivx,k,j,i)] = f[1];
             flx[ix5(nv,f3,f2,f1,m,ivy,k,j,i)] = f[2];
             flx[ix5(nv,f3,f2,f1,m,ivz,k,j,i)] = f[3];
-            if (ideal) flx[ix5(nv,f3,f2,f1,m,IEN,k,j,i)] = f[4];
+            if (ideal && rsolver != AKMI_RS_ADVECT) flx[ix5(nv,f3,f2,f1,m,IEN,k,j,i)] = f[4];
             ey[ix4(N3,N2,N1,m,k,j,i)] = -f[ob];
             ez[ix4(N3,N2,N1,m,k,j,i)] = f[ob + 1];
           }

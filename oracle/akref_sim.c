@@ -93,8 +93,8 @@ akref_sim *akref_create(const akref_params *par) {
   if (s->nb1*p->mb_nx1 != p->nx1 || s->nb2*p->mb_nx2 != p->nx2 || s->nb3*p->mb_nx3 != p->nx3) {
     free(s); return NULL;
   }
-  /* rsolver = advect only for kinematic problems and vice versa (hydro.cpp:244-278); hydro only here */
-  if ((p->kinematic != 0) != (p->rsolver == AKMI_RS_ADVECT) || (p->kinematic && p->is_mhd)) {
+  /* rsolver = advect only for kinematic problems and vice versa (hydro.cpp:244-278, mhd.cpp:292-326) */
+  if ((p->kinematic != 0) != (p->rsolver == AKMI_RS_ADVECT)) {
     free(s); return NULL;
   }
   /* <hydro>|<mhd>/fofc: src/hydro/hydro.cpp:153-190, src/mhd/mhd.cpp:199-235 (ghost-zone checks) */

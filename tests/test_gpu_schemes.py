@@ -199,6 +199,12 @@ KINEMATIC = [
      dict(alpha_iso=0.02, nu_iso=0.01)),
     ("linear_wave_hydro", 32, 2, 16, 6, dict(rsolver="advect", extra=_KIN + ("problem/vx0=0.5", "hydro/eos=isothermal")),
      dict(nu_iso=0.02)),
+    # kinematic MHD: advect_mhd leaves the energy flux alone, so the resistive Poynting flux accumulates in it
+    ("linear_wave_mhd", 64, 1, 32, 8, dict(rsolver="advect", extra=_KIN + ("problem/vx0=0.5",)), dict(eta_ohm=0.02)),
+    ("orszag_tang", 32, 2, 16, 6, dict(rsolver="advect", extra=_KIN), dict(eta_ohm=0.005, nu_iso=0.002)),
+    ("orszag_tang", 24, 3, 12, 4, dict(rsolver="advect", cfl=0.3, recon="wenoz", ng=3, extra=_KIN), dict(eta_ohm=0.004)),
+    ("linear_wave_mhd", 32, 2, 16, 5, dict(rsolver="advect", extra=_KIN + ("problem/vx0=0.5", "mhd/eos=isothermal")),
+     dict(eta_ohm=0.01)),
 ]
 
 
@@ -206,16 +212,16 @@ KINEMATIC = [
 def test_kinematic_advect_runs_are_bit_identical(case):
     """advect_hyd + akmi_kinematic_newdt (+ the diffusion adders, which is what kinematic runs are for)"""
     problem, n, dims, mb, cycles, kw, params = case
-    sim, osim, _ = pu.make_pair(problem, n, dims, mb, params=params, **kw)
+    sim, osim, is_mhd = pu.make_pair(problem, n, dims, mb, params=params, **kw)
     assert sim.pmesh.dt == osim.dt
     for _ in range(cycles):
         assert sim.Execute(max_cycles=1) and osim.step()
         assert sim.pmesh.dt == osim.dt
-    d = pu.compare_fields(pu.product_arrays(sim), pu.oracle_arrays(osim, False), False)
+    d = pu.compare_fields(pu.product_arrays(sim), pu.oracle_arrays(osim, is_mhd), is_mhd)
     assert sim.pmesh.time == osim.time and d["bitwise_equal"], d
 
 
-@pytest.mark.parametrize("which", ["visc", "cond2d"])
+@pytest.mark.parametrize("which", ["visc", "cond2d", "resist"])
 def test_diffusion_pgen_matches_the_cpu_backend(which):
     """the reference's diffusion regressions (test_diffusion_{visc,conduct}_cpu.py) run against this
     implementation through the oracle-backed host (tools/run_reference_suite.sh); here the same
@@ -227,7 +233,10 @@ def test_diffusion_pgen_matches_the_cpu_backend(which):
                      "hydro/nu_iso=0.25", "time/tlim=0.3"],
             "cond2d": ["mesh/nx1=32", "mesh/nx2=32", "meshblock/nx1=16", "meshblock/nx2=16",
                        "problem/conduction_test=true", "problem/spread_x2=true", "hydro/alpha_iso=0.5",
-                       "time/tlim=0.2"]}[which]
+                       "time/tlim=0.2"],
+            "resist": ["mesh/nx1=64", "meshblock/nx1=32", "problem/vel_comp=3", "time/tlim=0.3"]}[which]
+    deck, base = ("diffusion_mhd.athinput", "diffusion_resist") if which == "resist" else \
+                 ("diffusion.athinput", "diffusion")
     here = os.getcwd()
     out = []
     try:
@@ -236,12 +245,12 @@ def test_diffusion_pgen_matches_the_cpu_backend(which):
                 if backend == "oracle":
                     cpu_backend.install()
                 try:
-                    assert main(["-i", "diffusion.athinput", "-d", d] + args) == 0
+                    assert main(["-i", deck, "-d", d] + args) == 0
                 finally:
                     os.chdir(here)
                     if backend == "oracle":
                         cpu_backend.uninstall()
-                out.append(open(os.path.join(d, "diffusion-errs.dat")).read())
+                out.append(open(os.path.join(d, base + "-errs.dat")).read())
     finally:
         os.chdir(here)
     assert out[0] == out[1]
