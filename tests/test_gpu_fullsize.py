@@ -1,0 +1,103 @@
+"""gpu: BASELINE.json's FULL sizes (C2 hydro 128^3, C3 MHD 256^3), where the CPU oracle is too slow
+to run beside the HIP path.  Parity is carried to these sizes by properties that do not depend on
+the size: the fused stage kernels and the task-granular kernels (each bit-identical to the oracle at
+fixture size) must agree bit for bit; the result must not depend on the MeshBlock decomposition
+(one 256^3 block vs eight 128^3 blocks exchanging ghost zones); mass, momentum and total energy of
+a periodic box are conserved to round-off; div B stays at round-off."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import parity_util as pu  # noqa: E402
+
+
+def _run(problem, n, mb, cycles, fused, **kw):
+    import torch
+    from athenak_amd.main import Simulation, load_deck
+    deck, ov = pu.deck_overrides(problem, n, 3, mb, **kw)
+    pin = load_deck(deck, ov)
+    blk = "mhd" if pin.DoesBlockExist("mhd") else "hydro"
+    pin.blocks[blk]["fused_stage"] = "true" if fused else "false"
+    sim = Simulation(pin)
+    ph = sim.phys
+    ind = sim.pmesh.mb_indcs
+    a = (slice(None), slice(None), slice(ind.ks, ind.ke + 1), slice(ind.js, ind.je + 1),
+         slice(ind.is_, ind.ie + 1))
+    tot0 = ph.u0[a].sum(dim=(0, 2, 3, 4)).cpu().numpy()
+    assert sim.Execute(max_cycles=cycles) == cycles
+    torch.cuda.synchronize()
+    return sim, tot0, ph.u0[a].sum(dim=(0, 2, 3, 4)).cpu().numpy(), a
+
+
+def _global(sim, t):
+    """active cells of a cell-centred (nmb, nvar, ...) tensor assembled into the global mesh"""
+    import torch
+    pm = sim.pmesh
+    ind = pm.mb_indcs
+    nv = t.shape[1]
+    out = torch.empty((nv, pm.mesh_indcs.nx3, pm.mesh_indcs.nx2, pm.mesh_indcs.nx1), dtype=t.dtype,
+                      device=t.device)
+    for m, l in enumerate(pm.lloc_eachmb):
+        out[:, l[2]*ind.nx3:(l[2] + 1)*ind.nx3, l[1]*ind.nx2:(l[1] + 1)*ind.nx2,
+            l[0]*ind.nx1:(l[0] + 1)*ind.nx1] = t[m][:, ind.ks:ind.ke + 1, ind.js:ind.je + 1, ind.is_:ind.ie + 1]
+    return out
+
+
+def _divb(sim):
+    ph, ind = sim.phys, sim.pmesh.mb_indcs
+    k, j, i = slice(ind.ks, ind.ke + 1), slice(ind.js, ind.je + 1), slice(ind.is_, ind.ie + 1)
+    k1, j1, i1 = slice(ind.ks + 1, ind.ke + 2), slice(ind.js + 1, ind.je + 2), slice(ind.is_ + 1, ind.ie + 2)
+    dx = sim.pmesh.pmb_pack.pmb.dx[0]
+    d = ((ph.b0.x1f[:, k, j, i1] - ph.b0.x1f[:, k, j, i])/dx[0] +
+         (ph.b0.x2f[:, k, j1, i] - ph.b0.x2f[:, k, j, i])/dx[1] +
+         (ph.b0.x3f[:, k1, j, i] - ph.b0.x3f[:, k, j, i])/dx[2])
+    return float(d.abs().max())
+
+
+def test_c3_mhd_256_fused_equals_task_path_and_conserves():
+    """C3: Orszag-Tang 256^3, PLM+HLLD+CT, RK2, cfl 0.3, 4 cycles"""
+    import torch
+    sf, t0, t1, a = _run("orszag_tang", 256, 256, 4, True, cfl=0.3)
+    # periodic box: sums of the conserved variables change only by round-off of 1.7e7-term sums
+    scale = np.abs(t0).max()
+    assert np.all(np.abs(t1 - t0) <= 1e-12*scale*np.maximum(1.0, np.abs(t0)/scale)), (t0, t1)
+    assert _divb(sf) < 1e-11
+    uf = sf.phys.u0.clone()
+    bf = [sf.phys.b0.x1f.clone(), sf.phys.b0.x2f.clone(), sf.phys.b0.x3f.clone()]
+    tf, dtf = sf.pmesh.time, sf.pmesh.dt
+    del sf
+    torch.cuda.empty_cache()
+    ss, _, _, _ = _run("orszag_tang", 256, 256, 4, False, cfl=0.3)
+    assert (ss.pmesh.time, ss.pmesh.dt) == (tf, dtf)
+    assert torch.equal(ss.phys.u0, uf)
+    assert all(torch.equal(x, y) for x, y in zip((ss.phys.b0.x1f, ss.phys.b0.x2f, ss.phys.b0.x3f), bf))
+
+
+def test_c3_mhd_256_is_independent_of_the_block_decomposition():
+    """one 256^3 MeshBlock vs eight 128^3 MeshBlocks (ghost exchange, Z-ordered pack): same bits"""
+    import torch
+    s1, _, _, _ = _run("orszag_tang", 256, 256, 3, True, cfl=0.3)
+    g1 = _global(s1, s1.phys.u0).clone()
+    w1 = _global(s1, s1.phys.bcc0).clone()
+    t1 = (s1.pmesh.time, s1.pmesh.dt)
+    del s1
+    torch.cuda.empty_cache()
+    s8, _, _, _ = _run("orszag_tang", 256, 128, 3, True, cfl=0.3)
+    assert (s8.pmesh.time, s8.pmesh.dt) == t1
+    assert torch.equal(_global(s8, s8.phys.u0), g1)
+    assert torch.equal(_global(s8, s8.phys.bcc0), w1)
+
+
+def test_c2_hydro_128_fused_equals_task_path():
+    """C2: Sod 128^3, PLM+HLLC, RK2, cfl 0.3 (outflow in x1): fused == task-granular, both hosts'
+    decomposition 1 x 128^3 == 8 x 64^3"""
+    import torch
+    sf, _, _, _ = _run("sod", 128, 128, 6, True, cfl=0.3)
+    ss, _, _, _ = _run("sod", 128, 128, 6, False, cfl=0.3)
+    assert (ss.pmesh.time, ss.pmesh.dt) == (sf.pmesh.time, sf.pmesh.dt)
+    assert torch.equal(ss.phys.u0, sf.phys.u0) and torch.equal(ss.phys.w0, sf.phys.w0)
+    s8, _, _, _ = _run("sod", 128, 64, 6, True, cfl=0.3)
+    assert torch.equal(_global(s8, s8.phys.u0), _global(sf, sf.phys.u0))
+    # mass leaves only through the x1 outflow faces; the transverse momenta stay exactly zero
+    assert float(sf.phys.u0[:, 2:4].abs().max()) == 0.0
