@@ -258,7 +258,7 @@ struct UpdArgs {
 #define AKMI_PREFETCH_UPD 1
 #endif
 #ifndef AKMI_PREFETCH_X1
-#define AKMI_PREFETCH_X1 1
+#define AKMI_PREFETCH_X1 0
 #endif
 constexpr int ML = AKMI_ML;            // faces marched per thread (chunk length), full-size packs
 
