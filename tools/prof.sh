@@ -8,5 +8,5 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $out -- python $root/bench.py --no-cpu-baseline "$@" > $out/bench.log 2>&1
 python $root/tools/kernel_stats.py $out "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline $*" > $root/gpurun_out/${tag}_kernel_stats.txt
-tail -1 $out/bench.log > $root/gpurun_out/${tag}_bench.json
+grep "^{\"metric\"" $out/bench.log | tail -1 > $root/gpurun_out/${tag}_bench.json
 cat $root/gpurun_out/${tag}_kernel_stats.txt | head -24
