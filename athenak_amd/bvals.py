@@ -58,13 +58,13 @@ class HipBvalsKernels:
                                                capi._p(buf), capi._p(b1), capi._p(b2), capi._p(b3),
                                                capi._stream()), "bvals_fc_unpack")
 
-    def hydro_bcs(self, pack, nvar, bcs, u):
-        capi.check(self.L.akmi_hydro_bcs(C.byref(pack), nvar, capi._p(bcs), capi._p(u),
-                                         capi._stream()), "hydro_bcs")
+    def hydro_bcs(self, pack, nvar, bcs, u, u_in=None):
+        capi.check(self.L.akmi_hydro_bcs_inflow(C.byref(pack), nvar, capi._p(bcs), capi._p(u_in),
+                                                capi._p(u), capi._stream()), "hydro_bcs")
 
-    def bfield_bcs(self, pack, bcs, b1, b2, b3):
-        capi.check(self.L.akmi_bfield_bcs(C.byref(pack), capi._p(bcs), capi._p(b1), capi._p(b2),
-                                          capi._p(b3), capi._stream()), "bfield_bcs")
+    def bfield_bcs(self, pack, bcs, b1, b2, b3, b_in=None):
+        capi.check(self.L.akmi_bfield_bcs_inflow(C.byref(pack), capi._p(bcs), capi._p(b_in), capi._p(b1),
+                                                 capi._p(b2), capi._p(b3), capi._stream()), "bfield_bcs")
 
 
 class _Channel:
@@ -159,6 +159,9 @@ class MeshBoundaryValues:
     def set_pack(self, pack_c, nvar):
         self.pack_c = pack_c
         self.nvar = nvar
+        # inflow states (bvals.cpp:323-326), [variable][BoundaryFace]; a problem generator fills them
+        self.u_in = torch.zeros((nvar, 6), dtype=torch.float64, device=self.device)
+        self.b_in = torch.zeros((3, 6), dtype=torch.float64, device=self.device)
         self.cc = self._plan(lambda d: nvar*self.k.cc_segsize(pack_c, d))
         self.fc = self._plan(lambda d: self.k.fc_segsize(pack_c, d))
 
@@ -232,7 +235,7 @@ class MeshBoundaryValues:
 
     # ---- physical boundaries -----------------------------------------------------
     def HydroBCs(self, u):
-        self.k.hydro_bcs(self.pack_c, self.nvar, self.bcs, u)
+        self.k.hydro_bcs(self.pack_c, self.nvar, self.bcs, u, self.u_in)
 
     def BFieldBCs(self, b):
-        self.k.bfield_bcs(self.pack_c, self.bcs, b.x1f, b.x2f, b.x3f)
+        self.k.bfield_bcs(self.pack_c, self.bcs, b.x1f, b.x2f, b.x3f, self.b_in)

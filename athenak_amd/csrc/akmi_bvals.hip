@@ -181,7 +181,8 @@ k_pack(Geo g, Comp q, int nv, const int *__restrict__ send_tab,
 // indices including ghosts; outflow and reflect.
 template <int DIR>
 __global__ void __launch_bounds__(256)
-k_hydro_bc(Geo g, int nv, const int *__restrict__ bcs, double *__restrict__ u) {
+k_hydro_bc(Geo g, int nv, const int *__restrict__ bcs, const double *__restrict__ u_in,
+           double *__restrict__ u) {
   const int t1 = (DIR == 0) ? g.N2 : g.N1;            // fastest transverse extent
   const int t2 = (DIR == 2) ? g.N2 : g.N3;            // slowest transverse extent
   const long long tot = (long long)g.nmb*nv*t2*t1;
@@ -201,13 +202,20 @@ k_hydro_bc(Geo g, int nv, const int *__restrict__ bcs, double *__restrict__ u) {
     return u[ix5(nv, g.N3, g.N2, g.N1, m, n, k, j, i)];
   };
   const double sgn = (n == 1 + DIR) ? -1.0 : 1.0;
+  const bool normal = (n == 1 + DIR);
   for (int q = 0; q < g.ng; ++q) {
     if (bi == AKMI_BC_REFLECT) at(s - q - 1) = sgn*at(s + q);
     else if (bi == AKMI_BC_OUTFLOW) at(s - q - 1) = at(s);
+    else if (bi == AKMI_BC_INFLOW) at(s - q - 1) = u_in[6*n + 2*DIR];
+    else if (bi == AKMI_BC_DIODE) at(s - q - 1) = normal ? fmin(0.0, at(s)) : at(s);
+    else if (bi == AKMI_BC_VACUUM) at(s - q - 1) = 0.0;
   }
   for (int q = 0; q < g.ng; ++q) {
     if (bo == AKMI_BC_REFLECT) at(e + q + 1) = sgn*at(e - q);
     else if (bo == AKMI_BC_OUTFLOW) at(e + q + 1) = at(e);
+    else if (bo == AKMI_BC_INFLOW) at(e + q + 1) = u_in[6*n + 2*DIR + 1];
+    else if (bo == AKMI_BC_DIODE) at(e + q + 1) = normal ? fmax(0.0, at(e)) : at(e);
+    else if (bo == AKMI_BC_VACUUM) at(e + q + 1) = 0.0;
   }
 }
 
@@ -216,8 +224,8 @@ k_hydro_bc(Geo g, int nv, const int *__restrict__ bcs, double *__restrict__ u) {
 // direction exactly as in the reference.
 template <int DIR>
 __global__ void __launch_bounds__(256)
-k_bfield_bc(Geo g, const int *__restrict__ bcs, double *__restrict__ b1, double *__restrict__ b2,
-            double *__restrict__ b3) {
+k_bfield_bc(Geo g, const int *__restrict__ bcs, const double *__restrict__ b_in,
+            double *__restrict__ b1, double *__restrict__ b2, double *__restrict__ b3) {
   const int t1 = (DIR == 0) ? g.N2 : g.N1;
   const int t2 = (DIR == 2) ? g.N2 : g.N3;
   const long long tot = (long long)g.nmb*t2*t1;
@@ -246,8 +254,12 @@ k_bfield_bc(Geo g, const int *__restrict__ bcs, double *__restrict__ b1, double 
   for (int q = 0; q < g.ng; ++q) {
     for (int side = 0; side < 2; ++side) {
       const int bc = side ? bo : bi;
-      if (bc != AKMI_BC_REFLECT && bc != AKMI_BC_OUTFLOW) continue;
+      // diode and vacuum treat the field like outflow (bfield_bcs.cpp:88-97); inflow: b_in
+      if (bc != AKMI_BC_REFLECT && bc != AKMI_BC_OUTFLOW && bc != AKMI_BC_DIODE &&
+          bc != AKMI_BC_VACUUM && bc != AKMI_BC_INFLOW) continue;
       const bool refl = (bc == AKMI_BC_REFLECT);
+      const bool infl = (bc == AKMI_BC_INFLOW);
+      const int face = 2*DIR + side;
       // ghost index / source index for the normal component (face-centred along DIR)
       const int gn = side ? e + q + 2 : s - q - 1;
       const int sn = side ? (refl ? e - q : e + 1) : (refl ? s + q + 1 : s);
@@ -255,25 +267,28 @@ k_bfield_bc(Geo g, const int *__restrict__ bcs, double *__restrict__ b1, double 
       const int gt = side ? e + q + 1 : s - q - 1;
       const int stt = side ? (refl ? e - q : e) : (refl ? s + q : s);
       const double sg = refl ? -1.0 : 1.0;
+      // value stored in a ghost face of component c: the inflow constant or the (reflected) source
+#define BV(c, expr) (infl ? b_in[6*(c) + face] : (expr))
       if (DIR == 0) {
-        B1(gn, a, b) = sg*B1(sn, a, b);
-        B2(gt, a, b) = B2(stt, a, b);
-        if (a == N2 - 1) B2(gt, a + 1, b) = B2(stt, a + 1, b);
-        B3(gt, a, b) = B3(stt, a, b);
-        if (b == N3 - 1) B3(gt, a, b + 1) = B3(stt, a, b + 1);
+        B1(gn, a, b) = BV(0, sg*B1(sn, a, b));
+        B2(gt, a, b) = BV(1, B2(stt, a, b));
+        if (a == N2 - 1) B2(gt, a + 1, b) = BV(1, B2(stt, a + 1, b));
+        B3(gt, a, b) = BV(2, B3(stt, a, b));
+        if (b == N3 - 1) B3(gt, a, b + 1) = BV(2, B3(stt, a, b + 1));
       } else if (DIR == 1) {
-        B1(gt, a, b) = B1(stt, a, b);
-        if (a == N1 - 1) B1(gt, a + 1, b) = B1(stt, a + 1, b);
-        B2(gn, a, b) = sg*B2(sn, a, b);
-        B3(gt, a, b) = B3(stt, a, b);
-        if (b == N3 - 1) B3(gt, a, b + 1) = B3(stt, a, b + 1);
+        B1(gt, a, b) = BV(0, B1(stt, a, b));
+        if (a == N1 - 1) B1(gt, a + 1, b) = BV(0, B1(stt, a + 1, b));
+        B2(gn, a, b) = BV(1, sg*B2(sn, a, b));
+        B3(gt, a, b) = BV(2, B3(stt, a, b));
+        if (b == N3 - 1) B3(gt, a, b + 1) = BV(2, B3(stt, a, b + 1));
       } else {
-        B1(gt, a, b) = B1(stt, a, b);
-        if (a == N1 - 1) B1(gt, a + 1, b) = B1(stt, a + 1, b);
-        B2(gt, a, b) = B2(stt, a, b);
-        if (b == N2 - 1) B2(gt, a, b + 1) = B2(stt, a, b + 1);
-        B3(gn, a, b) = sg*B3(sn, a, b);
+        B1(gt, a, b) = BV(0, B1(stt, a, b));
+        if (a == N1 - 1) B1(gt, a + 1, b) = BV(0, B1(stt, a + 1, b));
+        B2(gt, a, b) = BV(1, B2(stt, a, b));
+        if (b == N2 - 1) B2(gt, a, b + 1) = BV(1, B2(stt, a, b + 1));
+        B3(gn, a, b) = BV(2, sg*B3(sn, a, b));
       }
+#undef BV
     }
   }
 }
@@ -355,43 +370,61 @@ int akmi_bvals_fc_unpack(const akmi_pack *p, const int *nghbr, const long long *
                          (hipStream_t)stream);
 }
 
-int akmi_hydro_bcs(const akmi_pack *p, int nvar, const int *bcs, double *u, void *stream) {
+static int hydro_bcs(const akmi_pack *p, int nvar, const int *bcs, const double *u_in, double *u,
+                     void *stream) {
   Geo g = make_geo(p);
   hipStream_t st = (hipStream_t)stream;
   {
     long long n = (long long)g.nmb*nvar*g.N3*g.N2;
-    k_hydro_bc<0><<<(int)((n + 255)/256), 256, 0, st>>>(g, nvar, bcs, u);
+    k_hydro_bc<0><<<(int)((n + 255)/256), 256, 0, st>>>(g, nvar, bcs, u_in, u);
   }
   if (g.multi_d) {
     long long n = (long long)g.nmb*nvar*g.N3*g.N1;
-    k_hydro_bc<1><<<(int)((n + 255)/256), 256, 0, st>>>(g, nvar, bcs, u);
+    k_hydro_bc<1><<<(int)((n + 255)/256), 256, 0, st>>>(g, nvar, bcs, u_in, u);
   }
   if (g.three_d) {
     long long n = (long long)g.nmb*nvar*g.N2*g.N1;
-    k_hydro_bc<2><<<(int)((n + 255)/256), 256, 0, st>>>(g, nvar, bcs, u);
+    k_hydro_bc<2><<<(int)((n + 255)/256), 256, 0, st>>>(g, nvar, bcs, u_in, u);
   }
   AKMI_CHECK_LAUNCH("hydro_bcs");
   return AKMI_COMPLETE;
 }
 
-int akmi_bfield_bcs(const akmi_pack *p, const int *bcs, double *bx1f, double *bx2f, double *bx3f,
-                    void *stream) {
+int akmi_hydro_bcs(const akmi_pack *p, int nvar, const int *bcs, double *u, void *stream) {
+  return hydro_bcs(p, nvar, bcs, nullptr, u, stream);
+}
+int akmi_hydro_bcs_inflow(const akmi_pack *p, int nvar, const int *bcs, const double *u_in, double *u,
+                          void *stream) {
+  return hydro_bcs(p, nvar, bcs, u_in, u, stream);
+}
+
+static int bfield_bcs(const akmi_pack *p, const int *bcs, const double *b_in, double *bx1f,
+                      double *bx2f, double *bx3f, void *stream) {
   Geo g = make_geo(p);
   hipStream_t st = (hipStream_t)stream;
   {
     long long n = (long long)g.nmb*g.N3*g.N2;
-    k_bfield_bc<0><<<(int)((n + 255)/256), 256, 0, st>>>(g, bcs, bx1f, bx2f, bx3f);
+    k_bfield_bc<0><<<(int)((n + 255)/256), 256, 0, st>>>(g, bcs, b_in, bx1f, bx2f, bx3f);
   }
   if (g.multi_d) {
     long long n = (long long)g.nmb*g.N3*g.N1;
-    k_bfield_bc<1><<<(int)((n + 255)/256), 256, 0, st>>>(g, bcs, bx1f, bx2f, bx3f);
+    k_bfield_bc<1><<<(int)((n + 255)/256), 256, 0, st>>>(g, bcs, b_in, bx1f, bx2f, bx3f);
   }
   if (g.three_d) {
     long long n = (long long)g.nmb*g.N2*g.N1;
-    k_bfield_bc<2><<<(int)((n + 255)/256), 256, 0, st>>>(g, bcs, bx1f, bx2f, bx3f);
+    k_bfield_bc<2><<<(int)((n + 255)/256), 256, 0, st>>>(g, bcs, b_in, bx1f, bx2f, bx3f);
   }
   AKMI_CHECK_LAUNCH("bfield_bcs");
   return AKMI_COMPLETE;
+}
+
+int akmi_bfield_bcs(const akmi_pack *p, const int *bcs, double *bx1f, double *bx2f, double *bx3f,
+                    void *stream) {
+  return bfield_bcs(p, bcs, nullptr, bx1f, bx2f, bx3f, stream);
+}
+int akmi_bfield_bcs_inflow(const akmi_pack *p, const int *bcs, const double *b_in, double *bx1f,
+                           double *bx2f, double *bx3f, void *stream) {
+  return bfield_bcs(p, bcs, b_in, bx1f, bx2f, bx3f, stream);
 }
 
 int akmi_calib_copy(double *dst, const double *src, long long n, void *stream);

@@ -15,8 +15,7 @@ from . import capi
 FLT_MAX = float(np.finfo(np.float32).max)
 FLT_MIN = float(np.finfo(np.float32).tiny)
 
-_BCNAMES = {"periodic": capi.BC["periodic"], "outflow": capi.BC["outflow"],
-            "reflect": capi.BC["reflect"], "user": capi.BC["user"]}
+_BCNAMES = {k: capi.BC[k] for k in ("periodic", "outflow", "reflect", "user", "inflow", "diode", "vacuum")}
 
 
 def LeftEdgeX(ith, n, xmin, xmax):
@@ -243,7 +242,7 @@ class Mesh:
             v = pin.GetOrAddString("mesh", name, "periodic")
             if v not in _BCNAMES:
                 raise RuntimeError("### FATAL ERROR boundary flag '%s' not supported on this "
-                                   "path (periodic/outflow/reflect/user)" % v)
+                                   "path (periodic/outflow/reflect/inflow/diode/vacuum/user)" % v)
             bcs.append(_BCNAMES[v])
         self.mesh_bcs = bcs
         per = capi.BC["periodic"]

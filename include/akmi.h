@@ -47,7 +47,9 @@ enum { AKMI_RECON_DC = 0, AKMI_RECON_PLM = 1, AKMI_RECON_PPM4 = 2, AKMI_RECON_PP
 enum { AKMI_RS_LLF = 0, AKMI_RS_HLLE = 1, AKMI_RS_HLLC = 2, AKMI_RS_HLLD = 3, AKMI_RS_ROE = 4,
        AKMI_RS_ADVECT = 5 /* kinematic runs (<time>/evolution = kinematic), task-granular entries only */ };
 /* BoundaryFlag, src/mesh/mesh.hpp */
-enum { AKMI_BC_BLOCK = -1, AKMI_BC_PERIODIC = 0, AKMI_BC_OUTFLOW = 1, AKMI_BC_REFLECT = 2 };
+enum { AKMI_BC_BLOCK = -1, AKMI_BC_PERIODIC = 0, AKMI_BC_OUTFLOW = 1, AKMI_BC_REFLECT = 2,
+       AKMI_BC_USER = 3 /* left to the caller's user function */, AKMI_BC_INFLOW = 4, AKMI_BC_DIODE = 5,
+       AKMI_BC_VACUUM = 6 };
 
 /* MeshBlockPack descriptor: RegionIndcs (src/mesh/mesh.hpp:35-41), mb_size.dx1..3
  * (src/mesh/mesh.hpp:25-29) and EOS_Data (src/eos/eos.hpp:27-34) by value. */
@@ -230,6 +232,14 @@ long long akmi_bvals_fc_segsize(const akmi_pack *p, int d);
 int akmi_hydro_bcs(const akmi_pack *p, int nvar, const int *bcs, double *u, void *stream);
 int akmi_bfield_bcs(const akmi_pack *p, const int *bcs, double *bx1f, double *bx2f,
                     double *bx3f, void *stream);
+/* the same with the inflow states of MeshBoundaryValues::u_in / b_in (src/bvals/bvals.cpp:323-326):
+ * u_in = device double[nvar][6], b_in = device double[3][6], indexed [variable][BoundaryFace].
+ * Flags handled: reflect, outflow, inflow, diode (normal velocity clipped to point outwards;
+ * field as outflow), vacuum (zeros; field as outflow); AKMI_BC_USER faces are left alone. */
+int akmi_hydro_bcs_inflow(const akmi_pack *p, int nvar, const int *bcs, const double *u_in, double *u,
+                          void *stream);
+int akmi_bfield_bcs_inflow(const akmi_pack *p, const int *bcs, const double *b_in, double *bx1f,
+                           double *bx2f, double *bx3f, void *stream);
 
 /* ---- Fused fast path ("one kernel sequence per MeshBlockPack stage") ----------------- *
  * Must produce results identical to the task chain above.  ws = device workspace of

@@ -59,6 +59,9 @@ int akref_resistive_fluxes(const akmi_pack *p, double eta_ohm, const double *bx1
 void akref_advect_hyd(int ideal, const double wl[5], const double wr[5], double flx[5]);
 void akref_advect_mhd(int nb, const double wl[7], const double wr[7], double bxi, double flx[7]);
 int akref_kinematic_newdt(const akmi_pack *p, const double *w0, double *dt3);
+int akref_hydro_bcs_inflow(const akmi_pack *p, int nvar, const int *bcs, const double *u_in, double *u);
+int akref_bfield_bcs_inflow(const akmi_pack *p, const int *bcs, const double *b_in, double *bx1f,
+                            double *bx2f, double *bx3f);
 int akref_rk4_copy_cons(const akmi_pack *p, double delta, const double *u0, double *u1);
 int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
                        double *flx1, double *flx2, double *flx3, int face_shaped);

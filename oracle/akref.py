@@ -14,7 +14,8 @@ _LIB = None
 
 RECON = {"dc": 0, "plm": 1, "ppm4": 2, "ppmx": 3, "wenoz": 4, "teno": 5}
 RSOLVER = {"llf": 0, "hlle": 1, "hllc": 2, "hlld": 3, "roe": 4, "advect": 5}
-BC = {"block": -1, "periodic": 0, "outflow": 1, "reflect": 2}
+BC = {"block": -1, "periodic": 0, "outflow": 1, "reflect": 2, "user": 3, "inflow": 4, "diode": 5,
+      "vacuum": 6}
 PGEN = {"linear_wave": 0, "shock_tube": 1, "orszag_tang": 2, "blast": 3}
 
 

@@ -2488,7 +2488,9 @@ int akref_bvals_fc_unpack(const akmi_pack *p, const int *nghbr, const long long 
 
 /* HydroBCs, src/bvals/physics/hydro_bcs.cpp:69-... (outflow, reflect); x1 over all (k,j)
  * incl. ghosts, then x2 over all (k,i), then x3 over all (j,i). */
-int akref_hydro_bcs(const akmi_pack *p, int nvar, const int *bcs, double *u) {
+/* u_in: [nvar][6] inflow states (MeshBoundaryValues::u_in, src/bvals/bvals.cpp:323-326), may be NULL
+ * when no face is flagged inflow */
+static int hydro_bcs_impl(const akmi_pack *p, int nvar, const int *bcs, const double *u_in, double *u) {
   G g = mkG(p);
   const int N1 = g.N1, N2 = g.N2, N3 = g.N3, ng = g.ng;
 #define U(m,n,k,j,i) u[ix5(nvar,N3,N2,N1,m,n,k,j,i)]
@@ -2500,10 +2502,16 @@ int akref_hydro_bcs(const akmi_pack *p, int nvar, const int *bcs, double *u) {
           for (int i = 0; i < ng; ++i) {
             if (bi == AKMI_BC_REFLECT) U(m,n,k,j,g.is-i-1) = (n == IVX ? -1.0 : 1.0)*U(m,n,k,j,g.is+i);
             else if (bi == AKMI_BC_OUTFLOW) U(m,n,k,j,g.is-i-1) = U(m,n,k,j,g.is);
+            else if (bi == AKMI_BC_INFLOW) U(m,n,k,j,g.is-i-1) = u_in[6*n + 0];
+            else if (bi == AKMI_BC_DIODE) U(m,n,k,j,g.is-i-1) = (n == IVX) ? fmin(0.0, U(m,n,k,j,g.is)) : U(m,n,k,j,g.is);
+            else if (bi == AKMI_BC_VACUUM) U(m,n,k,j,g.is-i-1) = 0.0;
           }
           for (int i = 0; i < ng; ++i) {
             if (bo == AKMI_BC_REFLECT) U(m,n,k,j,g.ie+i+1) = (n == IVX ? -1.0 : 1.0)*U(m,n,k,j,g.ie-i);
             else if (bo == AKMI_BC_OUTFLOW) U(m,n,k,j,g.ie+i+1) = U(m,n,k,j,g.ie);
+            else if (bo == AKMI_BC_INFLOW) U(m,n,k,j,g.ie+i+1) = u_in[6*n + 1];
+            else if (bo == AKMI_BC_DIODE) U(m,n,k,j,g.ie+i+1) = (n == IVX) ? fmax(0.0, U(m,n,k,j,g.ie)) : U(m,n,k,j,g.ie);
+            else if (bo == AKMI_BC_VACUUM) U(m,n,k,j,g.ie+i+1) = 0.0;
           }
         }
   if (!g.multi_d) return 0;
@@ -2515,10 +2523,16 @@ int akref_hydro_bcs(const akmi_pack *p, int nvar, const int *bcs, double *u) {
           for (int j = 0; j < ng; ++j) {
             if (bi == AKMI_BC_REFLECT) U(m,n,k,g.js-j-1,i) = (n == IVY ? -1.0 : 1.0)*U(m,n,k,g.js+j,i);
             else if (bi == AKMI_BC_OUTFLOW) U(m,n,k,g.js-j-1,i) = U(m,n,k,g.js,i);
+            else if (bi == AKMI_BC_INFLOW) U(m,n,k,g.js-j-1,i) = u_in[6*n + 2];
+            else if (bi == AKMI_BC_DIODE) U(m,n,k,g.js-j-1,i) = (n == IVY) ? fmin(0.0, U(m,n,k,g.js,i)) : U(m,n,k,g.js,i);
+            else if (bi == AKMI_BC_VACUUM) U(m,n,k,g.js-j-1,i) = 0.0;
           }
           for (int j = 0; j < ng; ++j) {
             if (bo == AKMI_BC_REFLECT) U(m,n,k,g.je+j+1,i) = (n == IVY ? -1.0 : 1.0)*U(m,n,k,g.je-j,i);
             else if (bo == AKMI_BC_OUTFLOW) U(m,n,k,g.je+j+1,i) = U(m,n,k,g.je,i);
+            else if (bo == AKMI_BC_INFLOW) U(m,n,k,g.je+j+1,i) = u_in[6*n + 3];
+            else if (bo == AKMI_BC_DIODE) U(m,n,k,g.je+j+1,i) = (n == IVY) ? fmax(0.0, U(m,n,k,g.je,i)) : U(m,n,k,g.je,i);
+            else if (bo == AKMI_BC_VACUUM) U(m,n,k,g.je+j+1,i) = 0.0;
           }
         }
   if (!g.three_d) return 0;
@@ -2530,19 +2544,34 @@ int akref_hydro_bcs(const akmi_pack *p, int nvar, const int *bcs, double *u) {
           for (int k = 0; k < ng; ++k) {
             if (bi == AKMI_BC_REFLECT) U(m,n,g.ks-k-1,j,i) = (n == IVZ ? -1.0 : 1.0)*U(m,n,g.ks+k,j,i);
             else if (bi == AKMI_BC_OUTFLOW) U(m,n,g.ks-k-1,j,i) = U(m,n,g.ks,j,i);
+            else if (bi == AKMI_BC_INFLOW) U(m,n,g.ks-k-1,j,i) = u_in[6*n + 4];
+            else if (bi == AKMI_BC_DIODE) U(m,n,g.ks-k-1,j,i) = (n == IVZ) ? fmin(0.0, U(m,n,g.ks,j,i)) : U(m,n,g.ks,j,i);
+            else if (bi == AKMI_BC_VACUUM) U(m,n,g.ks-k-1,j,i) = 0.0;
           }
           for (int k = 0; k < ng; ++k) {
             if (bo == AKMI_BC_REFLECT) U(m,n,g.ke+k+1,j,i) = (n == IVZ ? -1.0 : 1.0)*U(m,n,g.ke-k,j,i);
             else if (bo == AKMI_BC_OUTFLOW) U(m,n,g.ke+k+1,j,i) = U(m,n,g.ke,j,i);
+            else if (bo == AKMI_BC_INFLOW) U(m,n,g.ke+k+1,j,i) = u_in[6*n + 5];
+            else if (bo == AKMI_BC_DIODE) U(m,n,g.ke+k+1,j,i) = (n == IVZ) ? fmax(0.0, U(m,n,g.ke,j,i)) : U(m,n,g.ke,j,i);
+            else if (bo == AKMI_BC_VACUUM) U(m,n,g.ke+k+1,j,i) = 0.0;
           }
         }
 #undef U
   return 0;
 }
 
+int akref_hydro_bcs(const akmi_pack *p, int nvar, const int *bcs, double *u) {
+  return hydro_bcs_impl(p, nvar, bcs, NULL, u);
+}
+int akref_hydro_bcs_inflow(const akmi_pack *p, int nvar, const int *bcs, const double *u_in, double *u) {
+  return hydro_bcs_impl(p, nvar, bcs, u_in, u);
+}
+
 /* BFieldBCs, src/bvals/physics/bfield_bcs.cpp:66-... (outflow, reflect) */
-int akref_bfield_bcs(const akmi_pack *p, const int *bcs, double *bx1f, double *bx2f,
-                     double *bx3f) {
+/* b_in: [3][6] inflow field values (MeshBoundaryValues::b_in), may be NULL without inflow faces;
+ * diode and vacuum faces treat the field like outflow (bfield_bcs.cpp:88-97) */
+static int bfield_bcs_impl(const akmi_pack *p, const int *bcs, const double *b_in, double *bx1f,
+                           double *bx2f, double *bx3f) {
   G g = mkG(p);
   const int N1 = g.N1, N2 = g.N2, N3 = g.N3, ng = g.ng;
   const int is = g.is, ie = g.ie, js = g.js, je = g.je, ks = g.ks, ke = g.ke;
@@ -2560,12 +2589,18 @@ int akref_bfield_bcs(const akmi_pack *p, const int *bcs, double *bx1f, double *b
             if (j == N2-1) B2(m,k,j+1,is-i-1) = B2(m,k,j+1,is+i);
             B3(m,k,j,is-i-1) = B3(m,k,j,is+i);
             if (k == N3-1) B3(m,k+1,j,is-i-1) = B3(m,k+1,j,is+i);
-          } else if (bi == AKMI_BC_OUTFLOW) {
+          } else if (bi == AKMI_BC_OUTFLOW || bi == AKMI_BC_DIODE || bi == AKMI_BC_VACUUM) {
             B1(m,k,j,is-i-1) = B1(m,k,j,is);
             B2(m,k,j,is-i-1) = B2(m,k,j,is);
             if (j == N2-1) B2(m,k,j+1,is-i-1) = B2(m,k,j+1,is);
             B3(m,k,j,is-i-1) = B3(m,k,j,is);
             if (k == N3-1) B3(m,k+1,j,is-i-1) = B3(m,k+1,j,is);
+          } else if (bi == AKMI_BC_INFLOW) {
+            B1(m,k,j,is-i-1) = b_in[6*0 + 0];
+            B2(m,k,j,is-i-1) = b_in[6*1 + 0];
+            if (j == N2-1) B2(m,k,j+1,is-i-1) = b_in[6*1 + 0];
+            B3(m,k,j,is-i-1) = b_in[6*2 + 0];
+            if (k == N3-1) B3(m,k+1,j,is-i-1) = b_in[6*2 + 0];
           }
         }
         for (int i = 0; i < ng; ++i) {
@@ -2575,12 +2610,18 @@ int akref_bfield_bcs(const akmi_pack *p, const int *bcs, double *bx1f, double *b
             if (j == N2-1) B2(m,k,j+1,ie+i+1) = B2(m,k,j+1,ie-i);
             B3(m,k,j,ie+i+1) = B3(m,k,j,ie-i);
             if (k == N3-1) B3(m,k+1,j,ie+i+1) = B3(m,k+1,j,ie-i);
-          } else if (bo == AKMI_BC_OUTFLOW) {
+          } else if (bo == AKMI_BC_OUTFLOW || bo == AKMI_BC_DIODE || bo == AKMI_BC_VACUUM) {
             B1(m,k,j,ie+i+2) = B1(m,k,j,ie+1);
             B2(m,k,j,ie+i+1) = B2(m,k,j,ie);
             if (j == N2-1) B2(m,k,j+1,ie+i+1) = B2(m,k,j+1,ie);
             B3(m,k,j,ie+i+1) = B3(m,k,j,ie);
             if (k == N3-1) B3(m,k+1,j,ie+i+1) = B3(m,k+1,j,ie);
+          } else if (bo == AKMI_BC_INFLOW) {
+            B1(m,k,j,ie+i+2) = b_in[6*0 + 1];
+            B2(m,k,j,ie+i+1) = b_in[6*1 + 1];
+            if (j == N2-1) B2(m,k,j+1,ie+i+1) = b_in[6*1 + 1];
+            B3(m,k,j,ie+i+1) = b_in[6*2 + 1];
+            if (k == N3-1) B3(m,k+1,j,ie+i+1) = b_in[6*2 + 1];
           }
         }
       }
@@ -2596,12 +2637,18 @@ int akref_bfield_bcs(const akmi_pack *p, const int *bcs, double *bx1f, double *b
             B2(m,k,js-j-1,i) = -B2(m,k,js+j+1,i);
             B3(m,k,js-j-1,i) = B3(m,k,js+j,i);
             if (k == N3-1) B3(m,k+1,js-j-1,i) = B3(m,k+1,js+j,i);
-          } else if (bi == AKMI_BC_OUTFLOW) {
+          } else if (bi == AKMI_BC_OUTFLOW || bi == AKMI_BC_DIODE || bi == AKMI_BC_VACUUM) {
             B1(m,k,js-j-1,i) = B1(m,k,js,i);
             if (i == N1-1) B1(m,k,js-j-1,i+1) = B1(m,k,js,i+1);
             B2(m,k,js-j-1,i) = B2(m,k,js,i);
             B3(m,k,js-j-1,i) = B3(m,k,js,i);
             if (k == N3-1) B3(m,k+1,js-j-1,i) = B3(m,k+1,js,i);
+          } else if (bi == AKMI_BC_INFLOW) {
+            B1(m,k,js-j-1,i) = b_in[6*0 + 2];
+            if (i == N1-1) B1(m,k,js-j-1,i+1) = b_in[6*0 + 2];
+            B2(m,k,js-j-1,i) = b_in[6*1 + 2];
+            B3(m,k,js-j-1,i) = b_in[6*2 + 2];
+            if (k == N3-1) B3(m,k+1,js-j-1,i) = b_in[6*2 + 2];
           }
         }
         for (int j = 0; j < ng; ++j) {
@@ -2611,12 +2658,18 @@ int akref_bfield_bcs(const akmi_pack *p, const int *bcs, double *bx1f, double *b
             B2(m,k,je+j+2,i) = -B2(m,k,je-j,i);
             B3(m,k,je+j+1,i) = B3(m,k,je-j,i);
             if (k == N3-1) B3(m,k+1,je+j+1,i) = B3(m,k+1,je-j,i);
-          } else if (bo == AKMI_BC_OUTFLOW) {
+          } else if (bo == AKMI_BC_OUTFLOW || bo == AKMI_BC_DIODE || bo == AKMI_BC_VACUUM) {
             B1(m,k,je+j+1,i) = B1(m,k,je,i);
             if (i == N1-1) B1(m,k,je+j+1,i+1) = B1(m,k,je,i+1);
             B2(m,k,je+j+2,i) = B2(m,k,je+1,i);
             B3(m,k,je+j+1,i) = B3(m,k,je,i);
             if (k == N3-1) B3(m,k+1,je+j+1,i) = B3(m,k+1,je,i);
+          } else if (bo == AKMI_BC_INFLOW) {
+            B1(m,k,je+j+1,i) = b_in[6*0 + 3];
+            if (i == N1-1) B1(m,k,je+j+1,i+1) = b_in[6*0 + 3];
+            B2(m,k,je+j+2,i) = b_in[6*1 + 3];
+            B3(m,k,je+j+1,i) = b_in[6*2 + 3];
+            if (k == N3-1) B3(m,k+1,je+j+1,i) = b_in[6*2 + 3];
           }
         }
       }
@@ -2632,12 +2685,18 @@ int akref_bfield_bcs(const akmi_pack *p, const int *bcs, double *bx1f, double *b
             B2(m,ks-k-1,j,i) = B2(m,ks+k,j,i);
             if (j == N2-1) B2(m,ks-k-1,j+1,i) = B2(m,ks+k,j+1,i);
             B3(m,ks-k-1,j,i) = -B3(m,ks+k+1,j,i);
-          } else if (bi == AKMI_BC_OUTFLOW) {
+          } else if (bi == AKMI_BC_OUTFLOW || bi == AKMI_BC_DIODE || bi == AKMI_BC_VACUUM) {
             B1(m,ks-k-1,j,i) = B1(m,ks,j,i);
             if (i == N1-1) B1(m,ks-k-1,j,i+1) = B1(m,ks,j,i+1);
             B2(m,ks-k-1,j,i) = B2(m,ks,j,i);
             if (j == N2-1) B2(m,ks-k-1,j+1,i) = B2(m,ks,j+1,i);
             B3(m,ks-k-1,j,i) = B3(m,ks,j,i);
+          } else if (bi == AKMI_BC_INFLOW) {
+            B1(m,ks-k-1,j,i) = b_in[6*0 + 4];
+            if (i == N1-1) B1(m,ks-k-1,j,i+1) = b_in[6*0 + 4];
+            B2(m,ks-k-1,j,i) = b_in[6*1 + 4];
+            if (j == N2-1) B2(m,ks-k-1,j+1,i) = b_in[6*1 + 4];
+            B3(m,ks-k-1,j,i) = b_in[6*2 + 4];
           }
         }
         for (int k = 0; k < ng; ++k) {
@@ -2647,14 +2706,29 @@ int akref_bfield_bcs(const akmi_pack *p, const int *bcs, double *bx1f, double *b
             B2(m,ke+k+1,j,i) = B2(m,ke-k,j,i);
             if (j == N2-1) B2(m,ke+k+1,j+1,i) = B2(m,ke-k,j+1,i);
             B3(m,ke+k+2,j,i) = -B3(m,ke-k,j,i);
-          } else if (bo == AKMI_BC_OUTFLOW) {
+          } else if (bo == AKMI_BC_OUTFLOW || bo == AKMI_BC_DIODE || bo == AKMI_BC_VACUUM) {
             B1(m,ke+k+1,j,i) = B1(m,ke,j,i);
             if (i == N1-1) B1(m,ke+k+1,j,i+1) = B1(m,ke,j,i+1);
             B2(m,ke+k+1,j,i) = B2(m,ke,j,i);
             if (j == N2-1) B2(m,ke+k+1,j+1,i) = B2(m,ke,j+1,i);
             B3(m,ke+k+2,j,i) = B3(m,ke+1,j,i);
+          } else if (bo == AKMI_BC_INFLOW) {
+            B1(m,ke+k+1,j,i) = b_in[6*0 + 5];
+            if (i == N1-1) B1(m,ke+k+1,j,i+1) = b_in[6*0 + 5];
+            B2(m,ke+k+1,j,i) = b_in[6*1 + 5];
+            if (j == N2-1) B2(m,ke+k+1,j+1,i) = b_in[6*1 + 5];
+            B3(m,ke+k+2,j,i) = b_in[6*2 + 5];
           }
         }
       }
   return 0;
+}
+
+int akref_bfield_bcs(const akmi_pack *p, const int *bcs, double *bx1f, double *bx2f,
+                     double *bx3f) {
+  return bfield_bcs_impl(p, bcs, NULL, bx1f, bx2f, bx3f);
+}
+int akref_bfield_bcs_inflow(const akmi_pack *p, const int *bcs, const double *b_in, double *bx1f,
+                            double *bx2f, double *bx3f) {
+  return bfield_bcs_impl(p, bcs, b_in, bx1f, bx2f, bx3f);
 }

@@ -208,9 +208,10 @@ def test_task_mhd_chain(dims, recon):
     assert np.array_equal(dt, dtd.cpu().numpy())
 
 
-@pytest.mark.parametrize("bc", ["outflow", "reflect"])
+@pytest.mark.parametrize("bc", ["outflow", "reflect", "diode", "vacuum", "inflow", "mixed"])
 def test_task_bcs(bc):
-    """HydroBCs / BFieldBCs for outflow and reflect on all six faces"""
+    """HydroBCs / BFieldBCs for every physical boundary flag on all six faces (mixed: a different
+    flag on every face, user faces left untouched)"""
     from athenak_amd import capi
     L, R = capi.lib(), akref.lib()
     rng = np.random.default_rng(5)
@@ -220,15 +221,29 @@ def test_task_bcs(bc):
     dxd = _t(dx)
     pkd = capi.Pack.from_buffer_copy(bytes(pk))
     pkd.dx = dxd.data_ptr()
-    bcs = np.full((nmb, 6), akref.BC[bc], dtype=np.int32)
-    bcs[1, 0] = akref.BC["block"]
+    if bc == "mixed":
+        bcs = np.array([[akref.BC[k] for k in ("inflow", "diode", "vacuum", "reflect", "user", "outflow")],
+                        [akref.BC[k] for k in ("block", "vacuum", "diode", "inflow", "reflect", "diode")]],
+                       dtype=np.int32)
+    else:
+        bcs = np.full((nmb, 6), akref.BC[bc], dtype=np.int32)
+        bcs[1, 0] = akref.BC["block"]
+    u_in, b_in = rng.normal(size=(5, 6)), rng.normal(size=(3, 6))
     u = rng.normal(size=(nmb, 5, N, N, N))
     b = [rng.normal(size=(nmb, N, N, N+1)), rng.normal(size=(nmb, N, N+1, N)), rng.normal(size=(nmb, N+1, N, N))]
     ud, bd, bcd = _t(u), [_t(x) for x in b], _t(bcs)
-    R.akref_hydro_bcs(C.byref(pk), 5, akref.ptr(bcs), akref.ptr(u))
-    R.akref_bfield_bcs(C.byref(pk), akref.ptr(bcs), *[akref.ptr(x) for x in b])
-    capi.check(L.akmi_hydro_bcs(C.byref(pkd), 5, capi._p(bcd), capi._p(ud), None), "hbc")
-    capi.check(L.akmi_bfield_bcs(C.byref(pkd), capi._p(bcd), *[capi._p(x) for x in bd], None), "bbc")
+    if bc in ("inflow", "mixed"):
+        uid, bid = _t(u_in), _t(b_in)
+        R.akref_hydro_bcs_inflow(C.byref(pk), 5, akref.ptr(bcs), akref.ptr(u_in), akref.ptr(u))
+        R.akref_bfield_bcs_inflow(C.byref(pk), akref.ptr(bcs), akref.ptr(b_in), *[akref.ptr(x) for x in b])
+        capi.check(L.akmi_hydro_bcs_inflow(C.byref(pkd), 5, capi._p(bcd), capi._p(uid), capi._p(ud), None), "hbc")
+        capi.check(L.akmi_bfield_bcs_inflow(C.byref(pkd), capi._p(bcd), capi._p(bid),
+                                            *[capi._p(x) for x in bd], None), "bbc")
+    else:
+        R.akref_hydro_bcs(C.byref(pk), 5, akref.ptr(bcs), akref.ptr(u))
+        R.akref_bfield_bcs(C.byref(pk), akref.ptr(bcs), *[akref.ptr(x) for x in b])
+        capi.check(L.akmi_hydro_bcs(C.byref(pkd), 5, capi._p(bcd), capi._p(ud), None), "hbc")
+        capi.check(L.akmi_bfield_bcs(C.byref(pkd), capi._p(bcd), *[capi._p(x) for x in bd], None), "bbc")
     assert np.array_equal(u, ud.cpu().numpy())
     for x, y in zip(b, bd):
         assert np.array_equal(x, y.cpu().numpy())
