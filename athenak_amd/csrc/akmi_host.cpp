@@ -183,7 +183,9 @@ static int BCFlag(const std::string &v) {
   if (v == "periodic") return AKMI_BC_PERIODIC;
   if (v == "outflow") return AKMI_BC_OUTFLOW;
   if (v == "reflect") return AKMI_BC_REFLECT;
-  AKMI_FATAL("boundary flag '" + v + "' not supported on this path (periodic/outflow/reflect)");
+  if (v == "diode") return AKMI_BC_DIODE;       // hydro_bcs.cpp:105-113
+  if (v == "vacuum") return AKMI_BC_VACUUM;     // hydro_bcs.cpp:114-118
+  AKMI_FATAL("boundary flag '" + v + "' not supported by the C++ host (periodic/outflow/reflect/diode/vacuum; inflow and user: Python host)");
 }
 
 Mesh::Mesh(ParameterInput *pin) {

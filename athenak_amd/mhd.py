@@ -208,6 +208,9 @@ class MHD(FluidBase):
             return TaskStatus.complete
         self.pbval_u.HydroBCs(self.u0)
         self.pbval_b.BFieldBCs(self.b0)
+        pgen = self.pmy_pack.pmesh.pgen
+        if pgen is not None and pgen.user_bcs:                   # mhd_tasks.cpp:514-517
+            pgen.user_bcs_func()
         return TaskStatus.complete
 
     def ConToPrim(self, pdrive, stage):

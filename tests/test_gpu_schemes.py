@@ -258,7 +258,7 @@ def test_diffusion_pgen_matches_the_cpu_backend(which):
     assert 0.0 < err < 2e-9
 
 
-@pytest.mark.parametrize("fused", [True, False], ids=["fused", "split"])
+@pytest.mark.parametrize("fused", [True, False, "cpp"], ids=["fused", "split", "cpp"])
 @pytest.mark.parametrize("case", [
     ("sod", 64, 1, 32, 30, dict(cfl=0.4, rsolver="hllc", extra=("mesh/ix1_bc=diode", "mesh/ox1_bc=vacuum"))),
     ("sod", 32, 2, 16, 10, dict(cfl=0.3, rsolver="hlle", extra=("mesh/ix1_bc=reflect", "mesh/ox1_bc=diode",
@@ -272,7 +272,7 @@ def test_diffusion_pgen_matches_the_cpu_backend(which):
 def test_diode_and_vacuum_boundaries(case, fused):
     """hydro_bcs.cpp:105-118, bfield_bcs.cpp:88-97 in whole runs"""
     problem, n, dims, mb, cycles, kw = case
-    res = pu.compare_run(problem, n, dims, mb, cycles, fused=fused, **kw)
+    res = pu.compare_run(problem, n, dims, mb, cycles, fused=(fused is not False), native=(fused == "cpp"), **kw)
     assert res["cycles"] == cycles and res["time"][0] == res["time"][1]
     assert res["bitwise_equal"], res["diffs"]
 
