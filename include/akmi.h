@@ -241,6 +241,27 @@ int akmi_hydro_bcs_inflow(const akmi_pack *p, int nvar, const int *bcs, const do
 int akmi_bfield_bcs_inflow(const akmi_pack *p, const int *bcs, const double *b_in, double *bx1f,
                            double *bx2f, double *bx3f, void *stream);
 
+/* ---- SMR/AMR operators between a MeshBlock and its coarse buffer ---------- *
+ * Coarse arrays: cnx = nx/2 active cells, the same ng ghost cells, same layout:
+ * (nmb,nvar,cN3,cN2,cN1), faces +1 in their own direction (src/mesh/mesh.cpp:286-330).  Index boxes
+ * box = {il,iu,jl,ju,kl,ku} are COARSE indices (the iprol boxes of src/bvals/prolongation.cpp);
+ * fine index = (coarse - cis)*2 + is.  The mesh tree and the level-aware exchange that drive these
+ * operators in the reference are not part of this library yet. */
+/* MeshRefinement::RestrictCC (src/mesh/mesh_refinement.cpp:1223-1277) over the active coarse cells */
+int akmi_restrict_cc(const akmi_pack *p, int nvar, const double *u, double *cu, void *stream);
+/* MeshRefinement::RestrictFC (src/mesh/mesh_refinement.cpp:1283-1382) */
+int akmi_restrict_fc(const akmi_pack *p, const double *bx1f, const double *bx2f, const double *bx3f,
+                     double *cbx1f, double *cbx2f, double *cbx3f, void *stream);
+/* ProlongCC (src/mesh/prolongation.hpp:19-63): min-mod limited linear interpolation */
+int akmi_prolong_cc(const akmi_pack *p, int nvar, const int *box, const double *cu, double *u,
+                    void *stream);
+/* ProlongFCSharedX1Face/X2Face/X3Face (src/mesh/prolongation.hpp:69-160): component comp = 0,1,2 */
+int akmi_prolong_fc_shared(const akmi_pack *p, int comp, const int *box, const double *cb, double *b,
+                           void *stream);
+/* ProlongFCInternal (src/mesh/prolongation.hpp:166-230; Toth & Roe 2002), after the shared faces */
+int akmi_prolong_fc_internal(const akmi_pack *p, const int *box, double *bx1f, double *bx2f,
+                             double *bx3f, void *stream);
+
 /* ---- Fused fast path ("one kernel sequence per MeshBlockPack stage") ----------------- *
  * Must produce results identical to the task chain above.  ws = device workspace of
  * akmi_stage_workspace_bytes() bytes owned by the caller. */

@@ -62,6 +62,13 @@ int akref_kinematic_newdt(const akmi_pack *p, const double *w0, double *dt3);
 int akref_hydro_bcs_inflow(const akmi_pack *p, int nvar, const int *bcs, const double *u_in, double *u);
 int akref_bfield_bcs_inflow(const akmi_pack *p, const int *bcs, const double *b_in, double *bx1f,
                             double *bx2f, double *bx3f);
+/* SMR/AMR operators between a MeshBlock and its coarse buffer (no mesh tree behind them yet) */
+int akref_restrict_cc(const akmi_pack *p, int nvar, const double *u, double *cu);
+int akref_restrict_fc(const akmi_pack *p, const double *b1, const double *b2, const double *b3,
+                      double *cb1, double *cb2, double *cb3);
+int akref_prolong_cc(const akmi_pack *p, int nvar, const int box[6], const double *cu, double *u);
+int akref_prolong_fc_shared(const akmi_pack *p, int comp, const int box[6], const double *cb, double *b);
+int akref_prolong_fc_internal(const akmi_pack *p, const int box[6], double *b1, double *b2, double *b3);
 int akref_rk4_copy_cons(const akmi_pack *p, double delta, const double *u0, double *u1);
 int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
                        double *flx1, double *flx2, double *flx3, int face_shaped);

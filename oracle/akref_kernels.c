@@ -2732,3 +2732,233 @@ int akref_bfield_bcs_inflow(const akmi_pack *p, const int *bcs, const double *b_
                             double *bx2f, double *bx3f) {
   return bfield_bcs_impl(p, bcs, b_in, bx1f, bx2f, bx3f);
 }
+
+/* ---- SMR/AMR operators between a MeshBlock and its coarse buffer -------------
+ * Coarse arrays have cnx = nx/2 active cells and the same number of ghost cells:
+ * (nmb,nvar,cN3,cN2,cN1), faces +1 in their own direction; cis = ng, cjs = ng|0, cks = ng|0
+ * (src/mesh/mesh.cpp:286-330). */
+typedef struct { int cN1, cN2, cN3, cis, cie, cjs, cje, cks, cke; } CG;
+static CG mkCG(const G *g) {
+  CG c;
+  const int cnx1 = g->nx1/2, cnx2 = g->multi_d ? g->nx2/2 : 1, cnx3 = g->three_d ? g->nx3/2 : 1;
+  c.cN1 = cnx1 + 2*g->ng; c.cN2 = g->multi_d ? cnx2 + 2*g->ng : 1; c.cN3 = g->three_d ? cnx3 + 2*g->ng : 1;
+  c.cis = g->ng; c.cie = c.cis + cnx1 - 1;
+  c.cjs = g->multi_d ? g->ng : 0; c.cje = g->multi_d ? c.cjs + cnx2 - 1 : 0;
+  c.cks = g->three_d ? g->ng : 0; c.cke = g->three_d ? c.cks + cnx3 - 1 : 0;
+  return c;
+}
+
+/* MeshRefinement::RestrictCC, src/mesh/mesh_refinement.cpp:1223-1277 (second-order average) */
+int akref_restrict_cc(const akmi_pack *p, int nvar, const double *u, double *cu) {
+  G g = mkG(p); CG c = mkCG(&g);
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
+#define U(n,k,j,i) u[ix5(nvar,N3,N2,N1,m,n,k,j,i)]
+#define CU(n,k,j,i) cu[ix5(nvar,c.cN3,c.cN2,c.cN1,m,n,k,j,i)]
+  for (int m = 0; m < g.nmb; ++m) for (int n = 0; n < nvar; ++n)
+    for (int k = c.cks; k <= c.cke; ++k) for (int j = c.cjs; j <= c.cje; ++j)
+      for (int i = c.cis; i <= c.cie; ++i) {
+        int fi = 2*i - c.cis, fj = 2*j - c.cjs, fk = 2*k - c.cks;
+        if (!g.multi_d)
+          CU(n,k,j,i) = 0.5*(U(n,k,j,fi) + U(n,k,j,fi+1));
+        else if (!g.three_d)
+          CU(n,k,j,i) = 0.25*(U(n,k,fj,fi) + U(n,k,fj,fi+1) + U(n,k,fj+1,fi) + U(n,k,fj+1,fi+1));
+        else
+          CU(n,k,j,i) = 0.125*(U(n,fk,fj,fi) + U(n,fk,fj,fi+1) + U(n,fk,fj+1,fi) + U(n,fk,fj+1,fi+1)
+                             + U(n,fk+1,fj,fi) + U(n,fk+1,fj,fi+1) + U(n,fk+1,fj+1,fi) + U(n,fk+1,fj+1,fi+1));
+      }
+#undef U
+#undef CU
+  return 0;
+}
+
+#define FB1(k,j,i) b1[ix4(N3,N2,N1+1,m,k,j,i)]
+#define FB2(k,j,i) b2[ix4(N3,N2+1,N1,m,k,j,i)]
+#define FB3(k,j,i) b3[ix4(N3+1,N2,N1,m,k,j,i)]
+#define CB1(k,j,i) cb1[ix4(c.cN3,c.cN2,c.cN1+1,m,k,j,i)]
+#define CB2(k,j,i) cb2[ix4(c.cN3,c.cN2+1,c.cN1,m,k,j,i)]
+#define CB3(k,j,i) cb3[ix4(c.cN3+1,c.cN2,c.cN1,m,k,j,i)]
+
+/* MeshRefinement::RestrictFC, src/mesh/mesh_refinement.cpp:1283-1382 (area averages of the faces) */
+int akref_restrict_fc(const akmi_pack *p, const double *b1, const double *b2, const double *b3,
+                      double *cb1, double *cb2, double *cb3) {
+  G g = mkG(p); CG c = mkCG(&g);
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = c.cks; k <= c.cke; ++k) for (int j = c.cjs; j <= c.cje; ++j)
+      for (int i = c.cis; i <= c.cie; ++i) {
+        int fi = 2*i - c.cis, fj = 2*j - c.cjs, fk = 2*k - c.cks;
+        if (!g.multi_d) {
+          CB1(k,j,i) = FB1(k,j,fi);
+          if (i == c.cie) CB1(k,j,i+1) = FB1(k,j,fi+2);
+          double b2c = 0.5*(FB2(k,j,fi) + FB2(k,j,fi+1));
+          CB2(k,j,i) = b2c; CB2(k,j+1,i) = b2c;
+          double b3c = 0.5*(FB3(k,j,fi) + FB3(k,j,fi+1));
+          CB3(k,j,i) = b3c; CB3(k+1,j,i) = b3c;
+        } else if (!g.three_d) {
+          CB1(k,j,i) = 0.5*(FB1(k,fj,fi) + FB1(k,fj+1,fi));
+          if (i == c.cie) CB1(k,j,i+1) = 0.5*(FB1(k,fj,fi+2) + FB1(k,fj+1,fi+2));
+          CB2(k,j,i) = 0.5*(FB2(k,fj,fi) + FB2(k,fj,fi+1));
+          if (j == c.cje) CB2(k,j+1,i) = 0.5*(FB2(k,fj+2,fi) + FB2(k,fj+2,fi+1));
+          double b3c = 0.25*(FB3(k,fj,fi) + FB3(k,fj,fi+1) + FB3(k,fj+1,fi) + FB3(k,fj+1,fi+1));
+          CB3(k,j,i) = b3c; CB3(k+1,j,i) = b3c;
+        } else {
+          CB1(k,j,i) = 0.25*(FB1(fk,fj,fi) + FB1(fk,fj+1,fi) + FB1(fk+1,fj,fi) + FB1(fk+1,fj+1,fi));
+          if (i == c.cie)
+            CB1(k,j,i+1) = 0.25*(FB1(fk,fj,fi+2) + FB1(fk,fj+1,fi+2) + FB1(fk+1,fj,fi+2) + FB1(fk+1,fj+1,fi+2));
+          CB2(k,j,i) = 0.25*(FB2(fk,fj,fi) + FB2(fk,fj,fi+1) + FB2(fk+1,fj,fi) + FB2(fk+1,fj,fi+1));
+          if (j == c.cje)
+            CB2(k,j+1,i) = 0.25*(FB2(fk,fj+2,fi) + FB2(fk,fj+2,fi+1) + FB2(fk+1,fj+2,fi) + FB2(fk+1,fj+2,fi+1));
+          CB3(k,j,i) = 0.25*(FB3(fk,fj,fi) + FB3(fk,fj,fi+1) + FB3(fk,fj+1,fi) + FB3(fk,fj+1,fi+1));
+          if (k == c.cke)
+            CB3(k+1,j,i) = 0.25*(FB3(fk+2,fj,fi) + FB3(fk+2,fj,fi+1) + FB3(fk+2,fj+1,fi) + FB3(fk+2,fj+1,fi+1));
+        }
+      }
+  return 0;
+}
+
+static inline double sgn_(double x) { return (x < 0.0) ? -1.0 : 1.0; }     /* SIGN, src/athena.hpp:52 */
+static inline double mm8(double dl, double dr) {                          /* 0.125*(SIGN+SIGN)*fmin */
+  return 0.125*(sgn_(dl) + sgn_(dr))*fmin(fabs(dl), fabs(dr));
+}
+
+/* ProlongCC, src/mesh/prolongation.hpp:19-63, over the box of COARSE cells box = {il,iu,jl,ju,kl,ku};
+ * fine index fi = (i - cis)*2 + is (src/bvals/prolongation.cpp:524-526) */
+int akref_prolong_cc(const akmi_pack *p, int nvar, const int box[6], const double *cu, double *u) {
+  G g = mkG(p); CG c = mkCG(&g);
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
+#define A(n,k,j,i) u[ix5(nvar,N3,N2,N1,m,n,k,j,i)]
+#define CA(n,k,j,i) cu[ix5(nvar,c.cN3,c.cN2,c.cN1,m,n,k,j,i)]
+  for (int m = 0; m < g.nmb; ++m) for (int v = 0; v < nvar; ++v)
+    for (int k = box[4]; k <= box[5]; ++k) for (int j = box[2]; j <= box[3]; ++j)
+      for (int i = box[0]; i <= box[1]; ++i) {
+        int fi = (i - c.cis)*2 + g.is, fj = (j - c.cjs)*2 + g.js, fk = (k - c.cks)*2 + g.ks;
+        double dvar1 = mm8(CA(v,k,j,i) - CA(v,k,j,i-1), CA(v,k,j,i+1) - CA(v,k,j,i));
+        double dvar2 = 0.0, dvar3 = 0.0;
+        if (g.multi_d) dvar2 = mm8(CA(v,k,j,i) - CA(v,k,j-1,i), CA(v,k,j+1,i) - CA(v,k,j,i));
+        if (g.three_d) dvar3 = mm8(CA(v,k,j,i) - CA(v,k-1,j,i), CA(v,k+1,j,i) - CA(v,k,j,i));
+        A(v,fk,fj,fi) = CA(v,k,j,i) - dvar1 - dvar2 - dvar3;
+        A(v,fk,fj,fi+1) = CA(v,k,j,i) + dvar1 - dvar2 - dvar3;
+        if (g.multi_d) {
+          A(v,fk,fj+1,fi) = CA(v,k,j,i) - dvar1 + dvar2 - dvar3;
+          A(v,fk,fj+1,fi+1) = CA(v,k,j,i) + dvar1 + dvar2 - dvar3;
+        }
+        if (g.three_d) {
+          A(v,fk+1,fj,fi) = CA(v,k,j,i) - dvar1 - dvar2 + dvar3;
+          A(v,fk+1,fj,fi+1) = CA(v,k,j,i) + dvar1 - dvar2 + dvar3;
+          A(v,fk+1,fj+1,fi) = CA(v,k,j,i) - dvar1 + dvar2 + dvar3;
+          A(v,fk+1,fj+1,fi+1) = CA(v,k,j,i) + dvar1 + dvar2 + dvar3;
+        }
+      }
+#undef A
+#undef CA
+  return 0;
+}
+
+/* ProlongFCSharedX1Face/X2Face/X3Face, src/mesh/prolongation.hpp:69-160: faces of component comp
+ * (0,1,2) that a fine block shares with coarse faces, over a box of coarse FACE indices */
+int akref_prolong_fc_shared(const akmi_pack *p, int comp, const int box[6], const double *cb,
+                            double *b) {
+  G g = mkG(p); CG c = mkCG(&g);
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  const double *cb1 = cb, *cb2 = cb, *cb3 = cb;
+  double *b1 = b, *b2 = b, *b3 = b;
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = box[4]; k <= box[5]; ++k) for (int j = box[2]; j <= box[3]; ++j)
+      for (int i = box[0]; i <= box[1]; ++i) {
+        int fi = (i - c.cis)*2 + g.is;
+        int fj = g.multi_d ? (j - c.cjs)*2 + g.js : j;
+        int fk = g.three_d ? (k - c.cks)*2 + g.ks : k;
+        if (comp == 0) {
+          double dvar2 = 0.0, dvar3 = 0.0;
+          if (g.multi_d) dvar2 = mm8(CB1(k,j,i) - CB1(k,j-1,i), CB1(k,j+1,i) - CB1(k,j,i));
+          if (g.three_d) dvar3 = mm8(CB1(k,j,i) - CB1(k-1,j,i), CB1(k+1,j,i) - CB1(k,j,i));
+          FB1(fk,fj,fi) = CB1(k,j,i) - dvar2 - dvar3;
+          if (g.multi_d) FB1(fk,fj+1,fi) = CB1(k,j,i) + dvar2 - dvar3;
+          if (g.three_d) {
+            FB1(fk+1,fj,fi) = CB1(k,j,i) - dvar2 + dvar3;
+            FB1(fk+1,fj+1,fi) = CB1(k,j,i) + dvar2 + dvar3;
+          }
+        } else if (comp == 1) {
+          double dvar1 = mm8(CB2(k,j,i) - CB2(k,j,i-1), CB2(k,j,i+1) - CB2(k,j,i));
+          double dvar3 = 0.0;
+          if (g.three_d) dvar3 = mm8(CB2(k,j,i) - CB2(k-1,j,i), CB2(k+1,j,i) - CB2(k,j,i));
+          FB2(fk,fj,fi) = CB2(k,j,i) - dvar1 - dvar3;
+          FB2(fk,fj,fi+1) = CB2(k,j,i) + dvar1 - dvar3;
+          if (g.three_d) {
+            FB2(fk+1,fj,fi) = CB2(k,j,i) - dvar1 + dvar3;
+            FB2(fk+1,fj,fi+1) = CB2(k,j,i) + dvar1 + dvar3;
+          }
+        } else {
+          double dvar1 = mm8(CB3(k,j,i) - CB3(k,j,i-1), CB3(k,j,i+1) - CB3(k,j,i));
+          double dvar2 = 0.0;
+          if (g.multi_d) dvar2 = mm8(CB3(k,j,i) - CB3(k,j-1,i), CB3(k,j+1,i) - CB3(k,j,i));
+          FB3(fk,fj,fi) = CB3(k,j,i) - dvar1 - dvar2;
+          FB3(fk,fj,fi+1) = CB3(k,j,i) + dvar1 - dvar2;
+          if (g.multi_d) {
+            FB3(fk,fj+1,fi) = CB3(k,j,i) - dvar1 + dvar2;
+            FB3(fk,fj+1,fi+1) = CB3(k,j,i) + dvar1 + dvar2;
+          }
+        }
+      }
+  return 0;
+}
+
+/* ProlongFCInternal, src/mesh/prolongation.hpp:166-230 (divergence-preserving interpolation of Toth &
+ * Roe 2002 onto the faces inside a coarse cell) and the 1-D rule of src/bvals/prolongation.cpp:765-770,
+ * over a box of coarse CELL indices; the shared faces must have been set before */
+int akref_prolong_fc_internal(const akmi_pack *p, const int box[6], double *b1, double *b2, double *b3) {
+  G g = mkG(p); CG c = mkCG(&g);
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = box[4]; k <= box[5]; ++k) for (int j = box[2]; j <= box[3]; ++j)
+      for (int i = box[0]; i <= box[1]; ++i) {
+        int fi = (i - c.cis)*2 + g.is, fj = (j - c.cjs)*2 + g.js, fk = (k - c.cks)*2 + g.ks;
+        if (!g.multi_d) {
+          FB1(fk,fj,fi+1) = 0.5*(FB1(fk,fj,fi) + FB1(fk,fj,fi+2));
+        } else if (g.three_d) {
+          double Uxx = 0.0, Vyy = 0.0, Wzz = 0.0, Uxyz = 0.0, Vxyz = 0.0, Wxyz = 0.0;
+          for (int jj = 0; jj < 2; jj++) {
+            int jsgn = 2*jj - 1;
+            int fjj = fj + jj, fjp = fj + 2*jj;
+            for (int ii = 0; ii < 2; ii++) {
+              int isgn = 2*ii - 1;
+              int fii = fi + ii, fip = fi + 2*ii;
+              Uxx += isgn*(jsgn*(FB2(fk,fjp,fii) + FB2(fk+1,fjp,fii)) + (FB3(fk+2,fjj,fii) - FB3(fk,fjj,fii)));
+              Vyy += jsgn*((FB3(fk+2,fjj,fii) - FB3(fk,fjj,fii)) + isgn*(FB1(fk,fjj,fip) + FB1(fk+1,fjj,fip)));
+              Wzz += isgn*(FB1(fk+1,fjj,fip) - FB1(fk,fjj,fip)) + jsgn*(FB2(fk+1,fjp,fii) - FB2(fk,fjp,fii));
+              Uxyz += isgn*jsgn*(FB1(fk+1,fjj,fip) - FB1(fk,fjj,fip));
+              Vxyz += isgn*jsgn*(FB2(fk+1,fjp,fii) - FB2(fk,fjp,fii));
+              Wxyz += isgn*jsgn*(FB3(fk+2,fjj,fii) - FB3(fk,fjj,fii));
+            }
+          }
+          Uxx *= 0.125; Vyy *= 0.125; Wzz *= 0.125;
+          Uxyz *= 0.0625; Vxyz *= 0.0625; Wxyz *= 0.0625;
+          FB1(fk,fj,fi+1) = 0.5*(FB1(fk,fj,fi) + FB1(fk,fj,fi+2)) + Uxx - Vxyz - Wxyz;
+          FB1(fk,fj+1,fi+1) = 0.5*(FB1(fk,fj+1,fi) + FB1(fk,fj+1,fi+2)) + Uxx - Vxyz + Wxyz;
+          FB1(fk+1,fj,fi+1) = 0.5*(FB1(fk+1,fj,fi) + FB1(fk+1,fj,fi+2)) + Uxx + Vxyz - Wxyz;
+          FB1(fk+1,fj+1,fi+1) = 0.5*(FB1(fk+1,fj+1,fi) + FB1(fk+1,fj+1,fi+2)) + Uxx + Vxyz + Wxyz;
+          FB2(fk,fj+1,fi) = 0.5*(FB2(fk,fj,fi) + FB2(fk,fj+2,fi)) + Vyy - Uxyz - Wxyz;
+          FB2(fk,fj+1,fi+1) = 0.5*(FB2(fk,fj,fi+1) + FB2(fk,fj+2,fi+1)) + Vyy - Uxyz + Wxyz;
+          FB2(fk+1,fj+1,fi) = 0.5*(FB2(fk+1,fj,fi) + FB2(fk+1,fj+2,fi)) + Vyy + Uxyz - Wxyz;
+          FB2(fk+1,fj+1,fi+1) = 0.5*(FB2(fk+1,fj,fi+1) + FB2(fk+1,fj+2,fi+1)) + Vyy + Uxyz + Wxyz;
+          FB3(fk+1,fj,fi) = 0.5*(FB3(fk+2,fj,fi) + FB3(fk,fj,fi)) + Wzz - Uxyz - Vxyz;
+          FB3(fk+1,fj,fi+1) = 0.5*(FB3(fk+2,fj,fi+1) + FB3(fk,fj,fi+1)) + Wzz - Uxyz + Vxyz;
+          FB3(fk+1,fj+1,fi) = 0.5*(FB3(fk+2,fj+1,fi) + FB3(fk,fj+1,fi)) + Wzz + Uxyz - Vxyz;
+          FB3(fk+1,fj+1,fi+1) = 0.5*(FB3(fk+2,fj+1,fi+1) + FB3(fk,fj+1,fi+1)) + Wzz + Uxyz + Vxyz;
+        } else {
+          double tmp1 = 0.25*(FB2(fk,fj+2,fi+1) - FB2(fk,fj,fi+1) - FB2(fk,fj+2,fi) + FB2(fk,fj,fi));
+          double tmp2 = 0.25*(FB1(fk,fj,fi) - FB1(fk,fj,fi+2) - FB1(fk,fj+1,fi) + FB1(fk,fj+1,fi+2));
+          FB1(fk,fj,fi+1) = 0.5*(FB1(fk,fj,fi) + FB1(fk,fj,fi+2)) + tmp1;
+          FB1(fk,fj+1,fi+1) = 0.5*(FB1(fk,fj+1,fi) + FB1(fk,fj+1,fi+2)) + tmp1;
+          FB2(fk,fj+1,fi) = 0.5*(FB2(fk,fj,fi) + FB2(fk,fj+2,fi)) + tmp2;
+          FB2(fk,fj+1,fi+1) = 0.5*(FB2(fk,fj,fi+1) + FB2(fk,fj+2,fi+1)) + tmp2;
+        }
+      }
+  return 0;
+}
+#undef FB1
+#undef FB2
+#undef FB3
+#undef CB1
+#undef CB2
+#undef CB3

@@ -1,0 +1,180 @@
+"""SMR/AMR operators between a MeshBlock and its coarse buffer: RestrictCC/FC,
+ProlongCC, ProlongFCShared*, ProlongFCInternal.
+
+not gpu: properties of the oracle's restatement that the reference relies on --
+  * restriction of a prolongated block returns the coarse data (conservation of the cell averages),
+  * prolongation reproduces linear data exactly where the limiter is inactive,
+  * the face-field prolongation (shared faces + Toth & Roe interior) keeps div B of every fine
+    cell equal to that of its coarse parent, i.e. a divergence-free coarse field stays
+    divergence-free, and restricting the prolongated field returns the coarse faces.
+gpu: the HIP kernels against the oracle, bit for bit, in 1-D, 2-D and 3-D."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import akref
+
+DIMS = {1: (16, 1, 1), 2: (16, 12, 1), 3: (12, 8, 8)}
+
+
+def _setup(dims, ng=2, nmb=2, nvar=5, seed=3):
+    nx1, nx2, nx3 = DIMS[dims]
+    pk, dx = akref.make_pack(nmb, nx1, nx2, nx3, ng, np.ones((nmb, 3)), 1.4)
+    N1, N2, N3 = nx1 + 2*ng, (nx2 + 2*ng if nx2 > 1 else 1), (nx3 + 2*ng if nx3 > 1 else 1)
+    c1, c2, c3 = nx1//2 + 2*ng, (nx2//2 + 2*ng if nx2 > 1 else 1), (nx3//2 + 2*ng if nx3 > 1 else 1)
+    rng = np.random.default_rng(seed)
+    a = dict(pk=pk, dx=dx, ng=ng, nmb=nmb, nvar=nvar, N=(N3, N2, N1), cN=(c3, c2, c1), dims=dims,
+             cis=ng, cjs=ng if dims > 1 else 0, cks=ng if dims > 2 else 0,
+             cn=(nx3//2 if dims > 2 else 1, nx2//2 if dims > 1 else 1, nx1//2),
+             u=rng.normal(size=(nmb, nvar, N3, N2, N1)), cu=rng.normal(size=(nmb, nvar, c3, c2, c1)),
+             b=[rng.normal(size=(nmb, N3, N2, N1 + 1)), rng.normal(size=(nmb, N3, N2 + 1, N1)),
+                rng.normal(size=(nmb, N3 + 1, N2, N1))],
+             cb=[rng.normal(size=(nmb, c3, c2, c1 + 1)), rng.normal(size=(nmb, c3, c2 + 1, c1)),
+                 rng.normal(size=(nmb, c3 + 1, c2, c1))])
+    return a
+
+
+def _active_box(a):
+    """all active coarse cells"""
+    return np.array([a["cis"], a["cis"] + a["cn"][2] - 1, a["cjs"], a["cjs"] + a["cn"][1] - 1,
+                     a["cks"], a["cks"] + a["cn"][0] - 1], dtype=np.int32)
+
+
+def _shared_box(a, comp):
+    """coarse faces of component comp on the active coarse cells (incl. the +1 face)"""
+    b = _active_box(a)
+    b[2*comp + 1] += 1 if (comp == 0 or a["dims"] > comp) else 0
+    return b
+
+
+def _prolong_field(R, a):
+    """shared faces of all components, then the interior"""
+    for comp in range(3):
+        R.akref_prolong_fc_shared(C.byref(a["pk"]), comp, akref.ptr(_shared_box(a, comp)),
+                                  akref.ptr(a["cb"][comp]), akref.ptr(a["b"][comp]))
+    R.akref_prolong_fc_internal(C.byref(a["pk"]), akref.ptr(_active_box(a)), *[akref.ptr(x) for x in a["b"]])
+
+
+def _div(b, dims, sl):
+    k, j, i = sl
+    d = b[0][:, k, j, i.start + 1:i.stop + 1] - b[0][:, k, j, i]
+    if dims > 1:
+        d = d + b[1][:, k, j.start + 1:j.stop + 1, i] - b[1][:, k, j, i]
+    if dims > 2:
+        d = d + b[2][:, k.start + 1:k.stop + 1, j, i] - b[2][:, k, j, i]
+    return d
+
+
+@pytest.mark.parametrize("dims", [1, 2, 3])
+def test_restriction_undoes_prolongation(dims):
+    R = akref.lib()
+    a = _setup(dims)
+    box = _active_box(a)
+    R.akref_prolong_cc(C.byref(a["pk"]), a["nvar"], akref.ptr(box), akref.ptr(a["cu"]), akref.ptr(a["u"]))
+    cu2 = np.zeros_like(a["cu"])
+    R.akref_restrict_cc(C.byref(a["pk"]), a["nvar"], akref.ptr(a["u"]), akref.ptr(cu2))
+    act = (slice(None), slice(None), slice(box[4], box[5] + 1), slice(box[2], box[3] + 1), slice(box[0], box[1] + 1))
+    assert np.abs(cu2[act] - a["cu"][act]).max() < 1e-14
+
+
+@pytest.mark.parametrize("dims", [1, 2, 3])
+def test_prolongation_is_exact_for_linear_data(dims):
+    R = akref.lib()
+    a = _setup(dims)
+    c3, c2, c1 = a["cN"]
+    K, J, I = np.meshgrid(np.arange(c3), np.arange(c2), np.arange(c1), indexing="ij")
+    lin = 0.5 + 0.25*I + (0.125*J if dims > 1 else 0) - (0.375*K if dims > 2 else 0)
+    a["cu"][:] = lin
+    box = _active_box(a)
+    R.akref_prolong_cc(C.byref(a["pk"]), a["nvar"], akref.ptr(box), akref.ptr(a["cu"]), akref.ptr(a["u"]))
+    ng = a["ng"]
+    N3, N2, N1 = a["N"]
+    Kf, Jf, If = np.meshgrid(np.arange(N3), np.arange(N2), np.arange(N1), indexing="ij")
+    # fine cell centres in coarse index units: coarse i covers fine (i-cis)*2+is, +1
+    xi = a["cis"] + (If - ng)/2.0 - 0.25
+    xj = a["cjs"] + (Jf - ng)/2.0 - 0.25 if dims > 1 else 0*Jf
+    xk = a["cks"] + (Kf - ng)/2.0 - 0.25 if dims > 2 else 0*Kf
+    exact = 0.5 + 0.25*xi + (0.125*xj if dims > 1 else 0) - (0.375*xk if dims > 2 else 0)
+    s = (slice(None), slice(None), slice(ng, N3 - ng) if dims > 2 else slice(0, 1),
+         slice(ng, N2 - ng) if dims > 1 else slice(0, 1), slice(ng, N1 - ng))
+    assert np.abs(a["u"][s] - exact[s[2:]]).max() < 1e-14
+
+
+@pytest.mark.parametrize("dims", [2, 3])
+def test_field_prolongation_preserves_divergence(dims):
+    R = akref.lib()
+    a = _setup(dims)
+    _prolong_field(R, a)
+    ng = a["ng"]
+    N3, N2, N1 = a["N"]
+    fs = (slice(ng, N3 - ng) if dims > 2 else slice(0, 1), slice(ng, N2 - ng), slice(ng, N1 - ng))
+    cs = (slice(a["cks"], a["cks"] + a["cn"][0]), slice(a["cjs"], a["cjs"] + a["cn"][1]),
+          slice(a["cis"], a["cis"] + a["cn"][2]))
+    dfine = _div(a["b"], dims, fs)            # fine faces have half the area / spacing: sum of the
+    dcoarse = _div(a["cb"], dims, cs)         # 2^d children = 2^(d-1) x coarse divergence (unit spacings)
+    nmb = a["nmb"]
+    if dims == 2:
+        child = dfine.reshape(nmb, 1, a["cn"][1], 2, a["cn"][2], 2)
+        assert np.abs(child - 0.5*dcoarse[:, :, :, None, :, None]).max() < 1e-13
+    else:
+        child = dfine.reshape(nmb, a["cn"][0], 2, a["cn"][1], 2, a["cn"][2], 2)
+        assert np.abs(child - 0.5*dcoarse[:, :, None, :, None, :, None]).max() < 1e-13
+    # and restriction returns the coarse faces
+    cb2 = [np.zeros_like(x) for x in a["cb"]]
+    R.akref_restrict_fc(C.byref(a["pk"]), *[akref.ptr(x) for x in a["b"]], *[akref.ptr(x) for x in cb2])
+    for comp in range(dims):
+        bx = _shared_box(a, comp)
+        s = (slice(None), slice(bx[4], bx[5] + 1), slice(bx[2], bx[3] + 1), slice(bx[0], bx[1] + 1))
+        assert np.abs(cb2[comp][s] - a["cb"][comp][s]).max() < 1e-14, comp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ng", [2, 4])
+@pytest.mark.parametrize("dims", [1, 2, 3])
+def test_hip_operators_match_the_oracle(dims, ng):
+    import torch
+    from athenak_amd import capi
+    L, R = capi.lib(), akref.lib()
+    a = _setup(dims, ng=ng, seed=11 + dims)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    dxd = t(a["dx"])
+    pkd = capi.Pack.from_buffer_copy(bytes(a["pk"]))
+    pkd.dx = dxd.data_ptr()
+    P, nv = C.byref(pkd), a["nvar"]
+    ud, cud, bd, cbd = t(a["u"]), t(a["cu"]), [t(x) for x in a["b"]], [t(x) for x in a["cb"]]
+    ibox = lambda b: t(b).cpu().numpy()           # host int32 arrays are passed by pointer
+    # restriction
+    cu2, cu2d = np.zeros_like(a["cu"]), torch.zeros_like(cud)
+    R.akref_restrict_cc(C.byref(a["pk"]), nv, akref.ptr(a["u"]), akref.ptr(cu2))
+    capi.check(L.akmi_restrict_cc(P, nv, capi._p(ud), capi._p(cu2d), None), "restrict_cc")
+    assert np.array_equal(cu2, cu2d.cpu().numpy())
+    cb2, cb2d = [np.zeros_like(x) for x in a["cb"]], [torch.zeros_like(x) for x in cbd]
+    R.akref_restrict_fc(C.byref(a["pk"]), *[akref.ptr(x) for x in a["b"]], *[akref.ptr(x) for x in cb2])
+    capi.check(L.akmi_restrict_fc(P, *[capi._p(x) for x in bd], *[capi._p(x) for x in cb2d], None), "restrict_fc")
+    for x, y in zip(cb2, cb2d):
+        assert np.array_equal(x, y.cpu().numpy())
+    # prolongation of cell-centred data: active box and a ghost-side box (what a coarser neighbour fills)
+    for box in (_active_box(a), np.array([a["cis"] - ng//2, a["cis"] - 1, a["cjs"], a["cjs"] + a["cn"][1] - 1,
+                                          a["cks"], a["cks"] + a["cn"][0] - 1], dtype=np.int32)):
+        R.akref_prolong_cc(C.byref(a["pk"]), nv, akref.ptr(box), akref.ptr(a["cu"]), akref.ptr(a["u"]))
+        capi.check(L.akmi_prolong_cc(P, nv, box.ctypes.data_as(C.c_void_p), capi._p(cud), capi._p(ud), None),
+                   "prolong_cc")
+        assert np.array_equal(a["u"], ud.cpu().numpy())
+    # face field: shared faces of each component, then the interior
+    for comp in range(3):
+        box = _shared_box(a, comp)
+        R.akref_prolong_fc_shared(C.byref(a["pk"]), comp, akref.ptr(box), akref.ptr(a["cb"][comp]),
+                                  akref.ptr(a["b"][comp]))
+        capi.check(L.akmi_prolong_fc_shared(P, comp, box.ctypes.data_as(C.c_void_p), capi._p(cbd[comp]),
+                                            capi._p(bd[comp]), None), "prolong_fc_shared")
+        assert np.array_equal(a["b"][comp], bd[comp].cpu().numpy()), comp
+    box = _active_box(a)
+    R.akref_prolong_fc_internal(C.byref(a["pk"]), akref.ptr(box), *[akref.ptr(x) for x in a["b"]])
+    capi.check(L.akmi_prolong_fc_internal(P, box.ctypes.data_as(C.c_void_p), *[capi._p(x) for x in bd], None),
+               "prolong_fc_internal")
+    for x, y in zip(a["b"], bd):
+        assert np.array_equal(x, y.cpu().numpy())
+    # a box whose fine cells would lie outside the block is refused, not written
+    bad = np.array([0, 1, a["cjs"], a["cjs"], a["cks"], a["cks"]], dtype=np.int32)
+    assert L.akmi_prolong_cc(P, nv, bad.ctypes.data_as(C.c_void_p), capi._p(cud), capi._p(ud), None) < 0
