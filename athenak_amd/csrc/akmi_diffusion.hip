@@ -256,6 +256,156 @@ k_resist_flux(Geo g, double eta, const double *__restrict__ bx1f, const double *
   }
 }
 
+// ---- ambipolar diffusion, constant eta_ad (src/diffusion/ambipolar.cpp) ------------------------------
+struct Amb {                     // field access of MeshBlock m + edge currents (EdgeJ1/2/3, :30-58)
+  Bf b;
+  const double *bcc;             // bcc0 of block m: [3][N3][N2][N1]
+  size_t cs;
+  double dx1, dx2, dx3;
+  bool multi_d, three_d;
+  __device__ double cc(int n, int k, int j, int i) const { return bcc[n*cs + ((size_t)k*b.N2 + j)*b.N1 + i]; }
+  __device__ double j1(int k, int j, int i) const {
+    double v = 0.0;
+    if (multi_d) v += (b.x3f(k,j,i) - b.x3f(k,j-1,i))/dx2;
+    if (three_d) v -= (b.x2f(k,j,i) - b.x2f(k-1,j,i))/dx3;
+    return v;
+  }
+  __device__ double j2(int k, int j, int i) const {
+    double v = -(b.x3f(k,j,i) - b.x3f(k,j,i-1))/dx1;
+    if (three_d) v += (b.x1f(k,j,i) - b.x1f(k-1,j,i))/dx3;
+    return v;
+  }
+  __device__ double j3(int k, int j, int i) const {
+    double v = (b.x2f(k,j,i) - b.x2f(k,j,i-1))/dx1;
+    if (multi_d) v -= (b.x1f(k,j,i) - b.x1f(k,j-1,i))/dx2;
+    return v;
+  }
+};
+
+// Resistivity::AddEMFConstantAmbipolar, ambipolar.cpp:66-246: E += eta*(B^2 J - (J.B) B) on the edges
+__global__ void __launch_bounds__(DX*DY)
+k_amb_emf(Geo g, double eta, const double *__restrict__ bcc0, const double *__restrict__ bx1f,
+          const double *__restrict__ bx2f, const double *__restrict__ bx3f, double *__restrict__ e1,
+          double *__restrict__ e2, double *__restrict__ e3, int nk) {
+  const int i = g.is + blockIdx.x*DX + threadIdx.x;
+  const int j = g.js + blockIdx.y*DY + threadIdx.y;
+  const int m = blockIdx.z/nk;
+  const int k = g.ks + (blockIdx.z - m*nk);
+  if (i > g.ie + 1 || j > (g.multi_d ? g.je + 1 : g.js)) return;
+  const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  const Amb a{bview(g, bx1f, bx2f, bx3f, m), bcc0 + (size_t)m*3*cs, cs, g.dx[3*m], g.dx[3*m + 1],
+              g.dx[3*m + 2], (bool)g.multi_d, (bool)g.three_d};
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3, ks = g.ks, ke = g.ke, js = g.js, je = g.je;
+  if (!g.multi_d) {
+    const double intBx = a.b.x1f(ks,js,i);
+    const double intBy = 0.5*(a.cc(1,ks,js,i) + a.cc(1,ks,js,i-1));
+    const double intBz = 0.5*(a.cc(2,ks,js,i) + a.cc(2,ks,js,i-1));
+    const double intJ2 = a.j2(ks,js,i), intJ3 = a.j3(ks,js,i);
+    const double Bsq = sqr(intBx) + sqr(intBy) + sqr(intBz);
+    const double JdotB = intJ2*intBy + intJ3*intBz;
+    const double e2_amb = eta * (Bsq*intJ2 - JdotB*intBy);
+    const double e3_amb = eta * (Bsq*intJ3 - JdotB*intBz);
+    e2[ix4(N3 + 1, N2, N1 + 1, m, ks, js, i)] += e2_amb;
+    e2[ix4(N3 + 1, N2, N1 + 1, m, ke + 1, js, i)] += e2_amb;
+    e3[ix4(N3, N2 + 1, N1 + 1, m, ks, js, i)] += e3_amb;
+    e3[ix4(N3, N2 + 1, N1 + 1, m, ks, je + 1, i)] += e3_amb;
+  } else if (!g.three_d) {
+    const double intJ1_e1 = a.j1(ks,j,i);
+    const double intJ2_e1 = 0.25*(a.j2(ks,j-1,i) + a.j2(ks,j-1,i+1) + a.j2(ks,j,i) + a.j2(ks,j,i+1));
+    const double intJ3_e1 = 0.5*(a.j3(ks,j,i) + a.j3(ks,j,i+1));
+    const double intBx_e1 = 0.5*(a.cc(0,ks,j,i) + a.cc(0,ks,j-1,i));
+    const double intBy_e1 = a.b.x2f(ks,j,i);
+    const double intBz_e1 = 0.5*(a.cc(2,ks,j,i) + a.cc(2,ks,j-1,i));
+    const double Bsq_e1 = sqr(intBx_e1) + sqr(intBy_e1) + sqr(intBz_e1);
+    const double JdotB_e1 = intJ1_e1*intBx_e1 + intJ2_e1*intBy_e1 + intJ3_e1*intBz_e1;
+    const double e1_amb = eta * (Bsq_e1*intJ1_e1 - JdotB_e1*intBx_e1);
+    e1[ix4(N3 + 1, N2 + 1, N1, m, ks, j, i)] += e1_amb;
+    e1[ix4(N3 + 1, N2 + 1, N1, m, ke + 1, j, i)] += e1_amb;
+    const double intJ1_e2 = 0.25*(a.j1(ks,j,i-1) + a.j1(ks,j,i) + a.j1(ks,j+1,i-1) + a.j1(ks,j+1,i));
+    const double intJ2_e2 = a.j2(ks,j,i);
+    const double intJ3_e2 = 0.5*(a.j3(ks,j,i) + a.j3(ks,j+1,i));
+    const double intBx_e2 = a.b.x1f(ks,j,i);
+    const double intBy_e2 = 0.5*(a.cc(1,ks,j,i) + a.cc(1,ks,j,i-1));
+    const double intBz_e2 = 0.5*(a.cc(2,ks,j,i) + a.cc(2,ks,j,i-1));
+    const double Bsq_e2 = sqr(intBx_e2) + sqr(intBy_e2) + sqr(intBz_e2);
+    const double JdotB_e2 = intJ1_e2*intBx_e2 + intJ2_e2*intBy_e2 + intJ3_e2*intBz_e2;
+    const double e2_amb = eta * (Bsq_e2*intJ2_e2 - JdotB_e2*intBy_e2);
+    e2[ix4(N3 + 1, N2, N1 + 1, m, ks, j, i)] += e2_amb;
+    e2[ix4(N3 + 1, N2, N1 + 1, m, ke + 1, j, i)] += e2_amb;
+    const double intJ1_e3 = 0.5*(a.j1(ks,j,i-1) + a.j1(ks,j,i));
+    const double intJ2_e3 = 0.5*(a.j2(ks,j-1,i) + a.j2(ks,j,i));
+    const double intJ3_e3 = a.j3(ks,j,i);
+    const double intBx_e3 = 0.5*(a.b.x1f(ks,j,i) + a.b.x1f(ks,j-1,i));
+    const double intBy_e3 = 0.5*(a.b.x2f(ks,j,i) + a.b.x2f(ks,j,i-1));
+    const double intBz_e3 = 0.25*(a.cc(2,ks,j,i) + a.cc(2,ks,j-1,i) + a.cc(2,ks,j,i-1) + a.cc(2,ks,j-1,i-1));
+    const double Bsq_e3 = sqr(intBx_e3) + sqr(intBy_e3) + sqr(intBz_e3);
+    const double JdotB_e3 = intJ1_e3*intBx_e3 + intJ2_e3*intBy_e3 + intJ3_e3*intBz_e3;
+    e3[ix4(N3, N2 + 1, N1 + 1, m, ks, j, i)] += eta * (Bsq_e3*intJ3_e3 - JdotB_e3*intBz_e3);
+  } else {
+    const double intJ1_e1 = a.j1(k,j,i);
+    const double intJ2_e1 = 0.25*(a.j2(k,j-1,i) + a.j2(k,j-1,i+1) + a.j2(k,j,i) + a.j2(k,j,i+1));
+    const double intJ3_e1 = 0.25*(a.j3(k-1,j,i) + a.j3(k-1,j,i+1) + a.j3(k,j,i) + a.j3(k,j,i+1));
+    const double intBx_e1 = 0.25*(a.cc(0,k,j,i) + a.cc(0,k-1,j,i) + a.cc(0,k,j-1,i) + a.cc(0,k-1,j-1,i));
+    const double intBy_e1 = 0.5*(a.b.x2f(k,j,i) + a.b.x2f(k-1,j,i));
+    const double intBz_e1 = 0.5*(a.b.x3f(k,j,i) + a.b.x3f(k,j-1,i));
+    const double Bsq_e1 = sqr(intBx_e1) + sqr(intBy_e1) + sqr(intBz_e1);
+    const double JdotB_e1 = intJ1_e1*intBx_e1 + intJ2_e1*intBy_e1 + intJ3_e1*intBz_e1;
+    e1[ix4(N3 + 1, N2 + 1, N1, m, k, j, i)] += eta * (Bsq_e1*intJ1_e1 - JdotB_e1*intBx_e1);
+    const double intJ1_e2 = 0.25*(a.j1(k,j,i-1) + a.j1(k,j,i) + a.j1(k,j+1,i-1) + a.j1(k,j+1,i));
+    const double intJ2_e2 = a.j2(k,j,i);
+    const double intJ3_e2 = 0.25*(a.j3(k-1,j,i) + a.j3(k-1,j+1,i) + a.j3(k,j,i) + a.j3(k,j+1,i));
+    const double intBx_e2 = 0.5*(a.b.x1f(k,j,i) + a.b.x1f(k-1,j,i));
+    const double intBy_e2 = 0.25*(a.cc(1,k,j,i) + a.cc(1,k-1,j,i) + a.cc(1,k,j,i-1) + a.cc(1,k-1,j,i-1));
+    const double intBz_e2 = 0.5*(a.b.x3f(k,j,i) + a.b.x3f(k,j,i-1));
+    const double Bsq_e2 = sqr(intBx_e2) + sqr(intBy_e2) + sqr(intBz_e2);
+    const double JdotB_e2 = intJ1_e2*intBx_e2 + intJ2_e2*intBy_e2 + intJ3_e2*intBz_e2;
+    e2[ix4(N3 + 1, N2, N1 + 1, m, k, j, i)] += eta * (Bsq_e2*intJ2_e2 - JdotB_e2*intBy_e2);
+    const double intJ1_e3 = 0.25*(a.j1(k,j,i-1) + a.j1(k,j,i) + a.j1(k+1,j,i-1) + a.j1(k+1,j,i));
+    const double intJ2_e3 = 0.25*(a.j2(k,j-1,i) + a.j2(k,j,i) + a.j2(k+1,j-1,i) + a.j2(k+1,j,i));
+    const double intJ3_e3 = a.j3(k,j,i);
+    const double intBx_e3 = 0.5*(a.b.x1f(k,j,i) + a.b.x1f(k,j-1,i));
+    const double intBy_e3 = 0.5*(a.b.x2f(k,j,i) + a.b.x2f(k,j,i-1));
+    const double intBz_e3 = 0.25*(a.cc(2,k,j,i) + a.cc(2,k,j-1,i) + a.cc(2,k,j,i-1) + a.cc(2,k,j-1,i-1));
+    const double Bsq_e3 = sqr(intBx_e3) + sqr(intBy_e3) + sqr(intBz_e3);
+    const double JdotB_e3 = intJ1_e3*intBx_e3 + intJ2_e3*intBy_e3 + intJ3_e3*intBz_e3;
+    e3[ix4(N3, N2 + 1, N1 + 1, m, k, j, i)] += eta * (Bsq_e3*intJ3_e3 - JdotB_e3*intBz_e3);
+  }
+}
+
+// Resistivity::NewTimeStep with eta_ad != 0 (resistivity.cpp:313-345): min over the active cells of
+// SQR(dx)/(eta_ohm + eta_ad*B^2).  eta is a monotone function of the rounded B^2 sum, SQR(dx)/eta a
+// monotone function of eta: reduce max(B^2) per workgroup, evaluate once.
+__global__ void __launch_bounds__(DX*DY)
+k_resist_newdt(Geo g, double eta_o, double eta_a, const double *__restrict__ bcc0,
+               double *__restrict__ dtmin, int nk) {
+  const int i = g.is + blockIdx.x*DX + threadIdx.x;
+  const int j = g.js + blockIdx.y*DY + threadIdx.y;
+  const int m = blockIdx.z/nk;
+  const int k = g.ks + (blockIdx.z - m*nk);
+  double b2 = -1.0;
+  if (i <= g.ie && j <= g.je) {
+    const size_t cs = (size_t)g.N3*g.N2*g.N1;
+    const size_t c = ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i);
+    b2 = sqr(bcc0[c]) + sqr(bcc0[c + cs]) + sqr(bcc0[c + 2*cs]);
+  }
+  for (int off = 32; off > 0; off >>= 1) b2 = fmax(b2, __shfl_xor(b2, off, 64));
+  __shared__ double sm[DY];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.y] = b2;
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0) {
+    for (int q = 1; q < DY; ++q) b2 = fmax(b2, sm[q]);
+    if (b2 < 0.0) return;
+    const double eta = eta_o + eta_a*b2;
+    if (!(eta > 0.0)) return;
+    double v = sqr(g.dx[3*m])/eta;
+    if (g.multi_d) v = fmin(v, sqr(g.dx[3*m + 1])/eta);
+    if (g.three_d) v = fmin(v, sqr(g.dx[3*m + 2])/eta);
+    if (v < __hip_atomic_load(dtmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMin(reinterpret_cast<unsigned long long *>(dtmin),
+                (unsigned long long)__double_as_longlong(v));
+  }
+}
+
 static dim3 face_grid(const Geo &g, int dir, int &nk) {
   nk = g.ke - g.ks + 1 + (dir == 2);
   return dim3(cdiv(g.nx1 + (dir == 0), DX), cdiv(g.je - g.js + 1 + (dir == 1), DY), nk*g.nmb);
@@ -355,6 +505,29 @@ int akmi_resistive_fluxes(const akmi_pack *p, double eta_ohm, const double *bx1f
     k_resist_flux<2><<<g2, block, 0, st>>>(g, eta_ohm, bx1f, bx2f, bx3f, flx3, nk);
   }
   AKMI_CHECK_LAUNCH("resistive_fluxes");
+  return AKMI_COMPLETE;
+}
+
+int akmi_ambipolar_emfs(const akmi_pack *p, double eta_ad, const double *bcc0, const double *bx1f,
+                        const double *bx2f, const double *bx3f, double *e1, double *e2, double *e3,
+                        void *stream) {
+  Geo g = make_geo(p);
+  const int nk = g.three_d ? g.ke - g.ks + 2 : 1;
+  dim3 grid(cdiv(g.nx1 + 1, DX), cdiv(g.multi_d ? g.nx2 + 1 : 1, DY), nk*g.nmb), block(DX, DY);
+  k_amb_emf<<<grid, block, 0, (hipStream_t)stream>>>(g, eta_ad, bcc0, bx1f, bx2f, bx3f, e1, e2, e3, nk);
+  AKMI_CHECK_LAUNCH("ambipolar_emfs");
+  return AKMI_COMPLETE;
+}
+
+int akmi_resistive_newdt(const akmi_pack *p, double eta_ohm, double eta_ad, const double *bcc0,
+                         double *dtmin, void *stream) {
+  Geo g = make_geo(p);
+  hipStream_t st = (hipStream_t)stream;
+  k_set_fltmax<<<1, 64, 0, st>>>(dtmin);
+  const int nk = g.ke - g.ks + 1;
+  dim3 grid(cdiv(g.nx1, DX), cdiv(g.je - g.js + 1, DY), nk*g.nmb), block(DX, DY);
+  k_resist_newdt<<<grid, block, 0, st>>>(g, eta_ohm, eta_ad, bcc0, dtmin, nk);
+  AKMI_CHECK_LAUNCH("resistive_newdt");
   return AKMI_COMPLETE;
 }
 

@@ -96,8 +96,10 @@ class Resistivity(_Diffusion):
         super().__init__(phys)
         self.eta_ohm = pin.GetOrAddReal("mhd", "eta_ohm", 0.0)
         self.eta_ad = pin.GetOrAddReal("mhd", "eta_ad", 0.0)
-        if self.eta_ad != 0.0:
-            raise RuntimeError("### FATAL ERROR <mhd>/eta_ad: ambipolar diffusion is not on this path")
+        if self.eta_ad != 0.0 and phys.peos.eos_data.is_ideal:
+            raise RuntimeError("### FATAL ERROR <mhd>/eta_ad with the ideal-gas EOS (ambipolar heating "
+                               "flux) is not on this path; isothermal MHD only")
+        self.dtmin = torch.zeros(1, dtype=torch.float64, device=phys.device)
 
     def AddResistiveEMFs(self, b0, efld):
         if self.eta_ohm != 0.0:                                  # resistivity.cpp:49-51
@@ -105,6 +107,11 @@ class Resistivity(_Diffusion):
                 C.byref(self.phys.pack_c), C.c_double(self.eta_ohm), capi._p(b0.x1f), capi._p(b0.x2f),
                 capi._p(b0.x3f), capi._p(efld.x1e), capi._p(efld.x2e), capi._p(efld.x3e),
                 capi._stream()), "resistive_emfs")
+        if self.eta_ad != 0.0:                                   # resistivity.cpp:52-54
+            capi.check(self.L.akmi_ambipolar_emfs(
+                C.byref(self.phys.pack_c), C.c_double(self.eta_ad), capi._p(self.phys.bcc0),
+                capi._p(b0.x1f), capi._p(b0.x2f), capi._p(b0.x3f), capi._p(efld.x1e), capi._p(efld.x2e),
+                capi._p(efld.x3e), capi._stream()), "ambipolar_emfs")
 
     def AddResistiveFluxes(self, b0, flx):
         if self.eta_ohm != 0.0:                                  # resistivity.cpp:64-66
@@ -114,7 +121,13 @@ class Resistivity(_Diffusion):
                 capi._stream()), "resistive_fluxes")
 
     def NewTimeStep(self):
-        self.dtnew = self._const_dt(self.eta_ohm) if self.eta_ohm > 0.0 else FLT_MAX
+        if self.eta_ad == 0.0:                                   # resistivity.cpp:298-311
+            self.dtnew = self._const_dt(self.eta_ohm) if self.eta_ohm > 0.0 else FLT_MAX
+            return
+        capi.check(self.L.akmi_resistive_newdt(                  # resistivity.cpp:313-345
+            C.byref(self.phys.pack_c), C.c_double(self.eta_ohm), C.c_double(self.eta_ad),
+            capi._p(self.phys.bcc0), capi._p(self.dtmin), capi._stream()), "resistive_newdt")
+        self.dtnew = float(self.dtmin.item())*_fac(self.pmy_pack.pmesh)
 
 
 def make_diffusion(phys, pin, blk):

@@ -69,6 +69,10 @@ int akref_restrict_fc(const akmi_pack *p, const double *b1, const double *b2, co
 int akref_prolong_cc(const akmi_pack *p, int nvar, const int box[6], const double *cu, double *u);
 int akref_prolong_fc_shared(const akmi_pack *p, int comp, const int box[6], const double *cb, double *b);
 int akref_prolong_fc_internal(const akmi_pack *p, const int box[6], double *b1, double *b2, double *b3);
+int akref_ambipolar_emfs(const akmi_pack *p, double eta_ad, const double *bcc0, const double *bx1f,
+                         const double *bx2f, const double *bx3f, double *e1, double *e2, double *e3);
+int akref_resistive_newdt(const akmi_pack *p, double eta_ohm, double eta_ad, const double *bcc0,
+                          double *dtmin);
 int akref_rk4_copy_cons(const akmi_pack *p, double delta, const double *u0, double *u1);
 int akref_hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
                        double *flx1, double *flx2, double *flx3, int face_shaped);
@@ -161,6 +165,7 @@ typedef struct akref_params {
   int nscalars;                    /* passive scalars appended to the fluid variables */
   int fofc;                        /* <hydro>/fofc: first-order flux correction */
   int kinematic;                   /* <time>/evolution = kinematic (with rsolver = advect) */
+  double eta_ad;                   /* ambipolar diffusion coefficient (isothermal MHD only here) */
   double nu_iso, alpha_iso, eta_ohm; /* constant viscosity / thermal diffusivity / Ohmic resistivity
                                       * (0 = not requested), src/diffusion */
   /* <problem> */

@@ -44,6 +44,7 @@ class Params(C.Structure):
                 ("is_ideal", C.c_int), ("iso_cs", C.c_double), ("nscalars", C.c_int),
                 ("fofc", C.c_int),
                 ("kinematic", C.c_int),
+                ("eta_ad", C.c_double),
                 ("nu_iso", C.c_double), ("alpha_iso", C.c_double), ("eta_ohm", C.c_double),
                 ("pgen", C.c_int),
                 ("wave_flag", C.c_int), ("along_x1", C.c_int), ("along_x2", C.c_int),

@@ -2962,3 +2962,163 @@ int akref_prolong_fc_internal(const akmi_pack *p, const int box[6], double *b1, 
 #undef CB1
 #undef CB2
 #undef CB3
+
+/* ---- ambipolar diffusion, constant eta_ad (src/diffusion/ambipolar.cpp) ---------------------------- */
+#define AB1(k,j,i) bx1f[ix4(N3,N2,N1+1,m,(k),(j),(i))]
+#define AB2(k,j,i) bx2f[ix4(N3,N2+1,N1,m,(k),(j),(i))]
+#define AB3(k,j,i) bx3f[ix4(N3+1,N2,N1,m,(k),(j),(i))]
+#define ABC(n,k,j,i) bcc0[ix5(3,N3,N2,N1,m,(n),(k),(j),(i))]
+#define AE1(k,j,i) e1[ix4(N3+1,N2+1,N1,m,(k),(j),(i))]
+#define AE2(k,j,i) e2[ix4(N3+1,N2,N1+1,m,(k),(j),(i))]
+#define AE3(k,j,i) e3[ix4(N3,N2+1,N1+1,m,(k),(j),(i))]
+/* EdgeJ1/2/3, ambipolar.cpp:30-58 */
+#define EJ1(k,j,i) ((g.multi_d ? (AB3(k,j,i) - AB3(k,(j)-1,i))/dx2 : 0.0) - (g.three_d ? (AB2(k,j,i) - AB2((k)-1,j,i))/dx3 : 0.0))
+
+static inline double edge_j1(const G *g, const double *bx2f, const double *bx3f, int N1, int N2, int N3,
+                             int m, int k, int j, int i, double dx2, double dx3) {
+  double j1 = 0.0;
+  if (g->multi_d) j1 += (AB3(k,j,i) - AB3(k,j-1,i))/dx2;
+  if (g->three_d) j1 -= (AB2(k,j,i) - AB2(k-1,j,i))/dx3;
+  return j1;
+}
+static inline double edge_j2(const G *g, const double *bx1f, const double *bx3f, int N1, int N2, int N3,
+                             int m, int k, int j, int i, double dx1, double dx3) {
+  double j2 = -(AB3(k,j,i) - AB3(k,j,i-1))/dx1;
+  if (g->three_d) j2 += (AB1(k,j,i) - AB1(k-1,j,i))/dx3;
+  return j2;
+}
+static inline double edge_j3(const G *g, const double *bx1f, const double *bx2f, int N1, int N2, int N3,
+                             int m, int k, int j, int i, double dx1, double dx2) {
+  double j3 = (AB2(k,j,i) - AB2(k,j,i-1))/dx1;
+  if (g->multi_d) j3 -= (AB1(k,j,i) - AB1(k,j-1,i))/dx2;
+  return j3;
+}
+#undef EJ1
+
+/* Resistivity::AddEMFConstantAmbipolar, src/diffusion/ambipolar.cpp:66-246:
+ * E += eta_ad*(B^2 J - (J.B) B) with J and B averaged to each edge */
+int akref_ambipolar_emfs(const akmi_pack *p, double eta, const double *bcc0, const double *bx1f,
+                         const double *bx2f, const double *bx3f, double *e1, double *e2, double *e3) {
+  G g = mkG(p);
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  const int is = g.is, ie = g.ie, js = g.js, je = g.je, ks = g.ks, ke = g.ke;
+#define J1(k,j,i) edge_j1(&g, bx2f, bx3f, N1, N2, N3, m, k, j, i, dx2, dx3)
+#define J2(k,j,i) edge_j2(&g, bx1f, bx3f, N1, N2, N3, m, k, j, i, dx1, dx3)
+#define J3(k,j,i) edge_j3(&g, bx1f, bx2f, N1, N2, N3, m, k, j, i, dx1, dx2)
+  for (int m = 0; m < g.nmb; ++m) {
+    const double dx1 = p->dx[3*m], dx2 = p->dx[3*m+1], dx3 = p->dx[3*m+2];
+    if (!g.multi_d) {
+      for (int i = is; i <= ie+1; ++i) {
+        double intBx = AB1(ks,js,i);
+        double intBy = 0.5*(ABC(1,ks,js,i) + ABC(1,ks,js,i-1));
+        double intBz = 0.5*(ABC(2,ks,js,i) + ABC(2,ks,js,i-1));
+        double intJ2 = J2(ks,js,i), intJ3 = J3(ks,js,i);
+        double Bsq = SQR(intBx) + SQR(intBy) + SQR(intBz);
+        double JdotB = intJ2*intBy + intJ3*intBz;
+        double e2_amb = eta * (Bsq*intJ2 - JdotB*intBy);
+        double e3_amb = eta * (Bsq*intJ3 - JdotB*intBz);
+        AE2(ks,js,i) += e2_amb; AE2(ke+1,js,i) += e2_amb;
+        AE3(ks,js,i) += e3_amb; AE3(ks,je+1,i) += e3_amb;
+      }
+    } else if (!g.three_d) {
+      for (int j = js; j <= je+1; ++j) for (int i = is; i <= ie+1; ++i) {
+        double intJ1_e1 = J1(ks,j,i);
+        double intJ2_e1 = 0.25*(J2(ks,j-1,i) + J2(ks,j-1,i+1) + J2(ks,j,i) + J2(ks,j,i+1));
+        double intJ3_e1 = 0.5*(J3(ks,j,i) + J3(ks,j,i+1));
+        double intBx_e1 = 0.5*(ABC(0,ks,j,i) + ABC(0,ks,j-1,i));
+        double intBy_e1 = AB2(ks,j,i);
+        double intBz_e1 = 0.5*(ABC(2,ks,j,i) + ABC(2,ks,j-1,i));
+        double Bsq_e1 = SQR(intBx_e1) + SQR(intBy_e1) + SQR(intBz_e1);
+        double JdotB_e1 = intJ1_e1*intBx_e1 + intJ2_e1*intBy_e1 + intJ3_e1*intBz_e1;
+        double e1_amb = eta * (Bsq_e1*intJ1_e1 - JdotB_e1*intBx_e1);
+        AE1(ks,j,i) += e1_amb; AE1(ke+1,j,i) += e1_amb;
+
+        double intJ1_e2 = 0.25*(J1(ks,j,i-1) + J1(ks,j,i) + J1(ks,j+1,i-1) + J1(ks,j+1,i));
+        double intJ2_e2 = J2(ks,j,i);
+        double intJ3_e2 = 0.5*(J3(ks,j,i) + J3(ks,j+1,i));
+        double intBx_e2 = AB1(ks,j,i);
+        double intBy_e2 = 0.5*(ABC(1,ks,j,i) + ABC(1,ks,j,i-1));
+        double intBz_e2 = 0.5*(ABC(2,ks,j,i) + ABC(2,ks,j,i-1));
+        double Bsq_e2 = SQR(intBx_e2) + SQR(intBy_e2) + SQR(intBz_e2);
+        double JdotB_e2 = intJ1_e2*intBx_e2 + intJ2_e2*intBy_e2 + intJ3_e2*intBz_e2;
+        double e2_amb = eta * (Bsq_e2*intJ2_e2 - JdotB_e2*intBy_e2);
+        AE2(ks,j,i) += e2_amb; AE2(ke+1,j,i) += e2_amb;
+
+        double intJ1_e3 = 0.5*(J1(ks,j,i-1) + J1(ks,j,i));
+        double intJ2_e3 = 0.5*(J2(ks,j-1,i) + J2(ks,j,i));
+        double intJ3_e3 = J3(ks,j,i);
+        double intBx_e3 = 0.5*(AB1(ks,j,i) + AB1(ks,j-1,i));
+        double intBy_e3 = 0.5*(AB2(ks,j,i) + AB2(ks,j,i-1));
+        double intBz_e3 = 0.25*(ABC(2,ks,j,i) + ABC(2,ks,j-1,i) + ABC(2,ks,j,i-1) + ABC(2,ks,j-1,i-1));
+        double Bsq_e3 = SQR(intBx_e3) + SQR(intBy_e3) + SQR(intBz_e3);
+        double JdotB_e3 = intJ1_e3*intBx_e3 + intJ2_e3*intBy_e3 + intJ3_e3*intBz_e3;
+        double e3_amb = eta * (Bsq_e3*intJ3_e3 - JdotB_e3*intBz_e3);
+        AE3(ks,j,i) += e3_amb;
+      }
+    } else {
+      for (int k = ks; k <= ke+1; ++k) for (int j = js; j <= je+1; ++j) for (int i = is; i <= ie+1; ++i) {
+        double intJ1_e1 = J1(k,j,i);
+        double intJ2_e1 = 0.25*(J2(k,j-1,i) + J2(k,j-1,i+1) + J2(k,j,i) + J2(k,j,i+1));
+        double intJ3_e1 = 0.25*(J3(k-1,j,i) + J3(k-1,j,i+1) + J3(k,j,i) + J3(k,j,i+1));
+        double intBx_e1 = 0.25*(ABC(0,k,j,i) + ABC(0,k-1,j,i) + ABC(0,k,j-1,i) + ABC(0,k-1,j-1,i));
+        double intBy_e1 = 0.5*(AB2(k,j,i) + AB2(k-1,j,i));
+        double intBz_e1 = 0.5*(AB3(k,j,i) + AB3(k,j-1,i));
+        double Bsq_e1 = SQR(intBx_e1) + SQR(intBy_e1) + SQR(intBz_e1);
+        double JdotB_e1 = intJ1_e1*intBx_e1 + intJ2_e1*intBy_e1 + intJ3_e1*intBz_e1;
+        AE1(k,j,i) += eta * (Bsq_e1*intJ1_e1 - JdotB_e1*intBx_e1);
+
+        double intJ1_e2 = 0.25*(J1(k,j,i-1) + J1(k,j,i) + J1(k,j+1,i-1) + J1(k,j+1,i));
+        double intJ2_e2 = J2(k,j,i);
+        double intJ3_e2 = 0.25*(J3(k-1,j,i) + J3(k-1,j+1,i) + J3(k,j,i) + J3(k,j+1,i));
+        double intBx_e2 = 0.5*(AB1(k,j,i) + AB1(k-1,j,i));
+        double intBy_e2 = 0.25*(ABC(1,k,j,i) + ABC(1,k-1,j,i) + ABC(1,k,j,i-1) + ABC(1,k-1,j,i-1));
+        double intBz_e2 = 0.5*(AB3(k,j,i) + AB3(k,j,i-1));
+        double Bsq_e2 = SQR(intBx_e2) + SQR(intBy_e2) + SQR(intBz_e2);
+        double JdotB_e2 = intJ1_e2*intBx_e2 + intJ2_e2*intBy_e2 + intJ3_e2*intBz_e2;
+        AE2(k,j,i) += eta * (Bsq_e2*intJ2_e2 - JdotB_e2*intBy_e2);
+
+        double intJ1_e3 = 0.25*(J1(k,j,i-1) + J1(k,j,i) + J1(k+1,j,i-1) + J1(k+1,j,i));
+        double intJ2_e3 = 0.25*(J2(k,j-1,i) + J2(k,j,i) + J2(k+1,j-1,i) + J2(k+1,j,i));
+        double intJ3_e3 = J3(k,j,i);
+        double intBx_e3 = 0.5*(AB1(k,j,i) + AB1(k,j-1,i));
+        double intBy_e3 = 0.5*(AB2(k,j,i) + AB2(k,j,i-1));
+        double intBz_e3 = 0.25*(ABC(2,k,j,i) + ABC(2,k,j-1,i) + ABC(2,k,j,i-1) + ABC(2,k,j-1,i-1));
+        double Bsq_e3 = SQR(intBx_e3) + SQR(intBy_e3) + SQR(intBz_e3);
+        double JdotB_e3 = intJ1_e3*intBx_e3 + intJ2_e3*intBy_e3 + intJ3_e3*intBz_e3;
+        AE3(k,j,i) += eta * (Bsq_e3*intJ3_e3 - JdotB_e3*intBz_e3);
+      }
+    }
+  }
+#undef J1
+#undef J2
+#undef J3
+  return 0;
+}
+
+/* Resistivity::NewTimeStep with eta_ad != 0, src/diffusion/resistivity.cpp:313-345: the cell reduction
+ * min SQR(dx)/(eta_ohm + eta_ad*B^2) (before *fac) */
+int akref_resistive_newdt(const akmi_pack *p, double eta_o, double eta_a, const double *bcc0,
+                          double *dtmin) {
+  G g = mkG(p);
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  double min_dt = (double)FLT_MAX;
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = g.ks; k <= g.ke; ++k) for (int j = g.js; j <= g.je; ++j)
+      for (int i = g.is; i <= g.ie; ++i) {
+        double eta = eta_o + eta_a*(SQR(ABC(0,k,j,i)) + SQR(ABC(1,k,j,i)) + SQR(ABC(2,k,j,i)));
+        if (eta > 0.0) {
+          min_dt = fmin(min_dt, SQR(p->dx[3*m])/eta);
+          if (g.multi_d) min_dt = fmin(min_dt, SQR(p->dx[3*m+1])/eta);
+          if (g.three_d) min_dt = fmin(min_dt, SQR(p->dx[3*m+2])/eta);
+        }
+      }
+  *dtmin = min_dt;
+  return 0;
+}
+#undef AB1
+#undef AB2
+#undef AB3
+#undef ABC
+#undef AE1
+#undef AE2
+#undef AE3

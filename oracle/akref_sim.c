@@ -93,6 +93,9 @@ akref_sim *akref_create(const akref_params *par) {
   if (s->nb1*p->mb_nx1 != p->nx1 || s->nb2*p->mb_nx2 != p->nx2 || s->nb3*p->mb_nx3 != p->nx3) {
     free(s); return NULL;
   }
+  if (p->eta_ad != 0.0 && (!p->is_mhd || p->is_ideal)) {   /* the ambipolar energy flux is not restated */
+    free(s); return NULL;
+  }
   /* rsolver = advect only for kinematic problems and vice versa (hydro.cpp:244-278, mhd.cpp:292-326) */
   if ((p->kinematic != 0) != (p->rsolver == AKMI_RS_ADVECT)) {
     free(s); return NULL;
@@ -749,11 +752,15 @@ static void new_dt_task(akref_sim *s) {
       if (s->multi_d) s->dt_visc = fmin(s->dt_visc, fac*(dx[1]*dx[1])/p->nu_iso);
       if (s->three_d) s->dt_visc = fmin(s->dt_visc, fac*(dx[2]*dx[2])/p->nu_iso);
     }
-    if (p->is_mhd && p->eta_ohm > 0.0) {
+    if (p->is_mhd && p->eta_ad == 0.0 && p->eta_ohm > 0.0) {          /* resistivity.cpp:299-311 */
       s->dt_resist = fmin(s->dt_resist, fac*(dx[0]*dx[0])/p->eta_ohm);
       if (s->multi_d) s->dt_resist = fmin(s->dt_resist, fac*(dx[1]*dx[1])/p->eta_ohm);
       if (s->three_d) s->dt_resist = fmin(s->dt_resist, fac*(dx[2]*dx[2])/p->eta_ohm);
     }
+  }
+  if (p->is_mhd && p->eta_ad != 0.0) {                                 /* resistivity.cpp:313-345 */
+    akref_resistive_newdt(&s->pack, p->eta_ohm, p->eta_ad, s->bcc0, &s->dt_resist);
+    s->dt_resist *= fac;
   }
   if (p->alpha_iso != 0.0) {
     akref_conduction_newdt(&s->pack, p->alpha_iso, s->w0, &s->dt_cond);
@@ -766,7 +773,7 @@ static void mesh_new_dt(akref_sim *s) {
   s->dt = 2.0*s->dt;
   s->dt = fmin(s->dt, s->par.cfl*s->dtnew);
   if (s->par.nu_iso != 0.0) s->dt = fmin(s->dt, s->par.cfl*s->dt_visc);
-  if (s->par.is_mhd && s->par.eta_ohm != 0.0) s->dt = fmin(s->dt, s->par.cfl*s->dt_resist);
+  if (s->par.is_mhd && (s->par.eta_ohm != 0.0 || s->par.eta_ad != 0.0)) s->dt = fmin(s->dt, s->par.cfl*s->dt_resist);
   if (s->par.alpha_iso != 0.0) s->dt = fmin(s->dt, s->par.cfl*s->dt_cond);
   if ((s->time < s->tlim) && ((s->time + s->dt) > s->tlim)) s->dt = s->tlim - s->time;
 }
@@ -832,6 +839,8 @@ int akref_step(akref_sim *s) {
                          s->e[2]);
       if (p->eta_ohm != 0.0)         /* MHD::EField, mhd_tasks.cpp:381-383 */
         akref_resistive_emfs(pk, p->eta_ohm, s->b0[0], s->b0[1], s->b0[2], s->e[0], s->e[1], s->e[2]);
+      if (p->eta_ad != 0.0)          /* resistivity.cpp:52-54 */
+        akref_ambipolar_emfs(pk, p->eta_ad, s->bcc0, s->b0[0], s->b0[1], s->b0[2], s->e[0], s->e[1], s->e[2]);
       /* SendE/RecvE: on a uniform mesh every shared edge EMF is computed identically by
        * both owners, (a+a)*0.5==a: numerically a no-op. */
       akref_mhd_ct(pk, gam0, gam1, beta_dt, s->e[0], s->e[1], s->e[2], s->b0[0], s->b0[1],

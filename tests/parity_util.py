@@ -72,7 +72,7 @@ def oracle_kwargs(pin):
     for fl in ("dfloor", "pfloor", "tfloor", "sfloor", "sigma_max"):
         if pin.DoesParameterExist(blk, fl):
             kw[fl] = g(blk, fl)
-    for dc in ("nu_iso", "alpha_iso", "eta_ohm"):
+    for dc in ("nu_iso", "alpha_iso", "eta_ohm", "eta_ad"):
         if pin.DoesParameterExist(blk, dc):
             kw[dc] = g(blk, dc)
     if pin.DoesParameterExist(blk, "fofc") and pin.GetBoolean(blk, "fofc"):

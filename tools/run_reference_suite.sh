@@ -25,7 +25,7 @@ sys.path.insert(0, os.getcwd())
 import test_suite.testutils  # noqa: F401  (resolves ../vis/python relative to tst/)
 tests = [os.path.abspath("test_suite/nr/test_nr_%s_cpu.py" % t) for t in ("lwave1d", "isolwave1d", "sod", "rj2a")]
 # kinematic Gaussian-pulse diffusion regressions (viscosity 1-D, conduction 1-D and 2-D)
-tests += [os.path.abspath("test_suite/diffusion/test_diffusion_%s_cpu.py" % t) for t in ("visc", "conduct", "resist")]
+tests += [os.path.abspath("test_suite/diffusion/test_diffusion_%s_cpu.py" % t) for t in ("visc", "conduct", "resist", "ambipolar_linwave")]
 os.chdir("build/src")
 args = tests + ["-p", "no:cacheprovider", "-q"] + ([] if os.environ.get("AKMI_SUITE_KEEP_GOING") else ["-x"])
 if len(sys.argv) > 1:
