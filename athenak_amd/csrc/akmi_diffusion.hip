@@ -372,6 +372,111 @@ k_amb_emf(Geo g, double eta, const double *__restrict__ bcc0, const double *__re
   }
 }
 
+// eta*B^2*J on an edge with B averaged to it as in the EMF routine (3-D forms, ambipolar.cpp:362-480)
+__device__ __forceinline__ double amb_e1(const Amb &a, double eta, int k, int j, int i) {
+  const double Bx = 0.25*(a.cc(0,k,j,i) + a.cc(0,k-1,j,i) + a.cc(0,k,j-1,i) + a.cc(0,k-1,j-1,i));
+  const double By = 0.5*(a.b.x2f(k,j,i) + a.b.x2f(k-1,j,i));
+  const double Bz = 0.5*(a.b.x3f(k,j,i) + a.b.x3f(k,j-1,i));
+  return eta * (sqr(Bx) + sqr(By) + sqr(Bz)) * a.j1(k,j,i);
+}
+__device__ __forceinline__ double amb_e2(const Amb &a, double eta, int k, int j, int i) {
+  const double Bx = 0.5*(a.b.x1f(k,j,i) + a.b.x1f(k-1,j,i));
+  const double By = 0.25*(a.cc(1,k,j,i) + a.cc(1,k-1,j,i) + a.cc(1,k,j,i-1) + a.cc(1,k-1,j,i-1));
+  const double Bz = 0.5*(a.b.x3f(k,j,i) + a.b.x3f(k,j,i-1));
+  return eta * (sqr(Bx) + sqr(By) + sqr(Bz)) * a.j2(k,j,i);
+}
+__device__ __forceinline__ double amb_e3(const Amb &a, double eta, int k, int j, int i) {
+  const double Bx = 0.5*(a.b.x1f(k,j,i) + a.b.x1f(k,j-1,i));
+  const double By = 0.5*(a.b.x2f(k,j,i) + a.b.x2f(k,j,i-1));
+  const double Bz = 0.25*(a.cc(2,k,j,i) + a.cc(2,k,j-1,i) + a.cc(2,k,j,i-1) + a.cc(2,k,j-1,i-1));
+  return eta * (sqr(Bx) + sqr(By) + sqr(Bz)) * a.j3(k,j,i);
+}
+
+// Resistivity::AddFluxConstantAmbipolar, ambipolar.cpp:254-494 (energy flux, face-shaped arrays)
+template <int DIR>
+__global__ void __launch_bounds__(DX*DY)
+k_amb_flux(Geo g, double eta, const double *__restrict__ bcc0, const double *__restrict__ bx1f,
+           const double *__restrict__ bx2f, const double *__restrict__ bx3f, double *__restrict__ flx,
+           int nk) {
+  const int i = g.is + blockIdx.x*DX + threadIdx.x;
+  const int j = g.js + blockIdx.y*DY + threadIdx.y;
+  const int m = blockIdx.z/nk;
+  const int k = g.ks + (blockIdx.z - m*nk);
+  if (i > g.ie + (DIR == 0) || j > g.je + (DIR == 1)) return;
+  const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  const Amb a{bview(g, bx1f, bx2f, bx3f, m), bcc0 + (size_t)m*3*cs, cs, g.dx[3*m], g.dx[3*m + 1],
+              g.dx[3*m + 2], (bool)g.multi_d, (bool)g.three_d};
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  if constexpr (DIR == 0) {
+    double *f = flx + ix5(g.nvar, N3, N2, N1 + 1, m, 4, k, j, i);
+    if (!g.multi_d) {
+      const double Bx = a.b.x1f(k,j,i);
+      const double By = 0.5*(a.cc(1,k,j,i-1) + a.cc(1,k,j,i));
+      const double Bz = 0.5*(a.cc(2,k,j,i-1) + a.cc(2,k,j,i));
+      const double Bsq = sqr(Bx) + sqr(By) + sqr(Bz);
+      const double e2_fc = eta * Bsq * a.j2(k,j,i);
+      const double e3_fc = eta * Bsq * a.j3(k,j,i);
+      *f += e2_fc*Bz - e3_fc*By;
+    } else if (!g.three_d) {
+      double Bx = a.b.x1f(k,j,i);
+      double By = 0.5*(a.cc(1,k,j,i-1) + a.cc(1,k,j,i));
+      double Bz = 0.5*(a.cc(2,k,j,i-1) + a.cc(2,k,j,i));
+      const double e2_fc = eta * (sqr(Bx) + sqr(By) + sqr(Bz)) * a.j2(k,j,i);
+      Bx = 0.5*(a.b.x1f(k,j,i) + a.b.x1f(k,j-1,i));
+      By = 0.5*(a.b.x2f(k,j,i) + a.b.x2f(k,j,i-1));
+      Bz = 0.25*(a.cc(2,k,j,i) + a.cc(2,k,j-1,i) + a.cc(2,k,j,i-1) + a.cc(2,k,j-1,i-1));
+      const double e3_j = eta * (sqr(Bx) + sqr(By) + sqr(Bz)) * a.j3(k,j,i);
+      Bx = 0.5*(a.b.x1f(k,j+1,i) + a.b.x1f(k,j,i));
+      By = 0.5*(a.b.x2f(k,j+1,i) + a.b.x2f(k,j+1,i-1));
+      Bz = 0.25*(a.cc(2,k,j+1,i) + a.cc(2,k,j,i) + a.cc(2,k,j+1,i-1) + a.cc(2,k,j,i-1));
+      const double e3_jp1 = eta * (sqr(Bx) + sqr(By) + sqr(Bz)) * a.j3(k,j+1,i);
+      const double e3_fc = 0.5*(e3_j + e3_jp1);
+      const double b2_fc = 0.5*(a.cc(1,k,j,i-1) + a.cc(1,k,j,i));
+      const double b3_fc = 0.5*(a.cc(2,k,j,i-1) + a.cc(2,k,j,i));
+      *f += e2_fc*b3_fc - e3_fc*b2_fc;
+    } else {
+      const double e2_fc = 0.5*(amb_e2(a, eta, k, j, i) + amb_e2(a, eta, k + 1, j, i));
+      const double e3_fc = 0.5*(amb_e3(a, eta, k, j, i) + amb_e3(a, eta, k, j + 1, i));
+      const double b2_fc = 0.5*(a.cc(1,k,j,i-1) + a.cc(1,k,j,i));
+      const double b3_fc = 0.5*(a.cc(2,k,j,i-1) + a.cc(2,k,j,i));
+      *f += e2_fc*b3_fc - e3_fc*b2_fc;
+    }
+  } else if constexpr (DIR == 1) {
+    double *f = flx + ix5(g.nvar, N3, N2 + 1, N1, m, 4, k, j, i);
+    if (!g.three_d) {
+      double Bx = 0.5*(a.b.x1f(k,j,i) + a.b.x1f(k,j-1,i));
+      double By = 0.5*(a.b.x2f(k,j,i) + a.b.x2f(k,j,i-1));
+      double Bz = 0.25*(a.cc(2,k,j,i) + a.cc(2,k,j-1,i) + a.cc(2,k,j,i-1) + a.cc(2,k,j-1,i-1));
+      const double e3_i = eta * (sqr(Bx) + sqr(By) + sqr(Bz)) * a.j3(k,j,i);
+      Bx = 0.5*(a.b.x1f(k,j,i+1) + a.b.x1f(k,j-1,i+1));
+      By = 0.5*(a.b.x2f(k,j,i+1) + a.b.x2f(k,j,i));
+      Bz = 0.25*(a.cc(2,k,j,i+1) + a.cc(2,k,j-1,i+1) + a.cc(2,k,j,i) + a.cc(2,k,j-1,i));
+      const double e3_ip1 = eta * (sqr(Bx) + sqr(By) + sqr(Bz)) * a.j3(k,j,i+1);
+      const double e3_fc = 0.5*(e3_i + e3_ip1);
+      Bx = 0.5*(a.cc(0,k,j,i) + a.cc(0,k,j-1,i));
+      By = a.b.x2f(k,j,i);
+      Bz = 0.5*(a.cc(2,k,j,i) + a.cc(2,k,j-1,i));
+      const double e1_fc = eta * (sqr(Bx) + sqr(By) + sqr(Bz)) * a.j1(k,j,i);
+      const double b1_fc = 0.5*(a.cc(0,k,j-1,i) + a.cc(0,k,j,i));
+      const double b3_fc = 0.5*(a.cc(2,k,j-1,i) + a.cc(2,k,j,i));
+      *f += e3_fc*b1_fc - e1_fc*b3_fc;
+    } else {
+      const double e3_fc = 0.5*(amb_e3(a, eta, k, j, i) + amb_e3(a, eta, k, j, i + 1));
+      const double e1_fc = 0.5*(amb_e1(a, eta, k, j, i) + amb_e1(a, eta, k + 1, j, i));
+      const double b1_fc = 0.5*(a.cc(0,k,j-1,i) + a.cc(0,k,j,i));
+      const double b3_fc = 0.5*(a.cc(2,k,j-1,i) + a.cc(2,k,j,i));
+      *f += e3_fc*b1_fc - e1_fc*b3_fc;
+    }
+  } else {
+    double *f = flx + ix5(g.nvar, N3 + 1, N2, N1, m, 4, k, j, i);
+    const double e1_fc = 0.5*(amb_e1(a, eta, k, j, i) + amb_e1(a, eta, k, j + 1, i));
+    const double e2_fc = 0.5*(amb_e2(a, eta, k, j, i) + amb_e2(a, eta, k, j, i + 1));
+    const double b1_fc = 0.5*(a.cc(0,k-1,j,i) + a.cc(0,k,j,i));
+    const double b2_fc = 0.5*(a.cc(1,k-1,j,i) + a.cc(1,k,j,i));
+    *f += e1_fc*b2_fc - e2_fc*b1_fc;
+  }
+}
+
 // Resistivity::NewTimeStep with eta_ad != 0 (resistivity.cpp:313-345): min over the active cells of
 // SQR(dx)/(eta_ohm + eta_ad*B^2).  eta is a monotone function of the rounded B^2 sum, SQR(dx)/eta a
 // monotone function of eta: reduce max(B^2) per workgroup, evaluate once.
@@ -516,6 +621,30 @@ int akmi_ambipolar_emfs(const akmi_pack *p, double eta_ad, const double *bcc0, c
   dim3 grid(cdiv(g.nx1 + 1, DX), cdiv(g.multi_d ? g.nx2 + 1 : 1, DY), nk*g.nmb), block(DX, DY);
   k_amb_emf<<<grid, block, 0, (hipStream_t)stream>>>(g, eta_ad, bcc0, bx1f, bx2f, bx3f, e1, e2, e3, nk);
   AKMI_CHECK_LAUNCH("ambipolar_emfs");
+  return AKMI_COMPLETE;
+}
+
+int akmi_ambipolar_fluxes(const akmi_pack *p, double eta_ad, const double *bcc0, const double *bx1f,
+                          const double *bx2f, const double *bx3f, double *flx1, double *flx2,
+                          double *flx3, void *stream) {
+  if (!p->is_ideal) {
+    set_error("ambipolar_fluxes: needs the ideal gas EOS"); return AKMI_FAIL;
+  }
+  Geo g = make_geo(p);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 block(DX, DY);
+  int nk;
+  dim3 g0 = face_grid(g, 0, nk);
+  k_amb_flux<0><<<g0, block, 0, st>>>(g, eta_ad, bcc0, bx1f, bx2f, bx3f, flx1, nk);
+  if (g.multi_d) {
+    dim3 g1 = face_grid(g, 1, nk);
+    k_amb_flux<1><<<g1, block, 0, st>>>(g, eta_ad, bcc0, bx1f, bx2f, bx3f, flx2, nk);
+  }
+  if (g.three_d) {
+    dim3 g2 = face_grid(g, 2, nk);
+    k_amb_flux<2><<<g2, block, 0, st>>>(g, eta_ad, bcc0, bx1f, bx2f, bx3f, flx3, nk);
+  }
+  AKMI_CHECK_LAUNCH("ambipolar_fluxes");
   return AKMI_COMPLETE;
 }
 

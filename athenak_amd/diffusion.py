@@ -96,9 +96,6 @@ class Resistivity(_Diffusion):
         super().__init__(phys)
         self.eta_ohm = pin.GetOrAddReal("mhd", "eta_ohm", 0.0)
         self.eta_ad = pin.GetOrAddReal("mhd", "eta_ad", 0.0)
-        if self.eta_ad != 0.0 and phys.peos.eos_data.is_ideal:
-            raise RuntimeError("### FATAL ERROR <mhd>/eta_ad with the ideal-gas EOS (ambipolar heating "
-                               "flux) is not on this path; isothermal MHD only")
         self.dtmin = torch.zeros(1, dtype=torch.float64, device=phys.device)
 
     def AddResistiveEMFs(self, b0, efld):
@@ -119,6 +116,11 @@ class Resistivity(_Diffusion):
                 C.byref(self.phys.pack_c), C.c_double(self.eta_ohm), capi._p(b0.x1f), capi._p(b0.x2f),
                 capi._p(b0.x3f), capi._p(flx.x1f), capi._p(flx.x2f), capi._p(flx.x3f),
                 capi._stream()), "resistive_fluxes")
+        if self.eta_ad != 0.0:                                   # resistivity.cpp:67-69
+            capi.check(self.L.akmi_ambipolar_fluxes(
+                C.byref(self.phys.pack_c), C.c_double(self.eta_ad), capi._p(self.phys.bcc0),
+                capi._p(b0.x1f), capi._p(b0.x2f), capi._p(b0.x3f), capi._p(flx.x1f), capi._p(flx.x2f),
+                capi._p(flx.x3f), capi._stream()), "ambipolar_fluxes")
 
     def NewTimeStep(self):
         if self.eta_ad == 0.0:                                   # resistivity.cpp:298-311

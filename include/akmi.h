@@ -128,11 +128,15 @@ int akmi_resistive_emfs(const akmi_pack *p, double eta_ohm, const double *bx1f, 
 int akmi_resistive_fluxes(const akmi_pack *p, double eta_ohm, const double *bx1f, const double *bx2f,
                           const double *bx3f, double *flx1, double *flx2, double *flx3, void *stream);
 /* Resistivity::AddEMFConstantAmbipolar (src/diffusion/ambipolar.cpp:66-246): efld += eta_ad*(B^2 J -
- * (J.B) B) with J (EdgeJ1/2/3) and B (faces, bcc0) averaged to each edge.  The ambipolar energy flux
- * (AddFluxConstantAmbipolar) is not in this library: isothermal MHD only. */
+ * (J.B) B) with J (EdgeJ1/2/3) and B (faces, bcc0) averaged to each edge. */
 int akmi_ambipolar_emfs(const akmi_pack *p, double eta_ad, const double *bcc0, const double *bx1f,
                         const double *bx2f, const double *bx3f, double *e1, double *e2, double *e3,
                         void *stream);
+/* Resistivity::AddFluxConstantAmbipolar (src/diffusion/ambipolar.cpp:254-494): Poynting flux of the
+ * ambipolar field added to the energy component of the face-shaped MHD fluxes (ideal gas) */
+int akmi_ambipolar_fluxes(const akmi_pack *p, double eta_ad, const double *bcc0, const double *bx1f,
+                          const double *bx2f, const double *bx3f, double *flx1, double *flx2,
+                          double *flx3, void *stream);
 /* Resistivity::NewTimeStep with eta_ad != 0 (src/diffusion/resistivity.cpp:313-345): *dtmin (device) =
  * min over the active cells of SQR(dx)/(eta_ohm + eta_ad*B^2); the caller multiplies by fac */
 int akmi_resistive_newdt(const akmi_pack *p, double eta_ohm, double eta_ad, const double *bcc0,

@@ -71,6 +71,9 @@ int akref_prolong_fc_shared(const akmi_pack *p, int comp, const int box[6], cons
 int akref_prolong_fc_internal(const akmi_pack *p, const int box[6], double *b1, double *b2, double *b3);
 int akref_ambipolar_emfs(const akmi_pack *p, double eta_ad, const double *bcc0, const double *bx1f,
                          const double *bx2f, const double *bx3f, double *e1, double *e2, double *e3);
+int akref_ambipolar_fluxes(const akmi_pack *p, double eta_ad, const double *bcc0, const double *bx1f,
+                           const double *bx2f, const double *bx3f, double *flx1, double *flx2,
+                           double *flx3);
 int akref_resistive_newdt(const akmi_pack *p, double eta_ohm, double eta_ad, const double *bcc0,
                           double *dtmin);
 int akref_rk4_copy_cons(const akmi_pack *p, double delta, const double *u0, double *u1);

@@ -3095,6 +3095,131 @@ int akref_ambipolar_emfs(const akmi_pack *p, double eta, const double *bcc0, con
   return 0;
 }
 
+/* Resistivity::AddFluxConstantAmbipolar, src/diffusion/ambipolar.cpp:254-494: Poynting flux of the
+ * ambipolar field, E_amb ~ eta_ad*B^2*J on the edges around a face, added to the energy flux */
+int akref_ambipolar_fluxes(const akmi_pack *p, double eta, const double *bcc0, const double *bx1f,
+                           const double *bx2f, const double *bx3f, double *flx1, double *flx2,
+                           double *flx3) {
+  G g = mkG(p);
+  if (!p->is_ideal) return AKMI_FAIL;
+  const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  const int is = g.is, ie = g.ie, js = g.js, je = g.je, ks = g.ks, ke = g.ke;
+#define J1(k,j,i) edge_j1(&g, bx2f, bx3f, N1, N2, N3, m, k, j, i, dx2, dx3)
+#define J2(k,j,i) edge_j2(&g, bx1f, bx3f, N1, N2, N3, m, k, j, i, dx1, dx3)
+#define J3(k,j,i) edge_j3(&g, bx1f, bx2f, N1, N2, N3, m, k, j, i, dx1, dx2)
+#define F1E(k,j,i) flx1[ix5(nv,N3,N2,N1+1,m,IEN,k,j,i)]
+#define F2E(k,j,i) flx2[ix5(nv,N3,N2+1,N1,m,IEN,k,j,i)]
+#define F3E(k,j,i) flx3[ix5(nv,N3+1,N2,N1,m,IEN,k,j,i)]
+  for (int m = 0; m < g.nmb; ++m) {
+    const double dx1 = p->dx[3*m], dx2 = p->dx[3*m+1], dx3 = p->dx[3*m+2];
+    double Bx, By, Bz;
+    if (!g.multi_d) {
+      for (int i = is; i <= ie+1; ++i) {
+        Bx = AB1(ks,js,i);
+        By = 0.5*(ABC(1,ks,js,i-1) + ABC(1,ks,js,i));
+        Bz = 0.5*(ABC(2,ks,js,i-1) + ABC(2,ks,js,i));
+        double Bsq = SQR(Bx) + SQR(By) + SQR(Bz);
+        double e2_fc = eta * Bsq * J2(ks,js,i);
+        double e3_fc = eta * Bsq * J3(ks,js,i);
+        F1E(ks,js,i) += e2_fc*Bz - e3_fc*By;
+      }
+      continue;
+    }
+    if (!g.three_d) {
+      for (int j = js; j <= je; ++j) for (int i = is; i <= ie+1; ++i) {
+        Bx = AB1(ks,j,i);
+        By = 0.5*(ABC(1,ks,j,i-1) + ABC(1,ks,j,i));
+        Bz = 0.5*(ABC(2,ks,j,i-1) + ABC(2,ks,j,i));
+        double e2_fc = eta * (SQR(Bx) + SQR(By) + SQR(Bz)) * J2(ks,j,i);
+        Bx = 0.5*(AB1(ks,j,i) + AB1(ks,j-1,i));
+        By = 0.5*(AB2(ks,j,i) + AB2(ks,j,i-1));
+        Bz = 0.25*(ABC(2,ks,j,i) + ABC(2,ks,j-1,i) + ABC(2,ks,j,i-1) + ABC(2,ks,j-1,i-1));
+        double e3_j = eta * (SQR(Bx) + SQR(By) + SQR(Bz)) * J3(ks,j,i);
+        Bx = 0.5*(AB1(ks,j+1,i) + AB1(ks,j,i));
+        By = 0.5*(AB2(ks,j+1,i) + AB2(ks,j+1,i-1));
+        Bz = 0.25*(ABC(2,ks,j+1,i) + ABC(2,ks,j,i) + ABC(2,ks,j+1,i-1) + ABC(2,ks,j,i-1));
+        double e3_jp1 = eta * (SQR(Bx) + SQR(By) + SQR(Bz)) * J3(ks,j+1,i);
+        double e3_fc = 0.5*(e3_j + e3_jp1);
+        double b2_fc = 0.5*(ABC(1,ks,j,i-1) + ABC(1,ks,j,i));
+        double b3_fc = 0.5*(ABC(2,ks,j,i-1) + ABC(2,ks,j,i));
+        F1E(ks,j,i) += e2_fc*b3_fc - e3_fc*b2_fc;
+      }
+      for (int j = js; j <= je+1; ++j) for (int i = is; i <= ie; ++i) {
+        Bx = 0.5*(AB1(ks,j,i) + AB1(ks,j-1,i));
+        By = 0.5*(AB2(ks,j,i) + AB2(ks,j,i-1));
+        Bz = 0.25*(ABC(2,ks,j,i) + ABC(2,ks,j-1,i) + ABC(2,ks,j,i-1) + ABC(2,ks,j-1,i-1));
+        double e3_i = eta * (SQR(Bx) + SQR(By) + SQR(Bz)) * J3(ks,j,i);
+        Bx = 0.5*(AB1(ks,j,i+1) + AB1(ks,j-1,i+1));
+        By = 0.5*(AB2(ks,j,i+1) + AB2(ks,j,i));
+        Bz = 0.25*(ABC(2,ks,j,i+1) + ABC(2,ks,j-1,i+1) + ABC(2,ks,j,i) + ABC(2,ks,j-1,i));
+        double e3_ip1 = eta * (SQR(Bx) + SQR(By) + SQR(Bz)) * J3(ks,j,i+1);
+        double e3_fc = 0.5*(e3_i + e3_ip1);
+        Bx = 0.5*(ABC(0,ks,j,i) + ABC(0,ks,j-1,i));
+        By = AB2(ks,j,i);
+        Bz = 0.5*(ABC(2,ks,j,i) + ABC(2,ks,j-1,i));
+        double e1_fc = eta * (SQR(Bx) + SQR(By) + SQR(Bz)) * J1(ks,j,i);
+        double b1_fc = 0.5*(ABC(0,ks,j-1,i) + ABC(0,ks,j,i));
+        double b3_fc = 0.5*(ABC(2,ks,j-1,i) + ABC(2,ks,j,i));
+        F2E(ks,j,i) += e3_fc*b1_fc - e1_fc*b3_fc;
+      }
+      continue;
+    }
+    /* 3-D: edge fields eta*B^2*J with B averaged to the edge as in the EMF routine */
+#define E1EDGE(k,j,i) (Bx = 0.25*(ABC(0,k,j,i) + ABC(0,(k)-1,j,i) + ABC(0,k,(j)-1,i) + ABC(0,(k)-1,(j)-1,i)), \
+                       By = 0.5*(AB2(k,j,i) + AB2((k)-1,j,i)), Bz = 0.5*(AB3(k,j,i) + AB3(k,(j)-1,i)), \
+                       eta * (SQR(Bx) + SQR(By) + SQR(Bz)) * J1(k,j,i))
+#define E2EDGE(k,j,i) (Bx = 0.5*(AB1(k,j,i) + AB1((k)-1,j,i)), \
+                       By = 0.25*(ABC(1,k,j,i) + ABC(1,(k)-1,j,i) + ABC(1,k,j,(i)-1) + ABC(1,(k)-1,j,(i)-1)), \
+                       Bz = 0.5*(AB3(k,j,i) + AB3(k,j,(i)-1)), eta * (SQR(Bx) + SQR(By) + SQR(Bz)) * J2(k,j,i))
+#define E3EDGE(k,j,i) (Bx = 0.5*(AB1(k,j,i) + AB1(k,(j)-1,i)), By = 0.5*(AB2(k,j,i) + AB2(k,j,(i)-1)), \
+                       Bz = 0.25*(ABC(2,k,j,i) + ABC(2,k,(j)-1,i) + ABC(2,k,j,(i)-1) + ABC(2,k,(j)-1,(i)-1)), \
+                       eta * (SQR(Bx) + SQR(By) + SQR(Bz)) * J3(k,j,i))
+    for (int k = ks; k <= ke; ++k) for (int j = js; j <= je; ++j) for (int i = is; i <= ie+1; ++i) {
+      double e2_k = E2EDGE(k,j,i);
+      double e2_kp1 = E2EDGE(k+1,j,i);
+      double e2_fc = 0.5*(e2_k + e2_kp1);
+      double e3_j = E3EDGE(k,j,i);
+      double e3_jp1 = E3EDGE(k,j+1,i);
+      double e3_fc = 0.5*(e3_j + e3_jp1);
+      double b2_fc = 0.5*(ABC(1,k,j,i-1) + ABC(1,k,j,i));
+      double b3_fc = 0.5*(ABC(2,k,j,i-1) + ABC(2,k,j,i));
+      F1E(k,j,i) += e2_fc*b3_fc - e3_fc*b2_fc;
+    }
+    for (int k = ks; k <= ke; ++k) for (int j = js; j <= je+1; ++j) for (int i = is; i <= ie; ++i) {
+      double e3_i = E3EDGE(k,j,i);
+      double e3_ip1 = E3EDGE(k,j,i+1);
+      double e3_fc = 0.5*(e3_i + e3_ip1);
+      double e1_k = E1EDGE(k,j,i);
+      double e1_kp1 = E1EDGE(k+1,j,i);
+      double e1_fc = 0.5*(e1_k + e1_kp1);
+      double b1_fc = 0.5*(ABC(0,k,j-1,i) + ABC(0,k,j,i));
+      double b3_fc = 0.5*(ABC(2,k,j-1,i) + ABC(2,k,j,i));
+      F2E(k,j,i) += e3_fc*b1_fc - e1_fc*b3_fc;
+    }
+    for (int k = ks; k <= ke+1; ++k) for (int j = js; j <= je; ++j) for (int i = is; i <= ie; ++i) {
+      double e1_j = E1EDGE(k,j,i);
+      double e1_jp1 = E1EDGE(k,j+1,i);
+      double e1_fc = 0.5*(e1_j + e1_jp1);
+      double e2_i = E2EDGE(k,j,i);
+      double e2_ip1 = E2EDGE(k,j,i+1);
+      double e2_fc = 0.5*(e2_i + e2_ip1);
+      double b1_fc = 0.5*(ABC(0,k-1,j,i) + ABC(0,k,j,i));
+      double b2_fc = 0.5*(ABC(1,k-1,j,i) + ABC(1,k,j,i));
+      F3E(k,j,i) += e1_fc*b2_fc - e2_fc*b1_fc;
+    }
+#undef E1EDGE
+#undef E2EDGE
+#undef E3EDGE
+  }
+#undef J1
+#undef J2
+#undef J3
+#undef F1E
+#undef F2E
+#undef F3E
+  return 0;
+}
+
 /* Resistivity::NewTimeStep with eta_ad != 0, src/diffusion/resistivity.cpp:313-345: the cell reduction
  * min SQR(dx)/(eta_ohm + eta_ad*B^2) (before *fac) */
 int akref_resistive_newdt(const akmi_pack *p, double eta_o, double eta_a, const double *bcc0,

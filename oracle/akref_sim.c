@@ -93,7 +93,7 @@ akref_sim *akref_create(const akref_params *par) {
   if (s->nb1*p->mb_nx1 != p->nx1 || s->nb2*p->mb_nx2 != p->nx2 || s->nb3*p->mb_nx3 != p->nx3) {
     free(s); return NULL;
   }
-  if (p->eta_ad != 0.0 && (!p->is_mhd || p->is_ideal)) {   /* the ambipolar energy flux is not restated */
+  if (p->eta_ad != 0.0 && !p->is_mhd) {
     free(s); return NULL;
   }
   /* rsolver = advect only for kinematic problems and vice versa (hydro.cpp:244-278, mhd.cpp:292-326) */
@@ -827,6 +827,8 @@ int akref_step(akref_sim *s) {
       if (p->nu_iso != 0.0) akref_viscous_fluxes(pk, p->nu_iso, s->w0, s->flx1, s->flx2, s->flx3, 1);
       if (p->eta_ohm != 0.0 && p->is_ideal)
         akref_resistive_fluxes(pk, p->eta_ohm, s->b0[0], s->b0[1], s->b0[2], s->flx1, s->flx2, s->flx3);
+      if (p->eta_ad != 0.0 && p->is_ideal)                       /* resistivity.cpp:67-69 */
+        akref_ambipolar_fluxes(pk, p->eta_ad, s->bcc0, s->b0[0], s->b0[1], s->b0[2], s->flx1, s->flx2, s->flx3);
       if (p->fofc) {               /* mhd_tasks.cpp:209-211 */
         akref_mhd_fofc(pk, gam0, gam1, beta_dt, s->w0, s->bcc0, s->b0[0], s->b0[1], s->b0[2],
                        s->b1[0], s->b1[1], s->b1[2], s->u0, s->u1, s->flx1, s->flx2, s->flx3,

@@ -178,6 +178,11 @@ DIFFUSION = [
      dict(eta_ad=0.01)),
     ("linear_wave_mhd", 24, 3, (12, 24, 8), 4, dict(rsolver="llf", extra=("mhd/eos=isothermal", "problem/amp=0.1")),
      dict(eta_ad=0.02)),
+    # ideal gas: + the ambipolar Poynting flux in the energy equation
+    ("linear_wave_mhd", 64, 1, 32, 8, dict(rsolver="hlld", extra=("problem/amp=1.0e-2",)), dict(eta_ad=0.01)),
+    ("orszag_tang", 32, 2, 16, 6, dict(rsolver="hlld"), dict(eta_ad=0.01, eta_ohm=0.002)),
+    ("orszag_tang", 24, 3, 12, 4, dict(rsolver="hlle", cfl=0.3), dict(eta_ad=0.01)),
+    ("blast", 24, 3, (12, 24, 8), 4, dict(rsolver="hlld"), dict(eta_ad=0.002, nu_iso=0.001)),
 ]
 
 
