@@ -49,7 +49,8 @@ def main(argv=None):
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group(os.environ.get("AKMI_DIST_BACKEND", "nccl"))
     if rstfile is not None:
         sim = load_restart(rstfile, overrides, my_rank=rank, nranks=world, initialize=False)
