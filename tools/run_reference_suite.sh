@@ -26,6 +26,10 @@ import test_suite.testutils  # noqa: F401  (resolves ../vis/python relative to t
 tests = [os.path.abspath("test_suite/nr/test_nr_%s_cpu.py" % t) for t in ("lwave1d", "isolwave1d", "sod", "rj2a")]
 # kinematic Gaussian-pulse diffusion regressions (viscosity 1-D, conduction 1-D and 2-D)
 tests += [os.path.abspath("test_suite/diffusion/test_diffusion_%s_cpu.py" % t) for t in ("visc", "conduct", "resist", "ambipolar_linwave")]
+# AKMI_SUITE_PLANES=1: also the scripts the reference runs on its GPU CI machine (xy/yz/zx planes embedded in 3-D,
+# 3-D ambipolar wave); they drive the same executable, +30 min with the CPU backend
+if os.environ.get("AKMI_SUITE_PLANES"):
+    tests += [os.path.abspath("test_suite/diffusion/test_diffusion_%s_gpu.py" % t) for t in ("visc", "conduct", "resist", "ambipolar_linwave")]
 os.chdir("build/src")
 args = tests + ["-p", "no:cacheprovider", "-q"] + ([] if os.environ.get("AKMI_SUITE_KEEP_GOING") else ["-x"])
 if len(sys.argv) > 1:
