@@ -266,6 +266,42 @@ constexpr int ML = AKMI_ML;            // faces marched per thread (chunk length
 // marches (more, smaller chunks; one face per chunk is recomputed) for small packs, which would
 // otherwise leave most of the 256 CUs idle behind a few long serial chains.  Results do not
 // depend on the chunking.
+// Tile shape of k_corner_ct for e1 x e2 edge positions, among the shapes of at most 512 threads:
+// lanes launched (tiles x padded workgroup size), weighted by what the scan in
+// profiles/r01_v12_ct_tiles.txt shows -- short rows cost coalescing (~ 1 + 20/tw per lane), few
+// rows re-read the j-1 neighbours more often (~ 1 + 0.6/(th-1)), and a workgroup of 7 waves leaves
+// 2 of the 16 wave slots of a CU empty (106 VGPRs: 4 waves per SIMD).
+struct CtTile { int tw, th, n1, n2, threads; };
+static CtTile ct_tile(int e1, int e2) {
+  static int f_tw = -1, f_th = 0;
+  if (f_tw < 0) {                                    // AKMI_CT_TILE=tw,th pins the shape (experiments)
+    const char *e = getenv("AKMI_CT_TILE");
+    f_tw = 0;
+    if (e && sscanf(e, "%d,%d", &f_tw, &f_th) != 2) f_tw = 0;
+  }
+  CtTile best{0, 0, 0, 0, 0};
+  double best_cost = -1.0;
+  for (int n1 = 1; n1 <= e1; ++n1) {
+    const int tw = (e1 + n1 - 1)/n1 + 1;
+    if (tw > 130) continue;
+    if (tw < 18 && n1 > 1) break;
+    for (int th = 3; th <= 32; ++th) {
+      if (tw*th > 512) break;
+      if (f_tw > 0 && (tw != f_tw || th != f_th)) continue;
+      const int n2 = (e2 + th - 2)/(th - 1);
+      const int threads = (tw*th + 63)/64*64;
+      const int waves = threads/64;
+      const double cost = (double)n1*n2*threads*(6.3 + 130.0/tw)*(1.0 + 0.6/(th - 1))*16.0/(16/waves*waves);
+      if (best_cost < 0 || cost < best_cost) { best = CtTile{tw, th, n1, n2, threads}; best_cost = cost; }
+    }
+  }
+  if (best_cost < 0) {                               // pinned shape not among the candidates
+    const int tw = f_tw, th = f_th;
+    best = CtTile{tw, th, (e1 + tw - 2)/(tw - 1), (e2 + th - 2)/(th - 1), (tw*th + 63)/64*64};
+  }
+  return best;
+}
+
 static int march_len(long col_blocks, int ncells, int nmb, int lmax) {
   const long want = 2048;                       // workgroups per launch (scan: profiles/r01_small_packs.txt)
   long ml = col_blocks*(long)ncells*nmb/want;
@@ -530,16 +566,17 @@ __device__ __forceinline__ double upw(bool pos, double fa, double ca, double fb,
 // loads per corner).  Every face is read and written by exactly one thread (the overlap
 // column/row only computes edges), so the in-place update of b0 has no cross-workgroup hazard.
 // Arithmetic: the expressions of akmi_mhd_corner_e (akmi_tasks.hip) and k_ct_copy, unchanged.
-#ifndef AKMI_CJ
-#define AKMI_CJ 8
-#endif
 #ifndef AKMI_CKL
 #define AKMI_CKL 32
 #endif
-constexpr int CI = 64, CJ = AKMI_CJ;   // tile of edge positions (threads); owners: (CI-1) x (CJ-1)
 constexpr int CKL = AKMI_CKL;          // cell planes per k-chunk (one plane of edges recomputed)
+constexpr int CT_THREADS = 512;        // 8 waves: two workgroups per CU hide each other's barriers
 
-__global__ void __launch_bounds__(CI*CJ)
+// The tile of edge positions is tw x th threads (owners: (tw-1) x (th-1)), lanes flattened over
+// (ty, tx); the launcher picks the shape that wastes the fewest lanes for the block size (a 64-wide
+// tile needs two columns of tiles for the 65 edge columns of a 64^3 MeshBlock, a 34 x 15 tile does
+// 33 / 65 / 257 columns in 1 / 2 / 8).
+__global__ void __launch_bounds__(CT_THREADS)
 k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e2x1,
             const double *__restrict__ e1x2, const double *__restrict__ e3x2,
             const double *__restrict__ e2x3, const double *__restrict__ e1x3,
@@ -549,18 +586,23 @@ k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e
             double gam1, double beta_dt, double *__restrict__ b0x1f, double *__restrict__ b0x2f,
             double *__restrict__ b0x3f, double *__restrict__ b1x1f, double *__restrict__ b1x2f,
             double *__restrict__ b1x3f, int copy_b1, int kA, int kB, int top, int nchunk,
-            int ckl) {
-  __shared__ double s1[2][CJ][CI], s2[2][CJ][CI], s3[3][CJ][CI];
-  const int tx = threadIdx.x, ty = threadIdx.y;
-  const int i = g.is + blockIdx.x*(CI - 1) + tx;
-  const int j = g.js + blockIdx.y*(CJ - 1) + ty;
+            int ckl, int tw, int th) {
+  extern __shared__ double ct_lds[];     // e1, e2: 2 planes each, e3: 3 planes of th x tw
+  const int plane = tw*th;
+#define S1(p, y, x) ct_lds[(p)*plane + (y)*tw + (x)]
+#define S2(p, y, x) ct_lds[(2 + (p))*plane + (y)*tw + (x)]
+#define S3(p, y, x) ct_lds[(4 + (p))*plane + (y)*tw + (x)]
+  const int ty = threadIdx.x/tw, tx = threadIdx.x - ty*tw;
+  const bool in_tile = ty < th;          // the workgroup is padded to whole waves
+  const int i = g.is + blockIdx.x*(tw - 1) + tx;
+  const int j = g.js + blockIdx.y*(th - 1) + ty;
   const int m = blockIdx.z/nchunk;
   const int ch = blockIdx.z - m*nchunk;
   const int k0 = kA + ch*ckl;                                   // first cell plane of this chunk
   const int k1 = (k0 + ckl - 1 < kB) ? k0 + ckl - 1 : kB;       // last cell plane
   const bool wtop = top && (k1 == kB);                          // this chunk owns the x3-faces kB+1
-  const bool edge_ok = (i <= g.ie + 1) && (j <= g.je + 1);
-  const bool own = edge_ok && (tx < CI - 1) && (ty < CJ - 1);
+  const bool edge_ok = in_tile && (i <= g.ie + 1) && (j <= g.je + 1);
+  const bool own = edge_ok && (tx < tw - 1) && (ty < th - 1);
   const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
   double e1p = 0.0, e2p = 0.0, e3p = 0.0;                       // own edges of the previous plane
   // operands of the corner formulas that belong to plane k-1 (rolled from step to step)
@@ -620,7 +662,7 @@ k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e
       f1_km = f1_k; f2_km = f2_k; x2_km = x2_k; x1_km = x1_k;
       c1_mm = c1_0m; c1_m0 = c1_00; c2_mm = c2_0m; c2_m0 = c2_00;
     }
-    s1[p2][ty][tx] = e1; s2[p2][ty][tx] = e2; s3[p3][ty][tx] = e3;
+    if (in_tile) { S1(p2, ty, tx) = e1; S2(p2, ty, tx) = e2; S3(p3, ty, tx) = e3; }
     __syncthreads();
     if (own) {
       if (i <= g.ie && j <= g.je && (k <= k1 || wtop)) {          // x3-face of plane k (mhd_ct.cpp:67-77)
@@ -628,8 +670,8 @@ k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e
         const double b0v = b0x3f[c];
         const double b1v = copy_b1 ? b0v : b1x3f[c];
         double b = gam0*b0v + gam1*b1v;
-        b -= beta_dt*(s2[p2][ty][tx + 1] - e2)/dx1;
-        b += beta_dt*(s1[p2][ty + 1][tx] - e1)/dx2;
+        b -= beta_dt*(S2(p2, ty, tx + 1) - e2)/dx1;
+        b += beta_dt*(S1(p2, ty + 1, tx) - e1)/dx2;
         b0x3f[c] = b;
         if (copy_b1) b1x3f[c] = b0v;
       }
@@ -640,7 +682,7 @@ k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e
           const double b0v = b0x1f[c];
           const double b1v = copy_b1 ? b0v : b1x1f[c];
           double b = gam0*b0v + gam1*b1v;
-          b -= beta_dt*(s3[q3][ty + 1][tx] - e3p)/dx2;
+          b -= beta_dt*(S3(q3, ty + 1, tx) - e3p)/dx2;
           b += beta_dt*(e2 - e2p)/dx3;
           b0x1f[c] = b;
           if (copy_b1) b1x1f[c] = b0v;
@@ -650,7 +692,7 @@ k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e
           const double b0v = b0x2f[c];
           const double b1v = copy_b1 ? b0v : b1x2f[c];
           double b = gam0*b0v + gam1*b1v;
-          b += beta_dt*(s3[q3][ty][tx + 1] - e3p)/dx1;
+          b += beta_dt*(S3(q3, ty, tx + 1) - e3p)/dx1;
           b -= beta_dt*(e1 - e1p)/dx3;
           b0x2f[c] = b;
           if (copy_b1) b1x2f[c] = b0v;
@@ -1072,14 +1114,14 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
   auto ct = [&](int s) -> int {
     // CornerE + CT of slab s in one kernel (corner EMFs of the planes [kA, kB+1] stay on chip)
     const int top = (s == S - 1) ? 1 : 0;
-    const int ckl = march_len((long)cdiv(g.nx1 + 1, CI - 1)*cdiv(g.nx2 + 1, CJ - 1),
-                              kB(s) - kA(s) + 1, g.nmb, CKL);
+    const CtTile tl = ct_tile(g.nx1 + 1, g.nx2 + 1);
+    const int ckl = march_len((long)tl.n1*tl.n2, kB(s) - kA(s) + 1, g.nmb, CKL);
     const int nchunk = cdiv(kB(s) - kA(s) + 1, ckl);
-    dim3 grid(cdiv(g.nx1 + 1, CI - 1), cdiv(g.nx2 + 1, CJ - 1), nchunk*g.nmb), block(CI, CJ);
-    k_corner_ct<<<grid, block, 0, sb>>>(g, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5],
-                                        w.ecc[0], w.ecc[1], w.ecc[2], w.flx1, w.flx2, w.flx3, gam0,
-                                        gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f,
-                                        copy_u1, kA(s), kB(s), top, nchunk, ckl);
+    dim3 grid(tl.n1, tl.n2, nchunk*g.nmb), block(tl.threads);
+    k_corner_ct<<<grid, block, 7*tl.tw*tl.th*sizeof(double), sb>>>(
+        g, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5], w.ecc[0], w.ecc[1], w.ecc[2],
+        w.flx1, w.flx2, w.flx3, gam0, gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f,
+        copy_u1, kA(s), kB(s), top, nchunk, ckl, tl.tw, tl.th);
     AKMI_CHECK_LAUNCH("corner_ct");
     return AKMI_COMPLETE;
   };

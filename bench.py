@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nx", type=int, default=256, help="cells per GPU per dimension")
+    ap.add_argument("--mb", type=int, default=0,
+                    help="MeshBlock size per dimension (default: --nx, one MeshBlock per GPU); "
+                         "smaller blocks put (nx/mb)^3 MeshBlocks into each GPU's pack")
     ap.add_argument("--problem", default="orszag_tang", choices=["orszag_tang", "sod", "linear_wave"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-nx", type=int, default=64)
@@ -63,7 +66,7 @@ def make_pin(args, nblk):
         deck, blk = "linear_wave_hydro.athinput", "hydro"
         ov = []
     for q in range(3):
-        ov += ["mesh/nx%d=%d" % (q + 1, mesh[q]), "meshblock/nx%d=%d" % (q + 1, nx)]
+        ov += ["mesh/nx%d=%d" % (q + 1, mesh[q]), "meshblock/nx%d=%d" % (q + 1, args.mb or nx)]
     ov += ["time/nlim=-1", "time/tlim=1.0e9"]
     pin = load_deck(deck, ov)
     if args.split:
@@ -246,7 +249,8 @@ def main():
                                       "MeshBlocks, cfl 0.3, RK2, ng=2" % (
                                           args.problem, "ideal MHD PLM+HLLD+CT" if blk == "mhd" else
                                           "ideal hydro PLM+HLLC", args.nx, args.nx*nblk[0],
-                                          args.nx*nblk[1], args.nx*nblk[2], *nblk),
+                                          args.nx*nblk[1], args.nx*nblk[2],
+                                          *[b*args.nx//(args.mb or args.nx) for b in nblk]),
                           "path": "task-granular" if args.split else "fused stage",
                           "halo": "none (single periodic block: same-rank gather)" if world == 1
                           else "%s send/recv (torch.distributed), per-stage U and B messages posted "
