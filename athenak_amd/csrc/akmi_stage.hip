@@ -271,6 +271,7 @@ constexpr int ML = AKMI_ML;            // faces marched per thread (chunk length
 // profiles/r01_v12_ct_tiles.txt shows -- short rows cost coalescing (~ 1 + 20/tw per lane), few
 // rows re-read the j-1 neighbours more often (~ 1 + 0.6/(th-1)), and a workgroup of 7 waves leaves
 // 2 of the 16 wave slots of a CU empty (106 VGPRs: 4 waves per SIMD).
+constexpr int CT_THREADS = 512;        // 8 waves: two workgroups per CU hide each other's barriers
 struct CtTile { int tw, th, n1, n2, threads; };
 static CtTile ct_tile(int e1, int e2) {
   static int f_tw = -1, f_th = 0;
@@ -278,6 +279,7 @@ static CtTile ct_tile(int e1, int e2) {
     const char *e = getenv("AKMI_CT_TILE");
     f_tw = 0;
     if (e && sscanf(e, "%d,%d", &f_tw, &f_th) != 2) f_tw = 0;
+    if (f_tw < 2 || f_th < 2 || f_tw*f_th > CT_THREADS) f_tw = 0;
   }
   CtTile best{0, 0, 0, 0, 0};
   double best_cost = -1.0;
@@ -286,7 +288,7 @@ static CtTile ct_tile(int e1, int e2) {
     if (tw > 130) continue;
     if (tw < 18 && n1 > 1) break;
     for (int th = 3; th <= 32; ++th) {
-      if (tw*th > 512) break;
+      if (tw*th > CT_THREADS) break;
       if (f_tw > 0 && (tw != f_tw || th != f_th)) continue;
       const int n2 = (e2 + th - 2)/(th - 1);
       const int threads = (tw*th + 63)/64*64;
@@ -570,7 +572,6 @@ __device__ __forceinline__ double upw(bool pos, double fa, double ca, double fb,
 #define AKMI_CKL 32
 #endif
 constexpr int CKL = AKMI_CKL;          // cell planes per k-chunk (one plane of edges recomputed)
-constexpr int CT_THREADS = 512;        // 8 waves: two workgroups per CU hide each other's barriers
 
 // The tile of edge positions is tw x th threads (owners: (tw-1) x (th-1)), lanes flattened over
 // (ty, tx); the launcher picks the shape that wastes the fewest lanes for the block size (a 64-wide
@@ -838,6 +839,219 @@ k_c2p_newdt(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Hydro, 3-D, DC/PLM: the three sweeps and the RK update of a stage in ONE kernel.
+// A workgroup owns a tile of (tw-1) x (th-1) cell columns (lanes flattened over the tw x th
+// positions; the last column / row of positions only provides the face on its low side) and
+// marches along k.  Per plane k:
+//   * the plane of primitives (with a 2-low / 1-high halo in i and j) goes to LDS; the thread's
+//     own cells k-1, k, k+1 and the pending left state of the next x3 face stay in registers;
+//   * every position computes the flux of its low x1 face and of its low x2 face from LDS and the
+//     x3 face below cell k from registers; F1 and F2 are exchanged through LDS;
+//   * cell k-1 is finished: divf = dF1/dx1; divf += dF2/dx2; divf += dF3/dx3 (hydro_update.cpp:55-80
+//     order, the same rounding sequence as the three-kernel path).
+// HBM traffic per cell: w0 once (+halo, mostly L2 hits), u0 (+u1) once -- no flux or partial
+// divergence arrays.  The CT-extended ranges of MHD do not apply (faces is..ie+1 only).
+struct HydTile { int tw, th, n1, n2, threads; };
+constexpr int HS_THREADS = 512;
+#ifndef AKMI_HS_WAVES
+#define AKMI_HS_WAVES 2                 // waves per SIMD the register allocation aims at (3 and 4 spill)
+#endif
+
+static HydTile hyd_tile(int c1, int c2) {
+  // cost: lanes launched, short rows penalised like ct_tile; owners are (tw-1) x (th-1)
+  static const int maxt = getenv("AKMI_HS_MAXT") ? atoi(getenv("AKMI_HS_MAXT")) : 256;   // two workgroups per CU
+  static const int maxlds = getenv("AKMI_HS_LDS") ? atoi(getenv("AKMI_HS_LDS")) : 80*1024;       // two workgroups per CU
+  HydTile best{0, 0, 0, 0, 0};
+  double best_cost = -1.0;
+  for (int n1 = 1; n1 <= c1; ++n1) {
+    const int tw = (c1 + n1 - 1)/n1 + 1;
+    if (tw > 130) continue;
+    if (tw < 18 && n1 > 1) break;
+    for (int th = 3; th <= 32; ++th) {
+      if (tw*th > maxt) break;
+      if (3*(tw + 3) + 3*th > tw*th) continue;         // one halo entry per thread at most
+      if (2*(5*(tw + 3)*(th + 3) + 10*tw*th)*sizeof(double) > (size_t)maxlds) continue;
+      const int n2 = (c2 + th - 2)/(th - 1);
+      const int threads = (tw*th + 63)/64*64;
+      const double cost = (double)n1*n2*threads*(6.3 + 130.0/tw);
+      if (best_cost < 0 || cost < best_cost) { best = HydTile{tw, th, n1, n2, threads}; best_cost = cost; }
+    }
+  }
+  return best;
+}
+
+template <int RECON, int RS>
+__global__ void __launch_bounds__(HS_THREADS, AKMI_HS_WAVES)
+k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, int kA, int kB,
+                int nchunk, int ckl, int tw, int th) {
+  static_assert(RECON <= 1, "one-kernel hydro stage: DC and PLM");
+  extern __shared__ double hs_lds[];
+  const int pw = tw + 3, ph = th + 3;        // plane with halo: cols i0-2..i0+tw, rows j0-2..j0+th
+  const int swn = 5*ph*pw, sfn = 5*th*tw;
+  // two buffers of {plane, low x1-face fluxes, low x2-face fluxes}: step k reads plane k-1 from one
+  // and stores plane k into the other, so ONE barrier per step orders everything
+#define SW(b, n, y, x) hs_lds[(b)*(swn + 2*sfn) + ((n)*ph + (y))*pw + (x)]
+#define SF1(b, n, y, x) hs_lds[(b)*(swn + 2*sfn) + swn + ((n)*th + (y))*tw + (x)]
+#define SF2(b, n, y, x) hs_lds[(b)*(swn + 2*sfn) + swn + sfn + ((n)*th + (y))*tw + (x)]
+  const int tid = threadIdx.x;
+  const int r = tid/tw, t = tid - r*tw;
+  const bool in_tile = r < th;
+  const int i0 = g.is + blockIdx.x*(tw - 1), j0 = g.js + blockIdx.y*(th - 1);
+  const int i = i0 + t, j = j0 + r;
+  const int m = blockIdx.z/nchunk;
+  const int ch = blockIdx.z - m*nchunk;
+  const int k0 = kA + ch*ckl;
+  const int k1 = (k0 + ckl - 1 < kB) ? k0 + ckl - 1 : kB;
+  const bool cell_ok = in_tile && i < g.N1 && j < g.N2;                // the column exists in memory
+  const bool own = in_tile && t < tw - 1 && r < th - 1 && i <= g.ie && j <= g.je;
+  const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
+  const size_t cs = (size_t)g.N3*g.N2*g.N1, ps = (size_t)g.N2*g.N1;
+  const double *wb = w0 + (size_t)m*g.nvar*cs;
+  // halo entry of this thread: rows 0,1 and ph-1 in full, columns 0,1 and pw-1 of the tile rows
+  int hy = -1, hx = 0;
+  {
+    const int nh = 3*pw + 3*th;
+    if (tid < nh) {
+      if (tid < 3*pw) { const int q = tid/pw; hy = q < 2 ? q : ph - 1; hx = tid - q*pw; }
+      else { const int q = tid - 3*pw; const int rr = q/3, cc = q - rr*3; hy = 2 + rr; hx = cc < 2 ? cc : pw - 1; }
+      if (j0 - 2 + hy >= g.N2 || i0 - 2 + hx >= g.N1) hy = -1;
+    }
+  }
+  const size_t hcol = hy >= 0 ? (size_t)(j0 - 2 + hy)*g.N1 + (i0 - 2 + hx) : 0;
+  const size_t col = cell_ok ? (size_t)j*g.N1 + i : 0;
+  double W0[5], W1[5], PL[5], F3p[5], hv[5];
+#pragma unroll
+  for (int n = 0; n < 5; ++n) {
+    const double *q = wb + n*cs + col;
+    W0[n] = cell_ok ? q[(size_t)(k0 - 1)*ps] : 1.0;
+    W1[n] = cell_ok ? q[(size_t)k0*ps] : 1.0;
+    if constexpr (RECON == 1) {
+      const double qa = cell_ok ? q[(size_t)(k0 - 2)*ps] : 1.0;
+      double dummy;
+      plm(qa, W0[n], W1[n], PL[n], dummy);
+    } else {
+      PL[n] = 0.0;
+    }
+    F3p[n] = 0.0;
+    hv[n] = hy >= 0 ? wb[n*cs + (size_t)k0*ps + hcol] : 1.0;
+  }
+  // step k: x3 face k (below cell k) from registers; for k > k0 also the x1/x2 faces of plane k-1
+  // (in LDS since the previous step), which finishes cell k-1; plane k goes to the other buffer
+  int b = 0;
+  for (int k = k0; k <= k1 + 1; ++k, b ^= 1) {
+    const bool plane = k > k0;                        // workgroup-uniform
+    double wp[5];
+#pragma unroll
+    for (int n = 0; n < 5; ++n) wp[n] = cell_ok ? wb[n*cs + (size_t)(k + 1)*ps + col] : 1.0;
+    double pu0[5], pu1[5];
+    if (plane && own) {                               // operands of the update, used after the solves
+      const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k - 1, j, i);
+#pragma unroll
+      for (int n = 0; n < 5; ++n) {
+        pu0[n] = u.u0[c + n*cs];
+        pu1[n] = u.copy_u1 ? 0.0 : u.u1[c + n*cs];
+      }
+    }
+    if (plane && in_tile) {
+      {  // low x1 face of this position: cells i-2..i+1 of row j
+        double L[5], R[5];
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+          const double qm2 = SW(b, n, r + 2, t), qm1 = SW(b, n, r + 2, t + 1),
+                       q0 = SW(b, n, r + 2, t + 2), qp1 = SW(b, n, r + 2, t + 3);
+          if constexpr (RECON == 1) {
+            double dummy;
+            plm(qm2, qm1, q0, L[n], dummy);
+            plm(qm1, q0, qp1, dummy, R[n]);
+          } else {
+            L[n] = qm1; R[n] = q0;
+          }
+        }
+        double fd, fx, fy, fz, fe;
+        riemann_hyd<RS>(eos.gamma, L[0], L[1], L[2], L[3], L[4], R[0], R[1], R[2], R[3], R[4], fd, fx,
+                        fy, fz, fe);
+        SF1(b, 0, r, t) = fd; SF1(b, 1, r, t) = fx; SF1(b, 2, r, t) = fy; SF1(b, 3, r, t) = fz;
+        SF1(b, 4, r, t) = fe;
+      }
+      {  // low x2 face: cells j-2..j+1 of column i; sweep-aligned order (d, vy, vz, vx, e)
+        double L[5], R[5];
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+          const double qm2 = SW(b, n, r, t + 2), qm1 = SW(b, n, r + 1, t + 2),
+                       q0 = SW(b, n, r + 2, t + 2), qp1 = SW(b, n, r + 3, t + 2);
+          if constexpr (RECON == 1) {
+            double dummy;
+            plm(qm2, qm1, q0, L[n], dummy);
+            plm(qm1, q0, qp1, dummy, R[n]);
+          } else {
+            L[n] = qm1; R[n] = q0;
+          }
+        }
+        double fd, fx, fy, fz, fe;
+        riemann_hyd<RS>(eos.gamma, L[0], L[2], L[3], L[1], L[4], R[0], R[2], R[3], R[1], R[4], fd, fx,
+                        fy, fz, fe);
+        SF2(b, 0, r, t) = fd; SF2(b, 2, r, t) = fx; SF2(b, 3, r, t) = fy; SF2(b, 1, r, t) = fz;
+        SF2(b, 4, r, t) = fe;
+      }
+    }
+    // x3 face below cell k: sweep-aligned order (d, vz, vx, vy, e)
+    double f3[5];
+    {
+      double L[5], R[5];
+#pragma unroll
+      for (int n = 0; n < 5; ++n) {
+        if constexpr (RECON == 1) {
+          double qln;
+          L[n] = PL[n];
+          plm(W0[n], W1[n], wp[n], qln, R[n]);
+          PL[n] = qln;
+        } else {
+          L[n] = W0[n]; R[n] = W1[n];
+        }
+      }
+      double fd, fx, fy, fz, fe;
+      riemann_hyd<RS>(eos.gamma, L[0], L[3], L[1], L[2], L[4], R[0], R[3], R[1], R[2], R[4], fd, fx, fy,
+                      fz, fe);
+      f3[0] = fd; f3[3] = fx; f3[1] = fy; f3[2] = fz; f3[4] = fe;
+    }
+    if (k <= k1) {                                     // plane k for the next step
+      if (in_tile) {
+#pragma unroll
+        for (int n = 0; n < 5; ++n) SW(b ^ 1, n, r + 2, t + 2) = W1[n];
+      }
+      if (hy >= 0) {
+#pragma unroll
+        for (int n = 0; n < 5; ++n) SW(b ^ 1, n, hy, hx) = hv[n];
+        if (k + 1 <= k1) {
+#pragma unroll
+          for (int n = 0; n < 5; ++n) hv[n] = wb[n*cs + (size_t)(k + 1)*ps + hcol];
+        }
+      }
+    }
+    __syncthreads();
+    if (plane && own) {                                // finish cell k-1
+      const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k - 1, j, i);
+#pragma unroll
+      for (int n = 0; n < 5; ++n) {
+        double divf = (SF1(b, n, r, t + 1) - SF1(b, n, r, t))/dx1;
+        divf += (SF2(b, n, r + 1, t) - SF2(b, n, r, t))/dx2;
+        divf += (f3[n] - F3p[n])/dx3;
+        const double u0v = pu0[n];
+        const double u1v = u.copy_u1 ? u0v : pu1[n];
+        if (u.copy_u1) u.u1[c + n*cs] = u0v;
+        u.u0[c + n*cs] = u.gam0*u0v + u.gam1*u1v - u.beta_dt*divf;
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < 5; ++n) { F3p[n] = f3[n]; W0[n] = W1[n]; W1[n] = wp[n]; }
+  }
+#undef SW
+#undef SF1
+#undef SF2
+}
+
 __global__ void k_init_dt3(double *dt3) {
   if (threadIdx.x < 3) dt3[threadIdx.x] = (double)FLT_MAX;
 }
@@ -897,6 +1111,36 @@ static int launch_sweep_update(const Geo &g, const Scheme &sc, const SweepArgs &
   }
   if (rc != AKMI_COMPLETE) return rc;
   AKMI_CHECK_LAUNCH("sweep_update");
+  return AKMI_COMPLETE;
+}
+
+
+static int launch_hydro_stage3d(const Geo &g, const Scheme &sc, const double *w0, const UpdArgs &u,
+                                int kA, int kB, hipStream_t st) {
+  const HydTile tl = hyd_tile(g.nx1, g.nx2);
+  if (tl.tw == 0) { set_error("hydro_stage3d: no tile shape"); return AKMI_FAIL; }
+  const int ckl = march_len((long)tl.n1*tl.n2, kB - kA + 1, g.nmb, ML);
+  const int nchunk = cdiv(kB - kA + 1, ckl);
+  const size_t lds = 2*(5*(size_t)(tl.tw + 3)*(tl.th + 3) + 10*(size_t)tl.tw*tl.th)*sizeof(double);
+  dim3 grid(tl.n1, tl.n2, nchunk*g.nmb), block(tl.threads);
+  int rc = dispatch_scheme<false>(sc, [&](auto R, auto S) {
+    if constexpr (decltype(R)::value <= 1) {
+      auto kern = k_hydro_stage3d<decltype(R)::value, decltype(S)::value>;
+      if (lds > 64*1024 &&
+          hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds) != hipSuccess) {
+        set_error("hydro_stage3d: %zu bytes of LDS refused", lds);
+        return AKMI_FAIL;
+      }
+      kern<<<grid, block, lds, st>>>(g, sc.eos, w0, u, kA, kB, nchunk, ckl, tl.tw, tl.th);
+      return AKMI_COMPLETE;
+    } else {
+      set_error("hydro_stage3d: DC and PLM only");
+      return AKMI_FAIL;
+    }
+  });
+  if (rc != AKMI_COMPLETE) return rc;
+  AKMI_CHECK_LAUNCH("hydro_stage3d");
   return AKMI_COMPLETE;
 }
 
@@ -1097,6 +1341,8 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
   // developer/test knobs: AKMI_SLAB_CELLS (slab thickness), AKMI_ONE_STREAM=1 (no helper stream)
   static const int env_slab = getenv("AKMI_SLAB_CELLS") ? atoi(getenv("AKMI_SLAB_CELLS")) : 0;
   static const bool env_one = getenv("AKMI_ONE_STREAM") && atoi(getenv("AKMI_ONE_STREAM")) != 0;
+  // AKMI_HYDRO_ONE_KERNEL=0: the three-kernel sweep/march sequence also for hydro DC/PLM (A/B runs)
+  static const bool hyd_one = !(getenv("AKMI_HYDRO_ONE_KERNEL") && atoi(getenv("AKMI_HYDRO_ONE_KERNEL")) == 0);
   const int T = (phases != AKMI_PHASE_ALL) ? g.nx3 : (env_slab > 1 ? env_slab : AKMI_SLAB);
   const int S = (g.nx3 + T - 1)/T;
   if (S > MAX_SLABS) { set_error("too many slabs"); return AKMI_FAIL; }
@@ -1136,7 +1382,10 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
     b1.kl = kA(s) - (MHD ? 1 : 0); b1.ku = kB(s) + (MHD ? 1 : 0);
     b2.kl = b1.kl; b2.ku = b1.ku;
     b3.kl = kA(s); b3.ku = kB(s) + 1;
-    if (do_sweeps) {
+    if (do_sweeps && !MHD && hyd_one && sc.recon <= 1) {
+      // hydro DC/PLM: sweeps + update of the slab in one kernel
+      rc = launch_hydro_stage3d(g, sc, w0, u, kA(s), kB(s), st);
+    } else if (do_sweeps) {
     rc = MHD ? launch_sweep<0, MHD, MHD>(g, sc, b1, st)
              : launch_sweep<0, MHD, false>(g, sc, b1, st);
     // x2 sweep as a march along j that leaves acc = dF1/dx1 + dF2/dx2; x3 march consumes it

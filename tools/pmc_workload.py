@@ -23,7 +23,11 @@ nx = int(os.environ.get("AKMI_PMC_NX", "256"))
 ov = ["time/cfl_number=0.3", "time/nlim=-1", "time/tlim=1.0e9"]
 for q in (1, 2, 3):
     ov += ["mesh/nx%d=%d" % (q, nx), "meshblock/nx%d=%d" % (q, nx)]
-sim = Simulation(load_deck("orszag_tang.athinput", ov))
+deck = "orszag_tang.athinput"
+if os.environ.get("AKMI_PMC_PROBLEM", "") == "sod":          # hydro PLM+HLLC (bench.py --problem sod)
+    deck = "sod.athinput"
+    ov += ["mesh/ix1_bc=outflow", "mesh/ox1_bc=outflow"]
+sim = Simulation(load_deck(deck, ov))
 sim.Execute(max_cycles=2)
 torch.cuda.synchronize()
 print("done", sim.pmesh.ncycle)
