@@ -21,8 +21,8 @@ TOL = 1e-12     # north_star: <= 1e-12 relative L1 on the conserved variables
 
 def deck_overrides(problem, n, dims, mb=None, ng=None, recon=None, integrator=None, cfl=None,
                    nlim=None, extra=(), rsolver=None):
-    """deck name + override list for an n^dims mesh with mb^dims MeshBlocks (mb may be a
-    per-direction tuple)"""
+    """deck name + override list for an n^dims mesh with mb^dims MeshBlocks (n and mb may be
+    per-direction tuples)"""
     mb = mb or n
     deck = {"linear_wave_hydro": "linear_wave_hydro.athinput",
             "linear_wave_mhd": "linear_wave_mhd.athinput", "sod": "sod.athinput",
@@ -30,7 +30,7 @@ def deck_overrides(problem, n, dims, mb=None, ng=None, recon=None, integrator=No
             "rj2a": "rj2a.athinput"}[problem]
     ov = []
     for q in (1, 2, 3):
-        nn = n if q <= dims else 1
+        nn = (n[q - 1] if isinstance(n, (tuple, list)) else n) if q <= dims else 1
         mm = (mb[q - 1] if isinstance(mb, (tuple, list)) else mb) if q <= dims else 1
         ov += ["mesh/nx%d=%d" % (q, nn), "meshblock/nx%d=%d" % (q, mm)]
     if ng is not None:

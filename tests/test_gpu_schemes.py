@@ -83,6 +83,41 @@ def test_native_cpp_driver_schemes(case):
     assert res["cycles"] == cycles and res["bitwise_equal"], res["diffs"]
 
 
+# hydro DC/PLM in 3-D: the whole stage update is one kernel (k_hydro_stage3d) whose tile shape depends on
+# the block size -- every hydro solver, both reconstructions, blocks that do not fill the tiles, many small
+# blocks, outflow faces, the phased issue of multi-stage integrators
+HYDRO_ONE_KERNEL = [
+    ("sod", 24, 3, 12, 4, dict(cfl=0.3, recon="dc", rsolver="llf")),
+    ("sod", 24, 3, 24, 4, dict(cfl=0.3, recon="dc", rsolver="hllc", integrator="rk3")),
+    ("sod", (36, 28, 20), 3, (18, 14, 10), 4, dict(cfl=0.3, recon="plm", rsolver="roe", integrator="rk3")),
+    ("sod", (70, 12, 10), 3, (70, 12, 10), 3, dict(cfl=0.3, recon="plm", rsolver="hllc")),
+    ("sod", 32, 3, 8, 3, dict(cfl=0.3, recon="plm", rsolver="hlle", integrator="rk1")),
+    ("sod", 40, 3, 40, 3, dict(cfl=0.3, ng=3, recon="plm", rsolver="hllc",
+                               extra=("mesh/ix2_bc=outflow", "mesh/ox2_bc=outflow", "mesh/ix3_bc=reflect",
+                                      "mesh/ox3_bc=reflect"))),
+    ("linear_wave_hydro", 32, 3, 16, 3, dict(recon="plm", rsolver="llf", integrator="rk4")),
+    # oblique waves: every flux component of every direction is non-trivial
+    ("linear_wave_hydro", (32, 16, 24), 3, (16, 16, 8), 3, dict(recon="plm", rsolver="hllc")),
+    ("linear_wave_hydro", (20, 24, 28), 3, (20, 12, 14), 3, dict(recon="dc", rsolver="hlle", integrator="rk3")),
+    ("linear_wave_hydro", 24, 3, 24, 3, dict(recon="plm", rsolver="roe", ng=4)),
+]
+
+
+def _id1(c):
+    n = c[1] if isinstance(c[1], int) else "x".join(map(str, c[1]))
+    mb = c[3] if isinstance(c[3], int) else "x".join(map(str, c[3]))
+    return "%s-%s-mb%s-%s-%s-%s" % (c[0], n, mb, c[5]["recon"], c[5]["rsolver"], c[5].get("integrator", "rk2"))
+
+
+@pytest.mark.parametrize("case", HYDRO_ONE_KERNEL, ids=_id1)
+def test_hydro_one_kernel_stage_is_bit_identical(case):
+    problem, n, dims, mb, cycles, kw = case
+    res = pu.compare_run(problem, n, dims, mb, cycles, fused=True, **kw)
+    assert res["cycles"] == cycles
+    assert res["time"][0] == res["time"][1], res["time"]
+    assert res["bitwise_equal"], res["diffs"]
+
+
 RK4 = [
     ("linear_wave_hydro", 64, 1, 32, 8, dict(integrator="rk4", recon="wenoz", ng=3, rsolver="hllc")),
     ("sod", 24, 3, 12, 4, dict(integrator="rk4", cfl=0.3, rsolver="hlle")),
