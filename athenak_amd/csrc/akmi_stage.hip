@@ -304,11 +304,31 @@ static CtTile ct_tile(int e1, int e2) {
   return best;
 }
 
-static int march_len(long col_blocks, int ncells, int nmb, int lmax) {
+static int march_len(long col_blocks, int ncells, int nmb, int lmax, int wgs_per_cu = 0) {
   const long want = 2048;                       // workgroups per launch (scan: profiles/r01_small_packs.txt)
   long ml = col_blocks*(long)ncells*nmb/want;
   if (ml > lmax) ml = lmax;
   if (ml < 4) ml = 4;
+  static const int tail = getenv("AKMI_TAIL") ? atoi(getenv("AKMI_TAIL")) : 1;
+  if (wgs_per_cu > 0 && tail && ml < lmax) {          // packs too small for full-length marches
+    // equal-length workgroups run in rounds of (256 CUs x resident workgroups): pick the chunk
+    // length whose last round is fullest, charging the face each chunk recomputes.  Used by the
+    // x2/x3 marches of small packs (128^3: -7 % per march); full-length marches, k_corner_ct and
+    // k_hydro_stage3d measured no better than the plain rule (profiles/r01_v14_tail_ab.txt)
+    const double resident = 256.0*wgs_per_cu;
+    double best = -1.0;
+    long best_ml = ml;
+    for (long c = lmax; c >= 4; --c) {
+      const long nch = (ncells + c - 1)/c;
+      const double rounds = (double)(col_blocks*nch*nmb)/resident;
+      const double full = rounds <= 1.0 ? 1.0 : rounds/(double)(long)(rounds + 0.999999);
+      // below one round the launch is latency-bound: prefer more, shorter chunks up to a round
+      const double fill = rounds < 1.0 ? rounds : 1.0;
+      const double score = full*fill/(1.0 + 1.0/(double)c);
+      if (score > best) { best = score; best_ml = c; }
+    }
+    ml = best_ml;
+  }
   return (int)ml;
 }
 
@@ -1093,13 +1113,13 @@ static int launch_sweep_update(const Geo &g, const Scheme &sc, const SweepArgs &
       long np = (long)(a.ju - a.jl + 1)*g.N1;          // flattened rows
       const unsigned nb = (unsigned)((np + SX*SY - 1)/(SX*SY));
       const int nc = a.ku - a.kl > 0 ? a.ku - a.kl : 1;
-      ml = march_len(nb, nc, g.nmb, ML);
+      ml = march_len(nb, nc, g.nmb, ML, 3);
       grid = dim3(nb, cdiv(nc, ml), g.nmb);
     } else {
       long np = (long)(a.ku - a.kl + 1)*g.N1;          // flattened (k,i)
       const unsigned nb = (unsigned)((np + SX*SY - 1)/(SX*SY));
       const int nc = a.ju - a.jl > 0 ? a.ju - a.jl : 1;
-      ml = march_len(nb, nc, g.nmb, ML);
+      ml = march_len(nb, nc, g.nmb, ML, 3);
       grid = dim3(nb, cdiv(nc, ml), g.nmb);
     }
     constexpr int D = (DIR == 0) ? 1 : DIR;
