@@ -1402,7 +1402,7 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
     b1.kl = kA(s) - (MHD ? 1 : 0); b1.ku = kB(s) + (MHD ? 1 : 0);
     b2.kl = b1.kl; b2.ku = b1.ku;
     b3.kl = kA(s); b3.ku = kB(s) + 1;
-    if (do_sweeps && !MHD && hyd_one && sc.recon <= 1) {
+    if (do_sweeps && !MHD && hyd_one && sc.recon <= 1 && hyd_tile(g.nx1, g.nx2).tw > 0) {
       // hydro DC/PLM: sweeps + update of the slab in one kernel
       rc = launch_hydro_stage3d(g, sc, w0, u, kA(s), kB(s), st);
     } else if (do_sweeps) {

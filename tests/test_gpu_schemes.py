@@ -100,6 +100,9 @@ HYDRO_ONE_KERNEL = [
     ("linear_wave_hydro", (32, 16, 24), 3, (16, 16, 8), 3, dict(recon="plm", rsolver="hllc")),
     ("linear_wave_hydro", (20, 24, 28), 3, (20, 12, 14), 3, dict(recon="dc", rsolver="hlle", integrator="rk3")),
     ("linear_wave_hydro", 24, 3, 24, 3, dict(recon="plm", rsolver="roe", ng=4)),
+    # blocks smaller than any tile / too narrow for one (falls back to the three-kernel sequence)
+    ("linear_wave_hydro", (8, 4, 4), 3, (4, 2, 2), 3, dict(recon="plm", rsolver="hllc")),
+    ("linear_wave_hydro", (4, 8, 8), 3, (2, 4, 4), 3, dict(recon="plm", rsolver="hllc")),
 ]
 
 
