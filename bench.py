@@ -210,15 +210,17 @@ def main():
     stage_bytes = BYTES_PASS_A[blk] + BYTES_PASS_B[blk]
     ach = stage_bytes*ncell_rank/tS/1e9
     traffic, tsrc = None, None
-    tfile = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
-    if os.path.exists(tfile) and blk == "mhd" and args.nx == 256 and not args.split:
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json" if blk == "mhd" else
+                         "pmc_traffic_hydro_latest.json")
+    if os.path.exists(tfile) and args.nx == 256 and not args.split and not args.mb and \
+            args.problem in ("orszag_tang", "sod"):
         # HBM-side bytes per stage from rocprofv3 PMC counters (FETCH_SIZE / WRITE_SIZE in
         # separate passes, calibrated on a copy of known size; tools/pmc.sh), recorded for this
         # workload in a separate profiling run
         t = json.load(open(tfile))
         stage_kernels = [k for k in t["kernels"] if k.startswith("akmi::k_sweep") or
                          k.startswith("akmi::k_corner") or k.startswith("akmi::k_ct_copy") or
-                         k.startswith("akmi::k_c2p_newdt")]
+                         k.startswith("akmi::k_hydro_stage3d") or k.startswith("akmi::k_c2p_newdt")]
         traffic = round(sum(t["kernels"][k]["hbm_bytes_per_launch"] for k in stage_kernels))
         tsrc = "profiles/pmc_traffic_latest.json (%s)" % t.get("tag", "")
     roofline = {"bound": "hbm",
