@@ -222,7 +222,7 @@ def main():
                          k.startswith("akmi::k_corner") or k.startswith("akmi::k_ct_copy") or
                          k.startswith("akmi::k_hydro_stage3d") or k.startswith("akmi::k_c2p_newdt")]
         traffic = round(sum(t["kernels"][k]["hbm_bytes_per_launch"] for k in stage_kernels))
-        tsrc = "profiles/pmc_traffic_latest.json (%s)" % t.get("tag", "")
+        tsrc = "profiles/%s (%s)" % (os.path.basename(tfile), t.get("tag", ""))
     roofline = {"bound": "hbm",
                 "kernel": ("akmi_%s_stage_fused launch group (sweeps + update%s + c2p of active cells)"
                            % (blk, " + CornerE + CT" if blk == "mhd" else "")) if world == 1 else
