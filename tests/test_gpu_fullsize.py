@@ -75,7 +75,8 @@ def test_c3_mhd_256_fused_equals_task_path_and_conserves():
 
 
 def test_c3_mhd_256_is_independent_of_the_block_decomposition():
-    """one 256^3 MeshBlock vs eight 128^3 MeshBlocks (ghost exchange, Z-ordered pack): same bits"""
+    """one 256^3 MeshBlock vs eight 128^3 and sixty-four 64^3 MeshBlocks (ghost exchange, Z-ordered
+    pack, the tile shapes the kernels choose for those block sizes): same bits"""
     import torch
     s1, _, _, _ = _run("orszag_tang", 256, 256, 3, True, cfl=0.3)
     g1 = _global(s1, s1.phys.u0).clone()
@@ -83,10 +84,33 @@ def test_c3_mhd_256_is_independent_of_the_block_decomposition():
     t1 = (s1.pmesh.time, s1.pmesh.dt)
     del s1
     torch.cuda.empty_cache()
-    s8, _, _, _ = _run("orszag_tang", 256, 128, 3, True, cfl=0.3)
-    assert (s8.pmesh.time, s8.pmesh.dt) == t1
-    assert torch.equal(_global(s8, s8.phys.u0), g1)
-    assert torch.equal(_global(s8, s8.phys.bcc0), w1)
+    for mb in (128, 64):
+        s8, _, _, _ = _run("orszag_tang", 256, mb, 3, True, cfl=0.3)
+        assert (s8.pmesh.time, s8.pmesh.dt) == t1
+        assert torch.equal(_global(s8, s8.phys.u0), g1)
+        assert torch.equal(_global(s8, s8.phys.bcc0), w1)
+        del s8
+        torch.cuda.empty_cache()
+
+
+def test_hydro_256_one_kernel_stage_equals_task_path_and_small_blocks():
+    """hydro PLM+HLLC 256^3 (the bench's --problem sod): the one-kernel stage == the task-granular
+    kernels == 64 MeshBlocks of 64^3"""
+    import torch
+    sf, _, _, _ = _run("sod", 256, 256, 3, True, cfl=0.3)
+    uf, wf = sf.phys.u0.clone(), sf.phys.w0.clone()
+    gf = _global(sf, sf.phys.u0).clone()
+    tf = (sf.pmesh.time, sf.pmesh.dt)
+    del sf
+    torch.cuda.empty_cache()
+    ss, _, _, _ = _run("sod", 256, 256, 3, False, cfl=0.3)
+    assert (ss.pmesh.time, ss.pmesh.dt) == tf
+    assert torch.equal(ss.phys.u0, uf) and torch.equal(ss.phys.w0, wf)
+    del ss
+    torch.cuda.empty_cache()
+    s64, _, _, _ = _run("sod", 256, 64, 3, True, cfl=0.3)
+    assert (s64.pmesh.time, s64.pmesh.dt) == tf
+    assert torch.equal(_global(s64, s64.phys.u0), gf)
 
 
 def test_c2_hydro_128_fused_equals_task_path():
