@@ -262,6 +262,66 @@ static int check_box(const Geo &g, const CGeo &c, const int *box, int halo, int 
 
 using namespace akmi;
 
+// Restricted face fluxes for a coarser neighbour, buffer order of PackAndSendFluxCC
+// (src/bvals/flux_correct_cc.cpp:78-148); box = coarse index box, one face thick along DIR
+template <int DIR>
+__global__ void k_restrict_flux_cc(Geo g, CGeo c, Box bx, int nvar, const double *__restrict__ flx,
+                                   double *__restrict__ out) {
+  int m, v, k, j, i;
+  if (!box_index(bx, nvar, m, v, k, j, i)) return;
+  const int ni = bx.iu - bx.il + 1, nj = bx.ju - bx.jl + 1, nk = bx.ku - bx.kl + 1;
+  const int f3 = g.N3 + (DIR == 2), f2 = g.N2 + (DIR == 1), f1 = g.N1 + (DIR == 0);
+  const int fi = 2*i - c.cis, fj = 2*j - c.cjs, fk = 2*k - c.cks;
+#define FX(k, j, i) flx[ix5(nvar, f3, f2, f1, m, v, k, j, i)]
+  double r;
+  size_t o;
+  if constexpr (DIR == 0) {
+    if (!g.multi_d) r = FX(0, 0, fi);
+    else if (!g.three_d) r = 0.5*(FX(0, fj, fi) + FX(0, fj + 1, fi));
+    else r = 0.25*(FX(fk, fj, fi) + FX(fk, fj + 1, fi) + FX(fk + 1, fj, fi) + FX(fk + 1, fj + 1, fi));
+    o = (size_t)(j - bx.jl) + (size_t)nj*((k - bx.kl) + (size_t)nk*v);
+  } else if constexpr (DIR == 1) {
+    if (!g.three_d) r = 0.5*(FX(0, fj, fi) + FX(0, fj, fi + 1));
+    else r = 0.25*(FX(fk, fj, fi) + FX(fk, fj, fi + 1) + FX(fk + 1, fj, fi) + FX(fk + 1, fj, fi + 1));
+    o = (size_t)(i - bx.il) + (size_t)ni*((k - bx.kl) + (size_t)nk*v);
+  } else {
+    r = 0.25*(FX(fk, fj, fi) + FX(fk, fj, fi + 1) + FX(fk, fj + 1, fi) + FX(fk, fj + 1, fi + 1));
+    o = (size_t)(i - bx.il) + (size_t)ni*((j - bx.jl) + (size_t)nj*v);
+  }
+#undef FX
+  out[(size_t)m*nvar*ni*nj*nk + o] = r;
+}
+
+// Restricted edge EMFs for a coarser neighbour (PackAndSendFluxFC, src/bvals/flux_correct_fc.cpp:84-360):
+// the two fine edges of a coarse edge averaged along the edge's own direction
+template <int COMP>
+__global__ void k_restrict_emf(Geo g, CGeo c, Box bx, const double *__restrict__ e,
+                               double *__restrict__ out) {
+  int m, v, k, j, i;
+  if (!box_index(bx, 1, m, v, k, j, i)) return;
+  const int ni = bx.iu - bx.il + 1, nj = bx.ju - bx.jl + 1, nk = bx.ku - bx.kl + 1;
+  const int e3 = g.N3 + (COMP != 2), e2 = g.N2 + (COMP != 1), e1 = g.N1 + (COMP != 0);
+  const int fi = 2*i - c.cis, fj = g.multi_d ? 2*j - c.cjs : 0, fk = g.three_d ? 2*k - c.cks : 0;
+#define EE(k, j, i) e[ix4(e3, e2, e1, m, k, j, i)]
+  double r;
+  if constexpr (COMP == 0) r = g.multi_d ? 0.5*(EE(fk, fj, fi) + EE(fk, fj, fi + 1)) : EE(fk, fj, fi);
+  else if constexpr (COMP == 1) r = g.multi_d ? 0.5*(EE(fk, fj, fi) + EE(fk, fj + 1, fi)) : EE(fk, fj, fi);
+  else r = g.three_d ? 0.5*(EE(fk, fj, fi) + EE(fk + 1, fj, fi)) : EE(fk, fj, fi);
+#undef EE
+  out[(size_t)m*ni*nj*nk + (size_t)(i - bx.il) + (size_t)ni*((j - bx.jl) + (size_t)nj*(k - bx.kl))] = r;
+}
+
+// coarse box of a flux operator: inside the coarse index space incl. its upper faces/edges
+static int check_flux_box(const CGeo &c, const int *box, const char *who) {
+  if (box[0] > box[1] || box[2] > box[3] || box[4] > box[5] || box[0] < c.cis || box[1] > c.cie + 1 ||
+      box[2] < c.cjs || box[3] > c.cje + 1 || box[4] < c.cks || box[5] > c.cke + 1) {
+    set_error("%s: box [%d,%d]x[%d,%d]x[%d,%d] outside the coarse faces [%d,%d]x[%d,%d]x[%d,%d]", who, box[0],
+              box[1], box[2], box[3], box[4], box[5], c.cis, c.cie + 1, c.cjs, c.cje + 1, c.cks, c.cke + 1);
+    return AKMI_FAIL;
+  }
+  return AKMI_COMPLETE;
+}
+
 extern "C" {
 
 int akmi_restrict_cc(const akmi_pack *p, int nvar, const double *u, double *cu, void *stream) {
@@ -279,6 +339,45 @@ int akmi_restrict_fc(const akmi_pack *p, const double *bx1f, const double *bx2f,
   k_restrict_fc<<<box_grid(bx, 1, g.nmb), dim3(64, 4), 0, (hipStream_t)stream>>>(
       g, c, CFaces{bx1f, bx2f, bx3f}, Faces{cbx1f, cbx2f, cbx3f});
   AKMI_CHECK_LAUNCH("restrict_fc");
+  return AKMI_COMPLETE;
+}
+
+int akmi_restrict_flux_cc(const akmi_pack *p, int nvar, int dir, const int *box, const double *flx,
+                          double *out, void *stream) {
+  Geo g = make_geo(p); CGeo c = make_cgeo(g);
+  if (dir < 0 || dir > 2 || (dir == 1 && !g.multi_d) || (dir == 2 && !g.three_d)) {
+    set_error("restrict_flux_cc: dir = %d", dir); return AKMI_FAIL;
+  }
+  if (check_flux_box(c, box, "restrict_flux_cc") != AKMI_COMPLETE) return AKMI_FAIL;
+  if (box[2*dir] != box[2*dir + 1]) { set_error("restrict_flux_cc: the box must be one face thick along dir"); return AKMI_FAIL; }
+  // transverse extents are cells, not faces
+  const int hi[3] = {c.cie, c.cje, c.cke};
+  for (int d = 0; d < 3; ++d)
+    if (d != dir && box[2*d + 1] > hi[d]) { set_error("restrict_flux_cc: transverse range beyond the coarse cells"); return AKMI_FAIL; }
+  const Box bx{box[0], box[1], box[2], box[3], box[4], box[5]};
+  const dim3 grid = box_grid(bx, nvar, g.nmb), block(64, 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (dir == 0) k_restrict_flux_cc<0><<<grid, block, 0, st>>>(g, c, bx, nvar, flx, out);
+  else if (dir == 1) k_restrict_flux_cc<1><<<grid, block, 0, st>>>(g, c, bx, nvar, flx, out);
+  else k_restrict_flux_cc<2><<<grid, block, 0, st>>>(g, c, bx, nvar, flx, out);
+  AKMI_CHECK_LAUNCH("restrict_flux_cc");
+  return AKMI_COMPLETE;
+}
+
+int akmi_restrict_emf(const akmi_pack *p, int comp, const int *box, const double *e, double *out,
+                      void *stream) {
+  Geo g = make_geo(p); CGeo c = make_cgeo(g);
+  if (comp < 0 || comp > 2) { set_error("restrict_emf: comp = %d", comp); return AKMI_FAIL; }
+  if (check_flux_box(c, box, "restrict_emf") != AKMI_COMPLETE) return AKMI_FAIL;
+  const int hi[3] = {c.cie, c.cje, c.cke};
+  if (box[2*comp + 1] > hi[comp]) { set_error("restrict_emf: range along the edge beyond the coarse cells"); return AKMI_FAIL; }
+  const Box bx{box[0], box[1], box[2], box[3], box[4], box[5]};
+  const dim3 grid = box_grid(bx, 1, g.nmb), block(64, 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (comp == 0) k_restrict_emf<0><<<grid, block, 0, st>>>(g, c, bx, e, out);
+  else if (comp == 1) k_restrict_emf<1><<<grid, block, 0, st>>>(g, c, bx, e, out);
+  else k_restrict_emf<2><<<grid, block, 0, st>>>(g, c, bx, e, out);
+  AKMI_CHECK_LAUNCH("restrict_emf");
   return AKMI_COMPLETE;
 }
 

@@ -266,6 +266,19 @@ int akmi_restrict_cc(const akmi_pack *p, int nvar, const double *u, double *cu, 
 /* MeshRefinement::RestrictFC (src/mesh/mesh_refinement.cpp:1283-1382) */
 int akmi_restrict_fc(const akmi_pack *p, const double *bx1f, const double *bx2f, const double *bx3f,
                      double *cbx1f, double *cbx2f, double *cbx3f, void *stream);
+/* Conservation at fine/coarse faces: what a fine MeshBlock hands to a coarser neighbour.
+ * akmi_restrict_flux_cc: the 2x2 (2-D: 2, 1-D: 1) fine face fluxes of direction `dir` behind each coarse
+ * face of `box` (coarse indices il,iu,jl,ju,kl,ku; one face thick along dir), in the buffer order of
+ * MeshBoundaryValuesCC::PackAndSendFluxCC (src/bvals/flux_correct_cc.cpp:78-148):
+ * out[m][(t1-t1l) + n1*((t2-t2l) + n2*v)], (t1,t2) = (j,k) | (i,k) | (i,j).  flx is face-shaped
+ * (nmb,nvar,N3(+1),N2(+1),N1(+1)).
+ * akmi_restrict_emf: the two fine edges behind each coarse edge of component comp (x1e,x2e,x3e shapes of
+ * akmi_mhd_corner_e), MeshBoundaryValuesFC::PackAndSendFluxFC (src/bvals/flux_correct_fc.cpp:84-360):
+ * out[m][(i-il) + ni*((j-jl) + nj*(k-kl))]. */
+int akmi_restrict_flux_cc(const akmi_pack *p, int nvar, int dir, const int *box, const double *flx,
+                          double *out, void *stream);
+int akmi_restrict_emf(const akmi_pack *p, int comp, const int *box, const double *e, double *out,
+                      void *stream);
 /* ProlongCC (src/mesh/prolongation.hpp:19-63): min-mod limited linear interpolation */
 int akmi_prolong_cc(const akmi_pack *p, int nvar, const int *box, const double *cu, double *u,
                     void *stream);

@@ -2771,6 +2771,68 @@ int akref_restrict_cc(const akmi_pack *p, int nvar, const double *u, double *cu)
   return 0;
 }
 
+/* Restricted face fluxes a fine MeshBlock hands to a coarser neighbour, in the buffer order of
+ * PackAndSendFluxCC (src/bvals/flux_correct_cc.cpp:78-148): dir = face normal, box = coarse index box
+ * (il,iu,jl,ju,kl,ku) whose extent along dir is one face; flx is the face-shaped flux of that direction.
+ * out[m][(t1-t1l) + n1*((t2-t2l) + n2*v)], (t1,t2) = (j,k) / (i,k) / (i,j).  TEST INFRASTRUCTURE. */
+int akref_restrict_flux_cc(const akmi_pack *p, int nvar, int dir, const int *box, const double *flx,
+                           double *out) {
+  G g = mkG(p); CG c = mkCG(&g);
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  const int il = box[0], iu = box[1], jl = box[2], ju = box[3], kl = box[4], ku = box[5];
+  const int ni = iu - il + 1, nj = ju - jl + 1, nk = ku - kl + 1;
+  const int f3 = N3 + (dir == 2), f2 = N2 + (dir == 1), f1 = N1 + (dir == 0);
+  const size_t per = (size_t)nvar*ni*nj*nk;
+#define FX(v,k,j,i) flx[ix5(nvar,f3,f2,f1,m,v,k,j,i)]
+  for (int m = 0; m < g.nmb; ++m) for (int v = 0; v < nvar; ++v)
+    for (int k = kl; k <= ku; ++k) for (int j = jl; j <= ju; ++j) for (int i = il; i <= iu; ++i) {
+      const int fi = 2*i - c.cis, fj = 2*j - c.cjs, fk = 2*k - c.cks;
+      double r;
+      size_t o;
+      if (dir == 0) {
+        if (!g.multi_d) r = FX(v,0,0,fi);
+        else if (!g.three_d) r = 0.5*(FX(v,0,fj,fi) + FX(v,0,fj+1,fi));
+        else r = 0.25*(FX(v,fk,fj,fi) + FX(v,fk,fj+1,fi) + FX(v,fk+1,fj,fi) + FX(v,fk+1,fj+1,fi));
+        o = (size_t)(j - jl) + (size_t)nj*((k - kl) + (size_t)nk*v);
+      } else if (dir == 1) {
+        if (!g.three_d) r = 0.5*(FX(v,0,fj,fi) + FX(v,0,fj,fi+1));
+        else r = 0.25*(FX(v,fk,fj,fi) + FX(v,fk,fj,fi+1) + FX(v,fk+1,fj,fi) + FX(v,fk+1,fj,fi+1));
+        o = (size_t)(i - il) + (size_t)ni*((k - kl) + (size_t)nk*v);
+      } else {
+        r = 0.25*(FX(v,fk,fj,fi) + FX(v,fk,fj,fi+1) + FX(v,fk,fj+1,fi) + FX(v,fk,fj+1,fi+1));
+        o = (size_t)(i - il) + (size_t)ni*((j - jl) + (size_t)nj*v);
+      }
+      out[m*per + o] = r;
+    }
+#undef FX
+  return 0;
+}
+
+/* Restricted edge EMFs for a coarser neighbour (PackAndSendFluxFC, src/bvals/flux_correct_fc.cpp:84-360):
+ * the two fine edges that make up a coarse edge are averaged along the edge's own direction (no
+ * averaging along a direction the mesh does not have).  comp = 0,1,2 for x1e,x2e,x3e; box in coarse
+ * indices; out[m][(i-il) + ni*((j-jl) + nj*(k-kl))].  TEST INFRASTRUCTURE. */
+int akref_restrict_emf(const akmi_pack *p, int comp, const int *box, const double *e, double *out) {
+  G g = mkG(p); CG c = mkCG(&g);
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
+  const int il = box[0], iu = box[1], jl = box[2], ju = box[3], kl = box[4], ku = box[5];
+  const int ni = iu - il + 1, nj = ju - jl + 1, nk = ku - kl + 1;
+  const int e3 = N3 + (comp != 2), e2 = N2 + (comp != 1), e1 = N1 + (comp != 0);   /* efld shapes */
+  const size_t per = (size_t)ni*nj*nk;
+#define EE(k,j,i) e[ix4(e3,e2,e1,m,k,j,i)]
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = kl; k <= ku; ++k) for (int j = jl; j <= ju; ++j) for (int i = il; i <= iu; ++i) {
+      const int fi = 2*i - c.cis, fj = g.multi_d ? 2*j - c.cjs : 0, fk = g.three_d ? 2*k - c.cks : 0;
+      double r;
+      if (comp == 0) r = g.multi_d ? 0.5*(EE(fk,fj,fi) + EE(fk,fj,fi+1)) : EE(fk,fj,fi);
+      else if (comp == 1) r = g.multi_d ? 0.5*(EE(fk,fj,fi) + EE(fk,fj+1,fi)) : EE(fk,fj,fi);
+      else r = g.three_d ? 0.5*(EE(fk,fj,fi) + EE(fk+1,fj,fi)) : EE(fk,fj,fi);
+      out[m*per + (size_t)(i - il) + (size_t)ni*((j - jl) + (size_t)nj*(k - kl))] = r;
+    }
+#undef EE
+  return 0;
+}
+
 #define FB1(k,j,i) b1[ix4(N3,N2,N1+1,m,k,j,i)]
 #define FB2(k,j,i) b2[ix4(N3,N2+1,N1,m,k,j,i)]
 #define FB3(k,j,i) b3[ix4(N3+1,N2,N1,m,k,j,i)]

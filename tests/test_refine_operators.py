@@ -178,3 +178,129 @@ def test_hip_operators_match_the_oracle(dims, ng):
     # a box whose fine cells would lie outside the block is refused, not written
     bad = np.array([0, 1, a["cjs"], a["cjs"], a["cks"], a["cks"]], dtype=np.int32)
     assert L.akmi_prolong_cc(P, nv, bad.ctypes.data_as(C.c_void_p), capi._p(cud), capi._p(ud), None) < 0
+
+
+# ---- conservation at fine/coarse faces: restricted fluxes and edge EMFs ---------------------------
+def _flux_arrays(a, rng):
+    N3, N2, N1 = a["N"]
+    nmb, nv = a["nmb"], a["nvar"]
+    flx = [rng.normal(size=(nmb, nv, N3, N2, N1 + 1)), rng.normal(size=(nmb, nv, N3, N2 + 1, N1)),
+           rng.normal(size=(nmb, nv, N3 + 1, N2, N1))]
+    emf = [rng.normal(size=(nmb, N3 + 1, N2 + 1, N1)), rng.normal(size=(nmb, N3 + 1, N2, N1 + 1)),
+           rng.normal(size=(nmb, N3, N2 + 1, N1 + 1))]
+    return flx, emf
+
+
+def _face_boxes(a):
+    """(dir, box) of the six coarse block faces: one face thick along dir, the active cells across"""
+    out = []
+    lo = [a["cis"], a["cjs"], a["cks"]]
+    n = [a["cn"][2], a["cn"][1], a["cn"][0]]
+    for d in range(a["dims"]):
+        for side in (0, 1):
+            b = [lo[0], lo[0] + n[0] - 1, lo[1], lo[1] + n[1] - 1, lo[2], lo[2] + n[2] - 1]
+            f = lo[d] + (n[d] if side else 0)
+            b[2*d] = b[2*d + 1] = f
+            out.append((d, np.array(b, dtype=np.int32)))
+    return out
+
+
+def _edge_boxes(a):
+    """(comp, box): the edges of component comp lying in each block face they live on"""
+    out = []
+    lo = [a["cis"], a["cjs"], a["cks"]]
+    n = [a["cn"][2], a["cn"][1], a["cn"][0]]
+    for d, fb in _face_boxes(a):
+        for comp in range(3):
+            if comp == d:
+                continue
+            b = fb.copy()
+            for t in range(3):
+                if t != d and t != comp and t < a["dims"]:
+                    b[2*t + 1] += 1                      # edges across: one more than cells
+            out.append((comp, b))
+    return out
+
+
+@pytest.mark.parametrize("dims", [1, 2, 3])
+def test_restricted_fluxes_conserve(dims):
+    """area-weighted sum of the fine fluxes through a coarse face == the restricted flux; an EMF that is
+    constant along an edge restricts to itself; buffer order (t1 fastest, then t2, then variable)"""
+    R = akref.lib()
+    a = _setup(dims, ng=2, seed=21 + dims)
+    rng = np.random.default_rng(5)
+    flx, emf = _flux_arrays(a, rng)
+    nv = a["nvar"]
+    for d, box in _face_boxes(a):
+        ext = [box[1] - box[0] + 1, box[3] - box[2] + 1, box[5] - box[4] + 1]
+        out = np.zeros((a["nmb"], nv*ext[0]*ext[1]*ext[2]))
+        assert R.akref_restrict_flux_cc(C.byref(a["pk"]), nv, d, akref.ptr(box), akref.ptr(flx[d]),
+                                        akref.ptr(out)) == 0
+        t = [q for q in range(3) if q != d]                      # (t1, t2) = the transverse directions
+        o = out.reshape(a["nmb"], nv, ext[t[1]], ext[t[0]])
+        # the same number from numpy: mean over the fine faces behind each coarse face
+        f = flx[d]
+        fidx = [None, None, None]
+        cs = [a["cis"], a["cjs"], a["cks"]]
+        for q in range(3):
+            c = np.arange(box[2*q], box[2*q + 1] + 1)
+            fidx[q] = 2*c - cs[q] if q < dims else np.zeros(1, dtype=int)
+        acc = 0.0
+        cnt = 0
+        for dk in ((0, 1) if (dims > 2 and d != 2) else (0,)):
+            for dj in ((0, 1) if (dims > 1 and d != 1) else (0,)):
+                for di in ((0, 1) if d != 0 else (0,)):
+                    acc = acc + f[:, :, (fidx[2] + dk)[:, None, None], (fidx[1] + dj)[None, :, None],
+                                  (fidx[0] + di)[None, None, :]]
+                    cnt += 1
+        want = acc/cnt                                           # (nmb, nv, nk, nj, ni)
+        want = np.squeeze(want, axis=4 - d) if want.shape[4 - d] == 1 else want
+        assert np.allclose(o, want.reshape(o.shape), rtol=1e-15, atol=1e-15), d
+    for comp, box in _edge_boxes(a):
+        ext = [box[1] - box[0] + 1, box[3] - box[2] + 1, box[5] - box[4] + 1]
+        e = emf[comp].copy()
+        # constant along the edge direction
+        e[...] = np.take(e, [0], axis=3 - comp) if comp < dims else e
+        out = np.zeros((a["nmb"], ext[0]*ext[1]*ext[2]))
+        assert R.akref_restrict_emf(C.byref(a["pk"]), comp, akref.ptr(box), akref.ptr(e), akref.ptr(out)) == 0
+        o = out.reshape(a["nmb"], ext[2], ext[1], ext[0])
+        cs = [a["cis"], a["cjs"], a["cks"]]
+        fi = [2*np.arange(box[2*q], box[2*q + 1] + 1) - cs[q] if q < dims else np.zeros(1, dtype=int)
+              for q in range(3)]
+        want = e[:, fi[2][:, None, None], fi[1][None, :, None], fi[0][None, None, :]]
+        assert np.array_equal(o, want), comp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ng", [2, 3])
+@pytest.mark.parametrize("dims", [1, 2, 3])
+def test_hip_flux_restriction_matches_the_oracle(dims, ng):
+    import torch
+    from athenak_amd import capi
+    L, R = capi.lib(), akref.lib()
+    a = _setup(dims, ng=ng, seed=31 + dims)
+    flx, emf = _flux_arrays(a, np.random.default_rng(7))
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    dxd = t(a["dx"])
+    pkd = capi.Pack.from_buffer_copy(bytes(a["pk"]))
+    pkd.dx = dxd.data_ptr()
+    P, nv = C.byref(pkd), a["nvar"]
+    for d, box in _face_boxes(a):
+        n = nv*int(np.prod([box[2*q + 1] - box[2*q] + 1 for q in range(3)]))
+        out, outd = np.zeros((a["nmb"], n)), torch.zeros((a["nmb"], n), dtype=torch.float64, device="cuda")
+        R.akref_restrict_flux_cc(C.byref(a["pk"]), nv, d, akref.ptr(box), akref.ptr(flx[d]), akref.ptr(out))
+        capi.check(L.akmi_restrict_flux_cc(P, nv, d, box.ctypes.data_as(C.c_void_p), capi._p(t(flx[d])),
+                                           capi._p(outd), None), "restrict_flux_cc")
+        assert np.array_equal(out, outd.cpu().numpy()), d
+    for comp, box in _edge_boxes(a):
+        n = int(np.prod([box[2*q + 1] - box[2*q] + 1 for q in range(3)]))
+        out, outd = np.zeros((a["nmb"], n)), torch.zeros((a["nmb"], n), dtype=torch.float64, device="cuda")
+        R.akref_restrict_emf(C.byref(a["pk"]), comp, akref.ptr(box), akref.ptr(emf[comp]), akref.ptr(out))
+        capi.check(L.akmi_restrict_emf(P, comp, box.ctypes.data_as(C.c_void_p), capi._p(t(emf[comp])),
+                                       capi._p(outd), None), "restrict_emf")
+        assert np.array_equal(out, outd.cpu().numpy()), comp
+    # boxes outside the coarse index space are refused, not read
+    bad = np.array([0, 0, 0, 0, 0, 0], dtype=np.int32)
+    outd = torch.zeros(8, dtype=torch.float64, device="cuda")
+    assert L.akmi_restrict_flux_cc(P, nv, 0, bad.ctypes.data_as(C.c_void_p), capi._p(t(flx[0])),
+                                   capi._p(outd), None) != 0
