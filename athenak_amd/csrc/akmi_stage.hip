@@ -1146,11 +1146,14 @@ static int launch_hydro_stage3d(const Geo &g, const Scheme &sc, const double *w0
   int rc = dispatch_scheme<false>(sc, [&](auto R, auto S) {
     if constexpr (decltype(R)::value <= 1) {
       auto kern = k_hydro_stage3d<decltype(R)::value, decltype(S)::value>;
-      if (lds > 64*1024 &&
-          hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds) != hipSuccess) {
-        set_error("hydro_stage3d: %zu bytes of LDS refused", lds);
-        return AKMI_FAIL;
+      static size_t granted = 64*1024;                 // per instantiation; raised once per size
+      if (lds > granted) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) {
+          set_error("hydro_stage3d: %zu bytes of LDS refused", lds);
+          return AKMI_FAIL;
+        }
+        granted = lds;
       }
       kern<<<grid, block, lds, st>>>(g, sc.eos, w0, u, kA, kB, nchunk, ckl, tl.tw, tl.th);
       return AKMI_COMPLETE;
