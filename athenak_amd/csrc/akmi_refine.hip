@@ -322,6 +322,28 @@ static int check_flux_box(const CGeo &c, const int *box, const char *who) {
   return AKMI_COMPLETE;
 }
 
+// Primitive -> conserved over a box of fine cells: SingleP2C_* (src/eos/ideal_c2p_hyd.hpp:76-83,
+// ideal_c2p_mhd.hpp:75-84) as PrimToConsFineBndry applies them (src/bvals/prolong_prims.cpp:190-300)
+__global__ void k_prim2cons(Geo g, Box bx, int is_ideal, const double *__restrict__ w,
+                            const double *__restrict__ bcc, double *__restrict__ u) {
+  int m, v, k, j, i;
+  if (!box_index(bx, 1, m, v, k, j, i)) return;
+  const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
+  const double d = w[c], vx = w[c + cs], vy = w[c + 2*cs], vz = w[c + 3*cs];
+  u[c] = d; u[c + cs] = d*vx; u[c + 2*cs] = d*vy; u[c + 3*cs] = d*vz;
+  if (is_ideal) {
+    if (bcc) {
+      const size_t b = ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i);
+      const double bx_ = bcc[b], by = bcc[b + cs], bz = bcc[b + 2*cs];
+      u[c + 4*cs] = w[c + 4*cs] + 0.5*(d*(vx*vx + vy*vy + vz*vz) + (bx_*bx_ + by*by + bz*bz));
+    } else {
+      u[c + 4*cs] = w[c + 4*cs] + 0.5*d*(vx*vx + vy*vy + vz*vz);
+    }
+  }
+  for (int n = is_ideal ? 5 : 4; n < g.nvar; ++n) u[c + n*cs] = d*w[c + n*cs];
+}
+
 extern "C" {
 
 int akmi_restrict_cc(const akmi_pack *p, int nvar, const double *u, double *cu, void *stream) {
@@ -378,6 +400,21 @@ int akmi_restrict_emf(const akmi_pack *p, int comp, const int *box, const double
   else if (comp == 1) k_restrict_emf<1><<<grid, block, 0, st>>>(g, c, bx, e, out);
   else k_restrict_emf<2><<<grid, block, 0, st>>>(g, c, bx, e, out);
   AKMI_CHECK_LAUNCH("restrict_emf");
+  return AKMI_COMPLETE;
+}
+
+int akmi_prim2cons(const akmi_pack *p, const int *box, const double *w, const double *bcc, double *u,
+                   void *stream) {
+  Geo g = make_geo(p);
+  if (box[0] > box[1] || box[2] > box[3] || box[4] > box[5] || box[0] < 0 || box[1] >= g.N1 ||
+      box[2] < 0 || box[3] >= g.N2 || box[4] < 0 || box[5] >= g.N3) {
+    set_error("prim2cons: box [%d,%d]x[%d,%d]x[%d,%d] outside the block's cells", box[0], box[1], box[2],
+              box[3], box[4], box[5]);
+    return AKMI_FAIL;
+  }
+  const Box bx{box[0], box[1], box[2], box[3], box[4], box[5]};
+  k_prim2cons<<<box_grid(bx, 1, g.nmb), dim3(64, 4), 0, (hipStream_t)stream>>>(g, bx, p->is_ideal, w, bcc, u);
+  AKMI_CHECK_LAUNCH("prim2cons");
   return AKMI_COMPLETE;
 }
 

@@ -279,6 +279,12 @@ int akmi_restrict_flux_cc(const akmi_pack *p, int nvar, int dir, const int *box,
                           double *out, void *stream);
 int akmi_restrict_emf(const akmi_pack *p, int comp, const int *box, const double *e, double *out,
                       void *stream);
+/* Primitive -> conserved over the fine cells of `box` (il,iu,jl,ju,kl,ku): SingleP2C_IdealHyd/_IdealMHD/
+ * _Isothermal* (src/eos/ideal_c2p_hyd.hpp:76-83, ideal_c2p_mhd.hpp:75-84; scalars u = d*s), the step
+ * MeshBoundaryValuesCC::PrimToConsFineBndry performs after primitives were prolongated
+ * (src/bvals/prolong_prims.cpp:190-300,465-...).  bcc = NULL for hydro. */
+int akmi_prim2cons(const akmi_pack *p, const int *box, const double *w, const double *bcc, double *u,
+                   void *stream);
 /* ProlongCC (src/mesh/prolongation.hpp:19-63): min-mod limited linear interpolation */
 int akmi_prolong_cc(const akmi_pack *p, int nvar, const int *box, const double *cu, double *u,
                     void *stream);

@@ -67,6 +67,7 @@ int akref_restrict_cc(const akmi_pack *p, int nvar, const double *u, double *cu)
 int akref_restrict_flux_cc(const akmi_pack *p, int nvar, int dir, const int *box, const double *flx,
                            double *out);
 int akref_restrict_emf(const akmi_pack *p, int comp, const int *box, const double *e, double *out);
+int akref_prim2cons(const akmi_pack *p, const int *box, const double *w, const double *bcc, double *u);
 int akref_restrict_fc(const akmi_pack *p, const double *b1, const double *b2, const double *b3,
                       double *cb1, double *cb2, double *cb3);
 int akref_prolong_cc(const akmi_pack *p, int nvar, const int box[6], const double *cu, double *u);

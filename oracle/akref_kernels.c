@@ -2833,6 +2833,37 @@ int akref_restrict_emf(const akmi_pack *p, int comp, const int *box, const doubl
   return 0;
 }
 
+/* Primitive -> conserved over a box of fine cells (il,iu,jl,ju,kl,ku): SingleP2C_IdealHyd / _IdealMHD /
+ * _Isothermal* (src/eos/ideal_c2p_hyd.hpp:76-83, ideal_c2p_mhd.hpp:75-84) as MeshBoundaryValuesCC::
+ * PrimToConsFineBndry applies them after prolongating primitives (src/bvals/prolong_prims.cpp:190-300,
+ * 465-…); passive scalars u = d*s.  bcc == NULL: hydro.  TEST INFRASTRUCTURE. */
+int akref_prim2cons(const akmi_pack *p, const int *box, const double *w, const double *bcc, double *u) {
+  G g = mkG(p);
+  const int N1 = g.N1, N2 = g.N2, N3 = g.N3, nv = p->nvar;
+  const int nfl = p->is_ideal ? 5 : 4;
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = box[4]; k <= box[5]; ++k) for (int j = box[2]; j <= box[3]; ++j)
+      for (int i = box[0]; i <= box[1]; ++i) {
+#define W(n) w[ix5(nv,N3,N2,N1,m,n,k,j,i)]
+#define UU(n) u[ix5(nv,N3,N2,N1,m,n,k,j,i)]
+        const double d = W(0), vx = W(1), vy = W(2), vz = W(3);
+        UU(0) = d; UU(1) = d*vx; UU(2) = d*vy; UU(3) = d*vz;
+        if (p->is_ideal) {
+          if (bcc) {
+            const double bx = bcc[ix5(3,N3,N2,N1,m,0,k,j,i)], by = bcc[ix5(3,N3,N2,N1,m,1,k,j,i)],
+                         bz = bcc[ix5(3,N3,N2,N1,m,2,k,j,i)];
+            UU(4) = W(4) + 0.5*(d*(vx*vx + vy*vy + vz*vz) + (bx*bx + by*by + bz*bz));
+          } else {
+            UU(4) = W(4) + 0.5*d*(vx*vx + vy*vy + vz*vz);
+          }
+        }
+        for (int n = nfl; n < nv; ++n) UU(n) = d*W(n);
+#undef W
+#undef UU
+      }
+  return 0;
+}
+
 #define FB1(k,j,i) b1[ix4(N3,N2,N1+1,m,k,j,i)]
 #define FB2(k,j,i) b2[ix4(N3,N2+1,N1,m,k,j,i)]
 #define FB3(k,j,i) b3[ix4(N3+1,N2,N1,m,k,j,i)]

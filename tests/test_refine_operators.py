@@ -289,18 +289,93 @@ def test_hip_flux_restriction_matches_the_oracle(dims, ng):
         n = nv*int(np.prod([box[2*q + 1] - box[2*q] + 1 for q in range(3)]))
         out, outd = np.zeros((a["nmb"], n)), torch.zeros((a["nmb"], n), dtype=torch.float64, device="cuda")
         R.akref_restrict_flux_cc(C.byref(a["pk"]), nv, d, akref.ptr(box), akref.ptr(flx[d]), akref.ptr(out))
-        capi.check(L.akmi_restrict_flux_cc(P, nv, d, box.ctypes.data_as(C.c_void_p), capi._p(t(flx[d])),
+        fd = t(flx[d])
+        capi.check(L.akmi_restrict_flux_cc(P, nv, d, box.ctypes.data_as(C.c_void_p), capi._p(fd),
                                            capi._p(outd), None), "restrict_flux_cc")
         assert np.array_equal(out, outd.cpu().numpy()), d
     for comp, box in _edge_boxes(a):
         n = int(np.prod([box[2*q + 1] - box[2*q] + 1 for q in range(3)]))
         out, outd = np.zeros((a["nmb"], n)), torch.zeros((a["nmb"], n), dtype=torch.float64, device="cuda")
         R.akref_restrict_emf(C.byref(a["pk"]), comp, akref.ptr(box), akref.ptr(emf[comp]), akref.ptr(out))
-        capi.check(L.akmi_restrict_emf(P, comp, box.ctypes.data_as(C.c_void_p), capi._p(t(emf[comp])),
+        ed = t(emf[comp])
+        capi.check(L.akmi_restrict_emf(P, comp, box.ctypes.data_as(C.c_void_p), capi._p(ed),
                                        capi._p(outd), None), "restrict_emf")
         assert np.array_equal(out, outd.cpu().numpy()), comp
     # boxes outside the coarse index space are refused, not read
     bad = np.array([0, 0, 0, 0, 0, 0], dtype=np.int32)
     outd = torch.zeros(8, dtype=torch.float64, device="cuda")
-    assert L.akmi_restrict_flux_cc(P, nv, 0, bad.ctypes.data_as(C.c_void_p), capi._p(t(flx[0])),
+    fd = t(flx[0])
+    assert L.akmi_restrict_flux_cc(P, nv, 0, bad.ctypes.data_as(C.c_void_p), capi._p(fd),
                                    capi._p(outd), None) != 0
+
+
+# ---- primitive -> conserved of prolongated ghost cells --------------------------------------------
+def _p2c_numpy(w, bcc, ideal):
+    u = np.zeros_like(w)
+    d, vx, vy, vz = w[:, 0], w[:, 1], w[:, 2], w[:, 3]
+    u[:, 0], u[:, 1], u[:, 2], u[:, 3] = d, d*vx, d*vy, d*vz
+    nfl = 5 if ideal else 4
+    if ideal:
+        if bcc is None:
+            u[:, 4] = w[:, 4] + 0.5*d*(vx*vx + vy*vy + vz*vz)
+        else:
+            u[:, 4] = w[:, 4] + 0.5*(d*(vx*vx + vy*vy + vz*vz) +
+                                     (bcc[:, 0]*bcc[:, 0] + bcc[:, 1]*bcc[:, 1] + bcc[:, 2]*bcc[:, 2]))
+    for n in range(nfl, w.shape[1]):
+        u[:, n] = d*w[:, n]
+    return u
+
+
+def _p2c_case(dims, mhd, ideal, nscal, seed):
+    nx1, nx2, nx3 = DIMS[dims]
+    ng, nmb = 2, 2
+    nv = (5 if ideal else 4) + nscal
+    pk, dx = akref.make_pack(nmb, nx1, nx2, nx3, ng, np.ones((nmb, 3)), 1.4, nvar=nv)
+    pk.is_ideal = int(ideal)
+    N1, N2, N3 = nx1 + 2*ng, (nx2 + 2*ng if nx2 > 1 else 1), (nx3 + 2*ng if nx3 > 1 else 1)
+    rng = np.random.default_rng(seed)
+    w = rng.normal(size=(nmb, nv, N3, N2, N1))
+    w[:, 0] = np.abs(w[:, 0]) + 0.1
+    bcc = rng.normal(size=(nmb, 3, N3, N2, N1)) if mhd else None
+    box = np.array([0, ng - 1, 0, N2 - 1, 0, N3 - 1], dtype=np.int32)        # the inner-x1 ghost cells
+    return pk, dx, w, bcc, box
+
+
+@pytest.mark.parametrize("mhd,ideal,nscal", [(False, True, 0), (True, True, 0), (False, False, 2), (True, True, 1)])
+@pytest.mark.parametrize("dims", [1, 3])
+def test_prim2cons_is_the_reference_formula(dims, mhd, ideal, nscal):
+    R = akref.lib()
+    pk, dx, w, bcc, box = _p2c_case(dims, mhd, ideal, nscal, 41)
+    u = np.full_like(w, 7.0)
+    assert R.akref_prim2cons(C.byref(pk), akref.ptr(box), akref.ptr(w), akref.ptr(bcc) if mhd else None,
+                             akref.ptr(u)) == 0
+    want = _p2c_numpy(w, bcc, ideal)
+    sl = (slice(None), slice(None), slice(box[4], box[5] + 1), slice(box[2], box[3] + 1), slice(box[0], box[1] + 1))
+    assert np.array_equal(u[sl], want[sl])
+    mask = np.ones_like(u, dtype=bool)
+    mask[sl] = False
+    assert np.all(u[mask] == 7.0), "cells outside the box are not touched"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mhd,ideal,nscal", [(False, True, 0), (True, True, 0), (False, False, 2), (True, True, 1)])
+@pytest.mark.parametrize("dims", [1, 2, 3])
+def test_hip_prim2cons_matches_the_oracle(dims, mhd, ideal, nscal):
+    import torch
+    from athenak_amd import capi
+    L, R = capi.lib(), akref.lib()
+    pk, dx, w, bcc, box = _p2c_case(dims, mhd, ideal, nscal, 43)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    dxd = t(dx)
+    pkd = capi.Pack.from_buffer_copy(bytes(pk))
+    pkd.dx = dxd.data_ptr()
+    u = np.full_like(w, 7.0)
+    ud = t(u)
+    R.akref_prim2cons(C.byref(pk), akref.ptr(box), akref.ptr(w), akref.ptr(bcc) if mhd else None, akref.ptr(u))
+    wd, bd = t(w), (t(bcc) if mhd else None)         # named: the device arrays must outlive the launch
+    capi.check(L.akmi_prim2cons(C.byref(pkd), box.ctypes.data_as(C.c_void_p), capi._p(wd),
+                                capi._p(bd) if mhd else None, capi._p(ud), None), "prim2cons")
+    assert np.array_equal(u, ud.cpu().numpy())
+    bad = np.array([0, 10**6, 0, 0, 0, 0], dtype=np.int32)
+    assert L.akmi_prim2cons(C.byref(pkd), bad.ctypes.data_as(C.c_void_p), capi._p(wd), None, capi._p(ud),
+                            None) != 0
