@@ -112,16 +112,16 @@ def cpu_baseline(args, blk):
         return n**3*cyc/dt/1e6, cyc
 
     # the oracle's OpenMP loops run over (block, k) planes: at most n-way parallel
-    candidates = sorted({1, min(navail, 16), min(navail, n)})
+    candidates = sorted({1, min(navail, 16), min(navail, 32), min(navail, n)})
     best = None
     results = []
     for th in candidates:
-        v, cyc = timed(th, 6.0)
+        v, cyc = timed(th, 5.0)
         results.append("%d thr: %.3f" % (th, v))
         if best is None or v > best[0]:
             best = (v, th, cyc)
     return {"value": round(best[0], 4), "unit": "Mcell-updates/s", "cores": best[1], "kind": "port",
-            "sample": "%s %d^3 RK2, ~6 s per thread count, oracle = port of the reference's "
+            "sample": "%s %d^3 RK2, ~5 s per thread count, oracle = port of the reference's "
                       "split-kernel CPU sequence with OpenMP; Mcell-updates/s by threads: %s "
                       "(host has %d usable cores)" % (args.problem, n, "; ".join(results), navail)}
 
