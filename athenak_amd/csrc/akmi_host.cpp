@@ -349,7 +349,7 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
   nfluid = e.is_ideal ? 5 : 4;                 // no energy variable with the isothermal EOS
   nvars = nfluid + nscalars;                   // scalars follow the fluid variables
   // diffusion objects: hydro.cpp:77-98, mhd.cpp:104-130 (constant isotropic coefficients)
-  for (const char *n : {"nu_aniso", "alpha_aniso", "alpha_spitzer", "eta_ad"})
+  for (const char *n : {"nu_aniso", "alpha_aniso", "alpha_spitzer"})
     if (pin->DoesParameterExist(blk, n))
       AKMI_FATAL(std::string("<") + blk + ">/" + n + " is not on this path");
   if (pin->DoesParameterExist(blk, "nu_iso")) { has_visc = true; nu_iso = pin->GetReal(blk, "nu_iso"); }
@@ -357,8 +357,11 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
     if (!e.is_ideal) AKMI_FATAL("Thermal conduction requires ideal gas EOS");
     has_cond = true; alpha_iso = pin->GetReal(blk, "alpha_iso"); dtmin_cond.Realloc(1);
   }
-  if (blk == "mhd" && pin->DoesParameterExist(blk, "eta_ohm")) {
-    has_resist = true; eta_ohm = pin->GetReal(blk, "eta_ohm");
+  if (blk == "mhd" && (pin->DoesParameterExist(blk, "eta_ohm") || pin->DoesParameterExist(blk, "eta_ad"))) {
+    has_resist = true;                                       // mhd.cpp:121-130, resistivity.cpp:24-36
+    eta_ohm = pin->GetOrAddReal(blk, "eta_ohm", 0.0);
+    eta_ad = pin->GetOrAddReal(blk, "eta_ad", 0.0);
+    dtmin_cond.Realloc(1);                                   // scratch double of the cell reductions
   }
   fused = pin->GetOrAddBoolean(blk, "fused_stage", true);
   // the fused stage kernels are specialised for the ideal-gas variable set without extra fluxes
@@ -421,7 +424,15 @@ void FluidBase::DiffusionNewDt() {     // viscosity.cpp:232-251, conduction.cpp:
     return dt;
   };
   if (has_visc) dt_visc = nu_iso != 0.0 ? const_dt(nu_iso) : static_cast<Real>(FLT_MAX);
-  if (has_resist) dt_resist = eta_ohm > 0.0 ? const_dt(eta_ohm) : static_cast<Real>(FLT_MAX);
+  if (has_resist && eta_ad == 0.0) {                         // resistivity.cpp:298-311
+    dt_resist = eta_ohm > 0.0 ? const_dt(eta_ohm) : static_cast<Real>(FLT_MAX);
+  } else if (has_resist) {                                   // resistivity.cpp:313-345
+    AKCHK(akmi_resistive_newdt(&pack_c, eta_ohm, eta_ad, bcc_cells, dtmin_cond.p, stream));
+    Real d;
+    HIPCHK(hipMemcpyAsync(&d, dtmin_cond.p, sizeof(d), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    dt_resist = d*fac;
+  }
   if (has_cond) {
     if (alpha_iso != 0.0) {
       AKCHK(akmi_conduction_newdt(&pack_c, alpha_iso, w0.p, dtmin_cond.p, stream));
@@ -491,6 +502,7 @@ MHD::MHD(MeshBlockPack *pp, ParameterInput *pin) : FluidBase(pp, pin, "mhd") {
   const size_t n1 = ind.nx1 + 2*ind.ng, n2 = ind.nx2 > 1 ? ind.nx2 + 2*ind.ng : 1,
                n3 = ind.nx3 > 1 ? ind.nx3 + 2*ind.ng : 1;
   bcc0.Realloc(nmb*3*n3*n2*n1);
+  bcc_cells = bcc0.p;
   FaceAlloc(b0, nmb, 1, n3, n2, n1, 1);
   FaceAlloc(b1, nmb, 1, n3, n2, n1, 1);
   if (fused) {
@@ -712,6 +724,9 @@ TaskStatus MHD::Fluxes(Driver *d, int stage) {             // mhd_tasks.cpp:177-
   if (has_resist && eta_ohm != 0.0 && peos->eos_data.is_ideal)   // mhd_tasks.cpp:204-206
     AKCHK(akmi_resistive_fluxes(&pack_c, eta_ohm, b0.x1f.p, b0.x2f.p, b0.x3f.p, uflx.x1f.p,
                                 uflx.x2f.p, uflx.x3f.p, stream));
+  if (has_resist && eta_ad != 0.0 && peos->eos_data.is_ideal)    // resistivity.cpp:67-69
+    AKCHK(akmi_ambipolar_fluxes(&pack_c, eta_ad, bcc0.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, uflx.x1f.p,
+                                uflx.x2f.p, uflx.x3f.p, stream));
   if (use_fofc) {                                           // mhd_tasks.cpp:209-211
     AKCHK(akmi_mhd_fofc(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1],
                         d->beta[stage - 1]*pmy_pack->pmesh->dt, w0.p, bcc0.p, b0.x1f.p, b0.x2f.p,
@@ -748,6 +763,9 @@ TaskStatus MHD::EField(Driver *d, int stage) {             // mhd_corner_e.cpp:2
   if (!fused && has_resist && eta_ohm != 0.0)               // mhd_tasks.cpp:381-383
     AKCHK(akmi_resistive_emfs(&pack_c, eta_ohm, b0.x1f.p, b0.x2f.p, b0.x3f.p, efld.x1e.p, efld.x2e.p,
                               efld.x3e.p, stream));
+  if (!fused && has_resist && eta_ad != 0.0)                // resistivity.cpp:52-54
+    AKCHK(akmi_ambipolar_emfs(&pack_c, eta_ad, bcc0.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, efld.x1e.p,
+                              efld.x2e.p, efld.x3e.p, stream));
   return TaskStatus::complete;
 }
 TaskStatus MHD::CT(Driver *d, int stage) {                 // mhd_ct.cpp:23-80

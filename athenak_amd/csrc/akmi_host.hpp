@@ -197,7 +197,8 @@ class FluidBase {
   int nfluid = 5, nscalars = 0, nvars = 5;   // nhydro|nmhd (4 isothermal), passive scalars
   // constant-coefficient diffusion (src/diffusion): objects exist when the parameter is in the deck
   bool has_visc = false, has_cond = false, has_resist = false;
-  Real nu_iso = 0.0, alpha_iso = 0.0, eta_ohm = 0.0;
+  Real nu_iso = 0.0, alpha_iso = 0.0, eta_ohm = 0.0, eta_ad = 0.0;
+  const Real *bcc_cells = nullptr;     // MHD: cell-centred field, for the ambipolar time step
   Real dt_visc = static_cast<Real>(FLT_MAX), dt_cond = static_cast<Real>(FLT_MAX),
        dt_resist = static_cast<Real>(FLT_MAX);
   DvceArray<Real> dtmin_cond;

@@ -230,8 +230,6 @@ def test_diffusion_hooks_are_bit_identical(case, native):
     """akmi_viscous_fluxes / akmi_heat_fluxes / akmi_resistive_fluxes / akmi_resistive_emfs /
     akmi_conduction_newdt inside the task chain, and the diffusive time-step limits"""
     problem, n, dims, mb, cycles, kw, params = case
-    if native and "eta_ad" in params:
-        pytest.skip("ambipolar diffusion runs on the Python host (the C++ host exits with FATAL ERROR)")
     sim, osim, is_mhd = pu.make_pair(problem, n, dims, mb, params=params, native=native, **kw)
     assert (sim.dt if native else sim.pmesh.dt) == osim.dt
     for _ in range(cycles):
