@@ -455,7 +455,12 @@ static void FaceFree(DvceFaceFld &f) { f.x1f.Free(); f.x2f.Free(); f.x3f.Free();
 namespace hydro {
 Hydro::Hydro(MeshBlockPack *pp, ParameterInput *pin) : FluidBase(pp, pin, "hydro") {
   const std::string rs = pin->GetString("hydro", "rsolver");
-  if (rs == "llf") rsolver_method = AKMI_RS_LLF;
+  // dynamic problems: llf/hlle/hllc/roe; kinematic problems: advect (hydro.cpp:244-278)
+  kinematic = pin->GetOrAddString("time", "evolution", "dynamic") == "kinematic";
+  if (kinematic) {
+    if (rs != "advect") AKMI_FATAL("<hydro> rsolver = '" + rs + "' not implemented for kinematic problems");
+    rsolver_method = AKMI_RS_ADVECT; fused = false;
+  } else if (rs == "llf") rsolver_method = AKMI_RS_LLF;
   else if (rs == "hlle") rsolver_method = AKMI_RS_HLLE;
   else if (rs == "hllc") rsolver_method = AKMI_RS_HLLC;
   else if (rs == "roe") rsolver_method = AKMI_RS_ROE;
@@ -493,7 +498,12 @@ void Hydro::AssembleHydroTasks(std::map<std::string, std::shared_ptr<TaskList>> 
 namespace mhd {
 MHD::MHD(MeshBlockPack *pp, ParameterInput *pin) : FluidBase(pp, pin, "mhd") {
   const std::string rs = pin->GetString("mhd", "rsolver");
-  if (rs == "llf") rsolver_method = AKMI_RS_LLF;
+  // dynamic problems: llf/hlle/hlld; kinematic problems: advect (mhd.cpp:292-326)
+  kinematic = pin->GetOrAddString("time", "evolution", "dynamic") == "kinematic";
+  if (kinematic) {
+    if (rs != "advect") AKMI_FATAL("<mhd> rsolver = '" + rs + "' not implemented for kinematic problems");
+    rsolver_method = AKMI_RS_ADVECT; fused = false;
+  } else if (rs == "llf") rsolver_method = AKMI_RS_LLF;
   else if (rs == "hlle") rsolver_method = AKMI_RS_HLLE;
   else if (rs == "hlld") rsolver_method = AKMI_RS_HLLD;
   else AKMI_FATAL("<mhd> rsolver = '" + rs + "' not implemented (llf, hlle, hlld)");
@@ -552,8 +562,11 @@ void MHD::AssembleMHDTasks(std::map<std::string, std::shared_ptr<TaskList>> tl) 
 
 // ---- Driver -----------------------------------------------------------------------------------
 Driver::Driver(ParameterInput *pin, Mesh *pmesh) {       // driver.cpp:85-162
-  if (pin->GetOrAddString("time", "evolution", "dynamic") != "dynamic")
-    AKMI_FATAL("<time> evolution must be dynamic on this path");
+  {
+    const std::string ev = pin->GetOrAddString("time", "evolution", "dynamic");
+    if (ev != "dynamic" && ev != "kinematic")
+      AKMI_FATAL("<time> evolution = '" + ev + "' is not on this path (dynamic, kinematic)");
+  }
   integrator = pin->GetOrAddString("time", "integrator", "rk2");
   tlim = pin->GetReal("time", "tlim");
   nlim = pin->GetOrAddInteger("time", "nlim", -1);
@@ -692,7 +705,8 @@ TaskStatus Hydro::ConToPrim(Driver *d, int stage) {        // hydro_tasks.cpp:40
 }
 TaskStatus Hydro::NewTimeStep(Driver *d, int stage) {      // hydro_newdt.cpp:30-139
   if (stage != d->nexp_stages) return TaskStatus::complete;
-  if (!dt_ready_) AKCHK(akmi_hydro_newdt(&pack_c, w0.p, dt3.p, stream));
+  if (kinematic) AKCHK(akmi_kinematic_newdt(&pack_c, w0.p, dt3.p, stream));      // hydro_newdt.cpp:55-72
+  else if (!dt_ready_) AKCHK(akmi_hydro_newdt(&pack_c, w0.p, dt3.p, stream));
   dt_ready_ = false;
   FinishNewDt();
   DiffusionNewDt();
@@ -805,7 +819,8 @@ TaskStatus MHD::ConToPrim(Driver *d, int stage) {
 }
 TaskStatus MHD::NewTimeStep(Driver *d, int stage) {        // mhd_newdt.cpp:31-174
   if (stage != d->nexp_stages) return TaskStatus::complete;
-  if (!dt_ready_) AKCHK(akmi_mhd_newdt(&pack_c, w0.p, bcc0.p, dt3.p, stream));
+  if (kinematic) AKCHK(akmi_kinematic_newdt(&pack_c, w0.p, dt3.p, stream));      // mhd_newdt.cpp:56-73
+  else if (!dt_ready_) AKCHK(akmi_mhd_newdt(&pack_c, w0.p, bcc0.p, dt3.p, stream));
   dt_ready_ = false;
   FinishNewDt();
   DiffusionNewDt();

@@ -199,6 +199,7 @@ class FluidBase {
   bool has_visc = false, has_cond = false, has_resist = false;
   Real nu_iso = 0.0, alpha_iso = 0.0, eta_ohm = 0.0, eta_ad = 0.0;
   const Real *bcc_cells = nullptr;     // MHD: cell-centred field, for the ambipolar time step
+  bool kinematic = false;              // <time>/evolution = kinematic: advect solvers, velocity-only dt
   Real dt_visc = static_cast<Real>(FLT_MAX), dt_cond = static_cast<Real>(FLT_MAX),
        dt_resist = static_cast<Real>(FLT_MAX);
   DvceArray<Real> dtmin_cond;

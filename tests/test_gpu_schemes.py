@@ -259,12 +259,13 @@ KINEMATIC = [
 ]
 
 
+@pytest.mark.parametrize("native", [False, True], ids=["py", "cpp"])
 @pytest.mark.parametrize("case", KINEMATIC, ids=lambda c: "%s-%d^%d" % (c[0], c[1], c[2]))
-def test_kinematic_advect_runs_are_bit_identical(case):
+def test_kinematic_advect_runs_are_bit_identical(case, native):
     """advect_hyd + akmi_kinematic_newdt (+ the diffusion adders, which is what kinematic runs are for)"""
     problem, n, dims, mb, cycles, kw, params = case
-    sim, osim, is_mhd = pu.make_pair(problem, n, dims, mb, params=params, **kw)
-    assert sim.pmesh.dt == osim.dt
+    sim, osim, is_mhd = pu.make_pair(problem, n, dims, mb, params=params, native=native, **kw)
+    assert (sim.dt if native else sim.pmesh.dt) == osim.dt
     for _ in range(cycles):
         assert sim.Execute(max_cycles=1) and osim.step()
         assert sim.pmesh.dt == osim.dt
