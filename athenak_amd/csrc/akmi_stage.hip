@@ -235,6 +235,17 @@ k_sweep(Geo g, FaceEos eos, SweepArgs a, int nk) {
   }
 }
 
+#ifndef AKMI_POW2DX
+#define AKMI_POW2DX 0           // two copies of the loop cost more (register allocation) than the 15 divisions
+#endif
+// true when x is a normal power of two, i.e. 1/x is exact (mantissa bits all zero)
+__host__ __device__ inline bool is_pow2(double x) {
+  unsigned long long b;
+  memcpy(&b, &x, sizeof b);
+  const unsigned e = (unsigned)((b >> 52) & 0x7ff);
+  return (b & 0xfffffffffffffull) == 0 && e > 1 && e < 2046 && (b >> 63) == 0;
+}
+
 struct UpdArgs {
   double gam0, gam1, beta_dt;
   double *u0, *u1;
@@ -256,6 +267,12 @@ struct UpdArgs {
 #endif
 #ifndef AKMI_PREFETCH_UPD
 #define AKMI_PREFETCH_UPD 1
+#endif
+#ifndef AKMI_PREFETCH_U1
+#define AKMI_PREFETCH_U1 0      // +10 VGPRs: spills at 3 waves/SIMD, x3 march 1.07 -> 1.20 ms (profiles/r02_ab2.txt)
+#endif
+#ifndef AKMI_MARCH_WAVES
+#define AKMI_MARCH_WAVES 3
 #endif
 #ifndef AKMI_PREFETCH_X1
 #define AKMI_PREFETCH_X1 0
@@ -335,9 +352,9 @@ static int march_len(long col_blocks, int ncells, int nmb, int lmax, int wgs_per
 // MODE 0: last direction -- finish the RK update.  MODE 1 (x2 sweep of 3-D runs): store the
 // partial divergence acc = dF1/dx1 + dF2/dx2 for the x3 march, which then needs one array
 // instead of two face pairs per variable (USEACC).  Rounding sequence unchanged.
-template <int DIR, int RECON, bool MHD, int MODE, bool USEACC, int RS>
-__global__ void __launch_bounds__(SX*SY, (RECON >= 2 ? 2 : 3))
-k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int ml) {
+template <int DIR, int RECON, bool MHD, int MODE, bool USEACC, int RS, bool P2>
+__device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &eos, const SweepArgs &a,
+                                                  const UpdArgs &u, int ml, double *sm) {
   static_assert(DIR == 1 || DIR == 2, "marching kernel is for the x2/x3 sweeps");
   int i, j, k, m, s0;
   bool lane_ok;
@@ -372,7 +389,6 @@ k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int ml) {
   //   FP(n)   flux of the previous face
   // Keeping it out of the VGPRs lets the kernel run at the occupancy of the plain Riemann
   // kernel while every cell is loaded from HBM exactly once per sweep.
-  __shared__ double sm[(NV*NW + NV + 5)*NT];
   double *my = sm + threadIdx.y*SX + threadIdx.x;
 #define W_(n, c) my[((n)*NW + (c))*NT]
 #define PL_(n) my[(NV*NW + (n))*NT]
@@ -382,6 +398,8 @@ k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int ml) {
                           ((DIR == 1) ? (k >= g.ks && k <= g.ke) : (j >= g.js && j <= g.je));
   const int clo = (DIR == 1) ? g.js : g.ks, chi = (DIR == 1) ? g.je : g.ke;
   const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
+  constexpr bool p2 = P2;             // the launcher checked that dx1, dx2, dx3 are powers of two
+  const double rdx1 = 1.0/dx1, rdx2 = 1.0/dx2, rdx3 = 1.0/dx3;
   const size_t cs = (size_t)g.N3*g.N2*g.N1;
   const long st = (DIR == 1) ? (long)g.N1 : (long)g.N1*g.N2;
   // wave-uniform variable bases in sweep-aligned order d, vx, vy, vz, e, (by, bz) + one
@@ -453,12 +471,16 @@ k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int ml) {
     constexpr bool PRE = (DIR == 2) && USEACC && (MODE == 0) && AKMI_PREFETCH_UPD;
     const int sc = s - 1;                               // cell finished by this face
     const bool upd = t > 0 && col_active && sc >= clo && sc <= chi;
-    double pa[5], pu[5];
+    double pa[5], pu[5], pu1[5];
     if constexpr (PRE) {
       if (upd) {
         const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, sc, j, i);
 #pragma unroll
         for (int n = 0; n < 5; ++n) { pa[n] = u.acc[c + n*cs]; pu[n] = u.u0[c + n*cs]; }
+        if (AKMI_PREFETCH_U1 && !u.copy_u1) {
+#pragma unroll
+          for (int n = 0; n < 5; ++n) pu1[n] = u.u1[c + n*cs];
+        }
       }
     }
     // x2 march of 3-D runs: same idea for the x1 flux difference of the finished cell
@@ -468,7 +490,10 @@ k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int ml) {
         const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k, sc, i);
         const size_t fs1 = (size_t)g.N3*g.N2*(g.N1 + 1);
 #pragma unroll
-        for (int n = 0; n < 5; ++n) pa[n] = (u.flx1[c + n*fs1 + 1] - u.flx1[c + n*fs1])/dx1;
+        for (int n = 0; n < 5; ++n) {
+          const double d1 = u.flx1[c + n*fs1 + 1] - u.flx1[c + n*fs1];
+          pa[n] = p2 ? d1*rdx1 : d1/dx1;
+        }
       }
     }
     double fd, fx, fy, fz, fe;
@@ -501,23 +526,28 @@ k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int ml) {
         } else if constexpr (USEACC) {
           divf = u.acc[c + n*cs];
         } else {
-          divf = (u.flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, n, kc, jc, i + 1)] -
-                  u.flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, n, kc, jc, i)])/dx1;
+          const double d1 = u.flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, n, kc, jc, i + 1)] -
+                            u.flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, n, kc, jc, i)];
+          divf = p2 ? d1*rdx1 : d1/dx1;
         }
         if constexpr (DIR == 1) {
-          divf += (fv[n] - fprev)/dx2;
+          divf += p2 ? (fv[n] - fprev)*rdx2 : (fv[n] - fprev)/dx2;
         } else {
-          if constexpr (!USEACC)
-            divf += (u.flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, n, kc, jc + 1, i)] -
-                     u.flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, n, kc, jc, i)])/dx2;
-          divf += (fv[n] - fprev)/dx3;
+          if constexpr (!USEACC) {
+            const double d2 = u.flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, n, kc, jc + 1, i)] -
+                              u.flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, n, kc, jc, i)];
+            divf += p2 ? d2*rdx2 : d2/dx2;
+          }
+          divf += p2 ? (fv[n] - fprev)*rdx3 : (fv[n] - fprev)/dx3;
         }
         if constexpr (MODE == 1) {
           u.acc[c + n*cs] = divf;
         } else {
           double u0v;
           if constexpr (PRE) u0v = pu[n]; else u0v = u.u0[c + n*cs];
-          const double u1v = u.copy_u1 ? u0v : u.u1[c + n*cs];
+          double u1v;
+          if constexpr (PRE && AKMI_PREFETCH_U1) u1v = u.copy_u1 ? u0v : pu1[n];
+          else u1v = u.copy_u1 ? u0v : u.u1[c + n*cs];
           if (u.copy_u1) u.u1[c + n*cs] = u0v;
           u.u0[c + n*cs] = u.gam0*u0v + u.gam1*u1v - u.beta_dt*divf;
         }
@@ -529,6 +559,233 @@ k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int ml) {
 #undef W_
 #undef PL_
 #undef FP_
+}
+
+// the kernel proper: when the cell sizes of the block are powers of two, x/dx == x*(1/dx) bit for
+// bit (both are the correctly rounded value of the same real number, and 1/dx is exact), so the
+// divisions by dx become products; decided per block, two copies of the loop
+template <int DIR, int RECON, bool MHD, int MODE, bool USEACC, int RS>
+__global__ void __launch_bounds__(SX*SY, (RECON >= 2 ? 2 : AKMI_MARCH_WAVES))
+k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int ml) {
+  constexpr int NV = MHD ? 7 : 5;
+  __shared__ double sm[(NV*RollCfg<RECON>::NW + NV + 5)*SX*SY];
+  const int m = blockIdx.z;
+  constexpr bool TRY = AKMI_POW2DX && MHD && MODE == 0 && USEACC;     // the x3 march of the MHD stage
+  if (TRY && is_pow2(g.dx[3*m]) && is_pow2(g.dx[3*m + 1]) && is_pow2(g.dx[3*m + 2]))
+    sweep_update_body<DIR, RECON, MHD, MODE, USEACC, RS, TRY>(g, eos, a, u, ml, sm);
+  else
+    sweep_update_body<DIR, RECON, MHD, MODE, USEACC, RS, false>(g, eos, a, u, ml, sm);
+}
+
+// ---------------------------------------------------------------------------------------
+// MHD, 3-D: the x1 sweep folded into the x2 march (k_sweep12).  Lanes run over the flattened
+// (k,i) rows as in the x2 march; while a thread walks along j it also solves the x1 face on the
+// low side of its cell in row s-1 (the row whose cells the step finishes):
+//   * the limited states of a cell serve both of its x1 faces, so a lane reconstructs ITS cell
+//     and takes the left state of its face from the lane below (__shfl_up), as the x1 sweep does;
+//   * the x1 flux difference of the cell is F1(lane+1) - F1(lane) (__shfl_down): the 5-component
+//     x1 flux array (5 doubles written, 5+ read per cell) disappears, and w0/bcc0 are fetched
+//     from HBM once for both directions (the second access of a row hits L1/L2);
+//   * waves overlap by two lanes (lane 0 only provides a left state, lane 63 only a face):
+//     62 cells per wave.
+// Still stored for CornerE: the mass flux and the two face EMFs of both directions, the
+// cell-centred EMFs.  acc = dF1/dx1 + dF2/dx2 goes to the x3 march as before; the rounding
+// sequence of hydro_update.cpp:55-80 is unchanged.
+template <int RECON>
+__device__ __forceinline__ void cell_lr_x1(const double *__restrict__ q, const FaceEos &eos, int n,
+                                           double &ql_ip1, double &qr_i) {
+  if constexpr (RECON == 1) {
+    plm(q[-1], q[0], q[1], ql_ip1, qr_i);
+  } else if constexpr (RECON >= 2) {
+    recon5<RECON>(q[-2], q[-1], q[0], q[1], q[2], ql_ip1, qr_i);
+    if (n == 0) floor_lr<RECON, 1>(eos, ql_ip1, qr_i);
+    if (n == 4) floor_lr<RECON, 2>(eos, ql_ip1, qr_i);
+  } else {
+    ql_ip1 = q[0];
+    qr_i = q[0];
+  }
+}
+
+#ifndef AKMI_X12_WAVES
+#define AKMI_X12_WAVES 3
+#endif
+template <int RECON, int RS, bool P2>
+__device__ __forceinline__ void sweep12_body(const Geo &g, const FaceEos &eos, const SweepArgs &a1,
+                                             const SweepArgs &a2, const UpdArgs &u, int ml, double *sm) {
+  constexpr int NV = 7;
+  constexpr int NW = RollCfg<RECON>::NW;
+  constexpr int NT = SX*SY;
+  constexpr int CPW = SX - 2;                              // cells per wave
+  const int lane = threadIdx.x;
+  const long wv = (long)blockIdx.x*SY + threadIdx.y;       // wave index over the (k,i) rows
+  long p = wv*CPW + lane - 1;
+  const long np = (long)(a2.ku - a2.kl + 1)*g.N1;
+  if (wv*CPW - 1 >= np) return;                            // whole wave beyond the planes
+  if (p < 0) p = 0;
+  if (p > np - 1) p = np - 1;                              // clamped lanes compute, never store
+  const int kk = (int)(p/g.N1);
+  const int i = (int)(p - (long)kk*g.N1);
+  const int k = a2.kl + kk;
+  const int m = blockIdx.z;
+  const int s0 = a2.jl + blockIdx.y*ml;
+  const int shi = a2.ju;                                   // last x2 face
+  const bool inner = lane >= 1 && lane <= SX - 2 && (wv*CPW + lane - 1 == p);
+  const bool x2_ok = inner && i >= a2.il && i <= a2.iu;    // owns the x2 faces of this column
+  const bool x1_ok = inner && i >= a1.il && i <= a1.iu;    // owns the x1 faces of this column
+  const bool col_active = inner && i >= g.is && i <= g.ie && k >= g.ks && k <= g.ke;
+  double *my = sm + threadIdx.y*SX + threadIdx.x;
+#define W_(n, c) my[((n)*NW + (c))*NT]
+#define PL_(n) my[(NV*NW + (n))*NT]
+#define FP_(n) my[(NV*NW + NV + (n))*NT]
+  const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1];
+  const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  const long st = (long)g.N1;
+  const double *wb = a2.w0 + (size_t)m*g.nvar*cs;
+  const double *bb = a2.bcc0 + (size_t)m*3*cs;
+  // x2-aligned order of the march: d, vy, vz, vx, e, bz, bx
+  auto base2 = [&](int n) -> const double * {
+    return n == 0 ? wb : n == 1 ? wb + 2*cs : n == 2 ? wb + 3*cs : n == 3 ? wb + cs
+         : n == 4 ? wb + 4*cs : n == 5 ? bb + 2*cs : bb;
+  };
+  // x1-aligned order: d, vx, vy, vz, e, by, bz
+  auto base1 = [&](int n) -> const double * { return n < 5 ? wb + n*cs : bb + (n - 4)*cs; };
+  size_t off = ((size_t)k*g.N2 + s0)*g.N1 + i;
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    const double *q = base2(n) + off;
+    double pl, dummy;
+    if constexpr (RECON == 1) {
+      const double qa = q[-2*st], qb = q[-st], qc = q[0];
+      plm(qa, qb, qc, pl, dummy);
+      W_(n, 0) = qb; W_(n, 1) = qc;
+    } else if constexpr (RECON >= 2) {
+      const double qa = q[-3*st], qb = q[-2*st], qc = q[-st], qd = q[0], qe = q[st];
+      recon5<RECON>(qa, qb, qc, qd, qe, pl, dummy);
+      if (n == 0) floor_lr<RECON, 1>(eos, pl, dummy);
+      if (n == 4) floor_lr<RECON, 2>(eos, pl, dummy);
+      W_(n, 0) = qb; W_(n, 1) = qc; W_(n, 2) = qd; W_(n, 3) = qe;
+    } else {
+      pl = q[-st];
+      W_(n, 0) = q[0];
+    }
+    PL_(n) = pl;
+  }
+  const size_t f2st = (size_t)a2.f1;
+  const double *pbx2 = a2.bxf + ix4(a2.f3, a2.f2, a2.f1, m, k, s0, i);
+  // dx a power of two: x/dx == x*(1/dx) bit for bit (both are the correctly rounded value of the
+  // same real number), and the reciprocal is exact -- ten divisions per cell become products
+  constexpr bool p2 = P2;             // the launcher checked that dx1 and dx2 are powers of two
+  const double rdx1 = 1.0/dx1, rdx2 = 1.0/dx2;
+  for (int t = 0;; ++t) {
+    const int s = s0 + t;
+    if (s > shi + 1) break;                   // the last chunk ends with the x1 faces of row ju(x1)
+    if (t > ml && s <= shi) break;            // the others end with the face they share
+    // every step runs both solves on memory that exists; what a step may keep is decided at the
+    // stores (one basic block: the loads of both directions are issued together)
+    const bool do_x2 = s <= shi;
+    const int jr = s - 1;                     // row of the x1 faces of this step
+    const bool do_x1 = (t >= 1 || s0 == a2.jl) && jr >= a1.jl && jr <= a1.ju;
+    const size_t orow = ((size_t)k*g.N2 + jr)*g.N1 + i;
+    // ---- x1 face on the low side of cell (k, jr, i)
+    double qln[NV], qr[NV], q0[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const double *q = base1(n) + orow;
+      q0[n] = q[0];
+      cell_lr_x1<RECON>(q, eos, n, qln[n], qr[n]);
+    }
+    const double bxc = bb[orow];
+    const double bx1 = a1.bxf[ix4(a1.f3, a1.f2, a1.f1, m, k, jr, i)];
+    double L1[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) L1[n] = __shfl_up(qln[n], 1, 64);
+    Cons1D f1 = riemann_mhd<RS>(eos.gamma, L1[0], L1[1], L1[2], L1[3], L1[4], L1[5], L1[6], qr[0],
+                                qr[1], qr[2], qr[3], qr[4], qr[5], qr[6], bx1);
+    double dF1[5];
+    dF1[0] = __shfl_down(f1.d, 1, 64) - f1.d;
+    dF1[1] = __shfl_down(f1.mx, 1, 64) - f1.mx;
+    dF1[2] = __shfl_down(f1.my, 1, 64) - f1.my;
+    dF1[3] = __shfl_down(f1.mz, 1, 64) - f1.mz;
+    dF1[4] = __shfl_down(f1.e, 1, 64) - f1.e;
+    if (do_x1) {
+      if (inner && i >= a1.il - 1 && i <= a1.iu) {          // cell-centred E = -(v x B)
+        const size_t e = ix4(g.N3, g.N2, g.N1, m, k, jr, i);
+        a1.ecc1[e] = q0[3]*q0[5] - q0[2]*q0[6];
+        a1.ecc2[e] = q0[1]*q0[6] - q0[3]*bxc;
+        a1.ecc3[e] = q0[2]*bxc - q0[1]*q0[5];
+      }
+      if (x1_ok) {
+        a1.flx[ix5(g.nvar, a1.f3, a1.f2, a1.f1, m, 0, k, jr, i)] = f1.d;
+        const size_t ec = ix4(g.N3, g.N2, g.N1, m, k, jr, i);
+        a1.ey[ec] = -f1.by;
+        a1.ez[ec] = f1.bz;
+      }
+    }
+    // ---- x2 face s
+    double L[NV], R[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const double *q = base2(n) + off;
+      double qln2;
+      L[n] = PL_(n);
+      if constexpr (RECON == 1) {
+        const double qp = q[st];
+        const double w0 = W_(n, 0), w1 = W_(n, 1);
+        plm(w0, w1, qp, qln2, R[n]);
+        W_(n, 0) = w1; W_(n, 1) = qp;
+      } else if constexpr (RECON >= 2) {
+        const double qp = q[2*st];
+        const double w0 = W_(n, 0), w1 = W_(n, 1), w2 = W_(n, 2), w3 = W_(n, 3);
+        recon5<RECON>(w0, w1, w2, w3, qp, qln2, R[n]);
+        if (n == 0) floor_lr<RECON, 1>(eos, qln2, R[n]);
+        if (n == 4) floor_lr<RECON, 2>(eos, qln2, R[n]);
+        W_(n, 0) = w1; W_(n, 1) = w2; W_(n, 2) = w3; W_(n, 3) = qp;
+      } else {
+        const double w0 = W_(n, 0);
+        R[n] = w0;
+        qln2 = w0;
+        W_(n, 0) = q[st];
+      }
+      PL_(n) = qln2;
+    }
+    off += st;
+    Cons1D f2 = riemann_mhd<RS>(eos.gamma, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1],
+                                R[2], R[3], R[4], R[5], R[6], pbx2[(size_t)t*f2st]);
+    if (do_x2 && x2_ok && (t < ml || s == shi)) {
+      a2.flx[ix5(g.nvar, a2.f3, a2.f2, a2.f1, m, 0, k, s, i)] = f2.d;
+      const size_t ec = ix4(g.N3, g.N2, g.N1, m, k, s, i);
+      a2.ey[ec] = -f2.by;
+      a2.ez[ec] = f2.bz;
+    }
+    // x2 flux in natural component order: d, m1, m2, m3, E  (ivx = 2, ivy = 3, ivz = 1)
+    const double fv[5] = {f2.d, f2.mz, f2.mx, f2.my, f2.e};
+    const int sc = s - 1;
+    if (do_x2 && t > 0 && col_active && sc >= g.js && sc <= g.je) {
+      const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, sc, i);
+#pragma unroll
+      for (int n = 0; n < 5; ++n) {
+        double divf = p2 ? dF1[n]*rdx1 : dF1[n]/dx1;
+        divf += p2 ? (fv[n] - FP_(n))*rdx2 : (fv[n] - FP_(n))/dx2;
+        u.acc[c + n*cs] = divf;
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < 5; ++n) FP_(n) = fv[n];
+  }
+#undef W_
+#undef PL_
+#undef FP_
+}
+
+template <int RECON, int RS>
+__global__ void __launch_bounds__(SX*SY, (RECON >= 2 ? 2 : AKMI_X12_WAVES))
+k_sweep12(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
+  __shared__ double sm[(7*RollCfg<RECON>::NW + 7 + 5)*SX*SY];
+  const int m = blockIdx.z;
+  if (AKMI_POW2DX && is_pow2(g.dx[3*m]) && is_pow2(g.dx[3*m + 1]))      // see k_sweep_update
+    sweep12_body<RECON, RS, AKMI_POW2DX != 0>(g, eos, a1, a2, u, ml, sm);
+  else
+    sweep12_body<RECON, RS, false>(g, eos, a1, a2, u, ml, sm);
 }
 
 // 1-D problems: the sweep direction is the lane direction, so neighbouring faces are
@@ -597,8 +854,8 @@ constexpr int CKL = AKMI_CKL;          // cell planes per k-chunk (one plane of 
 // (ty, tx); the launcher picks the shape that wastes the fewest lanes for the block size (a 64-wide
 // tile needs two columns of tiles for the 65 edge columns of a 64^3 MeshBlock, a 34 x 15 tile does
 // 33 / 65 / 257 columns in 1 / 2 / 8).
-__global__ void __launch_bounds__(CT_THREADS)
-k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e2x1,
+template <bool P2>
+__device__ __forceinline__ void corner_ct_body(const Geo &g, const double *__restrict__ e3x1, const double *__restrict__ e2x1,
             const double *__restrict__ e1x2, const double *__restrict__ e3x2,
             const double *__restrict__ e2x3, const double *__restrict__ e1x3,
             const double *__restrict__ c1, const double *__restrict__ c2,
@@ -625,6 +882,9 @@ k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e
   const bool edge_ok = in_tile && (i <= g.ie + 1) && (j <= g.je + 1);
   const bool own = edge_ok && (tx < tw - 1) && (ty < th - 1);
   const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
+  constexpr bool p2 = P2;             // the launcher checked that dx1, dx2, dx3 are powers of two
+  const double rdx1 = 1.0/dx1, rdx2 = 1.0/dx2, rdx3 = 1.0/dx3;
+#define DIVX(x, q) (p2 ? (x)*r##q : (x)/q)
   double e1p = 0.0, e2p = 0.0, e3p = 0.0;                       // own edges of the previous plane
   // operands of the corner formulas that belong to plane k-1 (rolled from step to step)
   double f1_km = 0.0, f2_km = 0.0, x2_km = 0.0, x1_km = 0.0, c1_mm = 0.0, c1_m0 = 0.0, c2_mm = 0.0,
@@ -640,7 +900,7 @@ k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e
   }
   for (int k = k0; k <= k1 + 1; ++k) {
     const int t = k - k0;
-    const int p2 = t & 1, p3 = t % 3;
+    const int pp2 = t & 1, p3 = t % 3;
     double e1 = 0.0, e2 = 0.0, e3 = 0.0;
     if (edge_ok) {
       const double f1_k = flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k, j, i)];
@@ -683,7 +943,7 @@ k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e
       f1_km = f1_k; f2_km = f2_k; x2_km = x2_k; x1_km = x1_k;
       c1_mm = c1_0m; c1_m0 = c1_00; c2_mm = c2_0m; c2_m0 = c2_00;
     }
-    if (in_tile) { S1(p2, ty, tx) = e1; S2(p2, ty, tx) = e2; S3(p3, ty, tx) = e3; }
+    if (in_tile) { S1(pp2, ty, tx) = e1; S2(pp2, ty, tx) = e2; S3(p3, ty, tx) = e3; }
     __syncthreads();
     if (own) {
       if (i <= g.ie && j <= g.je && (k <= k1 || wtop)) {          // x3-face of plane k (mhd_ct.cpp:67-77)
@@ -691,8 +951,8 @@ k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e
         const double b0v = b0x3f[c];
         const double b1v = copy_b1 ? b0v : b1x3f[c];
         double b = gam0*b0v + gam1*b1v;
-        b -= beta_dt*(S2(p2, ty, tx + 1) - e2)/dx1;
-        b += beta_dt*(S1(p2, ty + 1, tx) - e1)/dx2;
+        b -= DIVX(beta_dt*(S2(pp2, ty, tx + 1) - e2), dx1);
+        b += DIVX(beta_dt*(S1(pp2, ty + 1, tx) - e1), dx2);
         b0x3f[c] = b;
         if (copy_b1) b1x3f[c] = b0v;
       }
@@ -703,8 +963,8 @@ k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e
           const double b0v = b0x1f[c];
           const double b1v = copy_b1 ? b0v : b1x1f[c];
           double b = gam0*b0v + gam1*b1v;
-          b -= beta_dt*(S3(q3, ty + 1, tx) - e3p)/dx2;
-          b += beta_dt*(e2 - e2p)/dx3;
+          b -= DIVX(beta_dt*(S3(q3, ty + 1, tx) - e3p), dx2);
+          b += DIVX(beta_dt*(e2 - e2p), dx3);
           b0x1f[c] = b;
           if (copy_b1) b1x1f[c] = b0v;
         }
@@ -713,8 +973,8 @@ k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e
           const double b0v = b0x2f[c];
           const double b1v = copy_b1 ? b0v : b1x2f[c];
           double b = gam0*b0v + gam1*b1v;
-          b += beta_dt*(S3(q3, ty, tx + 1) - e3p)/dx1;
-          b -= beta_dt*(e1 - e1p)/dx3;
+          b += DIVX(beta_dt*(S3(q3, ty, tx + 1) - e3p), dx1);
+          b -= DIVX(beta_dt*(e1 - e1p), dx3);
           b0x2f[c] = b;
           if (copy_b1) b1x2f[c] = b0v;
         }
@@ -722,6 +982,29 @@ k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e
     }
     e1p = e1; e2p = e2; e3p = e3;
   }
+}
+#undef DIVX
+
+__global__ void __launch_bounds__(CT_THREADS)
+k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e2x1,
+            const double *__restrict__ e1x2, const double *__restrict__ e3x2,
+            const double *__restrict__ e2x3, const double *__restrict__ e1x3,
+            const double *__restrict__ c1, const double *__restrict__ c2,
+            const double *__restrict__ c3, const double *__restrict__ flx1,
+            const double *__restrict__ flx2, const double *__restrict__ flx3, double gam0,
+            double gam1, double beta_dt, double *__restrict__ b0x1f, double *__restrict__ b0x2f,
+            double *__restrict__ b0x3f, double *__restrict__ b1x1f, double *__restrict__ b1x2f,
+            double *__restrict__ b1x3f, int copy_b1, int kA, int kB, int top, int nchunk,
+            int ckl, int tw, int th) {
+  const int m = blockIdx.z/nchunk;
+  if (AKMI_POW2DX && is_pow2(g.dx[3*m]) && is_pow2(g.dx[3*m + 1]) && is_pow2(g.dx[3*m + 2]))
+    corner_ct_body<AKMI_POW2DX != 0>(g, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, c1, c2, c3, flx1, flx2, flx3, gam0,
+                         gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f, copy_b1, kA, kB, top,
+                         nchunk, ckl, tw, th);
+  else
+    corner_ct_body<false>(g, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, c1, c2, c3, flx1, flx2, flx3, gam0,
+                          gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f, copy_b1, kA, kB, top,
+                          nchunk, ckl, tw, th);
 }
 
 // CT (mhd_ct.cpp:23-80) with CopyCons for B folded in at stage 1 (b1 <- b0 old)
@@ -1135,6 +1418,24 @@ static int launch_sweep_update(const Geo &g, const Scheme &sc, const SweepArgs &
 }
 
 
+// x1 sweep + x2 march of an MHD pack in one kernel (3-D)
+static int launch_sweep12(const Geo &g, const Scheme &sc, const SweepArgs &a1, const SweepArgs &a2,
+                          const UpdArgs &u, hipStream_t st) {
+  const long np = (long)(a2.ku - a2.kl + 1)*g.N1;          // flattened (k,i) rows
+  const long nwaves = (np + (SX - 2) - 1)/(SX - 2);
+  const unsigned nb = (unsigned)((nwaves + SY - 1)/SY);
+  const int nc = a2.ju - a2.jl > 0 ? a2.ju - a2.jl : 1;
+  const int ml = march_len(nb, nc, g.nmb, ML, 3);
+  dim3 grid(nb, cdiv(nc, ml), g.nmb), block(SX, SY);
+  int rc = dispatch_scheme<true>(sc, [&](auto R, auto S) {
+    k_sweep12<decltype(R)::value, decltype(S)::value><<<grid, block, 0, st>>>(g, sc.eos, a1, a2, u, ml);
+    return AKMI_COMPLETE;
+  });
+  if (rc != AKMI_COMPLETE) return rc;
+  AKMI_CHECK_LAUNCH("sweep12");
+  return AKMI_COMPLETE;
+}
+
 static int launch_hydro_stage3d(const Geo &g, const Scheme &sc, const double *w0, const UpdArgs &u,
                                 int kA, int kB, hipStream_t st) {
   const HydTile tl = hyd_tile(g.nx1, g.nx2);
@@ -1366,6 +1667,10 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
   static const bool env_one = getenv("AKMI_ONE_STREAM") && atoi(getenv("AKMI_ONE_STREAM")) != 0;
   // AKMI_HYDRO_ONE_KERNEL=0: the three-kernel sweep/march sequence also for hydro DC/PLM (A/B runs)
   static const bool hyd_one = !(getenv("AKMI_HYDRO_ONE_KERNEL") && atoi(getenv("AKMI_HYDRO_ONE_KERNEL")) == 0);
+  // AKMI_X12=1: x1 sweep folded into the x2 march (k_sweep12).  Bit-identical, 19 doubles per cell
+  // less traffic, but 1.86-2.02 ms against 0.70 + 0.91 ms for the two kernels (profiles/r02_ab2.txt):
+  // the fused loop body exceeds the 168 VGPRs of three waves per SIMD and spills.  Off by default.
+  static const bool x12 = getenv("AKMI_X12") && atoi(getenv("AKMI_X12")) != 0;
   const int T = (phases != AKMI_PHASE_ALL) ? g.nx3 : (env_slab > 1 ? env_slab : AKMI_SLAB);
   const int S = (g.nx3 + T - 1)/T;
   if (S > MAX_SLABS) { set_error("too many slabs"); return AKMI_FAIL; }
@@ -1408,12 +1713,16 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
     if (do_sweeps && !MHD && hyd_one && sc.recon <= 1 && hyd_tile(g.nx1, g.nx2).tw > 0) {
       // hydro DC/PLM: sweeps + update of the slab in one kernel
       rc = launch_hydro_stage3d(g, sc, w0, u, kA(s), kB(s), st);
+    } else if (do_sweeps && MHD && x12) {
+      // x1 sweep folded into the x2 march (no x1 flux array); x3 march consumes acc
+      if constexpr (MHD) rc = launch_sweep12(g, sc, b1, b2, u, st);
+      if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD, 0, true>(g, sc, b3, u, st);
     } else if (do_sweeps) {
-    rc = MHD ? launch_sweep<0, MHD, MHD>(g, sc, b1, st)
-             : launch_sweep<0, MHD, false>(g, sc, b1, st);
-    // x2 sweep as a march along j that leaves acc = dF1/dx1 + dF2/dx2; x3 march consumes it
-    if (rc == AKMI_COMPLETE) rc = launch_sweep_update<1, MHD, 1, false>(g, sc, b2, u, st);
-    if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD, 0, true>(g, sc, b3, u, st);
+      rc = MHD ? launch_sweep<0, MHD, MHD>(g, sc, b1, st)
+               : launch_sweep<0, MHD, false>(g, sc, b1, st);
+      // x2 sweep as a march along j that leaves acc = dF1/dx1 + dF2/dx2; x3 march consumes it
+      if (rc == AKMI_COMPLETE) rc = launch_sweep_update<1, MHD, 1, false>(g, sc, b2, u, st);
+      if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD, 0, true>(g, sc, b3, u, st);
     }
     if (rc != AKMI_COMPLETE) return rc;
     if (two) {
