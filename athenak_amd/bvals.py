@@ -98,7 +98,9 @@ class MeshBoundaryValues:
         tab = -np.ones((nmb, 27), dtype=np.int32)
         recv_items = {}   # peer -> list of (my gid, o)
         send_items = {}   # peer -> list of (receiver gid, receiver o, my local m, d)
-        for m in range(nmb):
+        # multilevel meshes: the exchange is MeshBoundaryValuesSMR's (bvals_smr.py); this object
+        # then only applies the physical boundary conditions
+        for m in range(nmb if not pm.multilevel else 0):
             for d in range(27):
                 g, r = int(pmb.nghbr_gid[m, d]), int(pmb.nghbr_rank[m, d])
                 if g < 0:

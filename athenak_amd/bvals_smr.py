@@ -1,0 +1,363 @@
+"""Boundary values of a statically refined MeshBlockPack.
+
+Host mirror of MeshBoundaryValuesCC / MeshBoundaryValuesFC for multilevel meshes
+(src/bvals/bvals.hpp:134-267): the 56 MeshBoundaryBuffers with their index ranges
+(InitializeBuffers src/bvals/bvals.cpp:322-439, InitSendIndices/InitRecvIndices
+src/bvals/buffs_cc.cpp, src/bvals/buffs_fc.cpp) become flat tables on the device and every task body
+(PackAndSend*/RecvAndUnpack*, FillCoarseInBndry*, Prolongate*, *FluxCC, *FluxFC) is one call through
+the C ABI (include/akmi.h, akmi_smr_*).  The index ranges are generated from ONE rule per direction:
+with `o` the offset of the slot along the direction, `f` the sub-block flag that applies to it (the
+tangential directions of a slot take f1, f2 in order) and `a` = 1 where a face-field component has
+its extra face, every range of the reference's tables is an interval of
+
+      lo = base_lo(o) + shift,   hi = base_hi(o) + shift
+
+whose pieces are listed in `_interval` below; the oracle restates the reference's case-by-case
+formulas, the tests compare the two tables entry by entry.
+
+Neighbours on another rank are not supported on this path yet (one pack per process holds the whole
+mesh); Mesh refuses `refinement = static` with more than one rank.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+from .mesh_tree import NeighborIndex
+from .tasklist import TaskStatus
+
+KINDS = ("same", "coar", "fine", "prol", "flxs", "flxc")      # order of the device tables
+
+
+def slot_list(ndim, multilevel):
+    """(slot, ox1, ox2, ox3, f1, f2) of every buffer InitializeBuffers sets up."""
+    nfx = 2 if multilevel else 1
+    nfy = 2 if multilevel and ndim > 1 else 1
+    nfz = 2 if multilevel and ndim > 2 else 1
+    out = []
+    for n in (-1, 1):
+        for fz in range(nfz):
+            for fy in range(nfy):
+                out.append((NeighborIndex(n, 0, 0, fy, fz), n, 0, 0, fy, fz))
+    if ndim > 1:
+        for m in (-1, 1):
+            for fz in range(nfz):
+                for fx in range(nfx):
+                    out.append((NeighborIndex(0, m, 0, fx, fz), 0, m, 0, fx, fz))
+        for m in (-1, 1):
+            for n in (-1, 1):
+                for fz in range(nfz):
+                    out.append((NeighborIndex(n, m, 0, fz, 0), n, m, 0, fz, 0))
+    if ndim > 2:
+        for l in (-1, 1):
+            for fy in range(nfy):
+                for fx in range(nfx):
+                    out.append((NeighborIndex(0, 0, l, fx, fy), 0, 0, l, fx, fy))
+        for l in (-1, 1):
+            for n in (-1, 1):
+                for fy in range(nfy):
+                    out.append((NeighborIndex(n, 0, l, fy, 0), n, 0, l, fy, 0))
+        for l in (-1, 1):
+            for m in (-1, 1):
+                for fx in range(nfx):
+                    out.append((NeighborIndex(0, m, l, fx, 0), 0, m, l, fx, 0))
+        for l in (-1, 1):
+            for m in (-1, 1):
+                for n in (-1, 1):
+                    out.append((NeighborIndex(n, m, l, 0, 0), n, m, l, 0, 0))
+    return out
+
+
+def _interval(kind, send, s, e, cs, ce, cnx, ng, act, o, f, a, st, ml_oth):
+    """[lo, hi] of one direction of one index table.
+    s,e / cs,ce: fine / coarse active range; act: the direction exists; o: slot offset along it;
+    f: sub-block flag; a: 1 for the direction a face-field component is normal to (0 for
+    cell-centred data); st: 1 where an edge-field component is staggered (EMF tables);
+    ml_oth: multilevel mesh and the slot is offset in another direction (face fields only)."""
+    if kind in ("flxs", "flxc"):
+        # one layer on the block surface; flxc of a sender is in coarse indices
+        if send:
+            lo, hi = (cs, ce) if kind == "flxc" else (s, e)
+        else:
+            lo, hi = s, e
+        if o == 0:
+            hi += st
+            if not send and kind == "flxc" and act:
+                lo, hi = (lo + cnx, hi) if f == 1 else (lo, hi - cnx)
+            return lo, hi
+        edge = (hi + 1) if o > 0 else lo
+        return edge, edge
+    if send:
+        lo, hi = (cs, ce) if kind == "coar" else (s, e)
+        if o == 0:
+            hi += a
+            if kind == "fine" and act:
+                lo, hi = (lo + cnx - ng, hi) if f == 1 else (lo, hi - (cnx - ng))
+            return lo, hi
+        if o > 0:
+            lo, hi = hi - ng + 1, hi
+            if kind == "fine":
+                hi += a
+            elif a and ml_oth:
+                hi += 1
+        else:
+            lo, hi = lo, lo + ng - 1
+            if kind == "fine":
+                hi += a
+            else:
+                lo, hi = lo + a, hi + a
+                if a and ml_oth:
+                    lo -= 1
+        return lo, hi
+    # receive side
+    n = ng//2 if kind == "prol" else ng
+    lo, hi = (cs, ce) if kind in ("coar", "prol") else (s, e)
+    if o == 0:
+        hi += a
+        if act:
+            if kind in ("coar", "prol"):
+                lo, hi = (lo, hi + n) if f == 0 else (lo - n, hi)
+            elif kind == "fine":
+                lo, hi = (lo + cnx, hi) if f == 1 else (lo, hi - cnx)
+        return lo, hi
+    if o > 0:
+        lo, hi = hi + 1 + a, hi + n + a
+        if kind == "coar":
+            lo -= a                      # the shared coarse face travels with the data from a coarser block
+        elif kind in ("same", "fine") and a and ml_oth:
+            lo -= 1
+    else:
+        lo, hi = lo - n, lo - 1
+        if kind == "coar":
+            hi += a
+        elif kind in ("same", "fine") and a and ml_oth:
+            hi += 1
+    return lo, hi
+
+
+def index_tables(indcs, ndim, multilevel):
+    """cc_tab, fc_tab [2][6][56][3][6] and ndat [2][56][2][5] as int32 arrays."""
+    ng = indcs.ng
+    S = (indcs.is_, indcs.js, indcs.ks)
+    E = (indcs.ie, indcs.je, indcs.ke)
+    nx = (indcs.nx1, indcs.nx2, indcs.nx3)
+    cnx = (indcs.nx1//2, indcs.nx2//2 if nx[1] > 1 else 1, indcs.nx3//2 if nx[2] > 1 else 1)
+    CS = (ng, ng if nx[1] > 1 else 0, ng if nx[2] > 1 else 0)
+    CE = tuple(CS[d] + cnx[d] - 1 if (d == 0 or nx[d] > 1) else 0 for d in range(3))
+    act = (True, nx[1] > 1, nx[2] > 1)
+    tabs = [np.zeros((2, 6, 56, 3, 6), dtype=np.int32) for _ in range(2)]
+    ndat = np.zeros((2, 56, 2, 5), dtype=np.int32)
+    for (n, ox1, ox2, ox3, f1, f2) in slot_list(ndim, multilevel):
+        o = (ox1, ox2, ox3)
+        fl = (f1, f1 if ox1 != 0 else f2, f1 if (ox1 != 0 and ox2 != 0) else f2)
+        for fc in (0, 1):
+            for sr in (0, 1):
+                for ki, kind in enumerate(KINDS):
+                    if kind == "same" and (f1 or f2):
+                        continue
+                    if kind == "prol" and sr == 0:
+                        continue
+                    if kind == "flxs" and not fc:
+                        continue
+                    for v in range(3 if fc else 1):
+                        for d in range(3):
+                            a = 1 if (fc and v == d) else 0
+                            st = 1 if (fc and v != d) else 0
+                            oth = bool(fc and multilevel and any(o[q] != 0 for q in range(3) if q != d))
+                            lo, hi = _interval(kind, sr == 0, S[d], E[d], CS[d], CE[d], cnx[d], ng, act[d],
+                                               o[d], fl[d], a, st, oth)
+                            tabs[fc][sr, ki, n, v, 2*d] = lo
+                            tabs[fc][sr, ki, n, v, 2*d + 1] = hi
+                # data counts: max over the components
+                for qi, kind in enumerate(("same", "coar", "fine", "flxs", "flxc")):
+                    ki = KINDS.index(kind)
+                    if (kind == "same" and (f1 or f2)) or (kind == "flxs" and not fc):
+                        continue
+                    b = tabs[fc][sr, ki, n]
+                    cnt = [(b[v, 1] - b[v, 0] + 1)*(b[v, 3] - b[v, 2] + 1)*(b[v, 5] - b[v, 4] + 1)
+                           for v in range(3 if fc else 1)]
+                    ndat[fc, n, sr, qi] = max(cnt)
+    return tabs[0], tabs[1], ndat
+
+
+def edge_counts(nghbr, mblev, nnghbr):
+    """nflx[nmb][48]: owners of each block edge after SumBoundaryFluxes(same level),
+    ZeroFluxesAtBoundaryWithFiner, SumBoundaryFluxes(finer) (src/bvals/flux_correct_fc.cpp:445-790);
+    the counting touches the neighbour table only."""
+    face_edges = {0: (16, 20, 32, 36), 4: (18, 22, 34, 38), 8: (16, 18, 40, 44), 12: (20, 22, 42, 46),
+                  24: (32, 34, 40, 42), 28: (36, 38, 44, 46)}
+    nmb = len(mblev)
+    nflx = np.ones((nmb, 48), dtype=np.int32)
+
+    def add(m, want_finer):
+        for n in range(min(nnghbr, 48)):
+            g, l = nghbr[m, n, 0], nghbr[m, n, 1]
+            if g < 0 or (l > mblev[m]) != want_finer or l < mblev[m]:
+                continue
+            if n in face_edges:
+                for q in face_edges[n]:
+                    nflx[m, q] += 1
+            elif 16 <= n < 24 or 32 <= n < 48:
+                nflx[m, n] += 1
+    for m in range(nmb):
+        add(m, False)
+        for n in range(min(nnghbr, 48)):
+            if nghbr[m, n, 0] >= 0 and nghbr[m, n, 1] > mblev[m]:
+                if n in face_edges:
+                    for q in face_edges[n]:
+                        nflx[m, q] = 0
+                elif 16 <= n < 24 or 32 <= n < 48:
+                    nflx[m, n] = 0
+        add(m, True)
+    return nflx
+
+
+class HipSmrKernels:
+    """the akmi_smr_* entry points (device tensors only)"""
+
+    def __init__(self):
+        self.L = capi.lib()
+
+    def _call(self, name, *args):
+        capi.check(getattr(self.L, name)(*args), name)
+
+    def exchange_cc(self, pack, smr, nvar, u, cu, buf):
+        self._call("akmi_smr_exchange_cc", C.byref(pack), C.byref(smr), nvar, capi._p(u), capi._p(cu),
+                   capi._p(buf), capi._stream())
+
+    def exchange_fc(self, pack, smr, b, cb, buf):
+        self._call("akmi_smr_exchange_fc", C.byref(pack), C.byref(smr), capi._p(b.x1f), capi._p(b.x2f),
+                   capi._p(b.x3f), capi._p(cb.x1f), capi._p(cb.x2f), capi._p(cb.x3f), capi._p(buf),
+                   capi._stream())
+
+    def fill_coarse_cc(self, pack, smr, nvar, u, cu):
+        self._call("akmi_smr_fill_coarse_cc", C.byref(pack), C.byref(smr), nvar, capi._p(u), capi._p(cu),
+                   capi._stream())
+
+    def fill_coarse_fc(self, pack, smr, b, cb):
+        self._call("akmi_smr_fill_coarse_fc", C.byref(pack), C.byref(smr), capi._p(b.x1f), capi._p(b.x2f),
+                   capi._p(b.x3f), capi._p(cb.x1f), capi._p(cb.x2f), capi._p(cb.x3f), capi._stream())
+
+    def prolong_cc(self, pack, smr, nvar, cu, u):
+        self._call("akmi_smr_prolong_cc", C.byref(pack), C.byref(smr), nvar, capi._p(cu), capi._p(u),
+                   capi._stream())
+
+    def prolong_fc(self, pack, smr, cb, b):
+        self._call("akmi_smr_prolong_fc", C.byref(pack), C.byref(smr), capi._p(cb.x1f), capi._p(cb.x2f),
+                   capi._p(cb.x3f), capi._p(b.x1f), capi._p(b.x2f), capi._p(b.x3f), capi._stream())
+
+    def flux_cc(self, pack, smr, nvar, face_shaped, flx, buf):
+        self._call("akmi_smr_flux_cc", C.byref(pack), C.byref(smr), nvar, int(face_shaped), capi._p(flx.x1f),
+                   capi._p(flx.x2f), capi._p(flx.x3f), capi._p(buf), capi._stream())
+
+    def emf_exchange(self, pack, smr, nflx, efld, buf):
+        self._call("akmi_smr_emf_exchange", C.byref(pack), C.byref(smr), capi._p(nflx), capi._p(efld.x1e),
+                   capi._p(efld.x2e), capi._p(efld.x3e), capi._p(buf), capi._stream())
+
+    def restrict_cc(self, pack, nvar, u, cu):
+        self._call("akmi_restrict_cc", C.byref(pack), nvar, capi._p(u), capi._p(cu), capi._stream())
+
+    def restrict_fc(self, pack, b, cb):
+        self._call("akmi_restrict_fc", C.byref(pack), capi._p(b.x1f), capi._p(b.x2f), capi._p(b.x3f),
+                   capi._p(cb.x1f), capi._p(cb.x2f), capi._p(cb.x3f), capi._stream())
+
+
+class MeshBoundaryValuesSMR:
+    """level-aware boundary values of one pack: tables on the device + the task bodies"""
+
+    def __init__(self, ppack, nvar, kernels=None, device=None):
+        device = device or capi.DEVICE
+        self.pmy_pack = ppack
+        self.device = device
+        self.k = kernels if kernels is not None else HipSmrKernels()
+        pm, pmb = ppack.pmesh, ppack.pmb
+        indcs = pm.mb_indcs
+        ndim = 3 if pm.three_d else (2 if pm.multi_d else 1)
+        self.nnghbr = 56 if ndim == 3 else (24 if ndim == 2 else 8)
+        self.nvar = nvar
+        nmb = ppack.nmb_thispack
+        cc, fc, ndat = index_tables(indcs, ndim, pm.multilevel)
+        self.cc_tab_host, self.fc_tab_host, self.ndat_host = cc, fc, ndat
+        # neighbour table: NeighborBlock {gid, lev, rank, dest} -> {local index, level, dest}
+        ng = -np.ones((nmb, 56, 3), dtype=np.int32)
+        for m in range(nmb):
+            for n, nb in pmb.nghbr[m].items():
+                if nb.rank != pm.my_rank:
+                    raise RuntimeError("### FATAL ERROR mesh refinement with MeshBlocks on other ranks "
+                                       "is not on this build's path yet")
+                ng[m, n] = (nb.gid - ppack.gids, nb.lev, nb.dest)
+        self.nghbr_host = ng
+        self.nflx_host = edge_counts(ng, pmb.mb_lev, self.nnghbr)
+        slot_ox = np.zeros((56, 3), dtype=np.int32)
+        for (n, ox1, ox2, ox3, f1, f2) in slot_list(ndim, pm.multilevel):
+            slot_ox[n] = (ox1, ox2, ox3)
+        # receive buffers: per slot nvar*max(ndat) doubles per block, slot after slot
+        layout = np.zeros((4, 56, 2), dtype=np.int64)
+        sizes = []
+        for cls, (fcq, nv, cols) in enumerate(((0, nvar, (0, 1, 2)), (0, nvar, (4,)), (1, 3, (0, 1, 2)),
+                                               (1, 3, (3, 4)))):
+            off = 0
+            for n in range(56):
+                stride = nv*int(ndat[fcq, n][:, list(cols)].max())
+                layout[cls, n] = (off, stride)
+                off += stride*nmb
+            sizes.append(off)
+
+        def dev(a):
+            return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.t_nghbr, self.t_lev = dev(ng), dev(pmb.mb_lev.astype(np.int32))
+        self.t_cc, self.t_fc, self.t_ndat = dev(cc), dev(fc), dev(ndat)
+        self.t_ox, self.t_layout, self.t_nflx = dev(slot_ox), dev(layout), dev(self.nflx_host)
+        self.buf = [torch.zeros(max(sz, 1), dtype=torch.float64, device=device) for sz in sizes]
+        self.smr_c = capi.Smr(self.nnghbr, 1 if pm.multilevel else 0, self.t_nghbr.data_ptr(),
+                              self.t_lev.data_ptr(), self.t_cc.data_ptr(), self.t_fc.data_ptr(),
+                              self.t_ndat.data_ptr(), self.t_ox.data_ptr(), self.t_layout.data_ptr())
+        self.pack_c = None
+
+    def set_pack(self, pack_c):
+        self.pack_c = pack_c
+
+    # ---- task bodies ----------------------------------------------------------------------------
+    def RestrictCC(self, u, cu):
+        self.k.restrict_cc(self.pack_c, self.nvar, u, cu)
+        return TaskStatus.complete
+
+    def RestrictFC(self, b, cb):
+        self.k.restrict_fc(self.pack_c, b, cb)
+        return TaskStatus.complete
+
+    def PackAndSendCC(self, u, cu):
+        """same-rank neighbours: pack and unpack run back to back on the stream"""
+        self.k.exchange_cc(self.pack_c, self.smr_c, self.nvar, u, cu, self.buf[0])
+        return TaskStatus.complete
+
+    def RecvAndUnpackCC(self, u, cu):
+        return TaskStatus.complete
+
+    def PackAndSendFC(self, b, cb):
+        self.k.exchange_fc(self.pack_c, self.smr_c, b, cb, self.buf[2])
+        return TaskStatus.complete
+
+    def RecvAndUnpackFC(self, b, cb):
+        return TaskStatus.complete
+
+    def FillCoarseInBndryCC(self, u, cu):
+        self.k.fill_coarse_cc(self.pack_c, self.smr_c, self.nvar, u, cu)
+
+    def FillCoarseInBndryFC(self, b, cb):
+        self.k.fill_coarse_fc(self.pack_c, self.smr_c, b, cb)
+
+    def ProlongateCC(self, u, cu):
+        self.k.prolong_cc(self.pack_c, self.smr_c, self.nvar, cu, u)
+
+    def ProlongateFC(self, b, cb):
+        self.k.prolong_fc(self.pack_c, self.smr_c, cb, b)
+
+    def PackAndSendFluxCC(self, flx, face_shaped):
+        self.k.flux_cc(self.pack_c, self.smr_c, self.nvar, face_shaped, flx, self.buf[1])
+        return TaskStatus.complete
+
+    def PackAndSendFluxFC(self, efld):
+        self.k.emf_exchange(self.pack_c, self.smr_c, self.t_nflx, efld, self.buf[3])
+        return TaskStatus.complete

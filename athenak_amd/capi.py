@@ -43,9 +43,18 @@ SYMBOLS = [
     "akmi_hydro_c2p_shell", "akmi_mhd_c2p_shell", "akmi_sim_create", "akmi_sim_initialize",
     "akmi_sim_execute", "akmi_sim_destroy", "akmi_sim_time", "akmi_sim_dt", "akmi_sim_tlim",
     "akmi_sim_ncycle", "akmi_sim_nmb", "akmi_sim_array", "akmi_sim_lloc",
+    "akmi_smr_exchange_cc", "akmi_smr_exchange_fc", "akmi_smr_fill_coarse_cc", "akmi_smr_fill_coarse_fc",
+    "akmi_smr_prolong_cc", "akmi_smr_prolong_fc", "akmi_smr_flux_cc", "akmi_smr_emf_exchange",
 ]
 
 _LIB = None
+
+
+class Smr(C.Structure):
+    """struct akmi_smr (include/akmi.h)"""
+    _fields_ = [("nnghbr", C.c_int), ("multilevel", C.c_int), ("nghbr", C.c_void_p),
+                ("mblev", C.c_void_p), ("cc_tab", C.c_void_p), ("fc_tab", C.c_void_p),
+                ("ndat", C.c_void_p), ("slot_ox", C.c_void_p), ("layout", C.c_void_p)]
 
 
 class AkmiError(RuntimeError):

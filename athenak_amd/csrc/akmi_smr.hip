@@ -1,0 +1,719 @@
+// akmi_smr.hip -- boundary values of a statically refined MeshBlockPack: the
+// level-aware exchange of cell- and face-centred variables through the 56 buffer slots of a
+// MeshBlock, the coarse-buffer fill and ghost prolongation, and the flux / EMF correction at
+// fine/coarse boundaries.  Replaces the bodies of
+//   MeshBoundaryValuesCC::PackAndSendCC / RecvAndUnpackCC      src/bvals/bvals_cc.cpp:42-447
+//   MeshBoundaryValuesFC::PackAndSendFC / RecvAndUnpackFC      src/bvals/bvals_fc.cpp:63-436
+//   FillCoarseInBndryCC/FC, ProlongateCC/FC                     src/bvals/prolongation.cpp:366-785
+//   PackAndSendFluxCC / RecvAndUnpackFluxCC                     src/bvals/flux_correct_cc.cpp:29-304
+//   PackAndSendFluxFC / RecvAndUnpackFluxFC (+Sum/Zero/Average) src/bvals/flux_correct_fc.cpp:29-1034
+// Everything is table driven: the host hands over the index boxes of every slot (the reference's
+// MeshBoundaryBuffer::isame/icoar/ifine/iprol/iflux_*), the neighbour table with levels and the
+// buffer layout; a workgroup owns one (block, slot[, variable]) and strides over the box.  Where
+// the reference orders overlapping writes (face fields: slots of a block are unpacked one after
+// the other), a workgroup owns (block, component) and walks the slots with a barrier in between.
+#include "akmi_common.hpp"
+
+namespace akmi {
+
+struct SGeo {
+  int N1, N2, N3, cN1, cN2, cN3;
+  int is, ie, js, je, ks, ke, cis, cjs, cks;
+  int multi_d, three_d;
+};
+static SGeo make_sgeo(const akmi_pack *p) {
+  Geo g = make_geo(p);
+  SGeo s;
+  s.N1 = g.N1; s.N2 = g.N2; s.N3 = g.N3;
+  const int cnx1 = g.nx1/2, cnx2 = g.multi_d ? g.nx2/2 : 1, cnx3 = g.three_d ? g.nx3/2 : 1;
+  s.cN1 = cnx1 + 2*g.ng; s.cN2 = g.multi_d ? cnx2 + 2*g.ng : 1; s.cN3 = g.three_d ? cnx3 + 2*g.ng : 1;
+  s.is = g.is; s.ie = g.ie; s.js = g.js; s.je = g.je; s.ks = g.ks; s.ke = g.ke;
+  s.cis = g.ng; s.cjs = g.multi_d ? g.ng : 0; s.cks = g.three_d ? g.ng : 0;
+  s.multi_d = g.multi_d; s.three_d = g.three_d;
+  return s;
+}
+
+struct Bx { int il, iu, jl, ju, kl, ku; };
+enum { K_SAME = 0, K_COAR = 1, K_FINE = 2, K_PROL = 3, K_FLXS = 4, K_FLXC = 5 };
+enum { T_SEND = 0, T_RECV = 1 };
+__device__ __forceinline__ Bx box_of(const int *tab, int sr, int kind, int n, int v) {
+  const int *q = tab + ((((size_t)sr*6 + kind)*56 + n)*3 + v)*6;
+  return Bx{q[0], q[1], q[2], q[3], q[4], q[5]};
+}
+__device__ __forceinline__ int bcount(const Bx &b) {
+  return (b.iu - b.il + 1)*(b.ju - b.jl + 1)*(b.ku - b.kl + 1);
+}
+// element e of a box -> (k,j,i), i fastest
+__device__ __forceinline__ void bdecode(const Bx &b, int e, int &k, int &j, int &i) {
+  const int ni = b.iu - b.il + 1, nj = b.ju - b.jl + 1;
+  i = b.il + e%ni; e /= ni;
+  j = b.jl + e%nj;
+  k = b.kl + e/nj;
+}
+
+// addressing of fine / coarse cell and face arrays
+__device__ __forceinline__ size_t c5(const SGeo &s, int coarse, int nv, int m, int v, int k, int j, int i) {
+  return coarse ? ix5(nv, s.cN3, s.cN2, s.cN1, m, v, k, j, i) : ix5(nv, s.N3, s.N2, s.N1, m, v, k, j, i);
+}
+__device__ __forceinline__ size_t f4(const SGeo &s, int coarse, int v, int m, int k, int j, int i) {
+  const int n1 = coarse ? s.cN1 : s.N1, n2 = coarse ? s.cN2 : s.N2, n3 = coarse ? s.cN3 : s.N3;
+  return ix4(n3 + (v == 2), n2 + (v == 1), n1 + (v == 0), m, k, j, i);
+}
+struct F3 { double *b[3]; };
+struct CF3 { const double *b[3]; };
+
+struct Tab {                      // device view of akmi_smr
+  int nnghbr, multilevel;
+  const int *ng, *lev, *cc, *fc, *ndat;
+  const long long *lay;
+};
+static Tab make_tab(const akmi_smr *t) {
+  return Tab{t->nnghbr, t->multilevel, t->nghbr, t->mblev, t->cc_tab, t->fc_tab, t->ndat, t->layout};
+}
+#define NGID(t, m, n) (t).ng[((size_t)(m)*56 + (n))*3]
+#define NLEV(t, m, n) (t).ng[((size_t)(m)*56 + (n))*3 + 1]
+#define NDST(t, m, n) (t).ng[((size_t)(m)*56 + (n))*3 + 2]
+// buffer of (block m, slot n): cls 0 cc vars, 1 cc flux, 2 fc vars, 3 fc flux
+__device__ __forceinline__ size_t buf_at(const Tab &t, int cls, int m, int n) {
+  const long long *l = t.lay + ((size_t)cls*56 + n)*2;
+  return (size_t)l[0] + (size_t)m*(size_t)l[1];
+}
+// ndat[fc][slot][send|recv][same, coar, fine, flxs, flxc]
+__device__ __forceinline__ int ndat_of(const Tab &t, int fc, int n, int sr, int q) {
+  return t.ndat[(((size_t)fc*56 + n)*2 + sr)*5 + q];
+}
+
+// ---- PackAndSendCC: block m writes into the receive buffer (dm, dn) of its neighbour -------------
+__global__ void __launch_bounds__(256)
+k_smr_pack_cc(SGeo s, Tab t, int nvar, const double *__restrict__ a, const double *__restrict__ ca,
+              double *__restrict__ buf) {
+  const int v = blockIdx.x%nvar, n = (blockIdx.x/nvar)%t.nnghbr, m = blockIdx.x/(nvar*t.nnghbr);
+  const int dm = NGID(t, m, n);
+  if (dm < 0) return;
+  const int nl = NLEV(t, m, n), ml = t.lev[m];
+  const Bx b = box_of(t.cc, T_SEND, nl < ml ? K_COAR : (nl == ml ? K_SAME : K_FINE), n, 0);
+  const int cnt = bcount(b);
+  double *out = buf + buf_at(t, 0, dm, NDST(t, m, n)) + (size_t)cnt*v;
+  const int coarse = nl < ml;
+  const double *src = coarse ? ca : a;
+  for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+    int k, j, i;
+    bdecode(b, e, k, j, i);
+    out[e] = src[c5(s, coarse, nvar, m, v, k, j, i)];
+  }
+}
+
+// ---- RecvAndUnpackCC ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_smr_unpack_cc(SGeo s, Tab t, int nvar, const double *__restrict__ buf, double *__restrict__ a,
+                double *__restrict__ ca) {
+  const int v = blockIdx.x%nvar, n = (blockIdx.x/nvar)%t.nnghbr, m = blockIdx.x/(nvar*t.nnghbr);
+  if (NGID(t, m, n) < 0) return;
+  const int nl = NLEV(t, m, n), ml = t.lev[m];
+  const Bx b = box_of(t.cc, T_RECV, nl < ml ? K_COAR : (nl == ml ? K_SAME : K_FINE), n, 0);
+  const int cnt = bcount(b);
+  const double *in = buf + buf_at(t, 0, m, n) + (size_t)cnt*v;
+  const int coarse = nl < ml;
+  double *dst = coarse ? ca : a;
+  for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+    int k, j, i;
+    bdecode(b, e, k, j, i);
+    dst[c5(s, coarse, nvar, m, v, k, j, i)] = in[e];
+  }
+}
+
+// ---- PackAndSendFC --------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_smr_pack_fc(SGeo s, Tab t, CF3 b, CF3 cb, double *__restrict__ buf) {
+  const int v = blockIdx.x%3, n = (blockIdx.x/3)%t.nnghbr, m = blockIdx.x/(3*t.nnghbr);
+  const int dm = NGID(t, m, n);
+  if (dm < 0) return;
+  const int nl = NLEV(t, m, n), ml = t.lev[m];
+  const int q = nl < ml ? 1 : (nl == ml ? 0 : 2);
+  const Bx bx = box_of(t.fc, T_SEND, q == 1 ? K_COAR : (q == 0 ? K_SAME : K_FINE), n, v);
+  const int cnt = bcount(bx);
+  const int dn = NDST(t, m, n);
+  // the receiver unpacks with ITS ndat of slot dn and the matching level relation
+  const int rq = q == 1 ? 2 : (q == 2 ? 1 : 0);
+  double *out = buf + buf_at(t, 2, dm, dn) + (size_t)ndat_of(t, 1, dn, T_RECV, rq)*v;
+  const int coarse = nl < ml;
+  const double *src = coarse ? cb.b[v] : b.b[v];
+  for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+    int k, j, i;
+    bdecode(bx, e, k, j, i);
+    out[e] = src[f4(s, coarse, v, m, k, j, i)];
+  }
+}
+
+__device__ __forceinline__ bool active_face(const SGeo &s, int v, int k, int j, int i) {   // IsActiveFCFace
+  return i >= s.is && i <= s.ie + (v == 0) && j >= s.js && j <= s.je + (v == 1) && k >= s.ks && k <= s.ke + (v == 2);
+}
+
+// ---- RecvAndUnpackFC: the slots of a (block, component) one after the other ----------------------
+__global__ void __launch_bounds__(256)
+k_smr_unpack_fc(SGeo s, Tab t, const double *__restrict__ buf, F3 b, F3 cb) {
+  const int v = blockIdx.x%3, m = blockIdx.x/3;
+  const int ml = t.lev[m];
+  for (int n = 0; n < t.nnghbr; ++n) {
+    if (NGID(t, m, n) < 0) continue;                       // uniform over the workgroup
+    const int nl = NLEV(t, m, n);
+    const int q = nl < ml ? 1 : (nl == ml ? 0 : 2);
+    const Bx bx = box_of(t.fc, T_RECV, q == 1 ? K_COAR : (q == 0 ? K_SAME : K_FINE), n, v);
+    const int cnt = bcount(bx);
+    const double *in = buf + buf_at(t, 2, m, n) + (size_t)ndat_of(t, 1, n, T_RECV, q)*v;
+    const int coarse = nl < ml;
+    double *dst = coarse ? cb.b[v] : b.b[v];
+    for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+      int k, j, i;
+      bdecode(bx, e, k, j, i);
+      if (!coarse && active_face(s, v, k, j, i)) continue;
+      dst[f4(s, coarse, v, m, k, j, i)] = in[e];
+    }
+    __syncthreads();
+  }
+}
+
+// ---- FillCoarseInBndryCC --------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_smr_fill_coarse_cc(SGeo s, Tab t, int nvar, const double *__restrict__ a, double *__restrict__ ca) {
+  const int v = blockIdx.x%nvar, n = (blockIdx.x/nvar)%t.nnghbr, m = blockIdx.x/(nvar*t.nnghbr);
+  if (NGID(t, m, n) < 0 || NLEV(t, m, n) != t.lev[m]) return;
+  const Bx r = box_of(t.cc, T_RECV, K_SAME, n, 0);
+  const Bx b{(r.il + s.cis)/2, (r.iu + s.cis)/2, (r.jl + s.cjs)/2, (r.ju + s.cjs)/2, (r.kl + s.cks)/2,
+             (r.ku + s.cks)/2};
+  const int cnt = bcount(b);
+  for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+    int k, j, i;
+    bdecode(b, e, k, j, i);
+    const int fi = (i - s.cis)*2 + s.is, fj = (j - s.cjs)*2 + s.js, fk = (k - s.cks)*2 + s.ks;
+    auto A = [&](int kk, int jj, int ii) { return a[c5(s, 0, nvar, m, v, kk, jj, ii)]; };
+    if (!s.three_d)
+      ca[c5(s, 1, nvar, m, v, b.kl, j, i)] = 0.25*(A(b.kl, fj, fi) + A(b.kl, fj, fi + 1) + A(b.kl, fj + 1, fi) + A(b.kl, fj + 1, fi + 1));
+    else
+      ca[c5(s, 1, nvar, m, v, k, j, i)] = 0.125*(A(fk, fj, fi) + A(fk, fj, fi + 1) + A(fk, fj + 1, fi) + A(fk, fj + 1, fi + 1)
+                                               + A(fk + 1, fj, fi) + A(fk + 1, fj, fi + 1) + A(fk + 1, fj + 1, fi) + A(fk + 1, fj + 1, fi + 1));
+  }
+}
+
+// ---- FillCoarseInBndryFC --------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_smr_fill_coarse_fc(SGeo s, Tab t, CF3 b, F3 cb) {
+  const int v = blockIdx.x%3, n = (blockIdx.x/3)%t.nnghbr, m = blockIdx.x/(3*t.nnghbr);
+  if (NGID(t, m, n) < 0 || NLEV(t, m, n) != t.lev[m]) return;
+  const Bx r = box_of(t.fc, T_RECV, K_SAME, n, v);
+  const Bx bx{(r.il + s.cis)/2, (r.iu + s.cis)/2, (r.jl + s.cjs)/2, (r.ju + s.cjs)/2, (r.kl + s.cks)/2,
+              (r.ku + s.cks)/2};
+  const int cnt = bcount(bx);
+  auto B = [&](int kk, int jj, int ii) { return b.b[v][f4(s, 0, v, m, kk, jj, ii)]; };
+  for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+    int k, j, i;
+    bdecode(bx, e, k, j, i);
+    const int fi = (i - s.cis)*2 + s.is, fj = (j - s.cjs)*2 + s.js, fk = (k - s.cks)*2 + s.ks;
+    const int kl = bx.kl;
+    if (!s.three_d) {
+      if (v == 0) cb.b[0][f4(s, 1, 0, m, kl, j, i)] = 0.5*(B(kl, fj, fi) + B(kl, fj + 1, fi));
+      else if (v == 1) cb.b[1][f4(s, 1, 1, m, kl, j, i)] = 0.5*(B(kl, fj, fi) + B(kl, fj, fi + 1));
+      else {
+        const double b3c = 0.25*(B(kl, fj, fi) + B(kl, fj, fi + 1) + B(kl, fj + 1, fi) + B(kl, fj + 1, fi + 1));
+        cb.b[2][f4(s, 1, 2, m, kl, j, i)] = b3c;
+        cb.b[2][f4(s, 1, 2, m, kl + 1, j, i)] = b3c;
+      }
+    } else {
+      double r4;
+      if (v == 0) r4 = 0.25*(B(fk, fj, fi) + B(fk, fj + 1, fi) + B(fk + 1, fj, fi) + B(fk + 1, fj + 1, fi));
+      else if (v == 1) r4 = 0.25*(B(fk, fj, fi) + B(fk, fj, fi + 1) + B(fk + 1, fj, fi) + B(fk + 1, fj, fi + 1));
+      else r4 = 0.25*(B(fk, fj, fi) + B(fk, fj, fi + 1) + B(fk, fj + 1, fi) + B(fk, fj + 1, fi + 1));
+      cb.b[v][f4(s, 1, v, m, k, j, i)] = r4;
+    }
+  }
+}
+
+__device__ __forceinline__ double s_sgn(double x) { return (x < 0.0) ? -1.0 : 1.0; }        // SIGN, athena.hpp:52
+__device__ __forceinline__ double s_mm8(double dl, double dr) {
+  return 0.125*(s_sgn(dl) + s_sgn(dr))*fmin(fabs(dl), fabs(dr));
+}
+
+// ---- ProlongateCC (ProlongCC, src/mesh/prolongation.hpp:19-63) -----------------------------------
+__global__ void __launch_bounds__(256)
+k_smr_prolong_cc(SGeo s, Tab t, int nvar, const double *__restrict__ ca, double *__restrict__ a) {
+  const int v = blockIdx.x%nvar, n = (blockIdx.x/nvar)%t.nnghbr, m = blockIdx.x/(nvar*t.nnghbr);
+  if (NGID(t, m, n) < 0 || !(NLEV(t, m, n) < t.lev[m])) return;
+  const Bx b = box_of(t.cc, T_RECV, K_PROL, n, 0);
+  const int cnt = bcount(b);
+  auto CA = [&](int kk, int jj, int ii) { return ca[c5(s, 1, nvar, m, v, kk, jj, ii)]; };
+  auto A = [&](int kk, int jj, int ii) -> double & { return a[c5(s, 0, nvar, m, v, kk, jj, ii)]; };
+  for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+    int k, j, i;
+    bdecode(b, e, k, j, i);
+    const int fi = (i - s.cis)*2 + s.is, fj = (j - s.cjs)*2 + s.js, fk = (k - s.cks)*2 + s.ks;
+    const double q = CA(k, j, i);
+    const double dvar1 = s_mm8(q - CA(k, j, i - 1), CA(k, j, i + 1) - q);
+    double dvar2 = 0.0, dvar3 = 0.0;
+    if (s.multi_d) dvar2 = s_mm8(q - CA(k, j - 1, i), CA(k, j + 1, i) - q);
+    if (s.three_d) dvar3 = s_mm8(q - CA(k - 1, j, i), CA(k + 1, j, i) - q);
+    A(fk, fj, fi) = q - dvar1 - dvar2 - dvar3;
+    A(fk, fj, fi + 1) = q + dvar1 - dvar2 - dvar3;
+    if (s.multi_d) {
+      A(fk, fj + 1, fi) = q - dvar1 + dvar2 - dvar3;
+      A(fk, fj + 1, fi + 1) = q + dvar1 + dvar2 - dvar3;
+    }
+    if (s.three_d) {
+      A(fk + 1, fj, fi) = q - dvar1 - dvar2 + dvar3;
+      A(fk + 1, fj, fi + 1) = q + dvar1 - dvar2 + dvar3;
+      A(fk + 1, fj + 1, fi) = q - dvar1 + dvar2 + dvar3;
+      A(fk + 1, fj + 1, fi + 1) = q + dvar1 + dvar2 + dvar3;
+    }
+  }
+}
+
+// offsets of slot n (the inverse of NeighborIndex, prolongation.cpp:28-53), passed as a table by the host
+struct Owned {
+  const SGeo &s; const Tab &t; int m, ox1, ox2, ox3, mylev;
+  // level of the finest existing neighbour across the face (ox) of the block, -1 when none
+  __device__ int maxlev(int a1, int a2, int a3) const {
+    int mx = -1;
+    // NeighborIndex of a face: x1 faces 0-7 (ix<0: 0..3, ix>0: 4..7), x2 faces 8-15, x3 faces 24-31
+    const int base = a1 != 0 ? (a1 < 0 ? 0 : 4) : (a2 != 0 ? (a2 < 0 ? 8 : 12) : (a3 < 0 ? 24 : 28));
+    for (int q = 0; q < 4; ++q) {
+      const int idx = base + q;
+      if (idx < t.nnghbr && NGID(t, m, idx) >= 0) { const int l = NLEV(t, m, idx); mx = l > mx ? l : mx; }
+    }
+    return mx;
+  }
+  // CanProlongateFCFace, prolongation.cpp:90-133
+  __device__ bool can(int v, int k, int j, int i) const {
+    if (!active_face(s, v, k, j, i)) return true;
+    int nox;
+    if (v == 0) {
+      if (i == s.is) nox = -1; else if (i == s.ie + 1) nox = 1; else return false;
+      return ox1 == nox && ox2 == 0 && ox3 == 0 && maxlev(nox, 0, 0) < mylev;
+    } else if (v == 1) {
+      if (j == s.js) nox = -1; else if (j == s.je + 1) nox = 1; else return false;
+      return ox1 == 0 && ox2 == nox && ox3 == 0 && maxlev(0, nox, 0) < mylev;
+    }
+    if (k == s.ks) nox = -1; else if (k == s.ke + 1) nox = 1; else return false;
+    return ox1 == 0 && ox2 == 0 && ox3 == nox && maxlev(0, 0, nox) < mylev;
+  }
+};
+
+// ---- ProlongateFC, shared faces (ProlongFCSharedX1/2/3FaceOwned, prolongation.cpp:149-258) -------
+__global__ void __launch_bounds__(256)
+k_smr_prolong_fc_shared(SGeo s, Tab t, const int *__restrict__ slot_ox, CF3 cb, F3 b) {
+  const int v = blockIdx.x%3, n = (blockIdx.x/3)%t.nnghbr, m = blockIdx.x/(3*t.nnghbr);
+  if (NGID(t, m, n) < 0 || !(NLEV(t, m, n) < t.lev[m])) return;
+  const Owned own{s, t, m, slot_ox[3*n], slot_ox[3*n + 1], slot_ox[3*n + 2], t.lev[m]};
+  const Bx bx = box_of(t.fc, T_RECV, K_PROL, n, v);
+  const int cnt = bcount(bx);
+  auto C = [&](int kk, int jj, int ii) { return cb.b[v][f4(s, 1, v, m, kk, jj, ii)]; };
+  auto ST = [&](int kk, int jj, int ii, double val) {
+    if (own.can(v, kk, jj, ii)) b.b[v][f4(s, 0, v, m, kk, jj, ii)] = val;
+  };
+  for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+    int k, j, i;
+    bdecode(bx, e, k, j, i);
+    const int fi = (i - s.cis)*2 + s.is;
+    const int fj = s.multi_d ? (j - s.cjs)*2 + s.js : j;
+    const int fk = s.three_d ? (k - s.cks)*2 + s.ks : k;
+    const double q = C(k, j, i);
+    if (v == 0) {
+      double dvar2 = 0.0, dvar3 = 0.0;
+      if (s.multi_d) dvar2 = s_mm8(q - C(k, j - 1, i), C(k, j + 1, i) - q);
+      if (s.three_d) dvar3 = s_mm8(q - C(k - 1, j, i), C(k + 1, j, i) - q);
+      ST(fk, fj, fi, q - dvar2 - dvar3);
+      if (s.multi_d) ST(fk, fj + 1, fi, q + dvar2 - dvar3);
+      if (s.three_d) { ST(fk + 1, fj, fi, q - dvar2 + dvar3); ST(fk + 1, fj + 1, fi, q + dvar2 + dvar3); }
+    } else if (v == 1) {
+      const double dvar1 = s_mm8(q - C(k, j, i - 1), C(k, j, i + 1) - q);
+      double dvar3 = 0.0;
+      if (s.three_d) dvar3 = s_mm8(q - C(k - 1, j, i), C(k + 1, j, i) - q);
+      ST(fk, fj, fi, q - dvar1 - dvar3);
+      ST(fk, fj, fi + 1, q + dvar1 - dvar3);
+      if (s.three_d) { ST(fk + 1, fj, fi, q - dvar1 + dvar3); ST(fk + 1, fj, fi + 1, q + dvar1 + dvar3); }
+    } else {
+      const double dvar1 = s_mm8(q - C(k, j, i - 1), C(k, j, i + 1) - q);
+      double dvar2 = 0.0;
+      if (s.multi_d) dvar2 = s_mm8(q - C(k, j - 1, i), C(k, j + 1, i) - q);
+      ST(fk, fj, fi, q - dvar1 - dvar2);
+      ST(fk, fj, fi + 1, q + dvar1 - dvar2);
+      if (s.multi_d) { ST(fk, fj + 1, fi, q - dvar1 + dvar2); ST(fk, fj + 1, fi + 1, q + dvar1 + dvar2); }
+    }
+  }
+}
+
+// ---- ProlongateFC, faces inside the coarse cells (ProlongFCInternalOwned, :260-359) ---------------
+__global__ void __launch_bounds__(256)
+k_smr_prolong_fc_internal(SGeo s, Tab t, const int *__restrict__ slot_ox, F3 b) {
+  const int n = blockIdx.x%t.nnghbr, m = blockIdx.x/t.nnghbr;
+  if (NGID(t, m, n) < 0 || !(NLEV(t, m, n) < t.lev[m])) return;
+  const Owned own{s, t, m, slot_ox[3*n], slot_ox[3*n + 1], slot_ox[3*n + 2], t.lev[m]};
+  const Bx p0 = box_of(t.fc, T_RECV, K_PROL, n, 0), p1 = box_of(t.fc, T_RECV, K_PROL, n, 1),
+           p2 = box_of(t.fc, T_RECV, K_PROL, n, 2);
+  const Bx bx{p2.il, p2.iu, p0.jl, p0.ju, p1.kl, p1.ku};
+  const int cnt = bcount(bx);
+  auto B1 = [&](int kk, int jj, int ii) { return b.b[0][f4(s, 0, 0, m, kk, jj, ii)]; };
+  auto B2 = [&](int kk, int jj, int ii) { return b.b[1][f4(s, 0, 1, m, kk, jj, ii)]; };
+  auto B3 = [&](int kk, int jj, int ii) { return b.b[2][f4(s, 0, 2, m, kk, jj, ii)]; };
+  auto ST = [&](int v, int kk, int jj, int ii, double val) {
+    if (own.can(v, kk, jj, ii)) b.b[v][f4(s, 0, v, m, kk, jj, ii)] = val;
+  };
+  for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+    int k, j, i;
+    bdecode(bx, e, k, j, i);
+    const int fi = (i - s.cis)*2 + s.is, fj = (j - s.cjs)*2 + s.js, fk = (k - s.cks)*2 + s.ks;
+    if (!s.multi_d) {
+      ST(0, fk, fj, fi + 1, 0.5*(B1(fk, fj, fi) + B1(fk, fj, fi + 2)));
+    } else if (s.three_d) {
+      double Uxx = 0.0, Vyy = 0.0, Wzz = 0.0, Uxyz = 0.0, Vxyz = 0.0, Wxyz = 0.0;
+      for (int jj = 0; jj < 2; jj++) {
+        const int jsgn = 2*jj - 1, fjj = fj + jj, fjp = fj + 2*jj;
+        for (int ii = 0; ii < 2; ii++) {
+          const int isgn = 2*ii - 1, fii = fi + ii, fip = fi + 2*ii;
+          Uxx += isgn*(jsgn*(B2(fk, fjp, fii) + B2(fk + 1, fjp, fii)) + (B3(fk + 2, fjj, fii) - B3(fk, fjj, fii)));
+          Vyy += jsgn*((B3(fk + 2, fjj, fii) - B3(fk, fjj, fii)) + isgn*(B1(fk, fjj, fip) + B1(fk + 1, fjj, fip)));
+          Wzz += isgn*(B1(fk + 1, fjj, fip) - B1(fk, fjj, fip)) + jsgn*(B2(fk + 1, fjp, fii) - B2(fk, fjp, fii));
+          Uxyz += isgn*jsgn*(B1(fk + 1, fjj, fip) - B1(fk, fjj, fip));
+          Vxyz += isgn*jsgn*(B2(fk + 1, fjp, fii) - B2(fk, fjp, fii));
+          Wxyz += isgn*jsgn*(B3(fk + 2, fjj, fii) - B3(fk, fjj, fii));
+        }
+      }
+      Uxx *= 0.125; Vyy *= 0.125; Wzz *= 0.125;
+      Uxyz *= 0.0625; Vxyz *= 0.0625; Wxyz *= 0.0625;
+      // all operands are read before any store of this cell (the stores touch only faces strictly
+      // inside the coarse cell, which no other cell reads)
+      const double a00 = 0.5*(B1(fk, fj, fi) + B1(fk, fj, fi + 2)), a01 = 0.5*(B1(fk, fj + 1, fi) + B1(fk, fj + 1, fi + 2)),
+                   a10 = 0.5*(B1(fk + 1, fj, fi) + B1(fk + 1, fj, fi + 2)), a11 = 0.5*(B1(fk + 1, fj + 1, fi) + B1(fk + 1, fj + 1, fi + 2));
+      const double c00 = 0.5*(B2(fk, fj, fi) + B2(fk, fj + 2, fi)), c01 = 0.5*(B2(fk, fj, fi + 1) + B2(fk, fj + 2, fi + 1)),
+                   c10 = 0.5*(B2(fk + 1, fj, fi) + B2(fk + 1, fj + 2, fi)), c11 = 0.5*(B2(fk + 1, fj, fi + 1) + B2(fk + 1, fj + 2, fi + 1));
+      const double d00 = 0.5*(B3(fk + 2, fj, fi) + B3(fk, fj, fi)), d01 = 0.5*(B3(fk + 2, fj, fi + 1) + B3(fk, fj, fi + 1)),
+                   d10 = 0.5*(B3(fk + 2, fj + 1, fi) + B3(fk, fj + 1, fi)), d11 = 0.5*(B3(fk + 2, fj + 1, fi + 1) + B3(fk, fj + 1, fi + 1));
+      ST(0, fk, fj, fi + 1, a00 + Uxx - Vxyz - Wxyz);
+      ST(0, fk, fj + 1, fi + 1, a01 + Uxx - Vxyz + Wxyz);
+      ST(0, fk + 1, fj, fi + 1, a10 + Uxx + Vxyz - Wxyz);
+      ST(0, fk + 1, fj + 1, fi + 1, a11 + Uxx + Vxyz + Wxyz);
+      ST(1, fk, fj + 1, fi, c00 + Vyy - Uxyz - Wxyz);
+      ST(1, fk, fj + 1, fi + 1, c01 + Vyy - Uxyz + Wxyz);
+      ST(1, fk + 1, fj + 1, fi, c10 + Vyy + Uxyz - Wxyz);
+      ST(1, fk + 1, fj + 1, fi + 1, c11 + Vyy + Uxyz + Wxyz);
+      ST(2, fk + 1, fj, fi, d00 + Wzz - Uxyz - Vxyz);
+      ST(2, fk + 1, fj, fi + 1, d01 + Wzz - Uxyz + Vxyz);
+      ST(2, fk + 1, fj + 1, fi, d10 + Wzz + Uxyz - Vxyz);
+      ST(2, fk + 1, fj + 1, fi + 1, d11 + Wzz + Uxyz + Vxyz);
+    } else {
+      const double tmp1 = 0.25*(B2(fk, fj + 2, fi + 1) - B2(fk, fj, fi + 1) - B2(fk, fj + 2, fi) + B2(fk, fj, fi));
+      const double tmp2 = 0.25*(B1(fk, fj, fi) - B1(fk, fj, fi + 2) - B1(fk, fj + 1, fi) + B1(fk, fj + 1, fi + 2));
+      const double a0 = 0.5*(B1(fk, fj, fi) + B1(fk, fj, fi + 2)), a1 = 0.5*(B1(fk, fj + 1, fi) + B1(fk, fj + 1, fi + 2));
+      const double c0 = 0.5*(B2(fk, fj, fi) + B2(fk, fj + 2, fi)), c1 = 0.5*(B2(fk, fj, fi + 1) + B2(fk, fj + 2, fi + 1));
+      ST(0, fk, fj, fi + 1, a0 + tmp1);
+      ST(0, fk, fj + 1, fi + 1, a1 + tmp1);
+      ST(1, fk, fj + 1, fi, c0 + tmp2);
+      ST(1, fk, fj + 1, fi + 1, c1 + tmp2);
+    }
+  }
+}
+
+// ---- PackAndSendFluxCC: restricted fluxes of a finer block into the coarser neighbour's buffer ----
+struct Flx3 { double *f[3]; };
+__global__ void __launch_bounds__(256)
+k_smr_pack_flux_cc(SGeo s, Tab t, int nvar, int fs, Flx3 flx, double *__restrict__ buf) {
+  const int v = blockIdx.x%nvar, n = (blockIdx.x/nvar)%t.nnghbr, m = blockIdx.x/(nvar*t.nnghbr);
+  const int dm = NGID(t, m, n);
+  if (dm < 0 || !(NLEV(t, m, n) < t.lev[m])) return;
+  int dir;
+  if (n < 8) dir = 0; else if (n < 16) dir = 1; else if (n >= 24 && n < 32) dir = 2; else return;
+  const Bx b = box_of(t.cc, T_SEND, K_FLXC, n, 0);
+  const int cnt = bcount(b);
+  double *out = buf + buf_at(t, 1, dm, NDST(t, m, n)) + (size_t)cnt*v;
+  const double *f = flx.f[dir];
+  auto X = [&](int kk, int jj, int ii) {
+    return f[ix5(nvar, s.N3 + (dir == 2 ? fs : 0), s.N2 + (dir == 1 ? fs : 0), s.N1 + (dir == 0 ? fs : 0), m, v, kk, jj, ii)];
+  };
+  for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+    int k, j, i;
+    bdecode(b, e, k, j, i);
+    const int fi = 2*i - s.cis, fj = 2*j - s.cjs, fk = 2*k - s.cks;
+    double r;
+    if (dir == 0) {
+      if (!s.multi_d) r = X(0, 0, fi);
+      else if (!s.three_d) r = 0.5*(X(0, fj, fi) + X(0, fj + 1, fi));
+      else r = 0.25*(X(fk, fj, fi) + X(fk, fj + 1, fi) + X(fk + 1, fj, fi) + X(fk + 1, fj + 1, fi));
+    } else if (dir == 1) {
+      if (!s.three_d) r = 0.5*(X(0, fj, fi) + X(0, fj, fi + 1));
+      else r = 0.25*(X(fk, fj, fi) + X(fk, fj, fi + 1) + X(fk + 1, fj, fi) + X(fk + 1, fj, fi + 1));
+    } else {
+      r = 0.25*(X(fk, fj, fi) + X(fk, fj, fi + 1) + X(fk, fj + 1, fi) + X(fk, fj + 1, fi + 1));
+    }
+    out[e] = r;       // box order (i fastest) == the reference's (j,k)/(i,k)/(i,j) order: one extent is 1
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_smr_unpack_flux_cc(SGeo s, Tab t, int nvar, int fs, const double *__restrict__ buf, Flx3 flx) {
+  const int v = blockIdx.x%nvar, n = (blockIdx.x/nvar)%t.nnghbr, m = blockIdx.x/(nvar*t.nnghbr);
+  if (NGID(t, m, n) < 0 || !(NLEV(t, m, n) > t.lev[m])) return;
+  int dir;
+  if (n < 8) dir = 0; else if (n < 16) dir = 1; else if (n >= 24 && n < 32) dir = 2; else return;
+  const Bx b = box_of(t.cc, T_RECV, K_FLXC, n, 0);
+  const int cnt = bcount(b);
+  const double *in = buf + buf_at(t, 1, m, n) + (size_t)cnt*v;
+  double *f = flx.f[dir];
+  for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+    int k, j, i;
+    bdecode(b, e, k, j, i);
+    f[ix5(nvar, s.N3 + (dir == 2 ? fs : 0), s.N2 + (dir == 1 ? fs : 0), s.N1 + (dir == 0 ? fs : 0), m, v, k, j, i)] = in[e];
+  }
+}
+
+// ---- edge EMFs ------------------------------------------------------------------------------------
+struct E3 { double *e[3]; };
+__device__ __forceinline__ size_t e4(const SGeo &s, int v, int m, int k, int j, int i) {
+  return ix4(s.N3 + (v != 2), s.N2 + (v != 1), s.N1 + (v != 0), m, k, j, i);
+}
+// which EMF components a slot carries (flux_correct_fc.cpp:78-284): faces the two tangential ones,
+// edges the one along the edge, corners none
+__device__ __forceinline__ bool slot_has(int n, int v) {
+  if (n < 8) return v != 0;
+  if (n < 16) return v != 1;
+  if (n < 24) return v == 2;
+  if (n < 32) return v != 2;
+  if (n < 40) return v == 1;
+  if (n < 48) return v == 0;
+  return false;
+}
+
+// PackAndSendFluxFC: same level -> the values themselves, coarser neighbour -> restricted pairs
+__global__ void __launch_bounds__(256)
+k_smr_pack_flux_fc(SGeo s, Tab t, E3 ef, double *__restrict__ buf) {
+  const int v = blockIdx.x%3, n = (blockIdx.x/3)%t.nnghbr, m = blockIdx.x/(3*t.nnghbr);
+  const int dm = NGID(t, m, n);
+  if (dm < 0 || !(NLEV(t, m, n) <= t.lev[m]) || !slot_has(n, v)) return;
+  const bool same = NLEV(t, m, n) == t.lev[m];
+  const Bx b = box_of(t.fc, T_SEND, same ? K_FLXS : K_FLXC, n, v);
+  const int cnt = bcount(b);
+  const int dn = NDST(t, m, n);
+  double *out = buf + buf_at(t, 3, dm, dn) + (size_t)ndat_of(t, 1, dn, T_RECV, same ? 3 : 4)*v;
+  const double *e = ef.e[v];
+  auto E = [&](int kk, int jj, int ii) { return e[e4(s, v, m, kk, jj, ii)]; };
+  for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
+    int k, j, i;
+    bdecode(b, q, k, j, i);
+    double r;
+    if (same) {
+      r = E(k, j, i);
+    } else {
+      const int fi = 2*i - s.cis, fj = s.multi_d ? 2*j - s.cjs : 0, fk = s.three_d ? 2*k - s.cks : 0;
+      // a coarse edge of component v is the average of the two fine edges along direction v; in
+      // collapsed directions there is one (flux_correct_fc.cpp:88-101,136-148,...)
+      if (v == 0) r = 0.5*(E(fk, fj, fi) + E(fk, fj, fi + 1));
+      else if (v == 1) r = s.multi_d ? 0.5*(E(fk, fj, fi) + E(fk, fj + 1, fi)) : E(0, 0, fi);
+      else r = s.three_d ? 0.5*(E(fk, fj, fi) + E(fk + 1, fj, fi)) : E(0, fj, fi);
+    }
+    out[q] = r;
+  }
+}
+
+// SumBoundaryFluxes: slots of a (block, component) one after the other
+__global__ void __launch_bounds__(256)
+k_smr_sum_flux_fc(SGeo s, Tab t, int same_level, const double *__restrict__ buf, E3 ef) {
+  const int v = blockIdx.x%3, m = blockIdx.x/3;
+  const int ml = t.lev[m];
+  double *e = ef.e[v];
+  for (int n = 0; n < t.nnghbr && n < 48; ++n) {
+    if (NGID(t, m, n) < 0) continue;
+    const int nl = NLEV(t, m, n);
+    if (!((same_level && nl == ml) || (!same_level && nl > ml)) || !slot_has(n, v)) continue;
+    const Bx b = box_of(t.fc, T_RECV, same_level ? K_FLXS : K_FLXC, n, v);
+    const int cnt = bcount(b);
+    const double *in = buf + buf_at(t, 3, m, n) + (size_t)ndat_of(t, 1, n, T_RECV, same_level ? 3 : 4)*v;
+    for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
+      int k, j, i;
+      bdecode(b, q, k, j, i);
+      e[e4(s, v, m, k, j, i)] += in[q];
+    }
+    __syncthreads();
+  }
+}
+
+// ZeroFluxesAtBoundaryWithFiner
+__global__ void __launch_bounds__(256)
+k_smr_zero_flux_fc(SGeo s, Tab t, E3 ef) {
+  const int v = blockIdx.x%3, n = (blockIdx.x/3)%t.nnghbr, m = blockIdx.x/(3*t.nnghbr);
+  if (n >= 48 || NGID(t, m, n) < 0 || !(NLEV(t, m, n) > t.lev[m]) || !slot_has(n, v)) return;
+  const Bx b = box_of(t.fc, T_RECV, K_FLXC, n, v);
+  const int cnt = bcount(b);
+  for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
+    int k, j, i;
+    bdecode(b, q, k, j, i);
+    ef.e[v][e4(s, v, m, k, j, i)] = 0.0;
+  }
+}
+
+// AverageBoundaryFluxes (flux_correct_fc.cpp:801-1034); nflx[nmb][48] from the host (the counting
+// of :470-570 and :676-760 depends on the neighbour table only)
+__global__ void __launch_bounds__(256)
+k_smr_average_flux_fc(SGeo s, Tab t, const int *__restrict__ nflx, E3 ef) {
+  const int v = blockIdx.x%3, n = (blockIdx.x/3)%t.nnghbr, m = blockIdx.x/(3*t.nnghbr);
+  if (n >= 48 || !slot_has(n, v)) return;
+  // only the first sub-block slot of a face / edge carries the averaging (n = 0,4,8,12,16,18,...)
+  const bool face = (n == 0 || n == 4 || n == 8 || n == 12 || n == 24 || n == 28);
+  const bool edge = (n >= 16 && n < 24 && n%2 == 0) || (n >= 32 && n < 48 && n%2 == 0);
+  if (!face && !edge) return;
+  Bx b = box_of(t.fc, T_RECV, K_FLXS, n, v);
+  if (b.iu < b.il || b.ju < b.jl || b.ku < b.kl) return;
+  double *e = ef.e[v];
+  if (edge) {
+    const double d = (double)nflx[(size_t)m*48 + n];
+    const int cnt = bcount(b);
+    for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
+      int k, j, i;
+      bdecode(b, q, k, j, i);
+      e[e4(s, v, m, k, j, i)] /= d;
+    }
+    return;
+  }
+  const int nl = NLEV(t, m, n), ml = t.lev[m];       // nl = -1 when there is no neighbour
+  // direction along which the face box is trimmed (same level) or halved (finer): the extended one,
+  // i.e. the tangential direction other than v
+  const int fdir = n < 8 ? 0 : (n < 16 ? 1 : 2);
+  const int tdir = 3 - fdir - v;
+  const bool tact = tdir == 0 ? true : (tdir == 1 ? s.multi_d != 0 : s.three_d != 0);
+  int *lo = tdir == 0 ? &b.il : (tdir == 1 ? &b.jl : &b.kl);
+  int *hi = tdir == 0 ? &b.iu : (tdir == 1 ? &b.ju : &b.ku);
+  if (nl == ml) {
+    if (tact) { *lo += 1; *hi -= 1; }
+  } else if (nl >= ml) {
+    if (!tact) return;
+    const int mid = *lo + (*hi - *lo + 1)/2;
+    *lo = mid; *hi = mid;
+  } else {
+    return;
+  }
+  if (*hi < *lo) return;
+  const int cnt = bcount(b);
+  for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
+    int k, j, i;
+    bdecode(b, q, k, j, i);
+    e[e4(s, v, m, k, j, i)] *= 0.5;
+  }
+}
+
+static int check_smr(const akmi_pack *p, const akmi_smr *t, const char *who) {
+  if (!p || !t || !t->nghbr || !t->mblev || !t->cc_tab || !t->fc_tab || !t->layout || !t->ndat) {
+    set_error("%s: incomplete akmi_smr descriptor", who);
+    return AKMI_FAIL;
+  }
+  if (p->nx1 % 2 || (p->nx2 > 1 && p->nx2 % 2) || (p->nx3 > 1 && p->nx3 % 2) || p->ng % 2) {
+    set_error("%s: MeshBlock cells and ghost cells must be even with mesh refinement", who);
+    return AKMI_FAIL;
+  }
+  return AKMI_COMPLETE;
+}
+
+}  // namespace akmi
+
+using namespace akmi;
+
+extern "C" {
+
+int akmi_smr_exchange_cc(const akmi_pack *p, const akmi_smr *t, int nvar, double *u, double *cu,
+                         double *buf, void *stream) {
+  if (check_smr(p, t, "smr_exchange_cc") != AKMI_COMPLETE) return AKMI_FAIL;
+  const SGeo s = make_sgeo(p);
+  const Tab tb = make_tab(t);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nb = (unsigned)p->nmb*tb.nnghbr*nvar;
+  k_smr_pack_cc<<<nb, 256, 0, st>>>(s, tb, nvar, u, cu, buf);
+  k_smr_unpack_cc<<<nb, 256, 0, st>>>(s, tb, nvar, buf, u, cu);
+  AKMI_CHECK_LAUNCH("smr_exchange_cc");
+  return AKMI_COMPLETE;
+}
+
+int akmi_smr_exchange_fc(const akmi_pack *p, const akmi_smr *t, double *b1, double *b2, double *b3,
+                         double *cb1, double *cb2, double *cb3, double *buf, void *stream) {
+  if (check_smr(p, t, "smr_exchange_fc") != AKMI_COMPLETE) return AKMI_FAIL;
+  const SGeo s = make_sgeo(p);
+  const Tab tb = make_tab(t);
+  hipStream_t st = (hipStream_t)stream;
+  k_smr_pack_fc<<<(unsigned)p->nmb*tb.nnghbr*3, 256, 0, st>>>(s, tb, CF3{{b1, b2, b3}}, CF3{{cb1, cb2, cb3}}, buf);
+  k_smr_unpack_fc<<<(unsigned)p->nmb*3, 256, 0, st>>>(s, tb, buf, F3{{b1, b2, b3}}, F3{{cb1, cb2, cb3}});
+  AKMI_CHECK_LAUNCH("smr_exchange_fc");
+  return AKMI_COMPLETE;
+}
+
+int akmi_smr_fill_coarse_cc(const akmi_pack *p, const akmi_smr *t, int nvar, const double *u, double *cu,
+                            void *stream) {
+  if (check_smr(p, t, "smr_fill_coarse_cc") != AKMI_COMPLETE) return AKMI_FAIL;
+  if (p->nx2 <= 1) return AKMI_COMPLETE;
+  const Tab tb = make_tab(t);
+  k_smr_fill_coarse_cc<<<(unsigned)p->nmb*tb.nnghbr*nvar, 256, 0, (hipStream_t)stream>>>(make_sgeo(p), tb, nvar, u, cu);
+  AKMI_CHECK_LAUNCH("smr_fill_coarse_cc");
+  return AKMI_COMPLETE;
+}
+
+int akmi_smr_fill_coarse_fc(const akmi_pack *p, const akmi_smr *t, const double *b1, const double *b2,
+                            const double *b3, double *cb1, double *cb2, double *cb3, void *stream) {
+  if (check_smr(p, t, "smr_fill_coarse_fc") != AKMI_COMPLETE) return AKMI_FAIL;
+  if (p->nx2 <= 1) return AKMI_COMPLETE;
+  const Tab tb = make_tab(t);
+  k_smr_fill_coarse_fc<<<(unsigned)p->nmb*tb.nnghbr*3, 256, 0, (hipStream_t)stream>>>(
+      make_sgeo(p), tb, CF3{{b1, b2, b3}}, F3{{cb1, cb2, cb3}});
+  AKMI_CHECK_LAUNCH("smr_fill_coarse_fc");
+  return AKMI_COMPLETE;
+}
+
+int akmi_smr_prolong_cc(const akmi_pack *p, const akmi_smr *t, int nvar, const double *cu, double *u,
+                        void *stream) {
+  if (check_smr(p, t, "smr_prolong_cc") != AKMI_COMPLETE) return AKMI_FAIL;
+  const Tab tb = make_tab(t);
+  k_smr_prolong_cc<<<(unsigned)p->nmb*tb.nnghbr*nvar, 256, 0, (hipStream_t)stream>>>(make_sgeo(p), tb, nvar, cu, u);
+  AKMI_CHECK_LAUNCH("smr_prolong_cc");
+  return AKMI_COMPLETE;
+}
+
+int akmi_smr_prolong_fc(const akmi_pack *p, const akmi_smr *t, const double *cb1, const double *cb2,
+                        const double *cb3, double *b1, double *b2, double *b3, void *stream) {
+  if (check_smr(p, t, "smr_prolong_fc") != AKMI_COMPLETE) return AKMI_FAIL;
+  if (!t->slot_ox) { set_error("smr_prolong_fc: slot offsets missing"); return AKMI_FAIL; }
+  const SGeo s = make_sgeo(p);
+  const Tab tb = make_tab(t);
+  hipStream_t st = (hipStream_t)stream;
+  k_smr_prolong_fc_shared<<<(unsigned)p->nmb*tb.nnghbr*3, 256, 0, st>>>(s, tb, t->slot_ox, CF3{{cb1, cb2, cb3}},
+                                                                     F3{{b1, b2, b3}});
+  k_smr_prolong_fc_internal<<<(unsigned)p->nmb*tb.nnghbr, 256, 0, st>>>(s, tb, t->slot_ox, F3{{b1, b2, b3}});
+  AKMI_CHECK_LAUNCH("smr_prolong_fc");
+  return AKMI_COMPLETE;
+}
+
+int akmi_smr_flux_cc(const akmi_pack *p, const akmi_smr *t, int nvar, int face_shaped, double *flx1,
+                     double *flx2, double *flx3, double *buf, void *stream) {
+  if (check_smr(p, t, "smr_flux_cc") != AKMI_COMPLETE) return AKMI_FAIL;
+  const SGeo s = make_sgeo(p);
+  const Tab tb = make_tab(t);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nb = (unsigned)p->nmb*tb.nnghbr*nvar;
+  const int fs = face_shaped ? 1 : 0;
+  k_smr_pack_flux_cc<<<nb, 256, 0, st>>>(s, tb, nvar, fs, Flx3{{flx1, flx2, flx3}}, buf);
+  k_smr_unpack_flux_cc<<<nb, 256, 0, st>>>(s, tb, nvar, fs, buf, Flx3{{flx1, flx2, flx3}});
+  AKMI_CHECK_LAUNCH("smr_flux_cc");
+  return AKMI_COMPLETE;
+}
+
+int akmi_smr_emf_exchange(const akmi_pack *p, const akmi_smr *t, const int *nflx, double *e1, double *e2,
+                          double *e3, double *buf, void *stream) {
+  if (check_smr(p, t, "smr_emf_exchange") != AKMI_COMPLETE) return AKMI_FAIL;
+  const SGeo s = make_sgeo(p);
+  const Tab tb = make_tab(t);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nb = (unsigned)p->nmb*tb.nnghbr*3;
+  const E3 ef{{e1, e2, e3}};
+  k_smr_pack_flux_fc<<<nb, 256, 0, st>>>(s, tb, ef, buf);
+  k_smr_sum_flux_fc<<<(unsigned)p->nmb*3, 256, 0, st>>>(s, tb, 1, buf, ef);
+  if (tb.multilevel) {
+    k_smr_zero_flux_fc<<<nb, 256, 0, st>>>(s, tb, ef);
+    k_smr_sum_flux_fc<<<(unsigned)p->nmb*3, 256, 0, st>>>(s, tb, 0, buf, ef);
+  }
+  k_smr_average_flux_fc<<<nb, 256, 0, st>>>(s, tb, nflx, ef);
+  AKMI_CHECK_LAUNCH("smr_emf_exchange");
+  return AKMI_COMPLETE;
+}
+
+}  // extern "C"

@@ -119,6 +119,24 @@ class FluidBase:
         self.dt3 = torch.zeros(3, dtype=torch.float64, device=device)
         self.dtnew = FLT_MAX
         self.ws = None
+        self.multilevel = pm.multilevel
+        if pm.multilevel:
+            # the restricted fluxes of finer neighbours replace face fluxes between Fluxes and
+            # RKUpdate (SendFlux/RecvFlux): the flux arrays of the task-granular path are needed
+            self.fused = False
+            # the coarse buffers seen as a pack of nx/2 cells: HydroBCsCoarse / BFieldBCsCoarse are
+            # the BC helpers on coarse indices (src/bvals/physics/hydro_bcs.cpp:51-67)
+            self.cpack_c = capi.Pack(self.nmb, self.nvars, indcs.nx1//2,
+                                     indcs.nx2//2 if indcs.nx2 > 1 else 1,
+                                     indcs.nx3//2 if indcs.nx3 > 1 else 1, indcs.ng,
+                                     self.dx_dev.data_ptr(), e.gamma, e.dfloor, e.pfloor, e.tfloor,
+                                     e.sfloor, e.sigma_max, e.iso_cs, 1 if e.is_ideal else 0)
+
+    def _coarse_shape(self):
+        """(cn3, cn2, cn1) of coarse_u0 (hydro.cpp:300-310)"""
+        i = self.pmy_pack.pmesh.mb_indcs
+        return (i.nx3//2 + 2*i.ng if i.nx3 > 1 else 1, i.nx2//2 + 2*i.ng if i.nx2 > 1 else 1,
+                i.nx1//2 + 2*i.ng)
 
     def _workspace(self, is_mhd):
         if self.ws is None:
@@ -148,7 +166,7 @@ class FluidBase:
 
 
 class Hydro(FluidBase):
-    def __init__(self, ppack, pin, device=None, bvals_kernels=None):
+    def __init__(self, ppack, pin, device=None, bvals_kernels=None, smr_kernels=None):
         device = device or capi.DEVICE
         self._setup(ppack, pin, "hydro", device)
         rs = pin.GetString("hydro", "rsolver")
@@ -172,6 +190,14 @@ class Hydro(FluidBase):
         self.uflx = None if self.fused else FaceFld(self.nmb, self.nvars, n3, n2, n1, device, face_shaped=False)
         self.pbval_u = MeshBoundaryValues(ppack, bvals_kernels, device)
         self.pbval_u.set_pack(self.pack_c, self.nvars)
+        self.psmr = None
+        if self.multilevel:
+            from .bvals_smr import MeshBoundaryValuesSMR
+            c3, c2, c1 = self._coarse_shape()
+            self.coarse_u0 = torch.zeros((self.nmb, self.nvars, c3, c2, c1), dtype=torch.float64,
+                                         device=device)
+            self.psmr = MeshBoundaryValuesSMR(ppack, self.nvars, smr_kernels, device)
+            self.psmr.set_pack(self.pack_c)
 
     # ---- task list assembly: hydro_tasks.cpp:48-80 ---------------------------------
     def AssembleHydroTasks(self, tl):
@@ -204,8 +230,30 @@ class Hydro(FluidBase):
     def _noop(self, pdrive, stage):
         return TaskStatus.complete
 
-    InitRecv = SendFlux = RecvFlux = HydroSrcTerms = SendU_OA = RecvU_OA = _noop
-    RestrictU = SendU_Shr = RecvU_Shr = Prolongate = ClearSend = ClearRecv = _noop
+    InitRecv = RecvFlux = HydroSrcTerms = SendU_OA = RecvU_OA = _noop
+    SendU_Shr = RecvU_Shr = ClearSend = ClearRecv = _noop
+
+    def SendFlux(self, pdrive, stage):
+        """hydro_tasks.cpp:206-215: restricted fluxes at fine/coarse boundaries (SMR only)"""
+        if self.multilevel:
+            return self.psmr.PackAndSendFluxCC(self.uflx, False)
+        return TaskStatus.complete
+
+    def RestrictU(self, pdrive, stage):
+        """hydro_tasks.cpp:291-300"""
+        if self.multilevel:
+            return self.psmr.RestrictCC(self.u0, self.coarse_u0)
+        return TaskStatus.complete
+
+    def Prolongate(self, pdrive, stage):
+        """hydro_tasks.cpp:381-400 (conserved variables; prolong_primitives is refused)"""
+        if self.multilevel:
+            self.psmr.FillCoarseInBndryCC(self.u0, self.coarse_u0)
+            if not self.pmy_pack.pmesh.strictly_periodic:
+                self.pbval_u.k.hydro_bcs(self.cpack_c, self.nvars, self.pbval_u.bcs, self.coarse_u0,
+                                         self.pbval_u.u_in)
+            self.psmr.ProlongateCC(self.u0, self.coarse_u0)
+        return TaskStatus.complete
 
     def CopyCons(self, pdrive, stage):
         """hydro_tasks.cpp:130-152 (folded into the fused stage kernel when fused)"""
@@ -276,6 +324,8 @@ class Hydro(FluidBase):
             self._dt_ready = bool(do_dt)
 
     def SendU(self, pdrive, stage):
+        if self.multilevel:
+            return self.psmr.PackAndSendCC(self.u0, self.coarse_u0)
         st = self.pbval_u.PackAndSendCC(self.u0)
         if self.fused and self.pbval_u.peers:
             # the messages are in flight on the transport's stream: convert the active cells
@@ -284,6 +334,8 @@ class Hydro(FluidBase):
         return st
 
     def RecvU(self, pdrive, stage):
+        if self.multilevel:
+            return self.psmr.RecvAndUnpackCC(self.u0, self.coarse_u0)
         return self.pbval_u.RecvAndUnpackCC(self.u0)
 
     def ApplyPhysicalBCs(self, pdrive, stage):

@@ -111,16 +111,19 @@ class MeshBlock:
         self.pmy_pack = pack
         self.nmb = nmb
         self.mb_gid = np.arange(igids, igids + nmb, dtype=np.int32)
-        self.mb_lev = np.zeros(nmb, dtype=np.int32)
+        # logical level of each block: root_level on a uniform mesh (meshblock.cpp:37)
+        self.mb_lev = np.array([pm.level_of(igids + m) for m in range(nmb)], dtype=np.int32)
         self.mb_size = [None]*nmb                              # RegionSize per block
         self.mb_bcs = np.zeros((nmb, 6), dtype=np.int32)       # BoundaryFlag per face
-        nb = (pm.nmb_rootx1, pm.nmb_rootx2, pm.nmb_rootx3)
+        nbr = (pm.nmb_rootx1, pm.nmb_rootx2, pm.nmb_rootx3)
         active = (True, pm.multi_d, pm.three_d)
         mmin = (ms.x1min, ms.x2min, ms.x3min)
         mmax = (ms.x1max, ms.x2max, ms.x3max)
         nxb = (pm.mb_indcs.nx1, pm.mb_indcs.nx2, pm.mb_indcs.nx3)
         for m in range(nmb):
             lloc = pm.lloc_eachmb[igids + m]
+            # blocks per direction at the level of this block: nmb_rootx << (lev - root_level)
+            nb = tuple(n << (int(self.mb_lev[m]) - pm.root_level) for n in nbr)
             lim = []
             for q in range(3):
                 l = lloc[q]
@@ -147,8 +150,16 @@ class MeshBlock:
 
     def SetNeighbors(self):
         """Same-level neighbour table (reduced NeighborBlock, src/mesh/mesh.hpp:47-52):
-        nghbr_gid[m][d], nghbr_rank[m][d] with d=(ox3+1)*9+(ox2+1)*3+(ox1+1); -1 = none."""
+        nghbr_gid[m][d], nghbr_rank[m][d] with d=(ox3+1)*9+(ox2+1)*3+(ox1+1); -1 = none.
+        Multilevel meshes: nghbr[m] = {slot: NeighborBlock(gid, lev, rank, dest)} with the 56
+        slots of NeighborIndex (src/mesh/meshblock.cpp:142-425)."""
         pm = self.pmy_pack.pmesh
+        if pm.multilevel:
+            from .mesh_tree import SetNeighbors
+            self.nghbr = [SetNeighbors(pm.ptree, pm.lloc_eachmb[int(g)], pm.rank_eachmb, True)
+                          for g in self.mb_gid]
+            self.nghbr_gid = self.nghbr_rank = None
+            return
         nb = (pm.nmb_rootx1, pm.nmb_rootx2, pm.nmb_rootx3)
         self.nghbr_gid = -np.ones((self.nmb, 27), dtype=np.int32)
         self.nghbr_rank = -np.ones((self.nmb, 27), dtype=np.int32)
@@ -259,16 +270,39 @@ class Mesh:
         self.nmb_total = self.nmb_rootx1*self.nmb_rootx2*self.nmb_rootx3
         self.multilevel = False
         self.adaptive = False
+        self.root_level = 0
+        self.ptree = None
+        ref = "none"
         if pin.DoesBlockExist("mesh_refinement"):
-            if pin.GetOrAddString("mesh_refinement", "refinement", "none") != "none":
-                raise RuntimeError("### FATAL ERROR mesh refinement is not on this build's path "
-                                   "(SURVEY.md section 8(f) item 1)")
-        # Z-ordered list of logical locations (x1 fastest), build_tree.cpp:243-258
-        ll = [(l1, l2, l3) for l3 in range(self.nmb_rootx3) for l2 in range(self.nmb_rootx2)
-              for l1 in range(self.nmb_rootx1)]
-        ll.sort(key=lambda l: _morton(*l))
-        self.lloc_eachmb = ll
-        self.gid_of_lloc = {l: i for i, l in enumerate(ll)}
+            ref = pin.GetOrAddString("mesh_refinement", "refinement", "none")
+        if ref == "static":
+            # Mesh::BuildTreeFromScratch with <refined_region*> blocks, build_tree.cpp:32-258
+            from .mesh_tree import BuildTreeFromScratch
+            if pin.DoesParameterExist("mesh_refinement", "prolong_primitives") and \
+                    pin.GetBoolean("mesh_refinement", "prolong_primitives"):
+                raise RuntimeError("### FATAL ERROR <mesh_refinement>/prolong_primitives is not on this "
+                                   "build's path")
+            if ng % 2:
+                raise RuntimeError("### FATAL ERROR Number of ghost cells must be divisible by two for "
+                                   "SMR/AMR calculations")
+            if nranks > 1:
+                raise RuntimeError("### FATAL ERROR mesh refinement with more than one rank is not on "
+                                   "this build's path yet")
+            self.ptree, ll, self.root_level, self.max_level = BuildTreeFromScratch(pin)
+            self.multilevel = True
+            self.lloc_eachmb = ll                      # LogicalLocation(lx1, lx2, lx3, level)
+            self.gid_of_lloc = {tuple(l): i for i, l in enumerate(ll)}
+            self.nmb_total = len(ll)
+        elif ref != "none":
+            raise RuntimeError("### FATAL ERROR <mesh_refinement>/refinement = '%s': only static "
+                               "refinement is on this build's path" % ref)
+        else:
+            # Z-ordered list of logical locations (x1 fastest), build_tree.cpp:243-258
+            ll = [(l1, l2, l3) for l3 in range(self.nmb_rootx3) for l2 in range(self.nmb_rootx2)
+                  for l1 in range(self.nmb_rootx1)]
+            ll.sort(key=lambda l: _morton(*l))
+            self.lloc_eachmb = ll
+            self.gid_of_lloc = {l: i for i, l in enumerate(ll)}
         if self.nmb_total < nranks:
             raise RuntimeError("### FATAL ERROR Fewer MeshBlocks (nmb_total=%d) than ranks "
                                "(nranks=%d)" % (self.nmb_total, nranks))
@@ -287,6 +321,10 @@ class Mesh:
         self.nmb_packs_thisrank = 1
         self.pmb_pack.AddMeshBlocks(pin)
         self.pgen = None
+
+    def level_of(self, gid):
+        """logical level of MeshBlock gid"""
+        return self.lloc_eachmb[gid].level if self.multilevel else self.root_level
 
     def NumberOfMeshBlockCells(self):
         return self.mb_indcs.nx1*self.mb_indcs.nx2*self.mb_indcs.nx3

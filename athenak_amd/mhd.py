@@ -15,7 +15,7 @@ from .tasklist import TaskID, TaskStatus
 
 
 class MHD(FluidBase):
-    def __init__(self, ppack, pin, device=None, bvals_kernels=None):
+    def __init__(self, ppack, pin, device=None, bvals_kernels=None, smr_kernels=None):
         device = device or capi.DEVICE
         self._setup(ppack, pin, "mhd", device)
         rs = pin.GetString("mhd", "rsolver")
@@ -47,6 +47,15 @@ class MHD(FluidBase):
         self.pbval_u = MeshBoundaryValues(ppack, bvals_kernels, device)
         self.pbval_u.set_pack(self.pack_c, self.nvars)
         self.pbval_b = self.pbval_u       # same neighbour tables; separate FC channel inside
+        self.psmr = None
+        if self.multilevel:
+            # coarse buffers (mhd.cpp:368-380) and the level-aware boundary values
+            from .bvals_smr import MeshBoundaryValuesSMR
+            c3, c2, c1 = self._coarse_shape()
+            self.coarse_u0 = torch.zeros((nmb, self.nvars, c3, c2, c1), dtype=torch.float64, device=device)
+            self.coarse_b0 = FaceFld(nmb, 0, c3, c2, c1, device)
+            self.psmr = MeshBoundaryValuesSMR(ppack, self.nvars, smr_kernels, device)
+            self.psmr.set_pack(self.pack_c)
 
     # ---- task list assembly: mhd_tasks.cpp:38-84 -----------------------------------
     def AssembleMHDTasks(self, tl):
@@ -77,14 +86,51 @@ class MHD(FluidBase):
     def _noop(self, pdrive, stage):
         return TaskStatus.complete
 
-    SaveMHDState = InitRecv = SendFlux = RecvFlux = MHDSrcTerms = SendU_OA = RecvU_OA = _noop
-    RestrictU = SendU_Shr = RecvU_Shr = SendB_OA = RecvB_OA = RestrictB = _noop
-    SendB_Shr = RecvB_Shr = Prolongate = ClearSend = ClearRecv = _noop
-    # SendE/RecvE (mhd_tasks.cpp:402-417): on a uniform mesh every copy of a shared edge EMF
-    # is computed by the same deterministic kernel from identical inputs, so the reference's
-    # sum-and-average, (a+a)*0.5, returns a bit for bit (flux_correct_fc.cpp:843-860):
-    # nothing to exchange.  Fine/coarse averaging belongs to SURVEY.md section 8(f) item 1.
-    SendE = RecvE = _noop
+    SaveMHDState = InitRecv = RecvFlux = MHDSrcTerms = SendU_OA = RecvU_OA = _noop
+    SendU_Shr = RecvU_Shr = SendB_OA = RecvB_OA = _noop
+    SendB_Shr = RecvB_Shr = ClearSend = ClearRecv = RecvE = _noop
+
+    def SendE(self, pdrive, stage):
+        """mhd_tasks.cpp:402-417 (PackAndSendFluxFC + RecvAndUnpackFluxFC).  On a uniform mesh every
+        copy of a shared edge EMF is computed by the same deterministic kernel from identical inputs:
+        the reference's sum and average, (a+a)*0.5 on faces and (((a+a)+a)+a)/4 on edges, return a
+        bit for bit (2a and 4a are exact, fl(3a)+a rounds to 4a), so nothing is exchanged there.
+        With levels this is the flux correction of the field: akmi_smr_emf_exchange."""
+        if self.multilevel:
+            return self.psmr.PackAndSendFluxFC(self.efld)
+        return TaskStatus.complete
+
+    def SendFlux(self, pdrive, stage):
+        """mhd_tasks.cpp:225-233"""
+        if self.multilevel:
+            return self.psmr.PackAndSendFluxCC(self.uflx, True)
+        return TaskStatus.complete
+
+    def RestrictU(self, pdrive, stage):
+        """mhd_tasks.cpp:315-322"""
+        if self.multilevel:
+            return self.psmr.RestrictCC(self.u0, self.coarse_u0)
+        return TaskStatus.complete
+
+    def RestrictB(self, pdrive, stage):
+        """mhd_tasks.cpp:691-697"""
+        if self.multilevel:
+            return self.psmr.RestrictFC(self.b0, self.coarse_b0)
+        return TaskStatus.complete
+
+    def Prolongate(self, pdrive, stage):
+        """mhd_tasks.cpp:527-552 (conserved variables; prolong_primitives is refused)"""
+        if self.multilevel:
+            ps, pb = self.psmr, self.pbval_u
+            ps.FillCoarseInBndryCC(self.u0, self.coarse_u0)
+            ps.FillCoarseInBndryFC(self.b0, self.coarse_b0)
+            if not self.pmy_pack.pmesh.strictly_periodic:
+                pb.k.hydro_bcs(self.cpack_c, self.nvars, pb.bcs, self.coarse_u0, pb.u_in)
+                pb.k.bfield_bcs(self.cpack_c, pb.bcs, self.coarse_b0.x1f, self.coarse_b0.x2f,
+                                self.coarse_b0.x3f, pb.b_in)
+            ps.ProlongateCC(self.u0, self.coarse_u0)
+            ps.ProlongateFC(self.b0, self.coarse_b0)
+        return TaskStatus.complete
 
     def _b(self, f):
         return capi._p(f.x1f), capi._p(f.x2f), capi._p(f.x3f)
@@ -159,9 +205,13 @@ class MHD(FluidBase):
             self._dt_ready = bool(do_dt)
 
     def SendU(self, pdrive, stage):
+        if self.multilevel:
+            return self.psmr.PackAndSendCC(self.u0, self.coarse_u0)
         return self.pbval_u.PackAndSendCC(self.u0)
 
     def RecvU(self, pdrive, stage):
+        if self.multilevel:
+            return self.psmr.RecvAndUnpackCC(self.u0, self.coarse_u0)
         if self.fused and self.pbval_u.peers:
             return TaskStatus.complete      # completed in RecvB, after the kernels it can hide under
         return self.pbval_u.RecvAndUnpackCC(self.u0)
@@ -192,12 +242,16 @@ class MHD(FluidBase):
         return TaskStatus.complete
 
     def SendB(self, pdrive, stage):
+        if self.multilevel:
+            return self.psmr.PackAndSendFC(self.b0, self.coarse_b0)
         st = self.pbval_b.PackAndSendFC(self.b0)
         if self.fused and self.pbval_u.peers:
             self._stage_phase(pdrive, stage, capi.PHASE_C2P)
         return st
 
     def RecvB(self, pdrive, stage):
+        if self.multilevel:
+            return self.psmr.RecvAndUnpackFC(self.b0, self.coarse_b0)
         if self.fused and self.pbval_u.peers:
             self.pbval_u.RecvAndUnpackCC(self.u0)
         return self.pbval_b.RecvAndUnpackFC(self.b0)

@@ -173,6 +173,36 @@ class ProblemGenerator:
         x3f = LeftEdgeX(k, ind.nx3, sz.x3min, sz.x3max)
         return x1v, x2v, x3v, x1f, x2f, x3f, sz
 
+    def _finer_edge_masks(self, m):
+        """Boolean masks over the edge-centred potentials a1, a2, a3 of block m ([nx3+1, nx2+1, nx1+1]
+        each): True where the edge lies on a face or edge shared with a FINER neighbour.  There the
+        reference evaluates the potential as the mean of the two fine-edge values, which makes the
+        flux through shared fine/coarse faces identical (linear_wave.cpp:569-667, cpaw.cpp:227-325).
+        None on a single-level mesh."""
+        pm = self.pmy_mesh_
+        if not pm.multilevel:
+            return None
+        ind = pm.mb_indcs
+        nb = pm.pmb_pack.pmb.nghbr[m]
+        mylev = int(pm.pmb_pack.pmb.mb_lev[m])
+
+        def finer(*slots):
+            return any(n in nb and nb[n].lev > mylev for n in slots)
+        n3, n2, n1 = ind.nx3 + 1, ind.nx2 + 1, ind.nx1 + 1
+        K, J, I = np.meshgrid(np.arange(n3), np.arange(n2), np.arange(n1), indexing="ij")
+        ilo, ihi, jlo, jhi, klo, khi = I == 0, I == ind.nx1, J == 0, J == ind.nx2, K == 0, K == ind.nx3
+        f = np.zeros((n3, n2, n1), dtype=bool)
+        x1 = (ilo & finer(0, 1, 2, 3)) | (ihi & finer(4, 5, 6, 7))
+        x2 = f.copy() if ind.nx2 == 1 else (jlo & finer(8, 9, 10, 11)) | (jhi & finer(12, 13, 14, 15))
+        x3 = f.copy() if ind.nx3 == 1 else (klo & finer(24, 25, 26, 27)) | (khi & finer(28, 29, 30, 31))
+        e12 = f.copy() if ind.nx2 == 1 else ((ilo & jlo & finer(16, 17)) | (ihi & jlo & finer(18, 19)) |
+                                             (ilo & jhi & finer(20, 21)) | (ihi & jhi & finer(22, 23)))
+        e31 = f.copy() if ind.nx3 == 1 else ((ilo & klo & finer(32, 33)) | (ihi & klo & finer(34, 35)) |
+                                             (ilo & khi & finer(36, 37)) | (ihi & khi & finer(38, 39)))
+        e23 = f.copy() if ind.nx3 == 1 else ((jlo & klo & finer(40, 41)) | (jhi & klo & finer(42, 43)) |
+                                             (jlo & khi & finer(44, 45)) | (jhi & khi & finer(46, 47)))
+        return (x2 | x3 | e23), (x1 | x3 | e31), (x1 | x2 | e12)
+
     def _active(self):
         ind = self.pmy_mesh_.mb_indcs
         return (slice(ind.ks, ind.ke + 1), slice(ind.js, ind.je + 1), slice(ind.is_, ind.ie + 1))
@@ -353,6 +383,11 @@ class ProblemGenerator:
                 a2 = A2(F1, V2, F3)
                 a3 = A3(F1, F2, V3)
                 dx1, dx2, dx3 = sz.dx1, sz.dx2, sz.dx3
+                masks = self._finer_edge_masks(m)
+                if masks is not None:                    # linear_wave.cpp:569-667
+                    a1 = np.where(masks[0], 0.5*(A1(V1 + 0.25*dx1, F2, F3) + A1(V1 - 0.25*dx1, F2, F3)), a1)
+                    a2 = np.where(masks[1], 0.5*(A2(F1, V2 + 0.25*dx2, F3) + A2(F1, V2 - 0.25*dx2, F3)), a2)
+                    a3 = np.where(masks[2], 0.5*(A3(F1, F2, V3 + 0.25*dx3) + A3(F1, F2, V3 - 0.25*dx3)), a3)
                 b1 = (a3[:-1, 1:, :] - a3[:-1, :-1, :])/dx2 - (a2[1:, :-1, :] - a2[:-1, :-1, :])/dx3
                 b2 = (a1[1:, :, :-1] - a1[:-1, :, :-1])/dx3 - (a3[:-1, :, 1:] - a3[:-1, :, :-1])/dx1
                 b3 = (a2[:, :-1, 1:] - a2[:, :-1, :-1])/dx1 - (a1[:, 1:, :-1] - a1[:, :-1, :-1])/dx2

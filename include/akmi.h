@@ -295,6 +295,60 @@ int akmi_prolong_fc_shared(const akmi_pack *p, int comp, const int *box, const d
 int akmi_prolong_fc_internal(const akmi_pack *p, const int *box, double *bx1f, double *bx2f,
                              double *bx3f, void *stream);
 
+/* ---- boundary values of a statically refined pack --------------------------
+ * The reference keeps, per MeshBoundaryValues object, 56 MeshBoundaryBuffers with the index ranges
+ * of every slot (src/bvals/bvals.hpp:62-107, buffs_cc.cpp, buffs_fc.cpp) and the NeighborBlock table
+ * of every MeshBlock (src/mesh/mesh.hpp:47-52).  A caller hands the same information over as flat
+ * device tables; the entry points below are the bodies of PackAndSend* / RecvAndUnpack* /
+ * FillCoarseInBndry* / Prolongate* / *FluxCC / *FluxFC for neighbours that live in the same pack.
+ *   nghbr   [nmb][56][3]   {index of the neighbour block in this pack or -1, its level, dest slot}
+ *   mblev   [nmb]          level of each block
+ *   cc_tab, fc_tab [2][6][56][3][6]  (send|recv) x (isame, icoar, ifine, iprol, iflux_same,
+ *                          iflux_coar) x slot x component x {bis,bie,bjs,bje,bks,bke}; cell-centred
+ *                          tables use component 0 only
+ *   ndat    [2][56][2][5]  (cc|fc) x slot x (send|recv) x {isame,icoar,ifine,iflxs,iflxc}_ndat
+ *   layout  [4][56][2]     (cc vars, cc flux, fc vars, fc flux) x slot x {offset, per-block stride}
+ *                          of the receive buffers inside the buffer the caller passes (doubles)
+ *   slot_ox [56][3]        offsets (ox1,ox2,ox3) of each slot (inverse of NeighborIndex,
+ *                          src/mesh/nghbr_index.hpp:28-54) */
+typedef struct akmi_smr {
+  int nnghbr;             /* 8 / 24 / 56: src/mesh/meshblock.cpp:145-147 */
+  int multilevel;
+  const int *nghbr, *mblev, *cc_tab, *fc_tab, *ndat, *slot_ox;
+  const long long *layout;
+} akmi_smr;
+/* RestrictU is akmi_restrict_cc / akmi_restrict_fc above.  SendU+RecvU (PackAndSendCC +
+ * RecvAndUnpackCC, src/bvals/bvals_cc.cpp:42-447): u ghost cells from same-level and finer neighbours,
+ * coarse buffer cu from coarser ones.  buf: receive buffers (layout[0]) */
+int akmi_smr_exchange_cc(const akmi_pack *p, const akmi_smr *t, int nvar, double *u, double *cu,
+                         double *buf, void *stream);
+/* SendB+RecvB (src/bvals/bvals_fc.cpp:63-436): slots unpacked in order, active faces never
+ * overwritten by same-level / finer data.  buf: layout[2] */
+int akmi_smr_exchange_fc(const akmi_pack *p, const akmi_smr *t, double *b1, double *b2, double *b3,
+                         double *cb1, double *cb2, double *cb3, double *buf, void *stream);
+/* FillCoarseInBndryCC / FC (src/bvals/prolongation.cpp:366-462,556-644) */
+int akmi_smr_fill_coarse_cc(const akmi_pack *p, const akmi_smr *t, int nvar, const double *u, double *cu,
+                            void *stream);
+int akmi_smr_fill_coarse_fc(const akmi_pack *p, const akmi_smr *t, const double *b1, const double *b2,
+                            const double *b3, double *cb1, double *cb2, double *cb3, void *stream);
+/* ProlongateCC / ProlongateFC (src/bvals/prolongation.cpp:470-546,650-785; the latter with the
+ * owned-face rule of :90-147) */
+int akmi_smr_prolong_cc(const akmi_pack *p, const akmi_smr *t, int nvar, const double *cu, double *u,
+                        void *stream);
+int akmi_smr_prolong_fc(const akmi_pack *p, const akmi_smr *t, const double *cb1, const double *cb2,
+                        const double *cb3, double *b1, double *b2, double *b3, void *stream);
+/* SendFlux+RecvFlux (PackAndSendFluxCC + RecvAndUnpackFluxCC, src/bvals/flux_correct_cc.cpp:29-304):
+ * the fluxes on faces shared with finer neighbours are replaced by the restricted fine fluxes.
+ * face_shaped: MHD flux arrays (N+1 along their direction), 0: hydro (cell-shaped).  buf: layout[1] */
+int akmi_smr_flux_cc(const akmi_pack *p, const akmi_smr *t, int nvar, int face_shaped, double *flx1,
+                     double *flx2, double *flx3, double *buf, void *stream);
+/* SendE+RecvE (PackAndSendFluxFC + RecvAndUnpackFluxFC, src/bvals/flux_correct_fc.cpp:29-1034): edge
+ * EMFs on block surfaces summed over same-level owners, replaced by the restricted EMFs of finer
+ * neighbours, averaged.  nflx [nmb][48]: contributions per block edge (the counting of
+ * SumBoundaryFluxes / ZeroFluxesAtBoundaryWithFiner, a function of the neighbour table).  buf: layout[3] */
+int akmi_smr_emf_exchange(const akmi_pack *p, const akmi_smr *t, const int *nflx, double *e1, double *e2,
+                          double *e3, double *buf, void *stream);
+
 /* ---- Fused fast path ("one kernel sequence per MeshBlockPack stage") ----------------- *
  * Must produce results identical to the task chain above.  ws = device workspace of
  * akmi_stage_workspace_bytes() bytes owned by the caller. */

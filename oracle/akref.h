@@ -187,9 +187,36 @@ typedef struct akref_params {
   double pi_amb, di_amb, prat, drat, b_amb, inner_radius, outer_radius;
   /* decomposition */
   int split_kernels;               /* unused (always split); reserved */
+  /* statically refined mesh: the Z-ordered leaves of the MeshBlockTree and their neighbour table,
+   * built by the caller (0 / NULL: uniform root grid).  smr_lloc[m] = {lx1,lx2,lx3,level},
+   * smr_nghbr[m][n] = {gid, level, dest} with n the NeighborIndex slot (56 per block) */
+  int smr_nmb, smr_root_level;
+  const int *smr_lloc, *smr_nghbr;
 } akref_params;
 
 typedef struct akref_sim akref_sim;
+
+/* ---- boundary values of a statically refined mesh (akref_smr.c) ------------------------- */
+typedef struct akref_smr akref_smr;
+akref_smr *akref_smr_create(const akmi_pack *p, int nvar, const int *nghbr, const int *mblev,
+                            int multilevel);
+void akref_smr_destroy(akref_smr *s);
+int akref_smr_finer(const akref_smr *s, int m, int n);
+int akref_smr_indices(const akref_smr *s, int fc, int send, int n, int *out);
+int akref_smr_send_cc(akref_smr *s, const double *u, const double *cu);
+int akref_smr_recv_cc(akref_smr *s, double *u, double *cu);
+int akref_smr_send_fc(akref_smr *s, const double *b1, const double *b2, const double *b3,
+                      const double *cb1, const double *cb2, const double *cb3);
+int akref_smr_recv_fc(akref_smr *s, double *b1, double *b2, double *b3, double *cb1, double *cb2,
+                      double *cb3);
+int akref_smr_fill_coarse_cc(akref_smr *s, const double *u, double *cu);
+int akref_smr_fill_coarse_fc(akref_smr *s, const double *b1, const double *b2, const double *b3,
+                             double *cb1, double *cb2, double *cb3);
+int akref_smr_prolong_cc(akref_smr *s, double *u, const double *cu);
+int akref_smr_prolong_fc(akref_smr *s, double *b1, double *b2, double *b3, const double *cb1,
+                         const double *cb2, const double *cb3);
+int akref_smr_flux_cc(akref_smr *s, double *flx1, double *flx2, double *flx3, int face_shaped);
+int akref_smr_flux_fc(akref_smr *s, double *e1, double *e2, double *e3);
 
 void akref_params_default(akref_params *p);
 akref_sim *akref_create(const akref_params *p);

@@ -57,13 +57,15 @@ class Params(C.Structure):
                 ("pi_amb", C.c_double), ("di_amb", C.c_double), ("prat", C.c_double),
                 ("drat", C.c_double), ("b_amb", C.c_double), ("inner_radius", C.c_double),
                 ("outer_radius", C.c_double),
-                ("split_kernels", C.c_int)]
+                ("split_kernels", C.c_int),
+                ("smr_nmb", C.c_int), ("smr_root_level", C.c_int),
+                ("smr_lloc", C.c_void_p), ("smr_nghbr", C.c_void_p)]
 
 
 def build(force=False):
     """Compile oracle/libakref.so with the committed Makefile."""
     so = os.path.join(_HERE, "libakref.so")
-    srcs = [os.path.join(_HERE, f) for f in ("akref_kernels.c", "akref_sim.c", "akref.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("akref_kernels.c", "akref_sim.c", "akref_smr.c", "akref.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "akmi.h"))
     if force or not os.path.exists(so) or any(
             os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s)):
@@ -158,8 +160,18 @@ def ptr(a):
 class Sim:
     """Whole-run oracle: mesh + pgen + RK driver on one process."""
 
-    def __init__(self, **kw):
+    def __init__(self, smr_lloc=None, smr_nghbr=None, smr_root_level=0, **kw):
         self.params = default_params(**kw)
+        if smr_lloc is not None:
+            # statically refined mesh: Z-ordered leaves {lx1,lx2,lx3,level} and their neighbour table
+            # {gid, level, dest} per NeighborIndex slot, built by the caller (kept alive here)
+            self._lloc = np.ascontiguousarray(smr_lloc, dtype=np.int32).reshape(-1, 4)
+            self._nghbr = np.ascontiguousarray(smr_nghbr, dtype=np.int32).reshape(-1, 56, 3)
+            assert len(self._lloc) == len(self._nghbr)
+            self.params.smr_nmb = len(self._lloc)
+            self.params.smr_root_level = int(smr_root_level)
+            self.params.smr_lloc = self._lloc.ctypes.data
+            self.params.smr_nghbr = self._nghbr.ctypes.data
         self.L = lib()
         self.h = self.L.akref_create(C.byref(self.params))
         if not self.h:

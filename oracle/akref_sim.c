@@ -34,6 +34,12 @@ struct akref_sim {
   unsigned char *fofc;             /* Hydro::fofc, src/hydro/hydro.hpp:116 */
   int nfofc;                       /* EventCounters::nfofc, src/mesh/mesh.hpp:71 */
   double gam0[4], gam1[4], beta[4], delta[4];
+  /* statically refined meshes (akref_smr.c): levels, coarse buffers, level-aware boundary values */
+  int multilevel, root_level;
+  int *lev;                        /* [nmb] logical level of each block */
+  akref_smr *smr;
+  double *cu0, *cw0, *cb0[3];      /* coarse_u0, coarse_w0 (unused: no prolong_prims), coarse_b0 */
+  akmi_pack cpack;                 /* the coarse arrays seen as a pack of nx/2 cells (for the BCs) */
 };
 
 /* src/coordinates/cell_locations.hpp:23-39 */
@@ -106,6 +112,9 @@ akref_sim *akref_create(const akref_params *par) {
     free(s); return NULL;
   }
   s->nmb = s->nb1*s->nb2*s->nb3;
+  s->multilevel = (p->smr_nmb > 0);
+  s->root_level = p->smr_root_level;
+  if (s->multilevel) s->nmb = p->smr_nmb;
   s->multi_d = p->nx2 > 1; s->three_d = p->nx3 > 1;
   const int ng = p->ng;
   s->N1 = p->mb_nx1 + 2*ng;
@@ -117,30 +126,44 @@ akref_sim *akref_create(const akref_params *par) {
   const int nmb = s->nmb;
 
   /* Z-ordered block list */
-  zent *z = (zent *)malloc(sizeof(zent)*nmb);
-  int c = 0;
-  for (int l3 = 0; l3 < s->nb3; ++l3)
-    for (int l2 = 0; l2 < s->nb2; ++l2)
-      for (int l1 = 0; l1 < s->nb1; ++l1) {
-        z[c].key = morton(l1, l2, l3); z[c].l[0] = l1; z[c].l[1] = l2; z[c].l[2] = l3; ++c;
-      }
-  qsort(z, nmb, sizeof(zent), zcmp);
   s->lloc = (int *)malloc(sizeof(int)*3*nmb);
-  int *gid_of = (int *)malloc(sizeof(int)*nmb);
-  for (int m = 0; m < nmb; ++m) {
-    for (int q = 0; q < 3; ++q) s->lloc[3*m+q] = z[m].l[q];
-    gid_of[(z[m].l[2]*s->nb2 + z[m].l[1])*s->nb1 + z[m].l[0]] = m;
+  s->lev = (int *)calloc(nmb, sizeof(int));
+  int *gid_of = NULL;
+  if (s->multilevel) {
+    /* leaves of the MeshBlockTree in Z-order, handed over by the test (tree walk: the product's
+     * host mirror of src/mesh/meshblock_tree.cpp); lloc = (lx1, lx2, lx3, level) per block */
+    for (int m = 0; m < nmb; ++m) {
+      for (int q = 0; q < 3; ++q) s->lloc[3*m+q] = p->smr_lloc[4*m+q];
+      s->lev[m] = p->smr_lloc[4*m+3];
+    }
+  } else {
+    zent *z = (zent *)malloc(sizeof(zent)*nmb);
+    int c = 0;
+    for (int l3 = 0; l3 < s->nb3; ++l3)
+      for (int l2 = 0; l2 < s->nb2; ++l2)
+        for (int l1 = 0; l1 < s->nb1; ++l1) {
+          z[c].key = morton(l1, l2, l3); z[c].l[0] = l1; z[c].l[1] = l2; z[c].l[2] = l3; ++c;
+        }
+    qsort(z, nmb, sizeof(zent), zcmp);
+    gid_of = (int *)malloc(sizeof(int)*nmb);
+    for (int m = 0; m < nmb; ++m) {
+      for (int q = 0; q < 3; ++q) s->lloc[3*m+q] = z[m].l[q];
+      gid_of[(z[m].l[2]*s->nb2 + z[m].l[1])*s->nb1 + z[m].l[0]] = m;
+    }
+    free(z);
   }
-  free(z);
 
   /* block sizes + BCs: src/mesh/meshblock.cpp:25-131 */
   s->dx = dalloc(3*nmb); s->xmin = dalloc(6*nmb);
   s->bcs = (int *)malloc(sizeof(int)*6*nmb);
   s->nghbr = (int *)malloc(sizeof(int)*27*nmb);
-  const int nb[3] = {s->nb1, s->nb2, s->nb3};
+  const int nbr[3] = {s->nb1, s->nb2, s->nb3};
   const double mmin[3] = {p->x1min, p->x2min, p->x3min}, mmax[3] = {p->x1max, p->x2max, p->x3max};
   const int mbn[3] = {p->mb_nx1, p->mb_nx2, p->mb_nx3};
   for (int m = 0; m < nmb; ++m) {
+    /* blocks per direction at this block's level: nmb_rootx << (level - root_level), meshblock.cpp:42 */
+    int nb[3];
+    for (int q = 0; q < 3; ++q) nb[q] = s->multilevel ? (nbr[q] << (s->lev[m] - s->root_level)) : nbr[q];
     for (int q = 0; q < 3; ++q) {
       int l = s->lloc[3*m+q];
       int active = (q == 0) || (q == 1 && s->multi_d) || (q == 2 && s->three_d);
@@ -153,7 +176,7 @@ akref_sim *akref_create(const akref_params *par) {
       s->dx[3*m+q] = (hi - lo)/(double)mbn[q];
     }
     /* neighbours (same level): periodic wrap where the mesh BC is periodic */
-    for (int d = 0; d < 27; ++d) {
+    for (int d = 0; d < 27 && !s->multilevel; ++d) {
       int o[3] = {d%3 - 1, (d/3)%3 - 1, d/9 - 1};
       int ok = (d != 13), l[3];
       if (!s->multi_d && o[1]) ok = 0;
@@ -166,7 +189,7 @@ akref_sim *akref_create(const akref_params *par) {
       s->nghbr[27*m+d] = ok ? gid_of[(l[2]*s->nb2 + l[1])*s->nb1 + l[0]] : -1;
     }
   }
-  free(gid_of);
+  free(gid_of);   /* NULL on a multilevel mesh */
 
   /* arrays: src/hydro/hydro.cpp:283-298, src/mhd/mhd.cpp:148-160,335-366 */
   const int N1 = s->N1, N2 = s->N2, N3 = s->N3;
@@ -194,6 +217,22 @@ akref_sim *akref_create(const akref_params *par) {
   s->pack.dx = s->dx; s->pack.gamma = p->gamma;
   s->pack.dfloor = p->dfloor; s->pack.pfloor = p->pfloor; s->pack.tfloor = p->tfloor;
   s->pack.sfloor = p->sfloor; s->pack.sigma_max = p->sigma_max;
+  if (s->multilevel) {
+    /* coarse buffers (hydro.cpp:300-310, mhd.cpp:368-380) + MeshBoundaryValues with levels */
+    s->smr = akref_smr_create(&s->pack, nv, p->smr_nghbr, s->lev, 1);
+    s->cpack = s->pack;
+    s->cpack.nx1 = p->mb_nx1/2;
+    s->cpack.nx2 = s->multi_d ? p->mb_nx2/2 : 1;
+    s->cpack.nx3 = s->three_d ? p->mb_nx3/2 : 1;
+    const int cN1 = s->cpack.nx1 + 2*ng, cN2 = s->multi_d ? s->cpack.nx2 + 2*ng : 1,
+              cN3 = s->three_d ? s->cpack.nx3 + 2*ng : 1;
+    s->cu0 = dalloc((size_t)nmb*nv*cN3*cN2*cN1);
+    if (p->is_mhd) {
+      s->cb0[0] = dalloc((size_t)nmb*cN3*cN2*(cN1+1));
+      s->cb0[1] = dalloc((size_t)nmb*cN3*(cN2+1)*cN1);
+      s->cb0[2] = dalloc((size_t)nmb*(cN3+1)*cN2*cN1);
+    }
+  }
 
   /* RK weights, src/driver/driver.cpp:93-130 */
   if (p->nstages == 1) { s->gam0[0] = 0.0; s->gam1[0] = 1.0; s->beta[0] = 1.0; }
@@ -223,7 +262,9 @@ void akref_destroy(akref_sim *s) {
   if (!s) return;
   free(s->lloc); free(s->nghbr); free(s->bcs); free(s->dx); free(s->xmin);
   free(s->u0); free(s->w0); free(s->u1); free(s->flx1); free(s->flx2); free(s->flx3);
-  free(s->bcc0); free(s->fofc);
+  free(s->bcc0); free(s->fofc); free(s->lev); free(s->cu0);
+  for (int q = 0; q < 3; ++q) free(s->cb0[q]);
+  akref_smr_destroy(s->smr);
   for (int q = 0; q < 3; ++q) { free(s->b0[q]); free(s->b1[q]); free(s->e[q]); }
   for (int q = 0; q < 6; ++q) free(s->efc[q]);
   free(s);
@@ -516,6 +557,37 @@ static void pgen_linear_wave(akref_sim *s, int set_ic) {
             a1[IA(k,j,i)] = lwA1(x1v, x2f, x3f, &lw);
             a2[IA(k,j,i)] = lwA2(x1f, x2v, x3f, &lw);
             a3[IA(k,j,i)] = lwA3(x1f, x2f, x3v, &lw);
+            if (s->multilevel) {
+              /* edges shared with a finer neighbour: the potential as the mean of the two fine-edge
+               * values, so that the flux through shared fine/coarse faces is identical, :569-667 */
+#define FNR(n) akref_smr_finer(s->smr, m, (n))
+              const int is = s->is, ie = s->ie, js = s->js, je = s->je, ks = s->ks, ke = s->ke;
+              const int x1lo = (FNR(0) || FNR(1) || FNR(2) || FNR(3)) && i == is;
+              const int x1hi = (FNR(4) || FNR(5) || FNR(6) || FNR(7)) && i == ie+1;
+              const int x2lo = nx2 > 1 && (FNR(8) || FNR(9) || FNR(10) || FNR(11)) && j == js;
+              const int x2hi = nx2 > 1 && (FNR(12) || FNR(13) || FNR(14) || FNR(15)) && j == je+1;
+              const int x3lo = nx3 > 1 && (FNR(24) || FNR(25) || FNR(26) || FNR(27)) && k == ks;
+              const int x3hi = nx3 > 1 && (FNR(28) || FNR(29) || FNR(30) || FNR(31)) && k == ke+1;
+              const int e12 = nx2 > 1 && (((FNR(16) || FNR(17)) && i == is && j == js) || ((FNR(18) || FNR(19)) && i == ie+1 && j == js) ||
+                              ((FNR(20) || FNR(21)) && i == is && j == je+1) || ((FNR(22) || FNR(23)) && i == ie+1 && j == je+1));
+              const int e31 = nx3 > 1 && (((FNR(32) || FNR(33)) && i == is && k == ks) || ((FNR(34) || FNR(35)) && i == ie+1 && k == ks) ||
+                              ((FNR(36) || FNR(37)) && i == is && k == ke+1) || ((FNR(38) || FNR(39)) && i == ie+1 && k == ke+1));
+              const int e23 = nx3 > 1 && (((FNR(40) || FNR(41)) && j == js && k == ks) || ((FNR(42) || FNR(43)) && j == je+1 && k == ks) ||
+                              ((FNR(44) || FNR(45)) && j == js && k == ke+1) || ((FNR(46) || FNR(47)) && j == je+1 && k == ke+1));
+#undef FNR
+              if (x2lo || x2hi || x3lo || x3hi || e23) {
+                double xl = x1v + 0.25*dx1, xr = x1v - 0.25*dx1;
+                a1[IA(k,j,i)] = 0.5*(lwA1(xl, x2f, x3f, &lw) + lwA1(xr, x2f, x3f, &lw));
+              }
+              if (x1lo || x1hi || x3lo || x3hi || e31) {
+                double xl = x2v + 0.25*dx2, xr = x2v - 0.25*dx2;
+                a2[IA(k,j,i)] = 0.5*(lwA2(x1f, xl, x3f, &lw) + lwA2(x1f, xr, x3f, &lw));
+              }
+              if (x1lo || x1hi || x2lo || x2hi || e12) {
+                double xl = x3v + 0.25*dx3, xr = x3v - 0.25*dx3;
+                a3[IA(k,j,i)] = 0.5*(lwA3(x1f, x2f, xl, &lw) + lwA3(x1f, x2f, xr, &lw));
+              }
+            }
           }
       for (int k = s->ks; k <= s->ke; ++k)
         for (int j = s->js; j <= s->je; ++j)
@@ -717,10 +789,43 @@ static int strictly_periodic(const akref_sim *s) {
 
 /* SendU/RecvU, SendB/RecvB, ApplyPhysicalBCs, ConToPrim over all cells incl. ghosts
  * (src/hydro/hydro_tasks.cpp:308-320,357-412; src/mhd/mhd_tasks.cpp:478-520) */
+/* the same chain on a multilevel mesh: RestrictU, SendU, RecvU, (RestrictB, SendB, RecvB,) Prolongate,
+ * ApplyPhysicalBCs (hydro_tasks.cpp:64-70,291-400; mhd_tasks.cpp:59-72,312-552).  with_u = 0: only the
+ * field part (the U exchange of an MHD stage happens before CornerE, mhd_tasks.cpp:59-61) */
+static void smr_exchange_u(akref_sim *s) {
+  akref_restrict_cc(&s->pack, s->nv, s->u0, s->cu0);
+  akref_smr_send_cc(s->smr, s->u0, s->cu0);
+  akref_smr_recv_cc(s->smr, s->u0, s->cu0);
+}
+static void smr_exchange_b(akref_sim *s) {
+  akref_restrict_fc(&s->pack, s->b0[0], s->b0[1], s->b0[2], s->cb0[0], s->cb0[1], s->cb0[2]);
+  akref_smr_send_fc(s->smr, s->b0[0], s->b0[1], s->b0[2], s->cb0[0], s->cb0[1], s->cb0[2]);
+  akref_smr_recv_fc(s->smr, s->b0[0], s->b0[1], s->b0[2], s->cb0[0], s->cb0[1], s->cb0[2]);
+}
+static void smr_prolongate(akref_sim *s) {
+  const int mhd = s->par.is_mhd;
+  akref_smr_fill_coarse_cc(s->smr, s->u0, s->cu0);
+  if (mhd) akref_smr_fill_coarse_fc(s->smr, s->b0[0], s->b0[1], s->b0[2], s->cb0[0], s->cb0[1], s->cb0[2]);
+  if (!strictly_periodic(s)) {            /* HydroBCsCoarse / BFieldBCsCoarse: the BC helpers on coarse indices */
+    akref_hydro_bcs(&s->cpack, s->nv, s->bcs, s->cu0);
+    if (mhd) akref_bfield_bcs(&s->cpack, s->bcs, s->cb0[0], s->cb0[1], s->cb0[2]);
+  }
+  akref_smr_prolong_cc(s->smr, s->u0, s->cu0);
+  if (mhd) akref_smr_prolong_fc(s->smr, s->b0[0], s->b0[1], s->b0[2], s->cb0[0], s->cb0[1], s->cb0[2]);
+}
+
 static void halo_bcs_c2p(akref_sim *s) {
   const akmi_pack *pk = &s->pack;
-  akref_bvals_cc_local(pk, s->nv, s->nghbr, s->u0);
-  if (s->par.is_mhd) akref_bvals_fc_local(pk, s->nghbr, s->b0[0], s->b0[1], s->b0[2]);
+  if (s->multilevel) {
+    /* Driver::InitBoundaryValuesAndPrimitives order (driver.cpp:586-630); inside a stage the U part
+     * has already run when u_done is set by akref_step */
+    smr_exchange_u(s);
+    if (s->par.is_mhd) smr_exchange_b(s);
+    smr_prolongate(s);
+  } else {
+    akref_bvals_cc_local(pk, s->nv, s->nghbr, s->u0);
+    if (s->par.is_mhd) akref_bvals_fc_local(pk, s->nghbr, s->b0[0], s->b0[1], s->b0[2]);
+  }
   if (!strictly_periodic(s)) {
     akref_hydro_bcs(pk, s->nv, s->bcs, s->u0);
     if (s->par.is_mhd) akref_bfield_bcs(pk, s->bcs, s->b0[0], s->b0[1], s->b0[2]);
@@ -835,6 +940,7 @@ int akref_step(akref_sim *s) {
                        s->efc[0], s->efc[1], s->efc[2], s->efc[3], s->efc[4], s->efc[5], s->fofc,
                        &s->nfofc);
       }
+      if (s->multilevel) akref_smr_flux_cc(s->smr, s->flx1, s->flx2, s->flx3, 1);   /* SendFlux/RecvFlux */
       akref_rk_update(pk, gam0, gam1, beta_dt, s->u0, s->u1, s->flx1, s->flx2, s->flx3, 1);
       akref_mhd_corner_e(pk, s->w0, s->bcc0, s->efc[0], s->efc[1], s->efc[2], s->efc[3],
                          s->efc[4], s->efc[5], s->flx1, s->flx2, s->flx3, s->e[0], s->e[1],
@@ -844,7 +950,9 @@ int akref_step(akref_sim *s) {
       if (p->eta_ad != 0.0)          /* resistivity.cpp:52-54 */
         akref_ambipolar_emfs(pk, p->eta_ad, s->bcc0, s->b0[0], s->b0[1], s->b0[2], s->e[0], s->e[1], s->e[2]);
       /* SendE/RecvE: on a uniform mesh every shared edge EMF is computed identically by
-       * both owners, (a+a)*0.5==a: numerically a no-op. */
+       * both owners; sum and average return the value itself (2a/2, ((2a+a)+a)/4 are exact), so the
+       * exchange is skipped there.  With levels it is the flux correction of the field. */
+      if (s->multilevel) akref_smr_flux_fc(s->smr, s->e[0], s->e[1], s->e[2]);
       akref_mhd_ct(pk, gam0, gam1, beta_dt, s->e[0], s->e[1], s->e[2], s->b0[0], s->b0[1],
                    s->b0[2], s->b1[0], s->b1[1], s->b1[2]);
     } else {
@@ -859,6 +967,7 @@ int akref_step(akref_sim *s) {
       if (p->fofc)
         akref_hydro_fofc(pk, gam0, gam1, beta_dt, s->w0, s->u0, s->u1, s->flx1, s->flx2, s->flx3, 0,
                          s->fofc, &s->nfofc);
+      if (s->multilevel) akref_smr_flux_cc(s->smr, s->flx1, s->flx2, s->flx3, 0);   /* SendFlux/RecvFlux */
       akref_rk_update(pk, gam0, gam1, beta_dt, s->u0, s->u1, s->flx1, s->flx2, s->flx3, 0);
     }
     halo_bcs_c2p(s);

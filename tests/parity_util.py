@@ -27,7 +27,9 @@ def deck_overrides(problem, n, dims, mb=None, ng=None, recon=None, integrator=No
     deck = {"linear_wave_hydro": "linear_wave_hydro.athinput",
             "linear_wave_mhd": "linear_wave_mhd.athinput", "sod": "sod.athinput",
             "orszag_tang": "orszag_tang.athinput", "blast": "blast_mhd.athinput",
-            "rj2a": "rj2a.athinput"}[problem]
+            "rj2a": "rj2a.athinput", "linear_wave_hydro_smr": "linear_wave_hydro_smr.athinput",
+            "linear_wave_mhd_smr": "linear_wave_mhd_smr.athinput",
+            "blast_smr": "blast_mhd_smr.athinput"}[problem]
     ov = []
     for q in (1, 2, 3):
         nn = (n[q - 1] if isinstance(n, (tuple, list)) else n) if q <= dims else 1
@@ -35,7 +37,7 @@ def deck_overrides(problem, n, dims, mb=None, ng=None, recon=None, integrator=No
         ov += ["mesh/nx%d=%d" % (q, nn), "meshblock/nx%d=%d" % (q, mm)]
     if ng is not None:
         ov.append("mesh/nghost=%d" % ng)
-    blk = "hydro" if problem in ("linear_wave_hydro", "sod") else "mhd"
+    blk = "hydro" if problem in ("linear_wave_hydro", "sod", "linear_wave_hydro_smr") else "mhd"
     if recon is not None:
         ov.append("%s/reconstruct=%s" % (blk, recon))
     if rsolver is not None:
@@ -96,6 +98,18 @@ def oracle_kwargs(pin):
     return kw
 
 
+def smr_tables(pm):
+    """the mesh tree of a multilevel product Mesh as the oracle takes it: Z-ordered leaves and the
+    56-slot neighbour table {gid, level, dest} (gid == index: one pack holds the whole mesh)"""
+    nmb = pm.nmb_total
+    lloc = np.array([[l.lx1, l.lx2, l.lx3, l.level] for l in pm.lloc_eachmb], dtype=np.int32)
+    ng = -np.ones((nmb, 56, 3), dtype=np.int32)
+    for m in range(nmb):
+        for n, nb in pm.pmb_pack.pmb.nghbr[m].items():
+            ng[m, n] = (nb.gid, nb.lev, nb.dest)
+    return dict(smr_lloc=lloc, smr_nghbr=ng, smr_root_level=pm.root_level)
+
+
 def rel_l1(a, b):
     den = np.abs(b).sum()
     return float(np.abs(a - b).sum()/den) if den > 0 else float(np.abs(a - b).sum())
@@ -148,12 +162,14 @@ def make_pair(problem, n, dims, mb=None, inject=True, fused=None, native=False, 
     for name, val in (params or {}).items():       # parameters absent from the decks (e.g. nu_iso:
         pin.blocks[blk][name] = repr(val)           # their presence alone creates the diffusion objects)
     okw = oracle_kwargs(pin)
-    osim = akref.Sim(**okw)
     if native:
         from athenak_amd.native import NativeSimulation
         sim = NativeSimulation(pin, initialize=False)
     else:
         sim = Simulation(pin, initialize=False)
+    if not native and sim.pmesh.multilevel:
+        okw.update(smr_tables(sim.pmesh))
+    osim = akref.Sim(**okw)
     is_mhd = bool(okw["is_mhd"])
     osim.initialize()
     if inject:
