@@ -12,8 +12,8 @@ its extra face, every range of the reference's tables is an interval of
 
       lo = base_lo(o) + shift,   hi = base_hi(o) + shift
 
-whose pieces are listed in `_interval` below; the oracle restates the reference's case-by-case
-formulas, the tests compare the two tables entry by entry.
+whose pieces are listed in `_interval` below; the test suite holds a case-by-case restatement of the
+reference's formulas and compares the two tables entry by entry.
 
 Neighbours on another rank are not supported on this path yet (one pack per process holds the whole
 mesh); Mesh refuses `refinement = static` with more than one rank.

@@ -217,6 +217,20 @@ int akref_smr_prolong_fc(akref_smr *s, double *b1, double *b2, double *b3, const
                          const double *cb2, const double *cb3);
 int akref_smr_flux_cc(akref_smr *s, double *flx1, double *flx2, double *flx3, int face_shaped);
 int akref_smr_flux_fc(akref_smr *s, double *e1, double *e2, double *e3);
+/* twins of akmi_smr_* (same arguments without the stream; `_t` where the handle-based name is taken) */
+int akref_smr_exchange_cc(const akmi_pack *p, const akmi_smr *t, int nvar, double *u, double *cu, double *buf);
+int akref_smr_exchange_fc(const akmi_pack *p, const akmi_smr *t, double *b1, double *b2, double *b3,
+                          double *cb1, double *cb2, double *cb3, double *buf);
+int akref_smr_fill_coarse_cc_t(const akmi_pack *p, const akmi_smr *t, int nvar, const double *u, double *cu);
+int akref_smr_fill_coarse_fc_t(const akmi_pack *p, const akmi_smr *t, const double *b1, const double *b2,
+                               const double *b3, double *cb1, double *cb2, double *cb3);
+int akref_smr_prolong_cc_t(const akmi_pack *p, const akmi_smr *t, int nvar, const double *cu, double *u);
+int akref_smr_prolong_fc_t(const akmi_pack *p, const akmi_smr *t, const double *cb1, const double *cb2,
+                           const double *cb3, double *b1, double *b2, double *b3);
+int akref_smr_flux_cc_t(const akmi_pack *p, const akmi_smr *t, int nvar, int face_shaped, double *flx1,
+                        double *flx2, double *flx3, double *buf);
+int akref_smr_emf_exchange(const akmi_pack *p, const akmi_smr *t, const int *nflx, double *e1, double *e2,
+                           double *e3, double *buf);
 
 void akref_params_default(akref_params *p);
 akref_sim *akref_create(const akref_params *p);

@@ -1029,3 +1029,69 @@ int akref_smr_flux_fc(akref_smr *s, double *e1, double *e2, double *e3) {
   free(nflx);
   return 0;
 }
+
+/* ---- twins of the product's akmi_smr_* entry points (same arguments; the tables of the descriptor
+ * other than the neighbour table and the levels are NOT read: the oracle builds its own index
+ * ranges).  Used by the CPU stand-in backend of the host-logic tests (tests/cpu_backend.py). -------- */
+static akref_smr *from_desc(const akmi_pack *p, const akmi_smr *t, int nvar) {
+  return akref_smr_create(p, nvar, t->nghbr, t->mblev, t->multilevel);
+}
+int akref_smr_exchange_cc(const akmi_pack *p, const akmi_smr *t, int nvar, double *u, double *cu, double *buf) {
+  (void)buf;
+  akref_smr *s = from_desc(p, t, nvar);
+  akref_smr_send_cc(s, u, cu);
+  akref_smr_recv_cc(s, u, cu);
+  akref_smr_destroy(s);
+  return 0;
+}
+int akref_smr_exchange_fc(const akmi_pack *p, const akmi_smr *t, double *b1, double *b2, double *b3,
+                          double *cb1, double *cb2, double *cb3, double *buf) {
+  (void)buf;
+  akref_smr *s = from_desc(p, t, 1);
+  akref_smr_send_fc(s, b1, b2, b3, cb1, cb2, cb3);
+  akref_smr_recv_fc(s, b1, b2, b3, cb1, cb2, cb3);
+  akref_smr_destroy(s);
+  return 0;
+}
+int akref_smr_fill_coarse_cc_t(const akmi_pack *p, const akmi_smr *t, int nvar, const double *u, double *cu) {
+  akref_smr *s = from_desc(p, t, nvar);
+  akref_smr_fill_coarse_cc(s, u, cu);
+  akref_smr_destroy(s);
+  return 0;
+}
+int akref_smr_fill_coarse_fc_t(const akmi_pack *p, const akmi_smr *t, const double *b1, const double *b2,
+                               const double *b3, double *cb1, double *cb2, double *cb3) {
+  akref_smr *s = from_desc(p, t, 1);
+  akref_smr_fill_coarse_fc(s, b1, b2, b3, cb1, cb2, cb3);
+  akref_smr_destroy(s);
+  return 0;
+}
+int akref_smr_prolong_cc_t(const akmi_pack *p, const akmi_smr *t, int nvar, const double *cu, double *u) {
+  akref_smr *s = from_desc(p, t, nvar);
+  akref_smr_prolong_cc(s, u, cu);
+  akref_smr_destroy(s);
+  return 0;
+}
+int akref_smr_prolong_fc_t(const akmi_pack *p, const akmi_smr *t, const double *cb1, const double *cb2,
+                           const double *cb3, double *b1, double *b2, double *b3) {
+  akref_smr *s = from_desc(p, t, 1);
+  akref_smr_prolong_fc(s, b1, b2, b3, cb1, cb2, cb3);
+  akref_smr_destroy(s);
+  return 0;
+}
+int akref_smr_flux_cc_t(const akmi_pack *p, const akmi_smr *t, int nvar, int face_shaped, double *flx1,
+                        double *flx2, double *flx3, double *buf) {
+  (void)buf;
+  akref_smr *s = from_desc(p, t, nvar);
+  akref_smr_flux_cc(s, flx1, flx2, flx3, face_shaped);
+  akref_smr_destroy(s);
+  return 0;
+}
+int akref_smr_emf_exchange(const akmi_pack *p, const akmi_smr *t, const int *nflx, double *e1, double *e2,
+                           double *e3, double *buf) {
+  (void)buf; (void)nflx;
+  akref_smr *s = from_desc(p, t, 1);
+  akref_smr_flux_fc(s, e1, e2, e3);
+  akref_smr_destroy(s);
+  return 0;
+}

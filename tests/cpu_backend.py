@@ -22,7 +22,10 @@ class OracleAsAkmi:
     def __getattr__(self, name):
         if not name.startswith("akmi_"):
             raise AttributeError(name)
-        fn = getattr(self.R, "akref_" + name[5:])
+        # handle-based oracle functions own the plain names of these: their ABI twins end in _t
+        twin = {"akmi_smr_fill_coarse_cc", "akmi_smr_fill_coarse_fc", "akmi_smr_prolong_cc",
+                "akmi_smr_prolong_fc", "akmi_smr_flux_cc"}
+        fn = getattr(self.R, "akref_" + name[5:] + ("_t" if name in twin else ""))
         if name.endswith("segsize"):
             fn.restype = C.c_longlong
             return fn
