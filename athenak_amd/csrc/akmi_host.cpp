@@ -156,6 +156,7 @@ template struct DvceArray<Real>;
 template struct DvceArray<int>;
 template struct DvceArray<char>;
 template struct DvceArray<unsigned char>;
+template struct DvceArray<long long>;
 
 // ---- Mesh -----------------------------------------------------------------------------------
 static Real LeftEdgeX(int ith, int n, Real xmin, Real xmax) {   // cell_locations.hpp:23-28
@@ -211,19 +212,28 @@ Mesh::Mesh(ParameterInput *pin) {
   mb_indcs = MakeIndcs(ng, mb1, mb2, mb3);
   nmb_rootx1 = nx1/mb1; nmb_rootx2 = nx2/mb2; nmb_rootx3 = nx3/mb3;
   nmb_total = nmb_rootx1*nmb_rootx2*nmb_rootx3;
-  if (pin->DoesBlockExist("mesh_refinement") &&
-      pin->GetOrAddString("mesh_refinement", "refinement", "none") != "none")
-    AKMI_FATAL("mesh refinement is not on this build's path (SURVEY.md section 8(f) item 1)");
-  // Z-ordered logical locations (build_tree.cpp:243-258)
-  struct Z { std::uint64_t key; int l[3]; };
-  std::vector<Z> z;
-  for (int l3 = 0; l3 < nmb_rootx3; ++l3)
-    for (int l2 = 0; l2 < nmb_rootx2; ++l2)
-      for (int l1 = 0; l1 < nmb_rootx1; ++l1) z.push_back({Morton(l1, l2, l3), {l1, l2, l3}});
-  std::sort(z.begin(), z.end(), [](const Z &a, const Z &b) { return a.key < b.key; });
-  lloc_eachmb.resize(3*nmb_total);
-  for (int m = 0; m < nmb_total; ++m)
-    for (int q = 0; q < 3; ++q) lloc_eachmb[3*m + q] = z[m].l[q];
+  std::string ref = "none";
+  if (pin->DoesBlockExist("mesh_refinement")) ref = pin->GetOrAddString("mesh_refinement", "refinement", "none");
+  if (ref == "static") {
+    if (pin->DoesParameterExist("mesh_refinement", "prolong_primitives") &&
+        pin->GetBoolean("mesh_refinement", "prolong_primitives"))
+      AKMI_FATAL("<mesh_refinement>/prolong_primitives is not on this build's path");
+    multilevel = true;
+    BuildTreeFromScratch(pin);                 // akmi_host_smr.cpp
+  } else if (ref != "none") {
+    AKMI_FATAL("<mesh_refinement>/refinement = '" + ref + "': only static refinement is on this build's path");
+  } else {
+    // Z-ordered logical locations (build_tree.cpp:243-258)
+    struct Z { std::uint64_t key; int l[3]; };
+    std::vector<Z> z;
+    for (int l3 = 0; l3 < nmb_rootx3; ++l3)
+      for (int l2 = 0; l2 < nmb_rootx2; ++l2)
+        for (int l1 = 0; l1 < nmb_rootx1; ++l1) z.push_back({Morton(l1, l2, l3), {l1, l2, l3}});
+    std::sort(z.begin(), z.end(), [](const Z &a, const Z &b) { return a.key < b.key; });
+    lloc_eachmb.resize(3*nmb_total);
+    for (int m = 0; m < nmb_total; ++m)
+      for (int q = 0; q < 3; ++q) lloc_eachmb[3*m + q] = z[m].l[q];
+  }
   time = pin->GetOrAddReal("time", "start_time", 0.0);
   dt = static_cast<Real>(FLT_MAX);            // build_tree.cpp:301
   dtold = 0.0;
@@ -237,19 +247,24 @@ Mesh::~Mesh() { delete pmb_pack; }
 MeshBlock::MeshBlock(MeshBlockPack *ppack, int igids, int nmb_) : nmb(nmb_) {
   Mesh *pm = ppack->pmesh;
   const RegionSize &ms = pm->mesh_size;
-  const int nb[3] = {pm->nmb_rootx1, pm->nmb_rootx2, pm->nmb_rootx3};
+  const int nbr[3] = {pm->nmb_rootx1, pm->nmb_rootx2, pm->nmb_rootx3};
   const bool active[3] = {true, pm->multi_d, pm->three_d};
   const Real mmin[3] = {ms.x1min, ms.x2min, ms.x3min}, mmax[3] = {ms.x1max, ms.x2max, ms.x3max};
   const int nxb[3] = {pm->mb_indcs.nx1, pm->mb_indcs.nx2, pm->mb_indcs.nx3};
   mb_gid.resize(nmb); mb_size.resize(nmb); mb_bcs.resize(6*nmb); nghbr.assign(27*nmb, -1);
-  std::vector<int> gid_of(nmb);
-  for (int m = 0; m < nmb; ++m) {
+  mb_lev.assign(nmb, pm->root_level);
+  std::vector<int> gid_of(pm->multilevel ? 0 : nmb);
+  for (int m = 0; m < nmb && !pm->multilevel; ++m) {
     const int *l = &pm->lloc_eachmb[3*(igids + m)];
-    gid_of[(l[2]*nb[1] + l[1])*nb[0] + l[0]] = m;
+    gid_of[(l[2]*nbr[1] + l[1])*nbr[0] + l[0]] = m;
   }
   std::vector<Real> dx(3*nmb);
   for (int m = 0; m < nmb; ++m) {
     mb_gid[m] = igids + m;
+    if (pm->multilevel) mb_lev[m] = pm->lloc_tree[igids + m].level;
+    // blocks per direction at the level of this block: nmb_rootx << (lev - root_level), meshblock.cpp:42
+    int nb[3];
+    for (int q = 0; q < 3; ++q) nb[q] = nbr[q] << (mb_lev[m] - pm->root_level);
     const int *l = &pm->lloc_eachmb[3*(igids + m)];
     Real lim[6];
     for (int q = 0; q < 3; ++q) {
@@ -262,7 +277,7 @@ MeshBlock::MeshBlock(MeshBlockPack *ppack, int igids, int nmb_) : nmb(nmb_) {
     RegionSize &s = mb_size[m];
     s.x1min = lim[0]; s.x1max = lim[1]; s.x2min = lim[2]; s.x2max = lim[3]; s.x3min = lim[4]; s.x3max = lim[5];
     s.dx1 = dx[3*m]; s.dx2 = dx[3*m + 1]; s.dx3 = dx[3*m + 2];
-    for (int d = 0; d < 27; ++d) {
+    for (int d = 0; d < 27 && !pm->multilevel; ++d) {
       int o[3] = {d%3 - 1, (d/3)%3 - 1, d/9 - 1};
       if (d == 13 || (!pm->multi_d && o[1]) || (!pm->three_d && o[2])) continue;
       int ll[3]; bool ok = true;
@@ -278,6 +293,7 @@ MeshBlock::MeshBlock(MeshBlockPack *ppack, int igids, int nmb_) : nmb(nmb_) {
   HIPCHK(hipMemcpy(d_dx.p, dx.data(), sizeof(Real)*3*nmb, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d_bcs.p, mb_bcs.data(), sizeof(int)*6*nmb, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d_nghbr.p, nghbr.data(), sizeof(int)*27*nmb, hipMemcpyHostToDevice));
+  if (pm->multilevel) SetNeighborsSMR(pm);
 }
 MeshBlock::~MeshBlock() { d_dx.Free(); d_bcs.Free(); d_nghbr.Free(); }
 
@@ -377,6 +393,17 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
   const size_t ncc = static_cast<size_t>(pp->nmb_thispack)*nvars*n3*n2*n1;
   u0.Realloc(ncc); w0.Realloc(ncc); u1.Realloc(ncc);
   counters.Realloc(3); dt3.Realloc(3);
+  multilevel = pp->pmesh->multilevel;
+  if (multilevel) {
+    // restricted fluxes replace face fluxes between Fluxes and RKUpdate: the task-granular flux arrays
+    fused = false;
+    cpack_c = pack_c;
+    cpack_c.nx1 = ind.nx1/2; cpack_c.nx2 = ind.nx2 > 1 ? ind.nx2/2 : 1; cpack_c.nx3 = ind.nx3 > 1 ? ind.nx3/2 : 1;
+    const size_t c1 = cpack_c.nx1 + 2*ind.ng, c2 = ind.nx2 > 1 ? cpack_c.nx2 + 2*ind.ng : 1,
+                 c3 = ind.nx3 > 1 ? cpack_c.nx3 + 2*ind.ng : 1;
+    coarse_u0.Realloc(static_cast<size_t>(pp->nmb_thispack)*nvars*c3*c2*c1);
+    psmr = new MeshBoundaryValuesSMR(pp, nvars);
+  }
   use_fofc = pin->GetOrAddBoolean(blk, "fofc", false);     // hydro.cpp:153-190, mhd.cpp:199-235
   if (use_fofc) {
     const int need = recon_method == AKMI_RECON_PLM ? 3 : (recon_method >= AKMI_RECON_PPM4 ? 4 : 2);
@@ -392,7 +419,8 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
 }
 FluidBase::~FluidBase() {
   u0.Free(); w0.Free(); u1.Free(); counters.Free(); dt3.Free(); ws.Free(); fofc.Free(); nfofc.Free();
-  dtmin_cond.Free();
+  dtmin_cond.Free(); coarse_u0.Free();
+  delete psmr;
   delete peos;
 }
 void FluidBase::FinishNewDt() {        // hydro_newdt.cpp:121-124
@@ -523,9 +551,14 @@ MHD::MHD(MeshBlockPack *pp, ParameterInput *pin) : FluidBase(pp, pin, "mhd") {
     efld.x3e.Realloc(nmb*n3*(n2 + 1)*(n1 + 1));
     for (DvceArray<Real> *a : {&e3x1, &e2x1, &e1x2, &e3x2, &e2x3, &e1x3}) a->Realloc(nmb*n3*n2*n1);
   }
+  if (multilevel) {                                                // mhd.cpp:368-380
+    const size_t c1 = cpack_c.nx1 + 2*ind.ng, c2 = ind.nx2 > 1 ? cpack_c.nx2 + 2*ind.ng : 1,
+                 c3 = ind.nx3 > 1 ? cpack_c.nx3 + 2*ind.ng : 1;
+    FaceAlloc(coarse_b0, nmb, 1, c3, c2, c1, 1);
+  }
 }
 MHD::~MHD() {
-  bcc0.Free(); FaceFree(b0); FaceFree(b1); FaceFree(uflx);
+  bcc0.Free(); FaceFree(b0); FaceFree(b1); FaceFree(uflx); FaceFree(coarse_b0);
   efld.x1e.Free(); efld.x2e.Free(); efld.x3e.Free();
   for (DvceArray<Real> *a : {&e3x1, &e2x1, &e1x2, &e3x2, &e2x3, &e1x3}) a->Free();
 }
@@ -604,10 +637,14 @@ void Driver::ExecuteTaskList(Mesh *pm, const std::string &tl, int stage) {   // 
 
 void Driver::InitBoundaryValuesAndPrimitives(Mesh *pm) {   // driver.cpp:569-653
   if (auto *ph = pm->pmb_pack->phydro) {
-    ph->SendU(this, 0); ph->RecvU(this, 0); ph->ApplyPhysicalBCs(this, 0); ph->ConToPrim(this, 0);
+    ph->RestrictU(this, 0);
+    ph->SendU(this, 0); ph->RecvU(this, 0); ph->Prolongate(this, 0);
+    ph->ApplyPhysicalBCs(this, 0); ph->ConToPrim(this, 0);
   }
   if (auto *pm_ = pm->pmb_pack->pmhd) {
+    pm_->RestrictU(this, 0); pm_->RestrictB(this, 0);
     pm_->SendU(this, 0); pm_->RecvU(this, 0); pm_->SendB(this, 0); pm_->RecvB(this, 0);
+    pm_->Prolongate(this, 0);
     pm_->ApplyPhysicalBCs(this, 0); pm_->ConToPrim(this, 0);
   }
 }
@@ -679,7 +716,28 @@ TaskStatus Hydro::RKUpdate(Driver *d, int stage) {         // hydro_update.cpp:2
   return TaskStatus::complete;
 }
 TaskStatus Hydro::SendU(Driver *d, int stage) {            // hydro_tasks.cpp:308-320 (same rank)
-  AKCHK(akmi_bvals_cc_local(&pack_c, nvars, pmy_pack->pmb->d_nghbr.p, u0.p, stream));
+  if (multilevel)
+    AKCHK(akmi_smr_exchange_cc(&pack_c, &psmr->smr_c, nvars, u0.p, coarse_u0.p, psmr->buf[0].p, stream));
+  else
+    AKCHK(akmi_bvals_cc_local(&pack_c, nvars, pmy_pack->pmb->d_nghbr.p, u0.p, stream));
+  return TaskStatus::complete;
+}
+TaskStatus Hydro::SendFlux(Driver *d, int stage) {         // hydro_tasks.cpp:206-215
+  if (multilevel)
+    AKCHK(akmi_smr_flux_cc(&pack_c, &psmr->smr_c, nvars, 0, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p,
+                           psmr->buf[1].p, stream));
+  return TaskStatus::complete;
+}
+TaskStatus Hydro::RestrictU(Driver *d, int stage) {        // hydro_tasks.cpp:291-300
+  if (multilevel) AKCHK(akmi_restrict_cc(&pack_c, nvars, u0.p, coarse_u0.p, stream));
+  return TaskStatus::complete;
+}
+TaskStatus Hydro::Prolongate(Driver *d, int stage) {       // hydro_tasks.cpp:381-400
+  if (!multilevel) return TaskStatus::complete;
+  AKCHK(akmi_smr_fill_coarse_cc(&pack_c, &psmr->smr_c, nvars, u0.p, coarse_u0.p, stream));
+  if (!pmy_pack->pmesh->strictly_periodic)               // HydroBCsCoarse: the BC helper on coarse indices
+    AKCHK(akmi_hydro_bcs(&cpack_c, nvars, pmy_pack->pmb->d_bcs.p, coarse_u0.p, stream));
+  AKCHK(akmi_smr_prolong_cc(&pack_c, &psmr->smr_c, nvars, coarse_u0.p, u0.p, stream));
   return TaskStatus::complete;
 }
 TaskStatus Hydro::ApplyPhysicalBCs(Driver *d, int stage) { // hydro_tasks.cpp:357-375
@@ -766,7 +824,52 @@ TaskStatus MHD::RKUpdate(Driver *d, int stage) {           // mhd_update.cpp:24-
   return TaskStatus::complete;
 }
 TaskStatus MHD::SendU(Driver *d, int stage) {
-  AKCHK(akmi_bvals_cc_local(&pack_c, nvars, pmy_pack->pmb->d_nghbr.p, u0.p, stream));
+  if (multilevel)
+    AKCHK(akmi_smr_exchange_cc(&pack_c, &psmr->smr_c, nvars, u0.p, coarse_u0.p, psmr->buf[0].p, stream));
+  else
+    AKCHK(akmi_bvals_cc_local(&pack_c, nvars, pmy_pack->pmb->d_nghbr.p, u0.p, stream));
+  return TaskStatus::complete;
+}
+TaskStatus MHD::SendFlux(Driver *d, int stage) {           // mhd_tasks.cpp:225-233
+  if (multilevel)
+    AKCHK(akmi_smr_flux_cc(&pack_c, &psmr->smr_c, nvars, 1, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p,
+                           psmr->buf[1].p, stream));
+  return TaskStatus::complete;
+}
+TaskStatus MHD::RestrictU(Driver *d, int stage) {          // mhd_tasks.cpp:315-322
+  if (multilevel) AKCHK(akmi_restrict_cc(&pack_c, nvars, u0.p, coarse_u0.p, stream));
+  return TaskStatus::complete;
+}
+TaskStatus MHD::RestrictB(Driver *d, int stage) {          // mhd_tasks.cpp:691-697
+  if (multilevel)
+    AKCHK(akmi_restrict_fc(&pack_c, b0.x1f.p, b0.x2f.p, b0.x3f.p, coarse_b0.x1f.p, coarse_b0.x2f.p,
+                           coarse_b0.x3f.p, stream));
+  return TaskStatus::complete;
+}
+// SendE + RecvE (mhd_tasks.cpp:402-417).  Uniform mesh: every copy of a shared edge EMF is computed by
+// the same deterministic kernel from identical inputs and the reference's sum and average return the
+// value itself (2a/2 and ((2a+a)+a)/4 are exact), so nothing is exchanged; with levels this is the
+// flux correction of the field
+TaskStatus MHD::SendE(Driver *d, int stage) {
+  if (multilevel)
+    AKCHK(akmi_smr_emf_exchange(&pack_c, &psmr->smr_c, psmr->d_nflx.p, efld.x1e.p, efld.x2e.p, efld.x3e.p,
+                                psmr->buf[3].p, stream));
+  return TaskStatus::complete;
+}
+TaskStatus MHD::Prolongate(Driver *d, int stage) {         // mhd_tasks.cpp:527-552
+  if (!multilevel) return TaskStatus::complete;
+  const akmi_smr *t = &psmr->smr_c;
+  AKCHK(akmi_smr_fill_coarse_cc(&pack_c, t, nvars, u0.p, coarse_u0.p, stream));
+  AKCHK(akmi_smr_fill_coarse_fc(&pack_c, t, b0.x1f.p, b0.x2f.p, b0.x3f.p, coarse_b0.x1f.p, coarse_b0.x2f.p,
+                                coarse_b0.x3f.p, stream));
+  if (!pmy_pack->pmesh->strictly_periodic) {
+    AKCHK(akmi_hydro_bcs(&cpack_c, nvars, pmy_pack->pmb->d_bcs.p, coarse_u0.p, stream));
+    AKCHK(akmi_bfield_bcs(&cpack_c, pmy_pack->pmb->d_bcs.p, coarse_b0.x1f.p, coarse_b0.x2f.p, coarse_b0.x3f.p,
+                          stream));
+  }
+  AKCHK(akmi_smr_prolong_cc(&pack_c, t, nvars, coarse_u0.p, u0.p, stream));
+  AKCHK(akmi_smr_prolong_fc(&pack_c, t, coarse_b0.x1f.p, coarse_b0.x2f.p, coarse_b0.x3f.p, b0.x1f.p, b0.x2f.p,
+                            b0.x3f.p, stream));
   return TaskStatus::complete;
 }
 TaskStatus MHD::EField(Driver *d, int stage) {             // mhd_corner_e.cpp:26-417
@@ -790,7 +893,11 @@ TaskStatus MHD::CT(Driver *d, int stage) {                 // mhd_ct.cpp:23-80
   return TaskStatus::complete;
 }
 TaskStatus MHD::SendB(Driver *d, int stage) {
-  AKCHK(akmi_bvals_fc_local(&pack_c, pmy_pack->pmb->d_nghbr.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, stream));
+  if (multilevel)
+    AKCHK(akmi_smr_exchange_fc(&pack_c, &psmr->smr_c, b0.x1f.p, b0.x2f.p, b0.x3f.p, coarse_b0.x1f.p,
+                               coarse_b0.x2f.p, coarse_b0.x3f.p, psmr->buf[2].p, stream));
+  else
+    AKCHK(akmi_bvals_fc_local(&pack_c, pmy_pack->pmb->d_nghbr.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, stream));
   return TaskStatus::complete;
 }
 TaskStatus MHD::ApplyPhysicalBCs(Driver *d, int stage) {   // mhd_tasks.cpp:501-520

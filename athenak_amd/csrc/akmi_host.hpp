@@ -47,6 +47,11 @@ class ParameterInput {
   Real GetOrAddReal(const std::string &b, const std::string &n, Real d);
   bool GetOrAddBoolean(const std::string &b, const std::string &n, bool d);
   void SetReal(const std::string &b, const std::string &n, Real v);
+  std::vector<std::string> BlockNames() const {
+    std::vector<std::string> v;
+    for (const auto &b : blocks_) v.push_back(b.first);
+    return v;
+  }
  private:
   std::map<std::string, std::map<std::string, std::string>> blocks_;
 };
@@ -131,11 +136,41 @@ struct DvceEdgeFld { DvceArray<Real> x1e, x2e, x3e; };
 class Mesh;
 class MeshBlockPack;
 
-class MeshBlock {       // meshblock.cpp:25-131 (uniform level)
+// ---- static mesh refinement (akmi_host_smr.cpp) ----------------------------------------------
+struct LogicalLocation { int lx1, lx2, lx3, level; };          // mesh.hpp:54-60
+int NeighborIndex(int ix, int iy, int iz, int n1, int n2);      // nghbr_index.hpp:28-54
+
+class MeshBlockTree {   // meshblock_tree.hpp:27-62, meshblock_tree.cpp
+ public:
+  struct Node {
+    LogicalLocation lloc;
+    std::vector<std::unique_ptr<Node>> leaf;   // empty: a leaf; entries may be null in the root grid
+    int gid;
+  };
+  MeshBlockTree(const int nmb_root[3], const bool periodic[6], int ndim);
+  void AddNode(const LogicalLocation &rloc);
+  void Refine(Node *node);
+  std::vector<LogicalLocation> CreateZOrderedLLList();
+  Node *FindNeighbor(const LogicalLocation &myloc, int ox1, int ox2, int ox3);
+  int root_level = 0;
+ private:
+  Node *MakeChild(Node *node, int n);
+  void CreateRoot(Node *node);
+  void Walk(Node *node, std::vector<LogicalLocation> &out);
+  bool Wrap(int &l, int d, int level) const;
+  std::unique_ptr<Node> root_;
+  int nmb_root_[3], ndim_, nleaf_;
+  bool periodic_[6];
+};
+
+class MeshBlock {       // meshblock.cpp:25-131
  public:
   MeshBlock(MeshBlockPack *ppack, int igids, int nmb);
   ~MeshBlock();
+  void SetNeighborsSMR(Mesh *pm);   // meshblock.cpp:142-425
   int nmb;
+  std::vector<int> mb_lev;        // logical level of each block
+  std::vector<int> nghbr_smr;     // multilevel: [nmb][56][3] {local index | -1, level, dest slot}
   std::vector<int> mb_gid;
   std::vector<RegionSize> mb_size;
   std::vector<int> mb_bcs;        // [nmb][6]
@@ -171,10 +206,29 @@ class Mesh {            // mesh.hpp:92-185
   int mesh_bcs[6];
   bool one_d, two_d, three_d, multi_d, strictly_periodic;
   int nmb_rootx1, nmb_rootx2, nmb_rootx3, nmb_total;
+  bool multilevel = false;        // <mesh_refinement>/refinement = static
+  int root_level = 0, max_level = 0;
+  std::unique_ptr<MeshBlockTree> ptree;
+  std::vector<LogicalLocation> lloc_tree;   // multilevel: Z-ordered leaves with their levels
+  void BuildTreeFromScratch(ParameterInput *pin);   // build_tree.cpp:32-258 (static refinement)
   std::vector<int> lloc_eachmb;   // [nmb_total][3], Z-ordered
   Real time, dt, dtold, cfl_no;
   int ncycle;
   MeshBlockPack *pmb_pack = nullptr;
+};
+
+// level-aware boundary values of one pack (src/bvals/bvals.hpp:134-267 on a multilevel mesh): the
+// buffer index tables on the device + the receive buffers; task bodies = akmi_smr_* calls
+class MeshBoundaryValuesSMR {
+ public:
+  MeshBoundaryValuesSMR(MeshBlockPack *pp, int nvar);
+  ~MeshBoundaryValuesSMR();
+  MeshBlockPack *pmy_pack;
+  int nvar, nnghbr;
+  akmi_smr smr_c;
+  DvceArray<int> d_nghbr, d_lev, d_cc, d_fc, d_ndat, d_ox, d_nflx;
+  DvceArray<long long> d_layout;
+  DvceArray<Real> buf[4];         // cc vars, cc flux, fc vars, fc flux
 };
 
 // physics base: what Hydro and MHD share ------------------------------------------------
@@ -208,6 +262,11 @@ class FluidBase {
   DvceArray<int> nfofc;                 // EventCounters::nfofc (mesh.hpp:71), kept on the device
   Real dtnew = static_cast<Real>(FLT_MAX);
   hipStream_t stream = nullptr;
+  // static mesh refinement: coarse buffers (hydro.cpp:300-310, mhd.cpp:368-380) + boundary values
+  bool multilevel = false;
+  akmi_pack cpack_c;                    // the coarse buffers as a pack of nx/2 cells (coarse BCs)
+  DvceArray<Real> coarse_u0;
+  MeshBoundaryValuesSMR *psmr = nullptr;
  protected:
   void FinishNewDt();
   void AddDiffusionFluxes(DvceFaceFld &flx, int face_shaped);   // hydro_tasks.cpp:183-189
@@ -225,14 +284,14 @@ class Hydro : public FluidBase {    // hydro.hpp:73-154
   TaskStatus InitRecv(Driver *d, int stage) { return TaskStatus::complete; }
   TaskStatus CopyCons(Driver *d, int stage);
   TaskStatus Fluxes(Driver *d, int stage);
-  TaskStatus SendFlux(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus SendFlux(Driver *d, int stage);
   TaskStatus RecvFlux(Driver *d, int stage) { return TaskStatus::complete; }
   TaskStatus RKUpdate(Driver *d, int stage);
   TaskStatus HydroSrcTerms(Driver *d, int stage) { return TaskStatus::complete; }
-  TaskStatus RestrictU(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus RestrictU(Driver *d, int stage);
   TaskStatus SendU(Driver *d, int stage);
   TaskStatus RecvU(Driver *d, int stage) { return TaskStatus::complete; }
-  TaskStatus Prolongate(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus Prolongate(Driver *d, int stage);
   TaskStatus ApplyPhysicalBCs(Driver *d, int stage);
   TaskStatus ConToPrim(Driver *d, int stage);
   TaskStatus NewTimeStep(Driver *d, int stage);
@@ -247,7 +306,7 @@ class MHD : public FluidBase {      // mhd.hpp:93-199
   MHD(MeshBlockPack *pp, ParameterInput *pin);
   ~MHD() override;
   DvceArray<Real> bcc0;
-  DvceFaceFld b0, b1, uflx;
+  DvceFaceFld b0, b1, uflx, coarse_b0;
   DvceEdgeFld efld;
   DvceArray<Real> e3x1, e2x1, e1x2, e3x2, e2x3, e1x3;
   void AssembleMHDTasks(std::map<std::string, std::shared_ptr<TaskList>> tl);
@@ -255,21 +314,21 @@ class MHD : public FluidBase {      // mhd.hpp:93-199
   TaskStatus InitRecv(Driver *d, int stage) { return TaskStatus::complete; }
   TaskStatus CopyCons(Driver *d, int stage);
   TaskStatus Fluxes(Driver *d, int stage);
-  TaskStatus SendFlux(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus SendFlux(Driver *d, int stage);
   TaskStatus RecvFlux(Driver *d, int stage) { return TaskStatus::complete; }
   TaskStatus RKUpdate(Driver *d, int stage);
   TaskStatus MHDSrcTerms(Driver *d, int stage) { return TaskStatus::complete; }
-  TaskStatus RestrictU(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus RestrictU(Driver *d, int stage);
   TaskStatus SendU(Driver *d, int stage);
   TaskStatus RecvU(Driver *d, int stage) { return TaskStatus::complete; }
   TaskStatus EField(Driver *d, int stage);
-  TaskStatus SendE(Driver *d, int stage) { return TaskStatus::complete; }   // identity on uniform meshes
+  TaskStatus SendE(Driver *d, int stage);      // identity on uniform meshes, EMF correction with levels
   TaskStatus RecvE(Driver *d, int stage) { return TaskStatus::complete; }
   TaskStatus CT(Driver *d, int stage);
-  TaskStatus RestrictB(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus RestrictB(Driver *d, int stage);
   TaskStatus SendB(Driver *d, int stage);
   TaskStatus RecvB(Driver *d, int stage) { return TaskStatus::complete; }
-  TaskStatus Prolongate(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus Prolongate(Driver *d, int stage);
   TaskStatus ApplyPhysicalBCs(Driver *d, int stage);
   TaskStatus ConToPrim(Driver *d, int stage);
   TaskStatus NewTimeStep(Driver *d, int stage);

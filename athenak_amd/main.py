@@ -37,7 +37,7 @@ class Simulation:
             raise RuntimeError("### FATAL ERROR mesh in the restart file %r does not match the "
                                "parameters %r" % (got, want))
         lloc = [tuple(int(x) for x in l[:3]) for l in hdr["lloc"]]
-        if lloc != [tuple(l) for l in pm.lloc_eachmb]:
+        if lloc != [tuple(l)[:3] for l in pm.lloc_eachmb]:
             raise RuntimeError("### FATAL ERROR MeshBlock order of the restart file differs")
         pm.time, pm.dt, pm.ncycle = hdr["time"], hdr["dt"], hdr["ncycle"]   # build_tree.cpp:365-369
         pk = pm.pmb_pack

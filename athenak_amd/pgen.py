@@ -143,7 +143,8 @@ class ProblemGenerator:
         name = pin.GetOrAddString("problem", "pgen_name", "none")
         self.pgen_name = name
         table = {"linear_wave": self.LinearWave, "shock_tube": self.ShockTube,
-                 "orszag_tang": self.OrszagTang, "blast": self.UserProblem, "diffusion": self.Diffusion}
+                 "orszag_tang": self.OrszagTang, "blast": self.UserProblem, "diffusion": self.Diffusion,
+                 "cpaw": self.AlfvenWave}
         # user-defined boundary conditions (pgen.cpp:57-62): enrolled by the problem function
         self.user_bcs = any(b == capi.BC["user"] for b in pmesh.mesh_bcs)
         self.user_bcs_func = None
@@ -395,6 +396,133 @@ class ProblemGenerator:
                 bf[1][m][ks, js.start:js.stop + 1, is_] = b2
                 bf[2][m][ks.start:ks.stop + 1, js, is_] = b3
         self._store(w, bf, to_u1=not self.set_initial_conditions)
+
+    # ---- circularly polarized Alfven wave (the reference's static-refinement regression) ----------
+    def AlfvenWave(self, pin, restart):
+        """ProblemGenerator::AlfvenWave, src/pgen/tests/cpaw.cpp:79-435 (MHD; conserved variables and
+        face fields from a vector potential, with the two-point potential on edges shared with finer
+        blocks, :227-325)"""
+        pm = self.pmy_mesh_
+        self.pgen_final_func = self.AlfvenWaveErrors
+        if restart:
+            return
+        if pm.pmb_pack.pmhd is None:
+            return
+        b_par, b_perp = pin.GetReal("problem", "b_par"), pin.GetReal("problem", "b_perp")
+        v_par, pres = pin.GetReal("problem", "v_par"), pin.GetReal("problem", "pres")
+        den = 1.0
+        v_perp = b_perp/math.sqrt(den)
+        along_x1 = pin.GetOrAddBoolean("problem", "along_x1", False)
+        along_x2 = pin.GetOrAddBoolean("problem", "along_x2", False)
+        along_x3 = pin.GetOrAddBoolean("problem", "along_x3", False)
+        if (along_x1 and (along_x2 or along_x3)) or (along_x2 and along_x3):
+            raise RuntimeError("### FATAL ERROR Can only specify one of along_x1/2/3 to be true")
+        if (along_x2 or along_x3) and pm.one_d:
+            raise RuntimeError("### FATAL ERROR Cannot specify waves along x2 or x3 axis in 1D")
+        if along_x3 and pm.two_d:
+            raise RuntimeError("### FATAL ERROR Cannot specify waves along x3 axis in 2D")
+        ms = pm.mesh_size
+        x1size, x2size, x3size = ms.x1max - ms.x1min, ms.x2max - ms.x2min, ms.x3max - ms.x3min
+        cos_a3, sin_a3, cos_a2, sin_a2 = 1.0, 0.0, 1.0, 0.0
+        if pm.multi_d and not along_x1:
+            ang_3 = math.atan(x1size/x2size)
+            sin_a3, cos_a3 = math.sin(ang_3), math.cos(ang_3)
+        if pm.three_d and not along_x1:
+            ang_2 = math.atan(0.5*(x1size*cos_a3 + x2size*sin_a3)/x3size)
+            sin_a2, cos_a2 = math.sin(ang_2), math.cos(ang_2)
+        if along_x2:
+            cos_a3, sin_a3, cos_a2, sin_a2 = 0.0, 1.0, 1.0, 0.0
+        if along_x3:
+            cos_a3, sin_a3, cos_a2, sin_a2 = 0.0, 1.0, 0.0, 1.0
+        lam = FLT_MAX
+        if cos_a2*cos_a3 > 0.0:
+            lam = min(lam, x1size*cos_a2*cos_a3)
+        if cos_a2*sin_a3 > 0.0:
+            lam = min(lam, x2size*cos_a2*sin_a3)
+        if sin_a2 > 0.0:
+            lam = min(lam, x3size*sin_a2)
+        k_par = 2.0*math.pi/lam
+        pol = 1.0 if pin.GetOrAddBoolean("problem", "right_polar", True) else -1.0
+        phys = pm.pmb_pack.pmhd
+        eos = phys.peos.eos_data
+        gm1 = eos.gamma - 1.0
+        if self.set_initial_conditions:
+            tlim = pin.GetReal("time", "tlim")
+            pin.SetReal("time", "tlim", tlim*abs(lam/(b_par/math.sqrt(den))))
+
+        def _xy(x1, x2, x3):
+            return (x1*cos_a2*cos_a3 + x2*cos_a2*sin_a3 + x3*sin_a2, -x1*sin_a3 + x2*cos_a3)
+
+        def A1(x1, x2, x3):
+            x, y = _xy(x1, x2, x3)
+            ay = pol*(b_perp/k_par)*np.sin(k_par*(x))
+            az = (b_perp/k_par)*np.cos(k_par*(x)) + b_par*y
+            return -ay*sin_a3 - az*sin_a2*cos_a3
+
+        def A2(x1, x2, x3):
+            x, y = _xy(x1, x2, x3)
+            ay = pol*(b_perp/k_par)*np.sin(k_par*(x))
+            az = (b_perp/k_par)*np.cos(k_par*(x)) + b_par*y
+            return ay*cos_a3 - az*sin_a2*sin_a3
+
+        def A3(x1, x2, x3):
+            x, y = _xy(x1, x2, x3)
+            az = (b_perp/k_par)*np.cos(k_par*(x)) + b_par*y
+            return az*cos_a2
+
+        w, bf = self._alloc_host()
+        u = np.zeros_like(w)
+        ks, js, is_ = self._active()
+        ind = pm.mb_indcs
+        for m in range(w.shape[0]):
+            x1v, x2v, x3v, x1f, x2f, x3f, sz = self._coords(m)
+            F3, F2, F1 = np.meshgrid(x3f, x2f, x1f, indexing="ij")
+            x1vx = CellCenterX(np.arange(ind.nx1 + 1), ind.nx1, sz.x1min, sz.x1max)
+            x2vx = CellCenterX(np.arange(ind.nx2 + 1), ind.nx2, sz.x2min, sz.x2max)
+            x3vx = CellCenterX(np.arange(ind.nx3 + 1), ind.nx3, sz.x3min, sz.x3max)
+            V3, V2, V1 = np.meshgrid(x3vx, x2vx, x1vx, indexing="ij")
+            a1, a2, a3 = A1(V1, F2, F3), A2(F1, V2, F3), A3(F1, F2, V3)
+            dx1, dx2, dx3 = sz.dx1, sz.dx2, sz.dx3
+            masks = self._finer_edge_masks(m)
+            if masks is not None:
+                a1 = np.where(masks[0], 0.5*(A1(V1 + 0.25*dx1, F2, F3) + A1(V1 - 0.25*dx1, F2, F3)), a1)
+                a2 = np.where(masks[1], 0.5*(A2(F1, V2 + 0.25*dx2, F3) + A2(F1, V2 - 0.25*dx2, F3)), a2)
+                a3 = np.where(masks[2], 0.5*(A3(F1, F2, V3 + 0.25*dx3) + A3(F1, F2, V3 - 0.25*dx3)), a3)
+            X3, X2, X1 = np.meshgrid(x3v, x2v, x1v, indexing="ij")
+            x = cos_a2*(X1*cos_a3 + X2*sin_a3) + X3*sin_a2
+            sn = np.sin(k_par*x)
+            cs = pol*np.cos(k_par*x)
+            mx = den*v_par
+            my = -pol*den*v_perp*sn
+            mz = -pol*den*v_perp*cs
+            u[m, IDN][ks, js, is_] = den
+            u[m, 1][ks, js, is_] = mx*cos_a2*cos_a3 - my*sin_a3 - mz*sin_a2*cos_a3
+            u[m, 2][ks, js, is_] = mx*cos_a2*sin_a3 + my*cos_a3 - mz*sin_a2*sin_a3
+            u[m, 3][ks, js, is_] = mx*sin_a2 + mz*cos_a2
+            b1 = (a3[:-1, 1:, :] - a3[:-1, :-1, :])/dx2 - (a2[1:, :-1, :] - a2[:-1, :-1, :])/dx3
+            b2 = (a1[1:, :, :-1] - a1[:-1, :, :-1])/dx3 - (a3[:-1, :, 1:] - a3[:-1, :, :-1])/dx1
+            b3 = (a2[:, :-1, 1:] - a2[:, :-1, :-1])/dx1 - (a1[:, 1:, :-1] - a1[:, :-1, :-1])/dx2
+            bf[0][m][ks, js, is_.start:is_.stop + 1] = b1
+            bf[1][m][ks, js.start:js.stop + 1, is_] = b2
+            bf[2][m][ks.start:ks.stop + 1, js, is_] = b3
+            if eos.is_ideal:
+                sq = lambda q: q*q
+                u[m, IEN][ks, js, is_] = pres/gm1 + \
+                    0.5*(sq(0.5*(b1[:, :, :-1] + b1[:, :, 1:])) + sq(0.5*(b2[:, :-1, :] + b2[:, 1:, :])) +
+                         sq(0.5*(b3[:-1, :, :] + b3[1:, :, :]))) + \
+                    (0.5/den)*(sq(u[m, 1][ks, js, is_]) + sq(u[m, 2][ks, js, is_]) + sq(u[m, 3][ks, js, is_]))
+        to_u1 = not self.set_initial_conditions
+        self._upload_cc(phys.u1 if to_u1 else phys.u0, u)
+        dst = phys.b1 if to_u1 else phys.b0
+        for q, name in enumerate(("x1f", "x2f", "x3f")):
+            self._upload_cc(getattr(dst, name), bf[q])
+
+    def AlfvenWaveErrors(self):
+        """AlfvenWaveErrors, cpaw.cpp:441-598: the error file of LinearWaveErrors"""
+        self.set_initial_conditions = False
+        self.AlfvenWave(self.pin, False)
+        self.set_initial_conditions = True
+        return self.OutputErrors()
 
     def LinearWaveErrors(self):
         """linear_wave.cpp:1430-1437 + pgen.cpp:680-900: returns [RMS-L1, L-infty, L1...]"""

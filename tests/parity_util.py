@@ -167,7 +167,7 @@ def make_pair(problem, n, dims, mb=None, inject=True, fused=None, native=False, 
         sim = NativeSimulation(pin, initialize=False)
     else:
         sim = Simulation(pin, initialize=False)
-    if not native and sim.pmesh.multilevel:
+    if sim.pmesh.multilevel:      # (the native host builds its own tree; the oracle gets the Python one)
         okw.update(smr_tables(sim.pmesh))
     osim = akref.Sim(**okw)
     is_mhd = bool(okw["is_mhd"])

@@ -52,6 +52,18 @@ def test_whole_run_parity_smr(name):
     assert r["time"][0] == r["time"][1] and r["dt"][0] == r["dt"][1]
 
 
+@pytest.mark.parametrize("name", ["hydro3d", "mhd3d", "blast3d_c5", "mhd2d", "hydro1d", "mhd3d_3levels", "blast3d_bcs"])
+def test_native_cpp_host_parity_smr(name):
+    """the C++ host (csrc/akmi_host.cpp + akmi_host_smr.cpp: its own MeshBlockTree, neighbour table, index
+    tables and task lists) on refined meshes: bit-identical to the oracle, same dt sequence"""
+    import parity_util as pu
+    problem, n, dims, mb, cycles, kw = CASES[name]
+    r = pu.compare_run(problem, n, dims, mb, cycles=cycles, native=True, **kw)
+    assert r["cycles"] == cycles
+    assert r["bitwise_equal"], r
+    assert r["time"][0] == r["time"][1] and r["dt"][0] == r["dt"][1]
+
+
 def test_config5_product_initial_conditions_and_invariants():
     """the product's own problem generator on the SMR blast agrees with the oracle's (numpy's and
     libm's exp/log may differ in the last place inside the pressure ramp, hence not bitwise), and

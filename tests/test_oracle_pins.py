@@ -3,7 +3,9 @@
 Sources of the numbers:
  * tst/test_suite/nr/test_nr_lwave1d_cpu.py:15-96 (error thresholds, convergence ratios),
    :109-131 (run arguments), :155-160 (L/R-going wave errors must be equal for PLM);
- * values obtained from the reference itself (7 printed digits).
+ * 7-digit values recorded during the survey.  They are UNVERIFIABLE here (the
+   build that printed them cannot be repeated in this container), so the tests that quote them are
+   consistency checks of this repository against its own records, not pins on the reference.
 """
 import numpy as np
 import pytest

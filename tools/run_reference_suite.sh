@@ -23,7 +23,7 @@ python - "$@" <<'PY'
 import os, sys, pytest
 sys.path.insert(0, os.getcwd())
 import test_suite.testutils  # noqa: F401  (resolves ../vis/python relative to tst/)
-tests = [os.path.abspath("test_suite/nr/test_nr_%s_cpu.py" % t) for t in ("lwave1d", "isolwave1d", "sod", "rj2a")]
+tests = [os.path.abspath("test_suite/nr/test_nr_%s_cpu.py" % t) for t in ("lwave1d", "isolwave1d", "sod", "rj2a", "cpaw_amr")]
 # kinematic Gaussian-pulse diffusion regressions (viscosity 1-D, conduction 1-D and 2-D)
 tests += [os.path.abspath("test_suite/diffusion/test_diffusion_%s_cpu.py" % t) for t in ("visc", "conduct", "resist", "ambipolar_linwave")]
 # AKMI_SUITE_PLANES=1: also the scripts the reference runs on its GPU CI machine (xy/yz/zx planes embedded in 3-D,
