@@ -191,8 +191,14 @@ class MHD(FluidBase):
 
     def _stage_phase(self, pdrive, stage, phases):
         """akmi_mhd_stage_phase: the parts of the fused stage named by the mask `phases`"""
-        gam0, gam1 = pdrive.gam0[stage - 1], pdrive.gam1[stage - 1]
-        beta_dt = pdrive.beta[stage - 1]*self.pmy_pack.pmesh.dt
+        # stage 0 = Driver::InitBoundaryValuesAndPrimitives: only the c2p part may run then (the RK
+        # weights of "stage 0" do not exist; [stage - 1] would silently pick the last stage's)
+        assert stage >= 1 or phases == capi.PHASE_C2P, (stage, phases)
+        if stage >= 1:
+            gam0, gam1 = pdrive.gam0[stage - 1], pdrive.gam1[stage - 1]
+            beta_dt = pdrive.beta[stage - 1]*self.pmy_pack.pmesh.dt
+        else:
+            gam0, gam1, beta_dt = 1.0, 0.0, 0.0
         do_dt = 1 if stage == pdrive.nexp_stages else 0
         capi.check(self.L.akmi_mhd_stage_phase(
             C.byref(self.pack_c), self.recon_method, self.rsolver_method, capi.d(gam0),

@@ -27,9 +27,13 @@ class ParameterInput:
             if not line or line.startswith("#"):
                 continue
             if line.startswith("<"):
+                if ">" not in line:                      # parameter_input.cpp:176-181
+                    raise ParameterInputError("### FATAL ERROR Block name '%s' not properly ended" % line[1:])
                 name = line[1:line.index(">")].strip()
                 if name == "par_end":
                     break
+                # a repeated <block> continues the first one and a repeated name replaces the value:
+                # FindOrAddBlock / AddParameter, parameter_input.cpp:266-282,328-352
                 block = self.blocks.setdefault(name, {})
                 continue
             if block is None:

@@ -35,15 +35,18 @@ BYTES_PASS_B = {"mhd": 16*8, "hydro": 10*8}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=55, help="timed cycles (BASELINE config 3: nlim = 55)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nx", type=int, default=256, help="cells per GPU per dimension")
     ap.add_argument("--mb", type=int, default=0,
                     help="MeshBlock size per dimension (default: --nx, one MeshBlock per GPU); "
                          "smaller blocks put (nx/mb)^3 MeshBlocks into each GPU's pack")
     ap.add_argument("--problem", default="orszag_tang", choices=["orszag_tang", "sod", "linear_wave"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-nx", type=int, default=64)
+    ap.add_argument("--cpu-sample-nx", type=int, default=128)
+    ap.add_argument("--recon", default=None, choices=["dc", "plm", "ppm4", "ppmx", "wenoz"],
+                    help="reconstruction (default: the deck's plm); ppm4 = the numerics of BASELINE config 5")
+    ap.add_argument("--ng", type=int, default=None, help="ghost cells (default 2; ppm4 needs >= 3)")
     ap.add_argument("--split", action="store_true", help="task-granular chain instead of fused stage")
     return ap.parse_args()
 
@@ -68,10 +71,21 @@ def make_pin(args, nblk):
     for q in range(3):
         ov += ["mesh/nx%d=%d" % (q + 1, mesh[q]), "meshblock/nx%d=%d" % (q + 1, args.mb or nx)]
     ov += ["time/nlim=-1", "time/tlim=1.0e9"]
+    if args.recon:
+        ov.append("%s/reconstruct=%s" % (blk, args.recon))
+    if args.ng or (args.recon in ("ppm4", "ppmx", "wenoz")):
+        ov.append("mesh/nghost=%d" % (args.ng or 4))
     pin = load_deck(deck, ov)
     if args.split:
         pin.blocks[blk]["fused_stage"] = "false"
     return pin, blk
+
+
+def lib_sha16():
+    """first 16 hex digits of the sha256 of the HIP library this process loaded"""
+    import hashlib
+    from athenak_amd import capi
+    return hashlib.sha256(open(capi.LIB_PATH, "rb").read()).hexdigest()[:16]
 
 
 def cpu_baseline(args, blk):
@@ -84,46 +98,49 @@ def cpu_baseline(args, blk):
         navail = os.cpu_count() or 1
     akref.lib()
     n = args.cpu_sample_nx
+    rec = args.recon or "plm"
+    ngc = args.ng or (4 if rec in ("ppm4", "ppmx", "wenoz") else 2)
     if args.problem == "orszag_tang":
-        kw = dict(is_mhd=1, recon="plm", rsolver="hlld", gamma=1.666666667, pgen="orszag_tang",
+        kw = dict(is_mhd=1, recon=rec, rsolver="hlld", gamma=1.666666667, pgen="orszag_tang",
                   bcs=["periodic"]*6)
     elif args.problem == "sod":
-        kw = dict(is_mhd=0, recon="plm", rsolver="hllc", gamma=1.4, pgen="shock_tube", shock_dir=1,
+        kw = dict(is_mhd=0, recon=rec, rsolver="hllc", gamma=1.4, pgen="shock_tube", shock_dir=1,
                   xshock=0.0, wl=[1.0, 0, 0, 0, 1.0, 0, 0, 0], wr=[0.125, 0, 0, 0, 0.1, 0, 0, 0],
                   bcs=["outflow", "outflow", "periodic", "periodic", "periodic", "periodic"])
     else:
-        kw = dict(is_mhd=0, recon="plm", rsolver="hllc", gamma=1.66666666667, pgen="linear_wave",
+        kw = dict(is_mhd=0, recon=rec, rsolver="hllc", gamma=1.66666666667, pgen="linear_wave",
                   wave_flag=0, amp=1e-3, dens=1.0, pgas=0.6, bcs=["periodic"]*6, x1min=0.0,
                   x1max=3.0, x2min=0.0, x2max=1.5, x3min=0.0, x3max=1.5)
 
     def timed(threads, budget):
         akref.lib().akref_set_threads(threads)
-        s = akref.Sim(nx1=n, nx2=n, nx3=n, mb_nx1=n, mb_nx2=n, mb_nx3=n, ng=2, nstages=2, cfl=0.3,
+        s = akref.Sim(nx1=n, nx2=n, nx3=n, mb_nx1=n, mb_nx2=n, mb_nx3=n, ng=ngc, nstages=2, cfl=0.3,
                       tlim=1e9, nlim=-1, **kw)
         s.initialize()
         s.step()                   # warm-up (page faults, caches)
         t0 = time.time()
         cyc = 0
-        while time.time() - t0 < budget and cyc < 400:
+        while (time.time() - t0 < budget and cyc < 400) or cyc < 1:
             s.step()
             cyc += 1
         dt = time.time() - t0
         s.close()
         return n**3*cyc/dt/1e6, cyc
 
-    # the oracle's OpenMP loops run over (block, k) planes: at most n-way parallel
-    candidates = sorted({1, min(navail, 16), min(navail, 32), min(navail, n)})
+    # the oracle's OpenMP loops run over the flattened (block, k, j) rows (the Kokkos-OpenMP /
+    # flat-MPI semantics of SURVEY 8(d)): 1 core, then powers of four up to every usable core
+    candidates = sorted({1, min(navail, 16), min(navail, 64), navail})
     best = None
     results = []
     for th in candidates:
-        v, cyc = timed(th, 5.0)
+        v, cyc = timed(th, 4.0)
         results.append("%d thr: %.3f" % (th, v))
         if best is None or v > best[0]:
             best = (v, th, cyc)
     return {"value": round(best[0], 4), "unit": "Mcell-updates/s", "cores": best[1], "kind": "port",
-            "sample": "%s %d^3 RK2, ~5 s per thread count, oracle = port of the reference's "
-                      "split-kernel CPU sequence with OpenMP; Mcell-updates/s by threads: %s "
-                      "(host has %d usable cores)" % (args.problem, n, "; ".join(results), navail)}
+            "sample": "%s %d^3 RK2 %s, ~4 s per thread count, oracle = port of the reference's "
+                      "split-kernel CPU sequence, OpenMP over (block,k,j); Mcell-updates/s by threads: %s "
+                      "(host has %d usable cores)" % (args.problem, n, rec, "; ".join(results), navail)}
 
 
 def main():
@@ -221,8 +238,14 @@ def main():
         stage_kernels = [k for k in t["kernels"] if k.startswith("akmi::k_sweep") or
                          k.startswith("akmi::k_corner") or k.startswith("akmi::k_ct_copy") or
                          k.startswith("akmi::k_hydro_stage3d") or k.startswith("akmi::k_c2p_newdt")]
-        traffic = round(sum(t["kernels"][k]["hbm_bytes_per_launch"] for k in stage_kernels))
-        tsrc = "profiles/%s (%s)" % (os.path.basename(tfile), t.get("tag", ""))
+        if t.get("lib_sha16") == lib_sha16() and not args.recon and not args.ng:
+            # counters of THIS build of the library only: the profiling run stamps the sha of the
+            # libakmi.so it measured (tools/pmc_summary.py)
+            traffic = round(sum(t["kernels"][k]["hbm_bytes_per_launch"] for k in stage_kernels))
+            tsrc = "profiles/%s (%s, lib %s)" % (os.path.basename(tfile), t.get("tag", ""), t["lib_sha16"])
+        else:
+            tsrc = "profiles/%s is of another build (lib %s, this run %s): traffic not reported" % (
+                os.path.basename(tfile), t.get("lib_sha16"), lib_sha16())
     roofline = {"bound": "hbm",
                 "kernel": ("akmi_%s_stage_fused launch group (sweeps + update%s + c2p of active cells)"
                            % (blk, " + CornerE + CT" if blk == "mhd" else "")) if world == 1 else
@@ -241,18 +264,21 @@ def main():
 
     if rank == 0:
         value = ncell_total*args.steps/el/1e6
-        out = {"metric": "Mcell-updates/s (3D MHD PLM+HLLD+CT RK2, %d^3 cells per GPU)" % args.nx
-               if blk == "mhd" else "Mcell-updates/s (3D hydro PLM+HLLC RK2, %d^3 per GPU)" % args.nx,
+        rname = (args.recon or "plm").upper()
+        out = {"metric": "Mcell-updates/s (3D MHD %s+HLLD+CT RK2, %d^3 cells per GPU)" % (rname, args.nx)
+               if blk == "mhd" else "Mcell-updates/s (3D hydro %s+HLLC RK2, %d^3 per GPU)" % (rname, args.nx),
                "value": round(value, 2), "unit": "Mcell-updates/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el/args.steps*1e3, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
                "data": "synthetic (closed-form %s initial condition)" % args.problem,
+               "lib_sha16": lib_sha16(),
                "config": {"workload": "%s 3D, %s, %d^3 cells per GPU, mesh %dx%dx%d in %dx%dx%d "
-                                      "MeshBlocks, cfl 0.3, RK2, ng=2" % (
-                                          args.problem, "ideal MHD PLM+HLLD+CT" if blk == "mhd" else
-                                          "ideal hydro PLM+HLLC", args.nx, args.nx*nblk[0],
+                                      "MeshBlocks, cfl 0.3, RK2, ng=%d" % (
+                                          args.problem, ("ideal MHD %s+HLLD+CT" % (args.recon or "plm").upper()) if blk == "mhd" else
+                                          ("ideal hydro %s+HLLC" % (args.recon or "plm").upper()), args.nx, args.nx*nblk[0],
                                           args.nx*nblk[1], args.nx*nblk[2],
-                                          *[b*args.nx//(args.mb or args.nx) for b in nblk]),
+                                          *[b*args.nx//(args.mb or args.nx) for b in nblk],
+                                          pm.mb_indcs.ng),
                           "path": "task-granular" if args.split else "fused stage",
                           "halo": "none (single periodic block: same-rank gather)" if world == 1
                           else "%s send/recv (torch.distributed), per-stage U and B messages posted "

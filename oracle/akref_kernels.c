@@ -1236,7 +1236,7 @@ static int hydro_fluxes_impl(const akmi_pack *p, int recon, int rsolver, const d
                     recon_dir(&g, p, 1, recon, 2, nv, w0, wl, wr, kl-1, ku+1, jl, ju, il, iu); ku = ku+1;
                     flx = flx3; f1 = N1; f3 = N3 + fs; }
     const int ivx = IVX + dir, ivy = IVX + (dir + 1)%3, ivz = IVX + (dir + 2)%3;
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(3) schedule(static)
     for (int m = 0; m < g.nmb; ++m)
       for (int k = kl; k <= ku; ++k)
         for (int j = jl; j <= ju; ++j)
@@ -1432,7 +1432,7 @@ int akref_hydro_c2p(const akmi_pack *p, double *u0, double *w0, int il, int iu, 
   const double efloor = p->pfloor/(p->gamma - 1.0);
   const double tfloor = p->tfloor, sfloor = p->sfloor, dfloor_ = p->dfloor;
   int sumd = 0, sume = 0, sumt = 0;
-#pragma omp parallel for collapse(2) schedule(static) reduction(+:sumd,sume,sumt)
+#pragma omp parallel for collapse(3) schedule(static) reduction(+:sumd,sume,sumt)
   for (int m = 0; m < g.nmb; ++m)
     for (int k = kl; k <= ku; ++k)
       for (int j = jl; j <= ju; ++j)
@@ -1472,7 +1472,7 @@ int akref_hydro_newdt(const akmi_pack *p, const double *w0, double *dt3) {
   G g = mkG(p);
   const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
   double dt1 = (double)FLT_MAX, dt2 = (double)FLT_MAX, dt3_ = (double)FLT_MAX;
-#pragma omp parallel for collapse(2) schedule(static) reduction(min:dt1,dt2,dt3_)
+#pragma omp parallel for collapse(3) schedule(static) reduction(min:dt1,dt2,dt3_)
   for (int m = 0; m < g.nmb; ++m)
     for (int k = g.ks; k <= g.ke; ++k)
       for (int j = g.js; j <= g.je; ++j)
@@ -1557,7 +1557,7 @@ static int mhd_fluxes_impl(const akmi_pack *p, int recon, int rsolver, const dou
     }
     const int ivx = IVX + dir, ivy = IVX + (dir + 1)%3, ivz = IVX + (dir + 2)%3;
     const int iby = (dir + 1)%3, ibz = (dir + 2)%3;
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(3) schedule(static)
     for (int m = 0; m < g.nmb; ++m)
       for (int k = kl; k <= ku; ++k)
         for (int j = jl; j <= ju; ++j)
@@ -2063,7 +2063,7 @@ int akref_mhd_corner_e(const akmi_pack *p, const double *w0, const double *bcc0,
     return 0;
   }
   /* 3D: e_cc_3d (src/mhd/mhd_corner_e.cpp:309-317) */
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(3) schedule(static)
   for (int m = 0; m < g.nmb; ++m)
     for (int k = ks-1; k <= ke+1; ++k)
       for (int j = js-1; j <= je+1; ++j)
@@ -2073,7 +2073,7 @@ int akref_mhd_corner_e(const akmi_pack *p, const double *w0, const double *bcc0,
           CC(e3cc,m,k,j,i) = W(IVY,m,k,j,i)*B(IBX,m,k,j,i) - W(IVX,m,k,j,i)*B(IBY,m,k,j,i);
         }
   /* emf3 (src/mhd/mhd_corner_e.cpp:338-414) */
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(3) schedule(static)
   for (int m = 0; m < g.nmb; ++m)
     for (int k = ks; k <= ke+1; ++k)
       for (int j = js; j <= je+1; ++j)
@@ -2127,7 +2127,7 @@ int akref_mhd_ct(const akmi_pack *p, double gam0, double gam1, double beta_dt,
   const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
   const int is = g.is, ie = g.ie, js = g.js, je = g.je, ks = g.ks, ke = g.ke;
   if (g.multi_d) {
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(3) schedule(static)
     for (int m = 0; m < g.nmb; ++m)
       for (int k = ks; k <= ke; ++k)
         for (int j = js; j <= je; ++j)
@@ -2139,7 +2139,7 @@ int akref_mhd_ct(const akmi_pack *p, double gam0, double gam1, double beta_dt,
               b0x1f[c] += beta_dt*(E2(m,k+1,j,i) - E2(m,k,j,i))/p->dx[3*m+2];
           }
   }
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(3) schedule(static)
   for (int m = 0; m < g.nmb; ++m)
     for (int k = ks; k <= ke; ++k)
       for (int j = js; j <= je+1; ++j)
@@ -2150,7 +2150,7 @@ int akref_mhd_ct(const akmi_pack *p, double gam0, double gam1, double beta_dt,
           if (g.three_d)
             b0x2f[c] -= beta_dt*(E1(m,k+1,j,i) - E1(m,k,j,i))/p->dx[3*m+2];
         }
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(3) schedule(static)
   for (int m = 0; m < g.nmb; ++m)
     for (int k = ks; k <= ke+1; ++k)
       for (int j = js; j <= je; ++j)
@@ -2202,7 +2202,7 @@ int akref_mhd_c2p(const akmi_pack *p, double *u0, const double *bx1f, const doub
   const double efloor = p->pfloor/(p->gamma - 1.0);
   const double tfloor = p->tfloor, sfloor = p->sfloor;
   int sumd = 0, sume = 0, sumt = 0;
-#pragma omp parallel for collapse(2) schedule(static) reduction(+:sumd,sume,sumt)
+#pragma omp parallel for collapse(3) schedule(static) reduction(+:sumd,sume,sumt)
   for (int m = 0; m < g.nmb; ++m)
     for (int k = kl; k <= ku; ++k)
       for (int j = jl; j <= ju; ++j)
@@ -2251,7 +2251,7 @@ int akref_mhd_newdt(const akmi_pack *p, const double *w0, const double *bcc0, do
   G g = mkG(p);
   const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
   double dt1 = (double)FLT_MAX, dt2 = (double)FLT_MAX, dt3_ = (double)FLT_MAX;
-#pragma omp parallel for collapse(2) schedule(static) reduction(min:dt1,dt2,dt3_)
+#pragma omp parallel for collapse(3) schedule(static) reduction(min:dt1,dt2,dt3_)
   for (int m = 0; m < g.nmb; ++m)
     for (int k = g.ks; k <= g.ke; ++k)
       for (int j = g.js; j <= g.je; ++j)

@@ -12,5 +12,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   mkdir -p $out
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out -- python $root/tools/pmc_workload.py > $out/log.txt 2>&1
 done
-python $root/tools/pmc_summary.py $root/gpurun_out/pmc_${tag}_FETCH_SIZE $root/gpurun_out/pmc_${tag}_WRITE_SIZE > $root/gpurun_out/${tag}_pmc_traffic.json
+python $root/tools/pmc_summary.py $root/gpurun_out/pmc_${tag}_FETCH_SIZE $root/gpurun_out/pmc_${tag}_WRITE_SIZE $tag > $root/gpurun_out/${tag}_pmc_traffic.json
 cat $root/gpurun_out/${tag}_pmc_traffic.json | head -60

@@ -38,6 +38,13 @@ def main():
         wr = write.get(k, 0.0)*(wscale or 1024.0)
         out["kernels"][k] = {"launches": nf.get(k, nw.get(k, 0)), "read_bytes_per_launch": rd,
                              "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
+    # which build of the library these counters belong to (bench.py refuses another build's numbers)
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.environ.get("AKMI_LIB") or os.path.join(root, "athenak_amd", "lib", "libakmi.so")
+    out["lib_sha16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
+    if len(sys.argv) > 3:
+        out["tag"] = sys.argv[3]
     print(json.dumps(out, indent=1))
 
 
