@@ -189,7 +189,8 @@ static int BCFlag(const std::string &v) {
   AKMI_FATAL("boundary flag '" + v + "' not supported by the C++ host (periodic/outflow/reflect/diode/vacuum; inflow and user: Python host)");
 }
 
-Mesh::Mesh(ParameterInput *pin) {
+Mesh::Mesh(ParameterInput *pin, int my_rank_, int nranks_, bool host_only_)
+    : my_rank(my_rank_), nranks(nranks_), host_only(host_only_) {
   mesh_size.x1min = pin->GetReal("mesh", "x1min"); mesh_size.x1max = pin->GetReal("mesh", "x1max");
   mesh_size.x2min = pin->GetReal("mesh", "x2min"); mesh_size.x2max = pin->GetReal("mesh", "x2max");
   mesh_size.x3min = pin->GetReal("mesh", "x3min"); mesh_size.x3max = pin->GetReal("mesh", "x3max");
@@ -239,8 +240,13 @@ Mesh::Mesh(ParameterInput *pin) {
   dtold = 0.0;
   cfl_no = pin->GetReal("time", "cfl_number");
   ncycle = 0;
-  pmb_pack = new MeshBlockPack(this, 0, nmb_total - 1);
-  pmb_pack->pmb = new MeshBlock(pmb_pack, 0, nmb_total);
+  if (multilevel && nranks > 1)
+    AKMI_FATAL("mesh refinement on more than one rank is not on this build's path");
+  // every MeshBlock costs the same (build_tree.cpp:262-272); one pack per rank (mesh.cpp:205-215)
+  LoadBalance(std::vector<float>(nmb_total, 1.0f));
+  const int gs = gids_eachrank[my_rank], nb = nmb_eachrank[my_rank];
+  pmb_pack = new MeshBlockPack(this, gs, gs + nb - 1);
+  pmb_pack->pmb = new MeshBlock(pmb_pack, gs, nb);
 }
 Mesh::~Mesh() { delete pmb_pack; }
 
@@ -251,12 +257,13 @@ MeshBlock::MeshBlock(MeshBlockPack *ppack, int igids, int nmb_) : nmb(nmb_) {
   const bool active[3] = {true, pm->multi_d, pm->three_d};
   const Real mmin[3] = {ms.x1min, ms.x2min, ms.x3min}, mmax[3] = {ms.x1max, ms.x2max, ms.x3max};
   const int nxb[3] = {pm->mb_indcs.nx1, pm->mb_indcs.nx2, pm->mb_indcs.nx3};
-  mb_gid.resize(nmb); mb_size.resize(nmb); mb_bcs.resize(6*nmb); nghbr.assign(27*nmb, -1);
+  mb_gid.resize(nmb); mb_size.resize(nmb); mb_bcs.resize(6*nmb);
+  nghbr_gid.assign(27*nmb, -1); nghbr_rank.assign(27*nmb, -1);
   mb_lev.assign(nmb, pm->root_level);
-  std::vector<int> gid_of(pm->multilevel ? 0 : nmb);
-  for (int m = 0; m < nmb && !pm->multilevel; ++m) {
-    const int *l = &pm->lloc_eachmb[3*(igids + m)];
-    gid_of[(l[2]*nbr[1] + l[1])*nbr[0] + l[0]] = m;
+  std::vector<int> gid_of(pm->multilevel ? 0 : pm->nmb_total);      // logical location -> global id
+  for (int g = 0; g < pm->nmb_total && !pm->multilevel; ++g) {
+    const int *l = &pm->lloc_eachmb[3*g];
+    gid_of[(l[2]*nbr[1] + l[1])*nbr[0] + l[0]] = g;
   }
   std::vector<Real> dx(3*nmb);
   for (int m = 0; m < nmb; ++m) {
@@ -286,13 +293,19 @@ MeshBlock::MeshBlock(MeshBlockPack *ppack, int igids, int nmb_) : nmb(nmb_) {
         if (ll[q] < 0) { if (pm->mesh_bcs[2*q] == AKMI_BC_PERIODIC) ll[q] += nb[q]; else ok = false; }
         else if (ll[q] >= nb[q]) { if (pm->mesh_bcs[2*q + 1] == AKMI_BC_PERIODIC) ll[q] -= nb[q]; else ok = false; }
       }
-      if (ok) nghbr[27*m + d] = gid_of[(ll[2]*nb[1] + ll[1])*nb[0] + ll[0]];
+      if (ok) {
+        const int g = gid_of[(ll[2]*nb[1] + ll[1])*nb[0] + ll[0]];
+        nghbr_gid[27*m + d] = g;
+        nghbr_rank[27*m + d] = pm->rank_eachmb[g];
+      }
     }
   }
+  BuildMeshBlockPlan(this, pm->my_rank, igids);       // akmi_host_comm.cpp: plan.tab = the device table
+  if (pm->host_only) return;
   d_dx.Realloc(3*nmb); d_bcs.Realloc(6*nmb); d_nghbr.Realloc(27*nmb);
   HIPCHK(hipMemcpy(d_dx.p, dx.data(), sizeof(Real)*3*nmb, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d_bcs.p, mb_bcs.data(), sizeof(int)*6*nmb, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(d_nghbr.p, nghbr.data(), sizeof(int)*27*nmb, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_nghbr.p, plan.tab.data(), sizeof(int)*27*nmb, hipMemcpyHostToDevice));
   if (pm->multilevel) SetNeighborsSMR(pm);
 }
 MeshBlock::~MeshBlock() { d_dx.Free(); d_bcs.Free(); d_nghbr.Free(); }
@@ -326,6 +339,9 @@ void Mesh::NewTimeStep(const Real tlim) {               // mesh.cpp:573-643
     if (f->has_resist) dt = std::min(dt, cfl_no*f->dt_resist);
     if (f->has_cond) dt = std::min(dt, cfl_no*f->dt_cond);
   }
+  // minimum over all ranks (mesh.cpp:634-637): ncclAllReduce(ncclMin) on the compute stream
+  for (FluidBase *f : phys)
+    if (f && nranks > 1) { Comm::World().AllReduceMin(&dt, 1, f->stream); break; }
   if ((time < tlim) && ((time + dt) > tlim)) dt = tlim - time;
 }
 
@@ -404,6 +420,7 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
     coarse_u0.Realloc(static_cast<size_t>(pp->nmb_thispack)*nvars*c3*c2*c1);
     psmr = new MeshBoundaryValuesSMR(pp, nvars);
   }
+  if (!multilevel && pp->pmesh->nranks > 1) pbval = new MeshBoundaryValues(pp, &pack_c, nvars, blk == "mhd");
   use_fofc = pin->GetOrAddBoolean(blk, "fofc", false);     // hydro.cpp:153-190, mhd.cpp:199-235
   if (use_fofc) {
     const int need = recon_method == AKMI_RECON_PLM ? 3 : (recon_method >= AKMI_RECON_PPM4 ? 4 : 2);
@@ -421,6 +438,7 @@ FluidBase::~FluidBase() {
   u0.Free(); w0.Free(); u1.Free(); counters.Free(); dt3.Free(); ws.Free(); fofc.Free(); nfofc.Free();
   dtmin_cond.Free(); coarse_u0.Free();
   delete psmr;
+  delete pbval;
   delete peos;
 }
 void FluidBase::FinishNewDt() {        // hydro_newdt.cpp:121-124
@@ -703,7 +721,11 @@ TaskStatus Hydro::Fluxes(Driver *d, int stage) {           // hydro_tasks.cpp:15
 }
 TaskStatus Hydro::RKUpdate(Driver *d, int stage) {         // hydro_update.cpp:23-83
   Real beta_dt = d->beta[stage - 1]*pmy_pack->pmesh->dt;
-  if (fused) {
+  if (fused && peers()) {
+    // off-rank neighbours: only the sweeps + update here, so that SendU can post the halo messages
+    // before the c2p of the active cells is enqueued
+    StagePhase(d, stage, AKMI_PHASE_SWEEPS);
+  } else if (fused) {
     int do_dt = (stage == d->nexp_stages);
     AKCHK(akmi_hydro_stage_fused(&pack_c, recon_method, rsolver_method, d->gam0[stage - 1],
                                  d->gam1[stage - 1], beta_dt, stage == 1, w0.p, u0.p, u1.p, do_dt,
@@ -715,11 +737,31 @@ TaskStatus Hydro::RKUpdate(Driver *d, int stage) {         // hydro_update.cpp:2
   }
   return TaskStatus::complete;
 }
-TaskStatus Hydro::SendU(Driver *d, int stage) {            // hydro_tasks.cpp:308-320 (same rank)
-  if (multilevel)
+void Hydro::StagePhase(Driver *d, int stage, int phases) {
+  // stage 0 = Driver::InitBoundaryValuesAndPrimitives: only the c2p part may run then
+  if (stage < 1 && phases != AKMI_PHASE_C2P) AKMI_FATAL("stage 0 has no RK weights");
+  const Real g0 = stage >= 1 ? d->gam0[stage - 1] : 1.0, g1 = stage >= 1 ? d->gam1[stage - 1] : 0.0;
+  const Real beta_dt = stage >= 1 ? d->beta[stage - 1]*pmy_pack->pmesh->dt : 0.0;
+  const int do_dt = (stage == d->nexp_stages);
+  AKCHK(akmi_hydro_stage_phase(&pack_c, recon_method, rsolver_method, g0, g1, beta_dt, stage == 1, w0.p,
+                               u0.p, u1.p, do_dt, counters.p, dt3.p, phases, ws.p, stream));
+  if (phases & AKMI_PHASE_C2P) { interior_done_ = true; dt_ready_ = do_dt; }
+}
+TaskStatus Hydro::SendU(Driver *d, int stage) {            // hydro_tasks.cpp:308-320
+  if (multilevel) {
     AKCHK(akmi_smr_exchange_cc(&pack_c, &psmr->smr_c, nvars, u0.p, coarse_u0.p, psmr->buf[0].p, stream));
-  else
+  } else if (pbval) {
+    pbval->PackAndSendCC(u0.p, stream);
+    // the messages are in flight on the communicator's stream: convert the active cells (they do
+    // not depend on the halo) underneath them
+    if (fused && peers()) StagePhase(d, stage, AKMI_PHASE_C2P);
+  } else {
     AKCHK(akmi_bvals_cc_local(&pack_c, nvars, pmy_pack->pmb->d_nghbr.p, u0.p, stream));
+  }
+  return TaskStatus::complete;
+}
+TaskStatus Hydro::RecvU(Driver *d, int stage) {            // hydro_tasks.cpp:327-339
+  if (pbval) pbval->RecvAndUnpackCC(u0.p, stream);
   return TaskStatus::complete;
 }
 TaskStatus Hydro::SendFlux(Driver *d, int stage) {         // hydro_tasks.cpp:206-215
@@ -810,7 +852,9 @@ TaskStatus MHD::Fluxes(Driver *d, int stage) {             // mhd_tasks.cpp:177-
 }
 TaskStatus MHD::RKUpdate(Driver *d, int stage) {           // mhd_update.cpp:24-84
   Real beta_dt = d->beta[stage - 1]*pmy_pack->pmesh->dt;
-  if (fused) {
+  if (fused && peers()) {
+    StagePhase(d, stage, AKMI_PHASE_SWEEPS);
+  } else if (fused) {
     int do_dt = (stage == d->nexp_stages);
     AKCHK(akmi_mhd_stage_fused(&pack_c, recon_method, rsolver_method, d->gam0[stage - 1],
                                d->gam1[stage - 1], beta_dt, stage == 1, w0.p, bcc0.p, u0.p, u1.p,
@@ -823,11 +867,36 @@ TaskStatus MHD::RKUpdate(Driver *d, int stage) {           // mhd_update.cpp:24-
   }
   return TaskStatus::complete;
 }
+void MHD::StagePhase(Driver *d, int stage, int phases) {
+  if (stage < 1 && phases != AKMI_PHASE_C2P) AKMI_FATAL("stage 0 has no RK weights");
+  const Real g0 = stage >= 1 ? d->gam0[stage - 1] : 1.0, g1 = stage >= 1 ? d->gam1[stage - 1] : 0.0;
+  const Real beta_dt = stage >= 1 ? d->beta[stage - 1]*pmy_pack->pmesh->dt : 0.0;
+  const int do_dt = (stage == d->nexp_stages);
+  AKCHK(akmi_mhd_stage_phase(&pack_c, recon_method, rsolver_method, g0, g1, beta_dt, stage == 1, w0.p,
+                             bcc0.p, u0.p, u1.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, b1.x1f.p, b1.x2f.p,
+                             b1.x3f.p, do_dt, counters.p, dt3.p, phases, ws.p, stream));
+  if (phases & AKMI_PHASE_C2P) { interior_done_ = true; dt_ready_ = do_dt; }
+}
+// Off-rank neighbours and the fused stage: sweeps+update -> pack+send U -> CornerE+CT -> pack+send B
+// -> c2p of the active cells (+dt) -> wait/unpack U, B -> BCs -> c2p of the ghost shell: the reference's
+// task order (mhd_tasks.cpp:48-75) with the transfers underneath the kernels that do not need them
 TaskStatus MHD::SendU(Driver *d, int stage) {
   if (multilevel)
     AKCHK(akmi_smr_exchange_cc(&pack_c, &psmr->smr_c, nvars, u0.p, coarse_u0.p, psmr->buf[0].p, stream));
+  else if (pbval)
+    pbval->PackAndSendCC(u0.p, stream);
   else
     AKCHK(akmi_bvals_cc_local(&pack_c, nvars, pmy_pack->pmb->d_nghbr.p, u0.p, stream));
+  return TaskStatus::complete;
+}
+TaskStatus MHD::RecvU(Driver *d, int stage) {
+  if (pbval && !(fused && peers())) pbval->RecvAndUnpackCC(u0.p, stream);   // else: in RecvB
+  return TaskStatus::complete;
+}
+TaskStatus MHD::RecvB(Driver *d, int stage) {
+  if (!pbval) return TaskStatus::complete;
+  if (fused && peers()) pbval->RecvAndUnpackCC(u0.p, stream);
+  pbval->RecvAndUnpackFC(b0, stream);
   return TaskStatus::complete;
 }
 TaskStatus MHD::SendFlux(Driver *d, int stage) {           // mhd_tasks.cpp:225-233
@@ -886,6 +955,7 @@ TaskStatus MHD::EField(Driver *d, int stage) {             // mhd_corner_e.cpp:2
   return TaskStatus::complete;
 }
 TaskStatus MHD::CT(Driver *d, int stage) {                 // mhd_ct.cpp:23-80
+  if (fused && peers()) StagePhase(d, stage, AKMI_PHASE_EMF_CT);
   if (!fused)
     AKCHK(akmi_mhd_ct(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1],
                       d->beta[stage - 1]*pmy_pack->pmesh->dt, efld.x1e.p, efld.x2e.p, efld.x3e.p,
@@ -896,8 +966,12 @@ TaskStatus MHD::SendB(Driver *d, int stage) {
   if (multilevel)
     AKCHK(akmi_smr_exchange_fc(&pack_c, &psmr->smr_c, b0.x1f.p, b0.x2f.p, b0.x3f.p, coarse_b0.x1f.p,
                                coarse_b0.x2f.p, coarse_b0.x3f.p, psmr->buf[2].p, stream));
-  else
+  else if (pbval) {
+    pbval->PackAndSendFC(b0, stream);
+    if (fused && peers()) StagePhase(d, stage, AKMI_PHASE_C2P);
+  } else {
     AKCHK(akmi_bvals_fc_local(&pack_c, pmy_pack->pmb->d_nghbr.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, stream));
+  }
   return TaskStatus::complete;
 }
 TaskStatus MHD::ApplyPhysicalBCs(Driver *d, int stage) {   // mhd_tasks.cpp:501-520
@@ -953,7 +1027,7 @@ extern "C" {
 void *akmi_sim_create(const char *deck_text, void *stream) {
   Sim *s = new Sim;
   s->pin.LoadFromString(deck_text);
-  s->pmesh = new Mesh(&s->pin);
+  s->pmesh = new Mesh(&s->pin, Comm::World().rank, Comm::World().nranks);
   s->pmesh->pmb_pack->AddPhysics(&s->pin);
   if (auto *ph = s->pmesh->pmb_pack->phydro) ph->stream = (hipStream_t)stream;
   if (auto *pm = s->pmesh->pmb_pack->pmhd) pm->stream = (hipStream_t)stream;
@@ -1006,5 +1080,7 @@ void *akmi_sim_array(void *h, const char *name, long long *count) {
 }
 
 const int *akmi_sim_lloc(void *h) { return static_cast<Sim *>(h)->pmesh->lloc_eachmb.data(); }
+int akmi_sim_gids(void *h) { return static_cast<Sim *>(h)->pmesh->pmb_pack->gids; }
+int akmi_sim_nmb_thisrank(void *h) { return static_cast<Sim *>(h)->pmesh->pmb_pack->nmb_thispack; }
 
 }  // extern "C"

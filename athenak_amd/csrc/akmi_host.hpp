@@ -8,15 +8,17 @@
 //   hydro::Hydro / mhd::MHD (arrays + task member functions)   src/hydro/hydro.hpp:73-154,
 //                                                              src/mhd/mhd.hpp:93-199
 //   Driver   src/driver/driver.cpp:93-162,290-307,314-459
-// Every task body is ONE call through the C ABI of include/akmi.h.  Single rank (all
-// MeshBlocks of the mesh in one pack on one GPU); multi-rank runs are driven by the Python
-// mirror (athenak_amd/*.py) because the launch contract is torch.distributed.
+// Every task body is ONE call through the C ABI of include/akmi.h.  One process per GPU: the
+// Z-ordered MeshBlock list is cut into one pack per rank (Mesh::LoadBalance), off-rank halos
+// travel as one message per peer and variable class through Comm (RCCL ncclSend/ncclRecv on
+// its own stream; akmi_host_comm.cpp), dt is reduced with ncclAllReduce(min).
 #ifndef AKMI_HOST_HPP_
 #define AKMI_HOST_HPP_
 #include <hip/hip_runtime.h>
 #include <cfloat>
 #include <cstdint>
 #include <functional>
+#include <array>
 #include <list>
 #include <map>
 #include <memory>
@@ -136,6 +138,57 @@ struct DvceEdgeFld { DvceArray<Real> x1e, x2e, x3e; };
 class Mesh;
 class MeshBlockPack;
 
+// ---- ranks: global_variable::my_rank / nranks and the MPI calls of the reference --------------
+// (src/globals.hpp, bvals.cpp:134-310 one message per peer rank, mesh.cpp:634-637 dt reduction).
+// Transports: RCCL (one GPU per rank; librccl is resolved at run time so that the library loads
+// on machines without it), or caller-supplied callbacks that move HOST buffers (another MPI, or
+// gloo in the tests where two ranks have to share the only GPU, which RCCL refuses).
+class Comm {
+ public:
+  static Comm &World();
+  enum class Kind { none, rccl, callback };
+  struct Msg { int peer; Real *send; long long nsend; Real *recv; long long nrecv; };
+  int rank = 0, nranks = 1;
+  Kind kind = Kind::none;
+  void InitRCCL(int rank, int nranks, const char id[128]);
+  void InitCallbacks(int rank, int nranks, akmi_comm_exchange_fn ex, akmi_comm_allreduce_min_fn ar,
+                     void *user);
+  void Finalize();
+  // all messages of one variable class (channel 0 = cell-centred, 1 = face-centred).  The data is
+  // ready on `compute` when Post is called; Wait makes `compute` wait for the receives.
+  void Post(const std::vector<Msg> &m, hipStream_t compute, int channel);
+  void Wait(hipStream_t compute, int channel);
+  void AllReduceMin(Real *host_vals, int n, hipStream_t compute);
+  static void GetUniqueId(char id[128]);
+ private:
+  void *nccl_ = nullptr;                 // ncclComm_t
+  hipStream_t comm_stream_ = nullptr;
+  hipEvent_t ready_[2] = {nullptr, nullptr}, done_[2] = {nullptr, nullptr};
+  Real *d_scratch_ = nullptr;            // device doubles for the dt reduction
+  akmi_comm_exchange_fn ex_ = nullptr;
+  akmi_comm_allreduce_min_fn ar_ = nullptr;
+  void *user_ = nullptr;
+  struct Staged { std::vector<Msg> m; std::vector<Real *> hs, hr; std::vector<long long> cs, cr; } staged_[2];
+};
+
+// who sends what to whom on a uniform mesh (bvals.py MeshBoundaryValues.__init__): pure host data
+struct ExchangePlan {
+  std::vector<int> peers;                                     // sorted ranks this rank talks to
+  std::vector<int> tab;                                       // [nmb][27] as include/akmi.h describes
+  std::map<int, std::vector<std::array<int, 2>>> recv_items;  // peer -> (my gid, direction o), sorted
+  std::map<int, std::vector<std::array<int, 4>>> send_items;  // peer -> (recv gid, recv o, my m, d), sorted
+};
+struct ExchangeChannel {                                      // one variable class (bvals.py _plan)
+  int nsend = 0;
+  std::vector<int> send_tab;                                  // [nsend][2] {m, d}
+  std::vector<long long> send_off, seg_off;
+  std::map<int, std::pair<long long, long long>> send_slices, recv_slices;   // peer -> [a, b) doubles
+  long long nsendbuf = 0, nrecvbuf = 0;
+};
+ExchangeChannel PlanChannel(const ExchangePlan &pl, const std::function<long long(int)> &segsize);
+class MeshBlock;
+void BuildMeshBlockPlan(MeshBlock *pmb, int my_rank, int gids);
+
 // ---- static mesh refinement (akmi_host_smr.cpp) ----------------------------------------------
 struct LogicalLocation { int lx1, lx2, lx3, level; };          // mesh.hpp:54-60
 int NeighborIndex(int ix, int iy, int iz, int n1, int n2);      // nghbr_index.hpp:28-54
@@ -174,7 +227,8 @@ class MeshBlock {       // meshblock.cpp:25-131
   std::vector<int> mb_gid;
   std::vector<RegionSize> mb_size;
   std::vector<int> mb_bcs;        // [nmb][6]
-  std::vector<int> nghbr;         // [nmb][27] local index or -1 (single rank)
+  std::vector<int> nghbr_gid, nghbr_rank;   // [nmb][27] same-level neighbour: gid (-1 none) and its rank
+  ExchangePlan plan;              // plan.tab = the device neighbour table (local index | -1 | remote slot)
   DvceArray<Real> d_dx;           // [nmb][3]
   DvceArray<int> d_bcs, d_nghbr;
 };
@@ -197,8 +251,13 @@ class MeshBlockPack {   // meshblock_pack.hpp:44-97
 
 class Mesh {            // mesh.hpp:92-185
  public:
-  explicit Mesh(ParameterInput *pin);
+  // host_only: tables only, no device memory (the exchange-plan unit test runs without a GPU)
+  explicit Mesh(ParameterInput *pin, int my_rank = 0, int nranks = 1, bool host_only = false);
   ~Mesh();
+  void LoadBalance(const std::vector<float> &clist);   // load_balance.cpp:38-88
+  int my_rank, nranks;
+  bool host_only;
+  std::vector<int> rank_eachmb, gids_eachrank, nmb_eachrank;
   void NewTimeStep(const Real tlim);   // mesh.cpp:573-643
   int NumberOfMeshBlockCells() const { return mb_indcs.nx1*mb_indcs.nx2*mb_indcs.nx3; }
   RegionSize mesh_size;
@@ -219,6 +278,27 @@ class Mesh {            // mesh.hpp:92-185
 
 // level-aware boundary values of one pack (src/bvals/bvals.hpp:134-267 on a multilevel mesh): the
 // buffer index tables on the device + the receive buffers; task bodies = akmi_smr_* calls
+// same-level exchange with off-rank neighbours (uniform meshes): buffers + device tables of one pack
+class MeshBoundaryValues {     // bvals.hpp:134-267, the off-rank part of bvals_cc.cpp / bvals_fc.cpp
+ public:
+  MeshBoundaryValues(MeshBlockPack *pp, const akmi_pack *pack, int nvar, bool with_fc);
+  ~MeshBoundaryValues();
+  MeshBlockPack *pmy_pack;
+  const akmi_pack *pack_c;
+  int nvar;
+  bool HasPeers() const;
+  void PackAndSendCC(Real *u, hipStream_t st);
+  void RecvAndUnpackCC(Real *u, hipStream_t st);
+  void PackAndSendFC(DvceFaceFld &b, hipStream_t st);
+  void RecvAndUnpackFC(DvceFaceFld &b, hipStream_t st);
+  ExchangeChannel ch[2];
+ private:
+  void Post(int c, hipStream_t st);
+  DvceArray<int> d_send_tab[2];
+  DvceArray<long long> d_send_off[2], d_seg_off[2];
+  DvceArray<Real> sendbuf[2], recvbuf[2];
+};
+
 class MeshBoundaryValuesSMR {
  public:
   MeshBoundaryValuesSMR(MeshBlockPack *pp, int nvar);
@@ -267,6 +347,8 @@ class FluidBase {
   akmi_pack cpack_c;                    // the coarse buffers as a pack of nx/2 cells (coarse BCs)
   DvceArray<Real> coarse_u0;
   MeshBoundaryValuesSMR *psmr = nullptr;
+  MeshBoundaryValues *pbval = nullptr;  // off-rank neighbours (uniform meshes, nranks > 1)
+  bool peers() const { return pbval && pbval->HasPeers(); }
  protected:
   void FinishNewDt();
   void AddDiffusionFluxes(DvceFaceFld &flx, int face_shaped);   // hydro_tasks.cpp:183-189
@@ -281,6 +363,7 @@ class Hydro : public FluidBase {    // hydro.hpp:73-154
   ~Hydro() override;
   DvceFaceFld uflx;
   void AssembleHydroTasks(std::map<std::string, std::shared_ptr<TaskList>> tl);
+  void StagePhase(Driver *d, int stage, int phases);   // akmi_hydro_stage_phase
   TaskStatus InitRecv(Driver *d, int stage) { return TaskStatus::complete; }
   TaskStatus CopyCons(Driver *d, int stage);
   TaskStatus Fluxes(Driver *d, int stage);
@@ -290,7 +373,7 @@ class Hydro : public FluidBase {    // hydro.hpp:73-154
   TaskStatus HydroSrcTerms(Driver *d, int stage) { return TaskStatus::complete; }
   TaskStatus RestrictU(Driver *d, int stage);
   TaskStatus SendU(Driver *d, int stage);
-  TaskStatus RecvU(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus RecvU(Driver *d, int stage);
   TaskStatus Prolongate(Driver *d, int stage);
   TaskStatus ApplyPhysicalBCs(Driver *d, int stage);
   TaskStatus ConToPrim(Driver *d, int stage);
@@ -310,6 +393,7 @@ class MHD : public FluidBase {      // mhd.hpp:93-199
   DvceEdgeFld efld;
   DvceArray<Real> e3x1, e2x1, e1x2, e3x2, e2x3, e1x3;
   void AssembleMHDTasks(std::map<std::string, std::shared_ptr<TaskList>> tl);
+  void StagePhase(Driver *d, int stage, int phases);   // akmi_mhd_stage_phase
   TaskStatus SaveMHDState(Driver *d, int stage) { return TaskStatus::complete; }
   TaskStatus InitRecv(Driver *d, int stage) { return TaskStatus::complete; }
   TaskStatus CopyCons(Driver *d, int stage);
@@ -320,14 +404,14 @@ class MHD : public FluidBase {      // mhd.hpp:93-199
   TaskStatus MHDSrcTerms(Driver *d, int stage) { return TaskStatus::complete; }
   TaskStatus RestrictU(Driver *d, int stage);
   TaskStatus SendU(Driver *d, int stage);
-  TaskStatus RecvU(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus RecvU(Driver *d, int stage);
   TaskStatus EField(Driver *d, int stage);
   TaskStatus SendE(Driver *d, int stage);      // identity on uniform meshes, EMF correction with levels
   TaskStatus RecvE(Driver *d, int stage) { return TaskStatus::complete; }
   TaskStatus CT(Driver *d, int stage);
   TaskStatus RestrictB(Driver *d, int stage);
   TaskStatus SendB(Driver *d, int stage);
-  TaskStatus RecvB(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus RecvB(Driver *d, int stage);
   TaskStatus Prolongate(Driver *d, int stage);
   TaskStatus ApplyPhysicalBCs(Driver *d, int stage);
   TaskStatus ConToPrim(Driver *d, int stage);

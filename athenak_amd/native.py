@@ -41,12 +41,16 @@ class NativeSimulation:
         self.L = capi.lib()
         stream = capi._stream()
         self.h = C.c_void_p(self.L.akmi_sim_create(pin.Dump().encode(), stream))
-        # a Python Mesh of the same deck gives the problem generators their coordinates
-        self.pmesh = Mesh(pin)
+        # a Python Mesh of the same deck gives the problem generators their coordinates; with a
+        # communicator (akmi_comm_init_*) both sides cut the block list the same way
+        # (tests/test_host_plan.py) and the arrays are those of this rank's pack
+        self.pmesh = Mesh(pin, my_rank=self.L.akmi_comm_rank(), nranks=self.L.akmi_comm_nranks())
+        assert self.pmesh.pmb_pack.gids == self.L.akmi_sim_gids(self.h)
         is_mhd = pin.DoesBlockExist("mhd")
         blk = "mhd" if is_mhd else "hydro"
         n3, n2, n1 = self.pmesh.mb_indcs.ncells
-        nmb = self.pmesh.nmb_total
+        nmb = self.pmesh.pmb_pack.nmb_thispack
+        assert nmb == self.L.akmi_sim_nmb_thisrank(self.h)
         ph = _PhysAlias()
         ph.peos = _Eos(pin, blk)
         ph.nfluid = 5 if ph.peos.eos_data.is_ideal else 4
@@ -111,3 +115,72 @@ class NativeSimulation:
             self.close()
         except Exception:
             pass
+
+
+# ---- ranks ------------------------------------------------------------------------------------------
+_KEEP = []      # callbacks handed to C must outlive the communicator
+
+
+def init_comm_from_torch_distributed():
+    """Give the C++ host a communicator for the ranks of the initialised torch.distributed job.
+    Backend nccl (= RCCL, one GPU per rank): rank 0 creates the RCCL id, a broadcast hands it to
+    every rank, and from there on the C++ host calls RCCL itself (ncclSend/ncclRecv/ncclAllReduce).
+    Any other backend: the C++ host stages its messages through pinned host memory and this
+    module moves them with torch.distributed point-to-point operations (tests: gloo, two ranks
+    sharing the only GPU of the box, which RCCL refuses)."""
+    import numpy as np
+    import torch.distributed as dist
+    L = capi.lib()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if dist.get_backend() == "nccl":
+        idb = C.create_string_buffer(128)
+        if rank == 0:
+            capi.check(L.akmi_comm_unique_id(idb), "comm_unique_id")
+        t = torch.frombuffer(bytearray(idb.raw), dtype=torch.uint8).cuda()
+        dist.broadcast(t, 0)
+        capi.check(L.akmi_comm_init_rccl(rank, world, bytes(t.cpu().numpy().tobytes())), "comm_init_rccl")
+        return "rccl"
+
+    EX = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p),
+                     C.POINTER(C.c_longlong), C.POINTER(C.c_void_p), C.POINTER(C.c_longlong))
+    AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+
+    def view(ptr, n):
+        return torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(n,)))
+
+    def exchange(user, npeer, peers, sp, sc, rp, rc):
+        try:
+            ops = []
+            for q in range(npeer):
+                if rc[q] > 0:
+                    ops.append(dist.P2POp(dist.irecv, view(rp[q], rc[q]), peers[q]))
+            for q in range(npeer):
+                if sc[q] > 0:
+                    ops.append(dist.P2POp(dist.isend, view(sp[q], sc[q]), peers[q]))
+            for w in (dist.batch_isend_irecv(ops) if ops else []):
+                w.wait()
+            return 0
+        except Exception:      # never unwind through C
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def allreduce_min(user, vals, n):
+        try:
+            t = view(vals, n)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    ex, ar = EX(exchange), AR(allreduce_min)
+    _KEEP[:] = [ex, ar]
+    capi.check(L.akmi_comm_init_callbacks(rank, world, ex, ar, None), "comm_init_callbacks")
+    return "callbacks"
+
+
+def finalize_comm():
+    capi.lib().akmi_comm_finalize()
+    _KEEP[:] = []

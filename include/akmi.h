@@ -422,9 +422,11 @@ int akmi_history_sums(const akmi_pack *p, int is_mhd, const double *u0, const do
 
 /* ---- native host driver (C++ mirror of Mesh/MeshBlockPack/TaskList/Driver/Hydro/MHD) ----- *
  * athenak_amd/csrc/akmi_host.{hpp,cpp}: the reference's operator surface for this path in
- * C++, every task body one call of the entries above.  Single rank: all MeshBlocks of the mesh
- * in one pack on the current GPU.  deck_text is an athinput deck (src/parameter_input.cpp
- * grammar).  Initial conditions are written by the caller into the arrays returned by
+ * C++, every task body one call of the entries above.  One process per GPU: with akmi_comm_init_*
+ * called first the Z-ordered MeshBlock list is cut into one pack per rank (Mesh::LoadBalance,
+ * src/mesh/load_balance.cpp:38-88) and the arrays of akmi_sim_array are those of THIS rank's pack
+ * (blocks akmi_sim_gids .. +akmi_sim_nmb_thisrank-1); without it: one rank, all MeshBlocks in one
+ * pack on the current GPU.  deck_text is an athinput deck (src/parameter_input.cpp grammar).  Initial conditions are written by the caller into the arrays returned by
  * akmi_sim_array (device pointers, layouts as above) before akmi_sim_initialize, which performs
  * Driver::Initialize (src/driver/driver.cpp:314-371); tlim_override > 0 replaces <time>/tlim
  * (the linear-wave generator rescales it).  akmi_sim_execute runs Driver::Execute for at most
@@ -440,6 +442,46 @@ int akmi_sim_ncycle(void *sim);
 int akmi_sim_nmb(void *sim);
 void *akmi_sim_array(void *sim, const char *name, long long *count);
 const int *akmi_sim_lloc(void *sim);
+int akmi_sim_gids(void *sim);            /* first global block id of this rank's pack */
+int akmi_sim_nmb_thisrank(void *sim);
+
+/* ---- ranks (global_variable::my_rank/nranks + the MPI calls of the reference's hot path:
+ * one Isend/Irecv per peer rank and variable class, src/bvals/bvals.cpp:134-310,
+ * bvals_cc.cpp:247-303; MPI_Allreduce(MIN) of dt, src/mesh/mesh.cpp:634-637) ------------------- *
+ * akmi_comm_init_rccl: RCCL over xGMI, one GPU per rank (hipSetDevice before the call).  id = the
+ * 128 bytes rank 0 obtained from akmi_comm_unique_id and handed to every rank by whatever launched
+ * the job (MPI_Bcast, a torch.distributed store, a file).  Messages are ncclSend/ncclRecv pairs
+ * grouped per variable class on the communicator's own stream, ordered against the compute stream
+ * with events; dt is reduced with ncclAllReduce(ncclMin).  akmi_comm_init_env does the same for a
+ * job started with RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment (the torchrun
+ * convention): rank 0 serves the id on MASTER_PORT+1 over TCP.
+ * akmi_comm_init_callbacks: any other transport.  exchange() receives HOST buffers (the library
+ * stages device data through pinned memory) and returns when all npeer receives are complete;
+ * allreduce_min() reduces n host doubles in place over all ranks.
+ * All return AKMI_COMPLETE or AKMI_FAIL (akmi_last_error()).  akmi_comm_finalize releases the
+ * communicator; akmi_sim_create reads the rank layout at the time it is called. */
+typedef int (*akmi_comm_exchange_fn)(void *user, int npeer, const int *peers,
+                                     const double *const *sendptr, const long long *sendcount,
+                                     double *const *recvptr, const long long *recvcount);
+typedef int (*akmi_comm_allreduce_min_fn)(void *user, double *vals, int n);
+int akmi_comm_unique_id(char id[128]);
+int akmi_comm_init_rccl(int rank, int nranks, const char id[128]);
+int akmi_comm_init_env(void);
+int akmi_comm_init_callbacks(int rank, int nranks, akmi_comm_exchange_fn exchange,
+                             akmi_comm_allreduce_min_fn allreduce_min, void *user);
+int akmi_comm_finalize(void);
+/* min over all ranks of n <= 8 host doubles, in place (RCCL: ncclAllReduce on `stream`) */
+int akmi_comm_allreduce_min(double *vals, int n, void *stream);
+int akmi_comm_rank(void);
+int akmi_comm_nranks(void);
+/* The exchange plan rank `rank` of `nranks` derives from the deck alone -- host code only, no
+ * device needed (tests/test_host_plan.py compares it with the Python host's plan).  fc = 0: the
+ * cell-centred channel with nvar variables, 1: the face-centred channel.  out (capacity cap,
+ * long long) receives: npeer, peers[npeer], {send_a, send_b, recv_a, recv_b}[npeer], nmb,
+ * tab[nmb*27], nsend, send_tab[nsend*2], send_off[nsend], nseg, seg_off[nseg].  Returns the
+ * number of entries needed (call again with a larger buffer if > cap), or -1 on error. */
+long long akmi_host_exchange_plan(const char *deck_text, int rank, int nranks, int nvar, int fc,
+                                  long long *out, long long cap);
 
 /* ---- measurement utility ------------------------------------------------------------ *
  * dst[i] = src[i] for n doubles with the library's own access pattern (8 B per lane,

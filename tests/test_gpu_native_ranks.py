@@ -1,0 +1,130 @@
+"""gpu: the C++ host (csrc/akmi_host*.cpp) on more than one rank.  Two processes, one MeshBlockPack
+each, share cuda:0 because the test box has one GPU; RCCL refuses two ranks on one device, so the
+communicator is the callback transport (host-staged messages moved by gloo) -- block->rank
+assignment, exchange plan, HIP pack/unpack of off-rank segments, phased fused stage, dt reduction
+are the production code.  Each rank's arrays must be BIT-IDENTICAL to the single-process oracle.
+The RCCL entry points themselves (run-time resolution of librccl, communicator, ncclAllReduce on
+the compute stream) are exercised on a one-rank communicator."""
+import ctypes as C
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from test_distributed_gloo import _free_port  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, case, fused, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import parity_util as pu
+    from oracle import akref
+    from athenak_amd import native
+    from athenak_amd.main import load_deck
+    problem, n, dims, mb, cycles, kw = case
+    deck, ov = pu.deck_overrides(problem, n, dims, mb, **kw)
+    pin = load_deck(deck, ov)
+    blk = "mhd" if pin.DoesBlockExist("mhd") else "hydro"
+    pin.blocks[blk]["fused_stage"] = "true" if fused else "false"
+    osim = akref.Sim(**pu.oracle_kwargs(pin))
+    osim.initialize()
+    assert native.init_comm_from_torch_distributed() == "callbacks"
+    sim = native.NativeSimulation(pin, initialize=False)
+    pk = sim.pmesh.pmb_pack
+    g0, g1 = pk.gids, pk.gide + 1
+    ph = sim.phys
+    ph.u0.copy_(torch.from_numpy(osim.array("u0")[g0:g1].copy()))
+    names = (("x1f", "b0x1f"), ("x2f", "b0x2f"), ("x3f", "b0x3f")) if blk == "mhd" else ()
+    for a, b in names:
+        getattr(ph.b0, a).copy_(torch.from_numpy(osim.array(b)[g0:g1].copy()))
+    sim.Initialize()
+    ok = sim.dt == osim.dt
+    for _ in range(cycles):
+        sim.Execute(max_cycles=1)
+        osim.step()
+    torch.cuda.synchronize()
+    ok = ok and np.array_equal(ph.u0.cpu().numpy(), osim.array("u0")[g0:g1])
+    ok = ok and np.array_equal(ph.w0.cpu().numpy(), osim.array("w0")[g0:g1])
+    for a, b in names:
+        ok = ok and np.array_equal(getattr(ph.b0, a).cpu().numpy(), osim.array(b)[g0:g1])
+    ok = ok and (sim.time == osim.time) and (sim.dt == osim.dt)
+    with open(os.path.join(outdir, "rank%d.txt" % rank), "w") as f:
+        f.write("%d %d %d\n" % (int(ok), sim.ncycle, pk.nmb_thispack))
+    sim.close()
+    native.finalize_comm()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+CASES = [
+    ("orszag_tang", 32, 3, 16, 3, dict(cfl=0.3)),             # 8 blocks, 4 per rank, all 26 directions
+    ("orszag_tang", 32, 3, (16, 32, 32), 2, dict(cfl=0.3)),   # ONE block per rank (bench layout)
+    ("sod", 128, 1, 32, 5, dict(cfl=0.3)),                    # outflow BCs + block boundaries
+    ("linear_wave_mhd", 24, 3, 12, 2, dict(ng=3, recon="ppm4", integrator="rk3")),
+    ("blast", 32, 2, 16, 3, {}),
+    ("linear_wave_hydro", 24, 3, 12, 2, {}),
+]
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "split"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%s-%s^%d-mb%s" % (c[0], c[1], c[2], c[3]))
+def test_two_ranks_cpp_host_matches_single_process_oracle(case, fused):
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), case, fused, d), nprocs=world, join=True)
+        for r in range(world):
+            ok, ncyc, nmb = map(int, open(os.path.join(d, "rank%d.txt" % r)).read().split())
+            assert ok == 1, "rank %d differs from the single-process oracle" % r
+            assert ncyc == case[4] and nmb >= 1
+
+
+def test_three_ranks_uneven_split():
+    world = 3
+    case = ("orszag_tang", 32, 3, 16, 2, dict(cfl=0.3))       # 3 + 3 + 2 blocks
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), case, True, d), nprocs=world, join=True)
+        got = [tuple(map(int, open(os.path.join(d, "rank%d.txt" % r)).read().split())) for r in range(world)]
+        assert all(g[0] == 1 and g[1] == 2 for g in got), got
+        assert sorted(g[2] for g in got) == [2, 3, 3]
+
+
+def _rccl_one_rank(rank, world, port, outdir):
+    """the RCCL path end to end on a one-rank communicator launched the torchrun way"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    from athenak_amd import capi
+    L = capi.lib()
+    capi.check(L.akmi_comm_init_env(), "comm_init_env")          # TCP bootstrap + ncclCommInitRank
+    assert (L.akmi_comm_rank(), L.akmi_comm_nranks()) == (0, 1)
+    v = (C.c_double*3)(3.5, -1.25, 7.0)
+    capi.check(L.akmi_comm_allreduce_min(v, 3, None), "allreduce")   # ncclAllReduce(ncclMin)
+    ok = list(v) == [3.5, -1.25, 7.0]
+    # and through the other bootstrap: explicit id
+    idb = C.create_string_buffer(128)
+    capi.check(L.akmi_comm_unique_id(idb), "unique_id")
+    capi.check(L.akmi_comm_init_rccl(0, 1, idb.raw), "init_rccl")
+    w = (C.c_double*1)(0.125)
+    capi.check(L.akmi_comm_allreduce_min(w, 1, None), "allreduce")
+    ok = ok and w[0] == 0.125
+    L.akmi_comm_finalize()
+    open(os.path.join(outdir, "ok.txt"), "w").write("%d" % int(ok))
+
+
+def test_rccl_entry_points_one_rank():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_rccl_one_rank, args=(1, _free_port(), d), nprocs=1, join=True)
+        assert open(os.path.join(d, "ok.txt")).read() == "1"
