@@ -349,6 +349,9 @@ class FluidBase {
   MeshBoundaryValuesSMR *psmr = nullptr;
   MeshBoundaryValues *pbval = nullptr;  // off-rank neighbours (uniform meshes, nranks > 1)
   bool peers() const { return pbval && pbval->HasPeers(); }
+  const Real *dt_dev = nullptr;         // set by the Driver when cycles are replayed from a hipGraph
+ public:
+  void FinishNewDtPublic() { FinishNewDt(); }
  protected:
   void FinishNewDt();
   void AddDiffusionFluxes(DvceFaceFld &flx, int face_shaped);   // hydro_tasks.cpp:183-189
@@ -433,6 +436,18 @@ class Driver {          // driver.cpp
   int nlim, nexp_stages;
   Real gam0[4], gam1[4], beta[4], delta[4];
   std::int64_t nmb_updated_ = 0;
+  ~Driver();
+  // One cycle (all stages) captured into a hipGraph and replayed: on small packs a cycle is a chain of
+  // dependent launches of a few microseconds each and the host cannot issue them fast enough.  Nothing
+  // in the captured calls changes from cycle to cycle except dt, which the kernels read from d_dt
+  // (akmi_*_stage_fused_dt).  Eligible: fused stage, one rank, uniform mesh.  <time>/cycle_graph = auto
+  // (1-D packs) | true | false; AKMI_CYCLE_GRAPH=0/1 overrides.
+  bool use_graph = false, capturing = false;
+  hipGraphExec_t cycle_exec = nullptr;
+  DvceArray<Real> d_dt;
+  Real *h_dt = nullptr;              // pinned
+ private:
+  void RunStages(Mesh *pm);
 };
 
 }  // namespace host

@@ -252,7 +252,13 @@ struct UpdArgs {
   const double *flx1, *flx2;      // fluxes of the earlier sweeps (face-shaped)
   int copy_u1;
   double *acc;                    // partial divergence (written by the x2 march, read by x3)
+  const double *dtp;              // non-null: beta_dt holds the RK weight beta and dt is read from
+                                  // device memory (a captured cycle replayed with a new time step)
 };
+// beta*dt: the product the host forms in RKUpdate (hydro_update.cpp:35), same operands, same rounding
+__device__ __forceinline__ double beta_dt_of(double beta_dt, const double *dtp) {
+  return dtp ? beta_dt*(*dtp) : beta_dt;
+}
 
 // last-direction sweep with the RK update fused, as a MARCH along the sweep direction:
 // each thread owns one transverse position (lanes run over the contiguous index, so every
@@ -549,7 +555,7 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
           if constexpr (PRE && AKMI_PREFETCH_U1) u1v = u.copy_u1 ? u0v : pu1[n];
           else u1v = u.copy_u1 ? u0v : u.u1[c + n*cs];
           if (u.copy_u1) u.u1[c + n*cs] = u0v;
-          u.u0[c + n*cs] = u.gam0*u0v + u.gam1*u1v - u.beta_dt*divf;
+          u.u0[c + n*cs] = u.gam0*u0v + u.gam1*u1v - beta_dt_of(u.beta_dt, u.dtp)*divf;
         }
       }
     }
@@ -822,7 +828,7 @@ k_sweep_update_1d(Geo g, FaceEos eos, SweepArgs a, UpdArgs u) {
     const double u0v = u.u0[c + n*cs];
     const double u1v = u.copy_u1 ? u0v : u.u1[c + n*cs];
     if (u.copy_u1) u.u1[c + n*cs] = u0v;
-    u.u0[c + n*cs] = u.gam0*u0v + u.gam1*u1v - u.beta_dt*divf;
+    u.u0[c + n*cs] = u.gam0*u0v + u.gam1*u1v - beta_dt_of(u.beta_dt, u.dtp)*divf;
   }
 }
 
@@ -864,7 +870,8 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const double *__res
             double gam1, double beta_dt, double *__restrict__ b0x1f, double *__restrict__ b0x2f,
             double *__restrict__ b0x3f, double *__restrict__ b1x1f, double *__restrict__ b1x2f,
             double *__restrict__ b1x3f, int copy_b1, int kA, int kB, int top, int nchunk,
-            int ckl, int tw, int th) {
+            int ckl, int tw, int th, const double *dtp) {
+  beta_dt = beta_dt_of(beta_dt, dtp);
   extern __shared__ double ct_lds[];     // e1, e2: 2 planes each, e3: 3 planes of th x tw
   const int plane = tw*th;
 #define S1(p, y, x) ct_lds[(p)*plane + (y)*tw + (x)]
@@ -995,16 +1002,16 @@ k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e
             double gam1, double beta_dt, double *__restrict__ b0x1f, double *__restrict__ b0x2f,
             double *__restrict__ b0x3f, double *__restrict__ b1x1f, double *__restrict__ b1x2f,
             double *__restrict__ b1x3f, int copy_b1, int kA, int kB, int top, int nchunk,
-            int ckl, int tw, int th) {
+            int ckl, int tw, int th, const double *dtp) {
   const int m = blockIdx.z/nchunk;
   if (AKMI_POW2DX && is_pow2(g.dx[3*m]) && is_pow2(g.dx[3*m + 1]) && is_pow2(g.dx[3*m + 2]))
     corner_ct_body<AKMI_POW2DX != 0>(g, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, c1, c2, c3, flx1, flx2, flx3, gam0,
                          gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f, copy_b1, kA, kB, top,
-                         nchunk, ckl, tw, th);
+                         nchunk, ckl, tw, th, dtp);
   else
     corner_ct_body<false>(g, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, c1, c2, c3, flx1, flx2, flx3, gam0,
                           gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f, copy_b1, kA, kB, top,
-                          nchunk, ckl, tw, th);
+                          nchunk, ckl, tw, th, dtp);
 }
 
 // CT (mhd_ct.cpp:23-80) with CopyCons for B folded in at stage 1 (b1 <- b0 old)
@@ -1013,7 +1020,8 @@ k_ct_copy(Geo g, double gam0, double gam1, double beta_dt, const double *__restr
           const double *__restrict__ e2, const double *__restrict__ e3, double *__restrict__ b0x1f,
           double *__restrict__ b0x2f, double *__restrict__ b0x3f, double *__restrict__ b1x1f,
           double *__restrict__ b1x2f, double *__restrict__ b1x3f, int copy_b1, int k0, int nk,
-          int kb) {
+          int kb, const double *dtp) {
+  beta_dt = beta_dt_of(beta_dt, dtp);
   // planes k in [k0, k0+nk-1]; x1f/x2f faces are updated for k <= kb (cells of this slab),
   // x3f faces for every k of the launch (the last slab also owns face ke+1)
   const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;   // rows [js,je+1] x N1
@@ -1344,7 +1352,7 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
         const double u0v = pu0[n];
         const double u1v = u.copy_u1 ? u0v : pu1[n];
         if (u.copy_u1) u.u1[c + n*cs] = u0v;
-        u.u0[c + n*cs] = u.gam0*u0v + u.gam1*u1v - u.beta_dt*divf;
+        u.u0[c + n*cs] = u.gam0*u0v + u.gam1*u1v - beta_dt_of(u.beta_dt, u.dtp)*divf;
       }
     }
 #pragma unroll
@@ -1360,6 +1368,16 @@ __global__ void k_init_dt3(double *dt3) {
 }
 
 // ---------------------------------------------------------------------------------------
+// A/B knob: unused dynamic LDS added to a launch caps how many of its workgroups a CU holds (the x1
+// sweep has no LDS of its own, a march workgroup 53 KB), leaving registers and LDS for the workgroups of
+// a memory-bound kernel running beside it on the helper stream of the slab pipeline.
+// AKMI_X1_LDS / AKMI_MARCH_LDS = bytes.
+static size_t extra_lds(int which) {
+  static const size_t v[2] = {getenv("AKMI_X1_LDS") ? (size_t)atol(getenv("AKMI_X1_LDS")) : 0,
+                              getenv("AKMI_MARCH_LDS") ? (size_t)atol(getenv("AKMI_MARCH_LDS")) : 0};
+  return v[which];
+}
+
 template <int DIR, bool MHD, bool ECC>
 static int launch_sweep(const Geo &g, const Scheme &sc, const SweepArgs &a, hipStream_t st) {
   int nk = a.ku - a.kl + 1;
@@ -1369,7 +1387,7 @@ static int launch_sweep(const Geo &g, const Scheme &sc, const SweepArgs &a, hipS
     // faces per wave: 63 when the lanes share their slopes (lane 0 of a wave only provides)
     const long per_wg = (long)(x1_share<DIR, decltype(R)::value>() ? SX - 1 : SX)*SY;
     dim3 grid((unsigned)((np + 1 + per_wg - 1)/per_wg), 1, nk*g.nmb);
-    k_sweep<DIR, decltype(R)::value, MHD, ECC, decltype(S)::value><<<grid, block, 0, st>>>(
+    k_sweep<DIR, decltype(R)::value, MHD, ECC, decltype(S)::value><<<grid, block, extra_lds(0), st>>>(
         g, sc.eos, a, nk);
     return AKMI_COMPLETE;
   });
@@ -1408,7 +1426,7 @@ static int launch_sweep_update(const Geo &g, const Scheme &sc, const SweepArgs &
     constexpr int D = (DIR == 0) ? 1 : DIR;
     rc = dispatch_scheme<MHD>(sc, [&](auto R, auto S) {
       k_sweep_update<D, decltype(R)::value, MHD, MODE, USEACC, decltype(S)::value>
-          <<<grid, block, 0, st>>>(g, sc.eos, a, u, ml);
+          <<<grid, block, extra_lds(1), st>>>(g, sc.eos, a, u, ml);
       return AKMI_COMPLETE;
     });
   }
@@ -1596,7 +1614,7 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
                         int copy_u1, const double *w0, const double *bcc0, double *u0, double *u1,
                         double *b0x1f, double *b0x2f, double *b0x3f, double *b1x1f, double *b1x2f,
                         double *b1x3f, void *ws, const C2PArgs &cp_in, hipStream_t st,
-                        int phases = AKMI_PHASE_ALL) {
+                        int phases = AKMI_PHASE_ALL, const double *dt_dev = nullptr) {
   if (check_scheme(p, recon, "stage") != AKMI_COMPLETE) return AKMI_FAIL;
   if (!p->is_ideal || p->nvar != 5) {
     set_error("fused stage kernels are specialised for the ideal-gas variable set without passive "
@@ -1614,7 +1632,8 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
   C2PArgs cp = cp_in;
   if (!(phases & AKMI_PHASE_C2P)) cp.enable = 0;
   const int ndim = g.three_d ? 3 : (g.multi_d ? 2 : 1);
-  UpdArgs u{gam0, gam1, beta_dt, u0, u1, w.flx1, w.flx2, copy_u1, w.acc};
+  // dt_dev: beta_dt is the RK weight beta, the kernels multiply it with *dt_dev (akmi_*_stage_fused_dt)
+  UpdArgs u{gam0, gam1, beta_dt, u0, u1, w.flx1, w.flx2, copy_u1, w.acc, dt_dev};
   int rc = AKMI_COMPLETE;
   // sweep ranges: hydro_fluxes.cpp:95-104 (no FOFC) / mhd_fluxes.cpp:117-248 (CT-extended)
   SweepArgs a1{w0, bcc0, b0x1f, w.flx1, w.efc[0], w.efc[1], w.ecc[0], w.ecc[1], w.ecc[2],
@@ -1651,7 +1670,7 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
       long npc = (long)(g.je - g.js + 2)*g.N1;
       dim3 grid((unsigned)((npc + SX*SY - 1)/(SX*SY)), 1, nkc*g.nmb), block(SX, SY);
       k_ct_copy<<<grid, block, 0, st>>>(g, gam0, gam1, beta_dt, w.e1, w.e2, w.e3, b0x1f, b0x2f, b0x3f,
-                                        b1x1f, b1x2f, b1x3f, copy_u1, g.ks, nkc, g.ke);
+                                        b1x1f, b1x2f, b1x3f, copy_u1, g.ks, nkc, g.ke, dt_dev);
       AKMI_CHECK_LAUNCH("ct");
     }
     if (cp.enable)
@@ -1695,7 +1714,7 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
     k_corner_ct<<<grid, block, 7*tl.tw*tl.th*sizeof(double), sb>>>(
         g, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5], w.ecc[0], w.ecc[1], w.ecc[2],
         w.flx1, w.flx2, w.flx3, gam0, gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f,
-        copy_u1, kA(s), kB(s), top, nchunk, ckl, tl.tw, tl.th);
+        copy_u1, kA(s), kB(s), top, nchunk, ckl, tl.tw, tl.th, dt_dev);
     AKMI_CHECK_LAUNCH("corner_ct");
     return AKMI_COMPLETE;
   };
@@ -1808,6 +1827,25 @@ int akmi_hydro_stage_fused(const akmi_pack *p, int recon, int rsolver, double ga
   C2PArgs cp{1, do_newdt, counters, dt3};
   return stage_update<false>(p, recon, rsolver, gam0, gam1, beta_dt, copy_u1, w0, nullptr, u0, u1, nullptr,
                              nullptr, nullptr, nullptr, nullptr, nullptr, ws, cp, (hipStream_t)stream);
+}
+
+int akmi_hydro_stage_fused_dt(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1,
+                              double beta, const double *dt_dev, int copy_u1, double *w0, double *u0,
+                              double *u1, int do_newdt, int *counters, double *dt3, void *ws, void *stream) {
+  C2PArgs cp{1, do_newdt, counters, dt3};
+  return stage_update<false>(p, recon, rsolver, gam0, gam1, beta, copy_u1, w0, nullptr, u0, u1, nullptr,
+                             nullptr, nullptr, nullptr, nullptr, nullptr, ws, cp, (hipStream_t)stream,
+                             AKMI_PHASE_ALL, dt_dev);
+}
+
+int akmi_mhd_stage_fused_dt(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1,
+                            double beta, const double *dt_dev, int copy_u1, double *w0, double *bcc0,
+                            double *u0, double *u1, double *b0x1f, double *b0x2f, double *b0x3f,
+                            double *b1x1f, double *b1x2f, double *b1x3f, int do_newdt, int *counters,
+                            double *dt3, void *ws, void *stream) {
+  C2PArgs cp{1, do_newdt, counters, dt3};
+  return stage_update<true>(p, recon, rsolver, gam0, gam1, beta, copy_u1, w0, bcc0, u0, u1, b0x1f, b0x2f,
+                            b0x3f, b1x1f, b1x2f, b1x3f, ws, cp, (hipStream_t)stream, AKMI_PHASE_ALL, dt_dev);
 }
 
 int akmi_mhd_stage_fused(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1,

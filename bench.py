@@ -48,6 +48,10 @@ def parse():
                     help="reconstruction (default: the deck's plm); ppm4 = the numerics of BASELINE config 5")
     ap.add_argument("--ng", type=int, default=None, help="ghost cells (default 2; ppm4 needs >= 3)")
     ap.add_argument("--split", action="store_true", help="task-granular chain instead of fused stage")
+    ap.add_argument("--native", action="store_true",
+                    help="drive the run from the C++ host (akmi_sim_*): Driver/TaskList in C++, halos and the dt "
+                         "reduction through RCCL called directly (ncclSend/ncclRecv/ncclAllReduce); the roofline "
+                         "entry is then the whole stage, not the kernel group")
     return ap.parse_args()
 
 
@@ -169,6 +173,8 @@ def main():
 
     nblk = block_grid(world)
     pin, blk = make_pin(args, nblk)
+    if args.native:
+        return main_native(args, pin, blk, nblk, rank, world)
     from athenak_amd.main import Simulation
     sim = Simulation(pin, my_rank=rank, nranks=world)
     pm, drv = sim.pmesh, sim.pdriver
@@ -289,6 +295,70 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, blk)
         print(json.dumps(out))
     if world > 1:
+        dist.destroy_process_group()
+
+
+def main_native(args, pin, blk, nblk, rank, world):
+    """the same timed region with the C++ host: Mesh/TaskList/Driver in C++, one C-ABI call per task,
+    RCCL called directly for the halos and the dt reduction when world > 1"""
+    import torch
+    from athenak_amd import native
+    transport = "none"
+    if world > 1:
+        import torch.distributed as dist
+        transport = native.init_comm_from_torch_distributed()
+    sim = native.NativeSimulation(pin)
+    pm = sim.pmesh
+    ncell_rank = pm.pmb_pack.nmb_thispack*pm.NumberOfMeshBlockCells()
+    ncell_total = pm.nmb_total*pm.NumberOfMeshBlockCells()
+    nstage = {"rk1": 1, "rk2": 2, "rk3": 3, "rk4": 4}[pin.GetString("time", "integrator")]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sim.Execute(max_cycles=args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    done = sim.Execute(max_cycles=args.steps)
+    barrier()
+    el = time.perf_counter() - t0
+    assert done == args.steps, (done, args.steps)
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    stage_bytes = BYTES_PASS_A[blk] + BYTES_PASS_B[blk]
+    ach = stage_bytes*ncell_rank*nstage*args.steps/el/1e9
+    if rank == 0:
+        rname = (args.recon or "plm").upper()
+        out = {"metric": "Mcell-updates/s (3D MHD %s+HLLD+CT RK2, %d^3 cells per GPU)" % (rname, args.nx)
+               if blk == "mhd" else "Mcell-updates/s (3D hydro %s+HLLC RK2, %d^3 per GPU)" % (rname, args.nx),
+               "value": round(ncell_total*args.steps/el/1e6, 2), "unit": "Mcell-updates/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el/args.steps*1e3, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic (closed-form %s initial condition)" % args.problem,
+               "lib_sha16": lib_sha16(),
+               "config": {"workload": "%s 3D, %s %s, %d^3 cells per GPU, %dx%dx%d MeshBlocks, cfl 0.3, RK2, ng=%d" % (
+                              args.problem, blk, rname, args.nx, *[b*args.nx//(args.mb or args.nx) for b in nblk],
+                              pm.mb_indcs.ng),
+                          "path": "fused stage", "host": "C++ (akmi_sim_*)",
+                          "halo": "none (single periodic block)" if world == 1 else
+                                  {"rccl": "RCCL called from the C++ host: grouped ncclSend/ncclRecv per variable "
+                                           "class on the communicator's stream, ncclAllReduce(min) for dt",
+                                   "callbacks": "host-staged callbacks (functional check only)"}[transport]},
+               "roofline": {"bound": "hbm", "kernel": "whole stage incl. halo exchange (C++ host)",
+                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(ach/HBM_PEAK_GBS, 4), "traffic": None,
+                            "algorithmic_bytes_per_cell_stage": stage_bytes}}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, blk)
+        print(json.dumps(out))
+    sim.close()
+    if world > 1:
+        native.finalize_comm()
         dist.destroy_process_group()
 
 

@@ -387,6 +387,19 @@ int akmi_mhd_stage_fused(const akmi_pack *p, int recon, int rsolver, double gam0
                          double *u1, double *b0x1f, double *b0x2f, double *b0x3f,
                          double *b1x1f, double *b1x2f, double *b1x3f, int do_newdt,
                          int *counters, double *dt3, void *ws, void *stream);
+/* The same with the time step in DEVICE memory: the kernels form beta*(*dt_dev) themselves (the
+ * product RKUpdate forms on the host, hydro_update.cpp:35 -- same operands, same rounding).  No
+ * argument of the call changes from cycle to cycle then, so a whole cycle can be captured into a
+ * hipGraph once and replayed (the C++ host does: akmi_host.cpp Driver::Execute). */
+int akmi_hydro_stage_fused_dt(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1,
+                              double beta, const double *dt_dev, int copy_u1, double *w0, double *u0,
+                              double *u1, int do_newdt, int *counters, double *dt3, void *ws,
+                              void *stream);
+int akmi_mhd_stage_fused_dt(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1,
+                            double beta, const double *dt_dev, int copy_u1, double *w0, double *bcc0,
+                            double *u0, double *u1, double *b0x1f, double *b0x2f, double *b0x3f,
+                            double *b1x1f, double *b1x2f, double *b1x3f, int do_newdt, int *counters,
+                            double *dt3, void *ws, void *stream);
 /* The same stage cut into its parts for callers that post halo messages in between (a rank
  * with off-rank neighbours sends u0 after SWEEPS and b0 after EMF_CT, so the transfers run
  * under CornerE/CT and under the c2p of the active cells, in the order of the reference's
@@ -430,7 +443,12 @@ int akmi_history_sums(const akmi_pack *p, int is_mhd, const double *u0, const do
  * akmi_sim_array (device pointers, layouts as above) before akmi_sim_initialize, which performs
  * Driver::Initialize (src/driver/driver.cpp:314-371); tlim_override > 0 replaces <time>/tlim
  * (the linear-wave generator rescales it).  akmi_sim_execute runs Driver::Execute for at most
- * max_cycles (<0: until tlim/nlim) and returns the number of cycles done. */
+ * max_cycles (<0: until tlim/nlim) and returns the number of cycles done; both return with the
+ * device work finished.  stream = NULL: the simulation runs on a stream of its own (the legacy null
+ * stream cannot be captured into a hipGraph) and waits for the device at entry.  On one rank with
+ * the fused stage a cycle can be captured once and replayed as a hipGraph with dt read from device
+ * memory: <time>/cycle_graph = auto (default: 1-D packs, where it pays) | true | false;
+ * AKMI_CYCLE_GRAPH=0/1 overrides the deck. */
 void *akmi_sim_create(const char *deck_text, void *stream);
 int akmi_sim_initialize(void *sim, double tlim_override);
 int akmi_sim_execute(void *sim, int max_cycles);

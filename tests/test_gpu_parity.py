@@ -416,6 +416,58 @@ def test_native_cpp_driver_parity(case, fused):
     assert res["bitwise_equal"], res["diffs"]
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "split"])
+@pytest.mark.parametrize("problem", ["orszag_tang", "sod"])
+def test_packs_of_thousands_of_small_blocks(problem, fused):
+    """6 912 MeshBlocks of 8^3 in one pack: every launch that puts (planes x blocks) on a grid axis
+    then has more than 65 535 workgroups along it (69 120 for the MHD x1 sweep) -- the size the CUDA
+    convention would refuse; HIP on gfx950 takes 32-bit grid sizes on every axis and the results stay
+    bit-identical to the oracle"""
+    res = pu.compare_run(problem, (192, 192, 96), 3, (8, 8, 8), 2, fused=fused, cfl=0.3)
+    assert res["cycles"] == 2
+    assert res["bitwise_equal"], res["diffs"]
+
+
+GRAPH_CASES = [("linear_wave_hydro", 256, 1, 256, 12, dict(extra=["problem/along_x1=true"])),          # C1 shape
+               ("linear_wave_mhd", 64, 1, 16, 12, dict(ng=3, extra=["problem/along_x1=true"])),
+               ("sod", 64, 1, 32, 8, dict(cfl=0.3)),                                                      # outflow BCs
+               ("orszag_tang", 32, 2, 16, 5, dict(cfl=0.3)),
+               ("orszag_tang", 32, 3, 16, 4, dict(cfl=0.3)),
+               ("sod", 32, 3, 32, 5, dict(cfl=0.3)),
+               ("linear_wave_mhd", 24, 3, 12, 3, dict(integrator="rk3"))]
+
+
+@pytest.mark.parametrize("case", GRAPH_CASES, ids=lambda c: "%s-%d^%d-mb%d" % (c[0], c[1], c[2], c[3]))
+def test_native_cycle_graph_is_bit_identical(case, monkeypatch):
+    """the C++ Driver replaying a captured cycle (hipGraph, dt read from device memory by
+    akmi_*_stage_fused_dt): same bits and the same dt sequence as the oracle, in every dimension
+    (the default turns the graph on for 1-D packs only; here it is forced on)"""
+    problem, n, dims, mb, cycles, kw = case
+    monkeypatch.setenv("AKMI_CYCLE_GRAPH", "1")
+    res = pu.compare_run(problem, n, dims, mb, cycles, fused=True, native=True, **kw)
+    assert res["cycles"] == cycles
+    assert res["time"][0] == res["time"][1], res["time"]
+    assert res["bitwise_equal"], res["diffs"]
+
+
+def test_native_cycle_graph_runs_to_tlim(monkeypatch):
+    """a whole run under the graph: the last time step is clipped to end at tlim exactly"""
+    from athenak_amd.main import load_deck
+    from athenak_amd.native import NativeSimulation
+    deck, ov = pu.deck_overrides("linear_wave_hydro", 64, 1, 64, extra=["problem/along_x1=true"])
+    out = []
+    for g in ("1", "0"):
+        monkeypatch.setenv("AKMI_CYCLE_GRAPH", g)
+        pin = load_deck(deck, [o for o in ov if not o.startswith("time/nlim")] + ["time/nlim=-1"])
+        sim = NativeSimulation(pin)
+        sim.Execute()
+        out.append((sim.ncycle, sim.time, sim.phys.u0.cpu().numpy().copy()))
+        assert sim.time == sim.tlim
+        sim.close()
+    assert out[0][0] == out[1][0] and out[0][0] > 50 and out[0][1] == out[1][1]
+    assert np.array_equal(out[0][2], out[1][2])
+
+
 ODD = [
     # problem, mesh (n1,n2,n3), block (b1,b2,b3), cycles, kwargs: sizes that are not multiples of the
     # wave, tile, march-chunk or k-chunk lengths of the kernels (64, 63x7 tiles, 32, 32)
