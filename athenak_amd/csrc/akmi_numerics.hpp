@@ -502,6 +502,13 @@ struct Cons1D { double d, mx, my, mz, e, by, bz; };
 
 // HLLD (ideal gas), src/mhd/rsolvers/hlld_mhd.hpp:41-347.  Returns the 7-component flux
 // (d,mx,my,mz,E,by,bz); the caller forms ey=-F(by), ez=+F(bz) (:346-347).
+// EO: skip intermediate states no lane of the wave needs (see below).  Thread-per-face kernels gain
+// (x1 sweep 689 -> 637 us at 256^3); the marching kernels sit at their register limit and lose
+// (x2 march 877 -> 1011 us with 28 B of scratch): profiles/r02_hlld_earlyout.txt.  Chosen per call site.
+#ifndef AKMI_HLLD_EARLYOUT
+#define AKMI_HLLD_EARLYOUT 1
+#endif
+template <bool EO = false>
 AKMI_DEV Cons1D hlld(double gamma, double wl_idn, double wl_ivx, double wl_ivy, double wl_ivz,
                      double wl_ien, double wl_iby, double wl_ibz, double wr_idn, double wr_ivx,
                      double wr_ivy, double wr_ivz, double wr_ien, double wr_iby, double wr_ibz,
@@ -573,103 +580,133 @@ AKMI_DEV Cons1D hlld(double gamma, double wl_idn, double wl_ivx, double wl_ivy, 
   double ptstr = ptr + ur.d*sdr*(spd2 - wr_ivx);
   double ptst = 0.5*(ptstr + ptstl);
 
-  ulst.mx = ulst.d*spd2;
-  if (fabs(ul.d*sdl*sdml - bxsq) < (SMALL)*ptst) {
-    ulst.my = ulst.d*wl_ivy;
-    ulst.mz = ulst.d*wl_ivz;
-    ulst.by = ul.by;
-    ulst.bz = ul.bz;
-  } else {
-    double tmp = bxi*(sdl - sdml)/(ul.d*sdl*sdml - bxsq);
-    ulst.my = ulst.d*(wl_ivy - ul.by*tmp);
-    ulst.mz = ulst.d*(wl_ivz - ul.bz*tmp);
-    tmp = (ul.d*sqr(sdl) - bxsq)/(ul.d*sdl*sdml - bxsq);
-    ulst.by = ul.by*tmp;
-    ulst.bz = ul.bz*tmp;
+  // Which intermediate states the selected flux needs (the selection below is the reference's,
+  // hlld_mhd.hpp:313-344): F_L and F_R none; F*_L only U*_L; F*_R only U*_R; the double-star fluxes
+  // both star states and the double-star states.  A state no lane of the wave needs is not computed
+  // (wave-uniform branch, no divergence): in super-Alfvenic smooth flow whole waves take F*_L or F*_R
+  // and skip half of the solver.  A state that IS computed is computed exactly as before.
+#if AKMI_HLLD_EARLYOUT
+  bool need_l = true, need_r = true, need_ds = true;
+  if constexpr (EO) {
+  // the branch of the selection below, by the same chain of comparisons (NaNs fall through alike)
+  const int sel = (spd0 >= 0.0) ? 0 : (spd4 <= 0.0) ? 1 : (spd1 >= 0.0) ? 2 : (spd2 >= 0.0) ? 3 : (spd3 > 0.0) ? 4 : 5;
+  need_l = __any(sel >= 2 && sel <= 4);
+  need_r = __any(sel >= 3);
+  need_ds = __any(sel == 3 || sel == 4);
   }
-  double vbstl = (ulst.mx*bxi + (ulst.my*ulst.by + ulst.mz*ulst.bz))*ulst_d_inv;
-  ulst.e = (sdl*ul.e - ptl*wl_ivx + ptst*spd2 +
-            bxi*(wl_ivx*bxi + (wl_ivy*ul.by + wl_ivz*ul.bz) - vbstl))*sdml_inv;
+#else
+  constexpr bool need_l = true, need_r = true, need_ds = true;
+#endif
+  double vbstl = 0.0, vbstr = 0.0;
+  if (need_l) {
+    ulst.mx = ulst.d*spd2;
+    if (fabs(ul.d*sdl*sdml - bxsq) < (SMALL)*ptst) {
+      ulst.my = ulst.d*wl_ivy;
+      ulst.mz = ulst.d*wl_ivz;
+      ulst.by = ul.by;
+      ulst.bz = ul.bz;
+    } else {
+      double tmp = bxi*(sdl - sdml)/(ul.d*sdl*sdml - bxsq);
+      ulst.my = ulst.d*(wl_ivy - ul.by*tmp);
+      ulst.mz = ulst.d*(wl_ivz - ul.bz*tmp);
+      tmp = (ul.d*sqr(sdl) - bxsq)/(ul.d*sdl*sdml - bxsq);
+      ulst.by = ul.by*tmp;
+      ulst.bz = ul.bz*tmp;
+    }
+    vbstl = (ulst.mx*bxi + (ulst.my*ulst.by + ulst.mz*ulst.bz))*ulst_d_inv;
+    ulst.e = (sdl*ul.e - ptl*wl_ivx + ptst*spd2 +
+              bxi*(wl_ivx*bxi + (wl_ivy*ul.by + wl_ivz*ul.bz) - vbstl))*sdml_inv;
 
-  urst.mx = urst.d*spd2;
-  if (fabs(ur.d*sdr*sdmr - bxsq) < (SMALL)*ptst) {
-    urst.my = urst.d*wr_ivy;
-    urst.mz = urst.d*wr_ivz;
-    urst.by = ur.by;
-    urst.bz = ur.bz;
-  } else {
-    double tmp = bxi*(sdr - sdmr)/(ur.d*sdr*sdmr - bxsq);
-    urst.my = urst.d*(wr_ivy - ur.by*tmp);
-    urst.mz = urst.d*(wr_ivz - ur.bz*tmp);
-    tmp = (ur.d*sqr(sdr) - bxsq)/(ur.d*sdr*sdmr - bxsq);
-    urst.by = ur.by*tmp;
-    urst.bz = ur.bz*tmp;
   }
-  double vbstr = (urst.mx*bxi + (urst.my*urst.by + urst.mz*urst.bz))*urst_d_inv;
-  urst.e = (sdr*ur.e - ptr*wr_ivx + ptst*spd2 +
-            bxi*(wr_ivx*bxi + (wr_ivy*ur.by + wr_ivz*ur.bz) - vbstr))*sdmr_inv;
+  if (need_r) {
+    urst.mx = urst.d*spd2;
+    if (fabs(ur.d*sdr*sdmr - bxsq) < (SMALL)*ptst) {
+      urst.my = urst.d*wr_ivy;
+      urst.mz = urst.d*wr_ivz;
+      urst.by = ur.by;
+      urst.bz = ur.bz;
+    } else {
+      double tmp = bxi*(sdr - sdmr)/(ur.d*sdr*sdmr - bxsq);
+      urst.my = urst.d*(wr_ivy - ur.by*tmp);
+      urst.mz = urst.d*(wr_ivz - ur.bz*tmp);
+      tmp = (ur.d*sqr(sdr) - bxsq)/(ur.d*sdr*sdmr - bxsq);
+      urst.by = ur.by*tmp;
+      urst.bz = ur.bz*tmp;
+    }
+    vbstr = (urst.mx*bxi + (urst.my*urst.by + urst.mz*urst.bz))*urst_d_inv;
+    urst.e = (sdr*ur.e - ptr*wr_ivx + ptst*spd2 +
+              bxi*(wr_ivx*bxi + (wr_ivy*ur.by + wr_ivz*ur.bz) - vbstr))*sdmr_inv;
 
-  if (0.5*bxsq < (SMALL)*ptst) {
-    uldst = ulst;
-    urdst = urst;
-  } else {
-    double invsumd = 1.0/(sqrtdl + sqrtdr);
-    double bxsig = (bxi > 0.0 ? 1.0 : -1.0);
-    uldst.d = ulst.d;
-    urdst.d = urst.d;
-    uldst.mx = ulst.mx;
-    urdst.mx = urst.mx;
-    double tmp = invsumd*(sqrtdl*(ulst.my*ulst_d_inv) + sqrtdr*(urst.my*urst_d_inv) +
-                          bxsig*(urst.by - ulst.by));
-    uldst.my = uldst.d*tmp;
-    urdst.my = urdst.d*tmp;
-    tmp = invsumd*(sqrtdl*(ulst.mz*ulst_d_inv) + sqrtdr*(urst.mz*urst_d_inv) +
-                   bxsig*(urst.bz - ulst.bz));
-    uldst.mz = uldst.d*tmp;
-    urdst.mz = urdst.d*tmp;
-    tmp = invsumd*(sqrtdl*urst.by + sqrtdr*ulst.by +
-                   bxsig*sqrtdl*sqrtdr*((urst.my*urst_d_inv) - (ulst.my*ulst_d_inv)));
-    uldst.by = urdst.by = tmp;
-    tmp = invsumd*(sqrtdl*urst.bz + sqrtdr*ulst.bz +
-                   bxsig*sqrtdl*sqrtdr*((urst.mz*urst_d_inv) - (ulst.mz*ulst_d_inv)));
-    uldst.bz = urdst.bz = tmp;
-    tmp = spd2*bxi + (uldst.my*uldst.by + uldst.mz*uldst.bz)/uldst.d;
-    uldst.e = ulst.e - sqrtdl*bxsig*(vbstl - tmp);
-    urdst.e = urst.e + sqrtdr*bxsig*(vbstr - tmp);
   }
+  if (need_ds) {
+    if (0.5*bxsq < (SMALL)*ptst) {
+      uldst = ulst;
+      urdst = urst;
+    } else {
+      double invsumd = 1.0/(sqrtdl + sqrtdr);
+      double bxsig = (bxi > 0.0 ? 1.0 : -1.0);
+      uldst.d = ulst.d;
+      urdst.d = urst.d;
+      uldst.mx = ulst.mx;
+      urdst.mx = urst.mx;
+      double tmp = invsumd*(sqrtdl*(ulst.my*ulst_d_inv) + sqrtdr*(urst.my*urst_d_inv) +
+                            bxsig*(urst.by - ulst.by));
+      uldst.my = uldst.d*tmp;
+      urdst.my = urdst.d*tmp;
+      tmp = invsumd*(sqrtdl*(ulst.mz*ulst_d_inv) + sqrtdr*(urst.mz*urst_d_inv) +
+                     bxsig*(urst.bz - ulst.bz));
+      uldst.mz = uldst.d*tmp;
+      urdst.mz = urdst.d*tmp;
+      tmp = invsumd*(sqrtdl*urst.by + sqrtdr*ulst.by +
+                     bxsig*sqrtdl*sqrtdr*((urst.my*urst_d_inv) - (ulst.my*ulst_d_inv)));
+      uldst.by = urdst.by = tmp;
+      tmp = invsumd*(sqrtdl*urst.bz + sqrtdr*ulst.bz +
+                     bxsig*sqrtdl*sqrtdr*((urst.mz*urst_d_inv) - (ulst.mz*ulst_d_inv)));
+      uldst.bz = urdst.bz = tmp;
+      tmp = spd2*bxi + (uldst.my*uldst.by + uldst.mz*uldst.bz)/uldst.d;
+      uldst.e = ulst.e - sqrtdl*bxsig*(vbstl - tmp);
+      urdst.e = urst.e + sqrtdr*bxsig*(vbstr - tmp);
+    }
 
-  uldst.d = spd1*(uldst.d - ulst.d);
-  uldst.mx = spd1*(uldst.mx - ulst.mx);
-  uldst.my = spd1*(uldst.my - ulst.my);
-  uldst.mz = spd1*(uldst.mz - ulst.mz);
-  uldst.e = spd1*(uldst.e - ulst.e);
-  uldst.by = spd1*(uldst.by - ulst.by);
-  uldst.bz = spd1*(uldst.bz - ulst.bz);
+    uldst.d = spd1*(uldst.d - ulst.d);
+    uldst.mx = spd1*(uldst.mx - ulst.mx);
+    uldst.my = spd1*(uldst.my - ulst.my);
+    uldst.mz = spd1*(uldst.mz - ulst.mz);
+    uldst.e = spd1*(uldst.e - ulst.e);
+    uldst.by = spd1*(uldst.by - ulst.by);
+    uldst.bz = spd1*(uldst.bz - ulst.bz);
 
-  ulst.d = spd0*(ulst.d - ul.d);
-  ulst.mx = spd0*(ulst.mx - ul.mx);
-  ulst.my = spd0*(ulst.my - ul.my);
-  ulst.mz = spd0*(ulst.mz - ul.mz);
-  ulst.e = spd0*(ulst.e - ul.e);
-  ulst.by = spd0*(ulst.by - ul.by);
-  ulst.bz = spd0*(ulst.bz - ul.bz);
+  }
+  if (need_l) {
+    ulst.d = spd0*(ulst.d - ul.d);
+    ulst.mx = spd0*(ulst.mx - ul.mx);
+    ulst.my = spd0*(ulst.my - ul.my);
+    ulst.mz = spd0*(ulst.mz - ul.mz);
+    ulst.e = spd0*(ulst.e - ul.e);
+    ulst.by = spd0*(ulst.by - ul.by);
+    ulst.bz = spd0*(ulst.bz - ul.bz);
 
-  urdst.d = spd3*(urdst.d - urst.d);
-  urdst.mx = spd3*(urdst.mx - urst.mx);
-  urdst.my = spd3*(urdst.my - urst.my);
-  urdst.mz = spd3*(urdst.mz - urst.mz);
-  urdst.e = spd3*(urdst.e - urst.e);
-  urdst.by = spd3*(urdst.by - urst.by);
-  urdst.bz = spd3*(urdst.bz - urst.bz);
+  }
+  if (need_ds) {
+    urdst.d = spd3*(urdst.d - urst.d);
+    urdst.mx = spd3*(urdst.mx - urst.mx);
+    urdst.my = spd3*(urdst.my - urst.my);
+    urdst.mz = spd3*(urdst.mz - urst.mz);
+    urdst.e = spd3*(urdst.e - urst.e);
+    urdst.by = spd3*(urdst.by - urst.by);
+    urdst.bz = spd3*(urdst.bz - urst.bz);
 
-  urst.d = spd4*(urst.d - ur.d);
-  urst.mx = spd4*(urst.mx - ur.mx);
-  urst.my = spd4*(urst.my - ur.my);
-  urst.mz = spd4*(urst.mz - ur.mz);
-  urst.e = spd4*(urst.e - ur.e);
-  urst.by = spd4*(urst.by - ur.by);
-  urst.bz = spd4*(urst.bz - ur.bz);
+  }
+  if (need_r) {
+    urst.d = spd4*(urst.d - ur.d);
+    urst.mx = spd4*(urst.mx - ur.mx);
+    urst.my = spd4*(urst.my - ur.my);
+    urst.mz = spd4*(urst.mz - ur.mz);
+    urst.e = spd4*(urst.e - ur.e);
+    urst.by = spd4*(urst.by - ur.by);
+    urst.bz = spd4*(urst.bz - ur.bz);
 
+  }
   if (spd0 >= 0.0) {
     flxi = fl;
   } else if (spd4 <= 0.0) {
@@ -826,14 +863,14 @@ AKMI_DEV Cons1D hlle_mhd(double gamma, double dl, double ul, double vl, double z
 }
 
 // MHD_RSolver selection at compile time: RS = AKMI_RS_LLF 0, HLLE 1, HLLD 3
-template <int RS>
+template <int RS, bool EO = false>
 AKMI_DEV Cons1D riemann_mhd(double gamma, double ld, double lx, double ly, double lz, double le,
                             double lby, double lbz, double rd, double rx, double ry, double rz,
                             double re, double rby, double rbz, double bxi) {
   if constexpr (RS == 5) return advect_mhd(ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
   else if constexpr (RS == 0) return llf_mhd(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
   else if constexpr (RS == 1) return hlle_mhd(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
-  else return hlld(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
+  else return hlld<EO>(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
 }
 
 // ---- isothermal EOS (EOS_Data::is_ideal == false): the same source lines as the ideal-gas

@@ -176,8 +176,8 @@ __device__ __forceinline__ void sweep_x1_shared(const Geo &g, const FaceEos &eos
   double fd, fx, fy, fz, fe, fby = 0.0, fbz = 0.0;
   if constexpr (MHD) {
     const double bxi = a.bxf[ix4(a.f3, a.f2, a.f1, m, k, j, i)];
-    Cons1D fl = riemann_mhd<RS>(eos.gamma, L[0], L[1], L[2], L[3], L[4], L[5], L[6], qr[0], qr[1],
-                                qr[2], qr[3], qr[4], qr[5], qr[6], bxi);
+    Cons1D fl = riemann_mhd<RS, true>(eos.gamma, L[0], L[1], L[2], L[3], L[4], L[5], L[6], qr[0], qr[1],
+                                      qr[2], qr[3], qr[4], qr[5], qr[6], bxi);
     fd = fl.d; fx = fl.mx; fy = fl.my; fz = fl.mz; fe = fl.e; fby = fl.by; fbz = fl.bz;
   } else {
     riemann_hyd<RS>(eos.gamma, L[0], L[1], L[2], L[3], L[4], qr[0], qr[1], qr[2], qr[3], qr[4], fd,

@@ -349,7 +349,7 @@ k_mhd_flux(Geo g, FaceEos eos, const double *__restrict__ w0, const double *__re
     fl = riemann_mhd_iso<RS>(eos, ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
   } else {
     face_states<RECON, 2>(q + 4*cs, s, eos, le, re);
-    fl = riemann_mhd<RS>(eos.gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
+    fl = riemann_mhd<RS, true>(eos.gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
   }
   const size_t fs = (size_t)f3*f2*f1;
   double *f = flx + ix5(g.nvar, f3, f2, f1, m, 0, k, j, i);
