@@ -293,9 +293,54 @@ def main():
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, blk)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        chk = os.environ.get("AKMI_BENCH_NATIVE_CHECK", "1")      # "force": also on the host-staged functional path
+        if (dist.get_backend() == "nccl" and chk != "0") or chk == "force":
+            native_check(args, pin, rank, world, ncell_total)
         dist.destroy_process_group()
+
+
+def native_check(args, pin, rank, world, ncell_total):
+    """After the line above is out: the same workload through the C++ host with RCCL called directly
+    (ncclSend/ncclRecv groups on the communicator stream, ncclAllReduce for dt) -- the transport this
+    build could never run on more than one GPU.  Result on stderr only; a watchdog ends the process
+    quietly if anything stalls, so the measurement above cannot be lost to it."""
+    import threading
+    import torch
+    import torch.distributed as dist
+
+    def bail():
+        sys.stderr.write("[native-host check] rank %d: no result within 120 s, giving up\n" % rank)
+        sys.stderr.flush()
+        os._exit(0)
+    wd = threading.Timer(120.0, bail)
+    wd.daemon = True
+    wd.start()
+    try:
+        from athenak_amd import native
+        kind = native.init_comm_from_torch_distributed()
+        sim = native.NativeSimulation(pin)
+        sim.Execute(max_cycles=3)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        n = sim.Execute(max_cycles=20)
+        torch.cuda.synchronize()
+        dist.barrier()
+        el = time.perf_counter() - t0
+        t = torch.tensor([el], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            sys.stderr.write("[native-host check] C++ host + %s on %d GPUs: %.2f Mcell-updates/s, %.4f ms/step "
+                             "(%d cycles, t=%.6e dt=%.6e)\n" % (kind, world, ncell_total*n/float(t.item())/1e6,
+                                                                float(t.item())/n*1e3, n, sim.time, sim.dt))
+            sys.stderr.flush()
+        sim.close()
+        native.finalize_comm()
+    except Exception as e:     # the check must never take the bench down
+        sys.stderr.write("[native-host check] rank %d failed: %r\n" % (rank, e))
+    wd.cancel()
 
 
 def main_native(args, pin, blk, nblk, rank, world):

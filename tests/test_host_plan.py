@@ -22,7 +22,10 @@ CASES = [
     ("orszag_tang", 32, 3, 16, 2),
     ("orszag_tang", 32, 3, 16, 3),                 # uneven: 3 + 3 + 2 blocks
     ("orszag_tang", 32, 3, 16, 8),                 # one block per rank: every neighbour is remote
-    ("orszag_tang", 32, 3, (16, 32, 32), 2),       # the bench layout at 2 GPUs
+    ("orszag_tang", 32, 3, (32, 32, 32), 1),       # one rank: every direction wraps onto the block itself
+    ("orszag_tang", 32, 3, (16, 32, 32), 2),       # the bench layouts (bench.py block_grid) at 2, 4, 8 GPUs:
+    ("orszag_tang", 32, 3, (16, 16, 32), 4),       # one block per rank; in the directions with one block the
+    ("orszag_tang", 32, 3, (16, 16, 16), 8),       # rank is its own +/- neighbour, in the others both are the same peer
     ("orszag_tang", 64, 3, 16, 5),
     ("sod", 128, 1, 32, 2),                        # outflow: faces without a neighbour
     ("sod", 128, 1, 32, 4),
