@@ -255,6 +255,39 @@ class HipSmrKernels:
         self._call("akmi_smr_emf_exchange", C.byref(pack), C.byref(smr), capi._p(nflx), capi._p(efld.x1e),
                    capi._p(efld.x2e), capi._p(efld.x3e), capi._p(buf), capi._stream())
 
+    # the two halves of each exchange (PackAndSend* | RecvAndUnpack*): messages travel in between
+    def pack_cc(self, pack, smr, nvar, u, cu, buf):
+        self._call("akmi_smr_pack_cc", C.byref(pack), C.byref(smr), nvar, capi._p(u), capi._p(cu), capi._p(buf),
+                   capi._stream())
+
+    def unpack_cc(self, pack, smr, nvar, buf, u, cu):
+        self._call("akmi_smr_unpack_cc", C.byref(pack), C.byref(smr), nvar, capi._p(buf), capi._p(u), capi._p(cu),
+                   capi._stream())
+
+    def pack_fc(self, pack, smr, b, cb, buf):
+        self._call("akmi_smr_pack_fc", C.byref(pack), C.byref(smr), capi._p(b.x1f), capi._p(b.x2f), capi._p(b.x3f),
+                   capi._p(cb.x1f), capi._p(cb.x2f), capi._p(cb.x3f), capi._p(buf), capi._stream())
+
+    def unpack_fc(self, pack, smr, buf, b, cb):
+        self._call("akmi_smr_unpack_fc", C.byref(pack), C.byref(smr), capi._p(buf), capi._p(b.x1f), capi._p(b.x2f),
+                   capi._p(b.x3f), capi._p(cb.x1f), capi._p(cb.x2f), capi._p(cb.x3f), capi._stream())
+
+    def pack_flux_cc(self, pack, smr, nvar, face_shaped, flx, buf):
+        self._call("akmi_smr_pack_flux_cc", C.byref(pack), C.byref(smr), nvar, 1 if face_shaped else 0,
+                   capi._p(flx.x1f), capi._p(flx.x2f), capi._p(flx.x3f), capi._p(buf), capi._stream())
+
+    def unpack_flux_cc(self, pack, smr, nvar, face_shaped, buf, flx):
+        self._call("akmi_smr_unpack_flux_cc", C.byref(pack), C.byref(smr), nvar, 1 if face_shaped else 0,
+                   capi._p(buf), capi._p(flx.x1f), capi._p(flx.x2f), capi._p(flx.x3f), capi._stream())
+
+    def pack_emf(self, pack, smr, efld, buf):
+        self._call("akmi_smr_pack_emf", C.byref(pack), C.byref(smr), capi._p(efld.x1e), capi._p(efld.x2e),
+                   capi._p(efld.x3e), capi._p(buf), capi._stream())
+
+    def unpack_emf(self, pack, smr, nflx, buf, efld):
+        self._call("akmi_smr_unpack_emf", C.byref(pack), C.byref(smr), capi._p(nflx), capi._p(buf),
+                   capi._p(efld.x1e), capi._p(efld.x2e), capi._p(efld.x3e), capi._stream())
+
     def restrict_cc(self, pack, nvar, u, cu):
         self._call("akmi_restrict_cc", C.byref(pack), nvar, capi._p(u), capi._p(cu), capi._stream())
 
@@ -279,14 +312,17 @@ class MeshBoundaryValuesSMR:
         nmb = ppack.nmb_thispack
         cc, fc, ndat = index_tables(indcs, ndim, pm.multilevel)
         self.cc_tab_host, self.fc_tab_host, self.ndat_host = cc, fc, ndat
-        # neighbour table: NeighborBlock {gid, lev, rank, dest} -> {local index, level, dest}
+        # neighbour table: NeighborBlock {gid, lev, rank, dest} -> {local index, level, dest}; a
+        # neighbour on another rank is marked by the index nmb (tested for existence only, see soff/roff)
         ng = -np.ones((nmb, 56, 3), dtype=np.int32)
+        remote = []                     # (m, n, NeighborBlock) on other ranks
         for m in range(nmb):
             for n, nb in pmb.nghbr[m].items():
                 if nb.rank != pm.my_rank:
-                    raise RuntimeError("### FATAL ERROR mesh refinement with MeshBlocks on other ranks "
-                                       "is not on this build's path yet")
-                ng[m, n] = (nb.gid - ppack.gids, nb.lev, nb.dest)
+                    ng[m, n] = (nmb, nb.lev, nb.dest)
+                    remote.append((m, n, nb))
+                else:
+                    ng[m, n] = (nb.gid - ppack.gids, nb.lev, nb.dest)
         self.nghbr_host = ng
         self.nflx_host = edge_counts(ng, pmb.mb_lev, self.nnghbr)
         slot_ox = np.zeros((56, 3), dtype=np.int32)
@@ -303,17 +339,123 @@ class MeshBoundaryValuesSMR:
                 layout[cls, n] = (off, stride)
                 off += stride*nmb
             sizes.append(off)
+        self.layout_host = layout
+        self._plan_ranks(remote, layout, sizes)
 
         def dev(a):
             return torch.from_numpy(np.ascontiguousarray(a)).to(device)
         self.t_nghbr, self.t_lev = dev(ng), dev(pmb.mb_lev.astype(np.int32))
         self.t_cc, self.t_fc, self.t_ndat = dev(cc), dev(fc), dev(ndat)
         self.t_ox, self.t_layout, self.t_nflx = dev(slot_ox), dev(layout), dev(self.nflx_host)
-        self.buf = [torch.zeros(max(sz, 1), dtype=torch.float64, device=device) for sz in sizes]
+        self.buf = [torch.zeros(max(sz, 1), dtype=torch.float64, device=device) for sz in self.buf_sizes]
+        self.t_soff = dev(self.soff_host) if self.peers else None
+        self.t_roff = dev(self.roff_host) if self.peers else None
         self.smr_c = capi.Smr(self.nnghbr, 1 if pm.multilevel else 0, self.t_nghbr.data_ptr(),
                               self.t_lev.data_ptr(), self.t_cc.data_ptr(), self.t_fc.data_ptr(),
-                              self.t_ndat.data_ptr(), self.t_ox.data_ptr(), self.t_layout.data_ptr())
+                              self.t_ndat.data_ptr(), self.t_ox.data_ptr(), self.t_layout.data_ptr(),
+                              self.t_soff.data_ptr() if self.peers else None,
+                              self.t_roff.data_ptr() if self.peers else None)
         self.pack_c = None
+        self._works = [[], [], [], []]
+        self._hsend = [None]*4
+        self._hrecv = [None]*4
+
+    # ---- ranks: where the segments of off-rank neighbours live and which slices travel -------------
+    @staticmethod
+    def carries(cls, lev_s, lev_r, dn):
+        """does the sender (level lev_s) fill the segment of the receiver's slot dn (level lev_r)?
+        Variables always; restricted fluxes go from fine to coarse across faces
+        (flux_correct_cc.cpp:60-76); edge EMFs to same-level and coarser neighbours across faces and
+        edges (flux_correct_fc.cpp:60-76)."""
+        if cls in (0, 2):
+            return True
+        if cls == 1:
+            return lev_s > lev_r and (dn < 16 or 24 <= dn < 32)
+        return lev_s >= lev_r and dn < 48
+
+    def _plan_ranks(self, remote, layout, local_sizes):
+        """Per class one buffer: [segments of neighbours in this pack, by (slot, block)] [segments
+        received from other ranks, rank after rank] [segments sent to other ranks, rank after rank].
+        Inside a message the segments are ordered by (receiver gid, receiver slot) -- both sides
+        derive that order from the tree alone (no header exchange).  A segment has the size of the
+        receiver's slot (layout stride), whatever the level relation."""
+        ppack = self.pmy_pack
+        pm, pmb = ppack.pmesh, ppack.pmb
+        nmb, gids = ppack.nmb_thispack, ppack.gids
+        self.peers = sorted({nb.rank for (_, _, nb) in remote})
+        soff = np.zeros((4, nmb, 56), dtype=np.int64)
+        roff = np.zeros((4, nmb, 56), dtype=np.int64)
+        for cls in range(4):
+            for m in range(nmb):
+                for n, nb in pmb.nghbr[m].items():
+                    if nb.rank == pm.my_rank:
+                        soff[cls, m, n] = layout[cls, nb.dest, 0] + (nb.gid - gids)*layout[cls, nb.dest, 1]
+                    roff[cls, m, n] = layout[cls, n, 0] + m*layout[cls, n, 1]
+        self.buf_sizes = list(local_sizes)
+        self.send_slices = [dict() for _ in range(4)]
+        self.recv_slices = [dict() for _ in range(4)]
+        for cls in range(4):
+            off = local_sizes[cls]
+            for r in self.peers:                       # what I receive from rank r
+                start = off
+                items = sorted((gids + m, n) for (m, n, nb) in remote if nb.rank == r and layout[cls, n, 1] > 0 and
+                               self.carries(cls, nb.lev, int(pmb.mb_lev[m]), n))
+                for (g, n) in items:
+                    roff[cls, g - gids, n] = off
+                    off += int(layout[cls, n, 1])
+                self.recv_slices[cls][r] = (start, off)
+            for r in self.peers:                       # what I send to rank r
+                start = off
+                items = sorted((nb.gid, nb.dest, m, n) for (m, n, nb) in remote if nb.rank == r and
+                               layout[cls, nb.dest, 1] > 0 and self.carries(cls, int(pmb.mb_lev[m]), nb.lev, nb.dest))
+                for (g, dn, m, n) in items:
+                    soff[cls, m, n] = off
+                    off += int(layout[cls, dn, 1])
+                self.send_slices[cls][r] = (start, off)
+            self.buf_sizes[cls] = off
+        self.soff_host, self.roff_host = soff, roff
+
+    def _staged(self):
+        import torch.distributed as dist
+        return torch.device(self.device).type == "cuda" and dist.get_backend() != "nccl"
+
+    def _post(self, cls):
+        """the messages of one class (bvals.cpp:134-310: one per peer rank)"""
+        if not self.peers:
+            return
+        import torch.distributed as dist
+        buf = self.buf[cls]
+        sbuf = rbuf = buf
+        if self._staged():
+            if self._hsend[cls] is None:
+                self._hsend[cls] = torch.empty(buf.shape, dtype=torch.float64, pin_memory=True)
+                self._hrecv[cls] = torch.empty(buf.shape, dtype=torch.float64, pin_memory=True)
+            for r in self.peers:
+                a, b = self.send_slices[cls][r]
+                self._hsend[cls][a:b].copy_(buf[a:b], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            sbuf, rbuf = self._hsend[cls], self._hrecv[cls]
+        ops = []
+        for r in self.peers:
+            a, b = self.recv_slices[cls][r]
+            if b > a:
+                ops.append(dist.P2POp(dist.irecv, rbuf[a:b], r))
+        for r in self.peers:
+            a, b = self.send_slices[cls][r]
+            if b > a:
+                ops.append(dist.P2POp(dist.isend, sbuf[a:b], r))
+        self._works[cls] = dist.batch_isend_irecv(ops) if ops else []
+
+    def _wait(self, cls):
+        if not self.peers:
+            return
+        for w in self._works[cls]:
+            w.wait()
+        self._works[cls] = []
+        if self._hrecv[cls] is not None:
+            for r in self.peers:
+                a, b = self.recv_slices[cls][r]
+                self.buf[cls][a:b].copy_(self._hrecv[cls][a:b], non_blocking=True)
 
     def set_pack(self, pack_c):
         self.pack_c = pack_c
@@ -328,18 +470,23 @@ class MeshBoundaryValuesSMR:
         return TaskStatus.complete
 
     def PackAndSendCC(self, u, cu):
-        """same-rank neighbours: pack and unpack run back to back on the stream"""
-        self.k.exchange_cc(self.pack_c, self.smr_c, self.nvar, u, cu, self.buf[0])
+        self.k.pack_cc(self.pack_c, self.smr_c, self.nvar, u, cu, self.buf[0])
+        self._post(0)
         return TaskStatus.complete
 
     def RecvAndUnpackCC(self, u, cu):
+        self._wait(0)
+        self.k.unpack_cc(self.pack_c, self.smr_c, self.nvar, self.buf[0], u, cu)
         return TaskStatus.complete
 
     def PackAndSendFC(self, b, cb):
-        self.k.exchange_fc(self.pack_c, self.smr_c, b, cb, self.buf[2])
+        self.k.pack_fc(self.pack_c, self.smr_c, b, cb, self.buf[2])
+        self._post(2)
         return TaskStatus.complete
 
     def RecvAndUnpackFC(self, b, cb):
+        self._wait(2)
+        self.k.unpack_fc(self.pack_c, self.smr_c, self.buf[2], b, cb)
         return TaskStatus.complete
 
     def FillCoarseInBndryCC(self, u, cu):
@@ -355,9 +502,21 @@ class MeshBoundaryValuesSMR:
         self.k.prolong_fc(self.pack_c, self.smr_c, cb, b)
 
     def PackAndSendFluxCC(self, flx, face_shaped):
-        self.k.flux_cc(self.pack_c, self.smr_c, self.nvar, face_shaped, flx, self.buf[1])
+        self.k.pack_flux_cc(self.pack_c, self.smr_c, self.nvar, face_shaped, flx, self.buf[1])
+        self._post(1)
+        return TaskStatus.complete
+
+    def RecvAndUnpackFluxCC(self, flx, face_shaped):
+        self._wait(1)
+        self.k.unpack_flux_cc(self.pack_c, self.smr_c, self.nvar, face_shaped, self.buf[1], flx)
         return TaskStatus.complete
 
     def PackAndSendFluxFC(self, efld):
-        self.k.emf_exchange(self.pack_c, self.smr_c, self.t_nflx, efld, self.buf[3])
+        self.k.pack_emf(self.pack_c, self.smr_c, efld, self.buf[3])
+        self._post(3)
+        return TaskStatus.complete
+
+    def RecvAndUnpackFluxFC(self, efld):
+        self._wait(3)
+        self.k.unpack_emf(self.pack_c, self.smr_c, self.t_nflx, self.buf[3], efld)
         return TaskStatus.complete

@@ -437,6 +437,7 @@ MeshBoundaryValuesSMR::MeshBoundaryValuesSMR(MeshBlockPack *pp, int nvar_) : pmy
     HIPCHK(hipMemset(buf[cls].p, 0, sizeof(Real)*sizes[cls]));
   }
   smr_c.nnghbr = nnghbr; smr_c.multilevel = 1;
+  smr_c.soff = nullptr; smr_c.roff = nullptr;        // one rank: layout[] addresses the buffers
   smr_c.nghbr = d_nghbr.p; smr_c.mblev = d_lev.p; smr_c.cc_tab = d_cc.p; smr_c.fc_tab = d_fc.p;
   smr_c.ndat = d_ndat.p; smr_c.slot_ox = d_ox.p; smr_c.layout = d_layout.p;
 }

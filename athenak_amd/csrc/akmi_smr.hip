@@ -66,9 +66,12 @@ struct Tab {                      // device view of akmi_smr
   int nnghbr, multilevel;
   const int *ng, *lev, *cc, *fc, *ndat;
   const long long *lay;
+  const long long *soff, *roff;   // [4][nmb][56] or null: where a segment is written / read (ranks)
+  int nmb;
 };
-static Tab make_tab(const akmi_smr *t) {
-  return Tab{t->nnghbr, t->multilevel, t->nghbr, t->mblev, t->cc_tab, t->fc_tab, t->ndat, t->layout};
+static Tab make_tab(const akmi_pack *p, const akmi_smr *t) {
+  return Tab{t->nnghbr, t->multilevel, t->nghbr, t->mblev, t->cc_tab, t->fc_tab, t->ndat, t->layout,
+             t->soff, t->roff, p->nmb};
 }
 #define NGID(t, m, n) (t).ng[((size_t)(m)*56 + (n))*3]
 #define NLEV(t, m, n) (t).ng[((size_t)(m)*56 + (n))*3 + 1]
@@ -77,6 +80,14 @@ static Tab make_tab(const akmi_smr *t) {
 __device__ __forceinline__ size_t buf_at(const Tab &t, int cls, int m, int n) {
   const long long *l = t.lay + ((size_t)cls*56 + n)*2;
   return (size_t)l[0] + (size_t)m*(size_t)l[1];
+}
+// where block m writes the segment of its slot n (into the receive buffer (dm, dn) of a neighbour in
+// this pack, or into the message to another rank) and where it reads the segment it receives
+__device__ __forceinline__ size_t seg_w(const Tab &t, int cls, int m, int n, int dm, int dn) {
+  return t.soff ? (size_t)t.soff[((size_t)cls*t.nmb + m)*56 + n] : buf_at(t, cls, dm, dn);
+}
+__device__ __forceinline__ size_t seg_r(const Tab &t, int cls, int m, int n) {
+  return t.roff ? (size_t)t.roff[((size_t)cls*t.nmb + m)*56 + n] : buf_at(t, cls, m, n);
 }
 // ndat[fc][slot][send|recv][same, coar, fine, flxs, flxc]
 __device__ __forceinline__ int ndat_of(const Tab &t, int fc, int n, int sr, int q) {
@@ -93,7 +104,7 @@ k_smr_pack_cc(SGeo s, Tab t, int nvar, const double *__restrict__ a, const doubl
   const int nl = NLEV(t, m, n), ml = t.lev[m];
   const Bx b = box_of(t.cc, T_SEND, nl < ml ? K_COAR : (nl == ml ? K_SAME : K_FINE), n, 0);
   const int cnt = bcount(b);
-  double *out = buf + buf_at(t, 0, dm, NDST(t, m, n)) + (size_t)cnt*v;
+  double *out = buf + seg_w(t, 0, m, n, dm, NDST(t, m, n)) + (size_t)cnt*v;
   const int coarse = nl < ml;
   const double *src = coarse ? ca : a;
   for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
@@ -112,7 +123,7 @@ k_smr_unpack_cc(SGeo s, Tab t, int nvar, const double *__restrict__ buf, double 
   const int nl = NLEV(t, m, n), ml = t.lev[m];
   const Bx b = box_of(t.cc, T_RECV, nl < ml ? K_COAR : (nl == ml ? K_SAME : K_FINE), n, 0);
   const int cnt = bcount(b);
-  const double *in = buf + buf_at(t, 0, m, n) + (size_t)cnt*v;
+  const double *in = buf + seg_r(t, 0, m, n) + (size_t)cnt*v;
   const int coarse = nl < ml;
   double *dst = coarse ? ca : a;
   for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
@@ -135,7 +146,7 @@ k_smr_pack_fc(SGeo s, Tab t, CF3 b, CF3 cb, double *__restrict__ buf) {
   const int dn = NDST(t, m, n);
   // the receiver unpacks with ITS ndat of slot dn and the matching level relation
   const int rq = q == 1 ? 2 : (q == 2 ? 1 : 0);
-  double *out = buf + buf_at(t, 2, dm, dn) + (size_t)ndat_of(t, 1, dn, T_RECV, rq)*v;
+  double *out = buf + seg_w(t, 2, m, n, dm, dn) + (size_t)ndat_of(t, 1, dn, T_RECV, rq)*v;
   const int coarse = nl < ml;
   const double *src = coarse ? cb.b[v] : b.b[v];
   for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
@@ -160,7 +171,7 @@ k_smr_unpack_fc(SGeo s, Tab t, const double *__restrict__ buf, F3 b, F3 cb) {
     const int q = nl < ml ? 1 : (nl == ml ? 0 : 2);
     const Bx bx = box_of(t.fc, T_RECV, q == 1 ? K_COAR : (q == 0 ? K_SAME : K_FINE), n, v);
     const int cnt = bcount(bx);
-    const double *in = buf + buf_at(t, 2, m, n) + (size_t)ndat_of(t, 1, n, T_RECV, q)*v;
+    const double *in = buf + seg_r(t, 2, m, n) + (size_t)ndat_of(t, 1, n, T_RECV, q)*v;
     const int coarse = nl < ml;
     double *dst = coarse ? cb.b[v] : b.b[v];
     for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
@@ -422,7 +433,7 @@ k_smr_pack_flux_cc(SGeo s, Tab t, int nvar, int fs, Flx3 flx, double *__restrict
   if (n < 8) dir = 0; else if (n < 16) dir = 1; else if (n >= 24 && n < 32) dir = 2; else return;
   const Bx b = box_of(t.cc, T_SEND, K_FLXC, n, 0);
   const int cnt = bcount(b);
-  double *out = buf + buf_at(t, 1, dm, NDST(t, m, n)) + (size_t)cnt*v;
+  double *out = buf + seg_w(t, 1, m, n, dm, NDST(t, m, n)) + (size_t)cnt*v;
   const double *f = flx.f[dir];
   auto X = [&](int kk, int jj, int ii) {
     return f[ix5(nvar, s.N3 + (dir == 2 ? fs : 0), s.N2 + (dir == 1 ? fs : 0), s.N1 + (dir == 0 ? fs : 0), m, v, kk, jj, ii)];
@@ -454,7 +465,7 @@ k_smr_unpack_flux_cc(SGeo s, Tab t, int nvar, int fs, const double *__restrict__
   if (n < 8) dir = 0; else if (n < 16) dir = 1; else if (n >= 24 && n < 32) dir = 2; else return;
   const Bx b = box_of(t.cc, T_RECV, K_FLXC, n, 0);
   const int cnt = bcount(b);
-  const double *in = buf + buf_at(t, 1, m, n) + (size_t)cnt*v;
+  const double *in = buf + seg_r(t, 1, m, n) + (size_t)cnt*v;
   double *f = flx.f[dir];
   for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
     int k, j, i;
@@ -490,7 +501,7 @@ k_smr_pack_flux_fc(SGeo s, Tab t, E3 ef, double *__restrict__ buf) {
   const Bx b = box_of(t.fc, T_SEND, same ? K_FLXS : K_FLXC, n, v);
   const int cnt = bcount(b);
   const int dn = NDST(t, m, n);
-  double *out = buf + buf_at(t, 3, dm, dn) + (size_t)ndat_of(t, 1, dn, T_RECV, same ? 3 : 4)*v;
+  double *out = buf + seg_w(t, 3, m, n, dm, dn) + (size_t)ndat_of(t, 1, dn, T_RECV, same ? 3 : 4)*v;
   const double *e = ef.e[v];
   auto E = [&](int kk, int jj, int ii) { return e[e4(s, v, m, kk, jj, ii)]; };
   for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
@@ -523,7 +534,7 @@ k_smr_sum_flux_fc(SGeo s, Tab t, int same_level, const double *__restrict__ buf,
     if (!((same_level && nl == ml) || (!same_level && nl > ml)) || !slot_has(n, v)) continue;
     const Bx b = box_of(t.fc, T_RECV, same_level ? K_FLXS : K_FLXC, n, v);
     const int cnt = bcount(b);
-    const double *in = buf + buf_at(t, 3, m, n) + (size_t)ndat_of(t, 1, n, T_RECV, same_level ? 3 : 4)*v;
+    const double *in = buf + seg_r(t, 3, m, n) + (size_t)ndat_of(t, 1, n, T_RECV, same_level ? 3 : 4)*v;
     for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
       int k, j, i;
       bdecode(b, q, k, j, i);
@@ -614,27 +625,28 @@ using namespace akmi;
 
 extern "C" {
 
-int akmi_smr_exchange_cc(const akmi_pack *p, const akmi_smr *t, int nvar, double *u, double *cu,
-                         double *buf, void *stream) {
+// phase: 1 = PackAndSend*, 2 = RecvAndUnpack*, 3 = both (neighbours in the same pack only)
+static int smr_exchange_cc(const akmi_pack *p, const akmi_smr *t, int nvar, double *u, double *cu,
+                           double *buf, void *stream, int phase) {
   if (check_smr(p, t, "smr_exchange_cc") != AKMI_COMPLETE) return AKMI_FAIL;
   const SGeo s = make_sgeo(p);
-  const Tab tb = make_tab(t);
+  const Tab tb = make_tab(p, t);
   hipStream_t st = (hipStream_t)stream;
   const unsigned nb = (unsigned)p->nmb*tb.nnghbr*nvar;
-  k_smr_pack_cc<<<nb, 256, 0, st>>>(s, tb, nvar, u, cu, buf);
-  k_smr_unpack_cc<<<nb, 256, 0, st>>>(s, tb, nvar, buf, u, cu);
+  if (phase & 1) k_smr_pack_cc<<<nb, 256, 0, st>>>(s, tb, nvar, u, cu, buf);
+  if (phase & 2) k_smr_unpack_cc<<<nb, 256, 0, st>>>(s, tb, nvar, buf, u, cu);
   AKMI_CHECK_LAUNCH("smr_exchange_cc");
   return AKMI_COMPLETE;
 }
 
-int akmi_smr_exchange_fc(const akmi_pack *p, const akmi_smr *t, double *b1, double *b2, double *b3,
-                         double *cb1, double *cb2, double *cb3, double *buf, void *stream) {
+static int smr_exchange_fc(const akmi_pack *p, const akmi_smr *t, double *b1, double *b2, double *b3,
+                           double *cb1, double *cb2, double *cb3, double *buf, void *stream, int phase) {
   if (check_smr(p, t, "smr_exchange_fc") != AKMI_COMPLETE) return AKMI_FAIL;
   const SGeo s = make_sgeo(p);
-  const Tab tb = make_tab(t);
+  const Tab tb = make_tab(p, t);
   hipStream_t st = (hipStream_t)stream;
-  k_smr_pack_fc<<<(unsigned)p->nmb*tb.nnghbr*3, 256, 0, st>>>(s, tb, CF3{{b1, b2, b3}}, CF3{{cb1, cb2, cb3}}, buf);
-  k_smr_unpack_fc<<<(unsigned)p->nmb*3, 256, 0, st>>>(s, tb, buf, F3{{b1, b2, b3}}, F3{{cb1, cb2, cb3}});
+  if (phase & 1) k_smr_pack_fc<<<(unsigned)p->nmb*tb.nnghbr*3, 256, 0, st>>>(s, tb, CF3{{b1, b2, b3}}, CF3{{cb1, cb2, cb3}}, buf);
+  if (phase & 2) k_smr_unpack_fc<<<(unsigned)p->nmb*3, 256, 0, st>>>(s, tb, buf, F3{{b1, b2, b3}}, F3{{cb1, cb2, cb3}});
   AKMI_CHECK_LAUNCH("smr_exchange_fc");
   return AKMI_COMPLETE;
 }
@@ -643,7 +655,7 @@ int akmi_smr_fill_coarse_cc(const akmi_pack *p, const akmi_smr *t, int nvar, con
                             void *stream) {
   if (check_smr(p, t, "smr_fill_coarse_cc") != AKMI_COMPLETE) return AKMI_FAIL;
   if (p->nx2 <= 1) return AKMI_COMPLETE;
-  const Tab tb = make_tab(t);
+  const Tab tb = make_tab(p, t);
   k_smr_fill_coarse_cc<<<(unsigned)p->nmb*tb.nnghbr*nvar, 256, 0, (hipStream_t)stream>>>(make_sgeo(p), tb, nvar, u, cu);
   AKMI_CHECK_LAUNCH("smr_fill_coarse_cc");
   return AKMI_COMPLETE;
@@ -653,7 +665,7 @@ int akmi_smr_fill_coarse_fc(const akmi_pack *p, const akmi_smr *t, const double 
                             const double *b3, double *cb1, double *cb2, double *cb3, void *stream) {
   if (check_smr(p, t, "smr_fill_coarse_fc") != AKMI_COMPLETE) return AKMI_FAIL;
   if (p->nx2 <= 1) return AKMI_COMPLETE;
-  const Tab tb = make_tab(t);
+  const Tab tb = make_tab(p, t);
   k_smr_fill_coarse_fc<<<(unsigned)p->nmb*tb.nnghbr*3, 256, 0, (hipStream_t)stream>>>(
       make_sgeo(p), tb, CF3{{b1, b2, b3}}, F3{{cb1, cb2, cb3}});
   AKMI_CHECK_LAUNCH("smr_fill_coarse_fc");
@@ -663,7 +675,7 @@ int akmi_smr_fill_coarse_fc(const akmi_pack *p, const akmi_smr *t, const double 
 int akmi_smr_prolong_cc(const akmi_pack *p, const akmi_smr *t, int nvar, const double *cu, double *u,
                         void *stream) {
   if (check_smr(p, t, "smr_prolong_cc") != AKMI_COMPLETE) return AKMI_FAIL;
-  const Tab tb = make_tab(t);
+  const Tab tb = make_tab(p, t);
   k_smr_prolong_cc<<<(unsigned)p->nmb*tb.nnghbr*nvar, 256, 0, (hipStream_t)stream>>>(make_sgeo(p), tb, nvar, cu, u);
   AKMI_CHECK_LAUNCH("smr_prolong_cc");
   return AKMI_COMPLETE;
@@ -674,7 +686,7 @@ int akmi_smr_prolong_fc(const akmi_pack *p, const akmi_smr *t, const double *cb1
   if (check_smr(p, t, "smr_prolong_fc") != AKMI_COMPLETE) return AKMI_FAIL;
   if (!t->slot_ox) { set_error("smr_prolong_fc: slot offsets missing"); return AKMI_FAIL; }
   const SGeo s = make_sgeo(p);
-  const Tab tb = make_tab(t);
+  const Tab tb = make_tab(p, t);
   hipStream_t st = (hipStream_t)stream;
   k_smr_prolong_fc_shared<<<(unsigned)p->nmb*tb.nnghbr*3, 256, 0, st>>>(s, tb, t->slot_ox, CF3{{cb1, cb2, cb3}},
                                                                      F3{{b1, b2, b3}});
@@ -683,37 +695,93 @@ int akmi_smr_prolong_fc(const akmi_pack *p, const akmi_smr *t, const double *cb1
   return AKMI_COMPLETE;
 }
 
-int akmi_smr_flux_cc(const akmi_pack *p, const akmi_smr *t, int nvar, int face_shaped, double *flx1,
-                     double *flx2, double *flx3, double *buf, void *stream) {
+static int smr_flux_cc(const akmi_pack *p, const akmi_smr *t, int nvar, int face_shaped, double *flx1,
+                       double *flx2, double *flx3, double *buf, void *stream, int phase) {
   if (check_smr(p, t, "smr_flux_cc") != AKMI_COMPLETE) return AKMI_FAIL;
   const SGeo s = make_sgeo(p);
-  const Tab tb = make_tab(t);
+  const Tab tb = make_tab(p, t);
   hipStream_t st = (hipStream_t)stream;
   const unsigned nb = (unsigned)p->nmb*tb.nnghbr*nvar;
   const int fs = face_shaped ? 1 : 0;
-  k_smr_pack_flux_cc<<<nb, 256, 0, st>>>(s, tb, nvar, fs, Flx3{{flx1, flx2, flx3}}, buf);
-  k_smr_unpack_flux_cc<<<nb, 256, 0, st>>>(s, tb, nvar, fs, buf, Flx3{{flx1, flx2, flx3}});
+  if (phase & 1) k_smr_pack_flux_cc<<<nb, 256, 0, st>>>(s, tb, nvar, fs, Flx3{{flx1, flx2, flx3}}, buf);
+  if (phase & 2) k_smr_unpack_flux_cc<<<nb, 256, 0, st>>>(s, tb, nvar, fs, buf, Flx3{{flx1, flx2, flx3}});
   AKMI_CHECK_LAUNCH("smr_flux_cc");
   return AKMI_COMPLETE;
 }
 
-int akmi_smr_emf_exchange(const akmi_pack *p, const akmi_smr *t, const int *nflx, double *e1, double *e2,
-                          double *e3, double *buf, void *stream) {
+static int smr_emf_exchange(const akmi_pack *p, const akmi_smr *t, const int *nflx, double *e1, double *e2,
+                            double *e3, double *buf, void *stream, int phase) {
   if (check_smr(p, t, "smr_emf_exchange") != AKMI_COMPLETE) return AKMI_FAIL;
   const SGeo s = make_sgeo(p);
-  const Tab tb = make_tab(t);
+  const Tab tb = make_tab(p, t);
   hipStream_t st = (hipStream_t)stream;
   const unsigned nb = (unsigned)p->nmb*tb.nnghbr*3;
   const E3 ef{{e1, e2, e3}};
-  k_smr_pack_flux_fc<<<nb, 256, 0, st>>>(s, tb, ef, buf);
-  k_smr_sum_flux_fc<<<(unsigned)p->nmb*3, 256, 0, st>>>(s, tb, 1, buf, ef);
-  if (tb.multilevel) {
-    k_smr_zero_flux_fc<<<nb, 256, 0, st>>>(s, tb, ef);
-    k_smr_sum_flux_fc<<<(unsigned)p->nmb*3, 256, 0, st>>>(s, tb, 0, buf, ef);
+  if (phase & 1) k_smr_pack_flux_fc<<<nb, 256, 0, st>>>(s, tb, ef, buf);
+  if (phase & 2) {
+    k_smr_sum_flux_fc<<<(unsigned)p->nmb*3, 256, 0, st>>>(s, tb, 1, buf, ef);
+    if (tb.multilevel) {
+      k_smr_zero_flux_fc<<<nb, 256, 0, st>>>(s, tb, ef);
+      k_smr_sum_flux_fc<<<(unsigned)p->nmb*3, 256, 0, st>>>(s, tb, 0, buf, ef);
+    }
+    k_smr_average_flux_fc<<<nb, 256, 0, st>>>(s, tb, nflx, ef);
   }
-  k_smr_average_flux_fc<<<nb, 256, 0, st>>>(s, tb, nflx, ef);
   AKMI_CHECK_LAUNCH("smr_emf_exchange");
   return AKMI_COMPLETE;
+}
+
+int akmi_smr_exchange_cc(const akmi_pack *p, const akmi_smr *t, int nvar, double *u, double *cu,
+                         double *buf, void *stream) {
+  return smr_exchange_cc(p, t, nvar, u, cu, buf, stream, 3);
+}
+int akmi_smr_pack_cc(const akmi_pack *p, const akmi_smr *t, int nvar, const double *u, const double *cu,
+                     double *buf, void *stream) {
+  return smr_exchange_cc(p, t, nvar, const_cast<double *>(u), const_cast<double *>(cu), buf, stream, 1);
+}
+int akmi_smr_unpack_cc(const akmi_pack *p, const akmi_smr *t, int nvar, const double *buf, double *u,
+                       double *cu, void *stream) {
+  return smr_exchange_cc(p, t, nvar, u, cu, const_cast<double *>(buf), stream, 2);
+}
+int akmi_smr_exchange_fc(const akmi_pack *p, const akmi_smr *t, double *b1, double *b2, double *b3,
+                         double *cb1, double *cb2, double *cb3, double *buf, void *stream) {
+  return smr_exchange_fc(p, t, b1, b2, b3, cb1, cb2, cb3, buf, stream, 3);
+}
+int akmi_smr_pack_fc(const akmi_pack *p, const akmi_smr *t, const double *b1, const double *b2,
+                     const double *b3, const double *cb1, const double *cb2, const double *cb3, double *buf,
+                     void *stream) {
+  return smr_exchange_fc(p, t, const_cast<double *>(b1), const_cast<double *>(b2), const_cast<double *>(b3),
+                         const_cast<double *>(cb1), const_cast<double *>(cb2), const_cast<double *>(cb3), buf,
+                         stream, 1);
+}
+int akmi_smr_unpack_fc(const akmi_pack *p, const akmi_smr *t, const double *buf, double *b1, double *b2,
+                       double *b3, double *cb1, double *cb2, double *cb3, void *stream) {
+  return smr_exchange_fc(p, t, b1, b2, b3, cb1, cb2, cb3, const_cast<double *>(buf), stream, 2);
+}
+int akmi_smr_flux_cc(const akmi_pack *p, const akmi_smr *t, int nvar, int face_shaped, double *flx1,
+                     double *flx2, double *flx3, double *buf, void *stream) {
+  return smr_flux_cc(p, t, nvar, face_shaped, flx1, flx2, flx3, buf, stream, 3);
+}
+int akmi_smr_pack_flux_cc(const akmi_pack *p, const akmi_smr *t, int nvar, int face_shaped, const double *flx1,
+                          const double *flx2, const double *flx3, double *buf, void *stream) {
+  return smr_flux_cc(p, t, nvar, face_shaped, const_cast<double *>(flx1), const_cast<double *>(flx2),
+                     const_cast<double *>(flx3), buf, stream, 1);
+}
+int akmi_smr_unpack_flux_cc(const akmi_pack *p, const akmi_smr *t, int nvar, int face_shaped, const double *buf,
+                            double *flx1, double *flx2, double *flx3, void *stream) {
+  return smr_flux_cc(p, t, nvar, face_shaped, flx1, flx2, flx3, const_cast<double *>(buf), stream, 2);
+}
+int akmi_smr_emf_exchange(const akmi_pack *p, const akmi_smr *t, const int *nflx, double *e1, double *e2,
+                          double *e3, double *buf, void *stream) {
+  return smr_emf_exchange(p, t, nflx, e1, e2, e3, buf, stream, 3);
+}
+int akmi_smr_pack_emf(const akmi_pack *p, const akmi_smr *t, const double *e1, const double *e2,
+                      const double *e3, double *buf, void *stream) {
+  return smr_emf_exchange(p, t, nullptr, const_cast<double *>(e1), const_cast<double *>(e2),
+                          const_cast<double *>(e3), buf, stream, 1);
+}
+int akmi_smr_unpack_emf(const akmi_pack *p, const akmi_smr *t, const int *nflx, const double *buf, double *e1,
+                        double *e2, double *e3, void *stream) {
+  return smr_emf_exchange(p, t, nflx, e1, e2, e3, const_cast<double *>(buf), stream, 2);
 }
 
 }  // extern "C"

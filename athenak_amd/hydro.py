@@ -230,13 +230,19 @@ class Hydro(FluidBase):
     def _noop(self, pdrive, stage):
         return TaskStatus.complete
 
-    InitRecv = RecvFlux = HydroSrcTerms = SendU_OA = RecvU_OA = _noop
+    InitRecv = HydroSrcTerms = SendU_OA = RecvU_OA = _noop
     SendU_Shr = RecvU_Shr = ClearSend = ClearRecv = _noop
 
     def SendFlux(self, pdrive, stage):
         """hydro_tasks.cpp:206-215: restricted fluxes at fine/coarse boundaries (SMR only)"""
         if self.multilevel:
             return self.psmr.PackAndSendFluxCC(self.uflx, False)
+        return TaskStatus.complete
+
+    def RecvFlux(self, pdrive, stage):
+        """hydro_tasks.cpp:222-232"""
+        if self.multilevel:
+            return self.psmr.RecvAndUnpackFluxCC(self.uflx, False)
         return TaskStatus.complete
 
     def RestrictU(self, pdrive, stage):

@@ -285,9 +285,6 @@ class Mesh:
             if ng % 2:
                 raise RuntimeError("### FATAL ERROR Number of ghost cells must be divisible by two for "
                                    "SMR/AMR calculations")
-            if nranks > 1:
-                raise RuntimeError("### FATAL ERROR mesh refinement with more than one rank is not on "
-                                   "this build's path yet")
             self.ptree, ll, self.root_level, self.max_level = BuildTreeFromScratch(pin)
             self.multilevel = True
             self.lloc_eachmb = ll                      # LogicalLocation(lx1, lx2, lx3, level)

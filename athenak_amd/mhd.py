@@ -86,9 +86,9 @@ class MHD(FluidBase):
     def _noop(self, pdrive, stage):
         return TaskStatus.complete
 
-    SaveMHDState = InitRecv = RecvFlux = MHDSrcTerms = SendU_OA = RecvU_OA = _noop
+    SaveMHDState = InitRecv = MHDSrcTerms = SendU_OA = RecvU_OA = _noop
     SendU_Shr = RecvU_Shr = SendB_OA = RecvB_OA = _noop
-    SendB_Shr = RecvB_Shr = ClearSend = ClearRecv = RecvE = _noop
+    SendB_Shr = RecvB_Shr = ClearSend = ClearRecv = _noop
 
     def SendE(self, pdrive, stage):
         """mhd_tasks.cpp:402-417 (PackAndSendFluxFC + RecvAndUnpackFluxFC).  On a uniform mesh every
@@ -104,6 +104,19 @@ class MHD(FluidBase):
         """mhd_tasks.cpp:225-233"""
         if self.multilevel:
             return self.psmr.PackAndSendFluxCC(self.uflx, True)
+        return TaskStatus.complete
+
+    def RecvFlux(self, pdrive, stage):
+        """mhd_tasks.cpp:240-250"""
+        if self.multilevel:
+            return self.psmr.RecvAndUnpackFluxCC(self.uflx, True)
+        return TaskStatus.complete
+
+    def RecvE(self, pdrive, stage):
+        """mhd_tasks.cpp:410-417: sum over same-level owners, zero at finer neighbours, sum their
+        restricted values, average"""
+        if self.multilevel:
+            return self.psmr.RecvAndUnpackFluxFC(self.efld)
         return TaskStatus.complete
 
     def RestrictU(self, pdrive, stage):

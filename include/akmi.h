@@ -316,6 +316,12 @@ typedef struct akmi_smr {
   int multilevel;
   const int *nghbr, *mblev, *cc_tab, *fc_tab, *ndat, *slot_ox;
   const long long *layout;
+  /* ranks: [4][nmb][56] offsets (doubles) inside the buffer of each class at which block m WRITES
+   * the segment of its slot n (soff: the receive segment of a neighbour in this pack, or a place in
+   * the message to another rank) and READS the segment it receives (roff).  NULL: everything is
+   * in this pack and layout[] alone addresses the buffers.  With them an off-rank neighbour is
+   * marked in nghbr by any index >= 0 (it is only tested for existence then). */
+  const long long *soff, *roff;
 } akmi_smr;
 /* RestrictU is akmi_restrict_cc / akmi_restrict_fc above.  SendU+RecvU (PackAndSendCC +
  * RecvAndUnpackCC, src/bvals/bvals_cc.cpp:42-447): u ghost cells from same-level and finer neighbours,
@@ -348,6 +354,27 @@ int akmi_smr_flux_cc(const akmi_pack *p, const akmi_smr *t, int nvar, int face_s
  * SumBoundaryFluxes / ZeroFluxesAtBoundaryWithFiner, a function of the neighbour table).  buf: layout[3] */
 int akmi_smr_emf_exchange(const akmi_pack *p, const akmi_smr *t, const int *nflx, double *e1, double *e2,
                           double *e3, double *buf, void *stream);
+/* The four exchanges cut at the point where the reference posts its MPI messages: *_pack_* = the
+ * PackAndSend* half (fills the segments soff names), *_unpack_* = the RecvAndUnpack* half (reads the
+ * segments roff names; for the EMFs: sum, zero, sum, average).  A caller with off-rank neighbours
+ * moves the per-rank slices of buf between the two calls. */
+int akmi_smr_pack_cc(const akmi_pack *p, const akmi_smr *t, int nvar, const double *u, const double *cu,
+                     double *buf, void *stream);
+int akmi_smr_unpack_cc(const akmi_pack *p, const akmi_smr *t, int nvar, const double *buf, double *u,
+                       double *cu, void *stream);
+int akmi_smr_pack_fc(const akmi_pack *p, const akmi_smr *t, const double *b1, const double *b2,
+                     const double *b3, const double *cb1, const double *cb2, const double *cb3, double *buf,
+                     void *stream);
+int akmi_smr_unpack_fc(const akmi_pack *p, const akmi_smr *t, const double *buf, double *b1, double *b2,
+                       double *b3, double *cb1, double *cb2, double *cb3, void *stream);
+int akmi_smr_pack_flux_cc(const akmi_pack *p, const akmi_smr *t, int nvar, int face_shaped, const double *flx1,
+                          const double *flx2, const double *flx3, double *buf, void *stream);
+int akmi_smr_unpack_flux_cc(const akmi_pack *p, const akmi_smr *t, int nvar, int face_shaped, const double *buf,
+                            double *flx1, double *flx2, double *flx3, void *stream);
+int akmi_smr_pack_emf(const akmi_pack *p, const akmi_smr *t, const double *e1, const double *e2,
+                      const double *e3, double *buf, void *stream);
+int akmi_smr_unpack_emf(const akmi_pack *p, const akmi_smr *t, const int *nflx, const double *buf, double *e1,
+                        double *e2, double *e3, void *stream);
 
 /* ---- Fused fast path ("one kernel sequence per MeshBlockPack stage") ----------------- *
  * Must produce results identical to the task chain above.  ws = device workspace of

@@ -35,6 +35,10 @@ struct akref_smr {
   int *gid, *lev, *dest;     /* [nmb][56] NeighborBlock, mesh.hpp:47-52 (rank: all on this process) */
   int *mblev;
   bv_t cc, fc;
+  /* twins of the ABI's pack / unpack halves: segments live in the CALLER's buffer, at soff/roff
+   * ([4][nmb][56]) or, without them, at layout[cls][slot] {offset, per-block stride} */
+  double *xbuf;
+  const long long *xlay, *soff, *roff;
 };
 
 /* NeighborIndex, src/mesh/nghbr_index.hpp:28-54 */
@@ -47,6 +51,19 @@ static int nidx(int ix, int iy, int iz, int n1, int n2) {
   }
   if (ix*iy == 0) return 24 + abs(ix)*(ix + 9) + abs(iy)*(iy + 17) + 2*(iz + 1) + n1 + 2*n2;
   return 48 + (ix + 1)/2 + (iy + 1) + 2*(iz + 1);
+}
+
+/* where block m writes the segment of slot n (receiver (dm, dn)) / reads the one it receives; cls 0 cc
+ * vars, 1 cc flux, 2 fc vars, 3 fc flux */
+static double *wseg(akref_smr *s, int cls, int m, int n, int dm, int dn, double *own, size_t stride) {
+  if (!s->xbuf) return own + (size_t)dm*stride;
+  if (s->soff) return s->xbuf + s->soff[((size_t)cls*s->nmb + m)*56 + n];
+  return s->xbuf + s->xlay[(cls*56 + dn)*2] + (size_t)dm*s->xlay[(cls*56 + dn)*2 + 1];
+}
+static const double *rseg(const akref_smr *s, int cls, int m, int n, const double *own, size_t stride) {
+  if (!s->xbuf) return own + (size_t)m*stride;
+  if (s->roff) return s->xbuf + s->roff[((size_t)cls*s->nmb + m)*56 + n];
+  return s->xbuf + s->xlay[(cls*56 + n)*2] + (size_t)m*s->xlay[(cls*56 + n)*2 + 1];
 }
 
 static int bsz(const bi_t *b) {
@@ -398,7 +415,7 @@ int akref_smr_send_cc(akref_smr *s, const double *a, const double *ca) {
     for (int v = 0; v < nvar; ++v) for (int k = kl; k <= ku; ++k) for (int j = jl; j <= ju; ++j)
       for (int i = il; i <= iu; ++i) {
         const size_t bi = (size_t)(i-il + ni*(j-jl + nj*(k-kl + nk*v)));
-        rb->vars[dm*rb->vstride + bi] = (nl >= ml) ? A5(a,nvar,m,v,k,j,i) : C5(ca,nvar,m,v,k,j,i);
+        wseg(s, 0, m, n, dm, dn, rb->vars, rb->vstride)[bi] = (nl >= ml) ? A5(a,nvar,m,v,k,j,i) : C5(ca,nvar,m,v,k,j,i);
       }
   }
   return 0;
@@ -418,7 +435,7 @@ int akref_smr_recv_cc(akref_smr *s, double *a, double *ca) {
     for (int v = 0; v < nvar; ++v) for (int k = kl; k <= ku; ++k) for (int j = jl; j <= ju; ++j)
       for (int i = il; i <= iu; ++i) {
         const size_t bi = (size_t)(i-il + ni*(j-jl + nj*(k-kl + nk*v)));
-        const double val = rb->vars[m*rb->vstride + bi];
+        const double val = rseg(s, 0, m, n, rb->vars, rb->vstride)[bi];
         if (nl >= ml) A5(a,nvar,m,v,k,j,i) = val; else C5(ca,nvar,m,v,k,j,i) = val;
       }
   }
@@ -442,7 +459,7 @@ int akref_smr_send_fc(akref_smr *s, const double *b1, const double *b2, const do
     bb_t *rb = &s->fc.recvbuf[dn];
     const double *src = (nl >= ml) ? (v == 0 ? b1 : (v == 1 ? b2 : b3)) : (v == 0 ? cb1 : (v == 1 ? cb2 : cb3));
     for (int k = kl; k <= ku; ++k) for (int j = jl; j <= ju; ++j) for (int i = il; i <= iu; ++i)
-      rb->vars[dm*rb->vstride + (size_t)ndat*v + (i-il + ni*(j-jl + nj*(k-kl)))] =
+      wseg(s, 2, m, n, dm, dn, rb->vars, rb->vstride)[(size_t)ndat*v + (i-il + ni*(j-jl + nj*(k-kl)))] =
           fget(s, src, v, nl < ml, m, k, j, i);
   }
   return 0;
@@ -471,7 +488,7 @@ int akref_smr_recv_fc(akref_smr *s, double *b1, double *b2, double *b3, double *
     const int il = x->bis, iu = x->bie, jl = x->bjs, ju = x->bje, kl = x->bks, ku = x->bke;
     const int ni = iu - il + 1, nj = ju - jl + 1;
     for (int k = kl; k <= ku; ++k) for (int j = jl; j <= ju; ++j) for (int i = il; i <= iu; ++i) {
-      const double val = rb->vars[m*rb->vstride + (size_t)ndat*v + (i-il + ni*(j-jl + nj*(k-kl)))];
+      const double val = rseg(s, 2, m, n, rb->vars, rb->vstride)[(size_t)ndat*v + (i-il + ni*(j-jl + nj*(k-kl)))];
       if (nl >= ml) {
         if (is_active_fc_face(s, v, k, j, i)) continue;
         fset(s, fptr(b1, b2, b3, v), v, 0, m, k, j, i, val);
@@ -702,12 +719,13 @@ int akref_smr_prolong_fc(akref_smr *s, double *b1, double *b2, double *b3, const
 /* ---- PackAndSendFluxCC + RecvAndUnpackFluxCC, src/bvals/flux_correct_cc.cpp:29-197,199-304.
  * Flux arrays flx1 (nmb,nvar,N3,N2,N1+fs), flx2, flx3: fs = 1 face-shaped (MHD, mhd.cpp:153-160),
  * fs = 0 cell-shaped (hydro, hydro.cpp:289-298). ------------------------------------------------ */
-int akref_smr_flux_cc(akref_smr *s, double *flx1, double *flx2, double *flx3, int fs) {
+static int flux_cc_phase(akref_smr *s, double *flx1, double *flx2, double *flx3, int fs, int phase) {
   const int nvar = s->cc.nvar;
   const int N1 = s->N1, N2 = s->N2, N3 = s->N3;
 #define X1(m,v,k,j,i) flx1[(((((size_t)(m)*nvar + (v))*N3 + (k))*N2 + (j))*(N1+fs) + (i))]
 #define X2(m,v,k,j,i) flx2[(((((size_t)(m)*nvar + (v))*N3 + (k))*(N2+fs) + (j))*N1 + (i))]
 #define X3(m,v,k,j,i) flx3[(((((size_t)(m)*nvar + (v))*(N3+fs) + (k))*N2 + (j))*N1 + (i))]
+  if (phase & 1)
   for (int m = 0; m < s->nmb; ++m) for (int n = 0; n < s->nnghbr; ++n) for (int v = 0; v < nvar; ++v) {
     if (!(s->gid[NG(m,n)] >= 0 && s->lev[NG(m,n)] < s->mblev[m])) continue;
     const bi_t *x = &s->cc.sendbuf[n].iflux_coar[0];
@@ -715,7 +733,7 @@ int akref_smr_flux_cc(akref_smr *s, double *flx1, double *flx2, double *flx3, in
     const int ni = iu - il + 1, nj = ju - jl + 1, nk = ku - kl + 1;
     const int dm = s->gid[NG(m,n)], dn = s->dest[NG(m,n)];
     bb_t *rb = &s->cc.recvbuf[dn];
-    double *out = rb->flux + dm*rb->fstride;
+    double *out = wseg(s, 1, m, n, dm, dn, rb->flux, rb->fstride);
     if (n < 8) {
       const int fi = 2*il - s->cis;
       for (int k = kl; k <= ku; ++k) for (int j = jl; j <= ju; ++j) {
@@ -743,13 +761,14 @@ int akref_smr_flux_cc(akref_smr *s, double *flx1, double *flx2, double *flx3, in
       }
     }
   }
+  if (phase & 2)
   for (int m = 0; m < s->nmb; ++m) for (int n = 0; n < s->nnghbr; ++n) for (int v = 0; v < nvar; ++v) {
     if (!(s->gid[NG(m,n)] >= 0 && s->lev[NG(m,n)] > s->mblev[m])) continue;
     const bb_t *rb = &s->cc.recvbuf[n];
     const bi_t *x = &rb->iflux_coar[0];
     const int il = x->bis, iu = x->bie, jl = x->bjs, ju = x->bje, kl = x->bks, ku = x->bke;
     const int ni = iu - il + 1, nj = ju - jl + 1, nk = ku - kl + 1;
-    const double *in = rb->flux + m*rb->fstride;
+    const double *in = rseg(s, 1, m, n, rb->flux, rb->fstride);
     if (n < 8) {
       for (int k = kl; k <= ku; ++k) for (int j = jl; j <= ju; ++j) X1(m,v,k,j,il) = in[(j-jl + nj*(k-kl + nk*v))];
     } else if (n < 16) {
@@ -762,6 +781,9 @@ int akref_smr_flux_cc(akref_smr *s, double *flx1, double *flx2, double *flx3, in
 #undef X2
 #undef X3
   return 0;
+}
+int akref_smr_flux_cc(akref_smr *s, double *flx1, double *flx2, double *flx3, int fs) {
+  return flux_cc_phase(s, flx1, flx2, flx3, fs, 3);
 }
 
 /* ---- PackAndSendFluxFC, src/bvals/flux_correct_fc.cpp:29-372 ---------------------------------- */
@@ -776,7 +798,7 @@ static void send_flux_fc(akref_smr *s, const double *e1, const double *e2, const
     const int ni = iu - il + 1, nj = ju - jl + 1;
     const int dm = s->gid[NG(m,n)], dn = s->dest[NG(m,n)];
     bb_t *rb = &s->fc.recvbuf[dn];
-    double *out = rb->flux + dm*rb->fstride + (size_t)ndat*v;
+    double *out = wseg(s, 3, m, n, dm, dn, rb->flux, rb->fstride) + (size_t)ndat*v;
     const int cis = s->cis, cjs = s->cjs, cks = s->cks;
     if (n < 8) {                                              /* x1 faces :78-123 */
       const int fi = 2*il - cis;
@@ -857,7 +879,7 @@ static void sum_boundary_fluxes(akref_smr *s, double *e1, double *e2, double *e3
     const int ndat = same_level ? rb->iflxs_ndat : rb->iflxc_ndat;
     const int il = x->bis, iu = x->bie, jl = x->bjs, ju = x->bje, kl = x->bks, ku = x->bke;
     const int ni = iu - il + 1, nj = ju - jl + 1;
-    const double *in = rb->flux + m*rb->fstride + (size_t)ndat*v;
+    const double *in = rseg(s, 3, m, n, rb->flux, rb->fstride) + (size_t)ndat*v;
     int *nf = nflx + 48*m;
     if (n < 8) {
       if (v == 0) {
@@ -1016,8 +1038,9 @@ static void average_boundary_fluxes(akref_smr *s, double *e1, double *e2, double
 }
 
 /* SendE + RecvE: PackAndSendFluxFC, then RecvAndUnpackFluxFC (flux_correct_fc.cpp:374-434) */
-int akref_smr_flux_fc(akref_smr *s, double *e1, double *e2, double *e3) {
-  send_flux_fc(s, e1, e2, e3);
+static int flux_fc_phase(akref_smr *s, double *e1, double *e2, double *e3, int phase) {
+  if (phase & 1) send_flux_fc(s, e1, e2, e3);
+  if (!(phase & 2)) return 0;
   int *nflx = (int *)malloc(sizeof(int)*48*s->nmb);
   for (int q = 0; q < 48*s->nmb; ++q) nflx[q] = 1;
   sum_boundary_fluxes(s, e1, e2, e3, 1, nflx);
@@ -1029,6 +1052,7 @@ int akref_smr_flux_fc(akref_smr *s, double *e1, double *e2, double *e3) {
   free(nflx);
   return 0;
 }
+int akref_smr_flux_fc(akref_smr *s, double *e1, double *e2, double *e3) { return flux_fc_phase(s, e1, e2, e3, 3); }
 
 /* ---- twins of the product's akmi_smr_* entry points (same arguments; the tables of the descriptor
  * other than the neighbour table and the levels are NOT read: the oracle builds its own index
@@ -1092,6 +1116,68 @@ int akref_smr_emf_exchange(const akmi_pack *p, const akmi_smr *t, const int *nfl
   (void)buf; (void)nflx;
   akref_smr *s = from_desc(p, t, 1);
   akref_smr_flux_fc(s, e1, e2, e3);
+  akref_smr_destroy(s);
+  return 0;
+}
+
+/* the pack / unpack halves (include/akmi.h): the segments live in the caller's buffer */
+static akref_smr *from_desc_x(const akmi_pack *p, const akmi_smr *t, int nvar, const double *buf) {
+  akref_smr *s = from_desc(p, t, nvar);
+  s->xbuf = (double *)buf; s->xlay = t->layout; s->soff = t->soff; s->roff = t->roff;
+  return s;
+}
+int akref_smr_pack_cc(const akmi_pack *p, const akmi_smr *t, int nvar, const double *u, const double *cu, double *buf) {
+  akref_smr *s = from_desc_x(p, t, nvar, buf);
+  akref_smr_send_cc(s, u, cu);
+  akref_smr_destroy(s);
+  return 0;
+}
+int akref_smr_unpack_cc(const akmi_pack *p, const akmi_smr *t, int nvar, const double *buf, double *u, double *cu) {
+  akref_smr *s = from_desc_x(p, t, nvar, buf);
+  akref_smr_recv_cc(s, u, cu);
+  akref_smr_destroy(s);
+  return 0;
+}
+int akref_smr_pack_fc(const akmi_pack *p, const akmi_smr *t, const double *b1, const double *b2, const double *b3,
+                      const double *cb1, const double *cb2, const double *cb3, double *buf) {
+  akref_smr *s = from_desc_x(p, t, 1, buf);
+  akref_smr_send_fc(s, b1, b2, b3, cb1, cb2, cb3);
+  akref_smr_destroy(s);
+  return 0;
+}
+int akref_smr_unpack_fc(const akmi_pack *p, const akmi_smr *t, const double *buf, double *b1, double *b2, double *b3,
+                        double *cb1, double *cb2, double *cb3) {
+  akref_smr *s = from_desc_x(p, t, 1, buf);
+  akref_smr_recv_fc(s, b1, b2, b3, cb1, cb2, cb3);
+  akref_smr_destroy(s);
+  return 0;
+}
+int akref_smr_pack_flux_cc(const akmi_pack *p, const akmi_smr *t, int nvar, int face_shaped, const double *flx1,
+                           const double *flx2, const double *flx3, double *buf) {
+  akref_smr *s = from_desc_x(p, t, nvar, buf);
+  flux_cc_phase(s, (double *)flx1, (double *)flx2, (double *)flx3, face_shaped, 1);
+  akref_smr_destroy(s);
+  return 0;
+}
+int akref_smr_unpack_flux_cc(const akmi_pack *p, const akmi_smr *t, int nvar, int face_shaped, const double *buf,
+                             double *flx1, double *flx2, double *flx3) {
+  akref_smr *s = from_desc_x(p, t, nvar, buf);
+  flux_cc_phase(s, flx1, flx2, flx3, face_shaped, 2);
+  akref_smr_destroy(s);
+  return 0;
+}
+int akref_smr_pack_emf(const akmi_pack *p, const akmi_smr *t, const double *e1, const double *e2, const double *e3,
+                       double *buf) {
+  akref_smr *s = from_desc_x(p, t, 1, buf);
+  flux_fc_phase(s, (double *)e1, (double *)e2, (double *)e3, 1);
+  akref_smr_destroy(s);
+  return 0;
+}
+int akref_smr_unpack_emf(const akmi_pack *p, const akmi_smr *t, const int *nflx, const double *buf, double *e1,
+                         double *e2, double *e3) {
+  (void)nflx;
+  akref_smr *s = from_desc_x(p, t, 1, buf);
+  flux_fc_phase(s, e1, e2, e3, 2);
   akref_smr_destroy(s);
   return 0;
 }

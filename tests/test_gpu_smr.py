@@ -184,6 +184,7 @@ def test_boundary_operators_on_random_data(mesh):
     u, cu = _rand(rng, (nmb, nvar, n3, n2, n1)), _rand(rng, (nmb, nvar, c3, c2, c1))
     du, dcu = T(u), T(cu)
     smr.PackAndSendCC(du, dcu)
+    smr.RecvAndUnpackCC(du, dcu)
     L.akref_smr_send_cc(h, P(u), P(cu))
     L.akref_smr_recv_cc(h, P(u), P(cu))
     same(du, u, "exchange_cc u"); same(dcu, cu, "exchange_cc cu")
@@ -197,6 +198,7 @@ def test_boundary_operators_on_random_data(mesh):
     b, cb = faces(n3, n2, n1), faces(c3, c2, c1)
     db, dcb = dev_faces(b, n3, n2, n1), dev_faces(cb, c3, c2, c1)
     smr.PackAndSendFC(db, dcb)
+    smr.RecvAndUnpackFC(db, dcb)
     L.akref_smr_send_fc(h, P(b[0]), P(b[1]), P(b[2]), P(cb[0]), P(cb[1]), P(cb[2]))
     L.akref_smr_recv_fc(h, P(b[0]), P(b[1]), P(b[2]), P(cb[0]), P(cb[1]), P(cb[2]))
     for q, (x, y) in enumerate(zip((db.x1f, db.x2f, db.x3f), b)):
@@ -219,6 +221,7 @@ def test_boundary_operators_on_random_data(mesh):
         for dst, a in zip((dfl.x1f, dfl.x2f, dfl.x3f), fl):
             dst.copy_(torch.from_numpy(a))
         smr.PackAndSendFluxCC(dfl, bool(fs))
+        smr.RecvAndUnpackFluxCC(dfl, bool(fs))
         L.akref_smr_flux_cc(h, P(fl[0]), P(fl[1]), P(fl[2]), fs)
         for q, (x, y) in enumerate(zip((dfl.x1f, dfl.x2f, dfl.x3f), fl)):
             same(x, y, "flux_cc fs=%d dir %d" % (fs, q))
@@ -228,6 +231,7 @@ def test_boundary_operators_on_random_data(mesh):
     for dst, a in zip((de.x1e, de.x2e, de.x3e), e):
         dst.copy_(torch.from_numpy(a))
     smr.PackAndSendFluxFC(de)
+    smr.RecvAndUnpackFluxFC(de)
     L.akref_smr_flux_fc(h, P(e[0]), P(e[1]), P(e[2]))
     for q, (x, y) in enumerate(zip((de.x1e, de.x2e, de.x3e), e)):
         same(x, y, "emf_exchange e%d" % (q + 1))

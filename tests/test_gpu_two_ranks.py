@@ -37,9 +37,13 @@ def _worker(rank, world, port, case, fused, outdir):
     pin = load_deck(deck, ov)
     blk = "mhd" if pin.DoesBlockExist("mhd") else "hydro"
     pin.blocks[blk]["fused_stage"] = "true" if fused else "false"
-    osim = akref.Sim(**pu.oracle_kwargs(pin))
-    osim.initialize()
     sim = Simulation(pin, my_rank=rank, nranks=world, initialize=False)
+    okw = pu.oracle_kwargs(pin)
+    if sim.pmesh.multilevel:           # the single-process oracle takes the tree of the whole mesh
+        from athenak_amd.mesh import Mesh
+        okw.update(pu.smr_tables(Mesh(pin)))
+    osim = akref.Sim(**okw)
+    osim.initialize()
     pk = sim.pmesh.pmb_pack
     g0, g1 = pk.gids, pk.gide + 1
     ph = sim.phys
@@ -58,7 +62,7 @@ def _worker(rank, world, port, case, fused, outdir):
     ok = ok and (sim.pmesh.time == osim.time) and (sim.pmesh.dt == osim.dt)
     with open(os.path.join(outdir, "rank%d.txt" % rank), "w") as f:
         f.write("%d %d %d %d\n" % (int(ok), sim.pmesh.ncycle, pk.nmb_thispack,
-                                   len(ph.pbval_u.peers)))
+                                   len(ph.psmr.peers) if sim.pmesh.multilevel else len(ph.pbval_u.peers)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -87,3 +91,26 @@ def test_two_ranks_hip_kernels_match_single_process_oracle(case, fused):
             ok, ncyc, nmb, npeers = map(int, open(os.path.join(d, "rank%d.txt" % r)).read().split())
             assert ok == 1, "rank %d differs from the single-process oracle" % r
             assert ncyc == case[4] and nmb >= 1 and npeers == 1
+
+
+SMR_CASES = [
+    # problem, mesh, dims, block, cycles, kwargs, ranks: refined meshes cut across ranks
+    ("linear_wave_mhd_smr", (32, 16, 16), 3, (8, 4, 4), 2, {}, 2),
+    ("linear_wave_mhd_smr", (32, 16, 16), 3, (8, 4, 4), 2, {}, 3),
+    ("linear_wave_hydro_smr", (32, 16, 16), 3, (8, 4, 4), 2, {}, 2),
+    ("linear_wave_mhd_smr", (32, 16, 1), 2, (8, 4, 1), 3, {}, 2),
+    ("blast_smr", (32, 32, 32), 3, (8, 8, 8), 2, {}, 2),               # config 5's shape: PPM4 + HLLD, ng = 4
+]
+
+
+@pytest.mark.parametrize("case", SMR_CASES, ids=lambda c: "%s-%s-mb%s-%dranks" % (c[0], c[1], c[3], c[6]))
+def test_refined_mesh_on_several_ranks_hip_kernels(case):
+    """level-aware segments, restricted fluxes and edge EMFs between ranks (akmi_smr_pack_* /
+    akmi_smr_unpack_* with the soff/roff tables); each rank bit-identical to the single-process oracle"""
+    world = case[6]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), case[:6], False, d), nprocs=world, join=True)
+        for r in range(world):
+            ok, ncyc, nmb, npeers = map(int, open(os.path.join(d, "rank%d.txt" % r)).read().split())
+            assert ok == 1, "rank %d differs from the single-process oracle" % r
+            assert ncyc == case[4] and nmb >= 1 and npeers >= 1
