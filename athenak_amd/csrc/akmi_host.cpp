@@ -240,8 +240,6 @@ Mesh::Mesh(ParameterInput *pin, int my_rank_, int nranks_, bool host_only_)
   dtold = 0.0;
   cfl_no = pin->GetReal("time", "cfl_number");
   ncycle = 0;
-  if (multilevel && nranks > 1)
-    AKMI_FATAL("mesh refinement on more than one rank is not on this build's path");
   // every MeshBlock costs the same (build_tree.cpp:262-272); one pack per rank (mesh.cpp:205-215)
   LoadBalance(std::vector<float>(nmb_total, 1.0f));
   const int gs = gids_eachrank[my_rank], nb = nmb_eachrank[my_rank];
@@ -805,7 +803,8 @@ void Hydro::StagePhase(Driver *d, int stage, int phases) {
 }
 TaskStatus Hydro::SendU(Driver *d, int stage) {            // hydro_tasks.cpp:308-320
   if (multilevel) {
-    AKCHK(akmi_smr_exchange_cc(&pack_c, &psmr->smr_c, nvars, u0.p, coarse_u0.p, psmr->buf[0].p, stream));
+    AKCHK(akmi_smr_pack_cc(&pack_c, &psmr->smr_c, nvars, u0.p, coarse_u0.p, psmr->buf[0].p, stream));
+    psmr->Post(0, stream);
   } else if (pbval) {
     pbval->PackAndSendCC(u0.p, stream);
     // the messages are in flight on the communicator's stream: convert the active cells (they do
@@ -817,13 +816,28 @@ TaskStatus Hydro::SendU(Driver *d, int stage) {            // hydro_tasks.cpp:30
   return TaskStatus::complete;
 }
 TaskStatus Hydro::RecvU(Driver *d, int stage) {            // hydro_tasks.cpp:327-339
-  if (pbval) pbval->RecvAndUnpackCC(u0.p, stream);
+  if (multilevel) {
+    psmr->Wait(0, stream);
+    AKCHK(akmi_smr_unpack_cc(&pack_c, &psmr->smr_c, nvars, psmr->buf[0].p, u0.p, coarse_u0.p, stream));
+  } else if (pbval) {
+    pbval->RecvAndUnpackCC(u0.p, stream);
+  }
+  return TaskStatus::complete;
+}
+TaskStatus Hydro::RecvFlux(Driver *d, int stage) {         // hydro_tasks.cpp:222-232
+  if (multilevel) {
+    psmr->Wait(1, stream);
+    AKCHK(akmi_smr_unpack_flux_cc(&pack_c, &psmr->smr_c, nvars, 0, psmr->buf[1].p, uflx.x1f.p, uflx.x2f.p,
+                                  uflx.x3f.p, stream));
+  }
   return TaskStatus::complete;
 }
 TaskStatus Hydro::SendFlux(Driver *d, int stage) {         // hydro_tasks.cpp:206-215
-  if (multilevel)
-    AKCHK(akmi_smr_flux_cc(&pack_c, &psmr->smr_c, nvars, 0, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p,
-                           psmr->buf[1].p, stream));
+  if (multilevel) {
+    AKCHK(akmi_smr_pack_flux_cc(&pack_c, &psmr->smr_c, nvars, 0, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p,
+                                psmr->buf[1].p, stream));
+    psmr->Post(1, stream);
+  }
   return TaskStatus::complete;
 }
 TaskStatus Hydro::RestrictU(Driver *d, int stage) {        // hydro_tasks.cpp:291-300
@@ -944,28 +958,58 @@ void MHD::StagePhase(Driver *d, int stage, int phases) {
 // -> c2p of the active cells (+dt) -> wait/unpack U, B -> BCs -> c2p of the ghost shell: the reference's
 // task order (mhd_tasks.cpp:48-75) with the transfers underneath the kernels that do not need them
 TaskStatus MHD::SendU(Driver *d, int stage) {
-  if (multilevel)
-    AKCHK(akmi_smr_exchange_cc(&pack_c, &psmr->smr_c, nvars, u0.p, coarse_u0.p, psmr->buf[0].p, stream));
-  else if (pbval)
+  if (multilevel) {
+    AKCHK(akmi_smr_pack_cc(&pack_c, &psmr->smr_c, nvars, u0.p, coarse_u0.p, psmr->buf[0].p, stream));
+    psmr->Post(0, stream);
+  } else if (pbval)
     pbval->PackAndSendCC(u0.p, stream);
   else
     AKCHK(akmi_bvals_cc_local(&pack_c, nvars, pmy_pack->pmb->d_nghbr.p, u0.p, stream));
   return TaskStatus::complete;
 }
 TaskStatus MHD::RecvU(Driver *d, int stage) {
-  if (pbval && !(fused && peers())) pbval->RecvAndUnpackCC(u0.p, stream);   // else: in RecvB
+  if (multilevel) {
+    psmr->Wait(0, stream);
+    AKCHK(akmi_smr_unpack_cc(&pack_c, &psmr->smr_c, nvars, psmr->buf[0].p, u0.p, coarse_u0.p, stream));
+  } else if (pbval && !(fused && peers())) {
+    pbval->RecvAndUnpackCC(u0.p, stream);                                     // else: in RecvB
+  }
+  return TaskStatus::complete;
+}
+TaskStatus MHD::RecvFlux(Driver *d, int stage) {           // mhd_tasks.cpp:240-250
+  if (multilevel) {
+    psmr->Wait(1, stream);
+    AKCHK(akmi_smr_unpack_flux_cc(&pack_c, &psmr->smr_c, nvars, 1, psmr->buf[1].p, uflx.x1f.p, uflx.x2f.p,
+                                  uflx.x3f.p, stream));
+  }
+  return TaskStatus::complete;
+}
+TaskStatus MHD::RecvE(Driver *d, int stage) {              // mhd_tasks.cpp:410-417
+  if (multilevel) {
+    psmr->Wait(3, stream);
+    AKCHK(akmi_smr_unpack_emf(&pack_c, &psmr->smr_c, psmr->d_nflx.p, psmr->buf[3].p, efld.x1e.p, efld.x2e.p,
+                              efld.x3e.p, stream));
+  }
   return TaskStatus::complete;
 }
 TaskStatus MHD::RecvB(Driver *d, int stage) {
+  if (multilevel) {
+    psmr->Wait(2, stream);
+    AKCHK(akmi_smr_unpack_fc(&pack_c, &psmr->smr_c, psmr->buf[2].p, b0.x1f.p, b0.x2f.p, b0.x3f.p,
+                             coarse_b0.x1f.p, coarse_b0.x2f.p, coarse_b0.x3f.p, stream));
+    return TaskStatus::complete;
+  }
   if (!pbval) return TaskStatus::complete;
   if (fused && peers()) pbval->RecvAndUnpackCC(u0.p, stream);
   pbval->RecvAndUnpackFC(b0, stream);
   return TaskStatus::complete;
 }
 TaskStatus MHD::SendFlux(Driver *d, int stage) {           // mhd_tasks.cpp:225-233
-  if (multilevel)
-    AKCHK(akmi_smr_flux_cc(&pack_c, &psmr->smr_c, nvars, 1, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p,
-                           psmr->buf[1].p, stream));
+  if (multilevel) {
+    AKCHK(akmi_smr_pack_flux_cc(&pack_c, &psmr->smr_c, nvars, 1, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p,
+                                psmr->buf[1].p, stream));
+    psmr->Post(1, stream);
+  }
   return TaskStatus::complete;
 }
 TaskStatus MHD::RestrictU(Driver *d, int stage) {          // mhd_tasks.cpp:315-322
@@ -983,9 +1027,10 @@ TaskStatus MHD::RestrictB(Driver *d, int stage) {          // mhd_tasks.cpp:691-
 // value itself (2a/2 and ((2a+a)+a)/4 are exact), so nothing is exchanged; with levels this is the
 // flux correction of the field
 TaskStatus MHD::SendE(Driver *d, int stage) {
-  if (multilevel)
-    AKCHK(akmi_smr_emf_exchange(&pack_c, &psmr->smr_c, psmr->d_nflx.p, efld.x1e.p, efld.x2e.p, efld.x3e.p,
-                                psmr->buf[3].p, stream));
+  if (multilevel) {
+    AKCHK(akmi_smr_pack_emf(&pack_c, &psmr->smr_c, efld.x1e.p, efld.x2e.p, efld.x3e.p, psmr->buf[3].p, stream));
+    psmr->Post(3, stream);
+  }
   return TaskStatus::complete;
 }
 TaskStatus MHD::Prolongate(Driver *d, int stage) {         // mhd_tasks.cpp:527-552
@@ -1026,10 +1071,11 @@ TaskStatus MHD::CT(Driver *d, int stage) {                 // mhd_ct.cpp:23-80
   return TaskStatus::complete;
 }
 TaskStatus MHD::SendB(Driver *d, int stage) {
-  if (multilevel)
-    AKCHK(akmi_smr_exchange_fc(&pack_c, &psmr->smr_c, b0.x1f.p, b0.x2f.p, b0.x3f.p, coarse_b0.x1f.p,
-                               coarse_b0.x2f.p, coarse_b0.x3f.p, psmr->buf[2].p, stream));
-  else if (pbval) {
+  if (multilevel) {
+    AKCHK(akmi_smr_pack_fc(&pack_c, &psmr->smr_c, b0.x1f.p, b0.x2f.p, b0.x3f.p, coarse_b0.x1f.p,
+                           coarse_b0.x2f.p, coarse_b0.x3f.p, psmr->buf[2].p, stream));
+    psmr->Post(2, stream);
+  } else if (pbval) {
     pbval->PackAndSendFC(b0, stream);
     if (fused && peers()) StagePhase(d, stage, AKMI_PHASE_C2P);
   } else {

@@ -154,7 +154,8 @@ class Comm {
   void InitCallbacks(int rank, int nranks, akmi_comm_exchange_fn ex, akmi_comm_allreduce_min_fn ar,
                      void *user);
   void Finalize();
-  // all messages of one variable class (channel 0 = cell-centred, 1 = face-centred).  The data is
+  // all messages of one variable class (uniform meshes: channel 0 = cell-centred, 1 = face-centred;
+  // refined meshes: 0 cc variables, 1 cc fluxes, 2 fc variables, 3 edge EMFs).  The data is
   // ready on `compute` when Post is called; Wait makes `compute` wait for the receives.
   void Post(const std::vector<Msg> &m, hipStream_t compute, int channel);
   void Wait(hipStream_t compute, int channel);
@@ -163,12 +164,12 @@ class Comm {
  private:
   void *nccl_ = nullptr;                 // ncclComm_t
   hipStream_t comm_stream_ = nullptr;
-  hipEvent_t ready_[2] = {nullptr, nullptr}, done_[2] = {nullptr, nullptr};
+  hipEvent_t ready_[4] = {nullptr, nullptr, nullptr, nullptr}, done_[4] = {nullptr, nullptr, nullptr, nullptr};
   Real *d_scratch_ = nullptr;            // device doubles for the dt reduction
   akmi_comm_exchange_fn ex_ = nullptr;
   akmi_comm_allreduce_min_fn ar_ = nullptr;
   void *user_ = nullptr;
-  struct Staged { std::vector<Msg> m; std::vector<Real *> hs, hr; std::vector<long long> cs, cr; } staged_[2];
+  struct Staged { std::vector<Msg> m; std::vector<Real *> hs, hr; std::vector<long long> cs, cr; } staged_[4];
 };
 
 // who sends what to whom on a uniform mesh (bvals.py MeshBoundaryValues.__init__): pure host data
@@ -223,7 +224,8 @@ class MeshBlock {       // meshblock.cpp:25-131
   void SetNeighborsSMR(Mesh *pm);   // meshblock.cpp:142-425
   int nmb;
   std::vector<int> mb_lev;        // logical level of each block
-  std::vector<int> nghbr_smr;     // multilevel: [nmb][56][3] {local index | -1, level, dest slot}
+  std::vector<int> nghbr_smr;     // multilevel: [nmb][56][3] {index in the pack | nmb: another rank | -1, level, dest slot}
+  std::vector<int> nghbr_smr_gid; // [nmb][56] global id of that neighbour
   std::vector<int> mb_gid;
   std::vector<RegionSize> mb_size;
   std::vector<int> mb_bcs;        // [nmb][6]
@@ -307,8 +309,13 @@ class MeshBoundaryValuesSMR {
   int nvar, nnghbr;
   akmi_smr smr_c;
   DvceArray<int> d_nghbr, d_lev, d_cc, d_fc, d_ndat, d_ox, d_nflx;
-  DvceArray<long long> d_layout;
+  DvceArray<long long> d_layout, d_soff, d_roff;
   DvceArray<Real> buf[4];         // cc vars, cc flux, fc vars, fc flux
+  // ranks: peers and the slices of buf[cls] that travel (akmi_smr::soff/roff address the segments)
+  std::vector<int> peers;
+  std::map<int, std::pair<long long, long long>> send_slices[4], recv_slices[4];
+  void Post(int cls, hipStream_t st);
+  void Wait(int cls, hipStream_t st);
 };
 
 // physics base: what Hydro and MHD share ------------------------------------------------
@@ -371,7 +378,7 @@ class Hydro : public FluidBase {    // hydro.hpp:73-154
   TaskStatus CopyCons(Driver *d, int stage);
   TaskStatus Fluxes(Driver *d, int stage);
   TaskStatus SendFlux(Driver *d, int stage);
-  TaskStatus RecvFlux(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus RecvFlux(Driver *d, int stage);
   TaskStatus RKUpdate(Driver *d, int stage);
   TaskStatus HydroSrcTerms(Driver *d, int stage) { return TaskStatus::complete; }
   TaskStatus RestrictU(Driver *d, int stage);
@@ -402,7 +409,7 @@ class MHD : public FluidBase {      // mhd.hpp:93-199
   TaskStatus CopyCons(Driver *d, int stage);
   TaskStatus Fluxes(Driver *d, int stage);
   TaskStatus SendFlux(Driver *d, int stage);
-  TaskStatus RecvFlux(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus RecvFlux(Driver *d, int stage);
   TaskStatus RKUpdate(Driver *d, int stage);
   TaskStatus MHDSrcTerms(Driver *d, int stage) { return TaskStatus::complete; }
   TaskStatus RestrictU(Driver *d, int stage);
@@ -410,7 +417,7 @@ class MHD : public FluidBase {      // mhd.hpp:93-199
   TaskStatus RecvU(Driver *d, int stage);
   TaskStatus EField(Driver *d, int stage);
   TaskStatus SendE(Driver *d, int stage);      // identity on uniform meshes, EMF correction with levels
-  TaskStatus RecvE(Driver *d, int stage) { return TaskStatus::complete; }
+  TaskStatus RecvE(Driver *d, int stage);
   TaskStatus CT(Driver *d, int stage);
   TaskStatus RestrictB(Driver *d, int stage);
   TaskStatus SendB(Driver *d, int stage);

@@ -107,7 +107,7 @@ void Comm::InitRCCL(int rank_, int nranks_, const char id[128]) {
   int lo = 0, hi = 0;
   HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
   HIPCHK(hipStreamCreateWithPriority(&comm_stream_, hipStreamNonBlocking, hi));
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < 4; ++q) {
     HIPCHK(hipEventCreateWithFlags(&ready_[q], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&done_[q], hipEventDisableTiming));
   }
@@ -125,7 +125,7 @@ void Comm::Finalize() {
   if (kind == Kind::rccl) {
     HIPCHK(hipStreamSynchronize(comm_stream_));
     rccl().CommDestroy(static_cast<ncclComm_t>(nccl_));
-    for (int q = 0; q < 2; ++q) { hipEventDestroy(ready_[q]); hipEventDestroy(done_[q]); }
+    for (int q = 0; q < 4; ++q) { hipEventDestroy(ready_[q]); hipEventDestroy(done_[q]); }
     hipStreamDestroy(comm_stream_);
     hipFree(d_scratch_);
     nccl_ = nullptr; comm_stream_ = nullptr; d_scratch_ = nullptr;

@@ -199,6 +199,8 @@ void Mesh::BuildTreeFromScratch(ParameterInput *pin) {
 // only where this block sits in that corner of its parent.
 void MeshBlock::SetNeighborsSMR(Mesh *pm) {
   nghbr_smr.assign(static_cast<size_t>(nmb)*56*3, -1);
+  nghbr_smr_gid.assign(static_cast<size_t>(nmb)*56, -1);
+  const int gids = mb_gid[0];
   MeshBlockTree &tree = *pm->ptree;
   const int ndim = pm->three_d ? 3 : (pm->multi_d ? 2 : 1);
   for (int m = 0; m < nmb; ++m) {
@@ -218,7 +220,11 @@ void MeshBlock::SetNeighborsSMR(Mesh *pm) {
       const int neg[3] = {-ox, -oy, -oz};
       auto set = [&](int n, const MeshBlockTree::Node *c, int dest) {
         int *q = &nghbr_smr[(static_cast<size_t>(m)*56 + n)*3];
-        q[0] = c->gid; q[1] = c->lloc.level; q[2] = dest;
+        // index in this pack, or nmb for a block of another rank (then only tested for existence: the
+        // segments of such neighbours are addressed through akmi_smr::soff/roff)
+        q[0] = pm->rank_eachmb[c->gid] == pm->my_rank ? c->gid - gids : nmb;
+        q[1] = c->lloc.level; q[2] = dest;
+        nghbr_smr_gid[static_cast<size_t>(m)*56 + n] = c->gid;
       };
       if (!nt->leaf.empty()) {                                  // finer: every touching child
         const int nf1 = nfree > 0 ? (fr[0] < ndim ? 2 : 1) : 1, nf2 = nfree > 1 ? (fr[1] < ndim ? 2 : 1) : 1;
@@ -424,6 +430,72 @@ MeshBoundaryValuesSMR::MeshBoundaryValuesSMR(MeshBlockPack *pp, int nvar_) : pmy
     }
     sizes[cls] = static_cast<size_t>(std::max<long long>(off, 1));
   }
+  // ---- ranks (bvals_smr.py _plan_ranks): per class one buffer [segments of neighbours in this pack,
+  // by (slot, block)] [segments received, rank after rank] [segments sent, rank after rank]; inside a
+  // message the segments are ordered by (receiver gid, receiver slot), each of the size of the
+  // receiver's slot
+  {
+    const int gids = pp->gids;
+    struct Rem { int m, n, gid, lev, dest, rank; };
+    std::vector<Rem> remote;
+    for (int m = 0; m < nmb; ++m)
+      for (int n = 0; n < 56; ++n) {
+        const int g = pmb->nghbr_smr_gid[static_cast<size_t>(m)*56 + n];
+        if (g < 0 || pm->rank_eachmb[g] == pm->my_rank) continue;
+        const int *q = &ngh[(static_cast<size_t>(m)*56 + n)*3];
+        remote.push_back({m, n, g, q[1], q[2], pm->rank_eachmb[g]});
+      }
+    for (const Rem &r : remote) if (std::find(peers.begin(), peers.end(), r.rank) == peers.end()) peers.push_back(r.rank);
+    std::sort(peers.begin(), peers.end());
+    auto carries = [](int cls, int lev_s, int lev_r, int dn) {
+      if (cls == 0 || cls == 2) return true;
+      if (cls == 1) return lev_s > lev_r && (dn < 16 || (dn >= 24 && dn < 32));
+      return lev_s >= lev_r && dn < 48;
+    };
+    auto lay = [&](int cls, int n, int q) { return layout[(static_cast<size_t>(cls)*56 + n)*2 + q]; };
+    std::vector<long long> soff(static_cast<size_t>(4)*nmb*56, 0), roff(static_cast<size_t>(4)*nmb*56, 0);
+    for (int cls = 0; cls < 4; ++cls) {
+      for (int m = 0; m < nmb; ++m)
+        for (int n = 0; n < 56; ++n) {
+          const int *q = &ngh[(static_cast<size_t>(m)*56 + n)*3];
+          if (q[0] < 0) continue;
+          if (q[0] < nmb) soff[(static_cast<size_t>(cls)*nmb + m)*56 + n] = lay(cls, q[2], 0) + q[0]*lay(cls, q[2], 1);
+          roff[(static_cast<size_t>(cls)*nmb + m)*56 + n] = lay(cls, n, 0) + m*lay(cls, n, 1);
+        }
+      long long off = lay(cls, 55, 0) + lay(cls, 55, 1)*nmb;      // end of the in-pack segments
+      for (int r : peers) {                       // what this rank receives from rank r
+        const long long start = off;
+        std::vector<std::array<int, 2>> items;
+        for (const Rem &x : remote)
+          if (x.rank == r && lay(cls, x.n, 1) > 0 && carries(cls, x.lev, pmb->mb_lev[x.m], x.n)) items.push_back({gids + x.m, x.n});
+        std::sort(items.begin(), items.end());
+        for (const auto &it : items) {
+          roff[(static_cast<size_t>(cls)*nmb + (it[0] - gids))*56 + it[1]] = off;
+          off += lay(cls, it[1], 1);
+        }
+        recv_slices[cls][r] = {start, off};
+      }
+      for (int r : peers) {                       // what it sends to rank r
+        const long long start = off;
+        std::vector<std::array<int, 4>> items;
+        for (const Rem &x : remote)
+          if (x.rank == r && lay(cls, x.dest, 1) > 0 && carries(cls, pmb->mb_lev[x.m], x.lev, x.dest))
+            items.push_back({x.gid, x.dest, x.m, x.n});
+        std::sort(items.begin(), items.end());
+        for (const auto &it : items) {
+          soff[(static_cast<size_t>(cls)*nmb + it[2])*56 + it[3]] = off;
+          off += lay(cls, it[1], 1);
+        }
+        send_slices[cls][r] = {start, off};
+      }
+      sizes[cls] = static_cast<size_t>(std::max<long long>(off, 1));
+    }
+    if (!peers.empty()) {
+      d_soff.Realloc(soff.size()); d_roff.Realloc(roff.size());
+      HIPCHK(hipMemcpy(d_soff.p, soff.data(), sizeof(long long)*soff.size(), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(d_roff.p, roff.data(), sizeof(long long)*roff.size(), hipMemcpyHostToDevice));
+    }
+  }
   auto up_i = [](DvceArray<int> &d, const std::vector<int> &h) {
     d.Realloc(h.size());
     HIPCHK(hipMemcpy(d.p, h.data(), sizeof(int)*h.size(), hipMemcpyHostToDevice));
@@ -437,15 +509,30 @@ MeshBoundaryValuesSMR::MeshBoundaryValuesSMR(MeshBlockPack *pp, int nvar_) : pmy
     HIPCHK(hipMemset(buf[cls].p, 0, sizeof(Real)*sizes[cls]));
   }
   smr_c.nnghbr = nnghbr; smr_c.multilevel = 1;
-  smr_c.soff = nullptr; smr_c.roff = nullptr;        // one rank: layout[] addresses the buffers
+  smr_c.soff = peers.empty() ? nullptr : d_soff.p;   // one rank: layout[] addresses the buffers
+  smr_c.roff = peers.empty() ? nullptr : d_roff.p;
   smr_c.nghbr = d_nghbr.p; smr_c.mblev = d_lev.p; smr_c.cc_tab = d_cc.p; smr_c.fc_tab = d_fc.p;
   smr_c.ndat = d_ndat.p; smr_c.slot_ox = d_ox.p; smr_c.layout = d_layout.p;
 }
 
 MeshBoundaryValuesSMR::~MeshBoundaryValuesSMR() {
   d_nghbr.Free(); d_lev.Free(); d_cc.Free(); d_fc.Free(); d_ndat.Free(); d_ox.Free(); d_nflx.Free();
-  d_layout.Free();
+  d_layout.Free(); d_soff.Free(); d_roff.Free();
   for (auto &b : buf) b.Free();
+}
+
+// the messages of one class: one per peer rank (bvals.cpp:134-310)
+void MeshBoundaryValuesSMR::Post(int cls, hipStream_t st) {
+  if (peers.empty()) return;
+  std::vector<Comm::Msg> m;
+  for (int r : peers) {
+    const auto s = send_slices[cls].at(r), v = recv_slices[cls].at(r);
+    m.push_back({r, buf[cls].p + s.first, s.second - s.first, buf[cls].p + v.first, v.second - v.first});
+  }
+  Comm::World().Post(m, st, cls);
+}
+void MeshBoundaryValuesSMR::Wait(int cls, hipStream_t st) {
+  if (!peers.empty()) Comm::World().Wait(st, cls);
 }
 
 }  // namespace host

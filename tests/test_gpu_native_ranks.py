@@ -40,7 +40,11 @@ def _worker(rank, world, port, case, fused, outdir):
     pin = load_deck(deck, ov)
     blk = "mhd" if pin.DoesBlockExist("mhd") else "hydro"
     pin.blocks[blk]["fused_stage"] = "true" if fused else "false"
-    osim = akref.Sim(**pu.oracle_kwargs(pin))
+    okw = pu.oracle_kwargs(pin)
+    if pin.DoesBlockExist("mesh_refinement"):     # the single-process oracle takes the tree of the whole mesh
+        from athenak_amd.mesh import Mesh
+        okw.update(pu.smr_tables(Mesh(pin)))
+    osim = akref.Sim(**okw)
     osim.initialize()
     assert native.init_comm_from_torch_distributed() == "callbacks"
     sim = native.NativeSimulation(pin, initialize=False)
@@ -86,6 +90,28 @@ def test_two_ranks_cpp_host_matches_single_process_oracle(case, fused):
     world = 2
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(world, _free_port(), case, fused, d), nprocs=world, join=True)
+        for r in range(world):
+            ok, ncyc, nmb = map(int, open(os.path.join(d, "rank%d.txt" % r)).read().split())
+            assert ok == 1, "rank %d differs from the single-process oracle" % r
+            assert ncyc == case[4] and nmb >= 1
+
+
+SMR_CASES = [
+    ("linear_wave_mhd_smr", (32, 16, 16), 3, (8, 4, 4), 2, {}, 2),
+    ("linear_wave_mhd_smr", (32, 16, 16), 3, (8, 4, 4), 2, {}, 3),
+    ("linear_wave_hydro_smr", (32, 16, 16), 3, (8, 4, 4), 2, {}, 2),
+    ("linear_wave_mhd_smr", (32, 16, 1), 2, (8, 4, 1), 3, {}, 2),
+    ("blast_smr", (32, 32, 32), 3, (8, 8, 8), 2, {}, 2),               # config 5's shape: PPM4 + HLLD, ng = 4
+]
+
+
+@pytest.mark.parametrize("case", SMR_CASES, ids=lambda c: "%s-%s-mb%s-%dranks" % (c[0], c[1], c[3], c[6]))
+def test_refined_mesh_on_several_ranks_cpp_host(case):
+    """the C++ host's own tree, neighbour table, segment tables (soff/roff) and per-peer slices of the
+    level-aware exchange, flux and edge-EMF correction; each rank bit-identical to the oracle"""
+    world = case[6]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), case[:6], False, d), nprocs=world, join=True)
         for r in range(world):
             ok, ncyc, nmb = map(int, open(os.path.join(d, "rank%d.txt" % r)).read().split())
             assert ok == 1, "rank %d differs from the single-process oracle" % r
