@@ -97,9 +97,25 @@ def cpu_baseline(args, blk):
     bounded sample of the same workload (same deck at sample_nx^3, a few cycles)"""
     from oracle import akref
     try:
-        navail = len(os.sched_getaffinity(0))
+        nsee = len(os.sched_getaffinity(0))
     except AttributeError:
-        navail = os.cpu_count() or 1
+        nsee = os.cpu_count() or 1
+    # what the container may actually use: the cgroup CPU quota (the GPU boxes show 256 hardware threads
+    # and grant 16 CPUs: cpu.max = "1600000 100000"); threads beyond it only take turns
+    navail, quota = nsee, None
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            t = open(f).read().split()
+            if f.endswith("cpu.max"):
+                if t[0] != "max":
+                    quota = int(t[0])/int(t[1])
+            elif int(t[0]) > 0:
+                quota = int(t[0])/int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if quota:
+        navail = max(1, min(nsee, int(round(quota))))
     akref.lib()
     n = args.cpu_sample_nx
     rec = args.recon or "plm"
@@ -132,8 +148,9 @@ def cpu_baseline(args, blk):
         return n**3*cyc/dt/1e6, cyc
 
     # the oracle's OpenMP loops run over the flattened (block, k, j) rows (the Kokkos-OpenMP /
-    # flat-MPI semantics of SURVEY 8(d)): 1 core, then powers of four up to every usable core
-    candidates = sorted({1, min(navail, 16), min(navail, 64), navail})
+    # flat-MPI semantics of SURVEY 8(d)): 1 core, half and all of the CPUs the container is granted, and
+    # twice that (to show that more threads than the quota do not help)
+    candidates = sorted({1, max(1, navail//2), navail, min(nsee, 2*navail)})
     best = None
     results = []
     for th in candidates:
@@ -144,7 +161,8 @@ def cpu_baseline(args, blk):
     return {"value": round(best[0], 4), "unit": "Mcell-updates/s", "cores": best[1], "kind": "port",
             "sample": "%s %d^3 RK2 %s, ~4 s per thread count, oracle = port of the reference's "
                       "split-kernel CPU sequence, OpenMP over (block,k,j); Mcell-updates/s by threads: %s "
-                      "(host has %d usable cores)" % (args.problem, n, rec, "; ".join(results), navail)}
+                      "(the host shows %d hardware threads; the cgroup CPU quota of this container is %s)" % (
+                          args.problem, n, rec, "; ".join(results), nsee, ("%g CPUs" % quota) if quota else "unlimited")}
 
 
 def main():
