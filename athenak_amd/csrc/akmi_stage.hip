@@ -517,6 +517,8 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
     } else {
       riemann_hyd<RS>(eos.gamma, L[0], L[1], L[2], L[3], L[4], R[0], R[1], R[2], R[3], R[4], fd, fx,
                       fy, fz, fe);
+      // passive scalars are advected by the mass flux (k_scalar_update): keep it
+      if (g.nvar > 5 && (t < ml || s == shi)) a.flx[ix5(g.nvar, a.f3, a.f2, a.f1, m, 0, k, j, i)] = fd;
     }
     double fv[5];
     fv[0] = fd; fv[ivx] = fx; fv[ivy] = fy; fv[ivz] = fz; fv[4] = fe;
@@ -812,6 +814,8 @@ k_sweep_update_1d(Geo g, FaceEos eos, SweepArgs a, UpdArgs u) {
       const size_t ec = ix4(g.N3, g.N2, g.N1, m, k, j, i);
       a.ey[ec] = -fby;
       a.ez[ec] = fbz;
+    } else {
+      if (g.nvar > 5) a.flx[ix5(g.nvar, a.f3, a.f2, a.f1, m, 0, k, j, i)] = fd;
     }
   }
   const double fv[5] = {fd, fx, fy, fz, fe};
@@ -829,6 +833,68 @@ k_sweep_update_1d(Geo g, FaceEos eos, SweepArgs a, UpdArgs u) {
     const double u1v = u.copy_u1 ? u0v : u.u1[c + n*cs];
     if (u.copy_u1) u.u1[c + n*cs] = u0v;
     u.u0[c + n*cs] = u.gam0*u0v + u.gam1*u1v - beta_dt_of(u.beta_dt, u.dtp)*divf;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Passive scalars of the fused stage (hydro_fluxes.cpp:135-147, mhd_fluxes.cpp:153-166 + RKUpdate): a
+// scalar's flux is the mass flux times its upwind reconstructed value, so the Riemann kernels only
+// have to leave the mass fluxes behind (the MHD sweeps store them anyway, for CornerE); this kernel
+// reconstructs each scalar at the six faces of a cell, forms the divergence in the reference's order
+// and applies the RK update, CopyCons folded in.  Same operations as the task-granular kernels.
+template <int RECON>
+__global__ void __launch_bounds__(SX*SY)
+k_scalar_update(Geo g, FaceEos eos, const double *__restrict__ w0, const double *__restrict__ m1,
+                const double *__restrict__ m2, const double *__restrict__ m3, UpdArgs u, int k0, int nk) {
+  const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;   // rows [js,je] x N1
+  const int jj = (int)(p/g.N1);
+  const int i = (int)(p - (long)jj*g.N1);
+  const int j = g.js + jj;
+  const int m = blockIdx.z/nk;
+  const int k = k0 + (blockIdx.z - m*nk);
+  if (i < g.is || i > g.ie || j > g.je) return;
+  const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
+  const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  const double bdt = beta_dt_of(u.beta_dt, u.dtp);
+  const double f1l = m1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k, j, i)];
+  const double f1h = m1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k, j, i + 1)];
+  double f2l = 0.0, f2h = 0.0, f3l = 0.0, f3h = 0.0;
+  if (g.multi_d) {
+    f2l = m2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, 0, k, j, i)];
+    f2h = m2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, 0, k, j + 1, i)];
+  }
+  if (g.three_d) {
+    f3l = m3[ix5(g.nvar, g.N3 + 1, g.N2, g.N1, m, 0, k, j, i)];
+    f3h = m3[ix5(g.nvar, g.N3 + 1, g.N2, g.N1, m, 0, k + 1, j, i)];
+  }
+  const long s2 = g.N1, s3 = (long)g.N1*g.N2;
+  for (int n = 5; n < g.nvar; ++n) {
+    const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, n, k, j, i);
+    const double *q = w0 + c;
+    double sl, sr;
+    face_states<RECON, 0>(q, 1, eos, sl, sr);
+    const double a_lo = f1l*((f1l >= 0.0) ? sl : sr);
+    face_states<RECON, 0>(q + 1, 1, eos, sl, sr);
+    const double a_hi = f1h*((f1h >= 0.0) ? sl : sr);
+    double divf = (a_hi - a_lo)/dx1;
+    if (g.multi_d) {
+      face_states<RECON, 0>(q, s2, eos, sl, sr);
+      const double b_lo = f2l*((f2l >= 0.0) ? sl : sr);
+      face_states<RECON, 0>(q + s2, s2, eos, sl, sr);
+      const double b_hi = f2h*((f2h >= 0.0) ? sl : sr);
+      divf += (b_hi - b_lo)/dx2;
+    }
+    if (g.three_d) {
+      face_states<RECON, 0>(q, s3, eos, sl, sr);
+      const double c_lo = f3l*((f3l >= 0.0) ? sl : sr);
+      face_states<RECON, 0>(q + s3, s3, eos, sl, sr);
+      const double c_hi = f3h*((f3h >= 0.0) ? sl : sr);
+      divf += (c_hi - c_lo)/dx3;
+    }
+    const double u0v = u.u0[c];
+    const double u1v = u.copy_u1 ? u0v : u.u1[c];
+    if (u.copy_u1) u.u1[c] = u0v;
+    u.u0[c] = u.gam0*u0v + u.gam1*u1v - bdt*divf;
   }
 }
 
@@ -1118,6 +1184,11 @@ k_c2p_newdt(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ 
     if (efl) { u0[c + 4*cs] = ue; atomicAdd(&counters[1], 1); }
     if (tfl) { u0[c + 4*cs] = ue; atomicAdd(&counters[2], 1); }
     w0[c] = wd; w0[c + cs] = wvx; w0[c + 2*cs] = wvy; w0[c + 3*cs] = wvz; w0[c + 4*cs] = we;
+    for (int n = 5; n < g.nvar; ++n) {        // scalars with their floor, ideal_hyd.cpp:94-101
+      double us = u0[c + n*cs];
+      if (us < 0.0) { us = 0.0; u0[c + n*cs] = 0.0; }
+      w0[c + n*cs] = us/ud;
+    }
     if (do_newdt && i >= g.is && i <= g.ie && j >= g.js && j <= g.je && k >= g.ks && k <= g.ke) {
       // hydro_newdt.cpp:97-118 / mhd_newdt.cpp:123-136
       const double pr = (eos.gamma - 1.0)*we;
@@ -1193,10 +1264,12 @@ static HydTile hyd_tile(int c1, int c2) {
   return best;
 }
 
-template <int RECON, int RS>
+// MASS: passive scalars ride along -- leave the three mass fluxes behind for k_scalar_update
+struct Mass3 { double *m1, *m2, *m3; };
+template <int RECON, int RS, bool MASS = false>
 __global__ void __launch_bounds__(HS_THREADS, AKMI_HS_WAVES)
 k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, int kA, int kB,
-                int nchunk, int ckl, int tw, int th) {
+                int nchunk, int ckl, int tw, int th, Mass3 ms) {
   static_assert(RECON <= 1, "one-kernel hydro stage: DC and PLM");
   extern __shared__ double hs_lds[];
   const int pw = tw + 3, ph = th + 3;        // plane with halo: cols i0-2..i0+tw, rows j0-2..j0+th
@@ -1285,6 +1358,9 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
                         fy, fz, fe);
         SF1(b, 0, r, t) = fd; SF1(b, 1, r, t) = fx; SF1(b, 2, r, t) = fy; SF1(b, 3, r, t) = fz;
         SF1(b, 4, r, t) = fe;
+        if constexpr (MASS) {
+          if (i <= g.ie + 1 && j <= g.je) ms.m1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k - 1, j, i)] = fd;
+        }
       }
       {  // low x2 face: cells j-2..j+1 of column i; sweep-aligned order (d, vy, vz, vx, e)
         double L[5], R[5];
@@ -1305,6 +1381,9 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
                         fy, fz, fe);
         SF2(b, 0, r, t) = fd; SF2(b, 2, r, t) = fx; SF2(b, 3, r, t) = fy; SF2(b, 1, r, t) = fz;
         SF2(b, 4, r, t) = fe;
+        if constexpr (MASS) {
+          if (i <= g.ie && j <= g.je + 1) ms.m2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, 0, k - 1, j, i)] = fd;
+        }
       }
     }
     // x3 face below cell k: sweep-aligned order (d, vz, vx, vy, e)
@@ -1326,6 +1405,9 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
       riemann_hyd<RS>(eos.gamma, L[0], L[3], L[1], L[2], L[4], R[0], R[3], R[1], R[2], R[4], fd, fx, fy,
                       fz, fe);
       f3[0] = fd; f3[3] = fx; f3[1] = fy; f3[2] = fz; f3[4] = fe;
+      if constexpr (MASS) {
+        if (own) ms.m3[ix5(g.nvar, g.N3 + 1, g.N2, g.N1, m, 0, k, j, i)] = fd;
+      }
     }
     if (k <= k1) {                                     // plane k for the next step
       if (in_tile) {
@@ -1454,8 +1536,9 @@ static int launch_sweep12(const Geo &g, const Scheme &sc, const SweepArgs &a1, c
   return AKMI_COMPLETE;
 }
 
+template <bool MASS>
 static int launch_hydro_stage3d(const Geo &g, const Scheme &sc, const double *w0, const UpdArgs &u,
-                                int kA, int kB, hipStream_t st) {
+                                int kA, int kB, hipStream_t st, Mass3 ms) {
   const HydTile tl = hyd_tile(g.nx1, g.nx2);
   if (tl.tw == 0) { set_error("hydro_stage3d: no tile shape"); return AKMI_FAIL; }
   const int ckl = march_len((long)tl.n1*tl.n2, kB - kA + 1, g.nmb, ML);
@@ -1464,7 +1547,7 @@ static int launch_hydro_stage3d(const Geo &g, const Scheme &sc, const double *w0
   dim3 grid(tl.n1, tl.n2, nchunk*g.nmb), block(tl.threads);
   int rc = dispatch_scheme<false>(sc, [&](auto R, auto S) {
     if constexpr (decltype(R)::value <= 1) {
-      auto kern = k_hydro_stage3d<decltype(R)::value, decltype(S)::value>;
+      auto kern = k_hydro_stage3d<decltype(R)::value, decltype(S)::value, MASS>;
       static size_t granted = 64*1024;                 // per instantiation; raised once per size
       if (lds > granted) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1474,7 +1557,7 @@ static int launch_hydro_stage3d(const Geo &g, const Scheme &sc, const double *w0
         }
         granted = lds;
       }
-      kern<<<grid, block, lds, st>>>(g, sc.eos, w0, u, kA, kB, nchunk, ckl, tl.tw, tl.th);
+      kern<<<grid, block, lds, st>>>(g, sc.eos, w0, u, kA, kB, nchunk, ckl, tl.tw, tl.th, ms);
       return AKMI_COMPLETE;
     } else {
       set_error("hydro_stage3d: DC and PLM only");
@@ -1537,6 +1620,11 @@ k_c2p_shell(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ 
   if (efl) { u0[c + 4*cs] = ue; atomicAdd(&counters[1], 1); }
   if (tfl) { u0[c + 4*cs] = ue; atomicAdd(&counters[2], 1); }
   w0[c] = wd; w0[c + cs] = wvx; w0[c + 2*cs] = wvy; w0[c + 3*cs] = wvz; w0[c + 4*cs] = we;
+  for (int n = 5; n < g.nvar; ++n) {
+    double us = u0[c + n*cs];
+    if (us < 0.0) { us = 0.0; u0[c + n*cs] = 0.0; }
+    w0[c + n*cs] = us/ud;
+  }
 }
 
 template <bool MHD>
@@ -1552,6 +1640,18 @@ static int c2p_shell(const akmi_pack *p, double *u0, const double *bx1f, const d
   k_c2p_shell<MHD><<<grid, 256, 0, st>>>(g, eos, u0, bx1f, bx2f, bx3f, w0, bcc0, counters);
   AKMI_CHECK_LAUNCH("c2p_shell");
   return AKMI_COMPLETE;
+}
+
+// passive scalars of the planes [k0, k0+nk-1] (after the sweeps that left the mass fluxes of these cells)
+static int launch_scalars(const Geo &g, const Scheme &sc, const double *w0, const double *m1,
+                          const double *m2, const double *m3, const UpdArgs &u, int k0, int nk,
+                          hipStream_t st) {
+  dim3 grid((unsigned)(((long)(g.je - g.js + 1)*g.N1 + SX*SY - 1)/(SX*SY)), 1, nk*g.nmb), block(SX, SY);
+  return dispatch_recon(sc.recon, [&](auto R) {
+    k_scalar_update<decltype(R)::value><<<grid, block, 0, st>>>(g, sc.eos, w0, m1, m2, m3, u, k0, nk);
+    AKMI_CHECK_LAUNCH("scalar_update");
+    return AKMI_COMPLETE;
+  });
 }
 
 template <bool MHD>
@@ -1616,9 +1716,9 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
                         double *b1x3f, void *ws, const C2PArgs &cp_in, hipStream_t st,
                         int phases = AKMI_PHASE_ALL, const double *dt_dev = nullptr) {
   if (check_scheme(p, recon, "stage") != AKMI_COMPLETE) return AKMI_FAIL;
-  if (!p->is_ideal || p->nvar != 5) {
-    set_error("fused stage kernels are specialised for the ideal-gas variable set without passive "
-              "scalars; use the task-granular entries for eos = isothermal or nscalars > 0");
+  if (!p->is_ideal || p->nvar < 5) {
+    set_error("fused stage kernels are specialised for the ideal-gas variable set (passive scalars may "
+              "ride along); use the task-granular entries for eos = isothermal");
     return AKMI_FAIL;
   }
   Geo g = make_geo(p);
@@ -1661,6 +1761,8 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
                : launch_sweep<0, MHD, false>(g, sc, a1, st);
       if (rc == AKMI_COMPLETE) rc = launch_sweep_update<1, MHD>(g, sc, a2, u, st);
     }
+    if (rc == AKMI_COMPLETE && do_sweeps && g.nvar > 5)
+      rc = launch_scalars(g, sc, w0, w.flx1, w.flx2, w.flx3, u, g.ks, g.ke - g.ks + 1, st);
     if (rc != AKMI_COMPLETE) return rc;
     if (do_emf) {
       rc = akmi_mhd_corner_e(p, w0, bcc0, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5],
@@ -1731,7 +1833,8 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
     b3.kl = kA(s); b3.ku = kB(s) + 1;
     if (do_sweeps && !MHD && hyd_one && sc.recon <= 1 && hyd_tile(g.nx1, g.nx2).tw > 0) {
       // hydro DC/PLM: sweeps + update of the slab in one kernel
-      rc = launch_hydro_stage3d(g, sc, w0, u, kA(s), kB(s), st);
+      rc = g.nvar > 5 ? launch_hydro_stage3d<true>(g, sc, w0, u, kA(s), kB(s), st, Mass3{w.flx1, w.flx2, w.flx3})
+                      : launch_hydro_stage3d<false>(g, sc, w0, u, kA(s), kB(s), st, Mass3{nullptr, nullptr, nullptr});
     } else if (do_sweeps && MHD && x12) {
       // x1 sweep folded into the x2 march (no x1 flux array); x3 march consumes acc
       if constexpr (MHD) rc = launch_sweep12(g, sc, b1, b2, u, st);
@@ -1743,6 +1846,8 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
       if (rc == AKMI_COMPLETE) rc = launch_sweep_update<1, MHD, 1, false>(g, sc, b2, u, st);
       if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD, 0, true>(g, sc, b3, u, st);
     }
+    if (rc == AKMI_COMPLETE && do_sweeps && g.nvar > 5)
+      rc = launch_scalars(g, sc, w0, w.flx1, w.flx2, w.flx3, u, kA(s), kB(s) - kA(s) + 1, st);
     if (rc != AKMI_COMPLETE) return rc;
     if (two) {
       (void)hipEventRecord(g_ev[s], st);

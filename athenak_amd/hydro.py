@@ -93,7 +93,7 @@ class FluidBase:
                                 self.dx_dev.data_ptr(), e.gamma, e.dfloor, e.pfloor, e.tfloor,
                                 e.sfloor, e.sigma_max, e.iso_cs, 1 if e.is_ideal else 0)
         self.fused = pin.GetOrAddBoolean(blk, "fused_stage", True)
-        if not e.is_ideal or self.nscalars > 0:
+        if not e.is_ideal:
             # the fused stage kernels are specialised for the ideal-gas variable set; isothermal
             # runs and runs with passive scalars use the task-granular kernels (one kernel per task)
             self.fused = False

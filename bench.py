@@ -48,6 +48,8 @@ def parse():
                     help="reconstruction (default: the deck's plm); ppm4 = the numerics of BASELINE config 5")
     ap.add_argument("--ng", type=int, default=None, help="ghost cells (default 2; ppm4 needs >= 3)")
     ap.add_argument("--split", action="store_true", help="task-granular chain instead of fused stage")
+    ap.add_argument("--set", action="append", default=[], metavar="block/name=value",
+                    help="extra deck parameter (side measurements, e.g. mhd/nscalars=2); named in config.workload")
     ap.add_argument("--native", action="store_true",
                     help="drive the run from the C++ host (akmi_sim_*): Driver/TaskList in C++, halos and the dt "
                          "reduction through RCCL called directly (ncclSend/ncclRecv/ncclAllReduce); the roofline "
@@ -80,6 +82,10 @@ def make_pin(args, nblk):
     if args.ng or (args.recon in ("ppm4", "ppmx", "wenoz")):
         ov.append("mesh/nghost=%d" % (args.ng or 4))
     pin = load_deck(deck, ov)
+    for kv in args.set:                    # may add parameters the deck does not have
+        b, rest = kv.split("/", 1)
+        name, val = rest.split("=", 1)
+        pin.blocks.setdefault(b, {})[name] = val
     if args.split:
         pin.blocks[blk]["fused_stage"] = "false"
     return pin, blk
@@ -309,7 +315,9 @@ def main():
                                "under CornerE/CT and the interior c2p" % (
                                    "RCCL" if dist.get_backend() == "nccl" else dist.get_backend())},
                "roofline": roofline}
-        if world == 1 and not args.no_cpu_baseline:
+        if args.set:
+            out["config"]["workload"] += " + " + " ".join(args.set)
+        if world == 1 and not args.no_cpu_baseline and not args.set:
             out["cpu_baseline"] = cpu_baseline(args, blk)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -536,7 +536,7 @@ def test_task_mhd_fluxes_wild_states_isothermal(recon, rs):
         assert np.array_equal(h[k], dv[k].cpu().numpy()), k
 
 
-# ---- passive scalars (task-granular kernels) -----------------------------------------------
+# ---- passive scalars (fused stage + task-granular kernels) -----------------------------------------------
 @pytest.mark.parametrize("case", [
     ("sod", 32, 3, 16, 4, dict(cfl=0.3, recon="plm", rsolver="hllc")),
     ("sod", 64, 1, 32, 8, dict(cfl=0.3, ng=3, recon="wenoz", rsolver="roe")),
@@ -546,7 +546,8 @@ def test_task_mhd_fluxes_wild_states_isothermal(recon, rs):
                                             extra=["problem/along_x1=true", "mhd/eos=isothermal"])),
 ], ids=lambda c: "%s-%d^%d-%s" % (c[0], c[1], c[2], c[5]["rsolver"]))
 @pytest.mark.parametrize("native", [False, True], ids=["py", "cpp"])
-def test_passive_scalars(case, native):
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "split"])
+def test_passive_scalars(case, native, fused):
     """two passive scalars (hydro_fluxes.cpp:135-147, ideal_hyd.cpp:94-101): s0 == 1, s1 = a
     profile.  Bit-identical to the oracle, and the mass density of scalar 0 stays bit-identical to
     the density itself (its flux is the mass flux times exactly 1)."""
@@ -555,7 +556,9 @@ def test_passive_scalars(case, native):
     blk = "hydro" if problem in ("linear_wave_hydro", "sod") else "mhd"
     kw = dict(kw)
     kw["extra"] = list(kw.get("extra", [])) + ["%s/nscalars=2" % blk]
-    sim, osim, is_mhd = pu.make_pair(problem, n, dims, mb, native=native, **kw)
+    # fused: the scalars ride along with the fused stage kernels (k_scalar_update; ideal gas only, the
+    # isothermal case stays on the task-granular kernels either way)
+    sim, osim, is_mhd = pu.make_pair(problem, n, dims, mb, native=native, fused=fused, **kw)
     u = osim.array("u0")
     nf = u.shape[1] - 2
     prof = 0.5 + 0.25*np.sin(np.arange(u[:, 0].size, dtype=np.float64)*0.37).reshape(u[:, 0].shape)
