@@ -186,8 +186,16 @@ def make_pair(problem, n, dims, mb=None, inject=True, fused=None, native=False, 
     return sim, osim, is_mhd
 
 
-def compare_run(problem, n, dims, mb=None, cycles=2, inject=True, fused=None, native=False, **kw):
+def compare_run(problem, n, dims, mb=None, cycles=2, inject=True, fused=None, native=False, keep=False, **kw):
     sim, osim, is_mhd = make_pair(problem, n, dims, mb, inject, fused, native, **kw)
+    totals0 = None
+    if keep:        # volume-weighted totals of the conserved variables before the first cycle
+        import numpy as _np
+        ind = sim.pmesh.mb_indcs
+        dx = _np.asarray(sim.pmesh.pmb_pack.pmb.dx)
+        vol = (dx[:, 0]*dx[:, 1]*dx[:, 2])[:, None]
+        a = sim.phys.u0[:, :, ind.ks:ind.ke + 1, ind.js:ind.je + 1, ind.is_:ind.ie + 1]
+        totals0 = (a.sum(dim=(2, 3, 4)).cpu().numpy()*vol).sum(axis=0)
     done = 0
     for _ in range(cycles):
         a = sim.Execute(max_cycles=1)
@@ -197,6 +205,9 @@ def compare_run(problem, n, dims, mb=None, cycles=2, inject=True, fused=None, na
         done += 1
     diffs = compare_fields(product_arrays(sim), oracle_arrays(osim, is_mhd), is_mhd)
     vals = [v for k, v in diffs.items() if k != "bitwise_equal"]
-    return {"diffs": diffs, "max_rel_l1": max(vals), "cycles": done,
-            "time": (sim.pmesh.time, osim.time), "dt": (sim.pmesh.dt, osim.dt),
-            "bitwise_equal": diffs["bitwise_equal"]}
+    out = {"diffs": diffs, "max_rel_l1": max(vals), "cycles": done,
+           "time": (sim.pmesh.time, osim.time), "dt": (sim.pmesh.dt, osim.dt),
+           "bitwise_equal": diffs["bitwise_equal"]}
+    if keep:
+        out["sim"], out["totals0"] = sim, totals0
+    return out

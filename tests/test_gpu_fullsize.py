@@ -125,3 +125,30 @@ def test_c2_hydro_128_fused_equals_task_path():
     assert torch.equal(_global(s8, s8.phys.u0), _global(sf, sf.phys.u0))
     # mass leaves only through the x1 outflow faces; the transverse momenta stay exactly zero
     assert float(sf.phys.u0[:, 2:4].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("native", [False, True], ids=["py", "cpp"])
+def test_c5_blast_smr_at_deck_size_is_bit_identical(native):
+    """BASELINE config 5 as the deck ships it -- 64^3 root grid in 16^3 MeshBlocks, the centre refined by one
+    level (120 blocks on two levels), PPM4 + HLLD + CT, ng = 4 -- is small enough for the oracle: the HIP path
+    through either host equals it bit for bit after 4 cycles, with the same dt sequence; div B stays at
+    round-off on every block and mass / energy are conserved across the fine/coarse faces"""
+    import torch
+    r = pu.compare_run("blast_smr", (64, 64, 64), 3, (16, 16, 16), cycles=4, native=native, keep=True)
+    assert r["cycles"] == 4 and r["bitwise_equal"], r.get("diffs")
+    assert r["time"][0] == r["time"][1] and r["dt"][0] == r["dt"][1]
+    sim = r["sim"]
+    pm = sim.pmesh
+    assert pm.nmb_total == 120 and sorted(set(int(l) for l in pm.pmb_pack.pmb.mb_lev)) == [pm.root_level, pm.root_level + 1]
+    ph, ind = sim.phys, pm.mb_indcs
+    k, j, i = slice(ind.ks, ind.ke + 1), slice(ind.js, ind.je + 1), slice(ind.is_, ind.ie + 1)
+    k1, j1, i1 = slice(ind.ks + 1, ind.ke + 2), slice(ind.js + 1, ind.je + 2), slice(ind.is_ + 1, ind.ie + 2)
+    dx = torch.as_tensor(np.asarray(pm.pmb_pack.pmb.dx), device="cuda")          # per block
+    d = ((ph.b0.x1f[:, k, j, i1] - ph.b0.x1f[:, k, j, i])/dx[:, 0, None, None, None] +
+         (ph.b0.x2f[:, k, j1, i] - ph.b0.x2f[:, k, j, i])/dx[:, 1, None, None, None] +
+         (ph.b0.x3f[:, k1, j, i] - ph.b0.x3f[:, k, j, i])/dx[:, 2, None, None, None])
+    assert float(d.abs().max()) <= 2e-11          # test_nr_divb_amr_mpicpu.py:38-40
+    vol = (dx[:, 0]*dx[:, 1]*dx[:, 2])[:, None]
+    tot = (ph.u0[:, :, k, j, i].sum(dim=(2, 3, 4))*vol).sum(dim=0).cpu().numpy()
+    tot0 = r["totals0"]
+    assert np.all(np.abs(tot - tot0) <= 1e-12*np.maximum(1.0, np.abs(tot0))), (tot, tot0)
