@@ -104,6 +104,25 @@ inline int dispatch_scheme(const Scheme &sc, F &&f) {
   });
 }
 
+// the fused stage kernels: the isothermal solvers are RS + 10 (rs_iso<RS>(), akmi_numerics.hpp)
+template <bool MHD, class F>
+inline int dispatch_scheme_eos(const Scheme &sc, F &&f) {
+  if (!sc.iso) return dispatch_scheme<MHD>(sc, f);
+  return dispatch_recon(sc.recon, [&](auto R) {
+    const int rs = sc.rsolver;
+    if (rs == AKMI_RS_LLF) return f(R, IC<10>{});
+    if (rs == AKMI_RS_HLLE) return f(R, IC<11>{});
+    if constexpr (MHD) {
+      if (rs == AKMI_RS_HLLD) return f(R, IC<13>{});
+      set_error("<mhd> rsolver = %d not implemented for the isothermal EOS (llf, hlle, hlld)", rs);
+    } else {
+      if (rs == AKMI_RS_ROE) return f(R, IC<14>{});
+      set_error("<hydro> rsolver = %d not implemented for the isothermal EOS (llf, hlle, roe)", rs);
+    }
+    return (int)AKMI_FAIL;
+  });
+}
+
 inline int check_scheme(const akmi_pack *p, int recon, const char *who) {
   if (p->nvar < (p->is_ideal ? 5 : 4)) {
     set_error("%s: nvar = %d is smaller than the fluid variable set of the EOS (5 ideal gas, 4 "

@@ -394,9 +394,9 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
     dtmin_cond.Realloc(1);                                   // scratch double of the cell reductions
   }
   fused = pin->GetOrAddBoolean(blk, "fused_stage", true);
-  // the fused stage kernels are specialised for the ideal-gas variable set (passive scalars ride along)
-  // without extra fluxes
-  if (!e.is_ideal || has_visc || has_cond || has_resist) fused = false;
+  // the fused stage kernels cover both equations of state and carry passive scalars along; extra fluxes
+  // (diffusion), FOFC and refined meshes use the task-granular kernels
+  if (has_visc || has_cond || has_resist) fused = false;
   pack_c.nmb = pp->nmb_thispack; pack_c.nvar = nvars;
   pack_c.nx1 = ind.nx1; pack_c.nx2 = ind.nx2; pack_c.nx3 = ind.nx3; pack_c.ng = ind.ng;
   pack_c.dx = pp->pmb->d_dx.p;

@@ -1208,6 +1208,29 @@ AKMI_DEV Cons1D riemann_mhd_iso(const FaceEos &eos, double ld, double lx, double
   else return hlld_iso(eos.iso_cs, eos.dfloor, ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
 }
 
+// The fused stage kernels carry the equation of state in their Riemann-solver template parameter:
+// RS >= 10 is the isothermal solver RS - 10 (llf 10, hlle 11, hlld 13, roe 14).  Isothermal states
+// have no energy variable: slot 4 of the kernels' variable arrays stays unused (rs_iso<RS>()).
+template <int RS> constexpr bool rs_iso() { return RS >= 10; }
+template <int RS, bool EO = false>
+AKMI_DEV Cons1D riemann_mhd_e(const FaceEos &eos, double ld, double lx, double ly, double lz, double le,
+                              double lby, double lbz, double rd, double rx, double ry, double rz,
+                              double re, double rby, double rbz, double bxi) {
+  if constexpr (RS >= 10) return riemann_mhd_iso<RS - 10>(eos, ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
+  else return riemann_mhd<RS, EO>(eos.gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
+}
+template <int RS>
+AKMI_DEV void riemann_hyd_e(const FaceEos &eos, double ld, double lx, double ly, double lz, double le,
+                            double rd, double rx, double ry, double rz, double re, double &f_d,
+                            double &f_mx, double &f_my, double &f_mz, double &f_e) {
+  if constexpr (RS >= 10) {
+    riemann_hyd_iso<RS - 10>(eos.iso_cs, ld, lx, ly, lz, rd, rx, ry, rz, f_d, f_mx, f_my, f_mz);
+    f_e = 0.0;
+  } else {
+    riemann_hyd<RS>(eos.gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, f_d, f_mx, f_my, f_mz, f_e);
+  }
+}
+
 // EOS_Data by value (src/eos/eos.hpp:27-34)
 struct Eos {
   double gamma, dfloor, pfloor, tfloor, sfloor, sigma_max, iso_cs;

@@ -79,7 +79,8 @@ __device__ __forceinline__ void face_flux(const Geo &g, const FaceEos &eos,
   face_states_u<RECON, 0>(q + ivx*cs, off, s, eos, lx, rx);
   face_states_u<RECON, 0>(q + ivy*cs, off, s, eos, ly, ry);
   face_states_u<RECON, 0>(q + ivz*cs, off, s, eos, lz, rz);
-  face_states_u<RECON, 2>(q + 4*cs, off, s, eos, le, re);
+  if constexpr (rs_iso<RS>()) { le = re = 0.0; }           // isothermal: no energy variable
+  else face_states_u<RECON, 2>(q + 4*cs, off, s, eos, le, re);
   if constexpr (MHD) {
     constexpr int iby = (DIR + 1)%3, ibz = (DIR + 2)%3;
     const double *b = bcc0 + (size_t)m*3*cs;
@@ -87,11 +88,10 @@ __device__ __forceinline__ void face_flux(const Geo &g, const FaceEos &eos,
     face_states_u<RECON, 0>(b + iby*cs, off, s, eos, lby, rby);
     face_states_u<RECON, 0>(b + ibz*cs, off, s, eos, lbz, rbz);
     const double bxi = bxf[ix4(f3, f2, f1, m, k, j, i)];
-    Cons1D fl = riemann_mhd<RS>(eos.gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby,
-                                rbz, bxi);
+    Cons1D fl = riemann_mhd_e<RS>(eos, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
     fd = fl.d; fx = fl.mx; fy = fl.my; fz = fl.mz; fe = fl.e; fby = fl.by; fbz = fl.bz;
   } else {
-    riemann_hyd<RS>(eos.gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, fd, fx, fy, fz, fe);
+    riemann_hyd_e<RS>(eos, ld, lx, ly, lz, le, rd, rx, ry, rz, re, fd, fx, fy, fz, fe);
     fby = fbz = 0.0;
   }
 }
@@ -148,6 +148,7 @@ __device__ __forceinline__ void sweep_x1_shared(const Geo &g, const FaceEos &eos
     const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
+      if (rs_iso<RS>() && n == 4) continue;             // isothermal: slot 4 (energy) stays unused
       const double *q = (n < 5) ? a.w0 + c + n*cs
                                 : a.bcc0 + ix5(3, g.N3, g.N2, g.N1, m, n - 4, k, j, i);   // by, bz
       const double qm = q[-1], q0 = q[0], qp = q[1];
@@ -176,16 +177,17 @@ __device__ __forceinline__ void sweep_x1_shared(const Geo &g, const FaceEos &eos
   double fd, fx, fy, fz, fe, fby = 0.0, fbz = 0.0;
   if constexpr (MHD) {
     const double bxi = a.bxf[ix4(a.f3, a.f2, a.f1, m, k, j, i)];
-    Cons1D fl = riemann_mhd<RS, true>(eos.gamma, L[0], L[1], L[2], L[3], L[4], L[5], L[6], qr[0], qr[1],
-                                      qr[2], qr[3], qr[4], qr[5], qr[6], bxi);
+    Cons1D fl = riemann_mhd_e<RS, true>(eos, L[0], L[1], L[2], L[3], L[4], L[5], L[6], qr[0], qr[1],
+                                        qr[2], qr[3], qr[4], qr[5], qr[6], bxi);
     fd = fl.d; fx = fl.mx; fy = fl.my; fz = fl.mz; fe = fl.e; fby = fl.by; fbz = fl.bz;
   } else {
-    riemann_hyd<RS>(eos.gamma, L[0], L[1], L[2], L[3], L[4], qr[0], qr[1], qr[2], qr[3], qr[4], fd,
-                    fx, fy, fz, fe);
+    riemann_hyd_e<RS>(eos, L[0], L[1], L[2], L[3], L[4], qr[0], qr[1], qr[2], qr[3], qr[4], fd,
+                      fx, fy, fz, fe);
   }
   const size_t fs = (size_t)a.f3*a.f2*a.f1;
   double *f = a.flx + ix5(g.nvar, a.f3, a.f2, a.f1, m, 0, k, j, i);
-  f[0] = fd; f[fs] = fx; f[2*fs] = fy; f[3*fs] = fz; f[4*fs] = fe;
+  f[0] = fd; f[fs] = fx; f[2*fs] = fy; f[3*fs] = fz;
+  if constexpr (!rs_iso<RS>()) f[4*fs] = fe;
   if constexpr (MHD) {
     const size_t ec = ix4(g.N3, g.N2, g.N1, m, k, j, i);
     a.ey[ec] = -fby;
@@ -227,7 +229,8 @@ k_sweep(Geo g, FaceEos eos, SweepArgs a, int nk) {
                                  fx, fy, fz, fe, fby, fbz);
   const size_t fs = (size_t)a.f3*a.f2*a.f1;
   double *f = a.flx + ix5(g.nvar, a.f3, a.f2, a.f1, m, 0, k, j, i);
-  f[0] = fd; f[ivx*fs] = fx; f[ivy*fs] = fy; f[ivz*fs] = fz; f[4*fs] = fe;
+  f[0] = fd; f[ivx*fs] = fx; f[ivy*fs] = fy; f[ivz*fs] = fz;
+  if constexpr (!rs_iso<RS>()) f[4*fs] = fe;
   if constexpr (MHD) {
     const size_t ec = ix4(g.N3, g.N2, g.N1, m, k, j, i);
     a.ey[ec] = -fby;
@@ -387,6 +390,7 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
   constexpr int ivx = 1 + DIR, ivy = 1 + (DIR + 1)%3, ivz = 1 + (DIR + 2)%3;
   constexpr int iby = (DIR + 1)%3, ibz = (DIR + 2)%3;
   constexpr int NV = MHD ? 7 : 5;
+  constexpr bool ISO = rs_iso<RS>();       // slot 4 (energy) of the variable arrays unused
   constexpr int NW = RollCfg<RECON>::NW;
   constexpr int NT = SX*SY;
   // marching state of this thread, parked in LDS ("LDS as an extension of the register file":
@@ -420,6 +424,7 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
   // prime the window: left state of the first face comes from cell s0-1
 #pragma unroll
   for (int n = 0; n < NV; ++n) {
+    if (ISO && n == 4) continue;
     const double *q = base(n) + off;
     double pl, dummy;
     if constexpr (RECON == 1) {
@@ -447,6 +452,7 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
     double L[NV], R[NV];
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
+      if (ISO && n == 4) { L[n] = R[n] = 0.0; continue; }      // isothermal: no energy variable
       const double *q = base(n) + off;
       double qln;
       L[n] = PL_(n);
@@ -482,10 +488,10 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
       if (upd) {
         const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, sc, j, i);
 #pragma unroll
-        for (int n = 0; n < 5; ++n) { pa[n] = u.acc[c + n*cs]; pu[n] = u.u0[c + n*cs]; }
+        for (int n = 0; n < 5; ++n) { if (ISO && n == 4) continue; pa[n] = u.acc[c + n*cs]; pu[n] = u.u0[c + n*cs]; }
         if (AKMI_PREFETCH_U1 && !u.copy_u1) {
 #pragma unroll
-          for (int n = 0; n < 5; ++n) pu1[n] = u.u1[c + n*cs];
+          for (int n = 0; n < 5; ++n) { if (ISO && n == 4) continue; pu1[n] = u.u1[c + n*cs]; }
         }
       }
     }
@@ -497,6 +503,7 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
         const size_t fs1 = (size_t)g.N3*g.N2*(g.N1 + 1);
 #pragma unroll
         for (int n = 0; n < 5; ++n) {
+          if (ISO && n == 4) continue;
           const double d1 = u.flx1[c + n*fs1 + 1] - u.flx1[c + n*fs1];
           pa[n] = p2 ? d1*rdx1 : d1/dx1;
         }
@@ -504,8 +511,8 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
     }
     double fd, fx, fy, fz, fe;
     if constexpr (MHD) {
-      Cons1D fl = riemann_mhd<RS>(eos.gamma, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1],
-                                  R[2], R[3], R[4], R[5], R[6], pbx[(size_t)t*fst]);
+      Cons1D fl = riemann_mhd_e<RS>(eos, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1],
+                                    R[2], R[3], R[4], R[5], R[6], pbx[(size_t)t*fst]);
       fd = fl.d; fx = fl.mx; fy = fl.my; fz = fl.mz; fe = fl.e;
       if (t < ml || s == shi) {
         // CornerE needs the sign of the mass flux and the two face EMFs of this direction
@@ -515,10 +522,10 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
         a.ez[ec] = fl.bz;
       }
     } else {
-      riemann_hyd<RS>(eos.gamma, L[0], L[1], L[2], L[3], L[4], R[0], R[1], R[2], R[3], R[4], fd, fx,
-                      fy, fz, fe);
+      riemann_hyd_e<RS>(eos, L[0], L[1], L[2], L[3], L[4], R[0], R[1], R[2], R[3], R[4], fd, fx,
+                        fy, fz, fe);
       // passive scalars are advected by the mass flux (k_scalar_update): keep it
-      if (g.nvar > 5 && (t < ml || s == shi)) a.flx[ix5(g.nvar, a.f3, a.f2, a.f1, m, 0, k, j, i)] = fd;
+      if (g.nvar > (ISO ? 4 : 5) && (t < ml || s == shi)) a.flx[ix5(g.nvar, a.f3, a.f2, a.f1, m, 0, k, j, i)] = fd;
     }
     double fv[5];
     fv[0] = fd; fv[ivx] = fx; fv[ivy] = fy; fv[ivz] = fz; fv[4] = fe;
@@ -527,6 +534,7 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
       const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, kc, jc, i);
 #pragma unroll
       for (int n = 0; n < 5; ++n) {
+        if (ISO && n == 4) continue;
         const double fprev = FP_(n);
         double divf;
         if constexpr (PRE || PRE1) {
@@ -562,7 +570,7 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
       }
     }
 #pragma unroll
-    for (int n = 0; n < 5; ++n) FP_(n) = fv[n];
+    for (int n = 0; n < 5; ++n) { if (ISO && n == 4) continue; FP_(n) = fv[n]; }
   }
 #undef W_
 #undef PL_
@@ -614,6 +622,10 @@ __device__ __forceinline__ void cell_lr_x1(const double *__restrict__ q, const F
   }
 }
 
+// the kernel is an experiment that lost (see stage_update): instantiated only with -DAKMI_X12_BUILD=1
+#ifndef AKMI_X12_BUILD
+#define AKMI_X12_BUILD 0
+#endif
 #ifndef AKMI_X12_WAVES
 #define AKMI_X12_WAVES 3
 #endif
@@ -815,7 +827,7 @@ k_sweep_update_1d(Geo g, FaceEos eos, SweepArgs a, UpdArgs u) {
       a.ey[ec] = -fby;
       a.ez[ec] = fbz;
     } else {
-      if (g.nvar > 5) a.flx[ix5(g.nvar, a.f3, a.f2, a.f1, m, 0, k, j, i)] = fd;
+      if (g.nvar > (rs_iso<RS>() ? 4 : 5)) a.flx[ix5(g.nvar, a.f3, a.f2, a.f1, m, 0, k, j, i)] = fd;
     }
   }
   const double fv[5] = {fd, fx, fy, fz, fe};
@@ -828,6 +840,7 @@ k_sweep_update_1d(Geo g, FaceEos eos, SweepArgs a, UpdArgs u) {
   const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
 #pragma unroll
   for (int n = 0; n < 5; ++n) {
+    if (rs_iso<RS>() && n == 4) continue;            // isothermal: no energy variable
     const double divf = (sF[n][threadIdx.x + 1] - fv[n])/dx1;
     const double u0v = u.u0[c + n*cs];
     const double u1v = u.copy_u1 ? u0v : u.u1[c + n*cs];
@@ -845,7 +858,9 @@ k_sweep_update_1d(Geo g, FaceEos eos, SweepArgs a, UpdArgs u) {
 template <int RECON>
 __global__ void __launch_bounds__(SX*SY)
 k_scalar_update(Geo g, FaceEos eos, const double *__restrict__ w0, const double *__restrict__ m1,
-                const double *__restrict__ m2, const double *__restrict__ m3, UpdArgs u, int k0, int nk) {
+                const double *__restrict__ m2, const double *__restrict__ m3, UpdArgs u, int k0, int nk,
+                int nf) {
+  // nf: number of fluid variables (5 ideal gas, 4 isothermal); the scalars follow them
   const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;   // rows [js,je] x N1
   const int jj = (int)(p/g.N1);
   const int i = (int)(p - (long)jj*g.N1);
@@ -868,7 +883,7 @@ k_scalar_update(Geo g, FaceEos eos, const double *__restrict__ w0, const double 
     f3h = m3[ix5(g.nvar, g.N3 + 1, g.N2, g.N1, m, 0, k + 1, j, i)];
   }
   const long s2 = g.N1, s3 = (long)g.N1*g.N2;
-  for (int n = 5; n < g.nvar; ++n) {
+  for (int n = nf; n < g.nvar; ++n) {
     const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, n, k, j, i);
     const double *q = w0 + c;
     double sl, sr;
@@ -1145,6 +1160,23 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+// SingleC2P_IsothermalHyd / _IsothermalMHD (isothermal_hyd.cpp:30-45, isothermal_mhd.cpp:32-47; density
+// floor fmax(dfloor, b^2/sigma_max) :104-106): no energy variable, scalars from variable 4 without a floor
+template <bool MHD>
+__device__ __forceinline__ void c2p_iso_cell(const Geo &g, const Eos &eos, double *__restrict__ u0,
+                                             double *__restrict__ w0, size_t c, size_t cs, double ubx,
+                                             double uby, double ubz, int *__restrict__ counters, double &wd,
+                                             double &wvx, double &wvy, double &wvz) {
+  double ud = u0[c];
+  double dfloor_ = eos.dfloor;
+  if constexpr (MHD) dfloor_ = fmax(eos.dfloor, (sqr(ubx) + sqr(uby) + sqr(ubz))/eos.sigma_max);
+  if (ud < dfloor_) { ud = dfloor_; u0[c] = ud; atomicAdd(&counters[0], 1); }
+  const double di = 1.0/ud;
+  wd = ud; wvx = di*u0[c + cs]; wvy = di*u0[c + 2*cs]; wvz = di*u0[c + 3*cs];
+  w0[c] = wd; w0[c + cs] = wvx; w0[c + 2*cs] = wvy; w0[c + 3*cs] = wvz;
+  for (int n = 4; n < g.nvar; ++n) w0[c + n*cs] = u0[c + n*cs]/ud;
+}
+
 template <bool MHD>
 __global__ void __launch_bounds__(SX*SY)
 k_c2p_newdt(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ bx1f,
@@ -1164,9 +1196,7 @@ k_c2p_newdt(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ 
   if (j <= ju && i >= il && i <= iu) {
     const size_t cs = (size_t)g.N3*g.N2*g.N1;
     const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
-    double ud = u0[c], umx = u0[c + cs], umy = u0[c + 2*cs], umz = u0[c + 3*cs], ue = u0[c + 4*cs];
-    double wd, wvx, wvy, wvz, we, ubx = 0, uby = 0, ubz = 0;
-    bool dfl = false, efl = false, tfl = false;
+    double wd, wvx, wvy, wvz, we = 0.0, ubx = 0, uby = 0, ubz = 0;
     if constexpr (MHD) {
       ubx = 0.5*(bx1f[ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i)] +
                  bx1f[ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i + 1)]);
@@ -1174,9 +1204,26 @@ k_c2p_newdt(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ 
                  bx2f[ix4(g.N3, g.N2 + 1, g.N1, m, k, j + 1, i)]);
       ubz = 0.5*(bx3f[ix4(g.N3 + 1, g.N2, g.N1, m, k, j, i)] +
                  bx3f[ix4(g.N3 + 1, g.N2, g.N1, m, k + 1, j, i)]);
-      c2p_mhd(eos, ud, umx, umy, umz, ue, ubx, uby, ubz, wd, wvx, wvy, wvz, we, dfl, efl, tfl);
       const size_t b = ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i);
       bcc0[b] = ubx; bcc0[b + cs] = uby; bcc0[b + 2*cs] = ubz;
+    }
+    const bool scan = do_newdt && i >= g.is && i <= g.ie && j >= g.js && j <= g.je && k >= g.ks && k <= g.ke;
+    if (!eos.is_ideal) {
+      c2p_iso_cell<MHD>(g, eos, u0, w0, c, cs, ubx, uby, ubz, counters, wd, wvx, wvy, wvz);
+      if (scan) {                             // hydro_newdt.cpp:109-111, mhd_newdt.cpp:137-144
+        if constexpr (MHD) {
+          mv1 = fabs(wvx) + fast_speed_iso(eos.iso_cs, wd, ubx, uby, ubz);
+          mv2 = fabs(wvy) + fast_speed_iso(eos.iso_cs, wd, uby, ubz, ubx);
+          mv3 = fabs(wvz) + fast_speed_iso(eos.iso_cs, wd, ubz, ubx, uby);
+        } else {
+          mv1 = fabs(wvx) + eos.iso_cs; mv2 = fabs(wvy) + eos.iso_cs; mv3 = fabs(wvz) + eos.iso_cs;
+        }
+      }
+    } else {
+    double ud = u0[c], umx = u0[c + cs], umy = u0[c + 2*cs], umz = u0[c + 3*cs], ue = u0[c + 4*cs];
+    bool dfl = false, efl = false, tfl = false;
+    if constexpr (MHD) {
+      c2p_mhd(eos, ud, umx, umy, umz, ue, ubx, uby, ubz, wd, wvx, wvy, wvz, we, dfl, efl, tfl);
     } else {
       c2p_hyd(eos, ud, umx, umy, umz, ue, wd, wvx, wvy, wvz, we, dfl, efl, tfl);
     }
@@ -1189,7 +1236,7 @@ k_c2p_newdt(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ 
       if (us < 0.0) { us = 0.0; u0[c + n*cs] = 0.0; }
       w0[c + n*cs] = us/ud;
     }
-    if (do_newdt && i >= g.is && i <= g.ie && j >= g.js && j <= g.je && k >= g.ks && k <= g.ke) {
+    if (scan) {
       // hydro_newdt.cpp:97-118 / mhd_newdt.cpp:123-136
       const double pr = (eos.gamma - 1.0)*we;
       if constexpr (MHD) {
@@ -1200,6 +1247,7 @@ k_c2p_newdt(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ 
         const double cs_ = sqrt(eos.gamma*pr/wd);
         mv1 = fabs(wvx) + cs_; mv2 = fabs(wvy) + cs_; mv3 = fabs(wvz) + cs_;
       }
+    }
     }
   }
   if (!do_newdt) return;        // uniform across the grid
@@ -1271,6 +1319,8 @@ __global__ void __launch_bounds__(HS_THREADS, AKMI_HS_WAVES)
 k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, int kA, int kB,
                 int nchunk, int ckl, int tw, int th, Mass3 ms) {
   static_assert(RECON <= 1, "one-kernel hydro stage: DC and PLM");
+  constexpr bool ISO = rs_iso<RS>();        // isothermal: variable 4 (energy) does not exist; its slots stay unused
+#define ISOSKIP if (ISO && n == 4) continue
   extern __shared__ double hs_lds[];
   const int pw = tw + 3, ph = th + 3;        // plane with halo: cols i0-2..i0+tw, rows j0-2..j0+th
   const int swn = 5*ph*pw, sfn = 5*th*tw;
@@ -1308,6 +1358,7 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
   double W0[5], W1[5], PL[5], F3p[5], hv[5];
 #pragma unroll
   for (int n = 0; n < 5; ++n) {
+      ISOSKIP;
     const double *q = wb + n*cs + col;
     W0[n] = cell_ok ? q[(size_t)(k0 - 1)*ps] : 1.0;
     W1[n] = cell_ok ? q[(size_t)k0*ps] : 1.0;
@@ -1328,21 +1379,23 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
     const bool plane = k > k0;                        // workgroup-uniform
     double wp[5];
 #pragma unroll
-    for (int n = 0; n < 5; ++n) wp[n] = cell_ok ? wb[n*cs + (size_t)(k + 1)*ps + col] : 1.0;
+    for (int n = 0; n < 5; ++n) { ISOSKIP; wp[n] = cell_ok ? wb[n*cs + (size_t)(k + 1)*ps + col] : 1.0; }
     double pu0[5], pu1[5];
     if (plane && own) {                               // operands of the update, used after the solves
       const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k - 1, j, i);
 #pragma unroll
       for (int n = 0; n < 5; ++n) {
+      ISOSKIP;
         pu0[n] = u.u0[c + n*cs];
         pu1[n] = u.copy_u1 ? 0.0 : u.u1[c + n*cs];
       }
     }
     if (plane && in_tile) {
       {  // low x1 face of this position: cells i-2..i+1 of row j
-        double L[5], R[5];
+        double L[5] = {0, 0, 0, 0, 0}, R[5] = {0, 0, 0, 0, 0};
 #pragma unroll
         for (int n = 0; n < 5; ++n) {
+      ISOSKIP;
           const double qm2 = SW(b, n, r + 2, t), qm1 = SW(b, n, r + 2, t + 1),
                        q0 = SW(b, n, r + 2, t + 2), qp1 = SW(b, n, r + 2, t + 3);
           if constexpr (RECON == 1) {
@@ -1354,7 +1407,7 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
           }
         }
         double fd, fx, fy, fz, fe;
-        riemann_hyd<RS>(eos.gamma, L[0], L[1], L[2], L[3], L[4], R[0], R[1], R[2], R[3], R[4], fd, fx,
+        riemann_hyd_e<RS>(eos, L[0], L[1], L[2], L[3], L[4], R[0], R[1], R[2], R[3], R[4], fd, fx,
                         fy, fz, fe);
         SF1(b, 0, r, t) = fd; SF1(b, 1, r, t) = fx; SF1(b, 2, r, t) = fy; SF1(b, 3, r, t) = fz;
         SF1(b, 4, r, t) = fe;
@@ -1363,9 +1416,10 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
         }
       }
       {  // low x2 face: cells j-2..j+1 of column i; sweep-aligned order (d, vy, vz, vx, e)
-        double L[5], R[5];
+        double L[5] = {0, 0, 0, 0, 0}, R[5] = {0, 0, 0, 0, 0};
 #pragma unroll
         for (int n = 0; n < 5; ++n) {
+      ISOSKIP;
           const double qm2 = SW(b, n, r, t + 2), qm1 = SW(b, n, r + 1, t + 2),
                        q0 = SW(b, n, r + 2, t + 2), qp1 = SW(b, n, r + 3, t + 2);
           if constexpr (RECON == 1) {
@@ -1377,7 +1431,7 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
           }
         }
         double fd, fx, fy, fz, fe;
-        riemann_hyd<RS>(eos.gamma, L[0], L[2], L[3], L[1], L[4], R[0], R[2], R[3], R[1], R[4], fd, fx,
+        riemann_hyd_e<RS>(eos, L[0], L[2], L[3], L[1], L[4], R[0], R[2], R[3], R[1], R[4], fd, fx,
                         fy, fz, fe);
         SF2(b, 0, r, t) = fd; SF2(b, 2, r, t) = fx; SF2(b, 3, r, t) = fy; SF2(b, 1, r, t) = fz;
         SF2(b, 4, r, t) = fe;
@@ -1389,9 +1443,10 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
     // x3 face below cell k: sweep-aligned order (d, vz, vx, vy, e)
     double f3[5];
     {
-      double L[5], R[5];
+      double L[5] = {0, 0, 0, 0, 0}, R[5] = {0, 0, 0, 0, 0};
 #pragma unroll
       for (int n = 0; n < 5; ++n) {
+      ISOSKIP;
         if constexpr (RECON == 1) {
           double qln;
           L[n] = PL[n];
@@ -1402,7 +1457,7 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
         }
       }
       double fd, fx, fy, fz, fe;
-      riemann_hyd<RS>(eos.gamma, L[0], L[3], L[1], L[2], L[4], R[0], R[3], R[1], R[2], R[4], fd, fx, fy,
+      riemann_hyd_e<RS>(eos, L[0], L[3], L[1], L[2], L[4], R[0], R[3], R[1], R[2], R[4], fd, fx, fy,
                       fz, fe);
       f3[0] = fd; f3[3] = fx; f3[1] = fy; f3[2] = fz; f3[4] = fe;
       if constexpr (MASS) {
@@ -1412,14 +1467,14 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
     if (k <= k1) {                                     // plane k for the next step
       if (in_tile) {
 #pragma unroll
-        for (int n = 0; n < 5; ++n) SW(b ^ 1, n, r + 2, t + 2) = W1[n];
+        for (int n = 0; n < 5; ++n) { ISOSKIP; SW(b ^ 1, n, r + 2, t + 2) = W1[n]; }
       }
       if (hy >= 0) {
 #pragma unroll
-        for (int n = 0; n < 5; ++n) SW(b ^ 1, n, hy, hx) = hv[n];
+        for (int n = 0; n < 5; ++n) { ISOSKIP; SW(b ^ 1, n, hy, hx) = hv[n]; }
         if (k + 1 <= k1) {
 #pragma unroll
-          for (int n = 0; n < 5; ++n) hv[n] = wb[n*cs + (size_t)(k + 1)*ps + hcol];
+          for (int n = 0; n < 5; ++n) { ISOSKIP; hv[n] = wb[n*cs + (size_t)(k + 1)*ps + hcol]; }
         }
       }
     }
@@ -1428,6 +1483,7 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
       const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k - 1, j, i);
 #pragma unroll
       for (int n = 0; n < 5; ++n) {
+      ISOSKIP;
         double divf = (SF1(b, n, r, t + 1) - SF1(b, n, r, t))/dx1;
         divf += (SF2(b, n, r + 1, t) - SF2(b, n, r, t))/dx2;
         divf += (f3[n] - F3p[n])/dx3;
@@ -1438,11 +1494,13 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
       }
     }
 #pragma unroll
-    for (int n = 0; n < 5; ++n) { F3p[n] = f3[n]; W0[n] = W1[n]; W1[n] = wp[n]; }
+    for (int n = 0; n < 5; ++n) {
+      ISOSKIP; F3p[n] = f3[n]; W0[n] = W1[n]; W1[n] = wp[n]; }
   }
 #undef SW
 #undef SF1
 #undef SF2
+#undef ISOSKIP
 }
 
 __global__ void k_init_dt3(double *dt3) {
@@ -1465,7 +1523,7 @@ static int launch_sweep(const Geo &g, const Scheme &sc, const SweepArgs &a, hipS
   int nk = a.ku - a.kl + 1;
   long np = (long)(a.ju - a.jl + 1)*g.N1;
   dim3 block(SX, SY);
-  int rc = dispatch_scheme<MHD>(sc, [&](auto R, auto S) {
+  int rc = dispatch_scheme_eos<MHD>(sc, [&](auto R, auto S) {
     // faces per wave: 63 when the lanes share their slopes (lane 0 of a wave only provides)
     const long per_wg = (long)(x1_share<DIR, decltype(R)::value>() ? SX - 1 : SX)*SY;
     dim3 grid((unsigned)((np + 1 + per_wg - 1)/per_wg), 1, nk*g.nmb);
@@ -1484,7 +1542,7 @@ static int launch_sweep_update(const Geo &g, const Scheme &sc, const SweepArgs &
   int rc;
   if constexpr (DIR == 0) {
     dim3 grid(cdiv(a.iu - a.il + 1, TX - 1), 1, g.nmb), block(TX, 1);
-    rc = dispatch_scheme<MHD>(sc, [&](auto R, auto S) {
+    rc = dispatch_scheme_eos<MHD>(sc, [&](auto R, auto S) {
       k_sweep_update_1d<decltype(R)::value, MHD, decltype(S)::value><<<grid, block, 0, st>>>(
           g, sc.eos, a, u);
       return AKMI_COMPLETE;
@@ -1506,7 +1564,7 @@ static int launch_sweep_update(const Geo &g, const Scheme &sc, const SweepArgs &
       grid = dim3(nb, cdiv(nc, ml), g.nmb);
     }
     constexpr int D = (DIR == 0) ? 1 : DIR;
-    rc = dispatch_scheme<MHD>(sc, [&](auto R, auto S) {
+    rc = dispatch_scheme_eos<MHD>(sc, [&](auto R, auto S) {
       k_sweep_update<D, decltype(R)::value, MHD, MODE, USEACC, decltype(S)::value>
           <<<grid, block, extra_lds(1), st>>>(g, sc.eos, a, u, ml);
       return AKMI_COMPLETE;
@@ -1527,6 +1585,7 @@ static int launch_sweep12(const Geo &g, const Scheme &sc, const SweepArgs &a1, c
   const int nc = a2.ju - a2.jl > 0 ? a2.ju - a2.jl : 1;
   const int ml = march_len(nb, nc, g.nmb, ML, 3);
   dim3 grid(nb, cdiv(nc, ml), g.nmb), block(SX, SY);
+#if AKMI_X12_BUILD
   int rc = dispatch_scheme<true>(sc, [&](auto R, auto S) {
     k_sweep12<decltype(R)::value, decltype(S)::value><<<grid, block, 0, st>>>(g, sc.eos, a1, a2, u, ml);
     return AKMI_COMPLETE;
@@ -1534,6 +1593,11 @@ static int launch_sweep12(const Geo &g, const Scheme &sc, const SweepArgs &a1, c
   if (rc != AKMI_COMPLETE) return rc;
   AKMI_CHECK_LAUNCH("sweep12");
   return AKMI_COMPLETE;
+#else
+  (void)grid; (void)block; (void)ml; (void)st;
+  set_error("AKMI_X12=1 needs a library built with -DAKMI_X12_BUILD=1 (the experiment of profiles/r02_ab2_*.txt)");
+  return AKMI_FAIL;
+#endif
 }
 
 template <bool MASS>
@@ -1545,7 +1609,7 @@ static int launch_hydro_stage3d(const Geo &g, const Scheme &sc, const double *w0
   const int nchunk = cdiv(kB - kA + 1, ckl);
   const size_t lds = 2*(5*(size_t)(tl.tw + 3)*(tl.th + 3) + 10*(size_t)tl.tw*tl.th)*sizeof(double);
   dim3 grid(tl.n1, tl.n2, nchunk*g.nmb), block(tl.threads);
-  int rc = dispatch_scheme<false>(sc, [&](auto R, auto S) {
+  int rc = dispatch_scheme_eos<false>(sc, [&](auto R, auto S) {
     if constexpr (decltype(R)::value <= 1) {
       auto kern = k_hydro_stage3d<decltype(R)::value, decltype(S)::value, MASS>;
       static size_t granted = 64*1024;                 // per instantiation; raised once per size
@@ -1600,19 +1664,23 @@ k_c2p_shell(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ 
   else { i = ii < g.ng ? ii : g.ie + 1 + (ii - g.ng); j = g.js + jj; k = g.ks + kk; }
   const size_t cs = (size_t)g.N3*g.N2*g.N1;
   const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
-  double ud = u0[c], umx = u0[c + cs], umy = u0[c + 2*cs], umz = u0[c + 3*cs], ue = u0[c + 4*cs];
   double wd, wvx, wvy, wvz, we;
-  bool dfl = false, efl = false, tfl = false;
+  double ubx = 0.0, uby = 0.0, ubz = 0.0;
   if constexpr (MHD) {
-    const double ubx = 0.5*(bx1f[ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i)] +
-                            bx1f[ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i + 1)]);
-    const double uby = 0.5*(bx2f[ix4(g.N3, g.N2 + 1, g.N1, m, k, j, i)] +
-                            bx2f[ix4(g.N3, g.N2 + 1, g.N1, m, k, j + 1, i)]);
-    const double ubz = 0.5*(bx3f[ix4(g.N3 + 1, g.N2, g.N1, m, k, j, i)] +
-                            bx3f[ix4(g.N3 + 1, g.N2, g.N1, m, k + 1, j, i)]);
-    c2p_mhd(eos, ud, umx, umy, umz, ue, ubx, uby, ubz, wd, wvx, wvy, wvz, we, dfl, efl, tfl);
+    ubx = 0.5*(bx1f[ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i)] + bx1f[ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i + 1)]);
+    uby = 0.5*(bx2f[ix4(g.N3, g.N2 + 1, g.N1, m, k, j, i)] + bx2f[ix4(g.N3, g.N2 + 1, g.N1, m, k, j + 1, i)]);
+    ubz = 0.5*(bx3f[ix4(g.N3 + 1, g.N2, g.N1, m, k, j, i)] + bx3f[ix4(g.N3 + 1, g.N2, g.N1, m, k + 1, j, i)]);
     const size_t b = ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i);
     bcc0[b] = ubx; bcc0[b + cs] = uby; bcc0[b + 2*cs] = ubz;
+  }
+  if (!eos.is_ideal) {
+    c2p_iso_cell<MHD>(g, eos, u0, w0, c, cs, ubx, uby, ubz, counters, wd, wvx, wvy, wvz);
+    return;
+  }
+  double ud = u0[c], umx = u0[c + cs], umy = u0[c + 2*cs], umz = u0[c + 3*cs], ue = u0[c + 4*cs];
+  bool dfl = false, efl = false, tfl = false;
+  if constexpr (MHD) {
+    c2p_mhd(eos, ud, umx, umy, umz, ue, ubx, uby, ubz, wd, wvx, wvy, wvz, we, dfl, efl, tfl);
   } else {
     c2p_hyd(eos, ud, umx, umy, umz, ue, wd, wvx, wvy, wvz, we, dfl, efl, tfl);
   }
@@ -1646,9 +1714,10 @@ static int c2p_shell(const akmi_pack *p, double *u0, const double *bx1f, const d
 static int launch_scalars(const Geo &g, const Scheme &sc, const double *w0, const double *m1,
                           const double *m2, const double *m3, const UpdArgs &u, int k0, int nk,
                           hipStream_t st) {
+  const int nf = sc.iso ? 4 : 5;
   dim3 grid((unsigned)(((long)(g.je - g.js + 1)*g.N1 + SX*SY - 1)/(SX*SY)), 1, nk*g.nmb), block(SX, SY);
   return dispatch_recon(sc.recon, [&](auto R) {
-    k_scalar_update<decltype(R)::value><<<grid, block, 0, st>>>(g, sc.eos, w0, m1, m2, m3, u, k0, nk);
+    k_scalar_update<decltype(R)::value><<<grid, block, 0, st>>>(g, sc.eos, w0, m1, m2, m3, u, k0, nk, nf);
     AKMI_CHECK_LAUNCH("scalar_update");
     return AKMI_COMPLETE;
   });
@@ -1716,14 +1785,13 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
                         double *b1x3f, void *ws, const C2PArgs &cp_in, hipStream_t st,
                         int phases = AKMI_PHASE_ALL, const double *dt_dev = nullptr) {
   if (check_scheme(p, recon, "stage") != AKMI_COMPLETE) return AKMI_FAIL;
-  if (!p->is_ideal || p->nvar < 5) {
-    set_error("fused stage kernels are specialised for the ideal-gas variable set (passive scalars may "
-              "ride along); use the task-granular entries for eos = isothermal");
+  if (p->nvar < (p->is_ideal ? 5 : 4)) {
+    set_error("stage: nvar = %d is smaller than the fluid variable set of the EOS", p->nvar);
     return AKMI_FAIL;
   }
   Geo g = make_geo(p);
   Eos eos = make_eos(p);
-  const Scheme sc{recon, rsolver, make_face_eos(p)};
+  const Scheme sc{recon, rsolver, make_face_eos(p), !p->is_ideal};
   StageWs w = carve(g, MHD ? 1 : 0, ws);
   // phases: a caller that exchanges halos between the parts of a stage (multi-rank runs) asks
   // for them one at a time; the parts communicate through u0/b0 and the workspace only
@@ -1761,7 +1829,7 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
                : launch_sweep<0, MHD, false>(g, sc, a1, st);
       if (rc == AKMI_COMPLETE) rc = launch_sweep_update<1, MHD>(g, sc, a2, u, st);
     }
-    if (rc == AKMI_COMPLETE && do_sweeps && g.nvar > 5)
+    if (rc == AKMI_COMPLETE && do_sweeps && g.nvar > (sc.iso ? 4 : 5))
       rc = launch_scalars(g, sc, w0, w.flx1, w.flx2, w.flx3, u, g.ks, g.ke - g.ks + 1, st);
     if (rc != AKMI_COMPLETE) return rc;
     if (do_emf) {
@@ -1833,7 +1901,7 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
     b3.kl = kA(s); b3.ku = kB(s) + 1;
     if (do_sweeps && !MHD && hyd_one && sc.recon <= 1 && hyd_tile(g.nx1, g.nx2).tw > 0) {
       // hydro DC/PLM: sweeps + update of the slab in one kernel
-      rc = g.nvar > 5 ? launch_hydro_stage3d<true>(g, sc, w0, u, kA(s), kB(s), st, Mass3{w.flx1, w.flx2, w.flx3})
+      rc = g.nvar > (sc.iso ? 4 : 5) ? launch_hydro_stage3d<true>(g, sc, w0, u, kA(s), kB(s), st, Mass3{w.flx1, w.flx2, w.flx3})
                       : launch_hydro_stage3d<false>(g, sc, w0, u, kA(s), kB(s), st, Mass3{nullptr, nullptr, nullptr});
     } else if (do_sweeps && MHD && x12) {
       // x1 sweep folded into the x2 march (no x1 flux array); x3 march consumes acc
@@ -1846,7 +1914,7 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
       if (rc == AKMI_COMPLETE) rc = launch_sweep_update<1, MHD, 1, false>(g, sc, b2, u, st);
       if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD, 0, true>(g, sc, b3, u, st);
     }
-    if (rc == AKMI_COMPLETE && do_sweeps && g.nvar > 5)
+    if (rc == AKMI_COMPLETE && do_sweeps && g.nvar > (sc.iso ? 4 : 5))
       rc = launch_scalars(g, sc, w0, w.flx1, w.flx2, w.flx3, u, kA(s), kB(s) - kA(s) + 1, st);
     if (rc != AKMI_COMPLETE) return rc;
     if (two) {

@@ -93,10 +93,8 @@ class FluidBase:
                                 self.dx_dev.data_ptr(), e.gamma, e.dfloor, e.pfloor, e.tfloor,
                                 e.sfloor, e.sigma_max, e.iso_cs, 1 if e.is_ideal else 0)
         self.fused = pin.GetOrAddBoolean(blk, "fused_stage", True)
-        if not e.is_ideal:
-            # the fused stage kernels are specialised for the ideal-gas variable set; isothermal
-            # runs and runs with passive scalars use the task-granular kernels (one kernel per task)
-            self.fused = False
+        # (the fused stage kernels cover both equations of state and carry passive scalars along; FOFC,
+        # the diffusion hooks and refined meshes use the task-granular kernels, see below)
         # first-order flux correction, hydro.cpp:153-190 / mhd.cpp:199-235
         self.use_fofc = pin.GetOrAddBoolean(blk, "fofc", False)
         if self.use_fofc:

@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--mb", type=int, default=0,
                     help="MeshBlock size per dimension (default: --nx, one MeshBlock per GPU); "
                          "smaller blocks put (nx/mb)^3 MeshBlocks into each GPU's pack")
-    ap.add_argument("--problem", default="orszag_tang", choices=["orszag_tang", "sod", "linear_wave"])
+    ap.add_argument("--problem", default="orszag_tang", choices=["orszag_tang", "sod", "linear_wave", "linear_wave_mhd"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-nx", type=int, default=128)
     ap.add_argument("--recon", default=None, choices=["dc", "plm", "ppm4", "ppmx", "wenoz"],
@@ -71,6 +71,9 @@ def make_pin(args, nblk):
     elif args.problem == "sod":
         deck, blk = "sod.athinput", "hydro"
         ov = ["time/cfl_number=0.3", "mesh/ix1_bc=outflow", "mesh/ox1_bc=outflow"]
+    elif args.problem == "linear_wave_mhd":        # side measurements (isothermal MHD: --set mhd/eos=isothermal)
+        deck, blk = "linear_wave_mhd.athinput", "mhd"
+        ov = ["problem/amp=0.1"]
     else:
         deck, blk = "linear_wave_hydro.athinput", "hydro"
         ov = []

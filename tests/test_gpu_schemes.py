@@ -429,20 +429,21 @@ def test_unknown_scheme_is_rejected():
     assert b"nghost" in L.akmi_last_error()
 
 
-# ---- isothermal EOS (task-granular kernels; the host falls back from the fused stage) ----------
+# ---- isothermal EOS (fused stage kernels: the isothermal solvers are their RS + 10; and the task-granular ones) ----
 ISO_RS = {"hydro": ["llf", "hlle", "roe"], "mhd": ["llf", "hlle", "hlld"]}
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "split"])
 @pytest.mark.parametrize("recon", ["plm", "ppm4", "ppmx", "wenoz"])
 @pytest.mark.parametrize("soe", ["hydro", "mhd"])
-def test_isothermal_lwave1d_matrix_is_bit_identical(soe, recon):
+def test_isothermal_lwave1d_matrix_is_bit_identical(soe, recon, fused):
     """run arguments of test_nr_isolwave1d_cpu.py (eos=isothermal, N=64, 4 blocks, ng=3) for every
     solver; initial data from the product's own problem generator (inject=False) so that the
     isothermal eigenvectors of pgen.py are compared with the oracle's as well"""
     for rs in ISO_RS[soe]:
         for wave in ((0, 3) if soe == "hydro" else (0, 2, 5)):
             res = pu.compare_run("linear_wave_%s" % soe, 64, 1, 16, 10, ng=3, recon=recon, rsolver=rs,
-                                 integrator="rk2" if recon == "plm" else "rk3", cfl=0.4, inject=False,
+                                 integrator="rk2" if recon == "plm" else "rk3", cfl=0.4, inject=False, fused=fused,
                                  extra=["problem/along_x1=true", "problem/amp=1.0e-6",
                                         "problem/wave_flag=%d" % wave, "%s/eos=isothermal" % soe])
             assert res["cycles"] == 10 and res["time"][0] == res["time"][1]
@@ -451,6 +452,8 @@ def test_isothermal_lwave1d_matrix_is_bit_identical(soe, recon):
 
 @pytest.mark.parametrize("case", [
     ("linear_wave_hydro", 24, 3, 12, 3, dict(ng=3, recon="wenoz", rsolver="roe")),
+    ("linear_wave_hydro", 24, 3, 12, 3, dict(recon="plm", rsolver="roe")),          # fused: the one-kernel hydro stage
+    ("linear_wave_mhd", 24, 3, 12, 3, dict(recon="plm", rsolver="hlld", extra=("problem/amp=0.1",))),   # fused: x1 sweep + marches + CornerE/CT
     ("linear_wave_hydro", 32, 2, 16, 4, dict(recon="plm", rsolver="hlle")),
     ("linear_wave_mhd", 24, 3, 12, 3, dict(ng=3, recon="ppmx", rsolver="hlld", integrator="rk3")),
     ("linear_wave_mhd", 32, 2, 16, 4, dict(recon="plm", rsolver="llf")),
@@ -458,12 +461,13 @@ def test_isothermal_lwave1d_matrix_is_bit_identical(soe, recon):
     ("rj2a", 128, 1, 64, 8, dict(cfl=0.3, rsolver="hlld")),
 ], ids=lambda c: "%s-%d^%d-%s" % (c[0], c[1], c[2], c[5]["rsolver"]))
 @pytest.mark.parametrize("native", [False, True], ids=["py", "cpp"])
-def test_isothermal_multi_d_runs_are_bit_identical(case, native):
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "split"])
+def test_isothermal_multi_d_runs_are_bit_identical(case, native, fused):
     problem, n, dims, mb, cycles, kw = case
     blk = "hydro" if problem in ("linear_wave_hydro", "sod") else "mhd"
     kw = dict(kw)
     kw["extra"] = list(kw.get("extra", [])) + ["%s/eos=isothermal" % blk]
-    res = pu.compare_run(problem, n, dims, mb, cycles, native=native, **kw)
+    res = pu.compare_run(problem, n, dims, mb, cycles, native=native, fused=fused, **kw)
     assert res["cycles"] == cycles and res["time"][0] == res["time"][1]
     assert res["bitwise_equal"], res["diffs"]
 
