@@ -277,11 +277,28 @@ __device__ __forceinline__ double beta_dt_of(double beta_dt, const double *dtp) 
 #ifndef AKMI_PREFETCH_UPD
 #define AKMI_PREFETCH_UPD 1
 #endif
+// The x3 march moves the most bytes of the stage and waits on memory 72 % of its wave cycles
+// (profiles/r02_v3_valu_counters.txt).  With the register budget of TWO waves per SIMD it can hold the
+// update operands u1 (AKMI_PREFETCH_U1) and the cells of the next step (AKMI_PREFETCH_W) in flight across
+// the Riemann solve: 1165 -> 907 us at 256^3, 202 VGPRs, no scratch (profiles/r02_prefetch_w.txt).  At three
+// waves the same prefetches spill (x3 march 1.07 -> 1.20-1.35 ms), and the x2 march loses at two waves.
 #ifndef AKMI_PREFETCH_U1
-#define AKMI_PREFETCH_U1 0      // +10 VGPRs: spills at 3 waves/SIMD, x3 march 1.07 -> 1.20 ms (profiles/r02_ab2.txt)
+#define AKMI_PREFETCH_U1 1
 #endif
 #ifndef AKMI_MARCH_WAVES
 #define AKMI_MARCH_WAVES 3
+#endif
+#ifndef AKMI_PREFETCH_W
+#define AKMI_PREFETCH_W 1       // x3 PLM march: load the cells of step t+1 during step t (2*NV more VGPRs)
+#endif
+#ifndef AKMI_PREFETCH_W2
+#define AKMI_PREFETCH_W2 0      // the same in the x2 march
+#endif
+#ifndef AKMI_X3_WAVES
+#define AKMI_X3_WAVES 2         // register budget of the x3 march (waves per SIMD)
+#endif
+#ifndef AKMI_X2_WAVES
+#define AKMI_X2_WAVES AKMI_MARCH_WAVES
 #endif
 #ifndef AKMI_PREFETCH_X1
 #define AKMI_PREFETCH_X1 0
@@ -445,10 +462,22 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
   }
   const size_t fst = (DIR == 1) ? (size_t)a.f1 : (size_t)a.f1*a.f2;   // face-array stride
   const double *pbx = MHD ? a.bxf + ix4(a.f3, a.f2, a.f1, m, k, j, i) : nullptr;
+  constexpr bool PW = RECON == 1 && ((AKMI_PREFETCH_W && DIR == 2) || (AKMI_PREFETCH_W2 && DIR == 1));
+  double nx[NV];                         // PW: cells s+1 of the coming step, loaded one step ahead
+  if constexpr (PW) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) nx[n] = (ISO && n == 4) ? 0.0 : (base(n) + off)[st];
+  }
   for (int t = 0; t <= ml; ++t) {
     const int s = s0 + t;
     if (s > shi) break;
     if constexpr (DIR == 1) j = s; else k = s;
+    double nx2[NV];
+    if constexpr (PW) {
+      const bool more = (t < ml) && (s < shi);           // a next step exists: its cell s+2 is inside the array
+#pragma unroll
+      for (int n = 0; n < NV; ++n) nx2[n] = (more && !(ISO && n == 4)) ? (base(n) + off)[2*st] : 0.0;
+    }
     double L[NV], R[NV];
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
@@ -457,7 +486,8 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
       double qln;
       L[n] = PL_(n);
       if constexpr (RECON == 1) {
-        const double qp = q[st];
+        double qp;
+        if constexpr (PW) qp = nx[n]; else qp = q[st];
         const double w0 = W_(n, 0), w1 = W_(n, 1);
         plm(w0, w1, qp, qln, R[n]);
         W_(n, 0) = w1; W_(n, 1) = qp;
@@ -571,6 +601,10 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
     }
 #pragma unroll
     for (int n = 0; n < 5; ++n) { if (ISO && n == 4) continue; FP_(n) = fv[n]; }
+    if constexpr (PW) {
+#pragma unroll
+      for (int n = 0; n < NV; ++n) nx[n] = nx2[n];
+    }
   }
 #undef W_
 #undef PL_
@@ -581,7 +615,7 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
 // bit (both are the correctly rounded value of the same real number, and 1/dx is exact), so the
 // divisions by dx become products; decided per block, two copies of the loop
 template <int DIR, int RECON, bool MHD, int MODE, bool USEACC, int RS>
-__global__ void __launch_bounds__(SX*SY, (RECON >= 2 ? 2 : AKMI_MARCH_WAVES))
+__global__ void __launch_bounds__(SX*SY, (RECON >= 2 ? 2 : (DIR == 2 ? AKMI_X3_WAVES : AKMI_X2_WAVES)))
 k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int ml) {
   constexpr int NV = MHD ? 7 : 5;
   __shared__ double sm[(NV*RollCfg<RECON>::NW + NV + 5)*SX*SY];
