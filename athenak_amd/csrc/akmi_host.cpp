@@ -745,6 +745,18 @@ int Driver::Execute(Mesh *pm, int max_cycles) {            // driver.cpp:380-459
   return n;
 }
 
+// copy_u1 of include/akmi.h: the first stage writes its result into the second register and the
+// registers are swapped afterwards (no CopyCons traffic).  The C2P part alone sees swapped pointers
+// already; RK4's second register is updated by CopyCons itself; a captured cycle graph has the
+// pointers baked in -- those keep the folded copy.
+static int CopyFlag(const Driver *d, int stage, int phases) {
+  if (stage != 1) return 0;
+  static const bool off = std::getenv("AKMI_OUT_OF_PLACE") && std::atoi(std::getenv("AKMI_OUT_OF_PLACE")) == 0;   // A/B switch
+  if (d->integrator == "rk4" || d->use_graph || off) return 1;
+  return (phases & (AKMI_PHASE_SWEEPS | AKMI_PHASE_EMF_CT)) ? 2 : 0;
+}
+template <typename T> static void SwapArr(DvceArray<T> &a, DvceArray<T> &b) { std::swap(a.p, b.p); std::swap(a.n, b.n); }
+
 // ---- task bodies: one C-ABI call each ------------------------------------------------------------
 namespace hydro {
 TaskStatus Hydro::CopyCons(Driver *d, int stage) {         // hydro_tasks.cpp:130-152
@@ -777,14 +789,16 @@ TaskStatus Hydro::RKUpdate(Driver *d, int stage) {         // hydro_update.cpp:2
     StagePhase(d, stage, AKMI_PHASE_SWEEPS);
   } else if (fused) {
     int do_dt = (stage == d->nexp_stages);
+    const int copy = CopyFlag(d, stage, AKMI_PHASE_ALL);
     if (dt_dev)
       AKCHK(akmi_hydro_stage_fused_dt(&pack_c, recon_method, rsolver_method, d->gam0[stage - 1],
-                                      d->gam1[stage - 1], d->beta[stage - 1], dt_dev, stage == 1, w0.p, u0.p,
+                                      d->gam1[stage - 1], d->beta[stage - 1], dt_dev, copy, w0.p, u0.p,
                                       u1.p, do_dt, counters.p, dt3.p, ws.p, stream));
     else
     AKCHK(akmi_hydro_stage_fused(&pack_c, recon_method, rsolver_method, d->gam0[stage - 1],
-                                 d->gam1[stage - 1], beta_dt, stage == 1, w0.p, u0.p, u1.p, do_dt,
+                                 d->gam1[stage - 1], beta_dt, copy, w0.p, u0.p, u1.p, do_dt,
                                  counters.p, dt3.p, ws.p, stream));
+    if (copy == 2) SwapArr(u0, u1);
     interior_done_ = true; dt_ready_ = do_dt;
   } else {
     AKCHK(akmi_rk_update(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1], beta_dt, u0.p, u1.p,
@@ -798,8 +812,10 @@ void Hydro::StagePhase(Driver *d, int stage, int phases) {
   const Real g0 = stage >= 1 ? d->gam0[stage - 1] : 1.0, g1 = stage >= 1 ? d->gam1[stage - 1] : 0.0;
   const Real beta_dt = stage >= 1 ? d->beta[stage - 1]*pmy_pack->pmesh->dt : 0.0;
   const int do_dt = (stage == d->nexp_stages);
-  AKCHK(akmi_hydro_stage_phase(&pack_c, recon_method, rsolver_method, g0, g1, beta_dt, stage == 1, w0.p,
+  const int copy = CopyFlag(d, stage, phases);
+  AKCHK(akmi_hydro_stage_phase(&pack_c, recon_method, rsolver_method, g0, g1, beta_dt, copy, w0.p,
                                u0.p, u1.p, do_dt, counters.p, dt3.p, phases, ws.p, stream));
+  if (copy == 2) SwapArr(u0, u1);
   if (phases & AKMI_PHASE_C2P) { interior_done_ = true; dt_ready_ = do_dt; }
 }
 TaskStatus Hydro::SendU(Driver *d, int stage) {            // hydro_tasks.cpp:308-320
@@ -928,16 +944,21 @@ TaskStatus MHD::RKUpdate(Driver *d, int stage) {           // mhd_update.cpp:24-
     StagePhase(d, stage, AKMI_PHASE_SWEEPS);
   } else if (fused) {
     int do_dt = (stage == d->nexp_stages);
+    const int copy = CopyFlag(d, stage, AKMI_PHASE_ALL);
     if (dt_dev)
       AKCHK(akmi_mhd_stage_fused_dt(&pack_c, recon_method, rsolver_method, d->gam0[stage - 1],
-                                    d->gam1[stage - 1], d->beta[stage - 1], dt_dev, stage == 1, w0.p, bcc0.p,
+                                    d->gam1[stage - 1], d->beta[stage - 1], dt_dev, copy, w0.p, bcc0.p,
                                     u0.p, u1.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, b1.x1f.p, b1.x2f.p, b1.x3f.p,
                                     do_dt, counters.p, dt3.p, ws.p, stream));
     else
     AKCHK(akmi_mhd_stage_fused(&pack_c, recon_method, rsolver_method, d->gam0[stage - 1],
-                               d->gam1[stage - 1], beta_dt, stage == 1, w0.p, bcc0.p, u0.p, u1.p,
+                               d->gam1[stage - 1], beta_dt, copy, w0.p, bcc0.p, u0.p, u1.p,
                                b0.x1f.p, b0.x2f.p, b0.x3f.p, b1.x1f.p, b1.x2f.p, b1.x3f.p, do_dt,
                                counters.p, dt3.p, ws.p, stream));
+    if (copy == 2) {
+      SwapArr(u0, u1);
+      SwapArr(b0.x1f, b1.x1f); SwapArr(b0.x2f, b1.x2f); SwapArr(b0.x3f, b1.x3f);
+    }
     interior_done_ = true; dt_ready_ = do_dt;
   } else {
     AKCHK(akmi_rk_update(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1], beta_dt, u0.p, u1.p,
@@ -950,9 +971,14 @@ void MHD::StagePhase(Driver *d, int stage, int phases) {
   const Real g0 = stage >= 1 ? d->gam0[stage - 1] : 1.0, g1 = stage >= 1 ? d->gam1[stage - 1] : 0.0;
   const Real beta_dt = stage >= 1 ? d->beta[stage - 1]*pmy_pack->pmesh->dt : 0.0;
   const int do_dt = (stage == d->nexp_stages);
-  AKCHK(akmi_mhd_stage_phase(&pack_c, recon_method, rsolver_method, g0, g1, beta_dt, stage == 1, w0.p,
+  const int copy = CopyFlag(d, stage, phases);
+  AKCHK(akmi_mhd_stage_phase(&pack_c, recon_method, rsolver_method, g0, g1, beta_dt, copy, w0.p,
                              bcc0.p, u0.p, u1.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, b1.x1f.p, b1.x2f.p,
                              b1.x3f.p, do_dt, counters.p, dt3.p, phases, ws.p, stream));
+  if (copy == 2) {
+    if (phases & AKMI_PHASE_SWEEPS) SwapArr(u0, u1);
+    if (phases & AKMI_PHASE_EMF_CT) { SwapArr(b0.x1f, b1.x1f); SwapArr(b0.x2f, b1.x2f); SwapArr(b0.x3f, b1.x3f); }
+  }
   if (phases & AKMI_PHASE_C2P) { interior_done_ = true; dt_ready_ = do_dt; }
 }
 // Off-rank neighbours and the fused stage: sweeps+update -> pack+send U -> CornerE+CT -> pack+send B

@@ -258,6 +258,18 @@ struct UpdArgs {
   const double *dtp;              // non-null: beta_dt holds the RK weight beta and dt is read from
                                   // device memory (a captured cycle replayed with a new time step)
 };
+// copy_u1 / copy_b1: 0 = the second register (u1, b1) holds the state of the start of the cycle;
+// 1 = first stage, CopyCons folded in: the register receives the old state, u0 / b0 the new one;
+// 2 = first stage OUT OF PLACE: u0 / b0 are only read, the new state goes to u1 / b1 and the caller
+//     swaps the two registers afterwards -- the copy (5 + 3 arrays written) disappears.  Only the cells /
+//     faces the update touches are written: the ghost zones of the new register are filled by the halo
+//     exchange and the boundary conditions that follow every stage.
+__device__ __forceinline__ void rk_store(double *__restrict__ u0, double *__restrict__ u1, int copy, size_t c,
+                                         double old, double res) {
+  if (copy == 2) { u1[c] = res; return; }
+  if (copy) u1[c] = old;
+  u0[c] = res;
+}
 // beta*dt: the product the host forms in RKUpdate (hydro_update.cpp:35), same operands, same rounding
 __device__ __forceinline__ double beta_dt_of(double beta_dt, const double *dtp) {
   return dtp ? beta_dt*(*dtp) : beta_dt;
@@ -290,6 +302,12 @@ __device__ __forceinline__ double beta_dt_of(double beta_dt, const double *dtp) 
 #endif
 #ifndef AKMI_PREFETCH_W
 #define AKMI_PREFETCH_W 1       // x3 PLM march: load the cells of step t+1 during step t (2*NV more VGPRs)
+#endif
+#ifndef AKMI_DBG_NOSOLVE
+#define AKMI_DBG_NOSOLVE 0
+#endif
+#ifndef AKMI_PPM_WREG
+#define AKMI_PPM_WREG 1         // marches with five-point reconstructions keep their window in registers
 #endif
 #ifndef AKMI_PREFETCH_W2
 #define AKMI_PREFETCH_W2 0      // the same in the x2 march
@@ -417,9 +435,15 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
   // Keeping it out of the VGPRs lets the kernel run at the occupancy of the plain Riemann
   // kernel while every cell is loaded from HBM exactly once per sweep.
   double *my = sm + threadIdx.y*SX + threadIdx.x;
-#define W_(n, c) my[((n)*NW + (c))*NT]
-#define PL_(n) my[(NV*NW + (n))*NT]
-#define FP_(n) my[(NV*NW + NV + (n))*NT]
+  // five-point reconstructions (NW = 4) run with the register budget of two waves per SIMD: their
+  // window stays in registers (WREG) and only PL/FP are parked -- 12 instead of 40 LDS slots per thread,
+  // 24 KB instead of 80 KB per workgroup, i.e. two workgroups per CU instead of one
+  constexpr bool WREG = (RECON >= 2) && AKMI_PPM_WREG;
+  constexpr int WB = WREG ? 0 : NV*NW;               // LDS slots taken by the window
+  double Wr[WREG ? NV : 1][WREG ? NW : 1];
+#define W_(n, c) (*(WREG ? &Wr[WREG ? (n) : 0][WREG ? (c) : 0] : &my[((n)*NW + (c))*NT]))
+#define PL_(n) my[(WB + (n))*NT]
+#define FP_(n) my[(WB + NV + (n))*NT]
   const int shi = (DIR == 1) ? a.ju : a.ku;           // last face along the sweep
   const bool col_active = (i >= g.is) && (i <= g.ie) &&
                           ((DIR == 1) ? (k >= g.ks && k <= g.ke) : (j >= g.js && j <= g.je));
@@ -541,8 +565,14 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
     }
     double fd, fx, fy, fz, fe;
     if constexpr (MHD) {
+#if AKMI_DBG_NOSOLVE      // timing experiment only (wrong results): what the march costs without its Riemann solve
+      Cons1D fl;
+      fl.d = L[0] + R[0]; fl.mx = L[1] + R[1]; fl.my = L[2] + R[2]; fl.mz = L[3] + R[3]; fl.e = L[4] + R[4];
+      fl.by = L[5] + R[5] + pbx[(size_t)t*fst]; fl.bz = L[6] + R[6];
+#else
       Cons1D fl = riemann_mhd_e<RS>(eos, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1],
                                     R[2], R[3], R[4], R[5], R[6], pbx[(size_t)t*fst]);
+#endif
       fd = fl.d; fx = fl.mx; fy = fl.my; fz = fl.mz; fe = fl.e;
       if (t < ml || s == shi) {
         // CornerE needs the sign of the mass flux and the two face EMFs of this direction
@@ -594,8 +624,7 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
           double u1v;
           if constexpr (PRE && AKMI_PREFETCH_U1) u1v = u.copy_u1 ? u0v : pu1[n];
           else u1v = u.copy_u1 ? u0v : u.u1[c + n*cs];
-          if (u.copy_u1) u.u1[c + n*cs] = u0v;
-          u.u0[c + n*cs] = u.gam0*u0v + u.gam1*u1v - beta_dt_of(u.beta_dt, u.dtp)*divf;
+          rk_store(u.u0, u.u1, u.copy_u1, c + n*cs, u0v, u.gam0*u0v + u.gam1*u1v - beta_dt_of(u.beta_dt, u.dtp)*divf);
         }
       }
     }
@@ -618,7 +647,7 @@ template <int DIR, int RECON, bool MHD, int MODE, bool USEACC, int RS>
 __global__ void __launch_bounds__(SX*SY, (RECON >= 2 ? 2 : (DIR == 2 ? AKMI_X3_WAVES : AKMI_X2_WAVES)))
 k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int ml) {
   constexpr int NV = MHD ? 7 : 5;
-  __shared__ double sm[(NV*RollCfg<RECON>::NW + NV + 5)*SX*SY];
+  __shared__ double sm[(((RECON >= 2) && AKMI_PPM_WREG ? 0 : NV*RollCfg<RECON>::NW) + NV + 5)*SX*SY];
   const int m = blockIdx.z;
   constexpr bool TRY = AKMI_POW2DX && MHD && MODE == 0 && USEACC;     // the x3 march of the MHD stage
   if (TRY && is_pow2(g.dx[3*m]) && is_pow2(g.dx[3*m + 1]) && is_pow2(g.dx[3*m + 2]))
@@ -878,8 +907,7 @@ k_sweep_update_1d(Geo g, FaceEos eos, SweepArgs a, UpdArgs u) {
     const double divf = (sF[n][threadIdx.x + 1] - fv[n])/dx1;
     const double u0v = u.u0[c + n*cs];
     const double u1v = u.copy_u1 ? u0v : u.u1[c + n*cs];
-    if (u.copy_u1) u.u1[c + n*cs] = u0v;
-    u.u0[c + n*cs] = u.gam0*u0v + u.gam1*u1v - beta_dt_of(u.beta_dt, u.dtp)*divf;
+    rk_store(u.u0, u.u1, u.copy_u1, c + n*cs, u0v, u.gam0*u0v + u.gam1*u1v - beta_dt_of(u.beta_dt, u.dtp)*divf);
   }
 }
 
@@ -942,8 +970,7 @@ k_scalar_update(Geo g, FaceEos eos, const double *__restrict__ w0, const double 
     }
     const double u0v = u.u0[c];
     const double u1v = u.copy_u1 ? u0v : u.u1[c];
-    if (u.copy_u1) u.u1[c] = u0v;
-    u.u0[c] = u.gam0*u0v + u.gam1*u1v - bdt*divf;
+    rk_store(u.u0, u.u1, u.copy_u1, c, u0v, u.gam0*u0v + u.gam1*u1v - bdt*divf);
   }
 }
 
@@ -1075,8 +1102,7 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const double *__res
         double b = gam0*b0v + gam1*b1v;
         b -= DIVX(beta_dt*(S2(pp2, ty, tx + 1) - e2), dx1);
         b += DIVX(beta_dt*(S1(pp2, ty + 1, tx) - e1), dx2);
-        b0x3f[c] = b;
-        if (copy_b1) b1x3f[c] = b0v;
+        rk_store(b0x3f, b1x3f, copy_b1, c, b0v, b);
       }
       if (k > k0) {
         const int kc = k - 1, q3 = (t + 2) % 3;                    // plane k-1 and its e3 buffer
@@ -1087,8 +1113,7 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const double *__res
           double b = gam0*b0v + gam1*b1v;
           b -= DIVX(beta_dt*(S3(q3, ty + 1, tx) - e3p), dx2);
           b += DIVX(beta_dt*(e2 - e2p), dx3);
-          b0x1f[c] = b;
-          if (copy_b1) b1x1f[c] = b0v;
+          rk_store(b0x1f, b1x1f, copy_b1, c, b0v, b);
         }
         if (i <= g.ie) {                                           // x2-face (:56-65)
           const size_t c = ix4(g.N3, g.N2 + 1, g.N1, m, kc, j, i);
@@ -1097,8 +1122,7 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const double *__res
           double b = gam0*b0v + gam1*b1v;
           b += DIVX(beta_dt*(S3(q3, ty, tx + 1) - e3p), dx1);
           b -= DIVX(beta_dt*(e1 - e1p), dx3);
-          b0x2f[c] = b;
-          if (copy_b1) b1x2f[c] = b0v;
+          rk_store(b0x2f, b1x2f, copy_b1, c, b0v, b);
         }
       }
     }
@@ -1158,9 +1182,10 @@ k_ct_copy(Geo g, double gam0, double gam1, double beta_dt, const double *__restr
       double b = gam0*b0v + gam1*b1v;
       b -= beta_dt*(E3(k, j + 1, i) - E3(k, j, i))/dx2;
       if (g.three_d) b += beta_dt*(E2(k + 1, j, i) - E2(k, j, i))/dx3;
-      b0x1f[c] = b;
+      rk_store(b0x1f, b1x1f, copy_b1, c, b0v, b);
+    } else if (copy_b1) {
+      b1x1f[c] = b0v;                  // 1-D: bx is constant; either way the register receives it
     }
-    if (copy_b1) b1x1f[c] = b0v;
   }
   if (i <= g.ie && k <= kb) {
     size_t c = ix4(g.N3, g.N2 + 1, g.N1, m, k, j, i);
@@ -1169,8 +1194,7 @@ k_ct_copy(Geo g, double gam0, double gam1, double beta_dt, const double *__restr
     double b = gam0*b0v + gam1*b1v;
     b += beta_dt*(E3(k, j, i + 1) - E3(k, j, i))/dx1;
     if (g.three_d) b -= beta_dt*(E1(k + 1, j, i) - E1(k, j, i))/dx3;
-    b0x2f[c] = b;
-    if (copy_b1) b1x2f[c] = b0v;
+    rk_store(b0x2f, b1x2f, copy_b1, c, b0v, b);
   }
   if (i <= g.ie && j <= g.je) {
     size_t c = ix4(g.N3 + 1, g.N2, g.N1, m, k, j, i);
@@ -1179,8 +1203,7 @@ k_ct_copy(Geo g, double gam0, double gam1, double beta_dt, const double *__restr
     double b = gam0*b0v + gam1*b1v;
     b -= beta_dt*(E2(k, j, i + 1) - E2(k, j, i))/dx1;
     if (g.multi_d) b += beta_dt*(E1(k, j + 1, i) - E1(k, j, i))/dx2;
-    b0x3f[c] = b;
-    if (copy_b1) b1x3f[c] = b0v;
+    rk_store(b0x3f, b1x3f, copy_b1, c, b0v, b);
   }
 #undef E1
 #undef E2
@@ -1523,8 +1546,7 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
         divf += (f3[n] - F3p[n])/dx3;
         const double u0v = pu0[n];
         const double u1v = u.copy_u1 ? u0v : pu1[n];
-        if (u.copy_u1) u.u1[c + n*cs] = u0v;
-        u.u0[c + n*cs] = u.gam0*u0v + u.gam1*u1v - beta_dt_of(u.beta_dt, u.dtp)*divf;
+        rk_store(u.u0, u.u1, u.copy_u1, c + n*cs, u0v, u.gam0*u0v + u.gam1*u1v - beta_dt_of(u.beta_dt, u.dtp)*divf);
       }
     }
 #pragma unroll
@@ -1836,6 +1858,11 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
   const int ndim = g.three_d ? 3 : (g.multi_d ? 2 : 1);
   // dt_dev: beta_dt is the RK weight beta, the kernels multiply it with *dt_dev (akmi_*_stage_fused_dt)
   UpdArgs u{gam0, gam1, beta_dt, u0, u1, w.flx1, w.flx2, copy_u1, w.acc, dt_dev};
+  // copy_u1 == 2 (out-of-place first stage): the new state lands in u1 / b1, which is what the c2p
+  // of the active cells has to read
+  double *un = copy_u1 == 2 ? u1 : u0;
+  const double *n1f = copy_u1 == 2 ? b1x1f : b0x1f, *n2f = copy_u1 == 2 ? b1x2f : b0x2f,
+               *n3f = copy_u1 == 2 ? b1x3f : b0x3f;
   int rc = AKMI_COMPLETE;
   // sweep ranges: hydro_fluxes.cpp:95-104 (no FOFC) / mhd_fluxes.cpp:117-248 (CT-extended)
   SweepArgs a1{w0, bcc0, b0x1f, w.flx1, w.efc[0], w.efc[1], w.ecc[0], w.ecc[1], w.ecc[2],
@@ -1878,7 +1905,7 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
       AKMI_CHECK_LAUNCH("ct");
     }
     if (cp.enable)
-      rc = launch_c2p<MHD>(g, eos, u0, b0x1f, b0x2f, b0x3f, const_cast<double *>(w0),
+      rc = launch_c2p<MHD>(g, eos, un, n1f, n2f, n3f, const_cast<double *>(w0),
                            const_cast<double *>(bcc0), cp.do_newdt, cp.counters, cp.dt3, g.is, g.ie,
                            g.js, g.je, g.ks, g.ke - g.ks + 1, st);
     return rc;
@@ -1923,7 +1950,7 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
     return AKMI_COMPLETE;
   };
   auto c2p = [&](int s) -> int {
-    return launch_c2p<MHD>(g, eos, u0, b0x1f, b0x2f, b0x3f, const_cast<double *>(w0),
+    return launch_c2p<MHD>(g, eos, un, n1f, n2f, n3f, const_cast<double *>(w0),
                            const_cast<double *>(bcc0), cp.do_newdt, cp.counters, cp.dt3, g.is, g.ie,
                            g.js, g.je, kA(s), kB(s) - kA(s) + 1, sb);
   };

@@ -7,6 +7,7 @@ call through the C ABI (include/akmi.h).  Device arrays are torch.float64 CUDA t
 reference's (m,n,k,j,i) LayoutRight order; torch is memory/stream plumbing only.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -161,6 +162,18 @@ class FluidBase:
         if pm.three_d:
             dtnew = min(dtnew, float(d[2]))
         self.dtnew = dtnew
+
+
+    @staticmethod
+    def _copy_flag(pdrive, stage, phases):
+        """copy_u1 of include/akmi.h: the first stage writes its result into the second register and
+        the registers are swapped (no CopyCons traffic); the C2P part alone sees swapped pointers
+        already; RK4's second register is updated by CopyCons itself, so it keeps the folded copy"""
+        if stage != 1:
+            return 0
+        if pdrive.integrator == "rk4" or os.environ.get("AKMI_OUT_OF_PLACE", "1") == "0":    # (A/B switch)
+            return 1
+        return 2 if phases & (capi.PHASE_SWEEPS | capi.PHASE_EMF_CT) else 0
 
 
 class Hydro(FluidBase):
@@ -323,12 +336,15 @@ class Hydro(FluidBase):
         else:
             gam0, gam1, beta_dt = 1.0, 0.0, 0.0
         do_dt = 1 if stage == pdrive.nexp_stages else 0
+        copy = self._copy_flag(pdrive, stage, phases)
         capi.check(self.L.akmi_hydro_stage_phase(
             C.byref(self.pack_c), self.recon_method, self.rsolver_method, capi.d(gam0),
-            capi.d(gam1), capi.d(beta_dt), 1 if stage == 1 else 0, capi._p(self.w0),
+            capi.d(gam1), capi.d(beta_dt), copy, capi._p(self.w0),
             capi._p(self.u0), capi._p(self.u1), do_dt, capi._p(self.counters),
             capi._p(self.dt3), phases, capi._p(self._workspace(0)), capi._stream()),
             "hydro_stage_phase")
+        if copy == 2:                      # out-of-place first stage: the registers trade places
+            self.u0, self.u1 = self.u1, self.u0
         if phases & capi.PHASE_C2P:
             self._interior_done = True
             self._dt_ready = bool(do_dt)

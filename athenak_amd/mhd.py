@@ -213,12 +213,18 @@ class MHD(FluidBase):
         else:
             gam0, gam1, beta_dt = 1.0, 0.0, 0.0
         do_dt = 1 if stage == pdrive.nexp_stages else 0
+        copy = self._copy_flag(pdrive, stage, phases)
         capi.check(self.L.akmi_mhd_stage_phase(
             C.byref(self.pack_c), self.recon_method, self.rsolver_method, capi.d(gam0),
-            capi.d(gam1), capi.d(beta_dt), 1 if stage == 1 else 0, capi._p(self.w0),
+            capi.d(gam1), capi.d(beta_dt), copy, capi._p(self.w0),
             capi._p(self.bcc0), capi._p(self.u0), capi._p(self.u1), *self._b(self.b0),
             *self._b(self.b1), do_dt, capi._p(self.counters), capi._p(self.dt3), phases,
             capi._p(self._workspace(1)), capi._stream()), "mhd_stage_phase")
+        if copy == 2:                      # out-of-place first stage: the registers trade places
+            if phases & capi.PHASE_SWEEPS:
+                self.u0, self.u1 = self.u1, self.u0
+            if phases & capi.PHASE_EMF_CT:
+                self.b0, self.b1 = self.b1, self.b0
         if phases & capi.PHASE_C2P:
             self._interior_done = True
             self._dt_ready = bool(do_dt)

@@ -56,6 +56,22 @@ class NativeSimulation:
         ph.nfluid = 5 if ph.peos.eos_data.is_ideal else 4
         ph.nscalars = pin.GetOrAddInteger(blk, "nscalars", 0)
         ph.nvars = nv = ph.nfluid + ph.nscalars
+        self._shape = (is_mhd, nmb, nv, n3, n2, n1)
+        self._phys = ph
+        self._refresh()
+        if is_mhd:
+            self.pmesh.pmb_pack.pmhd = ph
+        else:
+            self.pmesh.pmb_pack.phydro = ph
+        self.pmesh.pgen = ProblemGenerator(pin, self.pmesh)
+        if initialize:
+            self.Initialize()
+
+    def _refresh(self):
+        """(re)alias the native arrays: the C++ host swaps its two registers (u0/u1, b0/b1) after an
+        out-of-place first stage, so the pointers behind the names change from call to call"""
+        is_mhd, nmb, nv, n3, n2, n1 = self._shape
+        ph = self._phys
         ph.u0 = self._alias("u0", (nmb, nv, n3, n2, n1))
         ph.w0 = self._alias("w0", (nmb, nv, n3, n2, n1))
         ph.u1 = self._alias("u1", (nmb, nv, n3, n2, n1))
@@ -67,13 +83,6 @@ class NativeSimulation:
                 f.x2f = self._alias(reg + "x2f", (nmb, n3, n2 + 1, n1))
                 f.x3f = self._alias(reg + "x3f", (nmb, n3 + 1, n2, n1))
                 setattr(ph, reg, f)
-            self.pmesh.pmb_pack.pmhd = ph
-        else:
-            self.pmesh.pmb_pack.phydro = ph
-        self._phys = ph
-        self.pmesh.pgen = ProblemGenerator(pin, self.pmesh)
-        if initialize:
-            self.Initialize()
 
     def _alias(self, name, shape):
         cnt = C.c_longlong(0)
@@ -95,6 +104,7 @@ class NativeSimulation:
 
     def Execute(self, max_cycles=None):
         n = self.L.akmi_sim_execute(self.h, -1 if max_cycles is None else int(max_cycles))
+        self._refresh()
         self.pmesh.time = self.time
         self.pmesh.dt = self.dt
         self.pmesh.ncycle = self.ncycle

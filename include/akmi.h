@@ -382,7 +382,13 @@ int akmi_smr_unpack_emf(const akmi_pack *p, const akmi_smr *t, const int *nflx, 
 long long akmi_stage_workspace_bytes(const akmi_pack *p, int is_mhd);
 
 /* Hydro: Fluxes + RKUpdate fused (stage 1 reads u0 as u1 when u1==NULL is not allowed;
- * CopyCons semantics are folded in when copy_u1 != 0: u1 <- u0 before the update). */
+ * CopyCons semantics are folded in when copy_u1 != 0: u1 <- u0 before the update).
+ * copy_u1 == 2: the first stage OUT OF PLACE -- u0 (and b0) are only read, the new state is written
+ * to u1 (and b1), and the caller swaps the two registers (pointers) after the call; the copy of
+ * Hydro::CopyCons / MHD::CopyCons (5 + 3 arrays written) disappears.  Only the cells and faces the update
+ * touches are written; the ghost zones of the new register are filled by the halo exchange and the
+ * boundary conditions that follow every stage.  With akmi_*_stage_phase the swap of u follows the
+ * SWEEPS part and the swap of b the EMF_CT part (the C2P part is passed the swapped pointers). */
 int akmi_hydro_stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
                             double gam1, double beta_dt, int copy_u1, const double *w0,
                             double *u0, double *u1, void *ws, void *stream);
