@@ -101,6 +101,22 @@ def lib_sha16():
     return hashlib.sha256(open(capi.LIB_PATH, "rb").read()).hexdigest()[:16]
 
 
+def src_sha16():
+    """first 16 hex digits of the sha256 over the kernel sources and build flags: identical sources give
+    identical kernels even where two builds of libakmi.so differ in their bytes (hipcc embeds temporary
+    file names), which is what the traffic counters of a profiling run belong to"""
+    import hashlib
+    import __graft_entry__ as ge
+    h = hashlib.sha256(" ".join(ge.HIPCC_FLAGS).encode())
+    csrc = os.path.join(ROOT, "athenak_amd", "csrc")
+    for f in sorted(os.listdir(csrc)) + [os.path.join(ROOT, "include", "akmi.h")]:
+        path = f if os.path.isabs(f) else os.path.join(csrc, f)
+        if path.endswith((".hip", ".hpp", ".cpp", ".h")):
+            h.update(os.path.basename(path).encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(args, blk):
     """the oracle (port of the reference's split-kernel CPU sequence) on all host cores, on a
     bounded sample of the same workload (same deck at sample_nx^3, a few cycles)"""
@@ -271,14 +287,18 @@ def main():
         stage_kernels = [k for k in t["kernels"] if k.startswith("akmi::k_sweep") or
                          k.startswith("akmi::k_corner") or k.startswith("akmi::k_ct_copy") or
                          k.startswith("akmi::k_hydro_stage3d") or k.startswith("akmi::k_c2p_newdt")]
-        if t.get("lib_sha16") == lib_sha16() and not args.recon and not args.ng:
-            # counters of THIS build of the library only: the profiling run stamps the sha of the
-            # libakmi.so it measured (tools/pmc_summary.py)
+        same_lib = t.get("lib_sha16") == lib_sha16()
+        same_src = t.get("src_sha16") is not None and t.get("src_sha16") == src_sha16()
+        if (same_lib or same_src) and not args.recon and not args.ng and not args.set:
+            # counters of THIS library only: the profiling run stamps the sha of the libakmi.so it
+            # measured and of the sources it was built from (tools/pmc_summary.py)
             traffic = round(sum(t["kernels"][k]["hbm_bytes_per_launch"] for k in stage_kernels))
-            tsrc = "profiles/%s (%s, lib %s)" % (os.path.basename(tfile), t.get("tag", ""), t["lib_sha16"])
+            tsrc = "profiles/%s (%s, %s)" % (os.path.basename(tfile), t.get("tag", ""),
+                                              ("lib %s" % t["lib_sha16"]) if same_lib else
+                                              ("same sources %s, rebuilt library" % t["src_sha16"]))
         else:
-            tsrc = "profiles/%s is of another build (lib %s, this run %s): traffic not reported" % (
-                os.path.basename(tfile), t.get("lib_sha16"), lib_sha16())
+            tsrc = "profiles/%s is of another build (lib %s / sources %s, this run %s / %s): traffic not reported" % (
+                os.path.basename(tfile), t.get("lib_sha16"), t.get("src_sha16"), lib_sha16(), src_sha16())
     roofline = {"bound": "hbm",
                 "kernel": ("akmi_%s_stage_fused launch group (sweeps + update%s + c2p of active cells)"
                            % (blk, " + CornerE + CT" if blk == "mhd" else "")) if world == 1 else
@@ -305,7 +325,7 @@ def main():
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el/args.steps*1e3, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
                "data": "synthetic (closed-form %s initial condition)" % args.problem,
-               "lib_sha16": lib_sha16(),
+               "lib_sha16": lib_sha16(), "src_sha16": src_sha16(),
                "config": {"workload": "%s 3D, %s, %d^3 cells per GPU, mesh %dx%dx%d in %dx%dx%d "
                                       "MeshBlocks, cfl 0.3, RK2, ng=%d" % (
                                           args.problem, ("ideal MHD %s+HLLD+CT" % (args.recon or "plm").upper()) if blk == "mhd" else

@@ -43,6 +43,9 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = os.environ.get("AKMI_LIB") or os.path.join(root, "athenak_amd", "lib", "libakmi.so")
     out["lib_sha16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
+    sys.path.insert(0, root)
+    import bench
+    out["src_sha16"] = bench.src_sha16()
     if len(sys.argv) > 3:
         out["tag"] = sys.argv[3]
     print(json.dumps(out, indent=1))
