@@ -205,22 +205,24 @@ AKMI_DEV void face_states(const double *__restrict__ q, long s, const FaceEos &e
 // stencil neighbours differ only in the uniform part, so the compiler keeps ONE offset VGPR per
 // lane and forms the neighbour addresses on the scalar unit (global_load ... v_off, s[base]).
 template <int RECON, int FL = 0>
-AKMI_DEV void face_states_u(const double *__restrict__ base, unsigned off, long s,
+AKMI_DEV void face_states_u(const double *__restrict__ base, unsigned ob, long s,
                             const FaceEos &eos, double &ql, double &qr) {
+  // ob = BYTE offset of the lane (address = scalar base + zero-extended 32-bit VGPR)
+  auto at = [&](const double *b) { return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(b) + ob); };
   double dummy;
   if constexpr (RECON == 1) {
-    double qm2 = (base - 2*s)[off], qm1 = (base - s)[off], q0 = base[off], qp1 = (base + s)[off];
+    double qm2 = at(base - 2*s), qm1 = at(base - s), q0 = at(base), qp1 = at(base + s);
     plm(qm2, qm1, q0, ql, dummy);
     plm(qm1, q0, qp1, dummy, qr);
   } else if constexpr (RECON >= 2) {
-    double qm3 = (base - 3*s)[off], qm2 = (base - 2*s)[off], qm1 = (base - s)[off], q0 = base[off],
-           qp1 = (base + s)[off], qp2 = (base + 2*s)[off];
+    double qm3 = at(base - 3*s), qm2 = at(base - 2*s), qm1 = at(base - s), q0 = at(base),
+           qp1 = at(base + s), qp2 = at(base + 2*s);
     recon5<RECON>(qm3, qm2, qm1, q0, qp1, ql, dummy);
     recon5<RECON>(qm2, qm1, q0, qp1, qp2, dummy, qr);
     floor_lr<RECON, FL>(eos, ql, qr);
   } else {
-    ql = (base - s)[off];
-    qr = base[off];
+    ql = at(base - s);
+    qr = at(base);
   }
 }
 

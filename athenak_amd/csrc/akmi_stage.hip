@@ -62,6 +62,14 @@ static StageWs carve(const Geo &g, int is_mhd, void *ws) {
 }
 
 // ---------------------------------------------------------------------------------------
+// wave-uniform base + 32-bit byte offset of the lane
+__device__ __forceinline__ double ldu(const double *__restrict__ base, unsigned ob) {
+  return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + ob);
+}
+__device__ __forceinline__ void stu(double *__restrict__ base, unsigned ob, double v) {
+  *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + ob) = v;
+}
+
 // face flux from the cell stencil (registers only).  Returns flux in sweep-aligned order.
 template <int DIR, int RECON, bool MHD, int RS>
 __device__ __forceinline__ void face_flux(const Geo &g, const FaceEos &eos,
@@ -73,7 +81,7 @@ __device__ __forceinline__ void face_flux(const Geo &g, const FaceEos &eos,
   const size_t cs = (size_t)g.N3*g.N2*g.N1;
   // wave-uniform bases (m comes from blockIdx) + one 32-bit in-variable offset per lane
   const double *q = w0 + (size_t)m*g.nvar*cs;
-  const unsigned off = (unsigned)(((size_t)k*g.N2 + j)*g.N1 + i);
+  const unsigned off = (((unsigned)k*(unsigned)g.N2 + (unsigned)j)*(unsigned)g.N1 + (unsigned)i)*8u;   // bytes
   double ld, lx, ly, lz, le, rd, rx, ry, rz, re;
   face_states_u<RECON, 1>(q + 0*cs, off, s, eos, ld, rd);
   face_states_u<RECON, 0>(q + ivx*cs, off, s, eos, lx, rx);
@@ -87,7 +95,8 @@ __device__ __forceinline__ void face_flux(const Geo &g, const FaceEos &eos,
     double lby, lbz, rby, rbz;
     face_states_u<RECON, 0>(b + iby*cs, off, s, eos, lby, rby);
     face_states_u<RECON, 0>(b + ibz*cs, off, s, eos, lbz, rbz);
-    const double bxi = bxf[ix4(f3, f2, f1, m, k, j, i)];
+    const double bxi = ldu(bxf + (size_t)m*f3*f2*f1,
+                           (((unsigned)k*(unsigned)f2 + (unsigned)j)*(unsigned)f1 + (unsigned)i)*8u);
     Cons1D fl = riemann_mhd_e<RS>(eos, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
     fd = fl.d; fx = fl.mx; fy = fl.my; fz = fl.mz; fe = fl.e; fby = fl.by; fbz = fl.bz;
   } else {
@@ -140,18 +149,24 @@ __device__ __forceinline__ void sweep_x1_shared(const Geo &g, const FaceEos &eos
   const bool valid = p >= 0 && j <= a.ju && i >= 1 && i <= g.N1 - 2;
   constexpr int NV = MHD ? 7 : 5;
   const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  // addresses = wave-uniform base (block m, variable n: scalar unit) + ONE 32-bit byte offset per lane
+  // (global_load v, v_off, s[base]): no 64-bit integer multiplies on the vector unit.  A block-variable
+  // is below 4 GB (checked at launch).
+  const unsigned krow = (unsigned)k*(unsigned)g.N2 + (unsigned)a.jl;           // uniform
+  const unsigned oc = (krow*(unsigned)g.N1 + (unsigned)pc)*8u;                  // cell (k,j,i)
+  const unsigned of = (((unsigned)k*(unsigned)a.f2 + (unsigned)j)*(unsigned)a.f1 + (unsigned)i)*8u;   // face (k,j,i)
+  const double *wm = a.w0 + (size_t)m*g.nvar*cs;
+  const double *bm = MHD ? a.bcc0 + (size_t)m*3*cs : nullptr;
   double qln[NV], qr[NV];                 // left state of face i+1, right state of face i
 #pragma unroll
   for (int n = 0; n < NV; ++n) { qln[n] = 0.0; qr[n] = 0.0; }
   double vx = 0.0, vy = 0.0, vz = 0.0, by = 0.0, bz = 0.0;
   if (valid) {
-    const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
       if (rs_iso<RS>() && n == 4) continue;             // isothermal: slot 4 (energy) stays unused
-      const double *q = (n < 5) ? a.w0 + c + n*cs
-                                : a.bcc0 + ix5(3, g.N3, g.N2, g.N1, m, n - 4, k, j, i);   // by, bz
-      const double qm = q[-1], q0 = q[0], qp = q[1];
+      const double *q = (n < 5) ? wm + n*cs : bm + (n - 4)*cs;   // by, bz
+      const double qm = ldu(q - 1, oc), q0 = ldu(q, oc), qp = ldu(q + 1, oc);
       plm(qm, q0, qp, qln[n], qr[n]);
       if (n == 1) vx = q0;
       if (n == 2) vy = q0;
@@ -166,17 +181,17 @@ __device__ __forceinline__ void sweep_x1_shared(const Geo &g, const FaceEos &eos
   if (!valid) return;
   if constexpr (ECC) {
     if (i >= a.il - 1 && i <= a.iu) {
-      const double bx = a.bcc0[ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i)];
-      const size_t e = ix4(g.N3, g.N2, g.N1, m, k, j, i);
-      a.ecc1[e] = vz*by - vy*bz;
-      a.ecc2[e] = vx*bz - vz*bx;
-      a.ecc3[e] = vy*bx - vx*by;
+      const double bx = ldu(bm, oc);
+      stu(a.ecc1 + (size_t)m*cs, oc, vz*by - vy*bz);
+      stu(a.ecc2 + (size_t)m*cs, oc, vx*bz - vz*bx);
+      stu(a.ecc3 + (size_t)m*cs, oc, vy*bx - vx*by);
     }
   }
   if (threadIdx.x == 0 || i < a.il || i > a.iu) return;     // lane 0 only provides
   double fd, fx, fy, fz, fe, fby = 0.0, fbz = 0.0;
+  const size_t fs = (size_t)a.f3*a.f2*a.f1;
   if constexpr (MHD) {
-    const double bxi = a.bxf[ix4(a.f3, a.f2, a.f1, m, k, j, i)];
+    const double bxi = ldu(a.bxf + (size_t)m*fs, of);
     Cons1D fl = riemann_mhd_e<RS, true>(eos, L[0], L[1], L[2], L[3], L[4], L[5], L[6], qr[0], qr[1],
                                         qr[2], qr[3], qr[4], qr[5], qr[6], bxi);
     fd = fl.d; fx = fl.mx; fy = fl.my; fz = fl.mz; fe = fl.e; fby = fl.by; fbz = fl.bz;
@@ -184,14 +199,12 @@ __device__ __forceinline__ void sweep_x1_shared(const Geo &g, const FaceEos &eos
     riemann_hyd_e<RS>(eos, L[0], L[1], L[2], L[3], L[4], qr[0], qr[1], qr[2], qr[3], qr[4], fd,
                       fx, fy, fz, fe);
   }
-  const size_t fs = (size_t)a.f3*a.f2*a.f1;
-  double *f = a.flx + ix5(g.nvar, a.f3, a.f2, a.f1, m, 0, k, j, i);
-  f[0] = fd; f[fs] = fx; f[2*fs] = fy; f[3*fs] = fz;
-  if constexpr (!rs_iso<RS>()) f[4*fs] = fe;
+  double *f = a.flx + (size_t)m*g.nvar*fs;
+  stu(f, of, fd); stu(f + fs, of, fx); stu(f + 2*fs, of, fy); stu(f + 3*fs, of, fz);
+  if constexpr (!rs_iso<RS>()) stu(f + 4*fs, of, fe);
   if constexpr (MHD) {
-    const size_t ec = ix4(g.N3, g.N2, g.N1, m, k, j, i);
-    a.ey[ec] = -fby;
-    a.ez[ec] = fbz;
+    stu(a.ey + (size_t)m*cs, oc, -fby);
+    stu(a.ez + (size_t)m*cs, oc, fbz);
   }
 }
 
@@ -212,15 +225,14 @@ k_sweep(Geo g, FaceEos eos, SweepArgs a, int nk) {
   const int k = a.kl + (blockIdx.z - m*nk);
   if (j > a.ju || i < a.il - (ECC ? 1 : 0) || i > a.iu) return;
   const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  const unsigned oc = (((unsigned)k*(unsigned)g.N2 + (unsigned)a.jl)*(unsigned)g.N1 + (unsigned)p)*8u;   // cell (k,j,i)
   if constexpr (ECC) {
-    const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
-    const size_t b = ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i);
-    const double vx = a.w0[c + cs], vy = a.w0[c + 2*cs], vz = a.w0[c + 3*cs];
-    const double bx = a.bcc0[b], by = a.bcc0[b + cs], bz = a.bcc0[b + 2*cs];
-    const size_t e = ix4(g.N3, g.N2, g.N1, m, k, j, i);
-    a.ecc1[e] = vz*by - vy*bz;
-    a.ecc2[e] = vx*bz - vz*bx;
-    a.ecc3[e] = vy*bx - vx*by;
+    const double *wm = a.w0 + (size_t)m*g.nvar*cs, *bm = a.bcc0 + (size_t)m*3*cs;
+    const double vx = ldu(wm + cs, oc), vy = ldu(wm + 2*cs, oc), vz = ldu(wm + 3*cs, oc);
+    const double bx = ldu(bm, oc), by = ldu(bm + cs, oc), bz = ldu(bm + 2*cs, oc);
+    stu(a.ecc1 + (size_t)m*cs, oc, vz*by - vy*bz);
+    stu(a.ecc2 + (size_t)m*cs, oc, vx*bz - vz*bx);
+    stu(a.ecc3 + (size_t)m*cs, oc, vy*bx - vx*by);
     if (i < a.il) return;
   }
   constexpr int ivx = 1 + DIR, ivy = 1 + (DIR + 1)%3, ivz = 1 + (DIR + 2)%3;
@@ -228,13 +240,13 @@ k_sweep(Geo g, FaceEos eos, SweepArgs a, int nk) {
   face_flux<DIR, RECON, MHD, RS>(g, eos, a.w0, a.bcc0, a.bxf, a.f3, a.f2, a.f1, m, k, j, i, fd,
                                  fx, fy, fz, fe, fby, fbz);
   const size_t fs = (size_t)a.f3*a.f2*a.f1;
-  double *f = a.flx + ix5(g.nvar, a.f3, a.f2, a.f1, m, 0, k, j, i);
-  f[0] = fd; f[ivx*fs] = fx; f[ivy*fs] = fy; f[ivz*fs] = fz;
-  if constexpr (!rs_iso<RS>()) f[4*fs] = fe;
+  const unsigned of = (((unsigned)k*(unsigned)a.f2 + (unsigned)j)*(unsigned)a.f1 + (unsigned)i)*8u;       // face (k,j,i)
+  double *f = a.flx + (size_t)m*g.nvar*fs;
+  stu(f, of, fd); stu(f + ivx*fs, of, fx); stu(f + ivy*fs, of, fy); stu(f + ivz*fs, of, fz);
+  if constexpr (!rs_iso<RS>()) stu(f + 4*fs, of, fe);
   if constexpr (MHD) {
-    const size_t ec = ix4(g.N3, g.N2, g.N1, m, k, j, i);
-    a.ey[ec] = -fby;
-    a.ez[ec] = fbz;
+    stu(a.ey + (size_t)m*cs, oc, -fby);
+    stu(a.ez + (size_t)m*cs, oc, fbz);
   }
 }
 
@@ -271,6 +283,12 @@ __device__ __forceinline__ void rk_store(double *__restrict__ u0, double *__rest
   u0[c] = res;
 }
 // beta*dt: the product the host forms in RKUpdate (hydro_update.cpp:35), same operands, same rounding
+__device__ __forceinline__ void rk_store_u(double *__restrict__ u0, double *__restrict__ u1, int copy, unsigned ob,
+                                           double old, double res) {
+  if (copy == 2) { stu(u1, ob, res); return; }
+  if (copy) stu(u1, ob, old);
+  stu(u0, ob, res);
+}
 __device__ __forceinline__ double beta_dt_of(double beta_dt, const double *dtp) {
   return dtp ? beta_dt*(*dtp) : beta_dt;
 }
@@ -320,6 +338,12 @@ __device__ __forceinline__ double beta_dt_of(double beta_dt, const double *dtp) 
 #endif
 #ifndef AKMI_PREFETCH_X1
 #define AKMI_PREFETCH_X1 0
+#endif
+#ifndef AKMI_X2_EO
+#define AKMI_X2_EO 0            // wave-uniform early-outs of HLLD in the x2 / x3 march (registers!)
+#endif
+#ifndef AKMI_X3_EO
+#define AKMI_X3_EO 0
 #endif
 constexpr int ML = AKMI_ML;            // faces marched per thread (chunk length), full-size packs
 
@@ -455,9 +479,12 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
   const long st = (DIR == 1) ? (long)g.N1 : (long)g.N1*g.N2;
   // wave-uniform variable bases in sweep-aligned order d, vx, vy, vz, e, (by, bz) + one
   // per-lane element offset that advances by st per step
+  // (addresses = uniform base on the scalar unit + 32-bit byte offset of the lane: global_load v, v_off,
+  // s[base]; a block-variable is below 4 GB, checked at launch)
   const double *wb = a.w0 + (size_t)m*g.nvar*cs;
   const double *bb = MHD ? a.bcc0 + (size_t)m*3*cs : nullptr;
-  size_t off = ((size_t)k*g.N2 + j)*g.N1 + i;
+  unsigned off = (((unsigned)k*(unsigned)g.N2 + (unsigned)j)*(unsigned)g.N1 + (unsigned)i)*8u;   // cell s
+  const unsigned st8 = (unsigned)st*8u;
   auto base = [&](int n) -> const double * {
     return n == 0 ? wb : n == 1 ? wb + ivx*cs : n == 2 ? wb + ivy*cs : n == 3 ? wb + ivz*cs
          : n == 4 ? wb + 4*cs : n == 5 ? bb + iby*cs : bb + ibz*cs;
@@ -466,31 +493,40 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
 #pragma unroll
   for (int n = 0; n < NV; ++n) {
     if (ISO && n == 4) continue;
-    const double *q = base(n) + off;
+    const double *q = base(n);
     double pl, dummy;
     if constexpr (RECON == 1) {
-      const double qa = q[-2*st], qb = q[-st], qc = q[0];
+      const double qa = ldu(q - 2*st, off), qb = ldu(q - st, off), qc = ldu(q, off);
       plm(qa, qb, qc, pl, dummy);
       W_(n, 0) = qb; W_(n, 1) = qc;
     } else if constexpr (RECON >= 2) {
-      const double qa = q[-3*st], qb = q[-2*st], qc = q[-st], qd = q[0], qe = q[st];
+      const double qa = ldu(q - 3*st, off), qb = ldu(q - 2*st, off), qc = ldu(q - st, off), qd = ldu(q, off),
+                   qe = ldu(q + st, off);
       recon5<RECON>(qa, qb, qc, qd, qe, pl, dummy);
       if (n == 0) floor_lr<RECON, 1>(eos, pl, dummy);
       if (n == 4) floor_lr<RECON, 2>(eos, pl, dummy);
       W_(n, 0) = qb; W_(n, 1) = qc; W_(n, 2) = qd; W_(n, 3) = qe;
     } else {
-      pl = q[-st];
-      W_(n, 0) = q[0];
+      pl = ldu(q - st, off);
+      W_(n, 0) = ldu(q, off);
     }
     PL_(n) = pl;
   }
-  const size_t fst = (DIR == 1) ? (size_t)a.f1 : (size_t)a.f1*a.f2;   // face-array stride
-  const double *pbx = MHD ? a.bxf + ix4(a.f3, a.f2, a.f1, m, k, j, i) : nullptr;
+  // face (k,j,i) of this direction's face-shaped arrays (f3,f2,f1), advancing with the march
+  const size_t fs = (size_t)a.f3*a.f2*a.f1;
+  unsigned foff = (((unsigned)k*(unsigned)a.f2 + (unsigned)j)*(unsigned)a.f1 + (unsigned)i)*8u;
+  const unsigned fst8 = ((DIR == 1) ? (unsigned)a.f1 : (unsigned)a.f1*(unsigned)a.f2)*8u;
+  const double *bxm = MHD ? a.bxf + (size_t)m*fs : nullptr;
+  double *mfm = a.flx ? a.flx + (size_t)m*g.nvar*fs : nullptr;       // variable 0: the mass flux
+  // x1 fluxes (N3,N2,N1+1) of the cell row the step finishes (x2 march without acc)
+  const size_t fs1 = (size_t)g.N3*g.N2*(g.N1 + 1);
+  unsigned o1 = (((unsigned)k*(unsigned)g.N2 + (unsigned)j)*(unsigned)(g.N1 + 1) + (unsigned)i)*8u;
+  const unsigned st18 = (unsigned)(g.N1 + 1)*8u;
   constexpr bool PW = RECON == 1 && ((AKMI_PREFETCH_W && DIR == 2) || (AKMI_PREFETCH_W2 && DIR == 1));
   double nx[NV];                         // PW: cells s+1 of the coming step, loaded one step ahead
   if constexpr (PW) {
 #pragma unroll
-    for (int n = 0; n < NV; ++n) nx[n] = (ISO && n == 4) ? 0.0 : (base(n) + off)[st];
+    for (int n = 0; n < NV; ++n) nx[n] = (ISO && n == 4) ? 0.0 : ldu(base(n) + st, off);
   }
   for (int t = 0; t <= ml; ++t) {
     const int s = s0 + t;
@@ -500,23 +536,23 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
     if constexpr (PW) {
       const bool more = (t < ml) && (s < shi);           // a next step exists: its cell s+2 is inside the array
 #pragma unroll
-      for (int n = 0; n < NV; ++n) nx2[n] = (more && !(ISO && n == 4)) ? (base(n) + off)[2*st] : 0.0;
+      for (int n = 0; n < NV; ++n) nx2[n] = (more && !(ISO && n == 4)) ? ldu(base(n) + 2*st, off) : 0.0;
     }
     double L[NV], R[NV];
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
       if (ISO && n == 4) { L[n] = R[n] = 0.0; continue; }      // isothermal: no energy variable
-      const double *q = base(n) + off;
+      const double *q = base(n);
       double qln;
       L[n] = PL_(n);
       if constexpr (RECON == 1) {
         double qp;
-        if constexpr (PW) qp = nx[n]; else qp = q[st];
+        if constexpr (PW) qp = nx[n]; else qp = ldu(q + st, off);
         const double w0 = W_(n, 0), w1 = W_(n, 1);
         plm(w0, w1, qp, qln, R[n]);
         W_(n, 0) = w1; W_(n, 1) = qp;
       } else if constexpr (RECON >= 2) {
-        const double qp = q[2*st];
+        const double qp = ldu(q + 2*st, off);
         const double w0 = W_(n, 0), w1 = W_(n, 1), w2 = W_(n, 2), w3 = W_(n, 3);
         recon5<RECON>(w0, w1, w2, w3, qp, qln, R[n]);
         if (n == 0) floor_lr<RECON, 1>(eos, qln, R[n]);
@@ -526,11 +562,13 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
         const double w0 = W_(n, 0);
         R[n] = w0;
         qln = w0;
-        W_(n, 0) = q[st];
+        W_(n, 0) = ldu(q + st, off);
       }
       PL_(n) = qln;
     }
-    off += st;
+    const unsigned oc = off;                            // cell s == face s of the cell-shaped EMF arrays
+    const unsigned ocm = off - st8;                     // cell s-1, the one this face finishes
+    off += st8;
     // x3 march: fetch the update operands of the cell this face finishes BEFORE the Riemann solve,
     // so that their latency is covered by ~1000 VALU instructions instead of following them
     // (this kernel moves the most bytes of the stage and runs at 3 waves/SIMD)
@@ -540,12 +578,15 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
     double pa[5], pu[5], pu1[5];
     if constexpr (PRE) {
       if (upd) {
-        const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, sc, j, i);
+        const size_t mb = (size_t)m*g.nvar*cs;
 #pragma unroll
-        for (int n = 0; n < 5; ++n) { if (ISO && n == 4) continue; pa[n] = u.acc[c + n*cs]; pu[n] = u.u0[c + n*cs]; }
+        for (int n = 0; n < 5; ++n) {
+          if (ISO && n == 4) continue;
+          pa[n] = ldu(u.acc + mb + n*cs, ocm); pu[n] = ldu(u.u0 + mb + n*cs, ocm);
+        }
         if (AKMI_PREFETCH_U1 && !u.copy_u1) {
 #pragma unroll
-          for (int n = 0; n < 5; ++n) { if (ISO && n == 4) continue; pu1[n] = u.u1[c + n*cs]; }
+          for (int n = 0; n < 5; ++n) { if (ISO && n == 4) continue; pu1[n] = ldu(u.u1 + mb + n*cs, ocm); }
         }
       }
     }
@@ -553,12 +594,11 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
     constexpr bool PRE1 = (DIR == 1) && (MODE == 1) && !USEACC && AKMI_PREFETCH_X1;
     if constexpr (PRE1) {
       if (upd) {
-        const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k, sc, i);
-        const size_t fs1 = (size_t)g.N3*g.N2*(g.N1 + 1);
+        const double *f1 = u.flx1 + (size_t)m*g.nvar*fs1 - (g.N1 + 1);       // row sc = s-1
 #pragma unroll
         for (int n = 0; n < 5; ++n) {
           if (ISO && n == 4) continue;
-          const double d1 = u.flx1[c + n*fs1 + 1] - u.flx1[c + n*fs1];
+          const double d1 = ldu(f1 + n*fs1 + 1, o1) - ldu(f1 + n*fs1, o1);
           pa[n] = p2 ? d1*rdx1 : d1/dx1;
         }
       }
@@ -568,30 +608,30 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
 #if AKMI_DBG_NOSOLVE      // timing experiment only (wrong results): what the march costs without its Riemann solve
       Cons1D fl;
       fl.d = L[0] + R[0]; fl.mx = L[1] + R[1]; fl.my = L[2] + R[2]; fl.mz = L[3] + R[3]; fl.e = L[4] + R[4];
-      fl.by = L[5] + R[5] + pbx[(size_t)t*fst]; fl.bz = L[6] + R[6];
+      fl.by = L[5] + R[5] + ldu(bxm, foff); fl.bz = L[6] + R[6];
 #else
-      Cons1D fl = riemann_mhd_e<RS>(eos, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1],
-                                    R[2], R[3], R[4], R[5], R[6], pbx[(size_t)t*fst]);
+      Cons1D fl = riemann_mhd_e<RS, (DIR == 1 ? AKMI_X2_EO : AKMI_X3_EO) != 0>(
+          eos, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1], R[2], R[3], R[4], R[5], R[6], ldu(bxm, foff));
 #endif
       fd = fl.d; fx = fl.mx; fy = fl.my; fz = fl.mz; fe = fl.e;
       if (t < ml || s == shi) {
         // CornerE needs the sign of the mass flux and the two face EMFs of this direction
-        a.flx[ix5(g.nvar, a.f3, a.f2, a.f1, m, 0, k, j, i)] = fd;
-        const size_t ec = ix4(g.N3, g.N2, g.N1, m, k, j, i);
-        a.ey[ec] = -fl.by;
-        a.ez[ec] = fl.bz;
+        stu(mfm, foff, fd);
+        stu(a.ey + (size_t)m*cs, oc, -fl.by);
+        stu(a.ez + (size_t)m*cs, oc, fl.bz);
       }
     } else {
       riemann_hyd_e<RS>(eos, L[0], L[1], L[2], L[3], L[4], R[0], R[1], R[2], R[3], R[4], fd, fx,
                         fy, fz, fe);
       // passive scalars are advected by the mass flux (k_scalar_update): keep it
-      if (g.nvar > (ISO ? 4 : 5) && (t < ml || s == shi)) a.flx[ix5(g.nvar, a.f3, a.f2, a.f1, m, 0, k, j, i)] = fd;
+      if (g.nvar > (ISO ? 4 : 5) && (t < ml || s == shi)) stu(mfm, foff, fd);
     }
+    foff += fst8;
     double fv[5];
     fv[0] = fd; fv[ivx] = fx; fv[ivy] = fy; fv[ivz] = fz; fv[4] = fe;
     if (upd) {
       const int kc = (DIR == 2) ? sc : k, jc = (DIR == 1) ? sc : j;
-      const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, kc, jc, i);
+      const size_t mb = (size_t)m*g.nvar*cs;
 #pragma unroll
       for (int n = 0; n < 5; ++n) {
         if (ISO && n == 4) continue;
@@ -600,7 +640,11 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
         if constexpr (PRE || PRE1) {
           divf = pa[n];
         } else if constexpr (USEACC) {
-          divf = u.acc[c + n*cs];
+          divf = ldu(u.acc + mb + n*cs, ocm);
+        } else if constexpr (DIR == 1) {
+          const double *f1 = u.flx1 + (size_t)m*g.nvar*fs1 + n*fs1 - (g.N1 + 1);     // row sc = s-1
+          const double d1 = ldu(f1 + 1, o1) - ldu(f1, o1);
+          divf = p2 ? d1*rdx1 : d1/dx1;
         } else {
           const double d1 = u.flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, n, kc, jc, i + 1)] -
                             u.flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, n, kc, jc, i)];
@@ -617,19 +661,21 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
           divf += p2 ? (fv[n] - fprev)*rdx3 : (fv[n] - fprev)/dx3;
         }
         if constexpr (MODE == 1) {
-          u.acc[c + n*cs] = divf;
+          stu(u.acc + mb + n*cs, ocm, divf);
         } else {
           double u0v;
-          if constexpr (PRE) u0v = pu[n]; else u0v = u.u0[c + n*cs];
+          if constexpr (PRE) u0v = pu[n]; else u0v = ldu(u.u0 + mb + n*cs, ocm);
           double u1v;
           if constexpr (PRE && AKMI_PREFETCH_U1) u1v = u.copy_u1 ? u0v : pu1[n];
-          else u1v = u.copy_u1 ? u0v : u.u1[c + n*cs];
-          rk_store(u.u0, u.u1, u.copy_u1, c + n*cs, u0v, u.gam0*u0v + u.gam1*u1v - beta_dt_of(u.beta_dt, u.dtp)*divf);
+          else u1v = u.copy_u1 ? u0v : ldu(u.u1 + mb + n*cs, ocm);
+          rk_store_u(u.u0 + mb + n*cs, u.u1 + mb + n*cs, u.copy_u1, ocm, u0v,
+                     u.gam0*u0v + u.gam1*u1v - beta_dt_of(u.beta_dt, u.dtp)*divf);
         }
       }
     }
 #pragma unroll
     for (int n = 0; n < 5; ++n) { if (ISO && n == 4) continue; FP_(n) = fv[n]; }
+    o1 += st18;
     if constexpr (PW) {
 #pragma unroll
       for (int n = 0; n < NV; ++n) nx[n] = nx2[n];
@@ -1410,24 +1456,26 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
       if (j0 - 2 + hy >= g.N2 || i0 - 2 + hx >= g.N1) hy = -1;
     }
   }
-  const size_t hcol = hy >= 0 ? (size_t)(j0 - 2 + hy)*g.N1 + (i0 - 2 + hx) : 0;
-  const size_t col = cell_ok ? (size_t)j*g.N1 + i : 0;
+  // (scalar base of the plane + 32-bit byte offset of the lane within it)
+  const unsigned hcol = hy >= 0 ? ((unsigned)(j0 - 2 + hy)*(unsigned)g.N1 + (unsigned)(i0 - 2 + hx))*8u : 0u;
+  const unsigned col = cell_ok ? ((unsigned)j*(unsigned)g.N1 + (unsigned)i)*8u : 0u;
+  const size_t mb = (size_t)m*g.nvar*cs;
   double W0[5], W1[5], PL[5], F3p[5], hv[5];
 #pragma unroll
   for (int n = 0; n < 5; ++n) {
       ISOSKIP;
-    const double *q = wb + n*cs + col;
-    W0[n] = cell_ok ? q[(size_t)(k0 - 1)*ps] : 1.0;
-    W1[n] = cell_ok ? q[(size_t)k0*ps] : 1.0;
+    const double *q = wb + n*cs;
+    W0[n] = cell_ok ? ldu(q + (size_t)(k0 - 1)*ps, col) : 1.0;
+    W1[n] = cell_ok ? ldu(q + (size_t)k0*ps, col) : 1.0;
     if constexpr (RECON == 1) {
-      const double qa = cell_ok ? q[(size_t)(k0 - 2)*ps] : 1.0;
+      const double qa = cell_ok ? ldu(q + (size_t)(k0 - 2)*ps, col) : 1.0;
       double dummy;
       plm(qa, W0[n], W1[n], PL[n], dummy);
     } else {
       PL[n] = 0.0;
     }
     F3p[n] = 0.0;
-    hv[n] = hy >= 0 ? wb[n*cs + (size_t)k0*ps + hcol] : 1.0;
+    hv[n] = hy >= 0 ? ldu(wb + n*cs + (size_t)k0*ps, hcol) : 1.0;
   }
   // step k: x3 face k (below cell k) from registers; for k > k0 also the x1/x2 faces of plane k-1
   // (in LDS since the previous step), which finishes cell k-1; plane k goes to the other buffer
@@ -1436,15 +1484,15 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
     const bool plane = k > k0;                        // workgroup-uniform
     double wp[5];
 #pragma unroll
-    for (int n = 0; n < 5; ++n) { ISOSKIP; wp[n] = cell_ok ? wb[n*cs + (size_t)(k + 1)*ps + col] : 1.0; }
+    for (int n = 0; n < 5; ++n) { ISOSKIP; wp[n] = cell_ok ? ldu(wb + n*cs + (size_t)(k + 1)*ps, col) : 1.0; }
     double pu0[5], pu1[5];
     if (plane && own) {                               // operands of the update, used after the solves
-      const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k - 1, j, i);
+      const size_t c = mb + (size_t)(k - 1)*ps;
 #pragma unroll
       for (int n = 0; n < 5; ++n) {
       ISOSKIP;
-        pu0[n] = u.u0[c + n*cs];
-        pu1[n] = u.copy_u1 ? 0.0 : u.u1[c + n*cs];
+        pu0[n] = ldu(u.u0 + c + n*cs, col);
+        pu1[n] = u.copy_u1 ? 0.0 : ldu(u.u1 + c + n*cs, col);
       }
     }
     if (plane && in_tile) {
@@ -1531,13 +1579,13 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
         for (int n = 0; n < 5; ++n) { ISOSKIP; SW(b ^ 1, n, hy, hx) = hv[n]; }
         if (k + 1 <= k1) {
 #pragma unroll
-          for (int n = 0; n < 5; ++n) { ISOSKIP; hv[n] = wb[n*cs + (size_t)(k + 1)*ps + hcol]; }
+          for (int n = 0; n < 5; ++n) { ISOSKIP; hv[n] = ldu(wb + n*cs + (size_t)(k + 1)*ps, hcol); }
         }
       }
     }
     __syncthreads();
     if (plane && own) {                                // finish cell k-1
-      const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k - 1, j, i);
+      const size_t c = mb + (size_t)(k - 1)*ps;
 #pragma unroll
       for (int n = 0; n < 5; ++n) {
       ISOSKIP;
@@ -1546,7 +1594,8 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
         divf += (f3[n] - F3p[n])/dx3;
         const double u0v = pu0[n];
         const double u1v = u.copy_u1 ? u0v : pu1[n];
-        rk_store(u.u0, u.u1, u.copy_u1, c + n*cs, u0v, u.gam0*u0v + u.gam1*u1v - beta_dt_of(u.beta_dt, u.dtp)*divf);
+        rk_store_u(u.u0 + c + n*cs, u.u1 + c + n*cs, u.copy_u1, col, u0v,
+                   u.gam0*u0v + u.gam1*u1v - beta_dt_of(u.beta_dt, u.dtp)*divf);
       }
     }
 #pragma unroll
@@ -1847,6 +1896,12 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
   }
   Geo g = make_geo(p);
   Eos eos = make_eos(p);
+  // the sweeps address one variable of one MeshBlock with a 32-bit byte offset per lane
+  if ((size_t)(g.N3 + 1)*(g.N2 + 1)*(g.N1 + 1)*sizeof(double) >= ((size_t)1 << 32)) {
+    set_error("stage: a MeshBlock of %d x %d x %d cells (with ghosts) exceeds 4 GB per variable; use smaller "
+              "MeshBlocks", g.N1, g.N2, g.N3);
+    return AKMI_FAIL;
+  }
   const Scheme sc{recon, rsolver, make_face_eos(p), !p->is_ideal};
   StageWs w = carve(g, MHD ? 1 : 0, ws);
   // phases: a caller that exchanges halos between the parts of a stage (multi-rank runs) asks

@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--split", action="store_true", help="task-granular chain instead of fused stage")
     ap.add_argument("--set", action="append", default=[], metavar="block/name=value",
                     help="extra deck parameter (side measurements, e.g. mhd/nscalars=2); named in config.workload")
+    ap.add_argument("--native-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--native", action="store_true",
                     help="drive the run from the C++ host (akmi_sim_*): Driver/TaskList in C++, halos and the dt "
                          "reduction through RCCL called directly (ncclSend/ncclRecv/ncclAllReduce); the roofline "
@@ -196,7 +197,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 and not args.native_child:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # developer knobs for a functional check of the N>1 path on a 1-GPU box (RCCL refuses two
@@ -211,11 +212,13 @@ def main():
         else:
             dist.init_process_group(backend)
     else:
-        torch.cuda.set_device(0)
+        torch.cuda.set_device(0 if os.environ.get("AKMI_SHARE_GPU", "0") == "1" else local)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     nblk = block_grid(world)
     pin, blk = make_pin(args, nblk)
+    if args.native_child:
+        return native_child(args, pin, rank, world)
     if args.native:
         return main_native(args, pin, blk, nblk, rank, world)
     from athenak_amd.main import Simulation
@@ -311,7 +314,7 @@ def main():
                 "halo_bcs_shell_c2p_ms": round(tH*1e3, 4),
                 "whole_stage": {"achieved": round(stage_bytes*ncell_rank*drv.nexp_stages*args.steps
                                                   / el / 1e9, 1)},
-                "note": "measured traffic is 2.7x the algorithmic bytes (intermediates between the five kernels); "
+                "note": "measured traffic is 2.6x the algorithmic bytes (intermediates between the five kernels); "
                         "CornerE+CT and c2p already stream at 5.7-5.9 TB/s, the x3 march sits at its traffic, "
                         "the x1 sweep and x2 march are co-limited by ~1000 fp64 instructions per face: DESIGN.md 3"}
     roofline["whole_stage"]["frac"] = round(roofline["whole_stage"]["achieved"]/HBM_PEAK_GBS, 4)
@@ -345,52 +348,76 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, blk)
         print(json.dumps(out), flush=True)
     if world > 1:
-        chk = os.environ.get("AKMI_BENCH_NATIVE_CHECK", "1")      # "force": also on the host-staged functional path
-        if (dist.get_backend() == "nccl" and chk != "0") or chk == "force":
-            native_check(args, pin, rank, world, ncell_total)
+        chk = os.environ.get("AKMI_BENCH_NATIVE_CHECK", "1")
+        nccl = dist.get_backend() == "nccl"
+        dist.barrier()
         dist.destroy_process_group()
+        if (nccl and chk != "0") or chk == "force":      # force: developer check of the isolation
+            native_check(args, pin, rank, world, ncell_total)
 
 
 def native_check(args, pin, rank, world, ncell_total):
     """After the line above is out: the same workload through the C++ host with RCCL called directly
     (ncclSend/ncclRecv groups on the communicator stream, ncclAllReduce for dt) -- the transport this
-    build could never run on more than one GPU.  Result on stderr only; a watchdog ends the process
-    quietly if anything stalls, so the measurement above cannot be lost to it."""
-    import threading
-    import torch
-    import torch.distributed as dist
-
-    def bail():
-        sys.stderr.write("[native-host check] rank %d: no result within 120 s, giving up\n" % rank)
-        sys.stderr.flush()
-        os._exit(0)
-    wd = threading.Timer(120.0, bail)
-    wd.daemon = True
-    wd.start()
+    build could never run on more than one GPU.  Every rank starts a CHILD process for it (same GPU,
+    communicator bootstrapped over TCP by akmi_comm_init_env), so that neither an abort inside the
+    library nor a stall can change this process's exit status: the child is given 150 s and its
+    result goes to stderr only."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--native-child", "--gpus", str(world),
+           "--nx", str(args.nx), "--problem", args.problem, "--steps", "20", "--warmup", "3"]
+    if args.mb:
+        cmd += ["--mb", str(args.mb)]
+    if args.recon:
+        cmd += ["--recon", args.recon]
+    if args.ng:
+        cmd += ["--ng", str(args.ng)]
+    for s_ in (args.set or []):
+        cmd += ["--set", s_]
     try:
-        from athenak_amd import native
-        kind = native.init_comm_from_torch_distributed()
-        sim = native.NativeSimulation(pin)
-        sim.Execute(max_cycles=3)
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        n = sim.Execute(max_cycles=20)
-        torch.cuda.synchronize()
-        dist.barrier()
-        el = time.perf_counter() - t0
-        t = torch.tensor([el], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        if rank == 0:
-            sys.stderr.write("[native-host check] C++ host + %s on %d GPUs: %.2f Mcell-updates/s, %.4f ms/step "
-                             "(%d cycles, t=%.6e dt=%.6e)\n" % (kind, world, ncell_total*n/float(t.item())/1e6,
-                                                                float(t.item())/n*1e3, n, sim.time, sim.dt))
-            sys.stderr.flush()
-        sim.close()
-        native.finalize_comm()
+        p = subprocess.Popen(cmd, stdout=subprocess.DEVNULL)
+        try:
+            rc = p.wait(timeout=150)
+            if rc != 0:
+                sys.stderr.write("[native-host check] rank %d: child ended with status %d\n" % (rank, rc))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+            sys.stderr.write("[native-host check] rank %d: no result within 150 s, child stopped\n" % rank)
     except Exception as e:     # the check must never take the bench down
         sys.stderr.write("[native-host check] rank %d failed: %r\n" % (rank, e))
-    wd.cancel()
+    sys.stderr.flush()
+
+
+def native_child(args, pin, rank, world):
+    """body of the child process of native_check: C++ host + RCCL, no torch.distributed"""
+    import ctypes as C
+    import torch
+    from athenak_amd import capi, native
+    L = capi.lib()
+    capi.check(L.akmi_comm_init_env(), "comm_init_env")
+    sim = native.NativeSimulation(pin)
+    ncell_total = sim.pmesh.nmb_total*sim.pmesh.NumberOfMeshBlockCells()
+
+    def allmin(x):
+        v = (C.c_double*1)(x)
+        capi.check(L.akmi_comm_allreduce_min(v, 1, capi._stream()), "comm_allreduce_min")
+        return v[0]
+
+    sim.Execute(max_cycles=args.warmup)
+    torch.cuda.synchronize()
+    allmin(0.0)                                   # barrier
+    t0 = time.perf_counter()
+    n = sim.Execute(max_cycles=args.steps)
+    torch.cuda.synchronize()
+    el = -allmin(-(time.perf_counter() - t0))     # max over ranks
+    if rank == 0:
+        sys.stderr.write("[native-host check] C++ host + RCCL on %d GPUs: %.2f Mcell-updates/s, %.4f ms/step "
+                         "(%d cycles, t=%.6e dt=%.6e)\n" % (world, ncell_total*n/el/1e6, el/n*1e3, n,
+                                                            sim.time, sim.dt))
+        sys.stderr.flush()
+    sim.close()
+    native.finalize_comm()
 
 
 def main_native(args, pin, blk, nblk, rank, world):
