@@ -125,15 +125,16 @@ struct SweepArgs {
 // plain sweep (not the last direction): thread per face.  ECC: also emit e_cc for the right
 // cell of every face and for the extra column i = il-1 (mhd_corner_e.cpp:309-317 range
 // [is-1,ie+1] x [js-1,je+1] x [ks-1,ke+1] == the CT-extended x1 sweep, right cells).
-// x1 sweep with PLM: the limited slope of a cell serves both of its faces, so a lane computes the
-// slopes of ITS cell only (one division per variable instead of two) and takes the left state of
-// its face from the lane below through a wave shuffle.  Waves overlap by one lane (lane 0 only
+// x1 sweep with PLM / the five-point schemes: the reconstruction of a cell serves both of its faces
+// (ReconCellT, recon.hpp:40-118: cell c-1 writes wl(c), cell c writes wr(c)), so a lane reconstructs
+// ITS cell only (PLM: one division per variable instead of two) and takes the left state of its face
+// from the lane below through a wave shuffle.  Waves overlap by one lane (lane 0 only
 // provides): 63 faces per wave.  Same operands, same operations -> same bits.
 #ifndef AKMI_X1_SHARE
 #define AKMI_X1_SHARE 1
 #endif
 template <int DIR, int RECON>
-constexpr bool x1_share() { return DIR == 0 && RECON == 1 && AKMI_X1_SHARE; }
+constexpr bool x1_share() { return DIR == 0 && RECON >= 1 && AKMI_X1_SHARE; }
 
 template <int RECON, bool MHD, bool ECC, int RS>
 __device__ __forceinline__ void sweep_x1_shared(const Geo &g, const FaceEos &eos, const SweepArgs &a,
@@ -145,8 +146,9 @@ __device__ __forceinline__ void sweep_x1_shared(const Geo &g, const FaceEos &eos
   const int j = a.jl + jj;
   const int m = blockIdx.z/nk;
   const int k = a.kl + (blockIdx.z - m*nk);
-  // a lane owns cell i: slopes need i-1 and i+1 inside the row
-  const bool valid = p >= 0 && j <= a.ju && i >= 1 && i <= g.N1 - 2;
+  // a lane owns cell i: its stencil (i-1..i+1, five-point schemes i-2..i+2) has to be inside the row
+  constexpr int HW = RECON == 1 ? 1 : 2;
+  const bool valid = p >= 0 && j <= a.ju && i >= HW && i <= g.N1 - 1 - HW;
   constexpr int NV = MHD ? 7 : 5;
   const size_t cs = (size_t)g.N3*g.N2*g.N1;
   // addresses = wave-uniform base (block m, variable n: scalar unit) + ONE 32-bit byte offset per lane
@@ -167,7 +169,15 @@ __device__ __forceinline__ void sweep_x1_shared(const Geo &g, const FaceEos &eos
       if (rs_iso<RS>() && n == 4) continue;             // isothermal: slot 4 (energy) stays unused
       const double *q = (n < 5) ? wm + n*cs : bm + (n - 4)*cs;   // by, bz
       const double qm = ldu(q - 1, oc), q0 = ldu(q, oc), qp = ldu(q + 1, oc);
-      plm(qm, q0, qp, qln[n], qr[n]);
+      if constexpr (RECON == 1) {
+        plm(qm, q0, qp, qln[n], qr[n]);
+      } else {
+        const double qmm = ldu(q - 2, oc), qpp = ldu(q + 2, oc);
+        recon5<RECON>(qmm, qm, q0, qp, qpp, qln[n], qr[n]);
+        // the floors of recon.hpp:72-103 act on each state separately: per cell == per face
+        if (n == 0) floor_lr<RECON, 1>(eos, qln[n], qr[n]);
+        if (n == 4) floor_lr<RECON, 2>(eos, qln[n], qr[n]);
+      }
       if (n == 1) vx = q0;
       if (n == 2) vy = q0;
       if (n == 3) vz = q0;
@@ -338,6 +348,15 @@ __device__ __forceinline__ double beta_dt_of(double beta_dt, const double *dtp) 
 #endif
 #ifndef AKMI_PREFETCH_X1
 #define AKMI_PREFETCH_X1 0
+#endif
+#ifndef AKMI_PREFETCH_WP2
+#define AKMI_PREFETCH_WP2 1     // five-point schemes (two waves per SIMD): next cells prefetched in the x2 march,
+#endif
+#ifndef AKMI_PREFETCH_WP3
+#define AKMI_PREFETCH_WP3 1     // ... in the x3 march,
+#endif
+#ifndef AKMI_PREFETCH_X1P
+#define AKMI_PREFETCH_X1P 1     // ... the x1 flux difference fetched before the solve in the x2 march
 #endif
 #ifndef AKMI_X2_EO
 #define AKMI_X2_EO 0            // wave-uniform early-outs of HLLD in the x2 / x3 march (registers!)
@@ -522,11 +541,13 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
   const size_t fs1 = (size_t)g.N3*g.N2*(g.N1 + 1);
   unsigned o1 = (((unsigned)k*(unsigned)g.N2 + (unsigned)j)*(unsigned)(g.N1 + 1) + (unsigned)i)*8u;
   const unsigned st18 = (unsigned)(g.N1 + 1)*8u;
-  constexpr bool PW = RECON == 1 && ((AKMI_PREFETCH_W && DIR == 2) || (AKMI_PREFETCH_W2 && DIR == 1));
+  constexpr bool PW = (RECON == 1 && ((AKMI_PREFETCH_W && DIR == 2) || (AKMI_PREFETCH_W2 && DIR == 1))) ||
+                      (RECON >= 2 && ((AKMI_PREFETCH_WP3 && DIR == 2) || (AKMI_PREFETCH_WP2 && DIR == 1)));
+  constexpr int LA = RECON == 1 ? 1 : 2;            // the cell a step loads is LA cells ahead of cell s
   double nx[NV];                         // PW: cells s+1 of the coming step, loaded one step ahead
   if constexpr (PW) {
 #pragma unroll
-    for (int n = 0; n < NV; ++n) nx[n] = (ISO && n == 4) ? 0.0 : ldu(base(n) + st, off);
+    for (int n = 0; n < NV; ++n) nx[n] = (ISO && n == 4) ? 0.0 : ldu(base(n) + LA*st, off);
   }
   for (int t = 0; t <= ml; ++t) {
     const int s = s0 + t;
@@ -536,7 +557,7 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
     if constexpr (PW) {
       const bool more = (t < ml) && (s < shi);           // a next step exists: its cell s+2 is inside the array
 #pragma unroll
-      for (int n = 0; n < NV; ++n) nx2[n] = (more && !(ISO && n == 4)) ? ldu(base(n) + 2*st, off) : 0.0;
+      for (int n = 0; n < NV; ++n) nx2[n] = (more && !(ISO && n == 4)) ? ldu(base(n) + (LA + 1)*st, off) : 0.0;
     }
     double L[NV], R[NV];
 #pragma unroll
@@ -552,7 +573,8 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
         plm(w0, w1, qp, qln, R[n]);
         W_(n, 0) = w1; W_(n, 1) = qp;
       } else if constexpr (RECON >= 2) {
-        const double qp = ldu(q + 2*st, off);
+        double qp;
+        if constexpr (PW) qp = nx[n]; else qp = ldu(q + 2*st, off);
         const double w0 = W_(n, 0), w1 = W_(n, 1), w2 = W_(n, 2), w3 = W_(n, 3);
         recon5<RECON>(w0, w1, w2, w3, qp, qln, R[n]);
         if (n == 0) floor_lr<RECON, 1>(eos, qln, R[n]);
@@ -591,7 +613,7 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
       }
     }
     // x2 march of 3-D runs: same idea for the x1 flux difference of the finished cell
-    constexpr bool PRE1 = (DIR == 1) && (MODE == 1) && !USEACC && AKMI_PREFETCH_X1;
+    constexpr bool PRE1 = (DIR == 1) && (MODE == 1) && !USEACC && (RECON >= 2 ? AKMI_PREFETCH_X1P : AKMI_PREFETCH_X1);
     if constexpr (PRE1) {
       if (upd) {
         const double *f1 = u.flx1 + (size_t)m*g.nvar*fs1 - (g.N1 + 1);       // row sc = s-1
