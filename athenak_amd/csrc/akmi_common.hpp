@@ -160,5 +160,13 @@ void set_error(const char *fmt, ...);
 
 inline int cdiv(int a, int b) { return (a + b - 1)/b; }
 
+// akmi_stage.hip: the flux kernels of the task-granular entry points by the sweeps of the fused stage
+// (bcc0 == nullptr: hydro).  AKMI_COMPLETE / AKMI_FAIL, or -1 when the pack is outside what the sweeps
+// address (the caller then uses its own kernels).
+int sweeps_store_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0, const double *bcc0,
+                        const double *bx1f, const double *bx2f, const double *bx3f, double *flx1, double *flx2,
+                        double *flx3, int face_shaped, double *e3x1, double *e2x1, double *e1x2, double *e3x2,
+                        double *e2x3, double *e1x3, void *stream);
+
 }  // namespace akmi
 #endif

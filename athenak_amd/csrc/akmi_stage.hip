@@ -436,6 +436,8 @@ static int march_len(long col_blocks, int ncells, int nmb, int lmax, int wgs_per
   return (int)ml;
 }
 
+// MODE 2: no update at all, the five flux components of every face are stored (the flux kernels of the
+// task-granular entry points, sweeps_store_fluxes below).
 // MODE 0: last direction -- finish the RK update.  MODE 1 (x2 sweep of 3-D runs): store the
 // partial divergence acc = dF1/dx1 + dF2/dx2 for the x3 march, which then needs one array
 // instead of two face pairs per variable (USEACC).  Rounding sequence unchanged.
@@ -596,7 +598,7 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
     // (this kernel moves the most bytes of the stage and runs at 3 waves/SIMD)
     constexpr bool PRE = (DIR == 2) && USEACC && (MODE == 0) && AKMI_PREFETCH_UPD;
     const int sc = s - 1;                               // cell finished by this face
-    const bool upd = t > 0 && col_active && sc >= clo && sc <= chi;
+    const bool upd = MODE != 2 && t > 0 && col_active && sc >= clo && sc <= chi;
     double pa[5], pu[5], pu1[5];
     if constexpr (PRE) {
       if (upd) {
@@ -646,11 +648,17 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
       riemann_hyd_e<RS>(eos, L[0], L[1], L[2], L[3], L[4], R[0], R[1], R[2], R[3], R[4], fd, fx,
                         fy, fz, fe);
       // passive scalars are advected by the mass flux (k_scalar_update): keep it
-      if (g.nvar > (ISO ? 4 : 5) && (t < ml || s == shi)) stu(mfm, foff, fd);
+      if ((MODE == 2 || g.nvar > (ISO ? 4 : 5)) && (t < ml || s == shi)) stu(mfm, foff, fd);
     }
-    foff += fst8;
     double fv[5];
     fv[0] = fd; fv[ivx] = fx; fv[ivy] = fy; fv[ivz] = fz; fv[4] = fe;
+    if constexpr (MODE == 2) {            // task-granular callers: the whole flux of the face goes to memory
+      if (t < ml || s == shi) {
+#pragma unroll
+        for (int n = 1; n < 5; ++n) { if (ISO && n == 4) continue; stu(mfm + n*fs, foff, fv[n]); }
+      }
+    }
+    foff += fst8;
     if (upd) {
       const int kc = (DIR == 2) ? sc : k, jc = (DIR == 1) ? sc : j;
       const size_t mb = (size_t)m*g.nvar*cs;
@@ -1879,6 +1887,52 @@ static int ensure_aux() {
     }
   g_ev_ready = true;
   return AKMI_COMPLETE;
+}
+
+// ---------------------------------------------------------------------------------------
+// The flux kernels of the task-granular entry points (akmi_hydro_fluxes / akmi_mhd_fluxes: the path of
+// refined meshes and of everything the fused stage does not cover) by the sweeps of the fused stage:
+// the x1 sweep with the reconstruction of a cell shared between its two faces, the x2/x3 marches in
+// MODE 2.  Same outputs (all five flux components + the two face EMFs per direction, same ranges:
+// hydro_fluxes.cpp:95-104, mhd_fluxes.cpp:117-248), same arithmetic per face.
+template <bool MHD>
+static int sweeps_store_fluxes_t(const akmi_pack *p, int recon, int rsolver, const double *w0,
+                                 const double *bcc0, const double *bx1f, const double *bx2f, const double *bx3f,
+                                 double *flx1, double *flx2, double *flx3, int fsh, double *e3x1, double *e2x1,
+                                 double *e1x2, double *e3x2, double *e2x3, double *e1x3, hipStream_t st) {
+  Geo g = make_geo(p);
+  if ((size_t)(g.N3 + 1)*(g.N2 + 1)*(g.N1 + 1)*sizeof(double) >= ((size_t)1 << 32)) return -1;   // caller falls back
+  const Scheme sc{recon, rsolver, make_face_eos(p), !p->is_ideal};
+  SweepArgs a1{w0, bcc0, bx1f, flx1, e3x1, e2x1, nullptr, nullptr, nullptr,
+               g.is, g.ie + 1, g.js, g.je, g.ks, g.ke, g.N3, g.N2, g.N1 + fsh};
+  SweepArgs a2{w0, bcc0, bx2f, flx2, e1x2, e3x2, nullptr, nullptr, nullptr,
+               g.is, g.ie, g.js, g.je + 1, g.ks, g.ke, g.N3, g.N2 + fsh, g.N1};
+  SweepArgs a3{w0, bcc0, bx3f, flx3, e2x3, e1x3, nullptr, nullptr, nullptr,
+               g.is, g.ie, g.js, g.je, g.ks, g.ke + 1, g.N3 + fsh, g.N2, g.N1};
+  if (MHD) {
+    if (g.multi_d) { a1.jl = g.js - 1; a1.ju = g.je + 1; }
+    if (g.three_d) { a1.kl = g.ks - 1; a1.ku = g.ke + 1; }
+    a2.il = g.is - 1; a2.iu = g.ie + 1;
+    if (g.three_d) { a2.kl = g.ks - 1; a2.ku = g.ke + 1; }
+    a3.il = g.is - 1; a3.iu = g.ie + 1; a3.jl = g.js - 1; a3.ju = g.je + 1;
+  }
+  const UpdArgs u{};
+  int rc = launch_sweep<0, MHD, false>(g, sc, a1, st);
+  if (rc == AKMI_COMPLETE && g.multi_d) rc = launch_sweep_update<1, MHD, 2, false>(g, sc, a2, u, st);
+  if (rc == AKMI_COMPLETE && g.three_d) rc = launch_sweep_update<2, MHD, 2, false>(g, sc, a3, u, st);
+  return rc;
+}
+int sweeps_store_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0, const double *bcc0,
+                        const double *bx1f, const double *bx2f, const double *bx3f, double *flx1, double *flx2,
+                        double *flx3, int face_shaped, double *e3x1, double *e2x1, double *e1x2, double *e3x2,
+                        double *e2x3, double *e1x3, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (bcc0)
+    return sweeps_store_fluxes_t<true>(p, recon, rsolver, w0, bcc0, bx1f, bx2f, bx3f, flx1, flx2, flx3, 1,
+                                       e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, st);
+  return sweeps_store_fluxes_t<false>(p, recon, rsolver, w0, nullptr, nullptr, nullptr, nullptr, flx1, flx2,
+                                      flx3, face_shaped ? 1 : 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                      nullptr, st);
 }
 
 struct C2PArgs {          // interior c2p (+CFL scan) folded into the slab pipeline

@@ -811,6 +811,15 @@ int akmi_rk4_copy_cons(const akmi_pack *p, double delta, const double *u0, doubl
 
 static int fofc_checks(const akmi_pack *p, int recon, const char *what, bool ideal_only);
 
+// The flux kernels below are thread-per-face; the sweeps of the fused stage compute the same fluxes with
+// the reconstruction of a cell done once (akmi_stage.hip, sweeps_store_fluxes) and take over wherever they
+// cover the request: no passive scalars (those ride on the stored mass flux in the fused path), not the
+// kinematic "advect" solver, not the FOFC-extended ranges.  AKMI_TASK_SWEEPS=0: A/B switch.
+static bool use_sweeps(const akmi_pack *p, int rsolver, int ext) {
+  static const bool on = !(getenv("AKMI_TASK_SWEEPS") && atoi(getenv("AKMI_TASK_SWEEPS")) == 0);
+  return on && !ext && rsolver != AKMI_RS_ADVECT && p->nvar == (p->is_ideal ? 5 : 4);
+}
+
 static int hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0, double *flx1,
                         double *flx2, double *flx3, int face_shaped, void *stream, int ext) {
   if (check_scheme(p, recon, "hydro_fluxes") != AKMI_COMPLETE) return AKMI_FAIL;
@@ -822,6 +831,11 @@ static int hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double
   const Scheme sc{recon, rsolver, make_face_eos(p), !p->is_ideal};
   hipStream_t st = (hipStream_t)stream;
   int fsh = face_shaped ? 1 : 0;
+  if (use_sweeps(p, rsolver, ext)) {
+    const int r = sweeps_store_fluxes(p, recon, rsolver, w0, nullptr, nullptr, nullptr, nullptr, flx1, flx2, flx3,
+                                      fsh, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+    if (r != -1) return r;
+  }
   int rc = launch_hydro_flux<0>(g, sc, w0, flx1, fsh, st, ext);
   if (rc == AKMI_COMPLETE && g.multi_d) rc = launch_hydro_flux<1>(g, sc, w0, flx2, fsh, st, ext);
   if (rc == AKMI_COMPLETE && g.three_d) rc = launch_hydro_flux<2>(g, sc, w0, flx3, fsh, st, ext);
@@ -955,6 +969,11 @@ static int mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *
   Geo g = make_geo(p);
   const Scheme sc{recon, rsolver, make_face_eos(p), !p->is_ideal};
   hipStream_t st = (hipStream_t)stream;
+  if (use_sweeps(p, rsolver, ext)) {
+    const int r = sweeps_store_fluxes(p, recon, rsolver, w0, bcc0, bx1f, bx2f, bx3f, flx1, flx2, flx3, 1, e3x1,
+                                      e2x1, e1x2, e3x2, e2x3, e1x3, stream);
+    if (r != -1) return r;
+  }
   int rc = launch_mhd_flux<0>(g, sc, w0, bcc0, bx1f, flx1, e3x1, e2x1, st, ext);
   if (rc == AKMI_COMPLETE && g.multi_d)
     rc = launch_mhd_flux<1>(g, sc, w0, bcc0, bx2f, flx2, e1x2, e3x2, st, ext);
