@@ -137,6 +137,15 @@ inline int check_scheme(const akmi_pack *p, int recon, const char *who) {
   return AKMI_COMPLETE;
 }
 
+// wave-uniform base (scalar registers) + 32-bit BYTE offset of the lane: global_load v, v_off, s[base].
+// One variable of one MeshBlock has to stay below 4 GB (checked by the launchers that use it).
+__device__ __forceinline__ double ldu(const double *__restrict__ base, unsigned ob) {
+  return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + ob);
+}
+__device__ __forceinline__ void stu(double *__restrict__ base, unsigned ob, double v) {
+  *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + ob) = v;
+}
+
 // LayoutRight offsets (src/athena.hpp:111,127-128)
 __host__ __device__ __forceinline__ size_t ix5(int nv, int n3, int n2, int n1, int m, int n,
                                                int k, int j, int i) {

@@ -62,14 +62,6 @@ static StageWs carve(const Geo &g, int is_mhd, void *ws) {
 }
 
 // ---------------------------------------------------------------------------------------
-// wave-uniform base + 32-bit byte offset of the lane
-__device__ __forceinline__ double ldu(const double *__restrict__ base, unsigned ob) {
-  return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + ob);
-}
-__device__ __forceinline__ void stu(double *__restrict__ base, unsigned ob, double v) {
-  *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + ob) = v;
-}
-
 // face flux from the cell stencil (registers only).  Returns flux in sweep-aligned order.
 template <int DIR, int RECON, bool MHD, int RS>
 __device__ __forceinline__ void face_flux(const Geo &g, const FaceEos &eos,

@@ -489,6 +489,125 @@ k_corner_e_2d(Geo g, EccAccess cc, const double *__restrict__ e3x1,
       corner_e3(g, cc, e3x1, e3x2, flx1, flx2, m, ks, j, i);
 }
 
+
+// 3-D CornerE as a march along k (the form the fused stage uses, without its LDS tile and CT): a lane owns
+// the corner (j,i) of a flattened row, computes the cell-centred E = -(v x B) of ITS cell (k,j,i) and of
+// the cell below in j once per plane, takes the i-1 neighbours from the lane below (__shfl_up; waves
+// overlap by one lane, lane 0 only provides) and keeps the k-1 operands of the corner formulas in
+// registers from step to step.  25 loads per corner instead of ~70, upwinding by select instead of
+// branches, scalar-base addressing.  Same operands, same operations -> same bits as k_corner_e_3d.
+constexpr int CX = 64, CY = 4;
+__device__ __forceinline__ double upw_sel(bool pos, double fa, double ca, double fb, double cb) {
+  const double f = pos ? fa : fb, c = pos ? ca : cb;        // all four operands are loaded; select, no branch
+  return f - c;
+}
+__global__ void __launch_bounds__(CX*CY)
+k_corner_e_3d_march(Geo g, const double *__restrict__ w0, const double *__restrict__ bcc0,
+                    const double *__restrict__ e3x1, const double *__restrict__ e2x1,
+                    const double *__restrict__ e1x2, const double *__restrict__ e3x2,
+                    const double *__restrict__ e2x3, const double *__restrict__ e1x3,
+                    const double *__restrict__ flx1, const double *__restrict__ flx2,
+                    const double *__restrict__ flx3, double *__restrict__ e1, double *__restrict__ e2,
+                    double *__restrict__ e3, int ckl, int nchunk) {
+  const long p = ((long)blockIdx.x*CY + threadIdx.y)*(CX - 1) + (long)threadIdx.x - 1;
+  const long pc = p < 0 ? 0 : p;
+  const int jj = (int)(pc/g.N1);
+  const int i = (int)(pc - (long)jj*g.N1);
+  const int j = g.js + jj;
+  const int m = blockIdx.z/nchunk;
+  const int k0 = g.ks + (blockIdx.z - m*nchunk)*ckl;
+  const int k1 = (k0 + ckl - 1 < g.ke + 1) ? k0 + ckl - 1 : g.ke + 1;
+  // the lane reads cells / faces (k, j and j-1, i): i in [is-1, ie+1] (the column is-1 only provides)
+  const bool rd = p >= 0 && j <= g.je + 1 && i >= g.is - 1 && i <= g.ie + 1;
+  const bool wr = rd && threadIdx.x != 0 && i >= g.is;
+  const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  const size_t fs1 = (size_t)g.N3*g.N2*(g.N1 + 1), fs2 = (size_t)g.N3*(g.N2 + 1)*g.N1,
+               fs3 = (size_t)(g.N3 + 1)*g.N2*g.N1;
+  const double *wm = w0 + (size_t)m*g.nvar*cs, *bm = bcc0 + (size_t)m*3*cs;
+  const double *f1m = flx1 + (size_t)m*g.nvar*fs1, *f2m = flx2 + (size_t)m*g.nvar*fs2,
+               *f3m = flx3 + (size_t)m*g.nvar*fs3;
+  const unsigned N1 = (unsigned)g.N1, N2 = (unsigned)g.N2;
+  const unsigned row = (unsigned)j*N1 + (unsigned)i;                      // (j,i) in a cell-shaped plane
+  // byte offsets of (k0-1, j, i) in the array shapes involved; they advance by one plane per step
+  unsigned oc = (((unsigned)(k0 - 1)*N2)*N1 + row)*8u;                                  // (N3, N2, N1)
+  unsigned o1 = ((unsigned)(k0 - 1)*N2*(N1 + 1) + (unsigned)j*(N1 + 1) + (unsigned)i)*8u;   // (N3, N2, N1+1)
+  unsigned o2 = ((unsigned)(k0 - 1)*(N2 + 1)*N1 + row)*8u;                              // (N3, N2+1, N1)
+  unsigned o3 = oc;                                                                   // (N3+1, N2, N1): same rows
+  const unsigned pc8 = N2*N1*8u, p18 = N2*(N1 + 1)*8u, p28 = (N2 + 1)*N1*8u;
+  // edge arrays: e1 (N3+1, N2+1, N1), e2 (N3+1, N2, N1+1), e3 (N3, N2+1, N1+1)
+  unsigned q1 = ((unsigned)k0*(N2 + 1)*N1 + row)*8u;
+  unsigned q2 = ((unsigned)k0*N2*(N1 + 1) + (unsigned)j*(N1 + 1) + (unsigned)i)*8u;
+  unsigned q3 = ((unsigned)k0*(N2 + 1)*(N1 + 1) + (unsigned)j*(N1 + 1) + (unsigned)i)*8u;
+  const unsigned r18 = (N2 + 1)*N1*8u, r28 = N2*(N1 + 1)*8u, r38 = (N2 + 1)*(N1 + 1)*8u;
+  double *e1m = e1 + (size_t)m*(g.N3 + 1)*(g.N2 + 1)*g.N1, *e2m = e2 + (size_t)m*(g.N3 + 1)*g.N2*(g.N1 + 1),
+         *e3m = e3 + (size_t)m*g.N3*(g.N2 + 1)*(g.N1 + 1);
+  const double *x31 = e3x1 + (size_t)m*cs, *x21 = e2x1 + (size_t)m*cs, *x12 = e1x2 + (size_t)m*cs,
+               *x32 = e3x2 + (size_t)m*cs, *x23 = e2x3 + (size_t)m*cs, *x13 = e1x3 + (size_t)m*cs;
+  // cell-centred E of cell (k,j,i) -> c1, c2, c3 and of cell (k,j-1,i) -> c1, c3 (mhd_corner_e.cpp:309-317)
+  auto ecc = [&](unsigned o, double &c1, double &c2, double &c3) {
+    const double vx = ldu(wm + cs, o), vy = ldu(wm + 2*cs, o), vz = ldu(wm + 3*cs, o);
+    const double bx = ldu(bm, o), by = ldu(bm + cs, o), bz = ldu(bm + 2*cs, o);
+    c1 = vz*by - vy*bz; c2 = vx*bz - vz*bx; c3 = vy*bx - vx*by;
+  };
+  // plane k0-1: the operands the first step needs from below
+  double f1_km = 0.0, f2_km = 0.0, x2_km = 0.0, x1_km = 0.0, c1_mm = 0.0, c1_m0 = 0.0, c2_m0 = 0.0;
+  if (rd) {
+    double d2, d3;
+    ecc(oc, c1_m0, c2_m0, d3);
+    ecc(oc - N1*8u, c1_mm, d2, d3);
+    f1_km = ldu(f1m, o1); f2_km = ldu(f2m, o2);
+    x2_km = ldu(x12, oc); x1_km = ldu(x21, oc);
+  }
+  double c2_mm = __shfl_up(c2_m0, 1, 64);
+  for (int k = k0; k <= k1; ++k) {
+    oc += pc8; o1 += p18; o2 += p28; o3 += pc8;
+    double c1_00 = 0.0, c2_00 = 0.0, c3_00 = 0.0, c1_0m = 0.0, c3_m0 = 0.0;
+    double f1_k = 0.0, f1_jm = 0.0, f2_k = 0.0, f3_k = 0.0, f3_jm = 0.0;
+    double x2_k = 0.0, x1_k = 0.0, x13_jm = 0.0, x13_j = 0.0, x23_i = 0.0, x32_i = 0.0, x31_jm = 0.0, x31_j = 0.0;
+    if (rd) {
+      double d2;
+      ecc(oc, c1_00, c2_00, c3_00);
+      ecc(oc - N1*8u, c1_0m, d2, c3_m0);
+      f1_k = ldu(f1m, o1); f1_jm = ldu(f1m - (g.N1 + 1), o1);
+      f2_k = ldu(f2m, o2);
+      f3_k = ldu(f3m, o3); f3_jm = ldu(f3m - g.N1, o3);
+      x2_k = ldu(x12, oc); x1_k = ldu(x21, oc);
+      x13_jm = ldu(x13 - g.N1, oc); x13_j = ldu(x13, oc);
+      x23_i = ldu(x23, oc); x32_i = ldu(x32, oc);
+      x31_jm = ldu(x31 - g.N1, oc); x31_j = ldu(x31, oc);
+    }
+    const double c2_0m = __shfl_up(c2_00, 1, 64), c3_0m = __shfl_up(c3_00, 1, 64), c3_mm = __shfl_up(c3_m0, 1, 64);
+    const double f2_im = __shfl_up(f2_k, 1, 64), f3_im = __shfl_up(f3_k, 1, 64);
+    const double x23_im = __shfl_up(x23_i, 1, 64), x32_im = __shfl_up(x32_i, 1, 64);
+    if (wr) {
+      {  // E1 (mhd_corner_e.cpp:340-363)
+        const double e1_l3 = upw_sel(f2_km >= 0.0, x13_jm, c1_mm, x13_j, c1_m0);
+        const double e1_r3 = upw_sel(f2_k >= 0.0, x13_jm, c1_0m, x13_j, c1_00);
+        const double e1_l2 = upw_sel(f3_jm >= 0.0, x2_km, c1_mm, x2_k, c1_0m);
+        const double e1_r2 = upw_sel(f3_k >= 0.0, x2_km, c1_m0, x2_k, c1_00);
+        stu(e1m, q1, 0.25*(e1_l3 + e1_r3 + e1_l2 + e1_r2 + x2_km + x2_k + x13_jm + x13_j));
+      }
+      {  // E2 (:365-388)
+        const double e2_l3 = upw_sel(f1_km >= 0.0, x23_im, c2_mm, x23_i, c2_m0);
+        const double e2_r3 = upw_sel(f1_k >= 0.0, x23_im, c2_0m, x23_i, c2_00);
+        const double e2_l1 = upw_sel(f3_im >= 0.0, x1_km, c2_mm, x1_k, c2_0m);
+        const double e2_r1 = upw_sel(f3_k >= 0.0, x1_km, c2_m0, x1_k, c2_00);
+        stu(e2m, q2, 0.25*(e2_l3 + e2_r3 + e2_l1 + e2_r1 + x23_im + x23_i + x1_km + x1_k));
+      }
+      {  // E3 (:390-413)
+        const double e3_l2 = upw_sel(f1_jm >= 0.0, x32_im, c3_mm, x32_i, c3_m0);
+        const double e3_r2 = upw_sel(f1_k >= 0.0, x32_im, c3_0m, x32_i, c3_00);
+        const double e3_l1 = upw_sel(f2_im >= 0.0, x31_jm, c3_mm, x31_j, c3_0m);
+        const double e3_r1 = upw_sel(f2_k >= 0.0, x31_jm, c3_m0, x31_j, c3_00);
+        stu(e3m, q3, 0.25*(e3_l1 + e3_r1 + e3_l2 + e3_r2 + x32_im + x32_i + x31_jm + x31_j));
+      }
+    }
+    q1 += r18; q2 += r28; q3 += r38;
+    f1_km = f1_k; f2_km = f2_k; x2_km = x2_k; x1_km = x1_k;
+    c1_mm = c1_0m; c1_m0 = c1_00; c2_mm = c2_0m; c2_m0 = c2_00;
+  }
+}
+
 __global__ void __launch_bounds__(BX*BY)
 k_corner_e_3d(Geo g, EccAccess cc, const double *__restrict__ e3x1,
               const double *__restrict__ e2x1, const double *__restrict__ e1x2,
@@ -1057,9 +1176,23 @@ int akmi_mhd_corner_e(const akmi_pack *p, const double *w0, const double *bcc0,
     dim3 grid(cdiv(g.nx1 + 1, BX), cdiv(g.nx2 + 1, BY), g.nmb), block(BX, BY);
     k_corner_e_2d<<<grid, block, 0, st>>>(g, cc, e3x1, e2x1, e1x2, e3x2, flx1, flx2, e1, e2, e3);
   } else {
-    dim3 grid(cdiv(g.nx1 + 1, BX), cdiv(g.nx2 + 1, BY), (g.nx3 + 1)*g.nmb), block(BX, BY);
-    k_corner_e_3d<<<grid, block, 0, st>>>(g, cc, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, flx1, flx2,
-                                         flx3, e1, e2, e3);
+    static const bool march = !(getenv("AKMI_CORNER_MARCH") && atoi(getenv("AKMI_CORNER_MARCH")) == 0);
+    if (march && (size_t)(g.N3 + 1)*(g.N2 + 1)*(g.N1 + 1)*sizeof(double) < ((size_t)1 << 32)) {
+      const long np = (long)(g.nx2 + 1)*g.N1;                      // flattened rows js..je+1
+      const long per_wg = (long)(CX - 1)*CY;
+      const unsigned nb = (unsigned)((np + 1 + per_wg - 1)/per_wg);
+      const int nk = g.nx3 + 1;
+      long ckl = (long)nb*nk*g.nmb/2048;                           // ~2048 workgroups per launch
+      ckl = ckl > 32 ? 32 : (ckl < 4 ? 4 : ckl);
+      const int nchunk = cdiv(nk, (int)ckl);
+      dim3 grid(nb, 1, nchunk*g.nmb), block(CX, CY);
+      k_corner_e_3d_march<<<grid, block, 0, st>>>(g, w0, bcc0, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, flx1, flx2,
+                                                 flx3, e1, e2, e3, (int)ckl, nchunk);
+    } else {
+      dim3 grid(cdiv(g.nx1 + 1, BX), cdiv(g.nx2 + 1, BY), (g.nx3 + 1)*g.nmb), block(BX, BY);
+      k_corner_e_3d<<<grid, block, 0, st>>>(g, cc, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, flx1, flx2,
+                                           flx3, e1, e2, e3);
+    }
   }
   AKMI_CHECK_LAUNCH("corner_e");
   return AKMI_COMPLETE;
