@@ -1704,6 +1704,181 @@ static int launch_sweep_update(const Geo &g, const Scheme &sc, const SweepArgs &
 
 
 // x1 sweep + x2 march of an MHD pack in one kernel (3-D)
+// ---------------------------------------------------------------------------------------
+// k_sweep12s: the x1 sweep inside the x2 march, second form (PLM).  The cells of row s-1 whose x1 faces a
+// step solves are the cells the march loaded one step earlier: they sit in its window (LDS), so the x1
+// part issues TWO loads per step (the cell-centred By, which the x2 march does not carry, and the face
+// field) instead of 22; the i-1 / i+1 neighbours of the slopes, the left state of the face and the flux of
+// face i+1 come from the neighbouring lanes (wave shuffles).  Waves overlap by four lanes: lanes 0 and 63
+// only provide cells, lane 1 a left state, lane 62 a face flux; lanes 2..61 own cells.
+#ifndef AKMI_X12S_WAVES
+#define AKMI_X12S_WAVES 3
+#endif
+#ifndef AKMI_X12S_EO1
+#define AKMI_X12S_EO1 1
+#endif
+#ifndef AKMI_X12S_EO2
+#define AKMI_X12S_EO2 1
+#endif
+template <int RS>
+__global__ void __launch_bounds__(SX*SY, AKMI_X12S_WAVES)
+k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
+  constexpr int NV = 7, NW = 2, NT = SX*SY;
+  constexpr int CPW = SX - 4;                              // cells per wave
+  __shared__ double sm[(NV*NW + NV + 5)*SX*SY];
+  const int lane = threadIdx.x;
+  const long wv = (long)blockIdx.x*SY + threadIdx.y;       // wave index over the (k,i) rows
+  const long pe = wv*CPW + lane - 2;
+  const long np = (long)(a2.ku - a2.kl + 1)*g.N1;
+  if (wv*CPW - 2 >= np) return;                            // whole wave beyond the planes
+  const long p = pe < 0 ? 0 : (pe > np - 1 ? np - 1 : pe); // clamped lanes compute, never store
+  const int kk = (int)(p/g.N1);
+  const int i = (int)(p - (long)kk*g.N1);
+  const int k = a2.kl + kk;
+  const int m = blockIdx.z;
+  const int s0 = a2.jl + blockIdx.y*ml;
+  const int shi = a2.ju;                                   // last x2 face
+  const bool exact = pe == p;
+  const bool inner = exact && lane >= 2 && lane <= SX - 3;
+  const bool x2_ok = inner && i >= a2.il && i <= a2.iu;    // owns the x2 faces of this column
+  const bool x1_ok = inner && i >= a1.il && i <= a1.iu;    // owns the x1 faces of this column
+  const bool col_active = inner && i >= g.is && i <= g.ie && k >= g.ks && k <= g.ke;
+  double *my = sm + threadIdx.y*SX + threadIdx.x;
+#define W_(n, c) my[((n)*NW + (c))*NT]
+#define PL_(n) my[(NV*NW + (n))*NT]
+#define FP_(n) my[(NV*NW + NV + (n))*NT]
+  const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1];
+  const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  const long st = (long)g.N1;
+  const double *wb = a2.w0 + (size_t)m*g.nvar*cs;
+  const double *bb = a2.bcc0 + (size_t)m*3*cs;
+  // x2-aligned order of the march: d, vy, vz, vx, e, bz, bx
+  auto base2 = [&](int n) -> const double * {
+    return n == 0 ? wb : n == 1 ? wb + 2*cs : n == 2 ? wb + 3*cs : n == 3 ? wb + cs
+         : n == 4 ? wb + 4*cs : n == 5 ? bb + 2*cs : bb;
+  };
+  unsigned off = (((unsigned)k*(unsigned)g.N2 + (unsigned)s0)*(unsigned)g.N1 + (unsigned)i)*8u;    // cell (k, s, i)
+  const unsigned st8 = (unsigned)g.N1*8u;
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    const double *q = base2(n);
+    double pl, dummy;
+    const double qa = ldu(q - 2*st, off), qb = ldu(q - st, off), qc = ldu(q, off);
+    plm(qa, qb, qc, pl, dummy);
+    W_(n, 0) = qb; W_(n, 1) = qc;
+    PL_(n) = pl;
+  }
+  // face-shaped arrays: x2 faces (f3, f2, f1) = (N3, N2+1, N1), x1 faces (N3, N2, N1+1)
+  const size_t fs2 = (size_t)a2.f3*a2.f2*a2.f1, fs1 = (size_t)a1.f3*a1.f2*a1.f1;
+  unsigned foff2 = (((unsigned)k*(unsigned)a2.f2 + (unsigned)s0)*(unsigned)a2.f1 + (unsigned)i)*8u;   // x2 face s
+  const unsigned fst28 = (unsigned)a2.f1*8u;
+  unsigned foff1 = (((unsigned)k*(unsigned)a1.f2 + (unsigned)(s0 - 1))*(unsigned)a1.f1 + (unsigned)i)*8u;   // x1 face (k, s-1, i)
+  const unsigned fst18 = (unsigned)a1.f1*8u;
+  const double *bx2m = a2.bxf + (size_t)m*fs2, *bx1m = a1.bxf + (size_t)m*fs1;
+  double *mf2 = a2.flx + (size_t)m*g.nvar*fs2, *mf1 = a1.flx + (size_t)m*g.nvar*fs1;
+  const double *bym = bb + cs;                                                                   // cell-centred By
+  const size_t mb = (size_t)m*g.nvar*cs;
+  for (int t = 0;; ++t) {
+    const int s = s0 + t;
+    if (s > shi + 1) break;                   // the last chunk ends with the x1 faces of row ju(x1)
+    if (t > ml && s <= shi) break;            // the others end with the face they share
+    const bool do_x2 = s <= shi;
+    const int jr = s - 1;                     // row of the x1 faces of this step
+    const bool do_x1 = (t >= 1 || s0 == a2.jl) && jr >= a1.jl && jr <= a1.ju;
+    const unsigned orow = off - st8;          // cell (k, jr, i)
+    // ---- x1 face on the low side of cell (k, jr, i): the cell is W_(.,0) of the march
+    double f1d, f1x, f1y, f1z, f1e, f1by, f1bz;
+    double dF1[5];
+    {
+      // x1-aligned order d, vx, vy, vz, e, by, bz from the x2-aligned window d, vy, vz, vx, e, bz, bx
+      double q0[NV];
+      q0[0] = W_(0, 0); q0[1] = W_(3, 0); q0[2] = W_(1, 0); q0[3] = W_(2, 0); q0[4] = W_(4, 0);
+      q0[5] = ldu(bym, orow); q0[6] = W_(5, 0);
+      const double bxc = W_(6, 0);
+      const double bx1 = ldu(bx1m, foff1);
+      double qln[NV], qr[NV];
+#pragma unroll
+      for (int n = 0; n < NV; ++n) {
+        const double qm = __shfl_up(q0[n], 1, 64), qp = __shfl_down(q0[n], 1, 64);
+        plm(qm, q0[n], qp, qln[n], qr[n]);
+      }
+      if (do_x1 && inner && i >= a1.il - 1 && i <= a1.iu) {          // cell-centred E = -(v x B)
+        stu(a1.ecc1 + (size_t)m*cs, orow, q0[3]*q0[5] - q0[2]*q0[6]);
+        stu(a1.ecc2 + (size_t)m*cs, orow, q0[1]*q0[6] - q0[3]*bxc);
+        stu(a1.ecc3 + (size_t)m*cs, orow, q0[2]*bxc - q0[1]*q0[5]);
+      }
+      double L1[NV];
+#pragma unroll
+      for (int n = 0; n < NV; ++n) L1[n] = __shfl_up(qln[n], 1, 64);
+      Cons1D f1 = riemann_mhd_e<RS, AKMI_X12S_EO1 != 0>(eos, L1[0], L1[1], L1[2], L1[3], L1[4], L1[5], L1[6], qr[0],
+                                    qr[1], qr[2], qr[3], qr[4], qr[5], qr[6], bx1);
+      f1d = f1.d; f1x = f1.mx; f1y = f1.my; f1z = f1.mz; f1e = f1.e; f1by = f1.by; f1bz = f1.bz;
+      dF1[0] = __shfl_down(f1d, 1, 64) - f1d;
+      dF1[1] = __shfl_down(f1x, 1, 64) - f1x;
+      dF1[2] = __shfl_down(f1y, 1, 64) - f1y;
+      dF1[3] = __shfl_down(f1z, 1, 64) - f1z;
+      dF1[4] = __shfl_down(f1e, 1, 64) - f1e;
+      if (do_x1 && x1_ok) {
+        stu(mf1, foff1, f1d);
+        stu(a1.ey + (size_t)m*cs, orow, -f1by);
+        stu(a1.ez + (size_t)m*cs, orow, f1bz);
+      }
+    }
+    // ---- x2 face s
+    double L[NV], R[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      double qln2;
+      L[n] = PL_(n);
+      const double w0 = W_(n, 0), w1 = W_(n, 1);
+      const double qp = do_x2 ? ldu(base2(n) + st, off) : w1;      // beyond the last face: nothing is kept
+      plm(w0, w1, qp, qln2, R[n]);
+      W_(n, 0) = w1; W_(n, 1) = qp;
+      PL_(n) = qln2;
+    }
+    const double bx2 = do_x2 ? ldu(bx2m, foff2) : 0.0;
+    Cons1D f2 = riemann_mhd_e<RS, AKMI_X12S_EO2 != 0>(eos, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1],
+                                  R[2], R[3], R[4], R[5], R[6], bx2);
+    if (do_x2 && x2_ok && (t < ml || s == shi)) {
+      stu(mf2, foff2, f2.d);
+      stu(a2.ey + (size_t)m*cs, off, -f2.by);
+      stu(a2.ez + (size_t)m*cs, off, f2.bz);
+    }
+    // x2 flux in natural component order: d, m1, m2, m3, E  (ivx = 2, ivy = 3, ivz = 1)
+    const double fv[5] = {f2.d, f2.mz, f2.mx, f2.my, f2.e};
+    const int sc = s - 1;
+    if (do_x2 && t > 0 && col_active && sc >= g.js && sc <= g.je) {
+#pragma unroll
+      for (int n = 0; n < 5; ++n) {
+        double divf = dF1[n]/dx1;
+        divf += (fv[n] - FP_(n))/dx2;
+        stu(u.acc + mb + n*cs, orow, divf);
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < 5; ++n) FP_(n) = fv[n];
+    off += st8; foff2 += fst28; foff1 += fst18;
+  }
+#undef W_
+#undef PL_
+#undef FP_
+}
+
+static int launch_sweep12s(const Geo &g, const Scheme &sc, const SweepArgs &a1, const SweepArgs &a2,
+                           const UpdArgs &u, hipStream_t st) {
+  const long np = (long)(a2.ku - a2.kl + 1)*g.N1;          // flattened (k,i) rows
+  const long nwaves = (np + (SX - 4) - 1)/(SX - 4);
+  const unsigned nb = (unsigned)((nwaves + SY - 1)/SY);
+  const int nc = a2.ju - a2.jl > 0 ? a2.ju - a2.jl : 1;
+  const int ml = march_len(nb, nc, g.nmb, ML, 3);
+  dim3 grid(nb, cdiv(nc, ml), g.nmb), block(SX, SY);
+  const int rs = sc.rsolver;
+  if (sc.iso || sc.recon != 1 || rs != AKMI_RS_HLLD) { set_error("sweep12s: PLM + HLLD, ideal gas"); return AKMI_FAIL; }
+  k_sweep12s<3><<<grid, block, 0, st>>>(g, sc.eos, a1, a2, u, ml);
+  AKMI_CHECK_LAUNCH("sweep12s");
+  return AKMI_COMPLETE;
+}
+
 static int launch_sweep12(const Geo &g, const Scheme &sc, const SweepArgs &a1, const SweepArgs &a2,
                           const UpdArgs &u, hipStream_t st) {
   const long np = (long)(a2.ku - a2.kl + 1)*g.N1;          // flattened (k,i) rows
@@ -2043,7 +2218,11 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
   // AKMI_X12=1: x1 sweep folded into the x2 march (k_sweep12).  Bit-identical, 19 doubles per cell
   // less traffic, but 1.86-2.02 ms against 0.70 + 0.91 ms for the two kernels (profiles/r02_ab2.txt):
   // the fused loop body exceeds the 168 VGPRs of three waves per SIMD and spills.  Off by default.
-  static const bool x12 = getenv("AKMI_X12") && atoi(getenv("AKMI_X12")) != 0;
+  static const bool x12 = getenv("AKMI_X12") && atoi(getenv("AKMI_X12")) == 1;
+  // default (AKMI_X12 unset or 2): the second form, k_sweep12s -- the cells of the x1 faces come from the
+  // march's window, neighbours by wave shuffle: 1 436 us against 596 + 876 us for the two kernels and 2.5 GB
+  // less traffic per stage (profiles/r02_v9_x12s_ab.txt).  AKMI_X12=0: x1 sweep and x2 march as two kernels.
+  static const bool x12s = !getenv("AKMI_X12") || atoi(getenv("AKMI_X12")) == 2;
   const int T = (phases != AKMI_PHASE_ALL) ? g.nx3 : (env_slab > 1 ? env_slab : AKMI_SLAB);
   const int S = (g.nx3 + T - 1)/T;
   if (S > MAX_SLABS) { set_error("too many slabs"); return AKMI_FAIL; }
@@ -2087,6 +2266,11 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
       // hydro DC/PLM: sweeps + update of the slab in one kernel
       rc = g.nvar > (sc.iso ? 4 : 5) ? launch_hydro_stage3d<true>(g, sc, w0, u, kA(s), kB(s), st, Mass3{w.flx1, w.flx2, w.flx3})
                       : launch_hydro_stage3d<false>(g, sc, w0, u, kA(s), kB(s), st, Mass3{nullptr, nullptr, nullptr});
+    } else if (do_sweeps && MHD && x12s && sc.recon == 1 && !sc.iso && sc.rsolver == AKMI_RS_HLLD &&
+               g.nvar == 5) {
+      // x1 sweep inside the x2 march, cells from the march's window (k_sweep12s); x3 march consumes acc
+      if constexpr (MHD) rc = launch_sweep12s(g, sc, b1, b2, u, st);
+      if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD, 0, true>(g, sc, b3, u, st);
     } else if (do_sweeps && MHD && x12) {
       // x1 sweep folded into the x2 march (no x1 flux array); x3 march consumes acc
       if constexpr (MHD) rc = launch_sweep12(g, sc, b1, b2, u, st);
