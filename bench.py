@@ -314,9 +314,9 @@ def main():
                 "halo_bcs_shell_c2p_ms": round(tH*1e3, 4),
                 "whole_stage": {"achieved": round(stage_bytes*ncell_rank*drv.nexp_stages*args.steps
                                                   / el / 1e9, 1)},
-                "note": "measured traffic is 2.6x the algorithmic bytes (intermediates between the five kernels); "
+                "note": "measured traffic is 2.3x the algorithmic bytes (intermediates between the four kernels); "
                         "CornerE+CT and c2p already stream at 5.7-5.9 TB/s, the x3 march sits at its traffic, "
-                        "the x1 sweep and x2 march are co-limited by ~1000 fp64 instructions per face: DESIGN.md 3"}
+                        "the x1-in-x2 march is bound by ~2000 fp64 instructions per cell: DESIGN.md 3"}
     roofline["whole_stage"]["frac"] = round(roofline["whole_stage"]["achieved"]/HBM_PEAK_GBS, 4)
 
     if rank == 0:
