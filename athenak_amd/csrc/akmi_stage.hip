@@ -724,220 +724,6 @@ k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int ml) {
     sweep_update_body<DIR, RECON, MHD, MODE, USEACC, RS, false>(g, eos, a, u, ml, sm);
 }
 
-// ---------------------------------------------------------------------------------------
-// MHD, 3-D: the x1 sweep folded into the x2 march (k_sweep12).  Lanes run over the flattened
-// (k,i) rows as in the x2 march; while a thread walks along j it also solves the x1 face on the
-// low side of its cell in row s-1 (the row whose cells the step finishes):
-//   * the limited states of a cell serve both of its x1 faces, so a lane reconstructs ITS cell
-//     and takes the left state of its face from the lane below (__shfl_up), as the x1 sweep does;
-//   * the x1 flux difference of the cell is F1(lane+1) - F1(lane) (__shfl_down): the 5-component
-//     x1 flux array (5 doubles written, 5+ read per cell) disappears, and w0/bcc0 are fetched
-//     from HBM once for both directions (the second access of a row hits L1/L2);
-//   * waves overlap by two lanes (lane 0 only provides a left state, lane 63 only a face):
-//     62 cells per wave.
-// Still stored for CornerE: the mass flux and the two face EMFs of both directions, the
-// cell-centred EMFs.  acc = dF1/dx1 + dF2/dx2 goes to the x3 march as before; the rounding
-// sequence of hydro_update.cpp:55-80 is unchanged.
-template <int RECON>
-__device__ __forceinline__ void cell_lr_x1(const double *__restrict__ q, const FaceEos &eos, int n,
-                                           double &ql_ip1, double &qr_i) {
-  if constexpr (RECON == 1) {
-    plm(q[-1], q[0], q[1], ql_ip1, qr_i);
-  } else if constexpr (RECON >= 2) {
-    recon5<RECON>(q[-2], q[-1], q[0], q[1], q[2], ql_ip1, qr_i);
-    if (n == 0) floor_lr<RECON, 1>(eos, ql_ip1, qr_i);
-    if (n == 4) floor_lr<RECON, 2>(eos, ql_ip1, qr_i);
-  } else {
-    ql_ip1 = q[0];
-    qr_i = q[0];
-  }
-}
-
-// the kernel is an experiment that lost (see stage_update): instantiated only with -DAKMI_X12_BUILD=1
-#ifndef AKMI_X12_BUILD
-#define AKMI_X12_BUILD 0
-#endif
-#ifndef AKMI_X12_WAVES
-#define AKMI_X12_WAVES 3
-#endif
-template <int RECON, int RS, bool P2>
-__device__ __forceinline__ void sweep12_body(const Geo &g, const FaceEos &eos, const SweepArgs &a1,
-                                             const SweepArgs &a2, const UpdArgs &u, int ml, double *sm) {
-  constexpr int NV = 7;
-  constexpr int NW = RollCfg<RECON>::NW;
-  constexpr int NT = SX*SY;
-  constexpr int CPW = SX - 2;                              // cells per wave
-  const int lane = threadIdx.x;
-  const long wv = (long)blockIdx.x*SY + threadIdx.y;       // wave index over the (k,i) rows
-  long p = wv*CPW + lane - 1;
-  const long np = (long)(a2.ku - a2.kl + 1)*g.N1;
-  if (wv*CPW - 1 >= np) return;                            // whole wave beyond the planes
-  if (p < 0) p = 0;
-  if (p > np - 1) p = np - 1;                              // clamped lanes compute, never store
-  const int kk = (int)(p/g.N1);
-  const int i = (int)(p - (long)kk*g.N1);
-  const int k = a2.kl + kk;
-  const int m = blockIdx.z;
-  const int s0 = a2.jl + blockIdx.y*ml;
-  const int shi = a2.ju;                                   // last x2 face
-  const bool inner = lane >= 1 && lane <= SX - 2 && (wv*CPW + lane - 1 == p);
-  const bool x2_ok = inner && i >= a2.il && i <= a2.iu;    // owns the x2 faces of this column
-  const bool x1_ok = inner && i >= a1.il && i <= a1.iu;    // owns the x1 faces of this column
-  const bool col_active = inner && i >= g.is && i <= g.ie && k >= g.ks && k <= g.ke;
-  double *my = sm + threadIdx.y*SX + threadIdx.x;
-#define W_(n, c) my[((n)*NW + (c))*NT]
-#define PL_(n) my[(NV*NW + (n))*NT]
-#define FP_(n) my[(NV*NW + NV + (n))*NT]
-  const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1];
-  const size_t cs = (size_t)g.N3*g.N2*g.N1;
-  const long st = (long)g.N1;
-  const double *wb = a2.w0 + (size_t)m*g.nvar*cs;
-  const double *bb = a2.bcc0 + (size_t)m*3*cs;
-  // x2-aligned order of the march: d, vy, vz, vx, e, bz, bx
-  auto base2 = [&](int n) -> const double * {
-    return n == 0 ? wb : n == 1 ? wb + 2*cs : n == 2 ? wb + 3*cs : n == 3 ? wb + cs
-         : n == 4 ? wb + 4*cs : n == 5 ? bb + 2*cs : bb;
-  };
-  // x1-aligned order: d, vx, vy, vz, e, by, bz
-  auto base1 = [&](int n) -> const double * { return n < 5 ? wb + n*cs : bb + (n - 4)*cs; };
-  size_t off = ((size_t)k*g.N2 + s0)*g.N1 + i;
-#pragma unroll
-  for (int n = 0; n < NV; ++n) {
-    const double *q = base2(n) + off;
-    double pl, dummy;
-    if constexpr (RECON == 1) {
-      const double qa = q[-2*st], qb = q[-st], qc = q[0];
-      plm(qa, qb, qc, pl, dummy);
-      W_(n, 0) = qb; W_(n, 1) = qc;
-    } else if constexpr (RECON >= 2) {
-      const double qa = q[-3*st], qb = q[-2*st], qc = q[-st], qd = q[0], qe = q[st];
-      recon5<RECON>(qa, qb, qc, qd, qe, pl, dummy);
-      if (n == 0) floor_lr<RECON, 1>(eos, pl, dummy);
-      if (n == 4) floor_lr<RECON, 2>(eos, pl, dummy);
-      W_(n, 0) = qb; W_(n, 1) = qc; W_(n, 2) = qd; W_(n, 3) = qe;
-    } else {
-      pl = q[-st];
-      W_(n, 0) = q[0];
-    }
-    PL_(n) = pl;
-  }
-  const size_t f2st = (size_t)a2.f1;
-  const double *pbx2 = a2.bxf + ix4(a2.f3, a2.f2, a2.f1, m, k, s0, i);
-  // dx a power of two: x/dx == x*(1/dx) bit for bit (both are the correctly rounded value of the
-  // same real number), and the reciprocal is exact -- ten divisions per cell become products
-  constexpr bool p2 = P2;             // the launcher checked that dx1 and dx2 are powers of two
-  const double rdx1 = 1.0/dx1, rdx2 = 1.0/dx2;
-  for (int t = 0;; ++t) {
-    const int s = s0 + t;
-    if (s > shi + 1) break;                   // the last chunk ends with the x1 faces of row ju(x1)
-    if (t > ml && s <= shi) break;            // the others end with the face they share
-    // every step runs both solves on memory that exists; what a step may keep is decided at the
-    // stores (one basic block: the loads of both directions are issued together)
-    const bool do_x2 = s <= shi;
-    const int jr = s - 1;                     // row of the x1 faces of this step
-    const bool do_x1 = (t >= 1 || s0 == a2.jl) && jr >= a1.jl && jr <= a1.ju;
-    const size_t orow = ((size_t)k*g.N2 + jr)*g.N1 + i;
-    // ---- x1 face on the low side of cell (k, jr, i)
-    double qln[NV], qr[NV], q0[NV];
-#pragma unroll
-    for (int n = 0; n < NV; ++n) {
-      const double *q = base1(n) + orow;
-      q0[n] = q[0];
-      cell_lr_x1<RECON>(q, eos, n, qln[n], qr[n]);
-    }
-    const double bxc = bb[orow];
-    const double bx1 = a1.bxf[ix4(a1.f3, a1.f2, a1.f1, m, k, jr, i)];
-    double L1[NV];
-#pragma unroll
-    for (int n = 0; n < NV; ++n) L1[n] = __shfl_up(qln[n], 1, 64);
-    Cons1D f1 = riemann_mhd<RS>(eos.gamma, L1[0], L1[1], L1[2], L1[3], L1[4], L1[5], L1[6], qr[0],
-                                qr[1], qr[2], qr[3], qr[4], qr[5], qr[6], bx1);
-    double dF1[5];
-    dF1[0] = __shfl_down(f1.d, 1, 64) - f1.d;
-    dF1[1] = __shfl_down(f1.mx, 1, 64) - f1.mx;
-    dF1[2] = __shfl_down(f1.my, 1, 64) - f1.my;
-    dF1[3] = __shfl_down(f1.mz, 1, 64) - f1.mz;
-    dF1[4] = __shfl_down(f1.e, 1, 64) - f1.e;
-    if (do_x1) {
-      if (inner && i >= a1.il - 1 && i <= a1.iu) {          // cell-centred E = -(v x B)
-        const size_t e = ix4(g.N3, g.N2, g.N1, m, k, jr, i);
-        a1.ecc1[e] = q0[3]*q0[5] - q0[2]*q0[6];
-        a1.ecc2[e] = q0[1]*q0[6] - q0[3]*bxc;
-        a1.ecc3[e] = q0[2]*bxc - q0[1]*q0[5];
-      }
-      if (x1_ok) {
-        a1.flx[ix5(g.nvar, a1.f3, a1.f2, a1.f1, m, 0, k, jr, i)] = f1.d;
-        const size_t ec = ix4(g.N3, g.N2, g.N1, m, k, jr, i);
-        a1.ey[ec] = -f1.by;
-        a1.ez[ec] = f1.bz;
-      }
-    }
-    // ---- x2 face s
-    double L[NV], R[NV];
-#pragma unroll
-    for (int n = 0; n < NV; ++n) {
-      const double *q = base2(n) + off;
-      double qln2;
-      L[n] = PL_(n);
-      if constexpr (RECON == 1) {
-        const double qp = q[st];
-        const double w0 = W_(n, 0), w1 = W_(n, 1);
-        plm(w0, w1, qp, qln2, R[n]);
-        W_(n, 0) = w1; W_(n, 1) = qp;
-      } else if constexpr (RECON >= 2) {
-        const double qp = q[2*st];
-        const double w0 = W_(n, 0), w1 = W_(n, 1), w2 = W_(n, 2), w3 = W_(n, 3);
-        recon5<RECON>(w0, w1, w2, w3, qp, qln2, R[n]);
-        if (n == 0) floor_lr<RECON, 1>(eos, qln2, R[n]);
-        if (n == 4) floor_lr<RECON, 2>(eos, qln2, R[n]);
-        W_(n, 0) = w1; W_(n, 1) = w2; W_(n, 2) = w3; W_(n, 3) = qp;
-      } else {
-        const double w0 = W_(n, 0);
-        R[n] = w0;
-        qln2 = w0;
-        W_(n, 0) = q[st];
-      }
-      PL_(n) = qln2;
-    }
-    off += st;
-    Cons1D f2 = riemann_mhd<RS>(eos.gamma, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1],
-                                R[2], R[3], R[4], R[5], R[6], pbx2[(size_t)t*f2st]);
-    if (do_x2 && x2_ok && (t < ml || s == shi)) {
-      a2.flx[ix5(g.nvar, a2.f3, a2.f2, a2.f1, m, 0, k, s, i)] = f2.d;
-      const size_t ec = ix4(g.N3, g.N2, g.N1, m, k, s, i);
-      a2.ey[ec] = -f2.by;
-      a2.ez[ec] = f2.bz;
-    }
-    // x2 flux in natural component order: d, m1, m2, m3, E  (ivx = 2, ivy = 3, ivz = 1)
-    const double fv[5] = {f2.d, f2.mz, f2.mx, f2.my, f2.e};
-    const int sc = s - 1;
-    if (do_x2 && t > 0 && col_active && sc >= g.js && sc <= g.je) {
-      const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, sc, i);
-#pragma unroll
-      for (int n = 0; n < 5; ++n) {
-        double divf = p2 ? dF1[n]*rdx1 : dF1[n]/dx1;
-        divf += p2 ? (fv[n] - FP_(n))*rdx2 : (fv[n] - FP_(n))/dx2;
-        u.acc[c + n*cs] = divf;
-      }
-    }
-#pragma unroll
-    for (int n = 0; n < 5; ++n) FP_(n) = fv[n];
-  }
-#undef W_
-#undef PL_
-#undef FP_
-}
-
-template <int RECON, int RS>
-__global__ void __launch_bounds__(SX*SY, (RECON >= 2 ? 2 : AKMI_X12_WAVES))
-k_sweep12(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
-  __shared__ double sm[(7*RollCfg<RECON>::NW + 7 + 5)*SX*SY];
-  const int m = blockIdx.z;
-  if (AKMI_POW2DX && is_pow2(g.dx[3*m]) && is_pow2(g.dx[3*m + 1]))      // see k_sweep_update
-    sweep12_body<RECON, RS, AKMI_POW2DX != 0>(g, eos, a1, a2, u, ml, sm);
-  else
-    sweep12_body<RECON, RS, false>(g, eos, a1, a2, u, ml, sm);
-}
 
 // 1-D problems: the sweep direction is the lane direction, so neighbouring faces are
 // exchanged through LDS inside a TX-wide tile (overlap of one face between tiles).
@@ -1705,10 +1491,13 @@ static int launch_sweep_update(const Geo &g, const Scheme &sc, const SweepArgs &
 
 // x1 sweep + x2 march of an MHD pack in one kernel (3-D)
 // ---------------------------------------------------------------------------------------
-// k_sweep12s: the x1 sweep inside the x2 march, second form (PLM).  The cells of row s-1 whose x1 faces a
-// step solves are the cells the march loaded one step earlier: they sit in its window (LDS), so the x1
+// k_sweep12s: the x1 sweep inside the x2 march (MHD, 3-D, PLM).  While a thread walks along j it also solves
+// the x1 face on the low side of its cell in row s-1, the row whose cells the step finishes; the x1 flux
+// difference of the cell goes straight into acc = dF1/dx1 + dF2/dx2 (rounding sequence of
+// hydro_update.cpp:55-80 unchanged), so the 5-component x1 flux array is never written.  The cells of
+// row s-1 are the cells the march loaded one step earlier: they sit in its window (LDS), so the x1
 // part issues TWO loads per step (the cell-centred By, which the x2 march does not carry, and the face
-// field) instead of 22; the i-1 / i+1 neighbours of the slopes, the left state of the face and the flux of
+// field); the i-1 / i+1 neighbours of the slopes, the left state of the face and the flux of
 // face i+1 come from the neighbouring lanes (wave shuffles).  Waves overlap by four lanes: lanes 0 and 63
 // only provide cells, lane 1 a left state, lane 62 a face flux; lanes 2..61 own cells.
 #ifndef AKMI_X12S_WAVES
@@ -1879,28 +1668,6 @@ static int launch_sweep12s(const Geo &g, const Scheme &sc, const SweepArgs &a1, 
   return AKMI_COMPLETE;
 }
 
-static int launch_sweep12(const Geo &g, const Scheme &sc, const SweepArgs &a1, const SweepArgs &a2,
-                          const UpdArgs &u, hipStream_t st) {
-  const long np = (long)(a2.ku - a2.kl + 1)*g.N1;          // flattened (k,i) rows
-  const long nwaves = (np + (SX - 2) - 1)/(SX - 2);
-  const unsigned nb = (unsigned)((nwaves + SY - 1)/SY);
-  const int nc = a2.ju - a2.jl > 0 ? a2.ju - a2.jl : 1;
-  const int ml = march_len(nb, nc, g.nmb, ML, 3);
-  dim3 grid(nb, cdiv(nc, ml), g.nmb), block(SX, SY);
-#if AKMI_X12_BUILD
-  int rc = dispatch_scheme<true>(sc, [&](auto R, auto S) {
-    k_sweep12<decltype(R)::value, decltype(S)::value><<<grid, block, 0, st>>>(g, sc.eos, a1, a2, u, ml);
-    return AKMI_COMPLETE;
-  });
-  if (rc != AKMI_COMPLETE) return rc;
-  AKMI_CHECK_LAUNCH("sweep12");
-  return AKMI_COMPLETE;
-#else
-  (void)grid; (void)block; (void)ml; (void)st;
-  set_error("AKMI_X12=1 needs a library built with -DAKMI_X12_BUILD=1 (the experiment of profiles/r02_ab2_*.txt)");
-  return AKMI_FAIL;
-#endif
-}
 
 template <bool MASS>
 static int launch_hydro_stage3d(const Geo &g, const Scheme &sc, const double *w0, const UpdArgs &u,
@@ -2215,13 +1982,6 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
   static const bool env_one = getenv("AKMI_ONE_STREAM") && atoi(getenv("AKMI_ONE_STREAM")) != 0;
   // AKMI_HYDRO_ONE_KERNEL=0: the three-kernel sweep/march sequence also for hydro DC/PLM (A/B runs)
   static const bool hyd_one = !(getenv("AKMI_HYDRO_ONE_KERNEL") && atoi(getenv("AKMI_HYDRO_ONE_KERNEL")) == 0);
-  // AKMI_X12=1: x1 sweep folded into the x2 march (k_sweep12).  Bit-identical, 19 doubles per cell
-  // less traffic, but 1.86-2.02 ms against 0.70 + 0.91 ms for the two kernels (profiles/r02_ab2.txt):
-  // the fused loop body exceeds the 168 VGPRs of three waves per SIMD and spills.  Off by default.
-  static const bool x12 = getenv("AKMI_X12") && atoi(getenv("AKMI_X12")) == 1;
-  // default (AKMI_X12 unset or 2): the second form, k_sweep12s -- the cells of the x1 faces come from the
-  // march's window, neighbours by wave shuffle: 1 436 us against 596 + 876 us for the two kernels and 2.5 GB
-  // less traffic per stage (profiles/r02_v9_x12s_ab.txt).  AKMI_X12=0: x1 sweep and x2 march as two kernels.
   static const bool x12s = !getenv("AKMI_X12") || atoi(getenv("AKMI_X12")) == 2;
   const int T = (phases != AKMI_PHASE_ALL) ? g.nx3 : (env_slab > 1 ? env_slab : AKMI_SLAB);
   const int S = (g.nx3 + T - 1)/T;
@@ -2270,10 +2030,6 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
                g.nvar == 5) {
       // x1 sweep inside the x2 march, cells from the march's window (k_sweep12s); x3 march consumes acc
       if constexpr (MHD) rc = launch_sweep12s(g, sc, b1, b2, u, st);
-      if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD, 0, true>(g, sc, b3, u, st);
-    } else if (do_sweeps && MHD && x12) {
-      // x1 sweep folded into the x2 march (no x1 flux array); x3 march consumes acc
-      if constexpr (MHD) rc = launch_sweep12(g, sc, b1, b2, u, st);
       if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD, 0, true>(g, sc, b3, u, st);
     } else if (do_sweeps) {
       rc = MHD ? launch_sweep<0, MHD, MHD>(g, sc, b1, st)
