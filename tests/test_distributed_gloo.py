@@ -94,6 +94,27 @@ def test_two_ranks_match_single_process_oracle(case):
             assert ncyc == case[4] and nmb >= 1 and npeers == 1
 
 
+BENCH_LAYOUTS = [
+    # bench.py --gpus N: one MeshBlock per rank, the mesh 2x1x1 / 2x2x1 / 2x2x2 blocks, periodic.  In a
+    # direction with two blocks the +/- neighbours are the SAME peer, in a direction with one block the rank
+    # is its own neighbour; at 8 ranks every one of the 26 neighbours is off-rank
+    ("orszag_tang", (16, 8, 8), 3, (8, 8, 8), 2, dict(cfl=0.3), 2, 1),
+    ("orszag_tang", (16, 16, 8), 3, (8, 8, 8), 2, dict(cfl=0.3), 4, 3),
+    ("orszag_tang", (16, 16, 16), 3, (8, 8, 8), 2, dict(cfl=0.3), 8, 7),
+]
+
+
+@pytest.mark.parametrize("case", BENCH_LAYOUTS, ids=lambda c: "%dranks" % c[6])
+def test_bench_layouts_match_single_process_oracle(case):
+    world, peers = case[6], case[7]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), case[:6], d), nprocs=world, join=True)
+        for r in range(world):
+            ok, ncyc, nmb, npeers = map(int, open(os.path.join(d, "rank%d.txt" % r)).read().split())
+            assert ok == 1, "rank %d differs from the single-process oracle" % r
+            assert ncyc == case[4] and nmb == 1 and npeers == peers
+
+
 SMR_CASES = [
     # statically refined meshes cut across ranks: level-aware segments, restricted fluxes and edge EMFs
     # travel between ranks (bvals_smr.py _plan_ranks)

@@ -118,6 +118,25 @@ def test_refined_mesh_on_several_ranks_cpp_host(case):
             assert ncyc == case[4] and nmb >= 1
 
 
+BENCH_LAYOUTS = [
+    # bench.py --gpus 4 / 8: one MeshBlock per rank in a 2x2x1 / 2x2x2 periodic mesh (at 8 ranks every one of
+    # the 26 neighbours is off-rank and the +/- neighbours of a direction are the same peer)
+    ("orszag_tang", (32, 32, 16), 3, (16, 16, 16), 2, dict(cfl=0.3), 4),
+    ("orszag_tang", (32, 32, 32), 3, (16, 16, 16), 2, dict(cfl=0.3), 8),
+]
+
+
+@pytest.mark.parametrize("case", BENCH_LAYOUTS, ids=lambda c: "%dranks" % c[6])
+def test_bench_layouts_cpp_host(case):
+    world = case[6]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), case[:6], True, d), nprocs=world, join=True)
+        for r in range(world):
+            ok, ncyc, nmb = map(int, open(os.path.join(d, "rank%d.txt" % r)).read().split())
+            assert ok == 1, "rank %d differs from the single-process oracle" % r
+            assert ncyc == case[4] and nmb == 1
+
+
 def test_three_ranks_uneven_split():
     world = 3
     case = ("orszag_tang", 32, 3, 16, 2, dict(cfl=0.3))       # 3 + 3 + 2 blocks

@@ -93,6 +93,24 @@ def test_two_ranks_hip_kernels_match_single_process_oracle(case, fused):
             assert ncyc == case[4] and nmb >= 1 and npeers == 1
 
 
+BENCH_LAYOUTS = [
+    # bench.py --gpus 4 / 8: one MeshBlock per rank, 2x2x1 / 2x2x2 periodic mesh, fused stage in phases
+    ("orszag_tang", (32, 32, 16), 3, (16, 16, 16), 2, dict(cfl=0.3), 4, 3),
+    ("orszag_tang", (32, 32, 32), 3, (16, 16, 16), 2, dict(cfl=0.3), 8, 7),
+]
+
+
+@pytest.mark.parametrize("case", BENCH_LAYOUTS, ids=lambda c: "%dranks" % c[6])
+def test_bench_layouts_hip_kernels(case):
+    world, peers = case[6], case[7]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), case[:6], True, d), nprocs=world, join=True)
+        for r in range(world):
+            ok, ncyc, nmb, npeers = map(int, open(os.path.join(d, "rank%d.txt" % r)).read().split())
+            assert ok == 1, "rank %d differs from the single-process oracle" % r
+            assert ncyc == case[4] and nmb == 1 and npeers == peers
+
+
 SMR_CASES = [
     # problem, mesh, dims, block, cycles, kwargs, ranks: refined meshes cut across ranks
     ("linear_wave_mhd_smr", (32, 16, 16), 3, (8, 4, 4), 2, {}, 2),
