@@ -21,6 +21,19 @@ void set_error(const char *fmt, ...) {
 
 constexpr int BX = 64, BY = 4;
 
+// Lane mapping of the cell kernels below: the lanes of a launch run over the flattened rows
+// [jl, ju] x [0, N1) of a plane -- contiguous in memory, and a MeshBlock of 16 or 32 cells per row keeps
+// 2/3 - 4/5 of the lanes busy instead of the 1/4 - 1/2 it gets with threadIdx.x tied to i.
+__device__ __forceinline__ void flat_ij(const Geo &g, int jl, int &i, int &j) {
+  const long p = ((long)blockIdx.x*BY + threadIdx.y)*BX + threadIdx.x;
+  const int jj = (int)(p/g.N1);
+  i = (int)(p - (long)jj*g.N1);
+  j = jl + jj;
+}
+static inline dim3 flat_grid(const Geo &g, int nj, int nz) {
+  return dim3((unsigned)(((long)nj*g.N1 + BX*BY - 1)/(BX*BY)), 1, (unsigned)nz);
+}
+
 // ---------------------------------------------------------------------------------------
 // Hydro fluxes: reconstruct in registers + Riemann solver RS.  hydro_fluxes.cpp:77-229.
 template <int DIR, int RECON, int RS, bool ISO>
@@ -98,12 +111,12 @@ __global__ void __launch_bounds__(BX*BY)
 k_rk_update(Geo g, double gam0, double gam1, double beta_dt, double *__restrict__ u0,
             const double *__restrict__ u1, const double *__restrict__ flx1,
             const double *__restrict__ flx2, const double *__restrict__ flx3, int fsh) {
-  const int i = g.is + blockIdx.x*BX + threadIdx.x;
-  const int j = g.js + blockIdx.y*BY + threadIdx.y;
+  int i, j;
+  flat_ij(g, g.js, i, j);
   const int nk = g.ke - g.ks + 1;
   const int m = blockIdx.z/nk;
   const int k = g.ks + (blockIdx.z - m*nk);
-  if (i > g.ie || j > g.je) return;
+  if (i < g.is || i > g.ie || j > g.je) return;
   const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
   for (int n = 0; n < g.nvar; ++n) {
     double divf = (flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + fsh, m, n, k, j, i + 1)] -
@@ -128,11 +141,11 @@ k_c2p(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ bx1f,
       const double *__restrict__ bx2f, const double *__restrict__ bx3f,
       double *__restrict__ w0, double *__restrict__ bcc0, int il, int iu, int jl, int ju,
       int kl, int nk, int *__restrict__ counters) {
-  const int i = il + blockIdx.x*BX + threadIdx.x;
-  const int j = jl + blockIdx.y*BY + threadIdx.y;
+  int i, j;
+  flat_ij(g, jl, i, j);
   const int m = blockIdx.z/nk;
   const int k = kl + (blockIdx.z - m*nk);
-  if (i > iu || j > ju) return;
+  if (i < il || i > iu || j > ju) return;
   const size_t cs = (size_t)g.N3*g.N2*g.N1;
   const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
   double ubx = 0.0, uby = 0.0, ubz = 0.0;
@@ -242,13 +255,13 @@ template <bool MHD>
 __global__ void __launch_bounds__(BX*BY)
 k_newdt(Geo g, Eos eos, const double *__restrict__ w0, const double *__restrict__ bcc0,
         double *__restrict__ dt3) {
-  const int i = g.is + blockIdx.x*BX + threadIdx.x;
-  const int j = g.js + blockIdx.y*BY + threadIdx.y;
+  int i, j;
+  flat_ij(g, g.js, i, j);
   const int nk = g.ke - g.ks + 1;
   const int m = blockIdx.z/nk;
   const int k = g.ks + (blockIdx.z - m*nk);
   double d1 = (double)FLT_MAX, d2 = (double)FLT_MAX, d3 = (double)FLT_MAX;
-  if (i <= g.ie && j <= g.je) cell_dt<MHD>(g, eos, w0, bcc0, m, k, j, i, d1, d2, d3);
+  if (i >= g.is && i <= g.ie && j <= g.je) cell_dt<MHD>(g, eos, w0, bcc0, m, k, j, i, d1, d2, d3);
   block_min3_atomic(d1, d2, d3, dt3);
 }
 
@@ -659,12 +672,12 @@ k_ct(Geo g, double gam0, double gam1, double beta_dt, const double *__restrict__
      const double *__restrict__ e2, const double *__restrict__ e3, double *__restrict__ b0x1f,
      double *__restrict__ b0x2f, double *__restrict__ b0x3f, const double *__restrict__ b1x1f,
      const double *__restrict__ b1x2f, const double *__restrict__ b1x3f) {
-  const int i = g.is + blockIdx.x*BX + threadIdx.x;
-  const int j = g.js + blockIdx.y*BY + threadIdx.y;
+  int i, j;
+  flat_ij(g, g.js, i, j);
   const int nk = g.ke - g.ks + 2;
   const int m = blockIdx.z/nk;
   const int k = g.ks + (blockIdx.z - m*nk);
-  if (i > g.ie + 1 || j > g.je + 1) return;
+  if (i < g.is || i > g.ie + 1 || j > g.je + 1) return;
   const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
 #define E1(k, j, i) e1[ix4(g.N3 + 1, g.N2 + 1, g.N1, m, k, j, i)]
 #define E2(k, j, i) e2[ix4(g.N3 + 1, g.N2, g.N1 + 1, m, k, j, i)]
@@ -1002,7 +1015,7 @@ int akmi_rk_update(const akmi_pack *p, double gam0, double gam1, double beta_dt,
                    const double *u1, const double *flx1, const double *flx2,
                    const double *flx3, int face_shaped, void *stream) {
   Geo g = make_geo(p);
-  dim3 grid(cdiv(g.nx1, BX), cdiv(g.je - g.js + 1, BY), (g.ke - g.ks + 1)*g.nmb), block(BX, BY);
+  dim3 grid = flat_grid(g, g.je - g.js + 1, (g.ke - g.ks + 1)*g.nmb), block(BX, BY);
   k_rk_update<<<grid, block, 0, (hipStream_t)stream>>>(g, gam0, gam1, beta_dt, u0, u1, flx1, flx2,
                                                        flx3, face_shaped ? 1 : 0);
   AKMI_CHECK_LAUNCH("rk_update");
@@ -1013,7 +1026,7 @@ int akmi_hydro_c2p(const akmi_pack *p, double *u0, double *w0, int il, int iu, i
                    int kl, int ku, int *counters, void *stream) {
   Geo g = make_geo(p);
   int nk = ku - kl + 1;
-  dim3 grid(cdiv(iu - il + 1, BX), cdiv(ju - jl + 1, BY), nk*g.nmb), block(BX, BY);
+  dim3 grid = flat_grid(g, ju - jl + 1, nk*g.nmb), block(BX, BY);
   k_c2p<false><<<grid, block, 0, (hipStream_t)stream>>>(g, make_eos(p), u0, nullptr, nullptr,
       nullptr, w0, nullptr, il, iu, jl, ju, kl, nk, counters);
   AKMI_CHECK_LAUNCH("hydro_c2p");
@@ -1025,7 +1038,7 @@ int akmi_mhd_c2p(const akmi_pack *p, double *u0, const double *bx1f, const doubl
                  int kl, int ku, int *counters, void *stream) {
   Geo g = make_geo(p);
   int nk = ku - kl + 1;
-  dim3 grid(cdiv(iu - il + 1, BX), cdiv(ju - jl + 1, BY), nk*g.nmb), block(BX, BY);
+  dim3 grid = flat_grid(g, ju - jl + 1, nk*g.nmb), block(BX, BY);
   k_c2p<true><<<grid, block, 0, (hipStream_t)stream>>>(g, make_eos(p), u0, bx1f, bx2f, bx3f, w0,
       bcc0, il, iu, jl, ju, kl, nk, counters);
   AKMI_CHECK_LAUNCH("mhd_c2p");
@@ -1036,7 +1049,7 @@ int akmi_hydro_newdt(const akmi_pack *p, const double *w0, double *dt3, void *st
   Geo g = make_geo(p);
   hipStream_t st = (hipStream_t)stream;
   k_init_dt<<<1, 64, 0, st>>>(dt3);
-  dim3 grid(cdiv(g.nx1, BX), cdiv(g.je - g.js + 1, BY), (g.ke - g.ks + 1)*g.nmb), block(BX, BY);
+  dim3 grid = flat_grid(g, g.je - g.js + 1, (g.ke - g.ks + 1)*g.nmb), block(BX, BY);
   k_newdt<false><<<grid, block, 0, st>>>(g, make_eos(p), w0, nullptr, dt3);
   AKMI_CHECK_LAUNCH("hydro_newdt");
   return AKMI_COMPLETE;
@@ -1057,7 +1070,7 @@ int akmi_mhd_newdt(const akmi_pack *p, const double *w0, const double *bcc0, dou
   Geo g = make_geo(p);
   hipStream_t st = (hipStream_t)stream;
   k_init_dt<<<1, 64, 0, st>>>(dt3);
-  dim3 grid(cdiv(g.nx1, BX), cdiv(g.je - g.js + 1, BY), (g.ke - g.ks + 1)*g.nmb), block(BX, BY);
+  dim3 grid = flat_grid(g, g.je - g.js + 1, (g.ke - g.ks + 1)*g.nmb), block(BX, BY);
   k_newdt<true><<<grid, block, 0, st>>>(g, make_eos(p), w0, bcc0, dt3);
   AKMI_CHECK_LAUNCH("mhd_newdt");
   return AKMI_COMPLETE;
@@ -1202,7 +1215,7 @@ int akmi_mhd_ct(const akmi_pack *p, double gam0, double gam1, double beta_dt, co
                 const double *e2, const double *e3, double *b0x1f, double *b0x2f, double *b0x3f,
                 const double *b1x1f, const double *b1x2f, const double *b1x3f, void *stream) {
   Geo g = make_geo(p);
-  dim3 grid(cdiv(g.nx1 + 1, BX), cdiv(g.je - g.js + 2, BY), (g.ke - g.ks + 2)*g.nmb), block(BX, BY);
+  dim3 grid = flat_grid(g, g.je - g.js + 2, (g.ke - g.ks + 2)*g.nmb), block(BX, BY);
   k_ct<<<grid, block, 0, (hipStream_t)stream>>>(g, gam0, gam1, beta_dt, e1, e2, e3, b0x1f, b0x2f,
                                                 b0x3f, b1x1f, b1x2f, b1x3f);
   AKMI_CHECK_LAUNCH("ct");
