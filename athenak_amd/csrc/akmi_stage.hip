@@ -888,36 +888,49 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const double *__res
   constexpr bool p2 = P2;             // the launcher checked that dx1, dx2, dx3 are powers of two
   const double rdx1 = 1.0/dx1, rdx2 = 1.0/dx2, rdx3 = 1.0/dx3;
 #define DIVX(x, q) (p2 ? (x)*r##q : (x)/q)
+  // addresses: scalar base of (block, array) + a 32-bit byte offset per lane and array shape, advanced by one
+  // plane per step (no 64-bit index arithmetic on the vector unit, fewer address registers)
+  const size_t cs = (size_t)g.N3*g.N2*g.N1;
+  const long PS = (long)g.N2*g.N1, PS1 = (long)g.N2*(g.N1 + 1), PS2 = (long)(g.N2 + 1)*g.N1;   // plane strides
+  unsigned oc = (((unsigned)k0*(unsigned)g.N2 + (unsigned)j)*(unsigned)g.N1 + (unsigned)i)*8u;            // (.., N2, N1)
+  unsigned o1 = (((unsigned)k0*(unsigned)g.N2 + (unsigned)j)*(unsigned)(g.N1 + 1) + (unsigned)i)*8u;      // (.., N2, N1+1)
+  unsigned o2 = (((unsigned)k0*(unsigned)(g.N2 + 1) + (unsigned)j)*(unsigned)g.N1 + (unsigned)i)*8u;      // (.., N2+1, N1)
+  const double *f1m = flx1 + (size_t)m*g.nvar*g.N3*PS1, *f2m = flx2 + (size_t)m*g.nvar*g.N3*PS2,
+               *f3m = flx3 + (size_t)m*g.nvar*(g.N3 + 1)*PS;
+  const double *x31 = e3x1 + (size_t)m*cs, *x21 = e2x1 + (size_t)m*cs, *x12 = e1x2 + (size_t)m*cs,
+               *x32 = e3x2 + (size_t)m*cs, *x23 = e2x3 + (size_t)m*cs, *x13 = e1x3 + (size_t)m*cs;
+  const double *c1m = c1 + (size_t)m*cs, *c2m = c2 + (size_t)m*cs, *c3m = c3 + (size_t)m*cs;
+  double *b01 = b0x1f + (size_t)m*g.N3*PS1, *b02 = b0x2f + (size_t)m*g.N3*PS2, *b03 = b0x3f + (size_t)m*(g.N3 + 1)*PS;
+  double *b11 = b1x1f + (size_t)m*g.N3*PS1, *b12 = b1x2f + (size_t)m*g.N3*PS2, *b13 = b1x3f + (size_t)m*(g.N3 + 1)*PS;
   double e1p = 0.0, e2p = 0.0, e3p = 0.0;                       // own edges of the previous plane
   // operands of the corner formulas that belong to plane k-1 (rolled from step to step)
   double f1_km = 0.0, f2_km = 0.0, x2_km = 0.0, x1_km = 0.0, c1_mm = 0.0, c1_m0 = 0.0, c2_mm = 0.0,
          c2_m0 = 0.0;
   if (edge_ok) {
-    const int k = k0;
-    f1_km = flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k - 1, j, i)];
-    f2_km = flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, 0, k - 1, j, i)];
-    x2_km = CCE(e1x2, k - 1, j, i);
-    x1_km = CCE(e2x1, k - 1, j, i);
-    c1_mm = CCE(c1, k - 1, j - 1, i); c1_m0 = CCE(c1, k - 1, j, i);
-    c2_mm = CCE(c2, k - 1, j, i - 1); c2_m0 = CCE(c2, k - 1, j, i);
+    f1_km = ldu(f1m - PS1, o1);
+    f2_km = ldu(f2m - PS2, o2);
+    x2_km = ldu(x12 - PS, oc);
+    x1_km = ldu(x21 - PS, oc);
+    c1_mm = ldu(c1m - PS - g.N1, oc); c1_m0 = ldu(c1m - PS, oc);
+    c2_mm = ldu(c2m - PS - 1, oc); c2_m0 = ldu(c2m - PS, oc);
   }
   for (int k = k0; k <= k1 + 1; ++k) {
     const int t = k - k0;
     const int pp2 = t & 1, p3 = t % 3;
     double e1 = 0.0, e2 = 0.0, e3 = 0.0;
     if (edge_ok) {
-      const double f1_k = flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k, j, i)];
-      const double f1_jm = flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k, j - 1, i)];
-      const double f2_k = flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, 0, k, j, i)];
-      const double f2_im = flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, 0, k, j, i - 1)];
-      const double f3_k = flx3[ix5(g.nvar, g.N3 + 1, g.N2, g.N1, m, 0, k, j, i)];
-      const double f3_jm = flx3[ix5(g.nvar, g.N3 + 1, g.N2, g.N1, m, 0, k, j - 1, i)];
-      const double f3_im = flx3[ix5(g.nvar, g.N3 + 1, g.N2, g.N1, m, 0, k, j, i - 1)];
-      const double c1_0m = CCE(c1, k, j - 1, i), c1_00 = CCE(c1, k, j, i);
-      const double c2_0m = CCE(c2, k, j, i - 1), c2_00 = CCE(c2, k, j, i);
-      const double x2_k = CCE(e1x2, k, j, i), x1_k = CCE(e2x1, k, j, i);
+      const double f1_k = ldu(f1m, o1);
+      const double f1_jm = ldu(f1m - (g.N1 + 1), o1);
+      const double f2_k = ldu(f2m, o2);
+      const double f2_im = ldu(f2m - 1, o2);
+      const double f3_k = ldu(f3m, oc);
+      const double f3_jm = ldu(f3m - g.N1, oc);
+      const double f3_im = ldu(f3m - 1, oc);
+      const double c1_0m = ldu(c1m - g.N1, oc), c1_00 = ldu(c1m, oc);
+      const double c2_0m = ldu(c2m - 1, oc), c2_00 = ldu(c2m, oc);
+      const double x2_k = ldu(x12, oc), x1_k = ldu(x21, oc);
       {  // E1 (mhd_corner_e.cpp:340-363)
-        const double x3_jm = CCE(e1x3, k, j - 1, i), x3_j = CCE(e1x3, k, j, i);
+        const double x3_jm = ldu(x13 - g.N1, oc), x3_j = ldu(x13, oc);
         double e1_l3 = upw(f2_km >= 0.0, x3_jm, c1_mm, x3_j, c1_m0);
         double e1_r3 = upw(f2_k >= 0.0, x3_jm, c1_0m, x3_j, c1_00);
         double e1_l2 = upw(f3_jm >= 0.0, x2_km, c1_mm, x2_k, c1_0m);
@@ -925,7 +938,7 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const double *__res
         e1 = 0.25*(e1_l3 + e1_r3 + e1_l2 + e1_r2 + x2_km + x2_k + x3_jm + x3_j);
       }
       {  // E2 (:365-388)
-        const double x3_im = CCE(e2x3, k, j, i - 1), x3_i = CCE(e2x3, k, j, i);
+        const double x3_im = ldu(x23 - 1, oc), x3_i = ldu(x23, oc);
         double e2_l3 = upw(f1_km >= 0.0, x3_im, c2_mm, x3_i, c2_m0);
         double e2_r3 = upw(f1_k >= 0.0, x3_im, c2_0m, x3_i, c2_00);
         double e2_l1 = upw(f3_im >= 0.0, x1_km, c2_mm, x1_k, c2_0m);
@@ -933,10 +946,10 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const double *__res
         e2 = 0.25*(e2_l3 + e2_r3 + e2_l1 + e2_r1 + x3_im + x3_i + x1_km + x1_k);
       }
       {  // E3 (:390-413)
-        const double x2_im = CCE(e3x2, k, j, i - 1), x2_i = CCE(e3x2, k, j, i);
-        const double x1_jm = CCE(e3x1, k, j - 1, i), x1_j = CCE(e3x1, k, j, i);
-        const double c_mm = CCE(c3, k, j - 1, i - 1), c_m0 = CCE(c3, k, j - 1, i);
-        const double c_0m = CCE(c3, k, j, i - 1), c_00 = CCE(c3, k, j, i);
+        const double x2_im = ldu(x32 - 1, oc), x2_i = ldu(x32, oc);
+        const double x1_jm = ldu(x31 - g.N1, oc), x1_j = ldu(x31, oc);
+        const double c_mm = ldu(c3m - g.N1 - 1, oc), c_m0 = ldu(c3m - g.N1, oc);
+        const double c_0m = ldu(c3m - 1, oc), c_00 = ldu(c3m, oc);
         double e3_l2 = upw(f1_jm >= 0.0, x2_im, c_mm, x2_i, c_m0);
         double e3_r2 = upw(f1_k >= 0.0, x2_im, c_0m, x2_i, c_00);
         double e3_l1 = upw(f2_im >= 0.0, x1_jm, c_mm, x1_j, c_0m);
@@ -950,42 +963,43 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const double *__res
     __syncthreads();
     if (own) {
       if (i <= g.ie && j <= g.je && (k <= k1 || wtop)) {          // x3-face of plane k (mhd_ct.cpp:67-77)
-        const size_t c = ix4(g.N3 + 1, g.N2, g.N1, m, k, j, i);
-        const double b0v = b0x3f[c];
-        const double b1v = copy_b1 ? b0v : b1x3f[c];
+        const double b0v = ldu(b03, oc);
+        const double b1v = copy_b1 ? b0v : ldu(b13, oc);
         double b = gam0*b0v + gam1*b1v;
         b -= DIVX(beta_dt*(S2(pp2, ty, tx + 1) - e2), dx1);
         b += DIVX(beta_dt*(S1(pp2, ty + 1, tx) - e1), dx2);
-        rk_store(b0x3f, b1x3f, copy_b1, c, b0v, b);
+        rk_store_u(b03, b13, copy_b1, oc, b0v, b);
       }
       if (k > k0) {
-        const int kc = k - 1, q3 = (t + 2) % 3;                    // plane k-1 and its e3 buffer
+        const int q3 = (t + 2) % 3;                                // the e3 buffer of plane k-1
         if (j <= g.je) {                                           // x1-face (:45-54)
-          const size_t c = ix4(g.N3, g.N2, g.N1 + 1, m, kc, j, i);
-          const double b0v = b0x1f[c];
-          const double b1v = copy_b1 ? b0v : b1x1f[c];
+          const double b0v = ldu(b01 - PS1, o1);
+          const double b1v = copy_b1 ? b0v : ldu(b11 - PS1, o1);
           double b = gam0*b0v + gam1*b1v;
           b -= DIVX(beta_dt*(S3(q3, ty + 1, tx) - e3p), dx2);
           b += DIVX(beta_dt*(e2 - e2p), dx3);
-          rk_store(b0x1f, b1x1f, copy_b1, c, b0v, b);
+          rk_store_u(b01 - PS1, b11 - PS1, copy_b1, o1, b0v, b);
         }
         if (i <= g.ie) {                                           // x2-face (:56-65)
-          const size_t c = ix4(g.N3, g.N2 + 1, g.N1, m, kc, j, i);
-          const double b0v = b0x2f[c];
-          const double b1v = copy_b1 ? b0v : b1x2f[c];
+          const double b0v = ldu(b02 - PS2, o2);
+          const double b1v = copy_b1 ? b0v : ldu(b12 - PS2, o2);
           double b = gam0*b0v + gam1*b1v;
           b += DIVX(beta_dt*(S3(q3, ty, tx + 1) - e3p), dx1);
           b -= DIVX(beta_dt*(e1 - e1p), dx3);
-          rk_store(b0x2f, b1x2f, copy_b1, c, b0v, b);
+          rk_store_u(b02 - PS2, b12 - PS2, copy_b1, o2, b0v, b);
         }
       }
     }
     e1p = e1; e2p = e2; e3p = e3;
+    oc += (unsigned)PS*8u; o1 += (unsigned)PS1*8u; o2 += (unsigned)PS2*8u;
   }
 }
 #undef DIVX
 
-__global__ void __launch_bounds__(CT_THREADS)
+#ifndef AKMI_CT_WAVES
+#define AKMI_CT_WAVES 6         // waves per SIMD the register allocation aims at: 66 VGPRs, three workgroups per CU
+#endif                          // (two at the 114 VGPRs the compiler takes when left alone: 640-665 us against 621)
+__global__ void __launch_bounds__(CT_THREADS, AKMI_CT_WAVES)
 k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e2x1,
             const double *__restrict__ e1x2, const double *__restrict__ e3x2,
             const double *__restrict__ e2x3, const double *__restrict__ e1x3,
