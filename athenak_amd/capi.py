@@ -47,6 +47,7 @@ SYMBOLS = [
     "akmi_comm_rank", "akmi_comm_nranks", "akmi_host_exchange_plan",
     "akmi_smr_exchange_cc", "akmi_smr_exchange_fc", "akmi_smr_fill_coarse_cc", "akmi_smr_fill_coarse_fc",
     "akmi_smr_prolong_cc", "akmi_smr_prolong_fc", "akmi_smr_flux_cc", "akmi_smr_emf_exchange", "akmi_smr_pack_cc", "akmi_smr_unpack_cc", "akmi_smr_pack_fc",
+    "akmi_selftest_fp64",
     "akmi_smr_unpack_fc", "akmi_smr_pack_flux_cc", "akmi_smr_unpack_flux_cc", "akmi_smr_pack_emf", "akmi_smr_unpack_emf",
 ]
 

@@ -64,6 +64,9 @@ template <int V> using IC = std::integral_constant<int, V>;
 
 template <class F>
 inline int dispatch_recon(int recon, F &&f) {
+#ifdef AKMI_DEV_FAST      // developer builds (tools/build_variant.sh -DAKMI_DEV_FAST): PLM only, compiles in seconds
+  if (recon == AKMI_RECON_PLM) return f(IC<1>{});
+#else
   switch (recon) {
     case AKMI_RECON_DC:    return f(IC<0>{});
     case AKMI_RECON_PLM:   return f(IC<1>{});
@@ -72,6 +75,7 @@ inline int dispatch_recon(int recon, F &&f) {
     case AKMI_RECON_WENOZ: return f(IC<4>{});
     case AKMI_RECON_TENO:  return f(IC<5>{});
   }
+#endif
   set_error("reconstruct = %d not implemented", recon);
   return AKMI_FAIL;
 }
@@ -80,11 +84,13 @@ inline int dispatch_recon(int recon, F &&f) {
 // kernels only)
 template <bool MHD, bool ADV = false, class F>
 inline int dispatch_rsolver(int rs, F &&f) {
+#ifndef AKMI_DEV_FAST
   if (rs == AKMI_RS_LLF) return f(IC<0>{});
   if (rs == AKMI_RS_HLLE) return f(IC<1>{});
   if constexpr (ADV) {
     if (rs == AKMI_RS_ADVECT) return f(IC<5>{});
   }
+#endif
   if constexpr (MHD) {
     if (rs == AKMI_RS_HLLD) return f(IC<3>{});
     set_error("<mhd> rsolver = %d not implemented (llf, hlle, hlld)", rs);
@@ -108,6 +114,10 @@ inline int dispatch_scheme(const Scheme &sc, F &&f) {
 template <bool MHD, class F>
 inline int dispatch_scheme_eos(const Scheme &sc, F &&f) {
   if (!sc.iso) return dispatch_scheme<MHD>(sc, f);
+#ifdef AKMI_DEV_FAST
+  set_error("developer build: ideal gas only");
+  return AKMI_FAIL;
+#endif
   return dispatch_recon(sc.recon, [&](auto R) {
     const int rs = sc.rsolver;
     if (rs == AKMI_RS_LLF) return f(R, IC<10>{});
@@ -144,6 +154,14 @@ __device__ __forceinline__ double ldu(const double *__restrict__ base, unsigned 
 }
 __device__ __forceinline__ void stu(double *__restrict__ base, unsigned ob, double v) {
   *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + ob) = v;
+}
+
+// a wave-uniform double the vector unit computed (e.g. 1/dx), moved to scalar registers: frees two VGPRs per value
+__device__ __forceinline__ double to_sgpr(double x) {
+  const long long b = __double_as_longlong(x);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
 // LayoutRight offsets (src/athena.hpp:111,127-128)

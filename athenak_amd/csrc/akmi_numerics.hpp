@@ -16,6 +16,79 @@ namespace akmi {
 
 AKMI_DEV double sqr(double x) { return x*x; }
 
+// ---------------------------------------------------------------------------------------
+// Correctly rounded fp64 sqrt(x) and 1/x without the range handling of the compiler's expansions.
+//
+// hipcc expands `sqrt(x)` to 18 VALU instructions: v_rsq_f64, one Goldschmidt step, two residual
+// corrections (10 instructions) wrapped in a 2^256 pre-/post-scaling for x < 2^-767 (v_cmp, 2 v_cndmask,
+// 2 v_ldexp) and a zero/inf pass-through (v_cmp_class, 2 v_cndmask).  `1.0/x` becomes 11: two
+// v_div_scale, v_rcp_f64, two Newton steps, the quotient, its residual, v_div_fmas, v_div_fixup.
+// (profiles/r03_isa_audit.txt.)  For operands well inside the normal range the scaling is the
+// identity, v_div_fmas is a plain fma and the fix-ups pass the value through, so the same
+// iterations WITHOUT them return the same bits.  sqrt_x/rcp_x run that core when every lane of the
+// wave holds an operand with 2^-700 <= |x| < 2^700 (one integer add and one compare on the high
+// word) and take the compiler's full expansion otherwise (wave-uniform branch): zero, subnormal,
+// huge, infinite, NaN and negative operands never reach the short form.  Bit equality with `sqrt`
+// and `/` is asserted on >= 1e9 random and edge operands by tests/test_gpu_fastmath.py.
+// ---------------------------------------------------------------------------------------
+#ifndef AKMI_FAST_SQRT
+#define AKMI_FAST_SQRT 1
+#endif
+#ifndef AKMI_FAST_RCP
+#define AKMI_FAST_RCP 1
+#endif
+#ifndef AKMI_HLLD_FAST_RCP
+#define AKMI_HLLD_FAST_RCP 0   // rcp_x in hlld<.., FM>: measured neutral in k_sweep12s (1099 vs 1109 us) at 8 B of scratch: off
+#endif
+AKMI_DEV unsigned hi_word(double x) { return (unsigned)(__double_as_longlong(x) >> 32); }
+// true when 2^-700 <= |x| < 2^700: biased exponent in [323, 1723), sign shifted out
+AKMI_DEV bool in_core_range(double x) {
+  return ((hi_word(x) << 1) - (323u << 21)) < (1400u << 21);
+}
+AKMI_DEV double sqrt_core(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x*y;
+  double h = y*0.5;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+}
+AKMI_DEV double rcp_core(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(e, r, r);
+}
+template <bool FM = true>
+AKMI_DEV double sqrt_x(double x) {
+  if constexpr (!FM) return sqrt(x);
+#if AKMI_FAST_SQRT
+  // positive only: a set sign bit puts the high word outside the window as well
+  const bool ok = (hi_word(x) - (323u << 20)) < (1400u << 20);
+  if (__builtin_expect(__any(!ok), 0)) return sqrt(x);
+  return sqrt_core(x);
+#else
+  return sqrt(x);
+#endif
+}
+template <bool FM = true>
+AKMI_DEV double rcp_x(double x) {
+  if constexpr (!FM) return 1.0/x;
+#if AKMI_FAST_RCP
+  if (__builtin_expect(__any(!in_core_range(x)), 0)) return 1.0/x;
+  return rcp_core(x);
+#else
+  return 1.0/x;
+#endif
+}
+
 // PLM, src/reconstruct/plm.hpp:20-37 (van-Leer/harmonic slope on primitives)
 AKMI_DEV void plm(double qm, double q, double qp, double &ql_ip1, double &qr_i) {
   double dql = (q - qm);
@@ -491,13 +564,16 @@ AKMI_DEV void riemann_hyd(double gamma, double ld, double lx, double ly, double 
   else hllc(gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, f_d, f_mx, f_my, f_mz, f_e);
 }
 
-// IdealMHDFastSpeed, src/eos/eos.hpp:49-57
+// IdealMHDFastSpeed, src/eos/eos.hpp:49-57.  FM: the short square root (sqrt_x) -- chosen per call site,
+// like the early-outs of hlld(): it pays in the issue-bound k_sweep12s (1137 -> 1099 us) and costs the
+// memory-latency-bound marches registers and basic blocks (x3 march 984 -> 1020 us), profiles/r03_ab1.txt
+template <bool FM = false>
 AKMI_DEV double fast_speed(double gamma, double d, double p, double bx, double by, double bz) {
   double asq = gamma*p;
   double ct2 = by*by + bz*bz;
   double qsq = bx*bx + ct2 + asq;
   double tmp = bx*bx + ct2 - asq;
-  return sqrt(0.5*(qsq + sqrt(tmp*tmp + 4.0*asq*ct2))/d);
+  return sqrt_x<FM>(0.5*(qsq + sqrt_x<FM>(tmp*tmp + 4.0*asq*ct2))/d);
 }
 
 struct Cons1D { double d, mx, my, mz, e, by, bz; };
@@ -510,7 +586,7 @@ struct Cons1D { double d, mx, my, mz, e, by, bz; };
 #ifndef AKMI_HLLD_EARLYOUT
 #define AKMI_HLLD_EARLYOUT 1
 #endif
-template <bool EO = false>
+template <bool EO = false, bool FM = false>
 AKMI_DEV Cons1D hlld(double gamma, double wl_idn, double wl_ivx, double wl_ivy, double wl_ivz,
                      double wl_ien, double wl_iby, double wl_ibz, double wr_idn, double wr_ivx,
                      double wr_ivy, double wr_ivz, double wr_ien, double wr_iby, double wr_ibz,
@@ -533,8 +609,8 @@ AKMI_DEV Cons1D hlld(double gamma, double wl_idn, double wl_ivx, double wl_ivy, 
   ur.d = wr_idn; ur.mx = wr_ivx*ur.d; ur.my = wr_ivy*ur.d; ur.mz = wr_ivz*ur.d;
   ur.e = wr_ipr*igm1 + ker + pbr; ur.by = wr_iby; ur.bz = wr_ibz;
 
-  double cfl = fast_speed(gamma, wl_idn, wl_ipr, bxi, wl_iby, wl_ibz);
-  double cfr = fast_speed(gamma, wr_idn, wr_ipr, bxi, wr_iby, wr_ibz);
+  double cfl = fast_speed<FM>(gamma, wl_idn, wl_ipr, bxi, wl_iby, wl_ibz);
+  double cfr = fast_speed<FM>(gamma, wr_idn, wr_ipr, bxi, wr_iby, wr_ibz);
   double spd0 = fmin(wl_ivx - cfl, wr_ivx - cfr);
   double spd4 = fmax(wl_ivx + cfl, wr_ivx + cfr);
 
@@ -564,16 +640,16 @@ AKMI_DEV Cons1D hlld(double gamma, double wl_idn, double wl_ivx, double wl_ivy, 
 
   double sdml = spd0 - spd2;
   double sdmr = spd4 - spd2;
-  double sdml_inv = 1.0/sdml;
-  double sdmr_inv = 1.0/sdmr;
+  double sdml_inv = rcp_x<FM && AKMI_HLLD_FAST_RCP>(sdml);
+  double sdmr_inv = rcp_x<FM && AKMI_HLLD_FAST_RCP>(sdmr);
 
   Cons1D ulst, uldst, urdst, urst;
   ulst.d = ul.d*sdl*sdml_inv;
   urst.d = ur.d*sdr*sdmr_inv;
-  double ulst_d_inv = 1.0/ulst.d;
-  double urst_d_inv = 1.0/urst.d;
-  double sqrtdl = sqrt(ulst.d);
-  double sqrtdr = sqrt(urst.d);
+  double ulst_d_inv = rcp_x<FM && AKMI_HLLD_FAST_RCP>(ulst.d);
+  double urst_d_inv = rcp_x<FM && AKMI_HLLD_FAST_RCP>(urst.d);
+  double sqrtdl = sqrt_x<FM>(ulst.d);
+  double sqrtdr = sqrt_x<FM>(urst.d);
 
   double spd1 = spd2 - fabs(bxi)/sqrtdl;
   double spd3 = spd2 + fabs(bxi)/sqrtdr;
@@ -645,7 +721,7 @@ AKMI_DEV Cons1D hlld(double gamma, double wl_idn, double wl_ivx, double wl_ivy, 
       uldst = ulst;
       urdst = urst;
     } else {
-      double invsumd = 1.0/(sqrtdl + sqrtdr);
+      double invsumd = rcp_x<FM && AKMI_HLLD_FAST_RCP>(sqrtdl + sqrtdr);
       double bxsig = (bxi > 0.0 ? 1.0 : -1.0);
       uldst.d = ulst.d;
       urdst.d = urst.d;
@@ -865,14 +941,14 @@ AKMI_DEV Cons1D hlle_mhd(double gamma, double dl, double ul, double vl, double z
 }
 
 // MHD_RSolver selection at compile time: RS = AKMI_RS_LLF 0, HLLE 1, HLLD 3
-template <int RS, bool EO = false>
+template <int RS, bool EO = false, bool FM = false>
 AKMI_DEV Cons1D riemann_mhd(double gamma, double ld, double lx, double ly, double lz, double le,
                             double lby, double lbz, double rd, double rx, double ry, double rz,
                             double re, double rby, double rbz, double bxi) {
   if constexpr (RS == 5) return advect_mhd(ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
   else if constexpr (RS == 0) return llf_mhd(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
   else if constexpr (RS == 1) return hlle_mhd(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
-  else return hlld<EO>(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
+  else return hlld<EO, FM>(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
 }
 
 // ---- isothermal EOS (EOS_Data::is_ideal == false): the same source lines as the ideal-gas
@@ -1214,12 +1290,12 @@ AKMI_DEV Cons1D riemann_mhd_iso(const FaceEos &eos, double ld, double lx, double
 // RS >= 10 is the isothermal solver RS - 10 (llf 10, hlle 11, hlld 13, roe 14).  Isothermal states
 // have no energy variable: slot 4 of the kernels' variable arrays stays unused (rs_iso<RS>()).
 template <int RS> constexpr bool rs_iso() { return RS >= 10; }
-template <int RS, bool EO = false>
+template <int RS, bool EO = false, bool FM = false>
 AKMI_DEV Cons1D riemann_mhd_e(const FaceEos &eos, double ld, double lx, double ly, double lz, double le,
                               double lby, double lbz, double rd, double rx, double ry, double rz,
                               double re, double rby, double rbz, double bxi) {
   if constexpr (RS >= 10) return riemann_mhd_iso<RS - 10>(eos, ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
-  else return riemann_mhd<RS, EO>(eos.gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
+  else return riemann_mhd<RS, EO, FM>(eos.gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
 }
 template <int RS>
 AKMI_DEV void riemann_hyd_e(const FaceEos &eos, double ld, double lx, double ly, double lz, double le,

@@ -263,6 +263,13 @@ __host__ __device__ inline bool is_pow2(double x) {
   return (b & 0xfffffffffffffull) == 0 && e > 1 && e < 2046 && (b >> 63) == 0;
 }
 
+// for a power of two dx: x/dx == ldexp(x, pow2_shift(dx)) bit for bit (scaling by 2^n is exact up to the one
+// correct rounding into the subnormal range that the division performs as well); the shift is formed on the
+// scalar unit from the bits of the (wave-uniform) cell size: no reciprocal to keep in vector registers
+__device__ __forceinline__ int pow2_shift(double dx) {
+  return 1023 - (int)(((unsigned long long)__double_as_longlong(dx) >> 52) & 0x7ff);
+}
+
 struct UpdArgs {
   double gam0, gam1, beta_dt;
   double *u0, *u1;
@@ -350,6 +357,18 @@ __device__ __forceinline__ double beta_dt_of(double beta_dt, const double *dtp) 
 #ifndef AKMI_PREFETCH_X1P
 #define AKMI_PREFETCH_X1P 1     // ... the x1 flux difference fetched before the solve in the x2 march
 #endif
+#ifndef AKMI_X12S_FM
+#define AKMI_X12S_FM 1         // short sqrt / reciprocal forms (akmi_numerics.hpp) in the two solves of k_sweep12s
+#endif
+#ifndef AKMI_MARCH_FM
+#define AKMI_MARCH_FM 0        // ... in the marches: loses (registers, basic blocks), profiles/r03_ab1.txt
+#endif
+#ifndef AKMI_PREFETCH_BX
+#define AKMI_PREFETCH_BX 0      // marches that prefetch their cells: the face field of the next face too.  Measured: the
+#endif                          // x3 march LOSES (865 -> 942 us, profiles/r03_ab2.txt) although nothing drains before the solve
+#ifndef AKMI_PREFETCH_UNCOND
+#define AKMI_PREFETCH_UNCOND 0  // ... by unconditional loads (clamped address) instead of one scalar branch per load: 942 -> 965
+#endif
 #ifndef AKMI_X2_EO
 #define AKMI_X2_EO 0            // wave-uniform early-outs of HLLD in the x2 / x3 march (registers!)
 #endif
@@ -406,7 +425,11 @@ static int march_len(long col_blocks, int ncells, int nmb, int lmax, int wgs_per
   if (ml > lmax) ml = lmax;
   if (ml < 4) ml = 4;
   static const int tail = getenv("AKMI_TAIL") ? atoi(getenv("AKMI_TAIL")) : 1;
-  if (wgs_per_cu > 0 && tail && ml < lmax) {          // packs too small for full-length marches
+  // tail == 1: the rule below for every launch that asks for it (round 3: with the residency the kernel really
+  // has -- two workgroups per CU for the x3 march -- full-length marches gain too: 256^3 x3 march 965 -> 907-914 us
+  // at 14 instead of 32 faces, 8 chunks x 263 workgroups being 4.1 rounds of 512; profiles/r03_ab2.txt);
+  // tail == 2: the round-2 behaviour (short marches only)
+  if (wgs_per_cu > 0 && tail && (ml < lmax || tail == 1)) {
     // equal-length workgroups run in rounds of (256 CUs x resident workgroups): pick the chunk
     // length whose last round is fullest, charging the face each chunk recomputes.  Used by the
     // x2/x3 marches of small packs (128^3: -7 % per march); full-length marches, k_corner_ct and
@@ -414,7 +437,8 @@ static int march_len(long col_blocks, int ncells, int nmb, int lmax, int wgs_per
     const double resident = 256.0*wgs_per_cu;
     double best = -1.0;
     long best_ml = ml;
-    for (long c = lmax; c >= 4; --c) {
+    for (long c = (ml < lmax ? lmax : lmax + lmax/4); c >= 4; --c) {
+      if (ml < lmax && c > lmax) continue;
       const long nch = (ncells + c - 1)/c;
       const double rounds = (double)(col_blocks*nch*nmb)/resident;
       const double full = rounds <= 1.0 ? 1.0 : rounds/(double)(long)(rounds + 0.999999);
@@ -482,12 +506,15 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
 #define PL_(n) my[(WB + (n))*NT]
 #define FP_(n) my[(WB + NV + (n))*NT]
   const int shi = (DIR == 1) ? a.ju : a.ku;           // last face along the sweep
+  // beta*dt once per thread, in scalar registers (inside the update loop a device-resident dt was re-read,
+  // and waited for, once per variable and step)
+  const double bdt = (MODE == 0) ? to_sgpr(beta_dt_of(u.beta_dt, u.dtp)) : 0.0;
   const bool col_active = (i >= g.is) && (i <= g.ie) &&
                           ((DIR == 1) ? (k >= g.ks && k <= g.ke) : (j >= g.js && j <= g.je));
   const int clo = (DIR == 1) ? g.js : g.ks, chi = (DIR == 1) ? g.je : g.ke;
   const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
-  constexpr bool p2 = P2;             // the launcher checked that dx1, dx2, dx3 are powers of two
-  const double rdx1 = 1.0/dx1, rdx2 = 1.0/dx2, rdx3 = 1.0/dx3;
+  const bool p2 = P2 && is_pow2(dx1) && is_pow2(dx2) && is_pow2(dx3);      // wave-uniform: x/dx == ldexp(x, n) bit for bit
+  const int n1 = pow2_shift(dx1), n2 = pow2_shift(dx2), n3 = pow2_shift(dx3);
   const size_t cs = (size_t)g.N3*g.N2*g.N1;
   const long st = (DIR == 1) ? (long)g.N1 : (long)g.N1*g.N2;
   // wave-uniform variable bases in sweep-aligned order d, vx, vy, vz, e, (by, bz) + one
@@ -539,19 +566,39 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
                       (RECON >= 2 && ((AKMI_PREFETCH_WP3 && DIR == 2) || (AKMI_PREFETCH_WP2 && DIR == 1)));
   constexpr int LA = RECON == 1 ? 1 : 2;            // the cell a step loads is LA cells ahead of cell s
   double nx[NV];                         // PW: cells s+1 of the coming step, loaded one step ahead
+  // PW, MHD: the face field of the NEXT face as well.  Loads return in issue order, and the Riemann solve needs
+  // the face field first; fetched inside its own step it was the last load issued, so waiting for it drained
+  // the update operands and the prefetched cells too (s_waitcnt vmcnt(0) in front of the solve,
+  // profiles/r03_isa_audit.txt) -- nothing was in flight across the ~1000 instructions of the solve.
+  constexpr bool PBX = PW && MHD && AKMI_PREFETCH_BX;
+  double bx_n = 0.0;
   if constexpr (PW) {
 #pragma unroll
     for (int n = 0; n < NV; ++n) nx[n] = (ISO && n == 4) ? 0.0 : ldu(base(n) + LA*st, off);
+    if constexpr (PBX) bx_n = ldu(bxm, foff);
   }
   for (int t = 0; t <= ml; ++t) {
     const int s = s0 + t;
     if (s > shi) break;
     if constexpr (DIR == 1) j = s; else k = s;
     double nx2[NV];
+    double bx_c = 0.0;
     if constexpr (PW) {
       const bool more = (t < ml) && (s < shi);           // a next step exists: its cell s+2 is inside the array
+#if AKMI_PREFETCH_UNCOND
+      // unconditional (no scalar branch per load): without a next step the address is the cell the step itself
+      // uses, the value is never read
+      const long la2 = more ? (LA + 1)*st : LA*st;
+#pragma unroll
+      for (int n = 0; n < NV; ++n) nx2[n] = (ISO && n == 4) ? 0.0 : ldu(base(n) + la2, off);
+#else
 #pragma unroll
       for (int n = 0; n < NV; ++n) nx2[n] = (more && !(ISO && n == 4)) ? ldu(base(n) + (LA + 1)*st, off) : 0.0;
+#endif
+      if constexpr (PBX) {
+        bx_c = bx_n;
+        bx_n = ldu(bxm + (more ? (long)(fst8/8u) : 0l), foff);
+      }
     }
     double L[NV], R[NV];
 #pragma unroll
@@ -615,7 +662,7 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
         for (int n = 0; n < 5; ++n) {
           if (ISO && n == 4) continue;
           const double d1 = ldu(f1 + n*fs1 + 1, o1) - ldu(f1 + n*fs1, o1);
-          pa[n] = p2 ? d1*rdx1 : d1/dx1;
+          pa[n] = p2 ? ldexp(d1, n1) : d1/dx1;
         }
       }
     }
@@ -626,8 +673,10 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
       fl.d = L[0] + R[0]; fl.mx = L[1] + R[1]; fl.my = L[2] + R[2]; fl.mz = L[3] + R[3]; fl.e = L[4] + R[4];
       fl.by = L[5] + R[5] + ldu(bxm, foff); fl.bz = L[6] + R[6];
 #else
-      Cons1D fl = riemann_mhd_e<RS, (DIR == 1 ? AKMI_X2_EO : AKMI_X3_EO) != 0>(
-          eos, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1], R[2], R[3], R[4], R[5], R[6], ldu(bxm, foff));
+      double bxi;
+      if constexpr (PBX) bxi = bx_c; else bxi = ldu(bxm, foff);
+      Cons1D fl = riemann_mhd_e<RS, (DIR == 1 ? AKMI_X2_EO : AKMI_X3_EO) != 0, AKMI_MARCH_FM != 0>(
+          eos, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1], R[2], R[3], R[4], R[5], R[6], bxi);
 #endif
       fd = fl.d; fx = fl.mx; fy = fl.my; fz = fl.mz; fe = fl.e;
       if (t < ml || s == shi) {
@@ -666,21 +715,21 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
         } else if constexpr (DIR == 1) {
           const double *f1 = u.flx1 + (size_t)m*g.nvar*fs1 + n*fs1 - (g.N1 + 1);     // row sc = s-1
           const double d1 = ldu(f1 + 1, o1) - ldu(f1, o1);
-          divf = p2 ? d1*rdx1 : d1/dx1;
+          divf = p2 ? ldexp(d1, n1) : d1/dx1;
         } else {
           const double d1 = u.flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, n, kc, jc, i + 1)] -
                             u.flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, n, kc, jc, i)];
-          divf = p2 ? d1*rdx1 : d1/dx1;
+          divf = p2 ? ldexp(d1, n1) : d1/dx1;
         }
         if constexpr (DIR == 1) {
-          divf += p2 ? (fv[n] - fprev)*rdx2 : (fv[n] - fprev)/dx2;
+          divf += p2 ? ldexp(fv[n] - fprev, n2) : (fv[n] - fprev)/dx2;
         } else {
           if constexpr (!USEACC) {
             const double d2 = u.flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, n, kc, jc + 1, i)] -
                               u.flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, n, kc, jc, i)];
-            divf += p2 ? d2*rdx2 : d2/dx2;
+            divf += p2 ? ldexp(d2, n2) : d2/dx2;
           }
-          divf += p2 ? (fv[n] - fprev)*rdx3 : (fv[n] - fprev)/dx3;
+          divf += p2 ? ldexp(fv[n] - fprev, n3) : (fv[n] - fprev)/dx3;
         }
         if constexpr (MODE == 1) {
           stu(u.acc + mb + n*cs, ocm, divf);
@@ -691,7 +740,7 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
           if constexpr (PRE && AKMI_PREFETCH_U1) u1v = u.copy_u1 ? u0v : pu1[n];
           else u1v = u.copy_u1 ? u0v : ldu(u.u1 + mb + n*cs, ocm);
           rk_store_u(u.u0 + mb + n*cs, u.u1 + mb + n*cs, u.copy_u1, ocm, u0v,
-                     u.gam0*u0v + u.gam1*u1v - beta_dt_of(u.beta_dt, u.dtp)*divf);
+                     u.gam0*u0v + u.gam1*u1v - bdt*divf);
         }
       }
     }
@@ -718,10 +767,7 @@ k_sweep_update(Geo g, FaceEos eos, SweepArgs a, UpdArgs u, int ml) {
   __shared__ double sm[(((RECON >= 2) && AKMI_PPM_WREG ? 0 : NV*RollCfg<RECON>::NW) + NV + 5)*SX*SY];
   const int m = blockIdx.z;
   constexpr bool TRY = AKMI_POW2DX && MHD && MODE == 0 && USEACC;     // the x3 march of the MHD stage
-  if (TRY && is_pow2(g.dx[3*m]) && is_pow2(g.dx[3*m + 1]) && is_pow2(g.dx[3*m + 2]))
-    sweep_update_body<DIR, RECON, MHD, MODE, USEACC, RS, TRY>(g, eos, a, u, ml, sm);
-  else
-    sweep_update_body<DIR, RECON, MHD, MODE, USEACC, RS, false>(g, eos, a, u, ml, sm);
+  sweep_update_body<DIR, RECON, MHD, MODE, USEACC, RS, TRY>(g, eos, a, u, ml, sm);
 }
 
 
@@ -850,6 +896,9 @@ __device__ __forceinline__ double upw(bool pos, double fa, double ca, double fb,
 #ifndef AKMI_CKL
 #define AKMI_CKL 32
 #endif
+#ifndef AKMI_CT_HOIST
+#define AKMI_CT_HOIST 0        // measured neutral (k_corner_ct streams at 6.4 TB/s either way; 79 instead of 66 VGPRs)
+#endif
 constexpr int CKL = AKMI_CKL;          // cell planes per k-chunk (one plane of edges recomputed)
 
 // The tile of edge positions is tw x th threads (owners: (tw-1) x (th-1)), lanes flattened over
@@ -885,9 +934,10 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const double *__res
   const bool edge_ok = in_tile && (i <= g.ie + 1) && (j <= g.je + 1);
   const bool own = edge_ok && (tx < tw - 1) && (ty < th - 1);
   const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
-  constexpr bool p2 = P2;             // the launcher checked that dx1, dx2, dx3 are powers of two
-  const double rdx1 = 1.0/dx1, rdx2 = 1.0/dx2, rdx3 = 1.0/dx3;
-#define DIVX(x, q) (p2 ? (x)*r##q : (x)/q)
+  // cell sizes that are powers of two: x/dx == x*(1/dx) bit for bit (wave-uniform choice)
+  const bool p2 = P2 && is_pow2(dx1) && is_pow2(dx2) && is_pow2(dx3);
+  const int ndx1 = pow2_shift(dx1), ndx2 = pow2_shift(dx2), ndx3 = pow2_shift(dx3);
+#define DIVX(x, q) (p2 ? ldexp((x), n##q) : (x)/q)
   // addresses: scalar base of (block, array) + a 32-bit byte offset per lane and array shape, advanced by one
   // plane per step (no 64-bit index arithmetic on the vector unit, fewer address registers)
   const size_t cs = (size_t)g.N3*g.N2*g.N1;
@@ -918,6 +968,18 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const double *__res
     const int t = k - k0;
     const int pp2 = t & 1, p3 = t % 3;
     double e1 = 0.0, e2 = 0.0, e3 = 0.0;
+#if AKMI_CT_HOIST
+    // the face fields the CT part of this step updates, fetched together with the operands of the corner
+    // formulas (they used to follow the barrier one by one, each load waited for with vmcnt(0): six more
+    // serialised memory round trips per plane, profiles/r03_isa_audit.txt).  copy_b1: the second register
+    // is not read, the address falls back to b0 (a cache hit).
+    const bool ct3 = own && i <= g.ie && j <= g.je && (k <= k1 || wtop);
+    const bool ct1 = own && k > k0 && j <= g.je, ct2 = own && k > k0 && i <= g.ie;
+    double pb03 = 0.0, pb13 = 0.0, pb01 = 0.0, pb11 = 0.0, pb02 = 0.0, pb12 = 0.0;
+    if (ct3) { pb03 = ldu(b03, oc); pb13 = ldu(copy_b1 ? b03 : b13, oc); }
+    if (ct1) { pb01 = ldu(b01 - PS1, o1); pb11 = ldu((copy_b1 ? b01 : b11) - PS1, o1); }
+    if (ct2) { pb02 = ldu(b02 - PS2, o2); pb12 = ldu((copy_b1 ? b02 : b12) - PS2, o2); }
+#endif
     if (edge_ok) {
       const double f1_k = ldu(f1m, o1);
       const double f1_jm = ldu(f1m - (g.N1 + 1), o1);
@@ -963,8 +1025,12 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const double *__res
     __syncthreads();
     if (own) {
       if (i <= g.ie && j <= g.je && (k <= k1 || wtop)) {          // x3-face of plane k (mhd_ct.cpp:67-77)
+#if AKMI_CT_HOIST
+        const double b0v = pb03, b1v = pb13;
+#else
         const double b0v = ldu(b03, oc);
         const double b1v = copy_b1 ? b0v : ldu(b13, oc);
+#endif
         double b = gam0*b0v + gam1*b1v;
         b -= DIVX(beta_dt*(S2(pp2, ty, tx + 1) - e2), dx1);
         b += DIVX(beta_dt*(S1(pp2, ty + 1, tx) - e1), dx2);
@@ -973,16 +1039,24 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const double *__res
       if (k > k0) {
         const int q3 = (t + 2) % 3;                                // the e3 buffer of plane k-1
         if (j <= g.je) {                                           // x1-face (:45-54)
+#if AKMI_CT_HOIST
+          const double b0v = pb01, b1v = pb11;
+#else
           const double b0v = ldu(b01 - PS1, o1);
           const double b1v = copy_b1 ? b0v : ldu(b11 - PS1, o1);
+#endif
           double b = gam0*b0v + gam1*b1v;
           b -= DIVX(beta_dt*(S3(q3, ty + 1, tx) - e3p), dx2);
           b += DIVX(beta_dt*(e2 - e2p), dx3);
           rk_store_u(b01 - PS1, b11 - PS1, copy_b1, o1, b0v, b);
         }
         if (i <= g.ie) {                                           // x2-face (:56-65)
+#if AKMI_CT_HOIST
+          const double b0v = pb02, b1v = pb12;
+#else
           const double b0v = ldu(b02 - PS2, o2);
           const double b1v = copy_b1 ? b0v : ldu(b12 - PS2, o2);
+#endif
           double b = gam0*b0v + gam1*b1v;
           b += DIVX(beta_dt*(S3(q3, ty, tx + 1) - e3p), dx1);
           b -= DIVX(beta_dt*(e1 - e1p), dx3);
@@ -1010,15 +1084,9 @@ k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e
             double *__restrict__ b0x3f, double *__restrict__ b1x1f, double *__restrict__ b1x2f,
             double *__restrict__ b1x3f, int copy_b1, int kA, int kB, int top, int nchunk,
             int ckl, int tw, int th, const double *dtp) {
-  const int m = blockIdx.z/nchunk;
-  if (AKMI_POW2DX && is_pow2(g.dx[3*m]) && is_pow2(g.dx[3*m + 1]) && is_pow2(g.dx[3*m + 2]))
-    corner_ct_body<AKMI_POW2DX != 0>(g, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, c1, c2, c3, flx1, flx2, flx3, gam0,
-                         gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f, copy_b1, kA, kB, top,
-                         nchunk, ckl, tw, th, dtp);
-  else
-    corner_ct_body<false>(g, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, c1, c2, c3, flx1, flx2, flx3, gam0,
-                          gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f, copy_b1, kA, kB, top,
-                          nchunk, ckl, tw, th, dtp);
+  corner_ct_body<AKMI_POW2DX != 0>(g, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, c1, c2, c3, flx1, flx2, flx3, gam0,
+                                   gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f, copy_b1, kA, kB, top,
+                                   nchunk, ckl, tw, th, dtp);
 }
 
 // CT (mhd_ct.cpp:23-80) with CopyCons for B folded in at stage 1 (b1 <- b0 old)
@@ -1481,13 +1549,17 @@ static int launch_sweep_update(const Geo &g, const Scheme &sc, const SweepArgs &
       long np = (long)(a.ju - a.jl + 1)*g.N1;          // flattened rows
       const unsigned nb = (unsigned)((np + SX*SY - 1)/(SX*SY));
       const int nc = a.ku - a.kl > 0 ? a.ku - a.kl : 1;
-      ml = march_len(nb, nc, g.nmb, ML, 3);
+      static const int ml_env = getenv("AKMI_ML3") ? atoi(getenv("AKMI_ML3")) : 0;        // experiments
+      // resident workgroups per CU: the PLM march is compiled for AKMI_X3_WAVES waves per SIMD, the
+      // five-point schemes for two
+      const int res3 = (sc.recon >= AKMI_RECON_PPM4) ? 2 : AKMI_X3_WAVES;
+      ml = ml_env > 0 ? ml_env : march_len(nb, nc, g.nmb, ML, res3);
       grid = dim3(nb, cdiv(nc, ml), g.nmb);
     } else {
       long np = (long)(a.ku - a.kl + 1)*g.N1;          // flattened (k,i)
       const unsigned nb = (unsigned)((np + SX*SY - 1)/(SX*SY));
       const int nc = a.ju - a.jl > 0 ? a.ju - a.jl : 1;
-      ml = march_len(nb, nc, g.nmb, ML, 3);
+      ml = march_len(nb, nc, g.nmb, ML, (sc.recon >= AKMI_RECON_PPM4) ? 2 : AKMI_X2_WAVES);
       grid = dim3(nb, cdiv(nc, ml), g.nmb);
     }
     constexpr int D = (DIR == 0) ? 1 : DIR;
@@ -1523,6 +1595,9 @@ static int launch_sweep_update(const Geo &g, const Scheme &sc, const SweepArgs &
 #ifndef AKMI_X12S_EO2
 #define AKMI_X12S_EO2 1
 #endif
+#ifndef AKMI_X12S_ULOAD
+#define AKMI_X12S_ULOAD 1      // 1: the x2 loads of a step in one group after the x1 solve, 2: at the top of the step
+#endif
 template <int RS>
 __global__ void __launch_bounds__(SX*SY, AKMI_X12S_WAVES)
 k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
@@ -1551,6 +1626,11 @@ k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
 #define PL_(n) my[(NV*NW + (n))*NT]
 #define FP_(n) my[(NV*NW + NV + (n))*NT]
   const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1];
+  // blocks whose cell sizes are powers of two (the usual case: unit-length domains with 2^n cells, every level
+  // of a refined mesh): 1/dx is exact and x/dx == x*(1/dx) bit for bit (both are the correctly rounded value of
+  // the same real number), so the ten divisions of a step become products; wave-uniform branch per step
+  const bool p2 = AKMI_POW2DX && is_pow2(dx1) && is_pow2(dx2);
+  const int n1 = pow2_shift(dx1), n2 = pow2_shift(dx2);
   const size_t cs = (size_t)g.N3*g.N2*g.N1;
   const long st = (long)g.N1;
   const double *wb = a2.w0 + (size_t)m*g.nvar*cs;
@@ -1581,6 +1661,9 @@ k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
   double *mf2 = a2.flx + (size_t)m*g.nvar*fs2, *mf1 = a1.flx + (size_t)m*g.nvar*fs1;
   const double *bym = bb + cs;                                                                   // cell-centred By
   const size_t mb = (size_t)m*g.nvar*cs;
+#if AKMI_X12S_ULOAD == 3
+  double by_n = ldu(bym, off - st8), bx1_n = ldu(bx1m, foff1);
+#endif
   for (int t = 0;; ++t) {
     const int s = s0 + t;
     if (s > shi + 1) break;                   // the last chunk ends with the x1 faces of row ju(x1)
@@ -1589,6 +1672,27 @@ k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
     const int jr = s - 1;                     // row of the x1 faces of this step
     const bool do_x1 = (t >= 1 || s0 == a2.jl) && jr >= a1.jl && jr <= a1.ju;
     const unsigned orow = off - st8;          // cell (k, jr, i)
+    // Every load of the step is unconditional and issued in one group.  (With `do_x2 ? ldu(..) : w1` each of
+    // the seven cell loads sat in its own scalar branch followed by s_waitcnt vmcnt(0): eight serialised
+    // memory round trips per step, profiles/r03_isa_audit.txt.)  Beyond the last face the address is the
+    // row the window already holds, i.e. the value `w1` the old form substituted.
+#if AKMI_X12S_ULOAD == 3          // the two operands the x1 part needs first were fetched during the previous step
+    const double by_c = by_n, bx1 = bx1_n;
+    by_n = ldu(bym, off);
+    bx1_n = ldu(bx1m + a1.f1, foff1);
+#else
+    const double by_c = ldu(bym, orow);
+    const double bx1 = ldu(bx1m, foff1);
+#endif
+#if AKMI_X12S_ULOAD >= 2
+    double qn[NV];
+    {
+      const long stq = do_x2 ? st : 0;
+#pragma unroll
+      for (int n = 0; n < NV; ++n) qn[n] = ldu(base2(n) + stq, off);
+    }
+    const double bx2 = ldu(bx2m, do_x2 ? foff2 : foff2 - fst28);
+#endif
     // ---- x1 face on the low side of cell (k, jr, i): the cell is W_(.,0) of the march
     double f1d, f1x, f1y, f1z, f1e, f1by, f1bz;
     double dF1[5];
@@ -1596,9 +1700,8 @@ k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
       // x1-aligned order d, vx, vy, vz, e, by, bz from the x2-aligned window d, vy, vz, vx, e, bz, bx
       double q0[NV];
       q0[0] = W_(0, 0); q0[1] = W_(3, 0); q0[2] = W_(1, 0); q0[3] = W_(2, 0); q0[4] = W_(4, 0);
-      q0[5] = ldu(bym, orow); q0[6] = W_(5, 0);
+      q0[5] = by_c; q0[6] = W_(5, 0);
       const double bxc = W_(6, 0);
-      const double bx1 = ldu(bx1m, foff1);
       double qln[NV], qr[NV];
 #pragma unroll
       for (int n = 0; n < NV; ++n) {
@@ -1613,7 +1716,7 @@ k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
       double L1[NV];
 #pragma unroll
       for (int n = 0; n < NV; ++n) L1[n] = __shfl_up(qln[n], 1, 64);
-      Cons1D f1 = riemann_mhd_e<RS, AKMI_X12S_EO1 != 0>(eos, L1[0], L1[1], L1[2], L1[3], L1[4], L1[5], L1[6], qr[0],
+      Cons1D f1 = riemann_mhd_e<RS, AKMI_X12S_EO1 != 0, AKMI_X12S_FM != 0>(eos, L1[0], L1[1], L1[2], L1[3], L1[4], L1[5], L1[6], qr[0],
                                     qr[1], qr[2], qr[3], qr[4], qr[5], qr[6], bx1);
       f1d = f1.d; f1x = f1.mx; f1y = f1.my; f1z = f1.mz; f1e = f1.e; f1by = f1.by; f1bz = f1.bz;
       dF1[0] = __shfl_down(f1d, 1, 64) - f1d;
@@ -1628,19 +1731,34 @@ k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
       }
     }
     // ---- x2 face s
+#if AKMI_X12S_ULOAD == 1
+    double qn[NV];
+    {
+      const long stq = do_x2 ? st : 0;
+#pragma unroll
+      for (int n = 0; n < NV; ++n) qn[n] = ldu(base2(n) + stq, off);
+    }
+    const double bx2 = ldu(bx2m, do_x2 ? foff2 : foff2 - fst28);
+#endif
     double L[NV], R[NV];
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
       double qln2;
       L[n] = PL_(n);
       const double w0 = W_(n, 0), w1 = W_(n, 1);
+#if AKMI_X12S_ULOAD
+      const double qp = qn[n];
+#else
       const double qp = do_x2 ? ldu(base2(n) + st, off) : w1;      // beyond the last face: nothing is kept
+#endif
       plm(w0, w1, qp, qln2, R[n]);
       W_(n, 0) = w1; W_(n, 1) = qp;
       PL_(n) = qln2;
     }
+#if !AKMI_X12S_ULOAD
     const double bx2 = do_x2 ? ldu(bx2m, foff2) : 0.0;
-    Cons1D f2 = riemann_mhd_e<RS, AKMI_X12S_EO2 != 0>(eos, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1],
+#endif
+    Cons1D f2 = riemann_mhd_e<RS, AKMI_X12S_EO2 != 0, AKMI_X12S_FM != 0>(eos, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1],
                                   R[2], R[3], R[4], R[5], R[6], bx2);
     if (do_x2 && x2_ok && (t < ml || s == shi)) {
       stu(mf2, foff2, f2.d);
@@ -1651,11 +1769,20 @@ k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
     const double fv[5] = {f2.d, f2.mz, f2.mx, f2.my, f2.e};
     const int sc = s - 1;
     if (do_x2 && t > 0 && col_active && sc >= g.js && sc <= g.je) {
+      if (p2) {
 #pragma unroll
-      for (int n = 0; n < 5; ++n) {
-        double divf = dF1[n]/dx1;
-        divf += (fv[n] - FP_(n))/dx2;
-        stu(u.acc + mb + n*cs, orow, divf);
+        for (int n = 0; n < 5; ++n) {
+          double divf = ldexp(dF1[n], n1);
+          divf += ldexp(fv[n] - FP_(n), n2);
+          stu(u.acc + mb + n*cs, orow, divf);
+        }
+      } else {
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+          double divf = dF1[n]/dx1;
+          divf += (fv[n] - FP_(n))/dx2;
+          stu(u.acc + mb + n*cs, orow, divf);
+        }
       }
     }
 #pragma unroll
@@ -1673,7 +1800,8 @@ static int launch_sweep12s(const Geo &g, const Scheme &sc, const SweepArgs &a1, 
   const long nwaves = (np + (SX - 4) - 1)/(SX - 4);
   const unsigned nb = (unsigned)((nwaves + SY - 1)/SY);
   const int nc = a2.ju - a2.jl > 0 ? a2.ju - a2.jl : 1;
-  const int ml = march_len(nb, nc, g.nmb, ML, 3);
+  static const int ml_env = getenv("AKMI_ML12") ? atoi(getenv("AKMI_ML12")) : 0;      // experiments
+  const int ml = ml_env > 0 ? ml_env : march_len(nb, nc, g.nmb, ML, 3);
   dim3 grid(nb, cdiv(nc, ml), g.nmb), block(SX, SY);
   const int rs = sc.rsolver;
   if (sc.iso || sc.recon != 1 || rs != AKMI_RS_HLLD) { set_error("sweep12s: PLM + HLLD, ideal gas"); return AKMI_FAIL; }

@@ -540,6 +540,18 @@ long long akmi_host_exchange_plan(const char *deck_text, int rank, int nranks, i
  * calibrate the rocprofv3 FETCH_SIZE/WRITE_SIZE counters on gfx950 (tools/pmc.sh). */
 int akmi_calib_copy(double *dst, const double *src, long long n, void *stream);
 
+/* ---- arithmetic self-test ------------------------------------------------------------- *
+ * The stage kernels evaluate sqrt(x), 1/x and x/dx (dx a power of two) with shorter instruction
+ * sequences than the compiler's expansions (csrc/akmi_numerics.hpp: sqrt_x, rcp_x; pow2_shift);
+ * these must return the same bits, because the path is bit-comparable with the reference's CPU
+ * build (src/eos/eos.hpp:49-57, src/mhd/rsolvers/hlld_mhd.hpp:120-160, src/mhd/mhd_update.cpp:57-80
+ * are the expressions concerned).  mode 0: sqrt, 1: reciprocal, 2: division by a power of two.
+ * n operands (random in- and out-of-window patterns + a fixed edge table) are evaluated both ways on
+ * the device; *mismatch receives the number of operands whose results differ in any bit,
+ * *shortform_waves (may be NULL) the number of wave-iterations that really ran the short form. */
+int akmi_selftest_fp64(int mode, long long n, unsigned long long seed, long long *mismatch,
+                       long long *shortform_waves, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
