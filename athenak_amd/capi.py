@@ -41,7 +41,7 @@ SYMBOLS = [
     "akmi_hydro_c2p_newdt", "akmi_mhd_c2p_newdt", "akmi_calib_copy", "akmi_hydro_stage_fused", "akmi_mhd_stage_fused",
     "akmi_hydro_stage_phase", "akmi_mhd_stage_phase", "akmi_history_sums",
     "akmi_hydro_c2p_shell", "akmi_mhd_c2p_shell", "akmi_sim_create", "akmi_sim_initialize",
-    "akmi_sim_execute", "akmi_sim_destroy", "akmi_sim_time", "akmi_sim_dt", "akmi_sim_tlim",
+    "akmi_sim_execute", "akmi_sim_profile", "akmi_sim_profile_read", "akmi_sim_destroy", "akmi_sim_time", "akmi_sim_dt", "akmi_sim_tlim",
     "akmi_sim_ncycle", "akmi_sim_nmb", "akmi_sim_array", "akmi_sim_lloc", "akmi_sim_gids", "akmi_sim_nmb_thisrank",
     "akmi_comm_unique_id", "akmi_comm_init_rccl", "akmi_comm_init_env", "akmi_comm_init_callbacks", "akmi_hydro_stage_fused_dt", "akmi_mhd_stage_fused_dt", "akmi_comm_finalize", "akmi_comm_allreduce_min",
     "akmi_comm_rank", "akmi_comm_nranks", "akmi_host_exchange_plan",

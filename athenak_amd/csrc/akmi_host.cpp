@@ -339,7 +339,7 @@ void Mesh::NewTimeStep(const Real tlim) {               // mesh.cpp:573-643
   }
   // minimum over all ranks (mesh.cpp:634-637): ncclAllReduce(ncclMin) on the compute stream
   for (FluidBase *f : phys)
-    if (f && nranks > 1) { Comm::World().AllReduceMin(&dt, 1, f->stream); break; }
+    if (f && (nranks > 1 || SelfExchange())) { Comm::World().AllReduceMin(&dt, 1, f->stream); break; }
   if ((time < tlim) && ((time + dt) > tlim)) dt = tlim - time;
 }
 
@@ -419,7 +419,8 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
     coarse_u0.Realloc(static_cast<size_t>(pp->nmb_thispack)*nvars*c3*c2*c1);
     psmr = new MeshBoundaryValuesSMR(pp, nvars);
   }
-  if (!multilevel && pp->pmesh->nranks > 1) pbval = new MeshBoundaryValues(pp, &pack_c, nvars, blk == "mhd");
+  if (!multilevel && (pp->pmesh->nranks > 1 || SelfExchange()))
+    pbval = new MeshBoundaryValues(pp, &pack_c, nvars, blk == "mhd");
   use_fofc = pin->GetOrAddBoolean(blk, "fofc", false);     // hydro.cpp:153-190, mhd.cpp:199-235
   if (use_fofc) {
     const int need = recon_method == AKMI_RECON_PLM ? 3 : (recon_method >= AKMI_RECON_PPM4 ? 4 : 2);
@@ -658,7 +659,7 @@ Driver::Driver(ParameterInput *pin, Mesh *pmesh) {       // driver.cpp:85-162
     ++nphys;
     if (!f->fused || f->multilevel || f->kinematic || f->stream == nullptr) use_graph = false;
   }
-  if (pmesh->nranks > 1 || nphys != 1) use_graph = false;
+  if (pmesh->nranks > 1 || nphys != 1 || SelfExchange()) use_graph = false;
   if (use_graph) {
     d_dt.Realloc(1);
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h_dt), sizeof(Real)));
@@ -666,9 +667,35 @@ Driver::Driver(ParameterInput *pin, Mesh *pmesh) {       // driver.cpp:85-162
   }
 }
 Driver::~Driver() {
+  for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e);
   if (cycle_exec) (void)hipGraphExecDestroy(cycle_exec);
   if (h_dt) (void)hipHostFree(h_dt);
   d_dt.Free();
+}
+
+// event pair k = (prof_ev[2k], prof_ev[2k+1]); nothing is recorded while a cycle graph is captured or replayed
+void Driver::ProfMark(hipStream_t st) {
+  if (!prof_on || capturing || use_graph) return;
+  if (prof_used == prof_ev.size()) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    prof_ev.push_back(e);
+  }
+  HIPCHK(hipEventRecord(prof_ev[prof_used++], st));
+}
+int Driver::ProfRead(double *ms_total, long long *calls) {
+  double tot = 0.0;
+  const size_t np = prof_used/2;
+  for (size_t k = 0; k < np; ++k) {
+    HIPCHK(hipEventSynchronize(prof_ev[2*k + 1]));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, prof_ev[2*k], prof_ev[2*k + 1]));
+    tot += ms;
+  }
+  if (ms_total) *ms_total = tot;
+  if (calls) *calls = static_cast<long long>(np);
+  prof_used = 0;
+  return AKMI_COMPLETE;
 }
 
 void Driver::ExecuteTaskList(Mesh *pm, const std::string &tl, int stage) {   // driver.cpp:290-307
@@ -742,6 +769,10 @@ int Driver::Execute(Mesh *pm, int max_cycles) {            // driver.cpp:380-459
     pm->NewTimeStep(tlim);
     ++n;
   }
+  // an odd number of out-of-place first stages leaves u0 / b0 in the buffers that used to be u1 / b1: copy
+  // back once per call, so that device pointers handed out by akmi_sim_array stay valid across akmi_sim_execute
+  if (pm->pmb_pack->phydro) pm->pmb_pack->phydro->RestoreRegisters();
+  if (pm->pmb_pack->pmhd) pm->pmb_pack->pmhd->RestoreRegisters();
   return n;
 }
 
@@ -756,6 +787,28 @@ static int CopyFlag(const Driver *d, int stage, int phases) {
   return (phases & (AKMI_PHASE_SWEEPS | AKMI_PHASE_EMF_CT)) ? 2 : 0;
 }
 template <typename T> static void SwapArr(DvceArray<T> &a, DvceArray<T> &b) { std::swap(a.p, b.p); std::swap(a.n, b.n); }
+
+void FluidBase::RestoreRegisters() {
+  if (!u_swapped) return;
+  // u1 (the creation-time u0 buffer) holds a state nothing reads any more: the first stage of the next cycle
+  // overwrites it.  Current state -> that buffer, then the names trade places again.
+  HIPCHK(hipMemcpyAsync(u1.p, u0.p, u0.n*sizeof(Real), hipMemcpyDeviceToDevice, stream));
+  SwapArr(u0, u1);
+  u_swapped = false;
+}
+
+namespace mhd {
+void MHD::RestoreRegisters() {
+  FluidBase::RestoreRegisters();
+  if (!b_swapped) return;
+  DvceArray<Real> *cur[3] = {&b0.x1f, &b0.x2f, &b0.x3f}, *old[3] = {&b1.x1f, &b1.x2f, &b1.x3f};
+  for (int q = 0; q < 3; ++q) {
+    HIPCHK(hipMemcpyAsync(old[q]->p, cur[q]->p, cur[q]->n*sizeof(Real), hipMemcpyDeviceToDevice, stream));
+    SwapArr(*cur[q], *old[q]);
+  }
+  b_swapped = false;
+}
+}  // namespace mhd
 
 // ---- task bodies: one C-ABI call each ------------------------------------------------------------
 namespace hydro {
@@ -790,6 +843,7 @@ TaskStatus Hydro::RKUpdate(Driver *d, int stage) {         // hydro_update.cpp:2
   } else if (fused) {
     int do_dt = (stage == d->nexp_stages);
     const int copy = CopyFlag(d, stage, AKMI_PHASE_ALL);
+    d->ProfMark(stream);
     if (dt_dev)
       AKCHK(akmi_hydro_stage_fused_dt(&pack_c, recon_method, rsolver_method, d->gam0[stage - 1],
                                       d->gam1[stage - 1], d->beta[stage - 1], dt_dev, copy, w0.p, u0.p,
@@ -798,7 +852,8 @@ TaskStatus Hydro::RKUpdate(Driver *d, int stage) {         // hydro_update.cpp:2
     AKCHK(akmi_hydro_stage_fused(&pack_c, recon_method, rsolver_method, d->gam0[stage - 1],
                                  d->gam1[stage - 1], beta_dt, copy, w0.p, u0.p, u1.p, do_dt,
                                  counters.p, dt3.p, ws.p, stream));
-    if (copy == 2) SwapArr(u0, u1);
+    d->ProfMark(stream);
+    if (copy == 2) { SwapArr(u0, u1); u_swapped = !u_swapped; }
     interior_done_ = true; dt_ready_ = do_dt;
   } else {
     AKCHK(akmi_rk_update(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1], beta_dt, u0.p, u1.p,
@@ -813,9 +868,11 @@ void Hydro::StagePhase(Driver *d, int stage, int phases) {
   const Real beta_dt = stage >= 1 ? d->beta[stage - 1]*pmy_pack->pmesh->dt : 0.0;
   const int do_dt = (stage == d->nexp_stages);
   const int copy = CopyFlag(d, stage, phases);
+  d->ProfMark(stream);
   AKCHK(akmi_hydro_stage_phase(&pack_c, recon_method, rsolver_method, g0, g1, beta_dt, copy, w0.p,
                                u0.p, u1.p, do_dt, counters.p, dt3.p, phases, ws.p, stream));
-  if (copy == 2) SwapArr(u0, u1);
+  d->ProfMark(stream);
+  if (copy == 2) { SwapArr(u0, u1); u_swapped = !u_swapped; }
   if (phases & AKMI_PHASE_C2P) { interior_done_ = true; dt_ready_ = do_dt; }
 }
 TaskStatus Hydro::SendU(Driver *d, int stage) {            // hydro_tasks.cpp:308-320
@@ -945,6 +1002,7 @@ TaskStatus MHD::RKUpdate(Driver *d, int stage) {           // mhd_update.cpp:24-
   } else if (fused) {
     int do_dt = (stage == d->nexp_stages);
     const int copy = CopyFlag(d, stage, AKMI_PHASE_ALL);
+    d->ProfMark(stream);
     if (dt_dev)
       AKCHK(akmi_mhd_stage_fused_dt(&pack_c, recon_method, rsolver_method, d->gam0[stage - 1],
                                     d->gam1[stage - 1], d->beta[stage - 1], dt_dev, copy, w0.p, bcc0.p,
@@ -955,9 +1013,10 @@ TaskStatus MHD::RKUpdate(Driver *d, int stage) {           // mhd_update.cpp:24-
                                d->gam1[stage - 1], beta_dt, copy, w0.p, bcc0.p, u0.p, u1.p,
                                b0.x1f.p, b0.x2f.p, b0.x3f.p, b1.x1f.p, b1.x2f.p, b1.x3f.p, do_dt,
                                counters.p, dt3.p, ws.p, stream));
+    d->ProfMark(stream);
     if (copy == 2) {
-      SwapArr(u0, u1);
-      SwapArr(b0.x1f, b1.x1f); SwapArr(b0.x2f, b1.x2f); SwapArr(b0.x3f, b1.x3f);
+      SwapArr(u0, u1); u_swapped = !u_swapped;
+      SwapArr(b0.x1f, b1.x1f); SwapArr(b0.x2f, b1.x2f); SwapArr(b0.x3f, b1.x3f); b_swapped = !b_swapped;
     }
     interior_done_ = true; dt_ready_ = do_dt;
   } else {
@@ -972,12 +1031,16 @@ void MHD::StagePhase(Driver *d, int stage, int phases) {
   const Real beta_dt = stage >= 1 ? d->beta[stage - 1]*pmy_pack->pmesh->dt : 0.0;
   const int do_dt = (stage == d->nexp_stages);
   const int copy = CopyFlag(d, stage, phases);
+  d->ProfMark(stream);
   AKCHK(akmi_mhd_stage_phase(&pack_c, recon_method, rsolver_method, g0, g1, beta_dt, copy, w0.p,
                              bcc0.p, u0.p, u1.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, b1.x1f.p, b1.x2f.p,
                              b1.x3f.p, do_dt, counters.p, dt3.p, phases, ws.p, stream));
+  d->ProfMark(stream);
   if (copy == 2) {
-    if (phases & AKMI_PHASE_SWEEPS) SwapArr(u0, u1);
-    if (phases & AKMI_PHASE_EMF_CT) { SwapArr(b0.x1f, b1.x1f); SwapArr(b0.x2f, b1.x2f); SwapArr(b0.x3f, b1.x3f); }
+    if (phases & AKMI_PHASE_SWEEPS) { SwapArr(u0, u1); u_swapped = !u_swapped; }
+    if (phases & AKMI_PHASE_EMF_CT) {
+      SwapArr(b0.x1f, b1.x1f); SwapArr(b0.x2f, b1.x2f); SwapArr(b0.x3f, b1.x3f); b_swapped = !b_swapped;
+    }
   }
   if (phases & AKMI_PHASE_C2P) { interior_done_ = true; dt_ready_ = do_dt; }
 }
@@ -1160,6 +1223,7 @@ struct Sim {
 }  // namespace host
 }  // namespace akmi
 
+namespace akmi { void set_error(const char *fmt, ...); }
 using namespace akmi::host;
 
 extern "C" {
@@ -1194,6 +1258,22 @@ int akmi_sim_execute(void *h, int max_cycles) {
   Sim *s = static_cast<Sim *>(h);
   s->Enter();
   return s->pdriver->Execute(s->pmesh, max_cycles);
+}
+
+/* live timing of the fused-stage launch group: on != 0 starts recording a HIP event pair on the launch stream
+ * around every akmi_*_stage_fused / akmi_*_stage_phase call; akmi_sim_profile_read waits for the recorded
+ * events, returns their summed duration and count, and clears the record */
+int akmi_sim_profile(void *h, int on) {
+  Sim *s = static_cast<Sim *>(h);
+  if (!s->pdriver) { akmi::set_error("akmi_sim_profile: call akmi_sim_initialize first"); return AKMI_FAIL; }
+  s->pdriver->prof_on = on != 0;
+  if (on) s->pdriver->prof_used = 0;
+  return AKMI_COMPLETE;
+}
+int akmi_sim_profile_read(void *h, double *ms_total, long long *calls) {
+  Sim *s = static_cast<Sim *>(h);
+  if (!s->pdriver) { akmi::set_error("akmi_sim_profile_read: call akmi_sim_initialize first"); return AKMI_FAIL; }
+  return s->pdriver->ProfRead(ms_total, calls);
 }
 
 void akmi_sim_destroy(void *h) { delete static_cast<Sim *>(h); }

@@ -189,6 +189,7 @@ struct ExchangeChannel {                                      // one variable cl
 ExchangeChannel PlanChannel(const ExchangePlan &pl, const std::function<long long(int)> &segsize);
 class MeshBlock;
 void BuildMeshBlockPlan(MeshBlock *pmb, int my_rank, int gids);
+bool SelfExchange();   // AKMI_SELF_EXCHANGE=1 + RCCL communicator: same-rank neighbours through ncclSend/ncclRecv to self
 
 // ---- static mesh refinement (akmi_host_smr.cpp) ----------------------------------------------
 struct LogicalLocation { int lx1, lx2, lx3, level; };          // mesh.hpp:54-60
@@ -357,6 +358,10 @@ class FluidBase {
   MeshBoundaryValues *pbval = nullptr;  // off-rank neighbours (uniform meshes, nranks > 1)
   bool peers() const { return pbval && pbval->HasPeers(); }
   const Real *dt_dev = nullptr;         // set by the Driver when cycles are replayed from a hipGraph
+  // the out-of-place first stage trades the two registers; true while u0 / b0 live in the buffers that were
+  // u1 / b1 when the arrays were created (akmi_sim_execute copies back so that akmi_sim_array pointers stay valid)
+  bool u_swapped = false, b_swapped = false;
+  virtual void RestoreRegisters();
  public:
   void FinishNewDtPublic() { FinishNewDt(); }
  protected:
@@ -404,6 +409,7 @@ class MHD : public FluidBase {      // mhd.hpp:93-199
   DvceArray<Real> e3x1, e2x1, e1x2, e3x2, e2x3, e1x3;
   void AssembleMHDTasks(std::map<std::string, std::shared_ptr<TaskList>> tl);
   void StagePhase(Driver *d, int stage, int phases);   // akmi_mhd_stage_phase
+  void RestoreRegisters() override;
   TaskStatus SaveMHDState(Driver *d, int stage) { return TaskStatus::complete; }
   TaskStatus InitRecv(Driver *d, int stage) { return TaskStatus::complete; }
   TaskStatus CopyCons(Driver *d, int stage);
@@ -450,6 +456,13 @@ class Driver {          // driver.cpp
   // (akmi_*_stage_fused_dt).  Eligible: fused stage, one rank, uniform mesh.  <time>/cycle_graph = auto
   // (1-D packs) | true | false; AKMI_CYCLE_GRAPH=0/1 overrides.
   bool use_graph = false, capturing = false;
+  // akmi_sim_profile: live timing of the fused-stage launch group -- a HIP event pair on the launch stream
+  // around every akmi_*_stage_fused / akmi_*_stage_phase call of the cycles that follow (bench.py's roofline entry)
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;
+  size_t prof_used = 0;
+  void ProfMark(hipStream_t st);
+  int ProfRead(double *ms_total, long long *calls);
   hipGraphExec_t cycle_exec = nullptr;
   DvceArray<Real> d_dt;
   Real *h_dt = nullptr;              // pinned

@@ -26,6 +26,7 @@
 #include <cstring>
 #include <thread>
 
+#include <poll.h>
 #include <rccl/rccl.h>
 
 #include "akmi_host.hpp"
@@ -253,15 +254,25 @@ void Mesh::LoadBalance(const std::vector<float> &clist) {       // load_balance.
 // remote ghost regions are numbered ("slots") in (peer, my gid, direction) order; a message to a peer
 // carries the segments in (receiver gid, receiver direction) order -- the same order seen from the
 // other side
+// AKMI_SELF_EXCHANGE=1 with an RCCL communicator (functional check of the transport on however many GPUs there
+// are, one included): neighbours on THIS rank are treated like neighbours on another rank, with the rank itself
+// as the peer -- their ghost zones travel pack kernel -> send buffer -> ncclSend/ncclRecv to self inside the
+// group call -> receive buffer -> unpack kernel instead of the same-rank gather.  Results must not change.
+bool SelfExchange() {
+  static const bool on = std::getenv("AKMI_SELF_EXCHANGE") && std::atoi(std::getenv("AKMI_SELF_EXCHANGE")) != 0;
+  return on && Comm::World().kind == Comm::Kind::rccl;
+}
+
 static ExchangePlan BuildPlan(int my_rank, int gids, int nmb, const std::vector<int> &ngid,
                               const std::vector<int> &nrank) {
   ExchangePlan pl;
   pl.tab.assign(27*nmb, -1);
+  const bool self = SelfExchange();
   for (int m = 0; m < nmb; ++m)
     for (int d = 0; d < 27; ++d) {
       const int g = ngid[27*m + d], r = nrank[27*m + d];
       if (g < 0) continue;
-      if (r == my_rank) { pl.tab[27*m + d] = g - gids; continue; }
+      if (r == my_rank && !self) { pl.tab[27*m + d] = g - gids; continue; }
       pl.recv_items[r].push_back({gids + m, d});
       pl.send_items[r].push_back({g, 26 - d, m, d});
     }
@@ -399,9 +410,33 @@ static bool BootstrapId(int rank, int nranks, char id[128], std::string &err) {
     if (::bind(ls, reinterpret_cast<sockaddr *>(&a), sizeof(a)) != 0 || ::listen(ls, nranks) != 0) {
       err = "rank 0 cannot listen on port " + std::to_string(p); ::close(ls); return false;
     }
-    for (int q = 1; q < nranks; ++q) {
+    // every rank announces itself with its number; only ranks 1..nranks-1, each once, get the id.  Anything
+    // else that connects to the port is dropped, and a rank that never shows up costs AKMI_BOOTSTRAP_TIMEOUT
+    // seconds (default 120), not a hang.
+    const char *te = std::getenv("AKMI_BOOTSTRAP_TIMEOUT");
+    const int timeout_ms = 1000*(te ? std::atoi(te) : 120);
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<bool> seen(nranks, false);
+    int served = 0;
+    while (served < nranks - 1) {
+      const int left = timeout_ms - static_cast<int>(std::chrono::duration_cast<std::chrono::milliseconds>(
+                                         std::chrono::steady_clock::now() - t0).count());
+      pollfd pf{ls, POLLIN, 0};
+      if (left <= 0 || ::poll(&pf, 1, left) <= 0) {
+        err = "rank 0: " + std::to_string(nranks - 1 - served) + " rank(s) did not ask for the id within " +
+              std::to_string(timeout_ms/1000) + " s";
+        ::close(ls); return false;
+      }
       int fd = ::accept(ls, nullptr, nullptr);
-      if (fd < 0 || !SendAll(fd, id, 128)) { err = "rank 0: sending the id failed"; ::close(ls); return false; }
+      if (fd < 0) continue;
+      timeval tv{5, 0};
+      setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+      std::int32_t who = -1;
+      if (RecvAll(fd, reinterpret_cast<char *>(&who), sizeof(who)) && who >= 1 && who < nranks && !seen[who] &&
+          SendAll(fd, id, 128)) {
+        seen[who] = true;
+        ++served;
+      }
       ::close(fd);
     }
     ::close(ls);
@@ -415,7 +450,10 @@ static bool BootstrapId(int rank, int nranks, char id[128], std::string &err) {
   for (int attempt = 0; attempt < 600; ++attempt) {           // rank 0 may not be listening yet
     int fd = ::socket(AF_INET, SOCK_STREAM, 0);
     if (::connect(fd, res->ai_addr, res->ai_addrlen) == 0) {
-      const bool ok = RecvAll(fd, id, 128);
+      const std::int32_t who = rank;
+      timeval tv{30, 0};
+      setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+      const bool ok = SendAll(fd, reinterpret_cast<const char *>(&who), sizeof(who)) && RecvAll(fd, id, 128);
       ::close(fd); freeaddrinfo(res);
       if (!ok) err = "receiving the id from rank 0 failed";
       return ok;
@@ -435,12 +473,20 @@ using namespace akmi::host;
 
 extern "C" {
 
+// librccl is resolved at run time: a missing library is an error return of these entries, not an exit
+static bool RcclAvailable(const char *who) {
+  if (rccl().ok) return true;
+  akmi::set_error("%s: RCCL is not available (%s)", who, rccl().where.c_str());
+  return false;
+}
 int akmi_comm_unique_id(char id[128]) {
+  if (!RcclAvailable("comm_unique_id")) return AKMI_FAIL;
   Comm::GetUniqueId(id);
   return AKMI_COMPLETE;
 }
 int akmi_comm_init_rccl(int rank, int nranks, const char id[128]) {
   if (rank < 0 || nranks < 1 || rank >= nranks) { akmi::set_error("comm_init_rccl: rank %d of %d", rank, nranks); return AKMI_FAIL; }
+  if (!RcclAvailable("comm_init_rccl")) return AKMI_FAIL;
   Comm::World().InitRCCL(rank, nranks, id);
   return AKMI_COMPLETE;
 }
@@ -448,6 +494,7 @@ int akmi_comm_init_env(void) {
   const char *r = std::getenv("RANK"), *w = std::getenv("WORLD_SIZE"), *l = std::getenv("LOCAL_RANK");
   const int rank = r ? std::atoi(r) : 0, nranks = w ? std::atoi(w) : 1;
   if (l) { if (hipSetDevice(std::atoi(l)) != hipSuccess) { akmi::set_error("comm_init_env: hipSetDevice(LOCAL_RANK) failed"); return AKMI_FAIL; } }
+  if (!RcclAvailable("comm_init_env")) return AKMI_FAIL;
   char id[128];
   std::string err;
   if (!BootstrapId(rank, nranks, id, err)) { akmi::set_error("comm_init_env: %s", err.c_str()); return AKMI_FAIL; }

@@ -253,7 +253,7 @@ k_sweep(Geo g, FaceEos eos, SweepArgs a, int nk) {
 }
 
 #ifndef AKMI_POW2DX
-#define AKMI_POW2DX 0           // two copies of the loop cost more (register allocation) than the 15 divisions
+#define AKMI_POW2DX 1           // cell sizes that are powers of two: x/dx as one v_ldexp_f64 (wave-uniform choice at run time)
 #endif
 // true when x is a normal power of two, i.e. 1/x is exact (mantissa bits all zero)
 __host__ __device__ inline bool is_pow2(double x) {
@@ -1334,6 +1334,10 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
   const bool cell_ok = in_tile && i < g.N1 && j < g.N2;                // the column exists in memory
   const bool own = in_tile && t < tw - 1 && r < th - 1 && i <= g.ie && j <= g.je;
   const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
+  // power-of-two cell sizes: x/dx == ldexp(x, n) bit for bit (pow2_shift); beta*dt once, in scalar registers
+  const bool p2 = AKMI_POW2DX && is_pow2(dx1) && is_pow2(dx2) && is_pow2(dx3);
+  const int n1 = pow2_shift(dx1), n2 = pow2_shift(dx2), n3 = pow2_shift(dx3);
+  const double bdt = to_sgpr(beta_dt_of(u.beta_dt, u.dtp));
   const size_t cs = (size_t)g.N3*g.N2*g.N1, ps = (size_t)g.N2*g.N1;
   const double *wb = w0 + (size_t)m*g.nvar*cs;
   // halo entry of this thread: rows 0,1 and ph-1 in full, columns 0,1 and pw-1 of the tile rows
@@ -1479,13 +1483,15 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
 #pragma unroll
       for (int n = 0; n < 5; ++n) {
       ISOSKIP;
-        double divf = (SF1(b, n, r, t + 1) - SF1(b, n, r, t))/dx1;
-        divf += (SF2(b, n, r + 1, t) - SF2(b, n, r, t))/dx2;
-        divf += (f3[n] - F3p[n])/dx3;
+        const double d1 = SF1(b, n, r, t + 1) - SF1(b, n, r, t), d2 = SF2(b, n, r + 1, t) - SF2(b, n, r, t),
+                     d3 = f3[n] - F3p[n];
+        double divf = p2 ? ldexp(d1, n1) : d1/dx1;
+        divf += p2 ? ldexp(d2, n2) : d2/dx2;
+        divf += p2 ? ldexp(d3, n3) : d3/dx3;
         const double u0v = pu0[n];
         const double u1v = u.copy_u1 ? u0v : pu1[n];
         rk_store_u(u.u0 + c + n*cs, u.u1 + c + n*cs, u.copy_u1, col, u0v,
-                   u.gam0*u0v + u.gam1*u1v - beta_dt_of(u.beta_dt, u.dtp)*divf);
+                   u.gam0*u0v + u.gam1*u1v - bdt*divf);
       }
     }
 #pragma unroll

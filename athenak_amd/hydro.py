@@ -337,12 +337,20 @@ class Hydro(FluidBase):
             gam0, gam1, beta_dt = 1.0, 0.0, 0.0
         do_dt = 1 if stage == pdrive.nexp_stages else 0
         copy = self._copy_flag(pdrive, stage, phases)
+        ev = getattr(self, "stage_events", None)     # bench.py: HIP event pair around the launch group
+        if ev is not None:
+            import torch
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev.append((e0, e1))
+            e0.record()
         capi.check(self.L.akmi_hydro_stage_phase(
             C.byref(self.pack_c), self.recon_method, self.rsolver_method, capi.d(gam0),
             capi.d(gam1), capi.d(beta_dt), copy, capi._p(self.w0),
             capi._p(self.u0), capi._p(self.u1), do_dt, capi._p(self.counters),
             capi._p(self.dt3), phases, capi._p(self._workspace(0)), capi._stream()),
             "hydro_stage_phase")
+        if ev is not None:
+            e1.record()
         if copy == 2:                      # out-of-place first stage: the registers trade places
             self.u0, self.u1 = self.u1, self.u0
         if phases & capi.PHASE_C2P:

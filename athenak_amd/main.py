@@ -36,9 +36,9 @@ class Simulation:
         if got != want:
             raise RuntimeError("### FATAL ERROR mesh in the restart file %r does not match the "
                                "parameters %r" % (got, want))
-        lloc = [tuple(int(x) for x in l[:3]) for l in hdr["lloc"]]
-        if lloc != [tuple(l)[:3] for l in pm.lloc_eachmb]:
-            raise RuntimeError("### FATAL ERROR MeshBlock order of the restart file differs")
+        lloc = [tuple(int(x) for x in l[:4]) for l in hdr["lloc"]]          # (lx1, lx2, lx3, level) per block
+        if lloc != [tuple(l)[:3] + (pm.level_of(g),) for g, l in enumerate(pm.lloc_eachmb)]:
+            raise RuntimeError("### FATAL ERROR MeshBlock order or refinement levels of the restart file differ")
         pm.time, pm.dt, pm.ncycle = hdr["time"], hdr["dt"], hdr["ncycle"]   # build_tree.cpp:365-369
         pk = pm.pmb_pack
         arrays = []

@@ -314,8 +314,9 @@ class MeshBinaryOutput(BaseTypeOutput):
                 with open(fname, "ab") as f:
                     for mi, o in enumerate(self.outmbs):
                         l1, l2, l3 = pm.lloc_eachmb[o.mb_gid][:3]
-                        # level - root_level: 0 on the uniform meshes of this path
-                        f.write(struct.pack("<10i", o.ois, o.oie, o.ojs, o.oje, o.oks, o.oke, l1, l2, l3, 0))
+                        # binary.cpp:192-193: loc.level - root_level (0 on uniform meshes, >0 inside refined regions)
+                        f.write(struct.pack("<10i", o.ois, o.oie, o.ojs, o.oje, o.oks, o.oke, l1, l2, l3,
+                                            pm.level_of(o.mb_gid) - pm.root_level))
                         f.write(struct.pack("<6d", o.x1min, o.x1max, o.x2min, o.x2max, o.x3min, o.x3max))
                         f.write(np.ascontiguousarray(self.outarray[:, mi], dtype="<f4").tobytes())
             _barrier(pm)
@@ -357,9 +358,8 @@ class RestartOutput(BaseTypeOutput):
         header += _pack_region_indcs(pm.mesh_indcs, coarse=False)
         header += _pack_region_indcs(pm.mb_indcs, coarse=True)
         header += struct.pack("<ddi", pm.time, pm.dt, pm.ncycle)
-        lev = _root_level(pm)
-        for l in pm.lloc_eachmb:                              # LogicalLocation {lx1,lx2,lx3,level}
-            header += struct.pack("<iiii", l[0], l[1], l[2], lev)
+        for gid, l in enumerate(pm.lloc_eachmb):              # LogicalLocation {lx1,lx2,lx3,level}: the block's own level
+            header += struct.pack("<iiii", l[0], l[1], l[2], pm.level_of(gid))
         header += np.asarray(pm.cost_eachmb, dtype="<f4").tobytes()
         header += struct.pack("<Q", data_size)
         base = len(sbuf) + len(header)

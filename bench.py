@@ -191,6 +191,95 @@ def cpu_baseline(args, blk):
                           args.problem, n, rec, "; ".join(results), nsee, ("%g CPUs" % quota) if quota else "unlimited")}
 
 
+def run_python_host(args, pin, blk, rank, world):
+    """W warm-up + K timed cycles through the Python host (athenak_amd.main); the stage launch group
+    (akmi_*_stage_phase) is bracketed by HIP event pairs INSIDE the timed loop"""
+    import torch
+    from athenak_amd.main import Simulation
+    sim = Simulation(pin, my_rank=rank, nranks=world)
+    pm, drv = sim.pmesh, sim.pdriver
+    info = {"ncell_rank": pm.pmb_pack.nmb_thispack*pm.NumberOfMeshBlockCells(),
+            "ncell_total": pm.nmb_total*pm.NumberOfMeshBlockCells(), "nstage": drv.nexp_stages,
+            "ng": pm.mb_indcs.ng}
+    if world > 1:
+        import torch.distributed as dist
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        drv._cycle(pm)
+    sim.phys.stage_events = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        drv._cycle(pm)
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64,
+                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    evs, sim.phys.stage_events = sim.phys.stage_events, None
+    group_ms = sum(a.elapsed_time(b) for a, b in evs)
+    info.update(host="Python (athenak_amd.main)" + ("" if world == 1 else ", halos by torch.distributed batch_isend_irecv"),
+                el=el, steps=args.steps, value=info["ncell_total"]*args.steps/el/1e6, ms_per_step=el/args.steps*1e3,
+                group_ms=group_ms, group_calls=len(evs), time=float(pm.time), dt=float(pm.dt), ncycle=int(pm.ncycle))
+    del sim
+    torch.cuda.empty_cache()
+    return info
+
+
+def run_cpp_host(args, pin):
+    """the same W + K cycles through the C++ host (akmi_sim_*: Mesh/TaskList/Driver in C++, one C-ABI call per
+    task) in this process (one rank); launch-group timing by akmi_sim_profile (HIP events in the timed loop)"""
+    import ctypes as C
+    import torch
+    from athenak_amd import capi, native
+    L = capi.lib()
+    sim = native.NativeSimulation(pin)
+    pm = sim.pmesh
+    nstage = {"rk1": 1, "rk2": 2, "rk3": 3, "rk4": 4}[pin.GetString("time", "integrator")]
+    info = {"ncell_rank": pm.pmb_pack.nmb_thispack*pm.NumberOfMeshBlockCells(),
+            "ncell_total": pm.nmb_total*pm.NumberOfMeshBlockCells(), "nstage": nstage, "ng": pm.mb_indcs.ng}
+    sim.Execute(max_cycles=args.warmup)
+    capi.check(L.akmi_sim_profile(sim.h, 1), "sim_profile")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done = sim.Execute(max_cycles=args.steps)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms, calls = C.c_double(0.0), C.c_longlong(0)
+    capi.check(L.akmi_sim_profile_read(sim.h, C.byref(ms), C.byref(calls)), "sim_profile_read")
+    info.update(host="C++ (akmi_sim_*: Mesh, TaskList, Driver in C++; one C-ABI call per task)", el=el, steps=done,
+                value=info["ncell_total"]*done/el/1e6, ms_per_step=el/max(done, 1)*1e3, group_ms=ms.value,
+                group_calls=calls.value, time=sim.time, dt=sim.dt, ncycle=sim.ncycle)
+    sim.close()
+    torch.cuda.empty_cache()
+    return info
+
+
+def valu_floor(blk, nx, plain):
+    """second roof of the stage: the fp64 issue time of the VALU instructions the stage kernels execute
+    (SQ_INSTS_VALU of a separate counter run, tools/pmc_valu.sh -> profiles/valu_counters_latest.json, accepted
+    only for the library / sources of this run): instructions x 4 cycles / (1024 SIMDs x 2.4 GHz)"""
+    f = os.path.join(ROOT, "profiles", "valu_counters_latest.json" if blk == "mhd" else "valu_counters_hydro_latest.json")
+    if not (plain and nx == 256 and os.path.exists(f)):
+        return None
+    t = json.load(open(f))
+    if t.get("lib_sha16") != lib_sha16() and t.get("src_sha16") != src_sha16():
+        return {"ms": None, "source": "profiles/%s is of another build (sources %s, this run %s)" % (
+            os.path.basename(f), t.get("src_sha16"), src_sha16())}
+    insts = sum(v["insts_valu_per_launch"]*v.get("launches_per_stage", 1) for k, v in t["kernels"].items())
+    return {"ms": round(insts*4.0/(1024*2.4e9)*1e3, 4), "valu_wave_insts_per_stage": round(insts),
+            "source": "profiles/%s (%s): SQ_INSTS_VALU x 4 cycles / (256 CUs x 4 SIMDs x 2.4 GHz)" % (
+                os.path.basename(f), t.get("tag", ""))}
+
+
 def main():
     args = parse()
     import torch
@@ -221,80 +310,79 @@ def main():
         return native_child(args, pin, rank, world)
     if args.native:
         return main_native(args, pin, blk, nblk, rank, world)
-    from athenak_amd.main import Simulation
-    sim = Simulation(pin, my_rank=rank, nranks=world)
-    pm, drv = sim.pmesh, sim.pdriver
-    ncell_rank = pm.pmb_pack.nmb_thispack*pm.NumberOfMeshBlockCells()
-    ncell_total = pm.nmb_total*pm.NumberOfMeshBlockCells()
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+    # ---- both hosts over the same W warm-up + K timed cycles -------------------------------------------
+    # The C++ host is the path north_star names ("host code stays C++ ... RCCL"): it is the headline whenever it
+    # completed the K cycles and ended at the same (time, dt) as the Python host -- a wrong or skipped halo
+    # exchange cannot win the line by being faster.  The Python host is reported beside it (other_host); it is
+    # the headline only when the C++ host gave no result or a different one, and the line says why.
+    py = run_python_host(args, pin, blk, rank, world)
+    chk = os.environ.get("AKMI_BENCH_NATIVE_CHECK", "1")
+    cpp, why = None, None
+    if world == 1:
+        if chk != "0":
+            try:
+                cpp = run_cpp_host(args, pin)
+            except Exception as e:           # must never take the measurement down
+                why = "C++ host failed: %r" % (e,)
+        else:
+            why = "C++ host switched off (AKMI_BENCH_NATIVE_CHECK=0)"
+    else:
+        nccl = dist.get_backend() == "nccl"
+        dist.barrier()
+        dist.destroy_process_group()
+        if (nccl and chk != "0") or chk == "force":
+            cpp = native_check(args, rank, world)
+            if cpp is None:
+                why = "C++ host gave no result (see stderr)"
+        else:
+            why = "C++ host not run (%s)" % ("switched off" if chk == "0" else "backend is not RCCL")
+    if rank != 0:
+        return
+    if cpp is not None:
+        if cpp.get("steps") != args.steps:
+            why, cpp_ok = "C++ host completed %s of %d cycles" % (cpp.get("steps"), args.steps), False
+        elif cpp["time"] != py["time"] or cpp["dt"] != py["dt"]:
+            why, cpp_ok = ("C++ host ended at (t, dt) = (%r, %r), the Python host at (%r, %r): not accepted"
+                           % (cpp["time"], cpp["dt"], py["time"], py["dt"])), False
+        else:
+            cpp_ok = True
+    else:
+        cpp_ok = False
+    head, other = (cpp, py) if cpp_ok else (py, cpp)
+    for k in ("ncell_rank", "ncell_total", "nstage", "ng"):
+        head.setdefault(k, py[k])
 
-    for _ in range(args.warmup):
-        drv._cycle(pm)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        drv._cycle(pm)
-    barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64,
-                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-
-    # ---- roofline of the dominant launch group, from HIP events on the launch stream --------
-    # akmi_*_stage_fused = the whole stage except the halo exchange and the ghost-shell c2p:
-    # algorithmic bytes = SURVEY 8(d)'s per-cell-stage figure (MHD 384 B, hydro 240 B).
-    phys = sim.phys
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    tS = tH = 0.0
-    nprof = 3
-    for _ in range(nprof):
-        for stage in range(1, drv.nexp_stages + 1):
-            ev[0].record()
-            phys.CopyCons(drv, stage); phys.Fluxes(drv, stage); phys.RKUpdate(drv, stage)
-            if blk == "mhd":
-                phys.EField(drv, stage); phys.CT(drv, stage)
-            ev[1].record()
-            phys.SendU(drv, stage); phys.RecvU(drv, stage)
-            if blk == "mhd":
-                phys.SendB(drv, stage); phys.RecvB(drv, stage)
-            phys.ApplyPhysicalBCs(drv, stage)
-            phys.ConToPrim(drv, stage); phys.NewTimeStep(drv, stage)
-            ev[2].record()
-            torch.cuda.synchronize()
-            tS += ev[0].elapsed_time(ev[1]); tH += ev[1].elapsed_time(ev[2])
-        pm.time += pm.dt; pm.ncycle += 1; pm.NewTimeStep(drv.tlim)
-    nst = nprof*drv.nexp_stages
-    tS, tH = tS/nst*1e-3, tH/nst*1e-3                       # seconds per launch group
-    if world > 1:
-        # ranks with off-rank neighbours issue the stage in phases interleaved with the halo
-        # messages (mhd.py RKUpdate/SendU/CT/SendB): only the whole stage is a meaningful group
-        tS, tH = tS + tH, 0.0
+    # ---- roofline of the dominant launch group: HIP events of the headline host's timed loop ----------------
+    # akmi_*_stage_fused / _stage_phase = the whole stage except the halo exchange, the BCs and the ghost-shell
+    # c2p: algorithmic bytes = SURVEY 8(d)'s per-cell-stage figure (MHD 384 B, hydro 240 B).
+    nst = args.steps*py["nstage"]
     stage_bytes = BYTES_PASS_A[blk] + BYTES_PASS_B[blk]
+    ncell_rank = py["ncell_rank"]
+    plain = not (args.recon or args.ng or args.set or args.split or args.mb) and args.problem in ("orszag_tang", "sod")
+    if head.get("group_calls"):
+        tS = head["group_ms"]*1e-3/nst                        # seconds per stage in the launch group
+        rest_ms = head["ms_per_step"]/py["nstage"] - tS*1e3
+        kname = ("akmi_%s_stage_fused launch group (sweeps + update%s + c2p of active cells)" % (
+                     blk, " + CornerE + CT" if blk == "mhd" else "")) if world == 1 else \
+                "akmi_%s_stage_phase x3 of a rank (the halo messages travel between the phases)" % blk
+    else:                                                     # a child of an older build: whole stage only
+        tS, rest_ms = head["ms_per_step"]*1e-3/py["nstage"], None
+        kname = "whole stage of a rank incl. halo exchange"
     ach = stage_bytes*ncell_rank/tS/1e9
     traffic, tsrc = None, None
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json" if blk == "mhd" else
                          "pmc_traffic_hydro_latest.json")
-    if os.path.exists(tfile) and args.nx == 256 and not args.split and not args.mb and \
-            args.problem in ("orszag_tang", "sod"):
-        # HBM-side bytes per stage from rocprofv3 PMC counters (FETCH_SIZE / WRITE_SIZE in
-        # separate passes, calibrated on a copy of known size; tools/pmc.sh), recorded for this
-        # workload in a separate profiling run
+    if os.path.exists(tfile) and args.nx == 256 and plain:
+        # HBM-side bytes per stage from rocprofv3 PMC counters (FETCH_SIZE / WRITE_SIZE in separate passes,
+        # calibrated on a copy of known size; tools/pmc.sh), recorded for this workload in a separate run
         t = json.load(open(tfile))
         stage_kernels = [k for k in t["kernels"] if k.startswith("akmi::k_sweep") or
                          k.startswith("akmi::k_corner") or k.startswith("akmi::k_ct_copy") or
                          k.startswith("akmi::k_hydro_stage3d") or k.startswith("akmi::k_c2p_newdt")]
         same_lib = t.get("lib_sha16") == lib_sha16()
         same_src = t.get("src_sha16") is not None and t.get("src_sha16") == src_sha16()
-        if (same_lib or same_src) and not args.recon and not args.ng and not args.set:
-            # counters of THIS library only: the profiling run stamps the sha of the libakmi.so it
-            # measured and of the sources it was built from (tools/pmc_summary.py)
+        if same_lib or same_src:
             traffic = round(sum(t["kernels"][k]["hbm_bytes_per_launch"] for k in stage_kernels))
             tsrc = "profiles/%s (%s, %s)" % (os.path.basename(tfile), t.get("tag", ""),
                                               ("lib %s" % t["lib_sha16"]) if same_lib else
@@ -302,85 +390,58 @@ def main():
         else:
             tsrc = "profiles/%s is of another build (lib %s / sources %s, this run %s / %s): traffic not reported" % (
                 os.path.basename(tfile), t.get("lib_sha16"), t.get("src_sha16"), lib_sha16(), src_sha16())
-    roofline = {"bound": "hbm",
-                "kernel": ("akmi_%s_stage_fused launch group (sweeps + update%s + c2p of active cells)"
-                           % (blk, " + CornerE + CT" if blk == "mhd" else "")) if world == 1 else
-                          "whole stage of rank 0 incl. halo exchange (akmi_%s_stage_phase x3)" % blk,
+    whole = stage_bytes*ncell_rank*nst/head["el"]/1e9
+    roofline = {"bound": "hbm", "kernel": kname,
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach/HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                 "algorithmic_bytes_per_cell_stage": stage_bytes,
                 "algorithmic_bytes_per_launch": stage_bytes*ncell_rank,
                 "ms_per_launch": round(tS*1e3, 4),
-                "halo_bcs_shell_c2p_ms": round(tH*1e3, 4),
-                "whole_stage": {"achieved": round(stage_bytes*ncell_rank*drv.nexp_stages*args.steps
-                                                  / el / 1e9, 1)},
-                "note": "measured traffic is 2.3x the algorithmic bytes (intermediates between the four kernels); "
-                        "CornerE+CT and c2p already stream at 5.7-5.9 TB/s, the x3 march sits at its traffic, "
-                        "the x1-in-x2 march is bound by ~2000 fp64 instructions per cell: DESIGN.md 3"}
-    roofline["whole_stage"]["frac"] = round(roofline["whole_stage"]["achieved"]/HBM_PEAK_GBS, 4)
+                "timing": "HIP event pairs on the launch stream around every call of the group inside the timed "
+                          "loop of the headline host (%d calls)" % (head.get("group_calls") or 0),
+                "halo_bcs_shell_c2p_ms": None if rest_ms is None else round(rest_ms, 4),
+                "valu_floor": valu_floor(blk, args.nx, plain),
+                "whole_stage": {"achieved": round(whole, 1), "frac": round(whole/HBM_PEAK_GBS, 4)},
+                "note": "two roofs: HBM (algorithmic bytes / 8 TB/s) and fp64 issue (valu_floor.ms); the measured "
+                        "traffic is ~2.3x the algorithmic bytes (intermediates between the four kernels of the MHD "
+                        "stage): DESIGN.md 3"}
 
-    if rank == 0:
-        value = ncell_total*args.steps/el/1e6
-        rname = (args.recon or "plm").upper()
-        out = {"metric": "Mcell-updates/s (3D MHD %s+HLLD+CT RK2, %d^3 cells per GPU)" % (rname, args.nx)
-               if blk == "mhd" else "Mcell-updates/s (3D hydro %s+HLLC RK2, %d^3 per GPU)" % (rname, args.nx),
-               "value": round(value, 2), "unit": "Mcell-updates/s", "n_gpus": world,
-               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el/args.steps*1e3, 4),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-               "data": "synthetic (closed-form %s initial condition)" % args.problem,
-               "lib_sha16": lib_sha16(), "src_sha16": src_sha16(),
-               "config": {"workload": "%s 3D, %s, %d^3 cells per GPU, mesh %dx%dx%d in %dx%dx%d "
-                                      "MeshBlocks, cfl 0.3, RK2, ng=%d" % (
-                                          args.problem, ("ideal MHD %s+HLLD+CT" % (args.recon or "plm").upper()) if blk == "mhd" else
-                                          ("ideal hydro %s+HLLC" % (args.recon or "plm").upper()), args.nx, args.nx*nblk[0],
-                                          args.nx*nblk[1], args.nx*nblk[2],
-                                          *[b*args.nx//(args.mb or args.nx) for b in nblk],
-                                          pm.mb_indcs.ng),
-                          "path": "task-granular" if args.split else "fused stage",
-                          "halo": "none (single periodic block: same-rank gather)" if world == 1
-                          else "%s send/recv (torch.distributed), per-stage U and B messages posted "
-                               "under CornerE/CT and the interior c2p" % (
-                                   "RCCL" if dist.get_backend() == "nccl" else dist.get_backend())},
-               "roofline": roofline}
-        if args.set:
-            out["config"]["workload"] += " + " + " ".join(args.set)
-        if world == 1 and not args.no_cpu_baseline and not args.set:
-            out["cpu_baseline"] = cpu_baseline(args, blk)
-    chk = os.environ.get("AKMI_BENCH_NATIVE_CHECK", "1")
-    if world > 1 or chk == "force":
-        # N > 1: the same K timed cycles also through the C++ host, which calls RCCL itself; the faster
-        # host is the headline, the other one is reported beside it (native_check).  "force": developer
-        # check of this mechanism on a 1-GPU box
-        nccl = world > 1 and dist.get_backend() == "nccl"
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        nat = None
-        if (nccl and chk != "0") or chk == "force":
-            nat = native_check(args, rank, world)
-        if rank == 0:
-            py = {"host": "Python (athenak_amd.main), halos by torch.distributed batch_isend_irecv",
-                  "value": out["value"], "ms_per_step": out["ms_per_step"]}
-            if nat and nat.get("steps") == args.steps and nat["value"] > out["value"]:
-                out["value"], out["ms_per_step"] = round(nat["value"], 2), round(nat["ms_per_step"], 4)
-                out["config"]["host"] = "C++ (akmi_sim_*), one child process per rank"
-                out["config"]["halo"] = ("RCCL called from the C++ host: grouped ncclSend/ncclRecv per variable class "
-                                         "on the communicator's stream, ncclAllReduce(min) for dt")
-                tst = nat["ms_per_step"]*1e-3/drv.nexp_stages
-                ach = stage_bytes*ncell_rank/tst/1e9
-                roofline.update({"kernel": "whole stage of a rank incl. halo exchange (C++ host)",
-                                 "achieved": round(ach, 1), "frac": round(ach/HBM_PEAK_GBS, 4),
-                                 "ms_per_launch": round(tst*1e3, 4), "halo_bcs_shell_c2p_ms": 0.0,
-                                 "whole_stage": {"achieved": round(ach, 1), "frac": round(ach/HBM_PEAK_GBS, 4)}})
-                out["other_host"] = py
-            else:
-                out["config"]["host"] = py["host"]
-                out["other_host"] = ({"host": "C++ (akmi_sim_*) + RCCL called directly", "value": round(nat["value"], 2),
-                                      "ms_per_step": round(nat["ms_per_step"], 4)} if nat else
-                                     {"host": "C++ (akmi_sim_*) + RCCL called directly",
-                                      "value": None, "note": "no result (see stderr)" if chk != "0" else "switched off"})
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    rname = (args.recon or "plm").upper()
+    halo = "none (single periodic block: same-rank gather)" if world == 1 else (
+        "RCCL called from the C++ host: grouped ncclSend/ncclRecv per variable class on the communicator's stream, "
+        "ncclAllReduce(min) for dt; per-stage U and B messages posted under CornerE/CT and the interior c2p"
+        if cpp_ok else "RCCL send/recv through torch.distributed, per-stage U and B messages posted under "
+                       "CornerE/CT and the interior c2p")
+    out = {"metric": "Mcell-updates/s (3D MHD %s+HLLD+CT RK2, %d^3 cells per GPU)" % (rname, args.nx)
+           if blk == "mhd" else "Mcell-updates/s (3D hydro %s+HLLC RK2, %d^3 per GPU)" % (rname, args.nx),
+           "value": round(head["value"], 2), "unit": "Mcell-updates/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(head["ms_per_step"], 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+           "data": "synthetic (closed-form %s initial condition)" % args.problem,
+           "lib_sha16": lib_sha16(), "src_sha16": src_sha16(),
+           "config": {"workload": "%s 3D, %s, %d^3 cells per GPU, mesh %dx%dx%d in %dx%dx%d "
+                                  "MeshBlocks, cfl 0.3, RK2, ng=%d" % (
+                                      args.problem, ("ideal MHD %s+HLLD+CT" % rname) if blk == "mhd" else
+                                      ("ideal hydro %s+HLLC" % rname), args.nx, args.nx*nblk[0],
+                                      args.nx*nblk[1], args.nx*nblk[2],
+                                      *[b*args.nx//(args.mb or args.nx) for b in nblk], py["ng"]),
+                      "path": "task-granular" if args.split else "fused stage",
+                      "host": head["host"] + ("" if world == 1 or not cpp_ok else ", one child process per rank"),
+                      "halo": halo},
+           "roofline": roofline}
+    if why:
+        out["config"]["host_note"] = why
+    if cpp_ok:
+        out["config"]["host_check"] = "both hosts ended at t = %r, dt = %r after %d + %d cycles" % (
+            py["time"], py["dt"], args.warmup, args.steps)
+    out["other_host"] = None if other is None else {
+        "host": other["host"], "value": round(other["value"], 2), "ms_per_step": round(other["ms_per_step"], 4),
+        "stage_group_ms": round(other["group_ms"]/nst, 4) if other.get("group_calls") else None}
+    if args.set:
+        out["config"]["workload"] += " + " + " ".join(args.set)
+    if world == 1 and not args.no_cpu_baseline and not args.set:
+        out["cpu_baseline"] = cpu_baseline(args, blk)
+    print(json.dumps(out), flush=True)
 
 
 def native_check(args, rank, world):
@@ -441,20 +502,24 @@ def native_child(args, pin, rank, world):
         return v[0]
 
     sim.Execute(max_cycles=args.warmup)
+    capi.check(L.akmi_sim_profile(sim.h, 1), "sim_profile")
     torch.cuda.synchronize()
     allmin(0.0)                                   # barrier
     t0 = time.perf_counter()
     n = sim.Execute(max_cycles=args.steps)
     torch.cuda.synchronize()
     el = -allmin(-(time.perf_counter() - t0))     # max over ranks
+    ms, calls = C.c_double(0.0), C.c_longlong(0)
+    capi.check(L.akmi_sim_profile_read(sim.h, C.byref(ms), C.byref(calls)), "sim_profile_read")
     if rank == 0:
         sys.stderr.write("[C++ host] RCCL called directly, %d GPUs: %.2f Mcell-updates/s, %.4f ms/step "
                          "(%d cycles, t=%.6e dt=%.6e)\n" % (world, ncell_total*n/el/1e6, el/n*1e3, n,
                                                             sim.time, sim.dt))
         sys.stderr.flush()
         with open(args.native_child, "w") as f:
-            json.dump({"value": ncell_total*n/el/1e6, "ms_per_step": el/n*1e3, "steps": n,
-                       "time": sim.time, "dt": sim.dt}, f)
+            json.dump({"value": ncell_total*n/el/1e6, "ms_per_step": el/n*1e3, "steps": n, "el": el,
+                       "time": sim.time, "dt": sim.dt, "group_ms": ms.value, "group_calls": calls.value,
+                       "host": "C++ (akmi_sim_*: Mesh, TaskList, Driver in C++) + RCCL called directly"}, f)
     sim.close()
     native.finalize_comm()
 

@@ -481,10 +481,20 @@ int akmi_history_sums(const akmi_pack *p, int is_mhd, const double *u0, const do
  * stream cannot be captured into a hipGraph) and waits for the device at entry.  On one rank with
  * the fused stage a cycle can be captured once and replayed as a hipGraph with dt read from device
  * memory: <time>/cycle_graph = auto (default: 1-D packs, where it pays) | true | false;
- * AKMI_CYCLE_GRAPH=0/1 overrides the deck. */
+ * AKMI_CYCLE_GRAPH=0/1 overrides the deck.
+ * Pointers returned by akmi_sim_array stay valid for the lifetime of the simulation: inside a cycle the
+ * driver trades its two registers (u0/u1, b0/b1) after the out-of-place first stage, and
+ * akmi_sim_execute copies the state back into the register of that name before it returns whenever
+ * an odd number of trades has happened (one device-to-device copy per call, not per cycle).
+ * akmi_sim_profile(sim, 1): from now on a HIP event pair is recorded on the launch stream around every
+ * akmi_*_stage_fused / akmi_*_stage_phase call (the dominant launch group of a stage);
+ * akmi_sim_profile_read waits for the recorded events, returns their summed duration in ms and their
+ * number, and clears the record (bench.py: roofline.ms_per_launch measured inside the timed loop). */
 void *akmi_sim_create(const char *deck_text, void *stream);
 int akmi_sim_initialize(void *sim, double tlim_override);
 int akmi_sim_execute(void *sim, int max_cycles);
+int akmi_sim_profile(void *sim, int on);
+int akmi_sim_profile_read(void *sim, double *ms_total, long long *calls);
 void akmi_sim_destroy(void *sim);
 double akmi_sim_time(void *sim);
 double akmi_sim_dt(void *sim);

@@ -253,3 +253,98 @@ def test_restart_files_roundtrip(case, cpu_oracle_backend):
 @pytest.mark.parametrize("case", ["sod", "ot"])
 def test_restart_files_roundtrip_hip(case, fused):
     _restart_roundtrip(case, fused)
+
+
+# ---- refined meshes: the block headers carry the block's OWN level (round 3) ---------------------------------
+def _run_smr(workdir, extra):
+    """2-D hydro linear wave on the statically refined mesh of linear_wave_hydro_smr.athinput, four cycles, a
+    bin dump of the conserved variables and a restart dump every two cycles"""
+    from athenak_amd.__main__ import main
+    here = os.getcwd()
+    text = open(os.path.join(ROOT, "athenak_amd", "inputs", "linear_wave_hydro_smr.athinput")).read()
+    text += "<output1>\nfile_type = bin\nvariable = hydro_u\ndcycle = 2\n<output2>\nfile_type = rst\ndcycle = 2\n"
+    deck = os.path.join(workdir, "smr.athinput")
+    os.makedirs(workdir, exist_ok=True)
+    with open(deck, "w") as f:
+        f.write(text)
+    try:
+        rc = main(["-i", deck, "-d", workdir, "mesh/nx1=32", "mesh/nx2=16", "mesh/nx3=1",
+                   "meshblock/nx1=8", "meshblock/nx2=4", "meshblock/nx3=1", "refined_region1/x1min=1.2",
+                   "refined_region1/x1max=1.8", "refined_region1/x2min=0.6", "refined_region1/x2max=0.9",
+                   "time/nlim=4", "hydro/fused_stage=false"] + list(extra))
+        assert rc == 0
+    finally:
+        os.chdir(here)
+
+
+def _bin_block_headers(path):
+    """the 10 int32 + 6 float64 header of every MeshBlock record of a version-1.1 bin file"""
+    import struct
+    raw = open(path, "rb").read()
+    k = raw.index(b"  header offset=")
+    e = raw.index(b"\n", k)
+    n = int(raw[k:e].split(b"=")[1])
+    nvar = int(raw[:k].split(b"number of variables=")[1].split(b"\n")[0])
+    pos, out = e + 1 + n, []
+    while pos < len(raw):
+        h = struct.unpack_from("<10i", raw, pos)
+        out.append(h)
+        nx = [h[1] - h[0] + 1, h[3] - h[2] + 1, h[5] - h[4] + 1]
+        pos += 40 + 48 + 4*nvar*nx[0]*nx[1]*nx[2]
+    assert pos == len(raw)
+    return out
+
+
+def test_refined_mesh_bin_and_rst_carry_block_levels(cpu_oracle_backend):
+    """binary.cpp:192-193 writes loc.level - root_level per block, restart.cpp:115-124 the LogicalLocation with
+    its level; a dump of a refined mesh that stores the root level for every block is placed at the wrong
+    resolution by bin_convert / a restarted run"""
+    from athenak_amd import outputs
+    from athenak_amd.main import load_deck
+    from athenak_amd.mesh import Mesh
+    with tempfile.TemporaryDirectory() as d:
+        _run_smr(d, [])
+        pin = load_deck("linear_wave_hydro_smr.athinput", [
+            "mesh/nx1=32", "mesh/nx2=16", "mesh/nx3=1", "meshblock/nx1=8", "meshblock/nx2=4", "meshblock/nx3=1",
+            "refined_region1/x1min=1.2", "refined_region1/x1max=1.8", "refined_region1/x2min=0.6",
+            "refined_region1/x2max=0.9"])
+        pm = Mesh(pin)
+        levels = [pm.level_of(g) for g in range(pm.nmb_total)]
+        assert pm.multilevel and len(set(levels)) == 2, levels
+        hdrs = _bin_block_headers(os.path.join(d, "bin", "LinWave.hydro_u.00001.bin"))
+        assert len(hdrs) == pm.nmb_total
+        for g, h in enumerate(hdrs):
+            assert tuple(h[6:9]) == tuple(pm.lloc_eachmb[g][:3])
+            assert h[9] == levels[g] - pm.root_level, (g, h[9], levels[g], pm.root_level)
+        if os.path.isdir(REF_PY):                  # the reference's own reader (build container only)
+            sys.path.insert(0, REF_PY)
+            import types
+            if "h5py" not in sys.modules:
+                try:
+                    import h5py  # noqa: F401
+                except ImportError:
+                    sys.modules["h5py"] = types.ModuleType("h5py")
+            import bin_convert
+            b = bin_convert.read_binary(os.path.join(d, "bin", "LinWave.hydro_u.00001.bin"))
+            assert b["n_mbs"] == pm.nmb_total
+            assert [int(x) for x in b["mb_logical"][:, 3]] == [l - pm.root_level for l in levels]
+        _, hdr, _ = outputs.read_restart(os.path.join(d, "rst", "LinWave.00001.rst"))
+        assert hdr["root_level"] == pm.root_level
+        assert [int(x) for x in hdr["lloc"][:, 3]] == levels
+        assert [tuple(int(x) for x in l[:3]) for l in hdr["lloc"]] == [tuple(l)[:3] for l in pm.lloc_eachmb]
+
+
+def test_refined_mesh_restart_roundtrip(cpu_oracle_backend):
+    """a run restarted from the middle dump of a refined-mesh run writes the same final restart file"""
+    from athenak_amd.__main__ import main
+    with tempfile.TemporaryDirectory() as d1, tempfile.TemporaryDirectory() as d2:
+        _run_smr(d1, [])
+        here = os.getcwd()
+        try:
+            rc = main(["-r", os.path.join(d1, "rst", "LinWave.00001.rst"), "-d", d2])
+            assert rc == 0
+        finally:
+            os.chdir(here)
+        a = open(os.path.join(d1, "rst", "LinWave.00002.rst"), "rb").read()
+        b = open(os.path.join(d2, "rst", "LinWave.00002.rst"), "rb").read()
+        assert a == b

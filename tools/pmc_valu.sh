@@ -19,3 +19,4 @@ for k, c in acc.items():
     m = {n: sum(v)/len(v) for n, v in c.items()}
     print("%-44s %10.3g %12.4g %12.4g %12.4g %10.3g %10.3g" % (k[:44], m.get("GRBM_GUI_ACTIVE", 0), m.get("SQ_INSTS_VALU", 0), m.get("SQ_ACTIVE_INST_VALU", 0), m.get("SQ_WAVE_CYCLES", 0), m.get("SQ_WAIT_INST_ANY", 0), m.get("SQ_WAIT_ANY", 0)))
 PY
+python $root/tools/valu_summary.py $out $tag $root/gpurun_out/${tag}_valu_counters.json
