@@ -243,6 +243,16 @@ class HipSmrKernels:
         self._call("akmi_smr_prolong_cc", C.byref(pack), C.byref(smr), nvar, capi._p(cu), capi._p(u),
                    capi._stream())
 
+    def c2p_coarse(self, pack, smr, nvar, cu, cb, cw):
+        f = (capi._p(cb.x1f), capi._p(cb.x2f), capi._p(cb.x3f)) if cb is not None else (None, None, None)
+        self._call("akmi_smr_c2p_coarse", C.byref(pack), C.byref(smr), nvar, capi._p(cu), *f, capi._p(cw),
+                   capi._stream())
+
+    def p2c_fine(self, pack, smr, nvar, w, b, u):
+        f = (capi._p(b.x1f), capi._p(b.x2f), capi._p(b.x3f)) if b is not None else (None, None, None)
+        self._call("akmi_smr_p2c_fine", C.byref(pack), C.byref(smr), nvar, capi._p(w), *f, capi._p(u),
+                   capi._stream())
+
     def prolong_fc(self, pack, smr, cb, b):
         self._call("akmi_smr_prolong_fc", C.byref(pack), C.byref(smr), capi._p(cb.x1f), capi._p(cb.x2f),
                    capi._p(cb.x3f), capi._p(b.x1f), capi._p(b.x2f), capi._p(b.x3f), capi._stream())
@@ -500,6 +510,14 @@ class MeshBoundaryValuesSMR:
 
     def ProlongateFC(self, b, cb):
         self.k.prolong_fc(self.pack_c, self.smr_c, cb, b)
+
+    def ConsToPrimCoarseBndry(self, cu, cb, cw):
+        """prolong_prims.cpp:35-186 (cb None: hydro), 303-461"""
+        self.k.c2p_coarse(self.pack_c, self.smr_c, self.nvar, cu, cb, cw)
+
+    def PrimToConsFineBndry(self, w, b, u):
+        """prolong_prims.cpp:190-296 (b None: hydro), 465-575"""
+        self.k.p2c_fine(self.pack_c, self.smr_c, self.nvar, w, b, u)
 
     def PackAndSendFluxCC(self, flx, face_shaped):
         self.k.pack_flux_cc(self.pack_c, self.smr_c, self.nvar, face_shaped, flx, self.buf[1])

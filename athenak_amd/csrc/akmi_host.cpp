@@ -216,9 +216,8 @@ Mesh::Mesh(ParameterInput *pin, int my_rank_, int nranks_, bool host_only_)
   std::string ref = "none";
   if (pin->DoesBlockExist("mesh_refinement")) ref = pin->GetOrAddString("mesh_refinement", "refinement", "none");
   if (ref == "static") {
-    if (pin->DoesParameterExist("mesh_refinement", "prolong_primitives") &&
-        pin->GetBoolean("mesh_refinement", "prolong_primitives"))
-      AKMI_FATAL("<mesh_refinement>/prolong_primitives is not on this build's path");
+    // mesh_refinement.cpp:52: prolongate primitive instead of conserved variables into fine ghost zones
+    prolong_prims = pin->GetOrAddBoolean("mesh_refinement", "prolong_primitives", false);
     multilevel = true;
     BuildTreeFromScratch(pin);                 // akmi_host_smr.cpp
   } else if (ref != "none") {
@@ -436,7 +435,7 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
 }
 FluidBase::~FluidBase() {
   u0.Free(); w0.Free(); u1.Free(); counters.Free(); dt3.Free(); ws.Free(); fofc.Free(); nfofc.Free();
-  dtmin_cond.Free(); coarse_u0.Free();
+  dtmin_cond.Free(); coarse_u0.Free(); coarse_w0.Free();
   delete psmr;
   delete pbval;
   delete peos;
@@ -923,6 +922,13 @@ TaskStatus Hydro::Prolongate(Driver *d, int stage) {       // hydro_tasks.cpp:38
   AKCHK(akmi_smr_fill_coarse_cc(&pack_c, &psmr->smr_c, nvars, u0.p, coarse_u0.p, stream));
   if (!pmy_pack->pmesh->strictly_periodic)               // HydroBCsCoarse: the BC helper on coarse indices
     AKCHK(akmi_hydro_bcs(&cpack_c, nvars, pmy_pack->pmb->d_bcs.p, coarse_u0.p, stream));
+  if (pmy_pack->pmesh->prolong_prims) {                   // hydro_tasks.cpp:388-392
+    if (!coarse_w0.p) coarse_w0.Realloc(coarse_u0.n);
+    AKCHK(akmi_smr_c2p_coarse(&pack_c, &psmr->smr_c, nvars, coarse_u0.p, nullptr, nullptr, nullptr, coarse_w0.p, stream));
+    AKCHK(akmi_smr_prolong_cc(&pack_c, &psmr->smr_c, nvars, coarse_w0.p, w0.p, stream));
+    AKCHK(akmi_smr_p2c_fine(&pack_c, &psmr->smr_c, nvars, w0.p, nullptr, nullptr, nullptr, u0.p, stream));
+    return TaskStatus::complete;
+  }
   AKCHK(akmi_smr_prolong_cc(&pack_c, &psmr->smr_c, nvars, coarse_u0.p, u0.p, stream));
   return TaskStatus::complete;
 }
@@ -1133,6 +1139,16 @@ TaskStatus MHD::Prolongate(Driver *d, int stage) {         // mhd_tasks.cpp:527-
     AKCHK(akmi_hydro_bcs(&cpack_c, nvars, pmy_pack->pmb->d_bcs.p, coarse_u0.p, stream));
     AKCHK(akmi_bfield_bcs(&cpack_c, pmy_pack->pmb->d_bcs.p, coarse_b0.x1f.p, coarse_b0.x2f.p, coarse_b0.x3f.p,
                           stream));
+  }
+  if (pmy_pack->pmesh->prolong_prims) {                   // mhd_tasks.cpp:539-544
+    if (!coarse_w0.p) coarse_w0.Realloc(coarse_u0.n);
+    AKCHK(akmi_smr_c2p_coarse(&pack_c, t, nvars, coarse_u0.p, coarse_b0.x1f.p, coarse_b0.x2f.p, coarse_b0.x3f.p,
+                              coarse_w0.p, stream));
+    AKCHK(akmi_smr_prolong_cc(&pack_c, t, nvars, coarse_w0.p, w0.p, stream));
+    AKCHK(akmi_smr_prolong_fc(&pack_c, t, coarse_b0.x1f.p, coarse_b0.x2f.p, coarse_b0.x3f.p, b0.x1f.p, b0.x2f.p,
+                              b0.x3f.p, stream));
+    AKCHK(akmi_smr_p2c_fine(&pack_c, t, nvars, w0.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, u0.p, stream));
+    return TaskStatus::complete;
   }
   AKCHK(akmi_smr_prolong_cc(&pack_c, t, nvars, coarse_u0.p, u0.p, stream));
   AKCHK(akmi_smr_prolong_fc(&pack_c, t, coarse_b0.x1f.p, coarse_b0.x2f.p, coarse_b0.x3f.p, b0.x1f.p, b0.x2f.p,

@@ -269,6 +269,7 @@ class Mesh {            // mesh.hpp:92-185
   bool one_d, two_d, three_d, multi_d, strictly_periodic;
   int nmb_rootx1, nmb_rootx2, nmb_rootx3, nmb_total;
   bool multilevel = false;        // <mesh_refinement>/refinement = static
+  bool prolong_prims = false;     // <mesh_refinement>/prolong_primitives (mesh_refinement.cpp:52)
   int root_level = 0, max_level = 0;
   std::unique_ptr<MeshBlockTree> ptree;
   std::vector<LogicalLocation> lloc_tree;   // multilevel: Z-ordered leaves with their levels
@@ -353,7 +354,7 @@ class FluidBase {
   // static mesh refinement: coarse buffers (hydro.cpp:300-310, mhd.cpp:368-380) + boundary values
   bool multilevel = false;
   akmi_pack cpack_c;                    // the coarse buffers as a pack of nx/2 cells (coarse BCs)
-  DvceArray<Real> coarse_u0;
+  DvceArray<Real> coarse_u0, coarse_w0;  // coarse_w0: <mesh_refinement>/prolong_primitives = true only
   MeshBoundaryValuesSMR *psmr = nullptr;
   MeshBoundaryValues *pbval = nullptr;  // off-rank neighbours (uniform meshes, nranks > 1)
   bool peers() const { return pbval && pbval->HasPeers(); }

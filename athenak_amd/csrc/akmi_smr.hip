@@ -277,6 +277,83 @@ k_smr_prolong_cc(SGeo s, Tab t, int nvar, const double *__restrict__ ca, double 
   }
 }
 
+// ---- <mesh_refinement>/prolong_primitives = true (src/bvals/prolong_prims.cpp) -------------------------
+// ConsToPrimCoarseBndry (:35-186 hydro, :303-461 MHD): the coarse cells the prolongation stencil of slot n
+// reads (iprol widened by one cell in every active direction) from conserved to primitive variables; the
+// cell-centred field is the average of the COARSE face fields; floors act on the primitives only (the coarse
+// conserved array is scratch, :164-165), except that negative passive scalars are zeroed in place (:173-176).
+// Ideal gas (the reference calls SingleC2P_IdealHyd / _IdealMHD unconditionally).
+__global__ void __launch_bounds__(256)
+k_smr_c2p_coarse(SGeo s, Tab t, Eos eos, int nvar, int mhd, double *__restrict__ cu, CF3 cb, double *__restrict__ cw) {
+  const int n = blockIdx.x%t.nnghbr, m = blockIdx.x/t.nnghbr;
+  if (NGID(t, m, n) < 0 || !(NLEV(t, m, n) < t.lev[m])) return;
+  Bx b = box_of(t.cc, T_RECV, K_PROL, n, 0);
+  b.il -= 1; b.iu += 1;
+  if (s.multi_d) { b.jl -= 1; b.ju += 1; }
+  if (s.three_d) { b.kl -= 1; b.ku += 1; }
+  const int cnt = bcount(b);
+  for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+    int k, j, i;
+    bdecode(b, e, k, j, i);
+    double ud = cu[c5(s, 1, nvar, m, 0, k, j, i)], ue = cu[c5(s, 1, nvar, m, 4, k, j, i)];
+    const double umx = cu[c5(s, 1, nvar, m, 1, k, j, i)], umy = cu[c5(s, 1, nvar, m, 2, k, j, i)],
+                 umz = cu[c5(s, 1, nvar, m, 3, k, j, i)];
+    double wd, wx, wy, wz, we;
+    bool f1 = false, f2 = false, f3 = false;
+    if (mhd) {
+      const double bx = 0.5*(cb.b[0][f4(s, 1, 0, m, k, j, i)] + cb.b[0][f4(s, 1, 0, m, k, j, i + 1)]);
+      const double by = 0.5*(cb.b[1][f4(s, 1, 1, m, k, j, i)] + cb.b[1][f4(s, 1, 1, m, k, j + 1, i)]);
+      const double bz = 0.5*(cb.b[2][f4(s, 1, 2, m, k, j, i)] + cb.b[2][f4(s, 1, 2, m, k + 1, j, i)]);
+      c2p_mhd(eos, ud, umx, umy, umz, ue, bx, by, bz, wd, wx, wy, wz, we, f1, f2, f3);
+    } else {
+      c2p_hyd(eos, ud, umx, umy, umz, ue, wd, wx, wy, wz, we, f1, f2, f3);
+    }
+    cw[c5(s, 1, nvar, m, 0, k, j, i)] = wd; cw[c5(s, 1, nvar, m, 1, k, j, i)] = wx;
+    cw[c5(s, 1, nvar, m, 2, k, j, i)] = wy; cw[c5(s, 1, nvar, m, 3, k, j, i)] = wz;
+    cw[c5(s, 1, nvar, m, 4, k, j, i)] = we;
+    for (int v = 5; v < nvar; ++v) {
+      double sc = cu[c5(s, 1, nvar, m, v, k, j, i)];
+      if (sc < 0.0) { sc = 0.0; cu[c5(s, 1, nvar, m, v, k, j, i)] = 0.0; }
+      cw[c5(s, 1, nvar, m, v, k, j, i)] = sc/ud;
+    }
+  }
+}
+
+// PrimToConsFineBndry (:190-296 hydro, :465-575 MHD): the fine ghost cells slot n prolongated, back to conserved
+// variables (SingleP2C_IdealHyd / _IdealMHD, src/eos/ideal_c2p_hyd.hpp:76-83, ideal_c2p_mhd.hpp:76-84); the
+// cell-centred field is the average of the FINE face fields, which ProlongateFC has filled before.
+__global__ void __launch_bounds__(256)
+k_smr_p2c_fine(SGeo s, Tab t, int nvar, int mhd, const double *__restrict__ w, CF3 fb, double *__restrict__ u) {
+  const int n = blockIdx.x%t.nnghbr, m = blockIdx.x/t.nnghbr;
+  if (NGID(t, m, n) < 0 || !(NLEV(t, m, n) < t.lev[m])) return;
+  const Bx c = box_of(t.cc, T_RECV, K_PROL, n, 0);
+  Bx b;
+  b.il = (c.il - s.cis)*2 + s.is; b.iu = (c.iu - s.cis)*2 + s.is + 1;
+  b.jl = (c.jl - s.cjs)*2 + s.js; b.ju = (c.ju - s.cjs)*2 + s.js + (s.multi_d ? 1 : 0);
+  b.kl = (c.kl - s.cks)*2 + s.ks; b.ku = (c.ku - s.cks)*2 + s.ks + (s.three_d ? 1 : 0);
+  const int cnt = bcount(b);
+  for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+    int k, j, i;
+    bdecode(b, e, k, j, i);
+    const double d = w[c5(s, 0, nvar, m, 0, k, j, i)], vx = w[c5(s, 0, nvar, m, 1, k, j, i)],
+                 vy = w[c5(s, 0, nvar, m, 2, k, j, i)], vz = w[c5(s, 0, nvar, m, 3, k, j, i)],
+                 ei = w[c5(s, 0, nvar, m, 4, k, j, i)];
+    u[c5(s, 0, nvar, m, 0, k, j, i)] = d;
+    u[c5(s, 0, nvar, m, 1, k, j, i)] = d*vx;
+    u[c5(s, 0, nvar, m, 2, k, j, i)] = d*vy;
+    u[c5(s, 0, nvar, m, 3, k, j, i)] = d*vz;
+    if (mhd) {
+      const double bx = 0.5*(fb.b[0][f4(s, 0, 0, m, k, j, i)] + fb.b[0][f4(s, 0, 0, m, k, j, i + 1)]);
+      const double by = 0.5*(fb.b[1][f4(s, 0, 1, m, k, j, i)] + fb.b[1][f4(s, 0, 1, m, k, j + 1, i)]);
+      const double bz = 0.5*(fb.b[2][f4(s, 0, 2, m, k, j, i)] + fb.b[2][f4(s, 0, 2, m, k + 1, j, i)]);
+      u[c5(s, 0, nvar, m, 4, k, j, i)] = ei + 0.5*(d*(sqr(vx) + sqr(vy) + sqr(vz)) + (sqr(bx) + sqr(by) + sqr(bz)));
+    } else {
+      u[c5(s, 0, nvar, m, 4, k, j, i)] = ei + 0.5*d*(sqr(vx) + sqr(vy) + sqr(vz));
+    }
+    for (int v = 5; v < nvar; ++v) u[c5(s, 0, nvar, m, v, k, j, i)] = d*w[c5(s, 0, nvar, m, v, k, j, i)];
+  }
+}
+
 // offsets of slot n (the inverse of NeighborIndex, prolongation.cpp:28-53), passed as a table by the host
 struct Owned {
   const SGeo &s; const Tab &t; int m, ox1, ox2, ox3, mylev;
@@ -678,6 +755,37 @@ int akmi_smr_prolong_cc(const akmi_pack *p, const akmi_smr *t, int nvar, const d
   const Tab tb = make_tab(p, t);
   k_smr_prolong_cc<<<(unsigned)p->nmb*tb.nnghbr*nvar, 256, 0, (hipStream_t)stream>>>(make_sgeo(p), tb, nvar, cu, u);
   AKMI_CHECK_LAUNCH("smr_prolong_cc");
+  return AKMI_COMPLETE;
+}
+
+static int check_prims(const akmi_pack *p, int nvar, const char *who) {
+  if (!p->is_ideal || nvar < 5) {
+    // prolong_prims.cpp converts with SingleC2P_IdealHyd / _IdealMHD whatever the EOS of the run is
+    set_error("%s: prolong_primitives needs the ideal-gas EOS (5 fluid variables)", who);
+    return AKMI_FAIL;
+  }
+  return AKMI_COMPLETE;
+}
+
+int akmi_smr_c2p_coarse(const akmi_pack *p, const akmi_smr *t, int nvar, double *cu, const double *cb1,
+                        const double *cb2, const double *cb3, double *cw, void *stream) {
+  if (check_smr(p, t, "smr_c2p_coarse") != AKMI_COMPLETE || check_prims(p, nvar, "smr_c2p_coarse") != AKMI_COMPLETE)
+    return AKMI_FAIL;
+  const Tab tb = make_tab(p, t);
+  k_smr_c2p_coarse<<<(unsigned)p->nmb*tb.nnghbr, 256, 0, (hipStream_t)stream>>>(
+      make_sgeo(p), tb, make_eos(p), nvar, cb1 != nullptr, cu, CF3{{cb1, cb2, cb3}}, cw);
+  AKMI_CHECK_LAUNCH("smr_c2p_coarse");
+  return AKMI_COMPLETE;
+}
+
+int akmi_smr_p2c_fine(const akmi_pack *p, const akmi_smr *t, int nvar, const double *w, const double *b1,
+                      const double *b2, const double *b3, double *u, void *stream) {
+  if (check_smr(p, t, "smr_p2c_fine") != AKMI_COMPLETE || check_prims(p, nvar, "smr_p2c_fine") != AKMI_COMPLETE)
+    return AKMI_FAIL;
+  const Tab tb = make_tab(p, t);
+  k_smr_p2c_fine<<<(unsigned)p->nmb*tb.nnghbr, 256, 0, (hipStream_t)stream>>>(
+      make_sgeo(p), tb, nvar, b1 != nullptr, w, CF3{{b1, b2, b3}}, u);
+  AKMI_CHECK_LAUNCH("smr_p2c_fine");
   return AKMI_COMPLETE;
 }
 

@@ -263,13 +263,21 @@ class Hydro(FluidBase):
         return TaskStatus.complete
 
     def Prolongate(self, pdrive, stage):
-        """hydro_tasks.cpp:381-400 (conserved variables; prolong_primitives is refused)"""
+        """hydro_tasks.cpp:381-400"""
         if self.multilevel:
             self.psmr.FillCoarseInBndryCC(self.u0, self.coarse_u0)
             if not self.pmy_pack.pmesh.strictly_periodic:
                 self.pbval_u.k.hydro_bcs(self.cpack_c, self.nvars, self.pbval_u.bcs, self.coarse_u0,
                                          self.pbval_u.u_in)
-            self.psmr.ProlongateCC(self.u0, self.coarse_u0)
+            if self.pmy_pack.pmesh.prolong_prims:          # hydro_tasks.cpp:388-392
+                if getattr(self, "coarse_w0", None) is None:
+                    import torch
+                    self.coarse_w0 = torch.zeros_like(self.coarse_u0)
+                self.psmr.ConsToPrimCoarseBndry(self.coarse_u0, None, self.coarse_w0)
+                self.psmr.ProlongateCC(self.w0, self.coarse_w0)
+                self.psmr.PrimToConsFineBndry(self.w0, None, self.u0)
+            else:
+                self.psmr.ProlongateCC(self.u0, self.coarse_u0)
         return TaskStatus.complete
 
     def CopyCons(self, pdrive, stage):

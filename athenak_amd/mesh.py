@@ -232,6 +232,7 @@ class Mesh:
 
     def __init__(self, pin, my_rank=0, nranks=1):
         self.my_rank, self.nranks = my_rank, nranks
+        self.pin = pin
         g = pin.GetReal
         self.mesh_size = RegionSize(g("mesh", "x1min"), g("mesh", "x1max"), g("mesh", "x2min"),
                                     g("mesh", "x2max"), g("mesh", "x3min"), g("mesh", "x3max"))
@@ -269,6 +270,7 @@ class Mesh:
         self.nmb_rootx1, self.nmb_rootx2, self.nmb_rootx3 = nx1//mbx1, nx2//mbx2, nx3//mbx3
         self.nmb_total = self.nmb_rootx1*self.nmb_rootx2*self.nmb_rootx3
         self.multilevel = False
+        self.prolong_prims = False
         self.adaptive = False
         self.root_level = 0
         self.ptree = None
@@ -278,10 +280,8 @@ class Mesh:
         if ref == "static":
             # Mesh::BuildTreeFromScratch with <refined_region*> blocks, build_tree.cpp:32-258
             from .mesh_tree import BuildTreeFromScratch
-            if pin.DoesParameterExist("mesh_refinement", "prolong_primitives") and \
-                    pin.GetBoolean("mesh_refinement", "prolong_primitives"):
-                raise RuntimeError("### FATAL ERROR <mesh_refinement>/prolong_primitives is not on this "
-                                   "build's path")
+            # mesh_refinement.cpp:52: prolongate primitive instead of conserved variables into fine ghost zones
+            self.prolong_prims = pin.GetOrAddBoolean("mesh_refinement", "prolong_primitives", False)
             if ng % 2:
                 raise RuntimeError("### FATAL ERROR Number of ghost cells must be divisible by two for "
                                    "SMR/AMR calculations")

@@ -132,7 +132,7 @@ class MHD(FluidBase):
         return TaskStatus.complete
 
     def Prolongate(self, pdrive, stage):
-        """mhd_tasks.cpp:527-552 (conserved variables; prolong_primitives is refused)"""
+        """mhd_tasks.cpp:527-552"""
         if self.multilevel:
             ps, pb = self.psmr, self.pbval_u
             ps.FillCoarseInBndryCC(self.u0, self.coarse_u0)
@@ -141,8 +141,17 @@ class MHD(FluidBase):
                 pb.k.hydro_bcs(self.cpack_c, self.nvars, pb.bcs, self.coarse_u0, pb.u_in)
                 pb.k.bfield_bcs(self.cpack_c, pb.bcs, self.coarse_b0.x1f, self.coarse_b0.x2f,
                                 self.coarse_b0.x3f, pb.b_in)
-            ps.ProlongateCC(self.u0, self.coarse_u0)
-            ps.ProlongateFC(self.b0, self.coarse_b0)
+            if self.pmy_pack.pmesh.prolong_prims:          # mhd_tasks.cpp:539-544
+                if getattr(self, "coarse_w0", None) is None:
+                    import torch
+                    self.coarse_w0 = torch.zeros_like(self.coarse_u0)
+                ps.ConsToPrimCoarseBndry(self.coarse_u0, self.coarse_b0, self.coarse_w0)
+                ps.ProlongateCC(self.w0, self.coarse_w0)
+                ps.ProlongateFC(self.b0, self.coarse_b0)
+                ps.PrimToConsFineBndry(self.w0, self.b0, self.u0)
+            else:
+                ps.ProlongateCC(self.u0, self.coarse_u0)
+                ps.ProlongateFC(self.b0, self.coarse_b0)
         return TaskStatus.complete
 
     def _b(self, f):

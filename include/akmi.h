@@ -343,6 +343,17 @@ int akmi_smr_prolong_cc(const akmi_pack *p, const akmi_smr *t, int nvar, const d
                         void *stream);
 int akmi_smr_prolong_fc(const akmi_pack *p, const akmi_smr *t, const double *cb1, const double *cb2,
                         const double *cb3, double *b1, double *b2, double *b3, void *stream);
+/* <mesh_refinement>/prolong_primitives = true: the two conversions MHD::Prolongate / Hydro::Prolongate put
+ * round ProlongateCC (src/mhd/mhd_tasks.cpp:539-544, src/hydro/hydro_tasks.cpp:388-392).
+ * ConsToPrimCoarseBndry (src/bvals/prolong_prims.cpp:35-186, 303-461): coarse conserved -> coarse primitive
+ * variables on the cells the prolongation of every slot with a coarser neighbour reads (iprol widened by one);
+ * cb1..3 = coarse face fields (NULL: hydro); cu is only modified where a passive scalar is negative.
+ * PrimToConsFineBndry (:190-296, 465-575): the prolongated fine ghost cells of w back to conserved variables
+ * in u; b1..3 = fine face fields after ProlongateFC (NULL: hydro).  Ideal gas only, as in the reference. */
+int akmi_smr_c2p_coarse(const akmi_pack *p, const akmi_smr *t, int nvar, double *cu, const double *cb1,
+                        const double *cb2, const double *cb3, double *cw, void *stream);
+int akmi_smr_p2c_fine(const akmi_pack *p, const akmi_smr *t, int nvar, const double *w, const double *b1,
+                      const double *b2, const double *b3, double *u, void *stream);
 /* SendFlux+RecvFlux (PackAndSendFluxCC + RecvAndUnpackFluxCC, src/bvals/flux_correct_cc.cpp:29-304):
  * the fluxes on faces shared with finer neighbours are replaced by the restricted fine fluxes.
  * face_shaped: MHD flux arrays (N+1 along their direction), 0: hydro (cell-shaped).  buf: layout[1] */

@@ -195,6 +195,7 @@ typedef struct akref_params {
    * smr_nghbr[m][n] = {gid, level, dest} with n the NeighborIndex slot (56 per block) */
   int smr_nmb, smr_root_level;
   const int *smr_lloc, *smr_nghbr;
+  int prolong_prims;               /* <mesh_refinement>/prolong_primitives (mesh_refinement.cpp:52, default false) */
 } akref_params;
 
 typedef struct akref_sim akref_sim;
@@ -227,6 +228,14 @@ int akref_smr_exchange_fc(const akmi_pack *p, const akmi_smr *t, double *b1, dou
 int akref_smr_fill_coarse_cc_t(const akmi_pack *p, const akmi_smr *t, int nvar, const double *u, double *cu);
 int akref_smr_fill_coarse_fc_t(const akmi_pack *p, const akmi_smr *t, const double *b1, const double *b2,
                                const double *b3, double *cb1, double *cb2, double *cb3);
+int akref_smr_c2p_coarse(akref_smr *s, const akmi_pack *p, double *cu, const double *cb1, const double *cb2,
+                         const double *cb3, double *cw);
+int akref_smr_p2c_fine(akref_smr *s, const double *w, const double *b1, const double *b2, const double *b3,
+                       double *u);
+int akref_smr_c2p_coarse_t(const akmi_pack *p, const akmi_smr *t, int nvar, double *cu, const double *cb1,
+                           const double *cb2, const double *cb3, double *cw);
+int akref_smr_p2c_fine_t(const akmi_pack *p, const akmi_smr *t, int nvar, const double *w, const double *b1,
+                         const double *b2, const double *b3, double *u);
 int akref_smr_prolong_cc_t(const akmi_pack *p, const akmi_smr *t, int nvar, const double *cu, double *u);
 int akref_smr_prolong_fc_t(const akmi_pack *p, const akmi_smr *t, const double *cb1, const double *cb2,
                            const double *cb3, double *b1, double *b2, double *b3);

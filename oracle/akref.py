@@ -59,7 +59,7 @@ class Params(C.Structure):
                 ("outer_radius", C.c_double),
                 ("split_kernels", C.c_int),
                 ("smr_nmb", C.c_int), ("smr_root_level", C.c_int),
-                ("smr_lloc", C.c_void_p), ("smr_nghbr", C.c_void_p)]
+                ("smr_lloc", C.c_void_p), ("smr_nghbr", C.c_void_p), ("prolong_prims", C.c_int)]
 
 
 def build(force=False):

@@ -38,7 +38,7 @@ struct akref_sim {
   int multilevel, root_level;
   int *lev;                        /* [nmb] logical level of each block */
   akref_smr *smr;
-  double *cu0, *cw0, *cb0[3];      /* coarse_u0, coarse_w0 (unused: no prolong_prims), coarse_b0 */
+  double *cu0, *cw0, *cb0[3];      /* coarse_u0, coarse_w0 (prolong_prims only), coarse_b0 */
   akmi_pack cpack;                 /* the coarse arrays seen as a pack of nx/2 cells (for the BCs) */
 };
 
@@ -227,6 +227,7 @@ akref_sim *akref_create(const akref_params *par) {
     const int cN1 = s->cpack.nx1 + 2*ng, cN2 = s->multi_d ? s->cpack.nx2 + 2*ng : 1,
               cN3 = s->three_d ? s->cpack.nx3 + 2*ng : 1;
     s->cu0 = dalloc((size_t)nmb*nv*cN3*cN2*cN1);
+    s->cw0 = p->prolong_prims ? dalloc((size_t)nmb*nv*cN3*cN2*cN1) : NULL;
     if (p->is_mhd) {
       s->cb0[0] = dalloc((size_t)nmb*cN3*cN2*(cN1+1));
       s->cb0[1] = dalloc((size_t)nmb*cN3*(cN2+1)*cN1);
@@ -262,7 +263,7 @@ void akref_destroy(akref_sim *s) {
   if (!s) return;
   free(s->lloc); free(s->nghbr); free(s->bcs); free(s->dx); free(s->xmin);
   free(s->u0); free(s->w0); free(s->u1); free(s->flx1); free(s->flx2); free(s->flx3);
-  free(s->bcc0); free(s->fofc); free(s->lev); free(s->cu0);
+  free(s->bcc0); free(s->fofc); free(s->lev); free(s->cu0); free(s->cw0);
   for (int q = 0; q < 3; ++q) free(s->cb0[q]);
   akref_smr_destroy(s->smr);
   for (int q = 0; q < 3; ++q) { free(s->b0[q]); free(s->b1[q]); free(s->e[q]); }
@@ -809,6 +810,14 @@ static void smr_prolongate(akref_sim *s) {
   if (!strictly_periodic(s)) {            /* HydroBCsCoarse / BFieldBCsCoarse: the BC helpers on coarse indices */
     akref_hydro_bcs(&s->cpack, s->nv, s->bcs, s->cu0);
     if (mhd) akref_bfield_bcs(&s->cpack, s->bcs, s->cb0[0], s->cb0[1], s->cb0[2]);
+  }
+  if (s->par.prolong_prims) {             /* mhd_tasks.cpp:539-544, hydro_tasks.cpp:388-392 */
+    akref_smr_c2p_coarse(s->smr, &s->pack, s->cu0, mhd ? s->cb0[0] : NULL, mhd ? s->cb0[1] : NULL,
+                         mhd ? s->cb0[2] : NULL, s->cw0);
+    akref_smr_prolong_cc(s->smr, s->w0, s->cw0);
+    if (mhd) akref_smr_prolong_fc(s->smr, s->b0[0], s->b0[1], s->b0[2], s->cb0[0], s->cb0[1], s->cb0[2]);
+    akref_smr_p2c_fine(s->smr, s->w0, mhd ? s->b0[0] : NULL, mhd ? s->b0[1] : NULL, mhd ? s->b0[2] : NULL, s->u0);
+    return;
   }
   akref_smr_prolong_cc(s->smr, s->u0, s->cu0);
   if (mhd) akref_smr_prolong_fc(s->smr, s->b0[0], s->b0[1], s->b0[2], s->cb0[0], s->cb0[1], s->cb0[2]);

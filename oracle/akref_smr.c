@@ -1090,6 +1090,106 @@ int akref_smr_fill_coarse_fc_t(const akmi_pack *p, const akmi_smr *t, const doub
   akref_smr_destroy(s);
   return 0;
 }
+/* ---- <mesh_refinement>/prolong_primitives = true, src/bvals/prolong_prims.cpp ----------------------------- *
+ * SingleC2P_IdealHyd (src/eos/ideal_c2p_hyd.hpp:22-66) / SingleC2P_IdealMHD (ideal_c2p_mhd.hpp:20-67) on one
+ * state; u[0..4] = d,mx,my,mz,E (d is floored in place, as the reference's by-reference argument is),
+ * bcc = NULL: hydro */
+static void single_c2p_ideal(const akmi_pack *p, double *u, const double *bcc, double *w) {
+  const double gm1 = p->gamma - 1.0;
+  const double efloor = p->pfloor/gm1;
+  double dfl = p->dfloor, e_m = 0.0;
+  if (bcc) {
+    const double b2 = bcc[0]*bcc[0] + bcc[1]*bcc[1] + bcc[2]*bcc[2];
+    dfl = fmax(p->dfloor, b2/p->sigma_max);
+    e_m = 0.5*(bcc[0]*bcc[0] + bcc[1]*bcc[1] + bcc[2]*bcc[2]);
+  }
+  if (u[0] < dfl) u[0] = dfl;
+  w[0] = u[0];
+  const double di = 1.0/u[0];
+  w[1] = di*u[1]; w[2] = di*u[2]; w[3] = di*u[3];
+  const double e_k = 0.5*di*(u[1]*u[1] + u[2]*u[2] + u[3]*u[3]);
+  w[4] = bcc ? (u[4] - e_k - e_m) : (u[4] - e_k);
+  if (w[4] < efloor) w[4] = efloor;
+  if (gm1*w[4]*di < p->tfloor) w[4] = w[0]*p->tfloor/gm1;
+  const double spe_over_eps = gm1/pow(w[0], gm1);
+  const double spe = spe_over_eps*w[4]*di;
+  if (spe <= p->sfloor) w[4] = w[0]*p->sfloor/spe_over_eps;
+}
+#define FC1(a,m,k,j,i) (a)[((((size_t)(m)*s->cN3 + (k))*s->cN2 + (j))*(s->cN1 + 1) + (i))]
+#define FC2(a,m,k,j,i) (a)[((((size_t)(m)*s->cN3 + (k))*(s->cN2 + 1) + (j))*s->cN1 + (i))]
+#define FC3(a,m,k,j,i) (a)[((((size_t)(m)*(s->cN3 + 1) + (k))*s->cN2 + (j))*s->cN1 + (i))]
+#define FF1(a,m,k,j,i) (a)[((((size_t)(m)*s->N3 + (k))*s->N2 + (j))*(s->N1 + 1) + (i))]
+#define FF2(a,m,k,j,i) (a)[((((size_t)(m)*s->N3 + (k))*(s->N2 + 1) + (j))*s->N1 + (i))]
+#define FF3(a,m,k,j,i) (a)[((((size_t)(m)*(s->N3 + 1) + (k))*s->N2 + (j))*s->N1 + (i))]
+/* ConsToPrimCoarseBndry, prolong_prims.cpp:35-186 (hydro), 303-461 (MHD) */
+int akref_smr_c2p_coarse(akref_smr *s, const akmi_pack *p, double *cu, const double *cb1, const double *cb2,
+                         const double *cb3, double *cw) {
+  const int nvar = s->cc.nvar;
+  for (int m = 0; m < s->nmb; ++m) for (int n = 0; n < s->nnghbr; ++n) {
+    if (!(s->gid[NG(m,n)] >= 0 && s->lev[NG(m,n)] < s->mblev[m])) continue;
+    const bi_t *x = &s->cc.recvbuf[n].iprol[0];
+    int il = x->bis - 1, iu = x->bie + 1, jl = x->bjs, ju = x->bje, kl = x->bks, ku = x->bke;
+    if (s->multi_d) { jl -= 1; ju += 1; }
+    if (s->three_d) { kl -= 1; ku += 1; }
+    for (int k = kl; k <= ku; ++k) for (int j = jl; j <= ju; ++j) for (int i = il; i <= iu; ++i) {
+      double u[5], w[5], bcc[3];
+      for (int v = 0; v < 5; ++v) u[v] = C5(cu,nvar,m,v,k,j,i);
+      if (cb1) {
+        bcc[0] = 0.5*(FC1(cb1,m,k,j,i) + FC1(cb1,m,k,j,i+1));
+        bcc[1] = 0.5*(FC2(cb2,m,k,j,i) + FC2(cb2,m,k,j+1,i));
+        bcc[2] = 0.5*(FC3(cb3,m,k,j,i) + FC3(cb3,m,k+1,j,i));
+      }
+      single_c2p_ideal(p, u, cb1 ? bcc : NULL, w);
+      for (int v = 0; v < 5; ++v) C5(cw,nvar,m,v,k,j,i) = w[v];
+      for (int v = 5; v < nvar; ++v) {
+        if (C5(cu,nvar,m,v,k,j,i) < 0.0) C5(cu,nvar,m,v,k,j,i) = 0.0;
+        C5(cw,nvar,m,v,k,j,i) = C5(cu,nvar,m,v,k,j,i)/u[0];
+      }
+    }
+  }
+  return 0;
+}
+/* PrimToConsFineBndry, prolong_prims.cpp:190-296 (hydro), 465-575 (MHD); SingleP2C_IdealHyd / _IdealMHD */
+int akref_smr_p2c_fine(akref_smr *s, const double *w, const double *b1, const double *b2, const double *b3,
+                       double *u) {
+  const int nvar = s->cc.nvar;
+  for (int m = 0; m < s->nmb; ++m) for (int n = 0; n < s->nnghbr; ++n) {
+    if (!(s->gid[NG(m,n)] >= 0 && s->lev[NG(m,n)] < s->mblev[m])) continue;
+    const bi_t *x = &s->cc.recvbuf[n].iprol[0];
+    const int il = (x->bis - s->cis)*2 + s->is, iu = (x->bie - s->cis)*2 + s->is + 1;
+    const int jl = (x->bjs - s->cjs)*2 + s->js, ju = (x->bje - s->cjs)*2 + s->js + (s->multi_d ? 1 : 0);
+    const int kl = (x->bks - s->cks)*2 + s->ks, ku = (x->bke - s->cks)*2 + s->ks + (s->three_d ? 1 : 0);
+    for (int k = kl; k <= ku; ++k) for (int j = jl; j <= ju; ++j) for (int i = il; i <= iu; ++i) {
+      const double d = A5(w,nvar,m,0,k,j,i), vx = A5(w,nvar,m,1,k,j,i), vy = A5(w,nvar,m,2,k,j,i),
+                   vz = A5(w,nvar,m,3,k,j,i), e = A5(w,nvar,m,4,k,j,i);
+      A5(u,nvar,m,0,k,j,i) = d; A5(u,nvar,m,1,k,j,i) = d*vx; A5(u,nvar,m,2,k,j,i) = d*vy; A5(u,nvar,m,3,k,j,i) = d*vz;
+      if (b1) {
+        const double bx = 0.5*(FF1(b1,m,k,j,i) + FF1(b1,m,k,j,i+1));
+        const double by = 0.5*(FF2(b2,m,k,j,i) + FF2(b2,m,k,j+1,i));
+        const double bz = 0.5*(FF3(b3,m,k,j,i) + FF3(b3,m,k+1,j,i));
+        A5(u,nvar,m,4,k,j,i) = e + 0.5*(d*(vx*vx + vy*vy + vz*vz) + (bx*bx + by*by + bz*bz));
+      } else {
+        A5(u,nvar,m,4,k,j,i) = e + 0.5*d*(vx*vx + vy*vy + vz*vz);
+      }
+      for (int v = 5; v < nvar; ++v) A5(u,nvar,m,v,k,j,i) = d*A5(w,nvar,m,v,k,j,i);
+    }
+  }
+  return 0;
+}
+int akref_smr_c2p_coarse_t(const akmi_pack *p, const akmi_smr *t, int nvar, double *cu, const double *cb1,
+                           const double *cb2, const double *cb3, double *cw) {
+  akref_smr *s = from_desc(p, t, nvar);
+  akref_smr_c2p_coarse(s, p, cu, cb1, cb2, cb3, cw);
+  akref_smr_destroy(s);
+  return 0;
+}
+int akref_smr_p2c_fine_t(const akmi_pack *p, const akmi_smr *t, int nvar, const double *w, const double *b1,
+                         const double *b2, const double *b3, double *u) {
+  akref_smr *s = from_desc(p, t, nvar);
+  akref_smr_p2c_fine(s, w, b1, b2, b3, u);
+  akref_smr_destroy(s);
+  return 0;
+}
 int akref_smr_prolong_cc_t(const akmi_pack *p, const akmi_smr *t, int nvar, const double *cu, double *u) {
   akref_smr *s = from_desc(p, t, nvar);
   akref_smr_prolong_cc(s, u, cu);

@@ -24,7 +24,7 @@ class OracleAsAkmi:
             raise AttributeError(name)
         # handle-based oracle functions own the plain names of these: their ABI twins end in _t
         twin = {"akmi_smr_fill_coarse_cc", "akmi_smr_fill_coarse_fc", "akmi_smr_prolong_cc",
-                "akmi_smr_prolong_fc", "akmi_smr_flux_cc"}
+                "akmi_smr_prolong_fc", "akmi_smr_flux_cc", "akmi_smr_c2p_coarse", "akmi_smr_p2c_fine"}
         fn = getattr(self.R, "akref_" + name[5:] + ("_t" if name in twin else ""))
         if name.endswith("segsize"):
             fn.restype = C.c_longlong

@@ -125,3 +125,38 @@ def cons_from_prim(g, w, bcc=None):
     if bcc is not None:
         E = E + 0.5*(bcc[0]**2 + bcc[1]**2 + bcc[2]**2)
     return np.stack([r, r*vx, r*vy, r*vz, E])
+
+
+# ---------------------------------------------------------------------------------------------
+def plm_van_leer(q):
+    """Piecewise-linear face values of a row of cell averages with van Leer's harmonic limiter in its
+    flux-limiter form (van Leer 1974; LeVeque 2002 eq. 6.39b): slope_i = phi(r_i) * (q_{i+1} - q_i),
+    r_i = (q_i - q_{i-1}) / (q_{i+1} - q_i), phi(r) = (r + |r|) / (1 + |r|).  Returns (left, right) edge
+    values of every cell (ends unused)."""
+    q = np.asarray(q, dtype=float)
+    dL = np.zeros_like(q)
+    dR = np.zeros_like(q)
+    dL[1:] = q[1:] - q[:-1]
+    dR[:-1] = q[1:] - q[:-1]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = dL/dR
+        phi = (r + np.abs(r))/(1.0 + np.abs(r))
+        slope = np.where(dR != 0.0, phi*dR, 0.0)
+    slope = np.where(np.isfinite(slope), slope, 0.0)
+    slope = np.where(dL*dR > 0.0, slope, 0.0)
+    return q - 0.5*slope, q + 0.5*slope
+
+
+def faraday_circulation(E, axis, d):
+    """-(1/area) * closed line integral of E around every face normal to `axis`, counter-clockwise seen from
+    +axis (Stokes: dB_n/dt = -(curl E)_n).  E[c] = component c on the edges parallel to c, as arrays whose
+    index (k, j, i) is the edge at the LOW corner of cell (k, j, i) in the two directions transverse to c;
+    all three are cropped to a common cell-shaped (K, J, I) + 1 layout by the caller.  Array axes: x1 is the
+    last.  Returns dB_n/dt on the low face of every cell."""
+    b, c = (axis + 1) % 3, (axis + 2) % 3            # (n, b, c) right-handed
+    ax = {0: 2, 1: 1, 2: 0}
+    Eb, Ec = E[b], E[c]
+    hi = lambda A, comp: np.roll(A, -1, axis=ax[comp])
+    # walk: along +b at low c, along +c at high b, along -b at high c, along -c at low b
+    circ = Eb*d[b] + hi(Ec, b)*d[c] - hi(Eb, c)*d[b] - Ec*d[c]
+    return -circ/(d[b]*d[c])

@@ -79,6 +79,9 @@ def oracle_kwargs(pin):
             kw[dc] = g(blk, dc)
     if pin.DoesParameterExist(blk, "fofc") and pin.GetBoolean(blk, "fofc"):
         kw["fofc"] = 1
+    if pin.DoesParameterExist("mesh_refinement", "prolong_primitives") and \
+            pin.GetBoolean("mesh_refinement", "prolong_primitives"):
+        kw["prolong_prims"] = 1
     name = gs("problem", "pgen_name")
     kw["pgen"] = name
     P = lambda k, d=0.0: (g("problem", k) if pin.DoesParameterExist("problem", k) else d)
@@ -98,16 +101,31 @@ def oracle_kwargs(pin):
     return kw
 
 
-def smr_tables(pm):
-    """the mesh tree of a multilevel product Mesh as the oracle takes it: Z-ordered leaves and the
-    56-slot neighbour table {gid, level, dest} (gid == index: one pack holds the whole mesh)"""
+def product_smr_tables(pm):
+    """the product's own tree: Z-ordered leaves and 56-slot neighbour table {gid, level, dest}"""
     nmb = pm.nmb_total
     lloc = np.array([[l.lx1, l.lx2, l.lx3, l.level] for l in pm.lloc_eachmb], dtype=np.int32)
     ng = -np.ones((nmb, 56, 3), dtype=np.int32)
     for m in range(nmb):
         for n, nb in pm.pmb_pack.pmb.nghbr[m].items():
             ng[m, n] = (nb.gid, nb.lev, nb.dest)
-    return dict(smr_lloc=lloc, smr_nghbr=ng, smr_root_level=pm.root_level)
+    return lloc, ng
+
+
+def smr_tables(pm, pin=None):
+    """What the ORACLE is given for a refined mesh: the leaves and the neighbour table of
+    tests/independent_tree.py -- built from integer boxes, not by the product's tree walk -- so that a wrong
+    product tree shows up as a difference instead of being shared by both sides.  The leaf list has to agree
+    with the product's (the arrays are compared block by block); the neighbour tables are NOT compared here:
+    the runs are."""
+    import independent_tree
+    it = independent_tree.Mesh(pin if pin is not None else pm.pin)
+    lloc = np.array(it.lloc, dtype=np.int32)
+    plloc, _ = product_smr_tables(pm)
+    assert lloc.shape == plloc.shape and np.array_equal(lloc, plloc), \
+        "leaf list of the product differs from the independent construction"
+    assert it.root_level == pm.root_level
+    return dict(smr_lloc=lloc, smr_nghbr=it.nghbr, smr_root_level=it.root_level)
 
 
 def rel_l1(a, b):

@@ -30,6 +30,13 @@ CASES = {
     "hydro2d": ("linear_wave_hydro_smr", (32, 16, 1), 2, (8, 4, 1), 4, {}),
     "hydro1d": ("linear_wave_hydro_smr", (32, 1, 1), 1, (8, 1, 1), 6, {}),
     "mhd1d": ("linear_wave_mhd_smr", (32, 1, 1), 1, (8, 1, 1), 6, dict(rsolver="hlld")),
+    # <mesh_refinement>/prolong_primitives = true: ConsToPrimCoarseBndry -> ProlongateCC(w) -> PrimToConsFineBndry
+    "hydro3d_pprims": ("linear_wave_hydro_smr", (32, 16, 16), 3, B3, 3, dict(extra=("mesh_refinement/prolong_primitives=true",))),
+    "mhd3d_pprims": ("linear_wave_mhd_smr", (32, 16, 16), 3, B3, 3,
+                     dict(rsolver="hlld", extra=("mesh_refinement/prolong_primitives=true",))),
+    "blast3d_c5_pprims": ("blast_smr", (32, 32, 32), 3, (8, 8, 8), 2, dict(extra=("mesh_refinement/prolong_primitives=true",))),
+    "mhd2d_pprims": ("linear_wave_mhd_smr", (32, 16, 1), 2, (8, 4, 1), 3,
+                     dict(rsolver="hlld", extra=("mesh_refinement/prolong_primitives=true",))),
     # three levels: the 2:1 rule surrounds the level-2 region with level-1 blocks
     "mhd3d_3levels": ("linear_wave_mhd_smr", (32, 16, 16), 3, B3, 2,
                       dict(rsolver="hlld", extra=("refined_region1/level=2",))),
@@ -52,7 +59,8 @@ def test_whole_run_parity_smr(name):
     assert r["time"][0] == r["time"][1] and r["dt"][0] == r["dt"][1]
 
 
-@pytest.mark.parametrize("name", ["hydro3d", "mhd3d", "blast3d_c5", "mhd2d", "hydro1d", "mhd3d_3levels", "blast3d_bcs"])
+@pytest.mark.parametrize("name", ["hydro3d", "mhd3d", "blast3d_c5", "mhd2d", "hydro1d", "mhd3d_3levels", "blast3d_bcs",
+                                  "hydro3d_pprims", "mhd3d_pprims"])
 def test_native_cpp_host_parity_smr(name):
     """the C++ host (csrc/akmi_host.cpp + akmi_host_smr.cpp: its own MeshBlockTree, neighbour table, index
     tables and task lists) on refined meshes: bit-identical to the oracle, same dt sequence"""

@@ -267,3 +267,155 @@ def test_cons_to_prim_inverts_textbook_prim_to_cons(hip):
     u3 = np.zeros_like(u)
     be("prim2cons", pk, box, w, bcc, u3)
     assert np.max(np.abs(u3 - u)/np.maximum(1.0, np.abs(u))) < TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# round 3: the pieces that had no check outside the shared source -- PLM (the reconstruction of the headline
+# run), the signs of CT, the face-field prolongation and restriction of the refined-mesh path
+@pytest.mark.parametrize("hip", BACKENDS)
+def test_plm_flux_kernel_vs_van_leer(hip):
+    """*_hydro_fluxes with PLM states and the ADVECT solver exposes the reconstructed L/R states (as for
+    PPM4 above); src/reconstruct/plm.hpp:20-37 against van Leer's limiter in flux-limiter form"""
+    be = Backend(hip)
+    n, ng = 12, 2
+    pk, (N3, N2, N1) = mkpack(n, n, n, ng, 5)
+    rng = np.random.default_rng(23)
+    w = random_prims(rng, (N3, N2, N1))
+    w[0, 0, :, :, 5] = w[0, 0, :, :, 4]              # flat spots and extrema: limiter branches
+    w[0, 4, 6] = w[0, 4, 5]
+    f = [np.zeros((1, 5, N3, N2, N1)) for _ in range(3)]
+    be("hydro_fluxes", pk, akref.RECON["plm"], RS_ADVECT, w, f[0], f[1], f[2], 0)
+    worst, nlim = 0.0, 0
+    lo, hi = ng, ng + n
+    for d, ax in ((0, 2), (1, 1), (2, 0)):
+        iv = [(1, 2, 3), (2, 3, 1), (3, 1, 2)][d]
+        wd = np.moveaxis(w[0], 1 + ax, -1)
+        fd = np.moveaxis(f[d][0], 1 + ax, -1)
+        for p in range(lo, hi):
+            for q in range(lo, hi):
+                rows = wd[:, p, q, :]
+                LR = [ind.plm_van_leer(rows[v]) for v in range(5)]
+                nlim += sum(int(np.sum(LR[v][0][lo:hi] == rows[v][lo:hi])) for v in range(5))
+                for i in range(lo, hi + 1):
+                    wl = np.array([LR[v][1][i-1] for v in range(5)])
+                    wr = np.array([LR[v][0][i] for v in range(5)])
+                    s = wl if wl[iv[0]] >= 0.0 else wr
+                    vn = s[iv[0]]
+                    ex = np.zeros(5)
+                    ex[0] = s[0]*vn
+                    ex[iv[0]] = s[0]*vn*vn
+                    ex[iv[1]] = s[iv[1]]*vn
+                    ex[iv[2]] = s[iv[2]]*vn
+                    ex[4] = s[4]*vn
+                    worst = max(worst, np.max(np.abs(fd[:, p, q, i] - ex))/max(1.0, np.max(np.abs(ex))))
+    assert worst < TOL, worst
+    assert nlim > 100                               # the limiter did switch slopes off in places
+
+
+@pytest.mark.parametrize("hip", BACKENDS)
+def test_ct_is_the_discrete_stokes_theorem(hip):
+    """MHD::CT (src/mhd/mhd_ct.cpp:45-77): the change of every face field equals minus dt times the circulation
+    of a RANDOM edge field around that face divided by its area, with the right-hand orientation, for
+    dx1 != dx2 != dx3 -- signs and spacings checked against Stokes' theorem, not against the source; and the
+    divergence of the change vanishes"""
+    be = Backend(hip)
+    n, ng = 8, 2
+    dx = (0.37, 0.61, 1.13)
+    pk, (N3, N2, N1) = mkpack(n, n, n, ng, 5, dx)
+    rng = np.random.default_rng(29)
+    e1 = rng.normal(size=(1, N3 + 1, N2 + 1, N1))
+    e2 = rng.normal(size=(1, N3 + 1, N2, N1 + 1))
+    e3 = rng.normal(size=(1, N3, N2 + 1, N1 + 1))
+    b0 = [rng.normal(size=(1, N3, N2, N1 + 1)), rng.normal(size=(1, N3, N2 + 1, N1)), rng.normal(size=(1, N3 + 1, N2, N1))]
+    b1 = [x.copy() for x in b0]
+    old = [x.copy() for x in b0]
+    dt = 0.0137
+    be("mhd_ct", pk, C.c_double(1.0), C.c_double(0.0), C.c_double(dt), e1, e2, e3, b0[0], b0[1], b0[2], b1[0], b1[1], b1[2])
+    # a common (N3+1, N2+1, N1+1) layout: pad the short direction of each edge array
+    full = (N3 + 1, N2 + 1, N1 + 1)
+    E = []
+    for c, e in enumerate((e1, e2, e3)):
+        A = np.zeros(full)
+        A[:e.shape[1], :e.shape[2], :e.shape[3]] = e[0]
+        E.append(A)
+    s = slice(ng, ng + n)
+    worst = 0.0
+    rate = []
+    for axis in range(3):
+        db = ind.faraday_circulation(E, axis, dx)
+        got = (b0[axis][0] - old[axis][0])/dt
+        sl = [s, s, s]
+        sl[2 - axis] = slice(ng, ng + n + 1)          # faces: one more along their own direction
+        sl = tuple(sl)
+        worst = max(worst, np.max(np.abs(got[sl] - db[sl])))
+        rate.append(got)
+        assert np.max(np.abs(got[sl])) > 1.0
+    assert worst < 1e-10*np.max(np.abs(E[0]))/min(dx), worst
+    div = ((rate[0][s, s, ng + 1:ng + n + 1] - rate[0][s, s, s])/dx[0] + (rate[1][s, ng + 1:ng + n + 1, s] - rate[1][s, s, s])/dx[1]
+           + (rate[2][ng + 1:ng + n + 1, s, s] - rate[2][s, s, s])/dx[2])
+    assert np.max(np.abs(div)) < 1e-10*np.max(np.abs(rate[0]))/min(dx)
+
+
+def _curl_of_random_potential(rng, shape3, d=(1.0, 1.0, 1.0)):
+    """a solenoidal face field on a block of `shape3` = (n3, n2, n1) cells: B = curl A with A random on the edges"""
+    n3, n2, n1 = shape3
+    a1 = rng.normal(size=(n3 + 1, n2 + 1, n1))
+    a2 = rng.normal(size=(n3 + 1, n2, n1 + 1))
+    a3 = rng.normal(size=(n3, n2 + 1, n1 + 1))
+    b1 = (a3[:, 1:, :] - a3[:, :-1, :])/d[1] - (a2[1:, :, :] - a2[:-1, :, :])/d[2]
+    b2 = (a1[1:, :, :] - a1[:-1, :, :])/d[2] - (a3[:, :, 1:] - a3[:, :, :-1])/d[0]
+    b3 = (a2[:, :, 1:] - a2[:, :, :-1])/d[0] - (a1[:, 1:, :] - a1[:, :-1, :])/d[1]
+    return b1, b2, b3
+
+
+@pytest.mark.parametrize("hip", BACKENDS)
+def test_field_prolongation_keeps_a_solenoidal_field_solenoidal(hip):
+    """ProlongFCShared* + ProlongFCInternal (src/mesh/prolongation.hpp:69-230, Toth & Roe 2002): a coarse face
+    field that is the discrete curl of a random vector potential comes out divergence-free on every fine cell,
+    the four fine faces on a coarse face carry its flux, and RestrictFC (src/mesh/mesh_refinement.cpp:1283-1382)
+    -- by definition the area average of the fine faces -- returns the coarse field"""
+    be = Backend(hip)
+    n, ng = 8, 2
+    pk, (N3, N2, N1) = mkpack(n, n, n, ng, 5)
+    c = n//2 + 2*ng
+    rng = np.random.default_rng(31)
+    cb = [x[None].copy() for x in _curl_of_random_potential(rng, (c, c, c))]
+    fb = [np.zeros((1, N3, N2, N1 + 1)), np.zeros((1, N3, N2 + 1, N1)), np.zeros((1, N3 + 1, N2, N1))]
+    lo, hi = ng, ng + n//2 - 1
+    for comp in range(3):
+        box = np.array([lo, hi, lo, hi, lo, hi], dtype=np.int32)
+        box[2*comp + 1] += 1
+        be("prolong_fc_shared", pk, comp, box, cb[comp], fb[comp])
+    box = np.array([lo, hi, lo, hi, lo, hi], dtype=np.int32)
+    be("prolong_fc_internal", pk, box, fb[0], fb[1], fb[2])
+    s = slice(ng, ng + n)
+    s1 = slice(ng + 1, ng + n + 1)
+    div = (fb[0][0][s, s, s1] - fb[0][0][s, s, s]) + (fb[1][0][s, s1, s] - fb[1][0][s, s, s]) + (fb[2][0][s1, s, s] - fb[2][0][s, s, s])
+    scale = max(np.max(np.abs(x)) for x in cb)
+    assert np.max(np.abs(div)) < 1e-10*scale, np.max(np.abs(div))
+    assert max(np.max(np.abs(x[0][s, s, s])) for x in fb) > 0.5
+    # flux through every coarse face = sum of the fluxes through its four fine faces (areas 1 : 1/4)
+    cs = slice(lo, hi + 1)
+    cs1 = slice(lo, hi + 2)
+    f0 = fb[0][0][s, s, ng:ng + n + 1:2]
+    avg0 = 0.25*(f0[0::2, 0::2] + f0[1::2, 0::2] + f0[0::2, 1::2] + f0[1::2, 1::2])
+    assert np.max(np.abs(avg0 - cb[0][0][cs, cs, cs1])) < 1e-10*scale
+    f1 = fb[1][0][s, ng:ng + n + 1:2, s]
+    avg1 = 0.25*(f1[0::2, :, 0::2] + f1[1::2, :, 0::2] + f1[0::2, :, 1::2] + f1[1::2, :, 1::2])
+    assert np.max(np.abs(avg1 - cb[1][0][cs, cs1, cs])) < 1e-10*scale
+    f2 = fb[2][0][ng:ng + n + 1:2, s, s]
+    avg2 = 0.25*(f2[:, 0::2, 0::2] + f2[:, 1::2, 0::2] + f2[:, 0::2, 1::2] + f2[:, 1::2, 1::2])
+    assert np.max(np.abs(avg2 - cb[2][0][cs1, cs, cs])) < 1e-10*scale
+    # RestrictFC of an arbitrary solenoidal FINE field: area averages, and the coarse field is solenoidal too
+    fine = [x[None].copy() for x in _curl_of_random_potential(rng, (N3, N2, N1))]
+    cr = [np.zeros((1, c, c, c + 1)), np.zeros((1, c, c + 1, c)), np.zeros((1, c + 1, c, c))]
+    be("restrict_fc", pk, fine[0], fine[1], fine[2], cr[0], cr[1], cr[2])
+    g0 = fine[0][0][s, s, ng:ng + n + 1:2]
+    assert np.max(np.abs(0.25*(g0[0::2, 0::2] + g0[1::2, 0::2] + g0[0::2, 1::2] + g0[1::2, 1::2]) - cr[0][0][cs, cs, cs1])) < 1e-10*scale
+    g1 = fine[1][0][s, ng:ng + n + 1:2, s]
+    assert np.max(np.abs(0.25*(g1[0::2, :, 0::2] + g1[1::2, :, 0::2] + g1[0::2, :, 1::2] + g1[1::2, :, 1::2]) - cr[1][0][cs, cs1, cs])) < 1e-10*scale
+    g2 = fine[2][0][ng:ng + n + 1:2, s, s]
+    assert np.max(np.abs(0.25*(g2[:, 0::2, 0::2] + g2[:, 1::2, 0::2] + g2[:, 0::2, 1::2] + g2[:, 1::2, 1::2]) - cr[2][0][cs1, cs, cs])) < 1e-10*scale
+    cdiv = ((cr[0][0][cs, cs, lo + 1:hi + 2] - cr[0][0][cs, cs, cs]) + (cr[1][0][cs, lo + 1:hi + 2, cs] - cr[1][0][cs, cs, cs])
+            + (cr[2][0][lo + 1:hi + 2, cs, cs] - cr[2][0][cs, cs, cs]))
+    assert np.max(np.abs(cdiv)) < 1e-10*scale

@@ -214,3 +214,44 @@ def test_refined_region_errors():
         _build(SMR3D.replace("level = 1", "level = 0"))
     with pytest.raises(RuntimeError, match="divisible by 2"):
         _build(SMR3D.replace("nx1 = 64", "nx1 = 60").replace("nx1 = 16", "nx1 = 15"))
+
+
+# ---- round 3: the product's tree and neighbour table against a construction that does not walk a tree -------
+import pytest as _pytest
+
+_TREE_CASES = [
+    ("linear_wave_mhd_smr", (32, 16, 16), 3, (8, 4, 4), ()),
+    ("linear_wave_mhd_smr", (32, 16, 16), 3, (8, 4, 4), ("refined_region1/level=2",)),            # three levels
+    ("linear_wave_hydro_smr", (32, 16, 1), 2, (8, 4, 1), ()),
+    ("linear_wave_hydro_smr", (32, 1, 1), 1, (8, 1, 1), ()),
+    ("blast_smr", (32, 32, 32), 3, (8, 8, 8), ()),
+    ("blast_smr", (64, 64, 64), 3, (16, 16, 16), ()),                                              # config 5's own deck: 120 blocks
+    ("blast_smr", (32, 32, 32), 3, (8, 8, 8), ("mesh/ix1_bc=outflow", "mesh/ox1_bc=outflow", "mesh/ix2_bc=reflect",
+                                                "mesh/ox2_bc=reflect", "refined_region1/x1min=-0.5",
+                                                "refined_region1/x1max=-0.2", "refined_region1/x2min=-0.5",
+                                                "refined_region1/x2max=-0.2")),                   # region on a physical boundary
+    ("linear_wave_mhd_smr", (24, 12, 12), 3, (4, 4, 4), ("refined_region1/level=2",)),           # 6x3x3 root grid: not a power of two
+]
+
+
+@_pytest.mark.parametrize("case", _TREE_CASES, ids=lambda c: "%s-%s-mb%s%s" % (c[0], c[1], c[3], "-x" if c[4] else ""))
+def test_tree_and_neighbour_table_against_integer_box_construction(case):
+    """tests/independent_tree.py (integer boxes, contact classification; src/mesh/build_tree.cpp:150-238,
+    src/mesh/meshblock.cpp:142-425 semantics) gives the same Z-ordered leaves and the same 56-slot table
+    {gid, level, dest} as the product's tree walk, slot for slot"""
+    import numpy as np
+    import independent_tree
+    import parity_util as pu
+    from athenak_amd.main import load_deck
+    from athenak_amd.mesh import Mesh
+    problem, n, dims, mb, extra = case
+    deck, ov = pu.deck_overrides(problem, n, dims, mb, extra=extra)
+    pin = load_deck(deck, ov)
+    pm = Mesh(pin)
+    it = independent_tree.Mesh(pin)
+    lloc, ng = pu.product_smr_tables(pm)
+    assert np.array_equal(np.array(it.lloc, dtype=np.int32), lloc)
+    assert it.root_level == pm.root_level
+    nn = {1: 8, 2: 24, 3: 56}[dims]
+    assert np.array_equal(it.nghbr[:, :nn], ng[:, :nn]), np.argwhere(it.nghbr[:, :nn] != ng[:, :nn])[:10]
+    assert len(set(l[3] for l in it.lloc)) >= 2

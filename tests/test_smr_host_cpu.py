@@ -53,3 +53,55 @@ def test_smr_host_equals_oracle_driver(cpu_host):
     r = pu.compare_run("linear_wave_mhd_smr", (32, 16, 16), 3, (8, 4, 4), cycles=2, fused=False)
     assert r["bitwise_equal"] and r["cycles"] == 2
     assert r["dt"][0] == r["dt"][1]
+
+
+@pytest.mark.parametrize("problem", ["linear_wave_mhd_smr", "linear_wave_hydro_smr"])
+def test_prolong_primitives_host_equals_oracle_driver(cpu_host, problem):
+    """<mesh_refinement>/prolong_primitives = true (src/bvals/prolong_prims.cpp; switch at mhd_tasks.cpp:539,
+    hydro_tasks.cpp:388): the host's Prolongate task takes the conversion -> prolongation -> conversion route and
+    gives the bits of the oracle's driver; and the result differs from the default route (the option is live)"""
+    import parity_util as pu
+    on = pu.compare_run(problem, (32, 16, 16), 3, (8, 4, 4), cycles=2, fused=False, keep=True,
+                        extra=("mesh_refinement/prolong_primitives=true",))
+    assert on["bitwise_equal"] and on["cycles"] == 2 and on["dt"][0] == on["dt"][1]
+    off = pu.compare_run(problem, (32, 16, 16), 3, (8, 4, 4), cycles=2, fused=False, keep=True)
+    a, b = on["sim"].phys.u0.cpu().numpy(), off["sim"].phys.u0.cpu().numpy()
+    assert not np.array_equal(a, b)
+    assert np.abs(a - b).max() < 2e-4          # both are second-order prolongations of the same smooth wave (amp 1e-3)
+
+
+def test_prolong_primitives_keeps_a_uniform_state(cpu_host):
+    """definition-level check that shares nothing with the kernels but the ABI: a uniform primitive state
+    (d, v, p, B constant) is reproduced exactly in every fine ghost cell by c2p(coarse) -> limited-slope
+    prolongation (all slopes vanish) -> p2c(fine), whatever the conversion costs in round-off"""
+    import ctypes as C
+    import torch
+    from athenak_amd import capi
+    from athenak_amd.main import Simulation, load_deck
+    import parity_util as pu
+    deck, ov = pu.deck_overrides("linear_wave_mhd_smr", (32, 16, 16), 3, (8, 4, 4),
+                                 extra=("mesh_refinement/prolong_primitives=true", "problem/amp=0.0"))
+    sim = Simulation(load_deck(deck, ov))
+    ph = sim.phys
+    d, vx, vy, vz, p, bx, by, bz = 1.3, 0.4, -0.2, 0.1, 0.7, 0.5, -0.3, 0.25
+    gm1 = ph.peos.eos_data.gamma - 1.0
+    e = p/gm1 + 0.5*d*(vx*vx + vy*vy + vz*vz) + 0.5*(bx*bx + by*by + bz*bz)
+    for n, v in enumerate((d, d*vx, d*vy, d*vz, e)):
+        ph.u0[:, n] = v
+    ph.b0.x1f[:] = bx; ph.b0.x2f[:] = by; ph.b0.x3f[:] = bz
+    ref = ph.u0.clone()
+    ph.RestrictU(sim.pdriver, 1); ph.RestrictB(sim.pdriver, 1)
+    ph.SendU(sim.pdriver, 1); ph.RecvU(sim.pdriver, 1); ph.SendB(sim.pdriver, 1); ph.RecvB(sim.pdriver, 1)
+    ph.u0[:, :, :2] = -7.0                      # poison one ghost slab: prolongation must rewrite what it owns
+    ph.Prolongate(sim.pdriver, 1)
+    u = ph.u0.cpu().numpy()
+    lev = np.array(sim.pmesh.pmb_pack.pmb.mb_lev)
+    fine = np.where(lev == lev.max())[0]
+    touched = 0
+    for m in fine:
+        blk = u[m]
+        rewritten = blk[:, :2] != -7.0
+        touched += int(rewritten.sum())
+        assert np.allclose(blk[:, :2][rewritten], np.broadcast_to(ref[m].cpu().numpy()[:, :2], blk[:, :2].shape)[rewritten],
+                           rtol=0, atol=4e-16*abs(e))
+    assert touched > 0
