@@ -785,6 +785,10 @@ static int CopyFlag(const Driver *d, int stage, int phases) {
   if (d->integrator == "rk4" || d->use_graph || off) return 1;
   return (phases & (AKMI_PHASE_SWEEPS | AKMI_PHASE_EMF_CT)) ? 2 : 0;
 }
+static bool MergeC2P() {      // A/B switch, profiles/r03_whatif_merge_c2p.txt
+  static const bool on = !(std::getenv("AKMI_MERGE_C2P") && std::atoi(std::getenv("AKMI_MERGE_C2P")) == 0);
+  return on;
+}
 template <typename T> static void SwapArr(DvceArray<T> &a, DvceArray<T> &b) { std::swap(a.p, b.p); std::swap(a.n, b.n); }
 
 void FluidBase::RestoreRegisters() {
@@ -838,6 +842,10 @@ TaskStatus Hydro::RKUpdate(Driver *d, int stage) {         // hydro_update.cpp:2
   if (fused && peers()) {
     // off-rank neighbours: only the sweeps + update here, so that SendU can post the halo messages
     // before the c2p of the active cells is enqueued
+    StagePhase(d, stage, AKMI_PHASE_SWEEPS);
+  } else if (fused && !dt_dev && MergeC2P()) {
+    // no off-rank neighbour: ONE ConsToPrim over all cells after the ghost fill (ConToPrim) instead of c2p of the
+    // active cells here + c2p of the ghost shell there (thin slabs): 512 blocks of 32^3 1518 -> 1726 Mcell-updates/s
     StagePhase(d, stage, AKMI_PHASE_SWEEPS);
   } else if (fused) {
     int do_dt = (stage == d->nexp_stages);
@@ -946,7 +954,9 @@ TaskStatus Hydro::ConToPrim(Driver *d, int stage) {        // hydro_tasks.cpp:40
     AKCHK(akmi_hydro_c2p_shell(&pack_c, u0.p, w0.p, counters.p, stream));
   } else if (fused) {
     int do_dt = (stage == d->nexp_stages);
+    d->ProfMark(stream);
     AKCHK(akmi_hydro_c2p_newdt(&pack_c, u0.p, w0.p, do_dt, counters.p, dt3.p, stream));
+    d->ProfMark(stream);
     dt_ready_ = do_dt;
   } else {
     AKCHK(akmi_hydro_c2p(&pack_c, u0.p, w0.p, 0, n1 - 1, 0, n2 - 1, 0, n3 - 1, counters.p, stream));
@@ -1005,6 +1015,8 @@ TaskStatus MHD::RKUpdate(Driver *d, int stage) {           // mhd_update.cpp:24-
   Real beta_dt = d->beta[stage - 1]*pmy_pack->pmesh->dt;
   if (fused && peers()) {
     StagePhase(d, stage, AKMI_PHASE_SWEEPS);
+  } else if (fused && !dt_dev && MergeC2P()) {
+    StagePhase(d, stage, AKMI_PHASE_SWEEPS | AKMI_PHASE_EMF_CT);      // see Hydro::RKUpdate
   } else if (fused) {
     int do_dt = (stage == d->nexp_stages);
     const int copy = CopyFlag(d, stage, AKMI_PHASE_ALL);
@@ -1204,8 +1216,10 @@ TaskStatus MHD::ConToPrim(Driver *d, int stage) {
     AKCHK(akmi_mhd_c2p_shell(&pack_c, u0.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, w0.p, bcc0.p, counters.p, stream));
   } else if (fused) {
     int do_dt = (stage == d->nexp_stages);
+    d->ProfMark(stream);
     AKCHK(akmi_mhd_c2p_newdt(&pack_c, u0.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, w0.p, bcc0.p, do_dt,
                              counters.p, dt3.p, stream));
+    d->ProfMark(stream);
     dt_ready_ = do_dt;
   } else {
     AKCHK(akmi_mhd_c2p(&pack_c, u0.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, w0.p, bcc0.p, 0, n1 - 1, 0, n2 - 1,

@@ -270,6 +270,20 @@ __device__ __forceinline__ int pow2_shift(double dx) {
   return 1023 - (int)(((unsigned long long)__double_as_longlong(dx) >> 52) & 0x7ff);
 }
 
+// CornerE needs only the SIGN of the three mass fluxes (upwinding, mhd_corner_e.cpp:340-413).  In the 3-D
+// PLM+HLLD stage the sweeps therefore leave one 64-bit ballot word per wave and face row instead of one double
+// per face (`f >= 0.0`, the comparison CornerE makes): the producing wave and lane of a face follow from its
+// indices, so the consumer finds its bit without any atomics or clearing.  What-if builds bounded the gain at
+// 166 us per stage (profiles/r03_whatif_merge_c2p.txt: no mass-flux traffic at all); the real thing gains a
+// tenth of that (profiles/r03_mfbits_ab.txt), so it is an option (AKMI_MFBITS=1), not the default.
+//   x1 / x2 faces (k_sweep12s): wave wv = p/60, lane = p%60 + 2 with p = (k - kl12)*N1 + i; word (m, row, wv)
+//   x3 faces (x3 march):        wave = p3>>6, lane = p3&63 with p3 = (j - j3l)*N1 + i;      word (m, k - k3l, wave)
+struct MfBits {
+  unsigned long long *w1, *w2, *w3;     // null: the mass-flux arrays themselves
+  int j1l, nj1, j2l, nj2, kl12, nw12;
+  int j3l, k3l, nk3, nw3;
+};
+
 struct UpdArgs {
   double gam0, gam1, beta_dt;
   double *u0, *u1;
@@ -278,6 +292,7 @@ struct UpdArgs {
   double *acc;                    // partial divergence (written by the x2 march, read by x3)
   const double *dtp;              // non-null: beta_dt holds the RK weight beta and dt is read from
                                   // device memory (a captured cycle replayed with a new time step)
+  MfBits mb;                      // sign words of the mass fluxes (w1 == null: off)
 };
 // copy_u1 / copy_b1: 0 = the second register (u1, b1) holds the state of the start of the cycle;
 // 1 = first stage, CopyCons folded in: the register receives the old state, u0 / b0 the new one;
@@ -332,6 +347,9 @@ __device__ __forceinline__ double beta_dt_of(double beta_dt, const double *dtp) 
 #endif
 #ifndef AKMI_DBG_NOSOLVE
 #define AKMI_DBG_NOSOLVE 0
+#endif
+#ifndef AKMI_WHATIF
+#define AKMI_WHATIF 0           // timing experiments (wrong results), tools/r03_whatif.sh: upper bounds of what a fusion could save
 #endif
 #ifndef AKMI_PPM_WREG
 #define AKMI_PPM_WREG 1         // marches with five-point reconstructions keep their window in registers
@@ -679,9 +697,21 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
           eos, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1], R[2], R[3], R[4], R[5], R[6], bxi);
 #endif
       fd = fl.d; fx = fl.mx; fy = fl.my; fz = fl.mz; fe = fl.e;
+#if AKMI_WHATIF & 1     // timing experiment (wrong results): the x3 march without its three stores for CornerE
+      if (DIR == 2 && MODE == 0) fe += 0.0*(fl.by + fl.bz);
+      else
+#endif
       if (t < ml || s == shi) {
         // CornerE needs the sign of the mass flux and the two face EMFs of this direction
-        stu(mfm, foff, fd);
+#if !(AKMI_WHATIF & 4)
+        if (DIR == 2 && MODE == 0 && u.mb.w3) {
+          const unsigned long long act = __ballot(1), bits = __ballot(fd >= 0.0);
+          if ((int)threadIdx.x == __ffsll((long long)act) - 1)
+            u.mb.w3[((size_t)m*u.mb.nk3 + (s - u.mb.k3l))*u.mb.nw3 + ((size_t)blockIdx.x*SY + threadIdx.y)] = bits;
+        } else {
+          stu(mfm, foff, fd);
+        }
+#endif
         stu(a.ey + (size_t)m*cs, oc, -fl.by);
         stu(a.ez + (size_t)m*cs, oc, fl.bz);
       }
@@ -905,8 +935,8 @@ constexpr int CKL = AKMI_CKL;          // cell planes per k-chunk (one plane of 
 // (ty, tx); the launcher picks the shape that wastes the fewest lanes for the block size (a 64-wide
 // tile needs two columns of tiles for the 65 edge columns of a 64^3 MeshBlock, a 34 x 15 tile does
 // 33 / 65 / 257 columns in 1 / 2 / 8).
-template <bool P2>
-__device__ __forceinline__ void corner_ct_body(const Geo &g, const double *__restrict__ e3x1, const double *__restrict__ e2x1,
+template <bool P2, bool BITS>
+__device__ __forceinline__ void corner_ct_body(const Geo &g, const MfBits &mb, const double *__restrict__ e3x1, const double *__restrict__ e2x1,
             const double *__restrict__ e1x2, const double *__restrict__ e3x2,
             const double *__restrict__ e2x3, const double *__restrict__ e1x3,
             const double *__restrict__ c1, const double *__restrict__ c2,
@@ -954,11 +984,25 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const double *__res
   double *b11 = b1x1f + (size_t)m*g.N3*PS1, *b12 = b1x2f + (size_t)m*g.N3*PS2, *b13 = b1x3f + (size_t)m*(g.N3 + 1)*PS;
   double e1p = 0.0, e2p = 0.0, e3p = 0.0;                       // own edges of the previous plane
   // operands of the corner formulas that belong to plane k-1 (rolled from step to step)
-  double f1_km = 0.0, f2_km = 0.0, x2_km = 0.0, x1_km = 0.0, c1_mm = 0.0, c1_m0 = 0.0, c2_mm = 0.0,
-         c2_m0 = 0.0;
+  double x2_km = 0.0, x1_km = 0.0, c1_mm = 0.0, c1_m0 = 0.0, c2_mm = 0.0, c2_m0 = 0.0;
+  bool f1_km = false, f2_km = false;          // mass flux >= 0 on the x1 / x2 face of plane k-1
+  // BITS: the sign words the sweeps left behind (MfBits) instead of the mass-flux arrays
+  auto s12 = [&](const unsigned long long *w, int nj, int jl, int kk, int jj, int ii) -> bool {
+    const int pp = (kk - mb.kl12)*g.N1 + ii, wv = pp/60, ln = pp - wv*60 + 2;
+    return (w[((size_t)m*nj + (jj - jl))*mb.nw12 + wv] >> ln) & 1ull;
+  };
+  auto s3 = [&](int kk, int jj, int ii) -> bool {
+    const int pp = (jj - mb.j3l)*g.N1 + ii;
+    return (mb.w3[((size_t)m*mb.nk3 + (kk - mb.k3l))*mb.nw3 + (pp >> 6)] >> (pp & 63)) & 1ull;
+  };
   if (edge_ok) {
-    f1_km = ldu(f1m - PS1, o1);
-    f2_km = ldu(f2m - PS2, o2);
+    if constexpr (BITS) {
+      f1_km = s12(mb.w1, mb.nj1, mb.j1l, k0 - 1, j, i);
+      f2_km = s12(mb.w2, mb.nj2, mb.j2l, k0 - 1, j, i);
+    } else {
+      f1_km = ldu(f1m - PS1, o1) >= 0.0;
+      f2_km = ldu(f2m - PS2, o2) >= 0.0;
+    }
     x2_km = ldu(x12 - PS, oc);
     x1_km = ldu(x21 - PS, oc);
     c1_mm = ldu(c1m - PS - g.N1, oc); c1_m0 = ldu(c1m - PS, oc);
@@ -981,30 +1025,60 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const double *__res
     if (ct2) { pb02 = ldu(b02 - PS2, o2); pb12 = ldu((copy_b1 ? b02 : b12) - PS2, o2); }
 #endif
     if (edge_ok) {
-      const double f1_k = ldu(f1m, o1);
-      const double f1_jm = ldu(f1m - (g.N1 + 1), o1);
-      const double f2_k = ldu(f2m, o2);
-      const double f2_im = ldu(f2m - 1, o2);
-      const double f3_k = ldu(f3m, oc);
-      const double f3_jm = ldu(f3m - g.N1, oc);
-      const double f3_im = ldu(f3m - 1, oc);
+      bool f1_k, f1_jm, f2_k, f2_im, f3_k, f3_jm, f3_im;     // mass flux >= 0 on the faces round the corner
+#if AKMI_WHATIF & 4      // timing experiment (wrong results): CornerE without the three mass-flux arrays
+      const double x2w = ldu(x12, oc);
+      f1_k = x2w >= 0.0; f1_jm = f1_k; f2_k = !f1_k; f2_im = f1_k; f3_k = f1_k; f3_jm = !f1_k; f3_im = f1_k;
+#elif AKMI_WHATIF & 2    // ... without what the x3 march leaves behind (mass flux and face EMFs of x3)
+      f1_k = ldu(f1m, o1) >= 0.0;
+      f1_jm = ldu(f1m - (g.N1 + 1), o1) >= 0.0;
+      f2_k = ldu(f2m, o2) >= 0.0;
+      f2_im = ldu(f2m - 1, o2) >= 0.0;
+      f3_k = f1_k; f3_jm = f2_k; f3_im = f1_jm;
+#else
+      if constexpr (BITS) {
+        f1_k = s12(mb.w1, mb.nj1, mb.j1l, k, j, i);
+        f1_jm = s12(mb.w1, mb.nj1, mb.j1l, k, j - 1, i);
+        f2_k = s12(mb.w2, mb.nj2, mb.j2l, k, j, i);
+        f2_im = s12(mb.w2, mb.nj2, mb.j2l, k, j, i - 1);
+        f3_k = s3(k, j, i);
+        f3_jm = s3(k, j - 1, i);
+        f3_im = s3(k, j, i - 1);
+      } else {
+        f1_k = ldu(f1m, o1) >= 0.0;
+        f1_jm = ldu(f1m - (g.N1 + 1), o1) >= 0.0;
+        f2_k = ldu(f2m, o2) >= 0.0;
+        f2_im = ldu(f2m - 1, o2) >= 0.0;
+        f3_k = ldu(f3m, oc) >= 0.0;
+        f3_jm = ldu(f3m - g.N1, oc) >= 0.0;
+        f3_im = ldu(f3m - 1, oc) >= 0.0;
+      }
+#endif
       const double c1_0m = ldu(c1m - g.N1, oc), c1_00 = ldu(c1m, oc);
       const double c2_0m = ldu(c2m - 1, oc), c2_00 = ldu(c2m, oc);
       const double x2_k = ldu(x12, oc), x1_k = ldu(x21, oc);
       {  // E1 (mhd_corner_e.cpp:340-363)
+#if AKMI_WHATIF & 2
+        const double x3_jm = c1_0m, x3_j = c1_00;
+#else
         const double x3_jm = ldu(x13 - g.N1, oc), x3_j = ldu(x13, oc);
-        double e1_l3 = upw(f2_km >= 0.0, x3_jm, c1_mm, x3_j, c1_m0);
-        double e1_r3 = upw(f2_k >= 0.0, x3_jm, c1_0m, x3_j, c1_00);
-        double e1_l2 = upw(f3_jm >= 0.0, x2_km, c1_mm, x2_k, c1_0m);
-        double e1_r2 = upw(f3_k >= 0.0, x2_km, c1_m0, x2_k, c1_00);
+#endif
+        double e1_l3 = upw(f2_km, x3_jm, c1_mm, x3_j, c1_m0);
+        double e1_r3 = upw(f2_k, x3_jm, c1_0m, x3_j, c1_00);
+        double e1_l2 = upw(f3_jm, x2_km, c1_mm, x2_k, c1_0m);
+        double e1_r2 = upw(f3_k, x2_km, c1_m0, x2_k, c1_00);
         e1 = 0.25*(e1_l3 + e1_r3 + e1_l2 + e1_r2 + x2_km + x2_k + x3_jm + x3_j);
       }
       {  // E2 (:365-388)
+#if AKMI_WHATIF & 2
+        const double x3_im = c2_0m, x3_i = c2_00;
+#else
         const double x3_im = ldu(x23 - 1, oc), x3_i = ldu(x23, oc);
-        double e2_l3 = upw(f1_km >= 0.0, x3_im, c2_mm, x3_i, c2_m0);
-        double e2_r3 = upw(f1_k >= 0.0, x3_im, c2_0m, x3_i, c2_00);
-        double e2_l1 = upw(f3_im >= 0.0, x1_km, c2_mm, x1_k, c2_0m);
-        double e2_r1 = upw(f3_k >= 0.0, x1_km, c2_m0, x1_k, c2_00);
+#endif
+        double e2_l3 = upw(f1_km, x3_im, c2_mm, x3_i, c2_m0);
+        double e2_r3 = upw(f1_k, x3_im, c2_0m, x3_i, c2_00);
+        double e2_l1 = upw(f3_im, x1_km, c2_mm, x1_k, c2_0m);
+        double e2_r1 = upw(f3_k, x1_km, c2_m0, x1_k, c2_00);
         e2 = 0.25*(e2_l3 + e2_r3 + e2_l1 + e2_r1 + x3_im + x3_i + x1_km + x1_k);
       }
       {  // E3 (:390-413)
@@ -1012,10 +1086,10 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const double *__res
         const double x1_jm = ldu(x31 - g.N1, oc), x1_j = ldu(x31, oc);
         const double c_mm = ldu(c3m - g.N1 - 1, oc), c_m0 = ldu(c3m - g.N1, oc);
         const double c_0m = ldu(c3m - 1, oc), c_00 = ldu(c3m, oc);
-        double e3_l2 = upw(f1_jm >= 0.0, x2_im, c_mm, x2_i, c_m0);
-        double e3_r2 = upw(f1_k >= 0.0, x2_im, c_0m, x2_i, c_00);
-        double e3_l1 = upw(f2_im >= 0.0, x1_jm, c_mm, x1_j, c_0m);
-        double e3_r1 = upw(f2_k >= 0.0, x1_jm, c_m0, x1_j, c_00);
+        double e3_l2 = upw(f1_jm, x2_im, c_mm, x2_i, c_m0);
+        double e3_r2 = upw(f1_k, x2_im, c_0m, x2_i, c_00);
+        double e3_l1 = upw(f2_im, x1_jm, c_mm, x1_j, c_0m);
+        double e3_r1 = upw(f2_k, x1_jm, c_m0, x1_j, c_00);
         e3 = 0.25*(e3_l1 + e3_r1 + e3_l2 + e3_r2 + x2_im + x2_i + x1_jm + x1_j);
       }
       f1_km = f1_k; f2_km = f2_k; x2_km = x2_k; x1_km = x1_k;
@@ -1073,8 +1147,9 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const double *__res
 #ifndef AKMI_CT_WAVES
 #define AKMI_CT_WAVES 6         // waves per SIMD the register allocation aims at: 66 VGPRs, three workgroups per CU
 #endif                          // (two at the 114 VGPRs the compiler takes when left alone: 640-665 us against 621)
+template <bool BITS>
 __global__ void __launch_bounds__(CT_THREADS, AKMI_CT_WAVES)
-k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e2x1,
+k_corner_ct(Geo g, MfBits mb, const double *__restrict__ e3x1, const double *__restrict__ e2x1,
             const double *__restrict__ e1x2, const double *__restrict__ e3x2,
             const double *__restrict__ e2x3, const double *__restrict__ e1x3,
             const double *__restrict__ c1, const double *__restrict__ c2,
@@ -1084,7 +1159,7 @@ k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e
             double *__restrict__ b0x3f, double *__restrict__ b1x1f, double *__restrict__ b1x2f,
             double *__restrict__ b1x3f, int copy_b1, int kA, int kB, int top, int nchunk,
             int ckl, int tw, int th, const double *dtp) {
-  corner_ct_body<AKMI_POW2DX != 0>(g, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, c1, c2, c3, flx1, flx2, flx3, gam0,
+  corner_ct_body<AKMI_POW2DX != 0, BITS>(g, mb, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, c1, c2, c3, flx1, flx2, flx3, gam0,
                                    gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f, copy_b1, kA, kB, top,
                                    nchunk, ckl, tw, th, dtp);
 }
@@ -1730,8 +1805,14 @@ k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
       dF1[2] = __shfl_down(f1y, 1, 64) - f1y;
       dF1[3] = __shfl_down(f1z, 1, 64) - f1z;
       dF1[4] = __shfl_down(f1e, 1, 64) - f1e;
+      if (u.mb.w1 && do_x1) {
+        const unsigned long long bits = __ballot(x1_ok && f1d >= 0.0);
+        if (lane == 0 && wv < u.mb.nw12) u.mb.w1[((size_t)m*u.mb.nj1 + (jr - u.mb.j1l))*u.mb.nw12 + wv] = bits;
+      }
       if (do_x1 && x1_ok) {
-        stu(mf1, foff1, f1d);
+#if !(AKMI_WHATIF & 4)
+        if (!u.mb.w1) stu(mf1, foff1, f1d);
+#endif
         stu(a1.ey + (size_t)m*cs, orow, -f1by);
         stu(a1.ez + (size_t)m*cs, orow, f1bz);
       }
@@ -1766,8 +1847,14 @@ k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
 #endif
     Cons1D f2 = riemann_mhd_e<RS, AKMI_X12S_EO2 != 0, AKMI_X12S_FM != 0>(eos, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1],
                                   R[2], R[3], R[4], R[5], R[6], bx2);
+    if (u.mb.w2 && do_x2 && (t < ml || s == shi)) {
+      const unsigned long long bits = __ballot(x2_ok && f2.d >= 0.0);
+      if (lane == 0 && wv < u.mb.nw12) u.mb.w2[((size_t)m*u.mb.nj2 + (s - u.mb.j2l))*u.mb.nw12 + wv] = bits;
+    }
     if (do_x2 && x2_ok && (t < ml || s == shi)) {
-      stu(mf2, foff2, f2.d);
+#if !(AKMI_WHATIF & 4)
+      if (!u.mb.w2) stu(mf2, foff2, f2.d);
+#endif
       stu(a2.ey + (size_t)m*cs, off, -f2.by);
       stu(a2.ez + (size_t)m*cs, off, f2.bz);
     }
@@ -2070,7 +2157,7 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
   if (!(phases & AKMI_PHASE_C2P)) cp.enable = 0;
   const int ndim = g.three_d ? 3 : (g.multi_d ? 2 : 1);
   // dt_dev: beta_dt is the RK weight beta, the kernels multiply it with *dt_dev (akmi_*_stage_fused_dt)
-  UpdArgs u{gam0, gam1, beta_dt, u0, u1, w.flx1, w.flx2, copy_u1, w.acc, dt_dev};
+  UpdArgs u{gam0, gam1, beta_dt, u0, u1, w.flx1, w.flx2, copy_u1, w.acc, dt_dev, MfBits{}};
   // copy_u1 == 2 (out-of-place first stage): the new state lands in u1 / b1, which is what the c2p
   // of the active cells has to read
   double *un = copy_u1 == 2 ? u1 : u0;
@@ -2134,6 +2221,26 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
   const int T = (phases != AKMI_PHASE_ALL) ? g.nx3 : (env_slab > 1 ? env_slab : AKMI_SLAB);
   const int S = (g.nx3 + T - 1)/T;
   if (S > MAX_SLABS) { set_error("too many slabs"); return AKMI_FAIL; }
+  // sign words instead of mass-flux arrays (MfBits): the 3-D PLM+HLLD stage in one slab, no passive scalars; the
+  // words live in the memory of the (then unused) mass-flux arrays.  AKMI_MFBITS=0: A/B switch
+  // Measured (profiles/r03_mfbits_ab.txt): x3 march 886 -> 838-857 us, but k_corner_ct 643 -> 649-658 (its seven loads
+  // stay loads, plus the index arithmetic of the look-up) and k_sweep12s +10: +0..3 % on the bench, within the
+  // run-to-run spread.  Bit-identical; OFF by default (AKMI_MFBITS=1 switches it on).
+  static const bool env_bits = getenv("AKMI_MFBITS") && atoi(getenv("AKMI_MFBITS")) != 0;
+  if (MHD && env_bits && S == 1 && x12s && sc.recon == 1 && !sc.iso && sc.rsolver == AKMI_RS_HLLD && g.nvar == 5 &&
+      w.flx1) {
+    MfBits &b = u.mb;
+    b.w1 = reinterpret_cast<unsigned long long *>(w.flx1);
+    b.w2 = reinterpret_cast<unsigned long long *>(w.flx2);
+    b.w3 = reinterpret_cast<unsigned long long *>(w.flx3);
+    b.j1l = a1.jl; b.nj1 = a1.ju - a1.jl + 1;
+    b.j2l = a2.jl; b.nj2 = a2.ju - a2.jl + 1;
+    b.kl12 = a2.kl;                                           // one slab: kA - 1 = ks - 1
+    b.nw12 = (int)(((long)(a2.ku - a2.kl + 1)*g.N1 + (SX - 4) - 1)/(SX - 4));
+    b.j3l = a3.jl; b.k3l = a3.kl; b.nk3 = a3.ku - a3.kl + 1;
+    const long np3 = (long)(a3.ju - a3.jl + 1)*g.N1;
+    b.nw3 = (int)((np3 + SX*SY - 1)/(SX*SY))*SY;
+  }
   const bool two = (S > 1) && (MHD || cp.enable) && !env_one;
   hipStream_t sb = st;
   if (two) {
@@ -2152,10 +2259,16 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
     const int ckl = march_len((long)tl.n1*tl.n2, kB(s) - kA(s) + 1, g.nmb, CKL);
     const int nchunk = cdiv(kB(s) - kA(s) + 1, ckl);
     dim3 grid(tl.n1, tl.n2, nchunk*g.nmb), block(tl.threads);
-    k_corner_ct<<<grid, block, 7*tl.tw*tl.th*sizeof(double), sb>>>(
-        g, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5], w.ecc[0], w.ecc[1], w.ecc[2],
-        w.flx1, w.flx2, w.flx3, gam0, gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f,
-        copy_u1, kA(s), kB(s), top, nchunk, ckl, tl.tw, tl.th, dt_dev);
+    if (u.mb.w1)
+      k_corner_ct<true><<<grid, block, 7*tl.tw*tl.th*sizeof(double), sb>>>(
+          g, u.mb, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5], w.ecc[0], w.ecc[1], w.ecc[2],
+          w.flx1, w.flx2, w.flx3, gam0, gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f,
+          copy_u1, kA(s), kB(s), top, nchunk, ckl, tl.tw, tl.th, dt_dev);
+    else
+      k_corner_ct<false><<<grid, block, 7*tl.tw*tl.th*sizeof(double), sb>>>(
+          g, u.mb, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5], w.ecc[0], w.ecc[1], w.ecc[2],
+          w.flx1, w.flx2, w.flx3, gam0, gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f,
+          copy_u1, kA(s), kB(s), top, nchunk, ckl, tl.tw, tl.th, dt_dev);
     AKMI_CHECK_LAUNCH("corner_ct");
     return AKMI_COMPLETE;
   };

@@ -176,6 +176,10 @@ class FluidBase:
         return 2 if phases & (capi.PHASE_SWEEPS | capi.PHASE_EMF_CT) else 0
 
 
+import os as _os
+_MERGE_C2P = _os.environ.get("AKMI_MERGE_C2P", "1") != "0"      # A/B switch (profiles/r03_whatif_merge_c2p.txt)
+
+
 class Hydro(FluidBase):
     def __init__(self, ppack, pin, device=None, bvals_kernels=None, smr_kernels=None):
         device = device or capi.DEVICE
@@ -322,6 +326,10 @@ class Hydro(FluidBase):
             # off-rank neighbours: only the sweeps + update here, so that SendU can post the
             # halo messages before the c2p of the active cells is enqueued (see SendU)
             self._stage_phase(pdrive, stage, capi.PHASE_SWEEPS)
+        elif self.fused and _MERGE_C2P:
+            # no off-rank neighbour: ONE ConsToPrim over all cells after the ghost fill (ConToPrim below) instead of
+            # c2p(active cells) here + c2p(ghost shell) there
+            self._stage_phase(pdrive, stage, capi.PHASE_SWEEPS)
         elif self.fused:
             # pass A + ConsToPrim of the active cells (+ CFL scan on the last stage) in one
             # call; the ghost shell is converted in ConToPrim after the halo
@@ -402,9 +410,17 @@ class Hydro(FluidBase):
             return TaskStatus.complete
         if self.fused:
             do_dt = 1 if stage == pdrive.nexp_stages else 0
+            ev = getattr(self, "stage_events", None)     # bench.py: the conversion belongs to the stage's launch group
+            if ev is not None:
+                import torch
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev.append((e0, e1))
+                e0.record()
             capi.check(self.L.akmi_hydro_c2p_newdt(
                 C.byref(self.pack_c), capi._p(self.u0), capi._p(self.w0), do_dt,
                 capi._p(self.counters), capi._p(self.dt3), capi._stream()), "hydro_c2p_newdt")
+            if ev is not None:
+                e1.record()
             self._dt_ready = bool(do_dt)
             return TaskStatus.complete
         capi.check(self.L.akmi_hydro_c2p(C.byref(self.pack_c), capi._p(self.u0), capi._p(self.w0),

@@ -14,6 +14,10 @@ from .hydro import EdgeFld, FaceFld, FluidBase
 from .tasklist import TaskID, TaskStatus
 
 
+import os as _os
+_MERGE_C2P = _os.environ.get("AKMI_MERGE_C2P", "1") != "0"      # A/B switch (profiles/r03_whatif_merge_c2p.txt)
+
+
 class MHD(FluidBase):
     def __init__(self, ppack, pin, device=None, bvals_kernels=None, smr_kernels=None):
         device = device or capi.DEVICE
@@ -201,6 +205,11 @@ class MHD(FluidBase):
             # remaining kernels:  sweeps+update | SendU | CornerE+CT | SendB | c2p of the
             # active cells | RecvU, RecvB | BCs | c2p of the ghost shell
             self._stage_phase(pdrive, stage, capi.PHASE_SWEEPS)
+        elif self.fused and _MERGE_C2P:
+            # no off-rank neighbour: nothing travels underneath an early conversion of the active cells, so the
+            # stage ends with ONE ConsToPrim over all cells incl. the ghost zones, after the ghost fill
+            # (ConToPrim below), instead of c2p(active) here + c2p(ghost shell, thin slabs) there
+            self._stage_phase(pdrive, stage, capi.PHASE_SWEEPS | capi.PHASE_EMF_CT)
         elif self.fused:
             # pass A (fluxes, update, CornerE, CT) + ConsToPrim of the active cells (+ CFL scan
             # on the last stage) in one call
@@ -320,10 +329,18 @@ class MHD(FluidBase):
             return TaskStatus.complete
         if self.fused:
             do_dt = 1 if stage == pdrive.nexp_stages else 0
+            ev = getattr(self, "stage_events", None)     # bench.py: the conversion belongs to the stage's launch group
+            if ev is not None:
+                import torch
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev.append((e0, e1))
+                e0.record()
             capi.check(self.L.akmi_mhd_c2p_newdt(
                 C.byref(self.pack_c), capi._p(self.u0), *self._b(self.b0), capi._p(self.w0),
                 capi._p(self.bcc0), do_dt, capi._p(self.counters), capi._p(self.dt3),
                 capi._stream()), "mhd_c2p_newdt")
+            if ev is not None:
+                e1.record()
             self._dt_ready = bool(do_dt)
             return TaskStatus.complete
         capi.check(self.L.akmi_mhd_c2p(

@@ -363,8 +363,9 @@ def main():
     if head.get("group_calls"):
         tS = head["group_ms"]*1e-3/nst                        # seconds per stage in the launch group
         rest_ms = head["ms_per_step"]/py["nstage"] - tS*1e3
-        kname = ("akmi_%s_stage_fused launch group (sweeps + update%s + c2p of active cells)" % (
-                     blk, " + CornerE + CT" if blk == "mhd" else "")) if world == 1 else \
+        kname = ("the stage's kernel calls akmi_%s_stage_phase (sweeps + update%s) + akmi_%s_c2p_newdt (ConsToPrim of all "
+                 "cells + CFL scan), i.e. the stage without ghost fill and boundary conditions" % (
+                     blk, " + CornerE + CT" if blk == "mhd" else "", blk)) if world == 1 else \
                 "akmi_%s_stage_phase x3 of a rank (the halo messages travel between the phases)" % blk
     else:                                                     # a child of an older build: whole stage only
         tS, rest_ms = head["ms_per_step"]*1e-3/py["nstage"], None

@@ -1,0 +1,37 @@
+"""gpu: run-time options of the fused stage that change HOW a result is computed, never the result.  Each is read
+once per process, so every case runs in a process of its own and must be bit-identical to the oracle:
+  AKMI_MFBITS=1     sign words of the mass fluxes instead of the mass-flux arrays (MfBits, csrc/akmi_stage.hip)
+  AKMI_MERGE_C2P=0  c2p of the active cells inside the stage call + c2p of the ghost shell afterwards (the order a
+                    rank with off-rank neighbours uses) instead of one conversion after the ghost fill
+  AKMI_X12=0        x1 sweep and x2 march as two kernels
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+SCRIPT = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import parity_util as pu
+for native in (False, True):
+    for n, mb in ((32, 32), (32, 16), (40, 20)):
+        r = pu.compare_run("orszag_tang", n=n, dims=3, mb=mb, cycles=3, native=native)
+        assert r["bitwise_equal"] and r["cycles"] == 3 and r["dt"][0] == r["dt"][1], (native, n, mb, r)
+r = pu.compare_run("sod", n=32, dims=3, mb=16, cycles=3)
+assert r["bitwise_equal"], r
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+
+
+@pytest.mark.parametrize("env", [{"AKMI_MFBITS": "1"}, {"AKMI_MERGE_C2P": "0"}, {"AKMI_X12": "0"},
+                                 {"AKMI_MFBITS": "1", "AKMI_MERGE_C2P": "0"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
+def test_option_does_not_change_a_bit(env):
+    r = subprocess.run([sys.executable, "-c", SCRIPT], env=dict(os.environ, **env), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
