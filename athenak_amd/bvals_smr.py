@@ -19,6 +19,7 @@ Neighbours on another rank are not supported on this path yet (one pack per proc
 mesh); Mesh refuses `refinement = static` with more than one rank.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -253,6 +254,9 @@ class HipSmrKernels:
         self._call("akmi_smr_p2c_fine", C.byref(pack), C.byref(smr), nvar, capi._p(w), *f, capi._p(u),
                    capi._stream())
 
+    def gather_same(self, pack, nvar, tab27, u):
+        self._call("akmi_bvals_cc_local", C.byref(pack), nvar, capi._p(tab27), capi._p(u), capi._stream())
+
     def prolong_fc(self, pack, smr, cb, b):
         self._call("akmi_smr_prolong_fc", C.byref(pack), C.byref(smr), capi._p(cb.x1f), capi._p(cb.x2f),
                    capi._p(cb.x3f), capi._p(b.x1f), capi._p(b.x2f), capi._p(b.x3f), capi._stream())
@@ -298,11 +302,13 @@ class HipSmrKernels:
         self._call("akmi_smr_unpack_emf", C.byref(pack), C.byref(smr), capi._p(nflx), capi._p(buf),
                    capi._p(efld.x1e), capi._p(efld.x2e), capi._p(efld.x3e), capi._stream())
 
-    def restrict_cc(self, pack, nvar, u, cu):
-        self._call("akmi_restrict_cc", C.byref(pack), nvar, capi._p(u), capi._p(cu), capi._stream())
+    def restrict_cc(self, pack, nvar, u, cu, mask=None):
+        self._call("akmi_restrict_cc_masked", C.byref(pack), nvar, capi._p(mask) if mask is not None else None,
+                   capi._p(u), capi._p(cu), capi._stream())
 
-    def restrict_fc(self, pack, b, cb):
-        self._call("akmi_restrict_fc", C.byref(pack), capi._p(b.x1f), capi._p(b.x2f), capi._p(b.x3f),
+    def restrict_fc(self, pack, b, cb, mask=None):
+        self._call("akmi_restrict_fc_masked", C.byref(pack), capi._p(mask) if mask is not None else None,
+                   capi._p(b.x1f), capi._p(b.x2f), capi._p(b.x3f),
                    capi._p(cb.x1f), capi._p(cb.x2f), capi._p(cb.x3f), capi._stream())
 
 
@@ -360,11 +366,31 @@ class MeshBoundaryValuesSMR:
         self.buf = [torch.zeros(max(sz, 1), dtype=torch.float64, device=device) for sz in self.buf_sizes]
         self.t_soff = dev(self.soff_host) if self.peers else None
         self.t_roff = dev(self.roff_host) if self.peers else None
+        # same-level neighbours in this pack: one direct gather (akmi_bvals_cc_local with the 27-direction table of
+        # the uniform-mesh path) instead of pack -> buffer -> unpack; the SMR kernels skip those slots
+        same = -np.ones((nmb, 27), dtype=np.int32)
+        for m in range(nmb):
+            for o3 in (-1, 0, 1):
+                for o2 in (-1, 0, 1):
+                    for o1 in (-1, 0, 1):
+                        if (o1, o2, o3) == (0, 0, 0) or (ndim < 3 and o3) or (ndim < 2 and o2):
+                            continue
+                        n = NeighborIndex(o1, o2, o3, 0, 0)
+                        nb = pmb.nghbr[m].get(n)
+                        if nb is not None and nb.lev == int(pmb.mb_lev[m]) and nb.rank == pm.my_rank:
+                            same[m, (o3 + 1)*9 + (o2 + 1)*3 + (o1 + 1)] = nb.gid - ppack.gids
+        self.t_same = dev(same)
+        # blocks with a coarser neighbour: the only ones whose coarse ghost zones are ever read (by their prolongation)
+        needs = np.array([1 if any(nb.lev < int(pmb.mb_lev[m]) for nb in pmb.nghbr[m].values()) else 0
+                          for m in range(nmb)], dtype=np.uint8)
+        self.t_needs = dev(needs)
+        self.direct_same = 1 if os.environ.get("AKMI_SMR_DIRECT", "1") != "0" else 0
         self.smr_c = capi.Smr(self.nnghbr, 1 if pm.multilevel else 0, self.t_nghbr.data_ptr(),
                               self.t_lev.data_ptr(), self.t_cc.data_ptr(), self.t_fc.data_ptr(),
                               self.t_ndat.data_ptr(), self.t_ox.data_ptr(), self.t_layout.data_ptr(),
                               self.t_soff.data_ptr() if self.peers else None,
-                              self.t_roff.data_ptr() if self.peers else None)
+                              self.t_roff.data_ptr() if self.peers else None, self.direct_same,
+                              self.t_needs.data_ptr())
         self.pack_c = None
         self._works = [[], [], [], []]
         self._hsend = [None]*4
@@ -472,11 +498,11 @@ class MeshBoundaryValuesSMR:
 
     # ---- task bodies ----------------------------------------------------------------------------
     def RestrictCC(self, u, cu):
-        self.k.restrict_cc(self.pack_c, self.nvar, u, cu)
+        self.k.restrict_cc(self.pack_c, self.nvar, u, cu, self.t_needs)     # only blocks with a coarser neighbour
         return TaskStatus.complete
 
     def RestrictFC(self, b, cb):
-        self.k.restrict_fc(self.pack_c, b, cb)
+        self.k.restrict_fc(self.pack_c, b, cb, self.t_needs)
         return TaskStatus.complete
 
     def PackAndSendCC(self, u, cu):
@@ -487,6 +513,8 @@ class MeshBoundaryValuesSMR:
     def RecvAndUnpackCC(self, u, cu):
         self._wait(0)
         self.k.unpack_cc(self.pack_c, self.smr_c, self.nvar, self.buf[0], u, cu)
+        if self.direct_same:
+            self.k.gather_same(self.pack_c, self.nvar, self.t_same, u)
         return TaskStatus.complete
 
     def PackAndSendFC(self, b, cb):

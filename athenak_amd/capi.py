@@ -32,7 +32,7 @@ PHASE_SWEEPS, PHASE_EMF_CT, PHASE_C2P, PHASE_ALL = 1, 2, 4, 7     # AKMI_PHASE_*
 
 # every symbol include/akmi.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
-    "akmi_last_error", "akmi_version", "akmi_copy_cons", "akmi_rk4_copy_cons", "akmi_hydro_fluxes_fofc", "akmi_hydro_fofc", "akmi_mhd_fluxes_fofc", "akmi_mhd_fofc", "akmi_kinematic_newdt", "akmi_ambipolar_emfs", "akmi_ambipolar_fluxes", "akmi_resistive_newdt", "akmi_restrict_cc", "akmi_restrict_fc", "akmi_restrict_flux_cc", "akmi_restrict_emf", "akmi_prim2cons", "akmi_prolong_cc", "akmi_prolong_fc_shared", "akmi_prolong_fc_internal", "akmi_hydro_bcs_inflow", "akmi_bfield_bcs_inflow", "akmi_viscous_fluxes", "akmi_heat_fluxes", "akmi_conduction_newdt", "akmi_resistive_emfs", "akmi_resistive_fluxes", "akmi_hydro_fluxes", "akmi_rk_update",
+    "akmi_last_error", "akmi_version", "akmi_copy_cons", "akmi_rk4_copy_cons", "akmi_hydro_fluxes_fofc", "akmi_hydro_fofc", "akmi_mhd_fluxes_fofc", "akmi_mhd_fofc", "akmi_kinematic_newdt", "akmi_ambipolar_emfs", "akmi_ambipolar_fluxes", "akmi_resistive_newdt", "akmi_restrict_cc", "akmi_restrict_fc", "akmi_restrict_cc_masked", "akmi_restrict_fc_masked", "akmi_restrict_flux_cc", "akmi_restrict_emf", "akmi_prim2cons", "akmi_prolong_cc", "akmi_prolong_fc_shared", "akmi_prolong_fc_internal", "akmi_hydro_bcs_inflow", "akmi_bfield_bcs_inflow", "akmi_viscous_fluxes", "akmi_heat_fluxes", "akmi_conduction_newdt", "akmi_resistive_emfs", "akmi_resistive_fluxes", "akmi_hydro_fluxes", "akmi_rk_update",
     "akmi_hydro_c2p", "akmi_hydro_newdt", "akmi_mhd_fluxes", "akmi_mhd_corner_e", "akmi_mhd_ct",
     "akmi_mhd_c2p", "akmi_mhd_newdt", "akmi_bvals_cc_local", "akmi_bvals_cc_pack",
     "akmi_bvals_cc_unpack", "akmi_bvals_cc_segsize", "akmi_bvals_fc_local", "akmi_bvals_fc_pack",
@@ -46,7 +46,7 @@ SYMBOLS = [
     "akmi_comm_unique_id", "akmi_comm_init_rccl", "akmi_comm_init_env", "akmi_comm_init_callbacks", "akmi_hydro_stage_fused_dt", "akmi_mhd_stage_fused_dt", "akmi_comm_finalize", "akmi_comm_allreduce_min",
     "akmi_comm_rank", "akmi_comm_nranks", "akmi_host_exchange_plan",
     "akmi_smr_exchange_cc", "akmi_smr_exchange_fc", "akmi_smr_fill_coarse_cc", "akmi_smr_fill_coarse_fc",
-    "akmi_smr_prolong_cc", "akmi_smr_prolong_fc", "akmi_smr_c2p_coarse", "akmi_smr_p2c_fine", "akmi_smr_flux_cc", "akmi_smr_emf_exchange", "akmi_smr_pack_cc", "akmi_smr_unpack_cc", "akmi_smr_pack_fc",
+    "akmi_smr_prolong_cc", "akmi_smr_prolong_fc", "akmi_smr_c2p_coarse", "akmi_smr_p2c_fine", "akmi_mhd_fluxes_update", "akmi_smr_update_save_doubles", "akmi_smr_save_update_cells", "akmi_smr_redo_update", "akmi_smr_flux_cc", "akmi_smr_emf_exchange", "akmi_smr_pack_cc", "akmi_smr_unpack_cc", "akmi_smr_pack_fc",
     "akmi_selftest_fp64",
     "akmi_smr_unpack_fc", "akmi_smr_pack_flux_cc", "akmi_smr_unpack_flux_cc", "akmi_smr_pack_emf", "akmi_smr_unpack_emf",
 ]
@@ -59,7 +59,7 @@ class Smr(C.Structure):
     _fields_ = [("nnghbr", C.c_int), ("multilevel", C.c_int), ("nghbr", C.c_void_p),
                 ("mblev", C.c_void_p), ("cc_tab", C.c_void_p), ("fc_tab", C.c_void_p),
                 ("ndat", C.c_void_p), ("slot_ox", C.c_void_p), ("layout", C.c_void_p),
-                ("soff", C.c_void_p), ("roff", C.c_void_p)]
+                ("soff", C.c_void_p), ("roff", C.c_void_p), ("direct_same", C.c_int), ("needs_coarse", C.c_void_p)]
 
 
 class AkmiError(RuntimeError):
@@ -79,6 +79,7 @@ def lib():
         L.akmi_bvals_cc_segsize.restype = C.c_longlong
         L.akmi_bvals_fc_segsize.restype = C.c_longlong
         L.akmi_stage_workspace_bytes.restype = C.c_longlong
+        L.akmi_smr_update_save_doubles.restype = C.c_longlong
         L.akmi_sim_create.restype = C.c_void_p
         L.akmi_sim_array.restype = C.c_void_p
         L.akmi_sim_lloc.restype = C.POINTER(C.c_int)

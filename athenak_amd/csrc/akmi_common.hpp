@@ -164,6 +164,21 @@ __device__ __forceinline__ double to_sgpr(double x) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// true when x is a normal power of two, i.e. 1/x is exact (mantissa bits all zero)
+__host__ __device__ inline bool is_pow2(double x) {
+  unsigned long long b;
+  memcpy(&b, &x, sizeof b);
+  const unsigned e = (unsigned)((b >> 52) & 0x7ff);
+  return (b & 0xfffffffffffffull) == 0 && e > 1 && e < 2046 && (b >> 63) == 0;
+}
+
+// for a power of two dx: x/dx == ldexp(x, pow2_shift(dx)) bit for bit (scaling by 2^n is exact up to the one
+// correct rounding into the subnormal range that the division performs as well); the shift is formed on the
+// scalar unit from the bits of the (wave-uniform) cell size: no reciprocal to keep in vector registers
+__device__ __forceinline__ int pow2_shift(double dx) {
+  return 1023 - (int)(((unsigned long long)__double_as_longlong(dx) >> 52) & 0x7ff);
+}
+
 // LayoutRight offsets (src/athena.hpp:111,127-128)
 __host__ __device__ __forceinline__ size_t ix5(int nv, int n3, int n2, int n1, int m, int n,
                                                int k, int j, int i) {

@@ -408,6 +408,7 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
   u0.Realloc(ncc); w0.Realloc(ncc); u1.Realloc(ncc);
   counters.Realloc(3); dt3.Realloc(3);
   multilevel = pp->pmesh->multilevel;
+  const bool fused_req = fused;
   if (multilevel) {
     // restricted fluxes replace face fluxes between Fluxes and RKUpdate: the task-granular flux arrays
     fused = false;
@@ -432,10 +433,20 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
     fofc.Realloc(static_cast<size_t>(pp->nmb_thispack)*n3*n2*n1);    // zero-filled
     nfofc.Realloc(1);
   }
+  // option AKMI_SMR_SWEEP_UPDATE=1 (refined 3-D MHD meshes without FOFC/diffusion): the sweeps store their fluxes
+  // AND update u0 in the same pass; after the flux correction only the cells behind a corrected face are redone
+  // (include/akmi.h, akmi_mhd_fluxes_update).  Bit-identical, measured slower than the three tasks
+  // (profiles/r03_config5.txt), so off unless asked for.
+  const char *su = std::getenv("AKMI_SMR_SWEEP_UPDATE");
+  sweep_update = multilevel && fused_req && !use_fofc && blk == "mhd" && ind.nx3 > 1 && su && su[0] == '1';
+  if (sweep_update) {
+    upd_acc.Realloc(ncc);
+    upd_save.Realloc(static_cast<size_t>(akmi_smr_update_save_doubles(&pack_c, nvars)));
+  }
 }
 FluidBase::~FluidBase() {
   u0.Free(); w0.Free(); u1.Free(); counters.Free(); dt3.Free(); ws.Free(); fofc.Free(); nfofc.Free();
-  dtmin_cond.Free(); coarse_u0.Free(); coarse_w0.Free();
+  dtmin_cond.Free(); coarse_u0.Free(); coarse_w0.Free(); upd_acc.Free(); upd_save.Free();
   delete psmr;
   delete pbval;
   delete peos;
@@ -547,7 +558,7 @@ MHD::MHD(MeshBlockPack *pp, ParameterInput *pin) : FluidBase(pp, pin, "mhd") {
   kinematic = pin->GetOrAddString("time", "evolution", "dynamic") == "kinematic";
   if (kinematic) {
     if (rs != "advect") AKMI_FATAL("<mhd> rsolver = '" + rs + "' not implemented for kinematic problems");
-    rsolver_method = AKMI_RS_ADVECT; fused = false;
+    rsolver_method = AKMI_RS_ADVECT; fused = sweep_update = false;
   } else if (rs == "llf") rsolver_method = AKMI_RS_LLF;
   else if (rs == "hlle") rsolver_method = AKMI_RS_HLLE;
   else if (rs == "hlld") rsolver_method = AKMI_RS_HLLD;
@@ -900,6 +911,7 @@ TaskStatus Hydro::RecvU(Driver *d, int stage) {            // hydro_tasks.cpp:32
   if (multilevel) {
     psmr->Wait(0, stream);
     AKCHK(akmi_smr_unpack_cc(&pack_c, &psmr->smr_c, nvars, psmr->buf[0].p, u0.p, coarse_u0.p, stream));
+    if (psmr->smr_c.direct_same) AKCHK(akmi_bvals_cc_local(&pack_c, nvars, psmr->d_same.p, u0.p, stream));
   } else if (pbval) {
     pbval->RecvAndUnpackCC(u0.p, stream);
   }
@@ -922,7 +934,7 @@ TaskStatus Hydro::SendFlux(Driver *d, int stage) {         // hydro_tasks.cpp:20
   return TaskStatus::complete;
 }
 TaskStatus Hydro::RestrictU(Driver *d, int stage) {        // hydro_tasks.cpp:291-300
-  if (multilevel) AKCHK(akmi_restrict_cc(&pack_c, nvars, u0.p, coarse_u0.p, stream));
+  if (multilevel) AKCHK(akmi_restrict_cc_masked(&pack_c, nvars, psmr->smr_c.needs_coarse, u0.p, coarse_u0.p, stream));
   return TaskStatus::complete;
 }
 TaskStatus Hydro::Prolongate(Driver *d, int stage) {       // hydro_tasks.cpp:381-400
@@ -958,6 +970,10 @@ TaskStatus Hydro::ConToPrim(Driver *d, int stage) {        // hydro_tasks.cpp:40
     AKCHK(akmi_hydro_c2p_newdt(&pack_c, u0.p, w0.p, do_dt, counters.p, dt3.p, stream));
     d->ProfMark(stream);
     dt_ready_ = do_dt;
+  } else if (multilevel && stage == d->nexp_stages && !kinematic) {
+    // refined meshes (task-granular chain): the last conversion carries the CFL scan of NewTimeStep along
+    AKCHK(akmi_hydro_c2p_newdt(&pack_c, u0.p, w0.p, 1, counters.p, dt3.p, stream));
+    dt_ready_ = true;
   } else {
     AKCHK(akmi_hydro_c2p(&pack_c, u0.p, w0.p, 0, n1 - 1, 0, n2 - 1, 0, n3 - 1, counters.p, stream));
   }
@@ -987,6 +1003,16 @@ TaskStatus MHD::CopyCons(Driver *d, int stage) {           // mhd_tasks.cpp:162-
 }
 TaskStatus MHD::Fluxes(Driver *d, int stage) {             // mhd_tasks.cpp:177-216
   if (fused) return TaskStatus::complete;
+  if (sweep_update) {
+    // refined 3-D meshes: fluxes + RKUpdate in one pass; the cells behind a face that SendFlux/RecvFlux will
+    // correct are saved first and redone in RKUpdate
+    AKCHK(akmi_smr_save_update_cells(&pack_c, &psmr->smr_c, nvars, u0.p, upd_save.p, stream));
+    AKCHK(akmi_mhd_fluxes_update(&pack_c, recon_method, rsolver_method, d->gam0[stage - 1], d->gam1[stage - 1],
+                                 d->beta[stage - 1]*pmy_pack->pmesh->dt, w0.p, bcc0.p, b0.x1f.p, b0.x2f.p,
+                                 b0.x3f.p, u0.p, u1.p, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, e3x1.p, e2x1.p, e1x2.p,
+                                 e3x2.p, e2x3.p, e1x3.p, upd_acc.p, stream));
+    return TaskStatus::complete;
+  }
   if (use_fofc)                                             // mhd_fluxes.cpp:100-105
     AKCHK(akmi_mhd_fluxes_fofc(&pack_c, recon_method, rsolver_method, w0.p, bcc0.p, b0.x1f.p,
                                b0.x2f.p, b0.x3f.p, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, e3x1.p,
@@ -1037,6 +1063,9 @@ TaskStatus MHD::RKUpdate(Driver *d, int stage) {           // mhd_update.cpp:24-
       SwapArr(b0.x1f, b1.x1f); SwapArr(b0.x2f, b1.x2f); SwapArr(b0.x3f, b1.x3f); b_swapped = !b_swapped;
     }
     interior_done_ = true; dt_ready_ = do_dt;
+  } else if (sweep_update) {
+    AKCHK(akmi_smr_redo_update(&pack_c, &psmr->smr_c, nvars, d->gam0[stage - 1], d->gam1[stage - 1], beta_dt,
+                               upd_save.p, u0.p, u1.p, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, stream));
   } else {
     AKCHK(akmi_rk_update(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1], beta_dt, u0.p, u1.p,
                          uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, 1, stream));
@@ -1079,6 +1108,7 @@ TaskStatus MHD::RecvU(Driver *d, int stage) {
   if (multilevel) {
     psmr->Wait(0, stream);
     AKCHK(akmi_smr_unpack_cc(&pack_c, &psmr->smr_c, nvars, psmr->buf[0].p, u0.p, coarse_u0.p, stream));
+    if (psmr->smr_c.direct_same) AKCHK(akmi_bvals_cc_local(&pack_c, nvars, psmr->d_same.p, u0.p, stream));
   } else if (pbval && !(fused && peers())) {
     pbval->RecvAndUnpackCC(u0.p, stream);                                     // else: in RecvB
   }
@@ -1121,13 +1151,13 @@ TaskStatus MHD::SendFlux(Driver *d, int stage) {           // mhd_tasks.cpp:225-
   return TaskStatus::complete;
 }
 TaskStatus MHD::RestrictU(Driver *d, int stage) {          // mhd_tasks.cpp:315-322
-  if (multilevel) AKCHK(akmi_restrict_cc(&pack_c, nvars, u0.p, coarse_u0.p, stream));
+  if (multilevel) AKCHK(akmi_restrict_cc_masked(&pack_c, nvars, psmr->smr_c.needs_coarse, u0.p, coarse_u0.p, stream));
   return TaskStatus::complete;
 }
 TaskStatus MHD::RestrictB(Driver *d, int stage) {          // mhd_tasks.cpp:691-697
   if (multilevel)
-    AKCHK(akmi_restrict_fc(&pack_c, b0.x1f.p, b0.x2f.p, b0.x3f.p, coarse_b0.x1f.p, coarse_b0.x2f.p,
-                           coarse_b0.x3f.p, stream));
+    AKCHK(akmi_restrict_fc_masked(&pack_c, psmr->smr_c.needs_coarse, b0.x1f.p, b0.x2f.p, b0.x3f.p, coarse_b0.x1f.p,
+                                  coarse_b0.x2f.p, coarse_b0.x3f.p, stream));
   return TaskStatus::complete;
 }
 // SendE + RecvE (mhd_tasks.cpp:402-417).  Uniform mesh: every copy of a shared edge EMF is computed by
@@ -1221,6 +1251,10 @@ TaskStatus MHD::ConToPrim(Driver *d, int stage) {
                              counters.p, dt3.p, stream));
     d->ProfMark(stream);
     dt_ready_ = do_dt;
+  } else if (multilevel && stage == d->nexp_stages && !kinematic) {
+    AKCHK(akmi_mhd_c2p_newdt(&pack_c, u0.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, w0.p, bcc0.p, 1, counters.p, dt3.p,
+                             stream));
+    dt_ready_ = true;
   } else {
     AKCHK(akmi_mhd_c2p(&pack_c, u0.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, w0.p, bcc0.p, 0, n1 - 1, 0, n2 - 1,
                        0, n3 - 1, counters.p, stream));

@@ -309,8 +309,10 @@ class MeshBoundaryValuesSMR {
   ~MeshBoundaryValuesSMR();
   MeshBlockPack *pmy_pack;
   int nvar, nnghbr;
-  akmi_smr smr_c;
+  akmi_smr smr_c{};
   DvceArray<int> d_nghbr, d_lev, d_cc, d_fc, d_ndat, d_ox, d_nflx;
+  DvceArray<int> d_same;          // [nmb][27] same-level neighbours in this pack: filled by akmi_bvals_cc_local
+  DvceArray<unsigned char> d_needs;   // [nmb] block has a coarser neighbour (akmi_smr::needs_coarse)
   DvceArray<long long> d_layout, d_soff, d_roff;
   DvceArray<Real> buf[4];         // cc vars, cc flux, fc vars, fc flux
   // ranks: peers and the slices of buf[cls] that travel (akmi_smr::soff/roff address the segments)
@@ -347,6 +349,8 @@ class FluidBase {
        dt_resist = static_cast<Real>(FLT_MAX);
   DvceArray<Real> dtmin_cond;
   bool use_fofc = false;                // hydro.hpp:116-117, mhd.hpp
+  bool sweep_update = false;            // refined 3-D MHD: Fluxes updates u0 too, RKUpdate redoes corrected cells
+  DvceArray<Real> upd_acc, upd_save;    //   scratch of akmi_mhd_fluxes_update / akmi_smr_save_update_cells
   DvceArray<unsigned char> fofc;
   DvceArray<int> nfofc;                 // EventCounters::nfofc (mesh.hpp:71), kept on the device
   Real dtnew = static_cast<Real>(FLT_MAX);

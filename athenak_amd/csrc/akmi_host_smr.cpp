@@ -508,6 +508,29 @@ MeshBoundaryValuesSMR::MeshBoundaryValuesSMR(MeshBlockPack *pp, int nvar_) : pmy
     buf[cls].Realloc(sizes[cls]);
     HIPCHK(hipMemset(buf[cls].p, 0, sizeof(Real)*sizes[cls]));
   }
+  // same-level neighbours in this pack: one direct gather (the uniform-mesh kernel with a 27-direction table) instead
+  // of pack -> buffer -> unpack; akmi_smr::direct_same makes the SMR kernels skip those slots (AKMI_SMR_DIRECT=0: off)
+  {
+    std::vector<int> same(static_cast<size_t>(nmb)*27, -1);
+    for (int m = 0; m < nmb; ++m)
+      for (int o3 = -1; o3 <= 1; ++o3) for (int o2 = -1; o2 <= 1; ++o2) for (int o1 = -1; o1 <= 1; ++o1) {
+        if ((o1 == 0 && o2 == 0 && o3 == 0) || (ndim < 3 && o3) || (ndim < 2 && o2)) continue;
+        const int *q = &ngh[(static_cast<size_t>(m)*56 + NeighborIndex(o1, o2, o3, 0, 0))*3];
+        if (q[0] >= 0 && q[0] < nmb && q[1] == pmb->mb_lev[m]) same[static_cast<size_t>(m)*27 + (o3 + 1)*9 + (o2 + 1)*3 + (o1 + 1)] = q[0];
+      }
+    up_i(d_same, same);
+    std::vector<unsigned char> needs(nmb, 0);
+    for (int m = 0; m < nmb; ++m)
+      for (int n = 0; n < 56; ++n) {
+        const int *q = &ngh[(static_cast<size_t>(m)*56 + n)*3];
+        if (q[0] >= 0 && q[1] < pmb->mb_lev[m]) needs[m] = 1;
+      }
+    d_needs.Realloc(needs.size());
+    HIPCHK(hipMemcpy(d_needs.p, needs.data(), needs.size(), hipMemcpyHostToDevice));
+    smr_c.needs_coarse = d_needs.p;
+    const char *e = std::getenv("AKMI_SMR_DIRECT");
+    smr_c.direct_same = (e && std::atoi(e) == 0) ? 0 : 1;
+  }
   smr_c.nnghbr = nnghbr; smr_c.multilevel = 1;
   smr_c.soff = peers.empty() ? nullptr : d_soff.p;   // one rank: layout[] addresses the buffers
   smr_c.roff = peers.empty() ? nullptr : d_roff.p;
@@ -516,7 +539,7 @@ MeshBoundaryValuesSMR::MeshBoundaryValuesSMR(MeshBlockPack *pp, int nvar_) : pmy
 }
 
 MeshBoundaryValuesSMR::~MeshBoundaryValuesSMR() {
-  d_nghbr.Free(); d_lev.Free(); d_cc.Free(); d_fc.Free(); d_ndat.Free(); d_ox.Free(); d_nflx.Free();
+  d_nghbr.Free(); d_lev.Free(); d_cc.Free(); d_fc.Free(); d_ndat.Free(); d_ox.Free(); d_nflx.Free(); d_same.Free(); d_needs.Free();
   d_layout.Free(); d_soff.Free(); d_roff.Free();
   for (auto &b : buf) b.Free();
 }

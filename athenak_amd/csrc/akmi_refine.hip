@@ -44,10 +44,12 @@ __device__ __forceinline__ double mm8(double dl, double dr) {
 
 // MeshRefinement::RestrictCC, src/mesh/mesh_refinement.cpp:1223-1277
 __global__ void __launch_bounds__(256)
-k_restrict_cc(Geo g, CGeo c, int nvar, const double *__restrict__ u, double *__restrict__ cu) {
+k_restrict_cc(Geo g, CGeo c, int nvar, const unsigned char *__restrict__ mask, const double *__restrict__ u,
+              double *__restrict__ cu) {
   const Box bx{c.cis, c.cie, c.cjs, c.cje, c.cks, c.cke};
   int m, n, k, j, i;
   if (!box_index(bx, nvar, m, n, k, j, i)) return;
+  if (mask && !mask[m]) return;
   const int fi = 2*i - c.cis, fj = 2*j - c.cjs, fk = 2*k - c.cks;
   auto U = [&](int kk, int jj, int ii) { return u[ix5(nvar, g.N3, g.N2, g.N1, m, n, kk, jj, ii)]; };
   double r;
@@ -63,10 +65,11 @@ struct CFaces { const double *b1, *b2, *b3; };
 
 // MeshRefinement::RestrictFC, src/mesh/mesh_refinement.cpp:1283-1382
 __global__ void __launch_bounds__(256)
-k_restrict_fc(Geo g, CGeo c, CFaces f, Faces cf) {
+k_restrict_fc(Geo g, CGeo c, const unsigned char *__restrict__ mask, CFaces f, Faces cf) {
   const Box bx{c.cis, c.cie, c.cjs, c.cje, c.cks, c.cke};
   int m, v, k, j, i;
   if (!box_index(bx, 1, m, v, k, j, i)) return;
+  if (mask && !mask[m]) return;
   const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
   const int fi = 2*i - c.cis, fj = 2*j - c.cjs, fk = 2*k - c.cks;
   auto B1 = [&](int kk, int jj, int ii) { return f.b1[ix4(N3, N2, N1 + 1, m, kk, jj, ii)]; };
@@ -346,22 +349,30 @@ __global__ void k_prim2cons(Geo g, Box bx, int is_ideal, const double *__restric
 
 extern "C" {
 
-int akmi_restrict_cc(const akmi_pack *p, int nvar, const double *u, double *cu, void *stream) {
+int akmi_restrict_cc_masked(const akmi_pack *p, int nvar, const unsigned char *mask, const double *u, double *cu,
+                            void *stream) {
   Geo g = make_geo(p); CGeo c = make_cgeo(g);
   const Box bx{c.cis, c.cie, c.cjs, c.cje, c.cks, c.cke};
-  k_restrict_cc<<<box_grid(bx, nvar, g.nmb), dim3(64, 4), 0, (hipStream_t)stream>>>(g, c, nvar, u, cu);
+  k_restrict_cc<<<box_grid(bx, nvar, g.nmb), dim3(64, 4), 0, (hipStream_t)stream>>>(g, c, nvar, mask, u, cu);
   AKMI_CHECK_LAUNCH("restrict_cc");
   return AKMI_COMPLETE;
 }
+int akmi_restrict_cc(const akmi_pack *p, int nvar, const double *u, double *cu, void *stream) {
+  return akmi_restrict_cc_masked(p, nvar, nullptr, u, cu, stream);
+}
 
-int akmi_restrict_fc(const akmi_pack *p, const double *bx1f, const double *bx2f, const double *bx3f,
-                     double *cbx1f, double *cbx2f, double *cbx3f, void *stream) {
+int akmi_restrict_fc_masked(const akmi_pack *p, const unsigned char *mask, const double *bx1f, const double *bx2f,
+                            const double *bx3f, double *cbx1f, double *cbx2f, double *cbx3f, void *stream) {
   Geo g = make_geo(p); CGeo c = make_cgeo(g);
   const Box bx{c.cis, c.cie, c.cjs, c.cje, c.cks, c.cke};
   k_restrict_fc<<<box_grid(bx, 1, g.nmb), dim3(64, 4), 0, (hipStream_t)stream>>>(
-      g, c, CFaces{bx1f, bx2f, bx3f}, Faces{cbx1f, cbx2f, cbx3f});
+      g, c, mask, CFaces{bx1f, bx2f, bx3f}, Faces{cbx1f, cbx2f, cbx3f});
   AKMI_CHECK_LAUNCH("restrict_fc");
   return AKMI_COMPLETE;
+}
+int akmi_restrict_fc(const akmi_pack *p, const double *bx1f, const double *bx2f, const double *bx3f,
+                     double *cbx1f, double *cbx2f, double *cbx3f, void *stream) {
+  return akmi_restrict_fc_masked(p, nullptr, bx1f, bx2f, bx3f, cbx1f, cbx2f, cbx3f, stream);
 }
 
 int akmi_restrict_flux_cc(const akmi_pack *p, int nvar, int dir, const int *box, const double *flx,

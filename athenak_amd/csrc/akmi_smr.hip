@@ -68,10 +68,12 @@ struct Tab {                      // device view of akmi_smr
   const long long *lay;
   const long long *soff, *roff;   // [4][nmb][56] or null: where a segment is written / read (ranks)
   int nmb;
+  int direct;                     // akmi_smr::direct_same
+  const unsigned char *needs;     // akmi_smr::needs_coarse
 };
 static Tab make_tab(const akmi_pack *p, const akmi_smr *t) {
   return Tab{t->nnghbr, t->multilevel, t->nghbr, t->mblev, t->cc_tab, t->fc_tab, t->ndat, t->layout,
-             t->soff, t->roff, p->nmb};
+             t->soff, t->roff, p->nmb, t->direct_same, t->needs_coarse};
 }
 #define NGID(t, m, n) (t).ng[((size_t)(m)*56 + (n))*3]
 #define NLEV(t, m, n) (t).ng[((size_t)(m)*56 + (n))*3 + 1]
@@ -98,19 +100,22 @@ __device__ __forceinline__ int ndat_of(const Tab &t, int fc, int n, int sr, int 
 __global__ void __launch_bounds__(256)
 k_smr_pack_cc(SGeo s, Tab t, int nvar, const double *__restrict__ a, const double *__restrict__ ca,
               double *__restrict__ buf) {
-  const int v = blockIdx.x%nvar, n = (blockIdx.x/nvar)%t.nnghbr, m = blockIdx.x/(nvar*t.nnghbr);
+  // one workgroup per (block, slot), all variables (a fifth of the workgroups of the (block, slot, variable) grid:
+  // most slots of a block are empty and the launch itself was a third of the kernel's time)
+  const int n = blockIdx.x%t.nnghbr, m = blockIdx.x/t.nnghbr;
   const int dm = NGID(t, m, n);
   if (dm < 0) return;
   const int nl = NLEV(t, m, n), ml = t.lev[m];
+  if (t.direct && nl == ml && dm < t.nmb) return;          // filled by the caller's direct gather
   const Bx b = box_of(t.cc, T_SEND, nl < ml ? K_COAR : (nl == ml ? K_SAME : K_FINE), n, 0);
   const int cnt = bcount(b);
-  double *out = buf + seg_w(t, 0, m, n, dm, NDST(t, m, n)) + (size_t)cnt*v;
+  double *out = buf + seg_w(t, 0, m, n, dm, NDST(t, m, n));
   const int coarse = nl < ml;
   const double *src = coarse ? ca : a;
   for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
     int k, j, i;
     bdecode(b, e, k, j, i);
-    out[e] = src[c5(s, coarse, nvar, m, v, k, j, i)];
+    for (int v = 0; v < nvar; ++v) out[(size_t)cnt*v + e] = src[c5(s, coarse, nvar, m, v, k, j, i)];
   }
 }
 
@@ -118,18 +123,19 @@ k_smr_pack_cc(SGeo s, Tab t, int nvar, const double *__restrict__ a, const doubl
 __global__ void __launch_bounds__(256)
 k_smr_unpack_cc(SGeo s, Tab t, int nvar, const double *__restrict__ buf, double *__restrict__ a,
                 double *__restrict__ ca) {
-  const int v = blockIdx.x%nvar, n = (blockIdx.x/nvar)%t.nnghbr, m = blockIdx.x/(nvar*t.nnghbr);
+  const int n = blockIdx.x%t.nnghbr, m = blockIdx.x/t.nnghbr;
   if (NGID(t, m, n) < 0) return;
   const int nl = NLEV(t, m, n), ml = t.lev[m];
+  if (t.direct && nl == ml && NGID(t, m, n) < t.nmb) return;
   const Bx b = box_of(t.cc, T_RECV, nl < ml ? K_COAR : (nl == ml ? K_SAME : K_FINE), n, 0);
   const int cnt = bcount(b);
-  const double *in = buf + seg_r(t, 0, m, n) + (size_t)cnt*v;
+  const double *in = buf + seg_r(t, 0, m, n);
   const int coarse = nl < ml;
   double *dst = coarse ? ca : a;
   for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
     int k, j, i;
     bdecode(b, e, k, j, i);
-    dst[c5(s, coarse, nvar, m, v, k, j, i)] = in[e];
+    for (int v = 0; v < nvar; ++v) dst[c5(s, coarse, nvar, m, v, k, j, i)] = in[(size_t)cnt*v + e];
   }
 }
 
@@ -188,7 +194,7 @@ k_smr_unpack_fc(SGeo s, Tab t, const double *__restrict__ buf, F3 b, F3 cb) {
 __global__ void __launch_bounds__(256)
 k_smr_fill_coarse_cc(SGeo s, Tab t, int nvar, const double *__restrict__ a, double *__restrict__ ca) {
   const int v = blockIdx.x%nvar, n = (blockIdx.x/nvar)%t.nnghbr, m = blockIdx.x/(nvar*t.nnghbr);
-  if (NGID(t, m, n) < 0 || NLEV(t, m, n) != t.lev[m]) return;
+  if (NGID(t, m, n) < 0 || NLEV(t, m, n) != t.lev[m] || (t.needs && !t.needs[m])) return;
   const Bx r = box_of(t.cc, T_RECV, K_SAME, n, 0);
   const Bx b{(r.il + s.cis)/2, (r.iu + s.cis)/2, (r.jl + s.cjs)/2, (r.ju + s.cjs)/2, (r.kl + s.cks)/2,
              (r.ku + s.cks)/2};
@@ -210,7 +216,7 @@ k_smr_fill_coarse_cc(SGeo s, Tab t, int nvar, const double *__restrict__ a, doub
 __global__ void __launch_bounds__(256)
 k_smr_fill_coarse_fc(SGeo s, Tab t, CF3 b, F3 cb) {
   const int v = blockIdx.x%3, n = (blockIdx.x/3)%t.nnghbr, m = blockIdx.x/(3*t.nnghbr);
-  if (NGID(t, m, n) < 0 || NLEV(t, m, n) != t.lev[m]) return;
+  if (NGID(t, m, n) < 0 || NLEV(t, m, n) != t.lev[m] || (t.needs && !t.needs[m])) return;
   const Bx r = box_of(t.fc, T_RECV, K_SAME, n, v);
   const Bx bx{(r.il + s.cis)/2, (r.iu + s.cis)/2, (r.jl + s.cjs)/2, (r.ju + s.cjs)/2, (r.kl + s.cks)/2,
               (r.ku + s.cks)/2};
@@ -247,13 +253,14 @@ __device__ __forceinline__ double s_mm8(double dl, double dr) {
 // ---- ProlongateCC (ProlongCC, src/mesh/prolongation.hpp:19-63) -----------------------------------
 __global__ void __launch_bounds__(256)
 k_smr_prolong_cc(SGeo s, Tab t, int nvar, const double *__restrict__ ca, double *__restrict__ a) {
-  const int v = blockIdx.x%nvar, n = (blockIdx.x/nvar)%t.nnghbr, m = blockIdx.x/(nvar*t.nnghbr);
+  const int n = blockIdx.x%t.nnghbr, m = blockIdx.x/t.nnghbr;
   if (NGID(t, m, n) < 0 || !(NLEV(t, m, n) < t.lev[m])) return;
   const Bx b = box_of(t.cc, T_RECV, K_PROL, n, 0);
   const int cnt = bcount(b);
-  auto CA = [&](int kk, int jj, int ii) { return ca[c5(s, 1, nvar, m, v, kk, jj, ii)]; };
-  auto A = [&](int kk, int jj, int ii) -> double & { return a[c5(s, 0, nvar, m, v, kk, jj, ii)]; };
-  for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+  for (int ev = threadIdx.x; ev < cnt*nvar; ev += blockDim.x) {
+    const int v = ev/cnt, e = ev - v*cnt;
+    auto CA = [&](int kk, int jj, int ii) { return ca[c5(s, 1, nvar, m, v, kk, jj, ii)]; };
+    auto A = [&](int kk, int jj, int ii) -> double & { return a[c5(s, 0, nvar, m, v, kk, jj, ii)]; };
     int k, j, i;
     bdecode(b, e, k, j, i);
     const int fi = (i - s.cis)*2 + s.is, fj = (j - s.cjs)*2 + s.js, fk = (k - s.cks)*2 + s.ks;
@@ -551,6 +558,62 @@ k_smr_unpack_flux_cc(SGeo s, Tab t, int nvar, int fs, const double *__restrict__
   }
 }
 
+// ---- update-in-the-sweeps on refined meshes: save / redo of the cells next to a corrected face -------------------
+// The flux correction (k_smr_unpack_flux_cc) replaces the fluxes of a coarse block on the faces it shares with
+// finer neighbours.  When the sweeps have already updated u0 (akmi_mhd_fluxes_update), exactly the cells behind
+// those faces carry a wrong divergence: their state before the update is saved first (k_smr_save_cells) and the
+// update is repeated for them from the stored, corrected fluxes (k_smr_redo_update), with the expression and the
+// rounding order of RKUpdate (mhd_update.cpp:57-80).  Face slots 0-15 and 24-31 -> compact slot 0-23.
+__device__ __forceinline__ int face_slot(int n) { return n < 16 ? n : (n >= 24 && n < 32 ? n - 8 : -1); }
+__device__ __forceinline__ Bx cells_behind(const SGeo &s, const Bx &f, int dir) {
+  Bx c = f;
+  if (dir == 0) { c.il = c.iu = (f.il == s.is) ? f.il : f.il - 1; }
+  else if (dir == 1) { c.jl = c.ju = (f.jl == s.js) ? f.jl : f.jl - 1; }
+  else { c.kl = c.ku = (f.kl == s.ks) ? f.kl : f.kl - 1; }
+  return c;
+}
+__global__ void __launch_bounds__(256)
+k_smr_save_cells(SGeo s, Tab t, int nvar, long long cap, const double *__restrict__ u, double *__restrict__ save) {
+  const int n = blockIdx.x%t.nnghbr, m = blockIdx.x/t.nnghbr;
+  const int fsl = face_slot(n);
+  if (fsl < 0 || NGID(t, m, n) < 0 || !(NLEV(t, m, n) > t.lev[m])) return;
+  const int dir = n < 8 ? 0 : (n < 16 ? 1 : 2);
+  const Bx c = cells_behind(s, box_of(t.cc, T_RECV, K_FLXC, n, 0), dir);
+  const int cnt = bcount(c);
+  double *out = save + ((size_t)m*24 + fsl)*nvar*cap;
+  for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+    int k, j, i;
+    bdecode(c, e, k, j, i);
+    for (int v = 0; v < nvar; ++v) out[(size_t)v*cap + e] = u[c5(s, 0, nvar, m, v, k, j, i)];
+  }
+}
+__global__ void __launch_bounds__(256)
+k_smr_redo_update(SGeo s, Tab t, int nvar, long long cap, double gam0, double gam1, double beta_dt, const double *dxs,
+                  const double *__restrict__ save, double *__restrict__ u0, const double *__restrict__ u1, Flx3 flx) {
+  const int n = blockIdx.x%t.nnghbr, m = blockIdx.x/t.nnghbr;
+  const int fsl = face_slot(n);
+  if (fsl < 0 || NGID(t, m, n) < 0 || !(NLEV(t, m, n) > t.lev[m])) return;
+  const int dir = n < 8 ? 0 : (n < 16 ? 1 : 2);
+  const Bx c = cells_behind(s, box_of(t.cc, T_RECV, K_FLXC, n, 0), dir);
+  const int cnt = bcount(c);
+  const double *old = save + ((size_t)m*24 + fsl)*nvar*cap;
+  const double dx1 = dxs[3*m], dx2 = dxs[3*m + 1], dx3 = dxs[3*m + 2];
+  for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+    int k, j, i;
+    bdecode(c, e, k, j, i);
+    for (int v = 0; v < nvar; ++v) {
+      double divf = (flx.f[0][ix5(nvar, s.N3, s.N2, s.N1 + 1, m, v, k, j, i + 1)] -
+                     flx.f[0][ix5(nvar, s.N3, s.N2, s.N1 + 1, m, v, k, j, i)])/dx1;
+      divf += (flx.f[1][ix5(nvar, s.N3, s.N2 + 1, s.N1, m, v, k, j + 1, i)] -
+               flx.f[1][ix5(nvar, s.N3, s.N2 + 1, s.N1, m, v, k, j, i)])/dx2;
+      divf += (flx.f[2][ix5(nvar, s.N3 + 1, s.N2, s.N1, m, v, k + 1, j, i)] -
+               flx.f[2][ix5(nvar, s.N3 + 1, s.N2, s.N1, m, v, k, j, i)])/dx3;
+      const size_t q = c5(s, 0, nvar, m, v, k, j, i);
+      u0[q] = gam0*old[(size_t)v*cap + e] + gam1*u1[q] - beta_dt*divf;
+    }
+  }
+}
+
 // ---- edge EMFs ------------------------------------------------------------------------------------
 struct E3 { double *e[3]; };
 __device__ __forceinline__ size_t e4(const SGeo &s, int v, int m, int k, int j, int i) {
@@ -709,7 +772,7 @@ static int smr_exchange_cc(const akmi_pack *p, const akmi_smr *t, int nvar, doub
   const SGeo s = make_sgeo(p);
   const Tab tb = make_tab(p, t);
   hipStream_t st = (hipStream_t)stream;
-  const unsigned nb = (unsigned)p->nmb*tb.nnghbr*nvar;
+  const unsigned nb = (unsigned)p->nmb*tb.nnghbr;
   if (phase & 1) k_smr_pack_cc<<<nb, 256, 0, st>>>(s, tb, nvar, u, cu, buf);
   if (phase & 2) k_smr_unpack_cc<<<nb, 256, 0, st>>>(s, tb, nvar, buf, u, cu);
   AKMI_CHECK_LAUNCH("smr_exchange_cc");
@@ -753,7 +816,7 @@ int akmi_smr_prolong_cc(const akmi_pack *p, const akmi_smr *t, int nvar, const d
                         void *stream) {
   if (check_smr(p, t, "smr_prolong_cc") != AKMI_COMPLETE) return AKMI_FAIL;
   const Tab tb = make_tab(p, t);
-  k_smr_prolong_cc<<<(unsigned)p->nmb*tb.nnghbr*nvar, 256, 0, (hipStream_t)stream>>>(make_sgeo(p), tb, nvar, cu, u);
+  k_smr_prolong_cc<<<(unsigned)p->nmb*tb.nnghbr, 256, 0, (hipStream_t)stream>>>(make_sgeo(p), tb, nvar, cu, u);
   AKMI_CHECK_LAUNCH("smr_prolong_cc");
   return AKMI_COMPLETE;
 }
@@ -835,6 +898,36 @@ static int smr_emf_exchange(const akmi_pack *p, const akmi_smr *t, const int *nf
     k_smr_average_flux_fc<<<nb, 256, 0, st>>>(s, tb, nflx, ef);
   }
   AKMI_CHECK_LAUNCH("smr_emf_exchange");
+  return AKMI_COMPLETE;
+}
+
+long long akmi_smr_update_save_doubles(const akmi_pack *p, int nvar) {
+  const long long a = (long long)p->nx1*p->nx2, b = (long long)p->nx1*p->nx3, c = (long long)p->nx2*p->nx3;
+  const long long cap = ((a > b ? (a > c ? a : c) : (b > c ? b : c)) + 3)/4;      // a quarter of the largest face
+  return (long long)p->nmb*24*nvar*cap;
+}
+static long long save_cap(const akmi_pack *p, int nvar) { return akmi_smr_update_save_doubles(p, nvar)/((long long)p->nmb*24*nvar); }
+
+int akmi_smr_save_update_cells(const akmi_pack *p, const akmi_smr *t, int nvar, const double *u0, double *save,
+                               void *stream) {
+  if (check_smr(p, t, "smr_save_update_cells") != AKMI_COMPLETE) return AKMI_FAIL;
+  if (p->nx3 <= 1) { set_error("smr_save_update_cells: 3-D packs only"); return AKMI_FAIL; }
+  const Tab tb = make_tab(p, t);
+  k_smr_save_cells<<<(unsigned)p->nmb*tb.nnghbr, 256, 0, (hipStream_t)stream>>>(make_sgeo(p), tb, nvar, save_cap(p, nvar), u0, save);
+  AKMI_CHECK_LAUNCH("smr_save_update_cells");
+  return AKMI_COMPLETE;
+}
+
+int akmi_smr_redo_update(const akmi_pack *p, const akmi_smr *t, int nvar, double gam0, double gam1, double beta_dt,
+                         const double *save, double *u0, const double *u1, const double *flx1, const double *flx2,
+                         const double *flx3, void *stream) {
+  if (check_smr(p, t, "smr_redo_update") != AKMI_COMPLETE) return AKMI_FAIL;
+  if (p->nx3 <= 1) { set_error("smr_redo_update: 3-D packs only"); return AKMI_FAIL; }
+  const Tab tb = make_tab(p, t);
+  k_smr_redo_update<<<(unsigned)p->nmb*tb.nnghbr, 256, 0, (hipStream_t)stream>>>(
+      make_sgeo(p), tb, nvar, save_cap(p, nvar), gam0, gam1, beta_dt, p->dx, save, u0, u1,
+      Flx3{{const_cast<double *>(flx1), const_cast<double *>(flx2), const_cast<double *>(flx3)}});
+  AKMI_CHECK_LAUNCH("smr_redo_update");
   return AKMI_COMPLETE;
 }
 

@@ -118,15 +118,24 @@ k_rk_update(Geo g, double gam0, double gam1, double beta_dt, double *__restrict_
   const int k = g.ks + (blockIdx.z - m*nk);
   if (i < g.is || i > g.ie || j > g.je) return;
   const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
+  // cell sizes that are powers of two (every level of a refined mesh on a 2^n root grid): x/dx as one v_ldexp_f64,
+  // bit for bit the quotient (akmi_common.hpp pow2_shift; tests/test_gpu_fastmath.py)
+  const bool p2 = is_pow2(dx1) && is_pow2(dx2) && is_pow2(dx3);
+  const int n1 = pow2_shift(dx1), n2 = pow2_shift(dx2), n3 = pow2_shift(dx3);
   for (int n = 0; n < g.nvar; ++n) {
-    double divf = (flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + fsh, m, n, k, j, i + 1)] -
-                   flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + fsh, m, n, k, j, i)])/dx1;
-    if (g.multi_d)
-      divf += (flx2[ix5(g.nvar, g.N3, g.N2 + fsh, g.N1, m, n, k, j + 1, i)] -
-               flx2[ix5(g.nvar, g.N3, g.N2 + fsh, g.N1, m, n, k, j, i)])/dx2;
-    if (g.three_d)
-      divf += (flx3[ix5(g.nvar, g.N3 + fsh, g.N2, g.N1, m, n, k + 1, j, i)] -
-               flx3[ix5(g.nvar, g.N3 + fsh, g.N2, g.N1, m, n, k, j, i)])/dx3;
+    const double d1 = flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + fsh, m, n, k, j, i + 1)] -
+                      flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + fsh, m, n, k, j, i)];
+    double divf = p2 ? ldexp(d1, n1) : d1/dx1;
+    if (g.multi_d) {
+      const double d2 = flx2[ix5(g.nvar, g.N3, g.N2 + fsh, g.N1, m, n, k, j + 1, i)] -
+                        flx2[ix5(g.nvar, g.N3, g.N2 + fsh, g.N1, m, n, k, j, i)];
+      divf += p2 ? ldexp(d2, n2) : d2/dx2;
+    }
+    if (g.three_d) {
+      const double d3 = flx3[ix5(g.nvar, g.N3 + fsh, g.N2, g.N1, m, n, k + 1, j, i)] -
+                        flx3[ix5(g.nvar, g.N3 + fsh, g.N2, g.N1, m, n, k, j, i)];
+      divf += p2 ? ldexp(d3, n3) : d3/dx3;
+    }
     size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, n, k, j, i);
     u0[c] = gam0*u0[c] + gam1*u1[c] - beta_dt*divf;
   }
@@ -682,27 +691,31 @@ k_ct(Geo g, double gam0, double gam1, double beta_dt, const double *__restrict__
 #define E1(k, j, i) e1[ix4(g.N3 + 1, g.N2 + 1, g.N1, m, k, j, i)]
 #define E2(k, j, i) e2[ix4(g.N3 + 1, g.N2, g.N1 + 1, m, k, j, i)]
 #define E3(k, j, i) e3[ix4(g.N3, g.N2 + 1, g.N1 + 1, m, k, j, i)]
+  const bool p2 = is_pow2(dx1) && is_pow2(dx2) && is_pow2(dx3);      // x/dx as v_ldexp_f64, see k_rk_update
+  const int n1 = pow2_shift(dx1), n2 = pow2_shift(dx2), n3 = pow2_shift(dx3);
+#define DIVX(x, q) (p2 ? ldexp((x), n##q) : (x)/dx##q)
   if (g.multi_d && j <= g.je && k <= g.ke) {
     size_t c = ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i);
     double b = gam0*b0x1f[c] + gam1*b1x1f[c];
-    b -= beta_dt*(E3(k, j + 1, i) - E3(k, j, i))/dx2;
-    if (g.three_d) b += beta_dt*(E2(k + 1, j, i) - E2(k, j, i))/dx3;
+    b -= DIVX(beta_dt*(E3(k, j + 1, i) - E3(k, j, i)), 2);
+    if (g.three_d) b += DIVX(beta_dt*(E2(k + 1, j, i) - E2(k, j, i)), 3);
     b0x1f[c] = b;
   }
   if (i <= g.ie && k <= g.ke) {
     size_t c = ix4(g.N3, g.N2 + 1, g.N1, m, k, j, i);
     double b = gam0*b0x2f[c] + gam1*b1x2f[c];
-    b += beta_dt*(E3(k, j, i + 1) - E3(k, j, i))/dx1;
-    if (g.three_d) b -= beta_dt*(E1(k + 1, j, i) - E1(k, j, i))/dx3;
+    b += DIVX(beta_dt*(E3(k, j, i + 1) - E3(k, j, i)), 1);
+    if (g.three_d) b -= DIVX(beta_dt*(E1(k + 1, j, i) - E1(k, j, i)), 3);
     b0x2f[c] = b;
   }
   if (i <= g.ie && j <= g.je) {
     size_t c = ix4(g.N3 + 1, g.N2, g.N1, m, k, j, i);
     double b = gam0*b0x3f[c] + gam1*b1x3f[c];
-    b -= beta_dt*(E2(k, j, i + 1) - E2(k, j, i))/dx1;
-    if (g.multi_d) b += beta_dt*(E1(k, j + 1, i) - E1(k, j, i))/dx2;
+    b -= DIVX(beta_dt*(E2(k, j, i + 1) - E2(k, j, i)), 1);
+    if (g.multi_d) b += DIVX(beta_dt*(E1(k, j + 1, i) - E1(k, j, i)), 2);
     b0x3f[c] = b;
   }
+#undef DIVX
 #undef E1
 #undef E2
 #undef E3

@@ -119,9 +119,16 @@ class FluidBase:
         self.dtnew = FLT_MAX
         self.ws = None
         self.multilevel = pm.multilevel
+        self.sweep_update = False
         if pm.multilevel:
             # the restricted fluxes of finer neighbours replace face fluxes between Fluxes and
-            # RKUpdate (SendFlux/RecvFlux): the flux arrays of the task-granular path are needed
+            # RKUpdate (SendFlux/RecvFlux): the flux arrays of the task-granular path are needed.
+            # Option AKMI_SMR_SWEEP_UPDATE=1 (3-D MHD without FOFC/diffusion): the sweeps store their fluxes AND
+            # update u0 in the same pass; after the correction only the cells behind a corrected face are redone
+            # (include/akmi.h, akmi_mhd_fluxes_update).  Bit-identical, measured SLOWER than the three tasks
+            # (profiles/r03_config5.txt: the storing+updating PPM4 marches lose more than k_rk_update costs): off.
+            self.sweep_update = (self.fused and blk == "mhd" and indcs.nx3 > 1
+                                 and os.environ.get("AKMI_SMR_SWEEP_UPDATE", "0") == "1")
             self.fused = False
             # the coarse buffers seen as a pack of nx/2 cells: HydroBCsCoarse / BFieldBCsCoarse are
             # the BC helpers on coarse indices (src/bvals/physics/hydro_bcs.cpp:51-67)
@@ -422,6 +429,13 @@ class Hydro(FluidBase):
             if ev is not None:
                 e1.record()
             self._dt_ready = bool(do_dt)
+            return TaskStatus.complete
+        if self.multilevel and stage == pdrive.nexp_stages and not self.kinematic:
+            # refined meshes (task-granular chain): the last conversion carries the CFL scan along (see mhd.py)
+            capi.check(self.L.akmi_hydro_c2p_newdt(
+                C.byref(self.pack_c), capi._p(self.u0), capi._p(self.w0), 1,
+                capi._p(self.counters), capi._p(self.dt3), capi._stream()), "hydro_c2p_newdt")
+            self._dt_ready = True
             return TaskStatus.complete
         capi.check(self.L.akmi_hydro_c2p(C.byref(self.pack_c), capi._p(self.u0), capi._p(self.w0),
                                          0, n1 - 1, 0, n2 - 1, 0, n3 - 1, capi._p(self.counters),

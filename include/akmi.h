@@ -266,6 +266,13 @@ int akmi_restrict_cc(const akmi_pack *p, int nvar, const double *u, double *cu, 
 /* MeshRefinement::RestrictFC (src/mesh/mesh_refinement.cpp:1283-1382) */
 int akmi_restrict_fc(const akmi_pack *p, const double *bx1f, const double *bx2f, const double *bx3f,
                      double *cbx1f, double *cbx2f, double *cbx3f, void *stream);
+/* the same for the MeshBlocks m with mask[m] != 0 only (mask on the device, NULL = all).  On a statically refined
+ * mesh only a block with a coarser neighbour reads its coarse buffer (sends to that neighbour, prolongation
+ * stencils): akmi_smr::needs_coarse is that mask. */
+int akmi_restrict_cc_masked(const akmi_pack *p, int nvar, const unsigned char *mask, const double *u, double *cu,
+                            void *stream);
+int akmi_restrict_fc_masked(const akmi_pack *p, const unsigned char *mask, const double *bx1f, const double *bx2f,
+                            const double *bx3f, double *cbx1f, double *cbx2f, double *cbx3f, void *stream);
 /* Conservation at fine/coarse faces: what a fine MeshBlock hands to a coarser neighbour.
  * akmi_restrict_flux_cc: the 2x2 (2-D: 2, 1-D: 1) fine face fluxes of direction `dir` behind each coarse
  * face of `box` (coarse indices il,iu,jl,ju,kl,ku; one face thick along dir), in the buffer order of
@@ -322,6 +329,15 @@ typedef struct akmi_smr {
    * in this pack and layout[] alone addresses the buffers.  With them an off-rank neighbour is
    * marked in nghbr by any index >= 0 (it is only tested for existence then). */
   const long long *soff, *roff;
+  /* != 0: cell-centred ghost zones whose neighbour has the SAME level and lives in this pack are not packed /
+   * unpacked by akmi_smr_*_cc: the caller fills them with akmi_bvals_cc_local (one gather straight from the
+   * neighbour's active cells, no buffer round trip; the regions of different slots are disjoint for cell-centred
+   * data, so the order does not matter).  0 (a zero-initialised descriptor): every slot goes through the buffers. */
+  int direct_same;
+  /* [nmb] or NULL: != 0 for blocks with at least one coarser neighbour.  FillCoarseInBndryCC/FC write ghost zones
+   * of the COARSE arrays, which only ProlongateCC/FC of such a block ever read; with the table the fill skips the
+   * other blocks (NULL: every block, as the reference does; the fine arrays come out the same either way). */
+  const unsigned char *needs_coarse;
 } akmi_smr;
 /* RestrictU is akmi_restrict_cc / akmi_restrict_fc above.  SendU+RecvU (PackAndSendCC +
  * RecvAndUnpackCC, src/bvals/bvals_cc.cpp:42-447): u ghost cells from same-level and finer neighbours,
@@ -359,6 +375,27 @@ int akmi_smr_p2c_fine(const akmi_pack *p, const akmi_smr *t, int nvar, const dou
  * face_shaped: MHD flux arrays (N+1 along their direction), 0: hydro (cell-shaped).  buf: layout[1] */
 int akmi_smr_flux_cc(const akmi_pack *p, const akmi_smr *t, int nvar, int face_shaped, double *flx1,
                      double *flx2, double *flx3, double *buf, void *stream);
+/* ---- Fluxes + RKUpdate in one pass on refined meshes (3-D MHD) ------------------------------------------------ *
+ * On a refined mesh the reference's order is Fluxes -> SendFlux/RecvFlux -> RKUpdate (src/mhd/mhd_tasks.cpp:52-57):
+ * the update waits for the corrected fluxes, and a separate update kernel re-reads every flux.  Here the sweeps
+ * update u0 while they store their fluxes (akmi_mhd_fluxes_update = akmi_mhd_fluxes + akmi_rk_update in one pass;
+ * acc = caller's scratch of nmb*nvar*N3*N2*N1 doubles), and after the flux correction ONLY the cells of a coarse
+ * block that lie behind a face shared with a finer neighbour are recomputed, from their saved old state and the
+ * stored (now corrected) fluxes, in the rounding order of RKUpdate (src/mhd/mhd_update.cpp:57-80).  Order of calls:
+ *   akmi_smr_save_update_cells (u0 before the sweeps -> save, akmi_smr_update_save_doubles doubles)
+ *   akmi_mhd_fluxes_update     akmi_smr_pack_flux_cc / transfer / akmi_smr_unpack_flux_cc     akmi_smr_redo_update
+ * Bit-identical to the three-task sequence. */
+int akmi_mhd_fluxes_update(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1, double beta_dt,
+                           const double *w0, const double *bcc0, const double *bx1f, const double *bx2f,
+                           const double *bx3f, double *u0, const double *u1, double *flx1, double *flx2,
+                           double *flx3, double *e3x1, double *e2x1, double *e1x2, double *e3x2, double *e2x3,
+                           double *e1x3, double *acc, void *stream);
+long long akmi_smr_update_save_doubles(const akmi_pack *p, int nvar);
+int akmi_smr_save_update_cells(const akmi_pack *p, const akmi_smr *t, int nvar, const double *u0, double *save,
+                               void *stream);
+int akmi_smr_redo_update(const akmi_pack *p, const akmi_smr *t, int nvar, double gam0, double gam1, double beta_dt,
+                         const double *save, double *u0, const double *u1, const double *flx1, const double *flx2,
+                         const double *flx3, void *stream);
 /* SendE+RecvE (PackAndSendFluxFC + RecvAndUnpackFluxFC, src/bvals/flux_correct_fc.cpp:29-1034): edge
  * EMFs on block surfaces summed over same-level owners, replaced by the restricted EMFs of finer
  * neighbours, averaged.  nflx [nmb][48]: contributions per block edge (the counting of

@@ -2909,6 +2909,34 @@ int akref_restrict_fc(const akmi_pack *p, const double *b1, const double *b2, co
   return 0;
 }
 
+/* twins of akmi_restrict_cc_masked / akmi_restrict_fc_masked (include/akmi.h): RestrictCC / RestrictFC for the
+ * MeshBlocks with mask[m] != 0 (NULL: all), one block at a time through the functions above */
+int akref_restrict_cc_masked(const akmi_pack *p, int nvar, const unsigned char *mask, const double *u, double *cu) {
+  G g = mkG(p); CG c = mkCG(&g);
+  const size_t fs = (size_t)nvar*g.N3*g.N2*g.N1, cs = (size_t)nvar*c.cN3*c.cN2*c.cN1;
+  for (int m = 0; m < p->nmb; ++m) {
+    if (mask && !mask[m]) continue;
+    akmi_pack q = *p;
+    q.nmb = 1; q.dx = p->dx + 3*m;
+    akref_restrict_cc(&q, nvar, u + m*fs, cu + m*cs);
+  }
+  return 0;
+}
+int akref_restrict_fc_masked(const akmi_pack *p, const unsigned char *mask, const double *b1, const double *b2,
+                             const double *b3, double *cb1, double *cb2, double *cb3) {
+  G g = mkG(p); CG c = mkCG(&g);
+  const size_t f1 = (size_t)g.N3*g.N2*(g.N1 + 1), f2 = (size_t)g.N3*(g.N2 + 1)*g.N1, f3 = (size_t)(g.N3 + 1)*g.N2*g.N1;
+  const size_t c1 = (size_t)c.cN3*c.cN2*(c.cN1 + 1), c2 = (size_t)c.cN3*(c.cN2 + 1)*c.cN1,
+               c3 = (size_t)(c.cN3 + 1)*c.cN2*c.cN1;
+  for (int m = 0; m < p->nmb; ++m) {
+    if (mask && !mask[m]) continue;
+    akmi_pack q = *p;
+    q.nmb = 1; q.dx = p->dx + 3*m;
+    akref_restrict_fc(&q, b1 + m*f1, b2 + m*f2, b3 + m*f3, cb1 + m*c1, cb2 + m*c2, cb3 + m*c3);
+  }
+  return 0;
+}
+
 static inline double sgn_(double x) { return (x < 0.0) ? -1.0 : 1.0; }     /* SIGN, src/athena.hpp:52 */
 static inline double mm8(double dl, double dr) {                          /* 0.125*(SIGN+SIGN)*fmin */
   return 0.125*(sgn_(dl) + sgn_(dr))*fmin(fabs(dl), fabs(dr));
@@ -3340,3 +3368,22 @@ int akref_resistive_newdt(const akmi_pack *p, double eta_o, double eta_a, const 
 #undef AE1
 #undef AE2
 #undef AE3
+
+
+/* twins of the ABI's akmi_hydro_c2p_newdt / akmi_mhd_c2p_newdt (the product converts all cells and scans the CFL
+ * condition in one kernel): the reference's two tasks in their order -- ConToPrim over all cells incl. ghost
+ * zones (hydro_tasks.cpp:404-412, mhd_tasks.cpp:559-567), then NewTimeStep (hydro_newdt.cpp:30-139,
+ * mhd_newdt.cpp:31-174) when do_newdt.  TEST INFRASTRUCTURE (tests/cpu_backend.py). */
+int akref_hydro_c2p_newdt(const akmi_pack *p, double *u0, double *w0, int do_newdt, int *counters, double *dt3) {
+  const int n1 = p->nx1 + 2*p->ng, n2 = p->nx2 > 1 ? p->nx2 + 2*p->ng : 1, n3 = p->nx3 > 1 ? p->nx3 + 2*p->ng : 1;
+  akref_hydro_c2p(p, u0, w0, 0, n1 - 1, 0, n2 - 1, 0, n3 - 1, counters);
+  if (do_newdt) akref_hydro_newdt(p, w0, dt3);
+  return 0;
+}
+int akref_mhd_c2p_newdt(const akmi_pack *p, double *u0, const double *bx1f, const double *bx2f, const double *bx3f,
+                        double *w0, double *bcc0, int do_newdt, int *counters, double *dt3) {
+  const int n1 = p->nx1 + 2*p->ng, n2 = p->nx2 > 1 ? p->nx2 + 2*p->ng : 1, n3 = p->nx3 > 1 ? p->nx3 + 2*p->ng : 1;
+  akref_mhd_c2p(p, u0, bx1f, bx2f, bx3f, w0, bcc0, 0, n1 - 1, 0, n2 - 1, 0, n3 - 1, counters);
+  if (do_newdt) akref_mhd_newdt(p, w0, bcc0, dt3);
+  return 0;
+}

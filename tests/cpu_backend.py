@@ -26,7 +26,7 @@ class OracleAsAkmi:
         twin = {"akmi_smr_fill_coarse_cc", "akmi_smr_fill_coarse_fc", "akmi_smr_prolong_cc",
                 "akmi_smr_prolong_fc", "akmi_smr_flux_cc", "akmi_smr_c2p_coarse", "akmi_smr_p2c_fine"}
         fn = getattr(self.R, "akref_" + name[5:] + ("_t" if name in twin else ""))
-        if name.endswith("segsize"):
+        if name.endswith("segsize") or name.endswith("_doubles"):
             fn.restype = C.c_longlong
             return fn
 

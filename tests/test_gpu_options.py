@@ -4,6 +4,10 @@ once per process, so every case runs in a process of its own and must be bit-ide
   AKMI_MERGE_C2P=0  c2p of the active cells inside the stage call + c2p of the ghost shell afterwards (the order a
                     rank with off-rank neighbours uses) instead of one conversion after the ghost fill
   AKMI_X12=0        x1 sweep and x2 march as two kernels
+refined meshes:
+  AKMI_SMR_SWEEP_UPDATE=1  Fluxes updates u0 in the sweeps, RKUpdate redoes the cells behind corrected faces
+                           (akmi_mhd_fluxes_update / akmi_smr_save_update_cells / akmi_smr_redo_update)
+  AKMI_SMR_DIRECT=0        same-level cell-centred ghost zones through the pack/unpack buffers instead of directly
 """
 import os
 import subprocess
@@ -33,5 +37,29 @@ print("ok")
                          ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
 def test_option_does_not_change_a_bit(env):
     r = subprocess.run([sys.executable, "-c", SCRIPT], env=dict(os.environ, **env), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+SMR_SCRIPT = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import parity_util as pu
+for native in (False, True):
+    for problem, n, mb, kw in (("linear_wave_mhd_smr", (32, 16, 16), (8, 4, 4), dict(rsolver="hlld")),
+                               ("linear_wave_mhd_smr", (32, 16, 16), (8, 8, 8), dict(recon="ppm4", ng=4, rsolver="hlld")),
+                               ("blast_smr", (32, 32, 32), (8, 8, 8), {}),
+                               ("linear_wave_mhd_smr", (32, 16, 16), (8, 4, 4),
+                                dict(rsolver="hlld", integrator="rk3", extra=("refined_region1/level=2",)))):
+        r = pu.compare_run(problem, n, 3, mb, cycles=2, native=native, **kw)
+        assert r["bitwise_equal"] and r["cycles"] == 2 and r["dt"][0] == r["dt"][1], (native, problem, kw, r)
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+
+
+@pytest.mark.parametrize("env", [{"AKMI_SMR_SWEEP_UPDATE": "1"}, {"AKMI_SMR_DIRECT": "0"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
+def test_smr_option_does_not_change_a_bit(env):
+    r = subprocess.run([sys.executable, "-c", SMR_SCRIPT], env=dict(os.environ, **env), capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

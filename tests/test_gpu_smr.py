@@ -196,9 +196,13 @@ def test_boundary_operators_on_random_data(mesh):
     L.akref_smr_send_cc(h, P(u), P(cu))
     L.akref_smr_recv_cc(h, P(u), P(cu))
     same(du, u, "exchange_cc u"); same(dcu, cu, "exchange_cc cu")
+    # the product fills the coarse ghost zones only of blocks that prolongate (a coarser neighbour exists:
+    # akmi_smr::needs_coarse); nothing reads the others', the oracle fills them all
+    needs = smr.t_needs.cpu().numpy().astype(bool)
+    assert needs.any()
     smr.FillCoarseInBndryCC(du, dcu)
     L.akref_smr_fill_coarse_cc(h, P(u), P(cu))
-    same(dcu, cu, "fill_coarse_cc")
+    assert np.array_equal(dcu.cpu().numpy()[needs], cu[needs]), "fill_coarse_cc"
     smr.ProlongateCC(du, dcu)
     L.akref_smr_prolong_cc(h, P(u), P(cu))
     same(du, u, "prolong_cc")
@@ -216,7 +220,7 @@ def test_boundary_operators_on_random_data(mesh):
     smr.FillCoarseInBndryFC(db, dcb)
     L.akref_smr_fill_coarse_fc(h, P(b[0]), P(b[1]), P(b[2]), P(cb[0]), P(cb[1]), P(cb[2]))
     for q, (x, y) in enumerate(zip((dcb.x1f, dcb.x2f, dcb.x3f), cb)):
-        same(x, y, "fill_coarse_fc cb%d" % q)
+        assert np.array_equal(x.cpu().numpy()[needs], y[needs]), "fill_coarse_fc cb%d" % q
     smr.ProlongateFC(db, dcb)
     L.akref_smr_prolong_fc(h, P(b[0]), P(b[1]), P(b[2]), P(cb[0]), P(cb[1]), P(cb[2]))
     for q, (x, y) in enumerate(zip((db.x1f, db.x2f, db.x3f), b)):
