@@ -65,38 +65,40 @@ struct GhostSet {
   int ncomp;
 };
 
+// Index arithmetic: the block index carries (MeshBlock, variable, chunk of the slab) -- decoded once per thread from
+// wave-uniform values -- and the element inside the slab is a 32-bit number (a slab of one variable of one
+// MeshBlock is far below 2^31 elements; checked at launch).  The first version decoded a 64-bit flat index over
+// (block, variable, element) with four 64-bit divisions per element behind a 65535-workgroup grid-stride loop;
+// measured, that arithmetic was NOT what bounds the fill of many small blocks (960 blocks of 32^3, ng = 4:
+// 919 -> 895 us for 2.4 GB): the x1 slabs are rows of 2 ng doubles, 64-byte pieces of 128-byte lines on both sides.
 template <int KIND>
 __global__ void __launch_bounds__(256)
-k_ghost_fill(Geo g, GhostSet gs, int nv, const int *__restrict__ nghbr,
+k_ghost_fill(Geo g, GhostSet gs, int nv, unsigned chunks, const int *__restrict__ nghbr,
              const long long *__restrict__ seg_off, const double *__restrict__ recvbuf) {
   const Comp q = gs.q[blockIdx.y];
   double *__restrict__ a = gs.a[blockIdx.y];
   const int comp = gs.comp[blockIdx.y];
   const int mode = blockIdx.z;
-  int e1, e2, e3;
+  unsigned e1, e2, e3;
   if (mode == 0) { e1 = q.n1; e2 = q.n2; e3 = 2*q.d3.ng; }
   else if (mode == 1) { e1 = q.n1; e2 = 2*q.d2.ng; e3 = q.d3.eo - q.d3.s + 1; }
   else { e1 = 2*q.d1.ng; e2 = q.d2.eo - q.d2.s + 1; e3 = q.d3.eo - q.d3.s + 1; }
-  const long long per = (long long)e1*e2*e3;
-  const long long tot = per*nv*g.nmb;
-  for (long long t = (long long)blockIdx.x*blockDim.x + threadIdx.x; t < tot;
-       t += (long long)gridDim.x*blockDim.x) {
-    int m = (int)(t/(per*nv));
-    long long r = t - (long long)m*per*nv;
-    int n = (int)(r/per);
-    r -= (long long)n*per;
-    int kk = (int)(r/((long long)e1*e2));
-    r -= (long long)kk*e1*e2;
-    int jj = (int)(r/e1);
-    int ii = (int)(r - (long long)jj*e1);
+  const unsigned per = e1*e2*e3, e12 = e1*e2;
+  const unsigned mn = blockIdx.x/chunks, ch = blockIdx.x - mn*chunks;
+  const int m = (int)(mn/(unsigned)nv), n = (int)(mn - (unsigned)m*(unsigned)nv);
+  const size_t vbase = ((size_t)m*nv + n)*q.n3;
+  for (unsigned r = ch*256u + threadIdx.x; r < per; r += chunks*256u) {
+    const unsigned kk = r/e12, r2 = r - kk*e12;
+    const unsigned jj = r2/e1;
+    const int ii = (int)(r2 - jj*e1);
     int i, j, k;
-    if (mode == 0) { i = ii; j = jj; k = kk < q.d3.ng ? kk : q.d3.eo + 1 + (kk - q.d3.ng); }
-    else if (mode == 1) { i = ii; j = jj < q.d2.ng ? jj : q.d2.eo + 1 + (jj - q.d2.ng); k = q.d3.s + kk; }
-    else { i = ii < q.d1.ng ? ii : q.d1.eo + 1 + (ii - q.d1.ng); j = q.d2.s + jj; k = q.d3.s + kk; }
+    if (mode == 0) { i = ii; j = (int)jj; k = (int)kk < q.d3.ng ? (int)kk : q.d3.eo + 1 + ((int)kk - q.d3.ng); }
+    else if (mode == 1) { i = ii; j = (int)jj < q.d2.ng ? (int)jj : q.d2.eo + 1 + ((int)jj - q.d2.ng); k = q.d3.s + (int)kk; }
+    else { i = ii < q.d1.ng ? ii : q.d1.eo + 1 + (ii - q.d1.ng); j = q.d2.s + (int)jj; k = q.d3.s + (int)kk; }
     int o1 = q.d1.side(i), o2 = q.d2.side(j), o3 = q.d3.side(k);
     int d = (o3 + 1)*9 + (o2 + 1)*3 + (o1 + 1);
     int src = nghbr[m*27 + d];
-    size_t dst = ((((size_t)m*nv + n)*q.n3 + k)*q.n2 + j)*q.n1 + i;
+    size_t dst = ((vbase + k)*q.n2 + j)*q.n1 + i;
     if constexpr (KIND == 0) {
       if (src < 0) continue;
       a[dst] = a[((((size_t)src*nv + n)*q.n3 + (k - o3*q.d3.nx))*q.n2 + (j - o2*q.d2.nx))*q.n1 +
@@ -123,12 +125,20 @@ static int launch_ghost(const Geo &g, const GhostSet &gs, int nv, const int *ngh
     long long n0 = (long long)q.n1*q.n2*2*q.d3.ng;
     long long n1 = (long long)q.n1*2*q.d2.ng*(q.d3.eo - q.d3.s + 1);
     long long n2 = (long long)2*q.d1.ng*(q.d2.eo - q.d2.s + 1)*(q.d3.eo - q.d3.s + 1);
-    long long n = (n0 > n1 ? (n0 > n2 ? n0 : n2) : (n1 > n2 ? n1 : n2))*nv*g.nmb;
+    long long n = (n0 > n1 ? (n0 > n2 ? n0 : n2) : (n1 > n2 ? n1 : n2));
     if (n > nmax) nmax = n;
   }
-  long long nb = (nmax + 255)/256;
-  dim3 grid((unsigned)(nb > 65535 ? 65535 : nb), gs.ncomp, 3);
-  k_ghost_fill<KIND><<<grid, 256, 0, st>>>(g, gs, nv, nghbr, seg_off, recvbuf);
+  if (nmax >= (1ll << 31)) { set_error("bvals ghost fill: a ghost slab of one variable has 2^31 elements or more"); return AKMI_FAIL; }
+  // chunks of 256 elements per (MeshBlock, variable) slab; few enough of them that the whole grid stays below
+  // 2^31 - 1 workgroups and above a few thousand (a thread then strides over its slab)
+  const long long mnv = (long long)g.nmb*nv;
+  long long chunks = (nmax + 255)/256;
+  const long long cap = ((1ll << 31) - 1)/mnv;
+  if (chunks > cap) chunks = cap;
+  if (chunks > 64 && mnv*chunks > (1ll << 20)) { chunks = (1ll << 20)/mnv; if (chunks < 64) chunks = 64; if (chunks > cap) chunks = cap; }
+  if (chunks < 1) { set_error("bvals ghost fill: too many MeshBlocks x variables for one launch"); return AKMI_FAIL; }
+  dim3 grid((unsigned)(mnv*chunks), gs.ncomp, 3);
+  k_ghost_fill<KIND><<<grid, 256, 0, st>>>(g, gs, nv, (unsigned)chunks, nghbr, seg_off, recvbuf);
   AKMI_CHECK_LAUNCH("bvals ghost fill");
   return AKMI_COMPLETE;
 }

@@ -66,6 +66,7 @@ template <class F>
 inline int dispatch_recon(int recon, F &&f) {
 #ifdef AKMI_DEV_FAST      // developer builds (tools/build_variant.sh -DAKMI_DEV_FAST): PLM only, compiles in seconds
   if (recon == AKMI_RECON_PLM) return f(IC<1>{});
+  if (AKMI_DEV_FAST + 0 == 2 && recon == AKMI_RECON_PPM4) return f(IC<2>{});     // -DAKMI_DEV_FAST=2: + PPM4
 #else
   switch (recon) {
     case AKMI_RECON_DC:    return f(IC<0>{});

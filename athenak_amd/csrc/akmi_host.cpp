@@ -337,8 +337,11 @@ void Mesh::NewTimeStep(const Real tlim) {               // mesh.cpp:573-643
     if (f->has_cond) dt = std::min(dt, cfl_no*f->dt_cond);
   }
   // minimum over all ranks (mesh.cpp:634-637): ncclAllReduce(ncclMin) on the compute stream
+  // (already done on the device inside FinishNewDt when every physics module reports dt_reduced)
+  bool reduced = true;
+  for (FluidBase *f : phys) if (f && !f->dt_reduced) reduced = false;
   for (FluidBase *f : phys)
-    if (f && (nranks > 1 || SelfExchange())) { Comm::World().AllReduceMin(&dt, 1, f->stream); break; }
+    if (f && !reduced && (nranks > 1 || SelfExchange())) { Comm::World().AllReduceMin(&dt, 1, f->stream); break; }
   if ((time < tlim) && ((time + dt) > tlim)) dt = tlim - time;
 }
 
@@ -453,9 +456,16 @@ FluidBase::~FluidBase() {
 }
 void FluidBase::FinishNewDt() {        // hydro_newdt.cpp:121-124
   Real d[3];
+  Mesh *pm = pmy_pack->pmesh;
+  // several ranks, RCCL transport, no diffusion time steps: the minimum over the ranks (mesh.cpp:634-637) is taken
+  // of the three device-side values before they are read back -- ncclAllReduce(min) in place on the compute stream
+  // -- so a cycle has ONE host synchronisation (this read-back, which the reference has too: hydro_newdt.cpp:121)
+  // instead of read-back + H2D + all-reduce + read-back.  min_r(min(2 dt_old, cfl dt_r)) == min(2 dt_old, cfl min_r dt_r).
+  dt_reduced = false;
+  if ((pm->nranks > 1 || SelfExchange()) && !has_visc && !has_cond && !has_resist)
+    dt_reduced = Comm::World().AllReduceMinDevice(dt3.p, 3, stream);
   HIPCHK(hipMemcpyAsync(d, dt3.p, sizeof(d), hipMemcpyDeviceToHost, stream));
   HIPCHK(hipStreamSynchronize(stream));
-  Mesh *pm = pmy_pack->pmesh;
   dtnew = d[0];
   if (pm->multi_d) dtnew = std::min(dtnew, d[1]);
   if (pm->three_d) dtnew = std::min(dtnew, d[2]);

@@ -160,6 +160,9 @@ class Comm {
   void Post(const std::vector<Msg> &m, hipStream_t compute, int channel);
   void Wait(hipStream_t compute, int channel);
   void AllReduceMin(Real *host_vals, int n, hipStream_t compute);
+  // the same on values that are already in device memory, in place, asynchronous on `compute` (RCCL transport only;
+  // returns false -- nothing done -- for the callback transport or without peers)
+  bool AllReduceMinDevice(Real *dev_vals, int n, hipStream_t compute);
   static void GetUniqueId(char id[128]);
  private:
   void *nccl_ = nullptr;                 // ncclComm_t
@@ -349,6 +352,7 @@ class FluidBase {
        dt_resist = static_cast<Real>(FLT_MAX);
   DvceArray<Real> dtmin_cond;
   bool use_fofc = false;                // hydro.hpp:116-117, mhd.hpp
+  bool dt_reduced = false;              // dtnew is already the minimum over all ranks (FinishNewDt)
   bool sweep_update = false;            // refined 3-D MHD: Fluxes updates u0 too, RKUpdate redoes corrected cells
   DvceArray<Real> upd_acc, upd_save;    //   scratch of akmi_mhd_fluxes_update / akmi_smr_save_update_cells
   DvceArray<unsigned char> fofc;

@@ -216,6 +216,12 @@ void Comm::AllReduceMin(Real *v, int n, hipStream_t compute) {
   HIPCHK(hipStreamSynchronize(compute));
 }
 
+bool Comm::AllReduceMinDevice(Real *d, int n, hipStream_t compute) {
+  if (kind != Kind::rccl) return false;
+  NCCLCHK(rccl().AllReduce(d, d, static_cast<size_t>(n), ncclDouble, ncclMin, static_cast<ncclComm_t>(nccl_), compute));
+  return true;
+}
+
 // ---- block -> rank ------------------------------------------------------------------------------
 void Mesh::LoadBalance(const std::vector<float> &clist) {       // load_balance.cpp:38-88
   const int nb = static_cast<int>(clist.size());

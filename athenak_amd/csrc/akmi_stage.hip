@@ -125,6 +125,9 @@ struct SweepArgs {
 #ifndef AKMI_X1_SHARE
 #define AKMI_X1_SHARE 1
 #endif
+#ifndef AKMI_X1_GROUP_LOADS
+#define AKMI_X1_GROUP_LOADS 1
+#endif
 template <int DIR, int RECON>
 constexpr bool x1_share() { return DIR == 0 && RECON >= 1 && AKMI_X1_SHARE; }
 
@@ -155,16 +158,41 @@ __device__ __forceinline__ void sweep_x1_shared(const Geo &g, const FaceEos &eos
 #pragma unroll
   for (int n = 0; n < NV; ++n) { qln[n] = 0.0; qr[n] = 0.0; }
   double vx = 0.0, vy = 0.0, vz = 0.0, by = 0.0, bz = 0.0;
+  [[maybe_unused]] double bxi_pre = 0.0;
   if (valid) {
+#if AKMI_X1_GROUP_LOADS
+    // the five-point reconstructions branch (limiters), so every variable is a basic block of its own and its
+    // stencil loads were issued there: load -> s_waitcnt vmcnt(0) -> 43 VALU, seven times over
+    // (profiles/r03_isa_audit.txt, second audit).  All stencils are requested first; the waits count down.
+    double sq[NV][RECON == 1 ? 3 : 5];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      if (rs_iso<RS>() && n == 4) continue;
+      const double *q = (n < 5) ? wm + n*cs : bm + (n - 4)*cs;
+#pragma unroll
+      for (int d = 0; d < (RECON == 1 ? 3 : 5); ++d) sq[n][d] = ldu(q + d - (RECON == 1 ? 1 : 2), oc);
+    }
+    if constexpr (MHD) bxi_pre = ldu(a.bxf + (size_t)m*((size_t)a.f3*a.f2*a.f1), of);   // face (k,j,i) exists for a valid lane
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
       if (rs_iso<RS>() && n == 4) continue;             // isothermal: slot 4 (energy) stays unused
       const double *q = (n < 5) ? wm + n*cs : bm + (n - 4)*cs;   // by, bz
+#if AKMI_X1_GROUP_LOADS
+      constexpr int C = RECON == 1 ? 1 : 2;
+      const double qm = sq[n][C - 1], q0 = sq[n][C], qp = sq[n][C + 1];
+#else
       const double qm = ldu(q - 1, oc), q0 = ldu(q, oc), qp = ldu(q + 1, oc);
+#endif
       if constexpr (RECON == 1) {
         plm(qm, q0, qp, qln[n], qr[n]);
       } else {
+#if AKMI_X1_GROUP_LOADS
+        const double qmm = sq[n][0], qpp = sq[n][4];
+#else
         const double qmm = ldu(q - 2, oc), qpp = ldu(q + 2, oc);
+#endif
         recon5<RECON>(qmm, qm, q0, qp, qpp, qln[n], qr[n]);
         // the floors of recon.hpp:72-103 act on each state separately: per cell == per face
         if (n == 0) floor_lr<RECON, 1>(eos, qln[n], qr[n]);
@@ -193,7 +221,11 @@ __device__ __forceinline__ void sweep_x1_shared(const Geo &g, const FaceEos &eos
   double fd, fx, fy, fz, fe, fby = 0.0, fbz = 0.0;
   const size_t fs = (size_t)a.f3*a.f2*a.f1;
   if constexpr (MHD) {
+#if AKMI_X1_GROUP_LOADS
+    const double bxi = bxi_pre;
+#else
     const double bxi = ldu(a.bxf + (size_t)m*fs, of);
+#endif
     Cons1D fl = riemann_mhd_e<RS, true>(eos, L[0], L[1], L[2], L[3], L[4], L[5], L[6], qr[0], qr[1],
                                         qr[2], qr[3], qr[4], qr[5], qr[6], bxi);
     fd = fl.d; fx = fl.mx; fy = fl.my; fz = fl.mz; fe = fl.e; fby = fl.by; fbz = fl.bz;
