@@ -811,6 +811,14 @@ static bool MergeC2P() {      // A/B switch, profiles/r03_whatif_merge_c2p.txt
   return on;
 }
 template <typename T> static void SwapArr(DvceArray<T> &a, DvceArray<T> &b) { std::swap(a.p, b.p); std::swap(a.n, b.n); }
+// Task-granular path, first stage: CopyCons folded into an out-of-place RKUpdate / CT (akmi_rk_update_oop,
+// akmi_mhd_ct_oop), registers swapped afterwards -- no copy traffic.  Not with FOFC (its trial update reads u1/b1
+// before RKUpdate), RK4 (CopyCons updates the second register itself), the update-in-the-sweeps option.
+// A/B switch AKMI_TASK_OOP=0.
+bool FluidBase::OopFirst(const Driver *d, int stage) const {
+  static const bool off = std::getenv("AKMI_TASK_OOP") && std::atoi(std::getenv("AKMI_TASK_OOP")) == 0;
+  return stage == 1 && !fused && !use_fofc && !sweep_update && d->integrator != "rk4" && !off;
+}
 
 void FluidBase::RestoreRegisters() {
   if (!u_swapped) return;
@@ -837,7 +845,7 @@ void MHD::RestoreRegisters() {
 // ---- task bodies: one C-ABI call each ------------------------------------------------------------
 namespace hydro {
 TaskStatus Hydro::CopyCons(Driver *d, int stage) {         // hydro_tasks.cpp:130-152
-  if (stage == 1 && !fused) AKCHK(akmi_copy_cons(&pack_c, u0.p, u1.p, stream));
+  if (stage == 1 && !fused && !OopFirst(d, stage)) AKCHK(akmi_copy_cons(&pack_c, u0.p, u1.p, stream));
   if (stage > 1 && d->integrator == "rk4")
     AKCHK(akmi_rk4_copy_cons(&pack_c, d->delta[stage - 1], u0.p, u1.p, stream));
   return TaskStatus::complete;
@@ -883,6 +891,10 @@ TaskStatus Hydro::RKUpdate(Driver *d, int stage) {         // hydro_update.cpp:2
     d->ProfMark(stream);
     if (copy == 2) { SwapArr(u0, u1); u_swapped = !u_swapped; }
     interior_done_ = true; dt_ready_ = do_dt;
+  } else if (OopFirst(d, stage)) {
+    AKCHK(akmi_rk_update_oop(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1], beta_dt, u0.p, u1.p,
+                             uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, 0, stream));
+    SwapArr(u0, u1); u_swapped = !u_swapped;
   } else {
     AKCHK(akmi_rk_update(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1], beta_dt, u0.p, u1.p,
                          uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, 0, stream));
@@ -1003,7 +1015,7 @@ TaskStatus Hydro::NewTimeStep(Driver *d, int stage) {      // hydro_newdt.cpp:30
 
 namespace mhd {
 TaskStatus MHD::CopyCons(Driver *d, int stage) {           // mhd_tasks.cpp:162-170
-  if (stage == 1 && !fused) {
+  if (stage == 1 && !fused && !OopFirst(d, stage)) {
     AKCHK(akmi_copy_cons(&pack_c, u0.p, u1.p, stream));
     HIPCHK(hipMemcpyAsync(b1.x1f.p, b0.x1f.p, sizeof(Real)*b0.x1f.n, hipMemcpyDeviceToDevice, stream));
     HIPCHK(hipMemcpyAsync(b1.x2f.p, b0.x2f.p, sizeof(Real)*b0.x2f.n, hipMemcpyDeviceToDevice, stream));
@@ -1076,6 +1088,10 @@ TaskStatus MHD::RKUpdate(Driver *d, int stage) {           // mhd_update.cpp:24-
   } else if (sweep_update) {
     AKCHK(akmi_smr_redo_update(&pack_c, &psmr->smr_c, nvars, d->gam0[stage - 1], d->gam1[stage - 1], beta_dt,
                                upd_save.p, u0.p, u1.p, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, stream));
+  } else if (OopFirst(d, stage)) {
+    AKCHK(akmi_rk_update_oop(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1], beta_dt, u0.p, u1.p,
+                             uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, 1, stream));
+    SwapArr(u0, u1); u_swapped = !u_swapped;
   } else {
     AKCHK(akmi_rk_update(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1], beta_dt, u0.p, u1.p,
                          uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, 1, stream));
@@ -1222,10 +1238,16 @@ TaskStatus MHD::EField(Driver *d, int stage) {             // mhd_corner_e.cpp:2
 }
 TaskStatus MHD::CT(Driver *d, int stage) {                 // mhd_ct.cpp:23-80
   if (fused && peers()) StagePhase(d, stage, AKMI_PHASE_EMF_CT);
-  if (!fused)
+  if (!fused && OopFirst(d, stage)) {
+    AKCHK(akmi_mhd_ct_oop(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1],
+                          d->beta[stage - 1]*pmy_pack->pmesh->dt, efld.x1e.p, efld.x2e.p, efld.x3e.p,
+                          b0.x1f.p, b0.x2f.p, b0.x3f.p, b1.x1f.p, b1.x2f.p, b1.x3f.p, stream));
+    SwapArr(b0.x1f, b1.x1f); SwapArr(b0.x2f, b1.x2f); SwapArr(b0.x3f, b1.x3f); b_swapped = !b_swapped;
+  } else if (!fused) {
     AKCHK(akmi_mhd_ct(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1],
                       d->beta[stage - 1]*pmy_pack->pmesh->dt, efld.x1e.p, efld.x2e.p, efld.x3e.p,
                       b0.x1f.p, b0.x2f.p, b0.x3f.p, b1.x1f.p, b1.x2f.p, b1.x3f.p, stream));
+  }
   return TaskStatus::complete;
 }
 TaskStatus MHD::SendB(Driver *d, int stage) {

@@ -141,6 +141,45 @@ k_rk_update(Geo g, double gam0, double gam1, double beta_dt, double *__restrict_
   }
 }
 
+// First stage OUT OF PLACE (task-granular path): CopyCons (u1 := u0, hydro_tasks.cpp:130-152) followed by RKUpdate
+// leaves u1 = old state, u0 = gam0*old + gam1*old - beta_dt*divF in the active cells and the old state in the
+// ghost zones.  This kernel writes exactly that u0 into `dst` (every cell: active cells updated with the same
+// expression on the same operands -- u1 == u0 after CopyCons --, ghost cells copied) and leaves `src` alone; the caller
+// swaps the two registers.  One pass over the arrays instead of copy + update.
+__global__ void __launch_bounds__(BX*BY)
+k_rk_update_oop(Geo g, double gam0, double gam1, double beta_dt, const double *__restrict__ src,
+                double *__restrict__ dst, const double *__restrict__ flx1, const double *__restrict__ flx2,
+                const double *__restrict__ flx3, int fsh) {
+  int i, j;
+  flat_ij(g, 0, i, j);
+  const int m = blockIdx.z/g.N3;
+  const int k = blockIdx.z - m*g.N3;
+  if (j >= g.N2) return;
+  const bool act = i >= g.is && i <= g.ie && j >= g.js && j <= g.je && k >= g.ks && k <= g.ke;
+  const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
+  const bool p2 = is_pow2(dx1) && is_pow2(dx2) && is_pow2(dx3);
+  const int n1 = pow2_shift(dx1), n2 = pow2_shift(dx2), n3 = pow2_shift(dx3);
+  for (int n = 0; n < g.nvar; ++n) {
+    const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, n, k, j, i);
+    const double old = src[c];
+    if (!act) { dst[c] = old; continue; }
+    const double d1 = flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + fsh, m, n, k, j, i + 1)] -
+                      flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + fsh, m, n, k, j, i)];
+    double divf = p2 ? ldexp(d1, n1) : d1/dx1;
+    if (g.multi_d) {
+      const double d2 = flx2[ix5(g.nvar, g.N3, g.N2 + fsh, g.N1, m, n, k, j + 1, i)] -
+                        flx2[ix5(g.nvar, g.N3, g.N2 + fsh, g.N1, m, n, k, j, i)];
+      divf += p2 ? ldexp(d2, n2) : d2/dx2;
+    }
+    if (g.three_d) {
+      const double d3 = flx3[ix5(g.nvar, g.N3 + fsh, g.N2, g.N1, m, n, k + 1, j, i)] -
+                        flx3[ix5(g.nvar, g.N3 + fsh, g.N2, g.N1, m, n, k, j, i)];
+      divf += p2 ? ldexp(d3, n3) : d3/dx3;
+    }
+    dst[c] = gam0*old + gam1*old - beta_dt*divf;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // ConsToPrim: ideal_hyd.cpp:45-103, ideal_mhd.cpp:47-122.  Floor counters: one wave-level
 // ballot + one atomicAdd per wave that actually hit a floor (never on the hot path).
@@ -721,6 +760,64 @@ k_ct(Geo g, double gam0, double gam1, double beta_dt, const double *__restrict__
 #undef E3
 }
 
+// CT of the first stage out of place (see k_rk_update_oop): every face of the three arrays is written to the second
+// register -- the faces CT updates (mhd_ct.cpp:45-77 ranges) with gam0*b + gam1*b -/+ ..., all others copied.
+__global__ void __launch_bounds__(BX*BY)
+k_ct_oop(Geo g, double gam0, double gam1, double beta_dt, const double *__restrict__ e1,
+         const double *__restrict__ e2, const double *__restrict__ e3, const double *__restrict__ sx1f,
+         const double *__restrict__ sx2f, const double *__restrict__ sx3f, double *__restrict__ dx1f,
+         double *__restrict__ dx2f, double *__restrict__ dx3f) {
+  const long p = ((long)blockIdx.x*BY + threadIdx.y)*BX + threadIdx.x;      // rows of N1+1 over j in [0, N2]
+  const int j = (int)(p/(g.N1 + 1));
+  const int i = (int)(p - (long)j*(g.N1 + 1));
+  const int m = blockIdx.z/(g.N3 + 1);
+  const int k = blockIdx.z - m*(g.N3 + 1);
+  if (j > g.N2) return;
+  const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
+#define E1(k, j, i) e1[ix4(g.N3 + 1, g.N2 + 1, g.N1, m, k, j, i)]
+#define E2(k, j, i) e2[ix4(g.N3 + 1, g.N2, g.N1 + 1, m, k, j, i)]
+#define E3(k, j, i) e3[ix4(g.N3, g.N2 + 1, g.N1 + 1, m, k, j, i)]
+  const bool p2 = is_pow2(dx1) && is_pow2(dx2) && is_pow2(dx3);
+  const int n1 = pow2_shift(dx1), n2 = pow2_shift(dx2), n3 = pow2_shift(dx3);
+#define DIVX(x, q) (p2 ? ldexp((x), n##q) : (x)/dx##q)
+  // the ranges of k_ct: i in [is, ie+1], j in [js, je+1], k in [ks, ke+1], then per component
+  const bool in = i >= g.is && i <= g.ie + 1 && j >= g.js && j <= g.je + 1 && k >= g.ks && k <= g.ke + 1;
+  if (k < g.N3 && j < g.N2) {                                        // x1f (N3, N2, N1+1)
+    const size_t c = ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i);
+    double b = sx1f[c];
+    if (in && g.multi_d && j <= g.je && k <= g.ke) {
+      b = gam0*b + gam1*b;
+      b -= DIVX(beta_dt*(E3(k, j + 1, i) - E3(k, j, i)), 2);
+      if (g.three_d) b += DIVX(beta_dt*(E2(k + 1, j, i) - E2(k, j, i)), 3);
+    }
+    dx1f[c] = b;
+  }
+  if (k < g.N3 && i < g.N1) {                                        // x2f (N3, N2+1, N1)
+    const size_t c = ix4(g.N3, g.N2 + 1, g.N1, m, k, j, i);
+    double b = sx2f[c];
+    if (in && i <= g.ie && k <= g.ke) {
+      b = gam0*b + gam1*b;
+      b += DIVX(beta_dt*(E3(k, j, i + 1) - E3(k, j, i)), 1);
+      if (g.three_d) b -= DIVX(beta_dt*(E1(k + 1, j, i) - E1(k, j, i)), 3);
+    }
+    dx2f[c] = b;
+  }
+  if (j < g.N2 && i < g.N1) {                                        // x3f (N3+1, N2, N1)
+    const size_t c = ix4(g.N3 + 1, g.N2, g.N1, m, k, j, i);
+    double b = sx3f[c];
+    if (in && i <= g.ie && j <= g.je) {
+      b = gam0*b + gam1*b;
+      b -= DIVX(beta_dt*(E2(k, j, i + 1) - E2(k, j, i)), 1);
+      if (g.multi_d) b += DIVX(beta_dt*(E1(k, j + 1, i) - E1(k, j, i)), 2);
+    }
+    dx3f[c] = b;
+  }
+#undef DIVX
+#undef E1
+#undef E2
+#undef E3
+}
+
 // Hydro::FOFC part 1 (hydro_fofc.cpp:46-85): trial update + floor test of one cell
 __global__ void __launch_bounds__(BX*BY)
 k_fofc_flag_hyd(Geo g, Eos eos, double gam0, double gam1, double beta_dt,
@@ -1035,6 +1132,16 @@ int akmi_rk_update(const akmi_pack *p, double gam0, double gam1, double beta_dt,
   return AKMI_COMPLETE;
 }
 
+int akmi_rk_update_oop(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *u0, double *u1,
+                       const double *flx1, const double *flx2, const double *flx3, int face_shaped, void *stream) {
+  Geo g = make_geo(p);
+  dim3 grid = flat_grid(g, g.N2, g.N3*g.nmb), block(BX, BY);
+  k_rk_update_oop<<<grid, block, 0, (hipStream_t)stream>>>(g, gam0, gam1, beta_dt, u0, u1, flx1, flx2, flx3,
+                                                           face_shaped ? 1 : 0);
+  AKMI_CHECK_LAUNCH("rk_update_oop");
+  return AKMI_COMPLETE;
+}
+
 int akmi_hydro_c2p(const akmi_pack *p, double *u0, double *w0, int il, int iu, int jl, int ju,
                    int kl, int ku, int *counters, void *stream) {
   Geo g = make_geo(p);
@@ -1232,6 +1339,17 @@ int akmi_mhd_ct(const akmi_pack *p, double gam0, double gam1, double beta_dt, co
   k_ct<<<grid, block, 0, (hipStream_t)stream>>>(g, gam0, gam1, beta_dt, e1, e2, e3, b0x1f, b0x2f,
                                                 b0x3f, b1x1f, b1x2f, b1x3f);
   AKMI_CHECK_LAUNCH("ct");
+  return AKMI_COMPLETE;
+}
+
+int akmi_mhd_ct_oop(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *e1, const double *e2,
+                    const double *e3, const double *b0x1f, const double *b0x2f, const double *b0x3f, double *b1x1f,
+                    double *b1x2f, double *b1x3f, void *stream) {
+  Geo g = make_geo(p);
+  dim3 grid((unsigned)(((long)(g.N2 + 1)*(g.N1 + 1) + BX*BY - 1)/(BX*BY)), 1, (unsigned)((g.N3 + 1)*g.nmb)), block(BX, BY);
+  k_ct_oop<<<grid, block, 0, (hipStream_t)stream>>>(g, gam0, gam1, beta_dt, e1, e2, e3, b0x1f, b0x2f, b0x3f, b1x1f,
+                                                    b1x2f, b1x3f);
+  AKMI_CHECK_LAUNCH("ct_oop");
   return AKMI_COMPLETE;
 }
 

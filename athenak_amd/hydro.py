@@ -171,6 +171,14 @@ class FluidBase:
         self.dtnew = dtnew
 
 
+    def _oop_first(self, pdrive, stage):
+        """task-granular path, first stage: CopyCons folded into an out-of-place RKUpdate / CT
+        (akmi_rk_update_oop, akmi_mhd_ct_oop) and the registers swapped -- no copy traffic.  Not with FOFC (its
+        trial update reads u1/b1 before RKUpdate), RK4 (CopyCons updates the second register itself), or the
+        update-in-the-sweeps option."""
+        return (stage == 1 and not self.fused and not self.use_fofc and not self.sweep_update
+                and pdrive.integrator != "rk4" and _TASK_OOP)
+
     @staticmethod
     def _copy_flag(pdrive, stage, phases):
         """copy_u1 of include/akmi.h: the first stage writes its result into the second register and
@@ -185,6 +193,7 @@ class FluidBase:
 
 import os as _os
 _MERGE_C2P = _os.environ.get("AKMI_MERGE_C2P", "1") != "0"      # A/B switch (profiles/r03_whatif_merge_c2p.txt)
+_TASK_OOP = _os.environ.get("AKMI_TASK_OOP", "1") != "0"        # A/B switch: first stage of the task path out of place
 
 
 class Hydro(FluidBase):
@@ -293,7 +302,9 @@ class Hydro(FluidBase):
 
     def CopyCons(self, pdrive, stage):
         """hydro_tasks.cpp:130-152 (folded into the fused stage kernel when fused)"""
-        if stage == 1 and not self.fused:
+        if self._oop_first(pdrive, stage):
+            pass                                  # RKUpdate writes the new state into u1 and swaps the registers
+        elif stage == 1 and not self.fused:
             capi.check(self.L.akmi_copy_cons(C.byref(self.pack_c), capi._p(self.u0),
                                              capi._p(self.u1), capi._stream()), "copy_cons")
         elif stage > 1 and pdrive.integrator == "rk4":
@@ -341,6 +352,12 @@ class Hydro(FluidBase):
             # pass A + ConsToPrim of the active cells (+ CFL scan on the last stage) in one
             # call; the ghost shell is converted in ConToPrim after the halo
             self._stage_phase(pdrive, stage, capi.PHASE_ALL)
+        elif self._oop_first(pdrive, stage):
+            capi.check(self.L.akmi_rk_update_oop(
+                C.byref(self.pack_c), capi.d(gam0), capi.d(gam1), capi.d(beta_dt), capi._p(self.u0),
+                capi._p(self.u1), capi._p(self.uflx.x1f), capi._p(self.uflx.x2f),
+                capi._p(self.uflx.x3f), 0, capi._stream()), "rk_update_oop")
+            self.u0, self.u1 = self.u1, self.u0
         else:
             capi.check(self.L.akmi_rk_update(
                 C.byref(self.pack_c), capi.d(gam0), capi.d(gam1), capi.d(beta_dt), capi._p(self.u0),

@@ -167,6 +167,8 @@ class MHD(FluidBase):
 
     def CopyCons(self, pdrive, stage):
         """mhd_tasks.cpp:162-170"""
+        if self._oop_first(pdrive, stage):
+            return TaskStatus.complete            # RKUpdate / CT write u1 / b1 and swap the registers
         if stage == 1 and not self.fused:
             capi.check(self.L.akmi_copy_cons(C.byref(self.pack_c), capi._p(self.u0),
                                              capi._p(self.u1), capi._stream()), "copy_cons")
@@ -238,6 +240,11 @@ class MHD(FluidBase):
                 C.byref(self.pack_c), C.byref(ps.smr_c), self.nvars, capi.d(gam0), capi.d(gam1), capi.d(beta_dt),
                 capi._p(self.upd_save), capi._p(self.u0), capi._p(self.u1), *self._b(self.uflx),
                 capi._stream()), "smr_redo_update")
+        elif self._oop_first(pdrive, stage):
+            capi.check(self.L.akmi_rk_update_oop(
+                C.byref(self.pack_c), capi.d(gam0), capi.d(gam1), capi.d(beta_dt), capi._p(self.u0),
+                capi._p(self.u1), *self._b(self.uflx), 1, capi._stream()), "rk_update_oop")
+            self.u0, self.u1 = self.u1, self.u0
         else:
             capi.check(self.L.akmi_rk_update(
                 C.byref(self.pack_c), capi.d(gam0), capi.d(gam1), capi.d(beta_dt), capi._p(self.u0),
@@ -310,6 +317,13 @@ class MHD(FluidBase):
         elif not self.fused:
             gam0, gam1 = pdrive.gam0[stage - 1], pdrive.gam1[stage - 1]
             beta_dt = pdrive.beta[stage - 1]*self.pmy_pack.pmesh.dt
+            if self._oop_first(pdrive, stage):
+                capi.check(self.L.akmi_mhd_ct_oop(
+                    C.byref(self.pack_c), capi.d(gam0), capi.d(gam1), capi.d(beta_dt),
+                    capi._p(self.efld.x1e), capi._p(self.efld.x2e), capi._p(self.efld.x3e),
+                    *self._b(self.b0), *self._b(self.b1), capi._stream()), "mhd_ct_oop")
+                self.b0, self.b1 = self.b1, self.b0
+                return TaskStatus.complete
             capi.check(self.L.akmi_mhd_ct(
                 C.byref(self.pack_c), capi.d(gam0), capi.d(gam1), capi.d(beta_dt),
                 capi._p(self.efld.x1e), capi._p(self.efld.x2e), capi._p(self.efld.x3e),

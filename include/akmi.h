@@ -160,6 +160,17 @@ int akmi_rk_update(const akmi_pack *p, double gam0, double gam1, double beta_dt,
                    double *u0, const double *u1, const double *flx1, const double *flx2,
                    const double *flx3, int face_shaped, void *stream);
 
+/* First stage OUT OF PLACE on the task-granular path: CopyCons (u1 := u0, src/hydro/hydro_tasks.cpp:130-152)
+ * followed by RKUpdate in one pass.  u0 is only read; u1 receives, in EVERY cell, what CopyCons + akmi_rk_update would
+ * have left in u0 (active cells: gam0*u0 + gam1*u0 - beta_dt*divF, same operands and order; ghost cells: u0).
+ * Afterwards the caller swaps the two registers: the old u0 buffer IS the copy CopyCons would have made.
+ * akmi_mhd_ct_oop: the same for CopyCons of the face fields + CT (src/mhd/mhd_ct.cpp:23-80). */
+int akmi_rk_update_oop(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *u0, double *u1,
+                       const double *flx1, const double *flx2, const double *flx3, int face_shaped, void *stream);
+int akmi_mhd_ct_oop(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *e1, const double *e2,
+                    const double *e3, const double *b0x1f, const double *b0x2f, const double *b0x3f, double *b1x1f,
+                    double *b1x2f, double *b1x3f, void *stream);
+
 /* IdealHydro::ConsToPrim (src/eos/ideal_hyd.cpp:29-115) over [il,iu]x[jl,ju]x[kl,ku];
  * counters = device int[3] (dfloor,efloor,tfloor), incremented (not reset). */
 int akmi_hydro_c2p(const akmi_pack *p, double *u0, double *w0, int il, int iu, int jl,

@@ -67,6 +67,11 @@ int akref_bfield_bcs_inflow(const akmi_pack *p, const int *bcs, const double *b_
                             double *bx2f, double *bx3f);
 /* SMR/AMR operators between a MeshBlock and its coarse buffer (no mesh tree behind them yet) */
 int akref_restrict_cc(const akmi_pack *p, int nvar, const double *u, double *cu);
+int akref_rk_update_oop(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *u0, double *u1,
+                        const double *flx1, const double *flx2, const double *flx3, int face_shaped);
+int akref_mhd_ct_oop(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *e1, const double *e2,
+                     const double *e3, const double *b0x1f, const double *b0x2f, const double *b0x3f, double *b1x1f,
+                     double *b1x2f, double *b1x3f);
 int akref_restrict_cc_masked(const akmi_pack *p, int nvar, const unsigned char *mask, const double *u, double *cu);
 int akref_restrict_fc_masked(const akmi_pack *p, const unsigned char *mask, const double *b1, const double *b2,
                              const double *b3, double *cb1, double *cb2, double *cb3);

@@ -2909,6 +2909,25 @@ int akref_restrict_fc(const akmi_pack *p, const double *b1, const double *b2, co
   return 0;
 }
 
+/* twins of akmi_rk_update_oop / akmi_mhd_ct_oop (include/akmi.h): the reference's own sequence, CopyCons
+ * (hydro_tasks.cpp:130-152, mhd_tasks.cpp:162-170) then the update, with the roles of the registers as the ABI
+ * describes them: src stays, dst receives the new state */
+int akref_rk_update_oop(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *u0, double *u1,
+                        const double *flx1, const double *flx2, const double *flx3, int face_shaped) {
+  G g = mkG(p);
+  memcpy(u1, u0, sizeof(double)*(size_t)p->nmb*p->nvar*g.N3*g.N2*g.N1);
+  return akref_rk_update(p, gam0, gam1, beta_dt, u1, u0, flx1, flx2, flx3, face_shaped);
+}
+int akref_mhd_ct_oop(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *e1, const double *e2,
+                     const double *e3, const double *b0x1f, const double *b0x2f, const double *b0x3f, double *b1x1f,
+                     double *b1x2f, double *b1x3f) {
+  G g = mkG(p);
+  memcpy(b1x1f, b0x1f, sizeof(double)*(size_t)p->nmb*g.N3*g.N2*(g.N1 + 1));
+  memcpy(b1x2f, b0x2f, sizeof(double)*(size_t)p->nmb*g.N3*(g.N2 + 1)*g.N1);
+  memcpy(b1x3f, b0x3f, sizeof(double)*(size_t)p->nmb*(g.N3 + 1)*g.N2*g.N1);
+  return akref_mhd_ct(p, gam0, gam1, beta_dt, e1, e2, e3, b1x1f, b1x2f, b1x3f, b0x1f, b0x2f, b0x3f);
+}
+
 /* twins of akmi_restrict_cc_masked / akmi_restrict_fc_masked (include/akmi.h): RestrictCC / RestrictFC for the
  * MeshBlocks with mask[m] != 0 (NULL: all), one block at a time through the functions above */
 int akref_restrict_cc_masked(const akmi_pack *p, int nvar, const unsigned char *mask, const double *u, double *cu) {
