@@ -2280,7 +2280,10 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
   // AKMI_HYDRO_ONE_KERNEL=0: the three-kernel sweep/march sequence also for hydro DC/PLM (A/B runs)
   static const bool hyd_one = !(getenv("AKMI_HYDRO_ONE_KERNEL") && atoi(getenv("AKMI_HYDRO_ONE_KERNEL")) == 0);
   static const bool x12s = !getenv("AKMI_X12") || atoi(getenv("AKMI_X12")) == 2;
-  const int T = (phases != AKMI_PHASE_ALL) ? g.nx3 : (env_slab > 1 ? env_slab : AKMI_SLAB);
+  // (the slab pipeline covers the whole-stage call and the sweeps + CornerE + CT call; the other partial phases of a
+  //  rank with off-rank neighbours run one slab)
+  const bool slabs_ok = phases == AKMI_PHASE_ALL || phases == (AKMI_PHASE_SWEEPS | AKMI_PHASE_EMF_CT);
+  const int T = !slabs_ok ? g.nx3 : (env_slab > 1 ? env_slab : AKMI_SLAB);
   const int S = (g.nx3 + T - 1)/T;
   if (S > MAX_SLABS) { set_error("too many slabs"); return AKMI_FAIL; }
   // sign words instead of mass-flux arrays (MfBits): the 3-D PLM+HLLD stage in one slab, no passive scalars; the
