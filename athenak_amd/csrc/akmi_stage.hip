@@ -404,6 +404,9 @@ __device__ __forceinline__ double beta_dt_of(double beta_dt, const double *dtp) 
 #ifndef AKMI_PREFETCH_UNCOND
 #define AKMI_PREFETCH_UNCOND 0  // ... by unconditional loads (clamped address) instead of one scalar branch per load: 942 -> 965
 #endif
+#ifndef AKMI_BX_FIRST
+#define AKMI_BX_FIRST 0         // marches: the face field requested before the update operands of the step (measured: no effect, profiles/r03_ab4.txt)
+#endif
 #ifndef AKMI_X2_EO
 #define AKMI_X2_EO 0            // wave-uniform early-outs of HLLD in the x2 / x3 march (registers!)
 #endif
@@ -680,6 +683,12 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
     // so that their latency is covered by ~1000 VALU instructions instead of following them
     // (this kernel moves the most bytes of the stage and runs at 3 waves/SIMD)
     constexpr bool PRE = (DIR == 2) && USEACC && (MODE == 0) && AKMI_PREFETCH_UPD;
+    // the face field is the first thing the solve needs: requested BEFORE the update operands below, so that the wait
+    // in front of the solve is for the oldest load only (vmcnt counts in order) and the operands stay in flight
+    [[maybe_unused]] double bxi_first = 0.0;
+#if AKMI_BX_FIRST
+    if constexpr (MHD && !PBX) bxi_first = ldu(bxm, foff);
+#endif
     const int sc = s - 1;                               // cell finished by this face
     const bool upd = MODE != 2 && t > 0 && col_active && sc >= clo && sc <= chi;
     double pa[5], pu[5], pu1[5];
@@ -702,11 +711,13 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
     if constexpr (PRE1) {
       if (upd) {
         const double *f1 = u.flx1 + (size_t)m*g.nvar*fs1 - (g.N1 + 1);       // row sc = s-1
+        // the two fluxes stay as loaded until the update below: a subtraction or `p2 ? ldexp : /` here would put a
+        // wait (and, through the wave-uniform branch, one basic block per variable: load -> vmcnt(0), five times)
+        // in front of the solve that is meant to cover the latency (second audit, profiles/r03_isa_audit.txt)
 #pragma unroll
         for (int n = 0; n < 5; ++n) {
           if (ISO && n == 4) continue;
-          const double d1 = ldu(f1 + n*fs1 + 1, o1) - ldu(f1 + n*fs1, o1);
-          pa[n] = p2 ? ldexp(d1, n1) : d1/dx1;
+          pu[n] = ldu(f1 + n*fs1 + 1, o1); pa[n] = ldu(f1 + n*fs1, o1);
         }
       }
     }
@@ -718,7 +729,11 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
       fl.by = L[5] + R[5] + ldu(bxm, foff); fl.bz = L[6] + R[6];
 #else
       double bxi;
+#if AKMI_BX_FIRST
+      if constexpr (PBX) bxi = bx_c; else bxi = bxi_first;
+#else
       if constexpr (PBX) bxi = bx_c; else bxi = ldu(bxm, foff);
+#endif
       Cons1D fl = riemann_mhd_e<RS, (DIR == 1 ? AKMI_X2_EO : AKMI_X3_EO) != 0, AKMI_MARCH_FM != 0>(
           eos, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1], R[2], R[3], R[4], R[5], R[6], bxi);
 #endif
@@ -759,45 +774,75 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
     if (upd) {
       const int kc = (DIR == 2) ? sc : k, jc = (DIR == 1) ? sc : j;
       const size_t mb = (size_t)m*g.nvar*cs;
+      // operands of all variables first (one group of loads, counted waits), then the arithmetic with the
+      // power-of-two choice hoisted out of the loop over the variables: with `p2 ? ldexp : /` inside that loop
+      // every variable was a basic block of its own with its loads and an s_waitcnt vmcnt(0) at the top
+      // (the x3 march with its operands prefetched before the solve keeps the plain loop: nothing is loaded in it, and
+      //  the two-copy form costs it 870 -> 940 us, profiles/r03_ab5.txt)
+      if constexpr (PRE) {
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+          if (ISO && n == 4) continue;
+          const double dlast = fv[n] - FP_(n);
+          double divf = pa[n];
+          divf += p2 ? ldexp(dlast, n3) : dlast/dx3;
+          const double u0v = pu[n];
+          double u1v;
+          if constexpr (AKMI_PREFETCH_U1) u1v = u.copy_u1 ? u0v : pu1[n];
+          else u1v = u.copy_u1 ? u0v : ldu(u.u1 + mb + n*cs, ocm);
+          rk_store_u(u.u0 + mb + n*cs, u.u1 + mb + n*cs, u.copy_u1, ocm, u0v, u.gam0*u0v + u.gam1*u1v - bdt*divf);
+        }
+      } else {
+      double t1[5], t2[5], u0v[5], u1v[5];
 #pragma unroll
       for (int n = 0; n < 5; ++n) {
         if (ISO && n == 4) continue;
-        const double fprev = FP_(n);
-        double divf;
-        if constexpr (PRE || PRE1) {
-          divf = pa[n];
+        t2[n] = 0.0;
+        if constexpr (PRE1) {
+          t1[n] = pu[n] - pa[n];                          // x1 flux difference, fetched before the solve
+        } else if constexpr (PRE) {
+          t1[n] = pa[n];                                  // acc, fetched before the solve
         } else if constexpr (USEACC) {
-          divf = ldu(u.acc + mb + n*cs, ocm);
+          t1[n] = ldu(u.acc + mb + n*cs, ocm);
         } else if constexpr (DIR == 1) {
           const double *f1 = u.flx1 + (size_t)m*g.nvar*fs1 + n*fs1 - (g.N1 + 1);     // row sc = s-1
-          const double d1 = ldu(f1 + 1, o1) - ldu(f1, o1);
-          divf = p2 ? ldexp(d1, n1) : d1/dx1;
+          t1[n] = ldu(f1 + 1, o1) - ldu(f1, o1);
         } else {
-          const double d1 = u.flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, n, kc, jc, i + 1)] -
-                            u.flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, n, kc, jc, i)];
-          divf = p2 ? ldexp(d1, n1) : d1/dx1;
+          t1[n] = u.flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, n, kc, jc, i + 1)] -
+                  u.flx1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, n, kc, jc, i)];
+          t2[n] = u.flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, n, kc, jc + 1, i)] -
+                  u.flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, n, kc, jc, i)];
         }
-        if constexpr (DIR == 1) {
-          divf += p2 ? ldexp(fv[n] - fprev, n2) : (fv[n] - fprev)/dx2;
-        } else {
-          if constexpr (!USEACC) {
-            const double d2 = u.flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, n, kc, jc + 1, i)] -
-                              u.flx2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, n, kc, jc, i)];
-            divf += p2 ? ldexp(d2, n2) : d2/dx2;
+        if constexpr (MODE != 1) {
+          if constexpr (PRE) u0v[n] = pu[n]; else u0v[n] = ldu(u.u0 + mb + n*cs, ocm);
+          if constexpr (PRE && AKMI_PREFETCH_U1) u1v[n] = u.copy_u1 ? u0v[n] : pu1[n];
+          else u1v[n] = u.copy_u1 ? u0v[n] : ldu(u.u1 + mb + n*cs, ocm);
+        }
+      }
+      auto finish = [&](auto P2c) {
+        constexpr bool P2v = decltype(P2c)::value;
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+          if (ISO && n == 4) continue;
+          const double dlast = fv[n] - FP_(n);
+          double divf;
+          if constexpr ((PRE && !PRE1) || (USEACC && !PRE1)) divf = t1[n];           // acc: already a divergence
+          else divf = P2v ? ldexp(t1[n], n1) : t1[n]/dx1;
+          if constexpr (DIR == 1) {
+            divf += P2v ? ldexp(dlast, n2) : dlast/dx2;
+          } else {
+            if constexpr (!USEACC) divf += P2v ? ldexp(t2[n], n2) : t2[n]/dx2;
+            divf += P2v ? ldexp(dlast, n3) : dlast/dx3;
           }
-          divf += p2 ? ldexp(fv[n] - fprev, n3) : (fv[n] - fprev)/dx3;
+          if constexpr (MODE == 1) {
+            stu(u.acc + mb + n*cs, ocm, divf);
+          } else {
+            rk_store_u(u.u0 + mb + n*cs, u.u1 + mb + n*cs, u.copy_u1, ocm, u0v[n],
+                       u.gam0*u0v[n] + u.gam1*u1v[n] - bdt*divf);
+          }
         }
-        if constexpr (MODE == 1) {
-          stu(u.acc + mb + n*cs, ocm, divf);
-        } else {
-          double u0v;
-          if constexpr (PRE) u0v = pu[n]; else u0v = ldu(u.u0 + mb + n*cs, ocm);
-          double u1v;
-          if constexpr (PRE && AKMI_PREFETCH_U1) u1v = u.copy_u1 ? u0v : pu1[n];
-          else u1v = u.copy_u1 ? u0v : ldu(u.u1 + mb + n*cs, ocm);
-          rk_store_u(u.u0 + mb + n*cs, u.u1 + mb + n*cs, u.copy_u1, ocm, u0v,
-                     u.gam0*u0v + u.gam1*u1v - bdt*divf);
-        }
+      };
+      if (p2) finish(IC<1>{}); else finish(IC<0>{});
       }
     }
 #pragma unroll
