@@ -87,32 +87,52 @@ k_ghost_fill(Geo g, GhostSet gs, int nv, unsigned chunks, const int *__restrict_
   const unsigned mn = blockIdx.x/chunks, ch = blockIdx.x - mn*chunks;
   const int m = (int)(mn/(unsigned)nv), n = (int)(mn - (unsigned)m*(unsigned)nv);
   const size_t vbase = ((size_t)m*nv + n)*q.n3;
-  for (unsigned r = ch*256u + threadIdx.x; r < per; r += chunks*256u) {
-    const unsigned kk = r/e12, r2 = r - kk*e12;
-    const unsigned jj = r2/e1;
-    const int ii = (int)(r2 - jj*e1);
-    int i, j, k;
-    if (mode == 0) { i = ii; j = (int)jj; k = (int)kk < q.d3.ng ? (int)kk : q.d3.eo + 1 + ((int)kk - q.d3.ng); }
-    else if (mode == 1) { i = ii; j = (int)jj < q.d2.ng ? (int)jj : q.d2.eo + 1 + ((int)jj - q.d2.ng); k = q.d3.s + (int)kk; }
-    else { i = ii < q.d1.ng ? ii : q.d1.eo + 1 + (ii - q.d1.ng); j = q.d2.s + (int)jj; k = q.d3.s + (int)kk; }
-    int o1 = q.d1.side(i), o2 = q.d2.side(j), o3 = q.d3.side(k);
-    int d = (o3 + 1)*9 + (o2 + 1)*3 + (o1 + 1);
-    int src = nghbr[m*27 + d];
-    size_t dst = ((vbase + k)*q.n2 + j)*q.n1 + i;
-    if constexpr (KIND == 0) {
-      if (src < 0) continue;
-      a[dst] = a[((((size_t)src*nv + n)*q.n3 + (k - o3*q.d3.nx))*q.n2 + (j - o2*q.d2.nx))*q.n1 +
-                 (i - o1*q.d1.nx)];
-    } else {
-      if (src > -2) continue;
-      const int c1 = q.d1.cnt(o1), c2 = q.d2.cnt(o2), c3 = q.d3.cnt(o3);
-      long long base = seg_off[-(src + 2)];
-      if constexpr (KIND == 2)
-        for (int c = 1; c < comp; ++c) base += seg_count(make_comp(g, c), o1, o2, o3);
-      long long off = base + (((long long)n*c3 + (k - q.d3.lo(o3)))*c2 + (j - q.d2.lo(o2)))*c1 +
-                      (i - q.d1.lo(o1));
-      a[dst] = recvbuf[off];
+  // the 27 neighbour entries of this MeshBlock once per workgroup (LDS), not one dependent global load per element;
+  // GU elements per thread and pass, all loads of a pass before its stores: the kernel has next to no arithmetic,
+  // its rate is the number of bytes in flight (960 blocks of 32^3, ng = 4: 895 -> 748 us, profiles/r03_config5.txt)
+  __shared__ int s_src[27];
+  if (threadIdx.x < 27) s_src[threadIdx.x] = nghbr[m*27 + threadIdx.x];
+  __syncthreads();
+  constexpr int GU = 4;
+  const unsigned stride = chunks*256u;
+  for (unsigned r0 = ch*256u + threadIdx.x; r0 < per; r0 += stride*GU) {
+    double v[GU];
+    size_t dst[GU];
+    bool ok[GU];
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      const unsigned r = r0 + (unsigned)u*stride;
+      ok[u] = r < per;
+      v[u] = 0.0; dst[u] = 0;
+      if (!ok[u]) continue;
+      const unsigned kk = r/e12, r2 = r - kk*e12;
+      const unsigned jj = r2/e1;
+      const int ii = (int)(r2 - jj*e1);
+      int i, j, k;
+      if (mode == 0) { i = ii; j = (int)jj; k = (int)kk < q.d3.ng ? (int)kk : q.d3.eo + 1 + ((int)kk - q.d3.ng); }
+      else if (mode == 1) { i = ii; j = (int)jj < q.d2.ng ? (int)jj : q.d2.eo + 1 + ((int)jj - q.d2.ng); k = q.d3.s + (int)kk; }
+      else { i = ii < q.d1.ng ? ii : q.d1.eo + 1 + (ii - q.d1.ng); j = q.d2.s + (int)jj; k = q.d3.s + (int)kk; }
+      const int o1 = q.d1.side(i), o2 = q.d2.side(j), o3 = q.d3.side(k);
+      const int d = (o3 + 1)*9 + (o2 + 1)*3 + (o1 + 1);
+      const int src = s_src[d];
+      dst[u] = ((vbase + k)*q.n2 + j)*q.n1 + i;
+      if constexpr (KIND == 0) {
+        if (src < 0) { ok[u] = false; continue; }
+        v[u] = a[((((size_t)src*nv + n)*q.n3 + (k - o3*q.d3.nx))*q.n2 + (j - o2*q.d2.nx))*q.n1 + (i - o1*q.d1.nx)];
+      } else {
+        if (src > -2) { ok[u] = false; continue; }
+        const int c1 = q.d1.cnt(o1), c2 = q.d2.cnt(o2), c3 = q.d3.cnt(o3);
+        long long base = seg_off[-(src + 2)];
+        if constexpr (KIND == 2)
+          for (int c = 1; c < comp; ++c) base += seg_count(make_comp(g, c), o1, o2, o3);
+        const long long off = base + (((long long)n*c3 + (k - q.d3.lo(o3)))*c2 + (j - q.d2.lo(o2)))*c1 +
+                              (i - q.d1.lo(o1));
+        v[u] = recvbuf[off];
+      }
     }
+#pragma unroll
+    for (int u = 0; u < GU; ++u)
+      if (ok[u]) a[dst[u]] = v[u];
   }
 }
 
@@ -132,7 +152,7 @@ static int launch_ghost(const Geo &g, const GhostSet &gs, int nv, const int *ngh
   // chunks of 256 elements per (MeshBlock, variable) slab; few enough of them that the whole grid stays below
   // 2^31 - 1 workgroups and above a few thousand (a thread then strides over its slab)
   const long long mnv = (long long)g.nmb*nv;
-  long long chunks = (nmax + 255)/256;
+  long long chunks = (nmax + 256*4 - 1)/(256*4);          // GU = 4 elements per thread and pass (k_ghost_fill)
   const long long cap = ((1ll << 31) - 1)/mnv;
   if (chunks > cap) chunks = cap;
   if (chunks > 64 && mnv*chunks > (1ll << 20)) { chunks = (1ll << 20)/mnv; if (chunks < 64) chunks = 64; if (chunks > cap) chunks = cap; }
