@@ -154,6 +154,25 @@ def test_hip_operators_match_the_oracle(dims, ng):
     capi.check(L.akmi_restrict_fc(P, *[capi._p(x) for x in bd], *[capi._p(x) for x in cb2d], None), "restrict_fc")
     for x, y in zip(cb2, cb2d):
         assert np.array_equal(x, y.cpu().numpy())
+    # the masked forms (round 3): blocks with mask != 0 as above, the others untouched; oracle twin with the same mask
+    nmb = a["u"].shape[0]
+    mask = np.array([(m % 2) for m in range(nmb)], dtype=np.uint8) if nmb > 1 else np.ones(1, dtype=np.uint8)
+    maskd = t(mask)
+    cu3, cu3d = np.full_like(a["cu"], -7.0), torch.full_like(cud, -7.0)
+    R.akref_restrict_cc_masked(C.byref(a["pk"]), nv, akref.ptr(mask), akref.ptr(a["u"]), akref.ptr(cu3))
+    capi.check(L.akmi_restrict_cc_masked(P, nv, capi._p(maskd), capi._p(ud), capi._p(cu3d), None), "restrict_cc_masked")
+    assert np.array_equal(cu3, cu3d.cpu().numpy())
+    sel = mask.astype(bool)
+    act = (slice(None), slice(a["cks"], a["cks"] + a["cn"][0]), slice(a["cjs"], a["cjs"] + a["cn"][1]),
+           slice(a["cis"], a["cis"] + a["cn"][2]))
+    assert np.array_equal(cu3[sel][(slice(None),) + act], cu2[sel][(slice(None),) + act]) and np.all(cu3[~sel] == -7.0)
+    cb3, cb3d = [np.full_like(x, -7.0) for x in a["cb"]], [torch.full_like(x, -7.0) for x in cbd]
+    R.akref_restrict_fc_masked(C.byref(a["pk"]), akref.ptr(mask), *[akref.ptr(x) for x in a["b"]],
+                               *[akref.ptr(x) for x in cb3])
+    capi.check(L.akmi_restrict_fc_masked(P, capi._p(maskd), *[capi._p(x) for x in bd], *[capi._p(x) for x in cb3d],
+                                         None), "restrict_fc_masked")
+    for x, y in zip(cb3, cb3d):
+        assert np.array_equal(x, y.cpu().numpy()) and np.all(x[~sel] == -7.0)
     # prolongation of cell-centred data: active box and a ghost-side box (what a coarser neighbour fills)
     for box in (_active_box(a), np.array([a["cis"] - ng//2, a["cis"] - 1, a["cjs"], a["cjs"] + a["cn"][1] - 1,
                                           a["cks"], a["cks"] + a["cn"][0] - 1], dtype=np.int32)):
