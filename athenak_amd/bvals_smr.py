@@ -495,6 +495,19 @@ class MeshBoundaryValuesSMR:
 
     def set_pack(self, pack_c):
         self.pack_c = pack_c
+        # work lists of (block, slot) pairs (akmi_smr::lists, include/akmi.h): the SMR kernels are launched over the
+        # pairs that can have work instead of all nmb*56.  Built once by the library from the tables above.
+        # AKMI_SMR_LISTS=0: A/B switch.  (The CPU test backend has no use for them.)
+        if capi.DEVICE != "cpu" and os.environ.get("AKMI_SMR_LISTS", "1") != "0" and self.smr_c.lists is None:
+            import torch
+            nmb = int(pack_c.nmb)
+            self.t_lists = torch.zeros(2*nmb*56*6, dtype=torch.int32, device=self.device)
+            cnt = (C.c_int*6)()
+            capi.check(capi.lib().akmi_smr_build_lists(C.byref(pack_c), C.byref(self.smr_c), capi._p(self.t_lists), cnt,
+                                                       capi._stream()), "smr_build_lists")
+            self.smr_c.lists = self.t_lists.data_ptr()
+            for q in range(6):
+                self.smr_c.list_cnt[q] = cnt[q]
 
     # ---- task bodies ----------------------------------------------------------------------------
     def RestrictCC(self, u, cu):

@@ -46,7 +46,7 @@ SYMBOLS = [
     "akmi_comm_unique_id", "akmi_comm_init_rccl", "akmi_comm_init_env", "akmi_comm_init_callbacks", "akmi_hydro_stage_fused_dt", "akmi_mhd_stage_fused_dt", "akmi_comm_finalize", "akmi_comm_allreduce_min",
     "akmi_comm_rank", "akmi_comm_nranks", "akmi_host_exchange_plan",
     "akmi_smr_exchange_cc", "akmi_smr_exchange_fc", "akmi_smr_fill_coarse_cc", "akmi_smr_fill_coarse_fc",
-    "akmi_smr_prolong_cc", "akmi_smr_prolong_fc", "akmi_smr_c2p_coarse", "akmi_smr_p2c_fine", "akmi_mhd_fluxes_update", "akmi_smr_update_save_doubles", "akmi_smr_save_update_cells", "akmi_smr_redo_update", "akmi_smr_flux_cc", "akmi_smr_emf_exchange", "akmi_smr_pack_cc", "akmi_smr_unpack_cc", "akmi_smr_pack_fc",
+    "akmi_smr_prolong_cc", "akmi_smr_prolong_fc", "akmi_smr_c2p_coarse", "akmi_smr_p2c_fine", "akmi_smr_build_lists", "akmi_mhd_fluxes_update", "akmi_smr_update_save_doubles", "akmi_smr_save_update_cells", "akmi_smr_redo_update", "akmi_smr_flux_cc", "akmi_smr_emf_exchange", "akmi_smr_pack_cc", "akmi_smr_unpack_cc", "akmi_smr_pack_fc",
     "akmi_selftest_fp64",
     "akmi_smr_unpack_fc", "akmi_smr_pack_flux_cc", "akmi_smr_unpack_flux_cc", "akmi_smr_pack_emf", "akmi_smr_unpack_emf",
 ]
@@ -59,7 +59,8 @@ class Smr(C.Structure):
     _fields_ = [("nnghbr", C.c_int), ("multilevel", C.c_int), ("nghbr", C.c_void_p),
                 ("mblev", C.c_void_p), ("cc_tab", C.c_void_p), ("fc_tab", C.c_void_p),
                 ("ndat", C.c_void_p), ("slot_ox", C.c_void_p), ("layout", C.c_void_p),
-                ("soff", C.c_void_p), ("roff", C.c_void_p), ("direct_same", C.c_int), ("needs_coarse", C.c_void_p)]
+                ("soff", C.c_void_p), ("roff", C.c_void_p), ("direct_same", C.c_int), ("needs_coarse", C.c_void_p),
+                ("lists", C.c_void_p), ("list_cnt", C.c_int*6)]
 
 
 class AkmiError(RuntimeError):

@@ -421,6 +421,7 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
                  c3 = ind.nx3 > 1 ? cpack_c.nx3 + 2*ind.ng : 1;
     coarse_u0.Realloc(static_cast<size_t>(pp->nmb_thispack)*nvars*c3*c2*c1);
     psmr = new MeshBoundaryValuesSMR(pp, nvars);
+    psmr->BuildLists(&pack_c, stream);
   }
   if (!multilevel && (pp->pmesh->nranks > 1 || SelfExchange()))
     pbval = new MeshBoundaryValues(pp, &pack_c, nvars, blk == "mhd");

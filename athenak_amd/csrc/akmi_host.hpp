@@ -316,6 +316,8 @@ class MeshBoundaryValuesSMR {
   DvceArray<int> d_nghbr, d_lev, d_cc, d_fc, d_ndat, d_ox, d_nflx;
   DvceArray<int> d_same;          // [nmb][27] same-level neighbours in this pack: filled by akmi_bvals_cc_local
   DvceArray<unsigned char> d_needs;   // [nmb] block has a coarser neighbour (akmi_smr::needs_coarse)
+  DvceArray<int> d_lists;         // akmi_smr::lists (work lists of (block, slot) pairs)
+  void BuildLists(const akmi_pack *pk, hipStream_t st);
   DvceArray<long long> d_layout, d_soff, d_roff;
   DvceArray<Real> buf[4];         // cc vars, cc flux, fc vars, fc flux
   // ranks: peers and the slices of buf[cls] that travel (akmi_smr::soff/roff address the segments)

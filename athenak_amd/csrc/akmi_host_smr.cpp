@@ -538,7 +538,20 @@ MeshBoundaryValuesSMR::MeshBoundaryValuesSMR(MeshBlockPack *pp, int nvar_) : pmy
   smr_c.ndat = d_ndat.p; smr_c.slot_ox = d_ox.p; smr_c.layout = d_layout.p;
 }
 
+// Work lists (akmi_smr::lists): the SMR kernels are launched over the (block, slot) pairs that can have work instead
+// of all nmb*56; built once by the library from the tables.  AKMI_SMR_LISTS=0: A/B switch.
+void MeshBoundaryValuesSMR::BuildLists(const akmi_pack *pk, hipStream_t st) {
+  const char *e = std::getenv("AKMI_SMR_LISTS");
+  if (e && std::atoi(e) == 0) return;
+  d_lists.Realloc(static_cast<size_t>(2)*pk->nmb*56*AKMI_SMR_NLISTS);
+  int cnt[AKMI_SMR_NLISTS];
+  if (akmi_smr_build_lists(pk, &smr_c, d_lists.p, cnt, st) != AKMI_COMPLETE) AKMI_FATAL(std::string(akmi_last_error()));
+  smr_c.lists = d_lists.p;
+  for (int l = 0; l < AKMI_SMR_NLISTS; ++l) smr_c.list_cnt[l] = cnt[l];
+}
+
 MeshBoundaryValuesSMR::~MeshBoundaryValuesSMR() {
+  d_lists.Free();
   d_nghbr.Free(); d_lev.Free(); d_cc.Free(); d_fc.Free(); d_ndat.Free(); d_ox.Free(); d_nflx.Free(); d_same.Free(); d_needs.Free();
   d_layout.Free(); d_soff.Free(); d_roff.Free();
   for (auto &b : buf) b.Free();

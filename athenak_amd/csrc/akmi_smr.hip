@@ -12,6 +12,7 @@
 // buffer layout; a workgroup owns one (block, slot[, variable]) and strides over the box.  Where
 // the reference orders overlapping writes (face fields: slots of a block are unpacked one after
 // the other), a workgroup owns (block, component) and walks the slots with a barrier in between.
+#include <vector>
 #include "akmi_common.hpp"
 
 namespace akmi {
@@ -70,11 +71,29 @@ struct Tab {                      // device view of akmi_smr
   int nmb;
   int direct;                     // akmi_smr::direct_same
   const unsigned char *needs;     // akmi_smr::needs_coarse
+  const int *lists;               // akmi_smr::lists (work lists of (block, slot) pairs) or null
+  int cnt[AKMI_SMR_NLISTS];       // akmi_smr::list_cnt
+  int lstride;                    // ints between two lists: 2*nmb*56
 };
 static Tab make_tab(const akmi_pack *p, const akmi_smr *t) {
-  return Tab{t->nnghbr, t->multilevel, t->nghbr, t->mblev, t->cc_tab, t->fc_tab, t->ndat, t->layout,
-             t->soff, t->roff, p->nmb, t->direct_same, t->needs_coarse};
+  Tab tb{t->nnghbr, t->multilevel, t->nghbr, t->mblev, t->cc_tab, t->fc_tab, t->ndat, t->layout,
+         t->soff, t->roff, p->nmb, t->direct_same, t->needs_coarse, t->lists, {0}, 2*p->nmb*56};
+  for (int l = 0; l < AKMI_SMR_NLISTS; ++l) tb.cnt[l] = t->list_cnt[l];
+  return tb;
 }
+// Which (MeshBlock, slot) a workgroup works on.  The kernels below are launched over (block, slot[, component]); on a
+// refined mesh most of those pairs have nothing to do -- 27 of 56 slots of a block exist, a few per cent of them cross a
+// level -- and a launch of 161 000 workgroups that return at once still costs their dispatch (k_smr_average_flux_fc:
+// 248 us for a few MB).  With akmi_smr::lists (akmi_smr_build_lists) a launch covers only the pairs of the list that
+// is a superset of the kernel's own test; every kernel keeps that test, so a list can only cost time, never a result.
+enum { L_VALID = 0, L_VALID_CC = 1, L_COARSER = 2, L_FINER = 3, L_SAME_NEEDS = 4, L_AVG = 5 };
+__device__ __forceinline__ void wg_slot(const Tab &t, int L, int per, int &m, int &n, int &v) {
+  const int w = blockIdx.x/per;
+  v = blockIdx.x - w*per;
+  if (t.lists) { const int *q = t.lists + (size_t)L*t.lstride + 2*(size_t)w; m = q[0]; n = q[1]; }
+  else { n = w%t.nnghbr; m = w/t.nnghbr; }
+}
+static unsigned wg_count(const Tab &t, int L) { return t.lists ? (unsigned)t.cnt[L] : (unsigned)t.nmb*t.nnghbr; }
 #define NGID(t, m, n) (t).ng[((size_t)(m)*56 + (n))*3]
 #define NLEV(t, m, n) (t).ng[((size_t)(m)*56 + (n))*3 + 1]
 #define NDST(t, m, n) (t).ng[((size_t)(m)*56 + (n))*3 + 2]
@@ -102,7 +121,7 @@ k_smr_pack_cc(SGeo s, Tab t, int nvar, const double *__restrict__ a, const doubl
               double *__restrict__ buf) {
   // one workgroup per (block, slot), all variables (a fifth of the workgroups of the (block, slot, variable) grid:
   // most slots of a block are empty and the launch itself was a third of the kernel's time)
-  const int n = blockIdx.x%t.nnghbr, m = blockIdx.x/t.nnghbr;
+  int m, n, v; wg_slot(t, L_VALID_CC, 1, m, n, v); (void)v;
   const int dm = NGID(t, m, n);
   if (dm < 0) return;
   const int nl = NLEV(t, m, n), ml = t.lev[m];
@@ -123,7 +142,7 @@ k_smr_pack_cc(SGeo s, Tab t, int nvar, const double *__restrict__ a, const doubl
 __global__ void __launch_bounds__(256)
 k_smr_unpack_cc(SGeo s, Tab t, int nvar, const double *__restrict__ buf, double *__restrict__ a,
                 double *__restrict__ ca) {
-  const int n = blockIdx.x%t.nnghbr, m = blockIdx.x/t.nnghbr;
+  int m, n, v; wg_slot(t, L_VALID_CC, 1, m, n, v); (void)v;
   if (NGID(t, m, n) < 0) return;
   const int nl = NLEV(t, m, n), ml = t.lev[m];
   if (t.direct && nl == ml && NGID(t, m, n) < t.nmb) return;
@@ -142,7 +161,7 @@ k_smr_unpack_cc(SGeo s, Tab t, int nvar, const double *__restrict__ buf, double 
 // ---- PackAndSendFC --------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_smr_pack_fc(SGeo s, Tab t, CF3 b, CF3 cb, double *__restrict__ buf) {
-  const int v = blockIdx.x%3, n = (blockIdx.x/3)%t.nnghbr, m = blockIdx.x/(3*t.nnghbr);
+  int m, n, v; wg_slot(t, L_VALID, 3, m, n, v); (void)v;
   const int dm = NGID(t, m, n);
   if (dm < 0) return;
   const int nl = NLEV(t, m, n), ml = t.lev[m];
@@ -167,18 +186,39 @@ __device__ __forceinline__ bool active_face(const SGeo &s, int v, int k, int j, 
 }
 
 // ---- RecvAndUnpackFC: the slots of a (block, component) one after the other ----------------------
+// The slots are unpacked in the reference's order (regions of different slots overlap on refined meshes and the
+// later one wins), so a workgroup walks them with a barrier in between.  What a slot needs from the tables -- its box,
+// where its segment starts, which array it goes to -- is fetched for all slots at once into LDS first: inside the
+// walk those three dependent global look-ups per slot were most of the kernel's time (27 slots x ~2 us for a few KB).
+struct SlotMeta { Bx b; long long in; int q; };     // q: -1 no neighbour, 0 same level, 1 coarser, 2 finer
 __global__ void __launch_bounds__(256)
 k_smr_unpack_fc(SGeo s, Tab t, const double *__restrict__ buf, F3 b, F3 cb) {
   const int v = blockIdx.x%3, m = blockIdx.x/3;
   const int ml = t.lev[m];
+  __shared__ SlotMeta sm[56];
+  if ((int)threadIdx.x < t.nnghbr) {
+    const int n = threadIdx.x;
+    SlotMeta x;
+    x.q = -1; x.in = 0; x.b = Bx{0, -1, 0, -1, 0, -1};
+    if (NGID(t, m, n) >= 0) {
+      const int nl = NLEV(t, m, n);
+      x.q = nl < ml ? 1 : (nl == ml ? 0 : 2);
+      x.b = box_of(t.fc, T_RECV, x.q == 1 ? K_COAR : (x.q == 0 ? K_SAME : K_FINE), n, v);
+      x.in = (long long)seg_r(t, 2, m, n) + (long long)ndat_of(t, 1, n, T_RECV, x.q)*v;
+    }
+    sm[n] = x;
+  }
+  __syncthreads();
+  // (an order-preserving PARALLEL walk -- round numbers from box intersections, all slots of a round at once -- was
+  //  built and measured: planning the rounds in the kernel costs more than the walk saves, 43 -> 112 us at deck
+  //  size; profiles/r03_config5.txt)
   for (int n = 0; n < t.nnghbr; ++n) {
-    if (NGID(t, m, n) < 0) continue;                       // uniform over the workgroup
-    const int nl = NLEV(t, m, n);
-    const int q = nl < ml ? 1 : (nl == ml ? 0 : 2);
-    const Bx bx = box_of(t.fc, T_RECV, q == 1 ? K_COAR : (q == 0 ? K_SAME : K_FINE), n, v);
+    const int q = sm[n].q;
+    if (q < 0) continue;                                   // uniform over the workgroup
+    const Bx bx = sm[n].b;
     const int cnt = bcount(bx);
-    const double *in = buf + seg_r(t, 2, m, n) + (size_t)ndat_of(t, 1, n, T_RECV, q)*v;
-    const int coarse = nl < ml;
+    const double *in = buf + sm[n].in;
+    const int coarse = q == 1;
     double *dst = coarse ? cb.b[v] : b.b[v];
     for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
       int k, j, i;
@@ -193,7 +233,7 @@ k_smr_unpack_fc(SGeo s, Tab t, const double *__restrict__ buf, F3 b, F3 cb) {
 // ---- FillCoarseInBndryCC --------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_smr_fill_coarse_cc(SGeo s, Tab t, int nvar, const double *__restrict__ a, double *__restrict__ ca) {
-  const int v = blockIdx.x%nvar, n = (blockIdx.x/nvar)%t.nnghbr, m = blockIdx.x/(nvar*t.nnghbr);
+  int m, n, v; wg_slot(t, L_SAME_NEEDS, nvar, m, n, v); (void)v;
   if (NGID(t, m, n) < 0 || NLEV(t, m, n) != t.lev[m] || (t.needs && !t.needs[m])) return;
   const Bx r = box_of(t.cc, T_RECV, K_SAME, n, 0);
   const Bx b{(r.il + s.cis)/2, (r.iu + s.cis)/2, (r.jl + s.cjs)/2, (r.ju + s.cjs)/2, (r.kl + s.cks)/2,
@@ -215,7 +255,7 @@ k_smr_fill_coarse_cc(SGeo s, Tab t, int nvar, const double *__restrict__ a, doub
 // ---- FillCoarseInBndryFC --------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_smr_fill_coarse_fc(SGeo s, Tab t, CF3 b, F3 cb) {
-  const int v = blockIdx.x%3, n = (blockIdx.x/3)%t.nnghbr, m = blockIdx.x/(3*t.nnghbr);
+  int m, n, v; wg_slot(t, L_SAME_NEEDS, 3, m, n, v); (void)v;
   if (NGID(t, m, n) < 0 || NLEV(t, m, n) != t.lev[m] || (t.needs && !t.needs[m])) return;
   const Bx r = box_of(t.fc, T_RECV, K_SAME, n, v);
   const Bx bx{(r.il + s.cis)/2, (r.iu + s.cis)/2, (r.jl + s.cjs)/2, (r.ju + s.cjs)/2, (r.kl + s.cks)/2,
@@ -253,7 +293,7 @@ __device__ __forceinline__ double s_mm8(double dl, double dr) {
 // ---- ProlongateCC (ProlongCC, src/mesh/prolongation.hpp:19-63) -----------------------------------
 __global__ void __launch_bounds__(256)
 k_smr_prolong_cc(SGeo s, Tab t, int nvar, const double *__restrict__ ca, double *__restrict__ a) {
-  const int n = blockIdx.x%t.nnghbr, m = blockIdx.x/t.nnghbr;
+  int m, n, v; wg_slot(t, L_COARSER, 1, m, n, v); (void)v;
   if (NGID(t, m, n) < 0 || !(NLEV(t, m, n) < t.lev[m])) return;
   const Bx b = box_of(t.cc, T_RECV, K_PROL, n, 0);
   const int cnt = bcount(b);
@@ -292,7 +332,7 @@ k_smr_prolong_cc(SGeo s, Tab t, int nvar, const double *__restrict__ ca, double 
 // Ideal gas (the reference calls SingleC2P_IdealHyd / _IdealMHD unconditionally).
 __global__ void __launch_bounds__(256)
 k_smr_c2p_coarse(SGeo s, Tab t, Eos eos, int nvar, int mhd, double *__restrict__ cu, CF3 cb, double *__restrict__ cw) {
-  const int n = blockIdx.x%t.nnghbr, m = blockIdx.x/t.nnghbr;
+  int m, n, v; wg_slot(t, L_COARSER, 1, m, n, v); (void)v;
   if (NGID(t, m, n) < 0 || !(NLEV(t, m, n) < t.lev[m])) return;
   Bx b = box_of(t.cc, T_RECV, K_PROL, n, 0);
   b.il -= 1; b.iu += 1;
@@ -331,7 +371,7 @@ k_smr_c2p_coarse(SGeo s, Tab t, Eos eos, int nvar, int mhd, double *__restrict__
 // cell-centred field is the average of the FINE face fields, which ProlongateFC has filled before.
 __global__ void __launch_bounds__(256)
 k_smr_p2c_fine(SGeo s, Tab t, int nvar, int mhd, const double *__restrict__ w, CF3 fb, double *__restrict__ u) {
-  const int n = blockIdx.x%t.nnghbr, m = blockIdx.x/t.nnghbr;
+  int m, n, v; wg_slot(t, L_COARSER, 1, m, n, v); (void)v;
   if (NGID(t, m, n) < 0 || !(NLEV(t, m, n) < t.lev[m])) return;
   const Bx c = box_of(t.cc, T_RECV, K_PROL, n, 0);
   Bx b;
@@ -394,7 +434,7 @@ struct Owned {
 // ---- ProlongateFC, shared faces (ProlongFCSharedX1/2/3FaceOwned, prolongation.cpp:149-258) -------
 __global__ void __launch_bounds__(256)
 k_smr_prolong_fc_shared(SGeo s, Tab t, const int *__restrict__ slot_ox, CF3 cb, F3 b) {
-  const int v = blockIdx.x%3, n = (blockIdx.x/3)%t.nnghbr, m = blockIdx.x/(3*t.nnghbr);
+  int m, n, v; wg_slot(t, L_COARSER, 3, m, n, v); (void)v;
   if (NGID(t, m, n) < 0 || !(NLEV(t, m, n) < t.lev[m])) return;
   const Owned own{s, t, m, slot_ox[3*n], slot_ox[3*n + 1], slot_ox[3*n + 2], t.lev[m]};
   const Bx bx = box_of(t.fc, T_RECV, K_PROL, n, v);
@@ -438,7 +478,7 @@ k_smr_prolong_fc_shared(SGeo s, Tab t, const int *__restrict__ slot_ox, CF3 cb, 
 // ---- ProlongateFC, faces inside the coarse cells (ProlongFCInternalOwned, :260-359) ---------------
 __global__ void __launch_bounds__(256)
 k_smr_prolong_fc_internal(SGeo s, Tab t, const int *__restrict__ slot_ox, F3 b) {
-  const int n = blockIdx.x%t.nnghbr, m = blockIdx.x/t.nnghbr;
+  int m, n, v; wg_slot(t, L_COARSER, 1, m, n, v); (void)v;
   if (NGID(t, m, n) < 0 || !(NLEV(t, m, n) < t.lev[m])) return;
   const Owned own{s, t, m, slot_ox[3*n], slot_ox[3*n + 1], slot_ox[3*n + 2], t.lev[m]};
   const Bx p0 = box_of(t.fc, T_RECV, K_PROL, n, 0), p1 = box_of(t.fc, T_RECV, K_PROL, n, 1),
@@ -510,7 +550,7 @@ k_smr_prolong_fc_internal(SGeo s, Tab t, const int *__restrict__ slot_ox, F3 b) 
 struct Flx3 { double *f[3]; };
 __global__ void __launch_bounds__(256)
 k_smr_pack_flux_cc(SGeo s, Tab t, int nvar, int fs, Flx3 flx, double *__restrict__ buf) {
-  const int v = blockIdx.x%nvar, n = (blockIdx.x/nvar)%t.nnghbr, m = blockIdx.x/(nvar*t.nnghbr);
+  int m, n, v; wg_slot(t, L_COARSER, nvar, m, n, v); (void)v;
   const int dm = NGID(t, m, n);
   if (dm < 0 || !(NLEV(t, m, n) < t.lev[m])) return;
   int dir;
@@ -543,7 +583,7 @@ k_smr_pack_flux_cc(SGeo s, Tab t, int nvar, int fs, Flx3 flx, double *__restrict
 
 __global__ void __launch_bounds__(256)
 k_smr_unpack_flux_cc(SGeo s, Tab t, int nvar, int fs, const double *__restrict__ buf, Flx3 flx) {
-  const int v = blockIdx.x%nvar, n = (blockIdx.x/nvar)%t.nnghbr, m = blockIdx.x/(nvar*t.nnghbr);
+  int m, n, v; wg_slot(t, L_FINER, nvar, m, n, v); (void)v;
   if (NGID(t, m, n) < 0 || !(NLEV(t, m, n) > t.lev[m])) return;
   int dir;
   if (n < 8) dir = 0; else if (n < 16) dir = 1; else if (n >= 24 && n < 32) dir = 2; else return;
@@ -574,7 +614,7 @@ __device__ __forceinline__ Bx cells_behind(const SGeo &s, const Bx &f, int dir) 
 }
 __global__ void __launch_bounds__(256)
 k_smr_save_cells(SGeo s, Tab t, int nvar, long long cap, const double *__restrict__ u, double *__restrict__ save) {
-  const int n = blockIdx.x%t.nnghbr, m = blockIdx.x/t.nnghbr;
+  int m, n, v; wg_slot(t, L_FINER, 1, m, n, v); (void)v;
   const int fsl = face_slot(n);
   if (fsl < 0 || NGID(t, m, n) < 0 || !(NLEV(t, m, n) > t.lev[m])) return;
   const int dir = n < 8 ? 0 : (n < 16 ? 1 : 2);
@@ -590,7 +630,7 @@ k_smr_save_cells(SGeo s, Tab t, int nvar, long long cap, const double *__restric
 __global__ void __launch_bounds__(256)
 k_smr_redo_update(SGeo s, Tab t, int nvar, long long cap, double gam0, double gam1, double beta_dt, const double *dxs,
                   const double *__restrict__ save, double *__restrict__ u0, const double *__restrict__ u1, Flx3 flx) {
-  const int n = blockIdx.x%t.nnghbr, m = blockIdx.x/t.nnghbr;
+  int m, n, v; wg_slot(t, L_FINER, 1, m, n, v); (void)v;
   const int fsl = face_slot(n);
   if (fsl < 0 || NGID(t, m, n) < 0 || !(NLEV(t, m, n) > t.lev[m])) return;
   const int dir = n < 8 ? 0 : (n < 16 ? 1 : 2);
@@ -634,7 +674,7 @@ __device__ __forceinline__ bool slot_has(int n, int v) {
 // PackAndSendFluxFC: same level -> the values themselves, coarser neighbour -> restricted pairs
 __global__ void __launch_bounds__(256)
 k_smr_pack_flux_fc(SGeo s, Tab t, E3 ef, double *__restrict__ buf) {
-  const int v = blockIdx.x%3, n = (blockIdx.x/3)%t.nnghbr, m = blockIdx.x/(3*t.nnghbr);
+  int m, n, v; wg_slot(t, L_VALID, 3, m, n, v); (void)v;
   const int dm = NGID(t, m, n);
   if (dm < 0 || !(NLEV(t, m, n) <= t.lev[m]) || !slot_has(n, v)) return;
   const bool same = NLEV(t, m, n) == t.lev[m];
@@ -668,13 +708,27 @@ k_smr_sum_flux_fc(SGeo s, Tab t, int same_level, const double *__restrict__ buf,
   const int v = blockIdx.x%3, m = blockIdx.x/3;
   const int ml = t.lev[m];
   double *e = ef.e[v];
+  __shared__ SlotMeta sm[48];                 // table look-ups of all slots first (see k_smr_unpack_fc)
+  if ((int)threadIdx.x < 48) {
+    const int n = threadIdx.x;
+    SlotMeta x;
+    x.q = -1; x.in = 0; x.b = Bx{0, -1, 0, -1, 0, -1};
+    if (n < t.nnghbr && NGID(t, m, n) >= 0) {
+      const int nl = NLEV(t, m, n);
+      if (((same_level && nl == ml) || (!same_level && nl > ml)) && slot_has(n, v)) {
+        x.q = 0;
+        x.b = box_of(t.fc, T_RECV, same_level ? K_FLXS : K_FLXC, n, v);
+        x.in = (long long)seg_r(t, 3, m, n) + (long long)ndat_of(t, 1, n, T_RECV, same_level ? 3 : 4)*v;
+      }
+    }
+    sm[n] = x;
+  }
+  __syncthreads();
   for (int n = 0; n < t.nnghbr && n < 48; ++n) {
-    if (NGID(t, m, n) < 0) continue;
-    const int nl = NLEV(t, m, n);
-    if (!((same_level && nl == ml) || (!same_level && nl > ml)) || !slot_has(n, v)) continue;
-    const Bx b = box_of(t.fc, T_RECV, same_level ? K_FLXS : K_FLXC, n, v);
+    if (sm[n].q < 0) continue;
+    const Bx b = sm[n].b;
     const int cnt = bcount(b);
-    const double *in = buf + seg_r(t, 3, m, n) + (size_t)ndat_of(t, 1, n, T_RECV, same_level ? 3 : 4)*v;
+    const double *in = buf + sm[n].in;
     for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
       int k, j, i;
       bdecode(b, q, k, j, i);
@@ -687,7 +741,7 @@ k_smr_sum_flux_fc(SGeo s, Tab t, int same_level, const double *__restrict__ buf,
 // ZeroFluxesAtBoundaryWithFiner
 __global__ void __launch_bounds__(256)
 k_smr_zero_flux_fc(SGeo s, Tab t, E3 ef) {
-  const int v = blockIdx.x%3, n = (blockIdx.x/3)%t.nnghbr, m = blockIdx.x/(3*t.nnghbr);
+  int m, n, v; wg_slot(t, L_FINER, 3, m, n, v); (void)v;
   if (n >= 48 || NGID(t, m, n) < 0 || !(NLEV(t, m, n) > t.lev[m]) || !slot_has(n, v)) return;
   const Bx b = box_of(t.fc, T_RECV, K_FLXC, n, v);
   const int cnt = bcount(b);
@@ -702,7 +756,7 @@ k_smr_zero_flux_fc(SGeo s, Tab t, E3 ef) {
 // of :470-570 and :676-760 depends on the neighbour table only)
 __global__ void __launch_bounds__(256)
 k_smr_average_flux_fc(SGeo s, Tab t, const int *__restrict__ nflx, E3 ef) {
-  const int v = blockIdx.x%3, n = (blockIdx.x/3)%t.nnghbr, m = blockIdx.x/(3*t.nnghbr);
+  int m, n, v; wg_slot(t, L_AVG, 3, m, n, v); (void)v;
   if (n >= 48 || !slot_has(n, v)) return;
   // only the first sub-block slot of a face / edge carries the averaging (n = 0,4,8,12,16,18,...)
   const bool face = (n == 0 || n == 4 || n == 8 || n == 12 || n == 24 || n == 28);
@@ -747,6 +801,10 @@ k_smr_average_flux_fc(SGeo s, Tab t, const int *__restrict__ nflx, E3 ef) {
   }
 }
 
+// launch over the (block, slot) pairs of work list L (or the full grid without lists), `per` workgroups per pair
+#define SMR_LAUNCH(kern, L, per, stream, ...) \
+  do { const unsigned nwg_ = wg_count(tb, L)*(unsigned)(per); if (nwg_) kern<<<nwg_, 256, 0, stream>>>(__VA_ARGS__); } while (0)
+
 static int check_smr(const akmi_pack *p, const akmi_smr *t, const char *who) {
   if (!p || !t || !t->nghbr || !t->mblev || !t->cc_tab || !t->fc_tab || !t->layout || !t->ndat) {
     set_error("%s: incomplete akmi_smr descriptor", who);
@@ -772,9 +830,8 @@ static int smr_exchange_cc(const akmi_pack *p, const akmi_smr *t, int nvar, doub
   const SGeo s = make_sgeo(p);
   const Tab tb = make_tab(p, t);
   hipStream_t st = (hipStream_t)stream;
-  const unsigned nb = (unsigned)p->nmb*tb.nnghbr;
-  if (phase & 1) k_smr_pack_cc<<<nb, 256, 0, st>>>(s, tb, nvar, u, cu, buf);
-  if (phase & 2) k_smr_unpack_cc<<<nb, 256, 0, st>>>(s, tb, nvar, buf, u, cu);
+  if (phase & 1) SMR_LAUNCH(k_smr_pack_cc, L_VALID_CC, 1, st, s, tb, nvar, u, cu, buf);
+  if (phase & 2) SMR_LAUNCH(k_smr_unpack_cc, L_VALID_CC, 1, st, s, tb, nvar, buf, u, cu);
   AKMI_CHECK_LAUNCH("smr_exchange_cc");
   return AKMI_COMPLETE;
 }
@@ -785,7 +842,7 @@ static int smr_exchange_fc(const akmi_pack *p, const akmi_smr *t, double *b1, do
   const SGeo s = make_sgeo(p);
   const Tab tb = make_tab(p, t);
   hipStream_t st = (hipStream_t)stream;
-  if (phase & 1) k_smr_pack_fc<<<(unsigned)p->nmb*tb.nnghbr*3, 256, 0, st>>>(s, tb, CF3{{b1, b2, b3}}, CF3{{cb1, cb2, cb3}}, buf);
+  if (phase & 1) SMR_LAUNCH(k_smr_pack_fc, L_VALID, 3, st, s, tb, CF3{{b1, b2, b3}}, CF3{{cb1, cb2, cb3}}, buf);
   if (phase & 2) k_smr_unpack_fc<<<(unsigned)p->nmb*3, 256, 0, st>>>(s, tb, buf, F3{{b1, b2, b3}}, F3{{cb1, cb2, cb3}});
   AKMI_CHECK_LAUNCH("smr_exchange_fc");
   return AKMI_COMPLETE;
@@ -796,7 +853,7 @@ int akmi_smr_fill_coarse_cc(const akmi_pack *p, const akmi_smr *t, int nvar, con
   if (check_smr(p, t, "smr_fill_coarse_cc") != AKMI_COMPLETE) return AKMI_FAIL;
   if (p->nx2 <= 1) return AKMI_COMPLETE;
   const Tab tb = make_tab(p, t);
-  k_smr_fill_coarse_cc<<<(unsigned)p->nmb*tb.nnghbr*nvar, 256, 0, (hipStream_t)stream>>>(make_sgeo(p), tb, nvar, u, cu);
+  SMR_LAUNCH(k_smr_fill_coarse_cc, L_SAME_NEEDS, nvar, (hipStream_t)stream, make_sgeo(p), tb, nvar, u, cu);
   AKMI_CHECK_LAUNCH("smr_fill_coarse_cc");
   return AKMI_COMPLETE;
 }
@@ -806,8 +863,7 @@ int akmi_smr_fill_coarse_fc(const akmi_pack *p, const akmi_smr *t, const double 
   if (check_smr(p, t, "smr_fill_coarse_fc") != AKMI_COMPLETE) return AKMI_FAIL;
   if (p->nx2 <= 1) return AKMI_COMPLETE;
   const Tab tb = make_tab(p, t);
-  k_smr_fill_coarse_fc<<<(unsigned)p->nmb*tb.nnghbr*3, 256, 0, (hipStream_t)stream>>>(
-      make_sgeo(p), tb, CF3{{b1, b2, b3}}, F3{{cb1, cb2, cb3}});
+  SMR_LAUNCH(k_smr_fill_coarse_fc, L_SAME_NEEDS, 3, (hipStream_t)stream, make_sgeo(p), tb, CF3{{b1, b2, b3}}, F3{{cb1, cb2, cb3}});
   AKMI_CHECK_LAUNCH("smr_fill_coarse_fc");
   return AKMI_COMPLETE;
 }
@@ -816,7 +872,7 @@ int akmi_smr_prolong_cc(const akmi_pack *p, const akmi_smr *t, int nvar, const d
                         void *stream) {
   if (check_smr(p, t, "smr_prolong_cc") != AKMI_COMPLETE) return AKMI_FAIL;
   const Tab tb = make_tab(p, t);
-  k_smr_prolong_cc<<<(unsigned)p->nmb*tb.nnghbr, 256, 0, (hipStream_t)stream>>>(make_sgeo(p), tb, nvar, cu, u);
+  SMR_LAUNCH(k_smr_prolong_cc, L_COARSER, 1, (hipStream_t)stream, make_sgeo(p), tb, nvar, cu, u);
   AKMI_CHECK_LAUNCH("smr_prolong_cc");
   return AKMI_COMPLETE;
 }
@@ -835,7 +891,7 @@ int akmi_smr_c2p_coarse(const akmi_pack *p, const akmi_smr *t, int nvar, double 
   if (check_smr(p, t, "smr_c2p_coarse") != AKMI_COMPLETE || check_prims(p, nvar, "smr_c2p_coarse") != AKMI_COMPLETE)
     return AKMI_FAIL;
   const Tab tb = make_tab(p, t);
-  k_smr_c2p_coarse<<<(unsigned)p->nmb*tb.nnghbr, 256, 0, (hipStream_t)stream>>>(
+  SMR_LAUNCH(k_smr_c2p_coarse, L_COARSER, 1, (hipStream_t)stream,
       make_sgeo(p), tb, make_eos(p), nvar, cb1 != nullptr, cu, CF3{{cb1, cb2, cb3}}, cw);
   AKMI_CHECK_LAUNCH("smr_c2p_coarse");
   return AKMI_COMPLETE;
@@ -846,7 +902,7 @@ int akmi_smr_p2c_fine(const akmi_pack *p, const akmi_smr *t, int nvar, const dou
   if (check_smr(p, t, "smr_p2c_fine") != AKMI_COMPLETE || check_prims(p, nvar, "smr_p2c_fine") != AKMI_COMPLETE)
     return AKMI_FAIL;
   const Tab tb = make_tab(p, t);
-  k_smr_p2c_fine<<<(unsigned)p->nmb*tb.nnghbr, 256, 0, (hipStream_t)stream>>>(
+  SMR_LAUNCH(k_smr_p2c_fine, L_COARSER, 1, (hipStream_t)stream,
       make_sgeo(p), tb, nvar, b1 != nullptr, w, CF3{{b1, b2, b3}}, u);
   AKMI_CHECK_LAUNCH("smr_p2c_fine");
   return AKMI_COMPLETE;
@@ -859,9 +915,8 @@ int akmi_smr_prolong_fc(const akmi_pack *p, const akmi_smr *t, const double *cb1
   const SGeo s = make_sgeo(p);
   const Tab tb = make_tab(p, t);
   hipStream_t st = (hipStream_t)stream;
-  k_smr_prolong_fc_shared<<<(unsigned)p->nmb*tb.nnghbr*3, 256, 0, st>>>(s, tb, t->slot_ox, CF3{{cb1, cb2, cb3}},
-                                                                     F3{{b1, b2, b3}});
-  k_smr_prolong_fc_internal<<<(unsigned)p->nmb*tb.nnghbr, 256, 0, st>>>(s, tb, t->slot_ox, F3{{b1, b2, b3}});
+  SMR_LAUNCH(k_smr_prolong_fc_shared, L_COARSER, 3, st, s, tb, t->slot_ox, CF3{{cb1, cb2, cb3}}, F3{{b1, b2, b3}});
+  SMR_LAUNCH(k_smr_prolong_fc_internal, L_COARSER, 1, st, s, tb, t->slot_ox, F3{{b1, b2, b3}});
   AKMI_CHECK_LAUNCH("smr_prolong_fc");
   return AKMI_COMPLETE;
 }
@@ -872,10 +927,9 @@ static int smr_flux_cc(const akmi_pack *p, const akmi_smr *t, int nvar, int face
   const SGeo s = make_sgeo(p);
   const Tab tb = make_tab(p, t);
   hipStream_t st = (hipStream_t)stream;
-  const unsigned nb = (unsigned)p->nmb*tb.nnghbr*nvar;
   const int fs = face_shaped ? 1 : 0;
-  if (phase & 1) k_smr_pack_flux_cc<<<nb, 256, 0, st>>>(s, tb, nvar, fs, Flx3{{flx1, flx2, flx3}}, buf);
-  if (phase & 2) k_smr_unpack_flux_cc<<<nb, 256, 0, st>>>(s, tb, nvar, fs, buf, Flx3{{flx1, flx2, flx3}});
+  if (phase & 1) SMR_LAUNCH(k_smr_pack_flux_cc, L_COARSER, nvar, st, s, tb, nvar, fs, Flx3{{flx1, flx2, flx3}}, buf);
+  if (phase & 2) SMR_LAUNCH(k_smr_unpack_flux_cc, L_FINER, nvar, st, s, tb, nvar, fs, buf, Flx3{{flx1, flx2, flx3}});
   AKMI_CHECK_LAUNCH("smr_flux_cc");
   return AKMI_COMPLETE;
 }
@@ -886,18 +940,58 @@ static int smr_emf_exchange(const akmi_pack *p, const akmi_smr *t, const int *nf
   const SGeo s = make_sgeo(p);
   const Tab tb = make_tab(p, t);
   hipStream_t st = (hipStream_t)stream;
-  const unsigned nb = (unsigned)p->nmb*tb.nnghbr*3;
   const E3 ef{{e1, e2, e3}};
-  if (phase & 1) k_smr_pack_flux_fc<<<nb, 256, 0, st>>>(s, tb, ef, buf);
+  if (phase & 1) SMR_LAUNCH(k_smr_pack_flux_fc, L_VALID, 3, st, s, tb, ef, buf);
   if (phase & 2) {
     k_smr_sum_flux_fc<<<(unsigned)p->nmb*3, 256, 0, st>>>(s, tb, 1, buf, ef);
     if (tb.multilevel) {
-      k_smr_zero_flux_fc<<<nb, 256, 0, st>>>(s, tb, ef);
+      SMR_LAUNCH(k_smr_zero_flux_fc, L_FINER, 3, st, s, tb, ef);
       k_smr_sum_flux_fc<<<(unsigned)p->nmb*3, 256, 0, st>>>(s, tb, 0, buf, ef);
     }
-    k_smr_average_flux_fc<<<nb, 256, 0, st>>>(s, tb, nflx, ef);
+    SMR_LAUNCH(k_smr_average_flux_fc, L_AVG, 3, st, s, tb, nflx, ef);
   }
   AKMI_CHECK_LAUNCH("smr_emf_exchange");
+  return AKMI_COMPLETE;
+}
+
+// Work lists (include/akmi.h).  A set-up call: the neighbour table comes back to the host once, the lists are built
+// there with the tests of the kernels above (every list is a superset of its kernels' tests) and go to `lists`.
+int akmi_smr_build_lists(const akmi_pack *p, const akmi_smr *t, int *lists, int *counts, void *stream) {
+  if (check_smr(p, t, "smr_build_lists") != AKMI_COMPLETE) return AKMI_FAIL;
+  if (!lists || !counts) { set_error("smr_build_lists: lists / counts missing"); return AKMI_FAIL; }
+  hipStream_t st = (hipStream_t)stream;
+  const int nmb = p->nmb, nn = t->nnghbr;
+  std::vector<int> ng((size_t)nmb*56*3), lev(nmb);
+  std::vector<unsigned char> needs(nmb, 1);
+  if (hipMemcpyAsync(ng.data(), t->nghbr, ng.size()*sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipMemcpyAsync(lev.data(), t->mblev, lev.size()*sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      (t->needs_coarse && hipMemcpyAsync(needs.data(), t->needs_coarse, (size_t)nmb, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+      hipStreamSynchronize(st) != hipSuccess) {
+    set_error("smr_build_lists: cannot read the tables"); return AKMI_FAIL;
+  }
+  const size_t stride = (size_t)2*nmb*56;
+  std::vector<int> out(stride*AKMI_SMR_NLISTS, 0);
+  int cnt[AKMI_SMR_NLISTS] = {0};
+  auto push = [&](int L, int m, int n) { out[L*stride + 2*(size_t)cnt[L]] = m; out[L*stride + 2*(size_t)cnt[L] + 1] = n; ++cnt[L]; };
+  for (int m = 0; m < nmb; ++m) for (int n = 0; n < nn; ++n) {
+    const int gid = ng[((size_t)m*56 + n)*3], nl = ng[((size_t)m*56 + n)*3 + 1], ml = lev[m];
+    if (gid >= 0) {
+      push(L_VALID, m, n);
+      if (!(t->direct_same && nl == ml && gid < nmb)) push(L_VALID_CC, m, n);
+      if (nl < ml) push(L_COARSER, m, n);
+      if (nl > ml) push(L_FINER, m, n);
+      if (nl == ml && needs[m]) push(L_SAME_NEEDS, m, n);
+    }
+    // AverageBoundaryFluxes: the first sub-block slot of every face and edge, neighbour or not
+    const bool face = (n == 0 || n == 4 || n == 8 || n == 12 || n == 24 || n == 28);
+    const bool edge = (n >= 16 && n < 24 && n%2 == 0) || (n >= 32 && n < 48 && n%2 == 0);
+    if (face || edge) push(L_AVG, m, n);
+  }
+  if (hipMemcpyAsync(lists, out.data(), out.size()*sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) {
+    set_error("smr_build_lists: cannot write the lists"); return AKMI_FAIL;
+  }
+  for (int l = 0; l < AKMI_SMR_NLISTS; ++l) counts[l] = cnt[l];
   return AKMI_COMPLETE;
 }
 
@@ -913,7 +1007,7 @@ int akmi_smr_save_update_cells(const akmi_pack *p, const akmi_smr *t, int nvar, 
   if (check_smr(p, t, "smr_save_update_cells") != AKMI_COMPLETE) return AKMI_FAIL;
   if (p->nx3 <= 1) { set_error("smr_save_update_cells: 3-D packs only"); return AKMI_FAIL; }
   const Tab tb = make_tab(p, t);
-  k_smr_save_cells<<<(unsigned)p->nmb*tb.nnghbr, 256, 0, (hipStream_t)stream>>>(make_sgeo(p), tb, nvar, save_cap(p, nvar), u0, save);
+  SMR_LAUNCH(k_smr_save_cells, L_FINER, 1, (hipStream_t)stream, make_sgeo(p), tb, nvar, save_cap(p, nvar), u0, save);
   AKMI_CHECK_LAUNCH("smr_save_update_cells");
   return AKMI_COMPLETE;
 }
@@ -924,9 +1018,9 @@ int akmi_smr_redo_update(const akmi_pack *p, const akmi_smr *t, int nvar, double
   if (check_smr(p, t, "smr_redo_update") != AKMI_COMPLETE) return AKMI_FAIL;
   if (p->nx3 <= 1) { set_error("smr_redo_update: 3-D packs only"); return AKMI_FAIL; }
   const Tab tb = make_tab(p, t);
-  k_smr_redo_update<<<(unsigned)p->nmb*tb.nnghbr, 256, 0, (hipStream_t)stream>>>(
-      make_sgeo(p), tb, nvar, save_cap(p, nvar), gam0, gam1, beta_dt, p->dx, save, u0, u1,
-      Flx3{{const_cast<double *>(flx1), const_cast<double *>(flx2), const_cast<double *>(flx3)}});
+  SMR_LAUNCH(k_smr_redo_update, L_FINER, 1, (hipStream_t)stream, make_sgeo(p), tb, nvar, save_cap(p, nvar), gam0, gam1,
+             beta_dt, p->dx, save, u0, u1,
+             Flx3{{const_cast<double *>(flx1), const_cast<double *>(flx2), const_cast<double *>(flx3)}});
   AKMI_CHECK_LAUNCH("smr_redo_update");
   return AKMI_COMPLETE;
 }

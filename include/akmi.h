@@ -349,7 +349,19 @@ typedef struct akmi_smr {
    * of the COARSE arrays, which only ProlongateCC/FC of such a block ever read; with the table the fill skips the
    * other blocks (NULL: every block, as the reference does; the fine arrays come out the same either way). */
   const unsigned char *needs_coarse;
+  /* Work lists (optional; NULL / zero-initialised: every entry point launches over all (MeshBlock, slot) pairs).
+   * lists = device array of AKMI_SMR_NLISTS lists of (m, n) int pairs, list l at lists + l*2*nmb*56, list_cnt[l]
+   * pairs each, filled by akmi_smr_build_lists once after the tables above are in place.  The entry points then
+   * launch over the pairs of the list that covers their own test (existing neighbour; coarser; finer; same level of
+   * a block that prolongates; faces and edges that average their EMFs) instead of nmb*56 pairs of which a few per
+   * cent do anything.  Results cannot depend on the lists: every kernel still applies its own test. */
+  const int *lists;
+  int list_cnt[6];
 } akmi_smr;
+#define AKMI_SMR_NLISTS 6
+/* lists: device, 2*nmb*56*AKMI_SMR_NLISTS ints; counts: HOST, AKMI_SMR_NLISTS ints (copy them into list_cnt).
+ * Set-up call: synchronises `stream`.  direct_same and needs_coarse of *t must already have their final values. */
+int akmi_smr_build_lists(const akmi_pack *p, const akmi_smr *t, int *lists, int *counts, void *stream);
 /* RestrictU is akmi_restrict_cc / akmi_restrict_fc above.  SendU+RecvU (PackAndSendCC +
  * RecvAndUnpackCC, src/bvals/bvals_cc.cpp:42-447): u ghost cells from same-level and finer neighbours,
  * coarse buffer cu from coarser ones.  buf: receive buffers (layout[0]) */

@@ -8,6 +8,8 @@ refined meshes:
   AKMI_SMR_SWEEP_UPDATE=1  Fluxes updates u0 in the sweeps, RKUpdate redoes the cells behind corrected faces
                            (akmi_mhd_fluxes_update / akmi_smr_save_update_cells / akmi_smr_redo_update)
   AKMI_SMR_DIRECT=0        same-level cell-centred ghost zones through the pack/unpack buffers instead of directly
+  AKMI_SMR_LISTS=0         the level-boundary kernels launched over all nmb*56 (block, slot) pairs instead of the work
+                           lists of akmi_smr_build_lists
   AKMI_TASK_OOP=0          task-granular path: CopyCons + in-place RKUpdate / CT on the first stage instead of the
                            out-of-place update with swapped registers (akmi_rk_update_oop, akmi_mhd_ct_oop)
 """
@@ -59,7 +61,8 @@ print("ok")
 """ % (ROOT, os.path.join(ROOT, "tests"))
 
 
-@pytest.mark.parametrize("env", [{"AKMI_SMR_SWEEP_UPDATE": "1"}, {"AKMI_SMR_DIRECT": "0"}, {"AKMI_TASK_OOP": "0"}],
+@pytest.mark.parametrize("env", [{"AKMI_SMR_SWEEP_UPDATE": "1"}, {"AKMI_SMR_DIRECT": "0"}, {"AKMI_TASK_OOP": "0"},
+                                 {"AKMI_SMR_LISTS": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
 def test_smr_option_does_not_change_a_bit(env):
     r = subprocess.run([sys.executable, "-c", SMR_SCRIPT], env=dict(os.environ, **env), capture_output=True, text=True,
