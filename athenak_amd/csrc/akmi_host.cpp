@@ -396,6 +396,17 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
     dtmin_cond.Realloc(1);                                   // scratch double of the cell reductions
   }
   fused = pin->GetOrAddBoolean(blk, "fused_stage", true);
+  // small 3-D packs: the task-granular chain (one thread per face) beats the marching kernels of the fused stage
+  // (MHD 64^3: 1 050 against 810 Mcell-updates/s, equal at 96^3; profiles/r03_small_packs.txt); same bits either way.
+  // <hydro|mhd>/small_pack_tasks = false keeps the fused kernels.  AKMI_SMALL_PACK_TASKS=0: off
+  {
+    // (read without adding it to the deck: the parameter dump of the output files stays what the reference's is)
+    const bool small_ok = pin->DoesParameterExist(blk, "small_pack_tasks") ? pin->GetBoolean(blk, "small_pack_tasks") : true;
+    const char *sp = std::getenv("AKMI_SMALL_PACK_TASKS");
+    const long ncell_pack = static_cast<long>(pp->nmb_thispack)*ind.nx1*ind.nx2*ind.nx3;
+    if (small_ok && fused && ind.nx3 > 1 && nscalars == 0 && !(sp && std::atoi(sp) == 0) && ncell_pack <= 600000)
+      fused = false;                   // (not with passive scalars: the task path's sweeps do not carry them)
+  }
   // the fused stage kernels cover both equations of state and carry passive scalars along; extra fluxes
   // (diffusion), FOFC and refined meshes use the task-granular kernels
   if (has_visc || has_cond || has_resist) fused = false;

@@ -299,6 +299,26 @@ AKMI_DEV void face_states_u(const double *__restrict__ base, unsigned ob, long s
   }
 }
 
+// the same from a stencil that is already in registers: q[0..W-1] = cells f-LO .. f+W-LO-1 of face f
+// (W, LO = 2, 1 donor cell; 4, 2 PLM; 6, 3 the five-point schemes).  Same calls, same order as face_states_u.
+template <int RECON> constexpr int stencil_w() { return RECON == 0 ? 2 : (RECON == 1 ? 4 : 6); }
+template <int RECON> constexpr int stencil_lo() { return RECON == 0 ? 1 : (RECON == 1 ? 2 : 3); }
+template <int RECON, int FL = 0>
+AKMI_DEV void face_states_v(const double *q, const FaceEos &eos, double &ql, double &qr) {
+  double dummy;
+  if constexpr (RECON == 1) {
+    plm(q[0], q[1], q[2], ql, dummy);
+    plm(q[1], q[2], q[3], dummy, qr);
+  } else if constexpr (RECON >= 2) {
+    recon5<RECON>(q[0], q[1], q[2], q[3], q[4], ql, dummy);
+    recon5<RECON>(q[1], q[2], q[3], q[4], q[5], dummy, qr);
+    floor_lr<RECON, FL>(eos, ql, qr);
+  } else {
+    ql = q[0];
+    qr = q[1];
+  }
+}
+
 // HLLC, src/hydro/rsolvers/hllc_hyd.hpp:20-115.  States are (d, vx, vy, vz, e_int) with
 // vx along the sweep; flux is (d, mx, my, mz, E).
 AKMI_DEV void hllc(double gamma, double wl_idn, double wl_ivx, double wl_ivy, double wl_ivz,

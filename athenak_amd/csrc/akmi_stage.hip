@@ -61,6 +61,9 @@ static StageWs carve(const Geo &g, int is_mhd, void *ws) {
   return w;
 }
 
+#ifndef AKMI_X1_GROUP_LOADS
+#define AKMI_X1_GROUP_LOADS 1   // thread-per-face sweeps: all stencil loads of a face before the first reconstruction
+#endif
 // ---------------------------------------------------------------------------------------
 // face flux from the cell stencil (registers only).  Returns flux in sweep-aligned order.
 template <int DIR, int RECON, bool MHD, int RS>
@@ -75,6 +78,37 @@ __device__ __forceinline__ void face_flux(const Geo &g, const FaceEos &eos,
   const double *q = w0 + (size_t)m*g.nvar*cs;
   const unsigned off = (((unsigned)k*(unsigned)g.N2 + (unsigned)j)*(unsigned)g.N1 + (unsigned)i)*8u;   // bytes
   double ld, lx, ly, lz, le, rd, rx, ry, rz, re;
+#if AKMI_X1_GROUP_LOADS
+  // every stencil (and the face field) requested before the first reconstruction: the limiters branch, so with the
+  // loads inside face_states_u each variable waited for its own (see sweep_x1_shared)
+  constexpr int W = stencil_w<RECON>(), LO = stencil_lo<RECON>();
+  constexpr int NVs = MHD ? 7 : 5;
+  double sq[NVs][W];
+  const double *bq = MHD ? bcc0 + (size_t)m*3*cs : nullptr;
+  const double *vb[7] = {q, q + ivx*cs, q + ivy*cs, q + ivz*cs, q + 4*cs,
+                         MHD ? bq + ((DIR + 1)%3)*cs : nullptr, MHD ? bq + ((DIR + 2)%3)*cs : nullptr};
+#pragma unroll
+  for (int n = 0; n < NVs; ++n) {
+    if (rs_iso<RS>() && n == 4) continue;
+#pragma unroll
+    for (int d = 0; d < W; ++d) sq[n][d] = ldu(vb[n] + (long)(d - LO)*s, off);
+  }
+  [[maybe_unused]] double bxi_g = 0.0;
+  if constexpr (MHD) bxi_g = ldu(bxf + (size_t)m*f3*f2*f1,
+                                 (((unsigned)k*(unsigned)f2 + (unsigned)j)*(unsigned)f1 + (unsigned)i)*8u);
+  __builtin_amdgcn_sched_barrier(0);
+  face_states_v<RECON, 1>(sq[0], eos, ld, rd);
+  face_states_v<RECON, 0>(sq[1], eos, lx, rx);
+  face_states_v<RECON, 0>(sq[2], eos, ly, ry);
+  face_states_v<RECON, 0>(sq[3], eos, lz, rz);
+  if constexpr (rs_iso<RS>()) { le = re = 0.0; }           // isothermal: no energy variable
+  else face_states_v<RECON, 2>(sq[4], eos, le, re);
+  if constexpr (MHD) {
+    double lby, lbz, rby, rbz;
+    face_states_v<RECON, 0>(sq[5], eos, lby, rby);
+    face_states_v<RECON, 0>(sq[6], eos, lbz, rbz);
+    const double bxi = bxi_g;
+#else
   face_states_u<RECON, 1>(q + 0*cs, off, s, eos, ld, rd);
   face_states_u<RECON, 0>(q + ivx*cs, off, s, eos, lx, rx);
   face_states_u<RECON, 0>(q + ivy*cs, off, s, eos, ly, ry);
@@ -89,6 +123,7 @@ __device__ __forceinline__ void face_flux(const Geo &g, const FaceEos &eos,
     face_states_u<RECON, 0>(b + ibz*cs, off, s, eos, lbz, rbz);
     const double bxi = ldu(bxf + (size_t)m*f3*f2*f1,
                            (((unsigned)k*(unsigned)f2 + (unsigned)j)*(unsigned)f1 + (unsigned)i)*8u);
+#endif
     Cons1D fl = riemann_mhd_e<RS>(eos, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
     fd = fl.d; fx = fl.mx; fy = fl.my; fz = fl.mz; fe = fl.e; fby = fl.by; fbz = fl.bz;
   } else {
@@ -124,9 +159,6 @@ struct SweepArgs {
 // provides): 63 faces per wave.  Same operands, same operations -> same bits.
 #ifndef AKMI_X1_SHARE
 #define AKMI_X1_SHARE 1
-#endif
-#ifndef AKMI_X1_GROUP_LOADS
-#define AKMI_X1_GROUP_LOADS 1
 #endif
 template <int DIR, int RECON>
 constexpr bool x1_share() { return DIR == 0 && RECON >= 1 && AKMI_X1_SHARE; }
@@ -406,6 +438,9 @@ __device__ __forceinline__ double beta_dt_of(double beta_dt, const double *dtp) 
 #endif
 #ifndef AKMI_BX_FIRST
 #define AKMI_BX_FIRST 0         // marches: the face field requested before the update operands of the step (measured: no effect, profiles/r03_ab4.txt)
+#endif
+#ifndef AKMI_SMALL_FACE_SWEEPS
+#define AKMI_SMALL_FACE_SWEEPS 700000   // packs up to this many cells take thread-per-face x2/x3 sweeps on the task path (0: never)
 #endif
 #ifndef AKMI_X2_EO
 #define AKMI_X2_EO 0            // wave-uniform early-outs of HLLD in the x2 / x3 march (registers!)
@@ -2158,6 +2193,17 @@ static int sweeps_store_fluxes_t(const akmi_pack *p, int recon, int rsolver, con
   }
   const UpdArgs u{};
   int rc = launch_sweep<0, MHD, false>(g, sc, a1, st);
+#if AKMI_SMALL_FACE_SWEEPS
+  // small packs (the deck-size mesh of BASELINE config 5): a march is a chain of dependent steps per thread and a
+  // few hundred workgroups; one thread per face has no chain at all
+  static const int tf_env = getenv("AKMI_FACE_SWEEPS") ? atoi(getenv("AKMI_FACE_SWEEPS")) : -1;
+  const long ncell = (long)g.nmb*g.nx1*g.nx2*g.nx3;
+  if (g.three_d && (tf_env == 1 || (tf_env != 0 && ncell <= (long)AKMI_SMALL_FACE_SWEEPS))) {
+    if (rc == AKMI_COMPLETE) rc = launch_sweep<1, MHD, false>(g, sc, a2, st);
+    if (rc == AKMI_COMPLETE) rc = launch_sweep<2, MHD, false>(g, sc, a3, st);
+    return rc;
+  }
+#endif
   if (rc == AKMI_COMPLETE && g.multi_d) rc = launch_sweep_update<1, MHD, 2, false>(g, sc, a2, u, st);
   if (rc == AKMI_COMPLETE && g.three_d) rc = launch_sweep_update<2, MHD, 2, false>(g, sc, a3, u, st);
   return rc;

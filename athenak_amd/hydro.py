@@ -94,6 +94,17 @@ class FluidBase:
                                 self.dx_dev.data_ptr(), e.gamma, e.dfloor, e.pfloor, e.tfloor,
                                 e.sfloor, e.sigma_max, e.iso_cs, 1 if e.is_ideal else 0)
         self.fused = pin.GetOrAddBoolean(blk, "fused_stage", True)
+        # small 3-D packs: the marching kernels of the fused stage are chains of dependent steps over a few hundred
+        # workgroups; the task-granular chain with one thread per face is faster there (MHD 64^3: 1 050 against 810
+        # Mcell-updates/s, 48^3: 610 / 406; equal at 96^3; profiles/r03_small_packs.txt).  Same bits either way.
+        # <hydro|mhd>/small_pack_tasks = false keeps the fused kernels (the parity tests do: their meshes are all small);
+        # AKMI_SMALL_PACK_TASKS=0: off.  (Not with passive scalars: the task path's sweeps do not carry them.)
+        # (read without adding it to the deck: the parameter dump of the bin/rst writers stays what the reference's is)
+        small_ok = pin.GetBoolean(blk, "small_pack_tasks") if pin.DoesParameterExist(blk, "small_pack_tasks") else True
+        if (small_ok and self.fused and indcs.nx3 > 1 and self.nscalars == 0
+                and os.environ.get("AKMI_SMALL_PACK_TASKS", "1") != "0"
+                and self.nmb*indcs.nx1*indcs.nx2*indcs.nx3 <= 600000):
+            self.fused = False
         # (the fused stage kernels cover both equations of state and carry passive scalars along; FOFC,
         # the diffusion hooks and refined meshes use the task-granular kernels, see below)
         # first-order flux correction, hydro.cpp:153-190 / mhd.cpp:199-235

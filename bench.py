@@ -198,7 +198,8 @@ def run_python_host(args, pin, blk, rank, world):
     from athenak_amd.main import Simulation
     sim = Simulation(pin, my_rank=rank, nranks=world)
     pm, drv = sim.pmesh, sim.pdriver
-    info = {"ncell_rank": pm.pmb_pack.nmb_thispack*pm.NumberOfMeshBlockCells(),
+    info = {"fused": bool(sim.phys.fused),
+            "ncell_rank": pm.pmb_pack.nmb_thispack*pm.NumberOfMeshBlockCells(),
             "ncell_total": pm.nmb_total*pm.NumberOfMeshBlockCells(), "nstage": drv.nexp_stages,
             "ng": pm.mb_indcs.ng}
     if world > 1:
@@ -426,7 +427,10 @@ def main():
                                       ("ideal hydro %s+HLLC" % rname), args.nx, args.nx*nblk[0],
                                       args.nx*nblk[1], args.nx*nblk[2],
                                       *[b*args.nx//(args.mb or args.nx) for b in nblk], py["ng"]),
-                      "path": "task-granular" if args.split else "fused stage",
+                      "path": "fused stage" if py["fused"] else
+                              ("task-granular" if args.split else
+                               "task-granular (chosen by the hosts for a small 3-D pack: one thread per face beats the "
+                               "marching kernels there)"),
                       "host": head["host"] + ("" if world == 1 or not cpp_ok else ", one child process per rank"),
                       "halo": halo},
            "roofline": roofline}

@@ -177,6 +177,7 @@ def make_pair(problem, n, dims, mb=None, inject=True, fused=None, native=False, 
     blk = "mhd" if pin.DoesBlockExist("mhd") else "hydro"
     if fused is not None:
         pin.blocks[blk]["fused_stage"] = "true" if fused else "false"
+        pin.blocks[blk]["small_pack_tasks"] = "false"     # the fixtures are small: keep the path the test asks for
     for name, val in (params or {}).items():       # parameters absent from the decks (e.g. nu_iso:
         pin.blocks[blk][name] = repr(val)           # their presence alone creates the diffusion objects)
     okw = oracle_kwargs(pin)

@@ -40,6 +40,7 @@ def _worker(rank, world, port, case, fused, outdir):
     pin = load_deck(deck, ov)
     blk = "mhd" if pin.DoesBlockExist("mhd") else "hydro"
     pin.blocks[blk]["fused_stage"] = "true" if fused else "false"
+    pin.blocks[blk]["small_pack_tasks"] = "false"      # small fixture: the path the test asks for
     okw = pu.oracle_kwargs(pin)
     if pin.DoesBlockExist("mesh_refinement"):     # the single-process oracle takes the tree of the whole mesh
         from athenak_amd.mesh import Mesh

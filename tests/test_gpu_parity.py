@@ -549,6 +549,7 @@ def _run_odd(case, fused):
     pin = load_deck(deck, ov)
     b = "mhd" if pin.DoesBlockExist("mhd") else "hydro"
     pin.blocks[b]["fused_stage"] = "true" if fused else "false"
+    pin.blocks[b]["small_pack_tasks"] = "false"      # small fixture: the path the test asks for
     osim = akref.Sim(**pu.oracle_kwargs(pin))
     osim.initialize()
     sim = Simulation(pin, initialize=False)

@@ -42,6 +42,7 @@ def _run(self_exchange, case, fused, out):
     pin = load_deck(deck, ov)
     blk = "mhd" if pin.DoesBlockExist("mhd") else "hydro"
     pin.blocks[blk]["fused_stage"] = "true" if fused else "false"
+    pin.blocks[blk]["small_pack_tasks"] = "false"         # small fixture: keep the fused phase-split path under test
     if self_exchange:
         idb = C.create_string_buffer(128)
         capi.check(L.akmi_comm_unique_id(idb), "comm_unique_id")

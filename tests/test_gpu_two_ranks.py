@@ -37,6 +37,7 @@ def _worker(rank, world, port, case, fused, outdir):
     pin = load_deck(deck, ov)
     blk = "mhd" if pin.DoesBlockExist("mhd") else "hydro"
     pin.blocks[blk]["fused_stage"] = "true" if fused else "false"
+    pin.blocks[blk]["small_pack_tasks"] = "false"      # small fixture: the path the test asks for
     sim = Simulation(pin, my_rank=rank, nranks=world, initialize=False)
     okw = pu.oracle_kwargs(pin)
     if sim.pmesh.multilevel:           # the single-process oracle takes the tree of the whole mesh
