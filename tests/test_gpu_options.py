@@ -69,3 +69,32 @@ def test_smr_option_does_not_change_a_bit(env):
     r = subprocess.run([sys.executable, "-c", SMR_SCRIPT], env=dict(os.environ, **env), capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+MARCH_SCRIPT = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import parity_util as pu
+import test_gpu_schemes as sc
+for case in sc.MULTI_D:
+    problem, n, dims, mb, cycles, kw = case
+    if dims != 3:
+        continue
+    for native in (False, True):
+        r = pu.compare_run(problem, n, dims, mb, cycles, fused=False, native=native, **kw)
+        assert r["bitwise_equal"] and r["cycles"] == cycles, (case, native, r)
+for n, mb in ((32, 32), (32, 16), (40, 20)):
+    for problem in ("orszag_tang", "sod"):
+        r = pu.compare_run(problem, n=n, dims=3, mb=mb, cycles=3, fused=False)
+        assert r["bitwise_equal"], (problem, n, mb, r)
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+
+
+def test_storing_marches_on_small_packs():
+    """akmi_*_fluxes run their x2/x3 sweeps as one thread per face for packs up to 0.7 M cells -- every fixture of
+    the suite -- and as marches that store their fluxes above.  AKMI_FACE_SWEEPS=0 puts the marches back: the 3-D
+    task-granular cases of the scheme matrix through both hosts, bit-identical to the oracle."""
+    r = subprocess.run([sys.executable, "-c", MARCH_SCRIPT], env=dict(os.environ, AKMI_FACE_SWEEPS="0"),
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
