@@ -248,3 +248,43 @@ def test_boundary_operators_on_random_data(mesh):
     for q, (x, y) in enumerate(zip((de.x1e, de.x2e, de.x3e), e)):
         same(x, y, "emf_exchange e%d" % (q + 1))
     L.akref_smr_destroy(h)
+
+
+@pytest.mark.parametrize("mesh", ["3d", "3d_3lev_ng4", "2d"])
+def test_work_lists_hold_exactly_the_pairs_their_kernels_accept(mesh):
+    """akmi_smr_build_lists (round 3): each list must contain every (block, slot) pair the kernels launched over it
+    would accept -- a missing pair would silently skip work -- and nothing but pairs of valid slots.  Recomputed here
+    from the neighbour table with the predicates written out again."""
+    import torch
+    pm, smr, L, h, keep = _setup(*OPS_MESHES[mesh], nvar=5)
+    assert smr.smr_c.lists, "the host did not build work lists"
+    nmb = pm.nmb_total
+    ng = smr.t_nghbr.cpu().numpy().reshape(nmb, 56, 3)
+    lev = smr.t_lev.cpu().numpy()
+    needs = smr.t_needs.cpu().numpy()
+    lists = smr.t_lists.cpu().numpy().reshape(6, nmb*56, 2)
+    cnt = [int(smr.smr_c.list_cnt[q]) for q in range(6)]
+    nn = smr.nnghbr
+    want = [set() for _ in range(6)]
+    for m in range(nmb):
+        for n in range(nn):
+            gid, nl = int(ng[m, n, 0]), int(ng[m, n, 1])
+            ml = int(lev[m])
+            if gid >= 0:
+                want[0].add((m, n))
+                if not (smr.direct_same and nl == ml and gid < nmb):
+                    want[1].add((m, n))
+                if nl < ml:
+                    want[2].add((m, n))
+                if nl > ml:
+                    want[3].add((m, n))
+                if nl == ml and needs[m]:
+                    want[4].add((m, n))
+            if n in (0, 4, 8, 12, 24, 28) or (16 <= n < 24 and n % 2 == 0) or (32 <= n < 48 and n % 2 == 0):
+                want[5].add((m, n))
+    for q in range(6):
+        got = [tuple(int(x) for x in lists[q, e]) for e in range(cnt[q])]
+        assert len(got) == len(set(got)), "list %d repeats a pair" % q
+        assert set(got) == want[q], (q, len(got), len(want[q]))
+    assert cnt[2] > 0 and cnt[3] > 0                  # the meshes do have level boundaries
+    L.akref_smr_destroy(h)
