@@ -1783,7 +1783,7 @@ static int launch_sweep_update(const Geo &g, const Scheme &sc, const SweepArgs &
 #define AKMI_X12S_EO2 1
 #endif
 #ifndef AKMI_X12S_ULOAD
-#define AKMI_X12S_ULOAD 1      // 1: the x2 loads of a step in one group after the x1 solve, 2: at the top of the step
+#define AKMI_X12S_ULOAD 3      // 1: the x2 loads of a step in one group after the x1 solve, 2: at the top of the step, 3: + the two operands the x1 part needs first fetched one step ahead (1176 -> 1150 -> 1134-1144 us, profiles/r03_ab7.txt)
 #endif
 template <int RS>
 __global__ void __launch_bounds__(SX*SY, AKMI_X12S_WAVES)
