@@ -1,7 +1,12 @@
 #!/usr/bin/env python
 """bench.py -- Mcell-updates/s of the MeshBlock finite-volume update on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one rank per GPU.  Started by a launcher (`python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) the process is one of the
+ranks; started plain (`python3 bench.py --gpus N`, no WORLD_SIZE) it starts the N ranks itself through
+torch.distributed.run on 127.0.0.1 and passes rank 0's JSON line and the exit status through.
 
 Workload (BASELINE.json configs[2], the config the metric is quoted on): 3-D Orszag-Tang,
 256^3 cells per GPU, ideal MHD, PLM + HLLD + CT, RK2, cfl 0.3, one MeshBlock (pack) per GPU;
@@ -191,48 +196,68 @@ def cpu_baseline(args, blk):
                           args.problem, n, rec, "; ".join(results), nsee, ("%g CPUs" % quota) if quota else "unlimited")}
 
 
-def run_python_host(args, pin, blk, rank, world):
-    """W warm-up + K timed cycles through the Python host (athenak_amd.main); the stage launch group
-    (akmi_*_stage_phase) is bracketed by HIP event pairs INSIDE the timed loop"""
-    import torch
-    from athenak_amd.main import Simulation
-    sim = Simulation(pin, my_rank=rank, nranks=world)
-    pm, drv = sim.pmesh, sim.pdriver
-    info = {"fused": bool(sim.phys.fused),
-            "ncell_rank": pm.pmb_pack.nmb_thispack*pm.NumberOfMeshBlockCells(),
-            "ncell_total": pm.nmb_total*pm.NumberOfMeshBlockCells(), "nstage": drv.nexp_stages,
-            "ng": pm.mb_indcs.ng}
-    if world > 1:
-        import torch.distributed as dist
+class PythonHost:
+    """the Python host (athenak_amd.main) in three steps -- build, W warm-up cycles, K timed cycles -- so that at
+    N > 1, where the C++ host is measured first, it can stop after the warm-up once it has confirmed that result;
+    the stage launch group (akmi_*_stage_phase) is bracketed by HIP event pairs INSIDE the timed loop"""
 
-    def barrier():
+    def __init__(self, args, pin, rank, world):
+        from athenak_amd.main import Simulation
+        self.args, self.world = args, world
+        self.sim = Simulation(pin, my_rank=rank, nranks=world)
+        pm, drv = self.sim.pmesh, self.sim.pdriver
+        self.info = {"fused": bool(self.sim.phys.fused),
+                     "ncell_rank": pm.pmb_pack.nmb_thispack*pm.NumberOfMeshBlockCells(),
+                     "ncell_total": pm.nmb_total*pm.NumberOfMeshBlockCells(), "nstage": drv.nexp_stages,
+                     "ng": pm.mb_indcs.ng,
+                     "host": "Python (athenak_amd.main)" + ("" if world == 1 else
+                                                            ", halos by torch.distributed batch_isend_irecv")}
+
+    def barrier(self):
+        import torch
         torch.cuda.synchronize()
-        if world > 1:
+        if self.world > 1:
+            import torch.distributed as dist
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        drv._cycle(pm)
-    sim.phys.stage_events = []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        drv._cycle(pm)
-    barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64,
-                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    evs, sim.phys.stage_events = sim.phys.stage_events, None
-    group_ms = sum(a.elapsed_time(b) for a, b in evs)
-    info.update(host="Python (athenak_amd.main)" + ("" if world == 1 else ", halos by torch.distributed batch_isend_irecv"),
-                el=el, steps=args.steps, value=info["ncell_total"]*args.steps/el/1e6, ms_per_step=el/args.steps*1e3,
-                group_ms=group_ms, group_calls=len(evs), time=float(pm.time), dt=float(pm.dt), ncycle=int(pm.ncycle))
-    del sim
-    torch.cuda.empty_cache()
-    return info
+    def warm(self):
+        """W untimed cycles; returns (time, dt) there"""
+        pm, drv = self.sim.pmesh, self.sim.pdriver
+        for _ in range(self.args.warmup):
+            drv._cycle(pm)
+        self.barrier()
+        return float(pm.time), float(pm.dt)
+
+    def timed(self):
+        import torch
+        sim, args = self.sim, self.args
+        pm, drv = sim.pmesh, sim.pdriver
+        sim.phys.stage_events = []
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            drv._cycle(pm)
+        self.barrier()
+        el = time.perf_counter() - t0
+        if self.world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([el], dtype=torch.float64,
+                             device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        evs, sim.phys.stage_events = sim.phys.stage_events, None
+        group_ms = sum(a.elapsed_time(b) for a, b in evs)
+        info = self.info
+        info.update(el=el, steps=args.steps, value=info["ncell_total"]*args.steps/el/1e6,
+                    ms_per_step=el/args.steps*1e3, group_ms=group_ms, group_calls=len(evs), time=float(pm.time),
+                    dt=float(pm.dt), ncycle=int(pm.ncycle))
+        return info
+
+    def close(self):
+        import torch
+        self.sim = None
+        torch.cuda.empty_cache()
 
 
 def run_cpp_host(args, pin):
@@ -281,46 +306,74 @@ def valu_floor(blk, nx, plain):
                 os.path.basename(f), t.get("tag", ""))}
 
 
+def self_launch(args):
+    """`python3 bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks (one per GPU) through
+    torch.distributed.run on the loopback address; rank 0's JSON line goes to our stdout, the launcher's exit
+    status becomes ours"""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.native_child:
+        self_launch(args)
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not args.native_child:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # developer knobs for a functional check of the N>1 path on a 1-GPU box (RCCL refuses two
-        # ranks on one device): AKMI_SHARE_GPU=1 puts every rank on cuda:0, AKMI_DIST_BACKEND=gloo
-        # moves the halos through pinned host buffers.  Numbers from such a run mean nothing.
-        backend = os.environ.get("AKMI_DIST_BACKEND", "nccl")
-        if os.environ.get("AKMI_SHARE_GPU", "0") == "1":
-            local = 0
-        torch.cuda.set_device(local)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-    else:
-        torch.cuda.set_device(0 if os.environ.get("AKMI_SHARE_GPU", "0") == "1" else local)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (start it plain, or with torch.distributed.run "
+                 "--nproc-per-node %d)" % (args.gpus, world, args.gpus))
+    # developer knobs for a functional check of the N>1 path on a 1-GPU box (RCCL refuses two ranks on one
+    # device): AKMI_SHARE_GPU=1 puts every rank on cuda:0, AKMI_DIST_BACKEND=gloo moves the halos through pinned
+    # host buffers.  Numbers from such a run mean nothing.
+    backend = os.environ.get("AKMI_DIST_BACKEND", "nccl")
+    if os.environ.get("AKMI_SHARE_GPU", "0") == "1":
+        local = 0
+    torch.cuda.set_device(local)
 
     nblk = block_grid(world)
     pin, blk = make_pin(args, nblk)
     if args.native_child:
         return native_child(args, pin, rank, world)
     if args.native:
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(backend)
         return main_native(args, pin, blk, nblk, rank, world)
 
-    # ---- both hosts over the same W warm-up + K timed cycles -------------------------------------------
+    # ---- the two hosts ------------------------------------------------------------------------------------
     # The C++ host is the path north_star names ("host code stays C++ ... RCCL"): it is the headline whenever it
-    # completed the K cycles and ended at the same (time, dt) as the Python host -- a wrong or skipped halo
-    # exchange cannot win the line by being faster.  The Python host is reported beside it (other_host); it is
-    # the headline only when the C++ host gave no result or a different one, and the line says why.
-    py = run_python_host(args, pin, blk, rank, world)
+    # completed the K cycles and its (time, dt) agree with the Python host's at the same cycle -- a wrong or skipped
+    # halo exchange cannot win the line by being faster.
+    #   N = 1: both hosts run the same W + K cycles in this process; the Python host is reported as other_host.
+    #   N > 1: the C++ host + RCCL is measured FIRST (one child process per rank, so that neither an abort nor a
+    #          stall inside a transport that could only be exercised to self where it was built costs the bench);
+    #          the Python host then runs its W warm-up cycles, and if the C++ host stood at the same (time, dt)
+    #          after ITS warm-up the line is the C++ host's and the Python host stops there.  Only when the C++
+    #          host gave nothing, or something else, does the Python host run the K timed cycles (the fallback).
     chk = os.environ.get("AKMI_BENCH_NATIVE_CHECK", "1")
-    cpp, why = None, None
+    cpp, why, cpp_ok = None, None, False
     if world == 1:
+        host = PythonHost(args, pin, rank, world)
+        host.warm()
+        py = host.timed()
+        host.close()
         if chk != "0":
             try:
                 cpp = run_cpp_host(args, pin)
@@ -328,29 +381,64 @@ def main():
                 why = "C++ host failed: %r" % (e,)
         else:
             why = "C++ host switched off (AKMI_BENCH_NATIVE_CHECK=0)"
+        if cpp is not None:
+            if cpp.get("steps") != args.steps:
+                why = "C++ host completed %s of %d cycles" % (cpp.get("steps"), args.steps)
+            elif cpp["time"] != py["time"] or cpp["dt"] != py["dt"]:
+                why = ("C++ host ended at (t, dt) = (%r, %r), the Python host at (%r, %r): not accepted"
+                       % (cpp["time"], cpp["dt"], py["time"], py["dt"]))
+            else:
+                cpp_ok = True
+        check = "both hosts ended at t = %r, dt = %r after %d + %d cycles" % (
+            py["time"], py["dt"], args.warmup, args.steps)
     else:
-        nccl = dist.get_backend() == "nccl"
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if (backend == "nccl" and chk != "0") or chk == "force":
+            cpp = native_check(args, rank, world)          # rank 0 gets the result
+            if cpp is None and rank == 0:
+                why = "C++ host gave no result (see stderr)"
+        elif rank == 0:
+            why = "C++ host not run (%s)" % ("switched off" if chk == "0" else "backend is not RCCL")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+        host = PythonHost(args, pin, rank, world)
+        t_w = host.warm()
+        verdict = [None]
+        if rank == 0:
+            if cpp is not None and cpp.get("steps") != args.steps:
+                why, cpp = "C++ host completed %s of %d cycles" % (cpp.get("steps"), args.steps), None
+            if cpp is not None and args.warmup > 0:
+                if (cpp.get("time_w"), cpp.get("dt_w")) == t_w:
+                    verdict[0] = "accept"
+                else:
+                    why = ("C++ host stood at (t, dt) = (%r, %r) after the %d warm-up cycles, the Python host at "
+                           "(%r, %r): not accepted" % (cpp.get("time_w"), cpp.get("dt_w"), args.warmup, *t_w))
+                    cpp = None
+        dist.broadcast_object_list(verdict, src=0)
+        if verdict[0] == "accept":
+            py, cpp_ok = dict(host.info), True
+            check = "both hosts stood at t = %r, dt = %r after the %d warm-up cycles" % (*t_w, args.warmup)
+        else:
+            py = host.timed()
+            if rank == 0 and cpp is not None:           # no warm-up to compare at: compare at the end
+                if cpp["time"] == py["time"] and cpp["dt"] == py["dt"]:
+                    cpp_ok = True
+                    check = "both hosts ended at t = %r, dt = %r after %d + %d cycles" % (
+                        py["time"], py["dt"], args.warmup, args.steps)
+                else:
+                    why = ("C++ host ended at (t, dt) = (%r, %r), the Python host at (%r, %r): not accepted"
+                           % (cpp["time"], cpp["dt"], py["time"], py["dt"]))
+        host.close()
         dist.barrier()
         dist.destroy_process_group()
-        if (nccl and chk != "0") or chk == "force":
-            cpp = native_check(args, rank, world)
-            if cpp is None:
-                why = "C++ host gave no result (see stderr)"
-        else:
-            why = "C++ host not run (%s)" % ("switched off" if chk == "0" else "backend is not RCCL")
     if rank != 0:
         return
-    if cpp is not None:
-        if cpp.get("steps") != args.steps:
-            why, cpp_ok = "C++ host completed %s of %d cycles" % (cpp.get("steps"), args.steps), False
-        elif cpp["time"] != py["time"] or cpp["dt"] != py["dt"]:
-            why, cpp_ok = ("C++ host ended at (t, dt) = (%r, %r), the Python host at (%r, %r): not accepted"
-                           % (cpp["time"], cpp["dt"], py["time"], py["dt"])), False
-        else:
-            cpp_ok = True
-    else:
-        cpp_ok = False
     head, other = (cpp, py) if cpp_ok else (py, cpp)
+    if "value" not in (other or {}):
+        other = None                                       # the Python host stopped after confirming the C++ host
     for k in ("ncell_rank", "ncell_total", "nstage", "ng"):
         head.setdefault(k, py[k])
 
@@ -368,9 +456,12 @@ def main():
                  "cells + CFL scan), i.e. the stage without ghost fill and boundary conditions" % (
                      blk, " + CornerE + CT" if blk == "mhd" else "", blk)) if world == 1 else \
                 "akmi_%s_stage_phase x3 of a rank (the halo messages travel between the phases)" % blk
-    else:                                                     # a child of an older build: whole stage only
+    else:
+        # no launch-group events: the hosts took the task-granular chain (small 3-D pack, --split) -- the roofline is
+        # then the whole stage of a rank (every task, ghost fill and BCs included), and the fused kernels' VALU floor
+        # does not apply
         tS, rest_ms = head["ms_per_step"]*1e-3/py["nstage"], None
-        kname = "whole stage of a rank incl. halo exchange"
+        kname = "whole stage of a rank (task-granular chain: one kernel per reference task, incl. ghost exchange and BCs)"
     ach = stage_bytes*ncell_rank/tS/1e9
     traffic, tsrc = None, None
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json" if blk == "mhd" else
@@ -402,7 +493,7 @@ def main():
                 "timing": "HIP event pairs on the launch stream around every call of the group inside the timed "
                           "loop of the headline host (%d calls)" % (head.get("group_calls") or 0),
                 "halo_bcs_shell_c2p_ms": None if rest_ms is None else round(rest_ms, 4),
-                "valu_floor": valu_floor(blk, args.nx, plain),
+                "valu_floor": valu_floor(blk, args.nx, plain) if head.get("group_calls") else None,
                 "whole_stage": {"achieved": round(whole, 1), "frac": round(whole/HBM_PEAK_GBS, 4)},
                 "note": "two roofs: HBM (algorithmic bytes / 8 TB/s) and fp64 issue (valu_floor.ms); the measured "
                         "traffic is ~2.3x the algorithmic bytes (intermediates between the four kernels of the MHD "
@@ -437,8 +528,7 @@ def main():
     if why:
         out["config"]["host_note"] = why
     if cpp_ok:
-        out["config"]["host_check"] = "both hosts ended at t = %r, dt = %r after %d + %d cycles" % (
-            py["time"], py["dt"], args.warmup, args.steps)
+        out["config"]["host_check"] = check
     out["other_host"] = None if other is None else {
         "host": other["host"], "value": round(other["value"], 2), "ms_per_step": round(other["ms_per_step"], 4),
         "stage_group_ms": round(other["group_ms"]/nst, 4) if other.get("group_calls") else None}
@@ -464,6 +554,8 @@ def native_check(args, rank, world):
            "--warmup", str(args.warmup)]
     if args.mb:
         cmd += ["--mb", str(args.mb)]
+    if args.split:
+        cmd += ["--split"]
     if args.recon:
         cmd += ["--recon", args.recon]
     if args.ng:
@@ -507,6 +599,7 @@ def native_child(args, pin, rank, world):
         return v[0]
 
     sim.Execute(max_cycles=args.warmup)
+    time_w, dt_w = sim.time, sim.dt               # compared with the Python host's after the same cycles
     capi.check(L.akmi_sim_profile(sim.h, 1), "sim_profile")
     torch.cuda.synchronize()
     allmin(0.0)                                   # barrier
@@ -523,7 +616,8 @@ def native_child(args, pin, rank, world):
         sys.stderr.flush()
         with open(args.native_child, "w") as f:
             json.dump({"value": ncell_total*n/el/1e6, "ms_per_step": el/n*1e3, "steps": n, "el": el,
-                       "time": sim.time, "dt": sim.dt, "group_ms": ms.value, "group_calls": calls.value,
+                       "time": sim.time, "dt": sim.dt, "time_w": time_w, "dt_w": dt_w, "group_ms": ms.value,
+                       "group_calls": calls.value,
                        "host": "C++ (akmi_sim_*: Mesh, TaskList, Driver in C++) + RCCL called directly"}, f)
     sim.close()
     native.finalize_comm()

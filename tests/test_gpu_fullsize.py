@@ -1,9 +1,14 @@
-"""gpu: BASELINE.json's FULL sizes (C2 hydro 128^3, C3 MHD 256^3), where the CPU oracle is too slow
-to run beside the HIP path.  Parity is carried to these sizes by properties that do not depend on
-the size: the fused stage kernels and the task-granular kernels (each bit-identical to the oracle at
-fixture size) must agree bit for bit; the result must not depend on the MeshBlock decomposition
-(one 256^3 block vs eight 128^3 blocks exchanging ghost zones); mass, momentum and total energy of
-a periodic box are conserved to round-off; div B stays at round-off."""
+"""gpu: BASELINE.json's FULL sizes (C2 hydro 128^3, C3 MHD 256^3).
+
+Two kinds of evidence.  (1) The CPU oracle itself at full size: two cycles of C3 (Orszag-Tang 256^3, fused
+stage, through the Python host and through the C++ host) and of C2 (Sod 128^3) on identical injected initial data,
+the oracle on all the cores the box grants -- bit equality of the conserved variables and face fields and the same
+(time, dt).  The kernels pick other chunk lengths and tile shapes at these extents (march_len, ct_tile) than at
+the fixture sizes, so this closes the gap a common-mode error of both HIP paths at large extents would pass
+through.  (2) Properties that do not depend on the size, over more cycles than the oracle affords: the fused
+stage kernels and the task-granular kernels must agree bit for bit; the result must not depend on the MeshBlock
+decomposition (one 256^3 block vs eight 128^3 blocks exchanging ghost zones); mass, momentum and total energy
+of a periodic box are conserved to round-off; div B stays at round-off."""
 import numpy as np
 import pytest
 
@@ -53,6 +58,51 @@ def _divb(sim):
          (ph.b0.x2f[:, k, j1, i] - ph.b0.x2f[:, k, j, i])/dx[1] +
          (ph.b0.x3f[:, k1, j, i] - ph.b0.x3f[:, k, j, i])/dx[2])
     return float(d.abs().max())
+
+
+def _oracle_threads():
+    """all the CPUs the container may use (cgroup quota), for the oracle's OpenMP loops"""
+    import os
+    n = len(os.sched_getaffinity(0))
+    try:
+        t = open("/sys/fs/cgroup/cpu.max").read().split()
+        if t[0] != "max":
+            n = max(1, min(n, int(round(int(t[0])/int(t[1])))))
+    except (OSError, ValueError, IndexError):
+        pass
+    pu.akref.lib().akref_set_threads(n)
+    return n
+
+
+@pytest.mark.parametrize("native", [False, True], ids=["py", "cpp"])
+def test_c3_mhd_256_against_the_oracle(native):
+    """C3 at FULL size against the CPU oracle: Orszag-Tang 256^3, PLM+HLLD+CT, RK2, cfl 0.3, one MeshBlock, fused
+    stage, 2 cycles (4 stages, the first of each cycle out of place), identical injected initial data"""
+    import gc
+    import torch
+    _oracle_threads()
+    try:
+        r = pu.compare_run("orszag_tang", 256, 3, 256, cycles=2, fused=True, native=native, cfl=0.3)
+    finally:
+        pu.akref.lib().akref_set_threads(1)
+    assert r["cycles"] == 2
+    assert r["time"][0] == r["time"][1] and r["dt"][0] == r["dt"][1], (r["time"], r["dt"])
+    assert r["bitwise_equal"], r["diffs"]
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def test_c2_hydro_128_against_the_oracle():
+    """C2 at FULL size against the CPU oracle: Sod 128^3 single MeshBlock, PLM+HLLC, RK2, cfl 0.3 (outflow in
+    x1), the one-kernel hydro stage, 2 cycles"""
+    _oracle_threads()
+    try:
+        r = pu.compare_run("sod", 128, 3, 128, cycles=2, fused=True, cfl=0.3)
+    finally:
+        pu.akref.lib().akref_set_threads(1)
+    assert r["cycles"] == 2
+    assert r["time"][0] == r["time"][1] and r["dt"][0] == r["dt"][1], (r["time"], r["dt"])
+    assert r["bitwise_equal"], r["diffs"]
 
 
 def test_c3_mhd_256_fused_equals_task_path_and_conserves():
