@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cctype>
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
@@ -395,7 +396,13 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
     eta_ad = pin->GetOrAddReal(blk, "eta_ad", 0.0);
     dtmin_cond.Realloc(1);                                   // scratch double of the cell reductions
   }
-  fused = pin->GetOrAddBoolean(blk, "fused_stage", true);
+  // <hydro|mhd>/fused_stage = true | false | auto (default): an explicit true / false is kept as it is
+  std::string fs = pin->GetOrAddString(blk, "fused_stage", "auto");
+  for (char &c : fs) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+  if (fs != "auto" && fs != "true" && fs != "false" && fs != "1" && fs != "0")
+    AKMI_FATAL("<" + blk + ">/fused_stage = " + fs + ": true, false or auto");
+  const bool fused_given = fs != "auto";
+  fused = !(fs == "false" || fs == "0");
   // small 3-D packs: the task-granular chain (one thread per face) beats the marching kernels of the fused stage
   // (MHD 64^3: 1 050 against 810 Mcell-updates/s, equal at 96^3; profiles/r03_small_packs.txt); same bits either way.
   // <hydro|mhd>/small_pack_tasks = false keeps the fused kernels.  AKMI_SMALL_PACK_TASKS=0: off
@@ -404,7 +411,8 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
     const bool small_ok = pin->DoesParameterExist(blk, "small_pack_tasks") ? pin->GetBoolean(blk, "small_pack_tasks") : true;
     const char *sp = std::getenv("AKMI_SMALL_PACK_TASKS");
     const long ncell_pack = static_cast<long>(pp->nmb_thispack)*ind.nx1*ind.nx2*ind.nx3;
-    if (small_ok && fused && ind.nx3 > 1 && nscalars == 0 && !(sp && std::atoi(sp) == 0) && ncell_pack <= 600000)
+    if (small_ok && !fused_given && fused && ind.nx3 > 1 && nscalars == 0 && !(sp && std::atoi(sp) == 0) &&
+        ncell_pack <= AKMI_SMALL_PACK_CELLS)
       fused = false;                   // (not with passive scalars: the task path's sweeps do not carry them)
   }
   // the fused stage kernels cover both equations of state and carry passive scalars along; extra fluxes
@@ -436,6 +444,11 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
   }
   if (!multilevel && (pp->pmesh->nranks > 1 || SelfExchange()))
     pbval = new MeshBoundaryValues(pp, &pack_c, nvars, blk == "mhd");
+  // <mesh_refinement>/prolong_primitives converts with SingleC2P_IdealHyd / _IdealMHD whatever the EOS of the run is
+  // (prolong_prims.cpp:35-186); offered for the ideal gas only -- said at construction, not by the first Prolongate
+  if (pp->pmesh->multilevel && pp->pmesh->prolong_prims && !e.is_ideal)
+    AKMI_FATAL("<mesh_refinement>/prolong_primitives = true needs the ideal-gas EOS (<" + blk + ">/eos = " +
+               pin->GetString(blk, "eos") + ")");
   use_fofc = pin->GetOrAddBoolean(blk, "fofc", false);     // hydro.cpp:153-190, mhd.cpp:199-235
   if (use_fofc) {
     const int need = recon_method == AKMI_RECON_PLM ? 3 : (recon_method >= AKMI_RECON_PPM4 ? 4 : 2);
@@ -839,6 +852,9 @@ void FluidBase::RestoreRegisters() {
   HIPCHK(hipMemcpyAsync(u1.p, u0.p, u0.n*sizeof(Real), hipMemcpyDeviceToDevice, stream));
   SwapArr(u0, u1);
   u_swapped = false;
+  // akmi_sim_execute returns with every array complete, as it did when each cycle ended in the dt read-back: a
+  // caller may read the akmi_sim_array pointers on a stream of its own
+  HIPCHK(hipStreamSynchronize(stream));
 }
 
 namespace mhd {
@@ -851,6 +867,7 @@ void MHD::RestoreRegisters() {
     SwapArr(*cur[q], *old[q]);
   }
   b_swapped = false;
+  HIPCHK(hipStreamSynchronize(stream));
 }
 }  // namespace mhd
 

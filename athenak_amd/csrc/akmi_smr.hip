@@ -335,6 +335,9 @@ k_smr_c2p_coarse(SGeo s, Tab t, Eos eos, int nvar, int mhd, double *__restrict__
   int m, n, v; wg_slot(t, L_COARSER, 1, m, n, v); (void)v;
   if (NGID(t, m, n) < 0 || !(NLEV(t, m, n) < t.lev[m])) return;
   Bx b = box_of(t.cc, T_RECV, K_PROL, n, 0);
+  // (widened by one cell, as the reference does: the boxes of different slots of a block then overlap, and several
+  //  workgroups convert the same coarse cells concurrently -- every one of them writes the SAME values (cw, and cu
+  //  where a floor or a negative scalar was reset: functions of that cell's cu alone), so the race is benign)
   b.il -= 1; b.iu += 1;
   if (s.multi_d) { b.jl -= 1; b.ju += 1; }
   if (s.three_d) { b.kl -= 1; b.ku += 1; }

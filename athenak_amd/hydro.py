@@ -93,17 +93,25 @@ class FluidBase:
         self.pack_c = capi.Pack(self.nmb, self.nvars, indcs.nx1, indcs.nx2, indcs.nx3, indcs.ng,
                                 self.dx_dev.data_ptr(), e.gamma, e.dfloor, e.pfloor, e.tfloor,
                                 e.sfloor, e.sigma_max, e.iso_cs, 1 if e.is_ideal else 0)
-        self.fused = pin.GetOrAddBoolean(blk, "fused_stage", True)
+        # <hydro|mhd>/fused_stage = true | false | auto (default): an explicit true / false is kept as it is
+        fs = pin.GetOrAddString(blk, "fused_stage", "auto").lower()
+        if fs not in ("auto", "true", "false", "1", "0"):
+            raise RuntimeError("### FATAL ERROR <%s>/fused_stage = %s: true, false or auto" % (blk, fs))
+        fused_given = fs != "auto"
+        self.fused = fs not in ("false", "0")
         # small 3-D packs: the marching kernels of the fused stage are chains of dependent steps over a few hundred
         # workgroups; the task-granular chain with one thread per face is faster there (MHD 64^3: 1 050 against 810
         # Mcell-updates/s, 48^3: 610 / 406; equal at 96^3; profiles/r03_small_packs.txt).  Same bits either way.
         # <hydro|mhd>/small_pack_tasks = false keeps the fused kernels (the parity tests do: their meshes are all small);
         # AKMI_SMALL_PACK_TASKS=0: off.  (Not with passive scalars: the task path's sweeps do not carry them.)
         # (read without adding it to the deck: the parameter dump of the bin/rst writers stays what the reference's is)
+        # The switch applies only when the deck says <hydro|mhd>/fused_stage = auto (or nothing); the threshold is the one
+        # constant AKMI_SMALL_PACK_CELLS of include/akmi.h (capi.SMALL_PACK_CELLS), shared with the C++ host and with the
+        # library's choice of thread-per-face sweeps on the task path.
         small_ok = pin.GetBoolean(blk, "small_pack_tasks") if pin.DoesParameterExist(blk, "small_pack_tasks") else True
-        if (small_ok and self.fused and indcs.nx3 > 1 and self.nscalars == 0
+        if (small_ok and not fused_given and self.fused and indcs.nx3 > 1 and self.nscalars == 0
                 and os.environ.get("AKMI_SMALL_PACK_TASKS", "1") != "0"
-                and self.nmb*indcs.nx1*indcs.nx2*indcs.nx3 <= 600000):
+                and self.nmb*indcs.nx1*indcs.nx2*indcs.nx3 <= capi.SMALL_PACK_CELLS):
             self.fused = False
         # (the fused stage kernels cover both equations of state and carry passive scalars along; FOFC,
         # the diffusion hooks and refined meshes use the task-granular kernels, see below)
@@ -121,6 +129,12 @@ class FluidBase:
             n3, n2, n1 = indcs.ncells
             self.fofc = torch.zeros((self.nmb, n3, n2, n1), dtype=torch.uint8, device=device)
             self.nfofc = torch.zeros(1, dtype=torch.int32, device=device)   # EventCounters::nfofc
+        # <mesh_refinement>/prolong_primitives converts with SingleC2P_IdealHyd / _IdealMHD whatever the EOS of the run
+        # is (prolong_prims.cpp:35-186); this path offers it for the ideal gas only -- said here, when the physics
+        # module is built, not by the first Prolongate of the run (akmi_smr_c2p_coarse would refuse there)
+        if pm.multilevel and getattr(pm, "prolong_prims", False) and not e.is_ideal:
+            raise RuntimeError("### FATAL ERROR <mesh_refinement>/prolong_primitives = true needs the ideal-gas EOS "
+                               "(<%s>/eos = %s)" % (blk, pin.GetString(blk, "eos")))
         # viscosity / conduction / resistivity objects (hydro.cpp:77-98, mhd.cpp:104-130)
         from .diffusion import make_diffusion
         if make_diffusion(self, pin, blk):

@@ -67,8 +67,16 @@ typedef struct akmi_pack {
                           * no energy variable, src/eos/isothermal_hyd.cpp:20-23)        */
 } akmi_pack;
 
+/* Packs of up to this many cells count as "small" everywhere: both hosts run the task-granular chain instead of the
+ * fused stage for such 3-D packs (unless the deck sets <hydro|mhd>/fused_stage itself or small_pack_tasks = false),
+ * and the flux entries akmi_*_fluxes take one thread per face instead of the marching kernels. */
+#define AKMI_SMALL_PACK_CELLS 600000
+
 const char *akmi_last_error(void);
 int akmi_version(void);
+/* "production", or "experiments: ..." for a library built with -DAKMI_EXPERIMENTS (timing experiments that change
+ * results; __graft_entry__.build() never defines it and tests/test_capi_symbols.py refuses such a library) */
+const char *akmi_build_flags(void);
 
 /* ---- Hydro tasks ------------------------------------------------------------------ */
 /* Hydro::CopyCons (src/hydro/hydro_tasks.cpp:130-152): u1 <- u0 */

@@ -18,6 +18,9 @@ def _declared():
 def test_header_symbols_listed_in_binding():
     from athenak_amd import capi
     assert _declared() == sorted(capi.SYMBOLS)
+    # the one small-pack threshold both hosts and the library share
+    txt = open(os.path.join(ROOT, "include", "akmi.h")).read()
+    assert int(re.search(r"#define\s+AKMI_SMALL_PACK_CELLS\s+(\d+)", txt).group(1)) == capi.SMALL_PACK_CELLS
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"),
@@ -29,6 +32,9 @@ def test_library_builds_and_exports_all_symbols():
     for s in _declared():
         assert hasattr(lib, s), s
     assert lib.akmi_version() >= 100
+    # timing experiments that change results exist only behind -DAKMI_EXPERIMENTS; the library under test is not one
+    lib.akmi_build_flags.restype = ctypes.c_char_p
+    assert lib.akmi_build_flags() == b"production"
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

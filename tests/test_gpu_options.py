@@ -4,6 +4,8 @@ once per process, so every case runs in a process of its own and must be bit-ide
   AKMI_MERGE_C2P=0  c2p of the active cells inside the stage call + c2p of the ghost shell afterwards (the order a
                     rank with off-rank neighbours uses) instead of one conversion after the ghost fill
   AKMI_X12=0        x1 sweep and x2 march as two kernels
+  AKMI_M3CT=1       two-kernel pass A: k_sweep12s + k_march3ct (x3 flux, RK update, CornerE and CT in one k-march,
+                    the x3 face field of in-place stages read from the copy k_sweep12s leaves in the workspace)
 refined meshes:
   AKMI_SMR_SWEEP_UPDATE=1  Fluxes updates u0 in the sweeps, RKUpdate redoes the cells behind corrected faces
                            (akmi_mhd_fluxes_update / akmi_smr_save_update_cells / akmi_smr_redo_update)
@@ -27,18 +29,23 @@ SCRIPT = r"""
 import sys
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 import parity_util as pu
+# fused=True: the fixtures are small packs, which the hosts would otherwise hand to the task-granular chain
 for native in (False, True):
-    for n, mb in ((32, 32), (32, 16), (40, 20)):
-        r = pu.compare_run("orszag_tang", n=n, dims=3, mb=mb, cycles=3, native=native)
-        assert r["bitwise_equal"] and r["cycles"] == 3 and r["dt"][0] == r["dt"][1], (native, n, mb, r)
-r = pu.compare_run("sod", n=32, dims=3, mb=16, cycles=3)
+    for n, mb, kw in ((32, 32, {}), (32, 16, {}), (40, 20, {}), ((66, 34, 18), (66, 34, 18), {}),
+                      (32, 16, dict(integrator="rk3")), (24, 24, dict(integrator="rk1"))):
+        r = pu.compare_run("orszag_tang", n=n, dims=3, mb=mb, cycles=3, native=native, fused=True, **kw)
+        assert r["bitwise_equal"] and r["cycles"] == 3 and r["dt"][0] == r["dt"][1], (native, n, mb, kw, r)
+r = pu.compare_run("blast", 32, 3, 16, cycles=3, fused=True, recon="plm")
+assert r["bitwise_equal"], r
+r = pu.compare_run("sod", n=32, dims=3, mb=16, cycles=3, fused=True)
 assert r["bitwise_equal"], r
 print("ok")
 """ % (ROOT, os.path.join(ROOT, "tests"))
 
 
 @pytest.mark.parametrize("env", [{"AKMI_MFBITS": "1"}, {"AKMI_MERGE_C2P": "0"}, {"AKMI_X12": "0"},
-                                 {"AKMI_MFBITS": "1", "AKMI_MERGE_C2P": "0"}],
+                                 {"AKMI_MFBITS": "1", "AKMI_MERGE_C2P": "0"}, {"AKMI_M3CT": "1"},
+                                 {"AKMI_M3CT": "1", "AKMI_OUT_OF_PLACE": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
 def test_option_does_not_change_a_bit(env):
     r = subprocess.run([sys.executable, "-c", SCRIPT], env=dict(os.environ, **env), capture_output=True, text=True,
