@@ -2086,7 +2086,9 @@ static int launch_sweep_update(const Geo &g, const Scheme &sc, const SweepArgs &
 #ifndef AKMI_X12S_EO2
 #define AKMI_X12S_EO2 1
 #endif
-template <int RS>
+// SNAP: copy the x3 face field into the workspace on the way (UpdArgs::bz_snap; in-place stages followed by k_march3ct)
+// BITS: sign words instead of the two mass-flux arrays (MfBits)
+template <int RS, bool SNAP, bool BITS>
 __global__ void __launch_bounds__(SX*SY, AKMI_X12S_WAVES)
 k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
   constexpr int NV = 7, NW = 2, NT = SX*SY;
@@ -2174,8 +2176,8 @@ k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
     const double bx2 = ldu(bx2m, do_x2 ? foff2 : foff2 - fst28);
     // x3 face field of row jr on its way into the workspace (UpdArgs::bz_snap): face (k, jr, i) of the (N3+1, N2, N1)
     // array has the byte offset of cell (k, jr, i)
-    double bz_v = 0.0;
-    if (u.bz_snap) bz_v = ldu(u.bz_src + (size_t)m*(g.N3 + 1)*g.N2*g.N1, orow);
+    [[maybe_unused]] double bz_v = 0.0;
+    if constexpr (SNAP) bz_v = ldu(u.bz_src + (size_t)m*(g.N3 + 1)*g.N2*g.N1, orow);
     // ---- x1 face on the low side of cell (k, jr, i): the cell is W_(.,0) of the march
     double f1d, f1x, f1y, f1z, f1e, f1by, f1bz;
     double dF1[5];
@@ -2207,13 +2209,15 @@ k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
       dF1[2] = __shfl_down(f1y, 1, 64) - f1y;
       dF1[3] = __shfl_down(f1z, 1, 64) - f1z;
       dF1[4] = __shfl_down(f1e, 1, 64) - f1e;
-      if (u.mb.w1 && do_x1) {
-        const unsigned long long bits = __ballot(x1_ok && f1d >= 0.0);
-        if (lane == 0 && wv < u.mb.nw12) u.mb.w1[((size_t)m*u.mb.nj1 + (jr - u.mb.j1l))*u.mb.nw12 + wv] = bits;
+      if constexpr (BITS) {
+        if (do_x1) {
+          const unsigned long long bits = __ballot(x1_ok && f1d >= 0.0);
+          if (lane == 0 && wv < u.mb.nw12) u.mb.w1[((size_t)m*u.mb.nj1 + (jr - u.mb.j1l))*u.mb.nw12 + wv] = bits;
+        }
       }
       if (do_x1 && x1_ok) {
 #if !(AKMI_WHATIF & 4)
-        if (!u.mb.w1) stu(mf1, foff1, f1d);
+        if constexpr (!BITS) stu(mf1, foff1, f1d);
 #endif
         stu(a1.ey + (size_t)m*cs, orow, -f1by);
         stu(a1.ez + (size_t)m*cs, orow, f1bz);
@@ -2233,13 +2237,15 @@ k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
     }
     Cons1D f2 = riemann_mhd_e<RS, AKMI_X12S_EO2 != 0, AKMI_X12S_FM != 0>(eos, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1],
                                   R[2], R[3], R[4], R[5], R[6], bx2);
-    if (u.mb.w2 && do_x2 && (t < ml || s == shi)) {
-      const unsigned long long bits = __ballot(x2_ok && f2.d >= 0.0);
-      if (lane == 0 && wv < u.mb.nw12) u.mb.w2[((size_t)m*u.mb.nj2 + (s - u.mb.j2l))*u.mb.nw12 + wv] = bits;
+    if constexpr (BITS) {
+      if (do_x2 && (t < ml || s == shi)) {
+        const unsigned long long bits = __ballot(x2_ok && f2.d >= 0.0);
+        if (lane == 0 && wv < u.mb.nw12) u.mb.w2[((size_t)m*u.mb.nj2 + (s - u.mb.j2l))*u.mb.nw12 + wv] = bits;
+      }
     }
     if (do_x2 && x2_ok && (t < ml || s == shi)) {
 #if !(AKMI_WHATIF & 4)
-      if (!u.mb.w2) stu(mf2, foff2, f2.d);
+      if constexpr (!BITS) stu(mf2, foff2, f2.d);
 #endif
       stu(a2.ey + (size_t)m*cs, off, -f2.by);
       stu(a2.ez + (size_t)m*cs, off, f2.bz);
@@ -2264,7 +2270,9 @@ k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
         }
       }
     }
-    if (u.bz_snap && do_x1 && inner && k >= g.ks) stu(u.bz_snap + (size_t)m*(g.N3 + 1)*g.N2*g.N1, orow, bz_v);
+    if constexpr (SNAP) {
+      if (do_x1 && inner && k >= g.ks) stu(u.bz_snap + (size_t)m*(g.N3 + 1)*g.N2*g.N1, orow, bz_v);
+    }
 #pragma unroll
     for (int n = 0; n < 5; ++n) FP_(n) = fv[n];
     off += st8; foff2 += fst28; foff1 += fst18;
@@ -2285,7 +2293,9 @@ static int launch_sweep12s(const Geo &g, const Scheme &sc, const SweepArgs &a1, 
   dim3 grid(nb, cdiv(nc, ml), g.nmb), block(SX, SY);
   const int rs = sc.rsolver;
   if (sc.iso || sc.recon != 1 || rs != AKMI_RS_HLLD) { set_error("sweep12s: PLM + HLLD, ideal gas"); return AKMI_FAIL; }
-  k_sweep12s<3><<<grid, block, 0, st>>>(g, sc.eos, a1, a2, u, ml);
+  if (u.bz_snap) k_sweep12s<3, true, false><<<grid, block, 0, st>>>(g, sc.eos, a1, a2, u, ml);      // (never with sign words)
+  else if (u.mb.w1) k_sweep12s<3, false, true><<<grid, block, 0, st>>>(g, sc.eos, a1, a2, u, ml);
+  else k_sweep12s<3, false, false><<<grid, block, 0, st>>>(g, sc.eos, a1, a2, u, ml);
   AKMI_CHECK_LAUNCH("sweep12s");
   return AKMI_COMPLETE;
 }
