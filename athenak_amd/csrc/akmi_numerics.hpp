@@ -1,10 +1,16 @@
 // akmi_numerics.hpp -- per-cell / per-face device arithmetic of the MeshBlock update.
 //
-// Written for gfx950 (wave64, fp64 VALU).  Everything here is register-only: a face's L/R
-// states are reconstructed from the cell stencil in registers and handed straight to the
-// Riemann solver, so the reference's global L/R buffers (src/hydro/hydro.hpp:102-113,
-// src/mhd/mhd.hpp:134-137) never exist.  Operation order and parenthesisation follow the
-// cited reference lines so a -ffp-contract=off build is bit-comparable with the CPU path.
+// Written for gfx950 (wave64, fp64 VALU).  Everything here lives in registers: a face's two states are
+// reconstructed from the cell stencil and handed straight to the Riemann solver, so the reference's global L/R
+// buffers (src/hydro/hydro.hpp:102-113, src/mhd/mhd.hpp:134-137) never exist.
+//
+// Bit parity.  The library is compiled with -ffp-contract=off and every VALUE below is produced by the same
+// sequence of IEEE operations as in the reference function cited next to it (a sum keeps its association, a
+// division stays a division), so results compare bit for bit with the CPU path.  What parity does NOT fix is the
+// shape of the code: which values are alive at the same time, what is computed for both sides of a face and what
+// only for the side the answer comes from, what is shared between the two faces of a cell.  That shape is chosen
+// here for the register file (each function says how); the tables "value <- reference line" keep the audit
+// trail.  tests/test_numerics_host.py compiles this header for the CPU and compares it with the oracle.
 #ifndef AKMI_NUMERICS_HPP_
 #define AKMI_NUMERICS_HPP_
 #include <hip/hip_runtime.h>
@@ -89,144 +95,155 @@ AKMI_DEV double rcp_x(double x) {
 #endif
 }
 
-// PLM, src/reconstruct/plm.hpp:20-37 (van-Leer/harmonic slope on primitives)
-AKMI_DEV void plm(double qm, double q, double qp, double &ql_ip1, double &qr_i) {
-  double dql = (q - qm);
-  double dqr = (qp - q);
-  double dq2 = dql*dqr;
-  double dqm = dq2/(dql + dqr);
-  if (dq2 <= 0.0) dqm = 0.0;
-  ql_ip1 = q + dqm;
-  qr_i = q - dqm;
+// =======================================================================================
+// Reconstruction.  One call works on ONE cell and returns the values that cell contributes to its two faces
+// (ReconCellT, src/reconstruct/recon.hpp:40-118: cell c feeds the left state of face c+1 and the right state of
+// face c).  The sweeps are built around that: a lane / a march step reconstructs its cell once and hands one of
+// the two values to its neighbour, so every limiter is evaluated once per cell and direction.
+//   up   = value at the cell's upper face  (reference: ql(i+1))
+//   down = value at the cell's lower face  (reference: qr(i))
+// Arguments are the stencil in memory order: (.., below, here, above, ..).
+// =======================================================================================
+
+// piecewise linear, van Leer's harmonic mean of the two one-sided differences (src/reconstruct/plm.hpp:20-37):
+//   half = (dl*dr)/(dl + dr) where the differences agree in sign, 0 otherwise; faces = here +- half
+AKMI_DEV void plm(double below, double here, double above, double &up, double &down) {
+  const double dl = here - below, dr = above - here;
+  const double same = dl*dr;                        // > 0: a monotone stretch
+  double half = same/(dl + dr);
+  if (same <= 0.0) half = 0.0;
+  up = here + half;
+  down = here - half;
 }
 
-// PPM4, src/reconstruct/ppm.hpp:44-77 (Colella-Woodward limiters)
-AKMI_DEV void ppm4(double qm2, double qm1, double q, double qp1, double qp2, double &ql_ip1,
-                   double &qr_i) {
-  double qlv = (7.*(q + qm1) - (qm2 + qp1))/12.0;
-  double qrv = (7.*(q + qp1) - (qm1 + qp2))/12.0;
-  qlv = fmax(qlv, fmin(q, qm1));
-  qlv = fmin(qlv, fmax(q, qm1));
-  qrv = fmax(qrv, fmin(q, qp1));
-  qrv = fmin(qrv, fmax(q, qp1));
-  double qc = qrv - q;
-  double qd = qlv - q;
-  if ((qc*qd) >= 0.0) {
-    qlv = q;
-    qrv = q;
+// fourth-order face values shared by the PPM variants: (7(a + b) - (a' + b'))/12 with a, b the two cells at the
+// face and a', b' the next ones out (ppm.hpp:47-48, :87-88)
+AKMI_DEV double face4(double in_a, double in_b, double out_a, double out_b) {
+  return (7.*(in_a + in_b) - (out_a + out_b))/12.0;
+}
+// clip x into the interval spanned by p and q (ppm.hpp:51-54)
+AKMI_DEV double clip_between(double x, double p, double q) {
+  x = fmax(x, fmin(p, q));
+  return fmin(x, fmax(p, q));
+}
+// Colella-Woodward steepness limiter on the two deviations from the cell average (ppm.hpp:60-72, :166-171): where
+// one deviation is more than twice the other the parabola would overshoot inside the cell; pull the large one in
+AKMI_DEV void cw_pull_in(double here, double &lo, double &hi) {
+  const double dhi = hi - here, dlo = lo - here;
+  if (fabs(dhi) >= 2.0*fabs(dlo)) hi = here - 2.0*dlo;
+  if (fabs(dlo) >= 2.0*fabs(dhi)) lo = here - 2.0*dhi;
+}
+
+// PPM4, src/reconstruct/ppm.hpp:44-77 (Colella-Woodward limiters).  Stencil b2 b1 here a1 a2.
+AKMI_DEV void ppm4(double b2, double b1, double here, double a1, double a2, double &up, double &down) {
+  double lo = clip_between(face4(here, b1, b2, a1), here, b1);
+  double hi = clip_between(face4(here, a1, b1, a2), here, a1);
+  if (((hi - here)*(lo - here)) >= 0.0) {           // extremum inside the cell: flat
+    lo = here;
+    hi = here;
   } else {
-    if (fabs(qc) >= 2.0*fabs(qd)) qrv = q - 2.0*qd;
-    if (fabs(qd) >= 2.0*fabs(qc)) qlv = q - 2.0*qc;
+    cw_pull_in(here, lo, hi);
   }
-  ql_ip1 = qrv;
-  qr_i = qlv;
+  up = hi;
+  down = lo;
 }
 
 AKMI_DEV double sgn(double x) { return (x < 0.0) ? -1.0 : 1.0; }   // SIGN, src/athena.hpp:52
 
-// PPMX, src/reconstruct/ppm.hpp:84-181 (Colella & Sekora limiters, PH = Peterson & Hammett)
-AKMI_DEV void ppmx(double qm2, double qm1, double q, double qp1, double qp2, double &ql_ip1,
-                   double &qr_i) {
-  double qlv = (7.*(q + qm1) - (qm2 + qp1))/12.0;
-  double qrv = (7.*(q + qp1) - (qm1 + qp2))/12.0;
-  double d2qc = 3.0*((qm1 + q) - 2.0*qlv);
-  double d2ql = (qm2 + q) - 2.0*qm1;
-  double d2qr = (qm1 + qp1) - 2.0*q;
-  double d2qlim = 0.0;
-  double lim_slope = fmin(fabs(d2ql), fabs(d2qr));
-  if (d2qc > 0.0 && d2ql > 0.0 && d2qr > 0.0) d2qlim = sgn(d2qc)*fmin(1.25*lim_slope, fabs(d2qc));
-  if (d2qc < 0.0 && d2ql < 0.0 && d2qr < 0.0) d2qlim = sgn(d2qc)*fmin(1.25*lim_slope, fabs(d2qc));
-  if (((qm1 - qlv)*(q - qlv)) > 0.0) qlv = 0.5*(q + qm1) - d2qlim/6.0;
-  d2qc = 3.0*((q + qp1) - 2.0*qrv);
-  d2ql = d2qr;
-  d2qr = (q + qp2) - 2.0*qp1;
-  d2qlim = 0.0;
-  lim_slope = fmin(fabs(d2ql), fabs(d2qr));
-  if (d2qc > 0.0 && d2ql > 0.0 && d2qr > 0.0) d2qlim = sgn(d2qc)*fmin(1.25*lim_slope, fabs(d2qc));
-  if (d2qc < 0.0 && d2ql < 0.0 && d2qr < 0.0) d2qlim = sgn(d2qc)*fmin(1.25*lim_slope, fabs(d2qc));
-  if (((q - qrv)*(qp1 - qrv)) > 0.0) qrv = 0.5*(q + qp1) - d2qlim/6.0;
-  double qa = (qrv - q)*(q - qlv);
-  double qb = (qm1 - q)*(q - qp1);
-  if (qa <= 0.0 || qb <= 0.0) {
-    double d2q = 6.0*(qlv + qrv - 2.0*q);
-    double e2qc = (qm1 + qp1) - 2.0*q;
-    double e2ql = (qm2 + q) - 2.0*qm1;
-    double e2qr = (q + qp2) - 2.0*qp1;
-    d2qlim = 0.0;
-    lim_slope = fmin(fabs(e2ql), fabs(e2qr));
-    lim_slope = fmin(fabs(e2qc), lim_slope);
-    if (e2qc > 0.0 && e2ql > 0.0 && e2qr > 0.0 && d2q > 0.0)
-      d2qlim = sgn(d2q)*fmin(1.25*lim_slope, fabs(d2q));
-    if (e2qc < 0.0 && e2ql < 0.0 && e2qr < 0.0 && d2q < 0.0)
-      d2qlim = sgn(d2q)*fmin(1.25*lim_slope, fabs(d2q));
-    double rho = 0.0;
-    if (fabs(d2q) > (1.0e-12)*fmax(fabs(qm1), fmax(fabs(q), fabs(qp1)))) rho = d2qlim/d2q;
-    qlv = q + (qlv - q)*rho;
-    qrv = q + (qrv - q)*rho;
-  } else {
-    double qc = qrv - q;
-    double qd = qlv - q;
-    if (fabs(qc) >= 2.0*fabs(qd)) qrv = q - 2.0*qd;
-    if (fabs(qd) >= 2.0*fabs(qc)) qlv = q - 2.0*qc;
-  }
-  ql_ip1 = qrv;
-  qr_i = qlv;
+// Colella-Sekora second-derivative limiter (ppm.hpp:97-100, :108-111, :132-140): when the three (or four)
+// curvatures agree in sign, the smallest of 1.25 x the neighbours' and |centre|, with the centre's sign
+AKMI_DEV double cs_limited(double centre, double left, double right, double cap) {
+  double lim = 0.0;
+  if (centre > 0.0 && left > 0.0 && right > 0.0) lim = sgn(centre)*fmin(1.25*cap, fabs(centre));
+  if (centre < 0.0 && left < 0.0 && right < 0.0) lim = sgn(centre)*fmin(1.25*cap, fabs(centre));
+  return lim;
 }
 
-// Jiang-Shu smoothness indicators (wenoz.hpp:32-43 == teno.hpp:33-44) and the two 5th-order
-// face values for un-normalised weights (wenoz.hpp:58-81 == teno.hpp:64-86)
-AKMI_DEV void js_beta(double qm2, double qm1, double q, double qp1, double qp2, double &b0,
-                      double &b1, double &b2) {
-  const double c0 = 13./12., c1 = 0.25;
-  b0 = c0*sqr(qm2 + q - 2.0*qm1) + c1*sqr(qm2 + 3.0*q - 4.0*qm1);
-  b1 = c0*sqr(qm1 + qp1 - 2.0*q) + c1*sqr(qm1 - qp1);
-  b2 = c0*sqr(qp2 + q - 2.0*qp1) + c1*sqr(qp2 + 3.0*q - 4.0*qp1);
+// PPMX, src/reconstruct/ppm.hpp:84-181 (Colella & Sekora extremum-preserving limiters)
+AKMI_DEV void ppmx(double b2, double b1, double here, double a1, double a2, double &up, double &down) {
+  double lo = face4(here, b1, b2, a1);
+  double hi = face4(here, a1, b1, a2);
+  // curvatures of the three-cell parabolas centred on b1, here, a1
+  const double curv_b = (b2 + here) - 2.0*b1;
+  const double curv_0 = (b1 + a1) - 2.0*here;
+  const double curv_a = (here + a2) - 2.0*a1;
+  {  // lower face value outside the range of its two cells -> rebuild it from the limited curvature (:93-102)
+    const double c = 3.0*((b1 + here) - 2.0*lo);
+    const double lim = cs_limited(c, curv_b, curv_0, fmin(fabs(curv_b), fabs(curv_0)));
+    if (((b1 - lo)*(here - lo)) > 0.0) lo = 0.5*(here + b1) - lim/6.0;
+  }
+  {  // upper face value (:104-113)
+    const double c = 3.0*((here + a1) - 2.0*hi);
+    const double lim = cs_limited(c, curv_0, curv_a, fmin(fabs(curv_0), fabs(curv_a)));
+    if (((here - hi)*(a1 - hi)) > 0.0) hi = 0.5*(here + a1) - lim/6.0;
+  }
+  const double extremum_in = (hi - here)*(here - lo);
+  const double extremum_nb = (b1 - here)*(here - a1);
+  if (extremum_in <= 0.0 || extremum_nb <= 0.0) {    // local extremum: scale both deviations (:118-146)
+    const double c = 6.0*(lo + hi - 2.0*here);
+    double cap = fmin(fabs(curv_b), fabs(curv_a));
+    cap = fmin(fabs(curv_0), cap);
+    double lim = 0.0;
+    if (curv_0 > 0.0 && curv_b > 0.0 && curv_a > 0.0 && c > 0.0) lim = sgn(c)*fmin(1.25*cap, fabs(c));
+    if (curv_0 < 0.0 && curv_b < 0.0 && curv_a < 0.0 && c < 0.0) lim = sgn(c)*fmin(1.25*cap, fabs(c));
+    double scale = 0.0;
+    if (fabs(c) > (1.0e-12)*fmax(fabs(b1), fmax(fabs(here), fabs(a1)))) scale = lim/c;
+    lo = here + (lo - here)*scale;
+    hi = here + (hi - here)*scale;
+  } else {
+    cw_pull_in(here, lo, hi);
+  }
+  up = hi;
+  down = lo;
 }
-AKMI_DEV void weno_faces(double qm2, double qm1, double q, double qp1, double qp2, double wa,
-                         double wb, double wc, double va, double vc, double &ql_ip1,
-                         double &qr_i) {
-  double f0 = (2.0*qm2 - 7.0*qm1 + 11.0*q);
-  double f1 = (-1.0*qm1 + 5.0*q + 2.0*qp1);
-  double f2 = (2.0*q + 5.0*qp1 - qp2);
-  double asum = 6.0*(wa + wb + wc);
-  ql_ip1 = (f0*wa + f1*wb + f2*wc)/asum;
-  f0 = (2.0*qp2 - 7.0*qp1 + 11.0*q);
-  f1 = (-1.0*qp1 + 5.0*q + 2.0*qm1);
-  f2 = (2.0*q + 5.0*qm1 - qm2);
-  asum = 6.0*(va + wb + vc);
-  qr_i = (f0*va + f1*wb + f2*vc)/asum;
+
+// Jiang-Shu smoothness indicators of the three sub-stencils (wenoz.hpp:32-43 == teno.hpp:33-44)
+AKMI_DEV void smoothness3(double b2, double b1, double here, double a1, double a2, double &s_lo,
+                          double &s_mid, double &s_hi) {
+  const double k13 = 13./12., k4 = 0.25;
+  s_lo = k13*sqr(b2 + here - 2.0*b1) + k4*sqr(b2 + 3.0*here - 4.0*b1);
+  s_mid = k13*sqr(b1 + a1 - 2.0*here) + k4*sqr(b1 - a1);
+  s_hi = k13*sqr(a2 + here - 2.0*a1) + k4*sqr(a2 + 3.0*here - 4.0*a1);
+}
+// the two fifth-order face values from un-normalised weights (wenoz.hpp:58-81 == teno.hpp:64-86): weights
+// (u0,u1,u2) for the upper face, (d0,u1,d2) for the lower one -- the middle weight is shared
+AKMI_DEV void weighted_faces(double b2, double b1, double here, double a1, double a2, double u0, double u1,
+                             double u2, double d0, double d2, double &up, double &down) {
+  {
+    const double p0 = (2.0*b2 - 7.0*b1 + 11.0*here);
+    const double p1 = (-1.0*b1 + 5.0*here + 2.0*a1);
+    const double p2 = (2.0*here + 5.0*a1 - a2);
+    up = (p0*u0 + p1*u1 + p2*u2)/(6.0*(u0 + u1 + u2));
+  }
+  {
+    const double p0 = (2.0*a2 - 7.0*a1 + 11.0*here);
+    const double p1 = (-1.0*a1 + 5.0*here + 2.0*b1);
+    const double p2 = (2.0*here + 5.0*b1 - b2);
+    down = (p0*d0 + p1*u1 + p2*d2)/(6.0*(d0 + u1 + d2));
+  }
 }
 
 // WENO-Z, src/reconstruct/wenoz.hpp:29-84
-AKMI_DEV void wenoz(double qm2, double qm1, double q, double qp1, double qp2, double &ql_ip1,
-                    double &qr_i) {
-  double b0, b1, b2;
-  js_beta(qm2, qm1, q, qp1, qp2, b0, b1, b2);
-  const double epsL = 1.0e-42;
-  const double tau_5 = fabs(b0 - b2);
-  double ind0 = sqr(tau_5/(b0 + epsL));
-  double ind1 = sqr(tau_5/(b1 + epsL));
-  double ind2 = sqr(tau_5/(b2 + epsL));
-  weno_faces(qm2, qm1, q, qp1, qp2, 0.1*(1.0 + ind0), 0.6*(1.0 + ind1), 0.3*(1.0 + ind2),
-             0.1*(1.0 + ind2), 0.3*(1.0 + ind0), ql_ip1, qr_i);
+AKMI_DEV void wenoz(double b2, double b1, double here, double a1, double a2, double &up, double &down) {
+  double s0, s1, s2;
+  smoothness3(b2, b1, here, a1, a2, s0, s1, s2);
+  const double guard = 1.0e-42;
+  const double tau = fabs(s0 - s2);
+  const double z0 = sqr(tau/(s0 + guard)), z1 = sqr(tau/(s1 + guard)), z2 = sqr(tau/(s2 + guard));
+  weighted_faces(b2, b1, here, a1, a2, 0.1*(1.0 + z0), 0.6*(1.0 + z1), 0.3*(1.0 + z2), 0.1*(1.0 + z2),
+                 0.3*(1.0 + z0), up, down);
 }
 
-// TENO, src/reconstruct/teno.hpp:30-89
+// TENO, src/reconstruct/teno.hpp:30-89: a sub-stencil is either in (weight of the linear scheme) or out
 AKMI_DEV double cube(double x) { return x*x*x; }
-AKMI_DEV void teno(double qm2, double qm1, double q, double qp1, double qp2, double &ql_ip1,
-                   double &qr_i) {
-  double b0, b1, b2;
-  js_beta(qm2, qm1, q, qp1, qp2, b0, b1, b2);
-  const double epsT = 1.0e-40, cT = 1.0e-6;
-  double a0 = 1.0/sqr(cube(b0 + epsT));
-  double a1 = 1.0/sqr(cube(b1 + epsT));
-  double a2 = 1.0/sqr(cube(b2 + epsT));
-  double asum = a0 + a1 + a2;
-  double ind0 = (a0 < cT*asum ? 0.0 : 1.0);
-  double ind1 = (a1 < cT*asum ? 0.0 : 1.0);
-  double ind2 = (a2 < cT*asum ? 0.0 : 1.0);
-  weno_faces(qm2, qm1, q, qp1, qp2, 0.1*ind0, 0.6*ind1, 0.3*ind2, 0.1*ind2, 0.3*ind0, ql_ip1,
-             qr_i);
+AKMI_DEV void teno(double b2, double b1, double here, double a1, double a2, double &up, double &down) {
+  double s0, s1, s2;
+  smoothness3(b2, b1, here, a1, a2, s0, s1, s2);
+  const double guard = 1.0e-40, cut = 1.0e-6;
+  const double g0 = 1.0/sqr(cube(s0 + guard)), g1 = 1.0/sqr(cube(s1 + guard)), g2 = 1.0/sqr(cube(s2 + guard));
+  const double total = g0 + g1 + g2;
+  const double in0 = (g0 < cut*total ? 0.0 : 1.0), in1 = (g1 < cut*total ? 0.0 : 1.0), in2 = (g2 < cut*total ? 0.0 : 1.0);
+  weighted_faces(b2, b1, here, a1, a2, 0.1*in0, 0.6*in1, 0.3*in2, 0.1*in2, 0.3*in0, up, down);
 }
 
 // what the flux kernels need of EOS_Data: gamma and the floors of the L/R states
@@ -235,12 +252,11 @@ struct FaceEos { double gamma, dfloor, efloor, iso_cs; };
 
 // five-point reconstructions behind one name.  RECON: 2 ppm4, 3 ppmx, 4 wenoz, 5 teno
 template <int RECON>
-AKMI_DEV void recon5(double qm2, double qm1, double q, double qp1, double qp2, double &ql_ip1,
-                     double &qr_i) {
-  if constexpr (RECON == 2) ppm4(qm2, qm1, q, qp1, qp2, ql_ip1, qr_i);
-  else if constexpr (RECON == 3) ppmx(qm2, qm1, q, qp1, qp2, ql_ip1, qr_i);
-  else if constexpr (RECON == 4) wenoz(qm2, qm1, q, qp1, qp2, ql_ip1, qr_i);
-  else teno(qm2, qm1, q, qp1, qp2, ql_ip1, qr_i);
+AKMI_DEV void recon5(double b2, double b1, double here, double a1, double a2, double &up, double &down) {
+  if constexpr (RECON == 2) ppm4(b2, b1, here, a1, a2, up, down);
+  else if constexpr (RECON == 3) ppmx(b2, b1, here, a1, a2, up, down);
+  else if constexpr (RECON == 4) wenoz(b2, b1, here, a1, a2, up, down);
+  else teno(b2, b1, here, a1, a2, up, down);
 }
 
 // floors of ReconCellT (recon.hpp:72-103): only in the ppmx/wenoz/teno branches, only for the
@@ -251,1059 +267,868 @@ AKMI_DEV void floor_lr(const FaceEos &eos, double &a, double &b) {
   if constexpr (RECON >= 3 && FL == 2) { a = fmax(a, eos.efloor); b = fmax(b, eos.efloor); }
 }
 
-// L/R states of the face between cells (c-1) and c along a direction, for one variable.
-// q points at cell c; s is the element stride along the direction.
-// RECON: 0 dc, 1 plm, 2 ppm4, 3 ppmx, 4 wenoz, 5 teno (ReconCellT,
-// src/reconstruct/recon.hpp:40-118: cell c-1 writes wl(c), cell c writes wr(c)).
-template <int RECON, int FL = 0>
-AKMI_DEV void face_states(const double *__restrict__ q, long s, const FaceEos &eos, double &ql,
-                          double &qr) {
-  double dummy;
-  if constexpr (RECON == 1) {
-    double qm2 = q[-2*s], qm1 = q[-s], q0 = q[0], qp1 = q[s];
-    plm(qm2, qm1, q0, ql, dummy);
-    plm(qm1, q0, qp1, dummy, qr);
-  } else if constexpr (RECON >= 2) {
-    double qm3 = q[-3*s], qm2 = q[-2*s], qm1 = q[-s], q0 = q[0], qp1 = q[s], qp2 = q[2*s];
-    recon5<RECON>(qm3, qm2, qm1, q0, qp1, ql, dummy);
-    recon5<RECON>(qm2, qm1, q0, qp1, qp2, dummy, qr);
-    floor_lr<RECON, FL>(eos, ql, qr);
-  } else {
-    ql = q[-s];
-    qr = q[0];
-  }
-}
-
-// Same, addressed as (wave-uniform base pointer) + (32-bit per-lane element offset): the
-// stencil neighbours differ only in the uniform part, so the compiler keeps ONE offset VGPR per
-// lane and forms the neighbour addresses on the scalar unit (global_load ... v_off, s[base]).
-template <int RECON, int FL = 0>
-AKMI_DEV void face_states_u(const double *__restrict__ base, unsigned ob, long s,
-                            const FaceEos &eos, double &ql, double &qr) {
-  // ob = BYTE offset of the lane (address = scalar base + zero-extended 32-bit VGPR)
-  auto at = [&](const double *b) { return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(b) + ob); };
-  double dummy;
-  if constexpr (RECON == 1) {
-    double qm2 = at(base - 2*s), qm1 = at(base - s), q0 = at(base), qp1 = at(base + s);
-    plm(qm2, qm1, q0, ql, dummy);
-    plm(qm1, q0, qp1, dummy, qr);
-  } else if constexpr (RECON >= 2) {
-    double qm3 = at(base - 3*s), qm2 = at(base - 2*s), qm1 = at(base - s), q0 = at(base),
-           qp1 = at(base + s), qp2 = at(base + 2*s);
-    recon5<RECON>(qm3, qm2, qm1, q0, qp1, ql, dummy);
-    recon5<RECON>(qm2, qm1, q0, qp1, qp2, dummy, qr);
-    floor_lr<RECON, FL>(eos, ql, qr);
-  } else {
-    ql = at(base - s);
-    qr = at(base);
-  }
-}
-
-// the same from a stencil that is already in registers: q[0..W-1] = cells f-LO .. f+W-LO-1 of face f
-// (W, LO = 2, 1 donor cell; 4, 2 PLM; 6, 3 the five-point schemes).  Same calls, same order as face_states_u.
+// The two states of ONE face from a stencil of cells (thread-per-face kernels): the face lies between st[LO-1] and
+// st[LO]; its left state is the `up` value of the cell below it, its right state the `down` value of the cell above.
+// W cells: 2 (donor cell), 4 (PLM), 6 (five-point schemes).
 template <int RECON> constexpr int stencil_w() { return RECON == 0 ? 2 : (RECON == 1 ? 4 : 6); }
 template <int RECON> constexpr int stencil_lo() { return RECON == 0 ? 1 : (RECON == 1 ? 2 : 3); }
 template <int RECON, int FL = 0>
-AKMI_DEV void face_states_v(const double *q, const FaceEos &eos, double &ql, double &qr) {
-  double dummy;
+AKMI_DEV void face_states_v(const double *st, const FaceEos &eos, double &left, double &right) {
+  double unused;
   if constexpr (RECON == 1) {
-    plm(q[0], q[1], q[2], ql, dummy);
-    plm(q[1], q[2], q[3], dummy, qr);
+    plm(st[0], st[1], st[2], left, unused);
+    plm(st[1], st[2], st[3], unused, right);
   } else if constexpr (RECON >= 2) {
-    recon5<RECON>(q[0], q[1], q[2], q[3], q[4], ql, dummy);
-    recon5<RECON>(q[1], q[2], q[3], q[4], q[5], dummy, qr);
-    floor_lr<RECON, FL>(eos, ql, qr);
+    recon5<RECON>(st[0], st[1], st[2], st[3], st[4], left, unused);
+    recon5<RECON>(st[1], st[2], st[3], st[4], st[5], unused, right);
+    floor_lr<RECON, FL>(eos, left, right);
   } else {
-    ql = q[0];
-    qr = q[1];
+    left = st[0];
+    right = st[1];
   }
 }
+// ... the stencil fetched from memory: q points at the cell above the face, s is the element stride along the sweep
+template <int RECON, int FL = 0>
+AKMI_DEV void face_states(const double *__restrict__ q, long s, const FaceEos &eos, double &left, double &right) {
+  constexpr int W = stencil_w<RECON>(), LO = stencil_lo<RECON>();
+  double st[W];
+#pragma unroll
+  for (int c = 0; c < W; ++c) st[c] = q[(c - LO)*s];
+  face_states_v<RECON, FL>(st, eos, left, right);
+}
+// ... addressed as (wave-uniform base pointer) + (32-bit per-lane BYTE offset): the stencil neighbours differ only in
+// the uniform part, so the lane keeps ONE offset register and the neighbour addresses are formed on the scalar unit
+template <int RECON, int FL = 0>
+AKMI_DEV void face_states_u(const double *__restrict__ base, unsigned ob, long s, const FaceEos &eos, double &left,
+                            double &right) {
+  constexpr int W = stencil_w<RECON>(), LO = stencil_lo<RECON>();
+  double st[W];
+#pragma unroll
+  for (int c = 0; c < W; ++c)
+    st[c] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base + (c - LO)*s) + ob);
+  face_states_v<RECON, FL>(st, eos, left, right);
+}
 
-// HLLC, src/hydro/rsolvers/hllc_hyd.hpp:20-115.  States are (d, vx, vy, vz, e_int) with
-// vx along the sweep; flux is (d, mx, my, mz, E).
-AKMI_DEV void hllc(double gamma, double wl_idn, double wl_ivx, double wl_ivy, double wl_ivz,
-                   double wl_ien, double wr_idn, double wr_ivx, double wr_ivy, double wr_ivz,
-                   double wr_ien, double &f_d, double &f_mx, double &f_my, double &f_mz,
+// =======================================================================================
+// Hydrodynamic Riemann solvers.  A state is (d, u, v, w, e) = density, velocity along the sweep, the two
+// transverse velocities, internal energy density; the flux comes back as (d, mx, my, mz, E) in the same frame.
+// =======================================================================================
+
+// what a side contributes to every ideal-gas solver: pressure, total energy, mass flux
+struct GasSide { double p, E; };
+AKMI_DEV GasSide gas_side(double gamma, double igm1, double d, double u, double v, double w, double e) {
+  GasSide s;
+  s.p = (gamma - 1.0)*e;
+  s.E = s.p*igm1 + 0.5*d*(sqr(u) + sqr(v) + sqr(w));
+  return s;
+}
+
+// HLLC, src/hydro/rsolvers/hllc_hyd.hpp:20-115 (Toro's two-rarefaction pressure estimate for the wave speeds,
+// contact speed and contact pressure from the two HLL-like fluxes).
+//   value                     reference line
+//   cl, cr (sound speeds)     :46-47        pmid, shock factors gl, gr   :56-62
+//   sl, sr (outer speeds)     :65-66        bp, bm (signed bounds)       :70-71
+//   contact speed sc, pc      :82-87        flux weights wl, wr, wp      :100-108
+AKMI_DEV void hllc(double gamma, double dl, double ul, double vl, double wl, double el, double dr, double ur,
+                   double vr, double wr, double er, double &f_d, double &f_mx, double &f_my, double &f_mz,
                    double &f_e) {
   const double gm1 = gamma - 1.0;
   const double igm1 = 1.0/gm1;
-  const double alpha = (gamma + 1.0)/(2.0*gamma);
-  double wl_ipr = (gamma - 1.0)*wl_ien;
-  double wr_ipr = (gamma - 1.0)*wr_ien;
-  double qa, qb, qc, qd, qe, qf;
-  qa = sqrt(gamma*wl_ipr/wl_idn);
-  qb = sqrt(gamma*wr_ipr/wr_idn);
-  double el = wl_ipr*igm1 + 0.5*wl_idn*(sqr(wl_ivx) + sqr(wl_ivy) + sqr(wl_ivz));
-  double er = wr_ipr*igm1 + 0.5*wr_idn*(sqr(wr_ivx) + sqr(wr_ivy) + sqr(wr_ivz));
-  qc = 0.25*(wl_idn + wr_idn)*(qa + qb);
-  qd = 0.5*(wl_ipr + wr_ipr + (wl_ivx - wr_ivx)*qc);
-  qe = (qd <= wl_ipr) ? 1.0 : sqrt(1.0 + alpha*((qd/wl_ipr) - 1.0));
-  qf = (qd <= wr_ipr) ? 1.0 : sqrt(1.0 + alpha*((qd/wr_ipr) - 1.0));
-  qc = wl_ivx - qa*qe;
-  qd = wr_ivx + qb*qf;
-  qa = qd > 0.0 ? qd : 1.0e-20;
-  qb = qc < 0.0 ? qc : -1.0e-20;
-  qe = wl_ivx - qc;
-  qf = wr_ivx - qd;
-  qc = wl_ipr + qe*wl_idn*wl_ivx;
-  qd = wr_ipr + qf*wr_idn*wr_ivx;
-  double ml = wl_idn*qe;
-  double mr = -(wr_idn*qf);
-  double am = (qc - qd)/(ml + mr);
-  double cp = (ml*qd + mr*qc)/(ml + mr);
-  cp = cp > 0.0 ? cp : 0.0;
-  qe = wl_idn*(wl_ivx - qb);
-  qf = wr_idn*(wr_ivx - qa);
-  double fl_d = qe, fr_d = qf;
-  double fl_mx = qe*wl_ivx + wl_ipr, fr_mx = qf*wr_ivx + wr_ipr;
-  double fl_my = qe*wl_ivy, fr_my = qf*wr_ivy;
-  double fl_mz = qe*wl_ivz, fr_mz = qf*wr_ivz;
-  double fl_e = el*(wl_ivx - qb) + wl_ipr*wl_ivx;
-  double fr_e = er*(wr_ivx - qa) + wr_ipr*wr_ivx;
-  if (am >= 0.0) {
-    qc = am/(am - qb);
-    qd = 0.0;
-    qe = -qb/(am - qb);
+  const double shock_k = (gamma + 1.0)/(2.0*gamma);
+  const GasSide L = gas_side(gamma, igm1, dl, ul, vl, wl, el), R = gas_side(gamma, igm1, dr, ur, vr, wr, er);
+  const double cl = sqrt(gamma*L.p/dl), cr = sqrt(gamma*R.p/dr);
+  // two-rarefaction middle pressure, then the shock corrections of the outer speeds
+  const double zbar = 0.25*(dl + dr)*(cl + cr);
+  const double pmid = 0.5*(L.p + R.p + (ul - ur)*zbar);
+  const double gl = (pmid <= L.p) ? 1.0 : sqrt(1.0 + shock_k*((pmid/L.p) - 1.0));
+  const double gr = (pmid <= R.p) ? 1.0 : sqrt(1.0 + shock_k*((pmid/R.p) - 1.0));
+  const double sl = ul - cl*gl, sr = ur + cr*gr;
+  const double bp = sr > 0.0 ? sr : 1.0e-20;        // signed bounds of the fan
+  const double bm = sl < 0.0 ? sl : -1.0e-20;
+  // contact: speed and pressure from the jump conditions across the two outer waves
+  const double rel_l = ul - sl, rel_r = ur - sr;
+  const double tl = L.p + rel_l*dl*ul, tr = R.p + rel_r*dr*ur;
+  const double ml = dl*rel_l, mr = -(dr*rel_r);
+  const double sc = (tl - tr)/(ml + mr);
+  double pc = (ml*tr + mr*tl)/(ml + mr);
+  pc = pc > 0.0 ? pc : 0.0;
+  // fluxes along the lines x/t = bm and x/t = bp
+  const double ql = dl*(ul - bm), qr = dr*(ur - bp);
+  const double fl[5] = {ql, ql*ul + L.p, ql*vl, ql*wl, L.E*(ul - bm) + L.p*ul};
+  const double fr[5] = {qr, qr*ur + R.p, qr*vr, qr*wr, R.E*(ur - bp) + R.p*ur};
+  double wgt_l, wgt_r, wgt_p;                        // weights of fl, fr and of the contact pressure
+  if (sc >= 0.0) {
+    wgt_l = sc/(sc - bm);
+    wgt_r = 0.0;
+    wgt_p = -bm/(sc - bm);
   } else {
-    qc = 0.0;
-    qd = -am/(qa - am);
-    qe = qa/(qa - am);
+    wgt_l = 0.0;
+    wgt_r = -sc/(bp - sc);
+    wgt_p = bp/(bp - sc);
   }
-  f_d = qc*fl_d + qd*fr_d;
-  f_mx = qc*fl_mx + qd*fr_mx + qe*cp;
-  f_my = qc*fl_my + qd*fr_my;
-  f_mz = qc*fl_mz + qd*fr_mz;
-  f_e = qc*fl_e + qd*fr_e + qe*cp*am;
+  f_d = wgt_l*fl[0] + wgt_r*fr[0];
+  f_mx = wgt_l*fl[1] + wgt_r*fr[1] + wgt_p*pc;
+  f_my = wgt_l*fl[2] + wgt_r*fr[2];
+  f_mz = wgt_l*fl[3] + wgt_r*fr[3];
+  f_e = wgt_l*fl[4] + wgt_r*fr[4] + wgt_p*pc*sc;
 }
 
-// LLF, src/hydro/rsolvers/llf_hyd_singlestate.hpp:28-78 (ideal gas)
-AKMI_DEV void llf_hyd(double gamma, double ld, double lx, double ly, double lz, double le,
-                      double rd, double rx, double ry, double rz, double re, double &f_d,
-                      double &f_mx, double &f_my, double &f_mz, double &f_e) {
-  double qa = ld*lx;
-  double qb = rd*rx;
-  double s_d = qa + qb;
-  double s_mx = qa*lx + qb*rx;
-  double s_my = qa*ly + qb*ry;
-  double s_mz = qa*lz + qb*rz;
-  double pl = (gamma - 1.0)*le;
-  double pr = (gamma - 1.0)*re;
-  double el = le + 0.5*ld*(sqr(lx) + sqr(ly) + sqr(lz));
-  double er = re + 0.5*rd*(sqr(rx) + sqr(ry) + sqr(rz));
-  s_mx += (pl + pr);
-  double s_e = (el + pl)*lx + (er + pr)*rx;
-  qa = sqrt(gamma*pl/ld);
-  qb = sqrt(gamma*pr/rd);
-  double a = fmax((fabs(lx) + qa), (fabs(rx) + qb));
-  double du_d = a*(rd - ld);
-  double du_mx = a*(rd*rx - ld*lx);
-  double du_my = a*(rd*ry - ld*ly);
-  double du_mz = a*(rd*rz - ld*lz);
-  double du_e = a*(er - el);
-  f_d = 0.5*(s_d - du_d);
-  f_mx = 0.5*(s_mx - du_mx);
-  f_my = 0.5*(s_my - du_my);
-  f_mz = 0.5*(s_mz - du_mz);
-  f_e = 0.5*(s_e - du_e);
+// LLF, src/hydro/rsolvers/llf_hyd_singlestate.hpp:28-78 (ideal gas): half the sum of the two physical fluxes
+// minus half the largest signal speed times the jump of the conserved state
+AKMI_DEV void llf_hyd(double gamma, double dl, double ul, double vl, double wl, double el, double dr, double ur,
+                      double vr, double wr, double er, double &f_d, double &f_mx, double &f_my, double &f_mz,
+                      double &f_e) {
+  const double ml = dl*ul, mr = dr*ur;
+  const double pl = (gamma - 1.0)*el, pr = (gamma - 1.0)*er;
+  const double El = el + 0.5*dl*(sqr(ul) + sqr(vl) + sqr(wl));
+  const double Er = er + 0.5*dr*(sqr(ur) + sqr(vr) + sqr(wr));
+  double sum[5] = {ml + mr, ml*ul + mr*ur, ml*vl + mr*vr, ml*wl + mr*wr, 0.0};
+  sum[1] += (pl + pr);
+  sum[4] = (El + pl)*ul + (Er + pr)*ur;
+  const double cl = sqrt(gamma*pl/dl), cr = sqrt(gamma*pr/dr);
+  const double smax = fmax((fabs(ul) + cl), (fabs(ur) + cr));
+  const double jump[5] = {dr - dl, dr*ur - dl*ul, dr*vr - dl*vl, dr*wr - dl*wl, Er - El};
+  f_d = 0.5*(sum[0] - smax*jump[0]);
+  f_mx = 0.5*(sum[1] - smax*jump[1]);
+  f_my = 0.5*(sum[2] - smax*jump[2]);
+  f_mz = 0.5*(sum[3] - smax*jump[3]);
+  f_e = 0.5*(sum[4] - smax*jump[4]);
 }
 
-// HLLE, src/hydro/rsolvers/hlle_hyd.hpp:27-129 (ideal gas)
-AKMI_DEV void hlle_hyd(double gamma, double dl, double ul, double vl, double zl, double eil,
-                       double dr, double ur, double vr, double zr, double eir, double &f_d,
-                       double &f_mx, double &f_my, double &f_mz, double &f_e) {
+// Einfeldt's blend of the two fluxes taken along the lines x/t = bm <= 0 <= bp (hlle_*.hpp, last block): with
+// t = (bp + bm)/(2 (bp - bm)) the HLL flux is (fl + fr)/2 + (fl - fr) t
+AKMI_DEV double hll_tilt(double bp, double bm) {
+  double t = 0.0;
+  if (bp != bm) t = 0.5*(bp + bm)/(bp - bm);
+  return t;
+}
+
+// HLLE, src/hydro/rsolvers/hlle_hyd.hpp:27-129 (ideal gas): Roe-averaged velocity and enthalpy bound the fan
+AKMI_DEV void hlle_hyd(double gamma, double dl, double ul, double vl, double wl, double el, double dr, double ur,
+                       double vr, double wr, double er, double &f_d, double &f_mx, double &f_my, double &f_mz,
+                       double &f_e) {
   const double gm1 = gamma - 1.0;
   const double igm1 = 1.0/gm1;
-  double pl = (gamma - 1.0)*eil, pr = (gamma - 1.0)*eir;
-  double sqrtdl = sqrt(dl);
-  double sqrtdr = sqrt(dr);
-  double isdlpdr = 1.0/(sqrtdl + sqrtdr);
-  double roe_vx = (sqrtdl*ul + sqrtdr*ur)*isdlpdr;
-  double roe_vy = (sqrtdl*vl + sqrtdr*vr)*isdlpdr;
-  double roe_vz = (sqrtdl*zl + sqrtdr*zr)*isdlpdr;
-  double el = pl*igm1 + 0.5*dl*(sqr(ul) + sqr(vl) + sqr(zl));
-  double er = pr*igm1 + 0.5*dr*(sqr(ur) + sqr(vr) + sqr(zr));
-  double hroe = ((el + pl)/sqrtdl + (er + pr)/sqrtdr)*isdlpdr;
-  double qa = sqrt(gamma*pl/dl);
-  double qb = sqrt(gamma*pr/dr);
-  double a = hroe - 0.5*(sqr(roe_vx) + sqr(roe_vy) + sqr(roe_vz));
-  a = (a < 0.0) ? 0.0 : sqrt(gm1*a);
-  double al = fmin((roe_vx - a), (ul - qa));
-  double ar = fmax((roe_vx + a), (ur + qb));
-  double bp = (ar > 0.0) ? ar : 1.0e-20;
-  double bm = (al < 0.0) ? al : -1.0e-20;
-  qa = ul - bm;
-  qb = ur - bp;
-  double fl_d = dl*qa, fr_d = dr*qb;
-  double fl_mx = dl*ul*qa, fr_mx = dr*ur*qb;
-  double fl_my = dl*vl*qa, fr_my = dr*vr*qb;
-  double fl_mz = dl*zl*qa, fr_mz = dr*zr*qb;
-  fl_mx += pl;
-  fr_mx += pr;
-  double fl_e = el*qa + pl*ul;
-  double fr_e = er*qb + pr*ur;
-  qa = 0.0;
-  if (bp != bm) qa = 0.5*(bp + bm)/(bp - bm);
-  f_d = 0.5*(fl_d + fr_d) + qa*(fl_d - fr_d);
-  f_mx = 0.5*(fl_mx + fr_mx) + qa*(fl_mx - fr_mx);
-  f_my = 0.5*(fl_my + fr_my) + qa*(fl_my - fr_my);
-  f_mz = 0.5*(fl_mz + fr_mz) + qa*(fl_mz - fr_mz);
-  f_e = 0.5*(fl_e + fr_e) + qa*(fl_e - fr_e);
+  const GasSide L = gas_side(gamma, igm1, dl, ul, vl, wl, el), R = gas_side(gamma, igm1, dr, ur, vr, wr, er);
+  const double rl = sqrt(dl), rr = sqrt(dr);
+  const double inorm = 1.0/(rl + rr);
+  const double u_roe = (rl*ul + rr*ur)*inorm, v_roe = (rl*vl + rr*vr)*inorm, w_roe = (rl*wl + rr*wr)*inorm;
+  const double h_roe = ((L.E + L.p)/rl + (R.E + R.p)/rr)*inorm;
+  const double cl = sqrt(gamma*L.p/dl), cr = sqrt(gamma*R.p/dr);
+  double c_roe = h_roe - 0.5*(sqr(u_roe) + sqr(v_roe) + sqr(w_roe));
+  c_roe = (c_roe < 0.0) ? 0.0 : sqrt(gm1*c_roe);
+  const double smin = fmin((u_roe - c_roe), (ul - cl)), smax = fmax((u_roe + c_roe), (ur + cr));
+  const double bp = (smax > 0.0) ? smax : 1.0e-20;
+  const double bm = (smin < 0.0) ? smin : -1.0e-20;
+  const double rel_l = ul - bm, rel_r = ur - bp;
+  double fl[5] = {dl*rel_l, dl*ul*rel_l, dl*vl*rel_l, dl*wl*rel_l, L.E*rel_l + L.p*ul};
+  double fr[5] = {dr*rel_r, dr*ur*rel_r, dr*vr*rel_r, dr*wr*rel_r, R.E*rel_r + R.p*ur};
+  fl[1] += L.p;
+  fr[1] += R.p;
+  const double t = hll_tilt(bp, bm);
+  f_d = 0.5*(fl[0] + fr[0]) + t*(fl[0] - fr[0]);
+  f_mx = 0.5*(fl[1] + fr[1]) + t*(fl[1] - fr[1]);
+  f_my = 0.5*(fl[2] + fr[2]) + t*(fl[2] - fr[2]);
+  f_mz = 0.5*(fl[3] + fr[3]) + t*(fl[3] - fr[3]);
+  f_e = 0.5*(fl[4] + fr[4]) + t*(fl[4] - fr[4]);
 }
 
-// Roe with LLF fallback, src/hydro/rsolvers/roe_hyd.hpp:40-268 (RoeFluxAdb :183-268)
-AKMI_DEV void roe_hyd(double gamma, double ld, double lx, double ly, double lz, double lei,
-                      double rd, double rx, double ry, double rz, double rei, double &f_d,
-                      double &f_mx, double &f_my, double &f_mz, double &f_e) {
+// Roe's linearisation with an LLF fallback, src/hydro/rsolvers/roe_hyd.hpp:40-268 (RoeFluxAdb :183-268).
+// flux = (fl + fr)/2 - sum_k |lambda_k| alpha_k r_k / 2 over the five waves; if an intermediate density of the
+// linearised fan is negative the face falls back to LLF; supersonic faces take the upwind flux.
+AKMI_DEV void roe_hyd(double gamma, double dl, double ul, double vl, double wl, double el, double dr, double ur,
+                      double vr, double wr, double er, double &f_d, double &f_mx, double &f_my, double &f_mz,
+                      double &f_e) {
   const double gm1 = gamma - 1.0;
-  double wli[5] = {ld, lx, ly, lz, (gamma - 1.0)*lei};
-  double wri[5] = {rd, rx, ry, rz, (gamma - 1.0)*rei};
-  double fl[5], fr[5], du[5], ev[5], f[5];
-  double sqrtdl = sqrt(wli[0]);
-  double sqrtdr = sqrt(wri[0]);
-  double isdlpdr = 1.0/(sqrtdl + sqrtdr);
-  double v1 = (sqrtdl*wli[1] + sqrtdr*wri[1])*isdlpdr;
-  double v2 = (sqrtdl*wli[2] + sqrtdr*wri[2])*isdlpdr;
-  double v3 = (sqrtdl*wli[3] + sqrtdr*wri[3])*isdlpdr;
-  double el = wli[4]/gm1 + 0.5*wli[0]*(sqr(wli[1]) + sqr(wli[2]) + sqr(wli[3]));
-  double er = wri[4]/gm1 + 0.5*wri[0]*(sqr(wri[1]) + sqr(wri[2]) + sqr(wri[3]));
-  double h = ((el + wli[4])/sqrtdl + (er + wri[4])/sqrtdr)*isdlpdr;
-  double mxl = wli[0]*wli[1];
-  double mxr = wri[0]*wri[1];
-  fl[0] = mxl;            fr[0] = mxr;
-  fl[1] = mxl*wli[1];     fr[1] = mxr*wri[1];
-  fl[2] = mxl*wli[2];     fr[2] = mxr*wri[2];
-  fl[3] = mxl*wli[3];     fr[3] = mxr*wri[3];
-  fl[1] += wli[4];        fr[1] += wri[4];
-  fl[4] = (el + wli[4])*wli[1];
-  fr[4] = (er + wri[4])*wri[1];
-  du[0] = wri[0] - wli[0];
-  du[1] = wri[0]*wri[1] - wli[0]*wli[1];
-  du[2] = wri[0]*wri[2] - wli[0]*wli[2];
-  du[3] = wri[0]*wri[3] - wli[0]*wli[3];
-  du[4] = er - el;
+  const double pl = (gamma - 1.0)*el, pr = (gamma - 1.0)*er;
+  const double rl = sqrt(dl), rr = sqrt(dr);
+  const double inorm = 1.0/(rl + rr);
+  const double u = (rl*ul + rr*ur)*inorm, v = (rl*vl + rr*vr)*inorm, w = (rl*wl + rr*wr)*inorm;
+  const double El = pl/gm1 + 0.5*dl*(sqr(ul) + sqr(vl) + sqr(wl));
+  const double Er = pr/gm1 + 0.5*dr*(sqr(ur) + sqr(vr) + sqr(wr));
+  const double h = ((El + pl)/rl + (Er + pr)/rr)*inorm;
+  const double ml = dl*ul, mr = dr*ur;
+  double fl[5] = {ml, ml*ul, ml*vl, ml*wl, (El + pl)*ul};
+  double fr[5] = {mr, mr*ur, mr*vr, mr*wr, (Er + pr)*ur};
+  fl[1] += pl;
+  fr[1] += pr;
+  const double jump[5] = {dr - dl, dr*ur - dl*ul, dr*vr - dl*vl, dr*wr - dl*wl, Er - El};
+  double f[5];
 #pragma unroll
   for (int n = 0; n < 5; ++n) f[n] = 0.5*(fl[n] + fr[n]);
-  bool llf_flag = false;
-  {
-    double vsq = v1*v1 + v2*v2 + v3*v3;
-    double q = h - 0.5*vsq;
-    double cs_sq = (q < 0.0) ? (double)(FLT_MIN) : gm1*q;
-    double cs = sqrt(cs_sq);
-    ev[0] = v1 - cs; ev[1] = v1; ev[2] = v1; ev[3] = v1; ev[4] = v1 + cs;
-    double a[5];
-    double na = 0.5/cs_sq;
-    a[0]  = du[0]*(0.5*gm1*vsq + v1*cs);
-    a[0] -= du[1]*(gm1*v1 + cs);
-    a[0] -= du[2]*gm1*v2;
-    a[0] -= du[3]*gm1*v3;
-    a[0] += du[4]*gm1;
-    a[0] *= na;
-    a[1]  = du[0]*(-v2);
-    a[1] += du[2];
-    a[2]  = du[0]*(-v3);
-    a[2] += du[3];
-    double qa = gm1/cs_sq;
-    a[3]  = du[0]*(1.0 - na*gm1*vsq);
-    a[3] += du[1]*qa*v1;
-    a[3] += du[2]*qa*v2;
-    a[3] += du[3]*qa*v3;
-    a[3] -= du[4]*qa;
-    a[4]  = du[0]*(0.5*gm1*vsq - v1*cs);
-    a[4] -= du[1]*(gm1*v1 - cs);
-    a[4] -= du[2]*gm1*v2;
-    a[4] -= du[3]*gm1*v3;
-    a[4] += du[4]*gm1;
-    a[4] *= na;
-    double co[5];
-#pragma unroll
-    for (int n = 0; n < 5; ++n) co[n] = -0.5*fabs(ev[n])*a[n];
-    double dens = wli[0] + a[0];
-    if (dens < 0.0) llf_flag = true;
-    dens += a[3];
-    if (dens < 0.0) llf_flag = true;
-    f[0] += co[0];
-    f[0] += co[3];
-    f[0] += co[4];
-    f[1] += co[0]*(v1 - cs);
-    f[1] += co[3]*v1;
-    f[1] += co[4]*(v1 + cs);
-    f[2] += co[0]*v2;
-    f[2] += co[1];
-    f[2] += co[3]*v2;
-    f[2] += co[4]*v2;
-    f[3] += co[0]*v3;
-    f[3] += co[2];
-    f[3] += co[3]*v3;
-    f[3] += co[4]*v3;
-    f[4] += co[0]*(h - v1*cs);
-    f[4] += co[1]*v2;
-    f[4] += co[2]*v3;
-    f[4] += co[3]*0.5*vsq;
-    f[4] += co[4]*(h + v1*cs);
-  }
-  if (ev[0] >= 0.0) {
+  // eigen-decomposition of the jump at the Roe state (RoeFluxAdb)
+  const double vsq = u*u + v*v + w*w;
+  const double q = h - 0.5*vsq;
+  const double csq = (q < 0.0) ? (double)(FLT_MIN) : gm1*q;
+  const double c = sqrt(csq);
+  const double lam_lo = u - c, lam_hi = u + c;
+  const double half_icsq = 0.5/csq, g_csq = gm1/csq;
+  double a_lo = jump[0]*(0.5*gm1*vsq + u*c);        // acoustic wave u - c
+  a_lo -= jump[1]*(gm1*u + c);
+  a_lo -= jump[2]*gm1*v;
+  a_lo -= jump[3]*gm1*w;
+  a_lo += jump[4]*gm1;
+  a_lo *= half_icsq;
+  double a_v = jump[0]*(-v);                         // the two shear waves
+  a_v += jump[2];
+  double a_w = jump[0]*(-w);
+  a_w += jump[3];
+  double a_s = jump[0]*(1.0 - half_icsq*gm1*vsq);    // entropy wave
+  a_s += jump[1]*g_csq*u;
+  a_s += jump[2]*g_csq*v;
+  a_s += jump[3]*g_csq*w;
+  a_s -= jump[4]*g_csq;
+  double a_hi = jump[0]*(0.5*gm1*vsq - u*c);         // acoustic wave u + c
+  a_hi -= jump[1]*(gm1*u - c);
+  a_hi -= jump[2]*gm1*v;
+  a_hi -= jump[3]*gm1*w;
+  a_hi += jump[4]*gm1;
+  a_hi *= half_icsq;
+  const double k_lo = -0.5*fabs(lam_lo)*a_lo, k_v = -0.5*fabs(u)*a_v, k_w = -0.5*fabs(u)*a_w,
+               k_s = -0.5*fabs(u)*a_s, k_hi = -0.5*fabs(lam_hi)*a_hi;
+  bool fallback = false;
+  double dmid = dl + a_lo;
+  if (dmid < 0.0) fallback = true;
+  dmid += a_s;
+  if (dmid < 0.0) fallback = true;
+  f[0] += k_lo;
+  f[0] += k_s;
+  f[0] += k_hi;
+  f[1] += k_lo*(u - c);
+  f[1] += k_s*u;
+  f[1] += k_hi*(u + c);
+  f[2] += k_lo*v;
+  f[2] += k_v;
+  f[2] += k_s*v;
+  f[2] += k_hi*v;
+  f[3] += k_lo*w;
+  f[3] += k_w;
+  f[3] += k_s*w;
+  f[3] += k_hi*w;
+  f[4] += k_lo*(h - u*c);
+  f[4] += k_v*v;
+  f[4] += k_w*w;
+  f[4] += k_s*0.5*vsq;
+  f[4] += k_hi*(h + u*c);
+  if (lam_lo >= 0.0) {
 #pragma unroll
     for (int n = 0; n < 5; ++n) f[n] = fl[n];
   }
-  if (ev[4] <= 0.0) {
+  if (lam_hi <= 0.0) {
 #pragma unroll
     for (int n = 0; n < 5; ++n) f[n] = fr[n];
   }
-  if (llf_flag) {
-    double cl = sqrt(gamma*wli[4]/wli[0]);
-    double cr = sqrt(gamma*wri[4]/wri[0]);
-    double a = 0.5*fmax((fabs(wli[1]) + cl), (fabs(wri[1]) + cr));
+  if (fallback) {
+    const double cl = sqrt(gamma*pl/dl), cr = sqrt(gamma*pr/dr);
+    const double half_smax = 0.5*fmax((fabs(ul) + cl), (fabs(ur) + cr));
 #pragma unroll
-    for (int n = 0; n < 5; ++n) f[n] = 0.5*(fl[n] + fr[n]) - a*du[n];
+    for (int n = 0; n < 5; ++n) f[n] = 0.5*(fl[n] + fr[n]) - half_smax*jump[n];
   }
   f_d = f[0]; f_mx = f[1]; f_my = f[2]; f_mz = f[3]; f_e = f[4];
 }
 
-// Advect, src/hydro/rsolvers/advect_hyd.hpp:19-55: upwind flux by the sign of the left normal
-// velocity (kinematic runs).  As in the reference the transverse components are velocity times
-// velocity (no density factor) and the energy component is e_int*v.
-AKMI_DEV void advect_hyd(double ld, double lx, double ly, double lz, double le, double rd, double rx,
-                         double ry, double rz, double re, double &f_d, double &f_mx, double &f_my,
-                         double &f_mz, double &f_e) {
-  if (lx >= 0.0) {
-    f_d = ld*lx; f_mx = ld*lx*lx; f_my = ly*lx; f_mz = lz*lx; f_e = le*lx;
-  } else {
-    f_d = rd*rx; f_mx = rd*rx*rx; f_my = ry*rx; f_mz = rz*rx; f_e = re*rx;
-  }
+// Advect, src/hydro/rsolvers/advect_hyd.hpp:19-55: upwind flux by the sign of the left normal velocity
+// (kinematic runs).  As in the reference the transverse components are velocity times velocity (no density
+// factor) and the energy component is e_int*u.
+AKMI_DEV void advect_hyd(double dl, double ul, double vl, double wl, double el, double dr, double ur, double vr,
+                         double wr, double er, double &f_d, double &f_mx, double &f_my, double &f_mz, double &f_e) {
+  const bool from_left = ul >= 0.0;
+  const double d = from_left ? dl : dr, u = from_left ? ul : ur, v = from_left ? vl : vr, w = from_left ? wl : wr,
+               e = from_left ? el : er;
+  f_d = d*u; f_mx = d*u*u; f_my = v*u; f_mz = w*u; f_e = e*u;
 }
 
 // Hydro_RSolver selection at compile time: RS = AKMI_RS_LLF 0, HLLE 1, HLLC 2, ROE 4, ADVECT 5
 template <int RS>
-AKMI_DEV void riemann_hyd(double gamma, double ld, double lx, double ly, double lz, double le,
-                          double rd, double rx, double ry, double rz, double re, double &f_d,
-                          double &f_mx, double &f_my, double &f_mz, double &f_e) {
-  if constexpr (RS == 0) llf_hyd(gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, f_d, f_mx, f_my, f_mz, f_e);
-  else if constexpr (RS == 1) hlle_hyd(gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, f_d, f_mx, f_my, f_mz, f_e);
-  else if constexpr (RS == 4) roe_hyd(gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, f_d, f_mx, f_my, f_mz, f_e);
-  else if constexpr (RS == 5) advect_hyd(ld, lx, ly, lz, le, rd, rx, ry, rz, re, f_d, f_mx, f_my, f_mz, f_e);
-  else hllc(gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, f_d, f_mx, f_my, f_mz, f_e);
+AKMI_DEV void riemann_hyd(double gamma, double dl, double ul, double vl, double wl, double el, double dr,
+                          double ur, double vr, double wr, double er, double &f_d, double &f_mx, double &f_my,
+                          double &f_mz, double &f_e) {
+  if constexpr (RS == 0) llf_hyd(gamma, dl, ul, vl, wl, el, dr, ur, vr, wr, er, f_d, f_mx, f_my, f_mz, f_e);
+  else if constexpr (RS == 1) hlle_hyd(gamma, dl, ul, vl, wl, el, dr, ur, vr, wr, er, f_d, f_mx, f_my, f_mz, f_e);
+  else if constexpr (RS == 4) roe_hyd(gamma, dl, ul, vl, wl, el, dr, ur, vr, wr, er, f_d, f_mx, f_my, f_mz, f_e);
+  else if constexpr (RS == 5) advect_hyd(dl, ul, vl, wl, el, dr, ur, vr, wr, er, f_d, f_mx, f_my, f_mz, f_e);
+  else hllc(gamma, dl, ul, vl, wl, el, dr, ur, vr, wr, er, f_d, f_mx, f_my, f_mz, f_e);
 }
 
-// IdealMHDFastSpeed, src/eos/eos.hpp:49-57.  FM: the short square root (sqrt_x) -- chosen per call site,
-// like the early-outs of hlld(): it pays in the issue-bound k_sweep12s (1137 -> 1099 us) and costs the
-// memory-latency-bound marches registers and basic blocks (x3 march 984 -> 1020 us), profiles/r03_ab1.txt
-template <bool FM = false>
-AKMI_DEV double fast_speed(double gamma, double d, double p, double bx, double by, double bz) {
-  double asq = gamma*p;
-  double ct2 = by*by + bz*bz;
-  double qsq = bx*bx + ct2 + asq;
-  double tmp = bx*bx + ct2 - asq;
-  return sqrt_x<FM>(0.5*(qsq + sqrt_x<FM>(tmp*tmp + 4.0*asq*ct2))/d);
-}
-
+// =======================================================================================
+// MHD.  A state is (d, u, v, w, e, by, bz) with u and the face field bn along the sweep; fluxes are Cons1D in the
+// same frame: .by / .bz are F(by), F(bz) -- the caller stores ey = -F(by), ez = +F(bz) (hlld_mhd.hpp:346-347).
+// =======================================================================================
 struct Cons1D { double d, mx, my, mz, e, by, bz; };
 
-// HLLD (ideal gas), src/mhd/rsolvers/hlld_mhd.hpp:41-347.  Returns the 7-component flux
-// (d,mx,my,mz,E,by,bz); the caller forms ey=-F(by), ez=+F(bz) (:346-347).
-// EO: skip intermediate states no lane of the wave needs (see below).  Thread-per-face kernels gain
-// (x1 sweep 689 -> 637 us at 256^3); the marching kernels sit at their register limit and lose
-// (x2 march 877 -> 1011 us with 28 B of scratch): profiles/r02_hlld_earlyout.txt.  Chosen per call site.
+// fast magnetosonic speed from  a^2 = gamma p,  ct^2 = by^2 + bz^2,  bn  (IdealMHDFastSpeed, src/eos/eos.hpp:49-57):
+// cf^2 = ( (bn^2 + ct^2 + a^2) + sqrt((bn^2 + ct^2 - a^2)^2 + 4 a^2 ct^2) ) / (2 d)
+// FM: the short square root (sqrt_x) -- chosen per call site, like the early-outs of hlld(): it pays in the
+// issue-bound k_sweep12s (1137 -> 1099 us) and costs the memory-latency-bound marches registers and basic blocks
+// (x3 march 984 -> 1020 us), profiles/r03_ab1.txt
+template <bool FM = false>
+AKMI_DEV double fast_speed_of(double asq, double d, double bn, double by, double bz) {
+  const double ct2 = by*by + bz*bz;
+  const double total = bn*bn + ct2 + asq;
+  const double diff = bn*bn + ct2 - asq;
+  return sqrt_x<FM>(0.5*(total + sqrt_x<FM>(diff*diff + 4.0*asq*ct2))/d);
+}
+template <bool FM = false>
+AKMI_DEV double fast_speed(double gamma, double d, double p, double bn, double by, double bz) {
+  return fast_speed_of<FM>(gamma*p, d, bn, by, bz);
+}
+
+// HLLD (Miyoshi & Kusano 2005, ideal gas), src/mhd/rsolvers/hlld_mhd.hpp:41-347.
+//
+// The fan has five waves  sL <= sAL <= sM <= sAR <= sR  (outer fast waves, the two rotational waves, the contact) and
+// the flux is, per face,
+//     F_S                                  outside the fan                       (S = the upwind side)
+//     F_S + sS (U*_S - U_S)                between an outer and a rotational wave
+//     F_S + sS (U*_S - U_S) + sAS (U**_S - U*_S)    between a rotational wave and the contact
+// i.e. every face needs the physical flux, the star state and (sometimes) the double-star state of ONE side only --
+// the side the contact has moved away from.  The reference evaluates both sides, all four intermediate states and all
+// differences and picks at the end; here the order is
+//   1. what both sides contribute to the five speeds and the total star pressure        (scalars, both sides)
+//   2. the selection                                                                    (per lane)
+//   3. if a lane of the wave needs a double-star state: the transverse star components of BOTH sides and the four
+//      common double-star values (they mix the two sides)
+//   4. everything else -- F, U, U*, E*, U**, the differences and the sum -- for the lane's own side S, on operands
+//      picked per lane with selects.  Left and right formulas are the same sequence of operations on mirrored
+//      operands; the two places where a sign differs (sAL = sM - |bn|/sqrt(d*), sAR = sM + ..;  E**_L = E* - X,
+//      E**_R = E* + X) are x + y == x - (-y), exact in IEEE arithmetic.
+// Per value the operations are the reference's, so the result is bit-identical; what changes is that a lane carries
+// one side's seven-vectors instead of two sides' (registers) and computes one flux, one star state and one set of
+// differences instead of two, four and four (instructions).
+//   value (S = l or r)             reference lines          value                          reference lines
+//   E, pt, cf                      :66-88                    transverse star (my,mz,by,bz)   :171-190 (l) :203-222 (r)
+//   sL, sR, sM                     :91-92, :128-131          vb*, E*                          :192-200, :224-232
+//   d*, 1/d*, sqrt(d*), sAL, sAR   :139-151                  double star                      :235-277
+//   pt* (both), mean               :154-156                  differences, selection, sum      :280-344
+// EO: wave-uniform early-outs -- skip step 3 when no lane of the wave needs a double-star state, and steps 3-4 when
+// every lane is outside the fan.  FM: short square roots.  Both are chosen per call site (registers, see callers).
 #ifndef AKMI_HLLD_EARLYOUT
 #define AKMI_HLLD_EARLYOUT 1
 #endif
-template <bool EO = false, bool FM = false>
-AKMI_DEV Cons1D hlld(double gamma, double wl_idn, double wl_ivx, double wl_ivy, double wl_ivz,
-                     double wl_ien, double wl_iby, double wl_ibz, double wr_idn, double wr_ivx,
-                     double wr_ivy, double wr_ivz, double wr_ien, double wr_iby, double wr_ibz,
-                     double bxi) {
-  constexpr double SMALL = 1.0e-4;  // HLLD_SMALL_NUMBER, hlld_mhd.hpp:18
-  double gm1 = gamma - 1.0;
-  double igm1 = 1.0/gm1;
-  double wl_ipr = (gamma - 1.0)*wl_ien;
-  double wr_ipr = (gamma - 1.0)*wr_ien;
-
-  double bxsq = bxi*bxi;
-  double pbl = 0.5*(bxsq + (sqr(wl_iby) + sqr(wl_ibz)));
-  double pbr = 0.5*(bxsq + (sqr(wr_iby) + sqr(wr_ibz)));
-  double kel = 0.5*wl_idn*(sqr(wl_ivx) + (sqr(wl_ivy) + sqr(wl_ivz)));
-  double ker = 0.5*wr_idn*(sqr(wr_ivx) + (sqr(wr_ivy) + sqr(wr_ivz)));
-
-  Cons1D ul, ur;
-  ul.d = wl_idn; ul.mx = wl_ivx*ul.d; ul.my = wl_ivy*ul.d; ul.mz = wl_ivz*ul.d;
-  ul.e = wl_ipr*igm1 + kel + pbl; ul.by = wl_iby; ul.bz = wl_ibz;
-  ur.d = wr_idn; ur.mx = wr_ivx*ur.d; ur.my = wr_ivy*ur.d; ur.mz = wr_ivz*ur.d;
-  ur.e = wr_ipr*igm1 + ker + pbr; ur.by = wr_iby; ur.bz = wr_ibz;
-
-  double cfl = fast_speed<FM>(gamma, wl_idn, wl_ipr, bxi, wl_iby, wl_ibz);
-  double cfr = fast_speed<FM>(gamma, wr_idn, wr_ipr, bxi, wr_iby, wr_ibz);
-  double spd0 = fmin(wl_ivx - cfl, wr_ivx - cfr);
-  double spd4 = fmax(wl_ivx + cfl, wr_ivx + cfr);
-
-  double ptl = wl_ipr + pbl;
-  double ptr = wr_ipr + pbr;
-
-  Cons1D fl, fr, flxi;
-  fl.d = ul.mx;
-  fl.mx = ul.mx*wl_ivx + ptl - bxsq;
-  fl.my = ul.my*wl_ivx - bxi*ul.by;
-  fl.mz = ul.mz*wl_ivx - bxi*ul.bz;
-  fl.e = wl_ivx*(ul.e + ptl - bxsq) - bxi*(wl_ivy*ul.by + wl_ivz*ul.bz);
-  fl.by = ul.by*wl_ivx - bxi*wl_ivy;
-  fl.bz = ul.bz*wl_ivx - bxi*wl_ivz;
-
-  fr.d = ur.mx;
-  fr.mx = ur.mx*wr_ivx + ptr - bxsq;
-  fr.my = ur.my*wr_ivx - bxi*ur.by;
-  fr.mz = ur.mz*wr_ivx - bxi*ur.bz;
-  fr.e = wr_ivx*(ur.e + ptr - bxsq) - bxi*(wr_ivy*ur.by + wr_ivz*ur.bz);
-  fr.by = ur.by*wr_ivx - bxi*wr_ivy;
-  fr.bz = ur.bz*wr_ivx - bxi*wr_ivz;
-
-  double sdl = spd0 - wl_ivx;
-  double sdr = spd4 - wr_ivx;
-  double spd2 = (sdr*ur.mx - sdl*ul.mx + (ptl - ptr))/(sdr*ur.d - sdl*ul.d);
-
-  double sdml = spd0 - spd2;
-  double sdmr = spd4 - spd2;
-  double sdml_inv = rcp_x<FM && AKMI_HLLD_FAST_RCP>(sdml);
-  double sdmr_inv = rcp_x<FM && AKMI_HLLD_FAST_RCP>(sdmr);
-
-  Cons1D ulst, uldst, urdst, urst;
-  ulst.d = ul.d*sdl*sdml_inv;
-  urst.d = ur.d*sdr*sdmr_inv;
-  double ulst_d_inv = rcp_x<FM && AKMI_HLLD_FAST_RCP>(ulst.d);
-  double urst_d_inv = rcp_x<FM && AKMI_HLLD_FAST_RCP>(urst.d);
-  double sqrtdl = sqrt_x<FM>(ulst.d);
-  double sqrtdr = sqrt_x<FM>(urst.d);
-
-  double spd1 = spd2 - fabs(bxi)/sqrtdl;
-  double spd3 = spd2 + fabs(bxi)/sqrtdr;
-
-  double ptstl = ptl + ul.d*sdl*(spd2 - wl_ivx);
-  double ptstr = ptr + ur.d*sdr*(spd2 - wr_ivx);
-  double ptst = 0.5*(ptstr + ptstl);
-
-  // Which intermediate states the selected flux needs (the selection below is the reference's,
-  // hlld_mhd.hpp:313-344): F_L and F_R none; F*_L only U*_L; F*_R only U*_R; the double-star fluxes
-  // both star states and the double-star states.  A state no lane of the wave needs is not computed
-  // (wave-uniform branch, no divergence): in super-Alfvenic smooth flow whole waves take F*_L or F*_R
-  // and skip half of the solver.  A state that IS computed is computed exactly as before.
-#if AKMI_HLLD_EARLYOUT
-  bool need_l = true, need_r = true, need_ds = true;
-  if constexpr (EO) {
-  // the branch of the selection below, by the same chain of comparisons (NaNs fall through alike)
-  const int sel = (spd0 >= 0.0) ? 0 : (spd4 <= 0.0) ? 1 : (spd1 >= 0.0) ? 2 : (spd2 >= 0.0) ? 3 : (spd3 > 0.0) ? 4 : 5;
-  need_l = __any(sel >= 2 && sel <= 4);
-  need_r = __any(sel >= 3);
-  need_ds = __any(sel == 3 || sel == 4);
-  }
-#else
-  constexpr bool need_l = true, need_r = true, need_ds = true;
-#endif
-  double vbstl = 0.0, vbstr = 0.0;
-  if (need_l) {
-    ulst.mx = ulst.d*spd2;
-    if (fabs(ul.d*sdl*sdml - bxsq) < (SMALL)*ptst) {
-      ulst.my = ulst.d*wl_ivy;
-      ulst.mz = ulst.d*wl_ivz;
-      ulst.by = ul.by;
-      ulst.bz = ul.bz;
-    } else {
-      double tmp = bxi*(sdl - sdml)/(ul.d*sdl*sdml - bxsq);
-      ulst.my = ulst.d*(wl_ivy - ul.by*tmp);
-      ulst.mz = ulst.d*(wl_ivz - ul.bz*tmp);
-      tmp = (ul.d*sqr(sdl) - bxsq)/(ul.d*sdl*sdml - bxsq);
-      ulst.by = ul.by*tmp;
-      ulst.bz = ul.bz*tmp;
-    }
-    vbstl = (ulst.mx*bxi + (ulst.my*ulst.by + ulst.mz*ulst.bz))*ulst_d_inv;
-    ulst.e = (sdl*ul.e - ptl*wl_ivx + ptst*spd2 +
-              bxi*(wl_ivx*bxi + (wl_ivy*ul.by + wl_ivz*ul.bz) - vbstl))*sdml_inv;
-
-  }
-  if (need_r) {
-    urst.mx = urst.d*spd2;
-    if (fabs(ur.d*sdr*sdmr - bxsq) < (SMALL)*ptst) {
-      urst.my = urst.d*wr_ivy;
-      urst.mz = urst.d*wr_ivz;
-      urst.by = ur.by;
-      urst.bz = ur.bz;
-    } else {
-      double tmp = bxi*(sdr - sdmr)/(ur.d*sdr*sdmr - bxsq);
-      urst.my = urst.d*(wr_ivy - ur.by*tmp);
-      urst.mz = urst.d*(wr_ivz - ur.bz*tmp);
-      tmp = (ur.d*sqr(sdr) - bxsq)/(ur.d*sdr*sdmr - bxsq);
-      urst.by = ur.by*tmp;
-      urst.bz = ur.bz*tmp;
-    }
-    vbstr = (urst.mx*bxi + (urst.my*urst.by + urst.mz*urst.bz))*urst_d_inv;
-    urst.e = (sdr*ur.e - ptr*wr_ivx + ptst*spd2 +
-              bxi*(wr_ivx*bxi + (wr_ivy*ur.by + wr_ivz*ur.bz) - vbstr))*sdmr_inv;
-
-  }
-  if (need_ds) {
-    if (0.5*bxsq < (SMALL)*ptst) {
-      uldst = ulst;
-      urdst = urst;
-    } else {
-      double invsumd = rcp_x<FM && AKMI_HLLD_FAST_RCP>(sqrtdl + sqrtdr);
-      double bxsig = (bxi > 0.0 ? 1.0 : -1.0);
-      uldst.d = ulst.d;
-      urdst.d = urst.d;
-      uldst.mx = ulst.mx;
-      urdst.mx = urst.mx;
-      double tmp = invsumd*(sqrtdl*(ulst.my*ulst_d_inv) + sqrtdr*(urst.my*urst_d_inv) +
-                            bxsig*(urst.by - ulst.by));
-      uldst.my = uldst.d*tmp;
-      urdst.my = urdst.d*tmp;
-      tmp = invsumd*(sqrtdl*(ulst.mz*ulst_d_inv) + sqrtdr*(urst.mz*urst_d_inv) +
-                     bxsig*(urst.bz - ulst.bz));
-      uldst.mz = uldst.d*tmp;
-      urdst.mz = urdst.d*tmp;
-      tmp = invsumd*(sqrtdl*urst.by + sqrtdr*ulst.by +
-                     bxsig*sqrtdl*sqrtdr*((urst.my*urst_d_inv) - (ulst.my*ulst_d_inv)));
-      uldst.by = urdst.by = tmp;
-      tmp = invsumd*(sqrtdl*urst.bz + sqrtdr*ulst.bz +
-                     bxsig*sqrtdl*sqrtdr*((urst.mz*urst_d_inv) - (ulst.mz*ulst_d_inv)));
-      uldst.bz = urdst.bz = tmp;
-      tmp = spd2*bxi + (uldst.my*uldst.by + uldst.mz*uldst.bz)/uldst.d;
-      uldst.e = ulst.e - sqrtdl*bxsig*(vbstl - tmp);
-      urdst.e = urst.e + sqrtdr*bxsig*(vbstr - tmp);
-    }
-
-    uldst.d = spd1*(uldst.d - ulst.d);
-    uldst.mx = spd1*(uldst.mx - ulst.mx);
-    uldst.my = spd1*(uldst.my - ulst.my);
-    uldst.mz = spd1*(uldst.mz - ulst.mz);
-    uldst.e = spd1*(uldst.e - ulst.e);
-    uldst.by = spd1*(uldst.by - ulst.by);
-    uldst.bz = spd1*(uldst.bz - ulst.bz);
-
-  }
-  if (need_l) {
-    ulst.d = spd0*(ulst.d - ul.d);
-    ulst.mx = spd0*(ulst.mx - ul.mx);
-    ulst.my = spd0*(ulst.my - ul.my);
-    ulst.mz = spd0*(ulst.mz - ul.mz);
-    ulst.e = spd0*(ulst.e - ul.e);
-    ulst.by = spd0*(ulst.by - ul.by);
-    ulst.bz = spd0*(ulst.bz - ul.bz);
-
-  }
-  if (need_ds) {
-    urdst.d = spd3*(urdst.d - urst.d);
-    urdst.mx = spd3*(urdst.mx - urst.mx);
-    urdst.my = spd3*(urdst.my - urst.my);
-    urdst.mz = spd3*(urdst.mz - urst.mz);
-    urdst.e = spd3*(urdst.e - urst.e);
-    urdst.by = spd3*(urdst.by - urst.by);
-    urdst.bz = spd3*(urdst.bz - urst.bz);
-
-  }
-  if (need_r) {
-    urst.d = spd4*(urst.d - ur.d);
-    urst.mx = spd4*(urst.mx - ur.mx);
-    urst.my = spd4*(urst.my - ur.my);
-    urst.mz = spd4*(urst.mz - ur.mz);
-    urst.e = spd4*(urst.e - ur.e);
-    urst.by = spd4*(urst.by - ur.by);
-    urst.bz = spd4*(urst.bz - ur.bz);
-
-  }
-  if (spd0 >= 0.0) {
-    flxi = fl;
-  } else if (spd4 <= 0.0) {
-    flxi = fr;
-  } else if (spd1 >= 0.0) {
-    flxi.d = fl.d + ulst.d;     flxi.mx = fl.mx + ulst.mx;
-    flxi.my = fl.my + ulst.my;  flxi.mz = fl.mz + ulst.mz;
-    flxi.e = fl.e + ulst.e;     flxi.by = fl.by + ulst.by;  flxi.bz = fl.bz + ulst.bz;
-  } else if (spd2 >= 0.0) {
-    flxi.d = fl.d + ulst.d + uldst.d;      flxi.mx = fl.mx + ulst.mx + uldst.mx;
-    flxi.my = fl.my + ulst.my + uldst.my;  flxi.mz = fl.mz + ulst.mz + uldst.mz;
-    flxi.e = fl.e + ulst.e + uldst.e;
-    flxi.by = fl.by + ulst.by + uldst.by;  flxi.bz = fl.bz + ulst.bz + uldst.bz;
-  } else if (spd3 > 0.0) {
-    flxi.d = fr.d + urst.d + urdst.d;      flxi.mx = fr.mx + urst.mx + urdst.mx;
-    flxi.my = fr.my + urst.my + urdst.my;  flxi.mz = fr.mz + urst.mz + urdst.mz;
-    flxi.e = fr.e + urst.e + urdst.e;
-    flxi.by = fr.by + urst.by + urdst.by;  flxi.bz = fr.bz + urst.bz + urdst.bz;
+struct StarT { double my, mz, by, bz; };             // transverse components of a star state
+// :171-190 / :203-222 -- d = density, a = s - u, c = s - sM, da = d*a, ds = star density of the side
+AKMI_DEV StarT hlld_star_transverse(double d, double a, double c, double da, double ds, double v, double w,
+                                    double by, double bz, double bn, double bn2, double small_pt) {
+  StarT s;
+  const double den = da*c - bn2;
+  if (fabs(den) < small_pt) {                        // the rotational wave coincides with the outer one
+    s.my = ds*v;
+    s.mz = ds*w;
+    s.by = by;
+    s.bz = bz;
   } else {
-    flxi.d = fr.d + urst.d;     flxi.mx = fr.mx + urst.mx;
-    flxi.my = fr.my + urst.my;  flxi.mz = fr.mz + urst.mz;
-    flxi.e = fr.e + urst.e;     flxi.by = fr.by + urst.by;  flxi.bz = fr.bz + urst.bz;
+    const double kv = bn*(a - c)/den;
+    s.my = ds*(v - by*kv);
+    s.mz = ds*(w - bz*kv);
+    const double kb = (d*sqr(a) - bn2)/den;
+    s.by = by*kb;
+    s.bz = bz*kb;
   }
-  return flxi;
+  return s;
 }
 
-// LLF for MHD, src/mhd/rsolvers/llf_mhd_singlestate.hpp:28-89 (ideal gas).  by/bz of the
-// result are F(by), F(bz) in the convention of hlld(): the caller stores ey=-by, ez=+bz.
-AKMI_DEV Cons1D llf_mhd(double gamma, double ld, double lx, double ly, double lz, double le,
-                        double lby, double lbz, double rd, double rx, double ry, double rz,
-                        double re, double rby, double rbz, double bxi) {
-  double qa = ld*lx;
-  double qb = rd*rx;
-  double qc = 0.5*(sqr(lby) + sqr(lbz) - sqr(bxi));
-  double qd = 0.5*(sqr(rby) + sqr(rbz) - sqr(bxi));
-  double s_d = qa + qb;
-  double s_mx = qa*lx + qb*rx + qc + qd;
-  double s_my = qa*ly + qb*ry - bxi*(lby + rby);
-  double s_mz = qa*lz + qb*rz - bxi*(lbz + rbz);
-  double s_by = lby*lx + rby*rx - bxi*(ly + ry);
-  double s_bz = lbz*lx + rbz*rx - bxi*(lz + rz);
-  double pl = (gamma - 1.0)*le;
-  double pr = (gamma - 1.0)*re;
-  double el = le + 0.5*ld*(sqr(lx) + sqr(ly) + sqr(lz)) + qc + sqr(bxi);
-  double er = re + 0.5*rd*(sqr(rx) + sqr(ry) + sqr(rz)) + qd + sqr(bxi);
-  s_mx += (pl + pr);
-  double s_e = (el + pl + qc)*lx + (er + pr + qd)*rx;
-  s_e -= bxi*(lby*ly + lbz*lz);
-  s_e -= bxi*(rby*ry + rbz*rz);
-  qa = fast_speed(gamma, ld, pl, bxi, lby, lbz);
-  qb = fast_speed(gamma, rd, pr, bxi, rby, rbz);
-  double a = fmax((fabs(lx) + qa), (fabs(rx) + qb));
+template <bool EO = false, bool FM = false>
+AKMI_DEV Cons1D hlld(double gamma, double dl, double ul, double vl, double wl, double el, double byl, double bzl,
+                     double dr, double ur, double vr, double wr, double er, double byr, double bzr, double bn) {
+  constexpr double SMALL = 1.0e-4;                   // HLLD_SMALL_NUMBER, hlld_mhd.hpp:18
+  const double gm1 = gamma - 1.0;
+  const double igm1 = 1.0/gm1;
+  const double bn2 = bn*bn;
+  // ---- 1. both sides: pressure, total energy, total pressure, fast speed -> the five speeds, the star densities
+  const double pl = (gamma - 1.0)*el, pr = (gamma - 1.0)*er;
+  const double pml = 0.5*(bn2 + (sqr(byl) + sqr(bzl))), pmr = 0.5*(bn2 + (sqr(byr) + sqr(bzr)));
+  const double El = pl*igm1 + 0.5*dl*(sqr(ul) + (sqr(vl) + sqr(wl))) + pml;
+  const double Er = pr*igm1 + 0.5*dr*(sqr(ur) + (sqr(vr) + sqr(wr))) + pmr;
+  const double cfl = fast_speed<FM>(gamma, dl, pl, bn, byl, bzl), cfr = fast_speed<FM>(gamma, dr, pr, bn, byr, bzr);
+  const double sL = fmin(ul - cfl, ur - cfr), sR = fmax(ul + cfl, ur + cfr);
+  const double ptl = pl + pml, ptr = pr + pmr;
+  const double al = sL - ul, ar = sR - ur;                                      // speed of the outer wave relative to the gas
+  const double sM = (ar*(ur*dr) - al*(ul*dl) + (ptl - ptr))/(ar*dr - al*dl);    // contact
+  const double cl = sL - sM, cr = sR - sM;
+  const double icl = rcp_x<FM && AKMI_HLLD_FAST_RCP>(cl), icr = rcp_x<FM && AKMI_HLLD_FAST_RCP>(cr);
+  const double dal = dl*al, dar = dr*ar;
+  const double dsl = dal*icl, dsr = dar*icr;                                    // star densities
+  const double idsl = rcp_x<FM && AKMI_HLLD_FAST_RCP>(dsl), idsr = rcp_x<FM && AKMI_HLLD_FAST_RCP>(dsr);
+  const double rl = sqrt_x<FM>(dsl), rr = sqrt_x<FM>(dsr);
+  const double sAL = sM - fabs(bn)/rl, sAR = sM + fabs(bn)/rr;                   // rotational waves
+  const double ptsl = ptl + dal*(sM - ul), ptsr = ptr + dar*(sM - ur);
+  const double pts = 0.5*(ptsr + ptsl);                                          // total pressure of the star region
+  // ---- 2. which of the six fluxes (the chain of comparisons of :313-344; NaNs fall through alike)
+  const int sel = (sL >= 0.0) ? 0 : (sR <= 0.0) ? 1 : (sAL >= 0.0) ? 2 : (sM >= 0.0) ? 3 : (sAR > 0.0) ? 4 : 5;
+  const bool left = (sel == 0) || (sel == 2) || (sel == 3);      // the side the flux is built on
+  const bool inside = sel >= 2;                                  // needs a star state
+  const bool twice = (sel == 3) || (sel == 4);                   // needs a double-star state
+  bool any_inside = true, any_twice = true;
+#if AKMI_HLLD_EARLYOUT
+  if constexpr (EO) { any_inside = __any(inside); any_twice = __any(twice); }
+#endif
+  // ---- operands of the lane's own side
+  const double d = left ? dl : dr, u = left ? ul : ur, v = left ? vl : vr, w = left ? wl : wr;
+  const double by = left ? byl : byr, bz = left ? bzl : bzr;
+  const double E = left ? El : Er, pt = left ? ptl : ptr;
+  const double mx = u*d, my = v*d, mz = w*d;
+  // physical flux of that side (:94-110)
+  Cons1D F;
+  F.d = mx;
+  F.mx = mx*u + pt - bn2;
+  F.my = my*u - bn*by;
+  F.mz = mz*u - bn*bz;
+  F.e = u*(E + pt - bn2) - bn*(v*by + w*bz);
+  F.by = by*u - bn*v;
+  F.bz = bz*u - bn*w;
+  if (!any_inside) return F;                                     // the whole wave is outside its fans
+  const double small_pt = (SMALL)*pts;
+  // ---- 3. double-star states mix the sides: transverse star components of both, then the four common values
+  StarT T;                                                       // transverse star components of the lane's side
+  double ds_my = 0.0, ds_mz = 0.0, ds_by = 0.0, ds_bz = 0.0, ds_vb = 0.0;      // common double-star v, w, by, bz, v.B
+  bool degenerate = true;                                        // :235 -- no rotational discontinuity: U** = U*
+  double bsign = 1.0;
+  if (any_twice) {
+    const StarT Tl = hlld_star_transverse(dl, al, cl, dal, dsl, vl, wl, byl, bzl, bn, bn2, small_pt);
+    const StarT Tr = hlld_star_transverse(dr, ar, cr, dar, dsr, vr, wr, byr, bzr, bn, bn2, small_pt);
+    degenerate = 0.5*bn2 < small_pt;
+    if (!degenerate) {
+      const double inorm = rcp_x<FM && AKMI_HLLD_FAST_RCP>(rl + rr);
+      bsign = (bn > 0.0 ? 1.0 : -1.0);
+      const double vsl = Tl.my*idsl, vsr = Tr.my*idsr, wsl = Tl.mz*idsl, wsr = Tr.mz*idsr;   // star velocities
+      ds_my = inorm*(rl*vsl + rr*vsr + bsign*(Tr.by - Tl.by));
+      ds_mz = inorm*(rl*wsl + rr*wsr + bsign*(Tr.bz - Tl.bz));
+      ds_by = inorm*(rl*Tr.by + rr*Tl.by + bsign*rl*rr*(vsr - vsl));
+      ds_bz = inorm*(rl*Tr.bz + rr*Tl.bz + bsign*rl*rr*(wsr - wsl));
+      // v.B of the double-star region, from the LEFT double-star state (:272)
+      ds_vb = sM*bn + ((dsl*ds_my)*ds_by + (dsl*ds_mz)*ds_bz)/dsl;
+    }
+    T.my = left ? Tl.my : Tr.my; T.mz = left ? Tl.mz : Tr.mz;
+    T.by = left ? Tl.by : Tr.by; T.bz = left ? Tl.bz : Tr.bz;
+  }
+  // ---- 4. the lane's side
+  const double a = left ? al : ar, c = left ? cl : cr, ic = left ? icl : icr;
+  const double ds = left ? dsl : dsr, ids = left ? idsl : idsr;
+  const double sO = left ? sL : sR, sA = left ? sAL : sAR;
+  if (!any_twice) T = hlld_star_transverse(d, a, c, left ? dal : dar, ds, v, w, by, bz, bn, bn2, small_pt);
+  Cons1D S;                                                      // star state (:169-200 / :201-232)
+  S.d = ds;
+  S.mx = ds*sM;
+  S.my = T.my; S.mz = T.mz; S.by = T.by; S.bz = T.bz;
+  const double vb = (S.mx*bn + (S.my*S.by + S.mz*S.bz))*ids;
+  S.e = (a*E - pt*u + pts*sM + bn*(u*bn + (v*by + w*bz) - vb))*ic;
+  // flux = F + sO (U* - U) [+ sA (U** - U*)]
+  Cons1D out;
+  out.d = F.d + sO*(S.d - d);
+  out.mx = F.mx + sO*(S.mx - mx);
+  out.my = F.my + sO*(S.my - my);
+  out.mz = F.mz + sO*(S.mz - mz);
+  out.e = F.e + sO*(S.e - E);
+  out.by = F.by + sO*(S.by - by);
+  out.bz = F.bz + sO*(S.bz - bz);
+  if (any_twice) {
+    Cons1D D = S;                                                // double-star state; degenerate: the star state
+    if (!degenerate) {
+      D.my = ds*ds_my;
+      D.mz = ds*ds_mz;
+      D.by = ds_by;
+      D.bz = ds_bz;
+      const double r = left ? rl : rr;
+      const double x = r*bsign*(vb - ds_vb);                     // E**_l = E* - x,  E**_r = E* + x
+      D.e = S.e - (left ? x : -x);
+    }
+    const double t_d = out.d + sA*(D.d - S.d), t_mx = out.mx + sA*(D.mx - S.mx), t_my = out.my + sA*(D.my - S.my),
+                 t_mz = out.mz + sA*(D.mz - S.mz), t_e = out.e + sA*(D.e - S.e), t_by = out.by + sA*(D.by - S.by),
+                 t_bz = out.bz + sA*(D.bz - S.bz);
+    if (twice) { out.d = t_d; out.mx = t_mx; out.my = t_my; out.mz = t_mz; out.e = t_e; out.by = t_by; out.bz = t_bz; }
+  }
+  if (!inside) out = F;
+  return out;
+}
+
+// LLF for MHD, src/mhd/rsolvers/llf_mhd_singlestate.hpp:28-89 (ideal gas)
+AKMI_DEV Cons1D llf_mhd(double gamma, double dl, double ul, double vl, double wl, double el, double byl,
+                        double bzl, double dr, double ur, double vr, double wr, double er, double byr, double bzr,
+                        double bn) {
+  const double ml = dl*ul, mr = dr*ur;
+  const double pml = 0.5*(sqr(byl) + sqr(bzl) - sqr(bn)), pmr = 0.5*(sqr(byr) + sqr(bzr) - sqr(bn));   // pm - bn^2
+  const double pl = (gamma - 1.0)*el, pr = (gamma - 1.0)*er;
+  const double El = el + 0.5*dl*(sqr(ul) + sqr(vl) + sqr(wl)) + pml + sqr(bn);
+  const double Er = er + 0.5*dr*(sqr(ur) + sqr(vr) + sqr(wr)) + pmr + sqr(bn);
+  double sum[7];                                      // F(L) + F(R)
+  sum[0] = ml + mr;
+  sum[1] = ml*ul + mr*ur + pml + pmr;
+  sum[2] = ml*vl + mr*vr - bn*(byl + byr);
+  sum[3] = ml*wl + mr*wr - bn*(bzl + bzr);
+  sum[5] = byl*ul + byr*ur - bn*(vl + vr);
+  sum[6] = bzl*ul + bzr*ur - bn*(wl + wr);
+  sum[1] += (pl + pr);
+  sum[4] = (El + pl + pml)*ul + (Er + pr + pmr)*ur;
+  sum[4] -= bn*(byl*vl + bzl*wl);
+  sum[4] -= bn*(byr*vr + bzr*wr);
+  const double cfl = fast_speed(gamma, dl, pl, bn, byl, bzl), cfr = fast_speed(gamma, dr, pr, bn, byr, bzr);
+  const double smax = fmax((fabs(ul) + cfl), (fabs(ur) + cfr));
   Cons1D f;
-  f.d = 0.5*(s_d - a*(rd - ld));
-  f.mx = 0.5*(s_mx - a*(rd*rx - ld*lx));
-  f.my = 0.5*(s_my - a*(rd*ry - ld*ly));
-  f.mz = 0.5*(s_mz - a*(rd*rz - ld*lz));
-  f.e = 0.5*(s_e - a*(er - el));
-  f.by = 0.5*(s_by - a*(rby - lby));
-  f.bz = 0.5*(s_bz - a*(rbz - lbz));
+  f.d = 0.5*(sum[0] - smax*(dr - dl));
+  f.mx = 0.5*(sum[1] - smax*(dr*ur - dl*ul));
+  f.my = 0.5*(sum[2] - smax*(dr*vr - dl*vl));
+  f.mz = 0.5*(sum[3] - smax*(dr*wr - dl*wl));
+  f.e = 0.5*(sum[4] - smax*(Er - El));
+  f.by = 0.5*(sum[5] - smax*(byr - byl));
+  f.bz = 0.5*(sum[6] - smax*(bzr - bzl));
   return f;
 }
 
-// Advect for MHD, src/mhd/rsolvers/advect_mhd.hpp:18-58 (kinematic runs).  .e is NOT a flux: the
-// reference leaves the energy flux untouched, and so do the callers of this function.
-AKMI_DEV Cons1D advect_mhd(double ld, double lx, double ly, double lz, double lby, double lbz,
-                           double rd, double rx, double ry, double rz, double rby, double rbz,
-                           double bxi) {
+// Advect for MHD, src/mhd/rsolvers/advect_mhd.hpp:18-58 (kinematic runs).  .e is NOT a flux: the reference leaves the
+// energy flux untouched, and so do the callers of this function.
+AKMI_DEV Cons1D advect_mhd(double dl, double ul, double vl, double wl, double byl, double bzl, double dr, double ur,
+                           double vr, double wr, double byr, double bzr, double bn) {
+  const bool from_left = ul >= 0.0;
+  const double d = from_left ? dl : dr, u = from_left ? ul : ur, v = from_left ? vl : vr, w = from_left ? wl : wr;
+  const double by = from_left ? byl : byr, bz = from_left ? bzl : bzr;
   Cons1D f;
   f.my = 0.0; f.mz = 0.0; f.e = 0.0;
-  if (lx >= 0.0) {
-    f.d = ld*lx; f.mx = ld*lx*lx;
-    f.by = -(-lby*lx + bxi*ly);            // the caller stores ey = -f.by
-    f.bz = lbz*lx - bxi*lz;
-  } else {
-    f.d = rd*rx; f.mx = rd*rx*rx;
-    f.by = -(-rby*rx + bxi*ry);
-    f.bz = rbz*rx - bxi*rz;
-  }
+  f.d = d*u; f.mx = d*u*u;
+  f.by = -(-by*u + bn*v);                // the caller stores ey = -f.by
+  f.bz = bz*u - bn*w;
   return f;
+}
+
+// Roe averages every HLLE variant for MHD starts from (hlle_mhd.hpp:45-72)
+struct RoeMhd { double d, u, by, bz, x, y, rl, rr, inorm; };
+AKMI_DEV RoeMhd roe_mhd_mean(double dl, double ul, double byl, double bzl, double dr, double ur, double byr,
+                             double bzr) {
+  RoeMhd m;
+  m.rl = sqrt(dl);
+  m.rr = sqrt(dr);
+  m.inorm = 1.0/(m.rl + m.rr);
+  m.d = m.rl*m.rr;
+  m.u = (m.rl*ul + m.rr*ur)*m.inorm;
+  m.by = (m.rr*byl + m.rl*byr)*m.inorm;
+  m.bz = (m.rr*bzl + m.rl*bzr)*m.inorm;
+  m.x = 0.5*(sqr(byl - byr) + sqr(bzl - bzr))/(sqr(m.rl + m.rr));
+  m.y = 0.5*(dl + dr)/m.d;
+  return m;
+}
+// fast speed of the Roe state from its three squared speeds (hlle_mhd.hpp:97-108)
+AKMI_DEV double roe_fast(double vaxsq, double ct2, double asq) {
+  const double total = vaxsq + ct2 + asq;
+  const double diff = vaxsq + ct2 - asq;
+  return sqrt(0.5*(total + sqrt(diff*diff + 4.0*asq*ct2)));
+}
+AKMI_DEV void hll_blend(const Cons1D &fl, const Cons1D &fr, double t, bool with_e, Cons1D &f) {
+  f.d = 0.5*(fl.d + fr.d) + (fl.d - fr.d)*t;
+  f.mx = 0.5*(fl.mx + fr.mx) + (fl.mx - fr.mx)*t;
+  f.my = 0.5*(fl.my + fr.my) + (fl.my - fr.my)*t;
+  f.mz = 0.5*(fl.mz + fr.mz) + (fl.mz - fr.mz)*t;
+  f.e = with_e ? 0.5*(fl.e + fr.e) + (fl.e - fr.e)*t : 0.0;
+  f.by = 0.5*(fl.by + fr.by) + (fl.by - fr.by)*t;
+  f.bz = 0.5*(fl.bz + fr.bz) + (fl.bz - fr.bz)*t;
 }
 
 // HLLE for MHD, src/mhd/rsolvers/hlle_mhd.hpp:24-178 (ideal gas)
-AKMI_DEV Cons1D hlle_mhd(double gamma, double dl, double ul, double vl, double zl, double eil,
-                         double byl, double bzl, double dr, double ur, double vr, double zr,
-                         double eir, double byr, double bzr, double bxi) {
-  double gm1 = gamma - 1.0;
-  double igm1 = 1.0/gm1;
-  double pl = (gamma - 1.0)*eil, pr = (gamma - 1.0)*eir;
-  double sqrtdl = sqrt(dl);
-  double sqrtdr = sqrt(dr);
-  double isdlpdr = 1.0/(sqrtdl + sqrtdr);
-  double roe_d = sqrtdl*sqrtdr;
-  double roe_vx = (sqrtdl*ul + sqrtdr*ur)*isdlpdr;
-  double roe_vy = (sqrtdl*vl + sqrtdr*vr)*isdlpdr;
-  double roe_vz = (sqrtdl*zl + sqrtdr*zr)*isdlpdr;
-  double roe_by = (sqrtdr*byl + sqrtdl*byr)*isdlpdr;
-  double roe_bz = (sqrtdr*bzl + sqrtdl*bzr)*isdlpdr;
-  double x = 0.5*(sqr(byl - byr) + sqr(bzl - bzr))/(sqr(sqrtdl + sqrtdr));
-  double y = 0.5*(dl + dr)/roe_d;
-  double pbl = 0.5*(bxi*bxi + sqr(byl) + sqr(bzl));
-  double pbr = 0.5*(bxi*bxi + sqr(byr) + sqr(bzr));
-  double el = pl*igm1 + 0.5*dl*(sqr(ul) + sqr(vl) + sqr(zl)) + pbl;
-  double er = pr*igm1 + 0.5*dr*(sqr(ur) + sqr(vr) + sqr(zr)) + pbr;
-  double hroe = ((el + pl + pbl)/sqrtdl + (er + pr + pbr)/sqrtdr)*isdlpdr;
-  double cl = fast_speed(gamma, dl, pl, bxi, byl, bzl);
-  double cr = fast_speed(gamma, dr, pr, bxi, byr, bzr);
-  double btsq = sqr(roe_by) + sqr(roe_bz);
-  double vaxsq = bxi*bxi/roe_d;
-  double bt_starsq = (gm1 - (gm1 - 1.0)*y)*btsq;
-  double hp = hroe - (vaxsq + btsq/roe_d);
-  double vsq = sqr(roe_vx) + sqr(roe_vy) + sqr(roe_vz);
-  double twid_asq = fmax((gm1*(hp - 0.5*vsq) - (gm1 - 1.0)*x), 0.0);
-  double ct2 = bt_starsq/roe_d;
-  double tsum = vaxsq + ct2 + twid_asq;
-  double tdif = vaxsq + ct2 - twid_asq;
-  double cf2_cs2 = sqrt(tdif*tdif + 4.0*twid_asq*ct2);
-  double cfsq = 0.5*(tsum + cf2_cs2);
-  double a = sqrt(cfsq);
-  double al = fmin((roe_vx - a), (ul - cl));
-  double ar = fmax((roe_vx + a), (ur + cr));
-  double bp = ar > 0.0 ? ar : 1.0e-20;
-  double bm = al < 0.0 ? al : -1.0e-20;
-  double vxl = ul - bm;
-  double vxr = ur - bp;
-  double fl_d = dl*vxl, fr_d = dr*vxr;
-  double fl_mx = dl*ul*vxl + pbl - sqr(bxi);
-  double fr_mx = dr*ur*vxr + pbr - sqr(bxi);
-  double fl_my = dl*vl*vxl - bxi*byl;
-  double fr_my = dr*vr*vxr - bxi*byr;
-  double fl_mz = dl*zl*vxl - bxi*bzl;
-  double fr_mz = dr*zr*vxr - bxi*bzr;
-  fl_mx += pl;
-  fr_mx += pr;
-  double fl_e = el*vxl + ul*(pl + pbl - bxi*bxi);
-  double fr_e = er*vxr + ur*(pr + pbr - bxi*bxi);
-  fl_e -= bxi*(byl*vl + bzl*zl);
-  fr_e -= bxi*(byr*vr + bzr*zr);
-  double fl_by = byl*vxl - bxi*vl;
-  double fr_by = byr*vxr - bxi*vr;
-  double fl_bz = bzl*vxl - bxi*zl;
-  double fr_bz = bzr*vxr - bxi*zr;
-  double tmp = 0.0;
-  if (bp != bm) tmp = 0.5*(bp + bm)/(bp - bm);
+AKMI_DEV Cons1D hlle_mhd(double gamma, double dl, double ul, double vl, double wl, double el, double byl,
+                         double bzl, double dr, double ur, double vr, double wr, double er, double byr, double bzr,
+                         double bn) {
+  const double gm1 = gamma - 1.0;
+  const double igm1 = 1.0/gm1;
+  const double pl = (gamma - 1.0)*el, pr = (gamma - 1.0)*er;
+  const RoeMhd m = roe_mhd_mean(dl, ul, byl, bzl, dr, ur, byr, bzr);
+  const double v_roe = (m.rl*vl + m.rr*vr)*m.inorm, w_roe = (m.rl*wl + m.rr*wr)*m.inorm;
+  const double pml = 0.5*(bn*bn + sqr(byl) + sqr(bzl)), pmr = 0.5*(bn*bn + sqr(byr) + sqr(bzr));
+  const double El = pl*igm1 + 0.5*dl*(sqr(ul) + sqr(vl) + sqr(wl)) + pml;
+  const double Er = pr*igm1 + 0.5*dr*(sqr(ur) + sqr(vr) + sqr(wr)) + pmr;
+  const double h_roe = ((El + pl + pml)/m.rl + (Er + pr + pmr)/m.rr)*m.inorm;
+  const double cfl = fast_speed(gamma, dl, pl, bn, byl, bzl), cfr = fast_speed(gamma, dr, pr, bn, byr, bzr);
+  const double btsq = sqr(m.by) + sqr(m.bz);
+  const double vaxsq = bn*bn/m.d;
+  const double bt_starsq = (gm1 - (gm1 - 1.0)*m.y)*btsq;
+  const double hp = h_roe - (vaxsq + btsq/m.d);
+  const double vsq = sqr(m.u) + sqr(v_roe) + sqr(w_roe);
+  const double asq = fmax((gm1*(hp - 0.5*vsq) - (gm1 - 1.0)*m.x), 0.0);
+  const double c_roe = roe_fast(vaxsq, bt_starsq/m.d, asq);
+  const double smin = fmin((m.u - c_roe), (ul - cfl)), smax = fmax((m.u + c_roe), (ur + cfr));
+  const double bp = smax > 0.0 ? smax : 1.0e-20;
+  const double bm = smin < 0.0 ? smin : -1.0e-20;
+  const double rel_l = ul - bm, rel_r = ur - bp;
+  Cons1D fl, fr;
+  fl.d = dl*rel_l;                        fr.d = dr*rel_r;
+  fl.mx = dl*ul*rel_l + pml - sqr(bn);    fr.mx = dr*ur*rel_r + pmr - sqr(bn);
+  fl.my = dl*vl*rel_l - bn*byl;           fr.my = dr*vr*rel_r - bn*byr;
+  fl.mz = dl*wl*rel_l - bn*bzl;           fr.mz = dr*wr*rel_r - bn*bzr;
+  fl.mx += pl;                            fr.mx += pr;
+  fl.e = El*rel_l + ul*(pl + pml - bn*bn);
+  fr.e = Er*rel_r + ur*(pr + pmr - bn*bn);
+  fl.e -= bn*(byl*vl + bzl*wl);           fr.e -= bn*(byr*vr + bzr*wr);
+  fl.by = byl*rel_l - bn*vl;              fr.by = byr*rel_r - bn*vr;
+  fl.bz = bzl*rel_l - bn*wl;              fr.bz = bzr*rel_r - bn*wr;
   Cons1D f;
-  f.d = 0.5*(fl_d + fr_d) + (fl_d - fr_d)*tmp;
-  f.mx = 0.5*(fl_mx + fr_mx) + (fl_mx - fr_mx)*tmp;
-  f.my = 0.5*(fl_my + fr_my) + (fl_my - fr_my)*tmp;
-  f.mz = 0.5*(fl_mz + fr_mz) + (fl_mz - fr_mz)*tmp;
-  f.e = 0.5*(fl_e + fr_e) + (fl_e - fr_e)*tmp;
-  f.by = 0.5*(fl_by + fr_by) + (fl_by - fr_by)*tmp;
-  f.bz = 0.5*(fl_bz + fr_bz) + (fl_bz - fr_bz)*tmp;
+  hll_blend(fl, fr, hll_tilt(bp, bm), true, f);
   return f;
 }
 
-// MHD_RSolver selection at compile time: RS = AKMI_RS_LLF 0, HLLE 1, HLLD 3
+// MHD_RSolver selection at compile time: RS = AKMI_RS_LLF 0, HLLE 1, HLLD 3, ADVECT 5
 template <int RS, bool EO = false, bool FM = false>
-AKMI_DEV Cons1D riemann_mhd(double gamma, double ld, double lx, double ly, double lz, double le,
-                            double lby, double lbz, double rd, double rx, double ry, double rz,
-                            double re, double rby, double rbz, double bxi) {
-  if constexpr (RS == 5) return advect_mhd(ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
-  else if constexpr (RS == 0) return llf_mhd(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
-  else if constexpr (RS == 1) return hlle_mhd(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
-  else return hlld<EO, FM>(gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
+AKMI_DEV Cons1D riemann_mhd(double gamma, double dl, double ul, double vl, double wl, double el, double byl,
+                            double bzl, double dr, double ur, double vr, double wr, double er, double byr,
+                            double bzr, double bn) {
+  if constexpr (RS == 5) return advect_mhd(dl, ul, vl, wl, byl, bzl, dr, ur, vr, wr, byr, bzr, bn);
+  else if constexpr (RS == 0) return llf_mhd(gamma, dl, ul, vl, wl, el, byl, bzl, dr, ur, vr, wr, er, byr, bzr, bn);
+  else if constexpr (RS == 1) return hlle_mhd(gamma, dl, ul, vl, wl, el, byl, bzl, dr, ur, vr, wr, er, byr, bzr, bn);
+  else return hlld<EO, FM>(gamma, dl, ul, vl, wl, el, byl, bzl, dr, ur, vr, wr, er, byr, bzr, bn);
 }
 
-// ---- isothermal EOS (EOS_Data::is_ideal == false): the same source lines as the ideal-gas
-// functions above, with the branches the reference takes when there is no energy equation.
-// States (d, vx, vy, vz[, by, bz]); the energy slots of the common signatures are ignored.
-AKMI_DEV void llf_hyd_iso(double cs, double ld, double lx, double ly, double lz, double rd,
-                          double rx, double ry, double rz, double &f_d, double &f_mx, double &f_my,
-                          double &f_mz) {
-  double qa = ld*lx;
-  double qb = rd*rx;
-  double s_d = qa + qb;
-  double s_mx = qa*lx + qb*rx;
-  double s_my = qa*ly + qb*ry;
-  double s_mz = qa*lz + qb*rz;
-  s_mx += sqr(cs)*(ld + rd);
-  double a = fmax((fabs(lx) + cs), (fabs(rx) + cs));
-  f_d = 0.5*(s_d - a*(rd - ld));
-  f_mx = 0.5*(s_mx - a*(rd*rx - ld*lx));
-  f_my = 0.5*(s_my - a*(rd*ry - ld*ly));
-  f_mz = 0.5*(s_mz - a*(rd*rz - ld*lz));
+// =======================================================================================
+// Isothermal EOS (EOS_Data::is_ideal == false): states (d, u, v, w[, by, bz]), pressure cs^2 d, no energy equation.
+// The reference keeps these in the same source files as the ideal-gas solvers (its "if (eos.is_ideal)" branches).
+// =======================================================================================
+AKMI_DEV void llf_hyd_iso(double cs, double dl, double ul, double vl, double wl, double dr, double ur, double vr,
+                          double wr, double &f_d, double &f_mx, double &f_my, double &f_mz) {
+  const double ml = dl*ul, mr = dr*ur;
+  double sum_mx = ml*ul + mr*ur;
+  sum_mx += sqr(cs)*(dl + dr);
+  const double smax = fmax((fabs(ul) + cs), (fabs(ur) + cs));
+  f_d = 0.5*((ml + mr) - smax*(dr - dl));
+  f_mx = 0.5*(sum_mx - smax*(dr*ur - dl*ul));
+  f_my = 0.5*((ml*vl + mr*vr) - smax*(dr*vr - dl*vl));
+  f_mz = 0.5*((ml*wl + mr*wr) - smax*(dr*wr - dl*wl));
 }
 
-AKMI_DEV void hlle_hyd_iso(double iso_cs, double dl, double ul, double vl, double zl, double dr,
-                           double ur, double vr, double zr, double &f_d, double &f_mx,
-                           double &f_my, double &f_mz) {
-  double sqrtdl = sqrt(dl);
-  double sqrtdr = sqrt(dr);
-  double isdlpdr = 1.0/(sqrtdl + sqrtdr);
-  double roe_vx = (sqrtdl*ul + sqrtdr*ur)*isdlpdr;
-  double al = fmin((roe_vx - iso_cs), (ul - iso_cs));
-  double ar = fmax((roe_vx + iso_cs), (ur + iso_cs));
-  double bp = (ar > 0.0) ? ar : 1.0e-20;
-  double bm = (al < 0.0) ? al : -1.0e-20;
-  double qa = ul - bm;
-  double qb = ur - bp;
-  double fl_d = dl*qa, fr_d = dr*qb;
-  double fl_mx = dl*ul*qa, fr_mx = dr*ur*qb;
-  double fl_my = dl*vl*qa, fr_my = dr*vr*qb;
-  double fl_mz = dl*zl*qa, fr_mz = dr*zr*qb;
-  fl_mx += (iso_cs*iso_cs)*dl;
-  fr_mx += (iso_cs*iso_cs)*dr;
-  qa = 0.0;
-  if (bp != bm) qa = 0.5*(bp + bm)/(bp - bm);
-  f_d = 0.5*(fl_d + fr_d) + qa*(fl_d - fr_d);
-  f_mx = 0.5*(fl_mx + fr_mx) + qa*(fl_mx - fr_mx);
-  f_my = 0.5*(fl_my + fr_my) + qa*(fl_my - fr_my);
-  f_mz = 0.5*(fl_mz + fr_mz) + qa*(fl_mz - fr_mz);
+AKMI_DEV void hlle_hyd_iso(double cs, double dl, double ul, double vl, double wl, double dr, double ur, double vr,
+                           double wr, double &f_d, double &f_mx, double &f_my, double &f_mz) {
+  const double rl = sqrt(dl), rr = sqrt(dr);
+  const double inorm = 1.0/(rl + rr);
+  const double u_roe = (rl*ul + rr*ur)*inorm;
+  const double smin = fmin((u_roe - cs), (ul - cs)), smax = fmax((u_roe + cs), (ur + cs));
+  const double bp = (smax > 0.0) ? smax : 1.0e-20;
+  const double bm = (smin < 0.0) ? smin : -1.0e-20;
+  const double rel_l = ul - bm, rel_r = ur - bp;
+  double fl[4] = {dl*rel_l, dl*ul*rel_l, dl*vl*rel_l, dl*wl*rel_l};
+  double fr[4] = {dr*rel_r, dr*ur*rel_r, dr*vr*rel_r, dr*wr*rel_r};
+  fl[1] += (cs*cs)*dl;
+  fr[1] += (cs*cs)*dr;
+  const double t = hll_tilt(bp, bm);
+  f_d = 0.5*(fl[0] + fr[0]) + t*(fl[0] - fr[0]);
+  f_mx = 0.5*(fl[1] + fr[1]) + t*(fl[1] - fr[1]);
+  f_my = 0.5*(fl[2] + fr[2]) + t*(fl[2] - fr[2]);
+  f_mz = 0.5*(fl[3] + fr[3]) + t*(fl[3] - fr[3]);
 }
 
-// roe_hyd.hpp:40-181 with RoeFluxIso (:275-346)
-AKMI_DEV void roe_hyd_iso(double iso_cs, double ld, double lx, double ly, double lz, double rd,
-                          double rx, double ry, double rz, double &f_d, double &f_mx, double &f_my,
-                          double &f_mz) {
-  double wl[4] = {ld, lx, ly, lz}, wr[4] = {rd, rx, ry, rz};
-  double fl[4], fr[4], du[4], ev[4], f[4];
-  double sqrtdl = sqrt(wl[0]);
-  double sqrtdr = sqrt(wr[0]);
-  double isdlpdr = 1.0/(sqrtdl + sqrtdr);
-  double v1 = (sqrtdl*wl[1] + sqrtdr*wr[1])*isdlpdr;
-  double v2 = (sqrtdl*wl[2] + sqrtdr*wr[2])*isdlpdr;
-  double v3 = (sqrtdl*wl[3] + sqrtdr*wr[3])*isdlpdr;
-  double mxl = wl[0]*wl[1];
-  double mxr = wr[0]*wr[1];
-  fl[0] = mxl;           fr[0] = mxr;
-  fl[1] = mxl*wl[1];     fr[1] = mxr*wr[1];
-  fl[2] = mxl*wl[2];     fr[2] = mxr*wr[2];
-  fl[3] = mxl*wl[3];     fr[3] = mxr*wr[3];
-  fl[1] += (iso_cs*iso_cs)*wl[0];
-  fr[1] += (iso_cs*iso_cs)*wr[0];
-  du[0] = wr[0] - wl[0];
-  du[1] = wr[0]*wr[1] - wl[0]*wl[1];
-  du[2] = wr[0]*wr[2] - wl[0]*wl[2];
-  du[3] = wr[0]*wr[3] - wl[0]*wl[3];
+// roe_hyd.hpp:40-181 with RoeFluxIso (:275-346): four waves u - cs, u, u, u + cs
+AKMI_DEV void roe_hyd_iso(double cs, double dl, double ul, double vl, double wl, double dr, double ur, double vr,
+                          double wr, double &f_d, double &f_mx, double &f_my, double &f_mz) {
+  const double rl = sqrt(dl), rr = sqrt(dr);
+  const double inorm = 1.0/(rl + rr);
+  const double u = (rl*ul + rr*ur)*inorm, v = (rl*vl + rr*vr)*inorm, w = (rl*wl + rr*wr)*inorm;
+  const double ml = dl*ul, mr = dr*ur;
+  double fl[4] = {ml, ml*ul, ml*vl, ml*wl};
+  double fr[4] = {mr, mr*ur, mr*vr, mr*wr};
+  fl[1] += (cs*cs)*dl;
+  fr[1] += (cs*cs)*dr;
+  const double jump[4] = {dr - dl, dr*ur - dl*ul, dr*vr - dl*vl, dr*wr - dl*wl};
+  double f[4];
 #pragma unroll
   for (int n = 0; n < 4; ++n) f[n] = 0.5*(fl[n] + fr[n]);
-  bool llf_flag = false;
-  {
-    ev[0] = v1 - iso_cs; ev[1] = v1; ev[2] = v1; ev[3] = v1 + iso_cs;
-    double a[4];
-    a[0]  = du[0]*(0.5 + 0.5*v1/iso_cs);
-    a[0] -= du[1]*0.5/iso_cs;
-    a[1]  = du[0]*(-v2);
-    a[1] += du[2];
-    a[2]  = du[0]*(-v3);
-    a[2] += du[3];
-    a[3]  = du[0]*(0.5 - 0.5*v1/iso_cs);
-    a[3] += du[1]*0.5/iso_cs;
-    double co[4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n) co[n] = -0.5*fabs(ev[n])*a[n];
-    double dens = wl[0] + a[0];
-    if (dens < 0.0) llf_flag = true;
-    dens += a[3];
-    if (dens < 0.0) llf_flag = true;
-    f[0] += co[0];
-    f[0] += co[3];
-    f[1] += co[0]*(v1 - iso_cs);
-    f[1] += co[3]*(v1 + iso_cs);
-    f[2] += co[0]*v2;
-    f[2] += co[1];
-    f[2] += co[3]*v2;
-    f[3] += co[0]*v3;
-    f[3] += co[2];
-    f[3] += co[3]*v3;
-  }
-  if (ev[0] >= 0.0) {
+  const double lam_lo = u - cs, lam_hi = u + cs;
+  double a_lo = jump[0]*(0.5 + 0.5*u/cs);
+  a_lo -= jump[1]*0.5/cs;
+  double a_v = jump[0]*(-v);
+  a_v += jump[2];
+  double a_w = jump[0]*(-w);
+  a_w += jump[3];
+  double a_hi = jump[0]*(0.5 - 0.5*u/cs);
+  a_hi += jump[1]*0.5/cs;
+  const double k_lo = -0.5*fabs(lam_lo)*a_lo, k_v = -0.5*fabs(u)*a_v, k_w = -0.5*fabs(u)*a_w,
+               k_hi = -0.5*fabs(lam_hi)*a_hi;
+  bool fallback = false;
+  double dmid = dl + a_lo;
+  if (dmid < 0.0) fallback = true;
+  dmid += a_hi;
+  if (dmid < 0.0) fallback = true;
+  f[0] += k_lo;
+  f[0] += k_hi;
+  f[1] += k_lo*(u - cs);
+  f[1] += k_hi*(u + cs);
+  f[2] += k_lo*v;
+  f[2] += k_v;
+  f[2] += k_hi*v;
+  f[3] += k_lo*w;
+  f[3] += k_w;
+  f[3] += k_hi*w;
+  if (lam_lo >= 0.0) {
 #pragma unroll
     for (int n = 0; n < 4; ++n) f[n] = fl[n];
   }
-  if (ev[3] <= 0.0) {
+  if (lam_hi <= 0.0) {
 #pragma unroll
     for (int n = 0; n < 4; ++n) f[n] = fr[n];
   }
-  if (llf_flag) {
-    double a = 0.5*fmax((fabs(wl[1]) + iso_cs), (fabs(wr[1]) + iso_cs));
+  if (fallback) {
+    const double half_smax = 0.5*fmax((fabs(ul) + cs), (fabs(ur) + cs));
 #pragma unroll
-    for (int n = 0; n < 4; ++n) f[n] = 0.5*(fl[n] + fr[n]) - a*du[n];
+    for (int n = 0; n < 4; ++n) f[n] = 0.5*(fl[n] + fr[n]) - half_smax*jump[n];
   }
   f_d = f[0]; f_mx = f[1]; f_my = f[2]; f_mz = f[3];
 }
 
 // RS as in riemann_hyd (hllc does not exist for the isothermal EOS)
 template <int RS>
-AKMI_DEV void riemann_hyd_iso(double cs, double ld, double lx, double ly, double lz, double rd,
-                              double rx, double ry, double rz, double &f_d, double &f_mx,
-                              double &f_my, double &f_mz) {
-  if constexpr (RS == 0) llf_hyd_iso(cs, ld, lx, ly, lz, rd, rx, ry, rz, f_d, f_mx, f_my, f_mz);
-  else if constexpr (RS == 1) hlle_hyd_iso(cs, ld, lx, ly, lz, rd, rx, ry, rz, f_d, f_mx, f_my, f_mz);
+AKMI_DEV void riemann_hyd_iso(double cs, double dl, double ul, double vl, double wl, double dr, double ur,
+                              double vr, double wr, double &f_d, double &f_mx, double &f_my, double &f_mz) {
+  if constexpr (RS == 0) llf_hyd_iso(cs, dl, ul, vl, wl, dr, ur, vr, wr, f_d, f_mx, f_my, f_mz);
+  else if constexpr (RS == 1) hlle_hyd_iso(cs, dl, ul, vl, wl, dr, ur, vr, wr, f_d, f_mx, f_my, f_mz);
   else if constexpr (RS == 5) {
-    double fe;
-    advect_hyd(ld, lx, ly, lz, 0.0, rd, rx, ry, rz, 0.0, f_d, f_mx, f_my, f_mz, fe);
-  } else roe_hyd_iso(cs, ld, lx, ly, lz, rd, rx, ry, rz, f_d, f_mx, f_my, f_mz);
+    double unused;
+    advect_hyd(dl, ul, vl, wl, 0.0, dr, ur, vr, wr, 0.0, f_d, f_mx, f_my, f_mz, unused);
+  } else roe_hyd_iso(cs, dl, ul, vl, wl, dr, ur, vr, wr, f_d, f_mx, f_my, f_mz);
 }
 
-// isothermal fast speed, src/eos/eos.hpp:60-68
-AKMI_DEV double fast_speed_iso(double cs, double d, double bx, double by, double bz) {
-  double asq = (cs*cs)*d;
-  double ct2 = by*by + bz*bz;
-  double qsq = bx*bx + ct2 + asq;
-  double tmp = bx*bx + ct2 - asq;
-  return sqrt(0.5*(qsq + sqrt(tmp*tmp + 4.0*asq*ct2))/d);
+// isothermal fast speed, src/eos/eos.hpp:60-68: a^2 = cs^2 in the formula of fast_speed_of
+AKMI_DEV double fast_speed_iso(double cs, double d, double bn, double by, double bz) {
+  return fast_speed_of<false>((cs*cs)*d, d, bn, by, bz);
 }
 
-AKMI_DEV Cons1D llf_mhd_iso(double cs, double ld, double lx, double ly, double lz, double lby,
-                            double lbz, double rd, double rx, double ry, double rz, double rby,
-                            double rbz, double bxi) {
-  double qa = ld*lx;
-  double qb = rd*rx;
-  double qc = 0.5*(sqr(lby) + sqr(lbz) - sqr(bxi));
-  double qd = 0.5*(sqr(rby) + sqr(rbz) - sqr(bxi));
-  double s_d = qa + qb;
-  double s_mx = qa*lx + qb*rx + qc + qd;
-  double s_my = qa*ly + qb*ry - bxi*(lby + rby);
-  double s_mz = qa*lz + qb*rz - bxi*(lbz + rbz);
-  double s_by = lby*lx + rby*rx - bxi*(ly + ry);
-  double s_bz = lbz*lx + rbz*rx - bxi*(lz + rz);
-  s_mx += sqr(cs)*(ld + rd);
-  qa = fast_speed_iso(cs, ld, bxi, lby, lbz);
-  qb = fast_speed_iso(cs, rd, bxi, rby, rbz);
-  double a = fmax((fabs(lx) + qa), (fabs(rx) + qb));
+AKMI_DEV Cons1D llf_mhd_iso(double cs, double dl, double ul, double vl, double wl, double byl, double bzl,
+                            double dr, double ur, double vr, double wr, double byr, double bzr, double bn) {
+  const double ml = dl*ul, mr = dr*ur;
+  const double pml = 0.5*(sqr(byl) + sqr(bzl) - sqr(bn)), pmr = 0.5*(sqr(byr) + sqr(bzr) - sqr(bn));
+  double sum_mx = ml*ul + mr*ur + pml + pmr;
+  sum_mx += sqr(cs)*(dl + dr);
+  const double cfl = fast_speed_iso(cs, dl, bn, byl, bzl), cfr = fast_speed_iso(cs, dr, bn, byr, bzr);
+  const double smax = fmax((fabs(ul) + cfl), (fabs(ur) + cfr));
   Cons1D f;
-  f.d = 0.5*(s_d - a*(rd - ld));
-  f.mx = 0.5*(s_mx - a*(rd*rx - ld*lx));
-  f.my = 0.5*(s_my - a*(rd*ry - ld*ly));
-  f.mz = 0.5*(s_mz - a*(rd*rz - ld*lz));
+  f.d = 0.5*((ml + mr) - smax*(dr - dl));
+  f.mx = 0.5*(sum_mx - smax*(dr*ur - dl*ul));
+  f.my = 0.5*((ml*vl + mr*vr - bn*(byl + byr)) - smax*(dr*vr - dl*vl));
+  f.mz = 0.5*((ml*wl + mr*wr - bn*(bzl + bzr)) - smax*(dr*wr - dl*wl));
   f.e = 0.0;
-  f.by = 0.5*(s_by - a*(rby - lby));
-  f.bz = 0.5*(s_bz - a*(rbz - lbz));
+  f.by = 0.5*((byl*ul + byr*ur - bn*(vl + vr)) - smax*(byr - byl));
+  f.bz = 0.5*((bzl*ul + bzr*ur - bn*(wl + wr)) - smax*(bzr - bzl));
   return f;
 }
 
-AKMI_DEV Cons1D hlle_mhd_iso(double iso_cs, double dl, double ul, double vl, double zl,
-                             double byl, double bzl, double dr, double ur, double vr, double zr,
-                             double byr, double bzr, double bxi) {
-  double sqrtdl = sqrt(dl);
-  double sqrtdr = sqrt(dr);
-  double isdlpdr = 1.0/(sqrtdl + sqrtdr);
-  double roe_d = sqrtdl*sqrtdr;
-  double roe_vx = (sqrtdl*ul + sqrtdr*ur)*isdlpdr;
-  double roe_by = (sqrtdr*byl + sqrtdl*byr)*isdlpdr;
-  double roe_bz = (sqrtdr*bzl + sqrtdl*bzr)*isdlpdr;
-  double x = 0.5*(sqr(byl - byr) + sqr(bzl - bzr))/(sqr(sqrtdl + sqrtdr));
-  double y = 0.5*(dl + dr)/roe_d;
-  double pbl = 0.5*(bxi*bxi + sqr(byl) + sqr(bzl));
-  double pbr = 0.5*(bxi*bxi + sqr(byr) + sqr(bzr));
-  double cl = fast_speed_iso(iso_cs, dl, bxi, byl, bzl);
-  double cr = fast_speed_iso(iso_cs, dr, bxi, byr, bzr);
-  double btsq = sqr(roe_by) + sqr(roe_bz);
-  double vaxsq = bxi*bxi/roe_d;
-  double bt_starsq = btsq*y;
-  double twid_asq = iso_cs*iso_cs + x;
-  double ct2 = bt_starsq/roe_d;
-  double tsum = vaxsq + ct2 + twid_asq;
-  double tdif = vaxsq + ct2 - twid_asq;
-  double cf2_cs2 = sqrt(tdif*tdif + 4.0*twid_asq*ct2);
-  double cfsq = 0.5*(tsum + cf2_cs2);
-  double a = sqrt(cfsq);
-  double al = fmin((roe_vx - a), (ul - cl));
-  double ar = fmax((roe_vx + a), (ur + cr));
-  double bp = ar > 0.0 ? ar : 1.0e-20;
-  double bm = al < 0.0 ? al : -1.0e-20;
-  double vxl = ul - bm;
-  double vxr = ur - bp;
-  double fl_d = dl*vxl, fr_d = dr*vxr;
-  double fl_mx = dl*ul*vxl + pbl - sqr(bxi);
-  double fr_mx = dr*ur*vxr + pbr - sqr(bxi);
-  double fl_my = dl*vl*vxl - bxi*byl;
-  double fr_my = dr*vr*vxr - bxi*byr;
-  double fl_mz = dl*zl*vxl - bxi*bzl;
-  double fr_mz = dr*zr*vxr - bxi*bzr;
-  fl_mx += (iso_cs*iso_cs)*dl;
-  fr_mx += (iso_cs*iso_cs)*dr;
-  double fl_by = byl*vxl - bxi*vl;
-  double fr_by = byr*vxr - bxi*vr;
-  double fl_bz = bzl*vxl - bxi*zl;
-  double fr_bz = bzr*vxr - bxi*zr;
-  double tmp = 0.0;
-  if (bp != bm) tmp = 0.5*(bp + bm)/(bp - bm);
+AKMI_DEV Cons1D hlle_mhd_iso(double cs, double dl, double ul, double vl, double wl, double byl, double bzl,
+                             double dr, double ur, double vr, double wr, double byr, double bzr, double bn) {
+  const RoeMhd m = roe_mhd_mean(dl, ul, byl, bzl, dr, ur, byr, bzr);
+  const double pml = 0.5*(bn*bn + sqr(byl) + sqr(bzl)), pmr = 0.5*(bn*bn + sqr(byr) + sqr(bzr));
+  const double cfl = fast_speed_iso(cs, dl, bn, byl, bzl), cfr = fast_speed_iso(cs, dr, bn, byr, bzr);
+  const double btsq = sqr(m.by) + sqr(m.bz);
+  const double vaxsq = bn*bn/m.d;
+  const double bt_starsq = btsq*m.y;
+  const double asq = cs*cs + m.x;
+  const double c_roe = roe_fast(vaxsq, bt_starsq/m.d, asq);
+  const double smin = fmin((m.u - c_roe), (ul - cfl)), smax = fmax((m.u + c_roe), (ur + cfr));
+  const double bp = smax > 0.0 ? smax : 1.0e-20;
+  const double bm = smin < 0.0 ? smin : -1.0e-20;
+  const double rel_l = ul - bm, rel_r = ur - bp;
+  Cons1D fl, fr;
+  fl.d = dl*rel_l;                        fr.d = dr*rel_r;
+  fl.mx = dl*ul*rel_l + pml - sqr(bn);    fr.mx = dr*ur*rel_r + pmr - sqr(bn);
+  fl.my = dl*vl*rel_l - bn*byl;           fr.my = dr*vr*rel_r - bn*byr;
+  fl.mz = dl*wl*rel_l - bn*bzl;           fr.mz = dr*wr*rel_r - bn*bzr;
+  fl.mx += (cs*cs)*dl;                    fr.mx += (cs*cs)*dr;
+  fl.e = 0.0;                             fr.e = 0.0;
+  fl.by = byl*rel_l - bn*vl;              fr.by = byr*rel_r - bn*vr;
+  fl.bz = bzl*rel_l - bn*wl;              fr.bz = bzr*rel_r - bn*wr;
   Cons1D f;
-  f.d = 0.5*(fl_d + fr_d) + (fl_d - fr_d)*tmp;
-  f.mx = 0.5*(fl_mx + fr_mx) + (fl_mx - fr_mx)*tmp;
-  f.my = 0.5*(fl_my + fr_my) + (fl_my - fr_my)*tmp;
-  f.mz = 0.5*(fl_mz + fr_mz) + (fl_mz - fr_mz)*tmp;
-  f.e = 0.0;
-  f.by = 0.5*(fl_by + fr_by) + (fl_by - fr_by)*tmp;
-  f.bz = 0.5*(fl_bz + fr_bz) + (fl_bz - fr_bz)*tmp;
+  hll_blend(fl, fr, hll_tilt(bp, bm), false, f);
   return f;
 }
 
-// isothermal HLLD (Mignone 2007), src/mhd/rsolvers/hlld_mhd.hpp:349-545
-AKMI_DEV Cons1D hlld_iso(double iso_cs, double dfloor_, double wl_idn, double wl_ivx, double wl_ivy,
-                         double wl_ivz, double wl_iby, double wl_ibz, double wr_idn, double wr_ivx,
-                         double wr_ivy, double wr_ivz, double wr_iby, double wr_ibz, double bxi) {
+// isothermal HLLD (Mignone 2007), src/mhd/rsolvers/hlld_mhd.hpp:349-545.  Three regions between the outer waves sL, sR:
+// left star, centre (between the rotational waves sAL, sAR around the HLL-averaged speed), right star; density and
+// normal momentum are the HLL averages throughout the fan.
+//   value                               reference lines        value                        reference lines
+//   sL, sR, total pressures, F_l, F_r    :389-421               transverse star, per side     :455-490
+//   HLL averages d*, F(d), F(mx), u*     :424-437               centre state                  :493-499
+//   rotational speeds                    :440-441               selection                     :502-543
+struct IsoT { double my, mz, by, bz; };
+// :455-470 / :475-490 -- s = outer speed of the side, (d, u, v, w, by, bz) its state, (my, mz) its momenta
+AKMI_DEV IsoT hlld_iso_transverse(double s, double sAL, double sAR, bool near, double dhll, double ustar, double d,
+                                  double u, double v, double w, double my, double mz, double by, double bz,
+                                  double bn, double bn2) {
+  IsoT t;
+  const double span = (s - sAL)*(s - sAR);
+  if (near) {                                          // rotational and outer wave coincide on this side
+    t.my = my; t.mz = mz; t.by = by; t.bz = bz;
+  } else {
+    const double km = bn*(ustar - u)/span;
+    const double kb = (d*sqr(s - u) - bn2)/(dhll*span);
+    t.my = dhll*v - by*km;
+    t.mz = dhll*w - bz*km;
+    t.by = by*kb;
+    t.bz = bz*kb;
+  }
+  return t;
+}
+AKMI_DEV Cons1D hlld_iso(double cs, double dfloor_, double dl, double ul, double vl, double wl, double byl,
+                         double bzl, double dr, double ur, double vr, double wr, double byr, double bzr, double bn) {
   constexpr double SMALL = 1.0e-4;
-  double ul_d = wl_idn, ul_mx = wl_ivx*ul_d, ul_my = wl_ivy*ul_d, ul_mz = wl_ivz*ul_d;
-  double ul_by = wl_iby, ul_bz = wl_ibz;
-  double ur_d = wr_idn, ur_mx = wr_ivx*ur_d, ur_my = wr_ivy*ur_d, ur_mz = wr_ivz*ur_d;
-  double ur_by = wr_iby, ur_bz = wr_ibz;
-  double cfl = fast_speed_iso(iso_cs, wl_idn, bxi, wl_iby, wl_ibz);
-  double cfr = fast_speed_iso(iso_cs, wr_idn, bxi, wr_iby, wr_ibz);
-  double spd0 = fmin(wl_ivx - cfl, wr_ivx - cfr);
-  double spd4 = fmax(wl_ivx + cfl, wr_ivx + cfr);
-  double bxsq = bxi*bxi;
-  double ptl = sqr(iso_cs)*wl_idn + 0.5*(bxsq + sqr(wl_iby) + sqr(wl_ibz));
-  double ptr = sqr(iso_cs)*wr_idn + 0.5*(bxsq + sqr(wr_iby) + sqr(wr_ibz));
-  double fl_d = ul_mx;
-  double fl_mx = ul_mx*wl_ivx + ptl - bxsq;
-  double fl_my = ul_my*wl_ivx - bxi*ul_by;
-  double fl_mz = ul_mz*wl_ivx - bxi*ul_bz;
-  double fl_by = ul_by*wl_ivx - bxi*wl_ivy;
-  double fl_bz = ul_bz*wl_ivx - bxi*wl_ivz;
-  double fr_d = ur_mx;
-  double fr_mx = ur_mx*wr_ivx + ptr - bxsq;
-  double fr_my = ur_my*wr_ivx - bxi*ur_by;
-  double fr_mz = ur_mz*wr_ivx - bxi*ur_bz;
-  double fr_by = ur_by*wr_ivx - bxi*wr_ivy;
-  double fr_bz = ur_bz*wr_ivx - bxi*wr_ivz;
-  double idspd = 1.0/(spd4 - spd0);
-  double dhll = (spd4*ur_d - spd0*ul_d - fr_d + fl_d)*idspd;
+  const double mxl = ul*dl, myl = vl*dl, mzl = wl*dl, mxr = ur*dr, myr = vr*dr, mzr = wr*dr;
+  const double cfl = fast_speed_iso(cs, dl, bn, byl, bzl), cfr = fast_speed_iso(cs, dr, bn, byr, bzr);
+  const double sL = fmin(ul - cfl, ur - cfr), sR = fmax(ul + cfl, ur + cfr);
+  const double bn2 = bn*bn;
+  const double ptl = sqr(cs)*dl + 0.5*(bn2 + sqr(byl) + sqr(bzl)), ptr = sqr(cs)*dr + 0.5*(bn2 + sqr(byr) + sqr(bzr));
+  Cons1D fl, fr;
+  fl.d = mxl;                     fr.d = mxr;
+  fl.mx = mxl*ul + ptl - bn2;     fr.mx = mxr*ur + ptr - bn2;
+  fl.my = myl*ul - bn*byl;        fr.my = myr*ur - bn*byr;
+  fl.mz = mzl*ul - bn*bzl;        fr.mz = mzr*ur - bn*bzr;
+  fl.by = byl*ul - bn*vl;         fr.by = byr*ur - bn*vr;
+  fl.bz = bzl*ul - bn*wl;         fr.bz = bzr*ur - bn*wr;
+  // HLL averages over the fan
+  const double ifan = 1.0/(sR - sL);
+  double dhll = (sR*dr - sL*dl - fr.d + fl.d)*ifan;
   dhll = fmax(dhll, dfloor_);
-  double sqrtdhll = sqrt(dhll);
-  double fdhll = (spd4*fl_d - spd0*fr_d + spd4*spd0*(ur_d - ul_d))*idspd;
-  double fmxhll = (spd4*fl_mx - spd0*fr_mx + spd4*spd0*(ur_mx - ul_mx))*idspd;
-  double ustar = fdhll/dhll;
-  double mxhll = (spd4*ur_mx - spd0*ul_mx - fr_mx + fl_mx)*idspd;
-  double spd1 = ustar - fabs(bxi)/sqrtdhll;
-  double spd3 = ustar + fabs(bxi)/sqrtdhll;
-  double ulst_my, ulst_mz, ulst_by, ulst_bz, urst_my, urst_mz, urst_by, urst_bz;
-  double tmp = (spd0 - spd1)*(spd0 - spd3);
-  if (fabs(spd0 - spd1) < (SMALL)*iso_cs) {
-    ulst_my = ul_my; ulst_mz = ul_mz; ulst_by = ul_by; ulst_bz = ul_bz;
-  } else {
-    double mfact = bxi*(ustar - wl_ivx)/tmp;
-    double bfact = (ul_d*sqr(spd0 - wl_ivx) - bxsq)/(dhll*tmp);
-    ulst_my = dhll*wl_ivy - ul_by*mfact;
-    ulst_mz = dhll*wl_ivz - ul_bz*mfact;
-    ulst_by = ul_by*bfact;
-    ulst_bz = ul_bz*bfact;
-  }
-  tmp = (spd4 - spd1)*(spd4 - spd3);
-  if (fabs(spd4 - spd3) < (SMALL)*iso_cs) {
-    urst_my = ur_my; urst_mz = ur_mz; urst_by = ur_by; urst_bz = ur_bz;
-  } else {
-    double mfact = bxi*(ustar - wr_ivx)/tmp;
-    double bfact = (ur_d*sqr(spd4 - wr_ivx) - bxsq)/(dhll*tmp);
-    urst_my = dhll*wr_ivy - ur_by*mfact;
-    urst_mz = dhll*wr_ivz - ur_bz*mfact;
-    urst_by = ur_by*bfact;
-    urst_bz = ur_bz*bfact;
-  }
-  double x = sqrtdhll*(bxi > 0.0 ? 1.0 : -1.0);
-  double ucst_d = dhll;
-  double ucst_my = 0.5*(ulst_my + urst_my + (urst_by - ulst_by)*x);
-  double ucst_mz = 0.5*(ulst_mz + urst_mz + (urst_bz - ulst_bz)*x);
-  double ucst_by = 0.5*(ulst_by + urst_by + (urst_my - ulst_my)/x);
-  double ucst_bz = 0.5*(ulst_bz + urst_bz + (urst_mz - ulst_mz)/x);
+  const double rhll = sqrt(dhll);
+  const double fdhll = (sR*fl.d - sL*fr.d + sR*sL*(dr - dl))*ifan;
+  const double fmxhll = (sR*fl.mx - sL*fr.mx + sR*sL*(mxr - mxl))*ifan;
+  const double ustar = fdhll/dhll;
+  const double mxhll = (sR*mxr - sL*mxl - fr.mx + fl.mx)*ifan;
+  const double sAL = ustar - fabs(bn)/rhll, sAR = ustar + fabs(bn)/rhll;
+  const IsoT Tl = hlld_iso_transverse(sL, sAL, sAR, fabs(sL - sAL) < (SMALL)*cs, dhll, ustar, dl, ul, vl, wl, myl,
+                                      mzl, byl, bzl, bn, bn2);
+  const IsoT Tr = hlld_iso_transverse(sR, sAL, sAR, fabs(sR - sAR) < (SMALL)*cs, dhll, ustar, dr, ur, vr, wr, myr,
+                                      mzr, byr, bzr, bn, bn2);
+  // centre state
+  const double x = rhll*(bn > 0.0 ? 1.0 : -1.0);
+  const double c_my = 0.5*(Tl.my + Tr.my + (Tr.by - Tl.by)*x);
+  const double c_mz = 0.5*(Tl.mz + Tr.mz + (Tr.bz - Tl.bz)*x);
+  const double c_by = 0.5*(Tl.by + Tr.by + (Tr.my - Tl.my)/x);
+  const double c_bz = 0.5*(Tl.bz + Tr.bz + (Tr.mz - Tl.mz)/x);
   Cons1D f;
   f.e = 0.0;
-  if (spd0 >= 0.0) {
-    f.d = fl_d; f.mx = fl_mx; f.my = fl_my; f.mz = fl_mz; f.by = fl_by; f.bz = fl_bz;
-  } else if (spd4 <= 0.0) {
-    f.d = fr_d; f.mx = fr_mx; f.my = fr_my; f.mz = fr_mz; f.by = fr_by; f.bz = fr_bz;
-  } else if (spd1 >= 0.0) {
-    f.d = fl_d + spd0*(dhll - ul_d);
-    f.mx = fl_mx + spd0*(mxhll - ul_mx);
-    f.my = fl_my + spd0*(ulst_my - ul_my);
-    f.mz = fl_mz + spd0*(ulst_mz - ul_mz);
-    f.by = fl_by + spd0*(ulst_by - ul_by);
-    f.bz = fl_bz + spd0*(ulst_bz - ul_bz);
-  } else if (spd3 <= 0.0) {
-    f.d = fr_d + spd4*(dhll - ur_d);
-    f.mx = fr_mx + spd4*(mxhll - ur_mx);
-    f.my = fr_my + spd4*(urst_my - ur_my);
-    f.mz = fr_mz + spd4*(urst_mz - ur_mz);
-    f.by = fr_by + spd4*(urst_by - ur_by);
-    f.bz = fr_bz + spd4*(urst_bz - ur_bz);
+  if (sL >= 0.0) {
+    f.d = fl.d; f.mx = fl.mx; f.my = fl.my; f.mz = fl.mz; f.by = fl.by; f.bz = fl.bz;
+  } else if (sR <= 0.0) {
+    f.d = fr.d; f.mx = fr.mx; f.my = fr.my; f.mz = fr.mz; f.by = fr.by; f.bz = fr.bz;
+  } else if (sAL >= 0.0) {
+    f.d = fl.d + sL*(dhll - dl);
+    f.mx = fl.mx + sL*(mxhll - mxl);
+    f.my = fl.my + sL*(Tl.my - myl);
+    f.mz = fl.mz + sL*(Tl.mz - mzl);
+    f.by = fl.by + sL*(Tl.by - byl);
+    f.bz = fl.bz + sL*(Tl.bz - bzl);
+  } else if (sAR <= 0.0) {
+    f.d = fr.d + sR*(dhll - dr);
+    f.mx = fr.mx + sR*(mxhll - mxr);
+    f.my = fr.my + sR*(Tr.my - myr);
+    f.mz = fr.mz + sR*(Tr.mz - mzr);
+    f.by = fr.by + sR*(Tr.by - byr);
+    f.bz = fr.bz + sR*(Tr.bz - bzr);
   } else {
     f.d = dhll*ustar;
     f.mx = fmxhll;
-    f.my = ucst_my*ustar - bxi*ucst_by;
-    f.mz = ucst_mz*ustar - bxi*ucst_bz;
-    f.by = ucst_by*ustar - bxi*ucst_my/ucst_d;
-    f.bz = ucst_bz*ustar - bxi*ucst_mz/ucst_d;
+    f.my = c_my*ustar - bn*c_by;
+    f.mz = c_mz*ustar - bn*c_bz;
+    f.by = c_by*ustar - bn*c_my/dhll;
+    f.bz = c_bz*ustar - bn*c_mz/dhll;
   }
   return f;
 }
 
 template <int RS>
-AKMI_DEV Cons1D riemann_mhd_iso(const FaceEos &eos, double ld, double lx, double ly, double lz,
-                                double lby, double lbz, double rd, double rx, double ry, double rz,
-                                double rby, double rbz, double bxi) {
-  if constexpr (RS == 5) return advect_mhd(ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
-  else if constexpr (RS == 0) return llf_mhd_iso(eos.iso_cs, ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
-  else if constexpr (RS == 1) return hlle_mhd_iso(eos.iso_cs, ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
-  else return hlld_iso(eos.iso_cs, eos.dfloor, ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
+AKMI_DEV Cons1D riemann_mhd_iso(const FaceEos &eos, double dl, double ul, double vl, double wl, double byl,
+                                double bzl, double dr, double ur, double vr, double wr, double byr, double bzr,
+                                double bn) {
+  if constexpr (RS == 5) return advect_mhd(dl, ul, vl, wl, byl, bzl, dr, ur, vr, wr, byr, bzr, bn);
+  else if constexpr (RS == 0) return llf_mhd_iso(eos.iso_cs, dl, ul, vl, wl, byl, bzl, dr, ur, vr, wr, byr, bzr, bn);
+  else if constexpr (RS == 1) return hlle_mhd_iso(eos.iso_cs, dl, ul, vl, wl, byl, bzl, dr, ur, vr, wr, byr, bzr, bn);
+  else return hlld_iso(eos.iso_cs, eos.dfloor, dl, ul, vl, wl, byl, bzl, dr, ur, vr, wr, byr, bzr, bn);
 }
 
 // The fused stage kernels carry the equation of state in their Riemann-solver template parameter:
@@ -1311,24 +1136,27 @@ AKMI_DEV Cons1D riemann_mhd_iso(const FaceEos &eos, double ld, double lx, double
 // have no energy variable: slot 4 of the kernels' variable arrays stays unused (rs_iso<RS>()).
 template <int RS> constexpr bool rs_iso() { return RS >= 10; }
 template <int RS, bool EO = false, bool FM = false>
-AKMI_DEV Cons1D riemann_mhd_e(const FaceEos &eos, double ld, double lx, double ly, double lz, double le,
-                              double lby, double lbz, double rd, double rx, double ry, double rz,
-                              double re, double rby, double rbz, double bxi) {
-  if constexpr (RS >= 10) return riemann_mhd_iso<RS - 10>(eos, ld, lx, ly, lz, lby, lbz, rd, rx, ry, rz, rby, rbz, bxi);
-  else return riemann_mhd<RS, EO, FM>(eos.gamma, ld, lx, ly, lz, le, lby, lbz, rd, rx, ry, rz, re, rby, rbz, bxi);
+AKMI_DEV Cons1D riemann_mhd_e(const FaceEos &eos, double dl, double ul, double vl, double wl, double el,
+                              double byl, double bzl, double dr, double ur, double vr, double wr, double er,
+                              double byr, double bzr, double bn) {
+  if constexpr (RS >= 10) return riemann_mhd_iso<RS - 10>(eos, dl, ul, vl, wl, byl, bzl, dr, ur, vr, wr, byr, bzr, bn);
+  else return riemann_mhd<RS, EO, FM>(eos.gamma, dl, ul, vl, wl, el, byl, bzl, dr, ur, vr, wr, er, byr, bzr, bn);
 }
 template <int RS>
-AKMI_DEV void riemann_hyd_e(const FaceEos &eos, double ld, double lx, double ly, double lz, double le,
-                            double rd, double rx, double ry, double rz, double re, double &f_d,
-                            double &f_mx, double &f_my, double &f_mz, double &f_e) {
+AKMI_DEV void riemann_hyd_e(const FaceEos &eos, double dl, double ul, double vl, double wl, double el, double dr,
+                            double ur, double vr, double wr, double er, double &f_d, double &f_mx, double &f_my,
+                            double &f_mz, double &f_e) {
   if constexpr (RS >= 10) {
-    riemann_hyd_iso<RS - 10>(eos.iso_cs, ld, lx, ly, lz, rd, rx, ry, rz, f_d, f_mx, f_my, f_mz);
+    riemann_hyd_iso<RS - 10>(eos.iso_cs, dl, ul, vl, wl, dr, ur, vr, wr, f_d, f_mx, f_my, f_mz);
     f_e = 0.0;
   } else {
-    riemann_hyd<RS>(eos.gamma, ld, lx, ly, lz, le, rd, rx, ry, rz, re, f_d, f_mx, f_my, f_mz, f_e);
+    riemann_hyd<RS>(eos.gamma, dl, ul, vl, wl, el, dr, ur, vr, wr, er, f_d, f_mx, f_my, f_mz, f_e);
   }
 }
 
+// =======================================================================================
+// Conserved -> primitive, ideal gas (src/eos/ideal_c2p_hyd.hpp:22-66, ideal_c2p_mhd.hpp:20-67)
+// =======================================================================================
 // EOS_Data by value (src/eos/eos.hpp:27-34)
 struct Eos {
   double gamma, dfloor, pfloor, tfloor, sfloor, sigma_max, iso_cs;
@@ -1355,20 +1183,16 @@ AKMI_DEV bool entropy_floor_hit(double wd, double we, double di, double gm1, dou
   return (spe <= sfloor);
 }
 
-// SingleC2P_IdealHyd, src/eos/ideal_c2p_hyd.hpp:22-66
-AKMI_DEV void c2p_hyd(const Eos &eos, double &ud, double umx, double umy, double umz,
-                      double &ue, double &wd, double &wvx, double &wvy, double &wvz,
-                      double &we, bool &dfl, bool &efl, bool &tfl) {
+// The conversion of one cell; e_other = every energy that is not thermal (kinetic [+ magnetic]).  Floors in the
+// reference's order: density (caller), internal energy, temperature, entropy; ue is rewritten where a floor acts
+// on the energy (the entropy floor only resets the primitive, as the reference does).
+AKMI_DEV void c2p_thermal(const Eos &eos, double wd, double di, double e_kin, double e_mag, bool mhd, double &ue,
+                          double &we, bool &efl, bool &tfl) {
   const double efloor = eos.pfloor/(eos.gamma - 1.0);
   const double gm1 = eos.gamma - 1.0;
-  if (ud < eos.dfloor) { ud = eos.dfloor; dfl = true; }
-  wd = ud;
-  double di = 1.0/ud;
-  wvx = di*umx; wvy = di*umy; wvz = di*umz;
-  double e_k = 0.5*di*(sqr(umx) + sqr(umy) + sqr(umz));
-  we = (ue - e_k);
-  if (we < efloor) { we = efloor; ue = efloor + e_k; efl = true; }
-  if (gm1*we*di < eos.tfloor) { we = wd*eos.tfloor/gm1; ue = we + e_k; tfl = true; }
+  we = mhd ? (ue - e_kin - e_mag) : (ue - e_kin);
+  if (we < efloor) { we = efloor; ue = mhd ? (efloor + e_kin + e_mag) : (efloor + e_kin); efl = true; }
+  if (gm1*we*di < eos.tfloor) { we = wd*eos.tfloor/gm1; ue = mhd ? (we + e_kin + e_mag) : (we + e_kin); tfl = true; }
   double spe_over_eps;
   if (entropy_floor_hit(wd, we, di, gm1, eos.sfloor, spe_over_eps)) {
     we = wd*eos.sfloor/spe_over_eps;
@@ -1376,28 +1200,30 @@ AKMI_DEV void c2p_hyd(const Eos &eos, double &ud, double umx, double umy, double
   }
 }
 
-// SingleC2P_IdealMHD, src/eos/ideal_c2p_mhd.hpp:20-67
-AKMI_DEV void c2p_mhd(const Eos &eos, double &ud, double umx, double umy, double umz,
-                      double &ue, double ubx, double uby, double ubz, double &wd, double &wvx,
-                      double &wvy, double &wvz, double &we, bool &dfl, bool &efl, bool &tfl) {
-  const double b2 = sqr(ubx) + sqr(uby) + sqr(ubz);
-  const double dfloor_ = fmax(eos.dfloor, b2/eos.sigma_max);
-  const double efloor = eos.pfloor/(eos.gamma - 1.0);
-  const double gm1 = eos.gamma - 1.0;
-  if (ud < dfloor_) { ud = dfloor_; dfl = true; }
+// SingleC2P_IdealHyd
+AKMI_DEV void c2p_hyd(const Eos &eos, double &ud, double umx, double umy, double umz, double &ue, double &wd,
+                      double &wvx, double &wvy, double &wvz, double &we, bool &dfl, bool &efl, bool &tfl) {
+  if (ud < eos.dfloor) { ud = eos.dfloor; dfl = true; }
   wd = ud;
-  double di = 1.0/ud;
+  const double di = 1.0/ud;
   wvx = di*umx; wvy = di*umy; wvz = di*umz;
-  double e_k = 0.5*di*(sqr(umx) + sqr(umy) + sqr(umz));
-  double e_m = 0.5*(sqr(ubx) + sqr(uby) + sqr(ubz));
-  we = (ue - e_k - e_m);
-  if (we < efloor) { we = efloor; ue = efloor + e_k + e_m; efl = true; }
-  if (gm1*we*di < eos.tfloor) { we = wd*eos.tfloor/gm1; ue = we + e_k + e_m; tfl = true; }
-  double spe_over_eps;
-  if (entropy_floor_hit(wd, we, di, gm1, eos.sfloor, spe_over_eps)) {
-    we = wd*eos.sfloor/spe_over_eps;
-    efl = true;
-  }
+  const double e_kin = 0.5*di*(sqr(umx) + sqr(umy) + sqr(umz));
+  c2p_thermal(eos, wd, di, e_kin, 0.0, false, ue, we, efl, tfl);
+}
+
+// SingleC2P_IdealMHD: (ubx, uby, ubz) the cell-centred field; the density floor rises with b^2/sigma_max
+AKMI_DEV void c2p_mhd(const Eos &eos, double &ud, double umx, double umy, double umz, double &ue, double ubx,
+                      double uby, double ubz, double &wd, double &wvx, double &wvy, double &wvz, double &we,
+                      bool &dfl, bool &efl, bool &tfl) {
+  const double bsq = sqr(ubx) + sqr(uby) + sqr(ubz);
+  const double dfl_here = fmax(eos.dfloor, bsq/eos.sigma_max);
+  if (ud < dfl_here) { ud = dfl_here; dfl = true; }
+  wd = ud;
+  const double di = 1.0/ud;
+  wvx = di*umx; wvy = di*umy; wvz = di*umz;
+  const double e_kin = 0.5*di*(sqr(umx) + sqr(umy) + sqr(umz));
+  const double e_mag = 0.5*(sqr(ubx) + sqr(uby) + sqr(ubz));
+  c2p_thermal(eos, wd, di, e_kin, e_mag, true, ue, we, efl, tfl);
 }
 
 }  // namespace akmi
