@@ -12,7 +12,8 @@ from athenak_amd.native import NativeSimulation  # noqa: E402
 
 ncyc = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 extra = sys.argv[2:]
-for kind in ("python host", "c++ host"):
+hosts = [h for h in ("python host", "c++ host") if os.environ.get("AKMI_CONFIG5_HOSTS", "python,c++").find(h.split()[0]) >= 0]
+for kind in hosts:
     pin = load_deck("blast_mhd_smr.athinput", ["time/nlim=-1", "time/tlim=1.0e9"] + extra)
     sim = Simulation(pin) if kind == "python host" else NativeSimulation(pin)
     pm = sim.pmesh
