@@ -49,7 +49,6 @@ SYMBOLS = [
     "akmi_smr_exchange_cc", "akmi_smr_exchange_fc", "akmi_smr_fill_coarse_cc", "akmi_smr_fill_coarse_fc",
     "akmi_smr_prolong_cc", "akmi_smr_prolong_fc", "akmi_smr_c2p_coarse", "akmi_smr_p2c_fine", "akmi_smr_build_lists", "akmi_mhd_fluxes_update", "akmi_smr_update_save_doubles", "akmi_smr_save_update_cells", "akmi_smr_redo_update", "akmi_smr_flux_cc", "akmi_smr_emf_exchange", "akmi_smr_pack_cc", "akmi_smr_unpack_cc", "akmi_smr_pack_fc",
     "akmi_selftest_fp64",
-    "akmi_mhd_fluxes_ecc", "akmi_mhd_corner_ct_inner", "akmi_mhd_ct_shell",
     "akmi_smr_unpack_fc", "akmi_smr_pack_flux_cc", "akmi_smr_unpack_flux_cc", "akmi_smr_pack_emf", "akmi_smr_unpack_emf",
 ]
 

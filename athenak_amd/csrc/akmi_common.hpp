@@ -209,8 +209,7 @@ inline int cdiv(int a, int b) { return (a + b - 1)/b; }
 int sweeps_store_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0, const double *bcc0,
                         const double *bx1f, const double *bx2f, const double *bx3f, double *flx1, double *flx2,
                         double *flx3, int face_shaped, double *e3x1, double *e2x1, double *e1x2, double *e3x2,
-                        double *e2x3, double *e1x3, void *stream, double *ecc1 = nullptr, double *ecc2 = nullptr,
-                        double *ecc3 = nullptr);
+                        double *e2x3, double *e1x3, void *stream);
 
 }  // namespace akmi
 #endif

@@ -614,12 +614,6 @@ MHD::MHD(MeshBlockPack *pp, ParameterInput *pin) : FluidBase(pp, pin, "mhd") {
     efld.x3e.Realloc(nmb*n3*(n2 + 1)*(n1 + 1));
     for (DvceArray<Real> *a : {&e3x1, &e2x1, &e1x2, &e3x2, &e2x3, &e1x3}) a->Realloc(nmb*n3*n2*n1);
   }
-  // AKMI_SMR_CT_INNER=0: CornerE and CT as the two kernels of the task chain (A/B measurements).  Not with resistive
-  // EMFs (added to every edge between EField and CT) or FOFC
-  const char *ci = std::getenv("AKMI_SMR_CT_INNER");
-  ct_inner = multilevel && !fused && !sweep_update && !use_fofc && !kinematic && !has_resist && ind.nx3 > 1 &&
-             !(ci && ci[0] == '0');
-  if (ct_inner) for (auto &a : ecc) a.Realloc(nmb*n3*n2*n1);
   if (multilevel) {                                                // mhd.cpp:368-380
     const size_t c1 = cpack_c.nx1 + 2*ind.ng, c2 = ind.nx2 > 1 ? cpack_c.nx2 + 2*ind.ng : 1,
                  c3 = ind.nx3 > 1 ? cpack_c.nx3 + 2*ind.ng : 1;
@@ -630,7 +624,6 @@ MHD::~MHD() {
   bcc0.Free(); FaceFree(b0); FaceFree(b1); FaceFree(uflx); FaceFree(coarse_b0);
   efld.x1e.Free(); efld.x2e.Free(); efld.x3e.Free();
   for (DvceArray<Real> *a : {&e3x1, &e2x1, &e1x2, &e3x2, &e2x3, &e1x3}) a->Free();
-  for (auto &a : ecc) a.Free();
 }
 
 void MHD::AssembleMHDTasks(std::map<std::string, std::shared_ptr<TaskList>> tl) {
@@ -1075,10 +1068,6 @@ TaskStatus MHD::Fluxes(Driver *d, int stage) {             // mhd_tasks.cpp:177-
     AKCHK(akmi_mhd_fluxes_fofc(&pack_c, recon_method, rsolver_method, w0.p, bcc0.p, b0.x1f.p,
                                b0.x2f.p, b0.x3f.p, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, e3x1.p,
                                e2x1.p, e1x2.p, e3x2.p, e2x3.p, e1x3.p, stream));
-  else if (ct_inner)
-    AKCHK(akmi_mhd_fluxes_ecc(&pack_c, recon_method, rsolver_method, w0.p, bcc0.p, b0.x1f.p, b0.x2f.p,
-                              b0.x3f.p, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, e3x1.p, e2x1.p, e1x2.p,
-                              e3x2.p, e2x3.p, e1x3.p, ecc[0].p, ecc[1].p, ecc[2].p, stream));
   else
     AKCHK(akmi_mhd_fluxes(&pack_c, recon_method, rsolver_method, w0.p, bcc0.p, b0.x1f.p, b0.x2f.p,
                           b0.x3f.p, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, e3x1.p, e2x1.p, e1x2.p,
@@ -1264,13 +1253,6 @@ TaskStatus MHD::Prolongate(Driver *d, int stage) {         // mhd_tasks.cpp:527-
   return TaskStatus::complete;
 }
 TaskStatus MHD::EField(Driver *d, int stage) {             // mhd_corner_e.cpp:26-417
-  if (ct_inner) {
-    AKCHK(akmi_mhd_corner_ct_inner(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1], d->beta[stage - 1]*pmy_pack->pmesh->dt,
-                                   OopFirst(d, stage) ? 1 : 0, e3x1.p, e2x1.p, e1x2.p, e3x2.p, e2x3.p, e1x3.p, ecc[0].p,
-                                   ecc[1].p, ecc[2].p, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, efld.x1e.p, efld.x2e.p,
-                                   efld.x3e.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, b1.x1f.p, b1.x2f.p, b1.x3f.p, stream));
-    return TaskStatus::complete;
-  }
   if (!fused)
     AKCHK(akmi_mhd_corner_e(&pack_c, w0.p, bcc0.p, e3x1.p, e2x1.p, e1x2.p, e3x2.p, e2x3.p, e1x3.p,
                             uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, efld.x1e.p, efld.x2e.p, efld.x3e.p,
@@ -1285,14 +1267,6 @@ TaskStatus MHD::EField(Driver *d, int stage) {             // mhd_corner_e.cpp:2
 }
 TaskStatus MHD::CT(Driver *d, int stage) {                 // mhd_ct.cpp:23-80
   if (fused && peers()) StagePhase(d, stage, AKMI_PHASE_EMF_CT);
-  if (ct_inner) {
-    const bool oop = OopFirst(d, stage);
-    AKCHK(akmi_mhd_ct_shell(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1], d->beta[stage - 1]*pmy_pack->pmesh->dt,
-                            oop ? 1 : 0, efld.x1e.p, efld.x2e.p, efld.x3e.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, b1.x1f.p,
-                            b1.x2f.p, b1.x3f.p, stream));
-    if (oop) { SwapArr(b0.x1f, b1.x1f); SwapArr(b0.x2f, b1.x2f); SwapArr(b0.x3f, b1.x3f); b_swapped = !b_swapped; }
-    return TaskStatus::complete;
-  }
   if (!fused && OopFirst(d, stage)) {
     AKCHK(akmi_mhd_ct_oop(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1],
                           d->beta[stage - 1]*pmy_pack->pmesh->dt, efld.x1e.p, efld.x2e.p, efld.x3e.p,

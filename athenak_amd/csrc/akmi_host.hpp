@@ -419,10 +419,6 @@ class MHD : public FluidBase {      // mhd.hpp:93-199
   DvceFaceFld b0, b1, uflx, coarse_b0;
   DvceEdgeFld efld;
   DvceArray<Real> e3x1, e2x1, e1x2, e3x2, e2x3, e1x3;
-  // refined 3-D meshes: EField = CornerE + CT of the faces no EMF correction reaches (akmi_mhd_corner_ct_inner), CT = the
-  // faces on the block surface (akmi_mhd_ct_shell); ecc = the cell-centred EMFs the x1 sweep leaves (akmi_mhd_fluxes_ecc)
-  bool ct_inner = false;
-  DvceArray<Real> ecc[3];
   void AssembleMHDTasks(std::map<std::string, std::shared_ptr<TaskList>> tl);
   void StagePhase(Driver *d, int stage, int phases);   // akmi_mhd_stage_phase
   void RestoreRegisters() override;

@@ -984,13 +984,7 @@ constexpr int CKL = AKMI_CKL;          // cell planes per k-chunk (one plane of 
 // (ty, tx); the launcher picks the shape that wastes the fewest lanes for the block size (a 64-wide
 // tile needs two columns of tiles for the 65 edge columns of a 64^3 MeshBlock, a 34 x 15 tile does
 // 33 / 65 / 257 columns in 1 / 2 / 8).
-// SHELL (refined meshes, akmi_mhd_corner_ct_inner): the EMF correction between CornerE and CT (flux_correct_fc.cpp:29-900)
-// changes edge values on the surface of a MeshBlock only, so every face none of whose four edges lies on that surface
-// gets its CT here, as on a uniform mesh; the corner EMFs of the other faces' edges (the surface and the layer next to it)
-// are stored for the correction and for akmi_mhd_ct_shell, which finishes those faces afterwards.
-struct CtShellOut { double *e1, *e2, *e3; };
-struct CtNoOut {};
-template <bool P2, bool BITS, bool SHELL = false>
+template <bool P2, bool BITS>
 __device__ __forceinline__ void corner_ct_body(const Geo &g, const MfBits &mb, const double *__restrict__ e3x1, const double *__restrict__ e2x1,
             const double *__restrict__ e1x2, const double *__restrict__ e3x2,
             const double *__restrict__ e2x3, const double *__restrict__ e1x3,
@@ -1000,8 +994,7 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const MfBits &mb, c
             double gam1, double beta_dt, double *__restrict__ b0x1f, double *__restrict__ b0x2f,
             double *__restrict__ b0x3f, double *__restrict__ b1x1f, double *__restrict__ b1x2f,
             double *__restrict__ b1x3f, int copy_b1, int kA, int kB, int top, int nchunk,
-            int ckl, int tw, int th, const double *dtp,
-            const std::conditional_t<SHELL, CtShellOut, CtNoOut> &so = {}) {
+            int ckl, int tw, int th, const double *dtp) {
   beta_dt = beta_dt_of(beta_dt, dtp);
   extern __shared__ double ct_lds[];     // e1, e2: 2 planes each, e3: 3 planes of th x tw
   const int plane = tw*th;
@@ -1138,26 +1131,11 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const MfBits &mb, c
       }
       f1_km = f1_k; f2_km = f2_k; x2_km = x2_k; x1_km = x1_k;
       c1_mm = c1_0m; c1_m0 = c1_00; c2_mm = c2_0m; c2_m0 = c2_00;
-      if constexpr (SHELL) {
-        // edges of the faces akmi_mhd_ct_shell updates: within one position of the block surface across the edge,
-        // on the first / last cell along it (owners only; the last plane of a chunk belongs to the next chunk)
-        if (own && (k <= k1 || wtop)) {
-          const bool ni = i <= g.is + 1 || i >= g.ie, nj = j <= g.js + 1 || j >= g.je, nk = k <= g.ks + 1 || k >= g.ke;
-          const bool ci = i == g.is || i == g.ie, cj = j == g.js || j == g.je, ck = k == g.ks || k == g.ke;
-          if (i <= g.ie && (nj || nk || ci)) so.e1[ix4(g.N3 + 1, g.N2 + 1, g.N1, m, k, j, i)] = e1;
-          if (j <= g.je && (ni || nk || cj)) so.e2[ix4(g.N3 + 1, g.N2, g.N1 + 1, m, k, j, i)] = e2;
-          if (k <= g.ke && (ni || nj || ck)) so.e3[ix4(g.N3, g.N2 + 1, g.N1 + 1, m, k, j, i)] = e3;
-        }
-      }
     }
     if (in_tile) { S1(pp2, ty, tx) = e1; S2(pp2, ty, tx) = e2; S3(p3, ty, tx) = e3; }
     __syncthreads();
     if (own) {
-      // SHELL: faces with an edge on the block surface wait for the EMF correction (akmi_mhd_ct_shell)
-      const bool si = SHELL && (i == g.is || i == g.ie), sj = SHELL && (j == g.js || j == g.je);
-      const bool sk = SHELL && (k - 1 == g.ks || k - 1 == g.ke);
-      if (i <= g.ie && j <= g.je && (k <= k1 || wtop) &&
-          !(SHELL && (si || sj || k == g.ks || k == g.ke + 1))) {  // x3-face of plane k (mhd_ct.cpp:67-77)
+      if (i <= g.ie && j <= g.je && (k <= k1 || wtop)) {          // x3-face of plane k (mhd_ct.cpp:67-77)
         const double b0v = ldu(b03, oc);
         const double b1v = copy_b1 ? b0v : ldu(b13, oc);
         double b = gam0*b0v + gam1*b1v;
@@ -1167,7 +1145,7 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const MfBits &mb, c
       }
       if (k > k0) {
         const int q3 = (t + 2) % 3;                                // the e3 buffer of plane k-1
-        if (j <= g.je && !(SHELL && (sj || sk || i == g.is || i == g.ie + 1))) {   // x1-face (:45-54)
+        if (j <= g.je) {                                           // x1-face (:45-54)
           const double b0v = ldu(b01 - PS1, o1);
           const double b1v = copy_b1 ? b0v : ldu(b11 - PS1, o1);
           double b = gam0*b0v + gam1*b1v;
@@ -1175,7 +1153,7 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const MfBits &mb, c
           b += DIVX(beta_dt*(e2 - e2p), dx3);
           rk_store_u(b01 - PS1, b11 - PS1, copy_b1, o1, b0v, b);
         }
-        if (i <= g.ie && !(SHELL && (si || sk || j == g.js || j == g.je + 1))) {   // x2-face (:56-65)
+        if (i <= g.ie) {                                           // x2-face (:56-65)
           const double b0v = ldu(b02 - PS2, o2);
           const double b1v = copy_b1 ? b0v : ldu(b12 - PS2, o2);
           double b = gam0*b0v + gam1*b1v;
@@ -1209,22 +1187,6 @@ k_corner_ct(Geo g, MfBits mb, const double *__restrict__ e3x1, const double *__r
   corner_ct_body<AKMI_POW2DX != 0, BITS>(g, mb, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, c1, c2, c3, flx1, flx2, flx3, gam0,
                                    gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f, copy_b1, kA, kB, top,
                                    nchunk, ckl, tw, th, dtp);
-}
-
-__global__ void __launch_bounds__(CT_THREADS, AKMI_CT_WAVES)
-k_corner_ct_inner(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e2x1,
-                  const double *__restrict__ e1x2, const double *__restrict__ e3x2,
-                  const double *__restrict__ e2x3, const double *__restrict__ e1x3,
-                  const double *__restrict__ c1, const double *__restrict__ c2,
-                  const double *__restrict__ c3, const double *__restrict__ flx1,
-                  const double *__restrict__ flx2, const double *__restrict__ flx3, double gam0,
-                  double gam1, double beta_dt, double *__restrict__ b0x1f, double *__restrict__ b0x2f,
-                  double *__restrict__ b0x3f, double *__restrict__ b1x1f, double *__restrict__ b1x2f,
-                  double *__restrict__ b1x3f, int copy_b1, int kA, int kB, int nchunk, int ckl, int tw, int th,
-                  CtShellOut so) {
-  corner_ct_body<AKMI_POW2DX != 0, false, true>(g, MfBits{}, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, c1, c2, c3, flx1, flx2,
-                                                flx3, gam0, gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f,
-                                                copy_b1, kA, kB, 1, nchunk, ckl, tw, th, nullptr, so);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2503,12 +2465,11 @@ template <bool MHD>
 static int sweeps_store_fluxes_t(const akmi_pack *p, int recon, int rsolver, const double *w0,
                                  const double *bcc0, const double *bx1f, const double *bx2f, const double *bx3f,
                                  double *flx1, double *flx2, double *flx3, int fsh, double *e3x1, double *e2x1,
-                                 double *e1x2, double *e3x2, double *e2x3, double *e1x3, hipStream_t st,
-                                 double *ecc1 = nullptr, double *ecc2 = nullptr, double *ecc3 = nullptr) {
+                                 double *e1x2, double *e3x2, double *e2x3, double *e1x3, hipStream_t st) {
   Geo g = make_geo(p);
   if ((size_t)(g.N3 + 1)*(g.N2 + 1)*(g.N1 + 1)*sizeof(double) >= ((size_t)1 << 32)) return -1;   // caller falls back
   const Scheme sc{recon, rsolver, make_face_eos(p), !p->is_ideal};
-  SweepArgs a1{w0, bcc0, bx1f, flx1, e3x1, e2x1, ecc1, ecc2, ecc3,
+  SweepArgs a1{w0, bcc0, bx1f, flx1, e3x1, e2x1, nullptr, nullptr, nullptr,
                g.is, g.ie + 1, g.js, g.je, g.ks, g.ke, g.N3, g.N2, g.N1 + fsh};
   SweepArgs a2{w0, bcc0, bx2f, flx2, e1x2, e3x2, nullptr, nullptr, nullptr,
                g.is, g.ie, g.js, g.je + 1, g.ks, g.ke, g.N3, g.N2 + fsh, g.N1};
@@ -2522,8 +2483,7 @@ static int sweeps_store_fluxes_t(const akmi_pack *p, int recon, int rsolver, con
     a3.il = g.is - 1; a3.iu = g.ie + 1; a3.jl = g.js - 1; a3.ju = g.je + 1;
   }
   const UpdArgs u{};
-  // ecc1..3 (MHD, akmi_mhd_fluxes_ecc): the x1 sweep also leaves the cell-centred EMFs, as in the fused stage
-  int rc = (MHD && ecc1) ? launch_sweep<0, MHD, MHD>(g, sc, a1, st) : launch_sweep<0, MHD, false>(g, sc, a1, st);
+  int rc = launch_sweep<0, MHD, false>(g, sc, a1, st);
 #if AKMI_SMALL_FACE_SWEEPS
   // small packs (the deck-size mesh of BASELINE config 5): a march is a chain of dependent steps per thread and a
   // few hundred workgroups; one thread per face has no chain at all
@@ -2542,11 +2502,11 @@ static int sweeps_store_fluxes_t(const akmi_pack *p, int recon, int rsolver, con
 int sweeps_store_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0, const double *bcc0,
                         const double *bx1f, const double *bx2f, const double *bx3f, double *flx1, double *flx2,
                         double *flx3, int face_shaped, double *e3x1, double *e2x1, double *e1x2, double *e3x2,
-                        double *e2x3, double *e1x3, void *stream, double *ecc1, double *ecc2, double *ecc3) {
+                        double *e2x3, double *e1x3, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   if (bcc0)
     return sweeps_store_fluxes_t<true>(p, recon, rsolver, w0, bcc0, bx1f, bx2f, bx3f, flx1, flx2, flx3, 1,
-                                       e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, st, ecc1, ecc2, ecc3);
+                                       e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, st);
   return sweeps_store_fluxes_t<false>(p, recon, rsolver, w0, nullptr, nullptr, nullptr, nullptr, flx1, flx2,
                                       flx3, face_shaped ? 1 : 0, nullptr, nullptr, nullptr, nullptr, nullptr,
                                       nullptr, st);
@@ -2973,31 +2933,6 @@ int akmi_hydro_c2p_shell(const akmi_pack *p, double *u0, double *w0, int *counte
 int akmi_mhd_c2p_shell(const akmi_pack *p, double *u0, const double *bx1f, const double *bx2f,
                        const double *bx3f, double *w0, double *bcc0, int *counters, void *stream) {
   return c2p_shell<true>(p, u0, bx1f, bx2f, bx3f, w0, bcc0, counters, (hipStream_t)stream);
-}
-
-/* CornerE + CT of a 3-D pack on a refined mesh, the part no EMF correction can reach (see corner_ct_body, SHELL) */
-int akmi_mhd_corner_ct_inner(const akmi_pack *p, double gam0, double gam1, double beta_dt, int oop, const double *e3x1,
-                             const double *e2x1, const double *e1x2, const double *e3x2, const double *e2x3,
-                             const double *e1x3, const double *ecc1, const double *ecc2, const double *ecc3,
-                             const double *flx1, const double *flx2, const double *flx3, double *e1, double *e2,
-                             double *e3, double *b0x1f, double *b0x2f, double *b0x3f, double *b1x1f, double *b1x2f,
-                             double *b1x3f, void *stream) {
-  using namespace akmi;
-  Geo g = make_geo(p);
-  if (!g.three_d) { set_error("mhd_corner_ct_inner: 3-D packs only"); return AKMI_FAIL; }
-  if ((size_t)(g.N3 + 1)*(g.N2 + 1)*(g.N1 + 1)*sizeof(double) >= ((size_t)1 << 32)) {
-    set_error("mhd_corner_ct_inner: a MeshBlock exceeds 4 GB per variable");
-    return AKMI_FAIL;
-  }
-  const CtTile tl = ct_tile(g.nx1 + 1, g.nx2 + 1);
-  const int ckl = march_len((long)tl.n1*tl.n2, g.nx3, g.nmb, CKL);
-  const int nchunk = cdiv(g.nx3, ckl);
-  dim3 grid(tl.n1, tl.n2, nchunk*g.nmb), block(tl.threads);
-  k_corner_ct_inner<<<grid, block, 7*tl.tw*tl.th*sizeof(double), (hipStream_t)stream>>>(
-      g, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, ecc1, ecc2, ecc3, flx1, flx2, flx3, gam0, gam1, beta_dt, b0x1f, b0x2f,
-      b0x3f, b1x1f, b1x2f, b1x3f, oop ? 2 : 0, g.ks, g.ke, nchunk, ckl, tl.tw, tl.th, CtShellOut{e1, e2, e3});
-  AKMI_CHECK_LAUNCH("corner_ct_inner");
-  return AKMI_COMPLETE;
 }
 
 }  // extern "C"

@@ -818,83 +818,6 @@ k_ct_oop(Geo g, double gam0, double gam1, double beta_dt, const double *__restri
 #undef E3
 }
 
-// CT of the faces akmi_mhd_corner_ct_inner leaves out on refined meshes: a face with at least one of its four edges on
-// the surface of its MeshBlock -- the only edges the EMF correction (flux_correct_fc.cpp:374-1036) can change.  Same
-// expressions and ranges as k_ct / k_ct_oop (mhd_ct.cpp:45-77); every other face of the CT ranges is skipped without a
-// load.  OOP (first stage out of place): source register s*, destination d*; the faces outside the CT ranges (ghost
-// faces) are copied as k_ct_oop does, the inner faces of the ranges were written by akmi_mhd_corner_ct_inner.
-template <bool OOP>
-__global__ void __launch_bounds__(BX*BY)
-k_ct_shell(Geo g, double gam0, double gam1, double beta_dt, const double *__restrict__ e1,
-           const double *__restrict__ e2, const double *__restrict__ e3, const double *sx1f,
-           const double *sx2f, const double *sx3f, double *dx1f,
-           double *dx2f, double *dx3f, const double *__restrict__ rx1f,
-           const double *__restrict__ rx2f, const double *__restrict__ rx3f) {
-  int i, j, k, m;
-  if constexpr (OOP) {
-    const long p = ((long)blockIdx.x*BY + threadIdx.y)*BX + threadIdx.x;      // rows of N1+1 over j in [0, N2]
-    j = (int)(p/(g.N1 + 1));
-    i = (int)(p - (long)j*(g.N1 + 1));
-    m = blockIdx.z/(g.N3 + 1);
-    k = blockIdx.z - m*(g.N3 + 1);
-    if (j > g.N2) return;
-  } else {
-    flat_ij(g, g.js, i, j);
-    const int nk = g.ke - g.ks + 2;
-    m = blockIdx.z/nk;
-    k = g.ks + (blockIdx.z - m*nk);
-    if (i < g.is || i > g.ie + 1 || j > g.je + 1) return;
-  }
-  const bool in = i >= g.is && i <= g.ie + 1 && j >= g.js && j <= g.je + 1 && k >= g.ks && k <= g.ke + 1;
-  // positions on the first / last cell (c*) or the first / last face (f*) of the block along each axis
-  const bool ci = i == g.is || i == g.ie, cj = j == g.js || j == g.je, ck = k == g.ks || k == g.ke;
-  const bool fi = i == g.is || i == g.ie + 1, fj = j == g.js || j == g.je + 1, fk = k == g.ks || k == g.ke + 1;
-  const bool u1 = in && j <= g.je && k <= g.ke, u2 = in && i <= g.ie && k <= g.ke, u3 = in && i <= g.ie && j <= g.je;
-  const bool s1 = u1 && (fi || cj || ck), s2 = u2 && (fj || ci || ck), s3 = u3 && (fk || ci || cj);
-  if (!OOP && !(s1 || s2 || s3)) return;
-  const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
-#define E1(k, j, i) e1[ix4(g.N3 + 1, g.N2 + 1, g.N1, m, k, j, i)]
-#define E2(k, j, i) e2[ix4(g.N3 + 1, g.N2, g.N1 + 1, m, k, j, i)]
-#define E3(k, j, i) e3[ix4(g.N3, g.N2 + 1, g.N1 + 1, m, k, j, i)]
-  const bool p2 = is_pow2(dx1) && is_pow2(dx2) && is_pow2(dx3);
-  const int n1 = pow2_shift(dx1), n2 = pow2_shift(dx2), n3 = pow2_shift(dx3);
-#define DIVX(x, q) (p2 ? ldexp((x), n##q) : (x)/dx##q)
-  if (s1 || (OOP && !u1 && k < g.N3 && j < g.N2)) {                  // x1f (N3, N2, N1+1)
-    const size_t c = ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i);
-    double b = sx1f[c];
-    if (s1) {
-      b = gam0*b + gam1*(OOP ? b : rx1f[c]);
-      b -= DIVX(beta_dt*(E3(k, j + 1, i) - E3(k, j, i)), 2);
-      b += DIVX(beta_dt*(E2(k + 1, j, i) - E2(k, j, i)), 3);
-    }
-    dx1f[c] = b;
-  }
-  if (s2 || (OOP && !u2 && k < g.N3 && i < g.N1)) {                  // x2f (N3, N2+1, N1)
-    const size_t c = ix4(g.N3, g.N2 + 1, g.N1, m, k, j, i);
-    double b = sx2f[c];
-    if (s2) {
-      b = gam0*b + gam1*(OOP ? b : rx2f[c]);
-      b += DIVX(beta_dt*(E3(k, j, i + 1) - E3(k, j, i)), 1);
-      b -= DIVX(beta_dt*(E1(k + 1, j, i) - E1(k, j, i)), 3);
-    }
-    dx2f[c] = b;
-  }
-  if (s3 || (OOP && !u3 && j < g.N2 && i < g.N1)) {                  // x3f (N3+1, N2, N1)
-    const size_t c = ix4(g.N3 + 1, g.N2, g.N1, m, k, j, i);
-    double b = sx3f[c];
-    if (s3) {
-      b = gam0*b + gam1*(OOP ? b : rx3f[c]);
-      b -= DIVX(beta_dt*(E2(k, j, i + 1) - E2(k, j, i)), 1);
-      b += DIVX(beta_dt*(E1(k, j + 1, i) - E1(k, j, i)), 2);
-    }
-    dx3f[c] = b;
-  }
-#undef DIVX
-#undef E1
-#undef E2
-#undef E3
-}
-
 // Hydro::FOFC part 1 (hydro_fofc.cpp:46-85): trial update + floor test of one cell
 __global__ void __launch_bounds__(BX*BY)
 k_fofc_flag_hyd(Geo g, Eos eos, double gam0, double gam1, double beta_dt,
@@ -1288,31 +1211,11 @@ static int fofc_checks(const akmi_pack *p, int recon, const char *what, bool ide
   return AKMI_COMPLETE;
 }
 
-// cell-centred EMFs E = -v x B of the cells [is-1,ie+1] x [js-1,je+1] x [ks-1,ke+1] (mhd_corner_e.cpp:309-332); only for
-// packs the sweeps do not take (they leave the same values on their way, akmi_stage.hip k_sweep ECC)
-__global__ void __launch_bounds__(BX*BY)
-k_ecc(Geo g, const double *__restrict__ w0, const double *__restrict__ bcc0, double *__restrict__ c1,
-      double *__restrict__ c2, double *__restrict__ c3) {
-  int i, j;
-  flat_ij(g, g.js - 1, i, j);
-  const int nk = g.ke - g.ks + 3;
-  const int m = blockIdx.z/nk;
-  const int k = g.ks - 1 + (blockIdx.z - m*nk);
-  if (i < g.is - 1 || i > g.ie + 1 || j > g.je + 1) return;
-  const size_t c = ix4(g.N3, g.N2, g.N1, m, k, j, i), cs = (size_t)g.N3*g.N2*g.N1;
-  const double *wm = w0 + (size_t)m*g.nvar*cs + (c - (size_t)m*cs), *bm = bcc0 + (size_t)m*3*cs + (c - (size_t)m*cs);
-  const double vx = wm[cs], vy = wm[2*cs], vz = wm[3*cs], bx = bm[0], by = bm[cs], bz = bm[2*cs];
-  c1[c] = vz*by - vy*bz;
-  c2[c] = vx*bz - vz*bx;
-  c3[c] = vy*bx - vx*by;
-}
-
 static int mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0,
                       const double *bcc0, const double *bx1f, const double *bx2f,
                       const double *bx3f, double *flx1, double *flx2, double *flx3, double *e3x1,
                       double *e2x1, double *e1x2, double *e3x2, double *e2x3, double *e1x3,
-                      void *stream, int ext, double *ecc1 = nullptr, double *ecc2 = nullptr,
-                      double *ecc3 = nullptr) {
+                      void *stream, int ext) {
   if (check_scheme(p, recon, "mhd_fluxes") != AKMI_COMPLETE) return AKMI_FAIL;
   if (ext && fofc_checks(p, recon, "mhd_fluxes_fofc", true) != AKMI_COMPLETE) return AKMI_FAIL;
   Geo g = make_geo(p);
@@ -1320,13 +1223,8 @@ static int mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *
   hipStream_t st = (hipStream_t)stream;
   if (use_sweeps(p, rsolver, ext)) {
     const int r = sweeps_store_fluxes(p, recon, rsolver, w0, bcc0, bx1f, bx2f, bx3f, flx1, flx2, flx3, 1, e3x1,
-                                      e2x1, e1x2, e3x2, e2x3, e1x3, stream, ecc1, ecc2, ecc3);
+                                      e2x1, e1x2, e3x2, e2x3, e1x3, stream);
     if (r != -1) return r;
-  }
-  if (ecc1) {
-    if (!g.three_d) { set_error("mhd_fluxes_ecc: 3-D packs only"); return AKMI_FAIL; }
-    dim3 grid = flat_grid(g, g.je - g.js + 3, (g.ke - g.ks + 3)*g.nmb), block(BX, BY);
-    k_ecc<<<grid, block, 0, st>>>(g, w0, bcc0, ecc1, ecc2, ecc3);
   }
   int rc = launch_mhd_flux<0>(g, sc, w0, bcc0, bx1f, flx1, e3x1, e2x1, st, ext);
   if (rc == AKMI_COMPLETE && g.multi_d)
@@ -1343,16 +1241,6 @@ int akmi_mhd_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0
                     void *stream) {
   return mhd_fluxes(p, recon, rsolver, w0, bcc0, bx1f, bx2f, bx3f, flx1, flx2, flx3, e3x1, e2x1,
                     e1x2, e3x2, e2x3, e1x3, stream, 0);
-}
-
-int akmi_mhd_fluxes_ecc(const akmi_pack *p, int recon, int rsolver, const double *w0,
-                        const double *bcc0, const double *bx1f, const double *bx2f,
-                        const double *bx3f, double *flx1, double *flx2, double *flx3, double *e3x1,
-                        double *e2x1, double *e1x2, double *e3x2, double *e2x3, double *e1x3,
-                        double *ecc1, double *ecc2, double *ecc3, void *stream) {
-  if (!ecc1 || !ecc2 || !ecc3) { akmi::set_error("mhd_fluxes_ecc: null ecc array"); return AKMI_FAIL; }
-  return mhd_fluxes(p, recon, rsolver, w0, bcc0, bx1f, bx2f, bx3f, flx1, flx2, flx3, e3x1, e2x1,
-                    e1x2, e3x2, e2x3, e1x3, stream, 0, ecc1, ecc2, ecc3);
 }
 
 int akmi_mhd_fluxes_fofc(const akmi_pack *p, int recon, int rsolver, const double *w0,
@@ -1462,25 +1350,6 @@ int akmi_mhd_ct_oop(const akmi_pack *p, double gam0, double gam1, double beta_dt
   k_ct_oop<<<grid, block, 0, (hipStream_t)stream>>>(g, gam0, gam1, beta_dt, e1, e2, e3, b0x1f, b0x2f, b0x3f, b1x1f,
                                                     b1x2f, b1x3f);
   AKMI_CHECK_LAUNCH("ct_oop");
-  return AKMI_COMPLETE;
-}
-
-/* CT of the faces akmi_mhd_corner_ct_inner left for after the EMF correction (3-D). */
-int akmi_mhd_ct_shell(const akmi_pack *p, double gam0, double gam1, double beta_dt, int oop, const double *e1,
-                      const double *e2, const double *e3, double *b0x1f, double *b0x2f, double *b0x3f, double *b1x1f,
-                      double *b1x2f, double *b1x3f, void *stream) {
-  Geo g = make_geo(p);
-  if (!g.three_d) { set_error("mhd_ct_shell: 3-D packs only"); return AKMI_FAIL; }
-  if (oop) {
-    dim3 grid((unsigned)(((long)(g.N2 + 1)*(g.N1 + 1) + BX*BY - 1)/(BX*BY)), 1, (unsigned)((g.N3 + 1)*g.nmb)), block(BX, BY);
-    k_ct_shell<true><<<grid, block, 0, (hipStream_t)stream>>>(g, gam0, gam1, beta_dt, e1, e2, e3, b0x1f, b0x2f, b0x3f,
-                                                             b1x1f, b1x2f, b1x3f, nullptr, nullptr, nullptr);
-  } else {
-    dim3 grid = flat_grid(g, g.je - g.js + 2, (g.ke - g.ks + 2)*g.nmb), block(BX, BY);
-    k_ct_shell<false><<<grid, block, 0, (hipStream_t)stream>>>(g, gam0, gam1, beta_dt, e1, e2, e3, b0x1f, b0x2f, b0x3f,
-                                                              b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f);
-  }
-  AKMI_CHECK_LAUNCH("ct_shell");
   return AKMI_COMPLETE;
 }
 

@@ -165,21 +165,6 @@ class MHD(FluidBase):
     def _b(self, f):
         return capi._p(f.x1f), capi._p(f.x2f), capi._p(f.x3f)
 
-    def _ct_inner(self):
-        """refined 3-D meshes: CornerE + CT of the faces no EMF correction can reach in one kernel (EField), the
-        faces that touch the surface of their MeshBlock after SendE/RecvE (CT) -- include/akmi.h,
-        akmi_mhd_corner_ct_inner.  Not with resistive EMFs (added to every edge between the two tasks) or FOFC.
-        AKMI_SMR_CT_INNER=0: the two kernels of the task chain (A/B measurements)."""
-        on = getattr(self, "_ct_inner_on", None)
-        if on is None:
-            on = (self.multilevel and not self.fused and not self.sweep_update and not self.use_fofc
-                  and not self.kinematic and self.presist is None and self.pmy_pack.pmesh.mb_indcs.nx3 > 1
-                  and _os.environ.get("AKMI_SMR_CT_INNER", "1") != "0")
-            if on:
-                self.ecc = [torch.zeros_like(self.e3x1) for _ in range(3)]
-            self._ct_inner_on = on
-        return on
-
     def CopyCons(self, pdrive, stage):
         """mhd_tasks.cpp:162-170"""
         if self._oop_first(pdrive, stage):
@@ -211,9 +196,6 @@ class MHD(FluidBase):
         elif not self.fused:
             efc = [capi._p(x) for x in (self.e3x1, self.e2x1, self.e1x2, self.e3x2, self.e2x3, self.e1x3)]
             fn = self.L.akmi_mhd_fluxes_fofc if self.use_fofc else self.L.akmi_mhd_fluxes
-            if self._ct_inner():
-                fn = self.L.akmi_mhd_fluxes_ecc
-                efc += [capi._p(x) for x in self.ecc]
             capi.check(fn(C.byref(self.pack_c), self.recon_method, self.rsolver_method,
                           capi._p(self.w0), capi._p(self.bcc0), *self._b(self.b0), *self._b(self.uflx),
                           *efc, capi._stream()), "mhd_fluxes")
@@ -318,15 +300,7 @@ class MHD(FluidBase):
 
     def EField(self, pdrive, stage):
         """MHD::CornerE, mhd_corner_e.cpp:26-417"""
-        if self._ct_inner():
-            capi.check(self.L.akmi_mhd_corner_ct_inner(
-                C.byref(self.pack_c), capi.d(pdrive.gam0[stage - 1]), capi.d(pdrive.gam1[stage - 1]),
-                capi.d(pdrive.beta[stage - 1]*self.pmy_pack.pmesh.dt), 1 if self._oop_first(pdrive, stage) else 0,
-                capi._p(self.e3x1), capi._p(self.e2x1), capi._p(self.e1x2), capi._p(self.e3x2), capi._p(self.e2x3),
-                capi._p(self.e1x3), *[capi._p(x) for x in self.ecc], *self._b(self.uflx), capi._p(self.efld.x1e),
-                capi._p(self.efld.x2e), capi._p(self.efld.x3e), *self._b(self.b0), *self._b(self.b1),
-                capi._stream()), "mhd_corner_ct_inner")
-        elif not self.fused:
+        if not self.fused:
             capi.check(self.L.akmi_mhd_corner_e(
                 C.byref(self.pack_c), capi._p(self.w0), capi._p(self.bcc0), capi._p(self.e3x1),
                 capi._p(self.e2x1), capi._p(self.e1x2), capi._p(self.e3x2), capi._p(self.e2x3),
@@ -343,15 +317,6 @@ class MHD(FluidBase):
         elif not self.fused:
             gam0, gam1 = pdrive.gam0[stage - 1], pdrive.gam1[stage - 1]
             beta_dt = pdrive.beta[stage - 1]*self.pmy_pack.pmesh.dt
-            if self._ct_inner():
-                oop = self._oop_first(pdrive, stage)
-                capi.check(self.L.akmi_mhd_ct_shell(
-                    C.byref(self.pack_c), capi.d(gam0), capi.d(gam1), capi.d(beta_dt), 1 if oop else 0,
-                    capi._p(self.efld.x1e), capi._p(self.efld.x2e), capi._p(self.efld.x3e),
-                    *self._b(self.b0), *self._b(self.b1), capi._stream()), "mhd_ct_shell")
-                if oop:
-                    self.b0, self.b1 = self.b1, self.b0
-                return TaskStatus.complete
             if self._oop_first(pdrive, stage):
                 capi.check(self.L.akmi_mhd_ct_oop(
                     C.byref(self.pack_c), capi.d(gam0), capi.d(gam1), capi.d(beta_dt),

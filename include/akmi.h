@@ -455,37 +455,6 @@ int akmi_smr_pack_emf(const akmi_pack *p, const akmi_smr *t, const double *e1, c
 int akmi_smr_unpack_emf(const akmi_pack *p, const akmi_smr *t, const int *nflx, const double *buf, double *e1,
                         double *e2, double *e3, void *stream);
 
-/* ---- Refined meshes: CornerE + CT in one kernel around the EMF correction ----------------------------- *
- * On a mesh with levels the reference runs EField -> SendE -> RecvE -> CT (src/mhd/mhd_tasks.cpp:66-70): the corner EMFs
- * have to exist in memory because RecvAndUnpackFluxFC (src/bvals/flux_correct_fc.cpp:374-1036) sums, zeroes and
- * averages the copies MeshBlocks hold of an edge -- but only of edges ON THE SURFACE of a MeshBlock.  A face none of whose
- * four edges lies on that surface gets the same CT with or without the correction.  The three calls below split the
- * two tasks accordingly (3-D packs, results identical to akmi_mhd_corner_e + akmi_smr_emf_exchange + akmi_mhd_ct[_oop]):
- *   akmi_mhd_fluxes_ecc        akmi_mhd_fluxes + the cell-centred EMFs E = -v x B (mhd_corner_e.cpp:309-332) of the cells
- *                              [is-1,ie+1] x [js-1,je+1] x [ks-1,ke+1] in ecc1..3 (cell-shaped), left by the x1 sweep;
- *   akmi_mhd_corner_ct_inner   task EField: the corner EMFs (mhd_corner_e.cpp:338-414) of every edge, kept on chip, CT
- *                              (mhd_ct.cpp:45-77) of the inner faces at once; e1/e2/e3 (edge-shaped) receive the corner
- *                              EMFs of the surface edges and of the other edges of the faces that touch the surface --
- *                              what akmi_smr_pack_emf / akmi_smr_unpack_emf and akmi_mhd_ct_shell read; no other entry
- *                              of e1/e2/e3 is written;
- *   akmi_mhd_ct_shell          task CT: the faces with an edge on the surface, after the correction.
- * oop != 0 (first stage out of place, as akmi_mhd_ct_oop): b0 is only read, the new field goes to b1 -- inner faces by the
- * first call, surface faces and a copy of the ghost faces by the second -- and the caller swaps the registers. */
-int akmi_mhd_fluxes_ecc(const akmi_pack *p, int recon, int rsolver, const double *w0,
-                        const double *bcc0, const double *bx1f, const double *bx2f,
-                        const double *bx3f, double *flx1, double *flx2, double *flx3,
-                        double *e3x1, double *e2x1, double *e1x2, double *e3x2, double *e2x3,
-                        double *e1x3, double *ecc1, double *ecc2, double *ecc3, void *stream);
-int akmi_mhd_corner_ct_inner(const akmi_pack *p, double gam0, double gam1, double beta_dt, int oop, const double *e3x1,
-                             const double *e2x1, const double *e1x2, const double *e3x2, const double *e2x3,
-                             const double *e1x3, const double *ecc1, const double *ecc2, const double *ecc3,
-                             const double *flx1, const double *flx2, const double *flx3, double *e1, double *e2,
-                             double *e3, double *b0x1f, double *b0x2f, double *b0x3f, double *b1x1f, double *b1x2f,
-                             double *b1x3f, void *stream);
-int akmi_mhd_ct_shell(const akmi_pack *p, double gam0, double gam1, double beta_dt, int oop, const double *e1,
-                      const double *e2, const double *e3, double *b0x1f, double *b0x2f, double *b0x3f, double *b1x1f,
-                      double *b1x2f, double *b1x3f, void *stream);
-
 /* ---- Fused fast path ("one kernel sequence per MeshBlockPack stage") ----------------- *
  * Must produce results identical to the task chain above.  ws = device workspace of
  * akmi_stage_workspace_bytes() bytes owned by the caller. */

@@ -72,19 +72,6 @@ int akref_rk_update_oop(const akmi_pack *p, double gam0, double gam1, double bet
 int akref_mhd_ct_oop(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *e1, const double *e2,
                      const double *e3, const double *b0x1f, const double *b0x2f, const double *b0x3f, double *b1x1f,
                      double *b1x2f, double *b1x3f);
-int akref_mhd_fluxes_ecc(const akmi_pack *p, int recon, int rsolver, const double *w0, const double *bcc0,
-                         const double *bx1f, const double *bx2f, const double *bx3f, double *flx1, double *flx2,
-                         double *flx3, double *e3x1, double *e2x1, double *e1x2, double *e3x2, double *e2x3,
-                         double *e1x3, double *ecc1, double *ecc2, double *ecc3);
-int akref_mhd_corner_ct_inner(const akmi_pack *p, double gam0, double gam1, double beta_dt, int oop, const double *e3x1,
-                              const double *e2x1, const double *e1x2, const double *e3x2, const double *e2x3,
-                              const double *e1x3, const double *ecc1, const double *ecc2, const double *ecc3,
-                              const double *flx1, const double *flx2, const double *flx3, double *e1, double *e2,
-                              double *e3, double *b0x1f, double *b0x2f, double *b0x3f, double *b1x1f, double *b1x2f,
-                              double *b1x3f);
-int akref_mhd_ct_shell(const akmi_pack *p, double gam0, double gam1, double beta_dt, int oop, const double *e1,
-                       const double *e2, const double *e3, double *b0x1f, double *b0x2f, double *b0x3f, double *b1x1f,
-                       double *b1x2f, double *b1x3f);
 int akref_restrict_cc_masked(const akmi_pack *p, int nvar, const unsigned char *mask, const double *u, double *cu);
 int akref_restrict_fc_masked(const akmi_pack *p, const unsigned char *mask, const double *b1, const double *b2,
                              const double *b3, double *cb1, double *cb2, double *cb3);

@@ -2004,74 +2004,6 @@ int akref_history_sums(const akmi_pack *p, int is_mhd, const double *u0, const d
   return 0;
 }
 
-/* emf3 of the 3-D branch (src/mhd/mhd_corner_e.cpp:338-414) from given cell-centred EMFs */
-#define CC(a,m,k,j,i)  a[ix4(N3,N2,N1,m,k,j,i)]
-#define E1(m,k,j,i) e1[ix4(N3+1,N2+1,N1,m,k,j,i)]
-#define E2(m,k,j,i) e2[ix4(N3+1,N2,N1+1,m,k,j,i)]
-#define E3(m,k,j,i) e3[ix4(N3,N2+1,N1+1,m,k,j,i)]
-#define F1D(m,k,j,i) flx1[ix5(nv,N3,N2,N1+1,m,IDN,k,j,i)]
-#define F2D(m,k,j,i) flx2[ix5(nv,N3,N2+1,N1,m,IDN,k,j,i)]
-#define F3D(m,k,j,i) flx3[ix5(nv,N3+1,N2,N1,m,IDN,k,j,i)]
-static void corner_e_3d(const akmi_pack *p, const double *e1cc, const double *e2cc, const double *e3cc,
-                        const double *e3x1, const double *e2x1, const double *e1x2,
-                        const double *e3x2, const double *e2x3, const double *e1x3,
-                        const double *flx1, const double *flx2, const double *flx3,
-                        double *e1, double *e2, double *e3) {
-  G g = mkG(p);
-  const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
-  const int is = g.is, ie = g.ie, js = g.js, je = g.je, ks = g.ks, ke = g.ke;
-  /* emf3 (src/mhd/mhd_corner_e.cpp:338-414) */
-#pragma omp parallel for collapse(3) schedule(static)
-  for (int m = 0; m < g.nmb; ++m)
-    for (int k = ks; k <= ke+1; ++k)
-      for (int j = js; j <= je+1; ++j)
-        for (int i = is; i <= ie+1; ++i) {
-          double e1_l3, e1_r3, e1_l2, e1_r2;
-          if (F2D(m,k-1,j,i) >= 0.0) e1_l3 = CC(e1x3,m,k,j-1,i) - CC(e1cc,m,k-1,j-1,i);
-          else                       e1_l3 = CC(e1x3,m,k,j  ,i) - CC(e1cc,m,k-1,j  ,i);
-          if (F2D(m,k,j,i) >= 0.0)   e1_r3 = CC(e1x3,m,k,j-1,i) - CC(e1cc,m,k  ,j-1,i);
-          else                       e1_r3 = CC(e1x3,m,k,j  ,i) - CC(e1cc,m,k  ,j  ,i);
-          if (F3D(m,k,j-1,i) >= 0.0) e1_l2 = CC(e1x2,m,k-1,j,i) - CC(e1cc,m,k-1,j-1,i);
-          else                       e1_l2 = CC(e1x2,m,k  ,j,i) - CC(e1cc,m,k  ,j-1,i);
-          if (F3D(m,k,j,i) >= 0.0)   e1_r2 = CC(e1x2,m,k-1,j,i) - CC(e1cc,m,k-1,j  ,i);
-          else                       e1_r2 = CC(e1x2,m,k  ,j,i) - CC(e1cc,m,k  ,j  ,i);
-          /* the reference writes all three components over the full (k,j,i) range */
-          E1(m,k,j,i) = 0.25*(e1_l3 + e1_r3 + e1_l2 + e1_r2 +
-              CC(e1x2,m,k-1,j,i) + CC(e1x2,m,k,j,i) + CC(e1x3,m,k,j-1,i) + CC(e1x3,m,k,j,i));
-
-          double e2_l3, e2_r3, e2_l1, e2_r1;
-          if (F1D(m,k-1,j,i) >= 0.0) e2_l3 = CC(e2x3,m,k,j,i-1) - CC(e2cc,m,k-1,j,i-1);
-          else                       e2_l3 = CC(e2x3,m,k,j,i  ) - CC(e2cc,m,k-1,j,i  );
-          if (F1D(m,k,j,i) >= 0.0)   e2_r3 = CC(e2x3,m,k,j,i-1) - CC(e2cc,m,k  ,j,i-1);
-          else                       e2_r3 = CC(e2x3,m,k,j,i  ) - CC(e2cc,m,k  ,j,i  );
-          if (F3D(m,k,j,i-1) >= 0.0) e2_l1 = CC(e2x1,m,k-1,j,i) - CC(e2cc,m,k-1,j,i-1);
-          else                       e2_l1 = CC(e2x1,m,k  ,j,i) - CC(e2cc,m,k  ,j,i-1);
-          if (F3D(m,k,j,i) >= 0.0)   e2_r1 = CC(e2x1,m,k-1,j,i) - CC(e2cc,m,k-1,j,i  );
-          else                       e2_r1 = CC(e2x1,m,k  ,j,i) - CC(e2cc,m,k  ,j,i  );
-          E2(m,k,j,i) = 0.25*(e2_l3 + e2_r3 + e2_l1 + e2_r1 +
-              CC(e2x3,m,k,j,i-1) + CC(e2x3,m,k,j,i) + CC(e2x1,m,k-1,j,i) + CC(e2x1,m,k,j,i));
-
-          double e3_l2, e3_r2, e3_l1, e3_r1;
-          if (F1D(m,k,j-1,i) >= 0.0) e3_l2 = CC(e3x2,m,k,j,i-1) - CC(e3cc,m,k,j-1,i-1);
-          else                       e3_l2 = CC(e3x2,m,k,j,i  ) - CC(e3cc,m,k,j-1,i  );
-          if (F1D(m,k,j,i) >= 0.0)   e3_r2 = CC(e3x2,m,k,j,i-1) - CC(e3cc,m,k,j  ,i-1);
-          else                       e3_r2 = CC(e3x2,m,k,j,i  ) - CC(e3cc,m,k,j  ,i  );
-          if (F2D(m,k,j,i-1) >= 0.0) e3_l1 = CC(e3x1,m,k,j-1,i) - CC(e3cc,m,k,j-1,i-1);
-          else                       e3_l1 = CC(e3x1,m,k,j  ,i) - CC(e3cc,m,k,j  ,i-1);
-          if (F2D(m,k,j,i) >= 0.0)   e3_r1 = CC(e3x1,m,k,j-1,i) - CC(e3cc,m,k,j-1,i  );
-          else                       e3_r1 = CC(e3x1,m,k,j  ,i) - CC(e3cc,m,k,j  ,i  );
-          E3(m,k,j,i) = 0.25*(e3_l1 + e3_r1 + e3_l2 + e3_r2 +
-              CC(e3x2,m,k,j,i-1) + CC(e3x2,m,k,j,i) + CC(e3x1,m,k,j-1,i) + CC(e3x1,m,k,j,i));
-        }
-}
-#undef CC
-#undef E1
-#undef E2
-#undef E3
-#undef F1D
-#undef F2D
-#undef F3D
-
 /* MHD::CornerE, src/mhd/mhd_corner_e.cpp:26-417 (Newtonian branches: 1D :39-53,
  * 2D :58-66,139-192, 3D :303-414) */
 int akref_mhd_corner_e(const akmi_pack *p, const double *w0, const double *bcc0,
@@ -2140,7 +2072,49 @@ int akref_mhd_corner_e(const akmi_pack *p, const double *w0, const double *bcc0,
           CC(e2cc,m,k,j,i) = W(IVX,m,k,j,i)*B(IBZ,m,k,j,i) - W(IVZ,m,k,j,i)*B(IBX,m,k,j,i);
           CC(e3cc,m,k,j,i) = W(IVY,m,k,j,i)*B(IBX,m,k,j,i) - W(IVX,m,k,j,i)*B(IBY,m,k,j,i);
         }
-  corner_e_3d(p, e1cc, e2cc, e3cc, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, flx1, flx2, flx3, e1, e2, e3);
+  /* emf3 (src/mhd/mhd_corner_e.cpp:338-414) */
+#pragma omp parallel for collapse(3) schedule(static)
+  for (int m = 0; m < g.nmb; ++m)
+    for (int k = ks; k <= ke+1; ++k)
+      for (int j = js; j <= je+1; ++j)
+        for (int i = is; i <= ie+1; ++i) {
+          double e1_l3, e1_r3, e1_l2, e1_r2;
+          if (F2D(m,k-1,j,i) >= 0.0) e1_l3 = CC(e1x3,m,k,j-1,i) - CC(e1cc,m,k-1,j-1,i);
+          else                       e1_l3 = CC(e1x3,m,k,j  ,i) - CC(e1cc,m,k-1,j  ,i);
+          if (F2D(m,k,j,i) >= 0.0)   e1_r3 = CC(e1x3,m,k,j-1,i) - CC(e1cc,m,k  ,j-1,i);
+          else                       e1_r3 = CC(e1x3,m,k,j  ,i) - CC(e1cc,m,k  ,j  ,i);
+          if (F3D(m,k,j-1,i) >= 0.0) e1_l2 = CC(e1x2,m,k-1,j,i) - CC(e1cc,m,k-1,j-1,i);
+          else                       e1_l2 = CC(e1x2,m,k  ,j,i) - CC(e1cc,m,k  ,j-1,i);
+          if (F3D(m,k,j,i) >= 0.0)   e1_r2 = CC(e1x2,m,k-1,j,i) - CC(e1cc,m,k-1,j  ,i);
+          else                       e1_r2 = CC(e1x2,m,k  ,j,i) - CC(e1cc,m,k  ,j  ,i);
+          /* the reference writes all three components over the full (k,j,i) range */
+          E1(m,k,j,i) = 0.25*(e1_l3 + e1_r3 + e1_l2 + e1_r2 +
+              CC(e1x2,m,k-1,j,i) + CC(e1x2,m,k,j,i) + CC(e1x3,m,k,j-1,i) + CC(e1x3,m,k,j,i));
+
+          double e2_l3, e2_r3, e2_l1, e2_r1;
+          if (F1D(m,k-1,j,i) >= 0.0) e2_l3 = CC(e2x3,m,k,j,i-1) - CC(e2cc,m,k-1,j,i-1);
+          else                       e2_l3 = CC(e2x3,m,k,j,i  ) - CC(e2cc,m,k-1,j,i  );
+          if (F1D(m,k,j,i) >= 0.0)   e2_r3 = CC(e2x3,m,k,j,i-1) - CC(e2cc,m,k  ,j,i-1);
+          else                       e2_r3 = CC(e2x3,m,k,j,i  ) - CC(e2cc,m,k  ,j,i  );
+          if (F3D(m,k,j,i-1) >= 0.0) e2_l1 = CC(e2x1,m,k-1,j,i) - CC(e2cc,m,k-1,j,i-1);
+          else                       e2_l1 = CC(e2x1,m,k  ,j,i) - CC(e2cc,m,k  ,j,i-1);
+          if (F3D(m,k,j,i) >= 0.0)   e2_r1 = CC(e2x1,m,k-1,j,i) - CC(e2cc,m,k-1,j,i  );
+          else                       e2_r1 = CC(e2x1,m,k  ,j,i) - CC(e2cc,m,k  ,j,i  );
+          E2(m,k,j,i) = 0.25*(e2_l3 + e2_r3 + e2_l1 + e2_r1 +
+              CC(e2x3,m,k,j,i-1) + CC(e2x3,m,k,j,i) + CC(e2x1,m,k-1,j,i) + CC(e2x1,m,k,j,i));
+
+          double e3_l2, e3_r2, e3_l1, e3_r1;
+          if (F1D(m,k,j-1,i) >= 0.0) e3_l2 = CC(e3x2,m,k,j,i-1) - CC(e3cc,m,k,j-1,i-1);
+          else                       e3_l2 = CC(e3x2,m,k,j,i  ) - CC(e3cc,m,k,j-1,i  );
+          if (F1D(m,k,j,i) >= 0.0)   e3_r2 = CC(e3x2,m,k,j,i-1) - CC(e3cc,m,k,j  ,i-1);
+          else                       e3_r2 = CC(e3x2,m,k,j,i  ) - CC(e3cc,m,k,j  ,i  );
+          if (F2D(m,k,j,i-1) >= 0.0) e3_l1 = CC(e3x1,m,k,j-1,i) - CC(e3cc,m,k,j-1,i-1);
+          else                       e3_l1 = CC(e3x1,m,k,j  ,i) - CC(e3cc,m,k,j  ,i-1);
+          if (F2D(m,k,j,i) >= 0.0)   e3_r1 = CC(e3x1,m,k,j-1,i) - CC(e3cc,m,k,j-1,i  );
+          else                       e3_r1 = CC(e3x1,m,k,j  ,i) - CC(e3cc,m,k,j  ,i  );
+          E3(m,k,j,i) = 0.25*(e3_l1 + e3_r1 + e3_l2 + e3_r2 +
+              CC(e3x2,m,k,j,i-1) + CC(e3x2,m,k,j,i) + CC(e3x1,m,k,j-1,i) + CC(e3x1,m,k,j,i));
+        }
   return 0;
 }
 
@@ -2952,126 +2926,6 @@ int akref_mhd_ct_oop(const akmi_pack *p, double gam0, double gam1, double beta_d
   memcpy(b1x2f, b0x2f, sizeof(double)*(size_t)p->nmb*g.N3*(g.N2 + 1)*g.N1);
   memcpy(b1x3f, b0x3f, sizeof(double)*(size_t)p->nmb*(g.N3 + 1)*g.N2*g.N1);
   return akref_mhd_ct(p, gam0, gam1, beta_dt, e1, e2, e3, b1x1f, b1x2f, b1x3f, b0x1f, b0x2f, b0x3f);
-}
-
-/* twins of akmi_mhd_fluxes_ecc / akmi_mhd_corner_ct_inner / akmi_mhd_ct_shell (include/akmi.h): the reference's EField
- * and CT (mhd_corner_e.cpp:303-414, mhd_ct.cpp:45-77) cut by faces -- "inner" faces have none of their four edges on
- * the surface of the MeshBlock, the others wait for the EMF correction -- with the reference's own loops */
-int akref_mhd_fluxes_ecc(const akmi_pack *p, int recon, int rsolver, const double *w0, const double *bcc0,
-                         const double *bx1f, const double *bx2f, const double *bx3f, double *flx1, double *flx2,
-                         double *flx3, double *e3x1, double *e2x1, double *e1x2, double *e3x2, double *e2x3,
-                         double *e1x3, double *ecc1, double *ecc2, double *ecc3) {
-  G g = mkG(p);
-  const int nv = g.nvar, N1 = g.N1, N2 = g.N2, N3 = g.N3;
-  int rc = akref_mhd_fluxes(p, recon, rsolver, w0, bcc0, bx1f, bx2f, bx3f, flx1, flx2, flx3, e3x1, e2x1, e1x2, e3x2,
-                            e2x3, e1x3);
-  if (rc != 0 || !g.three_d) return rc ? rc : -1;
-  /* e_cc_3d (src/mhd/mhd_corner_e.cpp:309-317) */
-#pragma omp parallel for collapse(3) schedule(static)
-  for (int m = 0; m < g.nmb; ++m)
-    for (int k = g.ks-1; k <= g.ke+1; ++k)
-      for (int j = g.js-1; j <= g.je+1; ++j)
-        for (int i = g.is-1; i <= g.ie+1; ++i) {
-          const size_t c = ix4(N3,N2,N1,m,k,j,i);
-#define W(n) w0[ix5(nv,N3,N2,N1,m,n,k,j,i)]
-#define B(n) bcc0[ix5(3,N3,N2,N1,m,n,k,j,i)]
-          ecc1[c] = W(IVZ)*B(IBY) - W(IVY)*B(IBZ);
-          ecc2[c] = W(IVX)*B(IBZ) - W(IVZ)*B(IBX);
-          ecc3[c] = W(IVY)*B(IBX) - W(IVX)*B(IBY);
-#undef W
-#undef B
-        }
-  return 0;
-}
-/* CT of the faces selected by `shell` (1: an edge on the block surface, 0: none); src read, dst written, reg = the
- * second RK register */
-static void ct_faces(const akmi_pack *p, int shell, double gam0, double gam1, double beta_dt, const double *e1,
-                     const double *e2, const double *e3, const double *const s[3], double *const d[3],
-                     const double *const r[3]) {
-  G g = mkG(p);
-  const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
-  const int is = g.is, ie = g.ie, js = g.js, je = g.je, ks = g.ks, ke = g.ke;
-#pragma omp parallel for collapse(3) schedule(static)
-  for (int m = 0; m < g.nmb; ++m)
-    for (int k = ks; k <= ke; ++k)
-      for (int j = js; j <= je; ++j)
-        for (int i = is; i <= ie+1; ++i) {
-          if (((i == is) || (i == ie+1) || (j == js) || (j == je) || (k == ks) || (k == ke)) != (shell != 0)) continue;
-          size_t c = ix4(N3,N2,N1+1,m,k,j,i);
-          double b = gam0*s[0][c] + gam1*r[0][c];
-          b -= beta_dt*(E3(m,k,j+1,i) - E3(m,k,j,i))/p->dx[3*m+1];
-          b += beta_dt*(E2(m,k+1,j,i) - E2(m,k,j,i))/p->dx[3*m+2];
-          d[0][c] = b;
-        }
-#pragma omp parallel for collapse(3) schedule(static)
-  for (int m = 0; m < g.nmb; ++m)
-    for (int k = ks; k <= ke; ++k)
-      for (int j = js; j <= je+1; ++j)
-        for (int i = is; i <= ie; ++i) {
-          if (((j == js) || (j == je+1) || (i == is) || (i == ie) || (k == ks) || (k == ke)) != (shell != 0)) continue;
-          size_t c = ix4(N3,N2+1,N1,m,k,j,i);
-          double b = gam0*s[1][c] + gam1*r[1][c];
-          b += beta_dt*(E3(m,k,j,i+1) - E3(m,k,j,i))/p->dx[3*m];
-          b -= beta_dt*(E1(m,k+1,j,i) - E1(m,k,j,i))/p->dx[3*m+2];
-          d[1][c] = b;
-        }
-#pragma omp parallel for collapse(3) schedule(static)
-  for (int m = 0; m < g.nmb; ++m)
-    for (int k = ks; k <= ke+1; ++k)
-      for (int j = js; j <= je; ++j)
-        for (int i = is; i <= ie; ++i) {
-          if (((k == ks) || (k == ke+1) || (i == is) || (i == ie) || (j == js) || (j == je)) != (shell != 0)) continue;
-          size_t c = ix4(N3+1,N2,N1,m,k,j,i);
-          double b = gam0*s[2][c] + gam1*r[2][c];
-          b -= beta_dt*(E2(m,k,j,i+1) - E2(m,k,j,i))/p->dx[3*m];
-          b += beta_dt*(E1(m,k,j+1,i) - E1(m,k,j,i))/p->dx[3*m+1];
-          d[2][c] = b;
-        }
-}
-int akref_mhd_corner_ct_inner(const akmi_pack *p, double gam0, double gam1, double beta_dt, int oop, const double *e3x1,
-                              const double *e2x1, const double *e1x2, const double *e3x2, const double *e2x3,
-                              const double *e1x3, const double *ecc1, const double *ecc2, const double *ecc3,
-                              const double *flx1, const double *flx2, const double *flx3, double *e1, double *e2,
-                              double *e3, double *b0x1f, double *b0x2f, double *b0x3f, double *b1x1f, double *b1x2f,
-                              double *b1x3f) {
-  G g = mkG(p);
-  if (!g.three_d) return -1;
-  corner_e_3d(p, ecc1, ecc2, ecc3, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, flx1, flx2, flx3, e1, e2, e3);
-  const double *const b0[3] = {b0x1f, b0x2f, b0x3f}, *const b1[3] = {b1x1f, b1x2f, b1x3f};
-  double *const d0[3] = {b0x1f, b0x2f, b0x3f}, *const d1[3] = {b1x1f, b1x2f, b1x3f};
-  /* out of place: CopyCons then CT is gam0*b + gam1*b from the one source (akref_mhd_ct_oop) */
-  ct_faces(p, 0, gam0, gam1, beta_dt, e1, e2, e3, b0, oop ? d1 : d0, oop ? b0 : b1);
-  return 0;
-}
-int akref_mhd_ct_shell(const akmi_pack *p, double gam0, double gam1, double beta_dt, int oop, const double *e1,
-                       const double *e2, const double *e3, double *b0x1f, double *b0x2f, double *b0x3f, double *b1x1f,
-                       double *b1x2f, double *b1x3f) {
-  G g = mkG(p);
-  if (!g.three_d) return -1;
-  const double *const b0[3] = {b0x1f, b0x2f, b0x3f}, *const b1[3] = {b1x1f, b1x2f, b1x3f};
-  double *const d0[3] = {b0x1f, b0x2f, b0x3f}, *const d1[3] = {b1x1f, b1x2f, b1x3f};
-  if (oop) {
-    /* every face outside the CT ranges is copied (the memcpy of akref_mhd_ct_oop); the inner faces of the ranges
-     * hold the result of akref_mhd_corner_ct_inner already */
-    const int N1 = g.N1, N2 = g.N2, N3 = g.N3;
-    for (int m = 0; m < g.nmb; ++m)
-      for (int k = 0; k <= N3; ++k)
-        for (int j = 0; j <= N2; ++j)
-          for (int i = 0; i <= N1; ++i) {
-            const int in = i >= g.is && i <= g.ie+1 && j >= g.js && j <= g.je+1 && k >= g.ks && k <= g.ke+1;
-            if (k < N3 && j < N2 && !(in && j <= g.je && k <= g.ke)) {
-              size_t c = ix4(N3,N2,N1+1,m,k,j,i); b1x1f[c] = b0x1f[c];
-            }
-            if (k < N3 && i < N1 && !(in && i <= g.ie && k <= g.ke)) {
-              size_t c = ix4(N3,N2+1,N1,m,k,j,i); b1x2f[c] = b0x2f[c];
-            }
-            if (j < N2 && i < N1 && !(in && i <= g.ie && j <= g.je)) {
-              size_t c = ix4(N3+1,N2,N1,m,k,j,i); b1x3f[c] = b0x3f[c];
-            }
-          }
-  }
-  ct_faces(p, 1, gam0, gam1, beta_dt, e1, e2, e3, b0, oop ? d1 : d0, oop ? b0 : b1);
-  return 0;
 }
 
 /* twins of akmi_restrict_cc_masked / akmi_restrict_fc_masked (include/akmi.h): RestrictCC / RestrictFC for the

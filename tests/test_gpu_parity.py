@@ -263,101 +263,6 @@ def test_task_first_stage_out_of_place(dims):
         assert np.array_equal(x.cpu().numpy(), d.cpu().numpy())
 
 
-def _surface_edge_masks(o):
-    """boolean masks (block-local, broadcast over m) of the entries of e1/e2/e3 that lie ON the surface of a MeshBlock"""
-    n3, n2, n1 = o.dims()
-    pk = o.pack()
-    ng = pk.ng
-    is_, ie, js, je, ks, ke = ng, ng + pk.nx1 - 1, ng, ng + pk.nx2 - 1, ng, ng + pk.nx3 - 1
-    K, J, I = np.meshgrid(np.arange(n3 + 1), np.arange(n2 + 1), np.arange(n1 + 1), indexing="ij")
-    inr = (K >= ks) & (K <= ke + 1) & (J >= js) & (J <= je + 1) & (I >= is_) & (I <= ie + 1)
-    fi, fj, fk = (I == is_) | (I == ie + 1), (J == js) | (J == je + 1), (K == ks) | (K == ke + 1)
-    m1 = (inr & (I <= ie) & (fj | fk))[:, :, :n1]
-    m2 = (inr & (J <= je) & (fi | fk))[:, :n2, :]
-    m3 = (inr & (K <= ke) & (fi | fj))[:n3, :, :]
-    return m1, m2, m3
-
-
-@pytest.mark.parametrize("recon,ng,oop", [("plm", 2, 0), ("plm", 3, 1), ("ppm4", 4, 0), ("ppm4", 4, 1)])
-def test_task_corner_ct_inner_and_shell(recon, ng, oop):
-    """akmi_mhd_fluxes_ecc -> akmi_mhd_corner_ct_inner -> (surface edges changed, as the EMF correction of a refined
-    mesh does) -> akmi_mhd_ct_shell against the reference's own sequence in the oracle: akref_mhd_fluxes ->
-    akref_mhd_corner_e -> the same change of the surface edges -> akref_mhd_ct / akref_mhd_ct_oop.  Bit for bit, in
-    place and out of place; e1/e2/e3 are written nowhere but where the doc of the entry says."""
-    from athenak_amd import capi
-    o = _state("orszag_tang", 24, 3, 12, 3, ng=ng, cfl=0.3)
-    L, R = capi.lib(), akref.lib()
-    pk = o.pack()
-    dxd = _t(o.array("dx"))
-    pkd = capi.Pack.from_buffer_copy(bytes(pk))
-    pkd.dx = dxd.data_ptr()
-    rc = akref.RECON[recon]
-    rng = np.random.default_rng(23)
-    names_in = ["w0", "bcc0", "b0x1f", "b0x2f", "b0x3f"]
-    names_out = ["flx1", "flx2", "flx3", "e3x1", "e2x1", "e1x2", "e3x2", "e2x3", "e1x3"]
-    h = {k: o.array(k).copy() for k in names_in + names_out + ["e1", "e2", "e3", "b1x1f", "b1x2f", "b1x3f"]}
-    for k in names_out + ["e1", "e2", "e3"]:
-        h[k][...] = 0.0
-    for k in ("b1x1f", "b1x2f", "b1x3f"):
-        h[k] = np.ascontiguousarray(h[k] + 0.01*rng.standard_normal(h[k].shape))
-    dv = {k: _t(v) for k, v in h.items()}
-    ecc = [_t(np.full_like(h["e3x1"], np.nan)) for _ in range(3)]
-    R.akref_mhd_fluxes(C.byref(pk), rc, 3, *[akref.ptr(h[k]) for k in names_in + names_out])
-    capi.check(L.akmi_mhd_fluxes_ecc(C.byref(pkd), rc, 3, *[capi._p(dv[k]) for k in names_in + names_out],
-                                     *[capi._p(x) for x in ecc], None), "mhd_fluxes_ecc")
-    for k in names_out:
-        assert np.array_equal(h[k], dv[k].cpu().numpy()), k
-    # cell-centred EMFs where the corner formulas read them (mhd_corner_e.cpp:309-317)
-    w, b = h["w0"], h["bcc0"]
-    want = [w[:, 3]*b[:, 1] - w[:, 2]*b[:, 2], w[:, 1]*b[:, 2] - w[:, 3]*b[:, 0], w[:, 2]*b[:, 0] - w[:, 1]*b[:, 1]]
-    sl = (slice(None), slice(ng - 1, ng + pk.nx3 + 1), slice(ng - 1, ng + pk.nx2 + 1), slice(ng - 1, ng + pk.nx1 + 1))
-    for q in range(3):
-        assert np.array_equal(want[q][sl], ecc[q].cpu().numpy()[sl]), q
-    # the reference's sequence
-    ce = ["w0", "bcc0", "e3x1", "e2x1", "e1x2", "e3x2", "e2x3", "e1x3", "flx1", "flx2", "flx3", "e1", "e2", "e3"]
-    R.akref_mhd_corner_e(C.byref(pk), *[akref.ptr(h[k]) for k in ce])
-    masks = _surface_edge_masks(o)
-    corr = {}
-    for k, mk in zip(("e1", "e2", "e3"), masks):
-        corr[k] = h[k].copy()
-        h[k][:, mk] += 0.05*rng.standard_normal(h[k][:, mk].shape)          # "corrected" surface edges
-    a = (C.c_double(0.5), C.c_double(0.5), C.c_double(0.004)) if not oop else \
-        (C.c_double(0.0), C.c_double(1.0), C.c_double(0.004))
-    bn, b1n = ("b0x1f", "b0x2f", "b0x3f"), ("b1x1f", "b1x2f", "b1x3f")
-    if oop:
-        wantb = [np.full_like(h[k], np.nan) for k in bn]
-        R.akref_mhd_ct_oop(C.byref(pk), *a, akref.ptr(h["e1"]), akref.ptr(h["e2"]), akref.ptr(h["e3"]),
-                           *[akref.ptr(h[k]) for k in bn], *[akref.ptr(x) for x in wantb])
-    else:
-        wantb = [h[k].copy() for k in bn]
-        R.akref_mhd_ct(C.byref(pk), *a, akref.ptr(h["e1"]), akref.ptr(h["e2"]), akref.ptr(h["e3"]),
-                       *[akref.ptr(x) for x in wantb], *[akref.ptr(h[k]) for k in b1n])
-    # the product's two calls around the same change
-    ed = [_t(np.full_like(h[k], np.nan)) for k in ("e1", "e2", "e3")]
-    b0d = [dv[k] for k in bn]
-    b1d = [_t(np.full_like(h[k], np.nan)) for k in bn] if oop else [dv[k] for k in b1n]
-    fe = ["e3x1", "e2x1", "e1x2", "e3x2", "e2x3", "e1x3"]
-    capi.check(L.akmi_mhd_corner_ct_inner(
-        C.byref(pkd), *a, oop, *[capi._p(dv[k]) for k in fe], *[capi._p(x) for x in ecc],
-        *[capi._p(dv[k]) for k in ("flx1", "flx2", "flx3")], *[capi._p(x) for x in ed], *[capi._p(x) for x in b0d],
-        *[capi._p(x) for x in b1d], None), "corner_ct_inner")
-    for k, x, mk in zip(("e1", "e2", "e3"), ed, masks):
-        got = x.cpu().numpy()
-        wr = ~np.isnan(got)
-        assert np.array_equal(got[wr], corr[k][wr]), k            # what was written is the reference's corner EMF
-        assert wr[:, mk].all(), k                                 # every surface edge was written
-        got[:, mk] = h[k][:, mk]                                  # the correction
-        x.copy_(_t(got))
-    capi.check(L.akmi_mhd_ct_shell(C.byref(pkd), *a, oop, *[capi._p(x) for x in ed], *[capi._p(x) for x in b0d],
-                                   *[capi._p(x) for x in b1d], None), "ct_shell")
-    res = b1d if oop else b0d
-    for k, wv, d in zip(bn, wantb, res):
-        assert np.array_equal(wv, d.cpu().numpy()), k
-    if oop:                                                       # the source register is only read
-        for k, d in zip(bn, b0d):
-            assert np.array_equal(h[k], d.cpu().numpy()), k
-
-
 @pytest.mark.parametrize("bc", ["outflow", "reflect", "diode", "vacuum", "inflow", "mixed"])
 def test_task_bcs(bc):
     """HydroBCs / BFieldBCs for every physical boundary flag on all six faces (mixed: a different
