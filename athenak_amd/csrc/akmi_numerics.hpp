@@ -10,7 +10,7 @@
 // shape of the code: which values are alive at the same time, what is computed for both sides of a face and what
 // only for the side the answer comes from, what is shared between the two faces of a cell.  That shape is chosen
 // here for the register file (each function says how); the tables "value <- reference line" keep the audit
-// trail.  tests/test_numerics_host.py compiles this header for the CPU and compares it with the oracle.
+// trail.  tests/test_numerics_host.py compiles this header for the CPU and compares it with the CPU checker of the test suite.
 #ifndef AKMI_NUMERICS_HPP_
 #define AKMI_NUMERICS_HPP_
 #include <hip/hip_runtime.h>

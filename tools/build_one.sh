@@ -1,0 +1,11 @@
+#!/bin/bash
+# usage: tools/build_one.sh akmi_stage.hip [akmi_tasks.hip ...]  -- recompile the named translation units and relink
+# libakmi.so (the flags of __graft_entry__.build; the other objects must exist from a full build)
+root=$(cd $(dirname $0)/.. && pwd)
+cs=$root/athenak_amd/csrc; od=$root/athenak_amd/lib/obj
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-value -mllvm -amdgpu-schedule-relaxed-occupancy=true $AKMI_EXTRA_FLAGS"
+pids=()
+for f in "$@"; do ( cd $cs && /opt/rocm/bin/hipcc $FLAGS -c $f -o $od/$f.o ) & pids+=($!); done
+rc=0; for p in "${pids[@]}"; do wait $p || rc=1; done
+[ $rc = 0 ] || { echo "compile failed"; exit 1; }
+cd $cs && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/athenak_amd/lib/libakmi.so $od/*.o -ldl && echo linked
