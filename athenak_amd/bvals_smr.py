@@ -392,6 +392,7 @@ class MeshBoundaryValuesSMR:
                               self.t_roff.data_ptr() if self.peers else None, self.direct_same,
                               self.t_needs.data_ptr())
         self.pack_c = None
+        self._fcmap = None
         self._works = [[], [], [], []]
         self._hsend = [None]*4
         self._hrecv = [None]*4
@@ -530,14 +531,53 @@ class MeshBoundaryValuesSMR:
             self.k.gather_same(self.pack_c, self.nvar, self.t_same, u)
         return TaskStatus.complete
 
+    def _fc_maps(self):
+        """the face-field exchange as lists of element copies (include/akmi.h, akmi_smr_fc_map): [1] buffer <- arrays for
+        the messages to other ranks, [0] arrays <- arrays of this pack / received part of the buffer.  Built at the
+        first exchange; AKMI_SMR_FC_MAP=0: pack + slot-by-slot unpack (A/B switch).  HIP library only."""
+        if self._fcmap is None:
+            self._fcmap = False
+            if capi.DEVICE != "cpu" and os.environ.get("AKMI_SMR_FC_MAP", "1") != "0":
+                import torch
+                L, buf = capi.lib(), self.buf[2]
+                nb = int(buf.numel())
+                lo = min([a for (a, _) in self.send_slices[2].values()], default=nb) if self.peers else nb
+                maps = []
+                for which in (0, 1):
+                    args = (C.byref(self.pack_c), C.byref(self.smr_c), capi._p(buf), C.c_longlong(nb), C.c_longlong(lo),
+                            C.c_longlong(nb), which)
+                    tail = C.c_longlong(0)
+                    n = int(L.akmi_smr_fc_map(*args, None, C.c_longlong(0), C.byref(tail), capi._stream()))
+                    capi.check(n, "smr_fc_map")
+                    m = torch.zeros(max(2*n, 2), dtype=torch.int32, device=self.device)
+                    capi.check(int(L.akmi_smr_fc_map(*args, capi._p(m), C.c_longlong(n), C.byref(tail), capi._stream())),
+                               "smr_fc_map")
+                    maps.append((m, n, int(tail.value)))
+                self._fcmap = maps
+        return self._fcmap
+
+    def _fc_copy(self, which, b, cb):
+        m, n, tail = self._fcmap[which]
+        capi.check(capi.lib().akmi_smr_fc_copy(
+            C.byref(self.pack_c), capi._p(m), C.c_longlong(n), C.c_longlong(tail), C.c_longlong(int(self.buf[2].numel())),
+            capi._p(b.x1f),
+            capi._p(b.x2f), capi._p(b.x3f), capi._p(cb.x1f), capi._p(cb.x2f), capi._p(cb.x3f), capi._p(self.buf[2]),
+            capi._stream()), "smr_fc_copy")
+
     def PackAndSendFC(self, b, cb):
-        self.k.pack_fc(self.pack_c, self.smr_c, b, cb, self.buf[2])
+        if self._fc_maps():
+            self._fc_copy(1, b, cb)
+        else:
+            self.k.pack_fc(self.pack_c, self.smr_c, b, cb, self.buf[2])
         self._post(2)
         return TaskStatus.complete
 
     def RecvAndUnpackFC(self, b, cb):
         self._wait(2)
-        self.k.unpack_fc(self.pack_c, self.smr_c, self.buf[2], b, cb)
+        if self._fc_maps():
+            self._fc_copy(0, b, cb)
+        else:
+            self.k.unpack_fc(self.pack_c, self.smr_c, self.buf[2], b, cb)
         return TaskStatus.complete
 
     def FillCoarseInBndryCC(self, u, cu):

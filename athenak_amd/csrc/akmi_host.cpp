@@ -441,6 +441,7 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
     coarse_u0.Realloc(static_cast<size_t>(pp->nmb_thispack)*nvars*c3*c2*c1);
     psmr = new MeshBoundaryValuesSMR(pp, nvars);
     psmr->BuildLists(&pack_c, stream);
+    if (blk == "mhd") psmr->BuildFcMaps(&pack_c, stream);
   }
   if (!multilevel && (pp->pmesh->nranks > 1 || SelfExchange()))
     pbval = new MeshBoundaryValues(pp, &pack_c, nvars, blk == "mhd");
@@ -1188,6 +1189,11 @@ TaskStatus MHD::RecvE(Driver *d, int stage) {              // mhd_tasks.cpp:410-
 TaskStatus MHD::RecvB(Driver *d, int stage) {
   if (multilevel) {
     psmr->Wait(2, stream);
+    if (psmr->fc_map_on)
+      AKCHK(akmi_smr_fc_copy(&pack_c, psmr->d_fc_map[0].p, psmr->fc_np[0], psmr->fc_tail[0], static_cast<long long>(psmr->buf[2].n),
+                             b0.x1f.p, b0.x2f.p, b0.x3f.p, coarse_b0.x1f.p, coarse_b0.x2f.p, coarse_b0.x3f.p,
+                             psmr->buf[2].p, stream));
+    else
     AKCHK(akmi_smr_unpack_fc(&pack_c, &psmr->smr_c, psmr->buf[2].p, b0.x1f.p, b0.x2f.p, b0.x3f.p,
                              coarse_b0.x1f.p, coarse_b0.x2f.p, coarse_b0.x3f.p, stream));
     return TaskStatus::complete;
@@ -1281,6 +1287,11 @@ TaskStatus MHD::CT(Driver *d, int stage) {                 // mhd_ct.cpp:23-80
 }
 TaskStatus MHD::SendB(Driver *d, int stage) {
   if (multilevel) {
+    if (psmr->fc_map_on)
+      AKCHK(akmi_smr_fc_copy(&pack_c, psmr->d_fc_map[1].p, psmr->fc_np[1], psmr->fc_tail[1], static_cast<long long>(psmr->buf[2].n),
+                             b0.x1f.p, b0.x2f.p, b0.x3f.p, coarse_b0.x1f.p, coarse_b0.x2f.p, coarse_b0.x3f.p,
+                             psmr->buf[2].p, stream));
+    else
     AKCHK(akmi_smr_pack_fc(&pack_c, &psmr->smr_c, b0.x1f.p, b0.x2f.p, b0.x3f.p, coarse_b0.x1f.p,
                            coarse_b0.x2f.p, coarse_b0.x3f.p, psmr->buf[2].p, stream));
     psmr->Post(2, stream);

@@ -318,6 +318,12 @@ class MeshBoundaryValuesSMR {
   DvceArray<unsigned char> d_needs;   // [nmb] block has a coarser neighbour (akmi_smr::needs_coarse)
   DvceArray<int> d_lists;         // akmi_smr::lists (work lists of (block, slot) pairs)
   void BuildLists(const akmi_pack *pk, hipStream_t st);
+  // the face-field exchange as lists of element copies (akmi_smr_fc_map): [0] what the unpack does, [1] the outgoing
+  // messages; fc_map_on == false: akmi_smr_pack_fc + akmi_smr_unpack_fc (AKMI_SMR_FC_MAP=0)
+  DvceArray<int> d_fc_map[2];
+  long long fc_np[2] = {0, 0}, fc_tail[2] = {0, 0};
+  bool fc_map_on = false;
+  void BuildFcMaps(const akmi_pack *pk, hipStream_t st);
   DvceArray<long long> d_layout, d_soff, d_roff;
   DvceArray<Real> buf[4];         // cc vars, cc flux, fc vars, fc flux
   // ranks: peers and the slices of buf[cls] that travel (akmi_smr::soff/roff address the segments)

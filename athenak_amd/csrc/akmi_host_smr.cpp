@@ -550,8 +550,27 @@ void MeshBoundaryValuesSMR::BuildLists(const akmi_pack *pk, hipStream_t st) {
   for (int l = 0; l < AKMI_SMR_NLISTS; ++l) smr_c.list_cnt[l] = cnt[l];
 }
 
+// AKMI_SMR_FC_MAP=0: A/B switch (pack + slot-by-slot unpack of the face fields)
+void MeshBoundaryValuesSMR::BuildFcMaps(const akmi_pack *pk, hipStream_t st) {
+  const char *e = std::getenv("AKMI_SMR_FC_MAP");
+  if (e && std::atoi(e) == 0) return;
+  const long long nb = static_cast<long long>(buf[2].n);
+  long long lo = nb;
+  for (int r : peers) lo = std::min(lo, send_slices[2].at(r).first);
+  for (int which = 0; which < 2; ++which) {
+    long long tail = 0;
+    const long long n = akmi_smr_fc_map(pk, &smr_c, buf[2].p, nb, lo, nb, which, nullptr, 0, &tail, st);
+    if (n < 0) AKMI_FATAL(std::string(akmi_last_error()));
+    d_fc_map[which].Realloc(static_cast<size_t>(2*std::max<long long>(n, 1)));
+    if (akmi_smr_fc_map(pk, &smr_c, buf[2].p, nb, lo, nb, which, d_fc_map[which].p, n, &tail, st) != n)
+      AKMI_FATAL(std::string(akmi_last_error()));
+    fc_np[which] = n; fc_tail[which] = tail;
+  }
+  fc_map_on = true;
+}
+
 MeshBoundaryValuesSMR::~MeshBoundaryValuesSMR() {
-  d_lists.Free();
+  d_lists.Free(); d_fc_map[0].Free(); d_fc_map[1].Free();
   d_nghbr.Free(); d_lev.Free(); d_cc.Free(); d_fc.Free(); d_ndat.Free(); d_ox.Free(); d_nflx.Free(); d_same.Free(); d_needs.Free();
   d_layout.Free(); d_soff.Free(); d_roff.Free();
   for (auto &b : buf) b.Free();

@@ -839,6 +839,96 @@ static int smr_exchange_cc(const akmi_pack *p, const akmi_smr *t, int nvar, doub
   return AKMI_COMPLETE;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The face-field exchange as ONE list of element copies (akmi_smr_fc_map / akmi_smr_fc_copy).
+//
+// PackAndSendFC + RecvAndUnpackFC (bvals_fc.cpp:40-560) move values and nothing else: every ghost face of the fine or
+// coarse array of a MeshBlock ends up holding the value of ONE face of another array (the RestrictFC'ed coarse array of
+// a finer neighbour, the fine array of a same-level or coarser one) -- the one the LAST slot of the reference's
+// sequential unpack that covers it delivers, unless the block owns the face itself.  Which element that is depends on
+// the mesh only.  So the walk is run ONCE, at set-up, on arrays whose elements hold their own index: k_smr_pack_fc and
+// k_smr_unpack_fc, unchanged, leave in every element they write the index of the element the value came from, and the
+// pairs (destination, source) that differ from the identity ARE the exchange, in the reference's order of
+// precedence.  Per stage one launch copies them (k_smr_fc_copy): no slot walk (k_smr_unpack_fc: 27 dependent rounds
+// per (block, component)), no buffer round trip for neighbours in the pack.
+// Index space: [b1 | b2 | b3 | cb1 | cb2 | cb3 | buf], 32-bit.  With ranks the message to another rank is the part
+// [send_lo, send_hi) of buf: `which` = 1 lists (buffer element <- array element) for it, `which` = 0 lists what the
+// unpack does, with sources in the arrays of this pack or in the received part of buf.
+struct FcIdx { long long base[8]; };             // starts of the seven arrays in the index space, base[7] = end
+struct FcArr { double *a[7]; };
+__global__ void k_fc_codes(double *__restrict__ a, long long n, long long first) {
+  const long long i = (long long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (i < n) a[i] = (double)(first + i + 1);
+}
+// elements [lo, lo + n) of one array of the index space that do not hold their own code: per workgroup of 256 the
+// count (map == null) or the pairs, written in order at off[workgroup].  A pair whose SOURCE is itself overwritten by the
+// exchange (the restricted surface faces of a fine block's coarse array: sent to the coarser neighbour and received
+// from it) has to read the old value -- the reference packs every message before it unpacks any: such pairs are
+// counted in *ndep, replaced by a no-op in the ordered list and appended behind it (akmi_smr_fc_copy runs that tail
+// first, in a launch of its own).
+__global__ void __launch_bounds__(256)
+k_fc_pairs(const double *__restrict__ a, long long n, long long first, const double *__restrict__ tmp, long long ntmp,
+           int *__restrict__ cnt, const long long *__restrict__ off, int *__restrict__ map, long long np,
+           int *__restrict__ ndep, int *__restrict__ bad) {
+  const long long i = (long long)blockIdx.x*256 + threadIdx.x;
+  const bool in = i < n;
+  const double v = in ? a[i] : 0.0;
+  const bool ch = in && v != (double)(first + i + 1);
+  __shared__ int wsum[4];
+  const unsigned long long bal = __ballot(ch);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) wsum[wv] = __popcll(bal);
+  __syncthreads();
+  if (!map && threadIdx.x == 0) cnt[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  if (!ch) return;
+  const long long src = (long long)v - 1;
+  if (!(v >= 1.0) || v != (double)(src + 1)) { atomicAdd(bad, 1); return; }      // not a code: a value nobody wrote
+  bool dep = false;
+  if (src < ntmp && tmp[src] != (double)(src + 1)) {          // the source is a destination of another copy
+    dep = true;
+    const long long s2 = (long long)tmp[src] - 1;             // ... whose own source must then be an untouched one
+    if (s2 >= 0 && s2 < ntmp && tmp[s2] != (double)(s2 + 1)) atomicAdd(bad, 1);
+  }
+  if (!map) { if (dep) atomicAdd(ndep, 1); return; }
+  int r = __popcll(bal & ((1ull << lane) - 1ull));
+  for (int q = 0; q < wv; ++q) r += wsum[q];
+  const long long o = off[blockIdx.x] + r;
+  map[2*o] = (int)(first + i);
+  map[2*o + 1] = dep ? (int)(first + i) : (int)src;
+  if (dep) {
+    const long long t = np + atomicAdd(ndep, 1);
+    map[2*t] = (int)(first + i);
+    map[2*t + 1] = (int)src;
+  }
+}
+__device__ __forceinline__ double *fc_at(const FcIdx &ix, const FcArr &ar, int g) {
+  int q = 0;
+#pragma unroll
+  for (int t = 1; t < 7; ++t) q += ((long long)g >= ix.base[t]) ? 1 : 0;
+  return ar.a[q] + ((long long)g - ix.base[q]);
+}
+__global__ void __launch_bounds__(256)
+k_smr_fc_copy(FcIdx ix, FcArr ar, const int2 *__restrict__ map, long long np) {
+  const long long e = (long long)blockIdx.x*256 + threadIdx.x;
+  if (e >= np) return;
+  const int2 ds = map[e];
+  if (ds.x != ds.y) *fc_at(ix, ar, ds.x) = *fc_at(ix, ar, ds.y);
+}
+static FcIdx fc_index(const akmi_pack *p, long long buf_doubles) {
+  const SGeo s = make_sgeo(p);
+  FcIdx ix;
+  long long o = 0;
+  for (int c = 0; c < 2; ++c)
+    for (int v = 0; v < 3; ++v) {
+      const long long n1 = c ? s.cN1 : s.N1, n2 = c ? s.cN2 : s.N2, n3 = c ? s.cN3 : s.N3;
+      ix.base[c*3 + v] = o;
+      o += (long long)p->nmb*(n3 + (v == 2))*(n2 + (v == 1))*(n1 + (v == 0));
+    }
+  ix.base[6] = o;
+  ix.base[7] = o + buf_doubles;
+  return ix;
+}
+
 static int smr_exchange_fc(const akmi_pack *p, const akmi_smr *t, double *b1, double *b2, double *b3,
                            double *cb1, double *cb2, double *cb3, double *buf, void *stream, int phase) {
   if (check_smr(p, t, "smr_exchange_fc") != AKMI_COMPLETE) return AKMI_FAIL;
@@ -1080,6 +1170,82 @@ int akmi_smr_pack_emf(const akmi_pack *p, const akmi_smr *t, const double *e1, c
 int akmi_smr_unpack_emf(const akmi_pack *p, const akmi_smr *t, const int *nflx, const double *buf, double *e1,
                         double *e2, double *e3, void *stream) {
   return smr_emf_exchange(p, t, nflx, e1, e2, e3, const_cast<double *>(buf), stream, 2);
+}
+
+long long akmi_smr_fc_map(const akmi_pack *p, const akmi_smr *t, double *buf, long long buf_doubles, long long send_lo,
+                          long long send_hi, int which, int *map, long long cap, long long *ntail, void *stream) {
+  using namespace akmi;
+  if (check_smr(p, t, "smr_fc_map") != AKMI_COMPLETE) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const FcIdx ix = fc_index(p, buf_doubles);
+  if (ix.base[7] >= (1ll << 31)) { set_error("smr_fc_map: more than 2^31 face elements in a pack"); return -1; }
+  if (which && !(0 <= send_lo && send_lo <= send_hi && send_hi <= buf_doubles)) {
+    set_error("smr_fc_map: send range outside the buffer"); return -1;
+  }
+  const long long ntmp = ix.base[6];
+  double *tmp = nullptr;
+  int *d_cnt = nullptr, *d_flag = nullptr;          // d_flag[0]: pairs that read an overwritten source, [1]: errors
+  long long *d_off = nullptr;
+  long long result = -1;
+  // the region that is scanned: the six arrays (which = 0) or the outgoing part of the buffer (which = 1)
+  const double *scan = nullptr;
+  const long long first = which ? ntmp + send_lo : 0, n = which ? send_hi - send_lo : ntmp;
+  const unsigned nwg = (unsigned)((n + 255)/256);
+  std::vector<int> h_cnt(nwg);
+  std::vector<long long> h_off(nwg);
+  long long np = 0;
+  int h_flag[2] = {0, 0};
+#define FCM_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("smr_fc_map: %s", hipGetErrorString(e_)); goto done; } } while (0)
+  FCM_HIP(hipMalloc(&tmp, sizeof(double)*(size_t)(ntmp > 0 ? ntmp : 1)));
+  FCM_HIP(hipMalloc(&d_cnt, sizeof(int)*(size_t)(nwg + 1)));
+  FCM_HIP(hipMalloc(&d_off, sizeof(long long)*(size_t)(nwg + 1)));
+  FCM_HIP(hipMalloc(&d_flag, 2*sizeof(int)));
+  FCM_HIP(hipMemsetAsync(d_flag, 0, 2*sizeof(int), st));
+  k_fc_codes<<<(unsigned)((ntmp + 255)/256), 256, 0, st>>>(tmp, ntmp, 0);
+  if (buf_doubles > 0) k_fc_codes<<<(unsigned)((buf_doubles + 255)/256), 256, 0, st>>>(buf, buf_doubles, ntmp);
+  if (smr_exchange_fc(p, t, tmp + ix.base[0], tmp + ix.base[1], tmp + ix.base[2], tmp + ix.base[3], tmp + ix.base[4],
+                      tmp + ix.base[5], buf, stream, which ? 1 : 3) != AKMI_COMPLETE) goto done;
+  scan = which ? buf + send_lo : tmp;
+  if (n > 0) {
+    k_fc_pairs<<<nwg, 256, 0, st>>>(scan, n, first, tmp, ntmp, d_cnt, nullptr, nullptr, 0, d_flag, d_flag + 1);
+    FCM_HIP(hipMemcpyAsync(h_cnt.data(), d_cnt, sizeof(int)*nwg, hipMemcpyDeviceToHost, st));
+    FCM_HIP(hipMemcpyAsync(h_flag, d_flag, 2*sizeof(int), hipMemcpyDeviceToHost, st));
+    FCM_HIP(hipStreamSynchronize(st));
+    for (unsigned w = 0; w < nwg; ++w) { h_off[w] = np; np += h_cnt[w]; }
+  }
+  if (h_flag[1]) { set_error("smr_fc_map: %d copies are not independent element copies", h_flag[1]); goto done; }
+  if (map && np > 0) {
+    if (np + h_flag[0] > cap) { set_error("smr_fc_map: %lld pairs, room for %lld", np + h_flag[0], cap); goto done; }
+    FCM_HIP(hipMemcpyAsync(d_off, h_off.data(), sizeof(long long)*nwg, hipMemcpyHostToDevice, st));
+    FCM_HIP(hipMemsetAsync(d_flag, 0, 2*sizeof(int), st));
+    k_fc_pairs<<<nwg, 256, 0, st>>>(scan, n, first, tmp, ntmp, d_cnt, d_off, map, np, d_flag, d_flag + 1);
+  }
+  if (buf_doubles > 0) FCM_HIP(hipMemsetAsync(buf, 0, sizeof(double)*(size_t)buf_doubles, st));
+  FCM_HIP(hipStreamSynchronize(st));
+  { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { set_error("smr_fc_map: %s", hipGetErrorString(e_)); goto done; } }
+  if (ntail) *ntail = h_flag[0];
+  result = np + h_flag[0];
+done:
+#undef FCM_HIP
+  (void)hipFree(tmp); (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_flag);
+  return result;
+}
+
+int akmi_smr_fc_copy(const akmi_pack *p, const int *map, long long npairs, long long ntail, long long buf_doubles,
+                     double *b1, double *b2, double *b3, double *cb1, double *cb2, double *cb3, double *buf,
+                     void *stream) {
+  using namespace akmi;
+  if (npairs <= 0) return AKMI_COMPLETE;
+  const FcIdx ix = fc_index(p, buf_doubles);
+  const FcArr ar{{b1, b2, b3, cb1, cb2, cb3, buf}};
+  const int2 *m2 = reinterpret_cast<const int2 *>(map);
+  const long long head = npairs - ntail;
+  if (ntail > 0)         // the copies that read a face another copy overwrites: first
+    k_smr_fc_copy<<<(unsigned)((ntail + 255)/256), 256, 0, (hipStream_t)stream>>>(ix, ar, m2 + head, ntail);
+  if (head > 0)
+    k_smr_fc_copy<<<(unsigned)((head + 255)/256), 256, 0, (hipStream_t)stream>>>(ix, ar, m2, head);
+  AKMI_CHECK_LAUNCH("smr_fc_copy");
+  return AKMI_COMPLETE;
 }
 
 }  // extern "C"

@@ -455,6 +455,28 @@ int akmi_smr_pack_emf(const akmi_pack *p, const akmi_smr *t, const double *e1, c
 int akmi_smr_unpack_emf(const akmi_pack *p, const akmi_smr *t, const int *nflx, const double *buf, double *e1,
                         double *e2, double *e3, void *stream);
 
+/* The face-field exchange of a refined mesh as one list of element copies.  PackAndSendFC + RecvAndUnpackFC
+ * (src/bvals/bvals_fc.cpp:63-289, :300-436) only move values: which face of which array a ghost face receives -- with
+ * the precedence of the reference's slot-by-slot unpack where slots overlap, and never a face the block owns -- depends
+ * on the mesh alone.  akmi_smr_fc_map (set-up call, synchronises `stream`) finds the copies by running
+ * akmi_smr_pack_fc [+ akmi_smr_unpack_fc] once on scratch arrays whose elements hold their own index, and returns their
+ * number (-1: failure); map == NULL: count only; otherwise map receives (destination, source) pairs of 32-bit indices
+ * into the concatenation [b1 | b2 | b3 | cb1 | cb2 | cb3 | buf], sorted by destination (cap = pairs it has room for).
+ *   which = 0: what the unpack does (sources: arrays of this pack, or the part of buf other ranks fill);
+ *   which = 1: the outgoing messages, buf[send_lo, send_hi) <- arrays (ranks only; 0 pairs on one rank).
+ * The reference packs every message before it unpacks any, so a copy reads the value its source had BEFORE the exchange;
+ * the few copies whose source is itself a destination (surface faces of a fine block's coarse array) are the last *ntail
+ * pairs of the list -- akmi_smr_fc_copy performs them first, in a launch of their own -- and their place in the ordered
+ * part holds a no-op (destination == source).
+ * buf (the class-2 buffer of the exchange, buf_doubles long) is used as scratch and zeroed.  akmi_smr_fc_copy performs
+ * a list: one rank -- the which = 0 list in place of akmi_smr_pack_fc + akmi_smr_unpack_fc; ranks -- the which = 1
+ * list, the transfer, the which = 0 list. */
+long long akmi_smr_fc_map(const akmi_pack *p, const akmi_smr *t, double *buf, long long buf_doubles, long long send_lo,
+                          long long send_hi, int which, int *map, long long cap, long long *ntail, void *stream);
+int akmi_smr_fc_copy(const akmi_pack *p, const int *map, long long npairs, long long ntail, long long buf_doubles,
+                     double *b1, double *b2, double *b3, double *cb1, double *cb2, double *cb3, double *buf,
+                     void *stream);
+
 /* ---- Fused fast path ("one kernel sequence per MeshBlockPack stage") ----------------- *
  * Must produce results identical to the task chain above.  ws = device workspace of
  * akmi_stage_workspace_bytes() bytes owned by the caller. */
