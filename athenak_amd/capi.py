@@ -47,7 +47,7 @@ SYMBOLS = [
     "akmi_comm_unique_id", "akmi_comm_init_rccl", "akmi_comm_init_env", "akmi_comm_init_callbacks", "akmi_hydro_stage_fused_dt", "akmi_mhd_stage_fused_dt", "akmi_comm_finalize", "akmi_comm_allreduce_min",
     "akmi_comm_rank", "akmi_comm_nranks", "akmi_host_exchange_plan",
     "akmi_smr_exchange_cc", "akmi_smr_exchange_fc", "akmi_smr_fill_coarse_cc", "akmi_smr_fill_coarse_fc",
-    "akmi_smr_prolong_cc", "akmi_smr_prolong_fc", "akmi_smr_c2p_coarse", "akmi_smr_p2c_fine", "akmi_smr_build_lists", "akmi_mhd_fluxes_update", "akmi_smr_update_save_doubles", "akmi_smr_save_update_cells", "akmi_smr_redo_update", "akmi_smr_flux_cc", "akmi_smr_emf_exchange", "akmi_smr_pack_cc", "akmi_smr_unpack_cc", "akmi_smr_pack_fc",
+    "akmi_smr_prolong_cc", "akmi_smr_prolong_fc", "akmi_smr_c2p_coarse", "akmi_smr_p2c_fine", "akmi_smr_build_lists", "akmi_smr_flux_cc", "akmi_smr_emf_exchange", "akmi_smr_pack_cc", "akmi_smr_unpack_cc", "akmi_smr_pack_fc",
     "akmi_selftest_fp64",
     "akmi_smr_fc_map", "akmi_smr_fc_copy",
     "akmi_smr_unpack_fc", "akmi_smr_pack_flux_cc", "akmi_smr_unpack_flux_cc", "akmi_smr_pack_emf", "akmi_smr_unpack_emf",
@@ -82,7 +82,6 @@ def lib():
         L.akmi_bvals_cc_segsize.restype = C.c_longlong
         L.akmi_bvals_fc_segsize.restype = C.c_longlong
         L.akmi_stage_workspace_bytes.restype = C.c_longlong
-        L.akmi_smr_update_save_doubles.restype = C.c_longlong
         L.akmi_smr_fc_map.restype = C.c_longlong
         L.akmi_sim_create.restype = C.c_void_p
         L.akmi_sim_array.restype = C.c_void_p

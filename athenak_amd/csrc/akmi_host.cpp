@@ -462,20 +462,10 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
     fofc.Realloc(static_cast<size_t>(pp->nmb_thispack)*n3*n2*n1);    // zero-filled
     nfofc.Realloc(1);
   }
-  // option AKMI_SMR_SWEEP_UPDATE=1 (refined 3-D MHD meshes without FOFC/diffusion): the sweeps store their fluxes
-  // AND update u0 in the same pass; after the flux correction only the cells behind a corrected face are redone
-  // (include/akmi.h, akmi_mhd_fluxes_update).  Bit-identical, measured slower than the three tasks
-  // (profiles/r03_config5.txt), so off unless asked for.
-  const char *su = std::getenv("AKMI_SMR_SWEEP_UPDATE");
-  sweep_update = multilevel && fused_req && !use_fofc && blk == "mhd" && ind.nx3 > 1 && su && su[0] == '1';
-  if (sweep_update) {
-    upd_acc.Realloc(ncc);
-    upd_save.Realloc(static_cast<size_t>(akmi_smr_update_save_doubles(&pack_c, nvars)));
-  }
 }
 FluidBase::~FluidBase() {
   u0.Free(); w0.Free(); u1.Free(); counters.Free(); dt3.Free(); ws.Free(); fofc.Free(); nfofc.Free();
-  dtmin_cond.Free(); coarse_u0.Free(); coarse_w0.Free(); upd_acc.Free(); upd_save.Free();
+  dtmin_cond.Free(); coarse_u0.Free(); coarse_w0.Free();
   delete psmr;
   delete pbval;
   delete peos;
@@ -594,7 +584,7 @@ MHD::MHD(MeshBlockPack *pp, ParameterInput *pin) : FluidBase(pp, pin, "mhd") {
   kinematic = pin->GetOrAddString("time", "evolution", "dynamic") == "kinematic";
   if (kinematic) {
     if (rs != "advect") AKMI_FATAL("<mhd> rsolver = '" + rs + "' not implemented for kinematic problems");
-    rsolver_method = AKMI_RS_ADVECT; fused = sweep_update = false;
+    rsolver_method = AKMI_RS_ADVECT; fused = false;
   } else if (rs == "llf") rsolver_method = AKMI_RS_LLF;
   else if (rs == "hlle") rsolver_method = AKMI_RS_HLLE;
   else if (rs == "hlld") rsolver_method = AKMI_RS_HLLD;
@@ -843,7 +833,7 @@ template <typename T> static void SwapArr(DvceArray<T> &a, DvceArray<T> &b) { st
 // A/B switch AKMI_TASK_OOP=0.
 bool FluidBase::OopFirst(const Driver *d, int stage) const {
   static const bool off = std::getenv("AKMI_TASK_OOP") && std::atoi(std::getenv("AKMI_TASK_OOP")) == 0;
-  return stage == 1 && !fused && !use_fofc && !sweep_update && d->integrator != "rk4" && !off;
+  return stage == 1 && !fused && !use_fofc && d->integrator != "rk4" && !off;
 }
 
 void FluidBase::RestoreRegisters() {
@@ -1055,16 +1045,6 @@ TaskStatus MHD::CopyCons(Driver *d, int stage) {           // mhd_tasks.cpp:162-
 }
 TaskStatus MHD::Fluxes(Driver *d, int stage) {             // mhd_tasks.cpp:177-216
   if (fused) return TaskStatus::complete;
-  if (sweep_update) {
-    // refined 3-D meshes: fluxes + RKUpdate in one pass; the cells behind a face that SendFlux/RecvFlux will
-    // correct are saved first and redone in RKUpdate
-    AKCHK(akmi_smr_save_update_cells(&pack_c, &psmr->smr_c, nvars, u0.p, upd_save.p, stream));
-    AKCHK(akmi_mhd_fluxes_update(&pack_c, recon_method, rsolver_method, d->gam0[stage - 1], d->gam1[stage - 1],
-                                 d->beta[stage - 1]*pmy_pack->pmesh->dt, w0.p, bcc0.p, b0.x1f.p, b0.x2f.p,
-                                 b0.x3f.p, u0.p, u1.p, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, e3x1.p, e2x1.p, e1x2.p,
-                                 e3x2.p, e2x3.p, e1x3.p, upd_acc.p, stream));
-    return TaskStatus::complete;
-  }
   if (use_fofc)                                             // mhd_fluxes.cpp:100-105
     AKCHK(akmi_mhd_fluxes_fofc(&pack_c, recon_method, rsolver_method, w0.p, bcc0.p, b0.x1f.p,
                                b0.x2f.p, b0.x3f.p, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, e3x1.p,
@@ -1115,9 +1095,6 @@ TaskStatus MHD::RKUpdate(Driver *d, int stage) {           // mhd_update.cpp:24-
       SwapArr(b0.x1f, b1.x1f); SwapArr(b0.x2f, b1.x2f); SwapArr(b0.x3f, b1.x3f); b_swapped = !b_swapped;
     }
     interior_done_ = true; dt_ready_ = do_dt;
-  } else if (sweep_update) {
-    AKCHK(akmi_smr_redo_update(&pack_c, &psmr->smr_c, nvars, d->gam0[stage - 1], d->gam1[stage - 1], beta_dt,
-                               upd_save.p, u0.p, u1.p, uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, stream));
   } else if (OopFirst(d, stage)) {
     AKCHK(akmi_rk_update_oop(&pack_c, d->gam0[stage - 1], d->gam1[stage - 1], beta_dt, u0.p, u1.p,
                              uflx.x1f.p, uflx.x2f.p, uflx.x3f.p, 1, stream));

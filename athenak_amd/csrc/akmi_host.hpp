@@ -362,8 +362,6 @@ class FluidBase {
   bool use_fofc = false;                // hydro.hpp:116-117, mhd.hpp
   bool OopFirst(const Driver *d, int stage) const;     // first stage of the task path out of place (akmi_host.cpp)
   bool dt_reduced = false;              // dtnew is already the minimum over all ranks (FinishNewDt)
-  bool sweep_update = false;            // refined 3-D MHD: Fluxes updates u0 too, RKUpdate redoes corrected cells
-  DvceArray<Real> upd_acc, upd_save;    //   scratch of akmi_mhd_fluxes_update / akmi_smr_save_update_cells
   DvceArray<unsigned char> fofc;
   DvceArray<int> nfofc;                 // EventCounters::nfofc (mesh.hpp:71), kept on the device
   Real dtnew = static_cast<Real>(FLT_MAX);

@@ -601,62 +601,6 @@ k_smr_unpack_flux_cc(SGeo s, Tab t, int nvar, int fs, const double *__restrict__
   }
 }
 
-// ---- update-in-the-sweeps on refined meshes: save / redo of the cells next to a corrected face -------------------
-// The flux correction (k_smr_unpack_flux_cc) replaces the fluxes of a coarse block on the faces it shares with
-// finer neighbours.  When the sweeps have already updated u0 (akmi_mhd_fluxes_update), exactly the cells behind
-// those faces carry a wrong divergence: their state before the update is saved first (k_smr_save_cells) and the
-// update is repeated for them from the stored, corrected fluxes (k_smr_redo_update), with the expression and the
-// rounding order of RKUpdate (mhd_update.cpp:57-80).  Face slots 0-15 and 24-31 -> compact slot 0-23.
-__device__ __forceinline__ int face_slot(int n) { return n < 16 ? n : (n >= 24 && n < 32 ? n - 8 : -1); }
-__device__ __forceinline__ Bx cells_behind(const SGeo &s, const Bx &f, int dir) {
-  Bx c = f;
-  if (dir == 0) { c.il = c.iu = (f.il == s.is) ? f.il : f.il - 1; }
-  else if (dir == 1) { c.jl = c.ju = (f.jl == s.js) ? f.jl : f.jl - 1; }
-  else { c.kl = c.ku = (f.kl == s.ks) ? f.kl : f.kl - 1; }
-  return c;
-}
-__global__ void __launch_bounds__(256)
-k_smr_save_cells(SGeo s, Tab t, int nvar, long long cap, const double *__restrict__ u, double *__restrict__ save) {
-  int m, n, v; wg_slot(t, L_FINER, 1, m, n, v); (void)v;
-  const int fsl = face_slot(n);
-  if (fsl < 0 || NGID(t, m, n) < 0 || !(NLEV(t, m, n) > t.lev[m])) return;
-  const int dir = n < 8 ? 0 : (n < 16 ? 1 : 2);
-  const Bx c = cells_behind(s, box_of(t.cc, T_RECV, K_FLXC, n, 0), dir);
-  const int cnt = bcount(c);
-  double *out = save + ((size_t)m*24 + fsl)*nvar*cap;
-  for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
-    int k, j, i;
-    bdecode(c, e, k, j, i);
-    for (int v = 0; v < nvar; ++v) out[(size_t)v*cap + e] = u[c5(s, 0, nvar, m, v, k, j, i)];
-  }
-}
-__global__ void __launch_bounds__(256)
-k_smr_redo_update(SGeo s, Tab t, int nvar, long long cap, double gam0, double gam1, double beta_dt, const double *dxs,
-                  const double *__restrict__ save, double *__restrict__ u0, const double *__restrict__ u1, Flx3 flx) {
-  int m, n, v; wg_slot(t, L_FINER, 1, m, n, v); (void)v;
-  const int fsl = face_slot(n);
-  if (fsl < 0 || NGID(t, m, n) < 0 || !(NLEV(t, m, n) > t.lev[m])) return;
-  const int dir = n < 8 ? 0 : (n < 16 ? 1 : 2);
-  const Bx c = cells_behind(s, box_of(t.cc, T_RECV, K_FLXC, n, 0), dir);
-  const int cnt = bcount(c);
-  const double *old = save + ((size_t)m*24 + fsl)*nvar*cap;
-  const double dx1 = dxs[3*m], dx2 = dxs[3*m + 1], dx3 = dxs[3*m + 2];
-  for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
-    int k, j, i;
-    bdecode(c, e, k, j, i);
-    for (int v = 0; v < nvar; ++v) {
-      double divf = (flx.f[0][ix5(nvar, s.N3, s.N2, s.N1 + 1, m, v, k, j, i + 1)] -
-                     flx.f[0][ix5(nvar, s.N3, s.N2, s.N1 + 1, m, v, k, j, i)])/dx1;
-      divf += (flx.f[1][ix5(nvar, s.N3, s.N2 + 1, s.N1, m, v, k, j + 1, i)] -
-               flx.f[1][ix5(nvar, s.N3, s.N2 + 1, s.N1, m, v, k, j, i)])/dx2;
-      divf += (flx.f[2][ix5(nvar, s.N3 + 1, s.N2, s.N1, m, v, k + 1, j, i)] -
-               flx.f[2][ix5(nvar, s.N3 + 1, s.N2, s.N1, m, v, k, j, i)])/dx3;
-      const size_t q = c5(s, 0, nvar, m, v, k, j, i);
-      u0[q] = gam0*old[(size_t)v*cap + e] + gam1*u1[q] - beta_dt*divf;
-    }
-  }
-}
-
 // ---- edge EMFs ------------------------------------------------------------------------------------
 struct E3 { double *e[3]; };
 __device__ __forceinline__ size_t e4(const SGeo &s, int v, int m, int k, int j, int i) {
@@ -1088,35 +1032,6 @@ int akmi_smr_build_lists(const akmi_pack *p, const akmi_smr *t, int *lists, int 
   return AKMI_COMPLETE;
 }
 
-long long akmi_smr_update_save_doubles(const akmi_pack *p, int nvar) {
-  const long long a = (long long)p->nx1*p->nx2, b = (long long)p->nx1*p->nx3, c = (long long)p->nx2*p->nx3;
-  const long long cap = ((a > b ? (a > c ? a : c) : (b > c ? b : c)) + 3)/4;      // a quarter of the largest face
-  return (long long)p->nmb*24*nvar*cap;
-}
-static long long save_cap(const akmi_pack *p, int nvar) { return akmi_smr_update_save_doubles(p, nvar)/((long long)p->nmb*24*nvar); }
-
-int akmi_smr_save_update_cells(const akmi_pack *p, const akmi_smr *t, int nvar, const double *u0, double *save,
-                               void *stream) {
-  if (check_smr(p, t, "smr_save_update_cells") != AKMI_COMPLETE) return AKMI_FAIL;
-  if (p->nx3 <= 1) { set_error("smr_save_update_cells: 3-D packs only"); return AKMI_FAIL; }
-  const Tab tb = make_tab(p, t);
-  SMR_LAUNCH(k_smr_save_cells, L_FINER, 1, (hipStream_t)stream, make_sgeo(p), tb, nvar, save_cap(p, nvar), u0, save);
-  AKMI_CHECK_LAUNCH("smr_save_update_cells");
-  return AKMI_COMPLETE;
-}
-
-int akmi_smr_redo_update(const akmi_pack *p, const akmi_smr *t, int nvar, double gam0, double gam1, double beta_dt,
-                         const double *save, double *u0, const double *u1, const double *flx1, const double *flx2,
-                         const double *flx3, void *stream) {
-  if (check_smr(p, t, "smr_redo_update") != AKMI_COMPLETE) return AKMI_FAIL;
-  if (p->nx3 <= 1) { set_error("smr_redo_update: 3-D packs only"); return AKMI_FAIL; }
-  const Tab tb = make_tab(p, t);
-  SMR_LAUNCH(k_smr_redo_update, L_FINER, 1, (hipStream_t)stream, make_sgeo(p), tb, nvar, save_cap(p, nvar), gam0, gam1,
-             beta_dt, p->dx, save, u0, u1,
-             Flx3{{const_cast<double *>(flx1), const_cast<double *>(flx2), const_cast<double *>(flx3)}});
-  AKMI_CHECK_LAUNCH("smr_redo_update");
-  return AKMI_COMPLETE;
-}
 
 int akmi_smr_exchange_cc(const akmi_pack *p, const akmi_smr *t, int nvar, double *u, double *cu,
                          double *buf, void *stream) {

@@ -509,15 +509,11 @@ static int march_len(long col_blocks, int ncells, int nmb, int lmax, int wgs_per
 // MODE 0: last direction -- finish the RK update.  MODE 1 (x2 sweep of 3-D runs): store the
 // partial divergence acc = dF1/dx1 + dF2/dx2 for the x3 march, which then needs one array
 // instead of two face pairs per variable (USEACC).  Rounding sequence unchanged.
-// MODE 3 / 4 (refined meshes, round 3): MODE 1 / MODE 0 AND the store of MODE 2 -- the marches update in the same pass
-// and leave every flux behind, so that after the flux correction at fine/coarse faces only the cells next to a
-// corrected face are recomputed (akmi_smr_redo_update) instead of a second pass over all fluxes (k_rk_update).
-template <int DIR, int RECON, bool MHD, int MODE_IN, bool USEACC, int RS, bool P2>
+template <int DIR, int RECON, bool MHD, int MODE, bool USEACC, int RS, bool P2>
 __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &eos, const SweepArgs &a,
                                                   const UpdArgs &u, int ml, double *sm) {
   static_assert(DIR == 1 || DIR == 2, "marching kernel is for the x2/x3 sweeps");
-  constexpr bool STORE = MODE_IN >= 2;                               // all flux components of every face go to memory
-  constexpr int MODE = MODE_IN == 3 ? 1 : (MODE_IN == 4 ? 0 : MODE_IN);      // what happens to the divergence
+  constexpr bool STORE = MODE == 2;                                  // all flux components of every face go to memory
   int i, j, k, m, s0;
   bool lane_ok;
   if constexpr (DIR == 2) {
@@ -2512,42 +2508,6 @@ int sweeps_store_fluxes(const akmi_pack *p, int recon, int rsolver, const double
                                       nullptr, st);
 }
 
-// Fluxes + RKUpdate of a 3-D pack in one pass WITH all fluxes stored (refined meshes): x1 sweep (stores its
-// fluxes), x2 march MODE 3 (stores, acc = dF1/dx1 + dF2/dx2), x3 march MODE 4 (stores, finishes the update in the
-// reference's rounding order).  u0 is updated in place from u0, u1 (CopyCons stays the caller's task).
-template <bool MHD>
-static int sweeps_store_update_t(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1, double beta_dt,
-                                 const double *w0, const double *bcc0, const double *bx1f, const double *bx2f,
-                                 const double *bx3f, double *u0, const double *u1, double *flx1, double *flx2,
-                                 double *flx3, int fsh, double *e3x1, double *e2x1, double *e1x2, double *e3x2,
-                                 double *e2x3, double *e1x3, double *acc, hipStream_t st) {
-  Geo g = make_geo(p);
-  if (!g.three_d) { set_error("fluxes_update: 3-D packs only"); return AKMI_FAIL; }
-  if ((size_t)(g.N3 + 1)*(g.N2 + 1)*(g.N1 + 1)*sizeof(double) >= ((size_t)1 << 32)) {
-    set_error("fluxes_update: a MeshBlock exceeds 4 GB per variable");
-    return AKMI_FAIL;
-  }
-  if (check_scheme(p, recon, "fluxes_update") != AKMI_COMPLETE) return AKMI_FAIL;
-  const Scheme sc{recon, rsolver, make_face_eos(p), !p->is_ideal};
-  SweepArgs a1{w0, bcc0, bx1f, flx1, e3x1, e2x1, nullptr, nullptr, nullptr,
-               g.is, g.ie + 1, g.js, g.je, g.ks, g.ke, g.N3, g.N2, g.N1 + fsh};
-  SweepArgs a2{w0, bcc0, bx2f, flx2, e1x2, e3x2, nullptr, nullptr, nullptr,
-               g.is, g.ie, g.js, g.je + 1, g.ks, g.ke, g.N3, g.N2 + fsh, g.N1};
-  SweepArgs a3{w0, bcc0, bx3f, flx3, e2x3, e1x3, nullptr, nullptr, nullptr,
-               g.is, g.ie, g.js, g.je, g.ks, g.ke + 1, g.N3 + fsh, g.N2, g.N1};
-  if (MHD) {
-    a1.jl = g.js - 1; a1.ju = g.je + 1; a1.kl = g.ks - 1; a1.ku = g.ke + 1;
-    a2.il = g.is - 1; a2.iu = g.ie + 1; a2.kl = g.ks - 1; a2.ku = g.ke + 1;
-    a3.il = g.is - 1; a3.iu = g.ie + 1; a3.jl = g.js - 1; a3.ju = g.je + 1;
-  }
-  if (!fsh) { set_error("fluxes_update: face-shaped flux arrays only"); return AKMI_FAIL; }
-  UpdArgs u{gam0, gam1, beta_dt, u0, const_cast<double *>(u1), flx1, flx2, 0, acc, nullptr, MfBits{}};
-  int rc = launch_sweep<0, MHD, false>(g, sc, a1, st);
-  if (rc == AKMI_COMPLETE) rc = launch_sweep_update<1, MHD, 3, false>(g, sc, a2, u, st);
-  if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD, 4, true>(g, sc, a3, u, st);
-  return rc;
-}
-
 struct C2PArgs {          // interior c2p (+CFL scan) folded into the slab pipeline
   int enable, do_newdt;
   int *counters;
@@ -2820,15 +2780,6 @@ const char *akmi_build_flags(void) {
 long long akmi_stage_workspace_bytes(const akmi_pack *p, int is_mhd) {
   Geo g = make_geo(p);
   return (long long)carve(g, is_mhd, nullptr).total;
-}
-
-int akmi_mhd_fluxes_update(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1, double beta_dt,
-                           const double *w0, const double *bcc0, const double *bx1f, const double *bx2f,
-                           const double *bx3f, double *u0, const double *u1, double *flx1, double *flx2,
-                           double *flx3, double *e3x1, double *e2x1, double *e1x2, double *e3x2, double *e2x3,
-                           double *e1x3, double *acc, void *stream) {
-  return sweeps_store_update_t<true>(p, recon, rsolver, gam0, gam1, beta_dt, w0, bcc0, bx1f, bx2f, bx3f, u0, u1, flx1,
-                                     flx2, flx3, 1, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, acc, (hipStream_t)stream);
 }
 
 int akmi_hydro_stage_update(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1,

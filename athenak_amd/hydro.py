@@ -144,16 +144,11 @@ class FluidBase:
         self.dtnew = FLT_MAX
         self.ws = None
         self.multilevel = pm.multilevel
-        self.sweep_update = False
         if pm.multilevel:
             # the restricted fluxes of finer neighbours replace face fluxes between Fluxes and
             # RKUpdate (SendFlux/RecvFlux): the flux arrays of the task-granular path are needed.
-            # Option AKMI_SMR_SWEEP_UPDATE=1 (3-D MHD without FOFC/diffusion): the sweeps store their fluxes AND
-            # update u0 in the same pass; after the correction only the cells behind a corrected face are redone
-            # (include/akmi.h, akmi_mhd_fluxes_update).  Bit-identical, measured SLOWER than the three tasks
-            # (profiles/r03_config5.txt: the storing+updating PPM4 marches lose more than k_rk_update costs): off.
-            self.sweep_update = (self.fused and blk == "mhd" and indcs.nx3 > 1
-                                 and os.environ.get("AKMI_SMR_SWEEP_UPDATE", "0") == "1")
+            # (Updating in the sweeps and redoing the cells behind corrected faces was built in round 3, measured
+            # slower -- profiles/r03_config5.txt -- and removed in round 4.)
             self.fused = False
             # the coarse buffers seen as a pack of nx/2 cells: HydroBCsCoarse / BFieldBCsCoarse are
             # the BC helpers on coarse indices (src/bvals/physics/hydro_bcs.cpp:51-67)
@@ -201,7 +196,7 @@ class FluidBase:
         (akmi_rk_update_oop, akmi_mhd_ct_oop) and the registers swapped -- no copy traffic.  Not with FOFC (its
         trial update reads u1/b1 before RKUpdate), RK4 (CopyCons updates the second register itself), or the
         update-in-the-sweeps option."""
-        return (stage == 1 and not self.fused and not self.use_fofc and not self.sweep_update
+        return (stage == 1 and not self.fused and not self.use_fofc
                 and pdrive.integrator != "rk4" and _TASK_OOP)
 
     @staticmethod

@@ -29,7 +29,7 @@ class MHD(FluidBase):
             if rs != "advect":
                 raise RuntimeError("### FATAL ERROR <mhd> rsolver = '%s' not implemented for "
                                    "kinematic problems" % rs)
-            self.fused = self.sweep_update = False
+            self.fused = False
         elif rs not in ("llf", "hlle", "hlld"):                 # mhd.cpp: MHD_RSolver
             raise RuntimeError("### FATAL ERROR <mhd> rsolver = '%s' not implemented for dynamic "
                                "problems (llf, hlle, hlld on this path)" % rs)
@@ -60,10 +60,6 @@ class MHD(FluidBase):
             self.coarse_b0 = FaceFld(nmb, 0, c3, c2, c1, device)
             self.psmr = MeshBoundaryValuesSMR(ppack, self.nvars, smr_kernels, device)
             self.psmr.set_pack(self.pack_c)
-            if self.sweep_update:
-                self.upd_acc = torch.empty_like(self.u0)
-                nsave = int(self.L.akmi_smr_update_save_doubles(C.byref(self.pack_c), self.nvars))
-                self.upd_save = torch.zeros(nsave, dtype=torch.float64, device=device)
 
     # ---- task list assembly: mhd_tasks.cpp:38-84 -----------------------------------
     def AssembleMHDTasks(self, tl):
@@ -179,21 +175,7 @@ class MHD(FluidBase):
 
     def Fluxes(self, pdrive, stage):
         """mhd_tasks.cpp:177-216"""
-        if self.sweep_update:
-            # refined 3-D meshes: fluxes + RKUpdate in one pass; the cells behind a face that SendFlux/RecvFlux
-            # will correct are saved first and redone in RKUpdate (include/akmi.h, akmi_mhd_fluxes_update)
-            efc = [capi._p(x) for x in (self.e3x1, self.e2x1, self.e1x2, self.e3x2, self.e2x3, self.e1x3)]
-            ps = self.psmr
-            capi.check(self.L.akmi_smr_save_update_cells(
-                C.byref(self.pack_c), C.byref(ps.smr_c), self.nvars, capi._p(self.u0), capi._p(self.upd_save),
-                capi._stream()), "smr_save_update_cells")
-            capi.check(self.L.akmi_mhd_fluxes_update(
-                C.byref(self.pack_c), self.recon_method, self.rsolver_method,
-                capi.d(pdrive.gam0[stage - 1]), capi.d(pdrive.gam1[stage - 1]),
-                capi.d(pdrive.beta[stage - 1]*self.pmy_pack.pmesh.dt), capi._p(self.w0), capi._p(self.bcc0),
-                *self._b(self.b0), capi._p(self.u0), capi._p(self.u1), *self._b(self.uflx), *efc,
-                capi._p(self.upd_acc), capi._stream()), "mhd_fluxes_update")
-        elif not self.fused:
+        if not self.fused:
             efc = [capi._p(x) for x in (self.e3x1, self.e2x1, self.e1x2, self.e3x2, self.e2x3, self.e1x3)]
             fn = self.L.akmi_mhd_fluxes_fofc if self.use_fofc else self.L.akmi_mhd_fluxes
             capi.check(fn(C.byref(self.pack_c), self.recon_method, self.rsolver_method,
@@ -234,12 +216,6 @@ class MHD(FluidBase):
             # pass A (fluxes, update, CornerE, CT) + ConsToPrim of the active cells (+ CFL scan
             # on the last stage) in one call
             self._stage_phase(pdrive, stage, capi.PHASE_ALL)
-        elif self.sweep_update:
-            ps = self.psmr
-            capi.check(self.L.akmi_smr_redo_update(
-                C.byref(self.pack_c), C.byref(ps.smr_c), self.nvars, capi.d(gam0), capi.d(gam1), capi.d(beta_dt),
-                capi._p(self.upd_save), capi._p(self.u0), capi._p(self.u1), *self._b(self.uflx),
-                capi._stream()), "smr_redo_update")
         elif self._oop_first(pdrive, stage):
             capi.check(self.L.akmi_rk_update_oop(
                 C.byref(self.pack_c), capi.d(gam0), capi.d(gam1), capi.d(beta_dt), capi._p(self.u0),

@@ -48,6 +48,8 @@ def parse():
                          "smaller blocks put (nx/mb)^3 MeshBlocks into each GPU's pack")
     ap.add_argument("--problem", default="orszag_tang", choices=["orszag_tang", "sod", "linear_wave", "linear_wave_mhd"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the side measurements of the default run (configs[1] and configs[4]'s mesh on one GPU)")
     ap.add_argument("--cpu-sample-nx", type=int, default=128)
     ap.add_argument("--recon", default=None, choices=["dc", "plm", "ppm4", "ppmx", "wenoz"],
                     help="reconstruction (default: the deck's plm); ppm4 = the numerics of BASELINE config 5")
@@ -534,9 +536,56 @@ def main():
         "stage_group_ms": round(other["group_ms"]/nst, 4) if other.get("group_calls") else None}
     if args.set:
         out["config"]["workload"] += " + " + " ".join(args.set)
+    if world == 1 and plain and args.nx == 256 and args.problem == "orszag_tang" and not args.no_other_configs \
+            and not args.no_cpu_baseline:        # (the profiling tools run with --no-cpu-baseline: headline kernels only)
+        out["other_configs"] = other_configs(args)
     if world == 1 and not args.no_cpu_baseline and not args.set:
         out["cpu_baseline"] = cpu_baseline(args, blk)
     print(json.dumps(out), flush=True)
+
+
+def other_configs(args):
+    """Side measurements of the default one-GPU run, AFTER the timed region of the headline and never part of
+    `value`: the other single-GPU workloads of BASELINE.json through the C++ host, whole-run Mcell-updates/s --
+    configs[1] (sod 3-D, 128^3, one MeshBlock, PLM+HLLC) and configs[4]'s mesh on one GPU (3-D MHD blast, two levels
+    of static refinement, PPM4+HLLD+CT, ng = 4: the deck as shipped, 120 x 16^3, and at production size, 960 x 32^3).
+    A failure here is recorded, it never takes the line down."""
+    import copy
+    import torch
+    from athenak_amd import native
+    from athenak_amd.main import load_deck
+    res = []
+
+    def run(label, pin, warm, steps):
+        try:
+            sim = native.NativeSimulation(pin)
+            pm = sim.pmesh
+            ncell = pm.nmb_total*pm.NumberOfMeshBlockCells()
+            sim.Execute(max_cycles=warm)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            done = sim.Execute(max_cycles=steps)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            sim.close()
+            torch.cuda.empty_cache()
+            res.append({"config": label, "value": round(ncell*done/el/1e6, 1), "unit": "Mcell-updates/s",
+                        "meshblocks": int(pm.nmb_total), "cells": int(ncell), "steps": int(done),
+                        "ms_per_step": round(el/max(done, 1)*1e3, 4)})
+        except Exception as e:
+            res.append({"config": label, "value": None, "error": repr(e)[:300]})
+
+    a = copy.copy(args)
+    a.problem, a.nx = "sod", 128
+    pin, _ = make_pin(a, (1, 1, 1))
+    run("configs[1]: sod 3D, 128^3 single MeshBlock, ideal hydro PLM+HLLC, RK2, C++ host", pin, 5, 40)
+    ov = ["time/nlim=-1", "time/tlim=1.0e9"]
+    run("configs[4] mesh on one GPU, deck size: blast 3D MHD, 2-level static refinement, 120 MeshBlocks of 16^3, "
+        "PPM4+HLLD+CT, ng=4, C++ host", load_deck("blast_mhd_smr.athinput", ov), 5, 40)
+    prod = ["mesh/nx%d=256" % q for q in (1, 2, 3)] + ["meshblock/nx%d=32" % q for q in (1, 2, 3)]
+    run("configs[4] mesh on one GPU, production size: 960 MeshBlocks of 32^3 (256^3 root grid), C++ host",
+        load_deck("blast_mhd_smr.athinput", ov + prod), 2, 8)
+    return res
 
 
 def native_check(args, rank, world):

@@ -406,27 +406,6 @@ int akmi_smr_p2c_fine(const akmi_pack *p, const akmi_smr *t, int nvar, const dou
  * face_shaped: MHD flux arrays (N+1 along their direction), 0: hydro (cell-shaped).  buf: layout[1] */
 int akmi_smr_flux_cc(const akmi_pack *p, const akmi_smr *t, int nvar, int face_shaped, double *flx1,
                      double *flx2, double *flx3, double *buf, void *stream);
-/* ---- Fluxes + RKUpdate in one pass on refined meshes (3-D MHD) ------------------------------------------------ *
- * On a refined mesh the reference's order is Fluxes -> SendFlux/RecvFlux -> RKUpdate (src/mhd/mhd_tasks.cpp:52-57):
- * the update waits for the corrected fluxes, and a separate update kernel re-reads every flux.  Here the sweeps
- * update u0 while they store their fluxes (akmi_mhd_fluxes_update = akmi_mhd_fluxes + akmi_rk_update in one pass;
- * acc = caller's scratch of nmb*nvar*N3*N2*N1 doubles), and after the flux correction ONLY the cells of a coarse
- * block that lie behind a face shared with a finer neighbour are recomputed, from their saved old state and the
- * stored (now corrected) fluxes, in the rounding order of RKUpdate (src/mhd/mhd_update.cpp:57-80).  Order of calls:
- *   akmi_smr_save_update_cells (u0 before the sweeps -> save, akmi_smr_update_save_doubles doubles)
- *   akmi_mhd_fluxes_update     akmi_smr_pack_flux_cc / transfer / akmi_smr_unpack_flux_cc     akmi_smr_redo_update
- * Bit-identical to the three-task sequence. */
-int akmi_mhd_fluxes_update(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1, double beta_dt,
-                           const double *w0, const double *bcc0, const double *bx1f, const double *bx2f,
-                           const double *bx3f, double *u0, const double *u1, double *flx1, double *flx2,
-                           double *flx3, double *e3x1, double *e2x1, double *e1x2, double *e3x2, double *e2x3,
-                           double *e1x3, double *acc, void *stream);
-long long akmi_smr_update_save_doubles(const akmi_pack *p, int nvar);
-int akmi_smr_save_update_cells(const akmi_pack *p, const akmi_smr *t, int nvar, const double *u0, double *save,
-                               void *stream);
-int akmi_smr_redo_update(const akmi_pack *p, const akmi_smr *t, int nvar, double gam0, double gam1, double beta_dt,
-                         const double *save, double *u0, const double *u1, const double *flx1, const double *flx2,
-                         const double *flx3, void *stream);
 /* SendE+RecvE (PackAndSendFluxFC + RecvAndUnpackFluxFC, src/bvals/flux_correct_fc.cpp:29-1034): edge
  * EMFs on block surfaces summed over same-level owners, replaced by the restricted EMFs of finer
  * neighbours, averaged.  nflx [nmb][48]: contributions per block edge (the counting of

@@ -250,16 +250,6 @@ int akref_smr_p2c_fine_t(const akmi_pack *p, const akmi_smr *t, int nvar, const 
 int akref_smr_prolong_cc_t(const akmi_pack *p, const akmi_smr *t, int nvar, const double *cu, double *u);
 int akref_smr_prolong_fc_t(const akmi_pack *p, const akmi_smr *t, const double *cb1, const double *cb2,
                            const double *cb3, double *b1, double *b2, double *b3);
-long long akref_smr_update_save_doubles(const akmi_pack *p, int nvar);
-int akref_mhd_fluxes_update(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1, double beta_dt,
-                            const double *w0, const double *bcc0, const double *bx1f, const double *bx2f,
-                            const double *bx3f, double *u0, const double *u1, double *flx1, double *flx2,
-                            double *flx3, double *e3x1, double *e2x1, double *e1x2, double *e3x2, double *e2x3,
-                            double *e1x3, double *acc);
-int akref_smr_save_update_cells(const akmi_pack *p, const akmi_smr *t, int nvar, const double *u0, double *save);
-int akref_smr_redo_update(const akmi_pack *p, const akmi_smr *t, int nvar, double gam0, double gam1, double beta_dt,
-                          const double *save, double *u0, const double *u1, const double *flx1, const double *flx2,
-                          const double *flx3);
 int akref_smr_flux_cc_t(const akmi_pack *p, const akmi_smr *t, int nvar, int face_shaped, double *flx1,
                         double *flx2, double *flx3, double *buf);
 int akref_smr_emf_exchange(const akmi_pack *p, const akmi_smr *t, const int *nflx, double *e1, double *e2,

@@ -1266,74 +1266,6 @@ int akref_smr_unpack_flux_cc(const akmi_pack *p, const akmi_smr *t, int nvar, in
   akref_smr_destroy(s);
   return 0;
 }
-/* ---- twins of the update-in-the-sweeps entries (include/akmi.h: akmi_mhd_fluxes_update, akmi_smr_save_update_cells,
- * akmi_smr_redo_update).  The oracle keeps the reference's task order inside them: fluxes, then RKUpdate
- * (src/mhd/mhd_update.cpp:57-80) over every cell; the redo repeats RKUpdate's expression for the cells behind a
- * corrected face (boxes: recvbuf[n].iflux_coar, src/bvals/bvals.cpp InitRecvIndices) from the saved state. */
-long long akref_smr_update_save_doubles(const akmi_pack *p, int nvar) {
-  const long long a = (long long)p->nx1*p->nx2, b = (long long)p->nx1*p->nx3, c = (long long)p->nx2*p->nx3;
-  long long mx = a > b ? a : b;
-  if (c > mx) mx = c;
-  return (long long)p->nmb*24*nvar*((mx + 3)/4);
-}
-int akref_mhd_fluxes_update(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1, double beta_dt,
-                            const double *w0, const double *bcc0, const double *bx1f, const double *bx2f,
-                            const double *bx3f, double *u0, const double *u1, double *flx1, double *flx2,
-                            double *flx3, double *e3x1, double *e2x1, double *e1x2, double *e3x2, double *e2x3,
-                            double *e1x3, double *acc) {
-  (void)acc;
-  int rc = akref_mhd_fluxes(p, recon, rsolver, w0, bcc0, bx1f, bx2f, bx3f, flx1, flx2, flx3, e3x1, e2x1, e1x2, e3x2,
-                            e2x3, e1x3);
-  if (rc != 0) return rc;
-  return akref_rk_update(p, gam0, gam1, beta_dt, u0, u1, flx1, flx2, flx3, 1);
-}
-static int save_or_redo(const akmi_pack *p, const akmi_smr *t, int nvar, int redo, double gam0, double gam1,
-                        double beta_dt, double *save, double *u0, const double *u1, const double *flx1,
-                        const double *flx2, const double *flx3) {
-  akref_smr *s = from_desc(p, t, nvar);
-  const long long cap = akref_smr_update_save_doubles(p, nvar)/((long long)p->nmb*24*nvar);
-  const int N1 = s->N1, N2 = s->N2, N3 = s->N3;
-#define UU(a,m,v,k,j,i) (a)[(((((size_t)(m))*nvar + (v))*N3 + (k))*N2 + (j))*N1 + (i)]
-#define FXU1(m,v,k,j,i) flx1[(((((size_t)(m))*nvar + (v))*N3 + (k))*N2 + (j))*(N1+1) + (i)]
-#define FXU2(m,v,k,j,i) flx2[(((((size_t)(m))*nvar + (v))*N3 + (k))*(N2+1) + (j))*N1 + (i)]
-#define FXU3(m,v,k,j,i) flx3[(((((size_t)(m))*nvar + (v))*(N3+1) + (k))*N2 + (j))*N1 + (i)]
-  for (int m = 0; m < s->nmb; ++m) for (int n = 0; n < s->nnghbr; ++n) {
-    if (!(s->gid[NG(m,n)] >= 0 && s->lev[NG(m,n)] > s->mblev[m])) continue;
-    const int fsl = n < 16 ? n : ((n >= 24 && n < 32) ? n - 8 : -1);
-    if (fsl < 0) continue;
-    const bi_t *x = &s->cc.recvbuf[n].iflux_coar[0];
-    int il = x->bis, iu = x->bie, jl = x->bjs, ju = x->bje, kl = x->bks, ku = x->bke;
-    if (n < 8) il = iu = (il == s->is ? il : il - 1);
-    else if (n < 16) jl = ju = (jl == s->js ? jl : jl - 1);
-    else kl = ku = (kl == s->ks ? kl : kl - 1);
-    const int ni = iu - il + 1, nj = ju - jl + 1;
-    double *sv = save + ((size_t)m*24 + fsl)*nvar*cap;
-    const double dx1 = p->dx[3*m], dx2 = p->dx[3*m+1], dx3 = p->dx[3*m+2];
-    for (int v = 0; v < nvar; ++v) for (int k = kl; k <= ku; ++k) for (int j = jl; j <= ju; ++j)
-    for (int i = il; i <= iu; ++i) {
-      const size_t e = (size_t)(i - il) + (size_t)ni*((j - jl) + (size_t)nj*(k - kl));
-      if (!redo) { sv[(size_t)v*cap + e] = UU(u0,m,v,k,j,i); continue; }
-      double divf = (FXU1(m,v,k,j,i+1) - FXU1(m,v,k,j,i))/dx1;
-      divf += (FXU2(m,v,k,j+1,i) - FXU2(m,v,k,j,i))/dx2;
-      divf += (FXU3(m,v,k+1,j,i) - FXU3(m,v,k,j,i))/dx3;
-      UU(u0,m,v,k,j,i) = gam0*sv[(size_t)v*cap + e] + gam1*UU(u1,m,v,k,j,i) - beta_dt*divf;
-    }
-  }
-#undef UU
-#undef FXU1
-#undef FXU2
-#undef FXU3
-  akref_smr_destroy(s);
-  return 0;
-}
-int akref_smr_save_update_cells(const akmi_pack *p, const akmi_smr *t, int nvar, const double *u0, double *save) {
-  return save_or_redo(p, t, nvar, 0, 0, 0, 0, save, (double *)u0, 0, 0, 0, 0);
-}
-int akref_smr_redo_update(const akmi_pack *p, const akmi_smr *t, int nvar, double gam0, double gam1, double beta_dt,
-                          const double *save, double *u0, const double *u1, const double *flx1, const double *flx2,
-                          const double *flx3) {
-  return save_or_redo(p, t, nvar, 1, gam0, gam1, beta_dt, (double *)save, u0, u1, flx1, flx2, flx3);
-}
 
 int akref_smr_pack_emf(const akmi_pack *p, const akmi_smr *t, const double *e1, const double *e2, const double *e3,
                        double *buf) {

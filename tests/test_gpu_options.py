@@ -7,8 +7,6 @@ once per process, so every case runs in a process of its own and must be bit-ide
   AKMI_M3CT=1       two-kernel pass A: k_sweep12s + k_march3ct (x3 flux, RK update, CornerE and CT in one k-march,
                     the x3 face field of in-place stages read from the copy k_sweep12s leaves in the workspace)
 refined meshes:
-  AKMI_SMR_SWEEP_UPDATE=1  Fluxes updates u0 in the sweeps, RKUpdate redoes the cells behind corrected faces
-                           (akmi_mhd_fluxes_update / akmi_smr_save_update_cells / akmi_smr_redo_update)
   AKMI_SMR_DIRECT=0        same-level cell-centred ghost zones through the pack/unpack buffers instead of directly
   AKMI_SMR_LISTS=0         the level-boundary kernels launched over all nmb*56 (block, slot) pairs instead of the work
                            lists of akmi_smr_build_lists
@@ -71,7 +69,7 @@ print("ok")
 """ % (ROOT, os.path.join(ROOT, "tests"))
 
 
-@pytest.mark.parametrize("env", [{"AKMI_SMR_SWEEP_UPDATE": "1"}, {"AKMI_SMR_DIRECT": "0"}, {"AKMI_TASK_OOP": "0"},
+@pytest.mark.parametrize("env", [{"AKMI_SMR_DIRECT": "0"}, {"AKMI_TASK_OOP": "0"},
                                  {"AKMI_SMR_LISTS": "0"}, {"AKMI_FACE_SWEEPS": "0"}, {"AKMI_SMR_FC_MAP": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
 def test_smr_option_does_not_change_a_bit(env):
