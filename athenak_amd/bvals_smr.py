@@ -393,6 +393,7 @@ class MeshBoundaryValuesSMR:
                               self.t_needs.data_ptr())
         self.pack_c = None
         self._fcmap = None
+        self._ccmap = None
         self._works = [[], [], [], []]
         self._hsend = [None]*4
         self._hrecv = [None]*4
@@ -519,13 +520,40 @@ class MeshBoundaryValuesSMR:
         self.k.restrict_fc(self.pack_c, b, cb, self.t_needs)
         return TaskStatus.complete
 
+    def _cc_maps(self):
+        """one rank: the cell-centred exchange (pack + unpack across levels, direct same-level gather) as one list of
+        element copies applied to every variable (include/akmi.h, akmi_smr_cc_map); AKMI_SMR_CC_MAP=0: the three
+        kernels (A/B switch).  HIP library only; with ranks the messages go through the buffers."""
+        if self._ccmap is None:
+            self._ccmap = False
+            if capi.DEVICE != "cpu" and not self.peers and os.environ.get("AKMI_SMR_CC_MAP", "1") != "0":
+                import torch
+                L, buf = capi.lib(), self.buf[0]
+                args = (C.byref(self.pack_c), C.byref(self.smr_c), self.nvar, capi._p(self.t_same), capi._p(buf),
+                        C.c_longlong(int(buf.numel())))
+                tail = C.c_longlong(0)
+                n = int(L.akmi_smr_cc_map(*args, None, C.c_longlong(0), C.byref(tail), capi._stream()))
+                capi.check(n, "smr_cc_map")
+                m = torch.zeros(max(2*n, 2), dtype=torch.int32, device=self.device)
+                capi.check(int(L.akmi_smr_cc_map(*args, capi._p(m), C.c_longlong(n), C.byref(tail), capi._stream())),
+                           "smr_cc_map")
+                self._ccmap = (m, n, int(tail.value))
+        return self._ccmap
+
     def PackAndSendCC(self, u, cu):
-        self.k.pack_cc(self.pack_c, self.smr_c, self.nvar, u, cu, self.buf[0])
+        if not self._cc_maps():
+            self.k.pack_cc(self.pack_c, self.smr_c, self.nvar, u, cu, self.buf[0])
         self._post(0)
         return TaskStatus.complete
 
     def RecvAndUnpackCC(self, u, cu):
         self._wait(0)
+        if self._cc_maps():
+            m, n, tail = self._ccmap
+            capi.check(capi.lib().akmi_smr_cc_copy(C.byref(self.pack_c), self.nvar, capi._p(m), C.c_longlong(n),
+                                                   C.c_longlong(tail), capi._p(u), capi._p(cu), capi._stream()),
+                       "smr_cc_copy")
+            return TaskStatus.complete
         self.k.unpack_cc(self.pack_c, self.smr_c, self.nvar, self.buf[0], u, cu)
         if self.direct_same:
             self.k.gather_same(self.pack_c, self.nvar, self.t_same, u)

@@ -49,7 +49,7 @@ SYMBOLS = [
     "akmi_smr_exchange_cc", "akmi_smr_exchange_fc", "akmi_smr_fill_coarse_cc", "akmi_smr_fill_coarse_fc",
     "akmi_smr_prolong_cc", "akmi_smr_prolong_fc", "akmi_smr_c2p_coarse", "akmi_smr_p2c_fine", "akmi_smr_build_lists", "akmi_smr_flux_cc", "akmi_smr_emf_exchange", "akmi_smr_pack_cc", "akmi_smr_unpack_cc", "akmi_smr_pack_fc",
     "akmi_selftest_fp64",
-    "akmi_smr_fc_map", "akmi_smr_fc_copy",
+    "akmi_smr_fc_map", "akmi_smr_fc_copy", "akmi_smr_cc_map", "akmi_smr_cc_copy",
     "akmi_smr_unpack_fc", "akmi_smr_pack_flux_cc", "akmi_smr_unpack_flux_cc", "akmi_smr_pack_emf", "akmi_smr_unpack_emf",
 ]
 
@@ -83,6 +83,7 @@ def lib():
         L.akmi_bvals_fc_segsize.restype = C.c_longlong
         L.akmi_stage_workspace_bytes.restype = C.c_longlong
         L.akmi_smr_fc_map.restype = C.c_longlong
+        L.akmi_smr_cc_map.restype = C.c_longlong
         L.akmi_sim_create.restype = C.c_void_p
         L.akmi_sim_array.restype = C.c_void_p
         L.akmi_sim_lloc.restype = C.POINTER(C.c_int)

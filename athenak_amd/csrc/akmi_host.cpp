@@ -441,6 +441,7 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
     coarse_u0.Realloc(static_cast<size_t>(pp->nmb_thispack)*nvars*c3*c2*c1);
     psmr = new MeshBoundaryValuesSMR(pp, nvars);
     psmr->BuildLists(&pack_c, stream);
+    psmr->BuildCcMap(&pack_c, stream);
     if (blk == "mhd") psmr->BuildFcMaps(&pack_c, stream);
   }
   if (!multilevel && (pp->pmesh->nranks > 1 || SelfExchange()))
@@ -937,7 +938,8 @@ void Hydro::StagePhase(Driver *d, int stage, int phases) {
 }
 TaskStatus Hydro::SendU(Driver *d, int stage) {            // hydro_tasks.cpp:308-320
   if (multilevel) {
-    AKCHK(akmi_smr_pack_cc(&pack_c, &psmr->smr_c, nvars, u0.p, coarse_u0.p, psmr->buf[0].p, stream));
+    if (!psmr->cc_map_on)
+      AKCHK(akmi_smr_pack_cc(&pack_c, &psmr->smr_c, nvars, u0.p, coarse_u0.p, psmr->buf[0].p, stream));
     psmr->Post(0, stream);
   } else if (pbval) {
     pbval->PackAndSendCC(u0.p, stream);
@@ -952,8 +954,12 @@ TaskStatus Hydro::SendU(Driver *d, int stage) {            // hydro_tasks.cpp:30
 TaskStatus Hydro::RecvU(Driver *d, int stage) {            // hydro_tasks.cpp:327-339
   if (multilevel) {
     psmr->Wait(0, stream);
-    AKCHK(akmi_smr_unpack_cc(&pack_c, &psmr->smr_c, nvars, psmr->buf[0].p, u0.p, coarse_u0.p, stream));
-    if (psmr->smr_c.direct_same) AKCHK(akmi_bvals_cc_local(&pack_c, nvars, psmr->d_same.p, u0.p, stream));
+    if (psmr->cc_map_on) {
+      AKCHK(akmi_smr_cc_copy(&pack_c, nvars, psmr->d_cc_map.p, psmr->cc_np, psmr->cc_tail, u0.p, coarse_u0.p, stream));
+    } else {
+      AKCHK(akmi_smr_unpack_cc(&pack_c, &psmr->smr_c, nvars, psmr->buf[0].p, u0.p, coarse_u0.p, stream));
+      if (psmr->smr_c.direct_same) AKCHK(akmi_bvals_cc_local(&pack_c, nvars, psmr->d_same.p, u0.p, stream));
+    }
   } else if (pbval) {
     pbval->RecvAndUnpackCC(u0.p, stream);
   }
@@ -1129,7 +1135,8 @@ void MHD::StagePhase(Driver *d, int stage, int phases) {
 // task order (mhd_tasks.cpp:48-75) with the transfers underneath the kernels that do not need them
 TaskStatus MHD::SendU(Driver *d, int stage) {
   if (multilevel) {
-    AKCHK(akmi_smr_pack_cc(&pack_c, &psmr->smr_c, nvars, u0.p, coarse_u0.p, psmr->buf[0].p, stream));
+    if (!psmr->cc_map_on)
+      AKCHK(akmi_smr_pack_cc(&pack_c, &psmr->smr_c, nvars, u0.p, coarse_u0.p, psmr->buf[0].p, stream));
     psmr->Post(0, stream);
   } else if (pbval)
     pbval->PackAndSendCC(u0.p, stream);
@@ -1140,8 +1147,12 @@ TaskStatus MHD::SendU(Driver *d, int stage) {
 TaskStatus MHD::RecvU(Driver *d, int stage) {
   if (multilevel) {
     psmr->Wait(0, stream);
-    AKCHK(akmi_smr_unpack_cc(&pack_c, &psmr->smr_c, nvars, psmr->buf[0].p, u0.p, coarse_u0.p, stream));
-    if (psmr->smr_c.direct_same) AKCHK(akmi_bvals_cc_local(&pack_c, nvars, psmr->d_same.p, u0.p, stream));
+    if (psmr->cc_map_on) {
+      AKCHK(akmi_smr_cc_copy(&pack_c, nvars, psmr->d_cc_map.p, psmr->cc_np, psmr->cc_tail, u0.p, coarse_u0.p, stream));
+    } else {
+      AKCHK(akmi_smr_unpack_cc(&pack_c, &psmr->smr_c, nvars, psmr->buf[0].p, u0.p, coarse_u0.p, stream));
+      if (psmr->smr_c.direct_same) AKCHK(akmi_bvals_cc_local(&pack_c, nvars, psmr->d_same.p, u0.p, stream));
+    }
   } else if (pbval && !(fused && peers())) {
     pbval->RecvAndUnpackCC(u0.p, stream);                                     // else: in RecvB
   }

@@ -324,6 +324,11 @@ class MeshBoundaryValuesSMR {
   long long fc_np[2] = {0, 0}, fc_tail[2] = {0, 0};
   bool fc_map_on = false;
   void BuildFcMaps(const akmi_pack *pk, hipStream_t st);
+  // one rank: the cell-centred exchange as a copy list of variable 0 (akmi_smr_cc_map); AKMI_SMR_CC_MAP=0: off
+  DvceArray<int> d_cc_map;
+  long long cc_np = 0, cc_tail = 0;
+  bool cc_map_on = false;
+  void BuildCcMap(const akmi_pack *pk, hipStream_t st);
   DvceArray<long long> d_layout, d_soff, d_roff;
   DvceArray<Real> buf[4];         // cc vars, cc flux, fc vars, fc flux
   // ranks: peers and the slices of buf[cls] that travel (akmi_smr::soff/roff address the segments)

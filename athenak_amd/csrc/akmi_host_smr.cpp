@@ -569,8 +569,21 @@ void MeshBoundaryValuesSMR::BuildFcMaps(const akmi_pack *pk, hipStream_t st) {
   fc_map_on = true;
 }
 
+void MeshBoundaryValuesSMR::BuildCcMap(const akmi_pack *pk, hipStream_t st) {
+  const char *e = std::getenv("AKMI_SMR_CC_MAP");
+  if ((e && std::atoi(e) == 0) || !peers.empty()) return;
+  const long long nb = static_cast<long long>(buf[0].n);
+  long long tail = 0;
+  const long long n = akmi_smr_cc_map(pk, &smr_c, nvar, d_same.p, buf[0].p, nb, nullptr, 0, &tail, st);
+  if (n < 0) AKMI_FATAL(std::string(akmi_last_error()));
+  d_cc_map.Realloc(static_cast<size_t>(2*std::max<long long>(n, 1)));
+  if (akmi_smr_cc_map(pk, &smr_c, nvar, d_same.p, buf[0].p, nb, d_cc_map.p, n, &tail, st) != n)
+    AKMI_FATAL(std::string(akmi_last_error()));
+  cc_np = n; cc_tail = tail; cc_map_on = true;
+}
+
 MeshBoundaryValuesSMR::~MeshBoundaryValuesSMR() {
-  d_lists.Free(); d_fc_map[0].Free(); d_fc_map[1].Free();
+  d_lists.Free(); d_fc_map[0].Free(); d_fc_map[1].Free(); d_cc_map.Free();
   d_nghbr.Free(); d_lev.Free(); d_cc.Free(); d_fc.Free(); d_ndat.Free(); d_ox.Free(); d_nflx.Free(); d_same.Free(); d_needs.Free();
   d_layout.Free(); d_soff.Free(); d_roff.Free();
   for (auto &b : buf) b.Free();

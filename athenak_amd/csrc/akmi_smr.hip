@@ -810,14 +810,20 @@ __global__ void k_fc_codes(double *__restrict__ a, long long n, long long first)
 // from it) has to read the old value -- the reference packs every message before it unpacks any: such pairs are
 // counted in *ndep, replaced by a no-op in the ordered list and appended behind it (akmi_smr_fc_copy runs that tail
 // first, in a launch of its own).
+// VarSel (cell-centred variables): the copies of the nvar variables of a cell are the same copy nvar times -- keep the
+// pairs of variable 0 only; index space [u | cu], nu = elements of u, cs / ccs = cells per variable of a fine / coarse block
+struct VarSel { long long nu, cs, ccs; int nvar; };
+__device__ __forceinline__ bool var0(const VarSel &f, long long g) {
+  return f.nvar == 0 || (g < f.nu ? (g/f.cs)%f.nvar : ((g - f.nu)/f.ccs)%f.nvar) == 0;
+}
 __global__ void __launch_bounds__(256)
 k_fc_pairs(const double *__restrict__ a, long long n, long long first, const double *__restrict__ tmp, long long ntmp,
            int *__restrict__ cnt, const long long *__restrict__ off, int *__restrict__ map, long long np,
-           int *__restrict__ ndep, int *__restrict__ bad) {
+           int *__restrict__ ndep, int *__restrict__ bad, VarSel sel) {
   const long long i = (long long)blockIdx.x*256 + threadIdx.x;
   const bool in = i < n;
   const double v = in ? a[i] : 0.0;
-  const bool ch = in && v != (double)(first + i + 1);
+  const bool ch = in && v != (double)(first + i + 1) && var0(sel, first + i);
   __shared__ int wsum[4];
   const unsigned long long bal = __ballot(ch);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -827,6 +833,7 @@ k_fc_pairs(const double *__restrict__ a, long long n, long long first, const dou
   if (!ch) return;
   const long long src = (long long)v - 1;
   if (!(v >= 1.0) || v != (double)(src + 1)) { atomicAdd(bad, 1); return; }      // not a code: a value nobody wrote
+  if (sel.nvar && (src >= ntmp || !var0(sel, src))) { atomicAdd(bad, 1); return; }   // variable 0 comes from variable 0
   bool dep = false;
   if (src < ntmp && tmp[src] != (double)(src + 1)) {          // the source is a destination of another copy
     dep = true;
@@ -857,6 +864,34 @@ k_smr_fc_copy(FcIdx ix, FcArr ar, const int2 *__restrict__ map, long long np) {
   if (e >= np) return;
   const int2 ds = map[e];
   if (ds.x != ds.y) *fc_at(ix, ar, ds.x) = *fc_at(ix, ar, ds.y);
+}
+// the cell-centred list: pairs of variable 0 in the index space [u | cu]; variable v of a pair lies v*cs (fine array) or
+// v*ccs (coarse array) further on.  A thread moves all variables of its pair (the list is read once): loads of up to
+// eight variables first, then their stores.
+__global__ void __launch_bounds__(256)
+k_smr_cc_copy(VarSel f, double *__restrict__ u, double *__restrict__ cu, const int2 *__restrict__ map, long long np) {
+  const long long e = (long long)blockIdx.x*256 + threadIdx.x;
+  if (e >= np) return;
+  const int2 ds = map[e];
+  if (ds.x == ds.y) return;
+  const long long d = ds.x, s = ds.y;
+  const double *src = s < f.nu ? u + s : cu + (s - f.nu);
+  double *dst = d < f.nu ? u + d : cu + (d - f.nu);
+  const long long ss = s < f.nu ? f.cs : f.ccs, sd = d < f.nu ? f.cs : f.ccs;
+  for (int v0 = 0; v0 < f.nvar; v0 += 8) {
+    double val[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) if (v0 + q < f.nvar) val[q] = src[(v0 + q)*ss];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) if (v0 + q < f.nvar) dst[(v0 + q)*sd] = val[q];
+  }
+}
+static VarSel cc_sel(const akmi_pack *p, int nvar) {
+  const SGeo s = make_sgeo(p);
+  VarSel f;
+  f.cs = (long long)s.N3*s.N2*s.N1; f.ccs = (long long)s.cN3*s.cN2*s.cN1;
+  f.nu = (long long)p->nmb*nvar*f.cs; f.nvar = nvar;
+  return f;
 }
 static FcIdx fc_index(const akmi_pack *p, long long buf_doubles) {
   const SGeo s = make_sgeo(p);
@@ -1122,7 +1157,7 @@ long long akmi_smr_fc_map(const akmi_pack *p, const akmi_smr *t, double *buf, lo
                       tmp + ix.base[5], buf, stream, which ? 1 : 3) != AKMI_COMPLETE) goto done;
   scan = which ? buf + send_lo : tmp;
   if (n > 0) {
-    k_fc_pairs<<<nwg, 256, 0, st>>>(scan, n, first, tmp, ntmp, d_cnt, nullptr, nullptr, 0, d_flag, d_flag + 1);
+    k_fc_pairs<<<nwg, 256, 0, st>>>(scan, n, first, tmp, ntmp, d_cnt, nullptr, nullptr, 0, d_flag, d_flag + 1, VarSel{0, 1, 1, 0});
     FCM_HIP(hipMemcpyAsync(h_cnt.data(), d_cnt, sizeof(int)*nwg, hipMemcpyDeviceToHost, st));
     FCM_HIP(hipMemcpyAsync(h_flag, d_flag, 2*sizeof(int), hipMemcpyDeviceToHost, st));
     FCM_HIP(hipStreamSynchronize(st));
@@ -1133,7 +1168,7 @@ long long akmi_smr_fc_map(const akmi_pack *p, const akmi_smr *t, double *buf, lo
     if (np + h_flag[0] > cap) { set_error("smr_fc_map: %lld pairs, room for %lld", np + h_flag[0], cap); goto done; }
     FCM_HIP(hipMemcpyAsync(d_off, h_off.data(), sizeof(long long)*nwg, hipMemcpyHostToDevice, st));
     FCM_HIP(hipMemsetAsync(d_flag, 0, 2*sizeof(int), st));
-    k_fc_pairs<<<nwg, 256, 0, st>>>(scan, n, first, tmp, ntmp, d_cnt, d_off, map, np, d_flag, d_flag + 1);
+    k_fc_pairs<<<nwg, 256, 0, st>>>(scan, n, first, tmp, ntmp, d_cnt, d_off, map, np, d_flag, d_flag + 1, VarSel{0, 1, 1, 0});
   }
   if (buf_doubles > 0) FCM_HIP(hipMemsetAsync(buf, 0, sizeof(double)*(size_t)buf_doubles, st));
   FCM_HIP(hipStreamSynchronize(st));
@@ -1160,6 +1195,76 @@ int akmi_smr_fc_copy(const akmi_pack *p, const int *map, long long npairs, long 
   if (head > 0)
     k_smr_fc_copy<<<(unsigned)((head + 255)/256), 256, 0, (hipStream_t)stream>>>(ix, ar, m2, head);
   AKMI_CHECK_LAUNCH("smr_fc_copy");
+  return AKMI_COMPLETE;
+}
+
+long long akmi_smr_cc_map(const akmi_pack *p, const akmi_smr *t, int nvar, const int *same27, double *buf,
+                          long long buf_doubles, int *map, long long cap, long long *ntail, void *stream) {
+  using namespace akmi;
+  if (check_smr(p, t, "smr_cc_map") != AKMI_COMPLETE) return -1;
+  if (t->soff || t->roff) { set_error("smr_cc_map: one rank only (neighbours on other ranks go through the buffers)"); return -1; }
+  if (nvar < 1) { set_error("smr_cc_map: nvar"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  const VarSel sel = cc_sel(p, nvar);
+  const long long ncu = (long long)p->nmb*nvar*sel.ccs, ntmp = sel.nu + ncu;
+  if (ntmp + buf_doubles >= (1ll << 31)) { set_error("smr_cc_map: more than 2^31 elements in a pack"); return -1; }
+  double *tmp = nullptr;
+  int *d_cnt = nullptr, *d_flag = nullptr;
+  long long *d_off = nullptr;
+  long long result = -1, np = 0;
+  const unsigned nwg = (unsigned)((ntmp + 255)/256);
+  std::vector<int> h_cnt(nwg);
+  std::vector<long long> h_off(nwg);
+  int h_flag[2] = {0, 0};
+#define CCM_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("smr_cc_map: %s", hipGetErrorString(e_)); goto done; } } while (0)
+  CCM_HIP(hipMalloc(&tmp, sizeof(double)*(size_t)ntmp));
+  CCM_HIP(hipMalloc(&d_cnt, sizeof(int)*(size_t)(nwg + 1)));
+  CCM_HIP(hipMalloc(&d_off, sizeof(long long)*(size_t)(nwg + 1)));
+  CCM_HIP(hipMalloc(&d_flag, 2*sizeof(int)));
+  CCM_HIP(hipMemsetAsync(d_flag, 0, 2*sizeof(int), st));
+  k_fc_codes<<<(unsigned)((ntmp + 255)/256), 256, 0, st>>>(tmp, ntmp, 0);
+  if (buf_doubles > 0) k_fc_codes<<<(unsigned)((buf_doubles + 255)/256), 256, 0, st>>>(buf, buf_doubles, ntmp);
+  // the exchange as the hosts run it: pack + unpack across levels, then the direct same-level gather
+  if (smr_exchange_cc(p, t, nvar, tmp, tmp + sel.nu, buf, stream, 3) != AKMI_COMPLETE) goto done;
+  if (t->direct_same) {
+    if (!same27) { set_error("smr_cc_map: direct_same without the same-level table"); goto done; }
+    if (akmi_bvals_cc_local(p, nvar, same27, tmp, stream) != AKMI_COMPLETE) goto done;
+  }
+  k_fc_pairs<<<nwg, 256, 0, st>>>(tmp, ntmp, 0, tmp, ntmp, d_cnt, nullptr, nullptr, 0, d_flag, d_flag + 1, sel);
+  CCM_HIP(hipMemcpyAsync(h_cnt.data(), d_cnt, sizeof(int)*nwg, hipMemcpyDeviceToHost, st));
+  CCM_HIP(hipMemcpyAsync(h_flag, d_flag, 2*sizeof(int), hipMemcpyDeviceToHost, st));
+  CCM_HIP(hipStreamSynchronize(st));
+  for (unsigned w = 0; w < nwg; ++w) { h_off[w] = np; np += h_cnt[w]; }
+  if (h_flag[1]) { set_error("smr_cc_map: %d copies are not independent element copies", h_flag[1]); goto done; }
+  if (map && np > 0) {
+    if (np + h_flag[0] > cap) { set_error("smr_cc_map: %lld pairs, room for %lld", np + h_flag[0], cap); goto done; }
+    CCM_HIP(hipMemcpyAsync(d_off, h_off.data(), sizeof(long long)*nwg, hipMemcpyHostToDevice, st));
+    CCM_HIP(hipMemsetAsync(d_flag, 0, 2*sizeof(int), st));
+    k_fc_pairs<<<nwg, 256, 0, st>>>(tmp, ntmp, 0, tmp, ntmp, d_cnt, d_off, map, np, d_flag, d_flag + 1, sel);
+  }
+  if (buf_doubles > 0) CCM_HIP(hipMemsetAsync(buf, 0, sizeof(double)*(size_t)buf_doubles, st));
+  CCM_HIP(hipStreamSynchronize(st));
+  { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { set_error("smr_cc_map: %s", hipGetErrorString(e_)); goto done; } }
+  if (ntail) *ntail = h_flag[0];
+  result = np + h_flag[0];
+done:
+#undef CCM_HIP
+  (void)hipFree(tmp); (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_flag);
+  return result;
+}
+
+int akmi_smr_cc_copy(const akmi_pack *p, int nvar, const int *map, long long npairs, long long ntail, double *u,
+                     double *cu, void *stream) {
+  using namespace akmi;
+  if (npairs <= 0) return AKMI_COMPLETE;
+  const VarSel sel = cc_sel(p, nvar);
+  const int2 *m2 = reinterpret_cast<const int2 *>(map);
+  const long long head = npairs - ntail;
+  if (ntail > 0)
+    k_smr_cc_copy<<<(unsigned)((ntail + 255)/256), 256, 0, (hipStream_t)stream>>>(sel, u, cu, m2 + head, ntail);
+  if (head > 0)
+    k_smr_cc_copy<<<(unsigned)((head + 255)/256), 256, 0, (hipStream_t)stream>>>(sel, u, cu, m2, head);
+  AKMI_CHECK_LAUNCH("smr_cc_copy");
   return AKMI_COMPLETE;
 }
 

@@ -456,6 +456,16 @@ int akmi_smr_fc_copy(const akmi_pack *p, const int *map, long long npairs, long 
                      double *b1, double *b2, double *b3, double *cb1, double *cb2, double *cb3, double *buf,
                      void *stream);
 
+/* The same for the cell-centred variables (PackAndSendCC + RecvAndUnpackCC, src/bvals/bvals_cc.cpp:42-447, as this
+ * library performs them: akmi_smr_pack_cc + akmi_smr_unpack_cc across levels, then the direct same-level gather
+ * akmi_bvals_cc_local with the [nmb][27] table same27): the copies of the nvar variables of a cell are one copy nvar times,
+ * so the list holds the pairs of variable 0 in the index space [u | cu] and akmi_smr_cc_copy applies it to every variable.
+ * One rank only (returns -1 when akmi_smr::soff / roff are set: the caller keeps the three calls then). */
+long long akmi_smr_cc_map(const akmi_pack *p, const akmi_smr *t, int nvar, const int *same27, double *buf,
+                          long long buf_doubles, int *map, long long cap, long long *ntail, void *stream);
+int akmi_smr_cc_copy(const akmi_pack *p, int nvar, const int *map, long long npairs, long long ntail, double *u,
+                     double *cu, void *stream);
+
 /* ---- Fused fast path ("one kernel sequence per MeshBlockPack stage") ----------------- *
  * Must produce results identical to the task chain above.  ws = device workspace of
  * akmi_stage_workspace_bytes() bytes owned by the caller. */
