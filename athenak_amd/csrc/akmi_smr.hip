@@ -764,25 +764,6 @@ static int check_smr(const akmi_pack *p, const akmi_smr *t, const char *who) {
   return AKMI_COMPLETE;
 }
 
-}  // namespace akmi
-
-using namespace akmi;
-
-extern "C" {
-
-// phase: 1 = PackAndSend*, 2 = RecvAndUnpack*, 3 = both (neighbours in the same pack only)
-static int smr_exchange_cc(const akmi_pack *p, const akmi_smr *t, int nvar, double *u, double *cu,
-                           double *buf, void *stream, int phase) {
-  if (check_smr(p, t, "smr_exchange_cc") != AKMI_COMPLETE) return AKMI_FAIL;
-  const SGeo s = make_sgeo(p);
-  const Tab tb = make_tab(p, t);
-  hipStream_t st = (hipStream_t)stream;
-  if (phase & 1) SMR_LAUNCH(k_smr_pack_cc, L_VALID_CC, 1, st, s, tb, nvar, u, cu, buf);
-  if (phase & 2) SMR_LAUNCH(k_smr_unpack_cc, L_VALID_CC, 1, st, s, tb, nvar, buf, u, cu);
-  AKMI_CHECK_LAUNCH("smr_exchange_cc");
-  return AKMI_COMPLETE;
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // The face-field exchange as ONE list of element copies (akmi_smr_fc_map / akmi_smr_fc_copy).
 //
@@ -906,6 +887,25 @@ static FcIdx fc_index(const akmi_pack *p, long long buf_doubles) {
   ix.base[6] = o;
   ix.base[7] = o + buf_doubles;
   return ix;
+}
+
+}  // namespace akmi
+
+using namespace akmi;
+
+extern "C" {
+
+// phase: 1 = PackAndSend*, 2 = RecvAndUnpack*, 3 = both (neighbours in the same pack only)
+static int smr_exchange_cc(const akmi_pack *p, const akmi_smr *t, int nvar, double *u, double *cu,
+                           double *buf, void *stream, int phase) {
+  if (check_smr(p, t, "smr_exchange_cc") != AKMI_COMPLETE) return AKMI_FAIL;
+  const SGeo s = make_sgeo(p);
+  const Tab tb = make_tab(p, t);
+  hipStream_t st = (hipStream_t)stream;
+  if (phase & 1) SMR_LAUNCH(k_smr_pack_cc, L_VALID_CC, 1, st, s, tb, nvar, u, cu, buf);
+  if (phase & 2) SMR_LAUNCH(k_smr_unpack_cc, L_VALID_CC, 1, st, s, tb, nvar, buf, u, cu);
+  AKMI_CHECK_LAUNCH("smr_exchange_cc");
+  return AKMI_COMPLETE;
 }
 
 static int smr_exchange_fc(const akmi_pack *p, const akmi_smr *t, double *b1, double *b2, double *b3,

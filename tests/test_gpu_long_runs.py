@@ -39,3 +39,13 @@ def test_long_run_refined_mesh_bitwise():
         r = pu.compare_run("blast_smr", (32, 32, 32), 3, (8, 8, 8), cycles=40, native=native)
         assert r["cycles"] == 40 and r["dt"][0] == r["dt"][1], (native, r["cycles"], r["dt"])
         assert r["bitwise_equal"], (native, r["diffs"])
+
+
+def test_refined_mesh_production_block_size_bitwise():
+    """config 5's mesh with the MeshBlock size of its production run (32^3, ng = 4) on a 128^3 root grid: 120 MeshBlocks on
+    two levels, 3 cycles through the C++ host.  (The same check on 960 MeshBlocks of 16^3 -- the copy lists of the
+    exchange at the block count of the production mesh -- passes through both hosts but needs 85 s per host for the
+    oracle's set-up: tools/c5_mid_check.py.)"""
+    r = pu.compare_run("blast_smr", (128, 128, 128), 3, (32, 32, 32), cycles=3, native=True)
+    assert r["cycles"] == 3 and r["dt"][0] == r["dt"][1], (r["cycles"], r["dt"])
+    assert r["bitwise_equal"], r["diffs"]
