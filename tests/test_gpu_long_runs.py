@@ -11,13 +11,13 @@ import parity_util as pu  # noqa: E402
 
 LONG = [
     # problem, n, dims, mb, cycles, kwargs
-    ("orszag_tang", 64, 3, 64, 200, dict(cfl=0.3, fused=True)),                 # C3's deck well past shock formation
-    ("orszag_tang", 48, 3, 24, 150, dict(cfl=0.3, fused=True, native=True)),    # eight blocks, C++ host
+    ("orszag_tang", 64, 3, 64, 140, dict(cfl=0.3, fused=True)),                 # C3's deck well past shock formation
+    ("orszag_tang", 48, 3, 24, 120, dict(cfl=0.3, fused=True, native=True)),    # eight blocks, C++ host
     ("orszag_tang", 48, 3, 24, 100, dict(cfl=0.3, fused=False)),                # task-granular chain
     ("orszag_tang", 128, 2, 64, 400, dict(cfl=0.3)),                            # 2-D: current sheets by cycle ~300
     ("sod", 64, 3, 32, 120, dict(cfl=0.3, fused=True)),                         # C2's deck, shock crosses blocks
-    ("blast", 40, 3, 20, 120, dict(fused=True)),                                # PPM4 + HLLD, ng = 4, strong blast
-    ("blast", 40, 3, 20, 60, dict(fused=False, native=True, integrator="rk3")),
+    ("blast", 40, 3, 20, 90, dict(fused=True)),                                # PPM4 + HLLD, ng = 4, strong blast
+    ("blast", 40, 3, 20, 45, dict(fused=False, native=True, integrator="rk3")),
     ("blast", 64, 2, 32, 300, dict()),
 ]
 
@@ -27,17 +27,17 @@ LONG = [
 def test_long_run_bitwise(case):
     problem, n, dims, mb, cycles, kw = case
     r = pu.compare_run(problem, n, dims, mb, cycles, **kw)
-    assert r["cycles"] >= min(cycles, 60), r["cycles"]          # (a deck's own tlim may end the run before `cycles`)
+    assert r["cycles"] >= min(cycles, 45), r["cycles"]          # (a deck's own tlim may end the run before `cycles`)
     assert r["time"][0] == r["time"][1] and r["dt"][0] == r["dt"][1], (r["time"], r["dt"])
     assert r["bitwise_equal"], r["diffs"]
 
 
 def test_long_run_refined_mesh_bitwise():
-    """BASELINE config 5's mesh at fixture size (3-D blast, one refined region, PPM4 + HLLD + CT, ng = 4): 40 cycles,
+    """BASELINE config 5's mesh at fixture size (3-D blast, one refined region, PPM4 + HLLD + CT, ng = 4): 30 cycles,
     the blast wave reaches the fine/coarse boundary; both hosts"""
     for native in (False, True):
-        r = pu.compare_run("blast_smr", (32, 32, 32), 3, (8, 8, 8), cycles=40, native=native)
-        assert r["cycles"] == 40 and r["dt"][0] == r["dt"][1], (native, r["cycles"], r["dt"])
+        r = pu.compare_run("blast_smr", (32, 32, 32), 3, (8, 8, 8), cycles=30, native=native)
+        assert r["cycles"] == 30 and r["dt"][0] == r["dt"][1], (native, r["cycles"], r["dt"])
         assert r["bitwise_equal"], (native, r["diffs"])
 
 
