@@ -1764,22 +1764,43 @@ constexpr int HS_THREADS = 512;
 #endif
 
 static HydTile hyd_tile(int c1, int c2) {
-  // cost: lanes launched, short rows penalised like ct_tile; owners are (tw-1) x (th-1)
+  // The kernel is issue-bound (1 700 VALU instructions per cell, two waves per SIMD), so what a shape costs is the lanes
+  // it launches per owned column, not the length of its rows: cost = lanes launched (tiles x padded workgroup)
+  //   x (1 + 0.3 x plane-with-halo / owners)    the LDS plane every step loads: (tw+3)(th+3) entries for (tw-1)(th-1) owners
+  //   x (1 + 4/tw)                              short rows (tw = 9: +15 % measured)
+  //   / occupancy                               workgroups per CU by LDS x waves per workgroup, against the 8 waves the
+  //                                             220 VGPRs allow (a 192-thread tile with 57 KB: 6 waves, 38 x 5 was that)
+  // fitted to the scan in profiles/r04_hydro_tiles.txt (256^3: 38 x 5 1400 us, 23 x 11 1099, 28 x 9 1089; 128^3: 44 x 5
+  // 173 us, 23 x 11 158); the round-1 rule (ct_tile's: row length first) chose 38 x 5 / 44 x 5.
   static const int maxt = getenv("AKMI_HS_MAXT") ? atoi(getenv("AKMI_HS_MAXT")) : 256;   // two workgroups per CU
   static const int maxlds = getenv("AKMI_HS_LDS") ? atoi(getenv("AKMI_HS_LDS")) : 80*1024;       // two workgroups per CU
+  static int f_tw = -1, f_th = 0;                        // AKMI_HS_TILE=tw,th pins the shape (experiments)
+  if (f_tw < 0) {
+    const char *e = getenv("AKMI_HS_TILE");                 // "tw,th" or "twxth"
+    f_tw = 0;
+    if (e && sscanf(e, "%d%*[,x]%d", &f_tw, &f_th) != 2) f_tw = 0;
+    if (f_tw < 4 || f_th < 3 || f_tw*f_th > HS_THREADS) f_tw = 0;
+  }
+  if (f_tw > 0 && 3*(f_tw + 3) + 3*f_th <= f_tw*f_th &&
+      2*(5*(size_t)(f_tw + 3)*(f_th + 3) + 10*(size_t)f_tw*f_th)*sizeof(double) <= 150*1024)
+    return HydTile{f_tw, f_th, (c1 + f_tw - 2)/(f_tw - 1), (c2 + f_th - 2)/(f_th - 1), (f_tw*f_th + 63)/64*64};
   HydTile best{0, 0, 0, 0, 0};
   double best_cost = -1.0;
   for (int n1 = 1; n1 <= c1; ++n1) {
     const int tw = (c1 + n1 - 1)/n1 + 1;
     if (tw > 130) continue;
-    if (tw < 18 && n1 > 1) break;
-    for (int th = 3; th <= 32; ++th) {
+    if (tw < 8 && n1 > 1) break;
+    for (int th = 3; th <= 40; ++th) {
       if (tw*th > maxt) break;
       if (3*(tw + 3) + 3*th > tw*th) continue;         // one halo entry per thread at most
-      if (2*(5*(tw + 3)*(th + 3) + 10*tw*th)*sizeof(double) > (size_t)maxlds) continue;
+      const size_t lds = 2*(5*(size_t)(tw + 3)*(th + 3) + 10*(size_t)tw*th)*sizeof(double);
+      if (lds > (size_t)maxlds) continue;
       const int n2 = (c2 + th - 2)/(th - 1);
       const int threads = (tw*th + 63)/64*64;
-      const double cost = (double)n1*n2*threads*(6.3 + 130.0/tw);
+      const int waves_cu = (int)(160*1024/lds)*(threads/64);
+      const double occ = (waves_cu < 8 ? waves_cu : 8)/8.0;
+      const double halo = (double)(tw + 3)*(th + 3)/((double)(tw - 1)*(th - 1));
+      const double cost = (double)n1*n2*threads*(1.0 + 0.3*halo)*(1.0 + 4.0/tw)/occ;
       if (best_cost < 0 || cost < best_cost) { best = HydTile{tw, th, n1, n2, threads}; best_cost = cost; }
     }
   }
