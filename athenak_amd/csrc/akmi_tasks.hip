@@ -1315,8 +1315,12 @@ int akmi_mhd_corner_e(const akmi_pack *p, const double *w0, const double *bcc0,
       const long per_wg = (long)(CX - 1)*CY;
       const unsigned nb = (unsigned)((np + 1 + per_wg - 1)/per_wg);
       const int nk = g.nx3 + 1;
-      long ckl = (long)nb*nk*g.nmb/2048;                           // ~2048 workgroups per launch
-      ckl = ckl > 32 ? 32 : (ckl < 4 ? 4 : ckl);
+      // ~2048 workgroups per launch, chunks of EQUAL length (a chunk primes its k-1 operands: 33 planes as 32 + 1 cost
+      // a second workgroup per tile for one plane -- 960 blocks of 32^3: 1978 -> see profiles/r04_c5f_config5.txt)
+      long nch = 2048/((long)nb*g.nmb);
+      nch = nch < 1 ? 1 : (nch > (nk + 3)/4 ? (nk + 3)/4 : nch);
+      long ckl = (nk + nch - 1)/nch;
+      ckl = ckl > 48 ? 48 : ckl;
       const int nchunk = cdiv(nk, (int)ckl);
       dim3 grid(nb, 1, nchunk*g.nmb), block(CX, CY);
       k_corner_e_3d_march<<<grid, block, 0, st>>>(g, w0, bcc0, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, flx1, flx2,
