@@ -58,13 +58,24 @@ class HipBvalsKernels:
                                                capi._p(buf), capi._p(b1), capi._p(b2), capi._p(b3),
                                                capi._stream()), "bvals_fc_unpack")
 
+    def _dirs(self, bcs):
+        """bit d set: some MeshBlock has a physical boundary across direction d (anything but block / periodic); the
+        other directions are not launched (akmi_*_bcs_dirs).  Read from the flag table once per table."""
+        key = bcs.data_ptr()
+        cache = self.__dict__.setdefault("_dirs_cache", {})
+        if key not in cache:
+            f = bcs.detach().cpu().numpy().reshape(-1, 6)
+            phys = (f != capi.BC["block"]) & (f != capi.BC["periodic"])
+            cache[key] = sum(1 << q for q in range(3) if phys[:, 2*q:2*q + 2].any())
+        return cache[key]
+
     def hydro_bcs(self, pack, nvar, bcs, u, u_in=None):
-        capi.check(self.L.akmi_hydro_bcs_inflow(C.byref(pack), nvar, capi._p(bcs), capi._p(u_in),
-                                                capi._p(u), capi._stream()), "hydro_bcs")
+        capi.check(self.L.akmi_hydro_bcs_dirs(C.byref(pack), nvar, capi._p(bcs), self._dirs(bcs), capi._p(u_in),
+                                              capi._p(u), capi._stream()), "hydro_bcs")
 
     def bfield_bcs(self, pack, bcs, b1, b2, b3, b_in=None):
-        capi.check(self.L.akmi_bfield_bcs_inflow(C.byref(pack), capi._p(bcs), capi._p(b_in), capi._p(b1),
-                                                 capi._p(b2), capi._p(b3), capi._stream()), "bfield_bcs")
+        capi.check(self.L.akmi_bfield_bcs_dirs(C.byref(pack), capi._p(bcs), self._dirs(bcs), capi._p(b_in), capi._p(b1),
+                                               capi._p(b2), capi._p(b3), capi._stream()), "bfield_bcs")
 
 
 class _Channel:

@@ -33,7 +33,7 @@ SMALL_PACK_CELLS = 600000       # AKMI_SMALL_PACK_CELLS of include/akmi.h (tests
 
 # every symbol include/akmi.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
-    "akmi_last_error", "akmi_version", "akmi_build_flags", "akmi_copy_cons", "akmi_rk4_copy_cons", "akmi_hydro_fluxes_fofc", "akmi_hydro_fofc", "akmi_mhd_fluxes_fofc", "akmi_mhd_fofc", "akmi_kinematic_newdt", "akmi_ambipolar_emfs", "akmi_ambipolar_fluxes", "akmi_resistive_newdt", "akmi_restrict_cc", "akmi_restrict_fc", "akmi_restrict_cc_masked", "akmi_restrict_fc_masked", "akmi_restrict_flux_cc", "akmi_restrict_emf", "akmi_prim2cons", "akmi_prolong_cc", "akmi_prolong_fc_shared", "akmi_prolong_fc_internal", "akmi_hydro_bcs_inflow", "akmi_bfield_bcs_inflow", "akmi_viscous_fluxes", "akmi_heat_fluxes", "akmi_conduction_newdt", "akmi_resistive_emfs", "akmi_resistive_fluxes", "akmi_hydro_fluxes", "akmi_rk_update", "akmi_rk_update_oop", "akmi_mhd_ct_oop",
+    "akmi_last_error", "akmi_version", "akmi_build_flags", "akmi_copy_cons", "akmi_rk4_copy_cons", "akmi_hydro_fluxes_fofc", "akmi_hydro_fofc", "akmi_mhd_fluxes_fofc", "akmi_mhd_fofc", "akmi_kinematic_newdt", "akmi_ambipolar_emfs", "akmi_ambipolar_fluxes", "akmi_resistive_newdt", "akmi_restrict_cc", "akmi_restrict_fc", "akmi_restrict_cc_masked", "akmi_restrict_fc_masked", "akmi_restrict_flux_cc", "akmi_restrict_emf", "akmi_prim2cons", "akmi_prolong_cc", "akmi_prolong_fc_shared", "akmi_prolong_fc_internal", "akmi_hydro_bcs_inflow", "akmi_bfield_bcs_inflow", "akmi_hydro_bcs_dirs", "akmi_bfield_bcs_dirs", "akmi_viscous_fluxes", "akmi_heat_fluxes", "akmi_conduction_newdt", "akmi_resistive_emfs", "akmi_resistive_fluxes", "akmi_hydro_fluxes", "akmi_rk_update", "akmi_rk_update_oop", "akmi_mhd_ct_oop",
     "akmi_hydro_c2p", "akmi_hydro_newdt", "akmi_mhd_fluxes", "akmi_mhd_corner_e", "akmi_mhd_ct",
     "akmi_mhd_c2p", "akmi_mhd_newdt", "akmi_bvals_cc_local", "akmi_bvals_cc_pack",
     "akmi_bvals_cc_unpack", "akmi_bvals_cc_segsize", "akmi_bvals_fc_local", "akmi_bvals_fc_pack",

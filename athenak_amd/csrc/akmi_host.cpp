@@ -303,6 +303,10 @@ MeshBlock::MeshBlock(MeshBlockPack *ppack, int igids, int nmb_) : nmb(nmb_) {
   d_dx.Realloc(3*nmb); d_bcs.Realloc(6*nmb); d_nghbr.Realloc(27*nmb);
   HIPCHK(hipMemcpy(d_dx.p, dx.data(), sizeof(Real)*3*nmb, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d_bcs.p, mb_bcs.data(), sizeof(int)*6*nmb, hipMemcpyHostToDevice));
+  bc_dirs = 0;
+  for (int m = 0; m < nmb; ++m)
+    for (int f = 0; f < 6; ++f)
+      if (mb_bcs[6*m + f] != AKMI_BC_BLOCK && mb_bcs[6*m + f] != AKMI_BC_PERIODIC) bc_dirs |= 1 << (f/2);
   HIPCHK(hipMemcpy(d_nghbr.p, plan.tab.data(), sizeof(int)*27*nmb, hipMemcpyHostToDevice));
   if (pm->multilevel) SetNeighborsSMR(pm);
 }
@@ -989,7 +993,7 @@ TaskStatus Hydro::Prolongate(Driver *d, int stage) {       // hydro_tasks.cpp:38
   if (!multilevel) return TaskStatus::complete;
   AKCHK(akmi_smr_fill_coarse_cc(&pack_c, &psmr->smr_c, nvars, u0.p, coarse_u0.p, stream));
   if (!pmy_pack->pmesh->strictly_periodic)               // HydroBCsCoarse: the BC helper on coarse indices
-    AKCHK(akmi_hydro_bcs(&cpack_c, nvars, pmy_pack->pmb->d_bcs.p, coarse_u0.p, stream));
+    AKCHK(akmi_hydro_bcs_dirs(&cpack_c, nvars, pmy_pack->pmb->d_bcs.p, pmy_pack->pmb->bc_dirs, nullptr, coarse_u0.p, stream));
   if (pmy_pack->pmesh->prolong_prims) {                   // hydro_tasks.cpp:388-392
     if (!coarse_w0.p) coarse_w0.Realloc(coarse_u0.n);
     AKCHK(akmi_smr_c2p_coarse(&pack_c, &psmr->smr_c, nvars, coarse_u0.p, nullptr, nullptr, nullptr, coarse_w0.p, stream));
@@ -1002,7 +1006,7 @@ TaskStatus Hydro::Prolongate(Driver *d, int stage) {       // hydro_tasks.cpp:38
 }
 TaskStatus Hydro::ApplyPhysicalBCs(Driver *d, int stage) { // hydro_tasks.cpp:357-375
   if (pmy_pack->pmesh->strictly_periodic) return TaskStatus::complete;
-  AKCHK(akmi_hydro_bcs(&pack_c, nvars, pmy_pack->pmb->d_bcs.p, u0.p, stream));
+  AKCHK(akmi_hydro_bcs_dirs(&pack_c, nvars, pmy_pack->pmb->d_bcs.p, pmy_pack->pmb->bc_dirs, nullptr, u0.p, stream));
   return TaskStatus::complete;
 }
 TaskStatus Hydro::ConToPrim(Driver *d, int stage) {        // hydro_tasks.cpp:404-412
@@ -1227,8 +1231,8 @@ TaskStatus MHD::Prolongate(Driver *d, int stage) {         // mhd_tasks.cpp:527-
   AKCHK(akmi_smr_fill_coarse_fc(&pack_c, t, b0.x1f.p, b0.x2f.p, b0.x3f.p, coarse_b0.x1f.p, coarse_b0.x2f.p,
                                 coarse_b0.x3f.p, stream));
   if (!pmy_pack->pmesh->strictly_periodic) {
-    AKCHK(akmi_hydro_bcs(&cpack_c, nvars, pmy_pack->pmb->d_bcs.p, coarse_u0.p, stream));
-    AKCHK(akmi_bfield_bcs(&cpack_c, pmy_pack->pmb->d_bcs.p, coarse_b0.x1f.p, coarse_b0.x2f.p, coarse_b0.x3f.p,
+    AKCHK(akmi_hydro_bcs_dirs(&cpack_c, nvars, pmy_pack->pmb->d_bcs.p, pmy_pack->pmb->bc_dirs, nullptr, coarse_u0.p, stream));
+    AKCHK(akmi_bfield_bcs_dirs(&cpack_c, pmy_pack->pmb->d_bcs.p, pmy_pack->pmb->bc_dirs, nullptr, coarse_b0.x1f.p, coarse_b0.x2f.p, coarse_b0.x3f.p,
                           stream));
   }
   if (pmy_pack->pmesh->prolong_prims) {                   // mhd_tasks.cpp:539-544
@@ -1293,8 +1297,8 @@ TaskStatus MHD::SendB(Driver *d, int stage) {
 }
 TaskStatus MHD::ApplyPhysicalBCs(Driver *d, int stage) {   // mhd_tasks.cpp:501-520
   if (pmy_pack->pmesh->strictly_periodic) return TaskStatus::complete;
-  AKCHK(akmi_hydro_bcs(&pack_c, nvars, pmy_pack->pmb->d_bcs.p, u0.p, stream));
-  AKCHK(akmi_bfield_bcs(&pack_c, pmy_pack->pmb->d_bcs.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, stream));
+  AKCHK(akmi_hydro_bcs_dirs(&pack_c, nvars, pmy_pack->pmb->d_bcs.p, pmy_pack->pmb->bc_dirs, nullptr, u0.p, stream));
+  AKCHK(akmi_bfield_bcs_dirs(&pack_c, pmy_pack->pmb->d_bcs.p, pmy_pack->pmb->bc_dirs, nullptr, b0.x1f.p, b0.x2f.p, b0.x3f.p, stream));
   return TaskStatus::complete;
 }
 TaskStatus MHD::ConToPrim(Driver *d, int stage) {

@@ -233,6 +233,7 @@ class MeshBlock {       // meshblock.cpp:25-131
   std::vector<int> mb_gid;
   std::vector<RegionSize> mb_size;
   std::vector<int> mb_bcs;        // [nmb][6]
+  int bc_dirs = 7;                // bit d: some block has a physical boundary across direction d (akmi_*_bcs_dirs)
   std::vector<int> nghbr_gid, nghbr_rank;   // [nmb][27] same-level neighbour: gid (-1 none) and its rank
   ExchangePlan plan;              // plan.tab = the device neighbour table (local index | -1 | remote slot)
   DvceArray<Real> d_dx;           // [nmb][3]

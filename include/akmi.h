@@ -273,6 +273,12 @@ int akmi_hydro_bcs_inflow(const akmi_pack *p, int nvar, const int *bcs, const do
                           void *stream);
 int akmi_bfield_bcs_inflow(const akmi_pack *p, const int *bcs, const double *b_in, double *bx1f,
                            double *bx2f, double *bx3f, void *stream);
+/* The same with the set of directions that have a physical boundary at all (bit d = direction d; the caller derives it from
+ * the flags once): the other directions are not launched.  dirs = 7 equals the entries above; u_in / b_in may be NULL. */
+int akmi_hydro_bcs_dirs(const akmi_pack *p, int nvar, const int *bcs, int dirs, const double *u_in, double *u,
+                        void *stream);
+int akmi_bfield_bcs_dirs(const akmi_pack *p, const int *bcs, int dirs, const double *b_in, double *bx1f, double *bx2f,
+                         double *bx3f, void *stream);
 
 /* ---- SMR/AMR operators between a MeshBlock and its coarse buffer ---------- *
  * Coarse arrays: cnx = nx/2 active cells, the same ng ghost cells, same layout:

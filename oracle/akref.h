@@ -65,6 +65,9 @@ int akref_kinematic_newdt(const akmi_pack *p, const double *w0, double *dt3);
 int akref_hydro_bcs_inflow(const akmi_pack *p, int nvar, const int *bcs, const double *u_in, double *u);
 int akref_bfield_bcs_inflow(const akmi_pack *p, const int *bcs, const double *b_in, double *bx1f,
                             double *bx2f, double *bx3f);
+int akref_hydro_bcs_dirs(const akmi_pack *p, int nvar, const int *bcs, int dirs, const double *u_in, double *u);
+int akref_bfield_bcs_dirs(const akmi_pack *p, const int *bcs, int dirs, const double *b_in, double *bx1f, double *bx2f,
+                          double *bx3f);
 /* SMR/AMR operators between a MeshBlock and its coarse buffer (no mesh tree behind them yet) */
 int akref_restrict_cc(const akmi_pack *p, int nvar, const double *u, double *cu);
 int akref_rk_update_oop(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *u0, double *u1,

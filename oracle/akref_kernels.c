@@ -2732,6 +2732,17 @@ int akref_bfield_bcs_inflow(const akmi_pack *p, const int *bcs, const double *b_
                             double *bx2f, double *bx3f) {
   return bfield_bcs_impl(p, bcs, b_in, bx1f, bx2f, bx3f);
 }
+/* twins of akmi_hydro_bcs_dirs / akmi_bfield_bcs_dirs (include/akmi.h): `dirs` only says which directions have a physical
+ * boundary at all; the reference applies all of them (a direction without one is a no-op) */
+int akref_hydro_bcs_dirs(const akmi_pack *p, int nvar, const int *bcs, int dirs, const double *u_in, double *u) {
+  (void)dirs;
+  return akref_hydro_bcs_inflow(p, nvar, bcs, u_in, u);
+}
+int akref_bfield_bcs_dirs(const akmi_pack *p, const int *bcs, int dirs, const double *b_in, double *bx1f, double *bx2f,
+                          double *bx3f) {
+  (void)dirs;
+  return akref_bfield_bcs_inflow(p, bcs, b_in, bx1f, bx2f, bx3f);
+}
 
 /* ---- SMR/AMR operators between a MeshBlock and its coarse buffer -------------
  * Coarse arrays have cnx = nx/2 active cells and the same number of ghost cells:
