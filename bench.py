@@ -363,7 +363,8 @@ def main():
     # The C++ host is the path north_star names ("host code stays C++ ... RCCL"): it is the headline whenever it
     # completed the K cycles and its (time, dt) agree with the Python host's at the same cycle -- a wrong or skipped
     # halo exchange cannot win the line by being faster.
-    #   N = 1: both hosts run the same W + K cycles in this process; the Python host is reported as other_host.
+    #   N = 1: both hosts run the same W + K cycles in this process, the C++ host first; the Python host is reported as
+    #          other_host.
     #   N > 1: the C++ host + RCCL is measured FIRST (one child process per rank, so that neither an abort nor a
     #          stall inside a transport that could only be exercised to self where it was built costs the bench);
     #          the Python host then runs its W warm-up cycles, and if the C++ host stood at the same (time, dt)
@@ -372,10 +373,8 @@ def main():
     chk = os.environ.get("AKMI_BENCH_NATIVE_CHECK", "1")
     cpp, why, cpp_ok = None, None, False
     if world == 1:
-        host = PythonHost(args, pin, rank, world)
-        host.warm()
-        py = host.timed()
-        host.close()
+        # the C++ host first, as at N > 1 (it is the headline; consecutive runs of one process drift by a few per cent
+        # with the state of the chip -- profiles/r04_numerics_ab.txt -- and the order should not depend on N)
         if chk != "0":
             try:
                 cpp = run_cpp_host(args, pin)
@@ -383,6 +382,10 @@ def main():
                 why = "C++ host failed: %r" % (e,)
         else:
             why = "C++ host switched off (AKMI_BENCH_NATIVE_CHECK=0)"
+        host = PythonHost(args, pin, rank, world)
+        host.warm()
+        py = host.timed()
+        host.close()
         if cpp is not None:
             if cpp.get("steps") != args.steps:
                 why = "C++ host completed %s of %d cycles" % (cpp.get("steps"), args.steps)
