@@ -516,19 +516,24 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
   constexpr bool STORE = MODE == 2;                                  // all flux components of every face go to memory
   int i, j, k, m, s0;
   bool lane_ok;
+  // lanes over the flattened (row, i).  The storing marches (MODE 2: refined meshes, small MeshBlocks) run them over the
+  // columns of the sweep only -- [il, iu] instead of the N1 of the row: with four ghost cells a 32^3 block has 40 columns
+  // of which 34 carry a face, and nothing couples the lanes of a march.  The other modes keep the N1 rows (the sign
+  // words of MfBits are addressed by them; at 256^3 it is 258 of 260).
+  const int row_w = STORE ? a.iu - a.il + 1 : g.N1, row_0 = STORE ? a.il : 0;
   if constexpr (DIR == 2) {
-    const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;   // rows [jl,ju] x N1
-    const int jj = (int)(p/g.N1);
-    i = (int)(p - (long)jj*g.N1);
+    const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;   // rows [jl,ju] x row_w
+    const int jj = (int)(p/row_w);
+    i = row_0 + (int)(p - (long)jj*row_w);
     j = a.jl + jj;
     m = blockIdx.z;
     s0 = a.kl + blockIdx.y*ml;
     k = s0;
     lane_ok = (j <= a.ju) && (i >= a.il) && (i <= a.iu);
   } else {
-    const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;   // planes [kl,ku] x N1
-    const int kk = (int)(p/g.N1);
-    i = (int)(p - (long)kk*g.N1);
+    const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;   // planes [kl,ku] x row_w
+    const int kk = (int)(p/row_w);
+    i = row_0 + (int)(p - (long)kk*row_w);
     k = a.kl + kk;
     m = blockIdx.z;
     s0 = a.jl + blockIdx.y*ml;
@@ -2054,7 +2059,7 @@ static int launch_sweep_update(const Geo &g, const Scheme &sc, const SweepArgs &
     dim3 grid, block(SX, SY);
     int ml;
     if (DIR == 2) {
-      long np = (long)(a.ju - a.jl + 1)*g.N1;          // flattened rows
+      long np = (long)(a.ju - a.jl + 1)*(MODE == 2 ? a.iu - a.il + 1 : g.N1);          // flattened rows (sweep_update_body)
       const unsigned nb = (unsigned)((np + SX*SY - 1)/(SX*SY));
       const int nc = a.ku - a.kl > 0 ? a.ku - a.kl : 1;
       static const int ml_env = getenv("AKMI_ML3") ? atoi(getenv("AKMI_ML3")) : 0;        // experiments
@@ -2064,7 +2069,7 @@ static int launch_sweep_update(const Geo &g, const Scheme &sc, const SweepArgs &
       ml = ml_env > 0 ? ml_env : march_len(nb, nc, g.nmb, ML, res3);
       grid = dim3(nb, cdiv(nc, ml), g.nmb);
     } else {
-      long np = (long)(a.ku - a.kl + 1)*g.N1;          // flattened (k,i)
+      long np = (long)(a.ku - a.kl + 1)*(MODE == 2 ? a.iu - a.il + 1 : g.N1);          // flattened (k,i)
       const unsigned nb = (unsigned)((np + SX*SY - 1)/(SX*SY));
       const int nc = a.ju - a.jl > 0 ? a.ju - a.jl : 1;
       ml = march_len(nb, nc, g.nmb, ML, (sc.recon >= AKMI_RECON_PPM4) ? 2 : AKMI_X2_WAVES);
