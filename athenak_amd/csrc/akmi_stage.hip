@@ -146,10 +146,13 @@ constexpr bool x1_share() { return DIR == 0 && RECON >= 1 && AKMI_X1_SHARE; }
 template <int RECON, bool MHD, bool ECC, int RS>
 __device__ __forceinline__ void sweep_x1_shared(const Geo &g, const FaceEos &eos, const SweepArgs &a,
                                                 int nk) {
+  // lanes over the flattened (row, column) with the columns a row needs: cells il-1 .. iu (the first one only provides
+  // the left state of face il) -- not the N1 of the row: 34 of the 40 columns of a 32^3 MeshBlock with four ghost cells
   const long p = ((long)blockIdx.x*SY + threadIdx.y)*(SX - 1) + (long)threadIdx.x - 1;
   const long pc = p < 0 ? 0 : p;
-  const int jj = (int)(pc/g.N1);
-  const int i = (int)(pc - (long)jj*g.N1);
+  const int row_w = a.iu - a.il + 2;
+  const int jj = (int)(pc/row_w);
+  const int i = a.il - 1 + (int)(pc - (long)jj*row_w);
   const int j = a.jl + jj;
   const int m = blockIdx.z/nk;
   const int k = a.kl + (blockIdx.z - m*nk);
@@ -161,8 +164,7 @@ __device__ __forceinline__ void sweep_x1_shared(const Geo &g, const FaceEos &eos
   // addresses = wave-uniform base (block m, variable n: scalar unit) + ONE 32-bit byte offset per lane
   // (global_load v, v_off, s[base]): no 64-bit integer multiplies on the vector unit.  A block-variable
   // is below 4 GB (checked at launch).
-  const unsigned krow = (unsigned)k*(unsigned)g.N2 + (unsigned)a.jl;           // uniform
-  const unsigned oc = (krow*(unsigned)g.N1 + (unsigned)pc)*8u;                  // cell (k,j,i)
+  const unsigned oc = (((unsigned)k*(unsigned)g.N2 + (unsigned)j)*(unsigned)g.N1 + (unsigned)i)*8u;           // cell (k,j,i)
   const unsigned of = (((unsigned)k*(unsigned)a.f2 + (unsigned)j)*(unsigned)a.f1 + (unsigned)i)*8u;   // face (k,j,i)
   const double *wm = a.w0 + (size_t)m*g.nvar*cs;
   const double *bm = MHD ? a.bcc0 + (size_t)m*3*cs : nullptr;
@@ -2029,11 +2031,13 @@ static size_t extra_lds(int which) {
 template <int DIR, bool MHD, bool ECC>
 static int launch_sweep(const Geo &g, const Scheme &sc, const SweepArgs &a, hipStream_t st) {
   int nk = a.ku - a.kl + 1;
-  long np = (long)(a.ju - a.jl + 1)*g.N1;
   dim3 block(SX, SY);
   int rc = dispatch_scheme_eos<MHD>(sc, [&](auto R, auto S) {
-    // faces per wave: 63 when the lanes share their slopes (lane 0 of a wave only provides)
-    const long per_wg = (long)(x1_share<DIR, decltype(R)::value>() ? SX - 1 : SX)*SY;
+    // faces per wave: 63 when the lanes share their slopes (lane 0 of a wave only provides); those kernels run over
+    // the columns il-1 .. iu of a row (sweep_x1_shared), the plain one over its N1
+    constexpr bool share = x1_share<DIR, decltype(R)::value>();
+    const long np = (long)(a.ju - a.jl + 1)*(share ? a.iu - a.il + 2 : g.N1);
+    const long per_wg = (long)(share ? SX - 1 : SX)*SY;
     dim3 grid((unsigned)((np + 1 + per_wg - 1)/per_wg), 1, nk*g.nmb);
     k_sweep<DIR, decltype(R)::value, MHD, ECC, decltype(S)::value><<<grid, block, extra_lds(0), st>>>(
         g, sc.eos, a, nk);
