@@ -251,15 +251,18 @@ k_sweep(Geo g, FaceEos eos, SweepArgs a, int nk) {
   }
   // lanes run over the flattened rows [jl,ju] x [0,N1): contiguous in memory, and the few
   // ghost columns outside [il,iu] cost 2-4 idle lanes per 260 instead of a mostly empty wave
+  // lanes over the flattened (row, column) with the columns of the sweep only (ECC: one more on the low side), not the
+  // N1 of a row: a thread-per-face sweep has no coupling between lanes (18 of 24 columns at 16^3 with four ghost cells)
   const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;
-  const int jj = (int)(p/g.N1);
-  const int i = (int)(p - (long)jj*g.N1);
+  const int row_0 = a.il - (ECC ? 1 : 0), row_w = a.iu - row_0 + 1;
+  const int jj = (int)(p/row_w);
+  const int i = row_0 + (int)(p - (long)jj*row_w);
   const int j = a.jl + jj;
   const int m = blockIdx.z/nk;
   const int k = a.kl + (blockIdx.z - m*nk);
   if (j > a.ju || i < a.il - (ECC ? 1 : 0) || i > a.iu) return;
   const size_t cs = (size_t)g.N3*g.N2*g.N1;
-  const unsigned oc = (((unsigned)k*(unsigned)g.N2 + (unsigned)a.jl)*(unsigned)g.N1 + (unsigned)p)*8u;   // cell (k,j,i)
+  const unsigned oc = (((unsigned)k*(unsigned)g.N2 + (unsigned)j)*(unsigned)g.N1 + (unsigned)i)*8u;   // cell (k,j,i)
   if constexpr (ECC) {
     const double *wm = a.w0 + (size_t)m*g.nvar*cs, *bm = a.bcc0 + (size_t)m*3*cs;
     const double vx = ldu(wm + cs, oc), vy = ldu(wm + 2*cs, oc), vz = ldu(wm + 3*cs, oc);
@@ -2034,9 +2037,9 @@ static int launch_sweep(const Geo &g, const Scheme &sc, const SweepArgs &a, hipS
   dim3 block(SX, SY);
   int rc = dispatch_scheme_eos<MHD>(sc, [&](auto R, auto S) {
     // faces per wave: 63 when the lanes share their slopes (lane 0 of a wave only provides); those kernels run over
-    // the columns il-1 .. iu of a row (sweep_x1_shared), the plain one over its N1
+    // the columns il-1 .. iu of a row (sweep_x1_shared), the plain one over il (- 1 with ECC) .. iu
     constexpr bool share = x1_share<DIR, decltype(R)::value>();
-    const long np = (long)(a.ju - a.jl + 1)*(share ? a.iu - a.il + 2 : g.N1);
+    const long np = (long)(a.ju - a.jl + 1)*(share ? a.iu - a.il + 2 : a.iu - a.il + 1 + (ECC ? 1 : 0));
     const long per_wg = (long)(share ? SX - 1 : SX)*SY;
     dim3 grid((unsigned)((np + 1 + per_wg - 1)/per_wg), 1, nk*g.nmb);
     k_sweep<DIR, decltype(R)::value, MHD, ECC, decltype(S)::value><<<grid, block, extra_lds(0), st>>>(
