@@ -329,6 +329,9 @@ AKMI_DEV GasSide gas_side(double gamma, double igm1, double d, double u, double 
 //   cl, cr (sound speeds)     :46-47        pmid, shock factors gl, gr   :56-62
 //   sl, sr (outer speeds)     :65-66        bp, bm (signed bounds)       :70-71
 //   contact speed sc, pc      :82-87        flux weights wl, wr, wp      :100-108
+// FM: the four square roots through sqrt_x (same bits, ten instructions instead of eighteen behind a wave-uniform
+// range test); a flag per call site, as for hlld().
+template <bool FM = false>
 AKMI_DEV void hllc(double gamma, double dl, double ul, double vl, double wl, double el, double dr, double ur,
                    double vr, double wr, double er, double &f_d, double &f_mx, double &f_my, double &f_mz,
                    double &f_e) {
@@ -336,12 +339,12 @@ AKMI_DEV void hllc(double gamma, double dl, double ul, double vl, double wl, dou
   const double igm1 = 1.0/gm1;
   const double shock_k = (gamma + 1.0)/(2.0*gamma);
   const GasSide L = gas_side(gamma, igm1, dl, ul, vl, wl, el), R = gas_side(gamma, igm1, dr, ur, vr, wr, er);
-  const double cl = sqrt(gamma*L.p/dl), cr = sqrt(gamma*R.p/dr);
+  const double cl = sqrt_x<FM>(gamma*L.p/dl), cr = sqrt_x<FM>(gamma*R.p/dr);
   // two-rarefaction middle pressure, then the shock corrections of the outer speeds
   const double zbar = 0.25*(dl + dr)*(cl + cr);
   const double pmid = 0.5*(L.p + R.p + (ul - ur)*zbar);
-  const double gl = (pmid <= L.p) ? 1.0 : sqrt(1.0 + shock_k*((pmid/L.p) - 1.0));
-  const double gr = (pmid <= R.p) ? 1.0 : sqrt(1.0 + shock_k*((pmid/R.p) - 1.0));
+  const double gl = (pmid <= L.p) ? 1.0 : sqrt_x<FM>(1.0 + shock_k*((pmid/L.p) - 1.0));
+  const double gr = (pmid <= R.p) ? 1.0 : sqrt_x<FM>(1.0 + shock_k*((pmid/R.p) - 1.0));
   const double sl = ul - cl*gl, sr = ur + cr*gr;
   const double bp = sr > 0.0 ? sr : 1.0e-20;        // signed bounds of the fan
   const double bm = sl < 0.0 ? sl : -1.0e-20;
@@ -539,7 +542,7 @@ AKMI_DEV void advect_hyd(double dl, double ul, double vl, double wl, double el, 
 }
 
 // Hydro_RSolver selection at compile time: RS = AKMI_RS_LLF 0, HLLE 1, HLLC 2, ROE 4, ADVECT 5
-template <int RS>
+template <int RS, bool FM = false>
 AKMI_DEV void riemann_hyd(double gamma, double dl, double ul, double vl, double wl, double el, double dr,
                           double ur, double vr, double wr, double er, double &f_d, double &f_mx, double &f_my,
                           double &f_mz, double &f_e) {
@@ -547,7 +550,7 @@ AKMI_DEV void riemann_hyd(double gamma, double dl, double ul, double vl, double 
   else if constexpr (RS == 1) hlle_hyd(gamma, dl, ul, vl, wl, el, dr, ur, vr, wr, er, f_d, f_mx, f_my, f_mz, f_e);
   else if constexpr (RS == 4) roe_hyd(gamma, dl, ul, vl, wl, el, dr, ur, vr, wr, er, f_d, f_mx, f_my, f_mz, f_e);
   else if constexpr (RS == 5) advect_hyd(dl, ul, vl, wl, el, dr, ur, vr, wr, er, f_d, f_mx, f_my, f_mz, f_e);
-  else hllc(gamma, dl, ul, vl, wl, el, dr, ur, vr, wr, er, f_d, f_mx, f_my, f_mz, f_e);
+  else hllc<FM>(gamma, dl, ul, vl, wl, el, dr, ur, vr, wr, er, f_d, f_mx, f_my, f_mz, f_e);
 }
 
 // =======================================================================================
@@ -1142,7 +1145,7 @@ AKMI_DEV Cons1D riemann_mhd_e(const FaceEos &eos, double dl, double ul, double v
   if constexpr (RS >= 10) return riemann_mhd_iso<RS - 10>(eos, dl, ul, vl, wl, byl, bzl, dr, ur, vr, wr, byr, bzr, bn);
   else return riemann_mhd<RS, EO, FM>(eos.gamma, dl, ul, vl, wl, el, byl, bzl, dr, ur, vr, wr, er, byr, bzr, bn);
 }
-template <int RS>
+template <int RS, bool FM = false>
 AKMI_DEV void riemann_hyd_e(const FaceEos &eos, double dl, double ul, double vl, double wl, double el, double dr,
                             double ur, double vr, double wr, double er, double &f_d, double &f_mx, double &f_my,
                             double &f_mz, double &f_e) {
@@ -1150,7 +1153,7 @@ AKMI_DEV void riemann_hyd_e(const FaceEos &eos, double dl, double ul, double vl,
     riemann_hyd_iso<RS - 10>(eos.iso_cs, dl, ul, vl, wl, dr, ur, vr, wr, f_d, f_mx, f_my, f_mz);
     f_e = 0.0;
   } else {
-    riemann_hyd<RS>(eos.gamma, dl, ul, vl, wl, el, dr, ur, vr, wr, er, f_d, f_mx, f_my, f_mz, f_e);
+    riemann_hyd<RS, FM>(eos.gamma, dl, ul, vl, wl, el, dr, ur, vr, wr, er, f_d, f_mx, f_my, f_mz, f_e);
   }
 }
 

@@ -1758,32 +1758,42 @@ k_c2p_newdt(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ 
 // Hydro, 3-D, DC/PLM: the three sweeps and the RK update of a stage in ONE kernel.
 // A workgroup owns a tile of (tw-1) x (th-1) cell columns (lanes flattened over the tw x th
 // positions; the last column / row of positions only provides the face on its low side) and
-// marches along k.  Per plane k:
-//   * the plane of primitives (with a 2-low / 1-high halo in i and j) goes to LDS; the thread's
-//     own cells k-1, k, k+1 and the pending left state of the next x3 face stay in registers;
-//   * every position computes the flux of its low x1 face and of its low x2 face from LDS and the
-//     x3 face below cell k from registers; F1 and F2 are exchanged through LDS;
-//   * cell k-1 is finished: divf = dF1/dx1; divf += dF2/dx2; divf += dF3/dx3 (hydro_update.cpp:55-80
-//     order, the same rounding sequence as the three-kernel path).
-// HBM traffic per cell: w0 once (+halo, mostly L2 hits), u0 (+u1) once -- no flux or partial
-// divergence arrays.  The CT-extended ranges of MHD do not apply (faces is..ie+1 only).
+// marches along k.  Per step k (two barriers):
+//   (A) plane k-1 of the primitives sits in LDS (2-low / 1-high halo in i and j).  Every cell of it is
+//       reconstructed ONCE per in-plane direction: its position forms the limited slope from the two LDS
+//       neighbours, keeps the value at the cell's low face (right state of its own face) and hands the value at
+//       the high face to the position above through LDS (that position's left state).  The cells just outside
+//       the tile's low sides (one column, one row) are reconstructed by the first th + tw threads.
+//   (B) every position solves its low x1 and x2 face; the flux replaces the left state in the same LDS slot.
+//       The x3 face below cell k comes from registers (own cells k-1, k, k+1, pending left state).  Plane k
+//       replaces plane k-1 in LDS.
+//   (C) cell k-1 is finished: divf = dF1/dx1; divf += dF2/dx2; divf += dF3/dx3 (hydro_update.cpp:55-80
+//       order, the same rounding sequence as the three-kernel path).
+// HBM traffic per cell: w0 once (+halo, L2 hits: neighbouring tiles share an XCD, xcd_order), u0 (+u1) once --
+// no flux or partial divergence arrays.  The CT-extended ranges of MHD do not apply (faces is..ie+1 only).
 struct HydTile { int tw, th, n1, n2, threads; };
 constexpr int HS_THREADS = 512;
 #ifndef AKMI_HS_WAVES
-#define AKMI_HS_WAVES 2                 // waves per SIMD the register allocation aims at (3 and 4 spill)
+#define AKMI_HS_WAVES 3                 // waves per SIMD the register allocation aims at (168 VGPRs, 28 B of scratch: three
+                                        // doubles of the x3 march saved and restored once per step; 2: 178 VGPRs, 4: spills 172 B)
 #endif
 
+// LDS of a workgroup, in doubles: the plane with its halo and two face-shaped arrays per direction-pair
+constexpr int HS_ES = 5;                   // doubles per LDS entry (a padded 48-byte stride measured slower: profiles/r05_hydro_ab.txt)
+static size_t hyd_lds_doubles(int tw, int th) { return HS_ES*((size_t)(tw + 3)*(th + 3) + 2*(size_t)tw*th); }
+
 static HydTile hyd_tile(int c1, int c2) {
-  // The kernel is issue-bound (1 700 VALU instructions per cell, two waves per SIMD), so what a shape costs is the lanes
-  // it launches per owned column, not the length of its rows: cost = lanes launched (tiles x padded workgroup)
+  // The kernel is bound by the issue of dependent fp64 chains (1 330 VALU instructions per cell, three waves per SIMD), so
+  // what a shape costs is the lanes it launches per owned column, not the length of its rows:
+  //   cost = lanes launched (tiles x padded workgroup)
   //   x (1 + 0.3 x plane-with-halo / owners)    the LDS plane every step loads: (tw+3)(th+3) entries for (tw-1)(th-1) owners
   //   x (1 + 4/tw)                              short rows (tw = 9: +15 % measured)
-  //   / occupancy                               workgroups per CU by LDS x waves per workgroup, against the 8 waves the
-  //                                             220 VGPRs allow (a 192-thread tile with 57 KB: 6 waves, 38 x 5 was that)
-  // fitted to the scan in profiles/r04_hydro_tiles.txt (256^3: 38 x 5 1400 us, 23 x 11 1099, 28 x 9 1089; 128^3: 44 x 5
-  // 173 us, 23 x 11 158); the round-1 rule (ct_tile's: row length first) chose 38 x 5 / 44 x 5.
-  static const int maxt = getenv("AKMI_HS_MAXT") ? atoi(getenv("AKMI_HS_MAXT")) : 256;   // two workgroups per CU
-  static const int maxlds = getenv("AKMI_HS_LDS") ? atoi(getenv("AKMI_HS_LDS")) : 80*1024;       // two workgroups per CU
+  //   / occupancy                               workgroups per CU by LDS x waves per workgroup, against the 12 waves the
+  //                                             168 VGPRs allow
+  // fitted to the scans in profiles/r04_hydro_tiles.txt and r05_hydro_ab.txt (256^3, this kernel: 23 x 11 960 us, 28 x 9 964,
+  // 18 x 14 990, 21 x 12 990; 384-thread tiles 27 x 14 / 24 x 16: 1 380-1 480 -- six-wave workgroups leave wave slots idle).
+  static const int maxt = getenv("AKMI_HS_MAXT") ? atoi(getenv("AKMI_HS_MAXT")) : 256;   // three four-wave workgroups per CU
+  static const int maxlds = getenv("AKMI_HS_LDS") ? atoi(getenv("AKMI_HS_LDS")) : 53*1024;
   static int f_tw = -1, f_th = 0;                        // AKMI_HS_TILE=tw,th pins the shape (experiments)
   if (f_tw < 0) {
     const char *e = getenv("AKMI_HS_TILE");                 // "tw,th" or "twxth"
@@ -1792,7 +1802,7 @@ static HydTile hyd_tile(int c1, int c2) {
     if (f_tw < 4 || f_th < 3 || f_tw*f_th > HS_THREADS) f_tw = 0;
   }
   if (f_tw > 0 && 3*(f_tw + 3) + 3*f_th <= f_tw*f_th &&
-      2*(5*(size_t)(f_tw + 3)*(f_th + 3) + 10*(size_t)f_tw*f_th)*sizeof(double) <= 150*1024)
+      hyd_lds_doubles(f_tw, f_th)*sizeof(double) <= 150*1024)
     return HydTile{f_tw, f_th, (c1 + f_tw - 2)/(f_tw - 1), (c2 + f_th - 2)/(f_th - 1), (f_tw*f_th + 63)/64*64};
   HydTile best{0, 0, 0, 0, 0};
   double best_cost = -1.0;
@@ -1803,12 +1813,12 @@ static HydTile hyd_tile(int c1, int c2) {
     for (int th = 3; th <= 40; ++th) {
       if (tw*th > maxt) break;
       if (3*(tw + 3) + 3*th > tw*th) continue;         // one halo entry per thread at most
-      const size_t lds = 2*(5*(size_t)(tw + 3)*(th + 3) + 10*(size_t)tw*th)*sizeof(double);
+      const size_t lds = hyd_lds_doubles(tw, th)*sizeof(double);
       if (lds > (size_t)maxlds) continue;
       const int n2 = (c2 + th - 2)/(th - 1);
       const int threads = (tw*th + 63)/64*64;
       const int waves_cu = (int)(160*1024/lds)*(threads/64);
-      const double occ = (waves_cu < 8 ? waves_cu : 8)/8.0;
+      const double occ = (waves_cu < 12 ? waves_cu : 12)/12.0;
       const double halo = (double)(tw + 3)*(th + 3)/((double)(tw - 1)*(th - 1));
       const double cost = (double)n1*n2*threads*(1.0 + 0.3*halo)*(1.0 + 4.0/tw)/occ;
       if (best_cost < 0 || cost < best_cost) { best = HydTile{tw, th, n1, n2, threads}; best_cost = cost; }
@@ -1819,6 +1829,15 @@ static HydTile hyd_tile(int c1, int c2) {
 
 // MASS: passive scalars ride along -- leave the three mass fluxes behind for k_scalar_update
 struct Mass3 { double *m1, *m2, *m3; };
+// Workgroup -> tile order.  Workgroup b of a launch runs on XCD b % 8 (observed placement; nothing below depends on
+// it for correctness), and each XCD has its own L2.  A tile kernel whose neighbouring tiles re-read each other's edge
+// rows wants neighbours on the SAME XCD at about the same time: XCD x takes the x-th contiguous eighth of the tile
+// list, in list order.  The map is a bijection of [0, n) for every n.
+__device__ __forceinline__ unsigned xcd_order(unsigned b, unsigned n) {
+  const unsigned xcd = b & 7u, slot = b >> 3, q = n >> 3, rem = n & 7u;
+  return (xcd < rem ? xcd*(q + 1u) : rem*(q + 1u) + (xcd - rem)*q) + slot;
+}
+
 template <int RECON, int RS, bool MASS = false>
 __global__ void __launch_bounds__(HS_THREADS, AKMI_HS_WAVES)
 k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, int kA, int kB,
@@ -1828,26 +1847,36 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
 #define ISOSKIP if (ISO && n == 4) continue
   extern __shared__ double hs_lds[];
   const int pw = tw + 3, ph = th + 3;        // plane with halo: cols i0-2..i0+tw, rows j0-2..j0+th
-  const int swn = 5*ph*pw, sfn = 5*th*tw;
-  // two buffers of {plane, low x1-face fluxes, low x2-face fluxes}: step k reads plane k-1 from one
-  // and stores plane k into the other, so ONE barrier per step orders everything
-#define SW(b, n, y, x) hs_lds[(b)*(swn + 2*sfn) + ((n)*ph + (y))*pw + (x)]
-#define SF1(b, n, y, x) hs_lds[(b)*(swn + 2*sfn) + swn + ((n)*th + (y))*tw + (x)]
-#define SF2(b, n, y, x) hs_lds[(b)*(swn + 2*sfn) + swn + sfn + ((n)*th + (y))*tw + (x)]
+  const int qn = ph*pw, fn = th*tw;
+  constexpr int ES = HS_ES;                 // doubles per LDS entry (five used)
+  // SQ: primitives of the plane being worked on.  SX1/SX2 (one entry per position, x1 / x2 direction) hold FIRST the
+  // left state of the position's low face (written by the cell on the low side: every cell is reconstructed once per
+  // direction), THEN, after the solve, the flux of that face (written by the position itself, read by its low-side
+  // neighbour for the flux difference).  Entry (r,t) changes hands only between threads (r,t-1) / (r-1,t) and (r,t)
+  // across a barrier, so one array serves both and nothing is double-buffered.
+  // Layout: position-major, the five variables of an entry adjacent (stride 5 doubles: conflict-free for 64-bit
+  // accesses), so that one address register per thread and array serves every variable and the x-neighbours through
+  // the instruction's immediate offset; the y-neighbours cost one more register per array.
   const int tid = threadIdx.x;
   const int r = tid/tw, t = tid - r*tw;
   const bool in_tile = r < th;
-  const int i0 = g.is + blockIdx.x*(tw - 1), j0 = g.js + blockIdx.y*(th - 1);
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {                       // tiles of a k-chunk of a block side by side on one XCD (x fastest, then y, then chunk / block)
+    const unsigned lin = xcd_order(bx + gridDim.x*(by + gridDim.y*bz), gridDim.x*gridDim.y*gridDim.z);
+    const unsigned row = lin/gridDim.x;
+    bx = lin - row*gridDim.x; bz = row/gridDim.y; by = row - bz*gridDim.y;
+  }
+  const int i0 = g.is + (int)bx*(tw - 1), j0 = g.js + (int)by*(th - 1);
   const int i = i0 + t, j = j0 + r;
-  const int m = blockIdx.z/nchunk;
-  const int ch = blockIdx.z - m*nchunk;
+  const int m = (int)bz/nchunk;
+  const int ch = (int)bz - m*nchunk;
   const int k0 = kA + ch*ckl;
   const int k1 = (k0 + ckl - 1 < kB) ? k0 + ckl - 1 : kB;
   const bool cell_ok = in_tile && i < g.N1 && j < g.N2;                // the column exists in memory
   const bool own = in_tile && t < tw - 1 && r < th - 1 && i <= g.ie && j <= g.je;
   const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
   // power-of-two cell sizes: x/dx == ldexp(x, n) bit for bit (pow2_shift); beta*dt once, in scalar registers
-  const bool p2 = AKMI_POW2DX && is_pow2(dx1) && is_pow2(dx2) && is_pow2(dx3);
+  const bool p2 = AKMI_POW2DX && is_pow2(dx1) && is_pow2(dx2) && is_pow2(dx3);      // wave-uniform
   const int n1 = pow2_shift(dx1), n2 = pow2_shift(dx2), n3 = pow2_shift(dx3);
   const double bdt = to_sgpr(beta_dt_of(u.beta_dt, u.dtp));
   const size_t cs = (size_t)g.N3*g.N2*g.N1, ps = (size_t)g.N2*g.N1;
@@ -1859,11 +1888,23 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
     if (tid < nh) {
       if (tid < 3*pw) { const int q = tid/pw; hy = q < 2 ? q : ph - 1; hx = tid - q*pw; }
       else { const int q = tid - 3*pw; const int rr = q/3, cc = q - rr*3; hy = 2 + rr; hx = cc < 2 ? cc : pw - 1; }
-      if (j0 - 2 + hy >= g.N2 || i0 - 2 + hx >= g.N1) hy = -1;
     }
   }
+  const bool hload = hy >= 0 && j0 - 2 + hy < g.N2 && i0 - 2 + hx < g.N1;      // the halo cell exists in memory
+  // the cells just outside the tile's low sides have no position of their own: column 1 of the plane (rows of the
+  // tile) and row 1 (columns of the tile) are reconstructed by the first th + tw threads, one cell each, in the one
+  // direction in which a face of the tile needs them
+  int ha = -1, hb = 0, hc = 0, hd = 0;        // LDS offsets (per variable plane: + n*qn / + n*fn) of below, here, above, destination
+  if (tid < th) { ha = (tid + 2)*pw*ES; hb = ha + ES; hc = ha + 2*ES; hd = ES*qn + tid*tw*ES; }
+  else if (tid < th + tw) { const int c = tid - th; ha = (c + 2)*ES; hb = ha + ES*pw; hc = hb + ES*pw; hd = ES*qn + ES*fn + c*ES; }
+  // own entries: cell (r+2, t+2) of the plane, position (r, t) of the two face arrays
+  const int qo = in_tile ? ((r + 2)*pw + t + 2)*ES : 0, qy = ES*pw;
+  const int xo = in_tile ? ES*qn + (r*tw + t)*ES : ES*qn, x2o = xo + ES*fn, xy = ES*tw;
+  const int hq = hy >= 0 ? (hy*pw + hx)*ES : 0;
+#define SX1o(n) hs_lds[xo + (n)]
+#define SX2o(n) hs_lds[x2o + (n)]
   // (scalar base of the plane + 32-bit byte offset of the lane within it)
-  const unsigned hcol = hy >= 0 ? ((unsigned)(j0 - 2 + hy)*(unsigned)g.N1 + (unsigned)(i0 - 2 + hx))*8u : 0u;
+  const unsigned hcol = hload ? ((unsigned)(j0 - 2 + hy)*(unsigned)g.N1 + (unsigned)(i0 - 2 + hx))*8u : 0u;
   const unsigned col = cell_ok ? ((unsigned)j*(unsigned)g.N1 + (unsigned)i)*8u : 0u;
   const size_t mb = (size_t)m*g.nvar*cs;
   double W0[5], W1[5], PL[5], F3p[5], hv[5];
@@ -1878,15 +1919,14 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
       double dummy;
       plm(qa, W0[n], W1[n], PL[n], dummy);
     } else {
-      PL[n] = 0.0;
+      PL[n] = W0[n];
     }
     F3p[n] = 0.0;
-    hv[n] = hy >= 0 ? ldu(wb + n*cs + (size_t)k0*ps, hcol) : 1.0;
+    hv[n] = hload ? ldu(wb + n*cs + (size_t)k0*ps, hcol) : 1.0;
   }
   // step k: x3 face k (below cell k) from registers; for k > k0 also the x1/x2 faces of plane k-1
-  // (in LDS since the previous step), which finishes cell k-1; plane k goes to the other buffer
-  int b = 0;
-  for (int k = k0; k <= k1 + 1; ++k, b ^= 1) {
+  // (in LDS since the previous step), which finishes cell k-1; then plane k replaces it
+  for (int k = k0; k <= k1 + 1; ++k) {
     const bool plane = k > k0;                        // workgroup-uniform
     double wp[5];
 #pragma unroll
@@ -1901,53 +1941,69 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
         pu1[n] = u.copy_u1 ? 0.0 : ldu(u.u1 + c + n*cs, col);
       }
     }
-    if (plane && in_tile) {
-      {  // low x1 face of this position: cells i-2..i+1 of row j
-        double L[5] = {0, 0, 0, 0, 0}, R[5] = {0, 0, 0, 0, 0};
+    double f1[5] = {0, 0, 0, 0, 0}, f2[5] = {0, 0, 0, 0, 0};      // this position's own in-plane fluxes
+    if (plane) {
+      // (A) every cell of plane k-1 once per direction: the value at its upper face goes to the position above (its
+      // left state), the value at its lower face stays here (the right state of this position's own low face)
+      double R1[5] = {0, 0, 0, 0, 0}, R2[5] = {0, 0, 0, 0, 0};
+      if (in_tile) {
+        double U1[5] = {0, 0, 0, 0, 0}, U2[5] = {0, 0, 0, 0, 0};
 #pragma unroll
         for (int n = 0; n < 5; ++n) {
       ISOSKIP;
-          const double qm2 = SW(b, n, r + 2, t), qm1 = SW(b, n, r + 2, t + 1),
-                       q0 = SW(b, n, r + 2, t + 2), qp1 = SW(b, n, r + 2, t + 3);
           if constexpr (RECON == 1) {
-            double dummy;
-            plm(qm2, qm1, q0, L[n], dummy);
-            plm(qm1, q0, qp1, dummy, R[n]);
+            plm(hs_lds[qo - ES + n], W0[n], hs_lds[qo + ES + n], U1[n], R1[n]);
+            plm(hs_lds[qo - qy + n], W0[n], hs_lds[qo + qy + n], U2[n], R2[n]);
           } else {
-            L[n] = qm1; R[n] = q0;
+            R1[n] = W0[n]; R2[n] = W0[n]; U1[n] = W0[n]; U2[n] = W0[n];
           }
         }
-        double fd, fx, fy, fz, fe;
-        riemann_hyd_e<RS>(eos, L[0], L[1], L[2], L[3], L[4], R[0], R[1], R[2], R[3], R[4], fd, fx,
-                        fy, fz, fe);
-        SF1(b, 0, r, t) = fd; SF1(b, 1, r, t) = fx; SF1(b, 2, r, t) = fy; SF1(b, 3, r, t) = fz;
-        SF1(b, 4, r, t) = fe;
-        if constexpr (MASS) {
-          if (i <= g.ie + 1 && j <= g.je) ms.m1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k - 1, j, i)] = fd;
+        if (t + 1 < tw) {
+#pragma unroll
+          for (int n = 0; n < 5; ++n) { ISOSKIP; hs_lds[xo + ES + n] = U1[n]; }
+        }
+        if (r + 1 < th) {
+#pragma unroll
+          for (int n = 0; n < 5; ++n) { ISOSKIP; hs_lds[x2o + xy + n] = U2[n]; }
         }
       }
-      {  // low x2 face: cells j-2..j+1 of column i; sweep-aligned order (d, vy, vz, vx, e)
-        double L[5] = {0, 0, 0, 0, 0}, R[5] = {0, 0, 0, 0, 0};
+      if (ha >= 0) {
 #pragma unroll
         for (int n = 0; n < 5; ++n) {
       ISOSKIP;
-          const double qm2 = SW(b, n, r, t + 2), qm1 = SW(b, n, r + 1, t + 2),
-                       q0 = SW(b, n, r + 2, t + 2), qp1 = SW(b, n, r + 3, t + 2);
           if constexpr (RECON == 1) {
-            double dummy;
-            plm(qm2, qm1, q0, L[n], dummy);
-            plm(qm1, q0, qp1, dummy, R[n]);
+            double up, dummy;
+            plm(hs_lds[ha + n], hs_lds[hb + n], hs_lds[hc + n], up, dummy);
+            hs_lds[hd + n] = up;
           } else {
-            L[n] = qm1; R[n] = q0;
+            hs_lds[hd + n] = hs_lds[hb + n];
           }
         }
-        double fd, fx, fy, fz, fe;
-        riemann_hyd_e<RS>(eos, L[0], L[2], L[3], L[1], L[4], R[0], R[2], R[3], R[1], R[4], fd, fx,
-                        fy, fz, fe);
-        SF2(b, 0, r, t) = fd; SF2(b, 2, r, t) = fx; SF2(b, 3, r, t) = fy; SF2(b, 1, r, t) = fz;
-        SF2(b, 4, r, t) = fe;
-        if constexpr (MASS) {
-          if (i <= g.ie && j <= g.je + 1) ms.m2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, 0, k - 1, j, i)] = fd;
+      }
+      __syncthreads();
+      // (B) the two in-plane faces of this position; the flux takes the place of the left state
+      if (in_tile) {
+        {
+          double fd, fx, fy, fz, fe;
+          riemann_hyd_e<RS, true>(eos, SX1o(0), SX1o(1), SX1o(2), SX1o(3), ISO ? 0.0 : SX1o(4),
+                            R1[0], R1[1], R1[2], R1[3], R1[4], fd, fx, fy, fz, fe);
+          SX1o(0) = fd; SX1o(1) = fx; SX1o(2) = fy; SX1o(3) = fz;
+          if constexpr (!ISO) SX1o(4) = fe;
+          f1[0] = fd; f1[1] = fx; f1[2] = fy; f1[3] = fz; f1[4] = fe;
+          if constexpr (MASS) {
+            if (i <= g.ie + 1 && j <= g.je) ms.m1[ix5(g.nvar, g.N3, g.N2, g.N1 + 1, m, 0, k - 1, j, i)] = fd;
+          }
+        }
+        {  // sweep-aligned order (d, vy, vz, vx, e)
+          double fd, fx, fy, fz, fe;
+          riemann_hyd_e<RS, true>(eos, SX2o(0), SX2o(2), SX2o(3), SX2o(1), ISO ? 0.0 : SX2o(4),
+                            R2[0], R2[2], R2[3], R2[1], R2[4], fd, fx, fy, fz, fe);
+          SX2o(0) = fd; SX2o(2) = fx; SX2o(3) = fy; SX2o(1) = fz;
+          if constexpr (!ISO) SX2o(4) = fe;
+          f2[0] = fd; f2[2] = fx; f2[3] = fy; f2[1] = fz; f2[4] = fe;
+          if constexpr (MASS) {
+            if (i <= g.ie && j <= g.je + 1) ms.m2[ix5(g.nvar, g.N3, g.N2 + 1, g.N1, m, 0, k - 1, j, i)] = fd;
+          }
         }
       }
     }
@@ -1968,53 +2024,68 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
         }
       }
       double fd, fx, fy, fz, fe;
-      riemann_hyd_e<RS>(eos, L[0], L[3], L[1], L[2], L[4], R[0], R[3], R[1], R[2], R[4], fd, fx, fy,
+      riemann_hyd_e<RS, true>(eos, L[0], L[3], L[1], L[2], L[4], R[0], R[3], R[1], R[2], R[4], fd, fx, fy,
                       fz, fe);
       f3[0] = fd; f3[3] = fx; f3[1] = fy; f3[2] = fz; f3[4] = fe;
       if constexpr (MASS) {
         if (own) ms.m3[ix5(g.nvar, g.N3 + 1, g.N2, g.N1, m, 0, k, j, i)] = fd;
       }
     }
-    if (k <= k1) {                                     // plane k for the next step
+    if (k <= k1) {                                     // plane k for the next step (every reader of plane k-1 is past (A))
       if (in_tile) {
 #pragma unroll
-        for (int n = 0; n < 5; ++n) { ISOSKIP; SW(b ^ 1, n, r + 2, t + 2) = W1[n]; }
+        for (int n = 0; n < 5; ++n) { ISOSKIP; hs_lds[qo + n] = W1[n]; }
       }
       if (hy >= 0) {
 #pragma unroll
-        for (int n = 0; n < 5; ++n) { ISOSKIP; SW(b ^ 1, n, hy, hx) = hv[n]; }
-        if (k + 1 <= k1) {
+        for (int n = 0; n < 5; ++n) { ISOSKIP; hs_lds[hq + n] = hv[n]; }
+        if (hload && k + 1 <= k1) {
 #pragma unroll
           for (int n = 0; n < 5; ++n) { ISOSKIP; hv[n] = ldu(wb + n*cs + (size_t)(k + 1)*ps, hcol); }
         }
       }
     }
     __syncthreads();
-    if (plane && own) {                                // finish cell k-1
+    if (plane && own) {                                // (C) finish cell k-1
       const size_t c = mb + (size_t)(k - 1)*ps;
+      double divf[5];
+      if (p2) {                                        // one wave-uniform branch for the fifteen quotients
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+      ISOSKIP;
+          divf[n] = ldexp(hs_lds[xo + ES + n] - f1[n], n1);
+          divf[n] += ldexp(hs_lds[x2o + xy + n] - f2[n], n2);
+          divf[n] += ldexp(f3[n] - F3p[n], n3);
+        }
+      } else {
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+      ISOSKIP;
+          divf[n] = (hs_lds[xo + ES + n] - f1[n])/dx1;
+          divf[n] += (hs_lds[x2o + xy + n] - f2[n])/dx2;
+          divf[n] += (f3[n] - F3p[n])/dx3;
+        }
+      }
 #pragma unroll
       for (int n = 0; n < 5; ++n) {
       ISOSKIP;
-        const double d1 = SF1(b, n, r, t + 1) - SF1(b, n, r, t), d2 = SF2(b, n, r + 1, t) - SF2(b, n, r, t),
-                     d3 = f3[n] - F3p[n];
-        double divf = p2 ? ldexp(d1, n1) : d1/dx1;
-        divf += p2 ? ldexp(d2, n2) : d2/dx2;
-        divf += p2 ? ldexp(d3, n3) : d3/dx3;
         const double u0v = pu0[n];
         const double u1v = u.copy_u1 ? u0v : pu1[n];
         rk_store_u(u.u0 + c + n*cs, u.u1 + c + n*cs, u.copy_u1, col, u0v,
-                   u.gam0*u0v + u.gam1*u1v - bdt*divf);
+                   u.gam0*u0v + u.gam1*u1v - bdt*divf[n]);
       }
     }
 #pragma unroll
     for (int n = 0; n < 5; ++n) {
       ISOSKIP; F3p[n] = f3[n]; W0[n] = W1[n]; W1[n] = wp[n]; }
   }
-#undef SW
-#undef SF1
-#undef SF2
+#undef SQ
+#undef SX1o
+#undef SX2o
 #undef ISOSKIP
 }
+
+
 
 __global__ void k_init_dt3(double *dt3) {
   if (threadIdx.x < 3) dt3[threadIdx.x] = (double)FLT_MAX;
@@ -2337,7 +2408,7 @@ static int launch_hydro_stage3d(const Geo &g, const Scheme &sc, const double *w0
   if (tl.tw == 0) { set_error("hydro_stage3d: no tile shape"); return AKMI_FAIL; }
   const int ckl = march_len((long)tl.n1*tl.n2, kB - kA + 1, g.nmb, ML);
   const int nchunk = cdiv(kB - kA + 1, ckl);
-  const size_t lds = 2*(5*(size_t)(tl.tw + 3)*(tl.th + 3) + 10*(size_t)tl.tw*tl.th)*sizeof(double);
+  const size_t lds = hyd_lds_doubles(tl.tw, tl.th)*sizeof(double);
   dim3 grid(tl.n1, tl.n2, nchunk*g.nmb), block(tl.threads);
   int rc = dispatch_scheme_eos<false>(sc, [&](auto R, auto S) {
     if constexpr (decltype(R)::value <= 1) {
