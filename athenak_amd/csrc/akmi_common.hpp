@@ -157,6 +157,25 @@ __device__ __forceinline__ void stu(double *__restrict__ base, unsigned ob, doub
   *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + ob) = v;
 }
 
+// The value of the neighbouring lane of the wave (lane - 1 / lane + 1) as a DPP move of the two halves: two VALU
+// instructions per double, no trip through the LDS crossbar (ds_bpermute_b32 x 2 + address arithmetic + lgkmcnt wait is
+// what __shfl_up / __shfl_down(x, 1, 64) compile to).  Lane 0 / lane 63 keep their own value, as with __shfl_up / _down.
+// Every lane of the wave has to be active at the call.
+__device__ __forceinline__ double lane_below(double x) {          // == __shfl_up(x, 1, 64)
+  const long long v = __double_as_longlong(x);
+  int lo = (int)v, hi = (int)(v >> 32);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);     // wave_shr:1
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double lane_above(double x) {          // == __shfl_down(x, 1, 64)
+  const long long v = __double_as_longlong(x);
+  int lo = (int)v, hi = (int)(v >> 32);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);     // wave_shl:1
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
 // a wave-uniform double the vector unit computed (e.g. 1/dx), moved to scalar registers: frees two VGPRs per value
 __device__ __forceinline__ double to_sgpr(double x) {
   const long long b = __double_as_longlong(x);

@@ -413,6 +413,16 @@ __device__ __forceinline__ double beta_dt_of(double beta_dt, const double *dtp) 
 #ifndef AKMI_PREFETCH_X1P
 #define AKMI_PREFETCH_X1P 1     // ... the x1 flux difference fetched before the solve in the x2 march
 #endif
+#ifndef AKMI_DPP
+#define AKMI_DPP 1            // neighbour lanes by DPP moves instead of ds_bpermute (lane_below / lane_above)
+#endif
+#if AKMI_DPP
+#define AKMI_LANE_BELOW(x) lane_below(x)
+#define AKMI_LANE_ABOVE(x) lane_above(x)
+#else
+#define AKMI_LANE_BELOW(x) __shfl_up(x, 1, 64)
+#define AKMI_LANE_ABOVE(x) __shfl_down(x, 1, 64)
+#endif
 #ifndef AKMI_X12S_FM
 #define AKMI_X12S_FM 1         // short sqrt / reciprocal forms (akmi_numerics.hpp) in the two solves of k_sweep12s
 #endif
@@ -990,6 +1000,15 @@ constexpr int CKL = AKMI_CKL;          // cell planes per k-chunk (one plane of 
 // (ty, tx); the launcher picks the shape that wastes the fewest lanes for the block size (a 64-wide
 // tile needs two columns of tiles for the 65 edge columns of a 64^3 MeshBlock, a 34 x 15 tile does
 // 33 / 65 / 257 columns in 1 / 2 / 8).
+// Workgroup -> tile order.  Workgroup b of a launch runs on XCD b % 8 (observed placement; nothing below depends on
+// it for correctness), and each XCD has its own L2.  A tile kernel whose neighbouring tiles re-read each other's edge
+// rows wants neighbours on the SAME XCD at about the same time: XCD x takes the x-th contiguous eighth of the tile
+// list, in list order.  The map is a bijection of [0, n) for every n.
+__device__ __forceinline__ unsigned xcd_order(unsigned b, unsigned n) {
+  const unsigned xcd = b & 7u, slot = b >> 3, q = n >> 3, rem = n & 7u;
+  return (xcd < rem ? xcd*(q + 1u) : rem*(q + 1u) + (xcd - rem)*q) + slot;
+}
+
 template <bool P2, bool BITS>
 __device__ __forceinline__ void corner_ct_body(const Geo &g, const MfBits &mb, const double *__restrict__ e3x1, const double *__restrict__ e2x1,
             const double *__restrict__ e1x2, const double *__restrict__ e3x2,
@@ -1009,6 +1028,7 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const MfBits &mb, c
 #define S3(p, y, x) ct_lds[(4 + (p))*plane + (y)*tw + (x)]
   const int ty = threadIdx.x/tw, tx = threadIdx.x - ty*tw;
   const bool in_tile = ty < th;          // the workgroup is padded to whole waves
+  // (xcd_order, which pays in the hydro tile kernel, costs this bandwidth-bound one 2 %: 659 -> 675 us, profiles/r05_mhd_ab.txt)
   const int i = g.is + blockIdx.x*(tw - 1) + tx;
   const int j = g.js + blockIdx.y*(th - 1) + ty;
   const int m = blockIdx.z/nchunk;
@@ -1829,15 +1849,6 @@ static HydTile hyd_tile(int c1, int c2) {
 
 // MASS: passive scalars ride along -- leave the three mass fluxes behind for k_scalar_update
 struct Mass3 { double *m1, *m2, *m3; };
-// Workgroup -> tile order.  Workgroup b of a launch runs on XCD b % 8 (observed placement; nothing below depends on
-// it for correctness), and each XCD has its own L2.  A tile kernel whose neighbouring tiles re-read each other's edge
-// rows wants neighbours on the SAME XCD at about the same time: XCD x takes the x-th contiguous eighth of the tile
-// list, in list order.  The map is a bijection of [0, n) for every n.
-__device__ __forceinline__ unsigned xcd_order(unsigned b, unsigned n) {
-  const unsigned xcd = b & 7u, slot = b >> 3, q = n >> 3, rem = n & 7u;
-  return (xcd < rem ? xcd*(q + 1u) : rem*(q + 1u) + (xcd - rem)*q) + slot;
-}
-
 template <int RECON, int RS, bool MASS = false>
 __global__ void __launch_bounds__(HS_THREADS, AKMI_HS_WAVES)
 k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, int kA, int kB,
@@ -2290,7 +2301,7 @@ k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
       double qln[NV], qr[NV];
 #pragma unroll
       for (int n = 0; n < NV; ++n) {
-        const double qm = __shfl_up(q0[n], 1, 64), qp = __shfl_down(q0[n], 1, 64);
+        const double qm = AKMI_LANE_BELOW(q0[n]), qp = AKMI_LANE_ABOVE(q0[n]);
         plm(qm, q0[n], qp, qln[n], qr[n]);
       }
       if (do_x1 && inner && i >= a1.il - 1 && i <= a1.iu) {          // cell-centred E = -(v x B)
@@ -2300,15 +2311,15 @@ k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
       }
       double L1[NV];
 #pragma unroll
-      for (int n = 0; n < NV; ++n) L1[n] = __shfl_up(qln[n], 1, 64);
+      for (int n = 0; n < NV; ++n) L1[n] = AKMI_LANE_BELOW(qln[n]);
       Cons1D f1 = riemann_mhd_e<RS, AKMI_X12S_EO1 != 0, AKMI_X12S_FM != 0>(eos, L1[0], L1[1], L1[2], L1[3], L1[4], L1[5], L1[6], qr[0],
                                     qr[1], qr[2], qr[3], qr[4], qr[5], qr[6], bx1);
       f1d = f1.d; f1x = f1.mx; f1y = f1.my; f1z = f1.mz; f1e = f1.e; f1by = f1.by; f1bz = f1.bz;
-      dF1[0] = __shfl_down(f1d, 1, 64) - f1d;
-      dF1[1] = __shfl_down(f1x, 1, 64) - f1x;
-      dF1[2] = __shfl_down(f1y, 1, 64) - f1y;
-      dF1[3] = __shfl_down(f1z, 1, 64) - f1z;
-      dF1[4] = __shfl_down(f1e, 1, 64) - f1e;
+      dF1[0] = AKMI_LANE_ABOVE(f1d) - f1d;
+      dF1[1] = AKMI_LANE_ABOVE(f1x) - f1x;
+      dF1[2] = AKMI_LANE_ABOVE(f1y) - f1y;
+      dF1[3] = AKMI_LANE_ABOVE(f1z) - f1z;
+      dF1[4] = AKMI_LANE_ABOVE(f1e) - f1e;
       if constexpr (BITS) {
         if (do_x1) {
           const unsigned long long bits = __ballot(x1_ok && f1d >= 0.0);

@@ -572,9 +572,20 @@ def other_configs(args):
             el = time.perf_counter() - t0
             sim.close()
             torch.cuda.empty_cache()
+            # whole-step roofline of this workload: SURVEY 8(d)'s algorithmic bytes per cell and stage (hydro 240 B,
+            # MHD 384 B) x cells x 2 stages (RK2) / wall time of the timed cycles -- every kernel, exchange and boundary
+            # condition of the cycle included (kernel-time figures belong to a rocprof profile of the same lib_sha16:
+            # profiles/r05_hydro128_kernel_stats.txt, r05_config5.txt)
+            blk_ = "mhd" if pin.DoesBlockExist("mhd") else "hydro"
+            sb = BYTES_PASS_A[blk_] + BYTES_PASS_B[blk_]
+            ach = sb*ncell*2*done/el/1e9
             res.append({"config": label, "value": round(ncell*done/el/1e6, 1), "unit": "Mcell-updates/s",
                         "meshblocks": int(pm.nmb_total), "cells": int(ncell), "steps": int(done),
-                        "ms_per_step": round(el/max(done, 1)*1e3, 4)})
+                        "ms_per_step": round(el/max(done, 1)*1e3, 4),
+                        "roofline": {"bound": "hbm", "basis": "whole step (wall clock of the timed cycles)",
+                                     "algorithmic_bytes_per_cell_stage": sb, "stages_per_step": 2,
+                                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(ach/HBM_PEAK_GBS, 4)}})
         except Exception as e:
             res.append({"config": label, "value": None, "error": repr(e)[:300]})
 

@@ -146,6 +146,18 @@ def compare_fields(prod, orc, is_mhd):
         den = sum(np.abs(orc[k]).sum() for k in ("b0x1f", "b0x2f", "b0x3f"))
         out["B"] = float(num/den) if den > 0 else float(num)
     out["bitwise_equal"] = all(np.array_equal(prod[k], orc[k]) for k in prod)
+    # A/B of builds with relaxed arithmetic (tools/r05_contract.sh): AKMI_PARITY_TOL=1e-12 replaces the bit-for-bit
+    # requirement of every test that goes through here by north_star's bar (relative L1 of the conserved variables
+    # and the face field) and AKMI_PARITY_LOG collects the worst value per test.  Never set by the driver's runs.
+    tol = os.environ.get("AKMI_PARITY_TOL")
+    if tol:
+        worst = max(v for k, v in out.items() if k != "bitwise_equal")
+        log = os.environ.get("AKMI_PARITY_LOG")
+        if log:
+            with open(log, "a") as f:
+                f.write("%s\t%.3e\t%s\n" % (os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], worst,
+                                             "bitwise" if out["bitwise_equal"] else "differs"))
+        out["bitwise_equal"] = bool(worst <= float(tol))
     return out
 
 
