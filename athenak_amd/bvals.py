@@ -61,13 +61,13 @@ class HipBvalsKernels:
     def _dirs(self, bcs):
         """bit d set: some MeshBlock has a physical boundary across direction d (anything but block / periodic); the
         other directions are not launched (akmi_*_bcs_dirs).  Read from the flag table once per table."""
-        key = bcs.data_ptr()
-        cache = self.__dict__.setdefault("_dirs_cache", {})
-        if key not in cache:
+        mask = getattr(bcs, "_akmi_bc_dirs", None)      # kept ON the table (an address can be reused by the allocator for
+        if mask is None:                                # the next mesh's table; the tensor object cannot)
             f = bcs.detach().cpu().numpy().reshape(-1, 6)
             phys = (f != capi.BC["block"]) & (f != capi.BC["periodic"])
-            cache[key] = sum(1 << q for q in range(3) if phys[:, 2*q:2*q + 2].any())
-        return cache[key]
+            mask = sum(1 << q for q in range(3) if phys[:, 2*q:2*q + 2].any())
+            bcs._akmi_bc_dirs = mask
+        return mask
 
     def hydro_bcs(self, pack, nvar, bcs, u, u_in=None):
         capi.check(self.L.akmi_hydro_bcs_dirs(C.byref(pack), nvar, capi._p(bcs), self._dirs(bcs), capi._p(u_in),

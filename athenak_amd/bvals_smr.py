@@ -20,6 +20,7 @@ mesh); Mesh refuses `refinement = static` with more than one rank.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import torch
@@ -312,6 +313,20 @@ class HipSmrKernels:
                    capi._p(cb.x1f), capi._p(cb.x2f), capi._p(cb.x3f), capi._stream())
 
 
+
+def _map_or_fallback(build, name):
+    """A copy list is an optimisation of the pack / unpack kernels, which stay in the library: when the library cannot
+    build it (index space of 2^31 elements, no memory for the set-up scratch, an unclassifiable pair) warn once and use
+    the kernels.  AKMI_SMR_<name>_MAP=1 makes the list mandatory (the tests of the lists themselves)."""
+    try:
+        return build()
+    except capi.AkmiError as e:
+        if os.environ.get("AKMI_SMR_%s_MAP" % name) == "1":
+            raise
+        sys.stderr.write("### WARNING %s -- falling back to the pack / unpack kernels\n" % e)
+        return False
+
+
 class MeshBoundaryValuesSMR:
     """level-aware boundary values of one pack: tables on the device + the task bodies"""
 
@@ -527,17 +542,19 @@ class MeshBoundaryValuesSMR:
         if self._ccmap is None:
             self._ccmap = False
             if capi.DEVICE != "cpu" and not self.peers and os.environ.get("AKMI_SMR_CC_MAP", "1") != "0":
-                import torch
-                L, buf = capi.lib(), self.buf[0]
-                args = (C.byref(self.pack_c), C.byref(self.smr_c), self.nvar, capi._p(self.t_same), capi._p(buf),
-                        C.c_longlong(int(buf.numel())))
-                tail = C.c_longlong(0)
-                n = int(L.akmi_smr_cc_map(*args, None, C.c_longlong(0), C.byref(tail), capi._stream()))
-                capi.check(n, "smr_cc_map")
-                m = torch.zeros(max(2*n, 2), dtype=torch.int32, device=self.device)
-                capi.check(int(L.akmi_smr_cc_map(*args, capi._p(m), C.c_longlong(n), C.byref(tail), capi._stream())),
-                           "smr_cc_map")
-                self._ccmap = (m, n, int(tail.value))
+                def build():
+                    import torch
+                    L, buf = capi.lib(), self.buf[0]
+                    args = (C.byref(self.pack_c), C.byref(self.smr_c), self.nvar, capi._p(self.t_same), capi._p(buf),
+                            C.c_longlong(int(buf.numel())))
+                    tail = C.c_longlong(0)
+                    n = int(L.akmi_smr_cc_map(*args, None, C.c_longlong(0), C.byref(tail), capi._stream()))
+                    capi.check(n, "smr_cc_map")
+                    m = torch.zeros(max(2*n, 2), dtype=torch.int32, device=self.device)
+                    capi.check(int(L.akmi_smr_cc_map(*args, capi._p(m), C.c_longlong(n), C.byref(tail), capi._stream())),
+                               "smr_cc_map")
+                    return (m, n, int(tail.value))
+                self._ccmap = _map_or_fallback(build, "CC")
         return self._ccmap
 
     def PackAndSendCC(self, u, cu):
@@ -566,22 +583,24 @@ class MeshBoundaryValuesSMR:
         if self._fcmap is None:
             self._fcmap = False
             if capi.DEVICE != "cpu" and os.environ.get("AKMI_SMR_FC_MAP", "1") != "0":
-                import torch
-                L, buf = capi.lib(), self.buf[2]
-                nb = int(buf.numel())
-                lo = min([a for (a, _) in self.send_slices[2].values()], default=nb) if self.peers else nb
-                maps = []
-                for which in (0, 1):
-                    args = (C.byref(self.pack_c), C.byref(self.smr_c), capi._p(buf), C.c_longlong(nb), C.c_longlong(lo),
-                            C.c_longlong(nb), which)
-                    tail = C.c_longlong(0)
-                    n = int(L.akmi_smr_fc_map(*args, None, C.c_longlong(0), C.byref(tail), capi._stream()))
-                    capi.check(n, "smr_fc_map")
-                    m = torch.zeros(max(2*n, 2), dtype=torch.int32, device=self.device)
-                    capi.check(int(L.akmi_smr_fc_map(*args, capi._p(m), C.c_longlong(n), C.byref(tail), capi._stream())),
-                               "smr_fc_map")
-                    maps.append((m, n, int(tail.value)))
-                self._fcmap = maps
+                def build():
+                    import torch
+                    L, buf = capi.lib(), self.buf[2]
+                    nb = int(buf.numel())
+                    lo = min([a for (a, _) in self.send_slices[2].values()], default=nb) if self.peers else nb
+                    maps = []
+                    for which in (0, 1):
+                        args = (C.byref(self.pack_c), C.byref(self.smr_c), capi._p(buf), C.c_longlong(nb), C.c_longlong(lo),
+                                C.c_longlong(nb), which)
+                        tail = C.c_longlong(0)
+                        n = int(L.akmi_smr_fc_map(*args, None, C.c_longlong(0), C.byref(tail), capi._stream()))
+                        capi.check(n, "smr_fc_map")
+                        m = torch.zeros(max(2*n, 2), dtype=torch.int32, device=self.device)
+                        capi.check(int(L.akmi_smr_fc_map(*args, capi._p(m), C.c_longlong(n), C.byref(tail), capi._stream())),
+                                   "smr_fc_map")
+                        maps.append((m, n, int(tail.value)))
+                    return maps
+                self._fcmap = _map_or_fallback(build, "FC")
         return self._fcmap
 
     def _fc_copy(self, which, b, cb):

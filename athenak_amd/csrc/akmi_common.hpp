@@ -157,6 +157,12 @@ __device__ __forceinline__ void stu(double *__restrict__ base, unsigned ob, doub
   *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + ob) = v;
 }
 
+// gfx950 runs wave64 only; the kernels that count on it (ballot words, lane shifts, four waves per 256 threads) say so
+constexpr int AKMI_WAVE = 64;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(__AMDGCN_WAVEFRONT_SIZE)
+static_assert(__AMDGCN_WAVEFRONT_SIZE == AKMI_WAVE, "libakmi is written for 64-lane wavefronts (gfx950)");
+#endif
+
 // The value of the neighbouring lane of the wave (lane - 1 / lane + 1) as a DPP move of the two halves: two VALU
 // instructions per double, no trip through the LDS crossbar (ds_bpermute_b32 x 2 + address arithmetic + lgkmcnt wait is
 // what __shfl_up / __shfl_down(x, 1, 64) compile to).  Lane 0 / lane 63 keep their own value, as with __shfl_up / _down.

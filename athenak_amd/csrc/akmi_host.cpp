@@ -403,10 +403,13 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
   // <hydro|mhd>/fused_stage = true | false | auto (default): an explicit true / false is kept as it is
   std::string fs = pin->GetOrAddString(blk, "fused_stage", "auto");
   for (char &c : fs) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
-  if (fs != "auto" && fs != "true" && fs != "false" && fs != "1" && fs != "0")
-    AKMI_FATAL("<" + blk + ">/fused_stage = " + fs + ": true, false or auto");
+  // (the boolean spellings of ParameterInput::GetBoolean, src/parameter_input.cpp: "true" / "false" in any case, or an
+  //  integer, non-zero = true -- decks written for the boolean this key was before round 4 keep working)
+  const bool fs_int = !fs.empty() && fs.find_first_not_of("0123456789") == std::string::npos;
+  if (fs != "auto" && fs != "true" && fs != "false" && !fs_int)
+    AKMI_FATAL("<" + blk + ">/fused_stage = " + fs + ": true, false, an integer or auto");
   const bool fused_given = fs != "auto";
-  fused = !(fs == "false" || fs == "0");
+  fused = fs_int ? std::stol(fs) != 0 : fs != "false";
   // small 3-D packs: the task-granular chain (one thread per face) beats the marching kernels of the fused stage
   // (MHD 64^3: 1 050 against 810 Mcell-updates/s, equal at 96^3; profiles/r03_small_packs.txt); same bits either way.
   // <hydro|mhd>/small_pack_tasks = false keeps the fused kernels.  AKMI_SMALL_PACK_TASKS=0: off

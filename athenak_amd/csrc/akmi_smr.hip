@@ -797,6 +797,7 @@ struct VarSel { long long nu, cs, ccs; int nvar; };
 __device__ __forceinline__ bool var0(const VarSel &f, long long g) {
   return f.nvar == 0 || (g < f.nu ? (g/f.cs)%f.nvar : ((g - f.nu)/f.ccs)%f.nvar) == 0;
 }
+static_assert(AKMI_WAVE == 64, "k_fc_pairs: 64-lane ballots, four waves per 256-thread workgroup");
 __global__ void __launch_bounds__(256)
 k_fc_pairs(const double *__restrict__ a, long long n, long long first, const double *__restrict__ tmp, long long ntmp,
            int *__restrict__ cnt, const long long *__restrict__ off, int *__restrict__ map, long long np,
@@ -1198,6 +1199,25 @@ int akmi_smr_fc_copy(const akmi_pack *p, const int *map, long long npairs, long 
   return AKMI_COMPLETE;
 }
 
+// The cell-centred list keeps the pairs of variable 0 and akmi_smr_cc_copy applies them to every variable: check, once
+// at set-up, that the exchange really moved variable v > 0 exactly as variable 0 (same destination cell, same source
+// cell, variable v of the source's own register).
+static __global__ void __launch_bounds__(256)
+k_cc_var_check(const double *__restrict__ tmp, long long ntmp, akmi::VarSel f, int *__restrict__ bad) {
+  const long long g = (long long)blockIdx.x*256 + threadIdx.x;
+  if (g >= ntmp) return;
+  const bool in_u = g < f.nu;
+  const long long st = in_u ? f.cs : f.ccs;
+  const int v = (int)((in_u ? g/f.cs : (g - f.nu)/f.ccs)%f.nvar);
+  if (v == 0) return;
+  const long long g0 = g - (long long)v*st;
+  const double c0 = tmp[g0], c = tmp[g];
+  if (c0 == (double)(g0 + 1)) { if (c != (double)(g + 1)) atomicAdd(bad, 1); return; }     // untouched together
+  const long long s0 = (long long)c0 - 1;
+  const long long want = s0 + (long long)v*(s0 < f.nu ? f.cs : f.ccs);
+  if (c != (double)(want + 1)) atomicAdd(bad, 1);
+}
+
 long long akmi_smr_cc_map(const akmi_pack *p, const akmi_smr *t, int nvar, const int *same27, double *buf,
                           long long buf_doubles, int *map, long long cap, long long *ntail, void *stream) {
   using namespace akmi;
@@ -1231,11 +1251,12 @@ long long akmi_smr_cc_map(const akmi_pack *p, const akmi_smr *t, int nvar, const
     if (akmi_bvals_cc_local(p, nvar, same27, tmp, stream) != AKMI_COMPLETE) goto done;
   }
   k_fc_pairs<<<nwg, 256, 0, st>>>(tmp, ntmp, 0, tmp, ntmp, d_cnt, nullptr, nullptr, 0, d_flag, d_flag + 1, sel);
+  if (nvar > 1) k_cc_var_check<<<nwg, 256, 0, st>>>(tmp, ntmp, sel, d_flag + 1);
   CCM_HIP(hipMemcpyAsync(h_cnt.data(), d_cnt, sizeof(int)*nwg, hipMemcpyDeviceToHost, st));
   CCM_HIP(hipMemcpyAsync(h_flag, d_flag, 2*sizeof(int), hipMemcpyDeviceToHost, st));
   CCM_HIP(hipStreamSynchronize(st));
   for (unsigned w = 0; w < nwg; ++w) { h_off[w] = np; np += h_cnt[w]; }
-  if (h_flag[1]) { set_error("smr_cc_map: %d copies are not independent element copies", h_flag[1]); goto done; }
+  if (h_flag[1]) { set_error("smr_cc_map: %d copies are not independent element copies of all variables alike", h_flag[1]); goto done; }
   if (map && np > 0) {
     if (np + h_flag[0] > cap) { set_error("smr_cc_map: %lld pairs, room for %lld", np + h_flag[0], cap); goto done; }
     CCM_HIP(hipMemcpyAsync(d_off, h_off.data(), sizeof(long long)*nwg, hipMemcpyHostToDevice, st));

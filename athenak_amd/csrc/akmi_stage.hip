@@ -290,20 +290,6 @@ k_sweep(Geo g, FaceEos eos, SweepArgs a, int nk) {
 #ifndef AKMI_POW2DX
 #define AKMI_POW2DX 1           // cell sizes that are powers of two: x/dx as one v_ldexp_f64 (wave-uniform choice at run time)
 #endif
-// CornerE needs only the SIGN of the three mass fluxes (upwinding, mhd_corner_e.cpp:340-413).  In the 3-D
-// PLM+HLLD stage the sweeps therefore leave one 64-bit ballot word per wave and face row instead of one double
-// per face (`f >= 0.0`, the comparison CornerE makes): the producing wave and lane of a face follow from its
-// indices, so the consumer finds its bit without any atomics or clearing.  What-if builds bounded the gain at
-// 166 us per stage (profiles/r03_whatif_merge_c2p.txt: no mass-flux traffic at all); the real thing gains a
-// tenth of that (profiles/r03_mfbits_ab.txt), so it is an option (AKMI_MFBITS=1), not the default.
-//   x1 / x2 faces (k_sweep12s): wave wv = p/60, lane = p%60 + 2 with p = (k - kl12)*N1 + i; word (m, row, wv)
-//   x3 faces (x3 march):        wave = p3>>6, lane = p3&63 with p3 = (j - j3l)*N1 + i;      word (m, k - k3l, wave)
-struct MfBits {
-  unsigned long long *w1, *w2, *w3;     // null: the mass-flux arrays themselves
-  int j1l, nj1, j2l, nj2, kl12, nw12;
-  int j3l, k3l, nk3, nw3;
-};
-
 struct UpdArgs {
   double gam0, gam1, beta_dt;
   double *u0, *u1;
@@ -312,9 +298,6 @@ struct UpdArgs {
   double *acc;                    // partial divergence (written by the x2 march, read by x3)
   const double *dtp;              // non-null: beta_dt holds the RK weight beta and dt is read from
                                   // device memory (a captured cycle replayed with a new time step)
-  MfBits mb;                      // sign words of the mass fluxes (w1 == null: off)
-  const double *bz_src;           // k_sweep12s: copy the x3 face field bz_src -> bz_snap on its way (in-place stages
-  double *bz_snap;                // followed by k_march3ct, see there); null: no copy
 };
 // copy_u1 / copy_b1: 0 = the second register (u1, b1) holds the state of the start of the cycle;
 // 1 = first stage, CopyCons folded in: the register receives the old state, u0 / b0 the new one;
@@ -367,28 +350,6 @@ __device__ __forceinline__ double beta_dt_of(double beta_dt, const double *dtp) 
 #ifndef AKMI_PREFETCH_W
 #define AKMI_PREFETCH_W 1       // x3 PLM march: load the cells of step t+1 during step t (2*NV more VGPRs)
 #endif
-// Timing experiments that produce WRONG RESULTS (what a kernel would cost without its solve, without some of its
-// traffic, without its barriers: upper bounds of what a fusion could save).  They exist only in builds that define
-// AKMI_EXPERIMENTS, which __graft_entry__.build() never does; akmi_build_flags() reports such a build and
-// tests/test_capi_symbols.py refuses it.  A stray -DAKMI_WHATIF=.. without the guard is a compile error.
-#ifdef AKMI_EXPERIMENTS
-#ifndef AKMI_DBG_NOSOLVE
-#define AKMI_DBG_NOSOLVE 0      // the marches without their Riemann solve
-#endif
-#ifndef AKMI_WHATIF
-#define AKMI_WHATIF 0           // 1: x3 march without its stores for CornerE, 2: CornerE without x3 inputs, 4: no mass-flux arrays
-#endif
-#ifndef AKMI_M3_WHATIF
-#define AKMI_M3_WHATIF 0        // k_march3ct: 1: no barriers, 2: no Riemann solve
-#endif
-#else
-#if defined(AKMI_DBG_NOSOLVE) || defined(AKMI_WHATIF) || defined(AKMI_M3_WHATIF)
-#error "AKMI_DBG_NOSOLVE / AKMI_WHATIF / AKMI_M3_WHATIF change results: they need -DAKMI_EXPERIMENTS"
-#endif
-#define AKMI_DBG_NOSOLVE 0
-#define AKMI_WHATIF 0
-#define AKMI_M3_WHATIF 0
-#endif
 #ifndef AKMI_PPM_WREG
 #define AKMI_PPM_WREG 1         // marches with five-point reconstructions keep their window in registers
 #endif
@@ -430,7 +391,9 @@ __device__ __forceinline__ double beta_dt_of(double beta_dt, const double *dtp) 
 #define AKMI_MARCH_FM 0        // ... in the marches: loses (registers, basic blocks), profiles/r03_ab1.txt
 #endif
 #ifndef AKMI_SMALL_FACE_SWEEPS
-#define AKMI_SMALL_FACE_SWEEPS AKMI_SMALL_PACK_CELLS   // packs up to this many cells take thread-per-face x2/x3 sweeps on the task path (0: never)
+#define AKMI_SMALL_FACE_SWEEPS 700000   // task path: packs up to this many cells take thread-per-face x2/x3 sweeps (0: never); the crossover
+                                        // measured in round 3 (88^3 = 681 k cells still faster per face, profiles/r03_small_packs.txt); the HOSTS switch
+                                        // small packs to the task chain at AKMI_SMALL_PACK_CELLS (include/akmi.h)
 #endif
 #ifndef AKMI_X2_EO
 #define AKMI_X2_EO 0            // wave-uniform early-outs of HLLD in the x2 / x3 march (registers!)
@@ -533,8 +496,8 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
   bool lane_ok;
   // lanes over the flattened (row, i).  The storing marches (MODE 2: refined meshes, small MeshBlocks) run them over the
   // columns of the sweep only -- [il, iu] instead of the N1 of the row: with four ghost cells a 32^3 block has 40 columns
-  // of which 34 carry a face, and nothing couples the lanes of a march.  The other modes keep the N1 rows (the sign
-  // words of MfBits are addressed by them; at 256^3 it is 258 of 260).
+  // of which 34 carry a face, and nothing couples the lanes of a march.  The other modes keep the N1 rows (at 256^3
+  // 258 of 260 lanes carry a face).
   const int row_w = STORE ? a.iu - a.il + 1 : g.N1, row_0 = STORE ? a.il : 0;
   if constexpr (DIR == 2) {
     const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;   // rows [jl,ju] x row_w
@@ -725,31 +688,13 @@ __device__ __forceinline__ void sweep_update_body(const Geo &g, const FaceEos &e
     }
     double fd, fx, fy, fz, fe;
     if constexpr (MHD) {
-#if AKMI_DBG_NOSOLVE      // timing experiment only (wrong results): what the march costs without its Riemann solve
-      Cons1D fl;
-      fl.d = L[0] + R[0]; fl.mx = L[1] + R[1]; fl.my = L[2] + R[2]; fl.mz = L[3] + R[3]; fl.e = L[4] + R[4];
-      fl.by = L[5] + R[5] + ldu(bxm, foff); fl.bz = L[6] + R[6];
-#else
       const double bxi = ldu(bxm, foff);
       Cons1D fl = riemann_mhd_e<RS, (DIR == 1 ? AKMI_X2_EO : AKMI_X3_EO) != 0, AKMI_MARCH_FM != 0>(
           eos, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1], R[2], R[3], R[4], R[5], R[6], bxi);
-#endif
       fd = fl.d; fx = fl.mx; fy = fl.my; fz = fl.mz; fe = fl.e;
-#if AKMI_WHATIF & 1     // timing experiment (wrong results): the x3 march without its three stores for CornerE
-      if (DIR == 2 && MODE == 0) fe += 0.0*(fl.by + fl.bz);
-      else
-#endif
       if (t < ml || s == shi) {
         // CornerE needs the sign of the mass flux and the two face EMFs of this direction
-#if !(AKMI_WHATIF & 4)
-        if (DIR == 2 && MODE == 0 && u.mb.w3) {
-          const unsigned long long act = __ballot(1), bits = __ballot(fd >= 0.0);
-          if ((int)threadIdx.x == __ffsll((long long)act) - 1)
-            u.mb.w3[((size_t)m*u.mb.nk3 + (s - u.mb.k3l))*u.mb.nw3 + ((size_t)blockIdx.x*SY + threadIdx.y)] = bits;
-        } else {
-          stu(mfm, foff, fd);
-        }
-#endif
+        stu(mfm, foff, fd);
         stu(a.ey + (size_t)m*cs, oc, -fl.by);
         stu(a.ez + (size_t)m*cs, oc, fl.bz);
       }
@@ -1009,8 +954,8 @@ __device__ __forceinline__ unsigned xcd_order(unsigned b, unsigned n) {
   return (xcd < rem ? xcd*(q + 1u) : rem*(q + 1u) + (xcd - rem)*q) + slot;
 }
 
-template <bool P2, bool BITS>
-__device__ __forceinline__ void corner_ct_body(const Geo &g, const MfBits &mb, const double *__restrict__ e3x1, const double *__restrict__ e2x1,
+template <bool P2>
+__device__ __forceinline__ void corner_ct_body(const Geo &g, const double *__restrict__ e3x1, const double *__restrict__ e2x1,
             const double *__restrict__ e1x2, const double *__restrict__ e3x2,
             const double *__restrict__ e2x3, const double *__restrict__ e1x3,
             const double *__restrict__ c1, const double *__restrict__ c2,
@@ -1061,23 +1006,9 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const MfBits &mb, c
   // operands of the corner formulas that belong to plane k-1 (rolled from step to step)
   double x2_km = 0.0, x1_km = 0.0, c1_mm = 0.0, c1_m0 = 0.0, c2_mm = 0.0, c2_m0 = 0.0;
   bool f1_km = false, f2_km = false;          // mass flux >= 0 on the x1 / x2 face of plane k-1
-  // BITS: the sign words the sweeps left behind (MfBits) instead of the mass-flux arrays
-  auto s12 = [&](const unsigned long long *w, int nj, int jl, int kk, int jj, int ii) -> bool {
-    const int pp = (kk - mb.kl12)*g.N1 + ii, wv = pp/60, ln = pp - wv*60 + 2;
-    return (w[((size_t)m*nj + (jj - jl))*mb.nw12 + wv] >> ln) & 1ull;
-  };
-  auto s3 = [&](int kk, int jj, int ii) -> bool {
-    const int pp = (jj - mb.j3l)*g.N1 + ii;
-    return (mb.w3[((size_t)m*mb.nk3 + (kk - mb.k3l))*mb.nw3 + (pp >> 6)] >> (pp & 63)) & 1ull;
-  };
   if (edge_ok) {
-    if constexpr (BITS) {
-      f1_km = s12(mb.w1, mb.nj1, mb.j1l, k0 - 1, j, i);
-      f2_km = s12(mb.w2, mb.nj2, mb.j2l, k0 - 1, j, i);
-    } else {
-      f1_km = ldu(f1m - PS1, o1) >= 0.0;
-      f2_km = ldu(f2m - PS2, o2) >= 0.0;
-    }
+    f1_km = ldu(f1m - PS1, o1) >= 0.0;
+    f2_km = ldu(f2m - PS2, o2) >= 0.0;
     x2_km = ldu(x12 - PS, oc);
     x1_km = ldu(x21 - PS, oc);
     c1_mm = ldu(c1m - PS - g.N1, oc); c1_m0 = ldu(c1m - PS, oc);
@@ -1089,43 +1020,18 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const MfBits &mb, c
     double e1 = 0.0, e2 = 0.0, e3 = 0.0;
     if (edge_ok) {
       bool f1_k, f1_jm, f2_k, f2_im, f3_k, f3_jm, f3_im;     // mass flux >= 0 on the faces round the corner
-#if AKMI_WHATIF & 4      // timing experiment (wrong results): CornerE without the three mass-flux arrays
-      const double x2w = ldu(x12, oc);
-      f1_k = x2w >= 0.0; f1_jm = f1_k; f2_k = !f1_k; f2_im = f1_k; f3_k = f1_k; f3_jm = !f1_k; f3_im = f1_k;
-#elif AKMI_WHATIF & 2    // ... without what the x3 march leaves behind (mass flux and face EMFs of x3)
       f1_k = ldu(f1m, o1) >= 0.0;
       f1_jm = ldu(f1m - (g.N1 + 1), o1) >= 0.0;
       f2_k = ldu(f2m, o2) >= 0.0;
       f2_im = ldu(f2m - 1, o2) >= 0.0;
-      f3_k = f1_k; f3_jm = f2_k; f3_im = f1_jm;
-#else
-      if constexpr (BITS) {
-        f1_k = s12(mb.w1, mb.nj1, mb.j1l, k, j, i);
-        f1_jm = s12(mb.w1, mb.nj1, mb.j1l, k, j - 1, i);
-        f2_k = s12(mb.w2, mb.nj2, mb.j2l, k, j, i);
-        f2_im = s12(mb.w2, mb.nj2, mb.j2l, k, j, i - 1);
-        f3_k = s3(k, j, i);
-        f3_jm = s3(k, j - 1, i);
-        f3_im = s3(k, j, i - 1);
-      } else {
-        f1_k = ldu(f1m, o1) >= 0.0;
-        f1_jm = ldu(f1m - (g.N1 + 1), o1) >= 0.0;
-        f2_k = ldu(f2m, o2) >= 0.0;
-        f2_im = ldu(f2m - 1, o2) >= 0.0;
-        f3_k = ldu(f3m, oc) >= 0.0;
-        f3_jm = ldu(f3m - g.N1, oc) >= 0.0;
-        f3_im = ldu(f3m - 1, oc) >= 0.0;
-      }
-#endif
+      f3_k = ldu(f3m, oc) >= 0.0;
+      f3_jm = ldu(f3m - g.N1, oc) >= 0.0;
+      f3_im = ldu(f3m - 1, oc) >= 0.0;
       const double c1_0m = ldu(c1m - g.N1, oc), c1_00 = ldu(c1m, oc);
       const double c2_0m = ldu(c2m - 1, oc), c2_00 = ldu(c2m, oc);
       const double x2_k = ldu(x12, oc), x1_k = ldu(x21, oc);
       {  // E1 (mhd_corner_e.cpp:340-363)
-#if AKMI_WHATIF & 2
-        const double x3_jm = c1_0m, x3_j = c1_00;
-#else
         const double x3_jm = ldu(x13 - g.N1, oc), x3_j = ldu(x13, oc);
-#endif
         double e1_l3 = upw(f2_km, x3_jm, c1_mm, x3_j, c1_m0);
         double e1_r3 = upw(f2_k, x3_jm, c1_0m, x3_j, c1_00);
         double e1_l2 = upw(f3_jm, x2_km, c1_mm, x2_k, c1_0m);
@@ -1133,11 +1039,7 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const MfBits &mb, c
         e1 = 0.25*(e1_l3 + e1_r3 + e1_l2 + e1_r2 + x2_km + x2_k + x3_jm + x3_j);
       }
       {  // E2 (:365-388)
-#if AKMI_WHATIF & 2
-        const double x3_im = c2_0m, x3_i = c2_00;
-#else
         const double x3_im = ldu(x23 - 1, oc), x3_i = ldu(x23, oc);
-#endif
         double e2_l3 = upw(f1_km, x3_im, c2_mm, x3_i, c2_m0);
         double e2_r3 = upw(f1_k, x3_im, c2_0m, x3_i, c2_00);
         double e2_l1 = upw(f3_im, x1_km, c2_mm, x1_k, c2_0m);
@@ -1198,9 +1100,8 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const MfBits &mb, c
 #ifndef AKMI_CT_WAVES
 #define AKMI_CT_WAVES 6         // waves per SIMD the register allocation aims at: 66 VGPRs, three workgroups per CU
 #endif                          // (two at the 114 VGPRs the compiler takes when left alone: 640-665 us against 621)
-template <bool BITS>
 __global__ void __launch_bounds__(CT_THREADS, AKMI_CT_WAVES)
-k_corner_ct(Geo g, MfBits mb, const double *__restrict__ e3x1, const double *__restrict__ e2x1,
+k_corner_ct(Geo g, const double *__restrict__ e3x1, const double *__restrict__ e2x1,
             const double *__restrict__ e1x2, const double *__restrict__ e3x2,
             const double *__restrict__ e2x3, const double *__restrict__ e1x3,
             const double *__restrict__ c1, const double *__restrict__ c2,
@@ -1210,394 +1111,9 @@ k_corner_ct(Geo g, MfBits mb, const double *__restrict__ e3x1, const double *__r
             double *__restrict__ b0x3f, double *__restrict__ b1x1f, double *__restrict__ b1x2f,
             double *__restrict__ b1x3f, int copy_b1, int kA, int kB, int top, int nchunk,
             int ckl, int tw, int th, const double *dtp) {
-  corner_ct_body<AKMI_POW2DX != 0, BITS>(g, mb, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, c1, c2, c3, flx1, flx2, flx3, gam0,
+  corner_ct_body<AKMI_POW2DX != 0>(g, e3x1, e2x1, e1x2, e3x2, e2x3, e1x3, c1, c2, c3, flx1, flx2, flx3, gam0,
                                    gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f, copy_b1, kA, kB, top,
                                    nchunk, ckl, tw, th, dtp);
-}
-
-// ---------------------------------------------------------------------------------------
-// Pass A, second kernel of the 3-D PLM+HLLD stage: x3 flux + RK update + CornerE + CT in ONE k-march
-// (mhd_fluxes.cpp:203-263, mhd_update.cpp:50-81, mhd_corner_e.cpp:309-414, mhd_ct.cpp:45-77).
-//
-// k_sweep12s leaves acc = dF1/dx1 + dF2/dx2, the x1/x2 face EMFs, the cell-centred EMFs and the x1/x2 mass
-// fluxes.  This kernel is the rest of pass A: a workgroup owns a tile of (j,i) columns and marches along k.  Per
-// step k every thread solves the x3 face k of ITS column (window of the march in registers, cells one step
-// ahead in flight), finishes cell k-1 (u0 = gam0*u0 + gam1*u1 - beta_dt*(acc + dF3/dx3), reference rounding order),
-// hands e1x3 / e2x3 / the mass flux of the face to its j+1 / i+1 neighbours through LDS, forms the three corner
-// EMFs of the plane (formulas and operand order of corner_ct_body above), hands those to the j-1 / i-1 neighbours
-// and updates the face fields.  What the three-kernel form wrote and read back between the x3 march and
-// k_corner_ct -- e2x3, e1x3, flx3(IDN): 3 doubles written + 7 read per cell -- never exists, b0x3f is read once.
-//
-// Tile = tw x th threads: row 0 / column 0 only provide x3 faces (their corner EMFs would need faces of the tile
-// next door), row th-1 / column tw-1 only provide corner EMFs, the (tw-2) x (th-2) threads in between own
-// cells and faces -- every cell and face is written by exactly one thread.
-//
-// Hazard of an in-place stage (copy != 2): the owner of x3 face (k,j,i) rewrites b0x3f there while halo threads of
-// neighbouring tiles and the last step of the k-chunk below still read the OLD value as the longitudinal field of
-// their Riemann solve.  For those stages k_sweep12s (which runs before and has memory bandwidth to spare) copies
-// b0x3f into the workspace and the solves read the copy (M3Args::bz); an out-of-place stage reads b0x3f itself.
-#ifndef AKMI_M3_THREADS
-#define AKMI_M3_THREADS 256
-#endif
-#ifndef AKMI_M3_WGS
-#define AKMI_M3_WGS 2          // workgroups per CU the register allocation aims at (256 threads: 2 waves per SIMD)
-#endif
-#ifndef AKMI_M3_EO
-#define AKMI_M3_EO 0           // wave-uniform early-outs of HLLD (registers)
-#endif
-#ifndef AKMI_M3_FM
-#define AKMI_M3_FM 0           // short square root in the solve
-#endif
-#ifndef AKMI_M3_UPD_LATE
-#define AKMI_M3_UPD_LATE 0     // update operands of cell k-1 requested AFTER the solve and consumed at the end of the step
-#endif
-#ifndef AKMI_M3_PARK
-#define AKMI_M3_PARK 1         // window + pending left state of the march parked in LDS (21 slots per thread)
-#endif
-constexpr int M3_THREADS = AKMI_M3_THREADS;
-constexpr int M3_PLANES = 11;                       // LDS exchange planes of th x tw doubles (+ one plane of flag words)
-constexpr int M3_PARK = AKMI_M3_PARK ? 21 : 0;      // parked slots per thread
-struct M3Args {
-  const double *w0, *bcc0, *bz;                    // bz: longitudinal field of the x3 solves (b0x3f or its snapshot)
-  const double *emf;                               // e3x1 of the workspace; the other arrays of k_sweep12s by byte offset:
-  unsigned o_e2x1, o_e1x2, o_e3x2, o_c1, o_c2, o_c3;
-  const double *flx1, *flx2;                       // mass fluxes of the x1 / x2 faces
-  double *b0x1f, *b0x2f, *b0x3f, *b1x1f, *b1x2f, *b1x3f;
-  int kA, kB, top, nchunk, ckl, tw, th;
-};
-
-// Addresses: wave-uniform pointer (scalar unit) + ONE of three 32-bit byte offsets per lane (array shapes (N2,N1),
-// (N2,N1+1), (N2+1,N1)), advanced by a plane per step.  Everything else of an address -- variable, neighbour row /
-// column / plane, array of the workspace -- is SCALAR pointer arithmetic redone at every use (two s_add per load, the
-// scalar unit is idle): sgpr_opaque() hides the array bases from loop-invariant code motion, which would otherwise keep
-// one hoisted pointer pair per (array, variable, neighbour) -- forty pairs do not fit the scalar file -- or, with the
-// offsets folded into the lane offset, one induction VGPR per address.
-template <class T>
-__device__ __forceinline__ T *sgpr_opaque(T *p) {
-  asm volatile("" : "+s"(p));
-  return p;
-}
-
-template <int RS>
-__global__ void __launch_bounds__(M3_THREADS, AKMI_M3_WGS)
-k_march3ct(Geo g, FaceEos eos, M3Args a, UpdArgs u) {
-  extern __shared__ double m3_lds[];
-#if AKMI_M3_WHATIF & 1        // timing experiment (wrong results): no barriers
-#define M3_SYNC()
-#else
-#define M3_SYNC() __syncthreads()
-#endif
-  const int tw = a.tw, th = a.th, plane = tw*th;
-  // exchange planes: x3-face EMFs of the step, own operands the j+1 / i+1 neighbours need, corner EMFs
-  enum { P_E1X3 = 0, P_E2X3, P_C1, P_C2, P_C3, P_X32, P_X31, P_E1, P_E2, P_E3A, P_E3B };
-#define XS(p, y, x) m3_lds[(p)*plane + (y)*tw + (x)]
-  int *flagw = reinterpret_cast<int *>(m3_lds + M3_PLANES*plane);        // bit 0/1/2: mass flux of the x1/x2/x3 face >= 0
-#define FLG(y, x) flagw[(y)*tw + (x)]
-  double *park = m3_lds + (M3_PLANES + 1)*plane + threadIdx.x;           // slot s of this thread: park[s*M3_THREADS]
-  const int ty = threadIdx.x/tw, tx = threadIdx.x - ty*tw;
-  const bool in_tile = ty < th;          // the workgroup is padded to whole waves
-  const int iraw = g.is - 1 + blockIdx.x*(tw - 2) + tx, jraw = g.js - 1 + blockIdx.y*(th - 2) + ty;
-  const bool col_ok = in_tile && iraw <= g.ie + 1 && jraw <= g.je + 1;      // x3 faces: [is-1,ie+1] x [js-1,je+1]
-  const int i = iraw <= g.ie + 1 ? iraw : g.ie + 1, j = jraw <= g.je + 1 ? jraw : g.je + 1;   // clamped lanes compute, never store
-  const int m = blockIdx.z/a.nchunk;
-  const int ch = blockIdx.z - m*a.nchunk;
-  const int k0 = a.kA + ch*a.ckl;                                   // first cell plane of this chunk
-  const int k1 = (k0 + a.ckl - 1 < a.kB) ? k0 + a.ckl - 1 : a.kB;   // last cell plane
-  const bool wtop = a.top && (k1 == a.kB);                          // this chunk owns the x3-faces kB+1
-  const bool edge_ok = col_ok && tx >= 1 && ty >= 1;                // corner EMFs at (i-1/2, j-1/2, .)
-  const bool own = edge_ok && tx <= tw - 2 && ty <= th - 2;         // owner of cell (., j, i) and its low faces
-  const bool cell_ok = own && i <= g.ie && j <= g.je;
-  const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
-  const bool p2 = AKMI_POW2DX && is_pow2(dx1) && is_pow2(dx2) && is_pow2(dx3);   // wave-uniform: x/dx == ldexp(x, n)
-  const int ndx1 = pow2_shift(dx1), ndx2 = pow2_shift(dx2), ndx3 = pow2_shift(dx3);
-#define DIVX(x, q) (p2 ? ldexp((x), n##q) : (x)/q)
-  const double bdt = to_sgpr(beta_dt_of(u.beta_dt, u.dtp));
-  const int copy = u.copy_u1;
-  constexpr int NV = 7;
-  const long cs = (long)g.N3*g.N2*g.N1;
-  const long N1 = g.N1, PS = (long)g.N2*g.N1, PS1 = (long)g.N2*(g.N1 + 1), PS2 = (long)(g.N2 + 1)*g.N1;   // row / plane strides
-  unsigned oc = (((unsigned)k0*(unsigned)g.N2 + (unsigned)j)*(unsigned)g.N1 + (unsigned)i)*8u;            // (.., N2, N1)
-  unsigned o1 = (((unsigned)k0*(unsigned)g.N2 + (unsigned)j)*(unsigned)(g.N1 + 1) + (unsigned)i)*8u;      // (.., N2, N1+1)
-  unsigned o2 = (((unsigned)k0*(unsigned)(g.N2 + 1) + (unsigned)j)*(unsigned)g.N1 + (unsigned)i)*8u;      // (.., N2+1, N1)
-  const unsigned PS8 = (unsigned)PS*8u, PS18 = (unsigned)PS1*8u, PS28 = (unsigned)PS2*8u;
-  const double *wb_ = a.w0 + (size_t)m*g.nvar*cs, *bb_ = a.bcc0 + (size_t)m*3*cs;
-  const double *bz_ = a.bz + (size_t)m*(g.N3 + 1)*PS;
-  const double *f1_ = a.flx1 + (size_t)m*g.nvar*g.N3*PS1, *f2_ = a.flx2 + (size_t)m*g.nvar*g.N3*PS2;
-  const char *em_ = reinterpret_cast<const char *>(a.emf + (size_t)m*cs);     // e3x1; the others by byte distance
-  double *b01_ = a.b0x1f + (size_t)m*g.N3*PS1, *b02_ = a.b0x2f + (size_t)m*g.N3*PS2, *b03_ = a.b0x3f + (size_t)m*(g.N3 + 1)*PS;
-  double *b11_ = a.b1x1f + (size_t)m*g.N3*PS1, *b12_ = a.b1x2f + (size_t)m*g.N3*PS2, *b13_ = a.b1x3f + (size_t)m*(g.N3 + 1)*PS;
-  const double *acc_ = u.acc + (size_t)m*g.nvar*cs;
-  double *u0_ = u.u0 + (size_t)m*g.nvar*cs, *u1_ = u.u1 + (size_t)m*g.nvar*cs;
-  // x3-aligned order of the march: d, vz, vx, vy, e (w0 variables 0, 3, 1, 2, 4), bx, by (bcc0 variables 0, 1);
-  // dk: plane relative to the lane offset
-  auto ldq = [&](int n, const double *wq, const double *bq, long dk, unsigned o) -> double {
-    return n == 0 ? ldu(wq + dk*PS, o) : n == 1 ? ldu(wq + 3*cs + dk*PS, o) : n == 2 ? ldu(wq + cs + dk*PS, o)
-         : n == 3 ? ldu(wq + 2*cs + dk*PS, o) : n == 4 ? ldu(wq + 4*cs + dk*PS, o) : n == 5 ? ldu(bq + dk*PS, o)
-         : ldu(bq + cs + dk*PS, o);
-  };
-  auto emf = [&](const char *eq, unsigned arr) -> const double * { return reinterpret_cast<const double *>(eq + arr); };
-  // ---- marching state of the x3 sweep: last two cells and pending left state (parked in LDS), previous face flux
-#if AKMI_M3_PARK
-#define W0_(n) park[(n)*M3_THREADS]
-#define W1_(n) park[(NV + (n))*M3_THREADS]
-#define PL_(n) park[(2*NV + (n))*M3_THREADS]
-#else
-  double W0r[NV], W1r[NV], PLr[NV];
-#define W0_(n) W0r[n]
-#define W1_(n) W1r[n]
-#define PL_(n) PLr[n]
-#endif
-  double FP[5], nx[NV];
-#pragma unroll
-  for (int n = 0; n < NV; ++n) {
-    const double qa = ldq(n, wb_, bb_, -2, oc), qb = ldq(n, wb_, bb_, -1, oc), qc = ldq(n, wb_, bb_, 0, oc);
-    double pl, dummy;
-    plm(qa, qb, qc, pl, dummy);
-    W0_(n) = qb; W1_(n) = qc; PL_(n) = pl;
-    nx[n] = ldq(n, wb_, bb_, 1, oc);                              // cell k0+1, consumed by the first step
-  }
-  double bx_n = ldu(bz_, oc);                                     // face field of the first face
-#pragma unroll
-  for (int n = 0; n < 5; ++n) FP[n] = 0.0;
-  // ---- CornerE: own edges of the previous plane and the operands of the corner formulas that belong to plane k-1
-  double e1p = 0.0, e2p = 0.0, e3p = 0.0;
-  double x2_km = 0.0, x1_km = 0.0, c1_mm = 0.0, c1_m0 = 0.0, c2_mm = 0.0, c2_m0 = 0.0;
-  bool f1_km = false, f2_km = false;          // mass flux >= 0 on the x1 / x2 face of plane k-1
-  if (edge_ok) {
-    f1_km = ldu(f1_ - PS1, o1) >= 0.0;
-    f2_km = ldu(f2_ - PS2, o2) >= 0.0;
-    x2_km = ldu(emf(em_, a.o_e1x2) - PS, oc);
-    x1_km = ldu(emf(em_, a.o_e2x1) - PS, oc);
-    c1_mm = ldu(emf(em_, a.o_c1) - PS - N1, oc); c1_m0 = ldu(emf(em_, a.o_c1) - PS, oc);
-    c2_mm = ldu(emf(em_, a.o_c2) - PS - 1, oc); c2_m0 = ldu(emf(em_, a.o_c2) - PS, oc);
-  }
-  for (int k = k0; k <= k1 + 1; ++k) {
-    const int t = k - k0;
-    // array bases of this step (opaque: see the comment above the kernel)
-    const double *wq = sgpr_opaque(wb_), *bq = sgpr_opaque(bb_), *bzq = sgpr_opaque(bz_);
-    const double *f1q = sgpr_opaque(f1_), *f2q = sgpr_opaque(f2_), *accq = sgpr_opaque(acc_);
-    const char *eq = sgpr_opaque(em_);
-    double *u0q = sgpr_opaque(u0_), *u1q = sgpr_opaque(u1_);
-    double *b01 = sgpr_opaque(b01_), *b02 = sgpr_opaque(b02_), *b03 = sgpr_opaque(b03_);
-    double *b11 = sgpr_opaque(b11_), *b12 = sgpr_opaque(b12_), *b13 = sgpr_opaque(b13_);
-    // ---- x3 face k: reconstruction from the window and the cell fetched during the previous step
-    double L[NV], R[NV];
-#pragma unroll
-    for (int n = 0; n < NV; ++n) {
-      double qln;
-      L[n] = PL_(n);
-      const double w0v = W0_(n), w1v = W1_(n);
-      plm(w0v, w1v, nx[n], qln, R[n]);
-      W0_(n) = w1v; W1_(n) = nx[n];
-      PL_(n) = qln;
-    }
-    const double bxi = bx_n;
-    // ---- every load of the step in one group, in the order of use: update operands of cell k-1, own operands of
-    //      the corner formulas, the face fields CT updates, the cell and face field of the NEXT step
-    const bool upd = cell_ok && t > 0;                            // this face finishes cell k-1
-    double pa[5], pu[5], pu1[5];
-#define M3_LOAD_UPD()                                                                                              \
-    if (upd) {                                                                                                     \
-      _Pragma("unroll")                                                                                            \
-      for (int n = 0; n < 5; ++n) { pa[n] = ldu(accq + n*cs - PS, oc); pu[n] = ldu(u0q + n*cs - PS, oc); }         \
-      if (!copy) {                                                                                                 \
-        _Pragma("unroll")                                                                                          \
-        for (int n = 0; n < 5; ++n) pu1[n] = ldu(u1q + n*cs - PS, oc);                                             \
-      }                                                                                                            \
-    }
-#if !AKMI_M3_UPD_LATE
-    M3_LOAD_UPD()
-#endif
-    // own operands (every thread of the tile: row 0 / column 0 provide them to their neighbours)
-    const double f1v = ldu(f1q, o1), f2v = ldu(f2q, o2);
-    const double c1_00 = ldu(emf(eq, a.o_c1), oc), c2_00 = ldu(emf(eq, a.o_c2), oc), c_00 = ldu(emf(eq, a.o_c3), oc);
-    const double x2_k = ldu(emf(eq, a.o_e1x2), oc), x1_k = ldu(emf(eq, a.o_e2x1), oc);
-    const double x2_i = ldu(emf(eq, a.o_e3x2), oc), x1_j = ldu(emf(eq, 0u), oc);
-    const bool ct3 = own && i <= g.ie && j <= g.je && (k <= k1 || wtop);
-    const bool ct1 = own && k > k0 && j <= g.je, ct2 = own && k > k0 && i <= g.ie;
-    double pb03 = 0.0, pb13 = 0.0, pb01 = 0.0, pb11 = 0.0, pb02 = 0.0, pb12 = 0.0;
-    if (ct3) { pb03 = ldu(b03, oc); if (!copy) pb13 = ldu(b13, oc); }
-    if (ct1) { pb01 = ldu(b01 - PS1, o1); if (!copy) pb11 = ldu(b11 - PS1, o1); }
-    if (ct2) { pb02 = ldu(b02 - PS2, o2); if (!copy) pb12 = ldu(b12 - PS2, o2); }
-    const bool more = k <= k1;                                    // a next step exists: its cell k+2 is inside the array
-    if (more) {
-#pragma unroll
-      for (int n = 0; n < NV; ++n) nx[n] = ldq(n, wq, bq, 2, oc);
-      bx_n = ldu(bzq + PS, oc);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- HLLD
-#if AKMI_M3_WHATIF & 2      // timing experiment (wrong results): the march without its Riemann solve
-    Cons1D fl;
-    fl.d = L[0] + R[0]; fl.mx = L[1] + R[1]; fl.my = L[2] + R[2]; fl.mz = L[3] + R[3]; fl.e = L[4] + R[4];
-    fl.by = L[5] + R[5] + bxi; fl.bz = L[6] + R[6];
-#else
-    const Cons1D fl = riemann_mhd_e<RS, AKMI_M3_EO != 0, AKMI_M3_FM != 0>(
-        eos, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1], R[2], R[3], R[4], R[5], R[6], bxi);
-#endif
-    const double x3_e2 = -fl.by, x3_e1 = fl.bz;                   // e2x3, e1x3 of this face (hlld_mhd.hpp:346-347)
-    const bool f1_k = f1v >= 0.0, f2_k = f2v >= 0.0, f3_k = fl.d >= 0.0;
-    if (in_tile) {
-      XS(P_E1X3, ty, tx) = x3_e1; XS(P_E2X3, ty, tx) = x3_e2;
-      XS(P_C1, ty, tx) = c1_00; XS(P_C2, ty, tx) = c2_00; XS(P_C3, ty, tx) = c_00;
-      XS(P_X32, ty, tx) = x2_i; XS(P_X31, ty, tx) = x1_j;
-      FLG(ty, tx) = (f1_k ? 1 : 0) | (f2_k ? 2 : 0) | (f3_k ? 4 : 0);
-    }
-    // x3 flux in natural component order d, m1, m2, m3, E  (ivx = 3, ivy = 1, ivz = 2)
-    const double fv[5] = {fl.d, fl.my, fl.mz, fl.mx, fl.e};
-#define M3_UPDATE()                                                                                                \
-    if (upd) {                                                                                                     \
-      _Pragma("unroll")                                                                                            \
-      for (int n = 0; n < 5; ++n) {                                                                                \
-        double divf = pa[n];                                                                                       \
-        divf += DIVX(dl[n], dx3);                                                                                  \
-        const double u0v = pu[n];                                                                                  \
-        const double u1v = copy ? u0v : pu1[n];                                                                    \
-        rk_store_u(u0q + n*cs - PS, u1q + n*cs - PS, copy, oc, u0v, u.gam0*u0v + u.gam1*u1v - bdt*divf);           \
-      }                                                                                                            \
-    }
-    double dl[5];
-#pragma unroll
-    for (int n = 0; n < 5; ++n) { dl[n] = fv[n] - FP[n]; FP[n] = fv[n]; }
-#if AKMI_M3_UPD_LATE
-    M3_LOAD_UPD()             // consumed at the end of the step, after the two exchanges
-#else
-    M3_UPDATE()
-#endif
-    M3_SYNC();
-    double e1 = 0.0, e2 = 0.0, e3 = 0.0;
-    if (edge_ok) {
-      const int fj = FLG(ty - 1, tx), fi = FLG(ty, tx - 1);
-      const bool f1_jm = fj & 1, f3_jm = fj & 4, f2_im = fi & 2, f3_im = fi & 4;
-      const double c1_0m = XS(P_C1, ty - 1, tx), c2_0m = XS(P_C2, ty, tx - 1);
-      {  // E1 (mhd_corner_e.cpp:340-363)
-        const double x3_jm = XS(P_E1X3, ty - 1, tx), x3_j = x3_e1;
-        double e1_l3 = upw(f2_km, x3_jm, c1_mm, x3_j, c1_m0);
-        double e1_r3 = upw(f2_k, x3_jm, c1_0m, x3_j, c1_00);
-        double e1_l2 = upw(f3_jm, x2_km, c1_mm, x2_k, c1_0m);
-        double e1_r2 = upw(f3_k, x2_km, c1_m0, x2_k, c1_00);
-        e1 = 0.25*(e1_l3 + e1_r3 + e1_l2 + e1_r2 + x2_km + x2_k + x3_jm + x3_j);
-      }
-      {  // E2 (:365-388)
-        const double x3_im = XS(P_E2X3, ty, tx - 1), x3_i = x3_e2;
-        double e2_l3 = upw(f1_km, x3_im, c2_mm, x3_i, c2_m0);
-        double e2_r3 = upw(f1_k, x3_im, c2_0m, x3_i, c2_00);
-        double e2_l1 = upw(f3_im, x1_km, c2_mm, x1_k, c2_0m);
-        double e2_r1 = upw(f3_k, x1_km, c2_m0, x1_k, c2_00);
-        e2 = 0.25*(e2_l3 + e2_r3 + e2_l1 + e2_r1 + x3_im + x3_i + x1_km + x1_k);
-      }
-      {  // E3 (:390-413)
-        const double x2_im = XS(P_X32, ty, tx - 1), x1_jm = XS(P_X31, ty - 1, tx);
-        const double c_mm = XS(P_C3, ty - 1, tx - 1), c_m0 = XS(P_C3, ty - 1, tx), c_0m = XS(P_C3, ty, tx - 1);
-        double e3_l2 = upw(f1_jm, x2_im, c_mm, x2_i, c_m0);
-        double e3_r2 = upw(f1_k, x2_im, c_0m, x2_i, c_00);
-        double e3_l1 = upw(f2_im, x1_jm, c_mm, x1_j, c_0m);
-        double e3_r1 = upw(f2_k, x1_jm, c_m0, x1_j, c_00);
-        e3 = 0.25*(e3_l1 + e3_r1 + e3_l2 + e3_r2 + x2_im + x2_i + x1_jm + x1_j);
-      }
-      f1_km = f1_k; f2_km = f2_k; x2_km = x2_k; x1_km = x1_k;
-      c1_mm = c1_0m; c1_m0 = c1_00; c2_mm = c2_0m; c2_m0 = c2_00;
-    }
-    const int p3 = t & 1;
-    if (in_tile) { XS(P_E1, ty, tx) = e1; XS(P_E2, ty, tx) = e2; XS(P_E3A + p3, ty, tx) = e3; }
-    M3_SYNC();
-    if (ct3) {                                                    // x3-face of plane k (mhd_ct.cpp:67-77)
-      const double b0v = pb03, b1v = copy ? b0v : pb13;
-      double b = u.gam0*b0v + u.gam1*b1v;
-      b -= DIVX(bdt*(XS(P_E2, ty, tx + 1) - e2), dx1);
-      b += DIVX(bdt*(XS(P_E1, ty + 1, tx) - e1), dx2);
-      rk_store_u(b03, b13, copy, oc, b0v, b);
-    }
-    const int q3 = P_E3A + (p3 ^ 1);                              // the e3 plane of k-1
-    if (ct1) {                                                    // x1-face of plane k-1 (:45-54)
-      const double b0v = pb01, b1v = copy ? b0v : pb11;
-      double b = u.gam0*b0v + u.gam1*b1v;
-      b -= DIVX(bdt*(XS(q3, ty + 1, tx) - e3p), dx2);
-      b += DIVX(bdt*(e2 - e2p), dx3);
-      rk_store_u(b01 - PS1, b11 - PS1, copy, o1, b0v, b);
-    }
-    if (ct2) {                                                    // x2-face of plane k-1 (:56-65)
-      const double b0v = pb02, b1v = copy ? b0v : pb12;
-      double b = u.gam0*b0v + u.gam1*b1v;
-      b += DIVX(bdt*(XS(q3, ty, tx + 1) - e3p), dx1);
-      b -= DIVX(bdt*(e1 - e1p), dx3);
-      rk_store_u(b02 - PS2, b12 - PS2, copy, o2, b0v, b);
-    }
-#if AKMI_M3_UPD_LATE
-    M3_UPDATE()
-#endif
-    e1p = e1; e2p = e2; e3p = e3;
-    oc += PS8; o1 += PS18; o2 += PS28;
-  }
-#undef M3_LOAD_UPD
-#undef M3_SYNC
-#undef M3_UPDATE
-#undef XS
-#undef FLG
-#undef DIVX
-#undef W0_
-#undef W1_
-#undef PL_
-}
-
-struct M3Tile { int tw, th, n1, n2, threads; };
-static M3Tile m3_tile(int e1, int e2) {
-  // tile of tw x th threads, (tw-2) x (th-2) of them owners; e1 x e2 = positions to own (nx1+1, nx2+1).  Lanes
-  // launched, weighted like ct_tile(): short rows cost coalescing.  AKMI_M3_TILE=tw,th pins the shape.
-  static int f_tw = -1, f_th = 0;
-  if (f_tw < 0) {
-    const char *e = getenv("AKMI_M3_TILE");
-    f_tw = 0;
-    if (e && sscanf(e, "%dx%d", &f_tw, &f_th) != 2) f_tw = 0;
-    if (f_tw < 3 || f_th < 3 || f_tw*f_th > M3_THREADS) f_tw = 0;
-  }
-  M3Tile best{0, 0, 0, 0, 0};
-  double best_cost = -1.0;
-  for (int tw = 3; tw <= 130; ++tw)
-    for (int th = 3; th <= 64; ++th) {
-      if (tw*th > M3_THREADS) break;
-      if (f_tw > 0 && (tw != f_tw || th != f_th)) continue;
-      const int n1 = (e1 + tw - 3)/(tw - 2), n2 = (e2 + th - 3)/(th - 2);
-      const int threads = (tw*th + 63)/64*64;
-      const double cost = (double)n1*n2*threads*(1.0 + 20.0/tw);
-      if (best_cost < 0 || cost < best_cost) { best = M3Tile{tw, th, n1, n2, threads}; best_cost = cost; }
-    }
-  return best;
-}
-
-// false: the pack is outside what the kernel addresses with its folded 32-bit offsets (the caller takes the
-// four-kernel sequence)
-static bool march3ct_fits(const Geo &g) {
-  const size_t cs8 = (size_t)g.N3*g.N2*g.N1*8;
-  return (size_t)(g.nvar > 7 ? g.nvar : 7)*(cs8 + 256) + (size_t)(g.N2 + 1)*(g.N1 + 1)*64 < ((size_t)1 << 32);
-}
-
-static int launch_march3ct(const Geo &g, const Scheme &sc, M3Args a, const StageWs &w, const UpdArgs &u, hipStream_t st) {
-  if (sc.iso || sc.recon != 1 || sc.rsolver != AKMI_RS_HLLD) { set_error("march3ct: PLM + HLLD, ideal gas"); return AKMI_FAIL; }
-  const M3Tile tl = m3_tile(g.nx1 + 1, g.nx2 + 1);
-  if (tl.tw == 0) { set_error("march3ct: no tile shape"); return AKMI_FAIL; }
-  static const int ckl_env = getenv("AKMI_M3_CKL") ? atoi(getenv("AKMI_M3_CKL")) : 0;      // experiments
-  const int ckl = ckl_env > 0 ? ckl_env : march_len((long)tl.n1*tl.n2, a.kB - a.kA + 1, g.nmb, CKL, AKMI_M3_WGS);
-  a.ckl = ckl; a.nchunk = cdiv(a.kB - a.kA + 1, ckl); a.tw = tl.tw; a.th = tl.th;
-  // the face / cell-centred EMF arrays of the workspace by their distance from e3x1 (carved in this order)
-  a.emf = w.efc[0];
-  auto dist = [&](const double *q) { return (unsigned)((const char *)q - (const char *)w.efc[0]); };
-  a.o_e2x1 = dist(w.efc[1]); a.o_e1x2 = dist(w.efc[2]); a.o_e3x2 = dist(w.efc[3]);
-  a.o_c1 = dist(w.ecc[0]); a.o_c2 = dist(w.ecc[1]); a.o_c3 = dist(w.ecc[2]);
-  const size_t plane = (size_t)tl.tw*tl.th;
-  const size_t lds = ((M3_PLANES + 1)*plane + (size_t)M3_PARK*M3_THREADS)*sizeof(double);
-  static size_t granted = 64*1024;
-  if (lds > granted) {
-    if (hipFuncSetAttribute((const void *)k_march3ct<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      set_error("march3ct: %zu bytes of LDS refused", lds);
-      return AKMI_FAIL;
-    }
-    granted = lds;
-  }
-  dim3 grid(tl.n1, tl.n2, a.nchunk*g.nmb), block(tl.threads);
-  k_march3ct<3><<<grid, block, lds, st>>>(g, sc.eos, a, u);
-  AKMI_CHECK_LAUNCH("march3ct");
-  return AKMI_COMPLETE;
 }
 
 // CT (mhd_ct.cpp:23-80) with CopyCons for B folded in at stage 1 (b1 <- b0 old)
@@ -2102,17 +1618,6 @@ __global__ void k_init_dt3(double *dt3) {
   if (threadIdx.x < 3) dt3[threadIdx.x] = (double)FLT_MAX;
 }
 
-// ---------------------------------------------------------------------------------------
-// A/B knob: unused dynamic LDS added to a launch caps how many of its workgroups a CU holds (the x1
-// sweep has no LDS of its own, a march workgroup 53 KB), leaving registers and LDS for the workgroups of
-// a memory-bound kernel running beside it on the helper stream of the slab pipeline.
-// AKMI_X1_LDS / AKMI_MARCH_LDS = bytes.
-static size_t extra_lds(int which) {
-  static const size_t v[2] = {getenv("AKMI_X1_LDS") ? (size_t)atol(getenv("AKMI_X1_LDS")) : 0,
-                              getenv("AKMI_MARCH_LDS") ? (size_t)atol(getenv("AKMI_MARCH_LDS")) : 0};
-  return v[which];
-}
-
 template <int DIR, bool MHD, bool ECC>
 static int launch_sweep(const Geo &g, const Scheme &sc, const SweepArgs &a, hipStream_t st) {
   int nk = a.ku - a.kl + 1;
@@ -2124,7 +1629,7 @@ static int launch_sweep(const Geo &g, const Scheme &sc, const SweepArgs &a, hipS
     const long np = (long)(a.ju - a.jl + 1)*(share ? a.iu - a.il + 2 : a.iu - a.il + 1 + (ECC ? 1 : 0));
     const long per_wg = (long)(share ? SX - 1 : SX)*SY;
     dim3 grid((unsigned)((np + 1 + per_wg - 1)/per_wg), 1, nk*g.nmb);
-    k_sweep<DIR, decltype(R)::value, MHD, ECC, decltype(S)::value><<<grid, block, extra_lds(0), st>>>(
+    k_sweep<DIR, decltype(R)::value, MHD, ECC, decltype(S)::value><<<grid, block, 0, st>>>(
         g, sc.eos, a, nk);
     return AKMI_COMPLETE;
   });
@@ -2151,11 +1656,10 @@ static int launch_sweep_update(const Geo &g, const Scheme &sc, const SweepArgs &
       long np = (long)(a.ju - a.jl + 1)*(MODE == 2 ? a.iu - a.il + 1 : g.N1);          // flattened rows (sweep_update_body)
       const unsigned nb = (unsigned)((np + SX*SY - 1)/(SX*SY));
       const int nc = a.ku - a.kl > 0 ? a.ku - a.kl : 1;
-      static const int ml_env = getenv("AKMI_ML3") ? atoi(getenv("AKMI_ML3")) : 0;        // experiments
       // resident workgroups per CU: the PLM march is compiled for AKMI_X3_WAVES waves per SIMD, the
       // five-point schemes for two
       const int res3 = (sc.recon >= AKMI_RECON_PPM4) ? 2 : AKMI_X3_WAVES;
-      ml = ml_env > 0 ? ml_env : march_len(nb, nc, g.nmb, ML, res3);
+      ml = march_len(nb, nc, g.nmb, ML, res3);
       grid = dim3(nb, cdiv(nc, ml), g.nmb);
     } else {
       long np = (long)(a.ku - a.kl + 1)*(MODE == 2 ? a.iu - a.il + 1 : g.N1);          // flattened (k,i)
@@ -2167,7 +1671,7 @@ static int launch_sweep_update(const Geo &g, const Scheme &sc, const SweepArgs &
     constexpr int D = (DIR == 0) ? 1 : DIR;
     rc = dispatch_scheme_eos<MHD>(sc, [&](auto R, auto S) {
       k_sweep_update<D, decltype(R)::value, MHD, MODE, USEACC, decltype(S)::value>
-          <<<grid, block, extra_lds(1), st>>>(g, sc.eos, a, u, ml);
+          <<<grid, block, 0, st>>>(g, sc.eos, a, u, ml);
       return AKMI_COMPLETE;
     });
   }
@@ -2197,9 +1701,7 @@ static int launch_sweep_update(const Geo &g, const Scheme &sc, const SweepArgs &
 #ifndef AKMI_X12S_EO2
 #define AKMI_X12S_EO2 1
 #endif
-// SNAP: copy the x3 face field into the workspace on the way (UpdArgs::bz_snap; in-place stages followed by k_march3ct)
-// BITS: sign words instead of the two mass-flux arrays (MfBits)
-template <int RS, bool SNAP, bool BITS>
+template <int RS>
 __global__ void __launch_bounds__(SX*SY, AKMI_X12S_WAVES)
 k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
   constexpr int NV = 7, NW = 2, NT = SX*SY;
@@ -2285,10 +1787,6 @@ k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
       for (int n = 0; n < NV; ++n) qn[n] = ldu(base2(n) + stq, off);
     }
     const double bx2 = ldu(bx2m, do_x2 ? foff2 : foff2 - fst28);
-    // x3 face field of row jr on its way into the workspace (UpdArgs::bz_snap): face (k, jr, i) of the (N3+1, N2, N1)
-    // array has the byte offset of cell (k, jr, i)
-    [[maybe_unused]] double bz_v = 0.0;
-    if constexpr (SNAP) bz_v = ldu(u.bz_src + (size_t)m*(g.N3 + 1)*g.N2*g.N1, orow);
     // ---- x1 face on the low side of cell (k, jr, i): the cell is W_(.,0) of the march
     double f1d, f1x, f1y, f1z, f1e, f1by, f1bz;
     double dF1[5];
@@ -2320,16 +1818,8 @@ k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
       dF1[2] = AKMI_LANE_ABOVE(f1y) - f1y;
       dF1[3] = AKMI_LANE_ABOVE(f1z) - f1z;
       dF1[4] = AKMI_LANE_ABOVE(f1e) - f1e;
-      if constexpr (BITS) {
-        if (do_x1) {
-          const unsigned long long bits = __ballot(x1_ok && f1d >= 0.0);
-          if (lane == 0 && wv < u.mb.nw12) u.mb.w1[((size_t)m*u.mb.nj1 + (jr - u.mb.j1l))*u.mb.nw12 + wv] = bits;
-        }
-      }
       if (do_x1 && x1_ok) {
-#if !(AKMI_WHATIF & 4)
-        if constexpr (!BITS) stu(mf1, foff1, f1d);
-#endif
+        stu(mf1, foff1, f1d);
         stu(a1.ey + (size_t)m*cs, orow, -f1by);
         stu(a1.ez + (size_t)m*cs, orow, f1bz);
       }
@@ -2348,16 +1838,8 @@ k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
     }
     Cons1D f2 = riemann_mhd_e<RS, AKMI_X12S_EO2 != 0, AKMI_X12S_FM != 0>(eos, L[0], L[1], L[2], L[3], L[4], L[5], L[6], R[0], R[1],
                                   R[2], R[3], R[4], R[5], R[6], bx2);
-    if constexpr (BITS) {
-      if (do_x2 && (t < ml || s == shi)) {
-        const unsigned long long bits = __ballot(x2_ok && f2.d >= 0.0);
-        if (lane == 0 && wv < u.mb.nw12) u.mb.w2[((size_t)m*u.mb.nj2 + (s - u.mb.j2l))*u.mb.nw12 + wv] = bits;
-      }
-    }
     if (do_x2 && x2_ok && (t < ml || s == shi)) {
-#if !(AKMI_WHATIF & 4)
-      if constexpr (!BITS) stu(mf2, foff2, f2.d);
-#endif
+      stu(mf2, foff2, f2.d);
       stu(a2.ey + (size_t)m*cs, off, -f2.by);
       stu(a2.ez + (size_t)m*cs, off, f2.bz);
     }
@@ -2381,9 +1863,6 @@ k_sweep12s(Geo g, FaceEos eos, SweepArgs a1, SweepArgs a2, UpdArgs u, int ml) {
         }
       }
     }
-    if constexpr (SNAP) {
-      if (do_x1 && inner && k >= g.ks) stu(u.bz_snap + (size_t)m*(g.N3 + 1)*g.N2*g.N1, orow, bz_v);
-    }
 #pragma unroll
     for (int n = 0; n < 5; ++n) FP_(n) = fv[n];
     off += st8; foff2 += fst28; foff1 += fst18;
@@ -2399,14 +1878,11 @@ static int launch_sweep12s(const Geo &g, const Scheme &sc, const SweepArgs &a1, 
   const long nwaves = (np + (SX - 4) - 1)/(SX - 4);
   const unsigned nb = (unsigned)((nwaves + SY - 1)/SY);
   const int nc = a2.ju - a2.jl > 0 ? a2.ju - a2.jl : 1;
-  static const int ml_env = getenv("AKMI_ML12") ? atoi(getenv("AKMI_ML12")) : 0;      // experiments
-  const int ml = ml_env > 0 ? ml_env : march_len(nb, nc, g.nmb, ML, 3);
+  const int ml = march_len(nb, nc, g.nmb, ML, 3);
   dim3 grid(nb, cdiv(nc, ml), g.nmb), block(SX, SY);
   const int rs = sc.rsolver;
   if (sc.iso || sc.recon != 1 || rs != AKMI_RS_HLLD) { set_error("sweep12s: PLM + HLLD, ideal gas"); return AKMI_FAIL; }
-  if (u.bz_snap) k_sweep12s<3, true, false><<<grid, block, 0, st>>>(g, sc.eos, a1, a2, u, ml);      // (never with sign words)
-  else if (u.mb.w1) k_sweep12s<3, false, true><<<grid, block, 0, st>>>(g, sc.eos, a1, a2, u, ml);
-  else k_sweep12s<3, false, false><<<grid, block, 0, st>>>(g, sc.eos, a1, a2, u, ml);
+  k_sweep12s<3><<<grid, block, 0, st>>>(g, sc.eos, a1, a2, u, ml);
   AKMI_CHECK_LAUNCH("sweep12s");
   return AKMI_COMPLETE;
 }
@@ -2676,7 +2152,7 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
   if (!(phases & AKMI_PHASE_C2P)) cp.enable = 0;
   const int ndim = g.three_d ? 3 : (g.multi_d ? 2 : 1);
   // dt_dev: beta_dt is the RK weight beta, the kernels multiply it with *dt_dev (akmi_*_stage_fused_dt)
-  UpdArgs u{gam0, gam1, beta_dt, u0, u1, w.flx1, w.flx2, copy_u1, w.acc, dt_dev, MfBits{}, nullptr, nullptr};
+  UpdArgs u{gam0, gam1, beta_dt, u0, u1, w.flx1, w.flx2, copy_u1, w.acc, dt_dev};
   // copy_u1 == 2 (out-of-place first stage): the new state lands in u1 / b1, which is what the c2p
   // of the active cells has to read
   double *un = copy_u1 == 2 ? u1 : u0;
@@ -2736,41 +2212,12 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
   static const bool env_one = getenv("AKMI_ONE_STREAM") && atoi(getenv("AKMI_ONE_STREAM")) != 0;
   // AKMI_HYDRO_ONE_KERNEL=0: the three-kernel sweep/march sequence also for hydro DC/PLM (A/B runs)
   static const bool hyd_one = !(getenv("AKMI_HYDRO_ONE_KERNEL") && atoi(getenv("AKMI_HYDRO_ONE_KERNEL")) == 0);
-  static const bool x12s = !getenv("AKMI_X12") || atoi(getenv("AKMI_X12")) == 2;
   // (the slab pipeline covers the whole-stage call and the sweeps + CornerE + CT call; the other partial phases of a
   //  rank with off-rank neighbours run one slab)
   const bool slabs_ok = phases == AKMI_PHASE_ALL || phases == (AKMI_PHASE_SWEEPS | AKMI_PHASE_EMF_CT);
   const int T = !slabs_ok ? g.nx3 : (env_slab > 1 ? env_slab : AKMI_SLAB);
   const int S = (g.nx3 + T - 1)/T;
   if (S > MAX_SLABS) { set_error("too many slabs"); return AKMI_FAIL; }
-  // sign words instead of mass-flux arrays (MfBits): the 3-D PLM+HLLD stage in one slab, no passive scalars; the
-  // words live in the memory of the (then unused) mass-flux arrays.  AKMI_MFBITS=0: A/B switch
-  // Measured (profiles/r03_mfbits_ab.txt): x3 march 886 -> 838-857 us, but k_corner_ct 643 -> 649-658 (its seven loads
-  // stay loads, plus the index arithmetic of the look-up) and k_sweep12s +10: +0..3 % on the bench, within the
-  // run-to-run spread.  Bit-identical; OFF by default (AKMI_MFBITS=1 switches it on).
-  static const bool env_bits = getenv("AKMI_MFBITS") && atoi(getenv("AKMI_MFBITS")) != 0;
-  if (MHD && env_bits && S == 1 && x12s && sc.recon == 1 && !sc.iso && sc.rsolver == AKMI_RS_HLLD && g.nvar == 5 &&
-      w.flx1) {
-    MfBits &b = u.mb;
-    b.w1 = reinterpret_cast<unsigned long long *>(w.flx1);
-    b.w2 = reinterpret_cast<unsigned long long *>(w.flx2);
-    b.w3 = reinterpret_cast<unsigned long long *>(w.flx3);
-    b.j1l = a1.jl; b.nj1 = a1.ju - a1.jl + 1;
-    b.j2l = a2.jl; b.nj2 = a2.ju - a2.jl + 1;
-    b.kl12 = a2.kl;                                           // one slab: kA - 1 = ks - 1
-    b.nw12 = (int)(((long)(a2.ku - a2.kl + 1)*g.N1 + (SX - 4) - 1)/(SX - 4));
-    b.j3l = a3.jl; b.k3l = a3.kl; b.nk3 = a3.ku - a3.kl + 1;
-    const long np3 = (long)(a3.ju - a3.jl + 1)*g.N1;
-    b.nw3 = (int)((np3 + SX*SY - 1)/(SX*SY))*SY;
-  }
-  // two-kernel pass A (k_sweep12s + k_march3ct: x3 flux, update, CornerE and CT in one k-march) when the call covers
-  // sweeps AND CornerE/CT of a one-slab PLM+HLLD pack.  Bit-identical, built and measured in round 4 -- and it LOSES
-  // (k_march3ct 1.83-1.89 ms against 0.89 + 0.62 ms for the x3 march + k_corner_ct; 9.5 GB against 8.5 GB: the halo
-  // columns a tile needs for its neighbours' x3 EMFs are re-read from HBM; profiles/r04_march3ct.txt), so it is an
-  // option: AKMI_M3CT=1 selects it (tests/test_gpu_options.py keeps it bit-identical).
-  static const bool env_m3 = getenv("AKMI_M3CT") && atoi(getenv("AKMI_M3CT")) != 0;
-  const bool m3 = MHD && env_m3 && do_sweeps && do_emf && S == 1 && x12s && sc.recon == 1 && !sc.iso &&
-                  sc.rsolver == AKMI_RS_HLLD && g.nvar == 5 && !u.mb.w1 && march3ct_fits(g);
   const bool two = (S > 1) && (MHD || cp.enable) && !env_one;
   hipStream_t sb = st;
   if (two) {
@@ -2789,14 +2236,8 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
     const int ckl = march_len((long)tl.n1*tl.n2, kB(s) - kA(s) + 1, g.nmb, CKL);
     const int nchunk = cdiv(kB(s) - kA(s) + 1, ckl);
     dim3 grid(tl.n1, tl.n2, nchunk*g.nmb), block(tl.threads);
-    if (u.mb.w1)
-      k_corner_ct<true><<<grid, block, 7*tl.tw*tl.th*sizeof(double), sb>>>(
-          g, u.mb, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5], w.ecc[0], w.ecc[1], w.ecc[2],
-          w.flx1, w.flx2, w.flx3, gam0, gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f,
-          copy_u1, kA(s), kB(s), top, nchunk, ckl, tl.tw, tl.th, dt_dev);
-    else
-      k_corner_ct<false><<<grid, block, 7*tl.tw*tl.th*sizeof(double), sb>>>(
-          g, u.mb, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5], w.ecc[0], w.ecc[1], w.ecc[2],
+    k_corner_ct<<<grid, block, 7*tl.tw*tl.th*sizeof(double), sb>>>(
+          g, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5], w.ecc[0], w.ecc[1], w.ecc[2],
           w.flx1, w.flx2, w.flx3, gam0, gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f,
           copy_u1, kA(s), kB(s), top, nchunk, ckl, tl.tw, tl.th, dt_dev);
     AKMI_CHECK_LAUNCH("corner_ct");
@@ -2817,17 +2258,7 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
       // hydro DC/PLM: sweeps + update of the slab in one kernel
       rc = g.nvar > (sc.iso ? 4 : 5) ? launch_hydro_stage3d<true>(g, sc, w0, u, kA(s), kB(s), st, Mass3{w.flx1, w.flx2, w.flx3})
                       : launch_hydro_stage3d<false>(g, sc, w0, u, kA(s), kB(s), st, Mass3{nullptr, nullptr, nullptr});
-    } else if (m3) {
-      if constexpr (MHD) {
-        // in-place stage: the x3 solves of halo threads and chunk seams must see the OLD face field (k_march3ct)
-        const bool snap = copy_u1 != 2;
-        if (snap) { u.bz_src = b0x3f; u.bz_snap = w.flx3; }
-        rc = launch_sweep12s(g, sc, b1, b2, u, st);
-        M3Args ma{w0, bcc0, snap ? w.flx3 : b0x3f, nullptr, 0, 0, 0, 0, 0, 0,
-                  w.flx1, w.flx2, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f, kA(s), kB(s), 1, 0, 0, 0, 0};
-        if (rc == AKMI_COMPLETE) rc = launch_march3ct(g, sc, ma, w, u, st);
-      }
-    } else if (do_sweeps && MHD && x12s && sc.recon == 1 && !sc.iso && sc.rsolver == AKMI_RS_HLLD &&
+    } else if (do_sweeps && MHD && sc.recon == 1 && !sc.iso && sc.rsolver == AKMI_RS_HLLD &&
                g.nvar == 5) {
       // x1 sweep inside the x2 march, cells from the march's window (k_sweep12s); x3 march consumes acc
       // (the other order -- x3 march first, leaving dF3/dx3, k_sweep12s finishing the update -- was built and measured in
@@ -2851,7 +2282,6 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
     // HBM-bound chain, one slab behind (in-order on the helper stream)
     if (MHD && !do_emf) {
       if (cp.enable && (rc = c2p(s)) != AKMI_COMPLETE) return rc;      // partial phases: S == 1
-    } else if (m3) {                                                   // CornerE + CT were part of the march
     } else if (MHD) {
       if (s >= 1 && (rc = ct(s - 1)) != AKMI_COMPLETE) return rc;      // needs sweeps(s) done
       if (cp.enable && s >= 2 && (rc = c2p(s - 2)) != AKMI_COMPLETE) return rc;
@@ -2861,7 +2291,7 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
   }
   if (MHD && !do_emf) {
   } else if (MHD) {
-    if (!m3 && (rc = ct(S - 1)) != AKMI_COMPLETE) return rc;
+    if ((rc = ct(S - 1)) != AKMI_COMPLETE) return rc;
     if (cp.enable) {
       if (S >= 2 && (rc = c2p(S - 2)) != AKMI_COMPLETE) return rc;
       if ((rc = c2p(S - 1)) != AKMI_COMPLETE) return rc;
@@ -2883,10 +2313,7 @@ extern "C" {
 
 const char *akmi_build_flags(void) {
 #ifdef AKMI_EXPERIMENTS
-#define AKMI_STR2(x) #x
-#define AKMI_STR(x) AKMI_STR2(x)
-  return "experiments: AKMI_DBG_NOSOLVE=" AKMI_STR(AKMI_DBG_NOSOLVE) " AKMI_WHATIF=" AKMI_STR(AKMI_WHATIF)
-         " AKMI_M3_WHATIF=" AKMI_STR(AKMI_M3_WHATIF);
+  return "experiments";
 #else
   return "production";
 #endif

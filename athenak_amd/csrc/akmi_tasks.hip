@@ -1056,10 +1056,9 @@ static int fofc_checks(const akmi_pack *p, int recon, const char *what, bool ide
 // The flux kernels below are thread-per-face; the sweeps of the fused stage compute the same fluxes with
 // the reconstruction of a cell done once (akmi_stage.hip, sweeps_store_fluxes) and take over wherever they
 // cover the request: no passive scalars (those ride on the stored mass flux in the fused path), not the
-// kinematic "advect" solver, not the FOFC-extended ranges.  AKMI_TASK_SWEEPS=0: A/B switch.
+// kinematic "advect" solver, not the FOFC-extended ranges.
 static bool use_sweeps(const akmi_pack *p, int rsolver, int ext) {
-  static const bool on = !(getenv("AKMI_TASK_SWEEPS") && atoi(getenv("AKMI_TASK_SWEEPS")) == 0);
-  return on && !ext && rsolver != AKMI_RS_ADVECT && p->nvar == (p->is_ideal ? 5 : 4);
+  return !ext && rsolver != AKMI_RS_ADVECT && p->nvar == (p->is_ideal ? 5 : 4);
 }
 
 static int hydro_fluxes(const akmi_pack *p, int recon, int rsolver, const double *w0, double *flx1,
@@ -1309,8 +1308,7 @@ int akmi_mhd_corner_e(const akmi_pack *p, const double *w0, const double *bcc0,
     dim3 grid(cdiv(g.nx1 + 1, BX), cdiv(g.nx2 + 1, BY), g.nmb), block(BX, BY);
     k_corner_e_2d<<<grid, block, 0, st>>>(g, cc, e3x1, e2x1, e1x2, e3x2, flx1, flx2, e1, e2, e3);
   } else {
-    static const bool march = !(getenv("AKMI_CORNER_MARCH") && atoi(getenv("AKMI_CORNER_MARCH")) == 0);
-    if (march && (size_t)(g.N3 + 1)*(g.N2 + 1)*(g.N1 + 1)*sizeof(double) < ((size_t)1 << 32)) {
+    if ((size_t)(g.N3 + 1)*(g.N2 + 1)*(g.N1 + 1)*sizeof(double) < ((size_t)1 << 32)) {
       const long np = (long)(g.nx2 + 1)*g.N1;                      // flattened rows js..je+1
       const long per_wg = (long)(CX - 1)*CY;
       const unsigned nb = (unsigned)((np + 1 + per_wg - 1)/per_wg);

@@ -95,10 +95,11 @@ class FluidBase:
                                 e.sfloor, e.sigma_max, e.iso_cs, 1 if e.is_ideal else 0)
         # <hydro|mhd>/fused_stage = true | false | auto (default): an explicit true / false is kept as it is
         fs = pin.GetOrAddString(blk, "fused_stage", "auto").lower()
-        if fs not in ("auto", "true", "false", "1", "0"):
-            raise RuntimeError("### FATAL ERROR <%s>/fused_stage = %s: true, false or auto" % (blk, fs))
+        # (the boolean spellings of ParameterInput::GetBoolean: "true" / "false" in any case, or an integer, non-zero = true)
+        if fs not in ("auto", "true", "false") and not fs.isdigit():
+            raise RuntimeError("### FATAL ERROR <%s>/fused_stage = %s: true, false, an integer or auto" % (blk, fs))
         fused_given = fs != "auto"
-        self.fused = fs not in ("false", "0")
+        self.fused = (int(fs) != 0) if fs.isdigit() else fs != "false"
         # small 3-D packs: the marching kernels of the fused stage are chains of dependent steps over a few hundred
         # workgroups; the task-granular chain with one thread per face is faster there (MHD 64^3: 1 050 against 810
         # Mcell-updates/s, 48^3: 610 / 406; equal at 96^3; profiles/r03_small_packs.txt).  Same bits either way.

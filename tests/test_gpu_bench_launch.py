@@ -39,6 +39,19 @@ def test_bench_gpus_2_starts_its_own_ranks():
     assert "cpu_baseline" not in r                          # N = 1 only
 
 
+def test_bench_gpus_8_is_the_2x2x2_layout():
+    """the launch the driver makes on an 8-GPU node, shrunk to 32^3 per rank on a shared GPU: eight ranks, every one of
+    the 26 neighbours of a block on another rank, one JSON line.  (RCCL refuses eight ranks on one device, so the
+    messages travel over gloo and the C++/RCCL host, which needs one GPU per rank, says so in config.host_check.)"""
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--nx", "32", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    r = _one_json_line(p.stdout)
+    assert r["n_gpus"] == 8 and r["steps"] == 2 and r["scaling"] == "weak" and r["value"] > 0
+    assert "64x64x64" in r["config"]["workload"] and "2x2x2" in r["config"]["workload"]
+    assert "host_check" in r["config"] and "roofline" in r
+
+
 def test_bench_under_torch_distributed_run():
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29631", "bench.py", "--gpus", "2", "--nx", "64",
