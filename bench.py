@@ -304,7 +304,12 @@ def valu_floor(blk, nx, plain):
             os.path.basename(f), t.get("src_sha16"), src_sha16())}
     insts = sum(v["insts_valu_per_launch"]*v.get("launches_per_stage", 1) for k, v in t["kernels"].items())
     return {"ms": round(insts*4.0/(1024*2.4e9)*1e3, 4), "valu_wave_insts_per_stage": round(insts),
-            "source": "profiles/%s (%s): SQ_INSTS_VALU x 4 cycles / (256 CUs x 4 SIMDs x 2.4 GHz)" % (
+            # the pipe takes an fp64 instruction every 4 cycles, but a wave issues a DEPENDENT one only every ~8: at the two
+            # to three waves per SIMD of the stage kernels a division / square-root chain reaches ~2.2 ns per instruction and
+            # SIMD (tools/micro/fp64_issue.hip, profiles/r05_fp64_issue.txt) -- the roof such a stream really sits under
+            "ms_dependent_issue": round(insts*2.2e-9/1024*1e3, 4),
+            "source": "profiles/%s (%s): SQ_INSTS_VALU x 4 cycles / (256 CUs x 4 SIMDs x 2.4 GHz); ms_dependent_issue: "
+                      "x 2.2 ns per instruction and SIMD (measured issue rate of dependent fp64 chains at 2-3 waves per SIMD)" % (
                 os.path.basename(f), t.get("tag", ""))}
 
 

@@ -12,11 +12,11 @@ import parity_util as pu  # noqa: E402
 LONG = [
     # problem, n, dims, mb, cycles, kwargs
     ("orszag_tang", 64, 3, 64, 140, dict(cfl=0.3, fused=True)),                 # C3's deck well past shock formation
-    ("orszag_tang", 48, 3, 24, 120, dict(cfl=0.3, fused=True, native=True)),    # eight blocks, C++ host
-    ("orszag_tang", 48, 3, 24, 100, dict(cfl=0.3, fused=False)),                # task-granular chain
-    ("orszag_tang", 128, 2, 64, 400, dict(cfl=0.3)),                            # 2-D: current sheets by cycle ~300
-    ("sod", 64, 3, 32, 120, dict(cfl=0.3, fused=True)),                         # C2's deck, shock crosses blocks
-    ("blast", 40, 3, 20, 90, dict(fused=True)),                                # PPM4 + HLLD, ng = 4, strong blast
+    ("orszag_tang", 48, 3, 24, 100, dict(cfl=0.3, fused=True, native=True)),    # eight blocks, C++ host
+    ("orszag_tang", 48, 3, 24, 70, dict(cfl=0.3, fused=False)),                 # task-granular chain
+    ("orszag_tang", 128, 2, 64, 350, dict(cfl=0.3)),                            # 2-D: current sheets by cycle ~300
+    ("sod", 64, 3, 32, 90, dict(cfl=0.3, fused=True)),                          # C2's deck, shock crosses blocks
+    ("blast", 40, 3, 20, 70, dict(fused=True)),                                # PPM4 + HLLD, ng = 4, strong blast
     ("blast", 40, 3, 20, 45, dict(fused=False, native=True, integrator="rk3")),
     ("blast", 64, 2, 32, 300, dict()),
 ]
