@@ -359,13 +359,16 @@ AKMI_DEV void hllc(double gamma, double dl, double ul, double vl, double wl, dou
   const double ql = dl*(ul - bm), qr = dr*(ur - bp);
   const double fl[5] = {ql, ql*ul + L.p, ql*vl, ql*wl, L.E*(ul - bm) + L.p*ul};
   const double fr[5] = {qr, qr*ur + R.p, qr*vr, qr*wr, R.E*(ur - bp) + R.p*ur};
-  // weights of fl, fr and of the contact pressure: sc >= 0 takes (sc, -bm)/(sc - bm) for the left flux, otherwise
-  // (-sc, bp)/(bp - sc) for the right one -- the same two quotients on operands picked per lane (no divergent branch:
-  // a wave whose contact speeds differ in sign pays two divisions, not four)
-  const bool from_left = sc >= 0.0;
-  const double den = from_left ? sc - bm : bp - sc;
-  const double q_f = (from_left ? sc : -sc)/den, wgt_p = (from_left ? -bm : bp)/den;
-  const double wgt_l = from_left ? q_f : 0.0, wgt_r = from_left ? 0.0 : q_f;
+  double wgt_l, wgt_r, wgt_p;                        // weights of fl, fr and of the contact pressure
+  if (sc >= 0.0) {
+    wgt_l = sc/(sc - bm);
+    wgt_r = 0.0;
+    wgt_p = -bm/(sc - bm);
+  } else {
+    wgt_l = 0.0;
+    wgt_r = -sc/(bp - sc);
+    wgt_p = bp/(bp - sc);
+  }
   f_d = wgt_l*fl[0] + wgt_r*fr[0];
   f_mx = wgt_l*fl[1] + wgt_r*fr[1] + wgt_p*pc;
   f_my = wgt_l*fl[2] + wgt_r*fr[2];
