@@ -2024,25 +2024,6 @@ static int launch_c2p(const Geo &g, const Eos &eos, double *u0, const double *bx
 }
 
 // ---------------------------------------------------------------------------------------
-// helper stream + events for the slab pipeline (one process drives one GPU)
-constexpr int MAX_SLABS = 64;
-static hipStream_t g_aux = nullptr;
-static hipEvent_t g_ev[MAX_SLABS + 2];
-static bool g_ev_ready = false;
-static int ensure_aux() {
-  if (g_ev_ready) return AKMI_COMPLETE;
-  if (hipStreamCreateWithFlags(&g_aux, hipStreamNonBlocking) != hipSuccess) {
-    set_error("cannot create helper stream"); return AKMI_FAIL;
-  }
-  for (int q = 0; q < MAX_SLABS + 2; ++q)
-    if (hipEventCreateWithFlags(&g_ev[q], hipEventDisableTiming) != hipSuccess) {
-      set_error("cannot create event"); return AKMI_FAIL;
-    }
-  g_ev_ready = true;
-  return AKMI_COMPLETE;
-}
-
-// ---------------------------------------------------------------------------------------
 // The flux kernels of the task-granular entry points (akmi_hydro_fluxes / akmi_mhd_fluxes: the path of
 // refined meshes and of everything the fused stage does not cover) by the sweeps of the fused stage:
 // the x1 sweep with the reconstruction of a cell shared between its two faces, the x2/x3 marches in
@@ -2099,29 +2080,15 @@ int sweeps_store_fluxes(const akmi_pack *p, int recon, int rsolver, const double
                                       nullptr, st);
 }
 
-struct C2PArgs {          // interior c2p (+CFL scan) folded into the slab pipeline
+struct C2PArgs {          // ConsToPrim of the active cells (+ CFL scan) at the end of the stage call
   int enable, do_newdt;
   int *counters;
   double *dt3;
 };
 
-#ifndef AKMI_SLAB
-#define AKMI_SLAB 4096    // cells per k-slab of the pipeline (default: one slab)
-#endif
-
-// Pass A (+ optionally the interior part of pass B) of one stage.
-//
-// 3-D packs are cut into k-slabs that behave like independent sub-blocks: each slab runs its
-// x1/x2 sweeps on planes [kA-1,kB+1] and its x3 march on faces [kA,kB+1] (the same
-// CT-extension a MeshBlock applies at its own surface, mhd_fluxes.cpp:125-128), so CornerE
-// and CT of a slab need nothing from its neighbours; the duplicated planes receive
-// bit-identical values from both owners.  The VALU-bound chain (3 Riemann sweeps) is
-// enqueued on the caller's stream, the HBM-bound chain (CornerE, CT, interior c2p + CFL
-// scan) on a helper stream one slab behind, so the two kinds of kernels share the chip
-// instead of alternating.  Hazards (a slab's CT rewrites b0 and its c2p rewrites w0/bcc0,
-// which neighbouring slabs' sweeps still read) are ordered by events:
-//    CornerE(s) after sweeps(s);  CT(s) after sweeps(s-1), sweeps(s+1);
-//    c2p(s) after CT(s), CT(s+1), sweeps(s-1), sweeps(s+1).
+// Pass A (+ optionally the interior part of pass B) of one stage, in stream order: the Riemann sweeps with the RK update,
+// CornerE + CT, ConsToPrim of the active cells.  `phases` selects the parts, so that a rank with off-rank neighbours can
+// post its halo messages in between.
 template <bool MHD>
 static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1,
                         double beta_dt,
@@ -2206,105 +2173,53 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
     return rc;
   }
 
-  // ---- 3-D: slab pipeline on two streams ------------------------------------------------
-  // developer/test knobs: AKMI_SLAB_CELLS (slab thickness), AKMI_ONE_STREAM=1 (no helper stream)
-  static const int env_slab = getenv("AKMI_SLAB_CELLS") ? atoi(getenv("AKMI_SLAB_CELLS")) : 0;
-  static const bool env_one = getenv("AKMI_ONE_STREAM") && atoi(getenv("AKMI_ONE_STREAM")) != 0;
+  // ---- 3-D: the VALU-bound sweeps, then the HBM-bound CornerE + CT and ConsToPrim, in stream order.
+  // (Cutting the block into k-slabs and running the two groups on two streams one slab apart was built in round 1 and
+  //  measured slower at every slab thickness in rounds 1 and 3 -- profiles/r03_slab_ab.txt; it left the source in round 5.)
   // AKMI_HYDRO_ONE_KERNEL=0: the three-kernel sweep/march sequence also for hydro DC/PLM (A/B runs)
   static const bool hyd_one = !(getenv("AKMI_HYDRO_ONE_KERNEL") && atoi(getenv("AKMI_HYDRO_ONE_KERNEL")) == 0);
-  // (the slab pipeline covers the whole-stage call and the sweeps + CornerE + CT call; the other partial phases of a
-  //  rank with off-rank neighbours run one slab)
-  const bool slabs_ok = phases == AKMI_PHASE_ALL || phases == (AKMI_PHASE_SWEEPS | AKMI_PHASE_EMF_CT);
-  const int T = !slabs_ok ? g.nx3 : (env_slab > 1 ? env_slab : AKMI_SLAB);
-  const int S = (g.nx3 + T - 1)/T;
-  if (S > MAX_SLABS) { set_error("too many slabs"); return AKMI_FAIL; }
-  const bool two = (S > 1) && (MHD || cp.enable) && !env_one;
-  hipStream_t sb = st;
-  if (two) {
-    if ((rc = ensure_aux()) != AKMI_COMPLETE) return rc;
-    sb = g_aux;
-    // fork: the helper stream starts after everything already enqueued on the caller's stream
-    (void)hipEventRecord(g_ev[MAX_SLABS], st);
-    (void)hipStreamWaitEvent(sb, g_ev[MAX_SLABS], 0);
+  const int kA = g.ks, kB = g.ke;
+  SweepArgs b1 = a1, b2 = a2, b3 = a3;
+  b1.kl = kA - (MHD ? 1 : 0); b1.ku = kB + (MHD ? 1 : 0);
+  b2.kl = b1.kl; b2.ku = b1.ku;
+  b3.kl = kA; b3.ku = kB + 1;
+  if (do_sweeps && !MHD && hyd_one && sc.recon <= 1 && hyd_tile(g.nx1, g.nx2).tw > 0) {
+    // hydro DC/PLM: sweeps + update in one kernel
+    rc = g.nvar > (sc.iso ? 4 : 5) ? launch_hydro_stage3d<true>(g, sc, w0, u, kA, kB, st, Mass3{w.flx1, w.flx2, w.flx3})
+                    : launch_hydro_stage3d<false>(g, sc, w0, u, kA, kB, st, Mass3{nullptr, nullptr, nullptr});
+  } else if (do_sweeps && MHD && sc.recon == 1 && !sc.iso && sc.rsolver == AKMI_RS_HLLD && g.nvar == 5) {
+    // x1 sweep inside the x2 march, cells from the march's window (k_sweep12s); x3 march consumes acc
+    // (the other order -- x3 march first, leaving dF3/dx3, k_sweep12s finishing the update -- was built and measured in
+    //  round 4: x3 march 891 -> 602 us, k_sweep12s 1130 -> 1374 us, +1 % on the bench; profiles/r04_x3first.txt)
+    if constexpr (MHD) rc = launch_sweep12s(g, sc, b1, b2, u, st);
+    if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD, 0, true>(g, sc, b3, u, st);
+  } else if (do_sweeps) {
+    rc = MHD ? launch_sweep<0, MHD, MHD>(g, sc, b1, st)
+             : launch_sweep<0, MHD, false>(g, sc, b1, st);
+    // x2 sweep as a march along j that leaves acc = dF1/dx1 + dF2/dx2; x3 march consumes it
+    if (rc == AKMI_COMPLETE) rc = launch_sweep_update<1, MHD, 1, false>(g, sc, b2, u, st);
+    if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD, 0, true>(g, sc, b3, u, st);
   }
-  auto kA = [&](int s) { return g.ks + s*T; };
-  auto kB = [&](int s) { int e = g.ks + (s + 1)*T - 1; return e > g.ke ? g.ke : e; };
-  auto ct = [&](int s) -> int {
-    // CornerE + CT of slab s in one kernel (corner EMFs of the planes [kA, kB+1] stay on chip)
-    const int top = (s == S - 1) ? 1 : 0;
+  if (rc == AKMI_COMPLETE && do_sweeps && g.nvar > (sc.iso ? 4 : 5))
+    rc = launch_scalars(g, sc, w0, w.flx1, w.flx2, w.flx3, u, kA, kB - kA + 1, st);
+  if (rc != AKMI_COMPLETE) return rc;
+  if (MHD && do_emf) {
+    // CornerE + CT in one kernel (corner EMFs of the planes [ks, ke+1] stay on chip)
     const CtTile tl = ct_tile(g.nx1 + 1, g.nx2 + 1);
-    const int ckl = march_len((long)tl.n1*tl.n2, kB(s) - kA(s) + 1, g.nmb, CKL);
-    const int nchunk = cdiv(kB(s) - kA(s) + 1, ckl);
+    const int ckl = march_len((long)tl.n1*tl.n2, kB - kA + 1, g.nmb, CKL);
+    const int nchunk = cdiv(kB - kA + 1, ckl);
     dim3 grid(tl.n1, tl.n2, nchunk*g.nmb), block(tl.threads);
-    k_corner_ct<<<grid, block, 7*tl.tw*tl.th*sizeof(double), sb>>>(
-          g, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5], w.ecc[0], w.ecc[1], w.ecc[2],
-          w.flx1, w.flx2, w.flx3, gam0, gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f,
-          copy_u1, kA(s), kB(s), top, nchunk, ckl, tl.tw, tl.th, dt_dev);
+    k_corner_ct<<<grid, block, 7*tl.tw*tl.th*sizeof(double), st>>>(
+        g, w.efc[0], w.efc[1], w.efc[2], w.efc[3], w.efc[4], w.efc[5], w.ecc[0], w.ecc[1], w.ecc[2],
+        w.flx1, w.flx2, w.flx3, gam0, gam1, beta_dt, b0x1f, b0x2f, b0x3f, b1x1f, b1x2f, b1x3f,
+        copy_u1, kA, kB, 1, nchunk, ckl, tl.tw, tl.th, dt_dev);
     AKMI_CHECK_LAUNCH("corner_ct");
-    return AKMI_COMPLETE;
-  };
-  auto c2p = [&](int s) -> int {
-    return launch_c2p<MHD>(g, eos, un, n1f, n2f, n3f, const_cast<double *>(w0),
-                           const_cast<double *>(bcc0), cp.do_newdt, cp.counters, cp.dt3, g.is, g.ie,
-                           g.js, g.je, kA(s), kB(s) - kA(s) + 1, sb);
-  };
-  for (int s = 0; s < S; ++s) {
-    // VALU-bound chain of slab s on the caller's stream
-    SweepArgs b1 = a1, b2 = a2, b3 = a3;
-    b1.kl = kA(s) - (MHD ? 1 : 0); b1.ku = kB(s) + (MHD ? 1 : 0);
-    b2.kl = b1.kl; b2.ku = b1.ku;
-    b3.kl = kA(s); b3.ku = kB(s) + 1;
-    if (do_sweeps && !MHD && hyd_one && sc.recon <= 1 && hyd_tile(g.nx1, g.nx2).tw > 0) {
-      // hydro DC/PLM: sweeps + update of the slab in one kernel
-      rc = g.nvar > (sc.iso ? 4 : 5) ? launch_hydro_stage3d<true>(g, sc, w0, u, kA(s), kB(s), st, Mass3{w.flx1, w.flx2, w.flx3})
-                      : launch_hydro_stage3d<false>(g, sc, w0, u, kA(s), kB(s), st, Mass3{nullptr, nullptr, nullptr});
-    } else if (do_sweeps && MHD && sc.recon == 1 && !sc.iso && sc.rsolver == AKMI_RS_HLLD &&
-               g.nvar == 5) {
-      // x1 sweep inside the x2 march, cells from the march's window (k_sweep12s); x3 march consumes acc
-      // (the other order -- x3 march first, leaving dF3/dx3, k_sweep12s finishing the update -- was built and measured in
-      //  round 4: x3 march 891 -> 602 us, k_sweep12s 1130 -> 1374 us, +1 % on the bench; profiles/r04_x3first.txt)
-      if constexpr (MHD) rc = launch_sweep12s(g, sc, b1, b2, u, st);
-      if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD, 0, true>(g, sc, b3, u, st);
-    } else if (do_sweeps) {
-      rc = MHD ? launch_sweep<0, MHD, MHD>(g, sc, b1, st)
-               : launch_sweep<0, MHD, false>(g, sc, b1, st);
-      // x2 sweep as a march along j that leaves acc = dF1/dx1 + dF2/dx2; x3 march consumes it
-      if (rc == AKMI_COMPLETE) rc = launch_sweep_update<1, MHD, 1, false>(g, sc, b2, u, st);
-      if (rc == AKMI_COMPLETE) rc = launch_sweep_update<2, MHD, 0, true>(g, sc, b3, u, st);
-    }
-    if (rc == AKMI_COMPLETE && do_sweeps && g.nvar > (sc.iso ? 4 : 5))
-      rc = launch_scalars(g, sc, w0, w.flx1, w.flx2, w.flx3, u, kA(s), kB(s) - kA(s) + 1, st);
-    if (rc != AKMI_COMPLETE) return rc;
-    if (two) {
-      (void)hipEventRecord(g_ev[s], st);
-      (void)hipStreamWaitEvent(sb, g_ev[s], 0);       // everything below needs sweeps(<= s)
-    }
-    // HBM-bound chain, one slab behind (in-order on the helper stream)
-    if (MHD && !do_emf) {
-      if (cp.enable && (rc = c2p(s)) != AKMI_COMPLETE) return rc;      // partial phases: S == 1
-    } else if (MHD) {
-      if (s >= 1 && (rc = ct(s - 1)) != AKMI_COMPLETE) return rc;      // needs sweeps(s) done
-      if (cp.enable && s >= 2 && (rc = c2p(s - 2)) != AKMI_COMPLETE) return rc;
-    } else if (cp.enable) {
-      if (s >= 1 && (rc = c2p(s - 1)) != AKMI_COMPLETE) return rc;     // needs sweeps(s) done
-    }
   }
-  if (MHD && !do_emf) {
-  } else if (MHD) {
-    if ((rc = ct(S - 1)) != AKMI_COMPLETE) return rc;
-    if (cp.enable) {
-      if (S >= 2 && (rc = c2p(S - 2)) != AKMI_COMPLETE) return rc;
-      if ((rc = c2p(S - 1)) != AKMI_COMPLETE) return rc;
-    }
-  } else if (cp.enable) {
-    if ((rc = c2p(S - 1)) != AKMI_COMPLETE) return rc;
-  }
-  if (two) {
-    // join: later work on the caller's stream sees the helper stream's results
-    (void)hipEventRecord(g_ev[MAX_SLABS + 1], sb);
-    (void)hipStreamWaitEvent(st, g_ev[MAX_SLABS + 1], 0);
-  }
-  return AKMI_COMPLETE;
+  if (cp.enable)
+    rc = launch_c2p<MHD>(g, eos, un, n1f, n2f, n3f, const_cast<double *>(w0),
+                         const_cast<double *>(bcc0), cp.do_newdt, cp.counters, cp.dt3, g.is, g.ie,
+                         g.js, g.je, kA, kB - kA + 1, st);
+  return rc;
 }
 
 }  // namespace akmi

@@ -502,8 +502,7 @@ int akmi_mhd_c2p_newdt(const akmi_pack *p, double *u0, const double *bx1f,
                        int do_newdt, int *counters, double *dt3, void *stream);
 
 /* Whole stage in one call: pass A (as akmi_*_stage_update) + ConsToPrim of the ACTIVE cells
- * (+ the CFL scan when do_newdt) folded into the same slab pipeline, so that the HBM-bound
- * kernels overlap the Riemann sweeps of other slabs.  w0/bcc0 are read (old primitives) and
+ * (+ the CFL scan when do_newdt) in the same call.  w0/bcc0 are read (old primitives) and
  * rewritten for the active cells.  After the halo exchange / physical BCs the caller converts
  * the ghost shell with akmi_*_c2p_shell; together they equal akmi_*_c2p_newdt over all cells
  * (ConToPrim covers ghosts: src/hydro/hydro_tasks.cpp:404-412). */

@@ -396,31 +396,6 @@ def test_against_committed_golden_snapshots(name):
         assert np.array_equal(ph.b0.x3f.cpu().numpy(), g["final_b0x3f"])
 
 
-@pytest.mark.parametrize("case", [("orszag_tang", 24, 3, 24, 3, dict(cfl=0.3)),
-                                  ("orszag_tang", 24, 3, 12, 3, dict(cfl=0.3)),
-                                  ("sod", 24, 3, 24, 3, dict(cfl=0.3)),
-                                  ("blast", 24, 3, 24, 2, {})],
-                         ids=lambda c: "%s-%d^%d-mb%d" % (c[0], c[1], c[2], c[3]))
-def test_slab_pipeline_is_bit_identical(case):
-    """the two-stream k-slab pipeline of akmi_*_stage_fused (slab thickness forced to 8 and
-    5 cells through the developer knob AKMI_SLAB_CELLS, i.e. 3-5 slabs incl. a ragged last
-    one) against the oracle, in a fresh process per setting"""
-    import json
-    import os
-    import subprocess
-    import sys
-    problem, n, dims, mb, cycles, kw = case
-    code = ("import sys, json; sys.path[:0]=[%r, %r]; import parity_util as pu; "
-            "r = pu.compare_run(%r, %d, %d, %d, %d, fused=True, **%r); "
-            "print(json.dumps({'ok': bool(r['bitwise_equal']), 'cyc': r['cycles'], 'm': r['max_rel_l1']}))"
-            % (pu.ROOT, os.path.join(pu.ROOT, "tests"), problem, n, dims, mb, cycles, kw))
-    for slab in ("8", "5"):
-        env = dict(os.environ, AKMI_SLAB_CELLS=slab)
-        out = subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip().splitlines()[-1]
-        r = json.loads(out)
-        assert r["ok"] and r["cyc"] == cycles, (slab, r)
-
-
 def test_shared_edge_emfs_identical_across_blocks():
     """premise of skipping SendE/RecvE on uniform meshes: every copy of a
     block-surface edge EMF computed by the two (four) MeshBlocks that share it is bit-identical,
