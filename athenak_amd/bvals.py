@@ -36,6 +36,15 @@ class HipBvalsKernels:
         capi.check(self.L.akmi_bvals_cc_local(C.byref(pack), nvar, capi._p(nghbr), capi._p(u),
                                               capi._stream()), "bvals_cc_local")
 
+    def cc_local_bcs(self, pack, nvar, nghbr, bcs, u, u_in=None, dt3_reset=None):
+        """the gather and the physical boundary functions in one launch (packs without off-rank neighbours)"""
+        capi.check(self.L.akmi_bvals_cc_local_bcs(C.byref(pack), nvar, capi._p(nghbr), capi._p(bcs), capi._p(u_in),
+                                                  capi._p(u), capi._p(dt3_reset), capi._stream()), "bvals_cc_local_bcs")
+
+    def fc_local_bcs(self, pack, nghbr, bcs, b1, b2, b3, b_in=None):
+        capi.check(self.L.akmi_bvals_fc_local_bcs(C.byref(pack), capi._p(nghbr), capi._p(bcs), capi._p(b_in), capi._p(b1),
+                                                  capi._p(b2), capi._p(b3), capi._stream()), "bvals_fc_local_bcs")
+
     def cc_pack(self, pack, nvar, nsend, tab, off, u, buf):
         capi.check(self.L.akmi_bvals_cc_pack(C.byref(pack), nvar, nsend, capi._p(tab), capi._p(off),
                                              capi._p(u), capi._p(buf), capi._stream()), "bvals_cc_pack")
@@ -135,6 +144,12 @@ class MeshBoundaryValues:
         self.bcs = torch.from_numpy(np.ascontiguousarray(pmb.mb_bcs)).to(device)
         self.cc = None
         self.fc = None
+        # single-rank uniform meshes with physical boundaries: the gather applies the boundary functions as well
+        # (akmi_bvals_*_local_bcs); HydroBCs / BFieldBCs then have nothing left to do.  AKMI_FOLD_BCS=0: separate kernels.
+        import os
+        self.fold_bcs = (not self.peers and not pm.multilevel and not pm.strictly_periodic
+                         and os.environ.get("AKMI_FOLD_BCS", "1") != "0" and hasattr(getattr(self.k, "L", None), "akmi_bvals_cc_local_bcs"))
+        self._u_bcs_done = self._b_bcs_done = False
 
     # ------------------------------------------------------------------------------
     def _plan(self, segsize):
@@ -215,8 +230,13 @@ class MeshBoundaryValues:
             ch.recvbuf.copy_(ch.h_recv, non_blocking=True)
 
     # ---- cell-centred ------------------------------------------------------------
-    def PackAndSendCC(self, u):
-        """same-rank ghosts are final after this call; remote data is in flight."""
+    def PackAndSendCC(self, u, dt3_reset=None):
+        """same-rank ghosts are final after this call; remote data is in flight.  Returns with _u_bcs_done set when the
+        physical boundary functions were applied by the same launch (dt3_reset: that launch also resets the CFL minima)."""
+        if self.fold_bcs:
+            self.k.cc_local_bcs(self.pack_c, self.nvar, self.nghbr, self.bcs, u, self.u_in, dt3_reset)
+            self._u_bcs_done = True
+            return TaskStatus.complete
         self.k.cc_local(self.pack_c, self.nvar, self.nghbr, u)
         if self.peers:
             self.k.cc_pack(self.pack_c, self.nvar, self.cc.nsend, self.cc.send_tab, self.cc.send_off,
@@ -232,6 +252,10 @@ class MeshBoundaryValues:
 
     # ---- face-centred ------------------------------------------------------------
     def PackAndSendFC(self, b):
+        if self.fold_bcs:
+            self.k.fc_local_bcs(self.pack_c, self.nghbr, self.bcs, b.x1f, b.x2f, b.x3f, self.b_in)
+            self._b_bcs_done = True
+            return TaskStatus.complete
         self.k.fc_local(self.pack_c, self.nghbr, b.x1f, b.x2f, b.x3f)
         if self.peers:
             self.k.fc_pack(self.pack_c, self.fc.nsend, self.fc.send_tab, self.fc.send_off,
@@ -248,7 +272,13 @@ class MeshBoundaryValues:
 
     # ---- physical boundaries -----------------------------------------------------
     def HydroBCs(self, u):
+        if self._u_bcs_done:                 # applied by the gather of PackAndSendCC
+            self._u_bcs_done = False
+            return
         self.k.hydro_bcs(self.pack_c, self.nvar, self.bcs, u, self.u_in)
 
     def BFieldBCs(self, b):
+        if self._b_bcs_done:
+            self._b_bcs_done = False
+            return
         self.k.bfield_bcs(self.pack_c, self.bcs, b.x1f, b.x2f, b.x3f, self.b_in)

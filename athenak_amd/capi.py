@@ -35,12 +35,12 @@ SMALL_PACK_CELLS = 600000       # AKMI_SMALL_PACK_CELLS of include/akmi.h (tests
 SYMBOLS = [
     "akmi_last_error", "akmi_version", "akmi_build_flags", "akmi_copy_cons", "akmi_rk4_copy_cons", "akmi_hydro_fluxes_fofc", "akmi_hydro_fofc", "akmi_mhd_fluxes_fofc", "akmi_mhd_fofc", "akmi_kinematic_newdt", "akmi_ambipolar_emfs", "akmi_ambipolar_fluxes", "akmi_resistive_newdt", "akmi_restrict_cc", "akmi_restrict_fc", "akmi_restrict_cc_masked", "akmi_restrict_fc_masked", "akmi_restrict_flux_cc", "akmi_restrict_emf", "akmi_prim2cons", "akmi_prolong_cc", "akmi_prolong_fc_shared", "akmi_prolong_fc_internal", "akmi_hydro_bcs_inflow", "akmi_bfield_bcs_inflow", "akmi_hydro_bcs_dirs", "akmi_bfield_bcs_dirs", "akmi_viscous_fluxes", "akmi_heat_fluxes", "akmi_conduction_newdt", "akmi_resistive_emfs", "akmi_resistive_fluxes", "akmi_hydro_fluxes", "akmi_rk_update", "akmi_rk_update_oop", "akmi_mhd_ct_oop",
     "akmi_hydro_c2p", "akmi_hydro_newdt", "akmi_mhd_fluxes", "akmi_mhd_corner_e", "akmi_mhd_ct",
-    "akmi_mhd_c2p", "akmi_mhd_newdt", "akmi_bvals_cc_local", "akmi_bvals_cc_pack",
+    "akmi_mhd_c2p", "akmi_mhd_newdt", "akmi_bvals_cc_local", "akmi_bvals_cc_local_bcs", "akmi_bvals_fc_local_bcs", "akmi_bvals_cc_pack",
     "akmi_bvals_cc_unpack", "akmi_bvals_cc_segsize", "akmi_bvals_fc_local", "akmi_bvals_fc_pack",
     "akmi_bvals_fc_unpack", "akmi_bvals_fc_segsize", "akmi_hydro_bcs", "akmi_bfield_bcs",
     "akmi_stage_workspace_bytes", "akmi_hydro_stage_update", "akmi_mhd_stage_update",
     "akmi_hydro_c2p_newdt", "akmi_mhd_c2p_newdt", "akmi_calib_copy", "akmi_hydro_stage_fused", "akmi_mhd_stage_fused",
-    "akmi_hydro_stage_phase", "akmi_mhd_stage_phase", "akmi_history_sums",
+    "akmi_hydro_stage_phase", "akmi_mhd_stage_phase", "akmi_hydro_stage_phase_dt", "akmi_mhd_stage_phase_dt", "akmi_history_sums",
     "akmi_hydro_c2p_shell", "akmi_mhd_c2p_shell", "akmi_sim_create", "akmi_sim_initialize",
     "akmi_sim_execute", "akmi_sim_profile", "akmi_sim_profile_read", "akmi_sim_destroy", "akmi_sim_time", "akmi_sim_dt", "akmi_sim_tlim",
     "akmi_sim_ncycle", "akmi_sim_nmb", "akmi_sim_array", "akmi_sim_lloc", "akmi_sim_gids", "akmi_sim_nmb_thisrank",

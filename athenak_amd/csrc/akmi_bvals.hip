@@ -10,6 +10,7 @@
 // of nghbr[m][o].  Off-rank segments use the same index maps on both sides, so a segment
 // packed by the sender for direction d is exactly the receiver's ghost region for -d.
 #include "akmi_common.hpp"
+#include <cfloat>
 
 namespace akmi {
 
@@ -71,10 +72,47 @@ struct GhostSet {
 // (block, variable, element) with four 64-bit divisions per element behind a 65535-workgroup grid-stride loop;
 // measured, that arithmetic was NOT what bounds the fill of many small blocks (960 blocks of 32^3, ng = 4:
 // 919 -> 895 us for 2.4 GB): the x1 slabs are rows of 2 ng doubles, 64-byte pieces of 128-byte lines on both sides.
-template <int KIND>
+// BC = true (KIND 0 only): the physical boundary conditions of the pack folded into the gather.  The reference fills the
+// ghost zones from the neighbours and then applies the boundary functions direction by direction (x1, x2, x3), each over
+// ALL transverse indices (bvals/physics/hydro_bcs.cpp:69-230, bfield_bcs.cpp:66-300), so the value that ends up in a ghost
+// element is  T3(T2(T1(fill value at c')))  where c' is the element with every physically bounded ghost coordinate mapped
+// to its source coordinate (x3 first, then x2, then x1: the inverse order) and T_d the value rule of direction d (identity
+// for outflow, the sign of the normal component for reflect, the clamp for diode, constants for inflow / vacuum).  One
+// launch instead of the gather plus one kernel per bounded direction; every source element is an owned element of some
+// MeshBlock (or a ghost element nothing fills), never one this launch writes.
+struct GhostBC {
+  const int *bcs;        // [nmb][6] AKMI_BC_*
+  const double *in;      // inflow constants: u_in[nvar][6] (cell-centred set) / b_in[3][6] (face-centred set), may be null
+  double *dt3;           // when non-null: the three CFL minima are reset here (saves the k_init_dt3 launch of the last stage)
+};
+__host__ __device__ inline bool bc_is_physical(int f) {
+  return f == AKMI_BC_REFLECT || f == AKMI_BC_OUTFLOW || f == AKMI_BC_INFLOW || f == AKMI_BC_DIODE || f == AKMI_BC_VACUUM;
+}
+// source coordinate of ghost coordinate x on side o (-1 / +1) of a dimension under boundary type f; fcd: the array is
+// face-centred along this dimension (owned faces s..eo = e+1)
+__device__ __forceinline__ int bc_source(const Dim &dm, int x, int o, int f, bool fcd) {
+  if (f == AKMI_BC_REFLECT) return o < 0 ? 2*dm.s - (fcd ? 0 : 1) - x : 2*dm.eo + (fcd ? 0 : 1) - x;
+  return o < 0 ? dm.s : dm.eo;
+}
+// value rule of direction D (face = 2 D + side) for variable n of a cell-centred set (comp 0) or for face component comp
+__device__ __forceinline__ double bc_value(double v, int f, int D, int side, int comp, int n, const double *in) {
+  const bool normal = comp == 0 ? (n == 1 + D) : (comp == 1 + D);
+  if (f == AKMI_BC_REFLECT) {
+    if (comp == 0) { const double sgn = normal ? -1.0 : 1.0; return sgn*v; }
+    return normal ? -1.0*v : v;
+  }
+  if (f == AKMI_BC_INFLOW) return in[6*(comp == 0 ? n : comp - 1) + 2*D + side];
+  if (comp == 0) {
+    if (f == AKMI_BC_DIODE) return normal ? (side ? fmax(0.0, v) : fmin(0.0, v)) : v;
+    if (f == AKMI_BC_VACUUM) return 0.0;
+  }
+  return v;              // outflow; the field under diode / vacuum (bfield_bcs.cpp:88-97)
+}
+
+template <int KIND, bool BC = false>
 __global__ void __launch_bounds__(256)
 k_ghost_fill(Geo g, GhostSet gs, int nv, unsigned chunks, const int *__restrict__ nghbr,
-             const long long *__restrict__ seg_off, const double *__restrict__ recvbuf) {
+             const long long *__restrict__ seg_off, const double *__restrict__ recvbuf, GhostBC bc) {
   const Comp q = gs.q[blockIdx.y];
   double *__restrict__ a = gs.a[blockIdx.y];
   const int comp = gs.comp[blockIdx.y];
@@ -91,7 +129,13 @@ k_ghost_fill(Geo g, GhostSet gs, int nv, unsigned chunks, const int *__restrict_
   // GU elements per thread and pass, all loads of a pass before its stores: the kernel has next to no arithmetic,
   // its rate is the number of bytes in flight (960 blocks of 32^3, ng = 4: 895 -> 748 us, profiles/r03_config5.txt)
   __shared__ int s_src[27];
+  __shared__ int s_bc[6];
   if (threadIdx.x < 27) s_src[threadIdx.x] = nghbr[m*27 + threadIdx.x];
+  if constexpr (BC) {
+    if (threadIdx.x >= 32 && threadIdx.x < 38) s_bc[threadIdx.x - 32] = bc.bcs[6*m + threadIdx.x - 32];
+    if (bc.dt3 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x >= 64 && threadIdx.x < 67)
+      bc.dt3[threadIdx.x - 64] = (double)FLT_MAX;
+  }
   __syncthreads();
   constexpr int GU = 4;
   const unsigned stride = chunks*256u;
@@ -112,10 +156,31 @@ k_ghost_fill(Geo g, GhostSet gs, int nv, unsigned chunks, const int *__restrict_
       if (mode == 0) { i = ii; j = (int)jj; k = (int)kk < q.d3.ng ? (int)kk : q.d3.eo + 1 + ((int)kk - q.d3.ng); }
       else if (mode == 1) { i = ii; j = (int)jj < q.d2.ng ? (int)jj : q.d2.eo + 1 + ((int)jj - q.d2.ng); k = q.d3.s + (int)kk; }
       else { i = ii < q.d1.ng ? ii : q.d1.eo + 1 + (ii - q.d1.ng); j = q.d2.s + (int)jj; k = q.d3.s + (int)kk; }
-      const int o1 = q.d1.side(i), o2 = q.d2.side(j), o3 = q.d3.side(k);
+      int o1 = q.d1.side(i), o2 = q.d2.side(j), o3 = q.d3.side(k);
+      dst[u] = ((vbase + k)*q.n2 + j)*q.n1 + i;
+      if constexpr (BC) {
+        int f1 = -1, f2 = -1, f3 = -1, sd1 = 0, sd2 = 0, sd3 = 0;     // boundary type applied per direction (-1: none)
+        int kk2 = k, jj2 = j, ii2 = i;
+        if (o3 != 0) { sd3 = o3 > 0; const int f = s_bc[4 + sd3]; if (bc_is_physical(f)) { f3 = f; kk2 = bc_source(q.d3, k, o3, f, comp == 3); o3 = 0; } }
+        if (o2 != 0) { sd2 = o2 > 0; const int f = s_bc[2 + sd2]; if (bc_is_physical(f)) { f2 = f; jj2 = bc_source(q.d2, j, o2, f, comp == 2); o2 = 0; } }
+        if (o1 != 0) { sd1 = o1 > 0; const int f = s_bc[sd1]; if (bc_is_physical(f)) { f1 = f; ii2 = bc_source(q.d1, i, o1, f, comp == 1); o1 = 0; } }
+        const bool mapped = (f1 >= 0) || (f2 >= 0) || (f3 >= 0);
+        const int d = (o3 + 1)*9 + (o2 + 1)*3 + (o1 + 1);
+        int src = (d == 13) ? m : s_src[d];
+        int oo1 = o1, oo2 = o2, oo3 = o3;
+        if (src < 0) {
+          if (!mapped) { ok[u] = false; continue; }
+          src = m; oo1 = oo2 = oo3 = 0;           // nothing fills c': the boundary functions copy what it holds
+        }
+        double val = a[((((size_t)src*nv + n)*q.n3 + (kk2 - oo3*q.d3.nx))*q.n2 + (jj2 - oo2*q.d2.nx))*q.n1 + (ii2 - oo1*q.d1.nx)];
+        if (f1 >= 0) val = bc_value(val, f1, 0, sd1, comp, n, bc.in);
+        if (f2 >= 0) val = bc_value(val, f2, 1, sd2, comp, n, bc.in);
+        if (f3 >= 0) val = bc_value(val, f3, 2, sd3, comp, n, bc.in);
+        v[u] = val;
+        continue;
+      }
       const int d = (o3 + 1)*9 + (o2 + 1)*3 + (o1 + 1);
       const int src = s_src[d];
-      dst[u] = ((vbase + k)*q.n2 + j)*q.n1 + i;
       if constexpr (KIND == 0) {
         if (src < 0) { ok[u] = false; continue; }
         v[u] = a[((((size_t)src*nv + n)*q.n3 + (k - o3*q.d3.nx))*q.n2 + (j - o2*q.d2.nx))*q.n1 + (i - o1*q.d1.nx)];
@@ -136,9 +201,9 @@ k_ghost_fill(Geo g, GhostSet gs, int nv, unsigned chunks, const int *__restrict_
   }
 }
 
-template <int KIND>
+template <int KIND, bool BC = false>
 static int launch_ghost(const Geo &g, const GhostSet &gs, int nv, const int *nghbr,
-                        const long long *seg_off, const double *recvbuf, hipStream_t st) {
+                        const long long *seg_off, const double *recvbuf, hipStream_t st, GhostBC bc = GhostBC{}) {
   long long nmax = 1;
   for (int c = 0; c < gs.ncomp; ++c) {
     const Comp &q = gs.q[c];
@@ -158,7 +223,7 @@ static int launch_ghost(const Geo &g, const GhostSet &gs, int nv, const int *ngh
   if (chunks > 64 && mnv*chunks > (1ll << 20)) { chunks = (1ll << 20)/mnv; if (chunks < 64) chunks = 64; if (chunks > cap) chunks = cap; }
   if (chunks < 1) { set_error("bvals ghost fill: too many MeshBlocks x variables for one launch"); return AKMI_FAIL; }
   dim3 grid((unsigned)(mnv*chunks), gs.ncomp, 3);
-  k_ghost_fill<KIND><<<grid, 256, 0, st>>>(g, gs, nv, (unsigned)chunks, nghbr, seg_off, recvbuf);
+  k_ghost_fill<KIND, BC><<<grid, 256, 0, st>>>(g, gs, nv, (unsigned)chunks, nghbr, seg_off, recvbuf, bc);
   AKMI_CHECK_LAUNCH("bvals ghost fill");
   return AKMI_COMPLETE;
 }
@@ -348,6 +413,20 @@ long long akmi_bvals_fc_segsize(const akmi_pack *p, int d) {
 int akmi_bvals_cc_local(const akmi_pack *p, int nvar, const int *nghbr, double *u, void *stream) {
   Geo g = make_geo(p);
   return launch_ghost<0>(g, cc_set(g, u), nvar, nghbr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int akmi_bvals_cc_local_bcs(const akmi_pack *p, int nvar, const int *nghbr, const int *bcs, const double *u_in, double *u,
+                            double *dt3_reset, void *stream) {
+  Geo g = make_geo(p);
+  return launch_ghost<0, true>(g, cc_set(g, u), nvar, nghbr, nullptr, nullptr, (hipStream_t)stream,
+                               GhostBC{bcs, u_in, dt3_reset});
+}
+
+int akmi_bvals_fc_local_bcs(const akmi_pack *p, const int *nghbr, const int *bcs, const double *b_in, double *bx1f,
+                            double *bx2f, double *bx3f, void *stream) {
+  Geo g = make_geo(p);
+  return launch_ghost<0, true>(g, fc_set(g, bx1f, bx2f, bx3f), 1, nghbr, nullptr, nullptr, (hipStream_t)stream,
+                               GhostBC{bcs, b_in, nullptr});
 }
 
 int akmi_bvals_cc_unpack(const akmi_pack *p, int nvar, const int *nghbr, const long long *seg_off,

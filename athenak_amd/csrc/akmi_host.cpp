@@ -478,6 +478,24 @@ FluidBase::~FluidBase() {
   delete pbval;
   delete peos;
 }
+bool FluidBase::FoldBCs() {
+  const char *e = getenv("AKMI_FOLD_BCS");      // read per call: tests switch it inside one process
+  return !(e && atoi(e) == 0);
+}
+// same-rank gather of the conserved variables; on meshes with physical boundaries the boundary functions ride along
+void FluidBase::GatherU(Driver *d, int stage) {
+  if (FoldBCs() && !pmy_pack->pmesh->strictly_periodic) {
+    // the last stage of the fused path: the launch also resets the CFL minima its ConsToPrim scans into
+    // (not when the stage call has converted the active cells already: their scan is in dt3 by now)
+    Real *reset = (fused && !interior_done_ && stage >= 1 && stage == d->nexp_stages) ? dt3.p : nullptr;
+    AKCHK(akmi_bvals_cc_local_bcs(&pack_c, nvars, pmy_pack->pmb->d_nghbr.p, pmy_pack->pmb->d_bcs.p, nullptr, u0.p, reset,
+                                  stream));
+    u_bcs_done_ = true;
+    dt3_reset_ = reset != nullptr;
+  } else {
+    AKCHK(akmi_bvals_cc_local(&pack_c, nvars, pmy_pack->pmb->d_nghbr.p, u0.p, stream));
+  }
+}
 void FluidBase::FinishNewDt() {        // hydro_newdt.cpp:121-124
   Real d[3];
   Mesh *pm = pmy_pack->pmesh;
@@ -704,17 +722,59 @@ Driver::Driver(ParameterInput *pin, Mesh *pmesh) {       // driver.cpp:85-162
     if (!f->fused || f->multilevel || f->kinematic || f->stream == nullptr) use_graph = false;
   }
   if (pmesh->nranks > 1 || nphys != 1 || SelfExchange()) use_graph = false;
-  if (use_graph) {
-    d_dt.Realloc(1);
-    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h_dt), sizeof(Real)));
+  // run-ahead cycles (akmi_host.hpp): the same eligibility, plus no diffusion time steps (they are reduced on the host)
+  const std::string ra = pin->GetOrAddString("time", "run_ahead", "auto");
+  if (ra != "auto" && ra != "true" && ra != "false") AKMI_FATAL("<time>/run_ahead = auto, true or false");
+  run_ahead = ra != "false";
+  if (const char *e = std::getenv("AKMI_RUN_AHEAD")) run_ahead = std::atoi(e) != 0;
+  for (FluidBase *f : phys) {
+    if (!f) continue;
+    if (!f->fused || f->multilevel || f->kinematic || f->stream == nullptr || f->has_visc || f->has_cond || f->has_resist)
+      run_ahead = false;
+  }
+  if (pmesh->nranks > 1 || nphys != 1 || SelfExchange() || use_graph) run_ahead = false;
+  if (use_graph || run_ahead) {
+    d_dt.Realloc(2);
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h_dt), 2*sizeof(Real)));
     for (FluidBase *f : phys) if (f) f->dt_dev = d_dt.p;
+  }
+  if (run_ahead) {
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&ra_slot), 6*sizeof(Real)));
+    for (hipEvent_t &e : ra_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
 }
 Driver::~Driver() {
   for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e);
   if (cycle_exec) (void)hipGraphExecDestroy(cycle_exec);
   if (h_dt) (void)hipHostFree(h_dt);
+  if (ra_slot) (void)hipHostFree(ra_slot);
+  for (hipEvent_t e : ra_ev) if (e) (void)hipEventDestroy(e);
   d_dt.Free();
+}
+
+// Mesh::NewTimeStep (mesh.cpp:573-643) for one physics module without diffusion, on the device: st = {dt, time}
+__global__ void k_mesh_newdt(const Real *__restrict__ dt3, Real *__restrict__ st, Real tlim, Real cfl_no, int multi_d,
+                             int three_d, Real *__restrict__ slot) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Real dt = st[0], time = st[1];
+  time = time + dt;                                         // driver.cpp:444
+  Real dtnew = dt3[0];                                      // hydro_newdt.cpp:121-124
+  if (multi_d) dtnew = (dt3[1] < dtnew) ? dt3[1] : dtnew;
+  if (three_d) dtnew = (dt3[2] < dtnew) ? dt3[2] : dtnew;
+  dt = 2.0*dt;                                              // mesh.cpp:577
+  const Real c = cfl_no*dtnew;
+  dt = (c < dt) ? c : dt;
+  if ((time < tlim) && ((time + dt) > tlim)) dt = tlim - time;
+  st[0] = dt; st[1] = time;
+  slot[0] = dt; slot[1] = time; slot[2] = dtnew;
+}
+void Driver::EnqueueMeshNewDt(FluidBase *f) {
+  Mesh *pm = f->pmy_pack->pmesh;
+  const int s = static_cast<int>(ra_cycle & 1);
+  k_mesh_newdt<<<1, 64, 0, f->stream>>>(f->dt3.p, d_dt.p, tlim, pm->cfl_no, pm->multi_d ? 1 : 0, pm->three_d ? 1 : 0,
+                                        ra_slot + 3*s);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ra_ev[s], f->stream));
 }
 
 // event pair k = (prof_ev[2k], prof_ev[2k+1]); nothing is recorded while a cycle graph is captured or replayed
@@ -784,6 +844,41 @@ void Driver::RunStages(Mesh *pm) {                         // driver.cpp:398-423
 
 int Driver::Execute(Mesh *pm, int max_cycles) {            // driver.cpp:380-459
   int n = 0;
+  if (run_ahead) {
+    FluidBase *f = pm->pmb_pack->phydro ? static_cast<FluidBase *>(pm->pmb_pack->phydro)
+                                        : static_cast<FluidBase *>(pm->pmb_pack->pmhd);
+    h_dt[0] = pm->dt; h_dt[1] = pm->time;
+    HIPCHK(hipMemcpyAsync(d_dt.p, h_dt, 2*sizeof(Real), hipMemcpyHostToDevice, f->stream));
+    bool pending = false;                // a cycle is enqueued whose results the host has not read yet
+    auto collect = [&](long long cyc) {  // results of cycle `cyc` (counted like ra_cycle): dt of the cycle after it
+      const int s = static_cast<int>(cyc & 1);
+      HIPCHK(hipEventSynchronize(ra_ev[s]));
+      pm->dtold = pm->dt;
+      pm->dt = ra_slot[3*s];
+      f->dtnew = ra_slot[3*s + 2];
+      if (ra_slot[3*s + 1] != pm->time) AKMI_FATAL("run-ahead: the device clock left the host clock");
+    };
+    while ((pm->time < tlim) && (pm->ncycle < nlim || nlim < 0)) {       // pm->time: start of the cycle to enqueue, exact
+      if (max_cycles >= 0 && n >= max_cycles) break;
+      ra_active = true;                  // (Initialize's NewTimeStep takes the synchronous path)
+      RunStages(pm);                     // the kernels read dt from d_dt; NewTimeStep enqueues k_mesh_newdt
+      ra_active = false;
+      // dt of the cycle just enqueued is the result of the cycle before it, which has finished by now or will long
+      // before the one just enqueued does: the host needs it only here, to advance its clock
+      if (pending) collect(ra_cycle - 1);
+      ++ra_cycle;
+      pending = true;
+      pm->time = pm->time + pm->dt;
+      pm->ncycle++;
+      nmb_updated_ += pm->nmb_total;
+      ++n;
+    }
+    if (pending) collect(ra_cycle - 1);  // the last cycle: dt of the next one, and the clocks compared once more
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (pm->pmb_pack->phydro) pm->pmb_pack->phydro->RestoreRegisters();
+    if (pm->pmb_pack->pmhd) pm->pmb_pack->pmhd->RestoreRegisters();
+    return n;
+  }
   while ((pm->time < tlim) && (pm->ncycle < nlim || nlim < 0)) {
     if (max_cycles >= 0 && n >= max_cycles) break;
     if (use_graph) {
@@ -900,7 +995,7 @@ TaskStatus Hydro::RKUpdate(Driver *d, int stage) {         // hydro_update.cpp:2
     // off-rank neighbours: only the sweeps + update here, so that SendU can post the halo messages
     // before the c2p of the active cells is enqueued
     StagePhase(d, stage, AKMI_PHASE_SWEEPS);
-  } else if (fused && !dt_dev && MergeC2P()) {
+  } else if (fused && !d->use_graph && MergeC2P()) {
     // no off-rank neighbour: ONE ConsToPrim over all cells after the ghost fill (ConToPrim) instead of c2p of the
     // active cells here + c2p of the ghost shell there (thin slabs): 512 blocks of 32^3 1518 -> 1726 Mcell-updates/s
     StagePhase(d, stage, AKMI_PHASE_SWEEPS);
@@ -937,6 +1032,10 @@ void Hydro::StagePhase(Driver *d, int stage, int phases) {
   const int do_dt = (stage == d->nexp_stages);
   const int copy = CopyFlag(d, stage, phases);
   d->ProfMark(stream);
+  if (dt_dev && stage >= 1)
+    AKCHK(akmi_hydro_stage_phase_dt(&pack_c, recon_method, rsolver_method, g0, g1, d->beta[stage - 1], dt_dev, copy, w0.p,
+                                    u0.p, u1.p, do_dt, counters.p, dt3.p, phases, ws.p, stream));
+  else
   AKCHK(akmi_hydro_stage_phase(&pack_c, recon_method, rsolver_method, g0, g1, beta_dt, copy, w0.p,
                                u0.p, u1.p, do_dt, counters.p, dt3.p, phases, ws.p, stream));
   d->ProfMark(stream);
@@ -954,7 +1053,7 @@ TaskStatus Hydro::SendU(Driver *d, int stage) {            // hydro_tasks.cpp:30
     // not depend on the halo) underneath them
     if (fused && peers()) StagePhase(d, stage, AKMI_PHASE_C2P);
   } else {
-    AKCHK(akmi_bvals_cc_local(&pack_c, nvars, pmy_pack->pmb->d_nghbr.p, u0.p, stream));
+    GatherU(d, stage);
   }
   return TaskStatus::complete;
 }
@@ -1009,6 +1108,7 @@ TaskStatus Hydro::Prolongate(Driver *d, int stage) {       // hydro_tasks.cpp:38
 }
 TaskStatus Hydro::ApplyPhysicalBCs(Driver *d, int stage) { // hydro_tasks.cpp:357-375
   if (pmy_pack->pmesh->strictly_periodic) return TaskStatus::complete;
+  if (u_bcs_done_) { u_bcs_done_ = false; return TaskStatus::complete; }      // applied by the gather of SendU
   AKCHK(akmi_hydro_bcs_dirs(&pack_c, nvars, pmy_pack->pmb->d_bcs.p, pmy_pack->pmb->bc_dirs, nullptr, u0.p, stream));
   return TaskStatus::complete;
 }
@@ -1022,7 +1122,8 @@ TaskStatus Hydro::ConToPrim(Driver *d, int stage) {        // hydro_tasks.cpp:40
   } else if (fused) {
     int do_dt = (stage == d->nexp_stages);
     d->ProfMark(stream);
-    AKCHK(akmi_hydro_c2p_newdt(&pack_c, u0.p, w0.p, do_dt, counters.p, dt3.p, stream));
+    AKCHK(akmi_hydro_c2p_newdt(&pack_c, u0.p, w0.p, (do_dt && dt3_reset_) ? 2 : do_dt, counters.p, dt3.p, stream));
+    dt3_reset_ = false;
     d->ProfMark(stream);
     dt_ready_ = do_dt;
   } else if (multilevel && stage == d->nexp_stages && !kinematic) {
@@ -1040,6 +1141,7 @@ TaskStatus Hydro::NewTimeStep(Driver *d, int stage) {      // hydro_newdt.cpp:30
   else if (!dt_ready_) AKCHK(akmi_hydro_newdt(&pack_c, w0.p, dt3.p, stream));
   dt_ready_ = false;
   if (d->capturing) return TaskStatus::complete;   // the Driver reads dt3 after the graph launch
+  if (d->ra_active) { d->EnqueueMeshNewDt(this); return TaskStatus::complete; }
   FinishNewDt();
   DiffusionNewDt();
   return TaskStatus::complete;
@@ -1086,7 +1188,7 @@ TaskStatus MHD::RKUpdate(Driver *d, int stage) {           // mhd_update.cpp:24-
   Real beta_dt = d->beta[stage - 1]*pmy_pack->pmesh->dt;
   if (fused && peers()) {
     StagePhase(d, stage, AKMI_PHASE_SWEEPS);
-  } else if (fused && !dt_dev && MergeC2P()) {
+  } else if (fused && !d->use_graph && MergeC2P()) {
     StagePhase(d, stage, AKMI_PHASE_SWEEPS | AKMI_PHASE_EMF_CT);      // see Hydro::RKUpdate
   } else if (fused) {
     int do_dt = (stage == d->nexp_stages);
@@ -1125,6 +1227,11 @@ void MHD::StagePhase(Driver *d, int stage, int phases) {
   const int do_dt = (stage == d->nexp_stages);
   const int copy = CopyFlag(d, stage, phases);
   d->ProfMark(stream);
+  if (dt_dev && stage >= 1)
+    AKCHK(akmi_mhd_stage_phase_dt(&pack_c, recon_method, rsolver_method, g0, g1, d->beta[stage - 1], dt_dev, copy, w0.p,
+                                  bcc0.p, u0.p, u1.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, b1.x1f.p, b1.x2f.p,
+                                  b1.x3f.p, do_dt, counters.p, dt3.p, phases, ws.p, stream));
+  else
   AKCHK(akmi_mhd_stage_phase(&pack_c, recon_method, rsolver_method, g0, g1, beta_dt, copy, w0.p,
                              bcc0.p, u0.p, u1.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, b1.x1f.p, b1.x2f.p,
                              b1.x3f.p, do_dt, counters.p, dt3.p, phases, ws.p, stream));
@@ -1148,7 +1255,7 @@ TaskStatus MHD::SendU(Driver *d, int stage) {
   } else if (pbval)
     pbval->PackAndSendCC(u0.p, stream);
   else
-    AKCHK(akmi_bvals_cc_local(&pack_c, nvars, pmy_pack->pmb->d_nghbr.p, u0.p, stream));
+    GatherU(d, stage);
   return TaskStatus::complete;
 }
 TaskStatus MHD::RecvU(Driver *d, int stage) {
@@ -1293,6 +1400,10 @@ TaskStatus MHD::SendB(Driver *d, int stage) {
   } else if (pbval) {
     pbval->PackAndSendFC(b0, stream);
     if (fused && peers()) StagePhase(d, stage, AKMI_PHASE_C2P);
+  } else if (FoldBCs() && !pmy_pack->pmesh->strictly_periodic) {
+    AKCHK(akmi_bvals_fc_local_bcs(&pack_c, pmy_pack->pmb->d_nghbr.p, pmy_pack->pmb->d_bcs.p, nullptr, b0.x1f.p, b0.x2f.p,
+                                  b0.x3f.p, stream));
+    b_bcs_done_ = true;
   } else {
     AKCHK(akmi_bvals_fc_local(&pack_c, pmy_pack->pmb->d_nghbr.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, stream));
   }
@@ -1300,8 +1411,11 @@ TaskStatus MHD::SendB(Driver *d, int stage) {
 }
 TaskStatus MHD::ApplyPhysicalBCs(Driver *d, int stage) {   // mhd_tasks.cpp:501-520
   if (pmy_pack->pmesh->strictly_periodic) return TaskStatus::complete;
-  AKCHK(akmi_hydro_bcs_dirs(&pack_c, nvars, pmy_pack->pmb->d_bcs.p, pmy_pack->pmb->bc_dirs, nullptr, u0.p, stream));
-  AKCHK(akmi_bfield_bcs_dirs(&pack_c, pmy_pack->pmb->d_bcs.p, pmy_pack->pmb->bc_dirs, nullptr, b0.x1f.p, b0.x2f.p, b0.x3f.p, stream));
+  if (!u_bcs_done_)
+    AKCHK(akmi_hydro_bcs_dirs(&pack_c, nvars, pmy_pack->pmb->d_bcs.p, pmy_pack->pmb->bc_dirs, nullptr, u0.p, stream));
+  if (!b_bcs_done_)
+    AKCHK(akmi_bfield_bcs_dirs(&pack_c, pmy_pack->pmb->d_bcs.p, pmy_pack->pmb->bc_dirs, nullptr, b0.x1f.p, b0.x2f.p, b0.x3f.p, stream));
+  u_bcs_done_ = b_bcs_done_ = false;
   return TaskStatus::complete;
 }
 TaskStatus MHD::ConToPrim(Driver *d, int stage) {
@@ -1314,8 +1428,9 @@ TaskStatus MHD::ConToPrim(Driver *d, int stage) {
   } else if (fused) {
     int do_dt = (stage == d->nexp_stages);
     d->ProfMark(stream);
-    AKCHK(akmi_mhd_c2p_newdt(&pack_c, u0.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, w0.p, bcc0.p, do_dt,
+    AKCHK(akmi_mhd_c2p_newdt(&pack_c, u0.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, w0.p, bcc0.p, (do_dt && dt3_reset_) ? 2 : do_dt,
                              counters.p, dt3.p, stream));
+    dt3_reset_ = false;
     d->ProfMark(stream);
     dt_ready_ = do_dt;
   } else if (multilevel && stage == d->nexp_stages && !kinematic) {
@@ -1334,6 +1449,7 @@ TaskStatus MHD::NewTimeStep(Driver *d, int stage) {        // mhd_newdt.cpp:31-1
   else if (!dt_ready_) AKCHK(akmi_mhd_newdt(&pack_c, w0.p, bcc0.p, dt3.p, stream));
   dt_ready_ = false;
   if (d->capturing) return TaskStatus::complete;   // the Driver reads dt3 after the graph launch
+  if (d->ra_active) { d->EnqueueMeshNewDt(this); return TaskStatus::complete; }
   FinishNewDt();
   DiffusionNewDt();
   return TaskStatus::complete;

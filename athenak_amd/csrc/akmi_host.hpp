@@ -391,6 +391,12 @@ class FluidBase {
   void AddDiffusionFluxes(DvceFaceFld &flx, int face_shaped);   // hydro_tasks.cpp:183-189
   void DiffusionNewDt();                                        // hydro_newdt.cpp:128-133
   bool interior_done_ = false, dt_ready_ = false;
+  // single-rank uniform meshes: the gather of SendU / SendB applies the physical boundary functions as well
+  // (akmi_bvals_*_local_bcs); ApplyPhysicalBCs then has nothing left to do for that array.  AKMI_FOLD_BCS=0: the separate
+  // kernels (A/B runs).  dt3_reset_: that launch also reset the CFL minima of the last stage.
+  bool u_bcs_done_ = false, b_bcs_done_ = false, dt3_reset_ = false;
+  static bool FoldBCs();
+  void GatherU(Driver *d, int stage);
 };
 
 namespace hydro {
@@ -486,8 +492,22 @@ class Driver {          // driver.cpp
   void ProfMark(hipStream_t st);
   int ProfRead(double *ms_total, long long *calls);
   hipGraphExec_t cycle_exec = nullptr;
-  DvceArray<Real> d_dt;
+  DvceArray<Real> d_dt;              // [0] dt of the cycle being enqueued, [1] its start time (run-ahead mode)
   Real *h_dt = nullptr;              // pinned
+  // Run-ahead cycles.  The reference reads the new time step back at the end of every cycle (hydro_newdt.cpp:121-124,
+  // mesh.cpp:573-643) and the device idles while the host wakes up, computes dt and issues the next cycle's first
+  // launches -- 30-40 us, 10 % of a cycle of the 128^3 hydro deck.  Here Mesh::NewTimeStep runs ON the device at the end
+  // of the cycle (k_mesh_newdt: the same operations in the same order on (dt3, dt, time, tlim, cfl_no)), every kernel takes
+  // dt from device memory, and the host enqueues cycle n+1 while cycle n runs: to do that it needs time_(n+1) =
+  // time_n + dt_n only, and dt_n is the result of cycle n-1.  The results of a cycle reach the host through a pinned
+  // slot + event, one cycle late; Execute drains them before it returns, so (time, dt, ncycle) are exact at every
+  // akmi_sim_* call.  Eligible like the cycle graph: fused stage, one rank, uniform mesh, no diffusion time steps.
+  // <time>/run_ahead = auto (on when eligible) | true | false; AKMI_RUN_AHEAD=0/1 overrides.
+  bool run_ahead = false, ra_active = false;     // ra_active: inside the run-ahead loop of Execute
+  Real *ra_slot = nullptr;           // pinned, device-visible: 2 slots x {dt, time, dtnew}
+  hipEvent_t ra_ev[2] = {nullptr, nullptr};
+  long long ra_cycle = 0;            // cycles enqueued in run-ahead mode (slot = ra_cycle & 1)
+  void EnqueueMeshNewDt(FluidBase *f);
  private:
   void RunStages(Mesh *pm);
 };

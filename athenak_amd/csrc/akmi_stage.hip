@@ -2260,7 +2260,7 @@ int akmi_hydro_c2p_newdt(const akmi_pack *p, double *u0, double *w0, int do_newd
                          double *dt3, void *stream) {
   Geo g = make_geo(p);
   hipStream_t st = (hipStream_t)stream;
-  if (do_newdt) k_init_dt3<<<1, 64, 0, st>>>(dt3);
+  if (do_newdt == 1) k_init_dt3<<<1, 64, 0, st>>>(dt3);
   return launch_c2p<false>(g, make_eos(p), u0, nullptr, nullptr, nullptr, w0, nullptr, do_newdt,
                            counters, dt3, 0, g.N1 - 1, 0, g.N2 - 1, 0, g.N3, st);
 }
@@ -2270,7 +2270,7 @@ int akmi_mhd_c2p_newdt(const akmi_pack *p, double *u0, const double *bx1f, const
                        double *dt3, void *stream) {
   Geo g = make_geo(p);
   hipStream_t st = (hipStream_t)stream;
-  if (do_newdt) k_init_dt3<<<1, 64, 0, st>>>(dt3);
+  if (do_newdt == 1) k_init_dt3<<<1, 64, 0, st>>>(dt3);
   return launch_c2p<true>(g, make_eos(p), u0, bx1f, bx2f, bx3f, w0, bcc0, do_newdt, counters, dt3,
                           0, g.N1 - 1, 0, g.N2 - 1, 0, g.N3, st);
 }
@@ -2332,6 +2332,25 @@ int akmi_mhd_stage_phase(const akmi_pack *p, int recon, int rsolver, double gam0
   C2PArgs cp{1, do_newdt, counters, dt3};
   return stage_update<true>(p, recon, rsolver, gam0, gam1, beta_dt, copy_u1, w0, bcc0, u0, u1, b0x1f, b0x2f,
                             b0x3f, b1x1f, b1x2f, b1x3f, ws, cp, (hipStream_t)stream, phases);
+}
+
+int akmi_hydro_stage_phase_dt(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1, double beta,
+                              const double *dt_dev, int copy_u1, double *w0, double *u0, double *u1, int do_newdt,
+                              int *counters, double *dt3, int phases, void *ws, void *stream) {
+  if (phases <= 0 || phases > AKMI_PHASE_ALL) { set_error("stage_phase: bad phase mask"); return AKMI_FAIL; }
+  C2PArgs cp{1, do_newdt, counters, dt3};
+  return stage_update<false>(p, recon, rsolver, gam0, gam1, beta, copy_u1, w0, nullptr, u0, u1, nullptr,
+                             nullptr, nullptr, nullptr, nullptr, nullptr, ws, cp, (hipStream_t)stream, phases, dt_dev);
+}
+
+int akmi_mhd_stage_phase_dt(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1, double beta,
+                            const double *dt_dev, int copy_u1, double *w0, double *bcc0, double *u0, double *u1,
+                            double *b0x1f, double *b0x2f, double *b0x3f, double *b1x1f, double *b1x2f, double *b1x3f,
+                            int do_newdt, int *counters, double *dt3, int phases, void *ws, void *stream) {
+  if (phases <= 0 || phases > AKMI_PHASE_ALL) { set_error("stage_phase: bad phase mask"); return AKMI_FAIL; }
+  C2PArgs cp{1, do_newdt, counters, dt3};
+  return stage_update<true>(p, recon, rsolver, gam0, gam1, beta, copy_u1, w0, bcc0, u0, u1, b0x1f, b0x2f,
+                            b0x3f, b1x1f, b1x2f, b1x3f, ws, cp, (hipStream_t)stream, phases, dt_dev);
 }
 
 int akmi_hydro_c2p_shell(const akmi_pack *p, double *u0, double *w0, int *counters, void *stream) {

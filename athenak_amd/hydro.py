@@ -421,7 +421,12 @@ class Hydro(FluidBase):
     def SendU(self, pdrive, stage):
         if self.multilevel:
             return self.psmr.PackAndSendCC(self.u0, self.coarse_u0)
-        st = self.pbval_u.PackAndSendCC(self.u0)
+        reset = None
+        if (self.fused and self.pbval_u.fold_bcs and stage >= 1 and stage == pdrive.nexp_stages
+                and not getattr(self, "_interior_done", False)):
+            reset = self.dt3                 # the gather of the last stage also resets the CFL minima
+        st = self.pbval_u.PackAndSendCC(self.u0, reset)
+        self._dt3_reset = reset is not None
         if self.fused and self.pbval_u.peers:
             # the messages are in flight on the transport's stream: convert the active cells
             # (they do not depend on the halo) underneath them
@@ -462,8 +467,10 @@ class Hydro(FluidBase):
                 ev.append((e0, e1))
                 e0.record()
             capi.check(self.L.akmi_hydro_c2p_newdt(
-                C.byref(self.pack_c), capi._p(self.u0), capi._p(self.w0), do_dt,
+                C.byref(self.pack_c), capi._p(self.u0), capi._p(self.w0),
+                2 if (do_dt and getattr(self, "_dt3_reset", False)) else do_dt,
                 capi._p(self.counters), capi._p(self.dt3), capi._stream()), "hydro_c2p_newdt")
+            self._dt3_reset = False
             if ev is not None:
                 e1.record()
             self._dt_ready = bool(do_dt)

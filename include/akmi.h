@@ -280,6 +280,19 @@ int akmi_hydro_bcs_dirs(const akmi_pack *p, int nvar, const int *bcs, int dirs, 
 int akmi_bfield_bcs_dirs(const akmi_pack *p, const int *bcs, int dirs, const double *b_in, double *bx1f, double *bx2f,
                          double *bx3f, void *stream);
 
+/* Same-rank gather AND the physical boundary functions of the pack in ONE launch, for packs without off-rank neighbours
+ * (every nghbr entry >= -1): the result equals akmi_bvals_cc_local followed by akmi_hydro_bcs_inflow (resp.
+ * akmi_bvals_fc_local followed by akmi_bfield_bcs_inflow) bit for bit.  The reference applies its boundary functions one
+ * direction after the other over all transverse indices (hydro_bcs.cpp:69-230, bfield_bcs.cpp:66-300, called from
+ * hydro_tasks.cpp:357-375 / mhd_tasks.cpp after the receives); a ghost element therefore holds T3(T2(T1(x))) of ONE source
+ * element x, and the kernel fetches that element directly.  u_in / b_in may be NULL when no face is AKMI_BC_INFLOW.
+ * dt3_reset (may be NULL): the three CFL minima are set to FLT_MAX by the same launch, so the following
+ * akmi_*_c2p_newdt may be called with do_newdt = 2 ("scan, dt3 already reset"). */
+int akmi_bvals_cc_local_bcs(const akmi_pack *p, int nvar, const int *nghbr, const int *bcs, const double *u_in, double *u,
+                            double *dt3_reset, void *stream);
+int akmi_bvals_fc_local_bcs(const akmi_pack *p, const int *nghbr, const int *bcs, const double *b_in, double *bx1f,
+                            double *bx2f, double *bx3f, void *stream);
+
 /* ---- SMR/AMR operators between a MeshBlock and its coarse buffer ---------- *
  * Coarse arrays: cnx = nx/2 active cells, the same ng ghost cells, same layout:
  * (nmb,nvar,cN3,cN2,cN1), faces +1 in their own direction (src/mesh/mesh.cpp:286-330).  Index boxes
@@ -494,7 +507,8 @@ int akmi_mhd_stage_update(const akmi_pack *p, int recon, int rsolver, double gam
                           const double *bcc0, double *u0, double *u1, double *b0x1f,
                           double *b0x2f, double *b0x3f, double *b1x1f, double *b1x2f,
                           double *b1x3f, void *ws, void *stream);
-/* ConsToPrim + (optionally, last stage) NewTimeStep fused */
+/* ConsToPrim + (optionally, last stage) NewTimeStep fused.  do_newdt: 0 no scan, 1 reset dt3 and scan, 2 scan only (dt3 was
+ * reset earlier in stream order, e.g. by akmi_bvals_cc_local_bcs) */
 int akmi_hydro_c2p_newdt(const akmi_pack *p, double *u0, double *w0, int do_newdt,
                          int *counters, double *dt3, void *stream);
 int akmi_mhd_c2p_newdt(const akmi_pack *p, double *u0, const double *bx1f,
@@ -547,6 +561,15 @@ int akmi_mhd_stage_phase(const akmi_pack *p, int recon, int rsolver, double gam0
                          double *u1, double *b0x1f, double *b0x2f, double *b0x3f,
                          double *b1x1f, double *b1x2f, double *b1x3f, int do_newdt,
                          int *counters, double *dt3, int phases, void *ws, void *stream);
+/* the parts with dt read from device memory (beta = the RK weight alone, as in akmi_*_stage_fused_dt): for callers that
+ * enqueue a cycle before the previous cycle's new time step has reached the host */
+int akmi_hydro_stage_phase_dt(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1, double beta,
+                              const double *dt_dev, int copy_u1, double *w0, double *u0, double *u1, int do_newdt,
+                              int *counters, double *dt3, int phases, void *ws, void *stream);
+int akmi_mhd_stage_phase_dt(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1, double beta,
+                            const double *dt_dev, int copy_u1, double *w0, double *bcc0, double *u0, double *u1,
+                            double *b0x1f, double *b0x2f, double *b0x3f, double *b1x1f, double *b1x2f, double *b1x3f,
+                            int do_newdt, int *counters, double *dt3, int phases, void *ws, void *stream);
 int akmi_hydro_c2p_shell(const akmi_pack *p, double *u0, double *w0, int *counters,
                          void *stream);
 int akmi_mhd_c2p_shell(const akmi_pack *p, double *u0, const double *bx1f, const double *bx2f,

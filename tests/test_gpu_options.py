@@ -4,6 +4,10 @@ once per process, so every case runs in a process of its own and must be bit-ide
                     rank with off-rank neighbours uses) instead of one conversion after the ghost fill
   AKMI_OUT_OF_PLACE=0  C++ host: CopyCons + in-place first stage instead of the out-of-place stage with swapped registers
 (the sign-word, two-kernel-x12 and k_march3ct options of rounds 3-4 lost their measurements and left the source in round 5)
+C++ host, single rank, uniform mesh:
+  AKMI_RUN_AHEAD=0  the new time step read back at the end of every cycle (one host synchronisation per cycle) instead of
+                    Mesh::NewTimeStep on the device with the host one cycle ahead (default when eligible)
+  AKMI_FOLD_BCS=0   same-rank gather + one kernel per bounded direction instead of akmi_bvals_*_local_bcs (both hosts)
 refined meshes:
   AKMI_SMR_DIRECT=0        same-level cell-centred ghost zones through the pack/unpack buffers instead of directly
   AKMI_SMR_LISTS=0         the level-boundary kernels launched over all nmb*56 (block, slot) pairs instead of the work
@@ -104,4 +108,36 @@ def test_storing_marches_on_small_packs():
     task-granular cases of the scheme matrix through both hosts, bit-identical to the oracle."""
     r = subprocess.run([sys.executable, "-c", MARCH_SCRIPT], env=dict(os.environ, AKMI_FACE_SWEEPS="0"),
                        capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+RUN_SCRIPT = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import parity_util as pu
+# whole runs in ONE Execute call (the host enqueues cycle n+1 while cycle n runs), the last cycle clipped at tlim:
+# end state, clock, next dt and cycle count against the oracle's run
+for problem, n, dims, mb, kw in (("sod", 32, 3, 16, dict(cfl=0.3, extra=["time/tlim=0.06"])),
+                                 ("sod", 64, 1, 32, dict(cfl=0.3, extra=["time/tlim=0.05"])),
+                                 ("orszag_tang", 32, 3, 16, dict(cfl=0.3, extra=["time/tlim=0.03"])),
+                                 ("blast", 24, 3, 12, dict(extra=["time/tlim=0.008"])),
+                                 ("orszag_tang", 32, 2, 16, dict(cfl=0.3, integrator="rk3", extra=["time/tlim=0.03"]))):
+    for native in (True, False):
+        sim, osim, is_mhd = pu.make_pair(problem, n, dims, mb, fused=True, native=native, **kw)
+        sim.Execute()
+        osim.run()
+        d = pu.compare_fields(pu.product_arrays(sim), pu.oracle_arrays(osim, is_mhd), is_mhd)
+        assert d["bitwise_equal"], (problem, native, d)
+        assert sim.pmesh.time == osim.time == osim.tlim and sim.pmesh.dt == osim.dt, (problem, native, sim.pmesh.time, osim.time, sim.pmesh.dt, osim.dt)
+        assert sim.pmesh.ncycle == osim.ncycle and osim.ncycle > 5, (problem, sim.pmesh.ncycle, osim.ncycle)
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+
+
+@pytest.mark.parametrize("env", [{}, {"AKMI_RUN_AHEAD": "0"}, {"AKMI_FOLD_BCS": "0"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())) or "defaults")
+def test_whole_runs_to_tlim_in_one_execute_call(env):
+    r = subprocess.run([sys.executable, "-c", RUN_SCRIPT], env=dict(os.environ, **env), capture_output=True, text=True,
+                       timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

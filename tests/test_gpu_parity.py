@@ -305,6 +305,70 @@ def test_task_bcs(bc):
 
 
 @pytest.mark.parametrize("dims", [1, 2, 3])
+@pytest.mark.parametrize("bc", ["outflow", "reflect", "diode", "vacuum", "inflow", "mixed", "periodic_x2"])
+def test_task_gather_with_bcs_in_one_launch(bc, dims):
+    """akmi_bvals_cc_local_bcs / akmi_bvals_fc_local_bcs (gather + every physical boundary function in one launch)
+    against the reference's sequence -- gather, then the boundary functions direction by direction over all transverse
+    indices -- as the oracle restates it: two MeshBlocks side by side in x1 (inner faces `block`), every flag on the outer
+    faces; periodic_x2: x2 wraps onto the block itself, so corner ghosts compose a boundary function with a gather"""
+    from athenak_amd import capi
+    L, R = capi.lib(), akref.lib()
+    rng = np.random.default_rng(11 + dims)
+    nmb, nx, ng = 2, 6, 3
+    nxs = [nx if q < dims else 1 for q in range(3)]
+    N = [n + 2*ng if n > 1 else 1 for n in nxs]
+    pk, dx = akref.make_pack(nmb, nxs[0], nxs[1], nxs[2], ng, np.ones((nmb, 3)), 1.4)
+    dxd = _t(dx)
+    pkd = capi.Pack.from_buffer_copy(bytes(pk))
+    pkd.dx = dxd.data_ptr()
+    B = akref.BC
+    if bc == "mixed":
+        bcs = np.array([[B["inflow"], B["block"], B["vacuum"], B["reflect"], B["user"], B["outflow"]],
+                        [B["block"], B["vacuum"], B["diode"], B["inflow"], B["reflect"], B["diode"]]], dtype=np.int32)
+    elif bc == "periodic_x2":
+        bcs = np.array([[B["reflect"], B["block"], B["periodic"], B["periodic"], B["outflow"], B["diode"]],
+                        [B["block"], B["outflow"], B["periodic"], B["periodic"], B["outflow"], B["diode"]]], dtype=np.int32)
+    else:
+        bcs = np.full((nmb, 6), B[bc], dtype=np.int32)
+        bcs[0, 1] = bcs[1, 0] = B["block"]
+    # neighbours: across the shared x1 face (and its edges / corners where the transverse direction is not bounded)
+    ngh = -np.ones((nmb, 27), dtype=np.int32)
+    for m in range(nmb):
+        for d in range(27):
+            o1, o2, o3 = d % 3 - 1, (d//3) % 3 - 1, d//9 - 1
+            if d == 13 or (dims < 2 and o2) or (dims < 3 and o3):
+                continue
+            tgt = m + o1
+            if tgt < 0 or tgt >= nmb:
+                continue                                        # outer x1 face: physical
+            if o3 != 0:
+                continue                                        # x3 faces: physical in every case here
+            if o2 != 0 and bc != "periodic_x2":
+                continue
+            ngh[m, d] = tgt
+    u_in, b_in = rng.normal(size=(5, 6)), rng.normal(size=(3, 6))
+    u = rng.normal(size=(nmb, 5, N[2], N[1], N[0]))
+    b = [rng.normal(size=(nmb, N[2], N[1], N[0] + 1)), rng.normal(size=(nmb, N[2], N[1] + 1, N[0])),
+         rng.normal(size=(nmb, N[2] + 1, N[1], N[0]))]
+    ud, bd, bcd, nd = _t(u), [_t(x) for x in b], _t(bcs), _t(ngh)
+    uid, bid = _t(u_in), _t(b_in)
+    R.akref_bvals_cc_local(C.byref(pk), 5, akref.ptr(ngh), akref.ptr(u))
+    R.akref_bvals_fc_local(C.byref(pk), akref.ptr(ngh), *[akref.ptr(x) for x in b])
+    R.akref_hydro_bcs_inflow(C.byref(pk), 5, akref.ptr(bcs), akref.ptr(u_in), akref.ptr(u))
+    R.akref_bfield_bcs_inflow(C.byref(pk), akref.ptr(bcs), akref.ptr(b_in), *[akref.ptr(x) for x in b])
+    import torch
+    dt3 = torch.zeros(3, dtype=torch.float64, device="cuda")
+    capi.check(L.akmi_bvals_cc_local_bcs(C.byref(pkd), 5, capi._p(nd), capi._p(bcd), capi._p(uid), capi._p(ud),
+                                         capi._p(dt3), None), "cc_local_bcs")
+    capi.check(L.akmi_bvals_fc_local_bcs(C.byref(pkd), capi._p(nd), capi._p(bcd), capi._p(bid),
+                                         *[capi._p(x) for x in bd], None), "fc_local_bcs")
+    assert np.array_equal(u, ud.cpu().numpy())
+    for x, y in zip(b, bd):
+        assert np.array_equal(x, y.cpu().numpy())
+    assert (dt3.cpu().numpy() == np.float64(np.finfo(np.float32).max)).all()      # the CFL minima were reset
+
+
+@pytest.mark.parametrize("dims", [1, 2, 3])
 def test_task_bvals_pack_unpack_roundtrip(dims):
     """pack on the 'sender' + unpack on the 'receiver' == the same-rank gather, for every
     direction: emulate a remote neighbour with a second copy of the same pack"""
