@@ -487,7 +487,7 @@ void FluidBase::GatherU(Driver *d, int stage) {
   if (FoldBCs() && !pmy_pack->pmesh->strictly_periodic) {
     // the last stage of the fused path: the launch also resets the CFL minima its ConsToPrim scans into
     // (not when the stage call has converted the active cells already: their scan is in dt3 by now)
-    Real *reset = (fused && !interior_done_ && stage >= 1 && stage == d->nexp_stages) ? dt3.p : nullptr;
+    Real *reset = (fused && !interior_done_ && !d->ra_active && stage >= 1 && stage == d->nexp_stages) ? dt3.p : nullptr;
     AKCHK(akmi_bvals_cc_local_bcs(&pack_c, nvars, pmy_pack->pmb->d_nghbr.p, pmy_pack->pmb->d_bcs.p, nullptr, u0.p, reset,
                                   stream));
     u_bcs_done_ = true;
@@ -735,7 +735,7 @@ Driver::Driver(ParameterInput *pin, Mesh *pmesh) {       // driver.cpp:85-162
   if (pmesh->nranks > 1 || nphys != 1 || SelfExchange() || use_graph) run_ahead = false;
   if (use_graph || run_ahead) {
     d_dt.Realloc(2);
-    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h_dt), 2*sizeof(Real)));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h_dt), 5*sizeof(Real)));
     for (FluidBase *f : phys) if (f) f->dt_dev = d_dt.p;
   }
   if (run_ahead) {
@@ -753,7 +753,7 @@ Driver::~Driver() {
 }
 
 // Mesh::NewTimeStep (mesh.cpp:573-643) for one physics module without diffusion, on the device: st = {dt, time}
-__global__ void k_mesh_newdt(const Real *__restrict__ dt3, Real *__restrict__ st, Real tlim, Real cfl_no, int multi_d,
+__global__ void k_mesh_newdt(Real *__restrict__ dt3, Real *__restrict__ st, Real tlim, Real cfl_no, int multi_d,
                              int three_d, Real *__restrict__ slot) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   Real dt = st[0], time = st[1];
@@ -767,6 +767,7 @@ __global__ void k_mesh_newdt(const Real *__restrict__ dt3, Real *__restrict__ st
   if ((time < tlim) && ((time + dt) > tlim)) dt = tlim - time;
   st[0] = dt; st[1] = time;
   slot[0] = dt; slot[1] = time; slot[2] = dtnew;
+  dt3[0] = dt3[1] = dt3[2] = static_cast<Real>(FLT_MAX);    // the next cycle's scan starts from here (no k_init_dt3 launch)
 }
 void Driver::EnqueueMeshNewDt(FluidBase *f) {
   Mesh *pm = f->pmy_pack->pmesh;
@@ -848,7 +849,9 @@ int Driver::Execute(Mesh *pm, int max_cycles) {            // driver.cpp:380-459
     FluidBase *f = pm->pmb_pack->phydro ? static_cast<FluidBase *>(pm->pmb_pack->phydro)
                                         : static_cast<FluidBase *>(pm->pmb_pack->pmhd);
     h_dt[0] = pm->dt; h_dt[1] = pm->time;
+    h_dt[2] = h_dt[3] = h_dt[4] = static_cast<Real>(FLT_MAX);
     HIPCHK(hipMemcpyAsync(d_dt.p, h_dt, 2*sizeof(Real), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(hipMemcpyAsync(f->dt3.p, h_dt + 2, 3*sizeof(Real), hipMemcpyHostToDevice, f->stream));
     bool pending = false;                // a cycle is enqueued whose results the host has not read yet
     auto collect = [&](long long cyc) {  // results of cycle `cyc` (counted like ra_cycle): dt of the cycle after it
       const int s = static_cast<int>(cyc & 1);
@@ -1122,7 +1125,9 @@ TaskStatus Hydro::ConToPrim(Driver *d, int stage) {        // hydro_tasks.cpp:40
   } else if (fused) {
     int do_dt = (stage == d->nexp_stages);
     d->ProfMark(stream);
-    AKCHK(akmi_hydro_c2p_newdt(&pack_c, u0.p, w0.p, (do_dt && dt3_reset_) ? 2 : do_dt, counters.p, dt3.p, stream));
+    // (run-ahead cycles: k_mesh_newdt leaves the minima reset for the next cycle)
+    AKCHK(akmi_hydro_c2p_newdt(&pack_c, u0.p, w0.p, do_dt ? ((dt3_reset_ || d->ra_active) ? 2 : 1) : 0, counters.p, dt3.p,
+                               stream));
     dt3_reset_ = false;
     d->ProfMark(stream);
     dt_ready_ = do_dt;
@@ -1428,7 +1433,8 @@ TaskStatus MHD::ConToPrim(Driver *d, int stage) {
   } else if (fused) {
     int do_dt = (stage == d->nexp_stages);
     d->ProfMark(stream);
-    AKCHK(akmi_mhd_c2p_newdt(&pack_c, u0.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, w0.p, bcc0.p, (do_dt && dt3_reset_) ? 2 : do_dt,
+    AKCHK(akmi_mhd_c2p_newdt(&pack_c, u0.p, b0.x1f.p, b0.x2f.p, b0.x3f.p, w0.p, bcc0.p,
+                             do_dt ? ((dt3_reset_ || d->ra_active) ? 2 : 1) : 0,
                              counters.p, dt3.p, stream));
     dt3_reset_ = false;
     d->ProfMark(stream);

@@ -939,6 +939,9 @@ __device__ __forceinline__ double upw(bool pos, double fa, double ca, double fb,
 #ifndef AKMI_CKL
 #define AKMI_CKL 32
 #endif
+#ifndef AKMI_CT_XCD_ROWS
+#define AKMI_CT_XCD_ROWS 1
+#endif
 constexpr int CKL = AKMI_CKL;          // cell planes per k-chunk (one plane of edges recomputed)
 
 // The tile of edge positions is tw x th threads (owners: (tw-1) x (th-1)), lanes flattened over
@@ -974,10 +977,26 @@ __device__ __forceinline__ void corner_ct_body(const Geo &g, const double *__res
   const int ty = threadIdx.x/tw, tx = threadIdx.x - ty*tw;
   const bool in_tile = ty < th;          // the workgroup is padded to whole waves
   // (xcd_order, which pays in the hydro tile kernel, costs this bandwidth-bound one 2 %: 659 -> 675 us, profiles/r05_mhd_ab.txt)
-  const int i = g.is + blockIdx.x*(tw - 1) + tx;
-  const int j = g.js + blockIdx.y*(th - 1) + ty;
-  const int m = blockIdx.z/nchunk;
-  const int ch = blockIdx.z - m*nchunk;
+  // Workgroup -> tile: the tiles of one tile ROW (same j range, same k-chunk: neighbours in x1, whose edge columns and
+  // unaligned row ends share 64-/128-byte pieces of every operand row) go to ONE XCD, consecutive rows to consecutive
+  // XCDs, so that all eight L2s stream through the same planes at the same time: 625 -> 617 us at 256^3
+  // (profiles/r05_corner_ct_xcd_rows.txt; a whole k-chunk per XCD, xcd_order, costs 2 %).
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (AKMI_CT_XCD_ROWS) {
+    const unsigned n1 = gridDim.x, nrows = gridDim.y*gridDim.z, full = nrows & ~7u;
+    const unsigned b = bx + n1*(by + gridDim.y*bz);
+    if (b < n1*full) {                                           // whole groups of eight rows; the rest keeps its place
+      const unsigned xcd = b & 7u, slot = b >> 3;
+      const unsigned rl = slot/n1;
+      bx = slot - rl*n1;
+      const unsigned R = rl*8u + xcd;
+      bz = R/gridDim.y; by = R - bz*gridDim.y;
+    }
+  }
+  const int i = g.is + bx*(tw - 1) + tx;
+  const int j = g.js + by*(th - 1) + ty;
+  const int m = bz/nchunk;
+  const int ch = bz - m*nchunk;
   const int k0 = kA + ch*ckl;                                   // first cell plane of this chunk
   const int k1 = (k0 + ckl - 1 < kB) ? k0 + ckl - 1 : kB;       // last cell plane
   const bool wtop = top && (k1 == kB);                          // this chunk owns the x3-faces kB+1
@@ -1893,7 +1912,9 @@ static int launch_hydro_stage3d(const Geo &g, const Scheme &sc, const double *w0
                                 int kA, int kB, hipStream_t st, Mass3 ms) {
   const HydTile tl = hyd_tile(g.nx1, g.nx2);
   if (tl.tw == 0) { set_error("hydro_stage3d: no tile shape"); return AKMI_FAIL; }
-  const int ckl = march_len((long)tl.n1*tl.n2, kB - kA + 1, g.nmb, ML);
+  int ckl = march_len((long)tl.n1*tl.n2, kB - kA + 1, g.nmb, ML);
+  static const int ckl_env = getenv("AKMI_HS_CKL") ? atoi(getenv("AKMI_HS_CKL")) : 0;     // experiments: pin the chunk length
+  if (ckl_env > 0) ckl = ckl_env;                   // (128^3: the rule's 4 sits on the flat bottom, profiles/r05_hydro_host_ab.txt)
   const int nchunk = cdiv(kB - kA + 1, ckl);
   const size_t lds = hyd_lds_doubles(tl.tw, tl.th)*sizeof(double);
   dim3 grid(tl.n1, tl.n2, nchunk*g.nmb), block(tl.threads);
