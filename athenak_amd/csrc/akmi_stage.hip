@@ -942,6 +942,12 @@ __device__ __forceinline__ double upw(bool pos, double fa, double ca, double fb,
 #ifndef AKMI_CT_XCD_ROWS
 #define AKMI_CT_XCD_ROWS 1
 #endif
+#ifndef AKMI_C2P_PAIRS
+#define AKMI_C2P_PAIRS 1
+#endif
+#ifndef AKMI_C2P_PAIRS_MIN
+#define AKMI_C2P_PAIRS_MIN 4000000l
+#endif
 constexpr int CKL = AKMI_CKL;          // cell planes per k-chunk (one plane of edges recomputed)
 
 // The tile of edge positions is tw x th threads (owners: (tw-1) x (th-1)), lanes flattened over
@@ -1301,6 +1307,104 @@ k_c2p_newdt(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ 
       const double d = g.dx[3*m + threadIdx.x]/v;
       // one word saturates at ~88 atomics/us on this chip: only workgroups that can lower the
       // running minimum issue the atomic (the plain read is a filter, the atomic decides)
+      if (d < __hip_atomic_load(&dt3[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMin(reinterpret_cast<unsigned long long *>(&dt3[threadIdx.x]),
+                  (unsigned long long)__double_as_longlong(d));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Pass B, two cells per thread (ideal gas, no passive scalars, rows of an even number of cells): every access of
+// the cell-centred arrays is one 16-byte non-temporal access -- the streaming form that copies at 6.8 instead of
+// 6.2 TB/s on this chip (tools/micro/copy_bw.hip, profiles/r05_copy_bw.txt); the conversion reads each conserved
+// value once and its results are not read again before the cache has turned over.  x1 faces have rows of N1 + 1
+// (odd) elements: three 8-byte loads, shared with the neighbouring lanes through L1.
+typedef double d2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ d2_t ld2nt(const double *p) { return __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(p)); }
+__device__ __forceinline__ d2_t ld2(const double *p) { return *reinterpret_cast<const d2_t *>(p); }
+__device__ __forceinline__ void st2nt(double *p, double a, double b) {
+  d2_t v; v.x = a; v.y = b;
+  __builtin_nontemporal_store(v, reinterpret_cast<d2_t *>(p));
+}
+
+// (MHD: 86 VGPRs, five waves per SIMD; held to 80 / 64 registers it spills and runs at 383 / 605 us against 364-389,
+//  profiles/r05_c2p_pairs.txt)
+template <bool MHD>
+__global__ void __launch_bounds__(SX*SY)
+k_c2p_newdt2(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ bx1f,
+             const double *__restrict__ bx2f, const double *__restrict__ bx3f,
+             double *__restrict__ w0, double *__restrict__ bcc0, int do_newdt,
+             int *__restrict__ counters, double *__restrict__ dt3, int il, int iu, int jl, int ju,
+             int k0, int nk) {
+  // cells [il,iu] x [jl,ju] x [k0,k0+nk-1], il even and iu odd; lanes run over the cell PAIRS of the flattened rows
+  __shared__ double sm[3][SY];
+  const int hw = g.N1 >> 1;
+  const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;
+  const int jj = (int)(p/hw);
+  const int j = jl + jj;
+  const int i = 2*(int)(p - (long)jj*hw);
+  const int m = blockIdx.z/nk;
+  const int k = k0 + (blockIdx.z - m*nk);
+  double mv1 = 0.0, mv2 = 0.0, mv3 = 0.0;
+  if (j <= ju && i >= il && i <= iu) {
+    const size_t cs = (size_t)g.N3*g.N2*g.N1;
+    const size_t c = ix5(5, g.N3, g.N2, g.N1, m, 0, k, j, i);
+    double ubx[2] = {0.0, 0.0}, uby[2] = {0.0, 0.0}, ubz[2] = {0.0, 0.0};
+    if constexpr (MHD) {
+      const double *b1 = bx1f + ix4(g.N3, g.N2, g.N1 + 1, m, k, j, i);
+      const double f0 = b1[0], f1 = b1[1], f2 = b1[2];
+      ubx[0] = 0.5*(f0 + f1); ubx[1] = 0.5*(f1 + f2);
+      const d2_t y0 = ld2(bx2f + ix4(g.N3, g.N2 + 1, g.N1, m, k, j, i)), y1 = ld2(bx2f + ix4(g.N3, g.N2 + 1, g.N1, m, k, j + 1, i));
+      uby[0] = 0.5*(y0.x + y1.x); uby[1] = 0.5*(y0.y + y1.y);
+      const d2_t z0 = ld2(bx3f + ix4(g.N3 + 1, g.N2, g.N1, m, k, j, i)), z1 = ld2(bx3f + ix4(g.N3 + 1, g.N2, g.N1, m, k + 1, j, i));
+      ubz[0] = 0.5*(z0.x + z1.x); ubz[1] = 0.5*(z0.y + z1.y);
+      const size_t b = ix5(3, g.N3, g.N2, g.N1, m, 0, k, j, i);
+      st2nt(bcc0 + b, ubx[0], ubx[1]); st2nt(bcc0 + b + cs, uby[0], uby[1]); st2nt(bcc0 + b + 2*cs, ubz[0], ubz[1]);
+    }
+    const d2_t vd = ld2nt(u0 + c), vx = ld2nt(u0 + c + cs), vy = ld2nt(u0 + c + 2*cs), vz = ld2nt(u0 + c + 3*cs),
+               ve = ld2nt(u0 + c + 4*cs);
+    double ud[2] = {vd.x, vd.y}, ue[2] = {ve.x, ve.y};
+    const double umx[2] = {vx.x, vx.y}, umy[2] = {vy.x, vy.y}, umz[2] = {vz.x, vz.y};
+    double wd[2], wvx[2], wvy[2], wvz[2], we[2];
+    const bool act = do_newdt && j >= g.js && j <= g.je && k >= g.ks && k <= g.ke;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      bool dfl = false, efl = false, tfl = false;
+      if constexpr (MHD) {
+        c2p_mhd(eos, ud[q], umx[q], umy[q], umz[q], ue[q], ubx[q], uby[q], ubz[q], wd[q], wvx[q], wvy[q], wvz[q], we[q],
+                dfl, efl, tfl);
+      } else {
+        c2p_hyd(eos, ud[q], umx[q], umy[q], umz[q], ue[q], wd[q], wvx[q], wvy[q], wvz[q], we[q], dfl, efl, tfl);
+      }
+      if (dfl) { u0[c + q] = ud[q]; atomicAdd(&counters[0], 1); }
+      if (efl) { u0[c + q + 4*cs] = ue[q]; atomicAdd(&counters[1], 1); }
+      if (tfl) { u0[c + q + 4*cs] = ue[q]; atomicAdd(&counters[2], 1); }
+      if (act && i + q >= g.is && i + q <= g.ie) {
+        // hydro_newdt.cpp:97-118 / mhd_newdt.cpp:123-136
+        const double pr = (eos.gamma - 1.0)*we[q];
+        if constexpr (MHD) {
+          mv1 = fmax(mv1, fabs(wvx[q]) + fast_speed(eos.gamma, wd[q], pr, ubx[q], uby[q], ubz[q]));
+          mv2 = fmax(mv2, fabs(wvy[q]) + fast_speed(eos.gamma, wd[q], pr, uby[q], ubz[q], ubx[q]));
+          mv3 = fmax(mv3, fabs(wvz[q]) + fast_speed(eos.gamma, wd[q], pr, ubz[q], ubx[q], uby[q]));
+        } else {
+          const double cs_ = sqrt(eos.gamma*pr/wd[q]);
+          mv1 = fmax(mv1, fabs(wvx[q]) + cs_); mv2 = fmax(mv2, fabs(wvy[q]) + cs_); mv3 = fmax(mv3, fabs(wvz[q]) + cs_);
+        }
+      }
+    }
+    st2nt(w0 + c, wd[0], wd[1]); st2nt(w0 + c + cs, wvx[0], wvx[1]); st2nt(w0 + c + 2*cs, wvy[0], wvy[1]);
+    st2nt(w0 + c + 3*cs, wvz[0], wvz[1]); st2nt(w0 + c + 4*cs, we[0], we[1]);
+  }
+  if (!do_newdt) return;        // uniform across the grid
+  mv1 = wave_max(mv1); mv2 = wave_max(mv2); mv3 = wave_max(mv3);
+  if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.y] = mv1; sm[1][threadIdx.y] = mv2; sm[2][threadIdx.y] = mv3; }
+  __syncthreads();
+  if (threadIdx.y == 0 && threadIdx.x < 3) {
+    double v = sm[threadIdx.x][0];
+    for (int q = 1; q < SY; ++q) v = fmax(v, sm[threadIdx.x][q]);
+    if (v > 0.0) {
+      const double d = g.dx[3*m + threadIdx.x]/v;
       if (d < __hip_atomic_load(&dt3[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         atomicMin(reinterpret_cast<unsigned long long *>(&dt3[threadIdx.x]),
                   (unsigned long long)__double_as_longlong(d));
@@ -2038,6 +2142,19 @@ static int launch_c2p(const Geo &g, const Eos &eos, double *u0, const double *bx
                       int do_newdt, int *counters, double *dt3, int il, int iu, int jl, int ju,
                       int k0, int nk, hipStream_t st) {
   dim3 grid((unsigned)(((long)(ju - jl + 1)*g.N1 + SX*SY - 1)/(SX*SY)), 1, nk*g.nmb), block(SX, SY);
+#if AKMI_C2P_PAIRS
+  static const bool pairs_off = getenv("AKMI_C2P_PAIRS") && atoi(getenv("AKMI_C2P_PAIRS")) == 0;       // A/B switch
+  // (from ~4 M cells per launch: at 128^3 = 2.3 M the launch is latency-bound and half the threads lose 5 % of a cycle,
+  //  at 192^3 = 7.5 M the pairs gain 2.4 %, at 256^3 3.5 %; profiles/r05_c2p_pairs.txt)
+  const long ncell = (long)g.nmb*nk*(ju - jl + 1)*g.N1;
+  if (!pairs_off && ncell >= AKMI_C2P_PAIRS_MIN && eos.is_ideal && g.nvar == 5 && !(g.N1 & 1) && !(il & 1) && (iu & 1)) {
+    dim3 grid2((unsigned)(((long)(ju - jl + 1)*(g.N1/2) + SX*SY - 1)/(SX*SY)), 1, nk*g.nmb);
+    k_c2p_newdt2<MHD><<<grid2, block, 0, st>>>(g, eos, u0, bx1f, bx2f, bx3f, w0, bcc0, do_newdt, counters,
+                                               dt3, il, iu, jl, ju, k0, nk);
+    AKMI_CHECK_LAUNCH("c2p pairs");
+    return AKMI_COMPLETE;
+  }
+#endif
   k_c2p_newdt<MHD><<<grid, block, 0, st>>>(g, eos, u0, bx1f, bx2f, bx3f, w0, bcc0, do_newdt, counters,
                                            dt3, il, iu, jl, ju, k0, nk);
   AKMI_CHECK_LAUNCH("c2p");

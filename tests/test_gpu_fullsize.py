@@ -202,3 +202,51 @@ def test_c5_blast_smr_at_deck_size_is_bit_identical(native):
     tot = (ph.u0[:, :, k, j, i].sum(dim=(2, 3, 4))*vol).sum(dim=0).cpu().numpy()
     tot0 = r["totals0"]
     assert np.all(np.abs(tot - tot0) <= 1e-12*np.maximum(1.0, np.abs(tot0))), (tot, tot0)
+
+
+@pytest.mark.parametrize("mhd", [False, True], ids=["hydro", "mhd"])
+def test_paired_c2p_newdt_with_floors_against_the_oracle(mhd):
+    """akmi_*_c2p_newdt at a size that takes the two-cells-per-thread kernel (>= 4 M cells per launch: one MeshBlock of
+    160^3 + ghosts), random states with a tenth of the cells below the density or the pressure floor: u0, w0, bcc0, the
+    three floor counters and the three CFL minima against the oracle's ConsToPrim + NewTimeStep"""
+    import ctypes as C
+    import torch
+    from athenak_amd import capi
+    from oracle import akref
+    L, R = capi.lib(), akref.lib()
+    rng = np.random.default_rng(41)
+    nx, ng = 160, 2
+    N = nx + 2*ng
+    pk, dx = akref.make_pack(1, nx, nx, nx, ng, np.full((1, 3), 1.0/nx), 5.0/3.0)
+    pk.dfloor, pk.pfloor = 0.3, 0.2
+    dxd = torch.from_numpy(dx.copy()).cuda()
+    pkd = capi.Pack.from_buffer_copy(bytes(pk))
+    pkd.dx = dxd.data_ptr()
+    u = rng.uniform(0.5, 2.0, size=(1, 5, N, N, N))
+    u[:, 1:4] = rng.normal(size=u[:, 1:4].shape)
+    b = [rng.normal(size=(1, N, N, N + 1)), rng.normal(size=(1, N, N + 1, N)), rng.normal(size=(1, N + 1, N, N))] if mhd else []
+    emag = 0.0
+    if mhd:
+        emag = 0.5*((0.5*(b[0][..., :-1] + b[0][..., 1:]))**2 + (0.5*(b[1][:, :, :-1] + b[1][:, :, 1:]))**2 +
+                    (0.5*(b[2][:, :-1] + b[2][:, 1:]))**2)
+    u[:, 4] = 0.5*(u[:, 1]**2 + u[:, 2]**2 + u[:, 3]**2)/u[:, 0] + emag + rng.uniform(0.5, 3.0, size=u[:, 4].shape)
+    low = rng.random(size=u[:, 0].shape)
+    u[:, 0][low < 0.05] = 0.1
+    u[:, 4][(low > 0.05) & (low < 0.1)] = 0.01
+    w, bcc = np.zeros_like(u), np.zeros((1, 3, N, N, N))
+    cnt, dt3 = np.zeros(3, dtype=np.int32), np.zeros(3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    ud, wd, bd, bccd, cntd, dtd = t(u), t(w), [t(x) for x in b], t(bcc), t(cnt), t(dt3)
+    if mhd:
+        R.akref_mhd_c2p_newdt(C.byref(pk), akref.ptr(u), *[akref.ptr(x) for x in b], akref.ptr(w), akref.ptr(bcc), 1,
+                              akref.ptr(cnt), akref.ptr(dt3))
+        capi.check(L.akmi_mhd_c2p_newdt(C.byref(pkd), capi._p(ud), *[capi._p(x) for x in bd], capi._p(wd), capi._p(bccd), 1,
+                                        capi._p(cntd), capi._p(dtd), None), "mhd_c2p_newdt")
+        assert np.array_equal(bcc, bccd.cpu().numpy())
+    else:
+        R.akref_hydro_c2p_newdt(C.byref(pk), akref.ptr(u), akref.ptr(w), 1, akref.ptr(cnt), akref.ptr(dt3))
+        capi.check(L.akmi_hydro_c2p_newdt(C.byref(pkd), capi._p(ud), capi._p(wd), 1, capi._p(cntd), capi._p(dtd), None),
+                   "hydro_c2p_newdt")
+    assert np.array_equal(u, ud.cpu().numpy()) and np.array_equal(w, wd.cpu().numpy())
+    assert cnt.sum() > 1000 and np.array_equal(cnt, cntd.cpu().numpy()), (cnt, cntd)
+    assert np.array_equal(dt3, dtd.cpu().numpy()), (dt3, dtd)

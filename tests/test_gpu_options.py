@@ -8,6 +8,8 @@ C++ host, single rank, uniform mesh:
   AKMI_RUN_AHEAD=0  the new time step read back at the end of every cycle (one host synchronisation per cycle) instead of
                     Mesh::NewTimeStep on the device with the host one cycle ahead (default when eligible)
   AKMI_FOLD_BCS=0   same-rank gather + one kernel per bounded direction instead of akmi_bvals_*_local_bcs (both hosts)
+  AKMI_C2P_PAIRS=0  ConsToPrim with one cell per thread at every size (two cells per thread from 4 M cells per launch otherwise;
+                    the full-size tests of test_gpu_fullsize.py run the paired kernel against the oracle)
 refined meshes:
   AKMI_SMR_DIRECT=0        same-level cell-centred ghost zones through the pack/unpack buffers instead of directly
   AKMI_SMR_LISTS=0         the level-boundary kernels launched over all nmb*56 (block, slot) pairs instead of the work
@@ -135,7 +137,7 @@ print("ok")
 """ % (ROOT, os.path.join(ROOT, "tests"))
 
 
-@pytest.mark.parametrize("env", [{}, {"AKMI_RUN_AHEAD": "0"}, {"AKMI_FOLD_BCS": "0"}, {"AKMI_FOLD_BCS": "0", "AKMI_RUN_AHEAD": "0"}],
+@pytest.mark.parametrize("env", [{}, {"AKMI_FOLD_BCS": "0", "AKMI_RUN_AHEAD": "0", "AKMI_C2P_PAIRS": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())) or "defaults")
 def test_whole_runs_to_tlim_in_one_execute_call(env):
     r = subprocess.run([sys.executable, "-c", RUN_SCRIPT], env=dict(os.environ, **env), capture_output=True, text=True,
