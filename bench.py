@@ -283,7 +283,10 @@ def run_cpp_host(args, pin):
     el = time.perf_counter() - t0
     ms, calls = C.c_double(0.0), C.c_longlong(0)
     capi.check(L.akmi_sim_profile_read(sim.h, C.byref(ms), C.byref(calls)), "sim_profile_read")
-    info.update(host="C++ (akmi_sim_*: Mesh, TaskList, Driver in C++; one C-ABI call per task)", el=el, steps=done,
+    ra = os.environ.get("AKMI_RUN_AHEAD", "1") != "0" and pm.nranks == 1 and not pm.multilevel
+    info.update(host="C++ (akmi_sim_*: Mesh, TaskList, Driver in C++; one C-ABI call per task%s)" % (
+                    "; new time step on the device, host one cycle ahead, drained inside the timed region" if ra else ""),
+                el=el, steps=done,
                 value=info["ncell_total"]*done/el/1e6, ms_per_step=el/max(done, 1)*1e3, group_ms=ms.value,
                 group_calls=calls.value, time=sim.time, dt=sim.dt, ncycle=sim.ncycle)
     sim.close()
