@@ -124,7 +124,9 @@ for problem, n, dims, mb, kw in (("sod", 32, 3, 16, dict(cfl=0.3, extra=["time/t
                                  ("sod", 64, 1, 32, dict(cfl=0.3, extra=["time/tlim=0.05"])),
                                  ("orszag_tang", 32, 3, 16, dict(cfl=0.3, extra=["time/tlim=0.03"])),
                                  ("blast", 24, 3, 12, dict(extra=["time/tlim=0.05"])),
-                                 ("orszag_tang", 32, 2, 16, dict(cfl=0.3, integrator="rk3", extra=["time/tlim=0.03"]))):
+                                 ("orszag_tang", 32, 2, 16, dict(cfl=0.3, integrator="rk3", extra=["time/tlim=0.03"])),
+                                 ("sod", 32, 3, 16, dict(cfl=0.3, integrator="rk4", extra=["time/tlim=0.03"])),
+                                 ("orszag_tang", 24, 3, 24, dict(cfl=0.3, integrator="rk1", extra=["time/tlim=0.02"]))):
     for native in (True, False):
         sim, osim, is_mhd = pu.make_pair(problem, n, dims, mb, fused=True, native=native, **kw)
         sim.Execute()
