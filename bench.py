@@ -608,6 +608,16 @@ def other_configs(args):
     a.problem, a.nx = "sod", 128
     pin, _ = make_pin(a, (1, 1, 1))
     run("configs[1]: sod 3D, 128^3 single MeshBlock, ideal hydro PLM+HLLC, RK2, C++ host", pin, 5, 40)
+    # the same hydro scheme at the headline's size, and config 5's numerics (PPM4 + HLLD, ng = 4) on the headline's uniform mesh
+    a = copy.copy(args)
+    a.problem, a.nx = "sod", 256
+    pin, _ = make_pin(a, (1, 1, 1))
+    run("hydro at the headline's size: sod 3D, 256^3 single MeshBlock, ideal hydro PLM+HLLC, RK2, C++ host", pin, 3, 20)
+    a = copy.copy(args)
+    a.problem, a.nx, a.recon = "orszag_tang", 256, "ppm4"
+    pin, _ = make_pin(a, (1, 1, 1))
+    run("config 5's numerics on the headline's mesh: orszag_tang 3D, 256^3 single MeshBlock, MHD PPM4+HLLD+CT, ng=4, RK2, "
+        "C++ host", pin, 3, 15)
     ov = ["time/nlim=-1", "time/tlim=1.0e9"]
     run("configs[4] mesh on one GPU, deck size: blast 3D MHD, 2-level static refinement, 120 MeshBlocks of 16^3, "
         "PPM4+HLLD+CT, ng=4, C++ host", load_deck("blast_mhd_smr.athinput", ov), 5, 40)
