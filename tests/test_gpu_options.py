@@ -126,6 +126,13 @@ for problem, n, dims, mb, kw in (("sod", 32, 3, 16, dict(cfl=0.3, extra=["time/t
                                  ("blast", 24, 3, 12, dict(extra=["time/tlim=0.05"])),
                                  ("orszag_tang", 32, 2, 16, dict(cfl=0.3, integrator="rk3", extra=["time/tlim=0.03"])),
                                  ("sod", 32, 3, 16, dict(cfl=0.3, integrator="rk4", extra=["time/tlim=0.03"])),
+                                 # MHD with bounded faces in two directions, 2 x 2 x 2 MeshBlocks: cell- and face-centred gathers
+                                 # that compose a boundary function with a neighbour (edges and corners of the blocks)
+                                 ("orszag_tang", 32, 3, 16, dict(cfl=0.3, extra=["time/tlim=0.02", "mesh/ix1_bc=outflow",
+                                                                               "mesh/ox1_bc=reflect", "mesh/ix2_bc=reflect",
+                                                                               "mesh/ox2_bc=outflow"])),
+                                 ("blast", 24, 3, 12, dict(recon="plm", extra=["time/tlim=0.03", "mesh/ix3_bc=diode", "mesh/ox3_bc=diode",
+                                                                              "mesh/ix1_bc=outflow", "mesh/ox1_bc=outflow"])),
                                  ("orszag_tang", 24, 3, 24, dict(cfl=0.3, integrator="rk1", extra=["time/tlim=0.02"]))):
     for native in (True, False):
         sim, osim, is_mhd = pu.make_pair(problem, n, dims, mb, fused=True, native=native, **kw)
