@@ -1736,6 +1736,7 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
 }
 
 
+#include "akmi_mhd_stage3d.hpp"
 
 __global__ void k_init_dt3(double *dt3) {
   if (threadIdx.x < 3) dt3[threadIdx.x] = (double)FLT_MAX;
@@ -2316,6 +2317,8 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
   //  measured slower at every slab thickness in rounds 1 and 3 -- profiles/r03_slab_ab.txt; it left the source in round 5.)
   // AKMI_HYDRO_ONE_KERNEL=0: the three-kernel sweep/march sequence also for hydro DC/PLM (A/B runs)
   static const bool hyd_one = !(getenv("AKMI_HYDRO_ONE_KERNEL") && atoi(getenv("AKMI_HYDRO_ONE_KERNEL")) == 0);
+  // AKMI_MHD_ONE_KERNEL=1: k_mhd_stage3d instead of k_sweep12s + x3 march (A/B runs)
+  static const bool mhd_one = getenv("AKMI_MHD_ONE_KERNEL") && atoi(getenv("AKMI_MHD_ONE_KERNEL")) != 0;   // opt-in until it wins
   const int kA = g.ks, kB = g.ke;
   SweepArgs b1 = a1, b2 = a2, b3 = a3;
   b1.kl = kA - (MHD ? 1 : 0); b1.ku = kB + (MHD ? 1 : 0);
@@ -2325,6 +2328,14 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
     // hydro DC/PLM: sweeps + update in one kernel
     rc = g.nvar > (sc.iso ? 4 : 5) ? launch_hydro_stage3d<true>(g, sc, w0, u, kA, kB, st, Mass3{w.flx1, w.flx2, w.flx3})
                     : launch_hydro_stage3d<false>(g, sc, w0, u, kA, kB, st, Mass3{nullptr, nullptr, nullptr});
+  } else if (do_sweeps && MHD && mhd_one && sc.recon == 1 && !sc.iso && sc.rsolver == AKMI_RS_HLLD && g.nvar == 5 &&
+             mhd_tile(g.nx1 + 2, g.nx2 + 2).tw > 0) {
+    // MHD PLM + HLLD: the three sweeps + update in one kernel (k_mhd_stage3d)
+    if constexpr (MHD) {
+      const MhdStageArgs ma{w0, bcc0, b0x1f, b0x2f, b0x3f, w.flx1, w.flx2, w.flx3, w.efc[0], w.efc[1], w.efc[2], w.efc[3],
+                            w.efc[4], w.efc[5], w.ecc[0], w.ecc[1], w.ecc[2]};
+      rc = launch_mhd_stage3d(g, sc, ma, u, st);
+    }
   } else if (do_sweeps && MHD && sc.recon == 1 && !sc.iso && sc.rsolver == AKMI_RS_HLLD && g.nvar == 5) {
     // x1 sweep inside the x2 march, cells from the march's window (k_sweep12s); x3 march consumes acc
     // (the other order -- x3 march first, leaving dF3/dx3, k_sweep12s finishing the update -- was built and measured in
