@@ -87,6 +87,46 @@ class HipBvalsKernels:
                                                capi._p(b2), capi._p(b3), capi._stream()), "bfield_bcs")
 
 
+class HaloProfile:
+    """Where a multi-rank stage of the Python host spends its exchange (the mirror of akmi_comm_profile of the C++ host):
+    device time of the pack and unpack kernels (event pairs), the exposed wait for the receives -- a stall of the compute
+    stream with RCCL (event pair round the wait), host time spent blocked in wait() with a host-staged transport -- and the
+    dt all-reduce of a cycle.  Switched on by bench.py for its timed loop; None otherwise."""
+
+    def __init__(self):
+        self.pairs = {"pack": [], "wait": [], "unpack": []}
+        self.wait_host_s = 0.0
+        self.dt_reduce_s = 0.0
+        self.dt_calls = 0
+        self.bytes = 0
+        self.posts = 0
+        self.peers = 0
+
+    def mark(self, cat):
+        import torch
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.pairs[cat].append((a, b))
+        a.record()
+        return b
+
+    def summary(self, nstages, ncycles):
+        import torch
+        torch.cuda.synchronize()
+        ms = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in self.pairs.items()}
+        ns, nc = max(nstages, 1), max(ncycles, 1)
+        return {"pack_ms": round(ms["pack"]/ns, 5), "exposed_wait_ms": round((ms["wait"] + self.wait_host_s*1e3)/ns, 5),
+                "unpack_ms": round(ms["unpack"]/ns, 5), "dt_reduce_ms": round(self.dt_reduce_s*1e3/nc, 5),
+                "bytes_sent_per_stage": int(self.bytes/ns), "peers": int(self.peers), "rccl_ranks": None,
+                "posts_per_stage": round(self.posts/ns, 3),
+                "event_pairs": {k: len(v) for k, v in self.pairs.items()},
+                "what": "Python host, rank 0, timed loop: HIP event pairs round the pack / unpack kernels and round the wait "
+                        "for the receives (RCCL: the stall of the compute stream; host-staged transport: plus the host time "
+                        "blocked in wait()); dt all-reduce: host time of the call per cycle"}
+
+
+HALO_PROF = None        # a HaloProfile while bench.py times its loop
+
+
 class _Channel:
     """Send/recv plan of one variable class (CC or FC)."""
 
@@ -220,12 +260,25 @@ class MeshBoundaryValues:
             a, b = ch.send_slices[r]
             if b > a:
                 ops.append(dist.P2POp(dist.isend, sbuf[a:b], r))
+                if HALO_PROF is not None:
+                    HALO_PROF.bytes += 8*(b - a)
+        if HALO_PROF is not None:
+            HALO_PROF.posts += 1
+            HALO_PROF.peers = max(HALO_PROF.peers, len(self.peers))
         ch.works = dist.batch_isend_irecv(ops) if ops else []
 
     def _wait(self, ch):
+        prof = HALO_PROF
+        if prof is not None:
+            import time as _t
+            e1, t0 = prof.mark("wait"), _t.perf_counter()
         for w in ch.works:
             w.wait()
         ch.works = []
+        if prof is not None:
+            if ch.h_recv is not None:           # host-staged: wait() blocked the host, nothing stalled on the stream
+                prof.wait_host_s += _t.perf_counter() - t0
+            e1.record()
         if ch.h_recv is not None:
             ch.recvbuf.copy_(ch.h_recv, non_blocking=True)
 
@@ -239,15 +292,21 @@ class MeshBoundaryValues:
             return TaskStatus.complete
         self.k.cc_local(self.pack_c, self.nvar, self.nghbr, u)
         if self.peers:
+            e1 = HALO_PROF.mark("pack") if HALO_PROF is not None else None
             self.k.cc_pack(self.pack_c, self.nvar, self.cc.nsend, self.cc.send_tab, self.cc.send_off,
                            u, self.cc.sendbuf)
+            if e1 is not None:
+                e1.record()
             self._post(self.cc)
         return TaskStatus.complete
 
     def RecvAndUnpackCC(self, u):
         if self.peers:
             self._wait(self.cc)
+            e1 = HALO_PROF.mark("unpack") if HALO_PROF is not None else None
             self.k.cc_unpack(self.pack_c, self.nvar, self.nghbr, self.cc.seg_off, self.cc.recvbuf, u)
+            if e1 is not None:
+                e1.record()
         return TaskStatus.complete
 
     # ---- face-centred ------------------------------------------------------------
@@ -258,16 +317,22 @@ class MeshBoundaryValues:
             return TaskStatus.complete
         self.k.fc_local(self.pack_c, self.nghbr, b.x1f, b.x2f, b.x3f)
         if self.peers:
+            e1 = HALO_PROF.mark("pack") if HALO_PROF is not None else None
             self.k.fc_pack(self.pack_c, self.fc.nsend, self.fc.send_tab, self.fc.send_off,
                            b.x1f, b.x2f, b.x3f, self.fc.sendbuf)
+            if e1 is not None:
+                e1.record()
             self._post(self.fc)
         return TaskStatus.complete
 
     def RecvAndUnpackFC(self, b):
         if self.peers:
             self._wait(self.fc)
+            e1 = HALO_PROF.mark("unpack") if HALO_PROF is not None else None
             self.k.fc_unpack(self.pack_c, self.nghbr, self.fc.seg_off, self.fc.recvbuf,
                              b.x1f, b.x2f, b.x3f)
+            if e1 is not None:
+                e1.record()
         return TaskStatus.complete
 
     # ---- physical boundaries -----------------------------------------------------

@@ -101,7 +101,7 @@ __device__ __forceinline__ double bc_value(double v, int f, int D, int side, int
     if (comp == 0) { const double sgn = normal ? -1.0 : 1.0; return sgn*v; }
     return normal ? -1.0*v : v;
   }
-  if (f == AKMI_BC_INFLOW) return in[6*(comp == 0 ? n : comp - 1) + 2*D + side];
+  if (f == AKMI_BC_INFLOW) return in ? in[6*(comp == 0 ? n : comp - 1) + 2*D + side] : 0.0;   // no table (akmi.h allows NULL): zeros
   if (comp == 0) {
     if (f == AKMI_BC_DIODE) return normal ? (side ? fmax(0.0, v) : fmin(0.0, v)) : v;
     if (f == AKMI_BC_VACUUM) return 0.0;

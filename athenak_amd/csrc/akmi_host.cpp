@@ -7,9 +7,11 @@
 #include <cctype>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <sstream>
 
 namespace akmi {
+void set_error(const char *fmt, ...);
 namespace host {
 
 [[noreturn]] void Fatal(const char *file, int line, const std::string &msg) {
@@ -17,14 +19,24 @@ namespace host {
   std::exit(EXIT_FAILURE);     // the reference's error convention (e.g. src/mesh/mesh.cpp:234)
 }
 
+[[noreturn]] void Throw(const char *file, int line, const std::string &msg) {
+  const char *b = std::strrchr(file, '/');
+  throw HostError(std::string(b ? b + 1 : file) + ":" + std::to_string(line) + ": " + msg);
+}
+void NoteException(const char *entry) noexcept {
+  try { throw; }
+  catch (const std::exception &e) { akmi::set_error("%s: %s", entry, e.what()); }
+  catch (...) { akmi::set_error("%s: unknown C++ exception", entry); }
+}
+
 #define HIPCHK(x)                                                                   \
   do {                                                                              \
     hipError_t e_ = (x);                                                            \
-    if (e_ != hipSuccess) AKMI_FATAL(std::string(#x) + ": " + hipGetErrorString(e_)); \
+    if (e_ != hipSuccess) { (void)hipGetLastError(); AKMI_THROW(std::string(#x) + ": " + hipGetErrorString(e_)); } \
   } while (0)
 #define AKCHK(x)                                                              \
   do {                                                                        \
-    if ((x) < 0) AKMI_FATAL(std::string(#x) + ": " + akmi_last_error());      \
+    if ((x) < 0) AKMI_THROW(std::string(#x) + ": " + akmi_last_error());      \
   } while (0)
 
 // ---- ParameterInput (src/parameter_input.cpp:155-209,369-409,508-552) -------------------
@@ -145,6 +157,10 @@ TaskListStatus TaskList::DoAvailable(Driver *d, int s) {
 // ---- device arrays ------------------------------------------------------------------------
 template <typename T> void DvceArray<T>::Realloc(size_t count) {
   Free();
+  // AKMI_FAIL_ALLOC_AFTER=n (tests): the n-th device allocation of the process fails as an exhausted device would
+  static const long fail_at = std::getenv("AKMI_FAIL_ALLOC_AFTER") ? std::atol(std::getenv("AKMI_FAIL_ALLOC_AFTER")) : -1;
+  static long nalloc = 0;
+  if (fail_at >= 0 && ++nalloc > fail_at) AKMI_THROW("device allocation of " + std::to_string(count*sizeof(T)) + " bytes failed (injected)");
   n = count;
   HIPCHK(hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1)*sizeof(T)));
   HIPCHK(hipMemset(p, 0, std::max<size_t>(count, 1)*sizeof(T)));
@@ -504,9 +520,12 @@ void FluidBase::FinishNewDt() {        // hydro_newdt.cpp:121-124
   // -- so a cycle has ONE host synchronisation (this read-back, which the reference has too: hydro_newdt.cpp:121)
   // instead of read-back + H2D + all-reduce + read-back.  min_r(min(2 dt_old, cfl dt_r)) == min(2 dt_old, cfl min_r dt_r).
   dt_reduced = false;
-  if ((pm->nranks > 1 || SelfExchange()) && !has_visc && !has_cond && !has_resist)
+  const bool several = pm->nranks > 1 || SelfExchange();
+  if (several) Comm::World().ProfMark(Comm::kDtReduce, stream);
+  if (several && !has_visc && !has_cond && !has_resist)
     dt_reduced = Comm::World().AllReduceMinDevice(dt3.p, 3, stream);
   HIPCHK(hipMemcpyAsync(d, dt3.p, sizeof(d), hipMemcpyDeviceToHost, stream));
+  if (several) Comm::World().ProfMark(Comm::kDtReduce, stream);
   HIPCHK(hipStreamSynchronize(stream));
   dtnew = d[0];
   if (pm->multi_d) dtnew = std::min(dtnew, d[1]);
@@ -812,6 +831,8 @@ void Driver::ExecuteTaskList(Mesh *pm, const std::string &tl, int stage) {   // 
 }
 
 void Driver::InitBoundaryValuesAndPrimitives(Mesh *pm) {   // driver.cpp:569-653
+  if (pm->pmb_pack->phydro) pm->pmb_pack->phydro->BeginStage();
+  if (pm->pmb_pack->pmhd) pm->pmb_pack->pmhd->BeginStage();
   if (auto *ph = pm->pmb_pack->phydro) {
     ph->RestrictU(this, 0);
     ph->SendU(this, 0); ph->RecvU(this, 0); ph->Prolongate(this, 0);
@@ -836,6 +857,8 @@ void Driver::Initialize(Mesh *pm) {                        // driver.cpp:314-371
 void Driver::RunStages(Mesh *pm) {                         // driver.cpp:398-423
   ExecuteTaskList(pm, "before_timeintegrator", 0);
   for (int stage = 1; stage <= nexp_stages; ++stage) {
+    if (pm->pmb_pack->phydro) pm->pmb_pack->phydro->BeginStage();
+    if (pm->pmb_pack->pmhd) pm->pmb_pack->pmhd->BeginStage();
     ExecuteTaskList(pm, "before_stagen", stage);
     ExecuteTaskList(pm, "stagen", stage);
     ExecuteTaskList(pm, "after_stagen", stage);
@@ -859,12 +882,18 @@ int Driver::Execute(Mesh *pm, int max_cycles) {            // driver.cpp:380-459
       pm->dtold = pm->dt;
       pm->dt = ra_slot[3*s];
       f->dtnew = ra_slot[3*s + 2];
-      if (ra_slot[3*s + 1] != pm->time) AKMI_FATAL("run-ahead: the device clock left the host clock");
+      if (ra_slot[3*s + 1] != pm->time) AKMI_THROW("run-ahead: the device clock left the host clock");
     };
     while ((pm->time < tlim) && (pm->ncycle < nlim || nlim < 0)) {       // pm->time: start of the cycle to enqueue, exact
       if (max_cycles >= 0 && n >= max_cycles) break;
       ra_active = true;                  // (Initialize's NewTimeStep takes the synchronous path)
+      // the host's dt is the one of the cycle BEFORE the one being enqueued: every eligible task takes dt from device
+      // memory (stage_phase_dt / stage_fused_dt); a task that formed beta*pm->dt on the host would silently use the old
+      // value, so the field holds a NaN while the cycle is enqueued -- such a use shows in the first comparison
+      const Real dt_host = pm->dt;
+      pm->dt = std::numeric_limits<Real>::quiet_NaN();
       RunStages(pm);                     // the kernels read dt from d_dt; NewTimeStep enqueues k_mesh_newdt
+      pm->dt = dt_host;
       ra_active = false;
       // dt of the cycle just enqueued is the result of the cycle before it, which has finished by now or will long
       // before the one just enqueued does: the host needs it only here, to advance its clock
@@ -1482,35 +1511,48 @@ using namespace akmi::host;
 extern "C" {
 
 void *akmi_sim_create(const char *deck_text, void *stream) {
-  Sim *s = new Sim;
-  s->pin.LoadFromString(deck_text);
-  s->pmesh = new Mesh(&s->pin, Comm::World().rank, Comm::World().nranks);
-  s->pmesh->pmb_pack->AddPhysics(&s->pin);
-  if (!stream) {
-    HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
-    stream = s->own_stream;
+  Sim *s = nullptr;
+  try {
+    s = new Sim;
+    s->pin.LoadFromString(deck_text);
+    s->pmesh = new Mesh(&s->pin, Comm::World().rank, Comm::World().nranks);
+    s->pmesh->pmb_pack->AddPhysics(&s->pin);
+    if (!stream) {
+      HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+      stream = s->own_stream;
+    }
+    if (auto *ph = s->pmesh->pmb_pack->phydro) ph->stream = (hipStream_t)stream;
+    if (auto *pm = s->pmesh->pmb_pack->pmhd) pm->stream = (hipStream_t)stream;
+    return s;
+  } catch (...) {
+    NoteException("akmi_sim_create");
+    try { delete s; } catch (...) {}      // what the half-built objects own is released by their destructors
+    return nullptr;
   }
-  if (auto *ph = s->pmesh->pmb_pack->phydro) ph->stream = (hipStream_t)stream;
-  if (auto *pm = s->pmesh->pmb_pack->pmhd) pm->stream = (hipStream_t)stream;
-  return s;
 }
 
 /* the Driver reads <time>/tlim, which the linear-wave problem generator rescales: create it
  * after the initial conditions have been uploaded */
 int akmi_sim_initialize(void *h, double tlim_override) {
-  Sim *s = static_cast<Sim *>(h);
-  s->Enter();
-  if (tlim_override > 0.0) s->pin.SetReal("time", "tlim", tlim_override);
-  delete s->pdriver;
-  s->pdriver = new Driver(&s->pin, s->pmesh);
-  s->pdriver->Initialize(s->pmesh);
-  return AKMI_COMPLETE;
+  AKMI_C_ENTRY("akmi_sim_initialize", AKMI_FAIL,
+    Sim *s = static_cast<Sim *>(h);
+    s->Enter();
+    if (tlim_override > 0.0) s->pin.SetReal("time", "tlim", tlim_override);
+    delete s->pdriver;
+    s->pdriver = nullptr;
+    s->pdriver = new Driver(&s->pin, s->pmesh);
+    s->pdriver->Initialize(s->pmesh);
+    return AKMI_COMPLETE;
+  )
 }
 
 int akmi_sim_execute(void *h, int max_cycles) {
-  Sim *s = static_cast<Sim *>(h);
-  s->Enter();
-  return s->pdriver->Execute(s->pmesh, max_cycles);
+  AKMI_C_ENTRY("akmi_sim_execute", AKMI_FAIL,
+    Sim *s = static_cast<Sim *>(h);
+    if (!s->pdriver) { akmi::set_error("akmi_sim_execute: call akmi_sim_initialize first"); return AKMI_FAIL; }
+    s->Enter();
+    return s->pdriver->Execute(s->pmesh, max_cycles);
+  )
 }
 
 /* live timing of the fused-stage launch group: on != 0 starts recording a HIP event pair on the launch stream
@@ -1524,12 +1566,14 @@ int akmi_sim_profile(void *h, int on) {
   return AKMI_COMPLETE;
 }
 int akmi_sim_profile_read(void *h, double *ms_total, long long *calls) {
-  Sim *s = static_cast<Sim *>(h);
-  if (!s->pdriver) { akmi::set_error("akmi_sim_profile_read: call akmi_sim_initialize first"); return AKMI_FAIL; }
-  return s->pdriver->ProfRead(ms_total, calls);
+  AKMI_C_ENTRY("akmi_sim_profile_read", AKMI_FAIL,
+    Sim *s = static_cast<Sim *>(h);
+    if (!s->pdriver) { akmi::set_error("akmi_sim_profile_read: call akmi_sim_initialize first"); return AKMI_FAIL; }
+    return s->pdriver->ProfRead(ms_total, calls);
+  )
 }
 
-void akmi_sim_destroy(void *h) { delete static_cast<Sim *>(h); }
+void akmi_sim_destroy(void *h) { try { delete static_cast<Sim *>(h); } catch (...) { NoteException("akmi_sim_destroy"); } }
 
 double akmi_sim_time(void *h) { return static_cast<Sim *>(h)->pmesh->time; }
 double akmi_sim_dt(void *h) { return static_cast<Sim *>(h)->pmesh->dt; }
@@ -1540,6 +1584,7 @@ int akmi_sim_nmb(void *h) { return static_cast<Sim *>(h)->pmesh->nmb_total; }
 /* device pointer + element count of a named array: u0 w0 u1 bcc0 b0x1f b0x2f b0x3f b1x1f b1x2f
  * b1x3f dx ; lloc (host int[nmb][3]) via akmi_sim_lloc */
 void *akmi_sim_array(void *h, const char *name, long long *count) {
+  AKMI_C_ENTRY("akmi_sim_array", nullptr,
   Sim *s = static_cast<Sim *>(h);
   MeshBlockPack *pk = s->pmesh->pmb_pack;
   FluidBase *f = pk->phydro ? static_cast<FluidBase *>(pk->phydro) : static_cast<FluidBase *>(pk->pmhd);
@@ -1556,6 +1601,7 @@ void *akmi_sim_array(void *h, const char *name, long long *count) {
   if (!a) { if (count) *count = 0; return nullptr; }
   if (count) *count = static_cast<long long>(a->n);
   return a->p;
+  )
 }
 
 const int *akmi_sim_lloc(void *h) { return static_cast<Sim *>(h)->pmesh->lloc_eachmb.data(); }

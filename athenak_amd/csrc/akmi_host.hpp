@@ -22,6 +22,7 @@
 #include <list>
 #include <map>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <vector>
 #include "../../include/akmi.h"
@@ -60,6 +61,21 @@ class ParameterInput {
 
 [[noreturn]] void Fatal(const char *file, int line, const std::string &msg);
 #define AKMI_FATAL(msg) ::akmi::host::Fatal(__FILE__, __LINE__, (msg))
+
+// Errors of the INPUT DECK keep the reference's convention: "### FATAL ERROR in <file> at line <n>" + exit (AKMI_FATAL; e.g.
+// src/eos/eos.cpp:37-39, src/mesh/mesh.cpp:234).  Run-time failures -- a device allocation, a HIP / RCCL call, a library entry
+// that returned AKMI_FAIL -- are thrown as HostError; together with whatever else the C++ runtime throws (std::bad_alloc,
+// std::invalid_argument out of std::stoi on a malformed deck value, ...) they stop at the C entry points, which return
+// AKMI_FAIL / NULL with the message in akmi_last_error() (include/akmi.h:24-27; the TaskStatus::fail of
+// src/tasklist/task_list.hpp:30).  No C++ exception crosses `extern "C"`.
+struct HostError : std::runtime_error { using std::runtime_error::runtime_error; };
+[[noreturn]] void Throw(const char *file, int line, const std::string &msg);
+#define AKMI_THROW(msg) ::akmi::host::Throw(__FILE__, __LINE__, (msg))
+// the body of a C entry point: what it returns on an exception, then the statements
+void NoteException(const char *entry) noexcept;      // message of the exception in flight -> akmi_last_error()
+#define AKMI_C_ENTRY(entry, on_error, ...)                               \
+  try { __VA_ARGS__ }                                                    \
+  catch (...) { ::akmi::host::NoteException(entry); return on_error; }
 
 // ---------------------------------------------------------------------------------------
 class Driver;
@@ -164,7 +180,17 @@ class Comm {
   // returns false -- nothing done -- for the callback transport or without peers)
   bool AllReduceMinDevice(Real *dev_vals, int n, hipStream_t compute);
   static void GetUniqueId(char id[128]);
+  // exchange profile (akmi_comm_profile): event pairs on the compute stream per category
+  enum ProfCat { kPack = 0, kWait = 1, kUnpack = 2, kDtReduce = 3, kNCat = 4 };
+  bool prof_on = false;
+  void ProfMark(int cat, hipStream_t st);          // two calls = one pair
+  void ProfReset();
+  int ProfRead(double *out, int n);
  private:
+  std::vector<hipEvent_t> prof_ev_[kNCat];
+  size_t prof_used_[kNCat] = {0, 0, 0, 0};
+  long long prof_bytes_ = 0, prof_posts_ = 0;
+  int prof_peers_ = 0;
   void *nccl_ = nullptr;                 // ncclComm_t
   hipStream_t comm_stream_ = nullptr;
   hipEvent_t ready_[4] = {nullptr, nullptr, nullptr, nullptr}, done_[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -394,7 +420,13 @@ class FluidBase {
   // single-rank uniform meshes: the gather of SendU / SendB applies the physical boundary functions as well
   // (akmi_bvals_*_local_bcs); ApplyPhysicalBCs then has nothing left to do for that array.  AKMI_FOLD_BCS=0: the separate
   // kernels (A/B runs).  dt3_reset_: that launch also reset the CFL minima of the last stage.
+  // They are hand-shakes inside ONE stage (set by SendU / SendB, consumed by ApplyPhysicalBCs / ConToPrim of the same
+  // stage): the Driver clears them when a stage begins (BeginStage), so a task list that drops the consumer cannot leave one
+  // standing for a later stage.
   bool u_bcs_done_ = false, b_bcs_done_ = false, dt3_reset_ = false;
+ public:
+  void BeginStage() { u_bcs_done_ = b_bcs_done_ = dt3_reset_ = false; }
+ protected:
   static bool FoldBCs();
   void GatherU(Driver *d, int stage);
 };

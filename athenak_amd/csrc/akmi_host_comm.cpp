@@ -35,8 +35,8 @@ namespace akmi {
 void set_error(const char *fmt, ...);
 namespace host {
 
-#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
-  AKMI_FATAL(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+  (void)hipGetLastError(); AKMI_THROW(std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
 
 // ---- RCCL entry points, resolved at run time ----------------------------------------------------
 // libakmi.so has no link-time dependency on librccl: a Python process has torch's copy loaded
@@ -53,6 +53,7 @@ struct Rccl {
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;      // optional (the exchange profile reports it)
   bool ok = false;
   std::string where;
 };
@@ -72,14 +73,14 @@ Rccl &rccl() {
   if (!h) { r.where = "librccl not found"; return r; }
 #define SYM(f) r.f = reinterpret_cast<decltype(r.f)>(dlsym(h, "nccl" #f))
   SYM(GetUniqueId); SYM(CommInitRank); SYM(CommDestroy); SYM(Send); SYM(Recv); SYM(GroupStart);
-  SYM(GroupEnd); SYM(AllReduce); SYM(GetErrorString);
+  SYM(GroupEnd); SYM(AllReduce); SYM(GetErrorString); SYM(CommCount);
 #undef SYM
   r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.Send && r.Recv && r.GroupStart &&
          r.GroupEnd && r.AllReduce && r.GetErrorString;
   return r;
 }
 #define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) \
-  AKMI_FATAL(std::string(#x) + ": " + rccl().GetErrorString(r_)); } while (0)
+  AKMI_THROW(std::string(#x) + ": " + rccl().GetErrorString(r_)); } while (0)
 }  // namespace
 
 Comm &Comm::World() {
@@ -136,12 +137,55 @@ void Comm::Finalize() {
     for (Real *p : s.hr) hipHostFree(p);
     s.hs.clear(); s.hr.clear(); s.cs.clear(); s.cr.clear(); s.m.clear();
   }
+  for (int c = 0; c < kNCat; ++c) { for (hipEvent_t e : prof_ev_[c]) (void)hipEventDestroy(e); prof_ev_[c].clear(); }
+  ProfReset(); prof_on = false;
   rank = 0; nranks = 1; kind = Kind::none;
   ex_ = nullptr; ar_ = nullptr; user_ = nullptr;
 }
 
+// ---- exchange profile ---------------------------------------------------------------------------
+void Comm::ProfMark(int cat, hipStream_t st) {
+  if (!prof_on) return;
+  auto &ev = prof_ev_[cat];
+  if (prof_used_[cat] == ev.size()) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    ev.push_back(e);
+  }
+  HIPCHK(hipEventRecord(ev[prof_used_[cat]++], st));
+}
+void Comm::ProfReset() {
+  for (int c = 0; c < kNCat; ++c) prof_used_[c] = 0;
+  prof_bytes_ = 0; prof_posts_ = 0; prof_peers_ = 0;
+}
+int Comm::ProfRead(double *out, int n) {
+  if (!out || n < 12) { akmi::set_error("comm_profile_read: out needs room for 12 doubles"); return AKMI_FAIL; }
+  for (int c = 0; c < kNCat; ++c) {
+    double tot = 0.0;
+    const size_t np = prof_used_[c]/2;
+    for (size_t k = 0; k < np; ++k) {
+      HIPCHK(hipEventSynchronize(prof_ev_[c][2*k + 1]));
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, prof_ev_[c][2*k], prof_ev_[c][2*k + 1]));
+      tot += ms;
+    }
+    out[2*c] = tot; out[2*c + 1] = static_cast<double>(np);
+  }
+  out[8] = static_cast<double>(prof_bytes_); out[9] = static_cast<double>(prof_posts_); out[10] = prof_peers_;
+  int cnt = 0;
+  if (kind == Kind::rccl && rccl().CommCount) NCCLCHK(rccl().CommCount(static_cast<ncclComm_t>(nccl_), &cnt));
+  out[11] = cnt;
+  ProfReset();
+  return AKMI_COMPLETE;
+}
+
 void Comm::Post(const std::vector<Msg> &m, hipStream_t compute, int c) {
   if (m.empty()) return;
+  if (prof_on) {
+    for (const Msg &x : m) prof_bytes_ += x.nsend*static_cast<long long>(sizeof(Real));
+    ++prof_posts_;
+    prof_peers_ = std::max(prof_peers_, static_cast<int>(m.size()));
+  }
   if (kind == Kind::rccl) {
     ncclComm_t comm = static_cast<ncclComm_t>(nccl_);
     HIPCHK(hipEventRecord(ready_[c], compute));                 // the pack kernel has been enqueued
@@ -181,7 +225,10 @@ void Comm::Post(const std::vector<Msg> &m, hipStream_t compute, int c) {
 
 void Comm::Wait(hipStream_t compute, int c) {
   if (kind == Kind::rccl) {
+    // the two marks straddle nothing but the wait: their distance is the time the compute stream stalls for the receives
+    ProfMark(kWait, compute);
     HIPCHK(hipStreamWaitEvent(compute, done_[c], 0));
+    ProfMark(kWait, compute);
     return;
   }
   Staged &s = staged_[c];
@@ -364,31 +411,39 @@ void MeshBoundaryValues::Post(int c, hipStream_t st) {
   Comm::World().Post(m, st, c);
 }
 
-#define AKCHK(x) do { if ((x) < 0) AKMI_FATAL(std::string(#x) + ": " + akmi_last_error()); } while (0)
+#define AKCHK(x) do { if ((x) < 0) AKMI_THROW(std::string(#x) + ": " + akmi_last_error()); } while (0)
 
 void MeshBoundaryValues::PackAndSendCC(Real *u, hipStream_t st) {
   AKCHK(akmi_bvals_cc_local(pack_c, nvar, pmy_pack->pmb->d_nghbr.p, u, st));
   if (!HasPeers()) return;
+  Comm::World().ProfMark(Comm::kPack, st);
   AKCHK(akmi_bvals_cc_pack(pack_c, nvar, ch[0].nsend, d_send_tab[0].p, d_send_off[0].p, u, sendbuf[0].p, st));
+  Comm::World().ProfMark(Comm::kPack, st);
   Post(0, st);
 }
 void MeshBoundaryValues::RecvAndUnpackCC(Real *u, hipStream_t st) {
   if (!HasPeers()) return;
   Comm::World().Wait(st, 0);
+  Comm::World().ProfMark(Comm::kUnpack, st);
   AKCHK(akmi_bvals_cc_unpack(pack_c, nvar, pmy_pack->pmb->d_nghbr.p, d_seg_off[0].p, recvbuf[0].p, u, st));
+  Comm::World().ProfMark(Comm::kUnpack, st);
 }
 void MeshBoundaryValues::PackAndSendFC(DvceFaceFld &b, hipStream_t st) {
   AKCHK(akmi_bvals_fc_local(pack_c, pmy_pack->pmb->d_nghbr.p, b.x1f.p, b.x2f.p, b.x3f.p, st));
   if (!HasPeers()) return;
+  Comm::World().ProfMark(Comm::kPack, st);
   AKCHK(akmi_bvals_fc_pack(pack_c, ch[1].nsend, d_send_tab[1].p, d_send_off[1].p, b.x1f.p, b.x2f.p, b.x3f.p,
                            sendbuf[1].p, st));
+  Comm::World().ProfMark(Comm::kPack, st);
   Post(1, st);
 }
 void MeshBoundaryValues::RecvAndUnpackFC(DvceFaceFld &b, hipStream_t st) {
   if (!HasPeers()) return;
   Comm::World().Wait(st, 1);
+  Comm::World().ProfMark(Comm::kUnpack, st);
   AKCHK(akmi_bvals_fc_unpack(pack_c, pmy_pack->pmb->d_nghbr.p, d_seg_off[1].p, recvbuf[1].p, b.x1f.p, b.x2f.p,
                              b.x3f.p, st));
+  Comm::World().ProfMark(Comm::kUnpack, st);
 }
 
 // ---- bootstrap over TCP for jobs started the torchrun way -------------------------------------------
@@ -487,45 +542,58 @@ static bool RcclAvailable(const char *who) {
 }
 int akmi_comm_unique_id(char id[128]) {
   if (!RcclAvailable("comm_unique_id")) return AKMI_FAIL;
-  Comm::GetUniqueId(id);
-  return AKMI_COMPLETE;
+  AKMI_C_ENTRY("akmi_comm_unique_id", AKMI_FAIL, Comm::GetUniqueId(id); return AKMI_COMPLETE;)
 }
 int akmi_comm_init_rccl(int rank, int nranks, const char id[128]) {
   if (rank < 0 || nranks < 1 || rank >= nranks) { akmi::set_error("comm_init_rccl: rank %d of %d", rank, nranks); return AKMI_FAIL; }
   if (!RcclAvailable("comm_init_rccl")) return AKMI_FAIL;
-  Comm::World().InitRCCL(rank, nranks, id);
-  return AKMI_COMPLETE;
+  AKMI_C_ENTRY("akmi_comm_init_rccl", AKMI_FAIL, Comm::World().InitRCCL(rank, nranks, id); return AKMI_COMPLETE;)
 }
 int akmi_comm_init_env(void) {
   const char *r = std::getenv("RANK"), *w = std::getenv("WORLD_SIZE"), *l = std::getenv("LOCAL_RANK");
   const int rank = r ? std::atoi(r) : 0, nranks = w ? std::atoi(w) : 1;
   if (l) { if (hipSetDevice(std::atoi(l)) != hipSuccess) { akmi::set_error("comm_init_env: hipSetDevice(LOCAL_RANK) failed"); return AKMI_FAIL; } }
   if (!RcclAvailable("comm_init_env")) return AKMI_FAIL;
-  char id[128];
-  std::string err;
-  if (!BootstrapId(rank, nranks, id, err)) { akmi::set_error("comm_init_env: %s", err.c_str()); return AKMI_FAIL; }
-  Comm::World().InitRCCL(rank, nranks, id);
-  return AKMI_COMPLETE;
+  AKMI_C_ENTRY("akmi_comm_init_env", AKMI_FAIL,
+    char id[128];
+    std::string err;
+    if (!BootstrapId(rank, nranks, id, err)) { akmi::set_error("comm_init_env: %s", err.c_str()); return AKMI_FAIL; }
+    Comm::World().InitRCCL(rank, nranks, id);
+    return AKMI_COMPLETE;
+  )
 }
 int akmi_comm_init_callbacks(int rank, int nranks, akmi_comm_exchange_fn exchange,
                              akmi_comm_allreduce_min_fn allreduce_min, void *user) {
   if (rank < 0 || nranks < 1 || rank >= nranks || !exchange || !allreduce_min) {
     akmi::set_error("comm_init_callbacks: bad arguments"); return AKMI_FAIL;
   }
-  Comm::World().InitCallbacks(rank, nranks, exchange, allreduce_min, user);
-  return AKMI_COMPLETE;
+  AKMI_C_ENTRY("akmi_comm_init_callbacks", AKMI_FAIL,
+    Comm::World().InitCallbacks(rank, nranks, exchange, allreduce_min, user);
+    return AKMI_COMPLETE;
+  )
 }
-int akmi_comm_finalize(void) { Comm::World().Finalize(); return AKMI_COMPLETE; }
+int akmi_comm_finalize(void) { AKMI_C_ENTRY("akmi_comm_finalize", AKMI_FAIL, Comm::World().Finalize(); return AKMI_COMPLETE;) }
 int akmi_comm_allreduce_min(double *vals, int n, void *stream) {
-  Comm::World().AllReduceMin(vals, n, static_cast<hipStream_t>(stream));
-  return AKMI_COMPLETE;
+  AKMI_C_ENTRY("akmi_comm_allreduce_min", AKMI_FAIL,
+    Comm::World().AllReduceMin(vals, n, static_cast<hipStream_t>(stream));
+    return AKMI_COMPLETE;
+  )
 }
 int akmi_comm_rank(void) { return Comm::World().rank; }
 int akmi_comm_nranks(void) { return Comm::World().nranks; }
+int akmi_comm_profile(int on) {
+  Comm::World().prof_on = on != 0;
+  if (on) Comm::World().ProfReset();
+  return AKMI_COMPLETE;
+}
+int akmi_comm_profile_read(double *out, int n) {
+  AKMI_C_ENTRY("akmi_comm_profile_read", AKMI_FAIL, return Comm::World().ProfRead(out, n);)
+}
 
 long long akmi_host_exchange_plan(const char *deck_text, int rank, int nranks, int nvar, int fc,
                                   long long *out, long long cap) {
   if (rank < 0 || nranks < 1 || rank >= nranks) { akmi::set_error("host_exchange_plan: rank %d of %d", rank, nranks); return -1; }
+  AKMI_C_ENTRY("akmi_host_exchange_plan", -1,
   ParameterInput pin;
   pin.LoadFromString(deck_text);
   Mesh mesh(&pin, rank, nranks, true);
@@ -553,6 +621,7 @@ long long akmi_host_exchange_plan(const char *deck_text, int rank, int nranks, i
   const long long n = static_cast<long long>(v.size());
   if (out && n <= cap) std::memcpy(out, v.data(), sizeof(long long)*n);
   return n;
+  )
 }
 
 }  // extern "C"

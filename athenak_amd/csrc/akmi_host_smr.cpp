@@ -10,8 +10,8 @@
 #include <cstring>
 #include "akmi_host.hpp"
 
-#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
-  AKMI_FATAL(std::string("HIP error: ") + hipGetErrorString(e_)); } while (0)
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+  (void)hipGetLastError(); AKMI_THROW(std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
 
 namespace akmi {
 namespace host {

@@ -32,7 +32,15 @@
 #ifndef AKMI_MS_FM
 #define AKMI_MS_FM 1              // short square roots (sqrt_x)
 #endif
-constexpr int MS_THREADS = 256;
+#ifndef AKMI_MS_WHATIF
+#define AKMI_MS_WHATIF 0          // timing experiments (wrong results): 1 no barriers, 2 no global stores, 4 no extra halo cells, 8 no x3 solve
+#endif
+#define MS_STU(b, o, v) do { if (!(AKMI_MS_WHATIF & 16) || u.copy_u1 == 77) stu(b, o, v); } while (0)
+#define MS_SYNC() do { if (!(AKMI_MS_WHATIF & 1)) __syncthreads(); } while (0)
+#ifndef AKMI_MS_THREADS
+#define AKMI_MS_THREADS 256
+#endif
+constexpr int MS_THREADS = AKMI_MS_THREADS;
 constexpr int MS_PE = 9;            // doubles per plane entry (eight used; odd stride: conflict-free 64-bit accesses)
 constexpr int MS_FE = 7;            // doubles per face entry
 static size_t mhd_lds_doubles(int tw, int th) { return 2*MS_PE*((size_t)(tw + 3)*(th + 3)) + 2*MS_FE*(size_t)tw*th; }
@@ -47,7 +55,7 @@ static MhdTile mhd_tile(int c1, int c2) {
     if (e && sscanf(e, "%d%*[,x]%d", &f_tw, &f_th) != 2) f_tw = 0;
     if (f_tw < 4 || f_th < 3 || f_tw*f_th > MS_THREADS) f_tw = 0;
   }
-  static const int maxlds = getenv("AKMI_MS_LDS") ? atoi(getenv("AKMI_MS_LDS")) : 80*1024;
+  static const int maxlds = getenv("AKMI_MS_LDS") ? atoi(getenv("AKMI_MS_LDS")) : (MS_THREADS > 256 ? 160 : 80)*1024;
   if (f_tw > 0 && 3*(f_tw + 3) + 3*f_th <= f_tw*f_th && mhd_lds_doubles(f_tw, f_th)*sizeof(double) <= 150*1024)
     return MhdTile{f_tw, f_th, (c1 + f_tw - 2)/(f_tw - 1), (c2 + f_th - 2)/(f_th - 1), (f_tw*f_th + 63)/64*64};
   MhdTile best{0, 0, 0, 0, 0};
@@ -107,7 +115,7 @@ k_mhd_stage3d(Geo g, FaceEos eos, MhdStageArgs a, UpdArgs u, int nchunk, int ckl
   const int k0 = kA + ch*ckl;
   const int k1 = (k0 + ckl - 1 < kB) ? k0 + ckl - 1 : kB;
   const bool cell_ok = in_tile && i < g.N1 && j < g.N2;                // the column exists in memory
-  const bool own = in_tile && t < tw - 1 && r < th - 1 && i <= g.ie + 1 && j <= g.je + 1;
+  const bool own = !(AKMI_MS_WHATIF & 2) && in_tile && t < tw - 1 && r < th - 1 && i <= g.ie + 1 && j <= g.je + 1;
   const bool st1 = own && i >= g.is, st2 = own && j >= g.js;            // stores the x1 / x2 face on its low side
   const bool act = own && i >= g.is && i <= g.ie && j >= g.js && j <= g.je;
   const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
@@ -173,6 +181,7 @@ k_mhd_stage3d(Geo g, FaceEos eos, MhdStageArgs a, UpdArgs u, int nchunk, int ckl
   }
 #pragma unroll
   for (int n = 0; n < 5; ++n) F3p[n] = 0.0;
+  double bn1 = 0.0, bn2 = 0.0, bn3 = ldu(b3m + ps, oc);       // normal fields of the faces of the coming step
   // step k: x3 face k (below cell k); for k > k0 also the x1/x2 faces of plane k-1, which finishes cell k-1;
   // plane k+1 (loaded during the step) replaces plane k-1
   for (int k = k0; k <= k1 + 1; ++k) {
@@ -182,26 +191,35 @@ k_mhd_stage3d(Geo g, FaceEos eos, MhdStageArgs a, UpdArgs u, int nchunk, int ckl
     const bool upd = plane && act && k - 1 >= g.ks && k - 1 <= g.ke;
     const int pP = ((k - k0) & 1) ? PLSZ : 0, pC = PLSZ - pP;          // slots of plane k-1 and of plane k
     const int qP = qo + pP, qC = qo + pC;
-    const double bn1 = ldu(b1m, o1), bn2 = ldu(b2m, o2), bn3 = ldu(b3m + ps, oc);
     double f1[5] = {0, 0, 0, 0, 0}, f2[5] = {0, 0, 0, 0, 0};      // this position's own in-plane fluxes (d, m1, m2, m3, E)
     double wp[8], hv[8];
     double e2by = 0.0, e2bz = 0.0;
+    // the face fields of the NEXT step ride with the loads of plane k+1: the first wait of a step then comes a whole
+    // solve after the last store (a wait with stores outstanding is a wait for them as well)
+    double nb1, nb2, nb3;
     if (!plane) {
 #pragma unroll
       for (int n = 0; n < 8; ++n) { wp[n] = ldu(base(n) + s2, oc); hv[n] = ldu(base(n) + s2, oh); }
+      nb1 = ldu(b1m + ps1, o1); nb2 = ldu(b2m + ps2, o2); nb3 = ldu(b3m + 2*ps, oc);
     } else {
       // (A) every cell of plane k-1 once per direction
       double R1[8], R2[8];
 #pragma unroll
       for (int n = 0; n < 8; ++n) { R1[n] = 0.0; R2[n] = 0.0; }
       if (in_tile) {
-        double W0[8], U1[8], U2[8];
-#pragma unroll
-        for (int n = 0; n < 8; ++n) W0[n] = ms_lds[qP + n];
+        // the cell and its four in-plane neighbours, all requested before the first limiter (one LDS round trip)
+        double W0[8], Wl[8], Wr[8], Wd[8], Wu[8], U1[8], U2[8];
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
-          if (n != 5) plm(ms_lds[qP - PE + n], W0[n], ms_lds[qP + PE + n], U1[n], R1[n]);
-          if (n != 6) plm(ms_lds[qP - qy + n], W0[n], ms_lds[qP + qy + n], U2[n], R2[n]);
+          W0[n] = ms_lds[qP + n];
+          Wl[n] = ms_lds[qP - PE + n]; Wr[n] = ms_lds[qP + PE + n];
+          Wd[n] = ms_lds[qP - qy + n]; Wu[n] = ms_lds[qP + qy + n];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+          if (n != 5) plm(Wl[n], W0[n], Wr[n], U1[n], R1[n]);
+          if (n != 6) plm(Wd[n], W0[n], Wu[n], U2[n], R2[n]);
         }
         if (t + 1 < tw) {            // x1 face entry: d, vx, vy, vz, e, by, bz
 #pragma unroll
@@ -214,12 +232,12 @@ k_mhd_stage3d(Geo g, FaceEos eos, MhdStageArgs a, UpdArgs u, int nchunk, int ckl
           ms_lds[x2o + xy + 5] = U2[5]; ms_lds[x2o + xy + 6] = U2[7];
         }
         if (own) {                   // cell-centred E = -(v x B) of cell (k-1, j, i)  (mhd_corner_e.cpp:309-336)
-          stu(a.ecc1 + mc, oc, W0[3]*W0[6] - W0[2]*W0[7]);
-          stu(a.ecc2 + mc, oc, W0[1]*W0[7] - W0[3]*W0[5]);
-          stu(a.ecc3 + mc, oc, W0[2]*W0[5] - W0[1]*W0[6]);
+          MS_STU(a.ecc1 + mc, oc, W0[3]*W0[6] - W0[2]*W0[7]);
+          MS_STU(a.ecc2 + mc, oc, W0[1]*W0[7] - W0[3]*W0[5]);
+          MS_STU(a.ecc3 + mc, oc, W0[2]*W0[5] - W0[1]*W0[6]);
         }
       }
-      if (ha >= 0) {
+      if (ha >= 0 && !(AKMI_MS_WHATIF & 4)) {
         const int hA = ha + pP;
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
@@ -235,7 +253,7 @@ k_mhd_stage3d(Geo g, FaceEos eos, MhdStageArgs a, UpdArgs u, int nchunk, int ckl
           ms_lds[hd + 5] = up;
         }
       }
-      __syncthreads();
+      MS_SYNC();
       // (B) the two in-plane faces of this position; the fluid flux takes the place of the left state
       if (in_tile) {   // x1: (d, vx, vy, vz, e, by, bz), normal field bx1f
         const Cons1D f = riemann_mhd_e<RS, EO, FM>(eos, ms_lds[xo], ms_lds[xo + 1], ms_lds[xo + 2], ms_lds[xo + 3],
@@ -244,15 +262,16 @@ k_mhd_stage3d(Geo g, FaceEos eos, MhdStageArgs a, UpdArgs u, int nchunk, int ckl
 #pragma unroll
         for (int n = 0; n < 5; ++n) ms_lds[xo + n] = f1[n];
         if (st1) {
-          stu(mf1, o1, f.d);
-          stu(a.e3x1 + mc, oc, -f.by);
-          stu(a.e2x1 + mc, oc, f.bz);
+          MS_STU(mf1, o1, f.d);
+          MS_STU(a.e3x1 + mc, oc, -f.by);
+          MS_STU(a.e2x1 + mc, oc, f.bz);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
       // cell k+1 of the column and of the thread's halo entry: in flight during the x2 solve
 #pragma unroll
       for (int n = 0; n < 8; ++n) { wp[n] = ldu(base(n) + s2, oc); hv[n] = ldu(base(n) + s2, oh); }
+      nb1 = ldu(b1m + ps1, o1); nb2 = ldu(b2m + ps2, o2); nb3 = ldu(b3m + 2*ps, oc);
       __builtin_amdgcn_sched_barrier(0);
       if (in_tile) {   // x2: (d, vy, vz, vx, e, bz, bx), normal field bx2f
         const Cons1D f = riemann_mhd_e<RS, EO, FM>(eos, ms_lds[x2o], ms_lds[x2o + 2], ms_lds[x2o + 3], ms_lds[x2o + 1],
@@ -286,9 +305,9 @@ k_mhd_stage3d(Geo g, FaceEos eos, MhdStageArgs a, UpdArgs u, int nchunk, int ckl
     }
     __builtin_amdgcn_sched_barrier(0);
     if (plane && st2) {              // the x2 face's stores, after the wait for plane k+1 (a store between a load and its
-      stu(mf2, o2, f2[0]);           // wait makes the wait one for the store as well)
-      stu(a.e1x2 + mc, oc, -e2by);
-      stu(a.e3x2 + mc, oc, e2bz);
+      MS_STU(mf2, o2, f2[0]);           // wait makes the wait one for the store as well)
+      MS_STU(a.e1x2 + mc, oc, -e2by);
+      MS_STU(a.e3x2 + mc, oc, e2bz);
     }
     __builtin_amdgcn_sched_barrier(0);
     double pu0[5], pu1[5];
@@ -301,13 +320,13 @@ k_mhd_stage3d(Geo g, FaceEos eos, MhdStageArgs a, UpdArgs u, int nchunk, int ckl
     __builtin_amdgcn_sched_barrier(0);
     double f3[5] = {0, 0, 0, 0, 0};
     double e3by = 0.0, e3bz = 0.0;
-    if (do3) {
+    if (do3 && !(AKMI_MS_WHATIF & 8)) {
       const Cons1D f = riemann_mhd_e<RS, EO, FM>(eos, L[0], L[3], L[1], L[2], L[4], L[5], L[6], R[0], R[3], R[1], R[2],
                                                  R[4], R[5], R[6], bn3);
       f3[0] = f.d; f3[3] = f.mx; f3[1] = f.my; f3[2] = f.mz; f3[4] = f.e;
       e3by = f.by; e3bz = f.bz;
     }
-    __syncthreads();
+    MS_SYNC();
     if (upd) {                                         // (C) finish cell k-1
       double divf[5];
       if (p2) {                                        // one wave-uniform branch for the fifteen quotients
@@ -329,16 +348,17 @@ k_mhd_stage3d(Geo g, FaceEos eos, MhdStageArgs a, UpdArgs u, int nchunk, int ckl
       for (int n = 0; n < 5; ++n) {
         const double u0v = pu0[n];
         const double u1v = COPY ? u0v : pu1[n];
-        rk_store_u(u0m + n*cs, u1m + n*cs, u.copy_u1, oc, u0v, u.gam0*u0v + u.gam1*u1v - bdt*divf[n]);
+        if (!(AKMI_MS_WHATIF & 16) || u.copy_u1 == 77) rk_store_u(u0m + n*cs, u1m + n*cs, u.copy_u1, oc, u0v, u.gam0*u0v + u.gam1*u1v - bdt*divf[n]);
       }
     }
     if (do3 && own && k <= k1) {
-      stu(mf3 + ps, oc, f3[0]);
-      stu(a.e2x3 + mc + ps, oc, -e3by);
-      stu(a.e1x3 + mc + ps, oc, e3bz);
+      MS_STU(mf3 + ps, oc, f3[0]);
+      MS_STU(a.e2x3 + mc + ps, oc, -e3by);
+      MS_STU(a.e1x3 + mc + ps, oc, e3bz);
     }
 #pragma unroll
     for (int n = 0; n < 5; ++n) F3p[n] = f3[n];
+    bn1 = nb1; bn2 = nb2; bn3 = nb3;
     oc += (unsigned)ps*8u; o1 += (unsigned)ps1*8u; o2 += (unsigned)ps2*8u; oh += (unsigned)ps*8u;
   }
 }

@@ -62,6 +62,7 @@ class Driver:
 
     def InitBoundaryValuesAndPrimitives(self, pm):
         """driver.cpp:569-653: one halo exchange + BCs + c2p everywhere"""
+        self._begin_stage(pm)
         ph = pm.pmb_pack.phydro
         if ph is not None:
             ph.RestrictU(self, 0)
@@ -103,9 +104,23 @@ class Driver:
         if pout is not None and not res_flag:
             pout.MakeOutputs(pm, pin)
 
+    @staticmethod
+    def _begin_stage(pm):
+        """the hand-shake flags between SendU / SendB and ApplyPhysicalBCs / ConToPrim live inside one stage: none may be
+        left standing for the next one (a task list that drops the consumer)"""
+        pk = pm.pmb_pack
+        for ph in (getattr(pk, "phydro", None), getattr(pk, "pmhd", None)):
+            if ph is None:
+                continue
+            ph._dt3_reset = False
+            for bv in (getattr(ph, "pbval_u", None), getattr(ph, "pbval_b", None)):
+                if bv is not None and hasattr(bv, "_u_bcs_done"):
+                    bv._u_bcs_done = bv._b_bcs_done = False
+
     def _cycle(self, pm):
         self.ExecuteTaskList(pm, "before_timeintegrator", 0)
         for stage in range(1, self.nexp_stages + 1):
+            self._begin_stage(pm)
             self.ExecuteTaskList(pm, "before_stagen", stage)
             self.ExecuteTaskList(pm, "stagen", stage)
             self.ExecuteTaskList(pm, "after_stagen", stage)

@@ -349,8 +349,14 @@ class Mesh:
             import torch
             import torch.distributed as dist
             dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+            from . import bvals as _bv
+            import time as _t
+            t0 = _t.perf_counter()
             t = torch.tensor([self.dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             self.dt = float(t.item())
+            if _bv.HALO_PROF is not None:
+                _bv.HALO_PROF.dt_reduce_s += _t.perf_counter() - t0
+                _bv.HALO_PROF.dt_calls += 1
         if self.time < tlim and (self.time + self.dt) > tlim:
             self.dt = tlim - self.time

@@ -40,7 +40,10 @@ class NativeSimulation:
         self.pin = pin
         self.L = capi.lib()
         stream = capi._stream()
-        self.h = C.c_void_p(self.L.akmi_sim_create(pin.Dump().encode(), stream))
+        h = self.L.akmi_sim_create(pin.Dump().encode(), stream)
+        if not h:       # a run-time failure (device allocation, HIP); deck errors exit with "### FATAL ERROR" as the reference does
+            raise capi.AkmiError("akmi_sim_create failed: %s" % self.L.akmi_last_error().decode())
+        self.h = C.c_void_p(h)
         # a Python Mesh of the same deck gives the problem generators their coordinates; with a
         # communicator (akmi_comm_init_*) both sides cut the block list the same way
         # (tests/test_host_plan.py) and the arrays are those of this rank's pack
@@ -103,7 +106,7 @@ class NativeSimulation:
                    "sim_initialize")
 
     def Execute(self, max_cycles=None):
-        n = self.L.akmi_sim_execute(self.h, -1 if max_cycles is None else int(max_cycles))
+        n = capi.check(self.L.akmi_sim_execute(self.h, -1 if max_cycles is None else int(max_cycles)), "sim_execute")
         self._refresh()
         self.pmesh.time = self.time
         self.pmesh.dt = self.dt

@@ -236,12 +236,17 @@ class PythonHost:
         sim, args = self.sim, self.args
         pm, drv = sim.pmesh, sim.pdriver
         sim.phys.stage_events = []
+        from athenak_amd import bvals as _bv
+        _bv.HALO_PROF = _bv.HaloProfile() if self.world > 1 else None
         self.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             drv._cycle(pm)
         self.barrier()
         el = time.perf_counter() - t0
+        if _bv.HALO_PROF is not None:
+            self.info["halo"] = _bv.HALO_PROF.summary(args.steps*drv.nexp_stages, args.steps)
+            _bv.HALO_PROF = None
         if self.world > 1:
             import torch.distributed as dist
             t = torch.tensor([el], dtype=torch.float64,
@@ -262,6 +267,28 @@ class PythonHost:
         torch.cuda.empty_cache()
 
 
+HALO_KEYS = ("pack_ms", "exposed_wait_ms", "unpack_ms", "dt_reduce_ms")
+
+
+def comm_profile_read(L, nstages, ncycles):
+    """akmi_comm_profile_read -> the per-stage / per-cycle figures of roofline.halo (C++ host, RCCL transport): where a
+    multi-rank stage spends its exchange.  Pack, exposed wait and unpack are sums over the channels of a stage (cell-centred +
+    face-centred), averaged over the timed stages; the dt all-reduce + read-back is per cycle."""
+    import ctypes as C
+    from athenak_amd import capi
+    out = (C.c_double*12)()
+    capi.check(L.akmi_comm_profile_read(out, 12), "comm_profile_read")
+    v = list(out)
+    ns, nc = max(nstages, 1), max(ncycles, 1)
+    return {"pack_ms": round(v[0]/ns, 5), "exposed_wait_ms": round(v[2]/ns, 5), "unpack_ms": round(v[4]/ns, 5),
+            "dt_reduce_ms": round(v[6]/nc, 5), "bytes_sent_per_stage": int(v[8]/ns), "peers": int(v[10]),
+            "rccl_ranks": int(v[11]), "posts_per_stage": round(v[9]/ns, 3),
+            "event_pairs": {"pack": int(v[1]), "wait": int(v[3]), "unpack": int(v[5]), "dt_reduce": int(v[7])},
+            "what": "HIP event pairs on the compute stream of rank 0 inside the timed loop: pack kernels of the off-rank "
+                    "segments; the stall at hipStreamWaitEvent(receives done) -- zero when the transfer finished under the "
+                    "kernels enqueued before it; unpack kernels; per cycle the ncclAllReduce(min) of dt + its read-back"}
+
+
 def run_cpp_host(args, pin):
     """the same W + K cycles through the C++ host (akmi_sim_*: Mesh/TaskList/Driver in C++, one C-ABI call per
     task) in this process (one rank); launch-group timing by akmi_sim_profile (HIP events in the timed loop)"""
@@ -269,6 +296,14 @@ def run_cpp_host(args, pin):
     import torch
     from athenak_amd import capi, native
     L = capi.lib()
+    self_ex = os.environ.get("AKMI_SELF_EXCHANGE", "0") == "1"
+    if self_ex:
+        # functional run of the transport on ONE GPU: a one-rank RCCL communicator; every ghost zone of the block travels
+        # pack -> ncclSend/ncclRecv to self on the communicator's stream -> unpack, as on a rank with 26 off-rank
+        # neighbours (csrc/akmi_host_comm.cpp SelfExchange); results do not change, roofline.halo shows the parts
+        idb = C.create_string_buffer(128)
+        capi.check(L.akmi_comm_unique_id(idb), "comm_unique_id")
+        capi.check(L.akmi_comm_init_rccl(0, 1, idb.raw), "comm_init_rccl")
     sim = native.NativeSimulation(pin)
     pm = sim.pmesh
     nstage = {"rk1": 1, "rk2": 2, "rk3": 3, "rk4": 4}[pin.GetString("time", "integrator")]
@@ -276,6 +311,7 @@ def run_cpp_host(args, pin):
             "ncell_total": pm.nmb_total*pm.NumberOfMeshBlockCells(), "nstage": nstage, "ng": pm.mb_indcs.ng}
     sim.Execute(max_cycles=args.warmup)
     capi.check(L.akmi_sim_profile(sim.h, 1), "sim_profile")
+    capi.check(L.akmi_comm_profile(1), "comm_profile")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     done = sim.Execute(max_cycles=args.steps)
@@ -283,6 +319,8 @@ def run_cpp_host(args, pin):
     el = time.perf_counter() - t0
     ms, calls = C.c_double(0.0), C.c_longlong(0)
     capi.check(L.akmi_sim_profile_read(sim.h, C.byref(ms), C.byref(calls)), "sim_profile_read")
+    info["halo"] = comm_profile_read(L, done*nstage, done)
+    capi.check(L.akmi_comm_profile(0), "comm_profile")
     ra = os.environ.get("AKMI_RUN_AHEAD", "1") != "0" and pm.nranks == 1 and not pm.multilevel
     info.update(host="C++ (akmi_sim_*: Mesh, TaskList, Driver in C++; one C-ABI call per task%s)" % (
                     "; new time step on the device, host one cycle ahead, drained inside the timed region" if ra else ""),
@@ -290,6 +328,8 @@ def run_cpp_host(args, pin):
                 value=info["ncell_total"]*done/el/1e6, ms_per_step=el/max(done, 1)*1e3, group_ms=ms.value,
                 group_calls=calls.value, time=sim.time, dt=sim.dt, ncycle=sim.ncycle)
     sim.close()
+    if self_ex:
+        native.finalize_comm()
     torch.cuda.empty_cache()
     return info
 
@@ -511,11 +551,14 @@ def main():
                 "timing": "HIP event pairs on the launch stream around every call of the group inside the timed "
                           "loop of the headline host (%d calls)" % (head.get("group_calls") or 0),
                 "halo_bcs_shell_c2p_ms": None if rest_ms is None else round(rest_ms, 4),
+                # N > 1 (or AKMI_SELF_EXCHANGE=1): the exchange of the C++ host taken apart -- pack, exposed wait, unpack per
+                # stage, dt all-reduce per cycle, bytes and peers, the ranks RCCL reports (akmi_comm_profile)
+                "halo": (head.get("halo") if (head.get("halo") or {}).get("posts_per_stage") else None),
                 "valu_floor": valu_floor(blk, args.nx, plain) if head.get("group_calls") else None,
                 "whole_stage": {"achieved": round(whole, 1), "frac": round(whole/HBM_PEAK_GBS, 4)},
-                "note": "two roofs: HBM (algorithmic bytes / 8 TB/s) and fp64 issue (valu_floor.ms); the measured "
-                        "traffic is ~2.3x the algorithmic bytes (intermediates between the four kernels of the MHD "
-                        "stage): DESIGN.md 3"}
+                "note": "two roofs: HBM (algorithmic bytes / 8 TB/s) and fp64 issue (valu_floor.ms)%s: DESIGN.md 3" % (
+                    "; the measured traffic is %.2fx the algorithmic bytes (intermediates between the kernels of the stage, "
+                    "tile halos counted per XCD)" % (traffic/float(stage_bytes*ncell_rank)) if traffic else "")}
 
     rname = (args.recon or "plm").upper()
     halo = "none (single periodic block: same-rank gather)" if world == 1 else (
@@ -705,6 +748,7 @@ def native_child(args, pin, rank, world):
     sim.Execute(max_cycles=args.warmup)
     time_w, dt_w = sim.time, sim.dt               # compared with the Python host's after the same cycles
     capi.check(L.akmi_sim_profile(sim.h, 1), "sim_profile")
+    capi.check(L.akmi_comm_profile(1), "comm_profile")
     torch.cuda.synchronize()
     allmin(0.0)                                   # barrier
     t0 = time.perf_counter()
@@ -713,7 +757,13 @@ def native_child(args, pin, rank, world):
     el = -allmin(-(time.perf_counter() - t0))     # max over ranks
     ms, calls = C.c_double(0.0), C.c_longlong(0)
     capi.check(L.akmi_sim_profile_read(sim.h, C.byref(ms), C.byref(calls)), "sim_profile_read")
+    nstage = {"rk1": 1, "rk2": 2, "rk3": 3, "rk4": 4}[pin.GetString("time", "integrator")]
+    halo = comm_profile_read(L, n*nstage, n)
     if rank == 0:
+        sys.stderr.write("[C++ host] exchange per stage on rank 0: pack %.4f ms, exposed wait %.4f ms, unpack %.4f ms, "
+                         "%d bytes to %d peers; dt all-reduce + read-back %.4f ms per cycle; ncclCommCount = %d\n" % (
+                             halo["pack_ms"], halo["exposed_wait_ms"], halo["unpack_ms"], halo["bytes_sent_per_stage"],
+                             halo["peers"], halo["dt_reduce_ms"], halo["rccl_ranks"]))
         sys.stderr.write("[C++ host] RCCL called directly, %d GPUs: %.2f Mcell-updates/s, %.4f ms/step "
                          "(%d cycles, t=%.6e dt=%.6e)\n" % (world, ncell_total*n/el/1e6, el/n*1e3, n,
                                                             sim.time, sim.dt))
@@ -721,7 +771,7 @@ def native_child(args, pin, rank, world):
         with open(args.native_child, "w") as f:
             json.dump({"value": ncell_total*n/el/1e6, "ms_per_step": el/n*1e3, "steps": n, "el": el,
                        "time": sim.time, "dt": sim.dt, "time_w": time_w, "dt_w": dt_w, "group_ms": ms.value,
-                       "group_calls": calls.value,
+                       "group_calls": calls.value, "halo": halo,
                        "host": "C++ (akmi_sim_*: Mesh, TaskList, Driver in C++) + RCCL called directly"}, f)
     sim.close()
     native.finalize_comm()

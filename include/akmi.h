@@ -653,6 +653,16 @@ int akmi_comm_finalize(void);
 int akmi_comm_allreduce_min(double *vals, int n, void *stream);
 int akmi_comm_rank(void);
 int akmi_comm_nranks(void);
+/* Where a multi-rank stage spends its exchange (src/bvals/bvals_cc.cpp:108-135,247-258 pack / send / receive / unpack,
+ * src/mesh/mesh.cpp:634-637 the dt reduction): akmi_comm_profile(1) starts recording HIP event pairs on the compute stream
+ * round (0) the pack kernels of the off-rank segments, (1) the point where the compute stream waits for the receives of a
+ * channel -- the time it really stalls there, zero when the transfer finished under the kernels enqueued before it --,
+ * (2) the unpack kernels, (3) the dt all-reduce + read-back of a cycle.  akmi_comm_profile_read waits for the recorded
+ * events, clears the record and fills out[0..11] = {pack_ms, pack_calls, exposed_wait_ms, wait_calls, unpack_ms,
+ * unpack_calls, dt_reduce_ms, dt_calls, bytes_sent, posts, peers (most per post), ranks the communicator reports
+ * (ncclCommCount; 0 without RCCL)}.  n = capacity of out (>= 12). */
+int akmi_comm_profile(int on);
+int akmi_comm_profile_read(double *out, int n);
 /* The exchange plan rank `rank` of `nranks` derives from the deck alone -- host code only, no
  * device needed (tests/test_host_plan.py compares it with the Python host's plan).  fc = 0: the
  * cell-centred channel with nvar variables, 1: the face-centred channel.  out (capacity cap,

@@ -9,8 +9,31 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+def pytest_addoption(parser):
+    parser.addoption("--parity-tol", default=None, metavar="TOL",
+                     help="A/B runs of builds with relaxed arithmetic ONLY (tools/r05_contract.sh): replace the bit-for-bit "
+                          "requirement of the parity tests by this relative-L1 bar.  Never used by the driver's runs.")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # the tolerance mode is an explicit command-line choice: a stray AKMI_PARITY_TOL in the environment must not weaken
+    # the suite silently
+    tol = config.getoption("--parity-tol")
+    if tol is None and os.environ.get("AKMI_PARITY_TOL"):
+        raise pytest.UsageError("AKMI_PARITY_TOL is set in the environment but --parity-tol was not given: the parity tests "
+                                "assert bit equality; unset the variable (or pass --parity-tol for an A/B run)")
+    import parity_util
+    parity_util.RELAXED_TOL = float(tol) if tol is not None else None
+    if tol is not None:
+        os.environ["AKMI_PARITY_TOL"] = str(tol)        # tests that compare in a process of their own
+        os.environ["AKMI_PARITY_RELAXED_BY_OPTION"] = "1"
+
+
+def pytest_report_header(config):
+    tol = config.getoption("--parity-tol")
+    if tol is not None:
+        return "RELAXED PARITY MODE: bit equality replaced by relative L1 <= %s (--parity-tol) -- not a parity run" % tol
 
 
 def pytest_collection_modifyitems(config, items):

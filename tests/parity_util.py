@@ -17,6 +17,15 @@ if ROOT not in sys.path:
 from oracle import akref  # noqa: E402  (test infrastructure)
 
 TOL = 1e-12     # north_star: <= 1e-12 relative L1 on the conserved variables
+RELAXED_TOL = None      # set by `pytest --parity-tol` (tests/conftest.py) only
+
+
+def _tol_of_child_process():
+    """scripts the tests run in processes of their own (python -c ...): the variable is honoured only when the parent
+    session was started with --parity-tol, which exports AKMI_PARITY_RELAXED_BY_OPTION next to it"""
+    if os.environ.get("AKMI_PARITY_RELAXED_BY_OPTION") == "1":
+        return os.environ.get("AKMI_PARITY_TOL")
+    return None
 
 
 def deck_overrides(problem, n, dims, mb=None, ng=None, recon=None, integrator=None, cfl=None,
@@ -146,10 +155,13 @@ def compare_fields(prod, orc, is_mhd):
         den = sum(np.abs(orc[k]).sum() for k in ("b0x1f", "b0x2f", "b0x3f"))
         out["B"] = float(num/den) if den > 0 else float(num)
     out["bitwise_equal"] = all(np.array_equal(prod[k], orc[k]) for k in prod)
-    # A/B of builds with relaxed arithmetic (tools/r05_contract.sh): AKMI_PARITY_TOL=1e-12 replaces the bit-for-bit
+    # A/B of builds with relaxed arithmetic (tools/r05_contract.sh): `pytest --parity-tol=1e-12` replaces the bit-for-bit
     # requirement of every test that goes through here by north_star's bar (relative L1 of the conserved variables
-    # and the face field) and AKMI_PARITY_LOG collects the worst value per test.  Never set by the driver's runs.
-    tol = os.environ.get("AKMI_PARITY_TOL")
+    # and the face field) and AKMI_PARITY_LOG collects the worst value per test.  Never used by the driver's runs: without
+    # the option the session refuses to start when AKMI_PARITY_TOL is set (tests/conftest.py), and the true answer stays
+    # in out["bitwise_equal_strict"].
+    out["bitwise_equal_strict"] = out["bitwise_equal"]
+    tol = RELAXED_TOL if RELAXED_TOL is not None else _tol_of_child_process()
     if tol:
         worst = max(v for k, v in out.items() if k != "bitwise_equal")
         log = os.environ.get("AKMI_PARITY_LOG")
@@ -157,7 +169,7 @@ def compare_fields(prod, orc, is_mhd):
             with open(log, "a") as f:
                 f.write("%s\t%.3e\t%s\n" % (os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], worst,
                                              "bitwise" if out["bitwise_equal"] else "differs"))
-        out["bitwise_equal"] = bool(worst <= float(tol))
+        out["bitwise_equal"] = bool(worst <= float(tol))       # relaxed mode (explicit option) only
     return out
 
 

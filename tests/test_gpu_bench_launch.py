@@ -50,6 +50,12 @@ def test_bench_gpus_8_is_the_2x2x2_layout():
     assert r["n_gpus"] == 8 and r["steps"] == 2 and r["scaling"] == "weak" and r["value"] > 0
     assert "64x64x64" in r["config"]["workload"] and "2x2x2" in r["config"]["workload"]
     assert "host_check" in r["config"] and "roofline" in r
+    # the exchange taken apart (whichever host wrote the line): an 8-GPU run can be attributed from the record
+    halo = r["roofline"]["halo"]
+    for k in ("pack_ms", "exposed_wait_ms", "unpack_ms", "dt_reduce_ms", "bytes_sent_per_stage", "peers"):
+        assert k in halo, (k, halo)
+    assert halo["peers"] == 7 and halo["bytes_sent_per_stage"] > 0 and halo["posts_per_stage"] == 2.0   # U and B, 7 peers each
+    assert halo["pack_ms"] > 0 and halo["unpack_ms"] > 0
 
 
 def test_bench_under_torch_distributed_run():

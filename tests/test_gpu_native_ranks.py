@@ -87,8 +87,11 @@ CASES = [
 
 # every layout through the fused stage; the task-granular chain on the two 3-D MHD layouts (all 26 directions, one block
 # per rank) -- the other four layouts x split were multi-process launches for kernels the single-rank suite covers
-RUNS = [pytest.param(c, f, id="%s-%s^%d-mb%s-%s" % (c[0], c[1], c[2], c[3], "fused" if f else "split"))
-        for c, f in [(c, True) for c in CASES] + [(c, False) for c in CASES[:2]]]
+# + one LONG task-granular run across ranks (40 cycles of a wave that varies along all three axes, 8 blocks on 2 ranks): a
+# slip in the per-stage hand-shakes of the chain (gather / boundary functions / ConsToPrim) needs cycles to show
+LONG_SPLIT = ("linear_wave_mhd", 24, 3, 12, 40, {})
+RUNS = [pytest.param(c, f, id="%s-%s^%d-mb%s-%s%s" % (c[0], c[1], c[2], c[3], "fused" if f else "split", "-long" if c is LONG_SPLIT else ""))
+        for c, f in [(c, True) for c in CASES] + [(c, False) for c in CASES[:2]] + [(LONG_SPLIT, False)]]
 
 
 @pytest.mark.parametrize("case,fused", RUNS)

@@ -4,6 +4,7 @@ once per process, so every case runs in a process of its own and must be bit-ide
                     rank with off-rank neighbours uses) instead of one conversion after the ghost fill
   AKMI_OUT_OF_PLACE=0  C++ host: CopyCons + in-place first stage instead of the out-of-place stage with swapped registers
 (the sign-word, two-kernel-x12 and k_march3ct options of rounds 3-4 lost their measurements and left the source in round 5)
+  AKMI_MHD_ONE_KERNEL=1  the three MHD sweeps + update in one tile kernel (k_mhd_stage3d; opt-in, slower)
 C++ host, single rank, uniform mesh:
   AKMI_RUN_AHEAD=0  the new time step read back at the end of every cycle (one host synchronisation per cycle) instead of
                     Mesh::NewTimeStep on the device with the host one cycle ahead (default when eligible)
@@ -55,6 +56,16 @@ def test_option_does_not_change_a_bit(env):
     r = subprocess.run([sys.executable, "-c", SCRIPT], env=dict(os.environ, **env), capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_mhd_one_kernel_stage_is_bit_identical():
+    """AKMI_MHD_ONE_KERNEL=1: k_mhd_stage3d (x1/x2/x3 sweeps + RK update of a 3-D MHD PLM + HLLD stage in one tile kernel,
+    csrc/akmi_mhd_stage3d.hpp) instead of k_sweep12s + the x3 march.  Measured slower (profiles/r06_mhd_stage3d.txt), kept
+    as an opt-in path; the sweep of tools/m3_check.py (Orszag-Tang in several shapes and decompositions, RK1-3, blast at
+    ng = 4, a linear wave on two blocks with cell sizes that are no powers of two, both hosts) has to stay bitwise equal."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "m3_check.py")],
+                       env=dict(os.environ, AKMI_MHD_ONE_KERNEL="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "bad: 0" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
 SMR_SCRIPT = r"""

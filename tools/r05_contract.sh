@@ -4,7 +4,7 @@
 root=${GRAFT_REPO_ROOT:-$(pwd)}; cd $root; mkdir -p gpurun_out
 V=$root/athenak_amd/lib/variants/libakmi_contract.so
 rm -f gpurun_out/r05_contract_parity.tsv
-( AKMI_LIB=$V AKMI_PARITY_TOL=1e-12 AKMI_PARITY_LOG=$root/gpurun_out/r05_contract_parity.tsv timeout 1500 python -m pytest tests -m gpu -q -n 4 -p no:cacheprovider ) > gpurun_out/r05_contract_tests.txt 2>&1
+( AKMI_LIB=$V AKMI_PARITY_LOG=$root/gpurun_out/r05_contract_parity.tsv timeout 1500 python -m pytest tests -m gpu -q -n 4 -p no:cacheprovider --parity-tol=1e-12 ) > gpurun_out/r05_contract_tests.txt 2>&1
 tail -3 gpurun_out/r05_contract_tests.txt
 {
 echo "##### orszag_tang 256^3 (BASELINE config 3)"
