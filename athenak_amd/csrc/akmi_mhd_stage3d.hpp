@@ -239,18 +239,20 @@ k_mhd_stage3d(Geo g, FaceEos eos, MhdStageArgs a, UpdArgs u, int nchunk, int ckl
       }
       if (ha >= 0 && !(AKMI_MS_WHATIF & 4)) {
         const int hA = ha + pP;
+        // d, vx, vy, vz, e, bz and the transverse field that is reconstructed (by for x1, bx for x2: slot 5 of the entry
+        // either way); all three cells requested before the first limiter
+        const int nt = hdir == 1 ? 6 : 5;
+        double ea[7], eb[7], ec[7];
 #pragma unroll
-        for (int n = 0; n < 8; ++n) {
-          if (n == 5 || n == 6) continue;
-          double up, dummy;
-          plm(ms_lds[hA + n], ms_lds[hA + hs + n], ms_lds[hA + 2*hs + n], up, dummy);
-          ms_lds[hd + (n < 5 ? n : 6)] = up;
+        for (int q = 0; q < 7; ++q) {
+          const int n = q < 5 ? q : (q == 5 ? nt : 7);
+          ea[q] = ms_lds[hA + n]; eb[q] = ms_lds[hA + hs + n]; ec[q] = ms_lds[hA + 2*hs + n];
         }
-        {   // the transverse field that is reconstructed: by for x1, bx for x2 (slot 5 of the entry either way)
-          const int n = hdir == 1 ? 6 : 5;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
           double up, dummy;
-          plm(ms_lds[hA + n], ms_lds[hA + hs + n], ms_lds[hA + 2*hs + n], up, dummy);
-          ms_lds[hd + 5] = up;
+          plm(ea[q], eb[q], ec[q], up, dummy);
+          ms_lds[hd + q] = up;
         }
       }
       MS_SYNC();

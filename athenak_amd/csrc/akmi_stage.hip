@@ -1439,9 +1439,9 @@ constexpr int HS_THREADS = 512;
 
 // LDS of a workgroup, in doubles: the plane with its halo and two face-shaped arrays per direction-pair
 constexpr int HS_ES = 5;                   // doubles per LDS entry (a padded 48-byte stride measured slower: profiles/r05_hydro_ab.txt)
-static size_t hyd_lds_doubles(int tw, int th) { return HS_ES*((size_t)(tw + 3)*(th + 3) + 2*(size_t)tw*th); }
+static size_t hyd_lds_doubles(int tw, int th, int planes = 1) { return HS_ES*(planes*(size_t)(tw + 3)*(th + 3) + 2*(size_t)tw*th); }
 
-static HydTile hyd_tile(int c1, int c2) {
+static HydTile hyd_tile(int c1, int c2, int planes = 1) {
   // The kernel is bound by the issue of dependent fp64 chains (1 330 VALU instructions per cell, three waves per SIMD), so
   // what a shape costs is the lanes it launches per owned column, not the length of its rows:
   //   cost = lanes launched (tiles x padded workgroup)
@@ -1461,7 +1461,7 @@ static HydTile hyd_tile(int c1, int c2) {
     if (f_tw < 4 || f_th < 3 || f_tw*f_th > HS_THREADS) f_tw = 0;
   }
   if (f_tw > 0 && 3*(f_tw + 3) + 3*f_th <= f_tw*f_th &&
-      hyd_lds_doubles(f_tw, f_th)*sizeof(double) <= 150*1024)
+      hyd_lds_doubles(f_tw, f_th, planes)*sizeof(double) <= 150*1024)
     return HydTile{f_tw, f_th, (c1 + f_tw - 2)/(f_tw - 1), (c2 + f_th - 2)/(f_th - 1), (f_tw*f_th + 63)/64*64};
   HydTile best{0, 0, 0, 0, 0};
   double best_cost = -1.0;
@@ -1472,7 +1472,7 @@ static HydTile hyd_tile(int c1, int c2) {
     for (int th = 3; th <= 40; ++th) {
       if (tw*th > maxt) break;
       if (3*(tw + 3) + 3*th > tw*th) continue;         // one halo entry per thread at most
-      const size_t lds = hyd_lds_doubles(tw, th)*sizeof(double);
+      const size_t lds = hyd_lds_doubles(tw, th, planes)*sizeof(double);
       if (lds > (size_t)maxlds) continue;
       const int n2 = (c2 + th - 2)/(th - 1);
       const int threads = (tw*th + 63)/64*64;
@@ -1736,6 +1736,7 @@ k_hydro_stage3d(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, in
 }
 
 
+#include "akmi_hydro_stage3d2.hpp"
 #include "akmi_mhd_stage3d.hpp"
 
 __global__ void k_init_dt3(double *dt3) {
@@ -2015,17 +2016,20 @@ static int launch_sweep12s(const Geo &g, const Scheme &sc, const SweepArgs &a1, 
 template <bool MASS>
 static int launch_hydro_stage3d(const Geo &g, const Scheme &sc, const double *w0, const UpdArgs &u,
                                 int kA, int kB, hipStream_t st, Mass3 ms) {
-  const HydTile tl = hyd_tile(g.nx1, g.nx2);
+  // AKMI_HS2=0: the one-plane kernel of round 5 (A/B runs)
+  static const bool two = !(getenv("AKMI_HS2") && atoi(getenv("AKMI_HS2")) == 0);
+  const HydTile tl = hyd_tile(g.nx1, g.nx2, two ? 2 : 1);
   if (tl.tw == 0) { set_error("hydro_stage3d: no tile shape"); return AKMI_FAIL; }
   int ckl = march_len((long)tl.n1*tl.n2, kB - kA + 1, g.nmb, ML);
   static const int ckl_env = getenv("AKMI_HS_CKL") ? atoi(getenv("AKMI_HS_CKL")) : 0;     // experiments: pin the chunk length
   if (ckl_env > 0) ckl = ckl_env;                   // (128^3: the rule's 4 sits on the flat bottom, profiles/r05_hydro_host_ab.txt)
   const int nchunk = cdiv(kB - kA + 1, ckl);
-  const size_t lds = hyd_lds_doubles(tl.tw, tl.th)*sizeof(double);
+  const size_t lds = hyd_lds_doubles(tl.tw, tl.th, two ? 2 : 1)*sizeof(double);
   dim3 grid(tl.n1, tl.n2, nchunk*g.nmb), block(tl.threads);
   int rc = dispatch_scheme_eos<false>(sc, [&](auto R, auto S) {
     if constexpr (decltype(R)::value <= 1) {
-      auto kern = k_hydro_stage3d<decltype(R)::value, decltype(S)::value, MASS>;
+      auto kern = two ? k_hydro_stage3d2<decltype(R)::value, decltype(S)::value, MASS>
+                      : k_hydro_stage3d<decltype(R)::value, decltype(S)::value, MASS>;
       static size_t granted = 64*1024;                 // per instantiation; raised once per size
       if (lds > granted) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
