@@ -488,7 +488,7 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
   }
 }
 FluidBase::~FluidBase() {
-  u0.Free(); w0.Free(); u1.Free(); counters.Free(); dt3.Free(); ws.Free(); fofc.Free(); nfofc.Free();
+  u0.Free(); w0.Free(); u1.Free(); w1.Free(); counters.Free(); dt3.Free(); ws.Free(); fofc.Free(); nfofc.Free();
   dtmin_cond.Free(); coarse_u0.Free(); coarse_w0.Free();
   delete psmr;
   delete pbval;
@@ -962,6 +962,11 @@ static bool MergeC2P() {      // A/B switch, profiles/r03_whatif_merge_c2p.txt
   return on;
 }
 template <typename T> static void SwapArr(DvceArray<T> &a, DvceArray<T> &b) { std::swap(a.p, b.p); std::swap(a.n, b.n); }
+// hydro: ConsToPrim of the active cells inside the stage kernel (akmi_hydro_stage_w); AKMI_FUSE_C2P=0: A/B switch
+static bool FuseC2P() {
+  static const bool on = !(std::getenv("AKMI_FUSE_C2P") && std::atoi(std::getenv("AKMI_FUSE_C2P")) == 0);
+  return on;
+}
 // Task-granular path, first stage: CopyCons folded into an out-of-place RKUpdate / CT (akmi_rk_update_oop,
 // akmi_mhd_ct_oop), registers swapped afterwards -- no copy traffic.  Not with FOFC (its trial update reads u1/b1
 // before RKUpdate), RK4 (CopyCons updates the second register itself), the update-in-the-sweeps option.
@@ -972,6 +977,12 @@ bool FluidBase::OopFirst(const Driver *d, int stage) const {
 }
 
 void FluidBase::RestoreRegisters() {
+  if (w_swapped) {             // the primitives back into the buffer akmi_sim_array handed out
+    HIPCHK(hipMemcpyAsync(w1.p, w0.p, w0.n*sizeof(Real), hipMemcpyDeviceToDevice, stream));
+    SwapArr(w0, w1);
+    w_swapped = false;
+    if (!u_swapped) HIPCHK(hipStreamSynchronize(stream));
+  }
   if (!u_swapped) return;
   // u1 (the creation-time u0 buffer) holds a state nothing reads any more: the first stage of the next cycle
   // overwrites it.  Current state -> that buffer, then the names trade places again.
@@ -1027,6 +1038,22 @@ TaskStatus Hydro::RKUpdate(Driver *d, int stage) {         // hydro_update.cpp:2
     // off-rank neighbours: only the sweeps + update here, so that SendU can post the halo messages
     // before the c2p of the active cells is enqueued
     StagePhase(d, stage, AKMI_PHASE_SWEEPS);
+  } else if (fused && !d->use_graph && FuseC2P() &&
+             akmi_hydro_stage_w_eligible(&pack_c, recon_method, rsolver_method)) {
+    // the stage kernel converts the cells it finishes (their new state is in its registers) into the second primitive
+    // array; ConToPrim then only has the ghost shell left (after the ghost fill): no pass that reads u0 back
+    const int do_dt = (stage == d->nexp_stages);
+    const int copy = CopyFlag(d, stage, AKMI_PHASE_ALL);
+    if (!w1.p) w1.Realloc(w0.n);
+    int wrote = 0;
+    d->ProfMark(stream);
+    AKCHK(akmi_hydro_stage_w(&pack_c, recon_method, rsolver_method, d->gam0[stage - 1], d->gam1[stage - 1],
+                             dt_dev ? d->beta[stage - 1] : beta_dt, dt_dev, copy, w0.p, w1.p, u0.p, u1.p,
+                             do_dt ? (d->ra_active ? 2 : 1) : 0, counters.p, dt3.p, ws.p, stream, &wrote));
+    d->ProfMark(stream);
+    if (copy == 2) { SwapArr(u0, u1); u_swapped = !u_swapped; }
+    if (wrote) { SwapArr(w0, w1); w_swapped = !w_swapped; }
+    interior_done_ = true; dt_ready_ = do_dt;
   } else if (fused && !d->use_graph && MergeC2P()) {
     // no off-rank neighbour: ONE ConsToPrim over all cells after the ghost fill (ConToPrim) instead of c2p of the
     // active cells here + c2p of the ghost shell there (thin slabs): 512 blocks of 32^3 1518 -> 1726 Mcell-updates/s
@@ -1518,7 +1545,12 @@ void *akmi_sim_create(const char *deck_text, void *stream) {
     s->pmesh = new Mesh(&s->pin, Comm::World().rank, Comm::World().nranks);
     s->pmesh->pmb_pack->AddPhysics(&s->pin);
     if (!stream) {
-      HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+      // a stream of our own (the null stream cannot be captured into a graph), created with the DEFAULT flags: the same
+      // kernels run measurably slower on a hipStreamNonBlocking stream on this stack -- hydro 256^3 with ConsToPrim inside the
+      // stage kernel 6 880-6 930 against 7 900-8 170 Mcell-updates/s, the null stream 7 790-7 930 (profiles/r06_stream_kind.txt;
+      // AKMI_STREAM_NONBLOCKING=1 brings the old kind back for A/B runs)
+      static const bool nb = std::getenv("AKMI_STREAM_NONBLOCKING") && std::atoi(std::getenv("AKMI_STREAM_NONBLOCKING")) != 0;
+      HIPCHK(hipStreamCreateWithFlags(&s->own_stream, nb ? hipStreamNonBlocking : hipStreamDefault));
       stream = s->own_stream;
     }
     if (auto *ph = s->pmesh->pmb_pack->phydro) ph->stream = (hipStream_t)stream;

@@ -379,6 +379,9 @@ class FluidBase {
   bool fused;
   akmi_pack pack_c;
   DvceArray<Real> u0, w0, u1;
+  DvceArray<Real> w1;                   // second primitive array (allocated on first use): akmi_hydro_stage_w writes the new
+                                        // primitives of the active cells there while neighbours still read w0; then the two trade places
+  bool w_swapped = false;               // w0 lives in the buffer that was w1 when the arrays were created
   DvceArray<int> counters;
   DvceArray<Real> dt3;
   DvceArray<char> ws;

@@ -20,10 +20,24 @@
 #endif
 static size_t hyd2_lds_doubles(int tw, int th) { return HS_ES*(2*(size_t)(tw + 3)*(th + 3) + 2*(size_t)tw*th); }
 
-template <int RECON, int RS, bool MASS = false>
+// C2P: ConsToPrim of the cell the step finishes (+ the CFL scan on the last stage) in the same kernel -- the new conserved
+// state is in registers there, so pass B of the active cells costs five stores instead of a kernel that reads u0 back
+// (SingleC2P_IdealHyd, src/eos/ideal_c2p_hyd.hpp:22-66 with its floors and counters; hydro_newdt.cpp:97-118).  The new
+// primitives go to ANOTHER array of w0's shape (w_out): neighbouring tiles and chunks still read w0 while this one finishes,
+// in place is not possible; the caller swaps the two afterwards and converts the ghost shell after the ghost fill
+// (akmi_hydro_c2p_shell).  Ideal gas, no passive scalars.
+struct HydC2P {
+  double *w_out;
+  Eos eos;
+  int do_newdt;
+  int *counters;
+  double *dt3;
+};
+template <int RECON, int RS, bool MASS = false, bool C2P = false>
 __global__ void __launch_bounds__(HS_THREADS, AKMI_HS2_WAVES)
 k_hydro_stage3d2(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, int kA, int kB,
-                 int nchunk, int ckl, int tw, int th, Mass3 ms) {
+                 int nchunk, int ckl, int tw, int th, Mass3 ms, HydC2P cp) {
+  static_assert(!C2P || (!MASS && RS < 10), "ConsToPrim inside the stage kernel: ideal gas, no passive scalars");
   static_assert(RECON <= 1, "one-kernel hydro stage: DC and PLM");
   constexpr bool ISO = rs_iso<RS>();        // isothermal: variable 4 (energy) does not exist; its slots stay unused
 #define ISOSKIP if (ISO && n == 4) continue
@@ -103,6 +117,8 @@ k_hydro_stage3d2(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, i
   }
 #pragma unroll
   for (int n = 0; n < 5; ++n) F3p[n] = 0.0;
+  double mv1 = 0.0, mv2 = 0.0, mv3 = 0.0;           // C2P, last stage: running maxima of |v| + c_s over the thread's cells
+  double *wom = C2P ? cp.w_out + (size_t)m*g.nvar*cs : nullptr;
   // step k: x3 face k (below cell k); for k > k0 also the x1/x2 faces of plane k-1, which finishes cell k-1;
   // plane k+1 (loaded during the step) replaces plane k-1
   for (int k = k0; k <= k1 + 1; ++k) {
@@ -246,13 +262,25 @@ k_hydro_stage3d2(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, i
           divf[n] += (f3[n] - F3p[n])/dx3;
         }
       }
+      double un[5] = {0, 0, 0, 0, 0};
 #pragma unroll
-      for (int n = 0; n < 5; ++n) {
-        ISOSKIP;
-        const double u0v = pu0[n];
-        const double u1v = pu1[n];
-        rk_store_u(u0m + n*cs, u1m + n*cs, u.copy_u1, oc, u0v, u.gam0*u0v + u.gam1*u1v - bdt*divf[n]);
+      for (int n = 0; n < 5; ++n) { ISOSKIP; un[n] = u.gam0*pu0[n] + u.gam1*pu1[n] - bdt*divf[n]; }
+      if constexpr (C2P) {
+        double wd, wvx, wvy, wvz, we;
+        bool dfl = false, efl = false, tfl = false;
+        c2p_hyd<true>(cp.eos, un[0], un[1], un[2], un[3], un[4], wd, wvx, wvy, wvz, we, dfl, efl, tfl);   // floors rewrite un[0] / un[4]
+        if (dfl) atomicAdd(&cp.counters[0], 1);
+        if (efl) atomicAdd(&cp.counters[1], 1);
+        if (tfl) atomicAdd(&cp.counters[2], 1);
+        stu(wom, oc, wd); stu(wom + cs, oc, wvx); stu(wom + 2*cs, oc, wvy); stu(wom + 3*cs, oc, wvz); stu(wom + 4*cs, oc, we);
+        if (cp.do_newdt) {                             // hydro_newdt.cpp:97-118
+          const double pr = (cp.eos.gamma - 1.0)*we;
+          const double cs_ = sqrt(cp.eos.gamma*pr/wd);
+          mv1 = fmax(mv1, fabs(wvx) + cs_); mv2 = fmax(mv2, fabs(wvy) + cs_); mv3 = fmax(mv3, fabs(wvz) + cs_);
+        }
       }
+#pragma unroll
+      for (int n = 0; n < 5; ++n) { ISOSKIP; rk_store_u(u0m + n*cs, u1m + n*cs, u.copy_u1, oc, pu0[n], un[n]); }
     }
     if constexpr (MASS) {                              // passive scalars ride on the mass fluxes (k_scalar_update)
       if (plane && in_tile) {
@@ -264,6 +292,24 @@ k_hydro_stage3d2(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, i
 #pragma unroll
     for (int n = 0; n < 5; ++n) { ISOSKIP; F3p[n] = f3[n]; }
     oc += (unsigned)ps*8u; oh += (unsigned)ps*8u;
+  }
+  if constexpr (C2P) {
+    if (cp.do_newdt) {         // uniform across the grid: wave maxima, workgroup maxima through LDS, one division + filtered
+      __syncthreads();         // atomicMin per direction (min over cells of fl(dx/a) == fl(dx/max a): division is monotone)
+      mv1 = wave_max(mv1); mv2 = wave_max(mv2); mv3 = wave_max(mv3);
+      const int wv = tid >> 6, nwv = (int)(blockDim.x >> 6);
+      if ((tid & 63) == 0) { hs_lds[wv] = mv1; hs_lds[8 + wv] = mv2; hs_lds[16 + wv] = mv3; }
+      __syncthreads();
+      if (tid < 3) {
+        double v = hs_lds[8*tid];
+        for (int q = 1; q < nwv; ++q) v = fmax(v, hs_lds[8*tid + q]);
+        if (v > 0.0) {
+          const double d = g.dx[3*m + tid]/v;
+          if (d < __hip_atomic_load(&cp.dt3[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMin(reinterpret_cast<unsigned long long *>(&cp.dt3[tid]), (unsigned long long)__double_as_longlong(d));
+        }
+      }
+    }
   }
 #undef ISOSKIP
 }

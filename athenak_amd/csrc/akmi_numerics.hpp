@@ -1171,6 +1171,17 @@ struct Eos {
 // The reference pays a pow() per cell only to feed this comparison.  We evaluate a cheap
 // bracket first and fall back to the exact expression only if the bracket cannot decide,
 // so the outcome is identical while the common case costs a few flops.
+// COLD: the stage kernel that converts the cells it finishes (k_hydro_stage3d2<.., C2P>) takes the exact expression through a
+// real call -- inlined there, the constants of pow()'s polynomials are hoisted out of the k-loop into registers the kernel does
+// not have and spilled (156 B of scratch, reloaded every step); the conversion kernels keep it inline
+template <bool COLD = false> struct SpeExact {
+  static AKMI_DEV double over_eps(double wd, double gm1) { return gm1/pow(wd, gm1); }
+};
+__device__ __attribute__((noinline)) inline double spe_over_eps_call(double wd, double gm1) { return gm1/pow(wd, gm1); }
+template <> struct SpeExact<true> {
+  static AKMI_DEV double over_eps(double wd, double gm1) { return spe_over_eps_call(wd, gm1); }
+};
+template <bool COLD = false>
 AKMI_DEV bool entropy_floor_hit(double wd, double we, double di, double gm1, double sfloor,
                                 double &spe_over_eps) {
   // cheap estimate with float transcendental: relative error << 1e-3
@@ -1181,7 +1192,7 @@ AKMI_DEV bool entropy_floor_hit(double wd, double we, double di, double gm1, dou
       wd < 1.0e30) {
     return false;
   }
-  spe_over_eps = gm1/pow(wd, gm1);
+  spe_over_eps = SpeExact<COLD>::over_eps(wd, gm1);
   double spe = spe_over_eps*we*di;
   return (spe <= sfloor);
 }
@@ -1189,6 +1200,7 @@ AKMI_DEV bool entropy_floor_hit(double wd, double we, double di, double gm1, dou
 // The conversion of one cell; e_other = every energy that is not thermal (kinetic [+ magnetic]).  Floors in the
 // reference's order: density (caller), internal energy, temperature, entropy; ue is rewritten where a floor acts
 // on the energy (the entropy floor only resets the primitive, as the reference does).
+template <bool COLD = false>
 AKMI_DEV void c2p_thermal(const Eos &eos, double wd, double di, double e_kin, double e_mag, bool mhd, double &ue,
                           double &we, bool &efl, bool &tfl) {
   const double efloor = eos.pfloor/(eos.gamma - 1.0);
@@ -1197,13 +1209,14 @@ AKMI_DEV void c2p_thermal(const Eos &eos, double wd, double di, double e_kin, do
   if (we < efloor) { we = efloor; ue = mhd ? (efloor + e_kin + e_mag) : (efloor + e_kin); efl = true; }
   if (gm1*we*di < eos.tfloor) { we = wd*eos.tfloor/gm1; ue = mhd ? (we + e_kin + e_mag) : (we + e_kin); tfl = true; }
   double spe_over_eps;
-  if (entropy_floor_hit(wd, we, di, gm1, eos.sfloor, spe_over_eps)) {
+  if (entropy_floor_hit<COLD>(wd, we, di, gm1, eos.sfloor, spe_over_eps)) {
     we = wd*eos.sfloor/spe_over_eps;
     efl = true;
   }
 }
 
 // SingleC2P_IdealHyd
+template <bool COLD = false>
 AKMI_DEV void c2p_hyd(const Eos &eos, double &ud, double umx, double umy, double umz, double &ue, double &wd,
                       double &wvx, double &wvy, double &wvz, double &we, bool &dfl, bool &efl, bool &tfl) {
   if (ud < eos.dfloor) { ud = eos.dfloor; dfl = true; }
@@ -1211,7 +1224,7 @@ AKMI_DEV void c2p_hyd(const Eos &eos, double &ud, double umx, double umy, double
   const double di = 1.0/ud;
   wvx = di*umx; wvy = di*umy; wvz = di*umz;
   const double e_kin = 0.5*di*(sqr(umx) + sqr(umy) + sqr(umz));
-  c2p_thermal(eos, wd, di, e_kin, 0.0, false, ue, we, efl, tfl);
+  c2p_thermal<COLD>(eos, wd, di, e_kin, 0.0, false, ue, we, efl, tfl);
 }
 
 // SingleC2P_IdealMHD: (ubx, uby, ubz) the cell-centred field; the density floor rises with b^2/sigma_max

@@ -16,6 +16,7 @@
 //   per workgroup (LDS) and the workgroup's dx/max enters a 64-bit atomicMin.  Division is
 //   monotone, so min_cells fl(dx/a) == fl(dx/max_cells a): identical to the reference scan.
 #include <cstdlib>
+#include <map>
 #include "akmi_common.hpp"
 
 using namespace akmi;
@@ -2013,11 +2014,35 @@ static int launch_sweep12s(const Geo &g, const Scheme &sc, const SweepArgs &a1, 
 }
 
 
+// dynamic LDS beyond the 64 KB a kernel gets by default: granted once per kernel function and size
+static int ensure_lds(const void *kern, size_t lds, const char *who) {
+  static std::map<const void *, size_t> granted;
+  size_t &gr = granted.emplace(kern, (size_t)64*1024).first->second;
+  if (lds <= gr) return AKMI_COMPLETE;
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    set_error("%s: %zu bytes of LDS refused", who, lds);
+    return AKMI_FAIL;
+  }
+  gr = lds;
+  return AKMI_COMPLETE;
+}
+
+static bool hyd_two_planes() {      // AKMI_HS2=0: the one-plane kernel of round 5 (A/B runs)
+  static const bool two = !(getenv("AKMI_HS2") && atoi(getenv("AKMI_HS2")) == 0);
+  return two;
+}
+// may the stage kernel convert the cells it finishes (k_hydro_stage3d2<.., C2P>)?  3-D, DC / PLM, ideal gas, no passive
+// scalars, the two-plane kernel; AKMI_FUSE_C2P=0 switches it off (A/B runs)
+static bool hyd_c2p_inside(const Geo &g, const Scheme &sc) {
+  static const bool on = !(getenv("AKMI_FUSE_C2P") && atoi(getenv("AKMI_FUSE_C2P")) == 0);
+  return on && hyd_two_planes() && g.three_d && sc.recon <= 1 && !sc.iso && g.nvar == 5 && hyd_tile(g.nx1, g.nx2, 2).tw > 0;
+}
+
+// cpa: ConsToPrim of the finished cells inside the kernel (new primitives to cpa->w_out), nullptr: update only
 template <bool MASS>
 static int launch_hydro_stage3d(const Geo &g, const Scheme &sc, const double *w0, const UpdArgs &u,
-                                int kA, int kB, hipStream_t st, Mass3 ms) {
-  // AKMI_HS2=0: the one-plane kernel of round 5 (A/B runs)
-  static const bool two = !(getenv("AKMI_HS2") && atoi(getenv("AKMI_HS2")) == 0);
+                                int kA, int kB, hipStream_t st, Mass3 ms, const HydC2P *cpa = nullptr) {
+  const bool two = hyd_two_planes();
   const HydTile tl = hyd_tile(g.nx1, g.nx2, two ? 2 : 1);
   if (tl.tw == 0) { set_error("hydro_stage3d: no tile shape"); return AKMI_FAIL; }
   int ckl = march_len((long)tl.n1*tl.n2, kB - kA + 1, g.nmb, ML);
@@ -2027,23 +2052,30 @@ static int launch_hydro_stage3d(const Geo &g, const Scheme &sc, const double *w0
   const size_t lds = hyd_lds_doubles(tl.tw, tl.th, two ? 2 : 1)*sizeof(double);
   dim3 grid(tl.n1, tl.n2, nchunk*g.nmb), block(tl.threads);
   int rc = dispatch_scheme_eos<false>(sc, [&](auto R, auto S) {
-    if constexpr (decltype(R)::value <= 1) {
-      auto kern = two ? k_hydro_stage3d2<decltype(R)::value, decltype(S)::value, MASS>
-                      : k_hydro_stage3d<decltype(R)::value, decltype(S)::value, MASS>;
-      static size_t granted = 64*1024;                 // per instantiation; raised once per size
-      if (lds > granted) {
-        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) {
-          set_error("hydro_stage3d: %zu bytes of LDS refused", lds);
-          return AKMI_FAIL;
+    constexpr int RV = decltype(R)::value, SV = decltype(S)::value;
+    if constexpr (RV <= 1) {
+      if constexpr (!MASS && SV < 10) {
+        if (cpa) {
+          auto kern = k_hydro_stage3d2<RV, SV, false, true>;
+          if (ensure_lds((const void *)kern, lds, "hydro_stage3d") != AKMI_COMPLETE) return (int)AKMI_FAIL;
+          kern<<<grid, block, lds, st>>>(g, sc.eos, w0, u, kA, kB, nchunk, ckl, tl.tw, tl.th, ms, *cpa);
+          return (int)AKMI_COMPLETE;
         }
-        granted = lds;
       }
-      kern<<<grid, block, lds, st>>>(g, sc.eos, w0, u, kA, kB, nchunk, ckl, tl.tw, tl.th, ms);
-      return AKMI_COMPLETE;
+      if (cpa) { set_error("hydro_stage3d: ConsToPrim inside the kernel is for the ideal gas without passive scalars"); return (int)AKMI_FAIL; }
+      if (two) {
+        auto kern = k_hydro_stage3d2<RV, SV, MASS, false>;
+        if (ensure_lds((const void *)kern, lds, "hydro_stage3d") != AKMI_COMPLETE) return (int)AKMI_FAIL;
+        kern<<<grid, block, lds, st>>>(g, sc.eos, w0, u, kA, kB, nchunk, ckl, tl.tw, tl.th, ms, HydC2P{});
+      } else {
+        auto kern = k_hydro_stage3d<RV, SV, MASS>;
+        if (ensure_lds((const void *)kern, lds, "hydro_stage3d") != AKMI_COMPLETE) return (int)AKMI_FAIL;
+        kern<<<grid, block, lds, st>>>(g, sc.eos, w0, u, kA, kB, nchunk, ckl, tl.tw, tl.th, ms);
+      }
+      return (int)AKMI_COMPLETE;
     } else {
       set_error("hydro_stage3d: DC and PLM only");
-      return AKMI_FAIL;
+      return (int)AKMI_FAIL;
     }
   });
   if (rc != AKMI_COMPLETE) return rc;
@@ -2238,7 +2270,8 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
                         int copy_u1, const double *w0, const double *bcc0, double *u0, double *u1,
                         double *b0x1f, double *b0x2f, double *b0x3f, double *b1x1f, double *b1x2f,
                         double *b1x3f, void *ws, const C2PArgs &cp_in, hipStream_t st,
-                        int phases = AKMI_PHASE_ALL, const double *dt_dev = nullptr) {
+                        int phases = AKMI_PHASE_ALL, const double *dt_dev = nullptr, double *w_out = nullptr,
+                        int *wrote_new = nullptr) {
   if (check_scheme(p, recon, "stage") != AKMI_COMPLETE) return AKMI_FAIL;
   if (p->nvar < (p->is_ideal ? 5 : 4)) {
     set_error("stage: nvar = %d is smaller than the fluid variable set of the EOS", p->nvar);
@@ -2283,7 +2316,8 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
     if (g.three_d) { a2.kl = g.ks - 1; a2.ku = g.ke + 1; }
     a3.il = g.is - 1; a3.iu = g.ie + 1; a3.jl = g.js - 1; a3.ju = g.je + 1;
   }
-  if (cp.enable && cp.do_newdt) k_init_dt3<<<1, 64, 0, st>>>(cp.dt3);
+  if (cp.enable && cp.do_newdt == 1) k_init_dt3<<<1, 64, 0, st>>>(cp.dt3);       // 2: the caller has reset the minima
+  bool c2p_done = false;              // ConsToPrim of the active cells happened inside the sweeps' kernel
 
   if (ndim < 3) {
     // 1-D / 2-D: small problems, plain sequence on the caller's stream
@@ -2330,8 +2364,17 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
   b3.kl = kA; b3.ku = kB + 1;
   if (do_sweeps && !MHD && hyd_one && sc.recon <= 1 && hyd_tile(g.nx1, g.nx2).tw > 0) {
     // hydro DC/PLM: sweeps + update in one kernel
-    rc = g.nvar > (sc.iso ? 4 : 5) ? launch_hydro_stage3d<true>(g, sc, w0, u, kA, kB, st, Mass3{w.flx1, w.flx2, w.flx3})
-                    : launch_hydro_stage3d<false>(g, sc, w0, u, kA, kB, st, Mass3{nullptr, nullptr, nullptr});
+    if constexpr (!MHD) {
+      if (w_out && cp.enable && hyd_c2p_inside(g, sc)) {
+        const HydC2P hc{w_out, eos, cp.do_newdt, cp.counters, cp.dt3};
+        rc = launch_hydro_stage3d<false>(g, sc, w0, u, kA, kB, st, Mass3{nullptr, nullptr, nullptr}, &hc);
+        c2p_done = true;
+        if (wrote_new) *wrote_new = 1;
+      } else {
+        rc = g.nvar > (sc.iso ? 4 : 5) ? launch_hydro_stage3d<true>(g, sc, w0, u, kA, kB, st, Mass3{w.flx1, w.flx2, w.flx3})
+                        : launch_hydro_stage3d<false>(g, sc, w0, u, kA, kB, st, Mass3{nullptr, nullptr, nullptr});
+      }
+    }
   } else if (do_sweeps && MHD && mhd_one && sc.recon == 1 && !sc.iso && sc.rsolver == AKMI_RS_HLLD && g.nvar == 5 &&
              mhd_tile(g.nx1 + 2, g.nx2 + 2).tw > 0) {
     // MHD PLM + HLLD: the three sweeps + update in one kernel (k_mhd_stage3d)
@@ -2368,7 +2411,7 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
         copy_u1, kA, kB, 1, nchunk, ckl, tl.tw, tl.th, dt_dev);
     AKMI_CHECK_LAUNCH("corner_ct");
   }
-  if (cp.enable)
+  if (cp.enable && !c2p_done)
     rc = launch_c2p<MHD>(g, eos, un, n1f, n2f, n3f, const_cast<double *>(w0),
                          const_cast<double *>(bcc0), cp.do_newdt, cp.counters, cp.dt3, g.is, g.ie,
                          g.js, g.je, kA, kB - kA + 1, st);
@@ -2504,6 +2547,23 @@ int akmi_mhd_stage_phase_dt(const akmi_pack *p, int recon, int rsolver, double g
   C2PArgs cp{1, do_newdt, counters, dt3};
   return stage_update<true>(p, recon, rsolver, gam0, gam1, beta, copy_u1, w0, bcc0, u0, u1, b0x1f, b0x2f,
                             b0x3f, b1x1f, b1x2f, b1x3f, ws, cp, (hipStream_t)stream, phases, dt_dev);
+}
+
+int akmi_hydro_stage_w_eligible(const akmi_pack *p, int recon, int rsolver) {
+  Geo g = make_geo(p);
+  const Scheme sc{recon, rsolver, make_face_eos(p), !p->is_ideal};
+  return (rsolver == AKMI_RS_LLF || rsolver == AKMI_RS_HLLE || rsolver == AKMI_RS_HLLC || rsolver == AKMI_RS_ROE) &&
+         hyd_c2p_inside(g, sc) ? 1 : 0;
+}
+
+int akmi_hydro_stage_w(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1, double beta,
+                       const double *dt_dev, int copy_u1, double *w0, double *w0_new, double *u0, double *u1,
+                       int do_newdt, int *counters, double *dt3, void *ws, void *stream, int *wrote_new) {
+  if (wrote_new) *wrote_new = 0;
+  C2PArgs cp{1, do_newdt, counters, dt3};
+  return stage_update<false>(p, recon, rsolver, gam0, gam1, beta, copy_u1, w0, nullptr, u0, u1, nullptr, nullptr, nullptr,
+                             nullptr, nullptr, nullptr, ws, cp, (hipStream_t)stream, AKMI_PHASE_ALL, dt_dev, w0_new,
+                             wrote_new);
 }
 
 int akmi_hydro_c2p_shell(const akmi_pack *p, double *u0, double *w0, int *counters, void *stream) {

@@ -214,6 +214,7 @@ class FluidBase:
 
 import os as _os
 _MERGE_C2P = _os.environ.get("AKMI_MERGE_C2P", "1") != "0"      # A/B switch (profiles/r03_whatif_merge_c2p.txt)
+_FUSE_C2P = _os.environ.get("AKMI_FUSE_C2P", "1") != "0"        # hydro: ConsToPrim inside the stage kernel (akmi_hydro_stage_w)
 _TASK_OOP = _os.environ.get("AKMI_TASK_OOP", "1") != "0"        # A/B switch: first stage of the task path out of place
 
 
@@ -365,6 +366,10 @@ class Hydro(FluidBase):
             # off-rank neighbours: only the sweeps + update here, so that SendU can post the
             # halo messages before the c2p of the active cells is enqueued (see SendU)
             self._stage_phase(pdrive, stage, capi.PHASE_SWEEPS)
+        elif self.fused and _FUSE_C2P and self._w_eligible():
+            # the stage kernel converts the cells it finishes (their new state is in its registers) into the second
+            # primitive array; ConToPrim then only has the ghost shell left (after the ghost fill)
+            self._stage_w(pdrive, stage)
         elif self.fused and _MERGE_C2P:
             # no off-rank neighbour: ONE ConsToPrim over all cells after the ghost fill (ConToPrim below) instead of
             # c2p(active cells) here + c2p(ghost shell) there
@@ -385,6 +390,40 @@ class Hydro(FluidBase):
                 capi._p(self.u1), capi._p(self.uflx.x1f), capi._p(self.uflx.x2f),
                 capi._p(self.uflx.x3f), 0, capi._stream()), "rk_update")
         return TaskStatus.complete
+
+    def _w_eligible(self):
+        fn = getattr(self.L, "akmi_hydro_stage_w_eligible", None) if not hasattr(self.L, "R") else None   # (the CPU stand-in
+        return bool(fn and fn(C.byref(self.pack_c), self.recon_method, self.rsolver_method))                # of the tests has none)
+
+    def _stage_w(self, pdrive, stage):
+        """akmi_hydro_stage_w: the whole stage, ConsToPrim of the active cells inside the update kernel, the new
+        primitives in the second primitive array (the two trade places afterwards)"""
+        import torch
+        gam0, gam1 = pdrive.gam0[stage - 1], pdrive.gam1[stage - 1]
+        beta_dt = pdrive.beta[stage - 1]*self.pmy_pack.pmesh.dt
+        do_dt = 1 if stage == pdrive.nexp_stages else 0
+        copy = self._copy_flag(pdrive, stage, capi.PHASE_ALL)
+        if getattr(self, "w1", None) is None:
+            self.w1 = torch.zeros_like(self.w0)
+        ev = getattr(self, "stage_events", None)     # bench.py: HIP event pair around the launch group
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev.append((e0, e1))
+            e0.record()
+        wrote = C.c_int(0)
+        capi.check(self.L.akmi_hydro_stage_w(
+            C.byref(self.pack_c), self.recon_method, self.rsolver_method, capi.d(gam0), capi.d(gam1), capi.d(beta_dt),
+            None, copy, capi._p(self.w0), capi._p(self.w1), capi._p(self.u0), capi._p(self.u1), do_dt,
+            capi._p(self.counters), capi._p(self.dt3), capi._p(self._workspace(0)), capi._stream(), C.byref(wrote)),
+            "hydro_stage_w")
+        if ev is not None:
+            e1.record()
+        if copy == 2:                      # out-of-place first stage: the registers trade places
+            self.u0, self.u1 = self.u1, self.u0
+        if wrote.value:
+            self.w0, self.w1 = self.w1, self.w0
+        self._interior_done = True
+        self._dt_ready = bool(do_dt)
 
     def _stage_phase(self, pdrive, stage, phases):
         """akmi_hydro_stage_phase: the parts of the fused stage named by the mask `phases`"""

@@ -570,6 +570,19 @@ int akmi_mhd_stage_phase_dt(const akmi_pack *p, int recon, int rsolver, double g
                             const double *dt_dev, int copy_u1, double *w0, double *bcc0, double *u0, double *u1,
                             double *b0x1f, double *b0x2f, double *b0x3f, double *b1x1f, double *b1x2f, double *b1x3f,
                             int do_newdt, int *counters, double *dt3, int phases, void *ws, void *stream);
+/* Hydro, the whole stage with ConsToPrim of the active cells INSIDE the update kernel (3-D, DC / PLM, ideal gas, no passive
+ * scalars: akmi_hydro_stage_w_eligible returns 1): the kernel that finishes a cell holds its new conserved state in registers,
+ * so the conversion (src/eos/ideal_c2p_hyd.hpp:22-66, floors and counters included) and, with do_newdt, the CFL scan
+ * (src/hydro/hydro_newdt.cpp:97-118) cost five stores there instead of a pass that reads u0 back.  Other workgroups still
+ * read w0 while one finishes, so the new primitives of the ACTIVE cells go to w0_new, an array of w0's shape, and
+ * *wrote_new = 1: the caller uses w0_new as w0 from then on (swap the two) and fills its ghost cells with
+ * akmi_hydro_c2p_shell after the ghost fill of u0.  Where the kernel does not apply the call is akmi_hydro_stage_fused[_dt]
+ * (active cells converted in place in w0, *wrote_new = 0).  beta: the RK weight when dt_dev != NULL (dt read from device
+ * memory), beta*dt otherwise.  do_newdt: 0 no scan, 1 reset dt3 and scan, 2 scan (the caller has reset dt3). */
+int akmi_hydro_stage_w_eligible(const akmi_pack *p, int recon, int rsolver);
+int akmi_hydro_stage_w(const akmi_pack *p, int recon, int rsolver, double gam0, double gam1, double beta,
+                       const double *dt_dev, int copy_u1, double *w0, double *w0_new, double *u0, double *u1,
+                       int do_newdt, int *counters, double *dt3, void *ws, void *stream, int *wrote_new);
 int akmi_hydro_c2p_shell(const akmi_pack *p, double *u0, double *w0, int *counters,
                          void *stream);
 int akmi_mhd_c2p_shell(const akmi_pack *p, double *u0, const double *bx1f, const double *bx2f,

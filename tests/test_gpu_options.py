@@ -5,6 +5,7 @@ once per process, so every case runs in a process of its own and must be bit-ide
   AKMI_OUT_OF_PLACE=0  C++ host: CopyCons + in-place first stage instead of the out-of-place stage with swapped registers
 (the sign-word, two-kernel-x12 and k_march3ct options of rounds 3-4 lost their measurements and left the source in round 5)
   AKMI_MHD_ONE_KERNEL=1  the three MHD sweeps + update in one tile kernel (k_mhd_stage3d; opt-in, slower)
+  AKMI_FUSE_C2P=0 / AKMI_HS2=0 / AKMI_STREAM_NONBLOCKING=1  hydro one-kernel stage: see test_hydro_stage_option_does_not_change_a_bit
 C++ host, single rank, uniform mesh:
   AKMI_RUN_AHEAD=0  the new time step read back at the end of every cycle (one host synchronisation per cycle) instead of
                     Mesh::NewTimeStep on the device with the host one cycle ahead (default when eligible)
@@ -56,6 +57,19 @@ def test_option_does_not_change_a_bit(env):
     r = subprocess.run([sys.executable, "-c", SCRIPT], env=dict(os.environ, **env), capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("env", [{"AKMI_FUSE_C2P": "0"}, {"AKMI_HS2": "0"}, {"AKMI_STREAM_NONBLOCKING": "1"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
+def test_hydro_stage_option_does_not_change_a_bit(env):
+    """the hydro one-kernel stage: AKMI_FUSE_C2P=0 ConsToPrim as a pass of its own after the ghost fill instead of inside the
+    stage kernel (akmi_hydro_stage_w + second primitive array); AKMI_HS2=0 the one-plane kernel of round 5 (which also
+    excludes the conversion inside it); AKMI_STREAM_NONBLOCKING=1 the C++ host's stream created non-blocking.  The sweep of
+    tools/h3_check.py (shapes, decompositions, DC / PLM, every Riemann solver, isothermal, passive scalars, RK1-3, both hosts)
+    stays bitwise equal to the oracle -- as it is with the defaults (test_gpu_parity.py, test_gpu_schemes.py)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "h3_check.py")], env=dict(os.environ, **env),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "bad: 0" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
 def test_mhd_one_kernel_stage_is_bit_identical():

@@ -27,7 +27,11 @@ deck = "orszag_tang.athinput"
 if os.environ.get("AKMI_PMC_PROBLEM", "") == "sod":          # hydro PLM+HLLC (bench.py --problem sod)
     deck = "sod.athinput"
     ov += ["mesh/ix1_bc=outflow", "mesh/ox1_bc=outflow"]
-sim = Simulation(load_deck(deck, ov))
+if os.environ.get("AKMI_PMC_NATIVE", "") == "1":            # the C++ host instead of the Python host
+    from athenak_amd.native import NativeSimulation
+    sim = NativeSimulation(load_deck(deck, ov))
+else:
+    sim = Simulation(load_deck(deck, ov))
 sim.Execute(max_cycles=2)
 torch.cuda.synchronize()
 print("done", sim.pmesh.ncycle)
