@@ -500,6 +500,16 @@ bool FluidBase::FoldBCs() {
 }
 // same-rank gather of the conserved variables; on meshes with physical boundaries the boundary functions ride along
 void FluidBase::GatherU(Driver *d, int stage) {
+  static const bool ghost_c2p_off = std::getenv("AKMI_GHOST_C2P") && std::atoi(std::getenv("AKMI_GHOST_C2P")) == 0;    // A/B switch
+  if (want_ghost_c2p_ && !ghost_c2p_off && (FoldBCs() || pmy_pack->pmesh->strictly_periodic)) {
+    // the stage kernel has converted the active cells: gather + boundary functions + ConsToPrim of the ghost shell, one launch
+    want_ghost_c2p_ = false;
+    AKCHK(akmi_hydro_ghost_c2p(&pack_c, pmy_pack->pmb->d_nghbr.p, pmy_pack->pmesh->strictly_periodic ? nullptr : pmy_pack->pmb->d_bcs.p,
+                               nullptr, u0.p, w0.p, counters.p, stream));
+    u_bcs_done_ = true; shell_done_ = true;
+    return;
+  }
+  want_ghost_c2p_ = false;
   if (FoldBCs() && !pmy_pack->pmesh->strictly_periodic) {
     // the last stage of the fused path: the launch also resets the CFL minima its ConsToPrim scans into
     // (not when the stage call has converted the active cells already: their scan is in dt3 by now)
@@ -1054,6 +1064,7 @@ TaskStatus Hydro::RKUpdate(Driver *d, int stage) {         // hydro_update.cpp:2
     if (copy == 2) { SwapArr(u0, u1); u_swapped = !u_swapped; }
     if (wrote) { SwapArr(w0, w1); w_swapped = !w_swapped; }
     interior_done_ = true; dt_ready_ = do_dt;
+    want_ghost_c2p_ = true;
   } else if (fused && !d->use_graph && MergeC2P()) {
     // no off-rank neighbour: ONE ConsToPrim over all cells after the ghost fill (ConToPrim) instead of c2p of the
     // active cells here + c2p of the ghost shell there (thin slabs): 512 blocks of 32^3 1518 -> 1726 Mcell-updates/s
@@ -1177,7 +1188,8 @@ TaskStatus Hydro::ConToPrim(Driver *d, int stage) {        // hydro_tasks.cpp:40
             n3 = ind.nx3 > 1 ? ind.nx3 + 2*ind.ng : 1;
   if (fused && interior_done_) {
     interior_done_ = false;
-    AKCHK(akmi_hydro_c2p_shell(&pack_c, u0.p, w0.p, counters.p, stream));
+    if (!shell_done_) AKCHK(akmi_hydro_c2p_shell(&pack_c, u0.p, w0.p, counters.p, stream));
+    shell_done_ = false;
   } else if (fused) {
     int do_dt = (stage == d->nexp_stages);
     d->ProfMark(stream);

@@ -427,8 +427,11 @@ class FluidBase {
   // stage): the Driver clears them when a stage begins (BeginStage), so a task list that drops the consumer cannot leave one
   // standing for a later stage.
   bool u_bcs_done_ = false, b_bcs_done_ = false, dt3_reset_ = false;
+  // hydro, after akmi_hydro_stage_w: the gather of SendU also converts the ghost shell (akmi_hydro_ghost_c2p) -- want_:
+  // RKUpdate asks for it, shell_done_: ConToPrim has nothing left to do
+  bool want_ghost_c2p_ = false, shell_done_ = false;
  public:
-  void BeginStage() { u_bcs_done_ = b_bcs_done_ = dt3_reset_ = false; }
+  void BeginStage() { u_bcs_done_ = b_bcs_done_ = dt3_reset_ = want_ghost_c2p_ = shell_done_ = false; }
  protected:
   static bool FoldBCs();
   void GatherU(Driver *d, int stage);

@@ -113,6 +113,8 @@ class Driver:
             if ph is None:
                 continue
             ph._dt3_reset = False
+            ph._want_ghost_c2p = False
+            ph._shell_done = False
             for bv in (getattr(ph, "pbval_u", None), getattr(ph, "pbval_b", None)):
                 if bv is not None and hasattr(bv, "_u_bcs_done"):
                     bv._u_bcs_done = bv._b_bcs_done = False

@@ -215,6 +215,7 @@ class FluidBase:
 import os as _os
 _MERGE_C2P = _os.environ.get("AKMI_MERGE_C2P", "1") != "0"      # A/B switch (profiles/r03_whatif_merge_c2p.txt)
 _FUSE_C2P = _os.environ.get("AKMI_FUSE_C2P", "1") != "0"        # hydro: ConsToPrim inside the stage kernel (akmi_hydro_stage_w)
+_GHOST_C2P = _os.environ.get("AKMI_GHOST_C2P", "1") != "0"      # ... and of the ghost shell inside the gather (akmi_hydro_ghost_c2p)
 _TASK_OOP = _os.environ.get("AKMI_TASK_OOP", "1") != "0"        # A/B switch: first stage of the task path out of place
 
 
@@ -424,6 +425,7 @@ class Hydro(FluidBase):
             self.w0, self.w1 = self.w1, self.w0
         self._interior_done = True
         self._dt_ready = bool(do_dt)
+        self._want_ghost_c2p = True
 
     def _stage_phase(self, pdrive, stage, phases):
         """akmi_hydro_stage_phase: the parts of the fused stage named by the mask `phases`"""
@@ -460,6 +462,22 @@ class Hydro(FluidBase):
     def SendU(self, pdrive, stage):
         if self.multilevel:
             return self.psmr.PackAndSendCC(self.u0, self.coarse_u0)
+        if getattr(self, "_want_ghost_c2p", False):
+            # the stage kernel has converted the active cells (akmi_hydro_stage_w): gather + boundary functions +
+            # ConsToPrim of the ghost shell in one launch
+            self._want_ghost_c2p = False
+            bv, pm = self.pbval_u, self.pmy_pack.pmesh
+            pgen = pm.pgen
+            if (_GHOST_C2P and not bv.peers and (bv.fold_bcs or pm.strictly_periodic)
+                    and not (pgen is not None and pgen.user_bcs)):
+                capi.check(self.L.akmi_hydro_ghost_c2p(
+                    C.byref(self.pack_c), capi._p(bv.nghbr), None if pm.strictly_periodic else capi._p(bv.bcs),
+                    capi._p(bv.u_in), capi._p(self.u0), capi._p(self.w0), capi._p(self.counters), capi._stream()),
+                    "hydro_ghost_c2p")
+                bv._u_bcs_done = True
+                self._shell_done = True
+                self._dt3_reset = False
+                return TaskStatus.complete
         reset = None
         if (self.fused and self.pbval_u.fold_bcs and stage >= 1 and stage == pdrive.nexp_stages
                 and not getattr(self, "_interior_done", False)):
@@ -493,9 +511,11 @@ class Hydro(FluidBase):
         n3, n2, n1 = self.pmy_pack.pmesh.mb_indcs.ncells
         if self.fused and getattr(self, "_interior_done", False):
             self._interior_done = False
-            capi.check(self.L.akmi_hydro_c2p_shell(
-                C.byref(self.pack_c), capi._p(self.u0), capi._p(self.w0), capi._p(self.counters),
-                capi._stream()), "hydro_c2p_shell")
+            if not getattr(self, "_shell_done", False):
+                capi.check(self.L.akmi_hydro_c2p_shell(
+                    C.byref(self.pack_c), capi._p(self.u0), capi._p(self.w0), capi._p(self.counters),
+                    capi._stream()), "hydro_c2p_shell")
+            self._shell_done = False
             return TaskStatus.complete
         if self.fused:
             do_dt = 1 if stage == pdrive.nexp_stages else 0

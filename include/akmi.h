@@ -585,6 +585,12 @@ int akmi_hydro_stage_w(const akmi_pack *p, int recon, int rsolver, double gam0, 
                        int do_newdt, int *counters, double *dt3, void *ws, void *stream, int *wrote_new);
 int akmi_hydro_c2p_shell(const akmi_pack *p, double *u0, double *w0, int *counters,
                          void *stream);
+/* What is left of a hydro stage after akmi_hydro_stage_w on a pack without off-rank neighbours, in ONE launch:
+ * akmi_bvals_cc_local_bcs(u0) (same-rank gather + physical boundary functions; bcs may be NULL: no physical boundary) followed
+ * by akmi_hydro_c2p_shell(u0 -> w0) -- a thread per ghost cell gathers its five conserved variables, converts them and stores
+ * both.  Ideal gas, nvar = 5.  (src/bvals/bvals_cc.cpp:108-135, hydro_tasks.cpp:357-375,404-412.) */
+int akmi_hydro_ghost_c2p(const akmi_pack *p, const int *nghbr, const int *bcs, const double *u_in, double *u0, double *w0,
+                         int *counters, void *stream);
 int akmi_mhd_c2p_shell(const akmi_pack *p, double *u0, const double *bx1f, const double *bx2f,
                        const double *bx3f, double *w0, double *bcc0, int *counters,
                        void *stream);
