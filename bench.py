@@ -534,7 +534,11 @@ def main():
         same_lib = t.get("lib_sha16") == lib_sha16()
         same_src = t.get("src_sha16") is not None and t.get("src_sha16") == src_sha16()
         if same_lib or same_src:
-            traffic = round(sum(t["kernels"][k]["hbm_bytes_per_launch"] for k in stage_kernels))
+            # (the counter run does 2 RK2 cycles = 4 stages: a kernel launched once per stage has 4 launches, 5 with the
+            #  conversion of Driver::Initialize; a kernel that only runs there -- the hydro path converts inside its stage
+            #  kernel -- does not belong to a stage)
+            traffic = round(sum(t["kernels"][k]["hbm_bytes_per_launch"]*round(t["kernels"][k].get("launches", 4)/4.0)
+                                for k in stage_kernels))
             tsrc = "profiles/%s (%s, %s)" % (os.path.basename(tfile), t.get("tag", ""),
                                               ("lib %s" % t["lib_sha16"]) if same_lib else
                                               ("same sources %s, rebuilt library" % t["src_sha16"]))
