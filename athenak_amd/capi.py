@@ -45,7 +45,7 @@ SYMBOLS = [
     "akmi_sim_execute", "akmi_sim_profile", "akmi_sim_profile_read", "akmi_sim_destroy", "akmi_sim_time", "akmi_sim_dt", "akmi_sim_tlim",
     "akmi_sim_ncycle", "akmi_sim_nmb", "akmi_sim_array", "akmi_sim_lloc", "akmi_sim_gids", "akmi_sim_nmb_thisrank",
     "akmi_comm_unique_id", "akmi_comm_init_rccl", "akmi_comm_init_env", "akmi_comm_init_callbacks", "akmi_hydro_stage_fused_dt", "akmi_mhd_stage_fused_dt", "akmi_comm_finalize", "akmi_comm_allreduce_min",
-    "akmi_hydro_stage_w_eligible", "akmi_hydro_stage_w", "akmi_hydro_ghost_c2p", "akmi_comm_rank", "akmi_comm_nranks", "akmi_comm_profile", "akmi_comm_profile_read", "akmi_host_exchange_plan",
+    "akmi_hydro_stage_w_eligible", "akmi_hydro_stage_w", "akmi_hydro_ghost_uw", "akmi_comm_rank", "akmi_comm_nranks", "akmi_comm_profile", "akmi_comm_profile_read", "akmi_host_exchange_plan",
     "akmi_smr_exchange_cc", "akmi_smr_exchange_fc", "akmi_smr_fill_coarse_cc", "akmi_smr_fill_coarse_fc",
     "akmi_smr_prolong_cc", "akmi_smr_prolong_fc", "akmi_smr_c2p_coarse", "akmi_smr_p2c_fine", "akmi_smr_build_lists", "akmi_smr_flux_cc", "akmi_smr_emf_exchange", "akmi_smr_pack_cc", "akmi_smr_unpack_cc", "akmi_smr_pack_fc",
     "akmi_selftest_fp64",

@@ -84,6 +84,10 @@ struct GhostBC {
   const int *bcs;        // [nmb][6] AKMI_BC_*
   const double *in;      // inflow constants: u_in[nvar][6] (cell-centred set) / b_in[3][6] (face-centred set), may be null
   double *dt3;           // when non-null: the three CFL minima are reset here (saves the k_init_dt3 launch of the last stage)
+  // akmi_hydro_ghost_uw: floor flags of the source cells (one byte per cell, bits 0-2) and the three floor counters -- every
+  // ghost image of a cell a floor acted on counts as the reference's ConsToPrim over all cells counts it
+  const unsigned char *flags = nullptr;
+  int *counters = nullptr;
 };
 __host__ __device__ inline bool bc_is_physical(int f) {
   return f == AKMI_BC_REFLECT || f == AKMI_BC_OUTFLOW || f == AKMI_BC_INFLOW || f == AKMI_BC_DIODE || f == AKMI_BC_VACUUM;
@@ -173,6 +177,12 @@ k_ghost_fill(Geo g, GhostSet gs, int nv, unsigned chunks, const int *__restrict_
           src = m; oo1 = oo2 = oo3 = 0;           // nothing fills c': the boundary functions copy what it holds
         }
         double val = a[((((size_t)src*nv + n)*q.n3 + (kk2 - oo3*q.d3.nx))*q.n2 + (jj2 - oo2*q.d2.nx))*q.n1 + (ii2 - oo1*q.d1.nx)];
+        if (bc.flags && n == 0 && blockIdx.y == 0) {
+          const unsigned fl = bc.flags[(((size_t)src*q.n3 + (kk2 - oo3*q.d3.nx))*q.n2 + (jj2 - oo2*q.d2.nx))*q.n1 + (ii2 - oo1*q.d1.nx)];
+          if (fl & 1u) atomicAdd(&bc.counters[0], 1);
+          if (fl & 2u) atomicAdd(&bc.counters[1], 1);
+          if (fl & 4u) atomicAdd(&bc.counters[2], 1);
+        }
         if (f1 >= 0) val = bc_value(val, f1, 0, sd1, comp, n, bc.in);
         if (f2 >= 0) val = bc_value(val, f2, 1, sd2, comp, n, bc.in);
         if (f3 >= 0) val = bc_value(val, f3, 2, sd3, comp, n, bc.in);
@@ -226,82 +236,6 @@ static int launch_ghost(const Geo &g, const GhostSet &gs, int nv, const int *ngh
   k_ghost_fill<KIND, BC><<<grid, 256, 0, st>>>(g, gs, nv, (unsigned)chunks, nghbr, seg_off, recvbuf, bc);
   AKMI_CHECK_LAUNCH("bvals ghost fill");
   return AKMI_COMPLETE;
-}
-
-// ---- hydro: ghost fill of the conserved variables AND ConsToPrim of the ghost shell in one launch ---------------------
-// For a pack whose active cells were converted by the stage kernel (akmi_hydro_stage_w): what is left of a stage after it
-// is the ghost fill of u (same-rank gather + physical boundary functions, as k_ghost_fill<0, true>) and the conversion of
-// exactly those ghost cells (akmi_hydro_c2p_shell).  One thread per ghost CELL: it gathers the nv (= 5) variables of the
-// cell from the one source cell (index maps and value rules above), converts them (SingleC2P_IdealHyd with its floors and
-// counters, src/eos/ideal_c2p_hyd.hpp:22-66) and stores both u and w.  Ideal gas, no passive scalars; a ghost cell that
-// nothing fills (no neighbour, no physical boundary) is converted from what it holds, as the two launches did.
-__global__ void __launch_bounds__(256)
-k_ghost_fill_c2p(Geo g, Eos eos, Comp q, unsigned chunks, const int *__restrict__ nghbr, const int *__restrict__ bcs,
-                 const double *__restrict__ u_in, double *__restrict__ u, double *__restrict__ w,
-                 int *__restrict__ counters) {
-  const int mode = blockIdx.z;
-  unsigned e1, e2, e3;
-  if (mode == 0) { e1 = q.n1; e2 = q.n2; e3 = 2*q.d3.ng; }
-  else if (mode == 1) { e1 = q.n1; e2 = 2*q.d2.ng; e3 = q.d3.eo - q.d3.s + 1; }
-  else { e1 = 2*q.d1.ng; e2 = q.d2.eo - q.d2.s + 1; e3 = q.d3.eo - q.d3.s + 1; }
-  const unsigned per = e1*e2*e3, e12 = e1*e2;
-  const unsigned m = blockIdx.x/chunks, ch = blockIdx.x - m*chunks;
-  __shared__ int s_src[27];
-  __shared__ int s_bc[6];
-  if (threadIdx.x < 27) s_src[threadIdx.x] = nghbr[m*27 + threadIdx.x];
-  if (threadIdx.x >= 32 && threadIdx.x < 38) s_bc[threadIdx.x - 32] = bcs ? bcs[6*m + threadIdx.x - 32] : AKMI_BC_PERIODIC;
-  __syncthreads();
-  const size_t cs = (size_t)q.n3*q.n2*q.n1;
-  for (unsigned r = ch*256u + threadIdx.x; r < per; r += chunks*256u) {
-    const unsigned kk = r/e12, r2 = r - kk*e12;
-    const unsigned jj = r2/e1;
-    const int ii = (int)(r2 - jj*e1);
-    int i, j, k;
-    if (mode == 0) { i = ii; j = (int)jj; k = (int)kk < q.d3.ng ? (int)kk : q.d3.eo + 1 + ((int)kk - q.d3.ng); }
-    else if (mode == 1) { i = ii; j = (int)jj < q.d2.ng ? (int)jj : q.d2.eo + 1 + ((int)jj - q.d2.ng); k = q.d3.s + (int)kk; }
-    else { i = ii < q.d1.ng ? ii : q.d1.eo + 1 + (ii - q.d1.ng); j = q.d2.s + (int)jj; k = q.d3.s + (int)kk; }
-    int o1 = q.d1.side(i), o2 = q.d2.side(j), o3 = q.d3.side(k);
-    int f1 = -1, f2 = -1, f3 = -1, sd1 = 0, sd2 = 0, sd3 = 0;     // boundary type applied per direction (-1: none)
-    int kk2 = k, jj2 = j, ii2 = i;
-    if (o3 != 0) { sd3 = o3 > 0; const int f = s_bc[4 + sd3]; if (bc_is_physical(f)) { f3 = f; kk2 = bc_source(q.d3, k, o3, f, false); o3 = 0; } }
-    if (o2 != 0) { sd2 = o2 > 0; const int f = s_bc[2 + sd2]; if (bc_is_physical(f)) { f2 = f; jj2 = bc_source(q.d2, j, o2, f, false); o2 = 0; } }
-    if (o1 != 0) { sd1 = o1 > 0; const int f = s_bc[sd1]; if (bc_is_physical(f)) { f1 = f; ii2 = bc_source(q.d1, i, o1, f, false); o1 = 0; } }
-    const bool mapped = (f1 >= 0) || (f2 >= 0) || (f3 >= 0);
-    const int d = (o3 + 1)*9 + (o2 + 1)*3 + (o1 + 1);
-    int src = (d == 13) ? (int)m : s_src[d];
-    bool filled = true;
-    if (src < 0) {
-      src = (int)m; o1 = o2 = o3 = 0;
-      if (!mapped) { filled = false; kk2 = k; jj2 = j; ii2 = i; }      // nothing fills this cell: convert what it holds
-    }
-    const size_t so = (((size_t)src*5*q.n3 + (kk2 - o3*q.d3.nx))*q.n2 + (jj2 - o2*q.d2.nx))*q.n1 + (ii2 - o1*q.d1.nx);
-    const size_t dst = (((size_t)m*5*q.n3 + k)*q.n2 + j)*q.n1 + i;
-    double v[5];
-#pragma unroll
-    for (int n = 0; n < 5; ++n) v[n] = u[so + n*cs];
-    if (filled) {
-#pragma unroll
-      for (int n = 0; n < 5; ++n) {
-        if (f1 >= 0) v[n] = bc_value(v[n], f1, 0, sd1, 0, n, u_in);
-        if (f2 >= 0) v[n] = bc_value(v[n], f2, 1, sd2, 0, n, u_in);
-        if (f3 >= 0) v[n] = bc_value(v[n], f3, 2, sd3, 0, n, u_in);
-      }
-    }
-    double wd, wvx, wvy, wvz, we;
-    bool dfl = false, efl = false, tfl = false;
-    c2p_hyd(eos, v[0], v[1], v[2], v[3], v[4], wd, wvx, wvy, wvz, we, dfl, efl, tfl);     // floors rewrite v[0] / v[4]
-    if (dfl) atomicAdd(&counters[0], 1);
-    if (efl) atomicAdd(&counters[1], 1);
-    if (tfl) atomicAdd(&counters[2], 1);
-    if (filled) {
-#pragma unroll
-      for (int n = 0; n < 5; ++n) u[dst + n*cs] = v[n];
-    } else {
-      if (dfl) u[dst] = v[0];
-      if (efl || tfl) u[dst + 4*cs] = v[4];
-    }
-    w[dst] = wd; w[dst + cs] = wvx; w[dst + 2*cs] = wvy; w[dst + 3*cs] = wvz; w[dst + 4*cs] = we;
-  }
 }
 
 static GhostSet cc_set(const Geo &g, double *u) {
@@ -498,24 +432,37 @@ int akmi_bvals_cc_local_bcs(const akmi_pack *p, int nvar, const int *nghbr, cons
                                GhostBC{bcs, u_in, dt3_reset});
 }
 
-int akmi_hydro_ghost_c2p(const akmi_pack *p, const int *nghbr, const int *bcs, const double *u_in, double *u, double *w,
-                         int *counters, void *stream) {
+// Hydro, after akmi_hydro_stage_w: ghost zones of the conserved AND of the primitive variables in one launch.
+// The reference fills the ghost zones of u0 (neighbour copies, boundary functions) and then converts EVERY cell, so a ghost
+// cell's (u, w) is the conversion of the same numbers its source cell was converted from -- including the floors: the result
+// is the source cell's (u, w) under the value rule of the boundary (identity for a neighbour / periodic / outflow copy, the
+// sign of the normal momentum AND of the normal velocity for reflect; e_kin is even in both).  Converting the ghost copy of
+// an already floored u again is NOT that: (efloor + e_kin) - e_kin need not give efloor back.  So both arrays are gathered
+// with the index maps and value rules of k_ghost_fill<0, true>, and nothing is converted here.  Boundary types whose value
+// rule does not commute with the conversion (diode, vacuum, inflow, user) are refused: the caller keeps the separate
+// ConsToPrim pass for such packs.  The floor counters of the reference count every cell its ConsToPrim converts, ghost cells
+// included: akmi_hydro_stage_w leaves one flag byte per active cell at the start of its workspace, and every ghost image of
+// a flagged cell is counted here.
+int akmi_hydro_ghost_uw(const akmi_pack *p, const int *nghbr, const int *bcs, const int *bcs_host, double *u, double *w,
+                        const void *ws, int *counters, void *stream) {
   Geo g = make_geo(p);
-  if (!p->is_ideal || p->nvar != 5) { set_error("hydro_ghost_c2p: ideal gas without passive scalars"); return AKMI_FAIL; }
-  const Comp q = make_comp(g, 0);
-  const long long n0 = (long long)q.n1*q.n2*2*q.d3.ng, n1 = (long long)q.n1*2*q.d2.ng*(q.d3.eo - q.d3.s + 1),
-                  n2 = (long long)2*q.d1.ng*(q.d2.eo - q.d2.s + 1)*(q.d3.eo - q.d3.s + 1);
-  const long long nmax = n0 > n1 ? (n0 > n2 ? n0 : n2) : (n1 > n2 ? n1 : n2);
-  if (nmax >= (1ll << 31)) { set_error("hydro_ghost_c2p: a ghost slab has 2^31 cells or more"); return AKMI_FAIL; }
-  long long chunks = (nmax + 255)/256;
-  const long long cap = ((1ll << 31) - 1)/g.nmb;
-  if (chunks > cap) chunks = cap;
-  if (chunks > 64 && (long long)g.nmb*chunks > (1ll << 20)) { chunks = (1ll << 20)/g.nmb; if (chunks < 64) chunks = 64; if (chunks > cap) chunks = cap; }
-  if (chunks < 1) { set_error("hydro_ghost_c2p: too many MeshBlocks for one launch"); return AKMI_FAIL; }
-  dim3 grid((unsigned)(g.nmb*chunks), 1, 3);
-  k_ghost_fill_c2p<<<grid, 256, 0, (hipStream_t)stream>>>(g, make_eos(p), q, (unsigned)chunks, nghbr, bcs, u_in, u, w, counters);
-  AKMI_CHECK_LAUNCH("hydro_ghost_c2p");
-  return AKMI_COMPLETE;
+  if (!bcs || !bcs_host || !ws || !counters) { set_error("hydro_ghost_uw: bcs (device and host), ws and counters are required"); return AKMI_FAIL; }
+  if (bcs_host)
+    for (int q = 0; q < 6*p->nmb; ++q) {
+      const int f = bcs_host[q];
+      if (f != AKMI_BC_BLOCK && f != AKMI_BC_PERIODIC && f != AKMI_BC_OUTFLOW && f != AKMI_BC_REFLECT) {
+        set_error("hydro_ghost_uw: boundary type %d does not commute with ConsToPrim (periodic, outflow, reflect only)", f);
+        return AKMI_FAIL;
+      }
+    }
+  GhostSet gs{};
+  gs.q[0] = make_comp(g, 0); gs.a[0] = u; gs.comp[0] = 0;
+  gs.q[1] = make_comp(g, 0); gs.a[1] = w; gs.comp[1] = 0;
+  gs.ncomp = 2;
+  GhostBC bc{bcs, nullptr, nullptr};
+  bc.flags = static_cast<const unsigned char *>(ws);        // written by akmi_hydro_stage_w with the same workspace
+  bc.counters = counters;
+  return launch_ghost<0, true>(g, gs, p->nvar, nghbr, nullptr, nullptr, (hipStream_t)stream, bc);
 }
 
 int akmi_bvals_fc_local_bcs(const akmi_pack *p, const int *nghbr, const int *bcs, const double *b_in, double *bx1f,

@@ -494,18 +494,25 @@ FluidBase::~FluidBase() {
   delete pbval;
   delete peos;
 }
+// may the ghost zones of the primitives be filled like those of the conserved variables (akmi_hydro_ghost_uw)?  Only where
+// every boundary's value rule commutes with ConsToPrim: neighbour / periodic copies, outflow, reflect
+bool FluidBase::BcsCommuteWithC2P() const {
+  for (int f : pmy_pack->pmb->mb_bcs)
+    if (f != AKMI_BC_BLOCK && f != AKMI_BC_PERIODIC && f != AKMI_BC_OUTFLOW && f != AKMI_BC_REFLECT) return false;
+  return true;
+}
 bool FluidBase::FoldBCs() {
   const char *e = getenv("AKMI_FOLD_BCS");      // read per call: tests switch it inside one process
   return !(e && atoi(e) == 0);
 }
 // same-rank gather of the conserved variables; on meshes with physical boundaries the boundary functions ride along
 void FluidBase::GatherU(Driver *d, int stage) {
-  static const bool ghost_c2p_off = std::getenv("AKMI_GHOST_C2P") && std::atoi(std::getenv("AKMI_GHOST_C2P")) == 0;    // A/B switch
-  if (want_ghost_c2p_ && !ghost_c2p_off && (FoldBCs() || pmy_pack->pmesh->strictly_periodic)) {
-    // the stage kernel has converted the active cells: gather + boundary functions + ConsToPrim of the ghost shell, one launch
+  if (want_ghost_c2p_) {
+    // the stage kernel has converted the active cells (akmi_hydro_stage_w): ghost zones of u0 AND of the new primitive array
+    // by the same gather + boundary functions, one launch, nothing converted twice (see akmi_hydro_ghost_uw)
     want_ghost_c2p_ = false;
-    AKCHK(akmi_hydro_ghost_c2p(&pack_c, pmy_pack->pmb->d_nghbr.p, pmy_pack->pmesh->strictly_periodic ? nullptr : pmy_pack->pmb->d_bcs.p,
-                               nullptr, u0.p, w0.p, counters.p, stream));
+    AKCHK(akmi_hydro_ghost_uw(&pack_c, pmy_pack->pmb->d_nghbr.p, pmy_pack->pmb->d_bcs.p, pmy_pack->pmb->mb_bcs.data(), u0.p,
+                              w0.p, ws.p, counters.p, stream));
     u_bcs_done_ = true; shell_done_ = true;
     return;
   }
@@ -1048,7 +1055,7 @@ TaskStatus Hydro::RKUpdate(Driver *d, int stage) {         // hydro_update.cpp:2
     // off-rank neighbours: only the sweeps + update here, so that SendU can post the halo messages
     // before the c2p of the active cells is enqueued
     StagePhase(d, stage, AKMI_PHASE_SWEEPS);
-  } else if (fused && !d->use_graph && FuseC2P() &&
+  } else if (fused && !d->use_graph && FuseC2P() && BcsCommuteWithC2P() &&
              akmi_hydro_stage_w_eligible(&pack_c, recon_method, rsolver_method)) {
     // the stage kernel converts the cells it finishes (their new state is in its registers) into the second primitive
     // array; ConToPrim then only has the ghost shell left (after the ghost fill): no pass that reads u0 back

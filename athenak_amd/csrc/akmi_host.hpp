@@ -434,6 +434,7 @@ class FluidBase {
   void BeginStage() { u_bcs_done_ = b_bcs_done_ = dt3_reset_ = want_ghost_c2p_ = shell_done_ = false; }
  protected:
   static bool FoldBCs();
+  bool BcsCommuteWithC2P() const;
   void GatherU(Driver *d, int stage);
 };
 

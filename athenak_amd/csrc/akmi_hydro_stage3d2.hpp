@@ -27,6 +27,8 @@ static size_t hyd2_lds_doubles(int tw, int th) { return HS_ES*(2*(size_t)(tw + 3
 // in place is not possible; the caller swaps the two afterwards and converts the ghost shell after the ghost fill
 // (akmi_hydro_c2p_shell).  Ideal gas, no passive scalars.
 struct HydC2P {
+  unsigned char *flags;       // per cell (m, k, j, i): bit 0 / 1 / 2 = the density / energy / temperature floor acted -- the ghost
+                              // fill that follows counts the ghost images of such cells (the reference's counters include them)
   double *w_out;
   Eos eos;
   int do_newdt;
@@ -272,6 +274,7 @@ k_hydro_stage3d2(Geo g, FaceEos eos, const double *__restrict__ w0, UpdArgs u, i
         if (dfl) atomicAdd(&cp.counters[0], 1);
         if (efl) atomicAdd(&cp.counters[1], 1);
         if (tfl) atomicAdd(&cp.counters[2], 1);
+        cp.flags[(size_t)m*cs + (oc >> 3)] = (unsigned char)((dfl ? 1 : 0) | (efl ? 2 : 0) | (tfl ? 4 : 0));
         stu(wom, oc, wd); stu(wom + cs, oc, wvx); stu(wom + 2*cs, oc, wvy); stu(wom + 3*cs, oc, wvz); stu(wom + 4*cs, oc, we);
         if (cp.do_newdt) {                             // hydro_newdt.cpp:97-118
           const double pr = (cp.eos.gamma - 1.0)*we;

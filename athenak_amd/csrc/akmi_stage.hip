@@ -2366,7 +2366,8 @@ static int stage_update(const akmi_pack *p, int recon, int rsolver, double gam0,
     // hydro DC/PLM: sweeps + update in one kernel
     if constexpr (!MHD) {
       if (w_out && cp.enable && hyd_c2p_inside(g, sc)) {
-        const HydC2P hc{w_out, eos, cp.do_newdt, cp.counters, cp.dt3};
+        // (the floor flags of the cells, one byte each, at the start of the workspace: akmi_hydro_ghost_uw reads them there)
+        const HydC2P hc{reinterpret_cast<unsigned char *>(ws), w_out, eos, cp.do_newdt, cp.counters, cp.dt3};
         rc = launch_hydro_stage3d<false>(g, sc, w0, u, kA, kB, st, Mass3{nullptr, nullptr, nullptr}, &hc);
         c2p_done = true;
         if (wrote_new) *wrote_new = 1;

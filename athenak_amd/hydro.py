@@ -215,7 +215,6 @@ class FluidBase:
 import os as _os
 _MERGE_C2P = _os.environ.get("AKMI_MERGE_C2P", "1") != "0"      # A/B switch (profiles/r03_whatif_merge_c2p.txt)
 _FUSE_C2P = _os.environ.get("AKMI_FUSE_C2P", "1") != "0"        # hydro: ConsToPrim inside the stage kernel (akmi_hydro_stage_w)
-_GHOST_C2P = _os.environ.get("AKMI_GHOST_C2P", "1") != "0"      # ... and of the ghost shell inside the gather (akmi_hydro_ghost_c2p)
 _TASK_OOP = _os.environ.get("AKMI_TASK_OOP", "1") != "0"        # A/B switch: first stage of the task path out of place
 
 
@@ -393,8 +392,18 @@ class Hydro(FluidBase):
         return TaskStatus.complete
 
     def _w_eligible(self):
+        """akmi_hydro_stage_w + akmi_hydro_ghost_uw: no off-rank neighbour, every boundary's value rule commutes with
+        ConsToPrim (neighbour / periodic copies, outflow, reflect), no user boundary function"""
         fn = getattr(self.L, "akmi_hydro_stage_w_eligible", None) if not hasattr(self.L, "R") else None   # (the CPU stand-in
-        return bool(fn and fn(C.byref(self.pack_c), self.recon_method, self.rsolver_method))                # of the tests has none)
+        if not fn or self.pbval_u.peers:                                                                    # of the tests has none)
+            return False
+        pgen = self.pmy_pack.pmesh.pgen
+        if pgen is not None and pgen.user_bcs:
+            return False
+        ok = tuple(capi.BC[k] for k in ("block", "periodic", "outflow", "reflect"))
+        if any(int(f) not in ok for f in np.asarray(self.pmy_pack.pmb.mb_bcs).ravel()):
+            return False
+        return bool(fn(C.byref(self.pack_c), self.recon_method, self.rsolver_method))
 
     def _stage_w(self, pdrive, stage):
         """akmi_hydro_stage_w: the whole stage, ConsToPrim of the active cells inside the update kernel, the new
@@ -463,21 +472,18 @@ class Hydro(FluidBase):
         if self.multilevel:
             return self.psmr.PackAndSendCC(self.u0, self.coarse_u0)
         if getattr(self, "_want_ghost_c2p", False):
-            # the stage kernel has converted the active cells (akmi_hydro_stage_w): gather + boundary functions +
-            # ConsToPrim of the ghost shell in one launch
+            # the stage kernel has converted the active cells (akmi_hydro_stage_w): ghost zones of u0 AND of the new primitive
+            # array by the same gather + boundary functions, one launch, nothing converted twice (akmi_hydro_ghost_uw)
             self._want_ghost_c2p = False
             bv, pm = self.pbval_u, self.pmy_pack.pmesh
-            pgen = pm.pgen
-            if (_GHOST_C2P and not bv.peers and (bv.fold_bcs or pm.strictly_periodic)
-                    and not (pgen is not None and pgen.user_bcs)):
-                capi.check(self.L.akmi_hydro_ghost_c2p(
-                    C.byref(self.pack_c), capi._p(bv.nghbr), None if pm.strictly_periodic else capi._p(bv.bcs),
-                    capi._p(bv.u_in), capi._p(self.u0), capi._p(self.w0), capi._p(self.counters), capi._stream()),
-                    "hydro_ghost_c2p")
-                bv._u_bcs_done = True
-                self._shell_done = True
-                self._dt3_reset = False
-                return TaskStatus.complete
+            hb = np.ascontiguousarray(self.pmy_pack.pmb.mb_bcs, dtype=np.int32)
+            capi.check(self.L.akmi_hydro_ghost_uw(
+                C.byref(self.pack_c), capi._p(bv.nghbr), capi._p(bv.bcs), hb.ctypes.data_as(C.c_void_p), capi._p(self.u0),
+                capi._p(self.w0), capi._p(self._workspace(0)), capi._p(self.counters), capi._stream()), "hydro_ghost_uw")
+            bv._u_bcs_done = True
+            self._shell_done = True
+            self._dt3_reset = False
+            return TaskStatus.complete
         reset = None
         if (self.fused and self.pbval_u.fold_bcs and stage >= 1 and stage == pdrive.nexp_stages
                 and not getattr(self, "_interior_done", False)):

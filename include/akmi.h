@@ -575,8 +575,8 @@ int akmi_mhd_stage_phase_dt(const akmi_pack *p, int recon, int rsolver, double g
  * so the conversion (src/eos/ideal_c2p_hyd.hpp:22-66, floors and counters included) and, with do_newdt, the CFL scan
  * (src/hydro/hydro_newdt.cpp:97-118) cost five stores there instead of a pass that reads u0 back.  Other workgroups still
  * read w0 while one finishes, so the new primitives of the ACTIVE cells go to w0_new, an array of w0's shape, and
- * *wrote_new = 1: the caller uses w0_new as w0 from then on (swap the two) and fills its ghost cells with
- * akmi_hydro_c2p_shell after the ghost fill of u0.  Where the kernel does not apply the call is akmi_hydro_stage_fused[_dt]
+ * *wrote_new = 1: the caller uses w0_new as w0 from then on (swap the two) and fills the ghost cells of u0 and of it with
+ * akmi_hydro_ghost_uw (NOT by converting the ghost copies of the floored u0 again: see there).  Where the kernel does not apply the call is akmi_hydro_stage_fused[_dt]
  * (active cells converted in place in w0, *wrote_new = 0).  beta: the RK weight when dt_dev != NULL (dt read from device
  * memory), beta*dt otherwise.  do_newdt: 0 no scan, 1 reset dt3 and scan, 2 scan (the caller has reset dt3). */
 int akmi_hydro_stage_w_eligible(const akmi_pack *p, int recon, int rsolver);
@@ -585,12 +585,17 @@ int akmi_hydro_stage_w(const akmi_pack *p, int recon, int rsolver, double gam0, 
                        int do_newdt, int *counters, double *dt3, void *ws, void *stream, int *wrote_new);
 int akmi_hydro_c2p_shell(const akmi_pack *p, double *u0, double *w0, int *counters,
                          void *stream);
-/* What is left of a hydro stage after akmi_hydro_stage_w on a pack without off-rank neighbours, in ONE launch:
- * akmi_bvals_cc_local_bcs(u0) (same-rank gather + physical boundary functions; bcs may be NULL: no physical boundary) followed
- * by akmi_hydro_c2p_shell(u0 -> w0) -- a thread per ghost cell gathers its five conserved variables, converts them and stores
- * both.  Ideal gas, nvar = 5.  (src/bvals/bvals_cc.cpp:108-135, hydro_tasks.cpp:357-375,404-412.) */
-int akmi_hydro_ghost_c2p(const akmi_pack *p, const int *nghbr, const int *bcs, const double *u_in, double *u0, double *w0,
-                         int *counters, void *stream);
+/* What is left of a hydro stage after akmi_hydro_stage_w on a pack without off-rank neighbours: the ghost zones of u0 AND of
+ * the new primitive array, one launch, no conversion.  The reference converts every cell after the ghost fill
+ * (hydro_tasks.cpp:357-375,404-412), so a ghost cell's (u, w) equals its source cell's under the boundary's value rule
+ * (copy for neighbour / periodic / outflow, sign of the normal momentum and velocity for reflect) -- floors included, whereas
+ * converting the copy of an already floored u a second time would not reproduce it.  bcs: device int[nmb][6]; bcs_host: the
+ * same flags in host memory -- a pack with a diode, vacuum, inflow or user face is refused (AKMI_FAIL): keep
+ * akmi_bvals_cc_local_bcs + akmi_hydro_c2p_newdt (no akmi_hydro_stage_w) there.  ws: the workspace akmi_hydro_stage_w was
+ * given (it leaves one floor-flag byte per cell at its start); counters: the three floor counters -- every ghost image of a
+ * cell a floor acted on is counted, as the reference's ConsToPrim over all cells counts it. */
+int akmi_hydro_ghost_uw(const akmi_pack *p, const int *nghbr, const int *bcs, const int *bcs_host, double *u0, double *w0,
+                        const void *ws, int *counters, void *stream);
 int akmi_mhd_c2p_shell(const akmi_pack *p, double *u0, const double *bx1f, const double *bx2f,
                        const double *bx3f, double *w0, double *bcc0, int *counters,
                        void *stream);

@@ -59,13 +59,12 @@ def test_option_does_not_change_a_bit(env):
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-@pytest.mark.parametrize("env", [{"AKMI_FUSE_C2P": "0"}, {"AKMI_HS2": "0"}, {"AKMI_STREAM_NONBLOCKING": "1"}, {"AKMI_GHOST_C2P": "0"}],
+@pytest.mark.parametrize("env", [{"AKMI_FUSE_C2P": "0"}, {"AKMI_HS2": "0"}, {"AKMI_STREAM_NONBLOCKING": "1"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
 def test_hydro_stage_option_does_not_change_a_bit(env):
     """the hydro one-kernel stage: AKMI_FUSE_C2P=0 ConsToPrim as a pass of its own after the ghost fill instead of inside the
     stage kernel (akmi_hydro_stage_w + second primitive array); AKMI_HS2=0 the one-plane kernel of round 5 (which also
-    excludes the conversion inside it); AKMI_STREAM_NONBLOCKING=1 the C++ host's stream created non-blocking; AKMI_GHOST_C2P=0 the gather + boundary functions and
-    the conversion of the ghost shell as two launches instead of akmi_hydro_ghost_c2p.  The sweep of
+    excludes the conversion inside it); AKMI_STREAM_NONBLOCKING=1 the C++ host's stream created non-blocking.  The sweep of
     tools/h3_check.py (shapes, decompositions, DC / PLM, every Riemann solver, isothermal, passive scalars, RK1-3, both hosts)
     stays bitwise equal to the oracle -- as it is with the defaults (test_gpu_parity.py, test_gpu_schemes.py)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "h3_check.py")], env=dict(os.environ, **env),

@@ -588,3 +588,30 @@ def test_passive_scalars(case, native, fused):
         assert np.allclose(got[:, nf][a], got[:, 0][a], rtol=1e-13, atol=0.0)
     s1 = (got[:, nf + 1]/got[:, 0])[a]
     assert s1.min() >= 0.25 - 1e-12 and s1.max() <= 0.75 + 1e-12 and s1.std() > 0.01
+
+
+@pytest.mark.parametrize("native", [False, True], ids=["python-host", "cpp-host"])
+@pytest.mark.parametrize("bcs", ["outflow", "reflect"])
+def test_hydro_conversion_inside_the_stage_kernel_with_binding_floors(bcs, native):
+    """round 6: akmi_hydro_stage_w converts the cells it finishes inside k_hydro_stage3d2 (floors, floor counters, CFL scan) and
+    akmi_hydro_ghost_uw fills the ghost zones of u0 and w0 with the same gather (converting a floored ghost copy again would
+    not reproduce the reference: (efloor + e_kin) - e_kin need not be efloor).  Receding streams (u = -+4 either side of the middle of a
+    uniform gas) empty the middle of the tube: density and pressure fall below the floors there (dfloor 0.5, pfloor 0.39) cycle
+    after cycle, in active cells and -- through outflow / reflecting boundary functions of the transverse faces -- in ghost
+    cells.  u0 and w0 incl. ghosts, dt, and the three floor counters of the whole run against the oracle, both hosts."""
+    extra = ["mesh/%s=%s" % (f, bcs) for f in ("ix1_bc", "ox1_bc", "ix2_bc", "ox2_bc", "ix3_bc", "ox3_bc")]
+    extra += ["problem/ul=-4.0", "problem/ur=4.0", "problem/dr=1.0", "problem/pl=0.4", "problem/pr=0.4"]
+    sim, osim, is_mhd = pu.make_pair("sod", 32, 3, 16, fused=True, native=native, cfl=0.3, extra=extra,
+                                     params={"dfloor": 0.5, "pfloor": 0.39})
+    for _ in range(8):
+        assert sim.Execute(max_cycles=1) == 1 and osim.step()
+    d = pu.compare_fields(pu.product_arrays(sim), pu.oracle_arrays(osim, is_mhd), is_mhd)
+    assert d["bitwise_equal"], d
+    assert sim.pmesh.time == osim.time and sim.pmesh.dt == osim.dt
+    ph = sim.phys
+    assert np.array_equal(ph.w0.cpu().numpy(), osim.array("w0"))
+    assert ph.u0.cpu().numpy()[:, 0].min() == 0.5                 # the density floor binds
+    ocnt = osim.array("counters")
+    assert ocnt[0] > 100 and ocnt[1] > 100, ocnt
+    if not native:                                                # (the C++ host keeps its counters to itself)
+        assert np.array_equal(ph.counters.cpu().numpy(), ocnt), (ph.counters.cpu().numpy(), ocnt)
