@@ -251,33 +251,36 @@ static GhostSet fc_set(const Geo &g, double *b1, double *b2, double *b3) {
   return gs;
 }
 
-// ---- pack: one grid.y per segment --------------------------------------------------------
+// ---- pack: one grid.y per segment, one grid.z per component of the set (cell-centred: one; face field: x1f, x2f, x3f) ---
+struct PackSet { const double *a[3]; int comp0, ncomp; };      // comp0: component of a[0] (0 cell-centred, 1 x1f)
 __global__ void __launch_bounds__(256)
-k_pack(Geo g, Comp q, int nv, const int *__restrict__ send_tab,
-       const long long *__restrict__ send_off, long long comp_off_unused,
-       const double *__restrict__ a, double *__restrict__ sendbuf, int fc_comp) {
+k_pack(Geo g, PackSet ps, int nv, const int *__restrict__ send_tab, const long long *__restrict__ send_off,
+       double *__restrict__ sendbuf) {
   const int s = blockIdx.y;
   const int m = send_tab[2*s], d = send_tab[2*s + 1];
   int o1, o2, o3;
   if (!dir_valid(g, 26 - d, o1, o2, o3)) return;
+  const int fc_comp = ps.comp0 + (int)blockIdx.z;
+  const Comp q = make_comp(g, fc_comp);
+  const double *__restrict__ a = ps.a[blockIdx.z];
   const int c1 = q.d1.cnt(o1), c2 = q.d2.cnt(o2), c3 = q.d3.cnt(o3);
   long long base = send_off[s];
   if (fc_comp > 1) {  // FC segments hold x1f, x2f, x3f parts back to back
     for (int c = 1; c < fc_comp; ++c) base += seg_count(make_comp(g, c), o1, o2, o3);
   }
-  const long long tot = (long long)nv*c3*c2*c1;
-  for (long long t = (long long)blockIdx.x*blockDim.x + threadIdx.x; t < tot;
-       t += (long long)gridDim.x*blockDim.x) {
-    int n = (int)(t/((long long)c3*c2*c1));
-    long long r = t - (long long)n*c3*c2*c1;
-    int kk = (int)(r/((long long)c2*c1));
-    r -= (long long)kk*c2*c1;
-    int jj = (int)(r/c1);
-    int ii = (int)(r - (long long)jj*c1);
-    int i = q.d1.lo(o1) + ii - o1*q.d1.nx;
-    int j = q.d2.lo(o2) + jj - o2*q.d2.nx;
-    int k = q.d3.lo(o3) + kk - o3*q.d3.nx;
-    sendbuf[base + t] = a[((((size_t)m*nv + n)*q.n3 + k)*q.n2 + j)*q.n1 + i];
+  // 32-bit index arithmetic (a segment of one MeshBlock is far below 2^31 elements; checked at launch): the first form
+  // decoded a 64-bit flat index with three 64-bit divisions per element on 64 workgroups per segment and packed the 25 MB of a
+  // 256^3 block's 26 segments in 57 us (0.44 TB/s; `roofline.halo.pack_ms`)
+  const unsigned c12 = (unsigned)c2*(unsigned)c1, per = (unsigned)c3*c12, tot = (unsigned)nv*per;
+  const size_t vb = (size_t)m*nv;
+  for (unsigned t = blockIdx.x*256u + threadIdx.x; t < tot; t += gridDim.x*256u) {
+    const unsigned n = t/per, r = t - n*per;
+    const unsigned kk = r/c12, r2 = r - kk*c12;
+    const unsigned jj = r2/(unsigned)c1, ii = r2 - jj*(unsigned)c1;
+    const int i = q.d1.lo(o1) + (int)ii - o1*q.d1.nx;
+    const int j = q.d2.lo(o2) + (int)jj - o2*q.d2.nx;
+    const int k = q.d3.lo(o3) + (int)kk - o3*q.d3.nx;
+    sendbuf[base + t] = a[(((vb + n)*q.n3 + k)*q.n2 + j)*q.n1 + i];
   }
 }
 
@@ -478,13 +481,22 @@ int akmi_bvals_cc_unpack(const akmi_pack *p, int nvar, const int *nghbr, const l
   return launch_ghost<1>(g, cc_set(g, u), nvar, nghbr, seg_off, recvbuf, (hipStream_t)stream);
 }
 
+// workgroups per segment: the largest segment of the pack (a face slab of nv variables) in pieces of 1024 elements, at most 512
+// (a thread then strides); small segments leave most of them idle at once
+static unsigned pack_chunks(const Geo &g, int nv) {
+  const long long f1 = (long long)(g.N2 + 1)*(g.N3 + 1)*g.ng, f2 = (long long)(g.N1 + 1)*(g.N3 + 1)*g.ng,
+                  f3 = (long long)(g.N1 + 1)*(g.N2 + 1)*g.ng;
+  long long mx = f1 > f2 ? (f1 > f3 ? f1 : f3) : (f2 > f3 ? f2 : f3);
+  long long ch = (mx*nv + 1023)/1024;
+  return (unsigned)(ch < 1 ? 1 : (ch > 512 ? 512 : ch));
+}
+
 int akmi_bvals_cc_pack(const akmi_pack *p, int nvar, int nsend, const int *send_tab,
                        const long long *send_off, const double *u, double *sendbuf, void *stream) {
   if (nsend <= 0) return AKMI_COMPLETE;
   Geo g = make_geo(p);
-  dim3 grid(64, nsend);
-  k_pack<<<grid, 256, 0, (hipStream_t)stream>>>(g, make_comp(g, 0), nvar, send_tab, send_off, 0, u,
-                                               sendbuf, 0);
+  dim3 grid(pack_chunks(g, nvar), nsend, 1);
+  k_pack<<<grid, 256, 0, (hipStream_t)stream>>>(g, PackSet{{u, nullptr, nullptr}, 0, 1}, nvar, send_tab, send_off, sendbuf);
   AKMI_CHECK_LAUNCH("cc_pack");
   return AKMI_COMPLETE;
 }
@@ -500,12 +512,8 @@ int akmi_bvals_fc_pack(const akmi_pack *p, int nsend, const int *send_tab, const
                        void *stream) {
   if (nsend <= 0) return AKMI_COMPLETE;
   Geo g = make_geo(p);
-  const double *b[3] = {bx1f, bx2f, bx3f};
-  dim3 grid(32, nsend);
-  for (int c = 1; c <= 3; ++c) {
-    k_pack<<<grid, 256, 0, (hipStream_t)stream>>>(g, make_comp(g, c), 1, send_tab, send_off, 0,
-                                                 b[c - 1], sendbuf, c);
-  }
+  dim3 grid(pack_chunks(g, 1), nsend, 3);            // the three face components in one launch
+  k_pack<<<grid, 256, 0, (hipStream_t)stream>>>(g, PackSet{{bx1f, bx2f, bx3f}, 1, 3}, 1, send_tab, send_off, sendbuf);
   AKMI_CHECK_LAUNCH("fc_pack");
   return AKMI_COMPLETE;
 }
