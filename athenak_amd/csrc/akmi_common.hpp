@@ -157,6 +157,34 @@ __device__ __forceinline__ void stu(double *__restrict__ base, unsigned ob, doub
   *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + ob) = v;
 }
 
+// Lane mapping of the cell / face kernels that have one thread per element: the threads of a launch run over the box
+// [kl, kl+nk) x [jl, jl+nj) x columns of MeshBlock m, i fastest, in one of these forms (chosen per kernel and pack at launch,
+// measured on 120 blocks of 16^3 and 960 blocks of 32^3 with four ghost cells: profiles/r06_lane_mapping.txt):
+//   0                       rows of n1 elements (whole rows of the array: contiguous addresses across a wave), one group of
+//                           workgroups per plane: blockIdx.z = m*nk + plane
+//   FLAT_K                  the planes flattened too, blockIdx.z = m: a plane of a small MeshBlock is 1.1 - 2.3 workgroups, and
+//                           every plane rounds that up
+//   FLAT_K | FLAT_COLS      ... and only the columns [il, iu] of a row: the 16 active cells of a row of 24
+// `in` is false for the threads outside the box.
+enum { FLAT_K = 1, FLAT_COLS = 2 };
+struct Cell3 { int i, j, k, m; bool in; };
+__device__ __forceinline__ Cell3 flat_cells(int mode, int n1, int il, int iu, int jl, int nj, int kl, int nk) {
+  const unsigned p = (blockIdx.x*blockDim.y + threadIdx.y)*blockDim.x + threadIdx.x;
+  const unsigned c0 = (mode & FLAT_COLS) ? (unsigned)il : 0u, ni = (mode & FLAT_COLS) ? (unsigned)(iu - il + 1) : (unsigned)n1;
+  const unsigned plane = ni*(unsigned)nj;
+  unsigned kk, pr, m;
+  if (mode & FLAT_K) { kk = p/plane; pr = p - kk*plane; m = blockIdx.z; }
+  else { m = blockIdx.z/(unsigned)nk; kk = blockIdx.z - m*(unsigned)nk; pr = p; }
+  const unsigned jj = pr/ni;
+  const int i = (int)(c0 + pr - jj*ni);
+  return Cell3{i, jl + (int)jj, kl + (int)kk, (int)m, (int)kk < nk && (int)jj < nj && i >= il && i <= iu};
+}
+inline dim3 flat_cells_grid(int mode, int n1, int il, int iu, long nj, long nk, int nmb, int threads = 256) {
+  const long ni = (mode & FLAT_COLS) ? iu - il + 1 : n1;
+  if (mode & FLAT_K) return dim3((unsigned)((ni*nj*nk + threads - 1)/threads), 1, (unsigned)nmb);
+  return dim3((unsigned)((ni*nj + threads - 1)/threads), 1, (unsigned)(nmb*nk));
+}
+
 // gfx950 runs wave64 only; the kernels that count on it (ballot words, lane shifts, four waves per 256 threads) say so
 constexpr int AKMI_WAVE = 64;
 #if defined(__HIP_DEVICE_COMPILE__) && defined(__AMDGCN_WAVEFRONT_SIZE)

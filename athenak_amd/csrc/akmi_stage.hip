@@ -143,23 +143,31 @@ struct SweepArgs {
 #endif
 template <int DIR, int RECON>
 constexpr bool x1_share() { return DIR == 0 && RECON >= 1 && AKMI_X1_SHARE; }
+// k_sweep: the planes [kl, ku] flattened into the lane index as well (120 blocks of 16^3, PPM4 + HLLD: x1 sweep 40.7 -> 32,
+// x2 sweep 49.4 -> 36 us; the x3 sweep, whose stencil crosses the planes, is 4 % faster with one group of workgroups per
+// plane: 56.1 against 58.6 us) -- profiles/r06_lane_mapping.txt
+template <int DIR>
+constexpr bool sweep_kflat() { return DIR != 2; }
 
 template <int RECON, bool MHD, bool ECC, int RS>
 __device__ __forceinline__ void sweep_x1_shared(const Geo &g, const FaceEos &eos, const SweepArgs &a,
                                                 int nk) {
   // lanes over the flattened (row, column) with the columns a row needs: cells il-1 .. iu (the first one only provides
   // the left state of face il) -- not the N1 of the row: 34 of the 40 columns of a 32^3 MeshBlock with four ghost cells
+  // The flattening runs over the planes [kl, ku] of the MeshBlock as well (a plane of a 16^3 block is 18 x 18 positions:
+  // 1.3 workgroups of 252, i.e. two workgroups 64 % full when every plane starts a workgroup of its own).
   const long p = ((long)blockIdx.x*SY + threadIdx.y)*(SX - 1) + (long)threadIdx.x - 1;
-  const long pc = p < 0 ? 0 : p;
-  const int row_w = a.iu - a.il + 2;
-  const int jj = (int)(pc/row_w);
-  const int i = a.il - 1 + (int)(pc - (long)jj*row_w);
-  const int j = a.jl + jj;
-  const int m = blockIdx.z/nk;
-  const int k = a.kl + (blockIdx.z - m*nk);
+  const unsigned pc = p < 0 ? 0u : (unsigned)p;
+  const unsigned row_w = (unsigned)(a.iu - a.il + 2), plane = row_w*(unsigned)(a.ju - a.jl + 1);
+  const unsigned kk = pc/plane, pr = pc - kk*plane;
+  const unsigned jj = pr/row_w;
+  const int i = a.il - 1 + (int)(pr - jj*row_w);
+  const int j = a.jl + (int)jj;
+  const int m = blockIdx.z;
+  const int k = a.kl + (int)kk;
   // a lane owns cell i: its stencil (i-1..i+1, five-point schemes i-2..i+2) has to be inside the row
   constexpr int HW = RECON == 1 ? 1 : 2;
-  const bool valid = p >= 0 && j <= a.ju && i >= HW && i <= g.N1 - 1 - HW;
+  const bool valid = p >= 0 && (int)kk < nk && i >= HW && i <= g.N1 - 1 - HW;
   constexpr int NV = MHD ? 7 : 5;
   const size_t cs = (size_t)g.N3*g.N2*g.N1;
   // addresses = wave-uniform base (block m, variable n: scalar unit) + ONE 32-bit byte offset per lane
@@ -254,14 +262,20 @@ k_sweep(Geo g, FaceEos eos, SweepArgs a, int nk) {
   // ghost columns outside [il,iu] cost 2-4 idle lanes per 260 instead of a mostly empty wave
   // lanes over the flattened (row, column) with the columns of the sweep only (ECC: one more on the low side), not the
   // N1 of a row: a thread-per-face sweep has no coupling between lanes (18 of 24 columns at 16^3 with four ghost cells)
-  const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;
-  const int row_0 = a.il - (ECC ? 1 : 0), row_w = a.iu - row_0 + 1;
-  const int jj = (int)(p/row_w);
-  const int i = row_0 + (int)(p - (long)jj*row_w);
-  const int j = a.jl + jj;
-  const int m = blockIdx.z/nk;
-  const int k = a.kl + (blockIdx.z - m*nk);
-  if (j > a.ju || i < a.il - (ECC ? 1 : 0) || i > a.iu) return;
+  // ... and over the planes [kl, ku] of the MeshBlock (a plane of a 16^3 block is 17 x 18 faces: two workgroups 60 % full
+  // when every plane starts a workgroup of its own)
+  const unsigned p = (blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;
+  const int row_0 = a.il - (ECC ? 1 : 0);
+  const unsigned row_w = (unsigned)(a.iu - row_0 + 1), plane = row_w*(unsigned)(a.ju - a.jl + 1);
+  unsigned kk, pr, mm;
+  if (sweep_kflat<DIR>()) { kk = p/plane; pr = p - kk*plane; mm = blockIdx.z; }
+  else { mm = blockIdx.z/(unsigned)nk; kk = blockIdx.z - mm*(unsigned)nk; pr = p; }
+  const unsigned jj = pr/row_w;
+  const int i = row_0 + (int)(pr - jj*row_w);
+  const int j = a.jl + (int)jj;
+  const int m = (int)mm;
+  const int k = a.kl + (int)kk;
+  if ((int)kk >= nk || j > a.ju) return;
   const size_t cs = (size_t)g.N3*g.N2*g.N1;
   const unsigned oc = (((unsigned)k*(unsigned)g.N2 + (unsigned)j)*(unsigned)g.N1 + (unsigned)i)*8u;   // cell (k,j,i)
   if constexpr (ECC) {
@@ -1230,16 +1244,13 @@ k_c2p_newdt(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ 
             double *__restrict__ w0, double *__restrict__ bcc0, int do_newdt,
             int *__restrict__ counters, double *__restrict__ dt3, int il, int iu, int jl, int ju,
             int k0, int nk) {
-  // cells [il,iu] x [jl,ju] x [k0,k0+nk-1]; lanes run over the flattened rows [jl,ju] x N1
+  // cells [il,iu] x [jl,ju] x [k0,k0+nk-1]; lanes over the flattened rows [jl,ju] x N1 of one plane (flat_cells, akmi_common.hpp;
+  // with the planes flattened too this kernel is slower on small MeshBlocks: 49 -> 60 us on 120 blocks of 16^3)
   __shared__ double sm[3][SY];
-  const long p = ((long)blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;
-  const int jj = (int)(p/g.N1);
-  const int j = jl + jj;
-  const int i = (int)(p - (long)jj*g.N1);
-  const int m = blockIdx.z/nk;
-  const int k = k0 + (blockIdx.z - m*nk);
+  const Cell3 q = flat_cells(0, g.N1, il, iu, jl, ju - jl + 1, k0, nk);
+  const int i = q.i, j = q.j, k = q.k, m = q.m;
   double mv1 = 0.0, mv2 = 0.0, mv3 = 0.0;
-  if (j <= ju && i >= il && i <= iu) {
+  if (q.in) {
     const size_t cs = (size_t)g.N3*g.N2*g.N1;
     const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
     double wd, wvx, wvy, wvz, we = 0.0, ubx = 0, uby = 0, ubz = 0;
@@ -1752,9 +1763,10 @@ static int launch_sweep(const Geo &g, const Scheme &sc, const SweepArgs &a, hipS
     // faces per wave: 63 when the lanes share their slopes (lane 0 of a wave only provides); those kernels run over
     // the columns il-1 .. iu of a row (sweep_x1_shared), the plain one over il (- 1 with ECC) .. iu
     constexpr bool share = x1_share<DIR, decltype(R)::value>();
-    const long np = (long)(a.ju - a.jl + 1)*(share ? a.iu - a.il + 2 : a.iu - a.il + 1 + (ECC ? 1 : 0));
+    const bool kf = share || sweep_kflat<DIR>();
+    const long np = (long)(kf ? nk : 1)*(a.ju - a.jl + 1)*(share ? a.iu - a.il + 2 : a.iu - a.il + 1 + (ECC ? 1 : 0));   // of one MeshBlock
     const long per_wg = (long)(share ? SX - 1 : SX)*SY;
-    dim3 grid((unsigned)((np + 1 + per_wg - 1)/per_wg), 1, nk*g.nmb);
+    dim3 grid((unsigned)((np + 1 + per_wg - 1)/per_wg), 1, kf ? g.nmb : nk*g.nmb);
     k_sweep<DIR, decltype(R)::value, MHD, ECC, decltype(S)::value><<<grid, block, 0, st>>>(
         g, sc.eos, a, nk);
     return AKMI_COMPLETE;

@@ -21,18 +21,7 @@ void set_error(const char *fmt, ...) {
 
 constexpr int BX = 64, BY = 4;
 
-// Lane mapping of the cell kernels below: the lanes of a launch run over the flattened rows
-// [jl, ju] x [0, N1) of a plane -- contiguous in memory, and a MeshBlock of 16 or 32 cells per row keeps
-// 2/3 - 4/5 of the lanes busy instead of the 1/4 - 1/2 it gets with threadIdx.x tied to i.
-__device__ __forceinline__ void flat_ij(const Geo &g, int jl, int &i, int &j) {
-  const long p = ((long)blockIdx.x*BY + threadIdx.y)*BX + threadIdx.x;
-  const int jj = (int)(p/g.N1);
-  i = (int)(p - (long)jj*g.N1);
-  j = jl + jj;
-}
-static inline dim3 flat_grid(const Geo &g, int nj, int nz) {
-  return dim3((unsigned)(((long)nj*g.N1 + BX*BY - 1)/(BX*BY)), 1, (unsigned)nz);
-}
+// (lane mapping of the cell kernels below: flat_cells, akmi_common.hpp)
 
 // ---------------------------------------------------------------------------------------
 // Hydro fluxes: reconstruct in registers + Riemann solver RS.  hydro_fluxes.cpp:77-229.
@@ -110,13 +99,10 @@ static int launch_hydro_flux(const Geo &g, const Scheme &sc, const double *w0,
 __global__ void __launch_bounds__(BX*BY)
 k_rk_update(Geo g, double gam0, double gam1, double beta_dt, double *__restrict__ u0,
             const double *__restrict__ u1, const double *__restrict__ flx1,
-            const double *__restrict__ flx2, const double *__restrict__ flx3, int fsh) {
-  int i, j;
-  flat_ij(g, g.js, i, j);
-  const int nk = g.ke - g.ks + 1;
-  const int m = blockIdx.z/nk;
-  const int k = g.ks + (blockIdx.z - m*nk);
-  if (i < g.is || i > g.ie || j > g.je) return;
+            const double *__restrict__ flx2, const double *__restrict__ flx3, int fsh, int fm) {
+  const Cell3 q = flat_cells(fm, g.N1, g.is, g.ie, g.js, g.nx2, g.ks, g.nx3);
+  const int i = q.i, j = q.j, k = q.k, m = q.m;
+  if (!q.in) return;
   const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
   // cell sizes that are powers of two (every level of a refined mesh on a 2^n root grid): x/dx as one v_ldexp_f64,
   // bit for bit the quotient (akmi_common.hpp pow2_shift; tests/test_gpu_fastmath.py)
@@ -150,11 +136,9 @@ __global__ void __launch_bounds__(BX*BY)
 k_rk_update_oop(Geo g, double gam0, double gam1, double beta_dt, const double *__restrict__ src,
                 double *__restrict__ dst, const double *__restrict__ flx1, const double *__restrict__ flx2,
                 const double *__restrict__ flx3, int fsh) {
-  int i, j;
-  flat_ij(g, 0, i, j);
-  const int m = blockIdx.z/g.N3;
-  const int k = blockIdx.z - m*g.N3;
-  if (j >= g.N2) return;
+  const Cell3 q = flat_cells(FLAT_K, g.N1, 0, g.N1 - 1, 0, g.N2, 0, g.N3);
+  const int i = q.i, j = q.j, k = q.k, m = q.m;
+  if (!q.in) return;
   const bool act = i >= g.is && i <= g.ie && j >= g.js && j <= g.je && k >= g.ks && k <= g.ke;
   const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
   const bool p2 = is_pow2(dx1) && is_pow2(dx2) && is_pow2(dx3);
@@ -189,11 +173,9 @@ k_c2p(Geo g, Eos eos, double *__restrict__ u0, const double *__restrict__ bx1f,
       const double *__restrict__ bx2f, const double *__restrict__ bx3f,
       double *__restrict__ w0, double *__restrict__ bcc0, int il, int iu, int jl, int ju,
       int kl, int nk, int *__restrict__ counters) {
-  int i, j;
-  flat_ij(g, jl, i, j);
-  const int m = blockIdx.z/nk;
-  const int k = kl + (blockIdx.z - m*nk);
-  if (i < il || i > iu || j > ju) return;
+  const Cell3 q = flat_cells(0, g.N1, il, iu, jl, ju - jl + 1, kl, nk);
+  const int i = q.i, j = q.j, k = q.k, m = q.m;
+  if (!q.in) return;
   const size_t cs = (size_t)g.N3*g.N2*g.N1;
   const size_t c = ix5(g.nvar, g.N3, g.N2, g.N1, m, 0, k, j, i);
   double ubx = 0.0, uby = 0.0, ubz = 0.0;
@@ -303,13 +285,10 @@ template <bool MHD>
 __global__ void __launch_bounds__(BX*BY)
 k_newdt(Geo g, Eos eos, const double *__restrict__ w0, const double *__restrict__ bcc0,
         double *__restrict__ dt3) {
-  int i, j;
-  flat_ij(g, g.js, i, j);
-  const int nk = g.ke - g.ks + 1;
-  const int m = blockIdx.z/nk;
-  const int k = g.ks + (blockIdx.z - m*nk);
+  const Cell3 q = flat_cells(0, g.N1, g.is, g.ie, g.js, g.nx2, g.ks, g.nx3);
+  const int i = q.i, j = q.j, k = q.k, m = q.m;
   double d1 = (double)FLT_MAX, d2 = (double)FLT_MAX, d3 = (double)FLT_MAX;
-  if (i >= g.is && i <= g.ie && j <= g.je) cell_dt<MHD>(g, eos, w0, bcc0, m, k, j, i, d1, d2, d3);
+  if (q.in) cell_dt<MHD>(g, eos, w0, bcc0, m, k, j, i, d1, d2, d3);
   block_min3_atomic(d1, d2, d3, dt3);
 }
 
@@ -720,12 +699,9 @@ k_ct(Geo g, double gam0, double gam1, double beta_dt, const double *__restrict__
      const double *__restrict__ e2, const double *__restrict__ e3, double *__restrict__ b0x1f,
      double *__restrict__ b0x2f, double *__restrict__ b0x3f, const double *__restrict__ b1x1f,
      const double *__restrict__ b1x2f, const double *__restrict__ b1x3f) {
-  int i, j;
-  flat_ij(g, g.js, i, j);
-  const int nk = g.ke - g.ks + 2;
-  const int m = blockIdx.z/nk;
-  const int k = g.ks + (blockIdx.z - m*nk);
-  if (i < g.is || i > g.ie + 1 || j > g.je + 1) return;
+  const Cell3 q = flat_cells(FLAT_K, g.N1 + 1, g.is, g.ie + 1, g.js, g.je - g.js + 2, g.ks, g.ke - g.ks + 2);
+  const int i = q.i, j = q.j, k = q.k, m = q.m;
+  if (!q.in) return;
   const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
 #define E1(k, j, i) e1[ix4(g.N3 + 1, g.N2 + 1, g.N1, m, k, j, i)]
 #define E2(k, j, i) e2[ix4(g.N3 + 1, g.N2, g.N1 + 1, m, k, j, i)]
@@ -767,12 +743,9 @@ k_ct_oop(Geo g, double gam0, double gam1, double beta_dt, const double *__restri
          const double *__restrict__ e2, const double *__restrict__ e3, const double *__restrict__ sx1f,
          const double *__restrict__ sx2f, const double *__restrict__ sx3f, double *__restrict__ dx1f,
          double *__restrict__ dx2f, double *__restrict__ dx3f) {
-  const long p = ((long)blockIdx.x*BY + threadIdx.y)*BX + threadIdx.x;      // rows of N1+1 over j in [0, N2]
-  const int j = (int)(p/(g.N1 + 1));
-  const int i = (int)(p - (long)j*(g.N1 + 1));
-  const int m = blockIdx.z/(g.N3 + 1);
-  const int k = blockIdx.z - m*(g.N3 + 1);
-  if (j > g.N2) return;
+  const Cell3 q = flat_cells(FLAT_K, g.N1 + 1, 0, g.N1, 0, g.N2 + 1, 0, g.N3 + 1);      // every face index of the three arrays
+  const int i = q.i, j = q.j, k = q.k, m = q.m;
+  if (!q.in) return;
   const double dx1 = g.dx[3*m], dx2 = g.dx[3*m + 1], dx3 = g.dx[3*m + 2];
 #define E1(k, j, i) e1[ix4(g.N3 + 1, g.N2 + 1, g.N1, m, k, j, i)]
 #define E2(k, j, i) e2[ix4(g.N3 + 1, g.N2, g.N1 + 1, m, k, j, i)]
@@ -1124,9 +1097,13 @@ int akmi_rk_update(const akmi_pack *p, double gam0, double gam1, double beta_dt,
                    const double *u1, const double *flx1, const double *flx2,
                    const double *flx3, int face_shaped, void *stream) {
   Geo g = make_geo(p);
-  dim3 grid = flat_grid(g, g.je - g.js + 1, (g.ke - g.ks + 1)*g.nmb), block(BX, BY);
+  // MeshBlocks whose planes of active cells fill at most one workgroup: planes and columns flattened (120 blocks of 16^3:
+  // 40 -> 34 us); larger ones keep whole rows and one group of workgroups per plane (960 blocks of 32^3: 1 950 us against
+  // 2 040 with the planes flattened and 2 180 with the columns too) -- profiles/r06_lane_mapping.txt
+  const int fm = (g.three_d && g.nx1*g.nx2 <= BX*BY) ? (FLAT_K | FLAT_COLS) : 0;
+  dim3 grid = flat_cells_grid(fm, g.N1, g.is, g.ie, g.nx2, g.nx3, g.nmb), block(BX, BY);
   k_rk_update<<<grid, block, 0, (hipStream_t)stream>>>(g, gam0, gam1, beta_dt, u0, u1, flx1, flx2,
-                                                       flx3, face_shaped ? 1 : 0);
+                                                       flx3, face_shaped ? 1 : 0, fm);
   AKMI_CHECK_LAUNCH("rk_update");
   return AKMI_COMPLETE;
 }
@@ -1134,7 +1111,7 @@ int akmi_rk_update(const akmi_pack *p, double gam0, double gam1, double beta_dt,
 int akmi_rk_update_oop(const akmi_pack *p, double gam0, double gam1, double beta_dt, const double *u0, double *u1,
                        const double *flx1, const double *flx2, const double *flx3, int face_shaped, void *stream) {
   Geo g = make_geo(p);
-  dim3 grid = flat_grid(g, g.N2, g.N3*g.nmb), block(BX, BY);
+  dim3 grid = flat_cells_grid(FLAT_K, g.N1, 0, g.N1 - 1, g.N2, g.N3, g.nmb), block(BX, BY);
   k_rk_update_oop<<<grid, block, 0, (hipStream_t)stream>>>(g, gam0, gam1, beta_dt, u0, u1, flx1, flx2, flx3,
                                                            face_shaped ? 1 : 0);
   AKMI_CHECK_LAUNCH("rk_update_oop");
@@ -1145,7 +1122,7 @@ int akmi_hydro_c2p(const akmi_pack *p, double *u0, double *w0, int il, int iu, i
                    int kl, int ku, int *counters, void *stream) {
   Geo g = make_geo(p);
   int nk = ku - kl + 1;
-  dim3 grid = flat_grid(g, ju - jl + 1, nk*g.nmb), block(BX, BY);
+  dim3 grid = flat_cells_grid(0, g.N1, il, iu, ju - jl + 1, nk, g.nmb), block(BX, BY);
   k_c2p<false><<<grid, block, 0, (hipStream_t)stream>>>(g, make_eos(p), u0, nullptr, nullptr,
       nullptr, w0, nullptr, il, iu, jl, ju, kl, nk, counters);
   AKMI_CHECK_LAUNCH("hydro_c2p");
@@ -1157,7 +1134,7 @@ int akmi_mhd_c2p(const akmi_pack *p, double *u0, const double *bx1f, const doubl
                  int kl, int ku, int *counters, void *stream) {
   Geo g = make_geo(p);
   int nk = ku - kl + 1;
-  dim3 grid = flat_grid(g, ju - jl + 1, nk*g.nmb), block(BX, BY);
+  dim3 grid = flat_cells_grid(0, g.N1, il, iu, ju - jl + 1, nk, g.nmb), block(BX, BY);
   k_c2p<true><<<grid, block, 0, (hipStream_t)stream>>>(g, make_eos(p), u0, bx1f, bx2f, bx3f, w0,
       bcc0, il, iu, jl, ju, kl, nk, counters);
   AKMI_CHECK_LAUNCH("mhd_c2p");
@@ -1168,7 +1145,7 @@ int akmi_hydro_newdt(const akmi_pack *p, const double *w0, double *dt3, void *st
   Geo g = make_geo(p);
   hipStream_t st = (hipStream_t)stream;
   k_init_dt<<<1, 64, 0, st>>>(dt3);
-  dim3 grid = flat_grid(g, g.je - g.js + 1, (g.ke - g.ks + 1)*g.nmb), block(BX, BY);
+  dim3 grid = flat_cells_grid(0, g.N1, g.is, g.ie, g.nx2, g.nx3, g.nmb), block(BX, BY);
   k_newdt<false><<<grid, block, 0, st>>>(g, make_eos(p), w0, nullptr, dt3);
   AKMI_CHECK_LAUNCH("hydro_newdt");
   return AKMI_COMPLETE;
@@ -1189,7 +1166,7 @@ int akmi_mhd_newdt(const akmi_pack *p, const double *w0, const double *bcc0, dou
   Geo g = make_geo(p);
   hipStream_t st = (hipStream_t)stream;
   k_init_dt<<<1, 64, 0, st>>>(dt3);
-  dim3 grid = flat_grid(g, g.je - g.js + 1, (g.ke - g.ks + 1)*g.nmb), block(BX, BY);
+  dim3 grid = flat_cells_grid(0, g.N1, g.is, g.ie, g.nx2, g.nx3, g.nmb), block(BX, BY);
   k_newdt<true><<<grid, block, 0, st>>>(g, make_eos(p), w0, bcc0, dt3);
   AKMI_CHECK_LAUNCH("mhd_newdt");
   return AKMI_COMPLETE;
@@ -1337,7 +1314,7 @@ int akmi_mhd_ct(const akmi_pack *p, double gam0, double gam1, double beta_dt, co
                 const double *e2, const double *e3, double *b0x1f, double *b0x2f, double *b0x3f,
                 const double *b1x1f, const double *b1x2f, const double *b1x3f, void *stream) {
   Geo g = make_geo(p);
-  dim3 grid = flat_grid(g, g.je - g.js + 2, (g.ke - g.ks + 2)*g.nmb), block(BX, BY);
+  dim3 grid = flat_cells_grid(FLAT_K, g.N1 + 1, g.is, g.ie + 1, g.je - g.js + 2, g.ke - g.ks + 2, g.nmb), block(BX, BY);
   k_ct<<<grid, block, 0, (hipStream_t)stream>>>(g, gam0, gam1, beta_dt, e1, e2, e3, b0x1f, b0x2f,
                                                 b0x3f, b1x1f, b1x2f, b1x3f);
   AKMI_CHECK_LAUNCH("ct");
@@ -1348,7 +1325,7 @@ int akmi_mhd_ct_oop(const akmi_pack *p, double gam0, double gam1, double beta_dt
                     const double *e3, const double *b0x1f, const double *b0x2f, const double *b0x3f, double *b1x1f,
                     double *b1x2f, double *b1x3f, void *stream) {
   Geo g = make_geo(p);
-  dim3 grid((unsigned)(((long)(g.N2 + 1)*(g.N1 + 1) + BX*BY - 1)/(BX*BY)), 1, (unsigned)((g.N3 + 1)*g.nmb)), block(BX, BY);
+  dim3 grid = flat_cells_grid(FLAT_K, g.N1 + 1, 0, g.N1, g.N2 + 1, g.N3 + 1, g.nmb), block(BX, BY);
   k_ct_oop<<<grid, block, 0, (hipStream_t)stream>>>(g, gam0, gam1, beta_dt, e1, e2, e3, b0x1f, b0x2f, b0x3f, b1x1f,
                                                     b1x2f, b1x3f);
   AKMI_CHECK_LAUNCH("ct_oop");
