@@ -32,6 +32,9 @@
 #ifndef AKMI_MS_FM
 #define AKMI_MS_FM 1              // short square roots (sqrt_x)
 #endif
+#if defined(AKMI_MS_WHATIF) && AKMI_MS_WHATIF != 0 && !defined(AKMI_EXPERIMENTS)
+#error "AKMI_MS_WHATIF builds give wrong results: define AKMI_EXPERIMENTS too (akmi_build_flags() then says so)"
+#endif
 #ifndef AKMI_MS_WHATIF
 #define AKMI_MS_WHATIF 0          // timing experiments (wrong results): 1 no barriers, 2 no global stores, 4 no extra halo cells, 8 no x3 solve
 #endif

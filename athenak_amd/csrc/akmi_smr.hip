@@ -748,6 +748,113 @@ k_smr_average_flux_fc(SGeo s, Tab t, const int *__restrict__ nflx, E3 ef) {
   }
 }
 
+// RecvAndUnpackFluxFC after the messages are in (flux_correct_fc.cpp:374-1034) for one (MeshBlock, component) per workgroup:
+// the four steps above -- sum of the same-level contributions, zero where finer neighbours contribute, sum of theirs,
+// average -- touch the edges of block m only and read the buffer, so one workgroup can run them back to back with barriers
+// in between: one launch instead of four (120 blocks of 16^3: 13 + 5 + 13 + 11 us of mostly launch latency).  Same
+// operations on the same operands in the same order per edge as the four kernels.
+__global__ void __launch_bounds__(256)
+k_smr_emf_finish(SGeo s, Tab t, const int *__restrict__ nflx, const double *__restrict__ buf, E3 ef) {
+  const int v = blockIdx.x%3, m = blockIdx.x/3;
+  const int ml = t.lev[m];
+  double *e = ef.e[v];
+  __shared__ SlotMeta same[48], finer[48];    // receive boxes of the slots (q < 0: the slot contributes nothing)
+  if ((int)threadIdx.x < 48) {
+    const int n = threadIdx.x;
+    SlotMeta x, y;
+    x.q = -1; x.in = 0; x.b = Bx{0, -1, 0, -1, 0, -1};
+    y = x;
+    if (n < t.nnghbr && NGID(t, m, n) >= 0 && slot_has(n, v)) {
+      const int nl = NLEV(t, m, n);
+      if (nl == ml) {
+        x.q = 0;
+        x.b = box_of(t.fc, T_RECV, K_FLXS, n, v);
+        x.in = (long long)seg_r(t, 3, m, n) + (long long)ndat_of(t, 1, n, T_RECV, 3)*v;
+      } else if (nl > ml) {
+        y.q = 0;
+        y.b = box_of(t.fc, T_RECV, K_FLXC, n, v);
+        y.in = (long long)seg_r(t, 3, m, n) + (long long)ndat_of(t, 1, n, T_RECV, 4)*v;
+      }
+    }
+    same[n] = x; finer[n] = y;
+  }
+  __syncthreads();
+  auto add = [&](const SlotMeta &sm) {         // SumBoundaryFluxes: the slots one after the other
+    const Bx b = sm.b;
+    const int cnt = bcount(b);
+    const double *in = buf + sm.in;
+    for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
+      int k, j, i;
+      bdecode(b, q, k, j, i);
+      e[e4(s, v, m, k, j, i)] += in[q];
+    }
+  };
+  for (int n = 0; n < t.nnghbr && n < 48; ++n) {
+    if (same[n].q < 0) continue;               // (uniform over the workgroup)
+    add(same[n]);
+    __syncthreads();
+  }
+  if (t.multilevel) {
+    for (int n = 0; n < t.nnghbr && n < 48; ++n) {   // ZeroFluxesAtBoundaryWithFiner
+      if (finer[n].q < 0) continue;
+      const Bx b = finer[n].b;
+      const int cnt = bcount(b);
+      for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
+        int k, j, i;
+        bdecode(b, q, k, j, i);
+        e[e4(s, v, m, k, j, i)] = 0.0;
+      }
+    }
+    __syncthreads();
+    for (int n = 0; n < t.nnghbr && n < 48; ++n) {
+      if (finer[n].q < 0) continue;
+      add(finer[n]);
+      __syncthreads();
+    }
+  }
+  // AverageBoundaryFluxes (see k_smr_average_flux_fc): the boxes of different faces / edges are disjoint
+  for (int n = 0; n < t.nnghbr && n < 48; ++n) {               // (1-D: 8 slots, 2-D: 24)
+    if (!slot_has(n, v)) continue;
+    const bool face = (n == 0 || n == 4 || n == 8 || n == 12 || n == 24 || n == 28);
+    const bool edge = (n >= 16 && n < 24 && n%2 == 0) || (n >= 32 && n < 48 && n%2 == 0);
+    if (!face && !edge) continue;
+    Bx b = box_of(t.fc, T_RECV, K_FLXS, n, v);
+    if (b.iu < b.il || b.ju < b.jl || b.ku < b.kl) continue;
+    if (edge) {
+      const double d = (double)nflx[(size_t)m*48 + n];
+      const int cnt = bcount(b);
+      for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
+        int k, j, i;
+        bdecode(b, q, k, j, i);
+        e[e4(s, v, m, k, j, i)] /= d;
+      }
+      continue;
+    }
+    const int nl = NLEV(t, m, n);
+    const int fdir = n < 8 ? 0 : (n < 16 ? 1 : 2);
+    const int tdir = 3 - fdir - v;
+    const bool tact = tdir == 0 ? true : (tdir == 1 ? s.multi_d != 0 : s.three_d != 0);
+    int *lo = tdir == 0 ? &b.il : (tdir == 1 ? &b.jl : &b.kl);
+    int *hi = tdir == 0 ? &b.iu : (tdir == 1 ? &b.ju : &b.ku);
+    if (nl == ml) {
+      if (tact) { *lo += 1; *hi -= 1; }
+    } else if (nl >= ml) {
+      if (!tact) continue;
+      const int mid = *lo + (*hi - *lo + 1)/2;
+      *lo = mid; *hi = mid;
+    } else {
+      continue;
+    }
+    if (*hi < *lo) continue;
+    const int cnt = bcount(b);
+    for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
+      int k, j, i;
+      bdecode(b, q, k, j, i);
+      e[e4(s, v, m, k, j, i)] *= 0.5;
+    }
+  }
+}
+
 // launch over the (block, slot) pairs of work list L (or the full grid without lists), `per` workgroups per pair
 #define SMR_LAUNCH(kern, L, per, stream, ...) \
   do { const unsigned nwg_ = wg_count(tb, L)*(unsigned)(per); if (nwg_) kern<<<nwg_, 256, 0, stream>>>(__VA_ARGS__); } while (0)
@@ -1014,14 +1121,20 @@ static int smr_emf_exchange(const akmi_pack *p, const akmi_smr *t, const int *nf
   const Tab tb = make_tab(p, t);
   hipStream_t st = (hipStream_t)stream;
   const E3 ef{{e1, e2, e3}};
+  if ((phase & 2) && !nflx) { set_error("smr_emf_exchange: nflx missing"); return AKMI_FAIL; }
   if (phase & 1) SMR_LAUNCH(k_smr_pack_flux_fc, L_VALID, 3, st, s, tb, ef, buf);
   if (phase & 2) {
+    static const bool split4 = getenv("AKMI_SMR_EMF_SPLIT") && atoi(getenv("AKMI_SMR_EMF_SPLIT")) != 0;   // A/B: the four kernels
+    if (!split4) {
+      k_smr_emf_finish<<<(unsigned)p->nmb*3, 256, 0, st>>>(s, tb, nflx, buf, ef);
+    } else {
     k_smr_sum_flux_fc<<<(unsigned)p->nmb*3, 256, 0, st>>>(s, tb, 1, buf, ef);
     if (tb.multilevel) {
       SMR_LAUNCH(k_smr_zero_flux_fc, L_FINER, 3, st, s, tb, ef);
       k_smr_sum_flux_fc<<<(unsigned)p->nmb*3, 256, 0, st>>>(s, tb, 0, buf, ef);
     }
     SMR_LAUNCH(k_smr_average_flux_fc, L_AVG, 3, st, s, tb, nflx, ef);
+    }
   }
   AKMI_CHECK_LAUNCH("smr_emf_exchange");
   return AKMI_COMPLETE;
