@@ -144,10 +144,7 @@ struct SweepArgs {
 template <int DIR, int RECON>
 constexpr bool x1_share() { return DIR == 0 && RECON >= 1 && AKMI_X1_SHARE; }
 // k_sweep: the planes [kl, ku] flattened into the lane index as well (120 blocks of 16^3, PPM4 + HLLD: x1 sweep 40.7 -> 32,
-// x2 sweep 49.4 -> 36 us; the x3 sweep, whose stencil crosses the planes, is 4 % faster with one group of workgroups per
-// plane: 56.1 against 58.6 us) -- profiles/r06_lane_mapping.txt
-template <int DIR>
-constexpr bool sweep_kflat() { return DIR != 2; }
+// x2 sweep 49.4 -> 36 us) -- profiles/r06_lane_mapping.txt
 
 template <int RECON, bool MHD, bool ECC, int RS>
 __device__ __forceinline__ void sweep_x1_shared(const Geo &g, const FaceEos &eos, const SweepArgs &a,
@@ -267,13 +264,21 @@ k_sweep(Geo g, FaceEos eos, SweepArgs a, int nk) {
   const unsigned p = (blockIdx.x*SY + threadIdx.y)*SX + threadIdx.x;
   const int row_0 = a.il - (ECC ? 1 : 0);
   const unsigned row_w = (unsigned)(a.iu - row_0 + 1), plane = row_w*(unsigned)(a.ju - a.jl + 1);
-  unsigned kk, pr, mm;
-  if (sweep_kflat<DIR>()) { kk = p/plane; pr = p - kk*plane; mm = blockIdx.z; }
-  else { mm = blockIdx.z/(unsigned)nk; kk = blockIdx.z - mm*(unsigned)nk; pr = p; }
-  const unsigned jj = pr/row_w;
-  const int i = row_0 + (int)(pr - jj*row_w);
+  unsigned kk, jj, pr;
+  if (DIR != 2) {
+    kk = p/plane; pr = p - kk*plane;
+    jj = pr/row_w; pr -= jj*row_w;
+  } else {
+    // x3 sweep: (j; k; i) -- the lanes of a wave that are not neighbours in i are neighbours in k, the direction of the
+    // stencil, so the rows a wave loads overlap as they do in the x2 sweep (a wave of the (k; j; i) order reads six planes x
+    // its own rows and shares nothing: 57 us against 37 for the x2 sweep on 120 blocks of 16^3)
+    const unsigned slab = row_w*(unsigned)nk;
+    jj = p/slab; pr = p - jj*slab;
+    kk = pr/row_w; pr -= kk*row_w;
+  }
+  const int i = row_0 + (int)pr;
   const int j = a.jl + (int)jj;
-  const int m = (int)mm;
+  const int m = blockIdx.z;
   const int k = a.kl + (int)kk;
   if ((int)kk >= nk || j > a.ju) return;
   const size_t cs = (size_t)g.N3*g.N2*g.N1;
@@ -1763,10 +1768,9 @@ static int launch_sweep(const Geo &g, const Scheme &sc, const SweepArgs &a, hipS
     // faces per wave: 63 when the lanes share their slopes (lane 0 of a wave only provides); those kernels run over
     // the columns il-1 .. iu of a row (sweep_x1_shared), the plain one over il (- 1 with ECC) .. iu
     constexpr bool share = x1_share<DIR, decltype(R)::value>();
-    const bool kf = share || sweep_kflat<DIR>();
-    const long np = (long)(kf ? nk : 1)*(a.ju - a.jl + 1)*(share ? a.iu - a.il + 2 : a.iu - a.il + 1 + (ECC ? 1 : 0));   // of one MeshBlock
+    const long np = (long)nk*(a.ju - a.jl + 1)*(share ? a.iu - a.il + 2 : a.iu - a.il + 1 + (ECC ? 1 : 0));   // of one MeshBlock
     const long per_wg = (long)(share ? SX - 1 : SX)*SY;
-    dim3 grid((unsigned)((np + 1 + per_wg - 1)/per_wg), 1, kf ? g.nmb : nk*g.nmb);
+    dim3 grid((unsigned)((np + 1 + per_wg - 1)/per_wg), 1, g.nmb);
     k_sweep<DIR, decltype(R)::value, MHD, ECC, decltype(S)::value><<<grid, block, 0, st>>>(
         g, sc.eos, a, nk);
     return AKMI_COMPLETE;
