@@ -540,12 +540,14 @@ class Hydro(FluidBase):
                 e1.record()
             self._dt_ready = bool(do_dt)
             return TaskStatus.complete
-        if self.multilevel and stage == pdrive.nexp_stages and not self.kinematic:
-            # refined meshes (task-granular chain): the last conversion carries the CFL scan along (see mhd.py)
+        if self.multilevel and not self.kinematic:
+            # refined meshes (task-granular chain): the last conversion carries the CFL scan along, the others use the same
+            # entry without it (see mhd.py)
+            do_dt = 1 if stage == pdrive.nexp_stages else 0
             capi.check(self.L.akmi_hydro_c2p_newdt(
-                C.byref(self.pack_c), capi._p(self.u0), capi._p(self.w0), 1,
+                C.byref(self.pack_c), capi._p(self.u0), capi._p(self.w0), do_dt,
                 capi._p(self.counters), capi._p(self.dt3), capi._stream()), "hydro_c2p_newdt")
-            self._dt_ready = True
+            self._dt_ready = bool(do_dt)
             return TaskStatus.complete
         capi.check(self.L.akmi_hydro_c2p(C.byref(self.pack_c), capi._p(self.u0), capi._p(self.w0),
                                          0, n1 - 1, 0, n2 - 1, 0, n3 - 1, capi._p(self.counters),
