@@ -20,6 +20,8 @@ refined meshes:
                            instead of the copy list of akmi_smr_fc_map (default)
   AKMI_SMR_CC_MAP=0        cell-centred variables of refined meshes through pack / unpack / same-level gather instead of
                            the copy list of akmi_smr_cc_map (default on one rank)
+  AKMI_SMR_EMF_SPLIT=1     the four kernels of RecvAndUnpackFluxFC (sum, zero, sum, average) instead of one launch per
+                           (MeshBlock, component) that runs them back to back
   AKMI_FACE_SWEEPS=0       task-granular path, small packs: x2/x3 fluxes by the marching sweeps instead of one thread per face
   AKMI_TASK_OOP=0          task-granular path: CopyCons + in-place RKUpdate / CT on the first stage instead of the
                            out-of-place update with swapped registers (akmi_rk_update_oop, akmi_mhd_ct_oop)
@@ -101,7 +103,8 @@ print("ok")
 
 
 @pytest.mark.parametrize("env", [{"AKMI_SMR_DIRECT": "0"}, {"AKMI_TASK_OOP": "0"},
-                                 {"AKMI_SMR_LISTS": "0"}, {"AKMI_FACE_SWEEPS": "0"}, {"AKMI_SMR_FC_MAP": "0"}, {"AKMI_SMR_CC_MAP": "0"}],
+                                 {"AKMI_SMR_LISTS": "0"}, {"AKMI_FACE_SWEEPS": "0"}, {"AKMI_SMR_FC_MAP": "0"}, {"AKMI_SMR_CC_MAP": "0"},
+                                 {"AKMI_SMR_EMF_SPLIT": "1"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
 def test_smr_option_does_not_change_a_bit(env):
     r = subprocess.run([sys.executable, "-c", SMR_SCRIPT], env=dict(os.environ, **env), capture_output=True, text=True,
