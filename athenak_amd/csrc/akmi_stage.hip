@@ -2248,7 +2248,12 @@ static int sweeps_store_fluxes_t(const akmi_pack *p, int recon, int rsolver, con
   // few hundred workgroups; one thread per face has no chain at all
   static const int tf_env = getenv("AKMI_FACE_SWEEPS") ? atoi(getenv("AKMI_FACE_SWEEPS")) : -1;
   const long ncell = (long)g.nmb*g.nx1*g.nx2*g.nx3;
-  if (g.three_d && (tf_env == 1 || (tf_env != 0 && ncell <= (long)AKMI_SMALL_FACE_SWEEPS))) {
+  // ... and, since the face sweeps run their lanes over the flattened planes (x3: over (j; k; i)), packs of MeshBlocks of up
+  // to 96 cells per side at any size: x2 / x3 of 960 blocks of 32^3 (PPM4) 1 712 / 1 641 -> 1 563 / 1 622 us, 64 blocks of
+  // 64^3 (PLM) 752 / 720 -> 659 / 655, 8 blocks of 96^3 322 / 314 -> 306 / 285; 8 blocks of 128^3 even (642 / 673 against
+  // 664 / 668), one block of 256^3 the marches by 13 % (602 / 583 against 679 / 702) -- profiles/r06_lane_mapping.txt
+  const int nmax = g.nx1 > g.nx2 ? (g.nx1 > g.nx3 ? g.nx1 : g.nx3) : (g.nx2 > g.nx3 ? g.nx2 : g.nx3);
+  if (g.three_d && (tf_env == 1 || (tf_env != 0 && (ncell <= (long)AKMI_SMALL_FACE_SWEEPS || nmax <= 96)))) {
     if (rc == AKMI_COMPLETE) rc = launch_sweep<1, MHD, false>(g, sc, a2, st);
     if (rc == AKMI_COMPLETE) rc = launch_sweep<2, MHD, false>(g, sc, a3, st);
     return rc;
