@@ -22,7 +22,7 @@ refined meshes:
                            the copy list of akmi_smr_cc_map (default on one rank)
   AKMI_SMR_EMF_SPLIT=1     the four kernels of RecvAndUnpackFluxFC (sum, zero, sum, average) instead of one launch per
                            (MeshBlock, component) that runs them back to back
-  AKMI_FACE_SWEEPS=0       task-granular path, small packs: x2/x3 fluxes by the marching sweeps instead of one thread per face
+  AKMI_FACE_SWEEPS=0       task-granular path, small packs and MeshBlocks of up to 96 cells per side: x2/x3 fluxes by the marching sweeps instead of one thread per face
   AKMI_TASK_OOP=0          task-granular path: CopyCons + in-place RKUpdate / CT on the first stage instead of the
                            out-of-place update with swapped registers (akmi_rk_update_oop, akmi_mhd_ct_oop)
 """
