@@ -29,7 +29,7 @@ class Pack(C.Structure):
 
 
 PHASE_SWEEPS, PHASE_EMF_CT, PHASE_C2P, PHASE_ALL = 1, 2, 4, 7     # AKMI_PHASE_* of include/akmi.h
-SMALL_PACK_CELLS = 600000       # AKMI_SMALL_PACK_CELLS of include/akmi.h (tests/test_capi_symbols.py compares them)
+SMALL_PACK_CELLS = 375000       # AKMI_SMALL_PACK_CELLS of include/akmi.h (tests/test_capi_symbols.py compares them)
 
 # every symbol include/akmi.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [

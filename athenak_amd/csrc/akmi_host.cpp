@@ -426,15 +426,16 @@ FluidBase::FluidBase(MeshBlockPack *pp, ParameterInput *pin, const std::string &
     AKMI_FATAL("<" + blk + ">/fused_stage = " + fs + ": true, false, an integer or auto");
   const bool fused_given = fs != "auto";
   fused = fs_int ? std::stol(fs) != 0 : fs != "false";
-  // small 3-D packs: the task-granular chain (one thread per face) beats the marching kernels of the fused stage
-  // (MHD 64^3: 1 050 against 810 Mcell-updates/s, equal at 96^3; profiles/r03_small_packs.txt); same bits either way.
+  // small 3-D MHD packs: the task-granular chain (one thread per face) beats the marching kernels of the fused stage
+  // (64^3: 1 113 against 1 042 Mcell-updates/s, equal at 72^3); hydro packs keep the fused stage at every size (64^3: 2 838
+  // against 1 854) -- profiles/r06_small_packs.txt; same bits either way.
   // <hydro|mhd>/small_pack_tasks = false keeps the fused kernels.  AKMI_SMALL_PACK_TASKS=0: off
   {
     // (read without adding it to the deck: the parameter dump of the output files stays what the reference's is)
     const bool small_ok = pin->DoesParameterExist(blk, "small_pack_tasks") ? pin->GetBoolean(blk, "small_pack_tasks") : true;
     const char *sp = std::getenv("AKMI_SMALL_PACK_TASKS");
     const long ncell_pack = static_cast<long>(pp->nmb_thispack)*ind.nx1*ind.nx2*ind.nx3;
-    if (small_ok && !fused_given && fused && ind.nx3 > 1 && nscalars == 0 && !(sp && std::atoi(sp) == 0) &&
+    if (blk == "mhd" && small_ok && !fused_given && fused && ind.nx3 > 1 && nscalars == 0 && !(sp && std::atoi(sp) == 0) &&
         ncell_pack <= AKMI_SMALL_PACK_CELLS)
       fused = false;                   // (not with passive scalars: the task path's sweeps do not carry them)
   }

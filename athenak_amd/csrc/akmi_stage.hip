@@ -413,7 +413,7 @@ __device__ __forceinline__ double beta_dt_of(double beta_dt, const double *dtp) 
 #ifndef AKMI_SMALL_FACE_SWEEPS
 #define AKMI_SMALL_FACE_SWEEPS 700000   // task path: packs up to this many cells take thread-per-face x2/x3 sweeps (0: never); the crossover
                                         // measured in round 3 (88^3 = 681 k cells still faster per face, profiles/r03_small_packs.txt); the HOSTS switch
-                                        // small packs to the task chain at AKMI_SMALL_PACK_CELLS (include/akmi.h)
+                                        // small MHD packs to the task chain at AKMI_SMALL_PACK_CELLS (include/akmi.h)
 #endif
 #ifndef AKMI_X2_EO
 #define AKMI_X2_EO 0            // wave-uniform early-outs of HLLD in the x2 / x3 march (registers!)

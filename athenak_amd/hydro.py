@@ -100,9 +100,11 @@ class FluidBase:
             raise RuntimeError("### FATAL ERROR <%s>/fused_stage = %s: true, false, an integer or auto" % (blk, fs))
         fused_given = fs != "auto"
         self.fused = (int(fs) != 0) if fs.isdigit() else fs != "false"
-        # small 3-D packs: the marching kernels of the fused stage are chains of dependent steps over a few hundred
-        # workgroups; the task-granular chain with one thread per face is faster there (MHD 64^3: 1 050 against 810
-        # Mcell-updates/s, 48^3: 610 / 406; equal at 96^3; profiles/r03_small_packs.txt).  Same bits either way.
+        # small 3-D MHD packs: the marching kernels of the fused stage are chains of dependent steps over a few hundred
+        # workgroups; the task-granular chain with one thread per face is faster there (64^3: 1 113 against 1 042
+        # Mcell-updates/s, 48^3: 657 / 556; equal at 72^3, 80^3: 1 392 / 1 494).  Hydro packs keep the fused stage at every
+        # size: the one-kernel form wins everywhere (64^3: 2 838 against 1 854, 32^3: 485 / 303; PPM4 64^3: 1 839 / 1 583).
+        # profiles/r06_small_packs.txt.  Same bits either way.
         # <hydro|mhd>/small_pack_tasks = false keeps the fused kernels (the parity tests do: their meshes are all small);
         # AKMI_SMALL_PACK_TASKS=0: off.  (Not with passive scalars: the task path's sweeps do not carry them.)
         # (read without adding it to the deck: the parameter dump of the bin/rst writers stays what the reference's is)
@@ -110,7 +112,7 @@ class FluidBase:
         # constant AKMI_SMALL_PACK_CELLS of include/akmi.h (capi.SMALL_PACK_CELLS), shared with the C++ host and with the
         # library's choice of thread-per-face sweeps on the task path.
         small_ok = pin.GetBoolean(blk, "small_pack_tasks") if pin.DoesParameterExist(blk, "small_pack_tasks") else True
-        if (small_ok and not fused_given and self.fused and indcs.nx3 > 1 and self.nscalars == 0
+        if (blk == "mhd" and small_ok and not fused_given and self.fused and indcs.nx3 > 1 and self.nscalars == 0
                 and os.environ.get("AKMI_SMALL_PACK_TASKS", "1") != "0"
                 and self.nmb*indcs.nx1*indcs.nx2*indcs.nx3 <= capi.SMALL_PACK_CELLS):
             self.fused = False

@@ -67,10 +67,11 @@ typedef struct akmi_pack {
                           * no energy variable, src/eos/isothermal_hyd.cpp:20-23)        */
 } akmi_pack;
 
-/* Packs of up to this many cells count as "small" everywhere: both hosts run the task-granular chain instead of the
- * fused stage for such 3-D packs (unless the deck sets <hydro|mhd>/fused_stage itself or small_pack_tasks = false),
- * and the flux entries akmi_*_fluxes take one thread per face instead of the marching kernels. */
-#define AKMI_SMALL_PACK_CELLS 600000
+/* MHD packs of up to this many cells count as "small": both hosts run the task-granular chain instead of the fused stage
+ * for such 3-D packs (unless the deck sets mhd/fused_stage itself or small_pack_tasks = false) -- measured crossover 72^3
+ * (64^3: chain 1 113 against 1 042 Mcell-updates/s, 80^3: 1 392 against 1 494; PPM4 the same).  Hydro packs always take the
+ * fused stage: its one-kernel form wins at every size (64^3: 2 838 against 1 854, 32^3: 485 against 303).  INTEGRATION.md. */
+#define AKMI_SMALL_PACK_CELLS 375000
 
 const char *akmi_last_error(void);
 int akmi_version(void);
