@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6, GPU box: everything the committed library is judged on -- GPU suite (4 workers), MHD profiles (kernel stats, PMC traffic,
 # SQ counters) + default bench line, hydro profiles, PPM4 line, config 5.  usage: bash tools/r05_final.sh TAG
-tag=${1:-r06_v6}
+tag=${1:-r06_v7}
 root=${GRAFT_REPO_ROOT:-$(pwd)}; cd $root; mkdir -p gpurun_out
 ( time timeout 1500 python -m pytest tests -m gpu -q -n 4 ) > gpurun_out/${tag}_gpu_tests.txt 2>&1
 tail -4 gpurun_out/${tag}_gpu_tests.txt
